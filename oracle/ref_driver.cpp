@@ -1,0 +1,105 @@
+// ref_driver.cpp -- extern "C" doorway into the REAL reference translation units that build here unmodified.
+//
+// TEST INFRASTRUCTURE ONLY.  Compiled (by oracle/Makefile, only where /root/reference exists) together with
+// the reference's own sources, read in place from /root/reference/src:
+//     flan/phase_vocoder.cpp  flan/WindowFunctions.cpp  flan/PV/PVBuffer.cpp  flan/Utility/Bytes.cpp
+//     flan/Utility/buffer_access.cpp  flan/Utility/Interpolator.cpp  flan/Function.cpp  flan/Utility/execution.cpp ...
+// into oracle/_ref/libflanref.so.  No reference source is copied into this repository and no stand-in header or
+// library is written: translation units that need FFTW3f / libsndfile / MSVC's std::_Pi (Conversions/AudioPV.cpp,
+// PV/PVModify.cpp, PV/PV.cpp, Audio/*.cpp, FFTHelper.cpp) are simply NOT built -- see DESIGN.md.
+//
+// This file only forwards calls; it contains no algorithm.
+#include <complex>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "flan/phase_vocoder.h"
+#include "flan/WindowFunctions.h"
+#include "flan/PV/PVBuffer.h"
+
+extern "C" {
+
+void ref_phase_vocoder( double * phase_buffer, float re, float im, float bin_frequency, float analysis_rate, float sample_rate, float * m, float * f )
+	{
+	const flan::MF r = flan::phase_vocoder( *phase_buffer, std::complex<float>( re, im ), bin_frequency, analysis_rate, sample_rate );
+	*m = r.m; *f = r.f;
+	}
+
+void ref_inverse_phase_vocoder( double * phase_buffer, float m, float f, float analysis_rate, float * re, float * im )
+	{
+	const std::complex<float> c = flan::inverse_phase_vocoder( *phase_buffer, flan::MF{ m, f }, analysis_rate );
+	*re = c.real(); *im = c.imag();
+	}
+
+// Batched forms so that python can sweep millions of cases quickly.
+void ref_phase_vocoder_batch( int64_t count, double * phase_buffer, const float * re, const float * im, const float * bin_frequency,
+	float analysis_rate, float sample_rate, float * m, float * f )
+	{
+	for( int64_t i = 0; i < count; ++i )
+		{
+		const flan::MF r = flan::phase_vocoder( phase_buffer[i], std::complex<float>( re[i], im[i] ), bin_frequency[i], analysis_rate, sample_rate );
+		m[i] = r.m; f[i] = r.f;
+		}
+	}
+
+void ref_inverse_phase_vocoder_batch( int64_t count, double * phase_buffer, const float * m, const float * f, float analysis_rate, float * re, float * im )
+	{
+	for( int64_t i = 0; i < count; ++i )
+		{
+		const std::complex<float> c = flan::inverse_phase_vocoder( phase_buffer[i], flan::MF{ m[i], f[i] }, analysis_rate );
+		re[i] = c.real(); im[i] = c.imag();
+		}
+	}
+
+float ref_hann( float x ) { return flan::Windows::hann( x ); }
+
+float ref_pi2() { return flan::pi2; }
+
+// PVBuffer unit conversions on a buffer built with the given format.
+struct RefPVFormat { int32_t num_channels, num_frames, num_bins; float sample_rate, analysis_rate; int32_t window_size; };
+
+static flan::PVBuffer make_pv( const RefPVFormat & f )
+	{
+	flan::PVBuffer::Format fmt;
+	fmt.num_channels = f.num_channels; fmt.num_frames = f.num_frames; fmt.num_bins = f.num_bins;
+	fmt.sample_rate = f.sample_rate; fmt.analysis_rate = f.analysis_rate; fmt.window_size = f.window_size;
+	return flan::PVBuffer( fmt );
+	}
+
+int   ref_pv_hop_size( RefPVFormat f )  { return make_pv( f ).get_hop_size(); }
+int   ref_pv_dft_size( RefPVFormat f )  { return make_pv( f ).get_dft_size(); }
+float ref_pv_bin_to_frequency( RefPVFormat f, float b ) { return make_pv( f ).bin_to_frequency( b ); }
+float ref_pv_frequency_to_bin( RefPVFormat f, float x ) { return make_pv( f ).frequency_to_bin( x ); }
+float ref_pv_time_to_frame( RefPVFormat f, float t )    { return make_pv( f ).time_to_frame( t ); }
+float ref_pv_frame_to_time( RefPVFormat f, float x )    { return make_pv( f ).frame_to_time( x ); }
+int64_t ref_pv_buffer_pos( RefPVFormat f, int c, int fr, int b ) { return (int64_t) make_pv( f ).get_buffer_pos( c, fr, b ); }
+int ref_pv_is_nan_or_inf( RefPVFormat f, const float * mf )
+	{
+	flan::PVBuffer pv = make_pv( f );
+	std::memcpy( pv.get_buffer().data(), mf, sizeof( flan::MF ) * pv.get_buffer().size() );
+	return pv.is_nan_or_inf() ? 1 : 0;
+	}
+
+// .flan file format (PVBuffer.cpp:99-140 save, :216-273 load)
+int ref_pv_save( RefPVFormat f, const float * mf, const char * filename )
+	{
+	flan::PVBuffer pv = make_pv( f );
+	std::memcpy( pv.get_buffer().data(), mf, sizeof( flan::MF ) * pv.get_buffer().size() );
+	return pv.save( filename ) ? 1 : 0;
+	}
+
+int ref_pv_load( const char * filename, RefPVFormat * f, float * mf, int64_t mf_capacity )
+	{
+	flan::PVBuffer pv( std::string{ filename } );
+	const auto fmt = pv.get_format();
+	f->num_channels = fmt.num_channels; f->num_frames = fmt.num_frames; f->num_bins = fmt.num_bins;
+	f->sample_rate = fmt.sample_rate; f->analysis_rate = fmt.analysis_rate; f->window_size = fmt.window_size;
+	const int64_t count = (int64_t) pv.get_buffer().size();
+	if( mf && count <= mf_capacity )
+		std::memcpy( mf, pv.get_buffer().data(), sizeof( flan::MF ) * count );
+	return (int) ( count > 0 );
+	}
+
+} // extern "C"

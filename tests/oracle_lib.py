@@ -1,0 +1,202 @@
+"""ctypes doorway to the CPU checker under oracle/ (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.  The product
+(flan_amd/, include/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+_LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+_REF = os.path.join(ORACLE_DIR, "_ref", "libflanref.so")
+_R8B = os.path.join(ORACLE_DIR, "_ref", "libr8bref.so")
+
+f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+
+
+def build():
+    """(Re)build the checker; cheap when up to date."""
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+
+
+def _load():
+    if not os.path.exists(_LIB):
+        build()
+    lib = C.CDLL(_LIB)
+    lib.oracle_pi2.restype = C.c_float
+    lib.oracle_hann.restype = C.c_float
+    lib.oracle_hann.argtypes = [C.c_float]
+    lib.oracle_hann_window.argtypes = [f32p, C.c_int]
+    lib.oracle_phase_vocoder.argtypes = [C.POINTER(C.c_double), C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                         C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.oracle_inverse_phase_vocoder.argtypes = [C.POINTER(C.c_double), C.c_float, C.c_float, C.c_float,
+                                                 C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    for name in ("oracle_bin_to_frequency", "oracle_frequency_to_bin", "oracle_time_to_frame", "oracle_frame_to_time"):
+        fn = getattr(lib, name)
+        fn.restype = C.c_float
+        fn.argtypes = [C.c_float, C.c_float, C.c_int]
+    lib.oracle_r2c.argtypes = [f32p, C.c_int, f32p]
+    lib.oracle_c2r.argtypes = [f32p, C.c_int, f32p]
+    lib.oracle_num_pv_frames.restype = C.c_int64
+    lib.oracle_num_pv_frames.argtypes = [C.c_int64, C.c_int]
+    lib.oracle_analyze.argtypes = [f32p, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_int, C.c_int, f32p]
+    lib.oracle_hop_size.argtypes = [C.c_float, C.c_float]
+    lib.oracle_synthesize.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_int, f32p]
+    lib.oracle_modify_time_out_frames.restype = C.c_int64
+    lib.oracle_modify_time_out_frames.argtypes = [f32p, C.c_int64, C.c_int, C.c_float, C.c_int]
+    lib.oracle_modify_time.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_int, f32p, C.c_int64, f32p]
+    lib.oracle_stretch_map.argtypes = [f32p, C.c_int64, C.c_int, C.c_float, C.c_int]
+    lib.oracle_modify_frequency.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, C.c_float, f32p, f32p, f32p]
+    lib.oracle_repitch_map.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, C.c_float, f32p, f32p]
+    lib.oracle_shape_affine.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                        C.c_float, C.c_int, f32p]
+    lib.oracle_mid_side.argtypes = [f32p, C.c_int64, f32p]
+    lib.oracle_noise.argtypes = [f32p, C.c_int, C.c_int64, C.c_uint32]
+    return lib
+
+
+lib = _load()
+
+
+class RefPVFormat(C.Structure):
+    _fields_ = [("num_channels", C.c_int32), ("num_frames", C.c_int32), ("num_bins", C.c_int32),
+                ("sample_rate", C.c_float), ("analysis_rate", C.c_float), ("window_size", C.c_int32)]
+
+
+def load_ref():
+    """The real reference TUs (oracle/_ref/libflanref.so); None when it was never built (no /root/reference)."""
+    if not os.path.exists(_REF):
+        return None
+    ref = C.CDLL(_REF)
+    ref.ref_hann.restype = C.c_float
+    ref.ref_hann.argtypes = [C.c_float]
+    ref.ref_pi2.restype = C.c_float
+    ref.ref_phase_vocoder_batch.argtypes = [C.c_int64, f64p, f32p, f32p, f32p, C.c_float, C.c_float, f32p, f32p]
+    ref.ref_inverse_phase_vocoder_batch.argtypes = [C.c_int64, f64p, f32p, f32p, C.c_float, f32p, f32p]
+    ref.ref_pv_hop_size.argtypes = [RefPVFormat]
+    ref.ref_pv_dft_size.argtypes = [RefPVFormat]
+    for name in ("ref_pv_bin_to_frequency", "ref_pv_frequency_to_bin", "ref_pv_time_to_frame", "ref_pv_frame_to_time"):
+        fn = getattr(ref, name)
+        fn.restype = C.c_float
+        fn.argtypes = [RefPVFormat, C.c_float]
+    ref.ref_pv_buffer_pos.restype = C.c_int64
+    ref.ref_pv_buffer_pos.argtypes = [RefPVFormat, C.c_int, C.c_int, C.c_int]
+    ref.ref_pv_is_nan_or_inf.argtypes = [RefPVFormat, f32p]
+    ref.ref_pv_save.argtypes = [RefPVFormat, f32p, C.c_char_p]
+    ref.ref_pv_load.argtypes = [C.c_char_p, C.POINTER(RefPVFormat), C.c_void_p, C.c_int64]
+    return ref
+
+
+# ----------------------------------------------------------------------------------------------------------
+# numpy-level helpers
+# ----------------------------------------------------------------------------------------------------------
+
+def hann_window(window):
+    w = np.empty(window, np.float32)
+    lib.oracle_hann_window(w, window)
+    return w
+
+
+def num_pv_frames(n, hop):
+    return int(lib.oracle_num_pv_frames(n, hop))
+
+
+def analyze(audio, sample_rate, window=2048, hop=128, dft=4096):
+    """audio: float32 [ch][n] -> MF float32 [ch][F][bins][2]"""
+    audio = np.ascontiguousarray(audio, np.float32)
+    ch, n = audio.shape
+    F = num_pv_frames(n, hop)
+    out = np.empty((ch, F, dft // 2 + 1, 2), np.float32)
+    rc = lib.oracle_analyze(audio, ch, n, sample_rate, window, hop, dft, out.reshape(-1))
+    assert rc == 0, rc
+    return out
+
+
+def synthesize(pv, sample_rate, analysis_rate, window):
+    """pv: float32 [ch][F][bins][2] -> (audio float32 [ch][F*hop], nan_flag)"""
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    hop = lib.oracle_hop_size(sample_rate, analysis_rate)
+    out = np.empty((ch, F * hop), np.float32)
+    rc = lib.oracle_synthesize(pv.reshape(-1), ch, F, bins, sample_rate, analysis_rate, window, out.reshape(-1))
+    assert rc >= 0, rc
+    return out, rc
+
+
+def stretch_map(factor_grid, sample_rate, hop):
+    g = np.ascontiguousarray(factor_grid, np.float32).copy()
+    F, bins = g.shape
+    lib.oracle_stretch_map(g.reshape(-1), F, bins, sample_rate, hop)
+    return g
+
+
+def modify_time(pv, sample_rate, hop, mod_seconds):
+    pv = np.ascontiguousarray(pv, np.float32)
+    mod = np.ascontiguousarray(mod_seconds, np.float32)
+    ch, F, bins, _ = pv.shape
+    Fo = int(lib.oracle_modify_time_out_frames(mod.reshape(-1), F, bins, sample_rate, hop))
+    out = np.empty((ch, max(Fo, 0), bins, 2), np.float32)
+    if Fo > 0:
+        lib.oracle_modify_time(pv.reshape(-1), ch, F, bins, sample_rate, hop, mod.reshape(-1), Fo, out.reshape(-1))
+    return out
+
+
+def stretch(pv, sample_rate, hop, factor_grid):
+    return modify_time(pv, sample_rate, hop, stretch_map(factor_grid, sample_rate, hop))
+
+
+def repitch_map(pv, sample_rate, factor_grid):
+    pv = np.ascontiguousarray(pv, np.float32)
+    g = np.ascontiguousarray(factor_grid, np.float32).copy()
+    ch, F, bins, _ = pv.shape
+    inmod = np.empty((ch, F, bins), np.float32)
+    lib.oracle_repitch_map(pv.reshape(-1), ch, F, bins, sample_rate, g.reshape(-1), inmod.reshape(-1))
+    return g, inmod
+
+
+def modify_frequency(pv, sample_rate, mod_hz, in_modified):
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    out = np.empty_like(pv)
+    lib.oracle_modify_frequency(pv.reshape(-1), ch, F, bins, sample_rate,
+                                np.ascontiguousarray(mod_hz, np.float32).reshape(-1),
+                                np.ascontiguousarray(in_modified, np.float32).reshape(-1), out.reshape(-1))
+    return out
+
+
+def repitch(pv, sample_rate, factor_grid):
+    g, inmod = repitch_map(pv, sample_rate, factor_grid)
+    return modify_frequency(pv, sample_rate, g, inmod)
+
+
+def shape_affine(pv, sample_rate, a, b, c, d, use_shift_alignment=False):
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    out = np.empty_like(pv)
+    lib.oracle_shape_affine(pv.reshape(-1), ch, F, bins, sample_rate, a, b, c, d, int(use_shift_alignment), out.reshape(-1))
+    return out
+
+
+def mid_side(audio):
+    audio = np.ascontiguousarray(audio, np.float32)
+    assert audio.shape[0] == 2
+    out = np.empty_like(audio)
+    lib.oracle_mid_side(audio.reshape(-1), audio.shape[1], out.reshape(-1))
+    return out
+
+
+def noise(ch, n, seed=1234):
+    out = np.empty((ch, n), np.float32)
+    lib.oracle_noise(out.reshape(-1), ch, n, seed)
+    return out
+
+
+def sine(n, freq=440.0, amp=0.5, sr=48000.0):
+    """SURVEY 8c anchor signal: computed in double, rounded once."""
+    t = np.arange(n, dtype=np.float64)
+    return (amp * np.sin(2.0 * np.pi * freq * t / sr)).astype(np.float32)[None, :]
