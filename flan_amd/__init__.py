@@ -1,0 +1,165 @@
+"""flan_amd -- thin Python doorway to the MI355X phase-vocoder hot path (flan_amd/libflanhip.so).
+
+The product is the HIP library behind the C ABI in include/flanhip.h and the C++ host classes in include/flan/.
+This module is plumbing for tests and bench.py: it binds the C ABI with ctypes and nothing else.  There is no
+CPU fallback and no import of anything under oracle/: if the library is missing, importing fails; if no GPU is
+visible, every compute call raises FlanHipError(FLANHIP_ERR_NO_DEVICE).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libflanhip.so")
+
+OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_CANCELLED, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
+
+
+class FlanHipError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("flanhip error %d: %s" % (code, message))
+        self.code = code
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError("flan_amd/libflanhip.so is missing: build it with `python flan_amd/build.py` "
+                      "(hipcc --offload-arch=gfx950); there is no fallback path")
+
+lib = C.CDLL(LIB_PATH)
+
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_vp, _i64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
+
+_SIGS = {
+    "flanhip_version": (C.c_int, []),
+    "flanhip_last_error": (C.c_char_p, []),
+    "flanhip_device_count": (C.c_int, []),
+    "flanhip_set_device": (C.c_int, [_i32]),
+    "flanhip_num_pv_frames": (_i64, [_i64, _i32]),
+    "flanhip_hop_size": (C.c_int, [_f32, _f32]),
+    "flanhip_modify_time_out_frames": (_i64, [_vp, _i64, _i32, _f32, _i32]),
+    "flanhip_malloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
+    "flanhip_free": (C.c_int, [_vp]),
+    "flanhip_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "flanhip_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "flanhip_memset": (C.c_int, [_vp, _i32, C.c_size_t, _vp]),
+    "flanhip_stream_synchronize": (C.c_int, [_vp]),
+    "flanhip_analyze": (C.c_int, [_vp, _i64, _i64, _f32, _i32, _i32, _i32, _vp, C.POINTER(_i64), _vp]),
+    "flanhip_analyze_dev": (C.c_int, [_vp, _i64, _i64, _f32, _i32, _i32, _i32, _vp, _vp]),
+    "flanhip_synthesize": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _i32, _vp, C.POINTER(_i32), _vp]),
+    "flanhip_synthesize_workspace_bytes": (C.c_size_t, [_i64, _i64, _i32, _f32, _f32, _i32]),
+    "flanhip_synthesize_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp]),
+    "flanhip_modify_time": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i32, _vp, _i64, _vp, _vp]),
+    "flanhip_modify_time_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i32, _vp, _i64, _vp, _vp]),
+    "flanhip_stretch_map_dev": (C.c_int, [_vp, _i64, _i32, _f32, _i32, _vp, _vp]),
+    "flanhip_fill_dev": (C.c_int, [_vp, _i64, _f32, _vp]),
+    "flanhip_modify_frequency": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
+    "flanhip_modify_frequency_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
+    "flanhip_repitch_map_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _vp]),
+    "flanhip_shape_affine": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
+    "flanhip_shape_affine_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
+    "flanhip_shape_table_dev": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _f32, _i32, _vp, _vp]),
+    "flanhip_mid_side_dev": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "flanhip_noise_dev": (C.c_int, [_vp, _i64, _i64, C.c_uint32, _vp]),
+    "flanhip_sqdiff_dev": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+}
+
+EXPORTS = sorted(_SIGS)
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)          # AttributeError here == the library does not export what the header declares
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def last_error():
+    return lib.flanhip_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    if rc != OK:
+        raise FlanHipError(rc, last_error())
+    return rc
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_vp)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# host-buffer wrappers (numpy in, numpy out) -- exactly the calls the C++ flan::Audio / flan::PV classes make
+# ---------------------------------------------------------------------------------------------------------------
+
+def analyze(audio, sample_rate, window=2048, hop=128, dft=4096):
+    """Audio::convert_to_PV.  audio float32 [ch][n] -> float32 [ch][F][dft/2+1][2] (m, f)."""
+    audio = np.ascontiguousarray(audio, np.float32)
+    ch, n = audio.shape
+    F = lib.flanhip_num_pv_frames(n, hop)
+    out = np.empty((ch, F, dft // 2 + 1, 2), np.float32)
+    got = _i64(0)
+    check(lib.flanhip_analyze(_ptr(audio), ch, n, sample_rate, window, hop, dft, _ptr(out), C.byref(got), None))
+    assert got.value == F
+    return out
+
+
+def synthesize(pv, sample_rate, analysis_rate, window):
+    """PV::convert_to_audio.  pv float32 [ch][F][bins][2] -> (float32 [ch][F*hop], nan_flag)."""
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    hop = lib.flanhip_hop_size(sample_rate, analysis_rate)
+    out = np.empty((ch, F * hop), np.float32)
+    flag = _i32(0)
+    check(lib.flanhip_synthesize(_ptr(pv), ch, F, bins, sample_rate, analysis_rate, window, _ptr(out), C.byref(flag), None))
+    return out, flag.value
+
+
+def modify_time(pv, sample_rate, hop, mod_seconds):
+    pv = np.ascontiguousarray(pv, np.float32)
+    mod = np.ascontiguousarray(mod_seconds, np.float32)
+    ch, F, bins, _ = pv.shape
+    Fo = lib.flanhip_modify_time_out_frames(_ptr(mod), F, bins, sample_rate, hop)
+    out = np.empty((ch, max(Fo, 0), bins, 2), np.float32)
+    if Fo > 0:
+        check(lib.flanhip_modify_time(_ptr(pv), ch, F, bins, sample_rate, hop, _ptr(mod), Fo, _ptr(out), None))
+    return out
+
+
+def modify_frequency(pv, sample_rate, mod_hz, in_modified):
+    pv = np.ascontiguousarray(pv, np.float32)
+    mod = np.ascontiguousarray(mod_hz, np.float32)
+    inm = np.ascontiguousarray(in_modified, np.float32)
+    ch, F, bins, _ = pv.shape
+    out = np.empty_like(pv)
+    check(lib.flanhip_modify_frequency(_ptr(pv), ch, F, bins, sample_rate, _ptr(mod), _ptr(inm), _ptr(out), None))
+    return out
+
+
+def shape_affine(pv, sample_rate, a, b, c, d, use_shift_alignment=False):
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    out = np.empty_like(pv)
+    check(lib.flanhip_shape_affine(_ptr(pv), ch, F, bins, sample_rate, a, b, c, d, int(use_shift_alignment), _ptr(out), None))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# device-pointer wrappers: arguments are objects with .data_ptr() (torch tensors on the GPU) or raw ints
+# ---------------------------------------------------------------------------------------------------------------
+
+def _dp(t):
+    if t is None:
+        return None
+    return _vp(t.data_ptr() if hasattr(t, "data_ptr") else int(t))
+
+
+def analyze_dev(d_audio, ch, n, sample_rate, window, hop, dft, d_out, stream=None):
+    check(lib.flanhip_analyze_dev(_dp(d_audio), ch, n, sample_rate, window, hop, dft, _dp(d_out), _vp(stream or 0)))
+
+
+def synthesize_workspace_bytes(ch, F, bins, sample_rate, analysis_rate, window):
+    return int(lib.flanhip_synthesize_workspace_bytes(ch, F, bins, sample_rate, analysis_rate, window))
+
+
+def synthesize_dev(d_pv, ch, F, bins, sample_rate, analysis_rate, window, d_out, d_ws, d_nan=None, stream=None):
+    check(lib.flanhip_synthesize_dev(_dp(d_pv), ch, F, bins, sample_rate, analysis_rate, window, _dp(d_out), _dp(d_ws),
+                                     _dp(d_nan), _vp(stream or 0)))

@@ -1,0 +1,248 @@
+// conversions.hip -- Audio::convert_to_PV and PV::convert_to_audio behind the C ABI
+// (reference: Conversions/AudioPV.cpp:12-78 and :86-139).
+#include "flanhip_internal.h"
+#include "pv_kernels.h"
+#include <algorithm>
+
+namespace flanhip {
+
+static constexpr size_t kMaxLds = 160 * 1024;   // gfx950: 160 KiB LDS per CU, one workgroup may take all of it
+
+static size_t analyze_lds_bytes( int C, int W, int waves )
+	{
+	const int wpad = ( W + 3 ) & ~3;
+	return size_t( C ) * 8 + size_t( wpad ) * 4 + size_t( waves ) * padded_len( C ) * 8;
+	}
+
+static size_t synth_lds_bytes( int C, int W, int waves )
+	{
+	const int wpad = ( W + 3 ) & ~3;
+	return size_t( C ) * 8 + size_t( wpad ) * 4 + size_t( waves ) * ( size_t( padded_len( C + 1 ) ) * 8 + size_t( wpad ) * 4 );
+	}
+
+template<int LOG2C, int WAVES>
+static int run_analyze( const AnalyzeParams & p, hipStream_t s )
+	{
+	const size_t lds = analyze_lds_bytes( 1 << LOG2C, p.window_size, WAVES );
+	FLANHIP_REQUIRE( lds <= kMaxLds, FLANHIP_ERR_UNSUPPORTED, "window/dft too large for LDS" );
+	auto kern = k_analyze<LOG2C, WAVES>;
+	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;
+	const int64_t blocks = ( chains + WAVES - 1 ) / WAVES;
+	FLANHIP_REQUIRE( blocks < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
+	hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( 64 * WAVES ), lds, s, p );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft, flanhip_MF * d_out, hipStream_t s )
+	{
+	FLANHIP_REQUIRE( d_audio && d_out, FLANHIP_ERR_INVALID_ARG, "null buffer" );
+	FLANHIP_REQUIRE( ch > 0 && n >= 0 && W >= 2 && hop >= 1 && sr > 0.0f, FLANHIP_ERR_INVALID_ARG, "bad sizes" );
+	FLANHIP_REQUIRE( W <= dft, FLANHIP_ERR_INVALID_ARG, "window_size larger than dft_size" );
+	FLANHIP_REQUIRE( is_pow2( dft ) && dft >= 32 && dft <= 8192, FLANHIP_ERR_UNSUPPORTED, "dft_size must be a power of two in [32, 8192]" );
+	if( int rc = require_device() ) return rc;
+	const Plan * plan = nullptr;
+	if( int rc = get_plan( W, dft, &plan ) ) return rc;
+
+	AnalyzeParams p;
+	p.audio = d_audio; p.out = reinterpret_cast<MF*>( d_out );
+	p.window = plan->d_window; p.tw = plan->d_tw; p.tw2 = plan->d_tw2;
+	p.n = n; p.F = n / hop + 1;                                   // AudioPV.cpp:17
+	p.num_channels = int( ch ); p.window_size = W; p.hop = hop;
+	p.L = choose_chain_length( ch, p.F, 1 );
+	p.chains_per_channel = int( ( p.F + p.L - 1 ) / p.L );
+	p.sample_rate = sr;
+	p.analysis_rate = sr / hop;                                   // AudioPV.cpp:26 (float / int)
+
+	switch( ilog2( dft ) - 1 )
+		{
+		case 4:  return run_analyze<4, 4>( p, s );
+		case 5:  return run_analyze<5, 4>( p, s );
+		case 6:  return run_analyze<6, 4>( p, s );
+		case 7:  return run_analyze<7, 4>( p, s );
+		case 8:  return run_analyze<8, 4>( p, s );
+		case 9:  return run_analyze<9, 4>( p, s );
+		case 10: return run_analyze<10, 4>( p, s );
+		case 11: return run_analyze<11, 4>( p, s );
+		case 12: return run_analyze<12, 2>( p, s );
+		}
+	set_error( "unsupported dft_size %d", dft );
+	return FLANHIP_ERR_UNSUPPORTED;
+	}
+
+int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, SynthLayout * o )
+	{
+	FLANHIP_REQUIRE( ch > 0 && F > 0 && bins >= 2 && W >= 2 && sr > 0.0f && ar > 0.0f, FLANHIP_ERR_INVALID_ARG, "bad sizes" );
+	o->dft = ( bins - 1 ) * 2;                                    // PVBuffer.cpp:356-359
+	o->hop = int( sr / ar );                                      // PVBuffer.cpp:381-384
+	FLANHIP_REQUIRE( o->hop >= 1, FLANHIP_ERR_INVALID_ARG, "analysis_rate above sample_rate: hop size 0" );
+	FLANHIP_REQUIRE( W <= o->dft, FLANHIP_ERR_INVALID_ARG, "window_size larger than dft size" );
+	FLANHIP_REQUIRE( is_pow2( o->dft ) && o->dft >= 32 && o->dft <= 8192, FLANHIP_ERR_UNSUPPORTED, "dft size must be a power of two in [32, 8192]" );
+	o->head_len = std::max( W - o->hop, 0 );
+	const int overlap = ( W + o->hop - 1 ) / o->hop;              // frames covering one output sample
+	o->L = choose_chain_length( ch, F, std::max( overlap - 1, 1 ) );
+	o->chains_per_channel = int( ( F + o->L - 1 ) / o->L );
+	const int64_t chains = int64_t( o->chains_per_channel ) * ch;
+	o->carry_bytes = ( size_t( chains ) * bins * sizeof( double ) + 255 ) & ~size_t( 255 );
+	o->head_bytes = ( size_t( chains ) * o->head_len * sizeof( float ) + 255 ) & ~size_t( 255 );
+	o->total_bytes = o->carry_bytes + o->head_bytes + 256;
+	return FLANHIP_OK;
+	}
+
+template<int LOG2C, int WAVES>
+static int run_synth( const SynthParams & p, hipStream_t s )
+	{
+	const size_t lds = synth_lds_bytes( 1 << LOG2C, p.window_size, WAVES );
+	FLANHIP_REQUIRE( lds <= kMaxLds, FLANHIP_ERR_UNSUPPORTED, "window/dft too large for LDS" );
+	auto kern = k_synthesize<LOG2C, WAVES>;
+	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;
+	const int64_t blocks = ( chains + WAVES - 1 ) / WAVES;
+	hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( 64 * WAVES ), lds, s, p );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+template<int LOG2C, int W_BIG, int W_SMALL>
+static int run_synth_pick( const SynthParams & p, hipStream_t s )
+	{
+	if( synth_lds_bytes( 1 << LOG2C, p.window_size, W_BIG ) <= kMaxLds ) return run_synth<LOG2C, W_BIG>( p, s );
+	return run_synth<LOG2C, W_SMALL>( p, s );
+	}
+
+int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float ar, int W, float * d_out,
+	void * d_ws, int * d_nan, hipStream_t s )
+	{
+	FLANHIP_REQUIRE( d_pv && d_out && d_ws, FLANHIP_ERR_INVALID_ARG, "null buffer" );
+	SynthLayout lay;
+	if( int rc = synth_layout( ch, F, bins, sr, ar, W, &lay ) ) return rc;
+	if( int rc = require_device() ) return rc;
+	const Plan * plan = nullptr;
+	if( int rc = get_plan( W, lay.dft, &plan ) ) return rc;
+
+	SynthParams p;
+	p.pv = reinterpret_cast<const MF*>( d_pv ); p.out = d_out;
+	p.window = plan->d_window; p.tw = plan->d_tw; p.tw2 = plan->d_tw2;
+	p.carry = reinterpret_cast<double*>( d_ws );
+	p.head = reinterpret_cast<float*>( reinterpret_cast<char*>( d_ws ) + lay.carry_bytes );
+	p.nan_flag = d_nan;
+	p.F = F; p.out_len = F * lay.hop;                              // AudioPV.cpp:93
+	p.num_channels = int( ch ); p.window_size = W; p.hop = lay.hop; p.L = lay.L;
+	p.chains_per_channel = lay.chains_per_channel; p.head_len = lay.head_len; p.num_bins = bins;
+	p.analysis_rate = ar;
+	p.window_scale = 2.67f / ( lay.dft * W / lay.hop );            // AudioPV.cpp:99 (integer arithmetic in the divisor)
+
+	const int64_t chains = int64_t( p.chains_per_channel ) * ch;
+	FLANHIP_REQUIRE( chains < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
+	hipLaunchKernelGGL( k_phase_sums, dim3( (unsigned) chains ), dim3( 256 ), 0, s, p );
+	FLANHIP_CHECK( hipGetLastError() );
+	const int64_t cols = ch * bins;
+	hipLaunchKernelGGL( k_phase_scan, dim3( (unsigned) ( ( cols + 255 ) / 256 ) ), dim3( 256 ), 0, s, p );
+	FLANHIP_CHECK( hipGetLastError() );
+
+	int rc = FLANHIP_ERR_UNSUPPORTED;
+	switch( ilog2( lay.dft ) - 1 )
+		{
+		case 4:  rc = run_synth<4, 8>( p, s ); break;
+		case 5:  rc = run_synth<5, 8>( p, s ); break;
+		case 6:  rc = run_synth<6, 8>( p, s ); break;
+		case 7:  rc = run_synth<7, 8>( p, s ); break;
+		case 8:  rc = run_synth<8, 8>( p, s ); break;
+		case 9:  rc = run_synth<9, 8>( p, s ); break;
+		case 10: rc = run_synth<10, 8>( p, s ); break;
+		case 11: rc = run_synth_pick<11, 4, 2>( p, s ); break;
+		case 12: rc = run_synth<12, 1>( p, s ); break;
+		default: set_error( "unsupported dft size %d", lay.dft );
+		}
+	if( rc ) return rc;
+	if( p.head_len > 0 && p.chains_per_channel > 1 )
+		{
+		hipLaunchKernelGGL( k_ola_fixup, dim3( (unsigned) chains ), dim3( 256 ), 0, s, p );
+		FLANHIP_CHECK( hipGetLastError() );
+		}
+	return FLANHIP_OK;
+	}
+
+struct DeviceBuffer
+	{
+	void * p = nullptr;
+	~DeviceBuffer() { if( p ) (void) hipFree( p ); }
+	int alloc( size_t bytes ) { FLANHIP_CHECK( hipMalloc( &p, bytes ? bytes : 1 ) ); return FLANHIP_OK; }
+	};
+
+} // namespace flanhip
+
+using namespace flanhip;
+
+extern "C" {
+
+int flanhip_analyze_dev( const float * d_audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft, flanhip_MF * d_out, void * stream )
+	{
+	return launch_analyze( d_audio, ch, n, sr, W, hop, dft, d_out, (hipStream_t) stream );
+	}
+
+int flanhip_analyze( const float * audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft,
+	flanhip_MF * out, int64_t * num_pv_frames, volatile int * cancel )
+	{
+	FLANHIP_REQUIRE( audio && out, FLANHIP_ERR_INVALID_ARG, "null buffer" );
+	FLANHIP_REQUIRE( ch > 0 && n >= 0 && hop >= 1, FLANHIP_ERR_INVALID_ARG, "bad sizes" );
+	if( int rc = require_device() ) return rc;
+	const int64_t F = n / hop + 1;
+	const int bins = dft / 2 + 1;
+	if( num_pv_frames ) *num_pv_frames = F;
+	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;       // flan_CANCEL_POINT, AudioPV.cpp:49
+	DeviceBuffer d_audio, d_pv;
+	if( int rc = d_audio.alloc( sizeof( float ) * size_t( ch ) * n ) ) return rc;
+	if( int rc = d_pv.alloc( sizeof( flanhip_MF ) * size_t( ch ) * F * bins ) ) return rc;
+	FLANHIP_CHECK( hipMemcpy( d_audio.p, audio, sizeof( float ) * size_t( ch ) * n, hipMemcpyHostToDevice ) );
+	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
+	if( int rc = launch_analyze( (const float*) d_audio.p, ch, n, sr, W, hop, dft, (flanhip_MF*) d_pv.p, nullptr ) ) return rc;
+	FLANHIP_CHECK( hipDeviceSynchronize() );
+	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
+	FLANHIP_CHECK( hipMemcpy( out, d_pv.p, sizeof( flanhip_MF ) * size_t( ch ) * F * bins, hipMemcpyDeviceToHost ) );
+	return FLANHIP_OK;
+	}
+
+size_t flanhip_synthesize_workspace_bytes( int64_t ch, int64_t F, int bins, float sr, float ar, int W )
+	{
+	SynthLayout lay;
+	if( synth_layout( ch, F, bins, sr, ar, W, &lay ) ) return 0;
+	return lay.total_bytes;
+	}
+
+int flanhip_synthesize_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float ar, int W,
+	float * d_out, void * d_ws, int * d_nan, void * stream )
+	{
+	return launch_synthesize( d_pv, ch, F, bins, sr, ar, W, d_out, d_ws, d_nan, (hipStream_t) stream );
+	}
+
+int flanhip_synthesize( const flanhip_MF * pv, int64_t ch, int64_t F, int bins, float sr, float ar, int W,
+	float * out, int * nan_flag, volatile int * cancel )
+	{
+	FLANHIP_REQUIRE( pv && out, FLANHIP_ERR_INVALID_ARG, "null buffer" );
+	SynthLayout lay;
+	if( int rc = synth_layout( ch, F, bins, sr, ar, W, &lay ) ) return rc;
+	if( int rc = require_device() ) return rc;
+	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;       // flan_CANCEL_POINT, AudioPV.cpp:115
+	const size_t pv_bytes = sizeof( flanhip_MF ) * size_t( ch ) * F * bins;
+	const size_t out_bytes = sizeof( float ) * size_t( ch ) * F * lay.hop;
+	DeviceBuffer d_pv, d_out, d_ws, d_flag;
+	if( int rc = d_pv.alloc( pv_bytes ) ) return rc;
+	if( int rc = d_out.alloc( out_bytes ) ) return rc;
+	if( int rc = d_ws.alloc( lay.total_bytes ) ) return rc;
+	if( int rc = d_flag.alloc( sizeof( int ) ) ) return rc;
+	FLANHIP_CHECK( hipMemset( d_flag.p, 0, sizeof( int ) ) );
+	FLANHIP_CHECK( hipMemcpy( d_pv.p, pv, pv_bytes, hipMemcpyHostToDevice ) );
+	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
+	if( int rc = launch_synthesize( (const flanhip_MF*) d_pv.p, ch, F, bins, sr, ar, W, (float*) d_out.p, d_ws.p, (int*) d_flag.p, nullptr ) ) return rc;
+	FLANHIP_CHECK( hipDeviceSynchronize() );
+	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
+	FLANHIP_CHECK( hipMemcpy( out, d_out.p, out_bytes, hipMemcpyDeviceToHost ) );
+	int flag = 0;
+	FLANHIP_CHECK( hipMemcpy( &flag, d_flag.p, sizeof( int ), hipMemcpyDeviceToHost ) );
+	if( nan_flag ) *nan_flag = flag;
+	return FLANHIP_OK;
+	}
+
+} // extern "C"

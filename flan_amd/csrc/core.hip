@@ -1,0 +1,166 @@
+// core.hip -- error state, device plumbing, plan cache, shape helpers of the C ABI (include/flanhip.h).
+#include "flanhip_internal.h"
+#include <cstdlib>
+#include <cstring>
+
+namespace flanhip {
+
+static thread_local char g_error[512] = "";
+
+void set_error( const char * fmt, ... )
+	{
+	va_list ap; va_start( ap, fmt );
+	vsnprintf( g_error, sizeof( g_error ), fmt, ap );
+	va_end( ap );
+	}
+
+int require_device()
+	{
+	int count = 0;
+	if( hipGetDeviceCount( &count ) != hipSuccess || count <= 0 )
+		{
+		(void) hipGetLastError();
+		set_error( "no HIP device visible: the phase-vocoder path has no CPU fallback" );
+		return FLANHIP_ERR_NO_DEVICE;
+		}
+	return FLANHIP_OK;
+	}
+
+// WindowFunctions.cpp:8-13 as libstdc++ evaluates it: float product widened, ::cos(double), narrowed once.
+static float hann_host( float x )
+	{
+	const float pi = std::acos( -1.0f );
+	return float( 0.5f * ( 1.0f - std::cos( double( 2.0f * pi * x ) ) ) );
+	}
+
+static std::mutex g_plan_mutex;   // FFTHelper.cpp:9 serialises plan creation the same way
+static std::map<std::tuple<int, int, int>, Plan> g_plans;
+
+int get_plan( int window_size, int dft_size, const Plan ** out )
+	{
+	int device = 0;
+	FLANHIP_CHECK( hipGetDevice( &device ) );
+	std::lock_guard<std::mutex> lock( g_plan_mutex );
+	const auto key = std::make_tuple( device, window_size, dft_size );
+	auto it = g_plans.find( key );
+	if( it != g_plans.end() ) { *out = &it->second; return FLANHIP_OK; }
+
+	const int C = dft_size / 2;
+	std::vector<float> win( window_size );
+	for( int i = 0; i < window_size; ++i ) win[i] = hann_host( float( i ) / float( window_size - 1 ) );  // AudioPV.cpp:30-34
+	std::vector<float2> tw( C ), tw2( C + 1 );
+	const double pi = 3.14159265358979323846;
+	for( int k = 0; k < C; ++k ) tw[k] = make_float2( float( std::cos( -2.0 * pi * k / C ) ), float( std::sin( -2.0 * pi * k / C ) ) );
+	for( int k = 0; k <= C; ++k ) tw2[k] = make_float2( float( std::cos( -pi * k / C ) ), float( std::sin( -pi * k / C ) ) );
+
+	Plan plan;
+	FLANHIP_CHECK( hipMalloc( &plan.d_window, sizeof( float ) * window_size ) );
+	FLANHIP_CHECK( hipMalloc( &plan.d_tw, sizeof( float2 ) * C ) );
+	FLANHIP_CHECK( hipMalloc( &plan.d_tw2, sizeof( float2 ) * ( C + 1 ) ) );
+	FLANHIP_CHECK( hipMemcpy( plan.d_window, win.data(), sizeof( float ) * window_size, hipMemcpyHostToDevice ) );
+	FLANHIP_CHECK( hipMemcpy( plan.d_tw, tw.data(), sizeof( float2 ) * C, hipMemcpyHostToDevice ) );
+	FLANHIP_CHECK( hipMemcpy( plan.d_tw2, tw2.data(), sizeof( float2 ) * ( C + 1 ), hipMemcpyHostToDevice ) );
+	auto ins = g_plans.emplace( key, plan );
+	*out = &ins.first->second;
+	return FLANHIP_OK;
+	}
+
+int choose_chain_length( int64_t num_channels, int64_t num_frames, int min_len )
+	{
+	if( const char * env = std::getenv( "FLANHIP_CHAIN_LEN" ) )
+		{
+		const int v = std::atoi( env );
+		if( v > 0 ) return std::max( v, min_len );
+		}
+	// enough chains to give every SIMD of the 256 CUs a few wavefronts, long enough to amortise the per-chain halo
+	const int64_t total = num_channels * num_frames;
+	int64_t L = total / 4096;
+	if( L < 4 ) L = 4;
+	if( L > 64 ) L = 64;
+	if( L < min_len ) L = min_len;
+	return int( L );
+	}
+
+} // namespace flanhip
+
+using namespace flanhip;
+
+extern "C" {
+
+int flanhip_version( void ) { return 100; }   // 0.1.0
+const char * flanhip_last_error( void ) { return g_error; }
+
+int flanhip_device_count( void )
+	{
+	int count = 0;
+	if( hipGetDeviceCount( &count ) != hipSuccess ) { (void) hipGetLastError(); return 0; }
+	return count;
+	}
+
+int flanhip_set_device( int device )
+	{
+	if( int rc = require_device() ) return rc;
+	FLANHIP_CHECK( hipSetDevice( device ) );
+	return FLANHIP_OK;
+	}
+
+int64_t flanhip_num_pv_frames( int64_t num_audio_frames, int hop )
+	{
+	if( hop <= 0 || num_audio_frames < 0 ) return -1;
+	return num_audio_frames / hop + 1;                 // AudioPV.cpp:17: std::ceil of an INTEGER quotient, + 1
+	}
+
+int flanhip_hop_size( float sample_rate, float analysis_rate )
+	{
+	return int( sample_rate / analysis_rate );         // PVBuffer.cpp:381-384
+	}
+
+int64_t flanhip_modify_time_out_frames( const float * mod, int64_t num_frames, int num_bins, float sample_rate, int hop )
+	{
+	if( !mod || num_frames <= 0 || num_bins <= 0 || hop <= 0 ) return -1;
+	float mx = mod[0];                                  // FunctionSample::maximum(), FunctionSample.h:156-160
+	for( int64_t i = 1; i < num_frames * num_bins; ++i ) mx = std::max( mx, mod[i] );
+	const float last = std::ceil( mx * float( sample_rate ) / float( hop ) );  // PVModify.cpp:312, PVBuffer.cpp:428-431
+	return int64_t( int32_t( last ) );                  // :315 float -> Frame
+	}
+
+int flanhip_malloc( void ** dptr, size_t bytes )
+	{
+	FLANHIP_REQUIRE( dptr, FLANHIP_ERR_INVALID_ARG, "null out pointer" );
+	if( int rc = require_device() ) return rc;
+	FLANHIP_CHECK( hipMalloc( dptr, bytes ? bytes : 1 ) );
+	return FLANHIP_OK;
+	}
+
+int flanhip_free( void * dptr )
+	{
+	if( !dptr ) return FLANHIP_OK;
+	FLANHIP_CHECK( hipFree( dptr ) );
+	return FLANHIP_OK;
+	}
+
+int flanhip_memcpy_h2d( void * dst, const void * src, size_t bytes, void * stream )
+	{
+	FLANHIP_CHECK( hipMemcpyAsync( dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t) stream ) );
+	return FLANHIP_OK;
+	}
+
+int flanhip_memcpy_d2h( void * dst, const void * src, size_t bytes, void * stream )
+	{
+	FLANHIP_CHECK( hipMemcpyAsync( dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t) stream ) );
+	return FLANHIP_OK;
+	}
+
+int flanhip_memset( void * dst, int value, size_t bytes, void * stream )
+	{
+	FLANHIP_CHECK( hipMemsetAsync( dst, value, bytes, (hipStream_t) stream ) );
+	return FLANHIP_OK;
+	}
+
+int flanhip_stream_synchronize( void * stream )
+	{
+	FLANHIP_CHECK( hipStreamSynchronize( (hipStream_t) stream ) );
+	return FLANHIP_OK;
+	}
+
+} // extern "C"

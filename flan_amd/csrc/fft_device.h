@@ -1,0 +1,167 @@
+// fft_device.h -- wave-private, in-LDS Stockham FFT for gfx950 (one 64-lane wavefront per transform).
+//
+// Replaces the FFTW3f plans of the reference (FFTHelper.cpp:16-48: fftwf_plan_dft_r2c_1d / c2r_1d).
+// A real transform of size N is done as a complex transform of C = N/2 points plus a split/merge step.
+//
+// Layout: the C complex points live in a wave-private LDS buffer, index i stored at PAD(i) = i + (i >> 4)
+// (one float2 of padding per 16 keeps the radix-16 scatter writes of the first pass on distinct banks).
+// Each pass is in place: every lane first reads ALL of its butterflies' inputs into registers, then writes.
+// A wavefront issues its LDS operations in program order, so reads-before-writes within one wave needs no
+// barrier, only a compiler fence (wave_sync()).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace flanhip {
+
+__device__ __forceinline__ int PAD( int i ) { return i + ( i >> 4 ); }
+__host__ __device__ constexpr int padded_len( int n ) { return n + ( n >> 4 ) + 2; }
+
+__device__ __forceinline__ void wave_sync()
+	{
+	__builtin_amdgcn_fence( __ATOMIC_SEQ_CST, "wavefront" );
+	__builtin_amdgcn_wave_barrier();
+	}
+
+__device__ __forceinline__ float2 cadd( float2 a, float2 b ) { return make_float2( a.x + b.x, a.y + b.y ); }
+__device__ __forceinline__ float2 csub( float2 a, float2 b ) { return make_float2( a.x - b.x, a.y - b.y ); }
+__device__ __forceinline__ float2 cmul( float2 a, float2 b )
+	{
+	return make_float2( __builtin_fmaf( a.x, b.x, -( a.y * b.y ) ), __builtin_fmaf( a.x, b.y, a.y * b.x ) );
+	}
+// multiply by -i
+__device__ __forceinline__ float2 mul_mi( float2 a ) { return make_float2( a.y, -a.x ); }
+
+// cos/sin of 2*pi*k/16, k = 0..7  (twiddles inside the register DFTs)
+#define FLANHIP_C1 0.92387953251128675613f  /* cos(pi/8) */
+#define FLANHIP_S1 0.38268343236508977173f  /* sin(pi/8) */
+#define FLANHIP_SQH  0.70710678118654752440f  /* sqrt(1/2) */
+
+// x * exp(-2*pi*i*K/16)
+template<int K> __device__ __forceinline__ float2 mul_w16( float2 a )
+	{
+	if constexpr( K == 0 ) return a;
+	else if constexpr( K == 4 ) return mul_mi( a );
+	else if constexpr( K == 2 ) return make_float2( ( a.x + a.y ) * FLANHIP_SQH, ( a.y - a.x ) * FLANHIP_SQH );
+	else if constexpr( K == 6 ) return make_float2( ( a.y - a.x ) * FLANHIP_SQH, -( a.x + a.y ) * FLANHIP_SQH );
+	else if constexpr( K == 1 ) return cmul( a, make_float2(  FLANHIP_C1, -FLANHIP_S1 ) );
+	else if constexpr( K == 3 ) return cmul( a, make_float2(  FLANHIP_S1, -FLANHIP_C1 ) );
+	else if constexpr( K == 5 ) return cmul( a, make_float2( -FLANHIP_S1, -FLANHIP_C1 ) );
+	else                         return cmul( a, make_float2( -FLANHIP_C1, -FLANHIP_S1 ) ); // K == 7
+	}
+
+// Forward R-point DFT (sign -), natural order in and out, fully in registers.
+template<int R> struct Reg { float2 v[R]; };
+
+template<int R> __device__ __forceinline__ void dft_reg( float2 * v );
+
+template<> __device__ __forceinline__ void dft_reg<1>( float2 * ) {}
+template<> __device__ __forceinline__ void dft_reg<2>( float2 * v )
+	{
+	const float2 a = v[0], b = v[1];
+	v[0] = cadd( a, b ); v[1] = csub( a, b );
+	}
+template<> __device__ __forceinline__ void dft_reg<4>( float2 * v )
+	{
+	const float2 t0 = cadd( v[0], v[2] ), t1 = csub( v[0], v[2] );
+	const float2 t2 = cadd( v[1], v[3] ), t3 = mul_mi( csub( v[1], v[3] ) );
+	v[0] = cadd( t0, t2 ); v[1] = cadd( t1, t3 ); v[2] = csub( t0, t2 ); v[3] = csub( t1, t3 );
+	}
+template<> __device__ __forceinline__ void dft_reg<8>( float2 * v )
+	{
+	float2 e[4] = { v[0], v[2], v[4], v[6] };
+	float2 o[4] = { v[1], v[3], v[5], v[7] };
+	dft_reg<4>( e ); dft_reg<4>( o );
+	const float2 o1 = mul_w16<2>( o[1] ), o2 = mul_w16<4>( o[2] ), o3 = mul_w16<6>( o[3] );
+	v[0] = cadd( e[0], o[0] ); v[4] = csub( e[0], o[0] );
+	v[1] = cadd( e[1], o1 );   v[5] = csub( e[1], o1 );
+	v[2] = cadd( e[2], o2 );   v[6] = csub( e[2], o2 );
+	v[3] = cadd( e[3], o3 );   v[7] = csub( e[3], o3 );
+	}
+template<> __device__ __forceinline__ void dft_reg<16>( float2 * v )
+	{
+	// 4 x 4 decomposition: n = 4*n1 + n2, k = k1 + 4*k2
+	float2 c[4][4];
+	#pragma unroll
+	for( int n2 = 0; n2 < 4; ++n2 )
+		{
+		float2 t[4] = { v[n2], v[4 + n2], v[8 + n2], v[12 + n2] };
+		dft_reg<4>( t );
+		#pragma unroll
+		for( int k1 = 0; k1 < 4; ++k1 ) c[n2][k1] = t[k1];
+		}
+	// twiddle W16^(n2*k1)
+	c[1][1] = mul_w16<1>( c[1][1] ); c[1][2] = mul_w16<2>( c[1][2] ); c[1][3] = mul_w16<3>( c[1][3] );
+	c[2][1] = mul_w16<2>( c[2][1] ); c[2][2] = mul_w16<4>( c[2][2] ); c[2][3] = mul_w16<6>( c[2][3] );
+	c[3][1] = mul_w16<3>( c[3][1] ); c[3][2] = mul_w16<6>( c[3][2] );
+	// W16^9 = -W16^1
+		{
+		const float2 t = mul_w16<1>( c[3][3] );
+		c[3][3] = make_float2( -t.x, -t.y );
+		}
+	#pragma unroll
+	for( int k1 = 0; k1 < 4; ++k1 )
+		{
+		float2 t[4] = { c[0][k1], c[1][k1], c[2][k1], c[3][k1] };
+		dft_reg<4>( t );
+		#pragma unroll
+		for( int k2 = 0; k2 < 4; ++k2 ) v[k1 + 4 * k2] = t[k2];
+		}
+	}
+
+// One in-place Stockham pass of radix R over C points, sub-transform length NS on entry.
+// tw[i] = exp(-2*pi*i*i/C), i < C (LDS, shared by the block's waves).
+template<int C, int R, int NS>
+__device__ __forceinline__ void fft_pass( float2 * buf, const float2 * tw, int lane )
+	{
+	constexpr int NB = C / R;                       // butterflies in this pass
+	constexpr int PER = ( NB + 63 ) / 64;           // per lane
+	float2 v[PER][R];
+	#pragma unroll
+	for( int b = 0; b < PER; ++b )
+		{
+		const int j = lane + 64 * b;
+		if( NB >= 64 || j < NB )
+			{
+			#pragma unroll
+			for( int r = 0; r < R; ++r ) v[b][r] = buf[PAD( j + r * NB )];
+			}
+		}
+	wave_sync();
+	#pragma unroll
+	for( int b = 0; b < PER; ++b )
+		{
+		const int j = lane + 64 * b;
+		if( NB >= 64 || j < NB )
+			{
+			const int k = j & ( NS - 1 );
+			if constexpr( NS > 1 )
+				{
+				constexpr int STRIDE = C / ( NS * R );
+				#pragma unroll
+				for( int r = 1; r < R; ++r ) v[b][r] = cmul( v[b][r], tw[r * k * STRIDE] );
+				}
+			dft_reg<R>( v[b] );
+			const int base = ( j - k ) * R + k;
+			#pragma unroll
+			for( int r = 0; r < R; ++r ) buf[PAD( base + r * NS )] = v[b][r];
+			}
+		}
+	wave_sync();
+	}
+
+// Forward complex FFT of C = 2^LOG2C points, in place in `buf` (padded layout), natural order in and out.
+template<int LOG2C> __device__ __forceinline__ void fft_forward( float2 * buf, const float2 * tw, int lane )
+	{
+	constexpr int C = 1 << LOG2C;
+	if constexpr( LOG2C == 4 )       { fft_pass<C, 16, 1>( buf, tw, lane ); }
+	else if constexpr( LOG2C == 5 )  { fft_pass<C, 8, 1>( buf, tw, lane );  fft_pass<C, 4, 8>( buf, tw, lane ); }
+	else if constexpr( LOG2C == 6 )  { fft_pass<C, 8, 1>( buf, tw, lane );  fft_pass<C, 8, 8>( buf, tw, lane ); }
+	else if constexpr( LOG2C == 7 )  { fft_pass<C, 16, 1>( buf, tw, lane ); fft_pass<C, 8, 16>( buf, tw, lane ); }
+	else if constexpr( LOG2C == 8 )  { fft_pass<C, 16, 1>( buf, tw, lane ); fft_pass<C, 16, 16>( buf, tw, lane ); }
+	else if constexpr( LOG2C == 9 )  { fft_pass<C, 8, 1>( buf, tw, lane );  fft_pass<C, 8, 8>( buf, tw, lane );   fft_pass<C, 8, 64>( buf, tw, lane ); }
+	else if constexpr( LOG2C == 10 ) { fft_pass<C, 16, 1>( buf, tw, lane ); fft_pass<C, 16, 16>( buf, tw, lane ); fft_pass<C, 4, 256>( buf, tw, lane ); }
+	else if constexpr( LOG2C == 11 ) { fft_pass<C, 16, 1>( buf, tw, lane ); fft_pass<C, 16, 16>( buf, tw, lane ); fft_pass<C, 8, 256>( buf, tw, lane ); }
+	else                             { fft_pass<C, 16, 1>( buf, tw, lane ); fft_pass<C, 16, 16>( buf, tw, lane ); fft_pass<C, 16, 256>( buf, tw, lane ); }
+	}
+
+} // namespace flanhip

@@ -1,0 +1,55 @@
+// flanhip_internal.h -- host-side plumbing shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#include "flanhip.h"
+
+namespace flanhip {
+
+void set_error( const char * fmt, ... );
+
+#define FLANHIP_CHECK( expr )                                                                         \
+	do { hipError_t e_ = ( expr );                                                                    \
+		if( e_ != hipSuccess ) {                                                                      \
+			::flanhip::set_error( "%s failed: %s (%s:%d)", #expr, hipGetErrorString( e_ ), __FILE__, __LINE__ ); \
+			return FLANHIP_ERR_HIP; } } while( 0 )
+
+#define FLANHIP_REQUIRE( cond, code, msg )                                                            \
+	do { if( !( cond ) ) { ::flanhip::set_error( "%s: %s", __func__, msg ); return code; } } while( 0 )
+
+int require_device();   // FLANHIP_OK or FLANHIP_ERR_NO_DEVICE
+
+inline bool is_pow2( int64_t n ) { return n > 0 && ( n & ( n - 1 ) ) == 0; }
+inline int ilog2( int64_t n ) { int l = 0; while( ( int64_t( 1 ) << l ) < n ) ++l; return l; }
+inline bool cancelled( volatile int * c ) { return c && *c != 0; }
+
+// Device tables for one (window, dft) pair on one device: the analogue of the reference's FFTHelper plan
+// (FFTHelper.cpp:16-26) plus the sampled Hann window (AudioPV.cpp:30-34).  Built once, cached, never freed.
+struct Plan
+	{
+	float * d_window = nullptr;    // [W]   hann( i/(W-1) ), WindowFunctions.cpp:10-13 evaluated on the host in double
+	float2 * d_tw = nullptr;       // [C]   exp(-2 pi i k / C)
+	float2 * d_tw2 = nullptr;      // [C+1] exp(-2 pi i k / (2C))
+	};
+int get_plan( int window_size, int dft_size, const Plan ** out );
+
+// Chain length heuristics (frames per wavefront-chain)
+int choose_chain_length( int64_t num_channels, int64_t num_frames, int min_len );
+
+// Launchers implemented in analyze.hip / synthesize.hip / processors.hip
+int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft, flanhip_MF * d_out, hipStream_t s );
+int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float ar, int W, float * d_out,
+	void * d_ws, int * d_nan, hipStream_t s );
+
+struct SynthLayout { int hop, dft, L, chains_per_channel, head_len; size_t carry_bytes, head_bytes, total_bytes; };
+int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, SynthLayout * out );
+
+} // namespace flanhip

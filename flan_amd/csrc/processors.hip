@@ -1,0 +1,373 @@
+// processors.hip -- PV frame processors behind the C ABI: modify_time_base / stretch, modify_frequency_base / repitch,
+// shape (reference: PV/PVModify.cpp:196-257, :273-385; PV/PV.cpp:421-458).
+//
+// These algorithms are order dependent by definition (a running, magnitude-weighted average per (channel, bin) over
+// frames; a "louder wins, magnitudes add" rule per (channel, frame) over bins), so each kernel keeps the reference's
+// sequential order along the dependent axis and spreads the independent axes over lanes:
+//   k_modify_time      : lane = bin      (adjacent lanes -> adjacent bins: coalesced 8-byte MF traffic), loop over frames
+//   k_modify_frequency : lane = frame    (rows are walked by one lane; the row stays in L2)
+//   k_shape            : lane = element (no alignment) or lane = frame (shift alignment: conflict rule is sequential)
+#include "flanhip_internal.h"
+#include <algorithm>
+
+namespace flanhip {
+
+struct MFd { float m, f; };
+
+// PVBuffer.cpp:428-431, :433-436, :438-441, :443-446
+__device__ __forceinline__ float time_to_frame( float t, float sr, float hop ) { return t * sr / hop; }
+__device__ __forceinline__ float frame_to_time( float f, float sr, float hop ) { return f / ( sr / hop ); }
+__device__ __forceinline__ float frequency_to_bin( float f, float sr, float dft ) { return f / ( sr / dft ); }
+__device__ __forceinline__ float bin_to_frequency( float b, float sr, float dft ) { return b * sr / dft; }
+
+// modify_time_base, PVModify.cpp:319-359 (linear Interpolator, Utility/Interpolator.cpp:50-56).  out is zeroed by the caller.
+__global__ __launch_bounds__( 256 ) void k_modify_time( const MFd * in, int num_channels, int64_t F, int bins, float sr, float hop,
+	const float * mod, int64_t Fo, MFd * out )
+	{
+	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
+	if( idx >= int64_t( num_channels ) * bins ) return;
+	const int channel = int( idx / bins ), bin = int( idx % bins );
+	const MFd * ip = in + int64_t( channel ) * F * bins + bin;
+	MFd * op = out + int64_t( channel ) * Fo * bins + bin;
+	const float * mp = mod + bin;
+	MFd lMF = ip[0];
+	float lFrame = time_to_frame( mp[0], sr, hop );
+	for( int64_t frame = 1; frame < F; ++frame )                                   // :328
+		{
+		const MFd rMF = ip[frame * bins];
+		const float rFrame = time_to_frame( mp[frame * bins], sr, hop );            // :331
+		const bool forward = rFrame > lFrame;                                       // :332
+		const int start_frame = int( forward ? ceilf( lFrame ) : floorf( lFrame ) ); // :334
+		const int end_frame   = int( forward ? ceilf( rFrame ) : floorf( rFrame ) ); // :335
+		for( int x = start_frame; x != end_frame; forward ? ++x : --x )             // :340
+			{
+			if( x < 0 || Fo <= x ) continue;                                        // :342
+			const float mix = ( float( x ) - lFrame ) / ( rFrame - lFrame );        // :344
+			const float w0 = ( 1.0f - mix ) * lMF.m;
+			const float w1 = mix * rMF.m;
+			const float totalWeight = w0 + w1;
+			const float weightedFreqSum = w0 * lMF.f + w1 * rMF.f;
+			if( totalWeight == 0.0f ) break;                                        // :350-351 (`return` leaves this frame pair)
+			MFd o = op[int64_t( x ) * bins];
+			o.f = ( o.f * o.m + weightedFreqSum ) / ( o.m + totalWeight );          // :354
+			o.m += totalWeight;                                                     // :355
+			op[int64_t( x ) * bins] = o;
+			}
+		lMF = rMF; lFrame = rFrame;
+		}
+	}
+
+// PV::stretch, PVModify.cpp:376-382: inclusive running sum over frames per bin in fp32 (sequential order = the
+// reference's rounding), then frame_to_time; also the maximum of the result (FunctionSample::maximum, :312).
+__global__ __launch_bounds__( 256 ) void k_stretch_map( float * factor, int64_t F, int bins, float sr, float hop, float * d_max )
+	{
+	const int bin = blockIdx.x * blockDim.x + threadIdx.x;
+	float mx = -INFINITY;
+	if( bin < bins )
+		{
+		float run = 0.0f;
+		float * p = factor + bin;
+		for( int64_t frame = 0; frame < F; ++frame, p += bins )
+			{
+			run = ( frame == 0 ) ? *p : *p + run;                                   // factor[frame] += factor[frame-1]
+			const float t = frame_to_time( run, sr, hop );
+			*p = t;
+			mx = fmaxf( mx, t );
+			}
+		}
+	for( int o = 32; o > 0; o >>= 1 ) mx = fmaxf( mx, __shfl_xor( mx, o ) );
+	if( d_max && ( threadIdx.x & 63 ) == 0 && mx > -INFINITY )
+		{
+		// float max through an order-preserving integer key
+		int * addr = reinterpret_cast<int*>( d_max );
+		int old = *addr;
+		while( true )
+			{
+			const float cur = __int_as_float( old );
+			if( !( mx > cur ) ) break;
+			const int prev = atomicCAS( addr, old, __float_as_int( mx ) );
+			if( prev == old ) break;
+			old = prev;
+			}
+		}
+	}
+
+// PV::repitch, PVModify.cpp:278-284: inclusive running sum over bins per frame (fp32, sequential), bin_to_frequency.
+__global__ __launch_bounds__( 256 ) void k_repitch_scan( float * factor, int64_t F, int bins, float sr, float dft )
+	{
+	const int64_t frame = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
+	if( frame >= F ) return;
+	float * p = factor + frame * bins;
+	float run = 0.0f;
+	for( int bin = 0; bin < bins; ++bin )
+		{
+		run = ( bin == 0 ) ? p[0] : p[bin] + run;
+		p[bin] = bin_to_frequency( run, sr, dft );
+		}
+	}
+
+// PVModify.cpp:289-302: every MF's own frequency looked up (lerp) in the per-frame map.
+__global__ __launch_bounds__( 256 ) void k_repitch_lerp( const MFd * in, int64_t count, int64_t F, int bins, float sr, float dft,
+	const float * map, float * in_modified )
+	{
+	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
+	if( idx >= count ) return;
+	const int64_t frame = ( idx / bins ) % F;
+	const float fbin = fminf( fmaxf( frequency_to_bin( in[idx].f, sr, dft ), 0.0f ), float( bins - 1 ) - 0.0001f ); // std::clamp
+	const int lo = int( floorf( fbin ) );
+	const int hi = lo + 1;
+	const float lo_freq = map[frame * bins + lo];
+	const float hi_freq = map[frame * bins + hi];
+	const float r = fbin - float( lo );
+	in_modified[idx] = lo_freq * ( 1.0f - r ) + hi_freq * r;
+	}
+
+// modify_frequency_base, PVModify.cpp:207-253.  out is zeroed by the caller.  One lane per (channel, frame).
+__global__ __launch_bounds__( 64 ) void k_modify_frequency( const MFd * in, int num_channels, int64_t F, int bins, float sr, float dft,
+	const float * mod, const float * in_modified, MFd * out )
+	{
+	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
+	if( idx >= int64_t( num_channels ) * F ) return;
+	const int64_t frame = idx % F;
+	const MFd * row = in + idx * bins;
+	MFd * orow = out + idx * bins;
+	const float * mrow = mod + frame * bins;
+	const float * irow = in_modified + idx * bins;
+	float loBin = frequency_to_bin( mrow[0], sr, dft );
+	MFd loMF = { row[0].m, irow[0] };
+	for( int bin = 1; bin < bins; ++bin )                                           // :214
+		{
+		const float hiBin = frequency_to_bin( mrow[bin], sr, dft );                 // :219
+		const MFd hiMF = { row[bin].m, irow[bin] };                                 // :228
+		const bool forward = hiBin > loBin;                                         // :220
+		const int loR = int( forward ? ceilf( loBin ) : floorf( loBin ) );          // :222
+		const int hiR = int( forward ? ceilf( hiBin ) : floorf( hiBin ) );          // :223
+		const int start_bin = min( max( loR, 0 ), bins - 1 );                       // :224
+		const int end_bin   = min( max( hiR, 0 ), bins - 1 );                       // :225
+		for( int y = start_bin; y != end_bin; forward ? ++y : --y )                 // :230
+			{
+			const float mix = ( float( y ) - loBin ) / ( hiBin - loBin );           // :232
+			const float w0 = ( 1.0f - mix ) * loMF.m;
+			const float w1 = mix * hiMF.m;
+			const MFd mx = w0 < w1 ? loMF : hiMF;                                   // :237
+			MFd o = orow[y];
+			if( mx.m > o.m )                                                        // :239
+				{
+				o.m += mx.m;                                                        // :241
+				o.f = mx.f;                                                         // :242
+				orow[y] = o;
+				}
+			}
+		loBin = hiBin; loMF = hiMF;
+		}
+	}
+
+// PV::shape, PV.cpp:431-454.  AFFINE: shaped = { a*m + b, c*f + d }; otherwise shaped values come from `shaped_tbl`.
+template<bool AFFINE>
+__global__ __launch_bounds__( 256 ) void k_shape_plain( const MFd * in, const MFd * shaped_tbl, int64_t count, float a, float b, float c, float d, MFd * out )
+	{
+	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
+	if( idx >= count ) return;
+	if( AFFINE ) { const MFd v = in[idx]; out[idx] = MFd{ a * v.m + b, c * v.f + d }; }   // :436, :452
+	else out[idx] = shaped_tbl[idx];
+	}
+
+template<bool AFFINE>
+__global__ __launch_bounds__( 64 ) void k_shape_aligned( const MFd * in, const MFd * shaped_tbl, int64_t rows, int bins, float sr, float dft,
+	float a, float b, float c, float d, MFd * out )
+	{
+	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
+	if( idx >= rows ) return;
+	const MFd * row = in + idx * bins;
+	MFd * orow = out + idx * bins;
+	for( int bin = 0; bin < bins; ++bin )                                           // :433
+		{
+		const MFd v = row[bin];
+		const MFd s = AFFINE ? MFd{ a * v.m + b, c * v.f + d } : shaped_tbl[idx * bins + bin];
+		const int binShift = int( float( bin ) - frequency_to_bin( v.f, sr, dft ) ); // :440
+		const int shapedBin = int( frequency_to_bin( s.f, sr, dft ) + float( binShift ) ); // :441
+		if( shapedBin < 0 || bins <= shapedBin ) continue;                          // :442
+		if( s.m > orow[shapedBin].m ) orow[shapedBin] = s;                          // :445-447
+		}
+	}
+
+struct DevBuf
+	{
+	void * p = nullptr;
+	~DevBuf() { if( p ) (void) hipFree( p ); }
+	int alloc( size_t bytes ) { FLANHIP_CHECK( hipMalloc( &p, bytes ? bytes : 1 ) ); return FLANHIP_OK; }
+	};
+
+static int check_pv_args( const void * a, const void * b, int64_t ch, int64_t F, int bins, float sr )
+	{
+	FLANHIP_REQUIRE( a && b, FLANHIP_ERR_INVALID_ARG, "null buffer" );
+	FLANHIP_REQUIRE( ch > 0 && F > 0 && bins >= 2 && sr > 0.0f, FLANHIP_ERR_INVALID_ARG, "bad sizes" );
+	return require_device();
+	}
+
+} // namespace flanhip
+
+using namespace flanhip;
+
+extern "C" {
+
+int flanhip_modify_time_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, int hop, const float * d_mod,
+	int64_t Fo, flanhip_MF * d_out, void * stream )
+	{
+	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, sr ) ) return rc;
+	FLANHIP_REQUIRE( d_mod && hop >= 1 && Fo > 0, FLANHIP_ERR_INVALID_ARG, "bad map / output length" );
+	hipStream_t s = (hipStream_t) stream;
+	FLANHIP_CHECK( hipMemsetAsync( d_out, 0, sizeof( flanhip_MF ) * size_t( ch ) * Fo * bins, s ) );   // clear_buffer, PVModify.cpp:317
+	const int64_t threads = ch * bins;
+	hipLaunchKernelGGL( k_modify_time, dim3( (unsigned) ( ( threads + 255 ) / 256 ) ), dim3( 256 ), 0, s,
+		(const MFd*) d_pv, int( ch ), F, bins, sr, float( hop ), d_mod, Fo, (MFd*) d_out );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+int flanhip_modify_time( const flanhip_MF * pv, int64_t ch, int64_t F, int bins, float sr, int hop, const float * mod,
+	int64_t Fo, flanhip_MF * out, volatile int * cancel )
+	{
+	if( int rc = check_pv_args( pv, out, ch, F, bins, sr ) ) return rc;
+	FLANHIP_REQUIRE( mod && hop >= 1 && Fo > 0, FLANHIP_ERR_INVALID_ARG, "bad map / output length" );
+	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
+	DevBuf d_pv, d_mod, d_out;
+	const size_t in_bytes = sizeof( flanhip_MF ) * size_t( ch ) * F * bins, mod_bytes = sizeof( float ) * size_t( F ) * bins;
+	const size_t out_bytes = sizeof( flanhip_MF ) * size_t( ch ) * Fo * bins;
+	if( int rc = d_pv.alloc( in_bytes ) ) return rc;
+	if( int rc = d_mod.alloc( mod_bytes ) ) return rc;
+	if( int rc = d_out.alloc( out_bytes ) ) return rc;
+	FLANHIP_CHECK( hipMemcpy( d_pv.p, pv, in_bytes, hipMemcpyHostToDevice ) );
+	FLANHIP_CHECK( hipMemcpy( d_mod.p, mod, mod_bytes, hipMemcpyHostToDevice ) );
+	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
+	if( int rc = flanhip_modify_time_dev( (const flanhip_MF*) d_pv.p, ch, F, bins, sr, hop, (const float*) d_mod.p, Fo, (flanhip_MF*) d_out.p, nullptr ) ) return rc;
+	FLANHIP_CHECK( hipDeviceSynchronize() );
+	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
+	FLANHIP_CHECK( hipMemcpy( out, d_out.p, out_bytes, hipMemcpyDeviceToHost ) );
+	return FLANHIP_OK;
+	}
+
+int flanhip_stretch_map_dev( float * d_factor, int64_t F, int bins, float sr, int hop, float * d_max, void * stream )
+	{
+	FLANHIP_REQUIRE( d_factor && F > 0 && bins > 0 && hop >= 1, FLANHIP_ERR_INVALID_ARG, "bad arguments" );
+	if( int rc = require_device() ) return rc;
+	hipStream_t s = (hipStream_t) stream;
+	if( d_max )
+		{
+		const float ninf = -INFINITY;
+		FLANHIP_CHECK( hipMemcpyAsync( d_max, &ninf, sizeof( float ), hipMemcpyHostToDevice, s ) );
+		}
+	hipLaunchKernelGGL( k_stretch_map, dim3( ( bins + 255 ) / 256 ), dim3( 256 ), 0, s, d_factor, F, bins, sr, float( hop ), d_max );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+int flanhip_modify_frequency_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, const float * d_mod,
+	const float * d_in_modified, flanhip_MF * d_out, void * stream )
+	{
+	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, sr ) ) return rc;
+	FLANHIP_REQUIRE( d_mod && d_in_modified, FLANHIP_ERR_INVALID_ARG, "null map" );
+	hipStream_t s = (hipStream_t) stream;
+	FLANHIP_CHECK( hipMemsetAsync( d_out, 0, sizeof( flanhip_MF ) * size_t( ch ) * F * bins, s ) );    // clear_buffer, PVModify.cpp:205
+	const int64_t rows = ch * F;
+	hipLaunchKernelGGL( k_modify_frequency, dim3( (unsigned) ( ( rows + 63 ) / 64 ) ), dim3( 64 ), 0, s,
+		(const MFd*) d_pv, int( ch ), F, bins, sr, float( ( bins - 1 ) * 2 ), d_mod, d_in_modified, (MFd*) d_out );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+int flanhip_modify_frequency( const flanhip_MF * pv, int64_t ch, int64_t F, int bins, float sr, const float * mod,
+	const float * in_modified, flanhip_MF * out, volatile int * cancel )
+	{
+	if( int rc = check_pv_args( pv, out, ch, F, bins, sr ) ) return rc;
+	FLANHIP_REQUIRE( mod && in_modified, FLANHIP_ERR_INVALID_ARG, "null map" );
+	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
+	DevBuf d_pv, d_mod, d_inm, d_out;
+	const size_t pv_bytes = sizeof( flanhip_MF ) * size_t( ch ) * F * bins, mod_bytes = sizeof( float ) * size_t( F ) * bins;
+	const size_t inm_bytes = sizeof( float ) * size_t( ch ) * F * bins;
+	if( int rc = d_pv.alloc( pv_bytes ) ) return rc;
+	if( int rc = d_mod.alloc( mod_bytes ) ) return rc;
+	if( int rc = d_inm.alloc( inm_bytes ) ) return rc;
+	if( int rc = d_out.alloc( pv_bytes ) ) return rc;
+	FLANHIP_CHECK( hipMemcpy( d_pv.p, pv, pv_bytes, hipMemcpyHostToDevice ) );
+	FLANHIP_CHECK( hipMemcpy( d_mod.p, mod, mod_bytes, hipMemcpyHostToDevice ) );
+	FLANHIP_CHECK( hipMemcpy( d_inm.p, in_modified, inm_bytes, hipMemcpyHostToDevice ) );
+	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
+	if( int rc = flanhip_modify_frequency_dev( (const flanhip_MF*) d_pv.p, ch, F, bins, sr, (const float*) d_mod.p, (const float*) d_inm.p, (flanhip_MF*) d_out.p, nullptr ) ) return rc;
+	FLANHIP_CHECK( hipDeviceSynchronize() );
+	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
+	FLANHIP_CHECK( hipMemcpy( out, d_out.p, pv_bytes, hipMemcpyDeviceToHost ) );
+	return FLANHIP_OK;
+	}
+
+int flanhip_repitch_map_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float * d_factor,
+	float * d_in_modified, void * stream )
+	{
+	if( int rc = check_pv_args( d_pv, d_in_modified, ch, F, bins, sr ) ) return rc;
+	FLANHIP_REQUIRE( d_factor, FLANHIP_ERR_INVALID_ARG, "null factor grid" );
+	hipStream_t s = (hipStream_t) stream;
+	const float dft = float( ( bins - 1 ) * 2 );
+	hipLaunchKernelGGL( k_repitch_scan, dim3( (unsigned) ( ( F + 255 ) / 256 ) ), dim3( 256 ), 0, s, d_factor, F, bins, sr, dft );
+	FLANHIP_CHECK( hipGetLastError() );
+	const int64_t count = ch * F * bins;
+	hipLaunchKernelGGL( k_repitch_lerp, dim3( (unsigned) ( ( count + 255 ) / 256 ) ), dim3( 256 ), 0, s,
+		(const MFd*) d_pv, count, F, bins, sr, dft, d_factor, d_in_modified );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+static int shape_common( const flanhip_MF * d_pv, const flanhip_MF * d_tbl, bool affine, int64_t ch, int64_t F, int bins, float sr,
+	float a, float b, float c, float d, int align, flanhip_MF * d_out, hipStream_t s )
+	{
+	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, sr ) ) return rc;
+	const int64_t count = ch * F * bins;
+	const float dft = float( ( bins - 1 ) * 2 );
+	if( !align )
+		{
+		const unsigned blocks = (unsigned) ( ( count + 255 ) / 256 );
+		if( affine ) hipLaunchKernelGGL( k_shape_plain<true>, dim3( blocks ), dim3( 256 ), 0, s, (const MFd*) d_pv, (const MFd*) nullptr, count, a, b, c, d, (MFd*) d_out );
+		else         hipLaunchKernelGGL( k_shape_plain<false>, dim3( blocks ), dim3( 256 ), 0, s, (const MFd*) d_pv, (const MFd*) d_tbl, count, a, b, c, d, (MFd*) d_out );
+		}
+	else
+		{
+		FLANHIP_CHECK( hipMemsetAsync( d_out, 0, sizeof( flanhip_MF ) * size_t( count ), s ) );        // clear_buffer, PV.cpp:426
+		const int64_t rows = ch * F;
+		const unsigned blocks = (unsigned) ( ( rows + 63 ) / 64 );
+		if( affine ) hipLaunchKernelGGL( k_shape_aligned<true>, dim3( blocks ), dim3( 64 ), 0, s, (const MFd*) d_pv, (const MFd*) nullptr, rows, bins, sr, dft, a, b, c, d, (MFd*) d_out );
+		else         hipLaunchKernelGGL( k_shape_aligned<false>, dim3( blocks ), dim3( 64 ), 0, s, (const MFd*) d_pv, (const MFd*) d_tbl, rows, bins, sr, dft, a, b, c, d, (MFd*) d_out );
+		}
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+int flanhip_shape_affine_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float a, float b, float c, float d,
+	int align, flanhip_MF * d_out, void * stream )
+	{
+	return shape_common( d_pv, nullptr, true, ch, F, bins, sr, a, b, c, d, align, d_out, (hipStream_t) stream );
+	}
+
+int flanhip_shape_table_dev( const flanhip_MF * d_pv, const flanhip_MF * d_shaped, int64_t ch, int64_t F, int bins, float sr,
+	int align, flanhip_MF * d_out, void * stream )
+	{
+	FLANHIP_REQUIRE( d_shaped, FLANHIP_ERR_INVALID_ARG, "null shaped table" );
+	return shape_common( d_pv, d_shaped, false, ch, F, bins, sr, 0, 0, 0, 0, align, d_out, (hipStream_t) stream );
+	}
+
+int flanhip_shape_affine( const flanhip_MF * pv, int64_t ch, int64_t F, int bins, float sr, float a, float b, float c, float d,
+	int align, flanhip_MF * out, volatile int * cancel )
+	{
+	if( int rc = check_pv_args( pv, out, ch, F, bins, sr ) ) return rc;
+	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
+	DevBuf d_pv, d_out;
+	const size_t bytes = sizeof( flanhip_MF ) * size_t( ch ) * F * bins;
+	if( int rc = d_pv.alloc( bytes ) ) return rc;
+	if( int rc = d_out.alloc( bytes ) ) return rc;
+	FLANHIP_CHECK( hipMemcpy( d_pv.p, pv, bytes, hipMemcpyHostToDevice ) );
+	if( int rc = flanhip_shape_affine_dev( (const flanhip_MF*) d_pv.p, ch, F, bins, sr, a, b, c, d, align, (flanhip_MF*) d_out.p, nullptr ) ) return rc;
+	FLANHIP_CHECK( hipDeviceSynchronize() );
+	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
+	FLANHIP_CHECK( hipMemcpy( out, d_out.p, bytes, hipMemcpyDeviceToHost ) );
+	return FLANHIP_OK;
+	}
+
+} // extern "C"

@@ -1,0 +1,405 @@
+// pv_kernels.h -- analysis / synthesis kernels of the phase-vocoder hot path (gfx950).
+//
+// Work decomposition ("chains"): the reference walks the frames of a channel strictly in order because two pieces
+// of state cross from frame t-1 to frame t -- the previous phase of every bin in analysis
+// (Conversions/AudioPV.cpp:37,44; phase_vocoder.cpp:44-45) and the running phase of every bin in synthesis
+// (AudioPV.cpp:105,111; phase_vocoder.cpp:57-59).  Here a channel's frames are cut into chains of L consecutive
+// frames; ONE WAVEFRONT owns a chain, keeps that state in registers (lane l owns bins l, l+64, l+128, ...) and
+// walks its frames in order.  Chains are independent:
+//   analysis : a chain recomputes the phase of frame t0-1 (one extra FFT, no output) to seed `prev`.
+//   synthesis: a pre-pass sums the phase increments of every chain (k_phase_sums), a scan turns the sums into each
+//              chain's carry-in (k_phase_scan), and the overlap-add of the W-hop samples a chain shares with its
+//              predecessor goes through a small side buffer that k_ola_fixup adds afterwards, in a fixed order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fft_device.h"
+
+namespace flanhip {
+
+struct MF { float m, f; };
+
+// defines.h:44-45: pi = acos(-1.0f) (float), pi2 = pi * 2.0f  -> 6.2831854820251465 as a float, NOT 2*pi.
+#define FLANHIP_PI2_F 6.2831854820251465f
+#define FLANHIP_PI2_D 6.2831854820251465
+
+struct AnalyzeParams
+	{
+	const float * audio;      // [ch][n]
+	MF * out;                 // [ch][F][bins]
+	const float * window;     // [W]   hann( i/(W-1) )
+	const float2 * tw;        // [C]   exp(-2 pi i k / C)
+	const float2 * tw2;       // [C+1] exp(-2 pi i k / N), N = 2C
+	int64_t n;                // audio frames per channel
+	int64_t F;                // pv frames per channel
+	int num_channels;
+	int window_size;
+	int hop;
+	int L;                    // frames per chain
+	int chains_per_channel;
+	float sample_rate;
+	float analysis_rate;
+	};
+
+// phase_vocoder.cpp:37-52 with the reference's rounding sequence (the file is compiled with -ffp-contract=off).
+__device__ __forceinline__ MF phase_vocode_bin( float re, float im, float & prev_phase, float bin_frequency, float expected_phase_diff,
+	float analysis_rate, bool use_wrapping )
+	{
+	const float phase = atan2f( im, re );                                             // std::arg
+	const float phase_diff = float( double( phase ) - double( prev_phase ) );         // :44 (double subtraction, narrowed)
+	prev_phase = phase;                                                               // :45
+	const float delta_phase = phase_diff - expected_phase_diff;                       // :48
+	const float wrapped = use_wrapping ? delta_phase - FLANHIP_PI2_F * roundf( delta_phase / FLANHIP_PI2_F ) : delta_phase; // :39-42,49
+	const float delta_frequency = wrapped * analysis_rate / FLANHIP_PI2_F;            // :50
+	MF r;
+	r.m = hypotf( re, im );                                                           // std::abs
+	r.f = bin_frequency + delta_frequency;                                            // :52
+	return r;
+	}
+
+// Audio::convert_to_PV (Conversions/AudioPV.cpp:12-78).  One wavefront per chain, WAVES chains per block.
+template<int LOG2C, int WAVES>
+__global__ __launch_bounds__( 64 * WAVES ) void k_analyze( AnalyzeParams p )
+	{
+	constexpr int C = 1 << LOG2C;                   // complex points = dft/2
+	constexpr int E = ( C + 63 ) / 64;              // bins per lane (plus Nyquist on lane 0)
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	float2 * s_tw = reinterpret_cast<float2*>( smem );                      // [C]
+	float * s_win = reinterpret_cast<float*>( s_tw + C );                    // [W rounded up to even]
+	const int wpad = ( p.window_size + 3 ) & ~3;
+	float2 * s_buf_all = reinterpret_cast<float2*>( s_win + wpad );          // WAVES x padded_len(C)
+
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	for( int i = tid; i < C; i += 64 * WAVES ) s_tw[i] = p.tw[i];
+	for( int i = tid; i < p.window_size; i += 64 * WAVES ) s_win[i] = p.window[i];
+	__syncthreads();
+
+	float2 * buf = s_buf_all + wave * padded_len( C );
+	const int64_t chain = int64_t( blockIdx.x ) * WAVES + wave;
+	if( chain >= int64_t( p.chains_per_channel ) * p.num_channels ) return;
+	const int channel = int( chain / p.chains_per_channel );
+	const int64_t t0 = int64_t( chain % p.chains_per_channel ) * p.L;
+	const int64_t t1 = min( t0 + int64_t( p.L ), p.F );
+	const float * x = p.audio + int64_t( channel ) * p.n;
+	const int W = p.window_size, hop = p.hop;
+	const int dft = 2 * C;
+	const bool use_wrapping = p.analysis_rate < p.sample_rate;                // phase_vocoder.cpp:37
+
+	// per-lane constants: bin frequency (PVBuffer.cpp:443-446), expected phase advance (phase_vocoder.cpp:47), split twiddle
+	float binf[E + 1], expect[E + 1], prev[E + 1];
+	float2 w2[E];
+	#pragma unroll
+	for( int i = 0; i <= E; ++i )
+		{
+		const int k = ( i < E ) ? lane + 64 * i : C;
+		binf[i] = float( k ) * p.sample_rate / float( dft );
+		expect[i] = binf[i] / p.analysis_rate * FLANHIP_PI2_F;
+		prev[i] = 0.0f;                                                       // AudioPV.cpp:44
+		if( i < E ) w2[i] = p.tw2[min( k, C )];
+		}
+
+	for( int64_t t = ( t0 > 0 ? t0 - 1 : t0 ); t < t1; ++t )
+		{
+		const bool emit = t >= t0;
+		// window the frame into the FFT buffer as C complex points z[i] = ( x[2i], x[2i+1] )  (AudioPV.cpp:52-65)
+		const int64_t start = int64_t( hop ) * t - W / 2;
+		#pragma unroll
+		for( int q = 0; q < E; ++q )
+			{
+			const int i = lane + 64 * q;
+			if( C >= 64 || i < C )
+				{
+				const int s0 = 2 * i, s1 = 2 * i + 1;
+				float v0 = 0.0f, v1 = 0.0f;
+				if( s0 < W ) { const int64_t a = start + s0; if( a >= 0 && a < p.n ) v0 = x[a] * s_win[s0]; }
+				if( s1 < W ) { const int64_t a = start + s1; if( a >= 0 && a < p.n ) v1 = x[a] * s_win[s1]; }
+				buf[PAD( i )] = make_float2( v0, v1 );
+				}
+			}
+		wave_sync();
+		fft_forward<LOG2C>( buf, s_tw, lane );
+
+		// split the half-size transform into the real transform's bins and phase-vocode each bin (AudioPV.cpp:69-73)
+		MF * row = p.out + ( int64_t( channel ) * p.F + t ) * ( C + 1 );
+		const float2 z0 = buf[PAD( 0 )];
+		#pragma unroll
+		for( int q = 0; q < E; ++q )
+			{
+			const int k = lane + 64 * q;
+			if( C >= 64 || k < C )
+				{
+				const float2 zk = buf[PAD( k )];
+				const float2 zm = buf[PAD( ( C - k ) & ( C - 1 ) )];
+				const float ax = 0.5f * ( zk.x + zm.x ), ay = 0.5f * ( zk.y - zm.y );
+				const float dx = zk.x - zm.x, dy = zk.y + zm.y;
+				const float c = w2[q].x, s = w2[q].y;
+				float re = ax + 0.5f * __builtin_fmaf( c, dy, s * dx );
+				float im = ay - 0.5f * __builtin_fmaf( c, dx, -( s * dy ) );
+				if( k == 0 ) { re = z0.x + z0.y; im = 0.0f; }
+				const MF mf = phase_vocode_bin( re, im, prev[q], binf[q], expect[q], p.analysis_rate, use_wrapping );
+				if( emit ) row[k] = mf;
+				}
+			}
+		if( lane == 0 )
+			{
+			const MF mf = phase_vocode_bin( z0.x - z0.y, 0.0f, prev[E], binf[E], expect[E], p.analysis_rate, use_wrapping );
+			if( emit ) row[C] = mf;
+			}
+		wave_sync();
+		}
+	}
+
+// -------------------------------------------------------------------------------------------------------------
+// synthesis
+// -------------------------------------------------------------------------------------------------------------
+
+// phase_vocoder.cpp:57-59:  phase_buffer += float term; if( phase_buffer > pi2 ) phase_buffer = fmod( phase_buffer, pi2 )
+__device__ __forceinline__ double fold_phase( double ph )
+	{
+	if( ph > FLANHIP_PI2_D )
+		{
+		if( ph < 1.0e6 )
+			{
+			// exact fmod for moderate quotients: q*pi2 has <= 20+24 significant bits, the difference is exact
+			double q = floor( ph / FLANHIP_PI2_D );
+			double r = fma( -q, FLANHIP_PI2_D, ph );
+			if( r < 0.0 ) r += FLANHIP_PI2_D;
+			else if( r >= FLANHIP_PI2_D ) r -= FLANHIP_PI2_D;
+			ph = r;
+			}
+		else ph = fmod( ph, FLANHIP_PI2_D );
+		}
+	return ph;
+	}
+
+__device__ __forceinline__ float phase_term( float f, float analysis_rate )
+	{
+	return f / analysis_rate * FLANHIP_PI2_F;        // phase_vocoder.cpp:57
+	}
+
+struct SynthParams
+	{
+	const MF * pv;            // [ch][F][bins]
+	float * out;              // [ch][F*hop]
+	const float * window;     // [W] hann( i/(W-1) ) (unscaled)
+	const float2 * tw;        // [C]
+	const float2 * tw2;       // [C+1]
+	double * carry;           // [ch][chains][bins]  sums on entry to k_phase_scan, exclusive carries after
+	float * head;             // [ch][chains][W-hop] overlap shared with the previous chain
+	int * nan_flag;           // may be null
+	int64_t F;
+	int64_t out_len;          // F * hop
+	int num_channels;
+	int window_size;
+	int hop;
+	int L;
+	int chains_per_channel;
+	int head_len;             // max( W - hop, 0 )
+	int num_bins;
+	float analysis_rate;
+	float window_scale;       // AudioPV.cpp:99
+	};
+
+// Per-chain sums of the phase increments, folded exactly like the running phase, plus the NaN/Inf scan of
+// PVBuffer::is_nan_or_inf (PVBuffer.cpp:44-50).  One block per chain, threads over bins (coalesced 8-byte MF reads).
+__global__ __launch_bounds__( 256 ) void k_phase_sums( SynthParams p )
+	{
+	const int64_t chain = blockIdx.x;
+	const int channel = int( chain / p.chains_per_channel );
+	const int64_t t0 = int64_t( chain % p.chains_per_channel ) * p.L;
+	const int64_t t1 = min( t0 + int64_t( p.L ), p.F );
+	bool bad = false;
+	for( int k = threadIdx.x; k < p.num_bins; k += blockDim.x )
+		{
+		double ph = 0.0;
+		const MF * col = p.pv + ( int64_t( channel ) * p.F + t0 ) * p.num_bins + k;
+		for( int64_t t = t0; t < t1; ++t, col += p.num_bins )
+			{
+			const MF mf = *col;
+			bad |= isnan( mf.m ) || isnan( mf.f ) || isinf( mf.m ) || isinf( mf.f );
+			ph = fold_phase( ph + double( phase_term( mf.f, p.analysis_rate ) ) );
+			}
+		p.carry[chain * p.num_bins + k] = ph;
+		}
+	if( p.nan_flag && __any( bad ) && ( threadIdx.x & 63 ) == 0 ) atomicOr( p.nan_flag, 1 );
+	}
+
+// Exclusive scan of the chain sums along each channel, per bin: carry[c] = phase_buffer on entry to chain c.
+__global__ __launch_bounds__( 256 ) void k_phase_scan( SynthParams p )
+	{
+	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
+	if( idx >= int64_t( p.num_channels ) * p.num_bins ) return;
+	const int channel = int( idx / p.num_bins ), k = int( idx % p.num_bins );
+	double * c = p.carry + int64_t( channel ) * p.chains_per_channel * p.num_bins + k;
+	double run = 0.0;                                                          // AudioPV.cpp:111
+	for( int i = 0; i < p.chains_per_channel; ++i, c += p.num_bins )
+		{
+		const double s = *c;
+		*c = run;
+		run = fold_phase( run + s );
+		}
+	}
+
+// PV::convert_to_audio (Conversions/AudioPV.cpp:86-139).  One wavefront per chain.
+template<int LOG2C, int WAVES>
+__global__ __launch_bounds__( 64 * WAVES ) void k_synthesize( SynthParams p )
+	{
+	constexpr int C = 1 << LOG2C;
+	constexpr int E = ( C + 63 ) / 64;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	float2 * s_tw = reinterpret_cast<float2*>( smem );                       // [C]
+	const int W = p.window_size, hop = p.hop;
+	const int wpad = ( W + 3 ) & ~3;
+	float * s_win = reinterpret_cast<float*>( s_tw + C );                     // [wpad] scaled window
+	float2 * s_buf_all = reinterpret_cast<float2*>( s_win + wpad );           // WAVES x padded_len(C+1)
+	float * s_ring_all = reinterpret_cast<float*>( s_buf_all + WAVES * padded_len( C + 1 ) ); // WAVES x wpad
+
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	for( int i = tid; i < C; i += 64 * WAVES ) s_tw[i] = p.tw[i];
+	for( int i = tid; i < W; i += 64 * WAVES ) s_win[i] = p.window[i] * p.window_scale;   // AudioPV.cpp:102
+	float * ring = s_ring_all + wave * wpad;
+	for( int i = lane; i < W; i += 64 ) ring[i] = 0.0f;
+	__syncthreads();
+
+	float2 * buf = s_buf_all + wave * padded_len( C + 1 );
+	const int64_t chain = int64_t( blockIdx.x ) * WAVES + wave;
+	if( chain >= int64_t( p.chains_per_channel ) * p.num_channels ) return;
+	const int channel = int( chain / p.chains_per_channel );
+	const int chain_in_channel = int( chain % p.chains_per_channel );
+	const int64_t t0 = int64_t( chain_in_channel ) * p.L;
+	const int64_t t1 = min( t0 + int64_t( p.L ), p.F );
+	const bool last_chain = chain_in_channel == p.chains_per_channel - 1;
+	float * out = p.out + int64_t( channel ) * p.out_len;
+	float * head = p.head + chain * p.head_len;
+	const int64_t chain_start = int64_t( hop ) * t0 - W / 2;                  // first sample this chain touches
+	const int64_t own_start = chain_in_channel == 0 ? INT64_MIN : chain_start + p.head_len; // before this: shared with the previous chain
+
+	// running phase (phase_buffer, AudioPV.cpp:105) on entry to the chain
+	double ph[E + 1];
+	float2 w2[E];
+	#pragma unroll
+	for( int i = 0; i <= E; ++i )
+		{
+		const int k = ( i < E ) ? lane + 64 * i : C;
+		ph[i] = ( ( C >= 64 || i == E || k < C ) ) ? p.carry[chain * ( C + 1 ) + min( k, C )] : 0.0;
+		if( i < E ) w2[i] = p.tw2[min( k, C )];
+		}
+
+	int ring_base = 0;                                                         // ring[ring_base] <-> absolute sample `pos`
+	int64_t pos = chain_start;
+	for( int64_t t = t0; t < t1; ++t )
+		{
+		// inverse phase vocoder per bin (AudioPV.cpp:117-120, phase_vocoder.cpp:55-61) -> spectrum X[0..C] in LDS
+		const MF * row = p.pv + ( int64_t( channel ) * p.F + t ) * ( C + 1 );
+		#pragma unroll
+		for( int q = 0; q <= E; ++q )
+			{
+			const int k = ( q < E ) ? lane + 64 * q : C;
+			const bool active = ( q < E ) ? ( C >= 64 || k < C ) : ( lane == 0 );
+			if( active )
+				{
+				const MF mf = row[k];
+				ph[q] = fold_phase( ph[q] + double( phase_term( mf.f, p.analysis_rate ) ) );
+				float sn, cs;
+				sincosf( float( ph[q] ), &sn, &cs );
+				buf[PAD( k )] = make_float2( mf.m * cs, mf.m * sn );           // std::polar
+				}
+			}
+		wave_sync();
+		// merge X[0..C] into the half-size spectrum Z[k] = A[k] + i B[k]; stored conjugated so that the forward FFT
+		// evaluates the inverse transform ( ifft(Z) = conj( fft( conj Z ) ) ).  c2r ignores Im X[0], Im X[C].
+		float2 zc[E];
+		#pragma unroll
+		for( int q = 0; q < E; ++q )
+			{
+			const int k = lane + 64 * q;
+			if( C >= 64 || k < C )
+				{
+				float2 xk = buf[PAD( k )];
+				float2 xm = buf[PAD( C - k )];
+				if( k == 0 ) { xk.y = 0.0f; xm.y = 0.0f; }
+				// A = X[k] + conj X[C-k];  B = ( X[k] - conj X[C-k] ) * exp(+2 pi i k / N)
+				const float ax = xk.x + xm.x, ay = xk.y - xm.y;
+				const float dx = xk.x - xm.x, dy = xk.y + xm.y;
+				const float c = w2[q].x, s = -w2[q].y;                         // conj of exp(-2 pi i k/N)
+				const float bx = __builtin_fmaf( c, dx, -( s * dy ) ), by = __builtin_fmaf( c, dy, s * dx );
+				// Z = A + iB = ( ax - by, ay + bx ); store conj
+				zc[q] = make_float2( ax - by, -( ay + bx ) );
+				}
+			}
+		wave_sync();
+		#pragma unroll
+		for( int q = 0; q < E; ++q )
+			{
+			const int k = lane + 64 * q;
+			if( C >= 64 || k < C ) buf[PAD( k )] = zc[q];
+			}
+		wave_sync();
+		fft_forward<LOG2C>( buf, s_tw, lane );
+		// G = fft( conj Z ):  x[2n] = G[n].x, x[2n+1] = -G[n].y   (AudioPV.cpp:122; samples >= W are discarded)
+		// window and accumulate into the ring (AudioPV.cpp:133-134)
+		for( int n = lane; 2 * n < W; n += 64 )
+			{
+			const float2 g = buf[PAD( n )];
+			int i0 = ring_base + 2 * n; if( i0 >= W ) i0 -= W;
+			ring[i0] += g.x * s_win[2 * n];
+			if( 2 * n + 1 < W )
+				{
+				int i1 = i0 + 1; if( i1 >= W ) i1 -= W;
+				ring[i1] += ( -g.y ) * s_win[2 * n + 1];
+				}
+			}
+		wave_sync();
+		// the oldest `hop` samples are complete as far as this chain is concerned: emit and clear them
+		for( int e = lane; e < hop; e += 64 )
+			{
+			float v = 0.0f;
+			if( e < W )
+				{
+				int i = ring_base + e; if( i >= W ) i -= W;
+				v = ring[i]; ring[i] = 0.0f;
+				}
+			const int64_t a = pos + e;
+			if( a < own_start ) head[a - chain_start] = v;
+			else if( a >= 0 && a < p.out_len ) out[a] = v;
+			}
+		wave_sync();
+		pos += hop;
+		ring_base = ( hop < W ) ? ring_base + hop : 0;
+		if( ring_base >= W ) ring_base -= W;
+		}
+	// flush what is left in the ring (partial sums the next chain's head completes); the last chain of a channel
+	// zero-fills up to the end of the output (Audio( format ) is zero-initialised, AudioPV.cpp:95)
+	const int64_t ring_end = pos + ( hop < W ? W - hop : 0 );
+	const int64_t flush_end = last_chain ? max( ring_end, p.out_len ) : ring_end;
+	for( int64_t a = pos + lane; a < flush_end; a += 64 )
+		{
+		float v = 0.0f;
+		if( a < ring_end )
+			{
+			int i = ring_base + int( a - pos ); if( i >= W ) i -= W;
+			v = ring[i];
+			}
+		if( a < own_start ) head[a - chain_start] = v;
+		else if( a >= 0 && a < p.out_len ) out[a] = v;
+		}
+	}
+
+// out[head region of chain c] += head[c]  for every chain c >= 1 of a channel (fixed order => deterministic).
+__global__ __launch_bounds__( 256 ) void k_ola_fixup( SynthParams p )
+	{
+	const int64_t chain = blockIdx.x;
+	const int chain_in_channel = int( chain % p.chains_per_channel );
+	if( chain_in_channel == 0 ) return;
+	const int channel = int( chain / p.chains_per_channel );
+	const int64_t chain_start = int64_t( p.hop ) * ( int64_t( chain_in_channel ) * p.L ) - p.window_size / 2;
+	float * out = p.out + int64_t( channel ) * p.out_len;
+	const float * head = p.head + chain * p.head_len;
+	for( int e = threadIdx.x; e < p.head_len; e += blockDim.x )
+		{
+		const int64_t a = chain_start + e;
+		if( a >= 0 && a < p.out_len ) out[a] += head[e];
+		}
+	}
+
+} // namespace flanhip

@@ -1,0 +1,146 @@
+/* flanhip.h -- C ABI of the MI355X (gfx950) phase-vocoder hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.  The reference (loganmcbroom/Flan)
+ * has no FFI layer -- the path is a set of C++ member functions -- so each entry point below names the reference
+ * member function it stands in for (paths relative to /root/reference/src/flan).  The C++ host classes in
+ * include/flan/ (flan::Audio, flan::PV, flan::Function) are written on top of exactly these calls; INTEGRATION.md
+ * shows the binding a Flan maintainer would add.
+ *
+ * Conventions
+ *   - every function returns FLANHIP_OK (0) or a negative FLANHIP_ERR_*; nothing throws; flanhip_last_error() gives
+ *     the text of the last failure on the calling thread.
+ *   - host entry points (no suffix) take HOST pointers, do H2D / kernels / D2H on the current device and return
+ *     when the result is in the caller's buffer.  The caller owns all host memory.
+ *   - device entry points (_dev) take DEVICE pointers plus a hipStream_t passed as void* (NULL = default stream),
+ *     enqueue work and return without synchronising; results chain on-device so a
+ *     convert_to_PV -> stretch -> convert_to_audio pipeline never leaves HBM.
+ *   - layouts are the reference's: audio float[channel][frame] (Audio/AudioBuffer.cpp:479-482),
+ *     PV flanhip_MF[channel][frame][bin] (PV/PVBuffer.cpp:526-529).  All indices are 64-bit here (the reference's
+ *     int32 product overflows above 2^31 MFs, PV/PVBuffer.cpp:19-22).
+ *   - `cancel` (may be NULL) is the reference's canceller (defines.h:49-62): polled between kernel batches; when it
+ *     reads non-zero the call stops and returns FLANHIP_ERR_CANCELLED (the C++ layer then returns a null object).
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails with
+ *     FLANHIP_ERR_NO_DEVICE.
+ */
+#ifndef FLANHIP_H
+#define FLANHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLANHIP_OK                 0
+#define FLANHIP_ERR_INVALID_ARG   -1   /* null pointer, non-positive size, window > dft ...                    */
+#define FLANHIP_ERR_UNSUPPORTED   -2   /* dft size not a power of two in [32, 8192], chain constraints ...     */
+#define FLANHIP_ERR_HIP           -3   /* a HIP runtime call failed; see flanhip_last_error()                  */
+#define FLANHIP_ERR_CANCELLED     -4   /* the canceller was raised                                              */
+#define FLANHIP_ERR_NO_DEVICE     -5   /* no gfx950 device visible                                              */
+
+/* defines.h:31-35  struct MF { Magnitude m; Frequency f; } */
+typedef struct flanhip_MF { float m; float f; } flanhip_MF;
+
+/* ---- library / device ------------------------------------------------------------------------------------ */
+int          flanhip_version(void);                 /* 10000*major + 100*minor + patch */
+const char * flanhip_last_error(void);
+int          flanhip_device_count(void);            /* 0 when no device; never fails   */
+int          flanhip_set_device(int device);
+
+/* ---- shape helpers (pure host arithmetic, usable without a device) ---------------------------------------- */
+/* Conversions/AudioPV.cpp:17   numHops = ceil( num_frames / hop ) + 1, INTEGER division */
+int64_t flanhip_num_pv_frames(int64_t num_audio_frames, int hop);
+/* PV/PVBuffer.cpp:381-384      get_hop_size() = Frame( sample_rate / analysis_rate )     */
+int     flanhip_hop_size(float sample_rate, float analysis_rate);
+/* PV/PVModify.cpp:312-316      ceil( time_to_frame( max of the time map ) ), from a host grid float[F][bins] */
+int64_t flanhip_modify_time_out_frames(const float * mod_seconds, int64_t num_frames, int num_bins, float sample_rate, int hop);
+
+/* ---- device memory plumbing (so that C / C++ / ctypes callers need no HIP headers) ------------------------ */
+int flanhip_malloc(void ** dptr, size_t bytes);
+int flanhip_free(void * dptr);
+int flanhip_memcpy_h2d(void * dst, const void * src, size_t bytes, void * stream);
+int flanhip_memcpy_d2h(void * dst, const void * src, size_t bytes, void * stream);
+int flanhip_memset(void * dst, int value, size_t bytes, void * stream);
+int flanhip_stream_synchronize(void * stream);
+
+/* ---- Audio::convert_to_PV  (Conversions/AudioPV.cpp:12-78, phase_vocoder.cpp:5-53, WindowFunctions.cpp:10-13) - */
+/* audio: float[ch][n]; out: MF[ch][F][dft/2+1] with F = flanhip_num_pv_frames(n, hop), written to *num_pv_frames. */
+int flanhip_analyze(const float * audio, int64_t num_channels, int64_t num_audio_frames, float sample_rate,
+                    int window_size, int hop, int dft_size,
+                    flanhip_MF * out, int64_t * num_pv_frames, volatile int * cancel);
+int flanhip_analyze_dev(const float * d_audio, int64_t num_channels, int64_t num_audio_frames, float sample_rate,
+                        int window_size, int hop, int dft_size,
+                        flanhip_MF * d_out, void * stream);
+
+/* ---- PV::convert_to_audio  (Conversions/AudioPV.cpp:86-139, phase_vocoder.cpp:55-61) ------------------------- */
+/* pv: MF[ch][F][bins]; out: float[ch][F*hop], hop = flanhip_hop_size(sr, analysis_rate).
+ * *nan_flag (may be NULL) is set to 1 when the buffer holds a NaN/Inf (PV/PVBuffer.cpp:44-50; the reference prints
+ * a warning and carries on, AudioPV.cpp:88-89 -- so do we). */
+int flanhip_synthesize(const flanhip_MF * pv, int64_t num_channels, int64_t num_pv_frames, int num_bins,
+                       float sample_rate, float analysis_rate, int window_size,
+                       float * out, int * nan_flag, volatile int * cancel);
+/* Device form.  d_workspace must hold flanhip_synthesize_workspace_bytes(...) bytes; d_nan_flag (may be NULL) is a
+ * device int that is OR-ed with 1 on NaN/Inf (the caller zeroes it). */
+size_t flanhip_synthesize_workspace_bytes(int64_t num_channels, int64_t num_pv_frames, int num_bins,
+                                          float sample_rate, float analysis_rate, int window_size);
+int flanhip_synthesize_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_pv_frames, int num_bins,
+                           float sample_rate, float analysis_rate, int window_size,
+                           float * d_out, void * d_workspace, int * d_nan_flag, void * stream);
+
+/* ---- PV frame processors ------------------------------------------------------------------------------------- */
+/* modify_time_base (PV/PVModify.cpp:307-362, linear Interpolator): mod_seconds is the sampled time map float[F][bins]
+ * (FunctionSample2d layout, FunctionSample.h:173-199).  out: MF[ch][out_frames][bins], out_frames from
+ * flanhip_modify_time_out_frames(). */
+int flanhip_modify_time(const flanhip_MF * pv, int64_t num_channels, int64_t num_pv_frames, int num_bins,
+                        float sample_rate, int hop, const float * mod_seconds,
+                        int64_t out_frames, flanhip_MF * out, volatile int * cancel);
+int flanhip_modify_time_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_pv_frames, int num_bins,
+                            float sample_rate, int hop, const float * d_mod_seconds,
+                            int64_t out_frames, flanhip_MF * d_out, void * stream);
+/* PV::stretch front half (PV/PVModify.cpp:371-382): in-place inclusive prefix sum over frames per bin (fp32, sequential
+ * order) then frame_to_time.  d_factor: float[F][bins] factor grid in, seconds out.
+ * flanhip_stretch_max_dev also reduces the maximum of the result into *d_max (float). */
+int flanhip_stretch_map_dev(float * d_factor, int64_t num_pv_frames, int num_bins, float sample_rate, int hop,
+                            float * d_max, void * stream);
+/* PV::stretch with a constant-valued callable (what `[](TF){ return c; }` samples to): builds the grid on device. */
+int flanhip_fill_dev(float * d_grid, int64_t count, float value, void * stream);
+
+/* modify_frequency_base (PV/PVModify.cpp:196-257): mod_hz float[F][bins] = where each grid bin centre maps;
+ * in_modified float[ch][F][bins] = new frequency of every MF.  out: MF[ch][F][bins]. */
+int flanhip_modify_frequency(const flanhip_MF * pv, int64_t num_channels, int64_t num_pv_frames, int num_bins,
+                             float sample_rate, const float * mod_hz, const float * in_modified,
+                             flanhip_MF * out, volatile int * cancel);
+int flanhip_modify_frequency_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_pv_frames, int num_bins,
+                                 float sample_rate, const float * d_mod_hz, const float * d_in_modified,
+                                 flanhip_MF * d_out, void * stream);
+/* PV::repitch front half (PV/PVModify.cpp:273-302): d_factor float[F][bins] factor grid in -> Hz map out;
+ * d_in_modified float[ch][F][bins] out. */
+int flanhip_repitch_map_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_pv_frames, int num_bins,
+                            float sample_rate, float * d_factor, float * d_in_modified, void * stream);
+
+/* PV::shape (PV/PV.cpp:421-458) for the affine shaper  mf -> { a*m + b, c*f + d }; arbitrary host callables are
+ * evaluated by the C++ layer on the host grid and uploaded through flanhip_shape_table_dev. */
+int flanhip_shape_affine(const flanhip_MF * pv, int64_t num_channels, int64_t num_pv_frames, int num_bins,
+                         float sample_rate, float a, float b, float c, float d, int use_shift_alignment,
+                         flanhip_MF * out, volatile int * cancel);
+int flanhip_shape_affine_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_pv_frames, int num_bins,
+                             float sample_rate, float a, float b, float c, float d, int use_shift_alignment,
+                             flanhip_MF * d_out, void * stream);
+/* Same placement rule with the shaped values precomputed (d_shaped: MF[ch][F][bins] = shaper(in) per MF). */
+int flanhip_shape_table_dev(const flanhip_MF * d_pv, const flanhip_MF * d_shaped, int64_t num_channels,
+                            int64_t num_pv_frames, int num_bins, float sample_rate, int use_shift_alignment,
+                            flanhip_MF * d_out, void * stream);
+
+/* ---- Audio::convert_to_mid_side / convert_to_left_right (Audio/AudioConversions.cpp:32-56), stereo only ------ */
+int flanhip_mid_side_dev(const float * d_in, int64_t num_audio_frames, float * d_out, void * stream);
+
+/* ---- synthetic input + comparison utilities (bench / tests; defined by this project) -------------- */
+int flanhip_noise_dev(float * d_out, int64_t num_channels, int64_t num_audio_frames, uint32_t seed, void * stream);
+/* sum of squares of (a - b) and of b, as doubles: d_result[0] = sum (a-b)^2, d_result[1] = sum b^2 */
+int flanhip_sqdiff_dev(const float * d_a, const float * d_b, int64_t count, double * d_result, void * stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLANHIP_H */
