@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- PV analysis+resynthesis frames/sec on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of synthetic audio that is already resident in HBM:
+    Audio::convert_to_PV(2048, 512, dft 2048)  ->  PV::convert_to_audio        (flanhip_analyze_dev + flanhip_synthesize_dev)
+Workload at N=1: 8 channels x 60 s x 48 kHz uniform noise (the configuration BASELINE.json's north_star quotes its
+targets on: "60 s x 8-ch 48 kHz convertToPV->convertToAudio round-trip at 1 GPU").  With --gpus N every rank owns its
+own 8 channels (channels are independent: AudioPV.cpp:41,44,108,111), so the job is 8N channels, "scaling": "weak",
+with no collective inside the timed region.  The RCCL all-gather that reassembles the output buffer
+(float[8N][frames], channel-major so the gathered buffer IS the final layout) is timed separately and reported in
+"allgather" -- it is not part of the PV frames/s metric.
+
+PyTorch here is plumbing only: device buffers, the stream, events and torch.distributed.  The kernels are the HIP
+library flan_amd/libflanhip.so called through the C ABI (include/flanhip.h).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WINDOW, HOP, DFT, SR = 2048, 512, 2048, 48000.0
+BINS = DFT // 2 + 1
+HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy)
+# algorithmic bytes per PV frame at dft 2048 -- analysis reads hop*4 and writes bins*8, synthesis mirrors it
+BYTES_ANALYSIS = HOP * 4 + BINS * 8         # 10 248
+BYTES_SYNTHESIS = BINS * 8 + HOP * 4        # 10 248
+BYTES_ROUNDTRIP = BYTES_ANALYSIS + BYTES_SYNTHESIS   # 20 496
+
+
+def cpu_baseline(channels, seconds, threads):
+    """The CPU oracle (oracle/flan_oracle.cpp, a port of the reference path) on the host cores; checker code used as the
+    reported baseline only."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as O
+    from concurrent.futures import ThreadPoolExecutor
+    n = int(seconds * SR)
+    x = O.noise(channels, n, seed=1234)
+
+    def one(c):
+        pv = O.analyze(x[c:c + 1], SR, WINDOW, HOP, DFT)
+        out, _ = O.synthesize(pv, SR, SR / HOP, WINDOW)
+        return pv.shape[1]
+
+    t0 = time.perf_counter()
+    if threads <= 1:
+        frames = sum(one(c) for c in range(channels))
+    else:
+        with ThreadPoolExecutor(threads) as ex:       # ctypes releases the GIL; one channel per task
+            frames = sum(ex.map(one, range(channels)))
+    dt = time.perf_counter() - t0
+    return frames / dt, frames, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--channels", type=int, default=8, help="channels per GPU")
+    ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-gather", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import flan_amd as fa
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world != 1:
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback path)")
+    torch.cuda.set_device(local_rank)
+    fa.check(fa.lib.flanhip_set_device(local_rank))
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    ch, n = args.channels, int(args.seconds * SR)
+    F = int(fa.lib.flanhip_num_pv_frames(n, HOP))
+    ar = SR / HOP
+    frames_per_step = ch * F
+    stream = torch.cuda.current_stream().cuda_stream
+
+    audio = torch.empty((ch, n), dtype=torch.float32, device=dev)
+    fa.check(fa.lib.flanhip_noise_dev(ctypes.c_void_p(audio.data_ptr()), ch, n, 1234 + rank, ctypes.c_void_p(stream)))
+    pv = torch.empty((ch, F, BINS, 2), dtype=torch.float32, device=dev)
+    out = torch.empty((ch, F * HOP), dtype=torch.float32, device=dev)
+    ws = torch.empty(fa.synthesize_workspace_bytes(ch, F, BINS, SR, ar, WINDOW), dtype=torch.uint8, device=dev)
+    nan_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def analyze():
+        fa.analyze_dev(audio, ch, n, SR, WINDOW, HOP, DFT, pv, stream)
+
+    def synthesize():
+        fa.synthesize_dev(pv, ch, F, BINS, SR, ar, WINDOW, out, ws, nan_flag, stream)
+
+    def step():
+        analyze()
+        synthesize()
+
+    def sync_all():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * frames_per_step * args.steps / elapsed
+
+    # per-kernel timing with events on the launch stream (rank 0 only): k_analyze alone, the whole synthesis call, and
+    # k_synthesize alone (FLANHIP debug stage mask)
+    def event_time(fn, reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps     # ms per launch
+
+    extra = {}
+    roofline = None
+    if rank == 0:
+        reps = max(5, args.steps)
+        t_an = event_time(analyze, reps)
+        t_sy = event_time(synthesize, reps)
+        fa.lib.flanhip_debug_synth_stages(4)           # main kernel only (carry/head buffers left as they are)
+        t_sy_main = event_time(synthesize, reps)
+        fa.lib.flanhip_debug_synth_stages(1 | 2)       # pre-pass: k_phase_sums + k_phase_scan
+        t_sy_pre = event_time(synthesize, reps)
+        fa.lib.flanhip_debug_synth_stages(0xF)
+        extra["kernel_ms"] = {"k_analyze": round(t_an, 4), "synthesize_all": round(t_sy, 4),
+                              "k_synthesize": round(t_sy_main, 4), "k_phase_sums+scan": round(t_sy_pre, 4)}
+        if t_an >= t_sy_main:
+            kname, tk, b = "k_analyze", t_an, BYTES_ANALYSIS
+        else:
+            kname, tk, b = "k_synthesize", t_sy_main, BYTES_SYNTHESIS
+        achieved = frames_per_step * b / (tk * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "launch_ms": round(tk, 4), "algorithmic_bytes_per_launch": frames_per_step * b}
+        extra["roundtrip_hbm"] = {"achieved_GBs": round(frames_per_step * BYTES_ROUNDTRIP / (ms_per_step * 1e-3) / 1e9, 1),
+                                  "frac_of_8TBs": round(frames_per_step * BYTES_ROUNDTRIP / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    # the output-reassembly all-gather of the north star, outside the metric
+    if distributed and not args.no_gather:
+        gathered = torch.empty((world * ch, F * HOP), dtype=torch.float32, device=dev)
+        for _ in range(2):
+            dist.all_gather_into_tensor(gathered, out)
+        sync_all()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            dist.all_gather_into_tensor(gathered, out)
+        sync_all()
+        tg = (time.perf_counter() - t0) / reps
+        t = torch.tensor([tg], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tg = float(t.item())
+        extra["allgather"] = {"ms": round(tg * 1e3, 3), "bytes_per_rank": out.numel() * 4,
+                              "frames_per_s_with_gather": round(world * frames_per_step / (elapsed / args.steps + tg), 1)}
+
+    cpu = None
+    if rank == 0 and not args.no_cpu:
+        cores = os.cpu_count() or 1
+        v1, frames1, dt1 = cpu_baseline(ch, args.seconds, 1)
+        cpu = {"value": round(v1, 1), "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": "%d ch x %.0f s round trip (%d frames, %.1f s) by oracle/flan_oracle.cpp, 1 thread, fp64 radix-2 FFT (not FFTW)"
+                         % (ch, args.seconds, frames1, dt1)}
+        threads = min(cores, ch)
+        if threads > 1:
+            vN, _, dtN = cpu_baseline(ch, args.seconds, threads)
+            cpu["all_cores"] = {"value": round(vN, 1), "cores": threads, "host_cores": cores, "seconds": round(dtN, 2)}
+
+    if rank == 0:
+        line = {
+            "metric": "PV analysis+resynthesis frames/sec (2048-win, hop 512, 48 kHz)",
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%d ch x %.0f s x 48 kHz uniform noise per GPU, convert_to_PV(2048,512,dft 2048) -> convert_to_audio round trip"
+                                   % (ch, args.seconds),
+                       "channels_per_gpu": ch, "pv_frames_per_step_per_gpu": frames_per_step, "parallelism": "channel-shard x%d" % world},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        line.update(extra)
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -50,6 +50,7 @@ _SIGS = {
     "flanhip_synthesize": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _i32, _vp, C.POINTER(_i32), _vp]),
     "flanhip_synthesize_workspace_bytes": (C.c_size_t, [_i64, _i64, _i32, _f32, _f32, _i32]),
     "flanhip_synthesize_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp]),
+    "flanhip_debug_synth_stages": (None, [_i32]),
     "flanhip_modify_time": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i32, _vp, _i64, _vp, _vp]),
     "flanhip_modify_time_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i32, _vp, _i64, _vp, _vp]),
     "flanhip_stretch_map_dev": (C.c_int, [_vp, _i64, _i32, _f32, _i32, _vp, _vp]),

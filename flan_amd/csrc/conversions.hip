@@ -6,6 +6,7 @@
 
 namespace flanhip {
 
+static int g_synth_stage_mask = 0xF;             // flanhip_debug_synth_stages(): 1 sums, 2 scan, 4 main, 8 fix-up
 static constexpr size_t kMaxLds = 160 * 1024;   // gfx950: 160 KiB LDS per CU, one workgroup may take all of it
 
 static size_t analyze_lds_bytes( int C, int W, int waves )
@@ -135,14 +136,22 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 
 	const int64_t chains = int64_t( p.chains_per_channel ) * ch;
 	FLANHIP_REQUIRE( chains < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
-	hipLaunchKernelGGL( k_phase_sums, dim3( (unsigned) chains ), dim3( 256 ), 0, s, p );
-	FLANHIP_CHECK( hipGetLastError() );
-	const int64_t cols = ch * bins;
-	hipLaunchKernelGGL( k_phase_scan, dim3( (unsigned) ( ( cols + 255 ) / 256 ) ), dim3( 256 ), 0, s, p );
-	FLANHIP_CHECK( hipGetLastError() );
+	const int stages = g_synth_stage_mask;
+	if( stages & 1 )
+		{
+		hipLaunchKernelGGL( k_phase_sums, dim3( (unsigned) chains ), dim3( 256 ), 0, s, p );
+		FLANHIP_CHECK( hipGetLastError() );
+		}
+	if( stages & 2 )
+		{
+		const int64_t cols = ch * bins;
+		hipLaunchKernelGGL( k_phase_scan, dim3( (unsigned) ( ( cols + 255 ) / 256 ) ), dim3( 256 ), 0, s, p );
+		FLANHIP_CHECK( hipGetLastError() );
+		}
 
 	int rc = FLANHIP_ERR_UNSUPPORTED;
-	switch( ilog2( lay.dft ) - 1 )
+	if( !( stages & 4 ) ) rc = FLANHIP_OK;
+	else switch( ilog2( lay.dft ) - 1 )
 		{
 		case 4:  rc = run_synth<4, 8>( p, s ); break;
 		case 5:  rc = run_synth<5, 8>( p, s ); break;
@@ -156,7 +165,7 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 		default: set_error( "unsupported dft size %d", lay.dft );
 		}
 	if( rc ) return rc;
-	if( p.head_len > 0 && p.chains_per_channel > 1 )
+	if( ( stages & 8 ) && p.head_len > 0 && p.chains_per_channel > 1 )
 		{
 		hipLaunchKernelGGL( k_ola_fixup, dim3( (unsigned) chains ), dim3( 256 ), 0, s, p );
 		FLANHIP_CHECK( hipGetLastError() );
@@ -203,6 +212,8 @@ int flanhip_analyze( const float * audio, int64_t ch, int64_t n, float sr, int W
 	FLANHIP_CHECK( hipMemcpy( out, d_pv.p, sizeof( flanhip_MF ) * size_t( ch ) * F * bins, hipMemcpyDeviceToHost ) );
 	return FLANHIP_OK;
 	}
+
+void flanhip_debug_synth_stages( int mask ) { g_synth_stage_mask = mask & 0xF; }
 
 size_t flanhip_synthesize_workspace_bytes( int64_t ch, int64_t F, int bins, float sr, float ar, int W )
 	{

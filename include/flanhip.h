@@ -88,6 +88,10 @@ int flanhip_synthesize_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_
                            float sample_rate, float analysis_rate, int window_size,
                            float * d_out, void * d_workspace, int * d_nan_flag, void * stream);
 
+/* Bench/diagnostic knob: which of the synthesis kernels a call launches (bit 0 k_phase_sums, 1 k_phase_scan,
+ * 2 k_synthesize, 3 k_ola_fixup; default all).  Results are only meaningful with all four. */
+void flanhip_debug_synth_stages(int mask);
+
 /* ---- PV frame processors ------------------------------------------------------------------------------------- */
 /* modify_time_base (PV/PVModify.cpp:307-362, linear Interpolator): mod_seconds is the sampled time map float[F][bins]
  * (FunctionSample2d layout, FunctionSample.h:173-199).  out: MF[ch][out_frames][bins], out_frames from
