@@ -2,6 +2,7 @@
 // (reference: Conversions/AudioPV.cpp:12-78 and :86-139).
 #include "flanhip_internal.h"
 #include "pv_kernels.h"
+#include "pv_kernels_fast.h"
 #include <algorithm>
 
 namespace flanhip {
@@ -36,6 +37,59 @@ static int run_analyze( const AnalyzeParams & p, hipStream_t s )
 	return FLANHIP_OK;
 	}
 
+// Tuned kernels (dft 2048 / 4096): 6 wavefronts per block; two blocks (dft 2048) share a CU's 160 KiB of LDS, so the chip
+// holds 256 CUs x 12 wavefronts = 3072 chains at once.
+static constexpr int kFastWaves = 6;
+static constexpr int kFastTargetChains = 256 * 12;
+
+template<int LOG2C, int WAVES>
+static int run_analyze_fast( const AnalyzeParams & p, const FastTables & tb, hipStream_t s )
+	{
+	const size_t lds = FastLds<LOG2C>::bytes( WAVES );
+	static_assert( FastLds<LOG2C>::bytes( WAVES ) <= kMaxLds, "LDS budget" );
+	auto kern = k_analyze_fast<LOG2C, WAVES>;
+	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;
+	const int64_t blocks = ( chains + WAVES - 1 ) / WAVES;
+	FLANHIP_REQUIRE( blocks < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
+	hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( 64 * WAVES ), lds, s, p, tb );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+template<int LOG2C, int WAVES, int HOPQ>
+static int run_synth_fast( const SynthParams & p, const FastTables & tb, hipStream_t s )
+	{
+	const size_t lds = FastLds<LOG2C>::bytes( WAVES );
+	auto kern = k_synthesize_fast<LOG2C, WAVES, HOPQ>;
+	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;
+	const int64_t blocks = ( chains + WAVES - 1 ) / WAVES;
+	hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( 64 * WAVES ), lds, s, p, tb );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+template<int LOG2C>
+static int run_synth_fast_hop( const SynthParams & p, const FastTables & tb, hipStream_t s )
+	{
+	switch( p.hop / 128 )
+		{
+		case 1: return run_synth_fast<LOG2C, kFastWaves, 1>( p, tb, s );
+		case 2: return run_synth_fast<LOG2C, kFastWaves, 2>( p, tb, s );
+		case 4: return run_synth_fast<LOG2C, kFastWaves, 4>( p, tb, s );
+		case 8: return run_synth_fast<LOG2C, kFastWaves, 8>( p, tb, s );
+		}
+	return FLANHIP_ERR_UNSUPPORTED;
+	}
+
+static bool synth_fast_ok( int dft, int W, int hop )
+	{
+	const int hq = hop / 128;
+	return ( dft == 2048 || dft == 4096 ) && hop % 128 == 0 && ( hq == 1 || hq == 2 || hq == 4 || hq == 8 )
+		&& W % 128 == 0 && hop <= W && !force_generic();
+	}
+
 int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft, flanhip_MF * d_out, hipStream_t s )
 	{
 	FLANHIP_REQUIRE( d_audio && d_out, FLANHIP_ERR_INVALID_ARG, "null buffer" );
@@ -51,10 +105,17 @@ int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int 
 	p.window = plan->d_window; p.tw = plan->d_tw; p.tw2 = plan->d_tw2;
 	p.n = n; p.F = n / hop + 1;                                   // AudioPV.cpp:17
 	p.num_channels = int( ch ); p.window_size = W; p.hop = hop;
-	p.L = choose_chain_length( ch, p.F, 1 );
+	const bool fast = ( dft == 2048 || dft == 4096 ) && !force_generic();
+	p.L = choose_chain_length( ch, p.F, 1, fast ? kFastTargetChains : 4096 );
 	p.chains_per_channel = int( ( p.F + p.L - 1 ) / p.L );
 	p.sample_rate = sr;
 	p.analysis_rate = sr / hop;                                   // AudioPV.cpp:26 (float / int)
+
+	if( fast )
+		{
+		FastTables tb{ plan->d_tw1f, plan->d_tw3f, plan->d_tw2 };
+		return dft == 2048 ? run_analyze_fast<10, kFastWaves>( p, tb, s ) : run_analyze_fast<11, kFastWaves>( p, tb, s );
+		}
 
 	switch( ilog2( dft ) - 1 )
 		{
@@ -82,7 +143,7 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	FLANHIP_REQUIRE( is_pow2( o->dft ) && o->dft >= 32 && o->dft <= 8192, FLANHIP_ERR_UNSUPPORTED, "dft size must be a power of two in [32, 8192]" );
 	o->head_len = std::max( W - o->hop, 0 );
 	const int overlap = ( W + o->hop - 1 ) / o->hop;              // frames covering one output sample
-	o->L = choose_chain_length( ch, F, std::max( overlap - 1, 1 ) );
+	o->L = choose_chain_length( ch, F, std::max( overlap - 1, 1 ), synth_fast_ok( o->dft, W, o->hop ) ? kFastTargetChains : 4096 );
 	o->chains_per_channel = int( ( F + o->L - 1 ) / o->L );
 	const int64_t chains = int64_t( o->chains_per_channel ) * ch;
 	o->carry_bytes = ( size_t( chains ) * bins * sizeof( double ) + 255 ) & ~size_t( 255 );
@@ -139,18 +200,23 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	const int stages = g_synth_stage_mask;
 	if( stages & 1 )
 		{
-		hipLaunchKernelGGL( k_phase_sums, dim3( (unsigned) chains ), dim3( 256 ), 0, s, p );
+		hipLaunchKernelGGL( k_phase_sums2, dim3( (unsigned) chains, (unsigned) ( ( bins + 255 ) / 256 ) ), dim3( 256 ), 0, s, p );
 		FLANHIP_CHECK( hipGetLastError() );
 		}
 	if( stages & 2 )
 		{
 		const int64_t cols = ch * bins;
-		hipLaunchKernelGGL( k_phase_scan, dim3( (unsigned) ( ( cols + 255 ) / 256 ) ), dim3( 256 ), 0, s, p );
+		hipLaunchKernelGGL( k_phase_scan2, dim3( (unsigned) ( ( cols + 255 ) / 256 ) ), dim3( 256 ), 0, s, p );
 		FLANHIP_CHECK( hipGetLastError() );
 		}
 
 	int rc = FLANHIP_ERR_UNSUPPORTED;
 	if( !( stages & 4 ) ) rc = FLANHIP_OK;
+	else if( synth_fast_ok( lay.dft, W, lay.hop ) )
+		{
+		FastTables tb{ plan->d_tw1f, plan->d_tw3f, plan->d_tw2 };
+		rc = lay.dft == 2048 ? run_synth_fast_hop<10>( p, tb, s ) : run_synth_fast_hop<11>( p, tb, s );
+		}
 	else switch( ilog2( lay.dft ) - 1 )
 		{
 		case 4:  rc = run_synth<4, 8>( p, s ); break;

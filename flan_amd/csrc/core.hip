@@ -60,21 +60,42 @@ int get_plan( int window_size, int dft_size, const Plan ** out )
 	FLANHIP_CHECK( hipMemcpy( plan.d_window, win.data(), sizeof( float ) * window_size, hipMemcpyHostToDevice ) );
 	FLANHIP_CHECK( hipMemcpy( plan.d_tw, tw.data(), sizeof( float2 ) * C, hipMemcpyHostToDevice ) );
 	FLANHIP_CHECK( hipMemcpy( plan.d_tw2, tw2.data(), sizeof( float2 ) * ( C + 1 ), hipMemcpyHostToDevice ) );
+	if( dft_size == 2048 || dft_size == 4096 )
+		{
+		const int R3 = C / 256;
+		std::vector<float2> tw1( 15 * 16 ), tw3( size_t( R3 - 1 ) * 256 );
+		for( int r = 1; r < 16; ++r ) for( int k = 0; k < 16; ++k )
+			tw1[( r - 1 ) * 16 + k] = make_float2( float( std::cos( -2.0 * pi * r * k / 256.0 ) ), float( std::sin( -2.0 * pi * r * k / 256.0 ) ) );
+		for( int r = 1; r < R3; ++r ) for( int j = 0; j < 256; ++j )
+			tw3[size_t( r - 1 ) * 256 + j] = make_float2( float( std::cos( -2.0 * pi * r * j / C ) ), float( std::sin( -2.0 * pi * r * j / C ) ) );
+		FLANHIP_CHECK( hipMalloc( &plan.d_tw1f, sizeof( float2 ) * tw1.size() ) );
+		FLANHIP_CHECK( hipMalloc( &plan.d_tw3f, sizeof( float2 ) * tw3.size() ) );
+		FLANHIP_CHECK( hipMemcpy( plan.d_tw1f, tw1.data(), sizeof( float2 ) * tw1.size(), hipMemcpyHostToDevice ) );
+		FLANHIP_CHECK( hipMemcpy( plan.d_tw3f, tw3.data(), sizeof( float2 ) * tw3.size(), hipMemcpyHostToDevice ) );
+		}
 	auto ins = g_plans.emplace( key, plan );
 	*out = &ins.first->second;
 	return FLANHIP_OK;
 	}
 
-int choose_chain_length( int64_t num_channels, int64_t num_frames, int min_len )
+bool force_generic()
+	{
+	const char * env = std::getenv( "FLANHIP_FORCE_GENERIC" );
+	return env && env[0] == '1';
+	}
+
+int choose_chain_length( int64_t num_channels, int64_t num_frames, int min_len, int target_chains )
 	{
 	if( const char * env = std::getenv( "FLANHIP_CHAIN_LEN" ) )
 		{
 		const int v = std::atoi( env );
 		if( v > 0 ) return std::max( v, min_len );
 		}
-	// enough chains to give every SIMD of the 256 CUs a few wavefronts, long enough to amortise the per-chain halo
+	// One wavefront per chain.  target_chains = the wavefronts the chip holds at once for this kernel: with that many
+	// chains (or a little fewer) the whole grid is resident in a single wave of blocks -- no partial second round --
+	// and each chain is long enough to amortise its halo frame / overlap head.  Longer inputs run several rounds.
 	const int64_t total = num_channels * num_frames;
-	int64_t L = total / 4096;
+	int64_t L = ( total + target_chains - 1 ) / target_chains;
 	if( L < 4 ) L = 4;
 	if( L > 64 ) L = 64;
 	if( L < min_len ) L = min_len;

@@ -38,11 +38,14 @@ struct Plan
 	float * d_window = nullptr;    // [W]   hann( i/(W-1) ), WindowFunctions.cpp:10-13 evaluated on the host in double
 	float2 * d_tw = nullptr;       // [C]   exp(-2 pi i k / C)
 	float2 * d_tw2 = nullptr;      // [C+1] exp(-2 pi i k / (2C))
+	float2 * d_tw1f = nullptr;     // fast path (dft 2048/4096): [15][16]      exp(-2 pi i r k / 256)
+	float2 * d_tw3f = nullptr;     // fast path:                 [C/256-1][256] exp(-2 pi i r j / C)
 	};
 int get_plan( int window_size, int dft_size, const Plan ** out );
 
 // Chain length heuristics (frames per wavefront-chain)
-int choose_chain_length( int64_t num_channels, int64_t num_frames, int min_len );
+int choose_chain_length( int64_t num_channels, int64_t num_frames, int min_len, int target_chains );
+bool force_generic();   // FLANHIP_FORCE_GENERIC=1: never take the tuned dft 2048/4096 kernels (A/B and parity of both paths)
 
 // Launchers implemented in analyze.hip / synthesize.hip / processors.hip
 int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft, flanhip_MF * d_out, hipStream_t s );

