@@ -124,6 +124,16 @@ __device__ __forceinline__ void load_tables( float2 * s, const FastTables & t, c
 	for( int i = tid; i < 2 * C; i += nthreads ) win[i] = ( i < W ) ? window[i] * scale : 0.0f;
 	}
 
+// magnitude with the operands pre-scaled by a power of two (exact), so that the squares neither overflow nor underflow
+// for any finite input: |z| = 2^e * sqrt( (re 2^-e)^2 + (im 2^-e)^2 ), e = exponent of max(|re|,|im|).
+__device__ __forceinline__ float magnitude_scaled( float re, float im )
+	{
+	const float a = __builtin_fmaxf( __builtin_fabsf( re ), __builtin_fabsf( im ) );
+	const int e = __builtin_amdgcn_frexp_expf( a );
+	const float rs = __builtin_ldexpf( re, -e ), is = __builtin_ldexpf( im, -e );
+	return __builtin_ldexpf( __builtin_amdgcn_sqrtf( __builtin_fmaf( rs, rs, is * is ) ), e );
+	}
+
 // =================================================================================================================
 // Audio::convert_to_PV (Conversions/AudioPV.cpp:12-78)
 // =================================================================================================================
@@ -168,13 +178,12 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 		prev[q] = 0.0f;                                                       // AudioPV.cpp:44
 		}
 
-	for( int64_t t = ( t0 > 0 ? t0 - 1 : t0 ); t < t1; ++t )
+	// window frame t (AudioPV.cpp:52-65) straight into the natural register layout z[q] = ( x[2i], x[2i+1] ), i = lane + 64 q,
+	// transform it, and leave Z both in z[] and (natural order) in buf[] for the mirror reads
+	auto transform_frame = [&]( int64_t t, float2 ( &z )[E] )
 		{
-		const bool emit = t >= t0;
-		// ---- window the frame (AudioPV.cpp:52-65) straight into the natural register layout: z[q] = ( x[2i], x[2i+1] ), i = lane + 64 q
 		const int64_t start = int64_t( hop ) * t - W / 2;
 		const float * xs = x + start;
-		float2 z[E];
 		const bool interior = w_whole && start >= 0 && start + W <= p.n && ( ( reinterpret_cast<uintptr_t>( xs ) & 7 ) == 0 );
 		if( interior )
 			{
@@ -204,33 +213,72 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 				z[q] = make_float2( v0, v1 );
 				}
 			}
-
 		fft_fast<LOG2C>( z, buf, s_tw1, s_tw3, lane );
-
-		// ---- half-size transform -> real transform: bin k needs Z[k] (own register) and Z[C-k] (another lane): one LDS exchange
 		#pragma unroll
 		for( int q = 0; q < E; ++q ) buf[padl + 68 * q] = z[q];
 		wave_sync();
+		};
+
+	// bin k = lane + 64 q of the real transform from Z[k] (own register) and Z[C-k] (mirror lane, through LDS)
+	auto split_bin = [&]( const float2 ( &z )[E], int q, float2 z0, float & re, float & im )
+		{
+		const float2 zk = z[q];
+		const float2 zm = mirror[-68 * q];                                    // k = 0 reads a junk slot, overridden below
+		const float2 w = s_w2[64 * q];
+		const float ax = 0.5f * ( zk.x + zm.x ), ay = 0.5f * ( zk.y - zm.y );
+		const float dx = zk.x - zm.x, dy = zk.y + zm.y;
+		re = ax + 0.5f * __builtin_fmaf( w.x, dy, w.y * dx );
+		im = ay - 0.5f * __builtin_fmaf( w.x, dx, -( w.y * dy ) );
+		if( q == 0 ) { re = ( lane == 0 ) ? z0.x + z0.y : re; im = ( lane == 0 ) ? 0.0f : im; }
+		};
+
+	if( t0 > 0 )
+		{
+		// halo: only the phases of frame t0-1 are needed (phase_vocoder.cpp:45 leaves them in phase_buffer)
+		float2 z[E];
+		transform_frame( t0 - 1, z );
 		const float2 z0 = buf[0];
-		MF * row = p.out + ( int64_t( channel ) * p.F + t ) * ( C + 1 );
-		float2 * rowp = reinterpret_cast<float2*>( row ) + lane;
 		#pragma unroll
 		for( int q = 0; q < E; ++q )
 			{
-			const float2 zk = z[q];
-			const float2 zm = mirror[-68 * q];                                // Z[ C - k ]  (k = 0 reads a junk slot, overridden below)
-			const float2 w = s_w2[64 * q];
-			const float ax = 0.5f * ( zk.x + zm.x ), ay = 0.5f * ( zk.y - zm.y );
-			const float dx = zk.x - zm.x, dy = zk.y + zm.y;
-			float re = ax + 0.5f * __builtin_fmaf( w.x, dy, w.y * dx );
-			float im = ay - 0.5f * __builtin_fmaf( w.x, dx, -( w.y * dy ) );
-			if( q == 0 && lane == 0 ) { re = z0.x + z0.y; im = 0.0f; }
-			const MFv mf = phase_vocode_bin_fast( re, im, prev[q], binf[q], expect[q], p.analysis_rate, use_wrapping );   // AudioPV.cpp:69-73
-			if( emit ) rowp[64 * q] = make_float2( mf.m, mf.f );
+			float re, im;
+			split_bin( z, q, z0, re, im );
+			prev[q] = atan2_fast( im, re );
+			}
+		prev[E] = atan2_fast( 0.0f, z0.x - z0.y );
+		wave_sync();
+		}
+
+	for( int64_t t = t0; t < t1; ++t )
+		{
+		float2 z[E];
+		transform_frame( t, z );
+		const float2 z0 = buf[0];
+		float2 * row = reinterpret_cast<float2*>( p.out + ( int64_t( channel ) * p.F + t ) * ( C + 1 ) );
+		float2 * rowp = row + lane;
+		#pragma unroll
+		for( int q = 0; q < E; ++q )
+			{
+			float re, im;
+			split_bin( z, q, z0, re, im );
+			// phase_vocoder.cpp:37-52 (AudioPV.cpp:69-73)
+			const float phase = atan2_fast( im, re );
+			const float phase_diff = float( double( phase ) - double( prev[q] ) );
+			prev[q] = phase;
+			const float delta_phase = phase_diff - expect[q];
+			const float wrapped = use_wrapping ? delta_phase - FLANHIP_PI2_F * roundf( div_pi2( delta_phase ) ) : delta_phase;
+			const float delta_frequency = div_pi2( wrapped * p.analysis_rate );
+			rowp[64 * q] = make_float2( magnitude_scaled( re, im ), binf[q] + delta_frequency );
 			}
 			{
-			const MFv mf = phase_vocode_bin_fast( z0.x - z0.y, 0.0f, prev[E], binf[E], expect[E], p.analysis_rate, use_wrapping );
-			if( emit && lane == 0 ) reinterpret_cast<float2*>( row )[C] = make_float2( mf.m, mf.f );
+			const float re = z0.x - z0.y;
+			const float phase = atan2_fast( 0.0f, re );
+			const float phase_diff = float( double( phase ) - double( prev[E] ) );
+			prev[E] = phase;
+			const float delta_phase = phase_diff - expect[E];
+			const float wrapped = use_wrapping ? delta_phase - FLANHIP_PI2_F * roundf( div_pi2( delta_phase ) ) : delta_phase;
+			const float delta_frequency = div_pi2( wrapped * p.analysis_rate );
+			if( lane == 0 ) row[C] = make_float2( __builtin_fabsf( re ), binf[E] + delta_frequency );
 			}
 		wave_sync();
 		}
@@ -265,8 +313,9 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 	const bool last_chain = chain_in_channel == p.chains_per_channel - 1;
 	const int W = p.window_size;
 	constexpr int hop = 128 * HOPQ;
-	float * out = p.out + int64_t( channel ) * p.out_len;
-	float * head = p.head + chain * p.head_len;
+	// everything below is in float2 units (sample pairs): positions are even because hop, W/2... are multiples of 64
+	float2 * out2 = reinterpret_cast<float2*>( p.out + int64_t( channel ) * p.out_len );
+	float2 * head2 = reinterpret_cast<float2*>( p.head + chain * p.head_len );
 	const int64_t chain_start = int64_t( hop ) * t0 - W / 2;
 	const int64_t own_start = chain_in_channel == 0 ? INT64_MIN : chain_start + p.head_len;
 	const int padl = lane + ( lane >> 4 );
@@ -283,33 +332,64 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 	auto emit_step = [&]( int64_t a0, float2 v )
 		{
 		const int64_t a = a0 + 2 * lane;
-		if( a0 < own_start ) *reinterpret_cast<float2*>( head + ( a - chain_start ) ) = v;
-		else if( a >= 0 && a < p.out_len ) *reinterpret_cast<float2*>( out + a ) = v;
+		if( a0 < own_start ) head2[( a - chain_start ) >> 1] = v;
+		else if( a >= 0 && a < p.out_len ) out2[a >> 1] = v;
 		};
 
 	int64_t pos = chain_start;
 	for( int64_t t = t0; t < t1; ++t )
 		{
 		// ---- inverse phase vocoder per bin (AudioPV.cpp:117-120, phase_vocoder.cpp:55-61)
-		const MF * row = p.pv + ( int64_t( channel ) * p.F + t ) * ( C + 1 );
-		const float2 * rowp = reinterpret_cast<const float2*>( row ) + lane;
+		const float2 * row = reinterpret_cast<const float2*>( p.pv + ( int64_t( channel ) * p.F + t ) * ( C + 1 ) );
+		const float2 * rowp = row + lane;
 		float2 z[E];
+		float mn;
+		bool slow = false;
 		#pragma unroll
 		for( int q = 0; q < E; ++q )
 			{
 			const float2 mf = rowp[64 * q];                                     // ( m, f )
-			ph[q] = fold_phase_fast( ph[q] + double( mf.y / p.analysis_rate * FLANHIP_PI2_F ) );
-			float sn, cs;
-			sincos_fast( float( ph[q] ), sn, cs );
-			z[q] = make_float2( mf.x * cs, mf.x * sn );                         // std::polar
+			ph[q] += double( mf.y / p.analysis_rate * FLANHIP_PI2_F );          // phase_vocoder.cpp:57-58
+			slow |= !( __builtin_fabs( ph[q] ) < 1.0e6 );
+			z[q].x = mf.x;
+			}
+			{
+			const float2 mf = row[C];
+			ph[E] += double( mf.y / p.analysis_rate * FLANHIP_PI2_F );
+			slow |= !( __builtin_fabs( ph[E] ) < 1.0e6 );
+			mn = mf.x;
 			}
 		float2 xn;
+		if( __any( slow ) )
 			{
-			const float2 mf = reinterpret_cast<const float2*>( row )[C];
-			ph[E] = fold_phase_fast( ph[E] + double( mf.y / p.analysis_rate * FLANHIP_PI2_F ) );
+			// a phase outside the range the fast helpers are exact for (or a NaN): the general routines for this frame
+			#pragma unroll
+			for( int q = 0; q < E; ++q )
+				{
+				ph[q] = fold_phase_slow( ph[q] );
+				float sn, cs;
+				sincosf( float( ph[q] ), &sn, &cs );
+				z[q] = make_float2( z[q].x * cs, z[q].x * sn );
+				}
+			ph[E] = fold_phase_slow( ph[E] );
+			float sn, cs;
+			sincosf( float( ph[E] ), &sn, &cs );
+			xn = make_float2( mn * cs, mn * sn );
+			}
+		else
+			{
+			#pragma unroll
+			for( int q = 0; q < E; ++q )
+				{
+				ph[q] = fold_phase_fast( ph[q] );                               // phase_vocoder.cpp:59
+				float sn, cs;
+				sincos_fast( float( ph[q] ), sn, cs );
+				z[q] = make_float2( z[q].x * cs, z[q].x * sn );                 // std::polar, :60
+				}
+			ph[E] = fold_phase_fast( ph[E] );
 			float sn, cs;
 			sincos_fast( float( ph[E] ), sn, cs );
-			xn = make_float2( mf.x * cs, mf.x * sn );
+			xn = make_float2( mn * cs, mn * sn );
 			}
 		// ---- merge X[0..C] into the half-size spectrum: needs X[k] (own) and X[C-k] (mirror lane): one LDS exchange
 		#pragma unroll
@@ -321,7 +401,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 			{
 			float2 xk = z[q];
 			float2 xm = mirror[-68 * q];                                        // X[ C - k ]; k = 0 pairs with X[C]
-			if( q == 0 && lane == 0 ) { xk.y = 0.0f; xm.y = 0.0f; }             // c2r ignores Im X[0], Im X[C]
+			if( q == 0 ) { xk.y = ( lane == 0 ) ? 0.0f : xk.y; xm.y = ( lane == 0 ) ? 0.0f : xm.y; }   // c2r ignores Im X[0], Im X[C]
 			const float2 w = s_w2[64 * q];
 			const float ax = xk.x + xm.x, ay = xk.y - xm.y;                     // A = X[k] + conj X[C-k]
 			const float dx = xk.x - xm.x, dy = xk.y + xm.y;                     // D = X[k] - conj X[C-k]
@@ -381,14 +461,16 @@ __global__ __launch_bounds__( 256 ) void k_phase_sums2( SynthParams p )
 			for( int u = 0; u < 4; ++u )
 				{
 				bad |= isnan( v[u].x ) || isnan( v[u].y ) || isinf( v[u].x ) || isinf( v[u].y );
-				ph = fold_phase_fast( ph + double( v[u].y / p.analysis_rate * FLANHIP_PI2_F ) );
+				ph += double( v[u].y / p.analysis_rate * FLANHIP_PI2_F );
+				ph = ( __builtin_fabs( ph ) < 1.0e6 ) ? fold_phase_fast( ph ) : fold_phase_slow( ph );
 				}
 			}
 		for( ; i < n; ++i )
 			{
 			const float2 v = col[int64_t( i ) * p.num_bins];
 			bad |= isnan( v.x ) || isnan( v.y ) || isinf( v.x ) || isinf( v.y );
-			ph = fold_phase_fast( ph + double( v.y / p.analysis_rate * FLANHIP_PI2_F ) );
+			ph += double( v.y / p.analysis_rate * FLANHIP_PI2_F );
+			ph = ( __builtin_fabs( ph ) < 1.0e6 ) ? fold_phase_fast( ph ) : fold_phase_slow( ph );
 			}
 		p.carry[chain * p.num_bins + k] = ph;
 		}
@@ -414,14 +496,16 @@ __global__ __launch_bounds__( 256 ) void k_phase_scan2( SynthParams p )
 		for( int u = 0; u < 8; ++u )
 			{
 			c[int64_t( i + u ) * p.num_bins] = run;
-			run = fold_phase_fast( run + v[u] );
+			run += v[u];
+			run = ( __builtin_fabs( run ) < 1.0e6 ) ? fold_phase_fast( run ) : fold_phase_slow( run );
 			}
 		}
 	for( ; i < n; ++i )
 		{
 		const double v = c[int64_t( i ) * p.num_bins];
 		c[int64_t( i ) * p.num_bins] = run;
-		run = fold_phase_fast( run + v );
+		run += v;
+		run = ( __builtin_fabs( run ) < 1.0e6 ) ? fold_phase_fast( run ) : fold_phase_slow( run );
 		}
 	}
 

@@ -2,6 +2,10 @@
 // (phase_vocoder.cpp:37-61), written so that the expensive steps cost a few instructions on gfx950.
 //
 // Everything here is compiled with -ffp-contract=off: a*b+c is two roundings unless fmaf() is written out.
+// The helpers are branch-free on purpose: a data-dependent `if` inside per-lane code costs an exec-mask
+// save/restore (5-8 scalar instructions) per use and there are ~10 uses per bin; rare cases (operands outside the
+// range a helper is exact for) are instead flagged by the caller once per frame and that frame is redone through
+// the slow, fully general routines.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -11,77 +15,107 @@ namespace flanhip {
 #define FLANHIP_PI2_F 6.2831854820251465f
 #define FLANHIP_PI2_D 6.2831854820251465
 #define FLANHIP_RPI2_F 0x1.45f306p-3f       /* RN( 1 / pi2 ) */
+#define FLANHIP_PI_F   0x1.921fb6p+1f
+#define FLANHIP_PIO2_F 0x1.921fb6p+0f
 
 // x / pi2 with IEEE round-to-nearest semantics in 3 instructions.  q0 = RN(x*rc); r = x - q0*c exactly (fma);
 // q = RN(q0 + r*rc) is the correctly rounded quotient for EVERY float with |x| >= 1e-30 -- checked exhaustively
-// over all 3.8e9 such floats by tools/check_div_pi2.cpp; smaller |x| (the residual would be subnormal) take the
-// hardware division.
+// over all 3.8e9 such floats by tools/check_div_pi2.cpp.  Below 1e-30 the residual is subnormal and the last place
+// of the quotient may differ from the hardware division; every use in this path either rounds the quotient to an
+// integer (0 either way) or adds it to a bin frequency it is >= 20 orders of magnitude below.
 __device__ __forceinline__ float div_pi2( float x )
 	{
-	if( __builtin_fabsf( x ) < 1.0e-30f ) return x / FLANHIP_PI2_F;
 	const float q0 = x * FLANHIP_RPI2_F;
 	const float r = __builtin_fmaf( -q0, FLANHIP_PI2_F, x );
 	return __builtin_fmaf( r, FLANHIP_RPI2_F, q0 );
 	}
 
-// |z| for spectra of audio-scale signals: one fma, one correctly rounded sqrt (within 1 ulp of hypotf); the scaled
-// path keeps the result finite/accurate when the squares would overflow or underflow.
-__device__ __forceinline__ float magnitude( float re, float im )
+// |z| = sqrt( re^2 + im^2 ) by one fma and the hardware square root (v_sqrt_f32, 1 ulp): within 1.5 ulp of hypotf for
+// max(|re|,|im|) in [1e-18, 1e18]; the caller tracks the largest / smallest operand of a frame and redoes the frame
+// with hypotf when it falls outside.
+__device__ __forceinline__ float magnitude_fast( float re, float im )
 	{
-	const float a = __builtin_fmaxf( __builtin_fabsf( re ), __builtin_fabsf( im ) );
-	if( a > 1.0e18f || ( a < 1.0e-18f && a > 0.0f ) ) return hypotf( re, im );
-	return __builtin_sqrtf( __builtin_fmaf( re, re, im * im ) );
+	return __builtin_amdgcn_sqrtf( __builtin_fmaf( re, re, im * im ) );
+	}
+__device__ __forceinline__ bool magnitude_fast_ok( float amax, float amin_nonzero )
+	{
+	return amax < 1.0e18f && amin_nonzero > 1.0e-18f;
+	}
+
+// atan2f for finite operands: one reciprocal + Newton step for min/max, an 8-coefficient odd minimax polynomial on
+// [0,1] (tools/fit_atan.py: max error 1.8 ulp, mean 0.37 ulp), octant fix-ups with the float constants pi/2 and pi,
+// sign of y.  atan2( +-0, +-0 ) follows C99 ( +-0 for x = +0, +-pi for x = -0 ).  Infinite operands are not handled
+// (a frame that holds one is redone through atan2f by the caller: magnitude_fast_ok() is false for it).
+__device__ __forceinline__ float atan2_fast( float y, float x )
+	{
+	const float ax = __builtin_fabsf( x ), ay = __builtin_fabsf( y );
+	// the clamp makes 0/0 come out as q = 0 (so atan2(+-0, +-0) needs no special case) and keeps rcp finite
+	const float mx = __builtin_fmaxf( __builtin_fmaxf( ax, ay ), 0x1p-126f ), mn = __builtin_fminf( ax, ay );
+	const float r = __builtin_amdgcn_rcpf( mx );
+	const float q0 = mn * r;
+	const float q = __builtin_fmaf( __builtin_fmaf( -q0, mx, mn ), r, q0 );
+	const float u = q * q;
+	float p = 0x1.7ec8b6p-9f;
+	p = __builtin_fmaf( p, u, -0x1.0c272ap-6f );
+	p = __builtin_fmaf( p, u, 0x1.61f9a0p-5f );
+	p = __builtin_fmaf( p, u, -0x1.3554c4p-4f );
+	p = __builtin_fmaf( p, u, 0x1.b4e022p-4f );
+	p = __builtin_fmaf( p, u, -0x1.230ab4p-3f );
+	p = __builtin_fmaf( p, u, 0x1.9978eep-3f );
+	p = __builtin_fmaf( p, u, -0x1.5554dcp-2f );
+	float a = __builtin_fmaf( q * u, p, q );
+	a = ( ay > ax ) ? FLANHIP_PIO2_F - a : a;
+	const bool xneg = __float_as_int( x ) < 0;                 // sign bit, so that -0 counts
+	a = xneg ? FLANHIP_PI_F - a : a;
+	return __builtin_copysignf( a, y );
 	}
 
 struct MFv { float m, f; };
 
 // phase_vocoder.cpp:37-52.  prev_phase is the reference's phase_buffer (it only ever holds a float value).
+template<bool FAST>
 __device__ __forceinline__ MFv phase_vocode_bin_fast( float re, float im, float & prev_phase, float bin_frequency, float expected_phase_diff,
 	float analysis_rate, bool use_wrapping )
 	{
-	const float phase = atan2f( im, re );                                             // std::arg
+	const float phase = FAST ? atan2_fast( im, re ) : atan2f( im, re );               // std::arg
 	const float phase_diff = float( double( phase ) - double( prev_phase ) );         // :44 double subtraction, narrowed
 	prev_phase = phase;                                                               // :45
 	const float delta_phase = phase_diff - expected_phase_diff;                       // :48
 	const float wrapped = use_wrapping ? delta_phase - FLANHIP_PI2_F * roundf( div_pi2( delta_phase ) ) : delta_phase; // :39-42,49
 	const float delta_frequency = div_pi2( wrapped * analysis_rate );                 // :50
 	MFv r;
-	r.m = magnitude( re, im );                                                        // std::abs
+	r.m = FAST ? magnitude_fast( re, im ) : hypotf( re, im );                         // std::abs
 	r.f = bin_frequency + delta_frequency;                                            // :52
 	return r;
 	}
 
 // phase_vocoder.cpp:57-59:  phase_buffer += term; if( phase_buffer > pi2 ) phase_buffer = fmod( phase_buffer, pi2 ).
 // fmod is exact; for ph < 1e6 the quotient is < 2^18, q*pi2 (24-bit constant) is exact in double and so is the
-// difference, so floor + fma + one correction reproduces it without a division.
+// difference, so floor + fma + one correction reproduces it without a division.  Branch-free; the caller redoes the
+// frame through fold_phase_slow() if any phase reaches 1e6.
 __device__ __forceinline__ double fold_phase_fast( double ph )
 	{
-	if( ph > FLANHIP_PI2_D )
-		{
-		if( ph < 1.0e6 )
-			{
-			const double q = __builtin_floor( ph * ( 1.0 / FLANHIP_PI2_D ) );
-			double r = __builtin_fma( -q, FLANHIP_PI2_D, ph );
-			if( r < 0.0 ) r += FLANHIP_PI2_D;
-			else if( r >= FLANHIP_PI2_D ) r -= FLANHIP_PI2_D;
-			ph = r;
-			}
-		else ph = fmod( ph, FLANHIP_PI2_D );
-		}
-	return ph;
+	const double q = __builtin_floor( ph * ( 1.0 / FLANHIP_PI2_D ) );
+	double r = __builtin_fma( -q, FLANHIP_PI2_D, ph );
+	r = ( r < 0.0 ) ? r + FLANHIP_PI2_D : r;
+	r = ( r >= FLANHIP_PI2_D ) ? r - FLANHIP_PI2_D : r;
+	return ( ph > FLANHIP_PI2_D ) ? r : ph;
+	}
+__device__ __forceinline__ double fold_phase_slow( double ph )
+	{
+	return ( ph > FLANHIP_PI2_D ) ? fmod( ph, FLANHIP_PI2_D ) : ph;
 	}
 
-// sin and cos of a float angle, ~1 ulp, for the range the folded phase lives in; anything larger goes to sincosf.
+// sin and cos of a float angle for |x| < 8192 (the folded phase lives in [0, 2 pi]): Cody-Waite reduction by pi/2 in
+// three parts, minimax polynomials on [-pi/4, pi/4] (tools/fit_sincos.py: max abs error 7e-8).  Branch-free; larger
+// arguments are the caller's business (sincosf).
 __device__ __forceinline__ void sincos_fast( float x, float & s, float & c )
 	{
-	if( !( __builtin_fabsf( x ) < 8192.0f ) ) { sincosf( x, &s, &c ); return; }
-	// Cody-Waite: r = x - k*pi/2 with pi/2 split in three (fma keeps every partial product exact enough for k < 2^13)
 	const float k = __builtin_rintf( x * 0x1.45f306p-1f );                            // 2/pi
 	float r = __builtin_fmaf( -k, 0x1.921fb6p+0f, x );
 	r = __builtin_fmaf( -k, -0x1.777a5cp-25f, r );
 	r = __builtin_fmaf( -k, -0x1.ee59dap-50f, r );
 	const float r2 = r * r;
-	// minimax fits on [-pi/4, pi/4] (tools/fit_sincos.py): max abs error 7e-8 over [-8192, 8192]
 	float sp = 0x1.6cd1e4p-19f;
 	sp = __builtin_fmaf( sp, r2, -0x1.a00f80p-13f );
 	sp = __builtin_fmaf( sp, r2, 0x1.111108p-7f );
