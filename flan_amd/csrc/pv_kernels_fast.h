@@ -178,9 +178,9 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 		prev[q] = 0.0f;                                                       // AudioPV.cpp:44
 		}
 
-	// window frame t (AudioPV.cpp:52-65) straight into the natural register layout z[q] = ( x[2i], x[2i+1] ), i = lane + 64 q,
-	// transform it, and leave Z both in z[] and (natural order) in buf[] for the mirror reads
-	auto transform_frame = [&]( int64_t t, float2 ( &z )[E] )
+	// raw samples of frame t (AudioPV.cpp:52-62) in the natural register layout raw[q] = ( x[2i], x[2i+1] ), i = lane + 64 q.
+	// Issued one frame ahead of their use so that the HBM/L2 latency hides under the previous frame's per-bin math.
+	auto load_raw = [&]( int64_t t, float2 ( &raw )[E] )
 		{
 		const int64_t start = int64_t( hop ) * t - W / 2;
 		const float * xs = x + start;
@@ -189,16 +189,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 			{
 			const float2 * xp = reinterpret_cast<const float2*>( xs ) + lane;
 			#pragma unroll
-			for( int q = 0; q < E; ++q )
-				{
-				if( q < WQ )
-					{
-					const float2 v = xp[64 * q];
-					const float2 w = s_win[64 * q];
-					z[q] = make_float2( v.x * w.x, v.y * w.y );
-					}
-				else z[q] = make_float2( 0.0f, 0.0f );
-				}
+			for( int q = 0; q < E; ++q ) raw[q] = ( q < WQ ) ? xp[64 * q] : make_float2( 0.0f, 0.0f );
 			}
 		else
 			{
@@ -206,12 +197,22 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 			for( int q = 0; q < E; ++q )
 				{
 				const int s0 = 2 * ( lane + 64 * q );
-				const float2 w = s_win[64 * q];                               // zero beyond W
 				float v0 = 0.0f, v1 = 0.0f;
-				if( s0 < W )     { const int64_t a = start + s0;     if( a >= 0 && a < p.n ) v0 = x[a] * w.x; }
-				if( s0 + 1 < W ) { const int64_t a = start + s0 + 1; if( a >= 0 && a < p.n ) v1 = x[a] * w.y; }
-				z[q] = make_float2( v0, v1 );
+				if( s0 < W )     { const int64_t a = start + s0;     if( a >= 0 && a < p.n ) v0 = x[a]; }
+				if( s0 + 1 < W ) { const int64_t a = start + s0 + 1; if( a >= 0 && a < p.n ) v1 = x[a]; }
+				raw[q] = make_float2( v0, v1 );
 				}
+			}
+		};
+	// window (AudioPV.cpp:60; the table is zero beyond W, :65), transform, and leave Z both in z[] and (natural order) in
+	// buf[] for the mirror reads
+	auto transform_frame = [&]( float2 ( &z )[E] )
+		{
+		#pragma unroll
+		for( int q = 0; q < E; ++q )
+			{
+			const float2 w = s_win[64 * q];
+			z[q] = make_float2( z[q].x * w.x, z[q].y * w.y );
 			}
 		fft_fast<LOG2C>( z, buf, s_tw1, s_tw3, lane );
 		#pragma unroll
@@ -232,12 +233,14 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 		if( q == 0 ) { re = ( lane == 0 ) ? z0.x + z0.y : re; im = ( lane == 0 ) ? 0.0f : im; }
 		};
 
+	float2 z[E], zn[E];
 	if( t0 > 0 )
 		{
 		// halo: only the phases of frame t0-1 are needed (phase_vocoder.cpp:45 leaves them in phase_buffer)
-		float2 z[E];
-		transform_frame( t0 - 1, z );
+		load_raw( t0 - 1, z );
+		transform_frame( z );
 		const float2 z0 = buf[0];
+		load_raw( t0, zn );
 		#pragma unroll
 		for( int q = 0; q < E; ++q )
 			{
@@ -248,12 +251,15 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 		prev[E] = atan2_fast( 0.0f, z0.x - z0.y );
 		wave_sync();
 		}
+	else load_raw( t0, zn );
 
 	for( int64_t t = t0; t < t1; ++t )
 		{
-		float2 z[E];
-		transform_frame( t, z );
+		#pragma unroll
+		for( int q = 0; q < E; ++q ) z[q] = zn[q];
+		transform_frame( z );
 		const float2 z0 = buf[0];
+		if( t + 1 < t1 ) load_raw( t + 1, zn );                                // prefetch: in flight during the per-bin math below
 		float2 * row = reinterpret_cast<float2*>( p.out + ( int64_t( channel ) * p.F + t ) * ( C + 1 ) );
 		float2 * rowp = row + lane;
 		#pragma unroll
@@ -336,29 +342,40 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 		else if( a >= 0 && a < p.out_len ) out2[a >> 1] = v;
 		};
 
+	// MF row of frame t in the natural layout ( m, f ) of bin lane + 64 q; loaded one frame ahead of its use
+	auto load_row = [&]( int64_t t, float2 ( &mfr )[E], float2 & mfny )
+		{
+		const float2 * row = reinterpret_cast<const float2*>( p.pv + ( int64_t( channel ) * p.F + t ) * ( C + 1 ) );
+		const float2 * rowp = row + lane;
+		#pragma unroll
+		for( int q = 0; q < E; ++q ) mfr[q] = rowp[64 * q];
+		mfny = row[C];
+		};
+	float2 mfr[E], mfny;
+	load_row( t0, mfr, mfny );
+
 	int64_t pos = chain_start;
 	for( int64_t t = t0; t < t1; ++t )
 		{
 		// ---- inverse phase vocoder per bin (AudioPV.cpp:117-120, phase_vocoder.cpp:55-61)
-		const float2 * row = reinterpret_cast<const float2*>( p.pv + ( int64_t( channel ) * p.F + t ) * ( C + 1 ) );
-		const float2 * rowp = row + lane;
 		float2 z[E];
 		float mn;
 		bool slow = false;
 		#pragma unroll
 		for( int q = 0; q < E; ++q )
 			{
-			const float2 mf = rowp[64 * q];                                     // ( m, f )
+			const float2 mf = mfr[q];                                           // ( m, f )
 			ph[q] += double( mf.y / p.analysis_rate * FLANHIP_PI2_F );          // phase_vocoder.cpp:57-58
-			slow |= !( __builtin_fabs( ph[q] ) < 1.0e6 );
+			slow |= !( __builtin_fabs( ph[q] ) < double( FLANHIP_SINCOS_FAST_LIMIT ) );
 			z[q].x = mf.x;
 			}
 			{
-			const float2 mf = row[C];
+			const float2 mf = mfny;
 			ph[E] += double( mf.y / p.analysis_rate * FLANHIP_PI2_F );
-			slow |= !( __builtin_fabs( ph[E] ) < 1.0e6 );
+			slow |= !( __builtin_fabs( ph[E] ) < double( FLANHIP_SINCOS_FAST_LIMIT ) );
 			mn = mf.x;
 			}
+		if( t + 1 < t1 ) load_row( t + 1, mfr, mfny );                          // prefetch: in flight during the transform below
 		float2 xn;
 		if( __any( slow ) )
 			{
@@ -366,15 +383,13 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 			#pragma unroll
 			for( int q = 0; q < E; ++q )
 				{
-				ph[q] = fold_phase_slow( ph[q] );
-				float sn, cs;
-				sincosf( float( ph[q] ), &sn, &cs );
-				z[q] = make_float2( z[q].x * cs, z[q].x * sn );
+				ph[q] = fold_phase_any( ph[q] );
+				const float2 sc = sincos_wide( float( ph[q] ) );
+				z[q] = make_float2( z[q].x * sc.y, z[q].x * sc.x );
 				}
-			ph[E] = fold_phase_slow( ph[E] );
-			float sn, cs;
-			sincosf( float( ph[E] ), &sn, &cs );
-			xn = make_float2( mn * cs, mn * sn );
+			ph[E] = fold_phase_any( ph[E] );
+			const float2 sc = sincos_wide( float( ph[E] ) );
+			xn = make_float2( mn * sc.y, mn * sc.x );
 			}
 		else
 			{
@@ -385,6 +400,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 				float sn, cs;
 				sincos_fast( float( ph[q] ), sn, cs );
 				z[q] = make_float2( z[q].x * cs, z[q].x * sn );                 // std::polar, :60
+				__builtin_amdgcn_sched_barrier( 0 );                            // one bin at a time: keeps the temporaries of 16 bins from overlapping
 				}
 			ph[E] = fold_phase_fast( ph[E] );
 			float sn, cs;
@@ -408,6 +424,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 			const float c = w.x, sgn = -w.y;                                    // exp(+2 pi i k / N)
 			const float bx = __builtin_fmaf( c, dx, -( sgn * dy ) ), by = __builtin_fmaf( c, dy, sgn * dx );
 			z[q] = make_float2( ax - by, -( ay + bx ) );                        // conj( A + iB ): forward FFT of it = conj of the inverse
+			__builtin_amdgcn_sched_barrier( 0 );
 			}
 		wave_sync();
 		fft_fast<LOG2C>( z, buf, s_tw1, s_tw3, lane );
@@ -462,7 +479,7 @@ __global__ __launch_bounds__( 256 ) void k_phase_sums2( SynthParams p )
 				{
 				bad |= isnan( v[u].x ) || isnan( v[u].y ) || isinf( v[u].x ) || isinf( v[u].y );
 				ph += double( v[u].y / p.analysis_rate * FLANHIP_PI2_F );
-				ph = ( __builtin_fabs( ph ) < 1.0e6 ) ? fold_phase_fast( ph ) : fold_phase_slow( ph );
+				ph = ( __builtin_fabs( ph ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( ph ) : fold_phase_any( ph );
 				}
 			}
 		for( ; i < n; ++i )
@@ -470,7 +487,7 @@ __global__ __launch_bounds__( 256 ) void k_phase_sums2( SynthParams p )
 			const float2 v = col[int64_t( i ) * p.num_bins];
 			bad |= isnan( v.x ) || isnan( v.y ) || isinf( v.x ) || isinf( v.y );
 			ph += double( v.y / p.analysis_rate * FLANHIP_PI2_F );
-			ph = ( __builtin_fabs( ph ) < 1.0e6 ) ? fold_phase_fast( ph ) : fold_phase_slow( ph );
+			ph = ( __builtin_fabs( ph ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( ph ) : fold_phase_any( ph );
 			}
 		p.carry[chain * p.num_bins + k] = ph;
 		}
@@ -497,7 +514,7 @@ __global__ __launch_bounds__( 256 ) void k_phase_scan2( SynthParams p )
 			{
 			c[int64_t( i + u ) * p.num_bins] = run;
 			run += v[u];
-			run = ( __builtin_fabs( run ) < 1.0e6 ) ? fold_phase_fast( run ) : fold_phase_slow( run );
+			run = ( __builtin_fabs( run ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( run ) : fold_phase_any( run );
 			}
 		}
 	for( ; i < n; ++i )
@@ -505,7 +522,7 @@ __global__ __launch_bounds__( 256 ) void k_phase_scan2( SynthParams p )
 		const double v = c[int64_t( i ) * p.num_bins];
 		c[int64_t( i ) * p.num_bins] = run;
 		run += v;
-		run = ( __builtin_fabs( run ) < 1.0e6 ) ? fold_phase_fast( run ) : fold_phase_slow( run );
+		run = ( __builtin_fabs( run ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( run ) : fold_phase_any( run );
 		}
 	}
 

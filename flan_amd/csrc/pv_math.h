@@ -90,25 +90,70 @@ __device__ __forceinline__ MFv phase_vocode_bin_fast( float re, float im, float 
 	}
 
 // phase_vocoder.cpp:57-59:  phase_buffer += term; if( phase_buffer > pi2 ) phase_buffer = fmod( phase_buffer, pi2 ).
-// fmod is exact; for ph < 1e6 the quotient is < 2^18, q*pi2 (24-bit constant) is exact in double and so is the
-// difference, so floor + fma + one correction reproduces it without a division.  Branch-free; the caller redoes the
-// frame through fold_phase_slow() if any phase reaches 1e6.
+// fmod is exact; with P = pi2 * 2^j (exactly representable: pi2 is a 24-bit constant) and ph < 2^29 P the quotient
+// q = floor(ph/P) is below 2^29, q*P is exact in double and so is ph - q*P (fma), so floor + fma + one correction
+// reproduces fmod( ph, P ) without a division.  fold_phase_fast is the single stage j = 0 (ph < 3e9, i.e. every
+// phase a real PV produces); fold_phase_any chains stages for arbitrarily large ph.  NaN stays NaN, +inf becomes NaN
+// (as fmod does).
+__device__ __forceinline__ double fold_stage( double ph, double P, double rP )
+	{
+	const double q = __builtin_floor( ph * rP );
+	double r = __builtin_fma( -q, P, ph );
+	r = ( r < 0.0 ) ? r + P : r;
+	r = ( r >= P ) ? r - P : r;
+	return r;
+	}
 __device__ __forceinline__ double fold_phase_fast( double ph )
 	{
-	const double q = __builtin_floor( ph * ( 1.0 / FLANHIP_PI2_D ) );
-	double r = __builtin_fma( -q, FLANHIP_PI2_D, ph );
-	r = ( r < 0.0 ) ? r + FLANHIP_PI2_D : r;
-	r = ( r >= FLANHIP_PI2_D ) ? r - FLANHIP_PI2_D : r;
+	const double r = fold_stage( ph, FLANHIP_PI2_D, 1.0 / FLANHIP_PI2_D );
 	return ( ph > FLANHIP_PI2_D ) ? r : ph;
 	}
-__device__ __forceinline__ double fold_phase_slow( double ph )
+#define FLANHIP_FOLD_FAST_LIMIT 3.0e9
+__device__ __noinline__ double fold_phase_any( double ph )
 	{
-	return ( ph > FLANHIP_PI2_D ) ? fmod( ph, FLANHIP_PI2_D ) : ph;
+	if( !( ph > FLANHIP_PI2_D ) ) return ph;
+	if( ph > 1.7e308 ) return __builtin_nan( "" );
+	int e; (void) frexp( ph, &e );
+	for( int j = ( ( e > 3 ? e - 3 : 0 ) / 28 ) * 28; j >= 0; j -= 28 )
+		{
+		const double P = ldexp( FLANHIP_PI2_D, j );
+		if( ph >= P ) ph = fold_stage( ph, P, 1.0 / P );
+		}
+	return ph;
 	}
 
-// sin and cos of a float angle for |x| < 8192 (the folded phase lives in [0, 2 pi]): Cody-Waite reduction by pi/2 in
-// three parts, minimax polynomials on [-pi/4, pi/4] (tools/fit_sincos.py: max abs error 7e-8).  Branch-free; larger
-// arguments are the caller's business (sincosf).
+// sin and cos of a float angle beyond the range of sincos_fast: the same polynomials after a Cody-Waite reduction
+// carried out in double (valid while the quotient is an exact double integer with room to spare: |x| < 2^45; a float
+// that large has an ulp of 4e6 radians).
+__device__ __noinline__ float2 sincos_wide( float x )
+	{
+	const double xd = double( x );
+	const double k = __builtin_rint( xd * 0.63661977236758134308 );
+	double r = __builtin_fma( -k, 1.57079632679489655800e+00, xd );
+	r = __builtin_fma( -k, 6.12323399573676603587e-17, r );
+	r = __builtin_fma( -k, -1.49738490485916983693e-33, r );
+	const float rf = float( r );
+	const int q = int( k - 4.0 * __builtin_floor( k * 0.25 ) );
+	const float r2 = rf * rf;
+	float sp = 0x1.6cd1e4p-19f;
+	sp = __builtin_fmaf( sp, r2, -0x1.a00f80p-13f );
+	sp = __builtin_fmaf( sp, r2, 0x1.111108p-7f );
+	sp = __builtin_fmaf( sp, r2, -0x1.555556p-3f );
+	const float sr = __builtin_fmaf( rf * r2, sp, rf );
+	float cp = 0x1.99eb7cp-16f;
+	cp = __builtin_fmaf( cp, r2, -0x1.6c0c34p-10f );
+	cp = __builtin_fmaf( cp, r2, 0x1.55554ap-5f );
+	cp = __builtin_fmaf( cp, r2, -0x1.000000p-1f );
+	const float cr = __builtin_fmaf( cp, r2, 1.0f );
+	const float ss = ( q & 1 ) ? cr : sr;
+	const float cc = ( q & 1 ) ? sr : cr;
+	return make_float2( ( q & 2 ) ? -ss : ss, ( ( q + 1 ) & 2 ) ? -cc : cc );
+	}
+#define FLANHIP_SINCOS_FAST_LIMIT 0x1p22f
+
+// sin and cos of a float angle for |x| < 2^22 (the folded phase lives in [0, 2 pi]): Cody-Waite reduction by pi/2 in
+// three parts, minimax polynomials on [-pi/4, pi/4] (tools/fit_sincos.py: max abs error 7e-8 up to 8192, and below the
+// argument's own ulp beyond).  Branch-free; larger arguments are the caller's business (sincos_wide).
 __device__ __forceinline__ void sincos_fast( float x, float & s, float & c )
 	{
 	const float k = __builtin_rintf( x * 0x1.45f306p-1f );                            // 2/pi
