@@ -1,0 +1,192 @@
+"""GPU parity (P4) of the PV frame processors through the C ABI: modify_time / stretch, modify_frequency / repitch, shape,
+mid-side, and the device-resident chain that config 3 uses.  The kernels keep the reference's fp32 operation order, so the
+expectation is bit-equality with the oracle; the assertion allows 1e-6 relative (1e-5 is the north-star tolerance)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+SR = 48000.0
+
+
+@pytest.fixture(scope="module")
+def fa():
+    import flan_amd
+    assert flan_amd.lib.flanhip_device_count() > 0
+    return flan_amd
+
+
+@pytest.fixture(scope="module")
+def pv_small():
+    x = O.noise(2, 30000, seed=77)
+    return O.analyze(x, SR, 1024, 256, 1024)          # (2, 118, 513, 2)
+
+
+def report(name, got, ref):
+    same = float(np.mean(got.view(np.uint32) == ref.view(np.uint32)))
+    d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    rel = float(np.sqrt(np.sum(d ** 2) / max(np.sum(ref.astype(np.float64) ** 2), 1e-300)))
+    print("\n[P4 %s] bit-identical=%.6f  rel l2=%.3e  max abs=%.3e" % (name, same, rel, d.max() if d.size else 0.0))
+    return same, rel
+
+
+def factor_grids(F, bins):
+    rng = np.random.default_rng(5)
+    yield "const2", np.full((F, bins), 2.0, np.float32)
+    yield "const0.5", np.full((F, bins), 0.5, np.float32)
+    yield "random", rng.uniform(0.4, 2.5, (F, bins)).astype(np.float32)
+    t = np.linspace(0, 1, F, dtype=np.float32)[:, None]
+    yield "ramp", (0.5 + 2.0 * t + 0 * np.zeros((1, bins), np.float32)).astype(np.float32)
+
+
+def test_stretch(fa, pv_small):
+    ch, F, bins, _ = pv_small.shape
+    for name, g in factor_grids(F, bins):
+        ref = O.stretch(pv_small, SR, 256, g)
+        mod = O.stretch_map(g, SR, 256)
+        got = fa.modify_time(pv_small, SR, 256, mod)
+        assert got.shape == ref.shape, name
+        same, rel = report("stretch/" + name, got, ref)
+        assert rel <= 1e-6
+
+
+def test_modify_time_non_monotone(fa, pv_small):
+    """time maps that run backwards and beyond the output range (PVModify.cpp:332-342 handles both)"""
+    ch, F, bins, _ = pv_small.shape
+    rng = np.random.default_rng(9)
+    hop_s = 256 / SR
+    mod = (rng.uniform(-3, F + 3, (F, bins)) * hop_s).astype(np.float32)
+    ref = O.modify_time(pv_small, SR, 256, mod)
+    got = fa.modify_time(pv_small, SR, 256, mod)
+    assert got.shape == ref.shape
+    same, rel = report("modify_time/random-map", got, ref)
+    assert rel <= 1e-6
+
+
+def test_repitch_and_modify_frequency(fa, pv_small):
+    ch, F, bins, _ = pv_small.shape
+    for name, g in factor_grids(F, bins):
+        mod_hz, inmod = O.repitch_map(pv_small, SR, g)
+        ref = O.modify_frequency(pv_small, SR, mod_hz, inmod)
+        got = fa.modify_frequency(pv_small, SR, mod_hz, inmod)
+        same, rel = report("repitch/" + name, got, ref)
+        assert rel <= 1e-6
+    # an upside-down map (PVModify.cpp:220 `forward` false)
+    mod_hz = np.ascontiguousarray(np.tile(np.linspace(24000, 0, bins, dtype=np.float32), (F, 1)))
+    inmod = (24000.0 - pv_small[..., 1]).astype(np.float32)
+    ref = O.modify_frequency(pv_small, SR, mod_hz, inmod)
+    got = fa.modify_frequency(pv_small, SR, mod_hz, inmod)
+    same, rel = report("modify_frequency/reversed", got, ref)
+    assert rel <= 1e-6
+
+
+@pytest.mark.parametrize("align", [False, True])
+def test_shape_affine(fa, pv_small, align):
+    for (a, b, c, d) in [(1.0, 0.0, 1.0, 100.0), (0.5, 0.0, 2.0, 0.0), (1.0, 0.1, 0.5, -50.0)]:
+        ref = O.shape_affine(pv_small, SR, a, b, c, d, align)
+        got = fa.shape_affine(pv_small, SR, a, b, c, d, align)
+        same, rel = report("shape a=%g b=%g c=%g d=%g align=%d" % (a, b, c, d, align), got, ref)
+        assert rel <= 1e-6
+
+
+def _dev(fa, arr):
+    p = ctypes.c_void_p()
+    fa.check(fa.lib.flanhip_malloc(ctypes.byref(p), arr.nbytes))
+    fa.check(fa.lib.flanhip_memcpy_h2d(p, arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes, None))
+    return p
+
+
+def _host(fa, p, shape, dtype=np.float32):
+    out = np.empty(shape, dtype)
+    fa.check(fa.lib.flanhip_memcpy_d2h(out.ctypes.data_as(ctypes.c_void_p), p, out.nbytes, None))
+    fa.check(fa.lib.flanhip_stream_synchronize(None))
+    return out
+
+
+def test_device_chain_config3_shape(fa):
+    """BASELINE config 3 in small, never leaving HBM: convert_to_PV -> stretch(lambda -> 2) -> convert_to_audio through the
+    _dev entry points, against the same chain in the oracle."""
+    ch, n, W, hop, dft = 2, 40000, 2048, 512, 2048
+    x = O.noise(ch, n, seed=1234)
+    F = O.num_pv_frames(n, hop)
+    bins = dft // 2 + 1
+    ar = np.float32(SR) / np.float32(hop)
+    # oracle
+    pv_r = O.analyze(x, SR, W, hop, dft)
+    two = np.full((F, bins), 2.0, np.float32)
+    st_r = O.stretch(pv_r, SR, hop, two)
+    out_r, _ = O.synthesize(st_r, SR, ar, W)
+    # device
+    lib = fa.lib
+    d_x = _dev(fa, x)
+    d_pv = ctypes.c_void_p(); fa.check(lib.flanhip_malloc(ctypes.byref(d_pv), ch * F * bins * 8))
+    fa.check(lib.flanhip_analyze_dev(d_x, ch, n, SR, W, hop, dft, d_pv, None))
+    d_grid = ctypes.c_void_p(); fa.check(lib.flanhip_malloc(ctypes.byref(d_grid), F * bins * 4))
+    fa.check(lib.flanhip_fill_dev(d_grid, F * bins, 2.0, None))
+    d_max = ctypes.c_void_p(); fa.check(lib.flanhip_malloc(ctypes.byref(d_max), 4))
+    fa.check(lib.flanhip_stretch_map_dev(d_grid, F, bins, SR, hop, d_max, None))
+    mx = _host(fa, d_max, (1,))[0]
+    Fo = int(np.int32(np.ceil(np.float32(mx) * np.float32(SR) / np.float32(hop))))
+    assert Fo == st_r.shape[1] == 2 * F                      # stretch(2) maps frame t -> 2(t+1)  
+    d_st = ctypes.c_void_p(); fa.check(lib.flanhip_malloc(ctypes.byref(d_st), ch * Fo * bins * 8))
+    fa.check(lib.flanhip_modify_time_dev(d_pv, ch, F, bins, SR, hop, d_grid, Fo, d_st, None))
+    ws_bytes = lib.flanhip_synthesize_workspace_bytes(ch, Fo, bins, SR, ar, W)
+    d_ws = ctypes.c_void_p(); fa.check(lib.flanhip_malloc(ctypes.byref(d_ws), ws_bytes))
+    d_out = ctypes.c_void_p(); fa.check(lib.flanhip_malloc(ctypes.byref(d_out), ch * Fo * hop * 4))
+    fa.check(lib.flanhip_synthesize_dev(d_st, ch, Fo, bins, SR, ar, W, d_out, d_ws, None, None))
+    out_g = _host(fa, d_out, (ch, Fo * hop))
+    st_g = _host(fa, d_st, (ch, Fo, bins, 2))
+    for p in (d_x, d_pv, d_grid, d_max, d_st, d_ws, d_out):
+        lib.flanhip_free(p)
+    # P4 on the stretched PV (inputs differ by the analysis rounding noise, so compare magnitudes in l2)
+    m_g, m_r = st_g[..., 0].astype(np.float64), st_r[..., 0].astype(np.float64)
+    rel_m = np.sqrt(np.sum((m_g - m_r) ** 2) / np.sum(m_r ** 2))
+    rms = float(np.sqrt(np.mean((out_g.astype(np.float64) - out_r.astype(np.float64)) ** 2)))
+    print("\n[config3-small] stretched rel_m=%.3e  composite audio rms diff=%.3e (signal rms %.3f)" % (rel_m, rms, np.sqrt(np.mean(out_r.astype(np.float64) ** 2))))
+    assert rel_m <= 1e-5
+    # composite of three stages on 0.8 s of noise: reported, loosely bounded (stage-wise parity is asserted elsewhere;
+    # the reference's own composite moves by ~1e-4 when only its FFT backend changes)
+    assert rms <= 1e-3
+
+
+def test_repitch_map_dev(fa, pv_small):
+    ch, F, bins, _ = pv_small.shape
+    rng = np.random.default_rng(3)
+    g = rng.uniform(0.5, 2.0, (F, bins)).astype(np.float32)
+    ref_map, ref_inmod = O.repitch_map(pv_small, SR, g)
+    d_pv = _dev(fa, pv_small); d_g = _dev(fa, g)
+    d_in = ctypes.c_void_p(); fa.check(fa.lib.flanhip_malloc(ctypes.byref(d_in), ch * F * bins * 4))
+    fa.check(fa.lib.flanhip_repitch_map_dev(d_pv, ch, F, bins, SR, d_g, d_in, None))
+    got_map = _host(fa, d_g, (F, bins)); got_in = _host(fa, d_in, (ch, F, bins))
+    for p in (d_pv, d_g, d_in):
+        fa.lib.flanhip_free(p)
+    s1, r1 = report("repitch_map grid", got_map, ref_map)
+    s2, r2 = report("repitch_map in_modified", got_in, ref_inmod)
+    assert r1 <= 1e-6 and r2 <= 1e-6
+
+
+def test_mid_side_and_noise(fa):
+    n = 100003
+    x = O.noise(2, n, seed=42)
+    d_x = _dev(fa, x)
+    d_o = ctypes.c_void_p(); fa.check(fa.lib.flanhip_malloc(ctypes.byref(d_o), x.nbytes))
+    fa.check(fa.lib.flanhip_mid_side_dev(d_x, n, d_o, None))
+    got = _host(fa, d_o, (2, n))
+    ref = O.mid_side(x)
+    same, rel = report("mid_side", got, ref)
+    assert rel <= 1e-7
+    # the device noise generator produces the oracle's bits exactly (integer hash)
+    fa.check(fa.lib.flanhip_noise_dev(d_o, 2, n, 42, None))
+    got = _host(fa, d_o, (2, n))
+    assert np.array_equal(got.view(np.uint32), x.view(np.uint32))
+    # sum-of-squares helper
+    d_r = ctypes.c_void_p(); fa.check(fa.lib.flanhip_malloc(ctypes.byref(d_r), 16))
+    fa.check(fa.lib.flanhip_sqdiff_dev(d_x, d_o, 2 * n, d_r, None))
+    r = _host(fa, d_r, (2,), np.float64)
+    assert r[0] == 0.0 and r[1] == pytest.approx(float(np.sum(x.astype(np.float64) ** 2)), rel=1e-12)
+    for p in (d_x, d_o, d_r):
+        fa.lib.flanhip_free(p)
