@@ -1,0 +1,89 @@
+// AudioBuffer.cpp -- host/device mirrored audio container (reference: src/flan/Audio/AudioBuffer.cpp:17-29,479-482).
+#include "flan/AudioBuffer.h"
+
+#include <algorithm>
+#include <utility>
+
+#include "device_block.h"
+
+namespace flan {
+
+AudioBuffer::AudioBuffer() : format(), buffer() {}
+
+AudioBuffer::AudioBuffer( const Format & other ) : format( other ), buffer( count() ) {}
+
+AudioBuffer::AudioBuffer( std::vector<float> && temp_buffer, Channel num_channels, FrameRate sr )
+	: format(), buffer( std::move( temp_buffer ) )
+	{
+	format.num_channels = num_channels;
+	format.num_frames = num_channels > 0 ? Frame( buffer.size() / num_channels ) : 0;   // AudioBuffer.cpp:22
+	format.sample_rate = sr;
+	}
+
+AudioBuffer AudioBuffer::adopt_device( const Format & f, std::shared_ptr<detail::DeviceBlock> block )
+	{
+	AudioBuffer out;
+	out.format = f;
+	out.dev = std::move( block );
+	out.host_valid = false;
+	return out;
+	}
+
+AudioBuffer AudioBuffer::copy() const
+	{
+	AudioBuffer out;
+	out.format = format;
+	out.buffer = get_buffer();   // deep copy of the samples
+	return out;
+	}
+
+bool AudioBuffer::is_null() const { return count() == 0 || ( host_valid && buffer.empty() && !dev ) || format.sample_rate == 0; }
+
+void AudioBuffer::clear_buffer()
+	{
+	buffer.assign( count(), 0.0f );
+	host_valid = true;
+	dev.reset();
+	}
+
+const std::vector<float> & AudioBuffer::get_buffer() const
+	{
+	if( !host_valid )
+		{
+		buffer.resize( count() );
+		if( dev && count() )
+			{
+			detail::report( flanhip_memcpy_d2h( buffer.data(), dev->ptr, sizeof( float ) * count(), nullptr ), "download of audio" );
+			detail::report( flanhip_stream_synchronize( nullptr ), "synchronise" );
+			}
+		host_valid = true;
+		}
+	return buffer;
+	}
+
+std::vector<float> & AudioBuffer::get_buffer()
+	{
+	std::as_const( *this ).get_buffer();
+	dev.reset();                       // the caller may write: the host copy is the truth from here on
+	return buffer;
+	}
+
+Sample AudioBuffer::get_sample( Channel c, Frame f ) const { return get_buffer()[get_buffer_pos( c, f )]; }
+Sample & AudioBuffer::get_sample( Channel c, Frame f ) { return get_buffer()[get_buffer_pos( c, f )]; }
+void AudioBuffer::set_sample( Channel c, Frame f, Sample s ) { get_buffer()[get_buffer_pos( c, f )] = s; }
+
+const float * AudioBuffer::device_data() const
+	{
+	if( !dev )
+		{
+		if( count() == 0 ) return nullptr;
+		auto block = detail::DeviceBlock::allocate( sizeof( float ) * count() );
+		if( !block ) return nullptr;
+		if( !detail::report( flanhip_memcpy_h2d( block->ptr, buffer.data(), sizeof( float ) * count(), nullptr ), "upload of audio" ) ) return nullptr;
+		flanhip_stream_synchronize( nullptr );
+		dev = std::move( block );
+		}
+	return static_cast<const float*>( dev->ptr );
+	}
+
+} // namespace flan

@@ -1,0 +1,218 @@
+// PV.cpp -- conversions and frame processors of flan::PV over the C ABI
+// (reference: Conversions/AudioPV.cpp:86-145, PV/PVModify.cpp:196-385, PV/PV.cpp:421-458).
+#include "flan/PV.h"
+
+#include <cmath>
+#include <iostream>
+
+#include "device_block.h"
+#include "flan/Audio.h"
+
+namespace flan {
+
+namespace {
+using detail::DeviceBlock;
+
+std::shared_ptr<DeviceBlock> upload( const void * host, size_t bytes )
+	{
+	auto b = DeviceBlock::allocate( bytes );
+	if( !b ) return nullptr;
+	if( !detail::report( flanhip_memcpy_h2d( b->ptr, host, bytes, nullptr ), "upload" ) ) return nullptr;
+	return b;
+	}
+
+// the sampled factor / map grid of a Function on the device: constants are filled in place, callables are sampled on the host
+template<typename T>
+std::shared_ptr<DeviceBlock> grid_to_device( const FunctionSample2d<T> & s )
+	{
+	static_assert( sizeof( T ) == sizeof( float ), "float grids only" );
+	if( s.is_constant() )
+		{
+		auto b = DeviceBlock::allocate( sizeof( float ) * s.size() );
+		if( !b ) return nullptr;
+		if( !detail::report( flanhip_fill_dev( static_cast<float*>( b->ptr ), int64_t( s.size() ), float( s.get_constant() ), nullptr ), "fill" ) ) return nullptr;
+		return b;
+		}
+	return upload( s.get_vector().data(), sizeof( float ) * s.size() );
+	}
+}
+
+PV::PV() : PVBuffer( PVBuffer::Format() ) {}
+PV::PV( PVBuffer && other ) : PVBuffer( std::move( other ) ) {}
+PV PV::create_null() { return PVBuffer(); }
+PV PV::create_from_format( const PVBuffer::Format & f ) { return PVBuffer( f ); }
+PV PV::load_from_file( const std::string & filename ) { return PVBuffer( filename ); }
+PV PV::copy() const { return PVBuffer::copy(); }
+
+Audio PV::convert_to_audio( flan_CANCEL_ARG_CPP ) const
+	{
+	if( is_null() ) return Audio::create_null();
+	if( canceller ) return Audio::create_null();               // flan_CANCEL_POINT, AudioPV.cpp:115
+	AudioBuffer::Format af;                                    // AudioPV.cpp:91-94
+	af.num_channels = get_num_channels();
+	af.num_frames = get_num_frames() * get_hop_size();
+	af.sample_rate = get_sample_rate();
+	if( get_hop_size() < 1 ) return Audio::create_null();
+
+	const MF * d_pv = device_data();
+	if( !d_pv ) return Audio::create_null();
+	const size_t ws_bytes = flanhip_synthesize_workspace_bytes( get_num_channels(), get_num_frames(), get_num_bins(), get_sample_rate(), get_analysis_rate(), get_window_size() );
+	if( ws_bytes == 0 ) { detail::report( FLANHIP_ERR_UNSUPPORTED, "convert_to_audio (unsupported dft / window)" ); return Audio::create_null(); }
+	auto out = DeviceBlock::allocate( sizeof( float ) * size_t( af.num_channels ) * af.num_frames );
+	auto ws = DeviceBlock::allocate( ws_bytes );
+	auto flag = DeviceBlock::allocate( sizeof( int ) );
+	if( !out || !ws || !flag ) return Audio::create_null();
+	flanhip_memset( flag->ptr, 0, sizeof( int ), nullptr );
+	if( canceller ) return Audio::create_null();
+	if( !detail::report( flanhip_synthesize_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(),
+			get_sample_rate(), get_analysis_rate(), get_window_size(), static_cast<float*>( out->ptr ), ws->ptr, static_cast<int*>( flag->ptr ), nullptr ),
+			"convert_to_audio" ) ) return Audio::create_null();
+	int nan_flag = 0;
+	flanhip_memcpy_d2h( &nan_flag, flag->ptr, sizeof( int ), nullptr );
+	if( !detail::report( flanhip_stream_synchronize( nullptr ), "convert_to_audio" ) ) return Audio::create_null();
+	if( nan_flag )                                             // AudioPV.cpp:88-89
+		std::cout << "flan::convert_to_audio recieved a nan or infinite value. This often happens when dividing by zero in an earlier algorithm.";
+	if( canceller ) return Audio::create_null();
+	return AudioBuffer::adopt_device( af, std::move( out ) );
+	}
+
+Audio PV::convertToAudio( flan_CANCEL_ARG_CPP ) const { return convert_to_audio( canceller ); }
+
+Audio PV::convert_to_lr_audio( flan_CANCEL_ARG_CPP ) const
+	{
+	if( get_num_channels() != 2 ) return Audio::create_null(); // AudioPV.cpp:143
+	return convert_to_audio( canceller ).convert_to_left_right();
+	}
+
+// modify_time_base, PVModify.cpp:307-362
+static PV modify_time_device( const PV & me, std::shared_ptr<DeviceBlock> d_mod, float max_seconds )
+	{
+	const float last_output_frame = std::ceil( me.time_to_frame( max_seconds ) );    // :312
+	PVBuffer::Format f = me.get_format();
+	f.num_frames = Frame( last_output_frame );                                     // :315
+	if( f.num_frames <= 0 ) return PV();
+	const MF * d_pv = me.device_data();
+	auto out = DeviceBlock::allocate( sizeof( MF ) * size_t( f.num_channels ) * f.num_frames * f.num_bins );
+	if( !d_pv || !out ) return PV();
+	if( !detail::report( flanhip_modify_time_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), me.get_num_channels(), me.get_num_frames(), me.get_num_bins(),
+			me.get_sample_rate(), me.get_hop_size(), static_cast<const float*>( d_mod->ptr ), f.num_frames, static_cast<flanhip_MF*>( out->ptr ), nullptr ),
+			"modify_time" ) ) return PV();
+	if( !detail::report( flanhip_stream_synchronize( nullptr ), "modify_time" ) ) return PV();
+	return PVBuffer::adopt_device( f, std::move( out ) );
+	}
+
+PV PV::modify_time( const Function<TF, Second> & mod, const Interpolator & interp ) const
+	{
+	if( is_null() ) return PV();
+	if( !interp.is_linear() ) { std::cerr << "flan: only Interpolator::linear() runs on the device path" << std::endl; return PV(); }
+	const auto sampled = sample_function_over_domain( mod );                       // PVModify.cpp:367
+	float mx;
+	if( sampled.is_constant() ) mx = sampled.get_constant();
+	else mx = *std::max_element( sampled.get_vector().begin(), sampled.get_vector().end() );   // FunctionSample::maximum
+	auto d_mod = grid_to_device( sampled );
+	if( !d_mod ) return PV();
+	return modify_time_device( *this, std::move( d_mod ), mx );
+	}
+
+PV PV::stretch( const Function<TF, float> & factor, const Interpolator & interp ) const
+	{
+	if( is_null() ) return PV();
+	if( !interp.is_linear() ) { std::cerr << "flan: only Interpolator::linear() runs on the device path" << std::endl; return PV(); }
+	auto d_grid = grid_to_device( sample_function_over_domain( factor ) );         // PVModify.cpp:373
+	auto d_max = DeviceBlock::allocate( sizeof( float ) );
+	if( !d_grid || !d_max ) return PV();
+	// :376-382 running sum over frames per bin, frame_to_time -- on the device, plus the maximum modify_time_base needs
+	if( !detail::report( flanhip_stretch_map_dev( static_cast<float*>( d_grid->ptr ), get_num_frames(), get_num_bins(), get_sample_rate(), get_hop_size(),
+			static_cast<float*>( d_max->ptr ), nullptr ), "stretch" ) ) return PV();
+	float mx = 0.0f;
+	flanhip_memcpy_d2h( &mx, d_max->ptr, sizeof( float ), nullptr );
+	if( !detail::report( flanhip_stream_synchronize( nullptr ), "stretch" ) ) return PV();
+	return modify_time_device( *this, std::move( d_grid ), mx );
+	}
+
+// modify_frequency_base, PVModify.cpp:196-257
+static PV modify_frequency_device( const PV & me, const DeviceBlock & d_mod, const DeviceBlock & d_in_modified )
+	{
+	const MF * d_pv = me.device_data();
+	const size_t n = size_t( me.get_num_channels() ) * me.get_num_frames() * me.get_num_bins();
+	auto out = DeviceBlock::allocate( sizeof( MF ) * n );
+	if( !d_pv || !out ) return PV();
+	if( !detail::report( flanhip_modify_frequency_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), me.get_num_channels(), me.get_num_frames(), me.get_num_bins(),
+			me.get_sample_rate(), static_cast<const float*>( d_mod.ptr ), static_cast<const float*>( d_in_modified.ptr ), static_cast<flanhip_MF*>( out->ptr ), nullptr ),
+			"modify_frequency" ) ) return PV();
+	if( !detail::report( flanhip_stream_synchronize( nullptr ), "modify_frequency" ) ) return PV();
+	return PVBuffer::adopt_device( me.get_format(), std::move( out ) );
+	}
+
+PV PV::modify_frequency( const Function<TF, Frequency> & mod, const Interpolator & interp ) const
+	{
+	if( is_null() ) return PV();
+	if( !interp.is_linear() ) { std::cerr << "flan: only Interpolator::linear() runs on the device path" << std::endl; return PV(); }
+	auto d_mod = grid_to_device( sample_function_over_domain( mod ) );             // PVModify.cpp:261
+	if( !d_mod ) return PV();
+	// :263-268: the callable is evaluated at every MF's own (time, frequency): data dependent, so on the host
+	const std::vector<MF> & data = get_buffer();
+	std::vector<float> in_modified( data.size() );
+	const size_t per_channel = size_t( get_num_frames() ) * get_num_bins();
+	detail::for_each_index( 0, int( size_t( get_num_channels() ) * get_num_frames() ), mod.get_execution_policy(), [&]( int row )
+		{
+		const Frame frame = Frame( row % get_num_frames() );
+		const size_t base = size_t( row ) * get_num_bins();
+		for( Bin bin = 0; bin < get_num_bins(); ++bin )
+			in_modified[base + bin] = mod( TF{ frame_to_time( fFrame( frame ) ), data[base + bin].f } );
+		} );
+	(void) per_channel;
+	auto d_in = upload( in_modified.data(), sizeof( float ) * in_modified.size() );
+	if( !d_in ) return PV();
+	return modify_frequency_device( *this, *d_mod, *d_in );
+	}
+
+PV PV::repitch( const Function<TF, float> & factor, const Interpolator & interp ) const
+	{
+	if( is_null() ) return PV();
+	if( !interp.is_linear() ) { std::cerr << "flan: only Interpolator::linear() runs on the device path" << std::endl; return PV(); }
+	auto d_grid = grid_to_device( sample_function_over_domain( factor ) );         // PVModify.cpp:275
+	const size_t n = size_t( get_num_channels() ) * get_num_frames() * get_num_bins();
+	auto d_in = DeviceBlock::allocate( sizeof( float ) * n );
+	const MF * d_pv = device_data();
+	if( !d_grid || !d_in || !d_pv ) return PV();
+	// :278-302 running sum over bins, bin_to_frequency, per-MF lerp -- on the device
+	if( !detail::report( flanhip_repitch_map_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(), get_sample_rate(),
+			static_cast<float*>( d_grid->ptr ), static_cast<float*>( d_in->ptr ), nullptr ), "repitch" ) ) return PV();
+	return modify_frequency_device( *this, *d_grid, *d_in );
+	}
+
+PV PV::shape( const Function<MF, MF> & shaper, bool use_shift_alignment ) const
+	{
+	if( is_null() ) return PV();
+	// PV.cpp:435-436: the shaper sees every MF: evaluated on the host, the placement rule runs on the device
+	const std::vector<MF> & data = get_buffer();
+	std::vector<MF> shaped( data.size() );
+	detail::for_each_index( 0, int( size_t( get_num_channels() ) * get_num_frames() ), shaper.get_execution_policy(), [&]( int row )
+		{
+		const size_t base = size_t( row ) * get_num_bins();
+		for( Bin bin = 0; bin < get_num_bins(); ++bin ) shaped[base + bin] = shaper( data[base + bin] );
+		} );
+	auto d_shaped = upload( shaped.data(), sizeof( MF ) * shaped.size() );
+	const MF * d_pv = device_data();
+	auto out = DeviceBlock::allocate( sizeof( MF ) * shaped.size() );
+	if( !d_shaped || !d_pv || !out ) return PV();
+	if( !detail::report( flanhip_shape_table_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), static_cast<const flanhip_MF*>( d_shaped->ptr ), get_num_channels(),
+			get_num_frames(), get_num_bins(), get_sample_rate(), use_shift_alignment ? 1 : 0, static_cast<flanhip_MF*>( out->ptr ), nullptr ), "shape" ) ) return PV();
+	if( !detail::report( flanhip_stream_synchronize( nullptr ), "shape" ) ) return PV();
+	return PVBuffer::adopt_device( get_format(), std::move( out ) );
+	}
+
+PV PV::shape_affine( float a, float b, float c, float d, bool use_shift_alignment ) const
+	{
+	if( is_null() ) return PV();
+	const MF * d_pv = device_data();
+	auto out = DeviceBlock::allocate( sizeof( MF ) * size_t( get_num_channels() ) * get_num_frames() * get_num_bins() );
+	if( !d_pv || !out ) return PV();
+	if( !detail::report( flanhip_shape_affine_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(), get_sample_rate(),
+			a, b, c, d, use_shift_alignment ? 1 : 0, static_cast<flanhip_MF*>( out->ptr ), nullptr ), "shape_affine" ) ) return PV();
+	if( !detail::report( flanhip_stream_synchronize( nullptr ), "shape_affine" ) ) return PV();
+	return PVBuffer::adopt_device( get_format(), std::move( out ) );
+	}
+
+} // namespace flan

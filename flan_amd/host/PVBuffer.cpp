@@ -1,0 +1,184 @@
+// PVBuffer.cpp -- host/device mirrored PV container and the .flan file format
+// (reference: src/flan/PV/PVBuffer.cpp:19-50 constructors / null / NaN scan, :99-140 save, :216-273 load,
+//  src/flan/Utility/Bytes.cpp:70-118 writeRIFF).
+#include "flan/PVBuffer.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <utility>
+
+#include "device_block.h"
+
+namespace flan {
+
+PVBuffer::PVBuffer() : format(), buffer() {}
+PVBuffer::PVBuffer( const Format & other ) : format( other ), buffer( count() ) {}
+PVBuffer::PVBuffer( const std::string & filename ) : format(), buffer() { load( filename ); }
+
+PVBuffer PVBuffer::adopt_device( const Format & f, std::shared_ptr<detail::DeviceBlock> block )
+	{
+	PVBuffer out;
+	out.format = f;
+	out.dev = std::move( block );
+	out.host_valid = false;
+	return out;
+	}
+
+PVBuffer PVBuffer::copy() const
+	{
+	PVBuffer out;
+	out.format = format;
+	out.buffer = get_buffer();
+	return out;
+	}
+
+bool PVBuffer::is_null() const { return count() == 0 || ( host_valid && buffer.empty() && !dev ) || format.sample_rate == 0; }
+
+bool PVBuffer::is_nan_or_inf() const
+	{
+	for( const MF & mf : get_buffer() )
+		if( std::isnan( mf.m ) || std::isnan( mf.f ) || std::isinf( mf.m ) || std::isinf( mf.f ) ) return true;
+	return false;
+	}
+
+void PVBuffer::clear_buffer()
+	{
+	buffer.assign( count(), MF{ 0.0f, 0.0f } );
+	host_valid = true;
+	dev.reset();
+	}
+
+const std::vector<MF> & PVBuffer::get_buffer() const
+	{
+	if( !host_valid )
+		{
+		buffer.resize( count() );
+		if( dev && count() )
+			{
+			detail::report( flanhip_memcpy_d2h( buffer.data(), dev->ptr, sizeof( MF ) * count(), nullptr ), "download of PV" );
+			detail::report( flanhip_stream_synchronize( nullptr ), "synchronise" );
+			}
+		host_valid = true;
+		}
+	return buffer;
+	}
+
+std::vector<MF> & PVBuffer::get_buffer()
+	{
+	std::as_const( *this ).get_buffer();
+	dev.reset();
+	return buffer;
+	}
+
+MF PVBuffer::get_MF( Channel c, Frame f, Bin b ) const { return get_buffer()[get_buffer_pos( c, f, b )]; }
+MF & PVBuffer::get_MF( Channel c, Frame f, Bin b ) { return get_buffer()[get_buffer_pos( c, f, b )]; }
+
+const MF * PVBuffer::device_data() const
+	{
+	if( !dev )
+		{
+		if( count() == 0 ) return nullptr;
+		auto block = detail::DeviceBlock::allocate( sizeof( MF ) * count() );
+		if( !block ) return nullptr;
+		if( !detail::report( flanhip_memcpy_h2d( block->ptr, buffer.data(), sizeof( MF ) * count(), nullptr ), "upload of PV" ) ) return nullptr;
+		flanhip_stream_synchronize( nullptr );
+		dev = std::move( block );
+		}
+	return static_cast<const MF*>( dev->ptr );
+	}
+
+// ---- .flan files ---------------------------------------------------------------------------------------------------
+namespace {
+void put16( std::vector<uint8_t> & v, uint16_t x ) { v.push_back( x & 0xFF ); v.push_back( x >> 8 ); }
+void put32( std::vector<uint8_t> & v, uint32_t x ) { for( int i = 0; i < 4; ++i ) v.push_back( ( x >> ( 8 * i ) ) & 0xFF ); }
+void putTag( std::vector<uint8_t> & v, const char * t ) { for( int i = 0; i < 4; ++i ) v.push_back( uint8_t( t[i] ) ); }
+}
+
+bool PVBuffer::save( const std::string & filename ) const
+	{
+	const std::vector<MF> & data = get_buffer();
+	const double limit = std::pow( 2, 8 * 3 - 1 );                               // PVBuffer.cpp:101-102
+	const float window_size_f = float( get_dft_size() );                        // :103
+	const float max_frequency_f = get_sample_rate();                            // :104
+
+	std::vector<uint8_t> bytes( data.size() * 6 );
+	for( size_t i = 0; i < data.size(); ++i )                                    // :108-125 (same order: channel, frame, bin)
+		{
+		const int32_t m_32 = int32_t( double( std::clamp( data[i].m / window_size_f, -1.0f, 1.0f ) ) * limit );
+		const int32_t f_32 = int32_t( double( std::clamp( data[i].f / max_frequency_f, -1.0f, 1.0f ) ) * limit );
+		uint8_t * p = bytes.data() + i * 6;
+		p[0] = uint8_t( m_32 >> 0 ); p[1] = uint8_t( m_32 >> 8 ); p[2] = uint8_t( m_32 >> 16 );
+		p[3] = uint8_t( f_32 >> 0 ); p[4] = uint8_t( f_32 >> 8 ); p[5] = uint8_t( f_32 >> 16 );
+		}
+
+	// Bytes.cpp:70-118 writeRIFF( filename, "PV", ... ): RIFF chunk (size field is the constant 4), fmt chunk, data chunk
+	std::vector<uint8_t> head;
+	putTag( head, "RIFF" ); put32( head, 4 ); putTag( head, "PV\0\0" );
+	putTag( head, "fmt " ); put32( head, 2 + 2 + 4 * 6 + 2 );
+	put16( head, 1 );                                        // formatting
+	put16( head, uint16_t( get_num_channels() ) );
+	put32( head, uint32_t( get_num_frames() ) );
+	put32( head, uint32_t( get_num_bins() ) );
+	put32( head, uint32_t( get_sample_rate() ) );
+	put32( head, uint32_t( get_hop_size() ) );               // :134  (load() reads this field into analysis_rate, :245 -- reference asymmetry, kept)
+	put32( head, uint32_t( get_window_size() ) );
+	put32( head, 24 );
+	put16( head, 1 );                                        // window type: hann
+	putTag( head, "data" ); put32( head, uint32_t( bytes.size() ) );
+
+	std::ofstream file( filename, std::ios::binary );
+	if( !file ) { std::cout << "Error opening " + filename + " to write RIFF.\n"; return false; }
+	file.write( reinterpret_cast<const char*>( head.data() ), std::streamsize( head.size() ) );
+	file.write( reinterpret_cast<const char*>( bytes.data() ), std::streamsize( bytes.size() ) );
+	return true;
+	}
+
+bool PVBuffer::load( const std::string & filename )
+	{
+	auto bail = []( const std::string & s ) { std::cout << s << std::endl; return false; };
+	std::ifstream file( filename, std::ios::binary );
+	if( !file ) return bail( "Error opening " + filename + " to load PV." );
+
+	uint16_t u16 = 0; uint32_t u32 = 0; char tag[4];
+	file.read( tag, 4 ); if( std::strncmp( tag, "RIFF", 4 ) != 0 ) return bail( filename + " isn't a correctly formatted RIFF file.\n" );
+	file.read( tag, 4 );
+	file.read( tag, 4 ); if( std::strncmp( tag, "PV", 4 ) != 0 ) return bail( filename + " isn't a PV file.\n" );
+	Format fmt;
+	file.read( tag, 4 ); if( std::strncmp( tag, "fmt ", 4 ) != 0 ) return bail( filename + " isn't formatted correctly (\"fmt \" wasn't at the start of the format chunk).\n" );
+	file.read( reinterpret_cast<char*>( &u32 ), 4 );
+	file.read( reinterpret_cast<char*>( &u16 ), 2 ); if( u16 != 1 ) return bail( "Formatting must be 1 (signed int)." );
+	file.read( reinterpret_cast<char*>( &u16 ), 2 ); fmt.num_channels = u16;
+	file.read( reinterpret_cast<char*>( &u32 ), 4 ); fmt.num_frames = Frame( u32 );
+	file.read( reinterpret_cast<char*>( &u32 ), 4 ); fmt.num_bins = Bin( u32 );
+	file.read( reinterpret_cast<char*>( &u32 ), 4 ); fmt.sample_rate = FrameRate( u32 );
+	file.read( reinterpret_cast<char*>( &u32 ), 4 ); fmt.analysis_rate = FrameRate( u32 );   // PVBuffer.cpp:245 (the file holds the HOP here)
+	file.read( reinterpret_cast<char*>( &u32 ), 4 ); fmt.window_size = Frame( u32 );
+	file.read( reinterpret_cast<char*>( &u32 ), 4 ); if( u32 != 24 ) return bail( "Bit depth must be 24." );
+	file.read( reinterpret_cast<char*>( &u16 ), 2 ); if( u16 != 1 ) return bail( "PV window must be 1 (hann)." );
+	*this = PVBuffer( fmt );
+	file.read( tag, 4 ); if( std::strncmp( tag, "data", 4 ) != 0 ) return bail( filename + " isn't a correctly formatted PV file (\"data\" wasn't at the start of the data chunk).\n" );
+	file.read( reinterpret_cast<char*>( &u32 ), 4 );
+
+	const double limit = std::pow( 2, 23 );
+	const float window_size_f = float( get_dft_size() );
+	const float max_frequency_f = get_sample_rate();
+	auto get_float = [&]( float div )
+		{
+		int32_t i = 0;
+		file.read( reinterpret_cast<char*>( &i ), 3 );
+		if( i & 0x800000 ) i |= int32_t( 0xFF000000 );
+		return float( double( i ) / limit ) * div;
+		};
+	for( MF & mf : buffer )
+		{
+		const float m = get_float( window_size_f );
+		const float f = get_float( max_frequency_f );
+		mf = MF{ m, f };
+		}
+	return true;
+	}
+
+} // namespace flan

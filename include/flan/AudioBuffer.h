@@ -1,0 +1,67 @@
+// flan/AudioBuffer.h -- audio container (mirrors the reference's src/flan/Audio/AudioBuffer.h:20-39,138-228 and
+// AudioBuffer.cpp:17-29,479-482 for the parts the phase-vocoder path uses; no libsndfile I/O).
+//
+// Layout: float[channel][frame], channel-major.  Move-only, explicit copy(), like the reference.
+// MI355X addition: a buffer may live in HBM only.  Results of device algorithms stay on the device until host code asks
+// for the samples (get_buffer / get_sample), so convert_to_PV -> stretch -> convert_to_audio never crosses PCIe.
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "flan/defines.h"
+
+namespace flan {
+
+namespace detail { struct DeviceBlock; }
+
+class AudioBuffer
+	{
+public:
+	struct Format
+		{
+		Channel num_channels = 0;
+		Frame num_frames = 0;
+		FrameRate sample_rate = 48000;
+		};
+
+	AudioBuffer( const AudioBuffer & ) = delete;
+	AudioBuffer( AudioBuffer && ) = default;
+	AudioBuffer & operator=( const AudioBuffer & ) = delete;
+	AudioBuffer & operator=( AudioBuffer && ) = default;
+	~AudioBuffer() = default;
+
+	AudioBuffer();
+	explicit AudioBuffer( const Format & );                                     // zero-initialised samples (AudioBuffer.cpp:26-29)
+	AudioBuffer( std::vector<float> && buffer, Channel num_channels, FrameRate ); // AudioBuffer.cpp:17-24
+
+	AudioBuffer copy() const;
+	bool is_null() const;                                                         // empty buffer or sample_rate 0
+	void clear_buffer();
+
+	Format get_format() const { return format; }
+	Channel get_num_channels() const { return format.num_channels; }
+	Frame get_num_frames() const { return format.num_frames; }
+	FrameRate get_sample_rate() const { return format.sample_rate; }
+	Second get_length() const { return format.num_frames / format.sample_rate; }
+	size_t get_buffer_pos( Channel c, Frame f ) const { return size_t( c ) * format.num_frames + f; }   // AudioBuffer.cpp:479-482
+
+	Sample get_sample( Channel c, Frame f ) const;
+	Sample & get_sample( Channel c, Frame f );
+	void set_sample( Channel c, Frame f, Sample s );
+	const std::vector<float> & get_buffer() const;                               // downloads from HBM on first use
+	std::vector<float> & get_buffer();                                           // ... and drops the device copy (host now owns the truth)
+
+	// ---- device residency (MI355X) ----
+	bool is_device_resident() const { return bool( dev ); }
+	const float * device_data() const;                                           // uploads on first use; nullptr on failure
+	static AudioBuffer adopt_device( const Format &, std::shared_ptr<detail::DeviceBlock> );
+
+protected:
+	size_t count() const { return size_t( format.num_channels ) * size_t( format.num_frames ); }
+	Format format;
+	mutable std::vector<float> buffer;
+	mutable bool host_valid = true;
+	mutable std::shared_ptr<detail::DeviceBlock> dev;
+	};
+
+} // namespace flan

@@ -1,0 +1,122 @@
+// flan/Function.h -- the callback type of the PV frame processors (mirrors the reference's src/flan/Function.h:35-265 and
+// FunctionSample.h:18-199 for the parts the phase-vocoder path uses).
+//
+// A Function<I,O> is either a constant O or a std::function<O(I)>, plus the execution policy the user allows for
+// evaluating it.  Device kernels cannot call back into host code, so the PV methods sample a Function on the host over the
+// (frame, bin) grid (Function.h:155-171) and upload the grid; a CONSTANT never touches the host (the grid is filled on the
+// device).  Note a reference quirk we do not reproduce: there a constant Function breaks stretch/repitch (the in-place
+// prefix sum doubles the single shared constant each step, FunctionSample.h:186-190 with PVModify.cpp:278-280,376-378);
+// here a constant c behaves exactly like the callable `[](TF){ return c; }`.
+#pragma once
+#include <algorithm>
+#include <functional>
+#include <thread>
+#include <type_traits>
+#include <variant>
+#include <vector>
+
+#include "flan/defines.h"
+
+namespace flan {
+
+namespace detail {
+// Parallel policies: split the outer index range over the host cores; sequential policies: a plain loop.
+template<typename F>
+void for_each_index( int begin, int end, ExecutionPolicy policy, const F & body )
+	{
+	const int n = end - begin;
+	const bool parallel = policy == ExecutionPolicy::Parallel_Sequenced || policy == ExecutionPolicy::Parallel_Unsequenced;
+	const int workers = parallel ? std::max( 1, std::min<int>( std::thread::hardware_concurrency(), n / 64 ) ) : 1;
+	if( workers <= 1 ) { for( int i = begin; i < end; ++i ) body( i ); return; }
+	std::vector<std::thread> pool;
+	for( int w = 0; w < workers; ++w )
+		pool.emplace_back( [=, &body]{ for( int i = begin + w; i < end; i += workers ) body( i ); } );
+	for( auto & t : pool ) t.join();
+	}
+}
+
+// FunctionSample.h:173-199: a sampled function, either one constant or a grid [big][small]
+template<typename O>
+struct FunctionSample2d
+	{
+	std::variant<O, std::vector<O>> value;
+	size_t count;
+	size_t small_dim_size;
+	bool is_constant() const { return std::holds_alternative<O>( value ); }
+	const O & get_constant() const { return std::get<O>( value ); }
+	std::vector<O> & get_vector() { return std::get<std::vector<O>>( value ); }
+	const std::vector<O> & get_vector() const { return std::get<std::vector<O>>( value ); }
+	size_t size() const { return count; }
+	O at( Frame f, Bin b ) const { return is_constant() ? get_constant() : get_vector()[size_t( f ) * small_dim_size + b]; }
+	};
+
+template<typename I, typename O>
+struct Function
+	{
+	using StdFuncType = std::function<O( I )>;
+	using ReturnType = O;
+	using ArgType = I;
+
+	Function( const Function & ) = delete;
+	Function & operator=( const Function & ) = delete;
+	Function( Function && ) = default;
+	Function & operator=( Function && ) = default;
+
+	template<typename T, std::enable_if_t<std::is_convertible_v<T, O> && !std::is_convertible_v<T, StdFuncType>, int> = 0>
+	Function( T t0 ) : f( static_cast<O>( t0 ) ), execution_policy( ExecutionPolicy::Parallel_Unsequenced ) {}
+
+	template<typename T, std::enable_if_t<std::is_convertible_v<T, StdFuncType>, int> = 0>
+	Function( T && f_, ExecutionPolicy policy = ExecutionPolicy::Parallel_Unsequenced )
+		: f( StdFuncType( std::forward<T>( f_ ) ) ), execution_policy( policy ) {}
+
+	Function copy() const
+		{
+		if( is_constant() ) return Function( std::get<O>( f ) );
+		return Function( std::get<StdFuncType>( f ), execution_policy );
+		}
+	bool is_constant() const { return std::holds_alternative<O>( f ); }
+	const O & get_constant() const { return std::get<O>( f ); }
+	ExecutionPolicy get_execution_policy() const { return execution_policy; }
+
+	O operator()( I t ) const { return is_constant() ? std::get<O>( f ) : std::get<StdFuncType>( f )( t ); }
+
+	// Function.h:155-171: sample on the grid x in [x_start, x_end), y in [y_start, y_end), argument ( x*x_scale, y*y_scale ),
+	// result laid out [x][y].  Only for I constructible from two floats (TF).
+	FunctionSample2d<O> sample( float x_start, float x_end, float x_scale, float y_start, float y_end, float y_scale ) const
+		{
+		const int x_size = int( std::ceil( x_end - x_start ) );
+		const int y_size = int( std::ceil( y_end - y_start ) );
+		if( is_constant() ) return FunctionSample2d<O>{ std::get<O>( f ), size_t( x_size ) * y_size, size_t( y_size ) };
+		std::vector<O> out( size_t( x_size ) * y_size );
+		const StdFuncType & fn = std::get<StdFuncType>( f );
+		detail::for_each_index( int( x_start ), int( x_end ), execution_policy, [&]( int x )
+			{
+			for( int y = int( y_start ); y < y_end; ++y )
+				out[size_t( x - int( x_start ) ) * y_size + ( y - int( y_start ) )] = fn( I{ x * x_scale, y * y_scale } );
+			} );
+		return FunctionSample2d<O>{ std::move( out ), size_t( x_size ) * y_size, size_t( y_size ) };
+		}
+
+private:
+	std::variant<O, StdFuncType> f;
+	ExecutionPolicy execution_policy;
+	};
+
+// Utility/Interpolator.h: a [0,1] -> [0,1] shaping function used when a frame (bin) pair is spread over the output.
+// The device kernels implement the reference's default, Interpolator::linear() (Utility/Interpolator.cpp:50-56); any
+// other interpolator makes the PV method return a null PV (documented limitation of this path).
+class Interpolator
+	{
+public:
+	static Interpolator linear() { return Interpolator( true, []( float x ){ return x; } ); }
+	template<typename T, std::enable_if_t<std::is_convertible_v<T, std::function<float( float )>>, int> = 0>
+	Interpolator( T && fn ) : linear_( false ), f_( std::forward<T>( fn ) ) {}
+	float operator()( float x ) const { return f_( x ); }
+	bool is_linear() const { return linear_; }
+private:
+	Interpolator( bool lin, std::function<float( float )> fn ) : linear_( lin ), f_( std::move( fn ) ) {}
+	bool linear_;
+	std::function<float( float )> f_;
+	};
+
+} // namespace flan

@@ -1,0 +1,84 @@
+// flan/PVBuffer.h -- phase-vocoder container (mirrors the reference's src/flan/PV/PVBuffer.h:27-52,135-288 and
+// PVBuffer.cpp:19-50,341-384,428-446,526-529).
+//
+// Layout: MF[channel][frame][bin].  Move-only, explicit copy().  Like AudioBuffer, the data may live in HBM only.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "flan/defines.h"
+
+namespace flan {
+
+namespace detail { struct DeviceBlock; }
+
+class PVBuffer
+	{
+public:
+	struct Format
+		{
+		Channel num_channels = 0;
+		Frame num_frames = 0;
+		Bin num_bins = 0;
+		FrameRate sample_rate = 48000;
+		FrameRate analysis_rate = 48000 / 128;
+		Frame window_size = 0;
+		};
+
+	PVBuffer( const PVBuffer & ) = delete;
+	PVBuffer( PVBuffer && ) = default;
+	PVBuffer & operator=( const PVBuffer & ) = delete;
+	PVBuffer & operator=( PVBuffer && ) = default;
+	~PVBuffer() = default;
+
+	PVBuffer();
+	explicit PVBuffer( const Format & );
+	explicit PVBuffer( const std::string & filename );                           // load(), PVBuffer.cpp:24-29
+
+	PVBuffer copy() const;
+	bool is_null() const;                                                        // PVBuffer.cpp:39-42
+	bool is_nan_or_inf() const;                                                  // PVBuffer.cpp:44-50
+	void clear_buffer();
+
+	// .flan RIFF files (PVBuffer.cpp:99-140 save, :216-273 load): 24-bit m / dft and f / sample_rate
+	bool save( const std::string & filename ) const;
+	bool load( const std::string & filename );
+
+	Format get_format() const { return format; }
+	Channel get_num_channels() const { return format.num_channels; }
+	Frame get_num_frames() const { return format.num_frames; }
+	Bin get_num_bins() const { return format.num_bins; }
+	FrameRate get_sample_rate() const { return format.sample_rate; }
+	FrameRate get_analysis_rate() const { return format.analysis_rate; }
+	Frame get_window_size() const { return format.window_size; }
+	Frame get_dft_size() const { return ( format.num_bins - 1 ) * 2; }                                   // PVBuffer.cpp:356-359
+	Frame get_hop_size() const { return Frame( format.sample_rate / format.analysis_rate ); }           // PVBuffer.cpp:381-384
+	Second get_length() const { return frame_to_time( fFrame( format.num_frames ) ); }
+	Frequency get_height() const { return bin_to_frequency( fBin( format.num_bins ) ); }
+	fFrame time_to_frame( Second t ) const { return t * float( get_sample_rate() ) / float( get_hop_size() ); }      // :428-431
+	Second frame_to_time( fFrame f ) const { return f / ( float( get_sample_rate() ) / float( get_hop_size() ) ); }  // :433-436
+	fBin frequency_to_bin( Frequency f ) const { return f / ( float( get_sample_rate() ) / float( get_dft_size() ) ); } // :438-441
+	Frequency bin_to_frequency( fBin b ) const { return b * float( get_sample_rate() ) / float( get_dft_size() ); }  // :443-446
+	size_t get_buffer_pos( Channel c, Frame f, Bin b ) const                                             // :526-529, 64-bit here
+		{ return ( size_t( c ) * format.num_frames + f ) * format.num_bins + b; }
+
+	MF get_MF( Channel c, Frame f, Bin b ) const;
+	MF & get_MF( Channel c, Frame f, Bin b );
+	const std::vector<MF> & get_buffer() const;
+	std::vector<MF> & get_buffer();
+
+	// ---- device residency (MI355X) ----
+	bool is_device_resident() const { return bool( dev ); }
+	const MF * device_data() const;
+	static PVBuffer adopt_device( const Format &, std::shared_ptr<detail::DeviceBlock> );
+
+protected:
+	size_t count() const { return size_t( format.num_channels ) * size_t( format.num_frames ) * size_t( format.num_bins ); }
+	Format format;
+	mutable std::vector<MF> buffer;
+	mutable bool host_valid = true;
+	mutable std::shared_ptr<detail::DeviceBlock> dev;
+	};
+
+} // namespace flan

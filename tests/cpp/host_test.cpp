@@ -1,0 +1,153 @@
+// host_test.cpp -- exercises the C++ drop-in surface (include/flan/*.h) the way a Flan user program does
+// (cf. the reference's tests/flanTest.cpp:32-47: load -> convert_to_PV -> repitch(lambda) -> convert_to_audio).
+//   host_test              full run, needs an MI355X
+//   host_test --no-device  what must hold without a GPU: null objects, no crash, no CPU fallback
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "flan/flan.h"
+#include "flanhip.h"
+
+using namespace flan;
+
+static int failures = 0;
+#define CHECK( cond ) do { if( !( cond ) ) { std::printf( "FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond ); ++failures; } } while( 0 )
+static bool close_to( double a, double b, double rel ) { return std::fabs( a - b ) <= rel * std::fabs( b ) + 1e-30; }
+
+static_assert( !std::is_copy_constructible_v<Audio> && std::is_move_constructible_v<Audio>, "Audio is move-only (AudioBuffer.h:23-27)" );
+static_assert( !std::is_copy_constructible_v<PV> && std::is_move_constructible_v<PV>, "PV is move-only (PVBuffer.h:30-34)" );
+static_assert( !std::is_copy_constructible_v<Function<TF, float>>, "Function is move-only (Function.h:42-46)" );
+
+static Audio sine( int n )
+	{
+	std::vector<float> x( n );
+	for( int i = 0; i < n; ++i ) x[i] = float( 0.5 * std::sin( 2.0 * 3.14159265358979323846 * 440.0 * i / 48000.0 ) );
+	return Audio::create_from_buffer( std::move( x ), 1, 48000.0f );
+	}
+
+static uint32_t hash32( uint32_t x ) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+static Audio noise( int ch, int n, uint32_t seed )
+	{
+	std::vector<float> x( size_t( ch ) * n );
+	for( int c = 0; c < ch; ++c ) for( int i = 0; i < n; ++i )
+		x[size_t( c ) * n + i] = float( hash32( hash32( seed ^ ( uint32_t( c ) * 0x9E3779B9U ) ) + uint32_t( i ) * 0x85EBCA6BU ) >> 8 ) * ( 1.0f / 8388608.0f ) - 1.0f;
+	return Audio::create_from_buffer( std::move( x ), ch, 48000.0f );
+	}
+
+static void no_device_checks()
+	{
+	CHECK( flanhip_device_count() == 0 );
+	Audio a = sine( 4800 );
+	CHECK( !a.is_null() && a.get_num_frames() == 4800 && a.get_num_channels() == 1 );
+	PV pv = a.convert_to_PV( 2048, 512, 2048 );       // no device: the path fails loudly and returns a null object
+	CHECK( pv.is_null() );
+	CHECK( std::strstr( flanhip_last_error(), "no HIP device" ) != nullptr );
+	CHECK( pv.convert_to_audio().is_null() );
+	CHECK( pv.stretch( 2.0f ).is_null() );
+	CHECK( Audio().convert_to_PV().is_null() );
+	// host-side pieces that need no device
+	CHECK( flanhip_num_pv_frames( 240000, 512 ) == 469 );
+	CHECK( flanhip_hop_size( 48000.0f, 93.75f ) == 512 );
+	PVBuffer::Format f; f.num_channels = 1; f.num_frames = 3; f.num_bins = 5; f.sample_rate = 48000; f.analysis_rate = 48000.0f / 512; f.window_size = 8;
+	PV p = PV::create_from_format( f );
+	CHECK( !p.is_null() && p.get_dft_size() == 8 && p.get_hop_size() == 512 );
+	CHECK( p.bin_to_frequency( 1 ) == 6000.0f && p.frequency_to_bin( 12000.0f ) == 2.0f );
+	CHECK( close_to( p.time_to_frame( 1.0f ), 93.75, 1e-7 ) );
+	p.get_MF( 0, 1, 2 ) = MF{ 3.0f, 440.0f };
+	const std::string path = "/tmp/flan_host_test.flan";
+	CHECK( p.save( path ) );
+	PV q = PV::load_from_file( path );
+	CHECK( q.get_num_frames() == 3 && q.get_num_bins() == 5 && q.get_window_size() == 8 );
+	CHECK( q.get_analysis_rate() == 512.0f );         // the reference's save/load asymmetry: the hop lands in analysis_rate (PVBuffer.cpp:134,245)
+	CHECK( close_to( q.get_MF( 0, 1, 2 ).m, 3.0, 1e-6 ) && close_to( q.get_MF( 0, 1, 2 ).f, 440.0, 1e-4 ) );
+	Function<TF, float> c( 2.0f );
+	CHECK( c.is_constant() && c( TF{ 0, 0 } ) == 2.0f );
+	Function<TF, float> l( []( TF tf ){ return tf.t + tf.f; } );
+	auto s = p.sample_function_over_domain( l );
+	CHECK( !s.is_constant() && s.size() == 15 && close_to( s.at( 2, 3 ), 2.0 / 93.75 + 18000.0, 1e-6 ) );
+	}
+
+static void device_checks()
+	{
+	CHECK( flanhip_device_count() >= 1 );
+	// ---- BASELINE config 1 + SURVEY 8c anchors through the class surface
+	Audio a = sine( 240000 );
+	PV pv = a.convert_to_PV( 2048, 512, 2048 );
+	CHECK( !pv.is_null() && pv.is_device_resident() );
+	CHECK( pv.get_num_channels() == 1 && pv.get_num_frames() == 469 && pv.get_num_bins() == 1025 );
+	CHECK( pv.get_window_size() == 2048 && pv.get_hop_size() == 512 && pv.get_dft_size() == 2048 && pv.get_analysis_rate() == 93.75f );
+	CHECK( close_to( pv.get_MF( 0, 100, 19 ).m, 247.517, 2e-5 ) && close_to( pv.get_MF( 0, 100, 19 ).f, 440.0, 2e-6 ) );
+	CHECK( close_to( pv.get_MF( 0, 0, 19 ).m, 126.01691, 2e-5 ) && close_to( pv.get_MF( 0, 0, 19 ).f, 489.28607, 2e-6 ) );
+	Audio back = pv.convert_to_audio();
+	CHECK( back.get_num_frames() == 240128 && back.get_sample_rate() == 48000.0f );
+	CHECK( close_to( back.get_sample( 0, 1000 ), 0.43333316, 1e-5 ) );
+	double e = 0; for( float v : back.get_buffer() ) e += double( v ) * v;
+	CHECK( close_to( e, 30006.053, 1e-5 ) );
+	CHECK( !a.convertToPV( 2048, 512, 2048 ).convertToAudio().is_null() );   // older spellings
+	// default arguments are the reference's: window 2048, hop 128, dft 4096 (Audio.h:158-163)
+	PV dflt = sine( 20000 ).convert_to_PV();
+	CHECK( dflt.get_num_bins() == 2049 && dflt.get_hop_size() == 128 && dflt.get_num_frames() == 20000 / 128 + 1 );
+
+	// ---- frame processors, chained on the device
+	Audio n2 = noise( 2, 60000, 1234 );
+	PV p2 = n2.convert_to_PV( 2048, 512, 2048 );
+	PV st_l = p2.stretch( []( TF ){ return 2.0f; } );
+	PV st_c = p2.stretch( 2.0f );                     // a constant behaves like the callable (not like the reference's doubling bug)
+	CHECK( st_l.get_num_frames() == 2 * p2.get_num_frames() && st_c.get_num_frames() == st_l.get_num_frames() );
+	CHECK( std::memcmp( st_l.get_buffer().data(), st_c.get_buffer().data(), sizeof( MF ) * st_l.get_buffer().size() ) == 0 );
+	Audio st_audio = st_l.convert_to_audio();
+	CHECK( st_audio.get_num_frames() == st_l.get_num_frames() * 512 );
+	PV rp = p2.repitch( []( TF ){ return 2.0f; } );
+	CHECK( rp.get_num_frames() == p2.get_num_frames() && !rp.is_null() );
+	PV mt = p2.modify_time( []( TF tf ){ return tf.t * 0.5f; } );
+	CHECK( !mt.is_null() && mt.get_num_frames() == Frame( std::ceil( p2.time_to_frame( 0.5f * ( p2.get_num_frames() - 1 ) / 93.75f ) ) ) );
+	PV mfq = p2.modify_frequency( []( TF tf ){ return tf.f * 1.5f; } );
+	CHECK( !mfq.is_null() );
+	PV sh_l = p2.shape( []( MF mf ){ return MF{ mf.m, mf.f + 100.0f }; } );
+	PV sh_a = p2.shape_affine( 1.0f, 0.0f, 1.0f, 100.0f );
+	CHECK( std::memcmp( sh_l.get_buffer().data(), sh_a.get_buffer().data(), sizeof( MF ) * sh_l.get_buffer().size() ) == 0 );
+	PV sh_al = p2.shape( []( MF mf ){ return MF{ mf.m, mf.f * 2.0f }; }, true );
+	PV sh_aa = p2.shape_affine( 1.0f, 0.0f, 2.0f, 0.0f, true );
+	CHECK( std::memcmp( sh_al.get_buffer().data(), sh_aa.get_buffer().data(), sizeof( MF ) * sh_al.get_buffer().size() ) == 0 );
+	CHECK( p2.stretch( 2.0f, Interpolator( []( float x ){ return x * x; } ) ).is_null() );   // non-linear interpolators are not on the device path
+
+	// ---- mid/side
+	PV ms = n2.convert_to_ms_PV( 2048, 512, 2048 );
+	CHECK( !ms.is_null() );
+	Audio lr = ms.convert_to_lr_audio();
+	CHECK( lr.get_num_channels() == 2 && !lr.is_null() );
+	CHECK( sine( 1000 ).convert_to_ms_PV().is_null() );                            // mono: null (AudioPV.cpp:82)
+	Audio m = n2.convert_to_mid_side();
+	CHECK( close_to( m.get_sample( 0, 10 ), ( n2.get_sample( 0, 10 ) + n2.get_sample( 1, 10 ) ) / std::sqrt( 2.0f ), 1e-6 ) );
+
+	// ---- error behaviour: null objects, never exceptions
+	CHECK( Audio().convert_to_PV().is_null() );
+	CHECK( a.convert_to_PV( 2048, 512, 3000 ).is_null() );                          // dft not a power of two
+	CHECK( a.convert_to_PV( 4096, 512, 2048 ).is_null() );                          // window larger than dft
+	CHECK( PV().convert_to_audio().is_null() );
+	std::atomic<bool> cancel( true );
+	CHECK( a.convert_to_PV( 2048, 512, 2048, cancel ).is_null() );                  // flan_CANCEL_POINT
+	CHECK( pv.convert_to_audio( cancel ).is_null() );
+	// NaN in the PV: warning on stdout, result still produced (AudioPV.cpp:88-89)
+	PV bad = p2.copy();
+	bad.get_MF( 0, 3, 7 ).f = std::nanf( "" );
+	CHECK( bad.is_nan_or_inf() && !bad.convert_to_audio().is_null() );
+	// host writes invalidate the device mirror
+	PV w = p2.copy();
+	w.get_MF( 0, 0, 0 ) = MF{ 1.0f, 2.0f };
+	CHECK( !w.is_device_resident() && w.get_MF( 0, 0, 0 ).m == 1.0f );
+	}
+
+int main( int argc, char ** argv )
+	{
+	const bool no_device = argc > 1 && std::string( argv[1] ) == "--no-device";
+	if( no_device ) no_device_checks(); else device_checks();
+	std::printf( "\n%s (%d failures)\n", failures ? "FAILED" : "PASSED", failures );
+	return failures ? 1 : 0;
+	}
