@@ -70,6 +70,7 @@ def main():
 
     import torch
     import flan_amd as fa
+    from flan_amd import sharding
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -124,9 +125,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = sharding.max_over_ranks(dist, elapsed, dev)
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * frames_per_step * args.steps / elapsed
 
@@ -169,19 +168,16 @@ def main():
 
     # the output-reassembly all-gather of the north star, outside the metric
     if distributed and not args.no_gather:
-        gathered = torch.empty((world * ch, F * HOP), dtype=torch.float32, device=dev)
         for _ in range(2):
-            dist.all_gather_into_tensor(gathered, out)
+            gathered = sharding.gather_output(dist, out, world)
         sync_all()
         t0 = time.perf_counter()
         reps = 5
         for _ in range(reps):
-            dist.all_gather_into_tensor(gathered, out)
+            gathered = sharding.gather_output(dist, out, world)
         sync_all()
-        tg = (time.perf_counter() - t0) / reps
-        t = torch.tensor([tg], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        tg = float(t.item())
+        tg = sharding.max_over_ranks(dist, (time.perf_counter() - t0) / reps, dev)
+        assert gathered.shape == (world * ch, F * HOP)
         extra["allgather"] = {"ms": round(tg * 1e3, 3), "bytes_per_rank": out.numel() * 4,
                               "frames_per_s_with_gather": round(world * frames_per_step / (elapsed / args.steps + tg), 1)}
 

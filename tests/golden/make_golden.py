@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Regenerate the golden vectors under tests/golden/ from the CPU oracle (oracle/flan_oracle.cpp).
+
+The reference ships no fixtures for this path and its frame loops cannot be built here (FFTW3f / libsndfile absent), so
+these vectors are the oracle's own outputs: they pin the oracle against regressions and give the GPU tests fixed
+expected values that travel to the GPU box.  The oracle itself is pinned against the reference's buildable translation
+units (tests/test_oracle_vs_ref.py) and the SURVEY 8c anchors (tests/test_oracle_anchors.py).
+
+    python tests/golden/make_golden.py        # rewrites tests/golden/*.npz
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import oracle_lib as O  # noqa: E402
+
+SR = 48000.0
+CASES = {
+    # name: (channels, n, window, hop, dft, kind, seed)
+    "sine_0p25s": (1, 12000, 2048, 512, 2048, "sine", 0),
+    "noise_stereo_0p2s": (2, 9600, 2048, 512, 2048, "noise", 1234),
+    "noise_dft4096_hop128": (1, 6000, 2048, 128, 4096, "noise", 7),
+    "ragged_len": (1, 5003, 1024, 256, 1024, "noise", 11),
+    "one_frame": (1, 100, 2048, 512, 2048, "noise", 13),
+    "all_zero": (1, 3000, 1024, 256, 1024, "zeros", 0),
+}
+
+
+def make_input(kind, ch, n, seed):
+    if kind == "sine":
+        return O.sine(n)
+    if kind == "zeros":
+        return np.zeros((ch, n), np.float32)
+    return O.noise(ch, n, seed)
+
+
+def main():
+    for name, (ch, n, W, hop, dft, kind, seed) in CASES.items():
+        x = make_input(kind, ch, n, seed)
+        pv = O.analyze(x, SR, W, hop, dft)
+        ar = np.float32(SR) / np.float32(hop)
+        out, _ = O.synthesize(pv, SR, ar, W)
+        extra = {}
+        if name == "noise_stereo_0p2s":
+            F, bins = pv.shape[1], pv.shape[2]
+            two = np.full((F, bins), 2.0, np.float32)
+            extra["stretch2"] = O.stretch(pv, SR, hop, two)
+            extra["repitch2"] = O.repitch(pv, SR, two)
+            extra["shape_f_plus_100"] = O.shape_affine(pv, SR, 1.0, 0.0, 1.0, 100.0, False)
+            extra["shape_f_times_2_aligned"] = O.shape_affine(pv, SR, 1.0, 0.0, 2.0, 0.0, True)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), audio=x, pv=pv, out=out,
+                            params=np.array([ch, n, W, hop, dft], np.int64), **extra)
+        print(name, pv.shape, out.shape)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,75 @@
+"""The N>1 path on CPU: world_size-2 gloo.  Each rank runs the round trip on its channel shard (flan_amd.sharding), the
+shards are all-gathered in rank order and must equal the unsharded result BIT FOR BIT (P5): channel sharding changes
+nothing because no state crosses channels (AudioPV.cpp:41,44,108,111).  The compute stand-in on CPU is the oracle; on
+the GPUs bench.py runs the same sharding/gather code with the HIP kernels."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, total_channels, n, result_dir):
+    import oracle_lib as O
+    from flan_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sr, W, hop, dft = 48000.0, 1024, 256, 1024
+    x = O.noise(total_channels, n, seed=1234)          # every rank can regenerate the job's input (counter-based noise)
+    lo, hi = sharding.shard_channels(total_channels, world, rank)
+    pv = O.analyze(x[lo:hi], sr, W, hop, dft)
+    out, _ = O.synthesize(pv, sr, np.float32(sr) / np.float32(hop), W)
+    local = torch.from_numpy(out)
+    counts = [b - a for a, b in (sharding.shard_channels(total_channels, world, r) for r in range(world))]
+    if len(set(counts)) == 1:
+        full = sharding.gather_output(dist, local, world)
+    else:
+        full = sharding.gather_output_uneven(dist, local, counts)
+    t = sharding.max_over_ranks(dist, 1.0 + rank, torch.device("cpu"))
+    assert t == float(world)                            # slowest rank decides
+    if rank == 0:
+        np.save(os.path.join(result_dir, "gathered.npy"), full.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total_channels", [4, 3])
+def test_channel_sharding_world2_gloo(tmp_path, total_channels):
+    import oracle_lib as O
+    n = 6000
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, total_channels, n, str(tmp_path)), nprocs=2, join=True)
+    gathered = np.load(os.path.join(str(tmp_path), "gathered.npy"))
+    x = O.noise(total_channels, n, seed=1234)
+    pv = O.analyze(x, 48000.0, 1024, 256, 1024)
+    ref, _ = O.synthesize(pv, 48000.0, np.float32(48000.0) / np.float32(256), 1024)
+    assert gathered.shape == ref.shape
+    assert np.array_equal(gathered.view(np.uint32), ref.view(np.uint32))
+
+
+def test_shard_ranges():
+    from flan_amd import sharding
+    for total in (1, 3, 8, 64, 65):
+        for world in (1, 2, 4, 8):
+            ranges = [sharding.shard_channels(total, world, r) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == total
+            assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in ranges]
+            assert max(sizes) - min(sizes) <= 1
