@@ -4,6 +4,7 @@
 #include "pv_kernels.h"
 #include "pv_kernels_fast.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace flanhip {
 
@@ -39,8 +40,16 @@ static int run_analyze( const AnalyzeParams & p, hipStream_t s )
 
 // Tuned kernels (dft 2048 / 4096): 6 wavefronts per block; two blocks (dft 2048) share a CU's 160 KiB of LDS, so the chip
 // holds 256 CUs x 12 wavefronts = 3072 chains at once.
-static constexpr int kFastWaves = 6;
-static constexpr int kFastTargetChains = 256 * 12;
+// analysis fits 168 VGPRs -> 3 wavefronts per SIMD: 6-wave blocks, two per CU (LDS 2 x 76.8 KB), 3072 resident chains;
+// synthesis needs 256 VGPRs -> 2 per SIMD: one 8-wave block per CU (LDS 94 KB), 2048 resident chains.
+// dft 4096 doubles the per-wave LDS: 6-wave blocks, one per CU.
+static constexpr int kAnaWaves10 = 8, kSynWaves10 = 8, kWaves11 = 6;
+static int fast_target_chains( int dft, bool synth )
+	{
+	if( const char * env = std::getenv( "FLANHIP_TARGET_CHAINS" ) ) { const int v = std::atoi( env ); if( v > 0 ) return v; }
+	if( dft == 4096 ) return 256 * 6;
+	return 256 * 8;
+	}
 
 template<int LOG2C, int WAVES>
 static int run_analyze_fast( const AnalyzeParams & p, const FastTables & tb, hipStream_t s )
@@ -75,10 +84,10 @@ static int run_synth_fast_hop( const SynthParams & p, const FastTables & tb, hip
 	{
 	switch( p.hop / 128 )
 		{
-		case 1: return run_synth_fast<LOG2C, kFastWaves, 1>( p, tb, s );
-		case 2: return run_synth_fast<LOG2C, kFastWaves, 2>( p, tb, s );
-		case 4: return run_synth_fast<LOG2C, kFastWaves, 4>( p, tb, s );
-		case 8: return run_synth_fast<LOG2C, kFastWaves, 8>( p, tb, s );
+		case 1: return run_synth_fast<LOG2C, ( LOG2C == 10 ? kSynWaves10 : kWaves11 ), 1>( p, tb, s );
+		case 2: return run_synth_fast<LOG2C, ( LOG2C == 10 ? kSynWaves10 : kWaves11 ), 2>( p, tb, s );
+		case 4: return run_synth_fast<LOG2C, ( LOG2C == 10 ? kSynWaves10 : kWaves11 ), 4>( p, tb, s );
+		case 8: return run_synth_fast<LOG2C, ( LOG2C == 10 ? kSynWaves10 : kWaves11 ), 8>( p, tb, s );
 		}
 	return FLANHIP_ERR_UNSUPPORTED;
 	}
@@ -106,7 +115,7 @@ int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int 
 	p.n = n; p.F = n / hop + 1;                                   // AudioPV.cpp:17
 	p.num_channels = int( ch ); p.window_size = W; p.hop = hop;
 	const bool fast = ( dft == 2048 || dft == 4096 ) && !force_generic();
-	p.L = choose_chain_length( ch, p.F, 1, fast ? kFastTargetChains : 4096 );
+	p.L = choose_chain_length( ch, p.F, 1, fast ? fast_target_chains( dft, false ) : 4096 );
 	p.chains_per_channel = int( ( p.F + p.L - 1 ) / p.L );
 	p.sample_rate = sr;
 	p.analysis_rate = sr / hop;                                   // AudioPV.cpp:26 (float / int)
@@ -114,7 +123,7 @@ int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int 
 	if( fast )
 		{
 		FastTables tb{ plan->d_tw1f, plan->d_tw3f, plan->d_tw2 };
-		return dft == 2048 ? run_analyze_fast<10, kFastWaves>( p, tb, s ) : run_analyze_fast<11, kFastWaves>( p, tb, s );
+		return dft == 2048 ? run_analyze_fast<10, kAnaWaves10>( p, tb, s ) : run_analyze_fast<11, kWaves11>( p, tb, s );
 		}
 
 	switch( ilog2( dft ) - 1 )
@@ -143,7 +152,7 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	FLANHIP_REQUIRE( is_pow2( o->dft ) && o->dft >= 32 && o->dft <= 8192, FLANHIP_ERR_UNSUPPORTED, "dft size must be a power of two in [32, 8192]" );
 	o->head_len = std::max( W - o->hop, 0 );
 	const int overlap = ( W + o->hop - 1 ) / o->hop;              // frames covering one output sample
-	o->L = choose_chain_length( ch, F, std::max( overlap - 1, 1 ), synth_fast_ok( o->dft, W, o->hop ) ? kFastTargetChains : 4096 );
+	o->L = choose_chain_length( ch, F, std::max( overlap - 1, 1 ), synth_fast_ok( o->dft, W, o->hop ) ? fast_target_chains( o->dft, true ) : 4096 );
 	o->chains_per_channel = int( ( F + o->L - 1 ) / o->L );
 	const int64_t chains = int64_t( o->chains_per_channel ) * ch;
 	o->carry_bytes = ( size_t( chains ) * bins * sizeof( double ) + 255 ) & ~size_t( 255 );
