@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="run synthesis' pre-pass as its own kernel instead of inside analysis")
     args = ap.parse_args()
 
     import torch
@@ -101,11 +102,18 @@ def main():
     ws = torch.empty(fa.synthesize_workspace_bytes(ch, F, BINS, SR, ar, WINDOW), dtype=torch.uint8, device=dev)
     nan_flag = torch.zeros(1, dtype=torch.int32, device=dev)
 
+    # the round trip is fused by default: the analysis kernel leaves synthesis' pre-pass (per-chain phase sums) in the workspace
     def analyze():
-        fa.analyze_dev(audio, ch, n, SR, WINDOW, HOP, DFT, pv, stream)
+        if args.unfused:
+            fa.analyze_dev(audio, ch, n, SR, WINDOW, HOP, DFT, pv, stream)
+        else:
+            fa.analyze_dev_fused(audio, ch, n, SR, WINDOW, HOP, DFT, pv, ws, stream)
 
     def synthesize():
-        fa.synthesize_dev(pv, ch, F, BINS, SR, ar, WINDOW, out, ws, nan_flag, stream)
+        if args.unfused:
+            fa.synthesize_dev(pv, ch, F, BINS, SR, ar, WINDOW, out, ws, nan_flag, stream)
+        else:
+            fa.synthesize_dev_fused(pv, ch, F, BINS, SR, ar, WINDOW, out, ws, nan_flag, stream)
 
     def step():
         analyze()
@@ -129,32 +137,30 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * frames_per_step * args.steps / elapsed
 
-    # per-kernel timing with events on the launch stream (rank 0 only): k_analyze alone, the whole synthesis call, and
-    # k_synthesize alone (FLANHIP debug stage mask)
-    def event_time(fn, reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        fn()
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps     # ms per launch
-
+    # per-kernel timing with events on the launch stream (rank 0 only), inside the same analyse -> synthesise sequence as the
+    # timed region: events bracket k_analyze, the pre-pass (k_phase_sums unless fused, k_phase_scan), k_synthesize and
+    # k_ola_fixup of every step (flanhip_debug_synth_stages selects which synthesis kernels a call launches)
     extra = {}
     roofline = None
     if rank == 0:
         reps = max(5, args.steps)
-        t_an = event_time(analyze, reps)
-        t_sy = event_time(synthesize, reps)
-        fa.lib.flanhip_debug_synth_stages(4)           # main kernel only (carry/head buffers left as they are)
-        t_sy_main = event_time(synthesize, reps)
-        fa.lib.flanhip_debug_synth_stages(1 | 2)       # pre-pass: k_phase_sums + k_phase_scan
-        t_sy_pre = event_time(synthesize, reps)
+        acc = [0.0, 0.0, 0.0, 0.0]
+        for _ in range(reps):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            ev[0].record()
+            analyze()
+            ev[1].record()
+            for i, mask in enumerate((1 | 2, 4, 8)):
+                fa.lib.flanhip_debug_synth_stages(mask)
+                synthesize()
+                ev[2 + i].record()
+            torch.cuda.synchronize()
+            for i in range(4):
+                acc[i] += ev[i].elapsed_time(ev[i + 1]) / reps
         fa.lib.flanhip_debug_synth_stages(0xF)
-        extra["kernel_ms"] = {"k_analyze": round(t_an, 4), "synthesize_all": round(t_sy, 4),
-                              "k_synthesize": round(t_sy_main, 4), "k_phase_sums+scan": round(t_sy_pre, 4)}
+        t_an, t_pre, t_sy_main, t_fix = acc
+        extra["kernel_ms"] = {"k_analyze": round(t_an, 4), "prepass": round(t_pre, 4), "k_synthesize": round(t_sy_main, 4),
+                              "k_ola_fixup": round(t_fix, 4), "fused": not args.unfused}
         if t_an >= t_sy_main:
             kname, tk, b = "k_analyze", t_an, BYTES_ANALYSIS
         else:

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libflanhip.so")
+LIB_PATH = os.environ.get("FLAN_AMD_LIB") or os.path.join(_HERE, "libflanhip.so")   # FLAN_AMD_LIB: A/B a second build
 
 OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_CANCELLED, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5
 
@@ -50,6 +50,8 @@ _SIGS = {
     "flanhip_synthesize": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _i32, _vp, C.POINTER(_i32), _vp]),
     "flanhip_synthesize_workspace_bytes": (C.c_size_t, [_i64, _i64, _i32, _f32, _f32, _i32]),
     "flanhip_synthesize_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp]),
+    "flanhip_analyze_dev_fused": (C.c_int, [_vp, _i64, _i64, _f32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "flanhip_synthesize_dev_fused": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp]),
     "flanhip_debug_synth_stages": (None, [_i32]),
     "flanhip_modify_time": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i32, _vp, _i64, _vp, _vp]),
     "flanhip_modify_time_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i32, _vp, _i64, _vp, _vp]),
@@ -155,6 +157,15 @@ def _dp(t):
 
 def analyze_dev(d_audio, ch, n, sample_rate, window, hop, dft, d_out, stream=None):
     check(lib.flanhip_analyze_dev(_dp(d_audio), ch, n, sample_rate, window, hop, dft, _dp(d_out), _vp(stream or 0)))
+
+
+def analyze_dev_fused(d_audio, ch, n, sample_rate, window, hop, dft, d_out, d_ws, stream=None):
+    check(lib.flanhip_analyze_dev_fused(_dp(d_audio), ch, n, sample_rate, window, hop, dft, _dp(d_out), _dp(d_ws), _vp(stream or 0)))
+
+
+def synthesize_dev_fused(d_pv, ch, F, bins, sample_rate, analysis_rate, window, d_out, d_ws, d_nan=None, stream=None):
+    check(lib.flanhip_synthesize_dev_fused(_dp(d_pv), ch, F, bins, sample_rate, analysis_rate, window, _dp(d_out), _dp(d_ws),
+                                           _dp(d_nan), _vp(stream or 0)))
 
 
 def synthesize_workspace_bytes(ch, F, bins, sample_rate, analysis_rate, window):

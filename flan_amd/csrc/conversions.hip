@@ -51,12 +51,12 @@ static int fast_target_chains( int dft, bool synth )
 	return 256 * 8;
 	}
 
-template<int LOG2C, int WAVES>
+template<int LOG2C, int WAVES, bool SUMS>
 static int run_analyze_fast( const AnalyzeParams & p, const FastTables & tb, hipStream_t s )
 	{
 	const size_t lds = FastLds<LOG2C>::bytes( WAVES );
 	static_assert( FastLds<LOG2C>::bytes( WAVES ) <= kMaxLds, "LDS budget" );
-	auto kern = k_analyze_fast<LOG2C, WAVES>;
+	auto kern = k_analyze_fast<LOG2C, WAVES, SUMS>;
 	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;
 	const int64_t blocks = ( chains + WAVES - 1 ) / WAVES;
@@ -99,7 +99,7 @@ static bool synth_fast_ok( int dft, int W, int hop )
 		&& W % 128 == 0 && hop <= W && !force_generic();
 	}
 
-int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft, flanhip_MF * d_out, hipStream_t s )
+int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft, flanhip_MF * d_out, void * d_fused_ws, hipStream_t s )
 	{
 	FLANHIP_REQUIRE( d_audio && d_out, FLANHIP_ERR_INVALID_ARG, "null buffer" );
 	FLANHIP_REQUIRE( ch > 0 && n >= 0 && W >= 2 && hop >= 1 && sr > 0.0f, FLANHIP_ERR_INVALID_ARG, "bad sizes" );
@@ -114,16 +114,32 @@ int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int 
 	p.window = plan->d_window; p.tw = plan->d_tw; p.tw2 = plan->d_tw2;
 	p.n = n; p.F = n / hop + 1;                                   // AudioPV.cpp:17
 	p.num_channels = int( ch ); p.window_size = W; p.hop = hop;
-	const bool fast = ( dft == 2048 || dft == 4096 ) && !force_generic();
+	const bool fast = ( dft == 2048 || dft == 4096 ) && n >= 2 && n < ( int64_t( 1 ) << 31 ) - 8192 && !force_generic();
 	p.L = choose_chain_length( ch, p.F, 1, fast ? fast_target_chains( dft, false ) : 4096 );
 	p.chains_per_channel = int( ( p.F + p.L - 1 ) / p.L );
 	p.sample_rate = sr;
 	p.analysis_rate = sr / hop;                                   // AudioPV.cpp:26 (float / int)
+	DivPlan dp;
+	if( int rc = get_div_plan( p.analysis_rate, &dp ) ) return rc;
+	p.ar_div = DivC{ dp.c, dp.rc, dp.exact };
+	p.sums = nullptr; p.nan_out = nullptr;
+	if( d_fused_ws )
+		{
+		// use the chain layout convert_to_audio will use for this PV and leave its pre-pass results in the workspace
+		SynthLayout lay;
+		if( int rc = synth_layout( ch, p.F, dft / 2 + 1, sr, p.analysis_rate, W, &lay ) ) return rc;
+		p.L = lay.L;
+		p.chains_per_channel = lay.chains_per_channel;
+		p.sums = reinterpret_cast<double*>( d_fused_ws );
+		p.nan_out = reinterpret_cast<int*>( reinterpret_cast<char*>( d_fused_ws ) + lay.carry_bytes + lay.head_bytes );
+		FLANHIP_CHECK( hipMemsetAsync( p.nan_out, 0, sizeof( int ), s ) );
+		}
 
 	if( fast )
 		{
 		FastTables tb{ plan->d_tw1f, plan->d_tw3f, plan->d_tw2 };
-		return dft == 2048 ? run_analyze_fast<10, kAnaWaves10>( p, tb, s ) : run_analyze_fast<11, kWaves11>( p, tb, s );
+		if( p.sums ) return dft == 2048 ? run_analyze_fast<10, kAnaWaves10, true>( p, tb, s ) : run_analyze_fast<11, kWaves11, true>( p, tb, s );
+		return dft == 2048 ? run_analyze_fast<10, kAnaWaves10, false>( p, tb, s ) : run_analyze_fast<11, kWaves11, false>( p, tb, s );
 		}
 
 	switch( ilog2( dft ) - 1 )
@@ -157,7 +173,7 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	const int64_t chains = int64_t( o->chains_per_channel ) * ch;
 	o->carry_bytes = ( size_t( chains ) * bins * sizeof( double ) + 255 ) & ~size_t( 255 );
 	o->head_bytes = ( size_t( chains ) * o->head_len * sizeof( float ) + 255 ) & ~size_t( 255 );
-	o->total_bytes = o->carry_bytes + o->head_bytes + 256;
+	o->total_bytes = o->carry_bytes + o->head_bytes + 1024;        // tail: NaN flag (4 B at +0), dump area (512 B at +512)
 	return FLANHIP_OK;
 	}
 
@@ -183,7 +199,7 @@ static int run_synth_pick( const SynthParams & p, hipStream_t s )
 	}
 
 int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float ar, int W, float * d_out,
-	void * d_ws, int * d_nan, hipStream_t s )
+	void * d_ws, int * d_nan, bool presummed, hipStream_t s )
 	{
 	FLANHIP_REQUIRE( d_pv && d_out && d_ws, FLANHIP_ERR_INVALID_ARG, "null buffer" );
 	SynthLayout lay;
@@ -203,11 +219,16 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	p.chains_per_channel = lay.chains_per_channel; p.head_len = lay.head_len; p.num_bins = bins;
 	p.analysis_rate = ar;
 	p.window_scale = 2.67f / ( lay.dft * W / lay.hop );            // AudioPV.cpp:99 (integer arithmetic in the divisor)
+	DivPlan dp;
+	if( int rc = get_div_plan( ar, &dp ) ) return rc;
+	p.ar_div = DivC{ dp.c, dp.rc, dp.exact };
+	p.dump = reinterpret_cast<float*>( reinterpret_cast<char*>( d_ws ) + lay.carry_bytes + lay.head_bytes + 512 );
+	p.nan_in = presummed ? reinterpret_cast<const int*>( reinterpret_cast<char*>( d_ws ) + lay.carry_bytes + lay.head_bytes ) : nullptr;
 
 	const int64_t chains = int64_t( p.chains_per_channel ) * ch;
 	FLANHIP_REQUIRE( chains < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
 	const int stages = g_synth_stage_mask;
-	if( stages & 1 )
+	if( ( stages & 1 ) && !presummed )
 		{
 		hipLaunchKernelGGL( k_phase_sums2, dim3( (unsigned) chains, (unsigned) ( ( bins + 255 ) / 256 ) ), dim3( 256 ), 0, s, p );
 		FLANHIP_CHECK( hipGetLastError() );
@@ -215,7 +236,8 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	if( stages & 2 )
 		{
 		const int64_t cols = ch * bins;
-		hipLaunchKernelGGL( k_phase_scan2, dim3( (unsigned) ( ( cols + 255 ) / 256 ) ), dim3( 256 ), 0, s, p );
+		(void) cols;
+		hipLaunchKernelGGL( k_phase_scan2, dim3( (unsigned) ( ( bins + 31 ) / 32 ), (unsigned) ch ), dim3( 512 ), 0, s, p );
 		FLANHIP_CHECK( hipGetLastError() );
 		}
 
@@ -263,7 +285,20 @@ extern "C" {
 
 int flanhip_analyze_dev( const float * d_audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft, flanhip_MF * d_out, void * stream )
 	{
-	return launch_analyze( d_audio, ch, n, sr, W, hop, dft, d_out, (hipStream_t) stream );
+	return launch_analyze( d_audio, ch, n, sr, W, hop, dft, d_out, nullptr, (hipStream_t) stream );
+	}
+
+int flanhip_analyze_dev_fused( const float * d_audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft, flanhip_MF * d_out,
+	void * d_synth_workspace, void * stream )
+	{
+	FLANHIP_REQUIRE( d_synth_workspace, FLANHIP_ERR_INVALID_ARG, "null workspace" );
+	return launch_analyze( d_audio, ch, n, sr, W, hop, dft, d_out, d_synth_workspace, (hipStream_t) stream );
+	}
+
+int flanhip_synthesize_dev_fused( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float ar, int W,
+	float * d_out, void * d_ws, int * d_nan, void * stream )
+	{
+	return launch_synthesize( d_pv, ch, F, bins, sr, ar, W, d_out, d_ws, d_nan, true, (hipStream_t) stream );
 	}
 
 int flanhip_analyze( const float * audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft,
@@ -281,7 +316,7 @@ int flanhip_analyze( const float * audio, int64_t ch, int64_t n, float sr, int W
 	if( int rc = d_pv.alloc( sizeof( flanhip_MF ) * size_t( ch ) * F * bins ) ) return rc;
 	FLANHIP_CHECK( hipMemcpy( d_audio.p, audio, sizeof( float ) * size_t( ch ) * n, hipMemcpyHostToDevice ) );
 	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
-	if( int rc = launch_analyze( (const float*) d_audio.p, ch, n, sr, W, hop, dft, (flanhip_MF*) d_pv.p, nullptr ) ) return rc;
+	if( int rc = launch_analyze( (const float*) d_audio.p, ch, n, sr, W, hop, dft, (flanhip_MF*) d_pv.p, nullptr, nullptr ) ) return rc;
 	FLANHIP_CHECK( hipDeviceSynchronize() );
 	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
 	FLANHIP_CHECK( hipMemcpy( out, d_pv.p, sizeof( flanhip_MF ) * size_t( ch ) * F * bins, hipMemcpyDeviceToHost ) );
@@ -300,7 +335,7 @@ size_t flanhip_synthesize_workspace_bytes( int64_t ch, int64_t F, int bins, floa
 int flanhip_synthesize_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float ar, int W,
 	float * d_out, void * d_ws, int * d_nan, void * stream )
 	{
-	return launch_synthesize( d_pv, ch, F, bins, sr, ar, W, d_out, d_ws, d_nan, (hipStream_t) stream );
+	return launch_synthesize( d_pv, ch, F, bins, sr, ar, W, d_out, d_ws, d_nan, false, (hipStream_t) stream );
 	}
 
 int flanhip_synthesize( const flanhip_MF * pv, int64_t ch, int64_t F, int bins, float sr, float ar, int W,
@@ -321,7 +356,7 @@ int flanhip_synthesize( const flanhip_MF * pv, int64_t ch, int64_t F, int bins, 
 	FLANHIP_CHECK( hipMemset( d_flag.p, 0, sizeof( int ) ) );
 	FLANHIP_CHECK( hipMemcpy( d_pv.p, pv, pv_bytes, hipMemcpyHostToDevice ) );
 	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
-	if( int rc = launch_synthesize( (const flanhip_MF*) d_pv.p, ch, F, bins, sr, ar, W, (float*) d_out.p, d_ws.p, (int*) d_flag.p, nullptr ) ) return rc;
+	if( int rc = launch_synthesize( (const flanhip_MF*) d_pv.p, ch, F, bins, sr, ar, W, (float*) d_out.p, d_ws.p, (int*) d_flag.p, false, nullptr ) ) return rc;
 	FLANHIP_CHECK( hipDeviceSynchronize() );
 	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
 	FLANHIP_CHECK( hipMemcpy( out, d_out.p, out_bytes, hipMemcpyDeviceToHost ) );

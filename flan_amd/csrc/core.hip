@@ -78,6 +78,50 @@ int get_plan( int window_size, int dft_size, const Plan ** out )
 	return FLANHIP_OK;
 	}
 
+// every float bit pattern: does fma( fma( -x*rc, c, x ), rc, x*rc ) equal the hardware (IEEE) quotient x / c ?
+__global__ __launch_bounds__( 256 ) void k_verify_div( float c, float rc, unsigned int * mismatches )
+	{
+	unsigned int bad = 0;
+	for( uint64_t u = uint64_t( blockIdx.x ) * blockDim.x + threadIdx.x; u < ( uint64_t( 1 ) << 32 ); u += uint64_t( gridDim.x ) * blockDim.x )
+		{
+		const float x = __uint_as_float( uint32_t( u ) );
+		if( !( __builtin_fabsf( x ) >= 1.0e-30f ) || !( __builtin_fabsf( x ) <= 3.4028235e38f ) ) continue;
+		const float q0 = x * rc;
+		const float q = __builtin_fmaf( __builtin_fmaf( -q0, c, x ), rc, q0 );
+		const float ref = x / c;
+		bad += ( __float_as_uint( q ) != __float_as_uint( ref ) ) && !( ref != ref );
+		}
+	if( bad ) atomicAdd( mismatches, bad );
+	}
+
+static std::map<uint32_t, DivPlan> g_div_plans;
+
+int get_div_plan( float c, DivPlan * out )
+	{
+	uint32_t key; std::memcpy( &key, &c, 4 );
+	int device = 0;
+	FLANHIP_CHECK( hipGetDevice( &device ) );
+	std::lock_guard<std::mutex> lock( g_plan_mutex );
+	auto it = g_div_plans.find( key );
+	if( it != g_div_plans.end() ) { *out = it->second; return FLANHIP_OK; }
+	DivPlan d{ c, 1.0f / c, 0 };
+	const char * env = std::getenv( "FLANHIP_NO_FAST_DIV" );
+	if( !( env && env[0] == '1' ) && c > 1.0e-10f && c < 1.0e10f )
+		{
+		unsigned int * d_bad = nullptr, bad = 1;
+		FLANHIP_CHECK( hipMalloc( &d_bad, sizeof( unsigned int ) ) );
+		FLANHIP_CHECK( hipMemset( d_bad, 0, sizeof( unsigned int ) ) );
+		hipLaunchKernelGGL( k_verify_div, dim3( 4096 ), dim3( 256 ), 0, nullptr, d.c, d.rc, d_bad );
+		FLANHIP_CHECK( hipGetLastError() );
+		FLANHIP_CHECK( hipMemcpy( &bad, d_bad, sizeof( unsigned int ), hipMemcpyDeviceToHost ) );
+		FLANHIP_CHECK( hipFree( d_bad ) );
+		d.exact = bad == 0;
+		}
+	g_div_plans[key] = d;
+	*out = d;
+	return FLANHIP_OK;
+	}
+
 bool force_generic()
 	{
 	const char * env = std::getenv( "FLANHIP_FORCE_GENERIC" );

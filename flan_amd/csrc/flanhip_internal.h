@@ -43,14 +43,21 @@ struct Plan
 	};
 int get_plan( int window_size, int dft_size, const Plan ** out );
 
+// Division by a run-time constant: { c, RN(1/c), exact } where `exact` says the 3-instruction quotient (pv_math.h div_c) was
+// checked on the device against the hardware division for every float |x| >= 1e-30.  Cached per value of c.
+struct DivPlan { float c, rc; int exact; };
+int get_div_plan( float c, DivPlan * out );
+
 // Chain length heuristics (frames per wavefront-chain)
 int choose_chain_length( int64_t num_channels, int64_t num_frames, int min_len, int target_chains );
 bool force_generic();   // FLANHIP_FORCE_GENERIC=1: never take the tuned dft 2048/4096 kernels (A/B and parity of both paths)
 
 // Launchers implemented in analyze.hip / synthesize.hip / processors.hip
-int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft, flanhip_MF * d_out, hipStream_t s );
+// d_fused_ws (optional): a synthesis workspace for the PV being produced; analysis leaves the per-chain phase sums and a NaN flag
+// there so that launch_synthesize( ..., presummed = true ) can skip its pre-pass.
+int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft, flanhip_MF * d_out, void * d_fused_ws, hipStream_t s );
 int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float ar, int W, float * d_out,
-	void * d_ws, int * d_nan, hipStream_t s );
+	void * d_ws, int * d_nan, bool presummed, hipStream_t s );
 
 struct SynthLayout { int hop, dft, L, chains_per_channel, head_len; size_t carry_bytes, head_bytes, total_bytes; };
 int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, SynthLayout * out );

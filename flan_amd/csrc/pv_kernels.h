@@ -14,14 +14,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "fft_device.h"
+#include "pv_math.h"
 
 namespace flanhip {
 
 struct MF { float m, f; };
 
-// defines.h:44-45: pi = acos(-1.0f) (float), pi2 = pi * 2.0f  -> 6.2831854820251465 as a float, NOT 2*pi.
-#define FLANHIP_PI2_F 6.2831854820251465f
-#define FLANHIP_PI2_D 6.2831854820251465
 
 struct AnalyzeParams
 	{
@@ -39,6 +37,9 @@ struct AnalyzeParams
 	int chains_per_channel;
 	float sample_rate;
 	float analysis_rate;
+	DivC ar_div;              // analysis_rate as a divisor (pv_math.h)
+	double * sums;            // optional [ch][chains][bins]: per-chain sums of the phase increments synthesis will need
+	int * nan_out;            // optional: OR-ed with 1 when an output MF is NaN/Inf
 	};
 
 // phase_vocoder.cpp:37-52 with the reference's rounding sequence (the file is compiled with -ffp-contract=off).
@@ -98,6 +99,11 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze( AnalyzeParams p )
 		if( i < E ) w2[i] = p.tw2[min( k, C )];
 		}
 
+	double sum[E + 1];                                                        // fused round trip: see AnalyzeParams::sums
+	#pragma unroll
+	for( int i = 0; i <= E; ++i ) sum[i] = 0.0;
+	bool bad = false;
+
 	for( int64_t t = ( t0 > 0 ? t0 - 1 : t0 ); t < t1; ++t )
 		{
 		const bool emit = t >= t0;
@@ -137,15 +143,37 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze( AnalyzeParams p )
 				float im = ay - 0.5f * __builtin_fmaf( c, dx, -( s * dy ) );
 				if( k == 0 ) { re = z0.x + z0.y; im = 0.0f; }
 				const MF mf = phase_vocode_bin( re, im, prev[q], binf[q], expect[q], p.analysis_rate, use_wrapping );
-				if( emit ) row[k] = mf;
+				if( emit )
+					{
+					row[k] = mf;
+					sum[q] += double( mf.f / p.analysis_rate * FLANHIP_PI2_F );
+					bad |= isnan( mf.m ) || isnan( mf.f ) || isinf( mf.m ) || isinf( mf.f );
+					}
 				}
 			}
 		if( lane == 0 )
 			{
 			const MF mf = phase_vocode_bin( z0.x - z0.y, 0.0f, prev[E], binf[E], expect[E], p.analysis_rate, use_wrapping );
-			if( emit ) row[C] = mf;
+			if( emit )
+				{
+				row[C] = mf;
+				sum[E] += double( mf.f / p.analysis_rate * FLANHIP_PI2_F );
+				bad |= isnan( mf.m ) || isnan( mf.f ) || isinf( mf.m ) || isinf( mf.f );
+				}
 			}
 		wave_sync();
+		}
+	if( p.sums )
+		{
+		double * dst = p.sums + chain * ( C + 1 );
+		#pragma unroll
+		for( int q = 0; q < E; ++q )
+			{
+			const int k = lane + 64 * q;
+			if( C >= 64 || k < C ) dst[k] = ( __builtin_fabs( sum[q] ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( sum[q] ) : fold_phase_any( sum[q] );
+			}
+		if( lane == 0 ) dst[C] = ( __builtin_fabs( sum[E] ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( sum[E] ) : fold_phase_any( sum[E] );
+		if( p.nan_out && __any( bad ) && lane == 0 ) atomicOr( p.nan_out, 1 );
 		}
 	}
 
@@ -198,6 +226,9 @@ struct SynthParams
 	int num_bins;
 	float analysis_rate;
 	float window_scale;       // AudioPV.cpp:99
+	DivC ar_div;              // analysis_rate as a divisor (pv_math.h)
+	const int * nan_in;       // optional: a NaN flag left by the producer of the PV (fused round trip), folded into nan_flag
+	float * dump;             // 512 bytes of workspace that out-of-range lanes of k_synthesize_fast store into
 	};
 
 // Per-chain sums of the phase increments, folded exactly like the running phase, plus the NaN/Inf scan of

@@ -137,7 +137,7 @@ __device__ __forceinline__ float magnitude_scaled( float re, float im )
 // =================================================================================================================
 // Audio::convert_to_PV (Conversions/AudioPV.cpp:12-78)
 // =================================================================================================================
-template<int LOG2C, int WAVES>
+template<int LOG2C, int WAVES, bool SUMS>
 __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p, FastTables tb )
 	{
 	using L = FastLds<LOG2C>;
@@ -161,53 +161,67 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 	const int64_t t1 = min( t0 + int64_t( p.L ), p.F );
 	const float * x = p.audio + int64_t( channel ) * p.n;
 	const int W = p.window_size, hop = p.hop;
-	const int WQ = ( W + 127 ) >> 7;                                         // 128-sample steps the window covers
 	const bool w_whole = ( W & 127 ) == 0;
 	const bool use_wrapping = p.analysis_rate < p.sample_rate;                // phase_vocoder.cpp:37
 	const int padl = lane + ( lane >> 4 );
 	const float2 * mirror = buf + ( C * 17 ) / 16 - ( lane + ( ( lane + 15 ) >> 4 ) );   // PAD( M - lane ) = 17 M / 16 + this, M % 64 == 0
 
 	// per-lane constants: bin frequency (PVBuffer.cpp:443-446), expected phase advance (phase_vocoder.cpp:47)
-	float binf[E + 1], expect[E + 1], prev[E + 1];
+	// (the division by dft, a power of two, is exactly a multiplication; bin_frequency is recomputed per use, 2 instructions)
+	const float rdft = 1.0f / float( 2 * C );
+	auto bin_frequency = [&]( int q ) { return float( ( q < E ) ? lane + 64 * q : C ) * p.sample_rate * rdft; };
+	// ... and so is the expected phase advance (7 instructions) -- registers are the scarce resource of this kernel
+	auto expected_advance = [&]( int q ) { return div_c( bin_frequency( q ), p.ar_div ) * FLANHIP_PI2_F; };
+	float prev[E + 1];
 	#pragma unroll
-	for( int q = 0; q <= E; ++q )
-		{
-		const int k = ( q < E ) ? lane + 64 * q : C;
-		binf[q] = float( k ) * p.sample_rate / float( 2 * C );
-		expect[q] = binf[q] / p.analysis_rate * FLANHIP_PI2_F;
-		prev[q] = 0.0f;                                                       // AudioPV.cpp:44
-		}
+	for( int q = 0; q <= E; ++q ) prev[q] = 0.0f;                             // AudioPV.cpp:44
 
 	// raw samples of frame t (AudioPV.cpp:52-62) in the natural register layout raw[q] = ( x[2i], x[2i+1] ), i = lane + 64 q.
 	// Issued one frame ahead of their use so that the HBM/L2 latency hides under the previous frame's per-bin math.
+	// Always exactly E 8-byte loads per lane and no load inside a branch: the number of outstanding memory operations is
+	// then static, so the compiler waits with a counted s_waitcnt for these loads only instead of draining the MF
+	// stores issued after them.  Frames that stick out of the signal read from clamped addresses and are patched by
+	// fix_raw() (pure register arithmetic under a wave-uniform branch).
+	struct __attribute__(( packed, aligned( 4 ) )) f2u { float x, y; };      // pair at any 4-byte aligned address
+	// (32-bit sample indices: the host routes channels of 2^31 samples or more to the generic kernel)
+	const int n32 = int( p.n );
 	auto load_raw = [&]( int64_t t, float2 ( &raw )[E] )
 		{
-		const int64_t start = int64_t( hop ) * t - W / 2;
-		const float * xs = x + start;
-		const bool interior = w_whole && start >= 0 && start + W <= p.n && ( ( reinterpret_cast<uintptr_t>( xs ) & 7 ) == 0 );
-		if( interior )
+		const int start = int( int64_t( hop ) * t - W / 2 );
+		#pragma unroll
+		for( int q = 0; q < E; ++q )
 			{
-			const float2 * xp = reinterpret_cast<const float2*>( xs ) + lane;
-			#pragma unroll
-			for( int q = 0; q < E; ++q ) raw[q] = ( q < WQ ) ? xp[64 * q] : make_float2( 0.0f, 0.0f );
+			const int a0c = min( max( start + 2 * ( lane + 64 * q ), 0 ), n32 - 2 );   // n >= 2 on this path (host check)
+			const f2u v = *reinterpret_cast<const f2u*>( x + a0c );
+			raw[q] = make_float2( v.x, v.y );
 			}
-		else
+		};
+	auto frame_is_interior = [&]( int64_t t )
+		{
+		const int64_t start = int64_t( hop ) * t - W / 2;
+		return w_whole && start >= 0 && start + 2 * int64_t( C ) <= p.n;
+		};
+	auto fix_raw = [&]( int64_t t, float2 ( &raw )[E] )
+		{
+		const int start = int( int64_t( hop ) * t - W / 2 );
+		#pragma unroll
+		for( int q = 0; q < E; ++q )
 			{
-			#pragma unroll
-			for( int q = 0; q < E; ++q )
-				{
-				const int s0 = 2 * ( lane + 64 * q );
-				float v0 = 0.0f, v1 = 0.0f;
-				if( s0 < W )     { const int64_t a = start + s0;     if( a >= 0 && a < p.n ) v0 = x[a]; }
-				if( s0 + 1 < W ) { const int64_t a = start + s0 + 1; if( a >= 0 && a < p.n ) v1 = x[a]; }
-				raw[q] = make_float2( v0, v1 );
-				}
+			const int s0 = 2 * ( lane + 64 * q );
+			const int a0 = start + s0;
+			const int d = a0 - min( max( a0, 0 ), n32 - 2 );                     // 0: pair loaded as is; -1 / +1: shifted by one; else outside
+			float v0 = ( d == 0 ) ? raw[q].x : ( d == 1 ? raw[q].y : 0.0f );
+			float v1 = ( d == 0 ) ? raw[q].y : ( d == -1 ? raw[q].x : 0.0f );
+			if( s0 >= W ) v0 = 0.0f;                                             // AudioPV.cpp:65 (also keeps Inf * 0 out)
+			if( s0 + 1 >= W ) v1 = 0.0f;
+			raw[q] = make_float2( v0, v1 );
 			}
 		};
 	// window (AudioPV.cpp:60; the table is zero beyond W, :65), transform, and leave Z both in z[] and (natural order) in
 	// buf[] for the mirror reads
-	auto transform_frame = [&]( float2 ( &z )[E] )
+	auto transform_frame = [&]( int64_t t, float2 ( &z )[E] )
 		{
+		if( !frame_is_interior( t ) ) fix_raw( t, z );
 		#pragma unroll
 		for( int q = 0; q < E; ++q )
 			{
@@ -233,12 +247,19 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 		if( q == 0 ) { re = ( lane == 0 ) ? z0.x + z0.y : re; im = ( lane == 0 ) ? 0.0f : im; }
 		};
 
+	// fused round trip: per-chain sums of the phase increments convert_to_audio will integrate (its pre-pass, done here
+	// while f is in a register), and a NaN/Inf flag for PVBuffer::is_nan_or_inf
+	double sum[SUMS ? E + 1 : 1];
+	#pragma unroll
+	for( int q = 0; q < ( SUMS ? E + 1 : 1 ); ++q ) sum[q] = 0.0;
+	bool bad = false;
+
 	float2 z[E], zn[E];
 	if( t0 > 0 )
 		{
 		// halo: only the phases of frame t0-1 are needed (phase_vocoder.cpp:45 leaves them in phase_buffer)
 		load_raw( t0 - 1, z );
-		transform_frame( z );
+		transform_frame( t0 - 1, z );
 		const float2 z0 = buf[0];
 		load_raw( t0, zn );
 		#pragma unroll
@@ -257,9 +278,9 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 		{
 		#pragma unroll
 		for( int q = 0; q < E; ++q ) z[q] = zn[q];
-		transform_frame( z );
+		transform_frame( t, z );
 		const float2 z0 = buf[0];
-		if( t + 1 < t1 ) load_raw( t + 1, zn );                                // prefetch: in flight during the per-bin math below
+		load_raw( min( t + 1, t1 - 1 ), zn );                                  // prefetch (the last frame re-reads itself): in flight during the per-bin math below
 		float2 * row = reinterpret_cast<float2*>( p.out + ( int64_t( channel ) * p.F + t ) * ( C + 1 ) );
 		float2 * rowp = row + lane;
 		#pragma unroll
@@ -271,22 +292,47 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 			const float phase = atan2_fast( im, re );
 			const float phase_diff = float( double( phase ) - double( prev[q] ) );
 			prev[q] = phase;
-			const float delta_phase = phase_diff - expect[q];
+			const float delta_phase = phase_diff - expected_advance( q );
 			const float wrapped = use_wrapping ? delta_phase - FLANHIP_PI2_F * roundf( div_pi2( delta_phase ) ) : delta_phase;
 			const float delta_frequency = div_pi2( wrapped * p.analysis_rate );
-			rowp[64 * q] = make_float2( magnitude_scaled( re, im ), binf[q] + delta_frequency );
+			const float m = magnitude_scaled( re, im ), f = bin_frequency( q ) + delta_frequency;
+			rowp[64 * q] = make_float2( m, f );
+			if constexpr( SUMS )
+				{
+				sum[q] += double( div_c( f, p.ar_div ) * FLANHIP_PI2_F );            // phase_vocoder.cpp:57-58
+				bad |= !( __builtin_fabsf( m ) <= 3.4028235e38f ) || !( __builtin_fabsf( f ) <= 3.4028235e38f );
+				}
 			}
 			{
 			const float re = z0.x - z0.y;
 			const float phase = atan2_fast( 0.0f, re );
 			const float phase_diff = float( double( phase ) - double( prev[E] ) );
 			prev[E] = phase;
-			const float delta_phase = phase_diff - expect[E];
+			const float delta_phase = phase_diff - expected_advance( E );
 			const float wrapped = use_wrapping ? delta_phase - FLANHIP_PI2_F * roundf( div_pi2( delta_phase ) ) : delta_phase;
 			const float delta_frequency = div_pi2( wrapped * p.analysis_rate );
-			if( lane == 0 ) row[C] = make_float2( __builtin_fabsf( re ), binf[E] + delta_frequency );
+			const float f = bin_frequency( E ) + delta_frequency;
+			row[C] = make_float2( __builtin_fabsf( re ), f );   // every lane holds the same Nyquist value: an unconditional store keeps the
+			                                                    // number of outstanding memory operations static (counted s_waitcnt, no drain)
+			if constexpr( SUMS )
+				{
+				sum[E] += double( div_c( f, p.ar_div ) * FLANHIP_PI2_F );
+				bad |= !( __builtin_fabsf( re ) <= 3.4028235e38f ) || !( __builtin_fabsf( f ) <= 3.4028235e38f );
+				}
 			}
 		wave_sync();
+		}
+	if constexpr( SUMS )
+		{
+		double * dst = p.sums + chain * ( C + 1 );
+		#pragma unroll
+		for( int q = 0; q <= E; ++q )
+			{
+			const double v = ( __builtin_fabs( sum[q] ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( sum[q] ) : fold_phase_any( sum[q] );
+			if( q < E ) dst[lane + 64 * q] = v;
+			else if( lane == 0 ) dst[C] = v;
+			}
+		if( p.nan_out && __any( bad ) && lane == 0 ) atomicOr( p.nan_out, 1 );
 		}
 	}
 
@@ -335,11 +381,21 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 	for( int q = 0; q < E; ++q ) acc[q] = make_float2( 0.0f, 0.0f );
 
 	// one 128-sample step of finished (or partial) output leaves the chain
+	// Exactly one store instruction per step, never inside a branch (static count of outstanding memory operations, see
+	// k_analyze_fast): lanes that fall outside the output are pointed at a 512-byte dump area in the workspace.
+	float2 * dump2 = reinterpret_cast<float2*>( p.dump ) + lane;
 	auto emit_step = [&]( int64_t a0, float2 v )
 		{
 		const int64_t a = a0 + 2 * lane;
+#ifndef FLANHIP_STATIC_EMIT   /* measured: the branchy form is 10 % faster than redirecting out-of-range lanes to a dump area */
+		(void) dump2;
 		if( a0 < own_start ) head2[( a - chain_start ) >> 1] = v;
 		else if( a >= 0 && a < p.out_len ) out2[a >> 1] = v;
+#else
+		float2 * dst = ( a0 < own_start ) ? head2 + ( ( a - chain_start ) >> 1 ) : out2 + ( a >> 1 );
+		if( a0 >= own_start && !( a >= 0 && a < p.out_len ) ) dst = dump2;
+		*dst = v;
+#endif
 		};
 
 	// MF row of frame t in the natural layout ( m, f ) of bin lane + 64 q; loaded one frame ahead of its use
@@ -365,17 +421,21 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 		for( int q = 0; q < E; ++q )
 			{
 			const float2 mf = mfr[q];                                           // ( m, f )
-			ph[q] += double( mf.y / p.analysis_rate * FLANHIP_PI2_F );          // phase_vocoder.cpp:57-58
+			ph[q] += double( div_c( mf.y, p.ar_div ) * FLANHIP_PI2_F );          // phase_vocoder.cpp:57-58
 			slow |= !( __builtin_fabs( ph[q] ) < double( FLANHIP_SINCOS_FAST_LIMIT ) );
 			z[q].x = mf.x;
 			}
 			{
 			const float2 mf = mfny;
-			ph[E] += double( mf.y / p.analysis_rate * FLANHIP_PI2_F );
+			ph[E] += double( div_c( mf.y, p.ar_div ) * FLANHIP_PI2_F );
 			slow |= !( __builtin_fabs( ph[E] ) < double( FLANHIP_SINCOS_FAST_LIMIT ) );
 			mn = mf.x;
 			}
+#ifndef FLANHIP_STATIC_EMIT
 		if( t + 1 < t1 ) load_row( t + 1, mfr, mfny );                          // prefetch: in flight during the transform below
+#else
+		load_row( min( t + 1, t1 - 1 ), mfr, mfny );                            // prefetch (the last frame re-reads itself): in flight during the transform below
+#endif
 		float2 xn;
 		if( __any( slow ) )
 			{
@@ -454,8 +514,10 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 	for( int64_t a0 = pos + 128 * E; a0 < flush_end; a0 += 128 ) emit_step( a0, make_float2( 0.0f, 0.0f ) );
 	}
 
-// ---- faster pre-pass kernels (all sizes) -----------------------------------------------------------------------
-// One thread per (chain, bin): sums the chain's phase increments, folded like the running phase; NaN/Inf scan.
+// ---- pre-pass kernels (all sizes) --------------------------------------------------------------------------------
+// One thread per (chain, bin): the chain's phase increments summed in double and folded once (the running phase of
+// phase_vocoder.cpp:57-59 modulo pi2); NaN/Inf scan of PVBuffer::is_nan_or_inf.  Streaming read of the PV with 8 rows in
+// flight per thread.
 __global__ __launch_bounds__( 256 ) void k_phase_sums2( SynthParams p )
 	{
 	const int64_t chain = blockIdx.x;
@@ -469,60 +531,72 @@ __global__ __launch_bounds__( 256 ) void k_phase_sums2( SynthParams p )
 		double ph = 0.0;
 		const float2 * col = reinterpret_cast<const float2*>( p.pv + ( int64_t( channel ) * p.F + t0 ) * p.num_bins + k );
 		int i = 0;
-		for( ; i + 4 <= n; i += 4 )
+		for( ; i + 8 <= n; i += 8 )
 			{
-			float2 v[4];
+			float2 v[8];
 			#pragma unroll
-			for( int u = 0; u < 4; ++u ) v[u] = col[int64_t( i + u ) * p.num_bins];
+			for( int u = 0; u < 8; ++u ) v[u] = col[int64_t( i + u ) * p.num_bins];
 			#pragma unroll
-			for( int u = 0; u < 4; ++u )
+			for( int u = 0; u < 8; ++u )
 				{
-				bad |= isnan( v[u].x ) || isnan( v[u].y ) || isinf( v[u].x ) || isinf( v[u].y );
-				ph += double( v[u].y / p.analysis_rate * FLANHIP_PI2_F );
-				ph = ( __builtin_fabs( ph ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( ph ) : fold_phase_any( ph );
+				bad |= !( __builtin_fabsf( v[u].x ) <= 3.4028235e38f ) || !( __builtin_fabsf( v[u].y ) <= 3.4028235e38f );
+				ph += double( div_c( v[u].y, p.ar_div ) * FLANHIP_PI2_F );
 				}
+			if( !( __builtin_fabs( ph ) < 1.0e8 ) ) ph = fold_phase_any( ph );       // keep the partial sum small (never for real data)
 			}
 		for( ; i < n; ++i )
 			{
 			const float2 v = col[int64_t( i ) * p.num_bins];
-			bad |= isnan( v.x ) || isnan( v.y ) || isinf( v.x ) || isinf( v.y );
-			ph += double( v.y / p.analysis_rate * FLANHIP_PI2_F );
-			ph = ( __builtin_fabs( ph ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( ph ) : fold_phase_any( ph );
+			bad |= !( __builtin_fabsf( v.x ) <= 3.4028235e38f ) || !( __builtin_fabsf( v.y ) <= 3.4028235e38f );
+			ph += double( div_c( v.y, p.ar_div ) * FLANHIP_PI2_F );
 			}
-		p.carry[chain * p.num_bins + k] = ph;
+		p.carry[chain * p.num_bins + k] = ( __builtin_fabs( ph ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( ph ) : fold_phase_any( ph );
 		}
 	if( p.nan_flag && __any( bad ) && ( threadIdx.x & 63 ) == 0 ) atomicOr( p.nan_flag, 1 );
 	}
 
-// Exclusive scan of the chain sums along each channel, per bin.
-__global__ __launch_bounds__( 256 ) void k_phase_scan2( SynthParams p )
+// Exclusive scan of the chain sums along each channel, per bin (modular addition is associative, so the scan is cut in
+// SEG segments: 32 bins x 8 segments per block; each thread sums its segment, the segment totals are scanned through LDS,
+// then each thread rewrites its segment as exclusive prefixes).  carry[c] = phase_buffer on entry to chain c.
+__global__ __launch_bounds__( 512 ) void k_phase_scan2( SynthParams p )
 	{
-	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
-	if( idx >= int64_t( p.num_channels ) * p.num_bins ) return;
-	const int channel = int( idx / p.num_bins ), k = int( idx % p.num_bins );
-	double * c = p.carry + int64_t( channel ) * p.chains_per_channel * p.num_bins + k;
-	double run = 0.0;                                                          // AudioPV.cpp:111
+	constexpr int SEG = 16;                                                    // 32 bins x 16 segments = 512 threads
+	__shared__ double totals[SEG][32];
+	const int lane_bin = threadIdx.x & 31, seg = threadIdx.x >> 5;
+	const int channel = blockIdx.y;
+	const int k = blockIdx.x * 32 + lane_bin;
+	if( threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && p.nan_in && p.nan_flag && *p.nan_in ) atomicOr( p.nan_flag, 1 );
 	const int n = p.chains_per_channel;
-	int i = 0;
-	for( ; i + 8 <= n; i += 8 )
+	const int seg_len = ( n + SEG - 1 ) / SEG;
+	const int i0 = min( seg * seg_len, n ), i1 = min( i0 + seg_len, n );
+	const bool live = k < p.num_bins;
+	double * c = p.carry + int64_t( channel ) * n * p.num_bins + ( live ? k : 0 );
+	auto fold = []( double v ) { return ( __builtin_fabs( v ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( v ) : fold_phase_any( v ); };
+	double run = 0.0;
+	for( int i = i0; i < i1; i += 8 )
 		{
 		double v[8];
 		#pragma unroll
-		for( int u = 0; u < 8; ++u ) v[u] = c[int64_t( i + u ) * p.num_bins];
+		for( int u = 0; u < 8; ++u ) v[u] = ( live && i + u < i1 ) ? c[int64_t( i + u ) * p.num_bins] : 0.0;
+		#pragma unroll
+		for( int u = 0; u < 8; ++u ) run = fold( run + v[u] );
+		}
+	totals[seg][lane_bin] = run;
+	__syncthreads();
+	double offs = 0.0;                                                         // AudioPV.cpp:111
+	for( int s2 = 0; s2 < seg; ++s2 ) offs = fold( offs + totals[s2][lane_bin] );
+	run = offs;
+	for( int i = i0; i < i1; i += 8 )
+		{
+		double v[8];
+		#pragma unroll
+		for( int u = 0; u < 8; ++u ) v[u] = ( live && i + u < i1 ) ? c[int64_t( i + u ) * p.num_bins] : 0.0;
 		#pragma unroll
 		for( int u = 0; u < 8; ++u )
 			{
-			c[int64_t( i + u ) * p.num_bins] = run;
-			run += v[u];
-			run = ( __builtin_fabs( run ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( run ) : fold_phase_any( run );
+			if( live && i + u < i1 ) c[int64_t( i + u ) * p.num_bins] = run;
+			run = fold( run + v[u] );
 			}
-		}
-	for( ; i < n; ++i )
-		{
-		const double v = c[int64_t( i ) * p.num_bins];
-		c[int64_t( i ) * p.num_bins] = run;
-		run += v;
-		run = ( __builtin_fabs( run ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( run ) : fold_phase_any( run );
 		}
 	}
 

@@ -30,6 +30,21 @@ __device__ __forceinline__ float div_pi2( float x )
 	return __builtin_fmaf( r, FLANHIP_RPI2_F, q0 );
 	}
 
+// Division by a run-time constant c (the analysis rate).  The same 3-instruction form is correctly rounded for most, not
+// all, divisors; the host proves it for the c at hand by trying every float |x| >= 1e-30 on the device once per process
+// (core.hip: get_div_plan) and kernels take the hardware division when the proof failed.
+struct DivC { float c, rc; int exact; };
+__device__ __forceinline__ float div_c( float x, DivC d )
+	{
+	if( d.exact )
+		{
+		const float q0 = x * d.rc;
+		const float r = __builtin_fmaf( -q0, d.c, x );
+		return __builtin_fmaf( r, d.rc, q0 );
+		}
+	return x / d.c;
+	}
+
 // |z| = sqrt( re^2 + im^2 ) by one fma and the hardware square root (v_sqrt_f32, 1 ulp): within 1.5 ulp of hypotf for
 // max(|re|,|im|) in [1e-18, 1e18]; the caller tracks the largest / smallest operand of a frame and redoes the frame
 // with hypotf when it falls outside.

@@ -88,6 +88,17 @@ int flanhip_synthesize_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_
                            float sample_rate, float analysis_rate, int window_size,
                            float * d_out, void * d_workspace, int * d_nan_flag, void * stream);
 
+/* Fused round trip (convert_to_PV immediately followed, possibly after read-only use, by convert_to_audio of the SAME,
+ * unmodified PV): the analysis kernel also leaves in `d_synth_workspace` (sized by flanhip_synthesize_workspace_bytes for the
+ * PV it produces) what synthesis' pre-pass would compute -- the per-chain sums of the phase increments and the NaN/Inf flag --
+ * and flanhip_synthesize_dev_fused starts from them instead of re-reading the PV.  Results are identical to the unfused pair. */
+int flanhip_analyze_dev_fused(const float * d_audio, int64_t num_channels, int64_t num_audio_frames, float sample_rate,
+                              int window_size, int hop, int dft_size,
+                              flanhip_MF * d_out, void * d_synth_workspace, void * stream);
+int flanhip_synthesize_dev_fused(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_pv_frames, int num_bins,
+                                 float sample_rate, float analysis_rate, int window_size,
+                                 float * d_out, void * d_workspace, int * d_nan_flag, void * stream);
+
 /* Bench/diagnostic knob: which of the synthesis kernels a call launches (bit 0 k_phase_sums, 1 k_phase_scan,
  * 2 k_synthesize, 3 k_ola_fixup; default all).  Results are only meaningful with all four. */
 void flanhip_debug_synth_stages(int mask);

@@ -194,3 +194,48 @@ def test_generic_and_tuned_kernels_agree(fa, monkeypatch, dft, hop):
         res[mode] = (pv, out)
     d = np.abs(res["0"][1].astype(np.float64) - res["1"][1].astype(np.float64))
     assert d.max() <= 5e-6
+
+
+def test_fused_round_trip_equals_unfused(fa):
+    """flanhip_analyze_dev_fused + flanhip_synthesize_dev_fused (pre-pass done inside the analysis kernel) must give the very
+    same PV and audio as the plain pair, and must carry the NaN flag across."""
+    import ctypes
+    lib = fa.lib
+    sr = 48000.0
+    for (ch, n, W, hop, dft) in [(2, 70000, 2048, 512, 2048), (1, 30000, 2048, 128, 4096), (2, 20000, 1024, 256, 1024), (1, 9000, 400, 100, 512)]:
+        x = O.noise(ch, n, seed=31)
+        F = O.num_pv_frames(n, hop)
+        bins = dft // 2 + 1
+        ar = np.float32(sr) / np.float32(hop)
+        hop_s = lib.flanhip_hop_size(sr, ar)
+
+        def dev_alloc(nbytes):
+            p = ctypes.c_void_p()
+            fa.check(lib.flanhip_malloc(ctypes.byref(p), nbytes))
+            return p
+        d_x = dev_alloc(x.nbytes)
+        fa.check(lib.flanhip_memcpy_h2d(d_x, x.ctypes.data_as(ctypes.c_void_p), x.nbytes, None))
+        ws_bytes = lib.flanhip_synthesize_workspace_bytes(ch, F, bins, sr, ar, W)
+        res = []
+        for fused in (False, True):
+            d_pv, d_out, d_ws, d_flag = dev_alloc(ch * F * bins * 8), dev_alloc(ch * F * hop_s * 4), dev_alloc(ws_bytes), dev_alloc(4)
+            fa.check(lib.flanhip_memset(d_flag, 0, 4, None))
+            if fused:
+                fa.check(lib.flanhip_analyze_dev_fused(d_x, ch, n, sr, W, hop, dft, d_pv, d_ws, None))
+                fa.check(lib.flanhip_synthesize_dev_fused(d_pv, ch, F, bins, sr, ar, W, d_out, d_ws, d_flag, None))
+            else:
+                fa.check(lib.flanhip_analyze_dev(d_x, ch, n, sr, W, hop, dft, d_pv, None))
+                fa.check(lib.flanhip_synthesize_dev(d_pv, ch, F, bins, sr, ar, W, d_out, d_ws, d_flag, None))
+            pv = np.empty((ch, F, bins, 2), np.float32); out = np.empty((ch, F * hop_s), np.float32); flag = np.zeros(1, np.int32)
+            for host, dev in ((pv, d_pv), (out, d_out), (flag, d_flag)):
+                fa.check(lib.flanhip_memcpy_d2h(host.ctypes.data_as(ctypes.c_void_p), dev, host.nbytes, None))
+            fa.check(lib.flanhip_stream_synchronize(None))
+            res.append((pv, out, int(flag[0])))
+            for p in (d_pv, d_out, d_ws, d_flag):
+                lib.flanhip_free(p)
+        lib.flanhip_free(d_x)
+        assert np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32))
+        d = np.abs(res[0][1].astype(np.float64) - res[1][1].astype(np.float64))
+        print("\n[fused vs unfused dft=%d hop=%d] max audio diff %.3e" % (dft, hop, d.max()))
+        assert d.max() <= 1e-6
+        assert res[0][2] == res[1][2] == 0
