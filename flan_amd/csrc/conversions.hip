@@ -54,8 +54,8 @@ static int fast_target_chains( int dft, bool synth )
 template<int LOG2C, int WAVES, bool SUMS>
 static int run_analyze_fast( const AnalyzeParams & p, const FastTables & tb, hipStream_t s )
 	{
-	const size_t lds = FastLds<LOG2C>::bytes( WAVES );
-	static_assert( FastLds<LOG2C>::bytes( WAVES ) <= kMaxLds, "LDS budget" );
+	const size_t lds = FastLds<LOG2C>::bytes( WAVES, SUMS );
+	static_assert( FastLds<LOG2C>::bytes( WAVES, SUMS ) <= kMaxLds, "LDS budget" );
 	auto kern = k_analyze_fast<LOG2C, WAVES, SUMS>;
 	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;
@@ -138,7 +138,7 @@ int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int 
 	if( fast )
 		{
 		FastTables tb{ plan->d_tw1f, plan->d_tw3f, plan->d_tw2 };
-		if( p.sums ) return dft == 2048 ? run_analyze_fast<10, kAnaWaves10, true>( p, tb, s ) : run_analyze_fast<11, kWaves11, true>( p, tb, s );
+		if( p.sums ) return dft == 2048 ? run_analyze_fast<10, kAnaWaves10, true>( p, tb, s ) : run_analyze_fast<11, 3, true>( p, tb, s );
 		return dft == 2048 ? run_analyze_fast<10, kAnaWaves10, false>( p, tb, s ) : run_analyze_fast<11, kWaves11, false>( p, tb, s );
 		}
 

@@ -41,8 +41,9 @@ template<int LOG2C> struct FastLds
 	static constexpr int W2 = TW3 + fast_tw3_len( C );
 	static constexpr int WIN = W2 + C;                 // window as float2 pairs, C entries (2C floats, zero padded)
 	static constexpr int BUF = WIN + C;
-	static constexpr int BUF_LEN = padded_len( C + 1 );
-	static constexpr size_t bytes( int waves ) { return size_t( BUF + waves * BUF_LEN ) * 8; }
+	static constexpr int BUF_LEN = C + C / 16 + 1;     // highest slot used is PAD( C ) = C + C/16 (synthesis parks X[C] there)
+	static constexpr int SUM_LEN = ( C / 64 + 1 ) * 64; // per-wave chain sums (doubles), fused analysis only
+	static constexpr size_t bytes( int waves, bool sums = false ) { return size_t( BUF + waves * BUF_LEN + ( sums ? waves * SUM_LEN : 0 ) ) * 8; }
 	};
 
 // ---- the three FFT passes on the register array z[E] (natural layout in, natural layout out) -------------------
@@ -249,9 +250,14 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 
 	// fused round trip: per-chain sums of the phase increments convert_to_audio will integrate (its pre-pass, done here
 	// while f is in a register), and a NaN/Inf flag for PVBuffer::is_nan_or_inf
-	double sum[SUMS ? E + 1 : 1];
-	#pragma unroll
-	for( int q = 0; q < ( SUMS ? E + 1 : 1 ); ++q ) sum[q] = 0.0;
+	// The sums live in LDS (double [E+1][64] per wave): 34 more VGPRs would push the kernel into scratch spills, whose
+	// reloads count as memory operations and defeat the counted waits above.
+	double * s_sum = reinterpret_cast<double*>( s + L::BUF + WAVES * L::BUF_LEN ) + wave * L::SUM_LEN + lane;
+	if constexpr( SUMS )
+		{
+		#pragma unroll
+		for( int q = 0; q <= E; ++q ) s_sum[64 * q] = 0.0;
+		}
 	bool bad = false;
 
 	float2 z[E], zn[E];
@@ -299,7 +305,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 			rowp[64 * q] = make_float2( m, f );
 			if constexpr( SUMS )
 				{
-				sum[q] += double( div_c( f, p.ar_div ) * FLANHIP_PI2_F );            // phase_vocoder.cpp:57-58
+				s_sum[64 * q] += double( div_c( f, p.ar_div ) * FLANHIP_PI2_F );     // phase_vocoder.cpp:57-58
 				bad |= !( __builtin_fabsf( m ) <= 3.4028235e38f ) || !( __builtin_fabsf( f ) <= 3.4028235e38f );
 				}
 			}
@@ -316,7 +322,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 			                                                    // number of outstanding memory operations static (counted s_waitcnt, no drain)
 			if constexpr( SUMS )
 				{
-				sum[E] += double( div_c( f, p.ar_div ) * FLANHIP_PI2_F );
+				s_sum[64 * E] += double( div_c( f, p.ar_div ) * FLANHIP_PI2_F );
 				bad |= !( __builtin_fabsf( re ) <= 3.4028235e38f ) || !( __builtin_fabsf( f ) <= 3.4028235e38f );
 				}
 			}
@@ -328,7 +334,8 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 		#pragma unroll
 		for( int q = 0; q <= E; ++q )
 			{
-			const double v = ( __builtin_fabs( sum[q] ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( sum[q] ) : fold_phase_any( sum[q] );
+			const double sq = s_sum[64 * q];
+			const double v = ( __builtin_fabs( sq ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( sq ) : fold_phase_any( sq );
 			if( q < E ) dst[lane + 64 * q] = v;
 			else if( lane == 0 ) dst[C] = v;
 			}
