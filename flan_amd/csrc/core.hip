@@ -48,30 +48,30 @@ int get_plan( int window_size, int dft_size, const Plan ** out )
 	const int C = dft_size / 2;
 	std::vector<float> win( window_size );
 	for( int i = 0; i < window_size; ++i ) win[i] = hann_host( float( i ) / float( window_size - 1 ) );  // AudioPV.cpp:30-34
-	std::vector<float2> tw( C ), tw2( C + 1 );
+	std::vector<cf> tw( C ), tw2( C + 1 );
 	const double pi = 3.14159265358979323846;
-	for( int k = 0; k < C; ++k ) tw[k] = make_float2( float( std::cos( -2.0 * pi * k / C ) ), float( std::sin( -2.0 * pi * k / C ) ) );
-	for( int k = 0; k <= C; ++k ) tw2[k] = make_float2( float( std::cos( -pi * k / C ) ), float( std::sin( -pi * k / C ) ) );
+	for( int k = 0; k < C; ++k ) tw[k] = cf{ float( std::cos( -2.0 * pi * k / C ) ), float( std::sin( -2.0 * pi * k / C ) ) };
+	for( int k = 0; k <= C; ++k ) tw2[k] = cf{ float( std::cos( -pi * k / C ) ), float( std::sin( -pi * k / C ) ) };
 
 	Plan plan;
 	FLANHIP_CHECK( hipMalloc( &plan.d_window, sizeof( float ) * window_size ) );
-	FLANHIP_CHECK( hipMalloc( &plan.d_tw, sizeof( float2 ) * C ) );
-	FLANHIP_CHECK( hipMalloc( &plan.d_tw2, sizeof( float2 ) * ( C + 1 ) ) );
+	FLANHIP_CHECK( hipMalloc( &plan.d_tw, sizeof( cf ) * C ) );
+	FLANHIP_CHECK( hipMalloc( &plan.d_tw2, sizeof( cf ) * ( C + 1 ) ) );
 	FLANHIP_CHECK( hipMemcpy( plan.d_window, win.data(), sizeof( float ) * window_size, hipMemcpyHostToDevice ) );
-	FLANHIP_CHECK( hipMemcpy( plan.d_tw, tw.data(), sizeof( float2 ) * C, hipMemcpyHostToDevice ) );
-	FLANHIP_CHECK( hipMemcpy( plan.d_tw2, tw2.data(), sizeof( float2 ) * ( C + 1 ), hipMemcpyHostToDevice ) );
+	FLANHIP_CHECK( hipMemcpy( plan.d_tw, tw.data(), sizeof( cf ) * C, hipMemcpyHostToDevice ) );
+	FLANHIP_CHECK( hipMemcpy( plan.d_tw2, tw2.data(), sizeof( cf ) * ( C + 1 ), hipMemcpyHostToDevice ) );
 	if( dft_size == 2048 || dft_size == 4096 )
 		{
 		const int R3 = C / 256;
-		std::vector<float2> tw1( 15 * 16 ), tw3( size_t( R3 - 1 ) * 256 );
+		std::vector<cf> tw1( 15 * 16 ), tw3( size_t( R3 - 1 ) * 256 );
 		for( int r = 1; r < 16; ++r ) for( int k = 0; k < 16; ++k )
-			tw1[( r - 1 ) * 16 + k] = make_float2( float( std::cos( -2.0 * pi * r * k / 256.0 ) ), float( std::sin( -2.0 * pi * r * k / 256.0 ) ) );
+			tw1[( r - 1 ) * 16 + k] = cf{ float( std::cos( -2.0 * pi * r * k / 256.0 ) ), float( std::sin( -2.0 * pi * r * k / 256.0 ) ) };
 		for( int r = 1; r < R3; ++r ) for( int j = 0; j < 256; ++j )
-			tw3[size_t( r - 1 ) * 256 + j] = make_float2( float( std::cos( -2.0 * pi * r * j / C ) ), float( std::sin( -2.0 * pi * r * j / C ) ) );
-		FLANHIP_CHECK( hipMalloc( &plan.d_tw1f, sizeof( float2 ) * tw1.size() ) );
-		FLANHIP_CHECK( hipMalloc( &plan.d_tw3f, sizeof( float2 ) * tw3.size() ) );
-		FLANHIP_CHECK( hipMemcpy( plan.d_tw1f, tw1.data(), sizeof( float2 ) * tw1.size(), hipMemcpyHostToDevice ) );
-		FLANHIP_CHECK( hipMemcpy( plan.d_tw3f, tw3.data(), sizeof( float2 ) * tw3.size(), hipMemcpyHostToDevice ) );
+			tw3[size_t( r - 1 ) * 256 + j] = cf{ float( std::cos( -2.0 * pi * r * j / C ) ), float( std::sin( -2.0 * pi * r * j / C ) ) };
+		FLANHIP_CHECK( hipMalloc( &plan.d_tw1f, sizeof( cf ) * tw1.size() ) );
+		FLANHIP_CHECK( hipMalloc( &plan.d_tw3f, sizeof( cf ) * tw3.size() ) );
+		FLANHIP_CHECK( hipMemcpy( plan.d_tw1f, tw1.data(), sizeof( cf ) * tw1.size(), hipMemcpyHostToDevice ) );
+		FLANHIP_CHECK( hipMemcpy( plan.d_tw3f, tw3.data(), sizeof( cf ) * tw3.size(), hipMemcpyHostToDevice ) );
 		}
 	auto ins = g_plans.emplace( key, plan );
 	*out = &ins.first->second;

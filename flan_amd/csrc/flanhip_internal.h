@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "flanhip.h"
+#include "cf_type.h"
 
 namespace flanhip {
 
@@ -36,10 +37,10 @@ inline bool cancelled( volatile int * c ) { return c && *c != 0; }
 struct Plan
 	{
 	float * d_window = nullptr;    // [W]   hann( i/(W-1) ), WindowFunctions.cpp:10-13 evaluated on the host in double
-	float2 * d_tw = nullptr;       // [C]   exp(-2 pi i k / C)
-	float2 * d_tw2 = nullptr;      // [C+1] exp(-2 pi i k / (2C))
-	float2 * d_tw1f = nullptr;     // fast path (dft 2048/4096): [15][16]      exp(-2 pi i r k / 256)
-	float2 * d_tw3f = nullptr;     // fast path:                 [C/256-1][256] exp(-2 pi i r j / C)
+	cf * d_tw = nullptr;       // [C]   exp(-2 pi i k / C)
+	cf * d_tw2 = nullptr;      // [C+1] exp(-2 pi i k / (2C))
+	cf * d_tw1f = nullptr;     // fast path (dft 2048/4096): [15][16]      exp(-2 pi i r k / 256)
+	cf * d_tw3f = nullptr;     // fast path:                 [C/256-1][256] exp(-2 pi i r j / C)
 	};
 int get_plan( int window_size, int dft_size, const Plan ** out );
 

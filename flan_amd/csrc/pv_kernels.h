@@ -26,8 +26,8 @@ struct AnalyzeParams
 	const float * audio;      // [ch][n]
 	MF * out;                 // [ch][F][bins]
 	const float * window;     // [W]   hann( i/(W-1) )
-	const float2 * tw;        // [C]   exp(-2 pi i k / C)
-	const float2 * tw2;       // [C+1] exp(-2 pi i k / N), N = 2C
+	const cf * tw;        // [C]   exp(-2 pi i k / C)
+	const cf * tw2;       // [C+1] exp(-2 pi i k / N), N = 2C
 	int64_t n;                // audio frames per channel
 	int64_t F;                // pv frames per channel
 	int num_channels;
@@ -65,17 +65,17 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze( AnalyzeParams p )
 	constexpr int C = 1 << LOG2C;                   // complex points = dft/2
 	constexpr int E = ( C + 63 ) / 64;              // bins per lane (plus Nyquist on lane 0)
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	float2 * s_tw = reinterpret_cast<float2*>( smem );                      // [C]
+	cf * s_tw = reinterpret_cast<cf*>( smem );                      // [C]
 	float * s_win = reinterpret_cast<float*>( s_tw + C );                    // [W rounded up to even]
 	const int wpad = ( p.window_size + 3 ) & ~3;
-	float2 * s_buf_all = reinterpret_cast<float2*>( s_win + wpad );          // WAVES x padded_len(C)
+	cf * s_buf_all = reinterpret_cast<cf*>( s_win + wpad );          // WAVES x padded_len(C)
 
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	for( int i = tid; i < C; i += 64 * WAVES ) s_tw[i] = p.tw[i];
 	for( int i = tid; i < p.window_size; i += 64 * WAVES ) s_win[i] = p.window[i];
 	__syncthreads();
 
-	float2 * buf = s_buf_all + wave * padded_len( C );
+	cf * buf = s_buf_all + wave * padded_len( C );
 	const int64_t chain = int64_t( blockIdx.x ) * WAVES + wave;
 	if( chain >= int64_t( p.chains_per_channel ) * p.num_channels ) return;
 	const int channel = int( chain / p.chains_per_channel );
@@ -88,7 +88,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze( AnalyzeParams p )
 
 	// per-lane constants: bin frequency (PVBuffer.cpp:443-446), expected phase advance (phase_vocoder.cpp:47), split twiddle
 	float binf[E + 1], expect[E + 1], prev[E + 1];
-	float2 w2[E];
+	cf w2[E];
 	#pragma unroll
 	for( int i = 0; i <= E; ++i )
 		{
@@ -119,7 +119,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze( AnalyzeParams p )
 				float v0 = 0.0f, v1 = 0.0f;
 				if( s0 < W ) { const int64_t a = start + s0; if( a >= 0 && a < p.n ) v0 = x[a] * s_win[s0]; }
 				if( s1 < W ) { const int64_t a = start + s1; if( a >= 0 && a < p.n ) v1 = x[a] * s_win[s1]; }
-				buf[PAD( i )] = make_float2( v0, v1 );
+				buf[PAD( i )] = mk( v0, v1 );
 				}
 			}
 		wave_sync();
@@ -127,15 +127,15 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze( AnalyzeParams p )
 
 		// split the half-size transform into the real transform's bins and phase-vocode each bin (AudioPV.cpp:69-73)
 		MF * row = p.out + ( int64_t( channel ) * p.F + t ) * ( C + 1 );
-		const float2 z0 = buf[PAD( 0 )];
+		const cf z0 = buf[PAD( 0 )];
 		#pragma unroll
 		for( int q = 0; q < E; ++q )
 			{
 			const int k = lane + 64 * q;
 			if( C >= 64 || k < C )
 				{
-				const float2 zk = buf[PAD( k )];
-				const float2 zm = buf[PAD( ( C - k ) & ( C - 1 ) )];
+				const cf zk = buf[PAD( k )];
+				const cf zm = buf[PAD( ( C - k ) & ( C - 1 ) )];
 				const float ax = 0.5f * ( zk.x + zm.x ), ay = 0.5f * ( zk.y - zm.y );
 				const float dx = zk.x - zm.x, dy = zk.y + zm.y;
 				const float c = w2[q].x, s = w2[q].y;
@@ -210,8 +210,8 @@ struct SynthParams
 	const MF * pv;            // [ch][F][bins]
 	float * out;              // [ch][F*hop]
 	const float * window;     // [W] hann( i/(W-1) ) (unscaled)
-	const float2 * tw;        // [C]
-	const float2 * tw2;       // [C+1]
+	const cf * tw;        // [C]
+	const cf * tw2;       // [C+1]
 	double * carry;           // [ch][chains][bins]  sums on entry to k_phase_scan, exclusive carries after
 	float * head;             // [ch][chains][W-hop] overlap shared with the previous chain
 	int * nan_flag;           // may be null
@@ -278,11 +278,11 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize( SynthParams p )
 	constexpr int C = 1 << LOG2C;
 	constexpr int E = ( C + 63 ) / 64;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	float2 * s_tw = reinterpret_cast<float2*>( smem );                       // [C]
+	cf * s_tw = reinterpret_cast<cf*>( smem );                       // [C]
 	const int W = p.window_size, hop = p.hop;
 	const int wpad = ( W + 3 ) & ~3;
 	float * s_win = reinterpret_cast<float*>( s_tw + C );                     // [wpad] scaled window
-	float2 * s_buf_all = reinterpret_cast<float2*>( s_win + wpad );           // WAVES x padded_len(C+1)
+	cf * s_buf_all = reinterpret_cast<cf*>( s_win + wpad );           // WAVES x padded_len(C+1)
 	float * s_ring_all = reinterpret_cast<float*>( s_buf_all + WAVES * padded_len( C + 1 ) ); // WAVES x wpad
 
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize( SynthParams p )
 	for( int i = lane; i < W; i += 64 ) ring[i] = 0.0f;
 	__syncthreads();
 
-	float2 * buf = s_buf_all + wave * padded_len( C + 1 );
+	cf * buf = s_buf_all + wave * padded_len( C + 1 );
 	const int64_t chain = int64_t( blockIdx.x ) * WAVES + wave;
 	if( chain >= int64_t( p.chains_per_channel ) * p.num_channels ) return;
 	const int channel = int( chain / p.chains_per_channel );
@@ -307,7 +307,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize( SynthParams p )
 
 	// running phase (phase_buffer, AudioPV.cpp:105) on entry to the chain
 	double ph[E + 1];
-	float2 w2[E];
+	cf w2[E];
 	#pragma unroll
 	for( int i = 0; i <= E; ++i )
 		{
@@ -333,21 +333,21 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize( SynthParams p )
 				ph[q] = fold_phase( ph[q] + double( phase_term( mf.f, p.analysis_rate ) ) );
 				float sn, cs;
 				sincosf( float( ph[q] ), &sn, &cs );
-				buf[PAD( k )] = make_float2( mf.m * cs, mf.m * sn );           // std::polar
+				buf[PAD( k )] = mk( mf.m * cs, mf.m * sn );           // std::polar
 				}
 			}
 		wave_sync();
 		// merge X[0..C] into the half-size spectrum Z[k] = A[k] + i B[k]; stored conjugated so that the forward FFT
 		// evaluates the inverse transform ( ifft(Z) = conj( fft( conj Z ) ) ).  c2r ignores Im X[0], Im X[C].
-		float2 zc[E];
+		cf zc[E];
 		#pragma unroll
 		for( int q = 0; q < E; ++q )
 			{
 			const int k = lane + 64 * q;
 			if( C >= 64 || k < C )
 				{
-				float2 xk = buf[PAD( k )];
-				float2 xm = buf[PAD( C - k )];
+				cf xk = buf[PAD( k )];
+				cf xm = buf[PAD( C - k )];
 				if( k == 0 ) { xk.y = 0.0f; xm.y = 0.0f; }
 				// A = X[k] + conj X[C-k];  B = ( X[k] - conj X[C-k] ) * exp(+2 pi i k / N)
 				const float ax = xk.x + xm.x, ay = xk.y - xm.y;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize( SynthParams p )
 				const float c = w2[q].x, s = -w2[q].y;                         // conj of exp(-2 pi i k/N)
 				const float bx = __builtin_fmaf( c, dx, -( s * dy ) ), by = __builtin_fmaf( c, dy, s * dx );
 				// Z = A + iB = ( ax - by, ay + bx ); store conj
-				zc[q] = make_float2( ax - by, -( ay + bx ) );
+				zc[q] = mk( ax - by, -( ay + bx ) );
 				}
 			}
 		wave_sync();
@@ -371,7 +371,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize( SynthParams p )
 		// window and accumulate into the ring (AudioPV.cpp:133-134)
 		for( int n = lane; 2 * n < W; n += 64 )
 			{
-			const float2 g = buf[PAD( n )];
+			const cf g = buf[PAD( n )];
 			int i0 = ring_base + 2 * n; if( i0 >= W ) i0 -= W;
 			ring[i0] += g.x * s_win[2 * n];
 			if( 2 * n + 1 < W )

@@ -24,22 +24,22 @@ namespace flanhip {
 
 struct FastTables
 	{
-	const float2 * tw1;       // [15][16]        exp(-2 pi i r k / 256)
-	const float2 * tw3;       // [R3-1][256]     exp(-2 pi i r j / C)
-	const float2 * w2;        // [C]             exp(-2 pi i k / 2C)
+	const cf * tw1;       // [15][16]        exp(-2 pi i r k / 256)
+	const cf * tw3;       // [R3-1][256]     exp(-2 pi i r j / C)
+	const cf * w2;        // [C]             exp(-2 pi i k / 2C)
 	};
 
 __host__ __device__ constexpr int fast_tw1_len() { return 15 * 16; }
 __host__ __device__ constexpr int fast_tw3_len( int C ) { return ( C / 256 - 1 ) * 256; }
 
-// LDS carve (float2 units) shared by both kernels
+// LDS carve (cf units) shared by both kernels
 template<int LOG2C> struct FastLds
 	{
 	static constexpr int C = 1 << LOG2C;
 	static constexpr int TW1 = 0;
 	static constexpr int TW3 = TW1 + fast_tw1_len();
 	static constexpr int W2 = TW3 + fast_tw3_len( C );
-	static constexpr int WIN = W2 + C;                 // window as float2 pairs, C entries (2C floats, zero padded)
+	static constexpr int WIN = W2 + C;                 // window as cf pairs, C entries (2C floats, zero padded)
 	static constexpr int BUF = WIN + C;
 	static constexpr int BUF_LEN = C + C / 16 + 1;     // highest slot used is PAD( C ) = C + C/16 (synthesis parks X[C] there)
 	static constexpr int SUM_LEN = ( C / 64 + 1 ) * 64; // per-wave chain sums (doubles), fused analysis only
@@ -48,7 +48,7 @@ template<int LOG2C> struct FastLds
 
 // ---- the three FFT passes on the register array z[E] (natural layout in, natural layout out) -------------------
 template<int LOG2C>
-__device__ __forceinline__ void fft_fast( float2 ( &z )[( 1 << LOG2C ) / 64], float2 * buf, const float2 * s_tw1, const float2 * s_tw3, int lane )
+__device__ __forceinline__ void fft_fast( cf ( &z )[( 1 << LOG2C ) / 64], cf * buf, const cf * s_tw1, const cf * s_tw3, int lane )
 	{
 	constexpr int C = 1 << LOG2C;
 	constexpr int E = C / 64;
@@ -58,11 +58,11 @@ __device__ __forceinline__ void fft_fast( float2 ( &z )[( 1 << LOG2C ) / 64], fl
 
 	// pass 0: radix 16, sub-transform length 1 -> out[ j*16 + r ], j = lane + 64 b
 		{
-		float2 * wp = buf + 17 * lane;
+		cf * wp = buf + 17 * lane;
 		#pragma unroll
 		for( int b = 0; b < PER; ++b )
 			{
-			float2 v[16];
+			cf v[16];
 			#pragma unroll
 			for( int r = 0; r < 16; ++r ) v[r] = z[b + PER * r];
 			dft_reg<16>( v );
@@ -73,8 +73,8 @@ __device__ __forceinline__ void fft_fast( float2 ( &z )[( 1 << LOG2C ) / 64], fl
 	wave_sync();
 	// pass 1: radix 16, sub-transform length 16
 		{
-		float2 v[PER][16];
-		const float2 * rp = buf + padl;
+		cf v[PER][16];
+		const cf * rp = buf + padl;
 		#pragma unroll
 		for( int b = 0; b < PER; ++b )
 			{
@@ -82,8 +82,8 @@ __device__ __forceinline__ void fft_fast( float2 ( &z )[( 1 << LOG2C ) / 64], fl
 			for( int r = 0; r < 16; ++r ) v[b][r] = rp[68 * b + 68 * PER * r];
 			}
 		wave_sync();
-		const float2 * tp = s_tw1 + ( lane & 15 );
-		float2 * wp = buf + 17 * ( lane & ~15 ) + ( lane & 15 );
+		const cf * tp = s_tw1 + ( lane & 15 );
+		cf * wp = buf + 17 * ( lane & ~15 ) + ( lane & 15 );
 		#pragma unroll
 		for( int b = 0; b < PER; ++b )
 			{
@@ -97,12 +97,12 @@ __device__ __forceinline__ void fft_fast( float2 ( &z )[( 1 << LOG2C ) / 64], fl
 	wave_sync();
 	// pass 2: radix R3, sub-transform length 256; butterfly j = lane + 64 b, b < 4; result element j + 256 r = lane + 64 (b + 4 r)
 		{
-		const float2 * rp = buf + padl;
-		const float2 * tp = s_tw3 + lane;
+		const cf * rp = buf + padl;
+		const cf * tp = s_tw3 + lane;
 		#pragma unroll
 		for( int b = 0; b < 4; ++b )
 			{
-			float2 v[R3];
+			cf v[R3];
 			#pragma unroll
 			for( int r = 0; r < R3; ++r ) v[r] = rp[68 * b + 272 * r];
 			#pragma unroll
@@ -115,7 +115,7 @@ __device__ __forceinline__ void fft_fast( float2 ( &z )[( 1 << LOG2C ) / 64], fl
 	wave_sync();
 	}
 
-__device__ __forceinline__ void load_tables( float2 * s, const FastTables & t, const float * window, int W, float scale, int C, int tid, int nthreads )
+__device__ __forceinline__ void load_tables( cf * s, const FastTables & t, const float * window, int W, float scale, int C, int tid, int nthreads )
 	{
 	const int n1 = fast_tw1_len(), n3 = fast_tw3_len( C );
 	for( int i = tid; i < n1; i += nthreads ) s[i] = t.tw1[i];
@@ -145,15 +145,15 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 	constexpr int C = 1 << LOG2C;
 	constexpr int E = C / 64;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	float2 * s = reinterpret_cast<float2*>( smem );
+	cf * s = reinterpret_cast<cf*>( smem );
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	load_tables( s, tb, p.window, p.window_size, 1.0f, C, tid, 64 * WAVES );
 	__syncthreads();
-	const float2 * s_tw1 = s + L::TW1;
-	const float2 * s_tw3 = s + L::TW3;
-	const float2 * s_w2 = s + L::W2 + lane;
-	const float2 * s_win = s + L::WIN + lane;
-	float2 * buf = s + L::BUF + wave * L::BUF_LEN;
+	const cf * s_tw1 = s + L::TW1;
+	const cf * s_tw3 = s + L::TW3;
+	const cf * s_w2 = s + L::W2 + lane;
+	const cf * s_win = s + L::WIN + lane;
+	cf * buf = s + L::BUF + wave * L::BUF_LEN;
 
 	const int64_t chain = int64_t( blockIdx.x ) * WAVES + wave;
 	if( chain >= int64_t( p.chains_per_channel ) * p.num_channels ) return;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 	const bool w_whole = ( W & 127 ) == 0;
 	const bool use_wrapping = p.analysis_rate < p.sample_rate;                // phase_vocoder.cpp:37
 	const int padl = lane + ( lane >> 4 );
-	const float2 * mirror = buf + ( C * 17 ) / 16 - ( lane + ( ( lane + 15 ) >> 4 ) );   // PAD( M - lane ) = 17 M / 16 + this, M % 64 == 0
+	const cf * mirror = buf + ( C * 17 ) / 16 - ( lane + ( ( lane + 15 ) >> 4 ) );   // PAD( M - lane ) = 17 M / 16 + this, M % 64 == 0
 
 	// per-lane constants: bin frequency (PVBuffer.cpp:443-446), expected phase advance (phase_vocoder.cpp:47)
 	// (the division by dft, a power of two, is exactly a multiplication; bin_frequency is recomputed per use, 2 instructions)
@@ -186,7 +186,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 	struct __attribute__(( packed, aligned( 4 ) )) f2u { float x, y; };      // pair at any 4-byte aligned address
 	// (32-bit sample indices: the host routes channels of 2^31 samples or more to the generic kernel)
 	const int n32 = int( p.n );
-	auto load_raw = [&]( int64_t t, float2 ( &raw )[E] )
+	auto load_raw = [&]( int64_t t, cf ( &raw )[E] )
 		{
 		const int start = int( int64_t( hop ) * t - W / 2 );
 		#pragma unroll
@@ -194,7 +194,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 			{
 			const int a0c = min( max( start + 2 * ( lane + 64 * q ), 0 ), n32 - 2 );   // n >= 2 on this path (host check)
 			const f2u v = *reinterpret_cast<const f2u*>( x + a0c );
-			raw[q] = make_float2( v.x, v.y );
+			raw[q] = mk( v.x, v.y );
 			}
 		};
 	auto frame_is_interior = [&]( int64_t t )
@@ -202,7 +202,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 		const int64_t start = int64_t( hop ) * t - W / 2;
 		return w_whole && start >= 0 && start + 2 * int64_t( C ) <= p.n;
 		};
-	auto fix_raw = [&]( int64_t t, float2 ( &raw )[E] )
+	auto fix_raw = [&]( int64_t t, cf ( &raw )[E] )
 		{
 		const int start = int( int64_t( hop ) * t - W / 2 );
 		#pragma unroll
@@ -215,19 +215,19 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 			float v1 = ( d == 0 ) ? raw[q].y : ( d == -1 ? raw[q].x : 0.0f );
 			if( s0 >= W ) v0 = 0.0f;                                             // AudioPV.cpp:65 (also keeps Inf * 0 out)
 			if( s0 + 1 >= W ) v1 = 0.0f;
-			raw[q] = make_float2( v0, v1 );
+			raw[q] = mk( v0, v1 );
 			}
 		};
 	// window (AudioPV.cpp:60; the table is zero beyond W, :65), transform, and leave Z both in z[] and (natural order) in
 	// buf[] for the mirror reads
-	auto transform_frame = [&]( int64_t t, float2 ( &z )[E] )
+	auto transform_frame = [&]( int64_t t, cf ( &z )[E] )
 		{
 		if( !frame_is_interior( t ) ) fix_raw( t, z );
 		#pragma unroll
 		for( int q = 0; q < E; ++q )
 			{
-			const float2 w = s_win[64 * q];
-			z[q] = make_float2( z[q].x * w.x, z[q].y * w.y );
+			const cf w = s_win[64 * q];
+			z[q] = mk( z[q].x * w.x, z[q].y * w.y );
 			}
 		fft_fast<LOG2C>( z, buf, s_tw1, s_tw3, lane );
 		#pragma unroll
@@ -236,11 +236,11 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 		};
 
 	// bin k = lane + 64 q of the real transform from Z[k] (own register) and Z[C-k] (mirror lane, through LDS)
-	auto split_bin = [&]( const float2 ( &z )[E], int q, float2 z0, float & re, float & im )
+	auto split_bin = [&]( const cf ( &z )[E], int q, cf z0, float & re, float & im )
 		{
-		const float2 zk = z[q];
-		const float2 zm = mirror[-68 * q];                                    // k = 0 reads a junk slot, overridden below
-		const float2 w = s_w2[64 * q];
+		const cf zk = z[q];
+		const cf zm = mirror[-68 * q];                                    // k = 0 reads a junk slot, overridden below
+		const cf w = s_w2[64 * q];
 		const float ax = 0.5f * ( zk.x + zm.x ), ay = 0.5f * ( zk.y - zm.y );
 		const float dx = zk.x - zm.x, dy = zk.y + zm.y;
 		re = ax + 0.5f * __builtin_fmaf( w.x, dy, w.y * dx );
@@ -260,13 +260,13 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 		}
 	bool bad = false;
 
-	float2 z[E], zn[E];
+	cf z[E], zn[E];
 	if( t0 > 0 )
 		{
 		// halo: only the phases of frame t0-1 are needed (phase_vocoder.cpp:45 leaves them in phase_buffer)
 		load_raw( t0 - 1, z );
 		transform_frame( t0 - 1, z );
-		const float2 z0 = buf[0];
+		const cf z0 = buf[0];
 		load_raw( t0, zn );
 		#pragma unroll
 		for( int q = 0; q < E; ++q )
@@ -285,10 +285,10 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 		#pragma unroll
 		for( int q = 0; q < E; ++q ) z[q] = zn[q];
 		transform_frame( t, z );
-		const float2 z0 = buf[0];
+		const cf z0 = buf[0];
 		load_raw( min( t + 1, t1 - 1 ), zn );                                  // prefetch (the last frame re-reads itself): in flight during the per-bin math below
-		float2 * row = reinterpret_cast<float2*>( p.out + ( int64_t( channel ) * p.F + t ) * ( C + 1 ) );
-		float2 * rowp = row + lane;
+		cf * row = reinterpret_cast<cf*>( p.out + ( int64_t( channel ) * p.F + t ) * ( C + 1 ) );
+		cf * rowp = row + lane;
 		#pragma unroll
 		for( int q = 0; q < E; ++q )
 			{
@@ -302,7 +302,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 			const float wrapped = use_wrapping ? delta_phase - FLANHIP_PI2_F * roundf( div_pi2( delta_phase ) ) : delta_phase;
 			const float delta_frequency = div_pi2( wrapped * p.analysis_rate );
 			const float m = magnitude_scaled( re, im ), f = bin_frequency( q ) + delta_frequency;
-			rowp[64 * q] = make_float2( m, f );
+			rowp[64 * q] = mk( m, f );
 			if constexpr( SUMS )
 				{
 				s_sum[64 * q] += double( div_c( f, p.ar_div ) * FLANHIP_PI2_F );     // phase_vocoder.cpp:57-58
@@ -318,7 +318,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 			const float wrapped = use_wrapping ? delta_phase - FLANHIP_PI2_F * roundf( div_pi2( delta_phase ) ) : delta_phase;
 			const float delta_frequency = div_pi2( wrapped * p.analysis_rate );
 			const float f = bin_frequency( E ) + delta_frequency;
-			row[C] = make_float2( __builtin_fabsf( re ), f );   // every lane holds the same Nyquist value: an unconditional store keeps the
+			row[C] = mk( __builtin_fabsf( re ), f );   // every lane holds the same Nyquist value: an unconditional store keeps the
 			                                                    // number of outstanding memory operations static (counted s_waitcnt, no drain)
 			if constexpr( SUMS )
 				{
@@ -353,15 +353,15 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 	constexpr int C = 1 << LOG2C;
 	constexpr int E = C / 64;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	float2 * s = reinterpret_cast<float2*>( smem );
+	cf * s = reinterpret_cast<cf*>( smem );
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	load_tables( s, tb, p.window, p.window_size, p.window_scale, C, tid, 64 * WAVES );   // AudioPV.cpp:102: hann * window_scale
 	__syncthreads();
-	const float2 * s_tw1 = s + L::TW1;
-	const float2 * s_tw3 = s + L::TW3;
-	const float2 * s_w2 = s + L::W2 + lane;
-	const float2 * s_win = s + L::WIN + lane;
-	float2 * buf = s + L::BUF + wave * L::BUF_LEN;
+	const cf * s_tw1 = s + L::TW1;
+	const cf * s_tw3 = s + L::TW3;
+	const cf * s_w2 = s + L::W2 + lane;
+	const cf * s_win = s + L::WIN + lane;
+	cf * buf = s + L::BUF + wave * L::BUF_LEN;
 
 	const int64_t chain = int64_t( blockIdx.x ) * WAVES + wave;
 	if( chain >= int64_t( p.chains_per_channel ) * p.num_channels ) return;
@@ -372,26 +372,26 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 	const bool last_chain = chain_in_channel == p.chains_per_channel - 1;
 	const int W = p.window_size;
 	constexpr int hop = 128 * HOPQ;
-	// everything below is in float2 units (sample pairs): positions are even because hop, W/2... are multiples of 64
-	float2 * out2 = reinterpret_cast<float2*>( p.out + int64_t( channel ) * p.out_len );
-	float2 * head2 = reinterpret_cast<float2*>( p.head + chain * p.head_len );
+	// everything below is in cf units (sample pairs): positions are even because hop, W/2... are multiples of 64
+	cf * out2 = reinterpret_cast<cf*>( p.out + int64_t( channel ) * p.out_len );
+	cf * head2 = reinterpret_cast<cf*>( p.head + chain * p.head_len );
 	const int64_t chain_start = int64_t( hop ) * t0 - W / 2;
 	const int64_t own_start = chain_in_channel == 0 ? INT64_MIN : chain_start + p.head_len;
 	const int padl = lane + ( lane >> 4 );
-	const float2 * mirror = buf + ( C * 17 ) / 16 - ( lane + ( ( lane + 15 ) >> 4 ) );
+	const cf * mirror = buf + ( C * 17 ) / 16 - ( lane + ( ( lane + 15 ) >> 4 ) );
 
 	double ph[E + 1];                                                          // phase_buffer (AudioPV.cpp:105) on entry to the chain
 	#pragma unroll
 	for( int q = 0; q <= E; ++q ) ph[q] = p.carry[chain * ( C + 1 ) + ( q < E ? lane + 64 * q : C )];
-	float2 acc[E];                                                             // overlap-add accumulator: acc[q] <-> samples pos + 128 q + 2 lane (+1)
+	cf acc[E];                                                             // overlap-add accumulator: acc[q] <-> samples pos + 128 q + 2 lane (+1)
 	#pragma unroll
-	for( int q = 0; q < E; ++q ) acc[q] = make_float2( 0.0f, 0.0f );
+	for( int q = 0; q < E; ++q ) acc[q] = mk( 0.0f, 0.0f );
 
 	// one 128-sample step of finished (or partial) output leaves the chain
 	// Exactly one store instruction per step, never inside a branch (static count of outstanding memory operations, see
 	// k_analyze_fast): lanes that fall outside the output are pointed at a 512-byte dump area in the workspace.
-	float2 * dump2 = reinterpret_cast<float2*>( p.dump ) + lane;
-	auto emit_step = [&]( int64_t a0, float2 v )
+	cf * dump2 = reinterpret_cast<cf*>( p.dump ) + lane;
+	auto emit_step = [&]( int64_t a0, cf v )
 		{
 		const int64_t a = a0 + 2 * lane;
 #ifndef FLANHIP_STATIC_EMIT   /* measured: the branchy form is 10 % faster than redirecting out-of-range lanes to a dump area */
@@ -399,41 +399,41 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 		if( a0 < own_start ) head2[( a - chain_start ) >> 1] = v;
 		else if( a >= 0 && a < p.out_len ) out2[a >> 1] = v;
 #else
-		float2 * dst = ( a0 < own_start ) ? head2 + ( ( a - chain_start ) >> 1 ) : out2 + ( a >> 1 );
+		cf * dst = ( a0 < own_start ) ? head2 + ( ( a - chain_start ) >> 1 ) : out2 + ( a >> 1 );
 		if( a0 >= own_start && !( a >= 0 && a < p.out_len ) ) dst = dump2;
 		*dst = v;
 #endif
 		};
 
 	// MF row of frame t in the natural layout ( m, f ) of bin lane + 64 q; loaded one frame ahead of its use
-	auto load_row = [&]( int64_t t, float2 ( &mfr )[E], float2 & mfny )
+	auto load_row = [&]( int64_t t, cf ( &mfr )[E], cf & mfny )
 		{
-		const float2 * row = reinterpret_cast<const float2*>( p.pv + ( int64_t( channel ) * p.F + t ) * ( C + 1 ) );
-		const float2 * rowp = row + lane;
+		const cf * row = reinterpret_cast<const cf*>( p.pv + ( int64_t( channel ) * p.F + t ) * ( C + 1 ) );
+		const cf * rowp = row + lane;
 		#pragma unroll
 		for( int q = 0; q < E; ++q ) mfr[q] = rowp[64 * q];
 		mfny = row[C];
 		};
-	float2 mfr[E], mfny;
+	cf mfr[E], mfny;
 	load_row( t0, mfr, mfny );
 
 	int64_t pos = chain_start;
 	for( int64_t t = t0; t < t1; ++t )
 		{
 		// ---- inverse phase vocoder per bin (AudioPV.cpp:117-120, phase_vocoder.cpp:55-61)
-		float2 z[E];
+		cf z[E];
 		float mn;
 		bool slow = false;
 		#pragma unroll
 		for( int q = 0; q < E; ++q )
 			{
-			const float2 mf = mfr[q];                                           // ( m, f )
+			const cf mf = mfr[q];                                           // ( m, f )
 			ph[q] += double( div_c( mf.y, p.ar_div ) * FLANHIP_PI2_F );          // phase_vocoder.cpp:57-58
 			slow |= !( __builtin_fabs( ph[q] ) < double( FLANHIP_SINCOS_FAST_LIMIT ) );
 			z[q].x = mf.x;
 			}
 			{
-			const float2 mf = mfny;
+			const cf mf = mfny;
 			ph[E] += double( div_c( mf.y, p.ar_div ) * FLANHIP_PI2_F );
 			slow |= !( __builtin_fabs( ph[E] ) < double( FLANHIP_SINCOS_FAST_LIMIT ) );
 			mn = mf.x;
@@ -443,7 +443,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 #else
 		load_row( min( t + 1, t1 - 1 ), mfr, mfny );                            // prefetch (the last frame re-reads itself): in flight during the transform below
 #endif
-		float2 xn;
+		cf xn;
 		if( __any( slow ) )
 			{
 			// a phase outside the range the fast helpers are exact for (or a NaN): the general routines for this frame
@@ -452,11 +452,11 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 				{
 				ph[q] = fold_phase_any( ph[q] );
 				const float2 sc = sincos_wide( float( ph[q] ) );
-				z[q] = make_float2( z[q].x * sc.y, z[q].x * sc.x );
+				z[q] = mk( z[q].x * sc.y, z[q].x * sc.x );
 				}
 			ph[E] = fold_phase_any( ph[E] );
 			const float2 sc = sincos_wide( float( ph[E] ) );
-			xn = make_float2( mn * sc.y, mn * sc.x );
+			xn = mk( mn * sc.y, mn * sc.x );
 			}
 		else
 			{
@@ -466,13 +466,13 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 				ph[q] = fold_phase_fast( ph[q] );                               // phase_vocoder.cpp:59
 				float sn, cs;
 				sincos_fast( float( ph[q] ), sn, cs );
-				z[q] = make_float2( z[q].x * cs, z[q].x * sn );                 // std::polar, :60
+				z[q] = mk( z[q].x * cs, z[q].x * sn );                 // std::polar, :60
 				__builtin_amdgcn_sched_barrier( 0 );                            // one bin at a time: keeps the temporaries of 16 bins from overlapping
 				}
 			ph[E] = fold_phase_fast( ph[E] );
 			float sn, cs;
 			sincos_fast( float( ph[E] ), sn, cs );
-			xn = make_float2( mn * cs, mn * sn );
+			xn = mk( mn * cs, mn * sn );
 			}
 		// ---- merge X[0..C] into the half-size spectrum: needs X[k] (own) and X[C-k] (mirror lane): one LDS exchange
 		#pragma unroll
@@ -482,15 +482,15 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 		#pragma unroll
 		for( int q = 0; q < E; ++q )
 			{
-			float2 xk = z[q];
-			float2 xm = mirror[-68 * q];                                        // X[ C - k ]; k = 0 pairs with X[C]
+			cf xk = z[q];
+			cf xm = mirror[-68 * q];                                        // X[ C - k ]; k = 0 pairs with X[C]
 			if( q == 0 ) { xk.y = ( lane == 0 ) ? 0.0f : xk.y; xm.y = ( lane == 0 ) ? 0.0f : xm.y; }   // c2r ignores Im X[0], Im X[C]
-			const float2 w = s_w2[64 * q];
+			const cf w = s_w2[64 * q];
 			const float ax = xk.x + xm.x, ay = xk.y - xm.y;                     // A = X[k] + conj X[C-k]
 			const float dx = xk.x - xm.x, dy = xk.y + xm.y;                     // D = X[k] - conj X[C-k]
 			const float c = w.x, sgn = -w.y;                                    // exp(+2 pi i k / N)
 			const float bx = __builtin_fmaf( c, dx, -( sgn * dy ) ), by = __builtin_fmaf( c, dy, sgn * dx );
-			z[q] = make_float2( ax - by, -( ay + bx ) );                        // conj( A + iB ): forward FFT of it = conj of the inverse
+			z[q] = mk( ax - by, -( ay + bx ) );                        // conj( A + iB ): forward FFT of it = conj of the inverse
 			__builtin_amdgcn_sched_barrier( 0 );
 			}
 		wave_sync();
@@ -499,14 +499,14 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 		#pragma unroll
 		for( int q = 0; q < E; ++q )
 			{
-			const float2 w = s_win[64 * q];                                     // zero beyond W
+			const cf w = s_win[64 * q];                                     // zero beyond W
 			acc[q].x += z[q].x * w.x;
 			acc[q].y += ( -z[q].y ) * w.y;
 			}
 		#pragma unroll
 		for( int q = 0; q < HOPQ; ++q ) emit_step( pos + 128 * q, acc[q] );
 		#pragma unroll
-		for( int q = 0; q < E; ++q ) acc[q] = ( q + HOPQ < E ) ? acc[q + HOPQ] : make_float2( 0.0f, 0.0f );
+		for( int q = 0; q < E; ++q ) acc[q] = ( q + HOPQ < E ) ? acc[q + HOPQ] : mk( 0.0f, 0.0f );
 		pos += hop;
 		}
 	// flush the partial sums that the next chain's head completes; the last chain zero-fills to the end of the output
@@ -518,7 +518,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 		const int64_t a0 = pos + 128 * q;
 		if( a0 < flush_end ) emit_step( a0, acc[q] );
 		}
-	for( int64_t a0 = pos + 128 * E; a0 < flush_end; a0 += 128 ) emit_step( a0, make_float2( 0.0f, 0.0f ) );
+	for( int64_t a0 = pos + 128 * E; a0 < flush_end; a0 += 128 ) emit_step( a0, mk( 0.0f, 0.0f ) );
 	}
 
 // ---- pre-pass kernels (all sizes) --------------------------------------------------------------------------------
@@ -536,11 +536,11 @@ __global__ __launch_bounds__( 256 ) void k_phase_sums2( SynthParams p )
 	if( k < p.num_bins )
 		{
 		double ph = 0.0;
-		const float2 * col = reinterpret_cast<const float2*>( p.pv + ( int64_t( channel ) * p.F + t0 ) * p.num_bins + k );
+		const cf * col = reinterpret_cast<const cf*>( p.pv + ( int64_t( channel ) * p.F + t0 ) * p.num_bins + k );
 		int i = 0;
 		for( ; i + 8 <= n; i += 8 )
 			{
-			float2 v[8];
+			cf v[8];
 			#pragma unroll
 			for( int u = 0; u < 8; ++u ) v[u] = col[int64_t( i + u ) * p.num_bins];
 			#pragma unroll
@@ -553,7 +553,7 @@ __global__ __launch_bounds__( 256 ) void k_phase_sums2( SynthParams p )
 			}
 		for( ; i < n; ++i )
 			{
-			const float2 v = col[int64_t( i ) * p.num_bins];
+			const cf v = col[int64_t( i ) * p.num_bins];
 			bad |= !( __builtin_fabsf( v.x ) <= 3.4028235e38f ) || !( __builtin_fabsf( v.y ) <= 3.4028235e38f );
 			ph += double( div_c( v.y, p.ar_div ) * FLANHIP_PI2_F );
 			}
