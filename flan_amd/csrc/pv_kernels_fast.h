@@ -269,11 +269,13 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 		const cf z0 = buf[0];
 		load_raw( t0, zn );
 		#pragma unroll
-		for( int q = 0; q < E; ++q )
+		for( int q = 0; q < E; q += 2 )
 			{
-			float re, im;
-			split_bin( z, q, z0, re, im );
-			prev[q] = atan2_fast( im, re );
+			float re0, im0, re1, im1;
+			split_bin( z, q, z0, re0, im0 );
+			split_bin( z, q + 1, z0, re1, im1 );
+			const cf ph2 = atan2_fast_2( cf{ im0, im1 }, cf{ re0, re1 } );
+			prev[q] = ph2.x; prev[q + 1] = ph2.y;
 			}
 		prev[E] = atan2_fast( 0.0f, z0.x - z0.y );
 		wave_sync();
@@ -290,23 +292,36 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 		cf * row = reinterpret_cast<cf*>( p.out + ( int64_t( channel ) * p.F + t ) * ( C + 1 ) );
 		cf * rowp = row + lane;
 		#pragma unroll
-		for( int q = 0; q < E; ++q )
+		for( int q = 0; q < E; q += 2 )
 			{
-			float re, im;
-			split_bin( z, q, z0, re, im );
+			// two bins per iteration (k = lane + 64 q and k + 64), evaluated as one packed stream (pv_math.h)
+			float re0, im0, re1, im1;
+			split_bin( z, q, z0, re0, im0 );
+			split_bin( z, q + 1, z0, re1, im1 );
+			const cf re = cf{ re0, re1 }, im = cf{ im0, im1 };
 			// phase_vocoder.cpp:37-52 (AudioPV.cpp:69-73)
-			const float phase = atan2_fast( im, re );
-			const float phase_diff = float( double( phase ) - double( prev[q] ) );
-			prev[q] = phase;
-			const float delta_phase = phase_diff - expected_advance( q );
-			const float wrapped = use_wrapping ? delta_phase - FLANHIP_PI2_F * roundf( div_pi2( delta_phase ) ) : delta_phase;
-			const float delta_frequency = div_pi2( wrapped * p.analysis_rate );
-			const float m = magnitude_scaled( re, im ), f = bin_frequency( q ) + delta_frequency;
-			rowp[64 * q] = mk( m, f );
+			const cf phase = atan2_fast_2( im, re );
+			const cf phase_diff = phase - cf{ prev[q], prev[q + 1] };           // == float( double(phase) - double(prev) ), :44
+			prev[q] = phase.x; prev[q + 1] = phase.y;                            // :45
+			const cf binf = cf{ bin_frequency( q ), bin_frequency( q + 1 ) };
+			const cf delta_phase = phase_diff - div_c_2( binf, p.ar_div ) * bcast2( FLANHIP_PI2_F );          // :47-48
+			cf wrapped = delta_phase;
+			if( use_wrapping )
+				{
+				const cf turns = div_pi2_2( delta_phase );
+				wrapped = delta_phase - bcast2( FLANHIP_PI2_F ) * cf{ roundf( turns.x ), roundf( turns.y ) };    // :39-42,49
+				}
+			const cf f = binf + div_pi2_2( wrapped * bcast2( p.analysis_rate ) );                             // :50-52
+			const cf m = magnitude_scaled_2( re, im );
+			rowp[64 * q] = cf{ m.x, f.x };
+			rowp[64 * q + 64] = cf{ m.y, f.y };
 			if constexpr( SUMS )
 				{
-				s_sum[64 * q] += double( div_c( f, p.ar_div ) * FLANHIP_PI2_F );     // phase_vocoder.cpp:57-58
-				bad |= !( __builtin_fabsf( m ) <= 3.4028235e38f ) || !( __builtin_fabsf( f ) <= 3.4028235e38f );
+				const cf term = div_c_2( f, p.ar_div ) * bcast2( FLANHIP_PI2_F );                            // phase_vocoder.cpp:57-58
+				s_sum[64 * q] += double( term.x );
+				s_sum[64 * q + 64] += double( term.y );
+				bad |= !( __builtin_fabsf( m.x ) <= 3.4028235e38f ) || !( __builtin_fabsf( f.x ) <= 3.4028235e38f )
+				    || !( __builtin_fabsf( m.y ) <= 3.4028235e38f ) || !( __builtin_fabsf( f.y ) <= 3.4028235e38f );
 				}
 			}
 			{
@@ -461,13 +476,17 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 		else
 			{
 			#pragma unroll
-			for( int q = 0; q < E; ++q )
+			for( int q = 0; q < E; q += 2 )
 				{
 				ph[q] = fold_phase_fast( ph[q] );                               // phase_vocoder.cpp:59
-				float sn, cs;
-				sincos_fast( float( ph[q] ), sn, cs );
-				z[q] = mk( z[q].x * cs, z[q].x * sn );                 // std::polar, :60
-				__builtin_amdgcn_sched_barrier( 0 );                            // one bin at a time: keeps the temporaries of 16 bins from overlapping
+				ph[q + 1] = fold_phase_fast( ph[q + 1] );
+				cf sn, cs;
+				sincos_fast_2( cf{ float( ph[q] ), float( ph[q + 1] ) }, sn, cs );
+				const cf m2 = cf{ z[q].x, z[q + 1].x };
+				const cf xr = m2 * cs, xi = m2 * sn;                             // std::polar, :60
+				z[q] = cf{ xr.x, xi.x };
+				z[q + 1] = cf{ xr.y, xi.y };
+				__builtin_amdgcn_sched_barrier( 0 );                            // two bins at a time: keeps the temporaries of 16 bins from overlapping
 				}
 			ph[E] = fold_phase_fast( ph[E] );
 			float sn, cs;
