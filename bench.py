@@ -166,8 +166,17 @@ def main():
         else:
             kname, tk, b = "k_synthesize", t_sy_main, BYTES_SYNTHESIS
         achieved = frames_per_step * b / (tk * 1e-3) / 1e9
+        # HBM bytes per launch of that kernel from the committed PMC profile of this same workload (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE, corrected as profiles/r01_hbm_traffic.json explains); null for any other workload shape
+        traffic = None
+        try:
+            if ch == 8 and abs(args.seconds - 60.0) < 1e-9:
+                with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as fh:
+                    traffic = json.load(fh)[kname]["traffic_bytes"]
+        except Exception:
+            traffic = None
         roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "launch_ms": round(tk, 4), "algorithmic_bytes_per_launch": frames_per_step * b}
         extra["roundtrip_hbm"] = {"achieved_GBs": round(frames_per_step * BYTES_ROUNDTRIP / (ms_per_step * 1e-3) / 1e9, 1),
                                   "frac_of_8TBs": round(frames_per_step * BYTES_ROUNDTRIP / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
