@@ -21,18 +21,41 @@ __device__ __forceinline__ float frequency_to_bin( float f, float sr, float dft 
 __device__ __forceinline__ float bin_to_frequency( float b, float sr, float dft ) { return b * sr / dft; }
 
 // modify_time_base, PVModify.cpp:319-359 (linear Interpolator, Utility/Interpolator.cpp:50-56).  out is zeroed by the caller.
-__global__ __launch_bounds__( 256 ) void k_modify_time( const MFd * in, int num_channels, int64_t F, int bins, float sr, float hop,
-	const float * mod, int64_t Fo, MFd * out )
+//
+// The reference walks each (channel, bin) column frame pair by frame pair and ACCUMULATES into the output frames
+// [ceil(l), ceil(r)) the pair maps to -- order dependent in general.  But where the map of a bin never runs backwards
+// (r >= l for every pair: every stretch / slow-down / speed-up) those intervals are disjoint, every output frame receives
+// at most one contribution, and the pairs can be processed in any order: such columns are cut into `segments` runs of
+// frame pairs handled by different threads, with the reference's loop body unchanged.  Columns whose map does run backwards
+// (flag set by k_time_map_flags) are walked by one thread in the reference order.
+__global__ __launch_bounds__( 256 ) void k_time_map_flags( const float * mod, int64_t F, int bins, float sr, float hop, int * nonmono )
 	{
 	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
-	if( idx >= int64_t( num_channels ) * bins ) return;
-	const int channel = int( idx / bins ), bin = int( idx % bins );
+	if( idx >= ( F - 1 ) * bins ) return;
+	const int64_t frame = idx / bins + 1;
+	const int bin = int( idx % bins );
+	const float l = time_to_frame( mod[( frame - 1 ) * bins + bin], sr, hop );
+	const float r = time_to_frame( mod[frame * bins + bin], sr, hop );
+	if( !( r >= l ) ) nonmono[bin] = 1;                                            // backwards, or NaN
+	}
+
+__global__ __launch_bounds__( 256 ) void k_modify_time( const MFd * in, int num_channels, int64_t F, int bins, float sr, float hop,
+	const float * mod, int64_t Fo, MFd * out, const int * nonmono, int segments, int64_t seg_len )
+	{
+	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
+	const int64_t columns = int64_t( num_channels ) * bins;
+	if( idx >= columns * segments ) return;
+	const int seg = int( idx / columns );
+	const int channel = int( ( idx % columns ) / bins ), bin = int( idx % bins );
+	int64_t f0 = 1 + seg * seg_len, f1 = min( F, f0 + seg_len );
+	if( nonmono[bin] ) { if( seg != 0 ) return; f0 = 1; f1 = F; }                  // order matters for this column: one thread, all pairs
+	if( f0 >= f1 ) return;
 	const MFd * ip = in + int64_t( channel ) * F * bins + bin;
 	MFd * op = out + int64_t( channel ) * Fo * bins + bin;
 	const float * mp = mod + bin;
-	MFd lMF = ip[0];
-	float lFrame = time_to_frame( mp[0], sr, hop );
-	for( int64_t frame = 1; frame < F; ++frame )                                   // :328
+	MFd lMF = ip[( f0 - 1 ) * bins];
+	float lFrame = time_to_frame( mp[( f0 - 1 ) * bins], sr, hop );
+	for( int64_t frame = f0; frame < f1; ++frame )                                  // :328
 		{
 		const MFd rMF = ip[frame * bins];
 		const float rFrame = time_to_frame( mp[frame * bins], sr, hop );            // :331
@@ -59,35 +82,69 @@ __global__ __launch_bounds__( 256 ) void k_modify_time( const MFd * in, int num_
 
 // PV::stretch, PVModify.cpp:376-382: inclusive running sum over frames per bin in fp32 (sequential order = the
 // reference's rounding), then frame_to_time; also the maximum of the result (FunctionSample::maximum, :312).
+// A block owns 64 bins: tiles of 64 frames x 64 bins go through LDS so that all 256 threads move memory (coalesced rows)
+// while 64 of them carry the running sums down the tile.
 __global__ __launch_bounds__( 256 ) void k_stretch_map( float * factor, int64_t F, int bins, float sr, float hop, float * d_max )
 	{
-	const int bin = blockIdx.x * blockDim.x + threadIdx.x;
-	float mx = -INFINITY;
-	if( bin < bins )
+	constexpr int TB = 64, TF = 64;
+	__shared__ float tile[TF][TB + 1];
+	const int bin0 = blockIdx.x * TB;
+	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;                         // 64 bins x 4 rows per pass
+	float run = 0.0f, mx = -INFINITY;
+	for( int64_t fbase = 0; fbase < F; fbase += TF )
 		{
-		float run = 0.0f;
-		float * p = factor + bin;
-		for( int64_t frame = 0; frame < F; ++frame, p += bins )
+		#pragma unroll
+		for( int r = ty; r < TF; r += 4 )
 			{
-			run = ( frame == 0 ) ? *p : *p + run;                                   // factor[frame] += factor[frame-1]
-			const float t = frame_to_time( run, sr, hop );
-			*p = t;
-			mx = fmaxf( mx, t );
+			const int64_t f = fbase + r;
+			tile[r][tx] = ( f < F && bin0 + tx < bins ) ? factor[f * bins + bin0 + tx] : 0.0f;
 			}
-		}
-	for( int o = 32; o > 0; o >>= 1 ) mx = fmaxf( mx, __shfl_xor( mx, o ) );
-	if( d_max && ( threadIdx.x & 63 ) == 0 && mx > -INFINITY )
-		{
-		// float max through an order-preserving integer key
-		int * addr = reinterpret_cast<int*>( d_max );
-		int old = *addr;
-		while( true )
+		__syncthreads();
+		if( ty == 0 )
 			{
-			const float cur = __int_as_float( old );
-			if( !( mx > cur ) ) break;
-			const int prev = atomicCAS( addr, old, __float_as_int( mx ) );
-			if( prev == old ) break;
-			old = prev;
+			// the only sequential part: 64 dependent fp32 additions per column and tile
+			#pragma unroll
+			for( int r = 0; r < TF; ++r )
+				{
+				run = ( fbase + r == 0 ) ? tile[r][tx] : tile[r][tx] + run;                // factor[frame] += factor[frame-1]
+				tile[r][tx] = run;
+				}
+			}
+		__syncthreads();
+		#pragma unroll
+		for( int r = ty; r < TF; r += 4 )
+			{
+			const int64_t f = fbase + r;
+			if( f < F && bin0 + tx < bins )
+				{
+				const float t = frame_to_time( tile[r][tx], sr, hop );                     // PVModify.cpp:381-382
+				factor[f * bins + bin0 + tx] = t;
+				mx = fmaxf( mx, t );
+				}
+			}
+		__syncthreads();
+		}
+	// reduce the maximum over the block's 4 waves through LDS, then over the 64 lanes
+	__shared__ float wmax[4][64];
+	wmax[ty][tx] = mx;
+	__syncthreads();
+	if( ty == 0 )
+		{
+		mx = fmaxf( fmaxf( wmax[0][tx], wmax[1][tx] ), fmaxf( wmax[2][tx], wmax[3][tx] ) );
+		if( bin0 + tx >= bins ) mx = -INFINITY;
+		for( int o = 32; o > 0; o >>= 1 ) mx = fmaxf( mx, __shfl_xor( mx, o ) );
+		if( d_max && tx == 0 && mx > -INFINITY )
+			{
+			int * addr = reinterpret_cast<int*>( d_max );
+			int old = *addr;
+			while( true )
+				{
+				const float cur = __int_as_float( old );
+				if( !( mx > cur ) ) break;
+				const int prev = atomicCAS( addr, old, __float_as_int( mx ) );
+				if( prev == old ) break;
+				old = prev;
+				}
 			}
 		}
 	}
@@ -122,22 +179,33 @@ __global__ __launch_bounds__( 256 ) void k_repitch_lerp( const MFd * in, int64_t
 	in_modified[idx] = lo_freq * ( 1.0f - r ) + hi_freq * r;
 	}
 
-// modify_frequency_base, PVModify.cpp:207-253.  out is zeroed by the caller.  One lane per (channel, frame).
-__global__ __launch_bounds__( 64 ) void k_modify_frequency( const MFd * in, int num_channels, int64_t F, int bins, float sr, float dft,
+// modify_frequency_base, PVModify.cpp:207-253.  out is zeroed by the caller.  One WAVEFRONT per (channel, frame) row.
+// Same argument as k_modify_time: when the bin map of a row never runs backwards (hiBin >= loBin for every adjacent pair --
+// any repitch by positive factors) the output intervals [ceil(lo), ceil(hi)) of the pairs are disjoint, each output bin is
+// touched at most once and the 1024 pairs of the row are independent: the lanes take them 64 at a time.  A row whose map
+// does run backwards is walked by lane 0 in the reference order.
+__global__ __launch_bounds__( 256 ) void k_modify_frequency( const MFd * in, int num_channels, int64_t F, int bins, float sr, float dft,
 	const float * mod, const float * in_modified, MFd * out )
 	{
-	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
+	const int lane = threadIdx.x & 63;
+	const int64_t idx = int64_t( blockIdx.x ) * ( blockDim.x >> 6 ) + ( threadIdx.x >> 6 );
 	if( idx >= int64_t( num_channels ) * F ) return;
 	const int64_t frame = idx % F;
 	const MFd * row = in + idx * bins;
 	MFd * orow = out + idx * bins;
 	const float * mrow = mod + frame * bins;
 	const float * irow = in_modified + idx * bins;
-	float loBin = frequency_to_bin( mrow[0], sr, dft );
-	MFd loMF = { row[0].m, irow[0] };
-	for( int bin = 1; bin < bins; ++bin )                                           // :214
+
+	bool backwards = false;
+	for( int bin = 1 + lane; bin < bins; bin += 64 )
+		backwards |= !( frequency_to_bin( mrow[bin], sr, dft ) >= frequency_to_bin( mrow[bin - 1], sr, dft ) );
+	const bool sequential = __any( backwards );
+
+	auto pair = [&]( int bin )                                                      // :214-244 for the pair ( bin-1, bin )
 		{
+		const float loBin = frequency_to_bin( mrow[bin - 1], sr, dft );             // :218
 		const float hiBin = frequency_to_bin( mrow[bin], sr, dft );                 // :219
+		const MFd loMF = { row[bin - 1].m, irow[bin - 1] };                         // :227
 		const MFd hiMF = { row[bin].m, irow[bin] };                                 // :228
 		const bool forward = hiBin > loBin;                                         // :220
 		const int loR = int( forward ? ceilf( loBin ) : floorf( loBin ) );          // :222
@@ -158,7 +226,14 @@ __global__ __launch_bounds__( 64 ) void k_modify_frequency( const MFd * in, int 
 				orow[y] = o;
 				}
 			}
-		loBin = hiBin; loMF = hiMF;
+		};
+	if( !sequential )
+		{
+		for( int bin = 1 + lane; bin < bins; bin += 64 ) pair( bin );
+		}
+	else if( lane == 0 )
+		{
+		for( int bin = 1; bin < bins; ++bin ) pair( bin );
 		}
 	}
 
@@ -218,10 +293,24 @@ int flanhip_modify_time_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int
 	FLANHIP_REQUIRE( d_mod && hop >= 1 && Fo > 0, FLANHIP_ERR_INVALID_ARG, "bad map / output length" );
 	hipStream_t s = (hipStream_t) stream;
 	FLANHIP_CHECK( hipMemsetAsync( d_out, 0, sizeof( flanhip_MF ) * size_t( ch ) * Fo * bins, s ) );   // clear_buffer, PVModify.cpp:317
-	const int64_t threads = ch * bins;
+	int * d_flags = nullptr;                                                       // per bin: does the time map ever run backwards?
+	FLANHIP_CHECK( hipMallocAsync( reinterpret_cast<void**>( &d_flags ), sizeof( int ) * bins, s ) );
+	FLANHIP_CHECK( hipMemsetAsync( d_flags, 0, sizeof( int ) * bins, s ) );
+	if( F > 1 )
+		{
+		const int64_t pairs = ( F - 1 ) * bins;
+		hipLaunchKernelGGL( k_time_map_flags, dim3( (unsigned) ( ( pairs + 255 ) / 256 ) ), dim3( 256 ), 0, s, d_mod, F, bins, sr, float( hop ), d_flags );
+		FLANHIP_CHECK( hipGetLastError() );
+		}
+	// enough (column, segment) threads to fill the chip, segments of at least 16 frame pairs
+	const int64_t columns = ch * bins;
+	int segments = int( std::min<int64_t>( std::max<int64_t>( ( 256 * 2048 + columns - 1 ) / columns, 1 ), std::max<int64_t>( ( F - 1 ) / 16, 1 ) ) );
+	const int64_t seg_len = std::max<int64_t>( ( F - 1 + segments - 1 ) / segments, 1 );
+	const int64_t threads = columns * segments;
 	hipLaunchKernelGGL( k_modify_time, dim3( (unsigned) ( ( threads + 255 ) / 256 ) ), dim3( 256 ), 0, s,
-		(const MFd*) d_pv, int( ch ), F, bins, sr, float( hop ), d_mod, Fo, (MFd*) d_out );
+		(const MFd*) d_pv, int( ch ), F, bins, sr, float( hop ), d_mod, Fo, (MFd*) d_out, d_flags, segments, seg_len );
 	FLANHIP_CHECK( hipGetLastError() );
+	FLANHIP_CHECK( hipFreeAsync( d_flags, s ) );
 	return FLANHIP_OK;
 	}
 
@@ -257,7 +346,7 @@ int flanhip_stretch_map_dev( float * d_factor, int64_t F, int bins, float sr, in
 		const float ninf = -INFINITY;
 		FLANHIP_CHECK( hipMemcpyAsync( d_max, &ninf, sizeof( float ), hipMemcpyHostToDevice, s ) );
 		}
-	hipLaunchKernelGGL( k_stretch_map, dim3( ( bins + 255 ) / 256 ), dim3( 256 ), 0, s, d_factor, F, bins, sr, float( hop ), d_max );
+	hipLaunchKernelGGL( k_stretch_map, dim3( ( bins + 63 ) / 64 ), dim3( 256 ), 0, s, d_factor, F, bins, sr, float( hop ), d_max );
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;
 	}
@@ -270,7 +359,7 @@ int flanhip_modify_frequency_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F
 	hipStream_t s = (hipStream_t) stream;
 	FLANHIP_CHECK( hipMemsetAsync( d_out, 0, sizeof( flanhip_MF ) * size_t( ch ) * F * bins, s ) );    // clear_buffer, PVModify.cpp:205
 	const int64_t rows = ch * F;
-	hipLaunchKernelGGL( k_modify_frequency, dim3( (unsigned) ( ( rows + 63 ) / 64 ) ), dim3( 64 ), 0, s,
+	hipLaunchKernelGGL( k_modify_frequency, dim3( (unsigned) ( ( rows + 3 ) / 4 ) ), dim3( 256 ), 0, s,
 		(const MFd*) d_pv, int( ch ), F, bins, sr, float( ( bins - 1 ) * 2 ), d_mod, d_in_modified, (MFd*) d_out );
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""BASELINE config 3 on one MI355X, device-resident: 8 ch x 60 s noise -> convert_to_PV(2048,512,2048) -> stretch(x2) ->
+convert_to_audio, timed per stage with events (also repitch(x2) and shape(f+100) on the same PV)."""
+import ctypes
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import flan_amd as fa
+
+SR, W, HOP, DFT = 48000.0, 2048, 512, 2048
+BINS = DFT // 2 + 1
+ch, n = 8, 60 * 48000
+lib = fa.lib
+dev = torch.device("cuda", 0)
+F = int(lib.flanhip_num_pv_frames(n, HOP))
+ar = SR / HOP
+vp = ctypes.c_void_p
+
+
+def P(t):
+    return vp(t.data_ptr())
+
+
+audio = torch.empty((ch, n), dtype=torch.float32, device=dev)
+fa.check(lib.flanhip_noise_dev(P(audio), ch, n, 1234, None))
+pv = torch.empty((ch, F, BINS, 2), dtype=torch.float32, device=dev)
+grid = torch.empty((F, BINS), dtype=torch.float32, device=dev)
+dmax = torch.empty(1, dtype=torch.float32, device=dev)
+Fo = 2 * F
+st = torch.empty((ch, Fo, BINS, 2), dtype=torch.float32, device=dev)
+out = torch.empty((ch, Fo * HOP), dtype=torch.float32, device=dev)
+ws = torch.empty(fa.synthesize_workspace_bytes(ch, Fo, BINS, SR, ar, W), dtype=torch.uint8, device=dev)
+inmod = torch.empty((ch, F, BINS), dtype=torch.float32, device=dev)
+rp = torch.empty_like(pv)
+sh = torch.empty_like(pv)
+
+stages = {
+    "convert_to_PV": lambda: fa.check(lib.flanhip_analyze_dev(P(audio), ch, n, SR, W, HOP, DFT, P(pv), None)),
+    "stretch: fill+map": lambda: (fa.check(lib.flanhip_fill_dev(P(grid), F * BINS, 2.0, None)),
+                                  fa.check(lib.flanhip_stretch_map_dev(P(grid), F, BINS, SR, HOP, P(dmax), None))),
+    "stretch: modify_time": lambda: fa.check(lib.flanhip_modify_time_dev(P(pv), ch, F, BINS, SR, HOP, P(grid), Fo, P(st), None)),
+    "convert_to_audio(stretched)": lambda: fa.check(lib.flanhip_synthesize_dev(P(st), ch, Fo, BINS, SR, ar, W, P(out), P(ws), None, None)),
+    "repitch: fill+map": lambda: (fa.check(lib.flanhip_fill_dev(P(grid), F * BINS, 2.0, None)),
+                                  fa.check(lib.flanhip_repitch_map_dev(P(pv), ch, F, BINS, SR, P(grid), P(inmod), None))),
+    "repitch: modify_frequency": lambda: fa.check(lib.flanhip_modify_frequency_dev(P(pv), ch, F, BINS, SR, P(grid), P(inmod), P(rp), None)),
+    "shape(f+100)": lambda: fa.check(lib.flanhip_shape_affine_dev(P(pv), ch, F, BINS, SR, 1.0, 0.0, 1.0, 100.0, 0, P(sh), None)),
+    "shape(f*2, aligned)": lambda: fa.check(lib.flanhip_shape_affine_dev(P(pv), ch, F, BINS, SR, 1.0, 0.0, 2.0, 0.0, 1, P(sh), None)),
+}
+res = {}
+for name, fn in stages.items():
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    res[name] = round(e0.elapsed_time(e1) / reps, 4)
+total = res["convert_to_PV"] + res["stretch: fill+map"] + res["stretch: modify_time"] + res["convert_to_audio(stretched)"]
+print(json.dumps({"config": "3: 8ch 60s stretch x2", "input_frames": ch * F, "stage_ms": res, "config3_total_ms": round(total, 3),
+                  "input_frames_per_s": round(ch * F / (total * 1e-3), 1)}))
