@@ -150,16 +150,36 @@ __global__ __launch_bounds__( 256 ) void k_stretch_map( float * factor, int64_t 
 	}
 
 // PV::repitch, PVModify.cpp:278-284: inclusive running sum over bins per frame (fp32, sequential), bin_to_frequency.
+// A block owns 64 frames: tiles of 64 frames x 64 bins go through LDS (coalesced rows in and out), 64 threads carry the
+// running sums along their rows, all 256 apply bin_to_frequency.
 __global__ __launch_bounds__( 256 ) void k_repitch_scan( float * factor, int64_t F, int bins, float sr, float dft )
 	{
-	const int64_t frame = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
-	if( frame >= F ) return;
-	float * p = factor + frame * bins;
-	float run = 0.0f;
-	for( int bin = 0; bin < bins; ++bin )
+	constexpr int TB = 64, TF = 64;
+	__shared__ float tile[TF][TB + 1];
+	const int64_t frame0 = int64_t( blockIdx.x ) * TF;
+	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+	float run = 0.0f;                                                               // of frame frame0 + tx (threads with ty == 0)
+	for( int bbase = 0; bbase < bins; bbase += TB )
 		{
-		run = ( bin == 0 ) ? p[0] : p[bin] + run;
-		p[bin] = bin_to_frequency( run, sr, dft );
+		#pragma unroll
+		for( int r = ty; r < TF; r += 4 )
+			tile[r][tx] = ( frame0 + r < F && bbase + tx < bins ) ? factor[( frame0 + r ) * bins + bbase + tx] : 0.0f;
+		__syncthreads();
+		if( ty == 0 )
+			{
+			#pragma unroll
+			for( int c = 0; c < TB; ++c )
+				{
+				run = ( bbase + c == 0 ) ? tile[tx][c] : tile[tx][c] + run;                 // factor[frame][bin] += factor[frame][bin-1]
+				tile[tx][c] = run;
+				}
+			}
+		__syncthreads();
+		#pragma unroll
+		for( int r = ty; r < TF; r += 4 )
+			if( frame0 + r < F && bbase + tx < bins )
+				factor[( frame0 + r ) * bins + bbase + tx] = bin_to_frequency( tile[r][tx], sr, dft );   // :283-284
+		__syncthreads();
 		}
 	}
 
@@ -396,7 +416,7 @@ int flanhip_repitch_map_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int
 	FLANHIP_REQUIRE( d_factor, FLANHIP_ERR_INVALID_ARG, "null factor grid" );
 	hipStream_t s = (hipStream_t) stream;
 	const float dft = float( ( bins - 1 ) * 2 );
-	hipLaunchKernelGGL( k_repitch_scan, dim3( (unsigned) ( ( F + 255 ) / 256 ) ), dim3( 256 ), 0, s, d_factor, F, bins, sr, dft );
+	hipLaunchKernelGGL( k_repitch_scan, dim3( (unsigned) ( ( F + 63 ) / 64 ) ), dim3( 256 ), 0, s, d_factor, F, bins, sr, dft );
 	FLANHIP_CHECK( hipGetLastError() );
 	const int64_t count = ch * F * bins;
 	hipLaunchKernelGGL( k_repitch_lerp, dim3( (unsigned) ( ( count + 255 ) / 256 ) ), dim3( 256 ), 0, s,
