@@ -78,7 +78,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world != 1:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("FLAN_BENCH_FORCE_DIST") == "1"   # the env knob rehearses the RCCL path on one GPU
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback path)")
     torch.cuda.set_device(local_rank)
@@ -87,6 +87,8 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
+            os.environ["NCCL_DEBUG"] = "WARN"      # keep RCCL's version banner off stdout: rank 0 prints exactly one JSON line
         dist.init_process_group("nccl", device_id=dev)
 
     ch, n = args.channels, int(args.seconds * SR)
