@@ -64,6 +64,9 @@ _SIGS = {
     "flanhip_shape_affine_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
     "flanhip_shape_table_dev": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _f32, _i32, _vp, _vp]),
     "flanhip_mid_side_dev": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "flanhip_resample_out_frames": (_i64, [_i64, _f32, _f32]),
+    "flanhip_resample": (C.c_int, [_vp, _i64, _i64, _f32, _f32, _vp, _vp]),
+    "flanhip_resample_dev": (C.c_int, [_vp, _i64, _i64, _f32, _f32, _vp, _vp]),
     "flanhip_noise_dev": (C.c_int, [_vp, _i64, _i64, C.c_uint32, _vp]),
     "flanhip_sqdiff_dev": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
 }
@@ -134,6 +137,16 @@ def modify_frequency(pv, sample_rate, mod_hz, in_modified):
     ch, F, bins, _ = pv.shape
     out = np.empty_like(pv)
     check(lib.flanhip_modify_frequency(_ptr(pv), ch, F, bins, sample_rate, _ptr(mod), _ptr(inm), _ptr(out), None))
+    return out
+
+
+def resample(audio, src_rate, dst_rate):
+    """Audio::resample (2:1 only).  audio float32 [ch][n] -> float32 [ch][n_out]"""
+    audio = np.ascontiguousarray(audio, np.float32)
+    ch, n = audio.shape
+    n_out = lib.flanhip_resample_out_frames(n, src_rate, dst_rate)
+    out = np.empty((ch, n_out), np.float32)
+    check(lib.flanhip_resample(_ptr(audio), ch, n, src_rate, dst_rate, _ptr(out), None))
     return out
 
 

@@ -99,8 +99,18 @@ Audio Audio::resample( FrameRate new_sample_rate ) const
 	{
 	if( is_null() ) return Audio::create_null();
 	if( new_sample_rate == get_sample_rate() ) return copy();  // AudioConversions.cpp:18-19
-	std::cerr << "flan: Audio::resample is not part of the MI355X phase-vocoder path yet (SURVEY 8f rank 1)" << std::endl;
-	return Audio::create_null();
+	AudioBuffer::Format f = get_format();                      // :21-23
+	f.num_frames = Frame( flanhip_resample_out_frames( get_num_frames(), get_sample_rate(), new_sample_rate ) );
+	f.sample_rate = new_sample_rate;
+	if( f.num_frames <= 0 ) return Audio::create_null();
+	const float * d_in = device_data();
+	auto block = detail::DeviceBlock::allocate( sizeof( float ) * size_t( f.num_channels ) * f.num_frames );
+	if( !d_in || !block ) return Audio::create_null();
+	// r8brain CDSPResampler with default parameters, one stream over the whole buffer (:25-27); 2:1 ratios only on this path
+	if( !detail::report( flanhip_resample_dev( d_in, get_num_channels(), get_num_frames(), get_sample_rate(), new_sample_rate,
+			static_cast<float*>( block->ptr ), nullptr ), "resample" ) ) return Audio::create_null();
+	if( !detail::report( flanhip_stream_synchronize( nullptr ), "resample" ) ) return Audio::create_null();
+	return AudioBuffer::adopt_device( f, std::move( block ) );
 	}
 
 } // namespace flan

@@ -150,6 +150,17 @@ int flanhip_shape_table_dev(const flanhip_MF * d_pv, const flanhip_MF * d_shaped
 /* ---- Audio::convert_to_mid_side / convert_to_left_right (Audio/AudioConversions.cpp:32-56), stereo only ------ */
 int flanhip_mid_side_dev(const float * d_in, int64_t num_audio_frames, float * d_out, void * stream);
 
+/* ---- Audio::resample (Audio/AudioConversions.cpp:14-30, r8brain CDSPResampler with default parameters) --------- */
+/* AudioConversions.cpp:22: out frames = Frame( float(num_frames) * ( dst_rate / src_rate ) ) */
+int64_t flanhip_resample_out_frames(int64_t num_frames, float src_rate, float dst_rate);
+/* in: float[ch][n]; out: float[ch][flanhip_resample_out_frames(n,...)].  Like the reference, the whole channel-major buffer is
+ * resampled as ONE stream (filter ringing crosses channel boundaries).  Implemented for src_rate == 2 * dst_rate (96 -> 48 kHz:
+ * one 1621-tap linear-phase low-pass, latency consumed); other ratios return FLANHIP_ERR_UNSUPPORTED. */
+int flanhip_resample(const float * in, int64_t num_channels, int64_t num_frames, float src_rate, float dst_rate,
+                     float * out, volatile int * cancel);
+int flanhip_resample_dev(const float * d_in, int64_t num_channels, int64_t num_frames, float src_rate, float dst_rate,
+                         float * d_out, void * stream);
+
 /* ---- synthetic input + comparison utilities (bench / tests; defined by this project) -------------- */
 int flanhip_noise_dev(float * d_out, int64_t num_channels, int64_t num_audio_frames, uint32_t seed, void * stream);
 /* sum of squares of (a - b) and of b, as doubles: d_result[0] = sum (a-b)^2, d_result[1] = sum b^2 */

@@ -57,6 +57,10 @@ def _load():
                                         C.c_float, C.c_int, f32p]
     lib.oracle_mid_side.argtypes = [f32p, C.c_int64, f32p]
     lib.oracle_noise.argtypes = [f32p, C.c_int, C.c_int64, C.c_uint32]
+    lib.oracle_r8b_default_lowpass_half.argtypes = [f64p, C.c_int]
+    lib.oracle_resample_out_frames.restype = C.c_int64
+    lib.oracle_resample_out_frames.argtypes = [C.c_int64, C.c_float, C.c_float]
+    lib.oracle_resample_2to1.argtypes = [f32p, C.c_int64, f32p, C.c_int64]
     return lib
 
 
@@ -188,6 +192,26 @@ def mid_side(audio):
     out = np.empty_like(audio)
     lib.oracle_mid_side(audio.reshape(-1), audio.shape[1], out.reshape(-1))
     return out
+
+
+def resample_2to1(audio, src_rate, dst_rate):
+    """Audio::resample for src = 2 dst: [ch][n] -> [ch][n_out], the whole buffer as one stream"""
+    audio = np.ascontiguousarray(audio, np.float32)
+    ch, n = audio.shape
+    n_out = int(lib.oracle_resample_out_frames(n, src_rate, dst_rate))
+    out = np.empty((ch, n_out), np.float32)
+    rc = lib.oracle_resample_2to1(audio.reshape(-1), ch * n, out.reshape(-1), ch * n_out)
+    assert rc == 0
+    return out
+
+
+def load_r8b_ref():
+    """the real r8brain resampler the reference vendors (oracle/_ref/libr8bref.so); None when it was never built"""
+    if not os.path.exists(_R8B):
+        return None
+    ref = C.CDLL(_R8B)
+    ref.ref_r8b_resample.argtypes = [f32p, C.c_int, C.c_double, C.c_double, C.c_int, f32p, C.c_int]
+    return ref
 
 
 def noise(ch, n, seed=1234):

@@ -1,0 +1,49 @@
+"""Audio::resample (2:1): the CPU restatement (oracle/resample_oracle.cpp) against the REAL r8brain resampler vendored by the
+reference, compiled unmodified into oracle/_ref/libr8bref.so and driven exactly like Audio/AudioConversions.cpp:25-27."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+r8b = O.load_r8b_ref()
+pytestmark = pytest.mark.skipif(r8b is None, reason="oracle/_ref/libr8bref.so not built (no /root/reference)")
+
+
+def ref_resample(x, src, dst):
+    ch, n = x.shape
+    n_out = int(O.lib.oracle_resample_out_frames(n, src, dst))
+    out = np.zeros((ch, n_out), np.float32)
+    r8b.ref_r8b_resample(np.ascontiguousarray(x).reshape(-1), ch * n, float(src), float(dst), n, out.reshape(-1), ch * n_out)
+    return out
+
+
+def test_filter_is_the_1621_tap_design():
+    taps = np.zeros(4000)
+    n = O.lib.oracle_r8b_default_lowpass_half(taps, 4000)
+    assert n == 1621                          # flt_len=1621 latency=810
+    h = taps[:n]
+    assert np.allclose(h, h[::-1], rtol=0, atol=1e-18) and abs(h.sum() - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize("ch,n", [(2, 9600), (1, 20001), (2, 4801), (3, 1000), (1, 100)])
+def test_restatement_matches_r8brain(ch, n):
+    rng = np.random.default_rng(ch * 1000 + n)
+    x = rng.uniform(-1, 1, (ch, n)).astype(np.float32)
+    ours = O.resample_2to1(x, 96000.0, 48000.0)
+    theirs = ref_resample(x, 96000.0, 48000.0)
+    assert ours.shape == theirs.shape
+    d = ours.astype(np.float64) - theirs.astype(np.float64)
+    same = np.mean(ours.view(np.uint32) == theirs.view(np.uint32))
+    print("\n[resample %dx%d] rms diff %.2e  max %.2e  bit-identical %.5f" % (ch, n, np.sqrt(np.mean(d ** 2)), np.abs(d).max(), same))
+    assert np.abs(d).max() <= 2e-7            # one fp32 ulp at unit scale: the fp64 sums differ in the 16th digit only
+    assert same >= 0.995
+
+
+def test_impulse_and_channel_bleed():
+    """an impulse at the end of channel 0 rings into the start of channel 1: the buffer is one stream"""
+    x = np.zeros((2, 4000), np.float32)
+    x[0, 3999] = 1.0
+    ours = O.resample_2to1(x, 96000.0, 48000.0)
+    theirs = ref_resample(x, 96000.0, 48000.0)
+    assert np.abs(theirs[1, :50]).max() > 1e-3
+    assert np.abs(ours.astype(np.float64) - theirs).max() <= 2e-7

@@ -59,6 +59,18 @@ for name, fn in stages.items():
         fn()
     e1.record(); torch.cuda.synchronize()
     res[name] = round(e0.elapsed_time(e1) / reps, 4)
+# config 5's resample stage: stereo 60 s at 96 kHz -> 48 kHz
+x96 = torch.empty((2, 60 * 96000), dtype=torch.float32, device=dev)
+fa.check(lib.flanhip_noise_dev(P(x96), 2, 60 * 96000, 7, None))
+x48 = torch.empty((2, 60 * 48000), dtype=torch.float32, device=dev)
+fn5 = lambda: fa.check(lib.flanhip_resample_dev(P(x96), 2, 60 * 96000, 96000.0, 48000.0, P(x48), None))
+fn5(); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5):
+    fn5()
+e1.record(); torch.cuda.synchronize()
+res["config5: resample 2x60s 96k->48k"] = round(e0.elapsed_time(e1) / 5, 4)
 total = res["convert_to_PV"] + res["stretch: fill+map"] + res["stretch: modify_time"] + res["convert_to_audio(stretched)"]
 print(json.dumps({"config": "3: 8ch 60s stretch x2", "input_frames": ch * F, "stage_ms": res, "config3_total_ms": round(total, 3),
                   "input_frames_per_s": round(ch * F / (total * 1e-3), 1)}))
