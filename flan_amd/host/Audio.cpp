@@ -57,11 +57,21 @@ PV Audio::convert_to_PV( Frame window_size, Frame hop, Frame dft_size, flan_CANC
 	auto block = detail::DeviceBlock::allocate( sizeof( MF ) * size_t( f.num_channels ) * f.num_frames * f.num_bins );
 	if( !block ) return PV();
 	if( canceller ) return PV();
-	if( !detail::report( flanhip_analyze_dev( d_audio, f.num_channels, get_num_frames(), get_sample_rate(), window_size, hop, dft_size,
-			static_cast<flanhip_MF*>( block->ptr ), nullptr ), "convert_to_PV" ) ) return PV();
+	// fused round trip: the analysis kernel also leaves what convert_to_audio's pre-pass would compute (flanhip.h)
+	std::shared_ptr<detail::DeviceBlock> ws;
+	const size_t ws_bytes = flanhip_synthesize_workspace_bytes( f.num_channels, f.num_frames, f.num_bins, f.sample_rate, f.analysis_rate, f.window_size );
+	if( ws_bytes ) ws = detail::DeviceBlock::allocate( ws_bytes );
+	const int rc = ws
+		? flanhip_analyze_dev_fused( d_audio, f.num_channels, get_num_frames(), get_sample_rate(), window_size, hop, dft_size,
+			static_cast<flanhip_MF*>( block->ptr ), ws->ptr, nullptr )
+		: flanhip_analyze_dev( d_audio, f.num_channels, get_num_frames(), get_sample_rate(), window_size, hop, dft_size,
+			static_cast<flanhip_MF*>( block->ptr ), nullptr );
+	if( !detail::report( rc, "convert_to_PV" ) ) return PV();
 	if( !detail::report( flanhip_stream_synchronize( nullptr ), "convert_to_PV" ) ) return PV();
 	if( canceller ) return PV();
-	return PVBuffer::adopt_device( f, std::move( block ) );
+	PVBuffer out = PVBuffer::adopt_device( f, std::move( block ) );
+	if( ws ) out.attach_synthesis_workspace( std::move( ws ) );
+	return out;
 	}
 
 PV Audio::convertToPV( Frame window_size, Frame hop, Frame dft_size, flan_CANCEL_ARG_CPP ) const

@@ -59,14 +59,19 @@ Audio PV::convert_to_audio( flan_CANCEL_ARG_CPP ) const
 	const size_t ws_bytes = flanhip_synthesize_workspace_bytes( get_num_channels(), get_num_frames(), get_num_bins(), get_sample_rate(), get_analysis_rate(), get_window_size() );
 	if( ws_bytes == 0 ) { detail::report( FLANHIP_ERR_UNSUPPORTED, "convert_to_audio (unsupported dft / window)" ); return Audio::create_null(); }
 	auto out = DeviceBlock::allocate( sizeof( float ) * size_t( af.num_channels ) * af.num_frames );
-	auto ws = DeviceBlock::allocate( ws_bytes );
+	auto fused_ws = take_synthesis_workspace();                 // left by convert_to_PV when this PV came straight from it
+	const bool fused = fused_ws && fused_ws->bytes >= ws_bytes;
+	auto ws = fused ? fused_ws : DeviceBlock::allocate( ws_bytes );
 	auto flag = DeviceBlock::allocate( sizeof( int ) );
 	if( !out || !ws || !flag ) return Audio::create_null();
 	flanhip_memset( flag->ptr, 0, sizeof( int ), nullptr );
 	if( canceller ) return Audio::create_null();
-	if( !detail::report( flanhip_synthesize_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(),
-			get_sample_rate(), get_analysis_rate(), get_window_size(), static_cast<float*>( out->ptr ), ws->ptr, static_cast<int*>( flag->ptr ), nullptr ),
-			"convert_to_audio" ) ) return Audio::create_null();
+	const int rc = fused
+		? flanhip_synthesize_dev_fused( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(),
+			get_sample_rate(), get_analysis_rate(), get_window_size(), static_cast<float*>( out->ptr ), ws->ptr, static_cast<int*>( flag->ptr ), nullptr )
+		: flanhip_synthesize_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(),
+			get_sample_rate(), get_analysis_rate(), get_window_size(), static_cast<float*>( out->ptr ), ws->ptr, static_cast<int*>( flag->ptr ), nullptr );
+	if( !detail::report( rc, "convert_to_audio" ) ) return Audio::create_null();
 	int nan_flag = 0;
 	flanhip_memcpy_d2h( &nan_flag, flag->ptr, sizeof( int ), nullptr );
 	if( !detail::report( flanhip_stream_synchronize( nullptr ), "convert_to_audio" ) ) return Audio::create_null();

@@ -49,6 +49,7 @@ void PVBuffer::clear_buffer()
 	buffer.assign( count(), MF{ 0.0f, 0.0f } );
 	host_valid = true;
 	dev.reset();
+	synth_ws.reset();
 	}
 
 const std::vector<MF> & PVBuffer::get_buffer() const
@@ -70,6 +71,7 @@ std::vector<MF> & PVBuffer::get_buffer()
 	{
 	std::as_const( *this ).get_buffer();
 	dev.reset();
+	synth_ws.reset();                  // the caller may write: anything derived from the old data is stale
 	return buffer;
 	}
 

@@ -72,6 +72,10 @@ public:
 	bool is_device_resident() const { return bool( dev ); }
 	const MF * device_data() const;
 	static PVBuffer adopt_device( const Format &, std::shared_ptr<detail::DeviceBlock> );
+	/** convert_to_PV leaves convert_to_audio's pre-pass (per-chain phase sums, in a synthesis workspace) next to the data; it is
+	 *  valid while the data is untouched and is consumed by the first convert_to_audio (flanhip_*_fused in flanhip.h). */
+	void attach_synthesis_workspace( std::shared_ptr<detail::DeviceBlock> ws ) const { synth_ws = std::move( ws ); }
+	std::shared_ptr<detail::DeviceBlock> take_synthesis_workspace() const { auto w = std::move( synth_ws ); synth_ws.reset(); return w; }
 
 protected:
 	size_t count() const { return size_t( format.num_channels ) * size_t( format.num_frames ) * size_t( format.num_bins ); }
@@ -79,6 +83,7 @@ protected:
 	mutable std::vector<MF> buffer;
 	mutable bool host_valid = true;
 	mutable std::shared_ptr<detail::DeviceBlock> dev;
+	mutable std::shared_ptr<detail::DeviceBlock> synth_ws;
 	};
 
 } // namespace flan

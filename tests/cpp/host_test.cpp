@@ -90,6 +90,9 @@ static void device_checks()
 	double e = 0; for( float v : back.get_buffer() ) e += double( v ) * v;
 	CHECK( close_to( e, 30006.053, 1e-5 ) );
 	CHECK( !a.convertToPV( 2048, 512, 2048 ).convertToAudio().is_null() );   // older spellings
+	// the first convert_to_audio of a fresh PV takes the fused pre-pass, the second recomputes it: same audio either way
+	Audio back2 = pv.convert_to_audio();
+	CHECK( std::memcmp( back.get_buffer().data(), back2.get_buffer().data(), sizeof( float ) * back.get_buffer().size() ) == 0 );
 	// default arguments are the reference's: window 2048, hop 128, dft 4096 (Audio.h:158-163)
 	PV dflt = sine( 20000 ).convert_to_PV();
 	CHECK( dflt.get_num_bins() == 2049 && dflt.get_hop_size() == 128 && dflt.get_num_frames() == 20000 / 128 + 1 );
