@@ -166,6 +166,8 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 	const bool use_wrapping = p.analysis_rate < p.sample_rate;                // phase_vocoder.cpp:37
 	const int padl = lane + ( lane >> 4 );
 	const cf * mirror = buf + ( C * 17 ) / 16 - ( lane + ( ( lane + 15 ) >> 4 ) );   // PAD( M - lane ) = 17 M / 16 + this, M % 64 == 0
+	using VB = v8f;                                                           // bins evaluated together (pv_math.h)
+	constexpr int NV = 8;
 
 	// per-lane constants: bin frequency (PVBuffer.cpp:443-446), expected phase advance (phase_vocoder.cpp:47)
 	// (the division by dft, a power of two, is exactly a multiplication; bin_frequency is recomputed per use, 2 instructions)
@@ -269,13 +271,14 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 		const cf z0 = buf[0];
 		load_raw( t0, zn );
 		#pragma unroll
-		for( int q = 0; q < E; q += 2 )
+		for( int q0 = 0; q0 < E; q0 += NV )
 			{
-			float re0, im0, re1, im1;
-			split_bin( z, q, z0, re0, im0 );
-			split_bin( z, q + 1, z0, re1, im1 );
-			const cf ph2 = atan2_fast_2( cf{ im0, im1 }, cf{ re0, re1 } );
-			prev[q] = ph2.x; prev[q + 1] = ph2.y;
+			VB re, im;
+			#pragma unroll
+			for( int i = 0; i < NV; ++i ) { float r, m; split_bin( z, q0 + i, z0, r, m ); re[i] = r; im[i] = m; }
+			const VB ph2 = atan2_fast_v( im, re );
+			#pragma unroll
+			for( int i = 0; i < NV; ++i ) prev[q0 + i] = ph2[i];
 			}
 		prev[E] = atan2_fast( 0.0f, z0.x - z0.y );
 		wave_sync();
@@ -292,36 +295,41 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 		cf * row = reinterpret_cast<cf*>( p.out + ( int64_t( channel ) * p.F + t ) * ( C + 1 ) );
 		cf * rowp = row + lane;
 		#pragma unroll
-		for( int q = 0; q < E; q += 2 )
+		for( int q0 = 0; q0 < E; q0 += NV )
 			{
-			// two bins per iteration (k = lane + 64 q and k + 64), evaluated as one packed stream (pv_math.h)
-			float re0, im0, re1, im1;
-			split_bin( z, q, z0, re0, im0 );
-			split_bin( z, q + 1, z0, re1, im1 );
-			const cf re = cf{ re0, re1 }, im = cf{ im0, im1 };
-			// phase_vocoder.cpp:37-52 (AudioPV.cpp:69-73)
-			const cf phase = atan2_fast_2( im, re );
-			const cf phase_diff = phase - cf{ prev[q], prev[q + 1] };           // == float( double(phase) - double(prev) ), :44
-			prev[q] = phase.x; prev[q + 1] = phase.y;                            // :45
-			const cf binf = cf{ bin_frequency( q ), bin_frequency( q + 1 ) };
-			const cf delta_phase = phase_diff - div_c_2( binf, p.ar_div ) * bcast2( FLANHIP_PI2_F );          // :47-48
-			cf wrapped = delta_phase;
-			if( use_wrapping )
+			// NV bins per iteration (k = lane + 64 (q0 + i)), evaluated as one vector stream: NV/2 independent packed
+			// instructions per step of every dependent chain (pv_math.h)
+			VB re, im, pv, binf;
+			#pragma unroll
+			for( int i = 0; i < NV; ++i )
 				{
-				const cf turns = div_pi2_2( delta_phase );
-				wrapped = delta_phase - bcast2( FLANHIP_PI2_F ) * cf{ roundf( turns.x ), roundf( turns.y ) };    // :39-42,49
+				float r, m;
+				split_bin( z, q0 + i, z0, r, m );
+				re[i] = r; im[i] = m; pv[i] = prev[q0 + i]; binf[i] = bin_frequency( q0 + i );
 				}
-			const cf f = binf + div_pi2_2( wrapped * bcast2( p.analysis_rate ) );                             // :50-52
-			const cf m = magnitude_scaled_2( re, im );
-			rowp[64 * q] = cf{ m.x, f.x };
-			rowp[64 * q + 64] = cf{ m.y, f.y };
+			// phase_vocoder.cpp:37-52 (AudioPV.cpp:69-73)
+			const VB phase = atan2_fast_v( im, re );
+			const VB phase_diff = phase - pv;                                    // == float( double(phase) - double(prev) ), :44
+			const VB delta_phase = phase_diff - div_c_v( binf, p.ar_div ) * vsplat<VB>( FLANHIP_PI2_F );       // :47-48
+			VB wrapped = delta_phase;
+			if( use_wrapping ) wrapped = delta_phase - vsplat<VB>( FLANHIP_PI2_F ) * round_v( div_pi2_v( delta_phase ) );   // :39-42,49
+			const VB f = binf + div_pi2_v( wrapped * vsplat<VB>( p.analysis_rate ) );                          // :50-52
+			const VB m = magnitude_scaled_v( re, im );
+			#pragma unroll
+			for( int i = 0; i < NV; ++i )
+				{
+				prev[q0 + i] = phase[i];                                         // :45
+				rowp[64 * ( q0 + i )] = cf{ m[i], f[i] };
+				}
 			if constexpr( SUMS )
 				{
-				const cf term = div_c_2( f, p.ar_div ) * bcast2( FLANHIP_PI2_F );                            // phase_vocoder.cpp:57-58
-				s_sum[64 * q] += double( term.x );
-				s_sum[64 * q + 64] += double( term.y );
-				bad |= !( __builtin_fabsf( m.x ) <= 3.4028235e38f ) || !( __builtin_fabsf( f.x ) <= 3.4028235e38f )
-				    || !( __builtin_fabsf( m.y ) <= 3.4028235e38f ) || !( __builtin_fabsf( f.y ) <= 3.4028235e38f );
+				const VB term = div_c_v( f, p.ar_div ) * vsplat<VB>( FLANHIP_PI2_F );                          // phase_vocoder.cpp:57-58
+				#pragma unroll
+				for( int i = 0; i < NV; ++i )
+					{
+					s_sum[64 * ( q0 + i )] += double( term[i] );
+					bad |= !( __builtin_fabsf( m[i] ) <= 3.4028235e38f ) || !( __builtin_fabsf( f[i] ) <= 3.4028235e38f );
+					}
 				}
 			}
 			{
@@ -476,17 +484,23 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 		else
 			{
 			#pragma unroll
-			for( int q = 0; q < E; q += 2 )
+			for( int q0 = 0; q0 < E; q0 += 4 )
 				{
-				ph[q] = fold_phase_fast( ph[q] );                               // phase_vocoder.cpp:59
-				ph[q + 1] = fold_phase_fast( ph[q + 1] );
-				cf sn, cs;
-				sincos_fast_2( cf{ float( ph[q] ), float( ph[q + 1] ) }, sn, cs );
-				const cf m2 = cf{ z[q].x, z[q + 1].x };
-				const cf xr = m2 * cs, xi = m2 * sn;                             // std::polar, :60
-				z[q] = cf{ xr.x, xi.x };
-				z[q + 1] = cf{ xr.y, xi.y };
-				__builtin_amdgcn_sched_barrier( 0 );                            // two bins at a time: keeps the temporaries of 16 bins from overlapping
+				// four bins per iteration as one vector stream (pv_math.h): two independent packed instructions per step
+				v4f th, m4;
+				#pragma unroll
+				for( int i = 0; i < 4; ++i )
+					{
+					ph[q0 + i] = fold_phase_fast( ph[q0 + i] );                 // phase_vocoder.cpp:59
+					th[i] = float( ph[q0 + i] );
+					m4[i] = z[q0 + i].x;
+					}
+				v4f sn, cs;
+				sincos_fast_v( th, sn, cs );
+				const v4f xr = m4 * cs, xi = m4 * sn;                            // std::polar, :60
+				#pragma unroll
+				for( int i = 0; i < 4; ++i ) z[q0 + i] = cf{ xr[i], xi[i] };
+				__builtin_amdgcn_sched_barrier( 0 );                            // four bins at a time: keeps the temporaries of 16 bins from overlapping
 				}
 			ph[E] = fold_phase_fast( ph[E] );
 			float sn, cs;

@@ -86,87 +86,124 @@ __device__ __forceinline__ float atan2_fast( float y, float x )
 	return __builtin_copysignf( a, y );
 	}
 
-// ---- two bins at a time --------------------------------------------------------------------------------------------------
-// A plain fp32 VALU instruction occupies its SIMD for 4 cycles whatever it computes; the packed forms (v_pk_fma_f32,
-// v_pk_mul_f32, v_pk_add_f32) produce two results in the same slot.  The per-bin arithmetic of two adjacent-register bins is
-// therefore evaluated as one `cf` (native 2-float vector) stream: every add / multiply / fma below is a packed
-// instruction; only rcp, sqrt, round, compares and selects stay one per bin.  Same operations, same rounding, as the scalar
-// helpers above.
-__device__ __forceinline__ cf pk_fma2( cf a, cf b, cf c ) { return __builtin_elementwise_fma( a, b, c ); }
-__device__ __forceinline__ cf bcast2( float v ) { return cf{ v, v }; }
+// ---- several bins at a time ------------------------------------------------------------------------------------------------
+// The per-bin arithmetic is long DEPENDENT chains (Horner polynomials, Newton steps).  A gfx950 SIMD can start an fp32
+// VALU instruction every 2 cycles, but a dependent one only every ~5-7 (measured, tools/ubench/valu_issue.hip), and with 2
+// wavefronts per SIMD nothing else fills the gap: hipcc schedules the chain of ONE bin (or pair) back to back with s_nops.
+// So the helpers below are written on native float vectors of N = 4 or 8 bins: every step is N/2 independent packed
+// instructions (v_pk_fma_f32 ...), which is exactly the instruction-level parallelism the pipeline needs.  Same
+// operations and rounding as the scalar helpers above; rcp, sqrt, round, compares and selects stay one per bin.
+typedef float v4f __attribute__(( ext_vector_type( 4 ) ));
+typedef float v8f __attribute__(( ext_vector_type( 8 ) ));
+template<class V> struct vec_traits { static constexpr int N = int( sizeof( V ) / sizeof( float ) ); };
+template<class V> __device__ __forceinline__ V vfma( V a, V b, V c ) { return __builtin_elementwise_fma( a, b, c ); }
+template<class V> __device__ __forceinline__ V vsplat( float v ) { V r; for( int i = 0; i < vec_traits<V>::N; ++i ) r[i] = v; return r; }
 
-__device__ __forceinline__ cf div_pi2_2( cf x )
+template<class V> __device__ __forceinline__ V div_pi2_v( V x )
 	{
-	const cf q0 = x * bcast2( FLANHIP_RPI2_F );
-	const cf r = pk_fma2( -q0, bcast2( FLANHIP_PI2_F ), x );
-	return pk_fma2( r, bcast2( FLANHIP_RPI2_F ), q0 );
+	const V rc = vsplat<V>( FLANHIP_RPI2_F ), c = vsplat<V>( FLANHIP_PI2_F );
+	const V q0 = x * rc;
+	const V r = vfma( -q0, c, x );
+	return vfma( r, rc, q0 );
 	}
-__device__ __forceinline__ cf div_c_2( cf x, DivC d )
+template<class V> __device__ __forceinline__ V div_c_v( V x, DivC d )
 	{
 	if( d.exact )
 		{
-		const cf q0 = x * bcast2( d.rc );
-		const cf r = pk_fma2( -q0, bcast2( d.c ), x );
-		return pk_fma2( r, bcast2( d.rc ), q0 );
+		const V rc = vsplat<V>( d.rc ), c = vsplat<V>( d.c );
+		const V q0 = x * rc;
+		const V r = vfma( -q0, c, x );
+		return vfma( r, rc, q0 );
 		}
-	return cf{ x.x / d.c, x.y / d.c };
+	V q;
+	#pragma unroll
+	for( int i = 0; i < vec_traits<V>::N; ++i ) q[i] = x[i] / d.c;
+	return q;
 	}
-__device__ __forceinline__ cf atan2_fast_2( cf y, cf x )
+template<class V> __device__ __forceinline__ V round_v( V x )
 	{
-	const cf ax = __builtin_elementwise_abs( x ), ay = __builtin_elementwise_abs( y );
-	const cf mx = __builtin_elementwise_max( __builtin_elementwise_max( ax, ay ), bcast2( 0x1p-126f ) );
-	const cf mn = __builtin_elementwise_min( ax, ay );
-	const cf r = cf{ __builtin_amdgcn_rcpf( mx.x ), __builtin_amdgcn_rcpf( mx.y ) };
-	const cf q0 = mn * r;
-	const cf q = pk_fma2( pk_fma2( -q0, mx, mn ), r, q0 );
-	const cf u = q * q;
-	cf p = bcast2( 0x1.7ec8b6p-9f );
-	p = pk_fma2( p, u, bcast2( -0x1.0c272ap-6f ) );
-	p = pk_fma2( p, u, bcast2( 0x1.61f9a0p-5f ) );
-	p = pk_fma2( p, u, bcast2( -0x1.3554c4p-4f ) );
-	p = pk_fma2( p, u, bcast2( 0x1.b4e022p-4f ) );
-	p = pk_fma2( p, u, bcast2( -0x1.230ab4p-3f ) );
-	p = pk_fma2( p, u, bcast2( 0x1.9978eep-3f ) );
-	p = pk_fma2( p, u, bcast2( -0x1.5554dcp-2f ) );
-	cf a = pk_fma2( q * u, p, q );
-	const cf a1 = bcast2( FLANHIP_PIO2_F ) - a;
-	a = cf{ ay.x > ax.x ? a1.x : a.x, ay.y > ax.y ? a1.y : a.y };
-	const cf a2 = bcast2( FLANHIP_PI_F ) - a;
-	a = cf{ __float_as_int( x.x ) < 0 ? a2.x : a.x, __float_as_int( x.y ) < 0 ? a2.y : a.y };
-	return cf{ __builtin_copysignf( a.x, y.x ), __builtin_copysignf( a.y, y.y ) };
+	V r;
+	#pragma unroll
+	for( int i = 0; i < vec_traits<V>::N; ++i ) r[i] = roundf( x[i] );
+	return r;
 	}
-__device__ __forceinline__ cf magnitude_scaled_2( cf re, cf im )
+template<class V> __device__ __forceinline__ V atan2_fast_v( V y, V x )
 	{
-	const cf a = __builtin_elementwise_max( __builtin_elementwise_abs( re ), __builtin_elementwise_abs( im ) );
-	const int e0 = __builtin_amdgcn_frexp_expf( a.x ), e1 = __builtin_amdgcn_frexp_expf( a.y );
-	const cf rs = cf{ __builtin_ldexpf( re.x, -e0 ), __builtin_ldexpf( re.y, -e1 ) };
-	const cf is = cf{ __builtin_ldexpf( im.x, -e0 ), __builtin_ldexpf( im.y, -e1 ) };
-	const cf s2 = pk_fma2( rs, rs, is * is );
-	return cf{ __builtin_ldexpf( __builtin_amdgcn_sqrtf( s2.x ), e0 ), __builtin_ldexpf( __builtin_amdgcn_sqrtf( s2.y ), e1 ) };
+	constexpr int N = vec_traits<V>::N;
+	const V ax = __builtin_elementwise_abs( x ), ay = __builtin_elementwise_abs( y );
+	const V mx = __builtin_elementwise_max( __builtin_elementwise_max( ax, ay ), vsplat<V>( 0x1p-126f ) );
+	const V mn = __builtin_elementwise_min( ax, ay );
+	V r;
+	#pragma unroll
+	for( int i = 0; i < N; ++i ) r[i] = __builtin_amdgcn_rcpf( mx[i] );
+	const V q0 = mn * r;
+	const V q = vfma( vfma( -q0, mx, mn ), r, q0 );
+	const V u = q * q;
+	V p = vsplat<V>( 0x1.7ec8b6p-9f );
+	p = vfma( p, u, vsplat<V>( -0x1.0c272ap-6f ) );
+	p = vfma( p, u, vsplat<V>( 0x1.61f9a0p-5f ) );
+	p = vfma( p, u, vsplat<V>( -0x1.3554c4p-4f ) );
+	p = vfma( p, u, vsplat<V>( 0x1.b4e022p-4f ) );
+	p = vfma( p, u, vsplat<V>( -0x1.230ab4p-3f ) );
+	p = vfma( p, u, vsplat<V>( 0x1.9978eep-3f ) );
+	p = vfma( p, u, vsplat<V>( -0x1.5554dcp-2f ) );
+	V a = vfma( q * u, p, q );
+	const V a1 = vsplat<V>( FLANHIP_PIO2_F ) - a;
+	#pragma unroll
+	for( int i = 0; i < N; ++i ) a[i] = ay[i] > ax[i] ? a1[i] : a[i];
+	const V a2 = vsplat<V>( FLANHIP_PI_F ) - a;
+	#pragma unroll
+	for( int i = 0; i < N; ++i ) a[i] = __builtin_copysignf( __float_as_int( x[i] ) < 0 ? a2[i] : a[i], y[i] );
+	return a;
 	}
-__device__ __forceinline__ void sincos_fast_2( cf x, cf & s, cf & c )
+template<class V> __device__ __forceinline__ V magnitude_scaled_v( V re, V im )
 	{
-	const cf kf = x * bcast2( 0x1.45f306p-1f );
-	const cf k = cf{ __builtin_rintf( kf.x ), __builtin_rintf( kf.y ) };
-	cf r = pk_fma2( -k, bcast2( 0x1.921fb6p+0f ), x );
-	r = pk_fma2( -k, bcast2( -0x1.777a5cp-25f ), r );
-	r = pk_fma2( -k, bcast2( -0x1.ee59dap-50f ), r );
-	const cf r2 = r * r;
-	cf sp = bcast2( 0x1.6cd1e4p-19f );
-	sp = pk_fma2( sp, r2, bcast2( -0x1.a00f80p-13f ) );
-	sp = pk_fma2( sp, r2, bcast2( 0x1.111108p-7f ) );
-	sp = pk_fma2( sp, r2, bcast2( -0x1.555556p-3f ) );
-	const cf sr = pk_fma2( r * r2, sp, r );
-	cf cp = bcast2( 0x1.99eb7cp-16f );
-	cp = pk_fma2( cp, r2, bcast2( -0x1.6c0c34p-10f ) );
-	cp = pk_fma2( cp, r2, bcast2( 0x1.55554ap-5f ) );
-	cp = pk_fma2( cp, r2, bcast2( -0x1.000000p-1f ) );
-	const cf cr = pk_fma2( cp, r2, bcast2( 1.0f ) );
-	const int q0 = int( k.x ), q1 = int( k.y );
-	const float ss0 = ( q0 & 1 ) ? cr.x : sr.x, cc0 = ( q0 & 1 ) ? sr.x : cr.x;
-	const float ss1 = ( q1 & 1 ) ? cr.y : sr.y, cc1 = ( q1 & 1 ) ? sr.y : cr.y;
-	s = cf{ ( q0 & 2 ) ? -ss0 : ss0, ( q1 & 2 ) ? -ss1 : ss1 };
-	c = cf{ ( ( q0 + 1 ) & 2 ) ? -cc0 : cc0, ( ( q1 + 1 ) & 2 ) ? -cc1 : cc1 };
+	constexpr int N = vec_traits<V>::N;
+	const V a = __builtin_elementwise_max( __builtin_elementwise_abs( re ), __builtin_elementwise_abs( im ) );
+	int e[N];
+	V rs, is;
+	#pragma unroll
+	for( int i = 0; i < N; ++i )
+		{
+		e[i] = __builtin_amdgcn_frexp_expf( a[i] );
+		rs[i] = __builtin_ldexpf( re[i], -e[i] );
+		is[i] = __builtin_ldexpf( im[i], -e[i] );
+		}
+	const V s2 = vfma( rs, rs, is * is );
+	V m;
+	#pragma unroll
+	for( int i = 0; i < N; ++i ) m[i] = __builtin_ldexpf( __builtin_amdgcn_sqrtf( s2[i] ), e[i] );
+	return m;
+	}
+template<class V> __device__ __forceinline__ void sincos_fast_v( V x, V & s, V & c )
+	{
+	constexpr int N = vec_traits<V>::N;
+	const V kf = x * vsplat<V>( 0x1.45f306p-1f );
+	V k;
+	#pragma unroll
+	for( int i = 0; i < N; ++i ) k[i] = __builtin_rintf( kf[i] );
+	V r = vfma( -k, vsplat<V>( 0x1.921fb6p+0f ), x );
+	r = vfma( -k, vsplat<V>( -0x1.777a5cp-25f ), r );
+	r = vfma( -k, vsplat<V>( -0x1.ee59dap-50f ), r );
+	const V r2 = r * r;
+	V sp = vsplat<V>( 0x1.6cd1e4p-19f );
+	sp = vfma( sp, r2, vsplat<V>( -0x1.a00f80p-13f ) );
+	sp = vfma( sp, r2, vsplat<V>( 0x1.111108p-7f ) );
+	sp = vfma( sp, r2, vsplat<V>( -0x1.555556p-3f ) );
+	const V sr = vfma( r * r2, sp, r );
+	V cp = vsplat<V>( 0x1.99eb7cp-16f );
+	cp = vfma( cp, r2, vsplat<V>( -0x1.6c0c34p-10f ) );
+	cp = vfma( cp, r2, vsplat<V>( 0x1.55554ap-5f ) );
+	cp = vfma( cp, r2, vsplat<V>( -0x1.000000p-1f ) );
+	const V cr = vfma( cp, r2, vsplat<V>( 1.0f ) );
+	#pragma unroll
+	for( int i = 0; i < N; ++i )
+		{
+		const int q = int( k[i] );
+		const float ss = ( q & 1 ) ? cr[i] : sr[i], cc = ( q & 1 ) ? sr[i] : cr[i];
+		s[i] = ( q & 2 ) ? -ss : ss;
+		c[i] = ( ( q + 1 ) & 2 ) ? -cc : cc;
+		}
 	}
 
 struct MFv { float m, f; };
