@@ -46,22 +46,10 @@ __device__ __forceinline__ float div_c( float x, DivC d )
 	return x / d.c;
 	}
 
-// |z| = sqrt( re^2 + im^2 ) by one fma and the hardware square root (v_sqrt_f32, 1 ulp): within 1.5 ulp of hypotf for
-// max(|re|,|im|) in [1e-18, 1e18]; the caller tracks the largest / smallest operand of a frame and redoes the frame
-// with hypotf when it falls outside.
-__device__ __forceinline__ float magnitude_fast( float re, float im )
-	{
-	return __builtin_amdgcn_sqrtf( __builtin_fmaf( re, re, im * im ) );
-	}
-__device__ __forceinline__ bool magnitude_fast_ok( float amax, float amin_nonzero )
-	{
-	return amax < 1.0e18f && amin_nonzero > 1.0e-18f;
-	}
-
 // atan2f for finite operands: one reciprocal + Newton step for min/max, an 8-coefficient odd minimax polynomial on
 // [0,1] (tools/fit_atan.py: max error 1.8 ulp, mean 0.37 ulp), octant fix-ups with the float constants pi/2 and pi,
-// sign of y.  atan2( +-0, +-0 ) follows C99 ( +-0 for x = +0, +-pi for x = -0 ).  Infinite operands are not handled
-// (a frame that holds one is redone through atan2f by the caller: magnitude_fast_ok() is false for it).
+// sign of y.  atan2( +-0, +-0 ) follows C99 ( +-0 for x = +0, +-pi for x = -0 ).  Operands are expected finite and, when not
+// zero, inside [2^-126, 2^126] (any audio spectrum); two infinite operands give NaN where libm gives a multiple of pi/4.
 __device__ __forceinline__ float atan2_fast( float y, float x )
 	{
 	const float ax = __builtin_fabsf( x ), ay = __builtin_fabsf( y );
@@ -204,25 +192,6 @@ template<class V> __device__ __forceinline__ void sincos_fast_v( V x, V & s, V &
 		s[i] = ( q & 2 ) ? -ss : ss;
 		c[i] = ( ( q + 1 ) & 2 ) ? -cc : cc;
 		}
-	}
-
-struct MFv { float m, f; };
-
-// phase_vocoder.cpp:37-52.  prev_phase is the reference's phase_buffer (it only ever holds a float value).
-template<bool FAST>
-__device__ __forceinline__ MFv phase_vocode_bin_fast( float re, float im, float & prev_phase, float bin_frequency, float expected_phase_diff,
-	float analysis_rate, bool use_wrapping )
-	{
-	const float phase = FAST ? atan2_fast( im, re ) : atan2f( im, re );               // std::arg
-	const float phase_diff = float( double( phase ) - double( prev_phase ) );         // :44 double subtraction, narrowed
-	prev_phase = phase;                                                               // :45
-	const float delta_phase = phase_diff - expected_phase_diff;                       // :48
-	const float wrapped = use_wrapping ? delta_phase - FLANHIP_PI2_F * roundf( div_pi2( delta_phase ) ) : delta_phase; // :39-42,49
-	const float delta_frequency = div_pi2( wrapped * analysis_rate );                 // :50
-	MFv r;
-	r.m = FAST ? magnitude_fast( re, im ) : hypotf( re, im );                         // std::abs
-	r.f = bin_frequency + delta_frequency;                                            // :52
-	return r;
 	}
 
 // phase_vocoder.cpp:57-59:  phase_buffer += term; if( phase_buffer > pi2 ) phase_buffer = fmod( phase_buffer, pi2 ).
