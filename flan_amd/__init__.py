@@ -63,6 +63,13 @@ _SIGS = {
     "flanhip_shape_affine": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
     "flanhip_shape_affine_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
     "flanhip_shape_table_dev": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _f32, _i32, _vp, _vp]),
+    "flanhip_replace_amplitudes_dev": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _i64, _i64, _i32, _vp, _f32, _vp, _vp]),
+    "flanhip_subtract_amplitudes_dev": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _i64, _i64, _i32, _vp, _f32, _vp, _vp]),
+    "flanhip_resonate_out_frames": (_i64, [_i64, _f32, _f32, _i32]),
+    "flanhip_resonate_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i32, _i64, _vp, _f32, _vp, _vp]),
+    "flanhip_n_loudest_partials_dev": (C.c_int, [_vp, _i64, _i64, _i32, _vp, C.c_int32, _i32, _vp, _vp]),
+    "flanhip_desample_dev": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _f32, _i32, _vp, _vp]),
+    "flanhip_time_extrapolate_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i64, _i64, _i64, _vp, _vp, _vp]),
     "flanhip_mid_side_dev": (C.c_int, [_vp, _i64, _vp, _vp]),
     "flanhip_resample_out_frames": (_i64, [_i64, _f32, _f32]),
     "flanhip_resample": (C.c_int, [_vp, _i64, _i64, _f32, _f32, _vp, _vp]),
@@ -156,6 +163,114 @@ def shape_affine(pv, sample_rate, a, b, c, d, use_shift_alignment=False):
     out = np.empty_like(pv)
     check(lib.flanhip_shape_affine(_ptr(pv), ch, F, bins, sample_rate, a, b, c, d, int(use_shift_alignment), _ptr(out), None))
     return out
+
+
+class DeviceArray:
+    """A device buffer owned through the C ABI (flanhip_malloc / flanhip_free), optionally filled from a numpy array."""
+
+    def __init__(self, nbytes=None, host=None):
+        if host is not None:
+            host = np.ascontiguousarray(host)
+            nbytes = host.nbytes
+        self.nbytes = int(nbytes)
+        p = _vp()
+        check(lib.flanhip_malloc(C.byref(p), max(self.nbytes, 1)))
+        self.ptr = p.value
+        if host is not None and self.nbytes:
+            check(lib.flanhip_memcpy_h2d(_vp(self.ptr), _ptr(host), self.nbytes, None))
+
+    def data_ptr(self):
+        return self.ptr
+
+    def to_host(self, shape, dtype=np.float32):
+        out = np.empty(shape, dtype)
+        assert out.nbytes == self.nbytes, (out.nbytes, self.nbytes)
+        if self.nbytes:
+            check(lib.flanhip_memcpy_d2h(_ptr(out), _vp(self.ptr), self.nbytes, None))
+        check(lib.flanhip_stream_synchronize(None))
+        return out
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            lib.flanhip_free(_vp(self.ptr))
+            self.ptr = None
+
+
+def _grid_or_const(grid):
+    """(device pointer or None, constant) for a sampled user function: numpy grid, or a python scalar"""
+    if np.isscalar(grid):
+        return None, float(grid), None
+    d = DeviceArray(host=np.ascontiguousarray(grid, np.float32))
+    return _vp(d.ptr), 0.0, d
+
+
+def _combine_amplitudes(fn, pv, src, amount):
+    pv = np.ascontiguousarray(pv, np.float32)
+    src = np.ascontiguousarray(src, np.float32)
+    ch, F, bins, _ = pv.shape
+    sch, sF, sbins, _ = src.shape
+    d_pv, d_src, d_out = DeviceArray(host=pv), DeviceArray(host=src), DeviceArray(pv.nbytes)
+    a_ptr, a_const, _keep = _grid_or_const(amount)
+    check(fn(_vp(d_pv.ptr), ch, F, bins, _vp(d_src.ptr), sch, sF, sbins, a_ptr, a_const, _vp(d_out.ptr), None))
+    return d_out.to_host(pv.shape)
+
+
+def replace_amplitudes(pv, src, amount):
+    """PV::replace_amplitudes.  amount: float32 [F][bins] or a scalar"""
+    return _combine_amplitudes(lib.flanhip_replace_amplitudes_dev, pv, src, amount)
+
+
+def subtract_amplitudes(pv, src, amount):
+    """PV::subtract_amplitudes"""
+    return _combine_amplitudes(lib.flanhip_subtract_amplitudes_dev, pv, src, amount)
+
+
+def resonate(pv, sample_rate, hop, length_seconds, decay):
+    """PV::resonate.  decay: float32 [Fo][bins] over the OUTPUT's domain, or a scalar"""
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    Fo = int(lib.flanhip_resonate_out_frames(F, length_seconds, sample_rate, hop))
+    assert Fo >= F, Fo
+    d_pv, d_out = DeviceArray(host=pv), DeviceArray(ch * Fo * bins * 8)
+    d_ptr, d_const, _keep = _grid_or_const(decay)
+    check(lib.flanhip_resonate_dev(_vp(d_pv.ptr), ch, F, bins, sample_rate, hop, Fo, d_ptr, d_const, _vp(d_out.ptr), None))
+    return d_out.to_host((ch, Fo, bins, 2))
+
+
+def n_loudest_partials(pv, n, remove=False):
+    """PV::retain_n_loudest_partials / remove_n_loudest_partials.  n: int32 [F] or a scalar"""
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    d_pv, d_out = DeviceArray(host=pv), DeviceArray(pv.nbytes)
+    if np.isscalar(n):
+        n_ptr, n_const, _keep = None, int(n), None
+    else:
+        _keep = DeviceArray(host=np.ascontiguousarray(n, np.int32))
+        n_ptr, n_const = _vp(_keep.ptr), 0
+    check(lib.flanhip_n_loudest_partials_dev(_vp(d_pv.ptr), ch, F, bins, n_ptr, n_const, int(remove), _vp(d_out.ptr), None))
+    return d_out.to_host(pv.shape)
+
+
+def desample(pv, ratio, interp=0):
+    """PV::desample.  ratio: float32 [F][bins] or a scalar; interp: FLANHIP_INTERP_*"""
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    d_pv, d_out = DeviceArray(host=pv), DeviceArray(pv.nbytes)
+    r_ptr, r_const, _keep = _grid_or_const(ratio)
+    check(lib.flanhip_desample_dev(_vp(d_pv.ptr), ch, F, bins, r_ptr, r_const, interp, _vp(d_out.ptr), None))
+    return d_out.to_host(pv.shape)
+
+
+def time_extrapolate(pv, sample_rate, start_frame, end_frame, out_frames, interp_samples):
+    """PV::time_extrapolate after its input validation.  interp_samples: float32 [out_frames - start_frame]"""
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    samples = np.ascontiguousarray(interp_samples, np.float32)
+    assert samples.shape == (out_frames - start_frame,)
+    d_pv, d_s, d_out = DeviceArray(host=pv), DeviceArray(host=samples), DeviceArray(ch * out_frames * bins * 8)
+    check(lib.flanhip_time_extrapolate_dev(_vp(d_pv.ptr), ch, F, bins, sample_rate, start_frame, end_frame, out_frames,
+                                           _vp(d_s.ptr), _vp(d_out.ptr), None))
+    return d_out.to_host((ch, out_frames, bins, 2))
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -6,19 +6,12 @@
 // sequential order along the dependent axis and spreads the independent axes over lanes:
 //   k_modify_time      : lane = bin      (adjacent lanes -> adjacent bins: coalesced 8-byte MF traffic), loop over frames
 //   k_modify_frequency : lane = frame    (rows are walked by one lane; the row stays in L2)
-//   k_shape            : lane = element (no alignment) or lane = frame (shift alignment: conflict rule is sequential)
-#include "flanhip_internal.h"
+//   k_shape            : lane = element (no alignment) or wavefront = row (shift alignment: the sequential conflict rule is
+//                        resolved through LDS keys, processors_common.h)
+#include "processors_common.h"
 #include <algorithm>
 
 namespace flanhip {
-
-struct MFd { float m, f; };
-
-// PVBuffer.cpp:428-431, :433-436, :438-441, :443-446
-__device__ __forceinline__ float time_to_frame( float t, float sr, float hop ) { return t * sr / hop; }
-__device__ __forceinline__ float frame_to_time( float f, float sr, float hop ) { return f / ( sr / hop ); }
-__device__ __forceinline__ float frequency_to_bin( float f, float sr, float dft ) { return f / ( sr / dft ); }
-__device__ __forceinline__ float bin_to_frequency( float b, float sr, float dft ) { return b * sr / dft; }
 
 // modify_time_base, PVModify.cpp:319-359 (linear Interpolator, Utility/Interpolator.cpp:50-56).  out is zeroed by the caller.
 //
@@ -267,37 +260,36 @@ __global__ __launch_bounds__( 256 ) void k_shape_plain( const MFd * in, const MF
 	else out[idx] = shaped_tbl[idx];
 	}
 
+// Shift alignment (PV.cpp:438-448): one WAVEFRONT per (channel, frame) row; the sequential "strictly louder replaces" rule is
+// resolved through LDS keys (processors_common.h placement_offer).  keys: dynamic LDS, bins u64 per wave.
 template<bool AFFINE>
-__global__ __launch_bounds__( 64 ) void k_shape_aligned( const MFd * in, const MFd * shaped_tbl, int64_t rows, int bins, float sr, float dft,
+__global__ __launch_bounds__( 256 ) void k_shape_aligned( const MFd * in, const MFd * shaped_tbl, int64_t rows, int bins, float sr, float dft,
 	float a, float b, float c, float d, MFd * out )
 	{
-	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
+	extern __shared__ unsigned long long s_keys[];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int64_t idx = int64_t( blockIdx.x ) * ( blockDim.x >> 6 ) + wave;
 	if( idx >= rows ) return;
+	unsigned long long * keys = s_keys + size_t( wave ) * bins;
 	const MFd * row = in + idx * bins;
 	MFd * orow = out + idx * bins;
-	for( int bin = 0; bin < bins; ++bin )                                           // :433
+	auto shaped = [&]( int bin ) { const MFd v = row[bin]; return AFFINE ? MFd{ a * v.m + b, c * v.f + d } : shaped_tbl[idx * bins + bin]; };   // :436
+	for( int bin = lane; bin < bins; bin += 64 ) keys[bin] = 0ull;
+	wave_sync();
+	for( int bin = lane; bin < bins; bin += 64 )                                   // :433
 		{
-		const MFd v = row[bin];
-		const MFd s = AFFINE ? MFd{ a * v.m + b, c * v.f + d } : shaped_tbl[idx * bins + bin];
-		const int binShift = int( float( bin ) - frequency_to_bin( v.f, sr, dft ) ); // :440
-		const int shapedBin = int( frequency_to_bin( s.f, sr, dft ) + float( binShift ) ); // :441
+		const MFd s = shaped( bin );
+		const int binShift = to_int_sat( float( bin ) - frequency_to_bin( row[bin].f, sr, dft ) );      // :440
+		const int shapedBin = to_int_sat( frequency_to_bin( s.f, sr, dft ) + float( binShift ) );       // :441
 		if( shapedBin < 0 || bins <= shapedBin ) continue;                          // :442
-		if( s.m > orow[shapedBin].m ) orow[shapedBin] = s;                          // :445-447
+		placement_offer( keys, shapedBin, s.m, bin );                               // :445-447
 		}
-	}
-
-struct DevBuf
-	{
-	void * p = nullptr;
-	~DevBuf() { if( p ) (void) hipFree( p ); }
-	int alloc( size_t bytes ) { FLANHIP_CHECK( hipMalloc( &p, bytes ? bytes : 1 ) ); return FLANHIP_OK; }
-	};
-
-static int check_pv_args( const void * a, const void * b, int64_t ch, int64_t F, int bins, float sr )
-	{
-	FLANHIP_REQUIRE( a && b, FLANHIP_ERR_INVALID_ARG, "null buffer" );
-	FLANHIP_REQUIRE( ch > 0 && F > 0 && bins >= 2 && sr > 0.0f, FLANHIP_ERR_INVALID_ARG, "bad sizes" );
-	return require_device();
+	wave_sync();
+	for( int bin = lane; bin < bins; bin += 64 )
+		{
+		const unsigned long long key = keys[bin];
+		orow[bin] = key ? shaped( placement_winner( key ) ) : MFd{ 0.0f, 0.0f };    // :426 clear_buffer
+		}
 	}
 
 } // namespace flanhip
@@ -439,11 +431,13 @@ static int shape_common( const flanhip_MF * d_pv, const flanhip_MF * d_tbl, bool
 		}
 	else
 		{
-		FLANHIP_CHECK( hipMemsetAsync( d_out, 0, sizeof( flanhip_MF ) * size_t( count ), s ) );        // clear_buffer, PV.cpp:426
 		const int64_t rows = ch * F;
-		const unsigned blocks = (unsigned) ( ( rows + 63 ) / 64 );
-		if( affine ) hipLaunchKernelGGL( k_shape_aligned<true>, dim3( blocks ), dim3( 64 ), 0, s, (const MFd*) d_pv, (const MFd*) nullptr, rows, bins, sr, dft, a, b, c, d, (MFd*) d_out );
-		else         hipLaunchKernelGGL( k_shape_aligned<false>, dim3( blocks ), dim3( 64 ), 0, s, (const MFd*) d_pv, (const MFd*) d_tbl, rows, bins, sr, dft, a, b, c, d, (MFd*) d_out );
+		const size_t per_wave = sizeof( unsigned long long ) * size_t( bins );
+		FLANHIP_REQUIRE( per_wave <= 65536, FLANHIP_ERR_UNSUPPORTED, "shift alignment: more than 8192 bins" );
+		const int waves = int( std::min<size_t>( 4, 65536 / per_wave ) );
+		const unsigned blocks = (unsigned) ( ( rows + waves - 1 ) / waves );
+		if( affine ) hipLaunchKernelGGL( k_shape_aligned<true>, dim3( blocks ), dim3( 64 * waves ), per_wave * waves, s, (const MFd*) d_pv, (const MFd*) nullptr, rows, bins, sr, dft, a, b, c, d, (MFd*) d_out );
+		else         hipLaunchKernelGGL( k_shape_aligned<false>, dim3( blocks ), dim3( 64 * waves ), per_wave * waves, s, (const MFd*) d_pv, (const MFd*) d_tbl, rows, bins, sr, dft, a, b, c, d, (MFd*) d_out );
 		}
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;

@@ -147,6 +147,55 @@ int flanhip_shape_table_dev(const flanhip_MF * d_pv, const flanhip_MF * d_shaped
                             int64_t num_pv_frames, int num_bins, float sample_rate, int use_shift_alignment,
                             flanhip_MF * d_out, void * stream);
 
+/* ---- further PV frame processors.  User functions are SAMPLED BY THE CALLER, as the reference samples
+ * them on the host before its loops (PV.h:31-35, Function.h:141-171): a grid pointer, or NULL plus a constant. ------------- */
+
+/* Utility/Interpolator.cpp:14-101: the named interpolators a device kernel can evaluate itself */
+#define FLANHIP_INTERP_LINEAR        0
+#define FLANHIP_INTERP_MIDPOINT      1
+#define FLANHIP_INTERP_NEAREST       2
+#define FLANHIP_INTERP_FLOOR         3
+#define FLANHIP_INTERP_CEIL          4
+#define FLANHIP_INTERP_SMOOTHSTEP    5
+#define FLANHIP_INTERP_SMOOTHERSTEP  6
+#define FLANHIP_INTERP_SQRT          7
+#define FLANHIP_INTERP_SINE          8   /* cosf based: agrees with the host libm to 1-2 ulp, not bit for bit */
+
+/* PV::replace_amplitudes (PV/PV.cpp:205-236): out = { src.m * a + m * (1-a), f }, a = clamp(amount,0,1), on the overlap of the
+ * two PVs; zero elsewhere.  d_amount: float[F][bins] over THIS pv's domain, or NULL to use amount_const. */
+int flanhip_replace_amplitudes_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_frames, int num_bins,
+                                   const flanhip_MF * d_src, int64_t src_channels, int64_t src_frames, int src_bins,
+                                   const float * d_amount, float amount_const, flanhip_MF * d_out, void * stream);
+/* PV::subtract_amplitudes (PV/PV.cpp:238-264): out = copy, m = |m - src.m * amount| on the overlap (amount not clamped) */
+int flanhip_subtract_amplitudes_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_frames, int num_bins,
+                                    const flanhip_MF * d_src, int64_t src_channels, int64_t src_frames, int src_bins,
+                                    const float * d_amount, float amount_const, flanhip_MF * d_out, void * stream);
+
+/* PV::resonate (PV/PV.cpp:604-641).  Output frames (:613) = num_frames + ceil( time_to_frame( max(length,0) ) ). */
+int64_t flanhip_resonate_out_frames(int64_t num_frames, float length_seconds, float sample_rate, int hop);
+/* d_decay: float[out_frames][bins] sampled over the OUTPUT's domain (:616), or NULL to use decay_const; clamped to [0,1] (:617).
+ * The per-frame factor pow(decay, seconds per frame) (:631) is the host libm's powf for a constant (bit for bit the
+ * reference's call on this platform) and the correctly rounded power for a grid. */
+int flanhip_resonate_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_frames, int num_bins, float sample_rate, int hop,
+                         int64_t out_frames, const float * d_decay, float decay_const, flanhip_MF * d_out, void * stream);
+
+/* PV::retain_n_loudest_partials / remove_n_loudest_partials (PV/PV.cpp:552-602).  d_n: int32[num_frames], the sampled
+ * Function<Second,Bin> (:555), or NULL to use n_const; clamped to [0, num_frames] as the reference does (:556).
+ * Bins of equal |m| rank by ascending bin (the reference's std::sort leaves their order unspecified). */
+int flanhip_n_loudest_partials_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_frames, int num_bins,
+                                   const int32_t * d_n, int32_t n_const, int remove, flanhip_MF * d_out, void * stream);
+
+/* PV::desample (PV/PVModify.cpp:445-511).  d_ratio: float[F][bins] or NULL + ratio_const; interp: FLANHIP_INTERP_* */
+int flanhip_desample_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_frames, int num_bins,
+                         const float * d_ratio, float ratio_const, int interp, flanhip_MF * d_out, void * stream);
+
+/* PV::time_extrapolate (PV/PVModify.cpp:607-666) after its input validation: 0 <= start_frame < end_frame < num_frames,
+ * out_frames = end_frame + extrapolated frames (:627), d_interp_samples: float[out_frames - start_frame] sampled by the caller
+ * as :631-633 does.  d_out: MF[ch][out_frames][bins]. */
+int flanhip_time_extrapolate_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_frames, int num_bins, float sample_rate,
+                                 int64_t start_frame, int64_t end_frame, int64_t out_frames, const float * d_interp_samples,
+                                 flanhip_MF * d_out, void * stream);
+
 /* ---- Audio::convert_to_mid_side / convert_to_left_right (Audio/AudioConversions.cpp:32-56), stereo only ------ */
 int flanhip_mid_side_dev(const float * d_in, int64_t num_audio_frames, float * d_out, void * stream);
 

@@ -3,7 +3,7 @@
 // TEST INFRASTRUCTURE ONLY.  Compiled (by oracle/Makefile, only where /root/reference exists) together with
 // the reference's own sources, read in place from /root/reference/src:
 //     flan/phase_vocoder.cpp  flan/WindowFunctions.cpp  flan/PV/PVBuffer.cpp  flan/Utility/Bytes.cpp
-//     flan/Utility/buffer_access.cpp  flan/Utility/Interpolator.cpp  flan/Function.cpp  flan/Utility/execution.cpp ...
+//     flan/Utility/buffer_access.cpp  flan/Utility/Interpolator.cpp  flan/Utility/{Interval,Color,Rect}.cpp
 // into oracle/_ref/libflanref.so.  No reference source is copied into this repository and no stand-in header or
 // library is written: translation units that need FFTW3f / libsndfile / MSVC's std::_Pi (Conversions/AudioPV.cpp,
 // PV/PVModify.cpp, PV/PV.cpp, Audio/*.cpp, FFTHelper.cpp) are simply NOT built -- see DESIGN.md.
@@ -18,6 +18,7 @@
 #include "flan/phase_vocoder.h"
 #include "flan/WindowFunctions.h"
 #include "flan/PV/PVBuffer.h"
+#include "flan/Utility/Interpolator.h"
 
 extern "C" {
 
@@ -100,6 +101,25 @@ int ref_pv_load( const char * filename, RefPVFormat * f, float * mf, int64_t mf_
 	if( mf && count <= mf_capacity )
 		std::memcpy( mf, pv.get_buffer().data(), sizeof( flan::MF ) * count );
 	return (int) ( count > 0 );
+	}
+
+// Utility/Interpolator.cpp: the named interpolators, numbered as oracle_interpolate numbers them
+float ref_interpolate( int kind, float x )
+	{
+	using flan::Interpolator;
+	switch( kind )
+		{
+		case 0: return Interpolator::linear()( x );
+		case 1: return Interpolator::midpoint()( x );
+		case 2: return Interpolator::nearest()( x );
+		case 3: return Interpolator::floor()( x );
+		case 4: return Interpolator::ceil()( x );
+		case 5: return Interpolator::smoothstep()( x );
+		case 6: return Interpolator::smootherstep()( x );
+		case 7: return Interpolator::sqrt()( x );
+		case 8: return Interpolator::sine()( x );
+		}
+	return x;
 	}
 
 } // extern "C"

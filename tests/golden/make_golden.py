@@ -37,7 +37,27 @@ def make_input(kind, ch, n, seed):
     return O.noise(ch, n, seed)
 
 
+def ext_cases(pv):
+    """inputs + oracle outputs of the further frame processors (oracle/processors_oracle.cpp) on one small PV"""
+    ch, F, bins, _ = pv.shape
+    rng = np.random.default_rng(99)
+    amount = rng.uniform(-0.2, 1.2, (F, bins)).astype(np.float32)
+    src = pv[:, ::-1].copy()
+    n = rng.integers(0, 60, F).astype(np.int32)
+    ratio = rng.uniform(0.0, 0.6, (F, bins)).astype(np.float32)
+    start, end, Fo = 2, 12, 30
+    samples = O.time_extrapolate_interp_samples(start, end, Fo, 0)
+    return dict(pv=pv, amount=amount, src=src, n=n, ratio=ratio, te_params=np.array([start, end, Fo], np.int64), te_samples=samples,
+                replace=O.replace_amplitudes(pv, src, amount), subtract=O.subtract_amplitudes(pv, src, amount),
+                resonate=O.resonate(pv, SR, 256, 0.05, 0.5, pow_mode=0), retain=O.n_loudest_partials(pv, n, False),
+                remove=O.n_loudest_partials(pv, n, True), desample=O.desample(pv, ratio, 0),
+                time_extrapolate=O.time_extrapolate(pv, SR, start, end, Fo, samples))
+
+
 def main():
+    pv = O.analyze(O.noise(1, 5003, 11), SR, 1024, 256, 1024)
+    os.makedirs(os.path.join(HERE, "processors"), exist_ok=True)
+    np.savez_compressed(os.path.join(HERE, "processors", "processors_ext.npz"), **ext_cases(pv))
     for name, (ch, n, W, hop, dft, kind, seed) in CASES.items():
         x = make_input(kind, ch, n, seed)
         pv = O.analyze(x, SR, W, hop, dft)

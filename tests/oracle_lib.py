@@ -61,6 +61,17 @@ def _load():
     lib.oracle_resample_out_frames.restype = C.c_int64
     lib.oracle_resample_out_frames.argtypes = [C.c_int64, C.c_float, C.c_float]
     lib.oracle_resample_2to1.argtypes = [f32p, C.c_int64, f32p, C.c_int64]
+    i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+    lib.oracle_interpolate.restype = C.c_float
+    lib.oracle_interpolate.argtypes = [C.c_int, C.c_float]
+    for name in ("oracle_replace_amplitudes", "oracle_subtract_amplitudes"):
+        getattr(lib, name).argtypes = [f32p, C.c_int, C.c_int64, C.c_int, f32p, C.c_int, C.c_int64, C.c_int, f32p, f32p]
+    lib.oracle_resonate_out_frames.restype = C.c_int64
+    lib.oracle_resonate_out_frames.argtypes = [C.c_int64, C.c_float, C.c_float, C.c_int]
+    lib.oracle_resonate.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_int, C.c_int64, f32p, C.c_int, f32p]
+    lib.oracle_n_loudest_partials.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, i32p, C.c_int, f32p]
+    lib.oracle_desample.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, f32p, C.c_int, f32p]
+    lib.oracle_time_extrapolate.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_int64, C.c_int64, C.c_int64, f32p, f32p]
     return lib
 
 
@@ -93,6 +104,8 @@ def load_ref():
     ref.ref_pv_is_nan_or_inf.argtypes = [RefPVFormat, f32p]
     ref.ref_pv_save.argtypes = [RefPVFormat, f32p, C.c_char_p]
     ref.ref_pv_load.argtypes = [C.c_char_p, C.POINTER(RefPVFormat), C.c_void_p, C.c_int64]
+    ref.ref_interpolate.restype = C.c_float
+    ref.ref_interpolate.argtypes = [C.c_int, C.c_float]
     return ref
 
 
@@ -184,6 +197,76 @@ def shape_affine(pv, sample_rate, a, b, c, d, use_shift_alignment=False):
     out = np.empty_like(pv)
     lib.oracle_shape_affine(pv.reshape(-1), ch, F, bins, sample_rate, a, b, c, d, int(use_shift_alignment), out.reshape(-1))
     return out
+
+
+def _grid(g, F, bins):
+    """a sampled user function as a full float32 [F][bins] grid (scalars are broadcast, like a constant Function)"""
+    if np.isscalar(g):
+        return np.full((F, bins), g, np.float32)
+    g = np.ascontiguousarray(g, np.float32)
+    assert g.shape == (F, bins), (g.shape, F, bins)
+    return g
+
+
+def _combine(fn, pv, src, amount):
+    pv = np.ascontiguousarray(pv, np.float32)
+    src = np.ascontiguousarray(src, np.float32)
+    ch, F, bins, _ = pv.shape
+    sch, sF, sbins, _ = src.shape
+    out = np.empty_like(pv)
+    fn(pv.reshape(-1), ch, F, bins, src.reshape(-1), sch, sF, sbins, _grid(amount, F, bins).reshape(-1), out.reshape(-1))
+    return out
+
+
+def replace_amplitudes(pv, src, amount):
+    return _combine(lib.oracle_replace_amplitudes, pv, src, amount)
+
+
+def subtract_amplitudes(pv, src, amount):
+    return _combine(lib.oracle_subtract_amplitudes, pv, src, amount)
+
+
+def resonate(pv, sample_rate, hop, length_seconds, decay, pow_mode=0):
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    Fo = int(lib.oracle_resonate_out_frames(F, length_seconds, sample_rate, hop))
+    out = np.empty((ch, Fo, bins, 2), np.float32)
+    lib.oracle_resonate(pv.reshape(-1), ch, F, bins, sample_rate, hop, Fo, _grid(decay, Fo, bins).reshape(-1), pow_mode, out.reshape(-1))
+    return out
+
+
+def n_loudest_partials(pv, n, remove=False):
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    n = np.full(F, n, np.int32) if np.isscalar(n) else np.ascontiguousarray(n, np.int32)
+    out = np.empty_like(pv)
+    lib.oracle_n_loudest_partials(pv.reshape(-1), ch, F, bins, n, int(remove), out.reshape(-1))
+    return out
+
+
+def desample(pv, ratio, interp=0):
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    out = np.empty_like(pv)
+    lib.oracle_desample(pv.reshape(-1), ch, F, bins, _grid(ratio, F, bins).reshape(-1), interp, out.reshape(-1))
+    return out
+
+
+def time_extrapolate(pv, sample_rate, start_frame, end_frame, out_frames, interp_samples):
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    samples = np.ascontiguousarray(interp_samples, np.float32)
+    assert samples.shape == (out_frames - start_frame,)
+    out = np.empty((ch, out_frames, bins, 2), np.float32)
+    lib.oracle_time_extrapolate(pv.reshape(-1), ch, F, bins, sample_rate, start_frame, end_frame, out_frames, samples, out.reshape(-1))
+    return out
+
+
+def time_extrapolate_interp_samples(start_frame, end_frame, out_frames, interp=0):
+    """PVModify.cpp:631-633 literally (the sample for output frame start+k is interp((k - start)/(end - start)))"""
+    k = np.arange(out_frames - start_frame, dtype=np.int64)
+    x = (k - start_frame).astype(np.float32) / np.float32(end_frame - start_frame)
+    return np.array([lib.oracle_interpolate(interp, float(v)) for v in x], np.float32)
 
 
 def mid_side(audio):
