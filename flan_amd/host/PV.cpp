@@ -2,6 +2,7 @@
 // (reference: Conversions/AudioPV.cpp:86-145, PV/PVModify.cpp:196-385, PV/PV.cpp:421-458).
 #include "flan/PV.h"
 
+#include <algorithm>
 #include <cmath>
 #include <iostream>
 
@@ -218,6 +219,130 @@ PV PV::shape_affine( float a, float b, float c, float d, bool use_shift_alignmen
 			a, b, c, d, use_shift_alignment ? 1 : 0, static_cast<flanhip_MF*>( out->ptr ), nullptr ), "shape_affine" ) ) return PV();
 	if( !detail::report( flanhip_stream_synchronize( nullptr ), "shape_affine" ) ) return PV();
 	return PVBuffer::adopt_device( get_format(), std::move( out ) );
+	}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// further frame processors (PV/PV.cpp:205-264, :552-641; PV/PVModify.cpp:445-511, :607-666)
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+// a sampled Function<TF,float> as the ( device grid or nullptr, constant ) pair the C ABI takes
+struct GridArg { std::shared_ptr<DeviceBlock> block; const float * ptr = nullptr; float constant = 0.0f; bool ok = true; };
+GridArg grid_arg( const FunctionSample2d<float> & s )
+	{
+	GridArg g;
+	if( s.is_constant() ) { g.constant = s.get_constant(); return g; }
+	g.block = upload( s.get_vector().data(), sizeof( float ) * s.size() );
+	g.ok = bool( g.block );
+	if( g.ok ) g.ptr = static_cast<const float*>( g.block->ptr );
+	return g;
+	}
+PV finish( int rc, const char * what, const PVBuffer::Format & f, std::shared_ptr<DeviceBlock> out )
+	{
+	if( !detail::report( rc, what ) ) return PV();
+	if( !detail::report( flanhip_stream_synchronize( nullptr ), what ) ) return PV();
+	return PVBuffer::adopt_device( f, std::move( out ) );
+	}
+size_t mf_count( const PVBuffer::Format & f ) { return size_t( f.num_channels ) * f.num_frames * f.num_bins; }
+}
+
+static PV combine_amplitudes( const PV & me, const PV & amp_source, const Function<TF, float> & amount, bool subtract )
+	{
+	if( me.is_null() || amp_source.is_null() ) return PV();                        // PV.cpp:207-210
+	const GridArg g = grid_arg( me.sample_function_over_domain( amount ) );        // :211
+	const MF * d_pv = me.device_data();
+	const MF * d_src = amp_source.device_data();
+	auto out = DeviceBlock::allocate( sizeof( MF ) * mf_count( me.get_format() ) );
+	if( !g.ok || !d_pv || !d_src || !out ) return PV();
+	const auto fn = subtract ? flanhip_subtract_amplitudes_dev : flanhip_replace_amplitudes_dev;
+	const int rc = fn( reinterpret_cast<const flanhip_MF*>( d_pv ), me.get_num_channels(), me.get_num_frames(), me.get_num_bins(),
+		reinterpret_cast<const flanhip_MF*>( d_src ), amp_source.get_num_channels(), amp_source.get_num_frames(), amp_source.get_num_bins(),
+		g.ptr, g.constant, static_cast<flanhip_MF*>( out->ptr ), nullptr );
+	return finish( rc, subtract ? "subtract_amplitudes" : "replace_amplitudes", me.get_format(), std::move( out ) );
+	}
+
+PV PV::replace_amplitudes( const PV & amp_source, const Function<TF, float> & amount ) const { return combine_amplitudes( *this, amp_source, amount, false ); }
+PV PV::subtract_amplitudes( const PV & amp_source, const Function<TF, float> & amount ) const { return combine_amplitudes( *this, amp_source, amount, true ); }
+
+// predicateNLoudestPartials, PV.cpp:552-590
+static PV n_loudest( const PV & me, const Function<Second, Bin> & num_bins, bool remove )
+	{
+	if( me.is_null() ) return PV();
+	const auto sampled = num_bins.sample( 0, me.get_num_frames(), me.frame_to_time( 1 ) );   // :555
+	std::shared_ptr<DeviceBlock> d_n;
+	if( !sampled.is_constant() )
+		{
+		static_assert( sizeof( Bin ) == sizeof( int32_t ), "Bin is int32" );
+		d_n = upload( sampled.get_vector().data(), sizeof( int32_t ) * sampled.get_vector().size() );
+		if( !d_n ) return PV();
+		}
+	const MF * d_pv = me.device_data();
+	auto out = DeviceBlock::allocate( sizeof( MF ) * mf_count( me.get_format() ) );
+	if( !d_pv || !out ) return PV();
+	const int rc = flanhip_n_loudest_partials_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), me.get_num_channels(), me.get_num_frames(), me.get_num_bins(),
+		d_n ? static_cast<const int32_t*>( d_n->ptr ) : nullptr, sampled.is_constant() ? int32_t( sampled.get_constant() ) : 0, remove ? 1 : 0,
+		static_cast<flanhip_MF*>( out->ptr ), nullptr );
+	return finish( rc, remove ? "remove_n_loudest_partials" : "retain_n_loudest_partials", me.get_format(), std::move( out ) );
+	}
+
+PV PV::retain_n_loudest_partials( const Function<Second, Bin> & num_bins ) const { return n_loudest( *this, num_bins, false ); }
+PV PV::remove_n_loudest_partials( const Function<Second, Bin> & num_bins ) const { return n_loudest( *this, num_bins, true ); }
+
+PV PV::resonate( Second length, const Function<TF, float> & decay ) const
+	{
+	if( is_null() ) return PV();
+	const int64_t Fo = flanhip_resonate_out_frames( get_num_frames(), length, get_sample_rate(), get_hop_size() );   // PV.cpp:609-613
+	if( Fo < get_num_frames() ) return PV();
+	PVBuffer::Format f = get_format();
+	f.num_frames = Frame( Fo );
+	// :616: decay is sampled over the OUTPUT's domain
+	const GridArg g = grid_arg( decay.sample( 0, float( f.num_frames ), 1.0f / get_analysis_rate(), 0, float( f.num_bins ), bin_to_frequency( 1 ) ) );
+	const MF * d_pv = device_data();
+	auto out = DeviceBlock::allocate( sizeof( MF ) * mf_count( f ) );
+	if( !g.ok || !d_pv || !out ) return PV();
+	const int rc = flanhip_resonate_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(), get_sample_rate(),
+		get_hop_size(), Fo, g.ptr, g.constant, static_cast<flanhip_MF*>( out->ptr ), nullptr );
+	return finish( rc, "resonate", f, std::move( out ) );
+	}
+
+PV PV::desample( const Function<TF, float> & decimation_ratio, const Interpolator & interp ) const
+	{
+	if( is_null() ) return PV();
+	if( interp.kind() < 0 ) { std::cerr << "flan: desample runs the named interpolators only on the device path" << std::endl; return PV(); }
+	const GridArg g = grid_arg( sample_function_over_domain( decimation_ratio ) ); // PVModify.cpp:450
+	const MF * d_pv = device_data();
+	auto out = DeviceBlock::allocate( sizeof( MF ) * mf_count( get_format() ) );
+	if( !g.ok || !d_pv || !out ) return PV();
+	const int rc = flanhip_desample_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(), g.ptr, g.constant,
+		interp.kind(), static_cast<flanhip_MF*>( out->ptr ), nullptr );
+	return finish( rc, "desample", get_format(), std::move( out ) );
+	}
+
+PV PV::time_extrapolate( Second start_time, Second end_time, Second extrapolation_time, const Interpolator & interpolator ) const
+	{
+	if( is_null() ) return PV();
+	// Input validation, PVModify.cpp:612-617
+	start_time = std::clamp( start_time, 0.0f, get_length() );
+	if( end_time == -1 ) end_time = get_length();
+	end_time = std::clamp( end_time, 0.0f, get_length() );
+	if( start_time >= end_time ) return PV();
+	if( extrapolation_time <= 0 ) return PV();
+	const Frame start_frame = Frame( time_to_frame( start_time ) );                // :619-621
+	Frame end_frame = Frame( time_to_frame( end_time ) );
+	const Frame ext_frames = Frame( time_to_frame( extrapolation_time ) );
+	end_frame = std::min( end_frame, get_num_frames() - 1 );                       // the reference reads this frame unchecked (:649)
+	if( start_frame >= end_frame || ext_frames <= 0 ) return PV();
+	PVBuffer::Format f = get_format();
+	f.num_frames = end_frame + ext_frames;                                         // :623-624
+	std::vector<float> interp_samples( size_t( f.num_frames - start_frame ) );     // :631-633, literally
+	for( Frame frame = 0; frame < Frame( interp_samples.size() ); ++frame )
+		interp_samples[frame] = interpolator( float( frame - start_frame ) / float( end_frame - start_frame ) );
+	auto d_samples = upload( interp_samples.data(), sizeof( float ) * interp_samples.size() );
+	const MF * d_pv = device_data();
+	auto out = DeviceBlock::allocate( sizeof( MF ) * mf_count( f ) );
+	if( !d_samples || !d_pv || !out ) return PV();
+	const int rc = flanhip_time_extrapolate_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(),
+		get_sample_rate(), start_frame, end_frame, f.num_frames, static_cast<const float*>( d_samples->ptr ), static_cast<flanhip_MF*>( out->ptr ), nullptr );
+	return finish( rc, "time_extrapolate", f, std::move( out ) );
 	}
 
 } // namespace flan

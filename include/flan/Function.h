@@ -9,6 +9,7 @@
 // here a constant c behaves exactly like the callable `[](TF){ return c; }`.
 #pragma once
 #include <algorithm>
+#include <cmath>
 #include <functional>
 #include <thread>
 #include <type_traits>
@@ -97,25 +98,54 @@ struct Function
 		return FunctionSample2d<O>{ std::move( out ), size_t( x_size ) * y_size, size_t( y_size ) };
 		}
 
+	// Function.h:141-153: sample a function of one variable at x*scale, x in [start, end); a constant stays a constant
+	// (FunctionSample.h:18-40)
+	struct Sample1d
+		{
+		std::variant<O, std::vector<O>> value;
+		bool is_constant() const { return std::holds_alternative<O>( value ); }
+		const O & get_constant() const { return std::get<O>( value ); }
+		const std::vector<O> & get_vector() const { return std::get<std::vector<O>>( value ); }
+		};
+	Sample1d sample( int start, int end, float scale ) const
+		{
+		if( is_constant() ) return Sample1d{ std::get<O>( f ) };
+		std::vector<O> out( size_t( std::max( end - start, 0 ) ) );
+		const StdFuncType & fn = std::get<StdFuncType>( f );
+		detail::for_each_index( start, end, execution_policy, [&]( int x ){ out[size_t( x - start )] = fn( I( x * scale ) ); } );
+		return Sample1d{ std::move( out ) };
+		}
+
 private:
 	std::variant<O, StdFuncType> f;
 	ExecutionPolicy execution_policy;
 	};
 
 // Utility/Interpolator.h: a [0,1] -> [0,1] shaping function used when a frame (bin) pair is spread over the output.
-// The device kernels implement the reference's default, Interpolator::linear() (Utility/Interpolator.cpp:50-56); any
-// other interpolator makes the PV method return a null PV (documented limitation of this path).
+// The NAMED interpolators (Utility/Interpolator.cpp:14-101) carry a kind the device kernels can evaluate themselves
+// (FLANHIP_INTERP_* in flanhip.h); an interpolator built from an arbitrary callable has kind -1 and only runs in the
+// methods that sample it on the host first (time_extrapolate).  modify_time / modify_frequency / stretch / repitch run
+// Interpolator::linear(), the reference's default, only.
 class Interpolator
 	{
 public:
-	static Interpolator linear() { return Interpolator( true, []( float x ){ return x; } ); }
+	static Interpolator linear()       { return Interpolator( 0, []( float x ){ return x; } ); }
+	static Interpolator midpoint()     { return Interpolator( 1, []( float ){ return 0.5f; } ); }
+	static Interpolator nearest()      { return Interpolator( 2, []( float x ){ return std::round( x ); } ); }
+	static Interpolator floor()        { return Interpolator( 3, []( float ){ return 0.0f; } ); }
+	static Interpolator ceil()         { return Interpolator( 4, []( float ){ return 1.0f; } ); }
+	static Interpolator smoothstep()   { return Interpolator( 5, []( float x ){ return x * x * ( 3.0f - 2.0f * x ); } ); }
+	static Interpolator smootherstep() { return Interpolator( 6, []( float x ){ return x * x * x * ( x * ( x * 6.0f - 15.0f ) + 10.0f ); } ); }
+	static Interpolator sqrt()         { return Interpolator( 7, []( float x ){ return std::sqrt( x ); } ); }
+	static Interpolator sine()         { return Interpolator( 8, []( float x ){ return ( 1.0f - std::cos( std::acos( -1.0f ) * x ) ) / 2.0f; } ); }
 	template<typename T, std::enable_if_t<std::is_convertible_v<T, std::function<float( float )>>, int> = 0>
-	Interpolator( T && fn ) : linear_( false ), f_( std::forward<T>( fn ) ) {}
+	Interpolator( T && fn ) : kind_( -1 ), f_( std::forward<T>( fn ) ) {}
 	float operator()( float x ) const { return f_( x ); }
-	bool is_linear() const { return linear_; }
+	bool is_linear() const { return kind_ == 0; }
+	int kind() const { return kind_; }                                            // FLANHIP_INTERP_*, or -1
 private:
-	Interpolator( bool lin, std::function<float( float )> fn ) : linear_( lin ), f_( std::move( fn ) ) {}
-	bool linear_;
+	Interpolator( int kind, std::function<float( float )> fn ) : kind_( kind ), f_( std::move( fn ) ) {}
+	int kind_;
 	std::function<float( float )> f_;
 	};
 

@@ -45,6 +45,19 @@ public:
 	/** Extension (not in the reference): shape with the affine shaper mf -> { a*m + b, c*f + d } evaluated on the device;
 	 *  identical to shape( [=]( MF mf ){ return MF{ a*mf.m + b, c*mf.f + d }; }, use_shift_alignment ). */
 	PV shape_affine( float a, float b, float c, float d, bool use_shift_alignment = false ) const;
+
+	// ---- further frame processors (all on the device; user functions are sampled on the host like the reference does) ----
+	PV replace_amplitudes( const PV & amp_source, const Function<TF, float> & amount = 1 ) const;                     // PV.h:404-407 (PV.cpp:205-236)
+	PV subtract_amplitudes( const PV & amp_source, const Function<TF, float> & amount = 1 ) const;                    // PV.h:414-417 (PV.cpp:238-264)
+	PV retain_n_loudest_partials( const Function<Second, Bin> & num_bins ) const;                                     // PV.h:446-448 (PV.cpp:592-596)
+	PV remove_n_loudest_partials( const Function<Second, Bin> & num_bins ) const;                                     // PV.h:455-457 (PV.cpp:598-602)
+	PV resonate( Second length, const Function<TF, float> & decay ) const;                                            // PV.h:466-469 (PV.cpp:604-641)
+	/** Only the named interpolators (Interpolator::linear() ... sine()) run here: the mix is evaluated per output MF on the device. */
+	PV desample( const Function<TF, float> & decimation_ratio, const Interpolator & = Interpolator::linear() ) const; // PV.h:323-326 (PVModify.cpp:445-511)
+	/** Any interpolator (it is sampled on the host, PVModify.cpp:631-633).  The reference reads frame time_to_frame(end_time)
+	 *  unchecked (:649; one past the end for the default end_time = -1): here the end frame is clamped to the last frame. */
+	PV time_extrapolate( Second start_time, Second end_time, Second extrapolation_time,
+		const Interpolator & = Interpolator::linear() ) const;                                                        // PV.h:352-357 (PVModify.cpp:607-666)
 	};
 
 } // namespace flan

@@ -120,6 +120,44 @@ static void device_checks()
 	CHECK( std::memcmp( sh_al.get_buffer().data(), sh_aa.get_buffer().data(), sizeof( MF ) * sh_al.get_buffer().size() ) == 0 );
 	CHECK( p2.stretch( 2.0f, Interpolator( []( float x ){ return x * x; } ) ).is_null() );   // non-linear interpolators are not on the device path
 
+	// ---- further frame processors (PV.cpp:205-264, :552-641; PVModify.cpp:445-511, :607-666)
+		{
+		const Frame F = p2.get_num_frames();
+		const Bin B = p2.get_num_bins();
+		PV other = noise( 2, 40000, 99 ).convert_to_PV( 2048, 512, 2048 );       // fewer frames than p2
+		PV rep = p2.replace_amplitudes( other );                                  // amount defaults to 1 (PV.h:406)
+		CHECK( rep.get_num_frames() == F && rep.get_MF( 1, 5, 9 ).m == other.get_MF( 1, 5, 9 ).m * 1.0f + p2.get_MF( 1, 5, 9 ).m * 0.0f );
+		CHECK( rep.get_MF( 1, 5, 9 ).f == p2.get_MF( 1, 5, 9 ).f && rep.get_MF( 0, F - 1, 3 ).m == 0.0f );   // outside the overlap: cleared
+		PV rep_l = p2.replace_amplitudes( other, []( TF tf ){ return tf.t; } );
+		CHECK( close_to( rep_l.get_MF( 0, 40, 7 ).m, other.get_MF( 0, 40, 7 ).m * ( 40 / 93.75f ) + p2.get_MF( 0, 40, 7 ).m * ( 1.0f - 40 / 93.75f ), 1e-6 ) );
+		PV sub = p2.subtract_amplitudes( p2 );
+		CHECK( sub.get_MF( 0, 10, 10 ).m == 0.0f && sub.get_MF( 0, 10, 10 ).f == p2.get_MF( 0, 10, 10 ).f );
+		PV keep = p2.retain_n_loudest_partials( 10 ), drop = p2.remove_n_loudest_partials( 10 );
+		int kept = 0, dropped = 0;
+		for( Bin b = 0; b < B; ++b ) { kept += keep.get_MF( 0, 20, b ).m != 0.0f; dropped += drop.get_MF( 0, 20, b ).m == 0.0f; }
+		CHECK( kept == 10 && dropped == 10 );
+		PV keep_l = p2.retain_n_loudest_partials( []( Second t ){ return Bin( t * 100.0f ); } );
+		kept = 0;
+		for( Bin b = 0; b < B; ++b ) kept += keep_l.get_MF( 1, 50, b ).m != 0.0f;
+		CHECK( kept == Bin( p2.frame_to_time( 1 ) * 50 * 100.0f ) );
+		PV res = p2.resonate( 0.5f, 0.5f );
+		CHECK( res.get_num_frames() == F + Frame( std::ceil( 0.5f * 93.75f ) ) );
+		const float d = std::pow( 0.5f, 1.0f / 93.75f );
+		CHECK( res.get_MF( 0, F + 5, 12 ).m == res.get_MF( 0, F + 4, 12 ).m * d && res.get_MF( 0, F + 5, 12 ).f == res.get_MF( 0, F + 4, 12 ).f );
+		CHECK( !p2.resonate( 0.1f, []( TF tf ){ return tf.f > 1000.0f ? 0.9f : 0.1f; } ).is_null() );
+		PV des = p2.desample( 0.25f );
+		CHECK( des.get_MF( 0, 3, 30 ).m == p2.get_MF( 0, 3, 30 ).m * 1.0f + 0.0f * p2.get_MF( 0, 7, 30 ).m );          // frames 0, 3, 7, ... are selected
+		CHECK( des.get_MF( 0, 5, 30 ).m == 0.5f * p2.get_MF( 0, 3, 30 ).m + 0.5f * p2.get_MF( 0, 7, 30 ).m );
+		CHECK( p2.desample( 0.25f, Interpolator::ceil() ).get_MF( 0, 4, 30 ).m == 0.0f * p2.get_MF( 0, 3, 30 ).m + 1.0f * p2.get_MF( 0, 7, 30 ).m );
+		CHECK( p2.desample( 0.25f, Interpolator( []( float x ){ return x * x; } ) ).is_null() );      // arbitrary callables cannot run on the device
+		PV ext = p2.time_extrapolate( 0.2f, 0.6f, 0.5f );
+		const Frame sf = Frame( p2.time_to_frame( 0.2f ) ), ef = Frame( p2.time_to_frame( 0.6f ) );
+		CHECK( ext.get_num_frames() == ef + Frame( p2.time_to_frame( 0.5f ) ) );
+		CHECK( std::memcmp( ext.get_buffer().data(), p2.get_buffer().data(), sizeof( MF ) * size_t( sf ) * B ) == 0 );   // frames before start: copied
+		CHECK( !p2.time_extrapolate( 0.2f, -1, 0.5f, Interpolator( []( float x ){ return x * x; } ) ).is_null() );        // default end, any interpolator
+		CHECK( p2.time_extrapolate( 0.6f, 0.2f, 0.5f ).is_null() && p2.time_extrapolate( 0.2f, 0.6f, 0.0f ).is_null() );   // PVModify.cpp:616-617
+		}
+
 	// ---- mid/side
 	PV ms = n2.convert_to_ms_PV( 2048, 512, 2048 );
 	CHECK( !ms.is_null() );

@@ -49,6 +49,23 @@ stages = {
     "shape(f+100)": lambda: fa.check(lib.flanhip_shape_affine_dev(P(pv), ch, F, BINS, SR, 1.0, 0.0, 1.0, 100.0, 0, P(sh), None)),
     "shape(f*2, aligned)": lambda: fa.check(lib.flanhip_shape_affine_dev(P(pv), ch, F, BINS, SR, 1.0, 0.0, 2.0, 0.0, 1, P(sh), None)),
 }
+# further frame processors on the same 8 ch x 60 s PV: ms and the HBM rate of the MF traffic (8 B in + 8 B out)
+Fr = int(lib.flanhip_resonate_out_frames(F, 1.0, SR, HOP))
+res_out = torch.empty((ch, Fr, BINS, 2), dtype=torch.float32, device=dev)
+decay = torch.full((Fr, BINS), 0.7, dtype=torch.float32, device=dev)
+ext_start, ext_end, ext_Fo = 1000, 4000, 6000
+samples = torch.linspace(0, 1, ext_Fo - ext_start, dtype=torch.float32, device=dev)
+ext_out = torch.empty((ch, ext_Fo, BINS, 2), dtype=torch.float32, device=dev)
+stages.update({
+    "replace_amplitudes(0.5)": lambda: fa.check(lib.flanhip_replace_amplitudes_dev(P(pv), ch, F, BINS, P(rp), ch, F, BINS, None, 0.5, P(sh), None)),
+    "subtract_amplitudes(grid)": lambda: fa.check(lib.flanhip_subtract_amplitudes_dev(P(pv), ch, F, BINS, P(rp), ch, F, BINS, P(grid), 0.0, P(sh), None)),
+    "resonate(1 s, 0.7)": lambda: fa.check(lib.flanhip_resonate_dev(P(pv), ch, F, BINS, SR, HOP, Fr, None, 0.7, P(res_out), None)),
+    "resonate(1 s, grid)": lambda: fa.check(lib.flanhip_resonate_dev(P(pv), ch, F, BINS, SR, HOP, Fr, P(decay), 0.0, P(res_out), None)),
+    "retain_n_loudest(64)": lambda: fa.check(lib.flanhip_n_loudest_partials_dev(P(pv), ch, F, BINS, None, 64, 0, P(sh), None)),
+    "desample(0.1)": lambda: fa.check(lib.flanhip_desample_dev(P(pv), ch, F, BINS, None, 0.1, 0, P(sh), None)),
+    "time_extrapolate(2000 frames)": lambda: fa.check(lib.flanhip_time_extrapolate_dev(P(pv), ch, F, BINS, SR, ext_start, ext_end, ext_Fo,
+                                                                                         P(samples), P(ext_out), None)),
+})
 res = {}
 for name, fn in stages.items():
     fn(); torch.cuda.synchronize()
