@@ -13,14 +13,17 @@
 
 namespace flanhip {
 
-// modify_time_base, PVModify.cpp:319-359 (linear Interpolator, Utility/Interpolator.cpp:50-56).  out is zeroed by the caller.
+// modify_time_base, PVModify.cpp:319-359 (linear Interpolator, Utility/Interpolator.cpp:50-56).
 //
 // The reference walks each (channel, bin) column frame pair by frame pair and ACCUMULATES into the output frames
 // [ceil(l), ceil(r)) the pair maps to -- order dependent in general.  But where the map of a bin never runs backwards
-// (r >= l for every pair: every stretch / slow-down / speed-up) those intervals are disjoint, every output frame receives
-// at most one contribution, and the pairs can be processed in any order: such columns are cut into `segments` runs of
-// frame pairs handled by different threads, with the reference's loop body unchanged.  Columns whose map does run backwards
-// (flag set by k_time_map_flags) are walked by one thread in the reference order.
+// (r >= l for every pair: every stretch / slow-down / speed-up) those intervals are disjoint and tile
+// [ceil(l_first), ceil(r_last)) without gaps: every output frame receives at most one contribution, onto the cleared
+// value { 0, 0 } (:317).  Such columns are cut into `segments` runs of frame pairs handled by different threads, each thread
+// OWNS the output frames of its pairs: it writes them once (the accumulation onto { 0, 0 } written out literally), zeros where
+// the reference leaves a pair early (:350-351) and, at the two ends of the column, the frames no pair reaches -- no separate
+// clearing pass and no read-modify-write.  Columns whose map does run backwards (flag set by k_time_map_flags) are cleared
+// and then walked by one thread in the reference order.
 __global__ __launch_bounds__( 256 ) void k_time_map_flags( const float * mod, int64_t F, int bins, float sr, float hop, int * nonmono )
 	{
 	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
@@ -41,13 +44,18 @@ __global__ __launch_bounds__( 256 ) void k_modify_time( const MFd * in, int num_
 	const int seg = int( idx / columns );
 	const int channel = int( ( idx % columns ) / bins ), bin = int( idx % bins );
 	int64_t f0 = 1 + seg * seg_len, f1 = min( F, f0 + seg_len );
-	if( nonmono[bin] ) { if( seg != 0 ) return; f0 = 1; f1 = F; }                  // order matters for this column: one thread, all pairs
+	const bool sequential = nonmono[bin] != 0;
+	if( sequential ) { if( seg != 0 ) return; f0 = 1; f1 = F; }                    // order matters for this column: one thread, all pairs
 	if( f0 >= f1 ) return;
 	const MFd * ip = in + int64_t( channel ) * F * bins + bin;
 	MFd * op = out + int64_t( channel ) * Fo * bins + bin;
 	const float * mp = mod + bin;
+	const int Fo32 = int( Fo );
+	auto clear = [&]( int x0, int x1 ) { for( int x = x0; x < x1; ++x ) op[int64_t( x ) * bins] = MFd{ 0.0f, 0.0f }; };   // :317 clear_buffer
 	MFd lMF = ip[( f0 - 1 ) * bins];
 	float lFrame = time_to_frame( mp[( f0 - 1 ) * bins], sr, hop );
+	if( sequential ) clear( 0, Fo32 );
+	else if( f0 == 1 ) clear( 0, min( max( int( ceilf( lFrame ) ), 0 ), Fo32 ) );   // before the first pair's interval
 	for( int64_t frame = f0; frame < f1; ++frame )                                  // :328
 		{
 		const MFd rMF = ip[frame * bins];
@@ -55,78 +63,73 @@ __global__ __launch_bounds__( 256 ) void k_modify_time( const MFd * in, int num_
 		const bool forward = rFrame > lFrame;                                       // :332
 		const int start_frame = int( forward ? ceilf( lFrame ) : floorf( lFrame ) ); // :334
 		const int end_frame   = int( forward ? ceilf( rFrame ) : floorf( rFrame ) ); // :335
-		for( int x = start_frame; x != end_frame; forward ? ++x : --x )             // :340
+		if( !sequential )
 			{
-			if( x < 0 || Fo <= x ) continue;                                        // :342
-			const float mix = ( float( x ) - lFrame ) / ( rFrame - lFrame );        // :344
-			const float w0 = ( 1.0f - mix ) * lMF.m;
-			const float w1 = mix * rMF.m;
-			const float totalWeight = w0 + w1;
-			const float weightedFreqSum = w0 * lMF.f + w1 * rMF.f;
-			if( totalWeight == 0.0f ) break;                                        // :350-351 (`return` leaves this frame pair)
-			MFd o = op[int64_t( x ) * bins];
-			o.f = ( o.f * o.m + weightedFreqSum ) / ( o.m + totalWeight );          // :354
-			o.m += totalWeight;                                                     // :355
-			op[int64_t( x ) * bins] = o;
+			// forward or empty; frames outside [0, Fo) are skipped by :342 before anything is computed, so clamping is exact
+			const int x1 = min( max( end_frame, 0 ), Fo32 );
+			int x = min( max( start_frame, 0 ), Fo32 );
+			for( ; x < x1; ++x )                                                    // :340
+				{
+				const float mix = ( float( x ) - lFrame ) / ( rFrame - lFrame );    // :344
+				const float w0 = ( 1.0f - mix ) * lMF.m;
+				const float w1 = mix * rMF.m;
+				const float totalWeight = w0 + w1;
+				const float weightedFreqSum = w0 * lMF.f + w1 * rMF.f;
+				if( totalWeight == 0.0f ) break;                                    // :350-351 (`return` leaves this frame pair)
+				const MFd o = { 0.0f, 0.0f };                                       // the cleared output MF this pair alone reaches
+				op[int64_t( x ) * bins] = MFd{ o.m + totalWeight, ( o.f * o.m + weightedFreqSum ) / ( o.m + totalWeight ) };   // :354-355
+				}
+			clear( x, x1 );                                                         // frames the pair left untouched
 			}
+		else
+			for( int x = start_frame; x != end_frame; forward ? ++x : --x )         // :340
+				{
+				if( x < 0 || Fo <= x ) continue;                                    // :342
+				const float mix = ( float( x ) - lFrame ) / ( rFrame - lFrame );    // :344
+				const float w0 = ( 1.0f - mix ) * lMF.m;
+				const float w1 = mix * rMF.m;
+				const float totalWeight = w0 + w1;
+				const float weightedFreqSum = w0 * lMF.f + w1 * rMF.f;
+				if( totalWeight == 0.0f ) break;                                    // :350-351
+				MFd o = op[int64_t( x ) * bins];
+				o.f = ( o.f * o.m + weightedFreqSum ) / ( o.m + totalWeight );      // :354
+				o.m += totalWeight;                                                 // :355
+				op[int64_t( x ) * bins] = o;
+				}
 		lMF = rMF; lFrame = rFrame;
 		}
+	if( !sequential && f1 == F ) clear( min( max( int( ceilf( lFrame ) ), 0 ), Fo32 ), Fo32 );   // beyond the last pair's interval
 	}
 
 // PV::stretch, PVModify.cpp:376-382: inclusive running sum over frames per bin in fp32 (sequential order = the
 // reference's rounding), then frame_to_time; also the maximum of the result (FunctionSample::maximum, :312).
-// A block owns 64 bins: tiles of 64 frames x 64 bins go through LDS so that all 256 threads move memory (coalesced rows)
-// while 64 of them carry the running sums down the tile.
+// A block owns 64 bins (column_scan, processors_common.h).
+constexpr int kMapTB = 16, kMapTF = 896;                                           // k_stretch_map tile: 16 bins x 896 frames (61 KB of LDS)
 __global__ __launch_bounds__( 256 ) void k_stretch_map( float * factor, int64_t F, int bins, float sr, float hop, float * d_max )
 	{
-	constexpr int TB = 64, TF = 64;
-	__shared__ float tile[TF][TB + 1];
-	const int bin0 = blockIdx.x * TB;
-	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;                         // 64 bins x 4 rows per pass
+	__shared__ float lds[kMapTF * ( kMapTB + 1 )];
+	const int bin = blockIdx.x * kMapTB + threadIdx.x % kMapTB;
+	const bool valid = bin < bins;
 	float run = 0.0f, mx = -INFINITY;
-	for( int64_t fbase = 0; fbase < F; fbase += TF )
-		{
-		#pragma unroll
-		for( int r = ty; r < TF; r += 4 )
+	column_scan<kMapTF, kMapTB, 1, 1, false>( lds, F,
+		[&]( int64_t f, float ( &v )[1] ) { if( valid ) v[0] = factor[f * bins + bin]; },
+		[&]( int64_t f, float ( &v )[1] ) { run = ( f == 0 ) ? v[0] : v[0] + run; v[0] = run; },         // factor[frame] += factor[frame-1]
+		[&]( int64_t f, float ( &v )[1] )
 			{
-			const int64_t f = fbase + r;
-			tile[r][tx] = ( f < F && bin0 + tx < bins ) ? factor[f * bins + bin0 + tx] : 0.0f;
-			}
-		__syncthreads();
-		if( ty == 0 )
-			{
-			// the only sequential part: 64 dependent fp32 additions per column and tile
-			#pragma unroll
-			for( int r = 0; r < TF; ++r )
-				{
-				run = ( fbase + r == 0 ) ? tile[r][tx] : tile[r][tx] + run;                // factor[frame] += factor[frame-1]
-				tile[r][tx] = run;
-				}
-			}
-		__syncthreads();
-		#pragma unroll
-		for( int r = ty; r < TF; r += 4 )
-			{
-			const int64_t f = fbase + r;
-			if( f < F && bin0 + tx < bins )
-				{
-				const float t = frame_to_time( tile[r][tx], sr, hop );                     // PVModify.cpp:381-382
-				factor[f * bins + bin0 + tx] = t;
-				mx = fmaxf( mx, t );
-				}
-			}
-		__syncthreads();
-		}
-	// reduce the maximum over the block's 4 waves through LDS, then over the 64 lanes
-	__shared__ float wmax[4][64];
-	wmax[ty][tx] = mx;
+			if( !valid ) return;
+			const float t = frame_to_time( v[0], sr, hop );                           // PVModify.cpp:381-382
+			factor[f * bins + bin] = t;
+			mx = fmaxf( mx, t );
+			} );
+	// the block's maximum: over the lanes of each wave, then over the 4 waves through LDS, then into *d_max
+	for( int o = 32; o > 0; o >>= 1 ) mx = fmaxf( mx, __shfl_xor( mx, o ) );
+	__shared__ float wmax[4];
+	if( ( threadIdx.x & 63 ) == 0 ) wmax[threadIdx.x >> 6] = mx;
 	__syncthreads();
-	if( ty == 0 )
+	if( threadIdx.x == 0 )
 		{
-		mx = fmaxf( fmaxf( wmax[0][tx], wmax[1][tx] ), fmaxf( wmax[2][tx], wmax[3][tx] ) );
-		if( bin0 + tx >= bins ) mx = -INFINITY;
-		for( int o = 32; o > 0; o >>= 1 ) mx = fmaxf( mx, __shfl_xor( mx, o ) );
-		if( d_max && tx == 0 && mx > -INFINITY )
+		mx = fmaxf( fmaxf( wmax[0], wmax[1] ), fmaxf( wmax[2], wmax[3] ) );
+		if( d_max && mx > -INFINITY )
 			{
 			int * addr = reinterpret_cast<int*>( d_max );
 			int old = *addr;
@@ -147,7 +150,7 @@ __global__ __launch_bounds__( 256 ) void k_stretch_map( float * factor, int64_t 
 // running sums along their rows, all 256 apply bin_to_frequency.
 __global__ __launch_bounds__( 256 ) void k_repitch_scan( float * factor, int64_t F, int bins, float sr, float dft )
 	{
-	constexpr int TB = 64, TF = 64;
+	constexpr int TF = 64;
 	__shared__ float tile[TF][TB + 1];
 	const int64_t frame0 = int64_t( blockIdx.x ) * TF;
 	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -304,7 +307,8 @@ int flanhip_modify_time_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int
 	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, sr ) ) return rc;
 	FLANHIP_REQUIRE( d_mod && hop >= 1 && Fo > 0, FLANHIP_ERR_INVALID_ARG, "bad map / output length" );
 	hipStream_t s = (hipStream_t) stream;
-	FLANHIP_CHECK( hipMemsetAsync( d_out, 0, sizeof( flanhip_MF ) * size_t( ch ) * Fo * bins, s ) );   // clear_buffer, PVModify.cpp:317
+	FLANHIP_REQUIRE( Fo < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "2^31 output frames or more" );
+	if( F == 1 ) FLANHIP_CHECK( hipMemsetAsync( d_out, 0, sizeof( flanhip_MF ) * size_t( ch ) * Fo * bins, s ) );   // no frame pair: clear_buffer only, PVModify.cpp:317
 	int * d_flags = nullptr;                                                       // per bin: does the time map ever run backwards?
 	FLANHIP_CHECK( hipMallocAsync( reinterpret_cast<void**>( &d_flags ), sizeof( int ) * bins, s ) );
 	FLANHIP_CHECK( hipMemsetAsync( d_flags, 0, sizeof( int ) * bins, s ) );
@@ -358,7 +362,7 @@ int flanhip_stretch_map_dev( float * d_factor, int64_t F, int bins, float sr, in
 		const float ninf = -INFINITY;
 		FLANHIP_CHECK( hipMemcpyAsync( d_max, &ninf, sizeof( float ), hipMemcpyHostToDevice, s ) );
 		}
-	hipLaunchKernelGGL( k_stretch_map, dim3( ( bins + 63 ) / 64 ), dim3( 256 ), 0, s, d_factor, F, bins, sr, float( hop ), d_max );
+	hipLaunchKernelGGL( k_stretch_map, dim3( ( bins + kMapTB - 1 ) / kMapTB ), dim3( 256 ), 0, s, d_factor, F, bins, sr, float( hop ), d_max );
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;
 	}

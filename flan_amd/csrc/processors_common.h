@@ -52,6 +52,99 @@ __device__ __forceinline__ void placement_offer( unsigned long long * keys, int 
 	}
 __device__ __forceinline__ int placement_winner( unsigned long long key ) { return int( 0xFFFFFFFFu - unsigned( key & 0xFFFFFFFFull ) ); }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Column scans.  Several processors carry a state down the frames of every bin column in a fixed order (a running fp32 sum,
+// a selection accumulator, a decaying maximum): sequential per column by definition, and a PV has only ~1000 columns.
+// A block of 256 threads owns TBc (16 / 32 / 64) adjacent columns and walks them in tiles of TFr frames (few columns per
+// block = many blocks, deep tiles = many bytes in flight per block: these kernels are bound by latency x concurrency):
+//   * all 256 threads move the tile between HBM and LDS in coalesced rows, the NEXT tile is already in flight (registers)
+//     while the current one is scanned;
+//   * TBc threads of wave 0 each scan one column, CH rows at a time: CH batched LDS reads into registers, the
+//     recurrence on registers, CH batched writes -- no LDS round trip inside the dependent chain.
+// load( frame, v[NIN] ) / store( frame, v[NOUT] ) are called with frame < F for the thread's own column; step( frame, v )
+// replaces v[0..NIN) by v[0..NOUT) and is called in scan order (frames past F included: harmless, never stored).
+// lds: max(NIN,NOUT) * TFr * (TBc+1) floats.  Column of a thread: blockIdx.x * TBc + threadIdx.x % TBc.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int TB = 64;
+
+template<int TFr, int TBc, int NIN, int NOUT, bool REVERSE, class Load, class Step, class Store>
+__device__ __forceinline__ void column_scan( float * lds, int64_t F, Load load, Step step, Store store )
+	{
+	constexpr int NT = NIN > NOUT ? NIN : NOUT, NY = 256 / TBc, RP = TFr / NY, CH = 32;
+	static_assert( TFr % CH == 0 && TFr % NY == 0 && TBc <= 64, "tile shape" );
+	auto T = [&]( int a, int r, int c ) -> float & { return lds[( a * TFr + r ) * ( TBc + 1 ) + c]; };
+	const int tx = threadIdx.x % TBc, ty = threadIdx.x / TBc;
+	const int64_t tiles = ( F + TFr - 1 ) / TFr;
+	float pre[NIN][RP];
+	auto load_regs = [&]( int64_t tile_i )
+		{
+		#pragma unroll
+		for( int i = 0; i < RP; ++i )
+			{
+			const int64_t f = tile_i * TFr + ty + NY * i;
+			float v[NIN];
+			#pragma unroll
+			for( int a = 0; a < NIN; ++a ) v[a] = 0.0f;
+			if( f < F ) load( f, v );
+			#pragma unroll
+			for( int a = 0; a < NIN; ++a ) pre[a][i] = v[a];
+			}
+		};
+	load_regs( REVERSE ? tiles - 1 : 0 );
+	for( int64_t k = 0; k < tiles; ++k )
+		{
+		const int64_t tile_i = REVERSE ? tiles - 1 - k : k, fbase = tile_i * TFr;
+		#pragma unroll
+		for( int a = 0; a < NIN; ++a )
+			#pragma unroll
+			for( int i = 0; i < RP; ++i ) T( a, ty + NY * i, tx ) = pre[a][i];
+		__syncthreads();
+		if( k + 1 < tiles ) load_regs( REVERSE ? tile_i - 1 : tile_i + 1 );
+		if( threadIdx.x < TBc )
+			{
+			#pragma unroll 1
+			for( int c0 = 0; c0 < TFr; c0 += CH )
+				{
+				const int base = REVERSE ? TFr - CH - c0 : c0;
+				float col[NT][CH];
+				#pragma unroll
+				for( int a = 0; a < NIN; ++a )
+					#pragma unroll
+					for( int j = 0; j < CH; ++j ) col[a][j] = T( a, base + j, tx );
+				#pragma unroll
+				for( int jj = 0; jj < CH; ++jj )
+					{
+					const int j = REVERSE ? CH - 1 - jj : jj;
+					float v[NT];
+					#pragma unroll
+					for( int a = 0; a < NIN; ++a ) v[a] = col[a][j];
+					step( fbase + base + j, v );
+					#pragma unroll
+					for( int a = 0; a < NOUT; ++a ) col[a][j] = v[a];
+					}
+				#pragma unroll
+				for( int a = 0; a < NOUT; ++a )
+					#pragma unroll
+					for( int j = 0; j < CH; ++j ) T( a, base + j, tx ) = col[a][j];
+				}
+			}
+		__syncthreads();
+		#pragma unroll
+		for( int i = 0; i < RP; ++i )
+			{
+			const int64_t f = fbase + ty + NY * i;
+			if( f < F )
+				{
+				float v[NOUT];
+				#pragma unroll
+				for( int a = 0; a < NOUT; ++a ) v[a] = T( a, ty + NY * i, tx );
+				store( f, v );
+				}
+			}
+		__syncthreads();
+		}
+	}
+
 struct DevBuf
 	{
 	void * p = nullptr;

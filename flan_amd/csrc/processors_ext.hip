@@ -5,10 +5,10 @@
 // All of them stream MF[ch][F][bins] once (8 B per MF in, 8 B out): HBM-bound work.  Where the reference defines a result
 // through a sequential walk (a decaying running maximum over frames, a selection accumulator over frames, a "strictly louder
 // replaces" rule over bins, a sort) the kernel keeps that order along the dependent axis only:
-//   k_resonate          : block = 64 bins of one channel; 64 x 64 (frame x bin) tiles go through LDS so that all 256 threads move
-//                         memory in coalesced rows (the next tile is in flight during the scan) while 64 threads carry the
-//                         recurrence down the tile
-//   k_desample_select   : same tiling for the selection accumulator (channel independent), forward then backward over frames:
+//   k_resonate          : block = 16 bins of one channel; (frame x bin) tiles go through LDS so that all 256 threads move memory
+//                         (the next tile is in flight during the scan) while 16 threads carry the recurrence down the tile in
+//                         registers (column_scan, processors_common.h)
+//   k_desample_select   : same skeleton for the selection accumulator (channel independent), forward then backward over frames:
 //                         per (frame, bin) the selected frames on either side; k_desample_apply is then elementwise
 //   k_n_loudest         : wavefront per (channel, frame) row: the n-th largest |m| by a 31-step bisection on the bit pattern
 //                         (ballot + popcount, keys in LDS), ties by ascending bin
@@ -17,8 +17,6 @@
 #include <algorithm>
 
 namespace flanhip {
-
-constexpr int TB = 64, TF = 64;                                                     // tile: bins x frames
 
 // ---------------------------------------------------------------------------------------------------------------------
 // replace_amplitudes / subtract_amplitudes
@@ -57,58 +55,34 @@ __global__ __launch_bounds__( 256 ) void k_decay_pow( const float * decay, int64
 	decay_t[idx] = float( pow( double( clamp01( decay[idx] ) ), double( seconds_per_frame ) ) );
 	}
 
-// PV.cpp:619-638.  grid = ( ceil(bins/64), channels ).  decay_t: float[Fo][bins] or nullptr + constant.
+constexpr int kResTB = 16, kResTF = 128;                                            // k_resonate tile: 16 bins x 128 frames (3 x 8.5 KB of LDS)
+// PV.cpp:619-638.  grid = ( ceil(bins/16), channels ).  decay_t: float[Fo][bins] or nullptr + constant.  column_scan over
+// the OUTPUT's frames with ( m, f, decay_t ) in and ( m, f ) out.
 __global__ __launch_bounds__( 256 ) void k_resonate( const MFd * in, int64_t F, int bins, int64_t Fo, const float * decay_t, float decay_t_const, MFd * out )
 	{
-	__shared__ float tile_m[TF][TB + 1], tile_f[TF][TB + 1], tile_d[TF][TB + 1];
-	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-	const int bin = blockIdx.x * TB + tx;
+	__shared__ float lds[3 * kResTF * ( kResTB + 1 )];
+	const int bin = blockIdx.x * kResTB + threadIdx.x % kResTB;
 	const bool valid = bin < bins;
 	const MFd * ip = in + int64_t( blockIdx.y ) * F * bins + bin;
 	MFd * op = out + int64_t( blockIdx.y ) * Fo * bins + bin;
-	float pm[TF / 4], pf[TF / 4], pd[TF / 4];
-	auto load_regs = [&]( int64_t fbase )
-		{
-		#pragma unroll
-		for( int i = 0; i < TF / 4; ++i )
+	float sm = 0.0f, sf = 0.0f;                                                       // out[frame-1] of this column
+	column_scan<kResTF, kResTB, 3, 2, false>( lds, Fo,
+		[&]( int64_t f, float ( &v )[3] )
 			{
-			const int64_t f = fbase + ty + 4 * i;
-			MFd v = { __builtin_nanf( "" ), 0.0f };                                   // no input frame: `m > decayed` is false (:633)
-			if( valid && f < F ) v = ip[f * bins];
-			pm[i] = v.m; pf[i] = v.f;
-			pd[i] = ( valid && f < Fo && decay_t ) ? decay_t[f * bins + bin] : decay_t_const;
-			}
-		};
-	load_regs( 0 );
-	float sm = 0.0f, sf = 0.0f;                                                       // out[frame-1] of this column (threads with ty == 0)
-	for( int64_t fbase = 0; fbase < Fo; fbase += TF )
-		{
-		#pragma unroll
-		for( int i = 0; i < TF / 4; ++i ) { tile_m[ty + 4 * i][tx] = pm[i]; tile_f[ty + 4 * i][tx] = pf[i]; tile_d[ty + 4 * i][tx] = pd[i]; }
-		__syncthreads();
-		if( fbase + TF < Fo ) load_regs( fbase + TF );                                // in flight during the scan below
-		if( ty == 0 )
+			MFd mf = { __builtin_nanf( "" ), 0.0f };                                  // no input frame: `m > decayed` is false (:633)
+			if( valid && f < F ) mf = ip[f * bins];
+			v[0] = mf.m; v[1] = mf.f;
+			v[2] = ( valid && decay_t ) ? decay_t[f * bins + bin] : decay_t_const;
+			},
+		[&]( int64_t f, float ( &v )[3] )
 			{
-			#pragma unroll 16
-			for( int r = 0; r < TF; ++r )
-				{
-				const float im = tile_m[r][tx], jf = tile_f[r][tx];
-				const float decayed_amp = sm * tile_d[r][tx];                         // :632
-				const bool take = ( fbase + r == 0 ) || im > decayed_amp;             // :619-624 (frame 0 is copied), :633
-				sm = take ? im : decayed_amp;                                         // :634 / :636
-				sf = take ? jf : sf;
-				tile_m[r][tx] = sm; tile_f[r][tx] = sf;
-				}
-			}
-		__syncthreads();
-		#pragma unroll
-		for( int i = 0; i < TF / 4; ++i )
-			{
-			const int64_t f = fbase + ty + 4 * i;
-			if( valid && f < Fo ) op[f * bins] = MFd{ tile_m[ty + 4 * i][tx], tile_f[ty + 4 * i][tx] };
-			}
-		__syncthreads();
-		}
+			const float decayed_amp = sm * v[2];                                      // :632
+			const bool take = ( f == 0 ) || v[0] > decayed_amp;                       // :619-624 (frame 0 is copied), :633
+			sm = take ? v[0] : decayed_amp;                                           // :634 / :636
+			sf = take ? v[1] : sf;
+			v[0] = sm; v[1] = sf;
+			},
+		[&]( int64_t f, float ( &v )[2] ) { if( valid ) op[f * bins] = MFd{ v[0], v[1] }; } );
 	}
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -176,93 +150,44 @@ __global__ __launch_bounds__( 256 ) void k_n_loudest( const MFd * in, int64_t ro
 // ---------------------------------------------------------------------------------------------------------------------
 // desample
 // ---------------------------------------------------------------------------------------------------------------------
-// PVModify.cpp:461-475, forward: L[frame][bin] = the last selected frame <= frame (-1: none yet).  grid = ceil(bins/64).
+constexpr int kSelTB = 16, kSelTF = 896;                                            // selection scans: 16 bins x 896 frames (61 KB of LDS)
+// PVModify.cpp:461-475, forward: L[frame][bin] = the last selected frame <= frame (-1: none yet).  grid = ceil(bins/16).
 __global__ __launch_bounds__( 256 ) void k_desample_select( const float * ratio, float ratio_const, int64_t F, int bins, int * L )
 	{
-	__shared__ float tile[TF][TB + 1];
-	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-	const int bin = blockIdx.x * TB + tx;
+	__shared__ float lds[kSelTF * ( kSelTB + 1 )];
+	const int bin = blockIdx.x * kSelTB + threadIdx.x % kSelTB;
 	const bool valid = bin < bins;
-	float pr[TF / 4];
-	auto load_regs = [&]( int64_t fbase )
-		{
-		#pragma unroll
-		for( int i = 0; i < TF / 4; ++i )
-			{
-			const int64_t f = fbase + ty + 4 * i;
-			pr[i] = ( valid && f < F && ratio ) ? ratio[f * bins + bin] : ratio_const;
-			}
-		};
-	load_regs( 0 );
 	float accum = 1.0f;                                                               // :461
 	int last = -1;
-	for( int64_t fbase = 0; fbase < F; fbase += TF )
-		{
-		#pragma unroll
-		for( int i = 0; i < TF / 4; ++i ) tile[ty + 4 * i][tx] = pr[i];
-		__syncthreads();
-		if( fbase + TF < F ) load_regs( fbase + TF );
-		if( ty == 0 )
+	column_scan<kSelTF, kSelTB, 1, 1, false>( lds, F,
+		[&]( int64_t f, float ( &v )[1] ) { v[0] = ( valid && ratio ) ? ratio[f * bins + bin] : ratio_const; },
+		[&]( int64_t f, float ( &v )[1] )
 			{
-			#pragma unroll 16
-			for( int r = 0; r < TF; ++r )
-				{
-				accum += clamp01( tile[r][tx] );                                      // :468-469
-				const bool sel = accum >= 1.0f && fbase + r < F;                      // :470
-				last = sel ? int( fbase + r ) : last;
-				accum = sel ? accum - 1.0f : accum;                                   // :473
-				tile[r][tx] = __int_as_float( last );
-				}
-			}
-		__syncthreads();
-		#pragma unroll
-		for( int i = 0; i < TF / 4; ++i )
-			{
-			const int64_t f = fbase + ty + 4 * i;
-			if( valid && f < F ) L[f * bins + bin] = __float_as_int( tile[ty + 4 * i][tx] );
-			}
-		__syncthreads();
-		}
+			accum += clamp01( v[0] );                                                 // :468-469
+			const bool sel = accum >= 1.0f && f < F;                                  // :470
+			last = sel ? int( f ) : last;
+			accum = sel ? accum - 1.0f : accum;                                       // :473
+			v[0] = __int_as_float( last );
+			},
+		[&]( int64_t f, float ( &v )[1] ) { if( valid ) L[f * bins + bin] = __float_as_int( v[0] ); } );
 	}
 
 // backward: R[frame][bin] = the first selected frame > frame (-1: none).  Frame t is selected iff L[t] == t.
 __global__ __launch_bounds__( 256 ) void k_desample_next( const int * L, int64_t F, int bins, int * R )
 	{
-	__shared__ int tile[TF][TB + 1];
-	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-	const int bin = blockIdx.x * TB + tx;
+	__shared__ float lds[kSelTF * ( kSelTB + 1 )];
+	const int bin = blockIdx.x * kSelTB + threadIdx.x % kSelTB;
 	const bool valid = bin < bins;
 	int next = -1;
-	const int64_t tiles = ( F + TF - 1 ) / TF;
-	for( int64_t tile_i = tiles - 1; tile_i >= 0; --tile_i )
-		{
-		const int64_t fbase = tile_i * TF;
-		#pragma unroll
-		for( int i = 0; i < TF / 4; ++i )
+	column_scan<kSelTF, kSelTB, 1, 1, true>( lds, F,
+		[&]( int64_t f, float ( &v )[1] ) { v[0] = __int_as_float( valid ? L[f * bins + bin] : -2 ); },
+		[&]( int64_t f, float ( &v )[1] )
 			{
-			const int64_t f = fbase + ty + 4 * i;
-			tile[ty + 4 * i][tx] = ( valid && f < F ) ? L[f * bins + bin] : -2;
-			}
-		__syncthreads();
-		if( ty == 0 )
-			{
-			#pragma unroll 16
-			for( int r = TF - 1; r >= 0; --r )
-				{
-				const int l = tile[r][tx];
-				tile[r][tx] = next;
-				next = ( l == int( fbase + r ) ) ? l : next;
-				}
-			}
-		__syncthreads();
-		#pragma unroll
-		for( int i = 0; i < TF / 4; ++i )
-			{
-			const int64_t f = fbase + ty + 4 * i;
-			if( valid && f < F ) R[f * bins + bin] = tile[ty + 4 * i][tx];
-			}
-		__syncthreads();
-		}
+			const int l = __float_as_int( v[0] );
+			v[0] = __int_as_float( next );
+			next = ( f < F && l == int( f ) ) ? l : next;
+			},
+		[&]( int64_t f, float ( &v )[1] ) { if( valid ) R[f * bins + bin] = __float_as_int( v[0] ); } );
 	}
 
 // PVModify.cpp:483-506, one thread per output MF
@@ -397,7 +322,7 @@ int flanhip_resonate_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bi
 		const float d = decay_const < 0.0f ? 0.0f : ( 1.0f < decay_const ? 1.0f : decay_const );   // :617
 		decay_t_const = std::pow( d, seconds_per_frame );                             // :631, the platform's powf like the reference
 		}
-	hipLaunchKernelGGL( k_resonate, dim3( ( bins + TB - 1 ) / TB, (unsigned) ch ), dim3( 256 ), 0, s, (const MFd*) d_pv, F, bins, Fo,
+	hipLaunchKernelGGL( k_resonate, dim3( ( bins + kResTB - 1 ) / kResTB, (unsigned) ch ), dim3( 256 ), 0, s, (const MFd*) d_pv, F, bins, Fo,
 		(const float*) d_decay_t, decay_t_const, (MFd*) d_out );
 	FLANHIP_CHECK( hipGetLastError() );
 	if( d_decay_t ) FLANHIP_CHECK( hipFreeAsync( d_decay_t, s ) );
@@ -428,7 +353,7 @@ int flanhip_desample_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bi
 	int * d_lr = nullptr;                                                             // L then R: int[2][F][bins]
 	const size_t grid = size_t( F ) * bins;
 	FLANHIP_CHECK( hipMallocAsync( reinterpret_cast<void**>( &d_lr ), sizeof( int ) * 2 * grid, s ) );
-	const unsigned col_blocks = ( bins + TB - 1 ) / TB;
+	const unsigned col_blocks = ( bins + kSelTB - 1 ) / kSelTB;
 	hipLaunchKernelGGL( k_desample_select, dim3( col_blocks ), dim3( 256 ), 0, s, d_ratio, ratio_const, F, bins, d_lr );
 	hipLaunchKernelGGL( k_desample_next, dim3( col_blocks ), dim3( 256 ), 0, s, (const int*) d_lr, F, bins, d_lr + grid );
 	const int64_t count = ch * F * bins;

@@ -190,3 +190,28 @@ def test_mid_side_and_noise(fa):
     assert r[0] == 0.0 and r[1] == pytest.approx(float(np.sum(x.astype(np.float64) ** 2)), rel=1e-12)
     for p in (d_x, d_o, d_r):
         fa.lib.flanhip_free(p)
+
+
+def test_stretch_sparse_magnitudes(fa):
+    """zero magnitudes on integer frame positions make the reference leave a frame pair early (PVModify.cpp:350-351): the
+    frames it skips must stay cleared, also at the ends of a column that no pair reaches"""
+    rng = np.random.default_rng(31)
+    pv = rng.uniform(0, 1, (2, 90, 130, 2)).astype(np.float32)
+    pv[..., 0] *= rng.uniform(0, 1, (2, 90, 130)) < 0.4
+    pv[..., 1] *= 20000
+    F, bins = pv.shape[1], pv.shape[2]
+    for name, g in (("x2", np.full((F, bins), 2.0, np.float32)), ("x3", np.full((F, bins), 3.0, np.float32)),
+                    ("x0.5", np.full((F, bins), 0.5, np.float32)), ("random", rng.uniform(0.3, 4.0, (F, bins)).astype(np.float32))):
+        ref = O.stretch(pv, SR, 256, g)
+        got = fa.modify_time(pv, SR, 256, O.stretch_map(g, SR, 256))
+        assert got.shape == ref.shape, name
+        same, rel = report("stretch-sparse/" + name, got, ref)
+        assert same == 1.0
+    # a map that starts late and ends early: leading / trailing output frames are reached by no pair
+    hop_s = 256 / SR
+    mod = (np.linspace(20.0, 60.0, F, dtype=np.float32)[:, None] * np.ones((1, bins), np.float32) * hop_s).astype(np.float32)
+    mod[:, 5] = 200 * hop_s                                                      # one column far ahead: sets the output length
+    ref = O.modify_time(pv, SR, 256, mod)
+    got = fa.modify_time(pv, SR, 256, mod)
+    same, rel = report("modify_time/late-start", got, ref)
+    assert got.shape == ref.shape and same == 1.0
