@@ -107,13 +107,13 @@ __global__ __launch_bounds__( 256 ) void k_modify_time( const MFd * in, int num_
 constexpr int kMapTB = 16, kMapTF = 896;                                           // k_stretch_map tile: 16 bins x 896 frames (61 KB of LDS)
 __global__ __launch_bounds__( 256 ) void k_stretch_map( float * factor, int64_t F, int bins, float sr, float hop, float * d_max )
 	{
-	__shared__ float lds[kMapTF * ( kMapTB + 1 )];
+	__shared__ __attribute__(( aligned( 16 ) )) float lds[column_scan_lds_floats( kMapTF, kMapTB, 1 )];
 	const int bin = blockIdx.x * kMapTB + threadIdx.x % kMapTB;
 	const bool valid = bin < bins;
-	float run = 0.0f, mx = -INFINITY;
+	float run = -0.0f, mx = -INFINITY;                                             // -0 + x == x for every x: frame 0 needs no special case
 	column_scan<kMapTF, kMapTB, 1, 1, false>( lds, F,
 		[&]( int64_t f, float ( &v )[1] ) { if( valid ) v[0] = factor[f * bins + bin]; },
-		[&]( int64_t f, float ( &v )[1] ) { run = ( f == 0 ) ? v[0] : v[0] + run; v[0] = run; },         // factor[frame] += factor[frame-1]
+		[&]( int64_t f, float ( &v )[1] ) { run = v[0] + run; v[0] = run; },                             // factor[frame] += factor[frame-1]
 		[&]( int64_t f, float ( &v )[1] )
 			{
 			if( !valid ) return;
@@ -195,27 +195,33 @@ __global__ __launch_bounds__( 256 ) void k_repitch_lerp( const MFd * in, int64_t
 	in_modified[idx] = lo_freq * ( 1.0f - r ) + hi_freq * r;
 	}
 
-// modify_frequency_base, PVModify.cpp:207-253.  out is zeroed by the caller.  One WAVEFRONT per (channel, frame) row.
+// modify_frequency_base, PVModify.cpp:207-253.  One WAVEFRONT per (channel, frame) row; the output row is assembled in LDS
+// (cleared there, :205) and leaves with coalesced stores: no separate clearing pass over HBM and no read-modify-write.
 // Same argument as k_modify_time: when the bin map of a row never runs backwards (hiBin >= loBin for every adjacent pair --
 // any repitch by positive factors) the output intervals [ceil(lo), ceil(hi)) of the pairs are disjoint, each output bin is
-// touched at most once and the 1024 pairs of the row are independent: the lanes take them 64 at a time.  A row whose map
-// does run backwards is walked by lane 0 in the reference order.
+// touched at most once and the pairs of the row are independent: the lanes take them 64 at a time.  A row whose map
+// does run backwards is walked by lane 0 in the reference order.  s_rows: dynamic LDS, bins MF per wave.
 __global__ __launch_bounds__( 256 ) void k_modify_frequency( const MFd * in, int num_channels, int64_t F, int bins, float sr, float dft,
 	const float * mod, const float * in_modified, MFd * out )
 	{
-	const int lane = threadIdx.x & 63;
-	const int64_t idx = int64_t( blockIdx.x ) * ( blockDim.x >> 6 ) + ( threadIdx.x >> 6 );
+	extern __shared__ MFd s_rows[];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int64_t idx = int64_t( blockIdx.x ) * ( blockDim.x >> 6 ) + wave;
 	if( idx >= int64_t( num_channels ) * F ) return;
 	const int64_t frame = idx % F;
 	const MFd * row = in + idx * bins;
-	MFd * orow = out + idx * bins;
+	MFd * orow = s_rows + size_t( wave ) * bins;
 	const float * mrow = mod + frame * bins;
 	const float * irow = in_modified + idx * bins;
 
 	bool backwards = false;
-	for( int bin = 1 + lane; bin < bins; bin += 64 )
-		backwards |= !( frequency_to_bin( mrow[bin], sr, dft ) >= frequency_to_bin( mrow[bin - 1], sr, dft ) );
+	for( int bin = lane; bin < bins; bin += 64 )
+		{
+		orow[bin] = MFd{ 0.0f, 0.0f };                                              // :205 clear_buffer
+		if( bin >= 1 ) backwards |= !( frequency_to_bin( mrow[bin], sr, dft ) >= frequency_to_bin( mrow[bin - 1], sr, dft ) );
+		}
 	const bool sequential = __any( backwards );
+	wave_sync();
 
 	auto pair = [&]( int bin )                                                      // :214-244 for the pair ( bin-1, bin )
 		{
@@ -251,6 +257,9 @@ __global__ __launch_bounds__( 256 ) void k_modify_frequency( const MFd * in, int
 		{
 		for( int bin = 1; bin < bins; ++bin ) pair( bin );
 		}
+	wave_sync();
+	MFd * grow = out + idx * bins;
+	for( int bin = lane; bin < bins; bin += 64 ) grow[bin] = orow[bin];
 	}
 
 // PV::shape, PV.cpp:431-454.  AFFINE: shaped = { a*m + b, c*f + d }; otherwise shaped values come from `shaped_tbl`.
@@ -373,9 +382,11 @@ int flanhip_modify_frequency_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F
 	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, sr ) ) return rc;
 	FLANHIP_REQUIRE( d_mod && d_in_modified, FLANHIP_ERR_INVALID_ARG, "null map" );
 	hipStream_t s = (hipStream_t) stream;
-	FLANHIP_CHECK( hipMemsetAsync( d_out, 0, sizeof( flanhip_MF ) * size_t( ch ) * F * bins, s ) );    // clear_buffer, PVModify.cpp:205
 	const int64_t rows = ch * F;
-	hipLaunchKernelGGL( k_modify_frequency, dim3( (unsigned) ( ( rows + 3 ) / 4 ) ), dim3( 256 ), 0, s,
+	const size_t per_wave = sizeof( MFd ) * size_t( bins );
+	FLANHIP_REQUIRE( per_wave <= 65536, FLANHIP_ERR_UNSUPPORTED, "more than 8192 bins" );
+	const int waves = int( std::min<size_t>( 4, 65536 / per_wave ) );
+	hipLaunchKernelGGL( k_modify_frequency, dim3( (unsigned) ( ( rows + waves - 1 ) / waves ) ), dim3( 64 * waves ), per_wave * waves, s,
 		(const MFd*) d_pv, int( ch ), F, bins, sr, float( ( bins - 1 ) * 2 ), d_mod, d_in_modified, (MFd*) d_out );
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;

@@ -63,16 +63,18 @@ __device__ __forceinline__ int placement_winner( unsigned long long key ) { retu
 //     recurrence on registers, CH batched writes -- no LDS round trip inside the dependent chain.
 // load( frame, v[NIN] ) / store( frame, v[NOUT] ) are called with frame < F for the thread's own column; step( frame, v )
 // replaces v[0..NIN) by v[0..NOUT) and is called in scan order (frames past F included: harmless, never stored).
-// lds: max(NIN,NOUT) * TFr * (TBc+1) floats.  Column of a thread: blockIdx.x * TBc + threadIdx.x % TBc.
+// lds: max(NIN,NOUT) * TBc * (TFr+4) floats, 16-byte aligned (column_scan_lds_floats).  Column of a thread: blockIdx.x * TBc + threadIdx.x % TBc.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int TB = 64;
+__host__ __device__ constexpr int column_scan_lds_floats( int TFr, int TBc, int arrays ) { return arrays * TBc * ( TFr + 4 ); }
 
 template<int TFr, int TBc, int NIN, int NOUT, bool REVERSE, class Load, class Step, class Store>
 __device__ __forceinline__ void column_scan( float * lds, int64_t F, Load load, Step step, Store store )
 	{
 	constexpr int NT = NIN > NOUT ? NIN : NOUT, NY = 256 / TBc, RP = TFr / NY, CH = 32;
 	static_assert( TFr % CH == 0 && TFr % NY == 0 && TBc <= 64, "tile shape" );
-	auto T = [&]( int a, int r, int c ) -> float & { return lds[( a * TFr + r ) * ( TBc + 1 ) + c]; };
+	// column-major tile: the CH rows a scanning thread reads or writes at a time are contiguous (ds_read_b128 / ds_write_b128)
+	auto T = [&]( int a, int r, int c ) -> float & { return lds[( a * TBc + c ) * ( TFr + 4 ) + r]; };
 	const int tx = threadIdx.x % TBc, ty = threadIdx.x / TBc;
 	const int64_t tiles = ( F + TFr - 1 ) / TFr;
 	float pre[NIN][RP];

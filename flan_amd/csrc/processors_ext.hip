@@ -60,12 +60,15 @@ constexpr int kResTB = 16, kResTF = 128;                                        
 // the OUTPUT's frames with ( m, f, decay_t ) in and ( m, f ) out.
 __global__ __launch_bounds__( 256 ) void k_resonate( const MFd * in, int64_t F, int bins, int64_t Fo, const float * decay_t, float decay_t_const, MFd * out )
 	{
-	__shared__ float lds[3 * kResTF * ( kResTB + 1 )];
+	__shared__ __attribute__(( aligned( 16 ) )) float lds[column_scan_lds_floats( kResTF, kResTB, 3 )];
 	const int bin = blockIdx.x * kResTB + threadIdx.x % kResTB;
 	const bool valid = bin < bins;
 	const MFd * ip = in + int64_t( blockIdx.y ) * F * bins + bin;
 	MFd * op = out + int64_t( blockIdx.y ) * Fo * bins + bin;
-	float sm = 0.0f, sf = 0.0f;                                                       // out[frame-1] of this column
+	// out[frame-1] of this column.  Frame 0 is a copy of the input (:619-624): the state starts AS frame 0 and that step
+	// multiplies by 1, which leaves it in place -- the recurrence then has no special case inside its dependent chain.
+	float sm = 0.0f, sf = 0.0f;
+	if( valid && threadIdx.x < kResTB ) { const MFd first = ip[0]; sm = first.m; sf = first.f; }
 	column_scan<kResTF, kResTB, 3, 2, false>( lds, Fo,
 		[&]( int64_t f, float ( &v )[3] )
 			{
@@ -73,11 +76,12 @@ __global__ __launch_bounds__( 256 ) void k_resonate( const MFd * in, int64_t F, 
 			if( valid && f < F ) mf = ip[f * bins];
 			v[0] = mf.m; v[1] = mf.f;
 			v[2] = ( valid && decay_t ) ? decay_t[f * bins + bin] : decay_t_const;
+			if( f == 0 ) { v[0] = __builtin_nanf( "" ); v[2] = 1.0f; }
 			},
 		[&]( int64_t f, float ( &v )[3] )
 			{
 			const float decayed_amp = sm * v[2];                                      // :632
-			const bool take = ( f == 0 ) || v[0] > decayed_amp;                       // :619-624 (frame 0 is copied), :633
+			const bool take = v[0] > decayed_amp;                                     // :633
 			sm = take ? v[0] : decayed_amp;                                           // :634 / :636
 			sf = take ? v[1] : sf;
 			v[0] = sm; v[1] = sf;
@@ -88,60 +92,75 @@ __global__ __launch_bounds__( 256 ) void k_resonate( const MFd * in, int64_t F, 
 // ---------------------------------------------------------------------------------------------------------------------
 // retain / remove n loudest partials
 // ---------------------------------------------------------------------------------------------------------------------
-// predicateNLoudestPartials, PV.cpp:552-590.  One wavefront per (channel, frame) row; s_keys: dynamic LDS, bins u32 per wave.
+// predicateNLoudestPartials, PV.cpp:552-590.  One wavefront per (channel, frame) row.  The row's keys ( |m| bit patterns )
+// live in registers when bins <= 64 Q (Q = 3 ... 33: dft 256 ... 4096), else in LDS (s_keys32: bins u32 per wave).
+template<int Q>
 __global__ __launch_bounds__( 256 ) void k_n_loudest( const MFd * in, int64_t rows, int64_t F, int bins, const int * n_per_frame, int n_const,
 	int remove, MFd * out )
 	{
 	extern __shared__ unsigned s_keys32[];
+	constexpr bool REG = Q > 0;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int64_t idx = int64_t( blockIdx.x ) * ( blockDim.x >> 6 ) + wave;
 	if( idx >= rows ) return;
-	unsigned * keys = s_keys32 + size_t( wave ) * bins;
 	const MFd * row = in + idx * bins;
 	MFd * orow = out + idx * bins;
 	const int64_t frame = idx % F;
 	const int64_t n = min( max( int64_t( n_per_frame ? n_per_frame[frame] : n_const ), int64_t( 0 ) ), F );   // :556 (sic: frames)
-	for( int bin = lane; bin < bins; bin += 64 ) keys[bin] = __float_as_uint( row[bin].m ) & 0x7fffffffu;      // abs, :571
-	wave_sync();
+	const int groups = REG ? Q : ( bins + 63 ) / 64;
+	unsigned rkey[REG ? Q : 1];
+	MFd rmf[REG ? Q : 1];
+	unsigned * keys = s_keys32 + ( REG ? 0 : size_t( wave ) * bins );
+	if constexpr( REG )
+		{
+		#pragma unroll
+		for( int q = 0; q < Q; ++q )
+			{
+			const int bin = lane + 64 * q;
+			rmf[q] = bin < bins ? row[bin] : MFd{ 0.0f, 0.0f };
+			rkey[q] = __float_as_uint( rmf[q].m ) & 0x7fffffffu;                      // abs, :571
+			}
+		}
+	else
+		{
+		for( int bin = lane; bin < bins; bin += 64 ) keys[bin] = __float_as_uint( row[bin].m ) & 0x7fffffffu;
+		wave_sync();
+		}
+	auto key_of = [&]( int q ) { return REG ? rkey[REG ? q : 0] : keys[min( lane + 64 * q, bins - 1 )]; };
+	// number of bins of the row satisfying a predicate on ( key, valid )
+	auto count = [&]( auto pred )
+		{
+		int cnt = 0;
+		#pragma unroll
+		for( int q = 0; q < groups; ++q ) cnt += __popcll( __ballot( lane + 64 * q < bins && pred( key_of( q ) ) ) );
+		return cnt;
+		};
 
 	// T = the n-th largest key: the greatest T with #{ key >= T } >= n, found bit by bit
 	unsigned T = 0;
 	if( n > 0 && n < bins )
-		{
 		for( int bit = 30; bit >= 0; --bit )
 			{
 			const unsigned cand = T | ( 1u << bit );
-			int cnt = 0;
-			for( int base = 0; base < bins; base += 64 )
-				{
-				const int bin = base + lane;
-				cnt += __popcll( __ballot( bin < bins && keys[min( bin, bins - 1 )] >= cand ) );
-				}
-			if( cnt >= n ) T = cand;
+			if( count( [&]( unsigned k ) { return k >= cand; } ) >= n ) T = cand;
 			}
-		}
-	int greater = 0;
-	for( int base = 0; base < bins; base += 64 )
-		{
-		const int bin = base + lane;
-		greater += __popcll( __ballot( bin < bins && keys[min( bin, bins - 1 )] > T ) );
-		}
-	const int64_t ties_in = n - greater;                                              // bins equal to T that are among the n loudest
+	const int64_t ties_in = n - count( [&]( unsigned k ) { return k > T; } );         // bins equal to T that are among the n loudest
 	int seen = 0;                                                                     // equal bins below this 64-bin group
-	for( int base = 0; base < bins; base += 64 )
+	#pragma unroll
+	for( int q = 0; q < groups; ++q )
 		{
-		const int bin = base + lane;
+		const int bin = lane + 64 * q;
 		const bool valid = bin < bins;
-		const unsigned key = keys[min( bin, bins - 1 )];
+		const unsigned key = key_of( q );
 		const bool eq = valid && key == T;
 		const unsigned long long mask = __ballot( eq );
 		const int rank_eq = seen + __popcll( mask & ( ( 1ull << lane ) - 1ull ) );
 		seen += __popcll( mask );
-		bool among = n >= bins || ( n > 0 && ( key > T || ( eq && rank_eq < ties_in ) ) );   // rank < n
+		const bool among = n >= bins || ( n > 0 && ( key > T || ( eq && rank_eq < ties_in ) ) );   // rank < n
 		const bool keep = remove ? !among : among;                                    // :595 / :601
 		if( valid )
 			{
-			const MFd v = row[bin];
+			const MFd v = REG ? rmf[REG ? q : 0] : row[bin];
 			orow[bin] = keep ? v : MFd{ 0.0f, v.f };                                  // :581-584
 			}
 		}
@@ -154,17 +173,17 @@ constexpr int kSelTB = 16, kSelTF = 896;                                        
 // PVModify.cpp:461-475, forward: L[frame][bin] = the last selected frame <= frame (-1: none yet).  grid = ceil(bins/16).
 __global__ __launch_bounds__( 256 ) void k_desample_select( const float * ratio, float ratio_const, int64_t F, int bins, int * L )
 	{
-	__shared__ float lds[kSelTF * ( kSelTB + 1 )];
+	__shared__ __attribute__(( aligned( 16 ) )) float lds[column_scan_lds_floats( kSelTF, kSelTB, 1 )];
 	const int bin = blockIdx.x * kSelTB + threadIdx.x % kSelTB;
 	const bool valid = bin < bins;
 	float accum = 1.0f;                                                               // :461
 	int last = -1;
 	column_scan<kSelTF, kSelTB, 1, 1, false>( lds, F,
-		[&]( int64_t f, float ( &v )[1] ) { v[0] = ( valid && ratio ) ? ratio[f * bins + bin] : ratio_const; },
+		[&]( int64_t f, float ( &v )[1] ) { v[0] = clamp01( ( valid && ratio ) ? ratio[f * bins + bin] : ratio_const ); },   // :468
 		[&]( int64_t f, float ( &v )[1] )
 			{
-			accum += clamp01( v[0] );                                                 // :468-469
-			const bool sel = accum >= 1.0f && f < F;                                  // :470
+			accum += v[0];                                                            // :469
+			const bool sel = accum >= 1.0f;                                           // :470 (steps past the last frame are never stored)
 			last = sel ? int( f ) : last;
 			accum = sel ? accum - 1.0f : accum;                                       // :473
 			v[0] = __int_as_float( last );
@@ -175,7 +194,7 @@ __global__ __launch_bounds__( 256 ) void k_desample_select( const float * ratio,
 // backward: R[frame][bin] = the first selected frame > frame (-1: none).  Frame t is selected iff L[t] == t.
 __global__ __launch_bounds__( 256 ) void k_desample_next( const int * L, int64_t F, int bins, int * R )
 	{
-	__shared__ float lds[kSelTF * ( kSelTB + 1 )];
+	__shared__ __attribute__(( aligned( 16 ) )) float lds[column_scan_lds_floats( kSelTF, kSelTB, 1 )];
 	const int bin = blockIdx.x * kSelTB + threadIdx.x % kSelTB;
 	const bool valid = bin < bins;
 	int next = -1;
@@ -185,27 +204,35 @@ __global__ __launch_bounds__( 256 ) void k_desample_next( const int * L, int64_t
 			{
 			const int l = __float_as_int( v[0] );
 			v[0] = __int_as_float( next );
-			next = ( f < F && l == int( f ) ) ? l : next;
+			next = ( l == int( f ) ) ? l : next;                                      // rows past the last frame hold 0, never == f
 			},
 		[&]( int64_t f, float ( &v )[1] ) { if( valid ) R[f * bins + bin] = __float_as_int( v[0] ); } );
 	}
 
-// PVModify.cpp:483-506, one thread per output MF
-__global__ __launch_bounds__( 256 ) void k_desample_apply( const MFd * in, int64_t F, int bins, int64_t count, const int * L, const int * R, int interp, MFd * out )
+// PVModify.cpp:483-506, one thread per (frame, bin): the endpoints and the mix are the same for every channel
+__global__ __launch_bounds__( 256 ) void k_desample_apply( const MFd * in, int num_channels, int64_t F, int bins, const int * L, const int * R, int interp, MFd * out )
 	{
 	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
-	if( idx >= count ) return;
+	const int64_t per_channel = F * bins;
+	if( idx >= per_channel ) return;
 	const int bin = int( idx % bins );
-	const int64_t frame = ( idx / bins ) % F;
-	const int64_t channel = idx / ( int64_t( bins ) * F );
-	const int lFrame = L[frame * bins + bin], rFrame = R[frame * bins + bin];
-	if( lFrame < 0 || rFrame < 0 ) { out[idx] = MFd{ 0.0f, 0.0f }; return; }          // :453 clear_buffer, :482
-	const MFd lMF = in[( channel * F + lFrame ) * bins + bin];
-	const MFd rMF = in[( channel * F + rFrame ) * bins + bin];
-	const float mix = interpolate( interp, float( int( frame ) - lFrame ) / float( rFrame - lFrame ) );   // :491
-	const float w0 = ( 1.0f - mix ) * lMF.m;
-	const float w1 = mix * rMF.m;
-	out[idx] = MFd{ w0 + w1, w0 > w1 ? lMF.f : rMF.f };                               // :494-498
+	const int64_t frame = idx / bins;
+	const int lFrame = L[idx], rFrame = R[idx];
+	const bool none = lFrame < 0 || rFrame < 0;                                       // :453 clear_buffer, :482
+	const float mix = none ? 0.0f : interpolate( interp, float( int( frame ) - lFrame ) / float( rFrame - lFrame ) );   // :491
+	for( int channel = 0; channel < num_channels; ++channel )
+		{
+		MFd o = { 0.0f, 0.0f };
+		if( !none )
+			{
+			const MFd lMF = in[( int64_t( channel ) * F + lFrame ) * bins + bin];
+			const MFd rMF = in[( int64_t( channel ) * F + rFrame ) * bins + bin];
+			const float w0 = ( 1.0f - mix ) * lMF.m;
+			const float w1 = mix * rMF.m;
+			o = MFd{ w0 + w1, w0 > w1 ? lMF.f : rMF.f };                              // :494-498
+			}
+		out[int64_t( channel ) * per_channel + idx] = o;
+		}
 	}
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -333,12 +360,25 @@ int flanhip_n_loudest_partials_dev( const flanhip_MF * d_pv, int64_t ch, int64_t
 	flanhip_MF * d_out, void * stream )
 	{
 	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, 1.0f ) ) return rc;
-	const size_t per_wave = sizeof( unsigned ) * size_t( bins );
-	FLANHIP_REQUIRE( per_wave <= 65536, FLANHIP_ERR_UNSUPPORTED, "more than 16384 bins" );
-	const int waves = int( std::min<size_t>( 4, 65536 / per_wave ) );
 	const int64_t rows = ch * F;
-	hipLaunchKernelGGL( k_n_loudest, dim3( blocks_for( rows, waves ) ), dim3( 64 * waves ), per_wave * waves, (hipStream_t) stream,
-		(const MFd*) d_pv, rows, F, bins, (const int*) d_n, int( n_const ), remove ? 1 : 0, (MFd*) d_out );
+	hipStream_t s = (hipStream_t) stream;
+	const int q = ( bins + 63 ) / 64;
+	#define FLANHIP_NL( Q ) hipLaunchKernelGGL( k_n_loudest<Q>, dim3( blocks_for( rows, 4 ) ), dim3( 256 ), 0, s, (const MFd*) d_pv, rows, F, bins, \
+		(const int*) d_n, int( n_const ), remove ? 1 : 0, (MFd*) d_out )
+	if( q <= 3 ) FLANHIP_NL( 3 );
+	else if( q <= 5 ) FLANHIP_NL( 5 );
+	else if( q <= 9 ) FLANHIP_NL( 9 );
+	else if( q <= 17 ) FLANHIP_NL( 17 );
+	else if( q <= 33 ) FLANHIP_NL( 33 );
+	else
+		{
+		const size_t per_wave = sizeof( unsigned ) * size_t( bins );
+		FLANHIP_REQUIRE( per_wave <= 65536, FLANHIP_ERR_UNSUPPORTED, "more than 16384 bins" );
+		const int waves = int( std::min<size_t>( 4, 65536 / per_wave ) );
+		hipLaunchKernelGGL( k_n_loudest<0>, dim3( blocks_for( rows, waves ) ), dim3( 64 * waves ), per_wave * waves, s,
+			(const MFd*) d_pv, rows, F, bins, (const int*) d_n, int( n_const ), remove ? 1 : 0, (MFd*) d_out );
+		}
+	#undef FLANHIP_NL
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;
 	}
@@ -356,8 +396,7 @@ int flanhip_desample_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bi
 	const unsigned col_blocks = ( bins + kSelTB - 1 ) / kSelTB;
 	hipLaunchKernelGGL( k_desample_select, dim3( col_blocks ), dim3( 256 ), 0, s, d_ratio, ratio_const, F, bins, d_lr );
 	hipLaunchKernelGGL( k_desample_next, dim3( col_blocks ), dim3( 256 ), 0, s, (const int*) d_lr, F, bins, d_lr + grid );
-	const int64_t count = ch * F * bins;
-	hipLaunchKernelGGL( k_desample_apply, dim3( blocks_for( count, 256 ) ), dim3( 256 ), 0, s, (const MFd*) d_pv, F, bins, count,
+	hipLaunchKernelGGL( k_desample_apply, dim3( blocks_for( int64_t( grid ), 256 ) ), dim3( 256 ), 0, s, (const MFd*) d_pv, int( ch ), F, bins,
 		(const int*) d_lr, (const int*) ( d_lr + grid ), interp, (MFd*) d_out );
 	FLANHIP_CHECK( hipGetLastError() );
 	FLANHIP_CHECK( hipFreeAsync( d_lr, s ) );

@@ -186,3 +186,13 @@ def test_golden_vectors(fa):
     assert_identical("golden/remove", fa.n_loudest_partials(pv, g["n"], True), g["remove"])
     assert_identical("golden/desample", fa.desample(pv, g["ratio"], 0), g["desample"])
     assert_identical("golden/time_extrapolate", fa.time_extrapolate(pv, SR, start, end, Fo, g["te_samples"]), g["time_extrapolate"])
+
+
+def test_n_loudest_partials_wide_rows(fa):
+    """rows too wide for the register-resident keys (dft 8192: 4097 bins) take the LDS variant; dft 4096 the widest register one"""
+    rng = np.random.default_rng(17)
+    for bins in (2049, 4097):
+        pv = rng.uniform(0, 1, (1, 7, bins, 2)).astype(np.float32)
+        n = np.array([0, 1, 5, 6, 7, 3, 2], np.int32)
+        for remove in (False, True):
+            assert_identical("n_loudest/wide bins=%d" % bins, fa.n_loudest_partials(pv, n, remove), O.n_loudest_partials(pv, n, remove))
