@@ -177,9 +177,27 @@ def main():
                     traffic = json.load(fh)[kname]["traffic_bytes"]
         except Exception:
             traffic = None
+        # what a plain device-to-device copy of the same number of bytes reaches on this box (quote the measured
+        # copy rate beside the 8 TB/s spec); read + written bytes, like the algorithmic figure
+        copy_gbs = None
+        try:
+            src = pv.view(-1)[: frames_per_step * b // 8]          # half the bytes read, half written
+            dst = torch.empty_like(src)
+            dst.copy_(src)
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            for _ in range(10):
+                dst.copy_(src)
+            c1.record()
+            torch.cuda.synchronize()
+            copy_gbs = round(2 * src.numel() * 4 / (c0.elapsed_time(c1) / 10 * 1e-3) / 1e9, 1)
+            del dst
+        except Exception:
+            copy_gbs = None
         roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "launch_ms": round(tk, 4), "algorithmic_bytes_per_launch": frames_per_step * b}
+                    "launch_ms": round(tk, 4), "algorithmic_bytes_per_launch": frames_per_step * b,
+                    "copy_peak_measured": copy_gbs}
         extra["roundtrip_hbm"] = {"achieved_GBs": round(frames_per_step * BYTES_ROUNDTRIP / (ms_per_step * 1e-3) / 1e9, 1),
                                   "frac_of_8TBs": round(frames_per_step * BYTES_ROUNDTRIP / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 

@@ -74,6 +74,10 @@ _SIGS = {
     "flanhip_resample_out_frames": (_i64, [_i64, _f32, _f32]),
     "flanhip_resample": (C.c_int, [_vp, _i64, _i64, _f32, _f32, _vp, _vp]),
     "flanhip_resample_dev": (C.c_int, [_vp, _i64, _i64, _f32, _f32, _vp, _vp]),
+    "flanhip_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "flanhip_comm_init": (C.c_int, [C.c_char_p, _i32, _i32, C.POINTER(_vp)]),
+    "flanhip_comm_destroy": (C.c_int, [_vp]),
+    "flanhip_allgather_audio": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "flanhip_noise_dev": (C.c_int, [_vp, _i64, _i64, C.c_uint32, _vp]),
     "flanhip_sqdiff_dev": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
 }

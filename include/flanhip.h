@@ -210,6 +210,20 @@ int flanhip_resample(const float * in, int64_t num_channels, int64_t num_frames,
 int flanhip_resample_dev(const float * d_in, int64_t num_channels, int64_t num_frames, float src_rate, float dst_rate,
                          float * d_out, void * stream);
 
+/* ---- multi-GPU: reassembling the channel shards of the output.  One process per GPU; channels shard with no
+ * exchange during compute; the output step is ONE in-place all-gather over RCCL / xGMI.  RCCL is bound at run time (dlopen):
+ * without librccl.so these four return FLANHIP_ERR_UNSUPPORTED and everything else still works. ------------------------- */
+#define FLANHIP_COMM_ID_BYTES 128                     /* ncclUniqueId */
+/* rank 0 creates the id and hands the 128 bytes to the other ranks by whatever launcher it uses (MPI, a file, a socket ...) */
+int flanhip_comm_unique_id(char * id_out /* [FLANHIP_COMM_ID_BYTES] */);
+/* collective over all ranks; the device is the one current in this process (flanhip_set_device).  comm_out: an ncclComm_t */
+int flanhip_comm_init(const char * id, int world_size, int rank, void ** comm_out);
+int flanhip_comm_destroy(void * comm);
+/* d_all: float[world_size][count_per_rank]; this rank's shard (its channels, Audio layout float[ch][frames]) is already at
+ * d_all + rank * count_per_rank.  On return (stream order) d_all is the whole float[all channels][frames] buffer on every rank.
+ * comm may also be an ncclComm_t created elsewhere with the same RCCL. */
+int flanhip_allgather_audio(void * comm, float * d_all, int64_t count_per_rank, int rank, void * stream);
+
 /* ---- synthetic input + comparison utilities (bench / tests; defined by this project) -------------- */
 int flanhip_noise_dev(float * d_out, int64_t num_channels, int64_t num_audio_frames, uint32_t seed, void * stream);
 /* sum of squares of (a - b) and of b, as doubles: d_result[0] = sum (a-b)^2, d_result[1] = sum b^2 */
