@@ -38,16 +38,16 @@ static int run_analyze( const AnalyzeParams & p, hipStream_t s )
 	return FLANHIP_OK;
 	}
 
-// Tuned kernels (dft 2048 / 4096): 6 wavefronts per block; two blocks (dft 2048) share a CU's 160 KiB of LDS, so the chip
-// holds 256 CUs x 12 wavefronts = 3072 chains at once.
-// analysis fits 168 VGPRs -> 3 wavefronts per SIMD: 6-wave blocks, two per CU (LDS 2 x 76.8 KB), 3072 resident chains;
-// synthesis needs 256 VGPRs -> 2 per SIMD: one 8-wave block per CU (LDS 94 KB), 2048 resident chains.
-// dft 4096 doubles the per-wave LDS: 6-wave blocks, one per CU.
-static constexpr int kAnaWaves10 = 8, kSynWaves10 = 8, kWaves11 = 6;
+// Tuned kernels.  dft 2048: 16 complex points per lane, <= 256 VGPRs -> 2 wavefronts per SIMD: one 8-wave block per CU
+// (LDS 94 KB; 164 KB with the fused sums), 2048 resident chains.
+// dft 4096: 32 complex points per lane need ~400 registers: 4-wave blocks, ONE wavefront per SIMD, so that the compiler may use
+// the 256 AGPRs as spill space instead of scratch memory (6-wave blocks at 256 VGPRs spilled 400-850 B per lane to scratch and
+// ran synthesis 3.3x slower); 1024 resident chains.
+static constexpr int kAnaWaves10 = 8, kSynWaves10 = 8, kWaves11 = 4;
 static int fast_target_chains( int dft, bool synth )
 	{
 	if( const char * env = std::getenv( "FLANHIP_TARGET_CHAINS" ) ) { const int v = std::atoi( env ); if( v > 0 ) return v; }
-	if( dft == 4096 ) return 256 * 6;
+	if( dft == 4096 ) return 256 * 4;
 	return 256 * 8;
 	}
 
@@ -99,6 +99,11 @@ static bool synth_fast_ok( int dft, int W, int hop )
 		&& W % 128 == 0 && hop <= W && !force_generic();
 	}
 
+// Can the analysis of this shape also leave convert_to_audio's pre-pass in the workspace?  Not at dft 4096: its kernels hold 32
+// complex points per lane and run one wavefront per SIMD with the AGPRs as spill space; the per-chain sums would need LDS that
+// 4-wave blocks do not leave (185 KB).  Both fused entry points consult this, so the pair then simply runs unfused.
+static bool fused_prepass_supported( int dft ) { return dft != 4096; }
+
 int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft, flanhip_MF * d_out, void * d_fused_ws, hipStream_t s )
 	{
 	FLANHIP_REQUIRE( d_audio && d_out, FLANHIP_ERR_INVALID_ARG, "null buffer" );
@@ -123,7 +128,7 @@ int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int 
 	if( int rc = get_div_plan( p.analysis_rate, &dp ) ) return rc;
 	p.ar_div = DivC{ dp.c, dp.rc, dp.exact };
 	p.sums = nullptr; p.nan_out = nullptr;
-	if( d_fused_ws )
+	if( d_fused_ws && fused_prepass_supported( dft ) )
 		{
 		// use the chain layout convert_to_audio will use for this PV and leave its pre-pass results in the workspace
 		SynthLayout lay;
@@ -138,7 +143,7 @@ int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int 
 	if( fast )
 		{
 		FastTables tb{ plan->d_tw1f, plan->d_tw3f, plan->d_tw2 };
-		if( p.sums ) return dft == 2048 ? run_analyze_fast<10, kAnaWaves10, true>( p, tb, s ) : run_analyze_fast<11, 3, true>( p, tb, s );
+		if( p.sums ) return run_analyze_fast<10, kAnaWaves10, true>( p, tb, s );
 		return dft == 2048 ? run_analyze_fast<10, kAnaWaves10, false>( p, tb, s ) : run_analyze_fast<11, kWaves11, false>( p, tb, s );
 		}
 
@@ -207,6 +212,7 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	if( int rc = require_device() ) return rc;
 	const Plan * plan = nullptr;
 	if( int rc = get_plan( W, lay.dft, &plan ) ) return rc;
+	presummed = presummed && fused_prepass_supported( lay.dft );
 
 	SynthParams p;
 	p.pv = reinterpret_cast<const MF*>( d_pv ); p.out = d_out;
