@@ -78,7 +78,8 @@ static bool design_default_lowpass( double req_norm_freq, double gain, std::vect
 	return true;
 	}
 
-struct ResamplePlan { double * d_taps = nullptr; int fl2 = 0; };
+// d_he[q] = h[2 fl2 - 2 q] (q = 0 .. fl2), d_ho[q] = h[2 fl2 - 1 - 2 q] (q = 0 .. fl2 - 1): the taps in the order the kernel walks them
+struct ResamplePlan { double * d_he = nullptr; double * d_ho = nullptr; int fl2 = 0; };
 static std::mutex g_rs_mutex;
 static std::map<int, ResamplePlan> g_rs_plans;   // per device
 
@@ -91,40 +92,99 @@ static int get_resample_plan( const ResamplePlan ** out )
 	if( it != g_rs_plans.end() ) { *out = &it->second; return FLANHIP_OK; }
 	std::vector<double> h; int fl2 = 0;
 	FLANHIP_REQUIRE( design_default_lowpass( 0.5, 1.0, h, fl2 ), FLANHIP_ERR_UNSUPPORTED, "low-pass design outside the restated range" );
+	std::vector<double> he( fl2 + 1 ), ho( fl2 + 1, 0.0 );
+	for( int q = 0; q <= fl2; ++q ) he[q] = h[2 * fl2 - 2 * q];
+	for( int q = 0; q < fl2; ++q ) ho[q] = h[2 * fl2 - 1 - 2 * q];
 	ResamplePlan p; p.fl2 = fl2;
-	FLANHIP_CHECK( hipMalloc( &p.d_taps, sizeof( double ) * h.size() ) );
-	FLANHIP_CHECK( hipMemcpy( p.d_taps, h.data(), sizeof( double ) * h.size(), hipMemcpyHostToDevice ) );
+	FLANHIP_CHECK( hipMalloc( &p.d_he, sizeof( double ) * 2 * ( fl2 + 1 ) ) );
+	p.d_ho = p.d_he + ( fl2 + 1 );
+	FLANHIP_CHECK( hipMemcpy( p.d_he, he.data(), sizeof( double ) * ( fl2 + 1 ), hipMemcpyHostToDevice ) );
+	FLANHIP_CHECK( hipMemcpy( p.d_ho, ho.data(), sizeof( double ) * ( fl2 + 1 ), hipMemcpyHostToDevice ) );
 	*out = &g_rs_plans.emplace( device, p ).first->second;
 	return FLANHIP_OK;
 	}
 
-// One block = 256 consecutive outputs of the stream.  The 512 + 2*fl2 input samples the block needs and the taps are staged in
-// LDS (fp64); each thread runs the 2*fl2+1-term sum with fma, input index ascending.
-constexpr int RS_BLOCK = 256;
-__global__ __launch_bounds__( RS_BLOCK ) void k_resample_2to1( const float * in, int64_t total_in, const double * taps, int fl2, float * out, int64_t total_out )
+// out[k] = float( sum_m h[2 fl2 - m] x[2k - fl2 + m], m = 0 .. 2 fl2 ), one fp64 accumulator per output, m ascending (the checker's
+// operation order).  1621 fp64 FMAs per output: the job of this kernel is to keep the fp64 pipes fed.
+//   * A block stages the input span of its 2048 outputs in LDS as fp64, natural order.
+//   * The pair P[j] = ( x[2(k0+t+j) - fl2], x[.. + 1] ) that output k0+t meets at taps m = 2j, 2j+1 is the pair output k0+t+64r meets
+//     at m = 2(j-64r), 2(j-64r)+1.  So lane t owns the EIGHT outputs k0 + t + 64 r: one conflict-free 16-byte LDS read per j feeds
+//     16 FMAs (a single output per thread needs 4x the LDS bandwidth a CU has).
+//   * Taps are uniform across the wave: they arrive through the scalar cache as SGPR operands.
+//   * Outputs enter and leave the j loop 64 steps apart: the loop is cut into phases with a compile-time set of active outputs, so
+//     only real taps are ever multiplied (no zero padding: 0 * Inf must not leak into neighbours).
+constexpr int RS_R = 8, RS_WAVES = 4, RS_WAVE_OUT = 64 * RS_R, RS_BLOCK_OUT = RS_WAVES * RS_WAVE_OUT;
+struct rs_pair { double e, o; };
+
+template<int RLO, int RHI>
+__device__ __forceinline__ void rs_phase( const rs_pair * px, const double * __restrict__ he, const double * __restrict__ ho, int j0, int j1, double ( &acc )[RS_R] )
+	{
+	#pragma unroll 2
+	for( int j = j0; j < j1; ++j )
+		{
+		const rs_pair v = px[j];
+		#pragma unroll
+		for( int r = RLO; r <= RHI; ++r )
+			{
+			acc[r] = __builtin_fma( he[j - 64 * r], v.e, acc[r] );
+			acc[r] = __builtin_fma( ho[j - 64 * r], v.o, acc[r] );
+			}
+		}
+	}
+
+// j = fl2 + 64 S: the last tap (even m = 2 fl2) of output S, a full pair of taps for the outputs after it; then the 63 steps that follow
+template<int S>
+__device__ __forceinline__ void rs_ramp_down( const rs_pair * px, const double * __restrict__ he, const double * __restrict__ ho, int fl2, double ( &acc )[RS_R] )
+	{
+	const int j = fl2 + 64 * S;
+	acc[S] = __builtin_fma( he[fl2], px[j].e, acc[S] );
+	if constexpr( S + 1 < RS_R )
+		{
+		rs_phase<S + 1, RS_R - 1>( px, he, ho, j, j + 1, acc );
+		rs_phase<S + 1, RS_R - 1>( px, he, ho, j + 1, j + 64, acc );
+		rs_ramp_down<S + 1>( px, he, ho, fl2, acc );
+		}
+	}
+
+template<int R>
+__device__ __forceinline__ void rs_ramp_up( const rs_pair * px, const double * __restrict__ he, const double * __restrict__ ho, double ( &acc )[RS_R] )
+	{
+	if constexpr( R < RS_R - 1 )
+		{
+		rs_phase<0, R>( px, he, ho, 64 * R, 64 * ( R + 1 ), acc );
+		rs_ramp_up<R + 1>( px, he, ho, acc );
+		}
+	}
+
+__global__ __launch_bounds__( 64 * RS_WAVES ) void k_resample_2to1( const float * __restrict__ in, int64_t total_in, const double * __restrict__ he,
+	const double * __restrict__ ho, int fl2, float * __restrict__ out, int64_t total_out )
 	{
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	const int ntaps = 2 * fl2 + 1;
-	double * s_h = reinterpret_cast<double*>( smem );                       // [ntaps]
-	double * s_x = s_h + ntaps + 1;                                         // [2*RS_BLOCK + 2*fl2]
-	const int64_t k0 = int64_t( blockIdx.x ) * RS_BLOCK;
+	double * s_x = reinterpret_cast<double*>( smem );                       // [2 * RS_BLOCK_OUT + 2 * fl2 + 2], local index i <-> input x0 + i
+	const int64_t k0 = int64_t( blockIdx.x ) * RS_BLOCK_OUT;
 	const int64_t x0 = 2 * k0 - fl2;                                        // first input sample the block touches
-	const int span = 2 * RS_BLOCK + 2 * fl2;
-	for( int i = threadIdx.x; i < ntaps; i += RS_BLOCK ) s_h[i] = taps[i];
-	for( int i = threadIdx.x; i < span; i += RS_BLOCK )
+	const int span = 2 * RS_BLOCK_OUT + 2 * fl2 + 2;
+	for( int i = threadIdx.x; i < span; i += 64 * RS_WAVES )
 		{
 		const int64_t a = x0 + i;
 		s_x[i] = ( a >= 0 && a < total_in ) ? double( in[a] ) : 0.0;
 		}
 	__syncthreads();
-	const int64_t k = k0 + threadIdx.x;
-	if( k >= total_out ) return;
-	// out[k] = sum_i h[fl2 + (2k - i)] x[i], i = 2k-fl2 .. 2k+fl2  ->  local index i - x0 = 2*tid + m, tap index ntaps-1-m
-	const double * xp = s_x + 2 * threadIdx.x;
-	double acc = 0.0;
-	#pragma unroll 4
-	for( int m = 0; m < ntaps; ++m ) acc = __builtin_fma( s_h[ntaps - 1 - m], xp[m], acc );
-	out[k] = float( acc );
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int t = RS_WAVE_OUT * wave + lane;                                // outputs k0 + t + 64 r, r < RS_R
+	const rs_pair * px = reinterpret_cast<const rs_pair*>( s_x ) + t;
+	double acc[RS_R];
+	#pragma unroll
+	for( int r = 0; r < RS_R; ++r ) acc[r] = 0.0;
+	rs_ramp_up<0>( px, he, ho, acc );                                       // j in [0, 448): outputs join one by one
+	rs_phase<0, RS_R - 1>( px, he, ho, 64 * ( RS_R - 1 ), fl2, acc );       // all eight in flight
+	rs_ramp_down<0>( px, he, ho, fl2, acc );                                // j in [fl2, fl2 + 448]: outputs finish one by one
+	#pragma unroll
+	for( int r = 0; r < RS_R; ++r )
+		{
+		const int64_t k = k0 + t + 64 * r;
+		if( k < total_out ) out[k] = float( acc[r] );
+		}
 	}
 
 } // namespace flanhip
@@ -149,10 +209,11 @@ int flanhip_resample_dev( const float * d_in, int64_t ch, int64_t n, float src_r
 	const int64_t n_out = flanhip_resample_out_frames( n, src_rate, dst_rate );
 	const int64_t total_in = ch * n, total_out = ch * n_out;
 	if( total_out <= 0 ) return FLANHIP_OK;
-	const size_t lds = sizeof( double ) * ( size_t( 2 * plan->fl2 + 2 ) + size_t( 2 * RS_BLOCK + 2 * plan->fl2 ) );
+	FLANHIP_REQUIRE( plan->fl2 >= 64 * ( RS_R - 1 ), FLANHIP_ERR_UNSUPPORTED, "filter shorter than the kernel's ramp" );
+	const size_t lds = sizeof( double ) * size_t( 2 * RS_BLOCK_OUT + 2 * plan->fl2 + 2 );
 	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( k_resample_2to1 ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
-	hipLaunchKernelGGL( k_resample_2to1, dim3( (unsigned) ( ( total_out + RS_BLOCK - 1 ) / RS_BLOCK ) ), dim3( RS_BLOCK ), lds, (hipStream_t) stream,
-		d_in, total_in, plan->d_taps, plan->fl2, d_out, total_out );
+	hipLaunchKernelGGL( k_resample_2to1, dim3( (unsigned) ( ( total_out + RS_BLOCK_OUT - 1 ) / RS_BLOCK_OUT ) ), dim3( 64 * RS_WAVES ), lds, (hipStream_t) stream,
+		d_in, total_in, plan->d_he, plan->d_ho, plan->fl2, d_out, total_out );
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;
 	}
