@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="run synthesis' pre-pass as its own kernel instead of inside analysis")
+    ap.add_argument("--pcie", action="store_true", help="also time the host-buffer entry points (PCIe inclusive; reported in 'pcie_inclusive', never in 'value')")
     ap.add_argument("--dft", type=int, default=2048, choices=[2048, 4096],
                     help="2048: the primary measurement; 4096: the literal convert_to_PV(2048,512) default of the reference API (SURVEY 8)")
     args = ap.parse_args()
@@ -222,6 +223,22 @@ def main():
         assert gathered.shape == (world * ch, F * HOP)
         extra["allgather"] = {"ms": round(tg * 1e3, 3), "bytes_per_rank": out.numel() * 4,
                               "frames_per_s_with_gather": round(world * frames_per_step / (elapsed / args.steps + tg), 1)}
+
+    # the host-buffer C ABI (flanhip_analyze / flanhip_synthesize): upload, kernels, download -- for DESIGN.md, never the metric
+    if rank == 0 and args.pcie:
+        import numpy as np
+        x_host = audio.cpu().numpy()
+        fa.analyze(x_host[:1, :48000], SR, WINDOW, HOP, DFT)
+        t0 = time.perf_counter()
+        pv_host = fa.analyze(x_host, SR, WINDOW, HOP, DFT)
+        t1 = time.perf_counter()
+        out_host, _ = fa.synthesize(pv_host, SR, np.float32(SR) / np.float32(HOP), WINDOW)
+        t2 = time.perf_counter()
+        extra["pcie_inclusive"] = {"analyze_ms": round((t1 - t0) * 1e3, 2), "synthesize_ms": round((t2 - t1) * 1e3, 2),
+                                   "frames_per_s": round(frames_per_step / (t2 - t0), 1),
+                                   "bytes_moved": int(x_host.nbytes + 2 * pv_host.nbytes + out_host.nbytes),
+                                   "note": "pageable numpy buffers through flanhip_analyze + flanhip_synthesize (malloc, H2D, kernels, D2H)"}
+        del pv_host, out_host
 
     cpu = None
     if rank == 0 and not args.no_cpu:
