@@ -7,10 +7,16 @@
 // filter latency consumed (r8brain/CDSPBlockConvolver.h:62-184).  Convolution is convolution: here it is the direct fp64 sum
 //        out[k] = float( sum_{j=-fl2..fl2} h[j] * x[2k - j] ),   x = 0 outside the buffer,
 // with the 1621 taps of r8brain's Kaiser-power windowed sinc design computed once on the host.
-// Other rate ratios run through r8brain's multi-stage interpolators and are not implemented: FLANHIP_ERR_UNSUPPORTED.
+// The other ratios r8brain serves with a SINGLE block convolver (CDSPResampler.h:139-161: src*num == dst*den for (num,den) in
+// (1,3) (2,3) (3,2) (3,4); :165-207: dst == 2 src, dst == 3 src) are the same sum over a zero-stuffed input,
+//        out[k] = float( sum_j h[j] * xu[down*k - j] ),  xu[up*m] = x[m],
+// with the low-pass at cut-off 1/max(up,down) and DC gain `up` (k_resample_rational).  Every other ratio runs through r8brain's
+// half-band upsamplers / fractional interpolators and is not implemented: FLANHIP_ERR_UNSUPPORTED.
 #include "flanhip_internal.h"
 #include <cmath>
 #include <vector>
+#include <tuple>
+#include <algorithm>
 
 namespace flanhip {
 
@@ -78,29 +84,45 @@ static bool design_default_lowpass( double req_norm_freq, double gain, std::vect
 	return true;
 	}
 
-// d_he[q] = h[2 fl2 - 2 q] (q = 0 .. fl2), d_ho[q] = h[2 fl2 - 1 - 2 q] (q = 0 .. fl2 - 1): the taps in the order the kernel walks them
-struct ResamplePlan { double * d_he = nullptr; double * d_ho = nullptr; int fl2 = 0; };
-static std::mutex g_rs_mutex;
-static std::map<int, ResamplePlan> g_rs_plans;   // per device
+// Which single-step ratio is this?  CDSPResampler.h:139-161 (first match wins), then :165-207 with no half-band stage.
+static bool rational_ratio( double src, double dst, int & up, int & down )
+	{
+	static const int common[5][2] = { { 1, 2 }, { 1, 3 }, { 2, 3 }, { 3, 2 }, { 3, 4 } };
+	for( const auto & c : common )
+		if( src * c[0] == dst * c[1] ) { up = c[0]; down = c[1]; return true; }
+	if( src * 2 == dst ) { up = 2; down = 1; return true; }
+	if( src * 3 == dst ) { up = 3; down = 1; return true; }
+	return false;
+	}
 
-static int get_resample_plan( const ResamplePlan ** out )
+// Device copies of the taps for one (up, down): h[0 .. 2 fl2] in natural order, and for the 2:1 kernel
+// d_he[q] = h[2 fl2 - 2 q] (q = 0 .. fl2), d_ho[q] = h[2 fl2 - 1 - 2 q] (q = 0 .. fl2 - 1): the taps in the order it walks them
+struct ResamplePlan { double * d_h = nullptr; double * d_he = nullptr; double * d_ho = nullptr; int fl2 = 0; };
+static std::mutex g_rs_mutex;
+static std::map<std::tuple<int, int, int>, ResamplePlan> g_rs_plans;   // per (device, up, down)
+
+static int get_resample_plan( int up, int down, const ResamplePlan ** out )
 	{
 	int device = 0;
 	FLANHIP_CHECK( hipGetDevice( &device ) );
 	std::lock_guard<std::mutex> lock( g_rs_mutex );
-	auto it = g_rs_plans.find( device );
+	const auto key = std::make_tuple( device, up, down );
+	auto it = g_rs_plans.find( key );
 	if( it != g_rs_plans.end() ) { *out = &it->second; return FLANHIP_OK; }
 	std::vector<double> h; int fl2 = 0;
-	FLANHIP_REQUIRE( design_default_lowpass( 0.5, 1.0, h, fl2 ), FLANHIP_ERR_UNSUPPORTED, "low-pass design outside the restated range" );
+	FLANHIP_REQUIRE( design_default_lowpass( 1.0 / std::max( up, down ), double( up ), h, fl2 ), FLANHIP_ERR_UNSUPPORTED, "low-pass design outside the restated range" );
 	std::vector<double> he( fl2 + 1 ), ho( fl2 + 1, 0.0 );
 	for( int q = 0; q <= fl2; ++q ) he[q] = h[2 * fl2 - 2 * q];
 	for( int q = 0; q < fl2; ++q ) ho[q] = h[2 * fl2 - 1 - 2 * q];
 	ResamplePlan p; p.fl2 = fl2;
-	FLANHIP_CHECK( hipMalloc( &p.d_he, sizeof( double ) * 2 * ( fl2 + 1 ) ) );
+	const size_t nh = h.size();
+	FLANHIP_CHECK( hipMalloc( &p.d_h, sizeof( double ) * ( nh + 2 * ( fl2 + 1 ) ) ) );
+	p.d_he = p.d_h + nh;
 	p.d_ho = p.d_he + ( fl2 + 1 );
+	FLANHIP_CHECK( hipMemcpy( p.d_h, h.data(), sizeof( double ) * nh, hipMemcpyHostToDevice ) );
 	FLANHIP_CHECK( hipMemcpy( p.d_he, he.data(), sizeof( double ) * ( fl2 + 1 ), hipMemcpyHostToDevice ) );
 	FLANHIP_CHECK( hipMemcpy( p.d_ho, ho.data(), sizeof( double ) * ( fl2 + 1 ), hipMemcpyHostToDevice ) );
-	*out = &g_rs_plans.emplace( device, p ).first->second;
+	*out = &g_rs_plans.emplace( key, p ).first->second;
 	return FLANHIP_OK;
 	}
 
@@ -187,6 +209,39 @@ __global__ __launch_bounds__( 64 * RS_WAVES ) void k_resample_2to1( const float 
 		}
 	}
 
+// The general single-step ratio: out[k] = float( sum_m h[fl2 + down*k - up*m] * x[m] ), m ascending over |down*k - up*m| <= fl2.
+// One thread per output; a block of 256 outputs stages its input span (fp64) and the taps in LDS.
+constexpr int RSG_BLOCK = 256;
+__host__ __device__ inline int64_t rs_floor_div( int64_t a, int64_t b ) { return a >= 0 ? a / b : -( ( -a + b - 1 ) / b ); }
+__global__ __launch_bounds__( RSG_BLOCK ) void k_resample_rational( const float * __restrict__ in, int64_t total_in, const double * __restrict__ taps, int fl2,
+	int up, int down, int span, float * __restrict__ out, int64_t total_out )
+	{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int ntaps = 2 * fl2 + 1;
+	double * s_h = reinterpret_cast<double*>( smem );                       // [ntaps]
+	double * s_x = s_h + ntaps + 1;                                         // [span], local index i <-> input m_base + i
+	const int64_t k0 = int64_t( blockIdx.x ) * RSG_BLOCK;
+	const int64_t m_base = rs_floor_div( int64_t( down ) * k0 - fl2 + up - 1, up );   // ceil( ( down*k0 - fl2 ) / up )
+	for( int i = threadIdx.x; i < ntaps; i += RSG_BLOCK ) s_h[i] = taps[i];
+	for( int i = threadIdx.x; i < span; i += RSG_BLOCK )
+		{
+		const int64_t m = m_base + i;
+		s_x[i] = ( m >= 0 && m < total_in ) ? double( in[m] ) : 0.0;
+		}
+	__syncthreads();
+	const int64_t k = k0 + threadIdx.x;
+	if( k >= total_out ) return;
+	const int64_t c = int64_t( down ) * k;
+	const int64_t m_lo = rs_floor_div( c - fl2 + up - 1, up ), m_hi = rs_floor_div( c + fl2, up );
+	const double * xp = s_x + ( m_lo - m_base );
+	const double * hp = s_h + ( fl2 + c - int64_t( up ) * m_lo );           // tap of m_lo; the tap index falls by `up` per input sample
+	const int count = int( m_hi - m_lo + 1 );
+	double acc = 0.0;
+	#pragma unroll 4
+	for( int i = 0; i < count; ++i ) acc = __builtin_fma( hp[-up * i], xp[i], acc );   // zeros outside the buffer contribute +-0
+	out[k] = float( acc );
+	}
+
 } // namespace flanhip
 
 using namespace flanhip;
@@ -202,18 +257,31 @@ int64_t flanhip_resample_out_frames( int64_t num_frames, float src_rate, float d
 int flanhip_resample_dev( const float * d_in, int64_t ch, int64_t n, float src_rate, float dst_rate, float * d_out, void * stream )
 	{
 	FLANHIP_REQUIRE( d_in && d_out && ch > 0 && n > 0 && src_rate > 0.0f && dst_rate > 0.0f, FLANHIP_ERR_INVALID_ARG, "bad arguments" );
-	FLANHIP_REQUIRE( double( src_rate ) == 2.0 * double( dst_rate ), FLANHIP_ERR_UNSUPPORTED, "only the 2:1 (e.g. 96 kHz -> 48 kHz) ratio is implemented" );
+	int up = 0, down = 0;
+	FLANHIP_REQUIRE( rational_ratio( double( src_rate ), double( dst_rate ), up, down ), FLANHIP_ERR_UNSUPPORTED,
+		"only the single-step ratios are implemented (src:dst = 2:1, 3:1, 3:2, 2:3, 4:3, 1:2, 1:3)" );
 	if( int rc = require_device() ) return rc;
 	const ResamplePlan * plan = nullptr;
-	if( int rc = get_resample_plan( &plan ) ) return rc;
+	if( int rc = get_resample_plan( up, down, &plan ) ) return rc;
 	const int64_t n_out = flanhip_resample_out_frames( n, src_rate, dst_rate );
 	const int64_t total_in = ch * n, total_out = ch * n_out;
 	if( total_out <= 0 ) return FLANHIP_OK;
-	FLANHIP_REQUIRE( plan->fl2 >= 64 * ( RS_R - 1 ), FLANHIP_ERR_UNSUPPORTED, "filter shorter than the kernel's ramp" );
-	const size_t lds = sizeof( double ) * size_t( 2 * RS_BLOCK_OUT + 2 * plan->fl2 + 2 );
-	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( k_resample_2to1 ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
-	hipLaunchKernelGGL( k_resample_2to1, dim3( (unsigned) ( ( total_out + RS_BLOCK_OUT - 1 ) / RS_BLOCK_OUT ) ), dim3( 64 * RS_WAVES ), lds, (hipStream_t) stream,
-		d_in, total_in, plan->d_he, plan->d_ho, plan->fl2, d_out, total_out );
+	if( up == 1 && down == 2 && plan->fl2 >= 64 * ( RS_R - 1 ) )
+		{
+		const size_t lds = sizeof( double ) * size_t( 2 * RS_BLOCK_OUT + 2 * plan->fl2 + 2 );
+		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( k_resample_2to1 ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+		hipLaunchKernelGGL( k_resample_2to1, dim3( (unsigned) ( ( total_out + RS_BLOCK_OUT - 1 ) / RS_BLOCK_OUT ) ), dim3( 64 * RS_WAVES ), lds, (hipStream_t) stream,
+			d_in, total_in, plan->d_he, plan->d_ho, plan->fl2, d_out, total_out );
+		}
+	else
+		{
+		const int span = int( ( int64_t( down ) * ( RSG_BLOCK - 1 ) + 2 * plan->fl2 ) / up + 2 );
+		const size_t lds = sizeof( double ) * ( size_t( 2 * plan->fl2 + 2 ) + size_t( span ) );
+		FLANHIP_REQUIRE( lds <= 160 * 1024, FLANHIP_ERR_UNSUPPORTED, "filter too long for the LDS staging" );
+		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( k_resample_rational ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+		hipLaunchKernelGGL( k_resample_rational, dim3( (unsigned) ( ( total_out + RSG_BLOCK - 1 ) / RSG_BLOCK ) ), dim3( RSG_BLOCK ), lds, (hipStream_t) stream,
+			d_in, total_in, plan->d_h, plan->fl2, up, down, span, d_out, total_out );
+		}
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;
 	}
@@ -221,7 +289,7 @@ int flanhip_resample_dev( const float * d_in, int64_t ch, int64_t n, float src_r
 int flanhip_resample( const float * in, int64_t ch, int64_t n, float src_rate, float dst_rate, float * out, volatile int * cancel )
 	{
 	FLANHIP_REQUIRE( in && out && ch > 0 && n > 0, FLANHIP_ERR_INVALID_ARG, "bad arguments" );
-	FLANHIP_REQUIRE( double( src_rate ) == 2.0 * double( dst_rate ), FLANHIP_ERR_UNSUPPORTED, "only the 2:1 (e.g. 96 kHz -> 48 kHz) ratio is implemented" );
+	{ int up = 0, down = 0; FLANHIP_REQUIRE( rational_ratio( double( src_rate ), double( dst_rate ), up, down ), FLANHIP_ERR_UNSUPPORTED, "only the single-step ratios are implemented" ); }
 	if( int rc = require_device() ) return rc;
 	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
 	const int64_t n_out = flanhip_resample_out_frames( n, src_rate, dst_rate );

@@ -204,8 +204,10 @@ int flanhip_mid_side_dev(const float * d_in, int64_t num_audio_frames, float * d
 /* AudioConversions.cpp:22: out frames = Frame( float(num_frames) * ( dst_rate / src_rate ) ) */
 int64_t flanhip_resample_out_frames(int64_t num_frames, float src_rate, float dst_rate);
 /* in: float[ch][n]; out: float[ch][flanhip_resample_out_frames(n,...)].  Like the reference, the whole channel-major buffer is
- * resampled as ONE stream (filter ringing crosses channel boundaries).  Implemented for src_rate == 2 * dst_rate (96 -> 48 kHz:
- * one 1621-tap linear-phase low-pass, latency consumed); other ratios return FLANHIP_ERR_UNSUPPORTED. */
+ * resampled as ONE stream (filter ringing crosses channel boundaries).  Implemented: the ratios r8brain serves with a single
+ * block convolver (r8brain/CDSPResampler.h:139-207) -- src:dst = 2:1 (96 -> 48 kHz: 1621-tap linear-phase low-pass, the tuned
+ * kernel), 3:1, 3:2, 2:3, 4:3, 1:2, 1:3 -- latency consumed, zero-flushed tail.  Other ratios (half-band upsampler chains,
+ * fractional interpolators) return FLANHIP_ERR_UNSUPPORTED. */
 int flanhip_resample(const float * in, int64_t num_channels, int64_t num_frames, float src_rate, float dst_rate,
                      float * out, volatile int * cancel);
 int flanhip_resample_dev(const float * d_in, int64_t num_channels, int64_t num_frames, float src_rate, float dst_rate,

@@ -125,4 +125,40 @@ int oracle_resample_2to1( const float * in, int64_t total_in, float * out, int64
 	return 0;
 	}
 
+// The single-step rational ratios of CDSPResampler (r8brain/CDSPResampler.h:139-161: src*num == dst*den for (num,den) in
+// (1,2) (1,3) (2,3) (3,2) (3,4); :165-207 with c == 0: dst == 2 src, dst == 3 src): ONE CDSPBlockConvolver with the default low-pass
+// at cut-off 1/max(up,down) and DC gain `up` (getLPFilter( 1/max, tb, atten, phase, num ), :150-153,:193-195), whole-number
+// upsampling by zero stuffing (CDSPBlockConvolver.h copyUpsample), the filter latency consumed, every `down`-th sample kept
+// starting with the first (DownSkipInit = 0, InputDelay = 0 for a linear-phase filter):
+//        out[k] = float( sum_j h[j] * xu[down*k - j] ),  xu[up*m] = x[m], zero elsewhere and outside the buffer.
+// Sum in ascending input index m.  (up,down) = (1,2) is oracle_resample_2to1.
+int oracle_resample_rational( const float * in, int64_t total_in, float * out, int64_t total_out, int up, int down )
+	{
+	if( up < 1 || down < 1 ) return -1;
+	std::vector<double> h; int fl2 = 0;
+	if( !design_default_lowpass( 1.0 / ( up > down ? up : down ), double( up ), h, fl2 ) ) return -1;
+	for( int64_t k = 0; k < total_out; ++k )
+		{
+		double acc = 0.0;
+		const int64_t c = int64_t( down ) * k;                                      // position in the zero-stuffed stream
+		// input samples m with |c - up*m| <= fl2
+		int64_t m0 = ( c - fl2 + up - 1 ) / up; if( c - fl2 < 0 ) m0 = -( ( fl2 - c ) / up );
+		if( m0 < 0 ) m0 = 0;
+		int64_t m1 = ( c + fl2 ) / up;
+		if( m1 >= total_in ) m1 = total_in - 1;
+		for( int64_t m = m0; m <= m1; ++m ) acc += h[fl2 + ( c - up * m )] * double( in[m] );
+		out[k] = float( acc );
+		}
+	return 0;
+	}
+
+// taps of the default low-pass at cut-off `req_norm_freq` with DC gain `gain`, for tests; returns the tap count
+int oracle_r8b_default_lowpass( double req_norm_freq, double gain, double * taps, int capacity )
+	{
+	std::vector<double> h; int fl2 = 0;
+	if( !design_default_lowpass( req_norm_freq, gain, h, fl2 ) ) return -1;
+	if( taps ) for( int i = 0; i < int( h.size() ) && i < capacity; ++i ) taps[i] = h[i];
+	return int( h.size() );
+	}
+
 } // extern "C"

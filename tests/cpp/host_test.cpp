@@ -167,7 +167,7 @@ static void device_checks()
 	Audio m = n2.convert_to_mid_side();
 	CHECK( close_to( m.get_sample( 0, 10 ), ( n2.get_sample( 0, 10 ) + n2.get_sample( 1, 10 ) ) / std::sqrt( 2.0f ), 1e-6 ) );
 
-	// ---- resample (r8brain path): 2:1 on the device, other ratios refused with a null Audio
+	// ---- resample (r8brain path): its single-step ratios on the device, other ratios refused with a null Audio
 		{
 		std::vector<float> x( 2 * 19200 );
 		for( size_t i = 0; i < x.size(); ++i ) x[i] = float( hash32( uint32_t( i ) ) >> 8 ) * ( 1.0f / 8388608.0f ) - 1.0f;
@@ -175,7 +175,10 @@ static void device_checks()
 		Audio a48 = a96.resample( 48000.0f );
 		CHECK( !a48.is_null() && a48.get_num_frames() == 9600 && a48.get_sample_rate() == 48000.0f && a48.get_num_channels() == 2 );
 		CHECK( a96.resample( 96000.0f ).get_num_frames() == 19200 );               // same rate: a copy (AudioConversions.cpp:18-19)
-		CHECK( a96.resample( 44100.0f ).is_null() );
+		CHECK( a96.resample( 44100.0f ).is_null() );                              // not a single-step ratio of r8brain: refused
+		Audio a192 = a96.resample( 192000.0f );                                   // 1:2, 3:2 ... are single block-convolver steps too
+		CHECK( !a192.is_null() && a192.get_num_frames() == 38400 && a192.get_sample_rate() == 192000.0f );
+		CHECK( a96.resample( 64000.0f ).get_num_frames() == 12800 );
 		}
 
 	// ---- error behaviour: null objects, never exceptions

@@ -61,6 +61,8 @@ def _load():
     lib.oracle_resample_out_frames.restype = C.c_int64
     lib.oracle_resample_out_frames.argtypes = [C.c_int64, C.c_float, C.c_float]
     lib.oracle_resample_2to1.argtypes = [f32p, C.c_int64, f32p, C.c_int64]
+    lib.oracle_resample_rational.argtypes = [f32p, C.c_int64, f32p, C.c_int64, C.c_int, C.c_int]
+    lib.oracle_r8b_default_lowpass.argtypes = [C.c_double, C.c_double, f64p, C.c_int]
     i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
     lib.oracle_interpolate.restype = C.c_float
     lib.oracle_interpolate.argtypes = [C.c_int, C.c_float]
@@ -284,6 +286,21 @@ def resample_2to1(audio, src_rate, dst_rate):
     n_out = int(lib.oracle_resample_out_frames(n, src_rate, dst_rate))
     out = np.empty((ch, n_out), np.float32)
     rc = lib.oracle_resample_2to1(audio.reshape(-1), ch * n, out.reshape(-1), ch * n_out)
+    assert rc == 0
+    return out
+
+
+# the ratios r8brain serves with ONE block convolver (CDSPResampler.h:139-207): (src, dst) -> (up, down)
+SINGLE_STEP_RATIOS = {(2, 1): (1, 2), (3, 1): (1, 3), (3, 2): (2, 3), (2, 3): (3, 2), (4, 3): (3, 4), (1, 2): (2, 1), (1, 3): (3, 1)}
+
+
+def resample_rational(audio, src_rate, dst_rate, up, down):
+    """Audio::resample for a single-step ratio: [ch][n] -> [ch][n_out], the whole buffer as one stream"""
+    audio = np.ascontiguousarray(audio, np.float32)
+    ch, n = audio.shape
+    n_out = int(lib.oracle_resample_out_frames(n, src_rate, dst_rate))
+    out = np.empty((ch, n_out), np.float32)
+    rc = lib.oracle_resample_rational(audio.reshape(-1), ch * n, out.reshape(-1), ch * n_out, up, down)
     assert rc == 0
     return out
 

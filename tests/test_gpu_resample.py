@@ -27,6 +27,21 @@ def test_resample_2to1_parity(fa, ch, n):
     assert np.abs(d).max() <= 2e-7
 
 
+@pytest.mark.parametrize("src,dst,up,down", [(144000.0, 48000.0, 1, 3), (72000.0, 48000.0, 2, 3), (32000.0, 48000.0, 3, 2), (64000.0, 48000.0, 3, 4),
+                                             (48000.0, 96000.0, 2, 1), (16000.0, 48000.0, 3, 1), (88200.0, 44100.0, 1, 2)])
+def test_resample_single_step_ratios(fa, src, dst, up, down):
+    """the other ratios r8brain serves with one block convolver (k_resample_rational), ragged lengths, several channels"""
+    for ch, n in ((2, 30001), (3, 777), (1, 50)):
+        x = O.noise(ch, n, seed=n + up)
+        ref = O.resample_rational(x, src, dst, up, down)
+        got = fa.resample(x, src, dst)
+        assert got.shape == ref.shape
+        d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+        same = np.mean(got.view(np.uint32) == ref.view(np.uint32))
+        print("\n[resample %g->%g %dx%d] max diff %.2e  bit-identical %.5f" % (src, dst, ch, n, d.max() if d.size else 0.0, same if d.size else 1.0))
+        assert (d.max() if d.size else 0.0) <= 2e-7 and (same >= 0.999 if d.size else True)
+
+
 def test_unsupported_ratio(fa):
     import flan_amd
     x = O.noise(1, 1000, seed=1)

@@ -47,3 +47,38 @@ def test_impulse_and_channel_bleed():
     theirs = ref_resample(x, 96000.0, 48000.0)
     assert np.abs(theirs[1, :50]).max() > 1e-3
     assert np.abs(ours.astype(np.float64) - theirs).max() <= 2e-7
+
+
+RATES = [(144000.0, 48000.0, 1, 3), (72000.0, 48000.0, 2, 3), (32000.0, 48000.0, 3, 2), (64000.0, 48000.0, 3, 4), (48000.0, 96000.0, 2, 1),
+         (16000.0, 48000.0, 3, 1), (96000.0, 48000.0, 1, 2), (44100.0, 88200.0, 2, 1), (88200.0, 44100.0, 1, 2)]
+
+
+@pytest.mark.parametrize("src,dst,up,down", RATES)
+def test_single_step_ratios_match_r8brain(src, dst, up, down):
+    """every ratio CDSPResampler serves with one block convolver (CDSPResampler.h:139-207): zero-stuff by `up`, the default
+    low-pass at cut-off 1/max(up,down) with gain `up`, latency consumed, every `down`-th sample"""
+    rng = np.random.default_rng(int(src + dst))
+    for ch, n in ((2, 7001), (1, 300)):
+        x = rng.uniform(-1, 1, (ch, n)).astype(np.float32)
+        ours = O.resample_rational(x, src, dst, up, down)
+        theirs = ref_resample(x, src, dst)
+        assert ours.shape == theirs.shape
+        d = np.abs(ours.astype(np.float64) - theirs.astype(np.float64))
+        same = np.mean(ours.view(np.uint32) == theirs.view(np.uint32))
+        print("\n[resample %g->%g %dx%d] max diff %.2e  bit-identical %.5f" % (src, dst, ch, n, d.max(), same))
+        assert d.max() <= 3e-7 and same >= 0.995
+
+
+def test_rational_form_contains_the_2to1_restatement():
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, (2, 5000)).astype(np.float32)
+    a = O.resample_2to1(x, 96000.0, 48000.0)
+    b = O.resample_rational(x, 96000.0, 48000.0, 1, 2)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_filter_lengths_of_the_other_cutoffs():
+    taps = np.zeros(8000)
+    assert O.lib.oracle_r8b_default_lowpass(1.0 / 3.0, 1.0, taps, 8000) == 2431     # fl2 = 1215
+    assert O.lib.oracle_r8b_default_lowpass(0.25, 3.0, taps, 8000) == 3241          # fl2 = 1620, DC gain 3
+    assert abs(taps[:3241].sum() - 3.0) < 1e-11
