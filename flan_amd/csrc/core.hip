@@ -1,5 +1,6 @@
 // core.hip -- error state, device plumbing, plan cache, shape helpers of the C ABI (include/flanhip.h).
 #include "flanhip_internal.h"
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -135,14 +136,24 @@ int choose_chain_length( int64_t num_channels, int64_t num_frames, int min_len, 
 		const int v = std::atoi( env );
 		if( v > 0 ) return std::max( v, min_len );
 		}
-	// One wavefront per chain.  target_chains = the wavefronts the chip holds at once for this kernel: with that many
-	// chains (or a little fewer) the whole grid is resident in a single wave of blocks -- no partial second round --
-	// and each chain is long enough to amortise its halo frame / overlap head.  Longer inputs run several rounds.
+	// One wavefront per chain.  target_chains = the wavefronts the chip holds at once for this kernel.  All chains run
+	// concurrently and cost the same (L frames + one halo frame / overlap head), so the launch takes as long as ONE chain:
+	// the best cut is the longest chain that still gives every resident wavefront slot a chain -- a single round of blocks,
+	// the halo amortised over as many frames as possible.  Chains never span channels, so channels * ceil(F / L) can exceed
+	// the slots by a few chains when the channel count does not divide them; one chain too many would start a second,
+	// nearly empty round and double the time, so L grows until the grid fits.
+	// Very long inputs are cut into R full rounds of chains of at most ~512 frames (the halo is then 0.2 % anyway and each
+	// round works on a compact part of the buffers).
 	const int64_t total = num_channels * num_frames;
+	const int64_t cap = 512;
 	int64_t L = ( total + target_chains - 1 ) / target_chains;
+	const int64_t rounds = std::max<int64_t>( ( L + cap - 1 ) / cap, 1 );
+	const int64_t slots = int64_t( target_chains ) * rounds;
+	L = ( total + slots - 1 ) / slots;
 	if( L < 4 ) L = 4;
-	if( L > 64 ) L = 64;
 	if( L < min_len ) L = min_len;
+	while( num_channels * ( ( num_frames + L - 1 ) / L ) > slots && L < num_frames ) ++L;
+	if( L > ( int64_t( 1 ) << 30 ) ) L = int64_t( 1 ) << 30;
 	return int( L );
 	}
 
