@@ -239,3 +239,44 @@ def test_fused_round_trip_equals_unfused(fa):
         print("\n[fused vs unfused dft=%d hop=%d] max audio diff %.3e" % (dft, hop, d.max()))
         assert d.max() <= 1e-6
         assert res[0][2] == res[1][2] == 0
+
+
+def _random_shapes(count, seed):
+    """seeded shapes across every kernel variant: tuned dft 2048 / 4096 with hops that do / do not suit the register overlap-add,
+    generic dft 32 ... 8192, windows shorter than the dft, odd windows and hops, hops beyond the window, inputs shorter than a window"""
+    rng = np.random.default_rng(seed)
+    shapes = []
+    for i in range(count):
+        dft = int(rng.choice([32, 64, 128, 256, 512, 1024, 2048, 2048, 2048, 4096, 4096, 8192]))
+        W = dft if rng.random() < 0.4 else int(rng.integers(max(dft // 8, 2), dft + 1))
+        if dft >= 2048 and rng.random() < 0.5:
+            hop = int(rng.choice([128, 256, 384, 512, 640, 1024]))
+        else:
+            hop = int(rng.integers(1 if dft <= 256 else max(dft // 64, 1), 2 * W))
+        ch = int(rng.integers(1, 4))
+        frames = int(rng.integers(1, 40))
+        n = max(int(frames * hop + rng.integers(-hop // 2, hop // 2 + 1)), 1)
+        shapes.append((ch, n, W, hop, dft))
+    return shapes
+
+
+@pytest.mark.parametrize("ch,n,W,hop,dft", _random_shapes(36, 20260101), ids=lambda v: str(v))
+def test_random_shapes(fa, ch, n, W, hop, dft):
+    sr = 48000.0
+    x = O.noise(ch, n, seed=ch * 7 + W + hop)
+    ref = O.analyze(x, sr, W, hop, dft)
+    got = fa.analyze(x, sr, W, hop, dft)
+    assert got.shape == ref.shape
+    ar = np.float32(sr) / np.float32(hop)
+    rel_m, wrms_f, same, turns = p1_metrics(got, ref, float(ar))
+    out_ref, _ = O.synthesize(ref, sr, ar, W)
+    if O.lib.oracle_hop_size(sr, ar) != hop:
+        pytest.skip("hop %d is not recovered from sample_rate / analysis_rate in fp32 (PVBuffer.cpp:381-384): synthesis undefined" % hop)
+    out_got, flag = fa.synthesize(ref, sr, ar, W)
+    assert out_got.shape == out_ref.shape and flag == 0
+    scale = max(float(np.sqrt(np.mean(out_ref.astype(np.float64) ** 2))), 1e-30)
+    rms = float(np.sqrt(np.mean((out_got.astype(np.float64) - out_ref.astype(np.float64)) ** 2)))
+    print("\n[random %s] P1 rel_m=%.2e wrms_df=%.2e same=%.4f  P2 rms=%.2e (signal rms %.2e)" % ((ch, n, W, hop, dft), rel_m, wrms_f, same, rms, scale))
+    assert rel_m <= 1e-5
+    assert wrms_f <= 2e-3 * max(sr / dft / 23.4, 1.0)
+    assert rms <= 1e-5 * max(scale, 1.0)
