@@ -1,6 +1,7 @@
 // conversions.hip -- Audio::convert_to_PV and PV::convert_to_audio behind the C ABI
 // (reference: Conversions/AudioPV.cpp:12-78 and :86-139).
 #include "flanhip_internal.h"
+#include <atomic>
 #include "pv_kernels.h"
 #include "pv_kernels_fast.h"
 #include <algorithm>
@@ -127,7 +128,7 @@ int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int 
 	DivPlan dp;
 	if( int rc = get_div_plan( p.analysis_rate, &dp ) ) return rc;
 	p.ar_div = DivC{ dp.c, dp.rc, dp.exact };
-	p.sums = nullptr; p.nan_out = nullptr;
+	p.sums = nullptr; p.nan_out = nullptr; p.nan_epoch = 0;
 	if( d_fused_ws && fused_prepass_supported( dft ) )
 		{
 		// use the chain layout convert_to_audio will use for this PV and leave its pre-pass results in the workspace
@@ -137,7 +138,8 @@ int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int 
 		p.chains_per_channel = lay.chains_per_channel;
 		p.sums = reinterpret_cast<double*>( d_fused_ws );
 		p.nan_out = reinterpret_cast<int*>( reinterpret_cast<char*>( d_fused_ws ) + lay.carry_bytes + lay.head_bytes );
-		FLANHIP_CHECK( hipMemsetAsync( p.nan_out, 0, sizeof( int ), s ) );
+		static std::atomic<int> epoch{ 0 };
+		p.nan_epoch = ( epoch.fetch_add( 1 ) & 0x7ffffffe ) + 1;          // never 0
 		}
 
 	if( fast )

@@ -39,7 +39,8 @@ struct AnalyzeParams
 	float analysis_rate;
 	DivC ar_div;              // analysis_rate as a divisor (pv_math.h)
 	double * sums;            // optional [ch][chains][bins]: per-chain sums of the phase increments synthesis will need
-	int * nan_out;            // optional: OR-ed with 1 when an output MF is NaN/Inf
+	int * nan_out;            // optional: nan_out[0] = nan_epoch when an output MF is NaN/Inf, nan_out[2] = nan_epoch always
+	int nan_epoch;            // a fresh non-zero number per launch
 	};
 
 // phase_vocoder.cpp:37-52 with the reference's rounding sequence (the file is compiled with -ffp-contract=off).
@@ -173,7 +174,13 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze( AnalyzeParams p )
 			if( C >= 64 || k < C ) dst[k] = ( __builtin_fabs( sum[q] ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( sum[q] ) : fold_phase_any( sum[q] );
 			}
 		if( lane == 0 ) dst[C] = ( __builtin_fabs( sum[E] ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( sum[E] ) : fold_phase_any( sum[E] );
-		if( p.nan_out && __any( bad ) && lane == 0 ) atomicOr( p.nan_out, 1 );
+		const bool any_bad = __any( bad );
+		if( p.nan_out && lane == 0 )
+			{
+			// no clearing pass: the flag word is "set" when it equals this launch's epoch (written beside it by chain 0)
+			if( chain == 0 ) p.nan_out[2] = p.nan_epoch;
+			if( any_bad ) p.nan_out[0] = p.nan_epoch;
+			}
 		}
 	}
 
@@ -227,7 +234,7 @@ struct SynthParams
 	float analysis_rate;
 	float window_scale;       // AudioPV.cpp:99
 	DivC ar_div;              // analysis_rate as a divisor (pv_math.h)
-	const int * nan_in;       // optional: a NaN flag left by the producer of the PV (fused round trip), folded into nan_flag
+	const int * nan_in;       // optional: the { flag, -, epoch } words left by the producer of the PV (fused round trip): set iff equal
 	float * dump;             // 512 bytes of workspace that out-of-range lanes of k_synthesize_fast store into
 	};
 

@@ -362,7 +362,13 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 			if( q < E ) dst[lane + 64 * q] = v;
 			else if( lane == 0 ) dst[C] = v;
 			}
-		if( p.nan_out && __any( bad ) && lane == 0 ) atomicOr( p.nan_out, 1 );
+		const bool any_bad = __any( bad );
+		if( p.nan_out && lane == 0 )
+			{
+			// no clearing pass: the flag word is "set" when it equals this launch's epoch (written beside it by chain 0)
+			if( chain == 0 ) p.nan_out[2] = p.nan_epoch;
+			if( any_bad ) p.nan_out[0] = p.nan_epoch;
+			}
 		}
 	}
 
@@ -605,39 +611,62 @@ __global__ __launch_bounds__( 512 ) void k_phase_scan2( SynthParams p )
 	const int lane_bin = threadIdx.x & 31, seg = threadIdx.x >> 5;
 	const int channel = blockIdx.y;
 	const int k = blockIdx.x * 32 + lane_bin;
-	if( threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && p.nan_in && p.nan_flag && *p.nan_in ) atomicOr( p.nan_flag, 1 );
+	if( threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && p.nan_in && p.nan_flag && p.nan_in[0] == p.nan_in[2] && p.nan_in[2] != 0 ) atomicOr( p.nan_flag, 1 );
 	const int n = p.chains_per_channel;
 	const int seg_len = ( n + SEG - 1 ) / SEG;
 	const int i0 = min( seg * seg_len, n ), i1 = min( i0 + seg_len, n );
 	const bool live = k < p.num_bins;
 	double * c = p.carry + int64_t( channel ) * n * p.num_bins + ( live ? k : 0 );
 	auto fold = []( double v ) { return ( __builtin_fabs( v ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( v ) : fold_phase_any( v ); };
+	// a segment of up to 16 chains (every launch with <= 256 chains per channel: the single-round cut) stays in registers
+	// between the two passes; longer segments are read again
+	constexpr int KEEP = 16;
+	const bool keep = seg_len <= KEEP;
+	double held[KEEP];
 	double run = 0.0;
-	for( int i = i0; i < i1; i += 8 )
+	if( keep )
 		{
-		double v[8];
 		#pragma unroll
-		for( int u = 0; u < 8; ++u ) v[u] = ( live && i + u < i1 ) ? c[int64_t( i + u ) * p.num_bins] : 0.0;
+		for( int u = 0; u < KEEP; ++u ) held[u] = ( live && i0 + u < i1 ) ? c[int64_t( i0 + u ) * p.num_bins] : 0.0;
 		#pragma unroll
-		for( int u = 0; u < 8; ++u ) run = fold( run + v[u] );
+		for( int u = 0; u < KEEP; ++u ) run = fold( run + held[u] );           // + 0.0 past the end: fold( x ) of a folded x is x
 		}
+	else
+		for( int i = i0; i < i1; i += 8 )
+			{
+			double v[8];
+			#pragma unroll
+			for( int u = 0; u < 8; ++u ) v[u] = ( live && i + u < i1 ) ? c[int64_t( i + u ) * p.num_bins] : 0.0;
+			#pragma unroll
+			for( int u = 0; u < 8; ++u ) run = fold( run + v[u] );
+			}
 	totals[seg][lane_bin] = run;
 	__syncthreads();
 	double offs = 0.0;                                                         // AudioPV.cpp:111
 	for( int s2 = 0; s2 < seg; ++s2 ) offs = fold( offs + totals[s2][lane_bin] );
 	run = offs;
-	for( int i = i0; i < i1; i += 8 )
+	if( keep )
 		{
-		double v[8];
 		#pragma unroll
-		for( int u = 0; u < 8; ++u ) v[u] = ( live && i + u < i1 ) ? c[int64_t( i + u ) * p.num_bins] : 0.0;
-		#pragma unroll
-		for( int u = 0; u < 8; ++u )
+		for( int u = 0; u < KEEP; ++u )
 			{
-			if( live && i + u < i1 ) c[int64_t( i + u ) * p.num_bins] = run;
-			run = fold( run + v[u] );
+			if( live && i0 + u < i1 ) c[int64_t( i0 + u ) * p.num_bins] = run;
+			run = fold( run + held[u] );
 			}
 		}
+	else
+		for( int i = i0; i < i1; i += 8 )
+			{
+			double v[8];
+			#pragma unroll
+			for( int u = 0; u < 8; ++u ) v[u] = ( live && i + u < i1 ) ? c[int64_t( i + u ) * p.num_bins] : 0.0;
+			#pragma unroll
+			for( int u = 0; u < 8; ++u )
+				{
+				if( live && i + u < i1 ) c[int64_t( i + u ) * p.num_bins] = run;
+				run = fold( run + v[u] );
+				}
+			}
 	}
 
 } // namespace flanhip
