@@ -60,6 +60,7 @@ _SIGS = {
     "flanhip_modify_frequency": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
     "flanhip_modify_frequency_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
     "flanhip_repitch_map_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _vp]),
+    "flanhip_repitch_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _vp]),
     "flanhip_shape_affine": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
     "flanhip_shape_affine_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
     "flanhip_shape_table_dev": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _f32, _i32, _vp, _vp]),
@@ -216,6 +217,17 @@ def _combine_amplitudes(fn, pv, src, amount):
     d_pv, d_src, d_out = DeviceArray(host=pv), DeviceArray(host=src), DeviceArray(pv.nbytes)
     a_ptr, a_const, _keep = _grid_or_const(amount)
     check(fn(_vp(d_pv.ptr), ch, F, bins, _vp(d_src.ptr), sch, sF, sbins, a_ptr, a_const, _vp(d_out.ptr), None))
+    return d_out.to_host(pv.shape)
+
+
+def repitch(pv, sample_rate, factor_grid):
+    """PV::repitch.  factor_grid: float32 [F][bins] (the sampled factor); returns the repitched PV"""
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    g = np.ascontiguousarray(factor_grid, np.float32)
+    assert g.shape == (F, bins)
+    d_pv, d_g, d_out = DeviceArray(host=pv), DeviceArray(host=g), DeviceArray(pv.nbytes)
+    check(lib.flanhip_repitch_dev(_vp(d_pv.ptr), ch, F, bins, sample_rate, _vp(d_g.ptr), _vp(d_out.ptr), None))
     return d_out.to_host(pv.shape)
 
 

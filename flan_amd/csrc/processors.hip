@@ -201,6 +201,9 @@ __global__ __launch_bounds__( 256 ) void k_repitch_lerp( const MFd * in, int64_t
 // any repitch by positive factors) the output intervals [ceil(lo), ceil(hi)) of the pairs are disjoint, each output bin is
 // touched at most once and the pairs of the row are independent: the lanes take them 64 at a time.  A row whose map
 // does run backwards is walked by lane 0 in the reference order.  s_rows: dynamic LDS, bins MF per wave.
+// REPITCH: in_modified is not read but evaluated on the fly, PV::repitch's own rule (PVModify.cpp:289-302: every MF's frequency
+// looked up, lerp, in the row's map); the map row is then staged in LDS behind the output rows (bins floats per wave).
+template<bool REPITCH>
 __global__ __launch_bounds__( 256 ) void k_modify_frequency( const MFd * in, int num_channels, int64_t F, int bins, float sr, float dft,
 	const float * mod, const float * in_modified, MFd * out )
 	{
@@ -212,7 +215,25 @@ __global__ __launch_bounds__( 256 ) void k_modify_frequency( const MFd * in, int
 	const MFd * row = in + idx * bins;
 	MFd * orow = s_rows + size_t( wave ) * bins;
 	const float * mrow = mod + frame * bins;
-	const float * irow = in_modified + idx * bins;
+	const float * irow = REPITCH ? nullptr : in_modified + idx * bins;
+	if constexpr( REPITCH )
+		{
+		float * smap = reinterpret_cast<float*>( s_rows + size_t( blockDim.x >> 6 ) * bins ) + size_t( wave ) * bins;
+		for( int bin = lane; bin < bins; bin += 64 ) smap[bin] = mrow[bin];
+		mrow = smap;
+		wave_sync();
+		}
+	auto modified = [&]( int bin )                                                  // the frequency this MF is moved to
+		{
+		if constexpr( !REPITCH ) return irow[bin];
+		else
+			{
+			const float fbin = fminf( fmaxf( frequency_to_bin( row[bin].f, sr, dft ), 0.0f ), float( bins - 1 ) - 0.0001f );   // :293 std::clamp
+			const int lo = int( floorf( fbin ) );
+			const float r = fbin - float( lo );
+			return mrow[lo] * ( 1.0f - r ) + mrow[lo + 1] * r;                     // :295-301
+			}
+		};
 
 	bool backwards = false;
 	for( int bin = lane; bin < bins; bin += 64 )
@@ -227,8 +248,8 @@ __global__ __launch_bounds__( 256 ) void k_modify_frequency( const MFd * in, int
 		{
 		const float loBin = frequency_to_bin( mrow[bin - 1], sr, dft );             // :218
 		const float hiBin = frequency_to_bin( mrow[bin], sr, dft );                 // :219
-		const MFd loMF = { row[bin - 1].m, irow[bin - 1] };                         // :227
-		const MFd hiMF = { row[bin].m, irow[bin] };                                 // :228
+		const MFd loMF = { row[bin - 1].m, modified( bin - 1 ) };                   // :227
+		const MFd hiMF = { row[bin].m, modified( bin ) };                           // :228
 		const bool forward = hiBin > loBin;                                         // :220
 		const int loR = int( forward ? ceilf( loBin ) : floorf( loBin ) );          // :222
 		const int hiR = int( forward ? ceilf( hiBin ) : floorf( hiBin ) );          // :223
@@ -386,8 +407,26 @@ int flanhip_modify_frequency_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F
 	const size_t per_wave = sizeof( MFd ) * size_t( bins );
 	FLANHIP_REQUIRE( per_wave <= 65536, FLANHIP_ERR_UNSUPPORTED, "more than 8192 bins" );
 	const int waves = int( std::min<size_t>( 4, 65536 / per_wave ) );
-	hipLaunchKernelGGL( k_modify_frequency, dim3( (unsigned) ( ( rows + waves - 1 ) / waves ) ), dim3( 64 * waves ), per_wave * waves, s,
+	hipLaunchKernelGGL( k_modify_frequency<false>, dim3( (unsigned) ( ( rows + waves - 1 ) / waves ) ), dim3( 64 * waves ), per_wave * waves, s,
 		(const MFd*) d_pv, int( ch ), F, bins, sr, float( ( bins - 1 ) * 2 ), d_mod, d_in_modified, (MFd*) d_out );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+int flanhip_repitch_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float * d_factor, flanhip_MF * d_out, void * stream )
+	{
+	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, sr ) ) return rc;
+	FLANHIP_REQUIRE( d_factor, FLANHIP_ERR_INVALID_ARG, "null factor grid" );
+	hipStream_t s = (hipStream_t) stream;
+	const float dft = float( ( bins - 1 ) * 2 );
+	hipLaunchKernelGGL( k_repitch_scan, dim3( (unsigned) ( ( F + 63 ) / 64 ) ), dim3( 256 ), 0, s, d_factor, F, bins, sr, dft );   // PVModify.cpp:278-284
+	FLANHIP_CHECK( hipGetLastError() );
+	const int64_t rows = ch * F;
+	const size_t per_wave = ( sizeof( MFd ) + sizeof( float ) ) * size_t( bins );
+	FLANHIP_REQUIRE( per_wave <= 65536, FLANHIP_ERR_UNSUPPORTED, "more than 5461 bins" );
+	const int waves = int( std::min<size_t>( 4, 65536 / per_wave ) );
+	hipLaunchKernelGGL( k_modify_frequency<true>, dim3( (unsigned) ( ( rows + waves - 1 ) / waves ) ), dim3( 64 * waves ), per_wave * waves, s,
+		(const MFd*) d_pv, int( ch ), F, bins, sr, dft, (const float*) d_factor, (const float*) nullptr, (MFd*) d_out );
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;
 	}

@@ -178,14 +178,14 @@ PV PV::repitch( const Function<TF, float> & factor, const Interpolator & interp 
 	if( is_null() ) return PV();
 	if( !interp.is_linear() ) { std::cerr << "flan: only Interpolator::linear() runs on the device path" << std::endl; return PV(); }
 	auto d_grid = grid_to_device( sample_function_over_domain( factor ) );         // PVModify.cpp:275
-	const size_t n = size_t( get_num_channels() ) * get_num_frames() * get_num_bins();
-	auto d_in = DeviceBlock::allocate( sizeof( float ) * n );
 	const MF * d_pv = device_data();
-	if( !d_grid || !d_in || !d_pv ) return PV();
-	// :278-302 running sum over bins, bin_to_frequency, per-MF lerp -- on the device
-	if( !detail::report( flanhip_repitch_map_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(), get_sample_rate(),
-			static_cast<float*>( d_grid->ptr ), static_cast<float*>( d_in->ptr ), nullptr ), "repitch" ) ) return PV();
-	return modify_frequency_device( *this, *d_grid, *d_in );
+	auto out = DeviceBlock::allocate( sizeof( MF ) * size_t( get_num_channels() ) * get_num_frames() * get_num_bins() );
+	if( !d_grid || !d_pv || !out ) return PV();
+	// :278-302 running sum over bins, bin_to_frequency, per-MF lerp, then modify_frequency_base (:196-257) -- one call, on the device
+	if( !detail::report( flanhip_repitch_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(), get_sample_rate(),
+			static_cast<float*>( d_grid->ptr ), static_cast<flanhip_MF*>( out->ptr ), nullptr ), "repitch" ) ) return PV();
+	if( !detail::report( flanhip_stream_synchronize( nullptr ), "repitch" ) ) return PV();
+	return PVBuffer::adopt_device( get_format(), std::move( out ) );
 	}
 
 PV PV::shape( const Function<MF, MF> & shaper, bool use_shift_alignment ) const

@@ -134,6 +134,11 @@ int flanhip_modify_frequency_dev(const flanhip_MF * d_pv, int64_t num_channels, 
  * d_in_modified float[ch][F][bins] out. */
 int flanhip_repitch_map_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_pv_frames, int num_bins,
                             float sample_rate, float * d_factor, float * d_in_modified, void * stream);
+/* PV::repitch in one piece (PV/PVModify.cpp:273-305): d_factor float[F][bins] is turned into the Hz map in place (the running sum
+ * over bins, :278-284) and modify_frequency_base runs with every MF's target frequency looked up on the fly (:289-302) -- the
+ * same results as flanhip_repitch_map_dev + flanhip_modify_frequency_dev without the intermediate float[ch][F][bins] grid. */
+int flanhip_repitch_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_pv_frames, int num_bins, float sample_rate,
+                        float * d_factor, flanhip_MF * d_out, void * stream);
 
 /* PV::shape (PV/PV.cpp:421-458) for the affine shaper  mf -> { a*m + b, c*f + d }; arbitrary host callables are
  * evaluated by the C++ layer on the host grid and uploaded through flanhip_shape_table_dev. */

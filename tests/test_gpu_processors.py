@@ -215,3 +215,17 @@ def test_stretch_sparse_magnitudes(fa):
     got = fa.modify_time(pv, SR, 256, mod)
     same, rel = report("modify_time/late-start", got, ref)
     assert got.shape == ref.shape and same == 1.0
+
+
+def test_repitch_fused(fa, pv_small):
+    """flanhip_repitch_dev (map scan + on-the-fly lerp + modify_frequency_base in one call) == the oracle's PV::repitch"""
+    ch, F, bins, _ = pv_small.shape
+    for name, g in factor_grids(F, bins):
+        ref = O.repitch(pv_small, SR, g)
+        got = fa.repitch(pv_small, SR, g)
+        same, rel = report("repitch-fused/" + name, got, ref)
+        assert same == 1.0
+    rng = np.random.default_rng(77)
+    g = rng.uniform(-1.0, 3.0, (F, bins)).astype(np.float32)                  # negative factors: the bin map runs backwards
+    same, rel = report("repitch-fused/backwards", fa.repitch(pv_small, SR, g), O.repitch(pv_small, SR, g))
+    assert same == 1.0

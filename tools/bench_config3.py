@@ -46,6 +46,8 @@ stages = {
     "repitch: fill+map": lambda: (fa.check(lib.flanhip_fill_dev(P(grid), F * BINS, 2.0, None)),
                                   fa.check(lib.flanhip_repitch_map_dev(P(pv), ch, F, BINS, SR, P(grid), P(inmod), None))),
     "repitch: modify_frequency": lambda: fa.check(lib.flanhip_modify_frequency_dev(P(pv), ch, F, BINS, SR, P(grid), P(inmod), P(rp), None)),
+    "repitch: fused (fill + scan + modify_frequency)": lambda: (fa.check(lib.flanhip_fill_dev(P(grid), F * BINS, 2.0, None)),
+                                                                fa.check(lib.flanhip_repitch_dev(P(pv), ch, F, BINS, SR, P(grid), P(rp), None))),
     "shape(f+100)": lambda: fa.check(lib.flanhip_shape_affine_dev(P(pv), ch, F, BINS, SR, 1.0, 0.0, 1.0, 100.0, 0, P(sh), None)),
     "shape(f*2, aligned)": lambda: fa.check(lib.flanhip_shape_affine_dev(P(pv), ch, F, BINS, SR, 1.0, 0.0, 2.0, 0.0, 1, P(sh), None)),
 }
