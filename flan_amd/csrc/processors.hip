@@ -146,37 +146,39 @@ __global__ __launch_bounds__( 256 ) void k_stretch_map( float * factor, int64_t 
 	}
 
 // PV::repitch, PVModify.cpp:278-284: inclusive running sum over bins per frame (fp32, sequential), bin_to_frequency.
-// A block owns 64 frames: tiles of 64 frames x 64 bins go through LDS (coalesced rows in and out), 64 threads carry the
-// running sums along their rows, all 256 apply bin_to_frequency.
+// A block owns kRowsPerBlock frames: their rows are staged in LDS with coalesced loads, one thread per row carries the running
+// sum along its row (32 values at a time through registers), all threads apply bin_to_frequency on the way out.
+// s_rows: dynamic LDS, kRowsPerBlock * (bins + 1) floats.
+constexpr int kRowsPerBlock = 8;
 __global__ __launch_bounds__( 256 ) void k_repitch_scan( float * factor, int64_t F, int bins, float sr, float dft )
 	{
-	constexpr int TF = 64;
-	__shared__ float tile[TF][TB + 1];
-	const int64_t frame0 = int64_t( blockIdx.x ) * TF;
-	const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-	float run = 0.0f;                                                               // of frame frame0 + tx (threads with ty == 0)
-	for( int bbase = 0; bbase < bins; bbase += TB )
+	extern __shared__ float s_scan_rows[];
+	const int stride = bins + 1;                                                    // rows start in different banks
+	const int64_t frame0 = int64_t( blockIdx.x ) * kRowsPerBlock;
+	const int rows = int( min( int64_t( kRowsPerBlock ), F - frame0 ) );
+	float * g = factor + frame0 * bins;
+	for( int i = threadIdx.x; i < rows * bins; i += 256 ) s_scan_rows[( i / bins ) * stride + i % bins] = g[i];
+	__syncthreads();
+	if( threadIdx.x < rows )
 		{
-		#pragma unroll
-		for( int r = ty; r < TF; r += 4 )
-			tile[r][tx] = ( frame0 + r < F && bbase + tx < bins ) ? factor[( frame0 + r ) * bins + bbase + tx] : 0.0f;
-		__syncthreads();
-		if( ty == 0 )
+		float * r = s_scan_rows + threadIdx.x * stride;
+		float run = -0.0f;                                                          // -0 + x == x: bin 0 needs no special case
+		int b0 = 0;
+		for( ; b0 + 32 <= bins; b0 += 32 )
 			{
+			float v[32];
 			#pragma unroll
-			for( int c = 0; c < TB; ++c )
-				{
-				run = ( bbase + c == 0 ) ? tile[tx][c] : tile[tx][c] + run;                 // factor[frame][bin] += factor[frame][bin-1]
-				tile[tx][c] = run;
-				}
+			for( int j = 0; j < 32; ++j ) v[j] = r[b0 + j];
+			#pragma unroll
+			for( int j = 0; j < 32; ++j ) { run = v[j] + run; v[j] = run; }         // factor[frame][bin] += factor[frame][bin-1]
+			#pragma unroll
+			for( int j = 0; j < 32; ++j ) r[b0 + j] = v[j];
 			}
-		__syncthreads();
-		#pragma unroll
-		for( int r = ty; r < TF; r += 4 )
-			if( frame0 + r < F && bbase + tx < bins )
-				factor[( frame0 + r ) * bins + bbase + tx] = bin_to_frequency( tile[r][tx], sr, dft );   // :283-284
-		__syncthreads();
+		for( ; b0 < bins; ++b0 ) { run = r[b0] + run; r[b0] = run; }
 		}
+	__syncthreads();
+	for( int i = threadIdx.x; i < rows * bins; i += 256 )
+		g[i] = bin_to_frequency( s_scan_rows[( i / bins ) * stride + i % bins], sr, dft );   // :283-284
 	}
 
 // PVModify.cpp:289-302: every MF's own frequency looked up (lerp) in the per-frame map.
@@ -325,6 +327,16 @@ __global__ __launch_bounds__( 256 ) void k_shape_aligned( const MFd * in, const 
 		}
 	}
 
+static int launch_repitch_scan( float * d_factor, int64_t F, int bins, float sr, float dft, hipStream_t s )
+	{
+	const size_t lds = sizeof( float ) * kRowsPerBlock * size_t( bins + 1 );
+	FLANHIP_REQUIRE( lds <= 160 * 1024, FLANHIP_ERR_UNSUPPORTED, "more than 5119 bins" );
+	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( k_repitch_scan ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+	hipLaunchKernelGGL( k_repitch_scan, dim3( (unsigned) ( ( F + kRowsPerBlock - 1 ) / kRowsPerBlock ) ), dim3( 256 ), lds, s, d_factor, F, bins, sr, dft );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
 } // namespace flanhip
 
 using namespace flanhip;
@@ -419,8 +431,7 @@ int flanhip_repitch_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bin
 	FLANHIP_REQUIRE( d_factor, FLANHIP_ERR_INVALID_ARG, "null factor grid" );
 	hipStream_t s = (hipStream_t) stream;
 	const float dft = float( ( bins - 1 ) * 2 );
-	hipLaunchKernelGGL( k_repitch_scan, dim3( (unsigned) ( ( F + 63 ) / 64 ) ), dim3( 256 ), 0, s, d_factor, F, bins, sr, dft );   // PVModify.cpp:278-284
-	FLANHIP_CHECK( hipGetLastError() );
+	if( int rc = launch_repitch_scan( d_factor, F, bins, sr, dft, s ) ) return rc;                 // PVModify.cpp:278-284
 	const int64_t rows = ch * F;
 	const size_t per_wave = ( sizeof( MFd ) + sizeof( float ) ) * size_t( bins );
 	FLANHIP_REQUIRE( per_wave <= 65536, FLANHIP_ERR_UNSUPPORTED, "more than 5461 bins" );
@@ -462,8 +473,7 @@ int flanhip_repitch_map_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int
 	FLANHIP_REQUIRE( d_factor, FLANHIP_ERR_INVALID_ARG, "null factor grid" );
 	hipStream_t s = (hipStream_t) stream;
 	const float dft = float( ( bins - 1 ) * 2 );
-	hipLaunchKernelGGL( k_repitch_scan, dim3( (unsigned) ( ( F + 63 ) / 64 ) ), dim3( 256 ), 0, s, d_factor, F, bins, sr, dft );
-	FLANHIP_CHECK( hipGetLastError() );
+	if( int rc = launch_repitch_scan( d_factor, F, bins, sr, dft, s ) ) return rc;
 	const int64_t count = ch * F * bins;
 	hipLaunchKernelGGL( k_repitch_lerp, dim3( (unsigned) ( ( count + 255 ) / 256 ) ), dim3( 256 ), 0, s,
 		(const MFd*) d_pv, count, F, bins, sr, dft, d_factor, d_in_modified );
