@@ -108,7 +108,9 @@ constexpr int kMapTB = 16, kMapTF = 896;                                        
 __global__ __launch_bounds__( 256 ) void k_stretch_map( float * factor, int64_t F, int bins, float sr, float hop, float * d_max )
 	{
 	__shared__ __attribute__(( aligned( 16 ) )) float lds[column_scan_lds_floats( kMapTF, kMapTB, 1 )];
-	const int bin = blockIdx.x * kMapTB + threadIdx.x % kMapTB;
+	const int strip = xcd_contiguous_strip( blockIdx.x, ( bins + kMapTB - 1 ) / kMapTB );
+	if( strip < 0 ) return;
+	const int bin = strip * kMapTB + threadIdx.x % kMapTB;
 	const bool valid = bin < bins;
 	float run = -0.0f, mx = -INFINITY;                                             // -0 + x == x for every x: frame 0 needs no special case
 	column_scan<kMapTF, kMapTB, 1, 1, false>( lds, F,
@@ -404,7 +406,7 @@ int flanhip_stretch_map_dev( float * d_factor, int64_t F, int bins, float sr, in
 		const float ninf = -INFINITY;
 		FLANHIP_CHECK( hipMemcpyAsync( d_max, &ninf, sizeof( float ), hipMemcpyHostToDevice, s ) );
 		}
-	hipLaunchKernelGGL( k_stretch_map, dim3( ( bins + kMapTB - 1 ) / kMapTB ), dim3( 256 ), 0, s, d_factor, F, bins, sr, float( hop ), d_max );
+	hipLaunchKernelGGL( k_stretch_map, dim3( xcd_grid( ( bins + kMapTB - 1 ) / kMapTB ) ), dim3( 256 ), 0, s, d_factor, F, bins, sr, float( hop ), d_max );
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;
 	}

@@ -66,6 +66,19 @@ __device__ __forceinline__ int placement_winner( unsigned long long key ) { retu
 // lds: max(NIN,NOUT) * TBc * (TFr+4) floats, 16-byte aligned (column_scan_lds_floats).  Column of a thread: blockIdx.x * TBc + threadIdx.x % TBc.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int TB = 64;
+
+// Workgroups are dealt to the 8 XCDs round-robin (block b runs on XCD b % 8) and each XCD has its own L2.  Column strips that are
+// neighbours in memory share cache lines (a 16-bin strip is 64 B of every 128-B line), so neighbours should meet in ONE L2:
+// XCD x gets the contiguous run of strips [ x * ceil(n/8), ... ).  Returns the strip of this block, or -1 for the few blocks past
+// the end when n is not a multiple of 8 (the grid is rounded up to a multiple of 8).
+__device__ __forceinline__ int xcd_contiguous_strip( int block, int strips )
+	{
+	const int per_xcd = ( strips + 7 ) / 8;
+	const int strip = ( block % 8 ) * per_xcd + block / 8;
+	return ( block / 8 < per_xcd && strip < strips ) ? strip : -1;
+	}
+inline unsigned xcd_grid( int strips ) { return unsigned( ( ( strips + 7 ) / 8 ) * 8 ); }
+
 __host__ __device__ constexpr int column_scan_lds_floats( int TFr, int TBc, int arrays ) { return arrays * TBc * ( TFr + 4 ); }
 
 template<int TFr, int TBc, int NIN, int NOUT, bool REVERSE, class Load, class Step, class Store>

@@ -61,7 +61,9 @@ constexpr int kResTB = 16, kResTF = 128;                                        
 __global__ __launch_bounds__( 256 ) void k_resonate( const MFd * in, int64_t F, int bins, int64_t Fo, const float * decay_t, float decay_t_const, MFd * out )
 	{
 	__shared__ __attribute__(( aligned( 16 ) )) float lds[column_scan_lds_floats( kResTF, kResTB, 3 )];
-	const int bin = blockIdx.x * kResTB + threadIdx.x % kResTB;
+	const int strip = xcd_contiguous_strip( blockIdx.x, ( bins + kResTB - 1 ) / kResTB );
+	if( strip < 0 ) return;
+	const int bin = strip * kResTB + threadIdx.x % kResTB;
 	const bool valid = bin < bins;
 	const MFd * ip = in + int64_t( blockIdx.y ) * F * bins + bin;
 	MFd * op = out + int64_t( blockIdx.y ) * Fo * bins + bin;
@@ -174,7 +176,9 @@ constexpr int kSelTB = 16, kSelTF = 896;                                        
 __global__ __launch_bounds__( 256 ) void k_desample_select( const float * ratio, float ratio_const, int64_t F, int bins, int * L )
 	{
 	__shared__ __attribute__(( aligned( 16 ) )) float lds[column_scan_lds_floats( kSelTF, kSelTB, 1 )];
-	const int bin = blockIdx.x * kSelTB + threadIdx.x % kSelTB;
+	const int strip = xcd_contiguous_strip( blockIdx.x, ( bins + kSelTB - 1 ) / kSelTB );
+	if( strip < 0 ) return;
+	const int bin = strip * kSelTB + threadIdx.x % kSelTB;
 	const bool valid = bin < bins;
 	float accum = 1.0f;                                                               // :461
 	int last = -1;
@@ -195,7 +199,9 @@ __global__ __launch_bounds__( 256 ) void k_desample_select( const float * ratio,
 __global__ __launch_bounds__( 256 ) void k_desample_next( const int * L, int64_t F, int bins, int * R )
 	{
 	__shared__ __attribute__(( aligned( 16 ) )) float lds[column_scan_lds_floats( kSelTF, kSelTB, 1 )];
-	const int bin = blockIdx.x * kSelTB + threadIdx.x % kSelTB;
+	const int strip = xcd_contiguous_strip( blockIdx.x, ( bins + kSelTB - 1 ) / kSelTB );
+	if( strip < 0 ) return;
+	const int bin = strip * kSelTB + threadIdx.x % kSelTB;
 	const bool valid = bin < bins;
 	int next = -1;
 	column_scan<kSelTF, kSelTB, 1, 1, true>( lds, F,
@@ -349,7 +355,7 @@ int flanhip_resonate_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bi
 		const float d = decay_const < 0.0f ? 0.0f : ( 1.0f < decay_const ? 1.0f : decay_const );   // :617
 		decay_t_const = std::pow( d, seconds_per_frame );                             // :631, the platform's powf like the reference
 		}
-	hipLaunchKernelGGL( k_resonate, dim3( ( bins + kResTB - 1 ) / kResTB, (unsigned) ch ), dim3( 256 ), 0, s, (const MFd*) d_pv, F, bins, Fo,
+	hipLaunchKernelGGL( k_resonate, dim3( xcd_grid( ( bins + kResTB - 1 ) / kResTB ), (unsigned) ch ), dim3( 256 ), 0, s, (const MFd*) d_pv, F, bins, Fo,
 		(const float*) d_decay_t, decay_t_const, (MFd*) d_out );
 	FLANHIP_CHECK( hipGetLastError() );
 	if( d_decay_t ) FLANHIP_CHECK( hipFreeAsync( d_decay_t, s ) );
@@ -393,7 +399,7 @@ int flanhip_desample_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bi
 	int * d_lr = nullptr;                                                             // L then R: int[2][F][bins]
 	const size_t grid = size_t( F ) * bins;
 	FLANHIP_CHECK( hipMallocAsync( reinterpret_cast<void**>( &d_lr ), sizeof( int ) * 2 * grid, s ) );
-	const unsigned col_blocks = ( bins + kSelTB - 1 ) / kSelTB;
+	const unsigned col_blocks = xcd_grid( ( bins + kSelTB - 1 ) / kSelTB );
 	hipLaunchKernelGGL( k_desample_select, dim3( col_blocks ), dim3( 256 ), 0, s, d_ratio, ratio_const, F, bins, d_lr );
 	hipLaunchKernelGGL( k_desample_next, dim3( col_blocks ), dim3( 256 ), 0, s, (const int*) d_lr, F, bins, d_lr + grid );
 	hipLaunchKernelGGL( k_desample_apply, dim3( blocks_for( int64_t( grid ), 256 ) ), dim3( 256 ), 0, s, (const MFd*) d_pv, int( ch ), F, bins,
