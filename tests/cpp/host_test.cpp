@@ -181,6 +181,24 @@ static void device_checks()
 		CHECK( a96.resample( 64000.0f ).get_num_frames() == 12800 );
 		}
 
+	// ---- a long chain stays in HBM end to end: nothing below touches get_buffer() until the final check
+		{
+		std::vector<float> x( 2 * 96000 );
+		for( size_t i = 0; i < x.size(); ++i ) x[i] = float( hash32( uint32_t( i ) * 2654435761u ) >> 8 ) * ( 1.0f / 8388608.0f ) - 1.0f;
+		Audio in = Audio::create_from_buffer( std::move( x ), 2, 96000.0f );
+		PV chain = in.resample( 48000.0f ).convert_to_ms_PV( 2048, 512, 2048 );
+		CHECK( chain.is_device_resident() );
+		PV shaped = chain.stretch( 1.5f ).repitch( []( TF tf ){ return tf.t < 0.5f ? 1.0f : 1.25f; } ).retain_n_loudest_partials( 200 )
+			.resonate( 0.25f, 0.6f ).shape( []( MF mf ){ return MF{ mf.m * 0.5f, mf.f }; } );
+		CHECK( !shaped.is_null() && shaped.get_num_channels() == 2 );
+		Audio result = shaped.convert_to_lr_audio();
+		CHECK( !result.is_null() && result.get_sample_rate() == 48000.0f && result.get_num_channels() == 2 );
+		CHECK( result.get_num_frames() == shaped.get_num_frames() * 512 );
+		double energy = 0; bool finite = true;
+		for( float v : result.get_buffer() ) { energy += double( v ) * v; finite = finite && std::isfinite( v ); }
+		CHECK( finite && energy > 1.0 );
+		}
+
 	// ---- error behaviour: null objects, never exceptions
 	CHECK( Audio().convert_to_PV().is_null() );
 	CHECK( a.convert_to_PV( 2048, 512, 3000 ).is_null() );                          // dft not a power of two
