@@ -68,12 +68,13 @@ def main():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="run synthesis' pre-pass as its own kernel instead of inside analysis")
     ap.add_argument("--pcie", action="store_true", help="also time the host-buffer entry points (PCIe inclusive; reported in 'pcie_inclusive', never in 'value')")
+    ap.add_argument("--window", type=int, default=2048, help="2048: the BASELINE metric")
     ap.add_argument("--hop", type=int, default=512, help="512: the BASELINE metric; 128 with --dft 4096 is the reference API's default call")
-    ap.add_argument("--dft", type=int, default=2048, choices=[2048, 4096],
+    ap.add_argument("--dft", type=int, default=2048,
                     help="2048: the primary measurement; 4096: the literal convert_to_PV(2048,512) default of the reference API (SURVEY 8)")
     args = ap.parse_args()
-    global DFT, HOP, BINS, BYTES_ANALYSIS, BYTES_SYNTHESIS, BYTES_ROUNDTRIP
-    DFT, HOP = args.dft, args.hop
+    global DFT, HOP, WINDOW, BINS, BYTES_ANALYSIS, BYTES_SYNTHESIS, BYTES_ROUNDTRIP
+    DFT, HOP, WINDOW = args.dft, args.hop, args.window
     BINS = DFT // 2 + 1
     BYTES_ANALYSIS = BYTES_SYNTHESIS = HOP * 4 + BINS * 8      # 10 248 (dft 2048) / 18 440 (dft 4096)
     BYTES_ROUNDTRIP = BYTES_ANALYSIS + BYTES_SYNTHESIS
@@ -181,7 +182,7 @@ def main():
         # WRITE_SIZE, corrected as profiles/r01_hbm_traffic.json explains); null for any other workload shape
         traffic = None
         try:
-            if ch == 8 and abs(args.seconds - 60.0) < 1e-9 and DFT == 2048 and HOP == 512:
+            if ch == 8 and abs(args.seconds - 60.0) < 1e-9 and DFT == 2048 and HOP == 512 and WINDOW == 2048:
                 with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as fh:
                     traffic = json.load(fh)[kname]["traffic_bytes"]
         except Exception:
@@ -259,8 +260,8 @@ def main():
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%d ch x %.0f s x 48 kHz uniform noise per GPU, convert_to_PV(2048,%d,dft %d) -> convert_to_audio round trip"
-                                   % (ch, args.seconds, HOP, DFT),
+            "config": {"workload": "%d ch x %.0f s x 48 kHz uniform noise per GPU, convert_to_PV(%d,%d,dft %d) -> convert_to_audio round trip"
+                                   % (ch, args.seconds, WINDOW, HOP, DFT),
                        "channels_per_gpu": ch, "pv_frames_per_step_per_gpu": frames_per_step, "parallelism": "channel-shard x%d" % world},
             "roofline": roofline, "cpu_baseline": cpu,
         }

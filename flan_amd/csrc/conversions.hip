@@ -100,10 +100,10 @@ static bool synth_fast_ok( int dft, int W, int hop )
 		&& W % 128 == 0 && hop <= W && !force_generic();
 	}
 
-// Can the analysis of this shape also leave convert_to_audio's pre-pass in the workspace?  Not at dft 4096: its kernels hold 32
+// Can the analysis of this shape also leave convert_to_audio's pre-pass in the workspace?  Not at dft >= 4096: the kernels hold 32+
 // complex points per lane and run one wavefront per SIMD with the AGPRs as spill space; the per-chain sums would need LDS that
 // 4-wave blocks do not leave (185 KB).  Both fused entry points consult this, so the pair then simply runs unfused.
-static bool fused_prepass_supported( int dft ) { return dft != 4096; }
+static bool fused_prepass_supported( int dft ) { return dft < 4096; }
 
 int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft, flanhip_MF * d_out, void * d_fused_ws, hipStream_t s )
 	{

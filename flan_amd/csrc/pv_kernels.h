@@ -87,22 +87,34 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze( AnalyzeParams p )
 	const int dft = 2 * C;
 	const bool use_wrapping = p.analysis_rate < p.sample_rate;                // phase_vocoder.cpp:37
 
-	// per-lane constants: bin frequency (PVBuffer.cpp:443-446), expected phase advance (phase_vocoder.cpp:47), split twiddle
-	float binf[E + 1], expect[E + 1], prev[E + 1];
-	cf w2[E];
+	// per-lane constants: bin frequency (PVBuffer.cpp:443-446), expected phase advance (phase_vocoder.cpp:47), split twiddle.
+	// LEAN (dft >= 4096: 32+ bins per lane): only the previous phases stay in registers; the constants are recomputed /
+	// fetched (L1) per use and the fused pre-pass sums are not kept (conversions.hip: fused_prepass_supported) -- with all of
+	// them resident the dft 8192 kernel spilled 4 KB per lane to scratch.
+	constexpr bool LEAN = LOG2C >= 11;
+	constexpr int EC = LEAN ? 0 : E;                                          // length of the resident constant arrays
+	float binf_r[EC + 1], expect_r[EC + 1], prev[E + 1];
+	cf w2_r[EC + 1];
+	auto bin_of = [&]( int i ) { return ( i < E ) ? lane + 64 * i : C; };
+	auto binf_of = [&]( int i ) { return LEAN ? float( bin_of( i ) ) * p.sample_rate / float( dft ) : binf_r[LEAN ? 0 : i]; };
+	auto expect_of = [&]( int i ) { return LEAN ? binf_of( i ) / p.analysis_rate * FLANHIP_PI2_F : expect_r[LEAN ? 0 : i]; };
+	auto w2_of = [&]( int i ) { return LEAN ? p.tw2[min( bin_of( i ), C )] : w2_r[LEAN ? 0 : i]; };
 	#pragma unroll
 	for( int i = 0; i <= E; ++i )
 		{
-		const int k = ( i < E ) ? lane + 64 * i : C;
-		binf[i] = float( k ) * p.sample_rate / float( dft );
-		expect[i] = binf[i] / p.analysis_rate * FLANHIP_PI2_F;
 		prev[i] = 0.0f;                                                       // AudioPV.cpp:44
-		if( i < E ) w2[i] = p.tw2[min( k, C )];
+		if constexpr( !LEAN )
+			{
+			const int k = bin_of( i );
+			binf_r[i] = float( k ) * p.sample_rate / float( dft );
+			expect_r[i] = binf_r[i] / p.analysis_rate * FLANHIP_PI2_F;
+			if( i < E ) w2_r[i] = p.tw2[min( k, C )];
+			}
 		}
 
-	double sum[E + 1];                                                        // fused round trip: see AnalyzeParams::sums
+	double sum[EC + 1];                                                       // fused round trip: see AnalyzeParams::sums
 	#pragma unroll
-	for( int i = 0; i <= E; ++i ) sum[i] = 0.0;
+	for( int i = 0; i <= EC; ++i ) sum[i] = 0.0;
 	bool bad = false;
 
 	for( int64_t t = ( t0 > 0 ? t0 - 1 : t0 ); t < t1; ++t )
@@ -139,32 +151,33 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze( AnalyzeParams p )
 				const cf zm = buf[PAD( ( C - k ) & ( C - 1 ) )];
 				const float ax = 0.5f * ( zk.x + zm.x ), ay = 0.5f * ( zk.y - zm.y );
 				const float dx = zk.x - zm.x, dy = zk.y + zm.y;
-				const float c = w2[q].x, s = w2[q].y;
+				const cf w2v = w2_of( q );
+				const float c = w2v.x, s = w2v.y;
 				float re = ax + 0.5f * __builtin_fmaf( c, dy, s * dx );
 				float im = ay - 0.5f * __builtin_fmaf( c, dx, -( s * dy ) );
 				if( k == 0 ) { re = z0.x + z0.y; im = 0.0f; }
-				const MF mf = phase_vocode_bin( re, im, prev[q], binf[q], expect[q], p.analysis_rate, use_wrapping );
+				const MF mf = phase_vocode_bin( re, im, prev[q], binf_of( q ), expect_of( q ), p.analysis_rate, use_wrapping );
 				if( emit )
 					{
 					row[k] = mf;
-					sum[q] += double( mf.f / p.analysis_rate * FLANHIP_PI2_F );
+					if constexpr( !LEAN ) sum[q] += double( mf.f / p.analysis_rate * FLANHIP_PI2_F );
 					bad |= isnan( mf.m ) || isnan( mf.f ) || isinf( mf.m ) || isinf( mf.f );
 					}
 				}
 			}
 		if( lane == 0 )
 			{
-			const MF mf = phase_vocode_bin( z0.x - z0.y, 0.0f, prev[E], binf[E], expect[E], p.analysis_rate, use_wrapping );
+			const MF mf = phase_vocode_bin( z0.x - z0.y, 0.0f, prev[E], binf_of( E ), expect_of( E ), p.analysis_rate, use_wrapping );
 			if( emit )
 				{
 				row[C] = mf;
-				sum[E] += double( mf.f / p.analysis_rate * FLANHIP_PI2_F );
+				if constexpr( !LEAN ) sum[E] += double( mf.f / p.analysis_rate * FLANHIP_PI2_F );
 				bad |= isnan( mf.m ) || isnan( mf.f ) || isinf( mf.m ) || isinf( mf.f );
 				}
 			}
 		wave_sync();
 		}
-	if( p.sums )
+	if constexpr( !LEAN ) if( p.sums )
 		{
 		double * dst = p.sums + chain * ( C + 1 );
 		#pragma unroll
