@@ -60,13 +60,16 @@ def cpu_baseline(channels, seconds, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--channels", type=int, default=8, help="channels per GPU")
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="run synthesis' pre-pass as its own kernel instead of inside analysis")
+    ap.add_argument("--preroll-ms", type=float, default=80.0,
+                    help="untimed device warm-up before the W warm-up steps: the same steps run for this long so that the GPU's clocks "
+                         "have settled (measured: a launch takes 0.204 ms on a just-woken MI355X, 0.166 ms after ~40 ms of load); 0 disables")
     ap.add_argument("--pcie", action="store_true", help="also time the host-buffer entry points (PCIe inclusive; reported in 'pcie_inclusive', never in 'value')")
     ap.add_argument("--window", type=int, default=2048, help="2048: the BASELINE metric")
     ap.add_argument("--hop", type=int, default=512, help="512: the BASELINE metric; 128 with --dft 4096 is the reference API's default call")
@@ -136,6 +139,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # device warm-up (not the W warm-up steps of the contract, which follow): a GPU that has been idle needs tens of milliseconds of
+    # load before its clocks settle; without this a short run measures the ramp, not the kernels
+    preroll_steps = 0
+    if args.preroll_ms > 0:
+        t_end = time.perf_counter() + args.preroll_ms * 1e-3
+        while time.perf_counter() < t_end:
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            preroll_steps += 10
     for _ in range(args.warmup):
         step()
     sync_all()
@@ -265,6 +278,7 @@ def main():
                        "channels_per_gpu": ch, "pv_frames_per_step_per_gpu": frames_per_step, "parallelism": "channel-shard x%d" % world},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        line["device_warmup"] = {"preroll_ms": args.preroll_ms, "preroll_steps": preroll_steps}
         line.update(extra)
         print(json.dumps(line), flush=True)
     if distributed:

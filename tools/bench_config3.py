@@ -68,11 +68,16 @@ stages.update({
     "time_extrapolate(2000 frames)": lambda: fa.check(lib.flanhip_time_extrapolate_dev(P(pv), ch, F, BINS, SR, ext_start, ext_end, ext_Fo,
                                                                                          P(samples), P(ext_out), None)),
 })
+# device warm-up: an idle MI355X needs tens of milliseconds of load before its clocks settle (see bench.py --preroll-ms)
+import time
+t_end = time.perf_counter() + 0.1
+while time.perf_counter() < t_end:
+    stages["convert_to_PV"](); stages["shape(f+100)"](); torch.cuda.synchronize()
 res = {}
 for name, fn in stages.items():
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 5
+    reps = 20
     e0.record()
     for _ in range(reps):
         fn()

@@ -42,6 +42,8 @@ void run(int waves_per_simd) {
 }
 
 int main() {
+  // clocks: an idle MI355X needs tens of milliseconds of load before they settle -- spin ~150 ms first
+  { float* d; hipMalloc(&d, sizeof(float) * 256 * 1024); for (int i = 0; i < 60; ++i) k<4, false><<<256, 1024>>>(d, 4000, 1.0001f, 0.5f); hipDeviceSynchronize(); hipFree(d); }
   for (int w : {1, 2, 4}) { run<1, false>(w); run<4, false>(w); run<1, true>(w); run<4, true>(w); }
   return 0;
 }
