@@ -138,8 +138,7 @@ int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int 
 		p.chains_per_channel = lay.chains_per_channel;
 		p.sums = reinterpret_cast<double*>( d_fused_ws );
 		p.nan_out = reinterpret_cast<int*>( reinterpret_cast<char*>( d_fused_ws ) + lay.carry_bytes + lay.head_bytes );
-		static std::atomic<int> epoch{ 0 };
-		p.nan_epoch = ( epoch.fetch_add( 1 ) & 0x7ffffffe ) + 1;          // never 0
+		p.nan_epoch = next_epoch();
 		}
 
 	if( fast )
@@ -206,7 +205,7 @@ static int run_synth_pick( const SynthParams & p, hipStream_t s )
 	}
 
 int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float ar, int W, float * d_out,
-	void * d_ws, int * d_nan, bool presummed, hipStream_t s )
+	void * d_ws, int * d_nan, int presummed, hipStream_t s )
 	{
 	FLANHIP_REQUIRE( d_pv && d_out && d_ws, FLANHIP_ERR_INVALID_ARG, "null buffer" );
 	SynthLayout lay;
@@ -214,7 +213,7 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	if( int rc = require_device() ) return rc;
 	const Plan * plan = nullptr;
 	if( int rc = get_plan( W, lay.dft, &plan ) ) return rc;
-	presummed = presummed && fused_prepass_supported( lay.dft );
+	if( presummed == 1 && !fused_prepass_supported( lay.dft ) ) presummed = 0;   // the analysis of this size did not leave them
 
 	SynthParams p;
 	p.pv = reinterpret_cast<const MF*>( d_pv ); p.out = d_out;
@@ -232,11 +231,12 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	p.ar_div = DivC{ dp.c, dp.rc, dp.exact };
 	p.dump = reinterpret_cast<float*>( reinterpret_cast<char*>( d_ws ) + lay.carry_bytes + lay.head_bytes + 512 );
 	p.nan_in = presummed ? reinterpret_cast<const int*>( reinterpret_cast<char*>( d_ws ) + lay.carry_bytes + lay.head_bytes ) : nullptr;
+	p.skip_words = presummed == 2 ? p.nan_in : nullptr;
 
 	const int64_t chains = int64_t( p.chains_per_channel ) * ch;
 	FLANHIP_REQUIRE( chains < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
 	const int stages = g_synth_stage_mask;
-	if( ( stages & 1 ) && !presummed )
+	if( ( stages & 1 ) && presummed != 1 )
 		{
 		hipLaunchKernelGGL( k_phase_sums2, dim3( (unsigned) chains, (unsigned) ( ( bins + 255 ) / 256 ) ), dim3( 256 ), 0, s, p );
 		FLANHIP_CHECK( hipGetLastError() );
@@ -306,7 +306,13 @@ int flanhip_analyze_dev_fused( const float * d_audio, int64_t ch, int64_t n, flo
 int flanhip_synthesize_dev_fused( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float ar, int W,
 	float * d_out, void * d_ws, int * d_nan, void * stream )
 	{
-	return launch_synthesize( d_pv, ch, F, bins, sr, ar, W, d_out, d_ws, d_nan, true, (hipStream_t) stream );
+	return launch_synthesize( d_pv, ch, F, bins, sr, ar, W, d_out, d_ws, d_nan, 1, (hipStream_t) stream );
+	}
+
+int flanhip_synthesize_dev_fused_checked( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float ar, int W,
+	float * d_out, void * d_ws, int * d_nan, void * stream )
+	{
+	return launch_synthesize( d_pv, ch, F, bins, sr, ar, W, d_out, d_ws, d_nan, 2, (hipStream_t) stream );
 	}
 
 int flanhip_analyze( const float * audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft,

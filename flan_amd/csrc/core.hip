@@ -1,5 +1,6 @@
 // core.hip -- error state, device plumbing, plan cache, shape helpers of the C ABI (include/flanhip.h).
 #include "flanhip_internal.h"
+#include <atomic>
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -155,6 +156,12 @@ int choose_chain_length( int64_t num_channels, int64_t num_frames, int min_len, 
 	while( num_channels * ( ( num_frames + L - 1 ) / L ) > slots && L < num_frames ) ++L;
 	if( L > ( int64_t( 1 ) << 30 ) ) L = int64_t( 1 ) << 30;
 	return int( L );
+	}
+
+int next_epoch()
+	{
+	static std::atomic<int> epoch{ 0 };
+	return ( epoch.fetch_add( 1 ) & 0x7ffffffe ) + 1;                          // never 0
 	}
 
 } // namespace flanhip

@@ -57,8 +57,13 @@ bool force_generic();   // FLANHIP_FORCE_GENERIC=1: never take the tuned dft 204
 // d_fused_ws (optional): a synthesis workspace for the PV being produced; analysis leaves the per-chain phase sums and a NaN flag
 // there so that launch_synthesize( ..., presummed = true ) can skip its pre-pass.
 int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft, flanhip_MF * d_out, void * d_fused_ws, hipStream_t s );
+// presummed: 0 = run the pre-pass; 1 = the workspace holds the chain sums (left by the analysis that produced the PV);
+// 2 = it may hold them (left by modify_time when its time map allowed it): the pre-pass is launched and retires at once if so
 int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float ar, int W, float * d_out,
-	void * d_ws, int * d_nan, bool presummed, hipStream_t s );
+	void * d_ws, int * d_nan, int presummed, hipStream_t s );
+
+// A fresh non-zero number per producer launch: workspace words are "set" when they equal the launch's epoch (no clearing pass).
+int next_epoch();
 
 struct SynthLayout { int hop, dft, L, chains_per_channel, head_len; size_t carry_bytes, head_bytes, total_bytes; };
 int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, SynthLayout * out );

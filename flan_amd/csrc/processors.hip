@@ -9,6 +9,7 @@
 //   k_shape            : lane = element (no alignment) or wavefront = row (shift alignment: the sequential conflict rule is
 //                        resolved through LDS keys, processors_common.h)
 #include "processors_common.h"
+#include "pv_math.h"
 #include <algorithm>
 
 namespace flanhip {
@@ -24,6 +25,7 @@ namespace flanhip {
 // the reference leaves a pair early (:350-351) and, at the two ends of the column, the frames no pair reaches -- no separate
 // clearing pass and no read-modify-write.  Columns whose map does run backwards (flag set by k_time_map_flags) are cleared
 // and then walked by one thread in the reference order.
+// nonmono[bin] = 1 for such columns; nonmono[bins] = 1 if there is any
 __global__ __launch_bounds__( 256 ) void k_time_map_flags( const float * mod, int64_t F, int bins, float sr, float hop, int * nonmono )
 	{
 	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
@@ -32,12 +34,13 @@ __global__ __launch_bounds__( 256 ) void k_time_map_flags( const float * mod, in
 	const int bin = int( idx % bins );
 	const float l = time_to_frame( mod[( frame - 1 ) * bins + bin], sr, hop );
 	const float r = time_to_frame( mod[frame * bins + bin], sr, hop );
-	if( !( r >= l ) ) nonmono[bin] = 1;                                            // backwards, or NaN
+	if( !( r >= l ) ) { nonmono[bin] = 1; nonmono[bins] = 1; }                     // backwards, or NaN
 	}
 
 __global__ __launch_bounds__( 256 ) void k_modify_time( const MFd * in, int num_channels, int64_t F, int bins, float sr, float hop,
-	const float * mod, int64_t Fo, MFd * out, const int * nonmono, int segments, int64_t seg_len )
+	const float * mod, int64_t Fo, MFd * out, const int * nonmono, int segments, int64_t seg_len, int only_if_any )
 	{
+	if( only_if_any && !nonmono[bins] ) return;                                     // k_modify_time_chains does this PV
 	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
 	const int64_t columns = int64_t( num_channels ) * bins;
 	if( idx >= columns * segments ) return;
@@ -99,6 +102,111 @@ __global__ __launch_bounds__( 256 ) void k_modify_time( const MFd * in, int num_
 		lMF = rMF; lFrame = rFrame;
 		}
 	if( !sequential && f1 == F ) clear( min( max( int( ceilf( lFrame ) ), 0 ), Fo32 ), Fo32 );   // beyond the last pair's interval
+	}
+
+// The same algorithm cut by OUTPUT chains, for time maps that never run backwards (every column monotone): one thread owns the
+// output frames [c L, (c+1) L) of one (channel, bin) column, c = a chain of the convert_to_audio that will follow.  It finds the
+// first frame pair reaching into its range by bisection on the monotone map, writes every frame of the range exactly once
+// (values, or the cleared { 0, 0 }) and -- having the chain's frequencies in hand, in frame order -- also leaves that chain's
+// phase-increment sum (k_phase_sums2's result, bit for bit) and the NaN flag in the synthesis workspace.  A frame pair that
+// straddles two chains is evaluated by both owners up to their own frames, so the reference's early exit (:350-351) is seen by both.
+struct TimeChainParams
+	{
+	const MFd * in; const float * mod; MFd * out;
+	int64_t F, Fo;
+	int num_channels, bins, L, chains_per_channel;
+	float sr, hop, analysis_rate;
+	double * sums;            // [ch][chains][bins]
+	int * words;              // workspace tail: [0] NaN flag, [2] epoch, [4] "sums valid" (set iff equal to the epoch)
+	int epoch;
+	const int * nonmono;      // [bins + 1]
+	};
+
+__global__ __launch_bounds__( 256 ) void k_modify_time_chains( TimeChainParams p )
+	{
+	if( p.nonmono[p.bins] )                                                         // some column runs backwards: k_modify_time does this PV
+		{
+		if( blockIdx.x == 0 && threadIdx.x == 0 ) p.words[2] = p.epoch;             // the sums are NOT valid for this epoch
+		return;
+		}
+	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
+	const int64_t per_channel = int64_t( p.chains_per_channel ) * p.bins;
+	const bool live = idx < per_channel * p.num_channels;
+	bool bad = false;
+	if( live )
+		{
+		const int channel = int( idx / per_channel ), chain = int( ( idx % per_channel ) / p.bins ), bin = int( idx % p.bins );
+		const int bins = p.bins;
+		const int Fo32 = int( p.Fo );
+		const int x_lo = chain * p.L, x_hi = min( x_lo + p.L, Fo32 );
+		const MFd * ip = p.in + int64_t( channel ) * p.F * bins + bin;
+		MFd * op = p.out + int64_t( channel ) * p.Fo * bins + bin;
+		const float * mp = p.mod + bin;
+		auto frame_of = [&]( int64_t k ) { return time_to_frame( mp[k * bins], p.sr, p.hop ); };
+		auto pair_end = [&]( int64_t k ) { return min( max( int( ceilf( frame_of( k ) ) ), 0 ), Fo32 ); };   // clamped ceil( r ) of pair ( k-1, k )
+
+		// first pair whose (clamped) end lies beyond x_lo; pair_end is non-decreasing in k
+		int64_t lo = 1, hi = p.F;                                                   // answer in [1, F]; F = none
+		while( lo < hi )
+			{
+			const int64_t mid = ( lo + hi ) >> 1;
+			if( pair_end( mid ) > x_lo ) hi = mid; else lo = mid + 1;
+			}
+		double ph = 0.0;
+		int summed = 0;                                                             // frames of this chain already in ph
+		auto add_frame = [&]( int x, MFd v )                                        // x ascending, every frame of [x_lo, x_hi) exactly once
+			{
+			op[int64_t( x ) * bins] = v;
+			bad |= !( fabsf( v.m ) <= 3.4028235e38f ) || !( fabsf( v.f ) <= 3.4028235e38f );
+			ph += double( v.f / p.analysis_rate * FLANHIP_PI2_F );                  // phase_vocoder.cpp:57 (k_phase_sums2's term)
+			++summed;
+			// k_phase_sums2 keeps its partial sum small after every full group of 8 frames of the chain
+			if( ( summed & 7 ) == 0 && summed <= ( ( x_hi - x_lo ) & ~7 ) && !( fabs( ph ) < 1.0e8 ) ) ph = fold_phase_any( ph );
+			};
+		int cursor = x_lo;
+		if( lo < p.F )
+			{
+			float lFrame = frame_of( lo - 1 );
+			MFd lMF = ip[( lo - 1 ) * bins];
+			for( int64_t k = lo; k < p.F; ++k )                                     // :328
+				{
+				const MFd rMF = ip[k * bins];
+				const float rFrame = frame_of( k );                                 // :331
+				const int xs = min( max( int( ceilf( lFrame ) ), 0 ), Fo32 );       // :334-335, :342 (monotone: forward or empty)
+				const int xe = min( max( int( ceilf( rFrame ) ), 0 ), Fo32 );
+				if( xs >= x_hi ) break;
+				const int a = max( xs, x_lo ), b = min( xe, x_hi );
+				for( ; cursor < a; ++cursor ) add_frame( cursor, MFd{ 0.0f, 0.0f } );   // frames no pair reaches (before the first pair)
+				bool left = false;                                                  // has the reference left this pair (:350-351)?
+				for( int x = xs; x < b; ++x )
+					{
+					MFd v = { 0.0f, 0.0f };
+					if( !left )
+						{
+						const float mix = ( float( x ) - lFrame ) / ( rFrame - lFrame );        // :344
+						const float w0 = ( 1.0f - mix ) * lMF.m;
+						const float w1 = mix * rMF.m;
+						const float totalWeight = w0 + w1;
+						const float weightedFreqSum = w0 * lMF.f + w1 * rMF.f;
+						if( totalWeight == 0.0f ) left = true;
+						else
+							{
+							const MFd o = { 0.0f, 0.0f };                                       // the cleared output MF this pair alone reaches
+							v = MFd{ o.m + totalWeight, ( o.f * o.m + weightedFreqSum ) / ( o.m + totalWeight ) };   // :354-355
+							}
+						}
+					if( x >= a ) { add_frame( x, v ); cursor = x + 1; }
+					}
+				lMF = rMF; lFrame = rFrame;
+				}
+			}
+		for( ; cursor < x_hi; ++cursor ) add_frame( cursor, MFd{ 0.0f, 0.0f } );    // beyond the last pair
+		p.sums[( int64_t( channel ) * p.chains_per_channel + chain ) * bins + bin] =
+			( fabs( ph ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( ph ) : fold_phase_any( ph );
+		}
+	const bool any_bad = __any( bad );
+	if( ( threadIdx.x & 63 ) == 0 && any_bad ) p.words[0] = p.epoch;
+	if( blockIdx.x == 0 && threadIdx.x == 0 ) { p.words[2] = p.epoch; p.words[4] = p.epoch; }
 	}
 
 // PV::stretch, PVModify.cpp:376-382: inclusive running sum over frames per bin in fp32 (sequential order = the
@@ -354,8 +462,8 @@ int flanhip_modify_time_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int
 	FLANHIP_REQUIRE( Fo < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "2^31 output frames or more" );
 	if( F == 1 ) FLANHIP_CHECK( hipMemsetAsync( d_out, 0, sizeof( flanhip_MF ) * size_t( ch ) * Fo * bins, s ) );   // no frame pair: clear_buffer only, PVModify.cpp:317
 	int * d_flags = nullptr;                                                       // per bin: does the time map ever run backwards?
-	FLANHIP_CHECK( hipMallocAsync( reinterpret_cast<void**>( &d_flags ), sizeof( int ) * bins, s ) );
-	FLANHIP_CHECK( hipMemsetAsync( d_flags, 0, sizeof( int ) * bins, s ) );
+	FLANHIP_CHECK( hipMallocAsync( reinterpret_cast<void**>( &d_flags ), sizeof( int ) * ( bins + 1 ), s ) );
+	FLANHIP_CHECK( hipMemsetAsync( d_flags, 0, sizeof( int ) * ( bins + 1 ), s ) );
 	if( F > 1 )
 		{
 		const int64_t pairs = ( F - 1 ) * bins;
@@ -368,7 +476,49 @@ int flanhip_modify_time_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int
 	const int64_t seg_len = std::max<int64_t>( ( F - 1 + segments - 1 ) / segments, 1 );
 	const int64_t threads = columns * segments;
 	hipLaunchKernelGGL( k_modify_time, dim3( (unsigned) ( ( threads + 255 ) / 256 ) ), dim3( 256 ), 0, s,
-		(const MFd*) d_pv, int( ch ), F, bins, sr, float( hop ), d_mod, Fo, (MFd*) d_out, d_flags, segments, seg_len );
+		(const MFd*) d_pv, int( ch ), F, bins, sr, float( hop ), d_mod, Fo, (MFd*) d_out, d_flags, segments, seg_len, 0 );
+	FLANHIP_CHECK( hipGetLastError() );
+	FLANHIP_CHECK( hipFreeAsync( d_flags, s ) );
+	return FLANHIP_OK;
+	}
+
+int flanhip_modify_time_dev_fused( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float analysis_rate, const float * d_mod,
+	int64_t Fo, flanhip_MF * d_out, int window_size, void * d_ws, void * stream )
+	{
+	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, sr ) ) return rc;
+	FLANHIP_REQUIRE( d_mod && d_ws && analysis_rate > 0.0f && Fo > 0, FLANHIP_ERR_INVALID_ARG, "bad map / output length / workspace" );
+	FLANHIP_REQUIRE( Fo < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "2^31 output frames or more" );
+	hipStream_t s = (hipStream_t) stream;
+	SynthLayout lay;                                                               // the chains convert_to_audio will cut the OUTPUT into
+	if( int rc = synth_layout( ch, Fo, bins, sr, analysis_rate, window_size, &lay ) ) return rc;
+	const int hop = lay.hop;                                                       // PVBuffer.cpp:381-384: what PV::modify_time works with
+	int * d_flags = nullptr;                                                       // per bin: does the time map ever run backwards?  [bins]: any
+	FLANHIP_CHECK( hipMallocAsync( reinterpret_cast<void**>( &d_flags ), sizeof( int ) * ( bins + 1 ), s ) );
+	FLANHIP_CHECK( hipMemsetAsync( d_flags, 0, sizeof( int ) * ( bins + 1 ), s ) );
+	if( F > 1 )
+		{
+		const int64_t pairs = ( F - 1 ) * bins;
+		hipLaunchKernelGGL( k_time_map_flags, dim3( (unsigned) ( ( pairs + 255 ) / 256 ) ), dim3( 256 ), 0, s, d_mod, F, bins, sr, float( hop ), d_flags );
+		FLANHIP_CHECK( hipGetLastError() );
+		}
+	TimeChainParams p;
+	p.in = (const MFd*) d_pv; p.mod = d_mod; p.out = (MFd*) d_out;
+	p.F = F; p.Fo = Fo; p.num_channels = int( ch ); p.bins = bins; p.L = lay.L; p.chains_per_channel = lay.chains_per_channel;
+	p.sr = sr; p.hop = float( hop ); p.analysis_rate = analysis_rate;
+	p.sums = reinterpret_cast<double*>( d_ws );
+	p.words = reinterpret_cast<int*>( reinterpret_cast<char*>( d_ws ) + lay.carry_bytes + lay.head_bytes );
+	p.epoch = next_epoch();
+	p.nonmono = d_flags;
+	const int64_t owners = ch * int64_t( lay.chains_per_channel ) * bins;
+	hipLaunchKernelGGL( k_modify_time_chains, dim3( (unsigned) ( ( owners + 255 ) / 256 ) ), dim3( 256 ), 0, s, p );
+	FLANHIP_CHECK( hipGetLastError() );
+	// the general walk, for a PV with a column that runs backwards: retires at once otherwise
+	const int64_t columns = ch * bins;
+	int segments = int( std::min<int64_t>( std::max<int64_t>( ( 256 * 2048 + columns - 1 ) / columns, 1 ), std::max<int64_t>( ( F - 1 ) / 16, 1 ) ) );
+	const int64_t seg_len = std::max<int64_t>( ( F - 1 + segments - 1 ) / segments, 1 );
+	const int64_t threads = columns * segments;
+	hipLaunchKernelGGL( k_modify_time, dim3( (unsigned) ( ( threads + 255 ) / 256 ) ), dim3( 256 ), 0, s,
+		(const MFd*) d_pv, int( ch ), F, bins, sr, float( hop ), d_mod, Fo, (MFd*) d_out, d_flags, segments, seg_len, 1 );
 	FLANHIP_CHECK( hipGetLastError() );
 	FLANHIP_CHECK( hipFreeAsync( d_flags, s ) );
 	return FLANHIP_OK;

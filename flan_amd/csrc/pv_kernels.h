@@ -249,6 +249,7 @@ struct SynthParams
 	DivC ar_div;              // analysis_rate as a divisor (pv_math.h)
 	const int * nan_in;       // optional: the { flag, -, epoch } words left by the producer of the PV (fused round trip): set iff equal
 	float * dump;             // 512 bytes of workspace that out-of-range lanes of k_synthesize_fast store into
+	const int * skip_words;   // optional: the pre-pass retires at once when words [4] and [2] agree (the producer of the PV left the sums)
 	};
 
 // Per-chain sums of the phase increments, folded exactly like the running phase, plus the NaN/Inf scan of

@@ -60,15 +60,17 @@ Audio PV::convert_to_audio( flan_CANCEL_ARG_CPP ) const
 	const size_t ws_bytes = flanhip_synthesize_workspace_bytes( get_num_channels(), get_num_frames(), get_num_bins(), get_sample_rate(), get_analysis_rate(), get_window_size() );
 	if( ws_bytes == 0 ) { detail::report( FLANHIP_ERR_UNSUPPORTED, "convert_to_audio (unsupported dft / window)" ); return Audio::create_null(); }
 	auto out = DeviceBlock::allocate( sizeof( float ) * size_t( af.num_channels ) * af.num_frames );
-	auto fused_ws = take_synthesis_workspace();                 // left by convert_to_PV when this PV came straight from it
+	const bool conditional = synthesis_workspace_is_conditional();
+	auto fused_ws = take_synthesis_workspace();                 // left by convert_to_PV / modify_time when this PV came straight from them
 	const bool fused = fused_ws && fused_ws->bytes >= ws_bytes;
 	auto ws = fused ? fused_ws : DeviceBlock::allocate( ws_bytes );
 	auto flag = DeviceBlock::allocate( sizeof( int ) );
 	if( !out || !ws || !flag ) return Audio::create_null();
 	flanhip_memset( flag->ptr, 0, sizeof( int ), nullptr );
 	if( canceller ) return Audio::create_null();
+	const auto fused_entry = conditional ? flanhip_synthesize_dev_fused_checked : flanhip_synthesize_dev_fused;
 	const int rc = fused
-		? flanhip_synthesize_dev_fused( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(),
+		? fused_entry( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(),
 			get_sample_rate(), get_analysis_rate(), get_window_size(), static_cast<float*>( out->ptr ), ws->ptr, static_cast<int*>( flag->ptr ), nullptr )
 		: flanhip_synthesize_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(),
 			get_sample_rate(), get_analysis_rate(), get_window_size(), static_cast<float*>( out->ptr ), ws->ptr, static_cast<int*>( flag->ptr ), nullptr );
@@ -100,11 +102,21 @@ static PV modify_time_device( const PV & me, std::shared_ptr<DeviceBlock> d_mod,
 	const MF * d_pv = me.device_data();
 	auto out = DeviceBlock::allocate( sizeof( MF ) * size_t( f.num_channels ) * f.num_frames * f.num_bins );
 	if( !d_pv || !out ) return PV();
-	if( !detail::report( flanhip_modify_time_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), me.get_num_channels(), me.get_num_frames(), me.get_num_bins(),
-			me.get_sample_rate(), me.get_hop_size(), static_cast<const float*>( d_mod->ptr ), f.num_frames, static_cast<flanhip_MF*>( out->ptr ), nullptr ),
-			"modify_time" ) ) return PV();
+	// the kernel that writes the output can also leave convert_to_audio's pre-pass in a workspace for the new PV (it can when the
+	// time map never runs backwards -- decided on the device): hand that workspace to the result
+	const size_t ws_bytes = flanhip_synthesize_workspace_bytes( f.num_channels, f.num_frames, f.num_bins, f.sample_rate, f.analysis_rate, f.window_size );
+	auto ws = ws_bytes ? DeviceBlock::allocate( ws_bytes ) : nullptr;
+	const int rc = ws
+		? flanhip_modify_time_dev_fused( reinterpret_cast<const flanhip_MF*>( d_pv ), me.get_num_channels(), me.get_num_frames(), me.get_num_bins(),
+			me.get_sample_rate(), me.get_analysis_rate(), static_cast<const float*>( d_mod->ptr ), f.num_frames, static_cast<flanhip_MF*>( out->ptr ),
+			me.get_window_size(), ws->ptr, nullptr )
+		: flanhip_modify_time_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), me.get_num_channels(), me.get_num_frames(), me.get_num_bins(),
+			me.get_sample_rate(), me.get_hop_size(), static_cast<const float*>( d_mod->ptr ), f.num_frames, static_cast<flanhip_MF*>( out->ptr ), nullptr );
+	if( !detail::report( rc, "modify_time" ) ) return PV();
 	if( !detail::report( flanhip_stream_synchronize( nullptr ), "modify_time" ) ) return PV();
-	return PVBuffer::adopt_device( f, std::move( out ) );
+	PV result = PVBuffer::adopt_device( f, std::move( out ) );
+	if( ws ) result.attach_synthesis_workspace( std::move( ws ), true );
+	return result;
 	}
 
 PV PV::modify_time( const Function<TF, Second> & mod, const Interpolator & interp ) const

@@ -74,8 +74,11 @@ public:
 	static PVBuffer adopt_device( const Format &, std::shared_ptr<detail::DeviceBlock> );
 	/** convert_to_PV leaves convert_to_audio's pre-pass (per-chain phase sums, in a synthesis workspace) next to the data; it is
 	 *  valid while the data is untouched and is consumed by the first convert_to_audio (flanhip_*_fused in flanhip.h). */
-	void attach_synthesis_workspace( std::shared_ptr<detail::DeviceBlock> ws ) const { synth_ws = std::move( ws ); }
+	void attach_synthesis_workspace( std::shared_ptr<detail::DeviceBlock> ws, bool maybe = false ) const { synth_ws = std::move( ws ); synth_ws_maybe = maybe; }
 	std::shared_ptr<detail::DeviceBlock> take_synthesis_workspace() const { auto w = std::move( synth_ws ); synth_ws.reset(); return w; }
+	/** true: the workspace MAY hold the pre-pass (left by modify_time / stretch, whose time map decides on the device):
+	 *  convert_to_audio then goes through flanhip_synthesize_dev_fused_checked */
+	bool synthesis_workspace_is_conditional() const { return synth_ws_maybe; }
 
 protected:
 	size_t count() const { return size_t( format.num_channels ) * size_t( format.num_frames ) * size_t( format.num_bins ); }
@@ -84,6 +87,7 @@ protected:
 	mutable bool host_valid = true;
 	mutable std::shared_ptr<detail::DeviceBlock> dev;
 	mutable std::shared_ptr<detail::DeviceBlock> synth_ws;
+	mutable bool synth_ws_maybe = false;
 	};
 
 } // namespace flan

@@ -99,6 +99,11 @@ int flanhip_analyze_dev_fused(const float * d_audio, int64_t num_channels, int64
 int flanhip_synthesize_dev_fused(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_pv_frames, int num_bins,
                                  float sample_rate, float analysis_rate, int window_size,
                                  float * d_out, void * d_workspace, int * d_nan_flag, void * stream);
+/* ... and for a PV whose workspace MAY hold the pre-pass (flanhip_modify_time_dev_fused): the pre-pass kernel is launched and
+ * retires at once when the sums are there.  The hand-over is consumed: a second call on the same workspace runs the pre-pass. */
+int flanhip_synthesize_dev_fused_checked(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_pv_frames, int num_bins,
+                                         float sample_rate, float analysis_rate, int window_size,
+                                         float * d_out, void * d_workspace, int * d_nan_flag, void * stream);
 
 /* Bench/diagnostic knob: which of the synthesis kernels a call launches (bit 0 k_phase_sums, 1 k_phase_scan,
  * 2 k_synthesize, 3 k_ola_fixup; default all).  Results are only meaningful with all four. */
@@ -117,6 +122,13 @@ int flanhip_modify_time_dev(const flanhip_MF * d_pv, int64_t num_channels, int64
 /* PV::stretch front half (PV/PVModify.cpp:371-382): in-place inclusive prefix sum over frames per bin (fp32, sequential
  * order) then frame_to_time.  d_factor: float[F][bins] factor grid in, seconds out.
  * flanhip_stretch_max_dev also reduces the maximum of the result into *d_max (float). */
+/* modify_time for a PV that goes on to convert_to_audio: d_workspace is a synthesis workspace for the OUTPUT PV
+ * (flanhip_synthesize_workspace_bytes( ch, out_frames, bins, sr, analysis_rate, window_size ); hop = int( sr / analysis_rate )).  When the time map never runs
+ * backwards (every stretch) the kernel that writes the output also leaves convert_to_audio's pre-pass there;
+ * flanhip_synthesize_dev_fused_checked then skips its own.  Same output as flanhip_modify_time_dev in every case. */
+int flanhip_modify_time_dev_fused(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_pv_frames, int num_bins,
+                                  float sample_rate, float analysis_rate, const float * d_mod, int64_t out_frames,
+                                  flanhip_MF * d_out, int window_size, void * d_workspace, void * stream);
 int flanhip_stretch_map_dev(float * d_factor, int64_t num_pv_frames, int num_bins, float sample_rate, int hop,
                             float * d_max, void * stream);
 /* PV::stretch with a constant-valued callable (what `[](TF){ return c; }` samples to): builds the grid on device. */

@@ -229,3 +229,65 @@ def test_repitch_fused(fa, pv_small):
     g = rng.uniform(-1.0, 3.0, (F, bins)).astype(np.float32)                  # negative factors: the bin map runs backwards
     same, rel = report("repitch-fused/backwards", fa.repitch(pv_small, SR, g), O.repitch(pv_small, SR, g))
     assert same == 1.0
+
+
+def _dev_modify_time_and_synth(fa, pv, sr, hop, W, mod, fused):
+    """modify_time + convert_to_audio on the device, with (fused) or without the pre-pass hand-over; returns (stretched PV, audio, flag)"""
+    import ctypes as C
+    lib = fa.lib
+    ch, F, bins, _ = pv.shape
+    Fo = int(lib.flanhip_modify_time_out_frames(mod.ctypes.data_as(C.c_void_p), F, bins, sr, hop))
+    ar = np.float32(sr) / np.float32(hop)
+    d_pv, d_mod = fa.DeviceArray(host=pv), fa.DeviceArray(host=mod)
+    d_st, d_out = fa.DeviceArray(ch * Fo * bins * 8), fa.DeviceArray(ch * Fo * hop * 4)
+    d_ws = fa.DeviceArray(fa.synthesize_workspace_bytes(ch, Fo, bins, sr, float(ar), W))
+    d_flag = fa.DeviceArray(host=np.zeros(1, np.int32))
+    P = lambda d: C.c_void_p(d.ptr)
+    if fused:
+        fa.check(lib.flanhip_modify_time_dev_fused(P(d_pv), ch, F, bins, sr, ar, P(d_mod), Fo, P(d_st), W, P(d_ws), None))
+        fa.check(lib.flanhip_synthesize_dev_fused_checked(P(d_st), ch, Fo, bins, sr, ar, W, P(d_out), P(d_ws), P(d_flag), None))
+    else:
+        fa.check(lib.flanhip_modify_time_dev(P(d_pv), ch, F, bins, sr, hop, P(d_mod), Fo, P(d_st), None))
+        fa.check(lib.flanhip_synthesize_dev(P(d_st), ch, Fo, bins, sr, ar, W, P(d_out), P(d_ws), P(d_flag), None))
+    if fused:                                   # the hand-over is consumed: a second convert_to_audio on the same workspace recomputes its pre-pass
+        first = d_out.to_host((ch, Fo * hop))
+        fa.check(lib.flanhip_synthesize_dev_fused_checked(P(d_st), ch, Fo, bins, sr, ar, W, P(d_out), P(d_ws), P(d_flag), None))
+        again = d_out.to_host((ch, Fo * hop))
+        same = (first.view(np.uint32) == again.view(np.uint32)) | (np.isnan(first) & np.isnan(again))     # NaNs: any payload
+        assert same.all()
+    return d_st.to_host((ch, Fo, bins, 2)), d_out.to_host((ch, Fo * hop)), int(d_flag.to_host((1,), np.int32)[0])
+
+
+@pytest.mark.parametrize("dft,hop", [(1024, 256), (2048, 512), (4096, 512)])
+def test_modify_time_fused_prepass(fa, dft, hop):
+    """flanhip_modify_time_dev_fused leaves convert_to_audio's pre-pass in the workspace: same PV and the very same audio as the plain
+    pair, for monotone maps (hand-over used) and for a map that runs backwards (hand-over refused, pre-pass runs), NaN flag included"""
+    rng = np.random.default_rng(dft + hop)
+    W = min(dft, 2048)
+    x = O.noise(2, 40 * hop + 17, seed=dft)
+    pv = O.analyze(x, SR, W, hop, dft)
+    pv[..., 0] *= rng.uniform(0, 1, pv.shape[:3]) < 0.7                          # zero magnitudes: pairs the reference leaves early
+    ch, F, bins, _ = pv.shape
+    hop_s = hop / SR
+    maps = {
+        "x2": O.stretch_map(np.full((F, bins), 2.0, np.float32), SR, hop),
+        "x0.7": O.stretch_map(np.full((F, bins), 0.7, np.float32), SR, hop),
+        "random-monotone": O.stretch_map(rng.uniform(0.2, 3.0, (F, bins)).astype(np.float32), SR, hop),
+        "late-start": (np.linspace(9.0, 70.0, F, dtype=np.float32)[:, None] * np.ones((1, bins), np.float32) * hop_s).astype(np.float32),
+        "backwards": (rng.uniform(-2, F + 2, (F, bins)) * hop_s).astype(np.float32),
+    }
+    for name, mod in maps.items():
+        st_a, out_a, flag_a = _dev_modify_time_and_synth(fa, pv, SR, hop, W, mod, fused=False)
+        st_b, out_b, flag_b = _dev_modify_time_and_synth(fa, pv, SR, hop, W, mod, fused=True)
+        ref = O.modify_time(pv, SR, hop, mod)
+        assert np.array_equal(st_a.view(np.uint32), ref.view(np.uint32)), name
+        assert np.array_equal(st_b.view(np.uint32), ref.view(np.uint32)), name
+        assert np.array_equal(out_a.view(np.uint32), out_b.view(np.uint32)), name
+        assert flag_a == 0 and flag_b == 0, name
+    bad = pv.copy()
+    bad[1, 7, 11, 1] = np.nan
+    bad[1, 7, 11, 0] = 1.0
+    for name in ("x2", "backwards"):
+        _, _, flag_a = _dev_modify_time_and_synth(fa, bad, SR, hop, W, maps[name], fused=False)
+        _, _, flag_b = _dev_modify_time_and_synth(fa, bad, SR, hop, W, maps[name], fused=True)
+        assert flag_a == 1 and flag_b == 1, name

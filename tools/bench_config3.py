@@ -37,11 +37,17 @@ inmod = torch.empty((ch, F, BINS), dtype=torch.float32, device=dev)
 rp = torch.empty_like(pv)
 sh = torch.empty_like(pv)
 
+grid_t = torch.empty((F, BINS), dtype=torch.float32, device=dev)      # the x2 time map, kept for the hand-over stage (grid is reused below)
+fa.check(lib.flanhip_fill_dev(P(grid_t), F * BINS, 2.0, None))
+fa.check(lib.flanhip_stretch_map_dev(P(grid_t), F, BINS, SR, HOP, P(dmax), None))
 stages = {
     "convert_to_PV": lambda: fa.check(lib.flanhip_analyze_dev(P(audio), ch, n, SR, W, HOP, DFT, P(pv), None)),
     "stretch: fill+map": lambda: (fa.check(lib.flanhip_fill_dev(P(grid), F * BINS, 2.0, None)),
                                   fa.check(lib.flanhip_stretch_map_dev(P(grid), F, BINS, SR, HOP, P(dmax), None))),
     "stretch: modify_time": lambda: fa.check(lib.flanhip_modify_time_dev(P(pv), ch, F, BINS, SR, HOP, P(grid), Fo, P(st), None)),
+    "stretch: modify_time + convert_to_audio, pre-pass handed over": lambda: (
+        fa.check(lib.flanhip_modify_time_dev_fused(P(pv), ch, F, BINS, SR, ar, P(grid_t), Fo, P(st), W, P(ws), None)),
+        fa.check(lib.flanhip_synthesize_dev_fused_checked(P(st), ch, Fo, BINS, SR, ar, W, P(out), P(ws), None, None))),
     "convert_to_audio(stretched)": lambda: fa.check(lib.flanhip_synthesize_dev(P(st), ch, Fo, BINS, SR, ar, W, P(out), P(ws), None, None)),
     "repitch: fill+map": lambda: (fa.check(lib.flanhip_fill_dev(P(grid), F * BINS, 2.0, None)),
                                   fa.check(lib.flanhip_repitch_map_dev(P(pv), ch, F, BINS, SR, P(grid), P(inmod), None))),
@@ -95,6 +101,7 @@ for _ in range(5):
     fn5()
 e1.record(); torch.cuda.synchronize()
 res["config5: resample 2x60s 96k->48k"] = round(e0.elapsed_time(e1) / 5, 4)
-total = res["convert_to_PV"] + res["stretch: fill+map"] + res["stretch: modify_time"] + res["convert_to_audio(stretched)"]
-print(json.dumps({"config": "3: 8ch 60s stretch x2", "input_frames": ch * F, "stage_ms": res, "config3_total_ms": round(total, 3),
+total = res["convert_to_PV"] + res["stretch: fill+map"] + res["stretch: modify_time + convert_to_audio, pre-pass handed over"]
+total_plain = res["convert_to_PV"] + res["stretch: fill+map"] + res["stretch: modify_time"] + res["convert_to_audio(stretched)"]
+print(json.dumps({"config": "3: 8ch 60s stretch x2", "input_frames": ch * F, "stage_ms": res, "config3_total_ms": round(total, 3), "config3_total_ms_without_handover": round(total_plain, 3),
                   "input_frames_per_s": round(ch * F / (total * 1e-3), 1)}))
