@@ -100,11 +100,9 @@ static bool synth_fast_ok( int dft, int W, int hop )
 		&& W % 128 == 0 && hop <= W && !force_generic();
 	}
 
-// Can the analysis of this shape also leave convert_to_audio's pre-pass in the workspace?  Not at dft >= 4096: the kernels hold 32+
-// complex points per lane and run one wavefront per SIMD with the AGPRs as spill space; the per-chain sums would need LDS that
-// 4-wave blocks do not leave (185 KB).  Both fused entry points consult this, so the pair then simply runs unfused.
-static bool fused_prepass_supported( int dft ) { return dft < 4096; }
-
+// flanhip_analyze_dev_fused always leaves convert_to_audio's pre-pass in the workspace.  The tuned kernels and the generic
+// ones up to dft 2048 accumulate the sums while they have every f in a register; the generic kernels for dft >= 4096 keep no
+// such state (64 bins per lane), so there the pre-pass kernel itself is run on the fresh PV on the analysis' behalf.
 int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft, flanhip_MF * d_out, void * d_fused_ws, hipStream_t s )
 	{
 	FLANHIP_REQUIRE( d_audio && d_out, FLANHIP_ERR_INVALID_ARG, "null buffer" );
@@ -115,7 +113,7 @@ int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int 
 	const Plan * plan = nullptr;
 	if( int rc = get_plan( W, dft, &plan ) ) return rc;
 
-	AnalyzeParams p;
+	AnalyzeParams p{};
 	p.audio = d_audio; p.out = reinterpret_cast<MF*>( d_out );
 	p.window = plan->d_window; p.tw = plan->d_tw; p.tw2 = plan->d_tw2;
 	p.n = n; p.F = n / hop + 1;                                   // AudioPV.cpp:17
@@ -129,39 +127,62 @@ int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int 
 	if( int rc = get_div_plan( p.analysis_rate, &dp ) ) return rc;
 	p.ar_div = DivC{ dp.c, dp.rc, dp.exact };
 	p.sums = nullptr; p.nan_out = nullptr; p.nan_epoch = 0;
-	if( d_fused_ws && fused_prepass_supported( dft ) )
+	const bool kernel_sums = fast || dft < 4096;
+	SynthLayout fused_lay{};
+	if( d_fused_ws )
 		{
 		// use the chain layout convert_to_audio will use for this PV and leave its pre-pass results in the workspace
-		SynthLayout lay;
+		SynthLayout & lay = fused_lay;
 		if( int rc = synth_layout( ch, p.F, dft / 2 + 1, sr, p.analysis_rate, W, &lay ) ) return rc;
-		p.L = lay.L;
-		p.chains_per_channel = lay.chains_per_channel;
-		p.sums = reinterpret_cast<double*>( d_fused_ws );
-		p.nan_out = reinterpret_cast<int*>( reinterpret_cast<char*>( d_fused_ws ) + lay.carry_bytes + lay.head_bytes );
 		p.nan_epoch = next_epoch();
+		if( kernel_sums )
+			{
+			p.L = lay.L;
+			p.chains_per_channel = lay.chains_per_channel;
+			p.sums = reinterpret_cast<double*>( d_fused_ws );
+			p.nan_out = reinterpret_cast<int*>( reinterpret_cast<char*>( d_fused_ws ) + lay.carry_bytes + lay.head_bytes );
+			}
 		}
+	auto prepass_on_behalf = [&]() -> int                                         // dft >= 4096 through the generic kernels
+		{
+		if( !d_fused_ws || kernel_sums ) return FLANHIP_OK;
+		SynthParams q{};
+		q.pv = reinterpret_cast<const MF*>( d_out );
+		q.carry = reinterpret_cast<double*>( d_fused_ws );
+		q.F = p.F; q.num_channels = int( ch ); q.num_bins = dft / 2 + 1;
+		q.L = fused_lay.L; q.chains_per_channel = fused_lay.chains_per_channel;
+		q.analysis_rate = p.analysis_rate; q.ar_div = p.ar_div;
+		q.nan_words = reinterpret_cast<int*>( reinterpret_cast<char*>( d_fused_ws ) + fused_lay.carry_bytes + fused_lay.head_bytes );
+		q.nan_epoch = p.nan_epoch;
+		const int64_t chains = int64_t( q.chains_per_channel ) * ch;
+		hipLaunchKernelGGL( k_phase_sums2, dim3( (unsigned) chains, (unsigned) ( ( q.num_bins + 255 ) / 256 ) ), dim3( 256 ), 0, s, q );
+		FLANHIP_CHECK( hipGetLastError() );
+		return FLANHIP_OK;
+		};
 
 	if( fast )
 		{
 		FastTables tb{ plan->d_tw1f, plan->d_tw3f, plan->d_tw2 };
-		if( p.sums ) return run_analyze_fast<10, kAnaWaves10, true>( p, tb, s );
+		if( p.sums ) return dft == 2048 ? run_analyze_fast<10, kAnaWaves10, true>( p, tb, s ) : run_analyze_fast<11, kWaves11, true>( p, tb, s );
 		return dft == 2048 ? run_analyze_fast<10, kAnaWaves10, false>( p, tb, s ) : run_analyze_fast<11, kWaves11, false>( p, tb, s );
 		}
 
+	int rc = FLANHIP_ERR_UNSUPPORTED;
 	switch( ilog2( dft ) - 1 )
 		{
-		case 4:  return run_analyze<4, 4>( p, s );
-		case 5:  return run_analyze<5, 4>( p, s );
-		case 6:  return run_analyze<6, 4>( p, s );
-		case 7:  return run_analyze<7, 4>( p, s );
-		case 8:  return run_analyze<8, 4>( p, s );
-		case 9:  return run_analyze<9, 4>( p, s );
-		case 10: return run_analyze<10, 4>( p, s );
-		case 11: return run_analyze<11, 4>( p, s );
-		case 12: return run_analyze<12, 2>( p, s );
+		case 4:  rc = run_analyze<4, 4>( p, s ); break;
+		case 5:  rc = run_analyze<5, 4>( p, s ); break;
+		case 6:  rc = run_analyze<6, 4>( p, s ); break;
+		case 7:  rc = run_analyze<7, 4>( p, s ); break;
+		case 8:  rc = run_analyze<8, 4>( p, s ); break;
+		case 9:  rc = run_analyze<9, 4>( p, s ); break;
+		case 10: rc = run_analyze<10, 4>( p, s ); break;
+		case 11: rc = run_analyze<11, 4>( p, s ); break;
+		case 12: rc = run_analyze<12, 2>( p, s ); break;
+		default: set_error( "unsupported dft_size %d", dft ); break;
 		}
-	set_error( "unsupported dft_size %d", dft );
-	return FLANHIP_ERR_UNSUPPORTED;
+	if( rc ) return rc;
+	return prepass_on_behalf();
 	}
 
 int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, SynthLayout * o )
@@ -213,9 +234,8 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	if( int rc = require_device() ) return rc;
 	const Plan * plan = nullptr;
 	if( int rc = get_plan( W, lay.dft, &plan ) ) return rc;
-	if( presummed == 1 && !fused_prepass_supported( lay.dft ) ) presummed = 0;   // the analysis of this size did not leave them
 
-	SynthParams p;
+	SynthParams p{};                                               // every optional pointer null unless set below
 	p.pv = reinterpret_cast<const MF*>( d_pv ); p.out = d_out;
 	p.window = plan->d_window; p.tw = plan->d_tw; p.tw2 = plan->d_tw2;
 	p.carry = reinterpret_cast<double*>( d_ws );

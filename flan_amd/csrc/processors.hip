@@ -501,7 +501,7 @@ int flanhip_modify_time_dev_fused( const flanhip_MF * d_pv, int64_t ch, int64_t 
 		hipLaunchKernelGGL( k_time_map_flags, dim3( (unsigned) ( ( pairs + 255 ) / 256 ) ), dim3( 256 ), 0, s, d_mod, F, bins, sr, float( hop ), d_flags );
 		FLANHIP_CHECK( hipGetLastError() );
 		}
-	TimeChainParams p;
+	TimeChainParams p{};
 	p.in = (const MFd*) d_pv; p.mod = d_mod; p.out = (MFd*) d_out;
 	p.F = F; p.Fo = Fo; p.num_channels = int( ch ); p.bins = bins; p.L = lay.L; p.chains_per_channel = lay.chains_per_channel;
 	p.sr = sr; p.hop = float( hop ); p.analysis_rate = analysis_rate;

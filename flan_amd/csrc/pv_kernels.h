@@ -249,6 +249,8 @@ struct SynthParams
 	DivC ar_div;              // analysis_rate as a divisor (pv_math.h)
 	const int * nan_in;       // optional: the { flag, -, epoch } words left by the producer of the PV (fused round trip): set iff equal
 	float * dump;             // 512 bytes of workspace that out-of-range lanes of k_synthesize_fast store into
+	int * nan_words;          // optional (pre-pass run on behalf of a producer): the producer's { flag, -, epoch } words to write
+	int nan_epoch;
 	const int * skip_words;   // optional: the pre-pass retires at once when words [4] and [2] agree (the producer of the PV left the sums)
 	};
 

@@ -43,7 +43,7 @@ template<int LOG2C> struct FastLds
 	static constexpr int BUF = WIN + C;
 	static constexpr int BUF_LEN = C + C / 16 + 1;     // highest slot used is PAD( C ) = C + C/16 (synthesis parks X[C] there)
 	static constexpr int SUM_LEN = ( C / 64 + 1 ) * 64; // per-wave chain sums (doubles), fused analysis only
-	static constexpr size_t bytes( int waves, bool sums = false ) { return size_t( BUF + waves * BUF_LEN + ( sums ? waves * SUM_LEN : 0 ) ) * 8; }
+	static constexpr size_t bytes( int waves, bool sums = false ) { return size_t( BUF + waves * BUF_LEN + ( sums && LOG2C < 11 ? waves * SUM_LEN : 0 ) ) * 8; }   // dft 4096 keeps the sums in registers
 	};
 
 // ---- the three FFT passes on the register array z[E] (natural layout in, natural layout out) -------------------
@@ -254,11 +254,16 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 	// while f is in a register), and a NaN/Inf flag for PVBuffer::is_nan_or_inf
 	// The sums live in LDS (double [E+1][64] per wave): 34 more VGPRs would push the kernel into scratch spills, whose
 	// reloads count as memory operations and defeat the counted waits above.
+	// dft 4096 (one wavefront per SIMD, up to 512 registers with the AGPRs as spill space, and no LDS to spare): the sums are a
+	// register array there.
+	constexpr bool SUMS_REG = SUMS && LOG2C >= 11;
 	double * s_sum = reinterpret_cast<double*>( s + L::BUF + WAVES * L::BUF_LEN ) + wave * L::SUM_LEN + lane;
+	double r_sum[SUMS_REG ? E + 1 : 1];
+	auto sum_of = [&]( int q ) -> double & { if constexpr( SUMS_REG ) return r_sum[q]; else return s_sum[64 * q]; };
 	if constexpr( SUMS )
 		{
 		#pragma unroll
-		for( int q = 0; q <= E; ++q ) s_sum[64 * q] = 0.0;
+		for( int q = 0; q <= E; ++q ) sum_of( q ) = 0.0;
 		}
 	bool bad = false;
 
@@ -327,7 +332,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 				#pragma unroll
 				for( int i = 0; i < NV; ++i )
 					{
-					s_sum[64 * ( q0 + i )] += double( term[i] );
+					sum_of( q0 + i ) += double( term[i] );
 					bad |= !( __builtin_fabsf( m[i] ) <= 3.4028235e38f ) || !( __builtin_fabsf( f[i] ) <= 3.4028235e38f );
 					}
 				}
@@ -345,7 +350,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 			                                                    // number of outstanding memory operations static (counted s_waitcnt, no drain)
 			if constexpr( SUMS )
 				{
-				s_sum[64 * E] += double( div_c( f, p.ar_div ) * FLANHIP_PI2_F );
+				sum_of( E ) += double( div_c( f, p.ar_div ) * FLANHIP_PI2_F );
 				bad |= !( __builtin_fabsf( re ) <= 3.4028235e38f ) || !( __builtin_fabsf( f ) <= 3.4028235e38f );
 				}
 			}
@@ -357,7 +362,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 		#pragma unroll
 		for( int q = 0; q <= E; ++q )
 			{
-			const double sq = s_sum[64 * q];
+			const double sq = sum_of( q );
 			const double v = ( __builtin_fabs( sq ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( sq ) : fold_phase_any( sq );
 			if( q < E ) dst[lane + 64 * q] = v;
 			else if( lane == 0 ) dst[C] = v;
@@ -599,7 +604,13 @@ __global__ __launch_bounds__( 256 ) void k_phase_sums2( SynthParams p )
 			}
 		p.carry[chain * p.num_bins + k] = ( __builtin_fabs( ph ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( ph ) : fold_phase_any( ph );
 		}
-	if( p.nan_flag && __any( bad ) && ( threadIdx.x & 63 ) == 0 ) atomicOr( p.nan_flag, 1 );
+	const bool any_bad = __any( bad );
+	if( p.nan_flag && any_bad && ( threadIdx.x & 63 ) == 0 ) atomicOr( p.nan_flag, 1 );
+	if( p.nan_words )
+		{
+		if( blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 ) p.nan_words[2] = p.nan_epoch;
+		if( any_bad && ( threadIdx.x & 63 ) == 0 ) p.nan_words[0] = p.nan_epoch;
+		}
 	}
 
 // Exclusive scan of the chain sums along each channel, per bin (modular addition is associative, so the scan is cut in
