@@ -122,11 +122,13 @@ struct TimeChainParams
 	const int * nonmono;      // [bins + 1]
 	};
 
+// SUMS = false: the plain flanhip_modify_time_dev uses the same cut (any chain length) without a workspace.
+template<bool SUMS>
 __global__ __launch_bounds__( 256 ) void k_modify_time_chains( TimeChainParams p )
 	{
 	if( p.nonmono[p.bins] )                                                         // some column runs backwards: k_modify_time does this PV
 		{
-		if( blockIdx.x == 0 && threadIdx.x == 0 ) p.words[2] = p.epoch;             // the sums are NOT valid for this epoch
+		if( SUMS && blockIdx.x == 0 && threadIdx.x == 0 ) p.words[2] = p.epoch;     // the sums are NOT valid for this epoch
 		return;
 		}
 	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
@@ -157,11 +159,14 @@ __global__ __launch_bounds__( 256 ) void k_modify_time_chains( TimeChainParams p
 		auto add_frame = [&]( int x, MFd v )                                        // x ascending, every frame of [x_lo, x_hi) exactly once
 			{
 			op[int64_t( x ) * bins] = v;
-			bad |= !( fabsf( v.m ) <= 3.4028235e38f ) || !( fabsf( v.f ) <= 3.4028235e38f );
-			ph += double( v.f / p.analysis_rate * FLANHIP_PI2_F );                  // phase_vocoder.cpp:57 (k_phase_sums2's term)
-			++summed;
-			// k_phase_sums2 keeps its partial sum small after every full group of 8 frames of the chain
-			if( ( summed & 7 ) == 0 && summed <= ( ( x_hi - x_lo ) & ~7 ) && !( fabs( ph ) < 1.0e8 ) ) ph = fold_phase_any( ph );
+			if constexpr( SUMS )
+				{
+				bad |= !( fabsf( v.m ) <= 3.4028235e38f ) || !( fabsf( v.f ) <= 3.4028235e38f );
+				ph += double( v.f / p.analysis_rate * FLANHIP_PI2_F );              // phase_vocoder.cpp:57 (k_phase_sums2's term)
+				++summed;
+				// k_phase_sums2 keeps its partial sum small after every full group of 8 frames of the chain
+				if( ( summed & 7 ) == 0 && summed <= ( ( x_hi - x_lo ) & ~7 ) && !( fabs( ph ) < 1.0e8 ) ) ph = fold_phase_any( ph );
+				}
 			};
 		int cursor = x_lo;
 		if( lo < p.F )
@@ -201,12 +206,16 @@ __global__ __launch_bounds__( 256 ) void k_modify_time_chains( TimeChainParams p
 				}
 			}
 		for( ; cursor < x_hi; ++cursor ) add_frame( cursor, MFd{ 0.0f, 0.0f } );    // beyond the last pair
-		p.sums[( int64_t( channel ) * p.chains_per_channel + chain ) * bins + bin] =
-			( fabs( ph ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( ph ) : fold_phase_any( ph );
+		if constexpr( SUMS )
+			p.sums[( int64_t( channel ) * p.chains_per_channel + chain ) * bins + bin] =
+				( fabs( ph ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( ph ) : fold_phase_any( ph );
 		}
-	const bool any_bad = __any( bad );
-	if( ( threadIdx.x & 63 ) == 0 && any_bad ) p.words[0] = p.epoch;
-	if( blockIdx.x == 0 && threadIdx.x == 0 ) { p.words[2] = p.epoch; p.words[4] = p.epoch; }
+	if constexpr( SUMS )
+		{
+		const bool any_bad = __any( bad );
+		if( ( threadIdx.x & 63 ) == 0 && any_bad ) p.words[0] = p.epoch;
+		if( blockIdx.x == 0 && threadIdx.x == 0 ) { p.words[2] = p.epoch; p.words[4] = p.epoch; }
+		}
 	}
 
 // PV::stretch, PVModify.cpp:376-382: inclusive running sum over frames per bin in fp32 (sequential order = the
@@ -460,7 +469,6 @@ int flanhip_modify_time_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int
 	FLANHIP_REQUIRE( d_mod && hop >= 1 && Fo > 0, FLANHIP_ERR_INVALID_ARG, "bad map / output length" );
 	hipStream_t s = (hipStream_t) stream;
 	FLANHIP_REQUIRE( Fo < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "2^31 output frames or more" );
-	if( F == 1 ) FLANHIP_CHECK( hipMemsetAsync( d_out, 0, sizeof( flanhip_MF ) * size_t( ch ) * Fo * bins, s ) );   // no frame pair: clear_buffer only, PVModify.cpp:317
 	int * d_flags = nullptr;                                                       // per bin: does the time map ever run backwards?
 	FLANHIP_CHECK( hipMallocAsync( reinterpret_cast<void**>( &d_flags ), sizeof( int ) * ( bins + 1 ), s ) );
 	FLANHIP_CHECK( hipMemsetAsync( d_flags, 0, sizeof( int ) * ( bins + 1 ), s ) );
@@ -470,13 +478,22 @@ int flanhip_modify_time_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int
 		hipLaunchKernelGGL( k_time_map_flags, dim3( (unsigned) ( ( pairs + 255 ) / 256 ) ), dim3( 256 ), 0, s, d_mod, F, bins, sr, float( hop ), d_flags );
 		FLANHIP_CHECK( hipGetLastError() );
 		}
+	// monotone maps (every stretch): output chains of 64 frames, one thread per (channel, bin, chain) -- see k_modify_time_chains
+	TimeChainParams cp{};
+	cp.in = (const MFd*) d_pv; cp.mod = d_mod; cp.out = (MFd*) d_out;
+	cp.F = F; cp.Fo = Fo; cp.num_channels = int( ch ); cp.bins = bins; cp.L = 64; cp.chains_per_channel = int( ( Fo + 63 ) / 64 );
+	cp.sr = sr; cp.hop = float( hop ); cp.nonmono = d_flags;
+	const int64_t owners = ch * int64_t( cp.chains_per_channel ) * bins;
+	hipLaunchKernelGGL( k_modify_time_chains<false>, dim3( (unsigned) ( ( owners + 255 ) / 256 ) ), dim3( 256 ), 0, s, cp );
+	FLANHIP_CHECK( hipGetLastError() );
+	// the general walk, for a PV with a column that runs backwards (retires at once otherwise):
 	// enough (column, segment) threads to fill the chip, segments of at least 16 frame pairs
 	const int64_t columns = ch * bins;
 	int segments = int( std::min<int64_t>( std::max<int64_t>( ( 256 * 2048 + columns - 1 ) / columns, 1 ), std::max<int64_t>( ( F - 1 ) / 16, 1 ) ) );
 	const int64_t seg_len = std::max<int64_t>( ( F - 1 + segments - 1 ) / segments, 1 );
 	const int64_t threads = columns * segments;
 	hipLaunchKernelGGL( k_modify_time, dim3( (unsigned) ( ( threads + 255 ) / 256 ) ), dim3( 256 ), 0, s,
-		(const MFd*) d_pv, int( ch ), F, bins, sr, float( hop ), d_mod, Fo, (MFd*) d_out, d_flags, segments, seg_len, 0 );
+		(const MFd*) d_pv, int( ch ), F, bins, sr, float( hop ), d_mod, Fo, (MFd*) d_out, d_flags, segments, seg_len, 1 );
 	FLANHIP_CHECK( hipGetLastError() );
 	FLANHIP_CHECK( hipFreeAsync( d_flags, s ) );
 	return FLANHIP_OK;
@@ -510,7 +527,7 @@ int flanhip_modify_time_dev_fused( const flanhip_MF * d_pv, int64_t ch, int64_t 
 	p.epoch = next_epoch();
 	p.nonmono = d_flags;
 	const int64_t owners = ch * int64_t( lay.chains_per_channel ) * bins;
-	hipLaunchKernelGGL( k_modify_time_chains, dim3( (unsigned) ( ( owners + 255 ) / 256 ) ), dim3( 256 ), 0, s, p );
+	hipLaunchKernelGGL( k_modify_time_chains<true>, dim3( (unsigned) ( ( owners + 255 ) / 256 ) ), dim3( 256 ), 0, s, p );
 	FLANHIP_CHECK( hipGetLastError() );
 	// the general walk, for a PV with a column that runs backwards: retires at once otherwise
 	const int64_t columns = ch * bins;
