@@ -77,6 +77,8 @@ _SIGS = {
     "flanhip_resample_out_frames": (_i64, [_i64, _f32, _f32]),
     "flanhip_resample": (C.c_int, [_vp, _i64, _i64, _f32, _f32, _vp, _vp]),
     "flanhip_resample_dev": (C.c_int, [_vp, _i64, _i64, _f32, _f32, _vp, _vp]),
+    "flanhip_synthesize_prepass_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp]),
+    "flanhip_synthesize_dev_carry": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "flanhip_comm_unique_id": (C.c_int, [C.c_char_p]),
     "flanhip_comm_init": (C.c_int, [C.c_char_p, _i32, _i32, C.POINTER(_vp)]),
     "flanhip_comm_destroy": (C.c_int, [_vp]),

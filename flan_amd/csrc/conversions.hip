@@ -226,9 +226,9 @@ static int run_synth_pick( const SynthParams & p, hipStream_t s )
 	}
 
 int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float ar, int W, float * d_out,
-	void * d_ws, int * d_nan, int presummed, hipStream_t s )
+	void * d_ws, int * d_nan, int presummed, hipStream_t s, const double * d_carry_in, double * d_total_out, bool prepass_only )
 	{
-	FLANHIP_REQUIRE( d_pv && d_out && d_ws, FLANHIP_ERR_INVALID_ARG, "null buffer" );
+	FLANHIP_REQUIRE( d_pv && ( d_out || prepass_only ) && d_ws, FLANHIP_ERR_INVALID_ARG, "null buffer" );
 	SynthLayout lay;
 	if( int rc = synth_layout( ch, F, bins, sr, ar, W, &lay ) ) return rc;
 	if( int rc = require_device() ) return rc;
@@ -250,13 +250,14 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	if( int rc = get_div_plan( ar, &dp ) ) return rc;
 	p.ar_div = DivC{ dp.c, dp.rc, dp.exact };
 	p.dump = reinterpret_cast<float*>( reinterpret_cast<char*>( d_ws ) + lay.carry_bytes + lay.head_bytes + 512 );
-	p.nan_in = presummed ? reinterpret_cast<const int*>( reinterpret_cast<char*>( d_ws ) + lay.carry_bytes + lay.head_bytes ) : nullptr;
+	p.nan_in = ( presummed == 1 || presummed == 2 ) ? reinterpret_cast<const int*>( reinterpret_cast<char*>( d_ws ) + lay.carry_bytes + lay.head_bytes ) : nullptr;
 	p.skip_words = presummed == 2 ? p.nan_in : nullptr;
+	p.carry_in = d_carry_in; p.total_out = d_total_out; p.total_only = prepass_only ? 1 : 0;
 
 	const int64_t chains = int64_t( p.chains_per_channel ) * ch;
 	FLANHIP_REQUIRE( chains < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
-	const int stages = g_synth_stage_mask;
-	if( ( stages & 1 ) && presummed != 1 )
+	const int stages = prepass_only ? 3 : g_synth_stage_mask;
+	if( ( stages & 1 ) && presummed != 1 && presummed != 3 )
 		{
 		hipLaunchKernelGGL( k_phase_sums2, dim3( (unsigned) chains, (unsigned) ( ( bins + 255 ) / 256 ) ), dim3( 256 ), 0, s, p );
 		FLANHIP_CHECK( hipGetLastError() );
@@ -327,6 +328,20 @@ int flanhip_synthesize_dev_fused( const flanhip_MF * d_pv, int64_t ch, int64_t F
 	float * d_out, void * d_ws, int * d_nan, void * stream )
 	{
 	return launch_synthesize( d_pv, ch, F, bins, sr, ar, W, d_out, d_ws, d_nan, 1, (hipStream_t) stream );
+	}
+
+int flanhip_synthesize_prepass_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float ar, int W, void * d_ws,
+	double * d_total_out, int * d_nan, void * stream )
+	{
+	FLANHIP_REQUIRE( d_total_out, FLANHIP_ERR_INVALID_ARG, "null totals" );
+	return launch_synthesize( d_pv, ch, F, bins, sr, ar, W, nullptr, d_ws, d_nan, 0, (hipStream_t) stream, nullptr, d_total_out, true );
+	}
+
+int flanhip_synthesize_dev_carry( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float ar, int W, float * d_out,
+	void * d_ws, const double * d_carry_in, int * d_nan, void * stream )
+	{
+	// the chain sums are in the workspace (flanhip_synthesize_prepass_dev): scan from the carry, synthesise
+	return launch_synthesize( d_pv, ch, F, bins, sr, ar, W, d_out, d_ws, d_nan, 3, (hipStream_t) stream, d_carry_in, nullptr, false );
 	}
 
 int flanhip_synthesize_dev_fused_checked( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float ar, int W,

@@ -58,9 +58,13 @@ bool force_generic();   // FLANHIP_FORCE_GENERIC=1: never take the tuned dft 204
 // there so that launch_synthesize( ..., presummed = true ) can skip its pre-pass.
 int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft, flanhip_MF * d_out, void * d_fused_ws, hipStream_t s );
 // presummed: 0 = run the pre-pass; 1 = the workspace holds the chain sums (left by the analysis that produced the PV);
-// 2 = it may hold them (left by modify_time when its time map allowed it): the pre-pass is launched and retires at once if so
+// 2 = it may hold them (left by modify_time when its time map allowed it): the pre-pass is launched and retires at once if so;
+// 3 = it holds them and no producer words (flanhip_synthesize_prepass_dev)
+// carry_in / total_out (optional, double[ch][bins]): the running phases on entry to / after this PV, for a PV that is a frame
+// range of a longer one (flanhip_synthesize_prepass_dev / flanhip_synthesize_dev_carry); prepass_only: stop after the pre-pass
 int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float ar, int W, float * d_out,
-	void * d_ws, int * d_nan, int presummed, hipStream_t s );
+	void * d_ws, int * d_nan, int presummed, hipStream_t s, const double * d_carry_in = nullptr, double * d_total_out = nullptr,
+	bool prepass_only = false );
 
 // A fresh non-zero number per producer launch: workspace words are "set" when they equal the launch's epoch (no clearing pass).
 int next_epoch();

@@ -249,6 +249,9 @@ struct SynthParams
 	DivC ar_div;              // analysis_rate as a divisor (pv_math.h)
 	const int * nan_in;       // optional: the { flag, -, epoch } words left by the producer of the PV (fused round trip): set iff equal
 	float * dump;             // 512 bytes of workspace that out-of-range lanes of k_synthesize_fast store into
+	const double * carry_in;  // optional [ch][bins]: the running phase on entry to frame 0 of this PV (a frame range of a longer one)
+	double * total_out;       // optional [ch][bins]: the running phase after the last frame
+	int total_only;           // k_phase_scan2 leaves the chain sums untouched (only total_out is produced)
 	int * nan_words;          // optional (pre-pass run on behalf of a producer): the producer's { flag, -, epoch } words to write
 	int nan_epoch;
 	const int * skip_words;   // optional: the pre-pass retires at once when words [4] and [2] agree (the producer of the PV left the sums)

@@ -659,9 +659,14 @@ __global__ __launch_bounds__( 512 ) void k_phase_scan2( SynthParams p )
 			}
 	totals[seg][lane_bin] = run;
 	__syncthreads();
-	double offs = 0.0;                                                         // AudioPV.cpp:111
+	double offs = ( p.carry_in && live ) ? p.carry_in[int64_t( channel ) * p.num_bins + k] : 0.0;   // AudioPV.cpp:111 (0 for a whole PV)
 	for( int s2 = 0; s2 < seg; ++s2 ) offs = fold( offs + totals[s2][lane_bin] );
 	run = offs;
+	if( p.total_only )
+		{
+		if( p.total_out && live && seg == SEG - 1 ) p.total_out[int64_t( channel ) * p.num_bins + k] = fold( offs + totals[seg][lane_bin] );
+		return;
+		}
 	if( keep )
 		{
 		#pragma unroll
@@ -684,6 +689,7 @@ __global__ __launch_bounds__( 512 ) void k_phase_scan2( SynthParams p )
 				run = fold( run + v[u] );
 				}
 			}
+	if( p.total_out && live && seg == SEG - 1 ) p.total_out[int64_t( channel ) * p.num_bins + k] = run;   // the running phase after the last chain
 	}
 
 } // namespace flanhip

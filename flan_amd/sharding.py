@@ -40,3 +40,84 @@ def gather_output_uneven(dist, local_out, channel_counts):
         dist.broadcast(buf, src=r)
         parts.append(buf)
     return torch.cat(parts, dim=0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Frame-range sharding (secondary axis): few channels, long signals.  Rank r owns the PV frames [fb, fe) of EVERY
+# channel.  Pure geometry + exchange logic here; the device calls are flanhip_analyze_dev, flanhip_synthesize_prepass_dev and
+# flanhip_synthesize_dev_carry (include/flanhip.h).
+# ---------------------------------------------------------------------------------------------------------------
+
+PI2 = 6.2831854820251465          # the reference's float constant pi2 (defines.h:44-45), as the double the device folds by
+
+
+def frame_ranges(total_frames, world_size):
+    """Contiguous frame ranges [fb, fe) per rank, the first (total % world) ranks one frame longer."""
+    return [shard_channels(total_frames, world_size, r) for r in range(world_size)]
+
+
+def pad_frames(window, hop):
+    """silent frames on either side of a range so that every sample its frames reach lies inside the local output"""
+    return -(-(window // 2) // hop)
+
+
+def analysis_slice(n, hop, window, fb, fe, total_frames):
+    """Which samples rank needs to analyse frames [fb, fe) on its own, and where they land in the local PV.
+
+    Frame t reads samples [hop t - W/2, hop t + W/2) and the phases of frame t - 1.  The slice starts a few frames early so that
+    local frame (fb - 1 - g0) has its whole window inside it: its phases are then right, and every frame after it is right in
+    both m and f.  Returns (s0, s1, j0): analyse x[:, s0:s1] as a signal of its own; rows [j0, j0 + fe - fb) of the result are
+    the frames [fb, fe) of the whole signal, bit for bit."""
+    q = pad_frames(window, hop)
+    g0 = max(fb - 1 - q, 0)
+    s0 = hop * g0
+    s1 = n if fe >= total_frames else min(n, hop * (fe - 1) + window)
+    return s0, s1, fb - g0
+
+
+def fold_carry(totals):
+    """The running phase on entry to each rank from the per-rank totals (arrays [ch][bins], float64), folded like
+    phase_vocoder.cpp:59.  Returns one array per rank; rank 0 gets zeros."""
+    import math
+    import numpy as np
+    fold = np.vectorize(lambda v: math.fmod(v, PI2) if v > PI2 else v, otypes=[np.float64])
+    carries, run = [], np.zeros_like(totals[0], dtype=np.float64)
+    for t in totals:
+        carries.append(run.copy())
+        run = fold(run + np.asarray(t, np.float64))
+    return carries
+
+
+def place_local_output(global_out, local_out, fb, hop, pad):
+    """Add a rank's local synthesis output (frames padded by `pad` silent frames on either side, so it starts at global sample
+    hop (fb - pad)) into the job's output [ch][F hop]; what falls outside is dropped, like the reference drops it."""
+    start = hop * (fb - pad)
+    length = local_out.shape[1]
+    lo, hi = max(start, 0), min(start + length, global_out.shape[1])
+    if hi > lo:
+        global_out[:, lo:hi] += local_out[:, lo - start:hi - start]
+    return global_out
+
+
+def exchange_overlaps(dist, local_out, rank, world_size, hop, pad):
+    """Multi-process form of place_local_output: neighbours swap the 2 pad hop samples around their common boundary and add what
+    they receive; returns this rank's own samples [pad hop, len - pad hop) completed.  local_out: tensor [ch][(rows + 2 pad) hop]."""
+    import torch
+    z = pad * hop
+    own = local_out[:, z:local_out.shape[1] - z].clone()
+    reqs, recv_left, recv_right = [], None, None
+    if rank > 0:                                                   # my left padding zone belongs to rank - 1's last samples
+        recv_left = torch.empty((local_out.shape[0], z), dtype=local_out.dtype, device=local_out.device)
+        reqs.append(dist.isend(local_out[:, :z].contiguous(), dst=rank - 1))
+        reqs.append(dist.irecv(recv_left, src=rank - 1))
+    if rank < world_size - 1:
+        recv_right = torch.empty((local_out.shape[0], z), dtype=local_out.dtype, device=local_out.device)
+        reqs.append(dist.isend(local_out[:, local_out.shape[1] - z:].contiguous(), dst=rank + 1))
+        reqs.append(dist.irecv(recv_right, src=rank + 1))
+    for r in reqs:
+        r.wait()
+    if recv_left is not None:                                      # rank - 1's right padding zone = my first z samples
+        w = min(z, own.shape[1]); own[:, :w] += recv_left[:, :w]
+    if recv_right is not None:                                     # rank + 1's left padding zone = my last z samples
+        w = min(z, own.shape[1]); own[:, own.shape[1] - w:] += recv_right[:, z - w:]
+    return own

@@ -230,6 +230,21 @@ int flanhip_resample(const float * in, int64_t num_channels, int64_t num_frames,
 int flanhip_resample_dev(const float * d_in, int64_t num_channels, int64_t num_frames, float src_rate, float dst_rate,
                          float * d_out, void * stream);
 
+/* ---- a PV that is a FRAME RANGE of a longer one (few channels, long signals: frame ranges instead of channels shard across
+ * GPUs).  Analysis needs nothing new (a range of frames depends only on the samples under its windows and on the
+ * frame before it).  Synthesis integrates the phase over ALL earlier frames, so it runs in two steps with one small exchange
+ * between them:  (1) every rank: flanhip_synthesize_prepass_dev -> d_total_out[ch][bins], the phase its own frames add up to
+ * (mod pi2), the chain sums stay in the workspace;  (2) the ranks exchange the totals; rank r folds the totals of ranks < r into
+ * d_carry_in and calls flanhip_synthesize_dev_carry.  Samples within window/2 of a range boundary receive contributions from
+ * both neighbours: flan_amd/sharding.py pads each range with silent frames so that they land inside the local output, and adds
+ * the overlaps.  NaN flag as in flanhip_synthesize_dev (step 1 scans the data). ------------------------------------------------- */
+int flanhip_synthesize_prepass_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_pv_frames, int num_bins,
+                                   float sample_rate, float analysis_rate, int window_size, void * d_workspace,
+                                   double * d_total_out, int * d_nan_flag, void * stream);
+int flanhip_synthesize_dev_carry(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_pv_frames, int num_bins,
+                                 float sample_rate, float analysis_rate, int window_size, float * d_out, void * d_workspace,
+                                 const double * d_carry_in, int * d_nan_flag, void * stream);
+
 /* ---- multi-GPU: reassembling the channel shards of the output.  One process per GPU; channels shard with no
  * exchange during compute; the output step is ONE in-place all-gather over RCCL / xGMI.  RCCL is bound at run time (dlopen):
  * without librccl.so these four return FLANHIP_ERR_UNSUPPORTED and everything else still works. ------------------------- */

@@ -73,3 +73,62 @@ def test_shard_ranges():
             assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in ranges]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# frame-range sharding (flan_amd/sharding.py): geometry against the oracle, the overlap exchange over gloo
+# ---------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("W,hop,dft,n,world", [(1024, 256, 1024, 30000, 3), (512, 128, 512, 9000, 4), (1024, 300, 1024, 20011, 2)])
+def test_frame_range_analysis_slices_match_the_whole(W, hop, dft, n, world):
+    """analysis_slice: a rank that analyses only ITS samples gets its frames of the whole PV, bit for bit (checked on the oracle)"""
+    import oracle_lib as O
+    from flan_amd import sharding as S
+    x = O.noise(2, n, seed=W + hop)
+    full = O.analyze(x, 48000.0, W, hop, dft)
+    F = full.shape[1]
+    for fb, fe in S.frame_ranges(F, world):
+        s0, s1, j0 = S.analysis_slice(n, hop, W, fb, fe, F)
+        assert 0 <= s0 < s1 <= n
+        local = O.analyze(np.ascontiguousarray(x[:, s0:s1]), 48000.0, W, hop, dft)
+        piece = local[:, j0:j0 + (fe - fb)]
+        assert np.array_equal(piece.view(np.uint32), full[:, fb:fe].view(np.uint32)), (fb, fe)
+
+
+def test_fold_carry_matches_sequential_fold():
+    from flan_amd import sharding as S
+    import math
+    rng = np.random.default_rng(0)
+    totals = [rng.uniform(0, S.PI2, (2, 17)) for _ in range(5)]
+    carries = S.fold_carry(totals)
+    run = np.zeros((2, 17))
+    for t, c in zip(totals, carries):
+        assert np.array_equal(c, run)
+        run = np.vectorize(lambda v: math.fmod(v, S.PI2) if v > S.PI2 else v)(run + t)
+    assert (np.array(carries) <= S.PI2 + 1e-12).all()
+
+
+def _overlap_worker(rank, world, port, result_dir):
+    from flan_amd import sharding as S
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    hop, W, F, ch = 64, 256, 50, 2
+    pad = S.pad_frames(W, hop)
+    ranges = S.frame_ranges(F, world)
+    rng = np.random.default_rng(77)                                   # every rank draws every rank's local output: same numbers everywhere
+    locals_ = [rng.uniform(-1, 1, (ch, (fe - fb + 2 * pad) * hop)).astype(np.float32) for fb, fe in ranges]
+    expect = np.zeros((ch, F * hop), np.float32)
+    for (fb, fe), lo in zip(ranges, locals_):
+        S.place_local_output(expect, lo, fb, hop, pad)
+    fb, fe = ranges[rank]
+    own = S.exchange_overlaps(dist, torch.from_numpy(locals_[rank].copy()), rank, world, hop, pad).numpy()
+    # two contributions per sample at most, so the sum is the same in either order: exact
+    assert np.array_equal(own, expect[:, hop * fb:hop * fe]), rank
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_frame_range_overlap_exchange_gloo(tmp_path, world):
+    mp.spawn(_overlap_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
