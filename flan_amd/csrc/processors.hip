@@ -85,9 +85,14 @@ __global__ __launch_bounds__( 256 ) void k_modify_time( const MFd * in, int num_
 			clear( x, x1 );                                                         // frames the pair left untouched
 			}
 		else
-			for( int x = start_frame; x != end_frame; forward ? ++x : --x )         // :340
+			{
+			// :340-342 walks x from start_frame to end_frame and skips the frames outside [0, Fo) before computing anything: the
+			// same frames, in the same order, without spinning through up to 2^31 skipped ones when a map value is huge
+			const int step = forward ? 1 : -1;
+			const int x_first = forward ? max( start_frame, 0 ) : min( start_frame, Fo32 - 1 );
+			const int x_stop  = forward ? min( end_frame, Fo32 ) : max( end_frame, -1 );
+			for( int x = x_first; forward ? x < x_stop : x > x_stop; x += step )
 				{
-				if( x < 0 || Fo <= x ) continue;                                    // :342
 				const float mix = ( float( x ) - lFrame ) / ( rFrame - lFrame );    // :344
 				const float w0 = ( 1.0f - mix ) * lMF.m;
 				const float w1 = mix * rMF.m;
@@ -99,6 +104,7 @@ __global__ __launch_bounds__( 256 ) void k_modify_time( const MFd * in, int num_
 				o.m += totalWeight;                                                 // :355
 				op[int64_t( x ) * bins] = o;
 				}
+			}
 		lMF = rMF; lFrame = rFrame;
 		}
 	if( !sequential && f1 == F ) clear( min( max( int( ceilf( lFrame ) ), 0 ), Fo32 ), Fo32 );   // beyond the last pair's interval

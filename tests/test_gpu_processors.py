@@ -291,3 +291,26 @@ def test_modify_time_fused_prepass(fa, dft, hop):
         _, _, flag_a = _dev_modify_time_and_synth(fa, bad, SR, hop, W, maps[name], fused=False)
         _, _, flag_b = _dev_modify_time_and_synth(fa, bad, SR, hop, W, maps[name], fused=True)
         assert flag_a == 1 and flag_b == 1, name
+
+
+def test_modify_time_edge_shapes(fa):
+    """one-frame PVs, one-frame outputs, a constant map (every frame pair empty), outputs shorter than a chain"""
+    rng = np.random.default_rng(41)
+    hop = 256
+    hop_s = hop / SR
+    cases = []
+    pv1 = rng.uniform(0, 1, (2, 1, 65, 2)).astype(np.float32)                  # a single input frame: no pair at all
+    cases.append(("one-frame-in", pv1, np.full((1, 65), 7.3 * hop_s, np.float32)))
+    pv = rng.uniform(0, 1, (2, 30, 65, 2)).astype(np.float32)
+    cases.append(("one-frame-out", pv, np.linspace(0, 0.9 * hop_s, 30, dtype=np.float32)[:, None] * np.ones((1, 65), np.float32)))
+    cases.append(("constant-map", pv, np.full((30, 65), 12.0 * hop_s, np.float32)))
+    cases.append(("short-output", pv, np.linspace(0, 9.5 * hop_s, 30, dtype=np.float32)[:, None] * np.ones((1, 65), np.float32)))
+    # (a NaN in the map is not a test case: the reference's own frame loop then walks ~2^31 frames, PVModify.cpp:334-340)
+    for name, p, mod in cases:
+        mod = np.ascontiguousarray(mod, np.float32)
+        ref = O.modify_time(p, SR, hop, mod)
+        got = fa.modify_time(p, SR, hop, mod)
+        assert got.shape == ref.shape, name
+        if ref.size:
+            same, rel = report("modify_time/" + name, got, ref)
+            assert same == 1.0, name
