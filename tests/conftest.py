@@ -9,6 +9,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built artefacts (they are git-ignored): build them once (hipcc cross-compiles without a GPU)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "flan_amd", "libflanhip.so")) or not os.path.exists(os.path.join(root, "oracle", "liboracle.so")):
+        sys.path.insert(0, root)
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 def _gpu_available():
