@@ -109,3 +109,35 @@ def test_full_size_properties(name, ch, seconds, monkeypatch):
         monkeypatch.delenv("FLANHIP_CHAIN_LEN")
         torch.cuda.synchronize()
         assert bool(torch.equal(out_c.view(torch.int32), out2[c:c + 1].view(torch.int32)))
+
+
+def test_repeated_runs_are_bit_identical():
+    """the same buffers through the fused and the unfused round trip 40 times each: every PV and every output bit-identical to the
+    first (no race between chains, no dependence on what an earlier step left in the workspace)"""
+    import torch
+    import flan_amd as fa
+    dev = torch.device("cuda", 0)
+    ch, n = 8, 20 * 48000
+    F = int(fa.lib.flanhip_num_pv_frames(n, HOP))
+    x = torch.empty((ch, n), dtype=torch.float32, device=dev)
+    fa.check(fa.lib.flanhip_noise_dev(_p(x), ch, n, 99, None))
+    ws = torch.empty(fa.synthesize_workspace_bytes(ch, F, BINS, SR, AR, W), dtype=torch.uint8, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    first = None
+    for fused in (True, False):
+        for i in range(40):
+            pv = torch.empty((ch, F, BINS, 2), dtype=torch.float32, device=dev)
+            out = torch.empty((ch, F * HOP), dtype=torch.float32, device=dev)
+            if fused:
+                fa.analyze_dev_fused(x, ch, n, SR, W, HOP, DFT, pv, ws)
+                fa.synthesize_dev_fused(pv, ch, F, BINS, SR, AR, W, out, ws, flag)
+            else:
+                fa.analyze_dev(x, ch, n, SR, W, HOP, DFT, pv)
+                fa.synthesize_dev(pv, ch, F, BINS, SR, AR, W, out, ws, flag)
+            torch.cuda.synchronize()
+            if first is None:
+                first = (pv.clone(), out.clone())
+            else:
+                assert bool(torch.equal(pv.view(torch.int32), first[0].view(torch.int32))), (fused, i)
+                assert bool(torch.equal(out.view(torch.int32), first[1].view(torch.int32))), (fused, i)
+    assert int(flag.item()) == 0
