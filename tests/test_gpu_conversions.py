@@ -282,3 +282,21 @@ def test_random_shapes(fa, ch, n, W, hop, dft):
     assert rel_m <= 1e-5
     assert wrms_f <= 2e-3 * max(sr / dft / 23.4, 1.0)
     assert rms <= 1e-5 * max(scale, 1.0)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3])
+def test_degenerate_lengths(fa, n):
+    """empty and near-empty signals: one frame of (almost) silence through every dft class, like the reference would produce"""
+    sr = 48000.0
+    for (W, hop, dft) in ((2048, 512, 2048), (2048, 128, 4096), (256, 64, 256)):
+        x = O.noise(2, max(n, 1), seed=5)[:, :n].copy()
+        ref = O.analyze(x, sr, W, hop, dft)
+        got = fa.analyze(x, sr, W, hop, dft)
+        assert got.shape == ref.shape == (2, 1, dft // 2 + 1, 2)
+        m_r = ref[..., 0].astype(np.float64)
+        assert np.abs(got[..., 0] - m_r).max() <= 1e-6 * max(m_r.max(), 1e-30) + 1e-12
+        ar = np.float32(sr) / np.float32(hop)
+        out_ref, _ = O.synthesize(ref, sr, ar, W)
+        out_got, flag = fa.synthesize(ref, sr, ar, W)
+        assert out_got.shape == out_ref.shape and flag == 0
+        assert np.abs(out_got - out_ref).max() <= 1e-6
