@@ -8,8 +8,8 @@
 //   k_resonate          : block = 16 bins of one channel; (frame x bin) tiles go through LDS so that all 256 threads move memory
 //                         (the next tile is in flight during the scan) while 16 threads carry the recurrence down the tile in
 //                         registers (column_scan, processors_common.h)
-//   k_desample_select   : same skeleton for the selection accumulator (channel independent), forward then backward over frames:
-//                         per (frame, bin) the selected frames on either side; k_desample_apply is then elementwise
+//   k_desample_select   : same skeleton for the selection accumulator (channel independent): per (frame, bin) the last selected
+//                         frame; k_desample_apply finds the next one by bisection and interpolates every channel
 //   k_n_loudest         : wavefront per (channel, frame) row: the n-th largest |m| by a 31-step bisection on the bit pattern
 //                         (ballot + popcount, keys in LDS), ties by ascending bin
 //   k_time_extrapolate  : wavefront per output row, placement conflicts through LDS keys (processors_common.h)
@@ -195,35 +195,28 @@ __global__ __launch_bounds__( 256 ) void k_desample_select( const float * ratio,
 		[&]( int64_t f, float ( &v )[1] ) { if( valid ) L[f * bins + bin] = __float_as_int( v[0] ); } );
 	}
 
-// backward: R[frame][bin] = the first selected frame > frame (-1: none).  Frame t is selected iff L[t] == t.
-__global__ __launch_bounds__( 256 ) void k_desample_next( const int * L, int64_t F, int bins, int * R )
-	{
-	__shared__ __attribute__(( aligned( 16 ) )) float lds[column_scan_lds_floats( kSelTF, kSelTB, 1 )];
-	const int strip = xcd_contiguous_strip( blockIdx.x, ( bins + kSelTB - 1 ) / kSelTB );
-	if( strip < 0 ) return;
-	const int bin = strip * kSelTB + threadIdx.x % kSelTB;
-	const bool valid = bin < bins;
-	int next = -1;
-	column_scan<kSelTF, kSelTB, 1, 1, true>( lds, F,
-		[&]( int64_t f, float ( &v )[1] ) { v[0] = __int_as_float( valid ? L[f * bins + bin] : -2 ); },
-		[&]( int64_t f, float ( &v )[1] )
-			{
-			const int l = __float_as_int( v[0] );
-			v[0] = __int_as_float( next );
-			next = ( l == int( f ) ) ? l : next;                                      // rows past the last frame hold 0, never == f
-			},
-		[&]( int64_t f, float ( &v )[1] ) { if( valid ) R[f * bins + bin] = __float_as_int( v[0] ); } );
-	}
-
 // PVModify.cpp:483-506, one thread per (frame, bin): the endpoints and the mix are the same for every channel
-__global__ __launch_bounds__( 256 ) void k_desample_apply( const MFd * in, int num_channels, int64_t F, int bins, const int * L, const int * R, int interp, MFd * out )
+// The right endpoint is the first frame after `frame` whose L exceeds L[frame] (L is non-decreasing down a column and jumps to t
+// exactly at a selected frame t): found by bisection, 13 probes of an L2-resident grid -- cheaper than a second sequential scan.
+__global__ __launch_bounds__( 256 ) void k_desample_apply( const MFd * in, int num_channels, int64_t F, int bins, const int * L, int interp, MFd * out )
 	{
 	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
 	const int64_t per_channel = F * bins;
 	if( idx >= per_channel ) return;
 	const int bin = int( idx % bins );
 	const int64_t frame = idx / bins;
-	const int lFrame = L[idx], rFrame = R[idx];
+	const int lFrame = L[idx];
+	int rFrame = -1;
+	if( lFrame >= 0 )
+		{
+		int64_t lo = frame + 1, hi = F;                                             // answer in [frame + 1, F]; F = none
+		while( lo < hi )
+			{
+			const int64_t mid = ( lo + hi ) >> 1;
+			if( L[mid * bins + bin] > lFrame ) hi = mid; else lo = mid + 1;
+			}
+		if( lo < F ) rFrame = int( lo );
+		}
 	const bool none = lFrame < 0 || rFrame < 0;                                       // :453 clear_buffer, :482
 	const float mix = none ? 0.0f : interpolate( interp, float( int( frame ) - lFrame ) / float( rFrame - lFrame ) );   // :491
 	for( int channel = 0; channel < num_channels; ++channel )
@@ -396,14 +389,13 @@ int flanhip_desample_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bi
 	FLANHIP_REQUIRE( interp >= FLANHIP_INTERP_LINEAR && interp <= FLANHIP_INTERP_SINE, FLANHIP_ERR_INVALID_ARG, "unknown interpolator" );
 	FLANHIP_REQUIRE( F < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "2^31 frames or more" );
 	hipStream_t s = (hipStream_t) stream;
-	int * d_lr = nullptr;                                                             // L then R: int[2][F][bins]
+	int * d_lr = nullptr;                                                             // L: int[F][bins]
 	const size_t grid = size_t( F ) * bins;
-	FLANHIP_CHECK( hipMallocAsync( reinterpret_cast<void**>( &d_lr ), sizeof( int ) * 2 * grid, s ) );
+	FLANHIP_CHECK( hipMallocAsync( reinterpret_cast<void**>( &d_lr ), sizeof( int ) * grid, s ) );
 	const unsigned col_blocks = xcd_grid( ( bins + kSelTB - 1 ) / kSelTB );
 	hipLaunchKernelGGL( k_desample_select, dim3( col_blocks ), dim3( 256 ), 0, s, d_ratio, ratio_const, F, bins, d_lr );
-	hipLaunchKernelGGL( k_desample_next, dim3( col_blocks ), dim3( 256 ), 0, s, (const int*) d_lr, F, bins, d_lr + grid );
 	hipLaunchKernelGGL( k_desample_apply, dim3( blocks_for( int64_t( grid ), 256 ) ), dim3( 256 ), 0, s, (const MFd*) d_pv, int( ch ), F, bins,
-		(const int*) d_lr, (const int*) ( d_lr + grid ), interp, (MFd*) d_out );
+		(const int*) d_lr, interp, (MFd*) d_out );
 	FLANHIP_CHECK( hipGetLastError() );
 	FLANHIP_CHECK( hipFreeAsync( d_lr, s ) );
 	return FLANHIP_OK;
