@@ -7,8 +7,8 @@
 // frames; ONE WAVEFRONT owns a chain, keeps that state in registers (lane l owns bins l, l+64, l+128, ...) and
 // walks its frames in order.  Chains are independent:
 //   analysis : a chain recomputes the phase of frame t0-1 (one extra FFT, no output) to seed `prev`.
-//   synthesis: a pre-pass sums the phase increments of every chain (k_phase_sums), a scan turns the sums into each
-//              chain's carry-in (k_phase_scan), and the overlap-add of the W-hop samples a chain shares with its
+//   synthesis: a pre-pass sums the phase increments of every chain (k_phase_sums2), a scan turns the sums into each
+//              chain's carry-in (k_phase_scan2), and the overlap-add of the W-hop samples a chain shares with its
 //              predecessor goes through a small side buffer that k_ola_fixup adds afterwards, in a fixed order.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -232,7 +232,7 @@ struct SynthParams
 	const float * window;     // [W] hann( i/(W-1) ) (unscaled)
 	const cf * tw;        // [C]
 	const cf * tw2;       // [C+1]
-	double * carry;           // [ch][chains][bins]  sums on entry to k_phase_scan, exclusive carries after
+	double * carry;           // [ch][chains][bins]  sums on entry to k_phase_scan2, exclusive carries after
 	float * head;             // [ch][chains][W-hop] overlap shared with the previous chain
 	int * nan_flag;           // may be null
 	int64_t F;
@@ -257,45 +257,7 @@ struct SynthParams
 	const int * skip_words;   // optional: the pre-pass retires at once when words [4] and [2] agree (the producer of the PV left the sums)
 	};
 
-// Per-chain sums of the phase increments, folded exactly like the running phase, plus the NaN/Inf scan of
-// PVBuffer::is_nan_or_inf (PVBuffer.cpp:44-50).  One block per chain, threads over bins (coalesced 8-byte MF reads).
-__global__ __launch_bounds__( 256 ) void k_phase_sums( SynthParams p )
-	{
-	const int64_t chain = blockIdx.x;
-	const int channel = int( chain / p.chains_per_channel );
-	const int64_t t0 = int64_t( chain % p.chains_per_channel ) * p.L;
-	const int64_t t1 = min( t0 + int64_t( p.L ), p.F );
-	bool bad = false;
-	for( int k = threadIdx.x; k < p.num_bins; k += blockDim.x )
-		{
-		double ph = 0.0;
-		const MF * col = p.pv + ( int64_t( channel ) * p.F + t0 ) * p.num_bins + k;
-		for( int64_t t = t0; t < t1; ++t, col += p.num_bins )
-			{
-			const MF mf = *col;
-			bad |= isnan( mf.m ) || isnan( mf.f ) || isinf( mf.m ) || isinf( mf.f );
-			ph = fold_phase( ph + double( phase_term( mf.f, p.analysis_rate ) ) );
-			}
-		p.carry[chain * p.num_bins + k] = ph;
-		}
-	if( p.nan_flag && __any( bad ) && ( threadIdx.x & 63 ) == 0 ) atomicOr( p.nan_flag, 1 );
-	}
-
-// Exclusive scan of the chain sums along each channel, per bin: carry[c] = phase_buffer on entry to chain c.
-__global__ __launch_bounds__( 256 ) void k_phase_scan( SynthParams p )
-	{
-	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
-	if( idx >= int64_t( p.num_channels ) * p.num_bins ) return;
-	const int channel = int( idx / p.num_bins ), k = int( idx % p.num_bins );
-	double * c = p.carry + int64_t( channel ) * p.chains_per_channel * p.num_bins + k;
-	double run = 0.0;                                                          // AudioPV.cpp:111
-	for( int i = 0; i < p.chains_per_channel; ++i, c += p.num_bins )
-		{
-		const double s = *c;
-		*c = run;
-		run = fold_phase( run + s );
-		}
-	}
+// (the pre-pass kernels k_phase_sums2 / k_phase_scan2 that serve every size live in pv_kernels_fast.h)
 
 // PV::convert_to_audio (Conversions/AudioPV.cpp:86-139).  One wavefront per chain.
 template<int LOG2C, int WAVES>
