@@ -300,3 +300,51 @@ def test_degenerate_lengths(fa, n):
         out_got, flag = fa.synthesize(ref, sr, ar, W)
         assert out_got.shape == out_ref.shape and flag == 0
         assert np.abs(out_got - out_ref).max() <= 1e-6
+
+
+def _special_signals(n):
+    t = np.arange(n)
+    sigs = {
+        "impulse": np.where(t == 700, 1.0, 0.0),
+        "impulse-train": np.where(t % 512 == 0, 1.0, 0.0),
+        "dc": np.full(n, 0.25),
+        "nyquist": np.where(t % 2 == 0, 0.5, -0.5),
+        "square": np.where((t // 50) % 2 == 0, 1.0, -1.0),
+        "bin-centred-sine": np.sin(2 * np.pi * (48000.0 * 40 / 2048) * t / 48000.0),       # lands exactly on bin 40: exact zeros elsewhere (up to rounding)
+        "tiny-noise": O.noise(1, n, seed=1)[0] * 1e-30,
+        "huge-noise": O.noise(1, n, seed=2)[0] * 1e30,
+        "denormal-noise": O.noise(1, n, seed=3)[0] * 1e-42,
+        "step": np.where(t > n // 2, 1.0, 0.0),
+    }
+    return {k: np.ascontiguousarray(v, np.float32)[None, :] for k, v in sigs.items()}
+
+
+@pytest.mark.parametrize("dft,hop", [(2048, 512), (4096, 128), (1024, 256)])
+def test_special_signals(fa, dft, hop):
+    """signals that put exact zeros, exact axis angles, denormals and very large values through the per-bin math"""
+    sr = 48000.0
+    W = min(dft, 2048)
+    ar = np.float32(sr) / np.float32(hop)
+    for name, x in _special_signals(9000).items():
+        ref = O.analyze(x, sr, W, hop, dft)
+        got = fa.analyze(x, sr, W, hop, dft)
+        m_r, m_g = ref[..., 0].astype(np.float64), got[..., 0].astype(np.float64)
+        scale = max(m_r.max(), 1e-300)
+        rel = np.sqrt(np.sum((m_g - m_r) ** 2)) / max(np.sqrt(np.sum(m_r ** 2)), 1e-300)
+        assert np.isfinite(got).all(), name
+        # bins that hold rounding noise of an exactly cancelling sum have no meaningful relative error: judge against the frame's scale
+        # (denormal spectra: fp32 butterflies keep only the denormals' few bits, the oracle's fp64 FFT keeps all -- absolute floor)
+        assert rel <= 1e-5 or np.abs(m_g - m_r).max() <= max(2e-7 * scale, 1e-43), (name, rel)
+        if scale < 1e-35:
+            continue
+        # f of frame t hangs on the phase of frame t - 1 as well: both must stand clear of the rounding noise of the transform
+        sig = m_r > 1e-3 * scale
+        sig[:, 1:] &= m_r[:, :-1] > 1e-3 * scale
+        df = np.abs(got[..., 1].astype(np.float64) - ref[..., 1])[sig]
+        turns = np.rint(df / float(ar))
+        assert (np.abs(df - turns * float(ar)) <= 0.05).all(), (name, df.max() if df.size else 0)
+        out_ref, _ = O.synthesize(ref, sr, ar, W)
+        out_got, flag = fa.synthesize(ref, sr, ar, W)
+        s_out = max(float(np.abs(out_ref).max()), 1e-300)
+        assert flag == 0 and np.isfinite(out_got).all(), name
+        assert np.abs(out_got.astype(np.float64) - out_ref).max() <= 2e-5 * s_out + 1e-37, (name, np.abs(out_got.astype(np.float64) - out_ref).max(), s_out)
