@@ -67,10 +67,22 @@ static int run_analyze_fast( const AnalyzeParams & p, const FastTables & tb, hip
 	return FLANHIP_OK;
 	}
 
+// Which tuned synthesis kernel serves this shape?  0: none (generic kernels); 1: overlap-add accumulator in registers (hop 128 /
+// 256 / 512 / 1024, window a multiple of 128); 2: accumulator as an LDS ring (any hop <= window, any window <= dft).
+static constexpr int kRingWaves11 = 3;                                            // dft 4096 with the 16 KB ring per wave: 3 waves fit
+static int synth_fast_kind( int dft, int W, int hop )
+	{
+	if( !( dft == 2048 || dft == 4096 ) || hop > W || hop < 1 || force_generic() ) return 0;
+	const int hq = hop / 128;
+	if( hop % 128 == 0 && ( hq == 1 || hq == 2 || hq == 4 || hq == 8 ) && W % 128 == 0 ) return 1;
+	return 2;
+	}
+
 template<int LOG2C, int WAVES, int HOPQ>
 static int run_synth_fast( const SynthParams & p, const FastTables & tb, hipStream_t s )
 	{
-	const size_t lds = FastLds<LOG2C>::bytes( WAVES );
+	const size_t lds = FastLds<LOG2C>::bytes( WAVES ) + ( HOPQ == 0 ? FastLds<LOG2C>::ring_bytes( WAVES ) : 0 );
+	static_assert( FastLds<LOG2C>::bytes( WAVES ) + ( HOPQ == 0 ? FastLds<LOG2C>::ring_bytes( WAVES ) : 0 ) <= kMaxLds, "LDS budget" );
 	auto kern = k_synthesize_fast<LOG2C, WAVES, HOPQ>;
 	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;
@@ -83,6 +95,8 @@ static int run_synth_fast( const SynthParams & p, const FastTables & tb, hipStre
 template<int LOG2C>
 static int run_synth_fast_hop( const SynthParams & p, const FastTables & tb, hipStream_t s )
 	{
+	if( synth_fast_kind( 2 << LOG2C, p.window_size, p.hop ) == 2 )                // any other hop <= window: ring accumulator in LDS
+		return run_synth_fast<LOG2C, ( LOG2C == 10 ? kSynWaves10 : kRingWaves11 ), 0>( p, tb, s );
 	switch( p.hop / 128 )
 		{
 		case 1: return run_synth_fast<LOG2C, ( LOG2C == 10 ? kSynWaves10 : kWaves11 ), 1>( p, tb, s );
@@ -93,12 +107,7 @@ static int run_synth_fast_hop( const SynthParams & p, const FastTables & tb, hip
 	return FLANHIP_ERR_UNSUPPORTED;
 	}
 
-static bool synth_fast_ok( int dft, int W, int hop )
-	{
-	const int hq = hop / 128;
-	return ( dft == 2048 || dft == 4096 ) && hop % 128 == 0 && ( hq == 1 || hq == 2 || hq == 4 || hq == 8 )
-		&& W % 128 == 0 && hop <= W && !force_generic();
-	}
+static bool synth_fast_ok( int dft, int W, int hop ) { return synth_fast_kind( dft, W, hop ) != 0; }
 
 // flanhip_analyze_dev_fused always leaves convert_to_audio's pre-pass in the workspace.  The tuned kernels and the generic
 // ones up to dft 2048 accumulate the sums while they have every f in a register; the generic kernels for dft >= 4096 keep no
@@ -195,7 +204,9 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	FLANHIP_REQUIRE( is_pow2( o->dft ) && o->dft >= 32 && o->dft <= 8192, FLANHIP_ERR_UNSUPPORTED, "dft size must be a power of two in [32, 8192]" );
 	o->head_len = std::max( W - o->hop, 0 );
 	const int overlap = ( W + o->hop - 1 ) / o->hop;              // frames covering one output sample
-	o->L = choose_chain_length( ch, F, std::max( overlap - 1, 1 ), synth_fast_ok( o->dft, W, o->hop ) ? fast_target_chains( o->dft, true ) : 4096 );
+	const int kind = synth_fast_kind( o->dft, W, o->hop );
+	const int slots = kind == 0 ? 4096 : ( kind == 2 && o->dft == 4096 ) ? 256 * kRingWaves11 : fast_target_chains( o->dft, true );
+	o->L = choose_chain_length( ch, F, std::max( overlap - 1, 1 ), slots );
 	o->chains_per_channel = int( ( F + o->L - 1 ) / o->L );
 	const int64_t chains = int64_t( o->chains_per_channel ) * ch;
 	o->carry_bytes = ( size_t( chains ) * bins * sizeof( double ) + 255 ) & ~size_t( 255 );

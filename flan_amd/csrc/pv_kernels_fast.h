@@ -43,6 +43,7 @@ template<int LOG2C> struct FastLds
 	static constexpr int BUF = WIN + C;
 	static constexpr int BUF_LEN = C + C / 16 + 1;     // highest slot used is PAD( C ) = C + C/16 (synthesis parks X[C] there)
 	static constexpr int SUM_LEN = ( C / 64 + 1 ) * 64; // per-wave chain sums (doubles), fused analysis only
+	static constexpr size_t ring_bytes( int waves ) { return size_t( waves ) * 2 * C * 4; }   // k_synthesize_fast<.., 0>: a ring of 2C floats per wave
 	static constexpr size_t bytes( int waves, bool sums = false ) { return size_t( BUF + waves * BUF_LEN + ( sums && LOG2C < 11 ? waves * SUM_LEN : 0 ) ) * 8; }   // dft 4096 keeps the sums in registers
 	};
 
@@ -378,7 +379,8 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 	}
 
 // =================================================================================================================
-// PV::convert_to_audio (Conversions/AudioPV.cpp:86-139); HOPQ = hop / 128
+// PV::convert_to_audio (Conversions/AudioPV.cpp:86-139); HOPQ = hop / 128 for the hops 128 / 256 / 512 / 1024 (overlap-add
+// accumulator in registers); HOPQ = 0: any hop <= window, any window, accumulator = a ring of 2C floats per wave in LDS
 // =================================================================================================================
 template<int LOG2C, int WAVES, int HOPQ>
 __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p, FastTables tb )
@@ -405,10 +407,21 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 	const int64_t t1 = min( t0 + int64_t( p.L ), p.F );
 	const bool last_chain = chain_in_channel == p.chains_per_channel - 1;
 	const int W = p.window_size;
-	constexpr int hop = 128 * HOPQ;
-	// everything below is in cf units (sample pairs): positions are even because hop, W/2... are multiples of 64
-	cf * out2 = reinterpret_cast<cf*>( p.out + int64_t( channel ) * p.out_len );
-	cf * head2 = reinterpret_cast<cf*>( p.head + chain * p.head_len );
+	constexpr bool RING = HOPQ == 0;
+	const int hop = RING ? p.hop : 128 * HOPQ;
+	// register accumulator: everything is in cf units (sample pairs), positions are even because hop, W/2 are multiples of 64;
+	// ring accumulator: float units
+	float * out1 = p.out + int64_t( channel ) * p.out_len;
+	float * head1 = p.head + chain * p.head_len;
+	cf * out2 = reinterpret_cast<cf*>( out1 );
+	cf * head2 = reinterpret_cast<cf*>( head1 );
+	float * ring = reinterpret_cast<float*>( s + L::BUF + WAVES * L::BUF_LEN ) + wave * ( 2 * C );   // RING only
+	if constexpr( RING )
+		{
+		for( int i = lane; i < 2 * C; i += 64 ) ring[i] = 0.0f;
+		wave_sync();
+		}
+	int ring_base = 0;                                                         // ring[ring_base] <-> absolute sample `pos`
 	const int64_t chain_start = int64_t( hop ) * t0 - W / 2;
 	const int64_t own_start = chain_in_channel == 0 ? INT64_MIN : chain_start + p.head_len;
 	const int padl = lane + ( lane >> 4 );
@@ -540,29 +553,75 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 		wave_sync();
 		fft_fast<LOG2C>( z, buf, s_tw1, s_tw3, lane );
 		// ---- G = fft( conj Z ): x[2n] = G[n].x, x[2n+1] = -G[n].y; window and overlap-add (AudioPV.cpp:122-134)
-		#pragma unroll
-		for( int q = 0; q < E; ++q )
+		if constexpr( !RING )
 			{
-			const cf w = s_win[64 * q];                                     // zero beyond W
-			acc[q].x += z[q].x * w.x;
-			acc[q].y += ( -z[q].y ) * w.y;
+			#pragma unroll
+			for( int q = 0; q < E; ++q )
+				{
+				const cf w = s_win[64 * q];                                 // zero beyond W
+				acc[q].x += z[q].x * w.x;
+				acc[q].y += ( -z[q].y ) * w.y;
+				}
+			#pragma unroll
+			for( int q = 0; q < ( RING ? 1 : HOPQ ); ++q ) emit_step( pos + 128 * q, acc[q] );
+			#pragma unroll
+			for( int q = 0; q < E; ++q ) acc[q] = ( q + HOPQ < E ) ? acc[q + HOPQ] : mk( 0.0f, 0.0f );
 			}
-		#pragma unroll
-		for( int q = 0; q < HOPQ; ++q ) emit_step( pos + 128 * q, acc[q] );
-		#pragma unroll
-		for( int q = 0; q < E; ++q ) acc[q] = ( q + HOPQ < E ) ? acc[q + HOPQ] : mk( 0.0f, 0.0f );
+		else
+			{
+			#pragma unroll
+			for( int q = 0; q < E; ++q )
+				{
+				const cf w = s_win[64 * q];
+				const int s0 = 2 * ( lane + 64 * q );
+				if( s0 < W )
+					{
+					int i0 = ring_base + s0; if( i0 >= W ) i0 -= W;
+					ring[i0] += z[q].x * w.x;
+					if( s0 + 1 < W )
+						{
+						int i1 = i0 + 1; if( i1 >= W ) i1 -= W;
+						ring[i1] += ( -z[q].y ) * w.y;
+						}
+					}
+				}
+			wave_sync();
+			// the oldest `hop` samples are complete as far as this chain is concerned: emit and clear them (hop <= W)
+			for( int e = lane; e < hop; e += 64 )
+				{
+				int i = ring_base + e; if( i >= W ) i -= W;
+				const float v = ring[i];
+				ring[i] = 0.0f;
+				const int64_t a = pos + e;
+				if( a < own_start ) head1[a - chain_start] = v;
+				else if( a >= 0 && a < p.out_len ) out1[a] = v;
+				}
+			wave_sync();
+			ring_base += hop; if( ring_base >= W ) ring_base -= W;
+			}
 		pos += hop;
 		}
 	// flush the partial sums that the next chain's head completes; the last chain zero-fills to the end of the output
 	const int64_t ring_end = pos + ( W - hop );
 	const int64_t flush_end = last_chain ? max( ring_end, p.out_len ) : ring_end;
-	#pragma unroll
-	for( int q = 0; q < E; ++q )
+	if constexpr( !RING )
 		{
-		const int64_t a0 = pos + 128 * q;
-		if( a0 < flush_end ) emit_step( a0, acc[q] );
+		#pragma unroll
+		for( int q = 0; q < E; ++q )
+			{
+			const int64_t a0 = pos + 128 * q;
+			if( a0 < flush_end ) emit_step( a0, acc[q] );
+			}
+		for( int64_t a0 = pos + 128 * E; a0 < flush_end; a0 += 128 ) emit_step( a0, mk( 0.0f, 0.0f ) );
 		}
-	for( int64_t a0 = pos + 128 * E; a0 < flush_end; a0 += 128 ) emit_step( a0, mk( 0.0f, 0.0f ) );
+	else
+		for( int64_t a = pos + lane; a < flush_end; a += 64 )
+			{
+			float v = 0.0f;
+			if( a < ring_end ) { int i = ring_base + int( a - pos ); if( i >= W ) i -= W; v = ring[i]; }
+			if( a < own_start ) head1[a - chain_start] = v;
+			else if( a >= 0 && a < p.out_len ) out1[a] = v;
+			}
 	}
 
 // ---- pre-pass kernels (all sizes) --------------------------------------------------------------------------------
