@@ -168,3 +168,47 @@ def test_config2_full_size_parity_against_the_oracle():
     assert rel_m <= 1e-5 and wrms_f <= 2e-3 and same_f >= 0.98
     assert p2 <= 1e-5
     assert p3 <= 2e-4           # 60 s of noise: the reference's own FFT-backend self-noise is 8.9e-5 here
+
+
+def test_config3_full_length_parity_against_the_oracle():
+    """BASELINE config 3 at full length (60 s, stretch x2 by a sampled factor grid), on two of its eight channels (channels are
+    independent): analysis -> stretch -> synthesis, every stage against the oracle fed with the oracle's previous stage"""
+    import flan_amd as fa
+    x = O.noise(2, 60 * 48000, seed=77)
+    pv_ref = O.analyze(x, SR, W, HOP, DFT)
+    F, bins = pv_ref.shape[1], pv_ref.shape[2]
+    mod = O.stretch_map(np.full((F, bins), 2.0, np.float32), SR, HOP)
+    st_ref = O.modify_time(pv_ref, SR, HOP, mod)
+    st_got = fa.modify_time(pv_ref, SR, HOP, mod)
+    assert st_got.shape == st_ref.shape == (2, 2 * F, bins, 2)
+    assert np.array_equal(st_got.view(np.uint32), st_ref.view(np.uint32))       # P4: bit for bit
+    ar = np.float32(SR) / np.float32(HOP)
+    out_ref, _ = O.synthesize(st_ref, SR, ar, W)
+    out_got, flag = fa.synthesize(st_ref, SR, ar, W)
+    p2 = np.sqrt(np.mean((out_got.astype(np.float64) - out_ref) ** 2))
+    print("\n[config 3, full length: %d -> %d frames per channel] stretch bit-identical; P2 rms=%.2e" % (F, 2 * F, p2))
+    assert flag == 0 and p2 <= 1e-5
+
+
+def test_config5_ten_seconds_parity_against_the_oracle():
+    """BASELINE config 5 (stereo 96 kHz -> resample to 48 kHz -> convert_to_PV -> shape f + 100 Hz -> convert_to_audio), 10 of
+    its 60 seconds (the scalar oracle FIR needs ~0.4 s per second of audio): stage by stage against the oracle"""
+    import flan_amd as fa
+    x96 = O.noise(2, 10 * 96000, seed=1234)
+    x48_r = O.resample_2to1(x96, 96000.0, SR)
+    x48_g = fa.resample(x96, 96000.0, SR)
+    same = np.mean(x48_g.view(np.uint32) == x48_r.view(np.uint32))
+    assert x48_g.shape == x48_r.shape == (2, 10 * 48000) and same >= 0.9999
+    pv_r = O.analyze(x48_r, SR, W, HOP, DFT)
+    pv_g = fa.analyze(x48_r, SR, W, HOP, DFT)
+    m_r, m_g = pv_r[..., 0].astype(np.float64), pv_g[..., 0].astype(np.float64)
+    rel_m = np.sqrt(np.sum((m_g - m_r) ** 2) / np.sum(m_r ** 2))
+    sh_r = O.shape_affine(pv_r, SR, 1.0, 0.0, 1.0, 100.0, False)
+    sh_g = fa.shape_affine(pv_r, SR, 1.0, 0.0, 1.0, 100.0, False)
+    assert np.array_equal(sh_g.view(np.uint32), sh_r.view(np.uint32))
+    ar = np.float32(SR) / np.float32(HOP)
+    out_r, _ = O.synthesize(sh_r, SR, ar, W)
+    out_g, flag = fa.synthesize(sh_r, SR, ar, W)
+    p2 = np.sqrt(np.mean((out_g.astype(np.float64) - out_r) ** 2))
+    print("\n[config 5, 10 s] resample bit-identical=%.5f  P1 rel_m=%.2e  shape bit-identical  P2 rms=%.2e" % (same, rel_m, p2))
+    assert rel_m <= 1e-5 and p2 <= 1e-5 and flag == 0
