@@ -222,6 +222,21 @@ int flanhip_free( void * dptr )
 	return FLANHIP_OK;
 	}
 
+int flanhip_host_malloc( void ** hptr, size_t bytes )
+	{
+	FLANHIP_REQUIRE( hptr, FLANHIP_ERR_INVALID_ARG, "null out pointer" );
+	if( int rc = require_device() ) return rc;
+	FLANHIP_CHECK( hipHostMalloc( hptr, bytes ? bytes : 1, hipHostMallocDefault ) );
+	return FLANHIP_OK;
+	}
+
+int flanhip_host_free( void * hptr )
+	{
+	if( !hptr ) return FLANHIP_OK;
+	FLANHIP_CHECK( hipHostFree( hptr ) );
+	return FLANHIP_OK;
+	}
+
 int flanhip_memcpy_h2d( void * dst, const void * src, size_t bytes, void * stream )
 	{
 	FLANHIP_CHECK( hipMemcpyAsync( dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t) stream ) );

@@ -19,23 +19,63 @@ std::shared_ptr<DeviceBlock> upload( const void * host, size_t bytes )
 	auto b = DeviceBlock::allocate( bytes );
 	if( !b ) return nullptr;
 	if( !detail::report( flanhip_memcpy_h2d( b->ptr, host, bytes, nullptr ), "upload" ) ) return nullptr;
+	if( !detail::report( flanhip_stream_synchronize( nullptr ), "upload" ) ) return nullptr;   // a staging block goes back to its cache after this
 	return b;
 	}
 
-// the sampled factor / map grid of a Function on the device: constants are filled in place, callables are sampled on the host
+// sample_function_over_domain (PV.h:31-35) straight onto the device: a constant is filled there; a callable is sampled on the
+// host a slab of frames at a time into page-locked memory, each slab on its way over the link while the next is sampled.
+// `keep`, when given, receives the host copy (modify_time needs its maximum).
 template<typename T>
-std::shared_ptr<DeviceBlock> grid_to_device( const FunctionSample2d<T> & s )
+std::shared_ptr<DeviceBlock> function_grid_to_device( const PV & me, const Function<TF, T> & f, FunctionSample2d<T> * keep = nullptr )
 	{
 	static_assert( sizeof( T ) == sizeof( float ), "float grids only" );
-	if( s.is_constant() )
+	const int frames = me.get_num_frames(), bins = me.get_num_bins();
+	const size_t count = size_t( frames ) * bins;
+	if( f.is_constant() )
 		{
-		auto b = DeviceBlock::allocate( sizeof( float ) * s.size() );
+		auto b = DeviceBlock::allocate( sizeof( float ) * count );
 		if( !b ) return nullptr;
-		if( !detail::report( flanhip_fill_dev( static_cast<float*>( b->ptr ), int64_t( s.size() ), float( s.get_constant() ), nullptr ), "fill" ) ) return nullptr;
+		if( !detail::report( flanhip_fill_dev( static_cast<float*>( b->ptr ), int64_t( count ), float( f.get_constant() ), nullptr ), "fill" ) ) return nullptr;
+		if( keep ) *keep = FunctionSample2d<T>{ f.get_constant(), count, size_t( bins ) };
 		return b;
 		}
-	return upload( s.get_vector().data(), sizeof( float ) * s.size() );
+	typename FunctionSample2d<T>::Vector host( count );
+	auto b = DeviceBlock::allocate( sizeof( T ) * count );
+	if( !b ) return nullptr;
+	const int slabs = count * sizeof( T ) >= ( size_t( 4 ) << 20 ) ? 4 : 1;
+	for( int k = 0; k < slabs; ++k )
+		{
+		const int x0 = int( int64_t( frames ) * k / slabs ), x1 = int( int64_t( frames ) * ( k + 1 ) / slabs );
+		if( x1 <= x0 ) continue;
+		f.sample_into( host.data() + size_t( x0 ) * bins, float( x0 ), float( x1 ), 1.0f / me.get_analysis_rate(), 0, float( bins ), me.bin_to_frequency( 1 ) );
+		if( !detail::report( flanhip_memcpy_h2d( static_cast<char*>( b->ptr ) + sizeof( T ) * size_t( x0 ) * bins, host.data() + size_t( x0 ) * bins,
+				sizeof( T ) * size_t( x1 - x0 ) * bins, nullptr ), "upload" ) ) return nullptr;
+		}
+	if( !detail::report( flanhip_stream_synchronize( nullptr ), "upload" ) ) return nullptr;   // before the staging block goes back to its cache
+	if( keep ) *keep = FunctionSample2d<T>{ std::move( host ), count, size_t( bins ) };
+	return b;
 	}
+
+// FunctionSample::maximum (FunctionSample.h:156-160) = std::max_element, over the rows in parallel.  Its answer with NaNs in
+// the grid: the first element if that is a NaN, else the largest of the others.
+float grid_maximum( const FunctionSample2d<float> & s, ExecutionPolicy policy )
+	{
+	if( s.is_constant() ) return s.get_constant();
+	const auto & v = s.get_vector();
+	if( v.empty() || v[0] != v[0] ) return v.empty() ? 0.0f : v[0];
+	const size_t row = std::max<size_t>( s.small_dim_size, 1 ), rows = ( v.size() + row - 1 ) / row;
+	std::vector<float> row_max( rows );
+	detail::for_each_index( 0, int( rows ), policy, [&]( int r )
+		{
+		float mx = -INFINITY;
+		const size_t hi = std::min( v.size(), ( size_t( r ) + 1 ) * row );
+		for( size_t i = size_t( r ) * row; i < hi; ++i ) mx = v[i] > mx ? v[i] : mx;
+		row_max[size_t( r )] = mx;
+		}, 64 );
+	return *std::max_element( row_max.begin(), row_max.end() );
+	}
+
 }
 
 PV::PV() : PVBuffer( PVBuffer::Format() ) {}
@@ -123,11 +163,9 @@ PV PV::modify_time( const Function<TF, Second> & mod, const Interpolator & inter
 	{
 	if( is_null() ) return PV();
 	if( !interp.is_linear() ) { std::cerr << "flan: only Interpolator::linear() runs on the device path" << std::endl; return PV(); }
-	const auto sampled = sample_function_over_domain( mod );                       // PVModify.cpp:367
-	float mx;
-	if( sampled.is_constant() ) mx = sampled.get_constant();
-	else mx = *std::max_element( sampled.get_vector().begin(), sampled.get_vector().end() );   // FunctionSample::maximum
-	auto d_mod = grid_to_device( sampled );
+	FunctionSample2d<Second> sampled{ 0.0f, 0, 0 };
+	auto d_mod = function_grid_to_device( *this, mod, &sampled );                  // PVModify.cpp:367
+	const float mx = grid_maximum( sampled, mod.get_execution_policy() );          // FunctionSample::maximum
 	if( !d_mod ) return PV();
 	return modify_time_device( *this, std::move( d_mod ), mx );
 	}
@@ -136,7 +174,7 @@ PV PV::stretch( const Function<TF, float> & factor, const Interpolator & interp 
 	{
 	if( is_null() ) return PV();
 	if( !interp.is_linear() ) { std::cerr << "flan: only Interpolator::linear() runs on the device path" << std::endl; return PV(); }
-	auto d_grid = grid_to_device( sample_function_over_domain( factor ) );         // PVModify.cpp:373
+	auto d_grid = function_grid_to_device( *this, factor );                        // PVModify.cpp:373
 	auto d_max = DeviceBlock::allocate( sizeof( float ) );
 	if( !d_grid || !d_max ) return PV();
 	// :376-382 running sum over frames per bin, frame_to_time -- on the device, plus the maximum modify_time_base needs
@@ -166,11 +204,11 @@ PV PV::modify_frequency( const Function<TF, Frequency> & mod, const Interpolator
 	{
 	if( is_null() ) return PV();
 	if( !interp.is_linear() ) { std::cerr << "flan: only Interpolator::linear() runs on the device path" << std::endl; return PV(); }
-	auto d_mod = grid_to_device( sample_function_over_domain( mod ) );             // PVModify.cpp:261
+	auto d_mod = function_grid_to_device( *this, mod );                            // PVModify.cpp:261
 	if( !d_mod ) return PV();
 	// :263-268: the callable is evaluated at every MF's own (time, frequency): data dependent, so on the host
 	const std::vector<MF> & data = get_buffer();
-	std::vector<float> in_modified( data.size() );
+	detail::StagingVector<float> in_modified( data.size() );
 	const size_t per_channel = size_t( get_num_frames() ) * get_num_bins();
 	detail::for_each_index( 0, int( size_t( get_num_channels() ) * get_num_frames() ), mod.get_execution_policy(), [&]( int row )
 		{
@@ -178,7 +216,7 @@ PV PV::modify_frequency( const Function<TF, Frequency> & mod, const Interpolator
 		const size_t base = size_t( row ) * get_num_bins();
 		for( Bin bin = 0; bin < get_num_bins(); ++bin )
 			in_modified[base + bin] = mod( TF{ frame_to_time( fFrame( frame ) ), data[base + bin].f } );
-		} );
+		}, 16 );
 	(void) per_channel;
 	auto d_in = upload( in_modified.data(), sizeof( float ) * in_modified.size() );
 	if( !d_in ) return PV();
@@ -189,7 +227,7 @@ PV PV::repitch( const Function<TF, float> & factor, const Interpolator & interp 
 	{
 	if( is_null() ) return PV();
 	if( !interp.is_linear() ) { std::cerr << "flan: only Interpolator::linear() runs on the device path" << std::endl; return PV(); }
-	auto d_grid = grid_to_device( sample_function_over_domain( factor ) );         // PVModify.cpp:275
+	auto d_grid = function_grid_to_device( *this, factor );                        // PVModify.cpp:275
 	const MF * d_pv = device_data();
 	auto out = DeviceBlock::allocate( sizeof( MF ) * size_t( get_num_channels() ) * get_num_frames() * get_num_bins() );
 	if( !d_grid || !d_pv || !out ) return PV();
@@ -205,12 +243,12 @@ PV PV::shape( const Function<MF, MF> & shaper, bool use_shift_alignment ) const
 	if( is_null() ) return PV();
 	// PV.cpp:435-436: the shaper sees every MF: evaluated on the host, the placement rule runs on the device
 	const std::vector<MF> & data = get_buffer();
-	std::vector<MF> shaped( data.size() );
+	detail::StagingVector<MF> shaped( data.size() );
 	detail::for_each_index( 0, int( size_t( get_num_channels() ) * get_num_frames() ), shaper.get_execution_policy(), [&]( int row )
 		{
 		const size_t base = size_t( row ) * get_num_bins();
 		for( Bin bin = 0; bin < get_num_bins(); ++bin ) shaped[base + bin] = shaper( data[base + bin] );
-		} );
+		}, 16 );
 	auto d_shaped = upload( shaped.data(), sizeof( MF ) * shaped.size() );
 	const MF * d_pv = device_data();
 	auto out = DeviceBlock::allocate( sizeof( MF ) * shaped.size() );

@@ -8,19 +8,27 @@
 
 namespace flan { namespace detail {
 
+// host_runtime.cpp: blocks come from, and go back to, a cache of idle HBM blocks (every method synchronises before it returns,
+// so a block whose owner dies is idle); flanhip_malloc / flanhip_free only when the cache cannot serve.
+void * device_acquire( size_t bytes, size_t * capacity );   // nullptr on failure (flanhip_last_error() says why)
+void device_release( void * ptr, size_t capacity ) noexcept;
+void device_cache_flush() noexcept;                          // give every idle block back to the device
+
 struct DeviceBlock
 	{
 	void * ptr = nullptr;
-	size_t bytes = 0;
+	size_t bytes = 0;                                          // what was asked for
+	size_t capacity = 0;                                       // what the block holds
 	DeviceBlock() = default;
 	DeviceBlock( const DeviceBlock & ) = delete;
 	DeviceBlock & operator=( const DeviceBlock & ) = delete;
-	~DeviceBlock() { if( ptr ) flanhip_free( ptr ); }
+	~DeviceBlock() { if( ptr ) device_release( ptr, capacity ); }
 
 	static std::shared_ptr<DeviceBlock> allocate( size_t bytes )
 		{
 		auto b = std::make_shared<DeviceBlock>();
-		if( flanhip_malloc( &b->ptr, bytes ) != FLANHIP_OK )
+		b->ptr = device_acquire( bytes, &b->capacity );
+		if( !b->ptr )
 			{
 			std::cerr << "flan: device allocation of " << bytes << " bytes failed: " << flanhip_last_error() << std::endl;
 			return nullptr;

@@ -12,7 +12,9 @@
 #include <cmath>
 #include <functional>
 #include <thread>
+#include <new>
 #include <type_traits>
+#include <utility>
 #include <variant>
 #include <vector>
 
@@ -21,32 +23,60 @@
 namespace flan {
 
 namespace detail {
-// Parallel policies: split the outer index range over the host cores; sequential policies: a plain loop.
+// the host runtime in libflan_host (flan_amd/host/host_runtime.cpp): a persistent worker pool and page-locked staging memory
+int host_workers();                                                            // threads a parallel region runs on
+void pool_run( int n_tasks, void ( *fn )( void *, int ), void * ctx );         // fn( ctx, i ) for i in [0, n_tasks), load balanced
+void * staging_acquire( size_t bytes );                                        // page-locked when large and a device is there
+void staging_release( void * p ) noexcept;
+
+// Parallel policies: split the index range over the host cores in contiguous grains; sequential policies: a plain loop.
 template<typename F>
-void for_each_index( int begin, int end, ExecutionPolicy policy, const F & body )
+void for_each_index( int begin, int end, ExecutionPolicy policy, const F & body, int min_parallel = 128 )
 	{
 	const int n = end - begin;
 	const bool parallel = policy == ExecutionPolicy::Parallel_Sequenced || policy == ExecutionPolicy::Parallel_Unsequenced;
-	const int workers = parallel ? std::max( 1, std::min<int>( std::thread::hardware_concurrency(), n / 64 ) ) : 1;
-	if( workers <= 1 ) { for( int i = begin; i < end; ++i ) body( i ); return; }
-	std::vector<std::thread> pool;
-	for( int w = 0; w < workers; ++w )
-		pool.emplace_back( [=, &body]{ for( int i = begin + w; i < end; i += workers ) body( i ); } );
-	for( auto & t : pool ) t.join();
+	if( !parallel || n < min_parallel ) { for( int i = begin; i < end; ++i ) body( i ); return; }
+	struct Job { const F * body; int begin, end, grain; } job{ &body, begin, end, std::max( 1, n / ( host_workers() * 8 ) ) };
+	pool_run( ( n + job.grain - 1 ) / job.grain, []( void * ctx, int task )
+		{
+		const Job & j = *static_cast<const Job*>( ctx );
+		const int lo = j.begin + task * j.grain, hi = std::min( j.end, lo + j.grain );
+		for( int i = lo; i < hi; ++i ) ( *j.body )( i );
+		}, &job );
 	}
+
+// Allocator of the sampled grids: staging memory, and no zero fill for the value-initialised elements a sample overwrites anyway
+template<typename T>
+struct StagingAllocator
+	{
+	using value_type = T;
+	StagingAllocator() = default;
+	template<typename U> StagingAllocator( const StagingAllocator<U> & ) {}
+	T * allocate( size_t n ) { return static_cast<T*>( staging_acquire( n * sizeof( T ) ) ); }
+	void deallocate( T * p, size_t ) noexcept { staging_release( p ); }
+	template<typename U, typename... Args> void construct( U * p, Args &&... args )
+		{
+		if constexpr( sizeof...( args ) == 0 && std::is_trivially_default_constructible_v<U> ) (void) p;
+		else ::new( static_cast<void*>( p ) ) U( std::forward<Args>( args )... );
+		}
+	template<typename U> bool operator==( const StagingAllocator<U> & ) const { return true; }
+	template<typename U> bool operator!=( const StagingAllocator<U> & ) const { return false; }
+	};
+template<typename T> using StagingVector = std::vector<T, StagingAllocator<T>>;
 }
 
 // FunctionSample.h:173-199: a sampled function, either one constant or a grid [big][small]
 template<typename O>
 struct FunctionSample2d
 	{
-	std::variant<O, std::vector<O>> value;
+	using Vector = detail::StagingVector<O>;                                      // a std::vector in everything but where its memory comes from
+	std::variant<O, Vector> value;
 	size_t count;
 	size_t small_dim_size;
 	bool is_constant() const { return std::holds_alternative<O>( value ); }
 	const O & get_constant() const { return std::get<O>( value ); }
-	std::vector<O> & get_vector() { return std::get<std::vector<O>>( value ); }
-	const std::vector<O> & get_vector() const { return std::get<std::vector<O>>( value ); }
+	Vector & get_vector() { return std::get<Vector>( value ); }
+	const Vector & get_vector() const { return std::get<Vector>( value ); }
 	size_t size() const { return count; }
 	O at( Frame f, Bin b ) const { return is_constant() ? get_constant() : get_vector()[size_t( f ) * small_dim_size + b]; }
 	};
@@ -88,14 +118,22 @@ struct Function
 		const int x_size = int( std::ceil( x_end - x_start ) );
 		const int y_size = int( std::ceil( y_end - y_start ) );
 		if( is_constant() ) return FunctionSample2d<O>{ std::get<O>( f ), size_t( x_size ) * y_size, size_t( y_size ) };
-		std::vector<O> out( size_t( x_size ) * y_size );
+		typename FunctionSample2d<O>::Vector out( size_t( x_size ) * y_size );
+		sample_into( out.data(), x_start, x_end, x_scale, y_start, y_end, y_scale );
+		return FunctionSample2d<O>{ std::move( out ), size_t( x_size ) * y_size, size_t( y_size ) };
+		}
+
+	// the same grid written to memory of the caller's (rows [x_start, x_end) only, row x at out + (x - x_start) * y_size): what
+	// lets the PV methods upload one part of a grid while the next is being sampled.  Not for constants.
+	void sample_into( O * out, float x_start, float x_end, float x_scale, float y_start, float y_end, float y_scale ) const
+		{
+		const int y_size = int( std::ceil( y_end - y_start ) );
 		const StdFuncType & fn = std::get<StdFuncType>( f );
 		detail::for_each_index( int( x_start ), int( x_end ), execution_policy, [&]( int x )
 			{
 			for( int y = int( y_start ); y < y_end; ++y )
 				out[size_t( x - int( x_start ) ) * y_size + ( y - int( y_start ) )] = fn( I{ x * x_scale, y * y_scale } );
-			} );
-		return FunctionSample2d<O>{ std::move( out ), size_t( x_size ) * y_size, size_t( y_size ) };
+			}, 16 );
 		}
 
 	// Function.h:141-153: sample a function of one variable at x*scale, x in [start, end); a constant stays a constant

@@ -63,6 +63,10 @@ int flanhip_memcpy_h2d(void * dst, const void * src, size_t bytes, void * stream
 int flanhip_memcpy_d2h(void * dst, const void * src, size_t bytes, void * stream);
 int flanhip_memset(void * dst, int value, size_t bytes, void * stream);
 int flanhip_stream_synchronize(void * stream);
+/* page-locked host memory: what a caller samples a Function grid into (Function.h:155-171) so that the upload runs at the
+ * link's rate instead of through the runtime's staging copy.  Needs a device. */
+int flanhip_host_malloc(void ** hptr, size_t bytes);
+int flanhip_host_free(void * hptr);
 
 /* ---- Audio::convert_to_PV  (Conversions/AudioPV.cpp:12-78, phase_vocoder.cpp:5-53, WindowFunctions.cpp:10-13) - */
 /* audio: float[ch][n]; out: MF[ch][F][dft/2+1] with F = flanhip_num_pv_frames(n, hop), written to *num_pv_frames. */

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <stdexcept>
 #include <iostream>
 #include <string>
 #include <type_traits>
@@ -40,6 +41,54 @@ static Audio noise( int ch, int n, uint32_t seed )
 	return Audio::create_from_buffer( std::move( x ), ch, 48000.0f );
 	}
 
+// the worker pool and the staging memory behind Function::sample (flan_amd/host/host_runtime.cpp); runs with or without a device
+static void host_runtime_checks()
+	{
+	CHECK( detail::host_workers() >= 1 );
+	// a large grid sampled in parallel = the same grid sampled sequentially, element for element, and no element left untouched
+	Function<TF, float> par( []( TF tf ){ return tf.t * 3.0f + tf.f; } );
+	Function<TF, float> seq( []( TF tf ){ return tf.t * 3.0f + tf.f; }, ExecutionPolicy::Linear_Sequenced );
+	for( int frames : { 1, 15, 16, 17, 129, 1000 } )
+		{
+		const auto a = par.sample( 0, float( frames ), 0.01f, 0, 513, 23.4375f );
+		const auto b = seq.sample( 0, float( frames ), 0.01f, 0, 513, 23.4375f );
+		CHECK( a.size() == size_t( frames ) * 513 && a.get_vector().size() == a.size() );
+		CHECK( std::memcmp( a.get_vector().data(), b.get_vector().data(), sizeof( float ) * a.size() ) == 0 );
+		}
+	// every index exactly once, whatever the range
+	for( int n : { 0, 1, 127, 128, 129, 5000, 100003 } )
+		{
+		std::vector<std::atomic<int>> hits( size_t( n ) + 1 );
+		detail::for_each_index( 7, 7 + n, ExecutionPolicy::Parallel_Unsequenced, [&]( int i ){ hits[size_t( i - 7 )].fetch_add( 1 ); } );
+		bool once = true;
+		for( int i = 0; i < n; ++i ) once = once && hits[size_t( i )].load() == 1;
+		CHECK( once && hits[size_t( n )].load() == 0 );
+		}
+	// a parallel region started from inside one runs inline instead of deadlocking
+	std::atomic<long> total{ 0 };
+	detail::for_each_index( 0, 256, ExecutionPolicy::Parallel_Unsequenced, [&]( int )
+		{ detail::for_each_index( 0, 256, ExecutionPolicy::Parallel_Unsequenced, [&]( int ){ total.fetch_add( 1 ); } ); } );
+	CHECK( total.load() == 256 * 256 );
+	// what a callable throws reaches the caller, and the pool is usable afterwards
+	bool caught = false;
+	try { detail::for_each_index( 0, 4096, ExecutionPolicy::Parallel_Unsequenced, []( int i ){ if( i == 1234 ) throw std::runtime_error( "boom" ); } ); }
+	catch( const std::runtime_error & ) { caught = true; }
+	CHECK( caught );
+	total = 0;
+	detail::for_each_index( 0, 4096, ExecutionPolicy::Parallel_Unsequenced, [&]( int ){ total.fetch_add( 1 ); } );
+	CHECK( total.load() == 4096 );
+	// staging blocks: reusable, writable end to end, large and small
+	for( size_t bytes : { size_t( 1 ), size_t( 4096 ), size_t( 300 ) << 10, size_t( 5 ) << 20 } )
+		for( int rep = 0; rep < 3; ++rep )
+			{
+			auto * p = static_cast<unsigned char*>( detail::staging_acquire( bytes ) );
+			CHECK( p != nullptr );
+			std::memset( p, 0xA5, bytes );
+			CHECK( p[0] == 0xA5 && p[bytes - 1] == 0xA5 );
+			detail::staging_release( p );
+			}
+	}
+
 static void no_device_checks()
 	{
 	CHECK( flanhip_device_count() == 0 );
@@ -71,10 +120,12 @@ static void no_device_checks()
 	Function<TF, float> l( []( TF tf ){ return tf.t + tf.f; } );
 	auto s = p.sample_function_over_domain( l );
 	CHECK( !s.is_constant() && s.size() == 15 && close_to( s.at( 2, 3 ), 2.0 / 93.75 + 18000.0, 1e-6 ) );
+	host_runtime_checks();
 	}
 
 static void device_checks()
 	{
+	host_runtime_checks();                              // with a device the large staging blocks are page-locked
 	CHECK( flanhip_device_count() >= 1 );
 	// ---- BASELINE config 1 + SURVEY 8c anchors through the class surface
 	Audio a = sine( 240000 );
@@ -218,6 +269,38 @@ static void device_checks()
 	PV w = p2.copy();
 	w.get_MF( 0, 0, 0 ) = MF{ 1.0f, 2.0f };
 	CHECK( !w.is_device_resident() && w.get_MF( 0, 0, 0 ).m == 1.0f );
+	// ---- a grid large enough to go over in slabs (sampled slab k+1 while slab k uploads) = the same grid sampled in one piece
+	// and taken through the C ABI by hand; and the block cache hands memory back and forth without mixing results up
+		{
+		PV big = noise( 1, 700000, 5 ).convert_to_PV( 2048, 512, 2048 );
+		const auto g = []( TF tf ){ return 1.0f + 0.35f * std::sin( tf.t * 3.0f ) + tf.f * 1e-5f; };
+		CHECK( size_t( big.get_num_frames() ) * big.get_num_bins() * sizeof( float ) >= ( size_t( 4 ) << 20 ) );
+		const int64_t F = big.get_num_frames(); const int bins = big.get_num_bins();
+		auto grid = big.sample_function_over_domain( Function<TF, float>( g ) );
+		void * d_grid = nullptr, * d_max = nullptr, * d_out = nullptr;
+		CHECK( flanhip_malloc( &d_grid, sizeof( float ) * grid.size() ) == FLANHIP_OK && flanhip_malloc( &d_max, sizeof( float ) ) == FLANHIP_OK );
+		flanhip_memcpy_h2d( d_grid, grid.get_vector().data(), sizeof( float ) * grid.size(), nullptr );
+		CHECK( flanhip_stretch_map_dev( static_cast<float*>( d_grid ), F, bins, 48000.0f, 512, static_cast<float*>( d_max ), nullptr ) == FLANHIP_OK );
+		float mx = 0; flanhip_memcpy_d2h( &mx, d_max, sizeof( float ), nullptr ); flanhip_stream_synchronize( nullptr );
+		const int64_t Fo = int64_t( std::ceil( big.time_to_frame( mx ) ) );
+		CHECK( flanhip_malloc( &d_out, sizeof( MF ) * size_t( Fo ) * bins ) == FLANHIP_OK );
+		CHECK( flanhip_modify_time_dev( reinterpret_cast<const flanhip_MF*>( big.device_data() ), 1, F, bins, 48000.0f, 512, static_cast<const float*>( d_grid ), Fo,
+			static_cast<flanhip_MF*>( d_out ), nullptr ) == FLANHIP_OK );
+		std::vector<MF> by_hand( size_t( Fo ) * bins );
+		flanhip_memcpy_d2h( by_hand.data(), d_out, sizeof( MF ) * by_hand.size(), nullptr ); flanhip_stream_synchronize( nullptr );
+		for( int rep = 0; rep < 3; ++rep )                                            // rep > 0: every block involved comes out of the cache
+			{
+			PV st = big.stretch( g );
+			CHECK( st.get_num_frames() == Fo );
+			CHECK( st.get_buffer().size() == by_hand.size() && std::memcmp( st.get_buffer().data(), by_hand.data(), sizeof( MF ) * by_hand.size() ) == 0 );
+			Audio out = st.convert_to_audio();
+			CHECK( !out.is_null() && out.get_num_frames() == Fo * 512 );
+			}
+		const float last_time = big.frame_to_time( float( F - 1 ) );
+		PV mt_big = big.modify_time( [=]( TF tf ){ return tf.t * 0.5f + ( tf.f > 12000.0f ? 0.25f : 0.0f ); } );   // its length comes from the grid's maximum
+		CHECK( mt_big.get_num_frames() == Frame( std::ceil( big.time_to_frame( last_time * 0.5f + 0.25f ) ) ) );
+		flanhip_free( d_grid ); flanhip_free( d_max ); flanhip_free( d_out );
+		}
 	}
 
 int main( int argc, char ** argv )
