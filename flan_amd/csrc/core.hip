@@ -255,6 +255,23 @@ int flanhip_memset( void * dst, int value, size_t bytes, void * stream )
 	return FLANHIP_OK;
 	}
 
+int flanhip_stream_create( void ** stream )
+	{
+	FLANHIP_REQUIRE( stream, FLANHIP_ERR_INVALID_ARG, "null out pointer" );
+	if( int rc = require_device() ) return rc;
+	hipStream_t s = nullptr;
+	FLANHIP_CHECK( hipStreamCreateWithFlags( &s, hipStreamNonBlocking ) );
+	*stream = s;
+	return FLANHIP_OK;
+	}
+
+int flanhip_stream_destroy( void * stream )
+	{
+	if( !stream ) return FLANHIP_OK;
+	FLANHIP_CHECK( hipStreamDestroy( (hipStream_t) stream ) );
+	return FLANHIP_OK;
+	}
+
 int flanhip_stream_synchronize( void * stream )
 	{
 	FLANHIP_CHECK( hipStreamSynchronize( (hipStream_t) stream ) );

@@ -57,6 +57,49 @@ std::shared_ptr<DeviceBlock> function_grid_to_device( const PV & me, const Funct
 	return b;
 	}
 
+// A callable that must see the PV's own data (modify_frequency's mod at every MF's frequency, PVModify.cpp:263-268; shape's
+// shaper, PV.cpp:435-436) runs on the host: body( row, row's MFs, row's outputs ) for every (channel, frame) row, results on the
+// device.  When the data lives on the device only it is NOT brought into the PV's host vector: it comes over in slabs of rows
+// through page-locked memory, slab k+1 on its way down and slab k-1 on its way up while slab k is evaluated.
+template<typename Out, typename Body>
+std::shared_ptr<DeviceBlock> map_rows_to_device( const PV & me, ExecutionPolicy policy, const Body & body )
+	{
+	const int rows = int( size_t( me.get_num_channels() ) * me.get_num_frames() ), bins = me.get_num_bins();
+	const size_t count = size_t( rows ) * bins;
+	auto d_out = DeviceBlock::allocate( sizeof( Out ) * count );
+	if( !d_out ) return nullptr;
+	detail::StagingVector<Out> out( count );
+	const bool on_host = me.host_copy_is_current();
+	const MF * d_in = on_host ? nullptr : me.device_data();
+	if( !on_host && !d_in ) return nullptr;
+	detail::StagingVector<MF> in( on_host ? 0 : count );
+	const MF * src = on_host ? me.get_buffer().data() : in.data();
+	const int slabs = std::max( 1, std::min<int>( 16, int( count * sizeof( MF ) >> 22 ) ) );
+	const detail::CopyStreams streams = detail::copy_streams();                  // downloads and uploads on a stream each: both directions of the link at once
+	auto slab_begin = [&]( int k ){ return int( int64_t( rows ) * k / slabs ); };
+	auto fetch = [&]( int k )
+		{
+		if( on_host || k >= slabs ) return true;
+		const size_t lo = size_t( slab_begin( k ) ) * bins, hi = size_t( slab_begin( k + 1 ) ) * bins;
+		return hi <= lo || detail::report( flanhip_memcpy_d2h( in.data() + lo, d_in + lo, sizeof( MF ) * ( hi - lo ), streams.down ), "download" );
+		};
+	if( !detail::report( flanhip_stream_synchronize( nullptr ), "synchronise" ) ) return nullptr;   // whatever produced the data has finished
+	if( !fetch( 0 ) || !detail::report( flanhip_stream_synchronize( streams.down ), "download" ) ) return nullptr;
+	bool ok = true;
+	for( int k = 0; k < slabs && ok; ++k )
+		{
+		ok = fetch( k + 1 );
+		const int r0 = slab_begin( k ), r1 = slab_begin( k + 1 );
+		detail::for_each_index( r0, r1, policy, [&]( int row ){ body( row, src + size_t( row ) * bins, out.data() + size_t( row ) * bins ); }, 16 );
+		const size_t lo = size_t( r0 ) * bins, hi = size_t( r1 ) * bins;
+		if( ok && hi > lo ) ok = detail::report( flanhip_memcpy_h2d( static_cast<Out*>( d_out->ptr ) + lo, out.data() + lo, sizeof( Out ) * ( hi - lo ), streams.up ), "upload" );
+		ok = detail::report( flanhip_stream_synchronize( streams.down ), "download" ) && ok;       // slab k+1 is here
+		}
+	ok = detail::report( flanhip_stream_synchronize( streams.up ), "upload" ) && ok;               // before the staging blocks go back to their cache
+	if( !ok ) return nullptr;
+	return d_out;
+	}
+
 // FunctionSample::maximum (FunctionSample.h:156-160) = std::max_element, over the rows in parallel.  Its answer with NaNs in
 // the grid: the first element if that is a NaN, else the largest of the others.
 float grid_maximum( const FunctionSample2d<float> & s, ExecutionPolicy policy )
@@ -207,18 +250,11 @@ PV PV::modify_frequency( const Function<TF, Frequency> & mod, const Interpolator
 	auto d_mod = function_grid_to_device( *this, mod );                            // PVModify.cpp:261
 	if( !d_mod ) return PV();
 	// :263-268: the callable is evaluated at every MF's own (time, frequency): data dependent, so on the host
-	const std::vector<MF> & data = get_buffer();
-	detail::StagingVector<float> in_modified( data.size() );
-	const size_t per_channel = size_t( get_num_frames() ) * get_num_bins();
-	detail::for_each_index( 0, int( size_t( get_num_channels() ) * get_num_frames() ), mod.get_execution_policy(), [&]( int row )
+	auto d_in = map_rows_to_device<float>( *this, mod.get_execution_policy(), [&]( int row, const MF * mfs, float * out )
 		{
-		const Frame frame = Frame( row % get_num_frames() );
-		const size_t base = size_t( row ) * get_num_bins();
-		for( Bin bin = 0; bin < get_num_bins(); ++bin )
-			in_modified[base + bin] = mod( TF{ frame_to_time( fFrame( frame ) ), data[base + bin].f } );
-		}, 16 );
-	(void) per_channel;
-	auto d_in = upload( in_modified.data(), sizeof( float ) * in_modified.size() );
+		const Second t = frame_to_time( fFrame( Frame( row % get_num_frames() ) ) );
+		for( Bin bin = 0; bin < get_num_bins(); ++bin ) out[bin] = mod( TF{ t, mfs[bin].f } );
+		} );
 	if( !d_in ) return PV();
 	return modify_frequency_device( *this, *d_mod, *d_in );
 	}
@@ -242,16 +278,10 @@ PV PV::shape( const Function<MF, MF> & shaper, bool use_shift_alignment ) const
 	{
 	if( is_null() ) return PV();
 	// PV.cpp:435-436: the shaper sees every MF: evaluated on the host, the placement rule runs on the device
-	const std::vector<MF> & data = get_buffer();
-	detail::StagingVector<MF> shaped( data.size() );
-	detail::for_each_index( 0, int( size_t( get_num_channels() ) * get_num_frames() ), shaper.get_execution_policy(), [&]( int row )
-		{
-		const size_t base = size_t( row ) * get_num_bins();
-		for( Bin bin = 0; bin < get_num_bins(); ++bin ) shaped[base + bin] = shaper( data[base + bin] );
-		}, 16 );
-	auto d_shaped = upload( shaped.data(), sizeof( MF ) * shaped.size() );
+	auto d_shaped = map_rows_to_device<MF>( *this, shaper.get_execution_policy(), [&]( int, const MF * mfs, MF * out )
+		{ for( Bin bin = 0; bin < get_num_bins(); ++bin ) out[bin] = shaper( mfs[bin] ); } );
 	const MF * d_pv = device_data();
-	auto out = DeviceBlock::allocate( sizeof( MF ) * shaped.size() );
+	auto out = DeviceBlock::allocate( sizeof( MF ) * size_t( get_num_channels() ) * get_num_frames() * get_num_bins() );
 	if( !d_shaped || !d_pv || !out ) return PV();
 	if( !detail::report( flanhip_shape_table_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), static_cast<const flanhip_MF*>( d_shaped->ptr ), get_num_channels(),
 			get_num_frames(), get_num_bins(), get_sample_rate(), use_shift_alignment ? 1 : 0, static_cast<flanhip_MF*>( out->ptr ), nullptr ), "shape" ) ) return PV();

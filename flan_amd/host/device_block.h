@@ -12,7 +12,9 @@ namespace flan { namespace detail {
 // so a block whose owner dies is idle); flanhip_malloc / flanhip_free only when the cache cannot serve.
 void * device_acquire( size_t bytes, size_t * capacity );   // nullptr on failure (flanhip_last_error() says why)
 void device_release( void * ptr, size_t capacity ) noexcept;
-void device_cache_flush() noexcept;                          // give every idle block back to the device
+void device_cache_flush() noexcept;
+struct CopyStreams { void * down = nullptr, * up = nullptr; };  // one per direction, created once; both null when creation failed
+CopyStreams copy_streams();                          // give every idle block back to the device
 
 struct DeviceBlock
 	{

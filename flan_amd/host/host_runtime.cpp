@@ -180,6 +180,17 @@ void device_cache_flush() noexcept
 	for( auto & s : drop ) flanhip_free( s.first );
 	}
 
+CopyStreams copy_streams()
+	{
+	static const CopyStreams streams = []
+		{
+		CopyStreams c;
+		if( flanhip_stream_create( &c.down ) != FLANHIP_OK || flanhip_stream_create( &c.up ) != FLANHIP_OK ) c.down = c.up = nullptr;
+		return c;
+		}();
+	return streams;
+	}
+
 int host_workers() { return int( pool().threads.size() ) + 1; }
 
 void pool_run( int n_tasks, void ( *fn )( void *, int ), void * ctx )

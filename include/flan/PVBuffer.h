@@ -71,6 +71,7 @@ public:
 	// ---- device residency (MI355X) ----
 	bool is_device_resident() const { return bool( dev ); }
 	const MF * device_data() const;
+	bool host_copy_is_current() const { return host_valid; }                                             // false: the data lives on the device only
 	static PVBuffer adopt_device( const Format &, std::shared_ptr<detail::DeviceBlock> );
 	/** convert_to_PV leaves convert_to_audio's pre-pass (per-chain phase sums, in a synthesis workspace) next to the data; it is
 	 *  valid while the data is untouched and is consumed by the first convert_to_audio (flanhip_*_fused in flanhip.h). */

@@ -63,6 +63,10 @@ int flanhip_memcpy_h2d(void * dst, const void * src, size_t bytes, void * stream
 int flanhip_memcpy_d2h(void * dst, const void * src, size_t bytes, void * stream);
 int flanhip_memset(void * dst, int value, size_t bytes, void * stream);
 int flanhip_stream_synchronize(void * stream);
+/* a stream of the caller's own (e.g. one per copy direction, so that a download and an upload overlap); every entry point
+ * that takes `void * stream` accepts it, NULL stays the default stream */
+int flanhip_stream_create(void ** stream);
+int flanhip_stream_destroy(void * stream);
 /* page-locked host memory: what a caller samples a Function grid into (Function.h:155-171) so that the upload runs at the
  * link's rate instead of through the runtime's staging copy.  Needs a device. */
 int flanhip_host_malloc(void ** hptr, size_t bytes);

@@ -10,6 +10,7 @@
 #include <iostream>
 #include <string>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "flan/flan.h"
@@ -300,6 +301,21 @@ static void device_checks()
 		PV mt_big = big.modify_time( [=]( TF tf ){ return tf.t * 0.5f + ( tf.f > 12000.0f ? 0.25f : 0.0f ); } );   // its length comes from the grid's maximum
 		CHECK( mt_big.get_num_frames() == Frame( std::ceil( big.time_to_frame( last_time * 0.5f + 0.25f ) ) ) );
 		flanhip_free( d_grid ); flanhip_free( d_max ); flanhip_free( d_out );
+		// callables that see the data: the device-only PV goes through the slab pipeline, a PV with a current host copy is read in
+		// place; both must give what the device-evaluated affine shaper gives
+		CHECK( !big.host_copy_is_current() );
+		PV sh_slab = big.shape( []( MF mf ){ return MF{ mf.m * 0.5f, mf.f + 100.0f }; } );
+		CHECK( !big.host_copy_is_current() );                                         // shape() did not drag the PV to the host
+		PV sh_dev = big.shape_affine( 0.5f, 0.0f, 1.0f, 100.0f );
+		CHECK( std::memcmp( sh_slab.get_buffer().data(), sh_dev.get_buffer().data(), sizeof( MF ) * sh_dev.get_buffer().size() ) == 0 );
+		PV on_host = big.copy();
+		(void) std::as_const( on_host ).get_buffer();
+		CHECK( on_host.host_copy_is_current() );
+		PV sh_host = on_host.shape( []( MF mf ){ return MF{ mf.m * 0.5f, mf.f + 100.0f }; } );
+		CHECK( std::memcmp( sh_host.get_buffer().data(), sh_dev.get_buffer().data(), sizeof( MF ) * sh_dev.get_buffer().size() ) == 0 );
+		const auto bend = []( TF tf ){ return tf.f * ( 1.0f + 0.1f * tf.t ) + 20.0f; };
+		PV mf_slab = big.modify_frequency( bend ), mf_host = on_host.modify_frequency( bend );
+		CHECK( !mf_slab.is_null() && std::memcmp( mf_slab.get_buffer().data(), mf_host.get_buffer().data(), sizeof( MF ) * mf_host.get_buffer().size() ) == 0 );
 		}
 	}
 
