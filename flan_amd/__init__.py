@@ -77,6 +77,14 @@ _SIGS = {
     "flanhip_n_loudest_partials_dev": (C.c_int, [_vp, _i64, _i64, _i32, _vp, C.c_int32, _i32, _vp, _vp]),
     "flanhip_desample_dev": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _f32, _i32, _vp, _vp]),
     "flanhip_time_extrapolate_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "flanhip_get_frame_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i32, _vp, _vp]),
+    "flanhip_select_frames_dev": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp]),
+    "flanhip_freeze_plan": (_i64, [_i64, _f32, _i32, _vp, _vp, _i32, _vp]),
+    "flanhip_cut_frames_range": (C.c_int, [_i64, _i32, _i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "flanhip_cut_frames_dev": (C.c_int, [_vp, _i64, _i64, _i32, _i64, _i64, _vp, _vp]),
+    "flanhip_place_frames_dev": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _i64, _i64, _i32, _i64, _vp]),
+    "flanhip_select_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i32, _vp, _i64, _vp, _vp]),
+    "flanhip_harmonic_scale_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _i32, _i32, _vp, _vp]),
     "flanhip_mid_side_dev": (C.c_int, [_vp, _i64, _vp, _vp]),
     "flanhip_resample_out_frames": (_i64, [_i64, _f32, _f32]),
     "flanhip_resample": (C.c_int, [_vp, _i64, _i64, _f32, _f32, _vp, _vp]),
@@ -295,6 +303,101 @@ def time_extrapolate(pv, sample_rate, start_frame, end_frame, out_frames, interp
     check(lib.flanhip_time_extrapolate_dev(_vp(d_pv.ptr), ch, F, bins, sample_rate, start_frame, end_frame, out_frames,
                                            _vp(d_s.ptr), _vp(d_out.ptr), None))
     return d_out.to_host((ch, out_frames, bins, 2))
+
+
+def get_frame(pv, frame_pos, interp=0):
+    """PV::get_frame at the (already clamped) fractional frame position.  Returns [ch][1][bins][2]"""
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    d_pv, d_out = DeviceArray(host=pv), DeviceArray(ch * bins * 8)
+    check(lib.flanhip_get_frame_dev(_vp(d_pv.ptr), ch, F, bins, frame_pos, interp, _vp(d_out.ptr), None))
+    return d_out.to_host((ch, 1, bins, 2))
+
+
+def freeze_plan(num_frames, sample_rate, hop, times, lengths):
+    """PV::freeze's timing logic: int32 [out_frames], the input frame of every output frame (-1: stays zero)"""
+    times = np.ascontiguousarray(times, np.float32)
+    lengths = np.ascontiguousarray(lengths, np.float32)
+    assert times.shape == lengths.shape and times.ndim == 1
+    n = len(times)
+    tp = times.ctypes.data_as(_vp) if n else None
+    lp = lengths.ctypes.data_as(_vp) if n else None
+    Fo = lib.flanhip_freeze_plan(num_frames, sample_rate, hop, tp, lp, n, None)
+    if Fo < 0:
+        raise FlanHipError("flanhip_freeze_plan: bad arguments")
+    src = np.empty(Fo, np.int32)
+    lib.flanhip_freeze_plan(num_frames, sample_rate, hop, tp, lp, n, src.ctypes.data_as(_vp))
+    return src
+
+
+def select_frames(pv, src_frames):
+    """out[c][o] = pv[c][src_frames[o]], zero where src_frames[o] < 0 (the copy loops of PV::freeze)"""
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    src = np.ascontiguousarray(src_frames, np.int32)
+    Fo = len(src)
+    d_pv, d_src, d_out = DeviceArray(host=pv), DeviceArray(host=src), DeviceArray(ch * Fo * bins * 8)
+    check(lib.flanhip_select_frames_dev(_vp(d_pv.ptr), ch, F, bins, _vp(d_src.ptr), Fo, _vp(d_out.ptr), None))
+    return d_out.to_host((ch, Fo, bins, 2))
+
+
+def freeze(pv, sample_rate, hop, times, lengths):
+    """PV::freeze"""
+    return select_frames(pv, freeze_plan(np.shape(pv)[1], sample_rate, hop, times, lengths))
+
+
+def cut_frames(pv, start, end):
+    """PV::cut_frames; None for the null PV the reference returns"""
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    s, c = C.c_int32(0), C.c_int32(0)
+    check(lib.flanhip_cut_frames_range(F, start, end, C.byref(s), C.byref(c)))
+    if c.value <= 0:
+        return None
+    d_pv, d_out = DeviceArray(host=pv), DeviceArray(ch * c.value * bins * 8)
+    check(lib.flanhip_cut_frames_dev(_vp(d_pv.ptr), ch, F, bins, s.value, c.value, _vp(d_out.ptr), None))
+    return d_out.to_host((ch, c.value, bins, 2))
+
+
+def join(pvs):
+    """PV::join: the format of the first input, the frames of all of them one after the other"""
+    pvs = [np.ascontiguousarray(p, np.float32) for p in pvs]
+    ch, _, bins, _ = pvs[0].shape
+    Fo = sum(p.shape[1] for p in pvs)
+    d_out = DeviceArray(ch * Fo * bins * 8)
+    check(lib.flanhip_memset(_vp(d_out.ptr), 0, ch * Fo * bins * 8, None))
+    at = 0
+    for p in pvs:
+        d_in = DeviceArray(host=p)
+        check(lib.flanhip_place_frames_dev(_vp(d_in.ptr), p.shape[0], p.shape[1], p.shape[2], _vp(d_out.ptr), ch, Fo, bins, at, None))
+        check(lib.flanhip_stream_synchronize(None))
+        at += p.shape[1]
+    return d_out.to_host((ch, Fo, bins, 2))
+
+
+def select(pv, sample_rate, hop, selector_tf):
+    """PV::select.  selector_tf: float32 [out_frames][bins][2] = the selector sampled over the output's domain"""
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    sel = np.ascontiguousarray(selector_tf, np.float32)
+    Fo = sel.shape[0]
+    assert sel.shape == (Fo, bins, 2)
+    d_pv, d_sel, d_out = DeviceArray(host=pv), DeviceArray(host=sel), DeviceArray(ch * Fo * bins * 8)
+    check(lib.flanhip_select_dev(_vp(d_pv.ptr), ch, F, bins, sample_rate, hop, _vp(d_sel.ptr), Fo, _vp(d_out.ptr), None))
+    return d_out.to_host((ch, Fo, bins, 2))
+
+
+def harmonic_scale(pv, sample_rate, series, mode):
+    """PV::add_octaves (mode 0) / PV::add_harmonics (mode 1).  series: float32 [F][H]"""
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    series = np.ascontiguousarray(series, np.float32)
+    assert series.ndim == 2 and series.shape[0] == F
+    H = series.shape[1]
+    d_pv, d_out = DeviceArray(host=pv), DeviceArray(pv.nbytes)
+    d_s = DeviceArray(host=series) if H else None
+    check(lib.flanhip_harmonic_scale_dev(_vp(d_pv.ptr), ch, F, bins, sample_rate, _vp(d_s.ptr) if d_s else None, H, mode, _vp(d_out.ptr), None))
+    return d_out.to_host(pv.shape)
 
 
 # ---------------------------------------------------------------------------------------------------------------

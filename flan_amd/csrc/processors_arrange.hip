@@ -1,0 +1,300 @@
+// processors_arrange.hip -- the PV methods that select, rearrange and re-place frames and bins, behind the C ABI:
+// get_frame (PV/PV.cpp:24-39), select (:92-127), freeze (:129-198), cut_frames (:643-668), join (:698-720),
+// add_octaves / add_harmonics (:362-419).
+//
+// All but the last are gathers: every output MF is one input MF (or a blend of two), so they run at the rate HBM moves 8 B in and
+// 8 B out per MF.  A block owns one output row (channel, frame) and walks its bins: no index division per element, rows coalesced.
+// add_octaves / add_harmonics scatter every bin to the bins of its overtones with a "strictly louder replaces" rule in a fixed
+// visiting order; a block resolves one row through ds_max_u64 keys in LDS ( magnitude bits << 32 | ~visiting index ), like the
+// placement rule of shape / time_extrapolate (processors_common.h).
+#include "processors_common.h"
+#include <algorithm>
+
+namespace flanhip {
+
+// PV.cpp:24-39 with getBinInterpolated( Channel, float frame, Bin ), :62-73.  grid = ( ceil(bins/256), channels )
+__global__ __launch_bounds__( 256 ) void k_get_frame( const MFd * in, int64_t F, int bins, int64_t lo, int64_t hi, float mix, MFd * out )
+	{
+	const int bin = blockIdx.x * 256 + threadIdx.x;
+	if( bin >= bins ) return;
+	const int64_t channel = blockIdx.y;
+	const MFd l = in[( channel * F + lo ) * bins + bin], h = in[( channel * F + hi ) * bins + bin];
+	out[channel * bins + bin] = MFd{ ( 1.0f - mix ) * l.m + mix * h.m, ( 1.0f - mix ) * l.f + mix * h.f };   // :69-72
+	}
+
+// out[c][o][:] = in[c][src(o)][:], zero where src(o) is not a frame of the input; src(o) = src[o], or start + o when src is null.
+// freeze's copy loops (PV.cpp:176-195) and cut_frames (:660-665).  One block per output row.
+__global__ __launch_bounds__( 256 ) void k_select_frames( const MFd * in, int64_t F, int bins, const int * src, int64_t start, int64_t Fo, MFd * out )
+	{
+	const int64_t row = blockIdx.x;                                                   // channel * Fo + o
+	const int64_t o = row % Fo, channel = row / Fo;
+	const int64_t s = src ? int64_t( src[o] ) : start + o;
+	MFd * op = out + row * bins;
+	if( s < 0 || s >= F ) { for( int b = threadIdx.x; b < bins; b += 256 ) op[b] = MFd{ 0.0f, 0.0f }; return; }
+	const MFd * ip = in + ( channel * F + s ) * bins;
+	for( int b = threadIdx.x; b < bins; b += 256 ) op[b] = ip[b];
+	}
+
+// one input of join (PV.cpp:708-716): its rows to out rows [out_start, out_start + in_F), the channels and bins both have
+__global__ __launch_bounds__( 256 ) void k_place_frames( const MFd * in, int64_t in_F, int in_bins, MFd * out, int64_t out_F, int out_bins, int64_t out_start, int copy_bins )
+	{
+	const int64_t row = blockIdx.x;                                                   // channel * in_F + frame
+	const int64_t fr = row % in_F, channel = row / in_F;
+	const MFd * ip = in + row * in_bins;
+	MFd * op = out + ( channel * out_F + out_start + fr ) * out_bins;
+	for( int b = threadIdx.x; b < copy_bins; b += 256 ) op[b] = ip[b];
+	}
+
+// PV.cpp:106-123.  selector: TF[Fo][bins] as float2 ( t, f ).  One block per output row.
+__global__ __launch_bounds__( 256 ) void k_select( const MFd * in, int64_t F, int bins, float sr, float hop, float dft, const float2 * selector, int64_t Fo, MFd * out )
+	{
+	const int64_t row = blockIdx.x;
+	const int64_t fr = row % Fo, channel = row / Fo;
+	const float2 * sp = selector + fr * bins;
+	MFd * op = out + row * bins;
+	for( int b = threadIdx.x; b < bins; b += 256 )
+		{
+		const float2 s = sp[b];                                                       // :110
+		const int sf = to_int_sat( time_to_frame( s.x, sr, hop ) );                   // :111
+		const int sb = to_int_sat( frequency_to_bin( s.y, sr, dft ) );                // :112
+		MFd m{ 0.0f, 0.0f };
+		if( !( sf < 0 || F - 1 <= sf || sb < 0 || bins - 1 <= sb ) )                  // :114-116
+			{
+			m = in[( channel * F + sf ) * bins + sb];
+			if( s.y > 1.0f ) m.f *= bin_to_frequency( float( b ), sr, dft ) / s.y;    // :119-120
+			}
+		op[b] = m;
+		}
+	}
+
+// PV.cpp:381-404 for one (channel, frame) row per block.  MODE 0: octaves, f * pow( 2, h ) in double, rounded once (:411);
+// MODE 1: harmonics, f * ( h + 1 ) in fp32 (:417), h the 1-based harmonic number.  Visiting order of the reference: source bins
+// ascending, harmonics ascending inside; a candidate replaces the occupant only if strictly louder, the row starting from zeros.
+template<int MODE>
+__device__ __forceinline__ float harmonic_frequency( float f, int hh )
+	{
+	return MODE == 0 ? float( ldexp( double( f ), hh ) ) : f * float( hh + 1 );
+	}
+
+constexpr int kWideBins = 64;              // the lowest bins have up to `bins` overtones each: a wavefront shares one such bin's overtones
+
+// LDS: keys[bins]; when `staged`, also the input row and the row of the series (every offer reads both: from LDS the walk over a
+// bin's overtones costs LDS latency per step instead of an L2 round trip).
+template<int MODE>
+__global__ __launch_bounds__( 256 ) void k_harmonic_scale( const MFd * in, int64_t F, int bins, float sr, float dft, const float * series, int H, int staged, MFd * out )
+	{
+	extern __shared__ unsigned long long keys[];                                      // [bins] (+ MFd[bins] + float[H])
+	const int64_t row = blockIdx.x;
+	const int64_t fr = row % F;
+	const MFd * ip = in + row * bins;
+	const float * sp = series + fr * H;
+	for( int b = threadIdx.x; b < bins; b += 256 ) keys[b] = 0ull;
+	if( staged )
+		{
+		MFd * lrow = reinterpret_cast<MFd*>( keys + bins );
+		float * lser = reinterpret_cast<float*>( lrow + bins );
+		for( int b = threadIdx.x; b < bins; b += 256 ) lrow[b] = ip[b];
+		for( int h = threadIdx.x; h < H; h += 256 ) lser[h] = sp[h];
+		ip = lrow; sp = lser;
+		}
+	__syncthreads();
+	auto offer = [&]( int b, const MFd source, int h ) -> bool                        // false: this and every later overtone is past the last bin
+		{
+		const float hf = harmonic_frequency<MODE>( source.f, h + 1 );                 // :393
+		const int hb = to_int_sat( frequency_to_bin( hf, sr, dft ) );                 // :394
+		if( hb >= bins ) return false;                                                // :395
+		const float mag = source.m * sp[h];                                           // :398
+		if( hb >= 0 && mag > 0.0f )                                                   // :399: beats the initial 0 or a quieter occupant; false for NaN
+			atomicMax( &keys[hb], ( (unsigned long long) __float_as_uint( mag ) << 32 ) | (unsigned long long) ( 0xFFFFFFFFu - unsigned( b * H + h ) ) );
+		return true;
+		};
+	const int wide = MODE == 1 ? min( kWideBins, bins ) : 0;
+	for( int b = threadIdx.x >> 6; b < wide; b += 4 )                                 // one wavefront per low bin, lanes over its overtones
+		{
+		const MFd source = ip[b];
+		if( !( source.f <= 1.0f ) )                                                   // :389
+			for( int h = threadIdx.x & 63; h < H; h += 64 ) if( !offer( b, source, h ) ) break;   // overtone bins never decrease with h
+		}
+	for( int b = wide + threadIdx.x; b < bins; b += 256 )
+		{
+		const MFd source = ip[b];
+		if( source.f <= 1.0f ) continue;
+		for( int h = 0; h < H; ++h ) if( !offer( b, source, h ) ) break;
+		}
+	__syncthreads();
+	MFd * op = out + row * bins;
+	for( int b = threadIdx.x; b < bins; b += 256 )
+		{
+		const unsigned long long key = keys[b];
+		MFd r{ 0.0f, 0.0f };
+		if( key )
+			{
+			const unsigned seq = 0xFFFFFFFFu - unsigned( key & 0xFFFFFFFFull );
+			const int sb = int( seq / unsigned( H ) ), h = int( seq % unsigned( H ) );
+			r = MFd{ __uint_as_float( unsigned( key >> 32 ) ), harmonic_frequency<MODE>( ip[sb].f, h + 1 ) };   // :400
+			}
+		op[b] = r;
+		}
+	}
+
+} // namespace flanhip
+
+using namespace flanhip;
+
+extern "C" {
+
+int flanhip_get_frame_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float frame_pos, int interp_kind, flanhip_MF * d_out, void * stream )
+	{
+	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, 1.0f ) ) return rc;
+	FLANHIP_REQUIRE( frame_pos >= 0.0f && frame_pos <= float( F - 1 ), FLANHIP_ERR_INVALID_ARG, "frame position outside [0, F-1] (PV.cpp:28 clamps it)" );
+	FLANHIP_REQUIRE( interp_kind >= 0 && interp_kind <= FLANHIP_INTERP_SINE, FLANHIP_ERR_INVALID_ARG, "unknown interpolator" );
+	FLANHIP_REQUIRE( ch <= 65535, FLANHIP_ERR_INVALID_ARG, "too many channels" );
+	const float lo = std::floor( frame_pos ), hi = std::ceil( frame_pos );
+	float x = frame_pos - lo, mix = x;                                                // PV.cpp:67: the interpolator of [0,1) -> [0,1]
+	switch( interp_kind )                                                             // Utility/Interpolator.cpp:14-101, one value: on the host
+		{
+		case FLANHIP_INTERP_MIDPOINT: mix = 0.5f; break;
+		case FLANHIP_INTERP_NEAREST: mix = std::round( x ); break;
+		case FLANHIP_INTERP_FLOOR: mix = 0.0f; break;
+		case FLANHIP_INTERP_CEIL: mix = 1.0f; break;
+		case FLANHIP_INTERP_SMOOTHSTEP: mix = x * x * ( 3.0f - 2.0f * x ); break;
+		case FLANHIP_INTERP_SMOOTHERSTEP: mix = x * x * x * ( x * ( x * 6.0f - 15.0f ) + 10.0f ); break;
+		case FLANHIP_INTERP_SQRT: mix = std::sqrt( x ); break;
+		case FLANHIP_INTERP_SINE: mix = ( 1.0f - std::cos( std::acos( -1.0f ) * x ) ) / 2.0f; break;
+		default: break;
+		}
+	hipLaunchKernelGGL( k_get_frame, dim3( ( bins + 255 ) / 256, unsigned( ch ) ), dim3( 256 ), 0, (hipStream_t) stream, (const MFd*) d_pv, F, bins,
+		int64_t( lo ), int64_t( hi ), mix, (MFd*) d_out );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+static int select_frames( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, const int32_t * d_src, int64_t start, int64_t Fo, flanhip_MF * d_out, void * stream )
+	{
+	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, 1.0f ) ) return rc;
+	FLANHIP_REQUIRE( Fo > 0 && ch * Fo < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_INVALID_ARG, "bad output frame count" );
+	hipLaunchKernelGGL( k_select_frames, dim3( unsigned( ch * Fo ) ), dim3( 256 ), 0, (hipStream_t) stream, (const MFd*) d_pv, F, bins, d_src, start, Fo, (MFd*) d_out );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+int flanhip_select_frames_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, const int32_t * d_src_frames, int64_t out_frames, flanhip_MF * d_out, void * stream )
+	{
+	FLANHIP_REQUIRE( d_src_frames, FLANHIP_ERR_INVALID_ARG, "null frame map" );
+	return select_frames( d_pv, ch, F, bins, d_src_frames, 0, out_frames, d_out, stream );
+	}
+
+int flanhip_cut_frames_range( int64_t F, int32_t start, int32_t end, int32_t * start_out, int32_t * count_out )
+	{
+	FLANHIP_REQUIRE( start_out && count_out, FLANHIP_ERR_INVALID_ARG, "null out pointer" );
+	*start_out = 0; *count_out = 0;
+	if( end <= start || F <= 0 ) return FLANHIP_OK;                                   // PV.cpp:651: a null PV
+	start = std::clamp( start, int32_t( 0 ), int32_t( F - 1 ) );                      // :652-653
+	end = std::clamp( end, int32_t( 0 ), int32_t( F - 1 ) );
+	*start_out = start; *count_out = std::max( end - start, 0 );
+	return FLANHIP_OK;
+	}
+
+int flanhip_cut_frames_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, int64_t start, int64_t count, flanhip_MF * d_out, void * stream )
+	{
+	FLANHIP_REQUIRE( start >= 0 && count > 0 && start + count <= F, FLANHIP_ERR_INVALID_ARG, "frame range outside the PV" );
+	return select_frames( d_pv, ch, F, bins, nullptr, start, count, d_out, stream );
+	}
+
+int64_t flanhip_freeze_plan( int64_t F, float sr, int hop, const float * times, const float * lengths, int n, int32_t * src_frames )
+	{
+	if( F <= 0 || F > INT32_MAX || hop < 1 || !( sr > 0.0f ) || n < 0 || ( n > 0 && ( !times || !lengths ) ) ) return -1;
+	auto to_frame = [&]( float seconds )                                              // Frame( time_to_frame( t ) ), PVBuffer.cpp:428-431, saturating
+		{
+		const float v = seconds * sr / float( hop );
+		if( !( v == v ) ) return INT32_MIN;
+		if( v >= 2147483648.0f ) return INT32_MAX;
+		if( v <= -2147483648.0f ) return INT32_MIN;
+		return int32_t( v );
+		};
+	struct Event { int32_t frame, length; };
+	std::vector<Event> ev( static_cast<size_t>( n ) );
+	for( int i = 0; i < n; ++i )                                                      // PV.cpp:150-156
+		ev[size_t( i )] = Event{ std::clamp( to_frame( times[i] ), int32_t( 0 ), int32_t( F - 1 ) ), std::max( to_frame( lengths[i] ), int32_t( 0 ) ) };
+	// :159-165: sorted by frame, one event per frame.  The reference's sort is not stable, so WHICH of several events on one frame
+	// survives is unspecified there; here it is the first one given.
+	std::stable_sort( ev.begin(), ev.end(), []( const Event & a, const Event & b ){ return a.frame < b.frame; } );
+	ev.erase( std::unique( ev.begin(), ev.end(), []( const Event & a, const Event & b ){ return a.frame == b.frame; } ), ev.end() );
+	float total = 0;                                                                  // :167-168: a float
+	for( const Event & e : ev ) total += float( e.length );
+	const float frames_f = float( int32_t( F ) ) + total;                             // :170-171
+	if( !( frames_f < 2147483648.0f ) ) return -1;
+	const int64_t Fo = int64_t( frames_f );
+	if( !src_frames ) return Fo;
+	std::fill( src_frames, src_frames + Fo, int32_t( -1 ) );                          // frames the loops never reach stay zero
+	size_t k = 0;
+	int64_t o = 0;
+	for( int64_t in = 0; in < F; ++in )                                               // :176-195
+		{
+		if( k < ev.size() && in == ev[k].frame )
+			{
+			for( int32_t r = 0; r < ev[k].length; ++r, ++o ) if( o < Fo ) src_frames[o] = int32_t( in );
+			++k;
+			}
+		else { if( o < Fo ) src_frames[o] = int32_t( in ); ++o; }
+		}
+	return Fo;
+	}
+
+int flanhip_place_frames_dev( const flanhip_MF * d_in, int64_t in_ch, int64_t in_F, int in_bins, flanhip_MF * d_out, int64_t out_ch, int64_t out_F, int out_bins,
+	int64_t out_start, void * stream )
+	{
+	FLANHIP_REQUIRE( d_in && d_out, FLANHIP_ERR_INVALID_ARG, "null buffer" );
+	FLANHIP_REQUIRE( in_ch > 0 && in_F > 0 && in_bins > 0 && out_ch > 0 && out_F > 0 && out_bins > 0, FLANHIP_ERR_INVALID_ARG, "bad sizes" );
+	FLANHIP_REQUIRE( out_start >= 0 && out_start + in_F <= out_F, FLANHIP_ERR_INVALID_ARG, "frames do not fit the output" );
+	if( int rc = require_device() ) return rc;
+	const int64_t rows = std::min( in_ch, out_ch ) * in_F;
+	FLANHIP_REQUIRE( rows < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_INVALID_ARG, "too many rows" );
+	// rows of channels the output lacks are not visited: the grid covers min( in_ch, out_ch ) channels, which are the first ones
+	hipLaunchKernelGGL( k_place_frames, dim3( unsigned( rows ) ), dim3( 256 ), 0, (hipStream_t) stream, (const MFd*) d_in, in_F, in_bins, (MFd*) d_out, out_F, out_bins,
+		out_start, std::min( in_bins, out_bins ) );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+int flanhip_select_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, int hop, const float * d_selector_tf, int64_t out_frames,
+	flanhip_MF * d_out, void * stream )
+	{
+	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, sr ) ) return rc;
+	FLANHIP_REQUIRE( d_selector_tf && hop >= 1, FLANHIP_ERR_INVALID_ARG, "null selector grid or bad hop" );
+	FLANHIP_REQUIRE( out_frames > 0 && ch * out_frames < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_INVALID_ARG, "bad output frame count" );
+	hipLaunchKernelGGL( k_select, dim3( unsigned( ch * out_frames ) ), dim3( 256 ), 0, (hipStream_t) stream, (const MFd*) d_pv, F, bins, sr, float( hop ),
+		float( ( bins - 1 ) * 2 ), reinterpret_cast<const float2*>( d_selector_tf ), out_frames, (MFd*) d_out );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+int flanhip_harmonic_scale_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, const float * d_series, int num_harmonics, int mode,
+	flanhip_MF * d_out, void * stream )
+	{
+	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, sr ) ) return rc;
+	FLANHIP_REQUIRE( mode == 0 || mode == 1, FLANHIP_ERR_INVALID_ARG, "mode: 0 octaves, 1 harmonics" );
+	FLANHIP_REQUIRE( ch * F < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_INVALID_ARG, "too many rows" );
+	if( num_harmonics <= 0 )                                                          // no overtone is ever placed: the cleared output (PV.cpp:369-370)
+		{
+		FLANHIP_CHECK( hipMemsetAsync( d_out, 0, sizeof( MFd ) * size_t( ch ) * F * bins, (hipStream_t) stream ) );
+		return FLANHIP_OK;
+		}
+	FLANHIP_REQUIRE( d_series, FLANHIP_ERR_INVALID_ARG, "null series grid" );
+	FLANHIP_REQUIRE( int64_t( bins ) * num_harmonics < ( int64_t( 1 ) << 32 ), FLANHIP_ERR_UNSUPPORTED, "bins x harmonics does not fit the placement key" );
+	const size_t key_bytes = sizeof( unsigned long long ) * size_t( bins );
+	FLANHIP_REQUIRE( key_bytes <= 65536, FLANHIP_ERR_UNSUPPORTED, "dft sizes above 8192 are not supported by add_octaves / add_harmonics" );
+	const size_t staged_bytes = key_bytes + sizeof( MFd ) * size_t( bins ) + sizeof( float ) * size_t( num_harmonics );
+	const int staged = staged_bytes <= 65536 ? 1 : 0;                                 // input row and series row next to the keys when they fit
+	const size_t lds = staged ? staged_bytes : key_bytes;
+	if( mode == 0 )
+		hipLaunchKernelGGL( k_harmonic_scale<0>, dim3( unsigned( ch * F ) ), dim3( 256 ), lds, (hipStream_t) stream, (const MFd*) d_pv, F, bins, sr, float( ( bins - 1 ) * 2 ),
+			d_series, num_harmonics, staged, (MFd*) d_out );
+	else
+		hipLaunchKernelGGL( k_harmonic_scale<1>, dim3( unsigned( ch * F ) ), dim3( 256 ), lds, (hipStream_t) stream, (const MFd*) d_pv, F, bins, sr, float( ( bins - 1 ) * 2 ),
+			d_series, num_harmonics, staged, (MFd*) d_out );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+} // extern "C"

@@ -27,16 +27,26 @@ std::shared_ptr<DeviceBlock> upload( const void * host, size_t bytes )
 // host a slab of frames at a time into page-locked memory, each slab on its way over the link while the next is sampled.
 // `keep`, when given, receives the host copy (modify_time needs its maximum).
 template<typename T>
-std::shared_ptr<DeviceBlock> function_grid_to_device( const PV & me, const Function<TF, T> & f, FunctionSample2d<T> * keep = nullptr )
+std::shared_ptr<DeviceBlock> function_grid_to_device( const PV & me, const Function<TF, T> & f, FunctionSample2d<T> * keep = nullptr, Frame num_frames = -1 )
 	{
-	static_assert( sizeof( T ) == sizeof( float ), "float grids only" );
-	const int frames = me.get_num_frames(), bins = me.get_num_bins();
+	static_assert( std::is_trivially_copyable_v<T>, "plain grids only" );
+	const int frames = num_frames >= 0 ? num_frames : me.get_num_frames(), bins = me.get_num_bins();   // num_frames: a domain with this PV's rates but another length
 	const size_t count = size_t( frames ) * bins;
 	if( f.is_constant() )
 		{
-		auto b = DeviceBlock::allocate( sizeof( float ) * count );
+		auto b = DeviceBlock::allocate( sizeof( T ) * count );
 		if( !b ) return nullptr;
-		if( !detail::report( flanhip_fill_dev( static_cast<float*>( b->ptr ), int64_t( count ), float( f.get_constant() ), nullptr ), "fill" ) ) return nullptr;
+		if constexpr( std::is_same_v<T, float> )
+			{
+			if( !detail::report( flanhip_fill_dev( static_cast<float*>( b->ptr ), int64_t( count ), float( f.get_constant() ), nullptr ), "fill" ) ) return nullptr;
+			}
+		else
+			{
+			detail::StagingVector<T> host( count );
+			std::fill( host.begin(), host.end(), f.get_constant() );
+			if( !detail::report( flanhip_memcpy_h2d( b->ptr, host.data(), sizeof( T ) * count, nullptr ), "upload" ) ) return nullptr;
+			if( !detail::report( flanhip_stream_synchronize( nullptr ), "upload" ) ) return nullptr;
+			}
 		if( keep ) *keep = FunctionSample2d<T>{ f.get_constant(), count, size_t( bins ) };
 		return b;
 		}
@@ -423,6 +433,162 @@ PV PV::time_extrapolate( Second start_time, Second end_time, Second extrapolatio
 	const int rc = flanhip_time_extrapolate_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(),
 		get_sample_rate(), start_frame, end_frame, f.num_frames, static_cast<const float*>( d_samples->ptr ), static_cast<flanhip_MF*>( out->ptr ), nullptr );
 	return finish( rc, "time_extrapolate", f, std::move( out ) );
+	}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// selecting, rearranging and re-placing frames and bins (PV/PV.cpp:24-39, :92-198, :362-419, :643-727)
+// ---------------------------------------------------------------------------------------------------------------------
+PV PV::get_frame( Second time ) const
+	{
+	if( is_null() ) return PV();
+	const float selected = std::clamp( time_to_frame( time ), 0.0f, float( get_num_frames() - 1 ) );   // PV.cpp:28
+	PVBuffer::Format f = get_format();
+	f.num_frames = 1;                                                               // :30-31
+	const MF * d_pv = device_data();
+	auto out = DeviceBlock::allocate( sizeof( MF ) * mf_count( f ) );
+	if( !d_pv || !out ) return PV();
+	const int rc = flanhip_get_frame_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(), selected,
+		FLANHIP_INTERP_LINEAR, static_cast<flanhip_MF*>( out->ptr ), nullptr );
+	return finish( rc, "get_frame", f, std::move( out ) );
+	}
+
+PV PV::select( Second length, const Function<TF, TF> & selector ) const
+	{
+	if( is_null() ) return PV();
+	if( length <= 0.0f ) return PV();                                               // PV.cpp:98
+	PVBuffer::Format f = get_format();
+	f.num_frames = Frame( time_to_frame( length ) );                                // :100-101
+	if( f.num_frames <= 0 ) return PV();
+	auto d_sel = function_grid_to_device( *this, selector, static_cast<FunctionSample2d<TF>*>( nullptr ), f.num_frames );   // :103, over the OUTPUT's domain
+	const MF * d_pv = device_data();
+	auto out = DeviceBlock::allocate( sizeof( MF ) * mf_count( f ) );
+	if( !d_sel || !d_pv || !out ) return PV();
+	const int rc = flanhip_select_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(), get_sample_rate(),
+		get_hop_size(), static_cast<const float*>( d_sel->ptr ), f.num_frames, static_cast<flanhip_MF*>( out->ptr ), nullptr );
+	return finish( rc, "select", f, std::move( out ) );
+	}
+
+PV PV::freeze( const std::vector<Second> & pause_times, const std::vector<Second> & pause_lengths ) const
+	{
+	if( is_null() ) return PV();
+	if( pause_lengths.size() != pause_times.size() )                                // PV.cpp:135-139
+		{
+		std::cerr << "Error in flan::PV::freeze: pause_times and pause_lengths were not the same size.";
+		return PV();
+		}
+	const int n = int( pause_times.size() );
+	const int64_t Fo = flanhip_freeze_plan( get_num_frames(), get_sample_rate(), get_hop_size(), pause_times.data(), pause_lengths.data(), n, nullptr );
+	if( Fo <= 0 ) return PV();
+	detail::StagingVector<int32_t> src( static_cast<size_t>( Fo ) );
+	flanhip_freeze_plan( get_num_frames(), get_sample_rate(), get_hop_size(), pause_times.data(), pause_lengths.data(), n, src.data() );
+	PVBuffer::Format f = get_format();
+	f.num_frames = Frame( Fo );                                                     // :170-171
+	auto d_src = upload( src.data(), sizeof( int32_t ) * src.size() );
+	const MF * d_pv = device_data();
+	auto out = DeviceBlock::allocate( sizeof( MF ) * mf_count( f ) );
+	if( !d_src || !d_pv || !out ) return PV();
+	const int rc = flanhip_select_frames_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(),
+		static_cast<const int32_t*>( d_src->ptr ), Fo, static_cast<flanhip_MF*>( out->ptr ), nullptr );
+	return finish( rc, "freeze", f, std::move( out ) );
+	}
+
+// harmonic_scaler, PV.cpp:362-407
+static PV harmonic_scale( const PV & me, const Function<std::pair<Second, Harmonic>, float> & series, int mode, Harmonic num_harmonics )
+	{
+	const Frame frames = me.get_num_frames();
+	const size_t H = size_t( std::max( num_harmonics, 0 ) );
+	detail::StagingVector<float> sampled( H * frames );
+	detail::for_each_index( 0, frames, series.get_execution_policy(), [&]( int frame )   // :371-379: the callable sees the 0-based harmonic index
+		{
+		const Second t = me.frame_to_time( fFrame( frame ) );
+		for( size_t h = 0; h < H; ++h ) sampled[h + size_t( frame ) * H] = series( std::pair<Second, Harmonic>( t, Harmonic( h ) ) );
+		}, 16 );
+	auto d_series = H ? upload( sampled.data(), sizeof( float ) * sampled.size() ) : nullptr;
+	const MF * d_pv = me.device_data();
+	auto out = DeviceBlock::allocate( sizeof( MF ) * mf_count( me.get_format() ) );
+	if( ( H && !d_series ) || !d_pv || !out ) return PV();
+	const int rc = flanhip_harmonic_scale_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), me.get_num_channels(), frames, me.get_num_bins(), me.get_sample_rate(),
+		d_series ? static_cast<const float*>( d_series->ptr ) : nullptr, int( H ), mode, static_cast<flanhip_MF*>( out->ptr ), nullptr );
+	return finish( rc, mode == 0 ? "add_octaves" : "add_harmonics", me.get_format(), std::move( out ) );
+	}
+
+PV PV::add_octaves( const Function<std::pair<Second, Harmonic>, float> & series ) const
+	{
+	if( is_null() ) return PV();
+	return harmonic_scale( *this, series, 0, Harmonic( std::ceil( std::log2( get_height() ) ) ) );   // PV.cpp:412
+	}
+
+PV PV::add_harmonics( const Function<std::pair<Second, Harmonic>, float> & series ) const
+	{
+	if( is_null() ) return PV();
+	return harmonic_scale( *this, series, 1, get_num_bins() );                      // PV.cpp:418
+	}
+
+PV PV::cut_frames( Frame start, Frame end ) const
+	{
+	if( is_null() ) return PV::create_null();
+	int32_t first = 0, count = 0;
+	flanhip_cut_frames_range( get_num_frames(), start, end, &first, &count );       // PV.cpp:651-653
+	if( count <= 0 ) return PV::create_null();                                      // (an empty range gives an empty = null PV there too)
+	PVBuffer::Format f = get_format();
+	f.num_frames = count;
+	const MF * d_pv = device_data();
+	auto out = DeviceBlock::allocate( sizeof( MF ) * mf_count( f ) );
+	if( !d_pv || !out ) return PV();
+	const int rc = flanhip_cut_frames_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(), first, count,
+		static_cast<flanhip_MF*>( out->ptr ), nullptr );
+	return finish( rc, "cut_frames", f, std::move( out ) );
+	}
+
+std::vector<PV> PV::split_at_times( std::vector<Second> split_times ) const
+	{
+	if( is_null() ) return std::vector<PV>();
+	std::sort( split_times.begin(), split_times.end() );                            // PV.cpp:676
+	std::vector<Frame> split_frames;
+	split_frames.push_back( 0 );
+	for( Second t : split_times )                                                   // :680-686
+		{
+		const Frame f = Frame( time_to_frame( t ) );
+		if( f <= 0 ) continue;
+		if( get_num_frames() <= f ) break;
+		split_frames.push_back( f );
+		}
+	split_frames.push_back( get_num_frames() );
+	std::vector<PV> outs;
+	outs.reserve( split_frames.size() - 1 );
+	for( size_t i = 0; i + 1 < split_frames.size(); ++i ) outs.push_back( cut_frames( split_frames[i], split_frames[i + 1] ) );   // :690-693
+	return outs;
+	}
+
+PV PV::join( const std::vector<const PV *> & ins )
+	{
+	if( ins.size() == 0 ) return PV::create_null();
+	PVBuffer::Format f = ins[0]->get_format();                                      // PV.cpp:704
+	int64_t total = 0;
+	for( const PV * x : ins ) total += x->get_num_frames();                         // :705
+	if( total <= 0 || total > INT32_MAX ) return PV::create_null();
+	f.num_frames = Frame( total );
+	auto out = DeviceBlock::allocate( sizeof( MF ) * mf_count( f ) );
+	if( !out ) return PV();
+	if( !detail::report( flanhip_memset( out->ptr, 0, sizeof( MF ) * mf_count( f ), nullptr ), "join" ) ) return PV();   // :706-707
+	int64_t at = 0;
+	for( const PV * x : ins )                                                       // :709-717
+		{
+		if( x->get_num_frames() <= 0 || x->get_num_channels() <= 0 || x->get_num_bins() <= 0 ) continue;
+		const MF * d_in = x->device_data();
+		if( !d_in ) return PV();
+		if( !detail::report( flanhip_place_frames_dev( reinterpret_cast<const flanhip_MF*>( d_in ), x->get_num_channels(), x->get_num_frames(), x->get_num_bins(),
+				static_cast<flanhip_MF*>( out->ptr ), f.num_channels, f.num_frames, f.num_bins, at, nullptr ), "join" ) ) return PV();
+		at += x->get_num_frames();
+		}
+	return finish( FLANHIP_OK, "join", f, std::move( out ) );
+	}
+
+PV PV::join( const std::vector<PV> & ins )
+	{
+	std::vector<const PV *> ptrs( ins.size() );                                     // PV.cpp:16-22
+	std::transform( ins.begin(), ins.end(), ptrs.begin(), []( const PV & p ){ return &p; } );
+	return join( ptrs );
 	}
 
 } // namespace flan

@@ -2,6 +2,8 @@
 // conversions and the frame processors named by BASELINE.json's configs).
 #pragma once
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "flan/Function.h"
 #include "flan/PVBuffer.h"
@@ -58,6 +60,20 @@ public:
 	 *  unchecked (:649; one past the end for the default end_time = -1): here the end frame is clamped to the last frame. */
 	PV time_extrapolate( Second start_time, Second end_time, Second extrapolation_time,
 		const Interpolator & = Interpolator::linear() ) const;                                                        // PV.h:352-357 (PVModify.cpp:607-666)
+
+	// ---- selecting, rearranging and re-placing frames and bins ----
+	/** One frame, the linear blend of the two around `time` (clamped into the PV). */
+	PV get_frame( Second time ) const;                                                                                // PV.h:199-201 (PV.cpp:24-39)
+	/** Every output point reads the input point the selector names.  The selector is sampled on the host over the OUTPUT's grid. */
+	PV select( Second length, const Function<TF, TF> & selector ) const;                                              // PV.h:236-239 (PV.cpp:92-127)
+	/** Time freeze.  Of several pauses on one frame the first given is kept (unspecified in the reference: its sort is not stable). */
+	PV freeze( const std::vector<Second> & pause_times, const std::vector<Second> & pause_lengths ) const;            // PV.h:247-250 (PV.cpp:129-198)
+	PV add_octaves( const Function<std::pair<Second, Harmonic>, float> & series_scale ) const;                        // PV.h:387-389 (PV.cpp:409-413)
+	PV add_harmonics( const Function<std::pair<Second, Harmonic>, float> & series_scale ) const;                      // PV.h:394-396 (PV.cpp:415-419)
+	PV cut_frames( Frame start, Frame end ) const;                                                                    // PV.h:473-476 (PV.cpp:643-668)
+	std::vector<PV> split_at_times( std::vector<Second> split_times ) const;                                          // PV.h:478-480 (PV.cpp:670-696)
+	static PV join( const std::vector<const PV *> & ins );                                                            // PV.h:482-484 (PV.cpp:698-720)
+	static PV join( const std::vector<PV> & ins );                                                                    // PV.h:486-488 (PV.cpp:722-727)
 	};
 
 } // namespace flan

@@ -11,6 +11,7 @@ using Second = float;
 using Channel = int32_t;
 using Frame = int32_t;
 using Bin = int32_t;
+using Harmonic = int32_t;                   // defines.h:22
 using fFrame = float;
 using fBin = float;
 using Sample = float;

@@ -222,6 +222,38 @@ int flanhip_time_extrapolate_dev(const flanhip_MF * d_pv, int64_t num_channels, 
                                  int64_t start_frame, int64_t end_frame, int64_t out_frames, const float * d_interp_samples,
                                  flanhip_MF * d_out, void * stream);
 
+/* ---- PV methods that select, rearrange and re-place frames and bins (PV/PV.cpp:24-39, :92-198, :362-419, :643-720) ---- */
+/* PV::get_frame (PV/PV.cpp:24-39): one frame interpolated between its neighbours (getBinInterpolated, :62-73).
+ * frame_pos = clamp( time_to_frame( time ), 0, F-1 ) is the caller's (:28); d_out: MF[ch][1][bins]. */
+int flanhip_get_frame_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_frames, int num_bins, float frame_pos,
+                          int interp, flanhip_MF * d_out, void * stream);
+/* out[c][o][:] = pv[c][src[o]][:], zero where src[o] < 0: the copy loops of PV::freeze (PV/PV.cpp:176-195).
+ * d_src_frames: int32[out_frames] (flanhip_freeze_plan fills the host copy). */
+int flanhip_select_frames_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_frames, int num_bins,
+                              const int32_t * d_src_frames, int64_t out_frames, flanhip_MF * d_out, void * stream);
+/* PV::freeze's timing logic (PV/PV.cpp:140-171), host arithmetic: the output's frame count (returned; -1 on bad arguments) and,
+ * when src_frames is not NULL, the input frame every output frame repeats (-1: stays zero).  times / lengths: n pairs, seconds.
+ * Of several events on one frame the first given survives (unspecified in the reference: its sort is not stable). */
+int64_t flanhip_freeze_plan(int64_t num_frames, float sample_rate, int hop, const float * times, const float * lengths, int n,
+                            int32_t * src_frames);
+/* PV::cut_frames (PV/PV.cpp:643-668): its input validation (count 0 = the null PV it returns), and the copy. */
+int flanhip_cut_frames_range(int64_t num_frames, int32_t start, int32_t end, int32_t * start_out, int32_t * count_out);
+int flanhip_cut_frames_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_frames, int num_bins, int64_t start,
+                           int64_t count, flanhip_MF * d_out, void * stream);
+/* one input of PV::join (PV/PV.cpp:708-716): its frames to out frames [out_start, out_start + in_frames), the channels and bins
+ * both have; the caller clears d_out first (:706) */
+int flanhip_place_frames_dev(const flanhip_MF * d_in, int64_t in_channels, int64_t in_frames, int in_bins, flanhip_MF * d_out,
+                             int64_t out_channels, int64_t out_frames, int out_bins, int64_t out_start, void * stream);
+/* PV::select (PV/PV.cpp:92-127).  d_selector_tf: TF{ t, f }[out_frames][bins], the selector sampled over the OUTPUT's domain
+ * (:103); out_frames = Frame( time_to_frame( length ) ) (:101).  d_out: MF[ch][out_frames][bins]. */
+int flanhip_select_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_frames, int num_bins, float sample_rate, int hop,
+                       const float * d_selector_tf, int64_t out_frames, flanhip_MF * d_out, void * stream);
+/* PV::add_octaves (mode 0) / PV::add_harmonics (mode 1) (PV/PV.cpp:362-419).  d_series: float[F][num_harmonics], the series
+ * callable at ( frame_to_time( frame ), harmonic ) for the 0-based harmonic index, as :371-379 samples it; num_harmonics =
+ * ceil( log2( get_height() ) ) for octaves (:412), num_bins for harmonics (:418).  dft sizes up to 8192. */
+int flanhip_harmonic_scale_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_frames, int num_bins, float sample_rate,
+                               const float * d_series, int num_harmonics, int mode, flanhip_MF * d_out, void * stream);
+
 /* ---- Audio::convert_to_mid_side / convert_to_left_right (Audio/AudioConversions.cpp:32-56), stereo only ------ */
 int flanhip_mid_side_dev(const float * d_in, int64_t num_audio_frames, float * d_out, void * stream);
 

@@ -1,0 +1,202 @@
+// arrange_oracle.cpp -- CPU restatement of the PV methods that select, rearrange and re-place frames and bins:
+// get_frame, select, freeze, cut_frames, join, add_octaves / add_harmonics (PV/PV.cpp:24-39, :92-127, :129-198, :362-419,
+// :643-668, :698-720 of the reference; paths relative to /root/reference/src/flan).
+//
+// TEST INFRASTRUCTURE ONLY (same rules as flan_oracle.cpp: only tests/, smoke() and bench.py's cpu_baseline leg may use it).
+//
+// Pinning status: PV/PV.cpp is UNBUILDABLE here (FFTW3f, libsndfile, MSVC-only std::_Pi) and the reference ships no tests or
+// vectors for these methods: PARITY UNPINNED by reference fixtures.  The restatement is literal (same loops, same fp32
+// expressions, same order); where the reference is undefined the choice made is stated at the function.  User callables are
+// sampled by the CALLER the way the reference samples them on the host before its loops; this file takes the grids.
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+struct MF { float m, f; };
+struct TF { float t, f; };
+
+// PVBuffer.cpp:428-446
+float bin_to_frequency( float b, float sr, int dft ) { return b * float( sr ) / float( dft ); }
+float frequency_to_bin( float f, float sr, int dft ) { return f / ( float( sr ) / float( dft ) ); }
+float time_to_frame( float t, float sr, int hop ) { return t * float( sr ) / float( hop ); }
+
+// float -> Frame / Bin: undefined in C++ outside the int range; checker and device saturate, NaN -> INT_MIN
+int32_t to_int( float v )
+	{
+	if( !( v == v ) ) return INT32_MIN;
+	if( v >= 2147483648.0f ) return INT32_MAX;
+	if( v <= -2147483648.0f ) return INT32_MIN;
+	return int32_t( v );
+	}
+
+float interpolate( int kind, float x )                                   // Utility/Interpolator.cpp:14-101, as in processors_oracle.cpp
+	{
+	static const float pi = std::acos( -1.0f );
+	switch( kind )
+		{
+		case 1: return 0.5f;
+		case 2: return std::round( x );
+		case 3: return 0.0f;
+		case 4: return 1.0f;
+		case 5: return x * x * ( 3.0f - 2.0f * x );
+		case 6: return x * x * x * ( x * ( x * 6.0f - 15.0f ) + 10.0f );
+		case 7: return std::sqrt( x );
+		case 8: return ( 1.0f - std::cos( pi * x ) ) / 2.0f;
+		}
+	return x;
+	}
+
+inline size_t pos( int64_t F, int bins, int c, int64_t fr, int b ) { return ( size_t( c ) * size_t( F ) + size_t( fr ) ) * size_t( bins ) + size_t( b ); }
+
+}
+
+extern "C" {
+
+// PV.cpp:24-39 with getBinInterpolated( Channel, float frame, Bin ), :62-73.  frame_pos = clamp( time_to_frame( time ), 0, F-1 )
+// is the caller's (:28).  out: MF[ch][1][bins]
+int oracle_get_frame( const float * pv_mf, int ch, int64_t F, int bins, float frame_pos, int interp_kind, float * out_mf )
+	{
+	const MF * pv = reinterpret_cast<const MF*>( pv_mf );
+	MF * out = reinterpret_cast<MF*>( out_mf );
+	const int64_t lo = int64_t( std::floor( frame_pos ) ), hi = int64_t( std::ceil( frame_pos ) );
+	if( lo < 0 || hi >= F ) return -1;
+	const float mix = interpolate( interp_kind, frame_pos - std::floor( frame_pos ) );   // :67
+	for( int c = 0; c < ch; ++c )
+		for( int b = 0; b < bins; ++b )
+			{
+			const MF l = pv[pos( F, bins, c, lo, b )], h = pv[pos( F, bins, c, hi, b )];
+			out[size_t( c ) * bins + b] = MF{ ( 1.0f - mix ) * l.m + mix * h.m, ( 1.0f - mix ) * l.f + mix * h.f };   // :69-72
+			}
+	return 0;
+	}
+
+// PV.cpp:92-127.  selector: TF[Fo][bins], the selector sampled over the OUTPUT's domain (:103); out: MF[ch][Fo][bins], zero where
+// nothing is selected (the output is constructed zeroed).
+int oracle_select( const float * pv_mf, int ch, int64_t F, int bins, float sr, int hop, const float * selector_tf, int64_t Fo, float * out_mf )
+	{
+	const MF * pv = reinterpret_cast<const MF*>( pv_mf );
+	const TF * sel = reinterpret_cast<const TF*>( selector_tf );
+	MF * out = reinterpret_cast<MF*>( out_mf );
+	const int dft = ( bins - 1 ) * 2;
+	std::memset( out, 0, sizeof( MF ) * size_t( ch ) * Fo * bins );
+	for( int c = 0; c < ch; ++c )
+		for( int64_t fr = 0; fr < Fo; ++fr )
+			for( int b = 0; b < bins; ++b )
+				{
+				const TF s = sel[size_t( fr ) * bins + b];                                 // :110
+				const int32_t sf = to_int( time_to_frame( s.t, sr, hop ) );                // :111
+				const int32_t sb = to_int( frequency_to_bin( s.f, sr, dft ) );             // :112
+				if( sf < 0 || F - 1 <= sf || sb < 0 || bins - 1 <= sb ) continue;          // :114-116
+				MF m = pv[pos( F, bins, c, sf, sb )];
+				if( s.f > 1 ) m.f *= bin_to_frequency( float( b ), sr, dft ) / s.f;        // :119-120
+				out[pos( Fo, bins, c, fr, b )] = m;
+				}
+	return 0;
+	}
+
+// PV.cpp:129-198, the part that decides which input frame every output frame repeats.  times/lengths: n pairs, in seconds.
+// Returns the output's frame count (:167-171) and fills src[0 .. that) with the input frame of each output frame, -1 for the
+// frames the loops never write (they stay zero: each event swallows the frame it starts at, :178-187).  Call with src = nullptr
+// to get the count only.  std::sort's order among events on the same frame is unspecified in the reference (:159, not stable);
+// here the FIRST event given for a frame is the one that survives std::unique (:162-165).
+int64_t oracle_freeze_plan( int64_t F, float sr, int hop, const float * times, const float * lengths, int n, int32_t * src )
+	{
+	using FramePair = std::array<int32_t, 2>;
+	std::vector<FramePair> ev( static_cast<size_t>( std::max( n, 0 ) ) );
+	for( int i = 0; i < n; ++i )
+		ev[size_t( i )] = FramePair{ std::clamp( to_int( time_to_frame( times[i], sr, hop ) ), int32_t( 0 ), int32_t( F - 1 ) ),   // :152-155
+		                             std::max( to_int( time_to_frame( lengths[i], sr, hop ) ), int32_t( 0 ) ) };
+	std::stable_sort( ev.begin(), ev.end(), []( const FramePair & a, const FramePair & b ){ return a[0] < b[0]; } );
+	ev.erase( std::unique( ev.begin(), ev.end(), []( const FramePair & a, const FramePair & b ){ return a[0] == b[0]; } ), ev.end() );
+	float total = 0;                                                                 // :167-168, a float in the reference
+	for( auto & e : ev ) total += float( e[1] );
+	const int64_t Fo = int64_t( to_int( float( int32_t( F ) ) + total ) );            // :170-171: Frame += float
+	if( !src ) return Fo;
+	for( int64_t i = 0; i < Fo; ++i ) src[i] = -1;
+	size_t k = 0;
+	int64_t o = 0;
+	for( int64_t in = 0; in < F; ++in )                                              // :176-195
+		{
+		if( k < ev.size() && in == ev[k][0] )
+			{
+			for( int32_t r = 0; r < ev[k][1]; ++r ) { if( o < Fo ) src[o] = int32_t( in ); ++o; }
+			++k;
+			}
+		else { if( o < Fo ) src[o] = int32_t( in ); ++o; }
+		}
+	return Fo;
+	}
+
+// out[c][o][b] = pv[c][src[o]][b], zero where src[o] < 0: freeze's copy loops (:176-195) and cut_frames (:643-668, src[o] = start + o)
+int oracle_select_frames( const float * pv_mf, int ch, int64_t F, int bins, const int32_t * src, int64_t Fo, float * out_mf )
+	{
+	const MF * pv = reinterpret_cast<const MF*>( pv_mf );
+	MF * out = reinterpret_cast<MF*>( out_mf );
+	for( int c = 0; c < ch; ++c )
+		for( int64_t o = 0; o < Fo; ++o )
+			for( int b = 0; b < bins; ++b )
+				out[pos( Fo, bins, c, o, b )] = ( src[o] >= 0 && src[o] < F ) ? pv[pos( F, bins, c, src[o], b )] : MF{ 0.0f, 0.0f };
+	return 0;
+	}
+
+// PV.cpp:643-668: the validated ( start, count ) of cut_frames( start, end ); count 0 = a null PV
+void oracle_cut_frames_range( int64_t F, int32_t start, int32_t end, int32_t * start_out, int32_t * count_out )
+	{
+	*start_out = 0; *count_out = 0;
+	if( end <= start || F <= 0 ) return;                                             // :651
+	start = std::clamp( start, int32_t( 0 ), int32_t( F - 1 ) );                      // :652-653
+	end = std::clamp( end, int32_t( 0 ), int32_t( F - 1 ) );
+	*start_out = start; *count_out = std::max( end - start, 0 );
+	}
+
+// PV.cpp:698-720, one input of join: its frames go to out frames [out_start, out_start + in_F) for the channels and bins both
+// have; the rest of out is left as it is (join clears the output first, :706)
+int oracle_place_frames( const float * in_mf, int in_ch, int64_t in_F, int in_bins, float * out_mf, int out_ch, int64_t out_F, int out_bins, int64_t out_start )
+	{
+	const MF * in = reinterpret_cast<const MF*>( in_mf );
+	MF * out = reinterpret_cast<MF*>( out_mf );
+	if( out_start < 0 || out_start + in_F > out_F ) return -1;
+	for( int c = 0; c < in_ch && c < out_ch; ++c )
+		for( int64_t fr = 0; fr < in_F; ++fr )
+			for( int b = 0; b < in_bins && b < out_bins; ++b )
+				out[pos( out_F, out_bins, c, out_start + fr, b )] = in[pos( in_F, in_bins, c, fr, b )];
+	return 0;
+	}
+
+// PV.cpp:362-407 harmonic_scaler.  series: float[F][H], series( { frame_to_time( frame ), harmonic } ) for harmonic 0 .. H-1 (:371-379:
+// the callable sees the 0-based index).  mode 0 = add_octaves (:409-413): harmonic h (1-based) of f is f * pow( 2, h ), computed in
+// double and rounded to float; mode 1 = add_harmonics (:415-419): f * ( h + 1 ) in fp32.  A harmonic frequency that converts to a
+// negative bin (a NaN frequency) indexes out of bounds in the reference; here it is skipped.
+int oracle_harmonic_scale( const float * pv_mf, int ch, int64_t F, int bins, float sr, const float * series, int H, int mode, float * out_mf )
+	{
+	const MF * pv = reinterpret_cast<const MF*>( pv_mf );
+	MF * out = reinterpret_cast<MF*>( out_mf );
+	const int dft = ( bins - 1 ) * 2;
+	std::memset( out, 0, sizeof( MF ) * size_t( ch ) * F * bins );                    // :369-370
+	for( int c = 0; c < ch; ++c )
+		for( int64_t fr = 0; fr < F; ++fr )
+			for( int b = 0; b < bins; ++b )
+				{
+				const MF source = pv[pos( F, bins, c, fr, b )];
+				if( source.f <= 1.0f ) continue;                                          // :389
+				for( int h = 0; h < H; ++h )
+					{
+					const int hh = h + 1;                                                  // :393
+					const float hf = mode == 0 ? float( double( source.f ) * std::pow( 2.0, double( hh ) ) ) : source.f * float( hh + 1 );
+					const int32_t hb = to_int( frequency_to_bin( hf, sr, dft ) );          // :394
+					if( hb >= bins ) break;                                                // :395
+					if( hb < 0 ) continue;
+					MF & dest = out[pos( F, bins, c, fr, hb )];
+					const float mag = source.m * series[size_t( fr ) * H + h];             // :398
+					if( dest.m < mag ) dest = MF{ mag, hf };                               // :399-400
+					}
+				}
+	return 0;
+	}
+
+} // extern "C"

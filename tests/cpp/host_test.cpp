@@ -270,6 +270,49 @@ static void device_checks()
 	PV w = p2.copy();
 	w.get_MF( 0, 0, 0 ) = MF{ 1.0f, 2.0f };
 	CHECK( !w.is_device_resident() && w.get_MF( 0, 0, 0 ).m == 1.0f );
+	// ---- selecting, rearranging and re-placing frames (PV.cpp:24-39, :92-198, :362-419, :643-727)
+		{
+		const Frame F = p2.get_num_frames(); const Bin B = p2.get_num_bins();
+		PV fr = p2.get_frame( p2.frame_to_time( 20 ) );
+		CHECK( fr.get_num_frames() == 1 && fr.get_num_channels() == 2 && fr.get_MF( 1, 0, 33 ).m == p2.get_MF( 1, 20, 33 ).m && fr.get_MF( 1, 0, 33 ).f == p2.get_MF( 1, 20, 33 ).f );
+		PV half = p2.get_frame( p2.frame_to_time( 20.5f ) );
+		CHECK( half.get_MF( 0, 0, 7 ).m == 0.5f * p2.get_MF( 0, 20, 7 ).m + 0.5f * p2.get_MF( 0, 21, 7 ).m );
+		CHECK( p2.get_frame( 1e9f ).get_MF( 0, 0, 5 ).m == p2.get_MF( 0, F - 1, 5 ).m && p2.get_frame( -3.0f ).get_MF( 0, 0, 5 ).m == p2.get_MF( 0, 0, 5 ).m );
+		PV cut = p2.cut_frames( 10, 30 );
+		CHECK( cut.get_num_frames() == 20 && cut.get_MF( 1, 0, 9 ).f == p2.get_MF( 1, 10, 9 ).f && cut.get_MF( 0, 19, 100 ).m == p2.get_MF( 0, 29, 100 ).m );
+		CHECK( p2.cut_frames( 30, 10 ).is_null() && p2.cut_frames( 5, 5 ).is_null() );
+		CHECK( p2.cut_frames( 0, F + 100 ).get_num_frames() == F - 1 );               // the end clamps to F-1 (PV.cpp:653)
+		auto pieces = p2.split_at_times( { p2.frame_to_time( 40 ), p2.frame_to_time( 15 ), -1.0f, 1e9f } );
+		CHECK( pieces.size() == 3 && pieces[0].get_num_frames() == 15 && pieces[1].get_num_frames() == 25 && pieces[2].get_num_frames() == F - 1 - 40 );
+		PV joined = PV::join( pieces );
+		CHECK( joined.get_num_frames() == F - 1 && joined.get_num_channels() == 2 );
+		CHECK( std::memcmp( joined.get_buffer().data(), p2.cut_frames( 0, F ).get_buffer().data(), sizeof( MF ) * joined.get_buffer().size() ) == 0 );
+		CHECK( PV::join( std::vector<const PV *>() ).is_null() );
+		PV fz = p2.freeze( { p2.frame_to_time( 12 ) }, { p2.frame_to_time( 6 ) } );
+		CHECK( fz.get_num_frames() == F + 6 && fz.get_MF( 0, 12, 50 ).m == p2.get_MF( 0, 12, 50 ).m && fz.get_MF( 0, 17, 50 ).m == p2.get_MF( 0, 12, 50 ).m );
+		CHECK( fz.get_MF( 0, 18, 50 ).m == p2.get_MF( 0, 13, 50 ).m && fz.get_MF( 1, F + 4, 50 ).m == p2.get_MF( 1, F - 1, 50 ).m && fz.get_MF( 1, F + 5, 50 ).m == 0.0f );
+		CHECK( p2.freeze( { 0.1f, 0.2f }, { 0.1f } ).is_null() );                     // sizes differ: the reference's error
+		// a selector that reads everything from one second earlier, one octave down
+		PV sel = p2.select( p2.get_length(), []( TF tf ){ return TF{ tf.t - 0.1f, tf.f * 0.5f }; } );
+		CHECK( sel.get_num_frames() == Frame( p2.time_to_frame( p2.get_length() ) ) && !sel.is_null() );
+			{
+			const Frame fo = 60; const Bin bo = 40;
+			const TF s{ fo * ( 1.0f / p2.get_analysis_rate() ) - 0.1f, bo * p2.bin_to_frequency( 1 ) * 0.5f };
+			const MF src = p2.get_MF( 1, Frame( p2.time_to_frame( s.t ) ), Bin( p2.frequency_to_bin( s.f ) ) );
+			CHECK( sel.get_MF( 1, fo, bo ).m == src.m && sel.get_MF( 1, fo, bo ).f == src.f * ( p2.bin_to_frequency( float( bo ) ) / s.f ) );
+			CHECK( sel.get_MF( 0, 2, bo ).m == 0.0f );                                 // reads from before the start: left empty
+			}
+		CHECK( p2.select( 0.0f, []( TF tf ){ return tf; } ).is_null() );
+		// overtones of the 440 Hz sine: the octave lands in the bin of 880 Hz, from the loudest of the bins that claim it
+		PV oct = pv.add_octaves( []( std::pair<Second, Harmonic> ){ return 1.0f; } );
+		const float f19 = pv.get_MF( 0, 100, 19 ).f;
+		CHECK( oct.get_num_frames() == pv.get_num_frames() && oct.get_MF( 0, 100, Bin( pv.frequency_to_bin( f19 * 2.0f ) ) ).f == f19 * 2.0f );
+		CHECK( oct.get_MF( 0, 100, Bin( pv.frequency_to_bin( f19 * 2.0f ) ) ).m == pv.get_MF( 0, 100, 19 ).m );
+		PV har = pv.add_harmonics( []( std::pair<Second, Harmonic> th ){ return th.second == 1 ? 0.25f : 0.0f; } );   // harmonic index 1 = the third partial (PV.cpp:393,417)
+		CHECK( har.get_MF( 0, 100, Bin( pv.frequency_to_bin( f19 * 3.0f ) ) ).f == f19 * 3.0f && har.get_MF( 0, 100, Bin( pv.frequency_to_bin( f19 * 3.0f ) ) ).m == pv.get_MF( 0, 100, 19 ).m * 0.25f );
+		CHECK( har.get_MF( 0, 100, Bin( pv.frequency_to_bin( f19 * 2.0f ) ) ).m == 0.0f );
+		(void) B;
+		}
 	// ---- a grid large enough to go over in slabs (sampled slab k+1 while slab k uploads) = the same grid sampled in one piece
 	// and taken through the C ABI by hand; and the block cache hands memory back and forth without mixing results up
 		{

@@ -74,6 +74,15 @@ def _load():
     lib.oracle_n_loudest_partials.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, i32p, C.c_int, f32p]
     lib.oracle_desample.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, f32p, C.c_int, f32p]
     lib.oracle_time_extrapolate.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_int64, C.c_int64, C.c_int64, f32p, f32p]
+    lib.oracle_get_frame.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_int, f32p]
+    lib.oracle_select.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_int, f32p, C.c_int64, f32p]
+    lib.oracle_freeze_plan.restype = C.c_int64
+    lib.oracle_freeze_plan.argtypes = [C.c_int64, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.oracle_select_frames.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, i32p, C.c_int64, f32p]
+    lib.oracle_cut_frames_range.restype = None
+    lib.oracle_cut_frames_range.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.oracle_place_frames.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, f32p, C.c_int, C.c_int64, C.c_int, C.c_int64]
+    lib.oracle_harmonic_scale.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, C.c_float, f32p, C.c_int, C.c_int, f32p]
     return lib
 
 
@@ -269,6 +278,80 @@ def time_extrapolate_interp_samples(start_frame, end_frame, out_frames, interp=0
     k = np.arange(out_frames - start_frame, dtype=np.int64)
     x = (k - start_frame).astype(np.float32) / np.float32(end_frame - start_frame)
     return np.array([lib.oracle_interpolate(interp, float(v)) for v in x], np.float32)
+
+
+def get_frame(pv, frame_pos, interp=0):
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    out = np.empty((ch, 1, bins, 2), np.float32)
+    assert lib.oracle_get_frame(pv.reshape(-1), ch, F, bins, frame_pos, interp, out.reshape(-1)) == 0
+    return out
+
+
+def select(pv, sample_rate, hop, selector_tf):
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    sel = np.ascontiguousarray(selector_tf, np.float32)
+    Fo = sel.shape[0]
+    out = np.empty((ch, Fo, bins, 2), np.float32)
+    lib.oracle_select(pv.reshape(-1), ch, F, bins, sample_rate, hop, sel.reshape(-1), Fo, out.reshape(-1))
+    return out
+
+
+def freeze_plan(num_frames, sample_rate, hop, times, lengths):
+    times = np.ascontiguousarray(times, np.float32)
+    lengths = np.ascontiguousarray(lengths, np.float32)
+    n = len(times)
+    tp = times.ctypes.data if n else None
+    lp = lengths.ctypes.data if n else None
+    Fo = lib.oracle_freeze_plan(num_frames, sample_rate, hop, tp, lp, n, None)
+    src = np.empty(Fo, np.int32)
+    lib.oracle_freeze_plan(num_frames, sample_rate, hop, tp, lp, n, src.ctypes.data)
+    return src
+
+
+def select_frames(pv, src_frames):
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    src = np.ascontiguousarray(src_frames, np.int32)
+    out = np.empty((ch, len(src), bins, 2), np.float32)
+    lib.oracle_select_frames(pv.reshape(-1), ch, F, bins, src, len(src), out.reshape(-1))
+    return out
+
+
+def freeze(pv, sample_rate, hop, times, lengths):
+    return select_frames(pv, freeze_plan(np.shape(pv)[1], sample_rate, hop, times, lengths))
+
+
+def cut_frames(pv, start, end):
+    pv = np.ascontiguousarray(pv, np.float32)
+    s, c = C.c_int32(0), C.c_int32(0)
+    lib.oracle_cut_frames_range(pv.shape[1], start, end, C.byref(s), C.byref(c))
+    if c.value <= 0:
+        return None
+    return select_frames(pv, np.arange(s.value, s.value + c.value, dtype=np.int32))
+
+
+def join(pvs):
+    pvs = [np.ascontiguousarray(p, np.float32) for p in pvs]
+    ch, _, bins, _ = pvs[0].shape
+    Fo = sum(p.shape[1] for p in pvs)
+    out = np.zeros((ch, Fo, bins, 2), np.float32)
+    at = 0
+    for p in pvs:
+        assert lib.oracle_place_frames(p.reshape(-1), p.shape[0], p.shape[1], p.shape[2], out.reshape(-1), ch, Fo, bins, at) == 0
+        at += p.shape[1]
+    return out
+
+
+def harmonic_scale(pv, sample_rate, series, mode):
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    series = np.ascontiguousarray(series, np.float32)
+    H = series.shape[1]
+    out = np.empty_like(pv)
+    lib.oracle_harmonic_scale(pv.reshape(-1), ch, F, bins, sample_rate, series.reshape(-1) if H else np.zeros(1, np.float32), H, mode, out.reshape(-1))
+    return out
 
 
 def mid_side(audio):

@@ -1,0 +1,127 @@
+"""GPU parity of the frame-selecting / re-placing PV methods through the C ABI: get_frame, select, freeze, cut_frames, join,
+add_octaves / add_harmonics.  Copies, gathers and plain fp32 with the reference's operation order kept: the bar is BIT EQUALITY
+with the oracle (oracle/arrange_oracle.cpp)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+SR = 48000.0
+HOP = 256
+
+
+@pytest.fixture(scope="module")
+def fa():
+    import flan_amd
+    assert flan_amd.lib.flanhip_device_count() > 0
+    return flan_amd
+
+
+@pytest.fixture(scope="module")
+def pv_small():
+    return O.analyze(O.noise(2, 30000, seed=77), SR, 1024, HOP, 1024)          # (2, 118, 513, 2)
+
+
+@pytest.fixture(scope="module")
+def pv_wide():
+    return O.analyze(O.noise(3, 24000, seed=78), SR, 1024, HOP, 2048)          # (3, 94, 1025, 2)
+
+
+def assert_identical(name, got, ref):
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    same = float(np.mean(got.view(np.uint32) == ref.view(np.uint32)))
+    print("\n[P4 %s] bit-identical=%.6f" % (name, same))
+    assert same == 1.0, name
+
+
+def test_get_frame(fa, pv_small, pv_wide):
+    for pv in (pv_small, pv_wide):
+        F = pv.shape[1]
+        for pos in (0.0, 1.0, 17.25, 60.5, F - 1.0, F - 1.75):
+            for interp in range(9):
+                assert_identical("get_frame pos=%g interp=%d" % (pos, interp), fa.get_frame(pv, pos, interp), O.get_frame(pv, pos, interp))
+    with pytest.raises(fa.FlanHipError):
+        fa.get_frame(pv_small, float(pv_small.shape[1]))                            # the caller clamps (PV.cpp:28); beyond the PV is an error
+    with pytest.raises(fa.FlanHipError):
+        fa.get_frame(pv_small, -0.5)
+
+
+def test_freeze(fa, pv_small, pv_wide):
+    rng = np.random.default_rng(4)
+    for pv in (pv_small, pv_wide):
+        F = pv.shape[1]
+        T = F * HOP / SR
+        cases = [([], []), ([0.1], [0.05]), ([0.1], [0.0]), ([0.0, T, 0.1, 0.1], [0.01, 0.02, 0.03, 0.3]), ([-1.0, 1e9], [0.02, -1.0])]
+        cases.append((rng.uniform(0, T, 20), rng.uniform(0, 0.05, 20)))
+        for times, lengths in cases:
+            assert_identical("freeze %d events" % len(times), fa.freeze(pv, SR, HOP, times, lengths), O.freeze(pv, SR, HOP, times, lengths))
+
+
+def test_cut_frames_and_join(fa, pv_small, pv_wide):
+    F = pv_small.shape[1]
+    for start, end in ((0, F), (3, 11), (-5, 40), (F - 2, F + 7), (50, 51)):
+        assert_identical("cut_frames %d:%d" % (start, end), fa.cut_frames(pv_small, start, end), O.cut_frames(pv_small, start, end))
+    for start, end in ((5, 5), (9, 2), (F - 1, F + 7), (F + 3, F + 9)):
+        assert fa.cut_frames(pv_small, start, end) is None and O.cut_frames(pv_small, start, end) is None
+    parts = [pv_small[:, :7], pv_small[:, 7:20], pv_small[:, 20:]]
+    assert_identical("join of cuts", fa.join(parts), pv_small)
+    assert_identical("join, other shapes", fa.join([pv_small, pv_wide, pv_small[:1, :9, :100]]), O.join([pv_small, pv_wide, pv_small[:1, :9, :100]]))
+    assert_identical("join, wide first", fa.join([pv_wide, pv_small]), O.join([pv_wide, pv_small]))
+
+
+def selector_grids(pv, Fo, seed):
+    ch, F, bins, _ = pv.shape
+    rng = np.random.default_rng(seed)
+    T = F * HOP / SR
+    sel = np.empty((Fo, bins, 2), np.float32)
+    sel[..., 0] = rng.uniform(-0.02, T * 1.1, (Fo, bins))
+    sel[..., 1] = rng.uniform(-200.0, SR / 2 * 1.1, (Fo, bins))
+    yield "random", sel
+    # the identity selector: every output point reads its own time / frequency
+    t = (np.arange(Fo, dtype=np.float32) / np.float32(SR / HOP))[:, None]
+    f = (np.arange(bins, dtype=np.float32) * np.float32(SR) / np.float32((bins - 1) * 2))[None, :]
+    ident = np.stack(np.broadcast_arrays(t, f), axis=-1).astype(np.float32)
+    yield "identity", ident
+    weird = sel.copy()
+    weird[0, :5] = [(np.nan, 100.0), (0.01, np.nan), (np.inf, 100.0), (0.01, -np.inf), (0.01, 0.5)]
+    weird[-1, 5:8] = [(1e30, 1e30), (-1e30, 5.0), (0.0, 0.0)]
+    yield "non-finite", weird
+
+
+def test_select(fa, pv_small, pv_wide):
+    for pv in (pv_small, pv_wide):
+        for Fo in (1, 37, pv.shape[1] + 20):
+            for name, sel in selector_grids(pv, Fo, seed=Fo):
+                assert_identical("select/%s Fo=%d" % (name, Fo), fa.select(pv, SR, HOP, sel), O.select(pv, SR, HOP, sel))
+
+
+def test_add_octaves_and_harmonics(fa, pv_small, pv_wide):
+    rng = np.random.default_rng(6)
+    for pv in (pv_small, pv_wide):
+        ch, F, bins, _ = pv.shape
+        H_oct = int(np.ceil(np.log2(np.float32(bins * np.float32(SR) / np.float32((bins - 1) * 2)))))
+        for mode, H in ((0, H_oct), (1, bins), (1, 7), (0, 40), (1, 0)):
+            for sname, series in (("ones", np.ones((F, H), np.float32)), ("random", rng.uniform(-0.3, 1.0, (F, H)).astype(np.float32)),
+                                  ("decay", np.tile((0.7 ** np.arange(H, dtype=np.float32))[None, :], (F, 1)).astype(np.float32))):
+                assert_identical("harmonic_scale mode=%d H=%d %s" % (mode, H, sname), fa.harmonic_scale(pv, SR, series, mode), O.harmonic_scale(pv, SR, series, mode))
+    # dft 8192: the input row and the series no longer fit next to the placement keys (the kernel's other path); dft 16384: refused
+    big = O.analyze(O.noise(1, 4000, seed=3), SR, 1024, HOP, 8192)
+    for mode, H in ((0, 15), (1, big.shape[2])):
+        series = rng.uniform(0.0, 1.0, (big.shape[1], H)).astype(np.float32)
+        assert_identical("harmonic_scale dft 8192 mode=%d" % mode, fa.harmonic_scale(big, SR, series, mode), O.harmonic_scale(big, SR, series, mode))
+    huge = np.zeros((1, 2, 8193, 2), np.float32)
+    with pytest.raises(fa.FlanHipError):
+        fa.harmonic_scale(huge, SR, np.ones((2, 4), np.float32), 0)
+    # ties, zeros, negative and non-finite magnitudes / frequencies in the source
+    pv = pv_small.copy()
+    pv[0, 3, :, 0] = 1.0                                                             # every candidate equally loud: the first visited wins
+    pv[0, 4, 10:20, 0] = 0.0
+    pv[0, 5, 10:20, 0] = -2.0
+    pv[0, 6, 10, 0] = np.inf
+    pv[0, 7, 10:14, 1] = [np.nan, np.inf, -5.0, 1.0]
+    pv[1, 8, :, 1] = 30.0                                                            # every bin claims the same overtone bins
+    for mode, H in ((0, 15), (1, pv.shape[2])):
+        series = np.ones((pv.shape[1], H), np.float32)
+        assert_identical("harmonic_scale special mode=%d" % mode, fa.harmonic_scale(pv, SR, series, mode), O.harmonic_scale(pv, SR, series, mode))

@@ -1,0 +1,144 @@
+"""The CPU checker for the frame-selecting / re-placing PV methods (oracle/arrange_oracle.cpp) against independent numpy
+statements of the same reference loops (PV/PV.cpp:24-39, :92-198, :362-419, :643-720), and the library's host-side planning
+helpers (pure arithmetic, no device) against the checker."""
+import numpy as np
+
+import oracle_lib as O
+
+SR = 48000.0
+HOP = 256
+
+
+def small_pv(ch=2, n=9000, dft=512, seed=5):
+    return O.analyze(O.noise(ch, n, seed=seed), SR, dft, HOP, dft)
+
+
+def test_get_frame_is_the_blend_of_its_two_neighbours():
+    pv = small_pv()
+    F = pv.shape[1]
+    for pos in (0.0, 3.0, 3.25, 7.5, F - 1.0, F - 1.5):
+        got = O.get_frame(pv, pos)
+        lo, hi = int(np.floor(pos)), int(np.ceil(pos))
+        mix = np.float32(np.float32(pos) - np.float32(lo))
+        ref = (np.float32(1) - mix) * pv[:, lo] + mix * pv[:, hi]
+        assert np.array_equal(got[:, 0], ref.astype(np.float32)), pos
+    assert np.array_equal(O.get_frame(pv, 4.0)[:, 0], pv[:, 4])
+    assert np.array_equal(O.get_frame(pv, 4.3, interp=3)[:, 0], pv[:, 4])          # floor interpolator
+    assert np.array_equal(O.get_frame(pv, 4.3, interp=4)[:, 0], pv[:, 5])          # ceil interpolator
+
+
+def test_freeze_plan_follows_the_reference_loops():
+    F = 40
+    # one freeze of 5 frames at frame 10: frame 10 appears 5 times instead of once; one trailing frame stays empty
+    t10 = 10 * HOP / SR
+    src = O.freeze_plan(F, SR, HOP, [t10], [5 * HOP / SR])
+    assert len(src) == F + 5
+    assert list(src[:10]) == list(range(10)) and list(src[10:15]) == [10] * 5 and list(src[15:44]) == list(range(11, 40)) and src[44] == -1
+    # a freeze of length 0 drops its frame
+    src = O.freeze_plan(F, SR, HOP, [t10], [0.0])
+    assert len(src) == F and list(src[:39]) == [i for i in range(40) if i != 10] and src[39] == -1
+    # unsorted events, two on one frame (the first given survives), times clamped into the PV, negative lengths -> 0
+    src = O.freeze_plan(F, SR, HOP, [30 * HOP / SR, t10, t10, 1e9, -5.0], [2 * HOP / SR, 3 * HOP / SR, 7 * HOP / SR, 1 * HOP / SR, -1.0])
+    events = {0: 0, 10: 3, 30: 2, 39: 1}
+    expect = []
+    for i in range(F):
+        expect += [i] * events[i] if i in events else [i]
+    assert len(src) == F + 6 and list(src[:len(expect)]) == expect and np.all(src[len(expect):] == -1)
+    # no events: the identity
+    assert list(O.freeze_plan(F, SR, HOP, [], [])) == list(range(F))
+
+
+def test_library_planning_helpers_match_the_checker():
+    """flanhip_freeze_plan / flanhip_cut_frames_range are host arithmetic: they run without a device"""
+    import ctypes as C
+    import flan_amd
+    rng = np.random.default_rng(3)
+    for trial in range(200):
+        F = int(rng.integers(1, 300))
+        n = int(rng.integers(0, 9))
+        times = rng.uniform(-0.5, F * HOP / SR * 1.2, n).astype(np.float32)
+        if n > 2:
+            times[1] = times[0]
+        lengths = rng.uniform(-0.01, 0.05, n).astype(np.float32)
+        assert np.array_equal(flan_amd.freeze_plan(F, SR, HOP, times, lengths), O.freeze_plan(F, SR, HOP, times, lengths)), trial
+        start, end = int(rng.integers(-20, F + 20)), int(rng.integers(-20, F + 20))
+        s1, c1, s2, c2 = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        flan_amd.check(flan_amd.lib.flanhip_cut_frames_range(F, start, end, C.byref(s1), C.byref(c1)))
+        O.lib.oracle_cut_frames_range(F, start, end, C.byref(s2), C.byref(c2))
+        assert (s1.value, c1.value) == (s2.value, c2.value)
+        assert c1.value == (0 if end <= start else max(min(max(end, 0), F - 1) - min(max(start, 0), F - 1), 0))
+
+
+def test_cut_and_join():
+    pv = small_pv()
+    F = pv.shape[1]
+    assert O.cut_frames(pv, 5, 5) is None and O.cut_frames(pv, 9, 2) is None
+    assert np.array_equal(O.cut_frames(pv, 3, 11), pv[:, 3:11])
+    assert np.array_equal(O.cut_frames(pv, -4, F + 10), pv[:, 0:F - 1])             # the end clamps to F-1 (PV.cpp:653): the last frame is lost
+    a, b = pv[:, :7], pv[:, 7:20]
+    assert np.array_equal(O.join([a, b]), pv[:, :20])
+    other = O.analyze(O.noise(3, 3000, seed=9), SR, 1024, HOP, 1024)                # more channels, more bins than the first input
+    j = O.join([a, other])
+    assert j.shape == (2, 7 + other.shape[1], pv.shape[2], 2)
+    assert np.array_equal(j[:, 7:], other[:2, :, :pv.shape[2]])
+    fewer = pv[:1, :4, :100]
+    j = O.join([a, fewer])
+    assert np.array_equal(j[0, 7:, :100], fewer[0]) and not j[1, 7:].any() and not j[0, 7:, 100:].any()
+
+
+def test_select_against_numpy():
+    pv = small_pv()
+    ch, F, bins, _ = pv.shape
+    dft = (bins - 1) * 2
+    rng = np.random.default_rng(8)
+    Fo = 25
+    sel = np.empty((Fo, bins, 2), np.float32)
+    sel[..., 0] = rng.uniform(-0.02, F * HOP / SR * 1.1, (Fo, bins))
+    sel[..., 1] = rng.uniform(-200.0, SR / 2 * 1.1, (Fo, bins))
+    sel[3, 7] = (np.nan, 100.0)
+    sel[3, 8] = (0.01, np.nan)
+    sel[4, 9] = (0.01, 0.5)                                                         # s.f <= 1: the frequency is not rescaled
+    got = O.select(pv, SR, HOP, sel)
+    ref = np.zeros_like(got)
+    with np.errstate(invalid="ignore"):
+        sf_f = (sel[..., 0] * np.float32(SR) / np.float32(HOP)).astype(np.float32)
+        sb_f = (sel[..., 1] / (np.float32(SR) / np.float32(dft))).astype(np.float32)
+    for fr in range(Fo):
+        for b in range(bins):
+            if np.isnan(sf_f[fr, b]) or np.isnan(sb_f[fr, b]):
+                continue
+            sf, sb = int(sf_f[fr, b]), int(sb_f[fr, b])
+            if sf < 0 or F - 1 <= sf or sb < 0 or bins - 1 <= sb:
+                continue
+            m = pv[:, sf, sb].copy()
+            if sel[fr, b, 1] > 1:
+                m[:, 1] = m[:, 1] * np.float32(np.float32(np.float32(b) * np.float32(SR) / np.float32(dft)) / sel[fr, b, 1])
+            ref[:, fr, b] = m
+    assert np.array_equal(got, ref)
+    assert got.any()
+
+
+def test_harmonic_scale_against_numpy():
+    pv = small_pv(ch=1, n=4000, dft=256)
+    ch, F, bins, _ = pv.shape
+    dft = (bins - 1) * 2
+    rng = np.random.default_rng(2)
+    for mode, H in ((0, 15), (1, bins)):
+        series = rng.uniform(-0.2, 1.0, (F, H)).astype(np.float32)
+        got = O.harmonic_scale(pv, SR, series, mode)
+        ref = np.zeros_like(pv)
+        for fr in range(F):
+            for b in range(bins):
+                m, f = pv[0, fr, b]
+                if f <= 1.0:
+                    continue
+                for h in range(H):
+                    hf = np.float32(np.float64(f) * 2.0 ** (h + 1)) if mode == 0 else np.float32(f * np.float32(h + 2))
+                    hb = int(np.float32(hf / (np.float32(SR) / np.float32(dft))))
+                    if hb >= bins:
+                        break
+                    mag = np.float32(m * series[fr, h])
+                    if ref[0, fr, hb, 0] < mag:
+                        ref[0, fr, hb] = (mag, hf)
+        assert np.array_equal(got, ref), mode
+        assert got.any()

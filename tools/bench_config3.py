@@ -74,6 +74,25 @@ stages.update({
     "time_extrapolate(2000 frames)": lambda: fa.check(lib.flanhip_time_extrapolate_dev(P(pv), ch, F, BINS, SR, ext_start, ext_end, ext_Fo,
                                                                                          P(samples), P(ext_out), None)),
 })
+# selecting / re-placing methods on the same PV
+fz_src_host = fa.freeze_plan(F, SR, HOP, [10.0, 20.0, 30.0], [1.0, 2.0, 0.5])
+fz_Fo = len(fz_src_host)
+fz_src = torch.from_numpy(fz_src_host).to(dev)
+fz_out = torch.empty((ch, fz_Fo, BINS, 2), dtype=torch.float32, device=dev)
+sel_grid = torch.empty((F, BINS, 2), dtype=torch.float32, device=dev)
+sel_grid[..., 0] = (torch.arange(F, device=dev, dtype=torch.float32) / (SR / HOP))[:, None] * 0.5 + 1.0      # half speed from 1 s in
+sel_grid[..., 1] = (torch.arange(BINS, device=dev, dtype=torch.float32) * (SR / DFT))[None, :] * 0.75
+H_oct = 15
+ser_oct = torch.full((F, H_oct), 0.5, dtype=torch.float32, device=dev)
+ser_har = torch.full((F, BINS), 0.5, dtype=torch.float32, device=dev)
+stages.update({
+    "freeze(3 pauses)": lambda: fa.check(lib.flanhip_select_frames_dev(P(pv), ch, F, BINS, P(fz_src), fz_Fo, P(fz_out), None)),
+    "cut_frames(1000:5000)": lambda: fa.check(lib.flanhip_cut_frames_dev(P(pv), ch, F, BINS, 1000, 4000, P(sh), None)),
+    "join(one input)": lambda: fa.check(lib.flanhip_place_frames_dev(P(pv), ch, F, BINS, P(fz_out), ch, fz_Fo, BINS, 100, None)),
+    "select(grid)": lambda: fa.check(lib.flanhip_select_dev(P(pv), ch, F, BINS, SR, HOP, P(sel_grid), F, P(sh), None)),
+    "add_octaves": lambda: fa.check(lib.flanhip_harmonic_scale_dev(P(pv), ch, F, BINS, SR, P(ser_oct), H_oct, 0, P(sh), None)),
+    "add_harmonics": lambda: fa.check(lib.flanhip_harmonic_scale_dev(P(pv), ch, F, BINS, SR, P(ser_har), BINS, 1, P(sh), None)),
+})
 # device warm-up: an idle MI355X needs tens of milliseconds of load before its clocks settle (see bench.py --preroll-ms)
 import time
 t_end = time.perf_counter() + 0.1
