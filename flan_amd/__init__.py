@@ -85,6 +85,8 @@ _SIGS = {
     "flanhip_place_frames_dev": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _i64, _i64, _i32, _i64, _vp]),
     "flanhip_select_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i32, _vp, _i64, _vp, _vp]),
     "flanhip_harmonic_scale_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _i32, _i32, _vp, _vp]),
+    "flanhip_smear_time_plan": (C.c_int, [_i64, _i32, _f32, _i32, _vp, _f32, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "flanhip_smear_time_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i32, _vp, _f32, _vp, _i32, _vp, _i64, _i32, _i64, _vp, _vp]),
     "flanhip_mid_side_dev": (C.c_int, [_vp, _i64, _vp, _vp]),
     "flanhip_resample_out_frames": (_i64, [_i64, _f32, _f32]),
     "flanhip_resample": (C.c_int, [_vp, _i64, _i64, _f32, _f32, _vp, _vp]),
@@ -398,6 +400,36 @@ def harmonic_scale(pv, sample_rate, series, mode):
     d_s = DeviceArray(host=series) if H else None
     check(lib.flanhip_harmonic_scale_dev(_vp(d_pv.ptr), ch, F, bins, sample_rate, _vp(d_s.ptr) if d_s else None, H, mode, _vp(d_out.ptr), None))
     return d_out.to_host(pv.shape)
+
+
+def smear_time_plan(num_frames, num_bins, sample_rate, hop, smear):
+    """(true_left, out_frames, dist_samples_2) of PV::smear_time for a smear grid float32 [F][bins] or a scalar"""
+    left, Fo, half = C.c_int32(0), C.c_int64(0), C.c_int32(0)
+    if np.isscalar(smear):
+        check(lib.flanhip_smear_time_plan(num_frames, num_bins, sample_rate, hop, None, float(smear), C.byref(left), C.byref(Fo), C.byref(half)))
+    else:
+        g = np.ascontiguousarray(smear, np.float32)
+        assert g.shape == (num_frames, num_bins)
+        check(lib.flanhip_smear_time_plan(num_frames, num_bins, sample_rate, hop, g.ctypes.data_as(_vp), 0.0, C.byref(left), C.byref(Fo), C.byref(half)))
+    return left.value, Fo.value, half.value
+
+
+def smear_time(pv, sample_rate, hop, smear, granularity, dist, true_left, out_frames):
+    """PV::smear_time.  smear: float32 [F][bins] or scalar; granularity: int32 [F][bins] or scalar; dist: float32 [2 * dist_samples_2]"""
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    s_ptr, s_const, _k1 = _grid_or_const(smear)
+    if np.isscalar(granularity):
+        g_ptr, g_const, _k2 = None, int(granularity), None
+    else:
+        _k2 = DeviceArray(host=np.ascontiguousarray(granularity, np.int32))
+        g_ptr, g_const = _vp(_k2.ptr), 0
+    dist = np.ascontiguousarray(dist, np.float32)
+    d_dist = DeviceArray(host=dist) if len(dist) else None
+    d_pv, d_out = DeviceArray(host=pv), DeviceArray(ch * out_frames * bins * 8)
+    check(lib.flanhip_smear_time_dev(_vp(d_pv.ptr), ch, F, bins, sample_rate, hop, s_ptr, s_const, g_ptr, g_const,
+                                     _vp(d_dist.ptr) if d_dist else None, len(dist), true_left, out_frames, _vp(d_out.ptr), None))
+    return d_out.to_host((ch, out_frames, bins, 2))
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -137,6 +137,42 @@ __global__ __launch_bounds__( 256 ) void k_harmonic_scale( const MFd * in, int64
 		}
 	}
 
+// PV/PVModify.cpp:566-603 smear_time: one thread per output MF averages the MFs of its bin over the frames around it, weighted by
+// the sampled distribution; fp32 products, fp64 sums, like the reference.  Lanes are adjacent bins, so every step of the walk over
+// frames is one coalesced row segment.  grid = ( ceil(bins/256), out_frames, channels ) folded into x.
+__global__ __launch_bounds__( 256 ) void k_smear_time( const MFd * in, int64_t F, int bins, float sr, float hop, const float * smear, float smear_const,
+	const int * gran, int gran_const, const float * dist, int n_dist, int true_left, int64_t Fo, int blocks_per_row, MFd * out )
+	{
+	const int64_t row = blockIdx.x / blocks_per_row;                                  // channel * Fo + out_frame
+	const int b = int( blockIdx.x % blocks_per_row ) * 256 + threadIdx.x;
+	if( b >= bins ) return;
+	const int64_t of = row % Fo, channel = row / Fo;
+	const int64_t in_frame = min( max( of + true_left, int64_t( 0 ) ), F - 1 );       // :569
+	float smear_size_c = smear ? smear[in_frame * bins + b] : smear_const;
+	smear_size_c = smear_size_c < 0.0f ? 0.0f : smear_size_c;                         // :524
+	const int expansion = n_dist > 0 ? max( to_int_sat( time_to_frame( smear_size_c, sr, hop ) ), 0 ) : 0;   // :574 (a NaN size spreads over no frames)
+	const int granularity_c = max( gran ? gran[in_frame * bins + b] : gran_const, 1 );   // :579, :521
+	double mag_sum = 0, freq_sum = 0, total_dist_weight = 0, dist_weight_used = 0;
+	const MFd * col = in + channel * F * bins + b;
+	for( int64_t off = -int64_t( expansion ); off < expansion; off += granularity_c )
+		{
+		const float dist_input = frame_to_time( float( int( off ) ), sr, hop ) / smear_size_c;      // :583
+		int access = to_int_sat( float( n_dist ) * 0.5f * ( 1.0f + dist_input ) );                  // :584
+		access = min( max( access, 0 ), n_dist - 1 );                                                // :585
+		const float dist_c = dist[access];
+		total_dist_weight += double( dist_c );
+		const int64_t source = of + true_left + off;                                  // :589
+		if( source < 0 || source >= F ) continue;
+		const MFd mf_c = col[source * bins];
+		dist_weight_used += double( dist_c );
+		mag_sum += double( mf_c.m * dist_c );                                         // :594-595
+		freq_sum += double( mf_c.f * dist_c );
+		}
+	if( total_dist_weight > 0.0 ) mag_sum /= total_dist_weight;                       // :600-601
+	if( dist_weight_used > 0.0 ) freq_sum /= dist_weight_used;
+	out[row * bins + b] = MFd{ float( mag_sum ), float( freq_sum ) };
+	}
+
 } // namespace flanhip
 
 using namespace flanhip;
@@ -293,6 +329,58 @@ int flanhip_harmonic_scale_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, 
 	else
 		hipLaunchKernelGGL( k_harmonic_scale<1>, dim3( unsigned( ch * F ) ), dim3( 256 ), lds, (hipStream_t) stream, (const MFd*) d_pv, F, bins, sr, float( ( bins - 1 ) * 2 ),
 			d_series, num_harmonics, staged, (MFd*) d_out );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+int flanhip_smear_time_plan( int64_t F, int bins, float sr, int hop, const float * smear, float smear_const, int32_t * true_left, int64_t * out_frames, int32_t * dist_samples_2 )
+	{
+	FLANHIP_REQUIRE( true_left && out_frames && dist_samples_2, FLANHIP_ERR_INVALID_ARG, "null out pointer" );
+	FLANHIP_REQUIRE( F > 0 && F <= INT32_MAX && bins > 0 && hop >= 1 && sr > 0.0f, FLANHIP_ERR_INVALID_ARG, "bad sizes" );
+	auto expansion_of = [&]( float v )                                                // Frame( time_to_frame( max( s, 0 ) ) ), PVModify.cpp:524,:544
+		{
+		v = v < 0.0f ? 0.0f : v;
+		const float fr = v * sr / float( hop );
+		if( !( fr == fr ) ) return int64_t( 0 );
+		return int64_t( fr >= 2147483648.0f ? INT32_MAX : int32_t( fr ) );
+		};
+	int64_t left = 0, right = F - 1;                                                  // :536-537
+	float mx = smear ? smear[0] : smear_const;
+	mx = mx < 0.0f ? 0.0f : mx;
+	if( smear )
+		for( int64_t fr = 0; fr < F; ++fr )                                           // :538-550 (min / max over everything: the loop order is free)
+			for( int b = 0; b < bins; ++b )
+				{
+				float v = smear[fr * bins + b];
+				v = v < 0.0f ? 0.0f : v;
+				const int64_t e = expansion_of( v );
+				left = std::min( left, fr - e );
+				right = std::max( right, fr + e );
+				}
+	else { const int64_t e = expansion_of( smear_const ); left = -e; right = F - 1 + e; }
+	if( smear )                                                                       // FunctionSample::maximum = std::max_element, in buffer order
+		for( int64_t i = 1; i < F * bins; ++i ) { float v = smear[i]; v = v < 0.0f ? 0.0f : v; if( mx < v ) mx = v; }
+	FLANHIP_REQUIRE( left >= INT32_MIN && right - left <= INT32_MAX, FLANHIP_ERR_INVALID_ARG, "smear sizes beyond the frame range" );
+	*true_left = int32_t( left );
+	*out_frames = right - left;                                                       // :563
+	const int64_t half = expansion_of( mx ) * 2;                                      // :555-556
+	FLANHIP_REQUIRE( half <= INT32_MAX / 2, FLANHIP_ERR_INVALID_ARG, "smear sizes beyond the frame range" );
+	*dist_samples_2 = int32_t( half );
+	return FLANHIP_OK;
+	}
+
+int flanhip_smear_time_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, int hop, const float * d_smear, float smear_const,
+	const int32_t * d_granularity, int32_t granularity_const, const float * d_distribution, int64_t n_distribution, int32_t true_left, int64_t out_frames,
+	flanhip_MF * d_out, void * stream )
+	{
+	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, sr ) ) return rc;
+	FLANHIP_REQUIRE( hop >= 1 && out_frames > 0, FLANHIP_ERR_INVALID_ARG, "bad hop or output frame count" );
+	FLANHIP_REQUIRE( n_distribution >= 0 && n_distribution <= INT32_MAX && ( n_distribution == 0 || d_distribution ), FLANHIP_ERR_INVALID_ARG, "bad distribution table" );
+	const int blocks_per_row = ( bins + 255 ) / 256;
+	FLANHIP_REQUIRE( ch * out_frames * blocks_per_row < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_INVALID_ARG, "too many rows" );
+	// an empty table is legal only when no point spreads at all (dist_samples_2 = 0): the walk then never reads it
+	hipLaunchKernelGGL( k_smear_time, dim3( unsigned( ch * out_frames * blocks_per_row ) ), dim3( 256 ), 0, (hipStream_t) stream, (const MFd*) d_pv, F, bins, sr, float( hop ),
+		d_smear, smear_const, d_granularity, granularity_const, d_distribution, int( n_distribution ), true_left, out_frames, blocks_per_row, (MFd*) d_out );
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;
 	}

@@ -492,6 +492,41 @@ PV PV::freeze( const std::vector<Second> & pause_times, const std::vector<Second
 	return finish( rc, "freeze", f, std::move( out ) );
 	}
 
+PV PV::smear_time( const Function<TF, Second> & smear_size, const Function<TF, int> & granularity, const Function<Second, float> & distribution ) const
+	{
+	if( is_null() ) return PV();
+	// PVModify.cpp:520-524: both grids over this PV's domain (the clamps to >= 1 and >= 0 happen where the values are used)
+	FunctionSample2d<Second> smear_host{ 0.0f, 0, 0 };
+	std::shared_ptr<DeviceBlock> d_smear, d_gran;
+	if( !smear_size.is_constant() ) { d_smear = function_grid_to_device( *this, smear_size, &smear_host ); if( !d_smear ) return PV(); }
+	if( !granularity.is_constant() ) { d_gran = function_grid_to_device( *this, granularity ); if( !d_gran ) return PV(); }
+	int32_t true_left = 0, dist_samples_2 = 0;
+	int64_t Fo = 0;
+	if( !detail::report( flanhip_smear_time_plan( get_num_frames(), get_num_bins(), get_sample_rate(), get_hop_size(),
+			smear_size.is_constant() ? nullptr : smear_host.get_vector().data(), smear_size.is_constant() ? smear_size.get_constant() : 0.0f,
+			&true_left, &Fo, &dist_samples_2 ), "smear_time" ) ) return PV();       // :536-564
+	if( Fo <= 0 ) return PV();
+	// :558-560: the distribution sampled on [-1, 1)
+	std::vector<float> dist;
+	if( dist_samples_2 > 0 )
+		{
+		const auto sampled = distribution.sample( -dist_samples_2, dist_samples_2, 1.0f / dist_samples_2 );
+		if( sampled.is_constant() ) dist.assign( size_t( 2 ) * dist_samples_2, sampled.get_constant() );
+		else dist = sampled.get_vector();
+		}
+	auto d_dist = dist.empty() ? nullptr : upload( dist.data(), sizeof( float ) * dist.size() );
+	PVBuffer::Format f = get_format();
+	f.num_frames = Frame( Fo );                                                     // :562-563
+	const MF * d_pv = device_data();
+	auto out = DeviceBlock::allocate( sizeof( MF ) * mf_count( f ) );
+	if( ( !dist.empty() && !d_dist ) || !d_pv || !out ) return PV();
+	const int rc = flanhip_smear_time_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(), get_sample_rate(), get_hop_size(),
+		d_smear ? static_cast<const float*>( d_smear->ptr ) : nullptr, smear_size.is_constant() ? smear_size.get_constant() : 0.0f,
+		d_gran ? static_cast<const int32_t*>( d_gran->ptr ) : nullptr, granularity.is_constant() ? granularity.get_constant() : 0,
+		d_dist ? static_cast<const float*>( d_dist->ptr ) : nullptr, int64_t( dist.size() ), true_left, Fo, static_cast<flanhip_MF*>( out->ptr ), nullptr );
+	return finish( rc, "smear_time", f, std::move( out ) );
+	}
+
 // harmonic_scaler, PV.cpp:362-407
 static PV harmonic_scale( const PV & me, const Function<std::pair<Second, Harmonic>, float> & series, int mode, Harmonic num_harmonics )
 	{

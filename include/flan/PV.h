@@ -1,6 +1,7 @@
 // flan/PV.h -- the PV side of the phase-vocoder path (mirrors the reference's src/flan/PV/PV.h:27-96,270-310,420-432:
 // conversions and the frame processors named by BASELINE.json's configs).
 #pragma once
+#include <cmath>
 #include <string>
 #include <utility>
 #include <vector>
@@ -68,6 +69,10 @@ public:
 	PV select( Second length, const Function<TF, TF> & selector ) const;                                              // PV.h:236-239 (PV.cpp:92-127)
 	/** Time freeze.  Of several pauses on one frame the first given is kept (unspecified in the reference: its sort is not stable). */
 	PV freeze( const std::vector<Second> & pause_times, const std::vector<Second> & pause_lengths ) const;            // PV.h:247-250 (PV.cpp:129-198)
+	/** Every MF becomes the distribution-weighted average of its bin over the surrounding smear_size seconds, sampled every
+	 *  `granularity` frames (PV.h:327-340).  The default distribution is the reference's raised cosine. */
+	PV smear_time( const Function<TF, Second> & smear_size, const Function<TF, int> & granularity = 5,
+		const Function<Second, float> & distribution = []( Second t ){ return float( 0.5f * ( 1.0f + std::cos( 3.14159265358979323846 * t ) ) ); } ) const;   // (PVModify.cpp:513-605)
 	PV add_octaves( const Function<std::pair<Second, Harmonic>, float> & series_scale ) const;                        // PV.h:387-389 (PV.cpp:409-413)
 	PV add_harmonics( const Function<std::pair<Second, Harmonic>, float> & series_scale ) const;                      // PV.h:394-396 (PV.cpp:415-419)
 	PV cut_frames( Frame start, Frame end ) const;                                                                    // PV.h:473-476 (PV.cpp:643-668)

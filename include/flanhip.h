@@ -254,6 +254,17 @@ int flanhip_select_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t nu
 int flanhip_harmonic_scale_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_frames, int num_bins, float sample_rate,
                                const float * d_series, int num_harmonics, int mode, flanhip_MF * d_out, void * stream);
 
+/* PV::smear_time (PV/PVModify.cpp:513-605).  The caller samples the three callables as :520-524 and :558-560 do:
+ *   smear: float[F][bins] seconds (NULL: smear_const), clamped to >= 0 inside;  granularity: int32[F][bins] (NULL: the constant),
+ *   clamped to >= 1 inside;  distribution: float[2 * dist_samples_2], distribution( x / dist_samples_2 ), x in [-dist_samples_2, dist_samples_2).
+ * flanhip_smear_time_plan (host arithmetic, host grid): the frame the output starts at, its frame count (:563) and dist_samples_2 (:555-556). */
+int flanhip_smear_time_plan(int64_t num_frames, int num_bins, float sample_rate, int hop, const float * smear, float smear_const,
+                            int32_t * true_left, int64_t * out_frames, int32_t * dist_samples_2);
+int flanhip_smear_time_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_frames, int num_bins, float sample_rate, int hop,
+                           const float * d_smear, float smear_const, const int32_t * d_granularity, int32_t granularity_const,
+                           const float * d_distribution, int64_t n_distribution, int32_t true_left, int64_t out_frames,
+                           flanhip_MF * d_out, void * stream);
+
 /* ---- Audio::convert_to_mid_side / convert_to_left_right (Audio/AudioConversions.cpp:32-56), stereo only ------ */
 int flanhip_mid_side_dev(const float * d_in, int64_t num_audio_frames, float * d_out, void * stream);
 

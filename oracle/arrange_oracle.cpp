@@ -199,4 +199,76 @@ int oracle_harmonic_scale( const float * pv_mf, int ch, int64_t F, int bins, flo
 	return 0;
 	}
 
+// PV/PVModify.cpp:513-605 smear_time.  The caller samples the three callables the way :520-524 and :558-560 do; this file takes:
+//   smear: float[F][bins] or nullptr + smear_const (clamped to >= 0 here, :524);  gran: int32[F][bins] or nullptr + gran_const
+//   (clamped to >= 1 here, :521);  dist: float[n_dist], distribution( x / dist_samples_2 ) for x in [-dist_samples_2, dist_samples_2).
+// oracle_smear_time_plan: :536-564 -- the frame the output starts at, the output's frame count, and dist_samples_2.
+// A NaN smear size converts to a frame count that is undefined in the reference; here such a point spreads over no frames.
+static inline float smear_at( const float * smear, float smear_const, int64_t fr, int bins, int b )
+	{
+	const float v = smear ? smear[size_t( fr ) * bins + b] : smear_const;
+	return v < 0.0f ? 0.0f : v;                                                       // std::max( s, 0.0f ), :524
+	}
+static inline int32_t expansion_of( float smear_c, float sr, int hop )
+	{
+	const int32_t e = to_int( time_to_frame( smear_c, sr, hop ) );
+	return e < 0 ? 0 : e;
+	}
+
+void oracle_smear_time_plan( int64_t F, int bins, float sr, int hop, const float * smear, float smear_const, int32_t * true_left, int64_t * out_frames, int32_t * dist_samples_2 )
+	{
+	int64_t left = 0, right = F - 1;                                                  // :536-537
+	float mx = smear_at( smear, smear_const, 0, bins, 0 );                            // FunctionSample::maximum = std::max_element
+	for( int b = 0; b < bins; ++b )
+		for( int64_t fr = 0; fr < F; ++fr )                                           // :538-550
+			{
+			const float sz = smear_at( smear, smear_const, fr, bins, b );
+			const int64_t e = expansion_of( sz, sr, hop );
+			left = std::min( left, fr - e );
+			right = std::max( right, fr + e );
+			}
+	if( smear ) { for( int64_t i = 0; i < F * bins; ++i ) { const float v = smear_at( smear, 0.0f, i / bins, bins, int( i % bins ) ); if( mx < v ) mx = v; } }
+	*true_left = int32_t( left );
+	*out_frames = right - left;                                                       // :563
+	*dist_samples_2 = expansion_of( mx, sr, hop ) * 2;                                // :555-556
+	}
+
+int oracle_smear_time( const float * pv_mf, int ch, int64_t F, int bins, float sr, int hop, const float * smear, float smear_const, const int32_t * gran, int32_t gran_const,
+	const float * dist, int64_t n_dist, int32_t true_left, int64_t Fo, float * out_mf )
+	{
+	const MF * pv = reinterpret_cast<const MF*>( pv_mf );
+	MF * out = reinterpret_cast<MF*>( out_mf );
+	for( int c = 0; c < ch; ++c )
+		for( int64_t of = 0; of < Fo; ++of )
+			{
+			const int64_t in_frame = std::clamp<int64_t>( of + true_left, 0, F - 1 );   // :569
+			for( int b = 0; b < bins; ++b )
+				{
+				const float smear_size_c = smear_at( smear, smear_const, in_frame, bins, b );
+				const int32_t expansion = expansion_of( smear_size_c, sr, hop );          // :574
+				double mag_sum = 0, freq_sum = 0, total_dist_weight = 0, dist_weight_used = 0;
+				const int32_t granularity_c = std::max( gran ? gran[size_t( in_frame ) * bins + b] : gran_const, int32_t( 1 ) );   // :579, :521
+				for( int64_t off = -int64_t( expansion ); off < expansion; off += granularity_c )   // :580
+					{
+					const float dist_input = ( float( int32_t( off ) ) / ( float( sr ) / float( hop ) ) ) / smear_size_c;   // :583 frame_to_time( offset ) / smear
+					const float access_f = float( size_t( n_dist ) ) * 0.5f * ( 1 + dist_input );                           // :584
+					int32_t access = to_int( access_f );
+					access = std::clamp( access, int32_t( 0 ), int32_t( n_dist - 1 ) );   // :585
+					const float dist_c = dist[access];
+					total_dist_weight += dist_c;                                          // :587
+					const int64_t source = of + true_left + off;                          // :589
+					if( source < 0 || source >= F ) continue;
+					const MF mf_c = pv[pos( F, bins, c, source, b )];
+					dist_weight_used += dist_c;
+					mag_sum += mf_c.m * dist_c;                                           // :594-595: fp32 products, fp64 sums
+					freq_sum += mf_c.f * dist_c;
+					}
+				if( total_dist_weight > 0.0 ) mag_sum /= total_dist_weight;               // :600-601
+				if( dist_weight_used > 0.0 ) freq_sum /= dist_weight_used;
+				out[pos( Fo, bins, c, of, b )] = MF{ float( mag_sum ), float( freq_sum ) };
+				}
+			}
+	return 0;
+	}
+
 } // extern "C"

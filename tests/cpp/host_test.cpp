@@ -311,6 +311,17 @@ static void device_checks()
 		PV har = pv.add_harmonics( []( std::pair<Second, Harmonic> th ){ return th.second == 1 ? 0.25f : 0.0f; } );   // harmonic index 1 = the third partial (PV.cpp:393,417)
 		CHECK( har.get_MF( 0, 100, Bin( pv.frequency_to_bin( f19 * 3.0f ) ) ).f == f19 * 3.0f && har.get_MF( 0, 100, Bin( pv.frequency_to_bin( f19 * 3.0f ) ) ).m == pv.get_MF( 0, 100, 19 ).m * 0.25f );
 		CHECK( har.get_MF( 0, 100, Bin( pv.frequency_to_bin( f19 * 2.0f ) ) ).m == 0.0f );
+		// smear_time with a box distribution: the plain mean of the 2e frames around (PVModify.cpp:580-601); the output starts e frames early
+			{
+			const Frame e = Frame( p2.time_to_frame( 0.05f ) );
+			PV sm = p2.smear_time( 0.05f, 1, 1.0f );
+			CHECK( e == 4 && sm.get_num_frames() == F - 1 + 2 * e );
+			double mean_m = 0, mean_f = 0;
+			for( Frame k = -e; k < e; ++k ) { mean_m += double( p2.get_MF( 1, 30 + k, 77 ).m * 1.0f ); mean_f += double( p2.get_MF( 1, 30 + k, 77 ).f * 1.0f ); }
+			CHECK( sm.get_MF( 1, 30 + e, 77 ).m == float( mean_m / ( 2.0 * e ) ) && sm.get_MF( 1, 30 + e, 77 ).f == float( mean_f / ( 2.0 * e ) ) );
+			PV sm_default = p2.smear_time( []( TF tf ){ return tf.f < 6000.0f ? 0.03f : 0.08f; } );   // default granularity 5, raised cosine
+			CHECK( !sm_default.is_null() && sm_default.get_num_frames() == F - 1 + 2 * Frame( p2.time_to_frame( 0.08f ) ) );
+			}
 		(void) B;
 		}
 	// ---- a grid large enough to go over in slabs (sampled slab k+1 while slab k uploads) = the same grid sampled in one piece

@@ -83,6 +83,10 @@ def _load():
     lib.oracle_cut_frames_range.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.oracle_place_frames.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, f32p, C.c_int, C.c_int64, C.c_int, C.c_int64]
     lib.oracle_harmonic_scale.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, C.c_float, f32p, C.c_int, C.c_int, f32p]
+    lib.oracle_smear_time_plan.restype = None
+    lib.oracle_smear_time_plan.argtypes = [C.c_int64, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_float, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+    lib.oracle_smear_time.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
+                                      C.c_int32, C.c_int64, f32p]
     return lib
 
 
@@ -352,6 +356,41 @@ def harmonic_scale(pv, sample_rate, series, mode):
     out = np.empty_like(pv)
     lib.oracle_harmonic_scale(pv.reshape(-1), ch, F, bins, sample_rate, series.reshape(-1) if H else np.zeros(1, np.float32), H, mode, out.reshape(-1))
     return out
+
+
+def smear_time_plan(num_frames, num_bins, sample_rate, hop, smear):
+    left, Fo, half = C.c_int32(0), C.c_int64(0), C.c_int32(0)
+    if np.isscalar(smear):
+        lib.oracle_smear_time_plan(num_frames, num_bins, sample_rate, hop, None, float(smear), C.byref(left), C.byref(Fo), C.byref(half))
+    else:
+        g = np.ascontiguousarray(smear, np.float32)
+        lib.oracle_smear_time_plan(num_frames, num_bins, sample_rate, hop, g.ctypes.data, 0.0, C.byref(left), C.byref(Fo), C.byref(half))
+    return left.value, Fo.value, half.value
+
+
+def smear_time(pv, sample_rate, hop, smear, granularity, dist, true_left, out_frames):
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    sg = None if np.isscalar(smear) else np.ascontiguousarray(smear, np.float32)
+    gg = None if np.isscalar(granularity) else np.ascontiguousarray(granularity, np.int32)
+    dist = np.ascontiguousarray(dist, np.float32)
+    out = np.empty((ch, out_frames, bins, 2), np.float32)
+    lib.oracle_smear_time(pv.reshape(-1), ch, F, bins, sample_rate, hop, sg.ctypes.data if sg is not None else None, 0.0 if sg is not None else float(smear),
+                          gg.ctypes.data if gg is not None else None, 0 if gg is not None else int(granularity),
+                          dist.ctypes.data if len(dist) else None, len(dist), true_left, out_frames, out.reshape(-1))
+    return out
+
+
+def smear_distribution(dist_samples_2, fn=None):
+    """PVModify.cpp:558-560: distribution( x / dist_samples_2 ) for x in [-dist_samples_2, dist_samples_2); the default
+    distribution is PV.h:336-339, 0.5 ( 1 + cos( pi t ) ) in double, rounded to float"""
+    if dist_samples_2 <= 0:
+        return np.zeros(0, np.float32)
+    x = np.arange(-dist_samples_2, dist_samples_2, dtype=np.int64)
+    t = (x.astype(np.float32) * np.float32(np.float32(1.0) / np.float32(dist_samples_2))).astype(np.float32)
+    if fn is None:
+        return (0.5 * (1.0 + np.cos(np.pi * t.astype(np.float64)))).astype(np.float32)
+    return np.array([fn(float(v)) for v in t], np.float32)
 
 
 def mid_side(audio):

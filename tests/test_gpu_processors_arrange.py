@@ -125,3 +125,23 @@ def test_add_octaves_and_harmonics(fa, pv_small, pv_wide):
     for mode, H in ((0, 15), (1, pv.shape[2])):
         series = np.ones((pv.shape[1], H), np.float32)
         assert_identical("harmonic_scale special mode=%d" % mode, fa.harmonic_scale(pv, SR, series, mode), O.harmonic_scale(pv, SR, series, mode))
+
+
+def test_smear_time(fa, pv_small, pv_wide):
+    rng = np.random.default_rng(21)
+    for pv in (pv_small, pv_wide):
+        ch, F, bins, _ = pv.shape
+        grids = [(0.02, 1), (0.1, 5), (0.0, 5), (0.003, 1),
+                 (rng.uniform(-0.02, 0.12, (F, bins)).astype(np.float32), rng.integers(-2, 7, (F, bins)).astype(np.int32)),
+                 (rng.uniform(0.0, 0.05, (F, bins)).astype(np.float32), 2)]
+        weird = rng.uniform(0.0, 0.05, (F, bins)).astype(np.float32)
+        weird[3, :4] = [np.nan, np.inf, -np.inf, 1e-30]
+        weird[3, 1] = 0.2                                                            # (an infinite size is refused by the plan: not a frame count)
+        grids.append((weird, 1))
+        for smear, gran in grids:
+            left, Fo, half = O.smear_time_plan(F, bins, SR, HOP, smear)
+            assert (left, Fo, half) == fa.smear_time_plan(F, bins, SR, HOP, smear)
+            for dname, dist in (("hann", O.smear_distribution(half)), ("box", np.ones(2 * half, np.float32)), ("signed", rng.uniform(-1, 1, 2 * half).astype(np.float32))):
+                got = fa.smear_time(pv, SR, HOP, smear, gran, dist, left, Fo)
+                ref = O.smear_time(pv, SR, HOP, smear, gran, dist, left, Fo)
+                assert_identical("smear_time %s / %s" % ("grid" if not np.isscalar(smear) else smear, dname), got, ref)

@@ -142,3 +142,48 @@ def test_harmonic_scale_against_numpy():
                         ref[0, fr, hb] = (mag, hf)
         assert np.array_equal(got, ref), mode
         assert got.any()
+
+
+def test_smear_time_against_numpy_and_plan_helpers_agree():
+    import flan_amd
+    pv = small_pv(ch=1, n=5000, dft=128)
+    ch, F, bins, _ = pv.shape
+    rng = np.random.default_rng(12)
+    ar = np.float32(SR) / np.float32(HOP)
+    for smear, gran in ((0.02, 1), (0.05, 3), (rng.uniform(-0.01, 0.06, (F, bins)).astype(np.float32), rng.integers(-1, 5, (F, bins)).astype(np.int32)), (0.0, 5)):
+        plan = O.smear_time_plan(F, bins, SR, HOP, smear)
+        assert plan == flan_amd.smear_time_plan(F, bins, SR, HOP, smear)              # host arithmetic of the library, no device
+        left, Fo, half = plan
+        dist = O.smear_distribution(half)
+        assert len(dist) == 2 * half
+        got = O.smear_time(pv, SR, HOP, smear, gran, dist, left, Fo)
+        ref = np.zeros((1, Fo, bins, 2), np.float32)
+        for of in range(Fo):
+            inf = min(max(of + left, 0), F - 1)
+            for b in range(bins):
+                sz = np.float32(max(smear if np.isscalar(smear) else smear[inf, b], 0.0))
+                e = int(np.float32(sz * np.float32(SR) / np.float32(HOP)))
+                g = max(int(gran if np.isscalar(gran) else gran[inf, b]), 1)
+                ms = fs = tw = uw = 0.0
+                for off in range(-e, e, g):
+                    di = np.float32(np.float32(np.float32(off) / ar) / sz)
+                    acc = int(np.float32(np.float32(np.float32(len(dist)) * np.float32(0.5)) * np.float32(np.float32(1) + di)))
+                    acc = min(max(acc, 0), len(dist) - 1)
+                    d = dist[acc]
+                    tw += float(d)
+                    src = of + left + off
+                    if src < 0 or src >= F:
+                        continue
+                    uw += float(d)
+                    ms += float(np.float32(pv[0, src, b, 0] * d))
+                    fs += float(np.float32(pv[0, src, b, 1] * d))
+                if tw > 0:
+                    ms /= tw
+                if uw > 0:
+                    fs /= uw
+                ref[0, of, b] = (np.float32(ms), np.float32(fs))
+        assert np.array_equal(got, ref)
+    # no smear at all: the output is the input minus its last frame (PVModify.cpp:563: rightmost - leftmost), every MF zero
+    # because a point that spreads over no frames averages nothing (:580)
+    left, Fo, half = O.smear_time_plan(F, bins, SR, HOP, 0.0)
+    assert (left, Fo, half) == (0, F - 1, 0)
