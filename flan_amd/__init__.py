@@ -85,6 +85,8 @@ _SIGS = {
     "flanhip_place_frames_dev": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _i64, _i64, _i32, _i64, _vp]),
     "flanhip_select_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i32, _vp, _i64, _vp, _vp]),
     "flanhip_harmonic_scale_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _i32, _i32, _vp, _vp]),
+    "flanhip_modify_out_frames": (_i64, [_vp, _i64, _i32, _f32, _i32]),
+    "flanhip_modify_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i32, _vp, _vp, _i32, _i64, _vp, _vp]),
     "flanhip_smear_time_plan": (C.c_int, [_i64, _i32, _f32, _i32, _vp, _f32, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "flanhip_smear_time_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i32, _vp, _f32, _vp, _i32, _vp, _i64, _i32, _i64, _vp, _vp]),
     "flanhip_mid_side_dev": (C.c_int, [_vp, _i64, _vp, _vp]),
@@ -400,6 +402,27 @@ def harmonic_scale(pv, sample_rate, series, mode):
     d_s = DeviceArray(host=series) if H else None
     check(lib.flanhip_harmonic_scale_dev(_vp(d_pv.ptr), ch, F, bins, sample_rate, _vp(d_s.ptr) if d_s else None, H, mode, _vp(d_out.ptr), None))
     return d_out.to_host(pv.shape)
+
+
+def modify_out_frames(mod_tf, sample_rate, hop):
+    mod = np.ascontiguousarray(mod_tf, np.float32)
+    F, bins, _ = mod.shape
+    return int(lib.flanhip_modify_out_frames(mod.ctypes.data_as(_vp), F, bins, sample_rate, hop))
+
+
+def modify(pv, sample_rate, hop, mod_tf, in_f, interp=0, out_frames=None):
+    """PV::modify.  mod_tf: float32 [F][bins][2] (seconds, Hz); in_f: float32 [ch][F][bins]"""
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    mod = np.ascontiguousarray(mod_tf, np.float32)
+    in_f = np.ascontiguousarray(in_f, np.float32)
+    assert mod.shape == (F, bins, 2) and in_f.shape == (ch, F, bins)
+    Fo = modify_out_frames(mod, sample_rate, hop) if out_frames is None else out_frames
+    if Fo <= 0:
+        return None
+    d_pv, d_mod, d_f, d_out = DeviceArray(host=pv), DeviceArray(host=mod), DeviceArray(host=in_f), DeviceArray(ch * Fo * bins * 8)
+    check(lib.flanhip_modify_dev(_vp(d_pv.ptr), ch, F, bins, sample_rate, hop, _vp(d_mod.ptr), _vp(d_f.ptr), interp, Fo, _vp(d_out.ptr), None))
+    return d_out.to_host((ch, Fo, bins, 2))
 
 
 def smear_time_plan(num_frames, num_bins, sample_rate, hop, smear):

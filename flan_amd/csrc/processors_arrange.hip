@@ -173,6 +173,139 @@ __global__ __launch_bounds__( 256 ) void k_smear_time( const MFd * in, int64_t F
 	out[row * bins + b] = MFd{ float( mag_sum ), float( freq_sum ) };
 	}
 
+// ---------------------------------------------------------------------------------------------------------------------
+// PV::modify (PV/PVModify.cpp:15-193): every input quad is mapped to a quad of the output and rasterised there; an output point
+// keeps the loudest weighted corner offered to it.  Two passes over the output, which doubles as the key store (an MF and a key
+// are both 8 bytes):
+//   k_modify_offer    thread per input quad: walks its bounding box in the reference's order (x outside, y inside, `break` leaves
+//                     the column) and offers ( weight bits << 32 | ~quad index ) to every point it covers, global atomic max
+//   k_modify_resolve  thread per output point: decodes the winning quad, evaluates that one point again (same code, same bits) to learn
+//                     WHICH corner was the loudest, and replaces the key by { weight, that corner's mapped frequency }
+// The arithmetic is what g++ makes of the reference's expressions (see oracle/arrange_oracle.cpp): sqrt and the division after it in
+// double, rounded to float once.  Equally loud candidates: the first quad in ( frame, bin ) order (unspecified in the reference,
+// which runs frames in parallel under a mutex per output frame).
+// ---------------------------------------------------------------------------------------------------------------------
+struct Quad { float px[4], py[4], pm[4]; };
+
+// 0: not inside; 1: `break`; 2: candidate
+__device__ __forceinline__ int quad_point( const Quad & q, int xi, int yi, int interp_kind, float & weight, int & corner )
+	{
+	const float * px = q.px; const float * py = q.py;
+	const float x = float( xi ), y = float( yi );
+	const float D12x = px[1] - px[0], D12y = py[1] - py[0];                            // :87-90
+	const float D23x = px[2] - px[1], D23y = py[2] - py[1];
+	const float D34x = px[3] - px[2], D34y = py[3] - py[2];
+	const float D41x = px[0] - px[3], D41y = py[0] - py[3];
+	bool c = false;                                                                   // :105-109
+	if( ( ( py[0] <= y && y < py[3] ) || ( py[3] <= y && y < py[0] ) ) && ( x < D41x / D41y * ( y - py[0] ) + px[0] ) ) c = !c;
+	if( ( ( py[1] <= y && y < py[0] ) || ( py[0] <= y && y < py[1] ) ) && ( x < D12x / D12y * ( y - py[1] ) + px[1] ) ) c = !c;
+	if( ( ( py[2] <= y && y < py[1] ) || ( py[1] <= y && y < py[2] ) ) && ( x < D23x / D23y * ( y - py[2] ) + px[2] ) ) c = !c;
+	if( ( ( py[3] <= y && y < py[2] ) || ( py[2] <= y && y < py[3] ) ) && ( x < D34x / D34y * ( y - py[3] ) + px[3] ) ) c = !c;
+	if( !c ) return 0;
+	const float a0 = px[0], a1 = px[1] - px[0], a2 = px[3] - px[0], a3 = px[0] - px[1] + px[2] - px[3];   // :116-117
+	const float b0 = py[0], b1 = py[1] - py[0], b2 = py[3] - py[0], b3 = py[0] - py[1] + py[2] - py[3];
+	const float quadA = a3 * b2 - a2 * b3;                                            // :119-124
+	const float quadB = a3 * b0 - a0 * b3 + a1 * b2 - a2 * b1 + x * b3 - a3 * y;
+	const float quadC = a1 * b0 - a0 * b1 + x * b1 - a1 * y;
+	float m;
+	if( quadA == 0.0f )                                                               // :126-138
+		{
+		if( quadB == 0.0f ) return 1;
+		m = -quadC / quadB;
+		}
+	else
+		{
+		const float descriminant = quadB * quadB - 4.0f * quadA * quadC;
+		if( descriminant < 0.0f ) return 1;
+		m = float( ( double( -quadB ) + sqrt( double( descriminant ) ) ) / double( 2.0f * quadA ) );
+		}
+	const float lDenominator = a1 + a3 * m;                                           // :139-141
+	if( lDenominator == 0.0f ) return 1;
+	const float l = ( x - a0 - a2 * m ) / lDenominator;
+	const float epsilon = 0.0001f;                                                    // :144-145
+	if( fabsf( l - 0.5f ) > 0.5f + epsilon || fabsf( m - 0.5f ) > 0.5f + epsilon ) return 1;
+	const float interpL = interpolate( interp_kind, l ), interpM = interpolate( interp_kind, m );   // :147-148
+	const float w[4] = { ( 1.0f - interpL ) * ( 1.0f - interpM ) * q.pm[0], ( interpL ) * ( 1.0f - interpM ) * q.pm[1],   // :150-154
+	                     ( interpL ) * ( interpM ) * q.pm[2], ( 1.0f - interpL ) * ( interpM ) * q.pm[3] };
+	const float totalWeight = w[0] + w[1] + w[2] + w[3];                              // :155-156
+	if( totalWeight <= 0.0f ) return 1;
+	int largest = 0;                                                                  // std::max_element, :169-170
+	float best = w[0];
+	#pragma unroll
+	for( int i = 1; i < 4; ++i ) if( best < w[i] ) { best = w[i]; largest = i; }
+	weight = best;
+	corner = largest;
+	return 2;
+	}
+
+__device__ __forceinline__ Quad load_quad( const MFd * in_channel, const float2 * mod, int64_t frame, int bin, int bins, float sr, float hop, float dft )
+	{
+	const int64_t idx[4] = { ( frame - 1 ) * bins + bin - 1, frame * bins + bin - 1, frame * bins + bin, ( frame - 1 ) * bins + bin };   // :76-86
+	Quad q;
+	#pragma unroll
+	for( int k = 0; k < 4; ++k )
+		{
+		const float2 v = mod[idx[k]];
+		q.px[k] = time_to_frame( v.x, sr, hop );                                      // :23-26
+		q.py[k] = frequency_to_bin( v.y, sr, dft );
+		q.pm[k] = in_channel[idx[k]].m;
+		}
+	return q;
+	}
+
+__global__ __launch_bounds__( 256 ) void k_modify_offer( const MFd * in, int64_t F, int bins, float sr, float hop, float dft, const float2 * mod, int interp_kind,
+	int64_t Fo, int blocks_per_row, unsigned long long * out_keys )
+	{
+	const int64_t row = blockIdx.x / blocks_per_row;                                  // channel * ( F - 1 ) + ( frame - 1 )
+	const int bin = 1 + int( blockIdx.x % blocks_per_row ) * 256 + threadIdx.x;
+	if( bin >= bins ) return;
+	const int64_t frame = 1 + row % ( F - 1 ), channel = row / ( F - 1 );
+	const Quad q = load_quad( in + channel * F * bins, mod, frame, bin, bins, sr, hop, dft );
+	// A quad with a NaN or infinite corner is skipped: NaNs then run through every expression of :116-156 and no candidate survives
+	// them (except through the interpolators that ignore their argument -- an accident not reproduced), while the bounding box of
+	// such a quad is the whole output.
+	bool finite = true;
+	#pragma unroll
+	for( int k = 0; k < 4; ++k ) finite = finite && fabsf( q.px[k] ) < INFINITY && fabsf( q.py[k] ) < INFINITY;
+	if( !finite ) return;
+	// :93-96: the bounding box, clipped to the output
+	const int minx = to_int_sat( fmaxf( floorf( fminf( fminf( q.px[0], q.px[1] ), fminf( q.px[2], q.px[3] ) ) ), 0.0f ) );
+	const int miny = to_int_sat( fmaxf( floorf( fminf( fminf( q.py[0], q.py[1] ), fminf( q.py[2], q.py[3] ) ) ), 0.0f ) );
+	const int maxx = to_int_sat( fminf( ceilf( fmaxf( fmaxf( q.px[0], q.px[1] ), fmaxf( q.px[2], q.px[3] ) ) ), float( Fo - 1 ) ) );
+	const int maxy = to_int_sat( fminf( ceilf( fmaxf( fmaxf( q.py[0], q.py[1] ), fmaxf( q.py[2], q.py[3] ) ) ), float( bins - 1 ) ) );
+	const unsigned long long low = (unsigned long long) ( 0xFFFFFFFFu - unsigned( frame * bins + bin ) );
+	unsigned long long * keys = out_keys + channel * Fo * bins;
+	for( int x = minx; x <= maxx; ++x )                                               // :99-101
+		for( int y = miny; y <= maxy; ++y )
+			{
+			float weight; int corner;
+			const int r = quad_point( q, x, y, interp_kind, weight, corner );
+			if( r == 0 ) continue;
+			if( r == 1 ) break;
+			if( weight > 0.0f )                                                       // :175: beats the cleared output or a quieter occupant; false for NaN
+				atomicMax( &keys[int64_t( x ) * bins + y], ( (unsigned long long) __float_as_uint( weight ) << 32 ) | low );
+			}
+	}
+
+__global__ __launch_bounds__( 256 ) void k_modify_resolve( const MFd * in, int64_t F, int bins, float sr, float hop, float dft, const float2 * mod, const float * in_f,
+	int interp_kind, int64_t Fo, int blocks_per_row, MFd * out )
+	{
+	const int64_t row = blockIdx.x / blocks_per_row;                                  // channel * Fo + x
+	const int y = int( blockIdx.x % blocks_per_row ) * 256 + threadIdx.x;
+	if( y >= bins ) return;
+	const int64_t x = row % Fo, channel = row / Fo;
+	const unsigned long long key = reinterpret_cast<const unsigned long long *>( out )[row * bins + y];
+	if( key == 0ull ) return;                                                         // nothing offered: stays { 0, 0 }
+	const unsigned seq = 0xFFFFFFFFu - unsigned( key & 0xFFFFFFFFull );
+	const int64_t frame = seq / unsigned( bins );
+	const int bin = int( seq % unsigned( bins ) );
+	const Quad q = load_quad( in + channel * F * bins, mod, frame, bin, bins, sr, hop, dft );
+	float weight = 0.0f; int corner = 0;
+	quad_point( q, int( x ), y, interp_kind, weight, corner );                        // the offer again: same code, same bits
+	const int64_t idx[4] = { ( frame - 1 ) * bins + bin - 1, frame * bins + bin - 1, frame * bins + bin, ( frame - 1 ) * bins + bin };
+	out[row * bins + y] = MFd{ __uint_as_float( unsigned( key >> 32 ) ), in_f[channel * F * bins + idx[corner]] };   // :176
+	}
+
 } // namespace flanhip
 
 using namespace flanhip;
@@ -329,6 +462,41 @@ int flanhip_harmonic_scale_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, 
 	else
 		hipLaunchKernelGGL( k_harmonic_scale<1>, dim3( unsigned( ch * F ) ), dim3( 256 ), lds, (hipStream_t) stream, (const MFd*) d_pv, F, bins, sr, float( ( bins - 1 ) * 2 ),
 			d_series, num_harmonics, staged, (MFd*) d_out );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+int64_t flanhip_modify_out_frames( const float * mod_tf, int64_t F, int bins, float sr, int hop )
+	{
+	if( !mod_tf || F <= 0 || bins <= 0 || hop < 1 || !( sr > 0.0f ) ) return -1;
+	auto to_frame = [&]( float t ){ return t * sr / float( hop ); };                  // time_to_frame, PVBuffer.cpp:428-431
+	float mx = to_frame( mod_tf[0] );
+	for( int64_t i = 1; i < F * bins; ++i ) { const float v = to_frame( mod_tf[2 * i] ); if( mx < v ) mx = v; }   // PVModify.cpp:29: ranges::max_element, projected
+	const float last = std::ceil( mx );
+	if( last / ( sr / float( hop ) ) > 60.0f * 10.0f ) return -2;                     // :31: "longer than 10 minutes, which is currently disabled"
+	if( !( last == last ) || last < 1.0f ) return 0;
+	if( last >= 2147483648.0f ) return -1;
+	return int64_t( std::ceil( last ) );                                              // :38
+	}
+
+int flanhip_modify_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, int hop, const float * d_mod_tf, const float * d_in_f, int interp_kind,
+	int64_t out_frames, flanhip_MF * d_out, void * stream )
+	{
+	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, sr ) ) return rc;
+	FLANHIP_REQUIRE( d_mod_tf && d_in_f && hop >= 1 && out_frames > 0, FLANHIP_ERR_INVALID_ARG, "null grid, bad hop or bad output frame count" );
+	FLANHIP_REQUIRE( interp_kind >= 0 && interp_kind <= FLANHIP_INTERP_SINE, FLANHIP_ERR_INVALID_ARG, "unknown interpolator" );
+	FLANHIP_REQUIRE( F * bins < ( int64_t( 1 ) << 32 ), FLANHIP_ERR_UNSUPPORTED, "frames x bins does not fit the quad index" );
+	hipStream_t s = (hipStream_t) stream;
+	FLANHIP_CHECK( hipMemsetAsync( d_out, 0, sizeof( MFd ) * size_t( ch ) * out_frames * bins, s ) );   // PVModify.cpp:40
+	if( F < 2 ) return FLANHIP_OK;                                                    // no quads
+	const float dft = float( ( bins - 1 ) * 2 );
+	const int quad_blocks = ( bins - 1 + 255 ) / 256, point_blocks = ( bins + 255 ) / 256;
+	FLANHIP_REQUIRE( ch * ( F - 1 ) * quad_blocks < ( int64_t( 1 ) << 31 ) && ch * out_frames * point_blocks < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_INVALID_ARG, "too many rows" );
+	hipLaunchKernelGGL( k_modify_offer, dim3( unsigned( ch * ( F - 1 ) * quad_blocks ) ), dim3( 256 ), 0, s, (const MFd*) d_pv, F, bins, sr, float( hop ), dft,
+		reinterpret_cast<const float2*>( d_mod_tf ), interp_kind, out_frames, quad_blocks, reinterpret_cast<unsigned long long*>( d_out ) );
+	FLANHIP_CHECK( hipGetLastError() );
+	hipLaunchKernelGGL( k_modify_resolve, dim3( unsigned( ch * out_frames * point_blocks ) ), dim3( 256 ), 0, s, (const MFd*) d_pv, F, bins, sr, float( hop ), dft,
+		reinterpret_cast<const float2*>( d_mod_tf ), d_in_f, interp_kind, out_frames, point_blocks, (MFd*) d_out );
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;
 	}

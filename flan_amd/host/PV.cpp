@@ -492,6 +492,40 @@ PV PV::freeze( const std::vector<Second> & pause_times, const std::vector<Second
 	return finish( rc, "freeze", f, std::move( out ) );
 	}
 
+PV PV::modify( const Function<TF, TF> & mod, const Interpolator & interp ) const
+	{
+	if( is_null() ) return PV();
+	if( interp.kind() < 0 ) { std::cerr << "flan: modify runs the named interpolators only on the device path" << std::endl; return PV(); }
+	// PVModify.cpp:22: mod over this PV's grid -- on the host for the output's length (:28-38), on the device for the kernels
+	FunctionSample2d<TF> sampled{ TF{ 0.0f, 0.0f }, 0, 0 };
+	auto d_mod = function_grid_to_device( *this, mod, &sampled );
+	if( !d_mod ) return PV();
+	detail::StagingVector<TF> filled;
+	if( sampled.is_constant() ) filled.assign( sampled.size(), sampled.get_constant() );
+	const TF * host_grid = sampled.is_constant() ? filled.data() : sampled.get_vector().data();
+	const int64_t Fo = flanhip_modify_out_frames( reinterpret_cast<const float*>( host_grid ), get_num_frames(), get_num_bins(), get_sample_rate(), get_hop_size() );
+	if( Fo == -2 )                                                                  // :30-34
+		{
+		std::cout << "PV::modify tried to make a file longer than 10 minutes, which is currently disabled";
+		return PV();
+		}
+	if( Fo <= 0 ) return PV();
+	// :62-66: mod again, at every MF's own frequency -- data dependent, so on the host
+	auto d_in_f = map_rows_to_device<float>( *this, mod.get_execution_policy(), [&]( int row, const MF * mfs, float * out )
+		{
+		const Second t = frame_to_time( fFrame( Frame( row % get_num_frames() ) ) );
+		for( Bin bin = 0; bin < get_num_bins(); ++bin ) out[bin] = mod( TF{ t, mfs[bin].f } ).f;
+		} );
+	PVBuffer::Format f = get_format();
+	f.num_frames = Frame( Fo );
+	const MF * d_pv = device_data();
+	auto out = DeviceBlock::allocate( sizeof( MF ) * mf_count( f ) );
+	if( !d_in_f || !d_pv || !out ) return PV();
+	const int rc = flanhip_modify_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(), get_sample_rate(), get_hop_size(),
+		static_cast<const float*>( d_mod->ptr ), static_cast<const float*>( d_in_f->ptr ), interp.kind(), Fo, static_cast<flanhip_MF*>( out->ptr ), nullptr );
+	return finish( rc, "modify", f, std::move( out ) );
+	}
+
 PV PV::smear_time( const Function<TF, Second> & smear_size, const Function<TF, int> & granularity, const Function<Second, float> & distribution ) const
 	{
 	if( is_null() ) return PV();

@@ -40,6 +40,9 @@ public:
 	Audio convertToAudio( flan_CANCEL_ARG ) const;                               // older spelling
 
 	// ---- frame processors ----
+	/** The general time / frequency warp: every input quad is mapped by `mod` and rasterised into the output (PV.h:258-270).
+	 *  Named interpolators only.  Outputs longer than ten minutes are refused like the reference refuses them. */
+	PV modify( const Function<TF, TF> & mod, const Interpolator & = Interpolator::linear() ) const;                    // PV.h:267-270 (PVModify.cpp:15-193)
 	PV modify_frequency( const Function<TF, Frequency> & mod, const Interpolator & = Interpolator::linear() ) const;  // PV.h:276-279
 	PV modify_time( const Function<TF, Second> & mod, const Interpolator & = Interpolator::linear() ) const;          // PV.h:285-288
 	PV repitch( const Function<TF, float> & factor, const Interpolator & = Interpolator::linear() ) const;            // PV.h:294-297

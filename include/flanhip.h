@@ -254,6 +254,17 @@ int flanhip_select_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t nu
 int flanhip_harmonic_scale_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_frames, int num_bins, float sample_rate,
                                const float * d_series, int num_harmonics, int mode, flanhip_MF * d_out, void * stream);
 
+/* PV::modify (PV/PVModify.cpp:15-193): the general time / frequency warp.  The caller samples the callable twice, as the
+ * reference does:  d_mod_tf: TF{ t, f }[F][bins], mod over the input's grid (:22), seconds / Hz;  d_in_f: float[ch][F][bins],
+ * mod( { frame_to_time( frame ), the MF's own frequency } ).f (:62-66).  interp: FLANHIP_INTERP_*.
+ * flanhip_modify_out_frames (host arithmetic, host grid): the output's frame count (:28-38); -2 when it would be longer than 10
+ * minutes (the reference prints a message and returns a null PV, :30-34), 0 when there is nothing to make, -1 on bad arguments.
+ * Equally loud candidates for an output point: the first input quad in ( frame, bin ) order gives the frequency (unspecified in the
+ * reference, which runs frames in parallel); quads with a non-finite corner offer nothing. */
+int64_t flanhip_modify_out_frames(const float * mod_tf, int64_t num_frames, int num_bins, float sample_rate, int hop);
+int flanhip_modify_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_frames, int num_bins, float sample_rate, int hop,
+                       const float * d_mod_tf, const float * d_in_f, int interp, int64_t out_frames, flanhip_MF * d_out, void * stream);
+
 /* PV::smear_time (PV/PVModify.cpp:513-605).  The caller samples the three callables as :520-524 and :558-560 do:
  *   smear: float[F][bins] seconds (NULL: smear_const), clamped to >= 0 inside;  granularity: int32[F][bins] (NULL: the constant),
  *   clamped to >= 1 inside;  distribution: float[2 * dist_samples_2], distribution( x / dist_samples_2 ), x in [-dist_samples_2, dist_samples_2).

@@ -272,3 +272,123 @@ int oracle_smear_time( const float * pv_mf, int ch, int64_t F, int bins, float s
 	}
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PV/PVModify.cpp:15-193  PV::modify: every input quad ( frame-1 .. frame ) x ( bin-1 .. bin ) is mapped to a quad of the output and
+// rasterised there; an output point takes the loudest weighted corner offered to it.
+//   mod_tf:  TF[F][bins], the callable sampled over the input's domain (:22), seconds / Hz (converted to frames / bins here, :23-26)
+//   in_f:    float[ch][F][bins], mod( { frame_to_time( frame ), the MF's own frequency } ).f (:62-66)
+// Arithmetic follows what g++ makes of the reference's expressions: unqualified sqrt / fabs / floor / ceil / fmin / fmax on floats are the
+// C double functions there (only `using namespace std::ranges` is in scope), so the square root of the discriminant and the division
+// that follows run in double and round to float once (MSVC, the reference's other toolchain, picks the float overloads: <= 1 ulp in m).
+// The reference runs frames in parallel under a mutex per output frame (:71), so WHICH of several equally loud candidates gives a point
+// its frequency is unspecified there; here it is the first in ( frame, bin ) order of the quads.
+// A quad with a NaN or infinite corner is skipped: in the reference its bounding box is the whole output and NaNs run through every
+// expression of :116-156, so that nothing is written -- except with the interpolators that ignore their argument (midpoint, floor,
+// ceil), which turn a NaN position into a weight; that accident is not reproduced.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+// what one output point ( x, y ) gets from one quad.  0: not inside (next y); 1: `break` (the rest of this column of the bounding box
+// is skipped, :126-153); 2: a candidate { *weight, corner }
+int quad_point( const float px[4], const float py[4], const float pm[4], int x, int y, int interp_kind, float * weight, int * corner )
+	{
+	const float D12x = px[1] - px[0], D12y = py[1] - py[0];                            // :87-90
+	const float D23x = px[2] - px[1], D23y = py[2] - py[1];
+	const float D34x = px[3] - px[2], D34y = py[3] - py[2];
+	const float D41x = px[0] - px[3], D41y = py[0] - py[3];
+	bool c = false;                                                                   // :105-109
+	if( ( ( py[0] <= y && y < py[3] ) || ( py[3] <= y && y < py[0] ) ) && ( x < D41x / D41y * ( y - py[0] ) + px[0] ) ) c = !c;
+	if( ( ( py[1] <= y && y < py[0] ) || ( py[0] <= y && y < py[1] ) ) && ( x < D12x / D12y * ( y - py[1] ) + px[1] ) ) c = !c;
+	if( ( ( py[2] <= y && y < py[1] ) || ( py[1] <= y && y < py[2] ) ) && ( x < D23x / D23y * ( y - py[2] ) + px[2] ) ) c = !c;
+	if( ( ( py[3] <= y && y < py[2] ) || ( py[2] <= y && y < py[3] ) ) && ( x < D34x / D34y * ( y - py[3] ) + px[3] ) ) c = !c;
+	if( !c ) return 0;
+	const float alpha[4] = { px[0], px[1] - px[0], px[3] - px[0], px[0] - px[1] + px[2] - px[3] };   // :116-117
+	const float beta[4] = { py[0], py[1] - py[0], py[3] - py[0], py[0] - py[1] + py[2] - py[3] };
+	const float quadA = alpha[3] * beta[2] - alpha[2] * beta[3];                      // :119-124
+	const float quadB = alpha[3] * beta[0] - alpha[0] * beta[3] + alpha[1] * beta[2] - alpha[2] * beta[1] + x * beta[3] - alpha[3] * y;
+	const float quadC = alpha[1] * beta[0] - alpha[0] * beta[1] + x * beta[1] - alpha[1] * y;
+	float m;
+	if( quadA == 0.0f )                                                               // :126-138
+		{
+		if( quadB == 0.0f ) return 1;
+		m = -quadC / quadB;
+		}
+	else
+		{
+		const float descriminant = quadB * quadB - 4.0f * quadA * quadC;
+		if( descriminant < 0 ) return 1;
+		m = float( ( double( -quadB ) + std::sqrt( double( descriminant ) ) ) / double( 2.0f * quadA ) );
+		}
+	const float lDenominator = alpha[1] + alpha[3] * m;                               // :139-141
+	if( lDenominator == 0 ) return 1;
+	const float l = ( x - alpha[0] - alpha[2] * m ) / lDenominator;
+	const float epsilon = 0.0001f;                                                    // :144-145
+	if( std::fabs( l - 0.5f ) > 0.5f + epsilon || std::fabs( m - 0.5f ) > 0.5f + epsilon ) return 1;
+	const float interpL = interpolate( interp_kind, l ), interpM = interpolate( interp_kind, m );   // :147-148
+	const float w[4] = { ( 1.0f - interpL ) * ( 1.0f - interpM ) * pm[0], ( interpL ) * ( 1.0f - interpM ) * pm[1],   // :150-154
+	                     ( interpL ) * ( interpM ) * pm[2], ( 1.0f - interpL ) * ( interpM ) * pm[3] };
+	const float totalWeight = w[0] + w[1] + w[2] + w[3];                              // :155-156
+	if( totalWeight <= 0.0f ) return 1;
+	int largest = 0;                                                                  // std::max_element, :169-170
+	for( int i = 1; i < 4; ++i ) if( w[largest] < w[i] ) largest = i;
+	*weight = w[largest];
+	*corner = largest;
+	return 2;
+	}
+}
+
+extern "C" {
+
+// :28-40: the output's frame count from the sampled grid.  -2: longer than 10 minutes (the reference prints a message and returns a
+// null PV, :30-34); 0: nothing to make
+int64_t oracle_modify_out_frames( const float * mod_tf, int64_t F, int bins, float sr, int hop )
+	{
+	const TF * mod = reinterpret_cast<const TF*>( mod_tf );
+	float mx = time_to_frame( mod[0].t, sr, hop );
+	for( int64_t i = 1; i < F * bins; ++i ) { const float v = time_to_frame( mod[i].t, sr, hop ); if( mx < v ) mx = v; }   // ranges::max_element with projection
+	const float last = std::ceil( mx );                                               // :29
+	if( last / ( float( sr ) / float( hop ) ) > 60.0f * 10.0f ) return -2;            // :31
+	const int32_t Fo = to_int( std::ceil( last ) );                                   // :38
+	return Fo < 0 ? 0 : Fo;
+	}
+
+int oracle_modify( const float * pv_mf, int ch, int64_t F, int bins, float sr, int hop, const float * mod_tf, const float * in_f, int interp_kind, int64_t Fo, float * out_mf )
+	{
+	const MF * pv = reinterpret_cast<const MF*>( pv_mf );
+	const TF * mod = reinterpret_cast<const TF*>( mod_tf );
+	MF * out = reinterpret_cast<MF*>( out_mf );
+	const int dft = ( bins - 1 ) * 2;
+	std::memset( out, 0, sizeof( MF ) * size_t( ch ) * Fo * bins );                   // :40
+	std::vector<float> gx( size_t( F ) * bins ), gy( size_t( F ) * bins );
+	for( size_t i = 0; i < gx.size(); ++i ) { gx[i] = time_to_frame( mod[i].t, sr, hop ); gy[i] = frequency_to_bin( mod[i].f, sr, dft ); }   // :23-26
+	for( int c = 0; c < ch; ++c )
+		for( int64_t frame = 1; frame < F; ++frame )                                  // :70
+			for( int bin = 1; bin < bins; ++bin )
+				{
+				const size_t idx[4] = { size_t( frame - 1 ) * bins + bin - 1, size_t( frame ) * bins + bin - 1, size_t( frame ) * bins + bin, size_t( frame - 1 ) * bins + bin };   // :76-86
+				float px[4], py[4], pm[4];
+				for( int k = 0; k < 4; ++k ) { px[k] = gx[idx[k]]; py[k] = gy[idx[k]]; pm[k] = pv[size_t( c ) * F * bins + idx[k]].m; }
+				bool finite = true;                                                       // see the header: such quads offer nothing
+				for( int k = 0; k < 4; ++k ) finite = finite && std::isfinite( px[k] ) && std::isfinite( py[k] );
+				if( !finite ) continue;
+				// :93-96 (fmin / fmax / floor / ceil in double on float values: exact; the conversions to Frame / Bin saturate here)
+				const double minx_d = std::fmax( std::floor( std::fmin( std::fmin( px[0], px[1] ), std::fmin( px[2], px[3] ) ) ), 0 );
+				const double miny_d = std::fmax( std::floor( std::fmin( std::fmin( py[0], py[1] ), std::fmin( py[2], py[3] ) ) ), 0 );
+				const double maxx_d = std::fmin( std::ceil( std::fmax( std::fmax( px[0], px[1] ), std::fmax( px[2], px[3] ) ) ), double( Fo - 1 ) );
+				const double maxy_d = std::fmin( std::ceil( std::fmax( std::fmax( py[0], py[1] ), std::fmax( py[2], py[3] ) ) ), double( bins - 1 ) );
+				const int32_t minx = to_int( float( minx_d ) ), miny = to_int( float( miny_d ) ), maxx = to_int( float( maxx_d ) ), maxy = to_int( float( maxy_d ) );
+				for( int32_t x = minx; x <= maxx; ++x )                                   // :99-101
+					for( int32_t y = miny; y <= maxy; ++y )
+						{
+						float weight; int corner;
+						const int r = quad_point( px, py, pm, x, y, interp_kind, &weight, &corner );
+						if( r == 0 ) continue;
+						if( r == 1 ) break;
+						MF & o = out[pos( Fo, bins, c, x, y )];
+						if( weight > o.m ) o = MF{ weight, in_f[size_t( c ) * F * bins + idx[corner]] };   // :172-176
+						}
+				}
+	return 0;
+	}
+
+} // extern "C"

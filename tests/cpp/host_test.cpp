@@ -322,6 +322,18 @@ static void device_checks()
 			PV sm_default = p2.smear_time( []( TF tf ){ return tf.f < 6000.0f ? 0.03f : 0.08f; } );   // default granularity 5, raised cosine
 			CHECK( !sm_default.is_null() && sm_default.get_num_frames() == F - 1 + 2 * Frame( p2.time_to_frame( 0.08f ) ) );
 			}
+		// modify: a shift by three whole frames and up by four bins lands every MF where it says (rates here make frame <-> time exact:
+		// 48000 / 375 = 128); the frequency comes from mod at the MF's own frequency
+			{
+			PV ex = noise( 1, 30000, 9 ).convert_to_PV( 1024, 375, 1024 );
+			const float dt = 3.0f / 128.0f, df = 4.0f * 46.875f;
+			PV moved = ex.modify( [=]( TF tf ){ return TF{ tf.t + dt, tf.f + df }; } );
+			CHECK( moved.get_num_frames() == ex.get_num_frames() - 1 + 3 );
+			CHECK( moved.get_MF( 0, 13, 24 ).m == ex.get_MF( 0, 10, 20 ).m && moved.get_MF( 0, 13, 24 ).f == ex.get_MF( 0, 10, 20 ).f + df );
+			CHECK( moved.get_MF( 0, 2, 24 ).m == 0.0f && moved.get_MF( 0, 13, 3 ).m == 0.0f );
+			CHECK( ex.modify( []( TF tf ){ return TF{ tf.t + 700.0f, tf.f }; } ).is_null() );      // longer than ten minutes: refused
+			CHECK( ex.modify( []( TF tf ){ return tf; }, Interpolator( []( float v ){ return v; } ) ).is_null() );   // unnamed interpolator
+			}
 		(void) B;
 		}
 	// ---- a grid large enough to go over in slabs (sampled slab k+1 while slab k uploads) = the same grid sampled in one piece

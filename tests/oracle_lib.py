@@ -83,6 +83,9 @@ def _load():
     lib.oracle_cut_frames_range.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.oracle_place_frames.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, f32p, C.c_int, C.c_int64, C.c_int, C.c_int64]
     lib.oracle_harmonic_scale.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, C.c_float, f32p, C.c_int, C.c_int, f32p]
+    lib.oracle_modify_out_frames.restype = C.c_int64
+    lib.oracle_modify_out_frames.argtypes = [f32p, C.c_int64, C.c_int, C.c_float, C.c_int]
+    lib.oracle_modify.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_int, f32p, f32p, C.c_int, C.c_int64, f32p]
     lib.oracle_smear_time_plan.restype = None
     lib.oracle_smear_time_plan.argtypes = [C.c_int64, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_float, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
     lib.oracle_smear_time.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
@@ -355,6 +358,24 @@ def harmonic_scale(pv, sample_rate, series, mode):
     H = series.shape[1]
     out = np.empty_like(pv)
     lib.oracle_harmonic_scale(pv.reshape(-1), ch, F, bins, sample_rate, series.reshape(-1) if H else np.zeros(1, np.float32), H, mode, out.reshape(-1))
+    return out
+
+
+def modify_out_frames(mod_tf, sample_rate, hop):
+    mod = np.ascontiguousarray(mod_tf, np.float32)
+    return int(lib.oracle_modify_out_frames(mod.reshape(-1), mod.shape[0], mod.shape[1], sample_rate, hop))
+
+
+def modify(pv, sample_rate, hop, mod_tf, in_f, interp=0, out_frames=None):
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    mod = np.ascontiguousarray(mod_tf, np.float32)
+    in_f = np.ascontiguousarray(in_f, np.float32)
+    Fo = modify_out_frames(mod, sample_rate, hop) if out_frames is None else out_frames
+    if Fo <= 0:
+        return None
+    out = np.empty((ch, Fo, bins, 2), np.float32)
+    lib.oracle_modify(pv.reshape(-1), ch, F, bins, sample_rate, hop, mod.reshape(-1), in_f.reshape(-1), interp, Fo, out.reshape(-1))
     return out
 
 

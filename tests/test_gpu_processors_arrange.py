@@ -145,3 +145,50 @@ def test_smear_time(fa, pv_small, pv_wide):
                 got = fa.smear_time(pv, SR, HOP, smear, gran, dist, left, Fo)
                 ref = O.smear_time(pv, SR, HOP, smear, gran, dist, left, Fo)
                 assert_identical("smear_time %s / %s" % ("grid" if not np.isscalar(smear) else smear, dname), got, ref)
+
+
+def warp_grids(pv, hop, seed):
+    ch, F, bins, _ = pv.shape
+    dft = (bins - 1) * 2
+    rng = np.random.default_rng(seed)
+    t = (np.arange(F, dtype=np.float32) / np.float32(SR / hop))[:, None] * np.ones((1, bins), np.float32)
+    f = (np.arange(bins, dtype=np.float32) * np.float32(SR) / np.float32(dft))[None, :] * np.ones((F, 1), np.float32)
+    T = np.float32(F * hop / SR)
+    yield "identity", np.stack([t, f], -1)
+    yield "stretch 1.7, transpose 1.3", np.stack([t * np.float32(1.7), f * np.float32(1.3)], -1)
+    yield "shrink", np.stack([t * np.float32(0.4) + np.float32(0.01), f * np.float32(0.6) + np.float32(50)], -1)
+    yield "bend", np.stack([t + np.float32(0.02) * np.sin(f / np.float32(3000)).astype(np.float32), f * (np.float32(1) + np.float32(0.3) * t / T) + np.float32(40)], -1)
+    yield "fold", np.stack([T * np.abs(np.sin(t / T * np.float32(5))).astype(np.float32), np.float32(SR / 2) * np.abs(np.cos(f / np.float32(7000))).astype(np.float32)], -1)
+    yield "shear", np.stack([t + f / np.float32(SR) * T * np.float32(0.2), f + t / T * np.float32(2000)], -1)
+    jitter = np.stack([t + rng.uniform(-0.4, 0.4, t.shape).astype(np.float32) * np.float32(hop / SR),
+                       f + rng.uniform(-0.4, 0.4, f.shape).astype(np.float32) * np.float32(SR / dft)], -1)
+    yield "jitter", jitter
+    holes = jitter.copy()
+    holes[5, 7] = (np.nan, 100.0); holes[6, 9] = (0.01, np.inf); holes[8, 3] = (-np.inf, np.nan); holes[F - 1, bins - 1] = (np.nan, np.nan)
+    yield "non-finite corners", holes
+    yield "partly before time zero", np.stack([t - np.float32(0.05), f - np.float32(900)], -1)
+
+
+def test_modify(fa, pv_small, pv_wide):
+    for pv, hop in ((pv_small, HOP), (pv_wide, HOP)):
+        ch, F, bins, _ = pv.shape
+        in_f = np.random.default_rng(9).uniform(0, 24000, (ch, F, bins)).astype(np.float32)
+        for name, grid in warp_grids(pv, hop, seed=F):
+            grid = np.ascontiguousarray(grid, np.float32)
+            Fo = O.modify_out_frames(grid, SR, hop)
+            assert Fo == fa.modify_out_frames(grid, SR, hop), name
+            if Fo <= 0:
+                continue
+            for interp in ((0, 5, 6, 1, 3, 4, 2) if name in ("bend", "jitter") else (0,)):
+                got = fa.modify(pv, SR, hop, grid, in_f, interp, Fo)
+                ref = O.modify(pv, SR, hop, grid, in_f, interp, Fo)
+                assert_identical("modify/%s interp=%d Fo=%d" % (name, interp, Fo), got, ref)
+                assert name == "partly before time zero" or got.any()
+    # equal magnitudes everywhere: every candidate ties, the first quad in ( frame, bin ) order gives the frequency
+    flat = pv_small.copy(); flat[..., 0] = 1.0
+    in_f = np.random.default_rng(10).uniform(0, 24000, flat.shape[:3]).astype(np.float32)
+    for name, grid in warp_grids(flat, HOP, seed=1):
+        if name in ("shrink", "fold", "jitter"):
+            grid = np.ascontiguousarray(grid, np.float32)
+            Fo = O.modify_out_frames(grid, SR, HOP)
+            assert_identical("modify ties/%s" % name, fa.modify(flat, SR, HOP, grid, in_f, 0, Fo), O.modify(flat, SR, HOP, grid, in_f, 0, Fo))

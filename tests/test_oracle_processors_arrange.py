@@ -187,3 +187,48 @@ def test_smear_time_against_numpy_and_plan_helpers_agree():
     # because a point that spreads over no frames averages nothing (:580)
     left, Fo, half = O.smear_time_plan(F, bins, SR, HOP, 0.0)
     assert (left, Fo, half) == (0, F - 1, 0)
+
+
+def exact_grid(F, bins, dft, hop):
+    """the input's own ( time, frequency ) grid, with rates that make frame <-> time exact in fp32 (48000 / 375 = 128)"""
+    t = (np.arange(F, dtype=np.float32) / np.float32(SR / hop))[:, None]
+    f = (np.arange(bins, dtype=np.float32) * np.float32(SR) / np.float32(dft))[None, :]
+    return np.stack(np.broadcast_arrays(t, f), axis=-1).astype(np.float32)
+
+
+def test_modify_on_maps_with_known_answers():
+    """PV::modify (PVModify.cpp:15-193) where the rasterisation has a closed form"""
+    hop, dft = 375, 128
+    pv = O.analyze(O.noise(2, 4000, seed=5), SR, dft, hop, dft)
+    ch, F, bins, _ = pv.shape
+    ident = exact_grid(F, bins, dft, hop)
+    in_f = np.random.default_rng(1).uniform(0, 20000, (ch, F, bins)).astype(np.float32)
+    expect = np.stack([pv[..., 0], in_f], axis=-1)
+    # identity: every grid point is the ( l, m ) = ( 0, 0 ) corner of exactly one quad; the last frame and bin belong to none
+    assert O.modify_out_frames(ident, SR, hop) == F - 1
+    out = O.modify(pv, SR, hop, ident, in_f)
+    assert out.shape == (ch, F - 1, bins, 2)
+    assert np.array_equal(out[:, :, :bins - 1], expect[:, :F - 1, :bins - 1]) and not out[:, :, bins - 1].any()
+    # a shift by three whole frames
+    sh = ident.copy(); sh[..., 0] += np.float32(3 * hop / SR)
+    out = O.modify(pv, SR, hop, sh, in_f)
+    assert out.shape[1] == F + 2 and np.array_equal(out[:, 3:, :bins - 1], expect[:, :F - 1, :bins - 1]) and not out[:, :3].any()
+    # twice as slow: the frames in between take the louder of their two half-weighted neighbours, with that neighbour's frequency
+    st = ident.copy(); st[..., 0] *= 2
+    out = O.modify(pv, SR, hop, st, in_f)
+    assert np.array_equal(out[:, 0:2 * (F - 1):2, :bins - 1], expect[:, :F - 1, :bins - 1])
+    a, b = np.float32(0.5) * pv[:, :F - 1, :bins - 1, 0], np.float32(0.5) * pv[:, 1:F, :bins - 1, 0]
+    assert np.array_equal(out[:, 1:2 * (F - 1):2, :bins - 1, 0], np.maximum(a, b))
+    assert np.array_equal(out[:, 1:2 * (F - 1):2, :bins - 1, 1], np.where(a < b, in_f[:, 1:F, :bins - 1], in_f[:, :F - 1, :bins - 1]))
+    # the interpolators that ignore their argument: midpoint weighs every corner by a quarter
+    out = O.modify(pv, SR, hop, ident, in_f, interp=1)
+    corners = np.stack([pv[:, :F - 1, :bins - 1, 0], pv[:, 1:, :bins - 1, 0], pv[:, 1:, 1:, 0], pv[:, :F - 1, 1:, 0]])
+    assert np.array_equal(out[:, :, :bins - 1, 0], (np.float32(0.25) * corners).max(axis=0))
+    # longer than ten minutes: refused (:30-34); everything mapped before time zero: nothing to make
+    far = ident.copy(); far[..., 0] += np.float32(601.0)
+    assert O.modify_out_frames(far, SR, hop) == -2
+    back = ident.copy(); back[..., 0] -= np.float32(100.0)
+    assert O.modify_out_frames(back, SR, hop) == 0
+    import flan_amd
+    for g in (ident, sh, st, far, back):
+        assert flan_amd.modify_out_frames(g, SR, hop) == O.modify_out_frames(g, SR, hop)

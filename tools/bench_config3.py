@@ -85,7 +85,19 @@ sel_grid[..., 1] = (torch.arange(BINS, device=dev, dtype=torch.float32) * (SR / 
 H_oct = 15
 ser_oct = torch.full((F, H_oct), 0.5, dtype=torch.float32, device=dev)
 ser_har = torch.full((F, BINS), 0.5, dtype=torch.float32, device=dev)
+sm_e = int(0.1 * SR / HOP)
+sm_n = 4 * sm_e
+sm_dist = (0.5 * (1.0 + torch.cos(torch.pi * torch.arange(-2 * sm_e, 2 * sm_e, device=dev, dtype=torch.float32) / (2 * sm_e)))).contiguous()
+sm_out = torch.empty((ch, F - 1 + 2 * sm_e, BINS, 2), dtype=torch.float32, device=dev)
+warp = torch.empty((F, BINS, 2), dtype=torch.float32, device=dev)                # modify: twice as slow, a fifth up
+warp[..., 0] = (torch.arange(F, device=dev, dtype=torch.float32) / (SR / HOP))[:, None] * 2.0
+warp[..., 1] = (torch.arange(BINS, device=dev, dtype=torch.float32) * (SR / DFT))[None, :] * 1.2
+warp_f = (pv[..., 1] * 1.2).contiguous()
+warp_Fo = int(lib.flanhip_modify_out_frames(fa._vp(warp.cpu().numpy().ctypes.data), F, BINS, SR, HOP)) if False else 2 * (F - 1)
+warp_out = torch.empty((ch, warp_Fo, BINS, 2), dtype=torch.float32, device=dev)
 stages.update({
+    "modify(2 t, 1.2 f)": lambda: fa.check(lib.flanhip_modify_dev(P(pv), ch, F, BINS, SR, HOP, P(warp), P(warp_f), 0, warp_Fo, P(warp_out), None)),
+    "smear_time(0.1 s, 5)": lambda: fa.check(lib.flanhip_smear_time_dev(P(pv), ch, F, BINS, SR, HOP, None, 0.1, None, 5, P(sm_dist), sm_n, -sm_e, F - 1 + 2 * sm_e, P(sm_out), None)),
     "freeze(3 pauses)": lambda: fa.check(lib.flanhip_select_frames_dev(P(pv), ch, F, BINS, P(fz_src), fz_Fo, P(fz_out), None)),
     "cut_frames(1000:5000)": lambda: fa.check(lib.flanhip_cut_frames_dev(P(pv), ch, F, BINS, 1000, 4000, P(sh), None)),
     "join(one input)": lambda: fa.check(lib.flanhip_place_frames_dev(P(pv), ch, F, BINS, P(fz_out), ch, fz_Fo, BINS, 100, None)),
