@@ -87,6 +87,8 @@ _SIGS = {
     "flanhip_harmonic_scale_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _i32, _i32, _vp, _vp]),
     "flanhip_modify_out_frames": (_i64, [_vp, _i64, _i32, _f32, _i32]),
     "flanhip_modify_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i32, _vp, _vp, _i32, _i64, _vp, _vp]),
+    "flanhip_stretch_spline_out_frames": (_i64, [_vp, _i64]),
+    "flanhip_stretch_spline_dev": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp]),
     "flanhip_smear_time_plan": (C.c_int, [_i64, _i32, _f32, _i32, _vp, _f32, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "flanhip_smear_time_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i32, _vp, _f32, _vp, _i32, _vp, _i64, _i32, _i64, _vp, _vp]),
     "flanhip_mid_side_dev": (C.c_int, [_vp, _i64, _vp, _vp]),
@@ -328,7 +330,7 @@ def freeze_plan(num_frames, sample_rate, hop, times, lengths):
     lp = lengths.ctypes.data_as(_vp) if n else None
     Fo = lib.flanhip_freeze_plan(num_frames, sample_rate, hop, tp, lp, n, None)
     if Fo < 0:
-        raise FlanHipError("flanhip_freeze_plan: bad arguments")
+        raise FlanHipError(-1, "flanhip_freeze_plan: bad arguments")
     src = np.empty(Fo, np.int32)
     lib.flanhip_freeze_plan(num_frames, sample_rate, hop, tp, lp, n, src.ctypes.data_as(_vp))
     return src
@@ -422,6 +424,21 @@ def modify(pv, sample_rate, hop, mod_tf, in_f, interp=0, out_frames=None):
         return None
     d_pv, d_mod, d_f, d_out = DeviceArray(host=pv), DeviceArray(host=mod), DeviceArray(host=in_f), DeviceArray(ch * Fo * bins * 8)
     check(lib.flanhip_modify_dev(_vp(d_pv.ptr), ch, F, bins, sample_rate, hop, _vp(d_mod.ptr), _vp(d_f.ptr), interp, Fo, _vp(d_out.ptr), None))
+    return d_out.to_host((ch, Fo, bins, 2))
+
+
+def stretch_spline(pv, steps):
+    """PV::stretch_spline.  steps: uint32 [F-1], every one >= 1"""
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    steps = np.ascontiguousarray(steps, np.uint32)
+    assert steps.shape == (F - 1,)
+    Fo = int(lib.flanhip_stretch_spline_out_frames(steps.ctypes.data_as(_vp), F))
+    if Fo < 0:
+        raise FlanHipError(-1, "flanhip_stretch_spline_out_frames: bad steps")
+    d_pv, d_out = DeviceArray(host=pv), DeviceArray(ch * Fo * bins * 8)
+    check(lib.flanhip_stretch_spline_dev(_vp(d_pv.ptr), ch, F, bins, steps.ctypes.data_as(_vp), Fo, _vp(d_out.ptr), None))
+    check(lib.flanhip_stream_synchronize(None))
     return d_out.to_host((ch, Fo, bins, 2))
 
 

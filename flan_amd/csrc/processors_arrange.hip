@@ -9,6 +9,7 @@
 // placement rule of shape / time_extrapolate (processors_common.h).
 #include "processors_common.h"
 #include <algorithm>
+#include <vector>
 
 namespace flanhip {
 
@@ -306,6 +307,111 @@ __global__ __launch_bounds__( 256 ) void k_modify_resolve( const MFd * in, int64
 	out[row * bins + y] = MFd{ __uint_as_float( unsigned( key >> 32 ) ), in_f[channel * F * bins + idx[corner]] };   // :176
 	}
 
+// ---------------------------------------------------------------------------------------------------------------------
+// PV::stretch_spline (PV/PVModify.cpp:387-443): a natural cubic spline through every (channel, bin) column's magnitudes and one
+// through its frequencies, knots where the caller's per-frame steps put the input frames, evaluated on every output frame; fp64,
+// in the operation order of the spline the reference vendors (spline/spline.h:284-401 with band_matrix's LU, :187-261).
+// The tridiagonal matrix depends on the knots only: its LU factors are computed once on the host (flanhip_stretch_spline_dev) and
+// shared by all columns.  What remains per column is two first-order recurrences over the frames (L y = rhs forward, R b = y
+// backward) and the evaluation: one thread per ( channel, bin, m | f ), adjacent threads adjacent floats of a frame, so every step of
+// the walk moves whole coalesced rows; the intermediate vector lives in a workspace [frame][column].
+// ---------------------------------------------------------------------------------------------------------------------
+struct SplineFactors { const double * x, * sd, * lo, * up, * di; };       // knots; 1 / a_ii; L below the diagonal; R above it; R's diagonal
+
+// Only the two substitutions are sequential in the frame; the right-hand side before them and the coefficients and the evaluation
+// after them are independent per ( frame, column ) and run as ordinary wide kernels.
+
+// rhs( i ) * saved_diag( i ), spline.h:306 and the first factor of :233.  grid = ( ceil(row_floats/256) * F, channels )
+__global__ __launch_bounds__( 256 ) void k_spline_rhs( const float * in, int64_t F, int row_floats, SplineFactors fac, double * ws, int64_t ncols, int col_blocks )
+	{
+	const int col_in_channel = int( blockIdx.x % col_blocks ) * 256 + threadIdx.x;
+	if( col_in_channel >= row_floats ) return;
+	const int64_t i = blockIdx.x / col_blocks, channel = blockIdx.y;
+	double rhs = 0.0;
+	if( i > 0 && i + 1 < F )                                                          // 0 in the first and last row, :313,:327
+		{
+		const float * yp = in + ( channel * F + i ) * row_floats + col_in_channel;
+		const double y_prev = double( yp[-row_floats] ), y_cur = double( yp[0] ), y_next = double( yp[row_floats] );
+		const double x_prev = fac.x[i - 1], x_cur = fac.x[i], x_next = fac.x[i + 1];
+		rhs = ( y_next - y_cur ) / ( x_next - x_cur ) - ( y_cur - y_prev ) / ( x_cur - x_prev );
+		}
+	ws[i * ncols + channel * row_floats + col_in_channel] = rhs * fac.sd[i];
+	}
+
+// L y = rhs forward (spline.h:222-235), R b = y backward (:237-250): one thread per column, kSolveLanes columns per wavefront (the
+// walk is bound by the latency of its dependent fp64 steps, not by lanes: narrow wavefronts put a walk on every SIMD of the chip).
+// Batches of B frames: the loads of a batch are issued first (left in the loop they queue up behind the previous step's store).
+constexpr int kSolveLanes = 16;
+__global__ __launch_bounds__( 64 ) void k_spline_solve( int64_t F, SplineFactors fac, double * ws, int64_t ncols )
+	{
+	if( threadIdx.x >= kSolveLanes ) return;
+	const int64_t col = int64_t( blockIdx.x ) * kSolveLanes + threadIdx.x;
+	if( col >= ncols ) return;
+	double * wp = ws + col;                                                           // w( i ) = wp[i * ncols]
+	constexpr int B = 16;
+		{
+		double yt_prev = 0.0;
+		for( int64_t base = 0; base < F; base += B )
+			{
+			double w[B], los[B];
+			#pragma unroll
+			for( int k = 0; k < B; ++k ) { const int64_t i = base + k; w[k] = i < F ? wp[i * ncols] : 0.0; los[k] = i < F ? fac.lo[i] : 0.0; }
+			#pragma unroll
+			for( int k = 0; k < B; ++k )
+				{
+				double sum = 0;
+				if( base + k > 0 ) sum += los[k] * yt_prev;
+				w[k] = w[k] - sum;
+				yt_prev = w[k];
+				}
+			#pragma unroll
+			for( int k = 0; k < B; ++k ) if( base + k < F ) wp[( base + k ) * ncols] = w[k];
+			}
+		}
+		{
+		double b_next = 0.0;
+		for( int64_t top = F - 1; top >= 0; top -= B )
+			{
+			double w[B], ups[B], dis[B];
+			#pragma unroll
+			for( int k = 0; k < B; ++k ) { const int64_t i = top - k; w[k] = i >= 0 ? wp[i * ncols] : 0.0; ups[k] = i >= 0 ? fac.up[i] : 0.0; dis[k] = i >= 0 ? fac.di[i] : 1.0; }
+			#pragma unroll
+			for( int k = 0; k < B; ++k )
+				{
+				double sum = 0;
+				if( top - k < F - 1 ) sum += ups[k] * b_next;
+				w[k] = ( w[k] - sum ) / dis[k];
+				b_next = w[k];
+				}
+			#pragma unroll
+			for( int k = 0; k < B; ++k ) if( top - k >= 0 ) wp[( top - k ) * ncols] = w[k];
+			}
+		}
+	}
+
+// coefficients of a segment (:343-349) and the output frames it holds: operator() (:375-397) puts frame t into the segment that
+// starts at the last knot strictly below t (lower_bound), frame 0 into the first.  grid = ( ceil(row_floats/256) * (F-1), channels )
+__global__ __launch_bounds__( 256 ) void k_spline_eval( const float * in, int64_t F, int row_floats, SplineFactors fac, const double * ws, int64_t ncols, int64_t Fo, int col_blocks, float * out )
+	{
+	const int col_in_channel = int( blockIdx.x % col_blocks ) * 256 + threadIdx.x;
+	if( col_in_channel >= row_floats ) return;
+	const int64_t i = blockIdx.x / col_blocks, channel = blockIdx.y;
+	constexpr double third = 1.0 / 3.0;
+	const float * yp = in + ( channel * F + i ) * row_floats + col_in_channel;
+	const double * wp = ws + i * ncols + channel * row_floats + col_in_channel;
+	const double y0 = double( yp[0] ), y1 = double( yp[row_floats] ), b0 = wp[0], b1 = wp[ncols];
+	const double x0 = fac.x[i], x1 = fac.x[i + 1], dx = x1 - x0;
+	const double a = third * ( b1 - b0 ) / dx;
+	const double c = ( y1 - y0 ) / dx - third * ( 2.0 * b0 + b1 ) * dx;
+	float * op = out + channel * Fo * row_floats + col_in_channel;
+	const int64_t t_first = i == 0 ? 0 : int64_t( x0 ) + 1, t_last = min( int64_t( x1 ), Fo - 1 );
+	for( int64_t t = t_first; t <= t_last; ++t )
+		{
+		const double h = double( t ) - x0;
+		op[t * row_floats] = float( ( ( a * h + b0 ) * h + c ) * h + y0 );
+		}
+	}
+
 } // namespace flanhip
 
 using namespace flanhip;
@@ -498,6 +604,71 @@ int flanhip_modify_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins
 	hipLaunchKernelGGL( k_modify_resolve, dim3( unsigned( ch * out_frames * point_blocks ) ), dim3( 256 ), 0, s, (const MFd*) d_pv, F, bins, sr, float( hop ), dft,
 		reinterpret_cast<const float2*>( d_mod_tf ), d_in_f, interp_kind, out_frames, point_blocks, (MFd*) d_out );
 	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+int64_t flanhip_stretch_spline_out_frames( const uint32_t * steps, int64_t F )
+	{
+	if( !steps || F < 3 ) return -1;                                                  // spline.h:288: more than two knots
+	int64_t total = 0;
+	for( int64_t i = 0; i + 1 < F; ++i ) { if( steps[i] < 1 ) return -1; total += steps[i]; }   // PVModify.cpp:391-394: every step is at least 1
+	return total <= INT32_MAX ? total : -1;                                           // :399-405
+	}
+
+int flanhip_stretch_spline_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, const uint32_t * steps, int64_t out_frames, flanhip_MF * d_out, void * stream )
+	{
+	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, 1.0f ) ) return rc;
+	FLANHIP_REQUIRE( steps && F >= 3, FLANHIP_ERR_INVALID_ARG, "stretch_spline needs at least three frames (spline.h:288) and the per-frame steps" );
+	FLANHIP_REQUIRE( out_frames == flanhip_stretch_spline_out_frames( steps, F ), FLANHIP_ERR_INVALID_ARG, "out_frames is not the sum of the steps (each >= 1)" );
+	FLANHIP_REQUIRE( ch <= 65535 && int64_t( ( bins * 2 + 255 ) / 256 ) * F < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "stretch_spline: too many channels or frames" );
+	// the knots and the LU factors of the spline's tridiagonal system (spline.h:298-327, :187-219): the same for every column
+	const size_t n = size_t( F );
+	std::vector<double> host( 5 * n );
+	double * x = host.data(), * sd = x + n, * lo = sd + n, * up = lo + n, * di = up + n;
+	x[0] = 0.0;
+	for( size_t i = 0; i + 1 < n; ++i ) x[i + 1] = x[i] + double( steps[i] );           // PVModify.cpp:400-405 (integers: exact)
+	for( size_t i = 1; i + 1 < n; ++i )                                               // spline.h:302-306
+		{
+		lo[i] = 1.0 / 3.0 * ( x[i] - x[i - 1] );
+		di[i] = 2.0 / 3.0 * ( x[i + 1] - x[i - 1] );
+		up[i] = 1.0 / 3.0 * ( x[i + 1] - x[i] );
+		}
+	lo[0] = 0.0; di[0] = 2.0; up[0] = 0.0;                                            // :311-312
+	di[n - 1] = 2.0; lo[n - 1] = 0.0; up[n - 1] = 0.0;                                // :325-326
+	for( size_t i = 0; i < n; ++i )                                                   // :194-204
+		{
+		sd[i] = 1.0 / di[i];
+		if( i > 0 ) lo[i] *= sd[i];
+		if( i + 1 < n ) up[i] *= sd[i];
+		di[i] = 1.0;
+		}
+	for( size_t k = 0; k + 1 < n; ++k )                                               // :207-219
+		{
+		const double xk = -lo[k + 1] / di[k];
+		lo[k + 1] = -xk;
+		di[k + 1] = di[k + 1] + xk * up[k];
+		}
+	hipStream_t s = (hipStream_t) stream;
+	const int row_floats = bins * 2;
+	const int64_t ncols = ch * row_floats;
+	double * d_fac = nullptr, * d_ws = nullptr;
+	retain_pool_memory();
+	FLANHIP_CHECK( hipMallocAsync( reinterpret_cast<void**>( &d_fac ), sizeof( double ) * host.size(), s ) );
+	FLANHIP_CHECK( hipMallocAsync( reinterpret_cast<void**>( &d_ws ), sizeof( double ) * n * size_t( ncols ), s ) );
+	FLANHIP_CHECK( hipMemcpyAsync( d_fac, host.data(), sizeof( double ) * host.size(), hipMemcpyHostToDevice, s ) );
+	FLANHIP_CHECK( hipStreamSynchronize( s ) );                                       // `host` dies with this call
+	const SplineFactors fac{ d_fac, d_fac + n, d_fac + 2 * n, d_fac + 3 * n, d_fac + 4 * n };
+	const int64_t col_blocks = ( row_floats + 255 ) / 256;
+	hipLaunchKernelGGL( k_spline_rhs, dim3( unsigned( col_blocks * F ), unsigned( ch ) ), dim3( 256 ), 0, s, reinterpret_cast<const float*>( d_pv ), F, row_floats, fac, d_ws, ncols,
+		int( col_blocks ) );
+	FLANHIP_CHECK( hipGetLastError() );
+	hipLaunchKernelGGL( k_spline_solve, dim3( unsigned( ( ncols + kSolveLanes - 1 ) / kSolveLanes ) ), dim3( 64 ), 0, s, F, fac, d_ws, ncols );
+	FLANHIP_CHECK( hipGetLastError() );
+	hipLaunchKernelGGL( k_spline_eval, dim3( unsigned( col_blocks * ( F - 1 ) ), unsigned( ch ) ), dim3( 256 ), 0, s, reinterpret_cast<const float*>( d_pv ), F, row_floats, fac, d_ws, ncols,
+		out_frames, int( col_blocks ), reinterpret_cast<float*>( d_out ) );
+	FLANHIP_CHECK( hipGetLastError() );
+	FLANHIP_CHECK( hipFreeAsync( d_ws, s ) );
+	FLANHIP_CHECK( hipFreeAsync( d_fac, s ) );
 	return FLANHIP_OK;
 	}
 

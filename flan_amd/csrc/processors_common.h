@@ -167,6 +167,24 @@ struct DevBuf
 	int alloc( size_t bytes ) { FLANHIP_CHECK( hipMalloc( &p, bytes ? bytes : 1 ) ); return FLANHIP_OK; }
 	};
 
+// Entry points that need a transient workspace take it from the stream's memory pool (hipMallocAsync).  By default the pool hands
+// its memory back to the driver at every synchronisation, so each call would pay for mapping its workspace again (milliseconds for
+// hundreds of MB); tell the device's pool once to keep what it has been given.
+inline void retain_pool_memory()
+	{
+	static bool done[64] = {};
+	int device = 0;
+	if( hipGetDevice( &device ) != hipSuccess || device < 0 || device >= 64 || done[device] ) return;
+	hipMemPool_t pool = nullptr;
+	if( hipDeviceGetDefaultMemPool( &pool, device ) == hipSuccess && pool )
+		{
+		uint64_t keep = UINT64_MAX;
+		(void) hipMemPoolSetAttribute( pool, hipMemPoolAttrReleaseThreshold, &keep );
+		}
+	(void) hipGetLastError();
+	done[device] = true;
+	}
+
 inline int check_pv_args( const void * a, const void * b, int64_t ch, int64_t F, int bins, float sr )
 	{
 	FLANHIP_REQUIRE( a && b, FLANHIP_ERR_INVALID_ARG, "null buffer" );

@@ -526,6 +526,31 @@ PV PV::modify( const Function<TF, TF> & mod, const Interpolator & interp ) const
 	return finish( rc, "modify", f, std::move( out ) );
 	}
 
+PV PV::stretch_spline( const Function<Second, float> & interpolation ) const
+	{
+	if( is_null() ) return PV();
+	if( get_num_frames() < 3 ) { std::cerr << "flan: stretch_spline needs at least three frames" << std::endl; return PV(); }   // spline.h:288 asserts it
+	// PVModify.cpp:391-394 safeInterpolation; the float -> uint32 conversion (undefined for negatives and NaN there) saturates here
+	std::vector<uint32_t> steps( size_t( get_num_frames() - 1 ) );
+	const float seconds_per_frame = frame_to_time( 1 );
+	for( Frame frame = 0; frame + 1 < get_num_frames(); ++frame )
+		{
+		const float v = interpolation( frame * seconds_per_frame );
+		const uint32_t u = !( v >= 1.0f ) ? 0u : ( v >= 4294967296.0f ? 0xFFFFFFFFu : uint32_t( v ) );
+		steps[size_t( frame )] = std::max( u, 1u );
+		}
+	const int64_t Fo = flanhip_stretch_spline_out_frames( steps.data(), get_num_frames() );   // :399-405
+	if( Fo <= 0 ) return PV();
+	PVBuffer::Format f = get_format();
+	f.num_frames = Frame( Fo );
+	const MF * d_pv = device_data();
+	auto out = DeviceBlock::allocate( sizeof( MF ) * mf_count( f ) );
+	if( !d_pv || !out ) return PV();
+	const int rc = flanhip_stretch_spline_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(), steps.data(), Fo,
+		static_cast<flanhip_MF*>( out->ptr ), nullptr );
+	return finish( rc, "stretch_spline", f, std::move( out ) );
+	}
+
 PV PV::smear_time( const Function<TF, Second> & smear_size, const Function<TF, int> & granularity, const Function<Second, float> & distribution ) const
 	{
 	if( is_null() ) return PV();

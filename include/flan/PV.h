@@ -72,6 +72,9 @@ public:
 	PV select( Second length, const Function<TF, TF> & selector ) const;                                              // PV.h:236-239 (PV.cpp:92-127)
 	/** Time freeze.  Of several pauses on one frame the first given is kept (unspecified in the reference: its sort is not stable). */
 	PV freeze( const std::vector<Second> & pause_times, const std::vector<Second> & pause_lengths ) const;            // PV.h:247-250 (PV.cpp:129-198)
+	/** Cubic-spline stretch: frame k of the input is followed by max( uint32( interpolation( time of k ) ), 1 ) output frames; every
+	 *  bin's magnitudes and frequencies are splined through those knots in double precision (PV.h:308-316).  Needs 3+ frames. */
+	PV stretch_spline( const Function<Second, float> & interpolation ) const;                                        // PV.h:314-316 (PVModify.cpp:387-443)
 	/** Every MF becomes the distribution-weighted average of its bin over the surrounding smear_size seconds, sampled every
 	 *  `granularity` frames (PV.h:327-340).  The default distribution is the reference's raised cosine. */
 	PV smear_time( const Function<TF, Second> & smear_size, const Function<TF, int> & granularity = 5,

@@ -265,6 +265,14 @@ int64_t flanhip_modify_out_frames(const float * mod_tf, int64_t num_frames, int 
 int flanhip_modify_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_frames, int num_bins, float sample_rate, int hop,
                        const float * d_mod_tf, const float * d_in_f, int interp, int64_t out_frames, flanhip_MF * d_out, void * stream);
 
+/* PV::stretch_spline (PV/PVModify.cpp:387-443; the spline is the reference's vendored spline/spline.h:284-401, fp64).
+ * steps: HOST uint32[F-1], safeInterpolation( frame ) = max( uint32( interpolation( frame * frame_to_time( 1 ) ) ), 1 ) of every
+ * frame but the last (:391-394); the output has sum( steps ) frames (:399-405, flanhip_stretch_spline_out_frames; -1 when F < 3,
+ * a step is 0 or the sum does not fit a Frame).  Allocates its workspace (8 B x F x ch x bins x 2) from the stream's memory pool. */
+int64_t flanhip_stretch_spline_out_frames(const uint32_t * steps, int64_t num_frames);
+int flanhip_stretch_spline_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_frames, int num_bins,
+                               const uint32_t * steps, int64_t out_frames, flanhip_MF * d_out, void * stream);
+
 /* PV::smear_time (PV/PVModify.cpp:513-605).  The caller samples the three callables as :520-524 and :558-560 do:
  *   smear: float[F][bins] seconds (NULL: smear_const), clamped to >= 0 inside;  granularity: int32[F][bins] (NULL: the constant),
  *   clamped to >= 1 inside;  distribution: float[2 * dist_samples_2], distribution( x / dist_samples_2 ), x in [-dist_samples_2, dist_samples_2).

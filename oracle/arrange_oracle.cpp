@@ -392,3 +392,116 @@ int oracle_modify( const float * pv_mf, int ch, int64_t F, int bins, float sr, i
 	}
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PV/PVModify.cpp:387-443  PV::stretch_spline, with the cubic spline the reference vendors (spline/spline.h:284-401: natural
+// boundary conditions, tridiagonal system through band_matrix's LU with its row normalisation, :187-261).  The spline restated here
+// is pinned against the real header (oracle/_ref, tests/test_oracle_vs_ref.py).
+//   steps: uint32[F-1], safeInterpolation( frame ) = max( uint32( interpolation( frame * frame_to_time( 1 ) ) ), 1 ) (:391-394), the
+//   caller's; knot of frame k = sum of the steps before it; the output has sum( steps ) frames (:399-405).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct Spline
+	{
+	std::vector<double> x, y, a, b, c;
+	void set_points( const std::vector<double> & xs, const std::vector<double> & ys )   // spline.h:284-372, cubic branch, second_deriv = 0 both ends
+		{
+		x = xs; y = ys;
+		const int n = int( x.size() );
+		std::vector<double> lo( n, 0.0 ), di( n, 0.0 ), up( n, 0.0 ), rhs( n, 0.0 ), sd( n, 0.0 );   // A(i,i-1), A(i,i), A(i,i+1)
+		for( int i = 1; i < n - 1; ++i )                                              // :302-307
+			{
+			lo[i] = 1.0 / 3.0 * ( x[i] - x[i - 1] );
+			di[i] = 2.0 / 3.0 * ( x[i + 1] - x[i - 1] );
+			up[i] = 1.0 / 3.0 * ( x[i + 1] - x[i] );
+			rhs[i] = ( y[i + 1] - y[i] ) / ( x[i + 1] - x[i] ) - ( y[i] - y[i - 1] ) / ( x[i] - x[i - 1] );
+			}
+		di[0] = 2.0; up[0] = 0.0; rhs[0] = 0.0;                                       // :309-313
+		di[n - 1] = 2.0; lo[n - 1] = 0.0; rhs[n - 1] = 0.0;                           // :323-327
+		for( int i = 0; i < n; ++i )                                                  // lu_decompose, :194-204: every row scaled by 1 / a_ii
+			{
+			sd[i] = 1.0 / di[i];
+			if( i > 0 ) lo[i] *= sd[i];
+			if( i < n - 1 ) up[i] *= sd[i];
+			di[i] = 1.0;
+			}
+		for( int k = 0; k < n - 1; ++k )                                              // :207-219
+			{
+			const double xk = -lo[k + 1] / di[k];
+			lo[k + 1] = -xk;
+			di[k + 1] = di[k + 1] + xk * up[k];
+			}
+		std::vector<double> yt( n );                                                  // l_solve, :222-235
+		for( int i = 0; i < n; ++i )
+			{
+			double sum = 0;
+			if( i > 0 ) sum += lo[i] * yt[i - 1];
+			yt[i] = ( rhs[i] * sd[i] ) - sum;
+			}
+		b.assign( n, 0.0 );                                                           // r_solve, :237-250
+		for( int i = n - 1; i >= 0; --i )
+			{
+			double sum = 0;
+			if( i < n - 1 ) sum += up[i] * b[i + 1];
+			b[i] = ( yt[i] - sum ) / di[i];
+			}
+		a.assign( n, 0.0 ); c.assign( n, 0.0 );                                       // :343-349
+		for( int i = 0; i < n - 1; ++i )
+			{
+			a[i] = 1.0 / 3.0 * ( b[i + 1] - b[i] ) / ( x[i + 1] - x[i] );
+			c[i] = ( y[i + 1] - y[i] ) / ( x[i + 1] - x[i] ) - 1.0 / 3.0 * ( 2.0 * b[i] + b[i + 1] ) * ( x[i + 1] - x[i] );
+			}
+		const double h = x[n - 1] - x[n - 2];                                         // :366-370
+		a[n - 1] = 0.0;
+		c[n - 1] = 3.0 * a[n - 2] * h * h + 2.0 * b[n - 2] * h + c[n - 2];
+		}
+	double operator()( double t ) const                                               // :375-397
+		{
+		const size_t n = x.size();
+		const int idx = std::max( int( std::lower_bound( x.begin(), x.end(), t ) - x.begin() ) - 1, 0 );
+		const double h = t - x[idx];
+		if( t < x[0] ) return ( b[0] * h + c[0] ) * h + y[0];
+		if( t > x[n - 1] ) return ( b[n - 1] * h + c[n - 1] ) * h + y[n - 1];
+		return ( ( a[idx] * h + b[idx] ) * h + c[idx] ) * h + y[idx];
+		}
+	};
+}
+
+extern "C" {
+
+void oracle_spline( const double * x, const double * y, int n, const double * t, int nt, double * out )
+	{
+	Spline s;
+	s.set_points( std::vector<double>( x, x + n ), std::vector<double>( y, y + n ) );
+	for( int i = 0; i < nt; ++i ) out[i] = s( t[i] );
+	}
+
+int64_t oracle_stretch_spline_out_frames( const uint32_t * steps, int64_t F )
+	{
+	int32_t total = 0;                                                                // :399-405: Frame += uint32
+	for( int64_t i = 0; i + 1 < F; ++i ) total = int32_t( uint32_t( total ) + steps[i] );
+	return total;
+	}
+
+int oracle_stretch_spline( const float * pv_mf, int ch, int64_t F, int bins, const uint32_t * steps, int64_t Fo, float * out_mf )
+	{
+	if( F < 3 ) return -1;                                                            // spline.h:288 asserts more than two points
+	const MF * pv = reinterpret_cast<const MF*>( pv_mf );
+	MF * out = reinterpret_cast<MF*>( out_mf );
+	std::vector<double> Xs( static_cast<size_t>( F ) ), ms( static_cast<size_t>( F ) ), fs( static_cast<size_t>( F ) );
+	int32_t run = 0;
+	for( int64_t fr = 0; fr + 1 < F; ++fr ) { Xs[size_t( fr )] = run; run = int32_t( uint32_t( run ) + steps[fr] ); }   // :400-405
+	Xs[size_t( F - 1 )] = run;
+	for( int c = 0; c < ch; ++c )
+		for( int b = 0; b < bins; ++b )                                               // :413-441
+			{
+			for( int64_t fr = 0; fr < F; ++fr ) { ms[size_t( fr )] = pv[pos( F, bins, c, fr, b )].m; fs[size_t( fr )] = pv[pos( F, bins, c, fr, b )].f; }
+			Spline sm, sf;
+			sm.set_points( Xs, ms );
+			sf.set_points( Xs, fs );
+			for( int64_t fr = 0; fr < Fo; ++fr ) out[pos( Fo, bins, c, fr, b )] = MF{ float( sm( double( fr ) ) ), float( sf( double( fr ) ) ) };
+			}
+	return 0;
+	}
+
+} // extern "C"

@@ -4,6 +4,7 @@
 // the reference's own sources, read in place from /root/reference/src:
 //     flan/phase_vocoder.cpp  flan/WindowFunctions.cpp  flan/PV/PVBuffer.cpp  flan/Utility/Bytes.cpp
 //     flan/Utility/buffer_access.cpp  flan/Utility/Interpolator.cpp  flan/Utility/{Interval,Color,Rect}.cpp
+// and the header-only cubic spline the reference vendors (spline/spline.h, used by PV::stretch_spline, PV/PVModify.cpp:387-443)
 // into oracle/_ref/libflanref.so.  No reference source is copied into this repository and no stand-in header or
 // library is written: translation units that need FFTW3f / libsndfile / MSVC's std::_Pi (Conversions/AudioPV.cpp,
 // PV/PVModify.cpp, PV/PV.cpp, Audio/*.cpp, FFTHelper.cpp) are simply NOT built -- see DESIGN.md.
@@ -19,6 +20,7 @@
 #include "flan/WindowFunctions.h"
 #include "flan/PV/PVBuffer.h"
 #include "flan/Utility/Interpolator.h"
+#include "spline/spline.h"
 
 extern "C" {
 
@@ -120,6 +122,15 @@ float ref_interpolate( int kind, float x )
 		case 8: return Interpolator::sine()( x );
 		}
 	return x;
+	}
+
+// spline/spline.h as PV::stretch_spline uses it (PVModify.cpp:427-440): default boundary conditions, set_points( x, y ), then
+// evaluated at nt points
+void ref_spline( const double * x, const double * y, int n, const double * t, int nt, double * out )
+	{
+	tk::spline s;
+	s.set_points( std::vector<double>( x, x + n ), std::vector<double>( y, y + n ) );
+	for( int i = 0; i < nt; ++i ) out[i] = s( t[i] );
 	}
 
 } // extern "C"

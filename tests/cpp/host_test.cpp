@@ -334,6 +334,16 @@ static void device_checks()
 			CHECK( ex.modify( []( TF tf ){ return TF{ tf.t + 700.0f, tf.f }; } ).is_null() );      // longer than ten minutes: refused
 			CHECK( ex.modify( []( TF tf ){ return tf; }, Interpolator( []( float v ){ return v; } ) ).is_null() );   // unnamed interpolator
 			}
+		// stretch_spline: three output frames per input frame; frame 0 is the input's, the knots are reproduced up to rounding
+			{
+			PV sp = p2.stretch_spline( 3.0f );
+			CHECK( sp.get_num_frames() == 3 * ( F - 1 ) && sp.get_MF( 1, 0, 40 ).m == p2.get_MF( 1, 0, 40 ).m );
+			CHECK( close_to( sp.get_MF( 1, 30, 40 ).m, p2.get_MF( 1, 10, 40 ).m, 1e-5 ) && close_to( sp.get_MF( 0, 60, 7 ).f, p2.get_MF( 0, 20, 7 ).f, 1e-5 ) );
+			PV sp_var = p2.stretch_spline( [&]( Second t ){ return t < 0.3f ? -5.0f : 2.7f; } );   // below 1 (and negative): one frame per frame
+			const Frame early = Frame( std::ceil( 0.3f / p2.frame_to_time( 1 ) ) );
+			CHECK( sp_var.get_num_frames() == early + 2 * ( F - 1 - early ) );
+			CHECK( p2.cut_frames( 0, 2 ).stretch_spline( 2.0f ).is_null() );            // two frames: the spline needs three
+			}
 		(void) B;
 		}
 	// ---- a grid large enough to go over in slabs (sampled slab k+1 while slab k uploads) = the same grid sampled in one piece

@@ -86,6 +86,11 @@ def _load():
     lib.oracle_modify_out_frames.restype = C.c_int64
     lib.oracle_modify_out_frames.argtypes = [f32p, C.c_int64, C.c_int, C.c_float, C.c_int]
     lib.oracle_modify.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_int, f32p, f32p, C.c_int, C.c_int64, f32p]
+    lib.oracle_spline.restype = None
+    lib.oracle_spline.argtypes = [f64p, f64p, C.c_int, f64p, C.c_int, f64p]
+    lib.oracle_stretch_spline_out_frames.restype = C.c_int64
+    lib.oracle_stretch_spline_out_frames.argtypes = [C.c_void_p, C.c_int64]
+    lib.oracle_stretch_spline.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int64, f32p]
     lib.oracle_smear_time_plan.restype = None
     lib.oracle_smear_time_plan.argtypes = [C.c_int64, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_float, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
     lib.oracle_smear_time.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
@@ -124,6 +129,9 @@ def load_ref():
     ref.ref_pv_load.argtypes = [C.c_char_p, C.POINTER(RefPVFormat), C.c_void_p, C.c_int64]
     ref.ref_interpolate.restype = C.c_float
     ref.ref_interpolate.argtypes = [C.c_int, C.c_float]
+    if hasattr(ref, "ref_spline"):
+        ref.ref_spline.restype = None
+        ref.ref_spline.argtypes = [f64p, f64p, C.c_int, f64p, C.c_int, f64p]
     return ref
 
 
@@ -376,6 +384,25 @@ def modify(pv, sample_rate, hop, mod_tf, in_f, interp=0, out_frames=None):
         return None
     out = np.empty((ch, Fo, bins, 2), np.float32)
     lib.oracle_modify(pv.reshape(-1), ch, F, bins, sample_rate, hop, mod.reshape(-1), in_f.reshape(-1), interp, Fo, out.reshape(-1))
+    return out
+
+
+def spline(x, y, t):
+    x, y, t = (np.ascontiguousarray(v, np.float64) for v in (x, y, t))
+    out = np.empty(len(t), np.float64)
+    lib.oracle_spline(x, y, len(x), t, len(t), out)
+    return out
+
+
+def stretch_spline(pv, steps):
+    """PV::stretch_spline; steps: uint32 [F-1] = the safeInterpolation value of every frame but the last"""
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    steps = np.ascontiguousarray(steps, np.uint32)
+    assert steps.shape == (F - 1,)
+    Fo = int(lib.oracle_stretch_spline_out_frames(steps.ctypes.data, F))
+    out = np.empty((ch, Fo, bins, 2), np.float32)
+    assert lib.oracle_stretch_spline(pv.reshape(-1), ch, F, bins, steps.ctypes.data, Fo, out.reshape(-1)) == 0
     return out
 
 

@@ -192,3 +192,25 @@ def test_modify(fa, pv_small, pv_wide):
             grid = np.ascontiguousarray(grid, np.float32)
             Fo = O.modify_out_frames(grid, SR, HOP)
             assert_identical("modify ties/%s" % name, fa.modify(flat, SR, HOP, grid, in_f, 0, Fo), O.modify(flat, SR, HOP, grid, in_f, 0, Fo))
+
+
+def test_stretch_spline(fa, pv_small, pv_wide):
+    """fp64 recurrences in the vendored spline's operation order: bit-identical to the checker, which is itself pinned bit for bit
+    against the real spline.h (tests/test_oracle_vs_ref.py)"""
+    rng = np.random.default_rng(31)
+    for pv in (pv_small, pv_wide, pv_small[:, :3].copy(), pv_wide[:1, :4].copy()):
+        F = pv.shape[1]
+        for name, steps in (("ones", np.ones(F - 1, np.uint32)), ("twos", np.full(F - 1, 2, np.uint32)), ("random 1..9", rng.integers(1, 10, F - 1).astype(np.uint32)),
+                            ("one long", np.concatenate([[37], np.ones(F - 2)]).astype(np.uint32))):
+            got, ref = fa.stretch_spline(pv, steps), O.stretch_spline(pv, steps)
+            assert_identical("stretch_spline/%s F=%d" % (name, F), got, ref)
+    # steps of one: every output frame but the first sits ON a knot and is evaluated from the segment before it (lower_bound,
+    # spline.h:380-381): equal to the input up to the rounding of that evaluation, not bit for bit
+    ones = fa.stretch_spline(pv_small, np.ones(pv_small.shape[1] - 1, np.uint32))
+    assert ones.shape[1] == pv_small.shape[1] - 1
+    assert np.array_equal(ones[:, 0], pv_small[:, 0])
+    assert np.allclose(ones, pv_small[:, :-1], rtol=1e-5, atol=1e-3)
+    with pytest.raises(fa.FlanHipError):
+        fa.stretch_spline(pv_small[:, :2].copy(), np.ones(1, np.uint32))           # fewer than three knots
+    with pytest.raises(fa.FlanHipError):
+        fa.stretch_spline(pv_small, np.zeros(pv_small.shape[1] - 1, np.uint32))    # a step of 0: the knots would not increase

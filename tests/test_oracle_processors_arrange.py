@@ -232,3 +232,30 @@ def test_modify_on_maps_with_known_answers():
     import flan_amd
     for g in (ident, sh, st, far, back):
         assert flan_amd.modify_out_frames(g, SR, hop) == O.modify_out_frames(g, SR, hop)
+
+
+def test_stretch_spline_properties_and_plan_helper():
+    """the checker's stretch_spline (pinned against the real spline.h in test_oracle_vs_ref.py) on data with known splines"""
+    import flan_amd
+    F, bins = 40, 5
+    pv = np.zeros((1, F, bins, 2), np.float32)
+    k = np.arange(F, dtype=np.float32)
+    pv[0, :, 0, 0] = 3.0 + 0.5 * k                                                    # a straight line over uniform knots is its own natural spline
+    pv[0, :, 1, 0] = 7.0
+    pv[0, :, 2, 1] = 1000.0 - 2.0 * k
+    steps = np.full(F - 1, 4, np.uint32)
+    out = O.stretch_spline(pv, steps)
+    assert out.shape == (1, 4 * (F - 1), bins, 2)
+    t = np.arange(4 * (F - 1), dtype=np.float64) / 4.0
+    assert np.allclose(out[0, :, 0, 0], 3.0 + 0.5 * t, rtol=0, atol=1e-5)
+    assert np.array_equal(out[0, :, 1, 0], np.full(len(t), 7.0, np.float32))
+    assert np.allclose(out[0, :, 2, 1], 1000.0 - 2.0 * t, rtol=0, atol=1e-3)
+    assert not out[0, :, 3:].any()
+    # the library's step bookkeeping (host arithmetic) against the checker's
+    rng = np.random.default_rng(2)
+    for trial in range(50):
+        n = int(rng.integers(3, 200))
+        st = rng.integers(1, 1000, n - 1).astype(np.uint32)
+        assert flan_amd.lib.flanhip_stretch_spline_out_frames(st.ctypes.data, n) == O.lib.oracle_stretch_spline_out_frames(st.ctypes.data, n) == int(st.sum())
+    assert flan_amd.lib.flanhip_stretch_spline_out_frames(np.ones(1, np.uint32).ctypes.data, 2) == -1
+    assert flan_amd.lib.flanhip_stretch_spline_out_frames(np.array([1, 0, 1], np.uint32).ctypes.data, 4) == -1

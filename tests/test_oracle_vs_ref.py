@@ -132,3 +132,24 @@ def test_pvbuffer_unit_conversions_bit_exact():
             assert np.float32(ref.ref_pv_frame_to_time(fmt, v)).view(np.uint32) == np.float32(O.lib.oracle_frame_to_time(v, sr, hop_r)).view(np.uint32)
         # channel -> frame -> bin layout
         assert ref.ref_pv_buffer_pos(fmt, 1, 3, 5) == (1 * 7 + 3) * (dft // 2 + 1) + 5
+
+
+def test_cubic_spline_bit_exact():
+    """the spline restated in oracle/arrange_oracle.cpp against the header the reference vendors (spline/spline.h, compiled unmodified
+    into oracle/_ref), the way PV::stretch_spline uses it (PVModify.cpp:427-440): integer knots, float data, evaluated on the
+    integers in between -- and on arbitrary points, including outside the knots"""
+    rng = np.random.default_rng(77)
+    for n in (3, 4, 5, 17, 200, 3000):
+        for trial in range(4):
+            x = np.concatenate([[0], np.cumsum(rng.integers(1, 9, n - 1))]).astype(np.float64)
+            y = rng.normal(0, 100, n).astype(np.float32).astype(np.float64)
+            t = np.concatenate([np.arange(0, x[-1] + 1), rng.uniform(-5, x[-1] + 5, 200)])
+            ours = O.spline(x, y, t)
+            theirs = np.empty(len(t), np.float64)
+            ref.ref_spline(x, y, n, np.ascontiguousarray(t), len(t), theirs)
+            assert np.array_equal(ours.view(np.uint64), theirs.view(np.uint64)), (n, trial)
+    # non-integer knots too
+    x = np.sort(rng.uniform(0, 50, 40)); y = rng.normal(0, 1, 40); t = rng.uniform(-1, 51, 500)
+    theirs = np.empty(500, np.float64)
+    ref.ref_spline(x, y, 40, t, 500, theirs)
+    assert np.array_equal(O.spline(x, y, t).view(np.uint64), theirs.view(np.uint64))

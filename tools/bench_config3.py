@@ -95,7 +95,11 @@ warp[..., 1] = (torch.arange(BINS, device=dev, dtype=torch.float32) * (SR / DFT)
 warp_f = (pv[..., 1] * 1.2).contiguous()
 warp_Fo = int(lib.flanhip_modify_out_frames(fa._vp(warp.cpu().numpy().ctypes.data), F, BINS, SR, HOP)) if False else 2 * (F - 1)
 warp_out = torch.empty((ch, warp_Fo, BINS, 2), dtype=torch.float32, device=dev)
+import numpy as _np
+sp_steps = _np.full(F - 1, 2, _np.uint32)
+sp_out = torch.empty((ch, 2 * (F - 1), BINS, 2), dtype=torch.float32, device=dev)
 stages.update({
+    "stretch_spline(x2)": lambda: fa.check(lib.flanhip_stretch_spline_dev(P(pv), ch, F, BINS, fa._vp(sp_steps.ctypes.data), 2 * (F - 1), P(sp_out), None)),
     "modify(2 t, 1.2 f)": lambda: fa.check(lib.flanhip_modify_dev(P(pv), ch, F, BINS, SR, HOP, P(warp), P(warp_f), 0, warp_Fo, P(warp_out), None)),
     "smear_time(0.1 s, 5)": lambda: fa.check(lib.flanhip_smear_time_dev(P(pv), ch, F, BINS, SR, HOP, None, 0.1, None, 5, P(sm_dist), sm_n, -sm_e, F - 1 + 2 * sm_e, P(sm_out), None)),
     "freeze(3 pauses)": lambda: fa.check(lib.flanhip_select_frames_dev(P(pv), ch, F, BINS, P(fz_src), fz_Fo, P(fz_out), None)),
