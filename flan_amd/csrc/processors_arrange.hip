@@ -180,8 +180,8 @@ __global__ __launch_bounds__( 256 ) void k_smear_time( const MFd * in, int64_t F
 // are both 8 bytes):
 //   k_modify_offer    thread per input quad: walks its bounding box in the reference's order (x outside, y inside, `break` leaves
 //                     the column) and offers ( weight bits << 32 | ~quad index ) to every point it covers, global atomic max
-//   k_modify_resolve  thread per output point: decodes the winning quad, evaluates that one point again (same code, same bits) to learn
-//                     WHICH corner was the loudest, and replaces the key by { weight, that corner's mapped frequency }
+//   k_modify_resolve  thread per output point: decodes the winning quad and which of its corners was the loudest (two more bits of the
+//                     key) and replaces the key by { weight, that corner's mapped frequency }
 // The arithmetic is what g++ makes of the reference's expressions (see oracle/arrange_oracle.cpp): sqrt and the division after it in
 // double, rounded to float once.  Equally loud candidates: the first quad in ( frame, bin ) order (unspecified in the reference,
 // which runs frames in parallel under a mutex per output frame).
@@ -274,7 +274,7 @@ __global__ __launch_bounds__( 256 ) void k_modify_offer( const MFd * in, int64_t
 	const int miny = to_int_sat( fmaxf( floorf( fminf( fminf( q.py[0], q.py[1] ), fminf( q.py[2], q.py[3] ) ) ), 0.0f ) );
 	const int maxx = to_int_sat( fminf( ceilf( fmaxf( fmaxf( q.px[0], q.px[1] ), fmaxf( q.px[2], q.px[3] ) ) ), float( Fo - 1 ) ) );
 	const int maxy = to_int_sat( fminf( ceilf( fmaxf( fmaxf( q.py[0], q.py[1] ), fmaxf( q.py[2], q.py[3] ) ) ), float( bins - 1 ) ) );
-	const unsigned long long low = (unsigned long long) ( 0xFFFFFFFFu - unsigned( frame * bins + bin ) );
+	const unsigned seq4 = unsigned( frame * bins + bin ) << 2;                        // the loudest corner rides in the two low bits
 	unsigned long long * keys = out_keys + channel * Fo * bins;
 	for( int x = minx; x <= maxx; ++x )                                               // :99-101
 		for( int y = miny; y <= maxy; ++y )
@@ -284,27 +284,25 @@ __global__ __launch_bounds__( 256 ) void k_modify_offer( const MFd * in, int64_t
 			if( r == 0 ) continue;
 			if( r == 1 ) break;
 			if( weight > 0.0f )                                                       // :175: beats the cleared output or a quieter occupant; false for NaN
-				atomicMax( &keys[int64_t( x ) * bins + y], ( (unsigned long long) __float_as_uint( weight ) << 32 ) | low );
+				atomicMax( &keys[int64_t( x ) * bins + y], ( (unsigned long long) __float_as_uint( weight ) << 32 ) | (unsigned long long) ( 0xFFFFFFFFu - ( seq4 | unsigned( corner ) ) ) );
 			}
 	}
 
-__global__ __launch_bounds__( 256 ) void k_modify_resolve( const MFd * in, int64_t F, int bins, float sr, float hop, float dft, const float2 * mod, const float * in_f,
-	int interp_kind, int64_t Fo, int blocks_per_row, MFd * out )
+__global__ __launch_bounds__( 256 ) void k_modify_resolve( int64_t F, int bins, const float * in_f, int64_t Fo, int blocks_per_row, MFd * out )
 	{
 	const int64_t row = blockIdx.x / blocks_per_row;                                  // channel * Fo + x
 	const int y = int( blockIdx.x % blocks_per_row ) * 256 + threadIdx.x;
 	if( y >= bins ) return;
-	const int64_t x = row % Fo, channel = row / Fo;
+	const int64_t channel = row / Fo;
 	const unsigned long long key = reinterpret_cast<const unsigned long long *>( out )[row * bins + y];
 	if( key == 0ull ) return;                                                         // nothing offered: stays { 0, 0 }
-	const unsigned seq = 0xFFFFFFFFu - unsigned( key & 0xFFFFFFFFull );
+	const unsigned packed = 0xFFFFFFFFu - unsigned( key & 0xFFFFFFFFull );
+	const unsigned seq = packed >> 2;
+	const int corner = int( packed & 3u );
 	const int64_t frame = seq / unsigned( bins );
 	const int bin = int( seq % unsigned( bins ) );
-	const Quad q = load_quad( in + channel * F * bins, mod, frame, bin, bins, sr, hop, dft );
-	float weight = 0.0f; int corner = 0;
-	quad_point( q, int( x ), y, interp_kind, weight, corner );                        // the offer again: same code, same bits
-	const int64_t idx[4] = { ( frame - 1 ) * bins + bin - 1, frame * bins + bin - 1, frame * bins + bin, ( frame - 1 ) * bins + bin };
-	out[row * bins + y] = MFd{ __uint_as_float( unsigned( key >> 32 ) ), in_f[channel * F * bins + idx[corner]] };   // :176
+	const int64_t idx = ( frame - ( corner == 0 || corner == 3 ? 1 : 0 ) ) * bins + bin - ( corner < 2 ? 1 : 0 );   // :76-86: corners 0..3 of the quad
+	out[row * bins + y] = MFd{ __uint_as_float( unsigned( key >> 32 ) ), in_f[channel * F * bins + idx] };   // :176
 	}
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -591,7 +589,7 @@ int flanhip_modify_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins
 	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, sr ) ) return rc;
 	FLANHIP_REQUIRE( d_mod_tf && d_in_f && hop >= 1 && out_frames > 0, FLANHIP_ERR_INVALID_ARG, "null grid, bad hop or bad output frame count" );
 	FLANHIP_REQUIRE( interp_kind >= 0 && interp_kind <= FLANHIP_INTERP_SINE, FLANHIP_ERR_INVALID_ARG, "unknown interpolator" );
-	FLANHIP_REQUIRE( F * bins < ( int64_t( 1 ) << 32 ), FLANHIP_ERR_UNSUPPORTED, "frames x bins does not fit the quad index" );
+	FLANHIP_REQUIRE( F * bins < ( int64_t( 1 ) << 30 ), FLANHIP_ERR_UNSUPPORTED, "frames x bins does not fit the quad index" );
 	hipStream_t s = (hipStream_t) stream;
 	FLANHIP_CHECK( hipMemsetAsync( d_out, 0, sizeof( MFd ) * size_t( ch ) * out_frames * bins, s ) );   // PVModify.cpp:40
 	if( F < 2 ) return FLANHIP_OK;                                                    // no quads
@@ -601,8 +599,7 @@ int flanhip_modify_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins
 	hipLaunchKernelGGL( k_modify_offer, dim3( unsigned( ch * ( F - 1 ) * quad_blocks ) ), dim3( 256 ), 0, s, (const MFd*) d_pv, F, bins, sr, float( hop ), dft,
 		reinterpret_cast<const float2*>( d_mod_tf ), interp_kind, out_frames, quad_blocks, reinterpret_cast<unsigned long long*>( d_out ) );
 	FLANHIP_CHECK( hipGetLastError() );
-	hipLaunchKernelGGL( k_modify_resolve, dim3( unsigned( ch * out_frames * point_blocks ) ), dim3( 256 ), 0, s, (const MFd*) d_pv, F, bins, sr, float( hop ), dft,
-		reinterpret_cast<const float2*>( d_mod_tf ), d_in_f, interp_kind, out_frames, point_blocks, (MFd*) d_out );
+	hipLaunchKernelGGL( k_modify_resolve, dim3( unsigned( ch * out_frames * point_blocks ) ), dim3( 256 ), 0, s, F, bins, d_in_f, out_frames, point_blocks, (MFd*) d_out );
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;
 	}
