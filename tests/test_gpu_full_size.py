@@ -212,3 +212,92 @@ def test_config5_ten_seconds_parity_against_the_oracle():
     p2 = np.sqrt(np.mean((out_g.astype(np.float64) - out_r) ** 2))
     print("\n[config 5, 10 s] resample bit-identical=%.5f  P1 rel_m=%.2e  shape bit-identical  P2 rms=%.2e" % (same, rel_m, p2))
     assert rel_m <= 1e-5 and p2 <= 1e-5 and flag == 0
+
+
+def test_arranging_methods_at_the_config3_size():
+    """8 ch x 60 s through the frame-selecting / warping methods: identities that need no CPU run, and repeatability of the kernels
+    that resolve conflicts with atomics (modify, add_harmonics)"""
+    import torch
+    import flan_amd as fa
+    lib = fa.lib
+    dev = torch.device("cuda", 0)
+    ch, n = 8, 60 * 48000
+    F = int(lib.flanhip_num_pv_frames(n, HOP))
+    x = torch.empty((ch, n), dtype=torch.float32, device=dev)
+    fa.check(lib.flanhip_noise_dev(_p(x), ch, n, 99, None))
+    pv = torch.empty((ch, F, BINS, 2), dtype=torch.float32, device=dev)
+    fa.analyze_dev(x, ch, n, SR, W, HOP, DFT, pv)
+    torch.cuda.synchronize()
+
+    def same(a, b):
+        return bool(torch.equal(a.view(torch.int32), b.view(torch.int32)))
+
+    # cut into three pieces and joined again = the input minus its last frame (cut_frames clamps its end to F-1, PV.cpp:653)
+    cuts = [(0, 1000), (1000, 4000), (4000, F)]
+    joined = torch.zeros((ch, F - 1, BINS, 2), dtype=torch.float32, device=dev)
+    at = 0
+    for a, b in cuts:
+        s0, c0 = C.c_int32(), C.c_int32()
+        fa.check(lib.flanhip_cut_frames_range(F, a, b, C.byref(s0), C.byref(c0)))
+        piece = torch.empty((ch, c0.value, BINS, 2), dtype=torch.float32, device=dev)
+        fa.check(lib.flanhip_cut_frames_dev(_p(pv), ch, F, BINS, s0.value, c0.value, _p(piece), None))
+        fa.check(lib.flanhip_place_frames_dev(_p(piece), ch, c0.value, BINS, _p(joined), ch, F - 1, BINS, at, None))
+        at += c0.value
+    torch.cuda.synchronize()
+    assert at == F - 1 and same(joined, pv[:, :F - 1].contiguous())
+
+    # freeze with no pauses = a copy; with pauses every output frame is the input frame the plan names
+    src = fa.freeze_plan(F, SR, HOP, [], [])
+    assert np.array_equal(src, np.arange(F))
+    src = fa.freeze_plan(F, SR, HOP, [7.0, 31.5, 59.9], [0.5, 2.0, 1.0])
+    d_src = torch.from_numpy(src).to(dev)
+    fz = torch.empty((ch, len(src), BINS, 2), dtype=torch.float32, device=dev)
+    fa.check(lib.flanhip_select_frames_dev(_p(pv), ch, F, BINS, _p(d_src), len(src), _p(fz), None))
+    torch.cuda.synchronize()
+    valid = d_src >= 0
+    assert same(fz[:, valid], pv[:, d_src[valid].long()]) and not bool(fz[:, ~valid].any())
+
+    # get_frame on a whole frame = that frame
+    one = torch.empty((ch, 1, BINS, 2), dtype=torch.float32, device=dev)
+    fa.check(lib.flanhip_get_frame_dev(_p(pv), ch, F, BINS, 4321.0, 0, _p(one), None))
+    torch.cuda.synchronize()
+    assert same(one[:, 0], pv[:, 4321])
+
+    # modify with the identity map: twice, bit for bit; and wherever frame -> time -> frame is exact in fp32 (93.75 frames per second:
+    # not everywhere) a grid point is a corner of its quad and comes back as it went in
+    t = (torch.arange(F, device=dev, dtype=torch.float32) / (SR / HOP))[:, None].expand(F, BINS)
+    f = (torch.arange(BINS, device=dev, dtype=torch.float32) * (SR / DFT))[None, :].expand(F, BINS)
+    ident = torch.stack([t, f], dim=-1).contiguous()
+    in_f = pv[..., 1].contiguous()
+    outs = []
+    for rep in range(2):
+        o = torch.empty((ch, F - 1, BINS, 2), dtype=torch.float32, device=dev)
+        fa.check(lib.flanhip_modify_dev(_p(pv), ch, F, BINS, SR, HOP, _p(ident), _p(in_f), 0, F - 1, _p(o), None))
+        outs.append(o)
+    torch.cuda.synchronize()
+    assert same(outs[0], outs[1])
+    tf = (t[:, 0] * SR) / HOP
+    exact = tf == torch.arange(F, device=dev, dtype=torch.float32)
+    rows = (exact[:-1] & exact[1:]).nonzero().flatten()
+    rows = rows[rows < F - 1]
+    assert len(rows) > F // 4
+    assert same(outs[0][:, rows][:, :, :BINS - 1].contiguous(), pv[:, rows][:, :, :BINS - 1].contiguous()) and not bool(outs[0][:, :, BINS - 1].any())
+
+    # add_harmonics twice: the same bits (placement through atomics must not depend on timing)
+    series = torch.full((F, BINS), 0.5, dtype=torch.float32, device=dev)
+    hs = []
+    for rep in range(2):
+        o = torch.empty_like(pv)
+        fa.check(lib.flanhip_harmonic_scale_dev(_p(pv), ch, F, BINS, SR, _p(series), BINS, 1, _p(o), None))
+        hs.append(o)
+    torch.cuda.synchronize()
+    assert same(hs[0], hs[1]) and bool(hs[0].any())
+
+    # stretch_spline with steps of one reproduces the knots (each evaluated from the segment before it: rounding only)
+    steps = np.ones(F - 1, np.uint32)
+    sp = torch.empty((ch, F - 1, BINS, 2), dtype=torch.float32, device=dev)
+    fa.check(lib.flanhip_stretch_spline_dev(_p(pv), ch, F, BINS, C.c_void_p(steps.ctypes.data), F - 1, _p(sp), None))
+    torch.cuda.synchronize()
+    assert same(sp[:, 0], pv[:, 0])
+    err = (sp - pv[:, :F - 1]).abs().max().item()
+    assert err < 2e-2 * pv.abs().max().item() * 1e-3 + 1e-2, err
