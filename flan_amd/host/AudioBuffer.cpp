@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <utility>
 
+#include <iostream>
+
 #include "device_block.h"
 
 namespace flan {
@@ -50,12 +52,14 @@ const std::vector<float> & AudioBuffer::get_buffer() const
 	{
 	if( !host_valid )
 		{
-		buffer.resize( count() );
-		if( dev && count() )
+		if( buffer.capacity() < count() )                // fresh memory: let every worker fault its share of the pages in, not this thread alone
 			{
-			detail::report( flanhip_memcpy_d2h( buffer.data(), dev->ptr, sizeof( float ) * count(), nullptr ), "download of audio" );
-			detail::report( flanhip_stream_synchronize( nullptr ), "synchronise" );
+			buffer.reserve( count() );
+			detail::touch_pages( buffer.data(), sizeof( float ) * count() );
 			}
+		buffer.resize( count() );
+		if( dev && count() && !detail::download_to_host( buffer.data(), dev->ptr, sizeof( float ) * count() ) )
+			std::cerr << "flan: download of audio failed: " << flanhip_last_error() << std::endl;
 		host_valid = true;
 		}
 	return buffer;
@@ -79,8 +83,11 @@ const float * AudioBuffer::device_data() const
 		if( count() == 0 ) return nullptr;
 		auto block = detail::DeviceBlock::allocate( sizeof( float ) * count() );
 		if( !block ) return nullptr;
-		if( !detail::report( flanhip_memcpy_h2d( block->ptr, buffer.data(), sizeof( float ) * count(), nullptr ), "upload of audio" ) ) return nullptr;
-		flanhip_stream_synchronize( nullptr );
+		if( !detail::upload_from_host( block->ptr, buffer.data(), sizeof( float ) * count() ) )
+			{
+			std::cerr << "flan: upload of audio failed: " << flanhip_last_error() << std::endl;
+			return nullptr;
+			}
 		dev = std::move( block );
 		}
 	return static_cast<const float*>( dev->ptr );

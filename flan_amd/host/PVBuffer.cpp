@@ -56,12 +56,14 @@ const std::vector<MF> & PVBuffer::get_buffer() const
 	{
 	if( !host_valid )
 		{
-		buffer.resize( count() );
-		if( dev && count() )
+		if( buffer.capacity() < count() )                // fresh memory: let every worker fault its share of the pages in, not this thread alone
 			{
-			detail::report( flanhip_memcpy_d2h( buffer.data(), dev->ptr, sizeof( MF ) * count(), nullptr ), "download of PV" );
-			detail::report( flanhip_stream_synchronize( nullptr ), "synchronise" );
+			buffer.reserve( count() );
+			detail::touch_pages( buffer.data(), sizeof( MF ) * count() );
 			}
+		buffer.resize( count() );
+		if( dev && count() && !detail::download_to_host( buffer.data(), dev->ptr, sizeof( MF ) * count() ) )
+			std::cerr << "flan: download of PV failed: " << flanhip_last_error() << std::endl;
 		host_valid = true;
 		}
 	return buffer;
@@ -85,8 +87,11 @@ const MF * PVBuffer::device_data() const
 		if( count() == 0 ) return nullptr;
 		auto block = detail::DeviceBlock::allocate( sizeof( MF ) * count() );
 		if( !block ) return nullptr;
-		if( !detail::report( flanhip_memcpy_h2d( block->ptr, buffer.data(), sizeof( MF ) * count(), nullptr ), "upload of PV" ) ) return nullptr;
-		flanhip_stream_synchronize( nullptr );
+		if( !detail::upload_from_host( block->ptr, buffer.data(), sizeof( MF ) * count() ) )
+			{
+			std::cerr << "flan: upload of PV failed: " << flanhip_last_error() << std::endl;
+			return nullptr;
+			}
 		dev = std::move( block );
 		}
 	return static_cast<const MF*>( dev->ptr );

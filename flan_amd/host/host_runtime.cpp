@@ -5,6 +5,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdlib>
+#include <cstring>
 #include <exception>
 #include <fstream>
 #include <mutex>
@@ -189,6 +190,83 @@ CopyStreams copy_streams()
 		return c;
 		}();
 	return streams;
+	}
+
+namespace {
+constexpr size_t kSlab = size_t( 8 ) << 20;
+constexpr size_t kPiece = size_t( 256 ) << 10;
+
+struct CopyJob { char * dst; const char * src; size_t bytes; };
+void parallel_copy( void * dst, const void * src, size_t bytes )
+	{
+	CopyJob job{ static_cast<char*>( dst ), static_cast<const char*>( src ), bytes };
+	pool_run( int( ( bytes + kPiece - 1 ) / kPiece ), []( void * ctx, int i )
+		{
+		const CopyJob & j = *static_cast<const CopyJob*>( ctx );
+		const size_t lo = size_t( i ) * kPiece, n = std::min( kPiece, j.bytes - lo );
+		std::memcpy( j.dst + lo, j.src + lo, n );
+		}, &job );
+	}
+}
+
+void touch_pages( void * p, size_t bytes )
+	{
+	if( bytes < ( size_t( 4 ) << 20 ) ) return;
+	struct Job { volatile char * p; size_t bytes; } job{ static_cast<volatile char*>( p ), bytes };
+	constexpr size_t kRun = size_t( 2 ) << 20;
+	pool_run( int( ( bytes + kRun - 1 ) / kRun ), []( void * ctx, int i )
+		{
+		const Job & j = *static_cast<const Job*>( ctx );
+		const size_t lo = size_t( i ) * kRun, hi = std::min( j.bytes, lo + kRun );
+		for( size_t at = lo; at < hi; at += 4096 ) j.p[at] = 0;
+		}, &job );
+	}
+
+bool download_to_host( void * dst, const void * d_src, size_t bytes )
+	{
+	if( bytes == 0 ) return true;
+	const CopyStreams streams = copy_streams();
+	if( bytes < 2 * kSlab || !streams.down )
+		return flanhip_memcpy_d2h( dst, d_src, bytes, nullptr ) == FLANHIP_OK && flanhip_stream_synchronize( nullptr ) == FLANHIP_OK;
+	if( flanhip_stream_synchronize( nullptr ) != FLANHIP_OK ) return false;           // whatever produced the data has finished
+	char * stage[2] = { static_cast<char*>( staging_acquire( kSlab ) ), static_cast<char*>( staging_acquire( kSlab ) ) };
+	const size_t slabs = ( bytes + kSlab - 1 ) / kSlab;
+	auto fetch = [&]( size_t k )
+		{
+		const size_t lo = k * kSlab;
+		return flanhip_memcpy_d2h( stage[k & 1], static_cast<const char*>( d_src ) + lo, std::min( kSlab, bytes - lo ), streams.down ) == FLANHIP_OK;
+		};
+	bool ok = fetch( 0 );
+	for( size_t k = 0; k < slabs && ok; ++k )
+		{
+		ok = flanhip_stream_synchronize( streams.down ) == FLANHIP_OK;               // slab k is in its block
+		if( ok && k + 1 < slabs ) ok = fetch( k + 1 );                                // the other block: its last reader finished an iteration ago
+		if( ok ) parallel_copy( static_cast<char*>( dst ) + k * kSlab, stage[k & 1], std::min( kSlab, bytes - k * kSlab ) );
+		}
+	flanhip_stream_synchronize( streams.down );
+	staging_release( stage[0] ); staging_release( stage[1] );
+	return ok;
+	}
+
+bool upload_from_host( void * d_dst, const void * src, size_t bytes )
+	{
+	if( bytes == 0 ) return true;
+	const CopyStreams streams = copy_streams();
+	if( bytes < 2 * kSlab || !streams.up )
+		return flanhip_memcpy_h2d( d_dst, src, bytes, nullptr ) == FLANHIP_OK && flanhip_stream_synchronize( nullptr ) == FLANHIP_OK;
+	char * stage[2] = { static_cast<char*>( staging_acquire( kSlab ) ), static_cast<char*>( staging_acquire( kSlab ) ) };
+	const size_t slabs = ( bytes + kSlab - 1 ) / kSlab;
+	bool ok = true;
+	for( size_t k = 0; k < slabs && ok; ++k )
+		{
+		const size_t lo = k * kSlab, n = std::min( kSlab, bytes - lo );
+		parallel_copy( stage[k & 1], static_cast<const char*>( src ) + lo, n );         // while slab k-1 is on the link
+		if( k >= 1 ) ok = flanhip_stream_synchronize( streams.up ) == FLANHIP_OK;      // slab k-1 has left the other block (free for k+1)
+		if( ok ) ok = flanhip_memcpy_h2d( static_cast<char*>( d_dst ) + lo, stage[k & 1], n, streams.up ) == FLANHIP_OK;
+		}
+	ok = flanhip_stream_synchronize( streams.up ) == FLANHIP_OK && ok;
+	staging_release( stage[0] ); staging_release( stage[1] );
+	return ok;
 	}
 
 int host_workers() { return int( pool().threads.size() ) + 1; }

@@ -346,6 +346,20 @@ static void device_checks()
 			}
 		(void) B;
 		}
+	// ---- large host <-> device transfers go in slabs through page-locked blocks: what arrives is what was sent
+		{
+		Audio big_audio = noise( 3, 3000001, 77 );                                    // 36 MB, not a multiple of anything
+		const std::vector<float> sent = big_audio.get_buffer();
+		const float * d_audio = big_audio.device_data();                               // upload
+		std::vector<float> seen( sent.size() );
+		CHECK( d_audio != nullptr );
+		flanhip_memcpy_d2h( seen.data(), d_audio, sizeof( float ) * seen.size(), nullptr ); flanhip_stream_synchronize( nullptr );
+		CHECK( std::memcmp( seen.data(), sent.data(), sizeof( float ) * sent.size() ) == 0 );
+		Audio ms_audio = noise( 2, 5000003, 78 ).convert_to_mid_side();               // lives on the device only
+		std::vector<float> plain( size_t( 2 ) * 5000003 );
+		flanhip_memcpy_d2h( plain.data(), ms_audio.device_data(), sizeof( float ) * plain.size(), nullptr ); flanhip_stream_synchronize( nullptr );
+		CHECK( ms_audio.get_buffer().size() == plain.size() && std::memcmp( ms_audio.get_buffer().data(), plain.data(), sizeof( float ) * plain.size() ) == 0 );   // download
+		}
 	// ---- a grid large enough to go over in slabs (sampled slab k+1 while slab k uploads) = the same grid sampled in one piece
 	// and taken through the C ABI by hand; and the block cache hands memory back and forth without mixing results up
 		{

@@ -35,6 +35,13 @@ int main()
 		Audio out_c = st_c.convert_to_audio();
 		const auto t5 = clk::now();
 		if( pv.is_null() || out_l.is_null() || out_c.is_null() ) { std::printf( "FAILED\n" ); return 1; }
+		if( rep >= 4 )                                                              // what reading the result on the host costs on top
+			{
+			const auto t6 = clk::now();
+			const std::vector<float> & samples = out_c.get_buffer();
+			const auto t7 = clk::now();
+			std::printf( "        out.get_buffer(): %zu samples to the host in %.3f ms (%.1f GB/s)\n", samples.size(), ms( t6, t7 ), samples.size() * 4e-6 / ms( t6, t7 ) );
+			}
 		std::printf( "rep %d: convert_to_PV %.3f ms | stretch(lambda) %.3f ms, convert_to_audio %.3f ms | stretch(2.0f) %.3f ms, convert_to_audio %.3f ms"
 			" | config 3 end to end: %.3f ms (lambda) / %.3f ms (constant)\n", rep, ms( t0, t1 ), ms( t1, t2 ), ms( t2, t3 ), ms( t3, t4 ), ms( t4, t5 ),
 			ms( t0, t3 ), ms( t0, t1 ) + ms( t3, t5 ) );
