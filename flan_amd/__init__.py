@@ -41,6 +41,11 @@ _SIGS = {
     "flanhip_modify_time_out_frames": (_i64, [_vp, _i64, _i32, _f32, _i32]),
     "flanhip_malloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
     "flanhip_free": (C.c_int, [_vp]),
+    "flanhip_upload": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "flanhip_download": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "flanhip_touch_pages": (C.c_int, [_vp, C.c_size_t]),
+    "flanhip_host_workers": (C.c_int, []),
+    "flanhip_parallel_for": (C.c_int, [C.c_int, _vp, _vp]),
     "flanhip_stream_create": (C.c_int, [C.POINTER(_vp)]),
     "flanhip_stream_destroy": (C.c_int, [_vp]),
     "flanhip_host_malloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libflanhip.so")
-SOURCES = ["core.hip", "conversions.hip", "processors.hip", "processors_ext.hip", "processors_arrange.hip", "resample.hip", "utility.hip", "collective.hip"]
+SOURCES = ["core.hip", "conversions.hip", "processors.hip", "processors_ext.hip", "processors_arrange.hip", "resample.hip", "utility.hip", "collective.hip", "transfer.hip"]
 # -ffp-contract=off: the per-bin phase-vocoder arithmetic must round every fp32 operation individually, like the
 # reference; the FFT butterflies call fmaf explicitly where a fused multiply-add is wanted.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

@@ -374,12 +374,12 @@ int flanhip_analyze( const float * audio, int64_t ch, int64_t n, float sr, int W
 	DeviceBuffer d_audio, d_pv;
 	if( int rc = d_audio.alloc( sizeof( float ) * size_t( ch ) * n ) ) return rc;
 	if( int rc = d_pv.alloc( sizeof( flanhip_MF ) * size_t( ch ) * F * bins ) ) return rc;
-	FLANHIP_CHECK( hipMemcpy( d_audio.p, audio, sizeof( float ) * size_t( ch ) * n, hipMemcpyHostToDevice ) );
+	if( int rc_t = flanhip_upload( d_audio.p, audio, sizeof( float ) * size_t( ch ) * n ) ) return rc_t;
 	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
 	if( int rc = launch_analyze( (const float*) d_audio.p, ch, n, sr, W, hop, dft, (flanhip_MF*) d_pv.p, nullptr, nullptr ) ) return rc;
 	FLANHIP_CHECK( hipDeviceSynchronize() );
 	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
-	FLANHIP_CHECK( hipMemcpy( out, d_pv.p, sizeof( flanhip_MF ) * size_t( ch ) * F * bins, hipMemcpyDeviceToHost ) );
+	if( int rc_t = flanhip_download( out, d_pv.p, sizeof( flanhip_MF ) * size_t( ch ) * F * bins ) ) return rc_t;
 	return FLANHIP_OK;
 	}
 
@@ -414,12 +414,12 @@ int flanhip_synthesize( const flanhip_MF * pv, int64_t ch, int64_t F, int bins, 
 	if( int rc = d_ws.alloc( lay.total_bytes ) ) return rc;
 	if( int rc = d_flag.alloc( sizeof( int ) ) ) return rc;
 	FLANHIP_CHECK( hipMemset( d_flag.p, 0, sizeof( int ) ) );
-	FLANHIP_CHECK( hipMemcpy( d_pv.p, pv, pv_bytes, hipMemcpyHostToDevice ) );
+	if( int rc_t = flanhip_upload( d_pv.p, pv, pv_bytes ) ) return rc_t;
 	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
 	if( int rc = launch_synthesize( (const flanhip_MF*) d_pv.p, ch, F, bins, sr, ar, W, (float*) d_out.p, d_ws.p, (int*) d_flag.p, false, nullptr ) ) return rc;
 	FLANHIP_CHECK( hipDeviceSynchronize() );
 	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
-	FLANHIP_CHECK( hipMemcpy( out, d_out.p, out_bytes, hipMemcpyDeviceToHost ) );
+	if( int rc_t = flanhip_download( out, d_out.p, out_bytes ) ) return rc_t;
 	int flag = 0;
 	FLANHIP_CHECK( hipMemcpy( &flag, d_flag.p, sizeof( int ), hipMemcpyDeviceToHost ) );
 	if( nan_flag ) *nan_flag = flag;

@@ -559,13 +559,13 @@ int flanhip_modify_time( const flanhip_MF * pv, int64_t ch, int64_t F, int bins,
 	if( int rc = d_pv.alloc( in_bytes ) ) return rc;
 	if( int rc = d_mod.alloc( mod_bytes ) ) return rc;
 	if( int rc = d_out.alloc( out_bytes ) ) return rc;
-	FLANHIP_CHECK( hipMemcpy( d_pv.p, pv, in_bytes, hipMemcpyHostToDevice ) );
-	FLANHIP_CHECK( hipMemcpy( d_mod.p, mod, mod_bytes, hipMemcpyHostToDevice ) );
+	if( int rc_t = flanhip_upload( d_pv.p, pv, in_bytes ) ) return rc_t;
+	if( int rc_t = flanhip_upload( d_mod.p, mod, mod_bytes ) ) return rc_t;
 	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
 	if( int rc = flanhip_modify_time_dev( (const flanhip_MF*) d_pv.p, ch, F, bins, sr, hop, (const float*) d_mod.p, Fo, (flanhip_MF*) d_out.p, nullptr ) ) return rc;
 	FLANHIP_CHECK( hipDeviceSynchronize() );
 	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
-	FLANHIP_CHECK( hipMemcpy( out, d_out.p, out_bytes, hipMemcpyDeviceToHost ) );
+	if( int rc_t = flanhip_download( out, d_out.p, out_bytes ) ) return rc_t;
 	return FLANHIP_OK;
 	}
 
@@ -630,14 +630,14 @@ int flanhip_modify_frequency( const flanhip_MF * pv, int64_t ch, int64_t F, int 
 	if( int rc = d_mod.alloc( mod_bytes ) ) return rc;
 	if( int rc = d_inm.alloc( inm_bytes ) ) return rc;
 	if( int rc = d_out.alloc( pv_bytes ) ) return rc;
-	FLANHIP_CHECK( hipMemcpy( d_pv.p, pv, pv_bytes, hipMemcpyHostToDevice ) );
-	FLANHIP_CHECK( hipMemcpy( d_mod.p, mod, mod_bytes, hipMemcpyHostToDevice ) );
-	FLANHIP_CHECK( hipMemcpy( d_inm.p, in_modified, inm_bytes, hipMemcpyHostToDevice ) );
+	if( int rc_t = flanhip_upload( d_pv.p, pv, pv_bytes ) ) return rc_t;
+	if( int rc_t = flanhip_upload( d_mod.p, mod, mod_bytes ) ) return rc_t;
+	if( int rc_t = flanhip_upload( d_inm.p, in_modified, inm_bytes ) ) return rc_t;
 	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
 	if( int rc = flanhip_modify_frequency_dev( (const flanhip_MF*) d_pv.p, ch, F, bins, sr, (const float*) d_mod.p, (const float*) d_inm.p, (flanhip_MF*) d_out.p, nullptr ) ) return rc;
 	FLANHIP_CHECK( hipDeviceSynchronize() );
 	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
-	FLANHIP_CHECK( hipMemcpy( out, d_out.p, pv_bytes, hipMemcpyDeviceToHost ) );
+	if( int rc_t = flanhip_download( out, d_out.p, pv_bytes ) ) return rc_t;
 	return FLANHIP_OK;
 	}
 
@@ -704,11 +704,11 @@ int flanhip_shape_affine( const flanhip_MF * pv, int64_t ch, int64_t F, int bins
 	const size_t bytes = sizeof( flanhip_MF ) * size_t( ch ) * F * bins;
 	if( int rc = d_pv.alloc( bytes ) ) return rc;
 	if( int rc = d_out.alloc( bytes ) ) return rc;
-	FLANHIP_CHECK( hipMemcpy( d_pv.p, pv, bytes, hipMemcpyHostToDevice ) );
+	if( int rc_t = flanhip_upload( d_pv.p, pv, bytes ) ) return rc_t;
 	if( int rc = flanhip_shape_affine_dev( (const flanhip_MF*) d_pv.p, ch, F, bins, sr, a, b, c, d, align, (flanhip_MF*) d_out.p, nullptr ) ) return rc;
 	FLANHIP_CHECK( hipDeviceSynchronize() );
 	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
-	FLANHIP_CHECK( hipMemcpy( out, d_out.p, bytes, hipMemcpyDeviceToHost ) );
+	if( int rc_t = flanhip_download( out, d_out.p, bytes ) ) return rc_t;
 	return FLANHIP_OK;
 	}
 

@@ -297,11 +297,11 @@ int flanhip_resample( const float * in, int64_t ch, int64_t n, float src_rate, f
 	FLANHIP_CHECK( hipMalloc( &d_in, sizeof( float ) * size_t( ch * n ) ) );
 	if( hipMalloc( &d_out, sizeof( float ) * size_t( std::max<int64_t>( ch * n_out, 1 ) ) ) != hipSuccess ) { (void) hipFree( d_in ); set_error( "hipMalloc failed" ); return FLANHIP_ERR_HIP; }
 	int rc = FLANHIP_OK;
-	if( hipMemcpy( d_in, in, sizeof( float ) * size_t( ch * n ), hipMemcpyHostToDevice ) != hipSuccess ) { set_error( "upload failed" ); rc = FLANHIP_ERR_HIP; }
+	rc = flanhip_upload( d_in, in, sizeof( float ) * size_t( ch * n ) );
 	if( !rc ) rc = flanhip_resample_dev( d_in, ch, n, src_rate, dst_rate, d_out, nullptr );
 	if( !rc && hipDeviceSynchronize() != hipSuccess ) { set_error( "resample kernel failed" ); rc = FLANHIP_ERR_HIP; }
 	if( !rc && cancelled( cancel ) ) rc = FLANHIP_ERR_CANCELLED;
-	if( !rc && hipMemcpy( out, d_out, sizeof( float ) * size_t( ch * n_out ), hipMemcpyDeviceToHost ) != hipSuccess ) { set_error( "download failed" ); rc = FLANHIP_ERR_HIP; }
+	if( !rc ) rc = flanhip_download( out, d_out, sizeof( float ) * size_t( ch * n_out ) );
 	(void) hipFree( d_in ); (void) hipFree( d_out );
 	return rc;
 	}

@@ -13,8 +13,7 @@ namespace flan { namespace detail {
 void * device_acquire( size_t bytes, size_t * capacity );   // nullptr on failure (flanhip_last_error() says why)
 void device_release( void * ptr, size_t capacity ) noexcept;
 void device_cache_flush() noexcept;
-// Large transfers between ordinary (pageable) host memory and the device: slabs through two page-locked blocks, the link moving one
-// slab while the worker pool copies the other between the block and the caller's memory.  Small ones: one plain copy.  Synchronous.
+// Transfers between ordinary (pageable) host memory and the device (flanhip_download / flanhip_upload).  Synchronous.
 bool download_to_host( void * dst, const void * d_src, size_t bytes );
 bool upload_from_host( void * d_dst, const void * src, size_t bytes );
 void touch_pages( void * p, size_t bytes );                   // first touch of fresh memory on all workers (the kernel zeroes pages per toucher)

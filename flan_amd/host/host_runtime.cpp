@@ -1,7 +1,8 @@
 // host_runtime.cpp -- what sampling a Function on the host (Function.h:141-171 of the reference) needs to keep up with the device:
-// a persistent worker pool (the reference gets one from its parallel STL runtime; spawning threads per call costs more than the
-// sampling) and a cache of page-locked staging blocks (a grid sampled straight into one uploads at the link's rate; a fresh
-// pageable vector pays the page faults, the zero fill and the runtime's staging copy).
+// the persistent worker pool behind the C ABI (flanhip_parallel_for; the reference gets one from its parallel STL runtime, and
+// spawning threads per call costs more than the sampling), a cache of page-locked staging blocks (a grid sampled straight into one
+// uploads at the link's rate; a fresh pageable vector pays the page faults, the zero fill and the runtime's staging copy) and a
+// cache of idle HBM blocks.
 #include <atomic>
 #include <condition_variable>
 #include <cstdlib>
@@ -22,78 +23,6 @@
 namespace flan { namespace detail {
 
 namespace {
-
-int usable_cores()
-	{
-	if( const char * e = std::getenv( "FLAN_HOST_THREADS" ) ) { const int v = std::atoi( e ); if( v > 0 ) return v; }
-	int n = int( std::thread::hardware_concurrency() );
-	cpu_set_t set;
-	if( sched_getaffinity( 0, sizeof( set ), &set ) == 0 ) n = std::min( n, CPU_COUNT( &set ) );
-	std::ifstream quota( "/sys/fs/cgroup/cpu.max" );                                // "<quota> <period>" or "max <period>"
-	std::string q; long period = 0;
-	if( quota >> q >> period && q != "max" && period > 0 ) n = std::min<long>( n, std::max<long>( 1, ( std::atol( q.c_str() ) + period - 1 ) / period ) );
-	return std::max( 1, std::min( n, 64 ) );
-	}
-
-thread_local bool tls_is_worker = false;
-
-struct Pool
-	{
-	std::vector<std::thread> threads;
-	std::mutex job_mutex;                          // one parallel region at a time; a second caller runs its region inline
-	std::mutex m;
-	std::condition_variable wake, done;
-	uint64_t generation = 0;
-	bool stop = false;
-	void ( *fn )( void *, int ) = nullptr;
-	void * ctx = nullptr;
-	int n = 0;
-	std::atomic<int> next{ 0 };
-	int active = 0;
-	std::exception_ptr error;
-
-	Pool()
-		{
-		const int workers = usable_cores() - 1;      // the calling thread works too
-		for( int w = 0; w < workers; ++w ) threads.emplace_back( [this]{ worker(); } );
-		}
-	~Pool()
-		{
-		{ std::lock_guard<std::mutex> g( m ); stop = true; }
-		wake.notify_all();
-		for( auto & t : threads ) t.join();
-		}
-	void drain()
-		{
-		for( ;; )
-			{
-			const int i = next.fetch_add( 1, std::memory_order_relaxed );
-			if( i >= n ) return;
-			try { fn( ctx, i ); }
-			catch( ... ) { std::lock_guard<std::mutex> g( m ); if( !error ) error = std::current_exception(); }
-			}
-		}
-	void worker()
-		{
-		tls_is_worker = true;
-		uint64_t seen = 0;
-		std::unique_lock<std::mutex> l( m );
-		for( ;; )
-			{
-			wake.wait( l, [&]{ return stop || generation != seen; } );
-			if( stop ) return;
-			seen = generation;
-			l.unlock();
-			drain();
-			l.lock();
-			if( --active == 0 ) done.notify_one();
-			}
-		}
-	};
-
-// the three singletons below are never destroyed: objects of the user's with static lifetime may outlive any static of ours,
-// and the device runtime may be gone by the time statics die -- the process exit reclaims threads and memory
-Pool & pool() { static Pool * p = new Pool; return *p; }
 
 // ---- page-locked staging blocks ----
 struct Staging
@@ -192,101 +121,24 @@ CopyStreams copy_streams()
 	return streams;
 	}
 
-namespace {
-constexpr size_t kSlab = size_t( 8 ) << 20;
-constexpr size_t kPiece = size_t( 256 ) << 10;
+void touch_pages( void * p, size_t bytes ) { flanhip_touch_pages( p, bytes ); }
+bool download_to_host( void * dst, const void * d_src, size_t bytes ) { return flanhip_download( dst, d_src, bytes ) == FLANHIP_OK; }
+bool upload_from_host( void * d_dst, const void * src, size_t bytes ) { return flanhip_upload( d_dst, src, bytes ) == FLANHIP_OK; }
 
-struct CopyJob { char * dst; const char * src; size_t bytes; };
-void parallel_copy( void * dst, const void * src, size_t bytes )
-	{
-	CopyJob job{ static_cast<char*>( dst ), static_cast<const char*>( src ), bytes };
-	pool_run( int( ( bytes + kPiece - 1 ) / kPiece ), []( void * ctx, int i )
-		{
-		const CopyJob & j = *static_cast<const CopyJob*>( ctx );
-		const size_t lo = size_t( i ) * kPiece, n = std::min( kPiece, j.bytes - lo );
-		std::memcpy( j.dst + lo, j.src + lo, n );
-		}, &job );
-	}
-}
+int host_workers() { return flanhip_host_workers(); }
 
-void touch_pages( void * p, size_t bytes )
-	{
-	if( bytes < ( size_t( 4 ) << 20 ) ) return;
-	struct Job { volatile char * p; size_t bytes; } job{ static_cast<volatile char*>( p ), bytes };
-	constexpr size_t kRun = size_t( 2 ) << 20;
-	pool_run( int( ( bytes + kRun - 1 ) / kRun ), []( void * ctx, int i )
-		{
-		const Job & j = *static_cast<const Job*>( ctx );
-		const size_t lo = size_t( i ) * kRun, hi = std::min( j.bytes, lo + kRun );
-		for( size_t at = lo; at < hi; at += 4096 ) j.p[at] = 0;
-		}, &job );
-	}
-
-bool download_to_host( void * dst, const void * d_src, size_t bytes )
-	{
-	if( bytes == 0 ) return true;
-	const CopyStreams streams = copy_streams();
-	if( bytes < 2 * kSlab || !streams.down )
-		return flanhip_memcpy_d2h( dst, d_src, bytes, nullptr ) == FLANHIP_OK && flanhip_stream_synchronize( nullptr ) == FLANHIP_OK;
-	if( flanhip_stream_synchronize( nullptr ) != FLANHIP_OK ) return false;           // whatever produced the data has finished
-	char * stage[2] = { static_cast<char*>( staging_acquire( kSlab ) ), static_cast<char*>( staging_acquire( kSlab ) ) };
-	const size_t slabs = ( bytes + kSlab - 1 ) / kSlab;
-	auto fetch = [&]( size_t k )
-		{
-		const size_t lo = k * kSlab;
-		return flanhip_memcpy_d2h( stage[k & 1], static_cast<const char*>( d_src ) + lo, std::min( kSlab, bytes - lo ), streams.down ) == FLANHIP_OK;
-		};
-	bool ok = fetch( 0 );
-	for( size_t k = 0; k < slabs && ok; ++k )
-		{
-		ok = flanhip_stream_synchronize( streams.down ) == FLANHIP_OK;               // slab k is in its block
-		if( ok && k + 1 < slabs ) ok = fetch( k + 1 );                                // the other block: its last reader finished an iteration ago
-		if( ok ) parallel_copy( static_cast<char*>( dst ) + k * kSlab, stage[k & 1], std::min( kSlab, bytes - k * kSlab ) );
-		}
-	flanhip_stream_synchronize( streams.down );
-	staging_release( stage[0] ); staging_release( stage[1] );
-	return ok;
-	}
-
-bool upload_from_host( void * d_dst, const void * src, size_t bytes )
-	{
-	if( bytes == 0 ) return true;
-	const CopyStreams streams = copy_streams();
-	if( bytes < 2 * kSlab || !streams.up )
-		return flanhip_memcpy_h2d( d_dst, src, bytes, nullptr ) == FLANHIP_OK && flanhip_stream_synchronize( nullptr ) == FLANHIP_OK;
-	char * stage[2] = { static_cast<char*>( staging_acquire( kSlab ) ), static_cast<char*>( staging_acquire( kSlab ) ) };
-	const size_t slabs = ( bytes + kSlab - 1 ) / kSlab;
-	bool ok = true;
-	for( size_t k = 0; k < slabs && ok; ++k )
-		{
-		const size_t lo = k * kSlab, n = std::min( kSlab, bytes - lo );
-		parallel_copy( stage[k & 1], static_cast<const char*>( src ) + lo, n );         // while slab k-1 is on the link
-		if( k >= 1 ) ok = flanhip_stream_synchronize( streams.up ) == FLANHIP_OK;      // slab k-1 has left the other block (free for k+1)
-		if( ok ) ok = flanhip_memcpy_h2d( static_cast<char*>( d_dst ) + lo, stage[k & 1], n, streams.up ) == FLANHIP_OK;
-		}
-	ok = flanhip_stream_synchronize( streams.up ) == FLANHIP_OK && ok;
-	staging_release( stage[0] ); staging_release( stage[1] );
-	return ok;
-	}
-
-int host_workers() { return int( pool().threads.size() ) + 1; }
-
+// the pool lives behind the C ABI (flan_amd/csrc/transfer.hip) and runs plain functions; what a callable throws is carried out of
+// the region here and rethrown to the caller of the PV method
 void pool_run( int n_tasks, void ( *fn )( void *, int ), void * ctx )
 	{
-	if( n_tasks <= 0 ) return;
-	Pool & p = pool();
-	std::unique_lock<std::mutex> job( p.job_mutex, std::try_to_lock );
-	if( !job || tls_is_worker || p.threads.empty() || n_tasks == 1 ) { for( int i = 0; i < n_tasks; ++i ) fn( ctx, i ); return; }
+	struct Region { void ( *fn )( void *, int ); void * ctx; std::mutex m; std::exception_ptr error; } region{ fn, ctx, {}, nullptr };
+	flanhip_parallel_for( n_tasks, []( void * r, int i )
 		{
-		std::lock_guard<std::mutex> g( p.m );
-		p.fn = fn; p.ctx = ctx; p.n = n_tasks; p.next.store( 0 ); p.active = int( p.threads.size() ); p.error = nullptr;
-		++p.generation;
-		}
-	p.wake.notify_all();
-	p.drain();
-	std::unique_lock<std::mutex> l( p.m );
-	p.done.wait( l, [&]{ return p.active == 0; } );
-	if( p.error ) { auto e = p.error; p.error = nullptr; l.unlock(); std::rethrow_exception( e ); }
+		Region & reg = *static_cast<Region*>( r );
+		try { reg.fn( reg.ctx, i ); }
+		catch( ... ) { std::lock_guard<std::mutex> g( reg.m ); if( !reg.error ) reg.error = std::current_exception(); }
+		}, &region );
+	if( region.error ) std::rethrow_exception( region.error );
 	}
 
 void * staging_acquire( size_t bytes )

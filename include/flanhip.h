@@ -63,6 +63,18 @@ int flanhip_memcpy_h2d(void * dst, const void * src, size_t bytes, void * stream
 int flanhip_memcpy_d2h(void * dst, const void * src, size_t bytes, void * stream);
 int flanhip_memset(void * dst, int value, size_t bytes, void * stream);
 int flanhip_stream_synchronize(void * stream);
+/* Transfers between ordinary (pageable) host memory and the device, synchronous: what the host entry points below
+ * (flanhip_analyze, flanhip_synthesize, ...) use for the caller's buffers.  A download first lets a pool of worker threads fault
+ * the destination's pages in together (a fresh allocation costs more to fault in on one thread than to fill over the link), then
+ * both directions are the runtime's copies, which run at the link's rate.  flanhip_touch_pages is that first step on its own
+ * (it writes a zero into every page: for memory about to be overwritten).  flanhip_parallel_for runs fn( ctx, i ), i in [0, n), on
+ * those workers and the calling thread (as many threads as the process may use; FLAN_HOST_THREADS overrides); a region started
+ * while another runs, or from inside one, runs inline.  fn must not throw. */
+int flanhip_upload(void * d_dst, const void * src, size_t bytes);
+int flanhip_download(void * dst, const void * d_src, size_t bytes);
+int flanhip_touch_pages(void * ptr, size_t bytes);
+int flanhip_host_workers(void);
+int flanhip_parallel_for(int n_tasks, void (*fn)(void *, int), void * ctx);
 /* a stream of the caller's own (e.g. one per copy direction, so that a download and an upload overlap); every entry point
  * that takes `void * stream` accepts it, NULL stays the default stream */
 int flanhip_stream_create(void ** stream);
