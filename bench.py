@@ -265,7 +265,7 @@ def main():
         del pv_host, out_host
 
     cpu = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:        # the CPU leg is reported at N=1 only; the other ranks would idle behind it
         cores = os.cpu_count() or 1
         v1, frames1, dt1 = cpu_baseline(ch, args.seconds, 1)
         cpu = {"value": round(v1, 1), "unit": "frames/s", "cores": 1, "kind": "port",
