@@ -109,8 +109,11 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
-            os.environ["NCCL_DEBUG"] = "WARN"      # keep RCCL's version banner off stdout: rank 0 prints exactly one JSON line
+        # rank 0 prints exactly one JSON line on stdout: RCCL's own messages (its version banner, warnings such as "Could not read
+        # node #") go to stderr
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "WARN"
         dist.init_process_group("nccl", device_id=dev)
 
     ch, n = args.channels, int(args.seconds * SR)
