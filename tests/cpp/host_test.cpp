@@ -9,6 +9,7 @@
 #include <stdexcept>
 #include <iostream>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -345,6 +346,25 @@ static void device_checks()
 			CHECK( p2.cut_frames( 0, 2 ).stretch_spline( 2.0f ).is_null() );            // two frames: the spline needs three
 			}
 		(void) B;
+		}
+	// ---- the methods are re-entrant: four host threads run whole chains at once and get what one thread gets
+		{
+		auto chain = []( uint32_t seed )
+			{
+			Audio x = noise( 2, 40000 + 1000 * int( seed ), seed );
+			PV p = x.convert_to_PV( 2048, 512, 2048 );
+			PV q = p.stretch( []( TF tf ){ return 1.0f + tf.t; } ).shape( []( MF mf ){ return MF{ mf.m * 0.5f, mf.f + 10.0f }; } );
+			PV r = q.retain_n_loudest_partials( 40 ).add_octaves( []( std::pair<Second, Harmonic> ){ return 0.5f; } );
+			return r.convert_to_audio().get_buffer();
+			};
+		std::vector<std::vector<float>> alone( 4 ), together( 4 );
+		for( int t = 0; t < 4; ++t ) alone[size_t( t )] = chain( 100 + uint32_t( t ) );
+		std::vector<std::thread> threads;
+		for( int t = 0; t < 4; ++t ) threads.emplace_back( [&, t]{ for( int rep = 0; rep < 3; ++rep ) together[size_t( t )] = chain( 100 + uint32_t( t ) ); } );
+		for( auto & th : threads ) th.join();
+		for( int t = 0; t < 4; ++t )
+			CHECK( !alone[size_t( t )].empty() && alone[size_t( t )].size() == together[size_t( t )].size()
+				&& std::memcmp( alone[size_t( t )].data(), together[size_t( t )].data(), sizeof( float ) * alone[size_t( t )].size() ) == 0 );
 		}
 	// ---- large host <-> device transfers go in slabs through page-locked blocks: what arrives is what was sent
 		{
