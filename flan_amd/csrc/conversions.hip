@@ -15,12 +15,14 @@ static constexpr size_t kMaxLds = 160 * 1024;   // gfx950: 160 KiB LDS per CU, o
 static size_t analyze_lds_bytes( int C, int W, int waves )
 	{
 	const int wpad = ( W + 3 ) & ~3;
+	if( C >= 4096 ) return size_t( wpad ) * 4 + size_t( waves ) * ( size_t( padded_len( C ) ) * 8 + size_t( C + 4 ) * 4 );   // k_analyze BIG: no twiddles, previous phases
 	return size_t( C ) * 8 + size_t( wpad ) * 4 + size_t( waves ) * padded_len( C ) * 8;
 	}
 
 static size_t synth_lds_bytes( int C, int W, int waves )
 	{
 	const int wpad = ( W + 3 ) & ~3;
+	if( C >= 4096 ) return size_t( wpad ) * 4 + size_t( waves ) * ( size_t( padded_len( C + 1 ) ) * 8 + size_t( wpad ) * 4 + size_t( C + 2 ) * 8 );   // k_synthesize BIG
 	return size_t( C ) * 8 + size_t( wpad ) * 4 + size_t( waves ) * ( size_t( padded_len( C + 1 ) ) * 8 + size_t( wpad ) * 4 );
 	}
 

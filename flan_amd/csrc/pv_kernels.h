@@ -65,18 +65,26 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze( AnalyzeParams p )
 	{
 	constexpr int C = 1 << LOG2C;                   // complex points = dft/2
 	constexpr int E = ( C + 63 ) / 64;              // bins per lane (plus Nyquist on lane 0)
+	// dft 8192 (64 bins per lane): what the smaller sizes keep in registers across frames -- the previous phases -- lives in LDS,
+	// the per-bin loops are rolled (4 at a time) and the twiddles stay in global memory (L1): with everything resident and unrolled
+	// the kernel spilled 2.4 KB per lane to scratch and ran at a hundredth of the dft 2048 rate.  conversions.hip: analyze_lds_bytes
+	constexpr bool BIG = LOG2C >= 12;
+	constexpr int UNR = BIG ? 4 : E;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	cf * s_tw = reinterpret_cast<cf*>( smem );                      // [C]
-	float * s_win = reinterpret_cast<float*>( s_tw + C );                    // [W rounded up to even]
+	cf * s_tw = reinterpret_cast<cf*>( smem );                      // [C] (none when BIG)
+	float * s_win = reinterpret_cast<float*>( s_tw + ( BIG ? 0 : C ) );      // [W rounded up to even]
 	const int wpad = ( p.window_size + 3 ) & ~3;
 	cf * s_buf_all = reinterpret_cast<cf*>( s_win + wpad );          // WAVES x padded_len(C)
+	float * s_prev_all = reinterpret_cast<float*>( s_buf_all + WAVES * padded_len( C ) );   // WAVES x ( C + 4 ), BIG only
 
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	for( int i = tid; i < C; i += 64 * WAVES ) s_tw[i] = p.tw[i];
+	if constexpr( !BIG ) for( int i = tid; i < C; i += 64 * WAVES ) s_tw[i] = p.tw[i];
 	for( int i = tid; i < p.window_size; i += 64 * WAVES ) s_win[i] = p.window[i];
 	__syncthreads();
+	const cf * tw = BIG ? p.tw : s_tw;
 
 	cf * buf = s_buf_all + wave * padded_len( C );
+	float * s_prev = s_prev_all + wave * ( C + 4 );
 	const int64_t chain = int64_t( blockIdx.x ) * WAVES + wave;
 	if( chain >= int64_t( p.chains_per_channel ) * p.num_channels ) return;
 	const int channel = int( chain / p.chains_per_channel );
@@ -93,14 +101,15 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze( AnalyzeParams p )
 	// them resident the dft 8192 kernel spilled 4 KB per lane to scratch.
 	constexpr bool LEAN = LOG2C >= 11;
 	constexpr int EC = LEAN ? 0 : E;                                          // length of the resident constant arrays
-	float binf_r[EC + 1], expect_r[EC + 1], prev[E + 1];
+	float binf_r[EC + 1], expect_r[EC + 1], prev[( BIG ? 0 : E ) + 1];
 	cf w2_r[EC + 1];
 	auto bin_of = [&]( int i ) { return ( i < E ) ? lane + 64 * i : C; };
 	auto binf_of = [&]( int i ) { return LEAN ? float( bin_of( i ) ) * p.sample_rate / float( dft ) : binf_r[LEAN ? 0 : i]; };
 	auto expect_of = [&]( int i ) { return LEAN ? binf_of( i ) / p.analysis_rate * FLANHIP_PI2_F : expect_r[LEAN ? 0 : i]; };
 	auto w2_of = [&]( int i ) { return LEAN ? p.tw2[min( bin_of( i ), C )] : w2_r[LEAN ? 0 : i]; };
+	if constexpr( BIG ) { for( int k = lane; k <= C; k += 64 ) s_prev[k] = 0.0f; }   // AudioPV.cpp:44
 	#pragma unroll
-	for( int i = 0; i <= E; ++i )
+	for( int i = 0; i <= ( BIG ? 0 : E ); ++i )
 		{
 		prev[i] = 0.0f;                                                       // AudioPV.cpp:44
 		if constexpr( !LEAN )
@@ -122,7 +131,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze( AnalyzeParams p )
 		const bool emit = t >= t0;
 		// window the frame into the FFT buffer as C complex points z[i] = ( x[2i], x[2i+1] )  (AudioPV.cpp:52-65)
 		const int64_t start = int64_t( hop ) * t - W / 2;
-		#pragma unroll
+		#pragma unroll UNR
 		for( int q = 0; q < E; ++q )
 			{
 			const int i = lane + 64 * q;
@@ -136,12 +145,12 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze( AnalyzeParams p )
 				}
 			}
 		wave_sync();
-		fft_forward<LOG2C>( buf, s_tw, lane );
+		fft_forward<LOG2C>( buf, tw, lane );
 
 		// split the half-size transform into the real transform's bins and phase-vocode each bin (AudioPV.cpp:69-73)
 		MF * row = p.out + ( int64_t( channel ) * p.F + t ) * ( C + 1 );
 		const cf z0 = buf[PAD( 0 )];
-		#pragma unroll
+		#pragma unroll UNR
 		for( int q = 0; q < E; ++q )
 			{
 			const int k = lane + 64 * q;
@@ -156,7 +165,14 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze( AnalyzeParams p )
 				float re = ax + 0.5f * __builtin_fmaf( c, dy, s * dx );
 				float im = ay - 0.5f * __builtin_fmaf( c, dx, -( s * dy ) );
 				if( k == 0 ) { re = z0.x + z0.y; im = 0.0f; }
-				const MF mf = phase_vocode_bin( re, im, prev[q], binf_of( q ), expect_of( q ), p.analysis_rate, use_wrapping );
+				MF mf;
+				if constexpr( BIG )
+					{
+					float pr = s_prev[k];
+					mf = phase_vocode_bin( re, im, pr, binf_of( q ), expect_of( q ), p.analysis_rate, use_wrapping );
+					s_prev[k] = pr;
+					}
+				else mf = phase_vocode_bin( re, im, prev[BIG ? 0 : q], binf_of( q ), expect_of( q ), p.analysis_rate, use_wrapping );
 				if( emit )
 					{
 					row[k] = mf;
@@ -167,7 +183,14 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze( AnalyzeParams p )
 			}
 		if( lane == 0 )
 			{
-			const MF mf = phase_vocode_bin( z0.x - z0.y, 0.0f, prev[E], binf_of( E ), expect_of( E ), p.analysis_rate, use_wrapping );
+			MF mf;
+			if constexpr( BIG )
+				{
+				float pr = s_prev[C];
+				mf = phase_vocode_bin( z0.x - z0.y, 0.0f, pr, binf_of( E ), expect_of( E ), p.analysis_rate, use_wrapping );
+				s_prev[C] = pr;
+				}
+			else mf = phase_vocode_bin( z0.x - z0.y, 0.0f, prev[BIG ? 0 : E], binf_of( E ), expect_of( E ), p.analysis_rate, use_wrapping );
 			if( emit )
 				{
 				row[C] = mf;
@@ -265,16 +288,22 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize( SynthParams p )
 	{
 	constexpr int C = 1 << LOG2C;
 	constexpr int E = ( C + 63 ) / 64;
+	// dft 8192: the running phases (fp64, 65 per lane) live in LDS, the per-bin loop is rolled, twiddles come from global memory (L1):
+	// see k_analyze.  conversions.hip: synth_lds_bytes
+	constexpr bool BIG = LOG2C >= 12;
+	constexpr int UNR = BIG ? 2 : E + 1;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	cf * s_tw = reinterpret_cast<cf*>( smem );                       // [C]
+	cf * s_tw = reinterpret_cast<cf*>( smem );                       // [C] (none when BIG)
 	const int W = p.window_size, hop = p.hop;
 	const int wpad = ( W + 3 ) & ~3;
-	float * s_win = reinterpret_cast<float*>( s_tw + C );                     // [wpad] scaled window
+	float * s_win = reinterpret_cast<float*>( s_tw + ( BIG ? 0 : C ) );       // [wpad] scaled window
 	cf * s_buf_all = reinterpret_cast<cf*>( s_win + wpad );           // WAVES x padded_len(C+1)
 	float * s_ring_all = reinterpret_cast<float*>( s_buf_all + WAVES * padded_len( C + 1 ) ); // WAVES x wpad
+	double * s_ph_all = reinterpret_cast<double*>( s_ring_all + WAVES * wpad );   // WAVES x ( C + 2 ), BIG only (wpad is a multiple of 4: 16-byte aligned)
 
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	for( int i = tid; i < C; i += 64 * WAVES ) s_tw[i] = p.tw[i];
+	if constexpr( !BIG ) for( int i = tid; i < C; i += 64 * WAVES ) s_tw[i] = p.tw[i];
+	const cf * tw = BIG ? p.tw : s_tw;
 	for( int i = tid; i < W; i += 64 * WAVES ) s_win[i] = p.window[i] * p.window_scale;   // AudioPV.cpp:102
 	float * ring = s_ring_all + wave * wpad;
 	for( int i = lane; i < W; i += 64 ) ring[i] = 0.0f;
@@ -294,14 +323,19 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize( SynthParams p )
 	const int64_t own_start = chain_in_channel == 0 ? INT64_MIN : chain_start + p.head_len; // before this: shared with the previous chain
 
 	// running phase (phase_buffer, AudioPV.cpp:105) on entry to the chain
-	double ph[E + 1];
-	cf w2[E];
-	#pragma unroll
-	for( int i = 0; i <= E; ++i )
+	double ph[( BIG ? 0 : E ) + 1];
+	cf w2[BIG ? 1 : E];
+	double * s_ph = s_ph_all + wave * ( C + 2 );
+	if constexpr( BIG ) { for( int k = lane; k <= C; k += 64 ) s_ph[k] = p.carry[chain * ( C + 1 ) + k]; }
+	else
 		{
-		const int k = ( i < E ) ? lane + 64 * i : C;
-		ph[i] = ( ( C >= 64 || i == E || k < C ) ) ? p.carry[chain * ( C + 1 ) + min( k, C )] : 0.0;
-		if( i < E ) w2[i] = p.tw2[min( k, C )];
+		#pragma unroll
+		for( int i = 0; i <= E; ++i )
+			{
+			const int k = ( i < E ) ? lane + 64 * i : C;
+			ph[i] = ( ( C >= 64 || i == E || k < C ) ) ? p.carry[chain * ( C + 1 ) + min( k, C )] : 0.0;
+			if( i < E ) w2[i] = p.tw2[min( k, C )];
+			}
 		}
 
 	int ring_base = 0;                                                         // ring[ring_base] <-> absolute sample `pos`
@@ -310,7 +344,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize( SynthParams p )
 		{
 		// inverse phase vocoder per bin (AudioPV.cpp:117-120, phase_vocoder.cpp:55-61) -> spectrum X[0..C] in LDS
 		const MF * row = p.pv + ( int64_t( channel ) * p.F + t ) * ( C + 1 );
-		#pragma unroll
+		#pragma unroll UNR
 		for( int q = 0; q <= E; ++q )
 			{
 			const int k = ( q < E ) ? lane + 64 * q : C;
@@ -318,43 +352,73 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize( SynthParams p )
 			if( active )
 				{
 				const MF mf = row[k];
-				ph[q] = fold_phase( ph[q] + double( phase_term( mf.f, p.analysis_rate ) ) );
+				double phase;
+				if constexpr( BIG ) { phase = fold_phase( s_ph[k] + double( phase_term( mf.f, p.analysis_rate ) ) ); s_ph[k] = phase; }
+				else { phase = fold_phase( ph[BIG ? 0 : q] + double( phase_term( mf.f, p.analysis_rate ) ) ); ph[BIG ? 0 : q] = phase; }
 				float sn, cs;
-				sincosf( float( ph[q] ), &sn, &cs );
+				sincosf( float( phase ), &sn, &cs );
 				buf[PAD( k )] = mk( mf.m * cs, mf.m * sn );           // std::polar
 				}
 			}
 		wave_sync();
 		// merge X[0..C] into the half-size spectrum Z[k] = A[k] + i B[k]; stored conjugated so that the forward FFT
 		// evaluates the inverse transform ( ifft(Z) = conj( fft( conj Z ) ) ).  c2r ignores Im X[0], Im X[C].
-		cf zc[E];
-		#pragma unroll
-		for( int q = 0; q < E; ++q )
+		auto merge = [&]( int k, cf xk, cf xm ) -> cf
 			{
-			const int k = lane + 64 * q;
-			if( C >= 64 || k < C )
+			if( k == 0 ) { xk.y = 0.0f; xm.y = 0.0f; }
+			// A = X[k] + conj X[C-k];  B = ( X[k] - conj X[C-k] ) * exp(+2 pi i k / N)
+			const float ax = xk.x + xm.x, ay = xk.y - xm.y;
+			const float dx = xk.x - xm.x, dy = xk.y + xm.y;
+			const cf w2q = p.tw2[k];
+			const float c = w2q.x, s = -w2q.y;                                 // conj of exp(-2 pi i k/N)
+			const float bx = __builtin_fmaf( c, dx, -( s * dy ) ), by = __builtin_fmaf( c, dy, s * dx );
+			return mk( ax - by, -( ay + bx ) );                                // Z = A + iB = ( ax - by, ay + bx ); stored conjugated
+			};
+		if constexpr( BIG )
+			{
+			// in place, a lane owning bin k and its mirror C - k: both are read before either is written, no staging registers
+			#pragma unroll 2
+			for( int k = lane; k <= C / 2; k += 64 )
 				{
-				cf xk = buf[PAD( k )];
-				cf xm = buf[PAD( C - k )];
-				if( k == 0 ) { xk.y = 0.0f; xm.y = 0.0f; }
-				// A = X[k] + conj X[C-k];  B = ( X[k] - conj X[C-k] ) * exp(+2 pi i k / N)
-				const float ax = xk.x + xm.x, ay = xk.y - xm.y;
-				const float dx = xk.x - xm.x, dy = xk.y + xm.y;
-				const float c = w2[q].x, s = -w2[q].y;                         // conj of exp(-2 pi i k/N)
-				const float bx = __builtin_fmaf( c, dx, -( s * dy ) ), by = __builtin_fmaf( c, dy, s * dx );
-				// Z = A + iB = ( ax - by, ay + bx ); store conj
-				zc[q] = mk( ax - by, -( ay + bx ) );
+				const cf xk = buf[PAD( k )], xm = buf[PAD( C - k )];
+				const cf zk = merge( k, xk, xm );
+				if( k != 0 && k != C / 2 ) buf[PAD( C - k )] = merge( C - k, xm, xk );
+				buf[PAD( k )] = zk;
 				}
+			wave_sync();
 			}
-		wave_sync();
-		#pragma unroll
-		for( int q = 0; q < E; ++q )
+		else
 			{
-			const int k = lane + 64 * q;
-			if( C >= 64 || k < C ) buf[PAD( k )] = zc[q];
+			cf zc[E];
+			#pragma unroll
+			for( int q = 0; q < E; ++q )
+				{
+				const int k = lane + 64 * q;
+				if( C >= 64 || k < C )
+					{
+					cf xk = buf[PAD( k )];
+					cf xm = buf[PAD( C - k )];
+					if( k == 0 ) { xk.y = 0.0f; xm.y = 0.0f; }
+					// A = X[k] + conj X[C-k];  B = ( X[k] - conj X[C-k] ) * exp(+2 pi i k / N)
+					const float ax = xk.x + xm.x, ay = xk.y - xm.y;
+					const float dx = xk.x - xm.x, dy = xk.y + xm.y;
+					const cf w2q = BIG ? p.tw2[k] : w2[BIG ? 0 : q];
+					const float c = w2q.x, s = -w2q.y;                             // conj of exp(-2 pi i k/N)
+					const float bx = __builtin_fmaf( c, dx, -( s * dy ) ), by = __builtin_fmaf( c, dy, s * dx );
+					// Z = A + iB = ( ax - by, ay + bx ); store conj
+					zc[q] = mk( ax - by, -( ay + bx ) );
+					}
+				}
+			wave_sync();
+			#pragma unroll
+			for( int q = 0; q < E; ++q )
+				{
+				const int k = lane + 64 * q;
+				if( C >= 64 || k < C ) buf[PAD( k )] = zc[q];
+				}
+			wave_sync();
 			}
-		wave_sync();
-		fft_forward<LOG2C>( buf, s_tw, lane );
+		fft_forward<LOG2C>( buf, tw, lane );
 		// G = fft( conj Z ):  x[2n] = G[n].x, x[2n+1] = -G[n].y   (AudioPV.cpp:122; samples >= W are discarded)
 		// window and accumulate into the ring (AudioPV.cpp:133-134)
 		for( int n = lane; 2 * n < W; n += 64 )
