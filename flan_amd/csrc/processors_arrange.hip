@@ -272,8 +272,9 @@ __global__ __launch_bounds__( 256 ) void k_modify_offer( const MFd * in, int64_t
 	// :93-96: the bounding box, clipped to the output
 	const int minx = to_int_sat( fmaxf( floorf( fminf( fminf( q.px[0], q.px[1] ), fminf( q.px[2], q.px[3] ) ) ), 0.0f ) );
 	const int miny = to_int_sat( fmaxf( floorf( fminf( fminf( q.py[0], q.py[1] ), fminf( q.py[2], q.py[3] ) ) ), 0.0f ) );
-	const int maxx = to_int_sat( fminf( ceilf( fmaxf( fmaxf( q.px[0], q.px[1] ), fmaxf( q.px[2], q.px[3] ) ) ), float( Fo - 1 ) ) );
-	const int maxy = to_int_sat( fminf( ceilf( fmaxf( fmaxf( q.py[0], q.py[1] ), fmaxf( q.py[2], q.py[3] ) ) ), float( bins - 1 ) ) );
+	// ( the min in integers as well: float( Fo - 1 ) may round up once Fo passes 2^24 )
+	const int maxx = min( to_int_sat( fminf( ceilf( fmaxf( fmaxf( q.px[0], q.px[1] ), fmaxf( q.px[2], q.px[3] ) ) ), float( Fo - 1 ) ) ), int( Fo - 1 ) );
+	const int maxy = min( to_int_sat( fminf( ceilf( fmaxf( fmaxf( q.py[0], q.py[1] ), fmaxf( q.py[2], q.py[3] ) ) ), float( bins - 1 ) ) ), bins - 1 );
 	const unsigned seq4 = unsigned( frame * bins + bin ) << 2;                        // the loudest corner rides in the two low bits
 	unsigned long long * keys = out_keys + channel * Fo * bins;
 	for( int x = minx; x <= maxx; ++x )                                               // :99-101
