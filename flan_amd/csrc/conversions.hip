@@ -12,31 +12,32 @@ namespace flanhip {
 static int g_synth_stage_mask = 0xF;             // flanhip_debug_synth_stages(): 1 sums, 2 scan, 4 main, 8 fix-up
 static constexpr size_t kMaxLds = 160 * 1024;   // gfx950: 160 KiB LDS per CU, one workgroup may take all of it
 
-static size_t analyze_lds_bytes( int C, int W, int waves )
+// chains: the chains a block walks (one per wavefront; or ONE, walked by a team of several wavefronts, see k_analyze)
+static size_t analyze_lds_bytes( int C, int W, int chains, bool state_in_lds )
 	{
 	const int wpad = ( W + 3 ) & ~3;
-	if( C >= 4096 ) return size_t( wpad ) * 4 + size_t( waves ) * ( size_t( padded_len( C ) ) * 8 + size_t( C + 4 ) * 4 );   // k_analyze BIG: no twiddles, previous phases
-	return size_t( C ) * 8 + size_t( wpad ) * 4 + size_t( waves ) * padded_len( C ) * 8;
+	if( state_in_lds ) return size_t( wpad ) * 4 + size_t( chains ) * ( size_t( padded_len( C ) ) * 8 + size_t( C + 4 ) * 4 );   // k_analyze BIG: no twiddles, previous phases
+	return size_t( C ) * 8 + size_t( wpad ) * 4 + size_t( chains ) * padded_len( C ) * 8;
 	}
 
-static size_t synth_lds_bytes( int C, int W, int waves )
+static size_t synth_lds_bytes( int C, int W, int chains, bool state_in_lds )
 	{
 	const int wpad = ( W + 3 ) & ~3;
-	if( C >= 4096 ) return size_t( wpad ) * 4 + size_t( waves ) * ( size_t( padded_len( C + 1 ) ) * 8 + size_t( wpad ) * 4 + size_t( C + 2 ) * 8 );   // k_synthesize BIG
-	return size_t( C ) * 8 + size_t( wpad ) * 4 + size_t( waves ) * ( size_t( padded_len( C + 1 ) ) * 8 + size_t( wpad ) * 4 );
+	if( state_in_lds ) return size_t( wpad ) * 4 + size_t( chains ) * ( size_t( padded_len( C + 1 ) ) * 8 + size_t( wpad ) * 4 + size_t( C + 2 ) * 8 );   // k_synthesize BIG
+	return size_t( C ) * 8 + size_t( wpad ) * 4 + size_t( chains ) * ( size_t( padded_len( C + 1 ) ) * 8 + size_t( wpad ) * 4 );
 	}
 
-template<int LOG2C, int WAVES>
+template<int LOG2C, int WAVES, int T = 1>
 static int run_analyze( const AnalyzeParams & p, hipStream_t s )
 	{
-	const size_t lds = analyze_lds_bytes( 1 << LOG2C, p.window_size, WAVES );
+	const size_t lds = analyze_lds_bytes( 1 << LOG2C, p.window_size, WAVES, LOG2C >= 12 && T == 1 );
 	FLANHIP_REQUIRE( lds <= kMaxLds, FLANHIP_ERR_UNSUPPORTED, "window/dft too large for LDS" );
-	auto kern = k_analyze<LOG2C, WAVES>;
+	auto kern = k_analyze<LOG2C, WAVES, T>;
 	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;
 	const int64_t blocks = ( chains + WAVES - 1 ) / WAVES;
 	FLANHIP_REQUIRE( blocks < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
-	hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( 64 * WAVES ), lds, s, p );
+	hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( 64 * WAVES * T ), lds, s, p );
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;
 	}
@@ -47,6 +48,9 @@ static int run_analyze( const AnalyzeParams & p, hipStream_t s )
 // the 256 AGPRs as spill space instead of scratch memory (6-wave blocks at 256 VGPRs spilled 400-850 B per lane to scratch and
 // ran synthesis 3.3x slower); 1024 resident chains.
 static constexpr int kAnaWaves10 = 8, kSynWaves10 = 8, kWaves11 = 4;
+static constexpr int kTeamWaves12 = 8;           // generic kernels at dft 8192: one chain per block of 8 wavefronts (8 bins per thread), one block per CU
+// chains the chip holds at once for the generic kernels (one chain per team from dft 1024 up, LDS decides how many teams a CU takes)
+static int generic_target_chains( int dft ) { return dft >= 8192 ? 256 : dft == 4096 ? 512 : dft == 2048 ? 1024 : 4096; }
 static int fast_target_chains( int dft, bool synth )
 	{
 	if( const char * env = std::getenv( "FLANHIP_TARGET_CHAINS" ) ) { const int v = std::atoi( env ); if( v > 0 ) return v; }
@@ -130,7 +134,7 @@ int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int 
 	p.n = n; p.F = n / hop + 1;                                   // AudioPV.cpp:17
 	p.num_channels = int( ch ); p.window_size = W; p.hop = hop;
 	const bool fast = ( dft == 2048 || dft == 4096 ) && n >= 2 && n < ( int64_t( 1 ) << 31 ) - 8192 && !force_generic();
-	p.L = choose_chain_length( ch, p.F, 1, fast ? fast_target_chains( dft, false ) : 4096 );
+	p.L = choose_chain_length( ch, p.F, 1, fast ? fast_target_chains( dft, false ) : generic_target_chains( dft ) );
 	p.chains_per_channel = int( ( p.F + p.L - 1 ) / p.L );
 	p.sample_rate = sr;
 	p.analysis_rate = sr / hop;                                   // AudioPV.cpp:26 (float / int)
@@ -186,10 +190,10 @@ int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int 
 		case 6:  rc = run_analyze<6, 4>( p, s ); break;
 		case 7:  rc = run_analyze<7, 4>( p, s ); break;
 		case 8:  rc = run_analyze<8, 4>( p, s ); break;
-		case 9:  rc = run_analyze<9, 4>( p, s ); break;
-		case 10: rc = run_analyze<10, 4>( p, s ); break;
-		case 11: rc = run_analyze<11, 4>( p, s ); break;
-		case 12: rc = run_analyze<12, 2>( p, s ); break;
+		case 9:  rc = run_analyze<9, 1, 2>( p, s ); break;               // teams of 2 / 4 / 4 / 8 wavefronts per chain: measured best
+		case 10: rc = run_analyze<10, 1, 4>( p, s ); break;
+		case 11: rc = run_analyze<11, 1, 4>( p, s ); break;
+		case 12: rc = run_analyze<12, 1, kTeamWaves12>( p, s ); break;   // a block of 8 wavefronts per chain
 		default: set_error( "unsupported dft_size %d", dft ); break;
 		}
 	if( rc ) return rc;
@@ -207,7 +211,7 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	o->head_len = std::max( W - o->hop, 0 );
 	const int overlap = ( W + o->hop - 1 ) / o->hop;              // frames covering one output sample
 	const int kind = synth_fast_kind( o->dft, W, o->hop );
-	const int slots = kind == 0 ? 4096 : ( kind == 2 && o->dft == 4096 ) ? 256 * kRingWaves11 : fast_target_chains( o->dft, true );
+	const int slots = kind == 0 ? generic_target_chains( o->dft ) : ( kind == 2 && o->dft == 4096 ) ? 256 * kRingWaves11 : fast_target_chains( o->dft, true );
 	o->L = choose_chain_length( ch, F, std::max( overlap - 1, 1 ), slots );
 	o->chains_per_channel = int( ( F + o->L - 1 ) / o->L );
 	const int64_t chains = int64_t( o->chains_per_channel ) * ch;
@@ -217,25 +221,18 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	return FLANHIP_OK;
 	}
 
-template<int LOG2C, int WAVES>
+template<int LOG2C, int WAVES, int T = 1>
 static int run_synth( const SynthParams & p, hipStream_t s )
 	{
-	const size_t lds = synth_lds_bytes( 1 << LOG2C, p.window_size, WAVES );
+	const size_t lds = synth_lds_bytes( 1 << LOG2C, p.window_size, WAVES, LOG2C >= 12 && T == 1 );
 	FLANHIP_REQUIRE( lds <= kMaxLds, FLANHIP_ERR_UNSUPPORTED, "window/dft too large for LDS" );
-	auto kern = k_synthesize<LOG2C, WAVES>;
+	auto kern = k_synthesize<LOG2C, WAVES, T>;
 	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;
 	const int64_t blocks = ( chains + WAVES - 1 ) / WAVES;
-	hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( 64 * WAVES ), lds, s, p );
+	hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( 64 * WAVES * T ), lds, s, p );
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;
-	}
-
-template<int LOG2C, int W_BIG, int W_SMALL>
-static int run_synth_pick( const SynthParams & p, hipStream_t s )
-	{
-	if( synth_lds_bytes( 1 << LOG2C, p.window_size, W_BIG ) <= kMaxLds ) return run_synth<LOG2C, W_BIG>( p, s );
-	return run_synth<LOG2C, W_SMALL>( p, s );
 	}
 
 int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float ar, int W, float * d_out,
@@ -297,10 +294,10 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 		case 6:  rc = run_synth<6, 8>( p, s ); break;
 		case 7:  rc = run_synth<7, 8>( p, s ); break;
 		case 8:  rc = run_synth<8, 8>( p, s ); break;
-		case 9:  rc = run_synth<9, 8>( p, s ); break;
-		case 10: rc = run_synth<10, 8>( p, s ); break;
-		case 11: rc = run_synth_pick<11, 4, 2>( p, s ); break;
-		case 12: rc = run_synth<12, 1>( p, s ); break;
+		case 9:  rc = run_synth<9, 1, 2>( p, s ); break;
+		case 10: rc = run_synth<10, 1, 4>( p, s ); break;
+		case 11: rc = run_synth<11, 1, 4>( p, s ); break;
+		case 12: rc = run_synth<12, 1, kTeamWaves12>( p, s ); break;
 		default: set_error( "unsupported dft size %d", lay.dft );
 		}
 	if( rc ) return rc;

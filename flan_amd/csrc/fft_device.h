@@ -1,4 +1,4 @@
-// fft_device.h -- wave-private, in-LDS Stockham FFT for gfx950 (one 64-lane wavefront per transform).
+// fft_device.h -- in-LDS Stockham FFT for gfx950: one 64-lane wavefront per transform, or a team of several (TEAM template parameter).
 //
 // Replaces the FFTW3f plans of the reference (FFTHelper.cpp:16-48: fftwf_plan_dft_r2c_1d / c2r_1d).
 // A real transform of size N is done as a complex transform of C = N/2 points plus a split/merge step.
@@ -21,6 +21,12 @@ __device__ __forceinline__ void wave_sync()
 	{
 	__builtin_amdgcn_fence( __ATOMIC_SEQ_CST, "wavefront" );
 	__builtin_amdgcn_wave_barrier();
+	}
+
+// a transform shared by TEAM threads: one wavefront (a fence is enough, see above) or a whole block of 64 T threads (a barrier)
+template<int TEAM> __device__ __forceinline__ void team_sync()
+	{
+	if constexpr( TEAM == 64 ) wave_sync(); else __syncthreads();
 	}
 
 __device__ __forceinline__ cf mk( float a, float b ) { return cf{ a, b }; }
@@ -116,28 +122,28 @@ template<> __device__ __forceinline__ void dft_reg<16>( cf * v )
 
 // One in-place Stockham pass of radix R over C points, sub-transform length NS on entry.
 // tw[i] = exp(-2*pi*i*i/C), i < C (LDS, shared by the block's waves).
-template<int C, int R, int NS>
+template<int C, int R, int NS, int TEAM = 64>
 __device__ __forceinline__ void fft_pass( cf * buf, const cf * tw, int lane )
 	{
 	constexpr int NB = C / R;                       // butterflies in this pass
-	constexpr int PER = ( NB + 63 ) / 64;           // per lane
+	constexpr int PER = ( NB + TEAM - 1 ) / TEAM;   // per thread of the team
 	cf v[PER][R];
 	#pragma unroll
 	for( int b = 0; b < PER; ++b )
 		{
-		const int j = lane + 64 * b;
-		if( NB >= 64 || j < NB )
+		const int j = lane + TEAM * b;
+		if( NB >= TEAM || j < NB )
 			{
 			#pragma unroll
 			for( int r = 0; r < R; ++r ) v[b][r] = buf[PAD( j + r * NB )];
 			}
 		}
-	wave_sync();
+	team_sync<TEAM>();
 	#pragma unroll
 	for( int b = 0; b < PER; ++b )
 		{
-		const int j = lane + 64 * b;
-		if( NB >= 64 || j < NB )
+		const int j = lane + TEAM * b;
+		if( NB >= TEAM || j < NB )
 			{
 			const int k = j & ( NS - 1 );
 			if constexpr( NS > 1 )
@@ -152,22 +158,22 @@ __device__ __forceinline__ void fft_pass( cf * buf, const cf * tw, int lane )
 			for( int r = 0; r < R; ++r ) buf[PAD( base + r * NS )] = v[b][r];
 			}
 		}
-	wave_sync();
+	team_sync<TEAM>();
 	}
 
 // Forward complex FFT of C = 2^LOG2C points, in place in `buf` (padded layout), natural order in and out.
-template<int LOG2C> __device__ __forceinline__ void fft_forward( cf * buf, const cf * tw, int lane )
+template<int LOG2C, int TEAM = 64> __device__ __forceinline__ void fft_forward( cf * buf, const cf * tw, int lane )
 	{
 	constexpr int C = 1 << LOG2C;
-	if constexpr( LOG2C == 4 )       { fft_pass<C, 16, 1>( buf, tw, lane ); }
-	else if constexpr( LOG2C == 5 )  { fft_pass<C, 8, 1>( buf, tw, lane );  fft_pass<C, 4, 8>( buf, tw, lane ); }
-	else if constexpr( LOG2C == 6 )  { fft_pass<C, 8, 1>( buf, tw, lane );  fft_pass<C, 8, 8>( buf, tw, lane ); }
-	else if constexpr( LOG2C == 7 )  { fft_pass<C, 16, 1>( buf, tw, lane ); fft_pass<C, 8, 16>( buf, tw, lane ); }
-	else if constexpr( LOG2C == 8 )  { fft_pass<C, 16, 1>( buf, tw, lane ); fft_pass<C, 16, 16>( buf, tw, lane ); }
-	else if constexpr( LOG2C == 9 )  { fft_pass<C, 8, 1>( buf, tw, lane );  fft_pass<C, 8, 8>( buf, tw, lane );   fft_pass<C, 8, 64>( buf, tw, lane ); }
-	else if constexpr( LOG2C == 10 ) { fft_pass<C, 16, 1>( buf, tw, lane ); fft_pass<C, 16, 16>( buf, tw, lane ); fft_pass<C, 4, 256>( buf, tw, lane ); }
-	else if constexpr( LOG2C == 11 ) { fft_pass<C, 16, 1>( buf, tw, lane ); fft_pass<C, 16, 16>( buf, tw, lane ); fft_pass<C, 8, 256>( buf, tw, lane ); }
-	else                             { fft_pass<C, 16, 1>( buf, tw, lane ); fft_pass<C, 16, 16>( buf, tw, lane ); fft_pass<C, 16, 256>( buf, tw, lane ); }
+	if constexpr( LOG2C == 4 )       { fft_pass<C, 16, 1, TEAM>( buf, tw, lane ); }
+	else if constexpr( LOG2C == 5 )  { fft_pass<C, 8, 1, TEAM>( buf, tw, lane );  fft_pass<C, 4, 8, TEAM>( buf, tw, lane ); }
+	else if constexpr( LOG2C == 6 )  { fft_pass<C, 8, 1, TEAM>( buf, tw, lane );  fft_pass<C, 8, 8, TEAM>( buf, tw, lane ); }
+	else if constexpr( LOG2C == 7 )  { fft_pass<C, 16, 1, TEAM>( buf, tw, lane ); fft_pass<C, 8, 16, TEAM>( buf, tw, lane ); }
+	else if constexpr( LOG2C == 8 )  { fft_pass<C, 16, 1, TEAM>( buf, tw, lane ); fft_pass<C, 16, 16, TEAM>( buf, tw, lane ); }
+	else if constexpr( LOG2C == 9 )  { fft_pass<C, 8, 1, TEAM>( buf, tw, lane );  fft_pass<C, 8, 8, TEAM>( buf, tw, lane );   fft_pass<C, 8, 64, TEAM>( buf, tw, lane ); }
+	else if constexpr( LOG2C == 10 ) { fft_pass<C, 16, 1, TEAM>( buf, tw, lane ); fft_pass<C, 16, 16, TEAM>( buf, tw, lane ); fft_pass<C, 4, 256, TEAM>( buf, tw, lane ); }
+	else if constexpr( LOG2C == 11 ) { fft_pass<C, 16, 1, TEAM>( buf, tw, lane ); fft_pass<C, 16, 16, TEAM>( buf, tw, lane ); fft_pass<C, 8, 256, TEAM>( buf, tw, lane ); }
+	else                             { fft_pass<C, 16, 1, TEAM>( buf, tw, lane ); fft_pass<C, 16, 16, TEAM>( buf, tw, lane ); fft_pass<C, 16, 256, TEAM>( buf, tw, lane ); }
 	}
 
 } // namespace flanhip

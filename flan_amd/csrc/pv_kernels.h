@@ -4,8 +4,9 @@
 // of state cross from frame t-1 to frame t -- the previous phase of every bin in analysis
 // (Conversions/AudioPV.cpp:37,44; phase_vocoder.cpp:44-45) and the running phase of every bin in synthesis
 // (AudioPV.cpp:105,111; phase_vocoder.cpp:57-59).  Here a channel's frames are cut into chains of L consecutive
-// frames; ONE WAVEFRONT owns a chain, keeps that state in registers (lane l owns bins l, l+64, l+128, ...) and
-// walks its frames in order.  Chains are independent:
+// frames; ONE TEAM of threads owns a chain -- a wavefront, or from dft 1024 up a block of 2 to 8 wavefronts sharing the transform
+// through LDS -- keeps that state in registers (thread l owns bins l, l+TEAM, l+2 TEAM, ...) and walks its frames in order.
+// Chains are independent:
 //   analysis : a chain recomputes the phase of frame t0-1 (one extra FFT, no output) to seed `prev`.
 //   synthesis: a pre-pass sums the phase increments of every chain (k_phase_sums2), a scan turns the sums into each
 //              chain's carry-in (k_phase_scan2), and the overlap-add of the W-hop samples a chain shares with its
@@ -60,15 +61,19 @@ __device__ __forceinline__ MF phase_vocode_bin( float re, float im, float & prev
 	}
 
 // Audio::convert_to_PV (Conversions/AudioPV.cpp:12-78).  One wavefront per chain, WAVES chains per block.
-template<int LOG2C, int WAVES>
-__global__ __launch_bounds__( 64 * WAVES ) void k_analyze( AnalyzeParams p )
+template<int LOG2C, int WAVES, int T = 1>
+__global__ __launch_bounds__( 64 * WAVES * T ) void k_analyze( AnalyzeParams p )
 	{
 	constexpr int C = 1 << LOG2C;                   // complex points = dft/2
-	constexpr int E = ( C + 63 ) / 64;              // bins per lane (plus Nyquist on lane 0)
+	// A chain is walked by a TEAM of threads: one wavefront (T = 1, WAVES chains per block), or a whole block of T wavefronts sharing
+	// one transform through LDS (T > 1, one chain per block: the sizes whose bins do not fit one wavefront's registers).
+	static_assert( T == 1 || WAVES == 1, "a team of several wavefronts owns its block" );
+	constexpr int TEAM = 64 * T, NT = 64 * WAVES * T;
+	constexpr int E = ( C + TEAM - 1 ) / TEAM;      // bins per thread (plus Nyquist on thread 0 of the team)
 	// dft 8192 (64 bins per lane): what the smaller sizes keep in registers across frames -- the previous phases -- lives in LDS,
 	// the per-bin loops are rolled (4 at a time) and the twiddles stay in global memory (L1): with everything resident and unrolled
 	// the kernel spilled 2.4 KB per lane to scratch and ran at a hundredth of the dft 2048 rate.  conversions.hip: analyze_lds_bytes
-	constexpr bool BIG = LOG2C >= 12;
+	constexpr bool BIG = LOG2C >= 12 && T == 1;
 	constexpr int UNR = BIG ? 4 : E;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	cf * s_tw = reinterpret_cast<cf*>( smem );                      // [C] (none when BIG)
@@ -77,9 +82,9 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze( AnalyzeParams p )
 	cf * s_buf_all = reinterpret_cast<cf*>( s_win + wpad );          // WAVES x padded_len(C)
 	float * s_prev_all = reinterpret_cast<float*>( s_buf_all + WAVES * padded_len( C ) );   // WAVES x ( C + 4 ), BIG only
 
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	if constexpr( !BIG ) for( int i = tid; i < C; i += 64 * WAVES ) s_tw[i] = p.tw[i];
-	for( int i = tid; i < p.window_size; i += 64 * WAVES ) s_win[i] = p.window[i];
+	const int tid = threadIdx.x, lane = T == 1 ? ( tid & 63 ) : tid, wave = T == 1 ? ( tid >> 6 ) : 0;
+	if constexpr( !BIG ) for( int i = tid; i < C; i += NT ) s_tw[i] = p.tw[i];
+	for( int i = tid; i < p.window_size; i += NT ) s_win[i] = p.window[i];
 	__syncthreads();
 	const cf * tw = BIG ? p.tw : s_tw;
 
@@ -99,15 +104,15 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze( AnalyzeParams p )
 	// LEAN (dft >= 4096: 32+ bins per lane): only the previous phases stay in registers; the constants are recomputed /
 	// fetched (L1) per use and the fused pre-pass sums are not kept (conversions.hip: fused_prepass_supported) -- with all of
 	// them resident the dft 8192 kernel spilled 4 KB per lane to scratch.
-	constexpr bool LEAN = LOG2C >= 11;
+	constexpr bool LEAN = LOG2C >= 11 && T == 1;
 	constexpr int EC = LEAN ? 0 : E;                                          // length of the resident constant arrays
 	float binf_r[EC + 1], expect_r[EC + 1], prev[( BIG ? 0 : E ) + 1];
 	cf w2_r[EC + 1];
-	auto bin_of = [&]( int i ) { return ( i < E ) ? lane + 64 * i : C; };
+	auto bin_of = [&]( int i ) { return ( i < E ) ? lane + TEAM * i : C; };
 	auto binf_of = [&]( int i ) { return LEAN ? float( bin_of( i ) ) * p.sample_rate / float( dft ) : binf_r[LEAN ? 0 : i]; };
 	auto expect_of = [&]( int i ) { return LEAN ? binf_of( i ) / p.analysis_rate * FLANHIP_PI2_F : expect_r[LEAN ? 0 : i]; };
 	auto w2_of = [&]( int i ) { return LEAN ? p.tw2[min( bin_of( i ), C )] : w2_r[LEAN ? 0 : i]; };
-	if constexpr( BIG ) { for( int k = lane; k <= C; k += 64 ) s_prev[k] = 0.0f; }   // AudioPV.cpp:44
+	if constexpr( BIG ) { for( int k = lane; k <= C; k += TEAM ) s_prev[k] = 0.0f; }   // AudioPV.cpp:44
 	#pragma unroll
 	for( int i = 0; i <= ( BIG ? 0 : E ); ++i )
 		{
@@ -134,8 +139,8 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze( AnalyzeParams p )
 		#pragma unroll UNR
 		for( int q = 0; q < E; ++q )
 			{
-			const int i = lane + 64 * q;
-			if( C >= 64 || i < C )
+			const int i = lane + TEAM * q;
+			if( C >= TEAM || i < C )
 				{
 				const int s0 = 2 * i, s1 = 2 * i + 1;
 				float v0 = 0.0f, v1 = 0.0f;
@@ -144,8 +149,8 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze( AnalyzeParams p )
 				buf[PAD( i )] = mk( v0, v1 );
 				}
 			}
-		wave_sync();
-		fft_forward<LOG2C>( buf, tw, lane );
+		team_sync<TEAM>();
+		fft_forward<LOG2C, TEAM>( buf, tw, lane );
 
 		// split the half-size transform into the real transform's bins and phase-vocode each bin (AudioPV.cpp:69-73)
 		MF * row = p.out + ( int64_t( channel ) * p.F + t ) * ( C + 1 );
@@ -153,8 +158,8 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze( AnalyzeParams p )
 		#pragma unroll UNR
 		for( int q = 0; q < E; ++q )
 			{
-			const int k = lane + 64 * q;
-			if( C >= 64 || k < C )
+			const int k = lane + TEAM * q;
+			if( C >= TEAM || k < C )
 				{
 				const cf zk = buf[PAD( k )];
 				const cf zm = buf[PAD( ( C - k ) & ( C - 1 ) )];
@@ -198,7 +203,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze( AnalyzeParams p )
 				bad |= isnan( mf.m ) || isnan( mf.f ) || isinf( mf.m ) || isinf( mf.f );
 				}
 			}
-		wave_sync();
+		team_sync<TEAM>();
 		}
 	if constexpr( !LEAN ) if( p.sums )
 		{
@@ -206,15 +211,15 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze( AnalyzeParams p )
 		#pragma unroll
 		for( int q = 0; q < E; ++q )
 			{
-			const int k = lane + 64 * q;
-			if( C >= 64 || k < C ) dst[k] = ( __builtin_fabs( sum[q] ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( sum[q] ) : fold_phase_any( sum[q] );
+			const int k = lane + TEAM * q;
+			if( C >= TEAM || k < C ) dst[k] = ( __builtin_fabs( sum[q] ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( sum[q] ) : fold_phase_any( sum[q] );
 			}
 		if( lane == 0 ) dst[C] = ( __builtin_fabs( sum[E] ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( sum[E] ) : fold_phase_any( sum[E] );
 		const bool any_bad = __any( bad );
-		if( p.nan_out && lane == 0 )
+		if( p.nan_out && ( tid & 63 ) == 0 )                                      // one lane per wavefront of the team
 			{
 			// no clearing pass: the flag word is "set" when it equals this launch's epoch (written beside it by chain 0)
-			if( chain == 0 ) p.nan_out[2] = p.nan_epoch;
+			if( chain == 0 && lane == 0 ) p.nan_out[2] = p.nan_epoch;
 			if( any_bad ) p.nan_out[0] = p.nan_epoch;
 			}
 		}
@@ -283,14 +288,16 @@ struct SynthParams
 // (the pre-pass kernels k_phase_sums2 / k_phase_scan2 that serve every size live in pv_kernels_fast.h)
 
 // PV::convert_to_audio (Conversions/AudioPV.cpp:86-139).  One wavefront per chain.
-template<int LOG2C, int WAVES>
-__global__ __launch_bounds__( 64 * WAVES ) void k_synthesize( SynthParams p )
+template<int LOG2C, int WAVES, int T = 1>
+__global__ __launch_bounds__( 64 * WAVES * T ) void k_synthesize( SynthParams p )
 	{
 	constexpr int C = 1 << LOG2C;
-	constexpr int E = ( C + 63 ) / 64;
+	static_assert( T == 1 || WAVES == 1, "a team of several wavefronts owns its block" );
+	constexpr int TEAM = 64 * T, NT = 64 * WAVES * T;    // see k_analyze
+	constexpr int E = ( C + TEAM - 1 ) / TEAM;
 	// dft 8192: the running phases (fp64, 65 per lane) live in LDS, the per-bin loop is rolled, twiddles come from global memory (L1):
 	// see k_analyze.  conversions.hip: synth_lds_bytes
-	constexpr bool BIG = LOG2C >= 12;
+	constexpr bool BIG = LOG2C >= 12 && T == 1;
 	constexpr int UNR = BIG ? 2 : E + 1;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	cf * s_tw = reinterpret_cast<cf*>( smem );                       // [C] (none when BIG)
@@ -301,12 +308,12 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize( SynthParams p )
 	float * s_ring_all = reinterpret_cast<float*>( s_buf_all + WAVES * padded_len( C + 1 ) ); // WAVES x wpad
 	double * s_ph_all = reinterpret_cast<double*>( s_ring_all + WAVES * wpad );   // WAVES x ( C + 2 ), BIG only (wpad is a multiple of 4: 16-byte aligned)
 
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	if constexpr( !BIG ) for( int i = tid; i < C; i += 64 * WAVES ) s_tw[i] = p.tw[i];
+	const int tid = threadIdx.x, lane = T == 1 ? ( tid & 63 ) : tid, wave = T == 1 ? ( tid >> 6 ) : 0;
+	if constexpr( !BIG ) for( int i = tid; i < C; i += NT ) s_tw[i] = p.tw[i];
 	const cf * tw = BIG ? p.tw : s_tw;
-	for( int i = tid; i < W; i += 64 * WAVES ) s_win[i] = p.window[i] * p.window_scale;   // AudioPV.cpp:102
+	for( int i = tid; i < W; i += NT ) s_win[i] = p.window[i] * p.window_scale;   // AudioPV.cpp:102
 	float * ring = s_ring_all + wave * wpad;
-	for( int i = lane; i < W; i += 64 ) ring[i] = 0.0f;
+	for( int i = lane; i < W; i += TEAM ) ring[i] = 0.0f;
 	__syncthreads();
 
 	cf * buf = s_buf_all + wave * padded_len( C + 1 );
@@ -326,14 +333,14 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize( SynthParams p )
 	double ph[( BIG ? 0 : E ) + 1];
 	cf w2[BIG ? 1 : E];
 	double * s_ph = s_ph_all + wave * ( C + 2 );
-	if constexpr( BIG ) { for( int k = lane; k <= C; k += 64 ) s_ph[k] = p.carry[chain * ( C + 1 ) + k]; }
+	if constexpr( BIG ) { for( int k = lane; k <= C; k += TEAM ) s_ph[k] = p.carry[chain * ( C + 1 ) + k]; }
 	else
 		{
 		#pragma unroll
 		for( int i = 0; i <= E; ++i )
 			{
-			const int k = ( i < E ) ? lane + 64 * i : C;
-			ph[i] = ( ( C >= 64 || i == E || k < C ) ) ? p.carry[chain * ( C + 1 ) + min( k, C )] : 0.0;
+			const int k = ( i < E ) ? lane + TEAM * i : C;
+			ph[i] = ( ( C >= TEAM || i == E || k < C ) ) ? p.carry[chain * ( C + 1 ) + min( k, C )] : 0.0;
 			if( i < E ) w2[i] = p.tw2[min( k, C )];
 			}
 		}
@@ -347,8 +354,8 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize( SynthParams p )
 		#pragma unroll UNR
 		for( int q = 0; q <= E; ++q )
 			{
-			const int k = ( q < E ) ? lane + 64 * q : C;
-			const bool active = ( q < E ) ? ( C >= 64 || k < C ) : ( lane == 0 );
+			const int k = ( q < E ) ? lane + TEAM * q : C;
+			const bool active = ( q < E ) ? ( C >= TEAM || k < C ) : ( lane == 0 );
 			if( active )
 				{
 				const MF mf = row[k];
@@ -360,7 +367,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize( SynthParams p )
 				buf[PAD( k )] = mk( mf.m * cs, mf.m * sn );           // std::polar
 				}
 			}
-		wave_sync();
+		team_sync<TEAM>();
 		// merge X[0..C] into the half-size spectrum Z[k] = A[k] + i B[k]; stored conjugated so that the forward FFT
 		// evaluates the inverse transform ( ifft(Z) = conj( fft( conj Z ) ) ).  c2r ignores Im X[0], Im X[C].
 		auto merge = [&]( int k, cf xk, cf xm ) -> cf
@@ -378,14 +385,14 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize( SynthParams p )
 			{
 			// in place, a lane owning bin k and its mirror C - k: both are read before either is written, no staging registers
 			#pragma unroll 2
-			for( int k = lane; k <= C / 2; k += 64 )
+			for( int k = lane; k <= C / 2; k += TEAM )
 				{
 				const cf xk = buf[PAD( k )], xm = buf[PAD( C - k )];
 				const cf zk = merge( k, xk, xm );
 				if( k != 0 && k != C / 2 ) buf[PAD( C - k )] = merge( C - k, xm, xk );
 				buf[PAD( k )] = zk;
 				}
-			wave_sync();
+			team_sync<TEAM>();
 			}
 		else
 			{
@@ -393,8 +400,8 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize( SynthParams p )
 			#pragma unroll
 			for( int q = 0; q < E; ++q )
 				{
-				const int k = lane + 64 * q;
-				if( C >= 64 || k < C )
+				const int k = lane + TEAM * q;
+				if( C >= TEAM || k < C )
 					{
 					cf xk = buf[PAD( k )];
 					cf xm = buf[PAD( C - k )];
@@ -409,19 +416,19 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize( SynthParams p )
 					zc[q] = mk( ax - by, -( ay + bx ) );
 					}
 				}
-			wave_sync();
+			team_sync<TEAM>();
 			#pragma unroll
 			for( int q = 0; q < E; ++q )
 				{
-				const int k = lane + 64 * q;
-				if( C >= 64 || k < C ) buf[PAD( k )] = zc[q];
+				const int k = lane + TEAM * q;
+				if( C >= TEAM || k < C ) buf[PAD( k )] = zc[q];
 				}
-			wave_sync();
+			team_sync<TEAM>();
 			}
-		fft_forward<LOG2C>( buf, tw, lane );
+		fft_forward<LOG2C, TEAM>( buf, tw, lane );
 		// G = fft( conj Z ):  x[2n] = G[n].x, x[2n+1] = -G[n].y   (AudioPV.cpp:122; samples >= W are discarded)
 		// window and accumulate into the ring (AudioPV.cpp:133-134)
-		for( int n = lane; 2 * n < W; n += 64 )
+		for( int n = lane; 2 * n < W; n += TEAM )
 			{
 			const cf g = buf[PAD( n )];
 			int i0 = ring_base + 2 * n; if( i0 >= W ) i0 -= W;
@@ -432,9 +439,9 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize( SynthParams p )
 				ring[i1] += ( -g.y ) * s_win[2 * n + 1];
 				}
 			}
-		wave_sync();
+		team_sync<TEAM>();
 		// the oldest `hop` samples are complete as far as this chain is concerned: emit and clear them
-		for( int e = lane; e < hop; e += 64 )
+		for( int e = lane; e < hop; e += TEAM )
 			{
 			float v = 0.0f;
 			if( e < W )
@@ -446,7 +453,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize( SynthParams p )
 			if( a < own_start ) head[a - chain_start] = v;
 			else if( a >= 0 && a < p.out_len ) out[a] = v;
 			}
-		wave_sync();
+		team_sync<TEAM>();
 		pos += hop;
 		ring_base = ( hop < W ) ? ring_base + hop : 0;
 		if( ring_base >= W ) ring_base -= W;
@@ -455,7 +462,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize( SynthParams p )
 	// zero-fills up to the end of the output (Audio( format ) is zero-initialised, AudioPV.cpp:95)
 	const int64_t ring_end = pos + ( hop < W ? W - hop : 0 );
 	const int64_t flush_end = last_chain ? max( ring_end, p.out_len ) : ring_end;
-	for( int64_t a = pos + lane; a < flush_end; a += 64 )
+	for( int64_t a = pos + lane; a < flush_end; a += TEAM )
 		{
 		float v = 0.0f;
 		if( a < ring_end )
