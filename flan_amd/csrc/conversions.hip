@@ -142,7 +142,7 @@ int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int 
 	if( int rc = get_div_plan( p.analysis_rate, &dp ) ) return rc;
 	p.ar_div = DivC{ dp.c, dp.rc, dp.exact };
 	p.sums = nullptr; p.nan_out = nullptr; p.nan_epoch = 0;
-	const bool kernel_sums = fast || dft < 4096;
+	const bool kernel_sums = true;                                                // every analysis kernel launched keeps the sums (the one-wavefront LEAN variants did not)
 	SynthLayout fused_lay{};
 	if( d_fused_ws )
 		{
@@ -158,7 +158,7 @@ int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int 
 			p.nan_out = reinterpret_cast<int*>( reinterpret_cast<char*>( d_fused_ws ) + lay.carry_bytes + lay.head_bytes );
 			}
 		}
-	auto prepass_on_behalf = [&]() -> int                                         // dft >= 4096 through the generic kernels
+	auto prepass_on_behalf = [&]() -> int                                         // for an analysis kernel that keeps no sums (none does at present)
 		{
 		if( !d_fused_ws || kernel_sums ) return FLANHIP_OK;
 		SynthParams q{};

@@ -149,7 +149,7 @@ static void device_checks()
 	// default arguments are the reference's: window 2048, hop 128, dft 4096 (Audio.h:158-163)
 	PV dflt = sine( 20000 ).convert_to_PV();
 	CHECK( dflt.get_num_bins() == 2049 && dflt.get_hop_size() == 128 && dflt.get_num_frames() == 20000 / 128 + 1 );
-	Audio dflt_back = dflt.convert_to_audio();                                     // dft 4096: the fused entry points run unfused inside
+	Audio dflt_back = dflt.convert_to_audio();                                     // dft 4096, hop 128: the API's default shape
 	CHECK( dflt_back.get_num_frames() == dflt.get_num_frames() * 128 );
 	CHECK( close_to( dflt_back.get_sample( 0, 4000 ), sine( 20000 ).get_sample( 0, 4000 ) * 1.00074, 2e-3 ) );
 

@@ -202,7 +202,7 @@ def test_fused_round_trip_equals_unfused(fa):
     import ctypes
     lib = fa.lib
     sr = 48000.0
-    # dft 8192 (and 4096 through the generic kernels): the analysis kernel keeps no sums, the library runs the pre-pass on its behalf
+    # dft 8192 (and 4096 through the generic kernels): block-wide teams walk the chains; they leave the sums like every other analysis kernel
     for (ch, n, W, hop, dft) in [(2, 70000, 2048, 512, 2048), (1, 30000, 2048, 128, 4096), (2, 20000, 1024, 256, 1024), (1, 9000, 400, 100, 512),
                                  (1, 40000, 4096, 1024, 8192), (2, 30000, 2048, 300, 4096)]:
         x = O.noise(ch, n, seed=31)
