@@ -76,3 +76,25 @@ def test_product_never_imports_the_oracle():
                     if re.search(r"import\s+oracle|from\s+oracle|oracle_lib|liboracle|flan_oracle|-loracle|oracle/_ref|libflanref", text):
                         bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_worker_pool_and_page_touch_without_a_device():
+    """flanhip_parallel_for / flanhip_touch_pages are host plumbing: they work with no GPU (the C++ classes sample callables on them)"""
+    import ctypes as C
+    import numpy as np
+    import flan_amd
+    lib = flan_amd.lib
+    assert lib.flanhip_host_workers() >= 1
+    hits = np.zeros(10007, np.int32)
+    CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
+
+    def body(ctx, i):
+        hits[i] += 1                                  # every index is visited by exactly one thread
+    cb = CB(body)
+    assert lib.flanhip_parallel_for(len(hits), C.cast(cb, C.c_void_p), None) == 0
+    assert np.all(hits == 1)
+    assert lib.flanhip_parallel_for(0, C.cast(cb, C.c_void_p), None) == 0
+    assert lib.flanhip_parallel_for(5, None, None) != 0        # a null task is an error, not a crash
+    buf = np.full(8 << 20, 7, np.uint8)
+    assert lib.flanhip_touch_pages(buf.ctypes.data_as(C.c_void_p), buf.nbytes) == 0
+    assert buf[::4096].sum() == 0 and buf[1] == 7               # one zero per page, nothing else touched
