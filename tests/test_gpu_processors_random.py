@@ -100,3 +100,69 @@ def test_random_processors(fa, seed):
         out_frames = end + int(rng.integers(1, 40))
         samples = O.time_extrapolate_interp_samples(start, end, out_frames, int(rng.integers(0, 8)))
         assert same_bits(fa.time_extrapolate(pv, SR, start, end, out_frames, samples), O.time_extrapolate(pv, SR, start, end, out_frames, samples)), tag + " time_extrapolate"
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_arranging_processors(fa, seed):
+    """the frame-selecting / warping methods (oracle/arrange_oracle.cpp) over the same random shapes: bit equality"""
+    rng = np.random.default_rng(5000 + seed)
+    pv = random_pv(rng)
+    ch, F, bins, _ = pv.shape
+    dft = (bins - 1) * 2
+    hop = int(rng.choice([64, 128, 256, 512]))
+    hop_s = hop / SR
+    tag = "seed %d: %s hop %d" % (seed, pv.shape, hop)
+    t = (np.arange(F, dtype=np.float32) / np.float32(SR / hop))[:, None] * np.ones((1, bins), np.float32)
+    f = (np.arange(bins, dtype=np.float32) * np.float32(SR) / np.float32(dft))[None, :] * np.ones((F, 1), np.float32)
+
+    # ---- get_frame, freeze, cut_frames, join
+    pos = float(np.float32(rng.uniform(0, F - 1)))
+    interp = int(rng.integers(0, 7))
+    assert same_bits(fa.get_frame(pv, pos, interp), O.get_frame(pv, pos, interp)), tag + " get_frame"
+    n_ev = int(rng.integers(0, 6))
+    times = rng.uniform(-hop_s, (F + 1) * hop_s, n_ev).astype(np.float32)
+    lengths = rng.uniform(-hop_s, 6 * hop_s, n_ev).astype(np.float32)
+    assert same_bits(fa.freeze(pv, SR, hop, times, lengths), O.freeze(pv, SR, hop, times, lengths)), tag + " freeze"
+    a, b = sorted(int(v) for v in rng.integers(-3, F + 3, 2))
+    got, ref = fa.cut_frames(pv, a, b), O.cut_frames(pv, a, b)
+    assert (got is None and ref is None) or same_bits(got, ref), tag + " cut_frames"
+    other = random_pv(rng)
+    assert same_bits(fa.join([pv, other, pv[:1]]), O.join([pv, other, pv[:1]])), tag + " join"
+
+    # ---- select with a random selector grid
+    Fo = int(rng.integers(1, 2 * F + 3))
+    sel = np.empty((Fo, bins, 2), np.float32)
+    sel[..., 0] = rng.uniform(-2 * hop_s, (F + 2) * hop_s, (Fo, bins))
+    sel[..., 1] = rng.uniform(-500.0, SR / 2 + 500.0, (Fo, bins))
+    assert same_bits(fa.select(pv, SR, hop, sel), O.select(pv, SR, hop, sel)), tag + " select"
+
+    # ---- add_octaves / add_harmonics with random series
+    for mode, H in ((0, int(rng.integers(1, 20))), (1, int(rng.integers(1, bins + 1)))):
+        series = rng.uniform(-0.5, 1.5, (F, H)).astype(np.float32)
+        assert same_bits(fa.harmonic_scale(pv, SR, series, mode), O.harmonic_scale(pv, SR, series, mode)), tag + " harmonic_scale %d" % mode
+
+    # ---- smear_time with random grids
+    smear = (rng.uniform(-1, 5, (F, bins)) * hop_s).astype(np.float32) if rng.integers(0, 2) else float(rng.uniform(0, 4) * hop_s)
+    gran = rng.integers(-1, 4, (F, bins)).astype(np.int32) if rng.integers(0, 2) else int(rng.integers(1, 4))
+    left, Fs, half = O.smear_time_plan(F, bins, SR, hop, smear)
+    assert (left, Fs, half) == fa.smear_time_plan(F, bins, SR, hop, smear), tag + " smear plan"
+    if Fs > 0:
+        dist = rng.uniform(0, 1, 2 * half).astype(np.float32)
+        assert same_bits(fa.smear_time(pv, SR, hop, smear, gran, dist, left, Fs), O.smear_time(pv, SR, hop, smear, gran, dist, left, Fs)), tag + " smear_time"
+
+    # ---- modify with a smooth random warp (jittered affine map: quads stay small)
+    if F >= 2:
+        a11, a22 = rng.uniform(0.5, 1.8), rng.uniform(0.6, 1.4)
+        grid = np.stack([t * np.float32(a11) + np.float32(rng.uniform(0, 3) * hop_s) + rng.uniform(-0.3, 0.3, t.shape).astype(np.float32) * np.float32(hop_s),
+                         f * np.float32(a22) + np.float32(rng.uniform(-200, 200)) + rng.uniform(-0.3, 0.3, f.shape).astype(np.float32) * np.float32(SR / dft)], -1).astype(np.float32)
+        in_f = rng.uniform(0, SR / 2, (ch, F, bins)).astype(np.float32)
+        Fm = O.modify_out_frames(grid, SR, hop)
+        assert Fm == fa.modify_out_frames(grid, SR, hop), tag + " modify frames"
+        if Fm > 0:
+            k = int(rng.choice([0, 1, 3, 4, 5, 6]))
+            assert same_bits(fa.modify(pv, SR, hop, grid, in_f, k, Fm), O.modify(pv, SR, hop, grid, in_f, k, Fm)), tag + " modify interp %d" % k
+
+    # ---- stretch_spline with random steps
+    if F >= 3:
+        steps = rng.integers(1, 6, F - 1).astype(np.uint32)
+        assert same_bits(fa.stretch_spline(pv, steps), O.stretch_spline(pv, steps)), tag + " stretch_spline"
