@@ -44,18 +44,20 @@ struct AnalyzeParams
 	int nan_epoch;            // a fresh non-zero number per launch
 	};
 
-// phase_vocoder.cpp:37-52 with the reference's rounding sequence (the file is compiled with -ffp-contract=off).
+// phase_vocoder.cpp:37-52 with the reference's rounding sequence (the file is compiled with -ffp-contract=off); the same helpers as
+// the tuned kernels (pv_math.h): atan2_fast (1.8 ulp), divisions by pi2 as exact 3-instruction sequences, |z| as fma + sqrt on
+// operands scaled by a power of two.
 __device__ __forceinline__ MF phase_vocode_bin( float re, float im, float & prev_phase, float bin_frequency, float expected_phase_diff,
 	float analysis_rate, bool use_wrapping )
 	{
-	const float phase = atan2f( im, re );                                             // std::arg
+	const float phase = atan2_fast( im, re );                                         // std::arg
 	const float phase_diff = float( double( phase ) - double( prev_phase ) );         // :44 (double subtraction, narrowed)
 	prev_phase = phase;                                                               // :45
 	const float delta_phase = phase_diff - expected_phase_diff;                       // :48
-	const float wrapped = use_wrapping ? delta_phase - FLANHIP_PI2_F * roundf( delta_phase / FLANHIP_PI2_F ) : delta_phase; // :39-42,49
-	const float delta_frequency = wrapped * analysis_rate / FLANHIP_PI2_F;            // :50
+	const float wrapped = use_wrapping ? delta_phase - FLANHIP_PI2_F * roundf( div_pi2( delta_phase ) ) : delta_phase; // :39-42,49
+	const float delta_frequency = div_pi2( wrapped * analysis_rate );                 // :50
 	MF r;
-	r.m = hypotf( re, im );                                                           // std::abs
+	r.m = magnitude_scaled( re, im );                                                 // std::abs
 	r.f = bin_frequency + delta_frequency;                                            // :52
 	return r;
 	}
@@ -359,11 +361,17 @@ __global__ __launch_bounds__( 64 * WAVES * T ) void k_synthesize( SynthParams p 
 			if( active )
 				{
 				const MF mf = row[k];
-				double phase;
-				if constexpr( BIG ) { phase = fold_phase( s_ph[k] + double( phase_term( mf.f, p.analysis_rate ) ) ); s_ph[k] = phase; }
-				else { phase = fold_phase( ph[BIG ? 0 : q] + double( phase_term( mf.f, p.analysis_rate ) ) ); ph[BIG ? 0 : q] = phase; }
+				// phase_vocoder.cpp:57-60 with the tuned kernels' helpers: f / analysis_rate as an exact division by a constant, the
+				// fold without a division, sin / cos as polynomials after a Cody-Waite reduction; the general routines take over for
+				// phases outside the range those are exact for (never for a real PV)
+				const double term = double( div_c( mf.f, p.ar_div ) * FLANHIP_PI2_F );
+				double phase = ( BIG ? s_ph[k] : ph[BIG ? 0 : q] ) + term;
+				phase = ( __builtin_fabs( phase ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( phase ) : fold_phase_any( phase );
+				if constexpr( BIG ) s_ph[k] = phase; else ph[BIG ? 0 : q] = phase;
+				const float th = float( phase );
 				float sn, cs;
-				sincosf( float( phase ), &sn, &cs );
+				if( __builtin_fabsf( th ) < FLANHIP_SINCOS_FAST_LIMIT ) sincos_fast( th, sn, cs );
+				else { const float2 sc = sincos_wide( th ); sn = sc.x; cs = sc.y; }
 				buf[PAD( k )] = mk( mf.m * cs, mf.m * sn );           // std::polar
 				}
 			}

@@ -126,16 +126,6 @@ __device__ __forceinline__ void load_tables( cf * s, const FastTables & t, const
 	for( int i = tid; i < 2 * C; i += nthreads ) win[i] = ( i < W ) ? window[i] * scale : 0.0f;
 	}
 
-// magnitude with the operands pre-scaled by a power of two (exact), so that the squares neither overflow nor underflow
-// for any finite input: |z| = 2^e * sqrt( (re 2^-e)^2 + (im 2^-e)^2 ), e = exponent of max(|re|,|im|).
-__device__ __forceinline__ float magnitude_scaled( float re, float im )
-	{
-	const float a = __builtin_fmaxf( __builtin_fabsf( re ), __builtin_fabsf( im ) );
-	const int e = __builtin_amdgcn_frexp_expf( a );
-	const float rs = __builtin_ldexpf( re, -e ), is = __builtin_ldexpf( im, -e );
-	return __builtin_ldexpf( __builtin_amdgcn_sqrtf( __builtin_fmaf( rs, rs, is * is ) ), e );
-	}
-
 // =================================================================================================================
 // Audio::convert_to_PV (Conversions/AudioPV.cpp:12-78)
 // =================================================================================================================

@@ -227,6 +227,16 @@ __device__ __noinline__ double fold_phase_any( double ph )
 	return ph;
 	}
 
+// magnitude with the operands pre-scaled by a power of two (exact), so that the squares neither overflow nor underflow
+// for any finite input: |z| = 2^e * sqrt( (re 2^-e)^2 + (im 2^-e)^2 ), e = exponent of max(|re|,|im|).
+__device__ __forceinline__ float magnitude_scaled( float re, float im )
+	{
+	const float a = __builtin_fmaxf( __builtin_fabsf( re ), __builtin_fabsf( im ) );
+	const int e = __builtin_amdgcn_frexp_expf( a );
+	const float rs = __builtin_ldexpf( re, -e ), is = __builtin_ldexpf( im, -e );
+	return __builtin_ldexpf( __builtin_amdgcn_sqrtf( __builtin_fmaf( rs, rs, is * is ) ), e );
+	}
+
 // sin and cos of a float angle beyond the range of sincos_fast: the same polynomials after a Cody-Waite reduction
 // carried out in double (valid while the quotient is an exact double integer with room to spare: |x| < 2^45; a float
 // that large has an ulp of 4e6 radians).
