@@ -75,6 +75,8 @@ __global__ __launch_bounds__( 64 * WAVES * T ) void k_analyze( AnalyzeParams p )
 	// dft 8192 (64 bins per lane): what the smaller sizes keep in registers across frames -- the previous phases -- lives in LDS,
 	// the per-bin loops are rolled (4 at a time) and the twiddles stay in global memory (L1): with everything resident and unrolled
 	// the kernel spilled 2.4 KB per lane to scratch and ran at a hundredth of the dft 2048 rate.  conversions.hip: analyze_lds_bytes
+	// ( BIG and LEAN below describe ONE-WAVEFRONT walks of dft 8192 / 4096+: the launchers give those sizes to teams, T > 1, for which
+	// both are off; the variants stay for A/B runs )
 	constexpr bool BIG = LOG2C >= 12 && T == 1;
 	constexpr int UNR = BIG ? 4 : E;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
