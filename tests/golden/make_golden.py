@@ -54,10 +54,39 @@ def ext_cases(pv):
                 time_extrapolate=O.time_extrapolate(pv, SR, start, end, Fo, samples))
 
 
+def arrange_cases(pv):
+    """inputs + oracle outputs of the frame-selecting / warping methods (oracle/arrange_oracle.cpp) on one small PV"""
+    ch, F, bins, _ = pv.shape
+    hop, dft = 256, (bins - 1) * 2
+    rng = np.random.default_rng(123)
+    t = (np.arange(F, dtype=np.float32) / np.float32(SR / hop))[:, None] * np.ones((1, bins), np.float32)
+    f = (np.arange(bins, dtype=np.float32) * np.float32(SR) / np.float32(dft))[None, :] * np.ones((F, 1), np.float32)
+    times = np.array([0.02, 0.05, 0.05], np.float32)
+    lengths = np.array([0.01, 0.02, 0.5], np.float32)
+    sel = np.stack([rng.uniform(-0.01, F * hop / SR, (30, bins)), rng.uniform(-100, SR / 2, (30, bins))], -1).astype(np.float32)
+    series_oct = rng.uniform(0, 1, (F, 12)).astype(np.float32)
+    series_har = rng.uniform(0, 1, (F, 40)).astype(np.float32)
+    smear = rng.uniform(0, 0.02, (F, bins)).astype(np.float32)
+    left, Fs, half = O.smear_time_plan(F, bins, SR, hop, smear)
+    dist = O.smear_distribution(half)
+    warp = np.stack([t * np.float32(1.5) + np.float32(0.003) * np.sin(f / np.float32(2500)).astype(np.float32), f * np.float32(1.2) + np.float32(30)], -1).astype(np.float32)
+    in_f = rng.uniform(0, SR / 2, (ch, F, bins)).astype(np.float32)
+    Fm = O.modify_out_frames(warp, SR, hop)
+    steps = rng.integers(1, 5, F - 1).astype(np.uint32)
+    return dict(pv=pv, hop=np.int64(hop), times=times, lengths=lengths, sel=sel, series_oct=series_oct, series_har=series_har, smear=smear,
+                smear_plan=np.array([left, Fs, half], np.int64), dist=dist, warp=warp, in_f=in_f, modify_frames=np.int64(Fm), steps=steps,
+                get_frame=O.get_frame(pv, 7.25, 0), freeze=O.freeze(pv, SR, hop, times, lengths), cut=O.cut_frames(pv, 3, 17),
+                join=O.join([pv[:, :5], pv[:, 9:]]), select=O.select(pv, SR, hop, sel), octaves=O.harmonic_scale(pv, SR, series_oct, 0),
+                harmonics=O.harmonic_scale(pv, SR, series_har, 1), smear_time=O.smear_time(pv, SR, hop, smear, 2, dist, left, Fs),
+                modify=O.modify(pv, SR, hop, warp, in_f, 0, Fm), stretch_spline=O.stretch_spline(pv, steps))
+
+
 def main():
     pv = O.analyze(O.noise(1, 5003, 11), SR, 1024, 256, 1024)
     os.makedirs(os.path.join(HERE, "processors"), exist_ok=True)
     np.savez_compressed(os.path.join(HERE, "processors", "processors_ext.npz"), **ext_cases(pv))
+    small = O.analyze(O.noise(2, 4000, 17), SR, 256, 256, 256)
+    np.savez_compressed(os.path.join(HERE, "processors", "processors_arrange.npz"), **arrange_cases(small))
     for name, (ch, n, W, hop, dft, kind, seed) in CASES.items():
         x = make_input(kind, ch, n, seed)
         pv = O.analyze(x, SR, W, hop, dft)

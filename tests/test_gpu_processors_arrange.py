@@ -214,3 +214,11 @@ def test_stretch_spline(fa, pv_small, pv_wide):
         fa.stretch_spline(pv_small[:, :2].copy(), np.ones(1, np.uint32))           # fewer than three knots
     with pytest.raises(fa.FlanHipError):
         fa.stretch_spline(pv_small, np.zeros(pv_small.shape[1] - 1, np.uint32))    # a step of 0: the knots would not increase
+
+
+def test_golden_fixture(fa):
+    """the committed vectors of tests/golden/processors/processors_arrange.npz through the GPU library: bit for bit"""
+    from test_oracle_processors_arrange import _golden, golden_outputs
+    g = _golden()
+    for name, got in golden_outputs(fa, g).items():
+        assert_identical("golden/" + name, got, g[name])

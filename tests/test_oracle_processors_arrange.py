@@ -259,3 +259,27 @@ def test_stretch_spline_properties_and_plan_helper():
         assert flan_amd.lib.flanhip_stretch_spline_out_frames(st.ctypes.data, n) == O.lib.oracle_stretch_spline_out_frames(st.ctypes.data, n) == int(st.sum())
     assert flan_amd.lib.flanhip_stretch_spline_out_frames(np.ones(1, np.uint32).ctypes.data, 2) == -1
     assert flan_amd.lib.flanhip_stretch_spline_out_frames(np.array([1, 0, 1], np.uint32).ctypes.data, 4) == -1
+
+
+def _golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "processors", "processors_arrange.npz"))
+
+
+def golden_outputs(impl, g):
+    """every method of the fixture through `impl` (the checker here, the GPU library in test_gpu_processors_arrange.py)"""
+    pv, hop = g["pv"], int(g["hop"])
+    left, Fs, half = (int(v) for v in g["smear_plan"])
+    return dict(get_frame=impl.get_frame(pv, 7.25, 0), freeze=impl.freeze(pv, SR, hop, g["times"], g["lengths"]), cut=impl.cut_frames(pv, 3, 17),
+                join=impl.join([pv[:, :5], pv[:, 9:]]), select=impl.select(pv, SR, hop, g["sel"]), octaves=impl.harmonic_scale(pv, SR, g["series_oct"], 0),
+                harmonics=impl.harmonic_scale(pv, SR, g["series_har"], 1), smear_time=impl.smear_time(pv, SR, hop, g["smear"], 2, g["dist"], left, Fs),
+                modify=impl.modify(pv, SR, hop, g["warp"], g["in_f"], 0, int(g["modify_frames"])), stretch_spline=impl.stretch_spline(pv, g["steps"]))
+
+
+def test_checker_reproduces_the_golden_fixture():
+    """tests/golden/processors/processors_arrange.npz (written by tests/golden/make_golden.py): the checker must not drift"""
+    g = _golden()
+    assert (int(g["smear_plan"][0]), int(g["smear_plan"][1]), int(g["smear_plan"][2])) == O.smear_time_plan(g["pv"].shape[1], g["pv"].shape[2], SR, int(g["hop"]), g["smear"])
+    assert int(g["modify_frames"]) == O.modify_out_frames(g["warp"], SR, int(g["hop"]))
+    for name, got in golden_outputs(O, g).items():
+        assert got.shape == g[name].shape and np.array_equal(got.view(np.uint32), g[name].view(np.uint32)), name
