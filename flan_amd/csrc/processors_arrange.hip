@@ -1,8 +1,9 @@
 // processors_arrange.hip -- the PV methods that select, rearrange and re-place frames and bins, behind the C ABI:
 // get_frame (PV/PV.cpp:24-39), select (:92-127), freeze (:129-198), cut_frames (:643-668), join (:698-720),
-// add_octaves / add_harmonics (:362-419).
+// add_octaves / add_harmonics (:362-419); and, further down, each with its own notes: smear_time (PV/PVModify.cpp:513-605), modify
+// (:15-193, the general warp) and stretch_spline (:387-443, with the vendored spline/spline.h).
 //
-// All but the last are gathers: every output MF is one input MF (or a blend of two), so they run at the rate HBM moves 8 B in and
+// The first group, all but its last, are gathers: every output MF is one input MF (or a blend of two), so they run at the rate HBM moves 8 B in and
 // 8 B out per MF.  A block owns one output row (channel, frame) and walks its bins: no index division per element, rows coalesced.
 // add_octaves / add_harmonics scatter every bin to the bins of its overtones with a "strictly louder replaces" rule in a fixed
 // visiting order; a block resolves one row through ds_max_u64 keys in LDS ( magnitude bits << 32 | ~visiting index ), like the
