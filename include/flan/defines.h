@@ -6,19 +6,12 @@
 
 namespace flan {
 
+// defines.h:10-29 of the reference, by kind: indices and counts are 32-bit integers, everything measured is a float
 using Index = int;
-using Second = float;
-using Channel = int32_t;
-using Frame = int32_t;
-using Bin = int32_t;
-using Harmonic = int32_t;                   // defines.h:22
-using fFrame = float;
-using fBin = float;
-using Sample = float;
-using Frequency = float;
-using Magnitude = float;
-using FrameRate = float;
-using Radian = float;
+using Channel = int32_t;    using Frame = int32_t;      using Bin = int32_t;        using Harmonic = int32_t;
+using fFrame = float;       using fBin = float;         // fractional frame / bin positions
+using Second = float;       using Sample = float;       using Frequency = float;    using Magnitude = float;
+using FrameRate = float;    using Radian = float;
 
 struct MF { Magnitude m; Frequency f; };   // defines.h:31-35
 struct TF { Second t; Frequency f; };      // defines.h:37-41
