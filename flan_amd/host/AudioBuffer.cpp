@@ -6,6 +6,7 @@
 
 #include <iostream>
 
+#include <cmath>
 #include "device_block.h"
 
 namespace flan {
@@ -75,6 +76,33 @@ std::vector<float> & AudioBuffer::get_buffer()
 Sample AudioBuffer::get_sample( Channel c, Frame f ) const { return get_buffer()[get_buffer_pos( c, f )]; }
 Sample & AudioBuffer::get_sample( Channel c, Frame f ) { return get_buffer()[get_buffer_pos( c, f )]; }
 void AudioBuffer::set_sample( Channel c, Frame f, Sample s ) { get_buffer()[get_buffer_pos( c, f )] = s; }
+
+bool AudioBuffer::is_nan_or_inf() const
+	{
+	for( float v : get_buffer() ) if( std::isnan( v ) || std::isinf( v ) ) return true;   // AudioBuffer.cpp:58-64
+	return false;
+	}
+
+Sample AudioBuffer::get_max_sample_magnitude( Second start_time, Second end_time ) const
+	{
+	if( get_num_frames() <= 0 ) return 0;
+	if( end_time == 0 ) end_time = get_length();                                  // AudioBuffer.cpp:418-420
+	const Frame start_frame = std::clamp( Frame( time_to_frame( start_time ) ), 0, get_num_frames() - 1 );
+	const Frame end_frame = std::clamp( Frame( time_to_frame( end_time ) ), 0, get_num_frames() - 1 );
+	const std::vector<float> & data = get_buffer();
+	Magnitude m = 0;
+	for( Channel channel = 0; channel < get_num_channels(); ++channel )
+		for( Frame frame = start_frame; frame < end_frame; ++frame )
+			m = std::max( m, std::abs( data[get_buffer_pos( channel, frame )] ) );
+	return m;
+	}
+
+void AudioBuffer::print_summary() const
+	{
+	std::cout << "\n=========================== Audio Info ==========================="       // AudioBuffer.cpp:500-509
+	          << "\nChannels:\t" << get_num_channels() << "\nSamples:\t" << get_num_frames() << "\nSample Rate:\t" << get_sample_rate()
+	          << "\n==================================================================" << "\n\n";
+	}
 
 const float * AudioBuffer::device_data() const
 	{

@@ -97,6 +97,37 @@ const MF * PVBuffer::device_data() const
 	return static_cast<const MF*>( dev->ptr );
 	}
 
+Magnitude PVBuffer::get_max_partial_magnitude() const
+	{
+	float max_magnitude = 0;                                                     // PVBuffer.cpp:396-406
+	for( const MF & mf : get_buffer() ) max_magnitude = std::max( max_magnitude, std::abs( mf.m ) );
+	return max_magnitude;
+	}
+
+Magnitude PVBuffer::get_max_partial_magnitude( uint32_t start_frame, uint32_t end_frame, uint32_t start_bin, uint32_t end_bin ) const
+	{
+	if( end_frame == 0 ) end_frame = uint32_t( get_num_frames() );                // PVBuffer.cpp:410-411
+	if( end_bin == 0 ) end_bin = uint32_t( get_num_bins() );
+	end_frame = std::min( end_frame, uint32_t( get_num_frames() ) );              // (the reference reads past the end for larger values)
+	end_bin = std::min( end_bin, uint32_t( get_num_bins() ) );
+	const std::vector<MF> & data = get_buffer();
+	float max_magnitude = 0;
+	for( Channel channel = 0; channel < get_num_channels(); ++channel )
+		for( uint32_t frame = start_frame; frame < end_frame; ++frame )
+			for( uint32_t bin = start_bin; bin < end_bin; ++bin )
+				max_magnitude = std::max( max_magnitude, std::abs( data[get_buffer_pos( channel, Frame( frame ), Bin( bin ) )].m ) );
+	return max_magnitude;
+	}
+
+void PVBuffer::print_summary() const
+	{
+	std::cout << "\n=========================== PVBuffer Info ==========================="    // PVBuffer.cpp:535-548
+	          << "\nChannels:\t" << get_num_channels() << "\nSamples:\t" << get_num_frames() << "\nBins:\t" << get_num_bins()
+	          << "\nFrames/second:\t" << time_to_frame( 1 ) << "\nBins/Frequency:\t" << frequency_to_bin( 1 )
+	          << "\nHop size:\t" << get_hop_size() << "\nDFT size:\t" << get_dft_size()
+	          << "\n=======================================================================" << "\n\n";
+	}
+
 // ---- .flan files ---------------------------------------------------------------------------------------------------
 namespace {
 void put16( std::vector<uint8_t> & v, uint16_t x ) { v.push_back( x & 0xFF ); v.push_back( x >> 8 ); }

@@ -48,6 +48,16 @@ public:
 	Sample get_sample( Channel c, Frame f ) const;
 	Sample & get_sample( Channel c, Frame f );
 	void set_sample( Channel c, Frame f, Sample s );
+	// the rest of the host-side accessors (AudioBuffer.h:96,128,164-216); libsndfile I/O (load / save / play) is outside this library
+	Sample * get_sample_pointer( Channel c, Frame f ) { return get_buffer().data() + get_buffer_pos( c, f ); }       // AudioBuffer.cpp:450-458
+	const Sample * get_sample_pointer( Channel c, Frame f ) const { return get_buffer().data() + get_buffer_pos( c, f ); }
+	std::vector<Sample>::const_iterator channel_begin( Channel c ) const { return get_buffer().begin() + std::ptrdiff_t( get_buffer_pos( c, 0 ) ); }   // :469-477
+	std::vector<Sample>::const_iterator channel_end( Channel c ) const { return get_buffer().begin() + std::ptrdiff_t( get_buffer_pos( c + 1, 0 ) ); }
+	Second frame_to_time( fFrame f ) const { return f / get_sample_rate(); }                                         // :401-409
+	fFrame time_to_frame( Second t ) const { return t * float( get_sample_rate() ); }
+	bool is_nan_or_inf() const;                                                                                      // :58-64
+	Sample get_max_sample_magnitude( Second start_time = 0, Second end_time = 0 ) const;                             // :416-430
+	void print_summary() const;                                                                                      // :500-509
 	const std::vector<float> & get_buffer() const;                               // downloads from HBM on first use
 	std::vector<float> & get_buffer();                                           // ... and drops the device copy (host now owns the truth)
 

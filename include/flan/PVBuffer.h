@@ -3,6 +3,7 @@
 //
 // Layout: MF[channel][frame][bin].  Move-only, explicit copy().  Like AudioBuffer, the data may live in HBM only.
 #pragma once
+#include <algorithm>
 #include <memory>
 #include <string>
 #include <vector>
@@ -67,6 +68,23 @@ public:
 	MF & get_MF( Channel c, Frame f, Bin b );
 	const std::vector<MF> & get_buffer() const;
 	std::vector<MF> & get_buffer();
+
+	// the rest of the host-side accessors (PVBuffer.h:124,190-278): they work on the host copy (brought over on first use; the
+	// non-const ones make it the truth, like get_buffer())
+	void set_MF( Channel c, Frame f, Bin b, MF mf ) { get_MF( c, f, b ) = mf; }                                      // PVBuffer.cpp:472-475
+	MF * get_MF_pointer( Channel c, Frame f, Bin b ) { return get_buffer().data() + get_buffer_pos( c, f, b ); }      // :486-489
+	const MF * get_MF_pointer( Channel c, Frame f, Bin b ) const { return get_buffer().data() + get_buffer_pos( c, f, b ); }
+	std::vector<MF>::iterator channel_begin( Channel c ) { return get_buffer().begin() + std::ptrdiff_t( get_buffer_pos( c, 0, 0 ) ); }       // :506-524
+	std::vector<MF>::iterator channel_end( Channel c ) { return get_buffer().begin() + std::ptrdiff_t( get_buffer_pos( c + 1, 0, 0 ) ); }
+	std::vector<MF>::const_iterator channel_begin( Channel c ) const { return get_buffer().begin() + std::ptrdiff_t( get_buffer_pos( c, 0, 0 ) ); }
+	std::vector<MF>::const_iterator channel_end( Channel c ) const { return get_buffer().begin() + std::ptrdiff_t( get_buffer_pos( c + 1, 0, 0 ) ); }
+	Channel bound_channel( Channel c ) const { return std::clamp( c, 0, get_num_channels() - 1 ); }                  // :453-466
+	Frame bound_frame( Frame f ) const { return std::clamp( f, 0, get_num_frames() - 1 ); }
+	Bin bound_bin( Bin b ) const { return std::clamp( b, 0, get_num_bins() - 1 ); }
+	Frequency get_frequency_offset( Channel c, Frame f, Bin b ) const { return get_MF( c, f, b ).f - bin_to_frequency( fBin( b ) ); }   // :448-451
+	Magnitude get_max_partial_magnitude() const;                                                                     // :396-406
+	Magnitude get_max_partial_magnitude( uint32_t start_frame, uint32_t end_frame = 0, uint32_t start_bin = 0, uint32_t end_bin = 0 ) const;   // :408-426
+	void print_summary() const;                                                                                      // :327-330, :535-548
 
 	// ---- device residency (MI355X) ----
 	bool is_device_resident() const { return bool( dev ); }

@@ -117,6 +117,16 @@ static void no_device_checks()
 	CHECK( q.get_num_frames() == 3 && q.get_num_bins() == 5 && q.get_window_size() == 8 );
 	CHECK( q.get_analysis_rate() == 512.0f );         // the reference's save/load asymmetry: the hop lands in analysis_rate (PVBuffer.cpp:134,245)
 	CHECK( close_to( q.get_MF( 0, 1, 2 ).m, 3.0, 1e-6 ) && close_to( q.get_MF( 0, 1, 2 ).f, 440.0, 1e-4 ) );
+	// the small accessors of the buffer classes (PVBuffer.h:190-278, AudioBuffer.h:96-216)
+	p.set_MF( 0, 2, 4, MF{ -7.0f, 23999.0f } );
+	CHECK( p.get_MF_pointer( 0, 2, 4 )->m == -7.0f && p.get_max_partial_magnitude() == 7.0f && p.get_max_partial_magnitude( 0, 2 ) == 3.0f );
+	CHECK( p.channel_end( 0 ) - p.channel_begin( 0 ) == 15 && p.bound_bin( 99 ) == 4 && p.bound_frame( -3 ) == 0 && p.bound_channel( 5 ) == 0 );
+	CHECK( p.get_frequency_offset( 0, 1, 2 ) == 440.0f - 12000.0f );
+	Audio tiny = Audio::create_from_buffer( { 0.5f, -2.0f, 0.25f, 1.0f, 0.0f, -0.75f }, 2, 48000.0f );
+	CHECK( tiny.get_max_sample_magnitude() == 2.0f && !tiny.is_nan_or_inf() && tiny.time_to_frame( 0.5f ) == 24000.0f && tiny.frame_to_time( 48.0f ) == 0.001f );
+	CHECK( *tiny.get_sample_pointer( 1, 0 ) == 1.0f && tiny.channel_end( 1 ) - tiny.channel_begin( 1 ) == 3 );
+	tiny.set_sample( 0, 0, std::nanf( "" ) );
+	CHECK( tiny.is_nan_or_inf() );
 	Function<TF, float> c( 2.0f );
 	CHECK( c.is_constant() && c( TF{ 0, 0 } ) == 2.0f );
 	Function<TF, float> l( []( TF tf ){ return tf.t + tf.f; } );
