@@ -138,6 +138,30 @@ PV PV::create_from_format( const PVBuffer::Format & f ) { return PVBuffer( f ); 
 PV PV::load_from_file( const std::string & filename ) { return PVBuffer( filename ); }
 PV PV::copy() const { return PVBuffer::copy(); }
 
+// PV.cpp:41-90
+MF PV::getBinInterpolated( Channel channel, fFrame frame, fBin bin, const Interpolator & i ) const
+	{
+	const MF p0 = get_MF( channel, Frame( std::floor( frame ) ), Bin( std::floor( bin ) ) ), p1 = get_MF( channel, Frame( std::ceil( frame ) ), Bin( std::floor( bin ) ) );
+	const MF p2 = get_MF( channel, Frame( std::ceil( frame ) ), Bin( std::ceil( bin ) ) ), p3 = get_MF( channel, Frame( std::floor( frame ) ), Bin( std::ceil( bin ) ) );
+	const float l = i( frame - std::floor( frame ) ), m = i( bin - std::floor( bin ) );
+	const float mI = 1.0f - m, lI = 1.0f - l;
+	return MF{ mI * ( lI * p0.m + l * p1.m ) + m * ( lI * p3.m + l * p2.m ), mI * ( lI * p0.f + l * p1.f ) + m * ( lI * p3.f + l * p2.f ) };
+	}
+
+MF PV::getBinInterpolated( Channel channel, fFrame frame, Bin bin, const Interpolator & i ) const
+	{
+	const MF l = get_MF( channel, Frame( std::floor( frame ) ), bin ), h = get_MF( channel, Frame( std::ceil( frame ) ), bin );
+	const float mix = i( frame - std::floor( frame ) );
+	return MF{ ( 1.0f - mix ) * l.m + mix * h.m, ( 1.0f - mix ) * l.f + mix * h.f };
+	}
+
+MF PV::getBinInterpolated( Channel channel, Frame frame, fBin bin, const Interpolator & i ) const
+	{
+	const MF l = get_MF( channel, frame, Bin( std::floor( bin ) ) ), h = get_MF( channel, frame, Bin( std::ceil( bin ) ) );
+	const float mix = i( bin - std::floor( bin ) );
+	return MF{ ( 1.0f - mix ) * l.m + mix * h.m, ( 1.0f - mix ) * l.f + mix * h.f };
+	}
+
 Audio PV::convert_to_audio( flan_CANCEL_ARG_CPP ) const
 	{
 	if( is_null() ) return Audio::create_null();

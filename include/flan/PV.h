@@ -32,6 +32,20 @@ public:
 		return f.sample( 0, float( get_num_frames() ), 1.0f / get_analysis_rate(), 0, float( get_num_bins() ), bin_to_frequency( 1 ) );
 		}
 
+	/** PV.h:37-49: a function of time sampled at every frame */
+	template<typename T>
+	std::vector<T> sample_function_over_time_domain( const Function<Second, T> & f ) const
+		{
+		std::vector<T> out( static_cast<size_t>( get_num_frames() ) );
+		detail::for_each_index( 0, get_num_frames(), f.get_execution_policy(), [&]( int frame ){ out[size_t( frame )] = f( frame_to_time( fFrame( frame ) ) ); } );
+		return out;
+		}
+
+	/** A weighted approximation from the surrounding MFs (PV.h:203-222, PV.cpp:41-90); host-side accessors like get_MF */
+	MF getBinInterpolated( Channel channel, fFrame frame, fBin bin, const Interpolator & interp = Interpolator::linear() ) const;
+	MF getBinInterpolated( Channel channel, fFrame frame, Bin bin, const Interpolator & interp = Interpolator::linear() ) const;
+	MF getBinInterpolated( Channel channel, Frame frame, fBin bin, const Interpolator & interp = Interpolator::linear() ) const;
+
 	// ---- conversions ----
 	/** Phase accumulation, inverse FFT, Hann window, overlap-add (Conversions/AudioPV.cpp:86-139).  A NaN/Inf in the data
 	 *  prints the reference's warning and processing carries on. */

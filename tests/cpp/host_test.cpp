@@ -122,6 +122,10 @@ static void no_device_checks()
 	CHECK( p.get_MF_pointer( 0, 2, 4 )->m == -7.0f && p.get_max_partial_magnitude() == 7.0f && p.get_max_partial_magnitude( 0, 2 ) == 3.0f );
 	CHECK( p.channel_end( 0 ) - p.channel_begin( 0 ) == 15 && p.bound_bin( 99 ) == 4 && p.bound_frame( -3 ) == 0 && p.bound_channel( 5 ) == 0 );
 	CHECK( p.get_frequency_offset( 0, 1, 2 ) == 440.0f - 12000.0f );
+	p.set_MF( 0, 1, 3, MF{ 5.0f, 500.0f } );
+	CHECK( p.getBinInterpolated( 0, Frame( 1 ), 2.5f ).m == 0.5f * 3.0f + 0.5f * 5.0f && p.getBinInterpolated( 0, 1.0f, Bin( 2 ) ).f == 440.0f );
+	CHECK( p.getBinInterpolated( 0, 0.5f, 2.5f ).m == 0.5f * ( 0.5f * 0.0f + 0.5f * 3.0f ) + 0.5f * ( 0.5f * 0.0f + 0.5f * 5.0f ) );
+	CHECK( p.sample_function_over_time_domain( Function<Second, float>( []( Second t ){ return t * 2.0f; } ) ).size() == 3 );
 	Audio tiny = Audio::create_from_buffer( { 0.5f, -2.0f, 0.25f, 1.0f, 0.0f, -0.75f }, 2, 48000.0f );
 	CHECK( tiny.get_max_sample_magnitude() == 2.0f && !tiny.is_nan_or_inf() && tiny.time_to_frame( 0.5f ) == 24000.0f && tiny.frame_to_time( 48.0f ) == 0.001f );
 	CHECK( *tiny.get_sample_pointer( 1, 0 ) == 1.0f && tiny.channel_end( 1 ) - tiny.channel_begin( 1 ) == 3 );
