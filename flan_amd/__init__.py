@@ -36,6 +36,7 @@ _SIGS = {
     "flanhip_last_error": (C.c_char_p, []),
     "flanhip_device_count": (C.c_int, []),
     "flanhip_set_device": (C.c_int, [_i32]),
+    "flanhip_get_device": (C.c_int, [C.POINTER(C.c_int)]),
     "flanhip_num_pv_frames": (_i64, [_i64, _i32]),
     "flanhip_hop_size": (C.c_int, [_f32, _f32]),
     "flanhip_modify_time_out_frames": (_i64, [_vp, _i64, _i32, _f32, _i32]),

@@ -187,6 +187,14 @@ int flanhip_set_device( int device )
 	return FLANHIP_OK;
 	}
 
+int flanhip_get_device( int * device )
+	{
+	FLANHIP_REQUIRE( device, FLANHIP_ERR_INVALID_ARG, "null out pointer" );
+	if( int rc = require_device() ) return rc;
+	FLANHIP_CHECK( hipGetDevice( device ) );
+	return FLANHIP_OK;
+	}
+
 int64_t flanhip_num_pv_frames( int64_t num_audio_frames, int hop )
 	{
 	if( hop <= 0 || num_audio_frames < 0 ) return -1;

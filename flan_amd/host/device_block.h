@@ -10,8 +10,8 @@ namespace flan { namespace detail {
 
 // host_runtime.cpp: blocks come from, and go back to, a cache of idle HBM blocks (every method synchronises before it returns,
 // so a block whose owner dies is idle); flanhip_malloc / flanhip_free only when the cache cannot serve.
-void * device_acquire( size_t bytes, size_t * capacity );   // nullptr on failure (flanhip_last_error() says why)
-void device_release( void * ptr, size_t capacity ) noexcept;
+void * device_acquire( size_t bytes, size_t * capacity, int * device );   // nullptr on failure (flanhip_last_error() says why)
+void device_release( void * ptr, size_t capacity, int device ) noexcept;
 void device_cache_flush() noexcept;
 // Transfers between ordinary (pageable) host memory and the device (flanhip_download / flanhip_upload).  Synchronous.
 bool download_to_host( void * dst, const void * d_src, size_t bytes );
@@ -26,15 +26,16 @@ struct DeviceBlock
 	void * ptr = nullptr;
 	size_t bytes = 0;                                          // what was asked for
 	size_t capacity = 0;                                       // what the block holds
+	int device = 0;                                            // where it lives
 	DeviceBlock() = default;
 	DeviceBlock( const DeviceBlock & ) = delete;
 	DeviceBlock & operator=( const DeviceBlock & ) = delete;
-	~DeviceBlock() { if( ptr ) device_release( ptr, capacity ); }
+	~DeviceBlock() { if( ptr ) device_release( ptr, capacity, device ); }
 
 	static std::shared_ptr<DeviceBlock> allocate( size_t bytes )
 		{
 		auto b = std::make_shared<DeviceBlock>();
-		b->ptr = device_acquire( bytes, &b->capacity );
+		b->ptr = device_acquire( bytes, &b->capacity, &b->device );
 		if( !b->ptr )
 			{
 			std::cerr << "flan: device allocation of " << bytes << " bytes failed: " << flanhip_last_error() << std::endl;

@@ -43,7 +43,8 @@ Staging & staging() { static Staging * s = new Staging; return *s; }
 struct DeviceCache
 	{
 	std::mutex m;
-	std::vector<std::pair<void*, size_t>> spare;
+	struct Idle { void * ptr; size_t capacity; int device; };
+	std::vector<Idle> spare;                                     // a block goes back only to the device it came from
 	size_t spare_bytes = 0;
 	size_t keep = size_t( 16 ) << 30;                            // FLAN_DEVICE_CACHE_MB overrides; 0 = no cache
 	DeviceCache() { if( const char * e = std::getenv( "FLAN_DEVICE_CACHE_MB" ) ) keep = size_t( std::max( 0L, std::atol( e ) ) ) << 20; }
@@ -57,19 +58,23 @@ DeviceCache & device_cache() { static DeviceCache * c = new DeviceCache; return 
 
 } // namespace
 
-void * device_acquire( size_t bytes, size_t * capacity )
+void * device_acquire( size_t bytes, size_t * capacity, int * device )
 	{
 	DeviceCache & c = device_cache();
 	const size_t want = DeviceCache::round_up( bytes );
+	int current = 0;
+	if( flanhip_get_device( &current ) != FLANHIP_OK ) return nullptr;                // no device: flanhip_last_error() says so
+	*device = current;
 		{
 		std::lock_guard<std::mutex> g( c.m );
 		size_t best = c.spare.size();
-		for( size_t i = 0; i < c.spare.size(); ++i )               // smallest idle block that fits without wasting more than an eighth
-			if( c.spare[i].second >= want && c.spare[i].second - want <= want / 8 && ( best == c.spare.size() || c.spare[i].second < c.spare[best].second ) ) best = i;
+		for( size_t i = 0; i < c.spare.size(); ++i )               // smallest idle block of this device that fits without wasting more than an eighth
+			if( c.spare[i].device == current && c.spare[i].capacity >= want && c.spare[i].capacity - want <= want / 8
+				&& ( best == c.spare.size() || c.spare[i].capacity < c.spare[best].capacity ) ) best = i;
 		if( best != c.spare.size() )
 			{
-			void * p = c.spare[best].first;
-			*capacity = c.spare[best].second;
+			void * p = c.spare[best].ptr;
+			*capacity = c.spare[best].capacity;
 			c.spare_bytes -= *capacity;
 			c.spare[best] = c.spare.back(); c.spare.pop_back();
 			return p;
@@ -78,7 +83,6 @@ void * device_acquire( size_t bytes, size_t * capacity )
 	void * p = nullptr;
 	if( flanhip_malloc( &p, want ) != FLANHIP_OK || !p )
 		{
-		if( flanhip_device_count() <= 0 ) return nullptr;
 		device_cache_flush();                                      // out of memory with idle blocks held back: release them and try once more
 		p = nullptr;
 		if( flanhip_malloc( &p, want ) != FLANHIP_OK || !p ) return nullptr;
@@ -87,13 +91,13 @@ void * device_acquire( size_t bytes, size_t * capacity )
 	return p;
 	}
 
-void device_release( void * ptr, size_t capacity ) noexcept
+void device_release( void * ptr, size_t capacity, int device ) noexcept
 	{
 	if( !ptr ) return;
 	DeviceCache & c = device_cache();
 		{
 		std::lock_guard<std::mutex> g( c.m );
-		if( c.spare_bytes + capacity <= c.keep ) { c.spare.emplace_back( ptr, capacity ); c.spare_bytes += capacity; return; }
+		if( c.spare_bytes + capacity <= c.keep ) { c.spare.push_back( DeviceCache::Idle{ ptr, capacity, device } ); c.spare_bytes += capacity; return; }
 		}
 	flanhip_free( ptr );
 	}
@@ -101,13 +105,13 @@ void device_release( void * ptr, size_t capacity ) noexcept
 void device_cache_flush() noexcept
 	{
 	DeviceCache & c = device_cache();
-	std::vector<std::pair<void*, size_t>> drop;
+	std::vector<DeviceCache::Idle> drop;
 		{
 		std::lock_guard<std::mutex> g( c.m );
 		drop.swap( c.spare );
 		c.spare_bytes = 0;
 		}
-	for( auto & s : drop ) flanhip_free( s.first );
+	for( auto & s : drop ) flanhip_free( s.ptr );
 	}
 
 CopyStreams copy_streams()

@@ -47,6 +47,7 @@ int          flanhip_version(void);                 /* 10000*major + 100*minor +
 const char * flanhip_last_error(void);
 int          flanhip_device_count(void);            /* 0 when no device; never fails   */
 int          flanhip_set_device(int device);
+int          flanhip_get_device(int * device);      /* the calling thread's current device */
 
 /* ---- shape helpers (pure host arithmetic, usable without a device) ---------------------------------------- */
 /* Conversions/AudioPV.cpp:17   numHops = ceil( num_frames / hop ) + 1, INTEGER division */
