@@ -93,7 +93,7 @@ warp = torch.empty((F, BINS, 2), dtype=torch.float32, device=dev)               
 warp[..., 0] = (torch.arange(F, device=dev, dtype=torch.float32) / (SR / HOP))[:, None] * 2.0
 warp[..., 1] = (torch.arange(BINS, device=dev, dtype=torch.float32) * (SR / DFT))[None, :] * 1.2
 warp_f = (pv[..., 1] * 1.2).contiguous()
-warp_Fo = int(lib.flanhip_modify_out_frames(fa._vp(warp.cpu().numpy().ctypes.data), F, BINS, SR, HOP)) if False else 2 * (F - 1)
+warp_Fo = 2 * (F - 1)                                                            # = flanhip_modify_out_frames of this grid
 warp_out = torch.empty((ch, warp_Fo, BINS, 2), dtype=torch.float32, device=dev)
 import numpy as _np
 sp_steps = _np.full(F - 1, 2, _np.uint32)
