@@ -70,3 +70,11 @@ def test_config5_small(fa):
     rms = float(np.sqrt(np.mean((out_g.astype(np.float64) - out_r.astype(np.float64)) ** 2)))
     print("\n[config5-small] P2 rms %.3e" % rms)
     assert rms <= 1e-5
+
+
+def test_resample_fixture(fa):
+    """the committed vectors of tests/golden/resample.npz through the GPU library: bit for bit"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "resample.npz"))
+    assert np.array_equal(fa.resample(g["x96"], 96000.0, 48000.0).view(np.uint32), g["y48"].view(np.uint32))
+    assert np.array_equal(fa.resample(g["x32"], 32000.0, 48000.0).view(np.uint32), g["y48_from_32"].view(np.uint32))
