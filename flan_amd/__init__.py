@@ -83,6 +83,8 @@ _SIGS = {
     "flanhip_n_loudest_partials_dev": (C.c_int, [_vp, _i64, _i64, _i32, _vp, C.c_int32, _i32, _vp, _vp]),
     "flanhip_desample_dev": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _f32, _i32, _vp, _vp]),
     "flanhip_time_extrapolate_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "flanhip_shape_affine_dev_fused": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _i32, _vp, _vp]),
+    "flanhip_shape_table_dev_fused": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _f32, _f32, _vp, _i32, _vp, _vp]),
     "flanhip_get_frame_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i32, _vp, _vp]),
     "flanhip_select_frames_dev": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp]),
     "flanhip_freeze_plan": (_i64, [_i64, _f32, _i32, _vp, _vp, _i32, _vp]),

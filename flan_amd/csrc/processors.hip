@@ -420,6 +420,56 @@ __global__ __launch_bounds__( 256 ) void k_shape_plain( const MFd * in, const MF
 	else out[idx] = shaped_tbl[idx];
 	}
 
+// The same without alignment, walking chains: one thread per ( channel, chain of L frames, bin ) -- lanes are adjacent bins, so every
+// step moves whole coalesced row segments -- writes its frames in order and leaves convert_to_audio's pre-pass for the new PV in the
+// synthesis workspace: the chain's phase sum, bit for bit what k_phase_sums2 would compute from the output, and the NaN / Inf flag.
+struct ShapeChainParams
+	{
+	const MFd * in; const MFd * tbl; MFd * out;
+	int64_t F;
+	int num_channels, bins, L, chains_per_channel;
+	float a, b, c, d, analysis_rate;
+	double * sums;            // [ch][chains][bins]
+	int * words;              // workspace tail: [0] NaN flag, [2] epoch, [4] "sums valid" (set iff equal to the epoch)
+	int epoch;
+	};
+
+template<bool AFFINE>
+__global__ __launch_bounds__( 256 ) void k_shape_plain_chains( ShapeChainParams p )
+	{
+	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
+	const int64_t per_channel = int64_t( p.chains_per_channel ) * p.bins;
+	bool bad = false;
+	if( idx < per_channel * p.num_channels )
+		{
+		const int channel = int( idx / per_channel ), chain = int( ( idx % per_channel ) / p.bins ), bin = int( idx % p.bins );
+		const int64_t x_lo = int64_t( chain ) * p.L, x_hi = min( x_lo + p.L, p.F );
+		const int64_t base = int64_t( channel ) * p.F * p.bins + bin;
+		double ph = 0.0;
+		int summed = 0;
+		const int groups = int( x_hi - x_lo ) & ~7;
+		#pragma unroll 4
+		for( int64_t x = x_lo; x < x_hi; ++x )
+			{
+			const int64_t at = base + x * p.bins;
+			MFd v;
+			if( AFFINE ) { const MFd u = p.in[at]; v = MFd{ p.a * u.m + p.b, p.c * u.f + p.d }; }   // PV.cpp:436, :452
+			else v = p.tbl[at];
+			p.out[at] = v;
+			bad |= !( fabsf( v.m ) <= 3.4028235e38f ) || !( fabsf( v.f ) <= 3.4028235e38f );
+			ph += double( v.f / p.analysis_rate * FLANHIP_PI2_F );                  // phase_vocoder.cpp:57 (k_phase_sums2's term)
+			++summed;
+			// k_phase_sums2 keeps its partial sum small after every full group of 8 frames of the chain
+			if( ( summed & 7 ) == 0 && summed <= groups && !( fabs( ph ) < 1.0e8 ) ) ph = fold_phase_any( ph );
+			}
+		p.sums[( int64_t( channel ) * p.chains_per_channel + chain ) * p.bins + bin] =
+			( fabs( ph ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( ph ) : fold_phase_any( ph );
+		}
+	const bool any_bad = __any( bad );
+	if( ( threadIdx.x & 63 ) == 0 && any_bad ) p.words[0] = p.epoch;
+	if( blockIdx.x == 0 && threadIdx.x == 0 ) { p.words[2] = p.epoch; p.words[4] = p.epoch; }
+	}
+
 // Shift alignment (PV.cpp:438-448): one WAVEFRONT per (channel, frame) row; the sequential "strictly louder replaces" rule is
 // resolved through LDS keys (processors_common.h placement_offer).  keys: dynamic LDS, bins u64 per wave.
 template<bool AFFINE>
@@ -693,6 +743,41 @@ int flanhip_shape_table_dev( const flanhip_MF * d_pv, const flanhip_MF * d_shape
 	{
 	FLANHIP_REQUIRE( d_shaped, FLANHIP_ERR_INVALID_ARG, "null shaped table" );
 	return shape_common( d_pv, d_shaped, false, ch, F, bins, sr, 0, 0, 0, 0, align, d_out, (hipStream_t) stream );
+	}
+
+static int shape_fused( const flanhip_MF * d_pv, const flanhip_MF * d_tbl, bool affine, int64_t ch, int64_t F, int bins, float sr, float analysis_rate,
+	float a, float b, float c, float d, flanhip_MF * d_out, int window_size, void * d_ws, hipStream_t s )
+	{
+	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, sr ) ) return rc;
+	FLANHIP_REQUIRE( d_ws && analysis_rate > 0.0f, FLANHIP_ERR_INVALID_ARG, "bad workspace / analysis rate" );
+	SynthLayout lay;                                                               // the chains convert_to_audio will cut the result into
+	if( int rc = synth_layout( ch, F, bins, sr, analysis_rate, window_size, &lay ) ) return rc;
+	ShapeChainParams p{};
+	p.in = (const MFd*) d_pv; p.tbl = (const MFd*) d_tbl; p.out = (MFd*) d_out;
+	p.F = F; p.num_channels = int( ch ); p.bins = bins; p.L = lay.L; p.chains_per_channel = lay.chains_per_channel;
+	p.a = a; p.b = b; p.c = c; p.d = d; p.analysis_rate = analysis_rate;
+	p.sums = reinterpret_cast<double*>( d_ws );
+	p.words = reinterpret_cast<int*>( reinterpret_cast<char*>( d_ws ) + lay.carry_bytes + lay.head_bytes );
+	p.epoch = next_epoch();
+	const int64_t owners = ch * int64_t( lay.chains_per_channel ) * bins;
+	FLANHIP_REQUIRE( ( owners + 255 ) / 256 < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains" );
+	if( affine ) hipLaunchKernelGGL( k_shape_plain_chains<true>, dim3( (unsigned) ( ( owners + 255 ) / 256 ) ), dim3( 256 ), 0, s, p );
+	else         hipLaunchKernelGGL( k_shape_plain_chains<false>, dim3( (unsigned) ( ( owners + 255 ) / 256 ) ), dim3( 256 ), 0, s, p );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+int flanhip_shape_affine_dev_fused( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float analysis_rate, float a, float b, float c, float d,
+	flanhip_MF * d_out, int window_size, void * d_ws, void * stream )
+	{
+	return shape_fused( d_pv, nullptr, true, ch, F, bins, sr, analysis_rate, a, b, c, d, d_out, window_size, d_ws, (hipStream_t) stream );
+	}
+
+int flanhip_shape_table_dev_fused( const flanhip_MF * d_pv, const flanhip_MF * d_shaped, int64_t ch, int64_t F, int bins, float sr, float analysis_rate,
+	flanhip_MF * d_out, int window_size, void * d_ws, void * stream )
+	{
+	FLANHIP_REQUIRE( d_shaped, FLANHIP_ERR_INVALID_ARG, "null shaped table" );
+	return shape_fused( d_pv, d_shaped, false, ch, F, bins, sr, analysis_rate, 0, 0, 0, 0, d_out, window_size, d_ws, (hipStream_t) stream );
 	}
 
 int flanhip_shape_affine( const flanhip_MF * pv, int64_t ch, int64_t F, int bins, float sr, float a, float b, float c, float d,

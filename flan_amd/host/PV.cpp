@@ -317,10 +317,19 @@ PV PV::shape( const Function<MF, MF> & shaper, bool use_shift_alignment ) const
 	const MF * d_pv = device_data();
 	auto out = DeviceBlock::allocate( sizeof( MF ) * size_t( get_num_channels() ) * get_num_frames() * get_num_bins() );
 	if( !d_shaped || !d_pv || !out ) return PV();
-	if( !detail::report( flanhip_shape_table_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), static_cast<const flanhip_MF*>( d_shaped->ptr ), get_num_channels(),
-			get_num_frames(), get_num_bins(), get_sample_rate(), use_shift_alignment ? 1 : 0, static_cast<flanhip_MF*>( out->ptr ), nullptr ), "shape" ) ) return PV();
+	// without alignment the kernel that writes the result can leave convert_to_audio's pre-pass for it in a workspace
+	const size_t ws_bytes = use_shift_alignment ? 0 : flanhip_synthesize_workspace_bytes( get_num_channels(), get_num_frames(), get_num_bins(), get_sample_rate(), get_analysis_rate(), get_window_size() );
+	auto ws = ws_bytes ? DeviceBlock::allocate( ws_bytes ) : nullptr;
+	const int rc = ws
+		? flanhip_shape_table_dev_fused( reinterpret_cast<const flanhip_MF*>( d_pv ), static_cast<const flanhip_MF*>( d_shaped->ptr ), get_num_channels(), get_num_frames(),
+			get_num_bins(), get_sample_rate(), get_analysis_rate(), static_cast<flanhip_MF*>( out->ptr ), get_window_size(), ws->ptr, nullptr )
+		: flanhip_shape_table_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), static_cast<const flanhip_MF*>( d_shaped->ptr ), get_num_channels(),
+			get_num_frames(), get_num_bins(), get_sample_rate(), use_shift_alignment ? 1 : 0, static_cast<flanhip_MF*>( out->ptr ), nullptr );
+	if( !detail::report( rc, "shape" ) ) return PV();
 	if( !detail::report( flanhip_stream_synchronize( nullptr ), "shape" ) ) return PV();
-	return PVBuffer::adopt_device( get_format(), std::move( out ) );
+	PV result = PVBuffer::adopt_device( get_format(), std::move( out ) );
+	if( ws ) result.attach_synthesis_workspace( std::move( ws ) );
+	return result;
 	}
 
 PV PV::shape_affine( float a, float b, float c, float d, bool use_shift_alignment ) const
@@ -329,10 +338,18 @@ PV PV::shape_affine( float a, float b, float c, float d, bool use_shift_alignmen
 	const MF * d_pv = device_data();
 	auto out = DeviceBlock::allocate( sizeof( MF ) * size_t( get_num_channels() ) * get_num_frames() * get_num_bins() );
 	if( !d_pv || !out ) return PV();
-	if( !detail::report( flanhip_shape_affine_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(), get_sample_rate(),
-			a, b, c, d, use_shift_alignment ? 1 : 0, static_cast<flanhip_MF*>( out->ptr ), nullptr ), "shape_affine" ) ) return PV();
+	const size_t ws_bytes = use_shift_alignment ? 0 : flanhip_synthesize_workspace_bytes( get_num_channels(), get_num_frames(), get_num_bins(), get_sample_rate(), get_analysis_rate(), get_window_size() );
+	auto ws = ws_bytes ? DeviceBlock::allocate( ws_bytes ) : nullptr;
+	const int rc = ws
+		? flanhip_shape_affine_dev_fused( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(), get_sample_rate(), get_analysis_rate(),
+			a, b, c, d, static_cast<flanhip_MF*>( out->ptr ), get_window_size(), ws->ptr, nullptr )
+		: flanhip_shape_affine_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(), get_sample_rate(),
+			a, b, c, d, use_shift_alignment ? 1 : 0, static_cast<flanhip_MF*>( out->ptr ), nullptr );
+	if( !detail::report( rc, "shape_affine" ) ) return PV();
 	if( !detail::report( flanhip_stream_synchronize( nullptr ), "shape_affine" ) ) return PV();
-	return PVBuffer::adopt_device( get_format(), std::move( out ) );
+	PV result = PVBuffer::adopt_device( get_format(), std::move( out ) );
+	if( ws ) result.attach_synthesis_workspace( std::move( ws ) );
+	return result;
 	}
 
 // ---------------------------------------------------------------------------------------------------------------------

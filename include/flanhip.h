@@ -185,6 +185,14 @@ int flanhip_shape_affine_dev(const flanhip_MF * d_pv, int64_t num_channels, int6
 int flanhip_shape_table_dev(const flanhip_MF * d_pv, const flanhip_MF * d_shaped, int64_t num_channels,
                             int64_t num_pv_frames, int num_bins, float sample_rate, int use_shift_alignment,
                             flanhip_MF * d_out, void * stream);
+/* The same without shift alignment, leaving PV::convert_to_audio's pre-pass for the RESULT in a synthesis workspace (d_ws of
+ * flanhip_synthesize_workspace_bytes for the result's shape): follow with flanhip_synthesize_dev_fused on d_out. */
+int flanhip_shape_affine_dev_fused(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_frames, int num_bins, float sample_rate,
+                                   float analysis_rate, float a, float b, float c, float d, flanhip_MF * d_out, int window_size,
+                                   void * d_ws, void * stream);
+int flanhip_shape_table_dev_fused(const flanhip_MF * d_pv, const flanhip_MF * d_shaped, int64_t num_channels, int64_t num_frames,
+                                  int num_bins, float sample_rate, float analysis_rate, flanhip_MF * d_out, int window_size,
+                                  void * d_ws, void * stream);
 
 /* ---- further PV frame processors.  User functions are SAMPLED BY THE CALLER, as the reference samples
  * them on the host before its loops (PV.h:31-35, Function.h:141-171): a grid pointer, or NULL plus a constant. ------------- */

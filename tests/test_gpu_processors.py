@@ -314,3 +314,50 @@ def test_modify_time_edge_shapes(fa):
         if ref.size:
             same, rel = report("modify_time/" + name, got, ref)
             assert same == 1.0, name
+
+
+@pytest.mark.parametrize("dft,hop", [(2048, 512), (1024, 256), (4096, 128), (2048, 300)])
+def test_shape_fused_prepass(fa, dft, hop):
+    """flanhip_shape_affine_dev_fused / flanhip_shape_table_dev_fused leave convert_to_audio's pre-pass for their result in the
+    workspace: the same PV as the plain calls and the very same audio as the plain pair, NaN flag included"""
+    import ctypes as C
+    lib = fa.lib
+    rng = np.random.default_rng(dft * 3 + hop)
+    W = min(dft, 2048)
+    pv = O.analyze(O.noise(2, 57 * hop + 5, seed=hop), SR, W, hop, dft)
+    ch, F, bins, _ = pv.shape
+    ar = np.float32(SR) / np.float32(hop)
+    table = np.stack([pv[..., 0] * rng.uniform(0, 2, pv.shape[:3]).astype(np.float32), pv[..., 1] + rng.uniform(-300, 300, pv.shape[:3]).astype(np.float32)], -1).astype(np.float32)
+    P = lambda d: C.c_void_p(d.ptr)
+
+    def run(src, fused, use_table):
+        d_pv, d_tbl = fa.DeviceArray(host=src), fa.DeviceArray(host=table)
+        d_sh, d_out = fa.DeviceArray(src.nbytes), fa.DeviceArray(ch * F * hop * 4)
+        d_ws = fa.DeviceArray(fa.synthesize_workspace_bytes(ch, F, bins, SR, float(ar), W))
+        d_flag = fa.DeviceArray(host=np.zeros(1, np.int32))
+        if fused:
+            if use_table:
+                fa.check(lib.flanhip_shape_table_dev_fused(P(d_pv), P(d_tbl), ch, F, bins, SR, ar, P(d_sh), W, P(d_ws), None))
+            else:
+                fa.check(lib.flanhip_shape_affine_dev_fused(P(d_pv), ch, F, bins, SR, ar, 0.5, 0.25, 1.0, 100.0, P(d_sh), W, P(d_ws), None))
+            fa.check(lib.flanhip_synthesize_dev_fused(P(d_sh), ch, F, bins, SR, ar, W, P(d_out), P(d_ws), P(d_flag), None))
+        else:
+            if use_table:
+                fa.check(lib.flanhip_shape_table_dev(P(d_pv), P(d_tbl), ch, F, bins, SR, 0, P(d_sh), None))
+            else:
+                fa.check(lib.flanhip_shape_affine_dev(P(d_pv), ch, F, bins, SR, 0.5, 0.25, 1.0, 100.0, 0, P(d_sh), None))
+            fa.check(lib.flanhip_synthesize_dev(P(d_sh), ch, F, bins, SR, ar, W, P(d_out), P(d_ws), P(d_flag), None))
+        return d_sh.to_host(src.shape), d_out.to_host((ch, F * hop)), int(d_flag.to_host((1,), np.int32)[0])
+
+    for use_table in (False, True):
+        sh_a, out_a, flag_a = run(pv, False, use_table)
+        sh_b, out_b, flag_b = run(pv, True, use_table)
+        ref = table if use_table else O.shape_affine(pv, SR, 0.5, 0.25, 1.0, 100.0, False)
+        assert np.array_equal(sh_a.view(np.uint32), ref.view(np.uint32)) and np.array_equal(sh_b.view(np.uint32), ref.view(np.uint32)), use_table
+        assert np.array_equal(out_a.view(np.uint32), out_b.view(np.uint32)), use_table
+        assert flag_a == 0 and flag_b == 0
+    bad = pv.copy()
+    bad[1, 9, 13, 1] = np.inf
+    _, _, flag_a = run(bad, False, False)
+    _, _, flag_b = run(bad, True, False)
+    assert flag_a == 1 and flag_b == 1

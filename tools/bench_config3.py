@@ -40,6 +40,8 @@ sh = torch.empty_like(pv)
 grid_t = torch.empty((F, BINS), dtype=torch.float32, device=dev)      # the x2 time map, kept for the hand-over stage (grid is reused below)
 fa.check(lib.flanhip_fill_dev(P(grid_t), F * BINS, 2.0, None))
 fa.check(lib.flanhip_stretch_map_dev(P(grid_t), F, BINS, SR, HOP, P(dmax), None))
+ws_sh = torch.empty(fa.synthesize_workspace_bytes(ch, F, BINS, SR, ar, W), dtype=torch.uint8, device=dev)
+out_sh = torch.empty((ch, F * HOP), dtype=torch.float32, device=dev)
 stages = {
     "convert_to_PV": lambda: fa.check(lib.flanhip_analyze_dev(P(audio), ch, n, SR, W, HOP, DFT, P(pv), None)),
     "stretch: fill+map": lambda: (fa.check(lib.flanhip_fill_dev(P(grid), F * BINS, 2.0, None)),
@@ -55,6 +57,12 @@ stages = {
     "repitch: fused (fill + scan + modify_frequency)": lambda: (fa.check(lib.flanhip_fill_dev(P(grid), F * BINS, 2.0, None)),
                                                                 fa.check(lib.flanhip_repitch_dev(P(pv), ch, F, BINS, SR, P(grid), P(rp), None))),
     "shape(f+100)": lambda: fa.check(lib.flanhip_shape_affine_dev(P(pv), ch, F, BINS, SR, 1.0, 0.0, 1.0, 100.0, 0, P(sh), None)),
+    "shape(f+100) + convert_to_audio, pre-pass handed over": lambda: (
+        fa.check(lib.flanhip_shape_affine_dev_fused(P(pv), ch, F, BINS, SR, ar, 1.0, 0.0, 1.0, 100.0, P(sh), W, P(ws_sh), None)),
+        fa.check(lib.flanhip_synthesize_dev_fused(P(sh), ch, F, BINS, SR, ar, W, P(out_sh), P(ws_sh), None, None))),
+    "shape(f+100) + convert_to_audio, separate": lambda: (
+        fa.check(lib.flanhip_shape_affine_dev(P(pv), ch, F, BINS, SR, 1.0, 0.0, 1.0, 100.0, 0, P(sh), None)),
+        fa.check(lib.flanhip_synthesize_dev(P(sh), ch, F, BINS, SR, ar, W, P(out_sh), P(ws_sh), None, None))),
     "shape(f*2, aligned)": lambda: fa.check(lib.flanhip_shape_affine_dev(P(pv), ch, F, BINS, SR, 1.0, 0.0, 2.0, 0.0, 1, P(sh), None)),
 }
 # further frame processors on the same 8 ch x 60 s PV: ms and the HBM rate of the MF traffic (8 B in + 8 B out)
