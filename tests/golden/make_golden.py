@@ -89,7 +89,7 @@ def main():
     # and one up-sampling ratio; the resampler restated in oracle/resample_oracle.cpp is itself pinned against the vendored r8brain
     x96 = O.noise(2, 9600, 21)
     x32 = O.noise(2, 3200, 22)
-    np.savez_compressed(os.path.join(HERE, "resample.npz"), x96=x96, y48=O.resample_2to1(x96, 96000.0, 48000.0),
+    np.savez_compressed(os.path.join(HERE, "processors", "resample.npz"), x96=x96, y48=O.resample_2to1(x96, 96000.0, 48000.0),
                         x32=x32, y48_from_32=O.resample_rational(x32, 32000.0, 48000.0, 3, 2))
     small = O.analyze(O.noise(2, 4000, 17), SR, 256, 256, 256)
     np.savez_compressed(os.path.join(HERE, "processors", "processors_arrange.npz"), **arrange_cases(small))

@@ -73,8 +73,8 @@ def test_config5_small(fa):
 
 
 def test_resample_fixture(fa):
-    """the committed vectors of tests/golden/resample.npz through the GPU library: bit for bit"""
+    """the committed vectors of tests/golden/processors/resample.npz through the GPU library: bit for bit"""
     import os
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "resample.npz"))
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "processors", "resample.npz"))
     assert np.array_equal(fa.resample(g["x96"], 96000.0, 48000.0).view(np.uint32), g["y48"].view(np.uint32))
     assert np.array_equal(fa.resample(g["x32"], 32000.0, 48000.0).view(np.uint32), g["y48_from_32"].view(np.uint32))

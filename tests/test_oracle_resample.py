@@ -85,9 +85,9 @@ def test_filter_lengths_of_the_other_cutoffs():
 
 
 def test_checker_reproduces_the_resample_fixture():
-    """tests/golden/resample.npz (96 -> 48 kHz of a 2-channel 0.1 s buffer, plus 32 -> 48 kHz): the checker must not drift"""
+    """tests/golden/processors/resample.npz (96 -> 48 kHz of a 2-channel 0.1 s buffer, plus 32 -> 48 kHz): the checker must not drift"""
     import os
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "resample.npz"))
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "processors", "resample.npz"))
     assert np.array_equal(O.resample_2to1(g["x96"], 96000.0, 48000.0).view(np.uint32), g["y48"].view(np.uint32))
     assert np.array_equal(O.resample_rational(g["x32"], 32000.0, 48000.0, 3, 2).view(np.uint32), g["y48_from_32"].view(np.uint32))
     # the bleed itself: the tail of channel 0's filter response lands in the first samples of channel 1
