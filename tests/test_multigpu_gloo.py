@@ -50,12 +50,14 @@ def _worker(rank, world, port, total_channels, n, result_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("total_channels", [4, 3])
-def test_channel_sharding_world2_gloo(tmp_path, total_channels):
+@pytest.mark.parametrize("world,total_channels", [(2, 4), (2, 3), (4, 8), (4, 6)])
+def test_channel_sharding_world2_gloo(tmp_path, world, total_channels):
+    """channel sharding + output all-gather over gloo with 2 and 4 ranks (even and uneven shards): the gathered buffer is the
+    one-process result bit for bit"""
     import oracle_lib as O
     n = 6000
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, total_channels, n, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, total_channels, n, str(tmp_path)), nprocs=world, join=True)
     gathered = np.load(os.path.join(str(tmp_path), "gathered.npy"))
     x = O.noise(total_channels, n, seed=1234)
     pv = O.analyze(x, 48000.0, 1024, 256, 1024)
