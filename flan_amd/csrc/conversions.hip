@@ -4,12 +4,19 @@
 #include <atomic>
 #include "pv_kernels.h"
 #include "pv_kernels_fast.h"
+#include <type_traits>
+#include "pv_kernels_v2.h"
 #include <algorithm>
 #include <cstdlib>
 
 namespace flanhip {
 
 static int g_synth_stage_mask = 0xF;             // flanhip_debug_synth_stages(): 1 sums, 2 scan, 4 main, 8 fix-up
+// flanhip_debug_kernel_variant(): which dft 2048 kernel generation a call launches (A/B runs in one process).
+// analysis: 0 = round-1 kernel (8-wave blocks, 2 wavefronts per SIMD); 1 / 2 / 3 = v2 with 12-wave blocks (3 per SIMD) evaluating
+// 4 / 2 / 8 bins at a time; 4 (the default) / 6 / 7 = v2 in 8-wave blocks, 8 / 16 / 4 bins at a time
+static int g_ana_variant = 4, g_syn_variant = 0;
+static int ana_variant_waves( int v ) { return v == 0 || v == 4 || v == 6 || v == 7 || v > 100 ? 8 : 12; }
 static constexpr size_t kMaxLds = 160 * 1024;   // gfx950: 160 KiB LDS per CU, one workgroup may take all of it
 
 // chains: the chains a block walks (one per wavefront; or ONE, walked by a team of several wavefronts, see k_analyze)
@@ -55,7 +62,59 @@ static int fast_target_chains( int dft, bool synth )
 	{
 	if( const char * env = std::getenv( "FLANHIP_TARGET_CHAINS" ) ) { const int v = std::atoi( env ); if( v > 0 ) return v; }
 	if( dft == 4096 ) return 256 * 4;
+	if( !synth ) return 256 * ana_variant_waves( g_ana_variant );
 	return 256 * 8;
+	}
+
+template<int WAVES, bool SUMS, int NV, int ABL = 0>
+static int run_analyze_v2( const AnalyzeParams & p, const FastTables & tb, hipStream_t s )
+	{
+	const size_t lds = V2Lds::bytes( WAVES );
+	static_assert( V2Lds::bytes( WAVES ) <= kMaxLds, "LDS budget" );
+	auto kern = k_analyze_v2<WAVES, SUMS, NV, ABL>;
+	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;
+	const int64_t blocks = ( chains + WAVES - 1 ) / WAVES;
+	FLANHIP_REQUIRE( blocks < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
+	hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( 64 * WAVES ), lds, s, p, tb );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+template<bool SUMS>
+static int run_analyze_v2_variant( int v, const AnalyzeParams & p, const FastTables & tb, hipStream_t s )
+	{
+	switch( v )
+		{
+		case 1: return run_analyze_v2<12, SUMS, 4>( p, tb, s );
+		case 2: return run_analyze_v2<12, SUMS, 2>( p, tb, s );
+		case 3: return run_analyze_v2<12, SUMS, 8>( p, tb, s );
+		case 4: return run_analyze_v2<8, SUMS, 8>( p, tb, s );
+		case 6: return run_analyze_v2<8, SUMS, 16>( p, tb, s );
+		case 7: return run_analyze_v2<8, SUMS, 4>( p, tb, s );
+#ifdef FLANHIP_ABLATIONS
+		case 101: return run_analyze_v2<8, SUMS, 8, 1>( p, tb, s );
+		case 102: return run_analyze_v2<8, SUMS, 8, 2>( p, tb, s );
+		case 104: return run_analyze_v2<8, SUMS, 8, 4>( p, tb, s );
+		case 108: return run_analyze_v2<8, SUMS, 8, 8>( p, tb, s );
+		case 116: return run_analyze_v2<8, SUMS, 8, 16>( p, tb, s );
+		case 132: return run_analyze_v2<8, SUMS, 8, 32>( p, tb, s );
+		case 106: return run_analyze_v2<8, SUMS, 8, 6>( p, tb, s );
+		case 124: return run_analyze_v2<8, SUMS, 8, 24>( p, tb, s );
+		case 163: return run_analyze_v2<8, SUMS, 8, 63>( p, tb, s );
+		case 164: return run_analyze_v2<8, SUMS, 8, 64>( p, tb, s );
+		case 228: return run_analyze_v2<8, SUMS, 8, 128>( p, tb, s );
+		case 292: return run_analyze_v2<8, SUMS, 8, 192>( p, tb, s );
+		case 139: return run_analyze_v2<8, SUMS, 8, 39>( p, tb, s );
+		case 107: return run_analyze_v2<8, SUMS, 8, 7>( p, tb, s );
+		case 356: return run_analyze_v2<8, SUMS, 8, 256>( p, tb, s );
+		case 1124: return run_analyze_v2<8, SUMS, 8, 1024>( p, tb, s );
+		case 1163: return run_analyze_v2<8, SUMS, 8, 1024 + 39>( p, tb, s );
+		case 612: return run_analyze_v2<8, SUMS, 8, 512>( p, tb, s );
+		case 868: return run_analyze_v2<8, SUMS, 8, 768>( p, tb, s );
+#endif
+		}
+	return FLANHIP_ERR_UNSUPPORTED;
 	}
 
 template<int LOG2C, int WAVES, bool SUMS>
@@ -178,6 +237,7 @@ int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int 
 	if( fast )
 		{
 		FastTables tb{ plan->d_tw1f, plan->d_tw3f, plan->d_tw2 };
+		if( dft == 2048 && g_ana_variant != 0 ) return p.sums ? run_analyze_v2_variant<true>( g_ana_variant, p, tb, s ) : run_analyze_v2_variant<false>( g_ana_variant, p, tb, s );
 		if( p.sums ) return dft == 2048 ? run_analyze_fast<10, kAnaWaves10, true>( p, tb, s ) : run_analyze_fast<11, kWaves11, true>( p, tb, s );
 		return dft == 2048 ? run_analyze_fast<10, kAnaWaves10, false>( p, tb, s ) : run_analyze_fast<11, kWaves11, false>( p, tb, s );
 		}
@@ -383,6 +443,18 @@ int flanhip_analyze( const float * audio, int64_t ch, int64_t n, float sr, int W
 	}
 
 void flanhip_debug_synth_stages( int mask ) { g_synth_stage_mask = mask & 0xF; }
+void flanhip_debug_kernel_variant( int which, int variant ) { if( which == 0 ) g_ana_variant = variant; else g_syn_variant = variant; }
+#ifdef FLANHIP_STAMPS
+// diagnostic build only: the per-section cycle sums of the stamped kernels (16 words; [15] = wavefronts that reported), then cleared
+int flanhip_debug_read_stamps( unsigned long long * out16 )
+	{
+	FLANHIP_CHECK( hipDeviceSynchronize() );
+	FLANHIP_CHECK( hipMemcpyFromSymbol( out16, HIP_SYMBOL( g_stamp_acc ), 16 * sizeof( unsigned long long ) ) );
+	unsigned long long zero[16] = { 0 };
+	FLANHIP_CHECK( hipMemcpyToSymbol( HIP_SYMBOL( g_stamp_acc ), zero, sizeof( zero ) ) );
+	return FLANHIP_OK;
+	}
+#endif
 
 size_t flanhip_synthesize_workspace_bytes( int64_t ch, int64_t F, int bins, float sr, float ar, int W )
 	{

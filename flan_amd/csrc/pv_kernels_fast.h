@@ -47,9 +47,12 @@ template<int LOG2C> struct FastLds
 	static constexpr size_t bytes( int waves, bool sums = false ) { return size_t( BUF + waves * BUF_LEN + ( sums && LOG2C < 11 ? waves * SUM_LEN : 0 ) ) * 8; }   // dft 4096 keeps the sums in registers
 	};
 
+// diagnostic builds (FLANHIP_STAMPS) pass a functor that reads the clock between the passes; the product passes nothing
+struct NoStamp { __device__ __forceinline__ void operator()( int ) const {} };
+
 // ---- the three FFT passes on the register array z[E] (natural layout in, natural layout out) -------------------
-template<int LOG2C>
-__device__ __forceinline__ void fft_fast( cf ( &z )[( 1 << LOG2C ) / 64], cf * buf, const cf * s_tw1, const cf * s_tw3, int lane )
+template<int LOG2C, class ST = NoStamp>
+__device__ __forceinline__ void fft_fast( cf ( &z )[( 1 << LOG2C ) / 64], cf * buf, const cf * s_tw1, const cf * s_tw3, int lane, ST && st = ST() )
 	{
 	constexpr int C = 1 << LOG2C;
 	constexpr int E = C / 64;
@@ -72,6 +75,7 @@ __device__ __forceinline__ void fft_fast( cf ( &z )[( 1 << LOG2C ) / 64], cf * b
 			}
 		}
 	wave_sync();
+	st( 1 );
 	// pass 1: radix 16, sub-transform length 16
 		{
 		cf v[PER][16];
@@ -96,6 +100,7 @@ __device__ __forceinline__ void fft_fast( cf ( &z )[( 1 << LOG2C ) / 64], cf * b
 			}
 		}
 	wave_sync();
+	st( 2 );
 	// pass 2: radix R3, sub-transform length 256; butterfly j = lane + 64 b, b < 4; result element j + 256 r = lane + 64 (b + 4 r)
 		{
 		const cf * rp = buf + padl;

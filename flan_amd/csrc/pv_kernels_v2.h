@@ -1,0 +1,458 @@
+// pv_kernels_v2.h -- second generation of the dft 2048 analysis / synthesis kernels (C = 1024 complex points per frame).
+//
+// Same chain decomposition and the same register-resident 16 x 16 x 4 transform as pv_kernels_fast.h; what changes is what
+// the round-1 profiles showed to be the limit: with 2 wavefronts per SIMD each wavefront spent most of its time stalled (LDS
+// round trips of the transposes, dependent fp32 chains) and the SIMD issued on only ~50 % of its cycles.  These kernels are
+// written for THREE wavefronts per SIMD (12-wave blocks, <= 168 VGPRs) and for fewer issue slots per frame:
+//   * a lane owns bin PAIRS ( k, C - k ), k = lane + 64 q, q < 8: the real-transform split of both bins shares its sums,
+//     differences and twiddle products (half the work of splitting each bin on its own), only the upper half of the spectrum
+//     crosses LDS for the mirror exchange, and lane 0's pair ( 0, C ) is DC / Nyquist; bin C/2 is the one bin left over;
+//   * no register copy of the next frame: a frame's samples are loaded INTO the registers of the spectrum as those die (the upper
+//     half right after the mirror exchange, z[q] as soon as pair q has been split), a whole frame ahead of their use;
+//   * chains whose frames all lie inside the signal (all but the first and last chain of a channel) take loads with a
+//     wave-uniform base and immediate offsets; the clamped / patched loads of the edge frames live in a second loop body;
+//   * per-bin constants (bin frequency, expected phase advance) come from an LDS table built in the prologue;
+//   * |z| = max * sqrt( 1 + q^2 ) with the q = min / max that atan2 needs anyway (no exponent juggling, never overflows);
+//   * roundf( x ) = trunc( x + copysign( 0.49999997, x ) ) (exhaustively equal, tools/check_round_trick.c);
+//   * the NaN / Inf scan rides on the fp64 sums (a non-finite f makes its sum non-finite) and a running maximum of m.
+#pragma once
+#include "pv_kernels_fast.h"
+
+namespace flanhip {
+
+struct V2Lds
+	{
+	static constexpr int C = 1024;
+	static constexpr int TW1 = 0;                          // [15][16]
+	static constexpr int TW3 = TW1 + 240;                  // [3][256]
+	static constexpr int W2H = TW3 + 768;                  // [512]   0.5 exp(-2 pi i k / 2C), k < C/2
+	static constexpr int WIN = W2H + 512;                  // [2048 floats]
+	static constexpr int KC = WIN + 1024;                  // analysis: [512] float4 { binf(k), expected(k), binf(C-k), expected(C-k) }
+	static constexpr int BUF = KC + 1024;
+	static constexpr int BUF_LEN = C + C / 16 + 1;
+	static constexpr size_t bytes( int waves ) { return size_t( BUF + waves * BUF_LEN ) * 8; }
+	};
+
+typedef float v4f_t __attribute__(( ext_vector_type( 4 ) ));
+
+#ifdef FLANHIP_STAMPS
+// Diagnostic build only (tools/scripts/build_diag.sh stamps): where does a frame spend its cycles?  s_memtime between the sections of the
+// frame loop, per-section sums in scalar registers, added to g_stamp_acc once per wavefront.  Never quote this build's run time.
+__device__ unsigned long long g_stamp_acc[16];
+struct Stamps
+	{
+	unsigned long long last, acc[12], t_begin, r_begin;
+	__device__ __forceinline__ static unsigned long long realtime()
+		{
+		unsigned long long t;
+		asm volatile( "s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"( t ) :: "memory" );
+		return t;
+		}
+	__device__ __forceinline__ static unsigned long long now()
+		{
+		unsigned long long t;
+		__builtin_amdgcn_sched_barrier( 0 );
+		asm volatile( "s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"( t ) :: "memory" );
+		__builtin_amdgcn_sched_barrier( 0 );
+		return t;
+		}
+	__device__ __forceinline__ void init() { for( int i = 0; i < 12; ++i ) acc[i] = 0; r_begin = realtime(); last = now(); t_begin = last; }
+	__device__ __forceinline__ void operator()( int i ) { const unsigned long long t = now(); acc[i] += t - last; last = t; }
+	__device__ __forceinline__ void flush( int lane )
+		{
+		const unsigned long long t_end = now(), r_end = realtime();
+		if( lane == 0 )
+			{
+			for( int i = 0; i < 12; ++i ) atomicAdd( &g_stamp_acc[i], acc[i] );
+			atomicAdd( &g_stamp_acc[12], t_end - t_begin );                    // shader-clock ticks of the wavefront's life
+			atomicAdd( &g_stamp_acc[13], r_end - r_begin );                    // the same span in 100 MHz ticks
+			atomicAdd( &g_stamp_acc[15], 1ull );
+			}
+		}
+	};
+#else
+struct Stamps
+	{
+	__device__ __forceinline__ void init() {}
+	__device__ __forceinline__ void operator()( int ) const {}
+	__device__ __forceinline__ void flush( int ) {}
+	};
+#endif
+
+// roundf for every float (ties away from zero): trunc( x + copysign( prev( 0.5 ), x ) )
+template<class V> __device__ __forceinline__ V round_half_away_v( V x )
+	{
+	constexpr int N = vec_traits<V>::N;
+	V r;
+	#pragma unroll
+	for( int i = 0; i < N; ++i ) r[i] = __builtin_truncf( x[i] + __builtin_copysignf( 0x1.fffffep-2f, x[i] ) );
+	return r;
+	}
+__device__ __forceinline__ float round_half_away( float x ) { return __builtin_truncf( x + __builtin_copysignf( 0x1.fffffep-2f, x ) ); }
+
+// phase = atan2( im, re ) exactly as atan2_fast_v; mag = max( |re|, |im| ) * sqrt( 1 + q^2 ), q = min / max (correctly rounded).
+// The maximum is clamped to 2^-126 for the reciprocal; a spectrum component below that (a denormal, or zero) keeps its magnitude
+// through p2 = ( max 2^126 )^2 < 1 in place of the 1:  mag = 2^-126 sqrt( p2 + q^2 )  (for every other input p2 clamps to exactly 1)
+template<class V> __device__ __forceinline__ void polar_v( V re, V im, V & phase, V & mag )
+	{
+	constexpr int N = vec_traits<V>::N;
+	const V ax = __builtin_elementwise_abs( re ), ay = __builtin_elementwise_abs( im );
+	const V mxu = __builtin_elementwise_max( ax, ay );
+	const V mx = __builtin_elementwise_max( mxu, vsplat<V>( 0x1p-126f ) );
+	const V mn = __builtin_elementwise_min( ax, ay );
+	V r;
+	#pragma unroll
+	for( int i = 0; i < N; ++i ) r[i] = __builtin_amdgcn_rcpf( mx[i] );
+	const V q0 = mn * r;
+	const V q = vfma( vfma( -q0, mx, mn ), r, q0 );
+	const V u = q * q;
+	const V t = mxu * vsplat<V>( 0x1p126f );
+	const V h = vfma( q, q, __builtin_elementwise_min( t * t, vsplat<V>( 1.0f ) ) );
+	V p = vsplat<V>( 0x1.7ec8b6p-9f );
+	p = vfma( p, u, vsplat<V>( -0x1.0c272ap-6f ) );
+	p = vfma( p, u, vsplat<V>( 0x1.61f9a0p-5f ) );
+	p = vfma( p, u, vsplat<V>( -0x1.3554c4p-4f ) );
+	p = vfma( p, u, vsplat<V>( 0x1.b4e022p-4f ) );
+	p = vfma( p, u, vsplat<V>( -0x1.230ab4p-3f ) );
+	p = vfma( p, u, vsplat<V>( 0x1.9978eep-3f ) );
+	p = vfma( p, u, vsplat<V>( -0x1.5554dcp-2f ) );
+	V a = vfma( q * u, p, q );
+	const V a1 = vsplat<V>( FLANHIP_PIO2_F ) - a;
+	#pragma unroll
+	for( int i = 0; i < N; ++i ) a[i] = ay[i] > ax[i] ? a1[i] : a[i];
+	const V a2 = vsplat<V>( FLANHIP_PI_F ) - a;
+	#pragma unroll
+	for( int i = 0; i < N; ++i )
+		{
+		phase[i] = __builtin_copysignf( __float_as_int( re[i] ) < 0 ? a2[i] : a[i], im[i] );
+		mag[i] = mx[i] * __builtin_amdgcn_sqrtf( h[i] );
+		}
+	}
+
+// =================================================================================================================
+// Audio::convert_to_PV (Conversions/AudioPV.cpp:12-78), dft 2048
+// =================================================================================================================
+// ABL (A/B builds only, 0 in the product): leave a phase out to see what it costs in place -- 1 the FFT passes, 2 atan2 / magnitude,
+// 4 the wrap arithmetic, 8 the MF stores, 16 the sample loads, 32 the mirror read; 64: the MFs of two pairs in one 16-byte store and
+// 128: two sample pairs in one 16-byte load; 1024: plain instead of non-temporal MF stores; 256: every frame of a chain stored over the chain's FIRST row (the same store
+// instructions, no stream of fresh lines to HBM); 512: every frame loaded from the chain's first frame (TIMING ONLY: wrong places)
+template<int WAVES, bool SUMS, int NV, int ABL = 0>
+__global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, FastTables tb )
+	{
+	using L = V2Lds;
+	constexpr int C = 1024, E = 16, H = 8, NT = 64 * WAVES;
+	constexpr int NP = NV / 2;                                                  // bin pairs evaluated together
+	static_assert( NV == 2 || NV == 4 || NV == 8 || NV == 16, "1, 2, 4 or 8 pairs at a time" );
+	typedef float VB __attribute__(( ext_vector_type( NV ) ));
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	cf * s = reinterpret_cast<cf*>( smem );
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int W = p.window_size, hop = p.hop;
+
+	// ---- tables (block-wide) --------------------------------------------------------------------------------------------
+	for( int i = tid; i < 240; i += NT ) s[L::TW1 + i] = tb.tw1[i];
+	for( int i = tid; i < 768; i += NT ) s[L::TW3 + i] = tb.tw3[i];
+	for( int i = tid; i < 512; i += NT ) { const cf w = tb.w2[i]; s[L::W2H + i] = mk( 0.5f * w.x, 0.5f * w.y ); }
+		{
+		float * win = reinterpret_cast<float*>( s + L::WIN );
+		for( int i = tid; i < 2 * C; i += NT ) win[i] = ( i < W ) ? p.window[i] : 0.0f;          // AudioPV.cpp:60,65
+		// bin frequency (PVBuffer.cpp:443-446: the division by dft, a power of two, is exactly a multiplication) and expected phase
+		// advance (phase_vocoder.cpp:47) of the pair ( k, C - k )
+		v4f_t * kc = reinterpret_cast<v4f_t*>( s + L::KC );
+		const float rdft = 1.0f / float( 2 * C );
+		for( int k = tid; k < 512; k += NT )
+			{
+			const float bk = float( k ) * p.sample_rate * rdft, bm = float( C - k ) * p.sample_rate * rdft;
+			kc[k] = v4f_t{ bk, div_c( bk, p.ar_div ) * FLANHIP_PI2_F, bm, div_c( bm, p.ar_div ) * FLANHIP_PI2_F };
+			}
+		}
+	__syncthreads();
+	const cf * s_tw1 = s + L::TW1;
+	const cf * s_tw3 = s + L::TW3;
+	const cf * s_w2 = s + L::W2H + lane;
+	const cf * s_win = s + L::WIN + lane;
+	const v4f_t * s_kc = reinterpret_cast<const v4f_t*>( s + L::KC ) + lane;
+	cf * buf = s + L::BUF + wave * L::BUF_LEN;
+
+	const int64_t chain = int64_t( blockIdx.x ) * WAVES + wave;
+	if( chain >= int64_t( p.chains_per_channel ) * p.num_channels ) return;
+	const int channel = int( chain / p.chains_per_channel );
+	const int64_t t0 = int64_t( chain % p.chains_per_channel ) * p.L;
+	const int64_t t1 = min( t0 + int64_t( p.L ), p.F );
+	const float * x = p.audio + int64_t( channel ) * p.n;
+	const bool use_wrapping = p.analysis_rate < p.sample_rate;                // phase_vocoder.cpp:37
+	const int padl = lane + ( lane >> 4 );
+	const cf * mirror = buf + ( C * 17 ) / 16 - ( lane + ( ( lane + 15 ) >> 4 ) );   // mirror[-68 q] = slot PAD( C - lane - 64 q )
+	const int n32 = int( p.n );
+	struct __attribute__(( packed, aligned( 4 ) )) f2u { float x, y; };      // a sample pair at any 4-byte aligned address
+
+	// state that crosses frames: previous phases (phase_vocoder.cpp:45) of the lane's 8 pairs and of bin C/2
+	float prevk[H], prevm[H], prevx = 0.0f;
+	#pragma unroll
+	for( int q = 0; q < H; ++q ) { prevk[q] = 0.0f; prevm[q] = 0.0f; }        // AudioPV.cpp:44
+	// fused round trip: per-chain sums of the phase increments convert_to_audio will integrate (phase_vocoder.cpp:57-58)
+	double sumk[SUMS ? H : 1], summ[SUMS ? H : 1], sumx = 0.0;
+	if constexpr( SUMS )
+		{
+		#pragma unroll
+		for( int q = 0; q < H; ++q ) { sumk[q] = 0.0; summ[q] = 0.0; }
+		}
+	float mmax = 0.0f;                                                        // running maximum of the magnitudes (Inf scan)
+
+	// does every frame this chain touches (its halo frame included) lie inside the signal?  (AudioPV.cpp:52-62 needs no bounds then)
+	const int64_t tfirst = t0 > 0 ? t0 - 1 : t0;
+	const bool chain_fast = ( W & 127 ) == 0 && int64_t( hop ) * tfirst - W / 2 >= 0 && int64_t( hop ) * ( t1 - 1 ) - W / 2 + 2 * int64_t( C ) <= p.n;
+
+	Stamps st;
+	st.init();
+	cf z[E];
+	auto run_chain = [&]( auto fast_tag )
+		{
+		constexpr bool FAST = decltype( fast_tag )::value;
+		// sample pair i = lane + 64 q of frame t
+		auto load_pair = [&]( int64_t t, int q ) -> cf
+			{
+			const int start = int( int64_t( hop ) * ( ( ABL & 512 ) ? tfirst : t ) - W / 2 );
+			if constexpr( ( ABL & 16 ) != 0 ) return mk( float( start ) * 1e-9f + 0.25f, float( q ) );
+			else if constexpr( ( ABL & 128 ) != 0 && FAST )            // (interior chains only: the edge chains keep their clamped loads)
+				{
+				struct __attribute__(( packed, aligned( 4 ) )) f4u { float x, y, z, w; };
+				const f4u v = *reinterpret_cast<const f4u*>( x + start + 4 * lane + 256 * ( q / 2 ) );
+				return ( q & 1 ) ? mk( v.z, v.w ) : mk( v.x, v.y );
+				}
+			else if constexpr( FAST )
+				{
+				const f2u v = *reinterpret_cast<const f2u*>( x + start + 2 * lane + 128 * q );
+				return mk( v.x, v.y );
+				}
+			else
+				{
+				const int a0c = min( max( start + 2 * ( lane + 64 * q ), 0 ), n32 - 2 );   // n >= 2 on this path (host check)
+				const f2u v = *reinterpret_cast<const f2u*>( x + a0c );
+				return mk( v.x, v.y );
+				}
+			};
+		// edge frames: pairs loaded from clamped addresses are shifted / zeroed here (AudioPV.cpp:54-62, :65)
+		auto fix_raw = [&]( int64_t t )
+			{
+			const int start = int( int64_t( hop ) * t - W / 2 );
+			#pragma unroll
+			for( int q = 0; q < E; ++q )
+				{
+				const int s0 = 2 * ( lane + 64 * q );
+				const int a0 = start + s0;
+				const int d = a0 - min( max( a0, 0 ), n32 - 2 );                     // 0: pair loaded as is; -1 / +1: shifted by one; else outside
+				float v0 = ( d == 0 ) ? z[q].x : ( d == 1 ? z[q].y : 0.0f );
+				float v1 = ( d == 0 ) ? z[q].y : ( d == -1 ? z[q].x : 0.0f );
+				if( s0 >= W ) v0 = 0.0f;
+				if( s0 + 1 >= W ) v1 = 0.0f;
+				z[q] = mk( v0, v1 );
+				}
+			};
+		// window (AudioPV.cpp:60), transform; leaves the upper half of Z in buf (natural order) for the mirror reads
+		auto transform_frame = [&]( int64_t t )
+			{
+			if constexpr( !FAST ) fix_raw( t );
+			#pragma unroll
+			for( int q = 0; q < E; ++q )
+				{
+				const cf w = s_win[64 * q];
+				z[q] = mk( z[q].x * w.x, z[q].y * w.y );
+				}
+			st( 0 );                                                              // 0: wait for the samples, window
+			if constexpr( ( ABL & 1 ) == 0 )
+			fft_fast<10>( z, buf, s_tw1, s_tw3, lane, st );                       // 1, 2: passes 0, 1 (each with the transpose after it)
+			st( 3 );                                                              // 3: pass 2
+			#pragma unroll
+			for( int q = H; q < E; ++q ) buf[padl + 68 * q] = z[q];
+			wave_sync();
+			};
+
+		// The loop is ROTATED: an iteration is [ per-bin work of frame t, which also requests frame t + 1's samples and stores frame t's
+		// MFs ] then [ wait for those samples, window, transform of frame t + 1 ].  Request, stores and wait sit in one straight line
+		// of code, so the wait is a counted one (s_waitcnt vmcnt(9 ..)) that leaves the stores in flight.  With the wait at the TOP of
+		// a loop the compiler has to merge the state of the loop's entry edge (no stores behind the loads) with the back edge's and
+		// drains the whole queue, stores included, once per frame (measured: a quarter of the kernel's time).
+		// HALO: frame t0 - 1, of which only the phases are wanted (phase_vocoder.cpp:45 leaves them in phase_buffer): a compile-time
+		// switch, not a branch.
+		auto bins_of_frame = [&]( int64_t t, int64_t tn, auto halo_tag )
+			{
+			constexpr bool halo = decltype( halo_tag )::value;
+			const cf z512 = buf[544];                                             // Z[ C/2 ], slot PAD( 512 )
+			const cf z0 = z[0];                                                   // lane 0: Z[0]
+			#pragma unroll
+			for( int q = H; q < E; ++q ) z[q] = load_pair( tn, q );               // the upper half is in LDS now: its registers are free
+			st( 4 );                                                              // 4: mirror exchange written, upper half of the next frame requested
+			cf * row = reinterpret_cast<cf*>( p.out + ( int64_t( channel ) * p.F + ( ( ABL & 256 ) ? t0 : t ) ) * ( C + 1 ) );
+			cf * rowk = row + lane;
+			cf * rowm = row + ( C - lane );
+			// the MFs of the frame leave together at its end, BEHIND every request for the next frame's samples: memory operations retire
+			// in issue order, so a sample load issued after a store would not count as back before that store has been acknowledged
+			// (microseconds while the chip streams writes), and the transform of the next frame would wait for it
+			cf outk[halo ? 1 : H], outm[halo ? 1 : H];
+			#pragma unroll
+			for( int g = 0; g < H / NP; ++g )
+				{
+				VB re, im, pv, binf, expd;
+				#pragma unroll
+				for( int i = 0; i < NP; ++i )
+					{
+					const int q = g * NP + i;
+					// bins k = lane + 64 q and C - k of the real transform from Z[k] (own) and Z[C-k] (mirror lane, through LDS)
+					const cf zk = z[q];
+					const cf zm = ( ABL & 32 ) ? zk : mirror[-68 * q];              // lane 0, q = 0 reads an unused slot: overridden below
+					const cf w = s_w2[64 * q];                                      // 0.5 exp( -2 pi i k / 2C )
+					const v4f_t kc = s_kc[64 * q];
+					z[q] = load_pair( tn, q );                                      // Z[k] is consumed: next frame's samples take its place
+					const float sx = zk.x + zm.x, dy = zk.y + zm.y, dx = zk.x - zm.x, sy = zk.y - zm.y;
+					const float t1v = __builtin_fmaf( w.x, dy, w.y * dx );
+					const float t2v = __builtin_fmaf( w.x, dx, -( w.y * dy ) );
+					float rk = __builtin_fmaf( 0.5f, sx, t1v ), ik = __builtin_fmaf( 0.5f, sy, -t2v );
+					float rm = __builtin_fmaf( 0.5f, sx, -t1v ), imv = __builtin_fmaf( -0.5f, sy, -t2v );
+					if( q == 0 )
+						{
+						rk = ( lane == 0 ) ? z0.x + z0.y : rk;  ik = ( lane == 0 ) ? 0.0f : ik;      // X[0]
+						rm = ( lane == 0 ) ? z0.x - z0.y : rm;  imv = ( lane == 0 ) ? 0.0f : imv;    // X[C]
+						}
+					re[i] = rk; im[i] = ik; re[NP + i] = rm; im[NP + i] = imv;
+					pv[i] = prevk[q]; pv[NP + i] = prevm[q];
+					binf[i] = kc.x; expd[i] = kc.y; binf[NP + i] = kc.z; expd[NP + i] = kc.w;
+					}
+				// phase_vocoder.cpp:37-52 (AudioPV.cpp:69-73)
+				VB phase, m;
+				if constexpr( ( ABL & 2 ) == 0 ) polar_v( re, im, phase, m ); else { phase = re; m = im; }
+				#pragma unroll
+				for( int i = 0; i < NP; ++i ) { prevk[g * NP + i] = phase[i]; prevm[g * NP + i] = phase[NP + i]; }   // :45
+				if constexpr( !halo )
+					{
+					VB f;
+					if constexpr( ( ABL & 4 ) == 0 )
+						{
+						const VB phase_diff = phase - pv;                            // == float( double(phase) - double(prev) ), :44
+						const VB delta_phase = phase_diff - expd;                    // :47-48
+						VB wrapped = delta_phase;
+						if( use_wrapping ) wrapped = delta_phase - vsplat<VB>( FLANHIP_PI2_F ) * round_half_away_v( div_pi2_v( delta_phase ) );   // :39-42,49
+						f = binf + div_pi2_v( wrapped * vsplat<VB>( p.analysis_rate ) );                              // :50-52
+						}
+					else f = phase - pv + binf * expd;
+					#pragma unroll
+					for( int i = 0; i < NP; ++i )
+						{
+						const int q = g * NP + i;
+						outk[q] = cf{ m[i], f[i] };
+						outm[q] = cf{ m[NP + i], f[NP + i] };
+						}
+					if constexpr( SUMS )
+						{
+						const VB term = div_c_v( f, p.ar_div ) * vsplat<VB>( FLANHIP_PI2_F );                      // phase_vocoder.cpp:57-58
+						#pragma unroll
+						for( int i = 0; i < NP; ++i )
+							{
+							sumk[g * NP + i] += double( term[i] );
+							summ[g * NP + i] += double( term[NP + i] );
+							}
+						#pragma unroll
+						for( int i = 0; i < NV; i += 2 ) mmax = __builtin_fmaxf( mmax, __builtin_fmaxf( m[i], m[i + 1] ) );   // v_max3_f32
+						}
+					}
+				st( 5 + ( g & 3 ) );                                              // 5..8: the groups of bins (modulo 4)
+				}
+			if constexpr( !halo )
+				{
+				#pragma unroll
+				for( int q = 0; q < H; ++q )
+					{
+					if constexpr( ( ABL & 64 ) != 0 )
+						{
+						if( ( q & 1 ) == 0 )
+							{
+							*reinterpret_cast<v4f_t*>( reinterpret_cast<float*>( row ) + 4 * ( lane + 64 * ( q / 2 ) ) ) = v4f_t{ outk[q].x, outk[q].y, outk[q + 1].x, outk[q + 1].y };
+							*reinterpret_cast<v4f_t*>( reinterpret_cast<float*>( row ) + 4 * ( lane + 64 * ( q / 2 + 4 ) ) ) = v4f_t{ outm[q].x, outm[q].y, outm[q + 1].x, outm[q + 1].y };
+							}
+						}
+					else if constexpr( ( ABL & 1024 ) != 0 )
+						{
+						rowk[64 * q] = outk[q];
+						rowm[-64 * q] = outm[q];
+						}
+					else if constexpr( ( ABL & 8 ) == 0 )
+						{
+						// non-temporal: the PV is written once and read by another kernel much later; measured, these stores are acknowledged
+						// sooner than plain ones while the chip streams writes (the kernel 9 % faster, its memory traffic alone 27 %)
+						__builtin_nontemporal_store( outk[q], rowk + 64 * q );
+						__builtin_nontemporal_store( outm[q], rowm - 64 * q );
+						}
+					else asm volatile( "" :: "v"( outk[q].x ), "v"( outk[q].y ), "v"( outm[q].x ), "v"( outm[q].y ) );
+					}
+				}
+				{
+				// bin C/2 pairs with itself: X = conj Z[ C/2 ]; every lane carries the same value
+				const float re = z512.x, im = -z512.y;
+				const float phase = atan2_fast( im, re );
+				const float pvx = prevx;
+				prevx = phase;
+				if constexpr( !halo )
+					{
+					const float bx = float( C / 2 ) * p.sample_rate * ( 1.0f / float( 2 * C ) );
+					const float phase_diff = phase - pvx;
+					const float delta_phase = phase_diff - div_c( bx, p.ar_div ) * FLANHIP_PI2_F;
+					const float wrapped = use_wrapping ? delta_phase - FLANHIP_PI2_F * round_half_away( div_pi2( delta_phase ) ) : delta_phase;
+					const float f = bx + div_pi2( wrapped * p.analysis_rate );
+					const float m = magnitude_scaled( re, im );
+					if constexpr( ( ABL & 8 ) == 0 ) __builtin_nontemporal_store( mk( m, f ), row + C / 2 ); else asm volatile( "" :: "v"( m ), "v"( f ) );
+					if constexpr( SUMS )
+						{
+						sumx += double( div_c( f, p.ar_div ) * FLANHIP_PI2_F );
+						mmax = __builtin_fmaxf( mmax, m );
+						}
+					}
+				}
+			wave_sync();
+			st( 9 );                                                              // 9: bin C/2
+			};
+
+		#pragma unroll
+		for( int q = 0; q < E; ++q ) z[q] = load_pair( tfirst, q );
+		transform_frame( tfirst );
+		if( t0 > 0 )
+			{
+			bins_of_frame( t0 - 1, t0, std::true_type{} );
+			transform_frame( t0 );
+			}
+		for( int64_t t = t0; t < t1; ++t )
+			{
+			bins_of_frame( t, min( t + 1, t1 - 1 ), std::false_type{} );          // (the last frame requests itself again: nobody waits for it)
+			if( t + 1 < t1 ) transform_frame( t + 1 );
+			}
+		};
+	if( chain_fast ) run_chain( std::true_type{} ); else run_chain( std::false_type{} );
+	st.flush( lane );
+
+	if constexpr( SUMS )
+		{
+		double * dst = p.sums + chain * ( C + 1 );
+		bool bad = !( mmax <= 3.4028235e38f );
+		auto fold = [&]( double sq ) -> double
+			{
+			bad |= !( __builtin_fabs( sq ) <= 1.7976931348623157e308 );              // a NaN / Inf frequency poisons its sum
+			return ( __builtin_fabs( sq ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( sq ) : fold_phase_any( sq );
+			};
+		#pragma unroll
+		for( int q = 0; q < H; ++q )
+			{
+			dst[lane + 64 * q] = fold( sumk[q] );
+			dst[C - lane - 64 * q] = fold( summ[q] );
+			}
+		const double vx = fold( sumx );
+		if( lane == 0 ) dst[C / 2] = vx;
+		const bool any_bad = __any( bad );
+		if( p.nan_out && lane == 0 )
+			{
+			// no clearing pass: the flag word is "set" when it equals this launch's epoch (written beside it by chain 0)
+			if( chain == 0 ) p.nan_out[2] = p.nan_epoch;
+			if( any_bad ) p.nan_out[0] = p.nan_epoch;
+			}
+		}
+	}
+
+} // namespace flanhip
