@@ -15,7 +15,8 @@ static int g_synth_stage_mask = 0xF;             // flanhip_debug_synth_stages()
 // flanhip_debug_kernel_variant(): which dft 2048 kernel generation a call launches (A/B runs in one process).
 // analysis: 0 = round-1 kernel (8-wave blocks, 2 wavefronts per SIMD); 1 / 2 / 3 = v2 with 12-wave blocks (3 per SIMD) evaluating
 // 4 / 2 / 8 bins at a time; 4 (the default) / 6 / 7 = v2 in 8-wave blocks, 8 / 16 / 4 bins at a time
-static int g_ana_variant = 4, g_syn_variant = 0;
+// synthesis (register-accumulator hops): 0 = round-1 kernel; 1 (the default) = v2; 9 = v2 with plain instead of non-temporal row loads
+static int g_ana_variant = 4, g_syn_variant = 1;
 static int ana_variant_waves( int v ) { return v == 0 || v == 4 || v == 6 || v == 7 || v > 100 ? 8 : 12; }
 static constexpr size_t kMaxLds = 160 * 1024;   // gfx950: 160 KiB LDS per CU, one workgroup may take all of it
 
@@ -157,9 +158,42 @@ static int run_synth_fast( const SynthParams & p, const FastTables & tb, hipStre
 	return FLANHIP_OK;
 	}
 
+template<int WAVES, int HOPQ, int ABL = 0>
+static int run_synth_v2( const SynthParams & p, const FastTables & tb, hipStream_t s )
+	{
+	const size_t lds = V2LdsSyn::bytes( WAVES );
+	static_assert( V2LdsSyn::bytes( WAVES ) <= kMaxLds, "LDS budget" );
+	auto kern = k_synthesize_v2<WAVES, HOPQ, ABL>;
+	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;
+	const int64_t blocks = ( chains + WAVES - 1 ) / WAVES;
+	hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( 64 * WAVES ), lds, s, p, tb );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
 template<int LOG2C>
 static int run_synth_fast_hop( const SynthParams & p, const FastTables & tb, hipStream_t s )
 	{
+	if( LOG2C == 10 && g_syn_variant != 0 && synth_fast_kind( 2 << LOG2C, p.window_size, p.hop ) == 1 )
+		{
+		// v2: the register-accumulator hops of dft 2048
+		if( g_syn_variant == 9 && p.hop == 512 ) return run_synth_v2<8, 4, 1>( p, tb, s );       // A/B: plain instead of non-temporal row loads
+#ifdef FLANHIP_ABLATIONS
+		if( g_syn_variant == 102 && p.hop == 512 ) return run_synth_v2<8, 4, 2>( p, tb, s );
+		if( g_syn_variant == 104 && p.hop == 512 ) return run_synth_v2<8, 4, 4>( p, tb, s );
+		if( g_syn_variant == 106 && p.hop == 512 ) return run_synth_v2<8, 4, 6>( p, tb, s );
+		if( g_syn_variant == 108 && p.hop == 512 ) return run_synth_v2<8, 4, 8>( p, tb, s );
+		if( g_syn_variant == 114 && p.hop == 512 ) return run_synth_v2<8, 4, 14>( p, tb, s );
+#endif
+		switch( p.hop / 128 )
+			{
+			case 1: return run_synth_v2<8, 1>( p, tb, s );
+			case 2: return run_synth_v2<8, 2>( p, tb, s );
+			case 4: return run_synth_v2<8, 4>( p, tb, s );
+			case 8: return run_synth_v2<8, 8>( p, tb, s );
+			}
+		}
 	if( synth_fast_kind( 2 << LOG2C, p.window_size, p.hop ) == 2 )                // any other hop <= window: ring accumulator in LDS
 		return run_synth_fast<LOG2C, ( LOG2C == 10 ? kSynWaves10 : kRingWaves11 ), 0>( p, tb, s );
 	switch( p.hop / 128 )

@@ -455,4 +455,215 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 		}
 	}
 
+// =================================================================================================================
+// PV::convert_to_audio (Conversions/AudioPV.cpp:86-139), dft 2048; HOPQ = hop / 128 for the hops 128 / 256 / 512 / 1024
+// (overlap-add accumulator in registers).  Same ideas as k_analyze_v2:
+//   * a lane owns the bin pairs ( k, C - k ), k = lane + 64 q, q < 8: the merge of X[k], X[C-k] into the half-size spectrum gives Z[k] and
+//     Z[C-k] from shared sums and one twiddle product; only Z[C-k] crosses LDS (to the lane that owns it in the transform's layout);
+//   * the frame loop is rotated -- [ request row t + 1 | transform, window, overlap-add, stores of frame t | wait, per-bin work of
+//     row t + 1 ] -- so that the wait for the MF row is a counted one that leaves the output stores in flight;
+//   * the MF rows are read once: non-temporal loads.
+// =================================================================================================================
+struct V2LdsSyn
+	{
+	static constexpr int C = 1024;
+	static constexpr int TW1 = 0;
+	static constexpr int TW3 = TW1 + 240;
+	static constexpr int W2S = TW3 + 768;                  // [512]   ( cos, sin )( pi k / C ) = exp( +2 pi i k / 2C ), k < C/2
+	static constexpr int WIN = W2S + 512;                  // [2048 floats] hann * window_scale
+	static constexpr int BUF = WIN + 1024;
+	static constexpr int BUF_LEN = C + C / 16 + 1;
+	static constexpr size_t bytes( int waves ) { return size_t( BUF + waves * BUF_LEN ) * 8; }
+	};
+
+template<int WAVES, int HOPQ, int ABL = 0>
+__global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, FastTables tb )
+	{
+	using L = V2LdsSyn;
+	constexpr int C = 1024, E = 16, H = 8, NT = 64 * WAVES;
+	static_assert( HOPQ == 1 || HOPQ == 2 || HOPQ == 4 || HOPQ == 8, "hop 128 / 256 / 512 / 1024" );
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	cf * s = reinterpret_cast<cf*>( smem );
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int W = p.window_size;
+	for( int i = tid; i < 240; i += NT ) s[L::TW1 + i] = tb.tw1[i];
+	for( int i = tid; i < 768; i += NT ) s[L::TW3 + i] = tb.tw3[i];
+	for( int i = tid; i < 512; i += NT ) { const cf w = tb.w2[i]; s[L::W2S + i] = mk( w.x, -w.y ); }
+		{
+		float * win = reinterpret_cast<float*>( s + L::WIN );
+		for( int i = tid; i < 2 * C; i += NT ) win[i] = ( i < W ) ? p.window[i] * p.window_scale : 0.0f;      // AudioPV.cpp:102
+		}
+	__syncthreads();
+	const cf * s_tw1 = s + L::TW1;
+	const cf * s_tw3 = s + L::TW3;
+	const cf * s_w2 = s + L::W2S + lane;
+	const cf * s_win = s + L::WIN + lane;
+	cf * buf = s + L::BUF + wave * L::BUF_LEN;
+
+	const int64_t chain = int64_t( blockIdx.x ) * WAVES + wave;
+	if( chain >= int64_t( p.chains_per_channel ) * p.num_channels ) return;
+	const int channel = int( chain / p.chains_per_channel );
+	const int chain_in_channel = int( chain % p.chains_per_channel );
+	const int64_t t0 = int64_t( chain_in_channel ) * p.L;
+	const int64_t t1 = min( t0 + int64_t( p.L ), p.F );
+	const bool last_chain = chain_in_channel == p.chains_per_channel - 1;
+	constexpr int hop = 128 * HOPQ;
+	float * out1 = p.out + int64_t( channel ) * p.out_len;
+	cf * out2 = reinterpret_cast<cf*>( out1 );
+	cf * head2 = reinterpret_cast<cf*>( p.head + chain * p.head_len );
+	const int64_t chain_start = int64_t( hop ) * t0 - W / 2;
+	const int64_t own_start = chain_in_channel == 0 ? INT64_MIN : chain_start + p.head_len;
+	const int padl = lane + ( lane >> 4 );
+	cf * mirror = buf + ( C * 17 ) / 16 - ( lane + ( ( lane + 15 ) >> 4 ) );      // mirror[-68 q] = slot PAD( C - lane - 64 q )
+
+	// phase_buffer (AudioPV.cpp:105) on entry to the chain, of the lane's pairs and of bin C/2
+	double phk[H], phm[H], phx;
+	const double * carry = p.carry + chain * ( C + 1 );
+	#pragma unroll
+	for( int q = 0; q < H; ++q ) { phk[q] = carry[lane + 64 * q]; phm[q] = carry[C - lane - 64 * q]; }
+	phx = carry[C / 2];
+	cf acc[E];                                                                  // overlap-add accumulator: acc[q] <-> samples pos + 128 q + 2 lane (+1)
+	#pragma unroll
+	for( int q = 0; q < E; ++q ) acc[q] = mk( 0.0f, 0.0f );
+
+	// one 128-sample step of finished (or partial) output leaves the chain (positions are even: hop and W/2 are multiples of 64).
+	// Exactly one store instruction per step, never inside a branch: lanes that fall outside the output are pointed at a 512-byte dump
+	// area in the workspace, so the number of stores in flight behind the row request is static (counted wait, see the loop)
+	cf * dump2 = reinterpret_cast<cf*>( p.dump ) + lane;
+	auto emit_step = [&]( int64_t a0, cf v )
+		{
+		const int64_t a = a0 + 2 * lane;
+		cf * dst = ( a0 < own_start ) ? head2 + ( ( a - chain_start ) >> 1 ) : out2 + ( a >> 1 );
+		if( ( ABL & 4 ) || ( a0 >= own_start && !( a >= 0 && a < p.out_len ) ) ) dst = dump2;           // ABL 4 (timing only): every store to the dump area
+		*dst = v;
+		};
+	// MF row of frame t: ( m, f ) of the lane's pairs and of bin C/2
+	cf mfk[H], mfm[H], mfx;
+	auto load_row = [&]( int64_t t )
+		{
+		const cf * row = reinterpret_cast<const cf*>( p.pv + ( int64_t( channel ) * p.F + ( ( ABL & 2 ) ? t0 : t ) ) * ( C + 1 ) );   // ABL 2 (timing only): a hot row
+		const cf * rowk = row + lane;
+		const cf * rowm = row + ( C - lane );
+		#pragma unroll
+		for( int q = 0; q < H; ++q )
+			{
+			mfk[q] = ( ABL & 1 ) ? rowk[64 * q] : __builtin_nontemporal_load( rowk + 64 * q );
+			mfm[q] = ( ABL & 1 ) ? rowm[-64 * q] : __builtin_nontemporal_load( rowm - 64 * q );
+			}
+		mfx = ( ABL & 1 ) ? row[C / 2] : __builtin_nontemporal_load( row + C / 2 );
+		};
+
+	cf z[E];
+	// inverse phase vocoder of the row in mfk / mfm / mfx (AudioPV.cpp:117-120, phase_vocoder.cpp:55-61), merge of X[0..C] into the
+	// half-size spectrum conj( A + i B ) (the forward transform of it is the conjugate of the inverse one): leaves z[] complete
+	auto bins_of_row = [&]()
+		{
+		bool slow = false;
+		#pragma unroll
+		for( int q = 0; q < H; ++q )
+			{
+			phk[q] += double( div_c( mfk[q].y, p.ar_div ) * FLANHIP_PI2_F );       // phase_vocoder.cpp:57-58
+			phm[q] += double( div_c( mfm[q].y, p.ar_div ) * FLANHIP_PI2_F );
+			slow |= !( __builtin_fabs( phk[q] ) < double( FLANHIP_SINCOS_FAST_LIMIT ) ) || !( __builtin_fabs( phm[q] ) < double( FLANHIP_SINCOS_FAST_LIMIT ) );
+			}
+		phx += double( div_c( mfx.y, p.ar_div ) * FLANHIP_PI2_F );
+		slow |= !( __builtin_fabs( phx ) < double( FLANHIP_SINCOS_FAST_LIMIT ) );
+		cf xk[H], xm[H], xx;
+		if( __any( slow ) )
+			{
+			// a phase outside the range the fast helpers are exact for (or a NaN): the general routines for this frame
+			#pragma unroll
+			for( int q = 0; q < H; ++q )
+				{
+				phk[q] = fold_phase_any( phk[q] ); phm[q] = fold_phase_any( phm[q] );
+				const float2 a = sincos_wide( float( phk[q] ) ), b = sincos_wide( float( phm[q] ) );
+				xk[q] = mk( mfk[q].x * a.y, mfk[q].x * a.x );
+				xm[q] = mk( mfm[q].x * b.y, mfm[q].x * b.x );
+				}
+			phx = fold_phase_any( phx );
+			const float2 a = sincos_wide( float( phx ) );
+			xx = mk( mfx.x * a.y, mfx.x * a.x );
+			}
+		else
+			{
+			#pragma unroll
+			for( int q0 = 0; q0 < H; q0 += 2 )
+				{
+				// two pairs = four bins per iteration as one vector stream (pv_math.h)
+				v4f th, m4;
+				#pragma unroll
+				for( int i = 0; i < 2; ++i )
+					{
+					phk[q0 + i] = fold_phase_fast( phk[q0 + i] );                  // phase_vocoder.cpp:59
+					phm[q0 + i] = fold_phase_fast( phm[q0 + i] );
+					th[i] = float( phk[q0 + i] ); th[2 + i] = float( phm[q0 + i] );
+					m4[i] = mfk[q0 + i].x; m4[2 + i] = mfm[q0 + i].x;
+					}
+				v4f sn, cs;
+				sincos_fast_v( th, sn, cs );
+				const v4f xr = m4 * cs, xi = m4 * sn;                            // std::polar, :60
+				#pragma unroll
+				for( int i = 0; i < 2; ++i ) { xk[q0 + i] = cf{ xr[i], xi[i] }; xm[q0 + i] = cf{ xr[2 + i], xi[2 + i] }; }
+				__builtin_amdgcn_sched_barrier( 0 );                            // four bins at a time: keeps the temporaries of 16 bins from overlapping
+				}
+			phx = fold_phase_fast( phx );
+			float sn, cs;
+			sincos_fast( float( phx ), sn, cs );
+			xx = mk( mfx.x * cs, mfx.x * sn );
+			}
+		// ---- merge: Z[k] = conj( A + i B ), Z[C-k] likewise with A -> conj A, B -> -conj B ... written out per component below
+		#pragma unroll
+		for( int q = 0; q < H; ++q )
+			{
+			cf a = xk[q], b = xm[q];                                            // X[k], X[C-k]
+			if( q == 0 ) { a.y = ( lane == 0 ) ? 0.0f : a.y; b.y = ( lane == 0 ) ? 0.0f : b.y; }   // c2r ignores Im X[0], Im X[C]
+			const cf w = s_w2[64 * q];                                          // exp( +2 pi i k / N ): ( c, sgn )
+			const float ax = a.x + b.x, ay = a.y - b.y;                         // A = X[k] + conj X[C-k]
+			const float dx = a.x - b.x, dy = a.y + b.y;                         // D = X[k] - conj X[C-k]
+			const float bx = __builtin_fmaf( w.x, dx, -( w.y * dy ) ), by = __builtin_fmaf( w.x, dy, w.y * dx );
+			z[q] = mk( ax - by, -( ay + bx ) );                                 // Z[k]
+			mirror[-68 * q] = mk( ax + by, ay - bx );                           // Z[C-k] (lane 0, q = 0: an unused slot)
+			}
+		if( lane == 0 ) buf[544] = mk( 2.0f * xx.x, 2.0f * xx.y );              // Z[C/2] = 2 X[C/2] (slot PAD( 512 ))
+		wave_sync();
+		#pragma unroll
+		for( int q = H; q < E; ++q ) z[q] = buf[padl + 68 * q];
+		wave_sync();
+		};
+
+	load_row( t0 );
+	bins_of_row();
+	int64_t pos = chain_start;
+	for( int64_t t = t0; t < t1; ++t )
+		{
+		load_row( min( t + 1, t1 - 1 ) );                                       // (the last frame requests itself again: nobody waits for it)
+		if constexpr( ( ABL & 8 ) == 0 )                                        // ABL 8 (timing only): no transform
+		fft_fast<10>( z, buf, s_tw1, s_tw3, lane );
+		// ---- G = fft( conj Z ): x[2n] = G[n].x, x[2n+1] = -G[n].y; window and overlap-add (AudioPV.cpp:122-134)
+		#pragma unroll
+		for( int q = 0; q < E; ++q )
+			{
+			const cf w = s_win[64 * q];                                         // zero beyond W
+			acc[q].x += z[q].x * w.x;
+			acc[q].y += ( -z[q].y ) * w.y;
+			}
+		#pragma unroll
+		for( int q = 0; q < HOPQ; ++q ) emit_step( pos + 128 * q, acc[q] );
+		#pragma unroll
+		for( int q = 0; q < E; ++q ) acc[q] = ( q + HOPQ < E ) ? acc[q + HOPQ] : mk( 0.0f, 0.0f );
+		pos += hop;
+		if( t + 1 < t1 ) bins_of_row();
+		}
+	// flush the partial sums that the next chain's head completes; the last chain zero-fills to the end of the output
+	const int64_t ring_end = pos + ( W - hop );
+	const int64_t flush_end = last_chain ? max( ring_end, p.out_len ) : ring_end;
+	#pragma unroll
+	for( int q = 0; q < E; ++q )
+		{
+		const int64_t a0 = pos + 128 * q;
+		if( a0 < flush_end ) emit_step( a0, acc[q] );
+		}
+	for( int64_t a0 = pos + 128 * E; a0 < flush_end; a0 += 128 ) emit_step( a0, mk( 0.0f, 0.0f ) );
+	}
+
 } // namespace flanhip
