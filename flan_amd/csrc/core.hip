@@ -160,8 +160,10 @@ int choose_chain_length( int64_t num_channels, int64_t num_frames, int min_len, 
 
 int next_epoch()
 	{
-	static std::atomic<int> epoch{ 0 };
-	return ( epoch.fetch_add( 1 ) & 0x7ffffffe ) + 1;                          // never 0
+	// 1, 2, 3, ... 2^31 - 1, 1, ...: never 0, and two successive producer launches never share a number (the workspace words are
+	// recycled uncleared through the device cache: a repeated number would make stale words look freshly set)
+	static std::atomic<uint32_t> epoch{ 0 };
+	return int( epoch.fetch_add( 1 ) % 0x7fffffffu ) + 1;
 	}
 
 } // namespace flanhip

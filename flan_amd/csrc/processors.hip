@@ -134,7 +134,7 @@ __global__ __launch_bounds__( 256 ) void k_modify_time_chains( TimeChainParams p
 	{
 	if( p.nonmono[p.bins] )                                                         // some column runs backwards: k_modify_time does this PV
 		{
-		if( SUMS && blockIdx.x == 0 && threadIdx.x == 0 ) p.words[2] = p.epoch;     // the sums are NOT valid for this epoch
+		if( SUMS && blockIdx.x == 0 && threadIdx.x == 0 ) { p.words[2] = p.epoch; p.words[4] = 0; }   // the sums are NOT valid for this epoch: said explicitly, not left to staleness
 		return;
 		}
 	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;

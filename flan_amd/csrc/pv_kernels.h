@@ -223,7 +223,7 @@ __global__ __launch_bounds__( 64 * WAVES * T ) void k_analyze( AnalyzeParams p )
 		if( p.nan_out && ( tid & 63 ) == 0 )                                      // one lane per wavefront of the team
 			{
 			// no clearing pass: the flag word is "set" when it equals this launch's epoch (written beside it by chain 0)
-			if( chain == 0 && lane == 0 ) p.nan_out[2] = p.nan_epoch;
+			if( chain == 0 && lane == 0 ) { p.nan_out[2] = p.nan_epoch; p.nan_out[4] = p.nan_epoch; }
 			if( any_bad ) p.nan_out[0] = p.nan_epoch;
 			}
 		}

@@ -367,7 +367,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 		if( p.nan_out && lane == 0 )
 			{
 			// no clearing pass: the flag word is "set" when it equals this launch's epoch (written beside it by chain 0)
-			if( chain == 0 ) p.nan_out[2] = p.nan_epoch;
+			if( chain == 0 ) { p.nan_out[2] = p.nan_epoch; p.nan_out[4] = p.nan_epoch; }   // [4]: the sums of this epoch are in the workspace
 			if( any_bad ) p.nan_out[0] = p.nan_epoch;
 			}
 		}
@@ -662,7 +662,7 @@ __global__ __launch_bounds__( 256 ) void k_phase_sums2( SynthParams p )
 	if( p.nan_flag && any_bad && ( threadIdx.x & 63 ) == 0 ) atomicOr( p.nan_flag, 1 );
 	if( p.nan_words )
 		{
-		if( blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 ) p.nan_words[2] = p.nan_epoch;
+		if( blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 ) { p.nan_words[2] = p.nan_epoch; p.nan_words[4] = p.nan_epoch; }
 		if( any_bad && ( threadIdx.x & 63 ) == 0 ) p.nan_words[0] = p.nan_epoch;
 		}
 	}

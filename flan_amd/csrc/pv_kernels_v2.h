@@ -449,7 +449,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 		if( p.nan_out && lane == 0 )
 			{
 			// no clearing pass: the flag word is "set" when it equals this launch's epoch (written beside it by chain 0)
-			if( chain == 0 ) p.nan_out[2] = p.nan_epoch;
+			if( chain == 0 ) { p.nan_out[2] = p.nan_epoch; p.nan_out[4] = p.nan_epoch; }   // [4]: the sums of this epoch are in the workspace
 			if( any_bad ) p.nan_out[0] = p.nan_epoch;
 			}
 		}

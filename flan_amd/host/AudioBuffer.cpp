@@ -40,10 +40,15 @@ AudioBuffer AudioBuffer::copy() const
 	return out;
 	}
 
-bool AudioBuffer::is_null() const { return count() == 0 || ( host_valid && buffer.empty() && !dev ) || format.sample_rate == 0; }
+bool AudioBuffer::is_null() const
+	{
+	auto held = lock.hold();
+	return count() == 0 || ( host_valid && buffer.empty() && !dev ) || format.sample_rate == 0;
+	}
 
 void AudioBuffer::clear_buffer()
 	{
+	auto held = lock.hold();
 	buffer.assign( count(), 0.0f );
 	host_valid = true;
 	dev.reset();
@@ -51,6 +56,7 @@ void AudioBuffer::clear_buffer()
 
 const std::vector<float> & AudioBuffer::get_buffer() const
 	{
+	auto held = lock.hold();           // concurrent const methods on one object: the first one downloads, the others wait (mirror_lock.h)
 	if( !host_valid )
 		{
 		if( buffer.capacity() < count() )                // fresh memory: let every worker fault its share of the pages in, not this thread alone
@@ -69,6 +75,7 @@ const std::vector<float> & AudioBuffer::get_buffer() const
 std::vector<float> & AudioBuffer::get_buffer()
 	{
 	std::as_const( *this ).get_buffer();
+	auto held = lock.hold();
 	dev.reset();                       // the caller may write: the host copy is the truth from here on
 	return buffer;
 	}
@@ -104,8 +111,9 @@ void AudioBuffer::print_summary() const
 	          << "\n==================================================================" << "\n\n";
 	}
 
-const float * AudioBuffer::device_data() const
+std::shared_ptr<detail::DeviceBlock> AudioBuffer::device_block() const
 	{
+	auto held = lock.hold();
 	if( !dev )
 		{
 		if( count() == 0 ) return nullptr;
@@ -118,7 +126,13 @@ const float * AudioBuffer::device_data() const
 			}
 		dev = std::move( block );
 		}
-	return static_cast<const float*>( dev->ptr );
+	return dev;
+	}
+
+const float * AudioBuffer::device_data() const
+	{
+	const auto block = device_block();
+	return block ? static_cast<const float*>( block->ptr ) : nullptr;
 	}
 
 } // namespace flan

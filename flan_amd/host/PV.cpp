@@ -23,6 +23,24 @@ std::shared_ptr<DeviceBlock> upload( const void * host, size_t bytes )
 	return b;
 	}
 
+// Declared AFTER the staging vectors / device blocks of a function that starts asynchronous copies, so that it is destroyed FIRST: on
+// every way out -- an early `return nullptr`, an exception thrown by the user's callable (pool_run rethrows it) -- the copy streams
+// and the null stream are drained before page-locked and device blocks go back to their caches, where the next user could receive them
+// while a DMA still reads or writes them.
+struct DmaQuiesce
+	{
+	detail::CopyStreams streams;
+	explicit DmaQuiesce( detail::CopyStreams s = detail::CopyStreams() ) : streams( s ) {}
+	DmaQuiesce( const DmaQuiesce & ) = delete;
+	DmaQuiesce & operator=( const DmaQuiesce & ) = delete;
+	~DmaQuiesce()
+		{
+		if( streams.down ) (void) flanhip_stream_synchronize( streams.down );
+		if( streams.up ) (void) flanhip_stream_synchronize( streams.up );
+		(void) flanhip_stream_synchronize( nullptr );
+		}
+	};
+
 // sample_function_over_domain (PV.h:31-35) straight onto the device: a constant is filled there; a callable is sampled on the
 // host a slab of frames at a time into page-locked memory, each slab on its way over the link while the next is sampled.
 // `keep`, when given, receives the host copy (modify_time needs its maximum).
@@ -53,6 +71,7 @@ std::shared_ptr<DeviceBlock> function_grid_to_device( const PV & me, const Funct
 	typename FunctionSample2d<T>::Vector host( count );
 	auto b = DeviceBlock::allocate( sizeof( T ) * count );
 	if( !b ) return nullptr;
+	const DmaQuiesce quiesce;                                                     // the uploads below are asynchronous on the null stream: drained on every way out
 	const int slabs = count * sizeof( T ) >= ( size_t( 4 ) << 20 ) ? 4 : 1;
 	for( int k = 0; k < slabs; ++k )
 		{
@@ -86,6 +105,7 @@ std::shared_ptr<DeviceBlock> map_rows_to_device( const PV & me, ExecutionPolicy 
 	const MF * src = on_host ? me.get_buffer().data() : in.data();
 	const int slabs = std::max( 1, std::min<int>( 16, int( count * sizeof( MF ) >> 22 ) ) );
 	const detail::CopyStreams streams = detail::copy_streams();                  // downloads and uploads on a stream each: both directions of the link at once
+	const DmaQuiesce quiesce( streams );                                         // last declared, first destroyed: no copy outlives `in`, `out`, `d_out`
 	auto slab_begin = [&]( int k ){ return int( int64_t( rows ) * k / slabs ); };
 	auto fetch = [&]( int k )
 		{

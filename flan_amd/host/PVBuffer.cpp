@@ -35,7 +35,11 @@ PVBuffer PVBuffer::copy() const
 	return out;
 	}
 
-bool PVBuffer::is_null() const { return count() == 0 || ( host_valid && buffer.empty() && !dev ) || format.sample_rate == 0; }
+bool PVBuffer::is_null() const
+	{
+	auto held = lock.hold();
+	return count() == 0 || ( host_valid && buffer.empty() && !dev ) || format.sample_rate == 0;
+	}
 
 bool PVBuffer::is_nan_or_inf() const
 	{
@@ -46,6 +50,7 @@ bool PVBuffer::is_nan_or_inf() const
 
 void PVBuffer::clear_buffer()
 	{
+	auto held = lock.hold();
 	buffer.assign( count(), MF{ 0.0f, 0.0f } );
 	host_valid = true;
 	dev.reset();
@@ -54,6 +59,9 @@ void PVBuffer::clear_buffer()
 
 const std::vector<MF> & PVBuffer::get_buffer() const
 	{
+	// const methods may run concurrently on one object (they are pure reads in the reference): the first one brings the data over
+	// under the object's lock, the others wait for it; once host_valid is set no const method touches the vector again
+	auto held = lock.hold();
 	if( !host_valid )
 		{
 		if( buffer.capacity() < count() )                // fresh memory: let every worker fault its share of the pages in, not this thread alone
@@ -72,6 +80,7 @@ const std::vector<MF> & PVBuffer::get_buffer() const
 std::vector<MF> & PVBuffer::get_buffer()
 	{
 	std::as_const( *this ).get_buffer();
+	auto held = lock.hold();
 	dev.reset();
 	synth_ws.reset();                  // the caller may write: anything derived from the old data is stale
 	return buffer;
@@ -80,8 +89,9 @@ std::vector<MF> & PVBuffer::get_buffer()
 MF PVBuffer::get_MF( Channel c, Frame f, Bin b ) const { return get_buffer()[get_buffer_pos( c, f, b )]; }
 MF & PVBuffer::get_MF( Channel c, Frame f, Bin b ) { return get_buffer()[get_buffer_pos( c, f, b )]; }
 
-const MF * PVBuffer::device_data() const
+std::shared_ptr<detail::DeviceBlock> PVBuffer::device_block() const
 	{
+	auto held = lock.hold();
 	if( !dev )
 		{
 		if( count() == 0 ) return nullptr;
@@ -94,7 +104,13 @@ const MF * PVBuffer::device_data() const
 			}
 		dev = std::move( block );
 		}
-	return static_cast<const MF*>( dev->ptr );
+	return dev;
+	}
+
+const MF * PVBuffer::device_data() const
+	{
+	const auto block = device_block();
+	return block ? static_cast<const MF*>( block->ptr ) : nullptr;
 	}
 
 Magnitude PVBuffer::get_max_partial_magnitude() const
@@ -174,48 +190,63 @@ bool PVBuffer::save( const std::string & filename ) const
 	return true;
 	}
 
+// The file's fixed-size front matter as it lies on disk (little endian, no padding): RIFF header, "fmt " chunk, "data" chunk header.
+// One read, then a table of checks (the messages are the reference's, PVBuffer.cpp:216-273), then the 6-byte records in one read.
+namespace {
+#pragma pack( push, 1 )
+struct FlanFileHead
+	{
+	char riff[4]; uint32_t riff_size; char kind[4];
+	char fmt_tag[4]; uint32_t fmt_size;
+	uint16_t formatting, channels;
+	uint32_t frames, bins, sample_rate, hop_field, window_size, bit_depth;
+	uint16_t window_type;
+	char data_tag[4]; uint32_t data_size;
+	};
+#pragma pack( pop )
+static_assert( sizeof( FlanFileHead ) == 58, ".flan front matter is 58 bytes" );
+
+inline float unpack24( const uint8_t * p, float scale )
+	{
+	const int32_t v = int32_t( uint32_t( p[0] ) | uint32_t( p[1] ) << 8 | uint32_t( p[2] ) << 16 | ( p[2] & 0x80 ? 0xFF000000u : 0u ) );
+	return float( double( v ) / 8388608.0 ) * scale;                              // / 2^23, then back to magnitude / Hz (PVBuffer.cpp:254-262)
+	}
+}
+
 bool PVBuffer::load( const std::string & filename )
 	{
-	auto bail = []( const std::string & s ) { std::cout << s << std::endl; return false; };
 	std::ifstream file( filename, std::ios::binary );
-	if( !file ) return bail( "Error opening " + filename + " to load PV." );
+	if( !file ) { std::cout << "Error opening " + filename + " to load PV." << std::endl; return false; }
+	FlanFileHead h{};
+	file.read( reinterpret_cast<char*>( &h ), sizeof( h ) );
 
-	uint16_t u16 = 0; uint32_t u32 = 0; char tag[4];
-	file.read( tag, 4 ); if( std::strncmp( tag, "RIFF", 4 ) != 0 ) return bail( filename + " isn't a correctly formatted RIFF file.\n" );
-	file.read( tag, 4 );
-	file.read( tag, 4 ); if( std::strncmp( tag, "PV", 4 ) != 0 ) return bail( filename + " isn't a PV file.\n" );
-	Format fmt;
-	file.read( tag, 4 ); if( std::strncmp( tag, "fmt ", 4 ) != 0 ) return bail( filename + " isn't formatted correctly (\"fmt \" wasn't at the start of the format chunk).\n" );
-	file.read( reinterpret_cast<char*>( &u32 ), 4 );
-	file.read( reinterpret_cast<char*>( &u16 ), 2 ); if( u16 != 1 ) return bail( "Formatting must be 1 (signed int)." );
-	file.read( reinterpret_cast<char*>( &u16 ), 2 ); fmt.num_channels = u16;
-	file.read( reinterpret_cast<char*>( &u32 ), 4 ); fmt.num_frames = Frame( u32 );
-	file.read( reinterpret_cast<char*>( &u32 ), 4 ); fmt.num_bins = Bin( u32 );
-	file.read( reinterpret_cast<char*>( &u32 ), 4 ); fmt.sample_rate = FrameRate( u32 );
-	file.read( reinterpret_cast<char*>( &u32 ), 4 ); fmt.analysis_rate = FrameRate( u32 );   // PVBuffer.cpp:245 (the file holds the HOP here)
-	file.read( reinterpret_cast<char*>( &u32 ), 4 ); fmt.window_size = Frame( u32 );
-	file.read( reinterpret_cast<char*>( &u32 ), 4 ); if( u32 != 24 ) return bail( "Bit depth must be 24." );
-	file.read( reinterpret_cast<char*>( &u16 ), 2 ); if( u16 != 1 ) return bail( "PV window must be 1 (hann)." );
-	*this = PVBuffer( fmt );
-	file.read( tag, 4 ); if( std::strncmp( tag, "data", 4 ) != 0 ) return bail( filename + " isn't a correctly formatted PV file (\"data\" wasn't at the start of the data chunk).\n" );
-	file.read( reinterpret_cast<char*>( &u32 ), 4 );
-
-	const double limit = std::pow( 2, 23 );
-	const float window_size_f = float( get_dft_size() );
-	const float max_frequency_f = get_sample_rate();
-	auto get_float = [&]( float div )
-		{
-		int32_t i = 0;
-		file.read( reinterpret_cast<char*>( &i ), 3 );
-		if( i & 0x800000 ) i |= int32_t( 0xFF000000 );
-		return float( double( i ) / limit ) * div;
+	const struct { bool ok; std::string message; } checks[] = {
+		{ std::memcmp( h.riff, "RIFF", 4 ) == 0,     filename + " isn't a correctly formatted RIFF file.\n" },
+		{ std::memcmp( h.kind, "PV\0\0", 4 ) == 0,   filename + " isn't a PV file.\n" },
+		{ std::memcmp( h.fmt_tag, "fmt ", 4 ) == 0,  filename + " isn't formatted correctly (\"fmt \" wasn't at the start of the format chunk).\n" },
+		{ h.formatting == 1,                         "Formatting must be 1 (signed int)." },
+		{ h.bit_depth == 24,                         "Bit depth must be 24." },
+		{ h.window_type == 1,                        "PV window must be 1 (hann)." },
+		{ std::memcmp( h.data_tag, "data", 4 ) == 0, filename + " isn't a correctly formatted PV file (\"data\" wasn't at the start of the data chunk).\n" },
 		};
-	for( MF & mf : buffer )
-		{
-		const float m = get_float( window_size_f );
-		const float f = get_float( max_frequency_f );
-		mf = MF{ m, f };
-		}
+	for( const auto & c : checks )
+		if( !c.ok ) { std::cout << c.message << std::endl; return false; }
+
+	Format fmt;
+	fmt.num_channels = h.channels;
+	fmt.num_frames = Frame( h.frames );
+	fmt.num_bins = Bin( h.bins );
+	fmt.sample_rate = FrameRate( h.sample_rate );
+	fmt.analysis_rate = FrameRate( h.hop_field );              // the reference reads the HOP field into analysis_rate (PVBuffer.cpp:245): kept
+	fmt.window_size = Frame( h.window_size );
+	*this = PVBuffer( fmt );
+
+	std::vector<uint8_t> packed( buffer.size() * 6 );
+	file.read( reinterpret_cast<char*>( packed.data() ), std::streamsize( packed.size() ) );
+	const size_t got = size_t( file.gcount() ) / 6;            // a short file leaves the rest of the buffer zero, as the reference's failed reads do
+	const float m_scale = float( get_dft_size() ), f_scale = get_sample_rate();
+	for( size_t i = 0; i < std::min( got, buffer.size() ); ++i )
+		buffer[i] = MF{ unpack24( packed.data() + 6 * i, m_scale ), unpack24( packed.data() + 6 * i + 3, f_scale ) };
 	return true;
 	}
 

@@ -105,19 +105,26 @@ def exchange_overlaps(dist, local_out, rank, world_size, hop, pad):
     import torch
     z = pad * hop
     own = local_out[:, z:local_out.shape[1] - z].clone()
-    reqs, recv_left, recv_right = [], None, None
+    # a rank's padding zone must not reach beyond its immediate neighbour's own samples: every range holds at least `pad` frames
+    # (frame_ranges() hands out contiguous ranges; with fewer frames than that per rank, shard over fewer ranks)
+    if own.shape[1] < z:
+        raise ValueError("exchange_overlaps: a frame range of %d samples is shorter than the overlap zone of %d: use fewer ranks" % (own.shape[1], z))
+    ops, recv_left, recv_right = [], None, None
     if rank > 0:                                                   # my left padding zone belongs to rank - 1's last samples
         recv_left = torch.empty((local_out.shape[0], z), dtype=local_out.dtype, device=local_out.device)
-        reqs.append(dist.isend(local_out[:, :z].contiguous(), dst=rank - 1))
-        reqs.append(dist.irecv(recv_left, src=rank - 1))
+        ops.append(dist.P2POp(dist.isend, local_out[:, :z].contiguous(), rank - 1))
+        ops.append(dist.P2POp(dist.irecv, recv_left, rank - 1))
     if rank < world_size - 1:
         recv_right = torch.empty((local_out.shape[0], z), dtype=local_out.dtype, device=local_out.device)
-        reqs.append(dist.isend(local_out[:, local_out.shape[1] - z:].contiguous(), dst=rank + 1))
-        reqs.append(dist.irecv(recv_right, src=rank + 1))
-    for r in reqs:
-        r.wait()
+        ops.append(dist.P2POp(dist.isend, local_out[:, local_out.shape[1] - z:].contiguous(), rank + 1))
+        ops.append(dist.P2POp(dist.irecv, recv_right, rank + 1))
+    # one batch: with RCCL, unbatched isend-then-irecv on every rank is the send-first pattern that deadlocks once a message no
+    # longer fits the channel FIFO
+    if ops:
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
     if recv_left is not None:                                      # rank - 1's right padding zone = my first z samples
-        w = min(z, own.shape[1]); own[:, :w] += recv_left[:, :w]
+        own[:, :z] += recv_left
     if recv_right is not None:                                     # rank + 1's left padding zone = my last z samples
-        w = min(z, own.shape[1]); own[:, own.shape[1] - w:] += recv_right[:, z - w:]
+        own[:, own.shape[1] - z:] += recv_right
     return own

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "flan/defines.h"
+#include "flan/mirror_lock.h"
 
 namespace flan {
 
@@ -62,9 +63,10 @@ public:
 	std::vector<float> & get_buffer();                                           // ... and drops the device copy (host now owns the truth)
 
 	// ---- device residency (MI355X) ----
-	bool is_device_resident() const { return bool( dev ); }
+	bool is_device_resident() const { auto held = lock.hold(); return bool( dev ); }
 	const float * device_data() const;                                           // uploads on first use; nullptr on failure
 	static AudioBuffer adopt_device( const Format &, std::shared_ptr<detail::DeviceBlock> );
+	std::shared_ptr<detail::DeviceBlock> device_block() const;                   // the shared handle on the HBM copy (uploads on first use)
 
 protected:
 	size_t count() const { return size_t( format.num_channels ) * size_t( format.num_frames ); }
@@ -72,6 +74,7 @@ protected:
 	mutable std::vector<float> buffer;
 	mutable bool host_valid = true;
 	mutable std::shared_ptr<detail::DeviceBlock> dev;
+	detail::MirrorLock lock;                       // guards buffer / host_valid / dev against concurrent const methods (mirror_lock.h)
 	};
 
 } // namespace flan

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "flan/defines.h"
+#include "flan/mirror_lock.h"
 
 namespace flan {
 
@@ -87,17 +88,22 @@ public:
 	void print_summary() const;                                                                                      // :327-330, :535-548
 
 	// ---- device residency (MI355X) ----
-	bool is_device_resident() const { return bool( dev ); }
+	bool is_device_resident() const { auto held = lock.hold(); return bool( dev ); }
 	const MF * device_data() const;
-	bool host_copy_is_current() const { return host_valid; }                                             // false: the data lives on the device only
+	bool host_copy_is_current() const { auto held = lock.hold(); return host_valid; }                                             // false: the data lives on the device only
 	static PVBuffer adopt_device( const Format &, std::shared_ptr<detail::DeviceBlock> );
 	/** convert_to_PV leaves convert_to_audio's pre-pass (per-chain phase sums, in a synthesis workspace) next to the data; it is
 	 *  valid while the data is untouched and is consumed by the first convert_to_audio (flanhip_*_fused in flanhip.h). */
-	void attach_synthesis_workspace( std::shared_ptr<detail::DeviceBlock> ws, bool maybe = false ) const { synth_ws = std::move( ws ); synth_ws_maybe = maybe; }
-	std::shared_ptr<detail::DeviceBlock> take_synthesis_workspace() const { auto w = std::move( synth_ws ); synth_ws.reset(); return w; }
+	void attach_synthesis_workspace( std::shared_ptr<detail::DeviceBlock> ws, bool maybe = false ) const
+		{ auto held = lock.hold(); synth_ws = std::move( ws ); synth_ws_maybe = maybe; }
+	std::shared_ptr<detail::DeviceBlock> take_synthesis_workspace() const                                // one caller gets it, every other one nullptr
+		{ auto held = lock.hold(); auto w = std::move( synth_ws ); synth_ws.reset(); return w; }
 	/** true: the workspace MAY hold the pre-pass (left by modify_time / stretch, whose time map decides on the device):
 	 *  convert_to_audio then goes through flanhip_synthesize_dev_fused_checked */
-	bool synthesis_workspace_is_conditional() const { return synth_ws_maybe; }
+	bool synthesis_workspace_is_conditional() const { auto held = lock.hold(); return synth_ws_maybe; }
+	/** the shared handle on the HBM copy (uploads on first use; empty on failure): keeps the block alive for as long as a caller works on it,
+	 *  whatever other threads do to this object meanwhile */
+	std::shared_ptr<detail::DeviceBlock> device_block() const;
 
 protected:
 	size_t count() const { return size_t( format.num_channels ) * size_t( format.num_frames ) * size_t( format.num_bins ); }
@@ -107,6 +113,7 @@ protected:
 	mutable std::shared_ptr<detail::DeviceBlock> dev;
 	mutable std::shared_ptr<detail::DeviceBlock> synth_ws;
 	mutable bool synth_ws_maybe = false;
+	detail::MirrorLock lock;                       // guards buffer / host_valid / dev / synth_ws against concurrent const methods (mirror_lock.h)
 	};
 
 } // namespace flan

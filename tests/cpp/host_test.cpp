@@ -10,6 +10,7 @@
 #include <iostream>
 #include <string>
 #include <thread>
+#include <chrono>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -379,6 +380,52 @@ static void device_checks()
 		for( int t = 0; t < 4; ++t )
 			CHECK( !alone[size_t( t )].empty() && alone[size_t( t )].size() == together[size_t( t )].size()
 				&& std::memcmp( alone[size_t( t )].data(), together[size_t( t )].data(), sizeof( float ) * alone[size_t( t )].size() ) == 0 );
+		}
+	// ---- const methods of ONE object from several threads (pure reads in the reference): lazy download / upload and the workspace
+	//      hand-over are guarded by the object's lock (mirror_lock.h) -- every thread gets the single-threaded answer
+		{
+		Audio x = noise( 2, 60000, 911 );
+		const PV shared_pv = x.convert_to_PV( 2048, 512, 2048 );                       // device resident, pre-pass attached, host copy not yet made
+		const std::vector<float> expect = shared_pv.copy().convert_to_audio().get_buffer();
+		std::vector<std::vector<float>> got( 6 );
+		std::vector<double> energy( 6, 0.0 );
+		std::vector<std::thread> threads;
+		for( int t = 0; t < 6; ++t ) threads.emplace_back( [&, t]
+			{
+			if( t & 1 ) { for( const MF & mf : shared_pv.get_buffer() ) energy[size_t( t )] += double( mf.m ); }   // concurrent first download
+			got[size_t( t )] = shared_pv.convert_to_audio().get_buffer();            // concurrent hand-over of the one workspace
+			} );
+		for( auto & th : threads ) th.join();
+		for( int t = 0; t < 6; ++t )
+			{
+			CHECK( got[size_t( t )].size() == expect.size() );
+			double worst = 0;
+			for( size_t i = 0; i < expect.size() && i < got[size_t( t )].size(); ++i ) worst = std::max( worst, double( std::fabs( got[size_t( t )][i] - expect[i] ) ) );
+			CHECK( worst <= 1e-6 );                                                    // (fused and unfused pre-pass differ by rounding of partial sums only)
+			}
+		CHECK( energy[1] > 0 && energy[1] == energy[3] && energy[3] == energy[5] );
+		const Audio shared_audio = noise( 2, 50000, 912 );
+		std::vector<Frame> frames( 4, 0 );
+		std::vector<std::thread> t2;
+		for( int t = 0; t < 4; ++t ) t2.emplace_back( [&, t]{ frames[size_t( t )] = shared_audio.convert_to_PV( 2048, 512, 2048 ).get_num_frames(); } );   // concurrent first upload
+		for( auto & th : t2 ) th.join();
+		for( int t = 0; t < 4; ++t ) CHECK( frames[size_t( t )] == 50000 / 512 + 1 );
+		}
+	// ---- cancellation raised from a second thread while a long call is running (flan_CANCEL_POINT, defines.h:49-62): the call comes
+	//      back with a null object (or, if it won the race, with the full result) -- never with a partial one
+		{
+		Audio longish = noise( 8, 48000 * 20, 913 );                                   // a few stages of work: upload, analysis, synthesis
+		for( int trial = 0; trial < 4; ++trial )
+			{
+			std::atomic<bool> flag( false );
+			std::thread killer( [&]{ std::this_thread::sleep_for( std::chrono::microseconds( 200 * trial ) ); flag.store( true ); } );
+			PV p = longish.convert_to_PV( 2048, 512, 2048, flag );
+			Audio back = p.is_null() ? Audio() : p.convert_to_audio( flag );
+			killer.join();
+			CHECK( p.is_null() || p.get_num_frames() == 48000 * 20 / 512 + 1 );
+			CHECK( back.is_null() || back.get_num_frames() == p.get_num_frames() * 512 );
+			if( flag.load() && !p.is_null() ) CHECK( p.convert_to_audio( flag ).is_null() );   // once raised, every later call refuses
+			}
 		}
 	// ---- large host <-> device transfers go in slabs through page-locked blocks: what arrives is what was sent
 		{

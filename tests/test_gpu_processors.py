@@ -293,6 +293,46 @@ def test_modify_time_fused_prepass(fa, dft, hop):
         assert flag_a == 1 and flag_b == 1, name
 
 
+def test_two_fused_producers_share_one_workspace(fa):
+    """A workspace is recycled uncleared (device cache): a producer that leaves the pre-pass (a monotone time map, never converted)
+    followed on the SAME workspace by one that must not (a map that runs backwards).  The second convert_to_audio has to run its
+    own pre-pass -- the "sums valid" word of the first producer must not survive (it did while two successive launches could share
+    an epoch number)."""
+    import ctypes as C
+    lib = fa.lib
+    hop, dft, W = 512, 2048, 2048
+    rng = np.random.default_rng(77)
+    x = O.noise(2, 40 * hop + 5, seed=77)
+    pv = O.analyze(x, SR, W, hop, dft)
+    ch, F, bins, _ = pv.shape
+    hop_s = hop / SR
+    ar = np.float32(SR) / np.float32(hop)
+    mono = (np.arange(F, dtype=np.float32)[:, None] * np.ones((1, bins), np.float32) * hop_s).astype(np.float32)      # identity map: Fo = F
+    back = mono.copy()
+    back[5:9] = back[5:9][::-1]                                                                                          # a few frames run backwards, same extent
+    Fo = int(lib.flanhip_modify_time_out_frames(mono.ctypes.data_as(C.c_void_p), F, bins, SR, hop))
+    assert Fo == int(lib.flanhip_modify_time_out_frames(back.ctypes.data_as(C.c_void_p), F, bins, SR, hop))
+    P = lambda d: C.c_void_p(d.ptr)
+    d_pv = fa.DeviceArray(host=pv)
+    d_ws = fa.DeviceArray(fa.synthesize_workspace_bytes(ch, Fo, bins, SR, float(ar), W))
+    d_flag = fa.DeviceArray(host=np.zeros(1, np.int32))
+    d_st, d_out = fa.DeviceArray(ch * Fo * bins * 8), fa.DeviceArray(ch * Fo * hop * 4)
+    for _ in range(3):                                                                                                   # any parity of the epoch counter
+        d_mod = fa.DeviceArray(host=mono)
+        fa.check(lib.flanhip_modify_time_dev_fused(P(d_pv), ch, F, bins, SR, ar, P(d_mod), Fo, P(d_st), W, P(d_ws), None))   # leaves sums, never converted
+        d_mod2 = fa.DeviceArray(host=back)
+        fa.check(lib.flanhip_modify_time_dev_fused(P(d_pv), ch, F, bins, SR, ar, P(d_mod2), Fo, P(d_st), W, P(d_ws), None))  # must not hand anything over
+        fa.check(lib.flanhip_synthesize_dev_fused_checked(P(d_st), ch, Fo, bins, SR, ar, W, P(d_out), P(d_ws), P(d_flag), None))
+        got = d_out.to_host((ch, Fo * hop))
+        st = d_st.to_host((ch, Fo, bins, 2))
+        ref = O.modify_time(pv, SR, hop, back)
+        assert np.array_equal(st.view(np.uint32), ref.view(np.uint32))
+        d_ws2 = fa.DeviceArray(fa.synthesize_workspace_bytes(ch, Fo, bins, SR, float(ar), W))
+        fa.check(lib.flanhip_synthesize_dev(P(d_st), ch, Fo, bins, SR, ar, W, P(d_out), P(d_ws2), P(d_flag), None))
+        want = d_out.to_host((ch, Fo * hop))
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_modify_time_edge_shapes(fa):
     """one-frame PVs, one-frame outputs, a constant map (every frame pair empty), outputs shorter than a chain"""
     rng = np.random.default_rng(41)
