@@ -2,34 +2,35 @@
 """bench.py -- PV analysis+resynthesis frames/sec on MI355X (BASELINE.json metric).
 
 One "step" = one pass of the hot path over one batch of synthetic audio that is already resident in HBM:
-    Audio::convert_to_PV(2048, 512, dft 2048)  ->  PV::convert_to_audio        (flanhip_analyze_dev + flanhip_synthesize_dev)
-Workload at N=1: 8 channels x 60 s x 48 kHz uniform noise (the configuration BASELINE.json's north_star quotes its
-targets on: "60 s x 8-ch 48 kHz convertToPV->convertToAudio round-trip at 1 GPU").  With --gpus N every rank owns its
-own 8 channels (channels are independent: AudioPV.cpp:41,44,108,111), so the job is 8N channels, "scaling": "weak",
-with no collective inside the timed region.  The RCCL all-gather that reassembles the output buffer
-(float[8N][frames], channel-major so the gathered buffer IS the final layout) is timed separately and reported in
-"allgather" -- it is not part of the PV frames/s metric.
+    Audio::convert_to_PV(2048, 512, dft 2048)  ->  PV::convert_to_audio        (flanhip_analyze_dev_fused + flanhip_synthesize_dev_fused)
+Workload at N=1: 8 channels x 60 s x 48 kHz uniform noise (the configuration BASELINE.json's north_star quotes its targets on:
+"60 s x 8-ch 48 kHz convertToPV->convertToAudio round-trip at 1 GPU").  With --gpus N every rank owns its own 8 channels
+(channels are independent: AudioPV.cpp:41,44,108,111), so the job is 8N channels, "scaling": "weak", with no collective inside
+the timed region.  `--gpus N` with N > 1 and no WORLD_SIZE in the environment LAUNCHES the N ranks itself (torch.distributed.run,
+one process per GPU, 127.0.0.1 rendezvous) before anything here touches a GPU; under torchrun / the driver's own launch it is
+one of those ranks.  The RCCL all-gather that reassembles the output buffer (float[8N][frames], channel-major, so the gathered
+buffer IS the final layout) is reported beside the metric in "allgather": once on its own and once overlapped with the compute,
+per channel chunk on a side stream -- it is not part of the PV frames/s value.
 
-PyTorch here is plumbing only: device buffers, the stream, events and torch.distributed.  The kernels are the HIP
-library flan_amd/libflanhip.so called through the C ABI (include/flanhip.h).
+--seconds 600 gives the per-GPU shard of BASELINE config 4 (64 ch x 10 min over 8 GPUs = 8 ch x 600 s each).
+
+PyTorch here is plumbing only: device buffers, streams, events and torch.distributed.  The kernels are the HIP library
+flan_amd/libflanhip.so called through the C ABI (include/flanhip.h).
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WINDOW, HOP, DFT, SR = 2048, 512, 2048, 48000.0
-BINS = DFT // 2 + 1
+SR = 48000.0
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy)
-# SURVEY 8(d): algorithmic bytes per PV frame at dft 2048 -- analysis reads hop*4 and writes bins*8, synthesis mirrors it
-BYTES_ANALYSIS = HOP * 4 + BINS * 8         # 10 248
-BYTES_SYNTHESIS = BINS * 8 + HOP * 4        # 10 248
-BYTES_ROUNDTRIP = BYTES_ANALYSIS + BYTES_SYNTHESIS   # 20 496
 
 
 def baseline_metric():
@@ -41,9 +42,54 @@ def baseline_metric():
         return "PV analysis+resynthesis frames/sec (2048-win, hop 512, 48 kHz) at 1/2/4/8 GPU"
 
 
-def cpu_baseline(channels, seconds, threads):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--channels", type=int, default=8, help="channels per GPU")
+    ap.add_argument("--seconds", type=float, default=60.0, help="60: the metric's workload; 600: the per-GPU shard of BASELINE config 4")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--gather-chunks", type=int, default=1, help="channel chunks per batch in the overlapped all-gather measurement (1: whole batches, double buffered)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the 'configs' object (BASELINE configs 3 and 5, the API-default dft 4096 call)")
+    ap.add_argument("--unfused", action="store_true", help="run synthesis' pre-pass as its own kernel instead of inside analysis")
+    ap.add_argument("--preroll-ms", type=float, default=80.0,
+                    help="untimed device warm-up before the W warm-up steps: the same steps run for this long so that the GPU's clocks "
+                         "have settled (a just-woken MI355X runs the same launch ~20 %% slower for its first ~40 ms); 0 disables")
+    ap.add_argument("--pcie", action="store_true", help="also time the host-buffer entry points (PCIe inclusive; reported in 'pcie_inclusive', never in 'value')")
+    ap.add_argument("--window", type=int, default=2048, help="2048: the BASELINE metric")
+    ap.add_argument("--hop", type=int, default=512, help="512: the BASELINE metric; 128 with --dft 4096 is the reference API's default call")
+    ap.add_argument("--dft", type=int, default=2048,
+                    help="2048: the primary measurement; 4096: the literal convert_to_PV(2048,512) default of the reference API (SURVEY 8)")
+    ap.add_argument("--plan-only", action="store_true",
+                    help="no GPU work: the ranks rendezvous over gloo, agree on the plan and rank 0 prints it (what tests/ use to cover the launcher on CPU)")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    """--gpus N > 1 outside a distributed launch: start the N rank processes (one per GPU) and hand their verdict on.  Runs before
+    this process has made any GPU call (a process that has initialised the GPU must not start or become another program)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
+def cpu_baseline(channels, seconds, threads, window, hop, dft):
     """The CPU oracle (oracle/flan_oracle.cpp, a port of the reference path) on the host cores; checker code used as the
-    reported baseline only."""
+    reported baseline only.  Returns (frames/s, frames, seconds)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as O
@@ -52,8 +98,8 @@ def cpu_baseline(channels, seconds, threads):
     x = O.noise(channels, n, seed=1234)
 
     def one(c):
-        pv = O.analyze(x[c:c + 1], SR, WINDOW, HOP, DFT)
-        out, _ = O.synthesize(pv, SR, SR / HOP, WINDOW)
+        pv = O.analyze(x[c:c + 1], SR, window, hop, dft)
+        O.synthesize(pv, SR, SR / hop, window)
         return pv.shape[1]
 
     t0 = time.perf_counter()
@@ -66,57 +112,94 @@ def cpu_baseline(channels, seconds, threads):
     return frames / dt, frames, dt
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--channels", type=int, default=8, help="channels per GPU")
-    ap.add_argument("--seconds", type=float, default=60.0)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--unfused", action="store_true", help="run synthesis' pre-pass as its own kernel instead of inside analysis")
-    ap.add_argument("--preroll-ms", type=float, default=80.0,
-                    help="untimed device warm-up before the W warm-up steps: the same steps run for this long so that the GPU's clocks "
-                         "have settled (measured: a launch takes 0.204 ms on a just-woken MI355X, 0.166 ms after ~40 ms of load); 0 disables")
-    ap.add_argument("--pcie", action="store_true", help="also time the host-buffer entry points (PCIe inclusive; reported in 'pcie_inclusive', never in 'value')")
-    ap.add_argument("--window", type=int, default=2048, help="2048: the BASELINE metric")
-    ap.add_argument("--hop", type=int, default=512, help="512: the BASELINE metric; 128 with --dft 4096 is the reference API's default call")
-    ap.add_argument("--dft", type=int, default=2048,
-                    help="2048: the primary measurement; 4096: the literal convert_to_PV(2048,512) default of the reference API (SURVEY 8)")
-    args = ap.parse_args()
-    global DFT, HOP, WINDOW, BINS, BYTES_ANALYSIS, BYTES_SYNTHESIS, BYTES_ROUNDTRIP
-    DFT, HOP, WINDOW = args.dft, args.hop, args.window
-    BINS = DFT // 2 + 1
-    BYTES_ANALYSIS = BYTES_SYNTHESIS = HOP * 4 + BINS * 8      # 10 248 (dft 2048) / 18 440 (dft 4096)
-    BYTES_ROUNDTRIP = BYTES_ANALYSIS + BYTES_SYNTHESIS
+def cpu_fft_share(frames, dft, per_frame_seconds):
+    """How much of the oracle's time is its own FFT (fp64 radix-2, not FFTW): r2c + c2r per frame, timed alone on a sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as O
+    lib = O._load()
+    x = np.random.default_rng(1).uniform(-1, 1, dft).astype(np.float32)
+    X = np.zeros((dft // 2 + 1) * 2, np.float32)
+    y = np.zeros(dft, np.float32)
+    reps = max(200, min(4000, frames // 10))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        lib.oracle_r2c(x, dft, X)
+        lib.oracle_c2r(X, dft, y)
+    per = (time.perf_counter() - t0) / reps
+    return round(per / per_frame_seconds, 3), round(per * 1e6, 2)
 
-    import torch
-    import flan_amd as fa
-    from flan_amd import sharding
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world != 1:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
-    distributed = world > 1 or os.environ.get("FLAN_BENCH_FORCE_DIST") == "1"   # the env knob rehearses the RCCL path on one GPU
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    WINDOW, HOP, DFT = args.window, args.hop, args.dft
+    BINS = DFT // 2 + 1
+    # SURVEY 8(d): algorithmic bytes per PV frame -- analysis reads hop*4 and writes bins*8, synthesis mirrors it
+    BYTES_ANALYSIS = BYTES_SYNTHESIS = HOP * 4 + BINS * 8      # 10 248 (dft 2048) / 18 440 (dft 4096, hop 512)
+    BYTES_ROUNDTRIP = BYTES_ANALYSIS + BYTES_SYNTHESIS
+    ch, n = args.channels, int(args.seconds * SR)
+    parallelism = "channel-shard x%d" % world
+
+    if args.plan_only:
+        # the launcher, the rendezvous and the sharding arithmetic without a GPU (gloo): tests/test_bench_launcher.py
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        F = n // HOP + 1
+        mine = {"rank": rank, "channels": [rank * ch, rank * ch + ch], "frames": ch * F}
+        plans = [mine]
+        if world > 1:
+            plans = [None] * world
+            dist.all_gather_object(plans, mine)
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"plan_only": True, "metric": baseline_metric(), "n_gpus": world, "scaling": "weak",
+                              "config": {"workload": "%d ch x %.0f s per GPU" % (ch, args.seconds), "parallelism": parallelism},
+                              "total_channels": world * ch, "frames_per_step": sum(p["frames"] for p in plans), "ranks": plans}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    import torch
+    import flan_amd as fa
+    from flan_amd import sharding
+
+    # FLAN_BENCH_SHARE_GPU=1 rehearses the multi-rank path on ONE GPU: every rank uses cuda:0, the control plane runs over gloo and the
+    # RCCL gather is left out (RCCL refuses two ranks on one device); numbers from it say nothing about scaling
+    share_gpu = os.environ.get("FLAN_BENCH_SHARE_GPU") == "1"
+    distributed = world > 1 or os.environ.get("FLAN_BENCH_FORCE_DIST") == "1"   # FORCE_DIST: the RCCL path with one rank
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback path)")
-    torch.cuda.set_device(local_rank)
-    fa.check(fa.lib.flanhip_set_device(local_rank))
-    dev = torch.device("cuda", local_rank)
+    dev_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    fa.check(fa.lib.flanhip_set_device(dev_index))
+    dev = torch.device("cuda", dev_index)
+    dist = None
     if distributed:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # rank 0 prints exactly one JSON line on stdout: RCCL's own messages (its version banner, warnings such as "Could not read
-        # node #") go to stderr
+        # rank 0 prints exactly one JSON line on stdout: RCCL's own messages go to stderr
         os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
         if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
             os.environ["NCCL_DEBUG"] = "WARN"
-        dist.init_process_group("nccl", device_id=dev)
+        if "MASTER_PORT" not in os.environ:                  # FLAN_BENCH_FORCE_DIST=1 outside a launcher: a one-rank job of its own
+            os.environ["MASTER_PORT"] = str(free_port())
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    ctl_dev = torch.device("cpu") if share_gpu else dev      # where the control-plane tensors (max over ranks) live
 
-    ch, n = args.channels, int(args.seconds * SR)
     F = int(fa.lib.flanhip_num_pv_frames(n, HOP))
     ar = SR / HOP
     frames_per_step = ch * F
@@ -130,17 +213,17 @@ def main():
     nan_flag = torch.zeros(1, dtype=torch.int32, device=dev)
 
     # the round trip is fused by default: the analysis kernel leaves synthesis' pre-pass (per-chain phase sums) in the workspace
-    def analyze():
+    def analyze(a=audio, p=pv, w=ws, c=ch, s=stream):
         if args.unfused:
-            fa.analyze_dev(audio, ch, n, SR, WINDOW, HOP, DFT, pv, stream)
+            fa.analyze_dev(a, c, n, SR, WINDOW, HOP, DFT, p, s)
         else:
-            fa.analyze_dev_fused(audio, ch, n, SR, WINDOW, HOP, DFT, pv, ws, stream)
+            fa.analyze_dev_fused(a, c, n, SR, WINDOW, HOP, DFT, p, w, s)
 
-    def synthesize():
+    def synthesize(p=pv, o=out, w=ws, c=ch, s=stream):
         if args.unfused:
-            fa.synthesize_dev(pv, ch, F, BINS, SR, ar, WINDOW, out, ws, nan_flag, stream)
+            fa.synthesize_dev(p, c, F, BINS, SR, ar, WINDOW, o, w, nan_flag, s)
         else:
-            fa.synthesize_dev_fused(pv, ch, F, BINS, SR, ar, WINDOW, out, ws, nan_flag, stream)
+            fa.synthesize_dev_fused(p, c, F, BINS, SR, ar, WINDOW, o, w, nan_flag, s)
 
     def step():
         analyze()
@@ -170,7 +253,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if distributed:
-        elapsed = sharding.max_over_ranks(dist, elapsed, dev)
+        elapsed = sharding.max_over_ranks(dist, elapsed, ctl_dev)
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * frames_per_step * args.steps / elapsed
 
@@ -203,15 +286,22 @@ def main():
         else:
             kname, tk, b = "k_synthesize", t_sy_main, BYTES_SYNTHESIS
         achieved = frames_per_step * b / (tk * 1e-3) / 1e9
-        # HBM bytes per launch of that kernel from the committed PMC profile of this same workload (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE, corrected as profiles/r01_hbm_traffic.json explains); null for any other workload shape
-        traffic = None
+        # HBM bytes per launch of that kernel: not measurable from inside this process (PMC counters need rocprofv3), so the figure comes
+        # from the committed PMC profile of this same workload and build (tools/scripts/profile_bench.sh -> profiles/r02_hbm_traffic.json:
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, with the unit and gfx950 corrections the file explains) and is
+        # labelled with its source; null for any other workload shape
+        traffic, traffic_source = None, None
         try:
             if ch == 8 and abs(args.seconds - 60.0) < 1e-9 and DFT == 2048 and HOP == 512 and WINDOW == 2048:
-                with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as fh:
-                    traffic = json.load(fh)[kname]["traffic_bytes"]
+                for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+                    path = os.path.join(ROOT, "profiles", name)
+                    if os.path.exists(path):
+                        with open(path) as fh:
+                            traffic = json.load(fh)[kname]["traffic_bytes"]
+                        traffic_source = "profiles/" + name
+                        break
         except Exception:
-            traffic = None
+            traffic, traffic_source = None, None
         # what a plain device-to-device copy of the same number of bytes reaches on this box (quote the measured
         # copy rate beside the 8 TB/s spec); read + written bytes, like the algorithmic figure
         copy_gbs = None
@@ -230,14 +320,15 @@ def main():
         except Exception:
             copy_gbs = None
         roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "launch_ms": round(tk, 4), "algorithmic_bytes_per_launch": frames_per_step * b,
                     "copy_peak_measured": copy_gbs}
         extra["roundtrip_hbm"] = {"achieved_GBs": round(frames_per_step * BYTES_ROUNDTRIP / (ms_per_step * 1e-3) / 1e9, 1),
                                   "frac_of_8TBs": round(frames_per_step * BYTES_ROUNDTRIP / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
-    # the output-reassembly all-gather of the north star, outside the metric
-    if distributed and not args.no_gather:
+    # ---- the output-reassembly all-gather of the north star, outside the metric: on its own, and overlapped with the compute ----
+    if distributed and not args.no_gather and not share_gpu:
+        nranks = dist.get_world_size()
         for _ in range(2):
             gathered = sharding.gather_output(dist, out, world)
         sync_all()
@@ -246,10 +337,66 @@ def main():
         for _ in range(reps):
             gathered = sharding.gather_output(dist, out, world)
         sync_all()
-        tg = sharding.max_over_ranks(dist, (time.perf_counter() - t0) / reps, dev)
+        tg = sharding.max_over_ranks(dist, (time.perf_counter() - t0) / reps, ctl_dev)
         assert gathered.shape == (world * ch, F * HOP)
-        extra["allgather"] = {"ms": round(tg * 1e3, 3), "bytes_per_rank": out.numel() * 4,
-                              "frames_per_s_with_gather": round(world * frames_per_step / (elapsed / args.steps + tg), 1)}
+        del gathered
+        # overlapped: batch i's output travels (one batch of point-to-point operations into the final channel-major buffer, on a side
+        # stream) while batch i + 1 is analysed and synthesised -- two output buffers in turn; with --gather-chunks K > 1 the rank's
+        # channels are additionally cut into K chunks per batch, each sent as soon as it is done (smaller launches: slower compute)
+        chunks = max(1, min(args.gather_chunks, ch))
+        while ch % chunks:
+            chunks -= 1
+        k = ch // chunks
+        side = torch.cuda.Stream(device=dev)
+        outs = [out, torch.empty_like(out)]
+        finals = [torch.empty((world * ch, F * HOP), dtype=torch.float32, device=dev) for _ in range(2)]
+        wss = [torch.empty(fa.synthesize_workspace_bytes(k, F, BINS, SR, ar, WINDOW), dtype=torch.uint8, device=dev) for _ in range(chunks)]
+        pending = [[], []]
+
+        def step_with_gather(i):
+            b = i & 1
+            for r in pending[b]:                     # the gather that last used this pair of buffers
+                r.wait()
+            pending[b] = []
+            torch.cuda.current_stream().wait_stream(side)
+            for c in range(chunks):
+                c0 = c * k
+                o = outs[b][c0:c0 + k]
+                analyze(audio[c0:c0 + k], pv[c0:c0 + k], wss[c], k)
+                synthesize(pv[c0:c0 + k], o, wss[c], k)
+                done = torch.cuda.Event()
+                done.record()
+                side.wait_event(done)
+                with torch.cuda.stream(side):
+                    pending[b] += sharding.gather_chunk_into(dist, finals[b], o, rank, world, ch, c0)
+
+        def drain():
+            for b in (0, 1):
+                for r in pending[b]:
+                    r.wait()
+                pending[b] = []
+            torch.cuda.current_stream().wait_stream(side)
+
+        for i in range(4):
+            step_with_gather(i)
+        drain()
+        sync_all()
+        t0 = time.perf_counter()
+        reps = max(6, min(args.steps, 20))
+        for i in range(reps):
+            step_with_gather(i)
+        drain()
+        sync_all()
+        tov = sharding.max_over_ranks(dist, (time.perf_counter() - t0) / reps, ctl_dev)
+        for b in (0, 1):
+            assert bool(torch.equal(finals[b][rank * ch: rank * ch + ch], outs[b])), "the gathered buffer must hold this rank's channels in place"
+        extra["allgather"] = {"nranks": nranks, "ms_alone": round(tg * 1e3, 3), "bytes_per_rank": out.numel() * 4,
+                              "frames_per_s_compute_only": round(value, 1),
+                              "frames_per_s_compute_then_gather": round(world * frames_per_step / (elapsed / args.steps + tg), 1),
+                              "frames_per_s_gather_overlapped": round(world * frames_per_step / tov, 1),
+                              "overlapped_step_ms": round(tov * 1e3, 4), "channel_chunks": chunks,
+                              "overlap": "gather of batch i (side stream, p2p batch into the final layout) under the compute of batch i + 1"}
+        del finals, outs, wss
 
     # the host-buffer C ABI (flanhip_analyze / flanhip_synthesize): upload, kernels, download -- for DESIGN.md, never the metric
     if rank == 0 and args.pcie:
@@ -267,16 +414,29 @@ def main():
                                    "note": "pageable numpy buffers through flanhip_analyze + flanhip_synthesize (malloc, H2D, kernels, D2H)"}
         del pv_host, out_host
 
+    # ---- the other BASELINE configurations, timed the same way (device resident, events, after the same warm-up) ----
+    if rank == 0 and world == 1 and not args.no_configs:
+        del pv, out, ws
+        torch.cuda.empty_cache()
+        try:
+            extra["configs"] = other_configs(fa, torch, dev)
+        except Exception as e:                       # never lose the headline line to a side measurement
+            extra["configs"] = {"error": repr(e)}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:        # the CPU leg is reported at N=1 only; the other ranks would idle behind it
         cores = os.cpu_count() or 1
-        v1, frames1, dt1 = cpu_baseline(ch, args.seconds, 1)
+        sample_s = min(args.seconds, 60.0)           # bounded: at most 8 x 60 s = 45 008 frames (~4 s on one core, the same again on all)
+        v1, frames1, dt1 = cpu_baseline(ch, sample_s, 1, WINDOW, HOP, DFT)
+        share, fft_us = cpu_fft_share(frames1, DFT, dt1 / frames1)
         cpu = {"value": round(v1, 1), "unit": "frames/s", "cores": 1, "kind": "port",
                "sample": "%d ch x %.0f s round trip (%d frames, %.1f s) by oracle/flan_oracle.cpp, 1 thread, fp64 radix-2 FFT (not FFTW)"
-                         % (ch, args.seconds, frames1, dt1)}
+                         % (ch, sample_s, frames1, dt1),
+               "fft_share": share, "fft_us_per_frame": fft_us,
+               "fft_note": "r2c + c2r of the oracle's own FFT timed alone: this share of the oracle's time; FFTW would take ~3-5 us per transform"}
         threads = min(cores, ch)
         if threads > 1:
-            vN, _, dtN = cpu_baseline(ch, args.seconds, threads)
+            vN, _, dtN = cpu_baseline(ch, sample_s, threads, WINDOW, HOP, DFT)
             cpu["all_cores"] = {"value": round(vN, 1), "cores": threads, "host_cores": cores, "seconds": round(dtN, 2)}
 
     if rank == 0:
@@ -287,15 +447,114 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%d ch x %.0f s x 48 kHz uniform noise per GPU, convert_to_PV(%d,%d,dft %d) -> convert_to_audio round trip"
                                    % (ch, args.seconds, WINDOW, HOP, DFT),
-                       "channels_per_gpu": ch, "pv_frames_per_step_per_gpu": frames_per_step, "parallelism": "channel-shard x%d" % world},
+                       "channels_per_gpu": ch, "pv_frames_per_step_per_gpu": frames_per_step, "parallelism": parallelism},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if share_gpu:
+            line["rehearsal"] = "FLAN_BENCH_SHARE_GPU=1: %d ranks on one GPU, gloo control plane, no RCCL gather" % world
         line["device_warmup"] = {"preroll_ms": args.preroll_ms, "preroll_steps": preroll_steps}
         line.update(extra)
         print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def other_configs(fa, torch, dev):
+    """BASELINE configs 3 and 5 and the reference API's default call, device resident, per-stage events.  Reported beside the headline
+    ('configs'); never part of 'value'."""
+    lib = fa.lib
+    vp = ctypes.c_void_p
+
+    def P(t):
+        return vp(t.data_ptr())
+
+    def timed(fn, reps=10):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    res = {}
+    W, HOP, DFT = 2048, 512, 2048
+    BINS = DFT // 2 + 1
+    ch, n = 8, 60 * 48000
+    F = int(lib.flanhip_num_pv_frames(n, HOP))
+    ar = SR / HOP
+    audio = torch.empty((ch, n), dtype=torch.float32, device=dev)
+    fa.check(lib.flanhip_noise_dev(P(audio), ch, n, 1234, None))
+
+    # ---- config 3: 8 ch x 60 s -> convert_to_PV -> stretch( x2 ) -> convert_to_audio (PVModify.cpp:371-385, :307-362)
+    pv = torch.empty((ch, F, BINS, 2), dtype=torch.float32, device=dev)
+    grid = torch.empty((F, BINS), dtype=torch.float32, device=dev)
+    dmax = torch.empty(1, dtype=torch.float32, device=dev)
+    Fo = 2 * F
+    st = torch.empty((ch, Fo, BINS, 2), dtype=torch.float32, device=dev)
+    out = torch.empty((ch, Fo * HOP), dtype=torch.float32, device=dev)
+    ws = torch.empty(fa.synthesize_workspace_bytes(ch, Fo, BINS, SR, ar, W), dtype=torch.uint8, device=dev)
+
+    def config3():
+        fa.check(lib.flanhip_analyze_dev(P(audio), ch, n, SR, W, HOP, DFT, P(pv), None))
+        fa.check(lib.flanhip_fill_dev(P(grid), F * BINS, 2.0, None))
+        fa.check(lib.flanhip_stretch_map_dev(P(grid), F, BINS, SR, HOP, P(dmax), None))
+        fa.check(lib.flanhip_modify_time_dev_fused(P(pv), ch, F, BINS, SR, ar, P(grid), Fo, P(st), W, P(ws), None))
+        fa.check(lib.flanhip_synthesize_dev_fused_checked(P(st), ch, Fo, BINS, SR, ar, W, P(out), P(ws), None, None))
+    ms = timed(config3)
+    bytes_per_input_frame = 10248 + 24600 + 2 * 10248                      # SURVEY 8d: 55 344 B per input frame
+    res["config3_stretch_x2"] = {"workload": "8 ch x 60 s: convert_to_PV(2048,512,2048) -> stretch(x2) -> convert_to_audio", "ms": round(ms, 4),
+                                 "input_frames_per_s": round(ch * F / (ms * 1e-3), 1),
+                                 "algorithmic_GBs": round(ch * F * bytes_per_input_frame / (ms * 1e-3) / 1e9, 1),
+                                 "frac_of_8TBs": round(ch * F * bytes_per_input_frame / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    del st, out, ws, grid
+
+    # ---- config 5: stereo 60 s at 96 kHz -> resample( 48000 ) -> convert_to_PV -> shape( f + 100 Hz ) -> convert_to_audio
+    c5, n96, n48 = 2, 60 * 96000, 60 * 48000
+    x96 = torch.empty((c5, n96), dtype=torch.float32, device=dev)
+    fa.check(lib.flanhip_noise_dev(P(x96), c5, n96, 7, None))
+    x48 = torch.empty((c5, n48), dtype=torch.float32, device=dev)
+    F5 = int(lib.flanhip_num_pv_frames(n48, HOP))
+    pv5 = torch.empty((c5, F5, BINS, 2), dtype=torch.float32, device=dev)
+    sh5 = torch.empty_like(pv5)
+    out5 = torch.empty((c5, F5 * HOP), dtype=torch.float32, device=dev)
+    ws5 = torch.empty(fa.synthesize_workspace_bytes(c5, F5, BINS, SR, ar, W), dtype=torch.uint8, device=dev)
+    stages5 = {
+        "resample_96k_to_48k": lambda: fa.check(lib.flanhip_resample_dev(P(x96), c5, n96, 96000.0, 48000.0, P(x48), None)),
+        "convert_to_PV": lambda: fa.check(lib.flanhip_analyze_dev(P(x48), c5, n48, SR, W, HOP, DFT, P(pv5), None)),
+        "shape_f_plus_100_and_convert_to_audio": lambda: (
+            fa.check(lib.flanhip_shape_affine_dev_fused(P(pv5), c5, F5, BINS, SR, ar, 1.0, 0.0, 1.0, 100.0, P(sh5), W, P(ws5), None)),
+            fa.check(lib.flanhip_synthesize_dev_fused(P(sh5), c5, F5, BINS, SR, ar, W, P(out5), P(ws5), None, None))),
+    }
+    st5 = {k: round(timed(v, 5), 4) for k, v in stages5.items()}
+    total5 = sum(st5.values())
+    res["config5_resample_shape"] = {"workload": "2 ch x 60 s at 96 kHz: resample(48000) -> convert_to_PV(2048,512,2048) -> shape(f+100 Hz) -> convert_to_audio",
+                                     "stage_ms": st5, "ms": round(total5, 4), "pv_frames_per_s": round(c5 * F5 / (total5 * 1e-3), 1)}
+    del x96, x48, pv5, sh5, out5, ws5, pv
+
+    # ---- the reference API's own defaults: convert_to_PV() = ( 2048, 128, 4096 ) (Audio.h:158-163), and ( 2048, 512, 4096 )
+    for (hop, tag) in ((128, "api_default_2048_128_4096"), (512, "dft4096_hop512")):
+        dft, bins = 4096, 2049
+        Fd = int(lib.flanhip_num_pv_frames(n, hop))
+        ard = SR / hop
+        pvd = torch.empty((ch, Fd, bins, 2), dtype=torch.float32, device=dev)
+        outd = torch.empty((ch, Fd * hop), dtype=torch.float32, device=dev)
+        wsd = torch.empty(fa.synthesize_workspace_bytes(ch, Fd, bins, SR, ard, W), dtype=torch.uint8, device=dev)
+
+        def rt():
+            fa.analyze_dev_fused(audio, ch, n, SR, W, hop, dft, pvd, wsd, None)
+            fa.synthesize_dev_fused(pvd, ch, Fd, bins, SR, ard, W, outd, wsd, None, None)
+        msd = timed(rt, 5)
+        b = 2 * (hop * 4 + bins * 8)
+        res[tag] = {"workload": "8 ch x 60 s: convert_to_PV(2048,%d,4096) -> convert_to_audio" % hop, "ms": round(msd, 4),
+                    "frames_per_s": round(ch * Fd / (msd * 1e-3), 1), "algorithmic_GBs": round(ch * Fd * b / (msd * 1e-3) / 1e9, 1),
+                    "frac_of_8TBs": round(ch * Fd * b / (msd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        del pvd, outd, wsd
+    return res
 
 
 if __name__ == "__main__":

@@ -31,6 +31,22 @@ def gather_output(dist, local_out, world_size):
     return gathered
 
 
+def gather_chunk_into(dist, final, local_chunk, rank, world_size, ch_local, c0):
+    """The all-gather of ONE channel chunk, written straight into the final layout: rank r's channels [c0, c0 + k) of its
+    ch_local land in final[r * ch_local + c0 : r * ch_local + c0 + k].  One batch of point-to-point operations (every slice is
+    contiguous in the channel-major buffer), so a rank can issue it for chunk i on a side stream while it still computes
+    chunk i + 1 (bench.py; SURVEY 8e: the gather is per-link bound and should hide behind the compute).  Returns the requests."""
+    k = local_chunk.shape[0]
+    final[rank * ch_local + c0: rank * ch_local + c0 + k].copy_(local_chunk)
+    ops = []
+    for peer in range(world_size):
+        if peer == rank:
+            continue
+        ops.append(dist.P2POp(dist.isend, local_chunk, peer))
+        ops.append(dist.P2POp(dist.irecv, final[peer * ch_local + c0: peer * ch_local + c0 + k], peer))
+    return dist.batch_isend_irecv(ops) if ops else []
+
+
 def gather_output_uneven(dist, local_out, channel_counts):
     """Same for unequal shards (total channels not divisible by the world size): one broadcast per rank."""
     import torch
