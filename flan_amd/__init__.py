@@ -72,6 +72,10 @@ _SIGS = {
     "flanhip_fill_dev": (C.c_int, [_vp, _i64, _f32, _vp]),
     "flanhip_modify_frequency": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
     "flanhip_modify_frequency_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
+    "flanhip_modify_time_interp_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i32, _vp, _i64, _i32, _vp, _vp]),
+    "flanhip_modify_time_interp_dev_fused": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _vp, _i64, _i32, _vp, _i32, _vp, _vp]),
+    "flanhip_modify_frequency_interp_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _i32, _vp, _vp]),
+    "flanhip_repitch_interp_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _i32, _vp, _vp]),
     "flanhip_repitch_map_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _vp]),
     "flanhip_repitch_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _vp]),
     "flanhip_shape_affine": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
@@ -251,14 +255,37 @@ def _combine_amplitudes(fn, pv, src, amount):
     return d_out.to_host(pv.shape)
 
 
-def repitch(pv, sample_rate, factor_grid):
-    """PV::repitch.  factor_grid: float32 [F][bins] (the sampled factor); returns the repitched PV"""
+def repitch(pv, sample_rate, factor_grid, interp=0):
+    """PV::repitch.  factor_grid: float32 [F][bins] (the sampled factor); interp: FLANHIP_INTERP_*; returns the repitched PV"""
     pv = np.ascontiguousarray(pv, np.float32)
     ch, F, bins, _ = pv.shape
     g = np.ascontiguousarray(factor_grid, np.float32)
     assert g.shape == (F, bins)
     d_pv, d_g, d_out = DeviceArray(host=pv), DeviceArray(host=g), DeviceArray(pv.nbytes)
-    check(lib.flanhip_repitch_dev(_vp(d_pv.ptr), ch, F, bins, sample_rate, _vp(d_g.ptr), _vp(d_out.ptr), None))
+    check(lib.flanhip_repitch_interp_dev(_vp(d_pv.ptr), ch, F, bins, sample_rate, _vp(d_g.ptr), interp, _vp(d_out.ptr), None))
+    return d_out.to_host(pv.shape)
+
+
+def modify_time_interp(pv, sample_rate, hop, mod_seconds, interp):
+    """PV::modify_time with a named Interpolator (FLANHIP_INTERP_*), device entry point"""
+    pv = np.ascontiguousarray(pv, np.float32)
+    mod = np.ascontiguousarray(mod_seconds, np.float32)
+    ch, F, bins, _ = pv.shape
+    Fo = lib.flanhip_modify_time_out_frames(_ptr(mod), F, bins, sample_rate, hop)
+    if Fo <= 0:
+        return np.empty((ch, 0, bins, 2), np.float32)
+    d_pv, d_mod, d_out = DeviceArray(host=pv), DeviceArray(host=mod), DeviceArray(ch * Fo * bins * 8)
+    check(lib.flanhip_modify_time_interp_dev(_vp(d_pv.ptr), ch, F, bins, sample_rate, hop, _vp(d_mod.ptr), Fo, interp, _vp(d_out.ptr), None))
+    return d_out.to_host((ch, Fo, bins, 2))
+
+
+def modify_frequency_interp(pv, sample_rate, mod_hz, in_modified, interp):
+    """PV::modify_frequency with a named Interpolator (FLANHIP_INTERP_*), device entry point"""
+    pv = np.ascontiguousarray(pv, np.float32)
+    ch, F, bins, _ = pv.shape
+    d_pv, d_mod, d_in = DeviceArray(host=pv), DeviceArray(host=np.ascontiguousarray(mod_hz, np.float32)), DeviceArray(host=np.ascontiguousarray(in_modified, np.float32))
+    d_out = DeviceArray(pv.nbytes)
+    check(lib.flanhip_modify_frequency_interp_dev(_vp(d_pv.ptr), ch, F, bins, sample_rate, _vp(d_mod.ptr), _vp(d_in.ptr), interp, _vp(d_out.ptr), None))
     return d_out.to_host(pv.shape)
 
 

@@ -38,7 +38,7 @@ __global__ __launch_bounds__( 256 ) void k_time_map_flags( const float * mod, in
 	}
 
 __global__ __launch_bounds__( 256 ) void k_modify_time( const MFd * in, int num_channels, int64_t F, int bins, float sr, float hop,
-	const float * mod, int64_t Fo, MFd * out, const int * nonmono, int segments, int64_t seg_len, int only_if_any )
+	const float * mod, int64_t Fo, MFd * out, const int * nonmono, int segments, int64_t seg_len, int only_if_any, int interp )
 	{
 	if( only_if_any && !nonmono[bins] ) return;                                     // k_modify_time_chains does this PV
 	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__( 256 ) void k_modify_time( const MFd * in, int num_
 			int x = min( max( start_frame, 0 ), Fo32 );
 			for( ; x < x1; ++x )                                                    // :340
 				{
-				const float mix = ( float( x ) - lFrame ) / ( rFrame - lFrame );    // :344
+				const float mix = interpolate( interp, ( float( x ) - lFrame ) / ( rFrame - lFrame ) );    // :344 interp( ... ), Interpolator.cpp:14-101
 				const float w0 = ( 1.0f - mix ) * lMF.m;
 				const float w1 = mix * rMF.m;
 				const float totalWeight = w0 + w1;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__( 256 ) void k_modify_time( const MFd * in, int num_
 			const int x_stop  = forward ? min( end_frame, Fo32 ) : max( end_frame, -1 );
 			for( int x = x_first; forward ? x < x_stop : x > x_stop; x += step )
 				{
-				const float mix = ( float( x ) - lFrame ) / ( rFrame - lFrame );    // :344
+				const float mix = interpolate( interp, ( float( x ) - lFrame ) / ( rFrame - lFrame ) );    // :344 interp( ... ), Interpolator.cpp:14-101
 				const float w0 = ( 1.0f - mix ) * lMF.m;
 				const float w1 = mix * rMF.m;
 				const float totalWeight = w0 + w1;
@@ -126,6 +126,7 @@ struct TimeChainParams
 	int * words;              // workspace tail: [0] NaN flag, [2] epoch, [4] "sums valid" (set iff equal to the epoch)
 	int epoch;
 	const int * nonmono;      // [bins + 1]
+	int interp;               // FLANHIP_INTERP_*: the Interpolator of PVModify.cpp:344 (0 = linear)
 	};
 
 // SUMS = false: the plain flanhip_modify_time_dev uses the same cut (any chain length) without a workspace.
@@ -194,7 +195,7 @@ __global__ __launch_bounds__( 256 ) void k_modify_time_chains( TimeChainParams p
 					MFd v = { 0.0f, 0.0f };
 					if( !left )
 						{
-						const float mix = ( float( x ) - lFrame ) / ( rFrame - lFrame );        // :344
+						const float mix = interpolate( p.interp, ( float( x ) - lFrame ) / ( rFrame - lFrame ) );        // :344
 						const float w0 = ( 1.0f - mix ) * lMF.m;
 						const float w1 = mix * rMF.m;
 						const float totalWeight = w0 + w1;
@@ -332,7 +333,7 @@ __global__ __launch_bounds__( 256 ) void k_repitch_lerp( const MFd * in, int64_t
 // looked up, lerp, in the row's map); the map row is then staged in LDS behind the output rows (bins floats per wave).
 template<bool REPITCH>
 __global__ __launch_bounds__( 256 ) void k_modify_frequency( const MFd * in, int num_channels, int64_t F, int bins, float sr, float dft,
-	const float * mod, const float * in_modified, MFd * out )
+	const float * mod, const float * in_modified, MFd * out, int interp )
 	{
 	extern __shared__ MFd s_rows[];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -384,7 +385,7 @@ __global__ __launch_bounds__( 256 ) void k_modify_frequency( const MFd * in, int
 		const int end_bin   = min( max( hiR, 0 ), bins - 1 );                       // :225
 		for( int y = start_bin; y != end_bin; forward ? ++y : --y )                 // :230
 			{
-			const float mix = ( float( y ) - loBin ) / ( hiBin - loBin );           // :232
+			const float mix = interpolate( interp, ( float( y ) - loBin ) / ( hiBin - loBin ) );           // :232 interp( ... )
 			const float w0 = ( 1.0f - mix ) * loMF.m;
 			const float w1 = mix * hiMF.m;
 			const MFd mx = w0 < w1 ? loMF : hiMF;                                   // :237
@@ -518,10 +519,11 @@ using namespace flanhip;
 
 extern "C" {
 
-int flanhip_modify_time_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, int hop, const float * d_mod,
-	int64_t Fo, flanhip_MF * d_out, void * stream )
+static int modify_time_dev_impl( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, int hop, const float * d_mod,
+	int64_t Fo, flanhip_MF * d_out, int interp, void * stream )
 	{
 	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, sr ) ) return rc;
+	FLANHIP_REQUIRE( interp >= FLANHIP_INTERP_LINEAR && interp <= FLANHIP_INTERP_SINE, FLANHIP_ERR_INVALID_ARG, "unknown interpolator" );
 	FLANHIP_REQUIRE( d_mod && hop >= 1 && Fo > 0, FLANHIP_ERR_INVALID_ARG, "bad map / output length" );
 	hipStream_t s = (hipStream_t) stream;
 	FLANHIP_REQUIRE( Fo < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "2^31 output frames or more" );
@@ -538,7 +540,7 @@ int flanhip_modify_time_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int
 	TimeChainParams cp{};
 	cp.in = (const MFd*) d_pv; cp.mod = d_mod; cp.out = (MFd*) d_out;
 	cp.F = F; cp.Fo = Fo; cp.num_channels = int( ch ); cp.bins = bins; cp.L = 64; cp.chains_per_channel = int( ( Fo + 63 ) / 64 );
-	cp.sr = sr; cp.hop = float( hop ); cp.nonmono = d_flags;
+	cp.sr = sr; cp.hop = float( hop ); cp.nonmono = d_flags; cp.interp = interp;
 	const int64_t owners = ch * int64_t( cp.chains_per_channel ) * bins;
 	hipLaunchKernelGGL( k_modify_time_chains<false>, dim3( (unsigned) ( ( owners + 255 ) / 256 ) ), dim3( 256 ), 0, s, cp );
 	FLANHIP_CHECK( hipGetLastError() );
@@ -549,16 +551,17 @@ int flanhip_modify_time_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int
 	const int64_t seg_len = std::max<int64_t>( ( F - 1 + segments - 1 ) / segments, 1 );
 	const int64_t threads = columns * segments;
 	hipLaunchKernelGGL( k_modify_time, dim3( (unsigned) ( ( threads + 255 ) / 256 ) ), dim3( 256 ), 0, s,
-		(const MFd*) d_pv, int( ch ), F, bins, sr, float( hop ), d_mod, Fo, (MFd*) d_out, d_flags, segments, seg_len, 1 );
+		(const MFd*) d_pv, int( ch ), F, bins, sr, float( hop ), d_mod, Fo, (MFd*) d_out, d_flags, segments, seg_len, 1, interp );
 	FLANHIP_CHECK( hipGetLastError() );
 	FLANHIP_CHECK( hipFreeAsync( d_flags, s ) );
 	return FLANHIP_OK;
 	}
 
-int flanhip_modify_time_dev_fused( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float analysis_rate, const float * d_mod,
-	int64_t Fo, flanhip_MF * d_out, int window_size, void * d_ws, void * stream )
+static int modify_time_dev_fused_impl( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float analysis_rate, const float * d_mod,
+	int64_t Fo, flanhip_MF * d_out, int window_size, void * d_ws, int interp, void * stream )
 	{
 	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, sr ) ) return rc;
+	FLANHIP_REQUIRE( interp >= FLANHIP_INTERP_LINEAR && interp <= FLANHIP_INTERP_SINE, FLANHIP_ERR_INVALID_ARG, "unknown interpolator" );
 	FLANHIP_REQUIRE( d_mod && d_ws && analysis_rate > 0.0f && Fo > 0, FLANHIP_ERR_INVALID_ARG, "bad map / output length / workspace" );
 	FLANHIP_REQUIRE( Fo < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "2^31 output frames or more" );
 	hipStream_t s = (hipStream_t) stream;
@@ -581,7 +584,7 @@ int flanhip_modify_time_dev_fused( const flanhip_MF * d_pv, int64_t ch, int64_t 
 	p.sums = reinterpret_cast<double*>( d_ws );
 	p.words = reinterpret_cast<int*>( reinterpret_cast<char*>( d_ws ) + lay.carry_bytes + lay.head_bytes );
 	p.epoch = next_epoch();
-	p.nonmono = d_flags;
+	p.nonmono = d_flags; p.interp = interp;
 	const int64_t owners = ch * int64_t( lay.chains_per_channel ) * bins;
 	hipLaunchKernelGGL( k_modify_time_chains<true>, dim3( (unsigned) ( ( owners + 255 ) / 256 ) ), dim3( 256 ), 0, s, p );
 	FLANHIP_CHECK( hipGetLastError() );
@@ -591,10 +594,34 @@ int flanhip_modify_time_dev_fused( const flanhip_MF * d_pv, int64_t ch, int64_t 
 	const int64_t seg_len = std::max<int64_t>( ( F - 1 + segments - 1 ) / segments, 1 );
 	const int64_t threads = columns * segments;
 	hipLaunchKernelGGL( k_modify_time, dim3( (unsigned) ( ( threads + 255 ) / 256 ) ), dim3( 256 ), 0, s,
-		(const MFd*) d_pv, int( ch ), F, bins, sr, float( hop ), d_mod, Fo, (MFd*) d_out, d_flags, segments, seg_len, 1 );
+		(const MFd*) d_pv, int( ch ), F, bins, sr, float( hop ), d_mod, Fo, (MFd*) d_out, d_flags, segments, seg_len, 1, interp );
 	FLANHIP_CHECK( hipGetLastError() );
 	FLANHIP_CHECK( hipFreeAsync( d_flags, s ) );
 	return FLANHIP_OK;
+	}
+
+int flanhip_modify_time_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, int hop, const float * d_mod,
+	int64_t Fo, flanhip_MF * d_out, void * stream )
+	{
+	return modify_time_dev_impl( d_pv, ch, F, bins, sr, hop, d_mod, Fo, d_out, FLANHIP_INTERP_LINEAR, stream );
+	}
+
+int flanhip_modify_time_interp_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, int hop, const float * d_mod,
+	int64_t Fo, int interp, flanhip_MF * d_out, void * stream )
+	{
+	return modify_time_dev_impl( d_pv, ch, F, bins, sr, hop, d_mod, Fo, d_out, interp, stream );
+	}
+
+int flanhip_modify_time_dev_fused( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float analysis_rate, const float * d_mod,
+	int64_t Fo, flanhip_MF * d_out, int window_size, void * d_ws, void * stream )
+	{
+	return modify_time_dev_fused_impl( d_pv, ch, F, bins, sr, analysis_rate, d_mod, Fo, d_out, window_size, d_ws, FLANHIP_INTERP_LINEAR, stream );
+	}
+
+int flanhip_modify_time_interp_dev_fused( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float analysis_rate, const float * d_mod,
+	int64_t Fo, int interp, flanhip_MF * d_out, int window_size, void * d_ws, void * stream )
+	{
+	return modify_time_dev_fused_impl( d_pv, ch, F, bins, sr, analysis_rate, d_mod, Fo, d_out, window_size, d_ws, interp, stream );
 	}
 
 int flanhip_modify_time( const flanhip_MF * pv, int64_t ch, int64_t F, int bins, float sr, int hop, const float * mod,
@@ -634,10 +661,11 @@ int flanhip_stretch_map_dev( float * d_factor, int64_t F, int bins, float sr, in
 	return FLANHIP_OK;
 	}
 
-int flanhip_modify_frequency_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, const float * d_mod,
-	const float * d_in_modified, flanhip_MF * d_out, void * stream )
+static int modify_frequency_dev_impl( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, const float * d_mod,
+	const float * d_in_modified, flanhip_MF * d_out, int interp, void * stream )
 	{
 	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, sr ) ) return rc;
+	FLANHIP_REQUIRE( interp >= FLANHIP_INTERP_LINEAR && interp <= FLANHIP_INTERP_SINE, FLANHIP_ERR_INVALID_ARG, "unknown interpolator" );
 	FLANHIP_REQUIRE( d_mod && d_in_modified, FLANHIP_ERR_INVALID_ARG, "null map" );
 	hipStream_t s = (hipStream_t) stream;
 	const int64_t rows = ch * F;
@@ -645,14 +673,27 @@ int flanhip_modify_frequency_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F
 	FLANHIP_REQUIRE( per_wave <= 65536, FLANHIP_ERR_UNSUPPORTED, "more than 8192 bins" );
 	const int waves = int( std::min<size_t>( 4, 65536 / per_wave ) );
 	hipLaunchKernelGGL( k_modify_frequency<false>, dim3( (unsigned) ( ( rows + waves - 1 ) / waves ) ), dim3( 64 * waves ), per_wave * waves, s,
-		(const MFd*) d_pv, int( ch ), F, bins, sr, float( ( bins - 1 ) * 2 ), d_mod, d_in_modified, (MFd*) d_out );
+		(const MFd*) d_pv, int( ch ), F, bins, sr, float( ( bins - 1 ) * 2 ), d_mod, d_in_modified, (MFd*) d_out, interp );
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;
 	}
 
-int flanhip_repitch_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float * d_factor, flanhip_MF * d_out, void * stream )
+int flanhip_modify_frequency_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, const float * d_mod,
+	const float * d_in_modified, flanhip_MF * d_out, void * stream )
+	{
+	return modify_frequency_dev_impl( d_pv, ch, F, bins, sr, d_mod, d_in_modified, d_out, FLANHIP_INTERP_LINEAR, stream );
+	}
+
+int flanhip_modify_frequency_interp_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, const float * d_mod,
+	const float * d_in_modified, int interp, flanhip_MF * d_out, void * stream )
+	{
+	return modify_frequency_dev_impl( d_pv, ch, F, bins, sr, d_mod, d_in_modified, d_out, interp, stream );
+	}
+
+static int repitch_dev_impl( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float * d_factor, flanhip_MF * d_out, int interp, void * stream )
 	{
 	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, sr ) ) return rc;
+	FLANHIP_REQUIRE( interp >= FLANHIP_INTERP_LINEAR && interp <= FLANHIP_INTERP_SINE, FLANHIP_ERR_INVALID_ARG, "unknown interpolator" );
 	FLANHIP_REQUIRE( d_factor, FLANHIP_ERR_INVALID_ARG, "null factor grid" );
 	hipStream_t s = (hipStream_t) stream;
 	const float dft = float( ( bins - 1 ) * 2 );
@@ -662,9 +703,19 @@ int flanhip_repitch_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bin
 	FLANHIP_REQUIRE( per_wave <= 65536, FLANHIP_ERR_UNSUPPORTED, "more than 5461 bins" );
 	const int waves = int( std::min<size_t>( 4, 65536 / per_wave ) );
 	hipLaunchKernelGGL( k_modify_frequency<true>, dim3( (unsigned) ( ( rows + waves - 1 ) / waves ) ), dim3( 64 * waves ), per_wave * waves, s,
-		(const MFd*) d_pv, int( ch ), F, bins, sr, dft, (const float*) d_factor, (const float*) nullptr, (MFd*) d_out );
+		(const MFd*) d_pv, int( ch ), F, bins, sr, dft, (const float*) d_factor, (const float*) nullptr, (MFd*) d_out, interp );
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;
+	}
+
+int flanhip_repitch_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float * d_factor, flanhip_MF * d_out, void * stream )
+	{
+	return repitch_dev_impl( d_pv, ch, F, bins, sr, d_factor, d_out, FLANHIP_INTERP_LINEAR, stream );
+	}
+
+int flanhip_repitch_interp_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float * d_factor, int interp, flanhip_MF * d_out, void * stream )
+	{
+	return repitch_dev_impl( d_pv, ch, F, bins, sr, d_factor, d_out, interp, stream );
 	}
 
 int flanhip_modify_frequency( const flanhip_MF * pv, int64_t ch, int64_t F, int bins, float sr, const float * mod,

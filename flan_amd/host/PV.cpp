@@ -230,7 +230,7 @@ Audio PV::convert_to_lr_audio( flan_CANCEL_ARG_CPP ) const
 	}
 
 // modify_time_base, PVModify.cpp:307-362
-static PV modify_time_device( const PV & me, std::shared_ptr<DeviceBlock> d_mod, float max_seconds )
+static PV modify_time_device( const PV & me, std::shared_ptr<DeviceBlock> d_mod, float max_seconds, int interp )
 	{
 	const float last_output_frame = std::ceil( me.time_to_frame( max_seconds ) );    // :312
 	PVBuffer::Format f = me.get_format();
@@ -244,11 +244,11 @@ static PV modify_time_device( const PV & me, std::shared_ptr<DeviceBlock> d_mod,
 	const size_t ws_bytes = flanhip_synthesize_workspace_bytes( f.num_channels, f.num_frames, f.num_bins, f.sample_rate, f.analysis_rate, f.window_size );
 	auto ws = ws_bytes ? DeviceBlock::allocate( ws_bytes ) : nullptr;
 	const int rc = ws
-		? flanhip_modify_time_dev_fused( reinterpret_cast<const flanhip_MF*>( d_pv ), me.get_num_channels(), me.get_num_frames(), me.get_num_bins(),
-			me.get_sample_rate(), me.get_analysis_rate(), static_cast<const float*>( d_mod->ptr ), f.num_frames, static_cast<flanhip_MF*>( out->ptr ),
+		? flanhip_modify_time_interp_dev_fused( reinterpret_cast<const flanhip_MF*>( d_pv ), me.get_num_channels(), me.get_num_frames(), me.get_num_bins(),
+			me.get_sample_rate(), me.get_analysis_rate(), static_cast<const float*>( d_mod->ptr ), f.num_frames, interp, static_cast<flanhip_MF*>( out->ptr ),
 			me.get_window_size(), ws->ptr, nullptr )
-		: flanhip_modify_time_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), me.get_num_channels(), me.get_num_frames(), me.get_num_bins(),
-			me.get_sample_rate(), me.get_hop_size(), static_cast<const float*>( d_mod->ptr ), f.num_frames, static_cast<flanhip_MF*>( out->ptr ), nullptr );
+		: flanhip_modify_time_interp_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), me.get_num_channels(), me.get_num_frames(), me.get_num_bins(),
+			me.get_sample_rate(), me.get_hop_size(), static_cast<const float*>( d_mod->ptr ), f.num_frames, interp, static_cast<flanhip_MF*>( out->ptr ), nullptr );
 	if( !detail::report( rc, "modify_time" ) ) return PV();
 	if( !detail::report( flanhip_stream_synchronize( nullptr ), "modify_time" ) ) return PV();
 	PV result = PVBuffer::adopt_device( f, std::move( out ) );
@@ -259,18 +259,22 @@ static PV modify_time_device( const PV & me, std::shared_ptr<DeviceBlock> d_mod,
 PV PV::modify_time( const Function<TF, Second> & mod, const Interpolator & interp ) const
 	{
 	if( is_null() ) return PV();
-	if( !interp.is_linear() ) { std::cerr << "flan: only Interpolator::linear() runs on the device path" << std::endl; return PV(); }
+	// the named Interpolators (Utility/Interpolator.cpp:14-101) run on the device; an arbitrary callable would have to be evaluated at
+	// data-dependent, non-grid coordinates inside the kernels (PVModify.cpp:232, :344): refused, loudly
+	if( interp.kind() < 0 ) { std::cerr << "flan: this method runs the named Interpolators (linear, smoothstep, ...) only on the device path" << std::endl; return PV(); }
 	FunctionSample2d<Second> sampled{ 0.0f, 0, 0 };
 	auto d_mod = function_grid_to_device( *this, mod, &sampled );                  // PVModify.cpp:367
 	const float mx = grid_maximum( sampled, mod.get_execution_policy() );          // FunctionSample::maximum
 	if( !d_mod ) return PV();
-	return modify_time_device( *this, std::move( d_mod ), mx );
+	return modify_time_device( *this, std::move( d_mod ), mx, interp.kind() );
 	}
 
 PV PV::stretch( const Function<TF, float> & factor, const Interpolator & interp ) const
 	{
 	if( is_null() ) return PV();
-	if( !interp.is_linear() ) { std::cerr << "flan: only Interpolator::linear() runs on the device path" << std::endl; return PV(); }
+	// the named Interpolators (Utility/Interpolator.cpp:14-101) run on the device; an arbitrary callable would have to be evaluated at
+	// data-dependent, non-grid coordinates inside the kernels (PVModify.cpp:232, :344): refused, loudly
+	if( interp.kind() < 0 ) { std::cerr << "flan: this method runs the named Interpolators (linear, smoothstep, ...) only on the device path" << std::endl; return PV(); }
 	auto d_grid = function_grid_to_device( *this, factor );                        // PVModify.cpp:373
 	auto d_max = DeviceBlock::allocate( sizeof( float ) );
 	if( !d_grid || !d_max ) return PV();
@@ -280,18 +284,18 @@ PV PV::stretch( const Function<TF, float> & factor, const Interpolator & interp 
 	float mx = 0.0f;
 	flanhip_memcpy_d2h( &mx, d_max->ptr, sizeof( float ), nullptr );
 	if( !detail::report( flanhip_stream_synchronize( nullptr ), "stretch" ) ) return PV();
-	return modify_time_device( *this, std::move( d_grid ), mx );
+	return modify_time_device( *this, std::move( d_grid ), mx, interp.kind() );
 	}
 
 // modify_frequency_base, PVModify.cpp:196-257
-static PV modify_frequency_device( const PV & me, const DeviceBlock & d_mod, const DeviceBlock & d_in_modified )
+static PV modify_frequency_device( const PV & me, const DeviceBlock & d_mod, const DeviceBlock & d_in_modified, int interp )
 	{
 	const MF * d_pv = me.device_data();
 	const size_t n = size_t( me.get_num_channels() ) * me.get_num_frames() * me.get_num_bins();
 	auto out = DeviceBlock::allocate( sizeof( MF ) * n );
 	if( !d_pv || !out ) return PV();
-	if( !detail::report( flanhip_modify_frequency_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), me.get_num_channels(), me.get_num_frames(), me.get_num_bins(),
-			me.get_sample_rate(), static_cast<const float*>( d_mod.ptr ), static_cast<const float*>( d_in_modified.ptr ), static_cast<flanhip_MF*>( out->ptr ), nullptr ),
+	if( !detail::report( flanhip_modify_frequency_interp_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), me.get_num_channels(), me.get_num_frames(), me.get_num_bins(),
+			me.get_sample_rate(), static_cast<const float*>( d_mod.ptr ), static_cast<const float*>( d_in_modified.ptr ), interp, static_cast<flanhip_MF*>( out->ptr ), nullptr ),
 			"modify_frequency" ) ) return PV();
 	if( !detail::report( flanhip_stream_synchronize( nullptr ), "modify_frequency" ) ) return PV();
 	return PVBuffer::adopt_device( me.get_format(), std::move( out ) );
@@ -300,7 +304,9 @@ static PV modify_frequency_device( const PV & me, const DeviceBlock & d_mod, con
 PV PV::modify_frequency( const Function<TF, Frequency> & mod, const Interpolator & interp ) const
 	{
 	if( is_null() ) return PV();
-	if( !interp.is_linear() ) { std::cerr << "flan: only Interpolator::linear() runs on the device path" << std::endl; return PV(); }
+	// the named Interpolators (Utility/Interpolator.cpp:14-101) run on the device; an arbitrary callable would have to be evaluated at
+	// data-dependent, non-grid coordinates inside the kernels (PVModify.cpp:232, :344): refused, loudly
+	if( interp.kind() < 0 ) { std::cerr << "flan: this method runs the named Interpolators (linear, smoothstep, ...) only on the device path" << std::endl; return PV(); }
 	auto d_mod = function_grid_to_device( *this, mod );                            // PVModify.cpp:261
 	if( !d_mod ) return PV();
 	// :263-268: the callable is evaluated at every MF's own (time, frequency): data dependent, so on the host
@@ -310,20 +316,22 @@ PV PV::modify_frequency( const Function<TF, Frequency> & mod, const Interpolator
 		for( Bin bin = 0; bin < get_num_bins(); ++bin ) out[bin] = mod( TF{ t, mfs[bin].f } );
 		} );
 	if( !d_in ) return PV();
-	return modify_frequency_device( *this, *d_mod, *d_in );
+	return modify_frequency_device( *this, *d_mod, *d_in, interp.kind() );
 	}
 
 PV PV::repitch( const Function<TF, float> & factor, const Interpolator & interp ) const
 	{
 	if( is_null() ) return PV();
-	if( !interp.is_linear() ) { std::cerr << "flan: only Interpolator::linear() runs on the device path" << std::endl; return PV(); }
+	// the named Interpolators (Utility/Interpolator.cpp:14-101) run on the device; an arbitrary callable would have to be evaluated at
+	// data-dependent, non-grid coordinates inside the kernels (PVModify.cpp:232, :344): refused, loudly
+	if( interp.kind() < 0 ) { std::cerr << "flan: this method runs the named Interpolators (linear, smoothstep, ...) only on the device path" << std::endl; return PV(); }
 	auto d_grid = function_grid_to_device( *this, factor );                        // PVModify.cpp:275
 	const MF * d_pv = device_data();
 	auto out = DeviceBlock::allocate( sizeof( MF ) * size_t( get_num_channels() ) * get_num_frames() * get_num_bins() );
 	if( !d_grid || !d_pv || !out ) return PV();
 	// :278-302 running sum over bins, bin_to_frequency, per-MF lerp, then modify_frequency_base (:196-257) -- one call, on the device
-	if( !detail::report( flanhip_repitch_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(), get_sample_rate(),
-			static_cast<float*>( d_grid->ptr ), static_cast<flanhip_MF*>( out->ptr ), nullptr ), "repitch" ) ) return PV();
+	if( !detail::report( flanhip_repitch_interp_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(), get_sample_rate(),
+			static_cast<float*>( d_grid->ptr ), interp.kind(), static_cast<flanhip_MF*>( out->ptr ), nullptr ), "repitch" ) ) return PV();
 	if( !detail::report( flanhip_stream_synchronize( nullptr ), "repitch" ) ) return PV();
 	return PVBuffer::adopt_device( get_format(), std::move( out ) );
 	}

@@ -175,6 +175,21 @@ int flanhip_repitch_map_dev(const flanhip_MF * d_pv, int64_t num_channels, int64
  * same results as flanhip_repitch_map_dev + flanhip_modify_frequency_dev without the intermediate float[ch][F][bins] grid. */
 int flanhip_repitch_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_pv_frames, int num_bins, float sample_rate,
                         float * d_factor, flanhip_MF * d_out, void * stream);
+/* The same four with a named non-linear Interpolator (PVModify.cpp:232 and :344 apply interp( ... ) to the mixing coordinate of every
+ * output bin / frame; Utility/Interpolator.cpp:14-101).  interp: FLANHIP_INTERP_* (below); FLANHIP_INTERP_LINEAR gives the plain calls
+ * bit for bit. */
+int flanhip_modify_time_interp_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_pv_frames, int num_bins,
+                                   float sample_rate, int hop, const float * d_mod_seconds,
+                                   int64_t out_frames, int interp, flanhip_MF * d_out, void * stream);
+int flanhip_modify_time_interp_dev_fused(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_pv_frames, int num_bins,
+                                         float sample_rate, float analysis_rate, const float * d_mod_seconds,
+                                         int64_t out_frames, int interp, flanhip_MF * d_out, int window_size, void * d_synth_workspace, void * stream);
+int flanhip_modify_frequency_interp_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_pv_frames, int num_bins,
+                                        float sample_rate, const float * d_mod_hz, const float * d_in_modified,
+                                        int interp, flanhip_MF * d_out, void * stream);
+int flanhip_repitch_interp_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_pv_frames, int num_bins, float sample_rate,
+                               float * d_factor, int interp, flanhip_MF * d_out, void * stream);
+
 
 /* PV::shape (PV/PV.cpp:421-458) for the affine shaper  mf -> { a*m + b, c*f + d }; arbitrary host callables are
  * evaluated by the C++ layer on the host grid and uploaded through flanhip_shape_table_dev. */

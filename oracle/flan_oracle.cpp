@@ -301,8 +301,18 @@ int64_t oracle_modify_time_out_frames( const float * mod, int64_t num_frames, in
 	return int64_t( int32_t( last ) );
 	}
 
+float oracle_interpolate( int kind, float x );    // processors_oracle.cpp (Utility/Interpolator.cpp:14-101, pinned against the reference TU)
+
+int oracle_modify_time_interp( const float * pv_mf, int num_channels, int64_t num_frames, int num_bins, float sample_rate, int hop,
+	const float * mod, int64_t out_frames, int interp, float * out_mf );
 int oracle_modify_time( const float * pv_mf, int num_channels, int64_t num_frames, int num_bins, float sample_rate, int hop,
 	const float * mod, int64_t out_frames, float * out_mf )
+	{
+	return oracle_modify_time_interp( pv_mf, num_channels, num_frames, num_bins, sample_rate, hop, mod, out_frames, 0, out_mf );
+	}
+
+int oracle_modify_time_interp( const float * pv_mf, int num_channels, int64_t num_frames, int num_bins, float sample_rate, int hop,
+	const float * mod, int64_t out_frames, int interp, float * out_mf )
 	{
 	const MF * in = reinterpret_cast<const MF*>( pv_mf );
 	MF * out = reinterpret_cast<MF*>( out_mf );
@@ -322,7 +332,7 @@ int oracle_modify_time( const float * pv_mf, int num_channels, int64_t num_frame
 				for( int32_t x = start_frame; x != end_frame; forward ? ++x : --x ) // :340
 					{
 					if( x < 0 || out_frames <= x ) continue;       // :342
-					const float mix = ( x - lFrame ) / ( rFrame - lFrame ); // :344 (linear interp = identity)
+					const float mix = oracle_interpolate( interp, ( x - lFrame ) / ( rFrame - lFrame ) ); // :344 interp( ... ); linear = identity
 					const float w0 = ( 1.0f - mix ) * lMF.m;
 					const float w1 = mix * rMF.m;
 					const float totalWeight = w0 + w1;
@@ -350,8 +360,16 @@ void oracle_stretch_map( float * factor, int64_t num_frames, int num_bins, float
 
 // modify_frequency_base, PVModify.cpp:196-257, linear interpolator.
 // mod: float[F][bins] Hz (where each grid bin centre maps); in_modified: float[ch][F][bins] Hz (new frequency of each MF).
+int oracle_modify_frequency_interp( const float * pv_mf, int num_channels, int64_t num_frames, int num_bins, float sample_rate,
+	const float * mod, const float * in_modified, int interp, float * out_mf );
 int oracle_modify_frequency( const float * pv_mf, int num_channels, int64_t num_frames, int num_bins, float sample_rate,
 	const float * mod, const float * in_modified, float * out_mf )
+	{
+	return oracle_modify_frequency_interp( pv_mf, num_channels, num_frames, num_bins, sample_rate, mod, in_modified, 0, out_mf );
+	}
+
+int oracle_modify_frequency_interp( const float * pv_mf, int num_channels, int64_t num_frames, int num_bins, float sample_rate,
+	const float * mod, const float * in_modified, int interp, float * out_mf )
 	{
 	const int dft = ( num_bins - 1 ) * 2;
 	const MF * in = reinterpret_cast<const MF*>( pv_mf );
@@ -377,7 +395,7 @@ int oracle_modify_frequency( const float * pv_mf, int num_channels, int64_t num_
 				MF * orow = out + ( int64_t( channel ) * num_frames + frame ) * num_bins;
 				for( int32_t y = start_bin; y != end_bin; forward ? ++y : --y ) // :230
 					{
-					const float mix = ( float( y ) - loBin ) / ( hiBin - loBin ); // :232
+					const float mix = oracle_interpolate( interp, ( float( y ) - loBin ) / ( hiBin - loBin ) ); // :232 interp( ... ); linear = identity
 					const float w0 = ( 1.0f - mix ) * loMF.m;
 					const float w1 = mix * hiMF.m;
 					const MF & mx = w0 < w1 ? loMF : hiMF;          // :237

@@ -50,6 +50,8 @@ def _load():
     lib.oracle_modify_time_out_frames.restype = C.c_int64
     lib.oracle_modify_time_out_frames.argtypes = [f32p, C.c_int64, C.c_int, C.c_float, C.c_int]
     lib.oracle_modify_time.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_int, f32p, C.c_int64, f32p]
+    lib.oracle_modify_time_interp.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_int, f32p, C.c_int64, C.c_int, f32p]
+    lib.oracle_modify_frequency_interp.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, C.c_float, f32p, f32p, C.c_int, f32p]
     lib.oracle_stretch_map.argtypes = [f32p, C.c_int64, C.c_int, C.c_float, C.c_int]
     lib.oracle_modify_frequency.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, C.c_float, f32p, f32p, f32p]
     lib.oracle_repitch_map.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, C.c_float, f32p, f32p]
@@ -178,19 +180,19 @@ def stretch_map(factor_grid, sample_rate, hop):
     return g
 
 
-def modify_time(pv, sample_rate, hop, mod_seconds):
+def modify_time(pv, sample_rate, hop, mod_seconds, interp=0):
     pv = np.ascontiguousarray(pv, np.float32)
     mod = np.ascontiguousarray(mod_seconds, np.float32)
     ch, F, bins, _ = pv.shape
     Fo = int(lib.oracle_modify_time_out_frames(mod.reshape(-1), F, bins, sample_rate, hop))
     out = np.empty((ch, max(Fo, 0), bins, 2), np.float32)
     if Fo > 0:
-        lib.oracle_modify_time(pv.reshape(-1), ch, F, bins, sample_rate, hop, mod.reshape(-1), Fo, out.reshape(-1))
+        lib.oracle_modify_time_interp(pv.reshape(-1), ch, F, bins, sample_rate, hop, mod.reshape(-1), Fo, interp, out.reshape(-1))
     return out
 
 
-def stretch(pv, sample_rate, hop, factor_grid):
-    return modify_time(pv, sample_rate, hop, stretch_map(factor_grid, sample_rate, hop))
+def stretch(pv, sample_rate, hop, factor_grid, interp=0):
+    return modify_time(pv, sample_rate, hop, stretch_map(factor_grid, sample_rate, hop), interp)
 
 
 def repitch_map(pv, sample_rate, factor_grid):
@@ -202,19 +204,19 @@ def repitch_map(pv, sample_rate, factor_grid):
     return g, inmod
 
 
-def modify_frequency(pv, sample_rate, mod_hz, in_modified):
+def modify_frequency(pv, sample_rate, mod_hz, in_modified, interp=0):
     pv = np.ascontiguousarray(pv, np.float32)
     ch, F, bins, _ = pv.shape
     out = np.empty_like(pv)
-    lib.oracle_modify_frequency(pv.reshape(-1), ch, F, bins, sample_rate,
-                                np.ascontiguousarray(mod_hz, np.float32).reshape(-1),
-                                np.ascontiguousarray(in_modified, np.float32).reshape(-1), out.reshape(-1))
+    lib.oracle_modify_frequency_interp(pv.reshape(-1), ch, F, bins, sample_rate,
+                                       np.ascontiguousarray(mod_hz, np.float32).reshape(-1),
+                                       np.ascontiguousarray(in_modified, np.float32).reshape(-1), interp, out.reshape(-1))
     return out
 
 
-def repitch(pv, sample_rate, factor_grid):
+def repitch(pv, sample_rate, factor_grid, interp=0):
     g, inmod = repitch_map(pv, sample_rate, factor_grid)
-    return modify_frequency(pv, sample_rate, g, inmod)
+    return modify_frequency(pv, sample_rate, g, inmod, interp)
 
 
 def shape_affine(pv, sample_rate, a, b, c, d, use_shift_alignment=False):

@@ -401,3 +401,40 @@ def test_shape_fused_prepass(fa, dft, hop):
     _, _, flag_a = run(bad, False, False)
     _, _, flag_b = run(bad, True, False)
     assert flag_a == 1 and flag_b == 1
+
+
+@pytest.mark.parametrize("interp", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_named_interpolators_in_time_and_frequency_maps(fa, interp):
+    """PVModify.cpp:232 / :344 apply the Interpolator to the mixing coordinate: modify_time (monotone map: the chain kernel; a map that
+    runs backwards: the sequential walk), modify_frequency and repitch with every named interpolator, bit for bit against the oracle
+    (sine: its cosf is the device's, 1-2 ulp from libm's, so magnitudes / frequencies agree to rounding, not bit for bit)"""
+    rng = np.random.default_rng(100 + interp)
+    hop, dft, W = 256, 1024, 1024
+    x = O.noise(2, 30 * hop + 11, seed=200 + interp)
+    pv = O.analyze(x, SR, W, hop, dft)
+    pv[..., 0] *= rng.uniform(0, 1, pv.shape[:3]) < 0.8
+    ch, F, bins, _ = pv.shape
+    hop_s = hop / SR
+
+    def agree(got, ref, what):
+        assert got.shape == ref.shape, what
+        if interp == 8:                                  # a 1-ulp different mix can flip a "louder wins" / w0 < w1 decision: a handful of bins
+            close = np.isclose(got, ref, rtol=3e-6, atol=1e-6)
+            assert close.mean() >= 0.999, (what, close.mean())
+        else:
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), what
+    maps = {"x1.7": O.stretch_map(np.full((F, bins), 1.7, np.float32), SR, hop),
+            "random-monotone": O.stretch_map(rng.uniform(0.3, 2.5, (F, bins)).astype(np.float32), SR, hop),
+            "backwards": (rng.uniform(-2, F + 2, (F, bins)) * hop_s).astype(np.float32)}
+    for name, mod in maps.items():
+        agree(fa.modify_time_interp(pv, SR, hop, mod, interp), O.modify_time(pv, SR, hop, mod, interp), "modify_time/" + name)
+    f_of_bin = (np.arange(bins, dtype=np.float32) * np.float32(SR / dft))[None, :] * np.ones((F, 1), np.float32)
+    fmaps = {"x1.3": (f_of_bin * np.float32(1.3)).astype(np.float32), "folded": (np.abs(f_of_bin - 6000.0) * 1.5).astype(np.float32)}
+    for name, mod in fmaps.items():
+        inmod = (pv[..., 1] * np.float32(1.1)).astype(np.float32)
+        agree(fa.modify_frequency_interp(pv, SR, mod, inmod, interp), O.modify_frequency(pv, SR, mod, inmod, interp), "modify_frequency/" + name)
+    g = rng.uniform(0.5, 2.0, (F, bins)).astype(np.float32)
+    agree(fa.repitch(pv, SR, g, interp), O.repitch(pv, SR, g, interp), "repitch")
+    # linear through the new entry points == the plain calls
+    if interp == 1:
+        assert np.array_equal(fa.modify_time_interp(pv, SR, hop, maps["x1.7"], 0).view(np.uint32), fa.modify_time(pv, SR, hop, maps["x1.7"]).view(np.uint32))
