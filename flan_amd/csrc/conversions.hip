@@ -13,11 +13,11 @@ namespace flanhip {
 
 static int g_synth_stage_mask = 0xF;             // flanhip_debug_synth_stages(): 1 sums, 2 scan, 4 main, 8 fix-up
 // flanhip_debug_kernel_variant(): which dft 2048 kernel generation a call launches (A/B runs in one process).
-// analysis: 0 = round-1 kernel (8-wave blocks, 2 wavefronts per SIMD); 1 / 2 / 3 = v2 with 12-wave blocks (3 per SIMD) evaluating
-// 4 / 2 / 8 bins at a time; 4 (the default) / 6 / 7 = v2 in 8-wave blocks, 8 / 16 / 4 bins at a time
+// analysis: 0 = round-1 kernel; 4 (the default) / 6 / 7 = v2, 8 / 16 / 4 bins at a time (all in 8-wave blocks, 2 wavefronts per SIMD:
+// 12-wave blocks at <= 168 VGPRs were measured and dropped)
 // synthesis (register-accumulator hops): 0 = round-1 kernel; 1 (the default) = v2; 9 = v2 with plain instead of non-temporal row loads
 static int g_ana_variant = 4, g_syn_variant = 1;
-static int ana_variant_waves( int v ) { return v == 0 || v == 4 || v == 6 || v == 7 || v > 100 ? 8 : 12; }
+static int ana_variant_waves( int ) { return 8; }
 static constexpr size_t kMaxLds = 160 * 1024;   // gfx950: 160 KiB LDS per CU, one workgroup may take all of it
 
 // chains: the chains a block walks (one per wavefront; or ONE, walked by a team of several wavefronts, see k_analyze)
@@ -74,8 +74,7 @@ static int run_analyze_v2( const AnalyzeParams & p, const FastTables & tb, hipSt
 	static_assert( V2Lds::bytes( WAVES ) <= kMaxLds, "LDS budget" );
 	auto kern = k_analyze_v2<WAVES, SUMS, NV, ABL>;
 	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
-	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;
-	const int64_t blocks = ( chains + WAVES - 1 ) / WAVES;
+	const int64_t blocks = int64_t( ( p.chains_per_channel + WAVES - 1 ) / WAVES ) * p.num_channels;    // a block = a group of WAVES chains of one channel
 	FLANHIP_REQUIRE( blocks < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
 	hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( 64 * WAVES ), lds, s, p, tb );
 	FLANHIP_CHECK( hipGetLastError() );
@@ -87,9 +86,6 @@ static int run_analyze_v2_variant( int v, const AnalyzeParams & p, const FastTab
 	{
 	switch( v )
 		{
-		case 1: return run_analyze_v2<12, SUMS, 4>( p, tb, s );
-		case 2: return run_analyze_v2<12, SUMS, 2>( p, tb, s );
-		case 3: return run_analyze_v2<12, SUMS, 8>( p, tb, s );
 		case 4: return run_analyze_v2<8, SUMS, 8>( p, tb, s );
 		case 6: return run_analyze_v2<8, SUMS, 16>( p, tb, s );
 		case 7: return run_analyze_v2<8, SUMS, 4>( p, tb, s );
@@ -165,8 +161,8 @@ static int run_synth_v2( const SynthParams & p, const FastTables & tb, hipStream
 	static_assert( V2LdsSyn::bytes( WAVES ) <= kMaxLds, "LDS budget" );
 	auto kern = k_synthesize_v2<WAVES, HOPQ, ABL>;
 	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
-	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;
-	const int64_t blocks = ( chains + WAVES - 1 ) / WAVES;
+	static_assert( WAVES == 8, "SynthLayout::groups_per_channel counts groups of 8 chains" );
+	const int64_t blocks = int64_t( ( p.chains_per_channel + WAVES - 1 ) / WAVES ) * p.num_channels;
 	hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( 64 * WAVES ), lds, s, p, tb );
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;
@@ -250,6 +246,11 @@ int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int 
 			p.sums = reinterpret_cast<double*>( d_fused_ws );
 			p.nan_out = reinterpret_cast<int*>( reinterpret_cast<char*>( d_fused_ws ) + lay.carry_bytes + lay.head_bytes );
 			}
+		// the dft 2048 kernel also leaves one total per group of 8 chains: the synthesis kernel then needs no scan kernel in front of it
+		const bool groups_too = fast && dft == 2048 && g_ana_variant != 0 && kernel_sums;
+		p.group_sums = groups_too ? reinterpret_cast<double*>( reinterpret_cast<char*>( d_fused_ws ) + lay.group_offset ) : nullptr;
+		p.groups_per_channel = lay.groups_per_channel;
+		note_workspace_producer( d_fused_ws, groups_too ? 1 : 0 );
 		}
 	auto prepass_on_behalf = [&]() -> int                                         // for an analysis kernel that keeps no sums (none does at present)
 		{
@@ -311,7 +312,10 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	const int64_t chains = int64_t( o->chains_per_channel ) * ch;
 	o->carry_bytes = ( size_t( chains ) * bins * sizeof( double ) + 255 ) & ~size_t( 255 );
 	o->head_bytes = ( size_t( chains ) * o->head_len * sizeof( float ) + 255 ) & ~size_t( 255 );
-	o->total_bytes = o->carry_bytes + o->head_bytes + 1024;        // tail: NaN flag (4 B at +0), dump area (512 B at +512)
+	o->groups_per_channel = ( o->chains_per_channel + 7 ) / 8;
+	o->group_offset = o->carry_bytes + o->head_bytes + 1024;       // tail: NaN flag (4 B at +0), dump area (512 B at +512); then the group sums
+	o->group_bytes = ( size_t( ch ) * o->groups_per_channel * bins * sizeof( double ) + 255 ) & ~size_t( 255 );
+	o->total_bytes = o->group_offset + o->group_bytes;
 	return FLANHIP_OK;
 	}
 
@@ -361,12 +365,21 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	const int64_t chains = int64_t( p.chains_per_channel ) * ch;
 	FLANHIP_REQUIRE( chains < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
 	const int stages = prepass_only ? 3 : g_synth_stage_mask;
+	// The dft 2048 analysis kernel leaves group totals beside the chain sums (launch_analyze notes that for this workspace): the dft 2048
+	// synthesis kernel then works out its own carries and the scan kernel is not launched.  Any other producer or shape: the scan runs.
+	const bool self_carry = presummed == 1 && !prepass_only && !d_carry_in && !d_total_out && g_syn_variant != 0 && lay.dft == 2048
+		&& synth_fast_kind( lay.dft, W, lay.hop ) == 1 && workspace_producer( d_ws ) == 1;
+	if( self_carry )
+		{
+		p.group_sums = reinterpret_cast<const double*>( reinterpret_cast<char*>( d_ws ) + lay.group_offset );
+		p.groups_per_channel = lay.groups_per_channel;
+		}
 	if( ( stages & 1 ) && presummed != 1 && presummed != 3 )
 		{
 		hipLaunchKernelGGL( k_phase_sums2, dim3( (unsigned) chains, (unsigned) ( ( bins + 255 ) / 256 ) ), dim3( 256 ), 0, s, p );
 		FLANHIP_CHECK( hipGetLastError() );
 		}
-	if( stages & 2 )
+	if( ( stages & 2 ) && !self_carry )
 		{
 		const int64_t cols = ch * bins;
 		(void) cols;

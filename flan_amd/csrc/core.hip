@@ -158,6 +158,20 @@ int choose_chain_length( int64_t num_channels, int64_t num_frames, int min_len, 
 	return int( L );
 	}
 
+static std::mutex g_ws_mutex;
+static std::map<const void*, int> g_ws_producer;
+void note_workspace_producer( const void * d_ws, int kind )
+	{
+	std::lock_guard<std::mutex> lock( g_ws_mutex );
+	if( kind ) g_ws_producer[d_ws] = kind; else g_ws_producer.erase( d_ws );
+	}
+int workspace_producer( const void * d_ws )
+	{
+	std::lock_guard<std::mutex> lock( g_ws_mutex );
+	auto it = g_ws_producer.find( d_ws );
+	return it == g_ws_producer.end() ? 0 : it->second;
+	}
+
 int next_epoch()
 	{
 	// 1, 2, 3, ... 2^31 - 1, 1, ...: never 0, and two successive producer launches never share a number (the workspace words are

@@ -69,7 +69,13 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 // A fresh non-zero number per producer launch: workspace words are "set" when they equal the launch's epoch (no clearing pass).
 int next_epoch();
 
-struct SynthLayout { int hop, dft, L, chains_per_channel, head_len; size_t carry_bytes, head_bytes, total_bytes; };
+// groups: aligned runs of 8 consecutive chains of a channel (one 8-wave block of the dft 2048 kernels); group_bytes: one fp64 sum per
+// (channel, group, bin) behind the 1024-byte tail -- what lets the synthesis kernel compute its own carries (no scan kernel)
+struct SynthLayout { int hop, dft, L, chains_per_channel, head_len, groups_per_channel; size_t carry_bytes, head_bytes, group_offset, group_bytes, total_bytes; };
+// which producer last left its pre-pass in a synthesis workspace (host-side note, keyed by the workspace pointer, written when the
+// producer is launched and read when flanhip_synthesize_dev_fused is): 1 = chain sums AND group sums (the dft 2048 analysis kernel)
+void note_workspace_producer( const void * d_ws, int kind );
+int workspace_producer( const void * d_ws );
 int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, SynthLayout * out );
 
 } // namespace flanhip

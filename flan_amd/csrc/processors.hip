@@ -585,6 +585,7 @@ static int modify_time_dev_fused_impl( const flanhip_MF * d_pv, int64_t ch, int6
 	p.words = reinterpret_cast<int*>( reinterpret_cast<char*>( d_ws ) + lay.carry_bytes + lay.head_bytes );
 	p.epoch = next_epoch();
 	p.nonmono = d_flags; p.interp = interp;
+	note_workspace_producer( d_ws, 0 );                                               // chain sums (maybe), no group totals: convert_to_audio runs its scan
 	const int64_t owners = ch * int64_t( lay.chains_per_channel ) * bins;
 	hipLaunchKernelGGL( k_modify_time_chains<true>, dim3( (unsigned) ( ( owners + 255 ) / 256 ) ), dim3( 256 ), 0, s, p );
 	FLANHIP_CHECK( hipGetLastError() );
@@ -810,6 +811,7 @@ static int shape_fused( const flanhip_MF * d_pv, const flanhip_MF * d_tbl, bool 
 	p.sums = reinterpret_cast<double*>( d_ws );
 	p.words = reinterpret_cast<int*>( reinterpret_cast<char*>( d_ws ) + lay.carry_bytes + lay.head_bytes );
 	p.epoch = next_epoch();
+	note_workspace_producer( d_ws, 0 );                                               // chain sums, no group totals
 	const int64_t owners = ch * int64_t( lay.chains_per_channel ) * bins;
 	FLANHIP_REQUIRE( ( owners + 255 ) / 256 < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains" );
 	if( affine ) hipLaunchKernelGGL( k_shape_plain_chains<true>, dim3( (unsigned) ( ( owners + 255 ) / 256 ) ), dim3( 256 ), 0, s, p );

@@ -42,6 +42,8 @@ struct AnalyzeParams
 	double * sums;            // optional [ch][chains][bins]: per-chain sums of the phase increments synthesis will need
 	int * nan_out;            // optional: nan_out[0] = nan_epoch when an output MF is NaN/Inf, nan_out[2] = nan_epoch always
 	int nan_epoch;            // a fresh non-zero number per launch
+	double * group_sums;      // optional (dft 2048 kernel, blocks = groups of 8 chains of one channel): [ch][groups][bins] folded sums of each group's chains
+	int groups_per_channel;
 	};
 
 // phase_vocoder.cpp:37-52 with the reference's rounding sequence (the file is compiled with -ffp-contract=off); the same helpers as
@@ -287,6 +289,8 @@ struct SynthParams
 	int * nan_words;          // optional (pre-pass run on behalf of a producer): the producer's { flag, -, epoch } words to write
 	int nan_epoch;
 	const int * skip_words;   // optional: the pre-pass retires at once when words [4] and [2] agree (the producer of the PV left the sums)
+	const double * group_sums; // optional (dft 2048 kernel): the producer's per-group sums -- the kernel then computes its own carries from them and
+	int groups_per_channel;    // from the chain sums in `carry` (which it leaves untouched), and no scan kernel runs
 	};
 
 // (the pre-pass kernels k_phase_sums2 / k_phase_scan2 that serve every size live in pv_kernels_fast.h)

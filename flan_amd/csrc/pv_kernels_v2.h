@@ -174,10 +174,14 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 	const v4f_t * s_kc = reinterpret_cast<const v4f_t*>( s + L::KC ) + lane;
 	cf * buf = s + L::BUF + wave * L::BUF_LEN;
 
-	const int64_t chain = int64_t( blockIdx.x ) * WAVES + wave;
-	if( chain >= int64_t( p.chains_per_channel ) * p.num_channels ) return;
-	const int channel = int( chain / p.chains_per_channel );
-	const int64_t t0 = int64_t( chain % p.chains_per_channel ) * p.L;
+	// a block is a GROUP: WAVES consecutive chains of ONE channel (the last group of a channel may be short: its spare wavefronts idle).
+	// No wavefront leaves early: the fused epilogue below meets at a block barrier.
+	const int groups = ( p.chains_per_channel + WAVES - 1 ) / WAVES;
+	const int channel = int( blockIdx.x ) / groups, group = int( blockIdx.x ) % groups;
+	const int chain_in_channel = group * WAVES + wave;
+	const bool active = chain_in_channel < p.chains_per_channel;
+	const int64_t chain = int64_t( channel ) * p.chains_per_channel + ( active ? chain_in_channel : 0 );
+	const int64_t t0 = int64_t( active ? chain_in_channel : 0 ) * p.L;
 	const int64_t t1 = min( t0 + int64_t( p.L ), p.F );
 	const float * x = p.audio + int64_t( channel ) * p.n;
 	const bool use_wrapping = p.analysis_rate < p.sample_rate;                // phase_vocoder.cpp:37
@@ -425,32 +429,56 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 			if( t + 1 < t1 ) transform_frame( t + 1 );
 			}
 		};
-	if( chain_fast ) run_chain( std::true_type{} ); else run_chain( std::false_type{} );
+	if( active ) { if( chain_fast ) run_chain( std::true_type{} ); else run_chain( std::false_type{} ); }
 	st.flush( lane );
 
 	if constexpr( SUMS )
 		{
-		double * dst = p.sums + chain * ( C + 1 );
+		// the chain's sums, folded like phase_vocoder.cpp:59, go to the workspace (what k_phase_sums2 would compute) and -- staged in this
+		// wavefront's now idle transform buffer -- into the group's total: with one total per group of 8 chains the synthesis kernel can
+		// work out its own carries (a few dozen additions per bin) and the scan kernel between the two is not launched at all
+		double * stage = reinterpret_cast<double*>( buf );                        // 1025 doubles = 8200 B of the buffer's 8712
 		bool bad = !( mmax <= 3.4028235e38f );
 		auto fold = [&]( double sq ) -> double
 			{
 			bad |= !( __builtin_fabs( sq ) <= 1.7976931348623157e308 );              // a NaN / Inf frequency poisons its sum
 			return ( __builtin_fabs( sq ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( sq ) : fold_phase_any( sq );
 			};
-		#pragma unroll
-		for( int q = 0; q < H; ++q )
+		if( active )
 			{
-			dst[lane + 64 * q] = fold( sumk[q] );
-			dst[C - lane - 64 * q] = fold( summ[q] );
+			double * dst = p.sums + chain * ( C + 1 );
+			#pragma unroll
+			for( int q = 0; q < H; ++q )
+				{
+				const double a = fold( sumk[q] ), b = fold( summ[q] );
+				dst[lane + 64 * q] = a;             stage[lane + 64 * q] = a;
+				dst[C - lane - 64 * q] = b;         stage[C - lane - 64 * q] = b;
+				}
+			const double vx = fold( sumx );
+			if( lane == 0 ) { dst[C / 2] = vx; stage[C / 2] = vx; }
 			}
-		const double vx = fold( sumx );
-		if( lane == 0 ) dst[C / 2] = vx;
 		const bool any_bad = __any( bad );
-		if( p.nan_out && lane == 0 )
+		if( p.nan_out && lane == 0 && active )
 			{
 			// no clearing pass: the flag word is "set" when it equals this launch's epoch (written beside it by chain 0)
 			if( chain == 0 ) { p.nan_out[2] = p.nan_epoch; p.nan_out[4] = p.nan_epoch; }   // [4]: the sums of this epoch are in the workspace
 			if( any_bad ) p.nan_out[0] = p.nan_epoch;
+			}
+		if( p.group_sums )
+			{
+			__syncthreads();
+			const int live = min( WAVES, p.chains_per_channel - group * WAVES );      // wavefronts of this group that walked a chain
+			double * gdst = p.group_sums + ( int64_t( channel ) * groups + group ) * ( C + 1 );
+			for( int bin = tid; bin <= C; bin += NT )
+				{
+				double run = 0.0;
+				for( int w = 0; w < live; ++w )
+					{
+					const double v = run + reinterpret_cast<const double*>( s + L::BUF + w * L::BUF_LEN )[bin];
+					run = ( __builtin_fabs( v ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( v ) : fold_phase_any( v );
+					}
+				gdst[bin] = run;
+				}
 			}
 		}
 	}
@@ -500,10 +528,13 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 	const cf * s_win = s + L::WIN + lane;
 	cf * buf = s + L::BUF + wave * L::BUF_LEN;
 
-	const int64_t chain = int64_t( blockIdx.x ) * WAVES + wave;
-	if( chain >= int64_t( p.chains_per_channel ) * p.num_channels ) return;
-	const int channel = int( chain / p.chains_per_channel );
-	const int chain_in_channel = int( chain % p.chains_per_channel );
+	// a block is a GROUP of WAVES consecutive chains of one channel (see k_analyze_v2); spare wavefronts of a channel's last group idle
+	const int groups = ( p.chains_per_channel + WAVES - 1 ) / WAVES;
+	const int channel = int( blockIdx.x ) / groups, group = int( blockIdx.x ) % groups;
+	const int chain_in_channel_raw = group * WAVES + wave;
+	const bool active = chain_in_channel_raw < p.chains_per_channel;
+	const int chain_in_channel = active ? chain_in_channel_raw : 0;
+	const int64_t chain = int64_t( channel ) * p.chains_per_channel + chain_in_channel;
 	const int64_t t0 = int64_t( chain_in_channel ) * p.L;
 	const int64_t t1 = min( t0 + int64_t( p.L ), p.F );
 	const bool last_chain = chain_in_channel == p.chains_per_channel - 1;
@@ -518,10 +549,77 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 
 	// phase_buffer (AudioPV.cpp:105) on entry to the chain, of the lane's pairs and of bin C/2
 	double phk[H], phm[H], phx;
-	const double * carry = p.carry + chain * ( C + 1 );
-	#pragma unroll
-	for( int q = 0; q < H; ++q ) { phk[q] = carry[lane + 64 * q]; phm[q] = carry[C - lane - 64 * q]; }
-	phx = carry[C / 2];
+	if( p.group_sums )
+		{
+		// no scan kernel ran: `carry` still holds the chains' own sums, group_sums the totals of every group of 8 chains.  The running phase
+		// on entry to this chain = the groups before this one, then the chains of this group before this one, added and folded in order
+		// (phase_vocoder.cpp:57-59 modulo pi2: the same prefix k_phase_scan2 forms, associated group-wise).
+		// x + y folded like phase_vocoder.cpp:59.  Two folded sums add up to at most 2 pi2, where fmod( r, pi2 ) is the exact difference
+		// r - pi2 (Sterbenz): the short form is fold_phase_fast's own result there; anything else (negative, large, NaN) takes the long one
+		auto fold = []( double r )
+			{
+			if( r >= 0.0 && r <= 2.0 * FLANHIP_PI2_D ) return r > FLANHIP_PI2_D ? r - FLANHIP_PI2_D : r;
+			return ( __builtin_fabs( r ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( r ) : fold_phase_any( r );
+			};
+		// One thread per bin, its two or three bins side by side (independent dependency chains): first the groups before this one, then
+		// along the chains of this group, leaving every wavefront's carries in that wavefront's own transform buffer (1025 doubles of its
+		// 8712 bytes).  Loads go out in batches of 16 per bin ahead of the dependent additions: one memory round trip per batch.
+		const double * gs = p.group_sums + int64_t( channel ) * groups * ( C + 1 );
+		const double * sums0 = p.carry + ( int64_t( channel ) * p.chains_per_channel + int64_t( group ) * WAVES ) * ( C + 1 );   // the first chain of this group
+		const int live = min( WAVES, p.chains_per_channel - group * WAVES );
+		constexpr int NB = ( C + NT ) / NT;                                       // bins per thread: 3 for 512 threads (the third only for thread 0)
+		int bins_of[NB]; bool has[NB]; double run[NB];
+		#pragma unroll
+		for( int b = 0; b < NB; ++b ) { bins_of[b] = tid + NT * b; has[b] = bins_of[b] <= C; if( !has[b] ) bins_of[b] = C; run[b] = 0.0; }
+		double vc[NB][WAVES];                                                     // the chains of this group: requested first, used last
+		#pragma unroll
+		for( int b = 0; b < NB; ++b )
+			{
+			#pragma unroll
+			for( int w = 0; w < WAVES; ++w ) vc[b][w] = ( w < live ) ? sums0[int64_t( w ) * ( C + 1 ) + bins_of[b]] : 0.0;
+			}
+		for( int g0 = 0; g0 < group; g0 += 16 )
+			{
+			double v[NB][16];
+			#pragma unroll
+			for( int b = 0; b < NB; ++b )
+				{
+				#pragma unroll
+				for( int u = 0; u < 16; ++u ) v[b][u] = ( g0 + u < group ) ? gs[int64_t( g0 + u ) * ( C + 1 ) + bins_of[b]] : 0.0;
+				}
+			#pragma unroll
+			for( int u = 0; u < 16; ++u )
+				{
+				#pragma unroll
+				for( int b = 0; b < NB; ++b ) run[b] = fold( run[b] + v[b][u] );      // + 0.0 past the end: fold( x ) of a folded x is x
+				}
+			}
+		#pragma unroll
+		for( int w = 0; w < WAVES; ++w )
+			{
+			#pragma unroll
+			for( int b = 0; b < NB; ++b )
+				{
+				if( has[b] ) reinterpret_cast<double*>( s + L::BUF + w * L::BUF_LEN )[bins_of[b]] = run[b];   // phase_buffer on entry to chain w of the group
+				run[b] = fold( run[b] + vc[b][w] );
+				}
+			}
+		if( tid == 0 && blockIdx.x == 0 && p.nan_in && p.nan_flag && p.nan_in[0] == p.nan_in[2] && p.nan_in[2] != 0 ) atomicOr( p.nan_flag, 1 );
+		__syncthreads();
+		const double * mine = reinterpret_cast<const double*>( buf );
+		#pragma unroll
+		for( int q = 0; q < H; ++q ) { phk[q] = mine[lane + 64 * q]; phm[q] = mine[C - lane - 64 * q]; }
+		phx = mine[C / 2];
+		wave_sync();                                                              // own buffer only: read before the transform writes it
+		}
+	else if( active )
+		{
+		const double * carry = p.carry + chain * ( C + 1 );
+		#pragma unroll
+		for( int q = 0; q < H; ++q ) { phk[q] = carry[lane + 64 * q]; phm[q] = carry[C - lane - 64 * q]; }
+		phx = carry[C / 2];
+		}
+	if( !active ) return;
 	cf acc[E];                                                                  // overlap-add accumulator: acc[q] <-> samples pos + 128 q + 2 lane (+1)
 	#pragma unroll
 	for( int q = 0; q < E; ++q ) acc[q] = mk( 0.0f, 0.0f );
