@@ -15,7 +15,8 @@ static int g_synth_stage_mask = 0xF;             // flanhip_debug_synth_stages()
 // flanhip_debug_kernel_variant(): which dft 2048 kernel generation a call launches (A/B runs in one process).
 // analysis: 0 = round-1 kernel; 4 (the default) / 6 / 7 = v2, 8 / 16 / 4 bins at a time (all in 8-wave blocks, 2 wavefronts per SIMD:
 // 12-wave blocks at <= 168 VGPRs were measured and dropped)
-// synthesis (register-accumulator hops): 0 = round-1 kernel; 1 (the default) = v2; 9 = v2 with plain instead of non-temporal row loads
+// synthesis (register-accumulator hops): 0 = round-1 kernel; 1 (the default) = v2; 2 = v2 behind the scan kernel even where it could work
+// out its own carries; 9 = v2 with plain instead of non-temporal row loads
 static int g_ana_variant = 4, g_syn_variant = 1;
 static int ana_variant_waves( int ) { return 8; }
 static constexpr size_t kMaxLds = 160 * 1024;   // gfx950: 160 KiB LDS per CU, one workgroup may take all of it
@@ -367,7 +368,7 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	const int stages = prepass_only ? 3 : g_synth_stage_mask;
 	// The dft 2048 analysis kernel leaves group totals beside the chain sums (launch_analyze notes that for this workspace): the dft 2048
 	// synthesis kernel then works out its own carries and the scan kernel is not launched.  Any other producer or shape: the scan runs.
-	const bool self_carry = presummed == 1 && !prepass_only && !d_carry_in && !d_total_out && g_syn_variant != 0 && lay.dft == 2048
+	const bool self_carry = presummed == 1 && !prepass_only && !d_carry_in && !d_total_out && g_syn_variant != 0 && g_syn_variant != 2 && lay.dft == 2048
 		&& synth_fast_kind( lay.dft, W, lay.hop ) == 1 && workspace_producer( d_ws ) == 1;
 	if( self_carry )
 		{

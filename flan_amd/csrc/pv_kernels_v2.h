@@ -521,7 +521,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 		float * win = reinterpret_cast<float*>( s + L::WIN );
 		for( int i = tid; i < 2 * C; i += NT ) win[i] = ( i < W ) ? p.window[i] * p.window_scale : 0.0f;      // AudioPV.cpp:102
 		}
-	__syncthreads();
+	if( !p.group_sums ) __syncthreads();                                        // (with group sums the barrier of the carry prologue below serves the tables too)
 	const cf * s_tw1 = s + L::TW1;
 	const cf * s_tw3 = s + L::TW3;
 	const cf * s_w2 = s + L::W2S + lane;
@@ -546,6 +546,37 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 	const int64_t own_start = chain_in_channel == 0 ? INT64_MIN : chain_start + p.head_len;
 	const int padl = lane + ( lane >> 4 );
 	cf * mirror = buf + ( C * 17 ) / 16 - ( lane + ( ( lane + 15 ) >> 4 ) );      // mirror[-68 q] = slot PAD( C - lane - 64 q )
+
+	cf acc[E];                                                                  // overlap-add accumulator: acc[q] <-> samples pos + 128 q + 2 lane (+1)
+	#pragma unroll
+	for( int q = 0; q < E; ++q ) acc[q] = mk( 0.0f, 0.0f );
+
+	// one 128-sample step of finished (or partial) output leaves the chain (positions are even: hop and W/2 are multiples of 64).
+	// Exactly one store instruction per step, never inside a branch: lanes that fall outside the output are pointed at a 512-byte dump
+	// area in the workspace, so the number of stores in flight behind the row request is static (counted wait, see the loop)
+	cf * dump2 = reinterpret_cast<cf*>( p.dump ) + lane;
+	auto emit_step = [&]( int64_t a0, cf v )
+		{
+		const int64_t a = a0 + 2 * lane;
+		cf * dst = ( a0 < own_start ) ? head2 + ( ( a - chain_start ) >> 1 ) : out2 + ( a >> 1 );
+		if( ( ABL & 4 ) || ( a0 >= own_start && !( a >= 0 && a < p.out_len ) ) ) dst = dump2;           // ABL 4 (timing only): every store to the dump area
+		*dst = v;
+		};
+	// MF row of frame t: ( m, f ) of the lane's pairs and of bin C/2
+	cf mfk[H], mfm[H], mfx;
+	auto load_row = [&]( int64_t t )
+		{
+		const cf * row = reinterpret_cast<const cf*>( p.pv + ( int64_t( channel ) * p.F + ( ( ABL & 2 ) ? t0 : t ) ) * ( C + 1 ) );   // ABL 2 (timing only): a hot row
+		const cf * rowk = row + lane;
+		const cf * rowm = row + ( C - lane );
+		#pragma unroll
+		for( int q = 0; q < H; ++q )
+			{
+			mfk[q] = ( ABL & 1 ) ? rowk[64 * q] : __builtin_nontemporal_load( rowk + 64 * q );
+			mfm[q] = ( ABL & 1 ) ? rowm[-64 * q] : __builtin_nontemporal_load( rowm - 64 * q );
+			}
+		mfx = ( ABL & 1 ) ? row[C / 2] : __builtin_nontemporal_load( row + C / 2 );
+		};
 
 	// phase_buffer (AudioPV.cpp:105) on entry to the chain, of the lane's pairs and of bin C/2
 	double phk[H], phm[H], phx;
@@ -578,6 +609,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 			#pragma unroll
 			for( int w = 0; w < WAVES; ++w ) vc[b][w] = ( w < live ) ? sums0[int64_t( w ) * ( C + 1 ) + bins_of[b]] : 0.0;
 			}
+		if( active ) load_row( t0 );                                              // the first MF row travels while the carries are worked out
 		for( int g0 = 0; g0 < group; g0 += 16 )
 			{
 			double v[NB][16];
@@ -620,37 +652,6 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 		phx = carry[C / 2];
 		}
 	if( !active ) return;
-	cf acc[E];                                                                  // overlap-add accumulator: acc[q] <-> samples pos + 128 q + 2 lane (+1)
-	#pragma unroll
-	for( int q = 0; q < E; ++q ) acc[q] = mk( 0.0f, 0.0f );
-
-	// one 128-sample step of finished (or partial) output leaves the chain (positions are even: hop and W/2 are multiples of 64).
-	// Exactly one store instruction per step, never inside a branch: lanes that fall outside the output are pointed at a 512-byte dump
-	// area in the workspace, so the number of stores in flight behind the row request is static (counted wait, see the loop)
-	cf * dump2 = reinterpret_cast<cf*>( p.dump ) + lane;
-	auto emit_step = [&]( int64_t a0, cf v )
-		{
-		const int64_t a = a0 + 2 * lane;
-		cf * dst = ( a0 < own_start ) ? head2 + ( ( a - chain_start ) >> 1 ) : out2 + ( a >> 1 );
-		if( ( ABL & 4 ) || ( a0 >= own_start && !( a >= 0 && a < p.out_len ) ) ) dst = dump2;           // ABL 4 (timing only): every store to the dump area
-		*dst = v;
-		};
-	// MF row of frame t: ( m, f ) of the lane's pairs and of bin C/2
-	cf mfk[H], mfm[H], mfx;
-	auto load_row = [&]( int64_t t )
-		{
-		const cf * row = reinterpret_cast<const cf*>( p.pv + ( int64_t( channel ) * p.F + ( ( ABL & 2 ) ? t0 : t ) ) * ( C + 1 ) );   // ABL 2 (timing only): a hot row
-		const cf * rowk = row + lane;
-		const cf * rowm = row + ( C - lane );
-		#pragma unroll
-		for( int q = 0; q < H; ++q )
-			{
-			mfk[q] = ( ABL & 1 ) ? rowk[64 * q] : __builtin_nontemporal_load( rowk + 64 * q );
-			mfm[q] = ( ABL & 1 ) ? rowm[-64 * q] : __builtin_nontemporal_load( rowm - 64 * q );
-			}
-		mfx = ( ABL & 1 ) ? row[C / 2] : __builtin_nontemporal_load( row + C / 2 );
-		};
-
 	cf z[E];
 	// inverse phase vocoder of the row in mfk / mfm / mfx (AudioPV.cpp:117-120, phase_vocoder.cpp:55-61), merge of X[0..C] into the
 	// half-size spectrum conj( A + i B ) (the forward transform of it is the conjugate of the inverse one): leaves z[] complete
@@ -729,7 +730,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 		wave_sync();
 		};
 
-	load_row( t0 );
+	if( !p.group_sums ) load_row( t0 );
 	bins_of_row();
 	int64_t pos = chain_start;
 	for( int64_t t = t0; t < t1; ++t )
