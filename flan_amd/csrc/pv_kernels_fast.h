@@ -458,8 +458,8 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 		const cf * row = reinterpret_cast<const cf*>( p.pv + ( int64_t( channel ) * p.F + t ) * ( C + 1 ) );
 		const cf * rowp = row + lane;
 		#pragma unroll
-		for( int q = 0; q < E; ++q ) mfr[q] = rowp[64 * q];
-		mfny = row[C];
+		for( int q = 0; q < E; ++q ) mfr[q] = __builtin_nontemporal_load( rowp + 64 * q );   // the PV is read once
+		mfny = __builtin_nontemporal_load( row + C );
 		};
 	cf mfr[E], mfny;
 	load_row( t0, mfr, mfny );
