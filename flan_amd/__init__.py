@@ -188,7 +188,8 @@ def modify_frequency(pv, sample_rate, mod_hz, in_modified):
 
 
 def resample(audio, src_rate, dst_rate):
-    """Audio::resample (2:1 only).  audio float32 [ch][n] -> float32 [ch][n_out]"""
+    """Audio::resample (r8brain's single-step ratios and its block convolver + whole-stepping interpolator ratios, e.g. 44.1 <-> 48 kHz).
+    audio float32 [ch][n] -> float32 [ch][n_out]"""
     audio = np.ascontiguousarray(audio, np.float32)
     ch, n = audio.shape
     n_out = lib.flanhip_resample_out_frames(n, src_rate, dst_rate)

@@ -10,9 +10,15 @@
 // The other ratios r8brain serves with a SINGLE block convolver (CDSPResampler.h:139-161: src*num == dst*den for (num,den) in
 // (1,3) (2,3) (3,2) (3,4); :165-207: dst == 2 src, dst == 3 src) are the same sum over a zero-stuffed input,
 //        out[k] = float( sum_j h[j] * xu[down*k - j] ),  xu[up*m] = x[m],
-// with the low-pass at cut-off 1/max(up,down) and DC gain `up` (k_resample_rational).  Every other ratio runs through r8brain's
-// half-band upsamplers / fractional interpolators and is not implemented: FLANHIP_ERR_UNSUPPORTED.
+// with the low-pass at cut-off 1/max(up,down) and DC gain `up` (k_resample_rational).
+// 44.1 <-> 48 kHz and the other ratios r8brain serves with one block convolver FOLLOWED BY one whole-stepping CDSPFracInterpolator
+// (CDSPResampler.h:214-316 with no half-band stage, :319-378 likewise; CDSPFracInterpolator.h:573-602, :929-958) keep r8brain's two
+// stages: k_resample_rational writes the band-limited stream y in fp64 (2x zero-stuffed, or filtered in place), k_frac_whole walks it
+// with the bank of OutStep fractional-delay filters (28 taps at 206.91 dB).  Ratios that need half-band up/downsamplers (dst >= 2.02 src
+// off the 2^k / 3*2^k grid, src >= 4 dst) or the spline-interpolated bank (no whole stepping: rates without a small common divisor)
+// are not implemented: FLANHIP_ERR_UNSUPPORTED.
 #include "flanhip_internal.h"
+#include "processors_common.h"
 #include <cmath>
 #include <vector>
 #include <tuple>
@@ -94,6 +100,89 @@ static bool rational_ratio( double src, double dst, int & up, int & down )
 	if( src * 3 == dst ) { up = 3; down = 1; return true; }
 	return false;
 	}
+
+// ---- two-stage ratios: block convolver + whole-stepping fractional interpolator ---------------------------------------------------
+// CDSPFracInterpolator.h:539-558 (subtractive, at most 50 rounds) and :573-602
+static bool whole_stepping( double src, double dst, int & in_step, int & out_step )
+	{
+	double l = src, s = dst, gcd = 0.0;
+	bool found = false;
+	for( int it = 0; it < 50 && !found; ++it )
+		{
+		if( s <= 0.0 ) { gcd = l; found = true; break; }
+		const double r = l - s;
+		l = s;
+		s = std::fabs( r );
+		}
+	if( !found || gcd < 1.0 ) return false;
+	const double i0 = src / gcd, o0 = dst / gcd;
+	in_step = int( i0 ); out_step = int( o0 );
+	return i0 == in_step && o0 == out_step && out_step <= 1500;
+	}
+
+struct TwoStageShape { int up = 0; double norm_freq = 0, gain = 0; bool third = false; int in_step = 0, out_step = 0; };
+
+// Does CDSPResampler( src, dst ) come out as { block convolver, whole-stepping interpolator }?  Call after rational_ratio() said no.
+static bool two_stage_shape( double src, double dst, TwoStageShape & ts )
+	{
+	if( src == dst ) return false;
+	for( int i = 2; i <= 3; ++i )                                                 // CDSPResampler.h:174-212: 2^k / 3*2^k upsampling has half-band stages
+		for( int c = 1; src * ( i << c ) <= dst; ++c ) if( src * ( i << c ) == dst ) return false;
+	if( dst * 2 > src )                                                           // :214-316
+		{
+		const double thresh = src * 1.01;
+		int c = 0, div = 1;
+		while( !( dst < thresh * ( div * 2 ) ) ) { div *= 2; ++c; }                // :229-244
+		int t1, t2;
+		if( c == 1 && whole_stepping( src * 2.0, dst, t1, t2 ) ) c = 0;            // :266-276
+		if( c > 0 ) return false;
+		ts.up = 2; ts.norm_freq = dst > src ? 0.5 : 0.5 * dst / src; ts.gain = 2.0; ts.third = false;
+		return whole_stepping( src * 2.0, dst, ts.in_step, ts.out_step );
+		}
+	if( dst * 4.0 <= src ) return false;                                          // :321-331: half-band downsamplers
+	ts.up = 1; ts.norm_freq = dst / src; ts.gain = 1.0; ts.third = ts.norm_freq * 3.0 <= 1.0;   // :351-356, :368-376
+	return whole_stepping( src, dst, ts.in_step, ts.out_step );
+	}
+
+// CDSPFracDelayFilterBank( OutStep, 1, 2, 206.91, third ) (CDSPFracInterpolator.h:64-121, window parameters :289-348 -- the rows that
+// cover 206.91 dB): `fracs` filters of flt_len taps, row r delays by ( fracs - r ) / fracs samples.  Each is a Kaiser-power windowed
+// sinc sampled at t + delay, t = -fl2 .. fl2 - 1 (CDSPSincFilterGen.h:184-193, :246-257, :432-517), normalised to unit DC gain.
+static void frac_delay_bank( int fracs, bool third, std::vector<double> & bank, int & flt_len )
+	{
+	const double pi = 3.14159265358979323846;
+	const double beta = third ? 19.1718281840114810 : 10.2382664677006100;
+	const double power = third ? 1.2030083075440616 : 2.1608878780497056;
+	flt_len = third ? 22 : 28;
+	const int fl2 = flt_len / 2;
+	const double len2 = fl2, kdiv = bessel_i0_as( beta );
+	bank.assign( size_t( fracs ) * flt_len, 0.0 );
+	for( int r = 0; r < fracs; ++r )
+		{
+		double * op = &bank[size_t( r ) * flt_len];
+		const double delay = double( fracs - r ) / fracs, len2frac = delay / len2;
+		const double f0 = std::sin( delay * pi );
+		const bool unit = delay >= 1.0 - 1e-13 && delay <= 1.0 + 1e-13;
+		double sum = 0.0;
+		for( int i = 0; i < flt_len; ++i )
+			{
+			const int t = i - fl2;
+			const double n = 1.0 - sqr( t / len2 + len2frac );
+			const double w = std::pow( n < 0.0 ? 0.0 : bessel_i0_as( beta * std::sqrt( n ) ) / kdiv, power );
+			const double ut = t + delay;
+			double v;
+			if( t == ( unit ? -1 : 0 ) && std::fabs( ut ) <= 1e-13 ) v = w;      // the tap under the peak of the sinc
+			else if( i == flt_len - 1 && ut > len2 ) v = 0.0;
+			else v = ( ( t & 1 ) ? -f0 : f0 ) * w / ut / pi;
+			op[i] = v;
+			sum += v;
+			}
+		const double g = 1.0 / sum;
+		for( int i = 0; i < flt_len; ++i ) op[i] *= g;
+		}
+	}
+
+struct TwoStagePlan { double * d_h = nullptr; double * d_bank = nullptr; int fl2 = 0, flt_len = 0; TwoStageShape shape; };
+static std::map<std::tuple<int, double, double>, TwoStagePlan> g_ts_plans;   // per (device, src, dst)
 
 // Device copies of the taps for one (up, down): h[0 .. 2 fl2] in natural order, and for the 2:1 kernel
 // d_he[q] = h[2 fl2 - 2 q] (q = 0 .. fl2), d_ho[q] = h[2 fl2 - 1 - 2 q] (q = 0 .. fl2 - 1): the taps in the order it walks them
@@ -213,8 +302,9 @@ __global__ __launch_bounds__( 64 * RS_WAVES ) void k_resample_2to1( const float 
 // One thread per output; a block of 256 outputs stages its input span (fp64) and the taps in LDS.
 constexpr int RSG_BLOCK = 256;
 __host__ __device__ inline int64_t rs_floor_div( int64_t a, int64_t b ) { return a >= 0 ? a / b : -( ( -a + b - 1 ) / b ); }
+template<typename OutT>   // float: the resampled audio; double: the band-limited stream a fractional interpolator reads next
 __global__ __launch_bounds__( RSG_BLOCK ) void k_resample_rational( const float * __restrict__ in, int64_t total_in, const double * __restrict__ taps, int fl2,
-	int up, int down, int span, float * __restrict__ out, int64_t total_out )
+	int up, int down, int span, OutT * __restrict__ out, int64_t total_out )
 	{
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int ntaps = 2 * fl2 + 1;
@@ -239,12 +329,91 @@ __global__ __launch_bounds__( RSG_BLOCK ) void k_resample_rational( const float 
 	double acc = 0.0;
 	#pragma unroll 4
 	for( int i = 0; i < count; ++i ) acc = __builtin_fma( hp[-up * i], xp[i], acc );   // zeros outside the buffer contribute +-0
+	out[k] = OutT( acc );
+	}
+
+// CDSPFracInterpolator::convolve0 (CDSPFracInterpolator.h:929-958): output k sits k*in_step/out_step samples into y,
+//        p = ( k*in_step ) / out_step,  r = ( k*in_step ) % out_step,  out[k] = float( sum_i bank[r][i] * y[p - ( flt_len/2 - 1 ) + i] ),
+// i ascending, y = 0 before its start (the ring buffer's initial zeros, :771-778) and past what stage 1 wrote (never read: ny covers it).
+constexpr int FRAC_BLOCK = 256;
+__global__ __launch_bounds__( FRAC_BLOCK ) void k_frac_whole( const double * __restrict__ y, int64_t ny, const double * __restrict__ bank, int flt_len,
+	int in_step, int out_step, float * __restrict__ out, int64_t total_out )
+	{
+	const int64_t k = int64_t( blockIdx.x ) * FRAC_BLOCK + threadIdx.x;
+	if( k >= total_out ) return;
+	const int64_t pos = k * in_step, p = pos / out_step;
+	const double * ft = bank + ( pos - p * out_step ) * flt_len;
+	const int64_t a0 = p - ( flt_len / 2 - 1 );
+	double acc = 0.0;
+	if( a0 >= 0 && a0 + flt_len <= ny )
+		for( int i = 0; i < flt_len; ++i ) acc = __builtin_fma( ft[i], y[a0 + i], acc );
+	else
+		for( int i = 0; i < flt_len; ++i )
+			{
+			const int64_t a = a0 + i;
+			acc = __builtin_fma( ft[i], ( a >= 0 && a < ny ) ? y[a] : 0.0, acc );
+			}
 	out[k] = float( acc );
+	}
+
+static int get_two_stage_plan( double src, double dst, const TwoStagePlan ** out )
+	{
+	int device = 0;
+	FLANHIP_CHECK( hipGetDevice( &device ) );
+	std::lock_guard<std::mutex> lock( g_rs_mutex );
+	const auto key = std::make_tuple( device, src, dst );
+	auto it = g_ts_plans.find( key );
+	if( it != g_ts_plans.end() ) { *out = &it->second; return FLANHIP_OK; }
+	TwoStagePlan p;
+	FLANHIP_REQUIRE( two_stage_shape( src, dst, p.shape ), FLANHIP_ERR_UNSUPPORTED, "not a block convolver + whole-stepping interpolator ratio" );
+	std::vector<double> h, bank;
+	FLANHIP_REQUIRE( design_default_lowpass( p.shape.norm_freq, p.shape.gain, h, p.fl2 ), FLANHIP_ERR_UNSUPPORTED, "low-pass design outside the restated range" );
+	frac_delay_bank( p.shape.out_step, p.shape.third, bank, p.flt_len );
+	FLANHIP_CHECK( hipMalloc( &p.d_h, sizeof( double ) * ( h.size() + bank.size() ) ) );
+	p.d_bank = p.d_h + h.size();
+	FLANHIP_CHECK( hipMemcpy( p.d_h, h.data(), sizeof( double ) * h.size(), hipMemcpyHostToDevice ) );
+	FLANHIP_CHECK( hipMemcpy( p.d_bank, bank.data(), sizeof( double ) * bank.size(), hipMemcpyHostToDevice ) );
+	*out = &g_ts_plans.emplace( key, p ).first->second;
+	return FLANHIP_OK;
+	}
+
+static size_t rational_lds( int fl2, int up, int down, int & span )
+	{
+	span = int( ( int64_t( down ) * ( RSG_BLOCK - 1 ) + 2 * fl2 ) / up + 2 );
+	return sizeof( double ) * ( size_t( 2 * fl2 + 2 ) + size_t( span ) );
+	}
+
+static int resample_two_stage_dev( const float * d_in, int64_t total_in, double src, double dst, float * d_out, int64_t total_out, hipStream_t s )
+	{
+	const TwoStagePlan * plan = nullptr;
+	if( int rc = get_two_stage_plan( src, dst, &plan ) ) return rc;
+	const TwoStageShape & ts = plan->shape;
+	// the stretch of y the last output reads
+	const int64_t ny = ( ( total_out - 1 ) * ts.in_step ) / ts.out_step - ( plan->flt_len / 2 - 1 ) + plan->flt_len;
+	int span = 0;
+	const size_t lds = rational_lds( plan->fl2, ts.up, 1, span );
+	FLANHIP_REQUIRE( lds <= 160 * 1024, FLANHIP_ERR_UNSUPPORTED, "filter too long for the LDS staging" );
+	retain_pool_memory();
+	double * d_y = nullptr;
+	FLANHIP_CHECK( hipMallocAsync( reinterpret_cast<void**>( &d_y ), sizeof( double ) * size_t( ny ), s ) );
+	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( k_resample_rational<double> ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+	hipLaunchKernelGGL( k_resample_rational<double>, dim3( (unsigned) ( ( ny + RSG_BLOCK - 1 ) / RSG_BLOCK ) ), dim3( RSG_BLOCK ), lds, s,
+		d_in, total_in, plan->d_h, plan->fl2, ts.up, 1, span, d_y, ny );
+	hipLaunchKernelGGL( k_frac_whole, dim3( (unsigned) ( ( total_out + FRAC_BLOCK - 1 ) / FRAC_BLOCK ) ), dim3( FRAC_BLOCK ), 0, s,
+		d_y, ny, plan->d_bank, plan->flt_len, ts.in_step, ts.out_step, d_out, total_out );
+	const hipError_t launched = hipGetLastError();
+	FLANHIP_CHECK( hipFreeAsync( d_y, s ) );
+	FLANHIP_CHECK( launched );
+	return FLANHIP_OK;
 	}
 
 } // namespace flanhip
 
 using namespace flanhip;
+
+static const char * const k_unsupported_ratio =
+	"implemented: the single-step ratios (src:dst = 2:1, 3:1, 3:2, 2:3, 4:3, 1:2, 1:3) and block convolver + whole-stepping interpolator "
+	"ratios (44.1 <-> 48 kHz ...); this one needs r8brain's half-band stages or its spline-interpolated filter bank";
 
 extern "C" {
 
@@ -258,14 +427,16 @@ int flanhip_resample_dev( const float * d_in, int64_t ch, int64_t n, float src_r
 	{
 	FLANHIP_REQUIRE( d_in && d_out && ch > 0 && n > 0 && src_rate > 0.0f && dst_rate > 0.0f, FLANHIP_ERR_INVALID_ARG, "bad arguments" );
 	int up = 0, down = 0;
-	FLANHIP_REQUIRE( rational_ratio( double( src_rate ), double( dst_rate ), up, down ), FLANHIP_ERR_UNSUPPORTED,
-		"only the single-step ratios are implemented (src:dst = 2:1, 3:1, 3:2, 2:3, 4:3, 1:2, 1:3)" );
+	const bool single = rational_ratio( double( src_rate ), double( dst_rate ), up, down );
+	TwoStageShape ts;
+	FLANHIP_REQUIRE( single || two_stage_shape( double( src_rate ), double( dst_rate ), ts ), FLANHIP_ERR_UNSUPPORTED, k_unsupported_ratio );
 	if( int rc = require_device() ) return rc;
-	const ResamplePlan * plan = nullptr;
-	if( int rc = get_resample_plan( up, down, &plan ) ) return rc;
 	const int64_t n_out = flanhip_resample_out_frames( n, src_rate, dst_rate );
 	const int64_t total_in = ch * n, total_out = ch * n_out;
 	if( total_out <= 0 ) return FLANHIP_OK;
+	if( !single ) return resample_two_stage_dev( d_in, total_in, double( src_rate ), double( dst_rate ), d_out, total_out, (hipStream_t) stream );
+	const ResamplePlan * plan = nullptr;
+	if( int rc = get_resample_plan( up, down, &plan ) ) return rc;
 	if( up == 1 && down == 2 && plan->fl2 >= 64 * ( RS_R - 1 ) )
 		{
 		const size_t lds = sizeof( double ) * size_t( 2 * RS_BLOCK_OUT + 2 * plan->fl2 + 2 );
@@ -275,11 +446,11 @@ int flanhip_resample_dev( const float * d_in, int64_t ch, int64_t n, float src_r
 		}
 	else
 		{
-		const int span = int( ( int64_t( down ) * ( RSG_BLOCK - 1 ) + 2 * plan->fl2 ) / up + 2 );
-		const size_t lds = sizeof( double ) * ( size_t( 2 * plan->fl2 + 2 ) + size_t( span ) );
+		int span = 0;
+		const size_t lds = rational_lds( plan->fl2, up, down, span );
 		FLANHIP_REQUIRE( lds <= 160 * 1024, FLANHIP_ERR_UNSUPPORTED, "filter too long for the LDS staging" );
-		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( k_resample_rational ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
-		hipLaunchKernelGGL( k_resample_rational, dim3( (unsigned) ( ( total_out + RSG_BLOCK - 1 ) / RSG_BLOCK ) ), dim3( RSG_BLOCK ), lds, (hipStream_t) stream,
+		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( k_resample_rational<float> ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+		hipLaunchKernelGGL( k_resample_rational<float>, dim3( (unsigned) ( ( total_out + RSG_BLOCK - 1 ) / RSG_BLOCK ) ), dim3( RSG_BLOCK ), lds, (hipStream_t) stream,
 			d_in, total_in, plan->d_h, plan->fl2, up, down, span, d_out, total_out );
 		}
 	FLANHIP_CHECK( hipGetLastError() );
@@ -289,7 +460,9 @@ int flanhip_resample_dev( const float * d_in, int64_t ch, int64_t n, float src_r
 int flanhip_resample( const float * in, int64_t ch, int64_t n, float src_rate, float dst_rate, float * out, volatile int * cancel )
 	{
 	FLANHIP_REQUIRE( in && out && ch > 0 && n > 0, FLANHIP_ERR_INVALID_ARG, "bad arguments" );
-	{ int up = 0, down = 0; FLANHIP_REQUIRE( rational_ratio( double( src_rate ), double( dst_rate ), up, down ), FLANHIP_ERR_UNSUPPORTED, "only the single-step ratios are implemented" ); }
+	{ int up = 0, down = 0; TwoStageShape ts;
+	  FLANHIP_REQUIRE( rational_ratio( double( src_rate ), double( dst_rate ), up, down ) || two_stage_shape( double( src_rate ), double( dst_rate ), ts ),
+		FLANHIP_ERR_UNSUPPORTED, k_unsupported_ratio ); }
 	if( int rc = require_device() ) return rc;
 	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
 	const int64_t n_out = flanhip_resample_out_frames( n, src_rate, dst_rate );

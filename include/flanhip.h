@@ -332,8 +332,12 @@ int64_t flanhip_resample_out_frames(int64_t num_frames, float src_rate, float ds
 /* in: float[ch][n]; out: float[ch][flanhip_resample_out_frames(n,...)].  Like the reference, the whole channel-major buffer is
  * resampled as ONE stream (filter ringing crosses channel boundaries).  Implemented: the ratios r8brain serves with a single
  * block convolver (r8brain/CDSPResampler.h:139-207) -- src:dst = 2:1 (96 -> 48 kHz: 1621-tap linear-phase low-pass, the tuned
- * kernel), 3:1, 3:2, 2:3, 4:3, 1:2, 1:3 -- latency consumed, zero-flushed tail.  Other ratios (half-band upsampler chains,
- * fractional interpolators) return FLANHIP_ERR_UNSUPPORTED. */
+ * kernel), 3:1, 3:2, 2:3, 4:3, 1:2, 1:3 -- latency consumed, zero-flushed tail; and the ratios it serves with one block convolver
+ * followed by one whole-stepping CDSPFracInterpolator (CDSPResampler.h:214-316, :319-378 with no half-band stage;
+ * CDSPFracInterpolator.h:573-602): 44.1 <-> 48 kHz, 96 -> 44.1, 22.05 -> 48, 44.1 -> 96, 44.1 <-> 32 kHz ... (the _dev form takes a
+ * transient fp64 workspace of about 2 x the input from the stream's memory pool).  Ratios that need half-band up/downsampler chains
+ * (dst >= 2.02 src off the 2^k / 3*2^k grid, src >= 4 dst) or the spline-interpolated filter bank (rates without whole stepping)
+ * return FLANHIP_ERR_UNSUPPORTED. */
 int flanhip_resample(const float * in, int64_t num_channels, int64_t num_frames, float src_rate, float dst_rate,
                      float * out, volatile int * cancel);
 int flanhip_resample_dev(const float * d_in, int64_t num_channels, int64_t num_frames, float src_rate, float dst_rate,

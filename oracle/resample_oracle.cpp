@@ -90,6 +90,204 @@ bool design_default_lowpass( double req_norm_freq, double gain, std::vector<doub
 
 } // namespace
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The two-stage ratios (44.1 <-> 48 kHz and every other pair CDSPResampler serves with ONE block convolver followed by ONE
+// CDSPFracInterpolator, no half-band stages):
+//   * dst*2 > src, not a single-step ratio (CDSPResampler.h:214-316 with c == 0, which includes c == 1 turned into 0 by whole stepping,
+//     :268-276): CDSPBlockConvolver( getLPFilter( NormFreq, tb, atten, phase, 2.0 ), 2, 1 ) with NormFreq = 0.5 when upsampling and
+//     0.5*dst/src otherwise, then CDSPFracInterpolator( 2 src -> dst, IsThird = false );
+//   * 2 dst <= src < 4 dst, src not 2 dst or 3 dst (:319-378 with c == 0, UseInterp): CDSPBlockConvolver( getLPFilter( dst/src, ...,
+//     1.0 ), 1, 1 ), then CDSPFracInterpolator( src -> dst, IsThird = ( 3 dst <= src ) ).
+// Both filters are linear phase, so no fractional latency travels between the stages (CDSPBlockConvolver.h LatencyFrac = 0) and the
+// interpolator starts at position 0.  Only WHOLE-NUMBER STEPPING (getWholeStepping, CDSPFracInterpolator.h:573-602) is restated: the
+// interpolator then walks a bank of OutStep fractional-delay filters with exact integer positions (convolve0, :929-958); the
+// spline-interpolated bank of the other case (convolve2) re-bases its position counter at process() call boundaries and is not restated.
+namespace {
+
+// CDSPFracInterpolator.h:539-558
+bool find_gcd( double l, double s, double & gcd )
+	{
+	for( int it = 0; it < 50; ++it )
+		{
+		if( s <= 0.0 ) { gcd = l; return true; }
+		const double r = l - s;
+		l = s;
+		s = r < 0.0 ? -r : r;
+		}
+	return false;
+	}
+
+// CDSPFracInterpolator.h:573-602
+bool whole_stepping( double src, double dst, int & in_step, int & out_step )
+	{
+	double gcd;
+	if( !find_gcd( src, dst, gcd ) || gcd < 1.0 ) return false;
+	const double i0 = src / gcd, o0 = dst / gcd;
+	in_step = int( i0 ); out_step = int( o0 );
+	if( i0 != in_step || o0 != out_step ) return false;
+	return out_step <= 1500;
+	}
+
+struct TwoStage { int up; double norm_freq, gain; bool third; int in_step, out_step; };
+
+// which chain does CDSPResampler( src, dst ) build?  false: not one of the two-stage shapes above
+bool two_stage_shape( double src, double dst, TwoStage & ts )
+	{
+	if( src == dst ) return false;
+	static const int common[5][2] = { { 1, 2 }, { 1, 3 }, { 2, 3 }, { 3, 2 }, { 3, 4 } };            // CDSPResampler.h:142-170
+	for( const auto & c : common ) if( src * c[0] == dst * c[1] ) return false;
+	for( int i = 2; i <= 3; ++i )                                                                   // :174-212
+		for( int c = 0; src * ( i << c ) <= dst; ++c ) if( src * ( i << c ) == dst ) return false;
+	if( dst * 2 > src )                                                                            // :214
+		{
+		const double thresh = src * 1.01;                                                          // :229-244
+		int c = 0, div = 1;
+		while( !( dst < thresh * ( div * 2 ) ) ) { div *= 2; ++c; }
+		int t1, t2;
+		if( c == 1 && whole_stepping( src * 2.0, dst, t1, t2 ) ) c = 0;                            // :266-276
+		if( c > 0 ) return false;                                                                  // half-band upsamplers follow
+		ts.up = 2; ts.norm_freq = dst > src ? 0.5 : 0.5 * dst / src; ts.gain = 2.0; ts.third = false;   // :218-225, :312-313
+		return whole_stepping( src * 2.0, dst, ts.in_step, ts.out_step );
+		}
+	if( dst * 4.0 <= src ) return false;                                                           // :321-331: c > 0, half-band downsamplers
+	for( int downf = 2; downf <= 3; ++downf ) if( dst * downf == src ) return false;               // :340-349 (single step; matched above anyway)
+	ts.up = 1; ts.norm_freq = dst / src; ts.gain = 1.0; ts.third = ts.norm_freq * 3.0 <= 1.0;      // :351-356, :368-376
+	return whole_stepping( src, dst, ts.in_step, ts.out_step );
+	}
+
+// CDSPFracDelayFilterBank::getWinParams (CDSPFracInterpolator.h:289-348): Kaiser beta / window power by attenuation, filter length
+const double * frac_win_params( double att, bool third, int & flt_len )
+	{
+	static const double half[13][3] = {
+		{ 2.6504246356892924, 1.9035845248358245, 51.7280 }, { 4.0759654812373016, 1.5747323142948524, 67.1095 },
+		{ 4.9036508646352033, 1.6207644759455790, 81.8379 }, { 5.6131421124830716, 1.6947677220415129, 96.4021 },
+		{ 5.9433751253133691, 1.8730186383321272, 111.1300 }, { 6.8308658253825660, 1.8549555120377224, 125.4649 },
+		{ 7.6648458853758372, 1.8565765953924642, 139.7378 }, { 8.2038730802326842, 1.9269521308895179, 154.0532 },
+		{ 8.7865151489187561, 1.9775307528231671, 168.2101 }, { 9.5945013206755156, 1.9718457932433306, 182.1076 },
+		{ 10.5163048616210250, 1.9504085061576968, 195.5668 }, { 10.2382664677006100, 2.1608878780497056, 209.0609 },
+		{ 10.9976663155261660, 2.1536415815428249, 222.5009 } };
+	static const double thirds[10][3] = {
+		{ 4.0738201365282452, 1.5774150265957998, 67.2431 }, { 4.9502289040040495, 1.7149006172407628, 86.4870 },
+		{ 5.5995071332976192, 1.8930163359641823, 106.1171 }, { 6.3627287856776054, 1.9945748303811506, 125.2304 },
+		{ 7.4299554386534528, 1.9893399585993299, 144.3469 }, { 8.0667710807396436, 2.0928202837610885, 163.4098 },
+		{ 8.7469991933128526, 2.1640274270903488, 181.0694 }, { 10.0823164330540570, 2.0896732996403280, 199.2880 },
+		{ 19.1718281840114810, 1.2030083075440616, 215.2990 }, { 21.0914128488567630, 1.1919045429676862, 233.9152 } };
+	int i = 0;
+	if( third ) { while( i != 9 && thirds[i][2] < att ) ++i; flt_len = ( i + 3 ) * 2; return thirds[i]; }
+	while( i != 12 && half[i][2] < att ) ++i;
+	flt_len = ( i + 3 ) * 2;
+	return half[i];
+	}
+
+// One fractional-delay filter of the bank: CDSPSincFilterGen::initFrac + generateFrac with the Kaiser-power window
+// (CDSPSincFilterGen.h:184-193, :246-257, :432-517, :572-590) and normalizeFIRFilter( ., 1.0 ) (r8bbase.h:943-970).
+// Len2 = flt_len / 2 is a whole number here, so fl2 = Len2 and the first tap never falls outside the window (:444-450).
+void frac_delay_filter( int flt_len, double beta, double power, double delay, double * op )
+	{
+	const double pi = 3.14159265358979323846;
+	const int fl2 = flt_len / 2;
+	const double len2 = fl2;
+	const double kdiv = bessel_i0_as( beta ), len2frac = delay / len2;
+	int wn = -fl2;
+	auto win = [&]()
+		{
+		const double n = 1.0 - sqr( wn / len2 + len2frac );
+		++wn;
+		const double w = n < 0.0 ? 0.0 : bessel_i0_as( beta * std::sqrt( n ) ) / kdiv;
+		return std::pow( w, power );
+		};
+	const double f[2] = { std::sin( delay * pi ), -std::sin( delay * pi ) };
+	int t = -fl2;
+	const int mt = ( delay >= 1.0 - 1e-13 && delay <= 1.0 + 1e-13 ) ? -1 : 0;
+	for( ; t < mt; ++t ) *op++ = f[t & 1] * win() / ( t + delay ) / pi;
+	double ut = t + delay;
+	*op = std::fabs( ut ) <= 1e-13 ? win() : f[t & 1] * win() / ut / pi;
+	while( t < fl2 - 2 ) { ++op; ++t; *op = f[t & 1] * win() / ( t + delay ) / pi; }
+	++op; ++t;
+	ut = t + delay;
+	*op = ut > len2 ? 0.0 : f[t & 1] * win() / ut / pi;
+	op -= flt_len - 1;
+	double s = 0.0;
+	for( int i = 0; i < flt_len; ++i ) s += op[i];
+	s = 1.0 / s;
+	for( int i = 0; i < flt_len; ++i ) op[i] *= s;
+	}
+
+// CDSPFracDelayFilterBank( OutStep, 1, 2, 206.91, third ) (CDSPFracInterpolator.h:64-121): row r is the delay ( fracs - r ) / fracs
+void frac_delay_bank( int fracs, bool third, std::vector<double> & bank, int & flt_len )
+	{
+	const double * wp = frac_win_params( 206.91, third, flt_len );
+	const double beta = wp[0] < 1.0 ? 1.0 : wp[0] > 350.0 ? 350.0 : wp[0];
+	bank.assign( size_t( fracs ) * flt_len, 0.0 );
+	for( int r = 0; r < fracs; ++r ) frac_delay_filter( flt_len, beta, std::fabs( wp[1] ), double( fracs - r ) / fracs, &bank[size_t( r ) * flt_len] );
+	}
+
+} // namespace
+
+// 1 when ( src, dst ) is a two-stage ratio this file restates; fills what a test wants to look at
+extern "C" int oracle_resample_two_stage_shape( double src, double dst, int * up, double * norm_freq, int * third, int * in_step, int * out_step )
+	{
+	TwoStage ts{};
+	if( !two_stage_shape( src, dst, ts ) ) return 0;
+	if( up ) *up = ts.up;
+	if( norm_freq ) *norm_freq = ts.norm_freq;
+	if( third ) *third = ts.third ? 1 : 0;
+	if( in_step ) *in_step = ts.in_step;
+	if( out_step ) *out_step = ts.out_step;
+	return 1;
+	}
+
+// the bank, for tests: returns the filter length, rows [out_step][flt_len]
+extern "C" int oracle_r8b_frac_bank( int fracs, int third, double * rows, int capacity )
+	{
+	std::vector<double> bank; int flt_len = 0;
+	frac_delay_bank( fracs, third != 0, bank, flt_len );
+	if( rows ) for( size_t i = 0; i < bank.size() && i < size_t( capacity ); ++i ) rows[i] = bank[i];
+	return flt_len;
+	}
+
+// Audio::resample for a two-stage ratio.  Stage 1 (block convolver, latency consumed; the direct sum as above):
+//        y[n] = sum_m h[fl2 + n - up*m] * x[m],  m ascending, x = 0 outside the buffer, y = 0 for n < 0 (the interpolator's ring buffer
+//        starts with fl2i - 1 zeros, CDSPFracInterpolator.h:771-778);
+// stage 2 (convolve0): output k sits at k*in_step/out_step input samples: p = ( k*in_step ) / out_step, r = ( k*in_step ) % out_step,
+//        out[k] = float( sum_{i=0}^{flt_len-1} bank[r][i] * y[p - ( fl2i - 1 ) + i] ),  i ascending, separate multiply and add.
+extern "C" int oracle_resample_two_stage( const float * in, int64_t total_in, float * out, int64_t total_out, double src, double dst )
+	{
+	TwoStage ts{};
+	if( !two_stage_shape( src, dst, ts ) ) return -1;
+	std::vector<double> h; int fl2 = 0;
+	if( !design_default_lowpass( ts.norm_freq, ts.gain, h, fl2 ) ) return -1;
+	std::vector<double> bank; int flt_len = 0;
+	frac_delay_bank( ts.out_step, ts.third, bank, flt_len );
+	const int fll = flt_len / 2 - 1;
+	if( total_out <= 0 ) return 0;
+	const int64_t ny = ( ( total_out - 1 ) * ts.in_step ) / ts.out_step - fll + flt_len;
+	std::vector<double> y( size_t( ny > 0 ? ny : 0 ) );
+	const int up = ts.up;
+	for( int64_t n = 0; n < ny; ++n )
+		{
+		int64_t m0 = n - fl2 <= 0 ? 0 : ( n - fl2 + up - 1 ) / up;
+		int64_t m1 = ( n + fl2 ) / up;
+		if( m1 >= total_in ) m1 = total_in - 1;
+		double acc = 0.0;
+		for( int64_t m = m0; m <= m1; ++m ) acc += h[fl2 + ( n - up * m )] * double( in[m] );
+		y[size_t( n )] = acc;
+		}
+	for( int64_t k = 0; k < total_out; ++k )
+		{
+		const int64_t pos = k * ts.in_step, p = pos / ts.out_step;
+		const double * ft = &bank[size_t( pos % ts.out_step ) * flt_len];
+		double s = 0.0;
+		for( int i = 0; i < flt_len; ++i )
+			{
+			const int64_t a = p - fll + i;
+			s += ft[i] * ( a >= 0 && a < ny ? y[size_t( a )] : 0.0 );
+			}
+		out[k] = float( s );
+		}
+	return 0;
+	}
+
 extern "C" {
 
 // taps of the default low-pass at cut-off 1/2, for tests

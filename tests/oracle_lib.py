@@ -65,6 +65,10 @@ def _load():
     lib.oracle_resample_2to1.argtypes = [f32p, C.c_int64, f32p, C.c_int64]
     lib.oracle_resample_rational.argtypes = [f32p, C.c_int64, f32p, C.c_int64, C.c_int, C.c_int]
     lib.oracle_r8b_default_lowpass.argtypes = [C.c_double, C.c_double, f64p, C.c_int]
+    ip = C.POINTER(C.c_int)
+    lib.oracle_resample_two_stage_shape.argtypes = [C.c_double, C.c_double, ip, C.POINTER(C.c_double), ip, ip, ip]
+    lib.oracle_r8b_frac_bank.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int]
+    lib.oracle_resample_two_stage.argtypes = [f32p, C.c_int64, f32p, C.c_int64, C.c_double, C.c_double]
     i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
     lib.oracle_interpolate.restype = C.c_float
     lib.oracle_interpolate.argtypes = [C.c_int, C.c_float]
@@ -474,6 +478,33 @@ def resample_rational(audio, src_rate, dst_rate, up, down):
     out = np.empty((ch, n_out), np.float32)
     rc = lib.oracle_resample_rational(audio.reshape(-1), ch * n, out.reshape(-1), ch * n_out, up, down)
     assert rc == 0
+    return out
+
+
+def two_stage_shape(src_rate, dst_rate):
+    """None, or what CDSPResampler( src, dst ) builds when it is one block convolver + one whole-stepping interpolator"""
+    up, third, ins, outs, nf = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_double()
+    if not lib.oracle_resample_two_stage_shape(src_rate, dst_rate, C.byref(up), C.byref(nf), C.byref(third), C.byref(ins), C.byref(outs)):
+        return None
+    return dict(up=up.value, norm_freq=nf.value, third=bool(third.value), in_step=ins.value, out_step=outs.value)
+
+
+def frac_bank(fracs, third=False):
+    """the whole-stepping bank of fractional-delay filters: [fracs][flt_len] fp64"""
+    flt_len = lib.oracle_r8b_frac_bank(fracs, int(third), None, 0)
+    rows = np.zeros((fracs, flt_len))
+    lib.oracle_r8b_frac_bank(fracs, int(third), rows.ctypes.data, rows.size)
+    return rows
+
+
+def resample_two_stage(audio, src_rate, dst_rate):
+    """Audio::resample for a block convolver + whole-stepping interpolator ratio (44.1 <-> 48 kHz ...): [ch][n] -> [ch][n_out]"""
+    audio = np.ascontiguousarray(audio, np.float32)
+    ch, n = audio.shape
+    n_out = int(lib.oracle_resample_out_frames(n, src_rate, dst_rate))
+    out = np.empty((ch, n_out), np.float32)
+    rc = lib.oracle_resample_two_stage(audio.reshape(-1), ch * n, out.reshape(-1), ch * n_out, float(src_rate), float(dst_rate))
+    assert rc == 0, "not a two-stage ratio"
     return out
 
 

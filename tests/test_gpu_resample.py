@@ -42,12 +42,52 @@ def test_resample_single_step_ratios(fa, src, dst, up, down):
         assert (d.max() if d.size else 0.0) <= 2e-7 and (same >= 0.999 if d.size else True)
 
 
+TWO_STAGE = [(44100.0, 48000.0), (48000.0, 44100.0), (96000.0, 44100.0), (22050.0, 48000.0), (44100.0, 96000.0), (44100.0, 32000.0),
+             (32000.0, 44100.0), (44100.0, 12000.0), (11025.0, 8000.0)]
+
+
+@pytest.mark.parametrize("src,dst", TWO_STAGE)
+def test_resample_two_stage_ratios(fa, src, dst):
+    """44.1 <-> 48 kHz and the other block convolver + whole-stepping interpolator ratios (k_resample_rational<double> + k_frac_whole)
+    against the restatement, itself bit-identical to the real r8brain on these rates (test_oracle_resample.py): ragged lengths,
+    several channels (one stream: the ringing crosses channel boundaries), inputs shorter than either filter"""
+    assert O.two_stage_shape(src, dst) is not None
+    for ch, n in ((2, 30001), (3, 777), (1, 50)):
+        x = O.noise(ch, n, seed=n + int(dst))
+        ref = O.resample_two_stage(x, src, dst)
+        got = fa.resample(x, src, dst)
+        assert got.shape == ref.shape
+        d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+        same = np.mean(got.view(np.uint32) == ref.view(np.uint32))
+        print("\n[resample %g->%g %dx%d] max diff %.2e  bit-identical %.5f" % (src, dst, ch, n, d.max() if d.size else 0.0, same if d.size else 1.0))
+        assert (d.max() if d.size else 0.0) <= 1.2e-7 and (same >= 0.999 if d.size else True)
+
+
+def test_resample_two_stage_long(fa):
+    """a minute of 44.1 kHz stereo to 48 kHz: the sine comes out a sine (size-independent property; the oracle is not run at this size)"""
+    sr, n = 44100.0, 44100 * 60
+    t = np.arange(n, dtype=np.float64)
+    x = np.stack([0.5 * np.sin(2 * np.pi * 1000.0 * t / sr), 0.25 * np.sin(2 * np.pi * 15000.0 * t / sr)]).astype(np.float32)
+    y = fa.resample(x, sr, 48000.0)
+    assert y.shape == (2, int(O.lib.oracle_resample_out_frames(n, sr, 48000.0)))
+    # Audio::resample scales the frame count by the float ratio and walks the buffer as ONE stream: channel 1 starts where channel 0's
+    # n*48000/44100 samples end, a fraction of a sample away from y.shape[1]
+    u = np.arange(y.shape[1], dtype=np.float64)
+    mid = slice(4000, y.shape[1] - 4000)
+    assert np.abs(y[0, mid] - 0.5 * np.sin(2 * np.pi * 1000.0 * u[mid] / 48000.0)).max() <= 2e-6
+    exact = n * 48000.0 / 44100.0
+    shift = y.shape[1] - exact                        # channel 1 is read `shift` output samples late
+    assert np.abs(y[1, mid] - 0.25 * np.sin(2 * np.pi * 15000.0 * (u[mid] + shift) / 48000.0)).max() <= 2e-6
+
+
 def test_unsupported_ratio(fa):
+    """ratios r8brain serves through half-band stages or the spline-interpolated bank are refused, not approximated"""
     import flan_amd
     x = O.noise(1, 1000, seed=1)
-    with pytest.raises(flan_amd.FlanHipError) as e:
-        fa.resample(x, 44100.0, 48000.0)
-    assert e.value.code == flan_amd.ERR_UNSUPPORTED
+    for src, dst in ((8000.0, 44100.0), (96000.0, 16000.0), (44100.0, 22000.0), (44100.0, 48001.0)):
+        with pytest.raises(flan_amd.FlanHipError) as e:
+            fa.resample(x, src, dst)
+        assert e.value.code == flan_amd.ERR_UNSUPPORTED
 
 
 def test_config5_small(fa):
@@ -81,11 +121,11 @@ def test_resample_fixture(fa):
 
 
 @pytest.mark.parametrize("tag", ["c5_stereo_0p1s", "c5_mono_ragged", "c5_stereo_0p25s", "c5_three_short", "up_32_48", "down_144_48", "down_72_48",
-                                 "up_48_96", "up_16_48", "down_64_48"])
+                                 "up_48_96", "up_16_48", "down_64_48", "ms_441_48", "ms_48_441"])
 def test_resample_against_the_real_r8brain(fa, tag):
     """the HIP resampler against vectors the reference's vendored r8brain produced (tests/golden/ref_made/r8brain.npz, made by
-    make_ref_made.py from oracle/_ref/libr8bref.so): config 5's 96 -> 48 kHz incl. the 2-channel cross-channel bleed, and every other
-    single-step ratio.  >= 99.9 % of the samples bit-identical, the rest within one fp32 ulp at unit scale."""
+    make_ref_made.py from oracle/_ref/libr8bref.so): config 5's 96 -> 48 kHz incl. the 2-channel cross-channel bleed, every other
+    single-step ratio, and 44.1 <-> 48 kHz (block convolver + fractional interpolator).  >= 99.9 % of the samples bit-identical, the rest within one fp32 ulp at unit scale."""
     import os
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_made", "r8brain.npz"))
     x, y = g[tag + "_x"], g[tag + "_y"]

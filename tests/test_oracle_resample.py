@@ -77,6 +77,41 @@ def test_rational_form_contains_the_2to1_restatement():
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+TWO_STAGE = [(44100.0, 48000.0), (48000.0, 44100.0), (96000.0, 44100.0), (22050.0, 48000.0), (44100.0, 96000.0), (44100.0, 32000.0),
+             (32000.0, 44100.0), (44100.0, 12000.0), (48000.0, 22050.0), (11025.0, 8000.0)]
+
+
+@pytest.mark.parametrize("src,dst", TWO_STAGE)
+def test_two_stage_ratios_match_r8brain(src, dst):
+    """the ratios CDSPResampler serves with one block convolver and one whole-stepping CDSPFracInterpolator (CDSPResampler.h:214-316,
+    :319-378 without half-band stages): 2x zero-stuffing low-pass (or a low-pass in place when src >= 2 dst), then the bank of OutStep
+    fractional-delay filters (third-band parameters for 44100 -> 12000)"""
+    assert O.two_stage_shape(src, dst) is not None
+    rng = np.random.default_rng(int(src + dst))
+    for ch, n in ((2, 7001), (1, 300), (3, 20)):
+        x = rng.uniform(-1, 1, (ch, n)).astype(np.float32)
+        ours = O.resample_two_stage(x, src, dst)
+        theirs = ref_resample(x, src, dst)
+        assert ours.shape == theirs.shape
+        d = np.abs(ours.astype(np.float64) - theirs.astype(np.float64))
+        same = np.mean(ours.view(np.uint32) == theirs.view(np.uint32))
+        print("\n[resample %g->%g %dx%d] max diff %.2e  bit-identical %.5f" % (src, dst, ch, n, d.max(), same))
+        assert d.max() <= 1.2e-7 and same >= 0.999
+
+
+def test_two_stage_shapes():
+    assert O.two_stage_shape(44100.0, 48000.0) == dict(up=2, norm_freq=0.5, third=False, in_step=147, out_step=80)
+    assert O.two_stage_shape(48000.0, 44100.0) == dict(up=2, norm_freq=0.459375, third=False, in_step=320, out_step=147)
+    assert O.two_stage_shape(44100.0, 12000.0)["third"] is True and O.two_stage_shape(96000.0, 44100.0)["up"] == 1
+    for src, dst in ((96000.0, 48000.0), (32000.0, 48000.0), (48000.0, 192000.0), (8000.0, 44100.0), (96000.0, 16000.0), (44100.0, 22000.0),
+                     (44100.0, 48001.0), (48000.0, 48000.0)):
+        assert O.two_stage_shape(src, dst) is None, (src, dst)       # single step / half-band stages / no whole stepping / same rate
+    bank = O.frac_bank(80)
+    assert bank.shape == (80, 28) and np.allclose(bank.sum(1), 1.0, rtol=0, atol=1e-14)
+    assert bank[0, 13] == 1.0 and np.abs(np.delete(bank[0], 13)).max() < 1e-15      # row 0 is the unit delay: y passes through
+    assert O.frac_bank(40, third=True).shape == (40, 22)
+
+
 def test_filter_lengths_of_the_other_cutoffs():
     taps = np.zeros(8000)
     assert O.lib.oracle_r8b_default_lowpass(1.0 / 3.0, 1.0, taps, 8000) == 2431     # fl2 = 1215

@@ -92,6 +92,20 @@ def test_resample_restatement_against_real_r8brain_vectors(tag):
     assert same >= 0.999 and worst <= 1.2e-7            # one fp32 ulp at unit scale (the fp64 sums differ in the 16th digit only)
 
 
+@pytest.mark.parametrize("tag", ["ms_441_48", "ms_48_441"])
+def test_two_stage_restatement_against_real_r8brain_vectors(tag):
+    """44.1 <-> 48 kHz (block convolver + whole-stepping CDSPFracInterpolator): the restatement against the vendored r8brain's output"""
+    g = np.load(os.path.join(G, "r8brain.npz"))
+    x, y = g[tag + "_x"], g[tag + "_y"]
+    src, dst = (float(v) for v in g[tag + "_rates"])
+    got = O.resample_two_stage(x, src, dst)
+    assert got.shape == y.shape
+    same = np.mean(got.view(np.uint32) == y.view(np.uint32))
+    worst = np.abs(got.astype(np.float64) - y.astype(np.float64)).max()
+    print("\n[%s] bit-identical %.5f  worst %.2e" % (tag, same, worst))
+    assert same >= 0.999 and worst <= 1.2e-7
+
+
 def test_flan_file_written_by_the_reference_loads_here(tmp_path):
     """a .flan image produced by the reference's own PVBuffer::save (Bytes.cpp writeRIFF): our load() gives what the reference's load()
     gave, and our save() of that data reproduces the reference's bytes (host classes: flan_amd/host/PVBuffer.cpp through c_hooks.cpp)"""
