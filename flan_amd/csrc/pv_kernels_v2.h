@@ -585,12 +585,11 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 		// no scan kernel ran: `carry` still holds the chains' own sums, group_sums the totals of every group of 8 chains.  The running phase
 		// on entry to this chain = the groups before this one, then the chains of this group before this one, added and folded in order
 		// (phase_vocoder.cpp:57-59 modulo pi2: the same prefix k_phase_scan2 forms, associated group-wise).
-		// x + y folded like phase_vocoder.cpp:59.  Two folded sums add up to at most 2 pi2, where fmod( r, pi2 ) is the exact difference
-		// r - pi2 (Sterbenz): the short form is fold_phase_fast's own result there; anything else (negative, large, NaN) takes the long one
+		// x + y folded like phase_vocoder.cpp:59: the branch-free fold of the frame loop (pv_math.h) wherever it is exact, i.e. always but
+		// for sums beyond 3e9 rad or NaN, which take the general routine
 		auto fold = []( double r )
 			{
-			if( r >= 0.0 && r <= 2.0 * FLANHIP_PI2_D ) return r > FLANHIP_PI2_D ? r - FLANHIP_PI2_D : r;
-			return ( __builtin_fabs( r ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( r ) : fold_phase_any( r );
+			return ( __builtin_fabs( r ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_loop( r ) : fold_phase_any( r );
 			};
 		// One thread per bin, its two or three bins side by side (independent dependency chains): first the groups before this one, then
 		// along the chains of this group, leaving every wavefront's carries in that wavefront's own transform buffer (1025 doubles of its
@@ -693,8 +692,8 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 				#pragma unroll
 				for( int i = 0; i < 2; ++i )
 					{
-					phk[q0 + i] = fold_phase_fast( phk[q0 + i] );                  // phase_vocoder.cpp:59
-					phm[q0 + i] = fold_phase_fast( phm[q0 + i] );
+					phk[q0 + i] = fold_phase_loop( phk[q0 + i] );                  // phase_vocoder.cpp:59
+					phm[q0 + i] = fold_phase_loop( phm[q0 + i] );
 					th[i] = float( phk[q0 + i] ); th[2 + i] = float( phm[q0 + i] );
 					m4[i] = mfk[q0 + i].x; m4[2 + i] = mfm[q0 + i].x;
 					}
@@ -705,7 +704,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 				for( int i = 0; i < 2; ++i ) { xk[q0 + i] = cf{ xr[i], xi[i] }; xm[q0 + i] = cf{ xr[2 + i], xi[2 + i] }; }
 				__builtin_amdgcn_sched_barrier( 0 );                            // four bins at a time: keeps the temporaries of 16 bins from overlapping
 				}
-			phx = fold_phase_fast( phx );
+			phx = fold_phase_loop( phx );
 			float sn, cs;
 			sincos_fast( float( phx ), sn, cs );
 			xx = mk( mfx.x * cs, mfx.x * sn );

@@ -8,8 +8,6 @@ KIND=${1:-stamps}
 DEF=-DFLANHIP_STAMPS
 [ "$KIND" = ablations ] && DEF=-DFLANHIP_ABLATIONS
 [ "$KIND" = nopk ] && DEF="-Xclang -target-feature -Xclang -packed-fp32-ops"
-[ "$KIND" = twearly ] && DEF="-DFLANHIP_TW_EARLY"
-[ "$KIND" = prio ] && DEF="-DFLANHIP_PRIO"
 [ "$KIND" = maxilp ] && DEF="-mllvm -amdgpu-sched-strategy=max-ilp"
 [ "$KIND" = maxmem ] && DEF="-mllvm -amdgpu-sched-strategy=max-memory-clause"
 [ "$KIND" = iterilp ] && DEF="-mllvm -amdgpu-sched-strategy=iterative-ilp"
