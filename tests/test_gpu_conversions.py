@@ -5,6 +5,11 @@ Tolerances (BASELINE north_star: <= 1e-5 RMS vs the reference, stage-wise -- SUR
                 (the reference's own f flips by one fp32 step in ~0.8 % of bins when only its FFT backend changes)
   P2 synthesis: identical PV in -> RMS(audio diff) <= 1e-5 of unit scale (typically ~1e-7)
   P3 composite: round trip on the 5 s sine (config 1) <= 1e-5 RMS
+  NOT met, and said so: the composite on LONG NOISE (config 2).  north_star's 1e-5 holds stage-wise there (P1, P2) but the round trip
+  of 60 s of noise differs from the oracle's by 9.1e-5 RMS (10 s: ~3e-5): ~0.9 % of the bins get an f one fp32 step away from the
+  oracle's under ANY change of FFT arithmetic, and synthesis integrates f for the whole signal.  The reference itself moves by 8.9e-5
+  when only its FFT backend is swapped (SURVEY 7).  Those tests assert the measured floor with head-room (<= 2e-4) and print the value;
+  they do not claim the 1e-5.
 """
 import numpy as np
 import pytest
@@ -124,7 +129,8 @@ def test_roundtrip_config1(fa):
 
 
 def test_roundtrip_noise_composite(fa):
-    """60 s noise composite is reported against the reference's own 8.9e-5 self-noise floor; 10 s here."""
+    """The composite on noise does NOT meet north_star's 1e-5 (see the module docstring): 10 s here, measured ~3e-5, asserted against
+    the documented floor with head-room.  (60 s: 9.1e-5, tests/test_gpu_full_size.py; the reference's own FFT-swap self-noise is 8.9e-5.)"""
     x = O.noise(1, 480000, seed=99)
     sr = 48000.0
     pv_r = O.analyze(x, sr, 2048, 512, 2048)
@@ -133,7 +139,8 @@ def test_roundtrip_noise_composite(fa):
     out_g, _ = fa.synthesize(pv_g, sr, sr / 512, 2048)
     rms = float(np.sqrt(np.mean((out_g.astype(np.float64) - out_r.astype(np.float64)) ** 2)))
     print("\n[P3 noise 10 s] composite rms diff=%.3e (reference FFT-swap self-noise: 2.6e-5 @5 s, 8.9e-5 @60 s)" % rms)
-    assert rms <= 2e-4
+    assert rms <= 2e-4            # the documented exception, not the 1e-5 tolerance
+    assert rms > 1e-6             # if this ever drops to P2's level, the exception above is out of date: tighten it
 
 
 def test_nan_flag(fa):

@@ -145,7 +145,10 @@ def test_repeated_runs_are_bit_identical():
 
 def test_config2_full_size_parity_against_the_oracle():
     """BASELINE config 2 in full (stereo 60 s 48 kHz white noise, convert_to_PV(2048,512,2048) -> convert_to_audio): the oracle runs
-    the whole thing in a few seconds, so P1 / P2 / P3 are checked at the real size, not only on the head"""
+    the whole thing in a few seconds, so P1 / P2 / P3 are checked at the real size, not only on the head.
+    P1 and P2 meet north_star's 1e-5.  P3 (the composite) does NOT on this input: 9.1e-5 RMS measured, asserted as a documented floor
+    (<= 2e-4) -- ~0.9 % of the bins carry an f one fp32 step from the oracle's and 60 s of synthesis integrates it; the reference moves
+    by 8.9e-5 itself when only its FFT backend changes.  Config 1 (5 s sine) does meet 1e-5 as a composite (8e-7)."""
     import flan_amd as fa
     x = O.noise(2, 60 * 48000, seed=1234)
     pv_ref = O.analyze(x, SR, W, HOP, DFT)
@@ -167,7 +170,8 @@ def test_config2_full_size_parity_against_the_oracle():
     assert flag == 0
     assert rel_m <= 1e-5 and wrms_f <= 2e-3 and same_f >= 0.98
     assert p2 <= 1e-5
-    assert p3 <= 2e-4           # 60 s of noise: the reference's own FFT-backend self-noise is 8.9e-5 here
+    assert p3 <= 2e-4           # the documented exception to the 1e-5 (measured 9.1e-5; reference FFT-swap self-noise 8.9e-5)
+    assert p3 > 1e-5            # should this composite ever meet the tolerance, drop the exception instead of keeping a loose bound
 
 
 def test_config3_full_length_parity_against_the_oracle():
