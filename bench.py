@@ -113,19 +113,18 @@ def cpu_baseline(channels, seconds, threads, window, hop, dft):
 
 
 def cpu_fft_share(frames, dft, per_frame_seconds):
-    """How much of the oracle's time is its own FFT (fp64 radix-2, not FFTW): r2c + c2r per frame, timed alone on a sample."""
+    """How much of the oracle's time is its own FFT (fp64 radix-2, not FFTW): r2c + c2r per frame with one plan, timed alone."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as O
+    import ctypes
     lib = O._load()
-    x = np.random.default_rng(1).uniform(-1, 1, dft).astype(np.float32)
-    X = np.zeros((dft // 2 + 1) * 2, np.float32)
-    y = np.zeros(dft, np.float32)
-    reps = max(200, min(4000, frames // 10))
+    lib.oracle_fft_pairs.restype = ctypes.c_double
+    lib.oracle_fft_pairs.argtypes = [ctypes.c_int, ctypes.c_int]
+    reps = max(2000, min(20000, frames // 4))
+    lib.oracle_fft_pairs(dft, 200)                    # plan construction and first touch outside the clock
     t0 = time.perf_counter()
-    for _ in range(reps):
-        lib.oracle_r2c(x, dft, X)
-        lib.oracle_c2r(X, dft, y)
+    lib.oracle_fft_pairs(dft, reps)                   # one plan, reps x (r2c + c2r): what a frame of the round trip pays
     per = (time.perf_counter() - t0) / reps
     return round(per / per_frame_seconds, 3), round(per * 1e6, 2)
 

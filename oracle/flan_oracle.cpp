@@ -189,6 +189,26 @@ int oracle_c2r( const float * X, int n, float * x )
 	return 0;
 	}
 
+// `reps` forward + inverse transforms of one buffer with ONE plan, as the frame loops below use it (bench.py: the FFT's share of the
+// checker's time -- this FFT is not FFTW).  Returns a value that depends on the result so the loop cannot be dropped.
+double oracle_fft_pairs( int n, int reps )
+	{
+	if( !is_pow2( n ) ) return -1.0;
+	FFTPlan p( n ); std::vector<std::complex<double>> tmp( n );
+	std::vector<float> x( n ); std::vector<std::complex<float>> X( n / 2 + 1 );
+	for( int i = 0; i < n; ++i ) x[i] = float( ( i * 2654435761u ) >> 8 ) * ( 1.0f / 16777216.0f ) - 0.5f;
+	double acc = 0.0;
+	for( int r = 0; r < reps; ++r )
+		{
+		r2c( p, x.data(), X.data(), tmp );
+		c2r( p, X.data(), x.data(), tmp );
+		const float g = 1.0f / float( n );
+		for( int i = 0; i < n; ++i ) x[i] *= g;
+		acc += x[r % n];
+		}
+	return acc;
+	}
+
 // AudioPV.cpp:17  numHops = ceil( num_frames / hop ) + 1 with INTEGER division
 int64_t oracle_num_pv_frames( int64_t num_audio_frames, int hop ) { return num_audio_frames / hop + 1; }
 
