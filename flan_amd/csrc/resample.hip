@@ -120,14 +120,51 @@ static bool whole_stepping( double src, double dst, int & in_step, int & out_ste
 	return i0 == in_step && o0 == out_step && out_step <= 1500;
 	}
 
-struct TwoStageShape { int up = 0; double norm_freq = 0, gain = 0; bool third = false; int in_step = 0, out_step = 0; };
+// The half-band kernels getHBFilter / getHBFilterThird select at ReqAtten = 206.91 dB, by SteepIndex (CDSPHBUpsampler.h:43-215, :296-436):
+// half-band 13 / 7 / 5 / 4 taps, third-band 9 / 6 / 5.  Deeper chains (32x ...) are not served.
+struct HbTaps { double c[13]; int n; };
+static bool hb_kernel( int steep, bool third, HbTaps & k )
+	{
+	static const double h0[13] = { 6.2816416238782957e-001, -1.8809076918442266e-001, 9.0918539368474965e-002, -4.6765502172995604e-002, 2.3287520069933797e-002,
+		-1.0760626940880943e-002, 4.4853921118213676e-003, -1.6438774496992904e-003, 5.1441308429384374e-004, -1.3211724349740752e-004, 2.6191316362108199e-005,
+		-3.5802424384280469e-006, 2.5491272423372411e-007 };
+	static const double h1[7] = { 6.1610372237019151e-001, -1.5767891821295410e-001, 5.5089690570484962e-002, -1.6895755290596615e-002, 3.9416641999499014e-003,
+		-6.0603620400878633e-004, 4.5632598748568398e-005 };
+	static const double h2[5] = { 6.0626808278478261e-001, -1.3588224019070938e-001, 3.5544305138258458e-002, -6.5127022013993230e-003, 5.8255449020627736e-004 };
+	static const double h3[4] = { 5.9835028661892165e-001, -1.1999986095168852e-001, 2.4132530901858028e-002, -2.4829565783680927e-003 };
+	static const double t0[9] = { 6.2163188987470752e-001, -1.7108115412330563e-001, 6.9588371105224839e-002, -2.7339625869282957e-002, 9.2954473703765472e-003,
+		-2.5537181861669997e-003, 5.2572296540671394e-004, -7.1813366796731157e-005, 4.8802392556669750e-006 };
+	static const double t1[6] = { 6.1161456377889145e-001, -1.4743902036519768e-001, 4.5344160828746795e-002, -1.1207372108402218e-002, 1.8328498006058664e-003,
+		-1.4518194076022933e-004 };
+	static const double t2[5] = { 6.0590922849004858e-001, -1.3515953371903033e-001, 3.5020856634677522e-002, -6.3256195330255094e-003, 5.5506812768978109e-004 };
+	const double * src = nullptr; int n = 0;
+	if( third ) { if( steep == 0 ) { src = t0; n = 9; } else if( steep == 1 ) { src = t1; n = 6; } else if( steep == 2 ) { src = t2; n = 5; } }
+	else { if( steep == 0 ) { src = h0; n = 13; } else if( steep == 1 ) { src = h1; n = 7; } else if( steep == 2 ) { src = h2; n = 5; } else if( steep == 3 ) { src = h3; n = 4; } }
+	if( !src ) return false;
+	k.n = n;
+	for( int i = 0; i < 13; ++i ) k.c[i] = i < n ? src[i] : 0.0;
+	return true;
+	}
 
-// Does CDSPResampler( src, dst ) come out as { block convolver, whole-stepping interpolator }?  Call after rational_ratio() said no.
-static bool two_stage_shape( double src, double dst, TwoStageShape & ts )
+// What CDSPResampler( src, dst ) builds, for the chains served here:
+//   [ hb_down half-band downsamplers ] -> block convolver ( up, down, low-pass at norm_freq with DC gain `gain` ) -> [ hb_up half-band
+//   upsamplers ] -> [ whole-stepping fractional interpolator ]
+struct ChainShape { int hb_down = 0, up = 1, down = 1; double norm_freq = 0.5, gain = 1.0; int hb_up = 0; bool third = false, interp = false; int in_step = 0, out_step = 0; };
+
+static bool chain_shape( double src, double dst, ChainShape & ch )
 	{
 	if( src == dst ) return false;
-	for( int i = 2; i <= 3; ++i )                                                 // CDSPResampler.h:174-212: 2^k / 3*2^k upsampling has half-band stages
-		for( int c = 1; src * ( i << c ) <= dst; ++c ) if( src * ( i << c ) == dst ) return false;
+	HbTaps probe;
+	static const int common[5][2] = { { 1, 2 }, { 1, 3 }, { 2, 3 }, { 3, 2 }, { 3, 4 } };          // CDSPResampler.h:142-170
+	for( const auto & c : common )
+		if( src * c[0] == dst * c[1] ) { ch.up = c[0]; ch.down = c[1]; ch.norm_freq = 1.0 / std::max( c[0], c[1] ); ch.gain = c[0]; return true; }
+	for( int i = 2; i <= 3; ++i )                                                 // :174-212: dst = i 2^c src
+		for( int c = 0; src * ( i << c ) <= dst; ++c )
+			if( src * ( i << c ) == dst )
+				{
+				ch.up = i; ch.norm_freq = 1.0 / i; ch.gain = i; ch.hb_up = c; ch.third = ( i == 3 );
+				return c == 0 || hb_kernel( c - 1, ch.third, probe );
+				}
 	if( dst * 2 > src )                                                           // :214-316
 		{
 		const double thresh = src * 1.01;
@@ -135,13 +172,24 @@ static bool two_stage_shape( double src, double dst, TwoStageShape & ts )
 		while( !( dst < thresh * ( div * 2 ) ) ) { div *= 2; ++c; }                // :229-244
 		int t1, t2;
 		if( c == 1 && whole_stepping( src * 2.0, dst, t1, t2 ) ) c = 0;            // :266-276
-		if( c > 0 ) return false;
-		ts.up = 2; ts.norm_freq = dst > src ? 0.5 : 0.5 * dst / src; ts.gain = 2.0; ts.third = false;
-		return whole_stepping( src * 2.0, dst, ts.in_step, ts.out_step );
+		if( c > 0 ) return false;                                                  // intermediate interpolation with its own low-pass design: not served
+		ch.up = 2; ch.norm_freq = dst > src ? 0.5 : 0.5 * dst / src; ch.gain = 2.0; ch.interp = true;
+		return whole_stepping( src * 2.0, dst, ch.in_step, ch.out_step );
 		}
-	if( dst * 4.0 <= src ) return false;                                          // :321-331: half-band downsamplers
-	ts.up = 1; ts.norm_freq = dst / src; ts.gain = 1.0; ts.third = ts.norm_freq * 3.0 <= 1.0;   // :351-356, :368-376
-	return whole_stepping( src, dst, ts.in_step, ts.out_step );
+	double check = dst * 4.0;                                                     // :319-331
+	int c = 0;
+	while( check <= src ) { ++c; check *= 2.0; ch.gain *= 0.5; }
+	const int div = 1 << c;
+	ch.hb_down = c;
+	int downf = 0;
+	for( int d = 2; d <= 3; ++d ) if( dst * div * d == src ) { downf = d; break; }  // :340-349
+	if( downf ) { ch.down = downf; ch.norm_freq = 1.0 / downf; ch.third = ( downf == 3 ); }
+	else                                                                          // :351-356, :372-376
+		{
+		ch.norm_freq = dst * div / src; ch.third = ch.norm_freq * 3.0 <= 1.0; ch.interp = true;
+		if( !whole_stepping( src, dst * div, ch.in_step, ch.out_step ) ) return false;
+		}
+	return c == 0 || hb_kernel( c - 1, ch.third, probe );
 	}
 
 // CDSPFracDelayFilterBank( OutStep, 1, 2, 206.91, third ) (CDSPFracInterpolator.h:64-121, window parameters :289-348 -- the rows that
@@ -181,8 +229,8 @@ static void frac_delay_bank( int fracs, bool third, std::vector<double> & bank, 
 		}
 	}
 
-struct TwoStagePlan { double * d_h = nullptr; double * d_bank = nullptr; int fl2 = 0, flt_len = 0; TwoStageShape shape; };
-static std::map<std::tuple<int, double, double>, TwoStagePlan> g_ts_plans;   // per (device, src, dst)
+struct ChainPlan { double * d_h = nullptr; double * d_bank = nullptr; int fl2 = 0, flt_len = 0; ChainShape shape; };
+static std::map<std::tuple<int, double, double>, ChainPlan> g_chain_plans;   // per (device, src, dst)
 
 // Device copies of the taps for one (up, down): h[0 .. 2 fl2] in natural order, and for the 2:1 kernel
 // d_he[q] = h[2 fl2 - 2 q] (q = 0 .. fl2), d_ho[q] = h[2 fl2 - 1 - 2 q] (q = 0 .. fl2 - 1): the taps in the order it walks them
@@ -302,8 +350,8 @@ __global__ __launch_bounds__( 64 * RS_WAVES ) void k_resample_2to1( const float 
 // One thread per output; a block of 256 outputs stages its input span (fp64) and the taps in LDS.
 constexpr int RSG_BLOCK = 256;
 __host__ __device__ inline int64_t rs_floor_div( int64_t a, int64_t b ) { return a >= 0 ? a / b : -( ( -a + b - 1 ) / b ); }
-template<typename OutT>   // float: the resampled audio; double: the band-limited stream a fractional interpolator reads next
-__global__ __launch_bounds__( RSG_BLOCK ) void k_resample_rational( const float * __restrict__ in, int64_t total_in, const double * __restrict__ taps, int fl2,
+template<typename InT, typename OutT>   // float: the audio; double: the fp64 stream between the stages of a chain
+__global__ __launch_bounds__( RSG_BLOCK ) void k_resample_rational( const InT * __restrict__ in, int64_t total_in, const double * __restrict__ taps, int fl2,
 	int up, int down, int span, OutT * __restrict__ out, int64_t total_out )
 	{
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -356,24 +404,55 @@ __global__ __launch_bounds__( FRAC_BLOCK ) void k_frac_whole( const double * __r
 	out[k] = float( acc );
 	}
 
-static int get_two_stage_plan( double src, double dst, const TwoStagePlan ** out )
+// CDSPHBDownsampler (CDSPHBDownsampler.h:95-260): out[j] = in[2j] + sum_t c[t] ( in[2j+2t+1] + in[2j-2t-1] ), in = 0 outside [0, n_in)
+constexpr int HB_BLOCK = 256;
+template<typename InT>
+__global__ __launch_bounds__( HB_BLOCK ) void k_hb_down( const InT * __restrict__ in, int64_t n_in, HbTaps taps, double * __restrict__ out, int64_t n_out )
+	{
+	const int64_t j = int64_t( blockIdx.x ) * HB_BLOCK + threadIdx.x;
+	if( j >= n_out ) return;
+	auto at = [&]( int64_t i ) { return ( i >= 0 && i < n_in ) ? double( in[i] ) : 0.0; };
+	double acc = at( 2 * j );
+	for( int t = 0; t < taps.n; ++t ) acc = __builtin_fma( taps.c[t], at( 2 * j + 2 * t + 1 ) + at( 2 * j - 2 * t - 1 ), acc );
+	out[j] = acc;
+	}
+
+// CDSPHBUpsampler (CDSPHBUpsampler.h:560-720): out[2j] = in[j], out[2j+1] = sum_t c[t] ( in[j+1+t] + in[j-t] )
+template<typename OutT>
+__global__ __launch_bounds__( HB_BLOCK ) void k_hb_up( const double * __restrict__ in, int64_t n_in, HbTaps taps, OutT * __restrict__ out, int64_t n_out )
+	{
+	const int64_t o = int64_t( blockIdx.x ) * HB_BLOCK + threadIdx.x;
+	if( o >= n_out ) return;
+	auto at = [&]( int64_t i ) { return ( i >= 0 && i < n_in ) ? in[i] : 0.0; };
+	const int64_t j = o >> 1;
+	double acc;
+	if( ( o & 1 ) == 0 ) acc = at( j );
+	else
+		{
+		acc = taps.c[0] * ( at( j + 1 ) + at( j ) );
+		for( int t = 1; t < taps.n; ++t ) acc = __builtin_fma( taps.c[t], at( j + 1 + t ) + at( j - t ), acc );
+		}
+	out[o] = OutT( acc );
+	}
+
+static int get_chain_plan( double src, double dst, const ChainPlan ** out )
 	{
 	int device = 0;
 	FLANHIP_CHECK( hipGetDevice( &device ) );
 	std::lock_guard<std::mutex> lock( g_rs_mutex );
 	const auto key = std::make_tuple( device, src, dst );
-	auto it = g_ts_plans.find( key );
-	if( it != g_ts_plans.end() ) { *out = &it->second; return FLANHIP_OK; }
-	TwoStagePlan p;
-	FLANHIP_REQUIRE( two_stage_shape( src, dst, p.shape ), FLANHIP_ERR_UNSUPPORTED, "not a block convolver + whole-stepping interpolator ratio" );
+	auto it = g_chain_plans.find( key );
+	if( it != g_chain_plans.end() ) { *out = &it->second; return FLANHIP_OK; }
+	ChainPlan p;
+	FLANHIP_REQUIRE( chain_shape( src, dst, p.shape ), FLANHIP_ERR_UNSUPPORTED, "ratio not served" );
 	std::vector<double> h, bank;
 	FLANHIP_REQUIRE( design_default_lowpass( p.shape.norm_freq, p.shape.gain, h, p.fl2 ), FLANHIP_ERR_UNSUPPORTED, "low-pass design outside the restated range" );
-	frac_delay_bank( p.shape.out_step, p.shape.third, bank, p.flt_len );
-	FLANHIP_CHECK( hipMalloc( &p.d_h, sizeof( double ) * ( h.size() + bank.size() ) ) );
+	if( p.shape.interp ) frac_delay_bank( p.shape.out_step, p.shape.third, bank, p.flt_len );
+	FLANHIP_CHECK( hipMalloc( &p.d_h, sizeof( double ) * ( h.size() + bank.size() + 1 ) ) );
 	p.d_bank = p.d_h + h.size();
 	FLANHIP_CHECK( hipMemcpy( p.d_h, h.data(), sizeof( double ) * h.size(), hipMemcpyHostToDevice ) );
-	FLANHIP_CHECK( hipMemcpy( p.d_bank, bank.data(), sizeof( double ) * bank.size(), hipMemcpyHostToDevice ) );
-	*out = &g_ts_plans.emplace( key, p ).first->second;
+	if( !bank.empty() ) FLANHIP_CHECK( hipMemcpy( p.d_bank, bank.data(), sizeof( double ) * bank.size(), hipMemcpyHostToDevice ) );
+	*out = &g_chain_plans.emplace( key, p ).first->second;
 	return FLANHIP_OK;
 	}
 
@@ -383,26 +462,88 @@ static size_t rational_lds( int fl2, int up, int down, int & span )
 	return sizeof( double ) * ( size_t( 2 * fl2 + 2 ) + size_t( span ) );
 	}
 
-static int resample_two_stage_dev( const float * d_in, int64_t total_in, double src, double dst, float * d_out, int64_t total_out, hipStream_t s )
+template<typename InT, typename OutT>
+static int launch_rational( const InT * d_in, int64_t n_in, const ChainPlan & plan, OutT * d_out, int64_t n_out, hipStream_t s )
 	{
-	const TwoStagePlan * plan = nullptr;
-	if( int rc = get_two_stage_plan( src, dst, &plan ) ) return rc;
-	const TwoStageShape & ts = plan->shape;
-	// the stretch of y the last output reads
-	const int64_t ny = ( ( total_out - 1 ) * ts.in_step ) / ts.out_step - ( plan->flt_len / 2 - 1 ) + plan->flt_len;
 	int span = 0;
-	const size_t lds = rational_lds( plan->fl2, ts.up, 1, span );
+	const size_t lds = rational_lds( plan.fl2, plan.shape.up, plan.shape.down, span );
 	FLANHIP_REQUIRE( lds <= 160 * 1024, FLANHIP_ERR_UNSUPPORTED, "filter too long for the LDS staging" );
+	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( k_resample_rational<InT, OutT> ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+	hipLaunchKernelGGL( ( k_resample_rational<InT, OutT> ), dim3( (unsigned) ( ( n_out + RSG_BLOCK - 1 ) / RSG_BLOCK ) ), dim3( RSG_BLOCK ), lds, s,
+		d_in, n_in, plan.d_h, plan.fl2, plan.shape.up, plan.shape.down, span, d_out, n_out );
+	return FLANHIP_OK;
+	}
+
+// A chain with more than the block convolver in it: every stage on the whole stream in fp64 (r8brain's intermediate type), each for exactly
+// as many samples as the next one reads (zeros before the start and past the end, like the zeros oneshot() feeds); the last stage rounds to
+// float.  Intermediate streams live in the stream's memory pool.
+static int resample_chain_dev( const float * d_in, int64_t total_in, double src, double dst, float * d_out, int64_t total_out, hipStream_t s )
+	{
+	const ChainPlan * plan = nullptr;
+	if( int rc = get_chain_plan( src, dst, &plan ) ) return rc;
+	const ChainShape & ch = plan->shape;
+	HbTaps down_taps[4], up_taps[4];
+	FLANHIP_REQUIRE( ch.hb_down <= 4 && ch.hb_up <= 4, FLANHIP_ERR_UNSUPPORTED, "half-band chain too deep" );
+	for( int i = 0; i < ch.hb_down; ++i ) FLANHIP_REQUIRE( hb_kernel( ch.hb_down - 1 - i, ch.third, down_taps[i] ), FLANHIP_ERR_UNSUPPORTED, "half-band chain too deep" );   // CDSPResampler.h:358-365
+	for( int i = 0; i < ch.hb_up; ++i ) FLANHIP_REQUIRE( hb_kernel( i, ch.third, up_taps[i] ), FLANHIP_ERR_UNSUPPORTED, "half-band chain too deep" );                       // :203-209
+	// samples each stage has to deliver (backwards from the output)
+	int64_t need_up[5];
+	need_up[ch.hb_up] = ch.interp ? ( ( total_out - 1 ) * ch.in_step ) / ch.out_step - ( plan->flt_len / 2 - 1 ) + plan->flt_len : total_out;
+	for( int i = ch.hb_up - 1; i >= 0; --i ) need_up[i] = ( need_up[i + 1] - 1 ) / 2 + up_taps[i].n + 1;
+	const int64_t need_conv = std::max<int64_t>( need_up[0], 1 );
 	retain_pool_memory();
-	double * d_y = nullptr;
-	FLANHIP_CHECK( hipMallocAsync( reinterpret_cast<void**>( &d_y ), sizeof( double ) * size_t( ny ), s ) );
-	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( k_resample_rational<double> ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
-	hipLaunchKernelGGL( k_resample_rational<double>, dim3( (unsigned) ( ( ny + RSG_BLOCK - 1 ) / RSG_BLOCK ) ), dim3( RSG_BLOCK ), lds, s,
-		d_in, total_in, plan->d_h, plan->fl2, ts.up, 1, span, d_y, ny );
-	hipLaunchKernelGGL( k_frac_whole, dim3( (unsigned) ( ( total_out + FRAC_BLOCK - 1 ) / FRAC_BLOCK ) ), dim3( FRAC_BLOCK ), 0, s,
-		d_y, ny, plan->d_bank, plan->flt_len, ts.in_step, ts.out_step, d_out, total_out );
+	std::vector<void*> temps;
+	auto temp = [&]( int64_t count, double ** out ) -> int
+		{
+		FLANHIP_CHECK( hipMallocAsync( reinterpret_cast<void**>( out ), sizeof( double ) * size_t( std::max<int64_t>( count, 1 ) ), s ) );
+		temps.push_back( *out );
+		return FLANHIP_OK;
+		};
+	int rc = FLANHIP_OK;
+	const double * cur = nullptr; int64_t cur_len = total_in;                     // cur == nullptr: the stream is still the float input
+	for( int i = 0; i < ch.hb_down && !rc; ++i )
+		{
+		const int64_t n_out = ( cur_len + 2 * down_taps[i].n + 1 ) / 2 + 1;       // up to the end of the filter's tail
+		double * nxt = nullptr;
+		if( ( rc = temp( n_out, &nxt ) ) ) break;
+		const dim3 grid( (unsigned) ( ( n_out + HB_BLOCK - 1 ) / HB_BLOCK ) );
+		if( cur ) hipLaunchKernelGGL( k_hb_down<double>, grid, dim3( HB_BLOCK ), 0, s, cur, cur_len, down_taps[i], nxt, n_out );
+		else hipLaunchKernelGGL( k_hb_down<float>, grid, dim3( HB_BLOCK ), 0, s, d_in, cur_len, down_taps[i], nxt, n_out );
+		cur = nxt; cur_len = n_out;
+		}
+	const bool conv_is_last = ch.hb_up == 0 && !ch.interp;
+	if( !rc )
+		{
+		if( conv_is_last ) rc = cur ? launch_rational<double, float>( cur, cur_len, *plan, d_out, total_out, s ) : launch_rational<float, float>( d_in, cur_len, *plan, d_out, total_out, s );
+		else
+			{
+			double * nxt = nullptr;
+			if( !( rc = temp( need_conv, &nxt ) ) )
+				{
+				rc = cur ? launch_rational<double, double>( cur, cur_len, *plan, nxt, need_conv, s ) : launch_rational<float, double>( d_in, cur_len, *plan, nxt, need_conv, s );
+				cur = nxt; cur_len = need_conv;
+				}
+			}
+		}
+	for( int i = 0; i < ch.hb_up && !rc; ++i )
+		{
+		const int64_t n_out = need_up[i + 1];
+		const dim3 grid( (unsigned) ( ( n_out + HB_BLOCK - 1 ) / HB_BLOCK ) );
+		if( i == ch.hb_up - 1 && !ch.interp ) hipLaunchKernelGGL( k_hb_up<float>, grid, dim3( HB_BLOCK ), 0, s, cur, cur_len, up_taps[i], d_out, n_out );
+		else
+			{
+			double * nxt = nullptr;
+			if( ( rc = temp( n_out, &nxt ) ) ) break;
+			hipLaunchKernelGGL( k_hb_up<double>, grid, dim3( HB_BLOCK ), 0, s, cur, cur_len, up_taps[i], nxt, n_out );
+			cur = nxt; cur_len = n_out;
+			}
+		}
+	if( !rc && ch.interp )
+		hipLaunchKernelGGL( k_frac_whole, dim3( (unsigned) ( ( total_out + FRAC_BLOCK - 1 ) / FRAC_BLOCK ) ), dim3( FRAC_BLOCK ), 0, s,
+			cur, cur_len, plan->d_bank, plan->flt_len, ch.in_step, ch.out_step, d_out, total_out );
 	const hipError_t launched = hipGetLastError();
-	FLANHIP_CHECK( hipFreeAsync( d_y, s ) );
+	for( void * t : temps ) (void) hipFreeAsync( t, s );
+	if( rc ) return rc;
 	FLANHIP_CHECK( launched );
 	return FLANHIP_OK;
 	}
@@ -412,8 +553,9 @@ static int resample_two_stage_dev( const float * d_in, int64_t total_in, double 
 using namespace flanhip;
 
 static const char * const k_unsupported_ratio =
-	"implemented: the single-step ratios (src:dst = 2:1, 3:1, 3:2, 2:3, 4:3, 1:2, 1:3) and block convolver + whole-stepping interpolator "
-	"ratios (44.1 <-> 48 kHz ...); this one needs r8brain's half-band stages or its spline-interpolated filter bank";
+	"implemented: the single-step ratios (src:dst = 2:1, 3:1, 3:2, 2:3, 4:3, 1:2, 1:3), block convolver + whole-stepping interpolator ratios "
+	"(44.1 <-> 48 kHz ...) and half-band chains (4x, 8x, 16x, 6x, 12x up; src >= 4 dst down); this one needs r8brain's intermediate "
+	"interpolation with its own low-pass design, its spline-interpolated filter bank or a deeper half-band chain";
 
 extern "C" {
 
@@ -428,13 +570,13 @@ int flanhip_resample_dev( const float * d_in, int64_t ch, int64_t n, float src_r
 	FLANHIP_REQUIRE( d_in && d_out && ch > 0 && n > 0 && src_rate > 0.0f && dst_rate > 0.0f, FLANHIP_ERR_INVALID_ARG, "bad arguments" );
 	int up = 0, down = 0;
 	const bool single = rational_ratio( double( src_rate ), double( dst_rate ), up, down );
-	TwoStageShape ts;
-	FLANHIP_REQUIRE( single || two_stage_shape( double( src_rate ), double( dst_rate ), ts ), FLANHIP_ERR_UNSUPPORTED, k_unsupported_ratio );
+	ChainShape shape;
+	FLANHIP_REQUIRE( single || chain_shape( double( src_rate ), double( dst_rate ), shape ), FLANHIP_ERR_UNSUPPORTED, k_unsupported_ratio );
 	if( int rc = require_device() ) return rc;
 	const int64_t n_out = flanhip_resample_out_frames( n, src_rate, dst_rate );
 	const int64_t total_in = ch * n, total_out = ch * n_out;
 	if( total_out <= 0 ) return FLANHIP_OK;
-	if( !single ) return resample_two_stage_dev( d_in, total_in, double( src_rate ), double( dst_rate ), d_out, total_out, (hipStream_t) stream );
+	if( !single ) return resample_chain_dev( d_in, total_in, double( src_rate ), double( dst_rate ), d_out, total_out, (hipStream_t) stream );
 	const ResamplePlan * plan = nullptr;
 	if( int rc = get_resample_plan( up, down, &plan ) ) return rc;
 	if( up == 1 && down == 2 && plan->fl2 >= 64 * ( RS_R - 1 ) )
@@ -449,8 +591,8 @@ int flanhip_resample_dev( const float * d_in, int64_t ch, int64_t n, float src_r
 		int span = 0;
 		const size_t lds = rational_lds( plan->fl2, up, down, span );
 		FLANHIP_REQUIRE( lds <= 160 * 1024, FLANHIP_ERR_UNSUPPORTED, "filter too long for the LDS staging" );
-		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( k_resample_rational<float> ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
-		hipLaunchKernelGGL( k_resample_rational<float>, dim3( (unsigned) ( ( total_out + RSG_BLOCK - 1 ) / RSG_BLOCK ) ), dim3( RSG_BLOCK ), lds, (hipStream_t) stream,
+		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( k_resample_rational<float, float> ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+		hipLaunchKernelGGL( ( k_resample_rational<float, float> ), dim3( (unsigned) ( ( total_out + RSG_BLOCK - 1 ) / RSG_BLOCK ) ), dim3( RSG_BLOCK ), lds, (hipStream_t) stream,
 			d_in, total_in, plan->d_h, plan->fl2, up, down, span, d_out, total_out );
 		}
 	FLANHIP_CHECK( hipGetLastError() );
@@ -460,8 +602,8 @@ int flanhip_resample_dev( const float * d_in, int64_t ch, int64_t n, float src_r
 int flanhip_resample( const float * in, int64_t ch, int64_t n, float src_rate, float dst_rate, float * out, volatile int * cancel )
 	{
 	FLANHIP_REQUIRE( in && out && ch > 0 && n > 0, FLANHIP_ERR_INVALID_ARG, "bad arguments" );
-	{ int up = 0, down = 0; TwoStageShape ts;
-	  FLANHIP_REQUIRE( rational_ratio( double( src_rate ), double( dst_rate ), up, down ) || two_stage_shape( double( src_rate ), double( dst_rate ), ts ),
+	{ int up = 0, down = 0; ChainShape shape;
+	  FLANHIP_REQUIRE( rational_ratio( double( src_rate ), double( dst_rate ), up, down ) || chain_shape( double( src_rate ), double( dst_rate ), shape ),
 		FLANHIP_ERR_UNSUPPORTED, k_unsupported_ratio ); }
 	if( int rc = require_device() ) return rc;
 	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;

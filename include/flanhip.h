@@ -335,9 +335,11 @@ int64_t flanhip_resample_out_frames(int64_t num_frames, float src_rate, float ds
  * kernel), 3:1, 3:2, 2:3, 4:3, 1:2, 1:3 -- latency consumed, zero-flushed tail; and the ratios it serves with one block convolver
  * followed by one whole-stepping CDSPFracInterpolator (CDSPResampler.h:214-316, :319-378 with no half-band stage;
  * CDSPFracInterpolator.h:573-602): 44.1 <-> 48 kHz, 96 -> 44.1, 22.05 -> 48, 44.1 -> 96, 44.1 <-> 32 kHz ... (the _dev form takes a
- * transient fp64 workspace of about 2 x the input from the stream's memory pool).  Ratios that need half-band up/downsampler chains
- * (dst >= 2.02 src off the 2^k / 3*2^k grid, src >= 4 dst) or the spline-interpolated filter bank (rates without whole stepping)
- * return FLANHIP_ERR_UNSUPPORTED. */
+ * transient fp64 workspace of about 2 x the input from the stream's memory pool); and its half-band chains -- dst = 4, 8, 16, 6, 12 x src
+ * (block convolver + CDSPHBUpsamplers, CDSPResampler.h:174-212) and src >= 4 dst (CDSPHBDownsamplers + block convolver [+ interpolator],
+ * :319-378; 192 -> 48, 96 -> 16, 192 -> 44.1 kHz ...), up to four half-band stages (three for the third-band kernels).  Ratios that need
+ * r8brain's intermediate interpolation with a low-pass of its own transition band (dst >= 2.02 src off the 2^k / 3*2^k grid), its
+ * spline-interpolated filter bank (rates without whole stepping) or a deeper half-band chain return FLANHIP_ERR_UNSUPPORTED. */
 int flanhip_resample(const float * in, int64_t num_channels, int64_t num_frames, float src_rate, float dst_rate,
                      float * out, volatile int * cancel);
 int flanhip_resample_dev(const float * d_in, int64_t num_channels, int64_t num_frames, float src_rate, float dst_rate,

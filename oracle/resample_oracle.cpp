@@ -288,6 +288,179 @@ extern "C" int oracle_resample_two_stage( const float * in, int64_t total_in, fl
 	return 0;
 	}
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Chains with half-band stages (r8brain/CDSPResampler.h:174-212: dst = 2^c * i * src, i = 2 or 3, c >= 1; :319-378 with c >= 1:
+// src >= 4 dst).  CDSPHBUpsampler (CDSPHBUpsampler.h:560-720): out[2j] = in[j], out[2j+1] = sum_t flt[t] ( in[j+1+t] + in[j-t] );
+// CDSPHBDownsampler (CDSPHBDownsampler.h:95-260): out[j] = in[2j] + sum_t flt[t] ( in[2j+2t+1] + in[2j-2t-1] ); both zero latency,
+// in = 0 before the stream starts.  The kernels are the ones getHBFilter / getHBFilterThird pick at ReqAtten = 206.91 dB
+// (CDSPHBUpsampler.h:43-215, :296-436), by SteepIndex; deeper chains than listed here (16x and more) are not restated.
+namespace {
+
+const double * hb_kernel( int steep, bool third, int & n )
+	{
+	static const double h0[13] = { 6.2816416238782957e-001, -1.8809076918442266e-001, 9.0918539368474965e-002, -4.6765502172995604e-002,      // HBKernel_13, 215.1364 dB
+		2.3287520069933797e-002, -1.0760626940880943e-002, 4.4853921118213676e-003, -1.6438774496992904e-003, 5.1441308429384374e-004,
+		-1.3211724349740752e-004, 2.6191316362108199e-005, -3.5802424384280469e-006, 2.5491272423372411e-007 };
+	static const double h1[7] = { 6.1610372237019151e-001, -1.5767891821295410e-001, 5.5089690570484962e-002, -1.6895755290596615e-002,       // HBKernel_7b, 209.9472 dB
+		3.9416641999499014e-003, -6.0603620400878633e-004, 4.5632598748568398e-005 };
+	static const double h2[5] = { 6.0626808278478261e-001, -1.3588224019070938e-001, 3.5544305138258458e-002, -6.5127022013993230e-003,       // HBKernel_5c, 213.4984 dB
+		5.8255449020627736e-004 };
+	static const double h3[4] = { 5.9835028661892165e-001, -1.1999986095168852e-001, 2.4132530901858028e-002, -2.4829565783680927e-003 };     // HBKernel_4d, 220.6519 dB
+	static const double t0[9] = { 6.2163188987470752e-001, -1.7108115412330563e-001, 6.9588371105224839e-002, -2.7339625869282957e-002,       // third: HBKernel_9, 220.5199 dB
+		9.2954473703765472e-003, -2.5537181861669997e-003, 5.2572296540671394e-004, -7.1813366796731157e-005, 4.8802392556669750e-006 };
+	static const double t1[6] = { 6.1161456377889145e-001, -1.4743902036519768e-001, 4.5344160828746795e-002, -1.1207372108402218e-002,       // third: HBKernel_6b, 224.2705 dB
+		1.8328498006058664e-003, -1.4518194076022933e-004 };
+	static const double t2[5] = { 6.0590922849004858e-001, -1.3515953371903033e-001, 3.5020856634677522e-002, -6.3256195330255094e-003,       // third: HBKernel_5c, 248.8728 dB
+		5.5506812768978109e-004 };
+	if( third ) switch( steep ) { case 0: n = 9; return t0; case 1: n = 6; return t1; case 2: n = 5; return t2; default: n = 0; return nullptr; }
+	switch( steep ) { case 0: n = 13; return h0; case 1: n = 7; return h1; case 2: n = 5; return h2; case 3: n = 4; return h3; default: n = 0; return nullptr; }
+	}
+
+// what CDSPResampler( src, dst ) builds, for the shapes this file restates
+struct Chain
+	{
+	int hb_down = 0;                       // CDSPHBDownsampler stages in front (SteepIndex hb_down-1 .. 0)
+	int up = 1, down = 1; double norm_freq = 0.5, gain = 1.0;    // the block convolver
+	int hb_up = 0;                         // CDSPHBUpsampler stages behind it (SteepIndex 0 .. hb_up-1)
+	bool third = false;                    // third-band half-band kernels / interpolator bank
+	bool interp = false; int in_step = 0, out_step = 0;          // whole-stepping CDSPFracInterpolator last
+	};
+
+bool chain_shape( double src, double dst, Chain & ch )
+	{
+	if( src == dst ) return false;
+	static const int common[5][2] = { { 1, 2 }, { 1, 3 }, { 2, 3 }, { 3, 2 }, { 3, 4 } };            // CDSPResampler.h:142-170
+	for( const auto & c : common )
+		if( src * c[0] == dst * c[1] ) { ch.up = c[0]; ch.down = c[1]; ch.norm_freq = 1.0 / ( c[0] > c[1] ? c[0] : c[1] ); ch.gain = c[0]; return true; }
+	for( int i = 2; i <= 3; ++i )                                                                   // :174-212
+		for( int c = 0; src * ( i << c ) <= dst; ++c )
+			if( src * ( i << c ) == dst )
+				{
+				ch.up = i; ch.down = 1; ch.norm_freq = 1.0 / i; ch.gain = i; ch.hb_up = c; ch.third = ( i == 3 );
+				int n; return c == 0 || hb_kernel( c - 1, ch.third, n ) != nullptr;
+				}
+	TwoStage ts{};
+	if( dst * 2 > src )                                                                            // :214-316
+		{
+		if( !two_stage_shape( src, dst, ts ) ) return false;
+		ch.up = ts.up; ch.norm_freq = ts.norm_freq; ch.gain = ts.gain; ch.third = ts.third; ch.interp = true; ch.in_step = ts.in_step; ch.out_step = ts.out_step;
+		return true;
+		}
+	double check = dst * 4.0, fin_gain = 1.0;                                                      // :319-331
+	int c = 0;
+	while( check <= src ) { ++c; check *= 2.0; fin_gain *= 0.5; }
+	const int div = 1 << c;
+	ch.hb_down = c; ch.gain = fin_gain; ch.up = 1;
+	int downf = 0;
+	for( int d = 2; d <= 3; ++d ) if( dst * div * d == src ) { downf = d; break; }                 // :340-349
+	if( downf ) { ch.down = downf; ch.norm_freq = 1.0 / downf; ch.third = ( downf == 3 ); }
+	else                                                                                           // :351-356, :372-376
+		{
+		ch.down = 1; ch.norm_freq = dst * div / src; ch.third = ch.norm_freq * 3.0 <= 1.0;
+		ch.interp = true;
+		if( !whole_stepping( src, dst * div, ch.in_step, ch.out_step ) ) return false;
+		}
+	int n; return c == 0 || hb_kernel( c - 1, ch.third, n ) != nullptr;
+	}
+
+double at( const std::vector<double> & v, int64_t i ) { return i >= 0 && i < int64_t( v.size() ) ? v[size_t( i )] : 0.0; }
+
+} // namespace
+
+// 1 when this file restates the chain CDSPResampler( src, dst ) builds; the shape for tests
+extern "C" int oracle_resample_chain_shape( double src, double dst, int * hb_down, int * up, int * down, double * norm_freq, double * gain, int * hb_up, int * third,
+	int * interp, int * in_step, int * out_step )
+	{
+	Chain ch;
+	if( !chain_shape( src, dst, ch ) ) return 0;
+	if( hb_down ) *hb_down = ch.hb_down;
+	if( up ) *up = ch.up;
+	if( down ) *down = ch.down;
+	if( norm_freq ) *norm_freq = ch.norm_freq;
+	if( gain ) *gain = ch.gain;
+	if( hb_up ) *hb_up = ch.hb_up;
+	if( third ) *third = ch.third ? 1 : 0;
+	if( interp ) *interp = ch.interp ? 1 : 0;
+	if( in_step ) *in_step = ch.in_step;
+	if( out_step ) *out_step = ch.out_step;
+	return 1;
+	}
+
+// Audio::resample through any restated chain: [half-band downsamplers] -> block convolver -> [half-band upsamplers] -> [interpolator].
+// Every stage is evaluated on the whole stream in fp64 (r8brain's own intermediate type), zero before the start and past the input,
+// for exactly as many samples as the next stage reads; the last stage rounds to float.
+extern "C" int oracle_resample_chain( const float * in, int64_t total_in, float * out, int64_t total_out, double src, double dst )
+	{
+	Chain ch;
+	if( !chain_shape( src, dst, ch ) ) return -1;
+	if( total_out <= 0 ) return 0;
+	std::vector<double> h; int fl2 = 0;
+	if( !design_default_lowpass( ch.norm_freq, ch.gain, h, fl2 ) ) return -1;
+	std::vector<double> bank; int flt_len = 0;
+	if( ch.interp ) frac_delay_bank( ch.out_step, ch.third, bank, flt_len );
+	// how many samples of each stage's output the stage after it reads (backwards from the output)
+	int64_t need = total_out;
+	if( ch.interp ) need = ( ( total_out - 1 ) * ch.in_step ) / ch.out_step - ( flt_len / 2 - 1 ) + flt_len;
+	std::vector<int64_t> need_up( size_t( ch.hb_up ) + 1 );
+	need_up[size_t( ch.hb_up )] = need;                                            // output of the last upsampler (or of the convolver)
+	for( int s = ch.hb_up - 1; s >= 0; --s ) { int n; hb_kernel( s, ch.third, n ); need_up[size_t( s )] = ( need_up[size_t( s ) + 1] - 1 ) / 2 + n + 1; }
+	const int64_t need_conv = need_up[0];
+	// forward
+	std::vector<double> cur( in, in + total_in );
+	for( int i = 0; i < ch.hb_down; ++i )                                          // SteepIndex c-1-i (CDSPResampler.h:358-365)
+		{
+		int n; const double * flt = hb_kernel( ch.hb_down - 1 - i, ch.third, n );
+		std::vector<double> nxt( size_t( ( int64_t( cur.size() ) + 2 * n + 1 ) / 2 + 1 ) );   // the tail of the filter past the input's end
+		for( int64_t j = 0; j < int64_t( nxt.size() ); ++j )
+			{
+			double sacc = at( cur, 2 * j );
+			for( int t = 0; t < n; ++t ) sacc += flt[t] * ( at( cur, 2 * j + 2 * t + 1 ) + at( cur, 2 * j - 2 * t - 1 ) );
+			nxt[size_t( j )] = sacc;
+			}
+		cur.swap( nxt );
+		}
+		{
+		std::vector<double> nxt( size_t( need_conv > 0 ? need_conv : 0 ) );
+		const int64_t len_in = int64_t( cur.size() );
+		for( int64_t k = 0; k < need_conv; ++k )
+			{
+			const int64_t c = int64_t( ch.down ) * k;
+			int64_t m0 = c - fl2 <= 0 ? 0 : ( c - fl2 + ch.up - 1 ) / ch.up;
+			int64_t m1 = ( c + fl2 ) / ch.up;
+			if( m1 >= len_in ) m1 = len_in - 1;
+			double acc = 0.0;
+			for( int64_t m = m0; m <= m1; ++m ) acc += h[fl2 + ( c - ch.up * m )] * cur[size_t( m )];
+			nxt[size_t( k )] = acc;
+			}
+		cur.swap( nxt );
+		}
+	for( int s = 0; s < ch.hb_up; ++s )                                            // SteepIndex s (:203-209)
+		{
+		int n; const double * flt = hb_kernel( s, ch.third, n );
+		std::vector<double> nxt( size_t( need_up[size_t( s ) + 1] ) );
+		for( int64_t o = 0; o < int64_t( nxt.size() ); ++o )
+			{
+			const int64_t j = o >> 1;
+			if( ( o & 1 ) == 0 ) { nxt[size_t( o )] = at( cur, j ); continue; }
+			double sacc = flt[0] * ( at( cur, j + 1 ) + at( cur, j ) );
+			for( int t = 1; t < n; ++t ) sacc += flt[t] * ( at( cur, j + 1 + t ) + at( cur, j - t ) );
+			nxt[size_t( o )] = sacc;
+			}
+		cur.swap( nxt );
+		}
+	if( !ch.interp ) { for( int64_t k = 0; k < total_out; ++k ) out[k] = float( at( cur, k ) ); return 0; }
+	const int fll = flt_len / 2 - 1;
+	for( int64_t k = 0; k < total_out; ++k )
+		{
+		const int64_t pos = k * ch.in_step, p = pos / ch.out_step;
+		const double * ft = &bank[size_t( pos % ch.out_step ) * flt_len];
+		double sacc = 0.0;
+		for( int i = 0; i < flt_len; ++i ) sacc += ft[i] * at( cur, p - fll + i );
+		out[k] = float( sacc );
+		}
+	return 0;
+	}
+
 extern "C" {
 
 // taps of the default low-pass at cut-off 1/2, for tests

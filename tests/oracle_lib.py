@@ -69,6 +69,9 @@ def _load():
     lib.oracle_resample_two_stage_shape.argtypes = [C.c_double, C.c_double, ip, C.POINTER(C.c_double), ip, ip, ip]
     lib.oracle_r8b_frac_bank.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int]
     lib.oracle_resample_two_stage.argtypes = [f32p, C.c_int64, f32p, C.c_int64, C.c_double, C.c_double]
+    dp = C.POINTER(C.c_double)
+    lib.oracle_resample_chain_shape.argtypes = [C.c_double, C.c_double, ip, ip, ip, dp, dp, ip, ip, ip, ip, ip]
+    lib.oracle_resample_chain.argtypes = [f32p, C.c_int64, f32p, C.c_int64, C.c_double, C.c_double]
     i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
     lib.oracle_interpolate.restype = C.c_float
     lib.oracle_interpolate.argtypes = [C.c_int, C.c_float]
@@ -505,6 +508,29 @@ def resample_two_stage(audio, src_rate, dst_rate):
     out = np.empty((ch, n_out), np.float32)
     rc = lib.oracle_resample_two_stage(audio.reshape(-1), ch * n, out.reshape(-1), ch * n_out, float(src_rate), float(dst_rate))
     assert rc == 0, "not a two-stage ratio"
+    return out
+
+
+def chain_shape(src_rate, dst_rate):
+    """None, or the chain CDSPResampler( src, dst ) builds when the checker restates it: [half-band downsamplers] -> block convolver
+    -> [half-band upsamplers] -> [whole-stepping interpolator]"""
+    iv = [C.c_int() for _ in range(8)]
+    nf, gain = C.c_double(), C.c_double()
+    if not lib.oracle_resample_chain_shape(src_rate, dst_rate, C.byref(iv[0]), C.byref(iv[1]), C.byref(iv[2]), C.byref(nf), C.byref(gain),
+                                           C.byref(iv[3]), C.byref(iv[4]), C.byref(iv[5]), C.byref(iv[6]), C.byref(iv[7])):
+        return None
+    return dict(hb_down=iv[0].value, up=iv[1].value, down=iv[2].value, norm_freq=nf.value, gain=gain.value, hb_up=iv[3].value,
+                third=bool(iv[4].value), interp=bool(iv[5].value), in_step=iv[6].value, out_step=iv[7].value)
+
+
+def resample_chain(audio, src_rate, dst_rate):
+    """Audio::resample through any chain the checker restates: [ch][n] -> [ch][n_out], the whole buffer as one stream"""
+    audio = np.ascontiguousarray(audio, np.float32)
+    ch, n = audio.shape
+    n_out = int(lib.oracle_resample_out_frames(n, src_rate, dst_rate))
+    out = np.empty((ch, n_out), np.float32)
+    rc = lib.oracle_resample_chain(audio.reshape(-1), ch * n, out.reshape(-1), ch * n_out, float(src_rate), float(dst_rate))
+    assert rc == 0, "chain not restated"
     return out
 
 

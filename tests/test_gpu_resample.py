@@ -63,6 +63,27 @@ def test_resample_two_stage_ratios(fa, src, dst):
         assert (d.max() if d.size else 0.0) <= 1.2e-7 and (same >= 0.999 if d.size else True)
 
 
+HB_CHAINS = [(48000.0, 192000.0), (48000.0, 384000.0), (16000.0, 96000.0), (8000.0, 96000.0), (6000.0, 96000.0), (192000.0, 48000.0), (96000.0, 16000.0),
+             (192000.0, 24000.0), (192000.0, 44100.0), (384000.0, 16000.0), (768000.0, 48000.0)]
+
+
+@pytest.mark.parametrize("src,dst", HB_CHAINS)
+def test_resample_half_band_chains(fa, src, dst):
+    """r8brain's chains with half-band stages -- 4x / 8x / 16x / 6x / 12x up (block convolver + CDSPHBUpsamplers), src >= 4 dst down
+    (CDSPHBDownsamplers + block convolver [+ whole-stepping interpolator]) -- against the restatement, which test_oracle_resample.py holds
+    to the real r8brain on the same rate pairs"""
+    assert O.chain_shape(src, dst) is not None
+    for ch, n in ((2, 20001), (3, 777), (1, 40)):
+        x = O.noise(ch, n, seed=n + int(dst))
+        ref = O.resample_chain(x, src, dst)
+        got = fa.resample(x, src, dst)
+        assert got.shape == ref.shape
+        d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+        same = np.mean(got.view(np.uint32) == ref.view(np.uint32)) if d.size else 1.0
+        print("\n[resample %g->%g %dx%d] max diff %.2e  bit-identical %.5f" % (src, dst, ch, n, d.max() if d.size else 0.0, same))
+        assert (d.max() if d.size else 0.0) <= 1.2e-7 and same >= 0.999
+
+
 def test_resample_two_stage_long(fa):
     """a minute of 44.1 kHz stereo to 48 kHz: the sine comes out a sine (size-independent property; the oracle is not run at this size)"""
     sr, n = 44100.0, 44100 * 60
@@ -81,10 +102,11 @@ def test_resample_two_stage_long(fa):
 
 
 def test_unsupported_ratio(fa):
-    """ratios r8brain serves through half-band stages or the spline-interpolated bank are refused, not approximated"""
+    """ratios r8brain serves through intermediate interpolation with its own low-pass, a half-band chain deeper than 16x, or the
+    spline-interpolated bank are refused, not approximated"""
     import flan_amd
     x = O.noise(1, 1000, seed=1)
-    for src, dst in ((8000.0, 44100.0), (96000.0, 16000.0), (44100.0, 22000.0), (44100.0, 48001.0)):
+    for src, dst in ((8000.0, 44100.0), (1000.0, 64000.0), (44100.0, 22000.0), (44100.0, 48001.0)):
         with pytest.raises(flan_amd.FlanHipError) as e:
             fa.resample(x, src, dst)
         assert e.value.code == flan_amd.ERR_UNSUPPORTED

@@ -99,6 +99,37 @@ def test_two_stage_ratios_match_r8brain(src, dst):
         assert d.max() <= 1.2e-7 and same >= 0.999
 
 
+HB_CHAINS = [(48000.0, 192000.0), (44100.0, 176400.0), (48000.0, 384000.0), (16000.0, 96000.0), (8000.0, 96000.0), (6000.0, 96000.0), (192000.0, 48000.0),
+             (96000.0, 16000.0), (192000.0, 24000.0), (192000.0, 44100.0), (384000.0, 48000.0), (384000.0, 16000.0), (768000.0, 48000.0)]
+
+
+@pytest.mark.parametrize("src,dst", HB_CHAINS)
+def test_half_band_chains_match_r8brain(src, dst):
+    """chains with CDSPHBUpsampler / CDSPHBDownsampler stages (CDSPResampler.h:174-212, :319-378): the restatement against the vendored
+    r8brain, incl. third-band kernels (6x, 12x), three stages (16x up, 8x down of a 3:1) and half-band + interpolator (192 -> 44.1 kHz)"""
+    assert O.chain_shape(src, dst) is not None
+    rng = np.random.default_rng(int(src + dst))
+    for ch, n in ((2, 7001), (1, 300), (3, 20)):
+        x = rng.uniform(-1, 1, (ch, n)).astype(np.float32)
+        ours = O.resample_chain(x, src, dst)
+        theirs = ref_resample(x, src, dst)
+        assert ours.shape == theirs.shape
+        d = np.abs(ours.astype(np.float64) - theirs.astype(np.float64))
+        same = np.mean(ours.view(np.uint32) == theirs.view(np.uint32)) if d.size else 1.0
+        print("\n[resample %g->%g %dx%d] max diff %.2e  bit-identical %.5f" % (src, dst, ch, n, d.max() if d.size else 0.0, same))
+        assert (d.max() if d.size else 0.0) <= 1.2e-7 and same >= 0.995
+
+
+def test_chain_form_contains_the_other_restatements():
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-1, 1, (2, 5000)).astype(np.float32)
+    assert np.array_equal(O.resample_chain(x, 96000.0, 48000.0).view(np.uint32), O.resample_2to1(x, 96000.0, 48000.0).view(np.uint32))
+    assert np.array_equal(O.resample_chain(x, 32000.0, 48000.0).view(np.uint32), O.resample_rational(x, 32000.0, 48000.0, 3, 2).view(np.uint32))
+    assert np.array_equal(O.resample_chain(x, 44100.0, 48000.0).view(np.uint32), O.resample_two_stage(x, 44100.0, 48000.0).view(np.uint32))
+    for src, dst in ((8000.0, 44100.0), (1000.0, 64000.0), (44100.0, 22000.0), (48000.0, 48000.0)):
+        assert O.chain_shape(src, dst) is None, (src, dst)
+
+
 def test_two_stage_shapes():
     assert O.two_stage_shape(44100.0, 48000.0) == dict(up=2, norm_freq=0.5, third=False, in_step=147, out_step=80)
     assert O.two_stage_shape(48000.0, 44100.0) == dict(up=2, norm_freq=0.459375, third=False, in_step=320, out_step=147)
