@@ -47,7 +47,10 @@ def main():
                                        ("up_32_48", 2, 3200, 32000.0, 48000.0, 25), ("down_144_48", 2, 14400, 144000.0, 48000.0, 26),
                                        ("down_72_48", 1, 7201, 72000.0, 48000.0, 27), ("up_48_96", 2, 4800, 48000.0, 96000.0, 28),
                                        ("up_16_48", 1, 1601, 16000.0, 48000.0, 29), ("down_64_48", 2, 6400, 64000.0, 48000.0, 30),
-                                       ("ms_441_48", 2, 4410, 44100.0, 48000.0, 31), ("ms_48_441", 2, 4800, 48000.0, 44100.0, 32)):
+                                       ("ms_441_48", 2, 4410, 44100.0, 48000.0, 31), ("ms_48_441", 2, 4800, 48000.0, 44100.0, 32),
+                                       ("hb_48_192", 2, 1200, 48000.0, 192000.0, 33), ("hb_192_48", 2, 4800, 192000.0, 48000.0, 34),
+                                       ("hb_192_441", 1, 4800, 192000.0, 44100.0, 35), ("hb_8_96", 1, 400, 8000.0, 96000.0, 36),
+                                       ("hb_96_16", 2, 2400, 96000.0, 16000.0, 37)):
         x = O.noise(ch, n, seed)
         cases[tag + "_x"] = x
         cases[tag + "_y"] = r8b(r8, x, src, dst)

@@ -143,7 +143,8 @@ def test_resample_fixture(fa):
 
 
 @pytest.mark.parametrize("tag", ["c5_stereo_0p1s", "c5_mono_ragged", "c5_stereo_0p25s", "c5_three_short", "up_32_48", "down_144_48", "down_72_48",
-                                 "up_48_96", "up_16_48", "down_64_48", "ms_441_48", "ms_48_441"])
+                                 "up_48_96", "up_16_48", "down_64_48", "ms_441_48", "ms_48_441", "hb_48_192", "hb_192_48", "hb_192_441",
+                                 "hb_8_96", "hb_96_16"])
 def test_resample_against_the_real_r8brain(fa, tag):
     """the HIP resampler against vectors the reference's vendored r8brain produced (tests/golden/ref_made/r8brain.npz, made by
     make_ref_made.py from oracle/_ref/libr8bref.so): config 5's 96 -> 48 kHz incl. the 2-channel cross-channel bleed, every other
