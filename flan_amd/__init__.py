@@ -87,6 +87,8 @@ _SIGS = {
     "flanhip_resonate_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i32, _i64, _vp, _f32, _vp, _vp]),
     "flanhip_n_loudest_partials_dev": (C.c_int, [_vp, _i64, _i64, _i32, _vp, C.c_int32, _i32, _vp, _vp]),
     "flanhip_desample_dev": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _f32, _i32, _vp, _vp]),
+    "flanhip_interp_table_create": (C.c_int, [_vp, _vp]),
+    "flanhip_interp_table_destroy": (C.c_int, [_i32]),
     "flanhip_time_extrapolate_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i64, _i64, _i64, _vp, _vp, _vp]),
     "flanhip_shape_affine_dev_fused": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _i32, _vp, _vp]),
     "flanhip_shape_table_dev_fused": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _f32, _f32, _vp, _i32, _vp, _vp]),
@@ -324,6 +326,35 @@ def n_loudest_partials(pv, n, remove=False):
         n_ptr, n_const = _vp(_keep.ptr), 0
     check(lib.flanhip_n_loudest_partials_dev(_vp(d_pv.ptr), ch, F, bins, n_ptr, n_const, int(remove), _vp(d_out.ptr), None))
     return d_out.to_host(pv.shape)
+
+
+INTERP_TABLE_INTERVALS = 65536
+
+
+class InterpTable:
+    """an Interpolator built from a callable (Utility/Interpolator.h), sampled at i / 65536 and at NaN and registered with the library: use
+    `.kind` wherever a FLANHIP_INTERP_* kind is taken; a context manager (the table is destroyed on exit)"""
+
+    def __init__(self, fn):
+        n = INTERP_TABLE_INTERVALS
+        xs = np.arange(n + 1, dtype=np.float32) * np.float32(1.0 / n)
+        samples = np.empty(n + 2, np.float32)
+        samples[:n + 1] = [fn(np.float32(x)) for x in xs]
+        samples[n + 1] = fn(np.float32(np.nan))
+        kind = C.c_int(-1)
+        check(lib.flanhip_interp_table_create(_ptr(samples), C.byref(kind)))
+        self.kind = kind.value
+
+    def close(self):
+        if self.kind >= 0:
+            check(lib.flanhip_interp_table_destroy(self.kind))
+            self.kind = -1
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 def desample(pv, ratio, interp=0):

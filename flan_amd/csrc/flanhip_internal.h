@@ -78,4 +78,12 @@ void note_workspace_producer( const void * d_ws, int kind );
 int workspace_producer( const void * d_ws );
 int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, SynthLayout * out );
 
+// Interpolators: a named kind (FLANHIP_INTERP_LINEAR .. _SINE) or a live table registered with flanhip_interp_table_create (processors_ext.hip)
+bool valid_interp( int kind );
+float interp_eval_host( int kind, float x );            // one value on the host (get_frame): named kinds like Utility/Interpolator.cpp, tables like the device
+// every translation unit with kernels that call interpolate() keeps its own copy of the table pointers
+int processors_set_interp_lut( int slot, const float * d_table );
+int processors_ext_set_interp_lut( int slot, const float * d_table );
+int processors_arrange_set_interp_lut( int slot, const float * d_table );
+
 } // namespace flanhip

@@ -515,6 +515,8 @@ static int launch_repitch_scan( float * d_factor, int64_t F, int bins, float sr,
 
 } // namespace flanhip
 
+namespace flanhip { int processors_set_interp_lut( int slot, const float * d_table ) { return set_interp_lut_here( slot, d_table ); } }
+
 using namespace flanhip;
 
 extern "C" {
@@ -523,7 +525,7 @@ static int modify_time_dev_impl( const flanhip_MF * d_pv, int64_t ch, int64_t F,
 	int64_t Fo, flanhip_MF * d_out, int interp, void * stream )
 	{
 	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, sr ) ) return rc;
-	FLANHIP_REQUIRE( interp >= FLANHIP_INTERP_LINEAR && interp <= FLANHIP_INTERP_SINE, FLANHIP_ERR_INVALID_ARG, "unknown interpolator" );
+	FLANHIP_REQUIRE( valid_interp( interp ), FLANHIP_ERR_INVALID_ARG, "unknown interpolator" );
 	FLANHIP_REQUIRE( d_mod && hop >= 1 && Fo > 0, FLANHIP_ERR_INVALID_ARG, "bad map / output length" );
 	hipStream_t s = (hipStream_t) stream;
 	FLANHIP_REQUIRE( Fo < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "2^31 output frames or more" );
@@ -561,7 +563,7 @@ static int modify_time_dev_fused_impl( const flanhip_MF * d_pv, int64_t ch, int6
 	int64_t Fo, flanhip_MF * d_out, int window_size, void * d_ws, int interp, void * stream )
 	{
 	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, sr ) ) return rc;
-	FLANHIP_REQUIRE( interp >= FLANHIP_INTERP_LINEAR && interp <= FLANHIP_INTERP_SINE, FLANHIP_ERR_INVALID_ARG, "unknown interpolator" );
+	FLANHIP_REQUIRE( valid_interp( interp ), FLANHIP_ERR_INVALID_ARG, "unknown interpolator" );
 	FLANHIP_REQUIRE( d_mod && d_ws && analysis_rate > 0.0f && Fo > 0, FLANHIP_ERR_INVALID_ARG, "bad map / output length / workspace" );
 	FLANHIP_REQUIRE( Fo < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "2^31 output frames or more" );
 	hipStream_t s = (hipStream_t) stream;
@@ -666,7 +668,7 @@ static int modify_frequency_dev_impl( const flanhip_MF * d_pv, int64_t ch, int64
 	const float * d_in_modified, flanhip_MF * d_out, int interp, void * stream )
 	{
 	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, sr ) ) return rc;
-	FLANHIP_REQUIRE( interp >= FLANHIP_INTERP_LINEAR && interp <= FLANHIP_INTERP_SINE, FLANHIP_ERR_INVALID_ARG, "unknown interpolator" );
+	FLANHIP_REQUIRE( valid_interp( interp ), FLANHIP_ERR_INVALID_ARG, "unknown interpolator" );
 	FLANHIP_REQUIRE( d_mod && d_in_modified, FLANHIP_ERR_INVALID_ARG, "null map" );
 	hipStream_t s = (hipStream_t) stream;
 	const int64_t rows = ch * F;
@@ -694,7 +696,7 @@ int flanhip_modify_frequency_interp_dev( const flanhip_MF * d_pv, int64_t ch, in
 static int repitch_dev_impl( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float * d_factor, flanhip_MF * d_out, int interp, void * stream )
 	{
 	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, sr ) ) return rc;
-	FLANHIP_REQUIRE( interp >= FLANHIP_INTERP_LINEAR && interp <= FLANHIP_INTERP_SINE, FLANHIP_ERR_INVALID_ARG, "unknown interpolator" );
+	FLANHIP_REQUIRE( valid_interp( interp ), FLANHIP_ERR_INVALID_ARG, "unknown interpolator" );
 	FLANHIP_REQUIRE( d_factor, FLANHIP_ERR_INVALID_ARG, "null factor grid" );
 	hipStream_t s = (hipStream_t) stream;
 	const float dft = float( ( bins - 1 ) * 2 );

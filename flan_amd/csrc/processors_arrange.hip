@@ -414,6 +414,8 @@ __global__ __launch_bounds__( 256 ) void k_spline_eval( const float * in, int64_
 
 } // namespace flanhip
 
+namespace flanhip { int processors_arrange_set_interp_lut( int slot, const float * d_table ) { return set_interp_lut_here( slot, d_table ); } }
+
 using namespace flanhip;
 
 extern "C" {
@@ -422,22 +424,10 @@ int flanhip_get_frame_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int b
 	{
 	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, 1.0f ) ) return rc;
 	FLANHIP_REQUIRE( frame_pos >= 0.0f && frame_pos <= float( F - 1 ), FLANHIP_ERR_INVALID_ARG, "frame position outside [0, F-1] (PV.cpp:28 clamps it)" );
-	FLANHIP_REQUIRE( interp_kind >= 0 && interp_kind <= FLANHIP_INTERP_SINE, FLANHIP_ERR_INVALID_ARG, "unknown interpolator" );
+	FLANHIP_REQUIRE( valid_interp( interp_kind ), FLANHIP_ERR_INVALID_ARG, "unknown interpolator" );
 	FLANHIP_REQUIRE( ch <= 65535, FLANHIP_ERR_INVALID_ARG, "too many channels" );
 	const float lo = std::floor( frame_pos ), hi = std::ceil( frame_pos );
-	float x = frame_pos - lo, mix = x;                                                // PV.cpp:67: the interpolator of [0,1) -> [0,1]
-	switch( interp_kind )                                                             // Utility/Interpolator.cpp:14-101, one value: on the host
-		{
-		case FLANHIP_INTERP_MIDPOINT: mix = 0.5f; break;
-		case FLANHIP_INTERP_NEAREST: mix = std::round( x ); break;
-		case FLANHIP_INTERP_FLOOR: mix = 0.0f; break;
-		case FLANHIP_INTERP_CEIL: mix = 1.0f; break;
-		case FLANHIP_INTERP_SMOOTHSTEP: mix = x * x * ( 3.0f - 2.0f * x ); break;
-		case FLANHIP_INTERP_SMOOTHERSTEP: mix = x * x * x * ( x * ( x * 6.0f - 15.0f ) + 10.0f ); break;
-		case FLANHIP_INTERP_SQRT: mix = std::sqrt( x ); break;
-		case FLANHIP_INTERP_SINE: mix = ( 1.0f - std::cos( std::acos( -1.0f ) * x ) ) / 2.0f; break;
-		default: break;
-		}
+	const float mix = interp_eval_host( interp_kind, frame_pos - lo );                // PV.cpp:67: the interpolator of [0,1) -> [0,1], one value: on the host
 	hipLaunchKernelGGL( k_get_frame, dim3( ( bins + 255 ) / 256, unsigned( ch ) ), dim3( 256 ), 0, (hipStream_t) stream, (const MFd*) d_pv, F, bins,
 		int64_t( lo ), int64_t( hi ), mix, (MFd*) d_out );
 	FLANHIP_CHECK( hipGetLastError() );
@@ -590,7 +580,7 @@ int flanhip_modify_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins
 	{
 	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, sr ) ) return rc;
 	FLANHIP_REQUIRE( d_mod_tf && d_in_f && hop >= 1 && out_frames > 0, FLANHIP_ERR_INVALID_ARG, "null grid, bad hop or bad output frame count" );
-	FLANHIP_REQUIRE( interp_kind >= 0 && interp_kind <= FLANHIP_INTERP_SINE, FLANHIP_ERR_INVALID_ARG, "unknown interpolator" );
+	FLANHIP_REQUIRE( valid_interp( interp_kind ), FLANHIP_ERR_INVALID_ARG, "unknown interpolator" );
 	FLANHIP_REQUIRE( F * bins < ( int64_t( 1 ) << 30 ), FLANHIP_ERR_UNSUPPORTED, "frames x bins does not fit the quad index" );
 	hipStream_t s = (hipStream_t) stream;
 	FLANHIP_CHECK( hipMemsetAsync( d_out, 0, sizeof( MFd ) * size_t( ch ) * out_frames * bins, s ) );   // PVModify.cpp:40

@@ -23,9 +23,32 @@ __device__ __forceinline__ int to_int_sat( float v )
 // std::clamp( v, 0.0f, 1.0f ): NaN passes through
 __device__ __forceinline__ float clamp01( float v ) { return v < 0.0f ? 0.0f : ( 1.0f < v ? 1.0f : v ); }
 
+// An Interpolator built from a user's callable (Utility/Interpolator.h): the host samples it at i / FLANHIP_INTERP_TABLE_INTERVALS, i = 0 ..
+// INTERVALS, and at NaN (flanhip_interp_table_create); kinds FLANHIP_INTERP_TABLE_FIRST + slot read the table with linear interpolation
+// between neighbouring samples, the argument clamped to [0, 1] (every call site's argument is a position inside a pair: PVModify.cpp:232,
+// :344, :491).  The pointers sit in a __device__ array: one copy per translation unit (no relocatable device code), set through
+// set_interp_lut_here() from that unit.
+constexpr int kInterpLutSlots = 32;
+static __device__ const float * g_interp_lut[kInterpLutSlots];
+static inline int set_interp_lut_here( int slot, const float * d_table )
+	{
+	FLANHIP_CHECK( hipMemcpyToSymbol( HIP_SYMBOL( g_interp_lut ), &d_table, sizeof( d_table ), sizeof( d_table ) * size_t( slot ) ) );
+	return FLANHIP_OK;
+	}
+__device__ __forceinline__ float interpolate_table( int slot, float x )
+	{
+	const float * t = g_interp_lut[slot];
+	if( !( x == x ) ) return t[FLANHIP_INTERP_TABLE_INTERVALS + 1];
+	const float pos = ( x < 0.0f ? 0.0f : ( 1.0f < x ? 1.0f : x ) ) * float( FLANHIP_INTERP_TABLE_INTERVALS );
+	const int i = min( int( pos ), FLANHIP_INTERP_TABLE_INTERVALS - 1 );
+	const float a = t[i], b = t[i + 1];
+	return __builtin_fmaf( pos - float( i ), b - a, a );
+	}
+
 // Utility/Interpolator.cpp:14-101, numbered as include/flanhip.h numbers them (FLANHIP_INTERP_*)
 __device__ __forceinline__ float interpolate( int kind, float x )
 	{
+	if( kind >= FLANHIP_INTERP_TABLE_FIRST ) return interpolate_table( kind - FLANHIP_INTERP_TABLE_FIRST, x );
 	switch( kind )
 		{
 		case FLANHIP_INTERP_MIDPOINT:     return 0.5f;

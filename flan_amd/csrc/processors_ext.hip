@@ -14,6 +14,9 @@
 //                         (ballot + popcount, keys in LDS), ties by ascending bin
 //   k_time_extrapolate  : wavefront per output row, placement conflicts through LDS keys (processors_common.h)
 #include "processors_common.h"
+#include <mutex>
+#include <vector>
+#include <algorithm>
 #include <algorithm>
 
 namespace flanhip {
@@ -284,9 +287,93 @@ static unsigned blocks_for( int64_t count, int per_block ) { return (unsigned) (
 
 } // namespace flanhip
 
+namespace flanhip {
+
+int processors_ext_set_interp_lut( int slot, const float * d_table ) { return set_interp_lut_here( slot, d_table ); }
+
+// the tables of flanhip_interp_table_create: device copy for the kernels, host copy for the one-value evaluations
+struct InterpTable { float * d = nullptr; std::vector<float> host; int device = -1; };
+static std::mutex g_lut_mutex;
+static InterpTable g_luts[kInterpLutSlots];
+
+bool valid_interp( int kind )
+	{
+	if( kind >= FLANHIP_INTERP_LINEAR && kind <= FLANHIP_INTERP_SINE ) return true;
+	if( kind < FLANHIP_INTERP_TABLE_FIRST || kind >= FLANHIP_INTERP_TABLE_FIRST + kInterpLutSlots ) return false;
+	std::lock_guard<std::mutex> lock( g_lut_mutex );
+	return g_luts[kind - FLANHIP_INTERP_TABLE_FIRST].d != nullptr;
+	}
+
+float interp_eval_host( int kind, float x )
+	{
+	if( kind >= FLANHIP_INTERP_TABLE_FIRST )
+		{
+		std::lock_guard<std::mutex> lock( g_lut_mutex );
+		const std::vector<float> & t = g_luts[kind - FLANHIP_INTERP_TABLE_FIRST].host;
+		if( t.empty() ) return x;
+		if( !( x == x ) ) return t[FLANHIP_INTERP_TABLE_INTERVALS + 1];
+		const float pos = ( x < 0.0f ? 0.0f : ( 1.0f < x ? 1.0f : x ) ) * float( FLANHIP_INTERP_TABLE_INTERVALS );
+		const int i = std::min( int( pos ), FLANHIP_INTERP_TABLE_INTERVALS - 1 );
+		return std::fmaf( pos - float( i ), t[i + 1] - t[i], t[i] );
+		}
+	switch( kind )                                                                     // Utility/Interpolator.cpp:14-101
+		{
+		case FLANHIP_INTERP_MIDPOINT: return 0.5f;
+		case FLANHIP_INTERP_NEAREST: return std::round( x );
+		case FLANHIP_INTERP_FLOOR: return 0.0f;
+		case FLANHIP_INTERP_CEIL: return 1.0f;
+		case FLANHIP_INTERP_SMOOTHSTEP: return x * x * ( 3.0f - 2.0f * x );
+		case FLANHIP_INTERP_SMOOTHERSTEP: return x * x * x * ( x * ( x * 6.0f - 15.0f ) + 10.0f );
+		case FLANHIP_INTERP_SQRT: return std::sqrt( x );
+		case FLANHIP_INTERP_SINE: return ( 1.0f - std::cos( std::acos( -1.0f ) * x ) ) / 2.0f;
+		default: return x;
+		}
+	}
+
+} // namespace flanhip
+
 using namespace flanhip;
 
 extern "C" {
+
+int flanhip_interp_table_create( const float * samples, int * kind )
+	{
+	FLANHIP_REQUIRE( samples && kind, FLANHIP_ERR_INVALID_ARG, "null argument" );
+	if( int rc = require_device() ) return rc;
+	int device = 0;
+	FLANHIP_CHECK( hipGetDevice( &device ) );
+	const size_t count = size_t( FLANHIP_INTERP_TABLE_INTERVALS ) + 2;
+	std::lock_guard<std::mutex> lock( g_lut_mutex );
+	int slot = -1;
+	for( int i = 0; i < kInterpLutSlots && slot < 0; ++i ) if( !g_luts[i].d ) slot = i;
+	FLANHIP_REQUIRE( slot >= 0, FLANHIP_ERR_UNSUPPORTED, "all interpolator table slots are in use (flanhip_interp_table_destroy)" );
+	float * d = nullptr;
+	FLANHIP_CHECK( hipMalloc( &d, sizeof( float ) * count ) );
+	int rc = FLANHIP_OK;
+	if( hipMemcpy( d, samples, sizeof( float ) * count, hipMemcpyHostToDevice ) != hipSuccess ) { set_error( "hipMemcpy failed" ); rc = FLANHIP_ERR_HIP; }
+	if( !rc ) rc = processors_set_interp_lut( slot, d );
+	if( !rc ) rc = processors_ext_set_interp_lut( slot, d );
+	if( !rc ) rc = processors_arrange_set_interp_lut( slot, d );
+	if( rc ) { (void) hipFree( d ); return rc; }
+	g_luts[slot].d = d;
+	g_luts[slot].host.assign( samples, samples + count );
+	g_luts[slot].device = device;
+	*kind = FLANHIP_INTERP_TABLE_FIRST + slot;
+	return FLANHIP_OK;
+	}
+
+int flanhip_interp_table_destroy( int kind )
+	{
+	FLANHIP_REQUIRE( kind >= FLANHIP_INTERP_TABLE_FIRST && kind < FLANHIP_INTERP_TABLE_FIRST + kInterpLutSlots, FLANHIP_ERR_INVALID_ARG, "not a table kind" );
+	std::lock_guard<std::mutex> lock( g_lut_mutex );
+	InterpTable & t = g_luts[kind - FLANHIP_INTERP_TABLE_FIRST];
+	FLANHIP_REQUIRE( t.d, FLANHIP_ERR_INVALID_ARG, "table not alive" );
+	FLANHIP_CHECK( hipDeviceSynchronize() );                                           // kernels that read it may still be running
+	(void) hipFree( t.d );
+	t.d = nullptr; t.host.clear(); t.device = -1;
+	return FLANHIP_OK;
+	}
+
 
 static int combine_amplitudes( bool subtract, const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, const flanhip_MF * d_src, int64_t sch, int64_t sF,
 	int sbins, const float * d_amount, float amount_const, flanhip_MF * d_out, void * stream )
@@ -386,7 +473,7 @@ int flanhip_desample_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bi
 	flanhip_MF * d_out, void * stream )
 	{
 	if( int rc = check_pv_args( d_pv, d_out, ch, F, bins, 1.0f ) ) return rc;
-	FLANHIP_REQUIRE( interp >= FLANHIP_INTERP_LINEAR && interp <= FLANHIP_INTERP_SINE, FLANHIP_ERR_INVALID_ARG, "unknown interpolator" );
+	FLANHIP_REQUIRE( valid_interp( interp ), FLANHIP_ERR_INVALID_ARG, "unknown interpolator" );
 	FLANHIP_REQUIRE( F < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "2^31 frames or more" );
 	hipStream_t s = (hipStream_t) stream;
 	int * d_lr = nullptr;                                                             // L: int[F][bins]

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <limits>
 #include <iostream>
 
 #include "device_block.h"
@@ -229,6 +230,34 @@ Audio PV::convert_to_lr_audio( flan_CANCEL_ARG_CPP ) const
 	return convert_to_audio( canceller ).convert_to_left_right();
 	}
 
+// What the kernels need of an Interpolator: the named ones (Utility/Interpolator.cpp:14-101) are evaluated on the device by kind; one built
+// from a user's callable is sampled here at i / 65536 and registered as a table the kernels read with linear interpolation between the
+// samples (include/flanhip.h: flanhip_interp_table_create) -- the reference calls the callable from its parallel loops at the same kind of
+// argument, a position in [0, 1] inside a frame or bin pair (PVModify.cpp:232, :344, :491).  Sampled on the calling thread.
+namespace {
+class DeviceInterp
+	{
+public:
+	explicit DeviceInterp( const Interpolator & interp )
+		{
+		if( interp.kind() >= 0 ) { kind_ = interp.kind(); return; }
+		std::vector<float> table( size_t( FLANHIP_INTERP_TABLE_INTERVALS ) + 2 );
+		for( int i = 0; i <= FLANHIP_INTERP_TABLE_INTERVALS; ++i ) table[size_t( i )] = interp( float( i ) * ( 1.0f / float( FLANHIP_INTERP_TABLE_INTERVALS ) ) );
+		table.back() = interp( std::numeric_limits<float>::quiet_NaN() );
+		int kind = -1;
+		if( detail::report( flanhip_interp_table_create( table.data(), &kind ), "interpolator table" ) ) { kind_ = kind; owned_ = true; }
+		}
+	~DeviceInterp() { if( owned_ ) (void) flanhip_interp_table_destroy( kind_ ); }
+	DeviceInterp( const DeviceInterp & ) = delete;
+	DeviceInterp & operator=( const DeviceInterp & ) = delete;
+	bool ok() const { return kind_ >= 0; }
+	int kind() const { return kind_; }
+private:
+	int kind_ = -1;
+	bool owned_ = false;
+	};
+} // namespace
+
 // modify_time_base, PVModify.cpp:307-362
 static PV modify_time_device( const PV & me, std::shared_ptr<DeviceBlock> d_mod, float max_seconds, int interp )
 	{
@@ -259,22 +288,20 @@ static PV modify_time_device( const PV & me, std::shared_ptr<DeviceBlock> d_mod,
 PV PV::modify_time( const Function<TF, Second> & mod, const Interpolator & interp ) const
 	{
 	if( is_null() ) return PV();
-	// the named Interpolators (Utility/Interpolator.cpp:14-101) run on the device; an arbitrary callable would have to be evaluated at
-	// data-dependent, non-grid coordinates inside the kernels (PVModify.cpp:232, :344): refused, loudly
-	if( interp.kind() < 0 ) { std::cerr << "flan: this method runs the named Interpolators (linear, smoothstep, ...) only on the device path" << std::endl; return PV(); }
+	const DeviceInterp device_interp( interp );                                      // named kind, or the callable sampled into a table
+	if( !device_interp.ok() ) return PV();
 	FunctionSample2d<Second> sampled{ 0.0f, 0, 0 };
 	auto d_mod = function_grid_to_device( *this, mod, &sampled );                  // PVModify.cpp:367
 	const float mx = grid_maximum( sampled, mod.get_execution_policy() );          // FunctionSample::maximum
 	if( !d_mod ) return PV();
-	return modify_time_device( *this, std::move( d_mod ), mx, interp.kind() );
+	return modify_time_device( *this, std::move( d_mod ), mx, device_interp.kind() );
 	}
 
 PV PV::stretch( const Function<TF, float> & factor, const Interpolator & interp ) const
 	{
 	if( is_null() ) return PV();
-	// the named Interpolators (Utility/Interpolator.cpp:14-101) run on the device; an arbitrary callable would have to be evaluated at
-	// data-dependent, non-grid coordinates inside the kernels (PVModify.cpp:232, :344): refused, loudly
-	if( interp.kind() < 0 ) { std::cerr << "flan: this method runs the named Interpolators (linear, smoothstep, ...) only on the device path" << std::endl; return PV(); }
+	const DeviceInterp device_interp( interp );                                      // named kind, or the callable sampled into a table
+	if( !device_interp.ok() ) return PV();
 	auto d_grid = function_grid_to_device( *this, factor );                        // PVModify.cpp:373
 	auto d_max = DeviceBlock::allocate( sizeof( float ) );
 	if( !d_grid || !d_max ) return PV();
@@ -284,7 +311,7 @@ PV PV::stretch( const Function<TF, float> & factor, const Interpolator & interp 
 	float mx = 0.0f;
 	flanhip_memcpy_d2h( &mx, d_max->ptr, sizeof( float ), nullptr );
 	if( !detail::report( flanhip_stream_synchronize( nullptr ), "stretch" ) ) return PV();
-	return modify_time_device( *this, std::move( d_grid ), mx, interp.kind() );
+	return modify_time_device( *this, std::move( d_grid ), mx, device_interp.kind() );
 	}
 
 // modify_frequency_base, PVModify.cpp:196-257
@@ -304,9 +331,8 @@ static PV modify_frequency_device( const PV & me, const DeviceBlock & d_mod, con
 PV PV::modify_frequency( const Function<TF, Frequency> & mod, const Interpolator & interp ) const
 	{
 	if( is_null() ) return PV();
-	// the named Interpolators (Utility/Interpolator.cpp:14-101) run on the device; an arbitrary callable would have to be evaluated at
-	// data-dependent, non-grid coordinates inside the kernels (PVModify.cpp:232, :344): refused, loudly
-	if( interp.kind() < 0 ) { std::cerr << "flan: this method runs the named Interpolators (linear, smoothstep, ...) only on the device path" << std::endl; return PV(); }
+	const DeviceInterp device_interp( interp );                                      // named kind, or the callable sampled into a table
+	if( !device_interp.ok() ) return PV();
 	auto d_mod = function_grid_to_device( *this, mod );                            // PVModify.cpp:261
 	if( !d_mod ) return PV();
 	// :263-268: the callable is evaluated at every MF's own (time, frequency): data dependent, so on the host
@@ -316,22 +342,21 @@ PV PV::modify_frequency( const Function<TF, Frequency> & mod, const Interpolator
 		for( Bin bin = 0; bin < get_num_bins(); ++bin ) out[bin] = mod( TF{ t, mfs[bin].f } );
 		} );
 	if( !d_in ) return PV();
-	return modify_frequency_device( *this, *d_mod, *d_in, interp.kind() );
+	return modify_frequency_device( *this, *d_mod, *d_in, device_interp.kind() );
 	}
 
 PV PV::repitch( const Function<TF, float> & factor, const Interpolator & interp ) const
 	{
 	if( is_null() ) return PV();
-	// the named Interpolators (Utility/Interpolator.cpp:14-101) run on the device; an arbitrary callable would have to be evaluated at
-	// data-dependent, non-grid coordinates inside the kernels (PVModify.cpp:232, :344): refused, loudly
-	if( interp.kind() < 0 ) { std::cerr << "flan: this method runs the named Interpolators (linear, smoothstep, ...) only on the device path" << std::endl; return PV(); }
+	const DeviceInterp device_interp( interp );                                      // named kind, or the callable sampled into a table
+	if( !device_interp.ok() ) return PV();
 	auto d_grid = function_grid_to_device( *this, factor );                        // PVModify.cpp:275
 	const MF * d_pv = device_data();
 	auto out = DeviceBlock::allocate( sizeof( MF ) * size_t( get_num_channels() ) * get_num_frames() * get_num_bins() );
 	if( !d_grid || !d_pv || !out ) return PV();
 	// :278-302 running sum over bins, bin_to_frequency, per-MF lerp, then modify_frequency_base (:196-257) -- one call, on the device
 	if( !detail::report( flanhip_repitch_interp_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(), get_sample_rate(),
-			static_cast<float*>( d_grid->ptr ), interp.kind(), static_cast<flanhip_MF*>( out->ptr ), nullptr ), "repitch" ) ) return PV();
+			static_cast<float*>( d_grid->ptr ), device_interp.kind(), static_cast<flanhip_MF*>( out->ptr ), nullptr ), "repitch" ) ) return PV();
 	if( !detail::report( flanhip_stream_synchronize( nullptr ), "repitch" ) ) return PV();
 	return PVBuffer::adopt_device( get_format(), std::move( out ) );
 	}
@@ -466,13 +491,14 @@ PV PV::resonate( Second length, const Function<TF, float> & decay ) const
 PV PV::desample( const Function<TF, float> & decimation_ratio, const Interpolator & interp ) const
 	{
 	if( is_null() ) return PV();
-	if( interp.kind() < 0 ) { std::cerr << "flan: desample runs the named interpolators only on the device path" << std::endl; return PV(); }
+	const DeviceInterp device_interp( interp );                                      // named kind, or the callable sampled into a table
+	if( !device_interp.ok() ) return PV();
 	const GridArg g = grid_arg( sample_function_over_domain( decimation_ratio ) ); // PVModify.cpp:450
 	const MF * d_pv = device_data();
 	auto out = DeviceBlock::allocate( sizeof( MF ) * mf_count( get_format() ) );
 	if( !g.ok || !d_pv || !out ) return PV();
 	const int rc = flanhip_desample_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(), g.ptr, g.constant,
-		interp.kind(), static_cast<flanhip_MF*>( out->ptr ), nullptr );
+		device_interp.kind(), static_cast<flanhip_MF*>( out->ptr ), nullptr );
 	return finish( rc, "desample", get_format(), std::move( out ) );
 	}
 
@@ -564,7 +590,8 @@ PV PV::freeze( const std::vector<Second> & pause_times, const std::vector<Second
 PV PV::modify( const Function<TF, TF> & mod, const Interpolator & interp ) const
 	{
 	if( is_null() ) return PV();
-	if( interp.kind() < 0 ) { std::cerr << "flan: modify runs the named interpolators only on the device path" << std::endl; return PV(); }
+	const DeviceInterp device_interp( interp );                                      // named kind, or the callable sampled into a table
+	if( !device_interp.ok() ) return PV();
 	// PVModify.cpp:22: mod over this PV's grid -- on the host for the output's length (:28-38), on the device for the kernels
 	FunctionSample2d<TF> sampled{ TF{ 0.0f, 0.0f }, 0, 0 };
 	auto d_mod = function_grid_to_device( *this, mod, &sampled );
@@ -591,7 +618,7 @@ PV PV::modify( const Function<TF, TF> & mod, const Interpolator & interp ) const
 	auto out = DeviceBlock::allocate( sizeof( MF ) * mf_count( f ) );
 	if( !d_in_f || !d_pv || !out ) return PV();
 	const int rc = flanhip_modify_dev( reinterpret_cast<const flanhip_MF*>( d_pv ), get_num_channels(), get_num_frames(), get_num_bins(), get_sample_rate(), get_hop_size(),
-		static_cast<const float*>( d_mod->ptr ), static_cast<const float*>( d_in_f->ptr ), interp.kind(), Fo, static_cast<flanhip_MF*>( out->ptr ), nullptr );
+		static_cast<const float*>( d_mod->ptr ), static_cast<const float*>( d_in_f->ptr ), device_interp.kind(), Fo, static_cast<flanhip_MF*>( out->ptr ), nullptr );
 	return finish( rc, "modify", f, std::move( out ) );
 	}
 

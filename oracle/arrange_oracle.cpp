@@ -47,6 +47,9 @@ float interpolate( int kind, float x )                                   // Util
 		case 6: return x * x * x * ( x * ( x * 6.0f - 15.0f ) + 10.0f );
 		case 7: return std::sqrt( x );
 		case 8: return ( 1.0f - std::cos( pi * x ) ) / 2.0f;
+		case 100: return x * x;                                                      // stand-ins for a user's callable, as in processors_oracle.cpp
+		case 101: return x < 0.5f ? 2.0f * x * x : 1.0f - 2.0f * ( 1.0f - x ) * ( 1.0f - x );
+		case 102: return x < 0.3f ? 0.0f : 1.0f;
 		}
 	return x;
 	}

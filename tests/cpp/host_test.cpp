@@ -189,7 +189,17 @@ static void device_checks()
 	PV sh_al = p2.shape( []( MF mf ){ return MF{ mf.m, mf.f * 2.0f }; }, true );
 	PV sh_aa = p2.shape_affine( 1.0f, 0.0f, 2.0f, 0.0f, true );
 	CHECK( std::memcmp( sh_al.get_buffer().data(), sh_aa.get_buffer().data(), sizeof( MF ) * sh_al.get_buffer().size() ) == 0 );
-	CHECK( p2.stretch( 2.0f, Interpolator( []( float x ){ return x * x; } ) ).is_null() );   // non-linear interpolators are not on the device path
+		{
+		// an Interpolator built from a callable runs from a sampled table: the identity callable must give what linear() gives
+		PV st_named = p2.stretch( 2.0f );
+		PV st_call = p2.stretch( 2.0f, Interpolator( []( float x ){ return x; } ) );
+		CHECK( !st_call.is_null() && st_call.get_num_frames() == st_named.get_num_frames() );
+		size_t same = 0;
+		for( size_t i = 0; i < st_named.get_buffer().size(); ++i ) same += std::memcmp( &st_named.get_buffer()[i], &st_call.get_buffer()[i], sizeof( MF ) ) == 0;
+		CHECK( same >= st_named.get_buffer().size() * 999 / 1000 );
+		CHECK( !p2.stretch( 2.0f, Interpolator( []( float x ){ return x * x; } ) ).is_null() );
+		CHECK( !p2.repitch( 1.5f, Interpolator( []( float x ){ return x * x; } ) ).is_null() );
+		}
 
 	// ---- further frame processors (PV.cpp:205-264, :552-641; PVModify.cpp:445-511, :607-666)
 		{
@@ -220,7 +230,8 @@ static void device_checks()
 		CHECK( des.get_MF( 0, 3, 30 ).m == p2.get_MF( 0, 3, 30 ).m * 1.0f + 0.0f * p2.get_MF( 0, 7, 30 ).m );          // frames 0, 3, 7, ... are selected
 		CHECK( des.get_MF( 0, 5, 30 ).m == 0.5f * p2.get_MF( 0, 3, 30 ).m + 0.5f * p2.get_MF( 0, 7, 30 ).m );
 		CHECK( p2.desample( 0.25f, Interpolator::ceil() ).get_MF( 0, 4, 30 ).m == 0.0f * p2.get_MF( 0, 3, 30 ).m + 1.0f * p2.get_MF( 0, 7, 30 ).m );
-		CHECK( p2.desample( 0.25f, Interpolator( []( float x ){ return x * x; } ) ).is_null() );      // arbitrary callables cannot run on the device
+		// frames 3 and 7 are selected, frame 5 sits half way: the callable x^2 gives mix 0.25 (exactly a sample point of the table)
+		CHECK( p2.desample( 0.25f, Interpolator( []( float x ){ return x * x; } ) ).get_MF( 0, 5, 30 ).m == 0.75f * p2.get_MF( 0, 3, 30 ).m + 0.25f * p2.get_MF( 0, 7, 30 ).m );
 		PV ext = p2.time_extrapolate( 0.2f, 0.6f, 0.5f );
 		const Frame sf = Frame( p2.time_to_frame( 0.2f ) ), ef = Frame( p2.time_to_frame( 0.6f ) );
 		CHECK( ext.get_num_frames() == ef + Frame( p2.time_to_frame( 0.5f ) ) );
@@ -351,7 +362,7 @@ static void device_checks()
 			CHECK( moved.get_MF( 0, 13, 24 ).m == ex.get_MF( 0, 10, 20 ).m && moved.get_MF( 0, 13, 24 ).f == ex.get_MF( 0, 10, 20 ).f + df );
 			CHECK( moved.get_MF( 0, 2, 24 ).m == 0.0f && moved.get_MF( 0, 13, 3 ).m == 0.0f );
 			CHECK( ex.modify( []( TF tf ){ return TF{ tf.t + 700.0f, tf.f }; } ).is_null() );      // longer than ten minutes: refused
-			CHECK( ex.modify( []( TF tf ){ return tf; }, Interpolator( []( float v ){ return v; } ) ).is_null() );   // unnamed interpolator
+			CHECK( !ex.modify( []( TF tf ){ return tf; }, Interpolator( []( float v ){ return v; } ) ).is_null() );  // a callable interpolator: sampled table
 			}
 		// stretch_spline: three output frames per input frame; frame 0 is the input's, the knots are reproduced up to rounding
 			{

@@ -438,3 +438,57 @@ def test_named_interpolators_in_time_and_frequency_maps(fa, interp):
     # linear through the new entry points == the plain calls
     if interp == 1:
         assert np.array_equal(fa.modify_time_interp(pv, SR, hop, maps["x1.7"], 0).view(np.uint32), fa.modify_time(pv, SR, hop, maps["x1.7"]).view(np.uint32))
+
+
+CALLABLES = {100: lambda x: x * x,
+             101: lambda x: (np.float32(2.0) * x * x) if x < np.float32(0.5) else np.float32(1.0) - np.float32(2.0) * (np.float32(1.0) - x) * (np.float32(1.0) - x),
+             102: lambda x: np.float32(0.0) if x < np.float32(0.3) else np.float32(1.0)}
+
+
+@pytest.mark.parametrize("which", [100, 101, 102])
+def test_callable_interpolators_through_a_table(fa, which):
+    """An Interpolator built from a user's callable (Utility/Interpolator.h) in modify_time / modify_frequency / repitch / desample / modify:
+    the library reads it from a 65536-interval table (flanhip_interp_table_create), the checker calls the function itself (its kinds
+    100-102 are the same three functions: x^2, a two-piece quadratic ease, a step at 0.3).  The table is exact at its sample points and
+    within 3e-11 max|f''| between them, so nearly every MF comes out identical; a mix that differs in its last bit can flip a "louder
+    wins" decision, and the step smears over one interval (1.5e-5 of the unit range)."""
+    fn = CALLABLES[which]
+    rng = np.random.default_rng(300 + which)
+    hop, dft, W = 256, 1024, 1024
+    x = O.noise(2, 30 * hop + 11, seed=400 + which)
+    pv = O.analyze(x, SR, W, hop, dft)
+    pv[..., 0] *= rng.uniform(0, 1, pv.shape[:3]) < 0.8
+    ch, F, bins, _ = pv.shape
+    floor = 0.995 if which == 102 else 0.999
+
+    def agree(got, ref, what):
+        assert got.shape == ref.shape, what
+        close = np.isclose(got, ref, rtol=3e-6, atol=1e-6)
+        same = np.mean(got.view(np.uint32) == ref.view(np.uint32))
+        print("\n[callable %d] %-28s identical %.5f  close %.5f" % (which, what, same, close.mean()))
+        assert close.mean() >= floor, (what, close.mean())
+
+    with fa.InterpTable(fn) as table:
+        assert table.kind >= 16
+        hop_s = hop / SR
+        for name, mod in (("x1.7", O.stretch_map(np.full((F, bins), 1.7, np.float32), SR, hop)),
+                          ("backwards", (rng.uniform(-2, F + 2, (F, bins)) * hop_s).astype(np.float32))):
+            agree(fa.modify_time_interp(pv, SR, hop, mod, table.kind), O.modify_time(pv, SR, hop, mod, which), "modify_time/" + name)
+        f_of_bin = (np.arange(bins, dtype=np.float32) * np.float32(SR / dft))[None, :] * np.ones((F, 1), np.float32)
+        inmod = (pv[..., 1] * np.float32(1.1)).astype(np.float32)
+        mod = (f_of_bin * np.float32(1.3)).astype(np.float32)
+        agree(fa.modify_frequency_interp(pv, SR, mod, inmod, table.kind), O.modify_frequency(pv, SR, mod, inmod, which), "modify_frequency/x1.3")
+        g = rng.uniform(0.5, 2.0, (F, bins)).astype(np.float32)
+        agree(fa.repitch(pv, SR, g, table.kind), O.repitch(pv, SR, g, which), "repitch")
+        for name, ratio in (("const0.25", 0.25), ("random", rng.uniform(-0.2, 1.2, (F, bins)).astype(np.float32))):
+            agree(fa.desample(pv, ratio, table.kind), O.desample(pv, ratio, which), "desample/" + name)
+        # the general warp: a gentle bend of the (time, frequency) plane
+        t = (np.arange(F, dtype=np.float32) * np.float32(hop_s))[:, None] * np.ones((1, bins), np.float32)
+        grid = np.stack([t * np.float32(1.5) + np.float32(0.002) * np.sin(f_of_bin / 3000.0).astype(np.float32), f_of_bin * np.float32(1.1)], axis=-1).astype(np.float32)
+        grid = np.ascontiguousarray(grid)
+        Fo = O.modify_out_frames(grid, SR, hop)
+        in_f = rng.uniform(0, 24000, (ch, F, bins)).astype(np.float32)
+        agree(fa.modify(pv, SR, hop, grid, in_f, table.kind, Fo), O.modify(pv, SR, hop, grid, in_f, which, Fo), "modify/bend")
+        kind = table.kind
+    with pytest.raises(fa.FlanHipError):                 # destroyed: the kind is no longer valid
+        fa.desample(pv, 0.25, kind)
