@@ -53,6 +53,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--gather-chunks", type=int, default=1, help="channel chunks per batch in the overlapped all-gather measurement (1: whole batches, double buffered)")
     ap.add_argument("--no-configs", action="store_true", help="skip the 'configs' object (BASELINE configs 3 and 5, the API-default dft 4096 call)")
+    ap.add_argument("--kernel-variant", default="", help="diagnostic: WHICH=VARIANT[,..] for flanhip_debug_kernel_variant (A/B of kernel generations; never for the metric)")
     ap.add_argument("--unfused", action="store_true", help="run synthesis' pre-pass as its own kernel instead of inside analysis")
     ap.add_argument("--preroll-ms", type=float, default=80.0,
                     help="untimed device warm-up before the W warm-up steps: the same steps run for this long so that the GPU's clocks "
@@ -181,6 +182,9 @@ def main():
     dev_index = 0 if share_gpu else local_rank
     torch.cuda.set_device(dev_index)
     fa.check(fa.lib.flanhip_set_device(dev_index))
+    for kv in filter(None, args.kernel_variant.split(",")):
+        which, variant = (int(v) for v in kv.split("="))
+        fa.lib.flanhip_debug_kernel_variant(which, variant)
     dev = torch.device("cuda", dev_index)
     dist = None
     if distributed:

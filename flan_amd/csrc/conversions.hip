@@ -6,6 +6,7 @@
 #include "pv_kernels_fast.h"
 #include <type_traits>
 #include "pv_kernels_v2.h"
+#include "pv_kernels_eo.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -18,6 +19,7 @@ static int g_synth_stage_mask = 0xF;             // flanhip_debug_synth_stages()
 // synthesis (register-accumulator hops): 0 = round-1 kernel; 1 (the default) = v2; 2 = v2 behind the scan kernel even where it could work
 // out its own carries; 9 = v2 with plain instead of non-temporal row loads
 static int g_ana_variant = 4, g_syn_variant = 1;
+static int g_ana11_variant = 1;          // dft 4096, window <= 2048: 1 = teams of two wavefronts, two 1024-point transforms per frame (pv_kernels_eo.h), 0 = the round-1 kernel
 static int ana_variant_waves( int ) { return 8; }
 static constexpr size_t kMaxLds = 160 * 1024;   // gfx950: 160 KiB LDS per CU, one workgroup may take all of it
 
@@ -113,6 +115,37 @@ static int run_analyze_v2_variant( int v, const AnalyzeParams & p, const FastTab
 #endif
 		}
 	return FLANHIP_ERR_UNSUPPORTED;
+	}
+
+// dft 4096 with window <= 2048 as two 1024-point register transforms per frame (pv_kernels_eo.h): 8-wave blocks, 160 KB of LDS
+template<int WAVES, bool SUMS, int QV = 2>
+static int run_analyze_eo( const AnalyzeParams & p, const FastTables & tb, hipStream_t s )
+	{
+	const size_t lds = EoLds::bytes( WAVES );
+	static_assert( EoLds::bytes( WAVES ) <= kMaxLds, "LDS budget" );
+	auto kern = k_analyze_eo<WAVES, SUMS, QV>;
+	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;
+	const int64_t blocks = ( chains + WAVES - 1 ) / WAVES;
+	FLANHIP_REQUIRE( blocks < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
+	hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( 64 * WAVES ), lds, s, p, tb );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+template<int TEAMS, bool SUMS, int QV, bool DOUBLE = false>
+static int run_analyze_eo_team( const AnalyzeParams & p, const FastTables & tb, hipStream_t s )
+	{
+	const size_t lds = EoLds::bytes( DOUBLE ? 2 * TEAMS : TEAMS );             // a team's two wavefronts share one E and one O buffer (or two of each)
+	static_assert( EoLds::bytes( DOUBLE ? 2 * TEAMS : TEAMS ) <= kMaxLds, "LDS budget" );
+	auto kern = k_analyze_eo_team<TEAMS, SUMS, QV, DOUBLE>;
+	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;
+	const int64_t blocks = ( chains + TEAMS - 1 ) / TEAMS;
+	FLANHIP_REQUIRE( blocks < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
+	hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( 128 * TEAMS ), lds, s, p, tb );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
 	}
 
 template<int LOG2C, int WAVES, bool SUMS>
@@ -224,7 +257,9 @@ int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int 
 	p.n = n; p.F = n / hop + 1;                                   // AudioPV.cpp:17
 	p.num_channels = int( ch ); p.window_size = W; p.hop = hop;
 	const bool fast = ( dft == 2048 || dft == 4096 ) && n >= 2 && n < ( int64_t( 1 ) << 31 ) - 8192 && !force_generic();
-	p.L = choose_chain_length( ch, p.F, 1, fast ? fast_target_chains( dft, false ) : generic_target_chains( dft ) );
+	int target_chains = fast ? fast_target_chains( dft, false ) : generic_target_chains( dft );
+	if( fast && dft == 4096 && W <= 2048 && g_ana11_variant != 0 && g_ana11_variant != 3 && !d_fused_ws ) target_chains = 256 * 8;   // k_analyze_eo: 8 one-wavefront chains per CU
+	p.L = choose_chain_length( ch, p.F, 1, target_chains );
 	p.chains_per_channel = int( ( p.F + p.L - 1 ) / p.L );
 	p.sample_rate = sr;
 	p.analysis_rate = sr / hop;                                   // AudioPV.cpp:26 (float / int)
@@ -274,6 +309,16 @@ int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int 
 		{
 		FastTables tb{ plan->d_tw1f, plan->d_tw3f, plan->d_tw2 };
 		if( dft == 2048 && g_ana_variant != 0 ) return p.sums ? run_analyze_v2_variant<true>( g_ana_variant, p, tb, s ) : run_analyze_v2_variant<false>( g_ana_variant, p, tb, s );
+		if( dft == 4096 && W <= 2048 && g_ana11_variant != 0 )
+			{
+			// the fused round trip (with chain sums): teams of two wavefronts, two E / O buffer sets, one barrier per frame (0.34 ms for 8 ch x 60 s;
+			// one set and two barriers: 0.365; the round-1 kernel: 0.44).  Without sums one wavefront per chain is faster still (0.27 against 0.34:
+			// no barriers) and does not spill.  Variants 2.. are A/B builds of the same kernels.
+			if( !p.sums && g_ana11_variant != 3 ) return run_analyze_eo<8, false, 2>( p, tb, s );
+			if( g_ana11_variant == 2 ) return run_analyze_eo_team<4, true, 2, false>( p, tb, s );
+			if( g_ana11_variant == 3 ) return p.sums ? run_analyze_eo_team<4, true, 1, true>( p, tb, s ) : run_analyze_eo_team<4, false, 2, true>( p, tb, s );
+			return run_analyze_eo_team<4, true, 2, true>( p, tb, s );
+			}
 		if( p.sums ) return dft == 2048 ? run_analyze_fast<10, kAnaWaves10, true>( p, tb, s ) : run_analyze_fast<11, kWaves11, true>( p, tb, s );
 		return dft == 2048 ? run_analyze_fast<10, kAnaWaves10, false>( p, tb, s ) : run_analyze_fast<11, kWaves11, false>( p, tb, s );
 		}
@@ -491,7 +536,7 @@ int flanhip_analyze( const float * audio, int64_t ch, int64_t n, float sr, int W
 	}
 
 void flanhip_debug_synth_stages( int mask ) { g_synth_stage_mask = mask & 0xF; }
-void flanhip_debug_kernel_variant( int which, int variant ) { if( which == 0 ) g_ana_variant = variant; else g_syn_variant = variant; }
+void flanhip_debug_kernel_variant( int which, int variant ) { if( which == 0 ) g_ana_variant = variant; else if( which == 2 ) g_ana11_variant = variant; else g_syn_variant = variant; }
 #ifdef FLANHIP_STAMPS
 // diagnostic build only: the per-section cycle sums of the stamped kernels (16 words; [15] = wavefronts that reported), then cleared
 int flanhip_debug_read_stamps( unsigned long long * out16 )

@@ -1,0 +1,692 @@
+// pv_kernels_eo.h -- dft 4096 (the reference API's default dft_size) with window <= 2048: analysis as TWO 1024-point register transforms
+// per frame and wavefront instead of one 2048-point one.
+//
+// The round-1 kernel for this size (pv_kernels_fast.h, LOG2C = 11) keeps the 2048 complex points of a frame in registers: 32 per lane,
+// ~400 registers with the per-bin state, one wavefront per SIMD, and 17.4 KB of LDS per wavefront beside 49 KB of tables -- nothing
+// hides its LDS round trips and memory waits (0.23 of the HBM roofline against the dft 2048 kernels' 0.38).  Here the frame's packed
+// complex sequence c[n] = x[2n] + i x[2n+1] (n < 2048, zero from W/2 on) is split by parity:
+//        E = FFT1024( c[2m] ),  O = FFT1024( c[2m+1] ),      Z[k] = E[k] + w^k O[k],   Z[k+1024] = E[k] - w^k O[k],   w = exp( -2 pi i / 2048 )
+// each half the dft 2048 kernel's own register transform (fft_fast<10>, 16 points per lane, the upper half of its input zero because
+// the window is at most half the transform).  A lane owns the QUADS  k = lane + 64 q, q < 8:  from E[k], O[k] (its own registers) and
+// E[1024-k], O[1024-k] (the mirror lane's, through LDS) come Z[k], Z[1024+k], Z[1024-k], Z[2048-k], i.e. the two mirror pairs
+// ( k, 2048-k ) and ( 1024-k, 1024+k ) of the real-transform split: 4 bins per quad, 32 per lane, with the dft 2048 kernel's per-bin
+// code (polar_v, exact divisions, pv_kernels_v2.h).  Register budget and LDS per wavefront (2 x 8.7 KB) are the dft 2048 kernel's, so
+// blocks of 8 wavefronts = 2 per SIMD fit (160 KB of LDS exactly, with the 20 KB of tables).
+//   lane 0, q = 0: the quad degenerates to bins 0, 2048 (from Z[0]) and 1024 (= conj Z[1024], computed twice);
+//   k = 512: bins 512 and 1536, one pair, carried redundantly by every lane and stored by lane 0.
+#pragma once
+#include "pv_kernels_v2.h"
+
+#ifndef EO_EXP
+#define EO_EXP 0
+#endif
+
+namespace flanhip {
+
+struct EoLds
+	{
+	static constexpr int C = 1024;
+	static constexpr int TW1 = 0;                          // [15][16]
+	static constexpr int TW3 = TW1 + 240;                  // [3][256] for 1024 points
+	static constexpr int TWQ = TW3 + 768;                  // [512] float4 { 0.5 cos, -0.5 sin of 2 pi k / 4096 ; cos, -sin of 2 pi k / 2048 }
+	static constexpr int WIN = TWQ + 1024;                 // [2048 floats], zero beyond W
+	static constexpr int BUF = WIN + 1024;
+	static constexpr int BUF_LEN = C + C / 16 + 1;         // one half transform; a wavefront has two
+	static constexpr size_t bytes( int waves ) { return size_t( BUF + waves * 2 * BUF_LEN ) * 8; }
+	};
+
+// the real-transform split of one mirror pair ( j, N - j ): X[j] and X[N-j] from Z[j] = zk, Z[N-j] = zm and w = 0.5 exp( -2 pi i j / 2N )
+__device__ __forceinline__ void split_pair( cf zk, cf zm, float wx, float wy, float & rk, float & ik, float & rm, float & im )
+	{
+	const float sx = zk.x + zm.x, dy = zk.y + zm.y, dx = zk.x - zm.x, sy = zk.y - zm.y;
+	const float t1v = __builtin_fmaf( wx, dy, wy * dx );
+	const float t2v = __builtin_fmaf( wx, dx, -( wy * dy ) );
+	rk = __builtin_fmaf( 0.5f, sx, t1v );  ik = __builtin_fmaf( 0.5f, sy, -t2v );
+	rm = __builtin_fmaf( 0.5f, sx, -t1v ); im = __builtin_fmaf( -0.5f, sy, -t2v );
+	}
+
+template<int WAVES, bool SUMS, int QV = 2>      // QV: quads (of 4 bins) evaluated together as one vector stream
+__global__ __launch_bounds__( 64 * WAVES ) void k_analyze_eo( AnalyzeParams p, FastTables tb )
+	{
+	using L = EoLds;
+	constexpr int C = 1024, N2 = 2048, Q = 8, NT = 64 * WAVES;
+	typedef float VB __attribute__(( ext_vector_type( 4 * QV ) ));
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	cf * s = reinterpret_cast<cf*>( smem );
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int W = p.window_size, hop = p.hop;
+
+	// ---- tables (block-wide): the plan's tables are those of the 2048-point transform (tb.tw3: [7][256] exp( -2 pi i r j / 2048 ),
+	// tb.w2: exp( -2 pi i k / 4096 )); the 1024-point ones are every other row / entry of them
+	for( int i = tid; i < 240; i += NT ) s[L::TW1 + i] = tb.tw1[i];
+	for( int i = tid; i < 768; i += NT ) s[L::TW3 + i] = tb.tw3[( 2 * ( i >> 8 ) + 1 ) * 256 + ( i & 255 )];
+		{
+		v4f_t * twq = reinterpret_cast<v4f_t*>( s + L::TWQ );
+		for( int k = tid; k < 512; k += NT ) { const cf a = tb.w2[k], b = tb.w2[2 * k]; twq[k] = v4f_t{ 0.5f * a.x, 0.5f * a.y, b.x, b.y }; }
+		float * win = reinterpret_cast<float*>( s + L::WIN );
+		for( int i = tid; i < 2048; i += NT ) win[i] = ( i < W ) ? p.window[i] : 0.0f;            // AudioPV.cpp:60,65
+		}
+	__syncthreads();
+	const cf * s_tw1 = s + L::TW1;
+	const cf * s_tw3 = s + L::TW3;
+	const v4f_t * s_twq = reinterpret_cast<const v4f_t*>( s + L::TWQ ) + lane;
+	const v4f_t * s_win = reinterpret_cast<const v4f_t*>( s + L::WIN ) + lane;
+	cf * bufE = s + L::BUF + wave * 2 * L::BUF_LEN;
+	cf * bufO = bufE + L::BUF_LEN;
+
+	const int64_t chain = int64_t( blockIdx.x ) * WAVES + wave;
+	if( chain >= int64_t( p.chains_per_channel ) * p.num_channels ) return;   // no block barrier below
+	const int channel = int( chain / p.chains_per_channel );
+	const int64_t t0 = int64_t( chain % p.chains_per_channel ) * p.L;
+	const int64_t t1 = min( t0 + int64_t( p.L ), p.F );
+	const float * x = p.audio + int64_t( channel ) * p.n;
+	const bool use_wrapping = p.analysis_rate < p.sample_rate;                // phase_vocoder.cpp:37
+	const int padl = lane + ( lane >> 4 );
+	const int mir = ( C * 17 ) / 16 - ( lane + ( ( lane + 15 ) >> 4 ) );      // mirror slot of this lane: buf[mir - 68 q] = slot PAD( C - lane - 64 q )
+	const cf * mirrorE = bufE + mir;
+	const cf * mirrorO = bufO + mir;
+	const int n32 = int( p.n );
+	const float rdft = 1.0f / float( 2 * N2 );
+	const float flane = float( lane );
+
+	// state that crosses frames: previous phases (phase_vocoder.cpp:45) of the lane's 8 quads -- [q][0..3] = bins k, 2048-k, 1024-k,
+	// 1024+k -- and of bins 512, 1536
+	float prev[Q][4], prevs[2] = { 0.0f, 0.0f };
+	#pragma unroll
+	for( int q = 0; q < Q; ++q ) { prev[q][0] = 0.0f; prev[q][1] = 0.0f; prev[q][2] = 0.0f; prev[q][3] = 0.0f; }   // AudioPV.cpp:44
+	// Fused round trip: the chain's sum of phase increments (phase_vocoder.cpp:57-58), modulo pi2, for convert_to_audio.  68 registers of
+	// fp64 sums do not fit beside the transform (they spill, and spills break the counted waits), so the sum is TELESCOPED: an increment is
+	// the float  term = ( f / analysis_rate ) pi2,  and  term - ( phase_t - phase_{t-1} )  is a whole number of turns plus the rounding
+	// of f and term (~1e-4 rad).  Per bin only  R = sum_t [ term_t - ( phase_t - phase_{t-1} ) ] mod pi2  is kept, in ONE float (every
+	// r_t is formed in fp64 and is tiny, so the float sum is good to ~1e-11 rad); the chain's sum is  phase_last - phase_first + R  (mod pi2),
+	// with phase_first parked in the workspace row the result goes to.
+	float rs[SUMS ? Q : 1][4], rs2[2] = { 0.0f, 0.0f };
+	if constexpr( SUMS )
+		{
+		#pragma unroll
+		for( int q = 0; q < Q; ++q ) { rs[q][0] = 0.0f; rs[q][1] = 0.0f; rs[q][2] = 0.0f; rs[q][3] = 0.0f; }
+		}
+	auto residue = []( float term, float phase, float before ) -> float
+		{
+		const double d = double( term ) - ( double( phase ) - double( before ) );
+		const double n = __builtin_rint( d * ( 1.0 / FLANHIP_PI2_D ) );
+		return float( __builtin_fma( -n, FLANHIP_PI2_D, d ) );
+		};
+	float mmax = 0.0f;
+
+	const int64_t tfirst = t0 > 0 ? t0 - 1 : t0;
+	const bool chain_fast = W == 2048 && int64_t( hop ) * tfirst - W / 2 >= 0 && int64_t( hop ) * ( t1 - 1 ) - W / 2 + 2048 <= p.n;
+
+	// samples 4 i .. 4 i + 3 of frame t, i = lane + 64 q: c[2i] = ( x[4i], x[4i+1] ) is the even transform's point i, c[2i+1] the odd one's.
+	// The even halves are requested during the per-bin work of the frame before; the odd halves only when the even transform starts (it
+	// covers their latency) -- 16 registers less across the per-bin work than requesting all of a frame at once.
+	cf raw_e[Q], raw_o[Q];
+	auto run_chain = [&]( auto fast_tag )
+		{
+		constexpr bool FAST = decltype( fast_tag )::value;
+		struct __attribute__(( packed, aligned( 4 ) )) f2u { float x, y; };
+		auto load_half = [&]( int64_t t, int odd, cf ( &dst )[Q] )
+			{
+			const int start = int( int64_t( hop ) * t - W / 2 ) + 2 * odd;
+			#pragma unroll
+			for( int q = 0; q < Q; ++q )
+				{
+				const int a = start + 4 * ( lane + 64 * q );
+				if constexpr( FAST )
+					{
+					const f2u v = *reinterpret_cast<const f2u*>( x + a );
+					dst[q] = mk( v.x, v.y );
+					}
+				else
+					{
+					// edge chains (the first and the last of a channel): every sample on its own, zero outside the signal (AudioPV.cpp:54-62)
+					// and beyond the window (:65: zero, not sample x 0)
+					const int w0 = 4 * ( lane + 64 * q ) + 2 * odd;
+					const float v0 = ( a >= 0 && a < n32 && w0 < W ) ? x[a] : 0.0f;
+					const float v1 = ( a + 1 >= 0 && a + 1 < n32 && w0 + 1 < W ) ? x[a + 1] : 0.0f;
+					dst[q] = mk( v0, v1 );
+					}
+				}
+			};
+		// window (AudioPV.cpp:60), the two transforms; leaves E and O in natural order in bufE / bufO (a lane's own E[k], O[k] too: 32
+		// registers less across the per-bin work than keeping them)
+		auto transform_frame = [&]( int64_t t )
+			{
+			load_half( t, 1, raw_o );                                             // travels under the even transform
+			cf z[16];
+			#pragma unroll
+			for( int q = 0; q < Q; ++q )
+				{
+				const v4f_t wv = s_win[64 * q];
+				z[q] = mk( raw_e[q].x * wv.x, raw_e[q].y * wv.y );
+				z[Q + q] = mk( 0.0f, 0.0f );
+				}
+			fft_fast<10, NoStamp, !SUMS>( z, bufE, s_tw1, s_tw3, lane );
+			#pragma unroll
+			for( int q = 0; q < 2 * Q; ++q ) bufE[padl + 68 * q] = z[q];              // natural order: slot PAD( lane + 64 q )
+			#pragma unroll
+			for( int q = 0; q < Q; ++q )
+				{
+				const v4f_t wv = s_win[64 * q];
+				z[q] = mk( raw_o[q].x * wv.z, raw_o[q].y * wv.w );
+				z[Q + q] = mk( 0.0f, 0.0f );
+				}
+			fft_fast<10, NoStamp, !SUMS>( z, bufO, s_tw1, s_tw3, lane );
+			#pragma unroll
+			for( int q = 0; q < 2 * Q; ++q ) bufO[padl + 68 * q] = z[q];
+			wave_sync();
+			};
+
+		// per-bin work of frame t (requests frame tn's samples first); HALO: frame t0 - 1, of which only the phases are wanted
+		auto bins_of_frame = [&]( int64_t t, int64_t tn, auto halo_tag )
+			{
+			constexpr bool halo = decltype( halo_tag )::value;
+			const cf e512 = bufE[544], o512 = bufO[544];                          // slot PAD( 512 )
+			const cf e0 = bufE[padl], o0 = bufO[padl];                            // lane 0: E[0], O[0]
+			cf * row = reinterpret_cast<cf*>( p.out + ( int64_t( channel ) * p.F + t ) * ( N2 + 1 ) );
+			cf * row_a = row + lane;                                              // bin k          (+ 64 q)
+			cf * row_b = row + ( N2 - lane );                                     // bin 2048 - k   (- 64 q)
+			cf * row_c = row + ( C - lane );                                      // bin 1024 - k   (- 64 q)
+			cf * row_d = row + ( C + lane );                                      // bin 1024 + k   (+ 64 q)
+			#pragma unroll
+			for( int g = 0; g < Q / QV; ++g )
+				{
+				// the next frame's samples are requested half way through: by then half of e[] / o[] is dead and their registers hold the
+				// request (the 16 stores in front of it are long acknowledged when the transform waits for these loads)
+				if( g == Q / QV / 2 ) load_half( tn, 0, raw_e );
+				VB re, im, pv, binf;
+				#pragma unroll
+				for( int i = 0; i < QV; ++i )
+					{
+					const int q = QV * g + i;
+					const cf ek = bufE[padl + 68 * q], ok = bufO[padl + 68 * q];
+					const cf em = mirrorE[-68 * q], om = mirrorO[-68 * q];         // lane 0, q = 0 reads an unused slot: overridden below
+					const v4f_t tw = s_twq[64 * q];
+					// Z[k] = E[k] + w^k O[k], Z[1024+k] = E[k] - w^k O[k];  w^(1024-k) = -conj( w^k ):  Z[1024-k] = E[1024-k] - conj( w^k ) O[1024-k],
+					// Z[2048-k] = E[1024-k] + conj( w^k ) O[1024-k]
+					const float px = __builtin_fmaf( tw.z, ok.x, -( tw.w * ok.y ) ), py = __builtin_fmaf( tw.z, ok.y, tw.w * ok.x );
+					const float qx = __builtin_fmaf( tw.z, om.x, tw.w * om.y ), qy = __builtin_fmaf( tw.z, om.y, -( tw.w * om.x ) );
+					const cf zk = mk( ek.x + px, ek.y + py ), zk2 = mk( ek.x - px, ek.y - py );
+					const cf zm = mk( em.x - qx, em.y - qy ), zm2 = mk( em.x + qx, em.y + qy );
+					// pair ( k, 2048-k ) with 0.5 exp( -2 pi i k / 4096 ) = ( a, b ); pair ( 1024-k, 1024+k ) with 0.5 exp( -2 pi i ( 1024-k ) / 4096 ) = ( -b, -a )
+					float r0, i0, r1, i1, r2, i2, r3, i3;
+					split_pair( zk, zm2, tw.x, tw.y, r0, i0, r1, i1 );
+					split_pair( zm, zk2, -tw.y, -tw.x, r2, i2, r3, i3 );
+					if( q == 0 )
+						{
+						const bool l0 = lane == 0;
+						const cf z0 = mk( e0.x + o0.x, e0.y + o0.y ), zc = mk( e0.x - o0.x, e0.y - o0.y );   // Z[0], Z[1024]
+						r0 = l0 ? z0.x + z0.y : r0;  i0 = l0 ? 0.0f : i0;               // X[0]
+						r1 = l0 ? z0.x - z0.y : r1;  i1 = l0 ? 0.0f : i1;               // X[2048]
+						r2 = l0 ? zc.x : r2;  i2 = l0 ? -zc.y : i2;                     // X[1024] = conj Z[1024] ...
+						r3 = l0 ? zc.x : r3;  i3 = l0 ? -zc.y : i3;                     // ... twice (the quad's fourth bin is the same bin)
+						}
+					re[4 * i + 0] = r0; im[4 * i + 0] = i0; re[4 * i + 1] = r1; im[4 * i + 1] = i1;
+					re[4 * i + 2] = r2; im[4 * i + 2] = i2; re[4 * i + 3] = r3; im[4 * i + 3] = i3;
+					const float fk = flane + float( 64 * q );
+					binf[4 * i + 0] = fk * p.sample_rate * rdft;                                    // PVBuffer.cpp:443-446 (the division by dft is exact)
+					binf[4 * i + 1] = ( float( N2 ) - fk ) * p.sample_rate * rdft;
+					binf[4 * i + 2] = ( float( C ) - fk ) * p.sample_rate * rdft;
+					binf[4 * i + 3] = ( float( C ) + fk ) * p.sample_rate * rdft;
+					#pragma unroll
+					for( int j = 0; j < 4; ++j ) pv[4 * i + j] = prev[q][j];
+					}
+				// phase_vocoder.cpp:37-52 (AudioPV.cpp:69-73)
+				VB phase, m;
+				polar_v( re, im, phase, m );
+				#pragma unroll
+				for( int i = 0; i < QV; ++i )
+					{
+					#pragma unroll
+					for( int j = 0; j < 4; ++j ) prev[QV * g + i][j] = phase[4 * i + j];          // :45
+					}
+				if constexpr( !halo )
+					{
+					const VB expd = div_c_v( binf, p.ar_div ) * vsplat<VB>( FLANHIP_PI2_F );       // :47
+					const VB phase_diff = phase - pv;                                            // == float( double(phase) - double(prev) ), :44
+					const VB delta_phase = phase_diff - expd;                                    // :47-48
+					VB wrapped = delta_phase;
+					if( use_wrapping ) wrapped = delta_phase - vsplat<VB>( FLANHIP_PI2_F ) * round_half_away_v( div_pi2_v( delta_phase ) );   // :39-42,49
+					const VB f = binf + div_pi2_v( wrapped * vsplat<VB>( p.analysis_rate ) );      // :50-52
+					#pragma unroll
+					for( int i = 0; i < QV; ++i )
+						{
+						const int q = QV * g + i;
+						__builtin_nontemporal_store( cf{ m[4 * i + 0], f[4 * i + 0] }, row_a + 64 * q );
+						__builtin_nontemporal_store( cf{ m[4 * i + 1], f[4 * i + 1] }, row_b - 64 * q );
+						__builtin_nontemporal_store( cf{ m[4 * i + 2], f[4 * i + 2] }, row_c - 64 * q );
+						__builtin_nontemporal_store( cf{ m[4 * i + 3], f[4 * i + 3] }, row_d + 64 * q );
+						}
+					if constexpr( SUMS )
+						{
+						const VB term = div_c_v( f, p.ar_div ) * vsplat<VB>( FLANHIP_PI2_F );      // phase_vocoder.cpp:57-58
+						#pragma unroll
+						for( int i = 0; i < QV; ++i )
+							{
+							#pragma unroll
+#if EO_EXP & 1
+							for( int j = 0; j < 4; ++j ) rs[QV * g + i][j] += term[4 * i + j];
+#else
+							for( int j = 0; j < 4; ++j ) rs[QV * g + i][j] += residue( term[4 * i + j], phase[4 * i + j], pv[4 * i + j] );
+#endif
+							}
+						#pragma unroll
+						for( int i = 0; i < 4 * QV; i += 2 ) mmax = __builtin_fmaxf( mmax, __builtin_fmaxf( m[i], m[i + 1] ) );
+						}
+					}
+				}
+				{
+				// k = 512: Z[512] = E[512] - i O[512], Z[1536] = E[512] + i O[512]; bins 512 and 1536 are one mirror pair with
+				// 0.5 exp( -i pi / 4 ); every lane carries the same values, lane 0 stores them
+				const cf zk = mk( e512.x + o512.y, e512.y - o512.x ), zm = mk( e512.x - o512.y, e512.y + o512.x );
+				float r[2], im2[2];
+				split_pair( zk, zm, 0.35355339059327379f, -0.35355339059327379f, r[0], im2[0], r[1], im2[1] );
+				#pragma unroll
+				for( int j = 0; j < 2; ++j )
+					{
+					const float phase = atan2_fast( im2[j], r[j] );
+					const float pvx = prevs[j];
+					prevs[j] = phase;
+					if constexpr( !halo )
+						{
+						const float bx = float( j == 0 ? 512 : 1536 ) * p.sample_rate * rdft;
+						const float delta_phase = ( phase - pvx ) - div_c( bx, p.ar_div ) * FLANHIP_PI2_F;
+						const float wrapped = use_wrapping ? delta_phase - FLANHIP_PI2_F * round_half_away( div_pi2( delta_phase ) ) : delta_phase;
+						const float f = bx + div_pi2( wrapped * p.analysis_rate );
+						const float m = magnitude_scaled( r[j], im2[j] );
+						if( lane == 0 ) __builtin_nontemporal_store( mk( m, f ), row + ( j == 0 ? 512 : 1536 ) );
+						if constexpr( SUMS )
+							{
+							rs2[j] += residue( div_c( f, p.ar_div ) * FLANHIP_PI2_F, phase, pvx );
+							mmax = __builtin_fmaxf( mmax, m );
+							}
+						}
+					}
+				}
+			wave_sync();                                                          // the mirror halves are read: the next transform may overwrite them
+			};
+
+		load_half( tfirst, 0, raw_e );
+		transform_frame( tfirst );
+		if( t0 > 0 )
+			{
+			bins_of_frame( t0 - 1, t0, std::true_type{} );
+			transform_frame( t0 );
+			}
+		if constexpr( SUMS && !( EO_EXP & 2 ) )
+			{
+			// phase_first (zero for the first chain of a channel, AudioPV.cpp:44) waits in the workspace row of this chain's sums
+			double * dst = p.sums + chain * ( N2 + 1 );
+			#pragma unroll
+			for( int q = 0; q < Q; ++q )
+				{
+				const int k = lane + 64 * q;
+				dst[k] = double( prev[q][0] ); dst[N2 - k] = double( prev[q][1] );
+				if( k != 0 ) { dst[C - k] = double( prev[q][2] ); dst[C + k] = double( prev[q][3] ); }
+				else dst[C] = double( prev[q][2] );
+				}
+			if( lane == 0 ) { dst[512] = double( prevs[0] ); dst[1536] = double( prevs[1] ); }
+			}
+		for( int64_t t = t0; t < t1; ++t )
+			{
+			bins_of_frame( t, min( t + 1, t1 - 1 ), std::false_type{} );          // (the last frame requests itself again: nobody waits for it)
+			if( t + 1 < t1 ) transform_frame( t + 1 );
+			}
+		};
+	if( chain_fast ) run_chain( std::true_type{} ); else run_chain( std::false_type{} );
+
+	if constexpr( SUMS && ( EO_EXP & 2 ) )
+		{
+		double * dst = p.sums + chain * ( N2 + 1 );
+		#pragma unroll
+		for( int q = 0; q < Q; ++q ) dst[lane + 64 * q] = double( rs[q][0] + rs[q][1] + rs[q][2] + rs[q][3] + prev[q][0] + prev[q][1] + prev[q][2] + prev[q][3] ) + rs2[0] + rs2[1] + mmax;
+		}
+	if constexpr( SUMS && !( EO_EXP & 2 ) )
+		{
+		// the chain's sum = phase_last - phase_first + R, brought into [0, pi2) (the value k_phase_sums2 would fold to, up to ~1e-11 rad and,
+		// for a sum that is negative as a whole, one turn of the float constant pi2 = 2 pi + 1.7e-7)
+		bool bad = !( mmax <= 3.4028235e38f );
+		auto total = [&]( double first, float last, float r ) -> double
+			{
+			bad |= !( __builtin_fabsf( r ) <= 3.4028235e38f );                       // a NaN / Inf frequency poisons its residue
+			const double v = ( double( last ) - first ) + double( r );
+			const double w = __builtin_fma( -__builtin_floor( v * ( 1.0 / FLANHIP_PI2_D ) ), FLANHIP_PI2_D, v );
+			return w < 0.0 ? w + FLANHIP_PI2_D : ( w >= FLANHIP_PI2_D ? w - FLANHIP_PI2_D : w );
+			};
+		double * dst = p.sums + chain * ( N2 + 1 );
+		#pragma unroll
+		for( int q = 0; q < Q; ++q )
+			{
+			const int k = lane + 64 * q;
+			const double a = total( dst[k], prev[q][0], rs[q][0] ), b = total( dst[N2 - k], prev[q][1], rs[q][1] );
+			const double c = total( dst[C - k], prev[q][2], rs[q][2] );
+			dst[k] = a; dst[N2 - k] = b; dst[C - k] = c;
+			if( k != 0 ) dst[C + k] = total( dst[C + k], prev[q][3], rs[q][3] );   // (lane 0, q = 0: the quad's fourth bin is bin 1024 again)
+			}
+		if( lane == 0 ) { dst[512] = total( dst[512], prevs[0], rs2[0] ); dst[1536] = total( dst[1536], prevs[1], rs2[1] ); }
+		const bool any_bad = __any( bad );
+		if( p.nan_out && lane == 0 )
+			{
+			if( chain == 0 ) { p.nan_out[2] = p.nan_epoch; p.nan_out[4] = p.nan_epoch; }
+			if( any_bad ) p.nan_out[0] = p.nan_epoch;
+			}
+		}
+	}
+
+// =================================================================================================================
+// The same decomposition with a TEAM of two wavefronts per chain: wavefront 0 of a team transforms the even points and then owns the
+// quads k < 256, wavefront 1 the odd points and the quads 256 <= k < 512 (and k = 512).  Per frame a wavefront does exactly what the
+// dft 2048 kernel's wavefront does -- one 1024-point register transform and 16 bins -- so its registers (16 previous phases, 16 chain
+// sum residues instead of 32 + 32) fit the fused round trip's sums without spilling, which the one-wavefront form above does not
+// (its SUMS instantiation spills 400+ bytes per lane and drains the memory queue every frame: 0.70 ms against 0.27 ms without sums).
+// The two halves meet in the team's E / O buffers: two LDS-only block barriers per frame (every team of the block walks the same number
+// of iterations, idle ones included; the barrier does not wait for global stores).
+__device__ __forceinline__ void lds_block_sync()
+	{
+	asm volatile( "s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory" );
+	}
+
+template<int TEAMS, bool SUMS, int QV = 2, bool DOUBLE = false>   // DOUBLE: two E / O buffer sets per team, ONE barrier per frame
+__global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParams p, FastTables tb )
+	{
+	using L = EoLds;
+	constexpr int C = 1024, N2 = 2048, Q = 4, NT = 128 * TEAMS;            // Q: quads per lane of ONE wavefront
+	typedef float VB __attribute__(( ext_vector_type( 4 * QV ) ));           // QV quads (4 bins each) as one vector stream
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	cf * s = reinterpret_cast<cf*>( smem );
+	// the wavefront's number as a SCALAR (the compiler cannot see that threadIdx.x >> 6 is uniform): chain, frame range, role and the
+	// audio pointer derived from it then live in scalar registers, the sample loads take a scalar base, the branches on them are scalar
+	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane( tid >> 6 ), team = wave >> 1, role = wave & 1;
+	const int W = p.window_size, hop = p.hop;
+
+	for( int i = tid; i < 240; i += NT ) s[L::TW1 + i] = tb.tw1[i];
+	for( int i = tid; i < 768; i += NT ) s[L::TW3 + i] = tb.tw3[( 2 * ( i >> 8 ) + 1 ) * 256 + ( i & 255 )];
+		{
+		v4f_t * twq = reinterpret_cast<v4f_t*>( s + L::TWQ );
+		for( int k = tid; k < 512; k += NT ) { const cf a = tb.w2[k], b = tb.w2[2 * k]; twq[k] = v4f_t{ 0.5f * a.x, 0.5f * a.y, b.x, b.y }; }
+		float * win = reinterpret_cast<float*>( s + L::WIN );
+		for( int i = tid; i < 2048; i += NT ) win[i] = ( i < W ) ? p.window[i] : 0.0f;            // AudioPV.cpp:60,65
+		}
+	__syncthreads();
+	const cf * s_tw1 = s + L::TW1;
+	const cf * s_tw3 = s + L::TW3;
+	const v4f_t * s_twq = reinterpret_cast<const v4f_t*>( s + L::TWQ ) + lane + 256 * role;   // this wavefront's quads: k = lane + 64 ( 4 role + q )
+	const v4f_t * s_win = reinterpret_cast<const v4f_t*>( s + L::WIN ) + lane;
+	cf * const buf0 = s + L::BUF + team * ( DOUBLE ? 4 : 2 ) * L::BUF_LEN;     // set b: E at buf0 + 2 b BUF_LEN, O behind it
+
+	const int64_t chain_raw = int64_t( blockIdx.x ) * TEAMS + team;
+	const bool active = chain_raw < int64_t( p.chains_per_channel ) * p.num_channels;
+	const int64_t chain = active ? chain_raw : 0;
+	const int channel = int( chain / p.chains_per_channel );
+	const int64_t t0 = int64_t( chain % p.chains_per_channel ) * p.L;
+	const int64_t t1 = min( t0 + int64_t( p.L ), p.F );
+	const float * x = p.audio + int64_t( channel ) * p.n;
+	const bool use_wrapping = p.analysis_rate < p.sample_rate;                // phase_vocoder.cpp:37
+	const int padl = lane + ( lane >> 4 );
+	const int mir = ( C * 17 ) / 16 - ( lane + ( ( lane + 15 ) >> 4 ) );      // buf[mir - 68 q] = slot PAD( C - lane - 64 q )
+	const int n32 = int( p.n );
+	const float rdft = 1.0f / float( 2 * N2 );
+	const float fk0 = float( lane + 256 * role );                             // k of this wavefront's first quad
+
+	float prev[Q][4], prevs[2] = { 0.0f, 0.0f };
+	#pragma unroll
+	for( int q = 0; q < Q; ++q ) { prev[q][0] = 0.0f; prev[q][1] = 0.0f; prev[q][2] = 0.0f; prev[q][3] = 0.0f; }   // AudioPV.cpp:44
+	// the chain sums of the fused round trip, telescoped (see k_analyze_eo)
+	float rs[SUMS ? Q : 1][4], rs2[2] = { 0.0f, 0.0f };
+	if constexpr( SUMS )
+		{
+		#pragma unroll
+		for( int q = 0; q < Q; ++q ) { rs[q][0] = 0.0f; rs[q][1] = 0.0f; rs[q][2] = 0.0f; rs[q][3] = 0.0f; }
+		}
+	auto residue = []( float term, float phase, float before ) -> float
+		{
+		const double d = double( term ) - ( double( phase ) - double( before ) );
+		const double n = __builtin_rint( d * ( 1.0 / FLANHIP_PI2_D ) );
+		return float( __builtin_fma( -n, FLANHIP_PI2_D, d ) );
+		};
+	float mmax = 0.0f;
+
+	const int64_t tfirst = t0 > 0 ? t0 - 1 : t0;
+	const int frames = active ? int( t1 - tfirst ) : 0;                       // iterations with work (the halo frame included)
+	const int iters = p.L + 1;                                                // what every team of every block walks
+	const bool chain_fast = W == 2048 && int64_t( hop ) * tfirst - W / 2 >= 0 && int64_t( hop ) * ( t1 - 1 ) - W / 2 + 2048 <= p.n;
+
+	// phase_first (the phases of frame t0 - 1; zero for the first chain of a channel) waits in the workspace row the chain's sums go to
+	auto park_first_phases = [&]()
+		{
+		double * dst = p.sums + chain * ( N2 + 1 );
+		#pragma unroll
+		for( int q = 0; q < Q; ++q )
+			{
+			const int k = lane + 256 * role + 64 * q;
+			dst[k] = double( prev[q][0] ); dst[N2 - k] = double( prev[q][1] ); dst[C - k] = double( prev[q][2] );
+			if( k != 0 ) dst[C + k] = double( prev[q][3] );
+			}
+		if( role == 1 && lane == 0 ) { dst[512] = double( prevs[0] ); dst[1536] = double( prevs[1] ); }
+		};
+	cf raw[2 * Q];                                                            // this wavefront's half of a frame: points lane + 64 q, q < 8, of its parity
+	auto run_chain = [&]( auto fast_tag )
+		{
+		constexpr bool FAST = decltype( fast_tag )::value;
+		struct __attribute__(( packed, aligned( 4 ) )) f2u { float x, y; };
+		auto load_half = [&]( int64_t t )
+			{
+			const int start = int( int64_t( hop ) * t - W / 2 ) + 2 * role;
+			const float * xs = x + start + 4 * lane + 1024;                       // one address per lane: the eight loads reach -4096 .. +3072 bytes from it (immediates)
+			#pragma unroll
+			for( int q = 0; q < 2 * Q; ++q )
+				{
+				const int a = start + 4 * ( lane + 64 * q );
+				if constexpr( FAST )
+					{
+					const f2u v = *reinterpret_cast<const f2u*>( xs + ( 256 * q - 1024 ) );
+					raw[q] = mk( v.x, v.y );
+					}
+				else
+					{
+					const int w0 = 4 * ( lane + 64 * q ) + 2 * role;                    // zero outside the signal (AudioPV.cpp:54-62) and beyond the window (:65)
+					const float v0 = ( a >= 0 && a < n32 && w0 < W ) ? x[a] : 0.0f;
+					const float v1 = ( a + 1 >= 0 && a + 1 < n32 && w0 + 1 < W ) ? x[a + 1] : 0.0f;
+					raw[q] = mk( v0, v1 );
+					}
+				}
+			};
+		auto transform_frame = [&]( int set )
+			{
+			cf * mybuf = buf0 + ( 2 * set + role ) * L::BUF_LEN;
+			cf z[16];
+			#pragma unroll
+			for( int q = 0; q < 2 * Q; ++q )
+				{
+				const v4f_t wv = s_win[64 * q];
+				z[q] = role ? mk( raw[q].x * wv.z, raw[q].y * wv.w ) : mk( raw[q].x * wv.x, raw[q].y * wv.y );
+				z[2 * Q + q] = mk( 0.0f, 0.0f );
+				}
+			fft_fast<10>( z, mybuf, s_tw1, s_tw3, lane );
+			#pragma unroll
+			for( int q = 0; q < 4 * Q; ++q ) mybuf[padl + 68 * q] = z[q];              // natural order: slot PAD( lane + 64 q )
+			};
+
+		auto bins_of_frame = [&]( int64_t t, int64_t tn, int set, auto halo_tag )
+			{
+			constexpr bool halo = decltype( halo_tag )::value;
+			const cf * bufE = buf0 + 2 * set * L::BUF_LEN, * bufO = bufE + L::BUF_LEN;
+			cf * row = reinterpret_cast<cf*>( p.out + ( int64_t( channel ) * p.F + t ) * ( N2 + 1 ) );
+			const int k0 = lane + 256 * role;
+			cf * row_a = row + k0;                                                // bin k          (+ 64 q)
+			cf * row_b = row + ( N2 - k0 );                                       // bin 2048 - k   (- 64 q)
+			cf * row_c = row + ( C - k0 );                                        // bin 1024 - k   (- 64 q)
+			cf * row_d = row + ( C + k0 );                                        // bin 1024 + k   (+ 64 q)
+			const cf * ownE = bufE + padl + 272 * role, * ownO = bufO + padl + 272 * role;          // slot PAD( lane + 64 ( 4 role + q ) ) = padl + 68 ( 4 role + q )
+			const cf * mirE = bufE + mir - 272 * role, * mirO = bufO + mir - 272 * role;
+			#pragma unroll
+			for( int g = 0; g < Q / QV; ++g )
+				{
+				if( g == Q / QV / 2 ) load_half( tn );                                   // the next frame's half travels during the second half of the bins
+				VB re, im, pv, binf;
+				#pragma unroll
+				for( int i = 0; i < QV; ++i )
+					{
+					const int q = QV * g + i;
+					const cf ek = ownE[68 * q], ok = ownO[68 * q];
+					const cf em = mirE[-68 * q], om = mirO[-68 * q];                  // k = 0 (role 0, lane 0, q = 0) reads an unused slot: overridden below
+					const v4f_t tw = s_twq[64 * q];
+					const float px = __builtin_fmaf( tw.z, ok.x, -( tw.w * ok.y ) ), py = __builtin_fmaf( tw.z, ok.y, tw.w * ok.x );
+					const float qx = __builtin_fmaf( tw.z, om.x, tw.w * om.y ), qy = __builtin_fmaf( tw.z, om.y, -( tw.w * om.x ) );
+					const cf zk = mk( ek.x + px, ek.y + py ), zk2 = mk( ek.x - px, ek.y - py );
+					const cf zm = mk( em.x - qx, em.y - qy ), zm2 = mk( em.x + qx, em.y + qy );
+					float r0, i0, r1, i1, r2, i2, r3, i3;
+					split_pair( zk, zm2, tw.x, tw.y, r0, i0, r1, i1 );
+					split_pair( zm, zk2, -tw.y, -tw.x, r2, i2, r3, i3 );
+					if( q == 0 )
+						{
+						const bool l0 = k0 == 0;
+						const cf z0 = mk( ek.x + ok.x, ek.y + ok.y ), zc = mk( ek.x - ok.x, ek.y - ok.y );   // Z[0], Z[1024] where k = 0
+						r0 = l0 ? z0.x + z0.y : r0;  i0 = l0 ? 0.0f : i0;               // X[0]
+						r1 = l0 ? z0.x - z0.y : r1;  i1 = l0 ? 0.0f : i1;               // X[2048]
+						r2 = l0 ? zc.x : r2;  i2 = l0 ? -zc.y : i2;                     // X[1024] = conj Z[1024], twice
+						r3 = l0 ? zc.x : r3;  i3 = l0 ? -zc.y : i3;
+						}
+					re[4 * i + 0] = r0; im[4 * i + 0] = i0; re[4 * i + 1] = r1; im[4 * i + 1] = i1;
+					re[4 * i + 2] = r2; im[4 * i + 2] = i2; re[4 * i + 3] = r3; im[4 * i + 3] = i3;
+					const float fk = fk0 + float( 64 * q );
+					binf[4 * i + 0] = fk * p.sample_rate * rdft;                                    // PVBuffer.cpp:443-446
+					binf[4 * i + 1] = ( float( N2 ) - fk ) * p.sample_rate * rdft;
+					binf[4 * i + 2] = ( float( C ) - fk ) * p.sample_rate * rdft;
+					binf[4 * i + 3] = ( float( C ) + fk ) * p.sample_rate * rdft;
+					#pragma unroll
+					for( int j = 0; j < 4; ++j ) pv[4 * i + j] = prev[q][j];
+					}
+				VB phase, m;
+				polar_v( re, im, phase, m );                                        // phase_vocoder.cpp:37-52 (AudioPV.cpp:69-73)
+				#pragma unroll
+				for( int i = 0; i < QV; ++i )
+					{
+					#pragma unroll
+					for( int j = 0; j < 4; ++j ) prev[QV * g + i][j] = phase[4 * i + j];            // :45
+					}
+				if constexpr( !halo )
+					{
+					const VB expd = div_c_v( binf, p.ar_div ) * vsplat<VB>( FLANHIP_PI2_F );       // :47
+					const VB delta_phase = ( phase - pv ) - expd;                                // :44, :47-48
+					VB wrapped = delta_phase;
+					if( use_wrapping ) wrapped = delta_phase - vsplat<VB>( FLANHIP_PI2_F ) * round_half_away_v( div_pi2_v( delta_phase ) );   // :39-42,49
+					const VB f = binf + div_pi2_v( wrapped * vsplat<VB>( p.analysis_rate ) );      // :50-52
+					#pragma unroll
+					for( int i = 0; i < QV; ++i )
+						{
+						const int q = QV * g + i;
+						__builtin_nontemporal_store( cf{ m[4 * i + 0], f[4 * i + 0] }, row_a + 64 * q );
+						__builtin_nontemporal_store( cf{ m[4 * i + 1], f[4 * i + 1] }, row_b - 64 * q );
+						__builtin_nontemporal_store( cf{ m[4 * i + 2], f[4 * i + 2] }, row_c - 64 * q );
+						__builtin_nontemporal_store( cf{ m[4 * i + 3], f[4 * i + 3] }, row_d + 64 * q );
+						}
+					if constexpr( SUMS )
+						{
+						const VB term = div_c_v( f, p.ar_div ) * vsplat<VB>( FLANHIP_PI2_F );      // phase_vocoder.cpp:57-58
+						#pragma unroll
+						for( int i = 0; i < QV; ++i )
+							{
+							#pragma unroll
+							for( int j = 0; j < 4; ++j ) rs[QV * g + i][j] += residue( term[4 * i + j], phase[4 * i + j], pv[4 * i + j] );
+							__builtin_amdgcn_sched_barrier( 0 );                             // four residues at a time: their fp64 temporaries must not pile up
+							}
+						#pragma unroll
+						for( int i = 0; i < 4 * QV; i += 2 ) mmax = __builtin_fmaxf( mmax, __builtin_fmaxf( m[i], m[i + 1] ) );
+						}
+					}
+				}
+			if( role == 1 )
+				{
+				// k = 512 (the odd wavefront's): Z[512] = E[512] - i O[512], Z[1536] = E[512] + i O[512]; bins 512 and 1536 are one pair
+				const cf e512 = bufE[544], o512 = bufO[544];                          // slot PAD( 512 )
+				const cf zk = mk( e512.x + o512.y, e512.y - o512.x ), zm = mk( e512.x - o512.y, e512.y + o512.x );
+				float r[2], im2[2];
+				split_pair( zk, zm, 0.35355339059327379f, -0.35355339059327379f, r[0], im2[0], r[1], im2[1] );
+				#pragma unroll
+				for( int j = 0; j < 2; ++j )
+					{
+					const float phase = atan2_fast( im2[j], r[j] );
+					const float pvx = prevs[j];
+					prevs[j] = phase;
+					if constexpr( !halo )
+						{
+						const float bx = float( j == 0 ? 512 : 1536 ) * p.sample_rate * rdft;
+						const float delta_phase = ( phase - pvx ) - div_c( bx, p.ar_div ) * FLANHIP_PI2_F;
+						const float wrapped = use_wrapping ? delta_phase - FLANHIP_PI2_F * round_half_away( div_pi2( delta_phase ) ) : delta_phase;
+						const float f = bx + div_pi2( wrapped * p.analysis_rate );
+						const float m = magnitude_scaled( r[j], im2[j] );
+						if( lane == 0 ) __builtin_nontemporal_store( mk( m, f ), row + ( j == 0 ? 512 : 1536 ) );
+						if constexpr( SUMS )
+							{
+							rs2[j] += residue( div_c( f, p.ar_div ) * FLANHIP_PI2_F, phase, pvx );
+							mmax = __builtin_fmaxf( mmax, m );
+							}
+						}
+					}
+				}
+			};
+
+		// iteration i of a chain: frame tfirst + i (the first is the halo when t0 > 0).  Rotated like the dft 2048 kernel: the per-bin work of
+		// frame i, then the transform of frame i + 1; barriers after each (all teams, every iteration, work or not)
+		if( frames > 0 ) { load_half( tfirst ); transform_frame( 0 ); }
+		lds_block_sync();
+		for( int i = 0; i < iters; ++i )
+			{
+			const int set = DOUBLE ? ( i & 1 ) : 0;
+			if( i < frames )
+				{
+				const int64_t t = tfirst + i, tn = min( t + 1, t1 - 1 );           // (the last frame requests itself again: nobody waits for it)
+				if( t0 > 0 && i == 0 )
+					{
+					bins_of_frame( t, tn, set, std::true_type{} );
+					if constexpr( SUMS ) park_first_phases();                        // prev[] = the phases of frame t0 - 1
+					}
+				else bins_of_frame( t, tn, set, std::false_type{} );
+				}
+			// one buffer set: nobody may write the next frame's E / O before both halves have read this one's.  Two sets: the next frame goes
+			// to the other set, whose readers (the frame before this one) passed the previous barrier
+			if constexpr( !DOUBLE ) lds_block_sync();
+			if( i + 1 < frames ) transform_frame( DOUBLE ? ( set ^ 1 ) : 0 );
+			lds_block_sync();                                                     // the next frame's E / O are written
+			}
+		};
+	if constexpr( SUMS ) { if( active && t0 == 0 ) park_first_phases(); }        // AudioPV.cpp:44: zeros
+	if( chain_fast ) run_chain( std::true_type{} ); else run_chain( std::false_type{} );
+
+	if constexpr( SUMS )
+		{
+		// the chain's sum = phase_last - phase_first + R, brought into [0, pi2) (see k_analyze_eo)
+		bool bad = !( mmax <= 3.4028235e38f );
+		auto total = [&]( double first, float last, float r ) -> double
+			{
+			bad |= !( __builtin_fabsf( r ) <= 3.4028235e38f );                       // a NaN / Inf frequency poisons its residue
+			const double v = ( double( last ) - first ) + double( r );
+			const double w = __builtin_fma( -__builtin_floor( v * ( 1.0 / FLANHIP_PI2_D ) ), FLANHIP_PI2_D, v );
+			return w < 0.0 ? w + FLANHIP_PI2_D : ( w >= FLANHIP_PI2_D ? w - FLANHIP_PI2_D : w );
+			};
+		if( active )
+			{
+			double * dst = p.sums + chain * ( N2 + 1 );
+			#pragma unroll
+			for( int q = 0; q < Q; ++q )
+				{
+				const int k = lane + 256 * role + 64 * q;
+				const double a = total( dst[k], prev[q][0], rs[q][0] ), b = total( dst[N2 - k], prev[q][1], rs[q][1] );
+				const double c = total( dst[C - k], prev[q][2], rs[q][2] );
+				dst[k] = a; dst[N2 - k] = b; dst[C - k] = c;
+				if( k != 0 ) dst[C + k] = total( dst[C + k], prev[q][3], rs[q][3] );   // (k = 0: the quad's fourth bin is bin 1024 again)
+				}
+			if( role == 1 && lane == 0 ) { dst[512] = total( dst[512], prevs[0], rs2[0] ); dst[1536] = total( dst[1536], prevs[1], rs2[1] ); }
+			}
+		const bool any_bad = __any( bad ) && active;
+		if( p.nan_out && lane == 0 && active )
+			{
+			if( chain == 0 && role == 0 ) { p.nan_out[2] = p.nan_epoch; p.nan_out[4] = p.nan_epoch; }
+			if( any_bad ) p.nan_out[0] = p.nan_epoch;
+			}
+		}
+	}
+
+
+} // namespace flanhip

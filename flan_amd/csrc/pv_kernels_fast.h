@@ -51,7 +51,8 @@ template<int LOG2C> struct FastLds
 struct NoStamp { __device__ __forceinline__ void operator()( int ) const {} };
 
 // ---- the three FFT passes on the register array z[E] (natural layout in, natural layout out) -------------------
-template<int LOG2C, class ST = NoStamp>
+// TW_EARLY: request pass 1's twiddles together with its points, ahead of the fence (one LDS round trip less, 30 registers more at the peak)
+template<int LOG2C, class ST = NoStamp, bool TW_EARLY = true>
 __device__ __forceinline__ void fft_fast( cf ( &z )[( 1 << LOG2C ) / 64], cf * buf, const cf * s_tw1, const cf * s_tw3, int lane, ST && st = ST() )
 	{
 	constexpr int C = 1 << LOG2C;
@@ -90,15 +91,18 @@ __device__ __forceinline__ void fft_fast( cf ( &z )[( 1 << LOG2C ) / 64], cf * b
 		// LDS round trip for both instead of two in a row (measured: 1.5 % of either kernel)
 		cf tw[15];
 		const cf * tp = s_tw1 + ( lane & 15 );
-		#pragma unroll
-		for( int r = 1; r < 16; ++r ) tw[r - 1] = tp[( r - 1 ) * 16];
+		if constexpr( TW_EARLY )
+			{
+			#pragma unroll
+			for( int r = 1; r < 16; ++r ) tw[r - 1] = tp[( r - 1 ) * 16];
+			}
 		wave_sync();
 		cf * wp = buf + 17 * ( lane & ~15 ) + ( lane & 15 );
 		#pragma unroll
 		for( int b = 0; b < PER; ++b )
 			{
 			#pragma unroll
-			for( int r = 1; r < 16; ++r ) v[b][r] = cmul( v[b][r], tw[r - 1] );
+			for( int r = 1; r < 16; ++r ) v[b][r] = cmul( v[b][r], TW_EARLY ? tw[r - 1] : tp[( r - 1 ) * 16] );
 			dft_reg<16>( v[b] );
 			#pragma unroll
 			for( int r = 0; r < 16; ++r ) wp[1088 * b + 17 * r] = v[b][r];

@@ -106,8 +106,17 @@ template<class V> __device__ __forceinline__ void polar_v( V re, V im, V & phase
 	const V q0 = mn * r;
 	const V q = vfma( vfma( -q0, mx, mn ), r, q0 );
 	const V u = q * q;
-	const V t = mxu * vsplat<V>( 0x1p126f );
-	const V h = vfma( q, q, __builtin_elementwise_min( t * t, vsplat<V>( 1.0f ) ) );
+	// 1 + q^2, except where the larger component is below 2^-126 (zero or a denormal: digital silence): only then, decided per wavefront,
+	// is p2 = min( ( max 2^126 )^2, 1 ) worked out -- it is exactly 1 for every other input
+	V h = vfma( q, q, vsplat<V>( 1.0f ) );
+	float tiny = mxu[0];
+	#pragma unroll
+	for( int i = 1; i < N; ++i ) tiny = __builtin_fminf( tiny, mxu[i] );
+	if( __any( tiny < 0x1p-126f ) )
+		{
+		const V t = mxu * vsplat<V>( 0x1p126f );
+		h = vfma( q, q, __builtin_elementwise_min( t * t, vsplat<V>( 1.0f ) ) );
+		}
 	V p = vsplat<V>( 0x1.7ec8b6p-9f );
 	p = vfma( p, u, vsplat<V>( -0x1.0c272ap-6f ) );
 	p = vfma( p, u, vsplat<V>( 0x1.61f9a0p-5f ) );
