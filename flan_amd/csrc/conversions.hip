@@ -19,6 +19,7 @@ static int g_synth_stage_mask = 0xF;             // flanhip_debug_synth_stages()
 // synthesis (register-accumulator hops): 0 = round-1 kernel; 1 (the default) = v2; 2 = v2 behind the scan kernel even where it could work
 // out its own carries; 9 = v2 with plain instead of non-temporal row loads
 static int g_ana_variant = 4, g_syn_variant = 1;
+static int g_syn11_variant = 1;          // dft 4096 synthesis, window <= 2048, hop 256 / 512 / 1024: 1 = teams of two wavefronts (pv_kernels_eo.h), 0 = the round-1 kernel
 static int g_ana11_variant = 1;          // dft 4096, window <= 2048: 1 = teams of two wavefronts, two 1024-point transforms per frame (pv_kernels_eo.h), 0 = the round-1 kernel
 static int ana_variant_waves( int ) { return 8; }
 static constexpr size_t kMaxLds = 160 * 1024;   // gfx950: 160 KiB LDS per CU, one workgroup may take all of it
@@ -202,6 +203,21 @@ static int run_synth_v2( const SynthParams & p, const FastTables & tb, hipStream
 	return FLANHIP_OK;
 	}
 
+template<int TEAMS, int HS>
+static int run_synth_eo_team( const SynthParams & p, const FastTables & tb, hipStream_t s )
+	{
+	const size_t lds = EoLds::bytes( 2 * TEAMS );                              // two A / B buffer sets per team
+	static_assert( EoLds::bytes( 2 * TEAMS ) <= kMaxLds, "LDS budget" );
+	auto kern = k_synthesize_eo_team<TEAMS, HS>;
+	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;
+	const int64_t blocks = ( chains + TEAMS - 1 ) / TEAMS;
+	FLANHIP_REQUIRE( blocks < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
+	hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( 128 * TEAMS ), lds, s, p, tb );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
 template<int LOG2C>
 static int run_synth_fast_hop( const SynthParams & p, const FastTables & tb, hipStream_t s )
 	{
@@ -222,6 +238,16 @@ static int run_synth_fast_hop( const SynthParams & p, const FastTables & tb, hip
 			case 2: return run_synth_v2<8, 2>( p, tb, s );
 			case 4: return run_synth_v2<8, 4>( p, tb, s );
 			case 8: return run_synth_v2<8, 8>( p, tb, s );
+			}
+		}
+	if( LOG2C == 11 && g_syn11_variant != 0 && p.window_size <= 2048 && p.hop % 256 == 0 && synth_fast_kind( 2 << LOG2C, p.window_size, p.hop ) == 1 )
+		{
+		// dft 4096, window <= 2048, hop 256 / 512 / 1024: teams of two wavefronts, two 1024-point transforms per frame (pv_kernels_eo.h)
+		switch( p.hop / 256 )
+			{
+			case 1: return run_synth_eo_team<4, 1>( p, tb, s );
+			case 2: return run_synth_eo_team<4, 2>( p, tb, s );
+			case 4: return run_synth_eo_team<4, 4>( p, tb, s );
 			}
 		}
 	if( synth_fast_kind( 2 << LOG2C, p.window_size, p.hop ) == 2 )                // any other hop <= window: ring accumulator in LDS
@@ -536,7 +562,7 @@ int flanhip_analyze( const float * audio, int64_t ch, int64_t n, float sr, int W
 	}
 
 void flanhip_debug_synth_stages( int mask ) { g_synth_stage_mask = mask & 0xF; }
-void flanhip_debug_kernel_variant( int which, int variant ) { if( which == 0 ) g_ana_variant = variant; else if( which == 2 ) g_ana11_variant = variant; else g_syn_variant = variant; }
+void flanhip_debug_kernel_variant( int which, int variant ) { if( which == 0 ) g_ana_variant = variant; else if( which == 2 ) g_ana11_variant = variant; else if( which == 3 ) g_syn11_variant = variant; else g_syn_variant = variant; }
 #ifdef FLANHIP_STAMPS
 // diagnostic build only: the per-section cycle sums of the stamped kernels (16 words; [15] = wavefronts that reported), then cleared
 int flanhip_debug_read_stamps( unsigned long long * out16 )

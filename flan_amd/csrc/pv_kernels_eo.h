@@ -689,4 +689,246 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 	}
 
 
+// =================================================================================================================
+// PV::convert_to_audio (Conversions/AudioPV.cpp:86-139), dft 4096, window <= 2048, hop 256 / 512 / 1024: the mirror image of
+// k_analyze_eo_team.  A team of two wavefronts per chain.  Per frame each wavefront runs the inverse phase vocoder on its 16 bins (the
+// quads k = lane + 64 ( 4 role + q ), q < 4: bins k, 2048-k, 1024-k, 1024+k), merges them into the half-size spectrum Zc (conjugated: the
+// forward transform of it is the conjugate of the inverse one) at k, 1024+k, 1024-k, 2048-k and leaves
+//        A[k] = Zc[k] + Zc[k+1024],   B[k] = ( Zc[k] - Zc[k+1024] ) w^k      ( and the same at 1024-k;  w = exp( -2 pi i / 2048 ) )
+// in the team's buffers; after one LDS-only barrier wavefront 0 transforms A (1024 points: the EVEN output points G[2m], i.e. samples
+// 4m, 4m+1) and wavefront 1 transforms B (the odd ones: samples 4m+2, 4m+3), of which only m < 512 lie inside the window.  Each keeps its
+// half of the overlap-add accumulator in registers (16 floats per lane: sample 256 q + 4 lane + 2 role (+1)) and emits its half of the
+// finished hop.  Two buffer sets: one barrier per frame.
+template<int TEAMS, int HS>                                                  // HS = hop / 256
+__global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthParams p, FastTables tb )
+	{
+	using L = EoLds;
+	constexpr int C = 1024, N2 = 2048, Q = 4, NT = 128 * TEAMS, hop = 256 * HS;
+	static_assert( HS == 1 || HS == 2 || HS == 4, "hop 256 / 512 / 1024" );
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	cf * s = reinterpret_cast<cf*>( smem );
+	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane( tid >> 6 ), team = wave >> 1, role = wave & 1;
+	const int W = p.window_size;
+
+	for( int i = tid; i < 240; i += NT ) s[L::TW1 + i] = tb.tw1[i];
+	for( int i = tid; i < 768; i += NT ) s[L::TW3 + i] = tb.tw3[( 2 * ( i >> 8 ) + 1 ) * 256 + ( i & 255 )];
+		{
+		// { cos, sin of 2 pi k / 4096 ; cos, -sin of 2 pi k / 2048 }
+		v4f_t * twq = reinterpret_cast<v4f_t*>( s + L::TWQ );
+		for( int k = tid; k < 512; k += NT ) { const cf a = tb.w2[k], b = tb.w2[2 * k]; twq[k] = v4f_t{ a.x, -a.y, b.x, b.y }; }
+		float * win = reinterpret_cast<float*>( s + L::WIN );
+		for( int i = tid; i < 2048; i += NT ) win[i] = ( i < W ) ? p.window[i] * p.window_scale : 0.0f;   // AudioPV.cpp:102
+		}
+	__syncthreads();
+	const cf * s_tw1 = s + L::TW1;
+	const cf * s_tw3 = s + L::TW3;
+	const v4f_t * s_twq = reinterpret_cast<const v4f_t*>( s + L::TWQ ) + lane + 256 * role;
+	const v4f_t * s_win = reinterpret_cast<const v4f_t*>( s + L::WIN ) + lane;
+	cf * const buf0 = s + L::BUF + team * 4 * L::BUF_LEN;                       // set b: A at buf0 + 2 b BUF_LEN, B behind it
+
+	const int64_t chain_raw = int64_t( blockIdx.x ) * TEAMS + team;
+	const bool active = chain_raw < int64_t( p.chains_per_channel ) * p.num_channels;
+	const int64_t chain = active ? chain_raw : 0;
+	const int channel = int( chain / p.chains_per_channel );
+	const int chain_in_channel = int( chain % p.chains_per_channel );
+	const int64_t t0 = int64_t( chain_in_channel ) * p.L;
+	const int64_t t1 = min( t0 + int64_t( p.L ), p.F );
+	const bool last_chain = chain_in_channel == p.chains_per_channel - 1;
+	const int frames = active ? int( t1 - t0 ) : 0;
+	float * out1 = p.out + int64_t( channel ) * p.out_len;
+	cf * out2 = reinterpret_cast<cf*>( out1 );
+	cf * head2 = reinterpret_cast<cf*>( p.head + chain * p.head_len );
+	const int64_t chain_start = int64_t( hop ) * t0 - W / 2;
+	const int64_t own_start = chain_in_channel == 0 ? INT64_MIN : chain_start + p.head_len;
+	const int padl = lane + ( lane >> 4 );
+	const int mir = ( C * 17 ) / 16 - ( lane + ( ( lane + 15 ) >> 4 ) );
+	const int k0 = lane + 256 * role;                                           // k of this wavefront's first quad
+
+	// running phases (AudioPV.cpp:105) on entry to the chain: [q][0..3] = bins k, 2048-k, 1024-k, 1024+k; the odd wavefront also 512, 1536
+	double ph[Q][4], phs[2] = { 0.0, 0.0 };
+		{
+		const double * carry = p.carry + chain * ( N2 + 1 );
+		#pragma unroll
+		for( int q = 0; q < Q; ++q )
+			{
+			const int k = k0 + 64 * q;
+			ph[q][0] = carry[k]; ph[q][1] = carry[N2 - k]; ph[q][2] = carry[C - k]; ph[q][3] = carry[C + k];
+			}
+		if( role == 1 ) { phs[0] = carry[512]; phs[1] = carry[1536]; }
+		}
+	cf acc[2 * Q];                                                              // acc[q] <-> samples pos + 256 q + 4 lane + 2 role (+1)
+	#pragma unroll
+	for( int q = 0; q < 2 * Q; ++q ) acc[q] = mk( 0.0f, 0.0f );
+
+	// one 256-sample step of finished (or partial) output: this wavefront's half of it.  One store per step, never inside a branch (lanes
+	// outside the output store into the dump area): a static number of stores behind the row request, a counted wait (see k_synthesize_v2)
+	cf * dump2 = reinterpret_cast<cf*>( p.dump ) + lane;
+	auto emit_step = [&]( int64_t a0, cf v )
+		{
+		const int64_t a = a0 + 4 * lane + 2 * role;
+		cf * dst = ( a0 < own_start ) ? head2 + ( ( a - chain_start ) >> 1 ) : out2 + ( a >> 1 );
+		if( a0 >= own_start && !( a >= 0 && a < p.out_len ) ) dst = dump2;
+		*dst = v;
+		};
+	cf mf[Q][4], mfs[2];
+	auto load_row = [&]( int64_t t )
+		{
+		const cf * row = reinterpret_cast<const cf*>( p.pv + ( int64_t( channel ) * p.F + t ) * ( N2 + 1 ) );
+		const cf * ra = row + k0, * rb = row + ( N2 - k0 ), * rc = row + ( C - k0 ), * rd = row + ( C + k0 );
+		#pragma unroll
+		for( int q = 0; q < Q; ++q )
+			{
+			mf[q][0] = __builtin_nontemporal_load( ra + 64 * q );
+			mf[q][1] = __builtin_nontemporal_load( rb - 64 * q );
+			mf[q][2] = __builtin_nontemporal_load( rc - 64 * q );
+			mf[q][3] = __builtin_nontemporal_load( rd + 64 * q );
+			}
+		mfs[0] = __builtin_nontemporal_load( row + ( 512 + 1024 * 0 ) );          // (both wavefronts load them: a static number of loads; the even one ignores them)
+		mfs[1] = __builtin_nontemporal_load( row + 1536 );
+		};
+	// Zc[j], Zc[N-j] from X[j] = a, X[N-j] = b and w = exp( +2 pi i j / 2N ) (k_synthesize_v2's merge)
+	auto merge_pair = []( cf a, cf b, float wx, float wy, cf & zj, cf & zn )
+		{
+		const float ax = a.x + b.x, ay = a.y - b.y, dx = a.x - b.x, dy = a.y + b.y;
+		const float bx = __builtin_fmaf( wx, dx, -( wy * dy ) ), by = __builtin_fmaf( wx, dy, wy * dx );
+		zj = mk( ax - by, -( ay + bx ) );
+		zn = mk( ax + by, ay - bx );
+		};
+	// inverse phase vocoder of the row in mf[] (AudioPV.cpp:117-120, phase_vocoder.cpp:55-61), merge, A / B into buffer set `set`
+	auto bins_of_row = [&]( int set )
+		{
+		cf * bufA = buf0 + 2 * set * L::BUF_LEN, * bufB = bufA + L::BUF_LEN;
+		bool slow = false;
+		#pragma unroll
+		for( int q = 0; q < Q; ++q )
+			{
+			#pragma unroll
+			for( int j = 0; j < 4; ++j )
+				{
+				ph[q][j] += double( div_c( mf[q][j].y, p.ar_div ) * FLANHIP_PI2_F );   // phase_vocoder.cpp:57-58
+				slow |= !( __builtin_fabs( ph[q][j] ) < double( FLANHIP_SINCOS_FAST_LIMIT ) );
+				}
+			}
+		if( role == 1 )
+			{
+			#pragma unroll
+			for( int j = 0; j < 2; ++j )
+				{
+				phs[j] += double( div_c( mfs[j].y, p.ar_div ) * FLANHIP_PI2_F );
+				slow |= !( __builtin_fabs( phs[j] ) < double( FLANHIP_SINCOS_FAST_LIMIT ) );
+				}
+			}
+		const bool any_slow = __any( slow );
+		#pragma unroll
+		for( int q = 0; q < Q; ++q )
+			{
+			cf x[4];
+			if( any_slow )
+				{
+				#pragma unroll
+				for( int j = 0; j < 4; ++j )
+					{
+					ph[q][j] = fold_phase_any( ph[q][j] );
+					const float2 sc = sincos_wide( float( ph[q][j] ) );
+					x[j] = mk( mf[q][j].x * sc.y, mf[q][j].x * sc.x );
+					}
+				}
+			else
+				{
+				v4f th, m4;
+				#pragma unroll
+				for( int j = 0; j < 4; ++j ) { ph[q][j] = fold_phase_loop( ph[q][j] ); th[j] = float( ph[q][j] ); m4[j] = mf[q][j].x; }   // :59
+				v4f sn, cs;
+				sincos_fast_v( th, sn, cs );
+				const v4f xr = m4 * cs, xi = m4 * sn;                                // std::polar, :60
+				#pragma unroll
+				for( int j = 0; j < 4; ++j ) x[j] = cf{ xr[j], xi[j] };
+				}
+			if( q == 0 )
+				{
+				// k = 0: X[0], X[2048] are real (c2r ignores their imaginary parts); the quad's second pair is ( 1024, 1024 )
+				const bool l0 = k0 == 0;
+				x[0].y = l0 ? 0.0f : x[0].y;  x[1].y = l0 ? 0.0f : x[1].y;
+				}
+			const v4f_t tw = s_twq[64 * q];                                       // ( cos, sin )( 2 pi k / 4096 ), ( cos, -sin )( 2 pi k / 2048 )
+			cf zk, zn, zm, zk2;                                                   // Zc[k], Zc[2048-k], Zc[1024-k], Zc[1024+k]
+			merge_pair( x[0], x[1], tw.x, tw.y, zk, zn );
+			merge_pair( x[2], x[3], tw.y, tw.x, zm, zk2 );                        // exp( +2 pi i ( 1024-k ) / 4096 ) = ( sin, cos )
+			const cf dk = mk( zk.x - zk2.x, zk.y - zk2.y ), dm = mk( zm.x - zn.x, zm.y - zn.y );
+			const int slot = padl + 68 * ( 4 * role + q ), mslot = mir - 68 * ( 4 * role + q );
+			bufA[slot] = mk( zk.x + zk2.x, zk.y + zk2.y );
+			bufB[slot] = mk( __builtin_fmaf( dk.x, tw.z, -( dk.y * tw.w ) ), __builtin_fmaf( dk.x, tw.w, dk.y * tw.z ) );       // ( Zc[k] - Zc[k+1024] ) w^k
+			bufA[mslot] = mk( zm.x + zn.x, zm.y + zn.y );                          // (k = 0: slot PAD( 1024 ), unused)
+			bufB[mslot] = mk( -__builtin_fmaf( dm.x, tw.z, dm.y * tw.w ), __builtin_fmaf( dm.x, tw.w, -( dm.y * tw.z ) ) );    // x w^(1024-k) = x -conj( w^k )
+			__builtin_amdgcn_sched_barrier( 0 );                                  // a quad at a time: keeps the temporaries of 16 bins from overlapping
+			}
+		if( role == 1 )
+			{
+			// k = 512: bins 512 and 1536 are one pair, w = exp( +i pi / 4 ); A[512] = Zc[512] + Zc[1536], B[512] = ( Zc[512] - Zc[1536] ) ( -i )
+			cf x[2];
+			#pragma unroll
+			for( int j = 0; j < 2; ++j )
+				{
+				phs[j] = any_slow ? fold_phase_any( phs[j] ) : fold_phase_loop( phs[j] );
+				float sn, cs;
+				if( any_slow ) { const float2 sc = sincos_wide( float( phs[j] ) ); sn = sc.x; cs = sc.y; } else sincos_fast( float( phs[j] ), sn, cs );
+				x[j] = mk( mfs[j].x * cs, mfs[j].x * sn );
+				}
+			cf zk, zn;
+			merge_pair( x[0], x[1], 0.70710678118654752f, 0.70710678118654752f, zk, zn );
+			if( lane == 0 )
+				{
+				bufA[544] = mk( zk.x + zn.x, zk.y + zn.y );                            // slot PAD( 512 )
+				bufB[544] = mk( zk.y - zn.y, -( zk.x - zn.x ) );
+				}
+			}
+		};
+
+	int64_t pos = chain_start;
+	if( frames > 0 ) { load_row( t0 ); bins_of_row( 0 ); }
+	lds_block_sync();
+	const int iters = p.L;
+	for( int i = 0; i < iters; ++i )
+		{
+		const int set = i & 1;
+		if( i < frames )
+			{
+			const int64_t t = t0 + i;
+			load_row( min( t + 1, t1 - 1 ) );                                     // (the last frame requests itself again: nobody waits for it)
+			const cf * mybuf = buf0 + ( 2 * set + role ) * L::BUF_LEN;
+			cf z[16];
+			#pragma unroll
+			for( int q = 0; q < 16; ++q ) z[q] = mybuf[padl + 68 * q];
+			wave_sync();
+			fft_fast<10>( z, const_cast<cf*>( mybuf ), s_tw1, s_tw3, lane );
+			// G = fft( A or B ): samples 4m (+2 for B) = G[m].x, 4m+1 (+2) = -G[m].y, m = lane + 64 q < 512; window, overlap-add (AudioPV.cpp:122-134)
+			#pragma unroll
+			for( int q = 0; q < 2 * Q; ++q )
+				{
+				const v4f_t wv = s_win[64 * q];                                    // zero beyond W
+				acc[q].x += z[q].x * ( role ? wv.z : wv.x );
+				acc[q].y += ( -z[q].y ) * ( role ? wv.w : wv.y );
+				}
+			#pragma unroll
+			for( int q = 0; q < HS; ++q ) emit_step( pos + 256 * q, acc[q] );
+			#pragma unroll
+			for( int q = 0; q < 2 * Q; ++q ) acc[q] = ( q + HS < 2 * Q ) ? acc[q + HS] : mk( 0.0f, 0.0f );
+			pos += hop;
+			if( i + 1 < frames ) bins_of_row( set ^ 1 );
+			}
+		lds_block_sync();                                                         // the next frame's A / B are written (into the other set)
+		}
+	if( !active ) return;
+	// flush the partial sums that the next chain's head completes; the last chain zero-fills to the end of the output
+	const int64_t ring_end = pos + ( W - hop );
+	const int64_t flush_end = last_chain ? max( ring_end, p.out_len ) : ring_end;
+	#pragma unroll
+	for( int q = 0; q < 2 * Q; ++q )
+		{
+		const int64_t a0 = pos + 256 * q;
+		if( a0 < flush_end ) emit_step( a0, acc[q] );
+		}
+	for( int64_t a0 = pos + 256 * 2 * Q; a0 < flush_end; a0 += 256 ) emit_step( a0, mk( 0.0f, 0.0f ) );
+	}
+
 } // namespace flanhip

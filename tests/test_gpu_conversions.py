@@ -50,6 +50,15 @@ CASES = [
     ("sine_5s_cfg1", 1, 240000, 2048, 512, 2048, "sine"),
     ("noise_stereo", 2, 48000, 2048, 512, 2048, "noise"),
     ("noise_dft4096_hop128", 1, 20000, 2048, 128, 4096, "noise"),
+    # dft 4096, window <= 2048: two 1024-point transforms per frame (pv_kernels_eo.h); hop 256 / 512 / 1024 also in synthesis
+    ("noise_dft4096_hop512", 2, 50000, 2048, 512, 4096, "noise"),
+    ("noise_dft4096_hop256", 1, 30000, 2048, 256, 4096, "noise"),
+    ("noise_dft4096_hop1024_3ch", 3, 41000, 2048, 1024, 4096, "noise"),
+    ("dft4096_win1024_hop256", 1, 20000, 1024, 256, 4096, "noise"),
+    ("dft4096_short", 2, 3000, 2048, 512, 4096, "noise"),
+    ("dft4096_one_frame", 1, 300, 2048, 512, 4096, "noise"),
+    ("dft4096_win3000", 1, 30000, 3000, 512, 4096, "noise"),
+    ("sine_dft4096_hop512", 1, 48000, 2048, 512, 4096, "sine"),
     ("ragged_len", 3, 12345, 2048, 512, 2048, "noise"),
     ("one_frame", 1, 100, 2048, 512, 2048, "noise"),
     ("short_two_frames", 2, 600, 2048, 512, 2048, "noise"),
