@@ -240,10 +240,11 @@ static int run_synth_fast_hop( const SynthParams & p, const FastTables & tb, hip
 			case 8: return run_synth_v2<8, 8>( p, tb, s );
 			}
 		}
-	if( LOG2C == 11 && g_syn11_variant != 0 && p.window_size <= 2048 && p.hop % 256 == 0 && synth_fast_kind( 2 << LOG2C, p.window_size, p.hop ) == 1 )
+	if( LOG2C == 11 && g_syn11_variant != 0 && p.window_size <= 2048 && synth_fast_kind( 2 << LOG2C, p.window_size, p.hop ) == 1 )
 		{
-		// dft 4096, window <= 2048, hop 256 / 512 / 1024: teams of two wavefronts, two 1024-point transforms per frame (pv_kernels_eo.h)
-		switch( p.hop / 256 )
+		// dft 4096, window <= 2048, hop 128 / 256 / 512 / 1024: teams of two wavefronts, two 1024-point transforms per frame (pv_kernels_eo.h)
+		if( p.hop == 128 && p.window_size % 256 == 0 ) return run_synth_eo_team<4, 0>( p, tb, s );
+		if( p.hop % 256 == 0 && p.window_size % 256 == 0 ) switch( p.hop / 256 )
 			{
 			case 1: return run_synth_eo_team<4, 1>( p, tb, s );
 			case 2: return run_synth_eo_team<4, 2>( p, tb, s );

@@ -699,12 +699,15 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 // 4m, 4m+1) and wavefront 1 transforms B (the odd ones: samples 4m+2, 4m+3), of which only m < 512 lie inside the window.  Each keeps its
 // half of the overlap-add accumulator in registers (16 floats per lane: sample 256 q + 4 lane + 2 role (+1)) and emits its half of the
 // finished hop.  Two buffer sets: one barrier per frame.
-template<int TEAMS, int HS>                                                  // HS = hop / 256
+// Hop 128 (HS = 0; the reference API's default hop): a finished hop is HALF a 256-sample step -- the lower 32 lanes of acc[0] -- and the
+// accumulator moves on by 32 lanes: new acc[q] = { upper half of acc[q], lower half of acc[q+1] }, one v_permlane32_swap and one select
+// per register.
+template<int TEAMS, int HS>                                                  // HS = hop / 256; 0: hop 128
 __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthParams p, FastTables tb )
 	{
 	using L = EoLds;
-	constexpr int C = 1024, N2 = 2048, Q = 4, NT = 128 * TEAMS, hop = 256 * HS;
-	static_assert( HS == 1 || HS == 2 || HS == 4, "hop 256 / 512 / 1024" );
+	constexpr int C = 1024, N2 = 2048, Q = 4, NT = 128 * TEAMS, hop = HS ? 256 * HS : 128;
+	static_assert( HS == 0 || HS == 1 || HS == 2 || HS == 4, "hop 128 / 256 / 512 / 1024" );
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	cf * s = reinterpret_cast<cf*>( smem );
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane( tid >> 6 ), team = wave >> 1, role = wave & 1;
@@ -769,6 +772,19 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 		cf * dst = ( a0 < own_start ) ? head2 + ( ( a - chain_start ) >> 1 ) : out2 + ( a >> 1 );
 		if( a0 >= own_start && !( a >= 0 && a < p.out_len ) ) dst = dump2;
 		*dst = v;
+		};
+	// hop 128: one 128-sample half step -- the lanes 32 part .. 32 part + 31 of v hold samples a0 + 4 ( lane & 31 ) + 2 role (+1); the other lanes dump
+	auto emit_half = [&]( int64_t a0, cf v, int part )
+		{
+		const int64_t a = a0 + 4 * ( lane & 31 ) + 2 * role;
+		cf * dst = ( a0 < own_start ) ? head2 + ( ( a - chain_start ) >> 1 ) : out2 + ( a >> 1 );
+		if( ( lane >> 5 ) != part || ( a0 >= own_start && !( a >= 0 && a < p.out_len ) ) ) dst = dump2;
+		*dst = v;
+		};
+	auto rotate_half = []( float a, float b, bool low ) -> float          // lanes 0..31 <- a's lanes 32..63, lanes 32..63 <- b's lanes 0..31
+		{
+		const auto r = __builtin_amdgcn_permlane32_swap( __float_as_uint( a ), __float_as_uint( b ), false, false );   // r[0] = { a.lo, b.lo }, r[1] = { a.hi, b.hi }
+		return __uint_as_float( low ? r[1] : r[0] );
 		};
 	cf mf[Q][4], mfs[2];
 	auto load_row = [&]( int64_t t )
@@ -909,10 +925,24 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 				acc[q].x += z[q].x * ( role ? wv.z : wv.x );
 				acc[q].y += ( -z[q].y ) * ( role ? wv.w : wv.y );
 				}
-			#pragma unroll
-			for( int q = 0; q < HS; ++q ) emit_step( pos + 256 * q, acc[q] );
-			#pragma unroll
-			for( int q = 0; q < 2 * Q; ++q ) acc[q] = ( q + HS < 2 * Q ) ? acc[q + HS] : mk( 0.0f, 0.0f );
+			if constexpr( HS == 0 )
+				{
+				emit_half( pos, acc[0], 0 );
+				const bool low = lane < 32;
+				#pragma unroll
+				for( int q = 0; q < 2 * Q; ++q )
+					{
+					const cf nxt = ( q + 1 < 2 * Q ) ? acc[q + 1] : mk( 0.0f, 0.0f );
+					acc[q] = mk( rotate_half( acc[q].x, nxt.x, low ), rotate_half( acc[q].y, nxt.y, low ) );
+					}
+				}
+			else
+				{
+				#pragma unroll
+				for( int q = 0; q < HS; ++q ) emit_step( pos + 256 * q, acc[q] );
+				#pragma unroll
+				for( int q = 0; q < 2 * Q; ++q ) acc[q] = ( q + HS < 2 * Q ) ? acc[q + HS] : mk( 0.0f, 0.0f );
+				}
 			pos += hop;
 			if( i + 1 < frames ) bins_of_row( set ^ 1 );
 			}
@@ -922,13 +952,27 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 	// flush the partial sums that the next chain's head completes; the last chain zero-fills to the end of the output
 	const int64_t ring_end = pos + ( W - hop );
 	const int64_t flush_end = last_chain ? max( ring_end, p.out_len ) : ring_end;
-	#pragma unroll
-	for( int q = 0; q < 2 * Q; ++q )
+	if constexpr( HS == 0 )
 		{
-		const int64_t a0 = pos + 256 * q;
-		if( a0 < flush_end ) emit_step( a0, acc[q] );
+		// W - hop = 1920 samples = 7.5 steps: by halves (the next chain writes from ring_end on itself)
+		#pragma unroll
+		for( int h = 0; h < 4 * Q; ++h )
+			{
+			const int64_t a0 = pos + 128 * h;
+			if( a0 < flush_end ) emit_half( a0, acc[h >> 1], h & 1 );
+			}
+		for( int64_t a0 = pos + 128 * 4 * Q; a0 < flush_end; a0 += 128 ) emit_half( a0, mk( 0.0f, 0.0f ), 0 );
 		}
-	for( int64_t a0 = pos + 256 * 2 * Q; a0 < flush_end; a0 += 256 ) emit_step( a0, mk( 0.0f, 0.0f ) );
+	else
+		{
+		#pragma unroll
+		for( int q = 0; q < 2 * Q; ++q )
+			{
+			const int64_t a0 = pos + 256 * q;
+			if( a0 < flush_end ) emit_step( a0, acc[q] );
+			}
+		for( int64_t a0 = pos + 256 * 2 * Q; a0 < flush_end; a0 += 256 ) emit_step( a0, mk( 0.0f, 0.0f ) );
+		}
 	}
 
 } // namespace flanhip
