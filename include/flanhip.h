@@ -129,8 +129,9 @@ int flanhip_synthesize_dev_fused_checked(const flanhip_MF * d_pv, int64_t num_ch
 /* Bench/diagnostic knob: which of the synthesis kernels a call launches (bit 0 k_phase_sums, 1 k_phase_scan,
  * 2 k_synthesize, 3 k_ola_fixup; default all).  Results are only meaningful with all four. */
 void flanhip_debug_synth_stages(int mask);
-/* Bench/diagnostic knob: which generation of the dft 2048 kernels a call launches (which = 0 analysis, 1 synthesis; variant 0 =
- * the library's default).  Layout-changing like FLANHIP_TARGET_CHAINS: set it before sizing a workspace.  A/B runs only. */
+/* Bench/diagnostic knob: which generation of the tuned kernels a call launches (which = 0 / 1: dft 2048 analysis / synthesis, 2 / 3:
+ * dft 4096 analysis / synthesis; variant 0 = the round-1 kernel, the library's default otherwise).  Layout-changing like
+ * FLANHIP_TARGET_CHAINS: set it before sizing a workspace.  A/B runs only. */
 void flanhip_debug_kernel_variant(int which, int variant);
 
 /* ---- PV frame processors ------------------------------------------------------------------------------------- */
