@@ -53,7 +53,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_eo( AnalyzeParams p, F
 	typedef float VB __attribute__(( ext_vector_type( 4 * QV ) ));
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	cf * s = reinterpret_cast<cf*>( smem );
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane( tid >> 6 );   // a scalar: chain, frame range, audio pointer follow
 	const int W = p.window_size, hop = p.hop;
 
 	// ---- tables (block-wide): the plan's tables are those of the 2048-point transform (tb.tw3: [7][256] exp( -2 pi i r j / 2048 ),

@@ -364,3 +364,38 @@ def test_special_signals(fa, dft, hop):
         s_out = max(float(np.abs(out_ref).max()), 1e-300)
         assert flag == 0 and np.isfinite(out_got).all(), name
         assert np.abs(out_got.astype(np.float64) - out_ref).max() <= 2e-5 * s_out + 1e-37, (name, np.abs(out_got.astype(np.float64) - out_ref).max(), s_out)
+
+
+@pytest.mark.parametrize("hop", [128, 256, 512, 1024])
+def test_dft4096_kernel_generations_agree(fa, hop):
+    """dft 4096, window 2048: the round-2 kernels (two 1024-point transforms per frame: pv_kernels_eo.h; teams of two wavefronts in the fused
+    round trip and in synthesis) against the round-1 ones (one 2048-point register transform per wavefront) on the same input: the same
+    per-bin arithmetic behind two FFT factorisations -- PVs agree like two FFT backends do (magnitudes 1e-7, most f bit for bit), audio from
+    the SAME PV to 1e-6."""
+    sr, W, dft = 48000.0, 2048, 4096
+    x = O.noise(2, 60000 + 7 * hop, seed=hop)
+    ar = np.float32(sr) / np.float32(hop)
+    res = {}
+    try:
+        for gen in (0, 1):
+            fa.lib.flanhip_debug_kernel_variant(2, gen)
+            fa.lib.flanhip_debug_kernel_variant(3, gen)
+            pv = fa.analyze(x, sr, W, hop, dft)
+            res[gen] = pv
+    finally:
+        fa.lib.flanhip_debug_kernel_variant(2, 1)
+        fa.lib.flanhip_debug_kernel_variant(3, 1)
+    m0, m1 = res[0][..., 0].astype(np.float64), res[1][..., 0].astype(np.float64)
+    rel_m = np.sqrt(np.sum((m0 - m1) ** 2) / np.sum(m0 ** 2))
+    same_f = np.mean(res[0][..., 1].view(np.uint32) == res[1][..., 1].view(np.uint32))
+    out = {}
+    try:
+        for gen in (0, 1):
+            fa.lib.flanhip_debug_kernel_variant(3, gen)
+            out[gen], flag = fa.synthesize(res[1], sr, ar, W)
+            assert flag == 0
+    finally:
+        fa.lib.flanhip_debug_kernel_variant(3, 1)
+    d = np.abs(out[0].astype(np.float64) - out[1].astype(np.float64))
+    print("\n[dft 4096 hop %d] generations: rel_m %.2e  f bit-identical %.4f  audio max diff %.2e" % (hop, rel_m, same_f, d.max()))
+    assert rel_m <= 5e-7 and same_f >= 0.95 and d.max() <= 1e-6
