@@ -119,12 +119,12 @@ static int run_analyze_v2_variant( int v, const AnalyzeParams & p, const FastTab
 	}
 
 // dft 4096 with window <= 2048 as two 1024-point register transforms per frame (pv_kernels_eo.h): 8-wave blocks, 160 KB of LDS
-template<int WAVES, bool SUMS, int QV = 2>
+template<int WAVES, int QV = 2>
 static int run_analyze_eo( const AnalyzeParams & p, const FastTables & tb, hipStream_t s )
 	{
 	const size_t lds = EoLds::bytes( WAVES );
 	static_assert( EoLds::bytes( WAVES ) <= kMaxLds, "LDS budget" );
-	auto kern = k_analyze_eo<WAVES, SUMS, QV>;
+	auto kern = k_analyze_eo<WAVES, QV>;
 	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;
 	const int64_t blocks = ( chains + WAVES - 1 ) / WAVES;
@@ -341,7 +341,7 @@ int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int 
 			// the fused round trip (with chain sums): teams of two wavefronts, two E / O buffer sets, one barrier per frame (0.34 ms for 8 ch x 60 s;
 			// one set and two barriers: 0.365; the round-1 kernel: 0.44).  Without sums one wavefront per chain is faster still (0.27 against 0.34:
 			// no barriers) and does not spill.  Variants 2.. are A/B builds of the same kernels.
-			if( !p.sums && g_ana11_variant != 3 ) return run_analyze_eo<8, false, 2>( p, tb, s );
+			if( !p.sums && g_ana11_variant != 3 ) return run_analyze_eo<8, 2>( p, tb, s );
 			if( g_ana11_variant == 2 ) return run_analyze_eo_team<4, true, 2, false>( p, tb, s );
 			if( g_ana11_variant == 3 ) return p.sums ? run_analyze_eo_team<4, true, 1, true>( p, tb, s ) : run_analyze_eo_team<4, false, 2, true>( p, tb, s );
 			return run_analyze_eo_team<4, true, 2, true>( p, tb, s );

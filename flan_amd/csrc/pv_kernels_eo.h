@@ -17,10 +17,6 @@
 #pragma once
 #include "pv_kernels_v2.h"
 
-#ifndef EO_EXP
-#define EO_EXP 0
-#endif
-
 namespace flanhip {
 
 struct EoLds
@@ -45,7 +41,9 @@ __device__ __forceinline__ void split_pair( cf zk, cf zm, float wx, float wy, fl
 	rm = __builtin_fmaf( 0.5f, sx, -t1v ); im = __builtin_fmaf( -0.5f, sy, -t2v );
 	}
 
-template<int WAVES, bool SUMS, int QV = 2>      // QV: quads (of 4 bins) evaluated together as one vector stream
+// One wavefront per chain: for the plain convert_to_PV (no chain sums).  With the fused round trip's sums its state (32 previous phases
+// and 32 sum residues beside the transform) spills, however the loop is arranged -- that job is k_analyze_eo_team's, below.
+template<int WAVES, int QV = 2>                 // QV: quads (of 4 bins) evaluated together as one vector stream
 __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_eo( AnalyzeParams p, FastTables tb )
 	{
 	using L = EoLds;
@@ -94,25 +92,6 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_eo( AnalyzeParams p, F
 	float prev[Q][4], prevs[2] = { 0.0f, 0.0f };
 	#pragma unroll
 	for( int q = 0; q < Q; ++q ) { prev[q][0] = 0.0f; prev[q][1] = 0.0f; prev[q][2] = 0.0f; prev[q][3] = 0.0f; }   // AudioPV.cpp:44
-	// Fused round trip: the chain's sum of phase increments (phase_vocoder.cpp:57-58), modulo pi2, for convert_to_audio.  68 registers of
-	// fp64 sums do not fit beside the transform (they spill, and spills break the counted waits), so the sum is TELESCOPED: an increment is
-	// the float  term = ( f / analysis_rate ) pi2,  and  term - ( phase_t - phase_{t-1} )  is a whole number of turns plus the rounding
-	// of f and term (~1e-4 rad).  Per bin only  R = sum_t [ term_t - ( phase_t - phase_{t-1} ) ] mod pi2  is kept, in ONE float (every
-	// r_t is formed in fp64 and is tiny, so the float sum is good to ~1e-11 rad); the chain's sum is  phase_last - phase_first + R  (mod pi2),
-	// with phase_first parked in the workspace row the result goes to.
-	float rs[SUMS ? Q : 1][4], rs2[2] = { 0.0f, 0.0f };
-	if constexpr( SUMS )
-		{
-		#pragma unroll
-		for( int q = 0; q < Q; ++q ) { rs[q][0] = 0.0f; rs[q][1] = 0.0f; rs[q][2] = 0.0f; rs[q][3] = 0.0f; }
-		}
-	auto residue = []( float term, float phase, float before ) -> float
-		{
-		const double d = double( term ) - ( double( phase ) - double( before ) );
-		const double n = __builtin_rint( d * ( 1.0 / FLANHIP_PI2_D ) );
-		return float( __builtin_fma( -n, FLANHIP_PI2_D, d ) );
-		};
-	float mmax = 0.0f;
 
 	const int64_t tfirst = t0 > 0 ? t0 - 1 : t0;
 	const bool chain_fast = W == 2048 && int64_t( hop ) * tfirst - W / 2 >= 0 && int64_t( hop ) * ( t1 - 1 ) - W / 2 + 2048 <= p.n;
@@ -161,7 +140,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_eo( AnalyzeParams p, F
 				z[q] = mk( raw_e[q].x * wv.x, raw_e[q].y * wv.y );
 				z[Q + q] = mk( 0.0f, 0.0f );
 				}
-			fft_fast<10, NoStamp, !SUMS>( z, bufE, s_tw1, s_tw3, lane );
+			fft_fast<10>( z, bufE, s_tw1, s_tw3, lane );
 			#pragma unroll
 			for( int q = 0; q < 2 * Q; ++q ) bufE[padl + 68 * q] = z[q];              // natural order: slot PAD( lane + 64 q )
 			#pragma unroll
@@ -171,7 +150,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_eo( AnalyzeParams p, F
 				z[q] = mk( raw_o[q].x * wv.z, raw_o[q].y * wv.w );
 				z[Q + q] = mk( 0.0f, 0.0f );
 				}
-			fft_fast<10, NoStamp, !SUMS>( z, bufO, s_tw1, s_tw3, lane );
+			fft_fast<10>( z, bufO, s_tw1, s_tw3, lane );
 			#pragma unroll
 			for( int q = 0; q < 2 * Q; ++q ) bufO[padl + 68 * q] = z[q];
 			wave_sync();
@@ -257,22 +236,6 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_eo( AnalyzeParams p, F
 						__builtin_nontemporal_store( cf{ m[4 * i + 2], f[4 * i + 2] }, row_c - 64 * q );
 						__builtin_nontemporal_store( cf{ m[4 * i + 3], f[4 * i + 3] }, row_d + 64 * q );
 						}
-					if constexpr( SUMS )
-						{
-						const VB term = div_c_v( f, p.ar_div ) * vsplat<VB>( FLANHIP_PI2_F );      // phase_vocoder.cpp:57-58
-						#pragma unroll
-						for( int i = 0; i < QV; ++i )
-							{
-							#pragma unroll
-#if EO_EXP & 1
-							for( int j = 0; j < 4; ++j ) rs[QV * g + i][j] += term[4 * i + j];
-#else
-							for( int j = 0; j < 4; ++j ) rs[QV * g + i][j] += residue( term[4 * i + j], phase[4 * i + j], pv[4 * i + j] );
-#endif
-							}
-						#pragma unroll
-						for( int i = 0; i < 4 * QV; i += 2 ) mmax = __builtin_fmaxf( mmax, __builtin_fmaxf( m[i], m[i + 1] ) );
-						}
 					}
 				}
 				{
@@ -295,11 +258,6 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_eo( AnalyzeParams p, F
 						const float f = bx + div_pi2( wrapped * p.analysis_rate );
 						const float m = magnitude_scaled( r[j], im2[j] );
 						if( lane == 0 ) __builtin_nontemporal_store( mk( m, f ), row + ( j == 0 ? 512 : 1536 ) );
-						if constexpr( SUMS )
-							{
-							rs2[j] += residue( div_c( f, p.ar_div ) * FLANHIP_PI2_F, phase, pvx );
-							mmax = __builtin_fmaxf( mmax, m );
-							}
 						}
 					}
 				}
@@ -313,20 +271,6 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_eo( AnalyzeParams p, F
 			bins_of_frame( t0 - 1, t0, std::true_type{} );
 			transform_frame( t0 );
 			}
-		if constexpr( SUMS && !( EO_EXP & 2 ) )
-			{
-			// phase_first (zero for the first chain of a channel, AudioPV.cpp:44) waits in the workspace row of this chain's sums
-			double * dst = p.sums + chain * ( N2 + 1 );
-			#pragma unroll
-			for( int q = 0; q < Q; ++q )
-				{
-				const int k = lane + 64 * q;
-				dst[k] = double( prev[q][0] ); dst[N2 - k] = double( prev[q][1] );
-				if( k != 0 ) { dst[C - k] = double( prev[q][2] ); dst[C + k] = double( prev[q][3] ); }
-				else dst[C] = double( prev[q][2] );
-				}
-			if( lane == 0 ) { dst[512] = double( prevs[0] ); dst[1536] = double( prevs[1] ); }
-			}
 		for( int64_t t = t0; t < t1; ++t )
 			{
 			bins_of_frame( t, min( t + 1, t1 - 1 ), std::false_type{} );          // (the last frame requests itself again: nobody waits for it)
@@ -335,42 +279,6 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_eo( AnalyzeParams p, F
 		};
 	if( chain_fast ) run_chain( std::true_type{} ); else run_chain( std::false_type{} );
 
-	if constexpr( SUMS && ( EO_EXP & 2 ) )
-		{
-		double * dst = p.sums + chain * ( N2 + 1 );
-		#pragma unroll
-		for( int q = 0; q < Q; ++q ) dst[lane + 64 * q] = double( rs[q][0] + rs[q][1] + rs[q][2] + rs[q][3] + prev[q][0] + prev[q][1] + prev[q][2] + prev[q][3] ) + rs2[0] + rs2[1] + mmax;
-		}
-	if constexpr( SUMS && !( EO_EXP & 2 ) )
-		{
-		// the chain's sum = phase_last - phase_first + R, brought into [0, pi2) (the value k_phase_sums2 would fold to, up to ~1e-11 rad and,
-		// for a sum that is negative as a whole, one turn of the float constant pi2 = 2 pi + 1.7e-7)
-		bool bad = !( mmax <= 3.4028235e38f );
-		auto total = [&]( double first, float last, float r ) -> double
-			{
-			bad |= !( __builtin_fabsf( r ) <= 3.4028235e38f );                       // a NaN / Inf frequency poisons its residue
-			const double v = ( double( last ) - first ) + double( r );
-			const double w = __builtin_fma( -__builtin_floor( v * ( 1.0 / FLANHIP_PI2_D ) ), FLANHIP_PI2_D, v );
-			return w < 0.0 ? w + FLANHIP_PI2_D : ( w >= FLANHIP_PI2_D ? w - FLANHIP_PI2_D : w );
-			};
-		double * dst = p.sums + chain * ( N2 + 1 );
-		#pragma unroll
-		for( int q = 0; q < Q; ++q )
-			{
-			const int k = lane + 64 * q;
-			const double a = total( dst[k], prev[q][0], rs[q][0] ), b = total( dst[N2 - k], prev[q][1], rs[q][1] );
-			const double c = total( dst[C - k], prev[q][2], rs[q][2] );
-			dst[k] = a; dst[N2 - k] = b; dst[C - k] = c;
-			if( k != 0 ) dst[C + k] = total( dst[C + k], prev[q][3], rs[q][3] );   // (lane 0, q = 0: the quad's fourth bin is bin 1024 again)
-			}
-		if( lane == 0 ) { dst[512] = total( dst[512], prevs[0], rs2[0] ); dst[1536] = total( dst[1536], prevs[1], rs2[1] ); }
-		const bool any_bad = __any( bad );
-		if( p.nan_out && lane == 0 )
-			{
-			if( chain == 0 ) { p.nan_out[2] = p.nan_epoch; p.nan_out[4] = p.nan_epoch; }
-			if( any_bad ) p.nan_out[0] = p.nan_epoch;
-			}
-		}
 	}
 
 // =================================================================================================================
@@ -431,7 +339,12 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 	float prev[Q][4], prevs[2] = { 0.0f, 0.0f };
 	#pragma unroll
 	for( int q = 0; q < Q; ++q ) { prev[q][0] = 0.0f; prev[q][1] = 0.0f; prev[q][2] = 0.0f; prev[q][3] = 0.0f; }   // AudioPV.cpp:44
-	// the chain sums of the fused round trip, telescoped (see k_analyze_eo)
+	// Fused round trip: the chain's sum of phase increments (phase_vocoder.cpp:57-58), modulo pi2, for convert_to_audio -- TELESCOPED, so
+	// that it costs one float per bin instead of one double: an increment is the float  term = ( f / analysis_rate ) pi2,  and
+	// term - ( phase_t - phase_{t-1} )  is a whole number of turns plus the rounding of f and term (~1e-4 rad).  Per bin only
+	// R = sum_t [ term_t - ( phase_t - phase_{t-1} ) ] mod pi2  is kept (every r_t is formed in fp64 and is tiny, so the float sum is good
+	// to ~1e-11 rad); the chain's sum is  phase_last - phase_first + R  (mod pi2), with phase_first parked in the workspace row the result
+	// goes to.
 	float rs[SUMS ? Q : 1][4], rs2[2] = { 0.0f, 0.0f };
 	if constexpr( SUMS )
 		{
@@ -656,7 +569,8 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 
 	if constexpr( SUMS )
 		{
-		// the chain's sum = phase_last - phase_first + R, brought into [0, pi2) (see k_analyze_eo)
+		// the chain's sum = phase_last - phase_first + R, brought into [0, pi2): the value k_phase_sums2 would fold to, up to ~1e-11 rad and, for
+		// a sum that is negative as a whole, one turn of the float constant pi2 = 2 pi + 1.7e-7
 		bool bad = !( mmax <= 3.4028235e38f );
 		auto total = [&]( double first, float last, float r ) -> double
 			{
