@@ -149,7 +149,8 @@ static bool hb_kernel( int steep, bool third, HbTaps & k )
 // What CDSPResampler( src, dst ) builds, for the chains served here:
 //   [ hb_down half-band downsamplers ] -> block convolver ( up, down, low-pass at norm_freq with DC gain `gain` ) -> [ hb_up half-band
 //   upsamplers ] -> [ whole-stepping fractional interpolator ]
-struct ChainShape { int hb_down = 0, up = 1, down = 1; double norm_freq = 0.5, gain = 1.0; int hb_up = 0; bool third = false, interp = false; int in_step = 0, out_step = 0; };
+struct ChainShape { int hb_down = 0, up = 1, down = 1; double norm_freq = 0.5, gain = 1.0; int hb_up = 0; bool third = false, interp = false; int in_step = 0, out_step = 0;
+	bool spline = false; double isrc = 0.0, idst = 0.0; };   // spline: no whole stepping -- the interpolator runs from isrc to idst with the spline-interpolated bank
 
 static bool chain_shape( double src, double dst, ChainShape & ch )
 	{
@@ -174,7 +175,8 @@ static bool chain_shape( double src, double dst, ChainShape & ch )
 		if( c == 1 && whole_stepping( src * 2.0, dst, t1, t2 ) ) c = 0;            // :266-276
 		if( c > 0 ) return false;                                                  // intermediate interpolation with its own low-pass design: not served
 		ch.up = 2; ch.norm_freq = dst > src ? 0.5 : 0.5 * dst / src; ch.gain = 2.0; ch.interp = true;
-		return whole_stepping( src * 2.0, dst, ch.in_step, ch.out_step );
+		if( !whole_stepping( src * 2.0, dst, ch.in_step, ch.out_step ) ) { ch.spline = true; ch.isrc = src * 2.0; ch.idst = dst; }
+		return true;
 		}
 	double check = dst * 4.0;                                                     // :319-331
 	int c = 0;
@@ -187,7 +189,11 @@ static bool chain_shape( double src, double dst, ChainShape & ch )
 	else                                                                          // :351-356, :372-376
 		{
 		ch.norm_freq = dst * div / src; ch.third = ch.norm_freq * 3.0 <= 1.0; ch.interp = true;
-		if( !whole_stepping( src, dst * div, ch.in_step, ch.out_step ) ) return false;
+		if( !whole_stepping( src, dst * div, ch.in_step, ch.out_step ) )
+			{
+			if( c > 0 ) return false;                                                // half-band stages in front of the spline bank: not served
+			ch.spline = true; ch.isrc = src; ch.idst = dst * div;
+			}
 		}
 	return c == 0 || hb_kernel( c - 1, ch.third, probe );
 	}
@@ -195,41 +201,118 @@ static bool chain_shape( double src, double dst, ChainShape & ch )
 // CDSPFracDelayFilterBank( OutStep, 1, 2, 206.91, third ) (CDSPFracInterpolator.h:64-121, window parameters :289-348 -- the rows that
 // cover 206.91 dB): `fracs` filters of flt_len taps, row r delays by ( fracs - r ) / fracs samples.  Each is a Kaiser-power windowed
 // sinc sampled at t + delay, t = -fl2 .. fl2 - 1 (CDSPSincFilterGen.h:184-193, :246-257, :432-517), normalised to unit DC gain.
-static void frac_delay_bank( int fracs, bool third, std::vector<double> & bank, int & flt_len )
+static void frac_window_params( bool third, double & beta, double & power, double & att, int & flt_len )
 	{
-	const double pi = 3.14159265358979323846;
-	const double beta = third ? 19.1718281840114810 : 10.2382664677006100;
-	const double power = third ? 1.2030083075440616 : 2.1608878780497056;
+	beta = third ? 19.1718281840114810 : 10.2382664677006100;
+	power = third ? 1.2030083075440616 : 2.1608878780497056;
+	att = third ? 215.2990 : 209.0609;                                            // the table row's own attenuation (what roundReqAtten turns 206.91 into)
 	flt_len = third ? 22 : 28;
-	const int fl2 = flt_len / 2;
-	const double len2 = fl2, kdiv = bessel_i0_as( beta );
-	bank.assign( size_t( fracs ) * flt_len, 0.0 );
-	for( int r = 0; r < fracs; ++r )
-		{
-		double * op = &bank[size_t( r ) * flt_len];
-		const double delay = double( fracs - r ) / fracs, len2frac = delay / len2;
-		const double f0 = std::sin( delay * pi );
-		const bool unit = delay >= 1.0 - 1e-13 && delay <= 1.0 + 1e-13;
-		double sum = 0.0;
-		for( int i = 0; i < flt_len; ++i )
-			{
-			const int t = i - fl2;
-			const double n = 1.0 - sqr( t / len2 + len2frac );
-			const double w = std::pow( n < 0.0 ? 0.0 : bessel_i0_as( beta * std::sqrt( n ) ) / kdiv, power );
-			const double ut = t + delay;
-			double v;
-			if( t == ( unit ? -1 : 0 ) && std::fabs( ut ) <= 1e-13 ) v = w;      // the tap under the peak of the sinc
-			else if( i == flt_len - 1 && ut > len2 ) v = 0.0;
-			else v = ( ( t & 1 ) ? -f0 : f0 ) * w / ut / pi;
-			op[i] = v;
-			sum += v;
-			}
-		const double g = 1.0 / sum;
-		for( int i = 0; i < flt_len; ++i ) op[i] *= g;
-		}
 	}
 
-struct ChainPlan { double * d_h = nullptr; double * d_bank = nullptr; int fl2 = 0, flt_len = 0; ChainShape shape; };
+// one fractional-delay filter: taps t = -fl2 .. fl2 - 1 of the windowed sinc at t + delay (generateFrac, CDSPSincFilterGen.h:432-517, for any
+// delay the banks ask for: a negative one pushes the first tap out of the window, one above 1 the last), normalised to unit DC gain
+static void frac_delay_row( int flt_len, double beta, double power, double delay, double * op )
+	{
+	const double pi = 3.14159265358979323846;
+	const int fl2 = flt_len / 2;
+	const double len2 = fl2, kdiv = bessel_i0_as( beta ), len2frac = delay / len2;
+	const double f0 = std::sin( delay * pi );
+	const bool unit = delay >= 1.0 - 1e-13 && delay <= 1.0 + 1e-13;
+	double sum = 0.0;
+	for( int i = 0; i < flt_len; ++i )
+		{
+		const int t = i - fl2;
+		const double n = 1.0 - sqr( t / len2 + len2frac );
+		const double w = std::pow( n < 0.0 ? 0.0 : bessel_i0_as( beta * std::sqrt( n ) ) / kdiv, power );
+		const double ut = t + delay;
+		double v;
+		if( i == 0 && ut < -len2 ) v = 0.0;
+		else if( t == ( unit ? -1 : 0 ) && std::fabs( ut ) <= 1e-13 ) v = w;     // the tap under the peak of the sinc
+		else if( i == flt_len - 1 && ut > len2 ) v = 0.0;
+		else v = ( ( t & 1 ) ? -f0 : f0 ) * w / ut / pi;
+		op[i] = v;
+		sum += v;
+		}
+	const double g = 1.0 / sum;
+	for( int i = 0; i < flt_len; ++i ) op[i] *= g;
+	}
+
+static void frac_delay_bank( int fracs, bool third, std::vector<double> & bank, int & flt_len )
+	{
+	double beta, power, att;
+	frac_window_params( third, beta, power, att, flt_len );
+	bank.assign( size_t( fracs ) * flt_len, 0.0 );
+	for( int r = 0; r < fracs; ++r ) frac_delay_row( flt_len, beta, power, double( fracs - r ) / fracs, &bank[size_t( r ) * flt_len] );
+	}
+
+// The bank of the interpolator WITHOUT whole stepping (getFilterBank( -1, 3, 8, ... ), CDSPFracInterpolator.h:97-100, :115-165): FilterFracs =
+// ceil( 1.792462178761753 exp( 0.033300466782047 att ) ) rows -- att the table row's attenuation, 1893 / 2329 rows -- with the delays
+// ( fracs - i ) / fracs, i = -3 .. fracs + 4; then every tap of rows 0 .. fracs becomes { x0, c1, c2 }, the 8-point 2nd-order spline through that
+// tap of 8 consecutive rows (r8bbase.h:1019-1029): the kernel evaluates x0 + c1 x + c2 x^2 between two rows.
+static void frac_spline_bank( bool third, std::vector<double> & bank, int & flt_len, int & fracs )
+	{
+	double beta, power, att;
+	frac_window_params( third, beta, power, att, flt_len );
+	fracs = int( std::ceil( 1.792462178761753 * std::exp( 0.033300466782047 * att ) ) );
+	std::vector<double> raw( size_t( fracs + 8 ) * flt_len );
+	for( int r = 0; r < fracs + 8; ++r ) frac_delay_row( flt_len, beta, power, double( fracs - ( r - 3 ) ) / fracs, &raw[size_t( r ) * flt_len] );
+	bank.assign( size_t( fracs + 1 ) * flt_len * 3, 0.0 );
+	for( int r = 0; r <= fracs; ++r )
+		for( int i = 0; i < flt_len; ++i )
+			{
+			const double xm3 = raw[size_t( r ) * flt_len + i], xm2 = raw[size_t( r + 1 ) * flt_len + i], xm1 = raw[size_t( r + 2 ) * flt_len + i],
+				x0 = raw[size_t( r + 3 ) * flt_len + i], x1 = raw[size_t( r + 4 ) * flt_len + i], x2 = raw[size_t( r + 5 ) * flt_len + i],
+				x3 = raw[size_t( r + 6 ) * flt_len + i], x4 = raw[size_t( r + 7 ) * flt_len + i];
+			double * c = &bank[( size_t( r ) * flt_len + i ) * 3];
+			c[0] = x0;
+			c[1] = ( 61.0 * ( x1 - xm1 ) + 16.0 * ( xm2 - x2 ) + 3.0 * ( x3 - xm3 ) ) / 76.0;
+			c[2] = ( 106.0 * ( xm1 + x1 ) + 10.0 * x3 + 6.0 * xm3 - 3.0 * x4 - 29.0 * ( xm2 + x2 ) - 167.0 * x0 ) / 76.0;
+			}
+	}
+
+// The interpolator without whole stepping re-bases its position counter at the end of every process() call that leaves it above 1000
+// (CDSPFracInterpolator.h:884-895), and oneshot() makes one call per `chunk` input samples (CDSPResampler.h:494-552), of which the block
+// convolver has delivered max( 0, up fed - latency ) samples of y (CDSPBlockConvolver.h:62-100, CDSPFIRFilter.h:467-478).  So the exact fp64
+// read positions come in SEGMENTS: outputs j0 .. j0 + count - 1 read y at r0 + int( ( n + shift ) isrc / idst ), n = j - j0 (n = 0: r0 with
+// fraction f0).  Worked out on the host call by call -- a bisection per call, not a walk over the outputs.
+struct FracSegment { int64_t j0, count, r0; double shift, f0; };
+
+static void spline_segments( const ChainShape & ch, int fl2_conv, int flt_len, int64_t chunk, int64_t total_out, std::vector<FracSegment> & segs )
+	{
+	const int kernel_len = 2 * fl2_conv + 1;
+	int bits = 0; while( ( ( kernel_len - 1 ) >> bits ) != 0 ) ++bits;             // getBitOccupancy( KernelLen - 1 )
+	const int64_t latency = int64_t( ( 2 << std::max( bits, 1 ) ) - ( ( kernel_len - 1 + ch.up - 1 ) / ch.up ) * ch.up ) + fl2_conv;   // InputLen + the filter's latency
+	const int fl2i = flt_len / 2;
+	const double src = ch.isrc, dst = ch.idst;
+	FracSegment cur{ 0, 0, 0, 0.0, 0.0 };
+	auto read_abs = [&]( int64_t n ) { return n == 0 ? cur.r0 : cur.r0 + int64_t( ( double( n ) + cur.shift ) * src / dst ); };
+	int64_t j = 0;
+	for( int64_t call = 1; j < total_out; ++call )
+		{
+		const int64_t w = std::max<int64_t>( 0, call * chunk * ch.up - latency );   // samples of y written so far
+		// outputs n = cur.count, cur.count + 1, ... come while w - read_abs( n ) > fl2i: the first n that fails, by bisection (read_abs is monotone)
+		int64_t lo = cur.count, hi = cur.count;
+		if( w - read_abs( lo ) > fl2i )
+			{
+			hi = lo + int64_t( double( w - fl2i - read_abs( lo ) ) * dst / src ) + 4;
+			while( w - read_abs( hi ) > fl2i ) hi += 4;
+			while( hi - lo > 1 ) { const int64_t mid = lo + ( hi - lo ) / 2; if( w - read_abs( mid ) > fl2i ) lo = mid; else hi = mid; }
+			}
+		j += hi - cur.count;
+		cur.count = hi;
+		if( cur.count > 1000 )                                                     // InCounter > 1000 at the end of the call: re-base
+			{
+			const double next = ( double( cur.count ) + cur.shift ) * src / dst;
+			const int64_t next_int = int64_t( next );
+			const double frac = next - double( next_int );
+			segs.push_back( cur );
+			cur = FracSegment{ j, 0, cur.r0 + next_int, frac * dst / src, frac };
+			}
+		}
+	if( cur.count > 0 ) segs.push_back( cur );
+	}
+
+struct ChainPlan { double * d_h = nullptr; double * d_bank = nullptr; int fl2 = 0, flt_len = 0, fracs = 0; ChainShape shape; };
 static std::map<std::tuple<int, double, double>, ChainPlan> g_chain_plans;   // per (device, src, dst)
 
 // Device copies of the taps for one (up, down): h[0 .. 2 fl2] in natural order, and for the 2:1 kernel
@@ -435,6 +518,43 @@ __global__ __launch_bounds__( HB_BLOCK ) void k_hb_up( const double * __restrict
 	out[o] = OutT( acc );
 	}
 
+// CDSPFracInterpolator::convolve2 (CDSPFracInterpolator.h:960-1005): output j of segment { j0, count, r0, shift, f0 } sits n = j - j0 steps in,
+//        position = ( n + shift ) isrc / idst (fp64, in that order; n = 0: exactly r0 and f0),  p = r0 + int( position ),  frac = position - int( position );
+//        x = frac * fracs, row = int( x ), x -= row;   out[j] = float( sum_i ( c0 + c1 x + c2 x^2 )[row][i] * y[p - ( flt_len/2 - 1 ) + i] )
+__global__ __launch_bounds__( FRAC_BLOCK ) void k_frac_spline( const double * __restrict__ y, int64_t ny, const double * __restrict__ bank, int flt_len, int fracs,
+	const FracSegment * __restrict__ segs, int num_segs, double isrc, double idst, float * __restrict__ out, int64_t total_out )
+	{
+	const int64_t j = int64_t( blockIdx.x ) * FRAC_BLOCK + threadIdx.x;
+	if( j >= total_out ) return;
+	int lo = 0, hi = num_segs - 1;                                                // the last segment with j0 <= j
+	while( lo < hi ) { const int mid = ( lo + hi + 1 ) >> 1; if( segs[mid].j0 <= j ) lo = mid; else hi = mid - 1; }
+	const FracSegment sg = segs[lo];
+	const int64_t n = j - sg.j0;
+	int64_t p = sg.r0;
+	double frac = sg.f0;
+	if( n > 0 )
+		{
+		const double position = ( double( n ) + sg.shift ) * isrc / idst;
+		const int64_t whole = int64_t( position );
+		p += whole;
+		frac = position - double( whole );
+		}
+	double x = frac * double( fracs );
+	const int row = int( x );
+	x -= double( row );
+	const double x2 = x * x;
+	const double * ft = bank + size_t( row ) * flt_len * 3;
+	const int64_t a0 = p - ( flt_len / 2 - 1 );
+	double acc = 0.0;
+	for( int i = 0; i < flt_len; ++i )
+		{
+		const int64_t a = a0 + i;
+		const double v = ( a >= 0 && a < ny ) ? y[a] : 0.0;
+		acc = __builtin_fma( ( ft[3 * i] + ft[3 * i + 1] * x ) + ft[3 * i + 2] * x2, v, acc );
+		}
+	out[j] = float( acc );
+	}
+
 static int get_chain_plan( double src, double dst, const ChainPlan ** out )
 	{
 	int device = 0;
@@ -447,7 +567,8 @@ static int get_chain_plan( double src, double dst, const ChainPlan ** out )
 	FLANHIP_REQUIRE( chain_shape( src, dst, p.shape ), FLANHIP_ERR_UNSUPPORTED, "ratio not served" );
 	std::vector<double> h, bank;
 	FLANHIP_REQUIRE( design_default_lowpass( p.shape.norm_freq, p.shape.gain, h, p.fl2 ), FLANHIP_ERR_UNSUPPORTED, "low-pass design outside the restated range" );
-	if( p.shape.interp ) frac_delay_bank( p.shape.out_step, p.shape.third, bank, p.flt_len );
+	if( p.shape.interp && !p.shape.spline ) frac_delay_bank( p.shape.out_step, p.shape.third, bank, p.flt_len );
+	if( p.shape.spline ) frac_spline_bank( p.shape.third, bank, p.flt_len, p.fracs );
 	FLANHIP_CHECK( hipMalloc( &p.d_h, sizeof( double ) * ( h.size() + bank.size() + 1 ) ) );
 	p.d_bank = p.d_h + h.size();
 	FLANHIP_CHECK( hipMemcpy( p.d_h, h.data(), sizeof( double ) * h.size(), hipMemcpyHostToDevice ) );
@@ -477,7 +598,7 @@ static int launch_rational( const InT * d_in, int64_t n_in, const ChainPlan & pl
 // A chain with more than the block convolver in it: every stage on the whole stream in fp64 (r8brain's intermediate type), each for exactly
 // as many samples as the next one reads (zeros before the start and past the end, like the zeros oneshot() feeds); the last stage rounds to
 // float.  Intermediate streams live in the stream's memory pool.
-static int resample_chain_dev( const float * d_in, int64_t total_in, double src, double dst, float * d_out, int64_t total_out, hipStream_t s )
+static int resample_chain_dev( const float * d_in, int64_t total_in, int64_t chunk, double src, double dst, float * d_out, int64_t total_out, hipStream_t s )
 	{
 	const ChainPlan * plan = nullptr;
 	if( int rc = get_chain_plan( src, dst, &plan ) ) return rc;
@@ -488,7 +609,9 @@ static int resample_chain_dev( const float * d_in, int64_t total_in, double src,
 	for( int i = 0; i < ch.hb_up; ++i ) FLANHIP_REQUIRE( hb_kernel( i, ch.third, up_taps[i] ), FLANHIP_ERR_UNSUPPORTED, "half-band chain too deep" );                       // :203-209
 	// samples each stage has to deliver (backwards from the output)
 	int64_t need_up[5];
-	need_up[ch.hb_up] = ch.interp ? ( ( total_out - 1 ) * ch.in_step ) / ch.out_step - ( plan->flt_len / 2 - 1 ) + plan->flt_len : total_out;
+	need_up[ch.hb_up] = !ch.interp ? total_out
+		: ch.spline ? int64_t( std::ceil( double( total_out ) * ch.isrc / ch.idst ) ) + plan->flt_len + 8
+		: ( ( total_out - 1 ) * ch.in_step ) / ch.out_step - ( plan->flt_len / 2 - 1 ) + plan->flt_len;
 	for( int i = ch.hb_up - 1; i >= 0; --i ) need_up[i] = ( need_up[i + 1] - 1 ) / 2 + up_taps[i].n + 1;
 	const int64_t need_conv = std::max<int64_t>( need_up[0], 1 );
 	retain_pool_memory();
@@ -538,7 +661,25 @@ static int resample_chain_dev( const float * d_in, int64_t total_in, double src,
 			cur = nxt; cur_len = n_out;
 			}
 		}
-	if( !rc && ch.interp )
+	if( !rc && ch.spline )
+		{
+		std::vector<FracSegment> segs;
+		spline_segments( ch, plan->fl2, plan->flt_len, chunk, total_out, segs );
+		FracSegment * d_segs = nullptr;
+		if( hipMallocAsync( reinterpret_cast<void**>( &d_segs ), sizeof( FracSegment ) * segs.size(), s ) != hipSuccess ) { set_error( "hipMallocAsync failed" ); rc = FLANHIP_ERR_HIP; }
+		else
+			{
+			temps.push_back( d_segs );
+			if( hipMemcpyAsync( d_segs, segs.data(), sizeof( FracSegment ) * segs.size(), hipMemcpyHostToDevice, s ) != hipSuccess ) { set_error( "hipMemcpyAsync failed" ); rc = FLANHIP_ERR_HIP; }
+			else
+				{
+				(void) hipStreamSynchronize( s );                                   // the table is pageable host memory that dies with this call
+				hipLaunchKernelGGL( k_frac_spline, dim3( (unsigned) ( ( total_out + FRAC_BLOCK - 1 ) / FRAC_BLOCK ) ), dim3( FRAC_BLOCK ), 0, s,
+					cur, cur_len, plan->d_bank, plan->flt_len, plan->fracs, d_segs, int( segs.size() ), ch.isrc, ch.idst, d_out, total_out );
+				}
+			}
+		}
+	else if( !rc && ch.interp )
 		hipLaunchKernelGGL( k_frac_whole, dim3( (unsigned) ( ( total_out + FRAC_BLOCK - 1 ) / FRAC_BLOCK ) ), dim3( FRAC_BLOCK ), 0, s,
 			cur, cur_len, plan->d_bank, plan->flt_len, ch.in_step, ch.out_step, d_out, total_out );
 	const hipError_t launched = hipGetLastError();
@@ -553,9 +694,10 @@ static int resample_chain_dev( const float * d_in, int64_t total_in, double src,
 using namespace flanhip;
 
 static const char * const k_unsupported_ratio =
-	"implemented: the single-step ratios (src:dst = 2:1, 3:1, 3:2, 2:3, 4:3, 1:2, 1:3), block convolver + whole-stepping interpolator ratios "
-	"(44.1 <-> 48 kHz ...) and half-band chains (4x, 8x, 16x, 6x, 12x up; src >= 4 dst down); this one needs r8brain's intermediate "
-	"interpolation with its own low-pass design, its spline-interpolated filter bank or a deeper half-band chain";
+	"implemented: the single-step ratios (src:dst = 2:1, 3:1, 3:2, 2:3, 4:3, 1:2, 1:3), block convolver + interpolator ratios (any dst in "
+	"( src/4, 2.02 src ): 44.1 <-> 48 kHz, 44.1 kHz -> 48001 Hz ...) and half-band chains (4x, 8x, 16x, 6x, 12x up; src >= 4 dst down); this "
+	"one needs r8brain's intermediate interpolation with its own low-pass design, half-band stages in front of its spline-interpolated "
+	"filter bank, or a deeper half-band chain";
 
 extern "C" {
 
@@ -576,7 +718,7 @@ int flanhip_resample_dev( const float * d_in, int64_t ch, int64_t n, float src_r
 	const int64_t n_out = flanhip_resample_out_frames( n, src_rate, dst_rate );
 	const int64_t total_in = ch * n, total_out = ch * n_out;
 	if( total_out <= 0 ) return FLANHIP_OK;
-	if( !single ) return resample_chain_dev( d_in, total_in, double( src_rate ), double( dst_rate ), d_out, total_out, (hipStream_t) stream );
+	if( !single ) return resample_chain_dev( d_in, total_in, n, double( src_rate ), double( dst_rate ), d_out, total_out, (hipStream_t) stream );
 	const ResamplePlan * plan = nullptr;
 	if( int rc = get_resample_plan( up, down, &plan ) ) return rc;
 	if( up == 1 && down == 2 && plan->fl2 >= 64 * ( RS_R - 1 ) )

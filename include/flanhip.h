@@ -348,9 +348,13 @@ int64_t flanhip_resample_out_frames(int64_t num_frames, float src_rate, float ds
  * CDSPFracInterpolator.h:573-602): 44.1 <-> 48 kHz, 96 -> 44.1, 22.05 -> 48, 44.1 -> 96, 44.1 <-> 32 kHz ... (the _dev form takes a
  * transient fp64 workspace of about 2 x the input from the stream's memory pool); and its half-band chains -- dst = 4, 8, 16, 6, 12 x src
  * (block convolver + CDSPHBUpsamplers, CDSPResampler.h:174-212) and src >= 4 dst (CDSPHBDownsamplers + block convolver [+ interpolator],
- * :319-378; 192 -> 48, 96 -> 16, 192 -> 44.1 kHz ...), up to four half-band stages (three for the third-band kernels).  Ratios that need
- * r8brain's intermediate interpolation with a low-pass of its own transition band (dst >= 2.02 src off the 2^k / 3*2^k grid), its
- * spline-interpolated filter bank (rates without whole stepping) or a deeper half-band chain return FLANHIP_ERR_UNSUPPORTED. */
+ * :319-378; 192 -> 48, 96 -> 16, 192 -> 44.1 kHz ...), up to four half-band stages (three for the third-band kernels).  Rates with no small
+ * common divisor (44.1 kHz -> 48001 Hz, 48 kHz -> 50854.3 Hz ...: no whole stepping, CDSPFracInterpolator.h:573-602) run r8brain's
+ * spline-interpolated filter bank (convolve2, :960-1005) with its position counter re-based exactly where oneshot()'s process() calls end --
+ * one call per num_frames input samples, so the result depends on num_frames the way the reference's does; that _dev call synchronises the
+ * stream once (a small table goes up).  Ratios that need r8brain's intermediate interpolation with a low-pass of its own transition band
+ * (dst >= 2.02 src off the 2^k / 3*2^k grid), half-band stages in front of the spline bank (src >= 4 dst without whole stepping) or a deeper
+ * half-band chain return FLANHIP_ERR_UNSUPPORTED. */
 int flanhip_resample(const float * in, int64_t num_channels, int64_t num_frames, float src_rate, float dst_rate,
                      float * out, volatile int * cancel);
 int flanhip_resample_dev(const float * d_in, int64_t num_channels, int64_t num_frames, float src_rate, float dst_rate,

@@ -15,6 +15,7 @@
 // The low-pass is a Kaiser(beta 125)-power windowed sinc whose length / cut-off / window power come from r8brain's fitted
 // design formulas; I0 is the Abramowitz & Stegun 9.8.1 / 9.8.2 polynomial approximation r8brain uses (r8bbase.h:1216-1236).
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <vector>
 
@@ -198,6 +199,7 @@ void frac_delay_filter( int flt_len, double beta, double power, double delay, do
 		};
 	const double f[2] = { std::sin( delay * pi ), -std::sin( delay * pi ) };
 	int t = -fl2;
+	if( t + delay < -len2 ) { (void) win(); *op++ = 0.0; ++t; }                 // :444-450: a negative delay (the spline bank's rows beyond 1) pushes the first tap out of the window
 	const int mt = ( delay >= 1.0 - 1e-13 && delay <= 1.0 + 1e-13 ) ? -1 : 0;
 	for( ; t < mt; ++t ) *op++ = f[t & 1] * win() / ( t + delay ) / pi;
 	double ut = t + delay;
@@ -220,6 +222,50 @@ void frac_delay_bank( int fracs, bool third, std::vector<double> & bank, int & f
 	const double beta = wp[0] < 1.0 ? 1.0 : wp[0] > 350.0 ? 350.0 : wp[0];
 	bank.assign( size_t( fracs ) * flt_len, 0.0 );
 	for( int r = 0; r < fracs; ++r ) frac_delay_filter( flt_len, beta, std::fabs( wp[1] ), double( fracs - r ) / fracs, &bank[size_t( r ) * flt_len] );
+	}
+
+// ---- the interpolator WITHOUT whole stepping (CDSPFracInterpolator.h: getFilterBank( -1, 3, 8, ... ), convolve2 :960-1005) ---------------
+// The bank: FilterFracs = ceil( 1.792462178761753 exp( 0.033300466782047 ReqAtten ) ) rows plus 8 for the spline's reach (:97-100, :115-127:
+// row i has the delay ( FilterFracs - i ) / FilterFracs for i = -3 .. FilterFracs + 4), then every tap of rows 0 .. FilterFracs replaced in
+// place by the 8-point 2nd-order spline through that tap of 8 consecutive rows (r8bbase.h:1019-1029): { x0, c1, c2 } per tap.
+// (the cache rounds the requested attenuation UP to its table row first -- roundReqAtten, :394-398, :151-155 -- 209.0609 dB for the half-band
+// parameters, 215.2990 dB for the third-band ones: 1893 / 2329 rows)
+int spline_bank_fracs( bool third )
+	{
+	int flt_len; const double * wp = frac_win_params( 206.91, third, flt_len );
+	return int( std::ceil( 1.792462178761753 * std::exp( 0.033300466782047 * wp[2] ) ) );
+	}
+
+void frac_spline_bank( bool third, std::vector<double> & bank, int & flt_len, int & fracs )
+	{
+	fracs = spline_bank_fracs( third );
+	const double * wp = frac_win_params( 206.91, third, flt_len );
+	const double beta = wp[0] < 1.0 ? 1.0 : wp[0] > 350.0 ? 350.0 : wp[0];
+	const int rows = fracs + 8;
+	std::vector<double> raw( size_t( rows ) * flt_len );
+	for( int r = 0; r < rows; ++r ) frac_delay_filter( flt_len, beta, std::fabs( wp[1] ), double( fracs - ( r - 3 ) ) / fracs, &raw[size_t( r ) * flt_len] );
+	bank.assign( size_t( fracs + 1 ) * flt_len * 3, 0.0 );
+	for( int r = 0; r <= fracs; ++r )
+		for( int i = 0; i < flt_len; ++i )
+			{
+			auto x = [&]( int d ) { return raw[size_t( r + d ) * flt_len + i]; };   // xm3 = row r ... x4 = row r + 7
+			double * c = &bank[( size_t( r ) * flt_len + i ) * 3];
+			c[0] = x( 3 );
+			c[1] = ( 61.0 * ( x( 4 ) - x( 2 ) ) + 16.0 * ( x( 1 ) - x( 5 ) ) + 3.0 * ( x( 6 ) - x( 0 ) ) ) / 76.0;
+			c[2] = ( 106.0 * ( x( 2 ) + x( 4 ) ) + 10.0 * x( 6 ) + 6.0 * x( 0 ) - 3.0 * x( 7 ) - 29.0 * ( x( 1 ) + x( 5 ) ) - 167.0 * x( 3 ) ) / 76.0;
+			}
+	}
+
+// CDSPBlockConvolver's consumed latency (CDSPBlockConvolver.h:62-100 with a power-of-two UpFactor and DownFactor 1; CDSPFIRFilter.h:467-478):
+// the stream y it hands on after n_in input samples has max( 0, up n_in - latency ) samples
+int64_t block_convolver_latency( int fl2, int up )
+	{
+	const int kernel_len = 2 * fl2 + 1;
+	int bits = 0; while( ( ( kernel_len - 1 ) >> bits ) != 0 ) ++bits;            // getBitOccupancy (r8bbase.h:775-)
+	if( bits < 1 ) bits = 1;
+	const int block_len2 = 2 << bits;
+	const int prev_input = ( kernel_len - 1 + up - 1 ) / up;
+	return int64_t( block_len2 - prev_input * up ) + fl2;                          // InputLen + the filter's latency
 	}
 
 } // namespace
@@ -323,7 +369,8 @@ struct Chain
 	int up = 1, down = 1; double norm_freq = 0.5, gain = 1.0;    // the block convolver
 	int hb_up = 0;                         // CDSPHBUpsampler stages behind it (SteepIndex 0 .. hb_up-1)
 	bool third = false;                    // third-band half-band kernels / interpolator bank
-	bool interp = false; int in_step = 0, out_step = 0;          // whole-stepping CDSPFracInterpolator last
+	bool interp = false; int in_step = 0, out_step = 0;          // whole-stepping CDSPFracInterpolator last ...
+	bool spline = false; double isrc = 0.0, idst = 0.0;          // ... or the spline-interpolated bank when the rates have no whole stepping
 	};
 
 bool chain_shape( double src, double dst, Chain & ch )
@@ -342,8 +389,15 @@ bool chain_shape( double src, double dst, Chain & ch )
 	TwoStage ts{};
 	if( dst * 2 > src )                                                                            // :214-316
 		{
-		if( !two_stage_shape( src, dst, ts ) ) return false;
-		ch.up = ts.up; ch.norm_freq = ts.norm_freq; ch.gain = ts.gain; ch.third = ts.third; ch.interp = true; ch.in_step = ts.in_step; ch.out_step = ts.out_step;
+		if( two_stage_shape( src, dst, ts ) )
+			{
+			ch.up = ts.up; ch.norm_freq = ts.norm_freq; ch.gain = ts.gain; ch.third = ts.third; ch.interp = true; ch.in_step = ts.in_step; ch.out_step = ts.out_step;
+			return true;
+			}
+		// no whole stepping from 2 src: the same chain with the spline-interpolated bank, unless intermediate interpolation is chosen (:229-276)
+		const double thresh = src * 1.01;
+		if( !( dst < thresh * 2 ) ) return false;
+		ch.up = 2; ch.norm_freq = dst > src ? 0.5 : 0.5 * dst / src; ch.gain = 2.0; ch.interp = true; ch.spline = true; ch.isrc = src * 2.0; ch.idst = dst;
 		return true;
 		}
 	double check = dst * 4.0, fin_gain = 1.0;                                                      // :319-331
@@ -358,7 +412,11 @@ bool chain_shape( double src, double dst, Chain & ch )
 		{
 		ch.down = 1; ch.norm_freq = dst * div / src; ch.third = ch.norm_freq * 3.0 <= 1.0;
 		ch.interp = true;
-		if( !whole_stepping( src, dst * div, ch.in_step, ch.out_step ) ) return false;
+		if( !whole_stepping( src, dst * div, ch.in_step, ch.out_step ) )
+			{
+			if( c > 0 ) return false;                                                              // (half-band stages in front of the spline bank: not restated)
+			ch.spline = true; ch.isrc = src; ch.idst = dst * div;
+			}
 		}
 	int n; return c == 0 || hb_kernel( c - 1, ch.third, n ) != nullptr;
 	}
@@ -369,7 +427,7 @@ double at( const std::vector<double> & v, int64_t i ) { return i >= 0 && i < int
 
 // 1 when this file restates the chain CDSPResampler( src, dst ) builds; the shape for tests
 extern "C" int oracle_resample_chain_shape( double src, double dst, int * hb_down, int * up, int * down, double * norm_freq, double * gain, int * hb_up, int * third,
-	int * interp, int * in_step, int * out_step )
+	int * interp, int * in_step, int * out_step, int * spline )
 	{
 	Chain ch;
 	if( !chain_shape( src, dst, ch ) ) return 0;
@@ -383,24 +441,27 @@ extern "C" int oracle_resample_chain_shape( double src, double dst, int * hb_dow
 	if( interp ) *interp = ch.interp ? 1 : 0;
 	if( in_step ) *in_step = ch.in_step;
 	if( out_step ) *out_step = ch.out_step;
+	if( spline ) *spline = ch.spline ? 1 : 0;
 	return 1;
 	}
 
 // Audio::resample through any restated chain: [half-band downsamplers] -> block convolver -> [half-band upsamplers] -> [interpolator].
 // Every stage is evaluated on the whole stream in fp64 (r8brain's own intermediate type), zero before the start and past the input,
 // for exactly as many samples as the next stage reads; the last stage rounds to float.
-extern "C" int oracle_resample_chain( const float * in, int64_t total_in, float * out, int64_t total_out, double src, double dst )
+extern "C" int oracle_resample_chain( const float * in, int64_t total_in, float * out, int64_t total_out, double src, double dst, int64_t chunk )
 	{
 	Chain ch;
 	if( !chain_shape( src, dst, ch ) ) return -1;
 	if( total_out <= 0 ) return 0;
 	std::vector<double> h; int fl2 = 0;
 	if( !design_default_lowpass( ch.norm_freq, ch.gain, h, fl2 ) ) return -1;
-	std::vector<double> bank; int flt_len = 0;
-	if( ch.interp ) frac_delay_bank( ch.out_step, ch.third, bank, flt_len );
+	std::vector<double> bank; int flt_len = 0, fracs = 0;
+	if( ch.interp && !ch.spline ) frac_delay_bank( ch.out_step, ch.third, bank, flt_len );
+	if( ch.spline ) frac_spline_bank( ch.third, bank, flt_len, fracs );
 	// how many samples of each stage's output the stage after it reads (backwards from the output)
 	int64_t need = total_out;
-	if( ch.interp ) need = ( ( total_out - 1 ) * ch.in_step ) / ch.out_step - ( flt_len / 2 - 1 ) + flt_len;
+	if( ch.interp && !ch.spline ) need = ( ( total_out - 1 ) * ch.in_step ) / ch.out_step - ( flt_len / 2 - 1 ) + flt_len;
+	if( ch.spline ) need = int64_t( std::ceil( double( total_out ) * ch.isrc / ch.idst ) ) + flt_len + 8;
 	std::vector<int64_t> need_up( size_t( ch.hb_up ) + 1 );
 	need_up[size_t( ch.hb_up )] = need;                                            // output of the last upsampler (or of the convolver)
 	for( int s = ch.hb_up - 1; s >= 0; --s ) { int n; hb_kernel( s, ch.third, n ); need_up[size_t( s )] = ( need_up[size_t( s ) + 1] - 1 ) / 2 + n + 1; }
@@ -450,6 +511,41 @@ extern "C" int oracle_resample_chain( const float * in, int64_t total_in, float 
 		}
 	if( !ch.interp ) { for( int64_t k = 0; k < total_out; ++k ) out[k] = float( at( cur, k ) ); return 0; }
 	const int fll = flt_len / 2 - 1;
+	if( ch.spline )
+		{
+		// CDSPFracInterpolator::process + convolve2 (:826-895, :960-1005), call by call: oneshot() feeds `chunk` input samples per call
+		// (CDSPResampler.h:494-552: the resampler was built with MaxInLen = the channel's frame count), of which the block convolver has
+		// delivered max( 0, up * fed - latency ) samples of y; outputs come while more than flt_len / 2 samples lie ahead of the read position
+		// (:964); the position counter is re-based after every call that leaves it above 1000 (:884-895)
+		const int64_t latency = block_convolver_latency( fl2, ch.up );
+		const int fl2i = flt_len / 2;
+		int64_t read_abs = 0, j = 0;
+		int in_counter = 0, in_pos_int = 0;
+		double shift = 0.0, frac = 0.0;                                              // InitFracPos = 0 (linear-phase filters)
+		for( int64_t call = 1; j < total_out; ++call )
+			{
+			const int64_t w = std::max<int64_t>( 0, call * chunk * ch.up - latency );
+			while( w - read_abs > fl2i && j < total_out )
+				{
+				double x = frac * fracs;
+				const int fti = int( x );
+				x -= fti;
+				const double x2 = x * x;
+				const double * ftp = &bank[size_t( fti ) * flt_len * 3];
+				double sacc = 0.0;
+				for( int i = 0; i < flt_len; ++i ) sacc += ( ftp[3 * i] + ftp[3 * i + 1] * x + ftp[3 * i + 2] * x2 ) * at( cur, read_abs - fll + i );
+				out[j++] = float( sacc );
+				++in_counter;
+				const double next = ( in_counter + shift ) * ch.isrc / ch.idst;
+				const int next_int = int( next );
+				read_abs += next_int - in_pos_int;
+				in_pos_int = next_int;
+				frac = next - next_int;
+				}
+			if( in_counter > 1000 ) { in_counter = 0; in_pos_int = 0; shift = frac * ch.idst / ch.isrc; }
+			}
+		return 0;
+		}
 	for( int64_t k = 0; k < total_out; ++k )
 		{
 		const int64_t pos = k * ch.in_step, p = pos / ch.out_step;

@@ -50,7 +50,9 @@ def main():
                                        ("ms_441_48", 2, 4410, 44100.0, 48000.0, 31), ("ms_48_441", 2, 4800, 48000.0, 44100.0, 32),
                                        ("hb_48_192", 2, 1200, 48000.0, 192000.0, 33), ("hb_192_48", 2, 4800, 192000.0, 48000.0, 34),
                                        ("hb_192_441", 1, 4800, 192000.0, 44100.0, 35), ("hb_8_96", 1, 400, 8000.0, 96000.0, 36),
-                                       ("hb_96_16", 2, 2400, 96000.0, 16000.0, 37)):
+                                       ("hb_96_16", 2, 2400, 96000.0, 16000.0, 37),
+                                       ("sp_441_48001", 3, 2500, 44100.0, 48001.0, 38), ("sp_48_50854", 2, 3000, 48000.0, float(np.float32(50854.3)), 39),
+                                       ("sp_441_14000", 2, 4000, 44100.0, float(np.float32(14000.3)), 40)):
         x = O.noise(ch, n, seed)
         cases[tag + "_x"] = x
         cases[tag + "_y"] = r8b(r8, x, src, dst)

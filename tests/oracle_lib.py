@@ -70,8 +70,8 @@ def _load():
     lib.oracle_r8b_frac_bank.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int]
     lib.oracle_resample_two_stage.argtypes = [f32p, C.c_int64, f32p, C.c_int64, C.c_double, C.c_double]
     dp = C.POINTER(C.c_double)
-    lib.oracle_resample_chain_shape.argtypes = [C.c_double, C.c_double, ip, ip, ip, dp, dp, ip, ip, ip, ip, ip]
-    lib.oracle_resample_chain.argtypes = [f32p, C.c_int64, f32p, C.c_int64, C.c_double, C.c_double]
+    lib.oracle_resample_chain_shape.argtypes = [C.c_double, C.c_double, ip, ip, ip, dp, dp, ip, ip, ip, ip, ip, ip]
+    lib.oracle_resample_chain.argtypes = [f32p, C.c_int64, f32p, C.c_int64, C.c_double, C.c_double, C.c_int64]
     i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
     lib.oracle_interpolate.restype = C.c_float
     lib.oracle_interpolate.argtypes = [C.c_int, C.c_float]
@@ -514,13 +514,16 @@ def resample_two_stage(audio, src_rate, dst_rate):
 def chain_shape(src_rate, dst_rate):
     """None, or the chain CDSPResampler( src, dst ) builds when the checker restates it: [half-band downsamplers] -> block convolver
     -> [half-band upsamplers] -> [whole-stepping interpolator]"""
-    iv = [C.c_int() for _ in range(8)]
+    iv = [C.c_int() for _ in range(9)]
     nf, gain = C.c_double(), C.c_double()
     if not lib.oracle_resample_chain_shape(src_rate, dst_rate, C.byref(iv[0]), C.byref(iv[1]), C.byref(iv[2]), C.byref(nf), C.byref(gain),
-                                           C.byref(iv[3]), C.byref(iv[4]), C.byref(iv[5]), C.byref(iv[6]), C.byref(iv[7])):
+                                           C.byref(iv[3]), C.byref(iv[4]), C.byref(iv[5]), C.byref(iv[6]), C.byref(iv[7]), C.byref(iv[8])):
         return None
-    return dict(hb_down=iv[0].value, up=iv[1].value, down=iv[2].value, norm_freq=nf.value, gain=gain.value, hb_up=iv[3].value,
-                third=bool(iv[4].value), interp=bool(iv[5].value), in_step=iv[6].value, out_step=iv[7].value)
+    d = dict(hb_down=iv[0].value, up=iv[1].value, down=iv[2].value, norm_freq=nf.value, gain=gain.value, hb_up=iv[3].value,
+             third=bool(iv[4].value), interp=bool(iv[5].value), in_step=iv[6].value, out_step=iv[7].value)
+    if iv[8].value:
+        d["spline"] = True
+    return d
 
 
 def resample_chain(audio, src_rate, dst_rate):
@@ -529,7 +532,7 @@ def resample_chain(audio, src_rate, dst_rate):
     ch, n = audio.shape
     n_out = int(lib.oracle_resample_out_frames(n, src_rate, dst_rate))
     out = np.empty((ch, n_out), np.float32)
-    rc = lib.oracle_resample_chain(audio.reshape(-1), ch * n, out.reshape(-1), ch * n_out, float(src_rate), float(dst_rate))
+    rc = lib.oracle_resample_chain(audio.reshape(-1), ch * n, out.reshape(-1), ch * n_out, float(src_rate), float(dst_rate), n)   # oneshot feeds n samples per call
     assert rc == 0, "chain not restated"
     return out
 

@@ -84,6 +84,29 @@ def test_resample_half_band_chains(fa, src, dst):
         assert (d.max() if d.size else 0.0) <= 1.2e-7 and same >= 0.999
 
 
+SPLINE = [(44100.0, 48001.0), (48000.0, 50854.3), (44100.0, 22000.0), (44100.0, 44056.0), (96000.0, 44101.0), (44100.0, 14000.3)]
+
+
+@pytest.mark.parametrize("src,dst", SPLINE)
+def test_resample_without_whole_stepping(fa, src, dst):
+    """rates with no small common divisor: r8brain's interpolator then reads a spline-interpolated bank of 1893 (2329 third-band) fractional
+    delay filters at fp64 positions whose counter is re-based at every process() call (k_frac_spline; the call boundaries are worked out on
+    the host: spline_segments).  Several channels = several calls = several re-basings; against the restatement, which is bit-identical to
+    the vendored r8brain on these rates (test_oracle_resample.py)"""
+    src, dst = float(np.float32(src)), float(np.float32(dst))           # FrameRate is a float (Audio.h): r8brain sees the float's value
+    sh = O.chain_shape(src, dst)
+    assert sh is not None and sh.get("spline")
+    for ch, n in ((4, 20001), (3, 2500), (1, 300)):
+        x = O.noise(ch, n, seed=n + int(dst))
+        ref = O.resample_chain(x, src, dst)
+        got = fa.resample(x, src, dst)
+        assert got.shape == ref.shape
+        d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+        same = np.mean(got.view(np.uint32) == ref.view(np.uint32))
+        print("\n[resample %g->%g %dx%d] max diff %.2e  bit-identical %.5f" % (src, dst, ch, n, d.max(), same))
+        assert d.max() <= 1.2e-7 and same >= 0.999
+
+
 def test_resample_two_stage_long(fa):
     """a minute of 44.1 kHz stereo to 48 kHz: the sine comes out a sine (size-independent property; the oracle is not run at this size)"""
     sr, n = 44100.0, 44100 * 60
@@ -102,11 +125,11 @@ def test_resample_two_stage_long(fa):
 
 
 def test_unsupported_ratio(fa):
-    """ratios r8brain serves through intermediate interpolation with its own low-pass, a half-band chain deeper than 16x, or the
-    spline-interpolated bank are refused, not approximated"""
+    """ratios r8brain serves through intermediate interpolation with its own low-pass, a half-band chain deeper than 16x, or half-band
+    stages in front of the spline-interpolated bank are refused, not approximated"""
     import flan_amd
     x = O.noise(1, 1000, seed=1)
-    for src, dst in ((8000.0, 44100.0), (1000.0, 64000.0), (44100.0, 22000.0), (44100.0, 48001.0)):
+    for src, dst in ((8000.0, 44100.0), (1000.0, 64000.0), (192000.0, 44101.0), (11025.0, 48001.0)):
         with pytest.raises(flan_amd.FlanHipError) as e:
             fa.resample(x, src, dst)
         assert e.value.code == flan_amd.ERR_UNSUPPORTED
@@ -144,7 +167,7 @@ def test_resample_fixture(fa):
 
 @pytest.mark.parametrize("tag", ["c5_stereo_0p1s", "c5_mono_ragged", "c5_stereo_0p25s", "c5_three_short", "up_32_48", "down_144_48", "down_72_48",
                                  "up_48_96", "up_16_48", "down_64_48", "ms_441_48", "ms_48_441", "hb_48_192", "hb_192_48", "hb_192_441",
-                                 "hb_8_96", "hb_96_16"])
+                                 "hb_8_96", "hb_96_16", "sp_441_48001", "sp_48_50854", "sp_441_14000"])
 def test_resample_against_the_real_r8brain(fa, tag):
     """the HIP resampler against vectors the reference's vendored r8brain produced (tests/golden/ref_made/r8brain.npz, made by
     make_ref_made.py from oracle/_ref/libr8bref.so): config 5's 96 -> 48 kHz incl. the 2-channel cross-channel bleed, every other

@@ -92,10 +92,11 @@ def test_resample_restatement_against_real_r8brain_vectors(tag):
     assert same >= 0.999 and worst <= 1.2e-7            # one fp32 ulp at unit scale (the fp64 sums differ in the 16th digit only)
 
 
-@pytest.mark.parametrize("tag", ["ms_441_48", "ms_48_441", "hb_48_192", "hb_192_48", "hb_192_441", "hb_8_96", "hb_96_16"])
+@pytest.mark.parametrize("tag", ["ms_441_48", "ms_48_441", "hb_48_192", "hb_192_48", "hb_192_441", "hb_8_96", "hb_96_16", "sp_441_48001", "sp_48_50854", "sp_441_14000"])
 def test_two_stage_restatement_against_real_r8brain_vectors(tag):
     """44.1 <-> 48 kHz (block convolver + whole-stepping CDSPFracInterpolator) and the half-band chains (4x, 12x up; 4x, 6x down;
-    half-band + interpolator): the restatement against the vendored r8brain's output"""
+    half-band + interpolator) and rates without whole stepping (the spline-interpolated bank, re-based per call): the restatement against
+    the vendored r8brain's output"""
     g = np.load(os.path.join(G, "r8brain.npz"))
     x, y = g[tag + "_x"], g[tag + "_y"]
     src, dst = (float(v) for v in g[tag + "_rates"])
