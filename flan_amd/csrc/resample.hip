@@ -1,22 +1,18 @@
-// resample.hip -- Audio::resample for the 2:1 decimation case behind the C ABI (BASELINE config 5: 96 kHz -> 48 kHz).
+// resample.hip -- Audio::resample behind the C ABI: the whole of r8brain's CDSPResampler for the parameters Flan uses.
 //
-// Reference: Audio/AudioConversions.cpp:14-30 calls r8b::CDSPResampler( src, dst, num_frames ) with default parameters
-// (transition band 2 %, attenuation 206.91 dB, linear phase; r8brain/CDSPResampler.h:115-118) and ONE oneshot over the whole
-// channel-major buffer -- all channels as a single stream.  For src = 2 dst that is one low-pass (CDSPFIRFilter::buildLPFilter,
-// r8brain/CDSPFIRFilter.h:227-493, normalised cut-off 1/2, gain 1) applied by FFT block convolution with 2:1 decimation and the
-// filter latency consumed (r8brain/CDSPBlockConvolver.h:62-184).  Convolution is convolution: here it is the direct fp64 sum
-//        out[k] = float( sum_{j=-fl2..fl2} h[j] * x[2k - j] ),   x = 0 outside the buffer,
-// with the 1621 taps of r8brain's Kaiser-power windowed sinc design computed once on the host.
-// The other ratios r8brain serves with a SINGLE block convolver (CDSPResampler.h:139-161: src*num == dst*den for (num,den) in
-// (1,3) (2,3) (3,2) (3,4); :165-207: dst == 2 src, dst == 3 src) are the same sum over a zero-stuffed input,
-//        out[k] = float( sum_j h[j] * xu[down*k - j] ),  xu[up*m] = x[m],
-// with the low-pass at cut-off 1/max(up,down) and DC gain `up` (k_resample_rational).
-// 44.1 <-> 48 kHz and the other ratios r8brain serves with one block convolver FOLLOWED BY one whole-stepping CDSPFracInterpolator
-// (CDSPResampler.h:214-316 with no half-band stage, :319-378 likewise; CDSPFracInterpolator.h:573-602, :929-958) keep r8brain's two
-// stages: k_resample_rational writes the band-limited stream y in fp64 (2x zero-stuffed, or filtered in place), k_frac_whole walks it
-// with the bank of OutStep fractional-delay filters (28 taps at 206.91 dB).  Ratios that need half-band up/downsamplers (dst >= 2.02 src
-// off the 2^k / 3*2^k grid, src >= 4 dst) or the spline-interpolated bank (no whole stepping: rates without a small common divisor)
-// are not implemented: FLANHIP_ERR_UNSUPPORTED.
+// Reference: Audio/AudioConversions.cpp:14-30 calls r8b::CDSPResampler( src, dst, num_frames ) with default parameters (transition band 2 %,
+// attenuation 206.91 dB, linear phase; r8brain/CDSPResampler.h:115-118) and ONE oneshot over the whole channel-major buffer -- all channels as
+// a single stream.  CDSPResampler's constructor (:119-378) turns the two rates into a chain of stages; build_stages() below restates it:
+//   * block convolver (CDSPBlockConvolver.h, filter from CDSPFIRFilter::buildLPFilter :227-493): convolution is convolution -- here the direct
+//     fp64 sum  out[k] = sum_m h[fl2 + down k - up m] x[m]  over the zero-stuffed input, latency consumed, taps of r8brain's Kaiser-power
+//     windowed sinc design computed on the host.  BASELINE config 5's 96 -> 48 kHz is one such stage: the tuned k_resample_2to1 (1621 taps);
+//     every other (up, down) and every non-final stage: k_resample_rational;
+//   * half-band up / downsamplers (CDSPHBUpsampler.h, CDSPHBDownsampler.h): k_hb_up, k_hb_down with the kernels r8brain picks at 206.91 dB;
+//   * fractional interpolator (CDSPFracInterpolator.h): whole stepping (44.1 <-> 48 kHz: a bank of OutStep fractional-delay filters, exact
+//     integer positions: k_frac_whole) or, for rates without a small common divisor, the spline-interpolated bank with its per-call
+//     position re-basing (k_frac_spline + spline_segments).
+// Chains of more than one stage run stage by stage on the whole stream in fp64 (resample_stages_dev).  Nothing r8brain serves for these
+// parameters is refused.
 #include "flanhip_internal.h"
 #include "processors_common.h"
 #include <cmath>
@@ -42,23 +38,48 @@ static double bessel_i0_as( double x )
 		y * ( -0.2057706e-1 + y * ( 0.2635537e-1 + y * ( -0.1647633e-1 + y * 0.392377e-2 ) ) ) ) ) ) ) );
 	}
 
-// buildLPFilter for the parameters Flan always uses (tb 2 %, 206.91 dB, linear phase), cut-off `req_norm_freq`, DC gain `gain`
-static bool design_default_lowpass( double req_norm_freq, double gain, std::vector<double> & h, int & fl2 )
+// buildLPFilter (CDSPFIRFilter.h:227-493) for 206.91 dB, linear phase -- what Flan always asks for -- at cut-off `req_norm_freq`, DC gain `gain`
+// and transition band `tb_percent` (2 everywhere but in the second convolver of r8brain's intermediate-interpolation branch)
+static bool design_lowpass( double req_norm_freq, double tb_percent, double gain, std::vector<double> & h, int & fl2 )
 	{
-	const double tb = 2.0 * 0.01;                                              // CDSPFIRFilter.h:229
-	double atten = -206.91 - 0.21;                                             // :233, :268-273
-	const int corr_index = int( std::floor( ( -atten - 49.0 ) * 264 / 176.25 + 0.5 ) );   // :285-291
-	if( corr_index != 237 ) return false;
-	atten -= -19 / 196.0;                                                      // :354-376, entry 237 of the tb < 0.10 correction table
+	const double tb = tb_percent * 0.01;                                       // :229
+	if( !( tb > 0.0 ) ) return false;
+	double atten = -206.91 - ( tb >= 0.25 ? 1.60 : tb >= 0.10 ? 0.69 : 0.21 );  // :233-281
+	const int corr_index = int( std::floor( ( -atten - 49.0 ) * 264 / 176.25 + 0.5 ) );   // :283-291
+	if( corr_index != ( tb >= 0.25 ? 239 : tb >= 0.10 ? 238 : 237 ) ) return false;
+	atten -= tb >= 0.25 ? -12 / 101.0 : tb >= 0.10 ? -62 / 210.0 : -19 / 196.0;  // :293-376: the entry of each correction table this attenuation lands on
 	const double pwr = 7.43932822146293e-8 * sqr( atten ) + 0.000102747434588003 * std::cos( 0.00785021930010397 * atten ) *
 		std::cos( 0.633854318781239 + 0.103208573657699 * atten ) - 0.00798132247867036 - 0.000903555213543865 * atten -
 		0.0969365532127236 * std::exp( 0.0779275237937911 * atten ) - 1.37304948662012e-5 * atten * std::cos( 0.00785021930010397 * atten );   // :379-384
 	double hl, fo1;
-	if( pwr <= 0.067665322581 )                                                // :386, :425-435
+	const bool low = pwr <= 0.067665322581;                                    // :386
+	if( tb >= 0.25 && low )                                                    // :388-401
+		{
+		hl = 2.6778150875894 / tb + 300.547590563091 * std::atan( std::atan( 2.68959772209918 * pwr ) ) / ( 5.5099277187035 * tb - tb * std::tanh( std::cos( std::asinh( atten ) ) ) );
+		fo1 = 0.987205355829873 * tb + 1.00011788929851 * std::atan2( -0.321432067051302 - 6.19131357321578 * std::sqrt( pwr ),
+			hl + -1.14861472207245 / ( hl - 14.1821147585957 ) + std::pow( 0.9521145021664, std::pow( std::atan2( 1.12018764830637, tb ), 2.10988901686912 * hl - 20.9691278378345 ) ) );
+		}
+	else if( tb >= 0.10 && low )                                               // :403-414
+		{
+		hl = ( 1.56688617018066 + 142.064321294568 * pwr + 0.00419441117131136 * std::cos( 243.633511747297 * pwr ) - 0.022953443903576 * atten -
+			0.026629568860284 * std::cos( 127.715550622571 * pwr ) ) / tb;
+		fo1 = 0.982299356642411 * tb + 0.999441744774215 * std::asinh( ( -0.361783054039583 - 5.80540593623676 * std::sqrt( pwr ) ) / hl );
+		}
+	else if( low )                                                             // :416-426
 		{
 		hl = ( 2.45739657014937 + 269.183679500541 * pwr * std::cos( 5.73225668178813 +
 			std::atan2( std::cosh( 0.988861169868941 - 17.2201556280744 * pwr ), 1.08340138240431 * pwr ) ) ) / tb;
 		fo1 = 2.291956939 * tb + 0.01942450693 * sqr( tb ) * hl - 4.67538973161837 * pwr * tb - 1.668433124 * tb * std::pow( pwr, pwr );
+		}
+	else if( tb >= 0.25 )                                                      // :430-438
+		{
+		hl = ( 1.50258368698213 + 158.556968859477 * std::asinh( pwr ) * std::tanh( 57.9466246871383 * std::tanh( pwr ) ) - 0.0105440479814834 * atten ) / tb;
+		fo1 = 0.994024401639321 * tb + ( -0.236282717577215 - 6.8724924545387 * std::sqrt( std::sin( pwr ) ) ) / hl;
+		}
+	else if( tb >= 0.10 )                                                      // :440-449
+		{
+		hl = ( 1.50277377248945 + 158.222625721046 * std::asinh( pwr ) * std::tanh( 1.02875299001715 + 42.072277322604 * pwr ) - 0.0108380943845632 * atten ) / tb;
+		fo1 = 0.992539376734551 * tb + ( -0.251747813037178 - 6.74159892452584 * std::sqrt( std::tanh( std::tanh( std::tan( pwr ) ) ) ) ) / hl;
 		}
 	else                                                                       // :450-461
 		{
@@ -89,6 +110,7 @@ static bool design_default_lowpass( double req_norm_freq, double gain, std::vect
 	for( double & v : h ) v *= gain / s;
 	return true;
 	}
+static bool design_default_lowpass( double req_norm_freq, double gain, std::vector<double> & h, int & fl2 ) { return design_lowpass( req_norm_freq, 2.0, gain, h, fl2 ); }
 
 // Which single-step ratio is this?  CDSPResampler.h:139-161 (first match wins), then :165-207 with no half-band stage.
 static bool rational_ratio( double src, double dst, int & up, int & down )
@@ -121,7 +143,7 @@ static bool whole_stepping( double src, double dst, int & in_step, int & out_ste
 	}
 
 // The half-band kernels getHBFilter / getHBFilterThird select at ReqAtten = 206.91 dB, by SteepIndex (CDSPHBUpsampler.h:43-215, :296-436):
-// half-band 13 / 7 / 5 / 4 taps, third-band 9 / 6 / 5.  Deeper chains (32x ...) are not served.
+// half-band 13 / 7 / 5 / 4 / 4 / 3 taps (SteepIndex 0, 1, 2, 3, 4-5, 6+), third-band 9 / 6 / 5 / 4 / 3 / 3.
 struct HbTaps { double c[13]; int n; };
 static bool hb_kernel( int steep, bool third, HbTaps & k )
 	{
@@ -137,70 +159,89 @@ static bool hb_kernel( int steep, bool third, HbTaps & k )
 	static const double t1[6] = { 6.1161456377889145e-001, -1.4743902036519768e-001, 4.5344160828746795e-002, -1.1207372108402218e-002, 1.8328498006058664e-003,
 		-1.4518194076022933e-004 };
 	static const double t2[5] = { 6.0590922849004858e-001, -1.3515953371903033e-001, 3.5020856634677522e-002, -6.3256195330255094e-003, 5.5506812768978109e-004 };
+	static const double h45[4] = { 5.9819599535791312e-001, -1.1972157884617740e-001, 2.3977307400990484e-002, -2.4517239127622593e-003 };   // SteepIndex 4, 5
+	static const double h6[3] = { 5.8594191093025305e-001, -9.7662866644414148e-002, 1.1720955714177778e-002 };                              // 6 and beyond
+	static const double t3[4] = { 5.9823601283411165e-001, -1.1979369067338455e-001, 2.4017459011435899e-002, -2.4597811725236445e-003 };
+	static const double t45[3] = { 5.8596887233874539e-001, -9.7703321108182931e-002, 1.1734448775437802e-002 };
+	static const double t6[3] = { 5.8593945769687561e-001, -9.7659186594368730e-002, 1.1719728897494584e-002 };
 	const double * src = nullptr; int n = 0;
-	if( third ) { if( steep == 0 ) { src = t0; n = 9; } else if( steep == 1 ) { src = t1; n = 6; } else if( steep == 2 ) { src = t2; n = 5; } }
-	else { if( steep == 0 ) { src = h0; n = 13; } else if( steep == 1 ) { src = h1; n = 7; } else if( steep == 2 ) { src = h2; n = 5; } else if( steep == 3 ) { src = h3; n = 4; } }
+	if( steep < 0 ) return false;
+	if( third ) { if( steep == 0 ) { src = t0; n = 9; } else if( steep == 1 ) { src = t1; n = 6; } else if( steep == 2 ) { src = t2; n = 5; } else if( steep == 3 ) { src = t3; n = 4; }
+		else if( steep <= 5 ) { src = t45; n = 3; } else { src = t6; n = 3; } }
+	else { if( steep == 0 ) { src = h0; n = 13; } else if( steep == 1 ) { src = h1; n = 7; } else if( steep == 2 ) { src = h2; n = 5; } else if( steep == 3 ) { src = h3; n = 4; }
+		else if( steep <= 5 ) { src = h45; n = 4; } else { src = h6; n = 3; } }
 	if( !src ) return false;
 	k.n = n;
 	for( int i = 0; i < 13; ++i ) k.c[i] = i < n ? src[i] : 0.0;
 	return true;
 	}
 
-// What CDSPResampler( src, dst ) builds, for the chains served here:
-//   [ hb_down half-band downsamplers ] -> block convolver ( up, down, low-pass at norm_freq with DC gain `gain` ) -> [ hb_up half-band
-//   upsamplers ] -> [ whole-stepping fractional interpolator ]
-struct ChainShape { int hb_down = 0, up = 1, down = 1; double norm_freq = 0.5, gain = 1.0; int hb_up = 0; bool third = false, interp = false; int in_step = 0, out_step = 0;
-	bool spline = false; double isrc = 0.0, idst = 0.0; };   // spline: no whole stepping -- the interpolator runs from isrc to idst with the spline-interpolated bank
-
-static bool chain_shape( double src, double dst, ChainShape & ch )
+// What CDSPResampler( src, dst ) builds (its whole constructor, CDSPResampler.h:119-378), as a list of stages.  Every stage is evaluated on the
+// whole stream in fp64, r8brain's own intermediate type; the first reads the float audio, the last rounds to float.
+struct Stage
 	{
-	if( src == dst ) return false;
-	HbTaps probe;
-	static const int common[5][2] = { { 1, 2 }, { 1, 3 }, { 2, 3 }, { 3, 2 }, { 3, 4 } };          // CDSPResampler.h:142-170
+	enum Kind { HbDown, Conv, HbUp, Frac } kind = Conv;
+	HbTaps taps{};                                                                // half-band stages
+	int up = 1, down = 1; double nf = 0.5, tb = 2.0, gain = 1.0;                  // block convolver (tb in percent)
+	bool third = false, whole = true; int in_step = 0, out_step = 0; double isrc = 0.0, idst = 0.0;   // interpolator (whole stepping, or the spline bank)
+	const double * d_h = nullptr; int fl2 = 0;                                    // device tables, filled by get_stage_plan
+	const double * d_bank = nullptr; int flt_len = 0, fracs = 0;
+	};
+
+static bool build_stages( double src, double dst, std::vector<Stage> & st )
+	{
+	st.clear();
+	if( !( src > 0.0 ) || !( dst > 0.0 ) || !( src <= 1e12 ) || !( dst <= 1e12 ) || src == dst ) return false;   // (r8brain asserts positive rates; NaN fails too)
+	auto conv = [&]( int up, int down, double nf, double tb, double gain ) { Stage c; c.kind = Stage::Conv; c.up = up; c.down = down; c.nf = nf; c.tb = tb; c.gain = gain; st.push_back( c ); };
+	auto hb = [&]( Stage::Kind k, int steep, bool third ) { Stage h; h.kind = k; h.third = third; const bool ok = hb_kernel( steep, third, h.taps ); st.push_back( h ); return ok; };
+	auto frac = [&]( double isrc, double idst, bool third )
+		{
+		Stage f; f.kind = Stage::Frac; f.third = third; f.isrc = isrc; f.idst = idst;
+		f.whole = whole_stepping( isrc, idst, f.in_step, f.out_step );
+		st.push_back( f );
+		};
+	static const int common[5][2] = { { 1, 2 }, { 1, 3 }, { 2, 3 }, { 3, 2 }, { 3, 4 } };          // :142-170
 	for( const auto & c : common )
-		if( src * c[0] == dst * c[1] ) { ch.up = c[0]; ch.down = c[1]; ch.norm_freq = 1.0 / std::max( c[0], c[1] ); ch.gain = c[0]; return true; }
+		if( src * c[0] == dst * c[1] ) { conv( c[0], c[1], 1.0 / std::max( c[0], c[1] ), 2.0, c[0] ); return true; }
 	for( int i = 2; i <= 3; ++i )                                                 // :174-212: dst = i 2^c src
 		for( int c = 0; src * ( i << c ) <= dst; ++c )
 			if( src * ( i << c ) == dst )
 				{
-				ch.up = i; ch.norm_freq = 1.0 / i; ch.gain = i; ch.hb_up = c; ch.third = ( i == 3 );
-				return c == 0 || hb_kernel( c - 1, ch.third, probe );
+				conv( i, 1, 1.0 / i, 2.0, i );
+				for( int k = 0; k < c; ++k ) if( !hb( Stage::HbUp, k, i == 3 ) ) return false;
+				return true;
 				}
 	if( dst * 2 > src )                                                           // :214-316
 		{
+		conv( 2, 1, dst > src ? 0.5 : 0.5 * dst / src, 2.0, 2.0 );                 // :218-225
 		const double thresh = src * 1.01;
 		int c = 0, div = 1;
-		while( !( dst < thresh * ( div * 2 ) ) ) { div *= 2; ++c; }                // :229-244
+		while( !( dst < thresh * ( div * 2 ) ) ) { div *= 2; ++c; }                // :229-244 (:246-261: the 3x variant tests 3 div against the threshold 2 div just failed: it never wins)
 		int t1, t2;
 		if( c == 1 && whole_stepping( src * 2.0, dst, t1, t2 ) ) c = 0;            // :266-276
-		if( c > 0 ) return false;                                                  // intermediate interpolation with its own low-pass design: not served
-		ch.up = 2; ch.norm_freq = dst > src ? 0.5 : 0.5 * dst / src; ch.gain = 2.0; ch.interp = true;
-		if( !whole_stepping( src * 2.0, dst, ch.in_step, ch.out_step ) ) { ch.spline = true; ch.isrc = src * 2.0; ch.idst = dst; }
+		if( c > 0 )
+			{
+			// intermediate interpolation: to dst / 2^c first, then a 2x convolver whose transition band follows from the rates, then half-band upsamplers
+			frac( src * 2.0 * div, dst, false );                                   // :293-294
+			conv( 2, 1, 0.5, 100.0 * ( 1.0 - src * div / dst ) / 1.75, 2.0 );      // :296-302
+			for( int i = 1; i < c; ++i ) if( !hb( Stage::HbUp, i - 1, false ) ) return false;   // :304-308
+			}
+		else frac( src * 2.0, dst, false );                                        // :312-313
 		return true;
 		}
-	double check = dst * 4.0;                                                     // :319-331
+	double check = dst * 4.0, fin_gain = 1.0;                                     // :319-331
 	int c = 0;
-	while( check <= src ) { ++c; check *= 2.0; ch.gain *= 0.5; }
+	while( check <= src ) { ++c; check *= 2.0; fin_gain *= 0.5; }
 	const int div = 1 << c;
-	ch.hb_down = c;
-	int downf = 0;
-	for( int d = 2; d <= 3; ++d ) if( dst * div * d == src ) { downf = d; break; }  // :340-349
-	if( downf ) { ch.down = downf; ch.norm_freq = 1.0 / downf; ch.third = ( downf == 3 ); }
-	else                                                                          // :351-356, :372-376
-		{
-		ch.norm_freq = dst * div / src; ch.third = ch.norm_freq * 3.0 <= 1.0; ch.interp = true;
-		if( !whole_stepping( src, dst * div, ch.in_step, ch.out_step ) )
-			{
-			if( c > 0 ) return false;                                                // half-band stages in front of the spline bank: not served
-			ch.spline = true; ch.isrc = src; ch.idst = dst * div;
-			}
-		}
-	return c == 0 || hb_kernel( c - 1, ch.third, probe );
+	int downf = 1; double nf = 0.5; bool use_interp = true, third = false;
+	for( int d = 2; d <= 3; ++d ) if( dst * div * d == src ) { downf = d; nf = 1.0 / d; use_interp = false; third = ( d == 3 ); break; }   // :340-349
+	if( use_interp ) { nf = dst * div / src; third = nf * 3.0 <= 1.0; }           // :351-356
+	for( int i = 0; i < c; ++i ) if( !hb( Stage::HbDown, c - 1 - i, third ) ) return false;   // :358-365
+	conv( 1, downf, nf, 2.0, fin_gain );                                          // :367-370
+	if( use_interp ) frac( src, dst * div, third );                               // :372-376
+	return true;
 	}
 
-// CDSPFracDelayFilterBank( OutStep, 1, 2, 206.91, third ) (CDSPFracInterpolator.h:64-121, window parameters :289-348 -- the rows that
-// cover 206.91 dB): `fracs` filters of flt_len taps, row r delays by ( fracs - r ) / fracs samples.  Each is a Kaiser-power windowed
-// sinc sampled at t + delay, t = -fl2 .. fl2 - 1 (CDSPSincFilterGen.h:184-193, :246-257, :432-517), normalised to unit DC gain.
 static void frac_window_params( bool third, double & beta, double & power, double & att, int & flt_len )
 	{
 	beta = third ? 19.1718281840114810 : 10.2382664677006100;
@@ -277,19 +318,34 @@ static void frac_spline_bank( bool third, std::vector<double> & bank, int & flt_
 // fraction f0).  Worked out on the host call by call -- a bisection per call, not a walk over the outputs.
 struct FracSegment { int64_t j0, count, r0; double shift, f0; };
 
-static void spline_segments( const ChainShape & ch, int fl2_conv, int flt_len, int64_t chunk, int64_t total_out, std::vector<FracSegment> & segs )
+// samples a stage has handed on once n samples have gone into it: it consumes its latency and then keeps pace with its input
+// (CDSPHBDownsampler.h:95-150 with fl2 = 2 taps - 1; CDSPBlockConvolver.h:62-100, CDSPFIRFilter.h:467-478: InputLen + the filter's latency)
+static int64_t delivered( const Stage & s, int64_t n )
 	{
-	const int kernel_len = 2 * fl2_conv + 1;
-	int bits = 0; while( ( ( kernel_len - 1 ) >> bits ) != 0 ) ++bits;             // getBitOccupancy( KernelLen - 1 )
-	const int64_t latency = int64_t( ( 2 << std::max( bits, 1 ) ) - ( ( kernel_len - 1 + ch.up - 1 ) / ch.up ) * ch.up ) + fl2_conv;   // InputLen + the filter's latency
-	const int fl2i = flt_len / 2;
-	const double src = ch.isrc, dst = ch.idst;
+	if( s.kind == Stage::HbDown ) { const int fl2 = 2 * s.taps.n - 1; return n > fl2 ? ( n - fl2 + 1 ) >> 1 : 0; }
+	if( s.kind == Stage::Conv )
+		{
+		const int kernel_len = 2 * s.fl2 + 1;
+		int bits = 0; while( ( ( kernel_len - 1 ) >> bits ) != 0 ) ++bits;         // getBitOccupancy( KernelLen - 1 )
+		const int64_t latency = int64_t( ( 2 << std::max( bits, 1 ) ) - ( ( kernel_len - 1 + s.up - 1 ) / s.up ) * s.up ) + s.fl2;
+		return std::max<int64_t>( 0, n * s.up - latency ) / s.down;
+		}
+	return n;
+	}
+
+// the segments of interpolator stage k (see above): call c has seen c * chunk input samples of the whole chain
+static void spline_segments( const std::vector<Stage> & st, int k, int64_t chunk, int64_t n_out, std::vector<FracSegment> & segs )
+	{
+	const Stage & f = st[size_t( k )];
+	const int fl2i = f.flt_len / 2;
+	const double src = f.isrc, dst = f.idst;
 	FracSegment cur{ 0, 0, 0, 0.0, 0.0 };
 	auto read_abs = [&]( int64_t n ) { return n == 0 ? cur.r0 : cur.r0 + int64_t( ( double( n ) + cur.shift ) * src / dst ); };
 	int64_t j = 0;
-	for( int64_t call = 1; j < total_out; ++call )
+	for( int64_t call = 1; j < n_out; ++call )
 		{
-		const int64_t w = std::max<int64_t>( 0, call * chunk * ch.up - latency );   // samples of y written so far
+		int64_t w = call * chunk;                                                  // samples of the stream in front of the interpolator written so far
+		for( int q = 0; q < k; ++q ) w = delivered( st[size_t( q )], w );
 		// outputs n = cur.count, cur.count + 1, ... come while w - read_abs( n ) > fl2i: the first n that fails, by bisection (read_abs is monotone)
 		int64_t lo = cur.count, hi = cur.count;
 		if( w - read_abs( lo ) > fl2i )
@@ -312,8 +368,13 @@ static void spline_segments( const ChainShape & ch, int fl2_conv, int flt_len, i
 	if( cur.count > 0 ) segs.push_back( cur );
 	}
 
-struct ChainPlan { double * d_h = nullptr; double * d_bank = nullptr; int fl2 = 0, flt_len = 0, fracs = 0; ChainShape shape; };
-static std::map<std::tuple<int, double, double>, ChainPlan> g_chain_plans;   // per (device, src, dst)
+// device copies, cached for the process: low-pass taps per (device, cut-off, transition band, gain); interpolator banks per (device, rows or -1 for
+// the spline bank, third-band); the stage list with its pointers per (device, src, dst)
+struct DevTaps { double * d = nullptr; int fl2 = 0; };
+struct DevBank { double * d = nullptr; int flt_len = 0, fracs = 0; };
+static std::map<std::tuple<int, double, double, double>, DevTaps> g_dev_taps;
+static std::map<std::tuple<int, int, bool>, DevBank> g_dev_banks;
+static std::map<std::tuple<int, double, double>, std::vector<Stage>> g_stage_plans;
 
 // Device copies of the taps for one (up, down): h[0 .. 2 fl2] in natural order, and for the 2:1 kernel
 // d_he[q] = h[2 fl2 - 2 q] (q = 0 .. fl2), d_ho[q] = h[2 fl2 - 1 - 2 q] (q = 0 .. fl2 - 1): the taps in the order it walks them
@@ -467,8 +528,9 @@ __global__ __launch_bounds__( RSG_BLOCK ) void k_resample_rational( const InT * 
 //        p = ( k*in_step ) / out_step,  r = ( k*in_step ) % out_step,  out[k] = float( sum_i bank[r][i] * y[p - ( flt_len/2 - 1 ) + i] ),
 // i ascending, y = 0 before its start (the ring buffer's initial zeros, :771-778) and past what stage 1 wrote (never read: ny covers it).
 constexpr int FRAC_BLOCK = 256;
+template<typename OutT>
 __global__ __launch_bounds__( FRAC_BLOCK ) void k_frac_whole( const double * __restrict__ y, int64_t ny, const double * __restrict__ bank, int flt_len,
-	int in_step, int out_step, float * __restrict__ out, int64_t total_out )
+	int in_step, int out_step, OutT * __restrict__ out, int64_t total_out )
 	{
 	const int64_t k = int64_t( blockIdx.x ) * FRAC_BLOCK + threadIdx.x;
 	if( k >= total_out ) return;
@@ -484,7 +546,7 @@ __global__ __launch_bounds__( FRAC_BLOCK ) void k_frac_whole( const double * __r
 			const int64_t a = a0 + i;
 			acc = __builtin_fma( ft[i], ( a >= 0 && a < ny ) ? y[a] : 0.0, acc );
 			}
-	out[k] = float( acc );
+	out[k] = OutT( acc );
 	}
 
 // CDSPHBDownsampler (CDSPHBDownsampler.h:95-260): out[j] = in[2j] + sum_t c[t] ( in[2j+2t+1] + in[2j-2t-1] ), in = 0 outside [0, n_in)
@@ -521,8 +583,9 @@ __global__ __launch_bounds__( HB_BLOCK ) void k_hb_up( const double * __restrict
 // CDSPFracInterpolator::convolve2 (CDSPFracInterpolator.h:960-1005): output j of segment { j0, count, r0, shift, f0 } sits n = j - j0 steps in,
 //        position = ( n + shift ) isrc / idst (fp64, in that order; n = 0: exactly r0 and f0),  p = r0 + int( position ),  frac = position - int( position );
 //        x = frac * fracs, row = int( x ), x -= row;   out[j] = float( sum_i ( c0 + c1 x + c2 x^2 )[row][i] * y[p - ( flt_len/2 - 1 ) + i] )
+template<typename OutT>
 __global__ __launch_bounds__( FRAC_BLOCK ) void k_frac_spline( const double * __restrict__ y, int64_t ny, const double * __restrict__ bank, int flt_len, int fracs,
-	const FracSegment * __restrict__ segs, int num_segs, double isrc, double idst, float * __restrict__ out, int64_t total_out )
+	const FracSegment * __restrict__ segs, int num_segs, double isrc, double idst, OutT * __restrict__ out, int64_t total_out )
 	{
 	const int64_t j = int64_t( blockIdx.x ) * FRAC_BLOCK + threadIdx.x;
 	if( j >= total_out ) return;
@@ -552,28 +615,52 @@ __global__ __launch_bounds__( FRAC_BLOCK ) void k_frac_spline( const double * __
 		const double v = ( a >= 0 && a < ny ) ? y[a] : 0.0;
 		acc = __builtin_fma( ( ft[3 * i] + ft[3 * i + 1] * x ) + ft[3 * i + 2] * x2, v, acc );
 		}
-	out[j] = float( acc );
+	out[j] = OutT( acc );
 	}
 
-static int get_chain_plan( double src, double dst, const ChainPlan ** out )
+static int get_stage_plan( double src, double dst, const std::vector<Stage> ** out )
 	{
 	int device = 0;
 	FLANHIP_CHECK( hipGetDevice( &device ) );
 	std::lock_guard<std::mutex> lock( g_rs_mutex );
 	const auto key = std::make_tuple( device, src, dst );
-	auto it = g_chain_plans.find( key );
-	if( it != g_chain_plans.end() ) { *out = &it->second; return FLANHIP_OK; }
-	ChainPlan p;
-	FLANHIP_REQUIRE( chain_shape( src, dst, p.shape ), FLANHIP_ERR_UNSUPPORTED, "ratio not served" );
-	std::vector<double> h, bank;
-	FLANHIP_REQUIRE( design_default_lowpass( p.shape.norm_freq, p.shape.gain, h, p.fl2 ), FLANHIP_ERR_UNSUPPORTED, "low-pass design outside the restated range" );
-	if( p.shape.interp && !p.shape.spline ) frac_delay_bank( p.shape.out_step, p.shape.third, bank, p.flt_len );
-	if( p.shape.spline ) frac_spline_bank( p.shape.third, bank, p.flt_len, p.fracs );
-	FLANHIP_CHECK( hipMalloc( &p.d_h, sizeof( double ) * ( h.size() + bank.size() + 1 ) ) );
-	p.d_bank = p.d_h + h.size();
-	FLANHIP_CHECK( hipMemcpy( p.d_h, h.data(), sizeof( double ) * h.size(), hipMemcpyHostToDevice ) );
-	if( !bank.empty() ) FLANHIP_CHECK( hipMemcpy( p.d_bank, bank.data(), sizeof( double ) * bank.size(), hipMemcpyHostToDevice ) );
-	*out = &g_chain_plans.emplace( key, p ).first->second;
+	auto it = g_stage_plans.find( key );
+	if( it != g_stage_plans.end() ) { *out = &it->second; return FLANHIP_OK; }
+	std::vector<Stage> st;
+	FLANHIP_REQUIRE( build_stages( src, dst, st ), FLANHIP_ERR_UNSUPPORTED, "ratio not served" );
+	for( Stage & g : st )
+		{
+		if( g.kind == Stage::Conv )
+			{
+			const auto tkey = std::make_tuple( device, g.nf, g.tb, g.gain );
+			auto tt = g_dev_taps.find( tkey );
+			if( tt == g_dev_taps.end() )
+				{
+				std::vector<double> h; DevTaps t;
+				FLANHIP_REQUIRE( design_lowpass( g.nf, g.tb, g.gain, h, t.fl2 ), FLANHIP_ERR_UNSUPPORTED, "low-pass design outside the restated range" );
+				FLANHIP_CHECK( hipMalloc( &t.d, sizeof( double ) * h.size() ) );
+				FLANHIP_CHECK( hipMemcpy( t.d, h.data(), sizeof( double ) * h.size(), hipMemcpyHostToDevice ) );
+				tt = g_dev_taps.emplace( tkey, t ).first;
+				}
+			g.d_h = tt->second.d; g.fl2 = tt->second.fl2;
+			}
+		else if( g.kind == Stage::Frac )
+			{
+			const auto bkey = std::make_tuple( device, g.whole ? g.out_step : -1, g.third );
+			auto bt = g_dev_banks.find( bkey );
+			if( bt == g_dev_banks.end() )
+				{
+				std::vector<double> bank; DevBank b;
+				if( g.whole ) { frac_delay_bank( g.out_step, g.third, bank, b.flt_len ); b.fracs = g.out_step; }
+				else frac_spline_bank( g.third, bank, b.flt_len, b.fracs );
+				FLANHIP_CHECK( hipMalloc( &b.d, sizeof( double ) * bank.size() ) );
+				FLANHIP_CHECK( hipMemcpy( b.d, bank.data(), sizeof( double ) * bank.size(), hipMemcpyHostToDevice ) );
+				bt = g_dev_banks.emplace( bkey, b ).first;
+				}
+			g.d_bank = bt->second.d; g.flt_len = bt->second.flt_len; g.fracs = bt->second.fracs;
+			}
+		}
+	*out = &g_stage_plans.emplace( key, std::move( st ) ).first->second;
 	return FLANHIP_OK;
 	}
 
@@ -584,104 +671,98 @@ static size_t rational_lds( int fl2, int up, int down, int & span )
 	}
 
 template<typename InT, typename OutT>
-static int launch_rational( const InT * d_in, int64_t n_in, const ChainPlan & plan, OutT * d_out, int64_t n_out, hipStream_t s )
+static int launch_rational( const InT * d_in, int64_t n_in, const Stage & g, OutT * d_out, int64_t n_out, hipStream_t s )
 	{
 	int span = 0;
-	const size_t lds = rational_lds( plan.fl2, plan.shape.up, plan.shape.down, span );
+	const size_t lds = rational_lds( g.fl2, g.up, g.down, span );
 	FLANHIP_REQUIRE( lds <= 160 * 1024, FLANHIP_ERR_UNSUPPORTED, "filter too long for the LDS staging" );
 	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( k_resample_rational<InT, OutT> ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 	hipLaunchKernelGGL( ( k_resample_rational<InT, OutT> ), dim3( (unsigned) ( ( n_out + RSG_BLOCK - 1 ) / RSG_BLOCK ) ), dim3( RSG_BLOCK ), lds, s,
-		d_in, n_in, plan.d_h, plan.fl2, plan.shape.up, plan.shape.down, span, d_out, n_out );
+		d_in, n_in, g.d_h, g.fl2, g.up, g.down, span, d_out, n_out );
 	return FLANHIP_OK;
 	}
 
-// A chain with more than the block convolver in it: every stage on the whole stream in fp64 (r8brain's intermediate type), each for exactly
-// as many samples as the next one reads (zeros before the start and past the end, like the zeros oneshot() feeds); the last stage rounds to
-// float.  Intermediate streams live in the stream's memory pool.
-static int resample_chain_dev( const float * d_in, int64_t total_in, int64_t chunk, double src, double dst, float * d_out, int64_t total_out, hipStream_t s )
+// A chain of more than one stage: every stage for exactly as many samples as the next one reads (zeros before the start and past the end, like
+// the zeros oneshot() feeds), intermediate fp64 streams from the stream's memory pool.  `chunk`: the input samples per process() call of the
+// reference (the channel's frame count) -- it decides where the spline interpolator re-bases its position counter.
+static int resample_stages_dev( const float * d_in, int64_t total_in, int64_t chunk, double src, double dst, float * d_out, int64_t total_out, hipStream_t s )
 	{
-	const ChainPlan * plan = nullptr;
-	if( int rc = get_chain_plan( src, dst, &plan ) ) return rc;
-	const ChainShape & ch = plan->shape;
-	HbTaps down_taps[4], up_taps[4];
-	FLANHIP_REQUIRE( ch.hb_down <= 4 && ch.hb_up <= 4, FLANHIP_ERR_UNSUPPORTED, "half-band chain too deep" );
-	for( int i = 0; i < ch.hb_down; ++i ) FLANHIP_REQUIRE( hb_kernel( ch.hb_down - 1 - i, ch.third, down_taps[i] ), FLANHIP_ERR_UNSUPPORTED, "half-band chain too deep" );   // CDSPResampler.h:358-365
-	for( int i = 0; i < ch.hb_up; ++i ) FLANHIP_REQUIRE( hb_kernel( i, ch.third, up_taps[i] ), FLANHIP_ERR_UNSUPPORTED, "half-band chain too deep" );                       // :203-209
-	// samples each stage has to deliver (backwards from the output)
-	int64_t need_up[5];
-	need_up[ch.hb_up] = !ch.interp ? total_out
-		: ch.spline ? int64_t( std::ceil( double( total_out ) * ch.isrc / ch.idst ) ) + plan->flt_len + 8
-		: ( ( total_out - 1 ) * ch.in_step ) / ch.out_step - ( plan->flt_len / 2 - 1 ) + plan->flt_len;
-	for( int i = ch.hb_up - 1; i >= 0; --i ) need_up[i] = ( need_up[i + 1] - 1 ) / 2 + up_taps[i].n + 1;
-	const int64_t need_conv = std::max<int64_t>( need_up[0], 1 );
+	const std::vector<Stage> * plan = nullptr;
+	if( int rc = get_stage_plan( src, dst, &plan ) ) return rc;
+	const std::vector<Stage> & st = *plan;
+	const int ns = int( st.size() );
+	std::vector<int64_t> need( size_t( ns ), 0 );
+	need[size_t( ns - 1 )] = total_out;
+	for( int k = ns - 1; k > 0; --k )                                             // what stage k reads of stage k - 1
+		{
+		const Stage & g = st[size_t( k )];
+		const int64_t n = need[size_t( k )];
+		int64_t r;
+		if( g.kind == Stage::HbDown ) r = 2 * ( n - 1 ) + 2 * g.taps.n;
+		else if( g.kind == Stage::HbUp ) r = ( n - 1 ) / 2 + g.taps.n + 1;
+		else if( g.kind == Stage::Conv ) r = ( int64_t( g.down ) * ( n - 1 ) + g.fl2 ) / g.up + 1;
+		else if( g.whole ) r = ( ( n - 1 ) * g.in_step ) / g.out_step - ( g.flt_len / 2 - 1 ) + g.flt_len;
+		else r = int64_t( std::ceil( double( n ) * g.isrc / g.idst ) ) + g.flt_len + 8;
+		need[size_t( k - 1 )] = std::max<int64_t>( r, 1 );
+		}
 	retain_pool_memory();
 	std::vector<void*> temps;
-	auto temp = [&]( int64_t count, double ** out ) -> int
+	auto temp = [&]( size_t bytes, void ** out ) -> int
 		{
-		FLANHIP_CHECK( hipMallocAsync( reinterpret_cast<void**>( out ), sizeof( double ) * size_t( std::max<int64_t>( count, 1 ) ), s ) );
+		FLANHIP_CHECK( hipMallocAsync( out, std::max<size_t>( bytes, 8 ), s ) );
 		temps.push_back( *out );
 		return FLANHIP_OK;
 		};
 	int rc = FLANHIP_OK;
 	const double * cur = nullptr; int64_t cur_len = total_in;                     // cur == nullptr: the stream is still the float input
-	for( int i = 0; i < ch.hb_down && !rc; ++i )
+	for( int k = 0; k < ns && !rc; ++k )
 		{
-		const int64_t n_out = ( cur_len + 2 * down_taps[i].n + 1 ) / 2 + 1;       // up to the end of the filter's tail
+		const Stage & g = st[size_t( k )];
+		const bool last = k == ns - 1;
+		const int64_t n_out = need[size_t( k )];
 		double * nxt = nullptr;
-		if( ( rc = temp( n_out, &nxt ) ) ) break;
-		const dim3 grid( (unsigned) ( ( n_out + HB_BLOCK - 1 ) / HB_BLOCK ) );
-		if( cur ) hipLaunchKernelGGL( k_hb_down<double>, grid, dim3( HB_BLOCK ), 0, s, cur, cur_len, down_taps[i], nxt, n_out );
-		else hipLaunchKernelGGL( k_hb_down<float>, grid, dim3( HB_BLOCK ), 0, s, d_in, cur_len, down_taps[i], nxt, n_out );
-		cur = nxt; cur_len = n_out;
-		}
-	const bool conv_is_last = ch.hb_up == 0 && !ch.interp;
-	if( !rc )
-		{
-		if( conv_is_last ) rc = cur ? launch_rational<double, float>( cur, cur_len, *plan, d_out, total_out, s ) : launch_rational<float, float>( d_in, cur_len, *plan, d_out, total_out, s );
+		if( !last ) { void * t = nullptr; if( ( rc = temp( sizeof( double ) * size_t( n_out ), &t ) ) ) break; nxt = static_cast<double*>( t ); }
+		if( g.kind == Stage::HbDown )
+			{
+			const dim3 grid( (unsigned) ( ( n_out + HB_BLOCK - 1 ) / HB_BLOCK ) );
+			FLANHIP_REQUIRE( !last, FLANHIP_ERR_UNSUPPORTED, "a chain cannot end in a half-band downsampler" );
+			if( cur ) hipLaunchKernelGGL( k_hb_down<double>, grid, dim3( HB_BLOCK ), 0, s, cur, cur_len, g.taps, nxt, n_out );
+			else hipLaunchKernelGGL( k_hb_down<float>, grid, dim3( HB_BLOCK ), 0, s, d_in, cur_len, g.taps, nxt, n_out );
+			}
+		else if( g.kind == Stage::HbUp )
+			{
+			const dim3 grid( (unsigned) ( ( n_out + HB_BLOCK - 1 ) / HB_BLOCK ) );
+			if( last ) hipLaunchKernelGGL( k_hb_up<float>, grid, dim3( HB_BLOCK ), 0, s, cur, cur_len, g.taps, d_out, n_out );
+			else hipLaunchKernelGGL( k_hb_up<double>, grid, dim3( HB_BLOCK ), 0, s, cur, cur_len, g.taps, nxt, n_out );
+			}
+		else if( g.kind == Stage::Conv )
+			{
+			if( last ) rc = cur ? launch_rational<double, float>( cur, cur_len, g, d_out, n_out, s ) : launch_rational<float, float>( d_in, cur_len, g, d_out, n_out, s );
+			else rc = cur ? launch_rational<double, double>( cur, cur_len, g, nxt, n_out, s ) : launch_rational<float, double>( d_in, cur_len, g, nxt, n_out, s );
+			}
 		else
 			{
-			double * nxt = nullptr;
-			if( !( rc = temp( need_conv, &nxt ) ) )
+			const dim3 grid( (unsigned) ( ( n_out + FRAC_BLOCK - 1 ) / FRAC_BLOCK ) );
+			if( g.whole )
 				{
-				rc = cur ? launch_rational<double, double>( cur, cur_len, *plan, nxt, need_conv, s ) : launch_rational<float, double>( d_in, cur_len, *plan, nxt, need_conv, s );
-				cur = nxt; cur_len = need_conv;
+				if( last ) hipLaunchKernelGGL( k_frac_whole<float>, grid, dim3( FRAC_BLOCK ), 0, s, cur, cur_len, g.d_bank, g.flt_len, g.in_step, g.out_step, d_out, n_out );
+				else hipLaunchKernelGGL( k_frac_whole<double>, grid, dim3( FRAC_BLOCK ), 0, s, cur, cur_len, g.d_bank, g.flt_len, g.in_step, g.out_step, nxt, n_out );
 				}
-			}
-		}
-	for( int i = 0; i < ch.hb_up && !rc; ++i )
-		{
-		const int64_t n_out = need_up[i + 1];
-		const dim3 grid( (unsigned) ( ( n_out + HB_BLOCK - 1 ) / HB_BLOCK ) );
-		if( i == ch.hb_up - 1 && !ch.interp ) hipLaunchKernelGGL( k_hb_up<float>, grid, dim3( HB_BLOCK ), 0, s, cur, cur_len, up_taps[i], d_out, n_out );
-		else
-			{
-			double * nxt = nullptr;
-			if( ( rc = temp( n_out, &nxt ) ) ) break;
-			hipLaunchKernelGGL( k_hb_up<double>, grid, dim3( HB_BLOCK ), 0, s, cur, cur_len, up_taps[i], nxt, n_out );
-			cur = nxt; cur_len = n_out;
-			}
-		}
-	if( !rc && ch.spline )
-		{
-		std::vector<FracSegment> segs;
-		spline_segments( ch, plan->fl2, plan->flt_len, chunk, total_out, segs );
-		FracSegment * d_segs = nullptr;
-		if( hipMallocAsync( reinterpret_cast<void**>( &d_segs ), sizeof( FracSegment ) * segs.size(), s ) != hipSuccess ) { set_error( "hipMallocAsync failed" ); rc = FLANHIP_ERR_HIP; }
-		else
-			{
-			temps.push_back( d_segs );
-			if( hipMemcpyAsync( d_segs, segs.data(), sizeof( FracSegment ) * segs.size(), hipMemcpyHostToDevice, s ) != hipSuccess ) { set_error( "hipMemcpyAsync failed" ); rc = FLANHIP_ERR_HIP; }
 			else
 				{
+				std::vector<FracSegment> segs;
+				spline_segments( st, k, chunk, n_out, segs );
+				void * t = nullptr;
+				if( ( rc = temp( sizeof( FracSegment ) * segs.size(), &t ) ) ) break;
+				FracSegment * d_segs = static_cast<FracSegment*>( t );
+				if( hipMemcpyAsync( d_segs, segs.data(), sizeof( FracSegment ) * segs.size(), hipMemcpyHostToDevice, s ) != hipSuccess ) { set_error( "hipMemcpyAsync failed" ); rc = FLANHIP_ERR_HIP; break; }
 				(void) hipStreamSynchronize( s );                                   // the table is pageable host memory that dies with this call
-				hipLaunchKernelGGL( k_frac_spline, dim3( (unsigned) ( ( total_out + FRAC_BLOCK - 1 ) / FRAC_BLOCK ) ), dim3( FRAC_BLOCK ), 0, s,
-					cur, cur_len, plan->d_bank, plan->flt_len, plan->fracs, d_segs, int( segs.size() ), ch.isrc, ch.idst, d_out, total_out );
+				if( last ) hipLaunchKernelGGL( k_frac_spline<float>, grid, dim3( FRAC_BLOCK ), 0, s, cur, cur_len, g.d_bank, g.flt_len, g.fracs, d_segs, int( segs.size() ), g.isrc, g.idst, d_out, n_out );
+				else hipLaunchKernelGGL( k_frac_spline<double>, grid, dim3( FRAC_BLOCK ), 0, s, cur, cur_len, g.d_bank, g.flt_len, g.fracs, d_segs, int( segs.size() ), g.isrc, g.idst, nxt, n_out );
 				}
 			}
+		cur = nxt; cur_len = n_out;
 		}
-	else if( !rc && ch.interp )
-		hipLaunchKernelGGL( k_frac_whole, dim3( (unsigned) ( ( total_out + FRAC_BLOCK - 1 ) / FRAC_BLOCK ) ), dim3( FRAC_BLOCK ), 0, s,
-			cur, cur_len, plan->d_bank, plan->flt_len, ch.in_step, ch.out_step, d_out, total_out );
 	const hipError_t launched = hipGetLastError();
 	for( void * t : temps ) (void) hipFreeAsync( t, s );
 	if( rc ) return rc;
@@ -694,10 +775,7 @@ static int resample_chain_dev( const float * d_in, int64_t total_in, int64_t chu
 using namespace flanhip;
 
 static const char * const k_unsupported_ratio =
-	"implemented: the single-step ratios (src:dst = 2:1, 3:1, 3:2, 2:3, 4:3, 1:2, 1:3), block convolver + interpolator ratios (any dst in "
-	"( src/4, 2.02 src ): 44.1 <-> 48 kHz, 44.1 kHz -> 48001 Hz ...) and half-band chains (4x, 8x, 16x, 6x, 12x up; src >= 4 dst down); this "
-	"one needs r8brain's intermediate interpolation with its own low-pass design, half-band stages in front of its spline-interpolated "
-	"filter bank, or a deeper half-band chain";
+	"no chain of r8brain's stages for these rates (equal rates are a copy, not a resampling)";
 
 extern "C" {
 
@@ -712,13 +790,13 @@ int flanhip_resample_dev( const float * d_in, int64_t ch, int64_t n, float src_r
 	FLANHIP_REQUIRE( d_in && d_out && ch > 0 && n > 0 && src_rate > 0.0f && dst_rate > 0.0f, FLANHIP_ERR_INVALID_ARG, "bad arguments" );
 	int up = 0, down = 0;
 	const bool single = rational_ratio( double( src_rate ), double( dst_rate ), up, down );
-	ChainShape shape;
-	FLANHIP_REQUIRE( single || chain_shape( double( src_rate ), double( dst_rate ), shape ), FLANHIP_ERR_UNSUPPORTED, k_unsupported_ratio );
+	std::vector<Stage> probe;
+	FLANHIP_REQUIRE( single || build_stages( double( src_rate ), double( dst_rate ), probe ), FLANHIP_ERR_UNSUPPORTED, k_unsupported_ratio );
 	if( int rc = require_device() ) return rc;
 	const int64_t n_out = flanhip_resample_out_frames( n, src_rate, dst_rate );
 	const int64_t total_in = ch * n, total_out = ch * n_out;
 	if( total_out <= 0 ) return FLANHIP_OK;
-	if( !single ) return resample_chain_dev( d_in, total_in, n, double( src_rate ), double( dst_rate ), d_out, total_out, (hipStream_t) stream );
+	if( !single ) return resample_stages_dev( d_in, total_in, n, double( src_rate ), double( dst_rate ), d_out, total_out, (hipStream_t) stream );
 	const ResamplePlan * plan = nullptr;
 	if( int rc = get_resample_plan( up, down, &plan ) ) return rc;
 	if( up == 1 && down == 2 && plan->fl2 >= 64 * ( RS_R - 1 ) )
@@ -743,9 +821,9 @@ int flanhip_resample_dev( const float * d_in, int64_t ch, int64_t n, float src_r
 
 int flanhip_resample( const float * in, int64_t ch, int64_t n, float src_rate, float dst_rate, float * out, volatile int * cancel )
 	{
-	FLANHIP_REQUIRE( in && out && ch > 0 && n > 0, FLANHIP_ERR_INVALID_ARG, "bad arguments" );
-	{ int up = 0, down = 0; ChainShape shape;
-	  FLANHIP_REQUIRE( rational_ratio( double( src_rate ), double( dst_rate ), up, down ) || chain_shape( double( src_rate ), double( dst_rate ), shape ),
+	FLANHIP_REQUIRE( in && out && ch > 0 && n > 0 && src_rate > 0.0f && dst_rate > 0.0f, FLANHIP_ERR_INVALID_ARG, "bad arguments" );
+	{ int up = 0, down = 0; std::vector<Stage> probe;
+	  FLANHIP_REQUIRE( rational_ratio( double( src_rate ), double( dst_rate ), up, down ) || build_stages( double( src_rate ), double( dst_rate ), probe ),
 		FLANHIP_ERR_UNSUPPORTED, k_unsupported_ratio ); }
 	if( int rc = require_device() ) return rc;
 	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;

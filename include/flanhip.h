@@ -341,20 +341,16 @@ int flanhip_mid_side_dev(const float * d_in, int64_t num_audio_frames, float * d
 /* AudioConversions.cpp:22: out frames = Frame( float(num_frames) * ( dst_rate / src_rate ) ) */
 int64_t flanhip_resample_out_frames(int64_t num_frames, float src_rate, float dst_rate);
 /* in: float[ch][n]; out: float[ch][flanhip_resample_out_frames(n,...)].  Like the reference, the whole channel-major buffer is
- * resampled as ONE stream (filter ringing crosses channel boundaries).  Implemented: the ratios r8brain serves with a single
- * block convolver (r8brain/CDSPResampler.h:139-207) -- src:dst = 2:1 (96 -> 48 kHz: 1621-tap linear-phase low-pass, the tuned
- * kernel), 3:1, 3:2, 2:3, 4:3, 1:2, 1:3 -- latency consumed, zero-flushed tail; and the ratios it serves with one block convolver
- * followed by one whole-stepping CDSPFracInterpolator (CDSPResampler.h:214-316, :319-378 with no half-band stage;
- * CDSPFracInterpolator.h:573-602): 44.1 <-> 48 kHz, 96 -> 44.1, 22.05 -> 48, 44.1 -> 96, 44.1 <-> 32 kHz ... (the _dev form takes a
- * transient fp64 workspace of about 2 x the input from the stream's memory pool); and its half-band chains -- dst = 4, 8, 16, 6, 12 x src
- * (block convolver + CDSPHBUpsamplers, CDSPResampler.h:174-212) and src >= 4 dst (CDSPHBDownsamplers + block convolver [+ interpolator],
- * :319-378; 192 -> 48, 96 -> 16, 192 -> 44.1 kHz ...), up to four half-band stages (three for the third-band kernels).  Rates with no small
- * common divisor (44.1 kHz -> 48001 Hz, 48 kHz -> 50854.3 Hz ...: no whole stepping, CDSPFracInterpolator.h:573-602) run r8brain's
- * spline-interpolated filter bank (convolve2, :960-1005) with its position counter re-based exactly where oneshot()'s process() calls end --
- * one call per num_frames input samples, so the result depends on num_frames the way the reference's does; that _dev call synchronises the
- * stream once (a small table goes up).  Ratios that need r8brain's intermediate interpolation with a low-pass of its own transition band
- * (dst >= 2.02 src off the 2^k / 3*2^k grid), half-band stages in front of the spline bank (src >= 4 dst without whole stepping) or a deeper
- * half-band chain return FLANHIP_ERR_UNSUPPORTED. */
+ * resampled as ONE stream (filter ringing crosses channel boundaries).  Every chain CDSPResampler builds for two positive rates is served
+ * (r8brain/CDSPResampler.h:119-378): one block convolver (2:1 -- 96 -> 48 kHz, the tuned kernel --, 3:1, 3:2, 2:3, 4:3, 1:2, 1:3); block
+ * convolver + half-band upsamplers (4x, 8x ..., 6x, 12x ...); 2x convolver + fractional interpolator (44.1 <-> 48 kHz ...: whole stepping, or the
+ * spline-interpolated bank for rates without a small common divisor, e.g. 44.1 kHz -> 48001 Hz); intermediate interpolation (8 -> 44.1 kHz,
+ * 44.1 -> 192 kHz: 2x convolver, interpolator, a 2x convolver whose transition band follows from the rates, half-band upsamplers); half-band
+ * downsamplers + convolver [+ interpolator] (192 -> 48, 96 -> 16, 192 -> 44.1 kHz ...).  Chains of several stages take transient fp64 streams
+ * from the stream's memory pool; a chain with the spline bank synchronises the stream once (a small table goes up) and, like the reference,
+ * its result depends on num_frames (r8brain re-bases the interpolator's position counter once per process() call = per num_frames input
+ * samples).  Results: bit-identical to the vendored r8brain on the committed vectors (tests/golden/ref_made/r8brain.npz) but for samples
+ * within rounding of a tie (>= 99.9 % identical, the rest one fp32 ulp). */
 int flanhip_resample(const float * in, int64_t num_channels, int64_t num_frames, float src_rate, float dst_rate,
                      float * out, volatile int * cancel);
 int flanhip_resample_dev(const float * d_in, int64_t num_channels, int64_t num_frames, float src_rate, float dst_rate,

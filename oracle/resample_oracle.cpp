@@ -18,6 +18,9 @@
 #include <cstdlib>
 #include <cstdint>
 #include <vector>
+#include <string>
+#include <cstdio>
+#include <algorithm>
 
 namespace {
 
@@ -37,32 +40,65 @@ double bessel_i0_as( double x )
 		y * ( -0.2057706e-1 + y * ( 0.2635537e-1 + y * ( -0.1647633e-1 + y * 0.392377e-2 ) ) ) ) ) ) ) );
 	}
 
-// CDSPFIRFilter::buildLPFilter for ReqTransBand = 2 %, ReqAtten = 206.91 dB, linear phase (the only parameters Flan uses).
+// CDSPFIRFilter::buildLPFilter (CDSPFIRFilter.h:227-493) for ReqAtten = 206.91 dB, linear phase (what Flan always uses) and any transition
+// band (2 % everywhere but in the second convolver of the intermediate-interpolation branch, CDSPResampler.h:296-302).
 // Returns the 2*fl2+1 taps, DC gain `gain`, centre at index fl2.
-bool design_default_lowpass( double req_norm_freq, double gain, std::vector<double> & h, int & fl2 )
+bool design_lowpass( double req_norm_freq, double tb_percent, double gain, std::vector<double> & h, int & fl2 )
 	{
-	const double tb = 2.0 * 0.01;                                              // :229
+	const double tb = tb_percent * 0.01;                                       // :229
+	if( !( tb > 0.0 ) ) return false;
 	double atten = -206.91;                                                    // :233
-	atten -= 0.21;                                                             // :268-273 (tb < 0.10, ReqAtten >= 117)
-	const int corr_index = int( std::floor( ( -atten - 49.0 ) * 264 / 176.25 + 0.5 ) );   // :285-291
-	if( corr_index != 237 ) return false;
-	atten -= -19 / 196.0;                                                      // :354-376: entry 237 of the tb < 0.10 correction table is -19, scale 196
+	atten -= tb >= 0.25 ? 1.60 : tb >= 0.10 ? 0.69 : 0.21;                     // :235-281 (the ReqAtten >= 117 rows)
+	const int corr_index = int( std::floor( ( -atten - 49.0 ) * 264 / 176.25 + 0.5 ) );   // :283-291
+	// :293-376: the one entry of each correction table this attenuation lands on (index 239 / 238 / 237)
+	if( corr_index != ( tb >= 0.25 ? 239 : tb >= 0.10 ? 238 : 237 ) ) return false;
+	atten -= tb >= 0.25 ? -12 / 101.0 : tb >= 0.10 ? -62 / 210.0 : -19 / 196.0;
 	const double pwr = 7.43932822146293e-8 * sqr( atten ) + 0.000102747434588003 * std::cos( 0.00785021930010397 * atten ) *
 		std::cos( 0.633854318781239 + 0.103208573657699 * atten ) - 0.00798132247867036 - 0.000903555213543865 * atten -
 		0.0969365532127236 * std::exp( 0.0779275237937911 * atten ) - 1.37304948662012e-5 * atten * std::cos( 0.00785021930010397 * atten );   // :379-384
 	double hl, fo1;
-	if( pwr <= 0.067665322581 )                                                // :386, tb < 0.10 branch :425-435
+	if( pwr <= 0.067665322581 )                                                // :386
 		{
-		hl = ( 2.45739657014937 + 269.183679500541 * pwr * std::cos( 5.73225668178813 +
-			std::atan2( std::cosh( 0.988861169868941 - 17.2201556280744 * pwr ), 1.08340138240431 * pwr ) ) ) / tb;
-		fo1 = 2.291956939 * tb + 0.01942450693 * sqr( tb ) * hl - 4.67538973161837 * pwr * tb - 1.668433124 * tb * std::pow( pwr, pwr );
+		if( tb >= 0.25 )                                                       // :388-401
+			{
+			hl = 2.6778150875894 / tb + 300.547590563091 * std::atan( std::atan( 2.68959772209918 * pwr ) ) /
+				( 5.5099277187035 * tb - tb * std::tanh( std::cos( std::asinh( atten ) ) ) );
+			fo1 = 0.987205355829873 * tb + 1.00011788929851 * std::atan2( -0.321432067051302 - 6.19131357321578 * std::sqrt( pwr ),
+				hl + -1.14861472207245 / ( hl - 14.1821147585957 ) + std::pow( 0.9521145021664, std::pow( std::atan2( 1.12018764830637, tb ),
+				2.10988901686912 * hl - 20.9691278378345 ) ) );
+			}
+		else if( tb >= 0.10 )                                                  // :403-414
+			{
+			hl = ( 1.56688617018066 + 142.064321294568 * pwr + 0.00419441117131136 * std::cos( 243.633511747297 * pwr ) -
+				0.022953443903576 * atten - 0.026629568860284 * std::cos( 127.715550622571 * pwr ) ) / tb;
+			fo1 = 0.982299356642411 * tb + 0.999441744774215 * std::asinh( ( -0.361783054039583 - 5.80540593623676 * std::sqrt( pwr ) ) / hl );
+			}
+		else                                                                   // :416-426
+			{
+			hl = ( 2.45739657014937 + 269.183679500541 * pwr * std::cos( 5.73225668178813 +
+				std::atan2( std::cosh( 0.988861169868941 - 17.2201556280744 * pwr ), 1.08340138240431 * pwr ) ) ) / tb;
+			fo1 = 2.291956939 * tb + 0.01942450693 * sqr( tb ) * hl - 4.67538973161837 * pwr * tb - 1.668433124 * tb * std::pow( pwr, pwr );
+			}
 		}
-	else                                                                       // :450-461
+	else
 		{
-		hl = ( 1.15990238966306 * pwr - 5.02124037125213 * sqr( pwr ) - 0.158676856669827 * atten *
-			std::cos( 1.1609073390614 * pwr - 6.33932586197475 * pwr * sqr( pwr ) ) ) / tb;
-		fo1 = 0.867344453126885 * tb + 0.052693817907757 * tb * std::log( pwr ) + 0.0895511178735932 * tb * std::atan( 59.7538527741309 * pwr ) -
-			0.0745653568081453 * pwr * tb;
+		if( tb >= 0.25 )                                                       // :430-438
+			{
+			hl = ( 1.50258368698213 + 158.556968859477 * std::asinh( pwr ) * std::tanh( 57.9466246871383 * std::tanh( pwr ) ) - 0.0105440479814834 * atten ) / tb;
+			fo1 = 0.994024401639321 * tb + ( -0.236282717577215 - 6.8724924545387 * std::sqrt( std::sin( pwr ) ) ) / hl;
+			}
+		else if( tb >= 0.10 )                                                  // :440-449
+			{
+			hl = ( 1.50277377248945 + 158.222625721046 * std::asinh( pwr ) * std::tanh( 1.02875299001715 + 42.072277322604 * pwr ) - 0.0108380943845632 * atten ) / tb;
+			fo1 = 0.992539376734551 * tb + ( -0.251747813037178 - 6.74159892452584 * std::sqrt( std::tanh( std::tanh( std::tan( pwr ) ) ) ) ) / hl;
+			}
+		else                                                                   // :450-461
+			{
+			hl = ( 1.15990238966306 * pwr - 5.02124037125213 * sqr( pwr ) - 0.158676856669827 * atten *
+				std::cos( 1.1609073390614 * pwr - 6.33932586197475 * pwr * sqr( pwr ) ) ) / tb;
+			fo1 = 0.867344453126885 * tb + 0.052693817907757 * tb * std::log( pwr ) + 0.0895511178735932 * tb * std::atan( 59.7538527741309 * pwr ) -
+				0.0745653568081453 * pwr * tb;
+			}
 		}
 	const double pi = 3.14159265358979323846;
 	const double len2 = 0.25 * hl / req_norm_freq;                             // :468
@@ -88,6 +124,8 @@ bool design_default_lowpass( double req_norm_freq, double gain, std::vector<doub
 	for( double & v : h ) v *= gain / s;
 	return true;
 	}
+
+bool design_default_lowpass( double req_norm_freq, double gain, std::vector<double> & h, int & fl2 ) { return design_lowpass( req_norm_freq, 2.0, gain, h, fl2 ); }
 
 } // namespace
 
@@ -339,7 +377,7 @@ extern "C" int oracle_resample_two_stage( const float * in, int64_t total_in, fl
 // src >= 4 dst).  CDSPHBUpsampler (CDSPHBUpsampler.h:560-720): out[2j] = in[j], out[2j+1] = sum_t flt[t] ( in[j+1+t] + in[j-t] );
 // CDSPHBDownsampler (CDSPHBDownsampler.h:95-260): out[j] = in[2j] + sum_t flt[t] ( in[2j+2t+1] + in[2j-2t-1] ); both zero latency,
 // in = 0 before the stream starts.  The kernels are the ones getHBFilter / getHBFilterThird pick at ReqAtten = 206.91 dB
-// (CDSPHBUpsampler.h:43-215, :296-436), by SteepIndex; deeper chains than listed here (16x and more) are not restated.
+// (CDSPHBUpsampler.h:43-215, :296-436), by SteepIndex.
 namespace {
 
 const double * hb_kernel( int steep, bool third, int & n )
@@ -358,8 +396,14 @@ const double * hb_kernel( int steep, bool third, int & n )
 		1.8328498006058664e-003, -1.4518194076022933e-004 };
 	static const double t2[5] = { 6.0590922849004858e-001, -1.3515953371903033e-001, 3.5020856634677522e-002, -6.3256195330255094e-003,       // third: HBKernel_5c, 248.8728 dB
 		5.5506812768978109e-004 };
-	if( third ) switch( steep ) { case 0: n = 9; return t0; case 1: n = 6; return t1; case 2: n = 5; return t2; default: n = 0; return nullptr; }
-	switch( steep ) { case 0: n = 13; return h0; case 1: n = 7; return h1; case 2: n = 5; return h2; case 3: n = 4; return h3; default: n = 0; return nullptr; }
+	static const double h45[4] = { 5.9819599535791312e-001, -1.1972157884617740e-001, 2.3977307400990484e-002, -2.4517239127622593e-003 };    // HBKernel_4e, 268.8561 dB (SteepIndex 4, 5)
+	static const double h6[3] = { 5.8594191093025305e-001, -9.7662866644414148e-002, 1.1720955714177778e-002 };                               // HBKernel_3g, 275.5531 dB (6 and beyond)
+	static const double t3[4] = { 5.9823601283411165e-001, -1.1979369067338455e-001, 2.4017459011435899e-002, -2.4597811725236445e-003 };     // third: HBKernel_4d, 248.8578 dB
+	static const double t45[3] = { 5.8596887233874539e-001, -9.7703321108182931e-002, 1.1734448775437802e-002 };                              // third: HBKernel_3e, 224.4366 dB
+	static const double t6[3] = { 5.8593945769687561e-001, -9.7659186594368730e-002, 1.1719728897494584e-002 };                               // third: HBKernel_3g, 296.4833 dB
+	if( steep < 0 ) { n = 0; return nullptr; }
+	if( third ) switch( steep ) { case 0: n = 9; return t0; case 1: n = 6; return t1; case 2: n = 5; return t2; case 3: n = 4; return t3; case 4: case 5: n = 3; return t45; default: n = 3; return t6; }
+	switch( steep ) { case 0: n = 13; return h0; case 1: n = 7; return h1; case 2: n = 5; return h2; case 3: n = 4; return h3; case 4: case 5: n = 4; return h45; default: n = 3; return h6; }
 	}
 
 // what CDSPResampler( src, dst ) builds, for the shapes this file restates
@@ -424,6 +468,238 @@ bool chain_shape( double src, double dst, Chain & ch )
 double at( const std::vector<double> & v, int64_t i ) { return i >= 0 && i < int64_t( v.size() ) ? v[size_t( i )] : 0.0; }
 
 } // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The whole of CDSPResampler's constructor (CDSPResampler.h:119-378) as a list of stages, and a stage-by-stage evaluation on the whole
+// stream.  Adds to the chains above: the upsampling branch with INTERMEDIATE INTERPOLATION (dst >= 2.02 src off the 2^k / 3 2^k grid, :229-310:
+// 2x convolver -> interpolator to dst / 2^c -> a 2x convolver whose transition band follows from the rates -> c - 1 half-band upsamplers) and
+// half-band downsamplers in front of the spline-interpolated bank.
+namespace {
+
+struct Stage
+	{
+	enum Kind { HbDown, Conv, HbUp, Frac } kind;
+	int steep = 0; bool third = false;                                            // half-band stages; the interpolator's bank
+	int up = 1, down = 1; double nf = 0.5, tb = 2.0, gain = 1.0;                  // block convolver (tb in percent)
+	bool whole = true; int in_step = 0, out_step = 0; double isrc = 0.0, idst = 0.0;   // interpolator
+	};
+
+bool add_frac( std::vector<Stage> & st, double isrc, double idst, bool third )
+	{
+	Stage f; f.kind = Stage::Frac; f.third = third; f.isrc = isrc; f.idst = idst;
+	f.whole = whole_stepping( isrc, idst, f.in_step, f.out_step );
+	st.push_back( f );
+	return true;
+	}
+
+bool build_stages( double src, double dst, std::vector<Stage> & st )
+	{
+	st.clear();
+	if( !( src > 0.0 ) || !( dst > 0.0 ) || src == dst ) return false;
+	auto conv = [&]( int up, int down, double nf, double tb, double gain ) { Stage c; c.kind = Stage::Conv; c.up = up; c.down = down; c.nf = nf; c.tb = tb; c.gain = gain; st.push_back( c ); };
+	auto hb = [&]( Stage::Kind k, int steep, bool third ) { Stage h; h.kind = k; h.steep = steep; h.third = third; st.push_back( h ); int n; return hb_kernel( steep, third, n ) != nullptr; };
+	static const int common[5][2] = { { 1, 2 }, { 1, 3 }, { 2, 3 }, { 3, 2 }, { 3, 4 } };            // :142-170
+	for( const auto & c : common )
+		if( src * c[0] == dst * c[1] ) { conv( c[0], c[1], 1.0 / ( c[0] > c[1] ? c[0] : c[1] ), 2.0, c[0] ); return true; }
+	for( int i = 2; i <= 3; ++i )                                                                   // :174-212
+		for( int c = 0; src * ( i << c ) <= dst; ++c )
+			if( src * ( i << c ) == dst )
+				{
+				conv( i, 1, 1.0 / i, 2.0, i );
+				for( int k = 0; k < c; ++k ) if( !hb( Stage::HbUp, k, i == 3 ) ) return false;
+				return true;
+				}
+	if( dst * 2 > src )                                                                            // :214-316
+		{
+		conv( 2, 1, dst > src ? 0.5 : 0.5 * dst / src, 2.0, 2.0 );                                 // :218-225
+		const double thresh = src * 1.01;
+		int c = 0, div = 1;
+		while( !( dst < thresh * ( div * 2 ) ) ) { div *= 2; ++c; }                                // :229-244
+		// (:246-261: the 3x variant tries 3 div against the same threshold the loop above just failed at 2 div -- it never wins)
+		int t1, t2;
+		if( c == 1 && whole_stepping( src * 2.0, dst, t1, t2 ) ) c = 0;                            // :266-276
+		if( c > 0 )
+			{
+			add_frac( st, src * 2.0 * div, dst, false );                                           // :293-294
+			conv( 2, 1, 0.5, 100.0 * ( 1.0 - src * div / dst ) / 1.75, 2.0 );                      // :296-302
+			for( int i = 1; i < c; ++i ) if( !hb( Stage::HbUp, i - 1, false ) ) return false;      // :304-308
+			}
+		else add_frac( st, src * 2.0, dst, false );                                                // :312-313
+		return true;
+		}
+	double check = dst * 4.0, fin_gain = 1.0;                                                      // :319-331
+	int c = 0;
+	while( check <= src ) { ++c; check *= 2.0; fin_gain *= 0.5; }
+	const int div = 1 << c;
+	int downf = 1; double nf = 0.5; bool use_interp = true, third = false;
+	for( int d = 2; d <= 3; ++d ) if( dst * div * d == src ) { downf = d; nf = 1.0 / d; use_interp = false; third = ( d == 3 ); break; }   // :340-349
+	if( use_interp ) { nf = dst * div / src; third = nf * 3.0 <= 1.0; }                            // :351-356
+	for( int i = 0; i < c; ++i ) if( !hb( Stage::HbDown, c - 1 - i, third ) ) return false;        // :358-365
+	conv( 1, downf, nf, 2.0, fin_gain );                                                           // :367-370
+	if( use_interp ) add_frac( st, src, dst * div, third );                                        // :372-376
+	return true;
+	}
+
+// samples a stage has delivered once `n` samples have gone into it (every stage consumes its latency and then keeps pace with its input):
+// what decides how much of the stream each process() call hands the interpolator
+int64_t delivered( const Stage & s, int64_t n, int fl2_conv )
+	{
+	if( s.kind == Stage::HbDown )                                                                  // CDSPHBDownsampler.h:95-150: fl2 = 2 taps - 1
+		{
+		int taps; hb_kernel( s.steep, s.third, taps );
+		const int fl2 = 2 * taps - 1;
+		return n > fl2 ? ( n - fl2 + 1 ) >> 1 : 0;
+		}
+	if( s.kind == Stage::Conv ) return std::max<int64_t>( 0, n * s.up - block_convolver_latency( fl2_conv, s.up ) ) / s.down;
+	return n;
+	}
+
+int resample_by_stages( const std::vector<Stage> & st, const float * in, int64_t total_in, float * out, int64_t total_out, int64_t chunk )
+	{
+	if( total_out <= 0 ) return 0;
+	const int ns = int( st.size() );
+	// filters and banks
+	std::vector<std::vector<double>> taps; taps.resize( size_t( ns ) ); std::vector<int> fl2( size_t( ns ), 0 ), flt_len( size_t( ns ), 0 ), fracs( size_t( ns ), 0 );
+	for( int k = 0; k < ns; ++k )
+		{
+		if( st[k].kind == Stage::Conv && !design_lowpass( st[k].nf, st[k].tb, st[k].gain, taps[k], fl2[k] ) ) return -1;
+		if( st[k].kind == Stage::Frac ) { if( st[k].whole ) { frac_delay_bank( st[k].out_step, st[k].third, taps[k], flt_len[k] ); fracs[k] = st[k].out_step; } else frac_spline_bank( st[k].third, taps[k], flt_len[k], fracs[k] ); }
+		}
+	// samples each stage must deliver (backwards)
+	std::vector<int64_t> need; need.resize( size_t( ns ) );
+	need[ns - 1] = total_out;
+	for( int k = ns - 1; k > 0; --k )
+		{
+		const Stage & s = st[k];
+		const int64_t n = need[k];
+		int64_t r = n;
+		if( s.kind == Stage::HbDown ) { int t; hb_kernel( s.steep, s.third, t ); r = 2 * ( n - 1 ) + 2 * t; }
+		else if( s.kind == Stage::HbUp ) { int t; hb_kernel( s.steep, s.third, t ); r = ( n - 1 ) / 2 + t + 1; }
+		else if( s.kind == Stage::Conv ) r = ( int64_t( s.down ) * ( n - 1 ) + fl2[k] ) / s.up + 1;
+		else if( s.whole ) r = ( ( n - 1 ) * s.in_step ) / s.out_step - ( flt_len[k] / 2 - 1 ) + flt_len[k];
+		else r = int64_t( std::ceil( double( n ) * s.isrc / s.idst ) ) + flt_len[k] + 8;
+		need[k - 1] = std::max<int64_t>( r, 1 );
+		}
+	std::vector<double> cur( in, in + total_in );
+	for( int k = 0; k < ns; ++k )
+		{
+		const Stage & s = st[k];
+		std::vector<double> nxt( size_t( need[k] ) );
+		const int64_t n_out = need[k];
+		if( s.kind == Stage::HbDown )
+			{
+			int t; const double * flt = hb_kernel( s.steep, s.third, t );
+			for( int64_t j = 0; j < n_out; ++j )
+				{
+				double a = at( cur, 2 * j );
+				for( int i = 0; i < t; ++i ) a += flt[i] * ( at( cur, 2 * j + 2 * i + 1 ) + at( cur, 2 * j - 2 * i - 1 ) );
+				nxt[size_t( j )] = a;
+				}
+			}
+		else if( s.kind == Stage::HbUp )
+			{
+			int t; const double * flt = hb_kernel( s.steep, s.third, t );
+			for( int64_t o = 0; o < n_out; ++o )
+				{
+				const int64_t j = o >> 1;
+				if( ( o & 1 ) == 0 ) { nxt[size_t( o )] = at( cur, j ); continue; }
+				double a = flt[0] * ( at( cur, j + 1 ) + at( cur, j ) );
+				for( int i = 1; i < t; ++i ) a += flt[i] * ( at( cur, j + 1 + i ) + at( cur, j - i ) );
+				nxt[size_t( o )] = a;
+				}
+			}
+		else if( s.kind == Stage::Conv )
+			{
+			const std::vector<double> & h = taps[k]; const int f2 = fl2[k]; const int64_t len_in = int64_t( cur.size() );
+			for( int64_t o = 0; o < n_out; ++o )
+				{
+				const int64_t c = int64_t( s.down ) * o;
+				int64_t m0 = c - f2 <= 0 ? 0 : ( c - f2 + s.up - 1 ) / s.up, m1 = ( c + f2 ) / s.up;
+				if( m1 >= len_in ) m1 = len_in - 1;
+				double a = 0.0;
+				for( int64_t m = m0; m <= m1; ++m ) a += h[f2 + ( c - s.up * m )] * cur[size_t( m )];
+				nxt[size_t( o )] = a;
+				}
+			}
+		else if( s.whole )
+			{
+			const int fll = flt_len[k] / 2 - 1;
+			for( int64_t o = 0; o < n_out; ++o )
+				{
+				const int64_t pos = o * s.in_step, p = pos / s.out_step;
+				const double * ft = &taps[k][size_t( pos % s.out_step ) * flt_len[k]];
+				double a = 0.0;
+				for( int i = 0; i < flt_len[k]; ++i ) a += ft[i] * at( cur, p - fll + i );
+				nxt[size_t( o )] = a;
+				}
+			}
+		else
+			{
+			// CDSPFracInterpolator::process + convolve2, call by call (see oracle_resample_chain): what the stages in front have delivered
+			// after `call` calls of `chunk` input samples each
+			const int fll = flt_len[k] / 2 - 1, fl2i = flt_len[k] / 2;
+			int64_t read_abs = 0, j = 0;
+			int in_counter = 0, in_pos_int = 0;
+			double shift = 0.0, frac = 0.0;
+			for( int64_t call = 1; j < n_out; ++call )
+				{
+				int64_t w = call * chunk;
+				for( int q = 0; q < k; ++q ) w = delivered( st[q], w, fl2[q] );
+				while( w - read_abs > fl2i && j < n_out )
+					{
+					double x = frac * fracs[k];
+					const int fti = int( x );
+					x -= fti;
+					const double x2 = x * x;
+					const double * ftp = &taps[k][size_t( fti ) * flt_len[k] * 3];
+					double a = 0.0;
+					for( int i = 0; i < flt_len[k]; ++i ) a += ( ftp[3 * i] + ftp[3 * i + 1] * x + ftp[3 * i + 2] * x2 ) * at( cur, read_abs - fll + i );
+					nxt[size_t( j++ )] = a;
+					++in_counter;
+					const double next = ( in_counter + shift ) * s.isrc / s.idst;
+					const int next_int = int( next );
+					read_abs += next_int - in_pos_int;
+					in_pos_int = next_int;
+					frac = next - next_int;
+					}
+				if( in_counter > 1000 ) { in_counter = 0; in_pos_int = 0; shift = frac * s.idst / s.isrc; }
+				}
+			}
+		cur.swap( nxt );
+		}
+	for( int64_t k = 0; k < total_out; ++k ) out[k] = float( cur[size_t( k )] );
+	return 0;
+	}
+
+} // namespace
+
+// Audio::resample through whatever chain CDSPResampler builds for ( src, dst ); -1: a half-band chain deeper than the kernels restated
+extern "C" int oracle_resample_general( const float * in, int64_t total_in, float * out, int64_t total_out, double src, double dst, int64_t chunk )
+	{
+	std::vector<Stage> st;
+	if( !build_stages( src, dst, st ) ) return -1;
+	return resample_by_stages( st, in, total_in, out, total_out, chunk );
+	}
+
+// the stage list as text for tests: "hbdown:1 conv:1/2 ..." -- returns the number of stages, 0 when not restated
+extern "C" int oracle_resample_stage_list( double src, double dst, char * text, int capacity )
+	{
+	std::vector<Stage> st;
+	if( !build_stages( src, dst, st ) ) return 0;
+	std::string t;
+	for( const Stage & s : st )
+		{
+		char b[96];
+		if( s.kind == Stage::HbDown ) std::snprintf( b, sizeof b, "hbdown:%d%s ", s.steep, s.third ? "t" : "" );
+		else if( s.kind == Stage::HbUp ) std::snprintf( b, sizeof b, "hbup:%d%s ", s.steep, s.third ? "t" : "" );
+		else if( s.kind == Stage::Conv ) std::snprintf( b, sizeof b, "conv:%d/%d@%.6g,tb%.6g,g%.6g ", s.up, s.down, s.nf, s.tb, s.gain );
+		else if( s.whole ) std::snprintf( b, sizeof b, "frac:%d/%d%s ", s.in_step, s.out_step, s.third ? "t" : "" );
+		else std::snprintf( b, sizeof b, "spline:%.9g->%.9g%s ", s.isrc, s.idst, s.third ? "t" : "" );
+		t += b;
+		}
+	if( text && capacity > 0 ) { std::snprintf( text, size_t( capacity ), "%s", t.c_str() ); }
+	return int( st.size() );
+	}
 
 // 1 when this file restates the chain CDSPResampler( src, dst ) builds; the shape for tests
 extern "C" int oracle_resample_chain_shape( double src, double dst, int * hb_down, int * up, int * down, double * norm_freq, double * gain, int * hb_up, int * third,

@@ -257,7 +257,8 @@ static void device_checks()
 		Audio a48 = a96.resample( 48000.0f );
 		CHECK( !a48.is_null() && a48.get_num_frames() == 9600 && a48.get_sample_rate() == 48000.0f && a48.get_num_channels() == 2 );
 		CHECK( a96.resample( 96000.0f ).get_num_frames() == 19200 );               // same rate: a copy (AudioConversions.cpp:18-19)
-		CHECK( a96.resample( 11026.0f ).is_null() );                              // half-band stages in front of the spline bank: refused
+		CHECK( a96.resample( 1000.0f ).get_num_frames() == 200 );                 // 96x down: five third-band half-band stages and a 3:1 convolver
+		CHECK( a96.resample( 11026.0f ).get_num_frames() == 2205 );               // half-band stages in front of the spline bank
 		CHECK( a96.resample( 44101.0f ).get_num_frames() == 8820 );               // no whole stepping: the spline-interpolated bank
 		CHECK( a96.resample( 16000.0f ).get_num_frames() == 3200 );               // half-band downsampler + block convolver
 		Audio a441 = a96.resample( 44100.0f );                                    // block convolver + whole-stepping interpolator

@@ -72,6 +72,8 @@ def _load():
     dp = C.POINTER(C.c_double)
     lib.oracle_resample_chain_shape.argtypes = [C.c_double, C.c_double, ip, ip, ip, dp, dp, ip, ip, ip, ip, ip, ip]
     lib.oracle_resample_chain.argtypes = [f32p, C.c_int64, f32p, C.c_int64, C.c_double, C.c_double, C.c_int64]
+    lib.oracle_resample_general.argtypes = [f32p, C.c_int64, f32p, C.c_int64, C.c_double, C.c_double, C.c_int64]
+    lib.oracle_resample_stage_list.argtypes = [C.c_double, C.c_double, C.c_char_p, C.c_int]
     i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
     lib.oracle_interpolate.restype = C.c_float
     lib.oracle_interpolate.argtypes = [C.c_int, C.c_float]
@@ -533,6 +535,23 @@ def resample_chain(audio, src_rate, dst_rate):
     n_out = int(lib.oracle_resample_out_frames(n, src_rate, dst_rate))
     out = np.empty((ch, n_out), np.float32)
     rc = lib.oracle_resample_chain(audio.reshape(-1), ch * n, out.reshape(-1), ch * n_out, float(src_rate), float(dst_rate), n)   # oneshot feeds n samples per call
+    assert rc == 0, "chain not restated"
+    return out
+
+
+def resample_stages(src_rate, dst_rate):
+    """the chain CDSPResampler( src, dst ) builds, as text ("conv:2/1@0.5,tb2,g2 frac:147/80 "), or None when the checker does not restate it"""
+    buf = C.create_string_buffer(1024)
+    return buf.value.decode() if lib.oracle_resample_stage_list(float(src_rate), float(dst_rate), buf, 1024) else None
+
+
+def resample_general(audio, src_rate, dst_rate):
+    """Audio::resample through whatever chain r8brain builds (the stage-list form of the checker): [ch][n] -> [ch][n_out]"""
+    audio = np.ascontiguousarray(audio, np.float32)
+    ch, n = audio.shape
+    n_out = int(lib.oracle_resample_out_frames(n, src_rate, dst_rate))
+    out = np.empty((ch, n_out), np.float32)
+    rc = lib.oracle_resample_general(audio.reshape(-1), ch * n, out.reshape(-1), ch * n_out, float(src_rate), float(dst_rate), n)
     assert rc == 0, "chain not restated"
     return out
 

@@ -107,6 +107,26 @@ def test_resample_without_whole_stepping(fa, src, dst):
         assert d.max() <= 1.2e-7 and same >= 0.999
 
 
+GENERAL = [(8000.0, 44100.0), (11025.0, 48000.0), (8000.0, 48001.0), (44100.0, 192000.0), (192000.0, 44101.0), (96000.0, 11026.0), (1000.0, 44100.0)]
+
+
+@pytest.mark.parametrize("src,dst", GENERAL)
+def test_resample_general_chains(fa, src, dst):
+    """the rest of CDSPResampler's constructor: upsampling with intermediate interpolation (2x convolver -> interpolator -> a 2x convolver whose
+    transition band follows from the rates -> half-band upsamplers: 8 -> 44.1 kHz, 44.1 -> 192 kHz ...) and half-band downsamplers in front of
+    the spline-interpolated bank; the stage-list form of the checker is bit-identical to the vendored r8brain on these (test_oracle_resample.py)"""
+    assert O.resample_stages(src, dst) is not None
+    for ch, n in ((3, 5001), (2, 777), (1, 40)):
+        x = O.noise(ch, n, seed=n + int(dst))
+        ref = O.resample_general(x, src, dst)
+        got = fa.resample(x, src, dst)
+        assert got.shape == ref.shape
+        d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+        same = np.mean(got.view(np.uint32) == ref.view(np.uint32)) if d.size else 1.0
+        print("\n[resample %g->%g %dx%d] %s max diff %.2e  bit-identical %.5f" % (src, dst, ch, n, O.resample_stages(src, dst), d.max() if d.size else 0.0, same))
+        assert (d.max() if d.size else 0.0) <= 1.2e-7 and same >= 0.999
+
+
 def test_resample_two_stage_long(fa):
     """a minute of 44.1 kHz stereo to 48 kHz: the sine comes out a sine (size-independent property; the oracle is not run at this size)"""
     sr, n = 44100.0, 44100 * 60
@@ -124,15 +144,22 @@ def test_resample_two_stage_long(fa):
     assert np.abs(y[1, mid] - 0.25 * np.sin(2 * np.pi * 15000.0 * (u[mid] + shift) / 48000.0)).max() <= 2e-6
 
 
-def test_unsupported_ratio(fa):
-    """ratios r8brain serves through intermediate interpolation with its own low-pass, a half-band chain deeper than 16x, or half-band
-    stages in front of the spline-interpolated bank are refused, not approximated"""
+def test_extreme_ratios(fa):
+    """nothing is refused any more: half-band chains of any depth (the kernels r8brain picks at SteepIndex 4, 5, 6+ too) -- 64x up, 96x and 512x
+    down, 480x up through intermediate interpolation with a 26.7 % transition band -- against the stage-list checker (bit-identical to the
+    vendored r8brain on these: test_oracle_resample.py)"""
+    for src, dst, ch, n in ((1000.0, 64000.0, 2, 1501), (96000.0, 1000.0, 2, 30001), (768000.0, 1500.0, 1, 200001), (100.0, 48000.0, 1, 301)):
+        x = O.noise(ch, n, seed=n)
+        ref = O.resample_general(x, src, dst)
+        got = fa.resample(x, src, dst)
+        assert got.shape == ref.shape
+        d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+        same = np.mean(got.view(np.uint32) == ref.view(np.uint32))
+        print("\n[resample %g->%g %dx%d] %s max diff %.2e  bit-identical %.5f" % (src, dst, ch, n, O.resample_stages(src, dst), d.max(), same))
+        assert d.max() <= 1.2e-7 and same >= 0.999
     import flan_amd
-    x = O.noise(1, 1000, seed=1)
-    for src, dst in ((8000.0, 44100.0), (1000.0, 64000.0), (192000.0, 44101.0), (11025.0, 48001.0)):
-        with pytest.raises(flan_amd.FlanHipError) as e:
-            fa.resample(x, src, dst)
-        assert e.value.code == flan_amd.ERR_UNSUPPORTED
+    with pytest.raises(flan_amd.FlanHipError):
+        fa.resample(O.noise(1, 100, seed=1), 48000.0, 0.0)                      # not a rate
 
 
 def test_config5_small(fa):

@@ -141,14 +141,49 @@ def test_ratios_without_whole_stepping_match_r8brain(src, dst):
         assert d.max() <= 1.2e-7 and same >= 0.999
 
 
+GENERAL = [(1000.0, 64000.0), (96000.0, 1000.0), (500.0, 44100.0), (768000.0, 1500.0), (100.0, 48000.0), (8000.0, 44100.0), (11025.0, 48000.0), (8000.0, 48001.0), (16000.0, 44100.0), (44100.0, 192000.0), (22050.0, 96000.0), (192000.0, 44101.0),
+           (96000.0, 11026.0), (1000.0, 44100.0), (44100.0, 48000.0), (96000.0, 48000.0), (192000.0, 44100.0), (8000.0, 96000.0)]
+
+
+@pytest.mark.parametrize("src,dst", GENERAL)
+def test_stage_list_matches_r8brain(src, dst):
+    """the whole of CDSPResampler's constructor as a stage list (build_stages): upsampling with intermediate interpolation, half-band stages in
+    front of the spline bank, and every shape the other forms of the checker restate"""
+    assert O.resample_stages(src, dst) is not None
+    rng = np.random.default_rng(int(src + dst))
+    for ch, n in ((3, 5001), (1, 300)):
+        x = rng.uniform(-1, 1, (ch, n)).astype(np.float32)
+        ours = O.resample_general(x, src, dst)
+        theirs = ref_resample(x, src, dst)
+        assert ours.shape == theirs.shape
+        if ours.size == 0:
+            continue
+        d = np.abs(ours.astype(np.float64) - theirs.astype(np.float64))
+        same = np.mean(ours.view(np.uint32) == theirs.view(np.uint32))
+        print("\n[resample %g->%g %dx%d] %s max diff %.2e  bit-identical %.5f" % (src, dst, ch, n, O.resample_stages(src, dst), d.max(), same))
+        assert d.max() <= 1.2e-7 and same >= 0.995
+
+
+def test_stage_lists():
+    assert O.resample_stages(8000.0, 44100.0).split() == ["conv:2/1@0.5,tb2,g2", "frac:640/441", "conv:2/1@0.5,tb15.6787,g2", "hbup:0"]
+    assert O.resample_stages(44100.0, 48000.0).split() == ["conv:2/1@0.5,tb2,g2", "frac:147/80"]
+    assert O.resample_stages(192000.0, 44101.0).split()[0] == "hbdown:0" and O.resample_stages(192000.0, 44101.0).split()[-1].startswith("spline:")
+    assert O.resample_stages(1000.0, 64000.0).split() == ["conv:2/1@0.5,tb2,g2"] + ["hbup:%d" % i for i in range(5)]
+    assert O.resample_stages(96000.0, 1000.0).split()[:5] == ["hbdown:%dt" % i for i in (4, 3, 2, 1, 0)] and O.resample_stages(48000.0, 48000.0) is None
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1, 1, (2, 4000)).astype(np.float32)
+    for src, dst in ((96000.0, 48000.0), (44100.0, 48000.0), (192000.0, 48000.0), (44100.0, 48001.0)):
+        assert np.array_equal(O.resample_general(x, src, dst).view(np.uint32), O.resample_chain(x, src, dst).view(np.uint32)), (src, dst)
+
+
 def test_chain_form_contains_the_other_restatements():
     rng = np.random.default_rng(11)
     x = rng.uniform(-1, 1, (2, 5000)).astype(np.float32)
     assert np.array_equal(O.resample_chain(x, 96000.0, 48000.0).view(np.uint32), O.resample_2to1(x, 96000.0, 48000.0).view(np.uint32))
     assert np.array_equal(O.resample_chain(x, 32000.0, 48000.0).view(np.uint32), O.resample_rational(x, 32000.0, 48000.0, 3, 2).view(np.uint32))
     assert np.array_equal(O.resample_chain(x, 44100.0, 48000.0).view(np.uint32), O.resample_two_stage(x, 44100.0, 48000.0).view(np.uint32))
-    for src, dst in ((8000.0, 44100.0), (1000.0, 64000.0), (192000.0, 44101.0), (48000.0, 48000.0)):
-        assert O.chain_shape(src, dst) is None, (src, dst)
+    for src, dst in ((8000.0, 44100.0), (192000.0, 44101.0), (48000.0, 48000.0)):
+        assert O.chain_shape(src, dst) is None, (src, dst)       # (the older Chain form: intermediate interpolation and half-band + spline are the stage list's)
 
 
 def test_two_stage_shapes():
