@@ -1,4 +1,7 @@
-// resample_oracle.cpp -- CPU restatement of Audio::resample for the 2:1 decimation case (BASELINE config 5: 96 kHz -> 48 kHz).
+// resample_oracle.cpp -- CPU restatement of Audio::resample: r8brain's CDSPResampler for the parameters Flan uses.  It grew form by form, and
+// every form is kept because the tests hold them against each other: the 2:1 decimation (BASELINE config 5: 96 kHz -> 48 kHz) and the other
+// single-convolver ratios; convolver + whole-stepping interpolator (44.1 <-> 48 kHz); chains with half-band stages and the spline-interpolated
+// bank (oracle_resample_chain); and the whole constructor as a stage list (oracle_resample_general: what every other form is a special case of).
 //
 // TEST INFRASTRUCTURE ONLY (same rules as flan_oracle.cpp).  Pinned against the REAL r8brain resampler the reference vendors
 // (oracle/_ref/libr8bref.so, tests/test_oracle_resample.py).
