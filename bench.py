@@ -331,75 +331,78 @@ def main():
 
     # ---- the output-reassembly all-gather of the north star, outside the metric: on its own, and overlapped with the compute ----
     if distributed and not args.no_gather and not share_gpu:
-        nranks = dist.get_world_size()
-        for _ in range(2):
-            gathered = sharding.gather_output(dist, out, world)
-        sync_all()
-        t0 = time.perf_counter()
-        reps = 5
-        for _ in range(reps):
-            gathered = sharding.gather_output(dist, out, world)
-        sync_all()
-        tg = sharding.max_over_ranks(dist, (time.perf_counter() - t0) / reps, ctl_dev)
-        assert gathered.shape == (world * ch, F * HOP)
-        del gathered
-        # overlapped: batch i's output travels (one batch of point-to-point operations into the final channel-major buffer, on a side
-        # stream) while batch i + 1 is analysed and synthesised -- two output buffers in turn; with --gather-chunks K > 1 the rank's
-        # channels are additionally cut into K chunks per batch, each sent as soon as it is done (smaller launches: slower compute)
-        chunks = max(1, min(args.gather_chunks, ch))
-        while ch % chunks:
-            chunks -= 1
-        k = ch // chunks
-        side = torch.cuda.Stream(device=dev)
-        outs = [out, torch.empty_like(out)]
-        finals = [torch.empty((world * ch, F * HOP), dtype=torch.float32, device=dev) for _ in range(2)]
-        wss = [torch.empty(fa.synthesize_workspace_bytes(k, F, BINS, SR, ar, WINDOW), dtype=torch.uint8, device=dev) for _ in range(chunks)]
-        pending = [[], []]
+        try:
+            nranks = dist.get_world_size()
+            for _ in range(2):
+                gathered = sharding.gather_output(dist, out, world)
+            sync_all()
+            t0 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                gathered = sharding.gather_output(dist, out, world)
+            sync_all()
+            tg = sharding.max_over_ranks(dist, (time.perf_counter() - t0) / reps, ctl_dev)
+            assert gathered.shape == (world * ch, F * HOP)
+            del gathered
+            # overlapped: batch i's output travels (one batch of point-to-point operations into the final channel-major buffer, on a side
+            # stream) while batch i + 1 is analysed and synthesised -- two output buffers in turn; with --gather-chunks K > 1 the rank's
+            # channels are additionally cut into K chunks per batch, each sent as soon as it is done (smaller launches: slower compute)
+            chunks = max(1, min(args.gather_chunks, ch))
+            while ch % chunks:
+                chunks -= 1
+            k = ch // chunks
+            side = torch.cuda.Stream(device=dev)
+            outs = [out, torch.empty_like(out)]
+            finals = [torch.empty((world * ch, F * HOP), dtype=torch.float32, device=dev) for _ in range(2)]
+            wss = [torch.empty(fa.synthesize_workspace_bytes(k, F, BINS, SR, ar, WINDOW), dtype=torch.uint8, device=dev) for _ in range(chunks)]
+            pending = [[], []]
 
-        def step_with_gather(i):
-            b = i & 1
-            for r in pending[b]:                     # the gather that last used this pair of buffers
-                r.wait()
-            pending[b] = []
-            torch.cuda.current_stream().wait_stream(side)
-            for c in range(chunks):
-                c0 = c * k
-                o = outs[b][c0:c0 + k]
-                analyze(audio[c0:c0 + k], pv[c0:c0 + k], wss[c], k)
-                synthesize(pv[c0:c0 + k], o, wss[c], k)
-                done = torch.cuda.Event()
-                done.record()
-                side.wait_event(done)
-                with torch.cuda.stream(side):
-                    pending[b] += sharding.gather_chunk_into(dist, finals[b], o, rank, world, ch, c0)
-
-        def drain():
-            for b in (0, 1):
-                for r in pending[b]:
+            def step_with_gather(i):
+                b = i & 1
+                for r in pending[b]:                     # the gather that last used this pair of buffers
                     r.wait()
                 pending[b] = []
-            torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.current_stream().wait_stream(side)
+                for c in range(chunks):
+                    c0 = c * k
+                    o = outs[b][c0:c0 + k]
+                    analyze(audio[c0:c0 + k], pv[c0:c0 + k], wss[c], k)
+                    synthesize(pv[c0:c0 + k], o, wss[c], k)
+                    done = torch.cuda.Event()
+                    done.record()
+                    side.wait_event(done)
+                    with torch.cuda.stream(side):
+                        pending[b] += sharding.gather_chunk_into(dist, finals[b], o, rank, world, ch, c0)
 
-        for i in range(4):
-            step_with_gather(i)
-        drain()
-        sync_all()
-        t0 = time.perf_counter()
-        reps = max(6, min(args.steps, 20))
-        for i in range(reps):
-            step_with_gather(i)
-        drain()
-        sync_all()
-        tov = sharding.max_over_ranks(dist, (time.perf_counter() - t0) / reps, ctl_dev)
-        for b in (0, 1):
-            assert bool(torch.equal(finals[b][rank * ch: rank * ch + ch], outs[b])), "the gathered buffer must hold this rank's channels in place"
-        extra["allgather"] = {"nranks": nranks, "ms_alone": round(tg * 1e3, 3), "bytes_per_rank": out.numel() * 4,
-                              "frames_per_s_compute_only": round(value, 1),
-                              "frames_per_s_compute_then_gather": round(world * frames_per_step / (elapsed / args.steps + tg), 1),
-                              "frames_per_s_gather_overlapped": round(world * frames_per_step / tov, 1),
-                              "overlapped_step_ms": round(tov * 1e3, 4), "channel_chunks": chunks,
-                              "overlap": "gather of batch i (side stream, p2p batch into the final layout) under the compute of batch i + 1"}
-        del finals, outs, wss
+            def drain():
+                for b in (0, 1):
+                    for r in pending[b]:
+                        r.wait()
+                    pending[b] = []
+                torch.cuda.current_stream().wait_stream(side)
+
+            for i in range(4):
+                step_with_gather(i)
+            drain()
+            sync_all()
+            t0 = time.perf_counter()
+            reps = max(6, min(args.steps, 20))
+            for i in range(reps):
+                step_with_gather(i)
+            drain()
+            sync_all()
+            tov = sharding.max_over_ranks(dist, (time.perf_counter() - t0) / reps, ctl_dev)
+            for b in (0, 1):
+                assert bool(torch.equal(finals[b][rank * ch: rank * ch + ch], outs[b])), "the gathered buffer must hold this rank's channels in place"
+            extra["allgather"] = {"nranks": nranks, "ms_alone": round(tg * 1e3, 3), "bytes_per_rank": out.numel() * 4,
+                                  "frames_per_s_compute_only": round(value, 1),
+                                  "frames_per_s_compute_then_gather": round(world * frames_per_step / (elapsed / args.steps + tg), 1),
+                                  "frames_per_s_gather_overlapped": round(world * frames_per_step / tov, 1),
+                                  "overlapped_step_ms": round(tov * 1e3, 4), "channel_chunks": chunks,
+                                  "overlap": "gather of batch i (side stream, p2p batch into the final layout) under the compute of batch i + 1"}
+            del finals, outs, wss
+        except Exception as e:                       # (an error every rank raises alike: the headline line must survive a side measurement)
+            extra["allgather"] = {"error": repr(e)}
 
     # the host-buffer C ABI (flanhip_analyze / flanhip_synthesize): upload, kernels, download -- for DESIGN.md, never the metric
     if rank == 0 and args.pcie:
