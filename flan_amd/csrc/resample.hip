@@ -185,6 +185,7 @@ struct Stage
 	int up = 1, down = 1; double nf = 0.5, tb = 2.0, gain = 1.0;                  // block convolver (tb in percent)
 	bool third = false, whole = true; int in_step = 0, out_step = 0; double isrc = 0.0, idst = 0.0;   // interpolator (whole stepping, or the spline bank)
 	const double * d_h = nullptr; int fl2 = 0;                                    // device tables, filled by get_stage_plan
+	const double * d_g0 = nullptr; const double * d_g1 = nullptr; int up2_len = 0, up2_u_min = 0;   // the convolver's two phases when up == 2
 	const double * d_bank = nullptr; int flt_len = 0, fracs = 0;
 	};
 
@@ -370,7 +371,7 @@ static void spline_segments( const std::vector<Stage> & st, int k, int64_t chunk
 
 // device copies, cached for the process: low-pass taps per (device, cut-off, transition band, gain); interpolator banks per (device, rows or -1 for
 // the spline bank, third-band); the stage list with its pointers per (device, src, dst)
-struct DevTaps { double * d = nullptr; int fl2 = 0; };
+struct DevTaps { double * d = nullptr; int fl2 = 0; double * d_g0 = nullptr; double * d_g1 = nullptr; int len = 0, u_min = 0; };   // g0 / g1: the two phases for k_resample_up2
 struct DevBank { double * d = nullptr; int flt_len = 0, fracs = 0; };
 static std::map<std::tuple<int, double, double, double>, DevTaps> g_dev_taps;
 static std::map<std::tuple<int, int, bool>, DevBank> g_dev_banks;
@@ -487,6 +488,67 @@ __global__ __launch_bounds__( 64 * RS_WAVES ) void k_resample_2to1( const float 
 		{
 		const int64_t k = k0 + t + 64 * r;
 		if( k < total_out ) out[k] = float( acc[r] );
+		}
+	}
+
+// The 2x zero-stuffing convolver every interpolating chain starts with (and the 1:2 ratio on its own): y[2n + p] = sum_m h[fl2 + 2n + p - 2m] x[m]
+// is two ordinary FIR filters over x, one per output parity -- g_p[i] = h[fl2 + p - 2 ( u_min + i )] applied to x[n + u_min + i], both laid out
+// over the union of their ranges (the shorter one zero at an end: each is 810 / 811 taps of 1621).  Same scheme as k_resample_2to1: a block
+// stages the input span of its 2048 values of n in LDS as fp64; lane t owns n = n0 + t + 64 r, r < 8, whose two outputs meet input x[n0 + t +
+// u_min + j] at tap j - 64 r: one 8-byte LDS read per j feeds 16 FMAs; taps arrive as SGPR operands; ramp phases with compile-time active sets.
+template<int RLO, int RHI>
+__device__ __forceinline__ void up2_phase( const double * px, const double * __restrict__ g0, const double * __restrict__ g1, int j0, int j1, double ( &a0 )[RS_R], double ( &a1 )[RS_R] )
+	{
+	#pragma unroll 2
+	for( int j = j0; j < j1; ++j )
+		{
+		const double v = px[j];
+		#pragma unroll
+		for( int r = RLO; r <= RHI; ++r )
+			{
+			a0[r] = __builtin_fma( g0[j - 64 * r], v, a0[r] );
+			a1[r] = __builtin_fma( g1[j - 64 * r], v, a1[r] );
+			}
+		}
+	}
+template<int R> __device__ __forceinline__ void up2_ramp_up( const double * px, const double * __restrict__ g0, const double * __restrict__ g1, double ( &a0 )[RS_R], double ( &a1 )[RS_R] )
+	{
+	if constexpr( R < RS_R - 1 ) { up2_phase<0, R>( px, g0, g1, 64 * R, 64 * ( R + 1 ), a0, a1 ); up2_ramp_up<R + 1>( px, g0, g1, a0, a1 ); }
+	}
+template<int S> __device__ __forceinline__ void up2_ramp_down( const double * px, const double * __restrict__ g0, const double * __restrict__ g1, int len, double ( &a0 )[RS_R], double ( &a1 )[RS_R] )
+	{
+	if constexpr( S < RS_R - 1 ) { up2_phase<S + 1, RS_R - 1>( px, g0, g1, len + 64 * S, len + 64 * ( S + 1 ), a0, a1 ); up2_ramp_down<S + 1>( px, g0, g1, len, a0, a1 ); }
+	}
+
+template<typename InT, typename OutT>
+__global__ __launch_bounds__( 64 * RS_WAVES ) void k_resample_up2( const InT * __restrict__ in, int64_t total_in, const double * __restrict__ g0, const double * __restrict__ g1,
+	int len, int u_min, OutT * __restrict__ out, int64_t total_out )
+	{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	double * s_x = reinterpret_cast<double*>( smem );                           // [RS_BLOCK_OUT + len], local index i <-> input n0 + u_min + i
+	const int64_t n0 = int64_t( blockIdx.x ) * RS_BLOCK_OUT;
+	const int span = RS_BLOCK_OUT + len;
+	for( int i = threadIdx.x; i < span; i += 64 * RS_WAVES )
+		{
+		const int64_t a = n0 + u_min + i;
+		s_x[i] = ( a >= 0 && a < total_in ) ? double( in[a] ) : 0.0;
+		}
+	__syncthreads();
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int t = RS_WAVE_OUT * wave + lane;                                    // n = n0 + t + 64 r
+	const double * px = s_x + t;
+	double a0[RS_R], a1[RS_R];
+	#pragma unroll
+	for( int r = 0; r < RS_R; ++r ) { a0[r] = 0.0; a1[r] = 0.0; }
+	up2_ramp_up<0>( px, g0, g1, a0, a1 );                                       // j in [0, 448): the eight n join one by one
+	up2_phase<0, RS_R - 1>( px, g0, g1, 64 * ( RS_R - 1 ), len, a0, a1 );       // all eight in flight (len >= 448: host check)
+	up2_ramp_down<0>( px, g0, g1, len, a0, a1 );                                // j in [len, len + 448): they finish one by one
+	#pragma unroll
+	for( int r = 0; r < RS_R; ++r )
+		{
+		const int64_t k = 2 * ( n0 + t + 64 * r );
+		if( k < total_out ) out[k] = OutT( a0[r] );
+		if( k + 1 < total_out ) out[k + 1] = OutT( a1[r] );
 		}
 	}
 
@@ -638,11 +700,24 @@ static int get_stage_plan( double src, double dst, const std::vector<Stage> ** o
 				{
 				std::vector<double> h; DevTaps t;
 				FLANHIP_REQUIRE( design_lowpass( g.nf, g.tb, g.gain, h, t.fl2 ), FLANHIP_ERR_UNSUPPORTED, "low-pass design outside the restated range" );
-				FLANHIP_CHECK( hipMalloc( &t.d, sizeof( double ) * h.size() ) );
+				// the two output parities of a 2x zero-stuffing convolver as FIR filters over the input (k_resample_up2): phase p meets x[n + u] at tap
+				// fl2 + p - 2 u; both laid out over the union of their ranges of u
+				const int fl2 = t.fl2;
+				t.u_min = -( fl2 / 2 ); t.len = ( fl2 + 1 ) / 2 - t.u_min + 1;             // 0 <= fl2 + p - 2 u <= 2 fl2 for p = 0 or 1
+				std::vector<double> g( 2 * size_t( t.len ), 0.0 );
+				for( int p2 = 0; p2 < 2; ++p2 )
+					for( int i = 0; i < t.len; ++i )
+						{
+						const int tap = fl2 + p2 - 2 * ( t.u_min + i );
+						if( tap >= 0 && tap <= 2 * fl2 ) g[size_t( p2 ) * t.len + i] = h[size_t( tap )];
+						}
+				FLANHIP_CHECK( hipMalloc( &t.d, sizeof( double ) * ( h.size() + g.size() ) ) );
 				FLANHIP_CHECK( hipMemcpy( t.d, h.data(), sizeof( double ) * h.size(), hipMemcpyHostToDevice ) );
+				t.d_g0 = t.d + h.size(); t.d_g1 = t.d_g0 + t.len;
+				FLANHIP_CHECK( hipMemcpy( t.d_g0, g.data(), sizeof( double ) * g.size(), hipMemcpyHostToDevice ) );
 				tt = g_dev_taps.emplace( tkey, t ).first;
 				}
-			g.d_h = tt->second.d; g.fl2 = tt->second.fl2;
+			g.d_h = tt->second.d; g.fl2 = tt->second.fl2; g.d_g0 = tt->second.d_g0; g.d_g1 = tt->second.d_g1; g.up2_len = tt->second.len; g.up2_u_min = tt->second.u_min;
 			}
 		else if( g.kind == Stage::Frac )
 			{
@@ -673,6 +748,18 @@ static size_t rational_lds( int fl2, int up, int down, int & span )
 template<typename InT, typename OutT>
 static int launch_rational( const InT * d_in, int64_t n_in, const Stage & g, OutT * d_out, int64_t n_out, hipStream_t s )
 	{
+	if( g.up == 2 && g.down == 1 && g.d_g0 && g.up2_len >= 64 * ( RS_R - 1 ) )
+		{
+		const size_t lds2 = sizeof( double ) * size_t( RS_BLOCK_OUT + g.up2_len );
+		if( lds2 <= 160 * 1024 )
+			{
+			FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( k_resample_up2<InT, OutT> ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds2 ) ) );
+			const int64_t n_count = ( n_out + 1 ) / 2;
+			hipLaunchKernelGGL( ( k_resample_up2<InT, OutT> ), dim3( (unsigned) ( ( n_count + RS_BLOCK_OUT - 1 ) / RS_BLOCK_OUT ) ), dim3( 64 * RS_WAVES ), lds2, s,
+				d_in, n_in, g.d_g0, g.d_g1, g.up2_len, g.up2_u_min, d_out, n_out );
+			return FLANHIP_OK;
+			}
+		}
 	int span = 0;
 	const size_t lds = rational_lds( g.fl2, g.up, g.down, span );
 	FLANHIP_REQUIRE( lds <= 160 * 1024, FLANHIP_ERR_UNSUPPORTED, "filter too long for the LDS staging" );
@@ -789,7 +876,7 @@ int flanhip_resample_dev( const float * d_in, int64_t ch, int64_t n, float src_r
 	{
 	FLANHIP_REQUIRE( d_in && d_out && ch > 0 && n > 0 && src_rate > 0.0f && dst_rate > 0.0f, FLANHIP_ERR_INVALID_ARG, "bad arguments" );
 	int up = 0, down = 0;
-	const bool single = rational_ratio( double( src_rate ), double( dst_rate ), up, down );
+	const bool single = rational_ratio( double( src_rate ), double( dst_rate ), up, down ) && !( up == 2 && down == 1 );   // (1:2 goes through the stage list: its convolver is k_resample_up2)
 	std::vector<Stage> probe;
 	FLANHIP_REQUIRE( single || build_stages( double( src_rate ), double( dst_rate ), probe ), FLANHIP_ERR_UNSUPPORTED, k_unsupported_ratio );
 	if( int rc = require_device() ) return rc;
