@@ -5,8 +5,9 @@
 // a single stream.  CDSPResampler's constructor (:119-378) turns the two rates into a chain of stages; build_stages() below restates it:
 //   * block convolver (CDSPBlockConvolver.h, filter from CDSPFIRFilter::buildLPFilter :227-493): convolution is convolution -- here the direct
 //     fp64 sum  out[k] = sum_m h[fl2 + down k - up m] x[m]  over the zero-stuffed input, latency consumed, taps of r8brain's Kaiser-power
-//     windowed sinc design computed on the host.  BASELINE config 5's 96 -> 48 kHz is one such stage: the tuned k_resample_2to1 (1621 taps);
-//     every other (up, down) and every non-final stage: k_resample_rational;
+//     windowed sinc design computed on the host.  Tuned kernels: k_resample_down<2 | 3> (BASELINE config 5's 96 -> 48 kHz is one such stage,
+//     1621 taps), k_resample_up<1 | 2 | 3> (the 2x zero-stuffing convolver every interpolating chain starts with; the 1:1 low-pass in front of a
+//     decimating interpolator); 2:3, 3:2, 3:4 and filters shorter than the kernels' ramps: k_resample_rational;
 //   * half-band up / downsamplers (CDSPHBUpsampler.h, CDSPHBDownsampler.h): k_hb_up, k_hb_down with the kernels r8brain picks at 206.91 dB;
 //   * fractional interpolator (CDSPFracInterpolator.h): whole stepping (44.1 <-> 48 kHz: a bank of OutStep fractional-delay filters, exact
 //     integer positions: k_frac_whole) or, for rates without a small common divisor, the spline-interpolated bank with its per-call
@@ -110,18 +111,6 @@ static bool design_lowpass( double req_norm_freq, double tb_percent, double gain
 	for( double & v : h ) v *= gain / s;
 	return true;
 	}
-static bool design_default_lowpass( double req_norm_freq, double gain, std::vector<double> & h, int & fl2 ) { return design_lowpass( req_norm_freq, 2.0, gain, h, fl2 ); }
-
-// Which single-step ratio is this?  CDSPResampler.h:139-161 (first match wins), then :165-207 with no half-band stage.
-static bool rational_ratio( double src, double dst, int & up, int & down )
-	{
-	static const int common[5][2] = { { 1, 2 }, { 1, 3 }, { 2, 3 }, { 3, 2 }, { 3, 4 } };
-	for( const auto & c : common )
-		if( src * c[0] == dst * c[1] ) { up = c[0]; down = c[1]; return true; }
-	if( src * 2 == dst ) { up = 2; down = 1; return true; }
-	if( src * 3 == dst ) { up = 3; down = 1; return true; }
-	return false;
-	}
 
 // ---- two-stage ratios: block convolver + whole-stepping fractional interpolator ---------------------------------------------------
 // CDSPFracInterpolator.h:539-558 (subtractive, at most 50 rounds) and :573-602
@@ -185,7 +174,7 @@ struct Stage
 	int up = 1, down = 1; double nf = 0.5, tb = 2.0, gain = 1.0;                  // block convolver (tb in percent)
 	bool third = false, whole = true; int in_step = 0, out_step = 0; double isrc = 0.0, idst = 0.0;   // interpolator (whole stepping, or the spline bank)
 	const double * d_h = nullptr; int fl2 = 0;                                    // device tables, filled by get_stage_plan
-	const double * d_g0 = nullptr; const double * d_g1 = nullptr; int up2_len = 0, up2_u_min = 0;   // the convolver's two phases when up == 2
+	const double * d_poly = nullptr; int poly_len = 0, poly_u_min = 0;             // the taps as the tuned kernels walk them: `up` phases (down == 1), or `down` interleaves (up == 1)
 	const double * d_bank = nullptr; int flt_len = 0, fracs = 0;
 	};
 
@@ -371,42 +360,13 @@ static void spline_segments( const std::vector<Stage> & st, int k, int64_t chunk
 
 // device copies, cached for the process: low-pass taps per (device, cut-off, transition band, gain); interpolator banks per (device, rows or -1 for
 // the spline bank, third-band); the stage list with its pointers per (device, src, dst)
-struct DevTaps { double * d = nullptr; int fl2 = 0; double * d_g0 = nullptr; double * d_g1 = nullptr; int len = 0, u_min = 0; };   // g0 / g1: the two phases for k_resample_up2
+struct DevTaps { double * d = nullptr; int fl2 = 0; double * d_poly = nullptr; int len = 0, u_min = 0; };   // d: h[2 fl2 + 1]; poly: see Stage
 struct DevBank { double * d = nullptr; int flt_len = 0, fracs = 0; };
-static std::map<std::tuple<int, double, double, double>, DevTaps> g_dev_taps;
+static std::map<std::tuple<int, double, double, double, int, int>, DevTaps> g_dev_taps;
 static std::map<std::tuple<int, int, bool>, DevBank> g_dev_banks;
 static std::map<std::tuple<int, double, double>, std::vector<Stage>> g_stage_plans;
 
-// Device copies of the taps for one (up, down): h[0 .. 2 fl2] in natural order, and for the 2:1 kernel
-// d_he[q] = h[2 fl2 - 2 q] (q = 0 .. fl2), d_ho[q] = h[2 fl2 - 1 - 2 q] (q = 0 .. fl2 - 1): the taps in the order it walks them
-struct ResamplePlan { double * d_h = nullptr; double * d_he = nullptr; double * d_ho = nullptr; int fl2 = 0; };
 static std::mutex g_rs_mutex;
-static std::map<std::tuple<int, int, int>, ResamplePlan> g_rs_plans;   // per (device, up, down)
-
-static int get_resample_plan( int up, int down, const ResamplePlan ** out )
-	{
-	int device = 0;
-	FLANHIP_CHECK( hipGetDevice( &device ) );
-	std::lock_guard<std::mutex> lock( g_rs_mutex );
-	const auto key = std::make_tuple( device, up, down );
-	auto it = g_rs_plans.find( key );
-	if( it != g_rs_plans.end() ) { *out = &it->second; return FLANHIP_OK; }
-	std::vector<double> h; int fl2 = 0;
-	FLANHIP_REQUIRE( design_default_lowpass( 1.0 / std::max( up, down ), double( up ), h, fl2 ), FLANHIP_ERR_UNSUPPORTED, "low-pass design outside the restated range" );
-	std::vector<double> he( fl2 + 1 ), ho( fl2 + 1, 0.0 );
-	for( int q = 0; q <= fl2; ++q ) he[q] = h[2 * fl2 - 2 * q];
-	for( int q = 0; q < fl2; ++q ) ho[q] = h[2 * fl2 - 1 - 2 * q];
-	ResamplePlan p; p.fl2 = fl2;
-	const size_t nh = h.size();
-	FLANHIP_CHECK( hipMalloc( &p.d_h, sizeof( double ) * ( nh + 2 * ( fl2 + 1 ) ) ) );
-	p.d_he = p.d_h + nh;
-	p.d_ho = p.d_he + ( fl2 + 1 );
-	FLANHIP_CHECK( hipMemcpy( p.d_h, h.data(), sizeof( double ) * nh, hipMemcpyHostToDevice ) );
-	FLANHIP_CHECK( hipMemcpy( p.d_he, he.data(), sizeof( double ) * ( fl2 + 1 ), hipMemcpyHostToDevice ) );
-	FLANHIP_CHECK( hipMemcpy( p.d_ho, ho.data(), sizeof( double ) * ( fl2 + 1 ), hipMemcpyHostToDevice ) );
-	*out = &g_rs_plans.emplace( key, p ).first->second;
-	return FLANHIP_OK;
-	}
 
 // out[k] = float( sum_m h[2 fl2 - m] x[2k - fl2 + m], m = 0 .. 2 fl2 ), one fp64 accumulator per output, m ascending (the checker's
 // operation order).  1621 fp64 FMAs per output: the job of this kernel is to keep the fp64 pipes fed.
@@ -418,56 +378,65 @@ static int get_resample_plan( int up, int down, const ResamplePlan ** out )
 //   * Outputs enter and leave the j loop 64 steps apart: the loop is cut into phases with a compile-time set of active outputs, so
 //     only real taps are ever multiplied (no zero padding: 0 * Inf must not leak into neighbours).
 constexpr int RS_R = 8, RS_WAVES = 4, RS_WAVE_OUT = 64 * RS_R, RS_BLOCK_OUT = RS_WAVES * RS_WAVE_OUT;
-struct rs_pair { double e, o; };
+template<int D> struct rs_group { double v[D]; };
 
-template<int RLO, int RHI>
-__device__ __forceinline__ void rs_phase( const rs_pair * px, const double * __restrict__ he, const double * __restrict__ ho, int j0, int j1, double ( &acc )[RS_R] )
+// D: the decimation (2: the kernel described above; 3: 48 -> 16 kHz ...).  hd[d * ( Q + 1 ) + q] = h[2 fl2 - ( D q + d )], Q = 2 fl2 / D: the taps the
+// D samples of group j meet; the last group is cut after d_last = 2 fl2 % D.
+template<int D, int RLO, int RHI>
+__device__ __forceinline__ void rs_phase( const rs_group<D> * px, const double * const ( &hd )[D], int j0, int j1, double ( &acc )[RS_R] )
 	{
 	#pragma unroll 2
 	for( int j = j0; j < j1; ++j )
 		{
-		const rs_pair v = px[j];
+		const rs_group<D> v = px[j];
 		#pragma unroll
 		for( int r = RLO; r <= RHI; ++r )
 			{
-			acc[r] = __builtin_fma( he[j - 64 * r], v.e, acc[r] );
-			acc[r] = __builtin_fma( ho[j - 64 * r], v.o, acc[r] );
+			#pragma unroll
+			for( int d = 0; d < D; ++d ) acc[r] = __builtin_fma( hd[d][j - 64 * r], v.v[d], acc[r] );
 			}
 		}
 	}
 
-// j = fl2 + 64 S: the last tap (even m = 2 fl2) of output S, a full pair of taps for the outputs after it; then the 63 steps that follow
-template<int S>
-__device__ __forceinline__ void rs_ramp_down( const rs_pair * px, const double * __restrict__ he, const double * __restrict__ ho, int fl2, double ( &acc )[RS_R] )
+// j = Q + 64 S: the last taps (d <= d_last) of output S, a full group of taps for the outputs after it; then the 63 steps that follow
+template<int D, int S>
+__device__ __forceinline__ void rs_ramp_down( const rs_group<D> * px, const double * const ( &hd )[D], int q1, int d_last, double ( &acc )[RS_R] )
 	{
-	const int j = fl2 + 64 * S;
-	acc[S] = __builtin_fma( he[fl2], px[j].e, acc[S] );
+	const int j = q1 - 1 + 64 * S;
+	const rs_group<D> v = px[j];
+	#pragma unroll
+	for( int d = 0; d < D; ++d ) if( d <= d_last ) acc[S] = __builtin_fma( hd[d][q1 - 1], v.v[d], acc[S] );
 	if constexpr( S + 1 < RS_R )
 		{
-		rs_phase<S + 1, RS_R - 1>( px, he, ho, j, j + 1, acc );
-		rs_phase<S + 1, RS_R - 1>( px, he, ho, j + 1, j + 64, acc );
-		rs_ramp_down<S + 1>( px, he, ho, fl2, acc );
+		if constexpr( D == 2 )
+			{
+			rs_phase<D, S + 1, RS_R - 1>( px, hd, j, j + 1, acc );             // (peeling the first step: the compiler's code for the rest is 6 % faster for D = 2,
+			rs_phase<D, S + 1, RS_R - 1>( px, hd, j + 1, j + 64, acc );        //  25 % slower for D = 3 -- measured both ways)
+			}
+		else rs_phase<D, S + 1, RS_R - 1>( px, hd, j, j + 64, acc );
+		rs_ramp_down<D, S + 1>( px, hd, q1, d_last, acc );
 		}
 	}
 
-template<int R>
-__device__ __forceinline__ void rs_ramp_up( const rs_pair * px, const double * __restrict__ he, const double * __restrict__ ho, double ( &acc )[RS_R] )
+template<int D, int R>
+__device__ __forceinline__ void rs_ramp_up( const rs_group<D> * px, const double * const ( &hd )[D], double ( &acc )[RS_R] )
 	{
 	if constexpr( R < RS_R - 1 )
 		{
-		rs_phase<0, R>( px, he, ho, 64 * R, 64 * ( R + 1 ), acc );
-		rs_ramp_up<R + 1>( px, he, ho, acc );
+		rs_phase<D, 0, R>( px, hd, 64 * R, 64 * ( R + 1 ), acc );
+		rs_ramp_up<D, R + 1>( px, hd, acc );
 		}
 	}
 
-__global__ __launch_bounds__( 64 * RS_WAVES ) void k_resample_2to1( const float * __restrict__ in, int64_t total_in, const double * __restrict__ he,
-	const double * __restrict__ ho, int fl2, float * __restrict__ out, int64_t total_out )
+template<int D, typename InT, typename OutT>
+__global__ __launch_bounds__( 64 * RS_WAVES ) void k_resample_down( const InT * __restrict__ in, int64_t total_in, const double * __restrict__ taps, int fl2,
+	OutT * __restrict__ out, int64_t total_out )
 	{
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	double * s_x = reinterpret_cast<double*>( smem );                       // [2 * RS_BLOCK_OUT + 2 * fl2 + 2], local index i <-> input x0 + i
+	double * s_x = reinterpret_cast<double*>( smem );                       // [D * RS_BLOCK_OUT + 2 * fl2 + D], local index i <-> input x0 + i
 	const int64_t k0 = int64_t( blockIdx.x ) * RS_BLOCK_OUT;
-	const int64_t x0 = 2 * k0 - fl2;                                        // first input sample the block touches
-	const int span = 2 * RS_BLOCK_OUT + 2 * fl2 + 2;
+	const int64_t x0 = D * k0 - fl2;                                        // first input sample the block touches
+	const int span = D * RS_BLOCK_OUT + 2 * fl2 + D;
 	for( int i = threadIdx.x; i < span; i += 64 * RS_WAVES )
 		{
 		const int64_t a = x0 + i;
@@ -476,28 +445,33 @@ __global__ __launch_bounds__( 64 * RS_WAVES ) void k_resample_2to1( const float 
 	__syncthreads();
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int t = RS_WAVE_OUT * wave + lane;                                // outputs k0 + t + 64 r, r < RS_R
-	const rs_pair * px = reinterpret_cast<const rs_pair*>( s_x ) + t;
+	const rs_group<D> * px = reinterpret_cast<const rs_group<D>*>( s_x ) + t;
+	const int q1 = 2 * fl2 / D + 1, d_last = 2 * fl2 % D;
+	const double * hd[D];
+	#pragma unroll
+	for( int d = 0; d < D; ++d ) hd[d] = taps + d * q1;
 	double acc[RS_R];
 	#pragma unroll
 	for( int r = 0; r < RS_R; ++r ) acc[r] = 0.0;
-	rs_ramp_up<0>( px, he, ho, acc );                                       // j in [0, 448): outputs join one by one
-	rs_phase<0, RS_R - 1>( px, he, ho, 64 * ( RS_R - 1 ), fl2, acc );       // all eight in flight
-	rs_ramp_down<0>( px, he, ho, fl2, acc );                                // j in [fl2, fl2 + 448]: outputs finish one by one
+	rs_ramp_up<D, 0>( px, hd, acc );                                        // j in [0, 448): outputs join one by one
+	rs_phase<D, 0, RS_R - 1>( px, hd, 64 * ( RS_R - 1 ), q1 - 1, acc );     // all eight in flight (q1 - 1 >= 448: host check)
+	rs_ramp_down<D, 0>( px, hd, q1, d_last, acc );                          // j in [Q, Q + 448]: outputs finish one by one
 	#pragma unroll
 	for( int r = 0; r < RS_R; ++r )
 		{
 		const int64_t k = k0 + t + 64 * r;
-		if( k < total_out ) out[k] = float( acc[r] );
+		if( k < total_out ) out[k] = OutT( acc[r] );
 		}
 	}
 
-// The 2x zero-stuffing convolver every interpolating chain starts with (and the 1:2 ratio on its own): y[2n + p] = sum_m h[fl2 + 2n + p - 2m] x[m]
-// is two ordinary FIR filters over x, one per output parity -- g_p[i] = h[fl2 + p - 2 ( u_min + i )] applied to x[n + u_min + i], both laid out
-// over the union of their ranges (the shorter one zero at an end: each is 810 / 811 taps of 1621).  Same scheme as k_resample_2to1: a block
-// stages the input span of its 2048 values of n in LDS as fp64; lane t owns n = n0 + t + 64 r, r < 8, whose two outputs meet input x[n0 + t +
-// u_min + j] at tap j - 64 r: one 8-byte LDS read per j feeds 16 FMAs; taps arrive as SGPR operands; ramp phases with compile-time active sets.
-template<int RLO, int RHI>
-__device__ __forceinline__ void up2_phase( const double * px, const double * __restrict__ g0, const double * __restrict__ g1, int j0, int j1, double ( &a0 )[RS_R], double ( &a1 )[RS_R] )
+// The zero-stuffing convolver every interpolating chain starts with (2x; 3x for 16 -> 48 kHz ...), and the plain FIR of a 1:1 convolver stage (the
+// low-pass in front of a decimating interpolator, 96 -> 44.1 kHz ...): y[PH n + p] = sum_m h[fl2 + PH n + p - PH m] x[m] is PH ordinary FIR filters
+// over x, one per output phase -- g_p[i] = h[fl2 + p - PH ( u_min + i )] applied to x[n + u_min + i], all laid out over the union of their ranges
+// (zero where a phase has no tap: for 2x each is 810 / 811 taps of 1621).  Same scheme as k_resample_down: a block stages the input span of its
+// 2048 values of n in LDS as fp64; lane t owns n = n0 + t + 64 r, r < 8, whose PH outputs meet input x[n0 + t + u_min + j] at tap j - 64 r: one
+// 8-byte LDS read per j feeds 8 PH FMAs; taps arrive as SGPR operands; ramp phases with compile-time active sets.
+template<int PH, int RLO, int RHI>
+__device__ __forceinline__ void up_phase( const double * px, const double * const ( &g )[PH], int j0, int j1, double ( &a )[PH][RS_R] )
 	{
 	#pragma unroll 2
 	for( int j = j0; j < j1; ++j )
@@ -506,22 +480,22 @@ __device__ __forceinline__ void up2_phase( const double * px, const double * __r
 		#pragma unroll
 		for( int r = RLO; r <= RHI; ++r )
 			{
-			a0[r] = __builtin_fma( g0[j - 64 * r], v, a0[r] );
-			a1[r] = __builtin_fma( g1[j - 64 * r], v, a1[r] );
+			#pragma unroll
+			for( int p = 0; p < PH; ++p ) a[p][r] = __builtin_fma( g[p][j - 64 * r], v, a[p][r] );
 			}
 		}
 	}
-template<int R> __device__ __forceinline__ void up2_ramp_up( const double * px, const double * __restrict__ g0, const double * __restrict__ g1, double ( &a0 )[RS_R], double ( &a1 )[RS_R] )
+template<int PH, int R> __device__ __forceinline__ void up_ramp_up( const double * px, const double * const ( &g )[PH], double ( &a )[PH][RS_R] )
 	{
-	if constexpr( R < RS_R - 1 ) { up2_phase<0, R>( px, g0, g1, 64 * R, 64 * ( R + 1 ), a0, a1 ); up2_ramp_up<R + 1>( px, g0, g1, a0, a1 ); }
+	if constexpr( R < RS_R - 1 ) { up_phase<PH, 0, R>( px, g, 64 * R, 64 * ( R + 1 ), a ); up_ramp_up<PH, R + 1>( px, g, a ); }
 	}
-template<int S> __device__ __forceinline__ void up2_ramp_down( const double * px, const double * __restrict__ g0, const double * __restrict__ g1, int len, double ( &a0 )[RS_R], double ( &a1 )[RS_R] )
+template<int PH, int S> __device__ __forceinline__ void up_ramp_down( const double * px, const double * const ( &g )[PH], int len, double ( &a )[PH][RS_R] )
 	{
-	if constexpr( S < RS_R - 1 ) { up2_phase<S + 1, RS_R - 1>( px, g0, g1, len + 64 * S, len + 64 * ( S + 1 ), a0, a1 ); up2_ramp_down<S + 1>( px, g0, g1, len, a0, a1 ); }
+	if constexpr( S < RS_R - 1 ) { up_phase<PH, S + 1, RS_R - 1>( px, g, len + 64 * S, len + 64 * ( S + 1 ), a ); up_ramp_down<PH, S + 1>( px, g, len, a ); }
 	}
 
-template<typename InT, typename OutT>
-__global__ __launch_bounds__( 64 * RS_WAVES ) void k_resample_up2( const InT * __restrict__ in, int64_t total_in, const double * __restrict__ g0, const double * __restrict__ g1,
+template<int PH, typename InT, typename OutT>
+__global__ __launch_bounds__( 64 * RS_WAVES ) void k_resample_up( const InT * __restrict__ in, int64_t total_in, const double * __restrict__ taps,
 	int len, int u_min, OutT * __restrict__ out, int64_t total_out )
 	{
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -537,18 +511,24 @@ __global__ __launch_bounds__( 64 * RS_WAVES ) void k_resample_up2( const InT * _
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int t = RS_WAVE_OUT * wave + lane;                                    // n = n0 + t + 64 r
 	const double * px = s_x + t;
-	double a0[RS_R], a1[RS_R];
+	const double * g[PH];
+	double a[PH][RS_R];
 	#pragma unroll
-	for( int r = 0; r < RS_R; ++r ) { a0[r] = 0.0; a1[r] = 0.0; }
-	up2_ramp_up<0>( px, g0, g1, a0, a1 );                                       // j in [0, 448): the eight n join one by one
-	up2_phase<0, RS_R - 1>( px, g0, g1, 64 * ( RS_R - 1 ), len, a0, a1 );       // all eight in flight (len >= 448: host check)
-	up2_ramp_down<0>( px, g0, g1, len, a0, a1 );                                // j in [len, len + 448): they finish one by one
+	for( int p = 0; p < PH; ++p )
+		{
+		g[p] = taps + p * len;
+		#pragma unroll
+		for( int r = 0; r < RS_R; ++r ) a[p][r] = 0.0;
+		}
+	up_ramp_up<PH, 0>( px, g, a );                                              // j in [0, 448): the eight n join one by one
+	up_phase<PH, 0, RS_R - 1>( px, g, 64 * ( RS_R - 1 ), len, a );              // all eight in flight (len >= 448: host check)
+	up_ramp_down<PH, 0>( px, g, len, a );                                       // j in [len, len + 448): they finish one by one
 	#pragma unroll
 	for( int r = 0; r < RS_R; ++r )
 		{
-		const int64_t k = 2 * ( n0 + t + 64 * r );
-		if( k < total_out ) out[k] = OutT( a0[r] );
-		if( k + 1 < total_out ) out[k + 1] = OutT( a1[r] );
+		const int64_t k = PH * ( n0 + t + 64 * r );
+		#pragma unroll
+		for( int p = 0; p < PH; ++p ) if( k + p < total_out ) out[k + p] = OutT( a[p][r] );
 		}
 	}
 
@@ -694,30 +674,45 @@ static int get_stage_plan( double src, double dst, const std::vector<Stage> ** o
 		{
 		if( g.kind == Stage::Conv )
 			{
-			const auto tkey = std::make_tuple( device, g.nf, g.tb, g.gain );
+			const auto tkey = std::make_tuple( device, g.nf, g.tb, g.gain, g.up, g.down );
 			auto tt = g_dev_taps.find( tkey );
 			if( tt == g_dev_taps.end() )
 				{
-				std::vector<double> h; DevTaps t;
+				std::vector<double> h, poly; DevTaps t;
 				FLANHIP_REQUIRE( design_lowpass( g.nf, g.tb, g.gain, h, t.fl2 ), FLANHIP_ERR_UNSUPPORTED, "low-pass design outside the restated range" );
-				// the two output parities of a 2x zero-stuffing convolver as FIR filters over the input (k_resample_up2): phase p meets x[n + u] at tap
-				// fl2 + p - 2 u; both laid out over the union of their ranges of u
 				const int fl2 = t.fl2;
-				t.u_min = -( fl2 / 2 ); t.len = ( fl2 + 1 ) / 2 - t.u_min + 1;             // 0 <= fl2 + p - 2 u <= 2 fl2 for p = 0 or 1
-				std::vector<double> g( 2 * size_t( t.len ), 0.0 );
-				for( int p2 = 0; p2 < 2; ++p2 )
-					for( int i = 0; i < t.len; ++i )
-						{
-						const int tap = fl2 + p2 - 2 * ( t.u_min + i );
-						if( tap >= 0 && tap <= 2 * fl2 ) g[size_t( p2 ) * t.len + i] = h[size_t( tap )];
-						}
-				FLANHIP_CHECK( hipMalloc( &t.d, sizeof( double ) * ( h.size() + g.size() ) ) );
-				FLANHIP_CHECK( hipMemcpy( t.d, h.data(), sizeof( double ) * h.size(), hipMemcpyHostToDevice ) );
-				t.d_g0 = t.d + h.size(); t.d_g1 = t.d_g0 + t.len;
-				FLANHIP_CHECK( hipMemcpy( t.d_g0, g.data(), sizeof( double ) * g.size(), hipMemcpyHostToDevice ) );
+				if( g.down == 1 && g.up <= 3 )
+					{
+					// the `up` output phases of a zero-stuffing convolver as FIR filters over the input (k_resample_up; up == 1: the filter itself, reversed):
+					// phase p meets x[n + u] at tap fl2 + p - up u, 0 <= tap <= 2 fl2; all laid out over the union of their ranges of u
+					t.u_min = -( fl2 / g.up ); t.len = ( fl2 + g.up - 1 ) / g.up - t.u_min + 1;
+					poly.assign( size_t( g.up ) * t.len, 0.0 );
+					for( int p2 = 0; p2 < g.up; ++p2 )
+						for( int i = 0; i < t.len; ++i )
+							{
+							const int tap = fl2 + p2 - g.up * ( t.u_min + i );
+							if( tap >= 0 && tap <= 2 * fl2 ) poly[size_t( p2 ) * t.len + i] = h[size_t( tap )];
+							}
+					}
+				else if( g.up == 1 && g.down <= 3 )
+					{
+					// k_resample_down: interleave d of the reversed filter, poly[d * len + q] = h[2 fl2 - ( down q + d )]
+					t.len = 2 * fl2 / g.down + 1;
+					poly.assign( size_t( g.down ) * t.len, 0.0 );
+					for( int m = 0; m <= 2 * fl2; ++m ) poly[size_t( m % g.down ) * t.len + m / g.down] = h[size_t( 2 * fl2 - m )];
+					}
+				const size_t nh = h.size();
+				FLANHIP_CHECK( hipMalloc( &t.d, sizeof( double ) * ( nh + poly.size() ) ) );
+				FLANHIP_CHECK( hipMemcpy( t.d, h.data(), sizeof( double ) * nh, hipMemcpyHostToDevice ) );
+				if( !poly.empty() )
+					{
+					t.d_poly = t.d + nh;
+					FLANHIP_CHECK( hipMemcpy( t.d_poly, poly.data(), sizeof( double ) * poly.size(), hipMemcpyHostToDevice ) );
+					}
 				tt = g_dev_taps.emplace( tkey, t ).first;
 				}
-			g.d_h = tt->second.d; g.fl2 = tt->second.fl2; g.d_g0 = tt->second.d_g0; g.d_g1 = tt->second.d_g1; g.up2_len = tt->second.len; g.up2_u_min = tt->second.u_min;
+			const DevTaps & dt = tt->second;
+			g.d_h = dt.d; g.fl2 = dt.fl2; g.d_poly = dt.d_poly; g.poly_len = dt.len; g.poly_u_min = dt.u_min;
 			}
 		else if( g.kind == Stage::Frac )
 			{
@@ -748,16 +743,41 @@ static size_t rational_lds( int fl2, int up, int down, int & span )
 template<typename InT, typename OutT>
 static int launch_rational( const InT * d_in, int64_t n_in, const Stage & g, OutT * d_out, int64_t n_out, hipStream_t s )
 	{
-	if( g.up == 2 && g.down == 1 && g.d_g0 && g.up2_len >= 64 * ( RS_R - 1 ) )
+	// the tuned kernels (ramp phases of 64 steps per owned output: the filter must span them all)
+	if( g.d_poly && g.poly_len - 1 >= 64 * ( RS_R - 1 ) )
 		{
-		const size_t lds2 = sizeof( double ) * size_t( RS_BLOCK_OUT + g.up2_len );
-		if( lds2 <= 160 * 1024 )
+		const dim3 block( 64 * RS_WAVES );
+		auto blocks = [&]( int64_t n ) { return dim3( (unsigned) ( ( n + RS_BLOCK_OUT - 1 ) / RS_BLOCK_OUT ) ); };
+		if( g.down == 1 )
 			{
-			FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( k_resample_up2<InT, OutT> ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds2 ) ) );
-			const int64_t n_count = ( n_out + 1 ) / 2;
-			hipLaunchKernelGGL( ( k_resample_up2<InT, OutT> ), dim3( (unsigned) ( ( n_count + RS_BLOCK_OUT - 1 ) / RS_BLOCK_OUT ) ), dim3( 64 * RS_WAVES ), lds2, s,
-				d_in, n_in, g.d_g0, g.d_g1, g.up2_len, g.up2_u_min, d_out, n_out );
-			return FLANHIP_OK;
+			const size_t lds_up = sizeof( double ) * size_t( RS_BLOCK_OUT + g.poly_len );
+			auto go = [&]( auto kernel )
+				{
+				FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kernel ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds_up ) ) );
+				hipLaunchKernelGGL( kernel, blocks( ( n_out + g.up - 1 ) / g.up ), block, lds_up, s, d_in, n_in, g.d_poly, g.poly_len, g.poly_u_min, d_out, n_out );
+				return FLANHIP_OK;
+				};
+			if( lds_up <= 160 * 1024 )
+				{
+				if( g.up == 1 ) return go( k_resample_up<1, InT, OutT> );
+				if( g.up == 2 ) return go( k_resample_up<2, InT, OutT> );
+				if( g.up == 3 ) return go( k_resample_up<3, InT, OutT> );
+				}
+			}
+		else if( g.up == 1 )
+			{
+			const size_t lds_down = sizeof( double ) * size_t( g.down * RS_BLOCK_OUT + 2 * g.fl2 + g.down );
+			auto go = [&]( auto kernel )
+				{
+				FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kernel ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds_down ) ) );
+				hipLaunchKernelGGL( kernel, blocks( n_out ), block, lds_down, s, d_in, n_in, g.d_poly, g.fl2, d_out, n_out );
+				return FLANHIP_OK;
+				};
+			if( lds_down <= 160 * 1024 )
+				{
+				if( g.down == 2 ) return go( k_resample_down<2, InT, OutT> );
+				if( g.down == 3 ) return go( k_resample_down<3, InT, OutT> );
+				}
 			}
 		}
 	int span = 0;
@@ -875,43 +895,20 @@ int64_t flanhip_resample_out_frames( int64_t num_frames, float src_rate, float d
 int flanhip_resample_dev( const float * d_in, int64_t ch, int64_t n, float src_rate, float dst_rate, float * d_out, void * stream )
 	{
 	FLANHIP_REQUIRE( d_in && d_out && ch > 0 && n > 0 && src_rate > 0.0f && dst_rate > 0.0f, FLANHIP_ERR_INVALID_ARG, "bad arguments" );
-	int up = 0, down = 0;
-	const bool single = rational_ratio( double( src_rate ), double( dst_rate ), up, down ) && !( up == 2 && down == 1 );   // (1:2 goes through the stage list: its convolver is k_resample_up2)
 	std::vector<Stage> probe;
-	FLANHIP_REQUIRE( single || build_stages( double( src_rate ), double( dst_rate ), probe ), FLANHIP_ERR_UNSUPPORTED, k_unsupported_ratio );
+	FLANHIP_REQUIRE( build_stages( double( src_rate ), double( dst_rate ), probe ), FLANHIP_ERR_UNSUPPORTED, k_unsupported_ratio );
 	if( int rc = require_device() ) return rc;
 	const int64_t n_out = flanhip_resample_out_frames( n, src_rate, dst_rate );
 	const int64_t total_in = ch * n, total_out = ch * n_out;
 	if( total_out <= 0 ) return FLANHIP_OK;
-	if( !single ) return resample_stages_dev( d_in, total_in, n, double( src_rate ), double( dst_rate ), d_out, total_out, (hipStream_t) stream );
-	const ResamplePlan * plan = nullptr;
-	if( int rc = get_resample_plan( up, down, &plan ) ) return rc;
-	if( up == 1 && down == 2 && plan->fl2 >= 64 * ( RS_R - 1 ) )
-		{
-		const size_t lds = sizeof( double ) * size_t( 2 * RS_BLOCK_OUT + 2 * plan->fl2 + 2 );
-		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( k_resample_2to1 ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
-		hipLaunchKernelGGL( k_resample_2to1, dim3( (unsigned) ( ( total_out + RS_BLOCK_OUT - 1 ) / RS_BLOCK_OUT ) ), dim3( 64 * RS_WAVES ), lds, (hipStream_t) stream,
-			d_in, total_in, plan->d_he, plan->d_ho, plan->fl2, d_out, total_out );
-		}
-	else
-		{
-		int span = 0;
-		const size_t lds = rational_lds( plan->fl2, up, down, span );
-		FLANHIP_REQUIRE( lds <= 160 * 1024, FLANHIP_ERR_UNSUPPORTED, "filter too long for the LDS staging" );
-		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( k_resample_rational<float, float> ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
-		hipLaunchKernelGGL( ( k_resample_rational<float, float> ), dim3( (unsigned) ( ( total_out + RSG_BLOCK - 1 ) / RSG_BLOCK ) ), dim3( RSG_BLOCK ), lds, (hipStream_t) stream,
-			d_in, total_in, plan->d_h, plan->fl2, up, down, span, d_out, total_out );
-		}
-	FLANHIP_CHECK( hipGetLastError() );
-	return FLANHIP_OK;
+	return resample_stages_dev( d_in, total_in, n, double( src_rate ), double( dst_rate ), d_out, total_out, (hipStream_t) stream );
 	}
 
 int flanhip_resample( const float * in, int64_t ch, int64_t n, float src_rate, float dst_rate, float * out, volatile int * cancel )
 	{
 	FLANHIP_REQUIRE( in && out && ch > 0 && n > 0 && src_rate > 0.0f && dst_rate > 0.0f, FLANHIP_ERR_INVALID_ARG, "bad arguments" );
-	{ int up = 0, down = 0; std::vector<Stage> probe;
-	  FLANHIP_REQUIRE( rational_ratio( double( src_rate ), double( dst_rate ), up, down ) || build_stages( double( src_rate ), double( dst_rate ), probe ),
-		FLANHIP_ERR_UNSUPPORTED, k_unsupported_ratio ); }
+	{ std::vector<Stage> probe;
+	  FLANHIP_REQUIRE( build_stages( double( src_rate ), double( dst_rate ), probe ), FLANHIP_ERR_UNSUPPORTED, k_unsupported_ratio ); }
 	if( int rc = require_device() ) return rc;
 	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
 	const int64_t n_out = flanhip_resample_out_frames( n, src_rate, dst_rate );

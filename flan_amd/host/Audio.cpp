@@ -116,7 +116,7 @@ Audio Audio::resample( FrameRate new_sample_rate ) const
 	const float * d_in = device_data();
 	auto block = detail::DeviceBlock::allocate( sizeof( float ) * size_t( f.num_channels ) * f.num_frames );
 	if( !d_in || !block ) return Audio::create_null();
-	// r8brain CDSPResampler with default parameters, one stream over the whole buffer (:25-27); its single-step ratios only on this path
+	// r8brain CDSPResampler with default parameters, one stream over the whole buffer (:25-27), whatever chain of stages it builds for the two rates
 	if( !detail::report( flanhip_resample_dev( d_in, get_num_channels(), get_num_frames(), get_sample_rate(), new_sample_rate,
 			static_cast<float*>( block->ptr ), nullptr ), "resample" ) ) return Audio::create_null();
 	if( !detail::report( flanhip_stream_synchronize( nullptr ), "resample" ) ) return Audio::create_null();

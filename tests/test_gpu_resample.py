@@ -30,7 +30,7 @@ def test_resample_2to1_parity(fa, ch, n):
 @pytest.mark.parametrize("src,dst,up,down", [(144000.0, 48000.0, 1, 3), (72000.0, 48000.0, 2, 3), (32000.0, 48000.0, 3, 2), (64000.0, 48000.0, 3, 4),
                                              (48000.0, 96000.0, 2, 1), (16000.0, 48000.0, 3, 1), (88200.0, 44100.0, 1, 2)])
 def test_resample_single_step_ratios(fa, src, dst, up, down):
-    """the other ratios r8brain serves with one block convolver (k_resample_rational), ragged lengths, several channels"""
+    """the other ratios r8brain serves with one block convolver (k_resample_up / k_resample_down / k_resample_rational), ragged lengths, several channels"""
     for ch, n in ((2, 30001), (3, 777), (1, 50)):
         x = O.noise(ch, n, seed=n + up)
         ref = O.resample_rational(x, src, dst, up, down)
@@ -48,7 +48,7 @@ TWO_STAGE = [(44100.0, 48000.0), (48000.0, 44100.0), (96000.0, 44100.0), (22050.
 
 @pytest.mark.parametrize("src,dst", TWO_STAGE)
 def test_resample_two_stage_ratios(fa, src, dst):
-    """44.1 <-> 48 kHz and the other block convolver + whole-stepping interpolator ratios (k_resample_rational<double> + k_frac_whole)
+    """44.1 <-> 48 kHz and the other block convolver + whole-stepping interpolator ratios (k_resample_up + k_frac_whole)
     against the restatement, itself bit-identical to the real r8brain on these rates (test_oracle_resample.py): ragged lengths,
     several channels (one stream: the ringing crosses channel boundaries), inputs shorter than either filter"""
     assert O.two_stage_shape(src, dst) is not None
