@@ -293,6 +293,29 @@ __device__ __forceinline__ void lds_block_sync()
 	{
 	asm volatile( "s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory" );
 	}
+// The two wavefronts of ONE team meet; the other teams of the block are not involved (s_barrier would hold all eight wavefronts of the block
+// to the pace of the slowest one, every frame).  A counter in the team's LDS (slot 1087 of its first buffer: the padded layout ends at 1086,
+// the k = 0 lane's dummy mirror slot is 1088): each wavefront adds one when its LDS writes have landed, then polls until both have -- `target`
+// = 2 x the number of meetings so far.  Both wavefronts of a team walk the same number of meetings (idle iterations included), both are
+// resident (same block), so the wait ends; the poll count is bounded anyway, so that a logic error shows as wrong output, not as a hung GPU.
+typedef __attribute__(( address_space( 3 ) )) unsigned lds_u32;
+struct TeamSync
+	{
+	lds_u32 * flag; unsigned target; int lane;
+	__device__ __forceinline__ void meet()
+		{
+		target += 2;
+		asm volatile( "s_waitcnt lgkmcnt(0)" ::: "memory" );
+		if( lane == 0 ) (void) __hip_atomic_fetch_add( flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
+		for( int spins = 0; spins < ( 1 << 22 ); ++spins )
+			{
+			const unsigned v = __builtin_amdgcn_readfirstlane( __hip_atomic_load( flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP ) );
+			if( v >= target ) break;
+			__builtin_amdgcn_s_sleep( 1 );
+			}
+		asm volatile( "" ::: "memory" );
+		}
+	};
 
 template<int TEAMS, bool SUMS, int QV = 2, bool DOUBLE = false>   // DOUBLE: two E / O buffer sets per team, ONE barrier per frame
 __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParams p, FastTables tb )
@@ -315,12 +338,14 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 		float * win = reinterpret_cast<float*>( s + L::WIN );
 		for( int i = tid; i < 2048; i += NT ) win[i] = ( i < W ) ? p.window[i] : 0.0f;            // AudioPV.cpp:60,65
 		}
+	cf * const buf0 = s + L::BUF + team * ( DOUBLE ? 4 : 2 ) * L::BUF_LEN;     // set b: E at buf0 + 2 b BUF_LEN, O behind it
+	TeamSync team_sync{ (lds_u32*) reinterpret_cast<unsigned*>( buf0 + 1087 ), 0u, lane };
+	if( role == 0 && lane == 0 ) *team_sync.flag = 0u;
 	__syncthreads();
 	const cf * s_tw1 = s + L::TW1;
 	const cf * s_tw3 = s + L::TW3;
 	const v4f_t * s_twq = reinterpret_cast<const v4f_t*>( s + L::TWQ ) + lane + 256 * role;   // this wavefront's quads: k = lane + 64 ( 4 role + q )
 	const v4f_t * s_win = reinterpret_cast<const v4f_t*>( s + L::WIN ) + lane;
-	cf * const buf0 = s + L::BUF + team * ( DOUBLE ? 4 : 2 ) * L::BUF_LEN;     // set b: E at buf0 + 2 b BUF_LEN, O behind it
 
 	const int64_t chain_raw = int64_t( blockIdx.x ) * TEAMS + team;
 	const bool active = chain_raw < int64_t( p.chains_per_channel ) * p.num_channels;
@@ -543,7 +568,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 		// iteration i of a chain: frame tfirst + i (the first is the halo when t0 > 0).  Rotated like the dft 2048 kernel: the per-bin work of
 		// frame i, then the transform of frame i + 1; barriers after each (all teams, every iteration, work or not)
 		if( frames > 0 ) { load_half( tfirst ); transform_frame( 0 ); }
-		lds_block_sync();
+		team_sync.meet();
 		for( int i = 0; i < iters; ++i )
 			{
 			const int set = DOUBLE ? ( i & 1 ) : 0;
@@ -559,9 +584,9 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 				}
 			// one buffer set: nobody may write the next frame's E / O before both halves have read this one's.  Two sets: the next frame goes
 			// to the other set, whose readers (the frame before this one) passed the previous barrier
-			if constexpr( !DOUBLE ) lds_block_sync();
+			if constexpr( !DOUBLE ) team_sync.meet();
 			if( i + 1 < frames ) transform_frame( DOUBLE ? ( set ^ 1 ) : 0 );
-			lds_block_sync();                                                     // the next frame's E / O are written
+			team_sync.meet();                                                     // the next frame's E / O are written
 			}
 		};
 	if constexpr( SUMS ) { if( active && t0 == 0 ) park_first_phases(); }        // AudioPV.cpp:44: zeros
@@ -636,12 +661,14 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 		float * win = reinterpret_cast<float*>( s + L::WIN );
 		for( int i = tid; i < 2048; i += NT ) win[i] = ( i < W ) ? p.window[i] * p.window_scale : 0.0f;   // AudioPV.cpp:102
 		}
+	cf * const buf0 = s + L::BUF + team * 4 * L::BUF_LEN;                       // set b: A at buf0 + 2 b BUF_LEN, B behind it
+	TeamSync team_sync{ (lds_u32*) reinterpret_cast<unsigned*>( buf0 + 1087 ), 0u, lane };
+	if( role == 0 && lane == 0 ) *team_sync.flag = 0u;
 	__syncthreads();
 	const cf * s_tw1 = s + L::TW1;
 	const cf * s_tw3 = s + L::TW3;
 	const v4f_t * s_twq = reinterpret_cast<const v4f_t*>( s + L::TWQ ) + lane + 256 * role;
 	const v4f_t * s_win = reinterpret_cast<const v4f_t*>( s + L::WIN ) + lane;
-	cf * const buf0 = s + L::BUF + team * 4 * L::BUF_LEN;                       // set b: A at buf0 + 2 b BUF_LEN, B behind it
 
 	const int64_t chain_raw = int64_t( blockIdx.x ) * TEAMS + team;
 	const bool active = chain_raw < int64_t( p.chains_per_channel ) * p.num_channels;
@@ -816,7 +843,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 
 	int64_t pos = chain_start;
 	if( frames > 0 ) { load_row( t0 ); bins_of_row( 0 ); }
-	lds_block_sync();
+	team_sync.meet();
 	const int iters = p.L;
 	for( int i = 0; i < iters; ++i )
 		{
@@ -860,7 +887,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 			pos += hop;
 			if( i + 1 < frames ) bins_of_row( set ^ 1 );
 			}
-		lds_block_sync();                                                         // the next frame's A / B are written (into the other set)
+		team_sync.meet();                                                         // the next frame's A / B are written (into the other set)
 		}
 	if( !active ) return;
 	// flush the partial sums that the next chain's head completes; the last chain zero-fills to the end of the output
