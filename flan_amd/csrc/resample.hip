@@ -591,6 +591,57 @@ __global__ __launch_bounds__( FRAC_BLOCK ) void k_frac_whole( const double * __r
 	out[k] = OutT( acc );
 	}
 
+// The same sums with the whole bank and the block's span of y in LDS (the bank rows of 64 neighbouring outputs are 64 different cache lines:
+// gathered from memory, they are what k_frac_whole spends its time on).  A block owns 2048 consecutive outputs, a thread eight of them
+// (eight independent fp64 chains).  Rows padded to flt_len + 1 doubles: the rows of a wavefront's lanes then start in different banks.
+// Host checks: the bank fits (out_step <= ~400), in_step < 2^20 (32-bit positions inside a block).
+constexpr int FW_OUT = 2048, FW_PER = FW_OUT / FRAC_BLOCK;
+template<typename OutT>
+__global__ __launch_bounds__( FRAC_BLOCK ) void k_frac_whole_lds( const double * __restrict__ y, int64_t ny, const double * __restrict__ bank, int flt_len,
+	int in_step, int out_step, int span, OutT * __restrict__ out, int64_t total_out )
+	{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int rs = flt_len + 1;
+	double * s_bank = reinterpret_cast<double*>( smem );                       // [out_step][rs]
+	double * s_y = s_bank + out_step * rs;                                      // [span], local index i <-> y[a_base + i]
+	const int64_t k0 = int64_t( blockIdx.x ) * FW_OUT;
+	const int64_t pos0 = k0 * in_step, p0 = pos0 / out_step;
+	const unsigned r0 = unsigned( pos0 - p0 * out_step );
+	const int64_t a_base = p0 - ( flt_len / 2 - 1 );
+	for( int r = threadIdx.x / 32; r < out_step; r += FRAC_BLOCK / 32 )
+		{
+		const int i = threadIdx.x & 31;
+		if( i < flt_len ) s_bank[r * rs + i] = bank[r * flt_len + i];
+		}
+	for( int i = threadIdx.x; i < span; i += FRAC_BLOCK )
+		{
+		const int64_t a = a_base + i;
+		s_y[i] = ( a >= 0 && a < ny ) ? y[a] : 0.0;
+		}
+	__syncthreads();
+	const double * ft[FW_PER]; const double * yp[FW_PER]; double acc[FW_PER];
+	#pragma unroll
+	for( int j = 0; j < FW_PER; ++j )
+		{
+		const unsigned q = r0 + unsigned( threadIdx.x + FRAC_BLOCK * j ) * unsigned( in_step );
+		const unsigned dp = q / unsigned( out_step );
+		ft[j] = s_bank + ( q - dp * unsigned( out_step ) ) * rs;
+		yp[j] = s_y + dp;
+		acc[j] = 0.0;
+		}
+	for( int i = 0; i < flt_len; ++i )
+		{
+		#pragma unroll
+		for( int j = 0; j < FW_PER; ++j ) acc[j] = __builtin_fma( ft[j][i], yp[j][i], acc[j] );
+		}
+	#pragma unroll
+	for( int j = 0; j < FW_PER; ++j )
+		{
+		const int64_t k = k0 + threadIdx.x + FRAC_BLOCK * j;
+		if( k < total_out ) out[k] = OutT( acc[j] );
+		}
+	}
+
 // CDSPHBDownsampler (CDSPHBDownsampler.h:95-260): out[j] = in[2j] + sum_t c[t] ( in[2j+2t+1] + in[2j-2t-1] ), in = 0 outside [0, n_in)
 constexpr int HB_BLOCK = 256;
 template<typename InT>
@@ -852,7 +903,24 @@ static int resample_stages_dev( const float * d_in, int64_t total_in, int64_t ch
 			const dim3 grid( (unsigned) ( ( n_out + FRAC_BLOCK - 1 ) / FRAC_BLOCK ) );
 			if( g.whole )
 				{
-				if( last ) hipLaunchKernelGGL( k_frac_whole<float>, grid, dim3( FRAC_BLOCK ), 0, s, cur, cur_len, g.d_bank, g.flt_len, g.in_step, g.out_step, d_out, n_out );
+				// the last output of a block sits ( r0 + 2047 in_step ) / out_step samples behind the first, r0 < out_step
+				const int64_t span = ( int64_t( ( g.out_step - 1 ) ) + int64_t( FW_OUT - 1 ) * g.in_step ) / g.out_step + g.flt_len + 1;
+				const size_t lds = sizeof( double ) * ( size_t( g.out_step ) * ( g.flt_len + 1 ) + size_t( span ) );
+				if( g.flt_len <= 32 && g.in_step < ( 1 << 20 ) && lds <= 160 * 1024 )
+					{
+					const dim3 wide( (unsigned) ( ( n_out + FW_OUT - 1 ) / FW_OUT ) );
+					if( last )
+						{
+						FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( k_frac_whole_lds<float> ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+						hipLaunchKernelGGL( k_frac_whole_lds<float>, wide, dim3( FRAC_BLOCK ), lds, s, cur, cur_len, g.d_bank, g.flt_len, g.in_step, g.out_step, int( span ), d_out, n_out );
+						}
+					else
+						{
+						FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( k_frac_whole_lds<double> ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+						hipLaunchKernelGGL( k_frac_whole_lds<double>, wide, dim3( FRAC_BLOCK ), lds, s, cur, cur_len, g.d_bank, g.flt_len, g.in_step, g.out_step, int( span ), nxt, n_out );
+						}
+					}
+				else if( last ) hipLaunchKernelGGL( k_frac_whole<float>, grid, dim3( FRAC_BLOCK ), 0, s, cur, cur_len, g.d_bank, g.flt_len, g.in_step, g.out_step, d_out, n_out );
 				else hipLaunchKernelGGL( k_frac_whole<double>, grid, dim3( FRAC_BLOCK ), 0, s, cur, cur_len, g.d_bank, g.flt_len, g.in_step, g.out_step, nxt, n_out );
 				}
 			else
