@@ -840,6 +840,23 @@ static int launch_rational( const InT * d_in, int64_t n_in, const Stage & g, Out
 	return FLANHIP_OK;
 	}
 
+template<typename OutT>
+static int launch_frac_whole( const double * d_y, int64_t ny, const Stage & g, OutT * d_out, int64_t n_out, hipStream_t s )
+	{
+	// the last output of a block sits ( r0 + 2047 in_step ) / out_step samples behind the first, r0 < out_step
+	const int64_t span = ( int64_t( g.out_step - 1 ) + int64_t( FW_OUT - 1 ) * g.in_step ) / g.out_step + g.flt_len + 1;
+	const size_t lds = sizeof( double ) * ( size_t( g.out_step ) * ( g.flt_len + 1 ) + size_t( span ) );
+	if( g.flt_len <= 32 && g.in_step < ( 1 << 20 ) && lds <= 160 * 1024 )
+		{
+		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( k_frac_whole_lds<OutT> ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+		hipLaunchKernelGGL( k_frac_whole_lds<OutT>, dim3( (unsigned) ( ( n_out + FW_OUT - 1 ) / FW_OUT ) ), dim3( FRAC_BLOCK ), lds, s,
+			d_y, ny, g.d_bank, g.flt_len, g.in_step, g.out_step, int( span ), d_out, n_out );
+		}
+	else hipLaunchKernelGGL( k_frac_whole<OutT>, dim3( (unsigned) ( ( n_out + FRAC_BLOCK - 1 ) / FRAC_BLOCK ) ), dim3( FRAC_BLOCK ), 0, s,
+		d_y, ny, g.d_bank, g.flt_len, g.in_step, g.out_step, d_out, n_out );
+	return FLANHIP_OK;
+	}
+
 // A chain of more than one stage: every stage for exactly as many samples as the next one reads (zeros before the start and past the end, like
 // the zeros oneshot() feeds), intermediate fp64 streams from the stream's memory pool.  `chunk`: the input samples per process() call of the
 // reference (the channel's frame count) -- it decides where the spline interpolator re-bases its position counter.
@@ -849,6 +866,7 @@ static int resample_stages_dev( const float * d_in, int64_t total_in, int64_t ch
 	if( int rc = get_stage_plan( src, dst, &plan ) ) return rc;
 	const std::vector<Stage> & st = *plan;
 	const int ns = int( st.size() );
+	FLANHIP_REQUIRE( ns > 0 && st[size_t( ns - 1 )].kind != Stage::HbDown, FLANHIP_ERR_UNSUPPORTED, "a chain cannot end in a half-band downsampler" );
 	std::vector<int64_t> need( size_t( ns ), 0 );
 	need[size_t( ns - 1 )] = total_out;
 	for( int k = ns - 1; k > 0; --k )                                             // what stage k reads of stage k - 1
@@ -865,7 +883,7 @@ static int resample_stages_dev( const float * d_in, int64_t total_in, int64_t ch
 		}
 	retain_pool_memory();
 	std::vector<void*> temps;
-	auto temp = [&]( size_t bytes, void ** out ) -> int
+	auto temp = [&]( size_t bytes, void ** out ) -> int               // (an error here leaves the loop below; what was allocated before is freed after it)
 		{
 		FLANHIP_CHECK( hipMallocAsync( out, std::max<size_t>( bytes, 8 ), s ) );
 		temps.push_back( *out );
@@ -883,7 +901,6 @@ static int resample_stages_dev( const float * d_in, int64_t total_in, int64_t ch
 		if( g.kind == Stage::HbDown )
 			{
 			const dim3 grid( (unsigned) ( ( n_out + HB_BLOCK - 1 ) / HB_BLOCK ) );
-			FLANHIP_REQUIRE( !last, FLANHIP_ERR_UNSUPPORTED, "a chain cannot end in a half-band downsampler" );
 			if( cur ) hipLaunchKernelGGL( k_hb_down<double>, grid, dim3( HB_BLOCK ), 0, s, cur, cur_len, g.taps, nxt, n_out );
 			else hipLaunchKernelGGL( k_hb_down<float>, grid, dim3( HB_BLOCK ), 0, s, d_in, cur_len, g.taps, nxt, n_out );
 			}
@@ -901,28 +918,7 @@ static int resample_stages_dev( const float * d_in, int64_t total_in, int64_t ch
 		else
 			{
 			const dim3 grid( (unsigned) ( ( n_out + FRAC_BLOCK - 1 ) / FRAC_BLOCK ) );
-			if( g.whole )
-				{
-				// the last output of a block sits ( r0 + 2047 in_step ) / out_step samples behind the first, r0 < out_step
-				const int64_t span = ( int64_t( ( g.out_step - 1 ) ) + int64_t( FW_OUT - 1 ) * g.in_step ) / g.out_step + g.flt_len + 1;
-				const size_t lds = sizeof( double ) * ( size_t( g.out_step ) * ( g.flt_len + 1 ) + size_t( span ) );
-				if( g.flt_len <= 32 && g.in_step < ( 1 << 20 ) && lds <= 160 * 1024 )
-					{
-					const dim3 wide( (unsigned) ( ( n_out + FW_OUT - 1 ) / FW_OUT ) );
-					if( last )
-						{
-						FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( k_frac_whole_lds<float> ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
-						hipLaunchKernelGGL( k_frac_whole_lds<float>, wide, dim3( FRAC_BLOCK ), lds, s, cur, cur_len, g.d_bank, g.flt_len, g.in_step, g.out_step, int( span ), d_out, n_out );
-						}
-					else
-						{
-						FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( k_frac_whole_lds<double> ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
-						hipLaunchKernelGGL( k_frac_whole_lds<double>, wide, dim3( FRAC_BLOCK ), lds, s, cur, cur_len, g.d_bank, g.flt_len, g.in_step, g.out_step, int( span ), nxt, n_out );
-						}
-					}
-				else if( last ) hipLaunchKernelGGL( k_frac_whole<float>, grid, dim3( FRAC_BLOCK ), 0, s, cur, cur_len, g.d_bank, g.flt_len, g.in_step, g.out_step, d_out, n_out );
-				else hipLaunchKernelGGL( k_frac_whole<double>, grid, dim3( FRAC_BLOCK ), 0, s, cur, cur_len, g.d_bank, g.flt_len, g.in_step, g.out_step, nxt, n_out );
-				}
+			if( g.whole ) rc = last ? launch_frac_whole<float>( cur, cur_len, g, d_out, n_out, s ) : launch_frac_whole<double>( cur, cur_len, g, nxt, n_out, s );
 			else
 				{
 				std::vector<FracSegment> segs;
