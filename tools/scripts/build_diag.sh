@@ -7,12 +7,14 @@ R=$(cd "$(dirname "$0")/../.." && pwd)
 KIND=${1:-stamps}
 DEF=-DFLANHIP_STAMPS
 [ "$KIND" = ablations ] && DEF=-DFLANHIP_ABLATIONS
-[ "$KIND" = nopk ] && DEF="-Xclang -target-feature -Xclang -packed-fp32-ops"
+[ "$KIND" = packed ] && DEF="-DFLANHIP_DIAG_PACKED"     # the product's conversions.hip is built WITHOUT packed fp32 (flan_amd/build.py); this variant with
+NOPK="-Xclang -target-feature -Xclang -packed-fp32-ops"
+[ "$KIND" = packed ] && NOPK=""
 [ "$KIND" = maxilp ] && DEF="-mllvm -amdgpu-sched-strategy=max-ilp"
 [ "$KIND" = maxmem ] && DEF="-mllvm -amdgpu-sched-strategy=max-memory-clause"
 [ "$KIND" = iterilp ] && DEF="-mllvm -amdgpu-sched-strategy=iterative-ilp"
 python3 $R/flan_amd/build.py > /dev/null
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-gpu-rdc $DEF \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-gpu-rdc $DEF $NOPK \
   -I$R/include -I$R/flan_amd/csrc -c $R/flan_amd/csrc/conversions.hip -o /tmp/conversions_$KIND.o
 OBJS=$(ls $R/flan_amd/csrc/*.o | grep -v conversions.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/ubench/libflanhip_$KIND.so /tmp/conversions_$KIND.o $OBJS -ldl

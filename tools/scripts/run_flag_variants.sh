@@ -3,7 +3,7 @@ R=$GRAFT_REPO_ROOT
 : > $R/gpurun_out/flag_variants.txt
 for so in $R/tools/ubench/variants/libflanhip_*.so; do
   name=$(basename $so .so)
-  FLAN_AMD_LIB=$so timeout -k 10 120 python $R/bench.py --no-cpu --no-configs 2>/dev/null | python -c "
+  FLAN_AMD_LIB=$so timeout -k 10 120 python $R/bench.py --no-cpu --no-configs --steps 300 --warmup 20 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernel_ms']; print('$name', round(d['value']/1e6,1), d['ms_per_step'], k['k_analyze'], k['k_synthesize'])" >> $R/gpurun_out/flag_variants.txt || echo "$name failed" >> $R/gpurun_out/flag_variants.txt
 done
