@@ -93,7 +93,6 @@ static int run_analyze_v2_variant( int v, const AnalyzeParams & p, const FastTab
 		case 4: return run_analyze_v2<8, SUMS, 8>( p, tb, s );
 		case 6: return run_analyze_v2<8, SUMS, 16>( p, tb, s );
 		case 7: return run_analyze_v2<8, SUMS, 4>( p, tb, s );
-		case 8: return run_analyze_v2<8, SUMS, 2>( p, tb, s );
 #ifdef FLANHIP_ABLATIONS
 		case 101: return run_analyze_v2<8, SUMS, 8, 1>( p, tb, s );
 		case 102: return run_analyze_v2<8, SUMS, 8, 2>( p, tb, s );
