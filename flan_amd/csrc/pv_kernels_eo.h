@@ -364,24 +364,15 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 	float prev[Q][4], prevs[2] = { 0.0f, 0.0f };
 	#pragma unroll
 	for( int q = 0; q < Q; ++q ) { prev[q][0] = 0.0f; prev[q][1] = 0.0f; prev[q][2] = 0.0f; prev[q][3] = 0.0f; }   // AudioPV.cpp:44
-	// Fused round trip: the chain's sum of phase increments (phase_vocoder.cpp:57-58), modulo pi2, for convert_to_audio -- TELESCOPED, so
-	// that it costs one float per bin instead of one double: an increment is the float  term = ( f / analysis_rate ) pi2,  and
-	// term - ( phase_t - phase_{t-1} )  is a whole number of turns plus the rounding of f and term (~1e-4 rad).  Per bin only
-	// R = sum_t [ term_t - ( phase_t - phase_{t-1} ) ] mod pi2  is kept (every r_t is formed in fp64 and is tiny, so the float sum is good
-	// to ~1e-11 rad); the chain's sum is  phase_last - phase_first + R  (mod pi2), with phase_first parked in the workspace row the result
-	// goes to.
-	float rs[SUMS ? Q : 1][4], rs2[2] = { 0.0f, 0.0f };
+	// Fused round trip: the chain's sums of the phase increments convert_to_audio will integrate (phase_vocoder.cpp:57-58), one double per
+	// bin as in k_analyze_v2 (a wavefront of a team owns 16 bins: 32 registers, which this kernel has -- the one-wavefront form did not, and
+	// an earlier version of this one kept a telescoped float residue per bin instead, at nine fp64-class instructions per bin and frame)
+	double sm[SUMS ? Q : 1][4], sm2[2] = { 0.0, 0.0 };
 	if constexpr( SUMS )
 		{
 		#pragma unroll
-		for( int q = 0; q < Q; ++q ) { rs[q][0] = 0.0f; rs[q][1] = 0.0f; rs[q][2] = 0.0f; rs[q][3] = 0.0f; }
+		for( int q = 0; q < Q; ++q ) { sm[q][0] = 0.0; sm[q][1] = 0.0; sm[q][2] = 0.0; sm[q][3] = 0.0; }
 		}
-	auto residue = []( float term, float phase, float before ) -> float
-		{
-		const double d = double( term ) - ( double( phase ) - double( before ) );
-		const double n = __builtin_rint( d * ( 1.0 / FLANHIP_PI2_D ) );
-		return float( __builtin_fma( -n, FLANHIP_PI2_D, d ) );
-		};
 	float mmax = 0.0f;
 
 	const int64_t tfirst = t0 > 0 ? t0 - 1 : t0;
@@ -389,19 +380,6 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 	const int iters = p.L + 1;                                                // what every team of every block walks
 	const bool chain_fast = W == 2048 && int64_t( hop ) * tfirst - W / 2 >= 0 && int64_t( hop ) * ( t1 - 1 ) - W / 2 + 2048 <= p.n;
 
-	// phase_first (the phases of frame t0 - 1; zero for the first chain of a channel) waits in the workspace row the chain's sums go to
-	auto park_first_phases = [&]()
-		{
-		double * dst = p.sums + chain * ( N2 + 1 );
-		#pragma unroll
-		for( int q = 0; q < Q; ++q )
-			{
-			const int k = lane + 256 * role + 64 * q;
-			dst[k] = double( prev[q][0] ); dst[N2 - k] = double( prev[q][1] ); dst[C - k] = double( prev[q][2] );
-			if( k != 0 ) dst[C + k] = double( prev[q][3] );
-			}
-		if( role == 1 && lane == 0 ) { dst[512] = double( prevs[0] ); dst[1536] = double( prevs[1] ); }
-		};
 	cf raw[2 * Q];                                                            // this wavefront's half of a frame: points lane + 64 q, q < 8, of its parity
 	auto run_chain = [&]( auto fast_tag )
 		{
@@ -526,8 +504,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 						for( int i = 0; i < QV; ++i )
 							{
 							#pragma unroll
-							for( int j = 0; j < 4; ++j ) rs[QV * g + i][j] += residue( term[4 * i + j], phase[4 * i + j], pv[4 * i + j] );
-							__builtin_amdgcn_sched_barrier( 0 );                             // four residues at a time: their fp64 temporaries must not pile up
+							for( int j = 0; j < 4; ++j ) sm[QV * g + i][j] += double( term[4 * i + j] );
 							}
 						#pragma unroll
 						for( int i = 0; i < 4 * QV; i += 2 ) mmax = __builtin_fmaxf( mmax, __builtin_fmaxf( m[i], m[i + 1] ) );
@@ -557,7 +534,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 						if( lane == 0 ) __builtin_nontemporal_store( mk( m, f ), row + ( j == 0 ? 512 : 1536 ) );
 						if constexpr( SUMS )
 							{
-							rs2[j] += residue( div_c( f, p.ar_div ) * FLANHIP_PI2_F, phase, pvx );
+							sm2[j] += double( div_c( f, p.ar_div ) * FLANHIP_PI2_F );
 							mmax = __builtin_fmaxf( mmax, m );
 							}
 						}
@@ -575,11 +552,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 			if( i < frames )
 				{
 				const int64_t t = tfirst + i, tn = min( t + 1, t1 - 1 );           // (the last frame requests itself again: nobody waits for it)
-				if( t0 > 0 && i == 0 )
-					{
-					bins_of_frame( t, tn, set, std::true_type{} );
-					if constexpr( SUMS ) park_first_phases();                        // prev[] = the phases of frame t0 - 1
-					}
+				if( t0 > 0 && i == 0 ) bins_of_frame( t, tn, set, std::true_type{} );
 				else bins_of_frame( t, tn, set, std::false_type{} );
 				}
 			// one buffer set: nobody may write the next frame's E / O before both halves have read this one's.  Two sets: the next frame goes
@@ -589,20 +562,16 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 			team_sync.meet();                                                     // the next frame's E / O are written
 			}
 		};
-	if constexpr( SUMS ) { if( active && t0 == 0 ) park_first_phases(); }        // AudioPV.cpp:44: zeros
 	if( chain_fast ) run_chain( std::true_type{} ); else run_chain( std::false_type{} );
 
 	if constexpr( SUMS )
 		{
-		// the chain's sum = phase_last - phase_first + R, brought into [0, pi2): the value k_phase_sums2 would fold to, up to ~1e-11 rad and, for
-		// a sum that is negative as a whole, one turn of the float constant pi2 = 2 pi + 1.7e-7
+		// the chain's sums, folded like phase_vocoder.cpp:59: what k_phase_sums2 would leave in the workspace
 		bool bad = !( mmax <= 3.4028235e38f );
-		auto total = [&]( double first, float last, float r ) -> double
+		auto fold = [&]( double sq ) -> double
 			{
-			bad |= !( __builtin_fabsf( r ) <= 3.4028235e38f );                       // a NaN / Inf frequency poisons its residue
-			const double v = ( double( last ) - first ) + double( r );
-			const double w = __builtin_fma( -__builtin_floor( v * ( 1.0 / FLANHIP_PI2_D ) ), FLANHIP_PI2_D, v );
-			return w < 0.0 ? w + FLANHIP_PI2_D : ( w >= FLANHIP_PI2_D ? w - FLANHIP_PI2_D : w );
+			bad |= !( __builtin_fabs( sq ) <= 1.7976931348623157e308 );              // a NaN / Inf frequency poisons its sum
+			return ( __builtin_fabs( sq ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( sq ) : fold_phase_any( sq );
 			};
 		if( active )
 			{
@@ -611,12 +580,11 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 			for( int q = 0; q < Q; ++q )
 				{
 				const int k = lane + 256 * role + 64 * q;
-				const double a = total( dst[k], prev[q][0], rs[q][0] ), b = total( dst[N2 - k], prev[q][1], rs[q][1] );
-				const double c = total( dst[C - k], prev[q][2], rs[q][2] );
+				const double a = fold( sm[q][0] ), b = fold( sm[q][1] ), c = fold( sm[q][2] ), d = fold( sm[q][3] );
 				dst[k] = a; dst[N2 - k] = b; dst[C - k] = c;
-				if( k != 0 ) dst[C + k] = total( dst[C + k], prev[q][3], rs[q][3] );   // (k = 0: the quad's fourth bin is bin 1024 again)
+				if( k != 0 ) dst[C + k] = d;                                         // (k = 0: the quad's fourth bin is bin 1024 again)
 				}
-			if( role == 1 && lane == 0 ) { dst[512] = total( dst[512], prevs[0], rs2[0] ); dst[1536] = total( dst[1536], prevs[1], rs2[1] ); }
+			if( role == 1 && lane == 0 ) { dst[512] = fold( sm2[0] ); dst[1536] = fold( sm2[1] ); }
 			}
 		const bool any_bad = __any( bad ) && active;
 		if( p.nan_out && lane == 0 && active )
