@@ -42,7 +42,7 @@ __device__ __forceinline__ void split_pair( cf zk, cf zm, float wx, float wy, fl
 	}
 
 // One wavefront per chain: for the plain convert_to_PV (no chain sums).  With the fused round trip's sums its state (32 previous phases
-// and 32 sum residues beside the transform) spills, however the loop is arranged -- that job is k_analyze_eo_team's, below.
+// and 32 fp64 sums beside the transform) spills, however the loop is arranged -- that job is k_analyze_eo_team's, below.
 template<int WAVES, int QV = 2>                 // QV: quads (of 4 bins) evaluated together as one vector stream
 __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_eo( AnalyzeParams p, FastTables tb )
 	{
@@ -285,10 +285,9 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_eo( AnalyzeParams p, F
 // The same decomposition with a TEAM of two wavefronts per chain: wavefront 0 of a team transforms the even points and then owns the
 // quads k < 256, wavefront 1 the odd points and the quads 256 <= k < 512 (and k = 512).  Per frame a wavefront does exactly what the
 // dft 2048 kernel's wavefront does -- one 1024-point register transform and 16 bins -- so its registers (16 previous phases, 16 chain
-// sum residues instead of 32 + 32) fit the fused round trip's sums without spilling, which the one-wavefront form above does not
+// sums instead of 32 + 32) fit the fused round trip's sums without spilling, which the one-wavefront form above does not
 // (its SUMS instantiation spills 400+ bytes per lane and drains the memory queue every frame: 0.70 ms against 0.27 ms without sums).
-// The two halves meet in the team's E / O buffers: two LDS-only block barriers per frame (every team of the block walks the same number
-// of iterations, idle ones included; the barrier does not wait for global stores).
+// The two halves meet in the team's E / O buffers (TeamSync below; every team walks the same number of iterations, idle ones included).
 __device__ __forceinline__ void lds_block_sync()
 	{
 	asm volatile( "s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory" );
