@@ -211,6 +211,10 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 		for( int q = 0; q < H; ++q ) { sumk[q] = 0.0; summ[q] = 0.0; }
 		}
 	float mmax = 0.0f;                                                        // running maximum of the magnitudes (Inf scan)
+	// Bin C/2 pairs with itself and would cost every lane ~70 instructions per frame for ONE bin.  Instead lane ( i & 63 ) keeps Z[C/2] of
+	// the chain's i-th frame, and once per 64 frames (and at the chain's end) the wavefront works the batch off, one frame per lane:
+	// the same arithmetic, previous phase from the lane below, the fp64 sum taken in frame order.
+	cf ring = mk( 0.0f, 0.0f );
 
 	// does every frame this chain touches (its halo frame included) lie inside the signal?  (AudioPV.cpp:52-62 needs no bounds then)
 	const int64_t tfirst = t0 > 0 ? t0 - 1 : t0;
@@ -288,7 +292,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 		// drains the whole queue, stores included, once per frame (measured: a quarter of the kernel's time).
 		// HALO: frame t0 - 1, of which only the phases are wanted (phase_vocoder.cpp:45 leaves them in phase_buffer): a compile-time
 		// switch, not a branch.
-		auto bins_of_frame = [&]( int64_t t, int64_t tn, auto halo_tag )
+		auto bins_of_frame = [&]( int64_t t, int64_t tn, int fi, auto halo_tag )
 			{
 			constexpr bool halo = decltype( halo_tag )::value;
 			const cf z512 = buf[544];                                             // Z[ C/2 ], slot PAD( 512 )
@@ -398,43 +402,56 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 					else asm volatile( "" :: "v"( outk[q].x ), "v"( outk[q].y ), "v"( outm[q].x ), "v"( outm[q].y ) );
 					}
 				}
-				{
-				// bin C/2 pairs with itself: X = conj Z[ C/2 ]; every lane carries the same value
-				const float re = z512.x, im = -z512.y;
-				const float phase = atan2_fast( im, re );
-				const float pvx = prevx;
-				prevx = phase;
-				if constexpr( !halo )
-					{
-					const float bx = float( C / 2 ) * p.sample_rate * ( 1.0f / float( 2 * C ) );
-					const float phase_diff = phase - pvx;
-					const float delta_phase = phase_diff - div_c( bx, p.ar_div ) * FLANHIP_PI2_F;
-					const float wrapped = use_wrapping ? delta_phase - FLANHIP_PI2_F * round_half_away( div_pi2( delta_phase ) ) : delta_phase;
-					const float f = bx + div_pi2( wrapped * p.analysis_rate );
-					const float m = magnitude_scaled( re, im );
-					if constexpr( ( ABL & 8 ) == 0 ) __builtin_nontemporal_store( mk( m, f ), row + C / 2 ); else asm volatile( "" :: "v"( m ), "v"( f ) );
-					if constexpr( SUMS )
-						{
-						sumx += double( div_c( f, p.ar_div ) * FLANHIP_PI2_F );
-						mmax = __builtin_fmaxf( mmax, m );
-						}
-					}
-				}
+			ring = ( lane == ( fi & 63 ) ) ? z512 : ring;                          // Z[ C/2 ] of the chain's fi-th frame waits in lane fi % 64
 			wave_sync();
 			st( 9 );                                                              // 9: bin C/2
+			};
+
+		// the batch of bin C/2: lane j holds frame tb + j, j < nb (frame tfirst, the halo, only lends its phase)
+		auto flush_half_bin = [&]( int64_t tb, int nb )
+			{
+			const int64_t t = tb + lane;
+			const bool valid = lane < nb && t >= t0;
+			const float re = ring.x, im = -ring.y;                                // X = conj Z[ C/2 ]
+			const float phase = atan2_fast( im, re );
+			float pvx = __shfl_up( phase, 1 );                                    // the frame before: the lane below ...
+			pvx = ( lane == 0 ) ? prevx : pvx;                                    // ... or the last frame of the batch before (zero at a channel's start, AudioPV.cpp:44)
+			prevx = __shfl( phase, nb - 1 );
+			const float bx = float( C / 2 ) * p.sample_rate * ( 1.0f / float( 2 * C ) );
+			const float phase_diff = phase - pvx;
+			const float delta_phase = phase_diff - div_c( bx, p.ar_div ) * FLANHIP_PI2_F;
+			const float wrapped = use_wrapping ? delta_phase - FLANHIP_PI2_F * round_half_away( div_pi2( delta_phase ) ) : delta_phase;
+			const float f = bx + div_pi2( wrapped * p.analysis_rate );
+			const float m = magnitude_scaled( re, im );
+			if constexpr( ( ABL & 8 ) == 0 )
+				{
+				if( valid ) __builtin_nontemporal_store( mk( m, f ), reinterpret_cast<cf*>( p.out + ( int64_t( channel ) * p.F + ( ( ABL & 256 ) ? t0 : t ) ) * ( C + 1 ) ) + C / 2 );
+				}
+			else asm volatile( "" :: "v"( m ), "v"( f ) );
+			if constexpr( SUMS )
+				{
+				const float term = div_c( f, p.ar_div ) * FLANHIP_PI2_F;             // phase_vocoder.cpp:57-58
+				const int j0 = __builtin_amdgcn_readfirstlane( ( tb < t0 ) ? 1 : 0 ), j1 = __builtin_amdgcn_readfirstlane( nb );   // (uniform: scalar loop, v_readlane)
+				for( int j = j0; j < j1; ++j ) sumx += double( __uint_as_float( __builtin_amdgcn_readlane( __float_as_uint( term ), j ) ) );   // in frame order, like every other bin's sum
+				mmax = valid ? __builtin_fmaxf( mmax, m ) : mmax;
+				}
 			};
 
 		#pragma unroll
 		for( int q = 0; q < E; ++q ) z[q] = load_pair( tfirst, q );
 		transform_frame( tfirst );
+		int fi = 0;
 		if( t0 > 0 )
 			{
-			bins_of_frame( t0 - 1, t0, std::true_type{} );
+			bins_of_frame( t0 - 1, t0, fi, std::true_type{} );
+			++fi;
 			transform_frame( t0 );
 			}
 		for( int64_t t = t0; t < t1; ++t )
 			{
-			bins_of_frame( t, min( t + 1, t1 - 1 ), std::false_type{} );          // (the last frame requests itself again: nobody waits for it)
+			bins_of_frame( t, min( t + 1, t1 - 1 ), fi, std::false_type{} );      // (the last frame requests itself again: nobody waits for it)
+			++fi;
+			if( ( fi & 63 ) == 0 || t + 1 == t1 ) flush_half_bin( t + 1 - ( ( ( fi - 1 ) & 63 ) + 1 ), ( ( fi - 1 ) & 63 ) + 1 );
 			if( t + 1 < t1 ) transform_frame( t + 1 );
 			}
 		};
