@@ -373,6 +373,11 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 		for( int q = 0; q < Q; ++q ) { sm[q][0] = 0.0; sm[q][1] = 0.0; sm[q][2] = 0.0; sm[q][3] = 0.0; }
 		}
 	float mmax = 0.0f;
+	// The pair ( 512, 1536 ) is the odd wavefront's alone and would cost each of its lanes ~140 instructions per frame for two bins -- on the
+	// wavefront the other one waits for.  Instead lane ( i & 63 ) keeps E[512] and O[512] of the chain's i-th frame, and once per 64 frames
+	// (and at the chain's end) the batch is worked off one frame per lane (k_analyze_v2 does the same with its bin C/2).
+	cf ringE = mk( 0.0f, 0.0f ), ringO = mk( 0.0f, 0.0f );
+	int fidx = 0;                                                             // the iteration bins_of_frame is working on
 
 	const int64_t tfirst = t0 > 0 ? t0 - 1 : t0;
 	const int frames = active ? int( t1 - tfirst ) : 0;                       // iterations with work (the halo frame included)
@@ -512,37 +517,47 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 				}
 			if( role == 1 )
 				{
-				// k = 512 (the odd wavefront's): Z[512] = E[512] - i O[512], Z[1536] = E[512] + i O[512]; bins 512 and 1536 are one pair
 				const cf e512 = bufE[544], o512 = bufO[544];                          // slot PAD( 512 )
-				const cf zk = mk( e512.x + o512.y, e512.y - o512.x ), zm = mk( e512.x - o512.y, e512.y + o512.x );
-				float r[2], im2[2];
-				split_pair( zk, zm, 0.35355339059327379f, -0.35355339059327379f, r[0], im2[0], r[1], im2[1] );
-				#pragma unroll
-				for( int j = 0; j < 2; ++j )
-					{
-					const float phase = atan2_fast( im2[j], r[j] );
-					const float pvx = prevs[j];
-					prevs[j] = phase;
-					if constexpr( !halo )
-						{
-						const float bx = float( j == 0 ? 512 : 1536 ) * p.sample_rate * rdft;
-						const float delta_phase = ( phase - pvx ) - div_c( bx, p.ar_div ) * FLANHIP_PI2_F;
-						const float wrapped = use_wrapping ? delta_phase - FLANHIP_PI2_F * round_half_away( div_pi2( delta_phase ) ) : delta_phase;
-						const float f = bx + div_pi2( wrapped * p.analysis_rate );
-						const float m = magnitude_scaled( r[j], im2[j] );
-						if( lane == 0 ) __builtin_nontemporal_store( mk( m, f ), row + ( j == 0 ? 512 : 1536 ) );
-						if constexpr( SUMS )
-							{
-							sm2[j] += double( div_c( f, p.ar_div ) * FLANHIP_PI2_F );
-							mmax = __builtin_fmaxf( mmax, m );
-							}
-						}
-					}
+				const bool mine = lane == ( fidx & 63 );
+				ringE = mine ? e512 : ringE;  ringO = mine ? o512 : ringO;
 				}
 			};
 
 		// iteration i of a chain: frame tfirst + i (the first is the halo when t0 > 0).  Rotated like the dft 2048 kernel: the per-bin work of
 		// frame i, then the transform of frame i + 1; barriers after each (all teams, every iteration, work or not)
+		// the batch of the pair ( 512, 1536 ): lane j holds frame tb + j, j < nb (frame tfirst, the halo, only lends its phases)
+		auto flush_orphans = [&]( int64_t tb, int nb )
+			{
+			const int64_t t = tb + lane;
+			const bool valid = lane < nb && t >= t0;
+			// Z[512] = E[512] - i O[512], Z[1536] = E[512] + i O[512]; bins 512 and 1536 are one pair
+			const cf zk = mk( ringE.x + ringO.y, ringE.y - ringO.x ), zm = mk( ringE.x - ringO.y, ringE.y + ringO.x );
+			float r[2], im2[2];
+			split_pair( zk, zm, 0.35355339059327379f, -0.35355339059327379f, r[0], im2[0], r[1], im2[1] );
+			cf * rowp = reinterpret_cast<cf*>( p.out + ( int64_t( channel ) * p.F + ( valid ? t : t0 ) ) * ( N2 + 1 ) );
+			const int j0 = __builtin_amdgcn_readfirstlane( ( tb < t0 ) ? 1 : 0 ), j1 = __builtin_amdgcn_readfirstlane( nb );
+			#pragma unroll
+			for( int j = 0; j < 2; ++j )
+				{
+				const float phase = atan2_fast( im2[j], r[j] );
+				float pvx = __shfl_up( phase, 1 );                                 // the frame before: the lane below, or the batch before
+				pvx = ( lane == 0 ) ? prevs[j] : pvx;
+				prevs[j] = __shfl( phase, nb - 1 );
+				const float bx = float( j == 0 ? 512 : 1536 ) * p.sample_rate * rdft;
+				const float delta_phase = ( phase - pvx ) - div_c( bx, p.ar_div ) * FLANHIP_PI2_F;
+				const float wrapped = use_wrapping ? delta_phase - FLANHIP_PI2_F * round_half_away( div_pi2( delta_phase ) ) : delta_phase;
+				const float f = bx + div_pi2( wrapped * p.analysis_rate );
+				const float m = magnitude_scaled( r[j], im2[j] );
+				if( valid ) __builtin_nontemporal_store( mk( m, f ), rowp + ( j == 0 ? 512 : 1536 ) );
+				if constexpr( SUMS )
+					{
+					const float term = div_c( f, p.ar_div ) * FLANHIP_PI2_F;         // phase_vocoder.cpp:57-58
+					for( int l = j0; l < j1; ++l ) sm2[j] += double( __uint_as_float( __builtin_amdgcn_readlane( __float_as_uint( term ), l ) ) );   // frame order
+					mmax = valid ? __builtin_fmaxf( mmax, m ) : mmax;
+					}
+				}
+			};
+
 		if( frames > 0 ) { load_half( tfirst ); transform_frame( 0 ); }
 		team_sync.meet();
 		for( int i = 0; i < iters; ++i )
@@ -551,8 +566,10 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 			if( i < frames )
 				{
 				const int64_t t = tfirst + i, tn = min( t + 1, t1 - 1 );           // (the last frame requests itself again: nobody waits for it)
+				fidx = i;
 				if( t0 > 0 && i == 0 ) bins_of_frame( t, tn, set, std::true_type{} );
 				else bins_of_frame( t, tn, set, std::false_type{} );
+				if( role == 1 && ( ( i & 63 ) == 63 || i == frames - 1 ) ) flush_orphans( t - ( i & 63 ), ( i & 63 ) + 1 );
 				}
 			// one buffer set: nobody may write the next frame's E / O before both halves have read this one's.  Two sets: the next frame goes
 			// to the other set, whose readers (the frame before this one) passed the previous barrier
