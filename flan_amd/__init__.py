@@ -64,6 +64,7 @@ _SIGS = {
     "flanhip_synthesize_dev_fused": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp]),
     "flanhip_debug_synth_stages": (None, [_i32]),
     "flanhip_debug_kernel_variant": (None, [_i32, _i32]),
+    "flanhip_debug_resample_fft": (None, [_i32]),
     "flanhip_modify_time": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i32, _vp, _i64, _vp, _vp]),
     "flanhip_modify_time_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i32, _vp, _i64, _vp, _vp]),
     "flanhip_modify_time_dev_fused": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _vp, _i64, _vp, _i32, _vp, _vp]),

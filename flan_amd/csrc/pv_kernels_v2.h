@@ -57,7 +57,12 @@ struct Stamps
 		return t;
 		}
 	__device__ __forceinline__ void init() { for( int i = 0; i < 12; ++i ) acc[i] = 0; r_begin = realtime(); last = now(); t_begin = last; }
+#ifdef FLANHIP_STAMPS_CLOCK_ONLY
+	// clock-only form: the frame loop is the product's (no stamp, no fence inside it); only the wavefront's life is measured in both clocks
+	__device__ __forceinline__ void operator()( int ) const {}
+#else
 	__device__ __forceinline__ void operator()( int i ) { const unsigned long long t = now(); acc[i] += t - last; last = t; }
+#endif
 	__device__ __forceinline__ void flush( int lane )
 		{
 		const unsigned long long t_end = now(), r_end = realtime();

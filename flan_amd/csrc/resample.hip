@@ -16,6 +16,7 @@
 // parameters is refused.
 #include "flanhip_internal.h"
 #include "processors_common.h"
+#include "resample_fft.h"
 #include <cmath>
 #include <vector>
 #include <tuple>
@@ -176,6 +177,7 @@ struct Stage
 	const double * d_h = nullptr; int fl2 = 0;                                    // device tables, filled by get_stage_plan
 	const double * d_poly = nullptr; int poly_len = 0, poly_u_min = 0;             // the taps as the tuned kernels walk them: `up` phases (down == 1), or `down` interleaves (up == 1)
 	const double * d_bank = nullptr; int flt_len = 0, fracs = 0;
+	const cd * d_spec = nullptr;                                                  // up == 1, down == 2: FFT( taps ) / 4096 for k_resample_ols2 (resample_fft.h)
 	};
 
 static bool build_stages( double src, double dst, std::vector<Stage> & st )
@@ -360,7 +362,7 @@ static void spline_segments( const std::vector<Stage> & st, int k, int64_t chunk
 
 // device copies, cached for the process: low-pass taps per (device, cut-off, transition band, gain); interpolator banks per (device, rows or -1 for
 // the spline bank, third-band); the stage list with its pointers per (device, src, dst)
-struct DevTaps { double * d = nullptr; int fl2 = 0; double * d_poly = nullptr; int len = 0, u_min = 0; };   // d: h[2 fl2 + 1]; poly: see Stage
+struct DevTaps { double * d = nullptr; int fl2 = 0; double * d_poly = nullptr; int len = 0, u_min = 0; cd * d_spec = nullptr; };   // d: h[2 fl2 + 1]; poly: see Stage
 struct DevBank { double * d = nullptr; int flt_len = 0, fracs = 0; };
 static std::map<std::tuple<int, double, double, double, int, int>, DevTaps> g_dev_taps;
 static std::map<std::tuple<int, int, bool>, DevBank> g_dev_banks;
@@ -711,6 +713,65 @@ __global__ __launch_bounds__( FRAC_BLOCK ) void k_frac_spline( const double * __
 	out[j] = OutT( acc );
 	}
 
+// ---- tables of k_resample_ols2 (resample_fft.h), worked out in long double ----------------------------------------------------------
+static void ols_unit_circle( int n, std::vector<long double> & c, std::vector<long double> & sn )
+	{
+	c.resize( size_t( n ) ); sn.resize( size_t( n ) );
+	const long double two_pi = 6.283185307179586476925286766559005768L;
+	for( int m = 0; m < n; ++m ) { c[size_t( m )] = cosl( two_pi * m / n ); sn[size_t( m )] = sinl( two_pi * m / n ); }
+	}
+
+// spec[k] = ( 1 / N ) sum_t h[t] exp( -2 pi i k t / N ), k < N = 4096
+static void ols_filter_spectrum( const std::vector<double> & h, std::vector<cd> & spec )
+	{
+	std::vector<long double> c, sn;
+	ols_unit_circle( OLS_N, c, sn );
+	spec.resize( OLS_N );
+	for( int k = 0; k < OLS_N; ++k )
+		{
+		long double re = 0.0L, im = 0.0L;
+		for( size_t t = 0; t < h.size(); ++t )
+			{
+			const size_t m = ( size_t( k ) * t ) & ( OLS_N - 1 );
+			re += (long double) h[t] * c[m]; im -= (long double) h[t] * sn[m];
+			}
+		spec[size_t( k )] = cd{ double( re / OLS_N ), double( im / OLS_N ) };
+		}
+	}
+
+static std::map<int, cd*> g_ols_twiddles;                                         // per device
+static int ols_twiddles( const cd ** out )                                        // (caller holds g_rs_mutex)
+	{
+	int device = 0;
+	FLANHIP_CHECK( hipGetDevice( &device ) );
+	auto it = g_ols_twiddles.find( device );
+	if( it == g_ols_twiddles.end() )
+		{
+		std::vector<cd> tw( OlsTables::LEN );
+		auto fill = [&]( int at, int ns, int period )                            // [15][ns]: exp( -2 pi i r k / period )
+			{
+			std::vector<long double> c, sn;
+			ols_unit_circle( period, c, sn );
+			for( int r = 1; r < 16; ++r )
+				for( int k = 0; k < ns; ++k )
+					{
+					const size_t m = size_t( r * k ) % size_t( period );
+					tw[size_t( at + ( r - 1 ) * ns + k )] = cd{ double( c[m] ), double( -sn[m] ) };
+					}
+			};
+		fill( OlsTables::F1, 16, 256 ); fill( OlsTables::F2, 256, 4096 ); fill( OlsTables::I1, 8, 128 ); fill( OlsTables::I2, 128, 2048 );
+		cd * d = nullptr;
+		FLANHIP_CHECK( hipMalloc( &d, sizeof( cd ) * tw.size() ) );
+		FLANHIP_CHECK( hipMemcpy( d, tw.data(), sizeof( cd ) * tw.size(), hipMemcpyHostToDevice ) );
+		it = g_ols_twiddles.emplace( device, d ).first;
+		}
+	*out = it->second;
+	return FLANHIP_OK;
+	}
+
+// 0: always the direct sums (the checker's operation order); 1 (default): the FFT convolver where it applies
+static int g_resample_fft = 1;
+
 static int get_stage_plan( double src, double dst, const std::vector<Stage> ** out )
 	{
 	int device = 0;
@@ -760,10 +821,17 @@ static int get_stage_plan( double src, double dst, const std::vector<Stage> ** o
 					t.d_poly = t.d + nh;
 					FLANHIP_CHECK( hipMemcpy( t.d_poly, poly.data(), sizeof( double ) * poly.size(), hipMemcpyHostToDevice ) );
 					}
+				if( g.up == 1 && g.down == 2 && 2 * fl2 + 1 <= OLS_N / 2 + 1 )
+					{
+					std::vector<cd> spec;
+					ols_filter_spectrum( h, spec );
+					FLANHIP_CHECK( hipMalloc( &t.d_spec, sizeof( cd ) * spec.size() ) );
+					FLANHIP_CHECK( hipMemcpy( t.d_spec, spec.data(), sizeof( cd ) * spec.size(), hipMemcpyHostToDevice ) );
+					}
 				tt = g_dev_taps.emplace( tkey, t ).first;
 				}
 			const DevTaps & dt = tt->second;
-			g.d_h = dt.d; g.fl2 = dt.fl2; g.d_poly = dt.d_poly; g.poly_len = dt.len; g.poly_u_min = dt.u_min;
+			g.d_h = dt.d; g.fl2 = dt.fl2; g.d_poly = dt.d_poly; g.poly_len = dt.len; g.poly_u_min = dt.u_min; g.d_spec = dt.d_spec;
 			}
 		else if( g.kind == Stage::Frac )
 			{
@@ -794,6 +862,24 @@ static size_t rational_lds( int fl2, int up, int down, int & span )
 template<typename InT, typename OutT>
 static int launch_rational( const InT * d_in, int64_t n_in, const Stage & g, OutT * d_out, int64_t n_out, hipStream_t s )
 	{
+	// 2:1 from float to float (BASELINE config 5's 96 -> 48 kHz and the like): overlap-save FFT convolution, like the reference's block convolver
+	if constexpr( std::is_same<InT, float>::value && std::is_same<OutT, float>::value )
+		{
+		const int Lo = OLS_N / 2 - g.fl2;
+		if( g_resample_fft && g.d_spec && g.up == 1 && g.down == 2 && n_out >= 8 * int64_t( Lo ) )
+			{
+			const cd * tw = nullptr;
+				{
+				std::lock_guard<std::mutex> lock( g_rs_mutex );
+				if( int rc = ols_twiddles( &tw ) ) return rc;
+				}
+			const size_t lds = sizeof( cd ) * OLS_BUF;
+			FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( k_resample_ols2<InT, OutT> ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+			const int64_t blocks = ( n_out + 2 * int64_t( Lo ) - 1 ) / ( 2 * int64_t( Lo ) );
+			hipLaunchKernelGGL( ( k_resample_ols2<InT, OutT> ), dim3( (unsigned) blocks ), dim3( OLS_THREADS ), lds, s, d_in, n_in, g.d_spec, tw, g.fl2, d_out, n_out );
+			return FLANHIP_OK;
+			}
+		}
 	// the tuned kernels (ramp phases of 64 steps per owned output: the filter must span them all)
 	if( g.d_poly && g.poly_len - 1 >= 64 * ( RS_R - 1 ) )
 		{
@@ -955,6 +1041,8 @@ int64_t flanhip_resample_out_frames( int64_t num_frames, float src_rate, float d
 	// AudioConversions.cpp:22  format.num_frames *= new_sample_rate / get_sample_rate()   (Frame *= float)
 	return int64_t( int32_t( float( int32_t( num_frames ) ) * ( dst_rate / src_rate ) ) );
 	}
+
+void flanhip_debug_resample_fft( int on ) { g_resample_fft = on; }
 
 int flanhip_resample_dev( const float * d_in, int64_t ch, int64_t n, float src_rate, float dst_rate, float * d_out, void * stream )
 	{

@@ -133,6 +133,10 @@ void flanhip_debug_synth_stages(int mask);
  * dft 4096 analysis / synthesis; variant 0 = the round-1 kernel, the library's default otherwise).  Layout-changing like
  * FLANHIP_TARGET_CHAINS: set it before sizing a workspace.  A/B runs only. */
 void flanhip_debug_kernel_variant(int which, int variant);
+/* Bench/diagnostic knob: 1 (default) = Audio::resample's 2:1 block convolver runs as fp64 overlap-save FFT convolution (the reference's
+ * own method, r8brain/CDSPBlockConvolver.h:242-344) for float streams of at least 8 blocks; 0 = always the direct fp64 sums in the checker's
+ * operation order (what short inputs and the fp64 streams inside chains use anyway). */
+void flanhip_debug_resample_fft(int on);
 
 /* ---- PV frame processors ------------------------------------------------------------------------------------- */
 /* modify_time_base (PV/PVModify.cpp:307-362, linear Interpolator): mod_seconds is the sampled time map float[F][bins]

@@ -97,10 +97,14 @@ def test_analysis_parity(fa, name, ch, n, W, hop, dft, kind):
         assert np.array_equal(got[..., 0], ref[..., 0])
         return
     assert rel_m <= 1e-5
-    assert wrms_f <= 2e-3
+    assert wrms_f <= 5e-4      # measured 2e-5 .. 3.3e-4 Hz (the largest at dft 32, where a last-bit change of the phase is the most Hz)
     if kind == "noise":
         assert turns <= max(3, got[..., 0].size // 100000)
-        assert same >= 0.85     # informational floor; the binding criteria are rel_m and the weighted df above
+        # share of f words that are bit for bit the oracle's.  What is left differs by one rounding of the transform (two FFTs in two operation
+        # orders); how many f words that flips grows with analysis_rate / bin width, hence the floors by shape (measured: 0.990-0.997 at
+        # hop >= 512 and dft >= 2048, 0.984 at hop 256, 0.971 at hop 128 or dft 512, 0.96 / 0.90 / 0.86 at dft 256 / 64 / 32)
+        floor = 0.985 if ( hop >= 512 and dft >= 2048 ) else 0.98 if ( hop >= 256 and dft >= 1024 ) else 0.965 if dft >= 512 else 0.95 if dft >= 256 else 0.85
+        assert same >= floor
 
 
 @pytest.mark.parametrize("name,ch,n,W,hop,dft,kind", CASES, ids=[c[0] for c in CASES])

@@ -209,3 +209,41 @@ def test_resample_against_the_real_r8brain(fa, tag):
     worst = np.abs(got.astype(np.float64) - y.astype(np.float64)).max()
     print("\n[%s vs real r8brain] bit-identical %.5f  worst %.2e" % (tag, same, worst))
     assert same >= 0.999 and worst <= 1.2e-7
+
+
+@pytest.mark.parametrize("ch,n", [(1, 19808), (1, 19810), (1, 39615), (2, 24760), (3, 9907), (1, 250000)])
+def test_resample_fft_convolver_against_the_direct_sums(fa, ch, n):
+    """the 2:1 block convolver as fp64 overlap-save FFT convolution (k_resample_ols2, what streams of 8 blocks and more take) against the
+    direct fp64 sums in the checker's order (flanhip_debug_resample_fft(0)): stream lengths at the switch-over, at whole numbers of block
+    pairs, one past them, ragged; >= 99.9 % of the samples bit-identical, the rest one fp32 ulp at unit scale."""
+    x = O.noise(ch, n, seed=n + ch)
+    try:
+        fa.lib.flanhip_debug_resample_fft(0)
+        direct = fa.resample(x, 96000.0, 48000.0)
+    finally:
+        fa.lib.flanhip_debug_resample_fft(1)
+    got = fa.resample(x, 96000.0, 48000.0)
+    assert got.shape == direct.shape
+    same = np.mean(got.view(np.uint32) == direct.view(np.uint32))
+    worst = np.abs(got.astype(np.float64) - direct.astype(np.float64)).max()
+    print("\n[fft vs direct %dx%d] bit-identical %.5f  worst %.2e" % (ch, n, same, worst))
+    assert same >= 0.999 and worst <= 1.2e-7
+    assert np.array_equal(direct.view(np.uint32), O.resample_2to1(x, 96000.0, 48000.0).view(np.uint32))    # the direct kernel IS the checker's sum
+
+
+def test_config5_full_size_against_the_real_r8brain(fa):
+    """BASELINE config 5's resample at its FULL size (stereo 60 s, 96 -> 48 kHz) against what the reference's vendored r8brain made of the same
+    noise (tests/golden/ref_made/r8brain_config5_full.npz: six 32768-sample windows -- head, middle and tail of both channels, so the start-up,
+    the cross-channel bleed at the channel boundary and the zero-flushed end are all in -- made by make_ref_made.py --config5-full)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_made", "r8brain_config5_full.npz"))
+    x = O.noise(int(g["shape_in"][0]), int(g["shape_in"][1]), int(g["seed"]))
+    got = fa.resample(x, float(g["rates"][0]), float(g["rates"][1]))
+    assert got.shape == tuple(int(v) for v in g["shape_out"])
+    for i, (c, a) in enumerate(g["windows"]):
+        ref = g["w%d" % i]
+        cur = got[int(c), int(a):int(a) + ref.size]
+        same = np.mean(cur.view(np.uint32) == ref.view(np.uint32))
+        worst = np.abs(cur.astype(np.float64) - ref.astype(np.float64)).max()
+        print("\n[config 5 full size, channel %d from %d] bit-identical %.5f  worst %.2e" % (c, a, same, worst))
+        assert same >= 0.999 and worst <= 1.2e-7

@@ -7,6 +7,7 @@ R=$(cd "$(dirname "$0")/../.." && pwd)
 KIND=${1:-stamps}
 DEF=-DFLANHIP_STAMPS
 [ "$KIND" = ablations ] && DEF=-DFLANHIP_ABLATIONS
+[ "$KIND" = clock ] && DEF="-DFLANHIP_STAMPS -DFLANHIP_STAMPS_CLOCK_ONLY"   # the product's frame loop, only the wavefront's life stamped in both clocks (tools/stamp_report.py)
 [ "$KIND" = packed ] && DEF="-DFLANHIP_DIAG_PACKED"     # the product's conversions.hip is built WITHOUT packed fp32 (flan_amd/build.py); this variant with
 NOPK="-Xclang -target-feature -Xclang -packed-fp32-ops"
 [ "$KIND" = packed ] && NOPK=""
