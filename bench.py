@@ -239,6 +239,18 @@ def main():
 
     # device warm-up (not the W warm-up steps of the contract, which follow): a GPU that has been idle needs tens of milliseconds of
     # load before its clocks settle; without this a short run measures the ramp, not the kernels
+    # the cold figure first (what `--steps 5 --warmup 1 --preroll-ms 0` measures on a just-woken GPU): reported beside the steady-state value,
+    # never as it
+    cold = None
+    if args.preroll_ms > 0 and not distributed:
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        cold_s = (time.perf_counter() - t0) / 5
+        cold = {"steps": 5, "warmup": 1, "ms_per_step": round(cold_s * 1e3, 4), "frames_per_s": round(frames_per_step / cold_s, 1)}
     preroll_steps = 0
     if args.preroll_ms > 0:
         t_end = time.perf_counter() + args.preroll_ms * 1e-3
@@ -259,6 +271,17 @@ def main():
         elapsed = sharding.max_over_ranks(dist, elapsed, ctl_dev)
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * frames_per_step * args.steps / elapsed
+    # "hipEvent-timed, median of >= 20 runs" -- the same step, each one bracketed by events on the launch stream, reported
+    # beside the contract's barrier-to-barrier mean over K steps
+    n_med = max(20, min(args.steps, 200))
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_med)]
+    for e0, e1 in evs:
+        e0.record()
+        step()
+        e1.record()
+    torch.cuda.synchronize()
+    per = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+    step_ms_median = per[len(per) // 2]
 
     # per-kernel timing with events on the launch stream (rank 0 only), inside the same analyse -> synthesise sequence as the
     # timed region: events bracket k_analyze, the pre-pass (k_phase_sums unless fused, k_phase_scan), k_synthesize and
@@ -293,18 +316,22 @@ def main():
         # from the committed PMC profile of this same workload and build (tools/scripts/profile_bench.sh -> profiles/r02_hbm_traffic.json:
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, with the unit and gfx950 corrections the file explains) and is
         # labelled with its source; null for any other workload shape
+        # the profile carries the hash of the kernel sources it was taken on (flan_amd/build.py: kernel_source_hash): a profile of other
+        # kernels than the ones running is not quoted (traffic null, the reason in traffic_source)
         traffic, traffic_source = None, None
         try:
             if ch == 8 and abs(args.seconds - 60.0) < 1e-9 and DFT == 2048 and HOP == 512 and WINDOW == 2048:
-                for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
-                    path = os.path.join(ROOT, "profiles", name)
-                    if os.path.exists(path):
-                        with open(path) as fh:
-                            traffic = json.load(fh)[kname]["traffic_bytes"]
-                        traffic_source = "profiles/" + name
-                        break
-        except Exception:
-            traffic, traffic_source = None, None
+                from flan_amd.build import kernel_source_hash
+                path = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
+                with open(path) as fh:
+                    prof = json.load(fh)
+                if prof.get("kernel_source_hash") == kernel_source_hash():
+                    traffic = prof[kname]["traffic_bytes"]
+                    traffic_source = "profiles/r03_hbm_traffic.json"
+                else:
+                    traffic_source = "profiles/r03_hbm_traffic.json was taken on other kernel sources (%s, now %s): not quoted" % (str(prof.get("kernel_source_hash"))[:12], kernel_source_hash()[:12])
+        except Exception as e:
+            traffic, traffic_source = None, "no traffic profile: " + repr(e)
         # what a plain device-to-device copy of the same number of bytes reaches on this box (quote the measured
         # copy rate beside the 8 TB/s spec); read + written bytes, like the algorithmic figure
         copy_gbs = None
@@ -331,7 +358,25 @@ def main():
 
     # ---- the output-reassembly all-gather of the north star, outside the metric: on its own, and overlapped with the compute ----
     if distributed and not args.no_gather and not share_gpu:
+        # every side buffer is allocated BEFORE the first collective and the ranks agree (one all-reduce) that all of them got theirs: a rank
+        # that cannot allocate would otherwise leave the others waiting in a collective for ever.  Past that point nothing is caught: an
+        # error inside a collective ends the rank, and the launcher ends the job -- a failed job, not a hung one.
+        chunks = max(1, min(args.gather_chunks, ch))
+        while ch % chunks:
+            chunks -= 1
+        k = ch // chunks
+        side_ok, side_err = 1, None
         try:
+            side = torch.cuda.Stream(device=dev)
+            outs = [out, torch.empty_like(out)]
+            finals = [torch.empty((world * ch, F * HOP), dtype=torch.float32, device=dev) for _ in range(2)]
+            wss = [torch.empty(fa.synthesize_workspace_bytes(k, F, BINS, SR, ar, WINDOW), dtype=torch.uint8, device=dev) for _ in range(chunks)]
+        except Exception as e:
+            side_ok, side_err = 0, repr(e)
+        all_ok = sharding.min_over_ranks(dist, side_ok, ctl_dev) >= 1
+        if not all_ok:
+            extra["allgather"] = {"error": "a rank could not allocate the gather buffers: " + str(side_err)}
+        else:
             nranks = dist.get_world_size()
             for _ in range(2):
                 gathered = sharding.gather_output(dist, out, world)
@@ -347,14 +392,6 @@ def main():
             # overlapped: batch i's output travels (one batch of point-to-point operations into the final channel-major buffer, on a side
             # stream) while batch i + 1 is analysed and synthesised -- two output buffers in turn; with --gather-chunks K > 1 the rank's
             # channels are additionally cut into K chunks per batch, each sent as soon as it is done (smaller launches: slower compute)
-            chunks = max(1, min(args.gather_chunks, ch))
-            while ch % chunks:
-                chunks -= 1
-            k = ch // chunks
-            side = torch.cuda.Stream(device=dev)
-            outs = [out, torch.empty_like(out)]
-            finals = [torch.empty((world * ch, F * HOP), dtype=torch.float32, device=dev) for _ in range(2)]
-            wss = [torch.empty(fa.synthesize_workspace_bytes(k, F, BINS, SR, ar, WINDOW), dtype=torch.uint8, device=dev) for _ in range(chunks)]
             pending = [[], []]
 
             def step_with_gather(i):
@@ -401,8 +438,6 @@ def main():
                                   "overlapped_step_ms": round(tov * 1e3, 4), "channel_chunks": chunks,
                                   "overlap": "gather of batch i (side stream, p2p batch into the final layout) under the compute of batch i + 1"}
             del finals, outs, wss
-        except Exception as e:                       # (an error every rank raises alike: the headline line must survive a side measurement)
-            extra["allgather"] = {"error": repr(e)}
 
     # the host-buffer C ABI (flanhip_analyze / flanhip_synthesize): upload, kernels, download -- for DESIGN.md, never the metric
     if rank == 0 and args.pcie:
@@ -458,7 +493,15 @@ def main():
         }
         if share_gpu:
             line["rehearsal"] = "FLAN_BENCH_SHARE_GPU=1: %d ranks on one GPU, gloo control plane, no RCCL gather" % world
-        line["device_warmup"] = {"preroll_ms": args.preroll_ms, "preroll_steps": preroll_steps}
+        line["ms_per_step_median"] = round(step_ms_median, 4)          # median of >= 20 event-timed steps; ms_per_step: the K steps between barriers
+        line["value_median"] = round(world * frames_per_step / (step_ms_median * 1e-3), 1) if world == 1 else None
+        line["value_cold"] = cold["frames_per_s"] if cold else None       # a just-woken GPU, 5 steps after 1 (no clock pre-roll)
+        ag = extra.get("allgather") or {}
+        # what the N-GPU job delivers with the north star's output reassembly inside: the same frames / the time including the gather
+        line["value_gather_overlapped"] = ag.get("frames_per_s_gather_overlapped")
+        line["value_compute_then_gather"] = ag.get("frames_per_s_compute_then_gather")
+        line["rccl_nranks"] = ag.get("nranks")
+        line["device_warmup"] = {"preroll_ms": args.preroll_ms, "preroll_steps": preroll_steps, "cold": cold}
         line.update(extra)
         print(json.dumps(line), flush=True)
     if distributed:

@@ -22,6 +22,19 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 EXTRA = {"conversions.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]}
 
 
+def kernel_source_hash():
+    """SHA-256 over what the conversion kernels are built from (the .h / .hip sources of csrc that conversions.hip includes, and this
+    file with its flags): profiles/ stamp their numbers with it, and bench.py quotes a profile only for the kernels it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + ["conversions.hip", "core.hip"]
+    for name in names:
+        with open(os.path.join(CSRC, name), "rb") as fh:
+            h.update(name.encode() + b"\0" + fh.read())
+    h.update(" ".join(FLAGS[:-2] + EXTRA.get("conversions.hip", [])).encode())      # (without the -I paths: they differ between machines)
+    return h.hexdigest()
+
+
 def _stale(obj, deps):
     if not os.path.exists(obj):
         return True
@@ -40,12 +53,23 @@ def build(verbose=False, force=False):
             continue
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [path] + headers):
-            cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + ["-c", path, "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + ["-c", path, "-o", obj]
+        # the command line is part of what an object is: one built with other options (an older EXTRA, another HIPCC) is stale too
+        stamp, line = obj + ".flags", " ".join(cmd)
+        same_flags = os.path.exists(stamp) and open(stamp).read() == line
+        if force or not same_flags or _stale(obj, [path] + headers):
             if verbose:
-                print(" ".join(cmd), flush=True)
-            procs.append((src, subprocess.Popen(cmd)))
-    failed = [s for s, p in procs if p.wait() != 0]
+                print(line, flush=True)
+            if os.path.exists(stamp):
+                os.remove(stamp)
+            procs.append((src, subprocess.Popen(cmd), stamp, line))
+    failed = []
+    for src, proc, stamp, line in procs:
+        if proc.wait() != 0:
+            failed.append(src)
+        else:
+            with open(stamp, "w") as f:
+                f.write(line)
     if failed:
         raise RuntimeError("hipcc failed for: " + ", ".join(failed))
     if force or procs or _stale(LIB, objs):

@@ -1,5 +1,6 @@
-// cf_type.h -- the complex / pair type of the kernels: a native 2-float vector, so that elementwise arithmetic on it
-// compiles to gfx950's packed fp32 instructions (v_pk_add_f32, v_pk_mul_f32, v_pk_fma_f32: two results per issue slot).
+// cf_type.h -- the complex / pair type of the kernels: a native 2-float vector (an aligned register pair: 8-byte LDS and global accesses
+// take it whole).  conversions.hip is compiled WITHOUT packed fp32 (flan_amd/build.py): on gfx950 a v_pk_*_f32 occupies the SIMD for
+// two plain instructions' time (profiles/r03_a_issue_model.txt), so element-wise arithmetic on a cf is two plain instructions there.
 #pragma once
 namespace flanhip {
 typedef float cf __attribute__(( ext_vector_type( 2 ) ));

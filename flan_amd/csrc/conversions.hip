@@ -13,15 +13,13 @@
 namespace flanhip {
 
 static int g_synth_stage_mask = 0xF;             // flanhip_debug_synth_stages(): 1 sums, 2 scan, 4 main, 8 fix-up
-// flanhip_debug_kernel_variant(): which dft 2048 kernel generation a call launches (A/B runs in one process).
-// analysis: 0 = round-1 kernel; 4 (the default) / 6 / 7 = v2, 8 / 16 / 4 bins at a time (all in 8-wave blocks, 2 wavefronts per SIMD:
-// 12-wave blocks at <= 168 VGPRs were measured and dropped)
-// synthesis (register-accumulator hops): 0 = round-1 kernel; 1 (the default) = v2; 2 = v2 behind the scan kernel even where it could work
-// out its own carries; 9 = v2 with plain instead of non-temporal row loads
+// flanhip_debug_kernel_variant(): dft 2048 has ONE kernel generation (pv_kernels_v2.h); the variant numbers of `which` 0 / 1 select the
+// phase-ablated instantiations of diagnostic builds (FLANHIP_ABLATIONS: 101 ... for the analysis, 102 ... for the synthesis) and, for the
+// synthesis, 2 = behind the scan kernel even where it could work out its own carries.  dft 4096 keeps its round-1 kernels as the A/B
+// predecessor (`which` 2 / 3, variant 0) -- they are also what windows above 2048 run.
 static int g_ana_variant = 4, g_syn_variant = 1;
 static int g_syn11_variant = 1;          // dft 4096 synthesis, window <= 2048, hop 256 / 512 / 1024: 1 = teams of two wavefronts (pv_kernels_eo.h), 0 = the round-1 kernel
 static int g_ana11_variant = 1;          // dft 4096, window <= 2048: 1 = teams of two wavefronts, two 1024-point transforms per frame (pv_kernels_eo.h), 0 = the round-1 kernel
-static int ana_variant_waves( int ) { return 8; }
 static constexpr size_t kMaxLds = 160 * 1024;   // gfx950: 160 KiB LDS per CU, one workgroup may take all of it
 
 // chains: the chains a block walks (one per wavefront; or ONE, walked by a team of several wavefronts, see k_analyze)
@@ -59,7 +57,7 @@ static int run_analyze( const AnalyzeParams & p, hipStream_t s )
 // dft 4096: 32 complex points per lane need ~400 registers: 4-wave blocks, ONE wavefront per SIMD, so that the compiler may use
 // the 256 AGPRs as spill space instead of scratch memory (6-wave blocks at 256 VGPRs spilled 400-850 B per lane to scratch and
 // ran synthesis 3.3x slower); 1024 resident chains.
-static constexpr int kAnaWaves10 = 8, kSynWaves10 = 8, kWaves11 = 4;
+static constexpr int kSynWaves10 = 8, kWaves11 = 4;
 static constexpr int kTeamWaves12 = 8;           // generic kernels at dft 8192: one chain per block of 8 wavefronts (8 bins per thread), one block per CU
 // chains the chip holds at once for the generic kernels (one chain per team from dft 1024 up, LDS decides how many teams a CU takes)
 static int generic_target_chains( int dft ) { return dft >= 8192 ? 256 : dft == 4096 ? 512 : dft == 2048 ? 1024 : 4096; }
@@ -67,7 +65,6 @@ static int fast_target_chains( int dft, bool synth )
 	{
 	if( const char * env = std::getenv( "FLANHIP_TARGET_CHAINS" ) ) { const int v = std::atoi( env ); if( v > 0 ) return v; }
 	if( dft == 4096 ) return 256 * 4;
-	if( !synth ) return 256 * ana_variant_waves( g_ana_variant );
 	return 256 * 8;
 	}
 
@@ -90,9 +87,7 @@ static int run_analyze_v2_variant( int v, const AnalyzeParams & p, const FastTab
 	{
 	switch( v )
 		{
-		case 4: return run_analyze_v2<8, SUMS, 8>( p, tb, s );
-		case 6: return run_analyze_v2<8, SUMS, 16>( p, tb, s );
-		case 7: return run_analyze_v2<8, SUMS, 4>( p, tb, s );
+		default: return run_analyze_v2<8, SUMS, 8>( p, tb, s );                    // 8 bins at a time (16 and 4 were measured and dropped)
 #ifdef FLANHIP_ABLATIONS
 		case 101: return run_analyze_v2<8, SUMS, 8, 1>( p, tb, s );
 		case 102: return run_analyze_v2<8, SUMS, 8, 2>( p, tb, s );
@@ -115,7 +110,6 @@ static int run_analyze_v2_variant( int v, const AnalyzeParams & p, const FastTab
 		case 868: return run_analyze_v2<8, SUMS, 8, 768>( p, tb, s );
 #endif
 		}
-	return FLANHIP_ERR_UNSUPPORTED;
 	}
 
 // dft 4096 with window <= 2048 as two 1024-point register transforms per frame (pv_kernels_eo.h): 8-wave blocks, 160 KB of LDS
@@ -221,10 +215,9 @@ static int run_synth_eo_team( const SynthParams & p, const FastTables & tb, hipS
 template<int LOG2C>
 static int run_synth_fast_hop( const SynthParams & p, const FastTables & tb, hipStream_t s )
 	{
-	if( LOG2C == 10 && g_syn_variant != 0 && synth_fast_kind( 2 << LOG2C, p.window_size, p.hop ) == 1 )
+	if( LOG2C == 10 && synth_fast_kind( 2 << LOG2C, p.window_size, p.hop ) == 1 )
 		{
 		// v2: the register-accumulator hops of dft 2048
-		if( g_syn_variant == 9 && p.hop == 512 ) return run_synth_v2<8, 4, 1>( p, tb, s );       // A/B: plain instead of non-temporal row loads
 #ifdef FLANHIP_ABLATIONS
 		if( g_syn_variant == 102 && p.hop == 512 ) return run_synth_v2<8, 4, 2>( p, tb, s );
 		if( g_syn_variant == 104 && p.hop == 512 ) return run_synth_v2<8, 4, 4>( p, tb, s );
@@ -253,12 +246,12 @@ static int run_synth_fast_hop( const SynthParams & p, const FastTables & tb, hip
 		}
 	if( synth_fast_kind( 2 << LOG2C, p.window_size, p.hop ) == 2 )                // any other hop <= window: ring accumulator in LDS
 		return run_synth_fast<LOG2C, ( LOG2C == 10 ? kSynWaves10 : kRingWaves11 ), 0>( p, tb, s );
-	switch( p.hop / 128 )
+	if constexpr( LOG2C == 11 ) switch( p.hop / 128 )                              // (dft 2048's register-accumulator hops are all v2's, above)
 		{
-		case 1: return run_synth_fast<LOG2C, ( LOG2C == 10 ? kSynWaves10 : kWaves11 ), 1>( p, tb, s );
-		case 2: return run_synth_fast<LOG2C, ( LOG2C == 10 ? kSynWaves10 : kWaves11 ), 2>( p, tb, s );
-		case 4: return run_synth_fast<LOG2C, ( LOG2C == 10 ? kSynWaves10 : kWaves11 ), 4>( p, tb, s );
-		case 8: return run_synth_fast<LOG2C, ( LOG2C == 10 ? kSynWaves10 : kWaves11 ), 8>( p, tb, s );
+		case 1: return run_synth_fast<LOG2C, kWaves11, 1>( p, tb, s );
+		case 2: return run_synth_fast<LOG2C, kWaves11, 2>( p, tb, s );
+		case 4: return run_synth_fast<LOG2C, kWaves11, 4>( p, tb, s );
+		case 8: return run_synth_fast<LOG2C, kWaves11, 8>( p, tb, s );
 		}
 	return FLANHIP_ERR_UNSUPPORTED;
 	}
@@ -268,7 +261,20 @@ static bool synth_fast_ok( int dft, int W, int hop ) { return synth_fast_kind( d
 // flanhip_analyze_dev_fused always leaves convert_to_audio's pre-pass in the workspace.  The tuned kernels and the generic
 // ones up to dft 2048 accumulate the sums while they have every f in a register; the generic kernels for dft >= 4096 keep no
 // such state (64 bins per lane), so there the pre-pass kernel itself is run on the fresh PV on the analysis' behalf.
+static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft, flanhip_MF * d_out, void * d_fused_ws, hipStream_t s, bool * left_group_sums );
+
+// The note "this workspace holds group totals too" (which lets the dft 2048 synthesis skip its scan kernel) is written only once the producing
+// launch has been accepted, and withdrawn before it is attempted: a launch that fails leaves the workspace marked as needing the scan.
 int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft, flanhip_MF * d_out, void * d_fused_ws, hipStream_t s )
+	{
+	bool left_group_sums = false;
+	if( d_fused_ws ) note_workspace_producer( d_fused_ws, 0 );
+	const int rc = launch_analyze_body( d_audio, ch, n, sr, W, hop, dft, d_out, d_fused_ws, s, &left_group_sums );
+	if( !rc && d_fused_ws && left_group_sums ) note_workspace_producer( d_fused_ws, 1 );
+	return rc;
+	}
+
+static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft, flanhip_MF * d_out, void * d_fused_ws, hipStream_t s, bool * left_group_sums )
 	{
 	FLANHIP_REQUIRE( d_audio && d_out, FLANHIP_ERR_INVALID_ARG, "null buffer" );
 	FLANHIP_REQUIRE( ch > 0 && n >= 0 && W >= 2 && hop >= 1 && sr > 0.0f, FLANHIP_ERR_INVALID_ARG, "bad sizes" );
@@ -310,10 +316,10 @@ int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int 
 			p.nan_out = reinterpret_cast<int*>( reinterpret_cast<char*>( d_fused_ws ) + lay.carry_bytes + lay.head_bytes );
 			}
 		// the dft 2048 kernel also leaves one total per group of 8 chains: the synthesis kernel then needs no scan kernel in front of it
-		const bool groups_too = fast && dft == 2048 && g_ana_variant != 0 && kernel_sums;
+		const bool groups_too = fast && dft == 2048 && kernel_sums;
 		p.group_sums = groups_too ? reinterpret_cast<double*>( reinterpret_cast<char*>( d_fused_ws ) + lay.group_offset ) : nullptr;
 		p.groups_per_channel = lay.groups_per_channel;
-		note_workspace_producer( d_fused_ws, groups_too ? 1 : 0 );
+		*left_group_sums = groups_too;
 		}
 	auto prepass_on_behalf = [&]() -> int                                         // for an analysis kernel that keeps no sums (none does at present)
 		{
@@ -335,7 +341,7 @@ int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int 
 	if( fast )
 		{
 		FastTables tb{ plan->d_tw1f, plan->d_tw3f, plan->d_tw2 };
-		if( dft == 2048 && g_ana_variant != 0 ) return p.sums ? run_analyze_v2_variant<true>( g_ana_variant, p, tb, s ) : run_analyze_v2_variant<false>( g_ana_variant, p, tb, s );
+		if( dft == 2048 ) return p.sums ? run_analyze_v2_variant<true>( g_ana_variant, p, tb, s ) : run_analyze_v2_variant<false>( g_ana_variant, p, tb, s );
 		if( dft == 4096 && W <= 2048 && g_ana11_variant != 0 )
 			{
 			// the fused round trip (with chain sums): teams of two wavefronts, two E / O buffer sets, one barrier per frame (0.34 ms for 8 ch x 60 s;
@@ -346,8 +352,7 @@ int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int 
 			if( g_ana11_variant == 3 ) return p.sums ? run_analyze_eo_team<4, true, 1, true>( p, tb, s ) : run_analyze_eo_team<4, false, 2, true>( p, tb, s );
 			return run_analyze_eo_team<4, true, 2, true>( p, tb, s );
 			}
-		if( p.sums ) return dft == 2048 ? run_analyze_fast<10, kAnaWaves10, true>( p, tb, s ) : run_analyze_fast<11, kWaves11, true>( p, tb, s );
-		return dft == 2048 ? run_analyze_fast<10, kAnaWaves10, false>( p, tb, s ) : run_analyze_fast<11, kWaves11, false>( p, tb, s );
+		return p.sums ? run_analyze_fast<11, kWaves11, true>( p, tb, s ) : run_analyze_fast<11, kWaves11, false>( p, tb, s );
 		}
 
 	int rc = FLANHIP_ERR_UNSUPPORTED;
@@ -440,7 +445,7 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	const int stages = prepass_only ? 3 : g_synth_stage_mask;
 	// The dft 2048 analysis kernel leaves group totals beside the chain sums (launch_analyze notes that for this workspace): the dft 2048
 	// synthesis kernel then works out its own carries and the scan kernel is not launched.  Any other producer or shape: the scan runs.
-	const bool self_carry = presummed == 1 && !prepass_only && !d_carry_in && !d_total_out && g_syn_variant != 0 && g_syn_variant != 2 && lay.dft == 2048
+	const bool self_carry = presummed == 1 && !prepass_only && !d_carry_in && !d_total_out && g_syn_variant != 2 && lay.dft == 2048
 		&& synth_fast_kind( lay.dft, W, lay.hop ) == 1 && workspace_producer( d_ws ) == 1;
 	if( self_carry )
 		{

@@ -163,7 +163,11 @@ static std::map<const void*, int> g_ws_producer;
 void note_workspace_producer( const void * d_ws, int kind )
 	{
 	std::lock_guard<std::mutex> lock( g_ws_mutex );
-	if( kind ) g_ws_producer[d_ws] = kind; else g_ws_producer.erase( d_ws );
+	if( !kind ) { g_ws_producer.erase( d_ws ); return; }
+	// addresses the library never sees freed (a caller's own allocator) would pile up: forgetting everything is always safe -- a workspace
+	// without a note gets the scan kernel
+	if( g_ws_producer.size() >= 1024 ) g_ws_producer.clear();
+	g_ws_producer[d_ws] = kind;
 	}
 int workspace_producer( const void * d_ws )
 	{
@@ -242,6 +246,7 @@ int flanhip_malloc( void ** dptr, size_t bytes )
 int flanhip_free( void * dptr )
 	{
 	if( !dptr ) return FLANHIP_OK;
+	note_workspace_producer( dptr, 0 );                                               // (a freed address may come back as somebody else's workspace)
 	FLANHIP_CHECK( hipFree( dptr ) );
 	return FLANHIP_OK;
 	}

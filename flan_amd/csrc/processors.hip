@@ -55,17 +55,17 @@ __global__ __launch_bounds__( 256 ) void k_modify_time( const MFd * in, int num_
 	const float * mp = mod + bin;
 	const int Fo32 = int( Fo );
 	auto clear = [&]( int x0, int x1 ) { for( int x = x0; x < x1; ++x ) op[int64_t( x ) * bins] = MFd{ 0.0f, 0.0f }; };   // :317 clear_buffer
-	MFd lMF = ip[( f0 - 1 ) * bins];
-	float lFrame = time_to_frame( mp[( f0 - 1 ) * bins], sr, hop );
+	MFd mf_l = ip[( f0 - 1 ) * bins];
+	float at_l = time_to_frame( mp[( f0 - 1 ) * bins], sr, hop );
 	if( sequential ) clear( 0, Fo32 );
-	else if( f0 == 1 ) clear( 0, min( max( int( ceilf( lFrame ) ), 0 ), Fo32 ) );   // before the first pair's interval
+	else if( f0 == 1 ) clear( 0, min( max( int( ceilf( at_l ) ), 0 ), Fo32 ) );   // before the first pair's interval
 	for( int64_t frame = f0; frame < f1; ++frame )                                  // :328
 		{
-		const MFd rMF = ip[frame * bins];
-		const float rFrame = time_to_frame( mp[frame * bins], sr, hop );            // :331
-		const bool forward = rFrame > lFrame;                                       // :332
-		const int start_frame = int( forward ? ceilf( lFrame ) : floorf( lFrame ) ); // :334
-		const int end_frame   = int( forward ? ceilf( rFrame ) : floorf( rFrame ) ); // :335
+		const MFd mf_r = ip[frame * bins];
+		const float at_r = time_to_frame( mp[frame * bins], sr, hop );            // :331
+		const bool forward = at_r > at_l;                                       // :332
+		const int start_frame = int( forward ? ceilf( at_l ) : floorf( at_l ) ); // :334
+		const int end_frame   = int( forward ? ceilf( at_r ) : floorf( at_r ) ); // :335
 		if( !sequential )
 			{
 			// forward or empty; frames outside [0, Fo) are skipped by :342 before anything is computed, so clamping is exact
@@ -73,14 +73,14 @@ __global__ __launch_bounds__( 256 ) void k_modify_time( const MFd * in, int num_
 			int x = min( max( start_frame, 0 ), Fo32 );
 			for( ; x < x1; ++x )                                                    // :340
 				{
-				const float mix = interpolate( interp, ( float( x ) - lFrame ) / ( rFrame - lFrame ) );    // :344 interp( ... ), Interpolator.cpp:14-101
-				const float w0 = ( 1.0f - mix ) * lMF.m;
-				const float w1 = mix * rMF.m;
-				const float totalWeight = w0 + w1;
-				const float weightedFreqSum = w0 * lMF.f + w1 * rMF.f;
-				if( totalWeight == 0.0f ) break;                                    // :350-351 (`return` leaves this frame pair)
+				const float mix = interpolate( interp, ( float( x ) - at_l ) / ( at_r - at_l ) );    // :344 interp( ... ), Interpolator.cpp:14-101
+				const float share_l = ( 1.0f - mix ) * mf_l.m;
+				const float share_r = mix * mf_r.m;
+				const float weight = share_l + share_r;
+				const float freq_by_weight = share_l * mf_l.f + share_r * mf_r.f;
+				if( weight == 0.0f ) break;                                    // :350-351 (`return` leaves this frame pair)
 				const MFd o = { 0.0f, 0.0f };                                       // the cleared output MF this pair alone reaches
-				op[int64_t( x ) * bins] = MFd{ o.m + totalWeight, ( o.f * o.m + weightedFreqSum ) / ( o.m + totalWeight ) };   // :354-355
+				op[int64_t( x ) * bins] = MFd{ o.m + weight, ( o.f * o.m + freq_by_weight ) / ( o.m + weight ) };   // :354-355
 				}
 			clear( x, x1 );                                                         // frames the pair left untouched
 			}
@@ -93,21 +93,21 @@ __global__ __launch_bounds__( 256 ) void k_modify_time( const MFd * in, int num_
 			const int x_stop  = forward ? min( end_frame, Fo32 ) : max( end_frame, -1 );
 			for( int x = x_first; forward ? x < x_stop : x > x_stop; x += step )
 				{
-				const float mix = interpolate( interp, ( float( x ) - lFrame ) / ( rFrame - lFrame ) );    // :344 interp( ... ), Interpolator.cpp:14-101
-				const float w0 = ( 1.0f - mix ) * lMF.m;
-				const float w1 = mix * rMF.m;
-				const float totalWeight = w0 + w1;
-				const float weightedFreqSum = w0 * lMF.f + w1 * rMF.f;
-				if( totalWeight == 0.0f ) break;                                    // :350-351
+				const float mix = interpolate( interp, ( float( x ) - at_l ) / ( at_r - at_l ) );    // :344 interp( ... ), Interpolator.cpp:14-101
+				const float share_l = ( 1.0f - mix ) * mf_l.m;
+				const float share_r = mix * mf_r.m;
+				const float weight = share_l + share_r;
+				const float freq_by_weight = share_l * mf_l.f + share_r * mf_r.f;
+				if( weight == 0.0f ) break;                                    // :350-351
 				MFd o = op[int64_t( x ) * bins];
-				o.f = ( o.f * o.m + weightedFreqSum ) / ( o.m + totalWeight );      // :354
-				o.m += totalWeight;                                                 // :355
+				o.f = ( o.f * o.m + freq_by_weight ) / ( o.m + weight );      // :354
+				o.m += weight;                                                 // :355
 				op[int64_t( x ) * bins] = o;
 				}
 			}
-		lMF = rMF; lFrame = rFrame;
+		mf_l = mf_r; at_l = at_r;
 		}
-	if( !sequential && f1 == F ) clear( min( max( int( ceilf( lFrame ) ), 0 ), Fo32 ), Fo32 );   // beyond the last pair's interval
+	if( !sequential && f1 == F ) clear( min( max( int( ceilf( at_l ) ), 0 ), Fo32 ), Fo32 );   // beyond the last pair's interval
 	}
 
 // The same algorithm cut by OUTPUT chains, for time maps that never run backwards (every column monotone): one thread owns the
@@ -178,14 +178,14 @@ __global__ __launch_bounds__( 256 ) void k_modify_time_chains( TimeChainParams p
 		int cursor = x_lo;
 		if( lo < p.F )
 			{
-			float lFrame = frame_of( lo - 1 );
-			MFd lMF = ip[( lo - 1 ) * bins];
+			float at_l = frame_of( lo - 1 );
+			MFd mf_l = ip[( lo - 1 ) * bins];
 			for( int64_t k = lo; k < p.F; ++k )                                     // :328
 				{
-				const MFd rMF = ip[k * bins];
-				const float rFrame = frame_of( k );                                 // :331
-				const int xs = min( max( int( ceilf( lFrame ) ), 0 ), Fo32 );       // :334-335, :342 (monotone: forward or empty)
-				const int xe = min( max( int( ceilf( rFrame ) ), 0 ), Fo32 );
+				const MFd mf_r = ip[k * bins];
+				const float at_r = frame_of( k );                                 // :331
+				const int xs = min( max( int( ceilf( at_l ) ), 0 ), Fo32 );       // :334-335, :342 (monotone: forward or empty)
+				const int xe = min( max( int( ceilf( at_r ) ), 0 ), Fo32 );
 				if( xs >= x_hi ) break;
 				const int a = max( xs, x_lo ), b = min( xe, x_hi );
 				for( ; cursor < a; ++cursor ) add_frame( cursor, MFd{ 0.0f, 0.0f } );   // frames no pair reaches (before the first pair)
@@ -195,21 +195,21 @@ __global__ __launch_bounds__( 256 ) void k_modify_time_chains( TimeChainParams p
 					MFd v = { 0.0f, 0.0f };
 					if( !left )
 						{
-						const float mix = interpolate( p.interp, ( float( x ) - lFrame ) / ( rFrame - lFrame ) );        // :344
-						const float w0 = ( 1.0f - mix ) * lMF.m;
-						const float w1 = mix * rMF.m;
-						const float totalWeight = w0 + w1;
-						const float weightedFreqSum = w0 * lMF.f + w1 * rMF.f;
-						if( totalWeight == 0.0f ) left = true;
+						const float mix = interpolate( p.interp, ( float( x ) - at_l ) / ( at_r - at_l ) );        // :344
+						const float share_l = ( 1.0f - mix ) * mf_l.m;
+						const float share_r = mix * mf_r.m;
+						const float weight = share_l + share_r;
+						const float freq_by_weight = share_l * mf_l.f + share_r * mf_r.f;
+						if( weight == 0.0f ) left = true;
 						else
 							{
 							const MFd o = { 0.0f, 0.0f };                                       // the cleared output MF this pair alone reaches
-							v = MFd{ o.m + totalWeight, ( o.f * o.m + weightedFreqSum ) / ( o.m + totalWeight ) };   // :354-355
+							v = MFd{ o.m + weight, ( o.f * o.m + freq_by_weight ) / ( o.m + weight ) };   // :354-355
 							}
 						}
 					if( x >= a ) { add_frame( x, v ); cursor = x + 1; }
 					}
-				lMF = rMF; lFrame = rFrame;
+				mf_l = mf_r; at_l = at_r;
 				}
 			}
 		for( ; cursor < x_hi; ++cursor ) add_frame( cursor, MFd{ 0.0f, 0.0f } );    // beyond the last pair
@@ -386,9 +386,9 @@ __global__ __launch_bounds__( 256 ) void k_modify_frequency( const MFd * in, int
 		for( int y = start_bin; y != end_bin; forward ? ++y : --y )                 // :230
 			{
 			const float mix = interpolate( interp, ( float( y ) - loBin ) / ( hiBin - loBin ) );           // :232 interp( ... )
-			const float w0 = ( 1.0f - mix ) * loMF.m;
-			const float w1 = mix * hiMF.m;
-			const MFd mx = w0 < w1 ? loMF : hiMF;                                   // :237
+			const float share_l = ( 1.0f - mix ) * loMF.m;
+			const float share_r = mix * hiMF.m;
+			const MFd mx = share_l < share_r ? loMF : hiMF;                                   // :237
 			MFd o = orow[y];
 			if( mx.m > o.m )                                                        // :239
 				{

@@ -229,8 +229,8 @@ __device__ __forceinline__ int quad_point( const Quad & q, int xi, int yi, int i
 	const float interpL = interpolate( interp_kind, l ), interpM = interpolate( interp_kind, m );   // :147-148
 	const float w[4] = { ( 1.0f - interpL ) * ( 1.0f - interpM ) * q.pm[0], ( interpL ) * ( 1.0f - interpM ) * q.pm[1],   // :150-154
 	                     ( interpL ) * ( interpM ) * q.pm[2], ( 1.0f - interpL ) * ( interpM ) * q.pm[3] };
-	const float totalWeight = w[0] + w[1] + w[2] + w[3];                              // :155-156
-	if( totalWeight <= 0.0f ) return 1;
+	const float weight_sum = w[0] + w[1] + w[2] + w[3];                              // :155-156
+	if( weight_sum <= 0.0f ) return 1;
 	int largest = 0;                                                                  // std::max_element, :169-170
 	float best = w[0];
 	#pragma unroll

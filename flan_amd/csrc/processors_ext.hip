@@ -208,30 +208,30 @@ __global__ __launch_bounds__( 256 ) void k_desample_apply( const MFd * in, int n
 	if( idx >= per_channel ) return;
 	const int bin = int( idx % bins );
 	const int64_t frame = idx / bins;
-	const int lFrame = L[idx];
-	int rFrame = -1;
-	if( lFrame >= 0 )
+	const int before = L[idx];
+	int after = -1;
+	if( before >= 0 )
 		{
 		int64_t lo = frame + 1, hi = F;                                             // answer in [frame + 1, F]; F = none
 		while( lo < hi )
 			{
 			const int64_t mid = ( lo + hi ) >> 1;
-			if( L[mid * bins + bin] > lFrame ) hi = mid; else lo = mid + 1;
+			if( L[mid * bins + bin] > before ) hi = mid; else lo = mid + 1;
 			}
-		if( lo < F ) rFrame = int( lo );
+		if( lo < F ) after = int( lo );
 		}
-	const bool none = lFrame < 0 || rFrame < 0;                                       // :453 clear_buffer, :482
-	const float mix = none ? 0.0f : interpolate( interp, float( int( frame ) - lFrame ) / float( rFrame - lFrame ) );   // :491
+	const bool none = before < 0 || after < 0;                                       // :453 clear_buffer, :482
+	const float mix = none ? 0.0f : interpolate( interp, float( int( frame ) - before ) / float( after - before ) );   // :491
 	for( int channel = 0; channel < num_channels; ++channel )
 		{
 		MFd o = { 0.0f, 0.0f };
 		if( !none )
 			{
-			const MFd lMF = in[( int64_t( channel ) * F + lFrame ) * bins + bin];
-			const MFd rMF = in[( int64_t( channel ) * F + rFrame ) * bins + bin];
-			const float w0 = ( 1.0f - mix ) * lMF.m;
-			const float w1 = mix * rMF.m;
-			o = MFd{ w0 + w1, w0 > w1 ? lMF.f : rMF.f };                              // :494-498
+			const MFd a = in[( int64_t( channel ) * F + before ) * bins + bin];
+			const MFd b = in[( int64_t( channel ) * F + after ) * bins + bin];
+			const float share_a = ( 1.0f - mix ) * a.m;
+			const float share_b = mix * b.m;
+			o = MFd{ share_a + share_b, share_a > share_b ? a.f : b.f };                              // :494-498
 			}
 		out[int64_t( channel ) * per_channel + idx] = o;
 		}
@@ -300,8 +300,13 @@ bool valid_interp( int kind )
 	{
 	if( kind >= FLANHIP_INTERP_LINEAR && kind <= FLANHIP_INTERP_SINE ) return true;
 	if( kind < FLANHIP_INTERP_TABLE_FIRST || kind >= FLANHIP_INTERP_TABLE_FIRST + kInterpLutSlots ) return false;
+	// a table lives on the device it was created on (its pointer is published to that device's copies of g_interp_lut only): on any other
+	// device the kind is unknown
+	int device = -1;
+	if( hipGetDevice( &device ) != hipSuccess ) return false;
 	std::lock_guard<std::mutex> lock( g_lut_mutex );
-	return g_luts[kind - FLANHIP_INTERP_TABLE_FIRST].d != nullptr;
+	const InterpTable & t = g_luts[kind - FLANHIP_INTERP_TABLE_FIRST];
+	return t.d != nullptr && t.device == device;
 	}
 
 float interp_eval_host( int kind, float x )
@@ -368,10 +373,21 @@ int flanhip_interp_table_destroy( int kind )
 	std::lock_guard<std::mutex> lock( g_lut_mutex );
 	InterpTable & t = g_luts[kind - FLANHIP_INTERP_TABLE_FIRST];
 	FLANHIP_REQUIRE( t.d, FLANHIP_ERR_INVALID_ARG, "table not alive" );
-	FLANHIP_CHECK( hipDeviceSynchronize() );                                           // kernels that read it may still be running
+	// on the table's OWN device: kernels that read it may still be running there; its entries in that device's g_interp_lut copies are
+	// cleared so that a stale kind can never reach freed memory
+	int current = -1;
+	FLANHIP_CHECK( hipGetDevice( &current ) );
+	if( current != t.device ) FLANHIP_CHECK( hipSetDevice( t.device ) );
+	const int slot = kind - FLANHIP_INTERP_TABLE_FIRST;
+	int rc = FLANHIP_OK;
+	if( hipDeviceSynchronize() != hipSuccess ) { set_error( "hipDeviceSynchronize failed" ); rc = FLANHIP_ERR_HIP; }
+	if( !rc ) rc = processors_set_interp_lut( slot, nullptr );
+	if( !rc ) rc = processors_ext_set_interp_lut( slot, nullptr );
+	if( !rc ) rc = processors_arrange_set_interp_lut( slot, nullptr );
 	(void) hipFree( t.d );
 	t.d = nullptr; t.host.clear(); t.device = -1;
-	return FLANHIP_OK;
+	if( current != -1 ) (void) hipSetDevice( current );
+	return rc;
 	}
 
 

@@ -1,9 +1,9 @@
 // pv_kernels_v2.h -- second generation of the dft 2048 analysis / synthesis kernels (C = 1024 complex points per frame).
 //
-// Same chain decomposition and the same register-resident 16 x 16 x 4 transform as pv_kernels_fast.h; what changes is what
-// the round-1 profiles showed to be the limit: with 2 wavefronts per SIMD each wavefront spent most of its time stalled (LDS
-// round trips of the transposes, dependent fp32 chains) and the SIMD issued on only ~50 % of its cycles.  These kernels are
-// written for THREE wavefronts per SIMD (12-wave blocks, <= 168 VGPRs) and for fewer issue slots per frame:
+// Same chain decomposition and the same register-resident 16 x 16 x 4 transform as pv_kernels_fast.h (fft_fast), 8-wave blocks = 2
+// wavefronts per SIMD at <= 256 VGPRs (12-wave blocks at <= 168 VGPRs were measured in round 2 and dropped: no faster).  The kernels are
+// bound by the SIMD's issue / execute time, not by memory or latency (profiles/r03_stall_attribution.txt): what this file does about it
+// is fewer and cheaper instructions per frame:
 //   * a lane owns bin PAIRS ( k, C - k ), k = lane + 64 q, q < 8: the real-transform split of both bins shares its sums,
 //     differences and twiddle products (half the work of splitting each bin on its own), only the upper half of the spectrum
 //     crosses LDS for the mirror exchange, and lane 0's pair ( 0, C ) is DC / Nyquist; bin C/2 is the one bin left over;

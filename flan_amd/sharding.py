@@ -23,6 +23,14 @@ def max_over_ranks(dist, seconds, device):
     return float(t.item())
 
 
+def min_over_ranks(dist, value, device):
+    """The smallest of the ranks' values (e.g. an "all of us succeeded" flag: 1 only if every rank says 1)."""
+    import torch
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return float(t.item())
+
+
 def gather_output(dist, local_out, world_size):
     """All-gather equal-sized per-rank outputs [ch_local][frames] into [world*ch_local][frames] (the final layout)."""
     import torch
@@ -123,8 +131,14 @@ def exchange_overlaps(dist, local_out, rank, world_size, hop, pad):
     own = local_out[:, z:local_out.shape[1] - z].clone()
     # a rank's padding zone must not reach beyond its immediate neighbour's own samples: every range holds at least `pad` frames
     # (frame_ranges() hands out contiguous ranges; with fewer frames than that per rank, shard over fewer ranks)
-    if own.shape[1] < z:
-        raise ValueError("exchange_overlaps: a frame range of %d samples is shorter than the overlap zone of %d: use fewer ranks" % (own.shape[1], z))
+    # The decision is COLLECTIVE: ranges differ by one frame, so a per-rank check would raise on the short ranks only and leave their
+    # neighbours waiting in batch_isend_irecv for a peer that has gone.  Every rank learns the job's shortest range first (one small
+    # all-reduce) and all of them raise together, before any point-to-point operation is posted.
+    shortest = torch.tensor([own.shape[1]], dtype=torch.int64, device=local_out.device)
+    if world_size > 1:
+        dist.all_reduce(shortest, op=dist.ReduceOp.MIN)
+    if int(shortest.item()) < z:
+        raise ValueError("exchange_overlaps: the job's shortest frame range (%d samples) is shorter than the overlap zone of %d: use fewer ranks" % (int(shortest.item()), z))
     ops, recv_left, recv_right = [], None, None
     if rank > 0:                                                   # my left padding zone belongs to rank - 1's last samples
         recv_left = torch.empty((local_out.shape[0], z), dtype=local_out.dtype, device=local_out.device)

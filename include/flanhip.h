@@ -232,10 +232,11 @@ int flanhip_shape_table_dev_fused(const flanhip_MF * d_pv, const flanhip_MF * d_
 #define FLANHIP_INTERP_SINE          8   /* cosf based: agrees with the host libm to 1-2 ulp, not bit for bit */
 /* An Interpolator built from an arbitrary callable (Utility/Interpolator.h: Interpolator( std::function<float(float)> )): the caller samples it
  * at i / FLANHIP_INTERP_TABLE_INTERVALS, i = 0 .. INTERVALS, plus its value at NaN (INTERVALS + 2 floats, host memory), and gets a kind
- * (>= FLANHIP_INTERP_TABLE_FIRST, at most 32 alive per device) that every entry point taking FLANHIP_INTERP_* accepts.  The kernels read the
+ * (>= FLANHIP_INTERP_TABLE_FIRST, at most 32 alive per process) that every entry point taking FLANHIP_INTERP_* accepts ON THE DEVICE THAT WAS
+ * CURRENT AT CREATION -- on another device the kind is rejected as unknown (create one table per device).  The kernels read the
  * table with linear interpolation between neighbouring samples, argument clamped to [0, 1]: exact at the sample points, within
  * max|f''| / ( 8 INTERVALS^2 ) = 2.9e-11 max|f''| between them -- below one fp32 step for any smooth shaping curve; a jump of the callable is
- * smeared over one interval (1.5e-5 wide).  _destroy synchronises the device before the table is freed. */
+ * smeared over one interval (1.5e-5 wide).  _destroy synchronises the table's own device before the table is freed, whichever device is current. */
 #define FLANHIP_INTERP_TABLE_INTERVALS 65536
 #define FLANHIP_INTERP_TABLE_FIRST     16
 int flanhip_interp_table_create(const float * samples, int * kind);

@@ -134,3 +134,30 @@ def _overlap_worker(rank, world, port, result_dir):
 @pytest.mark.parametrize("world", [2, 3])
 def test_frame_range_overlap_exchange_gloo(tmp_path, world):
     mp.spawn(_overlap_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+
+
+def _short_range_worker(rank, world, port, result_dir):
+    from flan_amd import sharding as S
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    hop, W, ch = 64, 256, 1
+    pad = S.pad_frames(W, hop)                                        # 2 frames: the overlap zone is 128 samples
+    rows = [1, 3, 3][rank]                                            # rank 0's range is SHORTER than the zone, the others' are not
+    local = torch.zeros((ch, (rows + 2 * pad) * hop))
+    raised = False
+    try:
+        S.exchange_overlaps(dist, local, rank, world, hop, pad)
+    except ValueError:
+        raised = True
+    with open(os.path.join(result_dir, "rank%d" % rank), "w") as f:
+        f.write("1" if raised else "0")
+    dist.barrier()                                                    # every rank gets here: nobody is stuck in a point-to-point wait
+    dist.destroy_process_group()
+
+
+def test_overlap_exchange_refuses_collectively(tmp_path):
+    """a frame range shorter than the overlap zone on ONE rank: every rank raises (the decision is an all-reduce), none hangs"""
+    world = 3
+    mp.spawn(_short_range_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert [open(os.path.join(str(tmp_path), "rank%d" % r)).read() for r in range(world)] == ["1", "1", "1"]

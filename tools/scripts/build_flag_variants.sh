@@ -4,7 +4,8 @@
 R=$(cd "$(dirname "$0")/../.." && pwd)
 C=$R/flan_amd/csrc
 V=$R/tools/ubench/variants
-BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-gpu-rdc -I$R/include -I$C"
+# the product build of conversions.hip (flan_amd/build.py: no packed fp32) is the baseline every variant adds one option to
+BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-gpu-rdc -Xclang -target-feature -Xclang -packed-fp32-ops -I$R/include -I$C"
 OTHERS="$C/core.o $C/processors.o $C/processors_ext.o $C/processors_arrange.o $C/resample.o $C/utility.o $C/collective.o $C/transfer.o"
 build() { # name, flags...
   name=$1; shift
