@@ -7,6 +7,7 @@
 #include <type_traits>
 #include "pv_kernels_v2.h"
 #include "pv_kernels_eo.h"
+#include "pv_kernels_any.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -21,6 +22,41 @@ static int g_ana_variant = 4, g_syn_variant = 1;
 static int g_syn11_variant = 1;          // dft 4096 synthesis, window <= 2048, hop 256 / 512 / 1024: 1 = teams of two wavefronts (pv_kernels_eo.h), 0 = the round-1 kernel
 static int g_ana11_variant = 1;          // dft 4096, window <= 2048: 1 = teams of two wavefronts, two 1024-point transforms per frame (pv_kernels_eo.h), 0 = the round-1 kernel
 static constexpr size_t kMaxLds = 160 * 1024;   // gfx950: 160 KiB LDS per CU, one workgroup may take all of it
+
+// dft sizes: powers of two in [32, 8192] have FFT kernels (tuned or LDS-resident); every other EVEN size the reference would hand to FFTW
+// (FFTHelper.cpp:16-26) -- 3000, 16384 ... -- runs the direct-sum kernels of pv_kernels_any.h.  Odd sizes are refused: the reference's own
+// PVBuffer derives the dft size as ( bins - 1 ) * 2 (PVBuffer.cpp:356-359), so an odd one does not survive its own round trip.
+static constexpr int kMaxAnyDft = 1 << 20;
+static bool fft_size( int dft ) { return is_pow2( dft ) && dft >= 32 && dft <= 8192; }
+static bool dft_size_ok( int dft ) { return dft >= 4 && dft % 2 == 0 && dft <= kMaxAnyDft; }
+
+// unit[m] = ( cos, sin )( 2 pi m / N ) in double, exact at the quarter turns; per ( device, N ), never freed (like the plans)
+static std::mutex g_unit_mutex;
+static std::map<std::pair<int, int>, d2*> g_units;
+static int get_unit_circle( int N, const d2 ** out )
+	{
+	int device = 0;
+	FLANHIP_CHECK( hipGetDevice( &device ) );
+	std::lock_guard<std::mutex> lock( g_unit_mutex );
+	auto it = g_units.find( std::make_pair( device, N ) );
+	if( it == g_units.end() )
+		{
+		std::vector<d2> u( size_t( N ), d2{ 1.0, 0.0 } );
+		const long double two_pi = 6.283185307179586476925286766559005768L;
+		for( int m = 0; m < N; ++m ) u[size_t( m )] = d2{ double( cosl( two_pi * m / N ) ), double( sinl( two_pi * m / N ) ) };
+		u[0] = d2{ 1.0, 0.0 }; u[size_t( N / 2 )] = d2{ -1.0, 0.0 };
+		if( N % 4 == 0 ) { u[size_t( N / 4 )] = d2{ 0.0, 1.0 }; u[size_t( 3 * ( N / 4 ) )] = d2{ 0.0, -1.0 }; }
+		d2 * d = nullptr;
+		FLANHIP_CHECK( hipMalloc( &d, sizeof( d2 ) * size_t( N ) ) );
+		FLANHIP_CHECK( hipMemcpy( d, u.data(), sizeof( d2 ) * size_t( N ), hipMemcpyHostToDevice ) );
+		it = g_units.emplace( std::make_pair( device, N ), d ).first;
+		}
+	*out = it->second;
+	return FLANHIP_OK;
+	}
+// chains for the direct-sum kernels: enough blocks ( chains x bin blocks ) to fill the chip, chains of at least 7 frames (the halo frame
+// every chain but a channel's first recomputes is then <= 1/8 of its work)
+static int any_target_chains( int bins ) { return std::max( 16, 4096 / ( ( bins + ANY_THREADS - 1 ) / ANY_THREADS ) ); }
 
 // chains: the chains a block walks (one per wavefront; or ONE, walked by a team of several wavefronts, see k_analyze)
 static size_t analyze_lds_bytes( int C, int W, int chains, bool state_in_lds )
@@ -279,7 +315,8 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	FLANHIP_REQUIRE( d_audio && d_out, FLANHIP_ERR_INVALID_ARG, "null buffer" );
 	FLANHIP_REQUIRE( ch > 0 && n >= 0 && W >= 2 && hop >= 1 && sr > 0.0f, FLANHIP_ERR_INVALID_ARG, "bad sizes" );
 	FLANHIP_REQUIRE( W <= dft, FLANHIP_ERR_INVALID_ARG, "window_size larger than dft_size" );
-	FLANHIP_REQUIRE( is_pow2( dft ) && dft >= 32 && dft <= 8192, FLANHIP_ERR_UNSUPPORTED, "dft_size must be a power of two in [32, 8192]" );
+	FLANHIP_REQUIRE( dft_size_ok( dft ), FLANHIP_ERR_UNSUPPORTED, "dft_size must be even, at least 4 and at most 2^20" );
+	const bool any = !fft_size( dft );
 	if( int rc = require_device() ) return rc;
 	const Plan * plan = nullptr;
 	if( int rc = get_plan( W, dft, &plan ) ) return rc;
@@ -290,9 +327,9 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	p.n = n; p.F = n / hop + 1;                                   // AudioPV.cpp:17
 	p.num_channels = int( ch ); p.window_size = W; p.hop = hop;
 	const bool fast = ( dft == 2048 || dft == 4096 ) && n >= 2 && n < ( int64_t( 1 ) << 31 ) - 8192 && !force_generic();
-	int target_chains = fast ? fast_target_chains( dft, false ) : generic_target_chains( dft );
+	int target_chains = any ? any_target_chains( dft / 2 + 1 ) : fast ? fast_target_chains( dft, false ) : generic_target_chains( dft );
 	if( fast && dft == 4096 && W <= 2048 && g_ana11_variant != 0 && g_ana11_variant != 3 && !d_fused_ws ) target_chains = 256 * 8;   // k_analyze_eo: 8 one-wavefront chains per CU
-	p.L = choose_chain_length( ch, p.F, 1, target_chains );
+	p.L = choose_chain_length( ch, p.F, any ? 7 : 1, target_chains );
 	p.chains_per_channel = int( ( p.F + p.L - 1 ) / p.L );
 	p.sample_rate = sr;
 	p.analysis_rate = sr / hop;                                   // AudioPV.cpp:26 (float / int)
@@ -300,7 +337,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	if( int rc = get_div_plan( p.analysis_rate, &dp ) ) return rc;
 	p.ar_div = DivC{ dp.c, dp.rc, dp.exact };
 	p.sums = nullptr; p.nan_out = nullptr; p.nan_epoch = 0;
-	const bool kernel_sums = true;                                                // every analysis kernel launched keeps the sums (the one-wavefront LEAN variants did not)
+	const bool kernel_sums = !any;                                                // every FFT analysis kernel keeps the sums; the direct-sum kernel leaves them to the pre-pass kernel
 	SynthLayout fused_lay{};
 	if( d_fused_ws )
 		{
@@ -338,6 +375,17 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 		return FLANHIP_OK;
 		};
 
+	if( any )
+		{
+		const d2 * unit = nullptr;
+		if( int rc = get_unit_circle( dft, &unit ) ) return rc;
+		const int64_t chains = int64_t( p.chains_per_channel ) * ch;
+		const int bin_blocks = ( dft / 2 + 1 + ANY_THREADS - 1 ) / ANY_THREADS;
+		FLANHIP_REQUIRE( chains <= 65535, FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
+		hipLaunchKernelGGL( k_analyze_any, dim3( (unsigned) bin_blocks, (unsigned) chains ), dim3( ANY_THREADS ), 0, s, p, unit, dft );
+		FLANHIP_CHECK( hipGetLastError() );
+		return prepass_on_behalf();
+		}
 	if( fast )
 		{
 		FastTables tb{ plan->d_tw1f, plan->d_tw3f, plan->d_tw2 };
@@ -380,12 +428,14 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	o->hop = int( sr / ar );                                      // PVBuffer.cpp:381-384
 	FLANHIP_REQUIRE( o->hop >= 1, FLANHIP_ERR_INVALID_ARG, "analysis_rate above sample_rate: hop size 0" );
 	FLANHIP_REQUIRE( W <= o->dft, FLANHIP_ERR_INVALID_ARG, "window_size larger than dft size" );
-	FLANHIP_REQUIRE( is_pow2( o->dft ) && o->dft >= 32 && o->dft <= 8192, FLANHIP_ERR_UNSUPPORTED, "dft size must be a power of two in [32, 8192]" );
-	o->head_len = std::max( W - o->hop, 0 );
+	FLANHIP_REQUIRE( dft_size_ok( o->dft ), FLANHIP_ERR_UNSUPPORTED, "dft size must be even, at least 4 and at most 2^20" );
+	FLANHIP_REQUIRE( int64_t( o->dft ) * W < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "dft_size * window_size overflows the int product of AudioPV.cpp:99" );
+	o->any = !fft_size( o->dft );
+	o->head_len = o->any ? 0 : std::max( W - o->hop, 0 );        // (the direct-sum path overlap-adds whole frames from its own scratch: no chain heads)
 	const int overlap = ( W + o->hop - 1 ) / o->hop;              // frames covering one output sample
-	const int kind = synth_fast_kind( o->dft, W, o->hop );
-	const int slots = kind == 0 ? generic_target_chains( o->dft ) : ( kind == 2 && o->dft == 4096 ) ? 256 * kRingWaves11 : fast_target_chains( o->dft, true );
-	o->L = choose_chain_length( ch, F, std::max( overlap - 1, 1 ), slots );
+	const int kind = o->any ? 0 : synth_fast_kind( o->dft, W, o->hop );
+	const int slots = o->any ? any_target_chains( bins ) : kind == 0 ? generic_target_chains( o->dft ) : ( kind == 2 && o->dft == 4096 ) ? 256 * kRingWaves11 : fast_target_chains( o->dft, true );
+	o->L = choose_chain_length( ch, F, o->any ? 1 : std::max( overlap - 1, 1 ), slots );
 	o->chains_per_channel = int( ( F + o->L - 1 ) / o->L );
 	const int64_t chains = int64_t( o->chains_per_channel ) * ch;
 	o->carry_bytes = ( size_t( chains ) * bins * sizeof( double ) + 255 ) & ~size_t( 255 );
@@ -394,6 +444,14 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	o->group_offset = o->carry_bytes + o->head_bytes + 1024;       // tail: NaN flag (4 B at +0), dump area (512 B at +512); then the group sums
 	o->group_bytes = ( size_t( ch ) * o->groups_per_channel * bins * sizeof( double ) + 255 ) & ~size_t( 255 );
 	o->total_bytes = o->group_offset + o->group_bytes;
+	o->any_spec_offset = o->any_frames_offset = 0;
+	if( o->any )
+		{
+		// scratch of the direct-sum synthesis: the spectra X[ch][F][bins] (one PV's worth) and the windowed frames [ch][F][W]
+		o->any_spec_offset = o->total_bytes;
+		o->any_frames_offset = o->any_spec_offset + ( ( size_t( ch ) * size_t( F ) * size_t( bins ) * sizeof( cf ) + 255 ) & ~size_t( 255 ) );
+		o->total_bytes = o->any_frames_offset + ( ( size_t( ch ) * size_t( F ) * size_t( W ) * sizeof( float ) + 255 ) & ~size_t( 255 ) );
+		}
 	return FLANHIP_OK;
 	}
 
@@ -467,6 +525,41 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 
 	int rc = FLANHIP_ERR_UNSUPPORTED;
 	if( !( stages & 4 ) ) rc = FLANHIP_OK;
+	else if( lay.any )
+		{
+		// any even dft size without FFT kernels: spectra along the chains, c2r by its definition, overlap-add in frame order (pv_kernels_any.h)
+		const d2 * unit = nullptr;
+		if( int rc2 = get_unit_circle( lay.dft, &unit ) ) return rc2;
+		AnySynthParams q{};
+		q.pv = p.pv; q.carry = p.carry; q.out = d_out; q.window = p.window;
+		q.spec = reinterpret_cast<float*>( reinterpret_cast<char*>( d_ws ) + lay.any_spec_offset );
+		q.frames = reinterpret_cast<float*>( reinterpret_cast<char*>( d_ws ) + lay.any_frames_offset );
+		q.F = F; q.out_len = p.out_len; q.num_channels = int( ch ); q.bins = bins; q.N = lay.dft; q.W = W; q.hop = lay.hop;
+		q.L = lay.L; q.chains_per_channel = lay.chains_per_channel; q.analysis_rate = ar; q.window_scale = p.window_scale;
+		const unsigned bin_blocks = (unsigned) ( ( bins + ANY_THREADS - 1 ) / ANY_THREADS );
+		FLANHIP_REQUIRE( chains <= 65535, FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
+		const int64_t batches = ( ch * F + ANY_FB - 1 ) / ANY_FB;
+		FLANHIP_REQUIRE( batches <= 65535 * int64_t( 32768 ), FLANHIP_ERR_UNSUPPORTED, "too many frames for one launch" );
+		hipLaunchKernelGGL( k_any_spectra, dim3( bin_blocks, (unsigned) chains ), dim3( ANY_THREADS ), 0, s, q );
+		FLANHIP_CHECK( hipGetLastError() );
+		// frame batches over grid.y (<= 65535 per launch): long PVs in several launches of the same kernel over consecutive row ranges
+		const unsigned sample_blocks = (unsigned) ( ( W + ANY_THREADS - 1 ) / ANY_THREADS );
+		for( int64_t b0 = 0; b0 < batches; b0 += 65535 )
+			{
+			AnySynthParams qq = q;
+			const int64_t rows0 = b0 * ANY_FB, nb = std::min<int64_t>( 65535, batches - b0 );
+			qq.spec = q.spec + size_t( rows0 ) * size_t( bins ) * 2;
+			qq.frames = q.frames + size_t( rows0 ) * size_t( W );
+			// ( num_channels * F is only used as the row count there: hand the rows this launch owns )
+			qq.num_channels = 1; qq.F = std::min<int64_t>( ch * F - rows0, nb * ANY_FB );
+			hipLaunchKernelGGL( k_any_inverse, dim3( sample_blocks, (unsigned) nb ), dim3( ANY_THREADS ), 0, s, qq, unit );
+			FLANHIP_CHECK( hipGetLastError() );
+			}
+		const int64_t total = ch * p.out_len;
+		hipLaunchKernelGGL( k_any_overlap_add, dim3( (unsigned) ( ( total + 255 ) / 256 ) ), dim3( 256 ), 0, s, q );
+		FLANHIP_CHECK( hipGetLastError() );
+		rc = FLANHIP_OK;
+		}
 	else if( synth_fast_ok( lay.dft, W, lay.hop ) )
 		{
 		FastTables tb{ plan->d_tw1f, plan->d_tw3f, plan->d_tw2 };

@@ -24,8 +24,9 @@ public:
 	static Audio create_empty_with_frames( Frame num_frames, Channel num_channels = 1, FrameRate sample_rate = 48000.0f ); // Audio.h:93-97
 
 	// ---- conversions ----
-	/** Windowed STFT + per-bin phase vocoding (Conversions/AudioPV.cpp:12-78).  dft_size: a power of two in [32, 8192],
-	 *  >= window_size; anything else returns a null PV. */
+	/** Windowed STFT + per-bin phase vocoding (Conversions/AudioPV.cpp:12-78).  dft_size: any EVEN size >= window_size (the reference hands it
+	 *  to FFTW as it is, FFTHelper.cpp:16-26); powers of two in [32, 8192] run the FFT kernels, every other size the direct-sum kernels
+	 *  (slower, same results).  An odd size, or one below the window, returns a null PV. */
 	PV convert_to_PV( Frame window_size = 2048, Frame hop = 128, Frame dft_size = 4096, flan_CANCEL_ARG ) const;  // Audio.h:158-163
 	/** Stereo only: mid/side first (AudioPV.cpp:80-84). */
 	PV convert_to_ms_PV( Frame window_size = 2048, Frame hop = 128, Frame dft_size = 4096, flan_CANCEL_ARG ) const;

@@ -34,7 +34,7 @@ extern "C" {
 
 #define FLANHIP_OK                 0
 #define FLANHIP_ERR_INVALID_ARG   -1   /* null pointer, non-positive size, window > dft ...                    */
-#define FLANHIP_ERR_UNSUPPORTED   -2   /* dft size not a power of two in [32, 8192], chain constraints ...     */
+#define FLANHIP_ERR_UNSUPPORTED   -2   /* dft size odd, below 4 or above 2^20, chain constraints ...           */
 #define FLANHIP_ERR_HIP           -3   /* a HIP runtime call failed; see flanhip_last_error()                  */
 #define FLANHIP_ERR_CANCELLED     -4   /* the canceller was raised                                              */
 #define FLANHIP_ERR_NO_DEVICE     -5   /* no gfx950 device visible                                              */
@@ -87,6 +87,10 @@ int flanhip_host_free(void * hptr);
 
 /* ---- Audio::convert_to_PV  (Conversions/AudioPV.cpp:12-78, phase_vocoder.cpp:5-53, WindowFunctions.cpp:10-13) - */
 /* audio: float[ch][n]; out: MF[ch][F][dft/2+1] with F = flanhip_num_pv_frames(n, hop), written to *num_pv_frames. */
+/* dft_size: any even size in [4, 2^20] with window_size <= dft_size (FFTHelper.cpp:16-26 hands the caller's size to FFTW as it is).  Powers
+ * of two in [32, 8192] run FFT kernels; every other size -- 3000, 16384 ... -- the transform's definition summed in fp64 (pv_kernels_any.h):
+ * O( window x bins ) per frame, milliseconds where the FFT kernels need a fraction of one, same results.  flanhip_synthesize_workspace_bytes
+ * includes the scratch those sizes need ( one PV's worth of spectra + frames x window floats ). */
 int flanhip_analyze(const float * audio, int64_t num_channels, int64_t num_audio_frames, float sample_rate,
                     int window_size, int hop, int dft_size,
                     flanhip_MF * out, int64_t * num_pv_frames, volatile int * cancel);

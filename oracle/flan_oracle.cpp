@@ -35,16 +35,30 @@ const float k_pi  = std::acos( -1.0f );
 const float k_pi2 = k_pi * 2.0f;
 
 // ---------------------------------------------------------------------------------------------------------
-// FFT (stands in for FFTW3f at FFTHelper.cpp:21-24,41,47).  Iterative radix-2, fp64, twiddles from sincos in
-// fp64.  Power-of-two sizes only.
+// FFT (stands in for FFTW3f at FFTHelper.cpp:21-24,41,47), fp64.  Powers of two: iterative radix-2, twiddles from
+// sincos in fp64.  Every other size (FFTW takes any: FFTHelper.cpp:16-26 passes the caller's dft_size through):
+// recursive mixed radix over the prime factors (a prime factor p costs p^2 per butterfly), twiddles from an exact
+// table of the unit circle worked out in long double.  tests/test_oracle_fft.py holds both against numpy.fft.
 // ---------------------------------------------------------------------------------------------------------
 struct FFTPlan
 	{
 	int n = 0;
-	std::vector<std::complex<double>> w; // w[k] = exp(-2 pi i k / n), k < n/2
+	bool pow2 = true;
+	std::vector<std::complex<double>> w; // w[k] = exp(-2 pi i k / n), k < n/2 (power of two) or k < n (any size)
 	std::vector<int> rev;
-	explicit FFTPlan( int n_ ) : n( n_ ), w( n_ / 2 ), rev( n_ )
+	explicit FFTPlan( int n_ ) : n( n_ ), pow2( n_ > 0 && ( n_ & ( n_ - 1 ) ) == 0 )
 		{
+		if( !pow2 )
+			{
+			w.resize( n );
+			const long double two_pi = 6.283185307179586476925286766559005768L;
+			for( int k = 0; k < n; ++k ) w[k] = std::complex<double>( double( cosl( two_pi * k / n ) ), double( -sinl( two_pi * k / n ) ) );
+			w[0] = std::complex<double>( 1.0, 0.0 );
+			if( n % 2 == 0 ) w[n / 2] = std::complex<double>( -1.0, 0.0 );
+			if( n % 4 == 0 ) { w[n / 4] = std::complex<double>( 0.0, -1.0 ); w[3 * ( n / 4 )] = std::complex<double>( 0.0, 1.0 ); }
+			return;
+			}
+		w.resize( n / 2 ); rev.resize( n );
 		const double pi = 3.14159265358979323846;
 		for( int k = 0; k < n / 2; ++k )
 			w[k] = std::complex<double>( std::cos( -2.0 * pi * k / n ), std::sin( -2.0 * pi * k / n ) );
@@ -56,9 +70,39 @@ struct FFTPlan
 			rev[i] = r;
 			}
 		}
+	// out[k] = sum_j in[j * stride] exp( sign 2 pi i j k / m ), m a divisor of n: decimation in time over m's smallest prime factor
+	void any_rec( const std::complex<double> * in, int stride, int m, std::complex<double> * out, int sign ) const
+		{
+		if( m == 1 ) { out[0] = in[0]; return; }
+		int p = 2;
+		while( m % p ) ++p;
+		const int q = m / p, root = n / m;                                   // exp( -2 pi i j / m ) = w[j * root]
+		std::vector<std::complex<double>> sub( m );
+		for( int r = 0; r < p; ++r ) any_rec( in + size_t( r ) * stride, stride * p, q, sub.data() + size_t( r ) * q, sign );
+		for( int k = 0; k < q; ++k )
+			for( int c = 0; c < p; ++c )
+				{
+				const int kk = k + c * q;                                     // output index; input r contributes sub_r[k] w_m^( r kk )
+				std::complex<double> acc = sub[k];
+				for( int r = 1; r < p; ++r )
+					{
+					std::complex<double> t = w[size_t( ( int64_t( r ) * kk ) % m ) * root];
+					if( sign > 0 ) t = std::conj( t );
+					acc += sub[size_t( r ) * q + k] * t;
+					}
+				out[kk] = acc;
+				}
+		}
 	// in-place complex FFT; sign=-1 forward, +1 inverse (unnormalised)
 	void run( std::complex<double> * a, int sign ) const
 		{
+		if( !pow2 )
+			{
+			std::vector<std::complex<double>> out( n );
+			any_rec( a, 1, n, out.data(), sign );
+			std::copy( out.begin(), out.end(), a );
+			return;
+			}
 		for( int i = 0; i < n; ++i ) if( i < rev[i] ) std::swap( a[i], a[rev[i]] );
 		for( int len = 2; len <= n; len <<= 1 )
 			{
@@ -84,6 +128,9 @@ void r2c( const FFTPlan & p, const float * x, std::complex<float> * X, std::vect
 	for( int i = 0; i < p.n; ++i ) tmp[i] = std::complex<double>( x[i], 0.0 );
 	p.run( tmp.data(), -1 );
 	for( int k = 0; k <= p.n / 2; ++k ) X[k] = std::complex<float>( float( tmp[k].real() ), float( tmp[k].imag() ) );
+	// a real-input transform (FFTW's r2c) computes X[0] and X[N/2] as real numbers: their imaginary parts are exact zeros, not the
+	// 1e-17 a complex mixed-radix pass leaves there (the radix-2 path yields the zeros by itself)
+	if( !p.pow2 ) { X[0] = std::complex<float>( X[0].real(), 0.0f ); if( p.n % 2 == 0 ) X[p.n / 2] = std::complex<float>( X[p.n / 2].real(), 0.0f ); }
 	}
 
 // c2r: x[n] = sum_{k=0}^{N-1} X[k] exp(+2 pi i k n / N) with X[N-k] = conj X[k]; Im X[0], Im X[N/2] ignored;
@@ -176,14 +223,14 @@ float oracle_frame_to_time( float f, float sr, int hop ) { return frame_to_time(
 // r2c / c2r exposed for FFT unit tests
 int oracle_r2c( const float * x, int n, float * X /* (n/2+1)*2 */ )
 	{
-	if( !is_pow2( n ) ) return -1;
+	if( n < 2 || n % 2 ) return -1;
 	FFTPlan p( n ); std::vector<std::complex<double>> tmp( n );
 	r2c( p, x, reinterpret_cast<std::complex<float>*>( X ), tmp );
 	return 0;
 	}
 int oracle_c2r( const float * X, int n, float * x )
 	{
-	if( !is_pow2( n ) ) return -1;
+	if( n < 2 || n % 2 ) return -1;
 	FFTPlan p( n ); std::vector<std::complex<double>> tmp( n );
 	c2r( p, reinterpret_cast<const std::complex<float>*>( X ), x, tmp );
 	return 0;
@@ -216,7 +263,7 @@ int64_t oracle_num_pv_frames( int64_t num_audio_frames, int hop ) { return num_a
 // out: MF[ch][F][bins] (PVBuffer.cpp:526-529), F = n/hop + 1, bins = dft/2+1.
 int oracle_analyze( const float * audio, int num_channels, int64_t n, float sample_rate, int window_size, int hop, int dft_size, float * out_mf )
 	{
-	if( !is_pow2( dft_size ) || window_size > dft_size || window_size < 2 || hop < 1 ) return -1;
+	if( dft_size < 4 || dft_size % 2 || window_size > dft_size || window_size < 2 || hop < 1 ) return -1;   // any even size, like FFTW behind FFTHelper.cpp:16-26
 	const int num_bins = dft_size / 2 + 1;                       // :15
 	const int64_t num_hops = n / hop + 1;                        // :17
 	const float analysis_rate = sample_rate / hop;               // :26
@@ -263,7 +310,7 @@ int oracle_synthesize( const float * pv_mf, int num_channels, int64_t num_frames
 	{
 	const int dft_size = ( num_bins - 1 ) * 2;                   // PVBuffer.cpp:356-359
 	const int hop = int( sample_rate / analysis_rate );          // PVBuffer.cpp:381-384
-	if( !is_pow2( dft_size ) || hop < 1 || window_size > dft_size ) return -1;
+	if( dft_size < 4 || dft_size % 2 || hop < 1 || window_size > dft_size ) return -1;
 	const MF * pv = reinterpret_cast<const MF*>( pv_mf );
 	const int64_t out_frames = num_frames * hop;                 // :93
 

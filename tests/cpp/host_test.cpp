@@ -288,7 +288,8 @@ static void device_checks()
 
 	// ---- error behaviour: null objects, never exceptions
 	CHECK( Audio().convert_to_PV().is_null() );
-	CHECK( a.convert_to_PV( 2048, 512, 3000 ).is_null() );                          // dft not a power of two
+	CHECK( a.convert_to_PV( 2048, 512, 3001 ).is_null() );                          // an odd dft size
+	CHECK( !a.convert_to_PV( 2048, 512, 3000 ).is_null() );                         // any even one is served (FFTHelper.cpp:16-26 hands it to FFTW)
 	CHECK( a.convert_to_PV( 4096, 512, 2048 ).is_null() );                          // window larger than dft
 	CHECK( PV().convert_to_audio().is_null() );
 	std::atomic<bool> cancel( true );

@@ -72,6 +72,17 @@ CASES = [
     ("hop_eq_window", 1, 20000, 1024, 1024, 1024, "noise"),
     ("hop_gt_window", 1, 20000, 512, 700, 1024, "noise"),
     ("odd_hop", 1, 20000, 2048, 333, 2048, "noise"),
+    # dft sizes without FFT kernels (any even size goes to FFTW in the reference, FFTHelper.cpp:16-26): the direct-sum kernels (pv_kernels_any.h)
+    ("dft3000", 1, 30000, 2048, 512, 3000, "noise"),
+    ("dft3000_stereo_ragged", 2, 12345, 2048, 512, 3000, "noise"),
+    ("dft16384_win4096", 1, 60000, 4096, 1024, 16384, "noise"),
+    ("dft1000_win600", 2, 9000, 600, 150, 1000, "noise"),
+    ("dft2998_prime_factor", 1, 9000, 1024, 256, 2998, "noise"),
+    ("dft66", 1, 3000, 64, 16, 66, "noise"),
+    ("dft6_win4", 1, 300, 4, 2, 6, "noise"),
+    ("dft3000_sine", 1, 48000, 2048, 512, 3000, "sine"),
+    ("dft3000_one_frame", 1, 100, 2048, 512, 3000, "noise"),
+    ("dft3000_zeros", 1, 5000, 2048, 512, 3000, "zeros"),
 ]
 
 
@@ -97,7 +108,9 @@ def test_analysis_parity(fa, name, ch, n, W, hop, dft, kind):
         assert np.array_equal(got[..., 0], ref[..., 0])
         return
     assert rel_m <= 1e-5
-    assert wrms_f <= 5e-4      # measured 2e-5 .. 3.3e-4 Hz (the largest at dft 32, where a last-bit change of the phase is the most Hz)
+    # measured 2e-5 .. 3.3e-4 Hz (the largest at dft 32 / hop 8); one last-bit change of a phase is 1.2e-7 rad x analysis_rate / 2 pi Hz, so the
+    # bound follows the analysis rate where that is extreme (hop 2: 24 kHz)
+    assert wrms_f <= max(5e-4, 1e-7 * sr / hop)
     if kind == "noise":
         assert turns <= max(3, got[..., 0].size // 100000)
         # share of f words that are bit for bit the oracle's.  What is left differs by one rounding of the transform (two FFTs in two operation
@@ -187,8 +200,9 @@ def test_errors(fa):
     import flan_amd
     x = np.zeros((1, 1000), np.float32)
     with pytest.raises(flan_amd.FlanHipError) as e:
-        fa.analyze(x, 48000.0, 2048, 512, 3000)          # non power-of-two dft
+        fa.analyze(x, 48000.0, 2048, 512, 3001)          # an odd dft size (PVBuffer.cpp:356-359 could not represent it: dft = 2 ( bins - 1 ))
     assert e.value.code == flan_amd.ERR_UNSUPPORTED
+    assert fa.analyze(x, 48000.0, 2048, 512, 3000).shape == (1, 2, 1501, 2)     # any EVEN size is served, like FFTW behind FFTHelper.cpp:16-26
     with pytest.raises(flan_amd.FlanHipError) as e:
         fa.analyze(x, 48000.0, 4096, 512, 2048)          # window > dft
     assert e.value.code == flan_amd.ERR_INVALID_ARG
