@@ -103,21 +103,24 @@ template<class V> __device__ __forceinline__ void polar_v( V re, V im, V & phase
 	constexpr int N = vec_traits<V>::N;
 	const V ax = __builtin_elementwise_abs( re ), ay = __builtin_elementwise_abs( im );
 	const V mxu = __builtin_elementwise_max( ax, ay );
-	const V mx = __builtin_elementwise_max( mxu, vsplat<V>( 0x1p-126f ) );
 	const V mn = __builtin_elementwise_min( ax, ay );
+	// Is any larger component below 2^-126 (zero or a denormal: digital silence)?  Decided per wavefront: only then are the clamp of the
+	// divisor and p2 = min( ( max 2^126 )^2, 1 ) worked out -- for every other input the clamp changes nothing and p2 is exactly 1, so the
+	// common path carries neither (a v_max per bin saved: min / max are half-rate instructions on gfx950, profiles/r03_a_issue_model.txt)
+	float tiny = mxu[0];
+	#pragma unroll
+	for( int i = 1; i < N; ++i ) tiny = __builtin_fminf( tiny, mxu[i] );
+	const bool silence = __any( tiny < 0x1p-126f );
+	V mx = mxu;
+	if( silence ) mx = __builtin_elementwise_max( mxu, vsplat<V>( 0x1p-126f ) );
 	V r;
 	#pragma unroll
 	for( int i = 0; i < N; ++i ) r[i] = __builtin_amdgcn_rcpf( mx[i] );
 	const V q0 = mn * r;
 	const V q = vfma( vfma( -q0, mx, mn ), r, q0 );
 	const V u = q * q;
-	// 1 + q^2, except where the larger component is below 2^-126 (zero or a denormal: digital silence): only then, decided per wavefront,
-	// is p2 = min( ( max 2^126 )^2, 1 ) worked out -- it is exactly 1 for every other input
 	V h = vfma( q, q, vsplat<V>( 1.0f ) );
-	float tiny = mxu[0];
-	#pragma unroll
-	for( int i = 1; i < N; ++i ) tiny = __builtin_fminf( tiny, mxu[i] );
-	if( __any( tiny < 0x1p-126f ) )
+	if( silence )
 		{
 		const V t = mxu * vsplat<V>( 0x1p126f );
 		h = vfma( q, q, __builtin_elementwise_min( t * t, vsplat<V>( 1.0f ) ) );
@@ -199,6 +202,11 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 	const int64_t t1 = min( t0 + int64_t( p.L ), p.F );
 	const float * x = p.audio + int64_t( channel ) * p.n;
 	const bool use_wrapping = p.analysis_rate < p.sample_rate;                // phase_vocoder.cpp:37
+	// (the run-time constants of the per-bin arithmetic -- analysis_rate and its reciprocal pair -- are wave-uniform and sit in SGPRs; forcing
+	// them into VGPRs, because runs of VALU instructions with SGPR operands are slow ones in the issue microbenchmark, measured +-2 % in
+	// two A/B runs of either sign: in the noise, not kept)
+	const float k_ar = p.analysis_rate;
+	const DivC k_ard = p.ar_div;
 	const int padl = lane + ( lane >> 4 );
 	const cf * mirror = buf + ( C * 17 ) / 16 - ( lane + ( ( lane + 15 ) >> 4 ) );   // mirror[-68 q] = slot PAD( C - lane - 64 q )
 	const int n32 = int( p.n );
@@ -354,7 +362,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 						const VB delta_phase = phase_diff - expd;                    // :47-48
 						VB wrapped = delta_phase;
 						if( use_wrapping ) wrapped = delta_phase - vsplat<VB>( FLANHIP_PI2_F ) * round_half_away_v( div_pi2_v( delta_phase ) );   // :39-42,49
-						f = binf + div_pi2_v( wrapped * vsplat<VB>( p.analysis_rate ) );                              // :50-52
+						f = binf + div_pi2_v( wrapped * vsplat<VB>( k_ar ) );                              // :50-52
 						}
 					else f = phase - pv + binf * expd;
 					#pragma unroll
@@ -366,7 +374,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 						}
 					if constexpr( SUMS )
 						{
-						const VB term = div_c_v( f, p.ar_div ) * vsplat<VB>( FLANHIP_PI2_F );                      // phase_vocoder.cpp:57-58
+						const VB term = div_c_v( f, k_ard ) * vsplat<VB>( FLANHIP_PI2_F );                      // phase_vocoder.cpp:57-58
 						#pragma unroll
 						for( int i = 0; i < NP; ++i )
 							{
@@ -578,6 +586,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 	const int padl = lane + ( lane >> 4 );
 	cf * mirror = buf + ( C * 17 ) / 16 - ( lane + ( ( lane + 15 ) >> 4 ) );      // mirror[-68 q] = slot PAD( C - lane - 64 q )
 
+	const DivC k_ard = p.ar_div;
 	cf acc[E];                                                                  // overlap-add accumulator: acc[q] <-> samples pos + 128 q + 2 lane (+1)
 	#pragma unroll
 	for( int q = 0; q < E; ++q ) acc[q] = mk( 0.0f, 0.0f );
@@ -691,11 +700,11 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 		#pragma unroll
 		for( int q = 0; q < H; ++q )
 			{
-			phk[q] += double( div_c( mfk[q].y, p.ar_div ) * FLANHIP_PI2_F );       // phase_vocoder.cpp:57-58
-			phm[q] += double( div_c( mfm[q].y, p.ar_div ) * FLANHIP_PI2_F );
+			phk[q] += double( div_c( mfk[q].y, k_ard ) * FLANHIP_PI2_F );          // phase_vocoder.cpp:57-58
+			phm[q] += double( div_c( mfm[q].y, k_ard ) * FLANHIP_PI2_F );
 			slow |= !( __builtin_fabs( phk[q] ) < double( FLANHIP_SINCOS_FAST_LIMIT ) ) || !( __builtin_fabs( phm[q] ) < double( FLANHIP_SINCOS_FAST_LIMIT ) );
 			}
-		phx += double( div_c( mfx.y, p.ar_div ) * FLANHIP_PI2_F );
+		phx += double( div_c( mfx.y, k_ard ) * FLANHIP_PI2_F );
 		slow |= !( __builtin_fabs( phx ) < double( FLANHIP_SINCOS_FAST_LIMIT ) );
 		cf xk[H], xm[H], xx;
 		if( __any( slow ) )
