@@ -672,6 +672,13 @@ int flanhip_debug_read_stamps( unsigned long long * out16 )
 	FLANHIP_CHECK( hipMemcpyToSymbol( HIP_SYMBOL( g_stamp_acc ), zero, sizeof( zero ) ) );
 	return FLANHIP_OK;
 	}
+// ... and the start / end of every wavefront's life in the last launch (s_memrealtime ticks of 10 ns; 2 x 4096 words)
+int flanhip_debug_read_spans( unsigned long long * out8192 )
+	{
+	FLANHIP_CHECK( hipDeviceSynchronize() );
+	FLANHIP_CHECK( hipMemcpyFromSymbol( out8192, HIP_SYMBOL( g_stamp_span ), 8192 * sizeof( unsigned long long ) ) );
+	return FLANHIP_OK;
+	}
 #endif
 
 size_t flanhip_synthesize_workspace_bytes( int64_t ch, int64_t F, int bins, float sr, float ar, int W )

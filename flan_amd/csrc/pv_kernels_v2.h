@@ -39,6 +39,7 @@ typedef float v4f_t __attribute__(( ext_vector_type( 4 ) ));
 // Diagnostic build only (tools/scripts/build_diag.sh stamps): where does a frame spend its cycles?  s_memtime between the sections of the
 // frame loop, per-section sums in scalar registers, added to g_stamp_acc once per wavefront.  Never quote this build's run time.
 __device__ unsigned long long g_stamp_acc[16];
+__device__ unsigned long long g_stamp_span[2 * 4096];      // per wavefront (block * 8 + wave): s_memrealtime (100 MHz) at the start and at the end of its life
 struct Stamps
 	{
 	unsigned long long last, acc[12], t_begin, r_begin;
@@ -56,13 +57,31 @@ struct Stamps
 		__builtin_amdgcn_sched_barrier( 0 );
 		return t;
 		}
+#ifdef FLANHIP_STAMPS_CLOCK_ONLY
+	// nothing is kept across the kernel (a live value would cost the frame loop registers): the start goes to memory at once
+	__device__ __forceinline__ void init()
+		{
+		const unsigned long long r = realtime();
+		const unsigned w = blockIdx.x * ( blockDim.x >> 6 ) + ( threadIdx.x >> 6 );
+		if( ( threadIdx.x & 63 ) == 0 && w < 4096 ) g_stamp_span[2 * w] = r;
+		}
+#else
 	__device__ __forceinline__ void init() { for( int i = 0; i < 12; ++i ) acc[i] = 0; r_begin = realtime(); last = now(); t_begin = last; }
+#endif
 #ifdef FLANHIP_STAMPS_CLOCK_ONLY
 	// clock-only form: the frame loop is the product's (no stamp, no fence inside it); only the wavefront's life is measured in both clocks
 	__device__ __forceinline__ void operator()( int ) const {}
 #else
 	__device__ __forceinline__ void operator()( int i ) { const unsigned long long t = now(); acc[i] += t - last; last = t; }
 #endif
+#ifdef FLANHIP_STAMPS_CLOCK_ONLY
+	__device__ __forceinline__ void flush( int lane )
+		{
+		const unsigned long long r = realtime();
+		const unsigned w = blockIdx.x * ( blockDim.x >> 6 ) + ( threadIdx.x >> 6 );
+		if( lane == 0 && w < 4096 ) { g_stamp_span[2 * w + 1] = r; atomicAdd( &g_stamp_acc[15], 1ull ); }
+		}
+#else
 	__device__ __forceinline__ void flush( int lane )
 		{
 		const unsigned long long t_end = now(), r_end = realtime();
@@ -72,8 +91,11 @@ struct Stamps
 			atomicAdd( &g_stamp_acc[12], t_end - t_begin );                    // shader-clock ticks of the wavefront's life
 			atomicAdd( &g_stamp_acc[13], r_end - r_begin );                    // the same span in 100 MHz ticks
 			atomicAdd( &g_stamp_acc[15], 1ull );
+			const unsigned w = blockIdx.x * ( blockDim.x >> 6 ) + ( threadIdx.x >> 6 );
+			if( w < 4096 ) { g_stamp_span[2 * w] = r_begin; g_stamp_span[2 * w + 1] = r_end; }
 			}
 		}
+#endif
 	};
 #else
 struct Stamps
@@ -190,7 +212,9 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 	const cf * s_win = s + L::WIN + lane;
 	const v4f_t * s_kc = reinterpret_cast<const v4f_t*>( s + L::KC ) + lane;
 	cf * buf = s + L::BUF + wave * L::BUF_LEN;
-
+	// (Two wavefronts share a SIMD, one of wavefronts 0-3 and one of 4-7 of the block, and the older one wins: wavefronts 0-3 of every block
+	// finish after ~112 us, 4-7 after ~129 us, profiles/r03_b_wave_spans.txt.  s_setprio 1 for the younger half -- for the whole chain, for its
+	// first half, or whenever it is behind its partner's published frame count -- changed neither the split nor the launch's time: not kept.)
 	// a block is a GROUP: WAVES consecutive chains of ONE channel (the last group of a channel may be short: its spare wavefronts idle).
 	// No wavefront leaves early: the fused epilogue below meets at a block barrier.
 	const int groups = ( p.chains_per_channel + WAVES - 1 ) / WAVES;
@@ -231,17 +255,22 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 
 	// does every frame this chain touches (its halo frame included) lie inside the signal?  (AudioPV.cpp:52-62 needs no bounds then)
 	const int64_t tfirst = t0 > 0 ? t0 - 1 : t0;
-	const bool chain_fast = ( W & 127 ) == 0 && int64_t( hop ) * tfirst - W / 2 >= 0 && int64_t( hop ) * ( t1 - 1 ) - W / 2 + 2 * int64_t( C ) <= p.n;
+	// Does frame t lie inside the signal with all of its 2 C samples (AudioPV.cpp:52-62 needs no bounds then)?  Decided PER FRAME: the first
+	// and the last chain of a channel have two to four frames that reach outside, and a launch lasts as long as its slowest wavefront -- with
+	// the clamped-load body chosen per chain those 16 chains ran 17 % longer than the 2032 others and set the launch's time
+	// (profiles/r03_b_wave_spans.txt).
+	const bool w_whole = ( W & 127 ) == 0;
+	auto frame_inside = [&]( int64_t t ) { return w_whole && int64_t( hop ) * t - W / 2 >= 0 && int64_t( hop ) * t - W / 2 + 2 * int64_t( C ) <= p.n; };
 
 	Stamps st;
 	st.init();
 	cf z[E];
-	auto run_chain = [&]( auto fast_tag )
+	auto run_chain = [&]()
 		{
-		constexpr bool FAST = decltype( fast_tag )::value;
-		// sample pair i = lane + 64 q of frame t
-		auto load_pair = [&]( int64_t t, int q ) -> cf
+		// sample pair i = lane + 64 q of frame t (fast_tag: the frame lies inside the signal)
+		auto load_pair = [&]( int64_t t, int q, auto fast_tag ) -> cf
 			{
+			constexpr bool FAST = decltype( fast_tag )::value;
 			const int start = int( int64_t( hop ) * ( ( ABL & 512 ) ? tfirst : t ) - W / 2 );
 			if constexpr( ( ABL & 16 ) != 0 ) return mk( float( start ) * 1e-9f + 0.25f, float( q ) );
 			else if constexpr( ( ABL & 128 ) != 0 && FAST )            // (interior chains only: the edge chains keep their clamped loads)
@@ -280,9 +309,9 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 				}
 			};
 		// window (AudioPV.cpp:60), transform; leaves the upper half of Z in buf (natural order) for the mirror reads
-		auto transform_frame = [&]( int64_t t )
+		auto transform_frame = [&]( int64_t t, auto fast_tag )
 			{
-			if constexpr( !FAST ) fix_raw( t );
+			if constexpr( !decltype( fast_tag )::value ) fix_raw( t );
 			#pragma unroll
 			for( int q = 0; q < E; ++q )
 				{
@@ -305,13 +334,13 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 		// drains the whole queue, stores included, once per frame (measured: a quarter of the kernel's time).
 		// HALO: frame t0 - 1, of which only the phases are wanted (phase_vocoder.cpp:45 leaves them in phase_buffer): a compile-time
 		// switch, not a branch.
-		auto bins_of_frame = [&]( int64_t t, int64_t tn, int fi, auto halo_tag )
+		auto bins_of_frame = [&]( int64_t t, int64_t tn, int fi, auto halo_tag, auto next_fast )
 			{
 			constexpr bool halo = decltype( halo_tag )::value;
 			const cf z512 = buf[544];                                             // Z[ C/2 ], slot PAD( 512 )
 			const cf z0 = z[0];                                                   // lane 0: Z[0]
 			#pragma unroll
-			for( int q = H; q < E; ++q ) z[q] = load_pair( tn, q );               // the upper half is in LDS now: its registers are free
+			for( int q = H; q < E; ++q ) z[q] = load_pair( tn, q, next_fast );    // the upper half is in LDS now: its registers are free
 			st( 4 );                                                              // 4: mirror exchange written, upper half of the next frame requested
 			cf * row = reinterpret_cast<cf*>( p.out + ( int64_t( channel ) * p.F + ( ( ABL & 256 ) ? t0 : t ) ) * ( C + 1 ) );
 			cf * rowk = row + lane;
@@ -333,7 +362,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 					const cf zm = ( ABL & 32 ) ? zk : mirror[-68 * q];              // lane 0, q = 0 reads an unused slot: overridden below
 					const cf w = s_w2[64 * q];                                      // 0.5 exp( -2 pi i k / 2C )
 					const v4f_t kc = s_kc[64 * q];
-					z[q] = load_pair( tn, q );                                      // Z[k] is consumed: next frame's samples take its place
+					z[q] = load_pair( tn, q, next_fast );                           // Z[k] is consumed: next frame's samples take its place
 					const float sx = zk.x + zm.x, dy = zk.y + zm.y, dx = zk.x - zm.x, sy = zk.y - zm.y;
 					const float t1v = __builtin_fmaf( w.x, dy, w.y * dx );
 					const float t2v = __builtin_fmaf( w.x, dx, -( w.y * dy ) );
@@ -450,25 +479,42 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 				}
 			};
 
-		#pragma unroll
-		for( int q = 0; q < E; ++q ) z[q] = load_pair( tfirst, q );
-		transform_frame( tfirst );
+		constexpr std::true_type inside{};
+		constexpr std::false_type outside{};
+		if( frame_inside( tfirst ) )
+			{
+			#pragma unroll
+			for( int q = 0; q < E; ++q ) z[q] = load_pair( tfirst, q, inside );
+			transform_frame( tfirst, inside );
+			}
+		else
+			{
+			#pragma unroll
+			for( int q = 0; q < E; ++q ) z[q] = load_pair( tfirst, q, outside );
+			transform_frame( tfirst, outside );
+			}
 		int fi = 0;
 		if( t0 > 0 )
 			{
-			bins_of_frame( t0 - 1, t0, fi, std::true_type{} );
+			if( frame_inside( t0 ) ) { bins_of_frame( t0 - 1, t0, fi, std::true_type{}, inside ); transform_frame( t0, inside ); }
+			else { bins_of_frame( t0 - 1, t0, fi, std::true_type{}, outside ); transform_frame( t0, outside ); }
 			++fi;
-			transform_frame( t0 );
 			}
 		for( int64_t t = t0; t < t1; ++t )
 			{
-			bins_of_frame( t, min( t + 1, t1 - 1 ), fi, std::false_type{} );      // (the last frame requests itself again: nobody waits for it)
-			++fi;
-			if( ( fi & 63 ) == 0 || t + 1 == t1 ) flush_half_bin( t + 1 - ( ( ( fi - 1 ) & 63 ) + 1 ), ( ( fi - 1 ) & 63 ) + 1 );
-			if( t + 1 < t1 ) transform_frame( t + 1 );
+			const int64_t tn = min( t + 1, t1 - 1 );                               // (the last frame requests itself again: nobody waits for it)
+			const bool more = t + 1 < t1;
+			auto rest_of_step = [&]( auto next_fast )
+				{
+				bins_of_frame( t, tn, fi, std::false_type{}, next_fast );
+				++fi;
+				if( ( fi & 63 ) == 0 || !more ) flush_half_bin( t + 1 - ( ( ( fi - 1 ) & 63 ) + 1 ), ( ( fi - 1 ) & 63 ) + 1 );
+				if( more ) transform_frame( t + 1, next_fast );
+				};
+			if( frame_inside( tn ) ) rest_of_step( inside ); else rest_of_step( outside );
 			}
 		};
-	if( active ) { if( chain_fast ) run_chain( std::true_type{} ); else run_chain( std::false_type{} ); }
+	if( active ) run_chain();
 	st.flush( lane );
 
 	if constexpr( SUMS )
@@ -691,6 +737,8 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 		phx = carry[C / 2];
 		}
 	if( !active ) return;
+	Stamps st;                                                                  // (diagnostic builds: the wavefront's life, tools/wave_spans.py)
+	st.init();
 	cf z[E];
 	// inverse phase vocoder of the row in mfk / mfm / mfx (AudioPV.cpp:117-120, phase_vocoder.cpp:55-61), merge of X[0..C] into the
 	// half-size spectrum conj( A + i B ) (the forward transform of it is the conjugate of the inverse one): leaves z[] complete
@@ -802,6 +850,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 		if( a0 < flush_end ) emit_step( a0, acc[q] );
 		}
 	for( int64_t a0 = pos + 128 * E; a0 < flush_end; a0 += 128 ) emit_step( a0, mk( 0.0f, 0.0f ) );
+	st.flush( lane );
 	}
 
 } // namespace flanhip
