@@ -94,18 +94,22 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_eo( AnalyzeParams p, F
 	for( int q = 0; q < Q; ++q ) { prev[q][0] = 0.0f; prev[q][1] = 0.0f; prev[q][2] = 0.0f; prev[q][3] = 0.0f; }   // AudioPV.cpp:44
 
 	const int64_t tfirst = t0 > 0 ? t0 - 1 : t0;
-	const bool chain_fast = W == 2048 && int64_t( hop ) * tfirst - W / 2 >= 0 && int64_t( hop ) * ( t1 - 1 ) - W / 2 + 2048 <= p.n;
+	// does frame t lie inside the signal with all its 2048 samples?  Per FRAME, not per chain: the edge chains (the first and the last of a
+	// channel) have a few frames that reach outside, and a launch lasts as long as its slowest wavefront (see k_analyze_v2)
+	auto frame_inside = [&]( int64_t t ) { return W == 2048 && int64_t( hop ) * t - W / 2 >= 0 && int64_t( hop ) * t - W / 2 + 2048 <= p.n; };
+	constexpr std::true_type inside{};
+	constexpr std::false_type outside{};
 
 	// samples 4 i .. 4 i + 3 of frame t, i = lane + 64 q: c[2i] = ( x[4i], x[4i+1] ) is the even transform's point i, c[2i+1] the odd one's.
 	// The even halves are requested during the per-bin work of the frame before; the odd halves only when the even transform starts (it
 	// covers their latency) -- 16 registers less across the per-bin work than requesting all of a frame at once.
 	cf raw_e[Q], raw_o[Q];
-	auto run_chain = [&]( auto fast_tag )
+	auto run_chain = [&]()
 		{
-		constexpr bool FAST = decltype( fast_tag )::value;
 		struct __attribute__(( packed, aligned( 4 ) )) f2u { float x, y; };
-		auto load_half = [&]( int64_t t, int odd, cf ( &dst )[Q] )
+		auto load_half = [&]( int64_t t, int odd, cf ( &dst )[Q], auto fast_tag )
 			{
+			constexpr bool FAST = decltype( fast_tag )::value;
 			const int start = int( int64_t( hop ) * t - W / 2 ) + 2 * odd;
 			#pragma unroll
 			for( int q = 0; q < Q; ++q )
@@ -129,9 +133,9 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_eo( AnalyzeParams p, F
 			};
 		// window (AudioPV.cpp:60), the two transforms; leaves E and O in natural order in bufE / bufO (a lane's own E[k], O[k] too: 32
 		// registers less across the per-bin work than keeping them)
-		auto transform_frame = [&]( int64_t t )
+		auto transform_frame = [&]( int64_t t, auto fast_tag )
 			{
-			load_half( t, 1, raw_o );                                             // travels under the even transform
+			load_half( t, 1, raw_o, fast_tag );                                   // travels under the even transform
 			cf z[16];
 			#pragma unroll
 			for( int q = 0; q < Q; ++q )
@@ -157,7 +161,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_eo( AnalyzeParams p, F
 			};
 
 		// per-bin work of frame t (requests frame tn's samples first); HALO: frame t0 - 1, of which only the phases are wanted
-		auto bins_of_frame = [&]( int64_t t, int64_t tn, auto halo_tag )
+		auto bins_of_frame = [&]( int64_t t, int64_t tn, auto halo_tag, auto next_fast )
 			{
 			constexpr bool halo = decltype( halo_tag )::value;
 			const cf e512 = bufE[544], o512 = bufO[544];                          // slot PAD( 512 )
@@ -172,7 +176,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_eo( AnalyzeParams p, F
 				{
 				// the next frame's samples are requested half way through: by then half of e[] / o[] is dead and their registers hold the
 				// request (the 16 stores in front of it are long acknowledged when the transform waits for these loads)
-				if( g == Q / QV / 2 ) load_half( tn, 0, raw_e );
+				if( g == Q / QV / 2 ) load_half( tn, 0, raw_e, next_fast );
 				VB re, im, pv, binf;
 				#pragma unroll
 				for( int i = 0; i < QV; ++i )
@@ -264,20 +268,25 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_eo( AnalyzeParams p, F
 			wave_sync();                                                          // the mirror halves are read: the next transform may overwrite them
 			};
 
-		load_half( tfirst, 0, raw_e );
-		transform_frame( tfirst );
+		if( frame_inside( tfirst ) ) { load_half( tfirst, 0, raw_e, inside ); transform_frame( tfirst, inside ); }
+		else { load_half( tfirst, 0, raw_e, outside ); transform_frame( tfirst, outside ); }
 		if( t0 > 0 )
 			{
-			bins_of_frame( t0 - 1, t0, std::true_type{} );
-			transform_frame( t0 );
+			if( frame_inside( t0 ) ) { bins_of_frame( t0 - 1, t0, std::true_type{}, inside ); transform_frame( t0, inside ); }
+			else { bins_of_frame( t0 - 1, t0, std::true_type{}, outside ); transform_frame( t0, outside ); }
 			}
 		for( int64_t t = t0; t < t1; ++t )
 			{
-			bins_of_frame( t, min( t + 1, t1 - 1 ), std::false_type{} );          // (the last frame requests itself again: nobody waits for it)
-			if( t + 1 < t1 ) transform_frame( t + 1 );
+			const int64_t tn = min( t + 1, t1 - 1 );                               // (the last frame requests itself again: nobody waits for it)
+			auto rest_of_step = [&]( auto next_fast )
+				{
+				bins_of_frame( t, tn, std::false_type{}, next_fast );
+				if( t + 1 < t1 ) transform_frame( t + 1, next_fast );
+				};
+			if( frame_inside( tn ) ) rest_of_step( inside ); else rest_of_step( outside );
 			}
 		};
-	if( chain_fast ) run_chain( std::true_type{} ); else run_chain( std::false_type{} );
+	run_chain();
 
 	}
 
@@ -382,15 +391,17 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 	const int64_t tfirst = t0 > 0 ? t0 - 1 : t0;
 	const int frames = active ? int( t1 - tfirst ) : 0;                       // iterations with work (the halo frame included)
 	const int iters = p.L + 1;                                                // what every team of every block walks
-	const bool chain_fast = W == 2048 && int64_t( hop ) * tfirst - W / 2 >= 0 && int64_t( hop ) * ( t1 - 1 ) - W / 2 + 2048 <= p.n;
+	auto frame_inside = [&]( int64_t t ) { return W == 2048 && int64_t( hop ) * t - W / 2 >= 0 && int64_t( hop ) * t - W / 2 + 2048 <= p.n; };   // per frame (see k_analyze_eo)
+	constexpr std::true_type inside{};
+	constexpr std::false_type outside{};
 
 	cf raw[2 * Q];                                                            // this wavefront's half of a frame: points lane + 64 q, q < 8, of its parity
-	auto run_chain = [&]( auto fast_tag )
+	auto run_chain = [&]()
 		{
-		constexpr bool FAST = decltype( fast_tag )::value;
 		struct __attribute__(( packed, aligned( 4 ) )) f2u { float x, y; };
-		auto load_half = [&]( int64_t t )
+		auto load_half = [&]( int64_t t, auto fast_tag )
 			{
+			constexpr bool FAST = decltype( fast_tag )::value;
 			const int start = int( int64_t( hop ) * t - W / 2 ) + 2 * role;
 			const float * xs = x + start + 4 * lane + 1024;                       // one address per lane: the eight loads reach -4096 .. +3072 bytes from it (immediates)
 			#pragma unroll
@@ -427,7 +438,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 			for( int q = 0; q < 4 * Q; ++q ) mybuf[padl + 68 * q] = z[q];              // natural order: slot PAD( lane + 64 q )
 			};
 
-		auto bins_of_frame = [&]( int64_t t, int64_t tn, int set, auto halo_tag )
+		auto bins_of_frame = [&]( int64_t t, int64_t tn, int set, auto halo_tag, auto next_fast )
 			{
 			constexpr bool halo = decltype( halo_tag )::value;
 			const cf * bufE = buf0 + 2 * set * L::BUF_LEN, * bufO = bufE + L::BUF_LEN;
@@ -442,7 +453,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 			#pragma unroll
 			for( int g = 0; g < Q / QV; ++g )
 				{
-				if( g == Q / QV / 2 ) load_half( tn );                                   // the next frame's half travels during the second half of the bins
+				if( g == Q / QV / 2 ) load_half( tn, next_fast );                        // the next frame's half travels during the second half of the bins
 				VB re, im, pv, binf;
 				#pragma unroll
 				for( int i = 0; i < QV; ++i )
@@ -558,7 +569,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 				}
 			};
 
-		if( frames > 0 ) { load_half( tfirst ); transform_frame( 0 ); }
+		if( frames > 0 ) { if( frame_inside( tfirst ) ) load_half( tfirst, inside ); else load_half( tfirst, outside ); transform_frame( 0 ); }
 		team_sync.meet();
 		for( int i = 0; i < iters; ++i )
 			{
@@ -567,8 +578,16 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 				{
 				const int64_t t = tfirst + i, tn = min( t + 1, t1 - 1 );           // (the last frame requests itself again: nobody waits for it)
 				fidx = i;
-				if( t0 > 0 && i == 0 ) bins_of_frame( t, tn, set, std::true_type{} );
-				else bins_of_frame( t, tn, set, std::false_type{} );
+				if( frame_inside( tn ) )
+					{
+					if( t0 > 0 && i == 0 ) bins_of_frame( t, tn, set, std::true_type{}, inside );
+					else bins_of_frame( t, tn, set, std::false_type{}, inside );
+					}
+				else
+					{
+					if( t0 > 0 && i == 0 ) bins_of_frame( t, tn, set, std::true_type{}, outside );
+					else bins_of_frame( t, tn, set, std::false_type{}, outside );
+					}
 				if( role == 1 && ( ( i & 63 ) == 63 || i == frames - 1 ) ) flush_orphans( t - ( i & 63 ), ( i & 63 ) + 1 );
 				}
 			// one buffer set: nobody may write the next frame's E / O before both halves have read this one's.  Two sets: the next frame goes
@@ -578,7 +597,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 			team_sync.meet();                                                     // the next frame's E / O are written
 			}
 		};
-	if( chain_fast ) run_chain( std::true_type{} ); else run_chain( std::false_type{} );
+	run_chain();
 
 	if constexpr( SUMS )
 		{

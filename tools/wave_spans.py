@@ -63,6 +63,10 @@ def main():
     inner_blocks = np.array([b for b in range(256) if b % 32 not in (0, 31)])
     print("life by wave slot of the block (interior blocks, median): " + "  ".join("%d:%.1f" % (w, np.median(li.reshape(256, 8)[inner_blocks, w])) for w in range(8)))
     print("start by wave slot: " + "  ".join("%d:%.2f" % (w, np.median(st.reshape(256, 8)[inner_blocks, w])) for w in range(8)))
+    by_group = st.reshape(8, 32, 8).mean(2)          # [channel][group of 8 chains]: when the group's wavefronts enter their frame loop
+    print("start by group of the channel (median over channels): " + " ".join("%.1f" % v for v in np.median(by_group, 0)))
+    by_group_end = en.reshape(8, 32, 8).max(2)
+    print("end of the group's last wavefront (median over channels): " + " ".join("%.0f" % v for v in np.median(by_group_end, 0)))
     per_simd = li.reshape(256, 8)
     print("per block: fastest wave %.1f  slowest %.1f (median over blocks)" % (np.median(per_simd.min(1)), np.median(per_simd.max(1))))
 
