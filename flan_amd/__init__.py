@@ -55,6 +55,8 @@ _SIGS = {
     "flanhip_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "flanhip_memset": (C.c_int, [_vp, _i32, C.c_size_t, _vp]),
     "flanhip_stream_synchronize": (C.c_int, [_vp]),
+    "flanhip_wait_cancellable": (C.c_int, [_vp, _vp]),
+    "flanhip_wait_cancellable_fn": (C.c_int, [_vp, _vp, _vp]),
     "flanhip_analyze": (C.c_int, [_vp, _i64, _i64, _f32, _i32, _i32, _i32, _vp, C.POINTER(_i64), _vp]),
     "flanhip_analyze_dev": (C.c_int, [_vp, _i64, _i64, _f32, _i32, _i32, _i32, _vp, _vp]),
     "flanhip_synthesize": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _i32, _vp, C.POINTER(_i32), _vp]),

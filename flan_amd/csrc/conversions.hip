@@ -337,6 +337,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	if( int rc = get_div_plan( p.analysis_rate, &dp ) ) return rc;
 	p.ar_div = DivC{ dp.c, dp.rc, dp.exact };
 	p.sums = nullptr; p.nan_out = nullptr; p.nan_epoch = 0;
+	p.cancel = thread_cancel_word();                                              // kernels stop starting chains when the thread's wait raises it (core.hip)
 	const bool kernel_sums = !any;                                                // every FFT analysis kernel keeps the sums; the direct-sum kernel leaves them to the pre-pass kernel
 	SynthLayout fused_lay{};
 	if( d_fused_ws )
@@ -497,6 +498,7 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	p.nan_in = ( presummed == 1 || presummed == 2 ) ? reinterpret_cast<const int*>( reinterpret_cast<char*>( d_ws ) + lay.carry_bytes + lay.head_bytes ) : nullptr;
 	p.skip_words = presummed == 2 ? p.nan_in : nullptr;
 	p.carry_in = d_carry_in; p.total_out = d_total_out; p.total_only = prepass_only ? 1 : 0;
+	p.cancel = thread_cancel_word();
 
 	const int64_t chains = int64_t( p.chains_per_channel ) * ch;
 	FLANHIP_REQUIRE( chains < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
@@ -536,6 +538,7 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 		q.frames = reinterpret_cast<float*>( reinterpret_cast<char*>( d_ws ) + lay.any_frames_offset );
 		q.F = F; q.out_len = p.out_len; q.num_channels = int( ch ); q.bins = bins; q.N = lay.dft; q.W = W; q.hop = lay.hop;
 		q.L = lay.L; q.chains_per_channel = lay.chains_per_channel; q.analysis_rate = ar; q.window_scale = p.window_scale;
+		q.cancel = p.cancel;
 		const unsigned bin_blocks = (unsigned) ( ( bins + ANY_THREADS - 1 ) / ANY_THREADS );
 		FLANHIP_REQUIRE( chains <= 65535, FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
 		const int64_t batches = ( ch * F + ANY_FB - 1 ) / ANY_FB;
@@ -654,8 +657,7 @@ int flanhip_analyze( const float * audio, int64_t ch, int64_t n, float sr, int W
 	if( int rc_t = flanhip_upload( d_audio.p, audio, sizeof( float ) * size_t( ch ) * n ) ) return rc_t;
 	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
 	if( int rc = launch_analyze( (const float*) d_audio.p, ch, n, sr, W, hop, dft, (flanhip_MF*) d_pv.p, nullptr, nullptr ) ) return rc;
-	FLANHIP_CHECK( hipDeviceSynchronize() );
-	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
+	if( int rc = wait_cancellable( nullptr, cancel ? poll_volatile_int : nullptr, const_cast<int*>( cancel ) ) ) return rc;   // a flag raised while the kernels run stops them (core.hip)
 	if( int rc_t = flanhip_download( out, d_pv.p, sizeof( flanhip_MF ) * size_t( ch ) * F * bins ) ) return rc_t;
 	return FLANHIP_OK;
 	}
@@ -713,8 +715,7 @@ int flanhip_synthesize( const flanhip_MF * pv, int64_t ch, int64_t F, int bins, 
 	if( int rc_t = flanhip_upload( d_pv.p, pv, pv_bytes ) ) return rc_t;
 	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
 	if( int rc = launch_synthesize( (const flanhip_MF*) d_pv.p, ch, F, bins, sr, ar, W, (float*) d_out.p, d_ws.p, (int*) d_flag.p, false, nullptr ) ) return rc;
-	FLANHIP_CHECK( hipDeviceSynchronize() );
-	if( cancelled( cancel ) ) return FLANHIP_ERR_CANCELLED;
+	if( int rc = wait_cancellable( nullptr, cancel ? poll_volatile_int : nullptr, const_cast<int*>( cancel ) ) ) return rc;
 	if( int rc_t = flanhip_download( out, d_out.p, out_bytes ) ) return rc_t;
 	int flag = 0;
 	FLANHIP_CHECK( hipMemcpy( &flag, d_flag.p, sizeof( int ), hipMemcpyDeviceToHost ) );

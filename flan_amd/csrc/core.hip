@@ -1,5 +1,7 @@
 // core.hip -- error state, device plumbing, plan cache, shape helpers of the C ABI (include/flanhip.h).
 #include "flanhip_internal.h"
+#include <thread>
+#include <chrono>
 #include <atomic>
 #include <algorithm>
 #include <cstdlib>
@@ -176,6 +178,80 @@ int workspace_producer( const void * d_ws )
 	return it == g_ws_producer.end() ? 0 : it->second;
 	}
 
+// ---- cancellation inside a launch (defines.h:49-62: the reference polls its flag once per frame, AudioPV.cpp:49,115) -----------------
+// Every host thread owns one int of FINE-GRAINED device memory per device (coherent across the chip's XCDs and with the copy engines; page-locked
+// coherent host memory if that cannot be had), the CANCEL WORD: the conversion kernels launched by that thread get its address and read it,
+// past their caches, when a block starts (the direct-sum kernels also every few batches of frames).  wait_cancellable() waits for a stream
+// while it polls the caller's flag; when that rises it sets the word from a side stream, the blocks still to start retire at once (a block of
+// the FFT kernels walks at most 512 frames: ~3 ms), and the call returns FLANHIP_ERR_CANCELLED.  The word is the thread's own: a cancelled call
+// does not touch what other threads have in flight.
+struct CancelWord { int * dev = nullptr; volatile int * host = nullptr; hipStream_t side = nullptr; };   // host != nullptr: the host-memory fallback
+struct ThreadCancel { std::map<int, CancelWord> words; };
+static thread_local ThreadCancel t_cancel;
+
+static CancelWord * thread_cancel_entry()
+	{
+	int device = 0;
+	if( hipGetDevice( &device ) != hipSuccess ) return nullptr;
+	auto it = t_cancel.words.find( device );
+	if( it == t_cancel.words.end() )
+		{
+		CancelWord w;
+		void * d = nullptr;
+		if( hipExtMallocWithFlags( &d, 256, hipDeviceMallocFinegrained ) == hipSuccess && hipMemset( d, 0, 256 ) == hipSuccess )
+			{
+			w.dev = static_cast<int*>( d );
+			if( hipStreamCreateWithFlags( &w.side, hipStreamNonBlocking ) != hipSuccess ) { (void) hipGetLastError(); (void) hipFree( d ); return nullptr; }
+			}
+		else
+			{
+			(void) hipGetLastError();
+			void * h = nullptr; void * dp = nullptr;
+			if( hipHostMalloc( &h, 256, hipHostMallocCoherent | hipHostMallocMapped ) != hipSuccess ) { (void) hipGetLastError(); return nullptr; }
+			std::memset( h, 0, 256 );
+			if( hipHostGetDevicePointer( &dp, h, 0 ) != hipSuccess ) { (void) hipGetLastError(); (void) hipHostFree( h ); return nullptr; }
+			w.dev = static_cast<int*>( dp ); w.host = static_cast<volatile int*>( h );
+			}
+		it = t_cancel.words.emplace( device, w ).first;
+		}
+	return &it->second;
+	}
+
+int * thread_cancel_word()
+	{
+	CancelWord * w = thread_cancel_entry();
+	return w ? w->dev : nullptr;
+	}
+
+static void set_cancel_word( CancelWord & w, int value, bool wait )
+	{
+	if( w.host ) { *w.host = value; std::atomic_thread_fence( std::memory_order_seq_cst ); return; }
+	(void) hipMemsetAsync( w.dev, value, sizeof( int ), w.side );              // (a byte value: 1 gives 0x01010101 -- non-zero is all that counts)
+	if( wait ) (void) hipStreamSynchronize( w.side );
+	}
+
+int wait_cancellable( hipStream_t s, int ( *poll )( void * ), void * user )
+	{
+	CancelWord * w = poll ? thread_cancel_entry() : nullptr;
+	if( !w ) { FLANHIP_CHECK( hipStreamSynchronize( s ) ); return ( poll && poll( user ) ) ? FLANHIP_ERR_CANCELLED : FLANHIP_OK; }
+	hipEvent_t done;
+	FLANHIP_CHECK( hipEventCreateWithFlags( &done, hipEventDisableTiming ) );
+	if( hipEventRecord( done, s ) != hipSuccess ) { (void) hipEventDestroy( done ); set_error( "hipEventRecord failed" ); return FLANHIP_ERR_HIP; }
+	bool raised = false;
+	int spins = 0;
+	for( ;; )
+		{
+		const hipError_t q = hipEventQuery( done );
+		if( q == hipSuccess ) break;
+		if( q != hipErrorNotReady ) { (void) hipEventDestroy( done ); if( raised ) set_cancel_word( *w, 0, true ); set_error( "hipEventQuery failed" ); return FLANHIP_ERR_HIP; }
+		if( !raised && poll( user ) ) { set_cancel_word( *w, 1, false ); raised = true; }
+		if( ++spins < 200 ) std::this_thread::yield(); else std::this_thread::sleep_for( std::chrono::microseconds( 50 ) );
+		}
+	(void) hipEventDestroy( done );
+	if( raised ) { set_cancel_word( *w, 0, true ); return FLANHIP_ERR_CANCELLED; }     // (the stream has drained: nobody reads the word now)
+	return poll( user ) ? FLANHIP_ERR_CANCELLED : FLANHIP_OK;
+	}
+
 int next_epoch()
 	{
 	// 1, 2, 3, ... 2^31 - 1, 1, ...: never 0, and two successive producer launches never share a number (the workspace words are
@@ -305,6 +381,20 @@ int flanhip_stream_synchronize( void * stream )
 	{
 	FLANHIP_CHECK( hipStreamSynchronize( (hipStream_t) stream ) );
 	return FLANHIP_OK;
+	}
+
+static int poll_int_flag( void * user ) { volatile int * c = static_cast<volatile int*>( user ); return c && *c != 0; }
+
+int flanhip_wait_cancellable( void * stream, volatile int * cancel )
+	{
+	if( int rc = require_device() ) return rc;
+	return wait_cancellable( (hipStream_t) stream, cancel ? poll_int_flag : nullptr, const_cast<int*>( cancel ) );
+	}
+
+int flanhip_wait_cancellable_fn( void * stream, int ( *poll )( void * ), void * user )
+	{
+	if( int rc = require_device() ) return rc;
+	return wait_cancellable( (hipStream_t) stream, poll, user );
 	}
 
 } // extern "C"

@@ -31,6 +31,11 @@ int require_device();   // FLANHIP_OK or FLANHIP_ERR_NO_DEVICE
 inline bool is_pow2( int64_t n ) { return n > 0 && ( n & ( n - 1 ) ) == 0; }
 inline int ilog2( int64_t n ) { int l = 0; while( ( int64_t( 1 ) << l ) < n ) ++l; return l; }
 inline bool cancelled( volatile int * c ) { return c && *c != 0; }
+// cancellation inside a launch (core.hip): the calling thread's cancel word on the current device (kernels poll it; nullptr if it cannot be had),
+// and a wait for a stream that polls `poll( user )` and raises the word when it says so (FLANHIP_ERR_CANCELLED then)
+int * thread_cancel_word();
+int wait_cancellable( hipStream_t s, int ( *poll )( void * ), void * user );
+inline int poll_volatile_int( void * user ) { volatile int * c = static_cast<volatile int*>( user ); return c && *c != 0; }
 
 // Device tables for one (window, dft) pair on one device: the analogue of the reference's FFTHelper plan
 // (FFTHelper.cpp:16-26) plus the sampled Hann window (AudioPV.cpp:30-34).  Built once, cached, never freed.

@@ -44,7 +44,16 @@ struct AnalyzeParams
 	int nan_epoch;            // a fresh non-zero number per launch
 	double * group_sums;      // optional (dft 2048 kernel, blocks = groups of 8 chains of one channel): [ch][groups][bins] folded sums of each group's chains
 	int groups_per_channel;
+	const int * cancel;       // optional: the launching thread's cancel word (core.hip); a wavefront that finds it set when it starts walks no chain
 	};
+
+// Is the launch being cancelled?  cancel_peek() issues ONE read past the caches (the word is fine-grained memory) -- at the top of a kernel, so
+// that it travels under the prologue's table loads; cancel_seen() consumes it (wave-uniform by construction).
+__device__ __forceinline__ int cancel_peek( const int * word )
+	{
+	return word ? __hip_atomic_load( word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM ) : 0;
+	}
+__device__ __forceinline__ bool cancel_seen( int peeked ) { return __builtin_amdgcn_readfirstlane( peeked ) != 0; }
 
 // phase_vocoder.cpp:37-52 with the reference's rounding sequence (the file is compiled with -ffp-contract=off); the same helpers as
 // the tuned kernels (pv_math.h): atan2_fast (1.8 ulp), divisions by pi2 as exact 3-instruction sequences, |z| as fma + sqrt on
@@ -89,9 +98,14 @@ __global__ __launch_bounds__( 64 * WAVES * T ) void k_analyze( AnalyzeParams p )
 	float * s_prev_all = reinterpret_cast<float*>( s_buf_all + WAVES * padded_len( C ) );   // WAVES x ( C + 4 ), BIG only
 
 	const int tid = threadIdx.x, lane = T == 1 ? ( tid & 63 ) : tid, wave = T == 1 ? ( tid >> 6 ) : 0;
+	// cancellation (core.hip): a team of several wavefronts meets at block barriers in its frame loop, so the decision is the BLOCK's --
+	// thread 0 reads the word and everybody learns it at the barrier that ends the prologue
+	__shared__ int s_cancel;
+	if( tid == 0 ) s_cancel = cancel_peek( p.cancel );
 	if constexpr( !BIG ) for( int i = tid; i < C; i += NT ) s_tw[i] = p.tw[i];
 	for( int i = tid; i < p.window_size; i += NT ) s_win[i] = p.window[i];
 	__syncthreads();
+	if( s_cancel ) return;
 	const cf * tw = BIG ? p.tw : s_tw;
 
 	cf * buf = s_buf_all + wave * padded_len( C );
@@ -289,6 +303,7 @@ struct SynthParams
 	int * nan_words;          // optional (pre-pass run on behalf of a producer): the producer's { flag, -, epoch } words to write
 	int nan_epoch;
 	const int * skip_words;   // optional: the pre-pass retires at once when words [4] and [2] agree (the producer of the PV left the sums)
+	const int * cancel;        // optional: the launching thread's cancel word (see AnalyzeParams)
 	const double * group_sums; // optional (dft 2048 kernel): the producer's per-group sums -- the kernel then computes its own carries from them and
 	int groups_per_channel;    // from the chain sums in `carry` (which it leaves untouched), and no scan kernel runs
 	};
@@ -317,12 +332,15 @@ __global__ __launch_bounds__( 64 * WAVES * T ) void k_synthesize( SynthParams p 
 	double * s_ph_all = reinterpret_cast<double*>( s_ring_all + WAVES * wpad );   // WAVES x ( C + 2 ), BIG only (wpad is a multiple of 4: 16-byte aligned)
 
 	const int tid = threadIdx.x, lane = T == 1 ? ( tid & 63 ) : tid, wave = T == 1 ? ( tid >> 6 ) : 0;
+	__shared__ int s_cancel;                                                    // (see k_analyze)
+	if( tid == 0 ) s_cancel = cancel_peek( p.cancel );
 	if constexpr( !BIG ) for( int i = tid; i < C; i += NT ) s_tw[i] = p.tw[i];
 	const cf * tw = BIG ? p.tw : s_tw;
 	for( int i = tid; i < W; i += NT ) s_win[i] = p.window[i] * p.window_scale;   // AudioPV.cpp:102
 	float * ring = s_ring_all + wave * wpad;
 	for( int i = lane; i < W; i += TEAM ) ring[i] = 0.0f;
 	__syncthreads();
+	if( s_cancel ) return;
 
 	cf * buf = s_buf_all + wave * padded_len( C + 1 );
 	const int64_t chain = int64_t( blockIdx.x ) * WAVES + wave;

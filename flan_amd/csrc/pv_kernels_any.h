@@ -49,7 +49,11 @@ __global__ __launch_bounds__( ANY_THREADS ) void k_analyze_any( AnalyzeParams p,
 	const float expected = binf / p.analysis_rate * FLANHIP_PI2_F;                // phase_vocoder.cpp:47
 	const d2 step = have_bin ? d2{ unit[k].x, -unit[k].y } : d2{ 1.0, 0.0 };       // exp( -2 pi i k / N )
 	float prev = 0.0f;                                                            // AudioPV.cpp:44
-	for( int64_t tb = tfirst; tb < t1; tb += ANY_FB )
+	// cancellation (core.hip): these launches can last tenths of a second, so besides the block's start the word is read again every 8 batches
+	// of frames -- by thread 0, published through LDS at the barriers the sample tiles need anyway
+	__shared__ int s_cancel;
+	int batch = 0;
+	for( int64_t tb = tfirst; tb < t1; tb += ANY_FB, ++batch )
 		{
 		d2 acc[ANY_FB];
 		#pragma unroll
@@ -57,6 +61,7 @@ __global__ __launch_bounds__( ANY_THREADS ) void k_analyze_any( AnalyzeParams p,
 		for( int n0 = 0; n0 < W; n0 += ANY_TILE )
 			{
 			__syncthreads();
+			if( tid == 0 && n0 == 0 && ( batch & 7 ) == 0 ) s_cancel = cancel_peek( p.cancel );   // written between the two barriers, read after the second
 			#pragma unroll
 			for( int f = 0; f < ANY_FB; ++f )
 				{
@@ -68,6 +73,7 @@ __global__ __launch_bounds__( ANY_THREADS ) void k_analyze_any( AnalyzeParams p,
 				s_tile[f][tid] = double( v );
 				}
 			__syncthreads();
+			if( s_cancel ) return;                                                  // (block-uniform: everybody reads it after the same barrier)
 			if( have_bin )
 				{
 				const int len = min( ANY_TILE, W - n0 );
@@ -109,13 +115,14 @@ struct AnySynthParams
 	{
 	const MF * pv; const double * carry; float * spec; float * frames; float * out; const float * window;
 	int64_t F, out_len; int num_channels, bins, N, W, hop, L, chains_per_channel; float analysis_rate, window_scale;
+	const int * cancel;       // the launching thread's cancel word (core.hip), or null
 	};
 
 // inverse phase vocoder (AudioPV.cpp:117-120, phase_vocoder.cpp:55-61): thread = ( chain, bin ), frames in order; spec[ch][F][bins] = X
 __global__ __launch_bounds__( ANY_THREADS ) void k_any_spectra( AnySynthParams p )
 	{
 	const int k = int( blockIdx.x ) * ANY_THREADS + threadIdx.x;
-	if( k >= p.bins ) return;
+	if( k >= p.bins || cancel_seen( cancel_peek( p.cancel ) ) ) return;          // (no barriers in this kernel)
 	const int channel = int( blockIdx.y ) / p.chains_per_channel, chain = int( blockIdx.y ) % p.chains_per_channel;
 	const int64_t t0 = int64_t( chain ) * p.L, t1 = min( t0 + int64_t( p.L ), p.F );
 	double phase = p.carry[( int64_t( channel ) * p.chains_per_channel + chain ) * p.bins + k];
@@ -147,6 +154,10 @@ __global__ __launch_bounds__( ANY_THREADS ) void k_any_inverse( AnySynthParams p
 	double acc[ANY_FB];
 	#pragma unroll
 	for( int f = 0; f < ANY_FB; ++f ) acc[f] = 0.0;
+	__shared__ int s_cancel;
+	if( tid == 0 ) s_cancel = cancel_peek( p.cancel );
+	__syncthreads();
+	if( s_cancel ) return;
 	for( int k0 = 0; k0 < p.bins; k0 += ANY_TILE )
 		{
 		__syncthreads();

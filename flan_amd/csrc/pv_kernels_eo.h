@@ -73,7 +73,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_eo( AnalyzeParams p, F
 	cf * bufO = bufE + L::BUF_LEN;
 
 	const int64_t chain = int64_t( blockIdx.x ) * WAVES + wave;
-	if( chain >= int64_t( p.chains_per_channel ) * p.num_channels ) return;   // no block barrier below
+	if( chain >= int64_t( p.chains_per_channel ) * p.num_channels || cancel_seen( cancel_peek( p.cancel ) ) ) return;   // no block barrier below (cancelled: core.hip)
 	const int channel = int( chain / p.chains_per_channel );
 	const int64_t t0 = int64_t( chain % p.chains_per_channel ) * p.L;
 	const int64_t t1 = min( t0 + int64_t( p.L ), p.F );
@@ -356,7 +356,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 	const v4f_t * s_win = reinterpret_cast<const v4f_t*>( s + L::WIN ) + lane;
 
 	const int64_t chain_raw = int64_t( blockIdx.x ) * TEAMS + team;
-	const bool active = chain_raw < int64_t( p.chains_per_channel ) * p.num_channels;
+	const bool active = chain_raw < int64_t( p.chains_per_channel ) * p.num_channels && !cancel_seen( cancel_peek( p.cancel ) );   // (cancelled: core.hip; every team still walks its iterations and meets)
 	const int64_t chain = active ? chain_raw : 0;
 	const int channel = int( chain / p.chains_per_channel );
 	const int64_t t0 = int64_t( chain % p.chains_per_channel ) * p.L;
@@ -674,7 +674,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 	const v4f_t * s_win = reinterpret_cast<const v4f_t*>( s + L::WIN ) + lane;
 
 	const int64_t chain_raw = int64_t( blockIdx.x ) * TEAMS + team;
-	const bool active = chain_raw < int64_t( p.chains_per_channel ) * p.num_channels;
+	const bool active = chain_raw < int64_t( p.chains_per_channel ) * p.num_channels && !cancel_seen( cancel_peek( p.cancel ) );   // (cancelled: core.hip; every team still walks its iterations and meets)
 	const int64_t chain = active ? chain_raw : 0;
 	const int channel = int( chain / p.chains_per_channel );
 	const int chain_in_channel = int( chain % p.chains_per_channel );

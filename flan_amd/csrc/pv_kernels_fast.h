@@ -161,7 +161,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 	cf * buf = s + L::BUF + wave * L::BUF_LEN;
 
 	const int64_t chain = int64_t( blockIdx.x ) * WAVES + wave;
-	if( chain >= int64_t( p.chains_per_channel ) * p.num_channels ) return;
+	if( chain >= int64_t( p.chains_per_channel ) * p.num_channels || cancel_seen( cancel_peek( p.cancel ) ) ) return;   // (cancelled: core.hip)
 	const int channel = int( chain / p.chains_per_channel );
 	const int64_t t0 = int64_t( chain % p.chains_per_channel ) * p.L;
 	const int64_t t1 = min( t0 + int64_t( p.L ), p.F );
@@ -404,7 +404,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 	cf * buf = s + L::BUF + wave * L::BUF_LEN;
 
 	const int64_t chain = int64_t( blockIdx.x ) * WAVES + wave;
-	if( chain >= int64_t( p.chains_per_channel ) * p.num_channels ) return;
+	if( chain >= int64_t( p.chains_per_channel ) * p.num_channels || cancel_seen( cancel_peek( p.cancel ) ) ) return;   // (cancelled: core.hip)
 	const int channel = int( chain / p.chains_per_channel );
 	const int chain_in_channel = int( chain % p.chains_per_channel );
 	const int64_t t0 = int64_t( chain_in_channel ) * p.L;

@@ -187,6 +187,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 	cf * s = reinterpret_cast<cf*>( smem );
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int W = p.window_size, hop = p.hop;
+	const int cancel_word = cancel_peek( p.cancel );                           // travels under the table loads; a wavefront that finds it set walks no chain
 
 	// ---- tables (block-wide) --------------------------------------------------------------------------------------------
 	for( int i = tid; i < 240; i += NT ) s[L::TW1 + i] = tb.tw1[i];
@@ -220,7 +221,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 	const int groups = ( p.chains_per_channel + WAVES - 1 ) / WAVES;
 	const int channel = int( blockIdx.x ) / groups, group = int( blockIdx.x ) % groups;
 	const int chain_in_channel = group * WAVES + wave;
-	const bool active = chain_in_channel < p.chains_per_channel;
+	const bool active = chain_in_channel < p.chains_per_channel && !cancel_seen( cancel_word );
 	const int64_t chain = int64_t( channel ) * p.chains_per_channel + ( active ? chain_in_channel : 0 );
 	const int64_t t0 = int64_t( active ? chain_in_channel : 0 ) * p.L;
 	const int64_t t1 = min( t0 + int64_t( p.L ), p.F );
@@ -599,6 +600,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 	cf * s = reinterpret_cast<cf*>( smem );
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int W = p.window_size;
+	const int cancel_word = cancel_peek( p.cancel );
 	for( int i = tid; i < 240; i += NT ) s[L::TW1 + i] = tb.tw1[i];
 	for( int i = tid; i < 768; i += NT ) s[L::TW3 + i] = tb.tw3[i];
 	for( int i = tid; i < 512; i += NT ) { const cf w = tb.w2[i]; s[L::W2S + i] = mk( w.x, -w.y ); }
@@ -617,7 +619,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 	const int groups = ( p.chains_per_channel + WAVES - 1 ) / WAVES;
 	const int channel = int( blockIdx.x ) / groups, group = int( blockIdx.x ) % groups;
 	const int chain_in_channel_raw = group * WAVES + wave;
-	const bool active = chain_in_channel_raw < p.chains_per_channel;
+	const bool active = chain_in_channel_raw < p.chains_per_channel && !cancel_seen( cancel_word );
 	const int chain_in_channel = active ? chain_in_channel_raw : 0;
 	const int64_t chain = int64_t( channel ) * p.chains_per_channel + chain_in_channel;
 	const int64_t t0 = int64_t( chain_in_channel ) * p.L;

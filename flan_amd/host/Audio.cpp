@@ -67,8 +67,10 @@ PV Audio::convert_to_PV( Frame window_size, Frame hop, Frame dft_size, flan_CANC
 		: flanhip_analyze_dev( d_audio, f.num_channels, get_num_frames(), get_sample_rate(), window_size, hop, dft_size,
 			static_cast<flanhip_MF*>( block->ptr ), nullptr );
 	if( !detail::report( rc, "convert_to_PV" ) ) return PV();
-	if( !detail::report( flanhip_stream_synchronize( nullptr ), "convert_to_PV" ) ) return PV();
-	if( canceller ) return PV();
+	// flan_CANCEL_POINT while the kernels run: the flag is polled during the wait and stops the launch (flanhip_wait_cancellable_fn)
+	const int waited = flanhip_wait_cancellable_fn( nullptr, detail::poll_canceller, &canceller );
+	if( waited == FLANHIP_ERR_CANCELLED || canceller ) return PV();
+	if( !detail::report( waited, "convert_to_PV" ) ) return PV();
 	PVBuffer out = PVBuffer::adopt_device( f, std::move( block ) );
 	if( ws ) out.attach_synthesis_workspace( std::move( ws ) );
 	return out;

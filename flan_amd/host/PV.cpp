@@ -215,7 +215,9 @@ Audio PV::convert_to_audio( flan_CANCEL_ARG_CPP ) const
 	if( !detail::report( rc, "convert_to_audio" ) ) return Audio::create_null();
 	int nan_flag = 0;
 	flanhip_memcpy_d2h( &nan_flag, flag->ptr, sizeof( int ), nullptr );
-	if( !detail::report( flanhip_stream_synchronize( nullptr ), "convert_to_audio" ) ) return Audio::create_null();
+	const int waited = flanhip_wait_cancellable_fn( nullptr, detail::poll_canceller, &canceller );   // flan_CANCEL_POINT while the kernels run
+	if( waited == FLANHIP_ERR_CANCELLED ) return Audio::create_null();
+	if( !detail::report( waited, "convert_to_audio" ) ) return Audio::create_null();
 	if( nan_flag )                                             // AudioPV.cpp:88-89
 		std::cout << "flan::convert_to_audio recieved a nan or infinite value. This often happens when dividing by zero in an earlier algorithm.";
 	if( canceller ) return Audio::create_null();

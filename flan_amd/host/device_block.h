@@ -1,5 +1,6 @@
 // device_block.h -- RAII handle on a block of HBM obtained through the C ABI (flanhip_malloc / flanhip_free).
 #pragma once
+#include <atomic>
 #include <cstddef>
 #include <iostream>
 #include <memory>
@@ -45,6 +46,9 @@ struct DeviceBlock
 		return b;
 		}
 	};
+
+// the predicate flanhip_wait_cancellable_fn polls: the reference's canceller (defines.h:49-62) is a std::atomic<bool>&
+inline int poll_canceller( void * user ) { return static_cast<std::atomic<bool>*>( user )->load() ? 1 : 0; }
 
 inline bool report( int rc, const char * what )
 	{

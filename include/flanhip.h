@@ -64,6 +64,15 @@ int flanhip_memcpy_h2d(void * dst, const void * src, size_t bytes, void * stream
 int flanhip_memcpy_d2h(void * dst, const void * src, size_t bytes, void * stream);
 int flanhip_memset(void * dst, int value, size_t bytes, void * stream);
 int flanhip_stream_synchronize(void * stream);
+/* Cancellation INSIDE a launch (defines.h:49-62: the reference polls its flag once per frame, AudioPV.cpp:49,115).  Wait for `stream` like
+ * flanhip_stream_synchronize, but poll the caller's flag meanwhile; when it rises, the conversion kernels this thread has launched stop
+ * starting chains -- a block of the FFT kernels walks at most 512 frames (~3 ms), the direct-sum kernels look every few batches of frames --
+ * and the call returns FLANHIP_ERR_CANCELLED once the stream has drained (outputs are then unspecified).  Returns FLANHIP_OK when the work
+ * completed without the flag rising.  The _fn form takes a predicate (non-zero = cancel) instead of an int flag, for callers whose flag is
+ * not an int (the C++ classes' std::atomic<bool>&).  The host-buffer entry points (flanhip_analyze, flanhip_synthesize) wait this way with
+ * their own `cancel` argument. */
+int flanhip_wait_cancellable(void * stream, volatile int * cancel);
+int flanhip_wait_cancellable_fn(void * stream, int (*poll)(void * user), void * user);
 /* Transfers between ordinary (pageable) host memory and the device, synchronous: what the host entry points below
  * (flanhip_analyze, flanhip_synthesize, ...) use for the caller's buffers.  A download first lets a pool of worker threads fault
  * the destination's pages in together (a fresh allocation costs more to fault in on one thread than to fill over the link), then

@@ -417,3 +417,80 @@ def test_dft4096_kernel_generations_agree(fa, hop):
     d = np.abs(out[0].astype(np.float64) - out[1].astype(np.float64))
     print("\n[dft 4096 hop %d] generations: rel_m %.2e  f bit-identical %.4f  audio max diff %.2e" % (hop, rel_m, same_f, d.max()))
     assert rel_m <= 5e-7 and same_f >= 0.95 and d.max() <= 1e-6
+
+
+def test_cancellation_inside_a_launch(fa):
+    """defines.h:49-62 / AudioPV.cpp:49,115: the reference polls its canceller once per frame.  Here a flag raised WHILE the kernels run stops the
+    launch (flanhip_wait_cancellable: the thread's cancel word, read by every block when it starts and by the direct-sum kernels every few
+    batches): the wait returns FLANHIP_ERR_CANCELLED long before the work would have completed, and the thread's next call is unharmed."""
+    import ctypes
+    import threading
+    import time
+    import torch
+    import flan_amd
+    lib, vp = fa.lib, ctypes.c_void_p
+    dev = torch.device("cuda", 0)
+    fa.check(lib.flanhip_set_device(0))
+    sr, W, hop, dft = 48000.0, 4096, 1024, 16384                  # a direct-sum size: tenths of a second of kernel time
+    ch, n = 8, 90 * 48000
+    F = int(lib.flanhip_num_pv_frames(n, hop))
+    x = torch.empty((ch, n), dtype=torch.float32, device=dev)
+    fa.check(lib.flanhip_noise_dev(vp(x.data_ptr()), ch, n, 5, None))
+    pv = torch.empty((ch, F, dft // 2 + 1, 2), dtype=torch.float32, device=dev)
+
+    def launch():
+        fa.check(lib.flanhip_analyze_dev(vp(x.data_ptr()), ch, n, sr, W, hop, dft, vp(pv.data_ptr()), None))
+
+    flag = ctypes.c_int(0)
+    launch()
+    t0 = time.perf_counter()
+    assert lib.flanhip_wait_cancellable(None, ctypes.byref(flag)) == 0            # nobody raises the flag: an ordinary wait
+    launch()
+    t0 = time.perf_counter()
+    assert lib.flanhip_wait_cancellable(None, ctypes.byref(flag)) == 0
+    full = time.perf_counter() - t0
+    ref = pv[:, :3].clone()
+
+    def raise_later():
+        time.sleep(0.15 * full)
+        flag.value = 1
+    th = threading.Thread(target=raise_later)
+    pv.zero_()
+    launch()
+    t0 = time.perf_counter()
+    th.start()
+    rc = lib.flanhip_wait_cancellable(None, ctypes.byref(flag))
+    cut = time.perf_counter() - t0
+    th.join()
+    print("\n[cancel] full launch %.1f ms, cancelled after %.1f ms (flag raised at %.1f ms)" % (full * 1e3, cut * 1e3, 0.15 * full * 1e3))
+    assert rc == flan_amd.ERR_CANCELLED
+    assert cut <= 0.6 * full                                                          # it did not run to its end
+    flag.value = 0
+    launch()                                                                          # the thread's word was reset: the next call is whole
+    assert lib.flanhip_wait_cancellable(None, ctypes.byref(flag)) == 0
+    assert torch.equal(pv[:, :3].view(torch.int32), ref.view(torch.int32))
+    # the FFT kernels stop at block granularity: a launch of SEVERAL rounds of blocks (chains are capped at 512 frames and 2048 of them are
+    # resident: 16 ch x 600 s at hop 128 = 3.6 M frames is four rounds, ~12 ms) loses the rounds that have not started
+    del x, pv
+    W2, hop2, dft2, ch2 = 2048, 128, 2048, 16
+    n2 = 600 * 48000
+    F2 = int(lib.flanhip_num_pv_frames(n2, hop2))
+    x2 = torch.empty((ch2, n2), dtype=torch.float32, device=dev)
+    fa.check(lib.flanhip_noise_dev(vp(x2.data_ptr()), ch2, n2, 6, None))
+    pv2 = torch.empty((ch2, F2, dft2 // 2 + 1, 2), dtype=torch.float32, device=dev)
+    go = lambda: fa.check(lib.flanhip_analyze_dev(vp(x2.data_ptr()), ch2, n2, sr, W2, hop2, dft2, vp(pv2.data_ptr()), None))
+    go()
+    assert lib.flanhip_wait_cancellable(None, ctypes.byref(flag)) == 0
+    go()
+    t0 = time.perf_counter()
+    assert lib.flanhip_wait_cancellable(None, ctypes.byref(flag)) == 0
+    full2 = time.perf_counter() - t0
+    th = threading.Thread(target=lambda: (time.sleep(0.1 * full2), setattr(flag, "value", 1)))
+    go()
+    t0 = time.perf_counter()
+    th.start()
+    rc = lib.flanhip_wait_cancellable(None, ctypes.byref(flag))
+    cut2 = time.perf_counter() - t0
+    th.join()
+    print("[cancel, FFT kernels] full launch %.1f ms, cancelled after %.1f ms" % (full2 * 1e3, cut2 * 1e3))
+    assert rc == flan_amd.ERR_CANCELLED and cut2 <= 0.8 * full2
