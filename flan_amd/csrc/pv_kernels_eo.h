@@ -307,6 +307,9 @@ __device__ __forceinline__ void lds_block_sync()
 // = 2 x the number of meetings so far.  Both wavefronts of a team walk the same number of meetings (idle iterations included), both are
 // resident (same block), so the wait ends; the poll count is bounded anyway, so that a logic error shows as wrong output, not as a hung GPU.
 typedef __attribute__(( address_space( 3 ) )) unsigned lds_u32;
+#ifndef FLANHIP_TEAM_SLEEP
+#define FLANHIP_TEAM_SLEEP 1
+#endif
 struct TeamSync
 	{
 	lds_u32 * flag; unsigned target; int lane;
@@ -319,7 +322,7 @@ struct TeamSync
 			{
 			const unsigned v = __builtin_amdgcn_readfirstlane( __hip_atomic_load( flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP ) );
 			if( v >= target ) break;
-			__builtin_amdgcn_s_sleep( 1 );
+			__builtin_amdgcn_s_sleep( FLANHIP_TEAM_SLEEP );
 			}
 		asm volatile( "" ::: "memory" );
 		}
@@ -597,7 +600,10 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 			team_sync.meet();                                                     // the next frame's E / O are written
 			}
 		};
+	Stamps st;                                                                  // (diagnostic builds: the wavefront's life, tools/wave_spans.py)
+	st.init();
 	run_chain();
+	st.flush( lane );
 
 	if constexpr( SUMS )
 		{

@@ -32,6 +32,11 @@ def main():
     pv = torch.empty((ch, F, BINS, 2), dtype=torch.float32, device=dev)
     ws = torch.empty(fa.synthesize_workspace_bytes(ch, F, BINS, SR, SR / HOP, W), dtype=torch.uint8, device=dev)
     synth = "--syn" in sys.argv
+    if "--dft4096" in sys.argv:
+        DFT = 4096
+        BINS = DFT // 2 + 1
+        pv = torch.empty((ch, F, BINS, 2), dtype=torch.float32, device=dev)
+        ws = torch.empty(fa.synthesize_workspace_bytes(ch, F, BINS, SR, SR / HOP, W), dtype=torch.uint8, device=dev)
     out = torch.empty((ch, F * HOP), dtype=torch.float32, device=dev)
     nan_flag = torch.zeros(1, dtype=torch.int32, device=dev)
     for _ in range(300):
@@ -57,8 +62,9 @@ def main():
     print("end after the first start: median %.1f  p95 %.1f  max %.1f  (the launch lasts until the max)" % (np.median(en), np.percentile(en, 95), en.max()))
     order = np.argsort(-en)[:12]
     print("last to finish: " + "  ".join("ch%d/chain%d:%.1f" % (w // 256, w % 256, en[w]) for w in order))
-    edge = np.array([w for w in range(2048) if w % 256 in (0, 255)])
-    inner = np.array([w for w in range(2048) if w % 256 not in (0, 255)])
+    edge_set = (0, 1, 254, 255) if DFT == 4096 else (0, 255)          # dft 4096: a chain is a team of two wavefronts
+    edge = np.array([w for w in range(2048) if w % 256 in edge_set])
+    inner = np.array([w for w in range(2048) if w % 256 not in edge_set])
     print("edge chains (first / last of a channel): life median %.1f   interior chains: %.1f" % (np.median(li[edge]), np.median(li[inner])))
     inner_blocks = np.array([b for b in range(256) if b % 32 not in (0, 31)])
     print("life by wave slot of the block (interior blocks, median): " + "  ".join("%d:%.1f" % (w, np.median(li.reshape(256, 8)[inner_blocks, w])) for w in range(8)))
