@@ -32,6 +32,10 @@ def main():
     pv = torch.empty((ch, F, BINS, 2), dtype=torch.float32, device=dev)
     ws = torch.empty(fa.synthesize_workspace_bytes(ch, F, BINS, SR, SR / HOP, W), dtype=torch.uint8, device=dev)
     synth = "--syn" in sys.argv
+    for a in sys.argv:
+        if a.startswith("--ana-variant="):
+            fa.lib.flanhip_debug_kernel_variant(0, int(a.split("=")[1]))
+            print("analysis kernel variant", a.split("=")[1])
     if "--dft4096" in sys.argv:
         DFT = 4096
         BINS = DFT // 2 + 1
