@@ -117,36 +117,26 @@ template<class V> __device__ __forceinline__ V round_half_away_v( V x )
 	}
 __device__ __forceinline__ float round_half_away( float x ) { return __builtin_truncf( x + __builtin_copysignf( 0x1.fffffep-2f, x ) ); }
 
-// phase = atan2( im, re ) exactly as atan2_fast_v; mag = max( |re|, |im| ) * sqrt( 1 + q^2 ), q = min / max (correctly rounded).
-// The maximum is clamped to 2^-126 for the reciprocal; a spectrum component below that (a denormal, or zero) keeps its magnitude
-// through p2 = ( max 2^126 )^2 < 1 in place of the 1:  mag = 2^-126 sqrt( p2 + q^2 )  (for every other input p2 clamps to exactly 1)
-template<class V> __device__ __forceinline__ void polar_v( V re, V im, V & phase, V & mag )
+// the arithmetic behind polar_v once |re|, |im|, their maximum and minimum are known.  CLAMPED: the divisor clamped to 2^-126 and
+// p2 = min( ( max 2^126 )^2, 1 ) in place of the 1 under the root (digital silence, see polar_v)
+template<bool CLAMPED, class V> __device__ __forceinline__ void polar_tail( V re, V im, V ax, V ay, V mxu, V mn, V & phase, V & mag )
 	{
 	constexpr int N = vec_traits<V>::N;
-	const V ax = __builtin_elementwise_abs( re ), ay = __builtin_elementwise_abs( im );
-	const V mxu = __builtin_elementwise_max( ax, ay );
-	const V mn = __builtin_elementwise_min( ax, ay );
-	// Is any larger component below 2^-126 (zero or a denormal: digital silence)?  Decided per wavefront: only then are the clamp of the
-	// divisor and p2 = min( ( max 2^126 )^2, 1 ) worked out -- for every other input the clamp changes nothing and p2 is exactly 1, so the
-	// common path carries neither (a v_max per bin saved: min / max are half-rate instructions on gfx950, profiles/r03_a_issue_model.txt)
-	float tiny = mxu[0];
-	#pragma unroll
-	for( int i = 1; i < N; ++i ) tiny = __builtin_fminf( tiny, mxu[i] );
-	const bool silence = __any( tiny < 0x1p-126f );
 	V mx = mxu;
-	if( silence ) mx = __builtin_elementwise_max( mxu, vsplat<V>( 0x1p-126f ) );
+	if constexpr( CLAMPED ) mx = __builtin_elementwise_max( mxu, vsplat<V>( 0x1p-126f ) );
 	V r;
 	#pragma unroll
 	for( int i = 0; i < N; ++i ) r[i] = __builtin_amdgcn_rcpf( mx[i] );
 	const V q0 = mn * r;
 	const V q = vfma( vfma( -q0, mx, mn ), r, q0 );
 	const V u = q * q;
-	V h = vfma( q, q, vsplat<V>( 1.0f ) );
-	if( silence )
+	V h;
+	if constexpr( CLAMPED )
 		{
 		const V t = mxu * vsplat<V>( 0x1p126f );
 		h = vfma( q, q, __builtin_elementwise_min( t * t, vsplat<V>( 1.0f ) ) );
 		}
+	else h = vfma( q, q, vsplat<V>( 1.0f ) );
 	V p = vsplat<V>( 0x1.7ec8b6p-9f );
 	p = vfma( p, u, vsplat<V>( -0x1.0c272ap-6f ) );
 	p = vfma( p, u, vsplat<V>( 0x1.61f9a0p-5f ) );
@@ -166,6 +156,31 @@ template<class V> __device__ __forceinline__ void polar_v( V re, V im, V & phase
 		phase[i] = __builtin_copysignf( __float_as_int( re[i] ) < 0 ? a2[i] : a[i], im[i] );
 		mag[i] = mx[i] * __builtin_amdgcn_sqrtf( h[i] );
 		}
+	}
+
+// phase = atan2( im, re ) exactly as atan2_fast_v; mag = max( |re|, |im| ) * sqrt( 1 + q^2 ), q = min / max (correctly rounded).
+// The maximum is clamped to 2^-126 for the reciprocal; a spectrum component below that (a denormal, or zero) keeps its magnitude
+// through p2 = ( max 2^126 )^2 < 1 in place of the 1:  mag = 2^-126 sqrt( p2 + q^2 )  (for every other input p2 clamps to exactly 1).
+// Is any larger component below 2^-126 (zero or a denormal: digital silence)?  Decided per wavefront, and a BRANCH: for every other input
+// the clamp changes nothing and p2 is exactly 1, so the common path carries neither.  (Written as `if( silence ) mx = max( ... )` the
+// compiler turns the branch into a v_max and a v_cndmask per bin on the common path -- both half-rate instructions on gfx950,
+// profiles/r03_a_issue_model.txt; the asm statement in the rare arm is what keeps it a branch.)
+template<class V> __device__ __forceinline__ void polar_v( V re, V im, V & phase, V & mag )
+	{
+	constexpr int N = vec_traits<V>::N;
+	const V ax = __builtin_elementwise_abs( re ), ay = __builtin_elementwise_abs( im );
+	const V mxu = __builtin_elementwise_max( ax, ay );
+	const V mn = __builtin_elementwise_min( ax, ay );
+	float tiny = mxu[0];
+	#pragma unroll
+	for( int i = 1; i < N; ++i ) tiny = __builtin_fminf( tiny, mxu[i] );
+	if( __builtin_expect( __any( tiny < 0x1p-126f ), 0 ) )
+		{
+		asm volatile( "; digital silence" );
+		polar_tail<true>( re, im, ax, ay, mxu, mn, phase, mag );
+		asm volatile( "; end of the silence arm" );                               // (no tail shared with the common arm: merged tails cost it a register copy per bin)
+		}
+	else polar_tail<false>( re, im, ax, ay, mxu, mn, phase, mag );
 	}
 
 // =================================================================================================================
@@ -223,9 +238,19 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 	const int chain_in_channel = group * WAVES + wave;
 	const bool active = chain_in_channel < p.chains_per_channel && !cancel_seen( cancel_word );
 	const int64_t chain = int64_t( channel ) * p.chains_per_channel + ( active ? chain_in_channel : 0 );
-	const int64_t t0 = int64_t( active ? chain_in_channel : 0 ) * p.L;
-	const int64_t t1 = min( t0 + int64_t( p.L ), p.F );
+	// frame numbers are ints here ( F <= n / hop + 1 and the host admits n < 2^31 - 8192 on this path)
+	const int t0 = ( active ? chain_in_channel : 0 ) * p.L;
+	const int t1 = int( min( int64_t( t0 ) + p.L, p.F ) );
 	const float * x = p.audio + int64_t( channel ) * p.n;
+	const int n32 = int( p.n );
+	// Addresses: everything a block touches lies within ( WAVES L + 1 ) frames of the block's first halo frame tb0, so a global access is a
+	// SCALAR base (channel and group come from blockIdx) plus a 32-bit per-lane byte offset -- one VGPR per stream instead of a 64-bit
+	// pointer pair and 64-bit vector arithmetic per frame.  (The bases may point in front of the buffers for a channel's first group; no
+	// access does: the clamped loads of edge frames keep absolute addresses.)
+	const int tb0 = group * WAVES * p.L - 1;
+	const char * const xb = reinterpret_cast<const char*>( x ) + ( int64_t( hop ) * tb0 - W / 2 ) * 4;
+	char * const rb = reinterpret_cast<char*>( p.out + ( int64_t( channel ) * p.F + tb0 ) * ( C + 1 ) );
+	const unsigned lane8 = 8u * unsigned( lane );
 	const bool use_wrapping = p.analysis_rate < p.sample_rate;                // phase_vocoder.cpp:37
 	// (the run-time constants of the per-bin arithmetic -- analysis_rate and its reciprocal pair -- are wave-uniform and sit in SGPRs; forcing
 	// them into VGPRs, because runs of VALU instructions with SGPR operands are slow ones in the issue microbenchmark, measured +-2 % in
@@ -234,7 +259,6 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 	const DivC k_ard = p.ar_div;
 	const int padl = lane + ( lane >> 4 );
 	const cf * mirror = buf + ( C * 17 ) / 16 - ( lane + ( ( lane + 15 ) >> 4 ) );   // mirror[-68 q] = slot PAD( C - lane - 64 q )
-	const int n32 = int( p.n );
 	struct __attribute__(( packed, aligned( 4 ) )) f2u { float x, y; };      // a sample pair at any 4-byte aligned address
 
 	// state that crosses frames: previous phases (phase_vocoder.cpp:45) of the lane's 8 pairs and of bin C/2
@@ -255,13 +279,13 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 	cf ring = mk( 0.0f, 0.0f );
 
 	// does every frame this chain touches (its halo frame included) lie inside the signal?  (AudioPV.cpp:52-62 needs no bounds then)
-	const int64_t tfirst = t0 > 0 ? t0 - 1 : t0;
+	const int tfirst = t0 > 0 ? t0 - 1 : t0;
 	// Does frame t lie inside the signal with all of its 2 C samples (AudioPV.cpp:52-62 needs no bounds then)?  Decided PER FRAME: the first
 	// and the last chain of a channel have two to four frames that reach outside, and a launch lasts as long as its slowest wavefront -- with
 	// the clamped-load body chosen per chain those 16 chains ran 17 % longer than the 2032 others and set the launch's time
 	// (profiles/r03_b_wave_spans.txt).
 	const bool w_whole = ( W & 127 ) == 0;
-	auto frame_inside = [&]( int64_t t ) { return w_whole && int64_t( hop ) * t - W / 2 >= 0 && int64_t( hop ) * t - W / 2 + 2 * int64_t( C ) <= p.n; };
+	auto frame_inside = [&]( int t ) { return w_whole && hop * t - W / 2 >= 0 && hop * t - W / 2 + 2 * C <= n32; };   // ( hop t <= n: no overflow)
 
 	Stamps st;
 	st.init();
@@ -269,10 +293,10 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 	auto run_chain = [&]()
 		{
 		// sample pair i = lane + 64 q of frame t (fast_tag: the frame lies inside the signal)
-		auto load_pair = [&]( int64_t t, int q, auto fast_tag ) -> cf
+		auto load_pair = [&]( int t, int q, auto fast_tag ) -> cf
 			{
 			constexpr bool FAST = decltype( fast_tag )::value;
-			const int start = int( int64_t( hop ) * ( ( ABL & 512 ) ? tfirst : t ) - W / 2 );
+			const int start = hop * ( ( ABL & 512 ) ? tfirst : t ) - W / 2;
 			if constexpr( ( ABL & 16 ) != 0 ) return mk( float( start ) * 1e-9f + 0.25f, float( q ) );
 			else if constexpr( ( ABL & 128 ) != 0 && FAST )            // (interior chains only: the edge chains keep their clamped loads)
 				{
@@ -282,7 +306,9 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 				}
 			else if constexpr( FAST )
 				{
-				const f2u v = *reinterpret_cast<const f2u*>( x + start + 2 * lane + 128 * q );
+				// (two offsets 4096 bytes apart: the instruction's immediate reaches 4095)
+				const unsigned off = unsigned( hop * ( ( ( ABL & 512 ) ? tfirst : t ) - tb0 ) ) * 4u + lane8 + ( q >= 8 ? 4096u : 0u );
+				const f2u v = *reinterpret_cast<const f2u*>( xb + off + 512 * ( q & 7 ) );
 				return mk( v.x, v.y );
 				}
 			else
@@ -293,9 +319,9 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 				}
 			};
 		// edge frames: pairs loaded from clamped addresses are shifted / zeroed here (AudioPV.cpp:54-62, :65)
-		auto fix_raw = [&]( int64_t t )
+		auto fix_raw = [&]( int t )
 			{
-			const int start = int( int64_t( hop ) * t - W / 2 );
+			const int start = hop * t - W / 2;
 			#pragma unroll
 			for( int q = 0; q < E; ++q )
 				{
@@ -310,7 +336,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 				}
 			};
 		// window (AudioPV.cpp:60), transform; leaves the upper half of Z in buf (natural order) for the mirror reads
-		auto transform_frame = [&]( int64_t t, auto fast_tag )
+		auto transform_frame = [&]( int t, auto fast_tag )
 			{
 			if constexpr( !decltype( fast_tag )::value ) fix_raw( t );
 			#pragma unroll
@@ -335,7 +361,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 		// drains the whole queue, stores included, once per frame (measured: a quarter of the kernel's time).
 		// HALO: frame t0 - 1, of which only the phases are wanted (phase_vocoder.cpp:45 leaves them in phase_buffer): a compile-time
 		// switch, not a branch.
-		auto bins_of_frame = [&]( int64_t t, int64_t tn, int fi, auto halo_tag, auto next_fast )
+		auto bins_of_frame = [&]( int t, int tn, int fi, auto halo_tag, auto next_fast )
 			{
 			constexpr bool halo = decltype( halo_tag )::value;
 			const cf z512 = buf[544];                                             // Z[ C/2 ], slot PAD( 512 )
@@ -343,9 +369,10 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 			#pragma unroll
 			for( int q = H; q < E; ++q ) z[q] = load_pair( tn, q, next_fast );    // the upper half is in LDS now: its registers are free
 			st( 4 );                                                              // 4: mirror exchange written, upper half of the next frame requested
-			cf * row = reinterpret_cast<cf*>( p.out + ( int64_t( channel ) * p.F + ( ( ABL & 256 ) ? t0 : t ) ) * ( C + 1 ) );
-			cf * rowk = row + lane;
-			cf * rowm = row + ( C - lane );
+			const unsigned roff = unsigned( ( ( ABL & 256 ) ? t0 : t ) - tb0 ) * unsigned( ( C + 1 ) * 8 );
+			cf * row = reinterpret_cast<cf*>( rb + roff );
+			cf * rowk = reinterpret_cast<cf*>( rb + ( roff + lane8 ) );
+			cf * rowm = reinterpret_cast<cf*>( rb + ( roff + unsigned( C * 8 ) - lane8 ) );
 			// the MFs of the frame leave together at its end, BEHIND every request for the next frame's samples: memory operations retire
 			// in issue order, so a sample load issued after a store would not count as back before that store has been acknowledged
 			// (microseconds while the chip streams writes), and the transform of the next frame would wait for it
@@ -392,7 +419,10 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 						const VB delta_phase = phase_diff - expd;                    // :47-48
 						VB wrapped = delta_phase;
 						if( use_wrapping ) wrapped = delta_phase - vsplat<VB>( FLANHIP_PI2_F ) * round_half_away_v( div_pi2_v( delta_phase ) );   // :39-42,49
-						f = binf + div_pi2_v( wrapped * vsplat<VB>( k_ar ) );                              // :50-52
+						VB war;                                                       // (element by element: a splat of a run-time constant costs one SGPR per element)
+						#pragma unroll
+						for( int i = 0; i < NV; ++i ) war[i] = wrapped[i] * k_ar;
+						f = binf + div_pi2_v( war );                                  // :50-52
 						}
 					else f = phase - pv + binf * expd;
 					#pragma unroll
@@ -404,7 +434,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 						}
 					if constexpr( SUMS )
 						{
-						const VB term = div_c_v( f, k_ard ) * vsplat<VB>( FLANHIP_PI2_F );                      // phase_vocoder.cpp:57-58
+						const VB term = div_c_each( f, k_ard ) * vsplat<VB>( FLANHIP_PI2_F );                   // phase_vocoder.cpp:57-58
 						#pragma unroll
 						for( int i = 0; i < NP; ++i )
 							{
@@ -451,9 +481,9 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 			};
 
 		// the batch of bin C/2: lane j holds frame tb + j, j < nb (frame tfirst, the halo, only lends its phase)
-		auto flush_half_bin = [&]( int64_t tb, int nb )
+		auto flush_half_bin = [&]( int tb, int nb )
 			{
-			const int64_t t = tb + lane;
+			const int t = tb + lane;
 			const bool valid = lane < nb && t >= t0;
 			const float re = ring.x, im = -ring.y;                                // X = conj Z[ C/2 ]
 			const float phase = atan2_fast( im, re );
@@ -468,7 +498,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 			const float m = magnitude_scaled( re, im );
 			if constexpr( ( ABL & 8 ) == 0 )
 				{
-				if( valid ) __builtin_nontemporal_store( mk( m, f ), reinterpret_cast<cf*>( p.out + ( int64_t( channel ) * p.F + ( ( ABL & 256 ) ? t0 : t ) ) * ( C + 1 ) ) + C / 2 );
+				if( valid ) __builtin_nontemporal_store( mk( m, f ), reinterpret_cast<cf*>( rb + ( unsigned( ( ( ABL & 256 ) ? t0 : t ) - tb0 ) * unsigned( ( C + 1 ) * 8 ) + unsigned( C / 2 * 8 ) ) ) );
 				}
 			else asm volatile( "" :: "v"( m ), "v"( f ) );
 			if constexpr( SUMS )
@@ -501,9 +531,9 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 			else { bins_of_frame( t0 - 1, t0, fi, std::true_type{}, outside ); transform_frame( t0, outside ); }
 			++fi;
 			}
-		for( int64_t t = t0; t < t1; ++t )
+		for( int t = t0; t < t1; ++t )
 			{
-			const int64_t tn = min( t + 1, t1 - 1 );                               // (the last frame requests itself again: nobody waits for it)
+			const int tn = min( t + 1, t1 - 1 );                               // (the last frame requests itself again: nobody waits for it)
 			const bool more = t + 1 < t1;
 			auto rest_of_step = [&]( auto next_fast )
 				{

@@ -108,6 +108,26 @@ template<class V> __device__ __forceinline__ V div_c_v( V x, DivC d )
 	for( int i = 0; i < vec_traits<V>::N; ++i ) q[i] = x[i] / d.c;
 	return q;
 	}
+// the same, element by element with the constants as scalar operands: a vsplat of a run-time constant makes the compiler hold one SGPR
+// copy per element (8 x 2 for a DivC in an 8-bin stream), and the dft 2048 kernels have no SGPRs to spare
+template<class V> __device__ __forceinline__ V div_c_each( V x, DivC d )
+	{
+	V q;
+	if( d.exact )
+		{
+		#pragma unroll
+		for( int i = 0; i < vec_traits<V>::N; ++i )
+			{
+			const float q0 = x[i] * d.rc;
+			const float r = __builtin_fmaf( -q0, d.c, x[i] );
+			q[i] = __builtin_fmaf( r, d.rc, q0 );
+			}
+		return q;
+		}
+	#pragma unroll
+	for( int i = 0; i < vec_traits<V>::N; ++i ) q[i] = x[i] / d.c;
+	return q;
+	}
 template<class V> __device__ __forceinline__ V round_v( V x )
 	{
 	V r;
