@@ -225,12 +225,15 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_eo( AnalyzeParams p, F
 					}
 				if constexpr( !halo )
 					{
-					const VB expd = div_c_v( binf, p.ar_div ) * vsplat<VB>( FLANHIP_PI2_F );       // :47
+					const VB expd = div_c_each( binf, p.ar_div ) * vsplat<VB>( FLANHIP_PI2_F );       // :47
 					const VB phase_diff = phase - pv;                                            // == float( double(phase) - double(prev) ), :44
 					const VB delta_phase = phase_diff - expd;                                    // :47-48
 					VB wrapped = delta_phase;
 					if( use_wrapping ) wrapped = delta_phase - vsplat<VB>( FLANHIP_PI2_F ) * round_half_away_v( div_pi2_v( delta_phase ) );   // :39-42,49
-					const VB f = binf + div_pi2_v( wrapped * vsplat<VB>( p.analysis_rate ) );      // :50-52
+					VB war;                                                                  // (element by element: no SGPR copy per element of a splat)
+					#pragma unroll
+					for( int i = 0; i < int( sizeof( VB ) / sizeof( float ) ); ++i ) war[i] = wrapped[i] * p.analysis_rate;
+					const VB f = binf + div_pi2_v( war );                                    // :50-52
 					#pragma unroll
 					for( int i = 0; i < QV; ++i )
 						{
@@ -384,7 +387,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 		#pragma unroll
 		for( int q = 0; q < Q; ++q ) { sm[q][0] = 0.0; sm[q][1] = 0.0; sm[q][2] = 0.0; sm[q][3] = 0.0; }
 		}
-	float mmax = 0.0f;
+	unsigned mmax = 0u;                                                       // bit patterns, see k_analyze_v2
 	// The pair ( 512, 1536 ) is the odd wavefront's alone and would cost each of its lanes ~140 instructions per frame for two bins -- on the
 	// wavefront the other one waits for.  Instead lane ( i & 63 ) keeps E[512] and O[512] of the chain's i-th frame, and once per 64 frames
 	// (and at the chain's end) the batch is worked off one frame per lane (k_analyze_v2 does the same with its bin C/2).
@@ -501,11 +504,14 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 					}
 				if constexpr( !halo )
 					{
-					const VB expd = div_c_v( binf, p.ar_div ) * vsplat<VB>( FLANHIP_PI2_F );       // :47
+					const VB expd = div_c_each( binf, p.ar_div ) * vsplat<VB>( FLANHIP_PI2_F );       // :47
 					const VB delta_phase = ( phase - pv ) - expd;                                // :44, :47-48
 					VB wrapped = delta_phase;
 					if( use_wrapping ) wrapped = delta_phase - vsplat<VB>( FLANHIP_PI2_F ) * round_half_away_v( div_pi2_v( delta_phase ) );   // :39-42,49
-					const VB f = binf + div_pi2_v( wrapped * vsplat<VB>( p.analysis_rate ) );      // :50-52
+					VB war;                                                                  // (element by element: no SGPR copy per element of a splat)
+					#pragma unroll
+					for( int i = 0; i < int( sizeof( VB ) / sizeof( float ) ); ++i ) war[i] = wrapped[i] * p.analysis_rate;
+					const VB f = binf + div_pi2_v( war );                                    // :50-52
 					#pragma unroll
 					for( int i = 0; i < QV; ++i )
 						{
@@ -517,7 +523,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 						}
 					if constexpr( SUMS )
 						{
-						const VB term = div_c_v( f, p.ar_div ) * vsplat<VB>( FLANHIP_PI2_F );      // phase_vocoder.cpp:57-58
+						const VB term = div_c_each( f, p.ar_div ) * vsplat<VB>( FLANHIP_PI2_F );      // phase_vocoder.cpp:57-58
 						#pragma unroll
 						for( int i = 0; i < QV; ++i )
 							{
@@ -525,7 +531,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 							for( int j = 0; j < 4; ++j ) sm[QV * g + i][j] += double( term[4 * i + j] );
 							}
 						#pragma unroll
-						for( int i = 0; i < 4 * QV; i += 2 ) mmax = __builtin_fmaxf( mmax, __builtin_fmaxf( m[i], m[i + 1] ) );
+						for( int i = 0; i < 4 * QV; i += 2 ) mmax = max( mmax, max( __float_as_uint( m[i] ), __float_as_uint( m[i + 1] ) ) );
 						}
 					}
 				}
@@ -567,7 +573,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 					{
 					const float term = div_c( f, p.ar_div ) * FLANHIP_PI2_F;         // phase_vocoder.cpp:57-58
 					for( int l = j0; l < j1; ++l ) sm2[j] += double( __uint_as_float( __builtin_amdgcn_readlane( __float_as_uint( term ), l ) ) );   // frame order
-					mmax = valid ? __builtin_fmaxf( mmax, m ) : mmax;
+					mmax = valid ? max( mmax, __float_as_uint( m ) ) : mmax;
 					}
 				}
 			};
@@ -608,7 +614,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 	if constexpr( SUMS )
 		{
 		// the chain's sums, folded like phase_vocoder.cpp:59: what k_phase_sums2 would leave in the workspace
-		bool bad = !( mmax <= 3.4028235e38f );
+		bool bad = mmax >= 0x7f800000u;
 		auto fold = [&]( double sq ) -> double
 			{
 			bad |= !( __builtin_fabs( sq ) <= 1.7976931348623157e308 );              // a NaN / Inf frequency poisons its sum
@@ -765,13 +771,34 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 		{
 		cf * bufA = buf0 + 2 * set * L::BUF_LEN, * bufB = bufA + L::BUF_LEN;
 		bool slow = false;
+		// f / analysis_rate of the wavefront's 16 bins under ONE test of the divisor's plan (see k_synthesize_v2)
+		float dv[Q][4];
+		if( p.ar_div.exact )
+			{
+			const float dc = p.ar_div.c, drc = p.ar_div.rc;
+			#pragma unroll
+			for( int q = 0; q < Q; ++q )
+				{
+				#pragma unroll
+				for( int j = 0; j < 4; ++j ) { const float x = mf[q][j].y, q0 = x * drc; dv[q][j] = __builtin_fmaf( __builtin_fmaf( -q0, dc, x ), drc, q0 ); }   // pv_math.h: div_c
+				}
+			}
+		else
+			{
+			#pragma unroll
+			for( int q = 0; q < Q; ++q )
+				{
+				#pragma unroll
+				for( int j = 0; j < 4; ++j ) dv[q][j] = mf[q][j].y / p.ar_div.c;
+				}
+			}
 		#pragma unroll
 		for( int q = 0; q < Q; ++q )
 			{
 			#pragma unroll
 			for( int j = 0; j < 4; ++j )
 				{
-				ph[q][j] += double( div_c( mf[q][j].y, p.ar_div ) * FLANHIP_PI2_F );   // phase_vocoder.cpp:57-58
+				ph[q][j] += double( dv[q][j] * FLANHIP_PI2_F );                        // phase_vocoder.cpp:57-58
 				slow |= !( __builtin_fabs( ph[q][j] ) < double( FLANHIP_SINCOS_FAST_LIMIT ) );
 				}
 			}

@@ -272,7 +272,9 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 		#pragma unroll
 		for( int q = 0; q < H; ++q ) { sumk[q] = 0.0; summ[q] = 0.0; }
 		}
-	float mmax = 0.0f;                                                        // running maximum of the magnitudes (Inf scan)
+	// running maximum of the magnitudes (Inf / NaN scan) taken on their BIT PATTERNS: a magnitude is never negative, so unsigned order is float
+	// order with Inf and every NaN on top -- and an integer maximum needs no canonicalising v_max_f32 x, x per operand the way fmaxf does
+	unsigned mmax = 0u;
 	// Bin C/2 pairs with itself and would cost every lane ~70 instructions per frame for ONE bin.  Instead lane ( i & 63 ) keeps Z[C/2] of
 	// the chain's i-th frame, and once per 64 frames (and at the chain's end) the wavefront works the batch off, one frame per lane:
 	// the same arithmetic, previous phase from the lane below, the fp64 sum taken in frame order.
@@ -442,7 +444,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 							summ[g * NP + i] += double( term[NP + i] );
 							}
 						#pragma unroll
-						for( int i = 0; i < NV; i += 2 ) mmax = __builtin_fmaxf( mmax, __builtin_fmaxf( m[i], m[i + 1] ) );   // v_max3_f32
+						for( int i = 0; i < NV; i += 2 ) mmax = max( mmax, max( __float_as_uint( m[i] ), __float_as_uint( m[i + 1] ) ) );   // v_max3_u32
 						}
 					}
 				st( 5 + ( g & 3 ) );                                              // 5..8: the groups of bins (modulo 4)
@@ -506,7 +508,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 				const float term = div_c( f, p.ar_div ) * FLANHIP_PI2_F;             // phase_vocoder.cpp:57-58
 				const int j0 = __builtin_amdgcn_readfirstlane( ( tb < t0 ) ? 1 : 0 ), j1 = __builtin_amdgcn_readfirstlane( nb );   // (uniform: scalar loop, v_readlane)
 				for( int j = j0; j < j1; ++j ) sumx += double( __uint_as_float( __builtin_amdgcn_readlane( __float_as_uint( term ), j ) ) );   // in frame order, like every other bin's sum
-				mmax = valid ? __builtin_fmaxf( mmax, m ) : mmax;
+				mmax = valid ? max( mmax, __float_as_uint( m ) ) : mmax;
 				}
 			};
 
@@ -554,7 +556,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 		// wavefront's now idle transform buffer -- into the group's total: with one total per group of 8 chains the synthesis kernel can
 		// work out its own carries (a few dozen additions per bin) and the scan kernel between the two is not launched at all
 		double * stage = reinterpret_cast<double*>( buf );                        // 1025 doubles = 8200 B of the buffer's 8712
-		bool bad = !( mmax <= 3.4028235e38f );
+		bool bad = mmax >= 0x7f800000u;
 		auto fold = [&]( double sq ) -> double
 			{
 			bad |= !( __builtin_fabs( sq ) <= 1.7976931348623157e308 );              // a NaN / Inf frequency poisons its sum
@@ -661,6 +663,16 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 	cf * head2 = reinterpret_cast<cf*>( p.head + chain * p.head_len );
 	const int64_t chain_start = int64_t( hop ) * t0 - W / 2;
 	const int64_t own_start = chain_in_channel == 0 ? INT64_MIN : chain_start + p.head_len;
+	// Addresses of the frame loop: a SCALAR base per block (channel and group come from blockIdx) plus a 32-bit per-lane byte offset -- the
+	// MF rows and the finished output a block touches lie within WAVES L frames of its first frame tb0 (see k_analyze_v2)
+	const int64_t tb0 = int64_t( group ) * WAVES * p.L;
+	const int relf0 = ( active ? wave : 0 ) * p.L;                              // this chain's first frame, counted from tb0
+	const int nf = int( t1 - t0 );
+	const char * const pvb = reinterpret_cast<const char*>( p.pv + ( int64_t( channel ) * p.F + tb0 ) * ( C + 1 ) );
+	char * const ob = reinterpret_cast<char*>( out1 ) + ( int64_t( hop ) * tb0 - W / 2 ) * 4;   // (in front of the buffer for a channel's first group: its chain 0 takes the general emit_step)
+	const unsigned lane8 = 8u * unsigned( lane );
+	// every step a chain emits once its head is written lies inside the output, except for a channel's chain 0 (positions below 0)
+	const bool plain_emit = __builtin_amdgcn_readfirstlane( int( chain_in_channel != 0 ) ) != 0 && ( ABL & 4 ) == 0;
 	const int padl = lane + ( lane >> 4 );
 	cf * mirror = buf + ( C * 17 ) / 16 - ( lane + ( ( lane + 15 ) >> 4 ) );      // mirror[-68 q] = slot PAD( C - lane - 64 q )
 
@@ -682,11 +694,12 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 		};
 	// MF row of frame t: ( m, f ) of the lane's pairs and of bin C/2
 	cf mfk[H], mfm[H], mfx;
-	auto load_row = [&]( int64_t t )
+	auto load_row = [&]( int fr )                                               // fr: the frame, counted from tb0
 		{
-		const cf * row = reinterpret_cast<const cf*>( p.pv + ( int64_t( channel ) * p.F + ( ( ABL & 2 ) ? t0 : t ) ) * ( C + 1 ) );   // ABL 2 (timing only): a hot row
-		const cf * rowk = row + lane;
-		const cf * rowm = row + ( C - lane );
+		const unsigned ro = unsigned( ( ABL & 2 ) ? relf0 : fr ) * unsigned( ( C + 1 ) * 8 );   // ABL 2 (timing only): a hot row
+		const cf * row = reinterpret_cast<const cf*>( pvb + ro );
+		const cf * rowk = reinterpret_cast<const cf*>( pvb + ( ro + lane8 ) );
+		const cf * rowm = reinterpret_cast<const cf*>( pvb + ( ro + unsigned( C * 8 ) - lane8 ) );
 		#pragma unroll
 		for( int q = 0; q < H; ++q )
 			{
@@ -726,7 +739,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 			#pragma unroll
 			for( int w = 0; w < WAVES; ++w ) vc[b][w] = ( w < live ) ? sums0[int64_t( w ) * ( C + 1 ) + bins_of[b]] : 0.0;
 			}
-		if( active ) load_row( t0 );                                              // the first MF row travels while the carries are worked out
+		if( active ) load_row( relf0 );                                           // the first MF row travels while the carries are worked out
 		for( int g0 = 0; g0 < group; g0 += 16 )
 			{
 			double v[NB][16];
@@ -777,14 +790,30 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 	auto bins_of_row = [&]()
 		{
 		bool slow = false;
+		// f / analysis_rate of the row's 17 bins under ONE test of the divisor's plan (div_c per bin is a scalar branch per bin: 17 islands of
+		// three dependent instructions each instead of 17 interleaved chains)
+		float dk[H], dm[H], dx;
+		if( k_ard.exact )
+			{
+			auto div_exact = [&]( float x ) { const float q0 = x * k_ard.rc; return __builtin_fmaf( __builtin_fmaf( -q0, k_ard.c, x ), k_ard.rc, q0 ); };   // pv_math.h: div_c
+			#pragma unroll
+			for( int q = 0; q < H; ++q ) { dk[q] = div_exact( mfk[q].y ); dm[q] = div_exact( mfm[q].y ); }
+			dx = div_exact( mfx.y );
+			}
+		else
+			{
+			#pragma unroll
+			for( int q = 0; q < H; ++q ) { dk[q] = mfk[q].y / k_ard.c; dm[q] = mfm[q].y / k_ard.c; }
+			dx = mfx.y / k_ard.c;
+			}
 		#pragma unroll
 		for( int q = 0; q < H; ++q )
 			{
-			phk[q] += double( div_c( mfk[q].y, k_ard ) * FLANHIP_PI2_F );          // phase_vocoder.cpp:57-58
-			phm[q] += double( div_c( mfm[q].y, k_ard ) * FLANHIP_PI2_F );
+			phk[q] += double( dk[q] * FLANHIP_PI2_F );                             // phase_vocoder.cpp:57-58
+			phm[q] += double( dm[q] * FLANHIP_PI2_F );
 			slow |= !( __builtin_fabs( phk[q] ) < double( FLANHIP_SINCOS_FAST_LIMIT ) ) || !( __builtin_fabs( phm[q] ) < double( FLANHIP_SINCOS_FAST_LIMIT ) );
 			}
-		phx += double( div_c( mfx.y, k_ard ) * FLANHIP_PI2_F );
+		phx += double( dx * FLANHIP_PI2_F );
 		slow |= !( __builtin_fabs( phx ) < double( FLANHIP_SINCOS_FAST_LIMIT ) );
 		cf xk[H], xm[H], xx;
 		if( __any( slow ) )
@@ -849,12 +878,13 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 		wave_sync();
 		};
 
-	if( !p.group_sums ) load_row( t0 );
+	if( !p.group_sums ) load_row( relf0 );
 	bins_of_row();
 	int64_t pos = chain_start;
-	for( int64_t t = t0; t < t1; ++t )
+	int rel = 0;                                                                // pos - chain_start: the same number in every wavefront, a scalar
+	for( int i = 0; i < nf; ++i )
 		{
-		load_row( min( t + 1, t1 - 1 ) );                                       // (the last frame requests itself again: nobody waits for it)
+		load_row( relf0 + min( i + 1, nf - 1 ) );                               // (the last frame requests itself again: nobody waits for it)
 		if constexpr( ( ABL & 8 ) == 0 )                                        // ABL 8 (timing only): no transform
 		fft_fast<10>( z, buf, s_tw1, s_tw3, lane );
 		// ---- G = fft( conj Z ): x[2n] = G[n].x, x[2n+1] = -G[n].y; window and overlap-add (AudioPV.cpp:122-134)
@@ -865,12 +895,25 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 			acc[q].x += z[q].x * w.x;
 			acc[q].y += ( -z[q].y ) * w.y;
 			}
-		#pragma unroll
-		for( int q = 0; q < HOPQ; ++q ) emit_step( pos + 128 * q, acc[q] );
+		// HOPQ stores in either arm (the wait for the next row counts them).  The plain arm: past the chain's head every step goes to the
+		// output proper, all of it inside -- a scalar base, one 32-bit offset, immediates; the general arm (head steps, chain 0) costs ~17
+		// 64-bit vector instructions per step
+		if( plain_emit && rel >= p.head_len )
+			{
+			const unsigned oo = unsigned( hop * ( relf0 + i ) ) * 4u + lane8;
+			#pragma unroll
+			for( int q = 0; q < HOPQ; ++q ) *reinterpret_cast<cf*>( ob + oo + 512 * q ) = acc[q];
+			}
+		else
+			{
+			#pragma unroll
+			for( int q = 0; q < HOPQ; ++q ) emit_step( pos + 128 * q, acc[q] );
+			}
 		#pragma unroll
 		for( int q = 0; q < E; ++q ) acc[q] = ( q + HOPQ < E ) ? acc[q + HOPQ] : mk( 0.0f, 0.0f );
 		pos += hop;
-		if( t + 1 < t1 ) bins_of_row();
+		rel += hop;
+		if( i + 1 < nf ) bins_of_row();
 		}
 	// flush the partial sums that the next chain's head completes; the last chain zero-fills to the end of the output
 	const int64_t ring_end = pos + ( W - hop );

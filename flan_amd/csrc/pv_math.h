@@ -186,10 +186,11 @@ template<class V> __device__ __forceinline__ V magnitude_scaled_v( V re, V im )
 template<class V> __device__ __forceinline__ void sincos_fast_v( V x, V & s, V & c )
 	{
 	constexpr int N = vec_traits<V>::N;
+	// k = rint( x 2 / pi ) by the add-and-subtract of 1.5 2^23 (round to nearest even, exactly rint for |x 2 / pi| < 2^22): two full-rate
+	// additions where v_rndne_f32 and v_cvt_i32_f32 are half-rate instructions on gfx950, and the sum's low mantissa bits ARE k's low bits
 	const V kf = x * vsplat<V>( 0x1.45f306p-1f );
-	V k;
-	#pragma unroll
-	for( int i = 0; i < N; ++i ) k[i] = __builtin_rintf( kf[i] );
+	const V km = kf + vsplat<V>( 0x1.8p+23f );
+	const V k = km - vsplat<V>( 0x1.8p+23f );
 	V r = vfma( -k, vsplat<V>( 0x1.921fb6p+0f ), x );
 	r = vfma( -k, vsplat<V>( -0x1.777a5cp-25f ), r );
 	r = vfma( -k, vsplat<V>( -0x1.ee59dap-50f ), r );
@@ -207,7 +208,7 @@ template<class V> __device__ __forceinline__ void sincos_fast_v( V x, V & s, V &
 	#pragma unroll
 	for( int i = 0; i < N; ++i )
 		{
-		const int q = int( k[i] );
+		const int q = __float_as_int( km[i] );                                          // k modulo 2^22 in the low bits
 		const float ss = ( q & 1 ) ? cr[i] : sr[i], cc = ( q & 1 ) ? sr[i] : cr[i];
 		s[i] = ( q & 2 ) ? -ss : ss;
 		c[i] = ( ( q + 1 ) & 2 ) ? -cc : cc;
@@ -300,7 +301,8 @@ __device__ __noinline__ float2 sincos_wide( float x )
 // argument's own ulp beyond).  Branch-free; larger arguments are the caller's business (sincos_wide).
 __device__ __forceinline__ void sincos_fast( float x, float & s, float & c )
 	{
-	const float k = __builtin_rintf( x * 0x1.45f306p-1f );                            // 2/pi
+	const float km = x * 0x1.45f306p-1f + 0x1.8p+23f;                                 // rint( x 2 / pi ) + 1.5 2^23 (see sincos_fast_v)
+	const float k = km - 0x1.8p+23f;
 	float r = __builtin_fmaf( -k, 0x1.921fb6p+0f, x );
 	r = __builtin_fmaf( -k, -0x1.777a5cp-25f, r );
 	r = __builtin_fmaf( -k, -0x1.ee59dap-50f, r );
@@ -315,7 +317,7 @@ __device__ __forceinline__ void sincos_fast( float x, float & s, float & c )
 	cp = __builtin_fmaf( cp, r2, 0x1.55554ap-5f );
 	cp = __builtin_fmaf( cp, r2, -0x1.000000p-1f );
 	const float cr = __builtin_fmaf( cp, r2, 1.0f );
-	const int q = int( k );
+	const int q = __float_as_int( km );
 	const float ss = ( q & 1 ) ? cr : sr;
 	const float cc = ( q & 1 ) ? sr : cr;
 	s = ( q & 2 ) ? -ss : ss;
