@@ -511,17 +511,15 @@ def main():
 
 def other_configs(fa, torch, dev):
     """BASELINE configs 3 and 5 and the reference API's default call, device resident, per-stage events.  Reported beside the headline
-    ('configs'); never part of 'value'."""
+    ('configs'); never part of 'value'.  'ms' is the steady state (the median of five event-timed windows after ~60 ms of the same work, the
+    headline's protocol), 'ms_cold' the first window."""
     lib = fa.lib
     vp = ctypes.c_void_p
 
     def P(t):
         return vp(t.data_ptr())
 
-    def timed(fn, reps=10):
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize()
+    def window(fn, reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
@@ -529,6 +527,23 @@ def other_configs(fa, torch, dev):
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
+
+    cold_ms = {}
+
+    def timed(fn, reps=10, tag=None):
+        """Steady state, like the headline: the first window (3 calls in, on a GPU that has just idled through allocations) is kept as the
+        cold figure; then ~60 ms of the same work, and the median of five windows."""
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        cold = window(fn, reps)
+        if tag is not None:
+            cold_ms[tag] = round(cold, 4)
+        for _ in range(int(60.0 / max(cold, 1e-3)) + 1):
+            fn()
+        torch.cuda.synchronize()
+        w = sorted(window(fn, reps) for _ in range(5))
+        return w[2]
 
     res = {}
     W, HOP, DFT = 2048, 512, 2048
@@ -554,10 +569,10 @@ def other_configs(fa, torch, dev):
         fa.check(lib.flanhip_stretch_map_dev(P(grid), F, BINS, SR, HOP, P(dmax), None))
         fa.check(lib.flanhip_modify_time_dev_fused(P(pv), ch, F, BINS, SR, ar, P(grid), Fo, P(st), W, P(ws), None))
         fa.check(lib.flanhip_synthesize_dev_fused_checked(P(st), ch, Fo, BINS, SR, ar, W, P(out), P(ws), None, None))
-    ms = timed(config3)
+    ms = timed(config3, tag="config3")
     bytes_per_input_frame = 10248 + 24600 + 2 * 10248                      # 55 344 B per input frame
     res["config3_stretch_x2"] = {"workload": "8 ch x 60 s: convert_to_PV(2048,512,2048) -> stretch(x2) -> convert_to_audio", "ms": round(ms, 4),
-                                 "input_frames_per_s": round(ch * F / (ms * 1e-3), 1),
+                                 "ms_cold": cold_ms["config3"], "input_frames_per_s": round(ch * F / (ms * 1e-3), 1),
                                  "algorithmic_GBs": round(ch * F * bytes_per_input_frame / (ms * 1e-3) / 1e9, 1),
                                  "frac_of_8TBs": round(ch * F * bytes_per_input_frame / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     del st, out, ws, grid
@@ -579,10 +594,11 @@ def other_configs(fa, torch, dev):
             fa.check(lib.flanhip_shape_affine_dev_fused(P(pv5), c5, F5, BINS, SR, ar, 1.0, 0.0, 1.0, 100.0, P(sh5), W, P(ws5), None)),
             fa.check(lib.flanhip_synthesize_dev_fused(P(sh5), c5, F5, BINS, SR, ar, W, P(out5), P(ws5), None, None))),
     }
-    st5 = {k: round(timed(v, 5), 4) for k, v in stages5.items()}
+    st5 = {k: round(timed(v, 5, tag=k), 4) for k, v in stages5.items()}
     total5 = sum(st5.values())
     res["config5_resample_shape"] = {"workload": "2 ch x 60 s at 96 kHz: resample(48000) -> convert_to_PV(2048,512,2048) -> shape(f+100 Hz) -> convert_to_audio",
-                                     "stage_ms": st5, "ms": round(total5, 4), "pv_frames_per_s": round(c5 * F5 / (total5 * 1e-3), 1)}
+                                     "stage_ms": st5, "ms": round(total5, 4), "ms_cold": round(sum(cold_ms[k] for k in stages5), 4),
+                                     "pv_frames_per_s": round(c5 * F5 / (total5 * 1e-3), 1)}
     del x96, x48, pv5, sh5, out5, ws5, pv
 
     # ---- the reference API's own defaults: convert_to_PV() = ( 2048, 128, 4096 ) (Audio.h:158-163), and ( 2048, 512, 4096 )
@@ -597,9 +613,9 @@ def other_configs(fa, torch, dev):
         def rt():
             fa.analyze_dev_fused(audio, ch, n, SR, W, hop, dft, pvd, wsd, None)
             fa.synthesize_dev_fused(pvd, ch, Fd, bins, SR, ard, W, outd, wsd, None, None)
-        msd = timed(rt, 5)
+        msd = timed(rt, 5, tag=tag)
         b = 2 * (hop * 4 + bins * 8)
-        res[tag] = {"workload": "8 ch x 60 s: convert_to_PV(2048,%d,4096) -> convert_to_audio" % hop, "ms": round(msd, 4),
+        res[tag] = {"workload": "8 ch x 60 s: convert_to_PV(2048,%d,4096) -> convert_to_audio" % hop, "ms": round(msd, 4), "ms_cold": cold_ms[tag],
                     "frames_per_s": round(ch * Fd / (msd * 1e-3), 1), "algorithmic_GBs": round(ch * Fd * b / (msd * 1e-3) / 1e9, 1),
                     "frac_of_8TBs": round(ch * Fd * b / (msd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         del pvd, outd, wsd

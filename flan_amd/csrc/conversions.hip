@@ -294,6 +294,24 @@ static int run_synth_fast_hop( const SynthParams & p, const FastTables & tb, hip
 
 static bool synth_fast_ok( int dft, int W, int hop ) { return synth_fast_kind( dft, W, hop ) != 0; }
 
+// Chains per group of the kernels that pass group totals from analysis to synthesis (no scan kernel between the two): 8 for the dft 2048
+// pair (a block = 8 one-wavefront chains of a channel), 4 for the dft 4096 team kernels (4 teams per block) -- there only when the chains
+// of a channel fill whole blocks; 0: no group totals for this shape.
+// The carry prologue of group g reads g totals per bin, so it only pays while a channel has few groups: measured on 60 s per 8 channels'
+// worth of frames it beats the scan kernel from 8 channels up (32 groups per channel) and loses below (4 channels, 64 groups: -3 % dft 2048,
+// -4 % dft 4096; tools/ab_step.py --pairs 0:0,0:2 --channels ...).
+static constexpr int kSelfCarryMaxGroups = 40;
+static int self_carry_group( int dft, int W, int hop, int chains_per_channel )
+	{
+	if( synth_fast_kind( dft, W, hop ) != 1 ) return 0;
+	int g = 0;
+	if( dft == 2048 ) g = 8;
+	else if( dft == 4096 && W <= 2048 && W % 256 == 0 && ( hop == 128 || hop % 256 == 0 ) && chains_per_channel % 4 == 0
+		&& g_syn11_variant != 0 && g_ana11_variant == 1 ) g = 4;
+	if( g && ( chains_per_channel + g - 1 ) / g > kSelfCarryMaxGroups ) g = 0;
+	return g;
+	}
+
 // flanhip_analyze_dev_fused always leaves convert_to_audio's pre-pass in the workspace.  The tuned kernels and the generic
 // ones up to dft 2048 accumulate the sums while they have every f in a register; the generic kernels for dft >= 4096 keep no
 // such state (64 bins per lane), so there the pre-pass kernel itself is run on the fresh PV on the analysis' behalf.
@@ -353,8 +371,8 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 			p.sums = reinterpret_cast<double*>( d_fused_ws );
 			p.nan_out = reinterpret_cast<int*>( reinterpret_cast<char*>( d_fused_ws ) + lay.carry_bytes + lay.head_bytes );
 			}
-		// the dft 2048 kernel also leaves one total per group of 8 chains: the synthesis kernel then needs no scan kernel in front of it
-		const bool groups_too = fast && dft == 2048 && kernel_sums;
+		// the dft 2048 kernel (and the dft 4096 team kernel) also leaves one total per group of 8 (4) chains: the synthesis kernel then needs no scan kernel in front of it
+		const bool groups_too = fast && kernel_sums && self_carry_group( dft, W, hop, lay.chains_per_channel ) != 0;
 		p.group_sums = groups_too ? reinterpret_cast<double*>( reinterpret_cast<char*>( d_fused_ws ) + lay.group_offset ) : nullptr;
 		p.groups_per_channel = lay.groups_per_channel;
 		*left_group_sums = groups_too;
@@ -441,7 +459,8 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	const int64_t chains = int64_t( o->chains_per_channel ) * ch;
 	o->carry_bytes = ( size_t( chains ) * bins * sizeof( double ) + 255 ) & ~size_t( 255 );
 	o->head_bytes = ( size_t( chains ) * o->head_len * sizeof( float ) + 255 ) & ~size_t( 255 );
-	o->groups_per_channel = ( o->chains_per_channel + 7 ) / 8;
+	const int gsize = ( !o->any && o->dft == 4096 ) ? 4 : 8;       // self_carry_group
+	o->groups_per_channel = ( o->chains_per_channel + gsize - 1 ) / gsize;
 	o->group_offset = o->carry_bytes + o->head_bytes + 1024;       // tail: NaN flag (4 B at +0), dump area (512 B at +512); then the group sums
 	o->group_bytes = ( size_t( ch ) * o->groups_per_channel * bins * sizeof( double ) + 255 ) & ~size_t( 255 );
 	o->total_bytes = o->group_offset + o->group_bytes;
@@ -505,8 +524,8 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	const int stages = prepass_only ? 3 : g_synth_stage_mask;
 	// The dft 2048 analysis kernel leaves group totals beside the chain sums (launch_analyze notes that for this workspace): the dft 2048
 	// synthesis kernel then works out its own carries and the scan kernel is not launched.  Any other producer or shape: the scan runs.
-	const bool self_carry = presummed == 1 && !prepass_only && !d_carry_in && !d_total_out && g_syn_variant != 2 && lay.dft == 2048
-		&& synth_fast_kind( lay.dft, W, lay.hop ) == 1 && workspace_producer( d_ws ) == 1;
+	const bool self_carry = presummed == 1 && !prepass_only && !d_carry_in && !d_total_out && g_syn_variant != 2
+		&& self_carry_group( lay.dft, W, lay.hop, lay.chains_per_channel ) != 0 && workspace_producer( d_ws ) == 1;
 	if( self_carry )
 		{
 		p.group_sums = reinterpret_cast<const double*>( reinterpret_cast<char*>( d_ws ) + lay.group_offset );

@@ -580,23 +580,15 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 
 		if( frames > 0 ) { if( frame_inside( tfirst ) ) load_half( tfirst, inside ); else load_half( tfirst, outside ); transform_frame( 0 ); }
 		team_sync.meet();
-		for( int i = 0; i < iters; ++i )
+		auto iteration = [&]( int i, auto halo_tag )
 			{
 			const int set = DOUBLE ? ( i & 1 ) : 0;
 			if( i < frames )
 				{
 				const int64_t t = tfirst + i, tn = min( t + 1, t1 - 1 );           // (the last frame requests itself again: nobody waits for it)
 				fidx = i;
-				if( frame_inside( tn ) )
-					{
-					if( t0 > 0 && i == 0 ) bins_of_frame( t, tn, set, std::true_type{}, inside );
-					else bins_of_frame( t, tn, set, std::false_type{}, inside );
-					}
-				else
-					{
-					if( t0 > 0 && i == 0 ) bins_of_frame( t, tn, set, std::true_type{}, outside );
-					else bins_of_frame( t, tn, set, std::false_type{}, outside );
-					}
+				if( frame_inside( tn ) ) bins_of_frame( t, tn, set, halo_tag, inside );
+				else bins_of_frame( t, tn, set, halo_tag, outside );
 				if( role == 1 && ( ( i & 63 ) == 63 || i == frames - 1 ) ) flush_orphans( t - ( i & 63 ), ( i & 63 ) + 1 );
 				}
 			// one buffer set: nobody may write the next frame's E / O before both halves have read this one's.  Two sets: the next frame goes
@@ -604,7 +596,12 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 			if constexpr( !DOUBLE ) team_sync.meet();
 			if( i + 1 < frames ) transform_frame( DOUBLE ? ( set ^ 1 ) : 0 );
 			team_sync.meet();                                                     // the next frame's E / O are written
-			}
+			};
+		// The halo frame (of which only the phases are wanted) is iteration 0 of every chain but a channel's first: peeled, so that the loop
+		// proper holds one kind of iteration (with both kinds inside, the chain sums met at a join after every frame and the compiler paid
+		// a 64-bit register copy per sum and frame)
+		if( t0 > 0 ) iteration( 0, std::true_type{} ); else iteration( 0, std::false_type{} );
+		for( int i = 1; i < iters; ++i ) iteration( i, std::false_type{} );
 		};
 	Stamps st;                                                                  // (diagnostic builds: the wavefront's life, tools/wave_spans.py)
 	st.init();
@@ -620,6 +617,9 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 			bad |= !( __builtin_fabs( sq ) <= 1.7976931348623157e308 );              // a NaN / Inf frequency poisons its sum
 			return ( __builtin_fabs( sq ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( sq ) : fold_phase_any( sq );
 			};
+		// (with group totals wanted, see below: the sums also go to a stage behind the team's sync word -- slot 1087 -- and the dummy mirror slot:
+		// 2049 doubles of the team's four buffers, idle now that both wavefronts have passed the last meeting after their last read)
+		double * const stage = ( DOUBLE && p.group_sums ) ? reinterpret_cast<double*>( buf0 + 1090 ) : nullptr;
 		if( active )
 			{
 			double * dst = p.sums + chain * ( N2 + 1 );
@@ -630,14 +630,48 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 				const double a = fold( sm[q][0] ), b = fold( sm[q][1] ), c = fold( sm[q][2] ), d = fold( sm[q][3] );
 				dst[k] = a; dst[N2 - k] = b; dst[C - k] = c;
 				if( k != 0 ) dst[C + k] = d;                                         // (k = 0: the quad's fourth bin is bin 1024 again)
+				if( stage )
+					{
+					stage[k] = a; stage[N2 - k] = b; stage[C - k] = c;
+					if( k != 0 ) stage[C + k] = d;
+					}
 				}
-			if( role == 1 && lane == 0 ) { dst[512] = fold( sm2[0] ); dst[1536] = fold( sm2[1] ); }
+			if( role == 1 && lane == 0 )
+				{
+				const double a = fold( sm2[0] ), b = fold( sm2[1] );
+				dst[512] = a; dst[1536] = b;
+				if( stage ) { stage[512] = a; stage[1536] = b; }
+				}
 			}
 		const bool any_bad = __any( bad ) && active;
 		if( p.nan_out && lane == 0 && active )
 			{
 			if( chain == 0 && role == 0 ) { p.nan_out[2] = p.nan_epoch; p.nan_out[4] = p.nan_epoch; }
 			if( any_bad ) p.nan_out[0] = p.nan_epoch;
+			}
+		if constexpr( DOUBLE )
+			{
+			if( p.group_sums )
+				{
+				// The host hands group_sums only when chains_per_channel is a multiple of TEAMS: a block is then a GROUP of TEAMS consecutive chains of
+				// one channel, and one total per group lets the synthesis kernel work out its own carries (k_analyze_v2 does the same with its
+				// groups of 8; no scan kernel between the two).
+				__syncthreads();
+				const int gpc = p.chains_per_channel / TEAMS;
+				const int gchannel = int( blockIdx.x ) / gpc, group = int( blockIdx.x ) % gpc;
+				double * gdst = p.group_sums + ( int64_t( gchannel ) * gpc + group ) * ( N2 + 1 );
+				for( int bin = tid; bin <= N2; bin += NT )
+					{
+					double run = 0.0;
+					#pragma unroll
+					for( int w = 0; w < TEAMS; ++w )
+						{
+						const double v = run + reinterpret_cast<const double*>( s + L::BUF + w * 4 * L::BUF_LEN + 1090 )[bin];
+						run = ( __builtin_fabs( v ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( v ) : fold_phase_any( v );
+						}
+					gdst[bin] = run;
+					}
+				}
 			}
 		}
 	}
@@ -705,6 +739,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 
 	// running phases (AudioPV.cpp:105) on entry to the chain: [q][0..3] = bins k, 2048-k, 1024-k, 1024+k; the odd wavefront also 512, 1536
 	double ph[Q][4], phs[2] = { 0.0, 0.0 };
+	if( !p.group_sums )
 		{
 		const double * carry = p.carry + chain * ( N2 + 1 );
 		#pragma unroll
@@ -722,6 +757,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 	// one 256-sample step of finished (or partial) output: this wavefront's half of it.  One store per step, never inside a branch (lanes
 	// outside the output store into the dump area): a static number of stores behind the row request, a counted wait (see k_synthesize_v2)
 	cf * dump2 = reinterpret_cast<cf*>( p.dump ) + lane;
+	const unsigned lane_off = 16u * unsigned( lane ) + 8u * unsigned( role );     // bytes of samples 4 lane + 2 role
 	auto emit_step = [&]( int64_t a0, cf v )
 		{
 		const int64_t a = a0 + 4 * lane + 2 * role;
@@ -877,8 +913,70 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 			}
 		};
 
+	if( frames > 0 ) load_row( t0 );
+	if( p.group_sums )
+		{
+		// No scan kernel ran: `carry` still holds the chains' own sums, group_sums the totals of every group of TEAMS chains (the host hands it only
+		// when chains_per_channel is a multiple of TEAMS: a block is then one group of one channel).  The running phase on entry to a chain = the
+		// groups before this one, then the chains of this group before it, added and folded in order -- as in k_synthesize_v2, whose words
+		// these are: one thread per bin, four or five bins side by side, loads in batches ahead of the dependent additions; every team's carries
+		// land in the team's SECOND buffer set, which nobody writes before the first meeting.
+		auto fold = []( double r ) { return ( __builtin_fabs( r ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_loop( r ) : fold_phase_any( r ); };
+		const int gpc = p.chains_per_channel / TEAMS;
+		const int gchannel = int( blockIdx.x ) / gpc, group = int( blockIdx.x ) % gpc;
+		const double * gs = p.group_sums + int64_t( gchannel ) * gpc * ( N2 + 1 );
+		const double * sums0 = p.carry + ( int64_t( gchannel ) * p.chains_per_channel + int64_t( group ) * TEAMS ) * ( N2 + 1 );
+		constexpr int NB = ( N2 + NT ) / NT;                                       // bins per thread: 5 for 512 threads (the fifth only for thread 0)
+		constexpr int BATCH = 8;
+		int bins_of[NB]; bool has[NB]; double run[NB];
+		#pragma unroll
+		for( int b = 0; b < NB; ++b ) { bins_of[b] = tid + NT * b; has[b] = bins_of[b] <= N2; if( !has[b] ) bins_of[b] = N2; run[b] = 0.0; }
+		double vc[NB][TEAMS];
+		#pragma unroll
+		for( int b = 0; b < NB; ++b )
+			{
+			#pragma unroll
+			for( int w = 0; w < TEAMS; ++w ) vc[b][w] = sums0[int64_t( w ) * ( N2 + 1 ) + bins_of[b]];
+			}
+		for( int g0 = 0; g0 < group; g0 += BATCH )
+			{
+			double v[NB][BATCH];
+			#pragma unroll
+			for( int b = 0; b < NB; ++b )
+				{
+				#pragma unroll
+				for( int u = 0; u < BATCH; ++u ) v[b][u] = ( g0 + u < group ) ? gs[int64_t( g0 + u ) * ( N2 + 1 ) + bins_of[b]] : 0.0;
+				}
+			#pragma unroll
+			for( int u = 0; u < BATCH; ++u )
+				{
+				#pragma unroll
+				for( int b = 0; b < NB; ++b ) run[b] = fold( run[b] + v[b][u] );       // + 0.0 past the end: fold( x ) of a folded x is x
+				}
+			}
+		#pragma unroll
+		for( int w = 0; w < TEAMS; ++w )
+			{
+			#pragma unroll
+			for( int b = 0; b < NB; ++b )
+				{
+				if( has[b] ) reinterpret_cast<double*>( s + L::BUF + ( 4 * w + 2 ) * L::BUF_LEN )[bins_of[b]] = run[b];   // phase_buffer on entry to chain w of the group
+				run[b] = fold( run[b] + vc[b][w] );
+				}
+			}
+		if( tid == 0 && blockIdx.x == 0 && p.nan_in && p.nan_flag && p.nan_in[0] == p.nan_in[2] && p.nan_in[2] != 0 ) atomicOr( p.nan_flag, 1 );
+		__syncthreads();
+		const double * mine = reinterpret_cast<const double*>( buf0 + 2 * L::BUF_LEN );
+		#pragma unroll
+		for( int q = 0; q < Q; ++q )
+			{
+			const int k = k0 + 64 * q;
+			ph[q][0] = mine[k]; ph[q][1] = mine[N2 - k]; ph[q][2] = mine[C - k]; ph[q][3] = mine[C + k];
+			}
+		if( role == 1 ) { phs[0] = mine[512]; phs[1] = mine[1536]; }
+		}
 	int64_t pos = chain_start;
-	if( frames > 0 ) { load_row( t0 ); bins_of_row( 0 ); }
+	if( frames > 0 ) bins_of_row( 0 );
 	team_sync.meet();
 	const int iters = p.L;
 	for( int i = 0; i < iters; ++i )
@@ -915,8 +1013,18 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 				}
 			else
 				{
-				#pragma unroll
-				for( int q = 0; q < HS; ++q ) emit_step( pos + 256 * q, acc[q] );
+				// HS stores in either arm.  Past the chain's head every step of any chain but a channel's first goes to the output proper, all of
+				// it inside: a scalar address (the wavefront's number is a scalar here) plus the lane's constant offset; emit_step for the rest
+				if( chain_in_channel != 0 && pos >= own_start )
+					{
+					#pragma unroll
+					for( int q = 0; q < HS; ++q ) *reinterpret_cast<cf*>( reinterpret_cast<char*>( out1 + pos + 256 * q ) + lane_off ) = acc[q];
+					}
+				else
+					{
+					#pragma unroll
+					for( int q = 0; q < HS; ++q ) emit_step( pos + 256 * q, acc[q] );
+					}
 				#pragma unroll
 				for( int q = 0; q < 2 * Q; ++q ) acc[q] = ( q + HS < 2 * Q ) ? acc[q + HS] : mk( 0.0f, 0.0f );
 				}

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Whole fused round trip (analysis + everything convert_to_audio launches) per kernel-variant pair, interleaved in one process.
-    python tools/ab_step.py --pairs 4:1,4:2,0:0"""
+    python tools/ab_step.py --pairs 0:0,0:2 [--channels 1 --seconds 480 --dft 2048 --hop 512]
+(synthesis variant 2: the scan kernel instead of the carry prologue from group totals)"""
 import argparse, ctypes, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,14 +12,18 @@ def main():
     ap.add_argument("--pairs", default="4:1,4:2,0:0")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--channels", type=int, default=8)
+    ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("--dft", type=int, default=2048)
+    ap.add_argument("--hop", type=int, default=512)
     args = ap.parse_args()
     import torch
     import flan_amd as fa
-    W, HOP, DFT, SR = 2048, 512, 2048, 48000.0
+    W, HOP, DFT, SR = 2048, args.hop, args.dft, 48000.0
     BINS = DFT // 2 + 1
     dev = torch.device("cuda", 0)
     fa.check(fa.lib.flanhip_set_device(0))
-    ch, n = 8, int(60 * SR)
+    ch, n = args.channels, int(args.seconds * SR)
     F = int(fa.lib.flanhip_num_pv_frames(n, HOP))
     ar = SR / HOP
     audio = torch.empty((ch, n), dtype=torch.float32, device=dev)
@@ -61,7 +66,7 @@ def main():
     for k, v in state.items():
         ms = sorted(v["ms"])
         print("ana %d syn %d : median %.4f ms  min %.4f ms  (%.1f M frames/s)  rms vs first %s" % (k[0], k[1], ms[len(ms) // 2], ms[0], ch * F / ms[len(ms) // 2] / 1e3, v.get("rms_vs_first")))
-    fa.lib.flanhip_debug_kernel_variant(0, 4); fa.lib.flanhip_debug_kernel_variant(1, 1)
+    fa.lib.flanhip_debug_kernel_variant(0, 0); fa.lib.flanhip_debug_kernel_variant(1, 0)
 
 
 if __name__ == "__main__":
