@@ -138,9 +138,13 @@ __global__ __launch_bounds__( 256 ) void k_modify_time_chains( TimeChainParams p
 		if( SUMS && blockIdx.x == 0 && threadIdx.x == 0 ) { p.words[2] = p.epoch; p.words[4] = 0; }   // the sums are NOT valid for this epoch: said explicitly, not left to staleness
 		return;
 		}
-	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
+	// Workgroups are dealt to the 8 XCDs round-robin and each XCD has its own L2; blocks that are neighbours in `idx` write neighbouring
+	// 2 KB pieces of the same rows.  XCD x takes a contiguous run of blocks, so that the pieces of a row meet in one L2.
+	const int64_t nblocks = gridDim.x, per_xcd = ( nblocks + 7 ) / 8;
+	const int64_t vblock = int64_t( blockIdx.x % 8 ) * per_xcd + blockIdx.x / 8;
+	const int64_t idx = vblock * blockDim.x + threadIdx.x;
 	const int64_t per_channel = int64_t( p.chains_per_channel ) * p.bins;
-	const bool live = idx < per_channel * p.num_channels;
+	const bool live = int64_t( blockIdx.x / 8 ) < per_xcd && idx < per_channel * p.num_channels;
 	bool bad = false;
 	if( live )
 		{
@@ -544,7 +548,7 @@ static int modify_time_dev_impl( const flanhip_MF * d_pv, int64_t ch, int64_t F,
 	cp.F = F; cp.Fo = Fo; cp.num_channels = int( ch ); cp.bins = bins; cp.L = 64; cp.chains_per_channel = int( ( Fo + 63 ) / 64 );
 	cp.sr = sr; cp.hop = float( hop ); cp.nonmono = d_flags; cp.interp = interp;
 	const int64_t owners = ch * int64_t( cp.chains_per_channel ) * bins;
-	hipLaunchKernelGGL( k_modify_time_chains<false>, dim3( (unsigned) ( ( owners + 255 ) / 256 ) ), dim3( 256 ), 0, s, cp );
+	hipLaunchKernelGGL( k_modify_time_chains<false>, dim3( (unsigned) ( ( ( owners + 255 ) / 256 + 7 ) / 8 * 8 ) ), dim3( 256 ), 0, s, cp );
 	FLANHIP_CHECK( hipGetLastError() );
 	// the general walk, for a PV with a column that runs backwards (retires at once otherwise):
 	// enough (column, segment) threads to fill the chip, segments of at least 16 frame pairs
@@ -589,7 +593,7 @@ static int modify_time_dev_fused_impl( const flanhip_MF * d_pv, int64_t ch, int6
 	p.nonmono = d_flags; p.interp = interp;
 	note_workspace_producer( d_ws, 0 );                                               // chain sums (maybe), no group totals: convert_to_audio runs its scan
 	const int64_t owners = ch * int64_t( lay.chains_per_channel ) * bins;
-	hipLaunchKernelGGL( k_modify_time_chains<true>, dim3( (unsigned) ( ( owners + 255 ) / 256 ) ), dim3( 256 ), 0, s, p );
+	hipLaunchKernelGGL( k_modify_time_chains<true>, dim3( (unsigned) ( ( ( owners + 255 ) / 256 + 7 ) / 8 * 8 ) ), dim3( 256 ), 0, s, p );
 	FLANHIP_CHECK( hipGetLastError() );
 	// the general walk, for a PV with a column that runs backwards: retires at once otherwise
 	const int64_t columns = ch * bins;
