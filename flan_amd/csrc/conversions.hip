@@ -148,22 +148,7 @@ static int run_analyze_v2_variant( int v, const AnalyzeParams & p, const FastTab
 		}
 	}
 
-// dft 4096 with window <= 2048 as two 1024-point register transforms per frame (pv_kernels_eo.h): 8-wave blocks, 160 KB of LDS
-template<int WAVES, int QV = 2>
-static int run_analyze_eo( const AnalyzeParams & p, const FastTables & tb, hipStream_t s )
-	{
-	const size_t lds = EoLds::bytes( WAVES );
-	static_assert( EoLds::bytes( WAVES ) <= kMaxLds, "LDS budget" );
-	auto kern = k_analyze_eo<WAVES, QV>;
-	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
-	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;
-	const int64_t blocks = ( chains + WAVES - 1 ) / WAVES;
-	FLANHIP_REQUIRE( blocks < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
-	hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( 64 * WAVES ), lds, s, p, tb );
-	FLANHIP_CHECK( hipGetLastError() );
-	return FLANHIP_OK;
-	}
-
+// dft 4096 with window <= 2048 as two 1024-point register transforms per frame (pv_kernels_eo.h): teams of two wavefronts, 160 KB of LDS
 template<int TEAMS, bool SUMS, int QV, bool DOUBLE = false>
 static int run_analyze_eo_team( const AnalyzeParams & p, const FastTables & tb, hipStream_t s )
 	{
@@ -346,7 +331,6 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	p.num_channels = int( ch ); p.window_size = W; p.hop = hop;
 	const bool fast = ( dft == 2048 || dft == 4096 ) && n >= 2 && n < ( int64_t( 1 ) << 31 ) - 8192 && !force_generic();
 	int target_chains = any ? any_target_chains( dft / 2 + 1 ) : fast ? fast_target_chains( dft, false ) : generic_target_chains( dft );
-	if( fast && dft == 4096 && W <= 2048 && g_ana11_variant != 0 && g_ana11_variant != 3 && !d_fused_ws ) target_chains = 256 * 8;   // k_analyze_eo: 8 one-wavefront chains per CU
 	p.L = choose_chain_length( ch, p.F, any ? 7 : 1, target_chains );
 	p.chains_per_channel = int( ( p.F + p.L - 1 ) / p.L );
 	p.sample_rate = sr;
@@ -411,13 +395,9 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 		if( dft == 2048 ) return p.sums ? run_analyze_v2_variant<true>( g_ana_variant, p, tb, s ) : run_analyze_v2_variant<false>( g_ana_variant, p, tb, s );
 		if( dft == 4096 && W <= 2048 && g_ana11_variant != 0 )
 			{
-			// the fused round trip (with chain sums): teams of two wavefronts, two E / O buffer sets, one barrier per frame (0.34 ms for 8 ch x 60 s;
-			// one set and two barriers: 0.365; the round-1 kernel: 0.44).  Without sums one wavefront per chain is faster still (0.27 against 0.34:
-			// no barriers) and does not spill.  Variants 2.. are A/B builds of the same kernels.
-			if( !p.sums && g_ana11_variant != 3 ) return run_analyze_eo<8, 2>( p, tb, s );
-			if( g_ana11_variant == 2 ) return run_analyze_eo_team<4, true, 2, false>( p, tb, s );
-			if( g_ana11_variant == 3 ) return p.sums ? run_analyze_eo_team<4, true, 1, true>( p, tb, s ) : run_analyze_eo_team<4, false, 2, true>( p, tb, s );
-			return run_analyze_eo_team<4, true, 2, true>( p, tb, s );
+			// teams of two wavefronts, two E / O buffer sets, one meeting per frame (0.27 ms for 8 ch x 60 s with the fused round trip's chain sums,
+			// 0.28 without; one set and two meetings: +7 %; the round-1 kernel: 0.44)
+			return p.sums ? run_analyze_eo_team<4, true, 2, true>( p, tb, s ) : run_analyze_eo_team<4, false, 2, true>( p, tb, s );
 			}
 		return p.sums ? run_analyze_fast<11, kWaves11, true>( p, tb, s ) : run_analyze_fast<11, kWaves11, false>( p, tb, s );
 		}

@@ -9,9 +9,10 @@
 // each half the dft 2048 kernel's own register transform (fft_fast<10>, 16 points per lane, the upper half of its input zero because
 // the window is at most half the transform).  A lane owns the QUADS  k = lane + 64 q, q < 8:  from E[k], O[k] (its own registers) and
 // E[1024-k], O[1024-k] (the mirror lane's, through LDS) come Z[k], Z[1024+k], Z[1024-k], Z[2048-k], i.e. the two mirror pairs
-// ( k, 2048-k ) and ( 1024-k, 1024+k ) of the real-transform split: 4 bins per quad, 32 per lane, with the dft 2048 kernel's per-bin
-// code (polar_v, exact divisions, pv_kernels_v2.h).  Register budget and LDS per wavefront (2 x 8.7 KB) are the dft 2048 kernel's, so
-// blocks of 8 wavefronts = 2 per SIMD fit (160 KB of LDS exactly, with the 20 KB of tables).
+// ( k, 2048-k ) and ( 1024-k, 1024+k ) of the real-transform split: 4 bins per quad, with the dft 2048 kernel's per-bin
+// code (polar_v, exact divisions, pv_kernels_v2.h).  The two transforms of a frame belong to the two wavefronts of a TEAM (below), each
+// then owning half the quads: per frame a wavefront does what a dft 2048 wavefront does, with its register budget, and blocks of
+// 8 wavefronts = 4 teams = 2 wavefronts per SIMD fit (160 KB of LDS exactly: two E / O buffer sets per team and 24 KB of tables).
 //   lane 0, q = 0: the quad degenerates to bins 0, 2048 (from Z[0]) and 1024 (= conj Z[1024], computed twice);
 //   k = 512: bins 512 and 1536, one pair, carried redundantly by every lane and stored by lane 0.
 #pragma once
@@ -41,264 +42,14 @@ __device__ __forceinline__ void split_pair( cf zk, cf zm, float wx, float wy, fl
 	rm = __builtin_fmaf( 0.5f, sx, -t1v ); im = __builtin_fmaf( -0.5f, sy, -t2v );
 	}
 
-// One wavefront per chain: for the plain convert_to_PV (no chain sums).  With the fused round trip's sums its state (32 previous phases
-// and 32 fp64 sums beside the transform) spills, however the loop is arranged -- that job is k_analyze_eo_team's, below.
-template<int WAVES, int QV = 2>                 // QV: quads (of 4 bins) evaluated together as one vector stream
-__global__ __launch_bounds__( 64 * WAVES ) void k_analyze_eo( AnalyzeParams p, FastTables tb )
-	{
-	using L = EoLds;
-	constexpr int C = 1024, N2 = 2048, Q = 8, NT = 64 * WAVES;
-	typedef float VB __attribute__(( ext_vector_type( 4 * QV ) ));
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	cf * s = reinterpret_cast<cf*>( smem );
-	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane( tid >> 6 );   // a scalar: chain, frame range, audio pointer follow
-	const int W = p.window_size, hop = p.hop;
-
-	// ---- tables (block-wide): the plan's tables are those of the 2048-point transform (tb.tw3: [7][256] exp( -2 pi i r j / 2048 ),
-	// tb.w2: exp( -2 pi i k / 4096 )); the 1024-point ones are every other row / entry of them
-	for( int i = tid; i < 240; i += NT ) s[L::TW1 + i] = tb.tw1[i];
-	for( int i = tid; i < 768; i += NT ) s[L::TW3 + i] = tb.tw3[( 2 * ( i >> 8 ) + 1 ) * 256 + ( i & 255 )];
-		{
-		v4f_t * twq = reinterpret_cast<v4f_t*>( s + L::TWQ );
-		for( int k = tid; k < 512; k += NT ) { const cf a = tb.w2[k], b = tb.w2[2 * k]; twq[k] = v4f_t{ 0.5f * a.x, 0.5f * a.y, b.x, b.y }; }
-		float * win = reinterpret_cast<float*>( s + L::WIN );
-		for( int i = tid; i < 2048; i += NT ) win[i] = ( i < W ) ? p.window[i] : 0.0f;            // AudioPV.cpp:60,65
-		}
-	__syncthreads();
-	const cf * s_tw1 = s + L::TW1;
-	const cf * s_tw3 = s + L::TW3;
-	const v4f_t * s_twq = reinterpret_cast<const v4f_t*>( s + L::TWQ ) + lane;
-	const v4f_t * s_win = reinterpret_cast<const v4f_t*>( s + L::WIN ) + lane;
-	cf * bufE = s + L::BUF + wave * 2 * L::BUF_LEN;
-	cf * bufO = bufE + L::BUF_LEN;
-
-	const int64_t chain = int64_t( blockIdx.x ) * WAVES + wave;
-	if( chain >= int64_t( p.chains_per_channel ) * p.num_channels || cancel_seen( cancel_peek( p.cancel ) ) ) return;   // no block barrier below (cancelled: core.hip)
-	const int channel = int( chain / p.chains_per_channel );
-	const int64_t t0 = int64_t( chain % p.chains_per_channel ) * p.L;
-	const int64_t t1 = min( t0 + int64_t( p.L ), p.F );
-	const float * x = p.audio + int64_t( channel ) * p.n;
-	const bool use_wrapping = p.analysis_rate < p.sample_rate;                // phase_vocoder.cpp:37
-	const int padl = lane + ( lane >> 4 );
-	const int mir = ( C * 17 ) / 16 - ( lane + ( ( lane + 15 ) >> 4 ) );      // mirror slot of this lane: buf[mir - 68 q] = slot PAD( C - lane - 64 q )
-	const cf * mirrorE = bufE + mir;
-	const cf * mirrorO = bufO + mir;
-	const int n32 = int( p.n );
-	const float rdft = 1.0f / float( 2 * N2 );
-	const float flane = float( lane );
-
-	// state that crosses frames: previous phases (phase_vocoder.cpp:45) of the lane's 8 quads -- [q][0..3] = bins k, 2048-k, 1024-k,
-	// 1024+k -- and of bins 512, 1536
-	float prev[Q][4], prevs[2] = { 0.0f, 0.0f };
-	#pragma unroll
-	for( int q = 0; q < Q; ++q ) { prev[q][0] = 0.0f; prev[q][1] = 0.0f; prev[q][2] = 0.0f; prev[q][3] = 0.0f; }   // AudioPV.cpp:44
-
-	const int64_t tfirst = t0 > 0 ? t0 - 1 : t0;
-	// does frame t lie inside the signal with all its 2048 samples?  Per FRAME, not per chain: the edge chains (the first and the last of a
-	// channel) have a few frames that reach outside, and a launch lasts as long as its slowest wavefront (see k_analyze_v2)
-	auto frame_inside = [&]( int64_t t ) { return W == 2048 && int64_t( hop ) * t - W / 2 >= 0 && int64_t( hop ) * t - W / 2 + 2048 <= p.n; };
-	constexpr std::true_type inside{};
-	constexpr std::false_type outside{};
-
-	// samples 4 i .. 4 i + 3 of frame t, i = lane + 64 q: c[2i] = ( x[4i], x[4i+1] ) is the even transform's point i, c[2i+1] the odd one's.
-	// The even halves are requested during the per-bin work of the frame before; the odd halves only when the even transform starts (it
-	// covers their latency) -- 16 registers less across the per-bin work than requesting all of a frame at once.
-	cf raw_e[Q], raw_o[Q];
-	auto run_chain = [&]()
-		{
-		struct __attribute__(( packed, aligned( 4 ) )) f2u { float x, y; };
-		auto load_half = [&]( int64_t t, int odd, cf ( &dst )[Q], auto fast_tag )
-			{
-			constexpr bool FAST = decltype( fast_tag )::value;
-			const int start = int( int64_t( hop ) * t - W / 2 ) + 2 * odd;
-			#pragma unroll
-			for( int q = 0; q < Q; ++q )
-				{
-				const int a = start + 4 * ( lane + 64 * q );
-				if constexpr( FAST )
-					{
-					const f2u v = *reinterpret_cast<const f2u*>( x + a );
-					dst[q] = mk( v.x, v.y );
-					}
-				else
-					{
-					// edge chains (the first and the last of a channel): every sample on its own, zero outside the signal (AudioPV.cpp:54-62)
-					// and beyond the window (:65: zero, not sample x 0)
-					const int w0 = 4 * ( lane + 64 * q ) + 2 * odd;
-					const float v0 = ( a >= 0 && a < n32 && w0 < W ) ? x[a] : 0.0f;
-					const float v1 = ( a + 1 >= 0 && a + 1 < n32 && w0 + 1 < W ) ? x[a + 1] : 0.0f;
-					dst[q] = mk( v0, v1 );
-					}
-				}
-			};
-		// window (AudioPV.cpp:60), the two transforms; leaves E and O in natural order in bufE / bufO (a lane's own E[k], O[k] too: 32
-		// registers less across the per-bin work than keeping them)
-		auto transform_frame = [&]( int64_t t, auto fast_tag )
-			{
-			load_half( t, 1, raw_o, fast_tag );                                   // travels under the even transform
-			cf z[16];
-			#pragma unroll
-			for( int q = 0; q < Q; ++q )
-				{
-				const v4f_t wv = s_win[64 * q];
-				z[q] = mk( raw_e[q].x * wv.x, raw_e[q].y * wv.y );
-				z[Q + q] = mk( 0.0f, 0.0f );
-				}
-			fft_fast<10>( z, bufE, s_tw1, s_tw3, lane );
-			#pragma unroll
-			for( int q = 0; q < 2 * Q; ++q ) bufE[padl + 68 * q] = z[q];              // natural order: slot PAD( lane + 64 q )
-			#pragma unroll
-			for( int q = 0; q < Q; ++q )
-				{
-				const v4f_t wv = s_win[64 * q];
-				z[q] = mk( raw_o[q].x * wv.z, raw_o[q].y * wv.w );
-				z[Q + q] = mk( 0.0f, 0.0f );
-				}
-			fft_fast<10>( z, bufO, s_tw1, s_tw3, lane );
-			#pragma unroll
-			for( int q = 0; q < 2 * Q; ++q ) bufO[padl + 68 * q] = z[q];
-			wave_sync();
-			};
-
-		// per-bin work of frame t (requests frame tn's samples first); HALO: frame t0 - 1, of which only the phases are wanted
-		auto bins_of_frame = [&]( int64_t t, int64_t tn, auto halo_tag, auto next_fast )
-			{
-			constexpr bool halo = decltype( halo_tag )::value;
-			const cf e512 = bufE[544], o512 = bufO[544];                          // slot PAD( 512 )
-			const cf e0 = bufE[padl], o0 = bufO[padl];                            // lane 0: E[0], O[0]
-			cf * row = reinterpret_cast<cf*>( p.out + ( int64_t( channel ) * p.F + t ) * ( N2 + 1 ) );
-			cf * row_a = row + lane;                                              // bin k          (+ 64 q)
-			cf * row_b = row + ( N2 - lane );                                     // bin 2048 - k   (- 64 q)
-			cf * row_c = row + ( C - lane );                                      // bin 1024 - k   (- 64 q)
-			cf * row_d = row + ( C + lane );                                      // bin 1024 + k   (+ 64 q)
-			#pragma unroll
-			for( int g = 0; g < Q / QV; ++g )
-				{
-				// the next frame's samples are requested half way through: by then half of e[] / o[] is dead and their registers hold the
-				// request (the 16 stores in front of it are long acknowledged when the transform waits for these loads)
-				if( g == Q / QV / 2 ) load_half( tn, 0, raw_e, next_fast );
-				VB re, im, pv, binf;
-				#pragma unroll
-				for( int i = 0; i < QV; ++i )
-					{
-					const int q = QV * g + i;
-					const cf ek = bufE[padl + 68 * q], ok = bufO[padl + 68 * q];
-					const cf em = mirrorE[-68 * q], om = mirrorO[-68 * q];         // lane 0, q = 0 reads an unused slot: overridden below
-					const v4f_t tw = s_twq[64 * q];
-					// Z[k] = E[k] + w^k O[k], Z[1024+k] = E[k] - w^k O[k];  w^(1024-k) = -conj( w^k ):  Z[1024-k] = E[1024-k] - conj( w^k ) O[1024-k],
-					// Z[2048-k] = E[1024-k] + conj( w^k ) O[1024-k]
-					const float px = __builtin_fmaf( tw.z, ok.x, -( tw.w * ok.y ) ), py = __builtin_fmaf( tw.z, ok.y, tw.w * ok.x );
-					const float qx = __builtin_fmaf( tw.z, om.x, tw.w * om.y ), qy = __builtin_fmaf( tw.z, om.y, -( tw.w * om.x ) );
-					const cf zk = mk( ek.x + px, ek.y + py ), zk2 = mk( ek.x - px, ek.y - py );
-					const cf zm = mk( em.x - qx, em.y - qy ), zm2 = mk( em.x + qx, em.y + qy );
-					// pair ( k, 2048-k ) with 0.5 exp( -2 pi i k / 4096 ) = ( a, b ); pair ( 1024-k, 1024+k ) with 0.5 exp( -2 pi i ( 1024-k ) / 4096 ) = ( -b, -a )
-					float r0, i0, r1, i1, r2, i2, r3, i3;
-					split_pair( zk, zm2, tw.x, tw.y, r0, i0, r1, i1 );
-					split_pair( zm, zk2, -tw.y, -tw.x, r2, i2, r3, i3 );
-					if( q == 0 )
-						{
-						const bool l0 = lane == 0;
-						const cf z0 = mk( e0.x + o0.x, e0.y + o0.y ), zc = mk( e0.x - o0.x, e0.y - o0.y );   // Z[0], Z[1024]
-						r0 = l0 ? z0.x + z0.y : r0;  i0 = l0 ? 0.0f : i0;               // X[0]
-						r1 = l0 ? z0.x - z0.y : r1;  i1 = l0 ? 0.0f : i1;               // X[2048]
-						r2 = l0 ? zc.x : r2;  i2 = l0 ? -zc.y : i2;                     // X[1024] = conj Z[1024] ...
-						r3 = l0 ? zc.x : r3;  i3 = l0 ? -zc.y : i3;                     // ... twice (the quad's fourth bin is the same bin)
-						}
-					re[4 * i + 0] = r0; im[4 * i + 0] = i0; re[4 * i + 1] = r1; im[4 * i + 1] = i1;
-					re[4 * i + 2] = r2; im[4 * i + 2] = i2; re[4 * i + 3] = r3; im[4 * i + 3] = i3;
-					const float fk = flane + float( 64 * q );
-					binf[4 * i + 0] = fk * p.sample_rate * rdft;                                    // PVBuffer.cpp:443-446 (the division by dft is exact)
-					binf[4 * i + 1] = ( float( N2 ) - fk ) * p.sample_rate * rdft;
-					binf[4 * i + 2] = ( float( C ) - fk ) * p.sample_rate * rdft;
-					binf[4 * i + 3] = ( float( C ) + fk ) * p.sample_rate * rdft;
-					#pragma unroll
-					for( int j = 0; j < 4; ++j ) pv[4 * i + j] = prev[q][j];
-					}
-				// phase_vocoder.cpp:37-52 (AudioPV.cpp:69-73)
-				VB phase, m;
-				polar_v( re, im, phase, m );
-				#pragma unroll
-				for( int i = 0; i < QV; ++i )
-					{
-					#pragma unroll
-					for( int j = 0; j < 4; ++j ) prev[QV * g + i][j] = phase[4 * i + j];          // :45
-					}
-				if constexpr( !halo )
-					{
-					const VB expd = div_c_each( binf, p.ar_div ) * vsplat<VB>( FLANHIP_PI2_F );       // :47
-					const VB phase_diff = phase - pv;                                            // == float( double(phase) - double(prev) ), :44
-					const VB delta_phase = phase_diff - expd;                                    // :47-48
-					VB wrapped = delta_phase;
-					if( use_wrapping ) wrapped = delta_phase - vsplat<VB>( FLANHIP_PI2_F ) * round_half_away_v( div_pi2_v( delta_phase ) );   // :39-42,49
-					VB war;                                                                  // (element by element: no SGPR copy per element of a splat)
-					#pragma unroll
-					for( int i = 0; i < int( sizeof( VB ) / sizeof( float ) ); ++i ) war[i] = wrapped[i] * p.analysis_rate;
-					const VB f = binf + div_pi2_v( war );                                    // :50-52
-					#pragma unroll
-					for( int i = 0; i < QV; ++i )
-						{
-						const int q = QV * g + i;
-						__builtin_nontemporal_store( cf{ m[4 * i + 0], f[4 * i + 0] }, row_a + 64 * q );
-						__builtin_nontemporal_store( cf{ m[4 * i + 1], f[4 * i + 1] }, row_b - 64 * q );
-						__builtin_nontemporal_store( cf{ m[4 * i + 2], f[4 * i + 2] }, row_c - 64 * q );
-						__builtin_nontemporal_store( cf{ m[4 * i + 3], f[4 * i + 3] }, row_d + 64 * q );
-						}
-					}
-				}
-				{
-				// k = 512: Z[512] = E[512] - i O[512], Z[1536] = E[512] + i O[512]; bins 512 and 1536 are one mirror pair with
-				// 0.5 exp( -i pi / 4 ); every lane carries the same values, lane 0 stores them
-				const cf zk = mk( e512.x + o512.y, e512.y - o512.x ), zm = mk( e512.x - o512.y, e512.y + o512.x );
-				float r[2], im2[2];
-				split_pair( zk, zm, 0.35355339059327379f, -0.35355339059327379f, r[0], im2[0], r[1], im2[1] );
-				#pragma unroll
-				for( int j = 0; j < 2; ++j )
-					{
-					const float phase = atan2_fast( im2[j], r[j] );
-					const float pvx = prevs[j];
-					prevs[j] = phase;
-					if constexpr( !halo )
-						{
-						const float bx = float( j == 0 ? 512 : 1536 ) * p.sample_rate * rdft;
-						const float delta_phase = ( phase - pvx ) - div_c( bx, p.ar_div ) * FLANHIP_PI2_F;
-						const float wrapped = use_wrapping ? delta_phase - FLANHIP_PI2_F * round_half_away( div_pi2( delta_phase ) ) : delta_phase;
-						const float f = bx + div_pi2( wrapped * p.analysis_rate );
-						const float m = magnitude_scaled( r[j], im2[j] );
-						if( lane == 0 ) __builtin_nontemporal_store( mk( m, f ), row + ( j == 0 ? 512 : 1536 ) );
-						}
-					}
-				}
-			wave_sync();                                                          // the mirror halves are read: the next transform may overwrite them
-			};
-
-		if( frame_inside( tfirst ) ) { load_half( tfirst, 0, raw_e, inside ); transform_frame( tfirst, inside ); }
-		else { load_half( tfirst, 0, raw_e, outside ); transform_frame( tfirst, outside ); }
-		if( t0 > 0 )
-			{
-			if( frame_inside( t0 ) ) { bins_of_frame( t0 - 1, t0, std::true_type{}, inside ); transform_frame( t0, inside ); }
-			else { bins_of_frame( t0 - 1, t0, std::true_type{}, outside ); transform_frame( t0, outside ); }
-			}
-		for( int64_t t = t0; t < t1; ++t )
-			{
-			const int64_t tn = min( t + 1, t1 - 1 );                               // (the last frame requests itself again: nobody waits for it)
-			auto rest_of_step = [&]( auto next_fast )
-				{
-				bins_of_frame( t, tn, std::false_type{}, next_fast );
-				if( t + 1 < t1 ) transform_frame( t + 1, next_fast );
-				};
-			if( frame_inside( tn ) ) rest_of_step( inside ); else rest_of_step( outside );
-			}
-		};
-	run_chain();
-
-	}
-
 // =================================================================================================================
-// The same decomposition with a TEAM of two wavefronts per chain: wavefront 0 of a team transforms the even points and then owns the
+// A TEAM of two wavefronts per chain: wavefront 0 of a team transforms the even points and then owns the
 // quads k < 256, wavefront 1 the odd points and the quads 256 <= k < 512 (and k = 512).  Per frame a wavefront does exactly what the
 // dft 2048 kernel's wavefront does -- one 1024-point register transform and 16 bins -- so its registers (16 previous phases, 16 chain
-// sums instead of 32 + 32) fit the fused round trip's sums without spilling, which the one-wavefront form above does not
-// (its SUMS instantiation spills 400+ bytes per lane and drains the memory queue every frame: 0.70 ms against 0.27 ms without sums).
+// sums) fit the fused round trip's sums without spilling.  (Round 2 also had a one-wavefront-per-chain form of the same decomposition for
+// the plain convert_to_PV: 32 previous phases per lane, 256 VGPRs and 100-220 bytes of scratch reloaded inside the frame loop; once the
+// team kernel had lost its splats and canonicalising maxima it was the faster one without sums too -- 0.280 against 0.307 ms at hop 512 --
+// and the one-wavefront kernel was removed, round 3.)
 // The two halves meet in the team's E / O buffers (TeamSync below; every team walks the same number of iterations, idle ones included).
 __device__ __forceinline__ void lds_block_sync()
 	{
@@ -397,7 +148,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 	const int64_t tfirst = t0 > 0 ? t0 - 1 : t0;
 	const int frames = active ? int( t1 - tfirst ) : 0;                       // iterations with work (the halo frame included)
 	const int iters = p.L + 1;                                                // what every team of every block walks
-	auto frame_inside = [&]( int64_t t ) { return W == 2048 && int64_t( hop ) * t - W / 2 >= 0 && int64_t( hop ) * t - W / 2 + 2048 <= p.n; };   // per frame (see k_analyze_eo)
+	auto frame_inside = [&]( int64_t t ) { return W == 2048 && int64_t( hop ) * t - W / 2 >= 0 && int64_t( hop ) * t - W / 2 + 2048 <= p.n; };   // per frame (see k_analyze_v2)
 	constexpr std::true_type inside{};
 	constexpr std::false_type outside{};
 
