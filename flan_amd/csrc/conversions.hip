@@ -156,8 +156,7 @@ static int run_analyze_eo_team( const AnalyzeParams & p, const FastTables & tb, 
 	static_assert( EoLds::bytes( DOUBLE ? 2 * TEAMS : TEAMS ) <= kMaxLds, "LDS budget" );
 	auto kern = k_analyze_eo_team<TEAMS, SUMS, QV, DOUBLE>;
 	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
-	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;
-	const int64_t blocks = ( chains + TEAMS - 1 ) / TEAMS;
+	const int64_t blocks = int64_t( ( p.chains_per_channel + TEAMS - 1 ) / TEAMS ) * p.num_channels;   // a block = a group of TEAMS chains of one channel
 	FLANHIP_REQUIRE( blocks < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
 	hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( 128 * TEAMS ), lds, s, p, tb );
 	FLANHIP_CHECK( hipGetLastError() );
@@ -225,8 +224,7 @@ static int run_synth_eo_team( const SynthParams & p, const FastTables & tb, hipS
 	static_assert( EoLds::bytes( 2 * TEAMS ) <= kMaxLds, "LDS budget" );
 	auto kern = k_synthesize_eo_team<TEAMS, HS>;
 	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
-	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;
-	const int64_t blocks = ( chains + TEAMS - 1 ) / TEAMS;
+	const int64_t blocks = int64_t( ( p.chains_per_channel + TEAMS - 1 ) / TEAMS ) * p.num_channels;   // a block = a group of TEAMS chains of one channel
 	FLANHIP_REQUIRE( blocks < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
 	hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( 128 * TEAMS ), lds, s, p, tb );
 	FLANHIP_CHECK( hipGetLastError() );
@@ -280,8 +278,7 @@ static int run_synth_fast_hop( const SynthParams & p, const FastTables & tb, hip
 static bool synth_fast_ok( int dft, int W, int hop ) { return synth_fast_kind( dft, W, hop ) != 0; }
 
 // Chains per group of the kernels that pass group totals from analysis to synthesis (no scan kernel between the two): 8 for the dft 2048
-// pair (a block = 8 one-wavefront chains of a channel), 4 for the dft 4096 team kernels (4 teams per block) -- there only when the chains
-// of a channel fill whole blocks; 0: no group totals for this shape.
+// pair (a block = 8 one-wavefront chains of a channel), 4 for the dft 4096 team kernels (4 teams per block); 0: no group totals for this shape.
 // The carry prologue of group g reads g totals per bin, so it only pays while a channel has few groups: measured on 60 s per 8 channels'
 // worth of frames it beats the scan kernel from 8 channels up (32 groups per channel) and loses below (4 channels, 64 groups: -3 % dft 2048,
 // -4 % dft 4096; tools/ab_step.py --pairs 0:0,0:2 --channels ...).
@@ -291,8 +288,7 @@ static int self_carry_group( int dft, int W, int hop, int chains_per_channel )
 	if( synth_fast_kind( dft, W, hop ) != 1 ) return 0;
 	int g = 0;
 	if( dft == 2048 ) g = 8;
-	else if( dft == 4096 && W <= 2048 && W % 256 == 0 && ( hop == 128 || hop % 256 == 0 ) && chains_per_channel % 4 == 0
-		&& g_syn11_variant != 0 && g_ana11_variant == 1 ) g = 4;
+	else if( dft == 4096 && W <= 2048 && W % 256 == 0 && ( hop == 128 || hop % 256 == 0 ) && g_syn11_variant != 0 && g_ana11_variant != 0 ) g = 4;
 	if( g && ( chains_per_channel + g - 1 ) / g > kSelfCarryMaxGroups ) g = 0;
 	return g;
 	}

@@ -112,9 +112,13 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 	const v4f_t * s_twq = reinterpret_cast<const v4f_t*>( s + L::TWQ ) + lane + 256 * role;   // this wavefront's quads: k = lane + 64 ( 4 role + q )
 	const v4f_t * s_win = reinterpret_cast<const v4f_t*>( s + L::WIN ) + lane;
 
-	const int64_t chain_raw = int64_t( blockIdx.x ) * TEAMS + team;
-	const bool active = chain_raw < int64_t( p.chains_per_channel ) * p.num_channels && !cancel_seen( cancel_peek( p.cancel ) );   // (cancelled: core.hip; every team still walks its iterations and meets)
-	const int64_t chain = active ? chain_raw : 0;
+	// a block is a GROUP: TEAMS consecutive chains of ONE channel (the last group of a channel may be short: its spare teams idle -- they still
+	// walk their iterations and meet)
+	const int gpc = ( p.chains_per_channel + TEAMS - 1 ) / TEAMS;
+	const int gchannel = int( blockIdx.x ) / gpc, group = int( blockIdx.x ) % gpc;
+	const int chain_in_channel_raw = group * TEAMS + team;
+	const bool active = chain_in_channel_raw < p.chains_per_channel && !cancel_seen( cancel_peek( p.cancel ) );   // (cancelled: core.hip)
+	const int64_t chain = active ? int64_t( gchannel ) * p.chains_per_channel + chain_in_channel_raw : 0;
 	const int channel = int( chain / p.chains_per_channel );
 	const int64_t t0 = int64_t( chain % p.chains_per_channel ) * p.L;
 	const int64_t t1 = min( t0 + int64_t( p.L ), p.F );
@@ -404,18 +408,15 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 			{
 			if( p.group_sums )
 				{
-				// The host hands group_sums only when chains_per_channel is a multiple of TEAMS: a block is then a GROUP of TEAMS consecutive chains of
-				// one channel, and one total per group lets the synthesis kernel work out its own carries (k_analyze_v2 does the same with its
-				// groups of 8; no scan kernel between the two).
+				// one total per group lets the synthesis kernel work out its own carries (k_analyze_v2 does the same with its groups of 8; no scan
+				// kernel between the two)
 				__syncthreads();
-				const int gpc = p.chains_per_channel / TEAMS;
-				const int gchannel = int( blockIdx.x ) / gpc, group = int( blockIdx.x ) % gpc;
+				const int live = min( TEAMS, p.chains_per_channel - group * TEAMS );      // teams of this group that walked a chain
 				double * gdst = p.group_sums + ( int64_t( gchannel ) * gpc + group ) * ( N2 + 1 );
 				for( int bin = tid; bin <= N2; bin += NT )
 					{
 					double run = 0.0;
-					#pragma unroll
-					for( int w = 0; w < TEAMS; ++w )
+					for( int w = 0; w < live; ++w )
 						{
 						const double v = run + reinterpret_cast<const double*>( s + L::BUF + w * 4 * L::BUF_LEN + 1090 )[bin];
 						run = ( __builtin_fabs( v ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( v ) : fold_phase_any( v );
@@ -470,9 +471,12 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 	const v4f_t * s_twq = reinterpret_cast<const v4f_t*>( s + L::TWQ ) + lane + 256 * role;
 	const v4f_t * s_win = reinterpret_cast<const v4f_t*>( s + L::WIN ) + lane;
 
-	const int64_t chain_raw = int64_t( blockIdx.x ) * TEAMS + team;
-	const bool active = chain_raw < int64_t( p.chains_per_channel ) * p.num_channels && !cancel_seen( cancel_peek( p.cancel ) );   // (cancelled: core.hip; every team still walks its iterations and meets)
-	const int64_t chain = active ? chain_raw : 0;
+	// a block is a GROUP of TEAMS consecutive chains of one channel (see k_analyze_eo_team); spare teams of a channel's last group idle
+	const int gpc = ( p.chains_per_channel + TEAMS - 1 ) / TEAMS;
+	const int gchannel = int( blockIdx.x ) / gpc, group = int( blockIdx.x ) % gpc;
+	const int chain_in_channel_raw = group * TEAMS + team;
+	const bool active = chain_in_channel_raw < p.chains_per_channel && !cancel_seen( cancel_peek( p.cancel ) );   // (cancelled: core.hip; every team still walks its iterations and meets)
+	const int64_t chain = active ? int64_t( gchannel ) * p.chains_per_channel + chain_in_channel_raw : 0;
 	const int channel = int( chain / p.chains_per_channel );
 	const int chain_in_channel = int( chain % p.chains_per_channel );
 	const int64_t t0 = int64_t( chain_in_channel ) * p.L;
@@ -667,14 +671,12 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 	if( frames > 0 ) load_row( t0 );
 	if( p.group_sums )
 		{
-		// No scan kernel ran: `carry` still holds the chains' own sums, group_sums the totals of every group of TEAMS chains (the host hands it only
-		// when chains_per_channel is a multiple of TEAMS: a block is then one group of one channel).  The running phase on entry to a chain = the
+		// No scan kernel ran: `carry` still holds the chains' own sums, group_sums the totals of every group of TEAMS chains.  The running phase on entry to a chain = the
 		// groups before this one, then the chains of this group before it, added and folded in order -- as in k_synthesize_v2, whose words
 		// these are: one thread per bin, four or five bins side by side, loads in batches ahead of the dependent additions; every team's carries
 		// land in the team's SECOND buffer set, which nobody writes before the first meeting.
 		auto fold = []( double r ) { return ( __builtin_fabs( r ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_loop( r ) : fold_phase_any( r ); };
-		const int gpc = p.chains_per_channel / TEAMS;
-		const int gchannel = int( blockIdx.x ) / gpc, group = int( blockIdx.x ) % gpc;
+		const int live = min( TEAMS, p.chains_per_channel - group * TEAMS );
 		const double * gs = p.group_sums + int64_t( gchannel ) * gpc * ( N2 + 1 );
 		const double * sums0 = p.carry + ( int64_t( gchannel ) * p.chains_per_channel + int64_t( group ) * TEAMS ) * ( N2 + 1 );
 		constexpr int NB = ( N2 + NT ) / NT;                                       // bins per thread: 5 for 512 threads (the fifth only for thread 0)
@@ -687,7 +689,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 		for( int b = 0; b < NB; ++b )
 			{
 			#pragma unroll
-			for( int w = 0; w < TEAMS; ++w ) vc[b][w] = sums0[int64_t( w ) * ( N2 + 1 ) + bins_of[b]];
+			for( int w = 0; w < TEAMS; ++w ) vc[b][w] = ( w < live ) ? sums0[int64_t( w ) * ( N2 + 1 ) + bins_of[b]] : 0.0;
 			}
 		for( int g0 = 0; g0 < group; g0 += BATCH )
 			{

@@ -277,6 +277,50 @@ def test_fused_round_trip_equals_unfused(fa):
         assert res[0][2] == res[1][2] == 0
 
 
+@pytest.mark.parametrize("dft,hop,ch,n", [(2048, 512, 8, 300000), (4096, 512, 8, 300000), (4096, 128, 8, 100000), (4096, 1024, 8, 700000), (2048, 512, 3, 900000)])
+def test_carry_prologue_equals_scan_kernel(fa, dft, hop, ch, n):
+    """Fused round trip: the synthesis kernels that work out their own carries from the analysis' group totals (dft 2048: groups of 8 chains;
+    dft 4096 team kernels: groups of 4, the last group of a channel short) against the same launch with the scan kernel in front (synthesis
+    variant 2), 19-30 groups per channel (the last shape has 55: both runs take the scan kernel there): the same prefix sums associated
+    group-wise -- audio bit for bit, NaN flag clear."""
+    import ctypes
+    lib = fa.lib
+    sr, W = 48000.0, 2048
+    x = O.noise(ch, n, seed=dft + hop)
+    F = O.num_pv_frames(n, hop)
+    bins = dft // 2 + 1
+    ar = np.float32(sr) / np.float32(hop)
+
+    def dev_alloc(nbytes):
+        p = ctypes.c_void_p()
+        fa.check(lib.flanhip_malloc(ctypes.byref(p), nbytes))
+        return p
+    d_x = dev_alloc(x.nbytes)
+    fa.check(lib.flanhip_memcpy_h2d(d_x, x.ctypes.data_as(ctypes.c_void_p), x.nbytes, None))
+    ws_bytes = lib.flanhip_synthesize_workspace_bytes(ch, F, bins, sr, ar, W)
+    outs = {}
+    try:
+        for variant in (0, 2):
+            lib.flanhip_debug_kernel_variant(1, variant)
+            d_pv, d_out, d_ws, d_flag = dev_alloc(ch * F * bins * 8), dev_alloc(ch * F * hop * 4), dev_alloc(ws_bytes), dev_alloc(4)
+            fa.check(lib.flanhip_memset(d_flag, 0, 4, None))
+            fa.check(lib.flanhip_analyze_dev_fused(d_x, ch, n, sr, W, hop, dft, d_pv, d_ws, None))
+            fa.check(lib.flanhip_synthesize_dev_fused(d_pv, ch, F, bins, sr, ar, W, d_out, d_ws, d_flag, None))
+            out = np.empty((ch, F * hop), np.float32); flag = np.zeros(1, np.int32)
+            fa.check(lib.flanhip_memcpy_d2h(out.ctypes.data_as(ctypes.c_void_p), d_out, out.nbytes, None))
+            fa.check(lib.flanhip_memcpy_d2h(flag.ctypes.data_as(ctypes.c_void_p), d_flag, 4, None))
+            fa.check(lib.flanhip_stream_synchronize(None))
+            outs[variant] = (out, int(flag[0]))
+            for p in (d_pv, d_out, d_ws, d_flag):
+                lib.flanhip_free(p)
+    finally:
+        lib.flanhip_debug_kernel_variant(1, 0)
+        lib.flanhip_free(d_x)
+    assert outs[0][1] == 0 and outs[2][1] == 0
+    assert np.array_equal(outs[0][0].view(np.uint32), outs[2][0].view(np.uint32))
+    assert np.abs(outs[0][0]).max() > 0.1
+
+
 def _random_shapes(count, seed):
     """seeded shapes across every kernel variant: tuned dft 2048 / 4096 with hops that do / do not suit the register overlap-add,
     generic dft 32 ... 8192, windows shorter than the dft, odd windows and hops, hops beyond the window, inputs shorter than a window"""
