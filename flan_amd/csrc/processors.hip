@@ -232,16 +232,16 @@ __global__ __launch_bounds__( 256 ) void k_modify_time_chains( TimeChainParams p
 // PV::stretch, PVModify.cpp:376-382: inclusive running sum over frames per bin in fp32 (sequential order = the
 // reference's rounding), then frame_to_time; also the maximum of the result (FunctionSample::maximum, :312).
 // A block owns 64 bins (column_scan, processors_common.h).
-constexpr int kMapTB = 16, kMapTF = 896;                                           // k_stretch_map tile: 16 bins x 896 frames (61 KB of LDS)
-__global__ __launch_bounds__( 256 ) void k_stretch_map( float * factor, int64_t F, int bins, float sr, float hop, float * d_max )
+constexpr int kMapTB = 16, kMapTF = 224, kMapThreads = 512;                        // k_stretch_map tile: 16 bins x 224 frames, three of them in flight (44 KB of LDS); one scanning and seven moving waves (fifteen: no faster)
+__global__ __launch_bounds__( kMapThreads ) void k_stretch_map( float * factor, int64_t F, int bins, float sr, float hop, float * d_max )
 	{
-	__shared__ __attribute__(( aligned( 16 ) )) float lds[column_scan_lds_floats( kMapTF, kMapTB, 1 )];
+	__shared__ __attribute__(( aligned( 16 ) )) float lds[3 * column_scan_lds_floats( kMapTF, kMapTB, 1 )];
 	const int strip = xcd_contiguous_strip( blockIdx.x, ( bins + kMapTB - 1 ) / kMapTB );
 	if( strip < 0 ) return;
 	const int bin = strip * kMapTB + threadIdx.x % kMapTB;
 	const bool valid = bin < bins;
 	float run = -0.0f, mx = -INFINITY;                                             // -0 + x == x for every x: frame 0 needs no special case
-	column_scan<kMapTF, kMapTB, 1, 1, false>( lds, F,
+	column_scan_piped<kMapTF, kMapTB, 1, 1, false, kMapThreads>( lds, F,
 		[&]( int64_t f, float ( &v )[1] ) { if( valid ) v[0] = factor[f * bins + bin]; },
 		[&]( int64_t f, float ( &v )[1] ) { run = v[0] + run; v[0] = run; },                             // factor[frame] += factor[frame-1]
 		[&]( int64_t f, float ( &v )[1] )
@@ -253,12 +253,12 @@ __global__ __launch_bounds__( 256 ) void k_stretch_map( float * factor, int64_t 
 			} );
 	// the block's maximum: over the lanes of each wave, then over the 4 waves through LDS, then into *d_max
 	for( int o = 32; o > 0; o >>= 1 ) mx = fmaxf( mx, __shfl_xor( mx, o ) );
-	__shared__ float wmax[4];
+	__shared__ float wmax[kMapThreads / 64];
 	if( ( threadIdx.x & 63 ) == 0 ) wmax[threadIdx.x >> 6] = mx;
 	__syncthreads();
 	if( threadIdx.x == 0 )
 		{
-		mx = fmaxf( fmaxf( wmax[0], wmax[1] ), fmaxf( wmax[2], wmax[3] ) );
+		for( int w = 1; w < kMapThreads / 64; ++w ) mx = fmaxf( mx, wmax[w] );      // (thread 0's own mx is wmax[0])
 		if( d_max && mx > -INFINITY )
 			{
 			int * addr = reinterpret_cast<int*>( d_max );
@@ -663,7 +663,7 @@ int flanhip_stretch_map_dev( float * d_factor, int64_t F, int bins, float sr, in
 		const float ninf = -INFINITY;
 		FLANHIP_CHECK( hipMemcpyAsync( d_max, &ninf, sizeof( float ), hipMemcpyHostToDevice, s ) );
 		}
-	hipLaunchKernelGGL( k_stretch_map, dim3( xcd_grid( ( bins + kMapTB - 1 ) / kMapTB ) ), dim3( 256 ), 0, s, d_factor, F, bins, sr, float( hop ), d_max );
+	hipLaunchKernelGGL( k_stretch_map, dim3( xcd_grid( ( bins + kMapTB - 1 ) / kMapTB ) ), dim3( kMapThreads ), 0, s, d_factor, F, bins, sr, float( hop ), d_max );
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;
 	}

@@ -183,6 +183,109 @@ __device__ __forceinline__ void column_scan( float * lds, int64_t F, Load load, 
 		}
 	}
 
+// The same scan as a three-stage pipeline over tiles, for kernels whose time is the sum of column_scan's three phases rather than any one of
+// them (k_stretch_map: a running sum down 5 626 frames with 16 columns per block -- the scan itself is ~2 us per tile, moving the tile in and
+// out ~2.5 us each, one after the other).  Wave 0 only scans; the other waves of the block (THREADS - 64 threads) only move.  While tile k is scanned in buffer k % 3, the movers write
+// tile k - 1 back from ( k - 1 ) % 3, put the prefetched tile k + 1 into ( k + 1 ) % 3 and request tile k + 2 from memory: one barrier per
+// tile, and a tile's three phases overlap with its neighbours'.  lds: 3 * column_scan_lds_floats( TFr, TBc, max( NIN, NOUT ) ) floats.
+template<int TFr, int TBc, int NIN, int NOUT, bool REVERSE, int THREADS, class Load, class Step, class Store>
+__device__ __forceinline__ void column_scan_piped( float * lds, int64_t F, Load load, Step step, Store store )
+	{
+	constexpr int NT = NIN > NOUT ? NIN : NOUT, MOVERS = THREADS - 64, NY = MOVERS / TBc, RP = TFr / NY, CH = 32;
+	static_assert( TFr % CH == 0 && MOVERS % TBc == 0 && TFr % NY == 0 && TBc <= 64 && 64 % TBc == 0, "tile shape" );
+	constexpr int TILE = NT * TBc * ( TFr + 4 );
+	auto T = [&]( int buf, int a, int r, int c ) -> float & { return lds[buf * TILE + ( a * TBc + c ) * ( TFr + 4 ) + r]; };
+	const bool mover = threadIdx.x >= 64;
+	const int tx = threadIdx.x % TBc, ty = mover ? ( int( threadIdx.x ) - 64 ) / TBc : 0;
+	const int64_t tiles = ( F + TFr - 1 ) / TFr;
+	auto tile_of = [&]( int64_t k ) { return REVERSE ? tiles - 1 - k : k; };
+	float pre[NIN][RP];
+	auto load_regs = [&]( int64_t tile_i )
+		{
+		#pragma unroll
+		for( int i = 0; i < RP; ++i )
+			{
+			const int64_t f = tile_i * TFr + ty + NY * i;
+			float v[NIN];
+			#pragma unroll
+			for( int a = 0; a < NIN; ++a ) v[a] = 0.0f;
+			if( f < F ) load( f, v );
+			#pragma unroll
+			for( int a = 0; a < NIN; ++a ) pre[a][i] = v[a];
+			}
+		};
+	auto regs_to_lds = [&]( int buf )
+		{
+		#pragma unroll
+		for( int a = 0; a < NIN; ++a )
+			#pragma unroll
+			for( int i = 0; i < RP; ++i ) T( buf, a, ty + NY * i, tx ) = pre[a][i];
+		};
+	auto write_back = [&]( int buf, int64_t tile_i )
+		{
+		#pragma unroll
+		for( int i = 0; i < RP; ++i )
+			{
+			const int64_t f = tile_i * TFr + ty + NY * i;
+			if( f < F )
+				{
+				float v[NOUT];
+				#pragma unroll
+				for( int a = 0; a < NOUT; ++a ) v[a] = T( buf, a, ty + NY * i, tx );
+				store( f, v );
+				}
+			}
+		};
+	auto scan = [&]( int buf, int64_t tile_i )
+		{
+		const int64_t fbase = tile_i * TFr;
+		#pragma unroll 1
+		for( int c0 = 0; c0 < TFr; c0 += CH )
+			{
+			const int base = REVERSE ? TFr - CH - c0 : c0;
+			float col[NT][CH];
+			#pragma unroll
+			for( int a = 0; a < NIN; ++a )
+				#pragma unroll
+				for( int j = 0; j < CH; ++j ) col[a][j] = T( buf, a, base + j, tx );
+			#pragma unroll
+			for( int jj = 0; jj < CH; ++jj )
+				{
+				const int j = REVERSE ? CH - 1 - jj : jj;
+				float v[NT];
+				#pragma unroll
+				for( int a = 0; a < NIN; ++a ) v[a] = col[a][j];
+				step( fbase + base + j, v );
+				#pragma unroll
+				for( int a = 0; a < NOUT; ++a ) col[a][j] = v[a];
+				}
+			#pragma unroll
+			for( int a = 0; a < NOUT; ++a )
+				#pragma unroll
+				for( int j = 0; j < CH; ++j ) T( buf, a, base + j, tx ) = col[a][j];
+			}
+		};
+	if( tiles <= 0 ) return;
+	if( mover ) { load_regs( tile_of( 0 ) ); regs_to_lds( 0 ); if( tiles > 1 ) load_regs( tile_of( 1 ) ); }
+	__syncthreads();
+	for( int64_t k = 0; k < tiles; ++k )
+		{
+		const int b = int( k % 3 );
+		if( mover )
+			{
+			if( k >= 1 ) write_back( ( b + 2 ) % 3, tile_of( k - 1 ) );
+			if( k + 1 < tiles )
+				{
+				regs_to_lds( ( b + 1 ) % 3 );
+				if( k + 2 < tiles ) load_regs( tile_of( k + 2 ) );
+				}
+			}
+		else if( threadIdx.x < TBc ) scan( b, tile_of( k ) );
+		__syncthreads();
+		}
+	if( mover ) write_back( int( ( tiles - 1 ) % 3 ), tile_of( tiles - 1 ) );
+	}
+
 struct DevBuf
 	{
 	void * p = nullptr;
