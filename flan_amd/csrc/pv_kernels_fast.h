@@ -317,23 +317,27 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 				split_bin( z, q0 + i, z0, r, m );
 				re[i] = r; im[i] = m; pv[i] = prev[q0 + i]; binf[i] = bin_frequency( q0 + i );
 				}
-			// phase_vocoder.cpp:37-52 (AudioPV.cpp:69-73)
-			const VB phase = atan2_fast_v( im, re );
+			// phase_vocoder.cpp:37-52 (AudioPV.cpp:69-73); the dft 2048 kernels' per-bin code (pv_math.h: polar_v shares the reciprocal between
+			// atan2 and the magnitude; run-time constants as scalar operands)
+			VB phase, m;
+			polar_v( re, im, phase, m );
 			const VB phase_diff = phase - pv;                                    // == float( double(phase) - double(prev) ), :44
-			const VB delta_phase = phase_diff - div_c_v( binf, p.ar_div ) * vsplat<VB>( FLANHIP_PI2_F );       // :47-48
+			const VB delta_phase = phase_diff - div_c_each( binf, p.ar_div ) * vsplat<VB>( FLANHIP_PI2_F );    // :47-48
 			VB wrapped = delta_phase;
-			if( use_wrapping ) wrapped = delta_phase - vsplat<VB>( FLANHIP_PI2_F ) * round_v( div_pi2_v( delta_phase ) );   // :39-42,49
-			const VB f = binf + div_pi2_v( wrapped * vsplat<VB>( p.analysis_rate ) );                          // :50-52
-			const VB m = magnitude_scaled_v( re, im );
+			if( use_wrapping ) wrapped = delta_phase - vsplat<VB>( FLANHIP_PI2_F ) * round_half_away_v( div_pi2_v( delta_phase ) );   // :39-42,49
+			VB war;
+			#pragma unroll
+			for( int i = 0; i < NV; ++i ) war[i] = wrapped[i] * p.analysis_rate;
+			const VB f = binf + div_pi2_v( war );                               // :50-52
 			#pragma unroll
 			for( int i = 0; i < NV; ++i )
 				{
 				prev[q0 + i] = phase[i];                                         // :45
-				rowp[64 * ( q0 + i )] = cf{ m[i], f[i] };
+				__builtin_nontemporal_store( cf{ m[i], f[i] }, rowp + 64 * ( q0 + i ) );   // (written once, read by another kernel later: see k_analyze_v2)
 				}
 			if constexpr( SUMS )
 				{
-				const VB term = div_c_v( f, p.ar_div ) * vsplat<VB>( FLANHIP_PI2_F );                          // phase_vocoder.cpp:57-58
+				const VB term = div_c_each( f, p.ar_div ) * vsplat<VB>( FLANHIP_PI2_F );                       // phase_vocoder.cpp:57-58
 				#pragma unroll
 				for( int i = 0; i < NV; ++i )
 					{
@@ -475,20 +479,32 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 		cf z[E];
 		float mn;
 		bool slow = false;
+		// f / analysis_rate of the whole row under ONE test of the divisor's plan (see k_synthesize_v2)
+		float dv[E + 1];
+		if( p.ar_div.exact )
+			{
+			const float dc = p.ar_div.c, drc = p.ar_div.rc;
+			auto div_exact = [&]( float x ) { const float q0 = x * drc; return __builtin_fmaf( __builtin_fmaf( -q0, dc, x ), drc, q0 ); };   // pv_math.h: div_c
+			#pragma unroll
+			for( int q = 0; q < E; ++q ) dv[q] = div_exact( mfr[q].y );
+			dv[E] = div_exact( mfny.y );
+			}
+		else
+			{
+			#pragma unroll
+			for( int q = 0; q < E; ++q ) dv[q] = mfr[q].y / p.ar_div.c;
+			dv[E] = mfny.y / p.ar_div.c;
+			}
 		#pragma unroll
 		for( int q = 0; q < E; ++q )
 			{
-			const cf mf = mfr[q];                                           // ( m, f )
-			ph[q] += double( div_c( mf.y, p.ar_div ) * FLANHIP_PI2_F );          // phase_vocoder.cpp:57-58
+			ph[q] += double( dv[q] * FLANHIP_PI2_F );                            // phase_vocoder.cpp:57-58
 			slow |= !( __builtin_fabs( ph[q] ) < double( FLANHIP_SINCOS_FAST_LIMIT ) );
-			z[q].x = mf.x;
+			z[q].x = mfr[q].x;                                                   // m
 			}
-			{
-			const cf mf = mfny;
-			ph[E] += double( div_c( mf.y, p.ar_div ) * FLANHIP_PI2_F );
-			slow |= !( __builtin_fabs( ph[E] ) < double( FLANHIP_SINCOS_FAST_LIMIT ) );
-			mn = mf.x;
-			}
+		ph[E] += double( dv[E] * FLANHIP_PI2_F );
+		slow |= !( __builtin_fabs( ph[E] ) < double( FLANHIP_SINCOS_FAST_LIMIT ) );
+		mn = mfny.x;
 #ifndef FLANHIP_STATIC_EMIT
 		if( t + 1 < t1 ) load_row( t + 1, mfr, mfny );                          // prefetch: in flight during the transform below
 #else
@@ -519,7 +535,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 				#pragma unroll
 				for( int i = 0; i < 4; ++i )
 					{
-					ph[q0 + i] = fold_phase_fast( ph[q0 + i] );                 // phase_vocoder.cpp:59
+					ph[q0 + i] = fold_phase_loop( ph[q0 + i] );                 // phase_vocoder.cpp:59 (the four-instruction fold, pv_math.h)
 					th[i] = float( ph[q0 + i] );
 					m4[i] = z[q0 + i].x;
 					}
@@ -530,7 +546,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 				for( int i = 0; i < 4; ++i ) z[q0 + i] = cf{ xr[i], xi[i] };
 				__builtin_amdgcn_sched_barrier( 0 );                            // four bins at a time: keeps the temporaries of 16 bins from overlapping
 				}
-			ph[E] = fold_phase_fast( ph[E] );
+			ph[E] = fold_phase_loop( ph[E] );
 			float sn, cs;
 			sincos_fast( float( ph[E] ), sn, cs );
 			xn = mk( mn * cs, mn * sn );

@@ -324,4 +324,82 @@ __device__ __forceinline__ void sincos_fast( float x, float & s, float & c )
 	c = ( ( q + 1 ) & 2 ) ? -cc : cc;
 	}
 
+// roundf for every float (ties away from zero): trunc( x + copysign( prev( 0.5 ), x ) )
+template<class V> __device__ __forceinline__ V round_half_away_v( V x )
+	{
+	constexpr int N = vec_traits<V>::N;
+	V r;
+	#pragma unroll
+	for( int i = 0; i < N; ++i ) r[i] = __builtin_truncf( x[i] + __builtin_copysignf( 0x1.fffffep-2f, x[i] ) );
+	return r;
+	}
+__device__ __forceinline__ float round_half_away( float x ) { return __builtin_truncf( x + __builtin_copysignf( 0x1.fffffep-2f, x ) ); }
+
+// the arithmetic behind polar_v once |re|, |im|, their maximum and minimum are known.  CLAMPED: the divisor clamped to 2^-126 and
+// p2 = min( ( max 2^126 )^2, 1 ) in place of the 1 under the root (digital silence, see polar_v)
+template<bool CLAMPED, class V> __device__ __forceinline__ void polar_tail( V re, V im, V ax, V ay, V mxu, V mn, V & phase, V & mag )
+	{
+	constexpr int N = vec_traits<V>::N;
+	V mx = mxu;
+	if constexpr( CLAMPED ) mx = __builtin_elementwise_max( mxu, vsplat<V>( 0x1p-126f ) );
+	V r;
+	#pragma unroll
+	for( int i = 0; i < N; ++i ) r[i] = __builtin_amdgcn_rcpf( mx[i] );
+	const V q0 = mn * r;
+	const V q = vfma( vfma( -q0, mx, mn ), r, q0 );
+	const V u = q * q;
+	V h;
+	if constexpr( CLAMPED )
+		{
+		const V t = mxu * vsplat<V>( 0x1p126f );
+		h = vfma( q, q, __builtin_elementwise_min( t * t, vsplat<V>( 1.0f ) ) );
+		}
+	else h = vfma( q, q, vsplat<V>( 1.0f ) );
+	V p = vsplat<V>( 0x1.7ec8b6p-9f );
+	p = vfma( p, u, vsplat<V>( -0x1.0c272ap-6f ) );
+	p = vfma( p, u, vsplat<V>( 0x1.61f9a0p-5f ) );
+	p = vfma( p, u, vsplat<V>( -0x1.3554c4p-4f ) );
+	p = vfma( p, u, vsplat<V>( 0x1.b4e022p-4f ) );
+	p = vfma( p, u, vsplat<V>( -0x1.230ab4p-3f ) );
+	p = vfma( p, u, vsplat<V>( 0x1.9978eep-3f ) );
+	p = vfma( p, u, vsplat<V>( -0x1.5554dcp-2f ) );
+	V a = vfma( q * u, p, q );
+	const V a1 = vsplat<V>( FLANHIP_PIO2_F ) - a;
+	#pragma unroll
+	for( int i = 0; i < N; ++i ) a[i] = ay[i] > ax[i] ? a1[i] : a[i];
+	const V a2 = vsplat<V>( FLANHIP_PI_F ) - a;
+	#pragma unroll
+	for( int i = 0; i < N; ++i )
+		{
+		phase[i] = __builtin_copysignf( __float_as_int( re[i] ) < 0 ? a2[i] : a[i], im[i] );
+		mag[i] = mx[i] * __builtin_amdgcn_sqrtf( h[i] );
+		}
+	}
+
+// phase = atan2( im, re ) exactly as atan2_fast_v; mag = max( |re|, |im| ) * sqrt( 1 + q^2 ), q = min / max (correctly rounded).
+// The maximum is clamped to 2^-126 for the reciprocal; a spectrum component below that (a denormal, or zero) keeps its magnitude
+// through p2 = ( max 2^126 )^2 < 1 in place of the 1:  mag = 2^-126 sqrt( p2 + q^2 )  (for every other input p2 clamps to exactly 1).
+// Is any larger component below 2^-126 (zero or a denormal: digital silence)?  Decided per wavefront, and a BRANCH: for every other input
+// the clamp changes nothing and p2 is exactly 1, so the common path carries neither.  (Written as `if( silence ) mx = max( ... )` the
+// compiler turns the branch into a v_max and a v_cndmask per bin on the common path -- both half-rate instructions on gfx950,
+// profiles/r03_a_issue_model.txt; the asm statement in the rare arm is what keeps it a branch.)
+template<class V> __device__ __forceinline__ void polar_v( V re, V im, V & phase, V & mag )
+	{
+	constexpr int N = vec_traits<V>::N;
+	const V ax = __builtin_elementwise_abs( re ), ay = __builtin_elementwise_abs( im );
+	const V mxu = __builtin_elementwise_max( ax, ay );
+	const V mn = __builtin_elementwise_min( ax, ay );
+	float tiny = mxu[0];
+	#pragma unroll
+	for( int i = 1; i < N; ++i ) tiny = __builtin_fminf( tiny, mxu[i] );
+	if( __builtin_expect( __any( tiny < 0x1p-126f ), 0 ) )
+		{
+		asm volatile( "; digital silence" );
+		polar_tail<true>( re, im, ax, ay, mxu, mn, phase, mag );
+		asm volatile( "; end of the silence arm" );                               // (no tail shared with the common arm: merged tails cost it a register copy per bin)
+		}
+	else polar_tail<false>( re, im, ax, ay, mxu, mn, phase, mag );
+	}
+
+
 } // namespace flanhip
