@@ -65,7 +65,7 @@ __device__ __forceinline__ MF phase_vocode_bin( float re, float im, float & prev
 	const float phase_diff = float( double( phase ) - double( prev_phase ) );         // :44 (double subtraction, narrowed)
 	prev_phase = phase;                                                               // :45
 	const float delta_phase = phase_diff - expected_phase_diff;                       // :48
-	const float wrapped = use_wrapping ? delta_phase - FLANHIP_PI2_F * roundf( div_pi2( delta_phase ) ) : delta_phase; // :39-42,49
+	const float wrapped = use_wrapping ? delta_phase - FLANHIP_PI2_F * round_half_away( div_pi2( delta_phase ) ) : delta_phase; // :39-42,49 (roundf, exactly: pv_math.h)
 	const float delta_frequency = div_pi2( wrapped * analysis_rate );                 // :50
 	MF r;
 	r.m = magnitude_scaled( re, im );                                                 // std::abs
@@ -390,7 +390,7 @@ __global__ __launch_bounds__( 64 * WAVES * T ) void k_synthesize( SynthParams p 
 				// phases outside the range those are exact for (never for a real PV)
 				const double term = double( div_c( mf.f, p.ar_div ) * FLANHIP_PI2_F );
 				double phase = ( BIG ? s_ph[k] : ph[BIG ? 0 : q] ) + term;
-				phase = ( __builtin_fabs( phase ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( phase ) : fold_phase_any( phase );
+				phase = ( __builtin_fabs( phase ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_loop( phase ) : fold_phase_any( phase );   // (the four-instruction fold, pv_math.h)
 				if constexpr( BIG ) s_ph[k] = phase; else ph[BIG ? 0 : q] = phase;
 				const float th = float( phase );
 				float sn, cs;

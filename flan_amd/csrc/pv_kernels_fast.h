@@ -352,7 +352,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 			const float phase_diff = float( double( phase ) - double( prev[E] ) );
 			prev[E] = phase;
 			const float delta_phase = phase_diff - expected_advance( E );
-			const float wrapped = use_wrapping ? delta_phase - FLANHIP_PI2_F * roundf( div_pi2( delta_phase ) ) : delta_phase;
+			const float wrapped = use_wrapping ? delta_phase - FLANHIP_PI2_F * round_half_away( div_pi2( delta_phase ) ) : delta_phase;
 			const float delta_frequency = div_pi2( wrapped * p.analysis_rate );
 			const float f = bin_frequency( E ) + delta_frequency;
 			row[C] = mk( __builtin_fabsf( re ), f );   // every lane holds the same Nyquist value: an unconditional store keeps the
