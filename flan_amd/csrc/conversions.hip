@@ -149,12 +149,13 @@ static int run_analyze_v2_variant( int v, const AnalyzeParams & p, const FastTab
 	}
 
 // dft 4096 with window <= 2048 as two 1024-point register transforms per frame (pv_kernels_eo.h): teams of two wavefronts, 160 KB of LDS
-template<int TEAMS, bool SUMS, int QV, bool DOUBLE = false>
+template<int TEAMS, bool SUMS, int QV, bool DOUBLE = false, bool WBIG = false>
 static int run_analyze_eo_team( const AnalyzeParams & p, const FastTables & tb, hipStream_t s )
 	{
-	const size_t lds = EoLds::bytes( DOUBLE ? 2 * TEAMS : TEAMS );             // a team's two wavefronts share one E and one O buffer (or two of each)
-	static_assert( EoLds::bytes( DOUBLE ? 2 * TEAMS : TEAMS ) <= kMaxLds, "LDS budget" );
-	auto kern = k_analyze_eo_team<TEAMS, SUMS, QV, DOUBLE>;
+	using L = typename std::conditional<WBIG, EoLdsBig, EoLds>::type;
+	const size_t lds = L::bytes( DOUBLE ? 2 * TEAMS : TEAMS );                 // a team's two wavefronts share one E and one O buffer (or two of each)
+	static_assert( L::bytes( DOUBLE ? 2 * TEAMS : TEAMS ) <= kMaxLds, "LDS budget" );
+	auto kern = k_analyze_eo_team<TEAMS, SUMS, QV, DOUBLE, WBIG>;
 	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 	const int64_t blocks = int64_t( ( p.chains_per_channel + TEAMS - 1 ) / TEAMS ) * p.num_channels;   // a block = a group of TEAMS chains of one channel
 	FLANHIP_REQUIRE( blocks < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
@@ -217,12 +218,13 @@ static int run_synth_v2( const SynthParams & p, const FastTables & tb, hipStream
 	return FLANHIP_OK;
 	}
 
-template<int TEAMS, int HS>
+template<int TEAMS, int HS, bool WBIG = false>
 static int run_synth_eo_team( const SynthParams & p, const FastTables & tb, hipStream_t s )
 	{
-	const size_t lds = EoLds::bytes( 2 * TEAMS );                              // two A / B buffer sets per team
-	static_assert( EoLds::bytes( 2 * TEAMS ) <= kMaxLds, "LDS budget" );
-	auto kern = k_synthesize_eo_team<TEAMS, HS>;
+	using L = typename std::conditional<WBIG, EoLdsBig, EoLds>::type;
+	const size_t lds = L::bytes( WBIG ? TEAMS : 2 * TEAMS );                   // two A / B buffer sets per team (windows above 2048: one)
+	static_assert( L::bytes( WBIG ? TEAMS : 2 * TEAMS ) <= kMaxLds, "LDS budget" );
+	auto kern = k_synthesize_eo_team<TEAMS, HS, WBIG>;
 	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 	const int64_t blocks = int64_t( ( p.chains_per_channel + TEAMS - 1 ) / TEAMS ) * p.num_channels;   // a block = a group of TEAMS chains of one channel
 	FLANHIP_REQUIRE( blocks < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
@@ -261,6 +263,17 @@ static int run_synth_fast_hop( const SynthParams & p, const FastTables & tb, hip
 			case 1: return run_synth_eo_team<4, 1>( p, tb, s );
 			case 2: return run_synth_eo_team<4, 2>( p, tb, s );
 			case 4: return run_synth_eo_team<4, 4>( p, tb, s );
+			}
+		}
+	if( LOG2C == 11 && g_syn11_variant != 0 && p.window_size > 2048 && p.window_size % 256 == 0 && synth_fast_kind( 2 << LOG2C, p.window_size, p.hop ) == 1 )
+		{
+		// dft 4096 with windows above 2048 (window = dft is the plain STFT call): the same teams with full-length transforms, one buffer set
+		// (pv_kernels_eo.h: WBIG).  Hop 256 stays with the round-1 kernel: its accumulator shift and 16 accumulator pairs do not fit 256 registers
+		switch( p.hop )
+			{
+			case 128:  return run_synth_eo_team<4, 0, true>( p, tb, s );
+			case 512:  return run_synth_eo_team<4, 2, true>( p, tb, s );
+			case 1024: return run_synth_eo_team<4, 4, true>( p, tb, s );
 			}
 		}
 	if( synth_fast_kind( 2 << LOG2C, p.window_size, p.hop ) == 2 )                // any other hop <= window: ring accumulator in LDS
@@ -336,7 +349,11 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	p.ar_div = DivC{ dp.c, dp.rc, dp.exact };
 	p.sums = nullptr; p.nan_out = nullptr; p.nan_epoch = 0;
 	p.cancel = thread_cancel_word();                                              // kernels stop starting chains when the thread's wait raises it (core.hip)
-	const bool kernel_sums = !any;                                                // every FFT analysis kernel keeps the sums; the direct-sum kernel leaves them to the pre-pass kernel
+	// windows above 2048, plain convert_to_PV: the WBIG team kernel.  It has no registers for the fused round trip's chain sums, and the pre-pass
+	// kernel on its behalf costs more than it saves (0.147 + 0.107 ms against the round-1 kernel's 0.230 with sums, hop 1024): the fused call
+	// keeps the round-1 kernel
+	const bool team_big = fast && dft == 4096 && W > 2048 && g_ana11_variant != 0 && !d_fused_ws;
+	const bool kernel_sums = !any && !team_big;                                   // every other FFT analysis kernel keeps the sums; for the rest the pre-pass kernel runs on the analysis' behalf
 	SynthLayout fused_lay{};
 	if( d_fused_ws )
 		{
@@ -357,7 +374,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 		p.groups_per_channel = lay.groups_per_channel;
 		*left_group_sums = groups_too;
 		}
-	auto prepass_on_behalf = [&]() -> int                                         // for an analysis kernel that keeps no sums (none does at present)
+	auto prepass_on_behalf = [&]() -> int                                         // for an analysis kernel that keeps no sums
 		{
 		if( !d_fused_ws || kernel_sums ) return FLANHIP_OK;
 		SynthParams q{};
@@ -394,6 +411,12 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 			// teams of two wavefronts, two E / O buffer sets, one meeting per frame (0.27 ms for 8 ch x 60 s with the fused round trip's chain sums,
 			// 0.28 without; one set and two meetings: +7 %; the round-1 kernel: 0.44)
 			return p.sums ? run_analyze_eo_team<4, true, 2, true>( p, tb, s ) : run_analyze_eo_team<4, false, 2, true>( p, tb, s );
+			}
+		if( team_big )
+			{
+			// windows up to the whole transform: the same decomposition with full-length E / O inputs, one buffer set (pv_kernels_eo.h: WBIG)
+			if( int rc = run_analyze_eo_team<4, false, 2, false, true>( p, tb, s ) ) return rc;
+			return prepass_on_behalf();
 			}
 		return p.sums ? run_analyze_fast<11, kWaves11, true>( p, tb, s ) : run_analyze_fast<11, kWaves11, false>( p, tb, s );
 		}

@@ -31,6 +31,18 @@ struct EoLds
 	static constexpr int BUF_LEN = C + C / 16 + 1;         // one half transform; a wavefront has two
 	static constexpr size_t bytes( int waves ) { return size_t( BUF + waves * 2 * BUF_LEN ) * 8; }
 	};
+// the same with a window table of 4096 floats (windows above 2048: WBIG variants of the team kernels, one buffer set per team)
+struct EoLdsBig
+	{
+	static constexpr int C = 1024;
+	static constexpr int TW1 = 0;
+	static constexpr int TW3 = TW1 + 240;
+	static constexpr int TWQ = TW3 + 768;
+	static constexpr int WIN = TWQ + 1024;                 // [4096 floats], zero beyond W
+	static constexpr int BUF = WIN + 2048;
+	static constexpr int BUF_LEN = C + C / 16 + 1;
+	static constexpr size_t bytes( int waves ) { return size_t( BUF + waves * 2 * BUF_LEN ) * 8; }
+	};
 
 // the real-transform split of one mirror pair ( j, N - j ): X[j] and X[N-j] from Z[j] = zk, Z[N-j] = zm and w = 0.5 exp( -2 pi i j / 2N )
 __device__ __forceinline__ void split_pair( cf zk, cf zm, float wx, float wy, float & rk, float & ik, float & rm, float & im )
@@ -82,11 +94,16 @@ struct TeamSync
 		}
 	};
 
-template<int TEAMS, bool SUMS, int QV = 2, bool DOUBLE = false>   // DOUBLE: two E / O buffer sets per team, ONE barrier per frame
+// WBIG: windows up to 4096 (the whole transform): E and O inputs are no longer half zero -- 16 sample pairs per lane instead of 8, a 16 KB
+// window table, which leaves LDS for ONE buffer set (two meetings per frame) and no registers for the fused round trip's sums (the host runs
+// the pre-pass kernel on this kernel's behalf).
+template<int TEAMS, bool SUMS, int QV = 2, bool DOUBLE = false, bool WBIG = false>   // DOUBLE: two E / O buffer sets per team, ONE barrier per frame
 __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParams p, FastTables tb )
 	{
-	using L = EoLds;
+	using L = typename std::conditional<WBIG, EoLdsBig, EoLds>::type;
+	static_assert( !WBIG || ( !SUMS && !DOUBLE ), "windows above 2048: one buffer set, no chain sums" );
 	constexpr int C = 1024, N2 = 2048, Q = 4, NT = 128 * TEAMS;            // Q: quads per lane of ONE wavefront
+	constexpr int WQ = WBIG ? 16 : 8, WMAX = 256 * WQ;                       // sample pairs per lane of one wavefront's half frame; the window this kernel admits
 	typedef float VB __attribute__(( ext_vector_type( 4 * QV ) ));           // QV quads (4 bins each) as one vector stream
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	cf * s = reinterpret_cast<cf*>( smem );
@@ -101,7 +118,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 		v4f_t * twq = reinterpret_cast<v4f_t*>( s + L::TWQ );
 		for( int k = tid; k < 512; k += NT ) { const cf a = tb.w2[k], b = tb.w2[2 * k]; twq[k] = v4f_t{ 0.5f * a.x, 0.5f * a.y, b.x, b.y }; }
 		float * win = reinterpret_cast<float*>( s + L::WIN );
-		for( int i = tid; i < 2048; i += NT ) win[i] = ( i < W ) ? p.window[i] : 0.0f;            // AudioPV.cpp:60,65
+		for( int i = tid; i < WMAX; i += NT ) win[i] = ( i < W ) ? p.window[i] : 0.0f;            // AudioPV.cpp:60,65
 		}
 	cf * const buf0 = s + L::BUF + team * ( DOUBLE ? 4 : 2 ) * L::BUF_LEN;     // set b: E at buf0 + 2 b BUF_LEN, O behind it
 	TeamSync team_sync{ (lds_u32*) reinterpret_cast<unsigned*>( buf0 + 1087 ), 0u, lane };
@@ -152,11 +169,11 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 	const int64_t tfirst = t0 > 0 ? t0 - 1 : t0;
 	const int frames = active ? int( t1 - tfirst ) : 0;                       // iterations with work (the halo frame included)
 	const int iters = p.L + 1;                                                // what every team of every block walks
-	auto frame_inside = [&]( int64_t t ) { return W == 2048 && int64_t( hop ) * t - W / 2 >= 0 && int64_t( hop ) * t - W / 2 + 2048 <= p.n; };   // per frame (see k_analyze_v2)
+	auto frame_inside = [&]( int64_t t ) { return W == WMAX && int64_t( hop ) * t - W / 2 >= 0 && int64_t( hop ) * t - W / 2 + WMAX <= p.n; };   // per frame (see k_analyze_v2)
 	constexpr std::true_type inside{};
 	constexpr std::false_type outside{};
 
-	cf raw[2 * Q];                                                            // this wavefront's half of a frame: points lane + 64 q, q < 8, of its parity
+	cf raw[WQ];                                                               // this wavefront's half of a frame: points lane + 64 q, q < WQ, of its parity
 	auto run_chain = [&]()
 		{
 		struct __attribute__(( packed, aligned( 4 ) )) f2u { float x, y; };
@@ -166,7 +183,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 			const int start = int( int64_t( hop ) * t - W / 2 ) + 2 * role;
 			const float * xs = x + start + 4 * lane + 1024;                       // one address per lane: the eight loads reach -4096 .. +3072 bytes from it (immediates)
 			#pragma unroll
-			for( int q = 0; q < 2 * Q; ++q )
+			for( int q = 0; q < WQ; ++q )
 				{
 				const int a = start + 4 * ( lane + 64 * q );
 				if constexpr( FAST )
@@ -188,12 +205,13 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 			cf * mybuf = buf0 + ( 2 * set + role ) * L::BUF_LEN;
 			cf z[16];
 			#pragma unroll
-			for( int q = 0; q < 2 * Q; ++q )
+			for( int q = 0; q < WQ; ++q )
 				{
 				const v4f_t wv = s_win[64 * q];
 				z[q] = role ? mk( raw[q].x * wv.z, raw[q].y * wv.w ) : mk( raw[q].x * wv.x, raw[q].y * wv.y );
-				z[2 * Q + q] = mk( 0.0f, 0.0f );
 				}
+			#pragma unroll
+			for( int q = WQ; q < 16; ++q ) z[q] = mk( 0.0f, 0.0f );                  // (window at most half the transform: the first pass folds the zeros away)
 			fft_fast<10>( z, mybuf, s_tw1, s_tw3, lane );
 			#pragma unroll
 			for( int q = 0; q < 4 * Q; ++q ) mybuf[padl + 68 * q] = z[q];              // natural order: slot PAD( lane + 64 q )
@@ -442,11 +460,16 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 // Hop 128 (HS = 0; the reference API's default hop): a finished hop is HALF a 256-sample step -- the lower 32 lanes of acc[0] -- and the
 // accumulator moves on by 32 lanes: new acc[q] = { upper half of acc[q], lower half of acc[q+1] }, one v_permlane32_swap and one select
 // per register.
-template<int TEAMS, int HS>                                                  // HS = hop / 256; 0: hop 128
+// WBIG: windows up to 4096 -- all 1024 output points of each transform lie inside the window (16 accumulator pairs per lane instead of 8), the
+// window table is 16 KB, which leaves LDS for ONE A / B buffer set (two meetings per frame) and none for the carry prologue's stage (the scan
+// kernel runs in front).
+template<int TEAMS, int HS, bool WBIG = false>                               // HS = hop / 256; 0: hop 128
 __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthParams p, FastTables tb )
 	{
-	using L = EoLds;
+	using L = typename std::conditional<WBIG, EoLdsBig, EoLds>::type;
 	constexpr int C = 1024, N2 = 2048, Q = 4, NT = 128 * TEAMS, hop = HS ? 256 * HS : 128;
+	constexpr bool DOUBLE = !WBIG;
+	constexpr int WQ = WBIG ? 16 : 8, WMAX = 256 * WQ;                          // accumulator pairs per lane; the window this kernel admits
 	static_assert( HS == 0 || HS == 1 || HS == 2 || HS == 4, "hop 128 / 256 / 512 / 1024" );
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	cf * s = reinterpret_cast<cf*>( smem );
@@ -460,9 +483,9 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 		v4f_t * twq = reinterpret_cast<v4f_t*>( s + L::TWQ );
 		for( int k = tid; k < 512; k += NT ) { const cf a = tb.w2[k], b = tb.w2[2 * k]; twq[k] = v4f_t{ a.x, -a.y, b.x, b.y }; }
 		float * win = reinterpret_cast<float*>( s + L::WIN );
-		for( int i = tid; i < 2048; i += NT ) win[i] = ( i < W ) ? p.window[i] * p.window_scale : 0.0f;   // AudioPV.cpp:102
+		for( int i = tid; i < WMAX; i += NT ) win[i] = ( i < W ) ? p.window[i] * p.window_scale : 0.0f;   // AudioPV.cpp:102
 		}
-	cf * const buf0 = s + L::BUF + team * 4 * L::BUF_LEN;                       // set b: A at buf0 + 2 b BUF_LEN, B behind it
+	cf * const buf0 = s + L::BUF + team * ( DOUBLE ? 4 : 2 ) * L::BUF_LEN;      // set b: A at buf0 + 2 b BUF_LEN, B behind it
 	TeamSync team_sync{ (lds_u32*) reinterpret_cast<unsigned*>( buf0 + 1087 ), 0u, lane };
 	if( role == 0 && lane == 0 ) *team_sync.flag = 0u;
 	__syncthreads();
@@ -494,7 +517,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 
 	// running phases (AudioPV.cpp:105) on entry to the chain: [q][0..3] = bins k, 2048-k, 1024-k, 1024+k; the odd wavefront also 512, 1536
 	double ph[Q][4], phs[2] = { 0.0, 0.0 };
-	if( !p.group_sums )
+	if( !( DOUBLE && p.group_sums ) )
 		{
 		const double * carry = p.carry + chain * ( N2 + 1 );
 		#pragma unroll
@@ -505,9 +528,9 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 			}
 		if( role == 1 ) { phs[0] = carry[512]; phs[1] = carry[1536]; }
 		}
-	cf acc[2 * Q];                                                              // acc[q] <-> samples pos + 256 q + 4 lane + 2 role (+1)
+	cf acc[WQ];                                                                 // acc[q] <-> samples pos + 256 q + 4 lane + 2 role (+1)
 	#pragma unroll
-	for( int q = 0; q < 2 * Q; ++q ) acc[q] = mk( 0.0f, 0.0f );
+	for( int q = 0; q < WQ; ++q ) acc[q] = mk( 0.0f, 0.0f );
 
 	// one 256-sample step of finished (or partial) output: this wavefront's half of it.  One store per step, never inside a branch (lanes
 	// outside the output store into the dump area): a static number of stores behind the row request, a counted wait (see k_synthesize_v2)
@@ -669,7 +692,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 		};
 
 	if( frames > 0 ) load_row( t0 );
-	if( p.group_sums )
+	if( DOUBLE && p.group_sums )
 		{
 		// No scan kernel ran: `carry` still holds the chains' own sums, group_sums the totals of every group of TEAMS chains.  The running phase on entry to a chain = the
 		// groups before this one, then the chains of this group before it, added and folded in order -- as in k_synthesize_v2, whose words
@@ -734,7 +757,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 	const int iters = p.L;
 	for( int i = 0; i < iters; ++i )
 		{
-		const int set = i & 1;
+		const int set = DOUBLE ? ( i & 1 ) : 0;
 		if( i < frames )
 			{
 			const int64_t t = t0 + i;
@@ -745,9 +768,9 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 			for( int q = 0; q < 16; ++q ) z[q] = mybuf[padl + 68 * q];
 			wave_sync();
 			fft_fast<10>( z, const_cast<cf*>( mybuf ), s_tw1, s_tw3, lane );
-			// G = fft( A or B ): samples 4m (+2 for B) = G[m].x, 4m+1 (+2) = -G[m].y, m = lane + 64 q < 512; window, overlap-add (AudioPV.cpp:122-134)
+			// G = fft( A or B ): samples 4m (+2 for B) = G[m].x, 4m+1 (+2) = -G[m].y, m = lane + 64 q < 64 WQ; window, overlap-add (AudioPV.cpp:122-134)
 			#pragma unroll
-			for( int q = 0; q < 2 * Q; ++q )
+			for( int q = 0; q < WQ; ++q )
 				{
 				const v4f_t wv = s_win[64 * q];                                    // zero beyond W
 				acc[q].x += z[q].x * ( role ? wv.z : wv.x );
@@ -758,9 +781,9 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 				emit_half( pos, acc[0], 0 );
 				const bool low = lane < 32;
 				#pragma unroll
-				for( int q = 0; q < 2 * Q; ++q )
+				for( int q = 0; q < WQ; ++q )
 					{
-					const cf nxt = ( q + 1 < 2 * Q ) ? acc[q + 1] : mk( 0.0f, 0.0f );
+					const cf nxt = ( q + 1 < WQ ) ? acc[q + 1] : mk( 0.0f, 0.0f );
 					acc[q] = mk( rotate_half( acc[q].x, nxt.x, low ), rotate_half( acc[q].y, nxt.y, low ) );
 					}
 				}
@@ -779,12 +802,15 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 					for( int q = 0; q < HS; ++q ) emit_step( pos + 256 * q, acc[q] );
 					}
 				#pragma unroll
-				for( int q = 0; q < 2 * Q; ++q ) acc[q] = ( q + HS < 2 * Q ) ? acc[q + HS] : mk( 0.0f, 0.0f );
+				for( int q = 0; q < WQ; ++q ) acc[q] = ( q + HS < WQ ) ? acc[q + HS] : mk( 0.0f, 0.0f );
 				}
 			pos += hop;
-			if( i + 1 < frames ) bins_of_row( set ^ 1 );
 			}
-		team_sync.meet();                                                         // the next frame's A / B are written (into the other set)
+		// one buffer set: nobody may write the next frame's A / B before both wavefronts have transformed this one's (the transform uses its
+		// buffer as scratch).  Two sets: the next frame goes to the other set
+		if constexpr( !DOUBLE ) team_sync.meet();
+		if( i + 1 < frames ) bins_of_row( DOUBLE ? ( set ^ 1 ) : 0 );
+		team_sync.meet();                                                         // the next frame's A / B are written
 		}
 	if( !active ) return;
 	// flush the partial sums that the next chain's head completes; the last chain zero-fills to the end of the output
@@ -792,24 +818,24 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 	const int64_t flush_end = last_chain ? max( ring_end, p.out_len ) : ring_end;
 	if constexpr( HS == 0 )
 		{
-		// W - hop = 1920 samples = 7.5 steps: by halves (the next chain writes from ring_end on itself)
+		// W - hop = 1920 (3968) samples = 7.5 (15.5) steps: by halves (the next chain writes from ring_end on itself)
 		#pragma unroll
-		for( int h = 0; h < 4 * Q; ++h )
+		for( int h = 0; h < 2 * WQ; ++h )
 			{
 			const int64_t a0 = pos + 128 * h;
 			if( a0 < flush_end ) emit_half( a0, acc[h >> 1], h & 1 );
 			}
-		for( int64_t a0 = pos + 128 * 4 * Q; a0 < flush_end; a0 += 128 ) emit_half( a0, mk( 0.0f, 0.0f ), 0 );
+		for( int64_t a0 = pos + 128 * 2 * WQ; a0 < flush_end; a0 += 128 ) emit_half( a0, mk( 0.0f, 0.0f ), 0 );
 		}
 	else
 		{
 		#pragma unroll
-		for( int q = 0; q < 2 * Q; ++q )
+		for( int q = 0; q < WQ; ++q )
 			{
 			const int64_t a0 = pos + 256 * q;
 			if( a0 < flush_end ) emit_step( a0, acc[q] );
 			}
-		for( int64_t a0 = pos + 256 * 2 * Q; a0 < flush_end; a0 += 256 ) emit_step( a0, mk( 0.0f, 0.0f ) );
+		for( int64_t a0 = pos + 256 * WQ; a0 < flush_end; a0 += 256 ) emit_step( a0, mk( 0.0f, 0.0f ) );
 		}
 	}
 
