@@ -349,11 +349,9 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	p.ar_div = DivC{ dp.c, dp.rc, dp.exact };
 	p.sums = nullptr; p.nan_out = nullptr; p.nan_epoch = 0;
 	p.cancel = thread_cancel_word();                                              // kernels stop starting chains when the thread's wait raises it (core.hip)
-	// windows above 2048, plain convert_to_PV: the WBIG team kernel.  It has no registers for the fused round trip's chain sums, and the pre-pass
-	// kernel on its behalf costs more than it saves (0.147 + 0.107 ms against the round-1 kernel's 0.230 with sums, hop 1024): the fused call
-	// keeps the round-1 kernel
-	const bool team_big = fast && dft == 4096 && W > 2048 && g_ana11_variant != 0 && !d_fused_ws;
-	const bool kernel_sums = !any && !team_big;                                   // every other FFT analysis kernel keeps the sums; for the rest the pre-pass kernel runs on the analysis' behalf
+	// windows above 2048: the WBIG team kernels (pv_kernels_eo.h)
+	const bool team_big = fast && dft == 4096 && W > 2048 && g_ana11_variant != 0;
+	const bool kernel_sums = !any;                                   // every other FFT analysis kernel keeps the sums; for the rest the pre-pass kernel runs on the analysis' behalf
 	SynthLayout fused_lay{};
 	if( d_fused_ws )
 		{
@@ -374,7 +372,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 		p.groups_per_channel = lay.groups_per_channel;
 		*left_group_sums = groups_too;
 		}
-	auto prepass_on_behalf = [&]() -> int                                         // for an analysis kernel that keeps no sums
+	auto prepass_on_behalf = [&]() -> int                                         // for an analysis kernel that keeps no sums (none does at present)
 		{
 		if( !d_fused_ws || kernel_sums ) return FLANHIP_OK;
 		SynthParams q{};
@@ -415,8 +413,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 		if( team_big )
 			{
 			// windows up to the whole transform: the same decomposition with full-length E / O inputs, one buffer set (pv_kernels_eo.h: WBIG)
-			if( int rc = run_analyze_eo_team<4, false, 2, false, true>( p, tb, s ) ) return rc;
-			return prepass_on_behalf();
+			return p.sums ? run_analyze_eo_team<4, true, 2, false, true>( p, tb, s ) : run_analyze_eo_team<4, false, 2, false, true>( p, tb, s );
 			}
 		return p.sums ? run_analyze_fast<11, kWaves11, true>( p, tb, s ) : run_analyze_fast<11, kWaves11, false>( p, tb, s );
 		}

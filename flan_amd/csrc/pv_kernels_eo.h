@@ -95,13 +95,13 @@ struct TeamSync
 	};
 
 // WBIG: windows up to 4096 (the whole transform): E and O inputs are no longer half zero -- 16 sample pairs per lane instead of 8, a 16 KB
-// window table, which leaves LDS for ONE buffer set (two meetings per frame) and no registers for the fused round trip's sums (the host runs
-// the pre-pass kernel on this kernel's behalf).
+// window table, which leaves LDS for ONE buffer set (two meetings per frame).  With the fused round trip's sums the kernel sits at 256
+// VGPRs; what spills (48 bytes) spills inside the digital-silence arm of polar_v, not in the frame loop.
 template<int TEAMS, bool SUMS, int QV = 2, bool DOUBLE = false, bool WBIG = false>   // DOUBLE: two E / O buffer sets per team, ONE barrier per frame
 __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParams p, FastTables tb )
 	{
 	using L = typename std::conditional<WBIG, EoLdsBig, EoLds>::type;
-	static_assert( !WBIG || ( !SUMS && !DOUBLE ), "windows above 2048: one buffer set, no chain sums" );
+	static_assert( !WBIG || !DOUBLE, "windows above 2048: one buffer set" );
 	constexpr int C = 1024, N2 = 2048, Q = 4, NT = 128 * TEAMS;            // Q: quads per lane of ONE wavefront
 	constexpr int WQ = WBIG ? 16 : 8, WMAX = 256 * WQ;                       // sample pairs per lane of one wavefront's half frame; the window this kernel admits
 	typedef float VB __attribute__(( ext_vector_type( 4 * QV ) ));           // QV quads (4 bins each) as one vector stream
