@@ -268,10 +268,11 @@ static int run_synth_fast_hop( const SynthParams & p, const FastTables & tb, hip
 	if( LOG2C == 11 && g_syn11_variant != 0 && p.window_size > 2048 && p.window_size % 256 == 0 && synth_fast_kind( 2 << LOG2C, p.window_size, p.hop ) == 1 )
 		{
 		// dft 4096 with windows above 2048 (window = dft is the plain STFT call): the same teams with full-length transforms, one buffer set
-		// (pv_kernels_eo.h: WBIG).  Hop 256 stays with the round-1 kernel: its accumulator shift and 16 accumulator pairs do not fit 256 registers
+		// (pv_kernels_eo.h: WBIG)
 		switch( p.hop )
 			{
 			case 128:  return run_synth_eo_team<4, 0, true>( p, tb, s );
+			case 256:  return run_synth_eo_team<4, 1, true>( p, tb, s );
 			case 512:  return run_synth_eo_team<4, 2, true>( p, tb, s );
 			case 1024: return run_synth_eo_team<4, 4, true>( p, tb, s );
 			}

@@ -63,6 +63,7 @@ CASES = [
     ("dft4096_win4096_hop512", 1, 60000, 4096, 512, 4096, "noise"),
     ("dft4096_win4096_hop128", 1, 30000, 4096, 128, 4096, "noise"),
     ("dft4096_win3072_hop256", 1, 40000, 3072, 256, 4096, "noise"),
+    ("dft4096_win4096_hop256", 2, 50000, 4096, 256, 4096, "noise"),
     ("sine_dft4096_win4096", 1, 48000, 4096, 1024, 4096, "sine"),
     ("sine_dft4096_hop512", 1, 48000, 2048, 512, 4096, "sine"),
     ("ragged_len", 3, 12345, 2048, 512, 2048, "noise"),
