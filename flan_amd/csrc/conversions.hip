@@ -302,7 +302,7 @@ static int self_carry_group( int dft, int W, int hop, int chains_per_channel )
 	if( synth_fast_kind( dft, W, hop ) != 1 ) return 0;
 	int g = 0;
 	if( dft == 2048 ) g = 8;
-	else if( dft == 4096 && W <= 2048 && W % 256 == 0 && ( hop == 128 || hop % 256 == 0 ) && g_syn11_variant != 0 && g_ana11_variant != 0 ) g = 4;
+	else if( dft == 4096 && W % 256 == 0 && ( hop == 128 || hop % 256 == 0 ) && g_syn11_variant != 0 && g_ana11_variant != 0 ) g = 4;   // (windows above 2048: the WBIG variants)
 	if( g && ( chains_per_channel + g - 1 ) / g > kSelfCarryMaxGroups ) g = 0;
 	return g;
 	}

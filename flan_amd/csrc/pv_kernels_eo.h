@@ -76,6 +76,15 @@ typedef __attribute__(( address_space( 3 ) )) unsigned lds_u32;
 #ifndef FLANHIP_TEAM_SLEEP
 #define FLANHIP_TEAM_SLEEP 1
 #endif
+// A team's stage of 2049 doubles (chain sums on their way to a group total; carries on their way to the team's two wavefronts), in cf slots
+// relative to the team's first buffer.  Two buffer sets per team: analysis behind the sync word (slot 1087) and the dummy mirror slot, synthesis
+// in the second set.  One set (WBIG): from slot 0, stepping over the sync word -- bins from 1087 on sit two slots higher.
+template<bool ONE_SET> __device__ __forceinline__ int team_stage_slot( int bin, int base_two_sets )
+	{
+	if constexpr( ONE_SET ) return bin + ( bin >= 1087 ? 2 : 0 );
+	else return base_two_sets + bin;
+	}
+
 struct TeamSync
 	{
 	lds_u32 * flag; unsigned target; int lane;
@@ -390,9 +399,10 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 			bad |= !( __builtin_fabs( sq ) <= 1.7976931348623157e308 );              // a NaN / Inf frequency poisons its sum
 			return ( __builtin_fabs( sq ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( sq ) : fold_phase_any( sq );
 			};
-		// (with group totals wanted, see below: the sums also go to a stage behind the team's sync word -- slot 1087 -- and the dummy mirror slot:
-		// 2049 doubles of the team's four buffers, idle now that both wavefronts have passed the last meeting after their last read)
-		double * const stage = ( DOUBLE && p.group_sums ) ? reinterpret_cast<double*>( buf0 + 1090 ) : nullptr;
+		// (with group totals wanted, see below: the sums also go to a stage in the team's buffers -- team_stage_slot -- idle now that both
+		// wavefronts have passed the last meeting after their last read)
+		double * const stage = p.group_sums ? reinterpret_cast<double*>( buf0 ) : nullptr;
+		auto slot = [&]( int bin ) { return team_stage_slot<!DOUBLE>( bin, 1090 ); };
 		if( active )
 			{
 			double * dst = p.sums + chain * ( N2 + 1 );
@@ -405,15 +415,15 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 				if( k != 0 ) dst[C + k] = d;                                         // (k = 0: the quad's fourth bin is bin 1024 again)
 				if( stage )
 					{
-					stage[k] = a; stage[N2 - k] = b; stage[C - k] = c;
-					if( k != 0 ) stage[C + k] = d;
+					stage[slot( k )] = a; stage[slot( N2 - k )] = b; stage[slot( C - k )] = c;
+					if( k != 0 ) stage[slot( C + k )] = d;
 					}
 				}
 			if( role == 1 && lane == 0 )
 				{
 				const double a = fold( sm2[0] ), b = fold( sm2[1] );
 				dst[512] = a; dst[1536] = b;
-				if( stage ) { stage[512] = a; stage[1536] = b; }
+				if( stage ) { stage[slot( 512 )] = a; stage[slot( 1536 )] = b; }
 				}
 			}
 		const bool any_bad = __any( bad ) && active;
@@ -422,7 +432,6 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 			if( chain == 0 && role == 0 ) { p.nan_out[2] = p.nan_epoch; p.nan_out[4] = p.nan_epoch; }
 			if( any_bad ) p.nan_out[0] = p.nan_epoch;
 			}
-		if constexpr( DOUBLE )
 			{
 			if( p.group_sums )
 				{
@@ -436,7 +445,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 					double run = 0.0;
 					for( int w = 0; w < live; ++w )
 						{
-						const double v = run + reinterpret_cast<const double*>( s + L::BUF + w * 4 * L::BUF_LEN + 1090 )[bin];
+						const double v = run + reinterpret_cast<const double*>( s + L::BUF + w * ( DOUBLE ? 4 : 2 ) * L::BUF_LEN )[slot( bin )];
 						run = ( __builtin_fabs( v ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( v ) : fold_phase_any( v );
 						}
 					gdst[bin] = run;
@@ -461,8 +470,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 // accumulator moves on by 32 lanes: new acc[q] = { upper half of acc[q], lower half of acc[q+1] }, one v_permlane32_swap and one select
 // per register.
 // WBIG: windows up to 4096 -- all 1024 output points of each transform lie inside the window (16 accumulator pairs per lane instead of 8), the
-// window table is 16 KB, which leaves LDS for ONE A / B buffer set (two meetings per frame) and none for the carry prologue's stage (the scan
-// kernel runs in front).
+// window table is 16 KB, which leaves LDS for ONE A / B buffer set (two meetings per frame).
 template<int TEAMS, int HS, bool WBIG = false>                               // HS = hop / 256; 0: hop 128
 __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthParams p, FastTables tb )
 	{
@@ -517,7 +525,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 
 	// running phases (AudioPV.cpp:105) on entry to the chain: [q][0..3] = bins k, 2048-k, 1024-k, 1024+k; the odd wavefront also 512, 1536
 	double ph[Q][4], phs[2] = { 0.0, 0.0 };
-	if( !( DOUBLE && p.group_sums ) )
+	if( !p.group_sums )
 		{
 		const double * carry = p.carry + chain * ( N2 + 1 );
 		#pragma unroll
@@ -692,12 +700,13 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 		};
 
 	if( frames > 0 ) load_row( t0 );
-	if( DOUBLE && p.group_sums )
+	if( p.group_sums )
 		{
 		// No scan kernel ran: `carry` still holds the chains' own sums, group_sums the totals of every group of TEAMS chains.  The running phase on entry to a chain = the
 		// groups before this one, then the chains of this group before it, added and folded in order -- as in k_synthesize_v2, whose words
 		// these are: one thread per bin, four or five bins side by side, loads in batches ahead of the dependent additions; every team's carries
-		// land in the team's SECOND buffer set, which nobody writes before the first meeting.
+		// land in the team's SECOND buffer set, which nobody writes before the first meeting (one set: in the set itself, and the team meets once
+		// more before filling it).
 		auto fold = []( double r ) { return ( __builtin_fabs( r ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_loop( r ) : fold_phase_any( r ); };
 		const int live = min( TEAMS, p.chains_per_channel - group * TEAMS );
 		const double * gs = p.group_sums + int64_t( gchannel ) * gpc * ( N2 + 1 );
@@ -736,20 +745,23 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 			#pragma unroll
 			for( int b = 0; b < NB; ++b )
 				{
-				if( has[b] ) reinterpret_cast<double*>( s + L::BUF + ( 4 * w + 2 ) * L::BUF_LEN )[bins_of[b]] = run[b];   // phase_buffer on entry to chain w of the group
+				if( has[b] ) reinterpret_cast<double*>( s + L::BUF + w * ( DOUBLE ? 4 : 2 ) * L::BUF_LEN )[team_stage_slot<!DOUBLE>( bins_of[b], 2 * L::BUF_LEN )] = run[b];   // phase_buffer on entry to chain w of the group
 				run[b] = fold( run[b] + vc[b][w] );
 				}
 			}
 		if( tid == 0 && blockIdx.x == 0 && p.nan_in && p.nan_flag && p.nan_in[0] == p.nan_in[2] && p.nan_in[2] != 0 ) atomicOr( p.nan_flag, 1 );
 		__syncthreads();
-		const double * mine = reinterpret_cast<const double*>( buf0 + 2 * L::BUF_LEN );
+		const double * mine = reinterpret_cast<const double*>( buf0 );
+		auto slot = [&]( int bin ) { return team_stage_slot<!DOUBLE>( bin, 2 * L::BUF_LEN ); };
 		#pragma unroll
 		for( int q = 0; q < Q; ++q )
 			{
 			const int k = k0 + 64 * q;
-			ph[q][0] = mine[k]; ph[q][1] = mine[N2 - k]; ph[q][2] = mine[C - k]; ph[q][3] = mine[C + k];
+			ph[q][0] = mine[slot( k )]; ph[q][1] = mine[slot( N2 - k )]; ph[q][2] = mine[slot( C - k )]; ph[q][3] = mine[slot( C + k )];
 			}
-		if( role == 1 ) { phs[0] = mine[512]; phs[1] = mine[1536]; }
+		if( role == 1 ) { phs[0] = mine[slot( 512 )]; phs[1] = mine[slot( 1536 )]; }
+		// one buffer set: the stage IS the A / B buffers the first bins_of_row is about to fill -- both wavefronts read their carries first
+		if constexpr( !DOUBLE ) team_sync.meet();
 		}
 	int64_t pos = chain_start;
 	if( frames > 0 ) bins_of_row( 0 );

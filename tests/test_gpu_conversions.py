@@ -284,15 +284,16 @@ def test_fused_round_trip_equals_unfused(fa):
         assert res[0][2] == res[1][2] == 0
 
 
-@pytest.mark.parametrize("dft,hop,ch,n", [(2048, 512, 8, 300000), (4096, 512, 8, 300000), (4096, 128, 8, 100000), (4096, 1024, 8, 700000), (2048, 512, 3, 900000)])
-def test_carry_prologue_equals_scan_kernel(fa, dft, hop, ch, n):
+@pytest.mark.parametrize("dft,hop,ch,n,W", [(2048, 512, 8, 300000, 2048), (4096, 512, 8, 300000, 2048), (4096, 128, 8, 100000, 2048), (4096, 1024, 8, 700000, 2048),
+                                            (2048, 512, 3, 900000, 2048), (4096, 1024, 8, 700000, 4096), (4096, 512, 8, 300000, 3072)])
+def test_carry_prologue_equals_scan_kernel(fa, dft, hop, ch, n, W):
     """Fused round trip: the synthesis kernels that work out their own carries from the analysis' group totals (dft 2048: groups of 8 chains;
-    dft 4096 team kernels: groups of 4, the last group of a channel short) against the same launch with the scan kernel in front (synthesis
+    dft 4096 team kernels: groups of 4, the last group of a channel short; also their one-buffer-set variants for windows above 2048) against the same launch with the scan kernel in front (synthesis
     variant 2), 19-30 groups per channel (the last shape has 55: both runs take the scan kernel there): the same prefix sums associated
     group-wise -- audio bit for bit, NaN flag clear."""
     import ctypes
     lib = fa.lib
-    sr, W = 48000.0, 2048
+    sr = 48000.0
     x = O.noise(ch, n, seed=dft + hop)
     F = O.num_pv_frames(n, hop)
     bins = dft // 2 + 1
