@@ -65,6 +65,9 @@ CASES = [
     ("dft4096_win3072_hop256", 1, 40000, 3072, 256, 4096, "noise"),
     ("dft4096_win4096_hop256", 2, 50000, 4096, 256, 4096, "noise"),
     ("sine_dft4096_win4096", 1, 48000, 4096, 1024, 4096, "sine"),
+    ("dft4096_win4096_short", 2, 3000, 4096, 512, 4096, "noise"),
+    ("dft4096_win4096_one_frame", 1, 300, 4096, 1024, 4096, "noise"),
+    ("dft4096_win2304_hop128", 1, 20000, 2304, 128, 4096, "noise"),
     ("sine_dft4096_hop512", 1, 48000, 2048, 512, 4096, "sine"),
     ("ragged_len", 3, 12345, 2048, 512, 2048, "noise"),
     ("one_frame", 1, 100, 2048, 512, 2048, "noise"),
