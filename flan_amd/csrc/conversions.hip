@@ -107,6 +107,8 @@ static int fast_target_chains( int dft, bool synth )
 template<int WAVES, bool SUMS, int NV, int ABL = 0>
 static int run_analyze_v2( const AnalyzeParams & p, const FastTables & tb, hipStream_t s )
 	{
+	// 32-bit byte offsets from the block's first halo frame: ( WAVES L + 1 ) frames of hop samples / of 1025 MFs
+	FLANHIP_REQUIRE( ( int64_t( WAVES ) * p.L + 2 ) * std::max( int64_t( p.hop ) * 4, int64_t( 8200 ) ) < ( int64_t( 1 ) << 32 ), FLANHIP_ERR_UNSUPPORTED, "chain length x hop too large for the dft 2048 kernel" );
 	const size_t lds = V2Lds::bytes( WAVES );
 	static_assert( V2Lds::bytes( WAVES ) <= kMaxLds, "LDS budget" );
 	auto kern = k_analyze_v2<WAVES, SUMS, NV, ABL>;
@@ -207,6 +209,7 @@ static int run_synth_fast( const SynthParams & p, const FastTables & tb, hipStre
 template<int WAVES, int HOPQ, int ABL = 0>
 static int run_synth_v2( const SynthParams & p, const FastTables & tb, hipStream_t s )
 	{
+	FLANHIP_REQUIRE( ( int64_t( WAVES ) * p.L + 2 ) * 8200 < ( int64_t( 1 ) << 32 ), FLANHIP_ERR_UNSUPPORTED, "chain length too large for the dft 2048 kernel" );   // 32-bit byte offsets inside a block's frames
 	const size_t lds = V2LdsSyn::bytes( WAVES );
 	static_assert( V2LdsSyn::bytes( WAVES ) <= kMaxLds, "LDS budget" );
 	auto kern = k_synthesize_v2<WAVES, HOPQ, ABL>;
@@ -339,7 +342,9 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	p.window = plan->d_window; p.tw = plan->d_tw; p.tw2 = plan->d_tw2;
 	p.n = n; p.F = n / hop + 1;                                   // AudioPV.cpp:17
 	p.num_channels = int( ch ); p.window_size = W; p.hop = hop;
-	const bool fast = ( dft == 2048 || dft == 4096 ) && n >= 2 && n < ( int64_t( 1 ) << 31 ) - 8192 && !force_generic();
+	// (hop: the dft 2048 kernel addresses a block's samples by 32-bit byte offsets from the block's first frame -- up to 8 chains of <= ~512 frames,
+	// env overrides aside -- and the generic kernels serve the hops that would not fit: nothing anybody analyses with)
+	const bool fast = ( dft == 2048 || dft == 4096 ) && n >= 2 && n < ( int64_t( 1 ) << 31 ) - 8192 && hop <= 65536 && !force_generic();
 	int target_chains = any ? any_target_chains( dft / 2 + 1 ) : fast ? fast_target_chains( dft, false ) : generic_target_chains( dft );
 	p.L = choose_chain_length( ch, p.F, any ? 7 : 1, target_chains );
 	p.chains_per_channel = int( ( p.F + p.L - 1 ) / p.L );
