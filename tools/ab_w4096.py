@@ -1,3 +1,5 @@
+"""dft 4096 with window 4096: the round-1 kernels (variant 0) against the team kernels' WBIG variants (variant 1), interleaved in one process:
+plain analysis, fused analysis, fused round trip at hop 1024 and 512.   python tools/ab_w4096.py"""
 import ctypes, sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
