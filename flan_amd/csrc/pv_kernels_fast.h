@@ -693,15 +693,18 @@ __global__ __launch_bounds__( 256 ) void k_phase_sums2( SynthParams p )
 	}
 
 // Exclusive scan of the chain sums along each channel, per bin (modular addition is associative, so the scan is cut in
-// SEG segments: 32 bins x 8 segments per block; each thread sums its segment, the segment totals are scanned through LDS,
+// SEG segments: 512 / SEG bins x SEG segments per block; each thread sums its segment, the segment totals are scanned through LDS,
 // then each thread rewrites its segment as exclusive prefixes).  carry[c] = phase_buffer on entry to chain c.
+// SEG = 16 / 32 / 64 (32 / 16 / 8 bins per block), chosen by the host so that a segment has at most 32 chains where it can: few channels mean
+// many chains per channel (a stereo minute: 938), and a thread whose segment fits its registers makes ONE trip to memory per pass.
+template<int SEG>
 __global__ __launch_bounds__( 512 ) void k_phase_scan2( SynthParams p )
 	{
-	constexpr int SEG = 16;                                                    // 32 bins x 16 segments = 512 threads
-	__shared__ double totals[SEG][32];
-	const int lane_bin = threadIdx.x & 31, seg = threadIdx.x >> 5;
+	constexpr int BINS = 512 / SEG;
+	__shared__ double totals[SEG][BINS];
+	const int lane_bin = threadIdx.x % BINS, seg = threadIdx.x / BINS;
 	const int channel = blockIdx.y;
-	const int k = blockIdx.x * 32 + lane_bin;
+	const int k = blockIdx.x * BINS + lane_bin;
 	if( threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 )
 		{
 		if( p.nan_in && p.nan_flag && p.nan_in[0] == p.nan_in[2] && p.nan_in[2] != 0 ) atomicOr( p.nan_flag, 1 );
@@ -713,59 +716,66 @@ __global__ __launch_bounds__( 512 ) void k_phase_scan2( SynthParams p )
 	const int i0 = min( seg * seg_len, n ), i1 = min( i0 + seg_len, n );
 	const bool live = k < p.num_bins;
 	double * c = p.carry + int64_t( channel ) * n * p.num_bins + ( live ? k : 0 );
-	auto fold = []( double v ) { return ( __builtin_fabs( v ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( v ) : fold_phase_any( v ); };
-	// a segment of up to 16 chains (every launch with <= 256 chains per channel: the single-round cut) stays in registers
-	// between the two passes; longer segments are read again
-	constexpr int KEEP = 16;
+	// x + y folded like phase_vocoder.cpp:59.  The general fold (any magnitude, NaN) calls a routine, and a call inside unrolled code spills
+	// everything live; so the unrolled passes use the four-instruction fold (pv_math.h), exact below 3e9 rad, and only note whether any partial
+	// sum came within HALF that of its limit -- a thread that saw one (sums of a PV with wildly negative frequencies, NaN) redoes its segment with
+	// the general fold in a rolled loop.  (|offset + partial| stays below the limit when both stay below half of it.)
+	constexpr double HALF = 0.5 * FLANHIP_FOLD_FAST_LIMIT;
+	bool wild = false;
+	auto fold_quick = [&]( double v ) { wild |= !( __builtin_fabs( v ) < HALF ); return fold_phase_loop( v ); };
+	auto fold_any = []( double v ) { return ( __builtin_fabs( v ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_loop( v ) : fold_phase_any( v ); };
+	// The kernel is a handful of blocks waiting for memory: every chain sum a thread needs is requested before the first dependent addition.
+	// A segment of up to KEEP chains (any launch with <= 512 chains per channel) stays in registers between the two passes; longer segments
+	// (a stereo minute: 938 chains, 59 per segment) go in pieces of KEEP and are read a second time.
+	constexpr int KEEP = 32;
 	const bool keep = seg_len <= KEEP;
 	double held[KEEP];
 	double run = 0.0;
-	if( keep )
+	for( int i = i0; i < ( keep ? i0 + 1 : i1 ); i += KEEP )
 		{
 		#pragma unroll
-		for( int u = 0; u < KEEP; ++u ) held[u] = ( live && i0 + u < i1 ) ? c[int64_t( i0 + u ) * p.num_bins] : 0.0;
+		for( int u = 0; u < KEEP; ++u ) held[u] = ( live && i + u < i1 ) ? c[int64_t( i + u ) * p.num_bins] : 0.0;
 		#pragma unroll
-		for( int u = 0; u < KEEP; ++u ) run = fold( run + held[u] );           // + 0.0 past the end: fold( x ) of a folded x is x
+		for( int u = 0; u < KEEP; ++u ) run = fold_quick( run + held[u] );       // + 0.0 past the end: fold( x ) of a folded x is x
 		}
-	else
-		for( int i = i0; i < i1; i += 8 )
-			{
-			double v[8];
-			#pragma unroll
-			for( int u = 0; u < 8; ++u ) v[u] = ( live && i + u < i1 ) ? c[int64_t( i + u ) * p.num_bins] : 0.0;
-			#pragma unroll
-			for( int u = 0; u < 8; ++u ) run = fold( run + v[u] );
-			}
+	if( wild )
+		{
+		run = 0.0;
+		for( int i = i0; i < i1; ++i ) run = fold_any( run + ( live ? c[int64_t( i ) * p.num_bins] : 0.0 ) );
+		}
 	totals[seg][lane_bin] = run;
 	__syncthreads();
 	double offs = ( p.carry_in && live ) ? p.carry_in[int64_t( channel ) * p.num_bins + k] : 0.0;   // AudioPV.cpp:111 (0 for a whole PV)
-	for( int s2 = 0; s2 < seg; ++s2 ) offs = fold( offs + totals[s2][lane_bin] );
+	for( int s2 = 0; s2 < seg; ++s2 ) offs = fold_any( offs + totals[s2][lane_bin] );
 	run = offs;
 	if( p.total_only )
 		{
-		if( p.total_out && live && seg == SEG - 1 ) p.total_out[int64_t( channel ) * p.num_bins + k] = fold( offs + totals[seg][lane_bin] );
+		if( p.total_out && live && seg == SEG - 1 ) p.total_out[int64_t( channel ) * p.num_bins + k] = fold_any( offs + totals[seg][lane_bin] );
 		return;
 		}
-	if( keep )
+	wild |= !( __builtin_fabs( offs ) < HALF );
+	if( wild )
 		{
-		#pragma unroll
-		for( int u = 0; u < KEEP; ++u )
+		for( int i = i0; i < i1; ++i )
 			{
-			if( live && i0 + u < i1 ) c[int64_t( i0 + u ) * p.num_bins] = run;
-			run = fold( run + held[u] );
+			const double v = live ? c[int64_t( i ) * p.num_bins] : 0.0;
+			if( live ) c[int64_t( i ) * p.num_bins] = run;
+			run = fold_any( run + v );
 			}
 		}
 	else
-		for( int i = i0; i < i1; i += 8 )
+		for( int i = i0; i < ( keep ? i0 + 1 : i1 ); i += KEEP )
 			{
-			double v[8];
+			if( !keep )
+				{
+				#pragma unroll
+				for( int u = 0; u < KEEP; ++u ) held[u] = ( live && i + u < i1 ) ? c[int64_t( i + u ) * p.num_bins] : 0.0;
+				}
 			#pragma unroll
-			for( int u = 0; u < 8; ++u ) v[u] = ( live && i + u < i1 ) ? c[int64_t( i + u ) * p.num_bins] : 0.0;
-			#pragma unroll
-			for( int u = 0; u < 8; ++u )
+			for( int u = 0; u < KEEP; ++u )
 				{
 				if( live && i + u < i1 ) c[int64_t( i + u ) * p.num_bins] = run;
-				run = fold( run + v[u] );
+				run = fold_phase_loop( run + held[u] );
 				}
 			}
 	if( p.total_out && live && seg == SEG - 1 ) p.total_out[int64_t( channel ) * p.num_bins + k] = run;   // the running phase after the last chain
