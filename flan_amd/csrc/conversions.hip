@@ -296,17 +296,15 @@ static bool synth_fast_ok( int dft, int W, int hop ) { return synth_fast_kind( d
 
 // Chains per group of the kernels that pass group totals from analysis to synthesis (no scan kernel between the two): 8 for the dft 2048
 // pair (a block = 8 one-wavefront chains of a channel), 4 for the dft 4096 team kernels (4 teams per block); 0: no group totals for this shape.
-// The carry prologue of group g reads g totals per bin, so it only pays while a channel has few groups: measured on 60 s per 8 channels'
-// worth of frames it beats the scan kernel from 8 channels up (32 groups per channel) and loses below (4 channels, 64 groups: -3 % dft 2048,
-// -4 % dft 4096; tools/ab_step.py --pairs 0:0,0:2 --channels ...).
-static constexpr int kSelfCarryMaxGroups = 40;
 static int self_carry_group( int dft, int W, int hop, int chains_per_channel )
 	{
 	if( synth_fast_kind( dft, W, hop ) != 1 ) return 0;
 	int g = 0;
 	if( dft == 2048 ) g = 8;
 	else if( dft == 4096 && W % 256 == 0 && ( hop == 128 || hop % 256 == 0 ) && g_syn11_variant != 0 && g_ana11_variant != 0 ) g = 4;   // (windows above 2048: the WBIG variants)
-	if( g && ( chains_per_channel + g - 1 ) / g > kSelfCarryMaxGroups ) g = 0;
+	// any number of groups (their carries come from a scan of their own); with few chains per channel the scan over the chains themselves is as
+	// short and the groups' epilogue and prologue are pure cost (a 5 s mono file: 118 chains, 68 against 73 us per round trip)
+	if( chains_per_channel < 128 ) g = 0;
 	return g;
 	}
 
@@ -465,7 +463,7 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	o->groups_per_channel = ( o->chains_per_channel + gsize - 1 ) / gsize;
 	o->group_offset = o->carry_bytes + o->head_bytes + 1024;       // tail: NaN flag (4 B at +0), dump area (512 B at +512); then the group sums
 	o->group_bytes = ( size_t( ch ) * o->groups_per_channel * bins * sizeof( double ) + 255 ) & ~size_t( 255 );
-	o->total_bytes = o->group_offset + o->group_bytes;
+	o->total_bytes = o->group_offset + 2 * o->group_bytes;             // the producer's group totals, then the group carries the synthesis' own scan over them leaves
 	o->any_spec_offset = o->any_frames_offset = 0;
 	if( o->any )
 		{
@@ -531,7 +529,16 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	if( self_carry )
 		{
 		p.group_sums = reinterpret_cast<const double*>( reinterpret_cast<char*>( d_ws ) + lay.group_offset );
+		p.group_carry = reinterpret_cast<double*>( reinterpret_cast<char*>( d_ws ) + lay.group_offset + lay.group_bytes );
 		p.groups_per_channel = lay.groups_per_channel;
+		if( stages & 2 )
+			{
+			// the scan over the GROUP totals (an eighth / a quarter of the chains): every group's carry, from which the synthesis kernel's prologue
+			// and the chain sums give every chain's
+			if( p.groups_per_channel <= 512 ) hipLaunchKernelGGL( ( k_phase_scan2<16, true> ), dim3( (unsigned) ( ( bins + 31 ) / 32 ), (unsigned) ch ), dim3( 512 ), 0, s, p );
+			else hipLaunchKernelGGL( ( k_phase_scan2<32, true> ), dim3( (unsigned) ( ( bins + 15 ) / 16 ), (unsigned) ch ), dim3( 512 ), 0, s, p );
+			FLANHIP_CHECK( hipGetLastError() );
+			}
 		}
 	if( ( stages & 1 ) && presummed != 1 && presummed != 3 )
 		{

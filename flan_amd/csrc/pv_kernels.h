@@ -304,8 +304,9 @@ struct SynthParams
 	int nan_epoch;
 	const int * skip_words;   // optional: the pre-pass retires at once when words [4] and [2] agree (the producer of the PV left the sums)
 	const int * cancel;        // optional: the launching thread's cancel word (see AnalyzeParams)
-	const double * group_sums; // optional (dft 2048 kernel): the producer's per-group sums -- the kernel then computes its own carries from them and
-	int groups_per_channel;    // from the chain sums in `carry` (which it leaves untouched), and no scan kernel runs
+	const double * group_sums; // optional (dft 2048 / 4096 team kernels): the producer's per-group sums [ch][groups][bins] -- a scan over THEM (k_phase_scan2<SEG, true>:
+	int groups_per_channel;    // an eighth or a quarter of the chains) leaves each group's carry in group_carry, and the synthesis kernel works out its chains'
+	double * group_carry;      // carries from that and the chain sums in `carry` (which it leaves untouched): the scan over the chains is not launched
 	};
 
 // (the pre-pass kernels k_phase_sums2 / k_phase_scan2 that serve every size live in pv_kernels_fast.h)

@@ -702,17 +702,16 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 	if( frames > 0 ) load_row( t0 );
 	if( p.group_sums )
 		{
-		// No scan kernel ran: `carry` still holds the chains' own sums, group_sums the totals of every group of TEAMS chains.  The running phase on entry to a chain = the
-		// groups before this one, then the chains of this group before it, added and folded in order -- as in k_synthesize_v2, whose words
-		// these are: one thread per bin, four or five bins side by side, loads in batches ahead of the dependent additions; every team's carries
+		// No scan over the chains ran: `carry` still holds the chains' own sums, group_carry the running phase on entry to every group of TEAMS chains.
+		// The running phase on entry to a chain = that, then the chains of this group before it, added and folded in order -- as in k_synthesize_v2, whose words
+		// these are: one thread per bin, four or five bins side by side, every load ahead of the dependent additions; every team's carries
 		// land in the team's SECOND buffer set, which nobody writes before the first meeting (one set: in the set itself, and the team meets once
 		// more before filling it).
 		auto fold = []( double r ) { return ( __builtin_fabs( r ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_loop( r ) : fold_phase_any( r ); };
 		const int live = min( TEAMS, p.chains_per_channel - group * TEAMS );
-		const double * gs = p.group_sums + int64_t( gchannel ) * gpc * ( N2 + 1 );
+		const double * gs = p.group_carry + int64_t( gchannel ) * gpc * ( N2 + 1 );
 		const double * sums0 = p.carry + ( int64_t( gchannel ) * p.chains_per_channel + int64_t( group ) * TEAMS ) * ( N2 + 1 );
 		constexpr int NB = ( N2 + NT ) / NT;                                       // bins per thread: 5 for 512 threads (the fifth only for thread 0)
-		constexpr int BATCH = 8;
 		int bins_of[NB]; bool has[NB]; double run[NB];
 		#pragma unroll
 		for( int b = 0; b < NB; ++b ) { bins_of[b] = tid + NT * b; has[b] = bins_of[b] <= N2; if( !has[b] ) bins_of[b] = N2; run[b] = 0.0; }
@@ -723,22 +722,8 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 			#pragma unroll
 			for( int w = 0; w < TEAMS; ++w ) vc[b][w] = ( w < live ) ? sums0[int64_t( w ) * ( N2 + 1 ) + bins_of[b]] : 0.0;
 			}
-		for( int g0 = 0; g0 < group; g0 += BATCH )
-			{
-			double v[NB][BATCH];
-			#pragma unroll
-			for( int b = 0; b < NB; ++b )
-				{
-				#pragma unroll
-				for( int u = 0; u < BATCH; ++u ) v[b][u] = ( g0 + u < group ) ? gs[int64_t( g0 + u ) * ( N2 + 1 ) + bins_of[b]] : 0.0;
-				}
-			#pragma unroll
-			for( int u = 0; u < BATCH; ++u )
-				{
-				#pragma unroll
-				for( int b = 0; b < NB; ++b ) run[b] = fold( run[b] + v[b][u] );       // + 0.0 past the end: fold( x ) of a folded x is x
-				}
-			}
+		#pragma unroll
+		for( int b = 0; b < NB; ++b ) run[b] = gs[int64_t( group ) * ( N2 + 1 ) + bins_of[b]];   // the running phase on entry to this group (k_phase_scan2<SEG, true>)
 		#pragma unroll
 		for( int w = 0; w < TEAMS; ++w )
 			{

@@ -697,7 +697,9 @@ __global__ __launch_bounds__( 256 ) void k_phase_sums2( SynthParams p )
 // then each thread rewrites its segment as exclusive prefixes).  carry[c] = phase_buffer on entry to chain c.
 // SEG = 16 / 32 / 64 (32 / 16 / 8 bins per block), chosen by the host so that a segment has at most 32 chains where it can: few channels mean
 // many chains per channel (a stereo minute: 938), and a thread whose segment fits its registers makes ONE trip to memory per pass.
-template<int SEG>
+// GROUPS: the same scan over the producer's group totals (group_sums -> group_carry, out of place: a synthesis may be repeated on the same
+// workspace), for the synthesis kernels that take their chains' carries from a group's carry and the chain sums themselves.
+template<int SEG, bool GROUPS = false>
 __global__ __launch_bounds__( 512 ) void k_phase_scan2( SynthParams p )
 	{
 	constexpr int BINS = 512 / SEG;
@@ -705,17 +707,18 @@ __global__ __launch_bounds__( 512 ) void k_phase_scan2( SynthParams p )
 	const int lane_bin = threadIdx.x % BINS, seg = threadIdx.x / BINS;
 	const int channel = blockIdx.y;
 	const int k = blockIdx.x * BINS + lane_bin;
-	if( threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 )
+	if( !GROUPS && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 )
 		{
 		if( p.nan_in && p.nan_flag && p.nan_in[0] == p.nan_in[2] && p.nan_in[2] != 0 ) atomicOr( p.nan_flag, 1 );
 		// the sums become carries below: a handed-over pre-pass is good for one convert_to_audio only
 		if( p.skip_words ) const_cast<int*>( p.skip_words )[4] = 0;
 		}
-	const int n = p.chains_per_channel;
+	const int n = GROUPS ? p.groups_per_channel : p.chains_per_channel;
 	const int seg_len = ( n + SEG - 1 ) / SEG;
 	const int i0 = min( seg * seg_len, n ), i1 = min( i0 + seg_len, n );
 	const bool live = k < p.num_bins;
-	double * c = p.carry + int64_t( channel ) * n * p.num_bins + ( live ? k : 0 );
+	const double * c = ( GROUPS ? p.group_sums : p.carry ) + int64_t( channel ) * n * p.num_bins + ( live ? k : 0 );            // what is scanned ...
+	double * d = ( GROUPS ? p.group_carry : p.carry ) + int64_t( channel ) * n * p.num_bins + ( live ? k : 0 );                 // ... and where the exclusive prefixes go
 	// x + y folded like phase_vocoder.cpp:59.  The general fold (any magnitude, NaN) calls a routine, and a call inside unrolled code spills
 	// everything live; so the unrolled passes use the four-instruction fold (pv_math.h), exact below 3e9 rad, and only note whether any partial
 	// sum came within HALF that of its limit -- a thread that saw one (sums of a PV with wildly negative frequencies, NaN) redoes its segment with
@@ -745,10 +748,10 @@ __global__ __launch_bounds__( 512 ) void k_phase_scan2( SynthParams p )
 		}
 	totals[seg][lane_bin] = run;
 	__syncthreads();
-	double offs = ( p.carry_in && live ) ? p.carry_in[int64_t( channel ) * p.num_bins + k] : 0.0;   // AudioPV.cpp:111 (0 for a whole PV)
+	double offs = ( !GROUPS && p.carry_in && live ) ? p.carry_in[int64_t( channel ) * p.num_bins + k] : 0.0;   // AudioPV.cpp:111 (0 for a whole PV)
 	for( int s2 = 0; s2 < seg; ++s2 ) offs = fold_any( offs + totals[s2][lane_bin] );
 	run = offs;
-	if( p.total_only )
+	if( !GROUPS && p.total_only )
 		{
 		if( p.total_out && live && seg == SEG - 1 ) p.total_out[int64_t( channel ) * p.num_bins + k] = fold_any( offs + totals[seg][lane_bin] );
 		return;
@@ -759,7 +762,7 @@ __global__ __launch_bounds__( 512 ) void k_phase_scan2( SynthParams p )
 		for( int i = i0; i < i1; ++i )
 			{
 			const double v = live ? c[int64_t( i ) * p.num_bins] : 0.0;
-			if( live ) c[int64_t( i ) * p.num_bins] = run;
+			if( live ) d[int64_t( i ) * p.num_bins] = run;
 			run = fold_any( run + v );
 			}
 		}
@@ -774,11 +777,11 @@ __global__ __launch_bounds__( 512 ) void k_phase_scan2( SynthParams p )
 			#pragma unroll
 			for( int u = 0; u < KEEP; ++u )
 				{
-				if( live && i + u < i1 ) c[int64_t( i + u ) * p.num_bins] = run;
+				if( live && i + u < i1 ) d[int64_t( i + u ) * p.num_bins] = run;
 				run = fold_phase_loop( run + held[u] );
 				}
 			}
-	if( p.total_out && live && seg == SEG - 1 ) p.total_out[int64_t( channel ) * p.num_bins + k] = run;   // the running phase after the last chain
+	if( !GROUPS && p.total_out && live && seg == SEG - 1 ) p.total_out[int64_t( channel ) * p.num_bins + k] = run;   // the running phase after the last chain
 	}
 
 } // namespace flanhip

@@ -638,19 +638,19 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 	double phk[H], phm[H], phx;
 	if( p.group_sums )
 		{
-		// no scan kernel ran: `carry` still holds the chains' own sums, group_sums the totals of every group of 8 chains.  The running phase
-		// on entry to this chain = the groups before this one, then the chains of this group before this one, added and folded in order
-		// (phase_vocoder.cpp:57-59 modulo pi2: the same prefix k_phase_scan2 forms, associated group-wise).
+		// no scan over the chains ran: `carry` still holds the chains' own sums, group_carry the running phase on entry to every group of 8 chains
+		// (a scan over the producer's group totals: an eighth of the elements).  The running phase on entry to this chain = that, then the chains of
+		// this group before this one, added and folded in order (phase_vocoder.cpp:57-59 modulo pi2: the prefix k_phase_scan2 forms, associated group-wise).
 		// x + y folded like phase_vocoder.cpp:59: the branch-free fold of the frame loop (pv_math.h) wherever it is exact, i.e. always but
 		// for sums beyond 3e9 rad or NaN, which take the general routine
 		auto fold = []( double r )
 			{
 			return ( __builtin_fabs( r ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_loop( r ) : fold_phase_any( r );
 			};
-		// One thread per bin, its two or three bins side by side (independent dependency chains): first the groups before this one, then
-		// along the chains of this group, leaving every wavefront's carries in that wavefront's own transform buffer (1025 doubles of its
-		// 8712 bytes).  Loads go out in batches of 16 per bin ahead of the dependent additions: one memory round trip per batch.
-		const double * gs = p.group_sums + int64_t( channel ) * groups * ( C + 1 );
+		// One thread per bin, its two or three bins side by side (independent dependency chains), along the chains of this group, leaving every
+		// wavefront's carries in that wavefront's own transform buffer (1025 doubles of its 8712 bytes).  Every load goes out ahead of the
+		// dependent additions: one memory round trip.
+		const double * gs = p.group_carry + int64_t( channel ) * groups * ( C + 1 );
 		const double * sums0 = p.carry + ( int64_t( channel ) * p.chains_per_channel + int64_t( group ) * WAVES ) * ( C + 1 );   // the first chain of this group
 		const int live = min( WAVES, p.chains_per_channel - group * WAVES );
 		constexpr int NB = ( C + NT ) / NT;                                       // bins per thread: 3 for 512 threads (the third only for thread 0)
@@ -664,23 +664,9 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 			#pragma unroll
 			for( int w = 0; w < WAVES; ++w ) vc[b][w] = ( w < live ) ? sums0[int64_t( w ) * ( C + 1 ) + bins_of[b]] : 0.0;
 			}
+		#pragma unroll
+		for( int b = 0; b < NB; ++b ) run[b] = gs[int64_t( group ) * ( C + 1 ) + bins_of[b]];   // the running phase on entry to this group (k_phase_scan2<SEG, true>)
 		if( active ) load_row( relf0 );                                           // the first MF row travels while the carries are worked out
-		for( int g0 = 0; g0 < group; g0 += 16 )
-			{
-			double v[NB][16];
-			#pragma unroll
-			for( int b = 0; b < NB; ++b )
-				{
-				#pragma unroll
-				for( int u = 0; u < 16; ++u ) v[b][u] = ( g0 + u < group ) ? gs[int64_t( g0 + u ) * ( C + 1 ) + bins_of[b]] : 0.0;
-				}
-			#pragma unroll
-			for( int u = 0; u < 16; ++u )
-				{
-				#pragma unroll
-				for( int b = 0; b < NB; ++b ) run[b] = fold( run[b] + v[b][u] );      // + 0.0 past the end: fold( x ) of a folded x is x
-				}
-			}
 		#pragma unroll
 		for( int w = 0; w < WAVES; ++w )
 			{

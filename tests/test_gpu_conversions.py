@@ -287,13 +287,13 @@ def test_fused_round_trip_equals_unfused(fa):
         assert res[0][2] == res[1][2] == 0
 
 
-@pytest.mark.parametrize("dft,hop,ch,n,W", [(2048, 512, 8, 300000, 2048), (4096, 512, 8, 300000, 2048), (4096, 128, 8, 100000, 2048), (4096, 1024, 8, 700000, 2048),
-                                            (2048, 512, 3, 900000, 2048), (4096, 1024, 8, 700000, 4096), (4096, 512, 8, 300000, 3072)])
+@pytest.mark.parametrize("dft,hop,ch,n,W", [(2048, 512, 8, 300000, 2048), (4096, 512, 4, 600000, 2048), (4096, 128, 2, 400000, 2048), (4096, 1024, 4, 1400000, 2048),
+                                            (2048, 512, 3, 900000, 2048), (4096, 1024, 4, 1400000, 4096), (4096, 512, 4, 600000, 3072), (2048, 512, 1, 2000000, 2048)])
 def test_carry_prologue_equals_scan_kernel(fa, dft, hop, ch, n, W):
-    """Fused round trip: the synthesis kernels that work out their own carries from the analysis' group totals (dft 2048: groups of 8 chains;
-    dft 4096 team kernels: groups of 4, the last group of a channel short; also their one-buffer-set variants for windows above 2048) against the same launch with the scan kernel in front (synthesis
-    variant 2), 19-30 groups per channel (the last shape has 55: both runs take the scan kernel there): the same prefix sums associated
-    group-wise -- audio bit for bit, NaN flag clear."""
+    """Fused round trip: the synthesis kernels that take their chains' carries from a scan over the analysis' GROUP totals plus the chain sums
+    (dft 2048: groups of 8 chains; dft 4096 team kernels: groups of 4, the last group of a channel short; also their one-buffer-set variants for
+    windows above 2048) against the same launch with the scan over the chains themselves in front (synthesis variant 2); 147-977 chains per
+    channel: the same prefix sums associated group-wise -- audio bit for bit, NaN flag clear."""
     import ctypes
     lib = fa.lib
     sr = 48000.0
