@@ -529,9 +529,12 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	if( self_carry )
 		{
 		p.group_sums = reinterpret_cast<const double*>( reinterpret_cast<char*>( d_ws ) + lay.group_offset );
-		p.group_carry = reinterpret_cast<double*>( reinterpret_cast<char*>( d_ws ) + lay.group_offset + lay.group_bytes );
 		p.groups_per_channel = lay.groups_per_channel;
-		if( stages & 2 )
+		// up to 40 groups per channel the synthesis kernel adds the totals of the groups before its own itself (no kernel in front: measured
+		// cheaper, the scan kernel's floor is ~9 us); beyond, a scan over the group totals leaves every group's carry
+		const bool scan_groups = p.groups_per_channel > 40;
+		p.group_carry = scan_groups ? reinterpret_cast<double*>( reinterpret_cast<char*>( d_ws ) + lay.group_offset + lay.group_bytes ) : nullptr;
+		if( scan_groups && ( stages & 2 ) )
 			{
 			// the scan over the GROUP totals (an eighth / a quarter of the chains): every group's carry, from which the synthesis kernel's prologue
 			// and the chain sums give every chain's

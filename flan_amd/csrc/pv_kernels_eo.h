@@ -709,7 +709,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 		// more before filling it).
 		auto fold = []( double r ) { return ( __builtin_fabs( r ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_loop( r ) : fold_phase_any( r ); };
 		const int live = min( TEAMS, p.chains_per_channel - group * TEAMS );
-		const double * gs = p.group_carry + int64_t( gchannel ) * gpc * ( N2 + 1 );
+		const double * gs = ( p.group_carry ? p.group_carry : p.group_sums ) + int64_t( gchannel ) * gpc * ( N2 + 1 );
 		const double * sums0 = p.carry + ( int64_t( gchannel ) * p.chains_per_channel + int64_t( group ) * TEAMS ) * ( N2 + 1 );
 		constexpr int NB = ( N2 + NT ) / NT;                                       // bins per thread: 5 for 512 threads (the fifth only for thread 0)
 		int bins_of[NB]; bool has[NB]; double run[NB];
@@ -722,8 +722,32 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 			#pragma unroll
 			for( int w = 0; w < TEAMS; ++w ) vc[b][w] = ( w < live ) ? sums0[int64_t( w ) * ( N2 + 1 ) + bins_of[b]] : 0.0;
 			}
-		#pragma unroll
-		for( int b = 0; b < NB; ++b ) run[b] = gs[int64_t( group ) * ( N2 + 1 ) + bins_of[b]];   // the running phase on entry to this group (k_phase_scan2<SEG, true>)
+		if( p.group_carry )
+			{
+			#pragma unroll
+			for( int b = 0; b < NB; ++b ) run[b] = gs[int64_t( group ) * ( N2 + 1 ) + bins_of[b]];   // the running phase on entry to this group (k_phase_scan2<SEG, true>)
+			}
+		else
+			{
+			// few groups per channel: this group adds up the totals of the groups before it itself (see k_synthesize_v2)
+			constexpr int BATCH = 8;
+			for( int g0 = 0; g0 < group; g0 += BATCH )
+				{
+				double v[NB][BATCH];
+				#pragma unroll
+				for( int b = 0; b < NB; ++b )
+					{
+					#pragma unroll
+					for( int u = 0; u < BATCH; ++u ) v[b][u] = ( g0 + u < group ) ? gs[int64_t( g0 + u ) * ( N2 + 1 ) + bins_of[b]] : 0.0;
+					}
+				#pragma unroll
+				for( int u = 0; u < BATCH; ++u )
+					{
+					#pragma unroll
+					for( int b = 0; b < NB; ++b ) run[b] = fold( run[b] + v[b][u] );       // + 0.0 past the end: fold( x ) of a folded x is x
+					}
+				}
+			}
 		#pragma unroll
 		for( int w = 0; w < TEAMS; ++w )
 			{

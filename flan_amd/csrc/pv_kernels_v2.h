@@ -650,7 +650,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 		// One thread per bin, its two or three bins side by side (independent dependency chains), along the chains of this group, leaving every
 		// wavefront's carries in that wavefront's own transform buffer (1025 doubles of its 8712 bytes).  Every load goes out ahead of the
 		// dependent additions: one memory round trip.
-		const double * gs = p.group_carry + int64_t( channel ) * groups * ( C + 1 );
+		const double * gs = ( p.group_carry ? p.group_carry : p.group_sums ) + int64_t( channel ) * groups * ( C + 1 );
 		const double * sums0 = p.carry + ( int64_t( channel ) * p.chains_per_channel + int64_t( group ) * WAVES ) * ( C + 1 );   // the first chain of this group
 		const int live = min( WAVES, p.chains_per_channel - group * WAVES );
 		constexpr int NB = ( C + NT ) / NT;                                       // bins per thread: 3 for 512 threads (the third only for thread 0)
@@ -664,9 +664,33 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 			#pragma unroll
 			for( int w = 0; w < WAVES; ++w ) vc[b][w] = ( w < live ) ? sums0[int64_t( w ) * ( C + 1 ) + bins_of[b]] : 0.0;
 			}
-		#pragma unroll
-		for( int b = 0; b < NB; ++b ) run[b] = gs[int64_t( group ) * ( C + 1 ) + bins_of[b]];   // the running phase on entry to this group (k_phase_scan2<SEG, true>)
+		if( p.group_carry )
+			{
+			#pragma unroll
+			for( int b = 0; b < NB; ++b ) run[b] = gs[int64_t( group ) * ( C + 1 ) + bins_of[b]];   // the running phase on entry to this group (k_phase_scan2<SEG, true>)
+			}
 		if( active ) load_row( relf0 );                                           // the first MF row travels while the carries are worked out
+		if( !p.group_carry )
+			{
+			// few groups per channel (the host's choice): no scan over the group totals was launched -- this group adds up the totals of the groups
+			// before it itself, 16 loads per bin in flight (group g reads g totals: O(groups^2) bytes in all, cheaper than a kernel up to ~40 groups)
+			for( int g0 = 0; g0 < group; g0 += 16 )
+				{
+				double v[NB][16];
+				#pragma unroll
+				for( int b = 0; b < NB; ++b )
+					{
+					#pragma unroll
+					for( int u = 0; u < 16; ++u ) v[b][u] = ( g0 + u < group ) ? gs[int64_t( g0 + u ) * ( C + 1 ) + bins_of[b]] : 0.0;
+					}
+				#pragma unroll
+				for( int u = 0; u < 16; ++u )
+					{
+					#pragma unroll
+					for( int b = 0; b < NB; ++b ) run[b] = fold( run[b] + v[b][u] );      // + 0.0 past the end: fold( x ) of a folded x is x
+					}
+				}
+			}
 		#pragma unroll
 		for( int w = 0; w < WAVES; ++w )
 			{
