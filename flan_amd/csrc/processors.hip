@@ -23,24 +23,13 @@ namespace flanhip {
 // value { 0, 0 } (:317).  Such columns are cut into `segments` runs of frame pairs handled by different threads, each thread
 // OWNS the output frames of its pairs: it writes them once (the accumulation onto { 0, 0 } written out literally), zeros where
 // the reference leaves a pair early (:350-351) and, at the two ends of the column, the frames no pair reaches -- no separate
-// clearing pass and no read-modify-write.  Columns whose map does run backwards (flag set by k_time_map_flags) are cleared
+// clearing pass and no read-modify-write.  Columns whose map does run backwards (flag set by the first blocks of k_modify_time_chains) are cleared
 // and then walked by one thread in the reference order.
-// nonmono[bin] = 1 for such columns; nonmono[bins] = 1 if there is any
-__global__ __launch_bounds__( 256 ) void k_time_map_flags( const float * mod, int64_t F, int bins, float sr, float hop, int * nonmono )
-	{
-	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
-	if( idx >= ( F - 1 ) * bins ) return;
-	const int64_t frame = idx / bins + 1;
-	const int bin = int( idx % bins );
-	const float l = time_to_frame( mod[( frame - 1 ) * bins + bin], sr, hop );
-	const float r = time_to_frame( mod[frame * bins + bin], sr, hop );
-	if( !( r >= l ) ) { nonmono[bin] = 1; nonmono[bins] = 1; }                     // backwards, or NaN
-	}
-
 __global__ __launch_bounds__( 256 ) void k_modify_time( const MFd * in, int num_channels, int64_t F, int bins, float sr, float hop,
-	const float * mod, int64_t Fo, MFd * out, const int * nonmono, int segments, int64_t seg_len, int only_if_any, int interp )
+	const float * mod, int64_t Fo, MFd * out, const int * nonmono, int segments, int64_t seg_len, int only_if_any, int interp, int * words, int epoch )
 	{
-	if( only_if_any && !nonmono[bins] ) return;                                     // k_modify_time_chains does this PV
+	if( only_if_any && !nonmono[bins] ) return;                                     // k_modify_time_chains has done this PV
+	if( words && blockIdx.x == 0 && threadIdx.x == 0 ) { words[2] = epoch; words[4] = 0; }   // the chain sums k_modify_time_chains left are NOT this PV's
 	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
 	const int64_t columns = int64_t( num_channels ) * bins;
 	if( idx >= columns * segments ) return;
@@ -122,110 +111,204 @@ struct TimeChainParams
 	int64_t F, Fo;
 	int num_channels, bins, L, chains_per_channel;
 	float sr, hop, analysis_rate;
+	DivC ar_div;              // analysis_rate as a divisor (pv_math.h): the term of the phase sums, as k_phase_sums2 forms it
 	double * sums;            // [ch][chains][bins]
 	int * words;              // workspace tail: [0] NaN flag, [2] epoch, [4] "sums valid" (set iff equal to the epoch)
 	int epoch;
-	const int * nonmono;      // [bins + 1]
+	int * nonmono;            // [bins + 1], zeroed before the launch: written by the launch's first flag_blocks blocks
+	int flag_blocks;          // a multiple of 8
 	int interp;               // FLANHIP_INTERP_*: the Interpolator of PVModify.cpp:344 (0 = linear)
 	};
 
 // SUMS = false: the plain flanhip_modify_time_dev uses the same cut (any chain length) without a workspace.
-template<bool SUMS>
+//
+// Round 4 rebuilt the kernel around what the compiled round-1 version turned out to do (profiles/r04_config3_*).  Its output loop ended, every
+// iteration, in `s_waitcnt vmcnt(0)`: interpolate()'s table arm holds a load, the arms join below it, and on gfx950 loads and stores retire
+// through ONE in-order counter -- a wavefront waited for the acknowledgement of the frame it had just stored before computing the next
+// (one 512-byte store in flight per wavefront).  Now
+//   * LINEAR (the Interpolator every stretch uses) is a compile-time arm: no load anywhere in the output loop, stores leave back to back;
+//   * input frames arrive B at a time (MF + map value: 12 bytes per frame and lane) and their pairs are worked off from registers: the wait
+//     for a batch drains the previous batch's stores -- one round trip per B input frames instead of one per output frame (an in-order
+//     counter cannot wait for a load without the stores issued before it);
+//   * threads are numbered ( chain, channel, bin ): with the XCD-contiguous block order the channels of a chain -- which read the same rows
+//     of the time map -- meet in one L2 (channel-major numbering gave each XCD a channel of its own for the bench shape: the 23 MB map went
+//     through the fabric eight times, 184 of the launch's 681 MB of L2 misses; 267 -> 235 us);
+//   * the output pointer steps by a row per frame (every frame of [x_lo, x_hi) is written exactly once, in order); plain stores, NOT
+//     non-temporal ones: a row piece shares its first and last 128-byte line with the neighbouring wavefronts' pieces (rows are 8200 bytes),
+//     and those partial lines have to meet in the L2 before they leave for memory (tools/ubench/mtc_patterns.hip: stores alone 4.9 TB/s
+//     plain, 3.65 non-temporal; whole rows per block, two bins per thread, other block orders and chain lengths: all slower or equal);
+//   * the term of the phase sums divides by the analysis rate with the proven 3-instruction quotient (k_phase_sums2's own div_c);
+//   * the map's monotonicity check (k_time_map_flags' job) runs INSIDE this launch, on its first `flag_blocks` blocks, while the chain blocks
+//     work on the assumption that the map is monotone (every stretch).  k_modify_time, launched behind, reads the complete flags: if a
+//     column does run backwards it redoes the whole PV and takes the sums' validity word back.  (Chain blocks that already see the flag
+//     retire early; one that does not writes frames k_modify_time overwrites: every access is clamped, every loop bounded.)
+// Results: bit for bit the round-1 kernel's (tests/test_gpu_processors.py, test_gpu_full_size.py::test_config3_*).
+constexpr int kFlagRun = 16;                                                       // frame pairs per thread of the flag blocks
+template<bool SUMS, bool LINEAR, int B>
 __global__ __launch_bounds__( 256 ) void k_modify_time_chains( TimeChainParams p )
 	{
-	if( p.nonmono[p.bins] )                                                         // some column runs backwards: k_modify_time does this PV
+	if( int( blockIdx.x ) < p.flag_blocks )
 		{
-		if( SUMS && blockIdx.x == 0 && threadIdx.x == 0 ) { p.words[2] = p.epoch; p.words[4] = 0; }   // the sums are NOT valid for this epoch: said explicitly, not left to staleness
+		// nonmono[bin] = 1 for columns whose map runs backwards somewhere (or is NaN), nonmono[bins] = 1 if there is any: thread = ( run of
+		// kFlagRun frame pairs, bin ), lanes along the bins
+		const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
+		const int64_t runs = ( p.F - 1 + kFlagRun - 1 ) / kFlagRun;
+		if( idx >= runs * p.bins ) return;
+		const int bin = int( idx % p.bins );
+		const int64_t f0 = ( idx / p.bins ) * kFlagRun;                              // pairs ( f0, f0+1 ) ... ( f0+kFlagRun-1, f0+kFlagRun )
+		float t[kFlagRun + 1];
+		#pragma unroll
+		for( int i = 0; i <= kFlagRun; ++i ) t[i] = p.mod[min( f0 + i, p.F - 1 ) * p.bins + bin];
+		bool backwards = false;
+		#pragma unroll
+		for( int i = 0; i < kFlagRun; ++i )
+			backwards |= !( time_to_frame( t[i + 1], p.sr, p.hop ) >= time_to_frame( t[i], p.sr, p.hop ) );   // :332 (r >= l; false for NaN)
+		if( backwards ) { p.nonmono[bin] = 1; p.nonmono[p.bins] = 1; }
 		return;
 		}
-	// Workgroups are dealt to the 8 XCDs round-robin and each XCD has its own L2; blocks that are neighbours in `idx` write neighbouring
-	// 2 KB pieces of the same rows.  XCD x takes a contiguous run of blocks, so that the pieces of a row meet in one L2.
-	const int64_t nblocks = gridDim.x, per_xcd = ( nblocks + 7 ) / 8;
-	const int64_t vblock = int64_t( blockIdx.x % 8 ) * per_xcd + blockIdx.x / 8;
+	if( p.nonmono[p.bins] ) return;                                                 // already known to run backwards somewhere: k_modify_time does this PV
+	const int cblock = int( blockIdx.x ) - p.flag_blocks;                           // (flag_blocks is a multiple of 8: the XCD of a block is cblock % 8 too)
+	const int64_t nblocks = int64_t( gridDim.x ) - p.flag_blocks, per_xcd = ( nblocks + 7 ) / 8;   // XCD x takes a contiguous run of blocks (pieces of a row meet in one L2)
+	const int64_t vblock = int64_t( cblock % 8 ) * per_xcd + cblock / 8;
 	const int64_t idx = vblock * blockDim.x + threadIdx.x;
-	const int64_t per_channel = int64_t( p.chains_per_channel ) * p.bins;
-	const bool live = int64_t( blockIdx.x / 8 ) < per_xcd && idx < per_channel * p.num_channels;
-	bool bad = false;
+	// index order ( chain, channel, bin ): the channels of a chain sit in neighbouring blocks -- one XCD, one L2 -- because they all read the
+	// same rows of the time map (channel-major order sent each channel to an XCD of its own for the bench shape, and the map through the
+	// fabric eight times: 184 of the launch's 681 MB of L2 misses)
+	const int64_t per_chain = int64_t( p.num_channels ) * p.bins;
+	const bool live = int64_t( cblock / 8 ) < per_xcd && idx < per_chain * p.chains_per_channel;
+	unsigned worst = 0;                                                             // largest |bit pattern| among the written m and f: Inf / NaN sort on top
 	if( live )
 		{
-		const int channel = int( idx / per_channel ), chain = int( ( idx % per_channel ) / p.bins ), bin = int( idx % p.bins );
+		const int chain = int( idx / per_chain ), channel = int( ( idx % per_chain ) / p.bins ), bin = int( idx % p.bins );
 		const int bins = p.bins;
 		const int Fo32 = int( p.Fo );
 		const int x_lo = chain * p.L, x_hi = min( x_lo + p.L, Fo32 );
-		const MFd * ip = p.in + int64_t( channel ) * p.F * bins + bin;
-		MFd * op = p.out + int64_t( channel ) * p.Fo * bins + bin;
+		const cf * ip = reinterpret_cast<const cf*>( p.in ) + int64_t( channel ) * p.F * bins + bin;
 		const float * mp = p.mod + bin;
 		auto frame_of = [&]( int64_t k ) { return time_to_frame( mp[k * bins], p.sr, p.hop ); };
-		auto pair_end = [&]( int64_t k ) { return min( max( int( ceilf( frame_of( k ) ) ), 0 ), Fo32 ); };   // clamped ceil( r ) of pair ( k-1, k )
+		auto clamped_ceil = [&]( float at ) { return min( max( int( ceilf( at ) ), 0 ), Fo32 ); };
+		auto ends_beyond = [&]( int64_t k ) { return clamped_ceil( frame_of( k ) ) > x_lo; };   // pair ( k-1, k ); non-decreasing in k
 
-		// first pair whose (clamped) end lies beyond x_lo; pair_end is non-decreasing in k
-		int64_t lo = 1, hi = p.F;                                                   // answer in [1, F]; F = none
+		// The first pair that ends beyond x_lo: the answer is in [1, F] (F = none).  A plain bisection is 13 dependent reads of the map before the
+		// first byte moves; a map that is anywhere near proportional (every constant stretch) is found in two or three by galloping away from
+		// the proportional guess, the bisection finishing what is left.
+		int64_t lo = 1, hi = p.F;
+		if( p.F > 2 )
+			{
+			const int64_t g = min( max( int64_t( x_lo ) * ( p.F - 1 ) / p.Fo, int64_t( 1 ) ), p.F - 1 );
+			int64_t w = 1;
+			if( ends_beyond( g ) )
+				{
+				hi = g;                                                                  // answer in [1, g]
+				while( true )
+					{
+					const int64_t q = hi - w;
+					if( q < 1 ) break;
+					if( ends_beyond( q ) ) { hi = q; w *= 2; } else { lo = q + 1; break; }
+					}
+				}
+			else
+				{
+				lo = g + 1;                                                              // answer in [g + 1, F]
+				while( true )
+					{
+					const int64_t q = lo + w - 1;
+					if( q >= p.F ) break;
+					if( !ends_beyond( q ) ) { lo = q + 1; w *= 2; } else { hi = q; break; }
+					}
+				}
+			}
 		while( lo < hi )
 			{
 			const int64_t mid = ( lo + hi ) >> 1;
-			if( pair_end( mid ) > x_lo ) hi = mid; else lo = mid + 1;
+			if( ends_beyond( mid ) ) hi = mid; else lo = mid + 1;
 			}
 		double ph = 0.0;
-		int summed = 0;                                                             // frames of this chain already in ph
-		auto add_frame = [&]( int x, MFd v )                                        // x ascending, every frame of [x_lo, x_hi) exactly once
+		int summed = 0;
+		const int full8 = ( x_hi - x_lo ) & ~7;
+		cf * o = reinterpret_cast<cf*>( p.out ) + ( int64_t( channel ) * p.Fo + x_lo ) * bins + bin;   // the next frame to write
+		int cursor = x_lo;                                                          // ... and its number
+		auto add_frame = [&]( float m, float f )                                    // every frame of [x_lo, x_hi) exactly once, ascending
 			{
-			op[int64_t( x ) * bins] = v;
+			*o = cf{ m, f };
+			o += bins; ++cursor;
 			if constexpr( SUMS )
 				{
-				bad |= !( fabsf( v.m ) <= 3.4028235e38f ) || !( fabsf( v.f ) <= 3.4028235e38f );
-				ph += double( v.f / p.analysis_rate * FLANHIP_PI2_F );              // phase_vocoder.cpp:57 (k_phase_sums2's term)
+				worst = max( worst, max( __float_as_uint( m ) & 0x7FFFFFFFu, __float_as_uint( f ) & 0x7FFFFFFFu ) );
+				ph += double( div_c( f, p.ar_div ) * FLANHIP_PI2_F );               // phase_vocoder.cpp:57 (k_phase_sums2's term)
 				++summed;
 				// k_phase_sums2 keeps its partial sum small after every full group of 8 frames of the chain
-				if( ( summed & 7 ) == 0 && summed <= ( ( x_hi - x_lo ) & ~7 ) && !( fabs( ph ) < 1.0e8 ) ) ph = fold_phase_any( ph );
+				if( ( summed & 7 ) == 0 && summed <= full8 && !( fabs( ph ) < 1.0e8 ) ) ph = fold_phase_any( ph );
 				}
 			};
-		int cursor = x_lo;
 		if( lo < p.F )
 			{
 			float at_l = frame_of( lo - 1 );
-			MFd mf_l = ip[( lo - 1 ) * bins];
-			for( int64_t k = lo; k < p.F; ++k )                                     // :328
+			cf mf_l = ip[( lo - 1 ) * bins];
+			bool stop = false;
+			for( int64_t k = lo; k < p.F && !stop; k += B )                         // :328, B pairs per trip
 				{
-				const MFd mf_r = ip[k * bins];
-				const float at_r = frame_of( k );                                 // :331
-				const int xs = min( max( int( ceilf( at_l ) ), 0 ), Fo32 );       // :334-335, :342 (monotone: forward or empty)
-				const int xe = min( max( int( ceilf( at_r ) ), 0 ), Fo32 );
-				if( xs >= x_hi ) break;
-				const int a = max( xs, x_lo ), b = min( xe, x_hi );
-				for( ; cursor < a; ++cursor ) add_frame( cursor, MFd{ 0.0f, 0.0f } );   // frames no pair reaches (before the first pair)
-				bool left = false;                                                  // has the reference left this pair (:350-351)?
-				for( int x = xs; x < b; ++x )
+				cf mf[B]; float tm[B];
+				#pragma unroll
+				for( int j = 0; j < B; ++j )
 					{
-					MFd v = { 0.0f, 0.0f };
-					if( !left )
-						{
-						const float mix = interpolate( p.interp, ( float( x ) - at_l ) / ( at_r - at_l ) );        // :344
-						const float share_l = ( 1.0f - mix ) * mf_l.m;
-						const float share_r = mix * mf_r.m;
-						const float weight = share_l + share_r;
-						const float freq_by_weight = share_l * mf_l.f + share_r * mf_r.f;
-						if( weight == 0.0f ) left = true;
-						else
-							{
-							const MFd o = { 0.0f, 0.0f };                                       // the cleared output MF this pair alone reaches
-							v = MFd{ o.m + weight, ( o.f * o.m + freq_by_weight ) / ( o.m + weight ) };   // :354-355
-							}
-						}
-					if( x >= a ) { add_frame( x, v ); cursor = x + 1; }
+					const int64_t kk = min( k + j, p.F - 1 ) * bins;
+					mf[j] = ip[kk]; tm[j] = mp[kk];
 					}
-				mf_l = mf_r; at_l = at_r;
+				// every map value of the batch is converted here, last one first: the one wait for the whole batch (which also drains the previous
+				// batch's stores) stands in front of the pairs, and nothing below it waits for memory again
+				#pragma unroll
+				for( int j = B - 1; j >= 0; --j )
+					{
+					asm volatile( "" : "+v"( tm[j] ), "+v"( mf[j] ) );                    // (the values are wanted HERE, whichever pairs turn out to be walked)
+					tm[j] = time_to_frame( tm[j], p.sr, p.hop );                        // :331
+					}
+				#pragma unroll
+				for( int j = 0; j < B; ++j )
+					{
+					if( stop || k + j >= p.F ) continue;
+					const cf mf_r = mf[j];
+					const float at_r = tm[j];
+					const int xs = clamped_ceil( at_l ), xe = clamped_ceil( at_r );     // :334-335, :342 (monotone: forward or empty)
+					if( xs >= x_hi ) { stop = true; continue; }
+					const int a = max( xs, x_lo ), b = min( xe, x_hi );
+					while( cursor < a ) add_frame( 0.0f, 0.0f );                         // frames no pair reaches (before the first pair)
+					bool left = false;                                                  // has the reference left this pair (:350-351)?
+					const float span = at_r - at_l;
+					for( int x = xs; x < b; ++x )
+						{
+						float m = 0.0f, f = 0.0f;
+						if( !left )
+							{
+							const float pos = ( float( x ) - at_l ) / span;
+							const float mix = LINEAR ? pos : interpolate( p.interp, pos );  // :344
+							const float share_l = ( 1.0f - mix ) * mf_l.x;
+							const float share_r = mix * mf_r.x;
+							const float weight = share_l + share_r;
+							const float freq_by_weight = share_l * mf_l.y + share_r * mf_r.y;
+							if( weight == 0.0f ) left = true;
+							else
+								{
+								const float om = 0.0f, of = 0.0f;                               // the cleared output MF this pair alone reaches
+								m = om + weight; f = ( of * om + freq_by_weight ) / ( om + weight );   // :354-355
+								}
+							}
+						if( x == cursor ) add_frame( m, f );                                // x >= a, for a monotone map; a store never lands outside [x_lo, x_hi) whatever the map
+						}
+					mf_l = mf_r; at_l = at_r;
+					}
 				}
 			}
-		for( ; cursor < x_hi; ++cursor ) add_frame( cursor, MFd{ 0.0f, 0.0f } );    // beyond the last pair
+		while( cursor < x_hi ) add_frame( 0.0f, 0.0f );                             // beyond the last pair
 		if constexpr( SUMS )
 			p.sums[( int64_t( channel ) * p.chains_per_channel + chain ) * bins + bin] =
 				( fabs( ph ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( ph ) : fold_phase_any( ph );
 		}
 	if constexpr( SUMS )
 		{
-		const bool any_bad = __any( bad );
+		const bool any_bad = __any( worst > 0x7F7FFFFFu );
 		if( ( threadIdx.x & 63 ) == 0 && any_bad ) p.words[0] = p.epoch;
-		if( blockIdx.x == 0 && threadIdx.x == 0 ) { p.words[2] = p.epoch; p.words[4] = p.epoch; }
+		if( cblock == 0 && threadIdx.x == 0 ) { p.words[2] = p.epoch; p.words[4] = p.epoch; }   // (k_modify_time takes [4] back if the map runs backwards)
 		}
 	}
 
@@ -523,6 +606,23 @@ namespace flanhip { int processors_set_interp_lut( int slot, const float * d_tab
 
 using namespace flanhip;
 
+// the monotone-map kernel: its first blocks check the map (nonmono must be zeroed), the others walk the output chains
+// the monotone-map kernel: its first blocks check the map (nonmono must be zeroed), the others walk the output chains
+template<bool SUMS>
+static int launch_time_chains( TimeChainParams & p, hipStream_t s )
+	{
+	const int64_t flag_threads = ( ( p.F - 1 + kFlagRun - 1 ) / kFlagRun ) * p.bins;
+	p.flag_blocks = int( ( ( flag_threads + 255 ) / 256 + 7 ) / 8 * 8 );
+	const int64_t owners = int64_t( p.num_channels ) * p.chains_per_channel * p.bins;
+	const dim3 grid( (unsigned) ( p.flag_blocks + ( ( owners + 255 ) / 256 + 7 ) / 8 * 8 ) ), block( 256 );
+	// frames per trip: 2 with the linear Interpolator (58 VGPRs with the sums: eight wavefronts per SIMD; 4 frames: 68 registers, seven
+	// wavefronts, 1 % slower), 4 where the Interpolator is a run-time choice (80 registers either way)
+	if( p.interp != FLANHIP_INTERP_LINEAR ) hipLaunchKernelGGL( ( k_modify_time_chains<SUMS, false, 4> ), grid, block, 0, s, p );
+	else hipLaunchKernelGGL( ( k_modify_time_chains<SUMS, true, 2> ), grid, block, 0, s, p );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
 extern "C" {
 
 static int modify_time_dev_impl( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, int hop, const float * d_mod,
@@ -534,22 +634,15 @@ static int modify_time_dev_impl( const flanhip_MF * d_pv, int64_t ch, int64_t F,
 	hipStream_t s = (hipStream_t) stream;
 	FLANHIP_REQUIRE( Fo < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "2^31 output frames or more" );
 	int * d_flags = nullptr;                                                       // per bin: does the time map ever run backwards?
-	FLANHIP_CHECK( hipMallocAsync( reinterpret_cast<void**>( &d_flags ), sizeof( int ) * ( bins + 1 ), s ) );
-	FLANHIP_CHECK( hipMemsetAsync( d_flags, 0, sizeof( int ) * ( bins + 1 ), s ) );
-	if( F > 1 )
-		{
-		const int64_t pairs = ( F - 1 ) * bins;
-		hipLaunchKernelGGL( k_time_map_flags, dim3( (unsigned) ( ( pairs + 255 ) / 256 ) ), dim3( 256 ), 0, s, d_mod, F, bins, sr, float( hop ), d_flags );
-		FLANHIP_CHECK( hipGetLastError() );
-		}
-	// monotone maps (every stretch): output chains of 64 frames, one thread per (channel, bin, chain) -- see k_modify_time_chains
+	const size_t flag_bytes = ( sizeof( int ) * size_t( bins + 1 ) + 255 ) / 256 * 256;   // (a whole number of 256-byte pieces: the runtime's fill is then one kernel, not two)
+	FLANHIP_CHECK( hipMallocAsync( reinterpret_cast<void**>( &d_flags ), flag_bytes, s ) );
+	FLANHIP_CHECK( hipMemsetAsync( d_flags, 0, flag_bytes, s ) );
+	// monotone maps (every stretch): output chains of 32 frames, one thread per (channel, bin, chain) -- see k_modify_time_chains
 	TimeChainParams cp{};
 	cp.in = (const MFd*) d_pv; cp.mod = d_mod; cp.out = (MFd*) d_out;
-	cp.F = F; cp.Fo = Fo; cp.num_channels = int( ch ); cp.bins = bins; cp.L = 64; cp.chains_per_channel = int( ( Fo + 63 ) / 64 );
+	cp.F = F; cp.Fo = Fo; cp.num_channels = int( ch ); cp.bins = bins; cp.L = 32; cp.chains_per_channel = int( ( Fo + cp.L - 1 ) / cp.L );
 	cp.sr = sr; cp.hop = float( hop ); cp.nonmono = d_flags; cp.interp = interp;
-	const int64_t owners = ch * int64_t( cp.chains_per_channel ) * bins;
-	hipLaunchKernelGGL( k_modify_time_chains<false>, dim3( (unsigned) ( ( ( owners + 255 ) / 256 + 7 ) / 8 * 8 ) ), dim3( 256 ), 0, s, cp );
-	FLANHIP_CHECK( hipGetLastError() );
+	if( int rc = launch_time_chains<false>( cp, s ) ) return rc;
 	// the general walk, for a PV with a column that runs backwards (retires at once otherwise):
 	// enough (column, segment) threads to fill the chip, segments of at least 16 frame pairs
 	const int64_t columns = ch * bins;
@@ -557,7 +650,7 @@ static int modify_time_dev_impl( const flanhip_MF * d_pv, int64_t ch, int64_t F,
 	const int64_t seg_len = std::max<int64_t>( ( F - 1 + segments - 1 ) / segments, 1 );
 	const int64_t threads = columns * segments;
 	hipLaunchKernelGGL( k_modify_time, dim3( (unsigned) ( ( threads + 255 ) / 256 ) ), dim3( 256 ), 0, s,
-		(const MFd*) d_pv, int( ch ), F, bins, sr, float( hop ), d_mod, Fo, (MFd*) d_out, d_flags, segments, seg_len, 1, interp );
+		(const MFd*) d_pv, int( ch ), F, bins, sr, float( hop ), d_mod, Fo, (MFd*) d_out, d_flags, segments, seg_len, 1, interp, nullptr, 0 );
 	FLANHIP_CHECK( hipGetLastError() );
 	FLANHIP_CHECK( hipFreeAsync( d_flags, s ) );
 	return FLANHIP_OK;
@@ -575,33 +668,29 @@ static int modify_time_dev_fused_impl( const flanhip_MF * d_pv, int64_t ch, int6
 	if( int rc = synth_layout( ch, Fo, bins, sr, analysis_rate, window_size, &lay ) ) return rc;
 	const int hop = lay.hop;                                                       // PVBuffer.cpp:381-384: what PV::modify_time works with
 	int * d_flags = nullptr;                                                       // per bin: does the time map ever run backwards?  [bins]: any
-	FLANHIP_CHECK( hipMallocAsync( reinterpret_cast<void**>( &d_flags ), sizeof( int ) * ( bins + 1 ), s ) );
-	FLANHIP_CHECK( hipMemsetAsync( d_flags, 0, sizeof( int ) * ( bins + 1 ), s ) );
-	if( F > 1 )
-		{
-		const int64_t pairs = ( F - 1 ) * bins;
-		hipLaunchKernelGGL( k_time_map_flags, dim3( (unsigned) ( ( pairs + 255 ) / 256 ) ), dim3( 256 ), 0, s, d_mod, F, bins, sr, float( hop ), d_flags );
-		FLANHIP_CHECK( hipGetLastError() );
-		}
+	const size_t flag_bytes = ( sizeof( int ) * size_t( bins + 1 ) + 255 ) / 256 * 256;   // (a whole number of 256-byte pieces: the runtime's fill is then one kernel, not two)
+	FLANHIP_CHECK( hipMallocAsync( reinterpret_cast<void**>( &d_flags ), flag_bytes, s ) );
+	FLANHIP_CHECK( hipMemsetAsync( d_flags, 0, flag_bytes, s ) );
 	TimeChainParams p{};
 	p.in = (const MFd*) d_pv; p.mod = d_mod; p.out = (MFd*) d_out;
 	p.F = F; p.Fo = Fo; p.num_channels = int( ch ); p.bins = bins; p.L = lay.L; p.chains_per_channel = lay.chains_per_channel;
 	p.sr = sr; p.hop = float( hop ); p.analysis_rate = analysis_rate;
+	DivPlan dp;
+	if( int rc = get_div_plan( analysis_rate, &dp ) ) return rc;
+	p.ar_div = DivC{ dp.c, dp.rc, dp.exact };
 	p.sums = reinterpret_cast<double*>( d_ws );
 	p.words = reinterpret_cast<int*>( reinterpret_cast<char*>( d_ws ) + lay.carry_bytes + lay.head_bytes );
 	p.epoch = next_epoch();
 	p.nonmono = d_flags; p.interp = interp;
 	note_workspace_producer( d_ws, 0 );                                               // chain sums (maybe), no group totals: convert_to_audio runs its scan
-	const int64_t owners = ch * int64_t( lay.chains_per_channel ) * bins;
-	hipLaunchKernelGGL( k_modify_time_chains<true>, dim3( (unsigned) ( ( ( owners + 255 ) / 256 + 7 ) / 8 * 8 ) ), dim3( 256 ), 0, s, p );
-	FLANHIP_CHECK( hipGetLastError() );
+	if( int rc = launch_time_chains<true>( p, s ) ) return rc;
 	// the general walk, for a PV with a column that runs backwards: retires at once otherwise
 	const int64_t columns = ch * bins;
 	int segments = int( std::min<int64_t>( std::max<int64_t>( ( 256 * 2048 + columns - 1 ) / columns, 1 ), std::max<int64_t>( ( F - 1 ) / 16, 1 ) ) );
 	const int64_t seg_len = std::max<int64_t>( ( F - 1 + segments - 1 ) / segments, 1 );
 	const int64_t threads = columns * segments;
 	hipLaunchKernelGGL( k_modify_time, dim3( (unsigned) ( ( threads + 255 ) / 256 ) ), dim3( 256 ), 0, s,
-		(const MFd*) d_pv, int( ch ), F, bins, sr, float( hop ), d_mod, Fo, (MFd*) d_out, d_flags, segments, seg_len, 1, interp );
+		(const MFd*) d_pv, int( ch ), F, bins, sr, float( hop ), d_mod, Fo, (MFd*) d_out, d_flags, segments, seg_len, 1, interp, p.words, p.epoch );
 	FLANHIP_CHECK( hipGetLastError() );
 	FLANHIP_CHECK( hipFreeAsync( d_flags, s ) );
 	return FLANHIP_OK;
