@@ -75,7 +75,7 @@ for v in variants:
     del a, b, c
 for r in range(args.rounds):
     for v in variants:
-            for name, fn in (("fused", fused), ("plain", plain)):
+        for name, fn in (("fused", fused), ("plain", plain)):
             fn(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
