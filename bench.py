@@ -6,11 +6,11 @@ One "step" = one pass of the hot path over one batch of synthetic audio that is 
 Workload at N=1: 8 channels x 60 s x 48 kHz uniform noise (the configuration BASELINE.json's north_star quotes its targets on:
 "60 s x 8-ch 48 kHz convertToPV->convertToAudio round-trip at 1 GPU").  With --gpus N every rank owns its own 8 channels
 (channels are independent: AudioPV.cpp:41,44,108,111), so the job is 8N channels, "scaling": "weak", with no collective inside
-the timed region.  `--gpus N` with N > 1 and no WORLD_SIZE in the environment LAUNCHES the N ranks itself (torch.distributed.run,
+the compute.  `--gpus N` with N > 1 and no WORLD_SIZE in the environment LAUNCHES the N ranks itself (torch.distributed.run,
 one process per GPU, 127.0.0.1 rendezvous) before anything here touches a GPU; under torchrun / the driver's own launch it is
 one of those ranks.  The RCCL all-gather that reassembles the output buffer (float[8N][frames], channel-major, so the gathered
-buffer IS the final layout) is reported beside the metric in "allgather": once on its own and once overlapped with the compute,
-per channel chunk on a side stream -- it is not part of the PV frames/s value.
+buffer IS the final layout) is INSIDE the timed step at N > 1, overlapped with the next batch's compute on a side stream (the north star's
+path ends with it): `value` includes it, `value_compute_only` and the not-overlapped figure stand beside it ("allgather").
 
 --seconds 600 gives the per-GPU shard of BASELINE config 4 (64 ch x 10 min over 8 GPUs = 8 ch x 600 s each).
 
@@ -53,7 +53,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--gather-chunks", type=int, default=1, help="channel chunks per batch in the overlapped all-gather measurement (1: whole batches, double buffered)")
     ap.add_argument("--no-configs", action="store_true", help="skip the 'configs' object (BASELINE configs 3 and 5, the API-default dft 4096 call)")
-    ap.add_argument("--kernel-variant", default="", help="diagnostic: WHICH=VARIANT[,..] for flanhip_debug_kernel_variant (A/B of kernel generations; never for the metric)")
+    ap.add_argument("--kernel-variant", default="", help="diagnostic: WHICH=VALUE[,..] for flanhip_debug_option (A/B of kernel generations, chain lengths; never for the metric)")
     ap.add_argument("--unfused", action="store_true", help="run synthesis' pre-pass as its own kernel instead of inside analysis")
     ap.add_argument("--preroll-ms", type=float, default=80.0,
                     help="untimed device warm-up before the W warm-up steps: the same steps run for this long so that the GPU's clocks "
@@ -184,7 +184,7 @@ def main():
     fa.check(fa.lib.flanhip_set_device(dev_index))
     for kv in filter(None, args.kernel_variant.split(",")):
         which, variant = (int(v) for v in kv.split("="))
-        fa.lib.flanhip_debug_kernel_variant(which, variant)
+        fa.lib.flanhip_debug_option(which, variant)
     dev = torch.device("cuda", dev_index)
     dist = None
     if distributed:
@@ -222,11 +222,10 @@ def main():
         else:
             fa.analyze_dev_fused(a, c, n, SR, WINDOW, HOP, DFT, p, w, s)
 
-    def synthesize(p=pv, o=out, w=ws, c=ch, s=stream):
-        if args.unfused:
-            fa.synthesize_dev(p, c, F, BINS, SR, ar, WINDOW, o, w, nan_flag, s)
-        else:
-            fa.synthesize_dev_fused(p, c, F, BINS, SR, ar, WINDOW, o, w, nan_flag, s)
+    def synthesize(p=pv, o=out, w=ws, c=ch, s=stream, stages=0xF):
+        # stages (a per-call argument): which of the call's kernels are launched -- 1 k_phase_sums, 2 k_phase_scan, 4 k_synthesize, 8 k_ola_fixup;
+        # the per-kernel timing below brackets one at a time, every other call launches all of them
+        fa.synthesize_dev_stages(p, c, F, BINS, SR, ar, WINDOW, o, w, nan_flag, 0 if args.unfused else 1, stages, s)
 
     def step():
         analyze()
@@ -259,18 +258,86 @@ def main():
                 step()
             torch.cuda.synchronize()
             preroll_steps += 10
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        elapsed = sharding.max_over_ranks(dist, elapsed, ctl_dev)
+    # ---- N > 1: the north star's path ends with ONE all-gather that reassembles the output, so the timed step of a multi-GPU job includes it --
+    # overlapped: batch i's output travels (one batch of point-to-point operations straight into the final channel-major buffer, on a side
+    # stream) while batch i + 1 is analysed and synthesised, two output buffers in turn; with --gather-chunks K > 1 the rank's channels are
+    # additionally cut into K chunks per batch, each sent as soon as it is done (smaller launches: slower compute).  `value` is that;
+    # `value_compute_only` (the K steps without the gather: >= 6x at N = 8 by construction, channels being independent) stands beside it.
+    # Every side buffer is allocated BEFORE the first collective and the ranks agree (one all-reduce) that all of them got theirs: a rank that
+    # cannot allocate would otherwise leave the others waiting in a collective for ever.  Past that point nothing is caught: an error inside a
+    # collective ends the rank, and the launcher ends the job -- a failed job, not a hung one.
+    use_gather = distributed and not args.no_gather and not share_gpu
+    gather_err = None
+    if use_gather:
+        chunks = max(1, min(args.gather_chunks, ch))
+        while ch % chunks:
+            chunks -= 1
+        k = ch // chunks
+        side_ok, side_err = 1, None
+        try:
+            side = torch.cuda.Stream(device=dev)
+            outs = [out, torch.empty_like(out)]
+            finals = [torch.empty((world * ch, F * HOP), dtype=torch.float32, device=dev) for _ in range(2)]
+            wss = [torch.empty(fa.synthesize_workspace_bytes(k, F, BINS, SR, ar, WINDOW), dtype=torch.uint8, device=dev) for _ in range(chunks)]
+        except Exception as e:
+            side_ok, side_err = 0, repr(e)
+        if sharding.min_over_ranks(dist, side_ok, ctl_dev) < 1:
+            use_gather, gather_err = False, "a rank could not allocate the gather buffers: " + str(side_err)
+    if use_gather:
+        pending = [[], []]
+        counter = [0]
+
+        def step_with_gather():
+            i = counter[0]
+            counter[0] += 1
+            b = i & 1
+            for r in pending[b]:                     # the gather that last used this pair of buffers
+                r.wait()
+            pending[b] = []
+            torch.cuda.current_stream().wait_stream(side)
+            for c in range(chunks):
+                c0 = c * k
+                o = outs[b][c0:c0 + k]
+                analyze(audio[c0:c0 + k], pv[c0:c0 + k], wss[c], k)
+                synthesize(pv[c0:c0 + k], o, wss[c], k)
+                done = torch.cuda.Event()
+                done.record()
+                side.wait_event(done)
+                with torch.cuda.stream(side):
+                    pending[b] += sharding.gather_chunk_into(dist, finals[b], o, rank, world, ch, c0)
+
+        def drain():
+            for b in (0, 1):
+                for r in pending[b]:
+                    r.wait()
+                pending[b] = []
+            torch.cuda.current_stream().wait_stream(side)
+
+    def timed_region(step_fn, finish_fn):
+        """W untimed steps, then exactly K steps between barriers + device synchronisation; the slowest rank's time"""
+        for _ in range(args.warmup):
+            step_fn()
+        finish_fn()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_fn()
+        finish_fn()
+        sync_all()
+        dt = time.perf_counter() - t0
+        return sharding.max_over_ranks(dist, dt, ctl_dev) if distributed else dt
+
+    elapsed_compute = None
+    if use_gather:
+        elapsed = timed_region(step_with_gather, drain)
+        for b in (0, 1):
+            assert bool(torch.equal(finals[b][rank * ch: rank * ch + ch], outs[b])), "the gathered buffer must hold this rank's channels in place"
+        elapsed_compute = timed_region(step, lambda: None)
+    else:
+        elapsed = timed_region(step, lambda: None)
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * frames_per_step * args.steps / elapsed
+    value_compute_only = world * frames_per_step * args.steps / elapsed_compute if elapsed_compute else None
     # SURVEY 8(d): "hipEvent-timed, median of >= 20 runs" -- the same step, each one bracketed by events on the launch stream, reported
     # beside the contract's barrier-to-barrier mean over K steps
     n_med = max(20, min(args.steps, 200))
@@ -285,7 +352,7 @@ def main():
 
     # per-kernel timing with events on the launch stream (rank 0 only), inside the same analyse -> synthesise sequence as the
     # timed region: events bracket k_analyze, the pre-pass (k_phase_sums unless fused, k_phase_scan), k_synthesize and
-    # k_ola_fixup of every step (flanhip_debug_synth_stages selects which synthesis kernels a call launches)
+    # k_ola_fixup of every step (the `stages` argument of flanhip_synthesize_dev_stages selects which synthesis kernels a call launches)
     extra = {}
     roofline = None
     if rank == 0:
@@ -297,13 +364,11 @@ def main():
             analyze()
             ev[1].record()
             for i, mask in enumerate((1 | 2, 4, 8)):
-                fa.lib.flanhip_debug_synth_stages(mask)
-                synthesize()
+                synthesize(stages=mask)
                 ev[2 + i].record()
             torch.cuda.synchronize()
             for i in range(4):
                 acc[i] += ev[i].elapsed_time(ev[i + 1]) / reps
-        fa.lib.flanhip_debug_synth_stages(0xF)
         t_an, t_pre, t_sy_main, t_fix = acc
         extra["kernel_ms"] = {"k_analyze": round(t_an, 4), "prepass": round(t_pre, 4), "k_synthesize": round(t_sy_main, 4),
                               "k_ola_fixup": round(t_fix, 4), "fused": not args.unfused}
@@ -356,88 +421,30 @@ def main():
         extra["roundtrip_hbm"] = {"achieved_GBs": round(frames_per_step * BYTES_ROUNDTRIP / (ms_per_step * 1e-3) / 1e9, 1),
                                   "frac_of_8TBs": round(frames_per_step * BYTES_ROUNDTRIP / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
-    # ---- the output-reassembly all-gather of the north star, outside the metric: on its own, and overlapped with the compute ----
-    if distributed and not args.no_gather and not share_gpu:
-        # every side buffer is allocated BEFORE the first collective and the ranks agree (one all-reduce) that all of them got theirs: a rank
-        # that cannot allocate would otherwise leave the others waiting in a collective for ever.  Past that point nothing is caught: an
-        # error inside a collective ends the rank, and the launcher ends the job -- a failed job, not a hung one.
-        chunks = max(1, min(args.gather_chunks, ch))
-        while ch % chunks:
-            chunks -= 1
-        k = ch // chunks
-        side_ok, side_err = 1, None
-        try:
-            side = torch.cuda.Stream(device=dev)
-            outs = [out, torch.empty_like(out)]
-            finals = [torch.empty((world * ch, F * HOP), dtype=torch.float32, device=dev) for _ in range(2)]
-            wss = [torch.empty(fa.synthesize_workspace_bytes(k, F, BINS, SR, ar, WINDOW), dtype=torch.uint8, device=dev) for _ in range(chunks)]
-        except Exception as e:
-            side_ok, side_err = 0, repr(e)
-        all_ok = sharding.min_over_ranks(dist, side_ok, ctl_dev) >= 1
-        if not all_ok:
-            extra["allgather"] = {"error": "a rank could not allocate the gather buffers: " + str(side_err)}
-        else:
-            nranks = dist.get_world_size()
-            for _ in range(2):
-                gathered = sharding.gather_output(dist, out, world)
-            sync_all()
-            t0 = time.perf_counter()
-            reps = 5
-            for _ in range(reps):
-                gathered = sharding.gather_output(dist, out, world)
-            sync_all()
-            tg = sharding.max_over_ranks(dist, (time.perf_counter() - t0) / reps, ctl_dev)
-            assert gathered.shape == (world * ch, F * HOP)
-            del gathered
-            # overlapped: batch i's output travels (one batch of point-to-point operations into the final channel-major buffer, on a side
-            # stream) while batch i + 1 is analysed and synthesised -- two output buffers in turn; with --gather-chunks K > 1 the rank's
-            # channels are additionally cut into K chunks per batch, each sent as soon as it is done (smaller launches: slower compute)
-            pending = [[], []]
-
-            def step_with_gather(i):
-                b = i & 1
-                for r in pending[b]:                     # the gather that last used this pair of buffers
-                    r.wait()
-                pending[b] = []
-                torch.cuda.current_stream().wait_stream(side)
-                for c in range(chunks):
-                    c0 = c * k
-                    o = outs[b][c0:c0 + k]
-                    analyze(audio[c0:c0 + k], pv[c0:c0 + k], wss[c], k)
-                    synthesize(pv[c0:c0 + k], o, wss[c], k)
-                    done = torch.cuda.Event()
-                    done.record()
-                    side.wait_event(done)
-                    with torch.cuda.stream(side):
-                        pending[b] += sharding.gather_chunk_into(dist, finals[b], o, rank, world, ch, c0)
-
-            def drain():
-                for b in (0, 1):
-                    for r in pending[b]:
-                        r.wait()
-                    pending[b] = []
-                torch.cuda.current_stream().wait_stream(side)
-
-            for i in range(4):
-                step_with_gather(i)
-            drain()
-            sync_all()
-            t0 = time.perf_counter()
-            reps = max(6, min(args.steps, 20))
-            for i in range(reps):
-                step_with_gather(i)
-            drain()
-            sync_all()
-            tov = sharding.max_over_ranks(dist, (time.perf_counter() - t0) / reps, ctl_dev)
-            for b in (0, 1):
-                assert bool(torch.equal(finals[b][rank * ch: rank * ch + ch], outs[b])), "the gathered buffer must hold this rank's channels in place"
-            extra["allgather"] = {"nranks": nranks, "ms_alone": round(tg * 1e3, 3), "bytes_per_rank": out.numel() * 4,
-                                  "frames_per_s_compute_only": round(value, 1),
-                                  "frames_per_s_compute_then_gather": round(world * frames_per_step / (elapsed / args.steps + tg), 1),
-                                  "frames_per_s_gather_overlapped": round(world * frames_per_step / tov, 1),
-                                  "overlapped_step_ms": round(tov * 1e3, 4), "channel_chunks": chunks,
-                                  "overlap": "gather of batch i (side stream, p2p batch into the final layout) under the compute of batch i + 1"}
-            del finals, outs, wss
+    # ---- the same all-gather on its own (not overlapped), for the record beside the overlapped step the metric is quoted on ----
+    if gather_err:
+        extra["allgather"] = {"error": gather_err}
+    elif use_gather:
+        nranks = dist.get_world_size()
+        for _ in range(2):
+            gathered = sharding.gather_output(dist, out, world)
+        sync_all()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            gathered = sharding.gather_output(dist, out, world)
+        sync_all()
+        tg = sharding.max_over_ranks(dist, (time.perf_counter() - t0) / reps, ctl_dev)
+        assert gathered.shape == (world * ch, F * HOP)
+        del gathered
+        t_compute = elapsed_compute / args.steps
+        extra["allgather"] = {"nranks": nranks, "ms_alone": round(tg * 1e3, 3), "bytes_per_rank": out.numel() * 4,
+                              "frames_per_s_compute_only": round(value_compute_only, 1),
+                              "frames_per_s_compute_then_gather": round(world * frames_per_step / (t_compute + tg), 1),
+                              "frames_per_s_gather_overlapped": round(value, 1),
+                              "overlapped_step_ms": round(ms_per_step, 4), "compute_only_step_ms": round(t_compute * 1e3, 4), "channel_chunks": chunks,
+                              "overlap": "gather of batch i (side stream, p2p batch into the final layout) under the compute of batch i + 1"}
+        del finals, outs, wss
 
     # the host-buffer C ABI (flanhip_analyze / flanhip_synthesize): upload, kernels, download -- for DESIGN.md, never the metric
     if rank == 0 and args.pcie:
@@ -497,7 +504,10 @@ def main():
         line["value_median"] = round(world * frames_per_step / (step_ms_median * 1e-3), 1) if world == 1 else None
         line["value_cold"] = cold["frames_per_s"] if cold else None       # a just-woken GPU, 5 steps after 1 (no clock pre-roll)
         ag = extra.get("allgather") or {}
-        # what the N-GPU job delivers with the north star's output reassembly inside: the same frames / the time including the gather
+        # N > 1: `value` is the step WITH the north star's output reassembly (the all-gather overlapped with the next batch's compute);
+        # the compute-only figure and the not-overlapped one stand beside it.  N = 1: there is nothing to gather, `value` is the round trip
+        line["value_includes_gather"] = bool(use_gather)
+        line["value_compute_only"] = round(value_compute_only, 1) if value_compute_only else None
         line["value_gather_overlapped"] = ag.get("frames_per_s_gather_overlapped")
         line["value_compute_then_gather"] = ag.get("frames_per_s_compute_then_gather")
         line["rccl_nranks"] = ag.get("nranks")
@@ -553,6 +563,61 @@ def other_configs(fa, torch, dev):
     ar = SR / HOP
     audio = torch.empty((ch, n), dtype=torch.float32, device=dev)
     fa.check(lib.flanhip_noise_dev(P(audio), ch, n, 1234, None))
+
+    # ---- config 2: stereo 60 s, convert_to_PV -> convert_to_audio round trip (fused, like the headline) with its kernels timed one by one
+    c2 = 2
+    pv2 = torch.empty((c2, F, BINS, 2), dtype=torch.float32, device=dev)
+    out2 = torch.empty((c2, F * HOP), dtype=torch.float32, device=dev)
+    ws2 = torch.empty(fa.synthesize_workspace_bytes(c2, F, BINS, SR, ar, W), dtype=torch.uint8, device=dev)
+
+    def config2(stages=0xF):
+        fa.analyze_dev_fused(audio, c2, n, SR, W, HOP, DFT, pv2, ws2, None)
+        fa.synthesize_dev_stages(pv2, c2, F, BINS, SR, ar, W, out2, ws2, None, 1, stages, None)
+    ms2 = timed(config2, tag="config2")
+    k2 = [0.0] * 4
+    reps2 = 20
+    for _ in range(reps2):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        ev[0].record()
+        fa.analyze_dev_fused(audio, c2, n, SR, W, HOP, DFT, pv2, ws2, None)
+        ev[1].record()
+        for i, mask in enumerate((1 | 2, 4, 8)):
+            fa.synthesize_dev_stages(pv2, c2, F, BINS, SR, ar, W, out2, ws2, None, 1, mask, None)
+            ev[2 + i].record()
+        torch.cuda.synchronize()
+        for i in range(4):
+            k2[i] += ev[i].elapsed_time(ev[i + 1]) / reps2
+    b_rt = 2 * (HOP * 4 + BINS * 8)
+    res["config2_stereo_60s"] = {"workload": "2 ch x 60 s: convert_to_PV(2048,512,2048) -> convert_to_audio", "ms": round(ms2, 4), "ms_cold": cold_ms["config2"],
+                                 "frames_per_s": round(c2 * F / (ms2 * 1e-3), 1), "algorithmic_GBs": round(c2 * F * b_rt / (ms2 * 1e-3) / 1e9, 1),
+                                 "frac_of_8TBs": round(c2 * F * b_rt / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "kernel_ms": {"k_analyze": round(k2[0], 4), "scan (k_phase_scan2 over the group totals)": round(k2[1], 4),
+                                               "k_synthesize": round(k2[2], 4), "k_ola_fixup": round(k2[3], 4)}}
+    del pv2, out2, ws2
+
+    # ---- config 4's per-GPU shard: 8 ch x 600 s (64 ch x 10 min over 8 GPUs), the same round trip on one GPU (a 3.7 GB PV)
+    n4 = 600 * 48000
+    F4 = int(lib.flanhip_num_pv_frames(n4, HOP))
+    try:
+        audio4 = torch.empty((ch, n4), dtype=torch.float32, device=dev)
+        fa.check(lib.flanhip_noise_dev(P(audio4), ch, n4, 4321, None))
+        pv4 = torch.empty((ch, F4, BINS, 2), dtype=torch.float32, device=dev)
+        out4 = torch.empty((ch, F4 * HOP), dtype=torch.float32, device=dev)
+        ws4 = torch.empty(fa.synthesize_workspace_bytes(ch, F4, BINS, SR, ar, W), dtype=torch.uint8, device=dev)
+
+        def config4():
+            fa.analyze_dev_fused(audio4, ch, n4, SR, W, HOP, DFT, pv4, ws4, None)
+            fa.synthesize_dev_fused(pv4, ch, F4, BINS, SR, ar, W, out4, ws4, None, None)
+        ms4 = timed(config4, 3, tag="config4")
+        res["config4_shard_8ch_600s"] = {"workload": "8 ch x 600 s (one GPU's shard of 64 ch x 10 min over 8 GPUs): convert_to_PV(2048,512,2048) -> convert_to_audio",
+                                         "ms": round(ms4, 4), "ms_cold": cold_ms["config4"], "frames_per_s": round(ch * F4 / (ms4 * 1e-3), 1),
+                                         "algorithmic_GBs": round(ch * F4 * b_rt / (ms4 * 1e-3) / 1e9, 1),
+                                         "frac_of_8TBs": round(ch * F4 * b_rt / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                         "pv_bytes": ch * F4 * BINS * 8}
+        del audio4, pv4, out4, ws4
+    except Exception as e:
+        res["config4_shard_8ch_600s"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
 
     # ---- config 3: 8 ch x 60 s -> convert_to_PV -> stretch( x2 ) -> convert_to_audio (PVModify.cpp:371-385, :307-362)
     pv = torch.empty((ch, F, BINS, 2), dtype=torch.float32, device=dev)

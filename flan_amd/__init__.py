@@ -64,9 +64,8 @@ _SIGS = {
     "flanhip_synthesize_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp]),
     "flanhip_analyze_dev_fused": (C.c_int, [_vp, _i64, _i64, _f32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "flanhip_synthesize_dev_fused": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp]),
-    "flanhip_debug_synth_stages": (None, [_i32]),
-    "flanhip_debug_kernel_variant": (None, [_i32, _i32]),
-    "flanhip_debug_resample_fft": (None, [_i32]),
+    "flanhip_synthesize_dev_stages": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "flanhip_debug_option": (None, [_i32, _i32]),
     "flanhip_modify_time": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i32, _vp, _i64, _vp, _vp]),
     "flanhip_modify_time_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i32, _vp, _i64, _vp, _vp]),
     "flanhip_modify_time_dev_fused": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _vp, _i64, _vp, _i32, _vp, _vp]),
@@ -564,6 +563,37 @@ def analyze_dev_fused(d_audio, ch, n, sample_rate, window, hop, dft, d_out, d_ws
 def synthesize_dev_fused(d_pv, ch, F, bins, sample_rate, analysis_rate, window, d_out, d_ws, d_nan=None, stream=None):
     check(lib.flanhip_synthesize_dev_fused(_dp(d_pv), ch, F, bins, sample_rate, analysis_rate, window, _dp(d_out), _dp(d_ws),
                                            _dp(d_nan), _vp(stream or 0)))
+
+
+def synthesize_dev_stages(d_pv, ch, F, bins, sample_rate, analysis_rate, window, d_out, d_ws, d_nan, presummed, stages, stream=None):
+    """flanhip_synthesize_dev (presummed 0) / _fused (1) / _fused_checked (2) with the kernels to launch as a per-call argument
+    (1 k_phase_sums, 2 k_phase_scan, 4 k_synthesize, 8 k_ola_fixup): bench.py times one kernel at a time with it"""
+    check(lib.flanhip_synthesize_dev_stages(_dp(d_pv), ch, F, bins, sample_rate, analysis_rate, window, _dp(d_out), _dp(d_ws),
+                                            _dp(d_nan), presummed, stages, _vp(stream or 0)))
+
+
+# flanhip_debug_option: per-thread test / A-B hooks (include/flanhip.h)
+DEBUG_CHAIN_LEN, DEBUG_TARGET_CHAINS, DEBUG_FORCE_GENERIC, DEBUG_NO_FAST_DIV = 0, 1, 2, 3
+DEBUG_ANA_VARIANT, DEBUG_SYN_VARIANT, DEBUG_ANA4096_OLD, DEBUG_SYN4096_OLD, DEBUG_RESAMPLE_DIRECT = 4, 5, 6, 7, 8
+_DEBUG_NAMES = {"chain_len": 0, "target_chains": 1, "force_generic": 2, "no_fast_div": 3, "ana_variant": 4, "syn_variant": 5,
+                "ana4096_old": 6, "syn4096_old": 7, "resample_direct": 8}
+
+
+class debug_options:
+    """with fa.debug_options(chain_len=37): ...   -- the calling thread's hooks set for the block, cleared (0) afterwards"""
+
+    def __init__(self, **kw):
+        self.kw = {_DEBUG_NAMES[k]: int(v) for k, v in kw.items()}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            lib.flanhip_debug_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kw:
+            lib.flanhip_debug_option(k, 0)
+        return False
 
 
 def synthesize_workspace_bytes(ch, F, bins, sample_rate, analysis_rate, window):

@@ -13,14 +13,10 @@
 
 namespace flanhip {
 
-static int g_synth_stage_mask = 0xF;             // flanhip_debug_synth_stages(): 1 sums, 2 scan, 4 main, 8 fix-up
-// flanhip_debug_kernel_variant(): dft 2048 has ONE kernel generation (pv_kernels_v2.h); the variant numbers of `which` 0 / 1 select the
-// phase-ablated instantiations of diagnostic builds (FLANHIP_ABLATIONS: 101 ... for the analysis, 102 ... for the synthesis) and, for the
-// synthesis, 2 = behind the scan kernel even where it could work out its own carries.  dft 4096 keeps its round-1 kernels as the A/B
-// predecessor (`which` 2 / 3, variant 0) -- they are also what windows above 2048 run.
-static int g_ana_variant = 4, g_syn_variant = 1;
-static int g_syn11_variant = 1;          // dft 4096 synthesis, window <= 2048, hop 256 / 512 / 1024: 1 = teams of two wavefronts (pv_kernels_eo.h), 0 = the round-1 kernel
-static int g_ana11_variant = 1;          // dft 4096, window <= 2048: 1 = teams of two wavefronts, two 1024-point transforms per frame (pv_kernels_eo.h), 0 = the round-1 kernel
+// dft 2048 has ONE kernel generation (pv_kernels_v2.h); flanhip_debug_option's ANA / SYN_VARIANT select the phase-ablated instantiations of
+// diagnostic builds (FLANHIP_ABLATIONS: 101 ... for the analysis, 102 ... for the synthesis) and, for the synthesis, 2 = behind the scan
+// kernel even where it could work out its own carries.  dft 4096 keeps its round-1 kernels as the A/B predecessor (ANA4096_OLD / SYN4096_OLD)
+// -- they are also what windows that are no multiple of 256 run.  All per calling thread (core.hip: debug_options).
 static constexpr size_t kMaxLds = 160 * 1024;   // gfx950: 160 KiB LDS per CU, one workgroup may take all of it
 
 // dft sizes: powers of two in [32, 8192] have FFT kernels (tuned or LDS-resident); every other EVEN size the reference would hand to FFTW
@@ -96,12 +92,13 @@ static int run_analyze( const AnalyzeParams & p, hipStream_t s )
 static constexpr int kSynWaves10 = 8, kWaves11 = 4;
 static constexpr int kTeamWaves12 = 8;           // generic kernels at dft 8192: one chain per block of 8 wavefronts (8 bins per thread), one block per CU
 // chains the chip holds at once for the generic kernels (one chain per team from dft 1024 up, LDS decides how many teams a CU takes)
-static int generic_target_chains( int dft ) { return dft >= 8192 ? 256 : dft == 4096 ? 512 : dft == 2048 ? 1024 : 4096; }
+static int generic_target_chains( int dft ) { const int cus = cu_count(); return dft >= 8192 ? cus : dft == 4096 ? 2 * cus : dft == 2048 ? 4 * cus : 16 * cus; }
+// ... of the tuned kernels: every SIMD of the device holds two wavefronts of the dft 2048 kernels (8 chains per CU), one two-wavefront team
+// of the dft 4096 ones (4 per CU) -- counted from the device's own CU count (a CPX partition has 32, not 256)
 static int fast_target_chains( int dft, bool synth )
 	{
-	if( const char * env = std::getenv( "FLANHIP_TARGET_CHAINS" ) ) { const int v = std::atoi( env ); if( v > 0 ) return v; }
-	if( dft == 4096 ) return 256 * 4;
-	return 256 * 8;
+	if( const int v = debug_options().target_chains ) { if( v > 0 ) return v; }
+	return cu_count() * ( dft == 4096 ? 4 : 8 );
 	}
 
 template<int WAVES, bool SUMS, int NV, int ABL = 0>
@@ -243,11 +240,11 @@ static int run_synth_fast_hop( const SynthParams & p, const FastTables & tb, hip
 		{
 		// v2: the register-accumulator hops of dft 2048
 #ifdef FLANHIP_ABLATIONS
-		if( g_syn_variant == 102 && p.hop == 512 ) return run_synth_v2<8, 4, 2>( p, tb, s );
-		if( g_syn_variant == 104 && p.hop == 512 ) return run_synth_v2<8, 4, 4>( p, tb, s );
-		if( g_syn_variant == 106 && p.hop == 512 ) return run_synth_v2<8, 4, 6>( p, tb, s );
-		if( g_syn_variant == 108 && p.hop == 512 ) return run_synth_v2<8, 4, 8>( p, tb, s );
-		if( g_syn_variant == 114 && p.hop == 512 ) return run_synth_v2<8, 4, 14>( p, tb, s );
+		if( debug_options().syn_variant == 102 && p.hop == 512 ) return run_synth_v2<8, 4, 2>( p, tb, s );
+		if( debug_options().syn_variant == 104 && p.hop == 512 ) return run_synth_v2<8, 4, 4>( p, tb, s );
+		if( debug_options().syn_variant == 106 && p.hop == 512 ) return run_synth_v2<8, 4, 6>( p, tb, s );
+		if( debug_options().syn_variant == 108 && p.hop == 512 ) return run_synth_v2<8, 4, 8>( p, tb, s );
+		if( debug_options().syn_variant == 114 && p.hop == 512 ) return run_synth_v2<8, 4, 14>( p, tb, s );
 #endif
 		switch( p.hop / 128 )
 			{
@@ -257,7 +254,7 @@ static int run_synth_fast_hop( const SynthParams & p, const FastTables & tb, hip
 			case 8: return run_synth_v2<8, 8>( p, tb, s );
 			}
 		}
-	if( LOG2C == 11 && g_syn11_variant != 0 && p.window_size <= 2048 && synth_fast_kind( 2 << LOG2C, p.window_size, p.hop ) == 1 )
+	if( LOG2C == 11 && !debug_options().syn11_old && p.window_size <= 2048 && synth_fast_kind( 2 << LOG2C, p.window_size, p.hop ) == 1 )
 		{
 		// dft 4096, window <= 2048, hop 128 / 256 / 512 / 1024: teams of two wavefronts, two 1024-point transforms per frame (pv_kernels_eo.h)
 		if( p.hop == 128 && p.window_size % 256 == 0 ) return run_synth_eo_team<4, 0>( p, tb, s );
@@ -268,7 +265,7 @@ static int run_synth_fast_hop( const SynthParams & p, const FastTables & tb, hip
 			case 4: return run_synth_eo_team<4, 4>( p, tb, s );
 			}
 		}
-	if( LOG2C == 11 && g_syn11_variant != 0 && p.window_size > 2048 && p.window_size % 256 == 0 && synth_fast_kind( 2 << LOG2C, p.window_size, p.hop ) == 1 )
+	if( LOG2C == 11 && !debug_options().syn11_old && p.window_size > 2048 && p.window_size % 256 == 0 && synth_fast_kind( 2 << LOG2C, p.window_size, p.hop ) == 1 )
 		{
 		// dft 4096 with windows above 2048 (window = dft is the plain STFT call): the same teams with full-length transforms, one buffer set
 		// (pv_kernels_eo.h: WBIG)
@@ -301,7 +298,7 @@ static int self_carry_group( int dft, int W, int hop, int chains_per_channel )
 	if( synth_fast_kind( dft, W, hop ) != 1 ) return 0;
 	int g = 0;
 	if( dft == 2048 ) g = 8;
-	else if( dft == 4096 && W % 256 == 0 && ( hop == 128 || hop % 256 == 0 ) && g_syn11_variant != 0 && g_ana11_variant != 0 ) g = 4;   // (windows above 2048: the WBIG variants)
+	else if( dft == 4096 && W % 256 == 0 && ( hop == 128 || hop % 256 == 0 ) && !debug_options().syn11_old && !debug_options().ana11_old ) g = 4;   // (windows above 2048: the WBIG variants)
 	// any number of groups (their carries come from a scan of their own); with few chains per channel the scan over the chains themselves is as
 	// short and the groups' epilogue and prologue are pure cost (a 5 s mono file: 118 chains, 68 against 73 us per round trip)
 	if( chains_per_channel < 128 ) g = 0;
@@ -352,9 +349,9 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	if( int rc = get_div_plan( p.analysis_rate, &dp ) ) return rc;
 	p.ar_div = DivC{ dp.c, dp.rc, dp.exact };
 	p.sums = nullptr; p.nan_out = nullptr; p.nan_epoch = 0;
-	p.cancel = thread_cancel_word();                                              // kernels stop starting chains when the thread's wait raises it (core.hip)
+	p.cancel = thread_cancel_word( s );                                           // kernels stop starting chains when the thread's wait raises it (core.hip)
 	// windows above 2048: the WBIG team kernels (pv_kernels_eo.h)
-	const bool team_big = fast && dft == 4096 && W > 2048 && g_ana11_variant != 0;
+	const bool team_big = fast && dft == 4096 && W > 2048 && !debug_options().ana11_old;
 	const bool kernel_sums = !any;                                   // every other FFT analysis kernel keeps the sums; for the rest the pre-pass kernel runs on the analysis' behalf
 	SynthLayout fused_lay{};
 	if( d_fused_ws )
@@ -407,8 +404,8 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	if( fast )
 		{
 		FastTables tb{ plan->d_tw1f, plan->d_tw3f, plan->d_tw2 };
-		if( dft == 2048 ) return p.sums ? run_analyze_v2_variant<true>( g_ana_variant, p, tb, s ) : run_analyze_v2_variant<false>( g_ana_variant, p, tb, s );
-		if( dft == 4096 && W <= 2048 && g_ana11_variant != 0 )
+		if( dft == 2048 ) return p.sums ? run_analyze_v2_variant<true>( debug_options().ana_variant, p, tb, s ) : run_analyze_v2_variant<false>( debug_options().ana_variant, p, tb, s );
+		if( dft == 4096 && W <= 2048 && !debug_options().ana11_old )
 			{
 			// teams of two wavefronts, two E / O buffer sets, one meeting per frame (0.27 ms for 8 ch x 60 s with the fused round trip's chain sums,
 			// 0.28 without; one set and two meetings: +7 %; the round-1 kernel: 0.44)
@@ -453,7 +450,7 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	o->head_len = o->any ? 0 : std::max( W - o->hop, 0 );        // (the direct-sum path overlap-adds whole frames from its own scratch: no chain heads)
 	const int overlap = ( W + o->hop - 1 ) / o->hop;              // frames covering one output sample
 	const int kind = o->any ? 0 : synth_fast_kind( o->dft, W, o->hop );
-	const int slots = o->any ? any_target_chains( bins ) : kind == 0 ? generic_target_chains( o->dft ) : ( kind == 2 && o->dft == 4096 ) ? 256 * kRingWaves11 : fast_target_chains( o->dft, true );
+	const int slots = o->any ? any_target_chains( bins ) : kind == 0 ? generic_target_chains( o->dft ) : ( kind == 2 && o->dft == 4096 ) ? cu_count() * kRingWaves11 : fast_target_chains( o->dft, true );
 	o->L = choose_chain_length( ch, F, o->any ? 1 : std::max( overlap - 1, 1 ), slots );
 	o->chains_per_channel = int( ( F + o->L - 1 ) / o->L );
 	const int64_t chains = int64_t( o->chains_per_channel ) * ch;
@@ -490,7 +487,7 @@ static int run_synth( const SynthParams & p, hipStream_t s )
 	}
 
 int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float ar, int W, float * d_out,
-	void * d_ws, int * d_nan, int presummed, hipStream_t s, const double * d_carry_in, double * d_total_out, bool prepass_only )
+	void * d_ws, int * d_nan, int presummed, hipStream_t s, const double * d_carry_in, double * d_total_out, bool prepass_only, int stage_mask )
 	{
 	FLANHIP_REQUIRE( d_pv && ( d_out || prepass_only ) && d_ws, FLANHIP_ERR_INVALID_ARG, "null buffer" );
 	SynthLayout lay;
@@ -517,14 +514,14 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	p.nan_in = ( presummed == 1 || presummed == 2 ) ? reinterpret_cast<const int*>( reinterpret_cast<char*>( d_ws ) + lay.carry_bytes + lay.head_bytes ) : nullptr;
 	p.skip_words = presummed == 2 ? p.nan_in : nullptr;
 	p.carry_in = d_carry_in; p.total_out = d_total_out; p.total_only = prepass_only ? 1 : 0;
-	p.cancel = thread_cancel_word();
+	p.cancel = thread_cancel_word( s );
 
 	const int64_t chains = int64_t( p.chains_per_channel ) * ch;
 	FLANHIP_REQUIRE( chains < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
-	const int stages = prepass_only ? 3 : g_synth_stage_mask;
+	const int stages = prepass_only ? 3 : ( stage_mask & 0xF );
 	// The dft 2048 analysis kernel leaves group totals beside the chain sums (launch_analyze notes that for this workspace): the dft 2048
 	// synthesis kernel then works out its own carries and the scan kernel is not launched.  Any other producer or shape: the scan runs.
-	const bool self_carry = presummed == 1 && !prepass_only && !d_carry_in && !d_total_out && g_syn_variant != 2
+	const bool self_carry = presummed == 1 && !prepass_only && !d_carry_in && !d_total_out && debug_options().syn_variant != 2
 		&& self_carry_group( lay.dft, W, lay.hop, lay.chains_per_channel ) != 0 && workspace_producer( d_ws ) == 1;
 	if( self_carry )
 		{
@@ -696,8 +693,30 @@ int flanhip_analyze( const float * audio, int64_t ch, int64_t n, float sr, int W
 	return FLANHIP_OK;
 	}
 
-void flanhip_debug_synth_stages( int mask ) { g_synth_stage_mask = mask & 0xF; }
-void flanhip_debug_kernel_variant( int which, int variant ) { if( which == 0 ) g_ana_variant = variant; else if( which == 2 ) g_ana11_variant = variant; else if( which == 3 ) g_syn11_variant = variant; else g_syn_variant = variant; }
+int flanhip_synthesize_dev_stages( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float ar, int W,
+	float * d_out, void * d_ws, int * d_nan, int presummed, int stages, void * stream )
+	{
+	FLANHIP_REQUIRE( presummed >= 0 && presummed <= 2, FLANHIP_ERR_INVALID_ARG, "presummed: 0, 1 or 2" );
+	return launch_synthesize( d_pv, ch, F, bins, sr, ar, W, d_out, d_ws, d_nan, presummed, (hipStream_t) stream, nullptr, nullptr, false, stages );
+	}
+
+void flanhip_debug_option( int which, int value )
+	{
+	DebugOptions & o = debug_options();
+	switch( which )
+		{
+		case FLANHIP_DEBUG_CHAIN_LEN:       o.chain_len = value; break;
+		case FLANHIP_DEBUG_TARGET_CHAINS:   o.target_chains = value; break;
+		case FLANHIP_DEBUG_FORCE_GENERIC:   o.force_generic = value; break;
+		case FLANHIP_DEBUG_NO_FAST_DIV:     o.no_fast_div = value; break;
+		case FLANHIP_DEBUG_ANA_VARIANT:     o.ana_variant = value; break;
+		case FLANHIP_DEBUG_SYN_VARIANT:     o.syn_variant = value; break;
+		case FLANHIP_DEBUG_ANA4096_OLD:     o.ana11_old = value; break;
+		case FLANHIP_DEBUG_SYN4096_OLD:     o.syn11_old = value; break;
+		case FLANHIP_DEBUG_RESAMPLE_DIRECT: o.resample_direct = value; break;
+		default: break;
+		}
+	}
 #ifdef FLANHIP_STAMPS
 // diagnostic build only: the per-section cycle sums of the stamped kernels (16 words; [15] = wavefronts that reported), then cleared
 int flanhip_debug_read_stamps( unsigned long long * out16 )

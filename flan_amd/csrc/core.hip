@@ -1,5 +1,6 @@
 // core.hip -- error state, device plumbing, plan cache, shape helpers of the C ABI (include/flanhip.h).
 #include "flanhip_internal.h"
+#include "div_plans_proven.h"
 #include <thread>
 #include <chrono>
 #include <atomic>
@@ -109,8 +110,12 @@ int get_div_plan( float c, DivPlan * out )
 	auto it = g_div_plans.find( key );
 	if( it != g_div_plans.end() ) { *out = it->second; return FLANHIP_OK; }
 	DivPlan d{ c, 1.0f / c, 0 };
-	const char * env = std::getenv( "FLANHIP_NO_FAST_DIV" );
-	if( !( env && env[0] == '1' ) && c > 1.0e-10f && c < 1.0e10f )
+	// the analysis rates of everyday sample rates and hops were tried offline, all 2^32 dividends each (tools/check_div_c.cpp ->
+	// div_plans_proven.h): no launch of k_verify_div (2.4 ms) for those
+	bool known = false;
+	for( const ProvenDiv & pd : kProvenDivs ) if( pd.bits == key ) { d.exact = pd.exact; known = true; break; }
+	if( debug_options().no_fast_div ) { d.exact = 0; known = true; }
+	if( !known && c > 1.0e-10f && c < 1.0e10f )
 		{
 		unsigned int * d_bad = nullptr, bad = 1;
 		FLANHIP_CHECK( hipMalloc( &d_bad, sizeof( unsigned int ) ) );
@@ -126,19 +131,34 @@ int get_div_plan( float c, DivPlan * out )
 	return FLANHIP_OK;
 	}
 
-bool force_generic()
+// Test / A-B hooks (flanhip_debug_option): PER CALLING THREAD, all off by default, never set by the product paths (the C++ classes, bench.py's
+// timed region).  They replace what used to be process-wide variables and getenv() calls on every entry: a thread that sets one changes its own
+// calls only, and the library reads no environment variable on its call paths.
+DebugOptions & debug_options()
 	{
-	const char * env = std::getenv( "FLANHIP_FORCE_GENERIC" );
-	return env && env[0] == '1';
+	static thread_local DebugOptions o;
+	return o;
+	}
+
+bool force_generic() { return debug_options().force_generic != 0; }
+
+// compute units of the current device (hipDeviceProp_t::multiProcessorCount), cached per device: what "the wavefronts the chip holds at once"
+// is counted from -- 256 on a whole MI355X, 32 per XCD-partition in CPX mode
+int cu_count()
+	{
+	static std::atomic<int> cached[64];
+	int device = 0;
+	if( hipGetDevice( &device ) != hipSuccess ) { (void) hipGetLastError(); return 256; }
+	if( device >= 0 && device < 64 && cached[device].load( std::memory_order_relaxed ) > 0 ) return cached[device].load( std::memory_order_relaxed );
+	int n = 0;
+	if( hipDeviceGetAttribute( &n, hipDeviceAttributeMultiprocessorCount, device ) != hipSuccess || n <= 0 ) { (void) hipGetLastError(); n = 256; }
+	if( device >= 0 && device < 64 ) cached[device].store( n, std::memory_order_relaxed );
+	return n;
 	}
 
 int choose_chain_length( int64_t num_channels, int64_t num_frames, int min_len, int target_chains )
 	{
-	if( const char * env = std::getenv( "FLANHIP_CHAIN_LEN" ) )
-		{
-		const int v = std::atoi( env );
-		if( v > 0 ) return std::max( v, min_len );
-		}
+	if( const int v = debug_options().chain_len ) { if( v > 0 ) return std::max( v, min_len ); }     // (tests: results must not depend on the cut)
 	// One wavefront per chain.  target_chains = the wavefronts the chip holds at once for this kernel.  All chains run
 	// concurrently and cost the same (L frames + one halo frame / overlap head), so the launch takes as long as ONE chain:
 	// the best cut is the longest chain that still gives every resident wavefront slot a chain -- a single round of blocks,
@@ -179,76 +199,135 @@ int workspace_producer( const void * d_ws )
 	}
 
 // ---- cancellation inside a launch (defines.h:49-62: the reference polls its flag once per frame, AudioPV.cpp:49,115) -----------------
-// Every host thread owns one int of FINE-GRAINED device memory per device (coherent across the chip's XCDs and with the copy engines; page-locked
-// coherent host memory if that cannot be had), the CANCEL WORD: the conversion kernels launched by that thread get its address and read it,
-// past their caches, when a block starts (the direct-sum kernels also every few batches of frames).  wait_cancellable() waits for a stream
-// while it polls the caller's flag; when that rises it sets the word from a side stream, the blocks still to start retire at once (a block of
-// the FFT kernels walks at most 512 frames: ~3 ms), and the call returns FLANHIP_ERR_CANCELLED.  The word is the thread's own: a cancelled call
-// does not touch what other threads have in flight.
-struct CancelWord { int * dev = nullptr; volatile int * host = nullptr; hipStream_t side = nullptr; };   // host != nullptr: the host-memory fallback
-struct ThreadCancel { std::map<int, CancelWord> words; };
+// Every host thread holds, per device, a block of CANCEL WORDS in fine-grained device memory (coherent across the chip's XCDs and with the copy
+// engines; page-locked coherent host memory if that cannot be had): one word per STREAM the thread launches conversions on, each on a cache
+// line of its own.  A conversion kernel gets the address of its stream's word and reads it, past the caches, when a block starts (the
+// direct-sum kernels also every few batches of frames).  wait_cancellable( s ) waits for stream s while it polls the caller's flag; when that
+// rises it sets THAT stream's word from a side stream, the blocks still to start retire at once (a block of the FFT kernels walks at most 512
+// frames: ~3 ms), and the call returns FLANHIP_ERR_CANCELLED.  The scope of a cancellation is therefore the wait's own stream: what the
+// thread has in flight on its other streams, and what other threads have in flight anywhere, is not touched (round 3 had one word per thread:
+// a wait on stream A also stopped the thread's kernels on stream B, whose later plain synchronisation then reported success on half-written
+// output).  A thread with more than kCancelSlots live streams on one device re-uses the least recently used slot.
+// The blocks are drawn from a process-wide pool and go back to it when their thread ends (no HIP call in a thread's destructor, no
+// allocation or stream per short-lived thread: the pool never holds more blocks than threads were alive at once).
+constexpr int kCancelSlots = 64, kCancelStride = 16;                                // words; one 64-byte line per slot
+struct CancelBlock
+	{
+	int device = -1;
+	int * dev = nullptr; volatile int * host = nullptr;                               // host != nullptr: the host-memory fallback
+	hipStream_t side = nullptr;
+	hipStream_t owner[kCancelSlots] = {};                                             // the streams this thread has launched on, most recently used first ...
+	int slot_of[kCancelSlots] = {};                                                   // ... and the slot each of them holds
+	int used = 0;
+	};
+static std::mutex g_cancel_pool_mutex;
+static std::vector<CancelBlock*> g_cancel_pool;                                     // idle blocks (their words are 0: a wait clears what it raised)
+struct ThreadCancel
+	{
+	std::vector<CancelBlock*> blocks;                                                 // one per device this thread has used
+	~ThreadCancel()
+		{
+		std::lock_guard<std::mutex> lock( g_cancel_pool_mutex );
+		for( CancelBlock * b : blocks ) { b->used = 0; g_cancel_pool.push_back( b ); }
+		}
+	};
 static thread_local ThreadCancel t_cancel;
 
-static CancelWord * thread_cancel_entry()
+static CancelBlock * thread_cancel_block()
 	{
 	int device = 0;
-	if( hipGetDevice( &device ) != hipSuccess ) return nullptr;
-	auto it = t_cancel.words.find( device );
-	if( it == t_cancel.words.end() )
+	if( hipGetDevice( &device ) != hipSuccess ) { (void) hipGetLastError(); return nullptr; }
+	for( CancelBlock * b : t_cancel.blocks ) if( b->device == device ) return b;
 		{
-		CancelWord w;
-		void * d = nullptr;
-		if( hipExtMallocWithFlags( &d, 256, hipDeviceMallocFinegrained ) == hipSuccess && hipMemset( d, 0, 256 ) == hipSuccess )
-			{
-			w.dev = static_cast<int*>( d );
-			if( hipStreamCreateWithFlags( &w.side, hipStreamNonBlocking ) != hipSuccess ) { (void) hipGetLastError(); (void) hipFree( d ); return nullptr; }
-			}
-		else
-			{
-			(void) hipGetLastError();
-			void * h = nullptr; void * dp = nullptr;
-			if( hipHostMalloc( &h, 256, hipHostMallocCoherent | hipHostMallocMapped ) != hipSuccess ) { (void) hipGetLastError(); return nullptr; }
-			std::memset( h, 0, 256 );
-			if( hipHostGetDevicePointer( &dp, h, 0 ) != hipSuccess ) { (void) hipGetLastError(); (void) hipHostFree( h ); return nullptr; }
-			w.dev = static_cast<int*>( dp ); w.host = static_cast<volatile int*>( h );
-			}
-		it = t_cancel.words.emplace( device, w ).first;
+		std::lock_guard<std::mutex> lock( g_cancel_pool_mutex );
+		for( size_t i = 0; i < g_cancel_pool.size(); ++i )
+			if( g_cancel_pool[i]->device == device )
+				{
+				CancelBlock * b = g_cancel_pool[i];
+				g_cancel_pool.erase( g_cancel_pool.begin() + long( i ) );
+				t_cancel.blocks.push_back( b );
+				return b;
+				}
 		}
-	return &it->second;
+	CancelBlock * b = new CancelBlock;
+	b->device = device;
+	const size_t bytes = sizeof( int ) * kCancelSlots * kCancelStride;
+	void * d = nullptr;
+	if( hipExtMallocWithFlags( &d, bytes, hipDeviceMallocFinegrained ) == hipSuccess && hipMemset( d, 0, bytes ) == hipSuccess )
+		{
+		b->dev = static_cast<int*>( d );
+		if( hipStreamCreateWithFlags( &b->side, hipStreamNonBlocking ) != hipSuccess ) { (void) hipGetLastError(); (void) hipFree( d ); delete b; return nullptr; }
+		}
+	else
+		{
+		(void) hipGetLastError();
+		void * h = nullptr; void * dp = nullptr;
+		if( hipHostMalloc( &h, bytes, hipHostMallocCoherent | hipHostMallocMapped ) != hipSuccess ) { (void) hipGetLastError(); delete b; return nullptr; }
+		std::memset( h, 0, bytes );
+		if( hipHostGetDevicePointer( &dp, h, 0 ) != hipSuccess ) { (void) hipGetLastError(); (void) hipHostFree( h ); delete b; return nullptr; }
+		b->dev = static_cast<int*>( dp ); b->host = static_cast<volatile int*>( h );
+		}
+	t_cancel.blocks.push_back( b );
+	return b;
 	}
 
-int * thread_cancel_word()
+// the slot of stream s in the thread's block.  owner[] / slot_of[] are ordered most recently used first; a new stream takes a slot nobody
+// has had yet, or -- with kCancelSlots streams live -- the least recently used stream's
+static int cancel_slot( CancelBlock & b, hipStream_t s )
 	{
-	CancelWord * w = thread_cancel_entry();
-	return w ? w->dev : nullptr;
+	int at = -1;
+	for( int i = 0; i < b.used; ++i ) if( b.owner[i] == s ) { at = i; break; }
+	int slot;
+	if( at >= 0 ) slot = b.slot_of[at];
+	else if( b.used < kCancelSlots ) { at = b.used++; slot = at; }
+	else { at = kCancelSlots - 1; slot = b.slot_of[at]; }
+	for( int i = at; i > 0; --i ) { b.owner[i] = b.owner[i - 1]; b.slot_of[i] = b.slot_of[i - 1]; }
+	b.owner[0] = s; b.slot_of[0] = slot;
+	return slot;
 	}
 
-static void set_cancel_word( CancelWord & w, int value, bool wait )
+int * thread_cancel_word( hipStream_t s )
 	{
-	if( w.host ) { *w.host = value; std::atomic_thread_fence( std::memory_order_seq_cst ); return; }
-	(void) hipMemsetAsync( w.dev, value, sizeof( int ), w.side );              // (a byte value: 1 gives 0x01010101 -- non-zero is all that counts)
-	if( wait ) (void) hipStreamSynchronize( w.side );
+	CancelBlock * b = thread_cancel_block();
+	return b ? b->dev + cancel_slot( *b, s ) * kCancelStride : nullptr;
+	}
+
+static void set_cancel_word( CancelBlock & b, int slot, int value, bool wait )
+	{
+	if( b.host ) { b.host[slot * kCancelStride] = value; std::atomic_thread_fence( std::memory_order_seq_cst ); return; }
+	(void) hipMemsetAsync( b.dev + slot * kCancelStride, value, sizeof( int ), b.side );   // (a byte value: 1 gives 0x01010101 -- non-zero is all that counts)
+	if( wait ) (void) hipStreamSynchronize( b.side );
 	}
 
 int wait_cancellable( hipStream_t s, int ( *poll )( void * ), void * user )
 	{
-	CancelWord * w = poll ? thread_cancel_entry() : nullptr;
-	if( !w ) { FLANHIP_CHECK( hipStreamSynchronize( s ) ); return ( poll && poll( user ) ) ? FLANHIP_ERR_CANCELLED : FLANHIP_OK; }
+	CancelBlock * b = poll ? thread_cancel_block() : nullptr;
+	if( !b ) { FLANHIP_CHECK( hipStreamSynchronize( s ) ); return ( poll && poll( user ) ) ? FLANHIP_ERR_CANCELLED : FLANHIP_OK; }
+	const int slot = cancel_slot( *b, s );
+	// most waits end within the first few hundred microseconds and never see the flag rise: poll the stream itself for that long (no event, no
+	// sleep quantum on top of a 70 us round trip), then settle into event queries with short sleeps
+	for( int spins = 0; spins < 2000; ++spins )
+		{
+		const hipError_t q = hipStreamQuery( s );
+		if( q == hipSuccess ) return poll( user ) ? FLANHIP_ERR_CANCELLED : FLANHIP_OK;
+		if( q != hipErrorNotReady ) { (void) hipGetLastError(); set_error( "hipStreamQuery failed" ); return FLANHIP_ERR_HIP; }
+		if( poll( user ) ) break;
+		std::this_thread::yield();
+		}
 	hipEvent_t done;
 	FLANHIP_CHECK( hipEventCreateWithFlags( &done, hipEventDisableTiming ) );
 	if( hipEventRecord( done, s ) != hipSuccess ) { (void) hipEventDestroy( done ); set_error( "hipEventRecord failed" ); return FLANHIP_ERR_HIP; }
 	bool raised = false;
-	int spins = 0;
 	for( ;; )
 		{
 		const hipError_t q = hipEventQuery( done );
 		if( q == hipSuccess ) break;
-		if( q != hipErrorNotReady ) { (void) hipEventDestroy( done ); if( raised ) set_cancel_word( *w, 0, true ); set_error( "hipEventQuery failed" ); return FLANHIP_ERR_HIP; }
-		if( !raised && poll( user ) ) { set_cancel_word( *w, 1, false ); raised = true; }
-		if( ++spins < 200 ) std::this_thread::yield(); else std::this_thread::sleep_for( std::chrono::microseconds( 50 ) );
+		if( q != hipErrorNotReady ) { (void) hipEventDestroy( done ); if( raised ) set_cancel_word( *b, slot, 0, true ); set_error( "hipEventQuery failed" ); return FLANHIP_ERR_HIP; }
+		if( !raised && poll( user ) ) { set_cancel_word( *b, slot, 1, false ); raised = true; }
+		std::this_thread::sleep_for( std::chrono::microseconds( 50 ) );
 		}
 	(void) hipEventDestroy( done );
-	if( raised ) { set_cancel_word( *w, 0, true ); return FLANHIP_ERR_CANCELLED; }     // (the stream has drained: nobody reads the word now)
+	if( raised ) { set_cancel_word( *b, slot, 0, true ); return FLANHIP_ERR_CANCELLED; }   // (the stream has drained: nobody reads the word now)
 	return poll( user ) ? FLANHIP_ERR_CANCELLED : FLANHIP_OK;
 	}
 

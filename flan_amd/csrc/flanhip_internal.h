@@ -33,7 +33,7 @@ inline int ilog2( int64_t n ) { int l = 0; while( ( int64_t( 1 ) << l ) < n ) ++
 inline bool cancelled( volatile int * c ) { return c && *c != 0; }
 // cancellation inside a launch (core.hip): the calling thread's cancel word on the current device (kernels poll it; nullptr if it cannot be had),
 // and a wait for a stream that polls `poll( user )` and raises the word when it says so (FLANHIP_ERR_CANCELLED then)
-int * thread_cancel_word();
+int * thread_cancel_word( hipStream_t s );
 int wait_cancellable( hipStream_t s, int ( *poll )( void * ), void * user );
 inline int poll_volatile_int( void * user ) { volatile int * c = static_cast<volatile int*>( user ); return c && *c != 0; }
 
@@ -56,7 +56,20 @@ int get_div_plan( float c, DivPlan * out );
 
 // Chain length heuristics (frames per wavefront-chain)
 int choose_chain_length( int64_t num_channels, int64_t num_frames, int min_len, int target_chains );
-bool force_generic();   // FLANHIP_FORCE_GENERIC=1: never take the tuned dft 2048/4096 kernels (A/B and parity of both paths)
+// flanhip_debug_option (include/flanhip.h): per-thread test / A-B hooks, all off by default
+struct DebugOptions
+	{
+	int chain_len = 0;        // FLANHIP_DEBUG_CHAIN_LEN: frames per chain (0: the library's choice)
+	int target_chains = 0;    // FLANHIP_DEBUG_TARGET_CHAINS: chains the tuned kernels are cut for (0: what the device holds at once)
+	int force_generic = 0;    // FLANHIP_DEBUG_FORCE_GENERIC: never take the tuned dft 2048 / 4096 kernels (A/B and parity of both paths)
+	int no_fast_div = 0;      // FLANHIP_DEBUG_NO_FAST_DIV: hardware division by the analysis rate even where the 3-instruction quotient is proven
+	int ana_variant = 0, syn_variant = 0;      // dft 2048: ablated instantiations of diagnostic builds; synthesis 2 = behind the scan kernel
+	int ana11_old = 0, syn11_old = 0;          // dft 4096: 1 = the round-1 kernels instead of the team kernels (A/B predecessor)
+	int resample_direct = 0;                   // 1: the 2:1 block convolver always as direct sums
+	};
+DebugOptions & debug_options();
+bool force_generic();
+int cu_count();         // compute units of the current device
 
 // Launchers implemented in analyze.hip / synthesize.hip / processors.hip
 // d_fused_ws (optional): a synthesis workspace for the PV being produced; analysis leaves the per-chain phase sums and a NaN flag
@@ -69,7 +82,7 @@ int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int 
 // range of a longer one (flanhip_synthesize_prepass_dev / flanhip_synthesize_dev_carry); prepass_only: stop after the pre-pass
 int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float ar, int W, float * d_out,
 	void * d_ws, int * d_nan, int presummed, hipStream_t s, const double * d_carry_in = nullptr, double * d_total_out = nullptr,
-	bool prepass_only = false );
+	bool prepass_only = false, int stage_mask = 0xF );     // stage_mask: 1 sums, 2 scan, 4 main, 8 fix-up (flanhip_synthesize_dev_stages)
 
 // A fresh non-zero number per producer launch: workspace words are "set" when they equal the launch's epoch (no clearing pass).
 int next_epoch();

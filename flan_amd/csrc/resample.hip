@@ -770,7 +770,6 @@ static int ols_twiddles( const cd ** out )                                      
 	}
 
 // 0: always the direct sums (the checker's operation order); 1 (default): the FFT convolver where it applies
-static int g_resample_fft = 1;
 
 static int get_stage_plan( double src, double dst, const std::vector<Stage> ** out )
 	{
@@ -866,7 +865,7 @@ static int launch_rational( const InT * d_in, int64_t n_in, const Stage & g, Out
 	if constexpr( std::is_same<InT, float>::value && std::is_same<OutT, float>::value )
 		{
 		const int Lo = OLS_N / 2 - g.fl2;
-		if( g_resample_fft && g.d_spec && g.up == 1 && g.down == 2 && n_out >= 8 * int64_t( Lo ) )
+		if( !debug_options().resample_direct && g.d_spec && g.up == 1 && g.down == 2 && n_out >= 8 * int64_t( Lo ) )
 			{
 			const cd * tw = nullptr;
 				{
@@ -1042,7 +1041,6 @@ int64_t flanhip_resample_out_frames( int64_t num_frames, float src_rate, float d
 	return int64_t( int32_t( float( int32_t( num_frames ) ) * ( dst_rate / src_rate ) ) );
 	}
 
-void flanhip_debug_resample_fft( int on ) { g_resample_fft = on; }
 
 int flanhip_resample_dev( const float * d_in, int64_t ch, int64_t n, float src_rate, float dst_rate, float * d_out, void * stream )
 	{

@@ -71,6 +71,9 @@ int flanhip_stream_synchronize(void * stream);
  * completed without the flag rising.  The _fn form takes a predicate (non-zero = cancel) instead of an int flag, for callers whose flag is
  * not an int (the C++ classes' std::atomic<bool>&).  The host-buffer entry points (flanhip_analyze, flanhip_synthesize) wait this way with
  * their own `cancel` argument. */
+/* Scope: the wait on `stream` stops the conversion kernels THIS thread has launched on THAT stream; what the thread has in flight on its
+ * other streams (and what other threads have in flight anywhere) runs to completion.  (A thread that uses more than 64 streams at once on
+ * one device shares cancel words between them: such a stream may be stopped together with another one of the same thread.) */
 int flanhip_wait_cancellable(void * stream, volatile int * cancel);
 int flanhip_wait_cancellable_fn(void * stream, int (*poll)(void * user), void * user);
 /* Transfers between ordinary (pageable) host memory and the device, synchronous: what the host entry points below
@@ -139,17 +142,29 @@ int flanhip_synthesize_dev_fused_checked(const flanhip_MF * d_pv, int64_t num_ch
                                          float sample_rate, float analysis_rate, int window_size,
                                          float * d_out, void * d_workspace, int * d_nan_flag, void * stream);
 
-/* Bench/diagnostic knob: which of the synthesis kernels a call launches (bit 0 k_phase_sums, 1 k_phase_scan,
- * 2 k_synthesize, 3 k_ola_fixup; default all).  Results are only meaningful with all four. */
-void flanhip_debug_synth_stages(int mask);
-/* Bench/diagnostic knob: which generation of the tuned kernels a call launches (which = 0 / 1: dft 2048 analysis / synthesis, 2 / 3:
- * dft 4096 analysis / synthesis; variant 0 = the round-1 kernel, the library's default otherwise).  Layout-changing like
- * FLANHIP_TARGET_CHAINS: set it before sizing a workspace.  A/B runs only. */
-void flanhip_debug_kernel_variant(int which, int variant);
-/* Bench/diagnostic knob: 1 (default) = Audio::resample's 2:1 block convolver runs as fp64 overlap-save FFT convolution (the reference's
- * own method, r8brain/CDSPBlockConvolver.h:242-344) for float streams of at least 8 blocks; 0 = always the direct fp64 sums in the checker's
- * operation order (what short inputs and the fp64 streams inside chains use anyway). */
-void flanhip_debug_resample_fft(int on);
+/* The same call with the kernels it launches as a per-call argument: presummed 0 = flanhip_synthesize_dev, 1 = _fused, 2 = _fused_checked;
+ * stages: bit 0 k_phase_sums, 1 k_phase_scan, 2 k_synthesize, 3 k_ola_fixup (0xF: all of them, i.e. the plain entry points above).
+ * For timing ONE kernel of a call with events (bench.py's roofline object); the output is only meaningful with all four. */
+int flanhip_synthesize_dev_stages(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_pv_frames, int num_bins,
+                                  float sample_rate, float analysis_rate, int window_size,
+                                  float * d_out, void * d_workspace, int * d_nan_flag, int presummed, int stages, void * stream);
+
+/* Test / A-B hooks, PER CALLING THREAD (thread-local, all 0 = off by default; the library's own paths and the C++ classes never set them, and
+ * no entry point reads an environment variable).  A thread that sets one changes how ITS later calls are cut or routed -- never the results
+ * beyond the documented tolerances (tests/test_gpu_conversions.py holds that) -- and must size a workspace under the same settings it
+ * converts with (chain length and chain count decide the layout). */
+#define FLANHIP_DEBUG_CHAIN_LEN       0   /* frames per chain */
+#define FLANHIP_DEBUG_TARGET_CHAINS   1   /* chains the tuned kernels are cut for (default: what the device holds at once) */
+#define FLANHIP_DEBUG_FORCE_GENERIC   2   /* 1: never the tuned dft 2048 / 4096 kernels */
+#define FLANHIP_DEBUG_NO_FAST_DIV     3   /* 1: hardware division by the analysis rate */
+#define FLANHIP_DEBUG_ANA_VARIANT     4   /* dft 2048 analysis: ablated instantiations (diagnostic builds only) */
+#define FLANHIP_DEBUG_SYN_VARIANT     5   /* dft 2048 synthesis: 2 = behind the scan kernel even where it could work out its own carries; ablations */
+#define FLANHIP_DEBUG_ANA4096_OLD     6   /* 1: the round-1 dft 4096 analysis kernel instead of the team kernel (A/B predecessor) */
+#define FLANHIP_DEBUG_SYN4096_OLD     7   /* 1: the round-1 dft 4096 synthesis kernel */
+#define FLANHIP_DEBUG_RESAMPLE_DIRECT 8   /* 1: Audio::resample's 2:1 block convolver always as direct fp64 sums in the checker's operation order
+                                           * (default: fp64 overlap-save FFT convolution, the reference's own method, r8brain/CDSPBlockConvolver.h:242-344,
+                                           * for float streams of at least 8 blocks) */
+void flanhip_debug_option(int which, int value);
 
 /* ---- PV frame processors ------------------------------------------------------------------------------------- */
 /* modify_time_base (PV/PVModify.cpp:307-362, linear Interpolator): mod_seconds is the sampled time map float[F][bins]

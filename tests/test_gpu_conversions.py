@@ -188,16 +188,16 @@ def test_nan_flag(fa):
     assert out.shape == (1, pv.shape[1] * 256)
 
 
-def test_chain_length_invariance(fa, monkeypatch):
-    """the result must not depend on how frames are cut into chains (FLANHIP_CHAIN_LEN): bit-identical analysis,
+def test_chain_length_invariance(fa):
+    """the result must not depend on how frames are cut into chains (flanhip_debug_option: chain length): bit-identical analysis,
     synthesis equal to rounding of the overlap partial sums"""
     x = O.noise(2, 60000, seed=8)
     sr = 48000.0
     res = []
-    for L in ("4", "7", "64"):
-        monkeypatch.setenv("FLANHIP_CHAIN_LEN", L)
-        pv = fa.analyze(x, sr, 2048, 512, 2048)
-        out, _ = fa.synthesize(pv, sr, sr / 512, 2048)
+    for L in (4, 7, 64):
+        with fa.debug_options(chain_len=L):
+            pv = fa.analyze(x, sr, 2048, 512, 2048)
+            out, _ = fa.synthesize(pv, sr, sr / 512, 2048)
         res.append((pv, out))
     assert np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32))
     assert np.array_equal(res[0][0].view(np.uint32), res[2][0].view(np.uint32))
@@ -219,8 +219,8 @@ def test_errors(fa):
 
 
 @pytest.mark.parametrize("dft,hop", [(2048, 512), (4096, 128), (2048, 1024), (2048, 256), (4096, 1024)])
-def test_generic_and_tuned_kernels_agree(fa, monkeypatch, dft, hop):
-    """dft 2048 / 4096 have tuned kernels (pv_kernels_fast.h); FLANHIP_FORCE_GENERIC=1 routes the same call through the
+def test_generic_and_tuned_kernels_agree(fa, dft, hop):
+    """dft 2048 / 4096 have tuned kernels (pv_kernels_fast.h); the force_generic hook routes the same call through the
     generic ones (pv_kernels.h).  Both must sit within the parity tolerances of the oracle and of each other."""
     x = O.noise(2, 70000, seed=21)
     sr = 48000.0
@@ -228,9 +228,9 @@ def test_generic_and_tuned_kernels_agree(fa, monkeypatch, dft, hop):
     out_ref, _ = O.synthesize(ref, sr, np.float32(sr) / np.float32(hop), 2048)
     res = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("FLANHIP_FORCE_GENERIC", mode)
-        pv = fa.analyze(x, sr, 2048, hop, dft)
-        out, _ = fa.synthesize(ref, sr, np.float32(sr) / np.float32(hop), 2048)
+        with fa.debug_options(force_generic=int(mode)):
+            pv = fa.analyze(x, sr, 2048, hop, dft)
+            out, _ = fa.synthesize(ref, sr, np.float32(sr) / np.float32(hop), 2048)
         rel_m, wrms_f, same, turns = p1_metrics(pv, ref, sr / hop)
         rms = float(np.sqrt(np.mean((out.astype(np.float64) - out_ref.astype(np.float64)) ** 2)))
         print("\n[path generic=%s dft=%d hop=%d] rel_m=%.3e wrms_df=%.3e same=%.4f turns=%d  P2 rms=%.3e" % (mode, dft, hop, rel_m, wrms_f, same, turns, rms))
@@ -312,7 +312,7 @@ def test_carry_prologue_equals_scan_kernel(fa, dft, hop, ch, n, W):
     outs = {}
     try:
         for variant in (0, 2):
-            lib.flanhip_debug_kernel_variant(1, variant)
+            lib.flanhip_debug_option(fa.DEBUG_SYN_VARIANT, variant)
             d_pv, d_out, d_ws, d_flag = dev_alloc(ch * F * bins * 8), dev_alloc(ch * F * hop * 4), dev_alloc(ws_bytes), dev_alloc(4)
             fa.check(lib.flanhip_memset(d_flag, 0, 4, None))
             fa.check(lib.flanhip_analyze_dev_fused(d_x, ch, n, sr, W, hop, dft, d_pv, d_ws, None))
@@ -325,7 +325,7 @@ def test_carry_prologue_equals_scan_kernel(fa, dft, hop, ch, n, W):
             for p in (d_pv, d_out, d_ws, d_flag):
                 lib.flanhip_free(p)
     finally:
-        lib.flanhip_debug_kernel_variant(1, 0)
+        lib.flanhip_debug_option(fa.DEBUG_SYN_VARIANT, 0)
         lib.flanhip_free(d_x)
     assert outs[0][1] == 0 and outs[2][1] == 0
     assert np.array_equal(outs[0][0].view(np.uint32), outs[2][0].view(np.uint32))
@@ -451,24 +451,24 @@ def test_dft4096_kernel_generations_agree(fa, hop):
     res = {}
     try:
         for gen in (0, 1):
-            fa.lib.flanhip_debug_kernel_variant(2, gen)
-            fa.lib.flanhip_debug_kernel_variant(3, gen)
+            fa.lib.flanhip_debug_option(fa.DEBUG_ANA4096_OLD, 1 - gen)
+            fa.lib.flanhip_debug_option(fa.DEBUG_SYN4096_OLD, 1 - gen)
             pv = fa.analyze(x, sr, W, hop, dft)
             res[gen] = pv
     finally:
-        fa.lib.flanhip_debug_kernel_variant(2, 1)
-        fa.lib.flanhip_debug_kernel_variant(3, 1)
+        fa.lib.flanhip_debug_option(fa.DEBUG_ANA4096_OLD, 0)
+        fa.lib.flanhip_debug_option(fa.DEBUG_SYN4096_OLD, 0)
     m0, m1 = res[0][..., 0].astype(np.float64), res[1][..., 0].astype(np.float64)
     rel_m = np.sqrt(np.sum((m0 - m1) ** 2) / np.sum(m0 ** 2))
     same_f = np.mean(res[0][..., 1].view(np.uint32) == res[1][..., 1].view(np.uint32))
     out = {}
     try:
         for gen in (0, 1):
-            fa.lib.flanhip_debug_kernel_variant(3, gen)
+            fa.lib.flanhip_debug_option(fa.DEBUG_SYN4096_OLD, 1 - gen)
             out[gen], flag = fa.synthesize(res[1], sr, ar, W)
             assert flag == 0
     finally:
-        fa.lib.flanhip_debug_kernel_variant(3, 1)
+        fa.lib.flanhip_debug_option(fa.DEBUG_SYN4096_OLD, 0)
     d = np.abs(out[0].astype(np.float64) - out[1].astype(np.float64))
     print("\n[dft 4096 hop %d] generations: rel_m %.2e  f bit-identical %.4f  audio max diff %.2e" % (hop, rel_m, same_f, d.max()))
     assert rel_m <= 5e-7 and same_f >= 0.95 and d.max() <= 1e-6

@@ -78,15 +78,15 @@ def test_full_size_properties(name, ch, seconds, monkeypatch):
     print("[%s] round trip vs 1.00074 x input over the first 10 s: relative l2 = %.2e" % (name, float(err)))
     assert float(err) <= 1.2e-2
 
-    # ---- chain invariance (FLANHIP_CHAIN_LEN is read per call)
+    # ---- chain invariance (the chain-length hook of flanhip_debug_option, per thread)
     pv2 = torch.empty_like(pv)
     out2 = torch.empty_like(out)
-    monkeypatch.setenv("FLANHIP_CHAIN_LEN", "37")
-    # the workspace layout follows the chain length: size it under the same setting (debug knob, read per call)
+    fa.lib.flanhip_debug_option(fa.DEBUG_CHAIN_LEN, 37)
+    # the workspace layout follows the chain length: size it under the same setting
     ws37 = torch.empty(fa.synthesize_workspace_bytes(ch, F, BINS, SR, AR, W), dtype=torch.uint8, device=dev)
     fa.analyze_dev(x, ch, n, SR, W, HOP, DFT, pv2)
     fa.synthesize_dev(pv2, ch, F, BINS, SR, AR, W, out2, ws37, flag)
-    monkeypatch.delenv("FLANHIP_CHAIN_LEN")
+    fa.lib.flanhip_debug_option(fa.DEBUG_CHAIN_LEN, 0)
     torch.cuda.synchronize()
     assert bool(torch.equal(pv.view(torch.int32), pv2.view(torch.int32)))
     dmax = float((out - out2).abs().max())
@@ -101,12 +101,12 @@ def test_full_size_properties(name, ch, seconds, monkeypatch):
         torch.cuda.synchronize()
         assert bool(torch.equal(pv_c.view(torch.int32), pv[c:c + 1].view(torch.int32)))
         # synthesis: the chain length depends on the channel count, so pin it for an exact comparison
-        monkeypatch.setenv("FLANHIP_CHAIN_LEN", "64")
+        fa.lib.flanhip_debug_option(fa.DEBUG_CHAIN_LEN, 64)
         ws_c = torch.empty(fa.synthesize_workspace_bytes(1, F, BINS, SR, AR, W), dtype=torch.uint8, device=dev)
         ws64 = torch.empty(fa.synthesize_workspace_bytes(ch, F, BINS, SR, AR, W), dtype=torch.uint8, device=dev)
         fa.synthesize_dev(pv_c, 1, F, BINS, SR, AR, W, out_c, ws_c, flag)
         fa.synthesize_dev(pv, ch, F, BINS, SR, AR, W, out2, ws64, flag)
-        monkeypatch.delenv("FLANHIP_CHAIN_LEN")
+        fa.lib.flanhip_debug_option(fa.DEBUG_CHAIN_LEN, 0)
         torch.cuda.synchronize()
         assert bool(torch.equal(out_c.view(torch.int32), out2[c:c + 1].view(torch.int32)))
 

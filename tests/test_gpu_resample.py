@@ -214,14 +214,14 @@ def test_resample_against_the_real_r8brain(fa, tag):
 @pytest.mark.parametrize("ch,n", [(1, 19808), (1, 19810), (1, 39615), (2, 24760), (3, 9907), (1, 250000)])
 def test_resample_fft_convolver_against_the_direct_sums(fa, ch, n):
     """the 2:1 block convolver as fp64 overlap-save FFT convolution (k_resample_ols2, what streams of 8 blocks and more take) against the
-    direct fp64 sums in the checker's order (flanhip_debug_resample_fft(0)): stream lengths at the switch-over, at whole numbers of block
+    direct fp64 sums in the checker's order (the resample_direct hook of flanhip_debug_option): stream lengths at the switch-over, at whole numbers of block
     pairs, one past them, ragged; >= 99.9 % of the samples bit-identical, the rest one fp32 ulp at unit scale."""
     x = O.noise(ch, n, seed=n + ch)
     try:
-        fa.lib.flanhip_debug_resample_fft(0)
+        fa.lib.flanhip_debug_option(fa.DEBUG_RESAMPLE_DIRECT, 1)
         direct = fa.resample(x, 96000.0, 48000.0)
     finally:
-        fa.lib.flanhip_debug_resample_fft(1)
+        fa.lib.flanhip_debug_option(fa.DEBUG_RESAMPLE_DIRECT, 0)
     got = fa.resample(x, 96000.0, 48000.0)
     assert got.shape == direct.shape
     same = np.mean(got.view(np.uint32) == direct.view(np.uint32))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B timing of kernel variants in ONE process, interleaved rounds (flanhip_debug_kernel_variant).
+"""A/B timing of kernel variants in ONE process, interleaved rounds (flanhip_debug_option).
 
     python tools/ab_kernels.py --ana 0,1,2,3,4 [--fused] [--syn 0,1] [--rounds 7] [--reps 20]
 
@@ -65,7 +65,7 @@ def main():
         ref = None
         runs = {}
         for v in ana:
-            fa.lib.flanhip_debug_kernel_variant(0, v)
+            fa.lib.flanhip_debug_option(fa.DEBUG_ANA_VARIANT, v)
             ws = ws_for()
             pv.zero_()
             if args.fused:
@@ -91,7 +91,7 @@ def main():
         torch.cuda.synchronize()
         for _ in range(args.rounds):
             for v in ana:
-                fa.lib.flanhip_debug_kernel_variant(0, v)
+                fa.lib.flanhip_debug_option(fa.DEBUG_ANA_VARIANT, v)
                 ws = runs[v]["ws"]
                 if args.fused:
                     fn = lambda: fa.analyze_dev_fused(audio, ch, n, SR, W, HOP, DFT, pv, ws, stream)
@@ -103,13 +103,13 @@ def main():
             ms = sorted(runs[v]["ms"])
             med = ms[len(ms) // 2]
             res["analysis"][v] = {"median_ms": round(med, 4), "min_ms": round(ms[0], 4), "hbm_frac_algorithmic": round(bytes_per_launch / (med * 1e-3) / 8e12, 4), **runs[v]["info"]}
-        fa.lib.flanhip_debug_kernel_variant(0, 0)
+        fa.lib.flanhip_debug_option(fa.DEBUG_ANA_VARIANT, 0)
     # ---- synthesis variants (main kernel only: stage mask 4; the PV and the carries come from a fused analysis with variant 0 layout)
     if syn:
         ref = None
         runs = {}
         for v in syn:
-            fa.lib.flanhip_debug_kernel_variant(1, v)
+            fa.lib.flanhip_debug_option(fa.DEBUG_SYN_VARIANT, v)
             ws = ws_for()
             fa.analyze_dev(audio, ch, n, SR, W, HOP, DFT, pv, stream)
             out.zero_()
@@ -127,19 +127,17 @@ def main():
             runs[v] = {"info": info, "ms": [], "ws": ws}
         for _ in range(args.rounds):
             for v in syn:
-                fa.lib.flanhip_debug_kernel_variant(1, v)
+                fa.lib.flanhip_debug_option(fa.DEBUG_SYN_VARIANT, v)
                 ws = runs[v]["ws"]
                 fa.synthesize_dev(pv, ch, F, BINS, SR, ar, W, out, ws, nan_flag, stream)   # carries for this layout
-                fa.lib.flanhip_debug_synth_stages(4)
-                fn = lambda: fa.synthesize_dev(pv, ch, F, BINS, SR, ar, W, out, ws, nan_flag, stream)
+                fn = lambda: fa.synthesize_dev_stages(pv, ch, F, BINS, SR, ar, W, out, ws, nan_flag, 0, 4, stream)   # the main kernel alone
                 fn()
                 runs[v]["ms"].append(time_call(fn, args.reps))
-                fa.lib.flanhip_debug_synth_stages(0xF)
         for v in syn:
             ms = sorted(runs[v]["ms"])
             med = ms[len(ms) // 2]
             res["synthesis"][v] = {"median_ms": round(med, 4), "min_ms": round(ms[0], 4), "hbm_frac_algorithmic": round(bytes_per_launch / (med * 1e-3) / 8e12, 4), **runs[v]["info"]}
-        fa.lib.flanhip_debug_kernel_variant(1, 0)
+        fa.lib.flanhip_debug_option(fa.DEBUG_SYN_VARIANT, 0)
     text = json.dumps(res, indent=1)
     print(text)
     if args.out:

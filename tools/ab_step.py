@@ -34,7 +34,7 @@ def main():
     pairs = [tuple(int(v) for v in p.split(":")) for p in args.pairs.split(",")]
     state = {}
     for (a, s) in pairs:
-        fa.lib.flanhip_debug_kernel_variant(0, a); fa.lib.flanhip_debug_kernel_variant(1, s)
+        fa.lib.flanhip_debug_option(fa.DEBUG_ANA_VARIANT, a); fa.lib.flanhip_debug_option(fa.DEBUG_SYN_VARIANT, s)
         state[(a, s)] = {"ws": torch.empty(fa.synthesize_workspace_bytes(ch, F, BINS, SR, ar, W), dtype=torch.uint8, device=dev), "ms": []}
 
     def step(a, s):
@@ -43,7 +43,7 @@ def main():
         fa.synthesize_dev_fused(pv, ch, F, BINS, SR, ar, W, out, ws, flag, None)
     ref = None
     for (a, s) in pairs:
-        fa.lib.flanhip_debug_kernel_variant(0, a); fa.lib.flanhip_debug_kernel_variant(1, s)
+        fa.lib.flanhip_debug_option(fa.DEBUG_ANA_VARIANT, a); fa.lib.flanhip_debug_option(fa.DEBUG_SYN_VARIANT, s)
         for _ in range(60):
             step(a, s)
         torch.cuda.synchronize()
@@ -55,7 +55,7 @@ def main():
             state[(a, s)]["rms_vs_first"] = float(torch.sqrt((d * d).mean()).item())
     for _ in range(args.rounds):
         for (a, s) in pairs:
-            fa.lib.flanhip_debug_kernel_variant(0, a); fa.lib.flanhip_debug_kernel_variant(1, s)
+            fa.lib.flanhip_debug_option(fa.DEBUG_ANA_VARIANT, a); fa.lib.flanhip_debug_option(fa.DEBUG_SYN_VARIANT, s)
             step(a, s)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -66,7 +66,7 @@ def main():
     for k, v in state.items():
         ms = sorted(v["ms"])
         print("ana %d syn %d : median %.4f ms  min %.4f ms  (%.1f M frames/s)  rms vs first %s" % (k[0], k[1], ms[len(ms) // 2], ms[0], ch * F / ms[len(ms) // 2] / 1e3, v.get("rms_vs_first")))
-    fa.lib.flanhip_debug_kernel_variant(0, 0); fa.lib.flanhip_debug_kernel_variant(1, 0)
+    fa.lib.flanhip_debug_option(fa.DEBUG_ANA_VARIANT, 0); fa.lib.flanhip_debug_option(fa.DEBUG_SYN_VARIANT, 0)
 
 
 if __name__ == "__main__":

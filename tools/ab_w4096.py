@@ -27,7 +27,7 @@ for hop in (1024, 512):
         return e0.elapsed_time(e1) / reps
     for rnd in range(5):
         for v in (0, 1):
-            fa.lib.flanhip_debug_kernel_variant(2, v); fa.lib.flanhip_debug_kernel_variant(3, v)
+            fa.lib.flanhip_debug_option(fa.DEBUG_ANA4096_OLD, 1 - v); fa.lib.flanhip_debug_option(fa.DEBUG_SYN4096_OLD, 1 - v)
             for _ in range(20 if rnd == 0 else 3):
                 fa.analyze_dev(audio, ch, n, SR, W, hop, DFT, pv, None)
             res.setdefault((v, "ana_plain"), []).append(t(lambda: fa.analyze_dev(audio, ch, n, SR, W, hop, DFT, pv, None)))
@@ -35,4 +35,4 @@ for hop in (1024, 512):
             res.setdefault((v, "step_fused"), []).append(t(lambda: (fa.analyze_dev_fused(audio, ch, n, SR, W, hop, DFT, pv, ws, None), fa.synthesize_dev_fused(pv, ch, F, BINS, SR, ar, W, out, ws, flag, None))))
     for k, ms in sorted(res.items()):
         ms = sorted(ms); print("hop", hop, "variant", k[0], k[1], "median %.4f min %.4f ms" % (ms[len(ms)//2], ms[0]))
-    fa.lib.flanhip_debug_kernel_variant(2, 1); fa.lib.flanhip_debug_kernel_variant(3, 1)
+    fa.lib.flanhip_debug_option(fa.DEBUG_ANA4096_OLD, 1 - 1); fa.lib.flanhip_debug_option(fa.DEBUG_SYN4096_OLD, 1 - 1)

@@ -57,8 +57,8 @@ def main():
         return e0.elapsed_time(e1) / reps
 
     ana = {k: (lambda k=k: fa.analyze_dev_fused(inputs[k], ch, n, SR, W, HOP, DFT, pvs[k], wss[k], stream)) for k in inputs}
-    fa.lib.flanhip_debug_synth_stages(4)          # the main synthesis kernel alone
-    syn = {k: (lambda k=k: fa.synthesize_dev_fused(pvs[k], ch, F, BINS, SR, ar, W, out, wss[k], nan_flag, stream)) for k in inputs}
+    # the main synthesis kernel alone (stages = 4)
+    syn = {k: (lambda k=k: fa.synthesize_dev_stages(pvs[k], ch, F, BINS, SR, ar, W, out, wss[k], nan_flag, 1, 4, stream)) for k in inputs}
     for k in inputs:
         ana[k]()
     for _ in range(300):
@@ -72,7 +72,6 @@ def main():
         for k in inputs:
             syn[k]()
             res[k]["synthesis_ms"].append(time_call(syn[k], args.reps))
-    fa.lib.flanhip_debug_synth_stages(15)
     for k in inputs:
         a, s = sorted(res[k]["analysis_ms"]), sorted(res[k]["synthesis_ms"])
         print("%-40s analysis median %.4f min %.4f ms   synthesis median %.4f min %.4f ms" % (k, a[len(a) // 2], a[0], s[len(s) // 2], s[0]))

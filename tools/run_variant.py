@@ -32,8 +32,8 @@ def main():
     pv = torch.empty((ch, F, BINS, 2), dtype=torch.float32, device=dev)
     out = torch.empty((ch, F * HOP), dtype=torch.float32, device=dev)
     nan_flag = torch.zeros(1, dtype=torch.int32, device=dev)
-    fa.lib.flanhip_debug_kernel_variant(0, args.ana)
-    fa.lib.flanhip_debug_kernel_variant(1, args.syn)
+    fa.lib.flanhip_debug_option(fa.DEBUG_ANA_VARIANT, args.ana)
+    fa.lib.flanhip_debug_option(fa.DEBUG_SYN_VARIANT, args.syn)
     ws = torch.empty(fa.synthesize_workspace_bytes(ch, F, BINS, SR, ar, W), dtype=torch.uint8, device=dev)
     for _ in range(args.reps):
         if args.fused:

@@ -38,7 +38,7 @@ def main():
     pv = torch.empty((ch, F, BINS, 2), dtype=torch.float32, device=dev)
     buf = (ctypes.c_ulonglong * 16)()
     for v in [int(x) for x in args.ana.split(",")]:
-        fa.lib.flanhip_debug_kernel_variant(0, v)
+        fa.lib.flanhip_debug_option(fa.DEBUG_ANA_VARIANT, v)
         ws = torch.empty(fa.synthesize_workspace_bytes(ch, F, BINS, SR, SR / HOP, W), dtype=torch.uint8, device=dev)
         run = (lambda: fa.analyze_dev_fused(audio, ch, n, SR, W, HOP, DFT, pv, ws, stream)) if args.fused else (lambda: fa.analyze_dev(audio, ch, n, SR, W, HOP, DFT, pv, stream))
         for _ in range(50):
@@ -58,7 +58,7 @@ def main():
         for i, nm in enumerate(NAMES_ANA):
             if vals[i]:
                 print("   %-28s %8.0f ticks/frame  %5.1f %%" % (nm, vals[i] / frames, 100.0 * vals[i] / total))
-    fa.lib.flanhip_debug_kernel_variant(0, 0)
+    fa.lib.flanhip_debug_option(fa.DEBUG_ANA_VARIANT, 0)
 
 
 if __name__ == "__main__":

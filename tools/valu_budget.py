@@ -35,15 +35,15 @@ def run():
     nan_flag = torch.zeros(1, dtype=torch.int32, device=dev)
     ws = torch.empty(fa.synthesize_workspace_bytes(ch, F, BINS, SR, ar, W), dtype=torch.uint8, device=dev)
     for a in ANA:
-        fa.lib.flanhip_debug_kernel_variant(0, a)
-        fa.lib.flanhip_debug_kernel_variant(1, 1)
+        fa.lib.flanhip_debug_option(fa.DEBUG_ANA_VARIANT, a)
+        fa.lib.flanhip_debug_option(fa.DEBUG_SYN_VARIANT, 1)
         for _ in range(3):
             fa.analyze_dev_fused(audio, ch, n, SR, W, HOP, DFT, pv, ws, stream)
         torch.cuda.synchronize()
-    fa.lib.flanhip_debug_kernel_variant(0, 4)
+    fa.lib.flanhip_debug_option(fa.DEBUG_ANA_VARIANT, 4)
     fa.analyze_dev_fused(audio, ch, n, SR, W, HOP, DFT, pv, ws, stream)
     for s in SYN:
-        fa.lib.flanhip_debug_kernel_variant(1, s)
+        fa.lib.flanhip_debug_option(fa.DEBUG_SYN_VARIANT, s)
         for _ in range(3):
             fa.analyze_dev_fused(audio, ch, n, SR, W, HOP, DFT, pv, ws, stream)      # the synthesis consumes the producer note
             fa.synthesize_dev_fused(pv, ch, F, BINS, SR, ar, W, out, ws, nan_flag, stream)

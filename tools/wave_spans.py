@@ -34,7 +34,7 @@ def main():
     synth = "--syn" in sys.argv
     for a in sys.argv:
         if a.startswith("--ana-variant="):
-            fa.lib.flanhip_debug_kernel_variant(0, int(a.split("=")[1]))
+            fa.lib.flanhip_debug_option(fa.DEBUG_ANA_VARIANT, int(a.split("=")[1]))
             print("analysis kernel variant", a.split("=")[1])
     if "--dft4096" in sys.argv:
         DFT = 4096
