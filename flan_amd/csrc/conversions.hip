@@ -8,6 +8,7 @@
 #include "pv_kernels_v2.h"
 #include "pv_kernels_eo.h"
 #include "pv_kernels_any.h"
+#include "pv_kernels_mr.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -17,6 +18,7 @@ namespace flanhip {
 // diagnostic builds (FLANHIP_ABLATIONS: 101 ... for the analysis, 102 ... for the synthesis) and, for the synthesis, 2 = behind the scan
 // kernel even where it could work out its own carries.  dft 4096 keeps its round-1 kernels as the A/B predecessor (ANA4096_OLD / SYN4096_OLD)
 // -- they are also what windows that are no multiple of 256 run.  All per calling thread (core.hip: debug_options).
+
 static constexpr size_t kMaxLds = 160 * 1024;   // gfx950: 160 KiB LDS per CU, one workgroup may take all of it
 
 // dft sizes: powers of two in [32, 8192] have FFT kernels (tuned or LDS-resident); every other EVEN size the reference would hand to FFTW
@@ -24,6 +26,38 @@ static constexpr size_t kMaxLds = 160 * 1024;   // gfx950: 160 KiB LDS per CU, o
 // PVBuffer derives the dft size as ( bins - 1 ) * 2 (PVBuffer.cpp:356-359), so an odd one does not survive its own round trip.
 static constexpr int kMaxAnyDft = 1 << 20;
 static bool fft_size( int dft ) { return is_pow2( dft ) && dft >= 32 && dft <= 8192; }
+// ... and the sizes the mixed-radix kernels serve (pv_kernels_mr.h): half the size a product of 2, 3, 5, 7, 11, 13, at most 8192, and the block's
+// tables and state within the LDS of a CU for this window
+static int mr_blocks_per_cu( const MrPlan & pl, int W )
+	{
+	const size_t lds = std::max( mr_analyze_lds( pl.C, W, pl.win_lds, pl.kc_lds ), mr_synth_lds( pl.C, W, pl.win_lds, pl.kc_lds ) );
+	if( lds > kMaxLds ) return 0;
+	return int( std::min<size_t>( mr_pingpong( pl.C ) ? 2 : 1, kMaxLds / lds ) );      // (blocks of 8 wavefronts; four / two wavefronts per SIMD: the kernels' register budgets)
+	}
+static bool mr_size( int dft, int W, MrPlan * pl = nullptr )
+	{
+	MrPlan best;
+	if( fft_size( dft ) || debug_options().force_direct || !mr_make_plan( dft, &best ) ) return false;
+	// where the optional tables go: the layout that keeps the most blocks resident per CU; between equals the one with more tables in LDS
+	int best_blocks = 0;
+	for( int kc = 0; kc < 2; ++kc ) for( int wl = 0; wl < 2; ++wl )
+		{
+		MrPlan t = best; t.kc_lds = kc; t.win_lds = wl;
+		const int b = mr_blocks_per_cu( t, W );
+		if( b > best_blocks || ( b == best_blocks && b > 0 && kc + wl >= best.kc_lds + best.win_lds ) ) { best = t; best_blocks = b; }
+		}
+	if( best_blocks == 0 ) return false;
+	if( pl ) *pl = best;
+	return true;
+	}
+// chains the device holds at once for them: one block per chain
+static int mr_target_chains( int dft, int W )
+	{
+	MrPlan pl{};
+	if( !mr_size( dft, W, &pl ) ) return cu_count();
+	return cu_count() * std::max( 1, mr_blocks_per_cu( pl, W ) );
+	}
+
 static bool dft_size_ok( int dft ) { return dft >= 4 && dft % 2 == 0 && dft <= kMaxAnyDft; }
 
 // unit[m] = ( cos, sin )( 2 pi m / N ) in double, exact at the quarter turns; per ( device, N ), never freed (like the plans)
@@ -327,8 +361,10 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	FLANHIP_REQUIRE( ch > 0 && n >= 0 && W >= 2 && hop >= 1 && sr > 0.0f, FLANHIP_ERR_INVALID_ARG, "bad sizes" );
 	FLANHIP_REQUIRE( W <= dft, FLANHIP_ERR_INVALID_ARG, "window_size larger than dft_size" );
 	FLANHIP_REQUIRE( dft_size_ok( dft ), FLANHIP_ERR_UNSUPPORTED, "dft_size must be even, at least 4 and at most 2^20" );
-	const bool any = !fft_size( dft );
 	if( int rc = require_device() ) return rc;
+	MrPlan mr_plan{};
+	const bool mr = mr_size( dft, W, &mr_plan );
+	const bool any = !fft_size( dft ) && !mr;
 	const Plan * plan = nullptr;
 	if( int rc = get_plan( W, dft, &plan ) ) return rc;
 
@@ -340,7 +376,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	// (hop: the dft 2048 kernel addresses a block's samples by 32-bit byte offsets from the block's first frame -- up to 8 chains of <= ~512 frames,
 	// env overrides aside -- and the generic kernels serve the hops that would not fit: nothing anybody analyses with)
 	const bool fast = ( dft == 2048 || dft == 4096 ) && n >= 2 && n < ( int64_t( 1 ) << 31 ) - 8192 && hop <= 65536 && !force_generic();
-	int target_chains = any ? any_target_chains( dft / 2 + 1 ) : fast ? fast_target_chains( dft, false ) : generic_target_chains( dft );
+	int target_chains = any ? any_target_chains( dft / 2 + 1 ) : mr ? mr_target_chains( dft, W ) : fast ? fast_target_chains( dft, false ) : generic_target_chains( dft );
 	p.L = choose_chain_length( ch, p.F, any ? 7 : 1, target_chains );
 	p.chains_per_channel = int( ( p.F + p.L - 1 ) / p.L );
 	p.sample_rate = sr;
@@ -352,7 +388,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	p.cancel = thread_cancel_word( s );                                           // kernels stop starting chains when the thread's wait raises it (core.hip)
 	// windows above 2048: the WBIG team kernels (pv_kernels_eo.h)
 	const bool team_big = fast && dft == 4096 && W > 2048 && !debug_options().ana11_old;
-	const bool kernel_sums = !any;                                   // every other FFT analysis kernel keeps the sums; for the rest the pre-pass kernel runs on the analysis' behalf
+	const bool kernel_sums = !any && !mr;                            // every power-of-two analysis kernel keeps the sums; for the rest the pre-pass kernel runs on the analysis' behalf
 	SynthLayout fused_lay{};
 	if( d_fused_ws )
 		{
@@ -401,6 +437,17 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 		FLANHIP_CHECK( hipGetLastError() );
 		return prepass_on_behalf();
 		}
+	if( mr )
+		{
+		const int64_t chains = int64_t( p.chains_per_channel ) * ch;
+		FLANHIP_REQUIRE( chains < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
+		const size_t lds = mr_analyze_lds( mr_plan.C, W, mr_plan.win_lds, mr_plan.kc_lds );
+		auto kern = mr_pingpong( mr_plan.C ) ? k_analyze_mr<true> : k_analyze_mr<false>;
+		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+		hipLaunchKernelGGL( kern, dim3( (unsigned) chains ), dim3( MR_THREADS ), lds, s, p, mr_plan );
+		FLANHIP_CHECK( hipGetLastError() );
+		return prepass_on_behalf();
+		}
 	if( fast )
 		{
 		FastTables tb{ plan->d_tw1f, plan->d_tw3f, plan->d_tw2 };
@@ -446,11 +493,12 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	FLANHIP_REQUIRE( W <= o->dft, FLANHIP_ERR_INVALID_ARG, "window_size larger than dft size" );
 	FLANHIP_REQUIRE( dft_size_ok( o->dft ), FLANHIP_ERR_UNSUPPORTED, "dft size must be even, at least 4 and at most 2^20" );
 	FLANHIP_REQUIRE( int64_t( o->dft ) * W < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "dft_size * window_size overflows the int product of AudioPV.cpp:99" );
-	o->any = !fft_size( o->dft );
+	const bool mr = mr_size( o->dft, W );
+	o->any = !fft_size( o->dft ) && !mr;
 	o->head_len = o->any ? 0 : std::max( W - o->hop, 0 );        // (the direct-sum path overlap-adds whole frames from its own scratch: no chain heads)
 	const int overlap = ( W + o->hop - 1 ) / o->hop;              // frames covering one output sample
 	const int kind = o->any ? 0 : synth_fast_kind( o->dft, W, o->hop );
-	const int slots = o->any ? any_target_chains( bins ) : kind == 0 ? generic_target_chains( o->dft ) : ( kind == 2 && o->dft == 4096 ) ? cu_count() * kRingWaves11 : fast_target_chains( o->dft, true );
+	const int slots = o->any ? any_target_chains( bins ) : mr ? mr_target_chains( o->dft, W ) : kind == 0 ? generic_target_chains( o->dft ) : ( kind == 2 && o->dft == 4096 ) ? cu_count() * kRingWaves11 : fast_target_chains( o->dft, true );
 	o->L = choose_chain_length( ch, F, o->any ? 1 : std::max( overlap - 1, 1 ), slots );
 	o->chains_per_channel = int( ( F + o->L - 1 ) / o->L );
 	const int64_t chains = int64_t( o->chains_per_channel ) * ch;
@@ -594,6 +642,15 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 		FLANHIP_CHECK( hipGetLastError() );
 		rc = FLANHIP_OK;
 		}
+	else if( MrPlan mr_plan{}; mr_size( lay.dft, W, &mr_plan ) )
+		{
+		const size_t lds = mr_synth_lds( mr_plan.C, W, mr_plan.win_lds, mr_plan.kc_lds );
+		auto kern = mr_pingpong( mr_plan.C ) ? k_synthesize_mr<true> : k_synthesize_mr<false>;
+		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+		hipLaunchKernelGGL( kern, dim3( (unsigned) chains ), dim3( MR_THREADS ), lds, s, p, mr_plan );
+		FLANHIP_CHECK( hipGetLastError() );
+		rc = FLANHIP_OK;
+		}
 	else if( synth_fast_ok( lay.dft, W, lay.hop ) )
 		{
 		FastTables tb{ plan->d_tw1f, plan->d_tw3f, plan->d_tw2 };
@@ -714,6 +771,7 @@ void flanhip_debug_option( int which, int value )
 		case FLANHIP_DEBUG_ANA4096_OLD:     o.ana11_old = value; break;
 		case FLANHIP_DEBUG_SYN4096_OLD:     o.syn11_old = value; break;
 		case FLANHIP_DEBUG_RESAMPLE_DIRECT: o.resample_direct = value; break;
+		case FLANHIP_DEBUG_FORCE_DIRECT:    o.force_direct = value; break;
 		default: break;
 		}
 	}

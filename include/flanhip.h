@@ -164,6 +164,8 @@ int flanhip_synthesize_dev_stages(const flanhip_MF * d_pv, int64_t num_channels,
 #define FLANHIP_DEBUG_RESAMPLE_DIRECT 8   /* 1: Audio::resample's 2:1 block convolver always as direct fp64 sums in the checker's operation order
                                            * (default: fp64 overlap-save FFT convolution, the reference's own method, r8brain/CDSPBlockConvolver.h:242-344,
                                            * for float streams of at least 8 blocks) */
+#define FLANHIP_DEBUG_FORCE_DIRECT    9   /* 1: dft sizes without power-of-two kernels as direct fp64 sums (the transform's definition: pv_kernels_any.h),
+                                           * never the mixed-radix FFT kernels (pv_kernels_mr.h): the checker-order path, for A/B */
 void flanhip_debug_option(int which, int value);
 
 /* ---- PV frame processors ------------------------------------------------------------------------------------- */

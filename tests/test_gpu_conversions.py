@@ -82,7 +82,13 @@ CASES = [
     ("hop_eq_window", 1, 20000, 1024, 1024, 1024, "noise"),
     ("hop_gt_window", 1, 20000, 512, 700, 1024, "noise"),
     ("odd_hop", 1, 20000, 2048, 333, 2048, "noise"),
-    # dft sizes without FFT kernels (any even size goes to FFTW in the reference, FFTHelper.cpp:16-26): the direct-sum kernels (pv_kernels_any.h)
+    # dft sizes without power-of-two kernels (any even size goes to FFTW in the reference, FFTHelper.cpp:16-26): the mixed-radix kernels
+    # (pv_kernels_mr.h: half the size a product of 2, 3, 5, 7, 11, 13, at most 8192) and, for the rest (2998 = 2 x 1499), the direct sums
+    # (pv_kernels_any.h)
+    ("dft2002_radices_7_11_13", 1, 20000, 1024, 256, 2002, "noise"),
+    ("dft1920_win1024", 2, 20000, 1024, 256, 1920, "noise"),
+    ("dft12000_in_place_odd_radices", 1, 40000, 2048, 512, 12000, "noise"),
+    ("dft6000_hop300", 1, 30000, 2400, 300, 6000, "noise"),
     ("dft3000", 1, 30000, 2048, 512, 3000, "noise"),
     ("dft3000_stereo_ragged", 2, 12345, 2048, 512, 3000, "noise"),
     ("dft16384_win4096", 1, 60000, 4096, 1024, 16384, "noise"),
@@ -486,7 +492,7 @@ def test_cancellation_inside_a_launch(fa):
     lib, vp = fa.lib, ctypes.c_void_p
     dev = torch.device("cuda", 0)
     fa.check(lib.flanhip_set_device(0))
-    sr, W, hop, dft = 48000.0, 4096, 1024, 16384                  # a direct-sum size: tenths of a second of kernel time
+    sr, W, hop, dft = 48000.0, 4096, 1024, 9998                   # a direct-sum size (2 x 4999, a prime): a tenth of a second of kernel time
     ch, n = 8, 90 * 48000
     F = int(lib.flanhip_num_pv_frames(n, hop))
     x = torch.empty((ch, n), dtype=torch.float32, device=dev)
@@ -549,3 +555,76 @@ def test_cancellation_inside_a_launch(fa):
     th.join()
     print("[cancel, FFT kernels] full launch %.1f ms, cancelled after %.1f ms" % (full2 * 1e3, cut2 * 1e3))
     assert rc == flan_amd.ERR_CANCELLED and cut2 <= 0.8 * full2
+
+
+def test_cancellation_is_scoped_to_the_stream_waited_on(fa):
+    """A thread with conversions in flight on TWO streams cancels the wait on one of them: the other stream's kernels run to completion and
+    its later plain synchronisation reports a whole result (round 3 kept one cancel word per thread: the second stream's kernels stopped
+    starting chains too, and its synchronisation returned FLANHIP_OK on a half-written PV)."""
+    import ctypes
+    import threading
+    import time
+    import torch
+    import flan_amd
+    lib, vp = fa.lib, ctypes.c_void_p
+    dev = torch.device("cuda", 0)
+    fa.check(lib.flanhip_set_device(0))
+    sA, sB = vp(), vp()
+    fa.check(lib.flanhip_stream_create(ctypes.byref(sA)))
+    fa.check(lib.flanhip_stream_create(ctypes.byref(sB)))
+    sr, W, hop, dft = 48000.0, 2048, 128, 2048
+    ch, n = 16, 600 * 48000                                        # four rounds of blocks: ~10 ms
+    F = int(lib.flanhip_num_pv_frames(n, hop))
+    x = torch.empty((ch, n), dtype=torch.float32, device=dev)
+    fa.check(lib.flanhip_noise_dev(vp(x.data_ptr()), ch, n, 6, None))
+    pvA = torch.empty((ch, F, dft // 2 + 1, 2), dtype=torch.float32, device=dev)
+    chB, nB = 2, 300 * 48000
+    FB = int(lib.flanhip_num_pv_frames(nB, hop))
+    pvB = torch.empty((chB, FB, dft // 2 + 1, 2), dtype=torch.float32, device=dev)
+    refB = torch.empty_like(pvB)
+    fa.check(lib.flanhip_analyze_dev(vp(x.data_ptr()), chB, nB, sr, W, hop, dft, vp(refB.data_ptr()), None))
+    torch.cuda.synchronize()
+    flag = ctypes.c_int(0)
+    goA = lambda: fa.check(lib.flanhip_analyze_dev(vp(x.data_ptr()), ch, n, sr, W, hop, dft, vp(pvA.data_ptr()), sA))
+    goA()
+    t0 = time.perf_counter()
+    assert lib.flanhip_wait_cancellable(sA, ctypes.byref(flag)) == 0
+    goA()
+    t0 = time.perf_counter()
+    assert lib.flanhip_wait_cancellable(sA, ctypes.byref(flag)) == 0
+    full = time.perf_counter() - t0
+    pvB.zero_()
+    torch.cuda.synchronize()
+    th = threading.Thread(target=lambda: (time.sleep(0.1 * full), setattr(flag, "value", 1)))
+    goA()
+    fa.check(lib.flanhip_analyze_dev(vp(x.data_ptr()), chB, nB, sr, W, hop, dft, vp(pvB.data_ptr()), sB))   # the same thread, another stream
+    th.start()
+    rc = lib.flanhip_wait_cancellable(sA, ctypes.byref(flag))
+    th.join()
+    assert rc == flan_amd.ERR_CANCELLED
+    fa.check(lib.flanhip_stream_synchronize(sB))
+    torch.cuda.synchronize()
+    assert torch.equal(pvB.view(torch.int32), refB.view(torch.int32)), "the cancellation of stream A reached the kernels of stream B"
+    flag.value = 0
+    fa.check(lib.flanhip_stream_destroy(sA))
+    fa.check(lib.flanhip_stream_destroy(sB))
+
+
+@pytest.mark.parametrize("W,hop,dft", [(2048, 512, 3000), (4096, 1024, 16384), (600, 150, 1000)])
+def test_mixed_radix_kernels_against_the_direct_sums(fa, W, hop, dft):
+    """The mixed-radix FFT kernels (pv_kernels_mr.h) against the transform's definition summed in fp64 (pv_kernels_any.h, the force_direct hook)
+    on the same input: PVs agree like two FFT backends do, audio from the SAME PV to 1e-6."""
+    sr = 48000.0
+    x = O.noise(2, 40000 + 3 * hop, seed=dft)
+    ar = np.float32(sr) / np.float32(hop)
+    pv_fft = fa.analyze(x, sr, W, hop, dft)
+    out_fft, _ = fa.synthesize(pv_fft, sr, ar, W)
+    with fa.debug_options(force_direct=1):
+        pv_def = fa.analyze(x, sr, W, hop, dft)
+        out_def, _ = fa.synthesize(pv_fft, sr, ar, W)
+    m0, m1 = pv_def[..., 0].astype(np.float64), pv_fft[..., 0].astype(np.float64)
+    rel_m = np.sqrt(np.sum((m0 - m1) ** 2) / np.sum(m0 ** 2))
+    same_f = np.mean(pv_def[..., 1].view(np.uint32) == pv_fft[..., 1].view(np.uint32))
+    d = np.abs(out_fft.astype(np.float64) - out_def.astype(np.float64)).max()
+    print("\n[dft %d] FFT kernels vs direct sums: rel_m %.2e  f bit-identical %.4f  audio max diff %.2e" % (dft, rel_m, same_f, d))
+    assert rel_m <= 5e-7 and same_f >= 0.95 and d <= 1e-6

@@ -1,0 +1,11 @@
+# SQ counters of the mixed-radix kernels at (2048, 512, 3000), 8 ch x 60 s
+set -e
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+CMD="python $R/bench.py --window 2048 --hop 512 --dft ${1:-3000} --no-cpu --no-configs --steps 5 --warmup 2 --preroll-ms 0"
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $R/gpurun_out/prof_mr1 -- $CMD > /dev/null 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC SQ_LDS_BANK_CONFLICT --output-format csv -d $R/gpurun_out/prof_mr2 -- $CMD > /dev/null 2>&1
+cd $R
+python tools/pmc_summary.py gpurun_out/prof_mr1 gpurun_out/prof_mr2 > gpurun_out/mr_sq_counters.txt
+rm -rf gpurun_out/prof_mr1 gpurun_out/prof_mr2
+grep -A2 "_mr" gpurun_out/mr_sq_counters.txt | cut -c1-330
