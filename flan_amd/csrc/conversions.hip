@@ -672,7 +672,14 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	if( rc ) return rc;
 	if( ( stages & 8 ) && p.head_len > 0 && p.chains_per_channel > 1 )
 		{
-		hipLaunchKernelGGL( k_ola_fixup, dim3( (unsigned) chains ), dim3( 256 ), 0, s, p );
+		const bool quads = p.hop % 4 == 0 && ( W / 2 ) % 4 == 0 && p.head_len % 4 == 0 && p.out_len % 4 == 0
+			&& ( reinterpret_cast<uintptr_t>( p.out ) & 15 ) == 0 && ( reinterpret_cast<uintptr_t>( p.head ) & 15 ) == 0;
+		if( quads )
+			{
+			const int64_t threads = int64_t( ch ) * ( p.chains_per_channel - 1 ) * ( p.head_len / 4 );
+			hipLaunchKernelGGL( k_ola_fixup4, dim3( (unsigned) ( ( threads + 255 ) / 256 ) ), dim3( 256 ), 0, s, p );
+			}
+		else hipLaunchKernelGGL( k_ola_fixup, dim3( (unsigned) chains ), dim3( 256 ), 0, s, p );
 		FLANHIP_CHECK( hipGetLastError() );
 		}
 	return FLANHIP_OK;

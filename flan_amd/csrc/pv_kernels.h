@@ -524,5 +524,32 @@ __global__ __launch_bounds__( 256 ) void k_ola_fixup( SynthParams p )
 		if( a >= 0 && a < p.out_len ) out[a] += head[e];
 		}
 	}
+// The same sixteen bytes at a time, for the shapes whose heads start on 16-byte boundaries (hop, window / 2, the head length and the channel
+// length multiples of 4 samples, 16-byte aligned buffers: every tuned shape): one thread per float4 of every boundary, ( chain, quad ) flat over
+// the grid -- a quarter of the memory instructions and no idle first block per channel (8 ch x 60 s: 10 -> 6 us)
+__global__ __launch_bounds__( 256 ) void k_ola_fixup4( SynthParams p )
+	{
+	typedef float f4 __attribute__(( ext_vector_type( 4 ) ));
+	const int quads = p.head_len / 4, per_channel = p.chains_per_channel - 1;      // boundaries of a channel
+	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
+	if( idx >= int64_t( p.num_channels ) * per_channel * quads ) return;
+	const int q = int( idx % quads );
+	const int64_t b = idx / quads;
+	const int channel = int( b / per_channel ), chain_in_channel = int( b % per_channel ) + 1;
+	const int64_t chain = int64_t( channel ) * p.chains_per_channel + chain_in_channel;
+	const int64_t a = int64_t( p.hop ) * ( int64_t( chain_in_channel ) * p.L ) - p.window_size / 2 + 4 * q;
+	float * out = p.out + int64_t( channel ) * p.out_len;
+	const float * head = p.head + chain * p.head_len + 4 * q;
+	if( a >= 0 && a + 3 < p.out_len )
+		{
+		const f4 h = *reinterpret_cast<const f4*>( head );
+		f4 * o = reinterpret_cast<f4*>( out + a );
+		*o = *o + h;
+		}
+	else
+		{
+		for( int i = 0; i < 4; ++i ) if( a + i >= 0 && a + i < p.out_len ) out[a + i] += head[i];
+		}
+	}
 
 } // namespace flanhip
