@@ -509,6 +509,14 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	o->group_offset = o->carry_bytes + o->head_bytes + 1024;       // tail: NaN flag (4 B at +0), dump area (512 B at +512); then the group sums
 	o->group_bytes = ( size_t( ch ) * o->groups_per_channel * bins * sizeof( double ) + 255 ) & ~size_t( 255 );
 	o->total_bytes = o->group_offset + 2 * o->group_bytes;             // the producer's group totals, then the group carries the synthesis' own scan over them leaves
+	// the dft 2048 synthesis kernel adds the overlaps of neighbouring chains itself (pv_kernels_v2.h): a state word per chain and a second side buffer
+	o->fix_offset = o->tail_offset = 0;
+	if( !o->any && !mr && o->dft == 2048 && kind == 1 && o->head_len > 0 )
+		{
+		o->fix_offset = o->total_bytes;
+		o->tail_offset = o->fix_offset + ( ( size_t( chains ) * sizeof( int ) + 255 ) & ~size_t( 255 ) );
+		o->total_bytes = o->tail_offset + o->head_bytes;
+		}
 	o->any_spec_offset = o->any_frames_offset = 0;
 	if( o->any )
 		{
@@ -563,6 +571,13 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	p.skip_words = presummed == 2 ? p.nan_in : nullptr;
 	p.carry_in = d_carry_in; p.total_out = d_total_out; p.total_only = prepass_only ? 1 : 0;
 	p.cancel = thread_cancel_word( s );
+	const bool self_fix = lay.fix_offset != 0 && !debug_options().separate_fixup && !prepass_only;
+	if( self_fix )
+		{
+		p.fix_state = reinterpret_cast<int*>( reinterpret_cast<char*>( d_ws ) + lay.fix_offset );
+		p.tail = reinterpret_cast<float*>( reinterpret_cast<char*>( d_ws ) + lay.tail_offset );
+		p.fix_tag = int( ( unsigned( next_epoch() ) & 0x1FFFFFFFu ) << 2 );
+		}
 
 	const int64_t chains = int64_t( p.chains_per_channel ) * ch;
 	FLANHIP_REQUIRE( chains < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
@@ -670,7 +685,7 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 		default: set_error( "unsupported dft size %d", lay.dft );
 		}
 	if( rc ) return rc;
-	if( ( stages & 8 ) && p.head_len > 0 && p.chains_per_channel > 1 )
+	if( ( stages & 8 ) && p.head_len > 0 && p.chains_per_channel > 1 && !self_fix )
 		{
 		const bool quads = p.hop % 4 == 0 && ( W / 2 ) % 4 == 0 && p.head_len % 4 == 0 && p.out_len % 4 == 0
 			&& ( reinterpret_cast<uintptr_t>( p.out ) & 15 ) == 0 && ( reinterpret_cast<uintptr_t>( p.head ) & 15 ) == 0;
@@ -779,6 +794,7 @@ void flanhip_debug_option( int which, int value )
 		case FLANHIP_DEBUG_SYN4096_OLD:     o.syn11_old = value; break;
 		case FLANHIP_DEBUG_RESAMPLE_DIRECT: o.resample_direct = value; break;
 		case FLANHIP_DEBUG_FORCE_DIRECT:    o.force_direct = value; break;
+		case FLANHIP_DEBUG_SEPARATE_FIXUP:  o.separate_fixup = value; break;
 		default: break;
 		}
 	}

@@ -66,6 +66,7 @@ struct DebugOptions
 	int ana_variant = 0, syn_variant = 0;      // dft 2048: ablated instantiations of diagnostic builds; synthesis 2 = behind the scan kernel
 	int ana11_old = 0, syn11_old = 0;          // dft 4096: 1 = the round-1 kernels instead of the team kernels (A/B predecessor)
 	int resample_direct = 0;                   // 1: the 2:1 block convolver always as direct sums
+	int separate_fixup = 0;                    // 1: k_ola_fixup as its own launch even where the synthesis kernel adds the overlaps itself
 	int force_direct = 0;                      // 1: dft sizes without power-of-two kernels as direct fp64 sums (pv_kernels_any.h), never the mixed-radix kernels
 	};
 DebugOptions & debug_options();
@@ -91,6 +92,7 @@ int next_epoch();
 // groups: aligned runs of 8 consecutive chains of a channel (one 8-wave block of the dft 2048 kernels); group_bytes: one fp64 sum per
 // (channel, group, bin) behind the 1024-byte tail -- what lets the synthesis kernel compute its own carries (no scan kernel)
 struct SynthLayout { int hop, dft, L, chains_per_channel, head_len, groups_per_channel; size_t carry_bytes, head_bytes, group_offset, group_bytes, total_bytes;
+	size_t fix_offset, tail_offset;   // k_synthesize_v2's own overlap fix-up: a state word per chain, then a second side buffer the size of the heads' (0: not this shape)
 	bool any; size_t any_spec_offset, any_frames_offset; };   // any: a dft size without FFT kernels (pv_kernels_any.h) and its scratch in the workspace
 // which producer last left its pre-pass in a synthesis workspace (host-side note, keyed by the workspace pointer, written when the
 // producer is launched and read when flanhip_synthesize_dev_fused is): 1 = chain sums AND group sums (the dft 2048 analysis kernel)

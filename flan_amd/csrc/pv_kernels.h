@@ -307,6 +307,11 @@ struct SynthParams
 	const double * group_sums; // optional (dft 2048 / 4096 team kernels): the producer's per-group sums [ch][groups][bins] -- a scan over THEM (k_phase_scan2<SEG, true>:
 	int groups_per_channel;    // an eighth or a quarter of the chains) leaves each group's carry in group_carry, and the synthesis kernel works out its chains'
 	double * group_carry;      // carries from that and the chain sums in `carry` (which it leaves untouched): the scan over the chains is not launched
+	// k_synthesize_v2 adding the chains' overlaps itself (no k_ola_fixup launch, round 4): one state word per boundary, a side buffer for a
+	// chain's LAST partial sums beside `head` (its first ones), this launch's tag
+	int * fix_state;           // optional [chains]: word c belongs to the boundary between chain c - 1 and chain c of a channel
+	float * tail;              // [ch][chains][W-hop]
+	int fix_tag;               // ( epoch << 2 ): | 1 = the boundary's tail is in `tail`, | 2 = its head is in `head`
 	};
 
 // (the pre-pass kernels k_phase_sums2 / k_phase_scan2 that serve every size live in pv_kernels_fast.h)

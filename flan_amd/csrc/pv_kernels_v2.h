@@ -535,6 +535,19 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_v2( AnalyzeParams p, F
 //     row t + 1 ] -- so that the wait for the MF row is a counted one that leaves the output stores in flight;
 //   * the MF rows are read once: non-temporal loads.
 // =================================================================================================================
+// 8-byte loads / stores that other XCDs' wavefronts see inside a launch (agent scope: the L2s of two XCDs are not coherent for ordinary accesses)
+__device__ __forceinline__ void st_agent( cf * p, cf v )
+	{
+	unsigned long long bits; __builtin_memcpy( &bits, &v, 8 );
+	__hip_atomic_store( reinterpret_cast<unsigned long long*>( p ), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+	}
+__device__ __forceinline__ cf ld_agent( const cf * p )
+	{
+	const unsigned long long bits = __hip_atomic_load( reinterpret_cast<const unsigned long long*>( p ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+	cf v; __builtin_memcpy( &v, &bits, 8 );
+	return v;
+	}
+
 struct V2LdsSyn
 	{
 	static constexpr int C = 1024;
@@ -610,12 +623,14 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 	// Exactly one store instruction per step, never inside a branch: lanes that fall outside the output are pointed at a 512-byte dump
 	// area in the workspace, so the number of stores in flight behind the row request is static (counted wait, see the loop)
 	cf * dump2 = reinterpret_cast<cf*>( p.dump ) + lane;
+	const bool fix = p.fix_state != nullptr;                                    // this launch adds the chains' overlaps itself (below)
 	auto emit_step = [&]( int64_t a0, cf v )
 		{
 		const int64_t a = a0 + 2 * lane;
 		cf * dst = ( a0 < own_start ) ? head2 + ( ( a - chain_start ) >> 1 ) : out2 + ( a >> 1 );
 		if( ( ABL & 4 ) || ( a0 >= own_start && !( a >= 0 && a < p.out_len ) ) ) dst = dump2;           // ABL 4 (timing only): every store to the dump area
-		*dst = v;
+		if( fix && a0 < own_start ) st_agent( dst, v );                          // (the head another wavefront may come to add up: see the end of the kernel)
+		else *dst = v;
 		};
 	// MF row of frame t: ( m, f ) of the lane's pairs and of bin C/2
 	cf mfk[H], mfm[H], mfx;
@@ -853,13 +868,81 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 	// flush the partial sums that the next chain's head completes; the last chain zero-fills to the end of the output
 	const int64_t ring_end = pos + ( W - hop );
 	const int64_t flush_end = last_chain ? max( ring_end, p.out_len ) : ring_end;
-	#pragma unroll
-	for( int q = 0; q < E; ++q )
+	if( !fix || last_chain )
 		{
-		const int64_t a0 = pos + 128 * q;
-		if( a0 < flush_end ) emit_step( a0, acc[q] );
+		#pragma unroll
+		for( int q = 0; q < E; ++q )
+			{
+			const int64_t a0 = pos + 128 * q;
+			if( a0 < flush_end ) emit_step( a0, acc[q] );
+			}
+		for( int64_t a0 = pos + 128 * E; a0 < flush_end; a0 += 128 ) emit_step( a0, mk( 0.0f, 0.0f ) );
 		}
-	for( int64_t a0 = pos + 128 * E; a0 < flush_end; a0 += 128 ) emit_step( a0, mk( 0.0f, 0.0f ) );
+	// ---- the overlaps of neighbouring chains, added here instead of by a launch of their own (k_ola_fixup: a launch and two round trips to
+	// memory behind every convert_to_audio).  The W - hop samples at a boundary get the LAST partial sums of the chain before it (still in
+	// `acc` here) and the FIRST ones of the chain after it (in its `head` buffer since its first frames).  Whichever of the two wavefronts
+	// reaches its end second adds them up -- nobody waits for anybody, so the order in which blocks are scheduled cannot matter: a state
+	// word per boundary, written with an atomic exchange; the first to arrive leaves its half where the other finds it (the tail in `tail`;
+	// the head is in `head` already) BEHIND a drained memory queue, the second sees the first's tag in what the exchange returns.  The
+	// two halves cross XCDs inside a launch: they are written and read at agent scope (st_agent / ld_agent), past the L2s.  One addition
+	// per sample, tail + head, as k_ola_fixup does it: the same bits.
+	if( fix )
+		{
+		const int tag_tail = p.fix_tag | 1, tag_head = p.fix_tag | 2;
+		const int nsteps = p.head_len / 128;                                        // steps of 128 samples a boundary holds (W - hop, a multiple of 128 here)
+		auto exchange = [&]( int * word, int tag )
+			{
+			int old = 0;
+			if( lane == 0 ) old = __hip_atomic_exchange( word, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+			return __builtin_amdgcn_readfirstlane( old );
+			};
+		if( !last_chain )
+			{
+			// this chain's tail meets the next chain's head
+			int * word = p.fix_state + ( chain + 1 );
+			const cf * head_next = reinterpret_cast<const cf*>( p.head + ( chain + 1 ) * p.head_len ) + lane;
+			cf * tail_next = reinterpret_cast<cf*>( p.tail + ( chain + 1 ) * p.head_len ) + lane;
+			int seen = 0;
+			if( lane == 0 ) seen = __hip_atomic_load( word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+			bool add = __builtin_amdgcn_readfirstlane( seen ) == tag_head;          // the next chain is done already: its head is there to be added
+			if( !add )
+				{
+				#pragma unroll
+				for( int q = 0; q < E; ++q ) if( q < nsteps ) st_agent( tail_next + 64 * q, acc[q] );
+				asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );                    // the tail has landed before the word says so
+				add = exchange( word, tag_tail ) == tag_head;                         // (it arrived meanwhile and left the addition to us)
+				}
+			if( add )
+				{
+				cf h[E];
+				#pragma unroll
+				for( int q = 0; q < E; ++q ) h[q] = ( q < nsteps ) ? ld_agent( head_next + 64 * q ) : mk( 0.0f, 0.0f );
+				#pragma unroll
+				for( int q = 0; q < E; ++q )
+					{
+					const int64_t a = pos + 128 * q + 2 * lane;
+					if( q < nsteps && a >= 0 && a < p.out_len ) out2[a >> 1] = mk( acc[q].x + h[q].x, acc[q].y + h[q].y );
+					}
+				}
+			}
+		if( chain_in_channel != 0 )
+			{
+			// this chain's head meets the previous chain's tail
+			asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );                      // the head (frames ago) has landed
+			if( exchange( p.fix_state + chain, tag_head ) == tag_tail )
+				{
+				const cf * tl = reinterpret_cast<const cf*>( p.tail + chain * p.head_len ) + lane;
+				const cf * hd = head2 + lane;
+				#pragma unroll 4
+				for( int q = 0; q < nsteps; ++q )
+					{
+					const cf t = ld_agent( tl + 64 * q ), h = ld_agent( hd + 64 * q );
+					const int64_t a = chain_start + 128 * q + 2 * lane;
+					if( a >= 0 && a < p.out_len ) out2[a >> 1] = mk( t.x + h.x, t.y + h.y );
+					}
+				}
+			}
+		}
 	st.flush( lane );
 	}
 

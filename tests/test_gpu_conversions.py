@@ -628,3 +628,44 @@ def test_mixed_radix_kernels_against_the_direct_sums(fa, W, hop, dft):
     d = np.abs(out_fft.astype(np.float64) - out_def.astype(np.float64)).max()
     print("\n[dft %d] FFT kernels vs direct sums: rel_m %.2e  f bit-identical %.4f  audio max diff %.2e" % (dft, rel_m, same_f, d))
     assert rel_m <= 5e-7 and same_f >= 0.95 and d <= 1e-6
+
+
+@pytest.mark.parametrize("ch,seconds,W,hop,hooks", [
+    (8, 60, 2048, 512, {}),                                   # the bench shape: one round of 2048 chains
+    (8, 60, 2048, 512, {"chain_len": 7}),                     # 6432 chains on 2048 slots: chains of one boundary run in different rounds
+    (2, 60, 2048, 128, {}),                                   # stereo, hop 128 (15 steps per boundary), the scan kernel's layout
+    (3, 20, 1024, 256, {"target_chains": 4096}),              # a short window, twice the resident chains
+    (5, 33, 2048, 1024, {}),
+])
+def test_overlap_fixup_inside_the_kernel_equals_the_separate_launch(fa, ch, seconds, W, hop, hooks):
+    """k_synthesize_v2 adds the overlaps of neighbouring chains itself (whichever of the two wavefronts at a boundary ends second does it,
+    through agent-scope side buffers and a state word per boundary: pv_kernels_v2.h); with the separate_fixup hook k_ola_fixup does it in a
+    launch of its own.  One addition per sample either way: the outputs must be the same bits, launch after launch."""
+    import ctypes
+    import torch
+    dev = torch.device("cuda", 0)
+    lib, vp = fa.lib, ctypes.c_void_p
+    sr, dft = 48000.0, 2048
+    n = int(seconds * sr) + 123
+    F = int(lib.flanhip_num_pv_frames(n, hop))
+    ar = np.float32(sr) / np.float32(hop)
+    bins = dft // 2 + 1
+    x = torch.empty((ch, n), dtype=torch.float32, device=dev)
+    fa.check(lib.flanhip_noise_dev(vp(x.data_ptr()), ch, n, 77, None))
+    pv = torch.empty((ch, F, bins, 2), dtype=torch.float32, device=dev)
+    fa.check(lib.flanhip_analyze_dev(vp(x.data_ptr()), ch, n, sr, W, hop, dft, vp(pv.data_ptr()), None))
+    out_a = torch.empty((ch, F * hop), dtype=torch.float32, device=dev)
+    out_b = torch.empty_like(out_a)
+    with fa.debug_options(**hooks):
+        ws = torch.empty(fa.synthesize_workspace_bytes(ch, F, bins, sr, ar, W), dtype=torch.uint8, device=dev)
+        with fa.debug_options(separate_fixup=1):
+            fa.synthesize_dev(pv, ch, F, bins, sr, ar, W, out_b, ws, None)
+        torch.cuda.synchronize()
+        for rep in range(6):
+            out_a.fill_(float("nan"))
+            fa.synthesize_dev(pv, ch, F, bins, sr, ar, W, out_a, ws, None)
+            torch.cuda.synchronize()
+            same = torch.equal(out_a.view(torch.int32), out_b.view(torch.int32))
+            if not same:
+                bad = (out_a.view(torch.int32) != out_b.view(torch.int32)).nonzero()
+                raise AssertionError("launch %d: %d samples differ, first at %s" % (rep, bad.shape[0], bad[0].tolist()))
