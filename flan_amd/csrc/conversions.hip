@@ -571,7 +571,7 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	p.skip_words = presummed == 2 ? p.nan_in : nullptr;
 	p.carry_in = d_carry_in; p.total_out = d_total_out; p.total_only = prepass_only ? 1 : 0;
 	p.cancel = thread_cancel_word( s );
-	const bool self_fix = lay.fix_offset != 0 && !debug_options().separate_fixup && !prepass_only;
+	const bool self_fix = lay.fix_offset != 0 && debug_options().inline_fixup && !prepass_only;     // (off by default: built and measured, no faster -- DESIGN 4.0001)
 	if( self_fix )
 		{
 		p.fix_state = reinterpret_cast<int*>( reinterpret_cast<char*>( d_ws ) + lay.fix_offset );
@@ -794,7 +794,7 @@ void flanhip_debug_option( int which, int value )
 		case FLANHIP_DEBUG_SYN4096_OLD:     o.syn11_old = value; break;
 		case FLANHIP_DEBUG_RESAMPLE_DIRECT: o.resample_direct = value; break;
 		case FLANHIP_DEBUG_FORCE_DIRECT:    o.force_direct = value; break;
-		case FLANHIP_DEBUG_SEPARATE_FIXUP:  o.separate_fixup = value; break;
+		case FLANHIP_DEBUG_INLINE_FIXUP:    o.inline_fixup = value; break;
 		default: break;
 		}
 	}

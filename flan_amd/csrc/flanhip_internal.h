@@ -66,7 +66,7 @@ struct DebugOptions
 	int ana_variant = 0, syn_variant = 0;      // dft 2048: ablated instantiations of diagnostic builds; synthesis 2 = behind the scan kernel
 	int ana11_old = 0, syn11_old = 0;          // dft 4096: 1 = the round-1 kernels instead of the team kernels (A/B predecessor)
 	int resample_direct = 0;                   // 1: the 2:1 block convolver always as direct sums
-	int separate_fixup = 0;                    // 1: k_ola_fixup as its own launch even where the synthesis kernel adds the overlaps itself
+	int inline_fixup = 0;                      // 1: the dft 2048 synthesis kernel adds the chains' overlaps itself instead of k_ola_fixup in a launch of its own (measured: no faster)
 	int force_direct = 0;                      // 1: dft sizes without power-of-two kernels as direct fp64 sums (pv_kernels_any.h), never the mixed-radix kernels
 	};
 DebugOptions & debug_options();

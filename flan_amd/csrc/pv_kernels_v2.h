@@ -890,27 +890,33 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 		{
 		const int tag_tail = p.fix_tag | 1, tag_head = p.fix_tag | 2;
 		const int nsteps = p.head_len / 128;                                        // steps of 128 samples a boundary holds (W - hop, a multiple of 128 here)
-		auto exchange = [&]( int * word, int tag )
+		// both of this wavefront's boundaries at once: its head's tag goes out (the head landed frames ago: memory operations retire in order, and
+		// the queue is drained here anyway) while the word of the boundary behind its tail is read -- one round trip for the two
+		int * const word_h = p.fix_state + chain, * const word_t = p.fix_state + ( chain + 1 );
+		const bool has_head = chain_in_channel != 0, has_tail = !last_chain;
+		asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+		int old_h = 0, seen_t = 0;
+		if( lane == 0 )
 			{
-			int old = 0;
-			if( lane == 0 ) old = __hip_atomic_exchange( word, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-			return __builtin_amdgcn_readfirstlane( old );
-			};
-		if( !last_chain )
+			if( has_head ) old_h = __hip_atomic_exchange( word_h, tag_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+			if( has_tail ) seen_t = __hip_atomic_load( word_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+			}
+		old_h = __builtin_amdgcn_readfirstlane( old_h );
+		seen_t = __builtin_amdgcn_readfirstlane( seen_t );
+		if( has_tail )
 			{
 			// this chain's tail meets the next chain's head
-			int * word = p.fix_state + ( chain + 1 );
 			const cf * head_next = reinterpret_cast<const cf*>( p.head + ( chain + 1 ) * p.head_len ) + lane;
 			cf * tail_next = reinterpret_cast<cf*>( p.tail + ( chain + 1 ) * p.head_len ) + lane;
-			int seen = 0;
-			if( lane == 0 ) seen = __hip_atomic_load( word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-			bool add = __builtin_amdgcn_readfirstlane( seen ) == tag_head;          // the next chain is done already: its head is there to be added
+			bool add = seen_t == tag_head;                                            // the next chain is done already: its head is there to be added
 			if( !add )
 				{
 				#pragma unroll
 				for( int q = 0; q < E; ++q ) if( q < nsteps ) st_agent( tail_next + 64 * q, acc[q] );
 				asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );                    // the tail has landed before the word says so
-				add = exchange( word, tag_tail ) == tag_head;                         // (it arrived meanwhile and left the addition to us)
+				int old = 0;
+				if( lane == 0 ) old = __hip_atomic_exchange( word_t, tag_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+				add = __builtin_amdgcn_readfirstlane( old ) == tag_head;              // (it arrived meanwhile and left the addition to us)
 				}
 			if( add )
 				{
@@ -925,21 +931,17 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 					}
 				}
 			}
-		if( chain_in_channel != 0 )
+		if( has_head && old_h == tag_tail )
 			{
-			// this chain's head meets the previous chain's tail
-			asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );                      // the head (frames ago) has landed
-			if( exchange( p.fix_state + chain, tag_head ) == tag_tail )
+			// this chain's head meets the previous chain's tail, which was there first
+			const cf * tl = reinterpret_cast<const cf*>( p.tail + chain * p.head_len ) + lane;
+			const cf * hd = head2 + lane;
+			#pragma unroll 4
+			for( int q = 0; q < nsteps; ++q )
 				{
-				const cf * tl = reinterpret_cast<const cf*>( p.tail + chain * p.head_len ) + lane;
-				const cf * hd = head2 + lane;
-				#pragma unroll 4
-				for( int q = 0; q < nsteps; ++q )
-					{
-					const cf t = ld_agent( tl + 64 * q ), h = ld_agent( hd + 64 * q );
-					const int64_t a = chain_start + 128 * q + 2 * lane;
-					if( a >= 0 && a < p.out_len ) out2[a >> 1] = mk( t.x + h.x, t.y + h.y );
-					}
+				const cf t = ld_agent( tl + 64 * q ), h = ld_agent( hd + 64 * q );
+				const int64_t a = chain_start + 128 * q + 2 * lane;
+				if( a >= 0 && a < p.out_len ) out2[a >> 1] = mk( t.x + h.x, t.y + h.y );
 				}
 			}
 		}

@@ -166,8 +166,9 @@ int flanhip_synthesize_dev_stages(const flanhip_MF * d_pv, int64_t num_channels,
                                            * for float streams of at least 8 blocks) */
 #define FLANHIP_DEBUG_FORCE_DIRECT    9   /* 1: dft sizes without power-of-two kernels as direct fp64 sums (the transform's definition: pv_kernels_any.h),
                                            * never the mixed-radix FFT kernels (pv_kernels_mr.h): the checker-order path, for A/B */
-#define FLANHIP_DEBUG_SEPARATE_FIXUP 10   /* 1: the overlaps of neighbouring chains added by a launch of their own (k_ola_fixup) even where the dft 2048
-                                           * synthesis kernel adds them itself: the same sums, for A/B */
+#define FLANHIP_DEBUG_INLINE_FIXUP   10   /* 1: the dft 2048 synthesis kernel adds the overlaps of neighbouring chains itself (whichever of the two
+                                           * wavefronts at a boundary ends second; agent-scope side buffers) instead of k_ola_fixup in a launch of its
+                                           * own: the same sums; measured no faster, hence not the default */
 void flanhip_debug_option(int which, int value);
 
 /* ---- PV frame processors ------------------------------------------------------------------------------------- */

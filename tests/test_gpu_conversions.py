@@ -638,9 +638,10 @@ def test_mixed_radix_kernels_against_the_direct_sums(fa, W, hop, dft):
     (5, 33, 2048, 1024, {}),
 ])
 def test_overlap_fixup_inside_the_kernel_equals_the_separate_launch(fa, ch, seconds, W, hop, hooks):
-    """k_synthesize_v2 adds the overlaps of neighbouring chains itself (whichever of the two wavefronts at a boundary ends second does it,
-    through agent-scope side buffers and a state word per boundary: pv_kernels_v2.h); with the separate_fixup hook k_ola_fixup does it in a
-    launch of its own.  One addition per sample either way: the outputs must be the same bits, launch after launch."""
+    """With the inline_fixup hook k_synthesize_v2 adds the overlaps of neighbouring chains itself (whichever of the two wavefronts at a boundary
+    ends second does it, through agent-scope side buffers and a state word per boundary: pv_kernels_v2.h) instead of k_ola_fixup in a launch
+    of its own (the default: the in-kernel form measured no faster).  One addition per sample either way: the outputs must be the same bits,
+    launch after launch."""
     import ctypes
     import torch
     dev = torch.device("cuda", 0)
@@ -658,12 +659,12 @@ def test_overlap_fixup_inside_the_kernel_equals_the_separate_launch(fa, ch, seco
     out_b = torch.empty_like(out_a)
     with fa.debug_options(**hooks):
         ws = torch.empty(fa.synthesize_workspace_bytes(ch, F, bins, sr, ar, W), dtype=torch.uint8, device=dev)
-        with fa.debug_options(separate_fixup=1):
-            fa.synthesize_dev(pv, ch, F, bins, sr, ar, W, out_b, ws, None)
+        fa.synthesize_dev(pv, ch, F, bins, sr, ar, W, out_b, ws, None)
         torch.cuda.synchronize()
         for rep in range(6):
             out_a.fill_(float("nan"))
-            fa.synthesize_dev(pv, ch, F, bins, sr, ar, W, out_a, ws, None)
+            with fa.debug_options(inline_fixup=1):
+                fa.synthesize_dev(pv, ch, F, bins, sr, ar, W, out_a, ws, None)
             torch.cuda.synchronize()
             same = torch.equal(out_a.view(torch.int32), out_b.view(torch.int32))
             if not same:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""A/B in one process, interleaved rounds: the overlaps of neighbouring chains added inside k_synthesize_v2 (default) against k_ola_fixup as a
-launch of its own (the separate_fixup hook), fused round trip at several shapes.  ms per step, median and minimum."""
+"""A/B in one process, interleaved rounds: the overlaps of neighbouring chains added inside k_synthesize_v2 (the inline_fixup hook) against k_ola_fixup as a
+launch of its own (the default), fused round trip at several shapes.  ms per step, median and minimum."""
 import ctypes
 import json
 import os
@@ -14,7 +14,7 @@ SR, W, HOP, DFT = 48000.0, 2048, 512, 2048
 BINS = DFT // 2 + 1
 dev = torch.device("cuda", 0)
 res = {}
-for ch, seconds in ((8, 60), (2, 60), (8, 600)):
+for ch, seconds in ((1, 5), (8, 60), (2, 60), (8, 600)):
     n = int(seconds * SR)
     F = int(fa.lib.flanhip_num_pv_frames(n, HOP))
     ar = SR / HOP
@@ -34,7 +34,7 @@ for ch, seconds in ((8, 60), (2, 60), (8, 600)):
     reps = 20 if seconds < 100 else 5
     for r in range(9):
         for mode in (0, 1):
-            fa.lib.flanhip_debug_option(fa.DEBUG_SEPARATE_FIXUP, mode)
+            fa.lib.flanhip_debug_option(fa.DEBUG_INLINE_FIXUP, 1 - mode)
             step(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -42,7 +42,7 @@ for ch, seconds in ((8, 60), (2, 60), (8, 600)):
                 step()
             e1.record(); torch.cuda.synchronize()
             t[mode].append(e0.elapsed_time(e1) / reps)
-    fa.lib.flanhip_debug_option(fa.DEBUG_SEPARATE_FIXUP, 0)
+    fa.lib.flanhip_debug_option(fa.DEBUG_INLINE_FIXUP, 0)
     res["%d ch x %d s" % (ch, seconds)] = {("inside the kernel" if m == 0 else "separate launch"): {"median_ms": round(sorted(v)[len(v) // 2], 4), "min_ms": round(min(v), 4)} for m, v in t.items()}
     del audio, pv, out, ws
 print(json.dumps(res, indent=1))
