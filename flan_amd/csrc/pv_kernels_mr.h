@@ -192,13 +192,14 @@ template<bool PP> __device__ __forceinline__ MrLds mr_carve( unsigned char * sme
 	{
 	MrLds l;
 	cf * s_tw = reinterpret_cast<cf*>( smem );
-	const bool tw_lds = C <= MR_TW_LDS_MAX_C;
+	constexpr bool tw_lds = PP;                                                     // ( C <= MR_TW_LDS_MAX_C exactly when the passes ping-pong: mr_pingpong ) -- a compile-time fact, so
+	                                                                                // that the passes' twiddle reads are LDS instructions, not flat ones waited for one by one
 	l.buf = s_tw + ( tw_lds ? C : 0 );
 	l.buf2 = l.buf + padded_len( C + 1 );                                            // (PP: the passes' second buffer)
 	l.kc = reinterpret_cast<v4f_t*>( l.buf + ( PP ? 2 : 1 ) * padded_len( C + 1 ) );   // (padded_len( C + 1 ) cf from a 16-byte aligned start: still 8-byte aligned -- see mr_kc)
 	l.state = reinterpret_cast<unsigned char*>( reinterpret_cast<cf*>( l.kc ) + ( kc_lds ? 2 * ( C + 1 ) : 0 ) );
-	if( tw_lds ) for( int i = tid; i < C; i += MR_THREADS ) s_tw[i] = g_tw[i];
-	l.tw = tw_lds ? s_tw : g_tw;
+	if constexpr( tw_lds ) { for( int i = tid; i < C; i += MR_THREADS ) s_tw[i] = g_tw[i]; l.tw = s_tw; }
+	else l.tw = g_tw;
 	return l;
 	}
 // per-bin constants of bin k: { split twiddle exp( -pi i k / C ), bin frequency (PVBuffer.cpp:443-446), expected phase advance (phase_vocoder.cpp:47) }
