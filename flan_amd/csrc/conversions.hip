@@ -2,6 +2,7 @@
 // (reference: Conversions/AudioPV.cpp:12-78 and :86-139).
 #include "flanhip_internal.h"
 #include <atomic>
+#include <memory>
 #include "pv_kernels.h"
 #include "pv_kernels_fast.h"
 #include <type_traits>
@@ -60,28 +61,43 @@ static int mr_target_chains( int dft, int W )
 
 static bool dft_size_ok( int dft ) { return dft >= 4 && dft % 2 == 0 && dft <= kMaxAnyDft; }
 
-// unit[m] = ( cos, sin )( 2 pi m / N ) in double, exact at the quarter turns; per ( device, N ), never freed (like the plans)
+// unit[m] = ( cos, sin )( 2 pi m / N ) in double, exact at the quarter turns, for the direct-sum kernels; per ( device, N ), the four most
+// recently used sizes (16 bytes x N each, up to 2^20: a sweep over sizes must not pile them up), handed out as shared references like the plans
+struct UnitRef { d2 * d = nullptr; UnitRef() = default; UnitRef( const UnitRef & ) = delete; UnitRef & operator=( const UnitRef & ) = delete; ~UnitRef() { (void) hipFree( d ); (void) hipGetLastError(); } };
 static std::mutex g_unit_mutex;
-static std::map<std::pair<int, int>, d2*> g_units;
-static int get_unit_circle( int N, const d2 ** out )
+static std::vector<std::pair<std::pair<int, int>, std::shared_ptr<const UnitRef>>> & unit_cache() { static auto * v = new std::vector<std::pair<std::pair<int, int>, std::shared_ptr<const UnitRef>>>; return *v; }
+static int get_unit_circle( int N, std::shared_ptr<const UnitRef> * out )
 	{
 	int device = 0;
 	FLANHIP_CHECK( hipGetDevice( &device ) );
-	std::lock_guard<std::mutex> lock( g_unit_mutex );
-	auto it = g_units.find( std::make_pair( device, N ) );
-	if( it == g_units.end() )
+	const auto key = std::make_pair( device, N );
+	auto lookup = [&]() -> bool
 		{
-		std::vector<d2> u( size_t( N ), d2{ 1.0, 0.0 } );
-		const long double two_pi = 6.283185307179586476925286766559005768L;
-		for( int m = 0; m < N; ++m ) u[size_t( m )] = d2{ double( cosl( two_pi * m / N ) ), double( sinl( two_pi * m / N ) ) };
-		u[0] = d2{ 1.0, 0.0 }; u[size_t( N / 2 )] = d2{ -1.0, 0.0 };
-		if( N % 4 == 0 ) { u[size_t( N / 4 )] = d2{ 0.0, 1.0 }; u[size_t( 3 * ( N / 4 ) )] = d2{ 0.0, -1.0 }; }
-		d2 * d = nullptr;
-		FLANHIP_CHECK( hipMalloc( &d, sizeof( d2 ) * size_t( N ) ) );
-		FLANHIP_CHECK( hipMemcpy( d, u.data(), sizeof( d2 ) * size_t( N ), hipMemcpyHostToDevice ) );
-		it = g_units.emplace( std::make_pair( device, N ), d ).first;
+		auto & c = unit_cache();
+		for( size_t i = 0; i < c.size(); ++i ) if( c[i].first == key ) { auto e = c[i]; c.erase( c.begin() + long( i ) ); c.push_back( e ); *out = e.second; return true; }
+		return false;
+		};
+		{
+		std::lock_guard<std::mutex> lock( g_unit_mutex );
+		if( lookup() ) return FLANHIP_OK;
 		}
-	*out = it->second;
+	std::vector<d2> u( size_t( N ), d2{ 1.0, 0.0 } );                               // (outside the lock)
+	const long double two_pi = 6.283185307179586476925286766559005768L;
+	for( int m = 0; m < N; ++m ) u[size_t( m )] = d2{ double( cosl( two_pi * m / N ) ), double( sinl( two_pi * m / N ) ) };
+	u[0] = d2{ 1.0, 0.0 }; u[size_t( N / 2 )] = d2{ -1.0, 0.0 };
+	if( N % 4 == 0 ) { u[size_t( N / 4 )] = d2{ 0.0, 1.0 }; u[size_t( 3 * ( N / 4 ) )] = d2{ 0.0, -1.0 }; }
+	auto ref = std::make_shared<UnitRef>();
+	FLANHIP_CHECK( hipMalloc( &ref->d, sizeof( d2 ) * size_t( N ) ) );
+	FLANHIP_CHECK( hipMemcpy( ref->d, u.data(), sizeof( d2 ) * size_t( N ), hipMemcpyHostToDevice ) );
+	std::shared_ptr<const UnitRef> evicted;                                         // (released outside the lock: freeing waits for the device)
+		{
+		std::lock_guard<std::mutex> lock( g_unit_mutex );
+		if( lookup() ) return FLANHIP_OK;
+		auto & c = unit_cache();
+		c.emplace_back( key, ref );
+		if( c.size() > 4 ) { evicted = c.front().second; c.erase( c.begin() ); }
+		}
+	*out = ref;
 	return FLANHIP_OK;
 	}
 // chains for the direct-sum kernels: enough blocks ( chains x bin blocks ) to fill the chip, chains of at least 7 frames (the halo frame
@@ -365,8 +381,9 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	MrPlan mr_plan{};
 	const bool mr = mr_size( dft, W, &mr_plan );
 	const bool any = !fft_size( dft ) && !mr;
-	const Plan * plan = nullptr;
-	if( int rc = get_plan( W, dft, &plan ) ) return rc;
+	std::shared_ptr<const PlanRef> plan_ref;                                        // (held until the kernels below are launched)
+	if( int rc = get_plan( W, dft, &plan_ref ) ) return rc;
+	const Plan * plan = &plan_ref->plan;
 
 	AnalyzeParams p{};
 	p.audio = d_audio; p.out = reinterpret_cast<MF*>( d_out );
@@ -428,8 +445,9 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 
 	if( any )
 		{
-		const d2 * unit = nullptr;
-		if( int rc = get_unit_circle( dft, &unit ) ) return rc;
+		std::shared_ptr<const UnitRef> unit_ref;
+		if( int rc = get_unit_circle( dft, &unit_ref ) ) return rc;
+		const d2 * unit = unit_ref->d;
 		const int64_t chains = int64_t( p.chains_per_channel ) * ch;
 		const int bin_blocks = ( dft / 2 + 1 + ANY_THREADS - 1 ) / ANY_THREADS;
 		FLANHIP_REQUIRE( chains <= 65535, FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
@@ -549,8 +567,9 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	SynthLayout lay;
 	if( int rc = synth_layout( ch, F, bins, sr, ar, W, &lay ) ) return rc;
 	if( int rc = require_device() ) return rc;
-	const Plan * plan = nullptr;
-	if( int rc = get_plan( W, lay.dft, &plan ) ) return rc;
+	std::shared_ptr<const PlanRef> plan_ref;                                        // (held until the kernels below are launched)
+	if( int rc = get_plan( W, lay.dft, &plan_ref ) ) return rc;
+	const Plan * plan = &plan_ref->plan;
 
 	SynthParams p{};                                               // every optional pointer null unless set below
 	p.pv = reinterpret_cast<const MF*>( d_pv ); p.out = d_out;
@@ -624,8 +643,9 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	else if( lay.any )
 		{
 		// any even dft size without FFT kernels: spectra along the chains, c2r by its definition, overlap-add in frame order (pv_kernels_any.h)
-		const d2 * unit = nullptr;
-		if( int rc2 = get_unit_circle( lay.dft, &unit ) ) return rc2;
+		std::shared_ptr<const UnitRef> unit_ref;
+		if( int rc2 = get_unit_circle( lay.dft, &unit_ref ) ) return rc2;
+		const d2 * unit = unit_ref->d;
 		AnySynthParams q{};
 		q.pv = p.pv; q.carry = p.carry; q.out = d_out; q.window = p.window;
 		q.spec = reinterpret_cast<float*>( reinterpret_cast<char*>( d_ws ) + lay.any_spec_offset );

@@ -1,6 +1,7 @@
 // core.hip -- error state, device plumbing, plan cache, shape helpers of the C ABI (include/flanhip.h).
 #include "flanhip_internal.h"
 #include "div_plans_proven.h"
+#include <memory>
 #include <thread>
 #include <chrono>
 #include <atomic>
@@ -38,17 +39,40 @@ static float hann_host( float x )
 	return float( 0.5f * ( 1.0f - std::cos( double( 2.0f * pi * x ) ) ) );
 	}
 
-static std::mutex g_plan_mutex;   // FFTHelper.cpp:9 serialises plan creation the same way
-static std::map<std::tuple<int, int, int>, Plan> g_plans;
+// The plan cache.  Plans of the power-of-two sizes with FFT kernels (32 ... 8192: a few dozen KB each, a closed set of shapes per window) stay for
+// the life of the process, like FFTW's wisdom; plans of any OTHER dft size (the mixed-radix and direct-sum paths: tables of 8 bytes x dft and
+// more, up to 2^20) live in a small least-recently-used set -- a caller that sweeps sizes no longer grows the device's memory without bound.
+// A plan is handed out as a shared reference: the caller keeps it until its kernels are launched, and an evicted plan's tables are freed when
+// its last holder lets go (hipFree waits for the device, so kernels already launched finish first).  Tables are worked out BEFORE the lock is
+// taken: a first use of a large size does not stall other threads' launches behind a hundred thousand cos / sin calls.
+PlanRef::~PlanRef()
+	{
+	(void) hipFree( plan.d_window ); (void) hipFree( plan.d_tw ); (void) hipFree( plan.d_tw2 ); (void) hipFree( plan.d_tw1f ); (void) hipFree( plan.d_tw3f );
+	(void) hipGetLastError();
+	}
+static std::mutex g_plan_mutex;
+typedef std::tuple<int, int, int> PlanKey;
+// (heap objects that are never destroyed: at process exit the HIP runtime may be gone before static destructors run)
+static std::map<PlanKey, std::shared_ptr<const PlanRef>> & plan_map() { static auto * m = new std::map<PlanKey, std::shared_ptr<const PlanRef>>; return *m; }
+static std::vector<PlanKey> & plan_lru() { static auto * v = new std::vector<PlanKey>; return *v; }   // the evictable plans, most recently used last
+static constexpr size_t kEvictablePlans = 8;
+static bool plan_is_permanent( int dft_size ) { return is_pow2( dft_size ) && dft_size >= 32 && dft_size <= 8192; }
 
-int get_plan( int window_size, int dft_size, const Plan ** out )
+int get_plan( int window_size, int dft_size, std::shared_ptr<const PlanRef> * out )
 	{
 	int device = 0;
 	FLANHIP_CHECK( hipGetDevice( &device ) );
-	std::lock_guard<std::mutex> lock( g_plan_mutex );
-	const auto key = std::make_tuple( device, window_size, dft_size );
-	auto it = g_plans.find( key );
-	if( it != g_plans.end() ) { *out = &it->second; return FLANHIP_OK; }
+	const PlanKey key = std::make_tuple( device, window_size, dft_size );
+	auto touch = [&]()
+		{
+		auto & lru = plan_lru();
+		for( size_t i = 0; i < lru.size(); ++i ) if( lru[i] == key ) { lru.erase( lru.begin() + long( i ) ); lru.push_back( key ); break; }
+		};
+		{
+		std::lock_guard<std::mutex> lock( g_plan_mutex );
+		auto it = plan_map().find( key );
+		if( it != plan_map().end() ) { touch(); *out = it->second; return FLANHIP_OK; }
+		}
 
 	const int C = dft_size / 2;
 	std::vector<float> win( window_size );
@@ -58,7 +82,8 @@ int get_plan( int window_size, int dft_size, const Plan ** out )
 	for( int k = 0; k < C; ++k ) tw[k] = cf{ float( std::cos( -2.0 * pi * k / C ) ), float( std::sin( -2.0 * pi * k / C ) ) };
 	for( int k = 0; k <= C; ++k ) tw2[k] = cf{ float( std::cos( -pi * k / C ) ), float( std::sin( -pi * k / C ) ) };
 
-	Plan plan;
+	auto ref = std::make_shared<PlanRef>();
+	Plan & plan = ref->plan;
 	FLANHIP_CHECK( hipMalloc( &plan.d_window, sizeof( float ) * window_size ) );
 	FLANHIP_CHECK( hipMalloc( &plan.d_tw, sizeof( cf ) * C ) );
 	FLANHIP_CHECK( hipMalloc( &plan.d_tw2, sizeof( cf ) * ( C + 1 ) ) );
@@ -78,8 +103,25 @@ int get_plan( int window_size, int dft_size, const Plan ** out )
 		FLANHIP_CHECK( hipMemcpy( plan.d_tw1f, tw1.data(), sizeof( cf ) * tw1.size(), hipMemcpyHostToDevice ) );
 		FLANHIP_CHECK( hipMemcpy( plan.d_tw3f, tw3.data(), sizeof( cf ) * tw3.size(), hipMemcpyHostToDevice ) );
 		}
-	auto ins = g_plans.emplace( key, plan );
-	*out = &ins.first->second;
+	std::shared_ptr<const PlanRef> evicted;                                         // (released outside the lock: freeing waits for the device)
+		{
+		std::lock_guard<std::mutex> lock( g_plan_mutex );
+		auto it = plan_map().find( key );
+		if( it != plan_map().end() ) { touch(); *out = it->second; return FLANHIP_OK; }   // another thread was faster: ours is dropped
+		plan_map()[key] = ref;
+		if( !plan_is_permanent( dft_size ) )
+			{
+			auto & lru = plan_lru();
+			lru.push_back( key );
+			if( lru.size() > kEvictablePlans )
+				{
+				auto old = plan_map().find( lru.front() );
+				if( old != plan_map().end() ) { evicted = old->second; plan_map().erase( old ); }
+				lru.erase( lru.begin() );
+				}
+			}
+		}
+	*out = ref;
 	return FLANHIP_OK;
 	}
 

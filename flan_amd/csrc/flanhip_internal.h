@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cmath>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <tuple>
 #include <vector>
@@ -38,7 +39,7 @@ int wait_cancellable( hipStream_t s, int ( *poll )( void * ), void * user );
 inline int poll_volatile_int( void * user ) { volatile int * c = static_cast<volatile int*>( user ); return c && *c != 0; }
 
 // Device tables for one (window, dft) pair on one device: the analogue of the reference's FFTHelper plan
-// (FFTHelper.cpp:16-26) plus the sampled Hann window (AudioPV.cpp:30-34).  Built once, cached, never freed.
+// (FFTHelper.cpp:16-26) plus the sampled Hann window (AudioPV.cpp:30-34).  Built once, cached (core.hip: get_plan).
 struct Plan
 	{
 	float * d_window = nullptr;    // [W]   hann( i/(W-1) ), WindowFunctions.cpp:10-13 evaluated on the host in double
@@ -47,7 +48,8 @@ struct Plan
 	cf * d_tw1f = nullptr;     // fast path (dft 2048/4096): [15][16]      exp(-2 pi i r k / 256)
 	cf * d_tw3f = nullptr;     // fast path:                 [C/256-1][256] exp(-2 pi i r j / C)
 	};
-int get_plan( int window_size, int dft_size, const Plan ** out );
+struct PlanRef { Plan plan; PlanRef() = default; PlanRef( const PlanRef & ) = delete; PlanRef & operator=( const PlanRef & ) = delete; ~PlanRef(); };   // owns the tables
+int get_plan( int window_size, int dft_size, std::shared_ptr<const PlanRef> * out );   // keep the reference until the kernels that read the tables are launched
 
 // Division by a run-time constant: { c, RN(1/c), exact } where `exact` says the 3-instruction quotient (pv_math.h div_c) was
 // checked on the device against the hardware division for every float |x| >= 1e-30.  Cached per value of c.

@@ -337,7 +337,8 @@ __global__ __launch_bounds__( MR_THREADS, PP ? 4 : 2 ) void k_synthesize_mr( Syn
 	double * s_ph = reinterpret_cast<double*>( l.state );                             // [C + 2] (l.state is 8-byte aligned)
 	float * ring = reinterpret_cast<float*>( s_ph + ( C + 2 ) );                       // [wpad]
 	float * s_win = ring + wpad;                                                      // [wpad], if win_lds: the scaled window (AudioPV.cpp:102)
-	auto win = [&]( int i ) { return win_lds ? s_win[i] : p.window[i] * p.window_scale; };
+	// (either an LDS read or a global one, in arms of their own: `c ? lds[i] : mem[i]` becomes one FLAT load through a selected pointer)
+	auto win = [&]( int i ) { float v; if( win_lds ) { v = s_win[i]; asm volatile( "" : "+v"( v ) ); } else v = p.window[i] * p.window_scale; return v; };
 	for( int i = tid; i < W; i += MR_THREADS ) { ring[i] = 0.0f; if( win_lds ) s_win[i] = p.window[i] * p.window_scale; }
 	if( kc_lds ) for( int k = tid; k <= C; k += MR_THREADS ) reinterpret_cast<cf*>( l.kc )[2 * k] = p.tw2[k];   // (only the split twiddle is wanted here)
 
@@ -354,7 +355,7 @@ __global__ __launch_bounds__( MR_THREADS, PP ? 4 : 2 ) void k_synthesize_mr( Syn
 	for( int k = tid; k <= C; k += MR_THREADS ) s_ph[k] = p.carry[chain * ( C + 1 ) + k];   // the running phase (AudioPV.cpp:105) on entry to the chain
 	__syncthreads();
 	if( s_cancel ) return;
-	auto w2_of = [&]( int k ) { return kc_lds ? reinterpret_cast<const cf*>( l.kc )[2 * k] : p.tw2[k]; };
+	auto w2_of = [&]( int k ) { cf v; if( kc_lds ) { v = reinterpret_cast<const cf*>( l.kc )[2 * k]; asm volatile( "" : "+v"( v ) ); } else v = p.tw2[k]; return v; };
 	constexpr int U = 4;
 
 	int ring_base = 0;                                                                 // ring[ring_base] <-> absolute sample `pos`

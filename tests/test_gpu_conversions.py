@@ -630,6 +630,32 @@ def test_mixed_radix_kernels_against_the_direct_sums(fa, W, hop, dft):
     assert rel_m <= 5e-7 and same_f >= 0.95 and d <= 1e-6
 
 
+def test_plan_caches_are_bounded_and_evicted_sizes_come_back(fa):
+    """The plan / unit-circle caches keep only the most recently used few of the sizes without tuned kernels (core.hip get_plan, conversions.hip
+    get_unit_circle): a sweep over more sizes than they hold, mixed-radix and direct-sum, then the first sizes again -- the results of a size whose
+    tables were dropped and rebuilt are bit-identical to its first results, and the device's free memory does not shrink with the sweep."""
+    import torch
+    sr = 48000.0
+    sizes = [96 + 2 * i for i in range(14)] + [2 * 521, 2 * 523, 2 * 541, 2 * 547, 2 * 557, 2 * 563]     # 14 smooth-ish sizes, 6 with a large prime
+    first = {}
+    def run(dft):
+        x = O.noise(1, 20 * dft, seed=dft)
+        pv = fa.analyze(x, sr, dft, dft // 4, dft)
+        out, _ = fa.synthesize(pv, sr, np.float32(sr) / np.float32(dft // 4), dft)
+        return pv, out
+    for dft in sizes:
+        first[dft] = run(dft)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        for dft in sizes:
+            pv, out = run(dft)
+            assert np.array_equal(pv.view(np.uint32), first[dft][0].view(np.uint32)) and np.array_equal(out.view(np.uint32), first[dft][1].view(np.uint32)), dft
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 <= (2 << 20), (free0, free1)
+
+
 @pytest.mark.parametrize("ch,seconds,W,hop,hooks", [
     (8, 60, 2048, 512, {}),                                   # the bench shape: one round of 2048 chains
     (8, 60, 2048, 512, {"chain_len": 7}),                     # 6432 chains on 2048 slots: chains of one boundary run in different rounds
