@@ -316,23 +316,28 @@ __global__ __launch_bounds__( 256 ) void k_modify_time_chains( TimeChainParams p
 // reference's rounding), then frame_to_time; also the maximum of the result (FunctionSample::maximum, :312).
 // A block owns 64 bins (column_scan, processors_common.h).
 constexpr int kMapTB = 16, kMapTF = 224, kMapThreads = 512;                        // k_stretch_map tile: 16 bins x 224 frames, three of them in flight (44 KB of LDS); one scanning and seven moving waves (fifteen: no faster)
+// IDX32: F * bins fits 32 bits with room (every map up to hours of audio): a row's address is the grid pointer plus a 32-bit offset
+template<bool IDX32>
 __global__ __launch_bounds__( kMapThreads ) void k_stretch_map( float * factor, int64_t F, int bins, float sr, float hop, float * d_max )
 	{
 	__shared__ __attribute__(( aligned( 16 ) )) float lds[3 * column_scan_lds_floats( kMapTF, kMapTB, 1 )];
 	const int strip = xcd_contiguous_strip( blockIdx.x, ( bins + kMapTB - 1 ) / kMapTB );
 	if( strip < 0 ) return;
-	const int bin = strip * kMapTB + threadIdx.x % kMapTB;
-	const bool valid = bin < bins;
+	// (columns past the last bin of the last strip move and scan the last bin's column once more: the same values to the same addresses)
+	const int bin = min( strip * kMapTB + int( threadIdx.x % kMapTB ), bins - 1 );
+	auto at = [&]( int64_t f ) -> float *
+		{
+		if constexpr( IDX32 ) return factor + unsigned( int( f ) * bins + bin );
+		else return factor + ( f * bins + bin );
+		};
 	float run = -0.0f, mx = -INFINITY;                                             // -0 + x == x for every x: frame 0 needs no special case
-	column_scan_piped<kMapTF, kMapTB, 1, 1, false, kMapThreads>( lds, F,
-		[&]( int64_t f, float ( &v )[1] ) { if( valid ) v[0] = factor[f * bins + bin]; },
-		[&]( int64_t f, float ( &v )[1] ) { run = v[0] + run; v[0] = run; },                             // factor[frame] += factor[frame-1]
-		[&]( int64_t f, float ( &v )[1] )
+	column_scan_piped<kMapTF, kMapTB, kMapThreads>( lds, F, at,
+		[&]( float v ) { run = v + run; return run; },                               // factor[frame] += factor[frame-1]
+		[&]( int64_t, float v )
 			{
-			if( !valid ) return;
-			const float t = frame_to_time( v[0], sr, hop );                           // PVModify.cpp:381-382
-			factor[f * bins + bin] = t;
+			const float t = frame_to_time( v, sr, hop );                              // PVModify.cpp:381-382
 			mx = fmaxf( mx, t );
+			return t;
 			} );
 	// the block's maximum: over the lanes of each wave, then over the 4 waves through LDS, then into *d_max
 	for( int o = 32; o > 0; o >>= 1 ) mx = fmaxf( mx, __shfl_xor( mx, o ) );
@@ -752,7 +757,9 @@ int flanhip_stretch_map_dev( float * d_factor, int64_t F, int bins, float sr, in
 		const float ninf = -INFINITY;
 		FLANHIP_CHECK( hipMemcpyAsync( d_max, &ninf, sizeof( float ), hipMemcpyHostToDevice, s ) );
 		}
-	hipLaunchKernelGGL( k_stretch_map, dim3( xcd_grid( ( bins + kMapTB - 1 ) / kMapTB ) ), dim3( kMapThreads ), 0, s, d_factor, F, bins, sr, float( hop ), d_max );
+	const dim3 grid( xcd_grid( ( bins + kMapTB - 1 ) / kMapTB ) );
+	if( F * int64_t( bins ) < ( int64_t( 1 ) << 30 ) ) hipLaunchKernelGGL( k_stretch_map<true>, grid, dim3( kMapThreads ), 0, s, d_factor, F, bins, sr, float( hop ), d_max );
+	else hipLaunchKernelGGL( k_stretch_map<false>, grid, dim3( kMapThreads ), 0, s, d_factor, F, bins, sr, float( hop ), d_max );
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;
 	}

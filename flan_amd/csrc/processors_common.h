@@ -183,107 +183,130 @@ __device__ __forceinline__ void column_scan( float * lds, int64_t F, Load load, 
 		}
 	}
 
-// The same scan as a three-stage pipeline over tiles, for kernels whose time is the sum of column_scan's three phases rather than any one of
-// them (k_stretch_map: a running sum down 5 626 frames with 16 columns per block -- the scan itself is ~2 us per tile, moving the tile in and
-// out ~2.5 us each, one after the other).  Wave 0 only scans; the other waves of the block (THREADS - 64 threads) only move.  While tile k is scanned in buffer k % 3, the movers write
-// tile k - 1 back from ( k - 1 ) % 3, put the prefetched tile k + 1 into ( k + 1 ) % 3 and request tile k + 2 from memory: one barrier per
-// tile, and a tile's three phases overlap with its neighbours'.  lds: 3 * column_scan_lds_floats( TFr, TBc, max( NIN, NOUT ) ) floats.
-template<int TFr, int TBc, int NIN, int NOUT, bool REVERSE, int THREADS, class Load, class Step, class Store>
-__device__ __forceinline__ void column_scan_piped( float * lds, int64_t F, Load load, Step step, Store store )
+// A running fp32 sum down the frames of a grid, column by column and in frame order (sequential: the reference's roundings), as a three-stage
+// pipeline over tiles of TFr frames x TBc columns (k_stretch_map: 5 626 frames, 16 columns per block).  Wave 0 only scans -- its time is the
+// dependent chain of additions, ~6 cycles a frame; the other waves of the block (THREADS - 64 threads) only move: while tile k is scanned in LDS
+// buffer k % 3 they write tile k - 1 back from ( k - 1 ) % 3 and put tile k + 1 into ( k + 1 ) % 3.  The movers' rows are requested THREE tiles
+// ahead into three register sets, by hand-written loads and stores with hand-counted waits: a tile's 8 loads are followed in the memory queue by
+// 16 younger loads and 16 younger stores, loads and stores retire through ONE in-order counter (vmcnt), so `s_waitcnt vmcnt(32)` is "this
+// tile's rows are here" while everything younger stays in flight.  (The compiler's own counting gave vmcnt(0) at every merge of the tail arms: a
+// memory round trip per tile, 1.9 us x 26 tiles = the whole kernel.)  Every mover issues the same instructions whatever its rows: rows past F
+// read row F - 1, columns are clamped by the caller's addr() (they then store what their neighbour stores); only the LAST tile, whose rows may
+// end early, is written back by ordinary predicated stores.  lds: 3 * TBc * ( TFr + 4 ) floats.
+// addr( f ): this thread's element of row f; step( v ): the running sum; post( f, v ): the value stored for row f.
+__device__ __forceinline__ void asm_load( float & dst, const float * p ) { asm volatile( "global_load_dword %0, %1, off" : "=&v"( dst ) : "v"( p ) : "memory" ); }
+__device__ __forceinline__ void asm_store( float * p, float v ) { asm volatile( "global_store_dword %0, %1, off" : : "v"( p ), "v"( v ) : "memory" ); }
+template<int N> __device__ __forceinline__ void asm_wait_vm() { asm volatile( "s_waitcnt vmcnt(%0)" : : "n"( N ) : "memory" ); }
+__device__ __forceinline__ void lds_barrier()
 	{
-	constexpr int NT = NIN > NOUT ? NIN : NOUT, MOVERS = THREADS - 64, NY = MOVERS / TBc, RP = TFr / NY, CH = 32;
-	static_assert( TFr % CH == 0 && MOVERS % TBc == 0 && TFr % NY == 0 && TBc <= 64 && 64 % TBc == 0, "tile shape" );
-	constexpr int TILE = NT * TBc * ( TFr + 4 );
-	auto T = [&]( int buf, int a, int r, int c ) -> float & { return lds[buf * TILE + ( a * TBc + c ) * ( TFr + 4 ) + r]; };
+	__builtin_amdgcn_fence( __ATOMIC_RELEASE, "workgroup", "local" );               // (LDS only: nothing here waits for the movers' memory queue)
+	__builtin_amdgcn_s_barrier();
+	__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "workgroup", "local" );
+	}
+// PROBE (tools/ubench/scan_pipe.hip only): 1 = the scanning wavefront does nothing, 2 = the movers touch no memory, 3 = neither
+template<int TFr, int TBc, int THREADS, int PROBE = 0, class Addr, class Step, class Post>
+__device__ __forceinline__ void column_scan_piped( float * lds, int64_t F, Addr addr, Step step, Post post )
+	{
+	constexpr int MOVERS = THREADS - 64, NY = MOVERS / TBc, RP = TFr / NY, CH = 32, D = 3;
+	static_assert( TFr % CH == 0 && MOVERS % TBc == 0 && TFr % NY == 0 && TBc <= 64 && 64 % TBc == 0 && ( D - 1 ) * 2 * RP <= 63, "tile shape" );
+	constexpr int TILE = TBc * ( TFr + 4 );
+	auto T = [&]( int buf, int r, int c ) -> float & { return lds[buf * TILE + c * ( TFr + 4 ) + r]; };
 	const bool mover = threadIdx.x >= 64;
 	const int tx = threadIdx.x % TBc, ty = mover ? ( int( threadIdx.x ) - 64 ) / TBc : 0;
 	const int64_t tiles = ( F + TFr - 1 ) / TFr;
-	auto tile_of = [&]( int64_t k ) { return REVERSE ? tiles - 1 - k : k; };
-	float pre[NIN][RP];
-	auto load_regs = [&]( int64_t tile_i )
-		{
-		#pragma unroll
-		for( int i = 0; i < RP; ++i )
-			{
-			const int64_t f = tile_i * TFr + ty + NY * i;
-			float v[NIN];
-			#pragma unroll
-			for( int a = 0; a < NIN; ++a ) v[a] = 0.0f;
-			if( f < F ) load( f, v );
-			#pragma unroll
-			for( int a = 0; a < NIN; ++a ) pre[a][i] = v[a];
-			}
-		};
-	auto regs_to_lds = [&]( int buf )
-		{
-		#pragma unroll
-		for( int a = 0; a < NIN; ++a )
-			#pragma unroll
-			for( int i = 0; i < RP; ++i ) T( buf, a, ty + NY * i, tx ) = pre[a][i];
-		};
-	auto write_back = [&]( int buf, int64_t tile_i )
-		{
-		#pragma unroll
-		for( int i = 0; i < RP; ++i )
-			{
-			const int64_t f = tile_i * TFr + ty + NY * i;
-			if( f < F )
-				{
-				float v[NOUT];
-				#pragma unroll
-				for( int a = 0; a < NOUT; ++a ) v[a] = T( buf, a, ty + NY * i, tx );
-				store( f, v );
-				}
-			}
-		};
-	auto scan = [&]( int buf, int64_t tile_i )
-		{
-		const int64_t fbase = tile_i * TFr;
-		#pragma unroll 1
-		for( int c0 = 0; c0 < TFr; c0 += CH )
-			{
-			const int base = REVERSE ? TFr - CH - c0 : c0;
-			float col[NT][CH];
-			#pragma unroll
-			for( int a = 0; a < NIN; ++a )
-				#pragma unroll
-				for( int j = 0; j < CH; ++j ) col[a][j] = T( buf, a, base + j, tx );
-			#pragma unroll
-			for( int jj = 0; jj < CH; ++jj )
-				{
-				const int j = REVERSE ? CH - 1 - jj : jj;
-				float v[NT];
-				#pragma unroll
-				for( int a = 0; a < NIN; ++a ) v[a] = col[a][j];
-				step( fbase + base + j, v );
-				#pragma unroll
-				for( int a = 0; a < NOUT; ++a ) col[a][j] = v[a];
-				}
-			#pragma unroll
-			for( int a = 0; a < NOUT; ++a )
-				#pragma unroll
-				for( int j = 0; j < CH; ++j ) T( buf, a, base + j, tx ) = col[a][j];
-			}
-		};
 	if( tiles <= 0 ) return;
-	if( mover ) { load_regs( tile_of( 0 ) ); regs_to_lds( 0 ); if( tiles > 1 ) load_regs( tile_of( 1 ) ); }
-	__syncthreads();
-	for( int64_t k = 0; k < tiles; ++k )
+	float pre[D][RP];
+	auto request = [&]( int64_t tile_i, float ( &dst )[RP] )                        // always RP loads
 		{
-		const int b = int( k % 3 );
-		if( mover )
+		const int64_t f0 = min( tile_i, tiles - 1 ) * TFr + ty;
+		#pragma unroll
+		for( int i = 0; i < RP; ++i ) { if( PROBE & 2 ) dst[i] = 1.0f; else asm_load( dst[i], addr( min( f0 + NY * i, F - 1 ) ) ); }
+		};
+	auto to_lds = [&]( int buf, float ( &src )[RP] )
+		{
+		#pragma unroll
+		for( int i = 0; i < RP; ++i ) asm volatile( "" : "+v"( src[i] ) );          // (read below the wait just issued)
+		#pragma unroll
+		for( int i = 0; i < RP; ++i ) T( buf, ty + NY * i, tx ) = src[i];
+		};
+	auto write_back_full = [&]( int buf, int64_t tile_i )                           // always RP stores
+		{
+		const int64_t f0 = tile_i * TFr + ty;
+		float v[RP];
+		#pragma unroll
+		for( int i = 0; i < RP; ++i ) v[i] = T( buf, ty + NY * i, tx );
+		#pragma unroll
+		for( int i = 0; i < RP; ++i ) { const float t = post( f0 + NY * i, v[i] ); if( !( PROBE & 2 ) ) asm_store( addr( f0 + NY * i ), t ); }
+		};
+	// the scanning wavefront's tile, the whole tile unrolled.  What it costs (tools/ubench/scan_pipe.hip, profiles/r04_scan_pipe_ubench.txt): one
+	// wavefront issues a dependent v_add_f32 every 8.3 cycles and the LDS traffic -- a ds_read_b128 and a ds_write_b128 per four frames -- costs
+	// ~11 cycles per instruction whatever the schedule (hand-placed waits and reads a chunk ahead: the same time): ~14 cycles a frame, 33 of the
+	// kernel's 42 us.
+	auto scan = [&]( int buf )
+		{
+		constexpr int NCH = TFr / CH;
+		float col[2][CH];
+		#pragma unroll
+		for( int j = 0; j < CH; ++j ) col[0][j] = T( buf, j, tx );
+		#pragma unroll
+		for( int c = 0; c < NCH; ++c )
 			{
-			if( k >= 1 ) write_back( ( b + 2 ) % 3, tile_of( k - 1 ) );
-			if( k + 1 < tiles )
+			float ( &cur )[CH] = col[c & 1];
+			if( c + 1 < NCH )
 				{
-				regs_to_lds( ( b + 1 ) % 3 );
-				if( k + 2 < tiles ) load_regs( tile_of( k + 2 ) );
+				#pragma unroll
+				for( int j = 0; j < CH; ++j ) col[( c + 1 ) & 1][j] = T( buf, ( c + 1 ) * CH + j, tx );
 				}
+			#pragma unroll
+			for( int j = 0; j < CH; ++j ) cur[j] = step( cur[j] );
+			#pragma unroll
+			for( int j = 0; j < CH; ++j ) T( buf, c * CH + j, tx ) = cur[j];
 			}
-		else if( threadIdx.x < TBc ) scan( b, tile_of( k ) );
-		__syncthreads();
+		};
+	if( mover )
+		{
+		#pragma unroll
+		for( int d = 0; d < D; ++d ) request( d, pre[d] );
+		asm_wait_vm<( D - 1 ) * RP>();
+		to_lds( 0, pre[0] );
+		request( D, pre[0] );
 		}
-	if( mover ) write_back( int( ( tiles - 1 ) % 3 ), tile_of( tiles - 1 ) );
+	lds_barrier();
+	for( int64_t k0 = 0; k0 < tiles; k0 += D )
+		{
+		#pragma unroll
+		for( int u = 0; u < D; ++u )                                                // (D == 3 == the LDS buffers: buffer and register set are both static)
+			{
+			const int64_t k = k0 + u;
+			if( k >= tiles ) break;
+			if( mover )
+				{
+				if( k + 1 < tiles )
+					{
+					// tile k + 1's rows: behind them in the queue the loads of tiles k + 2, k + 3 and -- from the third iteration on -- the stores of
+					// the two iterations before this one
+					if( k >= D ) asm_wait_vm<( D - 1 ) * 2 * RP>(); else asm_wait_vm<( D - 1 ) * RP>();
+					to_lds( ( u + 1 ) % 3, pre[( u + 1 ) % D] );
+					request( k + 1 + D, pre[( u + 1 ) % D] );
+					}
+				if( k >= 1 ) write_back_full( ( u + 2 ) % 3, k - 1 );
+				}
+			else if( threadIdx.x < TBc && !( PROBE & 1 ) ) scan( u );
+			lds_barrier();
+			}
+		}
+	if( mover )
+		{
+		asm_wait_vm<0>();                                                           // (requests past the last tile are still in flight)
+		const int buf = int( ( tiles - 1 ) % 3 );
+		const int64_t f0 = ( tiles - 1 ) * TFr + ty;
+		#pragma unroll
+		for( int i = 0; i < RP; ++i )
+			{
+			const int64_t f = f0 + NY * i;
+			if( f < F ) *addr( f ) = post( f, T( buf, ty + NY * i, tx ) );
+			}
+		}
 	}
 
 struct DevBuf
