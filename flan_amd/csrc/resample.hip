@@ -747,7 +747,7 @@ static int ols_twiddles( const cd ** out )                                      
 	auto it = g_ols_twiddles.find( device );
 	if( it == g_ols_twiddles.end() )
 		{
-		std::vector<cd> tw( OlsTables::LEN );
+		std::vector<cd> tw( OlsTables::LEN + Ols3Tables::LEN );
 		auto fill = [&]( int at, int ns, int period )                            // [15][ns]: exp( -2 pi i r k / period )
 			{
 			std::vector<long double> c, sn;
@@ -760,6 +760,20 @@ static int ols_twiddles( const cd ** out )                                      
 					}
 			};
 		fill( OlsTables::F1, 16, 256 ); fill( OlsTables::F2, 256, 4096 ); fill( OlsTables::I1, 8, 128 ); fill( OlsTables::I2, 128, 2048 );
+		// k_resample_ols3's tables behind them: [7][ns]
+		auto fill8 = [&]( int at, int ns, int period )
+			{
+			std::vector<long double> c, sn;
+			ols_unit_circle( period, c, sn );
+			for( int r = 1; r < 8; ++r )
+				for( int k = 0; k < ns; ++k )
+					{
+					const size_t m = size_t( r * k ) % size_t( period );
+					tw[size_t( OlsTables::LEN + at + ( r - 1 ) * ns + k )] = cd{ double( c[m] ), double( -sn[m] ) };
+					}
+			};
+		fill8( Ols3Tables::F1, 8, 64 ); fill8( Ols3Tables::F2, 64, 512 ); fill8( Ols3Tables::F3, 512, 4096 );
+		fill8( Ols3Tables::I1, 4, 32 ); fill8( Ols3Tables::I2, 32, 256 ); fill8( Ols3Tables::I3, 256, 2048 );
 		cd * d = nullptr;
 		FLANHIP_CHECK( hipMalloc( &d, sizeof( cd ) * tw.size() ) );
 		FLANHIP_CHECK( hipMemcpy( d, tw.data(), sizeof( cd ) * tw.size(), hipMemcpyHostToDevice ) );
@@ -824,6 +838,13 @@ static int get_stage_plan( double src, double dst, const std::vector<Stage> ** o
 					{
 					std::vector<cd> spec;
 					ols_filter_spectrum( h, spec );
+					// behind it the same spectrum in the order k_resample_ols3's forward transform leaves the bins in: [t][q] = H[rev( q ) + 512 t]
+					spec.resize( 2 * OLS_N );
+					for( int tq = 0; tq < OLS_N; ++tq )
+						{
+						const int t8 = tq >> 9, q = tq & 511, rev = ( ( q & 7 ) << 6 ) | ( q & 56 ) | ( q >> 6 );
+						spec[size_t( OLS_N + tq )] = spec[size_t( rev + 512 * t8 )];
+						}
 					FLANHIP_CHECK( hipMalloc( &t.d_spec, sizeof( cd ) * spec.size() ) );
 					FLANHIP_CHECK( hipMemcpy( t.d_spec, spec.data(), sizeof( cd ) * spec.size(), hipMemcpyHostToDevice ) );
 					}
@@ -865,17 +886,24 @@ static int launch_rational( const InT * d_in, int64_t n_in, const Stage & g, Out
 	if constexpr( std::is_same<InT, float>::value && std::is_same<OutT, float>::value )
 		{
 		const int Lo = OLS_N / 2 - g.fl2;
-		if( !debug_options().resample_direct && g.d_spec && g.up == 1 && g.down == 2 && n_out >= 8 * int64_t( Lo ) )
+		if( debug_options().resample_direct != 1 && g.d_spec && g.up == 1 && g.down == 2 && n_out >= 8 * int64_t( Lo ) )
 			{
 			const cd * tw = nullptr;
 				{
 				std::lock_guard<std::mutex> lock( g_rs_mutex );
 				if( int rc = ols_twiddles( &tw ) ) return rc;
 				}
-			const size_t lds = sizeof( cd ) * OLS_BUF;
-			FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( k_resample_ols2<InT, OutT> ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 			const int64_t blocks = ( n_out + 2 * int64_t( Lo ) - 1 ) / ( 2 * int64_t( Lo ) );
-			hipLaunchKernelGGL( ( k_resample_ols2<InT, OutT> ), dim3( (unsigned) blocks ), dim3( OLS_THREADS ), lds, s, d_in, n_in, g.d_spec, tw, g.fl2, d_out, n_out );
+			if( debug_options().resample_direct == 2 )                              // (hook: the 256-thread radix-16 generation)
+				{
+				const size_t lds = sizeof( cd ) * OLS_BUF;
+				FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( k_resample_ols2<InT, OutT> ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+				hipLaunchKernelGGL( ( k_resample_ols2<InT, OutT> ), dim3( (unsigned) blocks ), dim3( OLS_THREADS ), lds, s, d_in, n_in, g.d_spec, tw, g.fl2, d_out, n_out );
+				return FLANHIP_OK;
+				}
+			const size_t lds = sizeof( cd ) * OLS3_BUF;
+			FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( k_resample_ols3<InT, OutT> ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+			hipLaunchKernelGGL( ( k_resample_ols3<InT, OutT> ), dim3( (unsigned) blocks ), dim3( OLS3_THREADS ), lds, s, d_in, n_in, g.d_spec + OLS_N, tw + OlsTables::LEN, g.fl2, d_out, n_out );
 			return FLANHIP_OK;
 			}
 		}

@@ -1,4 +1,5 @@
-// resample_fft.h -- the 2:1 block convolver of Audio::resample as fp64 overlap-save FFT convolution.
+// resample_fft.h -- the 2:1 block convolver of Audio::resample as fp64 overlap-save FFT convolution: k_resample_ols3 (below; what runs) and its
+// predecessor k_resample_ols2 (kept behind the resample_direct = 2 hook for A/B).
 //
 // Reference: r8brain/CDSPBlockConvolver.h:242-344 convolves by FFT overlap-save (for 96 -> 48 kHz: 1621 taps, blocks of 2476 new input
 // samples, fft 4096, inverse of half the size because only every second output is wanted).  The direct 1621-tap FIR of k_resample_down<2>
@@ -204,6 +205,173 @@ __global__ __launch_bounds__( OLS_THREADS ) void k_resample_ols2( const InT * __
 				const int64_t ka = k0 + u, kb = ka + Lo;
 				if( ka < total_out ) out[ka] = OutT( v[r].x );
 				if( kb < total_out ) out[kb] = OutT( -v[r].y );
+				}
+			}
+		}
+	}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// k_resample_ols3: the same convolver with twice the wavefronts per CU.  k_resample_ols2's counters (profiles/r04_resample_sq_counters.txt): a
+// wavefront waits 64 % of its life -- on table reads through L2 and on the barriers between six short passes -- with two wavefronts per SIMD
+// to cover that (256 threads x 16 points: 214 registers, 68 KB of LDS) and half the workgroup idle through the inverse passes.  Here: 512
+// threads x 8 points, radix-8 Stockham passes ( 4096 = 8 x 8 x 8 x 8 forward, 2048 = 4 x 8 x 8 x 8 inverse ), <= 128 registers: four
+// wavefronts per SIMD at the same LDS footprint (two workgroups per CU), ~4 200 fp64 wave-instructions per workgroup instead of 5 460, 66
+// memory reads per thread instead of 93.  The packing (two blocks as real and imaginary part), the fold E[k] = W[k] + W[k + 2048] and the dropped
+// wrap-around are k_resample_ols2's.
+struct Ols3Tables
+	{
+	static constexpr int F1 = 0;                     // [7][8]     exp( -2 pi i r k / 64 )     forward, sub-transforms of 8
+	static constexpr int F2 = F1 + 7 * 8;            // [7][64]    exp( -2 pi i r k / 512 )
+	static constexpr int F3 = F2 + 7 * 64;           // [7][512]   exp( -2 pi i r k / 4096 )
+	static constexpr int I1 = F3 + 7 * 512;          // [7][4]     exp( -2 pi i r k / 32 )     inverse ( 2048 points ), sub-transforms of 4
+	static constexpr int I2 = I1 + 7 * 4;            // [7][32]    exp( -2 pi i r k / 256 )
+	static constexpr int I3 = I2 + 7 * 32;           // [7][256]   exp( -2 pi i r k / 2048 )
+	static constexpr int LEN = I3 + 7 * 256;
+	};
+constexpr int OLS3_THREADS = 512;
+constexpr int OLS3_BUF = OLS_N + OLS_N / 8;            // one pad slot per 8: the radix-8 scatter of a pass lands on distinct banks
+__device__ __forceinline__ int ols3_pad( int i ) { return i + ( i >> 3 ); }
+
+// The transforms are IN PLACE -- forward decimation in frequency (natural order in, digit-reversed spectrum out), inverse decimation in time
+// (digit-reversed in, natural out) -- so a thread writes the slots it read and ONE barrier separates two passes (a Stockham pass needs two);
+// the filter spectrum is stored in the order the forward transform leaves the bins in (spec3[t * 512 + q] = H[rev( q ) + 512 t], rev = the
+// three radix-8 digits of q reversed), and the fold pairs ( k, k + 2048 ) are still one thread's: the last forward pass leaves thread q with
+// Z[rev( q ) + 512 t], t < 8, and position 4 q + r of the inverse's array is E[rev( q ) + 512 r] -- exactly the order a 4 x 8 x 8 x 8
+// decimation-in-time transform of 2048 points starts from.
+template<typename InT, typename OutT>
+__global__ __launch_bounds__( OLS3_THREADS, 2 ) void k_resample_ols3( const InT * __restrict__ in, int64_t total_in, const cd * __restrict__ spec3,
+	const cd * __restrict__ tw, int fl2, OutT * __restrict__ out, int64_t total_out )
+	{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	cd * buf = reinterpret_cast<cd*>( smem );
+	const int j = threadIdx.x;
+	const unsigned ju = threadIdx.x;                                             // (table offsets: 32-bit, no sign extension)
+	const int Lo = OLS_N / 2 - fl2, L = 2 * Lo;
+	const int64_t k0 = int64_t( 2 * blockIdx.x ) * Lo;                          // first output of the first block
+	const int64_t n0 = 2 * k0 - fl2;                                            // its segment starts here; the second block's L samples later
+	cd v[8], t[7], h7;
+	// ---- forward pass A (blocks of 4096): points j + 512 r straight from the signal (zero outside it, like the direct sum's bounds)
+	if( n0 >= 0 && n0 + L + OLS_N <= total_in )                                 // (every workgroup but the first and the last few: no bounds tests)
+		{
+		const InT * pa = in + n0 + j;
+		#pragma unroll
+		for( int r = 0; r < 8; ++r ) { v[r].x = double( pa[512 * r] ); v[r].y = double( pa[L + 512 * r] ); }
+		}
+	else
+		{
+		#pragma unroll
+		for( int r = 0; r < 8; ++r )
+			{
+			const int64_t a = n0 + j + 512 * r, b = a + L;
+			v[r].x = ( a >= 0 && a < total_in ) ? double( in[a] ) : 0.0;
+			v[r].y = ( b >= 0 && b < total_in ) ? double( in[b] ) : 0.0;
+			}
+		}
+	#pragma unroll
+	for( int r = 0; r < 7; ++r ) t[r] = tw[Ols3Tables::F3 + r * 512 + ju];
+	cd_dft8( v );
+	#pragma unroll
+	for( int r = 1; r < 8; ++r ) v[r] = cd_mul( v[r], t[r - 1] );
+	#pragma unroll
+	for( int r = 0; r < 7; ++r ) t[r] = tw[Ols3Tables::F2 + r * 64 + ( ju & 63 )];  // (the next pass's twiddles travel across the barrier)
+	#pragma unroll
+	for( int r = 0; r < 8; ++r ) buf[ols3_pad( j + 512 * r )] = v[r];
+	__syncthreads();
+	// ---- forward passes B (blocks of 512) and C (blocks of 64): butterfly, then the twiddle, back into the same slots
+	#pragma unroll
+	for( int pass = 0; pass < 2; ++pass )
+		{
+		const int base = pass == 0 ? ( j >> 6 ) * 512 + ( j & 63 ) : ( j >> 3 ) * 64 + ( j & 7 ), step = pass == 0 ? 64 : 8;
+		#pragma unroll
+		for( int r = 0; r < 8; ++r ) v[r] = buf[ols3_pad( base + step * r )];
+		cd_dft8( v );
+		#pragma unroll
+		for( int r = 1; r < 8; ++r ) v[r] = cd_mul( v[r], t[r - 1] );
+		if( pass == 0 )
+			{
+			#pragma unroll
+			for( int r = 0; r < 7; ++r ) t[r] = tw[Ols3Tables::F1 + r * 8 + ( ju & 7 )];
+			}
+		else
+			{
+			// (pass D has no twiddles: the filter's spectrum travels in their registers)
+			#pragma unroll
+			for( int r = 0; r < 7; ++r ) t[r] = spec3[ju + 512 * r];
+			h7 = spec3[ju + 512 * 7];
+			}
+		#pragma unroll
+		for( int r = 0; r < 8; ++r ) buf[ols3_pad( base + step * r )] = v[r];
+		__syncthreads();
+		}
+	// ---- forward pass D (blocks of 8, no twiddles): leaves Z[rev( j ) + 512 r] in v[r]
+	#pragma unroll
+	for( int r = 0; r < 8; ++r ) v[r] = buf[ols3_pad( 8 * j + r )];
+	cd_dft8( v );
+	// ---- filter, fold to the spectrum of every second output, conjugate for the inverse transform; inverse pass 1: radix 4 over E[rev( j ) + 512 r]
+	cd e[4];
+	#pragma unroll
+	for( int r = 0; r < 4; ++r )
+		{
+		const cd a = cd_mul( v[r], t[r] ), b = cd_mul( v[r + 4], r == 3 ? h7 : t[r + 4] );
+		e[r] = cd{ a.x + b.x, -( a.y + b.y ) };
+		}
+	cd_dft4( e[0], e[1], e[2], e[3] );
+	__syncthreads();                                                            // (pass D's reads of other threads' slots are done)
+	#pragma unroll
+	for( int r = 0; r < 4; ++r ) buf[ols3_pad( 4 * j + r )] = e[r];
+	const bool mine = j < 256;                                                  // 256 butterflies of 8 from here on
+	if( mine )
+		{
+		#pragma unroll
+		for( int r = 0; r < 7; ++r ) t[r] = tw[Ols3Tables::I1 + r * 4 + ( ju & 3 )];
+		}
+	__syncthreads();
+	// ---- inverse passes 2 (sub-transforms of 4 -> 32) and 3 (32 -> 256): the twiddle, then the butterfly, back into the same slots
+	#pragma unroll
+	for( int pass = 0; pass < 2; ++pass )
+		{
+		if( mine )
+			{
+			const int base = pass == 0 ? ( j >> 2 ) * 32 + ( j & 3 ) : ( j >> 5 ) * 256 + ( j & 31 ), step = pass == 0 ? 4 : 32;
+			#pragma unroll
+			for( int r = 0; r < 8; ++r ) v[r] = buf[ols3_pad( base + step * r )];
+			#pragma unroll
+			for( int r = 1; r < 8; ++r ) v[r] = cd_mul( v[r], t[r - 1] );
+			#pragma unroll
+			for( int r = 0; r < 7; ++r ) t[r] = pass == 0 ? tw[Ols3Tables::I2 + r * 32 + ( ju & 31 )] : tw[Ols3Tables::I3 + r * 256 + ju];
+			cd_dft8( v );
+			#pragma unroll
+			for( int r = 0; r < 8; ++r ) buf[ols3_pad( base + step * r )] = v[r];
+			}
+		__syncthreads();
+		}
+	if( mine )
+		{
+		// ---- inverse pass 4 (256 -> 2048): c[2u] of both blocks, u = j + 256 r
+		#pragma unroll
+		for( int r = 0; r < 8; ++r ) v[r] = buf[ols3_pad( j + 256 * r )];
+		#pragma unroll
+		for( int r = 1; r < 8; ++r ) v[r] = cd_mul( v[r], t[r - 1] );
+		cd_dft8( v );
+		if( k0 + L <= total_out )
+			{
+			OutT * po = out + k0 + ( j - fl2 );
+			#pragma unroll
+			for( int r = 0; r < 8; ++r )
+				if( j + 256 * r >= fl2 ) { po[256 * r] = OutT( v[r].x ); po[Lo + 256 * r] = OutT( -v[r].y ); }   // the first fl2 are the wrap-around of the circular convolution
+			}
+		else
+			{
+			#pragma unroll
+			for( int r = 0; r < 8; ++r )
+				{
+				const int u = j + 256 * r - fl2;
+				if( u >= 0 )
+					{
+					const int64_t ka = k0 + u, kb = ka + Lo;
+					if( ka < total_out ) out[ka] = OutT( v[r].x );
+					if( kb < total_out ) out[kb] = OutT( -v[r].y );
+					}
 				}
 			}
 		}

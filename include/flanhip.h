@@ -163,7 +163,7 @@ int flanhip_synthesize_dev_stages(const flanhip_MF * d_pv, int64_t num_channels,
 #define FLANHIP_DEBUG_SYN4096_OLD     7   /* 1: the round-1 dft 4096 synthesis kernel */
 #define FLANHIP_DEBUG_RESAMPLE_DIRECT 8   /* 1: Audio::resample's 2:1 block convolver always as direct fp64 sums in the checker's operation order
                                            * (default: fp64 overlap-save FFT convolution, the reference's own method, r8brain/CDSPBlockConvolver.h:242-344,
-                                           * for float streams of at least 8 blocks) */
+                                           * for float streams of at least 8 blocks); 2: the convolver's 256-thread radix-16 generation (A/B predecessor) */
 #define FLANHIP_DEBUG_FORCE_DIRECT    9   /* 1: dft sizes without power-of-two kernels as direct fp64 sums (the transform's definition: pv_kernels_any.h),
                                            * never the mixed-radix FFT kernels (pv_kernels_mr.h): the checker-order path, for A/B */
 #define FLANHIP_DEBUG_INLINE_FIXUP   10   /* 1: the dft 2048 synthesis kernel adds the overlaps of neighbouring chains itself (whichever of the two

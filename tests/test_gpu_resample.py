@@ -213,7 +213,7 @@ def test_resample_against_the_real_r8brain(fa, tag):
 
 @pytest.mark.parametrize("ch,n", [(1, 19808), (1, 19810), (1, 39615), (2, 24760), (3, 9907), (1, 250000)])
 def test_resample_fft_convolver_against_the_direct_sums(fa, ch, n):
-    """the 2:1 block convolver as fp64 overlap-save FFT convolution (k_resample_ols2, what streams of 8 blocks and more take) against the
+    """the 2:1 block convolver as fp64 overlap-save FFT convolution (k_resample_ols3, what streams of 8 blocks and more take) against the
     direct fp64 sums in the checker's order (the resample_direct hook of flanhip_debug_option): stream lengths at the switch-over, at whole numbers of block
     pairs, one past them, ragged; >= 99.9 % of the samples bit-identical, the rest one fp32 ulp at unit scale."""
     x = O.noise(ch, n, seed=n + ch)
@@ -228,6 +228,13 @@ def test_resample_fft_convolver_against_the_direct_sums(fa, ch, n):
     worst = np.abs(got.astype(np.float64) - direct.astype(np.float64)).max()
     print("\n[fft vs direct %dx%d] bit-identical %.5f  worst %.2e" % (ch, n, same, worst))
     assert same >= 0.999 and worst <= 1.2e-7
+    # the 256-thread radix-16 generation of the convolver (k_resample_ols2, hook value 2) against the same sums
+    try:
+        fa.lib.flanhip_debug_option(fa.DEBUG_RESAMPLE_DIRECT, 2)
+        old = fa.resample(x, 96000.0, 48000.0)
+    finally:
+        fa.lib.flanhip_debug_option(fa.DEBUG_RESAMPLE_DIRECT, 0)
+    assert np.mean(old.view(np.uint32) == direct.view(np.uint32)) >= 0.999 and np.abs(old.astype(np.float64) - direct.astype(np.float64)).max() <= 1.2e-7
     assert np.array_equal(direct.view(np.uint32), O.resample_2to1(x, 96000.0, 48000.0).view(np.uint32))    # the direct kernel IS the checker's sum
 
 

@@ -1,4 +1,4 @@
-# Audio::resample 96 -> 48 kHz (config 5's stage, k_resample_ols2): kernel time, SQ counters (what a wavefront's time goes into) and HBM traffic,
+# Audio::resample 96 -> 48 kHz (config 5's stage, k_resample_ols3): kernel time, SQ counters (what a wavefront's time goes into) and HBM traffic,
 # separate PMC passes; summaries in gpurun_out/resample_sq_counters.txt / resample_hbm_counters.txt / resample_kernel_stats.csv
 set -e
 R=$GRAFT_REPO_ROOT
@@ -21,6 +21,6 @@ python tools/pmc_summary.py gpurun_out/prof_rs_sq1 gpurun_out/prof_rs_sq2 gpurun
 python tools/pmc_summary.py gpurun_out/prof_rs_fetch gpurun_out/prof_rs_write > gpurun_out/resample_hbm_counters.txt
 find gpurun_out/prof_rs -name "*kernel_stats.csv" -exec cp {} gpurun_out/resample_kernel_stats.csv \;
 rm -rf gpurun_out/prof_rs gpurun_out/prof_rs_sq? gpurun_out/prof_rs_fetch gpurun_out/prof_rs_write
-grep -A3 "k_resample_ols2" gpurun_out/resample_sq_counters.txt | cut -c1-400
-grep -A1 "k_resample_ols2" gpurun_out/resample_hbm_counters.txt
+grep -A3 "k_resample_ols" gpurun_out/resample_sq_counters.txt | cut -c1-400
+grep -A1 "k_resample_ols" gpurun_out/resample_hbm_counters.txt
 cut -c1-140 gpurun_out/resample_kernel_stats.csv | head -5
