@@ -107,6 +107,22 @@ def _host(fa, p, shape, dtype=np.float32):
     return out
 
 
+@pytest.mark.parametrize("F,bins", [(1, 5), (3, 17), (223, 16), (224, 33), (225, 1025), (449, 100), (672, 7), (1000, 1025), (2, 1), (5626, 40)])
+def test_stretch_map_on_the_device(fa, F, bins):
+    """PV::stretch's time map (PVModify.cpp:376-382: a running fp32 sum down the frames of every bin, frame_to_time) and its maximum from
+    k_stretch_map against the oracle, bit for bit: one tile and several, whole tiles and ragged ones, strips with idle columns, one bin."""
+    rng = np.random.default_rng(F * 1000 + bins)
+    g = rng.uniform(0.1, 4.0, (F, bins)).astype(np.float32)
+    ref = O.stretch_map(g, SR, 256)
+    d_grid = _dev(fa, g)
+    d_max = _dev(fa, np.array([-np.inf], np.float32))
+    fa.check(fa.lib.flanhip_stretch_map_dev(d_grid, F, bins, SR, 256, d_max, None))
+    got, mx = _host(fa, d_grid, (F, bins)), _host(fa, d_max, (1,))[0]
+    fa.check(fa.lib.flanhip_free(d_grid)); fa.check(fa.lib.flanhip_free(d_max))
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert np.float32(mx) == ref.max()
+
+
 def test_device_chain_config3_shape(fa):
     """BASELINE config 3 in small, never leaving HBM: convert_to_PV -> stretch(lambda -> 2) -> convert_to_audio through the
     _dev entry points, against the same chain in the oracle."""
