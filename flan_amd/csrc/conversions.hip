@@ -543,6 +543,8 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 		o->any_frames_offset = o->any_spec_offset + ( ( size_t( ch ) * size_t( F ) * size_t( bins ) * sizeof( cf ) + 255 ) & ~size_t( 255 ) );
 		o->total_bytes = o->any_frames_offset + ( ( size_t( ch ) * size_t( F ) * size_t( W ) * sizeof( float ) + 255 ) & ~size_t( 255 ) );
 		}
+	o->flags_offset = o->total_bytes;
+	o->total_bytes += ( sizeof( int ) * size_t( bins + 1 ) + 255 ) & ~size_t( 255 );
 	return FLANHIP_OK;
 	}
 

@@ -94,6 +94,7 @@ int next_epoch();
 // groups: aligned runs of 8 consecutive chains of a channel (one 8-wave block of the dft 2048 kernels); group_bytes: one fp64 sum per
 // (channel, group, bin) behind the 1024-byte tail -- what lets the synthesis kernel compute its own carries (no scan kernel)
 struct SynthLayout { int hop, dft, L, chains_per_channel, head_len, groups_per_channel; size_t carry_bytes, head_bytes, group_offset, group_bytes, total_bytes;
+	size_t flags_offset;              // bins + 1 words for a producer's own notes (PV::modify_time: which columns of the time map run backwards)
 	size_t fix_offset, tail_offset;   // k_synthesize_v2's own overlap fix-up: a state word per chain, then a second side buffer the size of the heads' (0: not this shape)
 	bool any; size_t any_spec_offset, any_frames_offset; };   // any: a dft size without FFT kernels (pv_kernels_any.h) and its scratch in the workspace
 // which producer last left its pre-pass in a synthesis workspace (host-side note, keyed by the workspace pointer, written when the

@@ -26,9 +26,9 @@ namespace flanhip {
 // clearing pass and no read-modify-write.  Columns whose map does run backwards (flag set by the first blocks of k_modify_time_chains) are cleared
 // and then walked by one thread in the reference order.
 __global__ __launch_bounds__( 256 ) void k_modify_time( const MFd * in, int num_channels, int64_t F, int bins, float sr, float hop,
-	const float * mod, int64_t Fo, MFd * out, const int * nonmono, int segments, int64_t seg_len, int only_if_any, int interp, int * words, int epoch )
+	const float * mod, int64_t Fo, MFd * out, const int * nonmono, int flag_tag, int segments, int64_t seg_len, int only_if_any, int interp, int * words, int epoch )
 	{
-	if( only_if_any && !nonmono[bins] ) return;                                     // k_modify_time_chains has done this PV
+	if( only_if_any && nonmono[bins] != flag_tag ) return;                          // k_modify_time_chains has done this PV (a flag is set when it holds this call's tag)
 	if( words && blockIdx.x == 0 && threadIdx.x == 0 ) { words[2] = epoch; words[4] = 0; }   // the chain sums k_modify_time_chains left are NOT this PV's
 	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
 	const int64_t columns = int64_t( num_channels ) * bins;
@@ -36,7 +36,7 @@ __global__ __launch_bounds__( 256 ) void k_modify_time( const MFd * in, int num_
 	const int seg = int( idx / columns );
 	const int channel = int( ( idx % columns ) / bins ), bin = int( idx % bins );
 	int64_t f0 = 1 + seg * seg_len, f1 = min( F, f0 + seg_len );
-	const bool sequential = nonmono[bin] != 0;
+	const bool sequential = nonmono[bin] == flag_tag;
 	if( sequential ) { if( seg != 0 ) return; f0 = 1; f1 = F; }                    // order matters for this column: one thread, all pairs
 	if( f0 >= f1 ) return;
 	const MFd * ip = in + int64_t( channel ) * F * bins + bin;
@@ -115,7 +115,8 @@ struct TimeChainParams
 	double * sums;            // [ch][chains][bins]
 	int * words;              // workspace tail: [0] NaN flag, [2] epoch, [4] "sums valid" (set iff equal to the epoch)
 	int epoch;
-	int * nonmono;            // [bins + 1], zeroed before the launch: written by the launch's first flag_blocks blocks
+	int * nonmono;            // [bins + 1], NOT cleared: a flag is set when it holds flag_tag, a number no earlier call used (core.hip: next_epoch); written by the launch's first flag_blocks blocks
+	int flag_tag;
 	int flag_blocks;          // a multiple of 8
 	int interp;               // FLANHIP_INTERP_*: the Interpolator of PVModify.cpp:344 (0 = linear)
 	};
@@ -149,7 +150,7 @@ __global__ __launch_bounds__( 256 ) void k_modify_time_chains( TimeChainParams p
 	{
 	if( int( blockIdx.x ) < p.flag_blocks )
 		{
-		// nonmono[bin] = 1 for columns whose map runs backwards somewhere (or is NaN), nonmono[bins] = 1 if there is any: thread = ( run of
+		// nonmono[bin] = flag_tag for columns whose map runs backwards somewhere (or is NaN), nonmono[bins] = flag_tag if there is any: thread = ( run of
 		// kFlagRun frame pairs, bin ), lanes along the bins
 		const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
 		const int64_t runs = ( p.F - 1 + kFlagRun - 1 ) / kFlagRun;
@@ -163,10 +164,10 @@ __global__ __launch_bounds__( 256 ) void k_modify_time_chains( TimeChainParams p
 		#pragma unroll
 		for( int i = 0; i < kFlagRun; ++i )
 			backwards |= !( time_to_frame( t[i + 1], p.sr, p.hop ) >= time_to_frame( t[i], p.sr, p.hop ) );   // :332 (r >= l; false for NaN)
-		if( backwards ) { p.nonmono[bin] = 1; p.nonmono[p.bins] = 1; }
+		if( backwards ) { p.nonmono[bin] = p.flag_tag; p.nonmono[p.bins] = p.flag_tag; }
 		return;
 		}
-	if( p.nonmono[p.bins] ) return;                                                 // already known to run backwards somewhere: k_modify_time does this PV
+	if( p.nonmono[p.bins] == p.flag_tag ) return;                                   // already known to run backwards somewhere: k_modify_time does this PV
 	const int cblock = int( blockIdx.x ) - p.flag_blocks;                           // (flag_blocks is a multiple of 8: the XCD of a block is cblock % 8 too)
 	const int64_t nblocks = int64_t( gridDim.x ) - p.flag_blocks, per_xcd = ( nblocks + 7 ) / 8;   // XCD x takes a contiguous run of blocks (pieces of a row meet in one L2)
 	const int64_t vblock = int64_t( cblock % 8 ) * per_xcd + cblock / 8;
@@ -611,8 +612,8 @@ namespace flanhip { int processors_set_interp_lut( int slot, const float * d_tab
 
 using namespace flanhip;
 
-// the monotone-map kernel: its first blocks check the map (nonmono must be zeroed), the others walk the output chains
-// the monotone-map kernel: its first blocks check the map (nonmono must be zeroed), the others walk the output chains
+// the monotone-map kernel: its first blocks check the map (nonmono: tagged flags, no clearing), the others walk the output chains
+// the monotone-map kernel: its first blocks check the map (nonmono: tagged flags, no clearing), the others walk the output chains
 template<bool SUMS>
 static int launch_time_chains( TimeChainParams & p, hipStream_t s )
 	{
@@ -639,14 +640,14 @@ static int modify_time_dev_impl( const flanhip_MF * d_pv, int64_t ch, int64_t F,
 	hipStream_t s = (hipStream_t) stream;
 	FLANHIP_REQUIRE( Fo < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "2^31 output frames or more" );
 	int * d_flags = nullptr;                                                       // per bin: does the time map ever run backwards?
-	const size_t flag_bytes = ( sizeof( int ) * size_t( bins + 1 ) + 255 ) / 256 * 256;   // (a whole number of 256-byte pieces: the runtime's fill is then one kernel, not two)
-	FLANHIP_CHECK( hipMallocAsync( reinterpret_cast<void**>( &d_flags ), flag_bytes, s ) );
-	FLANHIP_CHECK( hipMemsetAsync( d_flags, 0, flag_bytes, s ) );
+	// (not cleared -- the runtime's fill is a 5 us kernel of its own: a flag counts as set when it holds this call's tag, and whatever the fresh
+	// allocation holds is at best an EARLIER call's tag)
+	FLANHIP_CHECK( hipMallocAsync( reinterpret_cast<void**>( &d_flags ), sizeof( int ) * size_t( bins + 1 ), s ) );
 	// monotone maps (every stretch): output chains of 32 frames, one thread per (channel, bin, chain) -- see k_modify_time_chains
 	TimeChainParams cp{};
 	cp.in = (const MFd*) d_pv; cp.mod = d_mod; cp.out = (MFd*) d_out;
 	cp.F = F; cp.Fo = Fo; cp.num_channels = int( ch ); cp.bins = bins; cp.L = 32; cp.chains_per_channel = int( ( Fo + cp.L - 1 ) / cp.L );
-	cp.sr = sr; cp.hop = float( hop ); cp.nonmono = d_flags; cp.interp = interp;
+	cp.sr = sr; cp.hop = float( hop ); cp.nonmono = d_flags; cp.flag_tag = next_epoch(); cp.interp = interp;
 	if( int rc = launch_time_chains<false>( cp, s ) ) return rc;
 	// the general walk, for a PV with a column that runs backwards (retires at once otherwise):
 	// enough (column, segment) threads to fill the chip, segments of at least 16 frame pairs
@@ -655,7 +656,7 @@ static int modify_time_dev_impl( const flanhip_MF * d_pv, int64_t ch, int64_t F,
 	const int64_t seg_len = std::max<int64_t>( ( F - 1 + segments - 1 ) / segments, 1 );
 	const int64_t threads = columns * segments;
 	hipLaunchKernelGGL( k_modify_time, dim3( (unsigned) ( ( threads + 255 ) / 256 ) ), dim3( 256 ), 0, s,
-		(const MFd*) d_pv, int( ch ), F, bins, sr, float( hop ), d_mod, Fo, (MFd*) d_out, d_flags, segments, seg_len, 1, interp, nullptr, 0 );
+		(const MFd*) d_pv, int( ch ), F, bins, sr, float( hop ), d_mod, Fo, (MFd*) d_out, d_flags, cp.flag_tag, segments, seg_len, 1, interp, nullptr, 0 );
 	FLANHIP_CHECK( hipGetLastError() );
 	FLANHIP_CHECK( hipFreeAsync( d_flags, s ) );
 	return FLANHIP_OK;
@@ -673,9 +674,9 @@ static int modify_time_dev_fused_impl( const flanhip_MF * d_pv, int64_t ch, int6
 	if( int rc = synth_layout( ch, Fo, bins, sr, analysis_rate, window_size, &lay ) ) return rc;
 	const int hop = lay.hop;                                                       // PVBuffer.cpp:381-384: what PV::modify_time works with
 	int * d_flags = nullptr;                                                       // per bin: does the time map ever run backwards?  [bins]: any
-	const size_t flag_bytes = ( sizeof( int ) * size_t( bins + 1 ) + 255 ) / 256 * 256;   // (a whole number of 256-byte pieces: the runtime's fill is then one kernel, not two)
-	FLANHIP_CHECK( hipMallocAsync( reinterpret_cast<void**>( &d_flags ), flag_bytes, s ) );
-	FLANHIP_CHECK( hipMemsetAsync( d_flags, 0, flag_bytes, s ) );
+	// in the workspace, not cleared: a flag counts as set when it holds this call's tag, and whatever the words hold is at best an EARLIER call's
+	// (a stream-ordered allocation costs the stream ~6 us at its release, the runtime's fill is a 5 us kernel of its own)
+	d_flags = reinterpret_cast<int*>( reinterpret_cast<char*>( d_ws ) + lay.flags_offset );
 	TimeChainParams p{};
 	p.in = (const MFd*) d_pv; p.mod = d_mod; p.out = (MFd*) d_out;
 	p.F = F; p.Fo = Fo; p.num_channels = int( ch ); p.bins = bins; p.L = lay.L; p.chains_per_channel = lay.chains_per_channel;
@@ -686,7 +687,7 @@ static int modify_time_dev_fused_impl( const flanhip_MF * d_pv, int64_t ch, int6
 	p.sums = reinterpret_cast<double*>( d_ws );
 	p.words = reinterpret_cast<int*>( reinterpret_cast<char*>( d_ws ) + lay.carry_bytes + lay.head_bytes );
 	p.epoch = next_epoch();
-	p.nonmono = d_flags; p.interp = interp;
+	p.nonmono = d_flags; p.flag_tag = p.epoch; p.interp = interp;
 	note_workspace_producer( d_ws, 0 );                                               // chain sums (maybe), no group totals: convert_to_audio runs its scan
 	if( int rc = launch_time_chains<true>( p, s ) ) return rc;
 	// the general walk, for a PV with a column that runs backwards: retires at once otherwise
@@ -695,9 +696,8 @@ static int modify_time_dev_fused_impl( const flanhip_MF * d_pv, int64_t ch, int6
 	const int64_t seg_len = std::max<int64_t>( ( F - 1 + segments - 1 ) / segments, 1 );
 	const int64_t threads = columns * segments;
 	hipLaunchKernelGGL( k_modify_time, dim3( (unsigned) ( ( threads + 255 ) / 256 ) ), dim3( 256 ), 0, s,
-		(const MFd*) d_pv, int( ch ), F, bins, sr, float( hop ), d_mod, Fo, (MFd*) d_out, d_flags, segments, seg_len, 1, interp, p.words, p.epoch );
+		(const MFd*) d_pv, int( ch ), F, bins, sr, float( hop ), d_mod, Fo, (MFd*) d_out, d_flags, p.flag_tag, segments, seg_len, 1, interp, p.words, p.epoch );
 	FLANHIP_CHECK( hipGetLastError() );
-	FLANHIP_CHECK( hipFreeAsync( d_flags, s ) );
 	return FLANHIP_OK;
 	}
 
