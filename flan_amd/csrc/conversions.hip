@@ -405,7 +405,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	p.cancel = thread_cancel_word( s );                                           // kernels stop starting chains when the thread's wait raises it (core.hip)
 	// windows above 2048: the WBIG team kernels (pv_kernels_eo.h)
 	const bool team_big = fast && dft == 4096 && W > 2048 && !debug_options().ana11_old;
-	const bool kernel_sums = !any && !mr;                            // every power-of-two analysis kernel keeps the sums; for the rest the pre-pass kernel runs on the analysis' behalf
+	const bool kernel_sums = !any && ( !mr || mr_pingpong( mr_plan.C ) );   // every power-of-two analysis kernel keeps the sums, and the mixed-radix one where its LDS has room; for the rest the pre-pass kernel runs on the analysis' behalf
 	SynthLayout fused_lay{};
 	if( d_fused_ws )
 		{
@@ -460,7 +460,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 		const int64_t chains = int64_t( p.chains_per_channel ) * ch;
 		FLANHIP_REQUIRE( chains < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
 		const size_t lds = mr_analyze_lds( mr_plan.C, W, mr_plan.win_lds, mr_plan.kc_lds );
-		auto kern = mr_pingpong( mr_plan.C ) ? k_analyze_mr<true> : k_analyze_mr<false>;
+		auto kern = !mr_pingpong( mr_plan.C ) ? k_analyze_mr<false, true> : mr_plan_is_big( mr_plan ) ? k_analyze_mr<true, true> : k_analyze_mr<true, false>;
 		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 		hipLaunchKernelGGL( kern, dim3( (unsigned) chains ), dim3( MR_THREADS ), lds, s, p, mr_plan );
 		FLANHIP_CHECK( hipGetLastError() );
@@ -682,7 +682,7 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	else if( MrPlan mr_plan{}; mr_size( lay.dft, W, &mr_plan ) )
 		{
 		const size_t lds = mr_synth_lds( mr_plan.C, W, mr_plan.win_lds, mr_plan.kc_lds );
-		auto kern = mr_pingpong( mr_plan.C ) ? k_synthesize_mr<true> : k_synthesize_mr<false>;
+		auto kern = !mr_pingpong( mr_plan.C ) ? k_synthesize_mr<false, true> : mr_plan_is_big( mr_plan ) ? k_synthesize_mr<true, true> : k_synthesize_mr<true, false>;
 		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 		hipLaunchKernelGGL( kern, dim3( (unsigned) chains ), dim3( MR_THREADS ), lds, s, p, mr_plan );
 		FLANHIP_CHECK( hipGetLastError() );
@@ -817,6 +817,7 @@ void flanhip_debug_option( int which, int value )
 		case FLANHIP_DEBUG_RESAMPLE_DIRECT: o.resample_direct = value; break;
 		case FLANHIP_DEBUG_FORCE_DIRECT:    o.force_direct = value; break;
 		case FLANHIP_DEBUG_INLINE_FIXUP:    o.inline_fixup = value; break;
+		case FLANHIP_DEBUG_WIDE_OFFSETS:    o.wide_offsets = value; break;
 		default: break;
 		}
 	}

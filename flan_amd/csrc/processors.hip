@@ -758,7 +758,7 @@ int flanhip_stretch_map_dev( float * d_factor, int64_t F, int bins, float sr, in
 		FLANHIP_CHECK( hipMemcpyAsync( d_max, &ninf, sizeof( float ), hipMemcpyHostToDevice, s ) );
 		}
 	const dim3 grid( xcd_grid( ( bins + kMapTB - 1 ) / kMapTB ) );
-	if( F * int64_t( bins ) < ( int64_t( 1 ) << 30 ) ) hipLaunchKernelGGL( k_stretch_map<true>, grid, dim3( kMapThreads ), 0, s, d_factor, F, bins, sr, float( hop ), d_max );
+	if( F * int64_t( bins ) < ( int64_t( 1 ) << 30 ) && !debug_options().wide_offsets ) hipLaunchKernelGGL( k_stretch_map<true>, grid, dim3( kMapThreads ), 0, s, d_factor, F, bins, sr, float( hop ), d_max );
 	else hipLaunchKernelGGL( k_stretch_map<false>, grid, dim3( kMapThreads ), 0, s, d_factor, F, bins, sr, float( hop ), d_max );
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;

@@ -26,8 +26,9 @@ struct MrPlan
 	int C, npass;
 	int win_lds;                                 // synthesis: the scaled window in LDS (not for C = 8192 with a 4096 window: read through L1 there)
 	int kc_lds;                                  // per-bin constants { split twiddle, bin frequency, expected phase advance } in LDS (where that costs no resident block)
-	unsigned char radix[MR_MAX_PASSES];          // C = product; 16s first (their passes want the short sub-transform lengths), then 8 / 4 / 2, then the odd ones
+	unsigned char radix[MR_MAX_PASSES];          // C = product; 16s first (in-place plans only; their passes want the short sub-transform lengths), then 8 / 4 / 2, then the odd ones
 	unsigned magic[MR_MAX_PASSES];               // floor( 2^32 / NS ) + 1 of the pass (NS = the product of the radices before it): j / NS = mulhi( j, magic ) for j < 2^13
+	unsigned short stride[MR_MAX_PASSES];        // C / ( NS R ) of the pass: the twiddle step per position inside a sub-transform (no division in the kernel)
 	};
 
 // C = 2^a 3^b 5^c 7^d 11^e 13^f <= 8192 ?  (host and device agree through the struct)
@@ -40,10 +41,15 @@ inline bool mr_make_plan( int dft, MrPlan * out )
 	pl.C = C;
 	int rest = C, n = 0;
 	auto take = [&]( int r ) { while( rest % r == 0 && n < MR_MAX_PASSES ) { pl.radix[n++] = (unsigned char) r; rest /= r; } };
-	take( 16 ); take( 8 ); take( 4 ); take( 2 ); take( 13 ); take( 11 ); take( 7 ); take( 5 ); take( 3 );
+	if( C > MR_TW_LDS_MAX_C ) take( 16 );            // (ping-pong passes -- C <= 4096 -- run at 128 registers: radix 8 at most, see mr_fft)
+	take( 8 ); take( 4 ); take( 2 ); take( 13 ); take( 11 ); take( 7 ); take( 5 ); take( 3 );
 	if( rest != 1 ) return false;
 	pl.npass = n;
-	for( int i = 0, NS = 1; i < n; NS *= pl.radix[i], ++i ) pl.magic[i] = NS > 1 ? unsigned( ( uint64_t( 1 ) << 32 ) / unsigned( NS ) ) + 1u : 0u;
+	for( int i = 0, NS = 1; i < n; NS *= pl.radix[i], ++i )
+		{
+		pl.magic[i] = NS > 1 ? unsigned( ( uint64_t( 1 ) << 32 ) / unsigned( NS ) ) + 1u : 0u;
+		pl.stride[i] = (unsigned short) ( C / ( NS * pl.radix[i] ) );
+		}
 	*out = pl;
 	return true;
 	}
@@ -52,7 +58,7 @@ inline bool mr_make_plan( int dft, MrPlan * out )
 // [per-bin constants ( C + 1 ) float4 if kc_lds][state]
 inline bool mr_pingpong( int C ) { return C <= MR_TW_LDS_MAX_C; }
 inline size_t mr_lds_common( int C, bool kc_lds ) { return ( C <= MR_TW_LDS_MAX_C ? size_t( C ) * 8 : 0 ) + ( mr_pingpong( C ) ? 2 : 1 ) * size_t( padded_len( C + 1 ) ) * 8 + ( kc_lds ? size_t( C + 1 ) * 16 : 0 ); }
-inline size_t mr_analyze_lds( int C, int W, bool win_lds, bool kc_lds ) { (void) W; (void) win_lds; return mr_lds_common( C, kc_lds ) + size_t( C + 4 ) * 4; }   // previous phases (the window is read from memory beside the samples)
+inline size_t mr_analyze_lds( int C, int W, bool win_lds, bool kc_lds ) { (void) W; (void) win_lds; return mr_lds_common( C, kc_lds ) + ( mr_pingpong( C ) ? size_t( C + 1 ) * 8 : 0 ) + size_t( C + 4 ) * 4; }   // the chain's phase sums (ping-pong sizes: the fused round trip's pre-pass, kept by the kernel itself), previous phases (the window is read from memory beside the samples)
 inline size_t mr_synth_lds( int C, int W, bool win_lds, bool kc_lds ) { return mr_lds_common( C, kc_lds ) + ( win_lds ? 2 : 1 ) * size_t( ( W + 3 ) & ~3 ) * 4 + size_t( C + 2 ) * 8; }   // scaled window, ring, running phases
 
 // ---- register DFTs: powers of two from fft_device.h, odd primes by the symmetric direct form ---------------------------------------
@@ -94,11 +100,10 @@ template<int R> __device__ __forceinline__ void dft_any_radix( cf * v )
 
 // One Stockham pass of radix R over C points, sub-transform length NS on entry (fft_device.h: fft_pass, with C and NS run-time).
 // PP: from `src` to `dst`, butterfly by butterfly; otherwise in place in `src`.
-template<int R, bool PP> __device__ __forceinline__ void mr_pass( cf * src, cf * dst, const cf * __restrict__ tw, int C, int NS, unsigned magic, int tid )
+template<int R, bool PP> __device__ __forceinline__ void mr_pass( cf * src, cf * dst, const cf * __restrict__ tw, int C, int NS, unsigned magic, int stride, int tid )
 	{
 	auto mod_ns = [&]( int j ) { return j - int( __umulhi( unsigned( j ), magic ) ) * NS; };   // j % NS, j < 2^13 (MrPlan::magic)
 	const int NB = C / R;
-	const int stride = NB / NS;                                                    // C / ( NS R )
 	if constexpr( PP )
 		{
 		#pragma unroll 1
@@ -161,30 +166,43 @@ template<int R, bool PP> __device__ __forceinline__ void mr_pass( cf * src, cf *
 
 // forward complex transform of the C points in `a` (padded layout, natural order in and out); every thread of the block calls it.  Returns where
 // the result stands: `a`, or with PP and an odd number of passes the second buffer `b`
-template<bool PP> __device__ __forceinline__ cf * mr_fft( cf * a, cf * b, const cf * __restrict__ tw, const MrPlan & pl, int tid )
+// Which radices a kernel is COMPILED with decides its registers: with the radix-16 butterfly or the 7- / 11- / 13-point forms in the switch the
+// 128-register ping-pong kernels spilled 26 / 38 registers -- loop invariants, reloaded one `scratch_load` + `s_waitcnt vmcnt(0)` at a time at the head
+// of EVERY pass (ten memory round trips per pass: dft 3000 spent half its time there).  So: ping-pong plans hold no 16 (mr_make_plan), and the large
+// odd radices are compiled into a second instantiation (BIG) that only plans containing one of them take.
+template<bool PP, bool BIG> __device__ __forceinline__ cf * mr_fft( cf * a, cf * b, const cf * __restrict__ tw, const MrPlan & pl, int tid )
 	{
 	int NS = 1;
 	cf * src = a, * dst = PP ? b : a;
 	for( int i = 0; i < pl.npass; ++i )
 		{
 		const int r = pl.radix[i];
+		bool done = true;
 		switch( r )
 			{
-			case 16: mr_pass<16, PP>( src, dst, tw, pl.C, NS, pl.magic[i], tid ); break;
-			case 8:  mr_pass<8, PP>( src, dst, tw, pl.C, NS, pl.magic[i], tid ); break;
-			case 4:  mr_pass<4, PP>( src, dst, tw, pl.C, NS, pl.magic[i], tid ); break;
-			case 2:  mr_pass<2, PP>( src, dst, tw, pl.C, NS, pl.magic[i], tid ); break;
-			case 3:  mr_pass<3, PP>( src, dst, tw, pl.C, NS, pl.magic[i], tid ); break;
-			case 5:  mr_pass<5, PP>( src, dst, tw, pl.C, NS, pl.magic[i], tid ); break;
-			case 7:  mr_pass<7, PP>( src, dst, tw, pl.C, NS, pl.magic[i], tid ); break;
-			case 11: mr_pass<11, PP>( src, dst, tw, pl.C, NS, pl.magic[i], tid ); break;
-			default: mr_pass<13, PP>( src, dst, tw, pl.C, NS, pl.magic[i], tid ); break;
+			case 8:  mr_pass<8, PP>( src, dst, tw, pl.C, NS, pl.magic[i], pl.stride[i], tid ); break;
+			case 4:  mr_pass<4, PP>( src, dst, tw, pl.C, NS, pl.magic[i], pl.stride[i], tid ); break;
+			case 2:  mr_pass<2, PP>( src, dst, tw, pl.C, NS, pl.magic[i], pl.stride[i], tid ); break;
+			case 3:  mr_pass<3, PP>( src, dst, tw, pl.C, NS, pl.magic[i], pl.stride[i], tid ); break;
+			case 5:  mr_pass<5, PP>( src, dst, tw, pl.C, NS, pl.magic[i], pl.stride[i], tid ); break;
+			default: done = false; break;
+			}
+		if constexpr( !PP ) { if( !done && r == 16 ) { mr_pass<16, PP>( src, dst, tw, pl.C, NS, pl.magic[i], pl.stride[i], tid ); done = true; } }
+		if constexpr( BIG )
+			{
+			if( !done ) switch( r )
+				{
+				case 7:  mr_pass<7, PP>( src, dst, tw, pl.C, NS, pl.magic[i], pl.stride[i], tid ); break;
+				case 11: mr_pass<11, PP>( src, dst, tw, pl.C, NS, pl.magic[i], pl.stride[i], tid ); break;
+				default: mr_pass<13, PP>( src, dst, tw, pl.C, NS, pl.magic[i], pl.stride[i], tid ); break;
+				}
 			}
 		NS *= r;
 		if constexpr( PP ) { cf * t = src; src = dst; dst = t; }
 		}
 	return src;
 	}
+inline bool mr_plan_is_big( const MrPlan & pl ) { for( int i = 0; i < pl.npass; ++i ) if( pl.radix[i] == 7 || pl.radix[i] == 11 || pl.radix[i] == 13 ) return true; return false; }
 
 // LDS carve-up shared by the two kernels
 struct MrLds { const cf * tw; cf * buf, * buf2; v4f_t * kc; unsigned char * state; };
@@ -222,7 +240,7 @@ __device__ __forceinline__ v4f_t mr_kc( const MrLds & l, bool kc_lds, const cf *
 
 // ---- Audio::convert_to_PV (Conversions/AudioPV.cpp:12-78): one block per chain --------------------------------------------------------
 // (PP: four wavefronts per SIMD = 128 registers, the rolled passes need ~70; in place: two per SIMD = 256 registers for the passes' unrolled butterflies)
-template<bool PP>
+template<bool PP, bool BIG>
 __global__ __launch_bounds__( MR_THREADS, PP ? 4 : 2 ) void k_analyze_mr( AnalyzeParams p, MrPlan pl )
 	{
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -233,10 +251,16 @@ __global__ __launch_bounds__( MR_THREADS, PP ? 4 : 2 ) void k_analyze_mr( Analyz
 	if( tid == 0 ) s_cancel = cancel_peek( p.cancel );
 	const MrLds l = mr_carve<PP>( smem, p.tw, C, kc_lds, tid );
 	cf * buf = l.buf;
-	float * s_prev = reinterpret_cast<float*>( l.state );                            // [C + 1]
+	// the fused round trip's pre-pass inside the kernel (ping-pong sizes; beyond, where the frame leaves no LDS for it, k_phase_sums2 reads the PV
+	// once more on the kernel's behalf): per bin the chain's phase increments summed in double, operation for operation what k_phase_sums2 does
+	const bool sums = PP && p.sums != nullptr;
+	double * s_sum = reinterpret_cast<double*>( l.state );                            // [C + 1] (PP; l.state is 8-byte aligned)
+	float * s_prev = reinterpret_cast<float*>( s_sum + ( PP ? C + 1 : 0 ) );          // [C + 1]
+	bool bad = false;
 	for( int k = tid; k <= C; k += MR_THREADS )
 		{
 		s_prev[k] = 0.0f;                                                              // AudioPV.cpp:44
+		if( PP ) s_sum[k] = 0.0;
 		if( kc_lds )
 			{
 			const v4f_t v = mr_kc_value( k, p.tw2[k], p.sample_rate, p.analysis_rate, dft );
@@ -285,7 +309,7 @@ __global__ __launch_bounds__( MR_THREADS, PP ? 4 : 2 ) void k_analyze_mr( Analyz
 				}
 			}
 		__syncthreads();
-		Z = mr_fft<PP>( in, other, l.tw, pl, tid );
+		Z = mr_fft<PP, BIG>( in, other, l.tw, pl, tid );
 
 		// the real transform's bins from the half-size one, each phase-vocoded (AudioPV.cpp:69-73)
 		MF * row = p.out + ( int64_t( channel ) * p.F + t ) * ( C + 1 );
@@ -314,15 +338,37 @@ __global__ __launch_bounds__( MR_THREADS, PP ? 4 : 2 ) void k_analyze_mr( Analyz
 				float pr = s_prev[k];
 				const MF mf = phase_vocode_bin( re, im, pr, kc[u].z, kc[u].w, p.analysis_rate, use_wrapping );
 				s_prev[k] = pr;
-				if( emit ) row[k] = mf;
+				if( emit )
+					{
+					row[k] = mf;
+					if( PP && sums )
+						{
+						// k_phase_sums2 (pv_kernels_fast.h): the same terms in the same order, the partial sum folded where that kernel folds it
+						double ph = s_sum[k] + double( div_c( mf.f, p.ar_div ) * FLANHIP_PI2_F );
+						if( ( ( t - t0 ) & 7 ) == 7 && !( __builtin_fabs( ph ) < 1.0e8 ) ) ph = fold_phase_any( ph );
+						s_sum[k] = ph;
+						bad |= !( __builtin_fabsf( mf.m ) <= 3.4028235e38f ) || !( __builtin_fabsf( mf.f ) <= 3.4028235e38f );
+						}
+					}
 				}
 			}
 		if constexpr( !PP ) __syncthreads();                                            // (one buffer: the next frame overwrites what the bins read)
 		}
+	if( PP && sums )
+		{
+		double * dst = p.sums + chain * ( C + 1 );
+		for( int k = tid; k <= C; k += MR_THREADS ) { const double ph = s_sum[k]; dst[k] = ( __builtin_fabs( ph ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( ph ) : fold_phase_any( ph ); }   // (own bins: no barrier)
+		const bool any_bad = __any( bad );
+		if( p.nan_out && ( tid & 63 ) == 0 )
+			{
+			if( chain == 0 && tid == 0 ) { p.nan_out[2] = p.nan_epoch; p.nan_out[4] = p.nan_epoch; }   // (no clearing pass: set = equal to this launch's epoch)
+			if( any_bad ) p.nan_out[0] = p.nan_epoch;
+			}
+		}
 	}
 
 // ---- PV::convert_to_audio (Conversions/AudioPV.cpp:86-139): one block per chain, from the carries of the common pre-pass ------------------
-template<bool PP>
+template<bool PP, bool BIG>
 __global__ __launch_bounds__( MR_THREADS, PP ? 4 : 2 ) void k_synthesize_mr( SynthParams p, MrPlan pl )
 	{
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -415,7 +461,7 @@ __global__ __launch_bounds__( MR_THREADS, PP ? 4 : 2 ) void k_synthesize_mr( Syn
 				}
 			}
 		__syncthreads();
-		const cf * G = mr_fft<PP>( buf, l.buf2, l.tw, pl, tid );
+		const cf * G = mr_fft<PP, BIG>( buf, l.buf2, l.tw, pl, tid );
 		// G = fft( conj Z ):  x[2n] = G[n].x, x[2n+1] = -G[n].y (AudioPV.cpp:122; samples from W on are discarded); window, accumulate (:133-134)
 		for( int n = tid; 2 * n < W; n += MR_THREADS )
 			{

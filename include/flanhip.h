@@ -169,6 +169,8 @@ int flanhip_synthesize_dev_stages(const flanhip_MF * d_pv, int64_t num_channels,
 #define FLANHIP_DEBUG_INLINE_FIXUP   10   /* 1: the dft 2048 synthesis kernel adds the overlaps of neighbouring chains itself (whichever of the two
                                            * wavefronts at a boundary ends second; agent-scope side buffers) instead of k_ola_fixup in a launch of its
                                            * own: the same sums; measured no faster, hence not the default */
+#define FLANHIP_DEBUG_WIDE_OFFSETS   11   /* 1: kernels that choose 32-bit element offsets for grids below 2^30 elements (k_stretch_map) take their 64-bit
+                                           * form whatever the size: the path of multi-gigabyte grids, testable on small ones */
 void flanhip_debug_option(int which, int value);
 
 /* ---- PV frame processors ------------------------------------------------------------------------------------- */

@@ -254,7 +254,10 @@ def test_fused_round_trip_equals_unfused(fa):
     sr = 48000.0
     # dft 8192 (and 4096 through the generic kernels): block-wide teams walk the chains; they leave the sums like every other analysis kernel
     for (ch, n, W, hop, dft) in [(2, 70000, 2048, 512, 2048), (1, 30000, 2048, 128, 4096), (2, 20000, 1024, 256, 1024), (1, 9000, 400, 100, 512),
-                                 (1, 40000, 4096, 1024, 8192), (2, 30000, 2048, 300, 4096)]:
+                                 (1, 40000, 4096, 1024, 8192), (2, 30000, 2048, 300, 4096),
+                                 # the mixed-radix kernels: sums kept by the analysis kernel (ping-pong sizes, with and without the large odd radices) or by
+                                 # the pre-pass kernel on its behalf (in place: 12000)
+                                 (2, 300000, 2048, 512, 3000), (1, 120000, 1024, 256, 2002), (1, 200000, 2048, 512, 12000), (1, 60000, 600, 150, 1000)]:
         x = O.noise(ch, n, seed=31)
         F = O.num_pv_frames(n, hop)
         bins = dft // 2 + 1

@@ -116,11 +116,14 @@ def test_stretch_map_on_the_device(fa, F, bins):
     ref = O.stretch_map(g, SR, 256)
     d_grid = _dev(fa, g)
     d_max = _dev(fa, np.array([-np.inf], np.float32))
-    fa.check(fa.lib.flanhip_stretch_map_dev(d_grid, F, bins, SR, 256, d_max, None))
-    got, mx = _host(fa, d_grid, (F, bins)), _host(fa, d_max, (1,))[0]
+    for wide in (0, 1):                                      # 32-bit element offsets (every grid below 2^30 elements) and the 64-bit form of larger ones
+        fa.check(fa.lib.flanhip_memcpy_h2d(d_grid, g.ctypes.data_as(ctypes.c_void_p), g.nbytes, None))
+        with fa.debug_options(wide_offsets=wide):
+            fa.check(fa.lib.flanhip_stretch_map_dev(d_grid, F, bins, SR, 256, d_max, None))
+        got, mx = _host(fa, d_grid, (F, bins)), _host(fa, d_max, (1,))[0]
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), wide
+        assert np.float32(mx) == ref.max(), wide
     fa.check(fa.lib.flanhip_free(d_grid)); fa.check(fa.lib.flanhip_free(d_max))
-    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
-    assert np.float32(mx) == ref.max()
 
 
 def test_device_chain_config3_shape(fa):
