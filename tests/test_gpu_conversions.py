@@ -382,6 +382,46 @@ def test_random_shapes(fa, ch, n, W, hop, dft):
     assert rms <= 1e-5 * max(scale, 1.0)
 
 
+def _random_smooth_shapes(count, seed):
+    """seeded shapes for the mixed-radix kernels (pv_kernels_mr.h): dft = 2 C with C a product of 2, 3, 5, 7, 11, 13 (not a power of two), ping-pong
+    and in-place sizes, plans with and without the large odd radices; windows up to the dft, hops up to beyond the window, ragged lengths"""
+    rng = np.random.default_rng(seed)
+    smooth = sorted({2 * a * b for a in (1, 2, 4, 8, 16, 32, 64, 128, 256) for b in (3, 5, 7, 9, 11, 13, 15, 21, 25, 27, 33, 35, 39, 45, 55, 63, 75, 77, 91, 125, 143, 375)
+                     if 24 <= 2 * a * b <= 16384})
+    shapes = []
+    for i in range(count):
+        dft = int(rng.choice(smooth))
+        W = dft if rng.random() < 0.4 else int(rng.integers(max(dft // 8, 2), dft + 1))
+        hop = int(rng.integers(max(dft // 64, 1), 2 * W)) if rng.random() < 0.3 else int(rng.integers(max(W // 8, 1), W + 1))
+        ch = int(rng.integers(1, 4))
+        frames = int(rng.integers(1, 30))
+        n = max(int(frames * hop + rng.integers(-hop // 2, hop // 2 + 1)), 1)
+        shapes.append((ch, n, W, hop, dft))
+    return shapes
+
+
+@pytest.mark.parametrize("ch,n,W,hop,dft", _random_smooth_shapes(28, 20261004), ids=lambda v: str(v))
+def test_random_smooth_sizes(fa, ch, n, W, hop, dft):
+    sr = 48000.0
+    x = O.noise(ch, n, seed=ch * 11 + W + hop)
+    ref = O.analyze(x, sr, W, hop, dft)
+    got = fa.analyze(x, sr, W, hop, dft)
+    assert got.shape == ref.shape and np.all(np.isfinite(got))
+    ar = np.float32(sr) / np.float32(hop)
+    rel_m, wrms_f, same, turns = p1_metrics(got, ref, float(ar))
+    if O.lib.oracle_hop_size(sr, ar) != hop:
+        pytest.skip("hop %d is not recovered from sample_rate / analysis_rate in fp32 (PVBuffer.cpp:381-384): synthesis undefined" % hop)
+    out_ref, _ = O.synthesize(ref, sr, ar, W)
+    out_got, flag = fa.synthesize(ref, sr, ar, W)
+    assert out_got.shape == out_ref.shape and flag == 0
+    scale = max(float(np.sqrt(np.mean(out_ref.astype(np.float64) ** 2))), 1e-30)
+    rms = float(np.sqrt(np.mean((out_got.astype(np.float64) - out_ref.astype(np.float64)) ** 2)))
+    print("\n[smooth %s] P1 rel_m=%.2e wrms_df=%.2e same=%.4f  P2 rms=%.2e (signal rms %.2e)" % ((ch, n, W, hop, dft), rel_m, wrms_f, same, rms, scale))
+    assert rel_m <= 1e-5
+    assert wrms_f <= 2e-3 * max(sr / dft / 23.4, 1.0)
+    assert rms <= 1e-5 * max(scale, 1.0)
+
+
 @pytest.mark.parametrize("n", [0, 1, 2, 3])
 def test_degenerate_lengths(fa, n):
     """empty and near-empty signals: one frame of (almost) silence through every dft class, like the reference would produce"""
