@@ -424,7 +424,13 @@ __global__ __launch_bounds__( 256 ) void k_repitch_lerp( const MFd * in, int64_t
 // does run backwards is walked by lane 0 in the reference order.  s_rows: dynamic LDS, bins MF per wave.
 // REPITCH: in_modified is not read but evaluated on the fly, PV::repitch's own rule (PVModify.cpp:289-302: every MF's frequency
 // looked up, lerp, in the row's map); the map row is then staged in LDS behind the output rows (bins floats per wave).
-template<bool REPITCH>
+// LINEAR: the linear Interpolator (every default call) as a compile-time arm -- interpolate()'s table arm holds a flat load, and where the arms join
+// every iteration of the pair loop waited for the whole memory queue.
+// Memory reads come in BATCHES of kFreqBatch loop steps, requested together ahead of the steps' arithmetic: with a load and its wait inside every
+// step a row cost its wavefront 17 + 17 memory round trips one after the other (0.35 ms for 45 008 rows whose bytes take 0.15; staging the input
+// row in LDS instead was measured: it halves the resident wavefronts and the kernel took 0.76 ms).
+constexpr int kFreqBatch = 6;
+template<bool REPITCH, bool LINEAR>
 __global__ __launch_bounds__( 256 ) void k_modify_frequency( const MFd * in, int num_channels, int64_t F, int bins, float sr, float dft,
 	const float * mod, const float * in_modified, MFd * out, int interp )
 	{
@@ -437,40 +443,57 @@ __global__ __launch_bounds__( 256 ) void k_modify_frequency( const MFd * in, int
 	MFd * orow = s_rows + size_t( wave ) * bins;
 	const float * mrow = mod + frame * bins;
 	const float * irow = REPITCH ? nullptr : in_modified + idx * bins;
+	constexpr int B = kFreqBatch;
+	bool backwards = false;
 	if constexpr( REPITCH )
 		{
 		float * smap = reinterpret_cast<float*>( s_rows + size_t( blockDim.x >> 6 ) * bins ) + size_t( wave ) * bins;
-		for( int bin = lane; bin < bins; bin += 64 ) smap[bin] = mrow[bin];
+		for( int bin0 = lane; bin0 < bins; bin0 += 64 * B )
+			{
+			float v[B];
+			#pragma unroll
+			for( int j = 0; j < B; ++j ) v[j] = mrow[min( bin0 + 64 * j, bins - 1 )];
+			#pragma unroll
+			for( int j = 0; j < B; ++j ) { const int bin = bin0 + 64 * j; if( bin < bins ) { smap[bin] = v[j]; orow[bin] = MFd{ 0.0f, 0.0f }; } }   // :205 clear_buffer
+			}
 		mrow = smap;
 		wave_sync();
+		for( int bin = 1 + lane; bin < bins; bin += 64 ) backwards |= !( frequency_to_bin( mrow[bin], sr, dft ) >= frequency_to_bin( mrow[bin - 1], sr, dft ) );
 		}
-	auto modified = [&]( int bin )                                                  // the frequency this MF is moved to
+	else
 		{
-		if constexpr( !REPITCH ) return irow[bin];
-		else
+		for( int bin0 = lane; bin0 < bins; bin0 += 64 * B )
 			{
-			const float fbin = fminf( fmaxf( frequency_to_bin( row[bin].f, sr, dft ), 0.0f ), float( bins - 1 ) - 0.0001f );   // :293 std::clamp
-			const int lo = int( floorf( fbin ) );
-			const float r = fbin - float( lo );
-			return mrow[lo] * ( 1.0f - r ) + mrow[lo + 1] * r;                     // :295-301
+			float v[B], u[B];
+			#pragma unroll
+			for( int j = 0; j < B; ++j ) { const int bin = min( bin0 + 64 * j, bins - 1 ); v[j] = mrow[bin]; u[j] = mrow[max( bin - 1, 0 )]; }
+			#pragma unroll
+			for( int j = 0; j < B; ++j )
+				{
+				const int bin = bin0 + 64 * j;
+				if( bin >= bins ) continue;
+				orow[bin] = MFd{ 0.0f, 0.0f };                                          // :205 clear_buffer
+				if( bin >= 1 ) backwards |= !( frequency_to_bin( v[j], sr, dft ) >= frequency_to_bin( u[j], sr, dft ) );
+				}
 			}
-		};
-
-	bool backwards = false;
-	for( int bin = lane; bin < bins; bin += 64 )
-		{
-		orow[bin] = MFd{ 0.0f, 0.0f };                                              // :205 clear_buffer
-		if( bin >= 1 ) backwards |= !( frequency_to_bin( mrow[bin], sr, dft ) >= frequency_to_bin( mrow[bin - 1], sr, dft ) );
 		}
 	const bool sequential = __any( backwards );
 	wave_sync();
 
-	auto pair = [&]( int bin )                                                      // :214-244 for the pair ( bin-1, bin )
+	auto modified_of = [&]( float f_of_bin ) -> float                                // REPITCH: the frequency an MF of frequency f is moved to (PVModify.cpp:289-302)
 		{
-		const float loBin = frequency_to_bin( mrow[bin - 1], sr, dft );             // :218
-		const float hiBin = frequency_to_bin( mrow[bin], sr, dft );                 // :219
-		const MFd loMF = { row[bin - 1].m, modified( bin - 1 ) };                   // :227
-		const MFd hiMF = { row[bin].m, modified( bin ) };                           // :228
+		const float fbin = fminf( fmaxf( frequency_to_bin( f_of_bin, sr, dft ), 0.0f ), float( bins - 1 ) - 0.0001f );   // :293 std::clamp
+		const int lo = int( floorf( fbin ) );
+		const float r = fbin - float( lo );
+		return mrow[lo] * ( 1.0f - r ) + mrow[lo + 1] * r;                         // :295-301 (mrow: the LDS copy)
+		};
+	// :214-244 for the pair ( bin-1, bin ), its operands in hand: the two MFs, their map entries (as bins), the frequencies they are moved to
+	auto pair = [&]( MFd in_lo, MFd in_hi, float map_lo, float map_hi, float to_lo, float to_hi )
+		{
+		const float loBin = frequency_to_bin( map_lo, sr, dft );                    // :218
+		const float hiBin = frequency_to_bin( map_hi, sr, dft );                    // :219
+		const MFd loMF = { in_lo.m, to_lo };                                        // :227
+		const MFd hiMF = { in_hi.m, to_hi };                                        // :228
 		const bool forward = hiBin > loBin;                                         // :220
 		const int loR = int( forward ? ceilf( loBin ) : floorf( loBin ) );          // :222
 		const int hiR = int( forward ? ceilf( hiBin ) : floorf( hiBin ) );          // :223
@@ -478,10 +501,11 @@ __global__ __launch_bounds__( 256 ) void k_modify_frequency( const MFd * in, int
 		const int end_bin   = min( max( hiR, 0 ), bins - 1 );                       // :225
 		for( int y = start_bin; y != end_bin; forward ? ++y : --y )                 // :230
 			{
-			const float mix = interpolate( interp, ( float( y ) - loBin ) / ( hiBin - loBin ) );           // :232 interp( ... )
+			const float xq = ( float( y ) - loBin ) / ( hiBin - loBin );
+			const float mix = LINEAR ? xq : interpolate( interp, xq );              // :232 interp( ... )
 			const float share_l = ( 1.0f - mix ) * loMF.m;
 			const float share_r = mix * hiMF.m;
-			const MFd mx = share_l < share_r ? loMF : hiMF;                                   // :237
+			const MFd mx = share_l < share_r ? loMF : hiMF;                         // :237
 			MFd o = orow[y];
 			if( mx.m > o.m )                                                        // :239
 				{
@@ -491,13 +515,37 @@ __global__ __launch_bounds__( 256 ) void k_modify_frequency( const MFd * in, int
 				}
 			}
 		};
+	auto pair_at = [&]( int bin )                                                   // (the sequential walk: one lane, operands read as it goes)
+		{
+		const MFd a = row[bin - 1], b = row[bin];
+		if constexpr( REPITCH ) pair( a, b, mrow[bin - 1], mrow[bin], modified_of( a.f ), modified_of( b.f ) );
+		else pair( a, b, mrow[bin - 1], mrow[bin], irow[bin - 1], irow[bin] );
+		};
 	if( !sequential )
 		{
-		for( int bin = 1 + lane; bin < bins; bin += 64 ) pair( bin );
+		for( int bin0 = 1 + lane; bin0 < bins; bin0 += 64 * B )
+			{
+			MFd a[B], b[B]; float ml[B], mh[B], tl[B], th[B];
+			#pragma unroll
+			for( int j = 0; j < B; ++j )
+				{
+				const int bin = min( bin0 + 64 * j, bins - 1 );
+				a[j] = row[bin - 1]; b[j] = row[bin];
+				if constexpr( !REPITCH ) { ml[j] = mrow[bin - 1]; mh[j] = mrow[bin]; tl[j] = irow[bin - 1]; th[j] = irow[bin]; }
+				}
+			#pragma unroll
+			for( int j = 0; j < B; ++j )
+				{
+				const int bin = bin0 + 64 * j;
+				if( bin >= bins ) continue;
+				if constexpr( REPITCH ) pair( a[j], b[j], mrow[bin - 1], mrow[bin], modified_of( a[j].f ), modified_of( b[j].f ) );
+				else pair( a[j], b[j], ml[j], mh[j], tl[j], th[j] );
+				}
+			}
 		}
 	else if( lane == 0 )
 		{
-		for( int bin = 1; bin < bins; ++bin ) pair( bin );
+		for( int bin = 1; bin < bins; ++bin ) pair_at( bin );
 		}
 	wave_sync();
 	MFd * grow = out + idx * bins;
@@ -775,7 +823,7 @@ static int modify_frequency_dev_impl( const flanhip_MF * d_pv, int64_t ch, int64
 	const size_t per_wave = sizeof( MFd ) * size_t( bins );
 	FLANHIP_REQUIRE( per_wave <= 65536, FLANHIP_ERR_UNSUPPORTED, "more than 8192 bins" );
 	const int waves = int( std::min<size_t>( 4, 65536 / per_wave ) );
-	hipLaunchKernelGGL( k_modify_frequency<false>, dim3( (unsigned) ( ( rows + waves - 1 ) / waves ) ), dim3( 64 * waves ), per_wave * waves, s,
+	hipLaunchKernelGGL( ( interp == FLANHIP_INTERP_LINEAR ? k_modify_frequency<false, true> : k_modify_frequency<false, false> ), dim3( (unsigned) ( ( rows + waves - 1 ) / waves ) ), dim3( 64 * waves ), per_wave * waves, s,
 		(const MFd*) d_pv, int( ch ), F, bins, sr, float( ( bins - 1 ) * 2 ), d_mod, d_in_modified, (MFd*) d_out, interp );
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;
@@ -805,7 +853,7 @@ static int repitch_dev_impl( const flanhip_MF * d_pv, int64_t ch, int64_t F, int
 	const size_t per_wave = ( sizeof( MFd ) + sizeof( float ) ) * size_t( bins );
 	FLANHIP_REQUIRE( per_wave <= 65536, FLANHIP_ERR_UNSUPPORTED, "more than 5461 bins" );
 	const int waves = int( std::min<size_t>( 4, 65536 / per_wave ) );
-	hipLaunchKernelGGL( k_modify_frequency<true>, dim3( (unsigned) ( ( rows + waves - 1 ) / waves ) ), dim3( 64 * waves ), per_wave * waves, s,
+	hipLaunchKernelGGL( ( interp == FLANHIP_INTERP_LINEAR ? k_modify_frequency<true, true> : k_modify_frequency<true, false> ), dim3( (unsigned) ( ( rows + waves - 1 ) / waves ) ), dim3( 64 * waves ), per_wave * waves, s,
 		(const MFd*) d_pv, int( ch ), F, bins, sr, dft, (const float*) d_factor, (const float*) nullptr, (MFd*) d_out, interp );
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;
