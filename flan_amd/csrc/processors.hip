@@ -625,22 +625,52 @@ __global__ __launch_bounds__( 256 ) void k_shape_aligned( const MFd * in, const 
 	unsigned long long * keys = s_keys + size_t( wave ) * bins;
 	const MFd * row = in + idx * bins;
 	MFd * orow = out + idx * bins;
-	auto shaped = [&]( int bin ) { const MFd v = row[bin]; return AFFINE ? MFd{ a * v.m + b, c * v.f + d } : shaped_tbl[idx * bins + bin]; };   // :436
+	// (memory reads in batches of kFreqBatch loop steps, requested together ahead of the steps' arithmetic: one round trip per batch, not per step)
+	constexpr int B = kFreqBatch;
+	auto shape_of = [&]( MFd v, MFd tbl ) { return AFFINE ? MFd{ a * v.m + b, c * v.f + d } : tbl; };   // :436
 	for( int bin = lane; bin < bins; bin += 64 ) keys[bin] = 0ull;
 	wave_sync();
-	for( int bin = lane; bin < bins; bin += 64 )                                   // :433
+	for( int bin0 = lane; bin0 < bins; bin0 += 64 * B )                             // :433
 		{
-		const MFd s = shaped( bin );
-		const int binShift = to_int_sat( float( bin ) - frequency_to_bin( row[bin].f, sr, dft ) );      // :440
-		const int shapedBin = to_int_sat( frequency_to_bin( s.f, sr, dft ) + float( binShift ) );       // :441
-		if( shapedBin < 0 || bins <= shapedBin ) continue;                          // :442
-		placement_offer( keys, shapedBin, s.m, bin );                               // :445-447
+		MFd v[B], t[B];
+		#pragma unroll
+		for( int j = 0; j < B; ++j )
+			{
+			const int bin = min( bin0 + 64 * j, bins - 1 );
+			v[j] = row[bin];
+			if constexpr( !AFFINE ) t[j] = shaped_tbl[idx * bins + bin]; else t[j] = MFd{ 0.0f, 0.0f };
+			}
+		#pragma unroll
+		for( int j = 0; j < B; ++j )
+			{
+			const int bin = bin0 + 64 * j;
+			if( bin >= bins ) continue;
+			const MFd s = shape_of( v[j], t[j] );
+			const int binShift = to_int_sat( float( bin ) - frequency_to_bin( v[j].f, sr, dft ) );          // :440
+			const int shapedBin = to_int_sat( frequency_to_bin( s.f, sr, dft ) + float( binShift ) );       // :441
+			if( shapedBin < 0 || bins <= shapedBin ) continue;                      // :442
+			placement_offer( keys, shapedBin, s.m, bin );                           // :445-447
+			}
 		}
 	wave_sync();
-	for( int bin = lane; bin < bins; bin += 64 )
+	for( int bin0 = lane; bin0 < bins; bin0 += 64 * B )
 		{
-		const unsigned long long key = keys[bin];
-		orow[bin] = key ? shaped( placement_winner( key ) ) : MFd{ 0.0f, 0.0f };    // :426 clear_buffer
+		unsigned long long key[B]; MFd v[B], t[B];
+		#pragma unroll
+		for( int j = 0; j < B; ++j ) key[j] = keys[min( bin0 + 64 * j, bins - 1 )];
+		#pragma unroll
+		for( int j = 0; j < B; ++j )
+			{
+			const int w = key[j] ? placement_winner( key[j] ) : 0;
+			v[j] = row[w];
+			if constexpr( !AFFINE ) t[j] = shaped_tbl[idx * bins + w]; else t[j] = MFd{ 0.0f, 0.0f };
+			}
+		#pragma unroll
+		for( int j = 0; j < B; ++j )
+			{
+			const int bin = bin0 + 64 * j;
+			if( bin < bins ) orow[bin] = key[j] ? shape_of( v[j], t[j] ) : MFd{ 0.0f, 0.0f };    // :426 clear_buffer
+			}
 		}
 	}
 
