@@ -200,7 +200,9 @@ def main():
         if share_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            # (a collective one rank never enters ends the job after three minutes, not after the backend's default ten)
+            import datetime
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=180))
     ctl_dev = torch.device("cpu") if share_gpu else dev      # where the control-plane tensors (max over ranks) live
 
     F = int(fa.lib.flanhip_num_pv_frames(n, HOP))
