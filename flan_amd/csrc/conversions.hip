@@ -230,7 +230,8 @@ static int run_analyze_fast( const AnalyzeParams & p, const FastTables & tb, hip
 
 // Which tuned synthesis kernel serves this shape?  0: none (generic kernels); 1: overlap-add accumulator in registers (hop 128 /
 // 256 / 512 / 1024, window a multiple of 128); 2: accumulator as an LDS ring (any hop <= window, any window <= dft).
-static constexpr int kRingWaves11 = 3;                                            // dft 4096 with the 16 KB ring per wave: 3 waves fit
+// dft 4096 with the LDS ring: the wavefronts (chains) per block that fit beside the tables -- four up to a window of ~2500 samples, three beyond
+static int ring_waves11( int W ) { return FastLds<11>::bytes( 4 ) + FastLds<11>::ring_bytes( 4, W ) <= kMaxLds ? 4 : 3; }
 static int synth_fast_kind( int dft, int W, int hop )
 	{
 	if( !( dft == 2048 || dft == 4096 ) || hop > W || hop < 1 || force_generic() ) return 0;
@@ -242,8 +243,9 @@ static int synth_fast_kind( int dft, int W, int hop )
 template<int LOG2C, int WAVES, int HOPQ>
 static int run_synth_fast( const SynthParams & p, const FastTables & tb, hipStream_t s )
 	{
-	const size_t lds = FastLds<LOG2C>::bytes( WAVES ) + ( HOPQ == 0 ? FastLds<LOG2C>::ring_bytes( WAVES ) : 0 );
-	static_assert( FastLds<LOG2C>::bytes( WAVES ) + ( HOPQ == 0 ? FastLds<LOG2C>::ring_bytes( WAVES ) : 0 ) <= kMaxLds, "LDS budget" );
+	const size_t lds = FastLds<LOG2C>::bytes( WAVES ) + ( HOPQ == 0 ? FastLds<LOG2C>::ring_bytes( WAVES, p.window_size ) : 0 );
+	static_assert( FastLds<LOG2C>::bytes( WAVES ) <= kMaxLds, "LDS budget" );
+	FLANHIP_REQUIRE( lds <= kMaxLds, FLANHIP_ERR_UNSUPPORTED, "window too long for the LDS ring" );
 	auto kern = k_synthesize_fast<LOG2C, WAVES, HOPQ>;
 	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;
@@ -328,7 +330,10 @@ static int run_synth_fast_hop( const SynthParams & p, const FastTables & tb, hip
 			}
 		}
 	if( synth_fast_kind( 2 << LOG2C, p.window_size, p.hop ) == 2 )                // any other hop <= window: ring accumulator in LDS
-		return run_synth_fast<LOG2C, ( LOG2C == 10 ? kSynWaves10 : kRingWaves11 ), 0>( p, tb, s );
+		{
+		if constexpr( LOG2C == 10 ) return run_synth_fast<LOG2C, kSynWaves10, 0>( p, tb, s );
+		else return ring_waves11( p.window_size ) == 4 ? run_synth_fast<LOG2C, 4, 0>( p, tb, s ) : run_synth_fast<LOG2C, 3, 0>( p, tb, s );
+		}
 	if constexpr( LOG2C == 11 ) switch( p.hop / 128 )                              // (dft 2048's register-accumulator hops are all v2's, above)
 		{
 		case 1: return run_synth_fast<LOG2C, kWaves11, 1>( p, tb, s );
@@ -516,7 +521,7 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	o->head_len = o->any ? 0 : std::max( W - o->hop, 0 );        // (the direct-sum path overlap-adds whole frames from its own scratch: no chain heads)
 	const int overlap = ( W + o->hop - 1 ) / o->hop;              // frames covering one output sample
 	const int kind = o->any ? 0 : synth_fast_kind( o->dft, W, o->hop );
-	const int slots = o->any ? any_target_chains( bins ) : mr ? mr_target_chains( o->dft, W ) : kind == 0 ? generic_target_chains( o->dft ) : ( kind == 2 && o->dft == 4096 ) ? cu_count() * kRingWaves11 : fast_target_chains( o->dft, true );
+	const int slots = o->any ? any_target_chains( bins ) : mr ? mr_target_chains( o->dft, W ) : kind == 0 ? generic_target_chains( o->dft ) : ( kind == 2 && o->dft == 4096 ) ? cu_count() * ring_waves11( W ) : fast_target_chains( o->dft, true );
 	o->L = choose_chain_length( ch, F, o->any ? 1 : std::max( overlap - 1, 1 ), slots );
 	o->chains_per_channel = int( ( F + o->L - 1 ) / o->L );
 	const int64_t chains = int64_t( o->chains_per_channel ) * ch;

@@ -43,7 +43,8 @@ template<int LOG2C> struct FastLds
 	static constexpr int BUF = WIN + C;
 	static constexpr int BUF_LEN = C + C / 16 + 1;     // highest slot used is PAD( C ) = C + C/16 (synthesis parks X[C] there)
 	static constexpr int SUM_LEN = ( C / 64 + 1 ) * 64; // per-wave chain sums (doubles), fused analysis only
-	static constexpr size_t ring_bytes( int waves ) { return size_t( waves ) * 2 * C * 4; }   // k_synthesize_fast<.., 0>: a ring of 2C floats per wave
+	static constexpr int ring_len( int W ) { return ( W + 63 ) & ~63; }         // k_synthesize_fast<.., 0>: a ring of W floats per wave (a whole number of wavefront rows)
+	static constexpr size_t ring_bytes( int waves, int W ) { return size_t( waves ) * size_t( ring_len( W ) ) * 4; }
 	static constexpr size_t bytes( int waves, bool sums = false ) { return size_t( BUF + waves * BUF_LEN + ( sums && LOG2C < 11 ? waves * SUM_LEN : 0 ) ) * 8; }   // dft 4096 keeps the sums in registers
 	};
 
@@ -388,7 +389,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p,
 
 // =================================================================================================================
 // PV::convert_to_audio (Conversions/AudioPV.cpp:86-139); HOPQ = hop / 128 for the hops 128 / 256 / 512 / 1024 (overlap-add
-// accumulator in registers); HOPQ = 0: any hop <= window, any window, accumulator = a ring of 2C floats per wave in LDS
+// accumulator in registers); HOPQ = 0: any hop <= window, any window, accumulator = a ring of W floats per wave in LDS
 // =================================================================================================================
 template<int LOG2C, int WAVES, int HOPQ>
 __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p, FastTables tb )
@@ -423,10 +424,11 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 	float * head1 = p.head + chain * p.head_len;
 	cf * out2 = reinterpret_cast<cf*>( out1 );
 	cf * head2 = reinterpret_cast<cf*>( head1 );
-	float * ring = reinterpret_cast<float*>( s + L::BUF + WAVES * L::BUF_LEN ) + wave * ( 2 * C );   // RING only
+	const int rlen = L::ring_len( W );
+	float * ring = reinterpret_cast<float*>( s + L::BUF + WAVES * L::BUF_LEN ) + wave * rlen;   // RING only
 	if constexpr( RING )
 		{
-		for( int i = lane; i < 2 * C; i += 64 ) ring[i] = 0.0f;
+		for( int i = lane; i < rlen; i += 64 ) ring[i] = 0.0f;
 		wave_sync();
 		}
 	int ring_base = 0;                                                         // ring[ring_base] <-> absolute sample `pos`
