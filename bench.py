@@ -620,6 +620,30 @@ def other_configs(fa, torch, dev):
                                                "k_synthesize": round(k2[2], 4), "k_ola_fixup": round(k2[3], 4)}}
     del pv2, out2, ws2
 
+    # ---- config 3: 8 ch x 60 s -> convert_to_PV -> stretch( x2 ) -> convert_to_audio (PVModify.cpp:371-385, :307-362)
+    pv = torch.empty((ch, F, BINS, 2), dtype=torch.float32, device=dev)
+    grid = torch.empty((F, BINS), dtype=torch.float32, device=dev)
+    dmax = torch.empty(1, dtype=torch.float32, device=dev)
+    Fo = 2 * F
+    st = torch.empty((ch, Fo, BINS, 2), dtype=torch.float32, device=dev)
+    out = torch.empty((ch, Fo * HOP), dtype=torch.float32, device=dev)
+    ws = torch.empty(fa.synthesize_workspace_bytes(ch, Fo, BINS, SR, ar, W), dtype=torch.uint8, device=dev)
+
+    def config3():
+        fa.check(lib.flanhip_analyze_dev(P(audio), ch, n, SR, W, HOP, DFT, P(pv), None))
+        fa.check(lib.flanhip_fill_dev(P(grid), F * BINS, 2.0, None))
+        fa.check(lib.flanhip_stretch_map_dev(P(grid), F, BINS, SR, HOP, P(dmax), None))
+        fa.check(lib.flanhip_modify_time_dev_fused(P(pv), ch, F, BINS, SR, ar, P(grid), Fo, P(st), W, P(ws), None))
+        fa.check(lib.flanhip_synthesize_dev_fused_checked(P(st), ch, Fo, BINS, SR, ar, W, P(out), P(ws), None, None))
+    ms = timed(config3, tag="config3")
+    bytes_per_input_frame = 10248 + 24600 + 2 * 10248                      # SURVEY 8d: 55 344 B per input frame
+    res["config3_stretch_x2"] = {"workload": "8 ch x 60 s: convert_to_PV(2048,512,2048) -> stretch(x2) -> convert_to_audio", "ms": round(ms, 4),
+                                 "ms_cold": cold_ms["config3"], "input_frames_per_s": round(ch * F / (ms * 1e-3), 1),
+                                 "algorithmic_GBs": round(ch * F * bytes_per_input_frame / (ms * 1e-3) / 1e9, 1),
+                                 "frac_of_8TBs": round(ch * F * bytes_per_input_frame / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    del st, out, ws, grid
+
+    # (BASELINE's order: config 3 before config 4's shard)
     # ---- config 4's per-GPU shard: 8 ch x 600 s (64 ch x 10 min over 8 GPUs), the same round trip on one GPU (a 3.7 GB PV)
     n4 = 600 * 48000
     F4 = int(lib.flanhip_num_pv_frames(n4, HOP))
@@ -643,29 +667,6 @@ def other_configs(fa, torch, dev):
     except Exception as e:
         res["config4_shard_8ch_600s"] = {"error": repr(e)}
     torch.cuda.empty_cache()
-
-    # ---- config 3: 8 ch x 60 s -> convert_to_PV -> stretch( x2 ) -> convert_to_audio (PVModify.cpp:371-385, :307-362)
-    pv = torch.empty((ch, F, BINS, 2), dtype=torch.float32, device=dev)
-    grid = torch.empty((F, BINS), dtype=torch.float32, device=dev)
-    dmax = torch.empty(1, dtype=torch.float32, device=dev)
-    Fo = 2 * F
-    st = torch.empty((ch, Fo, BINS, 2), dtype=torch.float32, device=dev)
-    out = torch.empty((ch, Fo * HOP), dtype=torch.float32, device=dev)
-    ws = torch.empty(fa.synthesize_workspace_bytes(ch, Fo, BINS, SR, ar, W), dtype=torch.uint8, device=dev)
-
-    def config3():
-        fa.check(lib.flanhip_analyze_dev(P(audio), ch, n, SR, W, HOP, DFT, P(pv), None))
-        fa.check(lib.flanhip_fill_dev(P(grid), F * BINS, 2.0, None))
-        fa.check(lib.flanhip_stretch_map_dev(P(grid), F, BINS, SR, HOP, P(dmax), None))
-        fa.check(lib.flanhip_modify_time_dev_fused(P(pv), ch, F, BINS, SR, ar, P(grid), Fo, P(st), W, P(ws), None))
-        fa.check(lib.flanhip_synthesize_dev_fused_checked(P(st), ch, Fo, BINS, SR, ar, W, P(out), P(ws), None, None))
-    ms = timed(config3, tag="config3")
-    bytes_per_input_frame = 10248 + 24600 + 2 * 10248                      # SURVEY 8d: 55 344 B per input frame
-    res["config3_stretch_x2"] = {"workload": "8 ch x 60 s: convert_to_PV(2048,512,2048) -> stretch(x2) -> convert_to_audio", "ms": round(ms, 4),
-                                 "ms_cold": cold_ms["config3"], "input_frames_per_s": round(ch * F / (ms * 1e-3), 1),
-                                 "algorithmic_GBs": round(ch * F * bytes_per_input_frame / (ms * 1e-3) / 1e9, 1),
-                                 "frac_of_8TBs": round(ch * F * bytes_per_input_frame / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-    del st, out, ws, grid
 
     # ---- config 5: stereo 60 s at 96 kHz -> resample( 48000 ) -> convert_to_PV -> shape( f + 100 Hz ) -> convert_to_audio
     c5, n96, n48 = 2, 60 * 96000, 60 * 48000

@@ -694,6 +694,32 @@ __global__ __launch_bounds__( 256 ) void k_phase_sums2( SynthParams p )
 		}
 	}
 
+// The totals of groups of `gsize` consecutive chains from the chains' sums, for a producer that left none (PV::modify_time's and PV::shape's fused forms,
+// k_phase_sums2 itself): with them the dft 2048 / 4096 synthesis kernels work out their chains' carries themselves (k_analyze_v2's epilogue does the
+// same additions in the same order: run = fold( run + sum of chain w ), w ascending) and the scan over all the chains -- 16 us for 34 MB at config 3 --
+// is not launched.  One thread per ( bin, group, channel ): the group's sums are requested together.
+template<int GSIZE>
+__global__ __launch_bounds__( 256 ) void k_group_sums( SynthParams p, double * out )
+	{
+	const int bin = blockIdx.x * 256 + threadIdx.x;
+	if( bin >= p.num_bins ) return;
+	const int group = blockIdx.y, channel = blockIdx.z;
+	const int live = min( GSIZE, p.chains_per_channel - group * GSIZE );
+	const double * src = p.carry + ( int64_t( channel ) * p.chains_per_channel + int64_t( group ) * GSIZE ) * p.num_bins + bin;
+	double v[GSIZE];
+	#pragma unroll
+	for( int w = 0; w < GSIZE; ++w ) v[w] = ( w < live ) ? src[int64_t( w ) * p.num_bins] : 0.0;
+	double run = 0.0;
+	#pragma unroll
+	for( int w = 0; w < GSIZE; ++w )
+		if( w < live )
+			{
+			const double t = run + v[w];
+			run = ( __builtin_fabs( t ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( t ) : fold_phase_any( t );
+			}
+	out[( int64_t( channel ) * p.groups_per_channel + group ) * p.num_bins + bin] = run;
+	}
+
 // Exclusive scan of the chain sums along each channel, per bin (modular addition is associative, so the scan is cut in
 // SEG segments: 512 / SEG bins x SEG segments per block; each thread sums its segment, the segment totals are scanned through LDS,
 // then each thread rewrites its segment as exclusive prefixes).  carry[c] = phase_buffer on entry to chain c.

@@ -15,6 +15,8 @@ SR, W, HOP, DFT = 48000.0, 2048, 512, 2048
 BINS = DFT // 2 + 1
 ch, n = 8, 60 * 48000
 lib = fa.lib
+if "--scan" in sys.argv:                       # A/B: the scan over all the chains in front of the synthesis instead of the group totals (syn_variant 2)
+    lib.flanhip_debug_option(fa.DEBUG_SYN_VARIANT, 2)
 dev = torch.device("cuda", 0)
 F = int(lib.flanhip_num_pv_frames(n, HOP))
 Fo = 2 * F
