@@ -465,6 +465,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 		const int64_t chains = int64_t( p.chains_per_channel ) * ch;
 		FLANHIP_REQUIRE( chains < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
 		const size_t lds = mr_analyze_lds( mr_plan.C, W, mr_plan.win_lds, mr_plan.kc_lds );
+		FLANHIP_REQUIRE( mr_plan_fits_kernels( mr_plan ), FLANHIP_ERR_UNSUPPORTED, "mixed-radix plan and kernels disagree" );
 		auto kern = !mr_pingpong( mr_plan.C ) ? k_analyze_mr<false, true> : mr_plan_is_big( mr_plan ) ? k_analyze_mr<true, true> : k_analyze_mr<true, false>;
 		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 		hipLaunchKernelGGL( kern, dim3( (unsigned) chains ), dim3( MR_THREADS ), lds, s, p, mr_plan );
@@ -709,6 +710,7 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	else if( MrPlan mr_plan{}; mr_size( lay.dft, W, &mr_plan ) )
 		{
 		const size_t lds = mr_synth_lds( mr_plan.C, W, mr_plan.win_lds, mr_plan.kc_lds );
+		FLANHIP_REQUIRE( mr_plan_fits_kernels( mr_plan ), FLANHIP_ERR_UNSUPPORTED, "mixed-radix plan and kernels disagree" );
 		auto kern = !mr_pingpong( mr_plan.C ) ? k_synthesize_mr<false, true> : mr_plan_is_big( mr_plan ) ? k_synthesize_mr<true, true> : k_synthesize_mr<true, false>;
 		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 		hipLaunchKernelGGL( kern, dim3( (unsigned) chains ), dim3( MR_THREADS ), lds, s, p, mr_plan );

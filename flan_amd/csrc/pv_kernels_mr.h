@@ -203,6 +203,8 @@ template<bool PP, bool BIG> __device__ __forceinline__ cf * mr_fft( cf * a, cf *
 	return src;
 	}
 inline bool mr_plan_is_big( const MrPlan & pl ) { for( int i = 0; i < pl.npass; ++i ) if( pl.radix[i] == 7 || pl.radix[i] == 11 || pl.radix[i] == 13 ) return true; return false; }
+// (what mr_fft's instantiations rely on: a ping-pong plan holds no radix 16; checked where a kernel is chosen)
+inline bool mr_plan_fits_kernels( const MrPlan & pl ) { if( !mr_pingpong( pl.C ) ) return true; for( int i = 0; i < pl.npass; ++i ) if( pl.radix[i] == 16 ) return false; return true; }
 
 // LDS carve-up shared by the two kernels
 struct MrLds { const cf * tw; cf * buf, * buf2; v4f_t * kc; unsigned char * state; };
