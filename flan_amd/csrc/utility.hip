@@ -14,9 +14,19 @@ __global__ __launch_bounds__( 256 ) void k_mid_side( const float * in, int64_t n
 	out[n + i] = ( l - r ) / sqrt2;                               // :47
 	}
 
+// (16 bytes per store over the 16-byte aligned middle; the few floats in front of it and behind it one by one)
 __global__ __launch_bounds__( 256 ) void k_fill( float * p, int64_t count, float v )
 	{
-	for( int64_t i = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x; i < count; i += int64_t( gridDim.x ) * blockDim.x ) p[i] = v;
+	typedef float f4 __attribute__(( ext_vector_type( 4 ) ));
+	const int64_t tid = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x, stride = int64_t( gridDim.x ) * blockDim.x;
+	const int64_t head = min( count, int64_t( ( 16 - ( reinterpret_cast<uintptr_t>( p ) & 15 ) ) & 15 ) / 4 );   // floats before the first 16-byte boundary
+	const int64_t quads = ( count - head ) / 4;
+	f4 * q = reinterpret_cast<f4*>( p + head );
+	const f4 vv = { v, v, v, v };
+	for( int64_t i = tid; i < quads; i += stride ) q[i] = vv;
+	const int64_t rest0 = head + 4 * quads;
+	if( tid < head ) p[tid] = v;
+	if( tid < count - rest0 ) p[rest0 + tid] = v;
 	}
 
 __device__ __forceinline__ uint32_t hash32( uint32_t x )
@@ -68,7 +78,7 @@ int flanhip_fill_dev( float * d_grid, int64_t count, float value, void * stream 
 	{
 	FLANHIP_REQUIRE( d_grid && count > 0, FLANHIP_ERR_INVALID_ARG, "bad arguments" );
 	if( int rc = require_device() ) return rc;
-	const unsigned blocks = (unsigned) std::min<int64_t>( ( count + 255 ) / 256, 4096 );
+	const unsigned blocks = (unsigned) std::min<int64_t>( ( count / 4 + 255 ) / 256 + 1, 4096 );
 	hipLaunchKernelGGL( k_fill, dim3( blocks ), dim3( 256 ), 0, (hipStream_t) stream, d_grid, count, value );
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;

@@ -107,6 +107,17 @@ def _host(fa, p, shape, dtype=np.float32):
     return out
 
 
+@pytest.mark.parametrize("count,offset", [(1, 0), (3, 1), (4, 0), (5, 3), (1023, 2), (1024, 0), (5626 * 1025, 0), (100003, 1)])
+def test_fill_on_the_device(fa, count, offset):
+    """flanhip_fill_dev (the constant Function's grid): 16-byte stores over the aligned middle, single floats at both ends -- every element set, nothing beyond"""
+    total = count + offset + 8
+    d = _dev(fa, np.full(total, -1.0, np.float32))
+    fa.check(fa.lib.flanhip_fill_dev(ctypes.c_void_p(d.value + 4 * offset), count, 2.5, None))
+    got = _host(fa, d, (total,))
+    fa.check(fa.lib.flanhip_free(d))
+    assert np.all(got[:offset] == -1.0) and np.all(got[offset:offset + count] == 2.5) and np.all(got[offset + count:] == -1.0)
+
+
 @pytest.mark.parametrize("F,bins", [(1, 5), (3, 17), (223, 16), (224, 33), (225, 1025), (449, 100), (672, 7), (1000, 1025), (2, 1), (5626, 40)])
 def test_stretch_map_on_the_device(fa, F, bins):
     """PV::stretch's time map (PVModify.cpp:376-382: a running fp32 sum down the frames of every bin, frame_to_time) and its maximum from
