@@ -7,6 +7,7 @@
 #include "pv_kernels_fast.h"
 #include <type_traits>
 #include "pv_kernels_v2.h"
+#include "pv_kernels_v3.h"
 #include "pv_kernels_eo.h"
 #include "pv_kernels_any.h"
 #include "pv_kernels_mr.h"
@@ -140,6 +141,12 @@ static int run_analyze( const AnalyzeParams & p, hipStream_t s )
 // the 256 AGPRs as spill space instead of scratch memory (6-wave blocks at 256 VGPRs spilled 400-850 B per lane to scratch and
 // ran synthesis 3.3x slower); 1024 resident chains.
 static constexpr int kSynWaves10 = 8, kWaves11 = 4;
+// dft 1024 / 512 (pv_kernels_v3.h): blocks of 8 one-wavefront chains; resident blocks per CU = wavefronts per SIMD / 2 (the kernels' register budgets)
+// dft 1024: blocks of 4 chains, 3 per CU (three wavefronts per SIMD at <= 168 registers); dft 512: blocks of 8 chains, 2 per CU (four at <= 128)
+static constexpr int kV3Waves9 = 4, kV3Occ9 = 3, kV3Waves8 = 8, kV3Occ8 = 4;
+static bool v3_size( int dft ) { return dft == 1024 || dft == 512; }
+// chains per group = wavefronts per block of the kernels that pass group totals from the analysis to the synthesis (0: none at this size)
+static int group_size_of( int dft ) { return dft == 2048 ? 8 : dft == 4096 ? 4 : dft == 1024 ? kV3Waves9 : dft == 512 ? kV3Waves8 : 8; }
 static constexpr int kTeamWaves12 = 8;           // generic kernels at dft 8192: one chain per block of 8 wavefronts (8 bins per thread), one block per CU
 // chains the chip holds at once for the generic kernels (one chain per team from dft 1024 up, LDS decides how many teams a CU takes)
 static int generic_target_chains( int dft ) { const int cus = cu_count(); return dft >= 8192 ? cus : dft == 4096 ? 2 * cus : dft == 2048 ? 4 * cus : 16 * cus; }
@@ -148,7 +155,8 @@ static int generic_target_chains( int dft ) { const int cus = cu_count(); return
 static int fast_target_chains( int dft, bool synth )
 	{
 	if( const int v = debug_options().target_chains ) { if( v > 0 ) return v; }
-	return cu_count() * ( dft == 4096 ? 4 : 8 );
+	// dft 1024 / 512 (pv_kernels_v3.h): four / eight wavefronts per SIMD
+	return cu_count() * ( dft == 4096 ? 4 : dft == 2048 ? 8 : 4 * ( dft == 1024 ? kV3Occ9 : kV3Occ8 ) );
 	}
 
 template<int WAVES, bool SUMS, int NV, int ABL = 0>
@@ -197,6 +205,57 @@ static int run_analyze_v2_variant( int v, const AnalyzeParams & p, const FastTab
 		}
 	}
 
+// dft 1024 / 512: one wavefront per chain, 8 / 4 points per lane (pv_kernels_v3.h)
+template<int LOG2C, bool SUMS>
+static int run_analyze_v3( const AnalyzeParams & p, hipStream_t s )
+	{
+	using L = V3Lds<LOG2C>;
+	constexpr int WAVES = LOG2C == 9 ? kV3Waves9 : kV3Waves8, OCC = LOG2C == 9 ? kV3Occ9 : kV3Occ8;
+	FLANHIP_REQUIRE( ( int64_t( WAVES ) * p.L + 2 ) * std::max( int64_t( p.hop ) * 4, int64_t( ( L::C + 1 ) * 8 ) ) < ( int64_t( 1 ) << 32 ), FLANHIP_ERR_UNSUPPORTED, "chain length x hop too large for the dft 1024 / 512 kernel" );
+	const size_t lds = L::bytes( WAVES, true );
+	static_assert( L::bytes( WAVES, true ) * ( 4 * OCC / WAVES ) <= kMaxLds, "LDS budget" );
+	auto kern = k_analyze_v3<LOG2C, WAVES, SUMS, OCC, 4>;
+	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+	const int64_t blocks = int64_t( ( p.chains_per_channel + WAVES - 1 ) / WAVES ) * p.num_channels;    // a block = a group of WAVES chains of one channel
+	FLANHIP_REQUIRE( blocks < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
+	hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( 64 * WAVES ), lds, s, p );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+template<int LOG2C, int HOPQ>
+static int run_synth_v3( const SynthParams & p, hipStream_t s )
+	{
+	using L = V3Lds<LOG2C>;
+	constexpr int WAVES = LOG2C == 9 ? kV3Waves9 : kV3Waves8, OCC = LOG2C == 9 ? kV3Occ9 : kV3Occ8;
+	FLANHIP_REQUIRE( ( int64_t( WAVES ) * p.L + 2 ) * ( ( L::C + 1 ) * 8 ) < ( int64_t( 1 ) << 32 ), FLANHIP_ERR_UNSUPPORTED, "chain length too large for the dft 1024 / 512 kernel" );
+	const size_t lds = L::bytes( WAVES, false );
+	auto kern = k_synthesize_v3<LOG2C, WAVES, HOPQ, OCC>;
+	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+	const int64_t blocks = int64_t( ( p.chains_per_channel + WAVES - 1 ) / WAVES ) * p.num_channels;
+	FLANHIP_REQUIRE( blocks < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
+	hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( 64 * WAVES ), lds, s, p );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+static int run_synth_v3_hop( int dft, const SynthParams & p, hipStream_t s )
+	{
+	if( dft == 1024 ) switch( p.hop / 128 )
+		{
+		case 1: return run_synth_v3<9, 1>( p, s );
+		case 2: return run_synth_v3<9, 2>( p, s );
+		case 4: return run_synth_v3<9, 4>( p, s );
+		case 8: return run_synth_v3<9, 8>( p, s );
+		}
+	if( dft == 512 ) switch( p.hop / 128 )
+		{
+		case 1: return run_synth_v3<8, 1>( p, s );
+		case 2: return run_synth_v3<8, 2>( p, s );
+		case 4: return run_synth_v3<8, 4>( p, s );
+		}
+	return FLANHIP_ERR_UNSUPPORTED;
+	}
+
 // dft 4096 with window <= 2048 as two 1024-point register transforms per frame (pv_kernels_eo.h): teams of two wavefronts, 160 KB of LDS
 template<int TEAMS, bool SUMS, int QV, bool DOUBLE = false, bool WBIG = false>
 static int run_analyze_eo_team( const AnalyzeParams & p, const FastTables & tb, hipStream_t s )
@@ -234,8 +293,9 @@ static int run_analyze_fast( const AnalyzeParams & p, const FastTables & tb, hip
 static int ring_waves11( int W ) { return FastLds<11>::bytes( 4 ) + FastLds<11>::ring_bytes( 4, W ) <= kMaxLds ? 4 : 3; }
 static int synth_fast_kind( int dft, int W, int hop )
 	{
-	if( !( dft == 2048 || dft == 4096 ) || hop > W || hop < 1 || force_generic() ) return 0;
+	if( !( dft == 2048 || dft == 4096 || v3_size( dft ) ) || hop > W || hop < 1 || force_generic() ) return 0;
 	const int hq = hop / 128;
+	if( v3_size( dft ) ) return ( hop % 128 == 0 && ( hq == 1 || hq == 2 || hq == 4 || hq == 8 ) && W % 128 == 0 ) ? 1 : 0;   // (no LDS-ring form at these sizes: the generic kernels)
 	if( hop % 128 == 0 && ( hq == 1 || hq == 2 || hq == 4 || hq == 8 ) && W % 128 == 0 ) return 1;
 	return 2;
 	}
@@ -352,7 +412,7 @@ static int self_carry_group( int dft, int W, int hop, int chains_per_channel )
 	{
 	if( synth_fast_kind( dft, W, hop ) != 1 ) return 0;
 	int g = 0;
-	if( dft == 2048 ) g = 8;
+	if( dft == 2048 || v3_size( dft ) ) g = group_size_of( dft );
 	else if( dft == 4096 && W % 256 == 0 && ( hop == 128 || hop % 256 == 0 ) && !debug_options().syn11_old && !debug_options().ana11_old ) g = 4;   // (windows above 2048: the WBIG variants)
 	// any number of groups (their carries come from a scan of their own); with few chains per channel the scan over the chains themselves is as
 	// short and the groups' epilogue and prologue are pure cost (a 5 s mono file: 118 chains, 68 against 73 us per round trip)
@@ -397,7 +457,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	p.num_channels = int( ch ); p.window_size = W; p.hop = hop;
 	// (hop: the dft 2048 kernel addresses a block's samples by 32-bit byte offsets from the block's first frame -- up to 8 chains of <= ~512 frames,
 	// env overrides aside -- and the generic kernels serve the hops that would not fit: nothing anybody analyses with)
-	const bool fast = ( dft == 2048 || dft == 4096 ) && n >= 2 && n < ( int64_t( 1 ) << 31 ) - 8192 && hop <= 65536 && !force_generic();
+	const bool fast = ( dft == 2048 || dft == 4096 || v3_size( dft ) ) && n >= 2 && n < ( int64_t( 1 ) << 31 ) - 8192 && hop <= 65536 && !force_generic();
 	int target_chains = any ? any_target_chains( dft / 2 + 1 ) : mr ? mr_target_chains( dft, W ) : fast ? fast_target_chains( dft, false ) : generic_target_chains( dft );
 	p.L = choose_chain_length( ch, p.F, any ? 7 : 1, target_chains );
 	p.chains_per_channel = int( ( p.F + p.L - 1 ) / p.L );
@@ -475,6 +535,8 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	if( fast )
 		{
 		FastTables tb{ plan->d_tw1f, plan->d_tw3f, plan->d_tw2 };
+		if( dft == 1024 ) return p.sums ? run_analyze_v3<9, true>( p, s ) : run_analyze_v3<9, false>( p, s );
+		if( dft == 512 ) return p.sums ? run_analyze_v3<8, true>( p, s ) : run_analyze_v3<8, false>( p, s );
 		if( dft == 2048 ) return p.sums ? run_analyze_v2_variant<true>( debug_options().ana_variant, p, tb, s ) : run_analyze_v2_variant<false>( debug_options().ana_variant, p, tb, s );
 		if( dft == 4096 && W <= 2048 && !debug_options().ana11_old )
 			{
@@ -528,7 +590,7 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	const int64_t chains = int64_t( o->chains_per_channel ) * ch;
 	o->carry_bytes = ( size_t( chains ) * bins * sizeof( double ) + 255 ) & ~size_t( 255 );
 	o->head_bytes = ( size_t( chains ) * o->head_len * sizeof( float ) + 255 ) & ~size_t( 255 );
-	const int gsize = ( !o->any && o->dft == 4096 ) ? 4 : 8;       // self_carry_group
+	const int gsize = o->any ? 8 : group_size_of( o->dft );        // self_carry_group
 	o->groups_per_channel = ( o->chains_per_channel + gsize - 1 ) / gsize;
 	o->group_offset = o->carry_bytes + o->head_bytes + 1024;       // tail: NaN flag (4 B at +0), dump area (512 B at +512); then the group sums
 	o->group_bytes = ( size_t( ch ) * o->groups_per_channel * bins * sizeof( double ) + 255 ) & ~size_t( 255 );
@@ -720,7 +782,7 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	else if( synth_fast_ok( lay.dft, W, lay.hop ) )
 		{
 		FastTables tb{ plan->d_tw1f, plan->d_tw3f, plan->d_tw2 };
-		rc = lay.dft == 2048 ? run_synth_fast_hop<10>( p, tb, s ) : run_synth_fast_hop<11>( p, tb, s );
+		rc = v3_size( lay.dft ) ? run_synth_v3_hop( lay.dft, p, s ) : lay.dft == 2048 ? run_synth_fast_hop<10>( p, tb, s ) : run_synth_fast_hop<11>( p, tb, s );
 		}
 	else switch( ilog2( lay.dft ) - 1 )
 		{

@@ -86,6 +86,27 @@ typedef float v8f __attribute__(( ext_vector_type( 8 ) ));
 template<class V> struct vec_traits { static constexpr int N = int( sizeof( V ) / sizeof( float ) ); };
 template<class V> __device__ __forceinline__ V vfma( V a, V b, V c ) { return __builtin_elementwise_fma( a, b, c ); }
 template<class V> __device__ __forceinline__ V vsplat( float v ) { V r; for( int i = 0; i < vec_traits<V>::N; ++i ) r[i] = v; return r; }
+template<class V> __device__ __forceinline__ V vabs( V a ) { return __builtin_elementwise_abs( a ); }
+template<class V> __device__ __forceinline__ V vmax( V a, V b ) { return __builtin_elementwise_max( a, b ); }
+template<class V> __device__ __forceinline__ V vmin( V a, V b ) { return __builtin_elementwise_min( a, b ); }
+// The same N-bin streams as N separate floats (pv_kernels_v3.h): a native vector that lives across the frame loop (the previous phases ARE
+// the last frame's phase vector) is a register TUPLE to the allocator -- four or eight consecutive aligned registers -- and under the
+// register caps of the dft 1024 / 512 kernels tuples are what it fails to place (it spills whole tuples to park one element).  The helpers
+// below take either kind: same operations, same order.
+template<int N_> struct FA
+	{
+	float v[N_];
+	__device__ __forceinline__ float & operator[]( int i ) { return v[i]; }
+	__device__ __forceinline__ float operator[]( int i ) const { return v[i]; }
+	};
+template<int N> __device__ __forceinline__ FA<N> operator+( FA<N> a, FA<N> b ) { FA<N> r; for( int i = 0; i < N; ++i ) r.v[i] = a.v[i] + b.v[i]; return r; }
+template<int N> __device__ __forceinline__ FA<N> operator-( FA<N> a, FA<N> b ) { FA<N> r; for( int i = 0; i < N; ++i ) r.v[i] = a.v[i] - b.v[i]; return r; }
+template<int N> __device__ __forceinline__ FA<N> operator*( FA<N> a, FA<N> b ) { FA<N> r; for( int i = 0; i < N; ++i ) r.v[i] = a.v[i] * b.v[i]; return r; }
+template<int N> __device__ __forceinline__ FA<N> operator-( FA<N> a ) { FA<N> r; for( int i = 0; i < N; ++i ) r.v[i] = -a.v[i]; return r; }
+template<int N> __device__ __forceinline__ FA<N> vfma( FA<N> a, FA<N> b, FA<N> c ) { FA<N> r; for( int i = 0; i < N; ++i ) r.v[i] = __builtin_fmaf( a.v[i], b.v[i], c.v[i] ); return r; }
+template<int N> __device__ __forceinline__ FA<N> vabs( FA<N> a ) { FA<N> r; for( int i = 0; i < N; ++i ) r.v[i] = __builtin_fabsf( a.v[i] ); return r; }
+template<int N> __device__ __forceinline__ FA<N> vmax( FA<N> a, FA<N> b ) { FA<N> r; for( int i = 0; i < N; ++i ) r.v[i] = __builtin_fmaxf( a.v[i], b.v[i] ); return r; }
+template<int N> __device__ __forceinline__ FA<N> vmin( FA<N> a, FA<N> b ) { FA<N> r; for( int i = 0; i < N; ++i ) r.v[i] = __builtin_fminf( a.v[i], b.v[i] ); return r; }
 
 template<class V> __device__ __forceinline__ V div_pi2_v( V x )
 	{
@@ -138,9 +159,9 @@ template<class V> __device__ __forceinline__ V round_v( V x )
 template<class V> __device__ __forceinline__ V atan2_fast_v( V y, V x )
 	{
 	constexpr int N = vec_traits<V>::N;
-	const V ax = __builtin_elementwise_abs( x ), ay = __builtin_elementwise_abs( y );
-	const V mx = __builtin_elementwise_max( __builtin_elementwise_max( ax, ay ), vsplat<V>( 0x1p-126f ) );
-	const V mn = __builtin_elementwise_min( ax, ay );
+	const V ax = vabs( x ), ay = vabs( y );
+	const V mx = vmax( vmax( ax, ay ), vsplat<V>( 0x1p-126f ) );
+	const V mn = vmin( ax, ay );
 	V r;
 	#pragma unroll
 	for( int i = 0; i < N; ++i ) r[i] = __builtin_amdgcn_rcpf( mx[i] );
@@ -167,7 +188,7 @@ template<class V> __device__ __forceinline__ V atan2_fast_v( V y, V x )
 template<class V> __device__ __forceinline__ V magnitude_scaled_v( V re, V im )
 	{
 	constexpr int N = vec_traits<V>::N;
-	const V a = __builtin_elementwise_max( __builtin_elementwise_abs( re ), __builtin_elementwise_abs( im ) );
+	const V a = vmax( vabs( re ), vabs( im ) );
 	int e[N];
 	V rs, is;
 	#pragma unroll
@@ -341,7 +362,7 @@ template<bool CLAMPED, class V> __device__ __forceinline__ void polar_tail( V re
 	{
 	constexpr int N = vec_traits<V>::N;
 	V mx = mxu;
-	if constexpr( CLAMPED ) mx = __builtin_elementwise_max( mxu, vsplat<V>( 0x1p-126f ) );
+	if constexpr( CLAMPED ) mx = vmax( mxu, vsplat<V>( 0x1p-126f ) );
 	V r;
 	#pragma unroll
 	for( int i = 0; i < N; ++i ) r[i] = __builtin_amdgcn_rcpf( mx[i] );
@@ -352,7 +373,7 @@ template<bool CLAMPED, class V> __device__ __forceinline__ void polar_tail( V re
 	if constexpr( CLAMPED )
 		{
 		const V t = mxu * vsplat<V>( 0x1p126f );
-		h = vfma( q, q, __builtin_elementwise_min( t * t, vsplat<V>( 1.0f ) ) );
+		h = vfma( q, q, vmin( t * t, vsplat<V>( 1.0f ) ) );
 		}
 	else h = vfma( q, q, vsplat<V>( 1.0f ) );
 	V p = vsplat<V>( 0x1.7ec8b6p-9f );
@@ -386,9 +407,9 @@ template<bool CLAMPED, class V> __device__ __forceinline__ void polar_tail( V re
 template<class V> __device__ __forceinline__ void polar_v( V re, V im, V & phase, V & mag )
 	{
 	constexpr int N = vec_traits<V>::N;
-	const V ax = __builtin_elementwise_abs( re ), ay = __builtin_elementwise_abs( im );
-	const V mxu = __builtin_elementwise_max( ax, ay );
-	const V mn = __builtin_elementwise_min( ax, ay );
+	const V ax = vabs( re ), ay = vabs( im );
+	const V mxu = vmax( ax, ay );
+	const V mn = vmin( ax, ay );
 	float tiny = mxu[0];
 	#pragma unroll
 	for( int i = 1; i < N; ++i ) tiny = __builtin_fminf( tiny, mxu[i] );
