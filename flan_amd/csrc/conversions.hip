@@ -96,7 +96,9 @@ static int get_unit_circle( int N, std::shared_ptr<const UnitRef> * out )
 		if( lookup() ) return FLANHIP_OK;
 		auto & c = unit_cache();
 		c.emplace_back( key, ref );
-		if( c.size() > 4 ) { evicted = c.front().second; c.erase( c.begin() ); }
+		size_t mine = 0;                                                            // (four per DEVICE, like the plans' bound)
+		for( const auto & e : c ) mine += e.first.first == device;
+		if( mine > 4 ) for( size_t i = 0; i < c.size(); ++i ) if( c[i].first.first == device ) { evicted = c[i].second; c.erase( c.begin() + long( i ) ); break; }
 		}
 	*out = ref;
 	return FLANHIP_OK;
@@ -141,12 +143,35 @@ static int run_analyze( const AnalyzeParams & p, hipStream_t s )
 // the 256 AGPRs as spill space instead of scratch memory (6-wave blocks at 256 VGPRs spilled 400-850 B per lane to scratch and
 // ran synthesis 3.3x slower); 1024 resident chains.
 static constexpr int kSynWaves10 = 8, kWaves11 = 4;
-// dft 1024 / 512 (pv_kernels_v3.h): blocks of 8 one-wavefront chains; resident blocks per CU = wavefronts per SIMD / 2 (the kernels' register budgets)
-// dft 1024: blocks of 4 chains, 3 per CU (three wavefronts per SIMD at <= 168 registers); dft 512: blocks of 8 chains, 2 per CU (four at <= 128)
-static constexpr int kV3Waves9 = 4, kV3Occ9 = 3, kV3Waves8 = 8, kV3Occ8 = 4;
+// dft 1024 / 512 (pv_kernels_v3.h): { index, wavefronts per block = chains per group, wavefronts per SIMD the registers are capped for, bins per vector
+// stream, frames the sample requests run ahead }.  Entry 0 is the product (measured, profiles/r05_v3_variants.txt: dft 1024 is as fast at two, three and
+// four wavefronts per SIMD in the analysis and 10 % faster at four in the synthesis; dft 512 is bound by the latency of its four passes' LDS round
+// trips and wants wavefronts, but spills under a 128-register cap); the others are the A/B partners behind
+// flanhip_debug_option( FLANHIP_DEBUG_ANA_VARIANT, index ) -- both kernels of a pair follow it: the group size is part of the workspace layout.
+#define FLANHIP_V3_CFGS_9( X ) X( 0, 8, 4, 4, 1 ) X( 1, 4, 3, 4, 1 ) X( 2, 8, 2, 8, 1 )
+#define FLANHIP_V3_CFGS_8( X ) X( 0, 4, 3, 4, 1 ) X( 1, 8, 4, 4, 1 ) X( 2, 8, 2, 4, 1 )
+struct V3Cfg { int waves, occ, nv; };
+static V3Cfg v3_cfg( int dft )
+	{
+	const int v = debug_options().ana_variant;
+#define X( I, W, O, N, P ) if( v == I ) return V3Cfg{ W, O, N };
+	if( dft == 1024 ) { FLANHIP_V3_CFGS_9( X ) return V3Cfg{ 8, 4, 4 }; }
+	FLANHIP_V3_CFGS_8( X )
+#undef X
+	return V3Cfg{ 4, 3, 4 };
+	}
+static int v3_index( int dft )
+	{
+	const int v = debug_options().ana_variant;
+#define X( I, W, O, N, P ) if( v == I ) return I;
+	if( dft == 1024 ) { FLANHIP_V3_CFGS_9( X ) return 0; }
+	FLANHIP_V3_CFGS_8( X )
+#undef X
+	return 0;
+	}
 static bool v3_size( int dft ) { return dft == 1024 || dft == 512; }
 // chains per group = wavefronts per block of the kernels that pass group totals from the analysis to the synthesis (0: none at this size)
-static int group_size_of( int dft ) { return dft == 2048 ? 8 : dft == 4096 ? 4 : dft == 1024 ? kV3Waves9 : dft == 512 ? kV3Waves8 : 8; }
+static int group_size_of( int dft ) { return dft == 2048 ? 8 : dft == 4096 ? 4 : v3_size( dft ) ? v3_cfg( dft ).waves : 8; }
 static constexpr int kTeamWaves12 = 8;           // generic kernels at dft 8192: one chain per block of 8 wavefronts (8 bins per thread), one block per CU
 // chains the chip holds at once for the generic kernels (one chain per team from dft 1024 up, LDS decides how many teams a CU takes)
 static int generic_target_chains( int dft ) { const int cus = cu_count(); return dft >= 8192 ? cus : dft == 4096 ? 2 * cus : dft == 2048 ? 4 * cus : 16 * cus; }
@@ -156,7 +181,7 @@ static int fast_target_chains( int dft, bool synth )
 	{
 	if( const int v = debug_options().target_chains ) { if( v > 0 ) return v; }
 	// dft 1024 / 512 (pv_kernels_v3.h): four / eight wavefronts per SIMD
-	return cu_count() * ( dft == 4096 ? 4 : dft == 2048 ? 8 : 4 * ( dft == 1024 ? kV3Occ9 : kV3Occ8 ) );
+	return cu_count() * ( dft == 4096 ? 4 : dft == 2048 ? 8 : 4 * v3_cfg( dft ).occ );
 	}
 
 template<int WAVES, bool SUMS, int NV, int ABL = 0>
@@ -206,15 +231,14 @@ static int run_analyze_v2_variant( int v, const AnalyzeParams & p, const FastTab
 	}
 
 // dft 1024 / 512: one wavefront per chain, 8 / 4 points per lane (pv_kernels_v3.h)
-template<int LOG2C, bool SUMS>
+template<int LOG2C, bool SUMS, int WAVES, int OCC, int NV, int PF>
 static int run_analyze_v3( const AnalyzeParams & p, hipStream_t s )
 	{
 	using L = V3Lds<LOG2C>;
-	constexpr int WAVES = LOG2C == 9 ? kV3Waves9 : kV3Waves8, OCC = LOG2C == 9 ? kV3Occ9 : kV3Occ8;
 	FLANHIP_REQUIRE( ( int64_t( WAVES ) * p.L + 2 ) * std::max( int64_t( p.hop ) * 4, int64_t( ( L::C + 1 ) * 8 ) ) < ( int64_t( 1 ) << 32 ), FLANHIP_ERR_UNSUPPORTED, "chain length x hop too large for the dft 1024 / 512 kernel" );
 	const size_t lds = L::bytes( WAVES, true );
 	static_assert( L::bytes( WAVES, true ) * ( 4 * OCC / WAVES ) <= kMaxLds, "LDS budget" );
-	auto kern = k_analyze_v3<LOG2C, WAVES, SUMS, OCC, 4>;
+	auto kern = k_analyze_v3<LOG2C, WAVES, SUMS, OCC, NV, ( PF & 255 ), ( PF >> 8 )>;    // (diagnostic configurations carry an ablation mask in the high bits)
 	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 	const int64_t blocks = int64_t( ( p.chains_per_channel + WAVES - 1 ) / WAVES ) * p.num_channels;    // a block = a group of WAVES chains of one channel
 	FLANHIP_REQUIRE( blocks < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
@@ -222,12 +246,23 @@ static int run_analyze_v3( const AnalyzeParams & p, hipStream_t s )
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;
 	}
+template<bool SUMS>
+static int run_analyze_v3_cfg( int dft, const AnalyzeParams & p, hipStream_t s )
+	{
+	const int idx = v3_index( dft );
+#define X( I, W, O, N, P ) if( idx == I ) return run_analyze_v3<9, SUMS, W, O, N, P>( p, s );
+	if( dft == 1024 ) { FLANHIP_V3_CFGS_9( X ) }
+#undef X
+#define X( I, W, O, N, P ) if( idx == I ) return run_analyze_v3<8, SUMS, W, O, N, P>( p, s );
+	if( dft == 512 ) { FLANHIP_V3_CFGS_8( X ) }
+#undef X
+	return FLANHIP_ERR_UNSUPPORTED;
+	}
 
-template<int LOG2C, int HOPQ>
+template<int LOG2C, int HOPQ, int WAVES, int OCC>
 static int run_synth_v3( const SynthParams & p, hipStream_t s )
 	{
 	using L = V3Lds<LOG2C>;
-	constexpr int WAVES = LOG2C == 9 ? kV3Waves9 : kV3Waves8, OCC = LOG2C == 9 ? kV3Occ9 : kV3Occ8;
 	FLANHIP_REQUIRE( ( int64_t( WAVES ) * p.L + 2 ) * ( ( L::C + 1 ) * 8 ) < ( int64_t( 1 ) << 32 ), FLANHIP_ERR_UNSUPPORTED, "chain length too large for the dft 1024 / 512 kernel" );
 	const size_t lds = L::bytes( WAVES, false );
 	auto kern = k_synthesize_v3<LOG2C, WAVES, HOPQ, OCC>;
@@ -238,21 +273,28 @@ static int run_synth_v3( const SynthParams & p, hipStream_t s )
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;
 	}
+template<int LOG2C, int WAVES, int OCC>
+static int run_synth_v3_hopq( const SynthParams & p, hipStream_t s )
+	{
+	switch( p.hop / 128 )
+		{
+		case 1: return run_synth_v3<LOG2C, 1, WAVES, OCC>( p, s );
+		case 2: return run_synth_v3<LOG2C, 2, WAVES, OCC>( p, s );
+		case 4: return run_synth_v3<LOG2C, 4, WAVES, OCC>( p, s );
+		case 8: if constexpr( LOG2C == 9 ) return run_synth_v3<LOG2C, 8, WAVES, OCC>( p, s );
+		}
+	return FLANHIP_ERR_UNSUPPORTED;
+	}
 static int run_synth_v3_hop( int dft, const SynthParams & p, hipStream_t s )
 	{
-	if( dft == 1024 ) switch( p.hop / 128 )
-		{
-		case 1: return run_synth_v3<9, 1>( p, s );
-		case 2: return run_synth_v3<9, 2>( p, s );
-		case 4: return run_synth_v3<9, 4>( p, s );
-		case 8: return run_synth_v3<9, 8>( p, s );
-		}
-	if( dft == 512 ) switch( p.hop / 128 )
-		{
-		case 1: return run_synth_v3<8, 1>( p, s );
-		case 2: return run_synth_v3<8, 2>( p, s );
-		case 4: return run_synth_v3<8, 4>( p, s );
-		}
+	const int idx = v3_index( dft );
+	// (the synthesis kernels have no NV: configurations that differ in it alone share an instantiation)
+#define X( I, W, O, N, P ) if( idx == I ) return run_synth_v3_hopq<9, W, O>( p, s );
+	if( dft == 1024 ) { FLANHIP_V3_CFGS_9( X ) }
+#undef X
+#define X( I, W, O, N, P ) if( idx == I ) return run_synth_v3_hopq<8, W, O>( p, s );
+	if( dft == 512 ) { FLANHIP_V3_CFGS_8( X ) }
+#undef X
 	return FLANHIP_ERR_UNSUPPORTED;
 	}
 
@@ -535,8 +577,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	if( fast )
 		{
 		FastTables tb{ plan->d_tw1f, plan->d_tw3f, plan->d_tw2 };
-		if( dft == 1024 ) return p.sums ? run_analyze_v3<9, true>( p, s ) : run_analyze_v3<9, false>( p, s );
-		if( dft == 512 ) return p.sums ? run_analyze_v3<8, true>( p, s ) : run_analyze_v3<8, false>( p, s );
+		if( v3_size( dft ) ) return p.sums ? run_analyze_v3_cfg<true>( dft, p, s ) : run_analyze_v3_cfg<false>( dft, p, s );
 		if( dft == 2048 ) return p.sums ? run_analyze_v2_variant<true>( debug_options().ana_variant, p, tb, s ) : run_analyze_v2_variant<false>( debug_options().ana_variant, p, tb, s );
 		if( dft == 4096 && W <= 2048 && !debug_options().ana11_old )
 			{

@@ -55,7 +55,7 @@ typedef std::tuple<int, int, int> PlanKey;
 // (heap objects that are never destroyed: at process exit the HIP runtime may be gone before static destructors run)
 static std::map<PlanKey, std::shared_ptr<const PlanRef>> & plan_map() { static auto * m = new std::map<PlanKey, std::shared_ptr<const PlanRef>>; return *m; }
 static std::vector<PlanKey> & plan_lru() { static auto * v = new std::vector<PlanKey>; return *v; }   // the evictable plans, most recently used last
-static constexpr size_t kEvictablePlans = 8;
+static constexpr size_t kEvictablePlans = 8;            // per device
 static bool plan_is_permanent( int dft_size ) { return is_pow2( dft_size ) && dft_size >= 32 && dft_size <= 8192; }
 
 int get_plan( int window_size, int dft_size, std::shared_ptr<const PlanRef> * out )
@@ -113,12 +113,17 @@ int get_plan( int window_size, int dft_size, std::shared_ptr<const PlanRef> * ou
 			{
 			auto & lru = plan_lru();
 			lru.push_back( key );
-			if( lru.size() > kEvictablePlans )
-				{
-				auto old = plan_map().find( lru.front() );
-				if( old != plan_map().end() ) { evicted = old->second; plan_map().erase( old ); }
-				lru.erase( lru.begin() );
-				}
+			// the bound is per DEVICE: a process that drives eight GPUs with a couple of such sizes each must not evict on every call
+			size_t mine = 0;
+			for( const PlanKey & k : lru ) mine += std::get<0>( k ) == device;
+			if( mine > kEvictablePlans )
+				for( size_t i = 0; i < lru.size(); ++i ) if( std::get<0>( lru[i] ) == device )
+					{
+					auto old = plan_map().find( lru[i] );
+					if( old != plan_map().end() ) { evicted = old->second; plan_map().erase( old ); }
+					lru.erase( lru.begin() + long( i ) );
+					break;
+					}
 			}
 		}
 	*out = ref;
@@ -148,15 +153,18 @@ int get_div_plan( float c, DivPlan * out )
 	uint32_t key; std::memcpy( &key, &c, 4 );
 	int device = 0;
 	FLANHIP_CHECK( hipGetDevice( &device ) );
+	// the calling thread's FLANHIP_DEBUG_NO_FAST_DIV hook is applied to what is handed out, never to what is cached: the cache is the process's,
+	// the hook the thread's
+	const bool no_fast = debug_options().no_fast_div != 0;
 	std::lock_guard<std::mutex> lock( g_plan_mutex );
 	auto it = g_div_plans.find( key );
-	if( it != g_div_plans.end() ) { *out = it->second; return FLANHIP_OK; }
+	if( it != g_div_plans.end() ) { *out = it->second; if( no_fast ) out->exact = 0; return FLANHIP_OK; }
 	DivPlan d{ c, 1.0f / c, 0 };
 	// the analysis rates of everyday sample rates and hops were tried offline, all 2^32 dividends each (tools/check_div_c.cpp ->
 	// div_plans_proven.h): no launch of k_verify_div (2.4 ms) for those
 	bool known = false;
 	for( const ProvenDiv & pd : kProvenDivs ) if( pd.bits == key ) { d.exact = pd.exact; known = true; break; }
-	if( debug_options().no_fast_div ) { d.exact = 0; known = true; }
+	if( !known && no_fast ) { *out = d; return FLANHIP_OK; }                      // (nothing proven, nothing cached: the hardware division it is)
 	if( !known && c > 1.0e-10f && c < 1.0e10f )
 		{
 		unsigned int * d_bad = nullptr, bad = 1;
@@ -170,6 +178,7 @@ int get_div_plan( float c, DivPlan * out )
 		}
 	g_div_plans[key] = d;
 	*out = d;
+	if( no_fast ) out->exact = 0;
 	return FLANHIP_OK;
 	}
 

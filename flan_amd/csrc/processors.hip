@@ -29,7 +29,9 @@ __global__ __launch_bounds__( 256 ) void k_modify_time( const MFd * in, int num_
 	const float * mod, int64_t Fo, MFd * out, const int * nonmono, int flag_tag, int segments, int64_t seg_len, int only_if_any, int interp, int * words, int epoch )
 	{
 	if( only_if_any && nonmono[bins] != flag_tag ) return;                          // k_modify_time_chains has done this PV (a flag is set when it holds this call's tag)
-	if( words && blockIdx.x == 0 && threadIdx.x == 0 ) { words[2] = epoch; words[4] = 0; }   // the chain sums k_modify_time_chains left are NOT this PV's
+	// the chain sums k_modify_time_chains left are NOT this PV's, and neither is the NaN / Inf word its chain blocks may have set from frames this
+	// kernel overwrites: both are taken back ([4] = 0 makes convert_to_audio's pre-pass scan the real PV again)
+	if( words && blockIdx.x == 0 && threadIdx.x == 0 ) { words[0] = 0; words[2] = epoch; words[4] = 0; }
 	const int64_t idx = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
 	const int64_t columns = int64_t( num_channels ) * bins;
 	if( idx >= columns * segments ) return;

@@ -702,6 +702,9 @@ template<int GSIZE>
 __global__ __launch_bounds__( 256 ) void k_group_sums( SynthParams p, double * out )
 	{
 	const int bin = blockIdx.x * 256 + threadIdx.x;
+	// a handed-over pre-pass is good for ONE convert_to_audio (include/flanhip.h: a second call on the same workspace runs the pre-pass): the word
+	// k_phase_sums2 -- launched in front of this kernel -- has just tested is taken back here, as k_phase_scan2 does on the path that runs it
+	if( p.skip_words && bin == 0 && blockIdx.y == 0 && blockIdx.z == 0 ) const_cast<int*>( p.skip_words )[4] = 0;
 	if( bin >= p.num_bins ) return;
 	const int group = blockIdx.y, channel = blockIdx.z;
 	const int live = min( GSIZE, p.chains_per_channel - group * GSIZE );

@@ -103,7 +103,10 @@ template<int LOG2C, int NT> __device__ __forceinline__ void v3_load_twiddles( cf
 // =================================================================================================================
 // Audio::convert_to_PV (Conversions/AudioPV.cpp:12-78), dft 1024 / 512.  See k_analyze_v2 for the reasons behind the loop's shape.
 // =================================================================================================================
-template<int LOG2C, int WAVES, bool SUMS, int OCC, int NV = 2 * ( V3Lds<LOG2C>::E / 2 )>
+// PF: frames the sample requests run ahead of their use (1: like k_analyze_v2, into the registers of the dying spectrum; 2: a frame further, through
+// a second register set -- the requests a transform waits for then sit IN FRONT of the last frame's MF stores in issue order, and the stores in front of
+// them are two frames old: at these sizes a frame is too short for one frame's lead to cover the acknowledgement of a row of stores)
+template<int LOG2C, int WAVES, bool SUMS, int OCC, int NV = 2 * ( V3Lds<LOG2C>::E / 2 ), int PF = 1, int ABL = 0>
 __global__ __launch_bounds__( 64 * WAVES, OCC ) void k_analyze_v3( AnalyzeParams p )
 	{
 	using L = V3Lds<LOG2C>;
@@ -178,13 +181,14 @@ __global__ __launch_bounds__( 64 * WAVES, OCC ) void k_analyze_v3( AnalyzeParams
 	const bool w_whole = ( W & 127 ) == 0;
 	auto frame_inside = [&]( int t ) { return w_whole && hop * t - W / 2 >= 0 && hop * t - W / 2 + 2 * C <= n32; };
 
-	cf z[E];
+	cf z[E], raw[PF == 2 ? E : 1];
 	auto run_chain = [&]()
 		{
 		auto load_pair = [&]( int t, int q, auto fast_tag ) -> cf
 			{
 			constexpr bool FAST = decltype( fast_tag )::value;
-			if constexpr( FAST )
+			if constexpr( ( ABL & 16 ) != 0 ) return mk( float( t ) * 1e-9f + 0.25f, float( q ) );      // (timing only: no sample loads)
+			else if constexpr( FAST )
 				{
 				const unsigned off = unsigned( hop * ( t - tb0 ) ) * 4u + lane8;
 				const f2u v = *reinterpret_cast<const f2u*>( xb + off + 512 * q );
@@ -233,13 +237,20 @@ __global__ __launch_bounds__( 64 * WAVES, OCC ) void k_analyze_v3( AnalyzeParams
 
 		// the rotated loop body: [ per-bin work of frame t, which also requests frame tn's samples and stores frame t's MFs ]; the caller
 		// then waits for those samples and transforms frame tn.  HALO: frame t0 - 1, of which only the phases are wanted.
+		// z[q] <- pair q of the frame after this one; tn: the frame REQUESTED now (PF = 1: that same frame; PF = 2: the one after it, and the
+		// frame handed to z arrived in `raw` a frame ago)
+		auto next_pair = [&]( int tn, int q, auto fast_tag )
+			{
+			if constexpr( PF == 2 ) { z[q] = raw[q]; raw[q] = load_pair( tn, q, fast_tag ); }
+			else z[q] = load_pair( tn, q, fast_tag );
+			};
 		auto bins_of_frame = [&]( int t, int tn, int fi, auto halo_tag, auto next_fast )
 			{
 			constexpr bool halo = decltype( halo_tag )::value;
 			const cf zh = buf[C / 2 + C / 2 / E];                                 // Z[ C/2 ], slot PAD( C/2 )
 			const cf z0 = z[0];                                                   // lane 0: Z[0]
 			#pragma unroll
-			for( int q = H; q < E; ++q ) z[q] = load_pair( tn, q, next_fast );    // the upper half is in LDS now: its registers are free
+			for( int q = H; q < E; ++q ) next_pair( tn, q, next_fast );           // the upper half is in LDS now: its registers are free
 			const unsigned roff = unsigned( t - tb0 ) * unsigned( ( C + 1 ) * 8 );
 			cf * rowk = reinterpret_cast<cf*>( rb + ( roff + lane8 ) );
 			cf * rowm = reinterpret_cast<cf*>( rb + ( roff + unsigned( C * 8 ) - lane8 ) );
@@ -257,7 +268,7 @@ __global__ __launch_bounds__( 64 * WAVES, OCC ) void k_analyze_v3( AnalyzeParams
 					const cf zm = mirror[-QS * q];                                  // lane 0, q = 0 reads an unused slot: overridden below
 					const cf w = s_w2[64 * q];                                      // 0.5 exp( -2 pi i k / 2C )
 					const v4f_t kc = s_kc[64 * q];
-					z[q] = load_pair( tn, q, next_fast );                           // Z[k] is consumed: next frame's samples take its place
+					next_pair( tn, q, next_fast );                                  // Z[k] is consumed: next frame's samples take its place
 					const float sx = zk.x + zm.x, dy = zk.y + zm.y, dx = zk.x - zm.x, sy = zk.y - zm.y;
 					const float t1v = __builtin_fmaf( w.x, dy, w.y * dx );
 					const float t2v = __builtin_fmaf( w.x, dx, -( w.y * dy ) );
@@ -313,8 +324,13 @@ __global__ __launch_bounds__( 64 * WAVES, OCC ) void k_analyze_v3( AnalyzeParams
 				#pragma unroll
 				for( int q = 0; q < H; ++q )
 					{
-					__builtin_nontemporal_store( outk[q], rowk + 64 * q );
-					__builtin_nontemporal_store( outm[q], rowm - 64 * q );
+					if constexpr( ( ABL & 8 ) != 0 ) asm volatile( "" :: "v"( outk[q].x ), "v"( outk[q].y ), "v"( outm[q].x ), "v"( outm[q].y ) );   // (timing only: no MF stores)
+					else if constexpr( ( ABL & 32 ) != 0 ) { rowk[64 * q] = outk[q]; rowm[-64 * q] = outm[q]; }                                  // (A/B: plain stores)
+					else
+						{
+						__builtin_nontemporal_store( outk[q], rowk + 64 * q );
+						__builtin_nontemporal_store( outm[q], rowm - 64 * q );
+						}
 					}
 				}
 			ring = ( lane == ( fi & 63 ) ) ? zh : ring;
@@ -349,40 +365,45 @@ __global__ __launch_bounds__( 64 * WAVES, OCC ) void k_analyze_v3( AnalyzeParams
 
 		constexpr std::true_type inside{};
 		constexpr std::false_type outside{};
-		if( frame_inside( tfirst ) )
+		// frame t's step requests frame min( t + PF, t1 - 1 ) (the last frames request the last one again: nobody waits for it) and transforms
+		// frame t + 1; `inside` bodies need both of them inside the signal
+		auto req = [&]( int t ) { return min( t + PF, t1 - 1 ); };
+		auto plain = [&]( int t ) { return frame_inside( min( t + 1, t1 - 1 ) ) && frame_inside( req( t ) ); };
+		if( frame_inside( tfirst ) && ( PF == 1 || frame_inside( req( tfirst - 1 ) ) ) )
 			{
 			#pragma unroll
 			for( int q = 0; q < E; ++q ) z[q] = load_pair( tfirst, q, inside );
+			if constexpr( PF == 2 ) { _Pragma( "unroll" ) for( int q = 0; q < E; ++q ) raw[q] = load_pair( req( tfirst - 1 ), q, inside ); }
 			transform_frame( tfirst, inside );
 			}
 		else
 			{
 			#pragma unroll
 			for( int q = 0; q < E; ++q ) z[q] = load_pair( tfirst, q, outside );
+			if constexpr( PF == 2 ) { _Pragma( "unroll" ) for( int q = 0; q < E; ++q ) raw[q] = load_pair( req( tfirst - 1 ), q, outside ); }
 			transform_frame( tfirst, outside );
 			}
 		int fi = 0;
 		if( t0 > 0 )
 			{
-			if( frame_inside( t0 ) ) { bins_of_frame( t0 - 1, t0, fi, std::true_type{}, inside ); transform_frame( t0, inside ); }
-			else { bins_of_frame( t0 - 1, t0, fi, std::true_type{}, outside ); transform_frame( t0, outside ); }
+			if( plain( t0 - 1 ) ) { bins_of_frame( t0 - 1, req( t0 - 1 ), fi, std::true_type{}, inside ); transform_frame( t0, inside ); }
+			else { bins_of_frame( t0 - 1, req( t0 - 1 ), fi, std::true_type{}, outside ); transform_frame( t0, outside ); }
 			++fi;
 			}
-		// Three loops, not one with a choice inside: the frames whose SUCCESSOR reaches outside the signal (a few at either end of a channel), and
+		// Three loops, not one with a choice inside: the frames whose SUCCESSORS reach outside the signal (a few at either end of a channel), and
 		// between them the loop every other frame takes, which holds the plain loads only -- with both bodies in one loop the edge body's
 		// invariants (clamped addresses, window masks per point) are hoisted in front of it and spill under the register cap.
 		auto step = [&]( int t, auto next_fast )
 			{
-			const int tn = min( t + 1, t1 - 1 );                               // (the last frame requests itself again: nobody waits for it)
 			const bool more = t + 1 < t1;
-			bins_of_frame( t, tn, fi, std::false_type{}, next_fast );
+			bins_of_frame( t, req( t ), fi, std::false_type{}, next_fast );
 			++fi;
 			if( ( fi & 63 ) == 0 || !more ) flush_half_bin( t + 1 - ( ( ( fi - 1 ) & 63 ) + 1 ), ( ( fi - 1 ) & 63 ) + 1 );
 			if( more ) transform_frame( t + 1, next_fast );
 			};
 		int t = t0;
-		for( ; t < t1 && !frame_inside( min( t + 1, t1 - 1 ) ); ++t ) step( t, outside );
-		for( ; t < t1 && frame_inside( min( t + 1, t1 - 1 ) ); ++t ) step( t, inside );
+		for( ; t < t1 && !plain( t ); ++t ) step( t, outside );
+		for( ; t < t1 && plain( t ); ++t ) step( t, inside );
 		for( ; t < t1; ++t ) step( t, outside );
 		};
 	if( active ) run_chain();

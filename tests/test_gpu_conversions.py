@@ -76,6 +76,17 @@ CASES = [
     ("small_dft256", 2, 9000, 256, 64, 256, "noise"),
     ("dft512_win400", 1, 9000, 400, 100, 512, "noise"),
     ("dft1024", 1, 30000, 1024, 256, 1024, "noise"),
+    # dft 1024 / 512: the one-wavefront-per-chain register kernels (pv_kernels_v3.h); synthesis hops 128 / 256 / 512 / 1024, windows that are multiples of 128
+    ("dft1024_hop128_stereo", 2, 41000, 1024, 128, 1024, "noise"),
+    ("dft1024_hop512_win768", 1, 50000, 768, 512, 1024, "noise"),
+    ("dft1024_ragged_3ch", 3, 12345, 1024, 256, 1024, "noise"),
+    ("dft1024_one_frame", 1, 100, 1024, 256, 1024, "noise"),
+    ("dft1024_sine", 1, 48000, 1024, 256, 1024, "sine"),
+    ("dft1024_zeros", 1, 5000, 1024, 256, 1024, "zeros"),
+    ("dft512", 2, 30000, 512, 128, 512, "noise"),
+    ("dft512_hop256_win384", 1, 30000, 384, 256, 512, "noise"),
+    ("dft512_short", 2, 700, 512, 128, 512, "noise"),
+    ("dft512_sine", 1, 48000, 512, 128, 512, "sine"),
     ("dft8192", 1, 40000, 4096, 1024, 8192, "noise"),
     ("dft64", 1, 3000, 64, 16, 64, "noise"),
     ("dft32_win32", 1, 1000, 32, 8, 32, "noise"),
@@ -126,7 +137,10 @@ def test_analysis_parity(fa, name, ch, n, W, hop, dft, kind):
     assert rel_m <= 1e-5
     # measured 2e-5 .. 3.3e-4 Hz (the largest at dft 32 / hop 8); one last-bit change of a phase is 1.2e-7 rad x analysis_rate / 2 pi Hz, so the
     # bound follows the analysis rate where that is extreme (hop 2: 24 kHz)
-    assert wrms_f <= max(5e-4, 1e-7 * sr / hop)
+    # (a pure tone through a short transform: the bins at 1e-6 of the peak hold rounding noise for a phase in the oracle too, f there is anybody's within
+    # an analysis rate, and with few bins per frame their m^2 df^2 is what the weighted figure consists of -- 7.2e-4 Hz at dft 512 from the tuned and 7.7e-4
+    # from the generic kernels alike, tools/dbg_sine.py)
+    assert wrms_f <= (1.5e-3 if kind == "sine" and dft < 1024 else max(5e-4, 1e-7 * sr / hop))
     if kind == "noise":
         assert turns <= max(3, got[..., 0].size // 100000)
         # share of f words that are bit for bit the oracle's.  What is left differs by one rounding of the transform (two FFTs in two operation
@@ -199,17 +213,18 @@ def test_chain_length_invariance(fa):
     synthesis equal to rounding of the overlap partial sums"""
     x = O.noise(2, 60000, seed=8)
     sr = 48000.0
-    res = []
-    for L in (4, 7, 64):
-        with fa.debug_options(chain_len=L):
-            pv = fa.analyze(x, sr, 2048, 512, 2048)
-            out, _ = fa.synthesize(pv, sr, sr / 512, 2048)
-        res.append((pv, out))
-    assert np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32))
-    assert np.array_equal(res[0][0].view(np.uint32), res[2][0].view(np.uint32))
-    for k in (1, 2):
-        d = np.abs(res[0][1].astype(np.float64) - res[k][1].astype(np.float64))
-        assert d.max() <= 2e-6
+    for (W, hop, dft) in ((2048, 512, 2048), (1024, 256, 1024), (512, 128, 512)):
+        res = []
+        for L in (4, 7, 64):
+            with fa.debug_options(chain_len=L):
+                pv = fa.analyze(x, sr, W, hop, dft)
+                out, _ = fa.synthesize(pv, sr, sr / hop, W)
+            res.append((pv, out))
+        assert np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32))
+        assert np.array_equal(res[0][0].view(np.uint32), res[2][0].view(np.uint32))
+        for k in (1, 2):
+            d = np.abs(res[0][1].astype(np.float64) - res[k][1].astype(np.float64))
+            assert d.max() <= 2e-6
 
 
 def test_errors(fa):
@@ -224,19 +239,20 @@ def test_errors(fa):
     assert e.value.code == flan_amd.ERR_INVALID_ARG
 
 
-@pytest.mark.parametrize("dft,hop", [(2048, 512), (4096, 128), (2048, 1024), (2048, 256), (4096, 1024)])
+@pytest.mark.parametrize("dft,hop", [(2048, 512), (4096, 128), (2048, 1024), (2048, 256), (4096, 1024), (1024, 256), (1024, 1024), (512, 128), (512, 256)])
 def test_generic_and_tuned_kernels_agree(fa, dft, hop):
-    """dft 2048 / 4096 have tuned kernels (pv_kernels_fast.h); the force_generic hook routes the same call through the
+    """dft 512 ... 4096 have tuned kernels (pv_kernels_v2.h, _v3.h, _eo.h); the force_generic hook routes the same call through the
     generic ones (pv_kernels.h).  Both must sit within the parity tolerances of the oracle and of each other."""
     x = O.noise(2, 70000, seed=21)
     sr = 48000.0
-    ref = O.analyze(x, sr, 2048, hop, dft)
-    out_ref, _ = O.synthesize(ref, sr, np.float32(sr) / np.float32(hop), 2048)
+    W = min(2048, dft)
+    ref = O.analyze(x, sr, W, hop, dft)
+    out_ref, _ = O.synthesize(ref, sr, np.float32(sr) / np.float32(hop), W)
     res = {}
     for mode in ("0", "1"):
         with fa.debug_options(force_generic=int(mode)):
-            pv = fa.analyze(x, sr, 2048, hop, dft)
-            out, _ = fa.synthesize(ref, sr, np.float32(sr) / np.float32(hop), 2048)
+            pv = fa.analyze(x, sr, W, hop, dft)
+            out, _ = fa.synthesize(ref, sr, np.float32(sr) / np.float32(hop), W)
         rel_m, wrms_f, same, turns = p1_metrics(pv, ref, sr / hop)
         rms = float(np.sqrt(np.mean((out.astype(np.float64) - out_ref.astype(np.float64)) ** 2)))
         print("\n[path generic=%s dft=%d hop=%d] rel_m=%.3e wrms_df=%.3e same=%.4f turns=%d  P2 rms=%.3e" % (mode, dft, hop, rel_m, wrms_f, same, turns, rms))
@@ -253,7 +269,7 @@ def test_fused_round_trip_equals_unfused(fa):
     lib = fa.lib
     sr = 48000.0
     # dft 8192 (and 4096 through the generic kernels): block-wide teams walk the chains; they leave the sums like every other analysis kernel
-    for (ch, n, W, hop, dft) in [(2, 70000, 2048, 512, 2048), (1, 30000, 2048, 128, 4096), (2, 20000, 1024, 256, 1024), (1, 9000, 400, 100, 512),
+    for (ch, n, W, hop, dft) in [(2, 70000, 2048, 512, 2048), (1, 30000, 2048, 128, 4096), (2, 20000, 1024, 256, 1024), (1, 9000, 400, 100, 512), (2, 40000, 512, 128, 512), (3, 90000, 1024, 512, 1024),
                                  (1, 40000, 4096, 1024, 8192), (2, 30000, 2048, 300, 4096),
                                  # the mixed-radix kernels: sums kept by the analysis kernel (ping-pong sizes, with and without the large odd radices) or by
                                  # the pre-pass kernel on its behalf (in place: 12000)
@@ -297,11 +313,12 @@ def test_fused_round_trip_equals_unfused(fa):
 
 
 @pytest.mark.parametrize("dft,hop,ch,n,W", [(2048, 512, 8, 300000, 2048), (4096, 512, 4, 600000, 2048), (4096, 128, 2, 400000, 2048), (4096, 1024, 4, 1400000, 2048),
-                                            (2048, 512, 3, 900000, 2048), (4096, 1024, 4, 1400000, 4096), (4096, 512, 4, 600000, 3072), (2048, 512, 1, 2000000, 2048)])
+                                            (2048, 512, 3, 900000, 2048), (4096, 1024, 4, 1400000, 4096), (4096, 512, 4, 600000, 3072), (2048, 512, 1, 2000000, 2048),
+                                            (1024, 256, 8, 600000, 1024), (1024, 512, 3, 900000, 768), (1024, 128, 1, 2000000, 1024), (512, 128, 2, 400000, 512), (512, 256, 5, 300000, 512)])
 def test_carry_prologue_equals_scan_kernel(fa, dft, hop, ch, n, W):
     """Fused round trip: the synthesis kernels that take their chains' carries from a scan over the analysis' GROUP totals plus the chain sums
-    (dft 2048: groups of 8 chains; dft 4096 team kernels: groups of 4, the last group of a channel short; also their one-buffer-set variants for
-    windows above 2048) against the same launch with the scan over the chains themselves in front (synthesis variant 2); 147-977 chains per
+    (dft 2048 / 1024: groups of 8 chains; dft 4096 team kernels and dft 512: groups of 4, the last group of a channel short; also the team kernels'
+    one-buffer-set variants for windows above 2048) against the same launch with the scan over the chains themselves in front (synthesis variant 2); 147-977 chains per
     channel: the same prefix sums associated group-wise -- audio bit for bit, NaN flag clear."""
     import ctypes
     lib = fa.lib
@@ -739,3 +756,48 @@ def test_overlap_fixup_inside_the_kernel_equals_the_separate_launch(fa, ch, seco
             if not same:
                 bad = (out_a.view(torch.int32) != out_b.view(torch.int32)).nonzero()
                 raise AssertionError("launch %d: %d samples differ, first at %s" % (rep, bad.shape[0], bad[0].tolist()))
+
+
+@pytest.mark.parametrize("W,hop,dft", [(1024, 256, 1024), (512, 128, 512)])
+def test_v3_kernel_configurations_agree(fa, W, hop, dft):
+    """The dft 1024 / 512 kernels are built for several block shapes (wavefronts per block = chains per group, registers per wavefront, bins per
+    vector stream: conversions.hip, FLANHIP_V3_CFGS_*); index 0 ships, the others are its A/B partners.  Same arithmetic per frame: the PV bit for
+    bit, the fused round trip's audio to the rounding of the overlap partial sums at the chain boundaries (the chain length follows the group size)."""
+    import ctypes
+    lib = fa.lib
+    sr = 48000.0
+    ch, n = 3, 700000
+    x = O.noise(ch, n, seed=dft)
+    F = O.num_pv_frames(n, hop)
+    bins = dft // 2 + 1
+    ar = np.float32(sr) / np.float32(hop)
+
+    def dev_alloc(nbytes):
+        p = ctypes.c_void_p()
+        fa.check(lib.flanhip_malloc(ctypes.byref(p), nbytes))
+        return p
+    d_x = dev_alloc(x.nbytes)
+    fa.check(lib.flanhip_memcpy_h2d(d_x, x.ctypes.data_as(ctypes.c_void_p), x.nbytes, None))
+    res = []
+    try:
+        for variant in (0, 1, 2):
+            lib.flanhip_debug_option(fa.DEBUG_ANA_VARIANT, variant)
+            ws_bytes = lib.flanhip_synthesize_workspace_bytes(ch, F, bins, sr, ar, W)
+            d_pv, d_out, d_ws, d_flag = dev_alloc(ch * F * bins * 8), dev_alloc(ch * F * hop * 4), dev_alloc(ws_bytes), dev_alloc(4)
+            fa.check(lib.flanhip_memset(d_flag, 0, 4, None))
+            fa.check(lib.flanhip_analyze_dev_fused(d_x, ch, n, sr, W, hop, dft, d_pv, d_ws, None))
+            fa.check(lib.flanhip_synthesize_dev_fused(d_pv, ch, F, bins, sr, ar, W, d_out, d_ws, d_flag, None))
+            pv = np.empty((ch, F, bins, 2), np.float32); out = np.empty((ch, F * hop), np.float32)
+            fa.check(lib.flanhip_memcpy_d2h(pv.ctypes.data_as(ctypes.c_void_p), d_pv, pv.nbytes, None))
+            fa.check(lib.flanhip_memcpy_d2h(out.ctypes.data_as(ctypes.c_void_p), d_out, out.nbytes, None))
+            fa.check(lib.flanhip_stream_synchronize(None))
+            res.append((pv, out))
+            for p in (d_pv, d_out, d_ws, d_flag):
+                lib.flanhip_free(p)
+    finally:
+        lib.flanhip_debug_option(fa.DEBUG_ANA_VARIANT, 0)
+        lib.flanhip_free(d_x)
+    for k in (1, 2):
+        assert np.array_equal(res[0][0].view(np.uint32), res[k][0].view(np.uint32))
+        assert np.abs(res[0][1].astype(np.float64) - res[k][1].astype(np.float64)).max() <= 2e-6
+    assert np.abs(res[0][1]).max() > 0.1

@@ -522,3 +522,43 @@ def test_callable_interpolators_through_a_table(fa, which):
         kind = table.kind
     with pytest.raises(fa.FlanHipError):                 # destroyed: the kind is no longer valid
         fa.desample(pv, 0.25, kind)
+
+
+def test_handed_over_prepass_is_consumed_once_with_many_chains(fa):
+    """include/flanhip.h: "a second call on the same workspace runs the pre-pass".  At >= 128 chains per channel the synthesis takes the group path
+    (k_group_sums + its own carries, no scan over the chains): the "sums valid" word has to be taken back there as the scan kernel does it --
+    a second flanhip_synthesize_dev_fused_checked on the same workspace with a DIFFERENT PV of the same shape must not reuse the first one's sums."""
+    import ctypes as C
+    lib = fa.lib
+    hop, dft, W = 512, 2048, 2048
+    ch = 2
+    n = 8 * 600 * hop                                                               # enough frames for >= 128 chains per channel on any device
+    x = O.noise(ch, n, seed=99)
+    ar = np.float32(SR) / np.float32(hop)
+    F = O.num_pv_frames(n, hop)
+    bins = dft // 2 + 1
+    P = lambda d: C.c_void_p(d.ptr)
+    d_x = fa.DeviceArray(host=x)
+    d_pv = fa.DeviceArray(ch * F * bins * 8)
+    fa.check(lib.flanhip_analyze_dev(P(d_x), ch, n, SR, W, hop, dft, P(d_pv), None))
+    hop_s = hop / SR
+    mono = (np.arange(F, dtype=np.float32)[:, None] * np.ones((1, bins), np.float32) * hop_s).astype(np.float32)      # identity map: Fo = F
+    Fo = int(lib.flanhip_modify_time_out_frames(mono.ctypes.data_as(C.c_void_p), F, bins, SR, hop))
+    d_mod = fa.DeviceArray(host=mono)
+    d_ws = fa.DeviceArray(fa.synthesize_workspace_bytes(ch, Fo, bins, SR, float(ar), W))
+    d_flag = fa.DeviceArray(host=np.zeros(1, np.int32))
+    d_st, d_out = fa.DeviceArray(ch * Fo * bins * 8), fa.DeviceArray(ch * Fo * hop * 4)
+    fa.check(lib.flanhip_modify_time_dev_fused(P(d_pv), ch, F, bins, SR, ar, P(d_mod), Fo, P(d_st), W, P(d_ws), None))     # hands its sums over
+    fa.check(lib.flanhip_synthesize_dev_fused_checked(P(d_st), ch, Fo, bins, SR, ar, W, P(d_out), P(d_ws), P(d_flag), None))
+    first = d_out.to_host((ch, Fo * hop))
+    # another PV of the same shape in the same buffer: every frequency moved -- its phase sums are different ones
+    st = d_st.to_host((ch, Fo, bins, 2))
+    st[..., 1] *= np.float32(1.25)
+    d_st2 = fa.DeviceArray(host=st)
+    fa.check(lib.flanhip_synthesize_dev_fused_checked(P(d_st2), ch, Fo, bins, SR, ar, W, P(d_out), P(d_ws), P(d_flag), None))
+    second = d_out.to_host((ch, Fo * hop))
+    d_ws2 = fa.DeviceArray(fa.synthesize_workspace_bytes(ch, Fo, bins, SR, float(ar), W))
+    fa.check(lib.flanhip_synthesize_dev(P(d_st2), ch, Fo, bins, SR, ar, W, P(d_out), P(d_ws2), P(d_flag), None))
+    want = d_out.to_host((ch, Fo * hop))
+    assert np.abs(first - want).max() > 1e-3                                         # (the two PVs do sound different)
+    assert np.array_equal(second.view(np.uint32), want.view(np.uint32))
