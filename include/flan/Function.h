@@ -119,6 +119,10 @@ struct Function
 		const int y_size = int( std::ceil( y_end - y_start ) );
 		if( is_constant() ) return FunctionSample2d<O>{ std::get<O>( f ), size_t( x_size ) * y_size, size_t( y_size ) };
 		typename FunctionSample2d<O>::Vector out( size_t( x_size ) * y_size );
+		// (the grid's memory is not cleared: whole-number bounds -- every call of the PV methods -- write every slot; fractional ones leave slots
+		// the reference's value-initialised vector holds as O())
+		if( x_start != std::floor( x_start ) || x_end != std::floor( x_end ) || y_start != std::floor( y_start ) || y_end != std::floor( y_end ) )
+			std::fill( out.begin(), out.end(), O() );
 		sample_into( out.data(), x_start, x_end, x_scale, y_start, y_end, y_scale );
 		return FunctionSample2d<O>{ std::move( out ), size_t( x_size ) * y_size, size_t( y_size ) };
 		}
@@ -129,10 +133,16 @@ struct Function
 		{
 		const int y_size = int( std::ceil( y_end - y_start ) );
 		const StdFuncType & fn = std::get<StdFuncType>( f );
+		// The reference's own arithmetic (Function.h:163-168), which matters when a bound has a fractional part: x runs over the INTEGERS
+		// [ int( x_start ), int( x_end ) ) (iota_iter takes an int), y from int( y_start ) while y < y_end (an int against a float), and a point's
+		// slot is buffer_access( int( y - y_start ), int( x - x_start ), y_size ) -- the float differences truncated, so with fractional
+		// starts two neighbouring points can share a slot (the later one stays) and slots past int( x_end ) keep their initial value.
+		// Pinned by tests/golden/ref_made/function_sample.npz, made by the reference's header itself.
 		detail::for_each_index( int( x_start ), int( x_end ), execution_policy, [&]( int x )
 			{
+			const int row = int( float( x ) - x_start );                             // (0 for the first x whatever the fraction: |int( s ) - s| < 1)
 			for( int y = int( y_start ); y < y_end; ++y )
-				out[size_t( x - int( x_start ) ) * y_size + ( y - int( y_start ) )] = fn( I{ x * x_scale, y * y_scale } );
+				out[size_t( row ) * y_size + int( float( y ) - y_start )] = fn( I{ x * x_scale, y * y_scale } );
 			}, 16 );
 		}
 

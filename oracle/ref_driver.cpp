@@ -134,3 +134,60 @@ void ref_spline( const double * x, const double * y, int n, const double * t, in
 	}
 
 } // extern "C"
+
+// ---- Function<I,O>::sample / FunctionSample2d (flan/Function.h:141-171, FunctionSample.h:173-199): the reference's own templates, instantiated on
+// a few fixed callables.  The header compiles unmodified here (its Graph / bitmap includes are declarations the driver never calls into).
+#include "flan/Function.h"
+
+namespace {
+// which: 0  tf.t a + tf.f b      1  a step in t at a and in f at b      2  NaN where the product t f is negative, else t - f      3  the CONSTANT a
+flan::Function<flan::TF, float> ref_fn2( int which, float a, float b, int policy )
+	{
+	const flan::ExecutionPolicy pol = static_cast<flan::ExecutionPolicy>( policy );
+	switch( which )
+		{
+		case 0: return flan::Function<flan::TF, float>( [a, b]( flan::TF tf ){ return tf.t * a + tf.f * b; }, pol );
+		case 1: return flan::Function<flan::TF, float>( [a, b]( flan::TF tf ){ return ( tf.t >= a ? 1.0f : 0.0f ) + ( tf.f >= b ? 2.0f : 0.0f ); }, pol );
+		case 2: return flan::Function<flan::TF, float>( []( flan::TF tf ){ return tf.t * tf.f < 0.0f ? std::numeric_limits<float>::quiet_NaN() : tf.t - tf.f; }, pol );
+		default: return flan::Function<flan::TF, float>( a );
+		}
+	}
+}
+
+extern "C" {
+
+// the 2-D sample.  Returns vec_size (FunctionSample.h:21); *is_constant / *small_dim as the reference reports them; the grid (or the one constant) in out
+// when it fits.  scan != 0: the in-place running sum down the frames of every bin through FunctionSample2d::at, exactly PV::stretch's loop
+// (PV/PVModify.cpp:376-378) -- on a constant sample at() aliases ONE value, which is the doubling SURVEY 7 records.
+int64_t ref_function_sample2d( int which, float a, float b, int policy, float x0, float x1, float xs, float y0, float y1, float ys, int scan,
+	float * out, int64_t capacity, int * is_constant, int64_t * small_dim )
+	{
+	const flan::Function<flan::TF, float> fn = ref_fn2( which, a, b, policy );
+	flan::FunctionSample2d<float> s = fn.sample( x0, x1, xs, y0, y1, ys );
+	if( scan )
+		{
+		const int frames = int( s.size() / ( s.small_dim_size ? s.small_dim_size : 1 ) ), bins = int( s.small_dim_size );
+		for( flan::Bin bin = 0; bin < bins; ++bin )
+			for( flan::Frame frame = 1; frame < frames; ++frame )
+				s.at( frame, bin ) += s.at( frame - 1, bin );
+		}
+	*is_constant = s.is_constant() ? 1 : 0;
+	*small_dim = int64_t( s.small_dim_size );
+	if( s.is_constant() ) { if( capacity >= 1 ) out[0] = s.get_constant(); }
+	else if( int64_t( s.size() ) <= capacity ) std::memcpy( out, s.get_vector().data(), sizeof( float ) * s.size() );
+	return int64_t( s.size() );
+	}
+
+// the 1-D sample (Function.h:141-153) of x a + b, or of the constant a (which != 0)
+int64_t ref_function_sample1d( int which, float a, float b, int policy, int start, int end, float scale, float * out, int64_t capacity, int * is_constant )
+	{
+	const flan::ExecutionPolicy pol = static_cast<flan::ExecutionPolicy>( policy );
+	const flan::Function<float, float> fn = which ? flan::Function<float, float>( a ) : flan::Function<float, float>( [a, b]( float x ){ return x * a + b; }, pol );
+	flan::FunctionSample<float> s = fn.sample( start, end, scale );
+	*is_constant = s.is_constant() ? 1 : 0;
+	if( s.is_constant() ) { if( capacity >= 1 ) out[0] = s.get_constant(); }
+	else if( int64_t( s.size() ) <= capacity ) std::memcpy( out, s.get_vector().data(), sizeof( float ) * s.size() );
+	return int64_t( s.size() );
+	}
+
+} // extern "C" (Function)

@@ -140,6 +140,11 @@ def load_ref():
     ref.ref_pv_load.argtypes = [C.c_char_p, C.POINTER(RefPVFormat), C.c_void_p, C.c_int64]
     ref.ref_interpolate.restype = C.c_float
     ref.ref_interpolate.argtypes = [C.c_int, C.c_float]
+    if hasattr(ref, "ref_function_sample2d"):
+        ref.ref_function_sample2d.restype = C.c_int64
+        ref.ref_function_sample2d.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int] + [C.c_float] * 6 + [C.c_int, f32p, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+        ref.ref_function_sample1d.restype = C.c_int64
+        ref.ref_function_sample1d.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float, f32p, C.c_int64, C.POINTER(C.c_int)]
     if hasattr(ref, "ref_spline"):
         ref.ref_spline.restype = None
         ref.ref_spline.argtypes = [f64p, f64p, C.c_int, f64p, C.c_int, f64p]
@@ -234,6 +239,16 @@ def shape_affine(pv, sample_rate, a, b, c, d, use_shift_alignment=False):
     out = np.empty_like(pv)
     lib.oracle_shape_affine(pv.reshape(-1), ch, F, bins, sample_rate, a, b, c, d, int(use_shift_alignment), out.reshape(-1))
     return out
+
+
+def sample_grid(fn, F, bins, analysis_rate, bin_width):
+    """The grid the checker's frame processors take for a user function of ( time, frequency ): [frame][bin], the argument of point ( x, y ) being
+    ( x * float32( 1 / analysis_rate ), y * bin_width ) with every product rounded to fp32 -- PV::sample_function_over_domain (PV/PV.h:31-35) through
+    Function::sample (Function.h:155-171).  tests/test_ref_made_golden.py holds this convention to grids the reference's own header made."""
+    xs = np.float32(1.0) / np.float32(analysis_rate)
+    t = (np.arange(F, dtype=np.float32) * xs).astype(np.float32)
+    f = (np.arange(bins, dtype=np.float32) * np.float32(bin_width)).astype(np.float32)
+    return np.asarray(fn(t[:, None], f[None, :]), np.float32).reshape(F, bins)
 
 
 def _grid(g, F, bins):

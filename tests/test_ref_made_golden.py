@@ -136,3 +136,79 @@ def test_flan_file_written_by_the_reference_loads_here(tmp_path):
     assert host.flan_pv_save_file(fmt0, np.ascontiguousarray(g["mf"]).reshape(-1), dst) == 1
     ours = open(dst, "rb").read()
     assert len(ours) == len(image) and ours[:10] == image[:10] and ours[12:] == image[12:]
+
+
+# ---- Function::sample: grids made by the reference's own Function.h / FunctionSample.h (oracle/ref_driver.cpp, compiled unmodified)
+
+def _host_lib():
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-s", "-C", os.path.join(root, "flan_amd", "host")], check=True)
+    C.CDLL(os.path.join(root, "flan_amd", "libflanhip.so"), mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(os.path.join(root, "flan_amd", "libflan_host.so"))
+    lib.flan_function_sample2d.restype = C.c_int64
+    lib.flan_function_sample2d.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int] + [C.c_float] * 6 + [O.f32p, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+    lib.flan_function_sample1d.restype = C.c_int64
+    lib.flan_function_sample1d.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_float, O.f32p, C.c_int64, C.POINTER(C.c_int)]
+    return lib
+
+
+def _same_floats(a, b):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return a.shape == b.shape and bool(np.all((_bits(a) == _bits(b)) | (np.isnan(a) & np.isnan(b))))
+
+
+def test_function_sample_2d_against_reference_made():
+    """include/flan/Function.h (the product's host code on the path of configs 3 and 5) against the grids the reference's Function<TF,float>::sample
+    produced: element count (the ceil of the extents), small dimension, [x][y] order, the sample points ( x * x_scale, y * y_scale ) for integer x and
+    y, the truncated slot arithmetic of fractional bounds (shared and untouched slots included), NaN results, and a constant staying a constant."""
+    g = np.load(os.path.join(G, "function_sample.npz"))
+    lib = _host_lib()
+    for i, (which, a, b, pol, x0, x1, xs, y0, y1, ys, scan) in enumerate(g["cases2d"]):
+        n_ref, const_ref, small_ref = (int(v) for v in g["s2d_%d_meta" % i])
+        if scan:
+            continue                                                                 # (the running sums: next test)
+        buf = np.full(1 << 16, -54321.0, np.float32)
+        const, small = C.c_int(0), C.c_int64(0)
+        n = lib.flan_function_sample2d(int(which), a, b, int(pol), x0, x1, np.float32(xs), y0, y1, np.float32(ys), buf, buf.size, C.byref(const), C.byref(small))
+        assert (n, const.value, small.value) == (n_ref, const_ref, small_ref), i
+        assert _same_floats(buf[:1 if const_ref else n], g["s2d_%d" % i]), i
+    # every execution policy walks the same points from a zero start (the PV methods' call)
+    for pol in range(4):
+        buf = np.full(1 << 16, -54321.0, np.float32)
+        const, small = C.c_int(0), C.c_int64(0)
+        n = lib.flan_function_sample2d(0, 3.0, 0.01, pol, 0.0, 37.0, np.float32(1.0 / 93.75), 0.0, 65.0, 375.0, buf, buf.size, C.byref(const), C.byref(small))
+        assert n == 2405 and _same_floats(buf[:n], g["s2d_1"]), pol
+
+
+def test_function_sample_scan_and_the_checkers_grid_convention():
+    """(i) PV::stretch's in-place running sum down the frames (PV/PVModify.cpp:376-378) as the reference ran it through FunctionSample2d::at on a
+    sampled grid: at( frame, bin ) = vector[ frame * small + bin ] -- the same sums taken on the product's grid in that order land on the same bits;
+    (ii) the checker's [frame][bin] grids (oracle_lib.sample_grid: what every frame-processor test hands the oracle and the device) are the
+    reference's grid for a PV's domain; (iii) the reference's constant case recorded as it is: at() aliases ONE value, so the running sum doubles it
+    once per (frame, bin) step -- 2 -> 2^61 over 15 x 4 steps.  The product deliberately treats a constant like the callable returning it
+    (include/flan/Function.h, tests/cpp/host_test.cpp)."""
+    g = np.load(os.path.join(G, "function_sample.npz"))
+    cases = g["cases2d"]
+    plain, scanned = g["s2d_1"].reshape(37, 65), g["s2d_2"].reshape(37, 65)
+    assert tuple(cases[1][4:10]) == tuple(cases[2][4:10]) and cases[2][10] == 1
+    run = plain.copy()
+    for f in range(1, 37):
+        run[f] = run[f - 1] + run[f]                                              # fp32, frame by frame, like the reference's +=
+    assert _same_floats(run, scanned)
+    grid = O.sample_grid(lambda t, f: t * np.float32(3.0) + f * np.float32(0.01), 37, 65, 93.75, 375.0)
+    assert _same_floats(grid, plain)
+    assert float(g["s2d_10"][0]) == 2.0 * 2.0 ** 60 and tuple(g["s2d_10_meta"]) == (64, 1, 4)
+    assert float(g["s2d_11"][0]) == 1.5 * 2.0 ** 4 and tuple(g["s2d_11_meta"]) == (6, 1, 2)
+
+
+def test_function_sample_1d_against_reference_made():
+    g = np.load(os.path.join(G, "function_sample.npz"))
+    lib = _host_lib()
+    for i, (which, a, b, pol, start, end, scale) in enumerate(g["cases1d"]):
+        n_ref, const_ref = (int(v) for v in g["s1d_%d_meta" % i])
+        buf = np.full(1 << 12, -54321.0, np.float32)
+        const = C.c_int(0)
+        n = lib.flan_function_sample1d(int(which), a, b, int(pol), int(start), int(end), np.float32(scale), buf, buf.size, C.byref(const))
+        assert (n, const.value) == (n_ref, const_ref), i
+        assert _same_floats(buf[:1 if const_ref else n], g["s1d_%d" % i]), i
