@@ -532,6 +532,10 @@ def main():
         # N > 1: `value` is the step WITH the north star's output reassembly (the all-gather overlapped with the next batch's compute);
         # the compute-only figure and the not-overlapped one stand beside it.  N = 1: there is nothing to gather, `value` is the round trip
         line["value_includes_gather"] = bool(use_gather)
+        # how the timed steps reassemble the output: one batch of point-to-point sends / receives per step straight into the final channel-major buffer
+        # on a side stream (the same bytes over the same xGMI links as north_star's one in-place ncclAllGather, whose form is value_compute_then_gather)
+        line["gather_kind"] = ("overlapped batch of isend / irecv into the final [rank][channel][sample] buffer; the collective form "
+                               "(all_gather_into_tensor, in place) is value_compute_then_gather") if use_gather else None
         line["value_compute_only"] = round(value_compute_only, 1) if value_compute_only else None
         line["value_gather_overlapped"] = ag.get("frames_per_s_gather_overlapped")
         line["value_compute_then_gather"] = ag.get("frames_per_s_compute_then_gather")
@@ -631,8 +635,7 @@ def other_configs(fa, torch, dev):
 
     def config3():
         fa.check(lib.flanhip_analyze_dev(P(audio), ch, n, SR, W, HOP, DFT, P(pv), None))
-        fa.check(lib.flanhip_fill_dev(P(grid), F * BINS, 2.0, None))
-        fa.check(lib.flanhip_stretch_map_dev(P(grid), F, BINS, SR, HOP, P(dmax), None))
+        fa.check(lib.flanhip_stretch_map_const_dev(2.0, P(grid), F, BINS, SR, HOP, P(dmax), None))     # the constant factor's map in closed form (round 5; fill + scan before)
         fa.check(lib.flanhip_modify_time_dev_fused(P(pv), ch, F, BINS, SR, ar, P(grid), Fo, P(st), W, P(ws), None))
         fa.check(lib.flanhip_synthesize_dev_fused_checked(P(st), ch, Fo, BINS, SR, ar, W, P(out), P(ws), None, None))
     ms = timed(config3, tag="config3")

@@ -66,11 +66,13 @@ _SIGS = {
     "flanhip_synthesize_dev_fused": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp]),
     "flanhip_synthesize_dev_stages": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _i32, _i32, _vp]),
     "flanhip_debug_option": (None, [_i32, _i32]),
+    "flanhip_debug_kernel_scratch_bytes": (_i32, [_i32]),
     "flanhip_modify_time": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i32, _vp, _i64, _vp, _vp]),
     "flanhip_modify_time_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _i32, _vp, _i64, _vp, _vp]),
     "flanhip_modify_time_dev_fused": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _vp, _i64, _vp, _i32, _vp, _vp]),
     "flanhip_synthesize_dev_fused_checked": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp]),
     "flanhip_stretch_map_dev": (C.c_int, [_vp, _i64, _i32, _f32, _i32, _vp, _vp]),
+    "flanhip_stretch_map_const_dev": (C.c_int, [_f32, _vp, _i64, _i32, _f32, _i32, _vp, _vp]),
     "flanhip_fill_dev": (C.c_int, [_vp, _i64, _f32, _vp]),
     "flanhip_modify_frequency": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
     "flanhip_modify_frequency_dev": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),

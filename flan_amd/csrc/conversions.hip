@@ -733,22 +733,25 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 			FLANHIP_CHECK( hipGetLastError() );
 			}
 		}
-	if( ( stages & 1 ) && presummed != 1 && presummed != 3 )
+	// Chain sums but no group totals (the pre-pass, or a producer that keeps the sums only: PV::modify_time, PV::shape): a small kernel adds
+	// up the groups, and the synthesis kernel works out its carries as above -- instead of the scan over all the chains (config 3: 5 us for 16)
+	const int gsize = self_carry_group( lay.dft, W, lay.hop, lay.chains_per_channel );
+	const bool group_kernel = !self_carry && gsize != 0 && stages == 0xF && !prepass_only && !d_carry_in && !d_total_out && debug_options().syn_variant != 2 && presummed != 3;
+	// ... and where the chain sums are still to be made (or may have been handed over: presummed 2), the pre-pass and that kernel are ONE launch
+	const bool sums_in_group_kernel = group_kernel && presummed != 1;
+	if( ( stages & 1 ) && presummed != 1 && presummed != 3 && !sums_in_group_kernel )
 		{
 		hipLaunchKernelGGL( k_phase_sums2, dim3( (unsigned) chains, (unsigned) ( ( bins + 255 ) / 256 ) ), dim3( 256 ), 0, s, p );
 		FLANHIP_CHECK( hipGetLastError() );
 		}
-	// Chain sums but no group totals (k_phase_sums2 just now, or a producer that keeps the sums only: PV::modify_time, PV::shape): a small kernel adds
-	// up the groups, and the synthesis kernel works out its carries as above -- instead of the scan over all the chains (config 3: 5 us for 16)
-	const int gsize = self_carry_group( lay.dft, W, lay.hop, lay.chains_per_channel );
-	const bool group_kernel = !self_carry && gsize != 0 && stages == 0xF && !prepass_only && !d_carry_in && !d_total_out && debug_options().syn_variant != 2 && presummed != 3;
 	if( group_kernel )
 		{
 		double * gs = reinterpret_cast<double*>( reinterpret_cast<char*>( d_ws ) + lay.group_offset );
 		p.groups_per_channel = lay.groups_per_channel;
 		const dim3 grid( (unsigned) ( ( bins + 255 ) / 256 ), (unsigned) lay.groups_per_channel, (unsigned) ch );
 		FLANHIP_REQUIRE( lay.groups_per_channel <= 65535 && ch <= 65535, FLANHIP_ERR_UNSUPPORTED, "too many groups / channels for one launch" );
-		if( gsize == 8 ) hipLaunchKernelGGL( k_group_sums<8>, grid, dim3( 256 ), 0, s, p, gs ); else hipLaunchKernelGGL( k_group_sums<4>, grid, dim3( 256 ), 0, s, p, gs );
+		if( sums_in_group_kernel ) { if( gsize == 8 ) hipLaunchKernelGGL( k_sums_and_groups<8>, grid, dim3( 256 ), 0, s, p, gs ); else hipLaunchKernelGGL( k_sums_and_groups<4>, grid, dim3( 256 ), 0, s, p, gs ); }
+		else if( gsize == 8 ) hipLaunchKernelGGL( k_group_sums<8>, grid, dim3( 256 ), 0, s, p, gs ); else hipLaunchKernelGGL( k_group_sums<4>, grid, dim3( 256 ), 0, s, p, gs );
 		FLANHIP_CHECK( hipGetLastError() );
 		p.group_sums = gs;
 		const bool scan_groups = p.groups_per_channel > 40;

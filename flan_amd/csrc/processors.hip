@@ -9,6 +9,7 @@
 //   k_shape            : lane = element (no alignment) or wavefront = row (shift alignment: the sequential conflict rule is
 //                        resolved through LDS keys, processors_common.h)
 #include "processors_common.h"
+#include "const_sum.h"
 #include "pv_math.h"
 #include <algorithm>
 
@@ -364,6 +365,67 @@ __global__ __launch_bounds__( kMapThreads ) void k_stretch_map( float * factor, 
 				}
 			}
 		}
+	}
+
+// PV::stretch with a CONSTANT factor (stretch by 2: the everyday call, and what a callable returning a constant samples to): every column of the
+// map is the same running sum of one number, and that sum has a closed form (const_sum.h: a few dozen steps for any frame, bit for bit the
+// sequential additions) -- no grid to fill, nothing to scan: a block computes the values of its kConstRows frames (one thread each) and all its
+// threads write the rows.  The maximum of a monotone sequence sits at one of its ends: block 0 writes it, no atomics and nothing to initialise.
+constexpr int kConstRows = 16;
+// LOG2K >= 0: the host has walked the sum once and hands over its value at every 2^LOG2K-th frame (const_sum.h); -1: every block walks for itself
+// (sums whose runs do not fit: none seen).  K is a template parameter and the marks are the LAST argument so that the address of a block's mark
+// depends on nothing that is itself loaded: every kernel-argument read goes out at once (they sit behind a ~2 us path: as a chain of four dependent
+// reads would queue up).  Measured (tools/time_const_map.py): 12.7 us for 5626 x 1025 -- ~6 us of launch with a 3.9 KB argument and prologue, ~6.5 us of
+// stores -- against 54.5 us for fill + scan.
+template<int LOG2K>
+__global__ __launch_bounds__( 256 ) void k_stretch_map_const( float * map, int64_t F, int bins, float sr, float hop, float * d_max, ConstSumMarks marks )
+	{
+	__shared__ float row_value[kConstRows];
+	const int64_t f0 = int64_t( blockIdx.x ) * kConstRows;
+	const int rows = int( min( int64_t( kConstRows ), F - f0 ) );
+	// frame t's sum from the mark at or below it: fewer than K real additions -- the recurrence itself (PVModify.cpp:376-378)
+	auto sum_at = [&]( int64_t t, int lane_steps )
+		{
+		if constexpr( LOG2K < 0 ) return const_running_sum( marks.c, uint64_t( t + lane_steps ) );
+		else
+			{
+			const int64_t k = t >> LOG2K;
+			float v = marks.at[k];
+			const int steps = int( t - ( k << LOG2K ) ) + lane_steps;
+			const int most = int( t - ( k << LOG2K ) ) + kConstRows - 1;             // (wave-uniform bound)
+			for( int j = 0; j < most; ++j ) v = ( j < steps ) ? v + marks.c : v;
+			return v;
+			}
+		};
+	if( threadIdx.x < 64 )
+		{
+		const float v = sum_at( f0, min( int( threadIdx.x ), kConstRows - 1 ) );
+		if( int( threadIdx.x ) < rows ) row_value[threadIdx.x] = frame_to_time( v, sr, hop );                      // :381-382
+		}
+	if( blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 128 && d_max )
+		{
+		// FunctionSample::maximum (:312) as the scanning kernel forms it: fmaxf over every element from -inf (a NaN never wins); the sequence is monotone
+		const float a = frame_to_time( marks.c, sr, hop ), b = frame_to_time( sum_at( F - 1, 0 ), sr, hop );
+		if( threadIdx.x == 64 ) *d_max = fmaxf( fmaxf( -INFINITY, a ), b );
+		}
+	__syncthreads();
+	// the block's rows are one contiguous run of rows * bins floats: 16-byte stores between a scalar head and tail (a row pitch of 1025 floats
+	// leaves a row 4-byte aligned only); the row of element i by a multiplication (i < 2^23: the float quotient is off by one at most)
+	float * out = map + f0 * bins;
+	const int total = rows * bins;
+	const float inv_bins = 1.0f / float( bins );
+	auto row_of = [&]( int i ) { int r = int( float( i ) * inv_bins ); r -= ( r * bins > i ); r += ( ( r + 1 ) * bins <= i ); return r; };
+	const int head = min( total, int( ( 16u - unsigned( reinterpret_cast<uintptr_t>( out ) & 15u ) ) & 15u ) / 4 );
+	const int quads = ( total - head ) / 4;
+	if( int( threadIdx.x ) < head ) out[threadIdx.x] = row_value[0];
+	for( int k = threadIdx.x; k < quads; k += 256 )
+		{
+		const int i = head + 4 * k;
+		const int r = row_of( i ), left = ( r + 1 ) * bins - i;                       // elements of row r from i on
+		const float a = row_value[r], b = row_value[min( r + 1, rows - 1 )];
+		*reinterpret_cast<float4*>( out + i ) = make_float4( a, left > 1 ? a : b, left > 2 ? a : b, left > 3 ? a : b );
+		}
+	for( int i = head + 4 * quads + threadIdx.x; i < total; i += 256 ) out[i] = row_value[rows - 1];
 	}
 
 // PV::repitch, PVModify.cpp:278-284: inclusive running sum over bins per frame (fp32, sequential), bin_to_frequency.
@@ -842,6 +904,38 @@ int flanhip_stretch_map_dev( float * d_factor, int64_t F, int bins, float sr, in
 	else hipLaunchKernelGGL( k_stretch_map<false>, grid, dim3( kMapThreads ), 0, s, d_factor, F, bins, sr, float( hop ), d_max );
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;
+	}
+
+extern "C" int flanhip_stretch_map_const_dev( float factor, float * d_map, int64_t F, int bins, float sr, int hop, float * d_max, void * stream )
+	{
+	FLANHIP_REQUIRE( d_map && F > 0 && bins > 0 && hop >= 1, FLANHIP_ERR_INVALID_ARG, "bad arguments" );
+	if( int rc = require_device() ) return rc;
+	const int64_t blocks = ( F + kConstRows - 1 ) / kConstRows;
+	FLANHIP_REQUIRE( blocks < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many frames for one launch" );
+	static thread_local ConstSumMarks marks;
+	const bool fits = const_sum_marks( factor, uint64_t( F - 1 ), &marks );
+	if( !fits ) { marks.c = factor; marks.log2K = 0; marks.count = 0; }
+	const dim3 grid( (unsigned) blocks ), block( 256 );
+	hipStream_t st = (hipStream_t) stream;
+	switch( fits ? marks.log2K : -1 )
+		{
+#define FLANHIP_CASE( L ) case L: hipLaunchKernelGGL( k_stretch_map_const<L>, grid, block, 0, st, d_map, F, bins, sr, float( hop ), d_max, marks ); break;
+		FLANHIP_CASE( 4 ) FLANHIP_CASE( 5 ) FLANHIP_CASE( 6 ) FLANHIP_CASE( 7 ) FLANHIP_CASE( 8 ) FLANHIP_CASE( 9 ) FLANHIP_CASE( 10 ) FLANHIP_CASE( 11 ) FLANHIP_CASE( 12 )
+#undef FLANHIP_CASE
+		default: hipLaunchKernelGGL( k_stretch_map_const<-1>, grid, block, 0, st, d_map, F, bins, sr, float( hop ), d_max, marks ); break;
+		}
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+extern "C" int flanhip_debug_kernel_scratch_bytes( int which )
+	{
+	if( int rc = require_device() ) return rc;
+	hipFuncAttributes a{};
+	const void * fn = which == 0 ? reinterpret_cast<const void*>( k_stretch_map<true> ) : which == 1 ? reinterpret_cast<const void*>( k_stretch_map<false> ) : nullptr;
+	FLANHIP_REQUIRE( fn, FLANHIP_ERR_INVALID_ARG, "unknown kernel" );
+	FLANHIP_CHECK( hipFuncGetAttributes( &a, fn ) );
+	return int( a.localSizeBytes );
 	}
 
 static int modify_frequency_dev_impl( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, const float * d_mod,

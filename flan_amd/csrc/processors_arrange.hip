@@ -150,28 +150,28 @@ __global__ __launch_bounds__( 256 ) void k_smear_time( const MFd * in, int64_t F
 	if( b >= bins ) return;
 	const int64_t of = row % Fo, channel = row / Fo;
 	const int64_t in_frame = min( max( of + true_left, int64_t( 0 ) ), F - 1 );       // :569
-	float smear_size_c = smear ? smear[in_frame * bins + b] : smear_const;
-	smear_size_c = smear_size_c < 0.0f ? 0.0f : smear_size_c;                         // :524
-	const int expansion = n_dist > 0 ? max( to_int_sat( time_to_frame( smear_size_c, sr, hop ) ), 0 ) : 0;   // :574 (a NaN size spreads over no frames)
-	const int granularity_c = max( gran ? gran[in_frame * bins + b] : gran_const, 1 );   // :579, :521
-	double mag_sum = 0, freq_sum = 0, total_dist_weight = 0, dist_weight_used = 0;
+	float width_s = smear ? smear[in_frame * bins + b] : smear_const;
+	width_s = width_s < 0.0f ? 0.0f : width_s;                         // :524
+	const int expansion = n_dist > 0 ? max( to_int_sat( time_to_frame( width_s, sr, hop ) ), 0 ) : 0;   // :574 (a NaN size spreads over no frames)
+	const int step = max( gran ? gran[in_frame * bins + b] : gran_const, 1 );   // :579, :521
+	double mag_sum = 0, freq_sum = 0, weight_all = 0, weight_inside = 0;
 	const MFd * col = in + channel * F * bins + b;
-	for( int64_t off = -int64_t( expansion ); off < expansion; off += granularity_c )
+	for( int64_t off = -int64_t( expansion ); off < expansion; off += step )
 		{
-		const float dist_input = frame_to_time( float( int( off ) ), sr, hop ) / smear_size_c;      // :583
-		int access = to_int_sat( float( n_dist ) * 0.5f * ( 1.0f + dist_input ) );                  // :584
+		const float rel_pos = frame_to_time( float( int( off ) ), sr, hop ) / width_s;      // :583
+		int access = to_int_sat( float( n_dist ) * 0.5f * ( 1.0f + rel_pos ) );                  // :584
 		access = min( max( access, 0 ), n_dist - 1 );                                                // :585
-		const float dist_c = dist[access];
-		total_dist_weight += double( dist_c );
+		const float w_tap = dist[access];
+		weight_all += double( w_tap );
 		const int64_t source = of + true_left + off;                                  // :589
 		if( source < 0 || source >= F ) continue;
-		const MFd mf_c = col[source * bins];
-		dist_weight_used += double( dist_c );
-		mag_sum += double( mf_c.m * dist_c );                                         // :594-595
-		freq_sum += double( mf_c.f * dist_c );
+		const MFd src_mf = col[source * bins];
+		weight_inside += double( w_tap );
+		mag_sum += double( src_mf.m * w_tap );                                         // :594-595
+		freq_sum += double( src_mf.f * w_tap );
 		}
-	if( total_dist_weight > 0.0 ) mag_sum /= total_dist_weight;                       // :600-601
-	if( dist_weight_used > 0.0 ) freq_sum /= dist_weight_used;
+	if( weight_all > 0.0 ) mag_sum /= weight_all;                       // :600-601
+	if( weight_inside > 0.0 ) freq_sum /= weight_inside;
 	out[row * bins + b] = MFd{ float( mag_sum ), float( freq_sum ) };
 	}
 
@@ -194,36 +194,36 @@ __device__ __forceinline__ int quad_point( const Quad & q, int xi, int yi, int i
 	{
 	const float * px = q.px; const float * py = q.py;
 	const float x = float( xi ), y = float( yi );
-	const float D12x = px[1] - px[0], D12y = py[1] - py[0];                            // :87-90
-	const float D23x = px[2] - px[1], D23y = py[2] - py[1];
-	const float D34x = px[3] - px[2], D34y = py[3] - py[2];
-	const float D41x = px[0] - px[3], D41y = py[0] - py[3];
+	const float e01x = px[1] - px[0], e01y = py[1] - py[0];                            // :87-90
+	const float e12x = px[2] - px[1], e12y = py[2] - py[1];
+	const float e23x = px[3] - px[2], e23y = py[3] - py[2];
+	const float e30x = px[0] - px[3], e30y = py[0] - py[3];
 	bool c = false;                                                                   // :105-109
-	if( ( ( py[0] <= y && y < py[3] ) || ( py[3] <= y && y < py[0] ) ) && ( x < D41x / D41y * ( y - py[0] ) + px[0] ) ) c = !c;
-	if( ( ( py[1] <= y && y < py[0] ) || ( py[0] <= y && y < py[1] ) ) && ( x < D12x / D12y * ( y - py[1] ) + px[1] ) ) c = !c;
-	if( ( ( py[2] <= y && y < py[1] ) || ( py[1] <= y && y < py[2] ) ) && ( x < D23x / D23y * ( y - py[2] ) + px[2] ) ) c = !c;
-	if( ( ( py[3] <= y && y < py[2] ) || ( py[2] <= y && y < py[3] ) ) && ( x < D34x / D34y * ( y - py[3] ) + px[3] ) ) c = !c;
+	if( ( ( py[0] <= y && y < py[3] ) || ( py[3] <= y && y < py[0] ) ) && ( x < e30x / e30y * ( y - py[0] ) + px[0] ) ) c = !c;
+	if( ( ( py[1] <= y && y < py[0] ) || ( py[0] <= y && y < py[1] ) ) && ( x < e01x / e01y * ( y - py[1] ) + px[1] ) ) c = !c;
+	if( ( ( py[2] <= y && y < py[1] ) || ( py[1] <= y && y < py[2] ) ) && ( x < e12x / e12y * ( y - py[2] ) + px[2] ) ) c = !c;
+	if( ( ( py[3] <= y && y < py[2] ) || ( py[2] <= y && y < py[3] ) ) && ( x < e23x / e23y * ( y - py[3] ) + px[3] ) ) c = !c;
 	if( !c ) return 0;
 	const float a0 = px[0], a1 = px[1] - px[0], a2 = px[3] - px[0], a3 = px[0] - px[1] + px[2] - px[3];   // :116-117
 	const float b0 = py[0], b1 = py[1] - py[0], b2 = py[3] - py[0], b3 = py[0] - py[1] + py[2] - py[3];
-	const float quadA = a3 * b2 - a2 * b3;                                            // :119-124
-	const float quadB = a3 * b0 - a0 * b3 + a1 * b2 - a2 * b1 + x * b3 - a3 * y;
-	const float quadC = a1 * b0 - a0 * b1 + x * b1 - a1 * y;
+	const float qa = a3 * b2 - a2 * b3;                                            // :119-124
+	const float qb = a3 * b0 - a0 * b3 + a1 * b2 - a2 * b1 + x * b3 - a3 * y;
+	const float qc = a1 * b0 - a0 * b1 + x * b1 - a1 * y;
 	float m;
-	if( quadA == 0.0f )                                                               // :126-138
+	if( qa == 0.0f )                                                               // :126-138
 		{
-		if( quadB == 0.0f ) return 1;
-		m = -quadC / quadB;
+		if( qb == 0.0f ) return 1;
+		m = -qc / qb;
 		}
 	else
 		{
-		const float descriminant = quadB * quadB - 4.0f * quadA * quadC;
-		if( descriminant < 0.0f ) return 1;
-		m = float( ( double( -quadB ) + sqrt( double( descriminant ) ) ) / double( 2.0f * quadA ) );
+		const float disc = qb * qb - 4.0f * qa * qc;
+		if( disc < 0.0f ) return 1;
+		m = float( ( double( -qb ) + sqrt( double( disc ) ) ) / double( 2.0f * qa ) );
 		}
-	const float lDenominator = a1 + a3 * m;                                           // :139-141
-	if( lDenominator == 0.0f ) return 1;
-	const float l = ( x - a0 - a2 * m ) / lDenominator;
+	const float den_l = a1 + a3 * m;                                           // :139-141
+	if( den_l == 0.0f ) return 1;
+	const float l = ( x - a0 - a2 * m ) / den_l;
 	const float epsilon = 0.0001f;                                                    // :144-145
 	if( fabsf( l - 0.5f ) > 0.5f + epsilon || fabsf( m - 0.5f ) > 0.5f + epsilon ) return 1;
 	const float interpL = interpolate( interp_kind, l ), interpM = interpolate( interp_kind, m );   // :147-148

@@ -758,7 +758,11 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 				run[b] = fold( run[b] + vc[b][w] );
 				}
 			}
-		if( tid == 0 && blockIdx.x == 0 && p.nan_in && p.nan_flag && p.nan_in[0] == p.nan_in[2] && p.nan_in[2] != 0 ) atomicOr( p.nan_flag, 1 );
+		if( tid == 0 && blockIdx.x == 0 )
+			{
+			if( p.nan_in && p.nan_flag && p.nan_in[0] == p.nan_in[2] && p.nan_in[2] != 0 ) atomicOr( p.nan_flag, 1 );
+			if( p.skip_words ) const_cast<int*>( p.skip_words )[4] = 0;              // a handed-over pre-pass is good for one convert_to_audio (k_sums_and_groups has read the word: a launch ago)
+			}
 		__syncthreads();
 		const double * mine = reinterpret_cast<const double*>( buf0 );
 		auto slot = [&]( int bin ) { return team_stage_slot<!DOUBLE>( bin, 2 * L::BUF_LEN ); };

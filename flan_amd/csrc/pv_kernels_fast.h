@@ -723,6 +723,76 @@ __global__ __launch_bounds__( 256 ) void k_group_sums( SynthParams p, double * o
 	out[( int64_t( channel ) * p.groups_per_channel + group ) * p.num_bins + bin] = run;
 	}
 
+// k_phase_sums2 and k_group_sums in one launch, for a convert_to_audio that may or may not have been handed its pre-pass
+// (flanhip_synthesize_dev_fused_checked behind PV::modify_time / PV::stretch): when the producer's words say the chain sums are there this is
+// k_group_sums; when they do not, a thread first sums its bin over the frames of each of its group's chains -- k_phase_sums2's additions in its
+// order, its NaN / Inf scan -- and leaves them in `carry` like that kernel.  The word is NOT taken back here (other blocks are still reading it): the
+// synthesis kernel's carry prologue does that (skip_words), one launch later.
+template<int GSIZE>
+__global__ __launch_bounds__( 256 ) void k_sums_and_groups( SynthParams p, double * out )
+	{
+	const int bin = blockIdx.x * 256 + threadIdx.x;
+	const bool handed = p.skip_words && p.skip_words[4] == p.skip_words[2] && p.skip_words[2] != 0;
+	const int group = blockIdx.y, channel = blockIdx.z;
+	const int live = min( GSIZE, p.chains_per_channel - group * GSIZE );
+	bool bad = false;
+	if( bin < p.num_bins )
+		{
+		double * sums = p.carry + ( int64_t( channel ) * p.chains_per_channel + int64_t( group ) * GSIZE ) * p.num_bins + bin;
+		double v[GSIZE];
+		if( handed )
+			{
+			#pragma unroll
+			for( int w = 0; w < GSIZE; ++w ) v[w] = ( w < live ) ? sums[int64_t( w ) * p.num_bins] : 0.0;
+			}
+		else
+			{
+			for( int w = 0; w < GSIZE; ++w )
+				{
+				v[w] = 0.0;
+				if( w >= live ) continue;
+				const int64_t t0 = ( int64_t( group ) * GSIZE + w ) * p.L;
+				const int n = int( min( t0 + int64_t( p.L ), p.F ) - t0 );
+				const cf * col = reinterpret_cast<const cf*>( p.pv + ( int64_t( channel ) * p.F + t0 ) * p.num_bins + bin );
+				double ph = 0.0;
+				int i = 0;
+				for( ; i + 8 <= n; i += 8 )                                            // (k_phase_sums2, statement for statement)
+					{
+					cf x[8];
+					#pragma unroll
+					for( int u = 0; u < 8; ++u ) x[u] = col[int64_t( i + u ) * p.num_bins];
+					#pragma unroll
+					for( int u = 0; u < 8; ++u )
+						{
+						bad |= !( __builtin_fabsf( x[u].x ) <= 3.4028235e38f ) || !( __builtin_fabsf( x[u].y ) <= 3.4028235e38f );
+						ph += double( div_c( x[u].y, p.ar_div ) * FLANHIP_PI2_F );
+						}
+					if( !( __builtin_fabs( ph ) < 1.0e8 ) ) ph = fold_phase_any( ph );
+					}
+				for( ; i < n; ++i )
+					{
+					const cf x = col[int64_t( i ) * p.num_bins];
+					bad |= !( __builtin_fabsf( x.x ) <= 3.4028235e38f ) || !( __builtin_fabsf( x.y ) <= 3.4028235e38f );
+					ph += double( div_c( x.y, p.ar_div ) * FLANHIP_PI2_F );
+					}
+				v[w] = ( __builtin_fabs( ph ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( ph ) : fold_phase_any( ph );
+				sums[int64_t( w ) * p.num_bins] = v[w];
+				}
+			}
+		double run = 0.0;
+		#pragma unroll
+		for( int w = 0; w < GSIZE; ++w )
+			if( w < live )
+				{
+				const double t = run + v[w];
+				run = ( __builtin_fabs( t ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( t ) : fold_phase_any( t );
+				}
+		out[( int64_t( channel ) * p.groups_per_channel + group ) * p.num_bins + bin] = run;
+		}
+	const bool any_bad = __any( bad );
+	if( p.nan_flag && any_bad && ( threadIdx.x & 63 ) == 0 ) atomicOr( p.nan_flag, 1 );
+	}
+
 // Exclusive scan of the chain sums along each channel, per bin (modular addition is associative, so the scan is cut in
 // SEG segments: 512 / SEG bins x SEG segments per block; each thread sums its segment, the segment totals are scanned through LDS,
 // then each thread rewrites its segment as exclusive prefixes).  carry[c] = phase_buffer on entry to chain c.

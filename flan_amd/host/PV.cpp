@@ -304,12 +304,24 @@ PV PV::stretch( const Function<TF, float> & factor, const Interpolator & interp 
 	if( is_null() ) return PV();
 	const DeviceInterp device_interp( interp );                                      // named kind, or the callable sampled into a table
 	if( !device_interp.ok() ) return PV();
-	auto d_grid = function_grid_to_device( *this, factor );                        // PVModify.cpp:373
 	auto d_max = DeviceBlock::allocate( sizeof( float ) );
-	if( !d_grid || !d_max ) return PV();
-	// :376-382 running sum over frames per bin, frame_to_time -- on the device, plus the maximum modify_time_base needs
-	if( !detail::report( flanhip_stretch_map_dev( static_cast<float*>( d_grid->ptr ), get_num_frames(), get_num_bins(), get_sample_rate(), get_hop_size(),
-			static_cast<float*>( d_max->ptr ), nullptr ), "stretch" ) ) return PV();
+	std::shared_ptr<DeviceBlock> d_grid;
+	if( factor.is_constant() )
+		{
+		// a constant factor: the map from the number alone (the running sum of a constant in closed form, csrc/const_sum.h) -- no grid, no scan
+		d_grid = DeviceBlock::allocate( sizeof( float ) * size_t( get_num_frames() ) * get_num_bins() );
+		if( !d_grid || !d_max ) return PV();
+		if( !detail::report( flanhip_stretch_map_const_dev( factor.get_constant(), static_cast<float*>( d_grid->ptr ), get_num_frames(), get_num_bins(), get_sample_rate(),
+				get_hop_size(), static_cast<float*>( d_max->ptr ), nullptr ), "stretch" ) ) return PV();
+		}
+	else
+		{
+		d_grid = function_grid_to_device( *this, factor );                           // PVModify.cpp:373
+		if( !d_grid || !d_max ) return PV();
+		// :376-382 running sum over frames per bin, frame_to_time -- on the device, plus the maximum modify_time_base needs
+		if( !detail::report( flanhip_stretch_map_dev( static_cast<float*>( d_grid->ptr ), get_num_frames(), get_num_bins(), get_sample_rate(), get_hop_size(),
+				static_cast<float*>( d_max->ptr ), nullptr ), "stretch" ) ) return PV();
+		}
 	float mx = 0.0f;
 	flanhip_memcpy_d2h( &mx, d_max->ptr, sizeof( float ), nullptr );
 	if( !detail::report( flanhip_stream_synchronize( nullptr ), "stretch" ) ) return PV();

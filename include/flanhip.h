@@ -172,6 +172,10 @@ int flanhip_synthesize_dev_stages(const flanhip_MF * d_pv, int64_t num_channels,
 #define FLANHIP_DEBUG_WIDE_OFFSETS   11   /* 1: kernels that choose 32-bit element offsets for grids below 2^30 elements (k_stretch_map) take their 64-bit
                                            * form whatever the size: the path of multi-gigabyte grids, testable on small ones */
 void flanhip_debug_option(int which, int value);
+/* Scratch (private memory) bytes per lane of a kernel whose hand-counted s_waitcnt values are only right while the compiler emits no memory
+ * operation of its own on that path -- a spill or reload is one (tests/test_gpu_processors.py holds them to 0).  which: 0 / 1 = k_stretch_map with
+ * 32-bit / 64-bit row offsets.  Negative: error. */
+int flanhip_debug_kernel_scratch_bytes(int which);
 
 /* ---- PV frame processors ------------------------------------------------------------------------------------- */
 /* modify_time_base (PV/PVModify.cpp:307-362, linear Interpolator): mod_seconds is the sampled time map float[F][bins]
@@ -184,8 +188,8 @@ int flanhip_modify_time_dev(const flanhip_MF * d_pv, int64_t num_channels, int64
                             float sample_rate, int hop, const float * d_mod_seconds,
                             int64_t out_frames, flanhip_MF * d_out, void * stream);
 /* PV::stretch front half (PV/PVModify.cpp:371-382): in-place inclusive prefix sum over frames per bin (fp32, sequential
- * order) then frame_to_time.  d_factor: float[F][bins] factor grid in, seconds out.
- * flanhip_stretch_max_dev also reduces the maximum of the result into *d_max (float). */
+ * order) then frame_to_time.  d_factor: float[F][bins] factor grid in, seconds out; flanhip_stretch_map_dev (below) also
+ * reduces the maximum of the result into *d_max (float) when that pointer is given. */
 /* modify_time for a PV that goes on to convert_to_audio: d_workspace is a synthesis workspace for the OUTPUT PV
  * (flanhip_synthesize_workspace_bytes( ch, out_frames, bins, sr, analysis_rate, window_size ); hop = int( sr / analysis_rate )).  When the time map never runs
  * backwards (every stretch) the kernel that writes the output also leaves convert_to_audio's pre-pass there;
@@ -195,7 +199,12 @@ int flanhip_modify_time_dev_fused(const flanhip_MF * d_pv, int64_t num_channels,
                                   flanhip_MF * d_out, int window_size, void * d_workspace, void * stream);
 int flanhip_stretch_map_dev(float * d_factor, int64_t num_pv_frames, int num_bins, float sample_rate, int hop,
                             float * d_max, void * stream);
-/* PV::stretch with a constant-valued callable (what `[](TF){ return c; }` samples to): builds the grid on device. */
+/* PV::stretch with a CONSTANT factor: the whole map (running sum down the frames + frame_to_time, and its maximum) from the factor alone -- the sum
+ * of a constant has a closed form that reproduces the sequential fp32 additions bit for bit (flan_amd/csrc/const_sum.h), so nothing is filled and
+ * nothing is scanned.  d_map: float[F][bins] out.  Same result as flanhip_fill_dev + flanhip_stretch_map_dev. */
+int flanhip_stretch_map_const_dev(float factor, float * d_map, int64_t num_pv_frames, int num_bins, float sample_rate, int hop,
+                                  float * d_max, void * stream);
+/* A grid filled with one value on the device (a constant-valued Function, sampled: `[](TF){ return c; }`). */
 int flanhip_fill_dev(float * d_grid, int64_t count, float value, void * stream);
 
 /* modify_frequency_base (PV/PVModify.cpp:196-257): mod_hz float[F][bins] = where each grid bin centre maps;

@@ -562,3 +562,48 @@ def test_handed_over_prepass_is_consumed_once_with_many_chains(fa):
     want = d_out.to_host((ch, Fo * hop))
     assert np.abs(first - want).max() > 1e-3                                         # (the two PVs do sound different)
     assert np.array_equal(second.view(np.uint32), want.view(np.uint32))
+
+
+def test_stretch_map_kernel_has_no_spills_and_survives_odd_grids(fa):
+    """k_stretch_map's movers wait with hand-counted s_waitcnt vmcnt values (processors_common.h: column_scan_piped): right only while the compiler
+    adds no memory operation of its own on that path -- a register spill is one and would let a wait pass before its rows have arrived.  So: no
+    scratch in either instantiation, and the map bit for bit the oracle's on grids around every tile edge (224 frames x 16 bins, three tiles in
+    flight) with both offset widths (the 400-grid form of this run: tools/stress_stretch_map.py)."""
+    import ctypes
+    lib = fa.lib
+    assert lib.flanhip_debug_kernel_scratch_bytes(0) == 0
+    assert lib.flanhip_debug_kernel_scratch_bytes(1) == 0
+    rng = np.random.default_rng(7)
+    for it in range(90):
+        F = int(rng.choice([1, 2, 3, 223, 224, 225, 447, 448, 449, 671, 672, 673, 895, 896, 897])) if rng.random() < 0.4 else int(rng.integers(1, 3000))
+        bins = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 257, 513, 1025, 2049])) if rng.random() < 0.5 else int(rng.integers(1, 1300))
+        g = rng.uniform(0.05, 4.0, (F, bins)).astype(np.float32)
+        ref = O.stretch_map(g, 48000.0, 256)
+        d, dm = fa.DeviceArray(host=g), fa.DeviceArray(host=np.zeros(1, np.float32))
+        with fa.debug_options(wide_offsets=int(rng.random() < 0.25)):
+            fa.check(lib.flanhip_stretch_map_dev(ctypes.c_void_p(d.ptr), F, bins, 48000.0, 256, ctypes.c_void_p(dm.ptr), None))
+        got, mx = d.to_host((F, bins)), dm.to_host((1,))
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (F, bins)
+        assert mx[0] == ref.max(), (F, bins)
+
+
+@pytest.mark.parametrize("F,bins", [(1, 1), (469, 1025), (5626, 1025), (37, 65), (3000, 257), (100000, 9)])
+def test_constant_stretch_map_in_closed_form(fa, F, bins):
+    """flanhip_stretch_map_const_dev: the map of a CONSTANT factor from the number alone -- the running fp32 sum of a constant reproduced without running
+    it (flan_amd/csrc/const_sum.h; tools/check_const_sum.cpp checks it step by step on the CPU) -- against the checker's sequential scan of the filled
+    grid and against the scanning kernel, bit for bit, maximum included: everyday factors, ties, sums that stand still, negative and denormal ones."""
+    import ctypes
+    lib = fa.lib
+    for c in (2.0, 0.5, 1.3, 0.7, 3.0, 1.0 / 3.0, 1e-3, 123.456, -1.5, 0.0, 8388607.5, 1e-40, 3e37):
+        g = np.full((F, bins), c, np.float32)
+        with np.errstate(over="ignore"):
+            ref = O.stretch_map(g, 48000.0, 256)
+        d, dm = fa.DeviceArray(F * bins * 4), fa.DeviceArray(host=np.full(1, 77.0, np.float32))
+        fa.check(lib.flanhip_stretch_map_const_dev(c, ctypes.c_void_p(d.ptr), F, bins, 48000.0, 256, ctypes.c_void_p(dm.ptr), None))
+        got, mx = d.to_host((F, bins)), dm.to_host((1,))
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (c, F, bins)
+        assert mx[0] == ref.max(), (c, F, bins)
+        d2, dm2 = fa.DeviceArray(host=g), fa.DeviceArray(host=np.zeros(1, np.float32))
+        fa.check(lib.flanhip_stretch_map_dev(ctypes.c_void_p(d2.ptr), F, bins, 48000.0, 256, ctypes.c_void_p(dm2.ptr), None))
+        assert np.array_equal(d2.to_host((F, bins)).view(np.uint32), got.view(np.uint32)), (c, F, bins)
+        assert dm2.to_host((1,))[0] == mx[0], (c, F, bins)

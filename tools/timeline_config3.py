@@ -34,8 +34,11 @@ ws = torch.empty(fa.synthesize_workspace_bytes(ch, Fo, BINS, SR, ar, W), dtype=t
 
 def config3():
     fa.check(lib.flanhip_analyze_dev(P(audio), ch, n, SR, W, HOP, DFT, P(pv), None))
-    fa.check(lib.flanhip_fill_dev(P(grid), F * BINS, 2.0, None))
-    fa.check(lib.flanhip_stretch_map_dev(P(grid), F, BINS, SR, HOP, P(dmax), None))
+    if "--grid" in sys.argv:                   # the general path (a sampled callable): a filled grid, scanned
+        fa.check(lib.flanhip_fill_dev(P(grid), F * BINS, 2.0, None))
+        fa.check(lib.flanhip_stretch_map_dev(P(grid), F, BINS, SR, HOP, P(dmax), None))
+    else:                                      # bench.py's config 3: the constant factor's map in closed form
+        fa.check(lib.flanhip_stretch_map_const_dev(2.0, P(grid), F, BINS, SR, HOP, P(dmax), None))
     fa.check(lib.flanhip_modify_time_dev_fused(P(pv), ch, F, BINS, SR, ar, P(grid), Fo, P(st), W, P(ws), None))
     fa.check(lib.flanhip_synthesize_dev_fused_checked(P(st), ch, Fo, BINS, SR, ar, W, P(out), P(ws), None, None))
 
