@@ -701,7 +701,12 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	p.skip_words = presummed == 2 ? p.nan_in : nullptr;
 	p.carry_in = d_carry_in; p.total_out = d_total_out; p.total_only = prepass_only ? 1 : 0;
 	p.cancel = thread_cancel_word( s );
-	const bool self_fix = lay.fix_offset != 0 && debug_options().inline_fixup && !prepass_only;     // (off by default: built and measured, no faster -- DESIGN 4.0001)
+	// the dft 2048 synthesis kernel adds the chains' overlaps itself where its chains are long enough to publish their heads from inside the frame
+	// loop (round 5: -2 % of the bench shape's step, -6 % of the stereo minute's; chains of a few frames would publish at their ends and pay
+	// the exchange there: +8 % at 1 ch x 5 s, so those keep k_ola_fixup as a launch of its own).  FLANHIP_DEBUG_INLINE_FIXUP: 1 always, 2 never.
+	const int fix_hook = debug_options().inline_fixup;
+	const bool self_fix = lay.fix_offset != 0 && !prepass_only && ( stage_mask & 0xF ) == 0xF && fix_hook != 2
+		&& ( fix_hook == 1 || lay.L >= ( lay.head_len + lay.hop - 1 ) / lay.hop + 3 );
 	if( self_fix )
 		{
 		p.fix_state = reinterpret_cast<int*>( reinterpret_cast<char*>( d_ws ) + lay.fix_offset );

@@ -836,9 +836,46 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 	bins_of_row();
 	int64_t pos = chain_start;
 	int rel = 0;                                                                // pos - chain_start: the same number in every wavefront, a scalar
-	for( int i = 0; i < nf; ++i )
+	// ---- the overlaps of neighbouring chains added here instead of by a launch of their own (k_ola_fixup: a launch and two round trips to memory
+	// behind every convert_to_audio; p.fix_state set).  The W - hop samples at a boundary get the LAST partial sums of the chain before it (in its
+	// `acc` when it ends) and the FIRST ones of the chain after it (in its `head` buffer since its first frames).  One word per boundary, tagged with
+	// the launch's epoch, written by atomic exchange; whoever finds the other side's tag there adds the two halves, so no wavefront ever waits for
+	// another and the order in which blocks are scheduled cannot matter.  Round 5: the head's owner publishes INSIDE its frame loop, as soon as the
+	// loop's own counted wait has proven the head's stores acknowledged (memory operations retire in order) -- in a launch of one round that is
+	// ~100 us before its neighbour ends; the tail's owner reads the word one frame before its last (the answer arrives under that frame's row wait),
+	// requests the head under its LAST transform and adds it to its accumulator as it leaves: no exchange, no round trip at the end of the launch
+	// (round 4's form -- both sides at their ends -- cost the launch the 5-7 us the separate kernel took).  The halves cross XCDs inside a launch:
+	// written and read at agent scope (st_agent / ld_agent).  One addition per sample, tail + head, as k_ola_fixup does it: the same bits.
+	const int tag_tail = p.fix_tag | 1, tag_head = p.fix_tag | 2;
+	const int nsteps = p.head_len / 128;                                        // steps of 128 samples a boundary holds (W - hop, a multiple of 128 here)
+	const bool has_head = chain_in_channel != 0, has_tail = !last_chain;
+	int * const word_h = p.fix_state + chain, * const word_t = p.fix_state + ( chain + 1 );      // (used under `fix` only)
+	const cf * const head_next = reinterpret_cast<const cf*>( p.head + ( chain + 1 ) * p.head_len ) + lane;
+	const int i_pub = ( p.head_len + hop - 1 ) / hop;                           // the frame whose row wait proves the head's stores have landed
+	int old_h = 0, seen_t = 0;                                                  // (lane 0's: what the head word held before this chain's tag; what the tail word holds)
+	bool published = false;
+	cf hx[E];                                                                   // the next chain's head (the last frame only: in the registers the MF rows leave)
+	auto frame_step = [&]( int i, auto last_tag ) -> bool
 		{
-		load_row( relf0 + min( i + 1, nf - 1 ) );                               // (the last frame requests itself again: nobody waits for it)
+		constexpr bool LAST = decltype( last_tag )::value;
+		bool have_head = false;
+		if constexpr( LAST )
+			{
+			if( fix && has_tail )
+				{
+				have_head = __builtin_amdgcn_readfirstlane( seen_t ) == tag_head;        // the neighbour's head was complete a frame ago
+				if( have_head )
+					{
+					#pragma unroll
+					for( int q = 0; q < E; ++q ) hx[q] = ( q < nsteps ) ? ld_agent( head_next + 64 * q ) : mk( 0.0f, 0.0f );
+					}
+				}
+			}
+		else
+			{
+			load_row( relf0 + i + 1 );
+			if( fix && has_tail && i == nf - 2 && lane == 0 ) seen_t = __hip_atomic_load( word_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+			}
 		if constexpr( ( ABL & 8 ) == 0 )                                        // ABL 8 (timing only): no transform
 		fft_fast<10>( z, buf, s_tw1, s_tw3, lane );
 		// ---- G = fft( conj Z ): x[2n] = G[n].x, x[2n+1] = -G[n].y; window and overlap-add (AudioPV.cpp:122-134)
@@ -867,8 +904,22 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 		for( int q = 0; q < E; ++q ) acc[q] = ( q + HOPQ < E ) ? acc[q + HOPQ] : mk( 0.0f, 0.0f );
 		pos += hop;
 		rel += hop;
-		if( i + 1 < nf ) bins_of_row();
-		}
+		if constexpr( !LAST )
+			{
+			bins_of_row();
+			if( fix && has_head && i == i_pub )
+				{
+				// the wait for row i + 1 has retired every store issued before that row was requested: the head's among them
+				asm volatile( "" ::: "memory" );
+				if( lane == 0 ) old_h = __hip_atomic_exchange( word_h, tag_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+				asm volatile( "" ::: "memory" );
+				published = true;
+				}
+			}
+		return have_head;
+		};
+	for( int i = 0; i + 1 < nf; ++i ) frame_step( i, std::false_type{} );
+	const bool have_head = frame_step( nf - 1, std::true_type{} );
 	// flush the partial sums that the next chain's head completes; the last chain zero-fills to the end of the output
 	const int64_t ring_end = pos + ( W - hop );
 	const int64_t flush_end = last_chain ? max( ring_end, p.out_len ) : ring_end;
@@ -882,62 +933,48 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 			}
 		for( int64_t a0 = pos + 128 * E; a0 < flush_end; a0 += 128 ) emit_step( a0, mk( 0.0f, 0.0f ) );
 		}
-	// ---- the overlaps of neighbouring chains, added here instead of by a launch of their own (k_ola_fixup: a launch and two round trips to
-	// memory behind every convert_to_audio).  The W - hop samples at a boundary get the LAST partial sums of the chain before it (still in
-	// `acc` here) and the FIRST ones of the chain after it (in its `head` buffer since its first frames).  Whichever of the two wavefronts
-	// reaches its end second adds them up -- nobody waits for anybody, so the order in which blocks are scheduled cannot matter: a state
-	// word per boundary, written with an atomic exchange; the first to arrive leaves its half where the other finds it (the tail in `tail`;
-	// the head is in `head` already) BEHIND a drained memory queue, the second sees the first's tag in what the exchange returns.  The
-	// two halves cross XCDs inside a launch: they are written and read at agent scope (st_agent / ld_agent), past the L2s.  One addition
-	// per sample, tail + head, as k_ola_fixup does it: the same bits.
 	if( fix )
 		{
-		const int tag_tail = p.fix_tag | 1, tag_head = p.fix_tag | 2;
-		const int nsteps = p.head_len / 128;                                        // steps of 128 samples a boundary holds (W - hop, a multiple of 128 here)
-		// both of this wavefront's boundaries at once: its head's tag goes out (the head landed frames ago: memory operations retire in order, and
-		// the queue is drained here anyway) while the word of the boundary behind its tail is read -- one round trip for the two
-		int * const word_h = p.fix_state + chain, * const word_t = p.fix_state + ( chain + 1 );
-		const bool has_head = chain_in_channel != 0, has_tail = !last_chain;
-		asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
-		int old_h = 0, seen_t = 0;
-		if( lane == 0 )
+		if( has_head && !published )
 			{
-			if( has_head ) old_h = __hip_atomic_exchange( word_h, tag_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-			if( has_tail ) seen_t = __hip_atomic_load( word_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+			// a chain too short to have published from its loop: now, behind a drained queue
+			asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+			if( lane == 0 ) old_h = __hip_atomic_exchange( word_h, tag_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
 			}
-		old_h = __builtin_amdgcn_readfirstlane( old_h );
-		seen_t = __builtin_amdgcn_readfirstlane( seen_t );
 		if( has_tail )
 			{
 			// this chain's tail meets the next chain's head
-			const cf * head_next = reinterpret_cast<const cf*>( p.head + ( chain + 1 ) * p.head_len ) + lane;
 			cf * tail_next = reinterpret_cast<cf*>( p.tail + ( chain + 1 ) * p.head_len ) + lane;
-			bool add = seen_t == tag_head;                                            // the next chain is done already: its head is there to be added
+			bool add = have_head;
 			if( !add )
 				{
+				// the neighbour had not published a frame ago (a launch of several rounds, a chain of one frame): leave the tail where it will
+				// find it, BEHIND a drained queue, and say so; if its tag has appeared meanwhile the addition is ours after all
 				#pragma unroll
 				for( int q = 0; q < E; ++q ) if( q < nsteps ) st_agent( tail_next + 64 * q, acc[q] );
-				asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );                    // the tail has landed before the word says so
+				asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
 				int old = 0;
 				if( lane == 0 ) old = __hip_atomic_exchange( word_t, tag_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
-				add = __builtin_amdgcn_readfirstlane( old ) == tag_head;              // (it arrived meanwhile and left the addition to us)
+				add = __builtin_amdgcn_readfirstlane( old ) == tag_head;
+				if( add )
+					{
+					#pragma unroll
+					for( int q = 0; q < E; ++q ) hx[q] = ( q < nsteps ) ? ld_agent( head_next + 64 * q ) : mk( 0.0f, 0.0f );
+					}
 				}
 			if( add )
 				{
-				cf h[E];
-				#pragma unroll
-				for( int q = 0; q < E; ++q ) h[q] = ( q < nsteps ) ? ld_agent( head_next + 64 * q ) : mk( 0.0f, 0.0f );
 				#pragma unroll
 				for( int q = 0; q < E; ++q )
 					{
 					const int64_t a = pos + 128 * q + 2 * lane;
-					if( q < nsteps && a >= 0 && a < p.out_len ) out2[a >> 1] = mk( acc[q].x + h[q].x, acc[q].y + h[q].y );
+					if( q < nsteps && a >= 0 && a < p.out_len ) out2[a >> 1] = mk( acc[q].x + hx[q].x, acc[q].y + hx[q].y );
 					}
 				}
 			}
-		if( has_head && old_h == tag_tail )
+		if( has_head && __builtin_amdgcn_readfirstlane( old_h ) == tag_tail )
 			{
-			// this chain's head meets the previous chain's tail, which was there first
+			// this chain's head meets the previous chain's tail, which was there when the head's tag went out
 			const cf * tl = reinterpret_cast<const cf*>( p.tail + chain * p.head_len ) + lane;
 			const cf * hd = head2 + lane;
 			#pragma unroll 4

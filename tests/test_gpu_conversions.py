@@ -722,12 +722,16 @@ def test_plan_caches_are_bounded_and_evicted_sizes_come_back(fa):
     (2, 60, 2048, 128, {}),                                   # stereo, hop 128 (15 steps per boundary), the scan kernel's layout
     (3, 20, 1024, 256, {"target_chains": 4096}),              # a short window, twice the resident chains
     (5, 33, 2048, 1024, {}),
+    (2, 10, 2048, 512, {"chain_len": 3}),                     # chains too short to publish their heads from inside the loop: the exchange at their ends
+    (2, 10, 2048, 512, {"chain_len": 4}),
+    (3, 7, 2048, 512, {"chain_len": 5}),                      # the head's tag goes out in the last frame but one
+    (1, 30, 2048, 256, {"chain_len": 9}),
 ])
 def test_overlap_fixup_inside_the_kernel_equals_the_separate_launch(fa, ch, seconds, W, hop, hooks):
-    """With the inline_fixup hook k_synthesize_v2 adds the overlaps of neighbouring chains itself (whichever of the two wavefronts at a boundary
-    ends second does it, through agent-scope side buffers and a state word per boundary: pv_kernels_v2.h) instead of k_ola_fixup in a launch
-    of its own (the default: the in-kernel form measured no faster).  One addition per sample either way: the outputs must be the same bits,
-    launch after launch."""
+    """k_synthesize_v2 adds the overlaps of neighbouring chains itself (a tagged word per boundary; the head's owner publishes from inside its frame
+    loop, the tail's owner picks the head up under its last transform; whoever finds the other's tag adds -- agent-scope side buffers:
+    pv_kernels_v2.h) where its chains are long enough (the library's choice, hook 0), always (hook 1) or never (hook 2: k_ola_fixup in a launch of
+    its own).  One addition per sample either way: the outputs must be the same bits, launch after launch."""
     import ctypes
     import torch
     dev = torch.device("cuda", 0)
@@ -745,11 +749,12 @@ def test_overlap_fixup_inside_the_kernel_equals_the_separate_launch(fa, ch, seco
     out_b = torch.empty_like(out_a)
     with fa.debug_options(**hooks):
         ws = torch.empty(fa.synthesize_workspace_bytes(ch, F, bins, sr, ar, W), dtype=torch.uint8, device=dev)
-        fa.synthesize_dev(pv, ch, F, bins, sr, ar, W, out_b, ws, None)
+        with fa.debug_options(inline_fixup=2):
+            fa.synthesize_dev(pv, ch, F, bins, sr, ar, W, out_b, ws, None)
         torch.cuda.synchronize()
-        for rep in range(6):
+        for rep in range(8):
             out_a.fill_(float("nan"))
-            with fa.debug_options(inline_fixup=1):
+            with fa.debug_options(inline_fixup=1 if rep < 6 else 0):
                 fa.synthesize_dev(pv, ch, F, bins, sr, ar, W, out_a, ws, None)
             torch.cuda.synchronize()
             same = torch.equal(out_a.view(torch.int32), out_b.view(torch.int32))

@@ -34,7 +34,7 @@ for ch, seconds in ((1, 5), (8, 60), (2, 60), (8, 600)):
     reps = 20 if seconds < 100 else 5
     for r in range(9):
         for mode in (0, 1):
-            fa.lib.flanhip_debug_option(fa.DEBUG_INLINE_FIXUP, 1 - mode)
+            fa.lib.flanhip_debug_option(fa.DEBUG_INLINE_FIXUP, 1 + mode)        # 1: inside the kernel, 2: never
             step(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
