@@ -636,9 +636,9 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	o->group_offset = o->carry_bytes + o->head_bytes + 1024;       // tail: NaN flag (4 B at +0), dump area (512 B at +512); then the group sums
 	o->group_bytes = ( size_t( ch ) * o->groups_per_channel * bins * sizeof( double ) + 255 ) & ~size_t( 255 );
 	o->total_bytes = o->group_offset + 2 * o->group_bytes;             // the producer's group totals, then the group carries the synthesis' own scan over them leaves
-	// the dft 2048 synthesis kernel adds the overlaps of neighbouring chains itself (pv_kernels_v2.h): a state word per chain and a second side buffer
+	// the dft 2048 / 1024 / 512 synthesis kernels add the overlaps of neighbouring chains themselves (pv_kernels_v2.h, _v3.h): a state word per chain and a second side buffer
 	o->fix_offset = o->tail_offset = 0;
-	if( !o->any && !mr && o->dft == 2048 && kind == 1 && o->head_len > 0 )
+	if( !o->any && !mr && ( o->dft == 2048 || v3_size( o->dft ) ) && kind == 1 && o->head_len > 0 )
 		{
 		o->fix_offset = o->total_bytes;
 		o->tail_offset = o->fix_offset + ( ( size_t( chains ) * sizeof( int ) + 255 ) & ~size_t( 255 ) );

@@ -517,12 +517,14 @@ __global__ __launch_bounds__( 64 * WAVES, OCC ) void k_synthesize_v3( SynthParam
 
 	// one 128-sample step leaves the chain; exactly one store instruction per step, never inside a branch (see k_synthesize_v2)
 	cf * dump2 = reinterpret_cast<cf*>( p.dump ) + lane;
+	const bool fix = p.fix_state != nullptr;                                    // this launch adds the chains' overlaps itself (below; see k_synthesize_v2)
 	auto emit_step = [&]( int64_t a0, cf v )
 		{
 		const int64_t a = a0 + 2 * lane;
 		cf * dst = ( a0 < own_start ) ? head2 + ( ( a - chain_start ) >> 1 ) : out2 + ( a >> 1 );
 		if( a0 >= own_start && !( a >= 0 && a < p.out_len ) ) dst = dump2;
-		*dst = v;
+		if( fix && a0 < own_start ) st_agent( dst, v );                          // (the head another wavefront may come to add up)
+		else *dst = v;
 		};
 	cf mfk[H], mfm[H], mfx;
 	auto load_row = [&]( int fr )                                               // fr: the frame, counted from tb0
@@ -711,9 +713,39 @@ __global__ __launch_bounds__( 64 * WAVES, OCC ) void k_synthesize_v3( SynthParam
 	bins_of_row();
 	int64_t pos = chain_start;
 	int rel = 0;
-	for( int i = 0; i < nf; ++i )
+	// the overlaps of neighbouring chains added by the chains themselves (p.fix_state set): k_synthesize_v2's protocol, statement for statement --
+	// a tagged word per boundary, the head's owner publishing from inside its frame loop, the tail's owner reading the word a frame before its last
+	// and requesting the head under its last transform
+	const int tag_tail = p.fix_tag | 1, tag_head = p.fix_tag | 2;
+	const int nsteps = p.head_len / 128;
+	const bool has_head = chain_in_channel != 0, has_tail = !last_chain;
+	int * const word_h = p.fix_state + chain, * const word_t = p.fix_state + ( chain + 1 );      // (used under `fix` only)
+	const cf * const head_next = reinterpret_cast<const cf*>( p.head + ( chain + 1 ) * p.head_len ) + lane;
+	const int i_pub = ( p.head_len + hop - 1 ) / hop;
+	int old_h = 0, seen_t = 0;
+	bool published = false;
+	cf hx[E];
+	auto frame_step = [&]( int i, auto last_tag ) -> bool
 		{
-		load_row( relf0 + min( i + 1, nf - 1 ) );                               // (the last frame requests itself again: nobody waits for it)
+		constexpr bool LAST = decltype( last_tag )::value;
+		bool have_head = false;
+		if constexpr( LAST )
+			{
+			if( fix && has_tail )
+				{
+				have_head = __builtin_amdgcn_readfirstlane( seen_t ) == tag_head;
+				if( have_head )
+					{
+					#pragma unroll
+					for( int q = 0; q < E; ++q ) hx[q] = ( q < nsteps ) ? ld_agent( head_next + 64 * q ) : mk( 0.0f, 0.0f );
+					}
+				}
+			}
+		else
+			{
+			load_row( relf0 + i + 1 );
+			if( fix && has_tail && i == nf - 2 && lane == 0 ) seen_t = __hip_atomic_load( word_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+			}
 		fft_v3<LOG2C>( z, buf, s_tw, lane );
 		// ---- G = fft( conj Z ): x[2n] = G[n].x, x[2n+1] = -G[n].y; window and overlap-add (AudioPV.cpp:122-134)
 		#pragma unroll
@@ -738,18 +770,82 @@ __global__ __launch_bounds__( 64 * WAVES, OCC ) void k_synthesize_v3( SynthParam
 		for( int q = 0; q < E; ++q ) acc[q] = ( q + HOPQ < E ) ? acc[q + HOPQ] : mk( 0.0f, 0.0f );
 		pos += hop;
 		rel += hop;
-		if( i + 1 < nf ) bins_of_row();
-		}
+		if constexpr( !LAST )
+			{
+			bins_of_row();
+			if( fix && has_head && i == i_pub )
+				{
+				asm volatile( "" ::: "memory" );                                  // (the row wait above has retired the head's stores)
+				if( lane == 0 ) old_h = __hip_atomic_exchange( word_h, tag_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+				asm volatile( "" ::: "memory" );
+				published = true;
+				}
+			}
+		return have_head;
+		};
+	for( int i = 0; i + 1 < nf; ++i ) frame_step( i, std::false_type{} );
+	const bool have_head = frame_step( nf - 1, std::true_type{} );
 	// flush the partial sums that the next chain's head completes; the last chain zero-fills to the end of the output
 	const int64_t ring_end = pos + ( W - hop );
 	const int64_t flush_end = last_chain ? max( ring_end, p.out_len ) : ring_end;
-	#pragma unroll
-	for( int q = 0; q < E; ++q )
+	if( !fix || last_chain )
 		{
-		const int64_t a0 = pos + 128 * q;
-		if( a0 < flush_end ) emit_step( a0, acc[q] );
+		#pragma unroll
+		for( int q = 0; q < E; ++q )
+			{
+			const int64_t a0 = pos + 128 * q;
+			if( a0 < flush_end ) emit_step( a0, acc[q] );
+			}
+		for( int64_t a0 = pos + 128 * E; a0 < flush_end; a0 += 128 ) emit_step( a0, mk( 0.0f, 0.0f ) );
 		}
-	for( int64_t a0 = pos + 128 * E; a0 < flush_end; a0 += 128 ) emit_step( a0, mk( 0.0f, 0.0f ) );
+	if( fix )
+		{
+		if( has_head && !published )
+			{
+			asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+			if( lane == 0 ) old_h = __hip_atomic_exchange( word_h, tag_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+			}
+		if( has_tail )
+			{
+			cf * tail_next = reinterpret_cast<cf*>( p.tail + ( chain + 1 ) * p.head_len ) + lane;
+			bool add = have_head;
+			if( !add )
+				{
+				#pragma unroll
+				for( int q = 0; q < E; ++q ) if( q < nsteps ) st_agent( tail_next + 64 * q, acc[q] );
+				asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+				int old = 0;
+				if( lane == 0 ) old = __hip_atomic_exchange( word_t, tag_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+				add = __builtin_amdgcn_readfirstlane( old ) == tag_head;
+				if( add )
+					{
+					#pragma unroll
+					for( int q = 0; q < E; ++q ) hx[q] = ( q < nsteps ) ? ld_agent( head_next + 64 * q ) : mk( 0.0f, 0.0f );
+					}
+				}
+			if( add )
+				{
+				#pragma unroll
+				for( int q = 0; q < E; ++q )
+					{
+					const int64_t a = pos + 128 * q + 2 * lane;
+					if( q < nsteps && a >= 0 && a < p.out_len ) out2[a >> 1] = mk( acc[q].x + hx[q].x, acc[q].y + hx[q].y );
+					}
+				}
+			}
+		if( has_head && __builtin_amdgcn_readfirstlane( old_h ) == tag_tail )
+			{
+			const cf * tl = reinterpret_cast<const cf*>( p.tail + chain * p.head_len ) + lane;
+			const cf * hd = head2 + lane;
+			#pragma unroll 4
+			for( int q = 0; q < nsteps; ++q )
+				{
+				const cf t = ld_agent( tl + 64 * q ), h = ld_agent( hd + 64 * q );
+				const int64_t a = chain_start + 128 * q + 2 * lane;
+				if( a >= 0 && a < p.out_len ) out2[a >> 1] = mk( t.x + h.x, t.y + h.y );
+				}
+			}
+		}
 	}
 
 } // namespace flanhip

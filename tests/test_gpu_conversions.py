@@ -726,6 +726,12 @@ def test_plan_caches_are_bounded_and_evicted_sizes_come_back(fa):
     (2, 10, 2048, 512, {"chain_len": 4}),
     (3, 7, 2048, 512, {"chain_len": 5}),                      # the head's tag goes out in the last frame but one
     (1, 30, 2048, 256, {"chain_len": 9}),
+    # the dft 1024 / 512 kernels (pv_kernels_v3.h): the same protocol
+    (8, 60, 1024, 256, {"dft": 1024}),
+    (2, 20, 1024, 128, {"dft": 1024, "chain_len": 11}),
+    (3, 9, 768, 512, {"dft": 1024, "chain_len": 3}),
+    (8, 30, 512, 128, {"dft": 512}),
+    (2, 9, 512, 256, {"dft": 512, "chain_len": 4}),
 ])
 def test_overlap_fixup_inside_the_kernel_equals_the_separate_launch(fa, ch, seconds, W, hop, hooks):
     """k_synthesize_v2 adds the overlaps of neighbouring chains itself (a tagged word per boundary; the head's owner publishes from inside its frame
@@ -736,7 +742,8 @@ def test_overlap_fixup_inside_the_kernel_equals_the_separate_launch(fa, ch, seco
     import torch
     dev = torch.device("cuda", 0)
     lib, vp = fa.lib, ctypes.c_void_p
-    sr, dft = 48000.0, 2048
+    hooks = dict(hooks)
+    sr, dft = 48000.0, hooks.pop("dft", 2048)
     n = int(seconds * sr) + 123
     F = int(lib.flanhip_num_pv_frames(n, hop))
     ar = np.float32(sr) / np.float32(hop)

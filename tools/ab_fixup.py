@@ -11,6 +11,8 @@ import torch
 import flan_amd as fa
 
 SR, W, HOP, DFT = 48000.0, 2048, 512, 2048
+if len(sys.argv) > 1:                          # another shape: tools/ab_fixup.py WINDOW HOP DFT
+    W, HOP, DFT = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 BINS = DFT // 2 + 1
 dev = torch.device("cuda", 0)
 res = {}
