@@ -333,6 +333,8 @@ static int run_analyze_fast( const AnalyzeParams & p, const FastTables & tb, hip
 // 256 / 512 / 1024, window a multiple of 128); 2: accumulator as an LDS ring (any hop <= window, any window <= dft).
 // dft 4096 with the LDS ring: the wavefronts (chains) per block that fit beside the tables -- four up to a window of ~2500 samples, three beyond
 static int ring_waves11( int W ) { return FastLds<11>::bytes( 4 ) + FastLds<11>::ring_bytes( 4, W ) <= kMaxLds ? 4 : 3; }
+// ... and with the team kernels' ring variant (round 5: k_synthesize_eo_team<.., -1, ..>): chains (teams) per block -- four up to a window of 2048, three beyond
+static int ring_teams11( int W ) { return debug_options().syn11_old ? ring_waves11( W ) : W <= 2048 ? 4 : 3; }
 static int synth_fast_kind( int dft, int W, int hop )
 	{
 	if( !( dft == 2048 || dft == 4096 || v3_size( dft ) ) || hop > W || hop < 1 || force_generic() ) return 0;
@@ -379,6 +381,22 @@ static int run_synth_eo_team( const SynthParams & p, const FastTables & tb, hipS
 	const size_t lds = L::bytes( WBIG ? TEAMS : 2 * TEAMS );                   // two A / B buffer sets per team (windows above 2048: one)
 	static_assert( L::bytes( WBIG ? TEAMS : 2 * TEAMS ) <= kMaxLds, "LDS budget" );
 	auto kern = k_synthesize_eo_team<TEAMS, HS, WBIG>;
+	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+	const int64_t blocks = int64_t( ( p.chains_per_channel + TEAMS - 1 ) / TEAMS ) * p.num_channels;   // a block = a group of TEAMS chains of one channel
+	FLANHIP_REQUIRE( blocks < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
+	hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( 128 * TEAMS ), lds, s, p, tb );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+// dft 4096, any hop <= window, any window: the team kernels with the overlap-add accumulator as a ring in LDS (pv_kernels_eo.h: HS = -1)
+template<int TEAMS, bool WBIG>
+static int run_synth_eo_team_ring( const SynthParams & p, const FastTables & tb, hipStream_t s )
+	{
+	using L = typename std::conditional<WBIG, EoLdsBig, EoLds>::type;
+	const size_t lds = L::bytes( TEAMS ) + size_t( TEAMS ) * size_t( ( p.window_size + 63 ) & ~63 ) * 4;     // one A / B buffer set per team, then the rings
+	FLANHIP_REQUIRE( lds <= kMaxLds && p.window_size <= ( WBIG ? 4096 : 2048 ), FLANHIP_ERR_UNSUPPORTED, "window too long for the LDS ring" );
+	auto kern = k_synthesize_eo_team<TEAMS, -1, WBIG>;
 	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 	const int64_t blocks = int64_t( ( p.chains_per_channel + TEAMS - 1 ) / TEAMS ) * p.num_channels;   // a block = a group of TEAMS chains of one channel
 	FLANHIP_REQUIRE( blocks < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
@@ -434,6 +452,7 @@ static int run_synth_fast_hop( const SynthParams & p, const FastTables & tb, hip
 	if( synth_fast_kind( 2 << LOG2C, p.window_size, p.hop ) == 2 )                // any other hop <= window: ring accumulator in LDS
 		{
 		if constexpr( LOG2C == 10 ) return run_synth_fast<LOG2C, kSynWaves10, 0>( p, tb, s );
+		else if( !debug_options().syn11_old ) return p.window_size <= 2048 ? run_synth_eo_team_ring<4, false>( p, tb, s ) : run_synth_eo_team_ring<3, true>( p, tb, s );
 		else return ring_waves11( p.window_size ) == 4 ? run_synth_fast<LOG2C, 4, 0>( p, tb, s ) : run_synth_fast<LOG2C, 3, 0>( p, tb, s );
 		}
 	if constexpr( LOG2C == 11 ) switch( p.hop / 128 )                              // (dft 2048's register-accumulator hops are all v2's, above)
@@ -452,9 +471,12 @@ static bool synth_fast_ok( int dft, int W, int hop ) { return synth_fast_kind( d
 // pair (a block = 8 one-wavefront chains of a channel), 4 for the dft 4096 team kernels (4 teams per block); 0: no group totals for this shape.
 static int self_carry_group( int dft, int W, int hop, int chains_per_channel )
 	{
-	if( synth_fast_kind( dft, W, hop ) != 1 ) return 0;
+	const int kind = synth_fast_kind( dft, W, hop );
 	int g = 0;
-	if( dft == 2048 || v3_size( dft ) ) g = group_size_of( dft );
+	// the LDS-ring form of the dft 4096 team synthesis (any hop, any window up to 2048: four teams per block like the analysis) takes the totals too
+	if( kind == 2 ) g = ( dft == 4096 && W <= 2048 && !debug_options().syn11_old && !debug_options().ana11_old ) ? 4 : 0;
+	else if( kind != 1 ) return 0;
+	else if( dft == 2048 || v3_size( dft ) ) g = group_size_of( dft );
 	else if( dft == 4096 && W % 256 == 0 && ( hop == 128 || hop % 256 == 0 ) && !debug_options().syn11_old && !debug_options().ana11_old ) g = 4;   // (windows above 2048: the WBIG variants)
 	// any number of groups (their carries come from a scan of their own); with few chains per channel the scan over the chains themselves is as
 	// short and the groups' epilogue and prologue are pure cost (a 5 s mono file: 118 chains, 68 against 73 us per round trip)
@@ -625,7 +647,7 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	o->head_len = o->any ? 0 : std::max( W - o->hop, 0 );        // (the direct-sum path overlap-adds whole frames from its own scratch: no chain heads)
 	const int overlap = ( W + o->hop - 1 ) / o->hop;              // frames covering one output sample
 	const int kind = o->any ? 0 : synth_fast_kind( o->dft, W, o->hop );
-	const int slots = o->any ? any_target_chains( bins ) : mr ? mr_target_chains( o->dft, W ) : kind == 0 ? generic_target_chains( o->dft ) : ( kind == 2 && o->dft == 4096 ) ? cu_count() * ring_waves11( W ) : fast_target_chains( o->dft, true );
+	const int slots = o->any ? any_target_chains( bins ) : mr ? mr_target_chains( o->dft, W ) : kind == 0 ? generic_target_chains( o->dft ) : ( kind == 2 && o->dft == 4096 ) ? cu_count() * ring_teams11( W ) : fast_target_chains( o->dft, true );
 	o->L = choose_chain_length( ch, F, o->any ? 1 : std::max( overlap - 1, 1 ), slots );
 	o->chains_per_channel = int( ( F + o->L - 1 ) / o->L );
 	const int64_t chains = int64_t( o->chains_per_channel ) * ch;

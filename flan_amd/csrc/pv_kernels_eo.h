@@ -178,7 +178,10 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 	const int64_t tfirst = t0 > 0 ? t0 - 1 : t0;
 	const int frames = active ? int( t1 - tfirst ) : 0;                       // iterations with work (the halo frame included)
 	const int iters = p.L + 1;                                                // what every team of every block walks
-	auto frame_inside = [&]( int64_t t ) { return W == WMAX && int64_t( hop ) * t - W / 2 >= 0 && int64_t( hop ) * t - W / 2 + WMAX <= p.n; };   // per frame (see k_analyze_v2)
+	// per frame (see k_analyze_v2): the plain loads take the whole transform's span of samples whatever the window (its table is zero beyond W), so the
+	// span, not the window, has to lie inside the signal (round 5: any window, not WMAX alone -- (2000, 500, 4096) and (4000, 1000, 4096) ran every frame
+	// through the clamped loads)
+	auto frame_inside = [&]( int64_t t ) { return int64_t( hop ) * t - W / 2 >= 0 && int64_t( hop ) * t - W / 2 + WMAX <= p.n; };
 	constexpr std::true_type inside{};
 	constexpr std::false_type outside{};
 
@@ -471,14 +474,19 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 // per register.
 // WBIG: windows up to 4096 -- all 1024 output points of each transform lie inside the window (16 accumulator pairs per lane instead of 8), the
 // window table is 16 KB, which leaves LDS for ONE A / B buffer set (two meetings per frame).
-template<int TEAMS, int HS, bool WBIG = false>                               // HS = hop / 256; 0: hop 128
+// HS = -1 (round 5): ANY hop <= window and any window -- the overlap-add accumulator is a ring of W floats per team in LDS instead of registers (one A / B
+// buffer set: the ring takes the second set's place; windows above 2048: three teams per block).  Both wavefronts add their windowed halves into the
+// ring, meet, and between that meeting and the next (the one that guards the A / B buffers anyway) send off and clear the hop samples that are final.
+template<int TEAMS, int HS, bool WBIG = false>                               // HS = hop / 256; 0: hop 128; -1: any hop, ring accumulator
 __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthParams p, FastTables tb )
 	{
 	using L = typename std::conditional<WBIG, EoLdsBig, EoLds>::type;
-	constexpr int C = 1024, N2 = 2048, Q = 4, NT = 128 * TEAMS, hop = HS ? 256 * HS : 128;
-	constexpr bool DOUBLE = !WBIG;
+	constexpr bool RING = HS < 0;
+	constexpr int C = 1024, N2 = 2048, Q = 4, NT = 128 * TEAMS;
+	const int hop = RING ? p.hop : HS ? 256 * HS : 128;
+	constexpr bool DOUBLE = !WBIG && !RING;
 	constexpr int WQ = WBIG ? 16 : 8, WMAX = 256 * WQ;                          // accumulator pairs per lane; the window this kernel admits
-	static_assert( HS == 0 || HS == 1 || HS == 2 || HS == 4, "hop 128 / 256 / 512 / 1024" );
+	static_assert( HS == -1 || HS == 0 || HS == 1 || HS == 2 || HS == 4, "hop 128 / 256 / 512 / 1024, or the ring" );
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	cf * s = reinterpret_cast<cf*>( smem );
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane( tid >> 6 ), team = wave >> 1, role = wave & 1;
@@ -494,6 +502,10 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 		for( int i = tid; i < WMAX; i += NT ) win[i] = ( i < W ) ? p.window[i] * p.window_scale : 0.0f;   // AudioPV.cpp:102
 		}
 	cf * const buf0 = s + L::BUF + team * ( DOUBLE ? 4 : 2 ) * L::BUF_LEN;      // set b: A at buf0 + 2 b BUF_LEN, B behind it
+	// RING: the teams' overlap-add rings behind the buffers, Wr floats each (W rounded up to a whole number of wavefront rows)
+	const int Wr = ( W + 63 ) & ~63;
+	float * const ring = reinterpret_cast<float*>( s + L::BUF + TEAMS * 2 * L::BUF_LEN ) + team * Wr;
+	if constexpr( RING ) { for( int i = lane + 64 * role; i < Wr; i += 128 ) ring[i] = 0.0f; }
 	TeamSync team_sync{ (lds_u32*) reinterpret_cast<unsigned*>( buf0 + 1087 ), 0u, lane };
 	if( role == 0 && lane == 0 ) *team_sync.flag = 0u;
 	__syncthreads();
@@ -777,6 +789,37 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 		if constexpr( !DOUBLE ) team_sync.meet();
 		}
 	int64_t pos = chain_start;
+	int ring_base = 0;                                                          // RING: the ring slot of output position `pos`
+	float * const head1 = p.head + chain * p.head_len;
+	// count samples from position a0 on leave the ring (slot ring_base on) for the head buffer, the output, or nowhere (outside the output)
+	const bool ring_pairs = RING && ( hop & 1 ) == 0 && ( W & 3 ) == 0;           // every position, hop and slot even: pairs stay pairs
+	auto ring_emit = [&]( int64_t a0, int count )
+		{
+		if( ring_pairs )
+			{
+			// (a0, count, own_start and out_len = F hop are even here: a pair lies on one side of every boundary)
+			for( int j = 2 * ( lane + 64 * role ); j < count; j += 256 )
+				{
+				int i0 = ring_base + j; i0 -= ( i0 >= Wr ) ? Wr : 0;
+				cf * slot = reinterpret_cast<cf*>( ring + i0 );
+				const cf v = *slot;
+				*slot = mk( 0.0f, 0.0f );
+				const int64_t a = a0 + j;
+				if( a < own_start ) *reinterpret_cast<cf*>( head1 + ( a - chain_start ) ) = v;
+				else if( a >= 0 && a < p.out_len ) *reinterpret_cast<cf*>( out1 + a ) = v;
+				}
+			return;
+			}
+		for( int j = lane + 64 * role; j < count; j += 128 )
+			{
+			int i0 = ring_base + j; i0 -= ( i0 >= Wr ) ? Wr : 0;
+			const float v = ring[i0];
+			ring[i0] = 0.0f;
+			const int64_t a = a0 + j;
+			if( a < own_start ) head1[a - chain_start] = v;
+			else if( a >= 0 && a < p.out_len ) out1[a] = v;
+			}
+		};
 	if( frames > 0 ) bins_of_row( 0 );
 	team_sync.meet();
 	const int iters = p.L;
@@ -794,6 +837,48 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 			wave_sync();
 			fft_fast<10>( z, const_cast<cf*>( mybuf ), s_tw1, s_tw3, lane );
 			// G = fft( A or B ): samples 4m (+2 for B) = G[m].x, 4m+1 (+2) = -G[m].y, m = lane + 64 q < 64 WQ; window, overlap-add (AudioPV.cpp:122-134)
+			if constexpr( RING )
+				{
+				// the windowed half frame into the ring: sample 4 m + 2 role (+1) of this frame sits ring_base + that many slots on, modulo Wr
+				if( ring_pairs )
+					{
+					// even hop and window: a sample pair is one aligned 8-byte slot pair that never straddles the ring's end
+					#pragma unroll
+					for( int q = 0; q < WQ; ++q )
+						{
+						const v4f_t wv = s_win[64 * q];
+						const int s0 = 4 * ( lane + 64 * q ) + 2 * role;
+						if( s0 < W )
+							{
+							int i0 = ring_base + s0; i0 -= ( i0 >= Wr ) ? Wr : 0;
+							cf * slot = reinterpret_cast<cf*>( ring + i0 );
+							const cf r = *slot;
+							*slot = mk( r.x + z[q].x * ( role ? wv.z : wv.x ), r.y + ( -z[q].y ) * ( role ? wv.w : wv.y ) );
+							}
+						}
+					}
+				else
+					{
+					#pragma unroll
+					for( int q = 0; q < WQ; ++q )
+						{
+						const v4f_t wv = s_win[64 * q];
+						const int s0 = 4 * ( lane + 64 * q ) + 2 * role;
+						if( s0 < W )
+							{
+							int i0 = ring_base + s0; i0 -= ( i0 >= Wr ) ? Wr : 0;
+							ring[i0] += z[q].x * ( role ? wv.z : wv.x );
+							if( s0 + 1 < W )
+								{
+								int i1 = i0 + 1; i1 -= ( i1 >= Wr ) ? Wr : 0;
+								ring[i1] += ( -z[q].y ) * ( role ? wv.w : wv.y );
+								}
+							}
+						}
+					}
+				}
+			else
+			{
 			#pragma unroll
 			for( int q = 0; q < WQ; ++q )
 				{
@@ -801,7 +886,9 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 				acc[q].x += z[q].x * ( role ? wv.z : wv.x );
 				acc[q].y += ( -z[q].y ) * ( role ? wv.w : wv.y );
 				}
-			if constexpr( HS == 0 )
+			}
+			if constexpr( RING ) {}
+			else if constexpr( HS == 0 )
 				{
 				emit_half( pos, acc[0], 0 );
 				const bool low = lane < 32;
@@ -829,11 +916,22 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 				#pragma unroll
 				for( int q = 0; q < WQ; ++q ) acc[q] = ( q + HS < WQ ) ? acc[q + HS] : mk( 0.0f, 0.0f );
 				}
-			pos += hop;
+			if constexpr( !RING ) pos += hop;
 			}
 		// one buffer set: nobody may write the next frame's A / B before both wavefronts have transformed this one's (the transform uses its
 		// buffer as scratch).  Two sets: the next frame goes to the other set
 		if constexpr( !DOUBLE ) team_sync.meet();
+		if constexpr( RING )
+			{
+			// both halves of this frame are in the ring: its first hop samples are final -- they leave (4-byte stores: a hop may be odd) and their
+			// slots are cleared for the frame that will reach them next (its additions come after the meeting below)
+			if( i < frames )
+				{
+				ring_emit( pos, hop );
+				ring_base += hop; ring_base -= ( ring_base >= Wr ) ? Wr : 0;
+				pos += hop;
+				}
+			}
 		if( i + 1 < frames ) bins_of_row( DOUBLE ? ( set ^ 1 ) : 0 );
 		team_sync.meet();                                                         // the next frame's A / B are written
 		}
@@ -841,7 +939,13 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 	// flush the partial sums that the next chain's head completes; the last chain zero-fills to the end of the output
 	const int64_t ring_end = pos + ( W - hop );
 	const int64_t flush_end = last_chain ? max( ring_end, p.out_len ) : ring_end;
-	if constexpr( HS == 0 )
+	if constexpr( RING )
+		{
+		// (the loop's last meeting is behind both wavefronts: the ring is complete)
+		ring_emit( pos, W - hop );
+		for( int64_t a = ring_end + lane + 64 * role; a < flush_end; a += 128 ) if( a >= 0 && a < p.out_len ) out1[a] = 0.0f;
+		}
+	else if constexpr( HS == 0 )
 		{
 		// W - hop = 1920 (3968) samples = 7.5 (15.5) steps: by halves (the next chain writes from ring_end on itself)
 		#pragma unroll

@@ -68,6 +68,14 @@ CASES = [
     ("dft4096_win4096_short", 2, 3000, 4096, 512, 4096, "noise"),
     ("dft4096_win4096_one_frame", 1, 300, 4096, 1024, 4096, "noise"),
     ("dft4096_win2304_hop128", 1, 20000, 2304, 128, 4096, "noise"),
+    # dft 4096 off the tuned grid (round 5): the team synthesis with its overlap-add accumulator as a ring in LDS (odd and even hops, windows that are no
+    # multiple of 256, windows above 2048: three teams per block)
+    ("dft4096_hop441", 2, 60000, 2048, 441, 4096, "noise"),
+    ("dft4096_win2000_hop500", 1, 50000, 2000, 500, 4096, "noise"),
+    ("dft4096_win4000_hop1000", 2, 90000, 4000, 1000, 4096, "noise"),
+    ("dft4096_win1999_hop333", 1, 30000, 1999, 333, 4096, "noise"),
+    ("dft4096_win3001_hop750", 1, 40000, 3001, 750, 4096, "noise"),
+    ("dft4096_hop_eq_window_1000", 1, 30000, 1000, 1000, 4096, "noise"),
     ("sine_dft4096_hop512", 1, 48000, 2048, 512, 4096, "sine"),
     ("ragged_len", 3, 12345, 2048, 512, 2048, "noise"),
     ("one_frame", 1, 100, 2048, 512, 2048, "noise"),
@@ -270,7 +278,7 @@ def test_fused_round_trip_equals_unfused(fa):
     sr = 48000.0
     # dft 8192 (and 4096 through the generic kernels): block-wide teams walk the chains; they leave the sums like every other analysis kernel
     for (ch, n, W, hop, dft) in [(2, 70000, 2048, 512, 2048), (1, 30000, 2048, 128, 4096), (2, 20000, 1024, 256, 1024), (1, 9000, 400, 100, 512), (2, 40000, 512, 128, 512), (3, 90000, 1024, 512, 1024),
-                                 (1, 40000, 4096, 1024, 8192), (2, 30000, 2048, 300, 4096),
+                                 (1, 40000, 4096, 1024, 8192), (2, 30000, 2048, 300, 4096), (3, 500000, 2000, 500, 4096), (2, 200000, 4000, 1000, 4096),
                                  # the mixed-radix kernels: sums kept by the analysis kernel (ping-pong sizes, with and without the large odd radices) or by
                                  # the pre-pass kernel on its behalf (in place: 12000)
                                  (2, 300000, 2048, 512, 3000), (1, 120000, 1024, 256, 2002), (1, 200000, 2048, 512, 12000), (1, 60000, 600, 150, 1000)]:
@@ -314,7 +322,7 @@ def test_fused_round_trip_equals_unfused(fa):
 
 @pytest.mark.parametrize("dft,hop,ch,n,W", [(2048, 512, 8, 300000, 2048), (4096, 512, 4, 600000, 2048), (4096, 128, 2, 400000, 2048), (4096, 1024, 4, 1400000, 2048),
                                             (2048, 512, 3, 900000, 2048), (4096, 1024, 4, 1400000, 4096), (4096, 512, 4, 600000, 3072), (2048, 512, 1, 2000000, 2048),
-                                            (1024, 256, 8, 600000, 1024), (1024, 512, 3, 900000, 768), (1024, 128, 1, 2000000, 1024), (512, 128, 2, 400000, 512), (512, 256, 5, 300000, 512)])
+                                            (4096, 441, 4, 600000, 2048), (4096, 500, 2, 900000, 2000), (1024, 256, 8, 600000, 1024), (1024, 512, 3, 900000, 768), (1024, 128, 1, 2000000, 1024), (512, 128, 2, 400000, 512), (512, 256, 5, 300000, 512)])
 def test_carry_prologue_equals_scan_kernel(fa, dft, hop, ch, n, W):
     """Fused round trip: the synthesis kernels that take their chains' carries from a scan over the analysis' GROUP totals plus the chain sums
     (dft 2048 / 1024: groups of 8 chains; dft 4096 team kernels and dft 512: groups of 4, the last group of a channel short; also the team kernels'
