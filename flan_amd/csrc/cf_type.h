@@ -4,4 +4,5 @@
 #pragma once
 namespace flanhip {
 typedef float cf __attribute__(( ext_vector_type( 2 ) ));
+struct d2 { double x, y; };   // a complex number in double (tables evaluated on the host: the unit circle of the direct sums, Bluestein's chirp)
 }

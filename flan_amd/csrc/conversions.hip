@@ -11,6 +11,7 @@
 #include "pv_kernels_eo.h"
 #include "pv_kernels_any.h"
 #include "pv_kernels_mr.h"
+#include "pv_kernels_bs.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -58,6 +59,36 @@ static int mr_target_chains( int dft, int W )
 	MrPlan pl{};
 	if( !mr_size( dft, W, &pl ) ) return cu_count();
 	return cu_count() * std::max( 1, mr_blocks_per_cu( pl, W ) );
+	}
+
+// ... and the sizes the chirp-z kernels serve (pv_kernels_bs.h, bs_plan.h): half the size with a prime factor above 13, 64 <= C <= 4096, the
+// block's tables and state within the LDS of a CU for this window
+static int bs_blocks_per_cu( const BsPlan & pl, int W )
+	{
+	const size_t lds = std::max( bs_analyze_lds( pl.C, pl.M ), bs_synth_lds( pl.C, pl.M, W, pl.win_lds != 0 ) );
+	if( lds > kMaxLds ) return 0;
+	return int( std::min<size_t>( bs_pingpong( pl.M ) ? 2 : 1, kMaxLds / lds ) );
+	}
+static bool bs_size( int dft, int W, BsPlan * pl = nullptr )
+	{
+	BsPlan best;
+	if( fft_size( dft ) || debug_options().force_direct || !bs_make_plan( dft, &best ) ) return false;
+	int best_blocks = 0;
+	for( int wl = 0; wl < 2; ++wl )
+		{
+		BsPlan t = best; t.win_lds = wl;
+		const int b = bs_blocks_per_cu( t, W );
+		if( b > 0 && b >= best_blocks ) { best = t; best_blocks = b; }
+		}
+	if( best_blocks == 0 ) return false;
+	if( pl ) *pl = best;
+	return true;
+	}
+static int bs_target_chains( int dft, int W )
+	{
+	BsPlan pl{};
+	if( !bs_size( dft, W, &pl ) ) return cu_count();
+	return cu_count() * std::max( 1, bs_blocks_per_cu( pl, W ) );
 	}
 
 static bool dft_size_ok( int dft ) { return dft >= 4 && dft % 2 == 0 && dft <= kMaxAnyDft; }
@@ -509,7 +540,9 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	if( int rc = require_device() ) return rc;
 	MrPlan mr_plan{};
 	const bool mr = mr_size( dft, W, &mr_plan );
-	const bool any = !fft_size( dft ) && !mr;
+	BsPlan bs_plan{};
+	const bool bs = !mr && bs_size( dft, W, &bs_plan );
+	const bool any = !fft_size( dft ) && !mr && !bs;
 	std::shared_ptr<const PlanRef> plan_ref;                                        // (held until the kernels below are launched)
 	if( int rc = get_plan( W, dft, &plan_ref ) ) return rc;
 	const Plan * plan = &plan_ref->plan;
@@ -522,7 +555,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	// (hop: the dft 2048 kernel addresses a block's samples by 32-bit byte offsets from the block's first frame -- up to 8 chains of <= ~512 frames,
 	// env overrides aside -- and the generic kernels serve the hops that would not fit: nothing anybody analyses with)
 	const bool fast = ( dft == 2048 || dft == 4096 || v3_size( dft ) ) && n >= 2 && n < ( int64_t( 1 ) << 31 ) - 8192 && hop <= 65536 && !force_generic();
-	int target_chains = any ? any_target_chains( dft / 2 + 1 ) : mr ? mr_target_chains( dft, W ) : fast ? fast_target_chains( dft, false ) : generic_target_chains( dft );
+	int target_chains = any ? any_target_chains( dft / 2 + 1 ) : mr ? mr_target_chains( dft, W ) : bs ? bs_target_chains( dft, W ) : fast ? fast_target_chains( dft, false ) : generic_target_chains( dft );
 	p.L = choose_chain_length( ch, p.F, any ? 7 : 1, target_chains );
 	p.chains_per_channel = int( ( p.F + p.L - 1 ) / p.L );
 	p.sample_rate = sr;
@@ -534,7 +567,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	p.cancel = thread_cancel_word( s );                                           // kernels stop starting chains when the thread's wait raises it (core.hip)
 	// windows above 2048: the WBIG team kernels (pv_kernels_eo.h)
 	const bool team_big = fast && dft == 4096 && W > 2048 && !debug_options().ana11_old;
-	const bool kernel_sums = !any && ( !mr || mr_pingpong( mr_plan.C ) );   // every power-of-two analysis kernel keeps the sums, and the mixed-radix one where its LDS has room; for the rest the pre-pass kernel runs on the analysis' behalf
+	const bool kernel_sums = !any && ( !mr || mr_pingpong( mr_plan.C ) ) && ( !bs || bs_pingpong( bs_plan.M ) );   // every power-of-two analysis kernel keeps the sums, and the mixed-radix one where its LDS has room; for the rest the pre-pass kernel runs on the analysis' behalf
 	SynthLayout fused_lay{};
 	if( d_fused_ws )
 		{
@@ -596,6 +629,19 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 		FLANHIP_CHECK( hipGetLastError() );
 		return prepass_on_behalf();
 		}
+	if( bs )
+		{
+		const int64_t chains = int64_t( p.chains_per_channel ) * ch;
+		FLANHIP_REQUIRE( chains < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
+		FLANHIP_REQUIRE( plan->d_bs_tw && plan->d_bs_chirp && plan->d_bs_bh, FLANHIP_ERR_UNSUPPORTED, "chirp-z plan and tables disagree" );
+		const size_t lds = bs_analyze_lds( bs_plan.C, bs_plan.M );
+		const BsTables g{ plan->d_bs_tw, plan->d_bs_chirp, plan->d_bs_bh };
+		auto kern = bs_pingpong( bs_plan.M ) ? k_analyze_bs<true> : k_analyze_bs<false>;
+		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+		hipLaunchKernelGGL( kern, dim3( (unsigned) chains ), dim3( MR_THREADS ), lds, s, p, bs_plan, g );
+		FLANHIP_CHECK( hipGetLastError() );
+		return prepass_on_behalf();
+		}
 	if( fast )
 		{
 		FastTables tb{ plan->d_tw1f, plan->d_tw3f, plan->d_tw2 };
@@ -643,11 +689,12 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	FLANHIP_REQUIRE( dft_size_ok( o->dft ), FLANHIP_ERR_UNSUPPORTED, "dft size must be even, at least 4 and at most 2^20" );
 	FLANHIP_REQUIRE( int64_t( o->dft ) * W < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "dft_size * window_size overflows the int product of AudioPV.cpp:99" );
 	const bool mr = mr_size( o->dft, W );
-	o->any = !fft_size( o->dft ) && !mr;
+	const bool bs = !mr && bs_size( o->dft, W );
+	o->any = !fft_size( o->dft ) && !mr && !bs;
 	o->head_len = o->any ? 0 : std::max( W - o->hop, 0 );        // (the direct-sum path overlap-adds whole frames from its own scratch: no chain heads)
 	const int overlap = ( W + o->hop - 1 ) / o->hop;              // frames covering one output sample
 	const int kind = o->any ? 0 : synth_fast_kind( o->dft, W, o->hop );
-	const int slots = o->any ? any_target_chains( bins ) : mr ? mr_target_chains( o->dft, W ) : kind == 0 ? generic_target_chains( o->dft ) : ( kind == 2 && o->dft == 4096 ) ? cu_count() * ring_teams11( W ) : fast_target_chains( o->dft, true );
+	const int slots = o->any ? any_target_chains( bins ) : mr ? mr_target_chains( o->dft, W ) : bs ? bs_target_chains( o->dft, W ) : kind == 0 ? generic_target_chains( o->dft ) : ( kind == 2 && o->dft == 4096 ) ? cu_count() * ring_teams11( W ) : fast_target_chains( o->dft, true );
 	o->L = choose_chain_length( ch, F, o->any ? 1 : std::max( overlap - 1, 1 ), slots );
 	o->chains_per_channel = int( ( F + o->L - 1 ) / o->L );
 	const int64_t chains = int64_t( o->chains_per_channel ) * ch;
@@ -847,6 +894,17 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 		auto kern = !mr_pingpong( mr_plan.C ) ? k_synthesize_mr<false, true> : mr_plan_is_big( mr_plan ) ? k_synthesize_mr<true, true> : k_synthesize_mr<true, false>;
 		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 		hipLaunchKernelGGL( kern, dim3( (unsigned) chains ), dim3( MR_THREADS ), lds, s, p, mr_plan );
+		FLANHIP_CHECK( hipGetLastError() );
+		rc = FLANHIP_OK;
+		}
+	else if( BsPlan bs_plan{}; bs_size( lay.dft, W, &bs_plan ) )
+		{
+		FLANHIP_REQUIRE( plan->d_bs_tw && plan->d_bs_chirp && plan->d_bs_bh, FLANHIP_ERR_UNSUPPORTED, "chirp-z plan and tables disagree" );
+		const size_t lds = bs_synth_lds( bs_plan.C, bs_plan.M, W, bs_plan.win_lds != 0 );
+		const BsTables g{ plan->d_bs_tw, plan->d_bs_chirp, plan->d_bs_bh };
+		auto kern = bs_pingpong( bs_plan.M ) ? k_synthesize_bs<true> : k_synthesize_bs<false>;
+		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+		hipLaunchKernelGGL( kern, dim3( (unsigned) chains ), dim3( MR_THREADS ), lds, s, p, bs_plan, g );
 		FLANHIP_CHECK( hipGetLastError() );
 		rc = FLANHIP_OK;
 		}

@@ -1,6 +1,8 @@
 // core.hip -- error state, device plumbing, plan cache, shape helpers of the C ABI (include/flanhip.h).
 #include "flanhip_internal.h"
 #include "div_plans_proven.h"
+#include "bs_plan.h"
+#include <complex>
 #include <memory>
 #include <thread>
 #include <chrono>
@@ -48,6 +50,7 @@ static float hann_host( float x )
 PlanRef::~PlanRef()
 	{
 	(void) hipFree( plan.d_window ); (void) hipFree( plan.d_tw ); (void) hipFree( plan.d_tw2 ); (void) hipFree( plan.d_tw1f ); (void) hipFree( plan.d_tw3f );
+	(void) hipFree( plan.d_bs_tw ); (void) hipFree( plan.d_bs_chirp ); (void) hipFree( plan.d_bs_bh );
 	(void) hipGetLastError();
 	}
 static std::mutex g_plan_mutex;
@@ -102,6 +105,44 @@ int get_plan( int window_size, int dft_size, std::shared_ptr<const PlanRef> * ou
 		FLANHIP_CHECK( hipMalloc( &plan.d_tw3f, sizeof( cf ) * tw3.size() ) );
 		FLANHIP_CHECK( hipMemcpy( plan.d_tw1f, tw1.data(), sizeof( cf ) * tw1.size(), hipMemcpyHostToDevice ) );
 		FLANHIP_CHECK( hipMemcpy( plan.d_tw3f, tw3.data(), sizeof( cf ) * tw3.size(), hipMemcpyHostToDevice ) );
+		}
+	if( BsPlan bp{}; bs_make_plan( dft_size, &bp ) )
+		{
+		// Bluestein's tables (pv_kernels_bs.h), all evaluated in double: the chirp from n^2 mod 2 C (exact integers), its transform by a radix-2 FFT
+		const int M = bp.M;
+		std::vector<cf> twm( M ); std::vector<d2> chirp( C ), bh( M );
+		for( int j = 0; j < M; ++j ) twm[j] = cf{ float( std::cos( -2.0 * pi * j / M ) ), float( std::sin( -2.0 * pi * j / M ) ) };
+		std::vector<std::complex<double>> b( M, std::complex<double>( 0.0, 0.0 ) );
+		for( int n = 0; n < C; ++n )
+			{
+			const int64_t q = ( int64_t( n ) * n ) % ( 2 * int64_t( C ) );
+			const std::complex<double> w( std::cos( pi * double( q ) / C ), std::sin( pi * double( q ) / C ) );
+			chirp[n] = d2{ w.real(), w.imag() };
+			b[n] = w;
+			if( n ) b[M - n] = w;
+			}
+		for( int i = 1, j = 0; i < M; ++i )                                          // bit reversal
+			{
+			int bit = M >> 1;
+			for( ; j & bit; bit >>= 1 ) j ^= bit;
+			j ^= bit;
+			if( i < j ) std::swap( b[i], b[j] );
+			}
+		for( int len = 2; len <= M; len <<= 1 )
+			for( int i = 0; i < M; i += len )
+				for( int k = 0; k < len / 2; ++k )
+					{
+					const std::complex<double> w( std::cos( -2.0 * pi * k / len ), std::sin( -2.0 * pi * k / len ) );
+					const std::complex<double> u = b[i + k], v = b[i + k + len / 2] * w;
+					b[i + k] = u + v; b[i + k + len / 2] = u - v;
+					}
+		for( int k = 0; k < M; ++k ) bh[k] = d2{ b[k].real() / M, b[k].imag() / M };
+		FLANHIP_CHECK( hipMalloc( &plan.d_bs_tw, sizeof( cf ) * M ) );
+		FLANHIP_CHECK( hipMalloc( &plan.d_bs_chirp, sizeof( d2 ) * C ) );
+		FLANHIP_CHECK( hipMalloc( &plan.d_bs_bh, sizeof( d2 ) * M ) );
+		FLANHIP_CHECK( hipMemcpy( plan.d_bs_tw, twm.data(), sizeof( cf ) * M, hipMemcpyHostToDevice ) );
+		FLANHIP_CHECK( hipMemcpy( plan.d_bs_chirp, chirp.data(), sizeof( d2 ) * C, hipMemcpyHostToDevice ) );
+		FLANHIP_CHECK( hipMemcpy( plan.d_bs_bh, bh.data(), sizeof( d2 ) * M, hipMemcpyHostToDevice ) );
 		}
 	std::shared_ptr<const PlanRef> evicted;                                         // (released outside the lock: freeing waits for the device)
 		{

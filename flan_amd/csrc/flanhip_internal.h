@@ -47,6 +47,9 @@ struct Plan
 	cf * d_tw2 = nullptr;      // [C+1] exp(-2 pi i k / (2C))
 	cf * d_tw1f = nullptr;     // fast path (dft 2048/4096): [15][16]      exp(-2 pi i r k / 256)
 	cf * d_tw3f = nullptr;     // fast path:                 [C/256-1][256] exp(-2 pi i r j / C)
+	cf * d_bs_tw = nullptr;    // chirp-z sizes (bs_plan.h): [M] exp(-2 pi i j / M)
+	d2 * d_bs_chirp = nullptr; //                            [C] exp(+pi i n^2 / C), in double
+	d2 * d_bs_bh = nullptr;    //                            [M] the chirp's transform / M, in double
 	};
 struct PlanRef { Plan plan; PlanRef() = default; PlanRef( const PlanRef & ) = delete; PlanRef & operator=( const PlanRef & ) = delete; ~PlanRef(); };   // owns the tables
 int get_plan( int window_size, int dft_size, std::shared_ptr<const PlanRef> * out );   // keep the reference until the kernels that read the tables are launched

@@ -18,7 +18,6 @@
 
 namespace flanhip {
 
-struct d2 { double x, y; };
 constexpr int ANY_FB = 4;            // frames per pass
 constexpr int ANY_TILE = 256;        // samples (analysis) / bins (synthesis) staged per step
 constexpr int ANY_THREADS = 256;
