@@ -112,13 +112,32 @@ CASES = [
     ("dft3000_stereo_ragged", 2, 12345, 2048, 512, 3000, "noise"),
     ("dft16384_win4096", 1, 60000, 4096, 1024, 16384, "noise"),
     ("dft1000_win600", 2, 9000, 600, 150, 1000, "noise"),
+    # ... and, since round 5, Bluestein's chirp-z form for sizes with a larger prime factor (pv_kernels_bs.h: 64 <= dft / 2 <= 4096; two layouts)
     ("dft2998_prime_factor", 1, 9000, 1024, 256, 2998, "noise"),
+    ("dft2998_full_window_stereo_ragged", 2, 12345, 2998, 750, 2998, "noise"),
+    ("dft5998_chirp_in_place", 1, 30000, 2048, 512, 5998, "noise"),
+    ("dft2018_chirp", 1, 20000, 1024, 256, 2018, "noise"),
+    ("dft134_chirp_small", 2, 3000, 128, 32, 134, "noise"),
+    ("dft4094_sine", 1, 48000, 2048, 512, 4094, "sine"),
+    ("dft2998_one_frame", 1, 100, 1024, 256, 2998, "noise"),
+    ("dft2998_zeros", 1, 5000, 1024, 256, 2998, "zeros"),
     ("dft66", 1, 3000, 64, 16, 66, "noise"),
     ("dft6_win4", 1, 300, 4, 2, 6, "noise"),
     ("dft3000_sine", 1, 48000, 2048, 512, 3000, "sine"),
     ("dft3000_one_frame", 1, 100, 2048, 512, 3000, "noise"),
     ("dft3000_zeros", 1, 5000, 2048, 512, 3000, "zeros"),
 ]
+
+
+def chirp_z_size(dft):
+    """bs_plan.h: half the size with a prime factor above 13, 64 <= dft / 2 <= 4096"""
+    c = dft // 2
+    if dft % 2 or c < 64 or c > 4096:
+        return False
+    for r in (2, 3, 5, 7, 11, 13):
+        while c % r == 0:
+            c //= r
+    return c != 1
 
 
 def make_input(kind, ch, n):
@@ -155,6 +174,10 @@ def test_analysis_parity(fa, name, ch, n, W, hop, dft, kind):
         # orders); how many f words that flips grows with analysis_rate / bin width, hence the floors by shape (measured: 0.990-0.997 at
         # hop >= 512 and dft >= 2048, 0.984 at hop 256, 0.971 at hop 128 or dft 512, 0.96 / 0.90 / 0.86 at dft 256 / 64 / 32)
         floor = 0.985 if ( hop >= 512 and dft >= 2048 ) else 0.98 if ( hop >= 256 and dft >= 1024 ) else 0.965 if dft >= 512 else 0.95 if dft >= 256 else 0.85
+        # Bluestein's form (pv_kernels_bs.h) runs TWO fp32 transforms of the next power of two above dft - 1 per frame, not one of dft / 2: with
+        # the chirp products and the split in double it measures 0.9795-0.981 at hop 256 where one transform gives 0.984 (all in fp32: 0.978)
+        if chirp_z_size(dft):
+            floor -= 0.006
         assert same >= floor
 
 
@@ -678,7 +701,7 @@ def test_cancellation_is_scoped_to_the_stream_waited_on(fa):
     fa.check(lib.flanhip_stream_destroy(sB))
 
 
-@pytest.mark.parametrize("W,hop,dft", [(2048, 512, 3000), (4096, 1024, 16384), (600, 150, 1000)])
+@pytest.mark.parametrize("W,hop,dft", [(2048, 512, 3000), (4096, 1024, 16384), (600, 150, 1000), (1024, 256, 2998), (2048, 512, 5998)])
 def test_mixed_radix_kernels_against_the_direct_sums(fa, W, hop, dft):
     """The mixed-radix FFT kernels (pv_kernels_mr.h) against the transform's definition summed in fp64 (pv_kernels_any.h, the force_direct hook)
     on the same input: PVs agree like two FFT backends do, audio from the SAME PV to 1e-6."""
