@@ -63,9 +63,17 @@ static int mr_target_chains( int dft, int W )
 
 // ... and the sizes the chirp-z kernels serve (pv_kernels_bs.h, bs_plan.h): half the size with a prime factor above 13, 64 <= C <= 4096, the
 // block's tables and state within the LDS of a CU for this window
+// the ping-pong layout's kernels with the per-thread table values in registers (pv_kernels_bs.h HOIST: 256 registers, so one block per CU) where
+// the LDS holds one block per CU anyway (M = 4096: (2048, 512, 2998) 4.46 -> 3.94 ms; at M = 2048 / 1024 the second block is worth more: 4.07 ms
+// against 5.8 at dft 2018).  The diagnostic hook ANA_VARIANT = 1 picks the kernels that read the tables every frame everywhere.
+static size_t bs_lds( const BsPlan & pl, int W ) { return std::max( bs_analyze_lds( pl.C, pl.M ), bs_synth_lds( pl.C, pl.M, W, pl.win_lds != 0 ) ); }
+static bool bs_hoist( const BsPlan & pl, int W )
+	{
+	return bs_pingpong( pl.M ) && pl.C < 4 * MR_THREADS && pl.M / 8 <= MR_THREADS && 2 * bs_lds( pl, W ) > kMaxLds && debug_options().ana_variant != 1;
+	}
 static int bs_blocks_per_cu( const BsPlan & pl, int W )
 	{
-	const size_t lds = std::max( bs_analyze_lds( pl.C, pl.M ), bs_synth_lds( pl.C, pl.M, W, pl.win_lds != 0 ) );
+	const size_t lds = bs_lds( pl, W );
 	if( lds > kMaxLds ) return 0;
 	return int( std::min<size_t>( bs_pingpong( pl.M ) ? 2 : 1, kMaxLds / lds ) );
 	}
@@ -636,7 +644,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 		FLANHIP_REQUIRE( plan->d_bs_tw && plan->d_bs_chirp && plan->d_bs_bh, FLANHIP_ERR_UNSUPPORTED, "chirp-z plan and tables disagree" );
 		const size_t lds = bs_analyze_lds( bs_plan.C, bs_plan.M );
 		const BsTables g{ plan->d_bs_tw, plan->d_bs_chirp, plan->d_bs_bh };
-		auto kern = bs_pingpong( bs_plan.M ) ? k_analyze_bs<true> : k_analyze_bs<false>;
+		auto kern = !bs_pingpong( bs_plan.M ) ? k_analyze_bs<false, false> : bs_hoist( bs_plan, W ) ? k_analyze_bs<true, true> : k_analyze_bs<true, false>;
 		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 		hipLaunchKernelGGL( kern, dim3( (unsigned) chains ), dim3( MR_THREADS ), lds, s, p, bs_plan, g );
 		FLANHIP_CHECK( hipGetLastError() );
@@ -902,7 +910,7 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 		FLANHIP_REQUIRE( plan->d_bs_tw && plan->d_bs_chirp && plan->d_bs_bh, FLANHIP_ERR_UNSUPPORTED, "chirp-z plan and tables disagree" );
 		const size_t lds = bs_synth_lds( bs_plan.C, bs_plan.M, W, bs_plan.win_lds != 0 );
 		const BsTables g{ plan->d_bs_tw, plan->d_bs_chirp, plan->d_bs_bh };
-		auto kern = bs_pingpong( bs_plan.M ) ? k_synthesize_bs<true> : k_synthesize_bs<false>;
+		auto kern = !bs_pingpong( bs_plan.M ) ? k_synthesize_bs<false, false> : bs_hoist( bs_plan, W ) ? k_synthesize_bs<true, true> : k_synthesize_bs<true, false>;
 		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 		hipLaunchKernelGGL( kern, dim3( (unsigned) chains ), dim3( MR_THREADS ), lds, s, p, bs_plan, g );
 		FLANHIP_CHECK( hipGetLastError() );

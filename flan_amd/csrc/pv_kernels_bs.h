@@ -42,12 +42,13 @@ inline size_t bs_synth_lds( int C, int M, int W, bool win_lds ) { return bs_lds_
 
 // The first pass of a transform (radix 8, sub-transform length 1: no twiddles), reading its input through what Bluestein needs there:
 // MUL = false: points from `limit` on are zero (never read);  MUL = true: conj( src[i] bh[i] ).
-template<bool PP, bool MUL> __device__ __forceinline__ void bs_pass0( cf * src, cf * dst, int M, int limit, const d2 * __restrict__ bh, int tid )
+// (bhr: the thread's own eight entries of bh held in registers by the caller -- HOIST kernels, whose M / 8 butterflies are at most one per thread)
+template<bool PP, bool MUL> __device__ __forceinline__ void bs_pass0( cf * src, cf * dst, int M, int limit, const d2 * __restrict__ bh, const d2 * bhr, int tid )
 	{
 	const int NB = M / 8;
-	auto fetch = [&]( int idx ) -> cf
+	auto fetch = [&]( int idx, int r ) -> cf
 		{
-		if constexpr( MUL ) return conj_f( cmul_d( src[PAD( idx )], bh[idx] ) );
+		if constexpr( MUL ) return conj_f( cmul_d( src[PAD( idx )], bhr ? bhr[r] : bh[idx] ) );
 		else return idx < limit ? src[PAD( idx )] : mk( 0.0f, 0.0f );
 		};
 	if constexpr( PP )
@@ -57,7 +58,7 @@ template<bool PP, bool MUL> __device__ __forceinline__ void bs_pass0( cf * src, 
 			{
 			cf v[8];
 			#pragma unroll
-			for( int r = 0; r < 8; ++r ) v[r] = fetch( j + r * NB );
+			for( int r = 0; r < 8; ++r ) v[r] = fetch( j + r * NB, r );
 			dft_reg<8>( v );
 			#pragma unroll
 			for( int r = 0; r < 8; ++r ) dst[PAD( j * 8 + r )] = v[r];
@@ -75,7 +76,7 @@ template<bool PP, bool MUL> __device__ __forceinline__ void bs_pass0( cf * src, 
 			if( j < NB )
 				{
 				#pragma unroll
-				for( int r = 0; r < 8; ++r ) v[b][r] = fetch( j + r * NB );
+				for( int r = 0; r < 8; ++r ) v[b][r] = fetch( j + r * NB, r );
 				}
 			}
 		__syncthreads();
@@ -95,10 +96,10 @@ template<bool PP, bool MUL> __device__ __forceinline__ void bs_pass0( cf * src, 
 	}
 
 // forward transform of the M points in `a` (natural order in and out), the first pass as above; returns where the result stands
-template<bool PP, bool MUL> __device__ __forceinline__ cf * bs_fft( cf * a, cf * b, const BsTables & tb, const BsPlan & pl, int limit, int tid )
+template<bool PP, bool MUL> __device__ __forceinline__ cf * bs_fft( cf * a, cf * b, const BsTables & tb, const BsPlan & pl, int limit, int tid, const d2 * bhr = nullptr )
 	{
 	cf * src = a, * dst = PP ? b : a;
-	bs_pass0<PP, MUL>( src, dst, pl.M, limit, tb.bh, tid );
+	bs_pass0<PP, MUL>( src, dst, pl.M, limit, tb.bh, bhr, tid );
 	if constexpr( PP ) { cf * t = src; src = dst; dst = t; }
 	int NS = 8;
 	for( int i = 1; i < pl.npass; ++i )
@@ -130,9 +131,14 @@ template<bool PP> __device__ __forceinline__ BsLds bs_carve( unsigned char * sme
 	}
 
 // ---- Audio::convert_to_PV (Conversions/AudioPV.cpp:12-78): one block per chain --------------------------------------------------------
-template<bool PP>
-__global__ __launch_bounds__( MR_THREADS, PP ? 4 : 2 ) void k_analyze_bs( AnalyzeParams p, BsPlan pl, BsTables g )
+// HOIST (ping-pong layout, C < 2048 = 4 x 512: every per-frame loop is ONE trip per thread): what a thread reads from the tables is the same every
+// frame -- its eight entries of bh, its four chirp values, per-bin constants and window samples -- so it reads them once, into registers (72 of
+// them: two wavefronts per SIMD, which is what one block per CU of the M = 4096 layout comes to anyway), and the next frame's samples are requested
+// under this frame's bins.  Without it a frame waited for L2 three times (12.8 us a frame at dft 2998; the passes themselves are ~4).
+template<bool PP, bool HOIST>
+__global__ __launch_bounds__( MR_THREADS, ( PP && !HOIST ) ? 4 : 2 ) void k_analyze_bs( AnalyzeParams p, BsPlan pl, BsTables g )
 	{
+	static_assert( PP || !HOIST, "HOIST is a ping-pong layout" );
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = threadIdx.x;
 	const int C = pl.C, M = pl.M, W = p.window_size, hop = p.hop, dft = 2 * C;
@@ -160,6 +166,35 @@ __global__ __launch_bounds__( MR_THREADS, PP ? 4 : 2 ) void k_analyze_bs( Analyz
 	const bool use_wrapping = p.analysis_rate < p.sample_rate;                        // phase_vocoder.cpp:37
 	constexpr int U = 4;
 	cf * in = buf;                                                                     // (two transforms of the same number of passes: the result lands where the frame went in)
+	// HOIST: the thread's constants, and the samples of the frame about to be transformed
+	d2 chr[U], bhr[8]; v4f_t kcr[U]; float w0r[U], w1r[U], xa0[U], xa1[U];
+	auto request = [&]( int64_t t )
+		{
+		const int64_t start = int64_t( hop ) * t - W / 2;
+		#pragma unroll
+		for( int u = 0; u < U; ++u )
+			{
+			const int i = tid + MR_THREADS * u;
+			const int64_t p0 = start + 2 * i, p1 = p0 + 1;
+			xa0[u] = ( i < C && 2 * i < W && p0 >= 0 && p0 < p.n ) ? x[p0] : 0.0f;
+			xa1[u] = ( i < C && 2 * i + 1 < W && p1 >= 0 && p1 < p.n ) ? x[p1] : 0.0f;
+			}
+		};
+	if constexpr( HOIST )
+		{
+		#pragma unroll
+		for( int u = 0; u < U; ++u )
+			{
+			const int i = tid + MR_THREADS * u;
+			chr[u] = g.chirp[min( i, C - 1 )];
+			kcr[u] = mr_kc_value( min( i, C ), p.tw2[min( i, C )], p.sample_rate, p.analysis_rate, dft );
+			w0r[u] = ( i < C && 2 * i < W ) ? p.window[2 * i] : 0.0f;
+			w1r[u] = ( i < C && 2 * i + 1 < W ) ? p.window[2 * i + 1] : 0.0f;
+			}
+		#pragma unroll
+		for( int r = 0; r < 8; ++r ) bhr[r] = g.bh[min( tid, M / 8 - 1 ) + r * ( M / 8 )];
+		request( t0 > 0 ? t0 - 1 : t0 );
+		}
 
 	for( int64_t t = ( t0 > 0 ? t0 - 1 : t0 ); t < t1; ++t )                           // (the frame before the chain only lends its phases: phase_vocoder.cpp:45)
 		{
@@ -167,7 +202,16 @@ __global__ __launch_bounds__( MR_THREADS, PP ? 4 : 2 ) void k_analyze_bs( Analyz
 		// a[n] = ( x[2n] win[2n], x[2n+1] win[2n+1] ) conj( w[n] ), n < C; zero beyond the window and outside the signal (AudioPV.cpp:52-65)
 		const int64_t start = int64_t( hop ) * t - W / 2;
 		cf * const other = PP ? ( in == buf ? l.buf2 : buf ) : buf;
-		for( int i0 = tid; i0 < C; i0 += U * MR_THREADS )
+		if constexpr( HOIST )
+			{
+			#pragma unroll
+			for( int u = 0; u < U; ++u )
+				{
+				const int i = tid + MR_THREADS * u;
+				if( i < C ) in[PAD( i )] = cmul_d( mk( xa0[u] * w0r[u], xa1[u] * w1r[u] ), conj_d( chr[u] ) );   // AudioPV.cpp:60 (0 outside), then the chirp
+				}
+			}
+		else for( int i0 = tid; i0 < C; i0 += U * MR_THREADS )
 			{
 			float a0[U], a1[U], w0[U], w1[U]; d2 ch[U];
 			#pragma unroll
@@ -189,7 +233,8 @@ __global__ __launch_bounds__( MR_THREADS, PP ? 4 : 2 ) void k_analyze_bs( Analyz
 			}
 		__syncthreads();
 		cf * const A = bs_fft<PP, false>( in, other, l.tb, pl, C, tid );
-		const cf * const R = bs_fft<PP, true>( A, A == in ? other : in, l.tb, pl, M, tid );
+		const cf * const R = bs_fft<PP, true>( A, A == in ? other : in, l.tb, pl, M, tid, HOIST ? bhr : nullptr );
+		if constexpr( HOIST ) { if( t + 1 < t1 ) request( t + 1 ); }
 
 		// the real transform's bins from the half-size one, each phase-vocoded (AudioPV.cpp:69-73);  Z[k] = conj( w[k] R[k] ),  w[C - k] = +- w[k]
 		MF * row = p.out + ( int64_t( channel ) * p.F + t ) * ( C + 1 );
@@ -201,6 +246,7 @@ __global__ __launch_bounds__( MR_THREADS, PP ? 4 : 2 ) void k_analyze_bs( Analyz
 			#pragma unroll
 			for( int u = 0; u < U; ++u )
 				{
+				if constexpr( HOIST ) { kc[u] = kcr[u]; ch[u] = chr[u]; continue; }      // (one trip: k0 = tid)
 				const int k = min( k0 + MR_THREADS * u, C );
 				kc[u] = mr_kc_value( k, p.tw2[k], p.sample_rate, p.analysis_rate, dft );
 				ch[u] = g.chirp[min( k, C - 1 )];
@@ -259,9 +305,11 @@ __global__ __launch_bounds__( MR_THREADS, PP ? 4 : 2 ) void k_analyze_bs( Analyz
 	}
 
 // ---- PV::convert_to_audio (Conversions/AudioPV.cpp:86-139): one block per chain, from the carries of the common pre-pass ------------------
-template<bool PP>
-__global__ __launch_bounds__( MR_THREADS, PP ? 4 : 2 ) void k_synthesize_bs( SynthParams p, BsPlan pl, BsTables g )
+// (HOIST as in k_analyze_bs: bh, chirp, split twiddles and the scaled window in registers; the next frame's PV row requested under the passes)
+template<bool PP, bool HOIST>
+__global__ __launch_bounds__( MR_THREADS, ( PP && !HOIST ) ? 4 : 2 ) void k_synthesize_bs( SynthParams p, BsPlan pl, BsTables g )
 	{
+	static_assert( PP || !HOIST, "HOIST is a ping-pong layout" );
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = threadIdx.x;
 	const int C = pl.C, M = pl.M, W = p.window_size, hop = p.hop;
@@ -291,6 +339,29 @@ __global__ __launch_bounds__( MR_THREADS, PP ? 4 : 2 ) void k_synthesize_bs( Syn
 	__syncthreads();
 	if( s_cancel ) return;
 	constexpr int U = 4;
+	d2 chr[U], bhr[8]; cf war[2], wbr[2]; float wn0[U], wn1[U]; MF mfr[U];
+	auto request = [&]( int64_t t )
+		{
+		const MF * row = p.pv + ( int64_t( channel ) * p.F + t ) * ( C + 1 );
+		#pragma unroll
+		for( int u = 0; u < U; ++u ) mfr[u] = row[min( tid + MR_THREADS * u, C )];
+		};
+	if constexpr( HOIST )
+		{
+		#pragma unroll
+		for( int u = 0; u < U; ++u )
+			{
+			const int n = tid + MR_THREADS * u;
+			chr[u] = g.chirp[min( n, C - 1 )];
+			wn0[u] = 2 * n < W ? p.window[2 * n] * p.window_scale : 0.0f;                // AudioPV.cpp:102
+			wn1[u] = 2 * n + 1 < W ? p.window[2 * n + 1] * p.window_scale : 0.0f;
+			}
+		#pragma unroll
+		for( int u = 0; u < 2; ++u ) { const int k = min( tid + MR_THREADS * u, C / 2 ); war[u] = p.tw2[k]; wbr[u] = p.tw2[C - k]; }
+		#pragma unroll
+		for( int r = 0; r < 8; ++r ) bhr[r] = g.bh[min( tid, M / 8 - 1 ) + r * ( M / 8 )];
+		request( t0 );
+		}
 
 	int ring_base = 0;
 	int64_t pos = chain_start;
@@ -302,7 +373,7 @@ __global__ __launch_bounds__( MR_THREADS, PP ? 4 : 2 ) void k_synthesize_bs( Syn
 			{
 			MF mfs[U];
 			#pragma unroll
-			for( int u = 0; u < U; ++u ) mfs[u] = row[min( k0 + MR_THREADS * u, C )];
+			for( int u = 0; u < U; ++u ) { if constexpr( HOIST ) mfs[u] = mfr[u]; else mfs[u] = row[min( k0 + MR_THREADS * u, C )]; }   // (HOIST: one trip, k0 = tid)
 			#pragma unroll
 			for( int u = 0; u < U; ++u )
 				{
@@ -320,6 +391,7 @@ __global__ __launch_bounds__( MR_THREADS, PP ? 4 : 2 ) void k_synthesize_bs( Syn
 				buf[PAD( k )] = mk( mf.m * cs, mf.m * sn );                               // std::polar, :60
 				}
 			}
+		if constexpr( HOIST ) { if( t + 1 < t1 ) request( t + 1 ); }
 		__syncthreads();
 		// merge X[0 .. C] into the conjugated half-size spectrum (k_synthesize_mr), each point times conj( w[k] ) on the way: a[k] of the chirp-z form
 		auto merge = [&]( int k, cf xk, cf xm, cf w2q ) -> cf
@@ -335,7 +407,11 @@ __global__ __launch_bounds__( MR_THREADS, PP ? 4 : 2 ) void k_synthesize_bs( Syn
 			{
 			cf wa[U], wb[U]; d2 ch[U];
 			#pragma unroll
-			for( int u = 0; u < U; ++u ) { const int k = min( k0 + MR_THREADS * u, C / 2 ); wa[u] = p.tw2[k]; wb[u] = p.tw2[C - k]; ch[u] = g.chirp[k]; }
+			for( int u = 0; u < U; ++u )
+				{
+				if constexpr( HOIST ) { wa[u] = war[u & 1]; wb[u] = wbr[u & 1]; ch[u] = chr[u]; continue; }   // (one trip; 2 k <= C < 2048: u < 2 is all there is)
+				const int k = min( k0 + MR_THREADS * u, C / 2 ); wa[u] = p.tw2[k]; wb[u] = p.tw2[C - k]; ch[u] = g.chirp[k];
+				}
 			#pragma unroll
 			for( int u = 0; u < U; ++u )
 				{
@@ -351,19 +427,25 @@ __global__ __launch_bounds__( MR_THREADS, PP ? 4 : 2 ) void k_synthesize_bs( Syn
 			}
 		__syncthreads();
 		cf * const A = bs_fft<PP, false>( buf, l.buf2, l.tb, pl, C, tid );
-		const cf * const R = bs_fft<PP, true>( A, A == buf ? l.buf2 : buf, l.tb, pl, M, tid );   // (lands in buf: two transforms of equally many passes)
+		const cf * const R = bs_fft<PP, true>( A, A == buf ? l.buf2 : buf, l.tb, pl, M, tid, HOIST ? bhr : nullptr );   // (lands in buf: two transforms of equally many passes)
 		// G[n] = conj( w[n] R[n] ) = fft_C( conj Z )[n]:  x[2n] = G[n].x, x[2n+1] = -G[n].y (AudioPV.cpp:122); window, accumulate (:133-134)
-		for( int n = tid; 2 * n < W; n += MR_THREADS )
+		auto accumulate = [&]( int n, d2 ch, float wa0, float wa1 )
 			{
-			const cf gn = conj_f( cmul_d( R[PAD( n )], g.chirp[n] ) );
+			const cf gn = conj_f( cmul_d( R[PAD( n )], ch ) );
 			int i0 = ring_base + 2 * n; if( i0 >= W ) i0 -= W;
-			ring[i0] += gn.x * win( 2 * n );
+			ring[i0] += gn.x * wa0;
 			if( 2 * n + 1 < W )
 				{
 				int i1 = i0 + 1; if( i1 >= W ) i1 -= W;
-				ring[i1] += ( -gn.y ) * win( 2 * n + 1 );
+				ring[i1] += ( -gn.y ) * wa1;
 				}
+			};
+		if constexpr( HOIST )
+			{
+			#pragma unroll
+			for( int u = 0; u < U; ++u ) { const int n = tid + MR_THREADS * u; if( 2 * n < W ) accumulate( n, chr[u], wn0[u], wn1[u] ); }   // ( W <= 2 C < 4096 )
 			}
+		else for( int n = tid; 2 * n < W; n += MR_THREADS ) accumulate( n, g.chirp[n], win( 2 * n ), 2 * n + 1 < W ? win( 2 * n + 1 ) : 0.0f );
 		__syncthreads();
 		for( int e = tid; e < hop; e += MR_THREADS )
 			{
