@@ -12,6 +12,7 @@
 #include "pv_kernels_any.h"
 #include "pv_kernels_mr.h"
 #include "pv_kernels_bs.h"
+#include "pv_kernels_big.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -98,6 +99,18 @@ static int bs_target_chains( int dft, int W )
 	if( !bs_size( dft, W, &pl ) ) return cu_count();
 	return cu_count() * std::max( 1, bs_blocks_per_cu( pl, W ) );
 	}
+
+// ... and the sizes above 16384 the residue-pair kernels serve (pv_kernels_big.h): half the size = C1 x C2 with C2 = 1024 ... 4096 a power of two,
+// C1 <= 256, the synthesis' ring within what the two transforms leave of a CU's LDS
+static bool big_size( int dft, int W, BigPlan * pl = nullptr )
+	{
+	BigPlan t;
+	if( fft_size( dft ) || debug_options().force_direct || dft <= 16384 || !big_make_plan( dft, W, &t ) ) return false;
+	if( big_synth_lds( t.C2, W ) > kMaxLds ) return false;
+	if( pl ) *pl = t;
+	return true;
+	}
+static int big_target_chains() { return cu_count(); }        // one block per CU, a chain is P blocks: P rounds
 
 static bool dft_size_ok( int dft ) { return dft >= 4 && dft % 2 == 0 && dft <= kMaxAnyDft; }
 
@@ -550,7 +563,9 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	const bool mr = mr_size( dft, W, &mr_plan );
 	BsPlan bs_plan{};
 	const bool bs = !mr && bs_size( dft, W, &bs_plan );
-	const bool any = !fft_size( dft ) && !mr && !bs;
+	BigPlan big_plan{};
+	const bool big = !mr && !bs && big_size( dft, W, &big_plan );
+	const bool any = !fft_size( dft ) && !mr && !bs && !big;
 	std::shared_ptr<const PlanRef> plan_ref;                                        // (held until the kernels below are launched)
 	if( int rc = get_plan( W, dft, &plan_ref ) ) return rc;
 	const Plan * plan = &plan_ref->plan;
@@ -563,7 +578,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	// (hop: the dft 2048 kernel addresses a block's samples by 32-bit byte offsets from the block's first frame -- up to 8 chains of <= ~512 frames,
 	// env overrides aside -- and the generic kernels serve the hops that would not fit: nothing anybody analyses with)
 	const bool fast = ( dft == 2048 || dft == 4096 || v3_size( dft ) ) && n >= 2 && n < ( int64_t( 1 ) << 31 ) - 8192 && hop <= 65536 && !force_generic();
-	int target_chains = any ? any_target_chains( dft / 2 + 1 ) : mr ? mr_target_chains( dft, W ) : bs ? bs_target_chains( dft, W ) : fast ? fast_target_chains( dft, false ) : generic_target_chains( dft );
+	int target_chains = any ? any_target_chains( dft / 2 + 1 ) : mr ? mr_target_chains( dft, W ) : bs ? bs_target_chains( dft, W ) : big ? big_target_chains() : fast ? fast_target_chains( dft, false ) : generic_target_chains( dft );
 	p.L = choose_chain_length( ch, p.F, any ? 7 : 1, target_chains );
 	p.chains_per_channel = int( ( p.F + p.L - 1 ) / p.L );
 	p.sample_rate = sr;
@@ -575,7 +590,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	p.cancel = thread_cancel_word( s );                                           // kernels stop starting chains when the thread's wait raises it (core.hip)
 	// windows above 2048: the WBIG team kernels (pv_kernels_eo.h)
 	const bool team_big = fast && dft == 4096 && W > 2048 && !debug_options().ana11_old;
-	const bool kernel_sums = !any && ( !mr || mr_pingpong( mr_plan.C ) ) && ( !bs || bs_pingpong( bs_plan.M ) );   // every power-of-two analysis kernel keeps the sums, and the mixed-radix one where its LDS has room; for the rest the pre-pass kernel runs on the analysis' behalf
+	const bool kernel_sums = !any && !big && ( !mr || mr_pingpong( mr_plan.C ) ) && ( !bs || bs_pingpong( bs_plan.M ) );   // every power-of-two analysis kernel keeps the sums, and the mixed-radix one where its LDS has room; for the rest the pre-pass kernel runs on the analysis' behalf
 	SynthLayout fused_lay{};
 	if( d_fused_ws )
 		{
@@ -634,6 +649,17 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 		auto kern = !mr_pingpong( mr_plan.C ) ? k_analyze_mr<false, true> : mr_plan_is_big( mr_plan ) ? k_analyze_mr<true, true> : k_analyze_mr<true, false>;
 		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 		hipLaunchKernelGGL( kern, dim3( (unsigned) chains ), dim3( MR_THREADS ), lds, s, p, mr_plan );
+		FLANHIP_CHECK( hipGetLastError() );
+		return prepass_on_behalf();
+		}
+	if( big )
+		{
+		const int64_t blocks = big_blocks( int64_t( p.chains_per_channel ) * ch, big_plan.P );
+		FLANHIP_REQUIRE( blocks < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
+		const size_t lds = big_analyze_lds( big_plan.C2 );
+		auto kern = big_plan.C2 == 4096 ? k_analyze_big<8> : big_plan.C2 == 2048 ? k_analyze_big<4> : k_analyze_big<2>;
+		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+		hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( MR_THREADS ), lds, s, p, big_plan );
 		FLANHIP_CHECK( hipGetLastError() );
 		return prepass_on_behalf();
 		}
@@ -698,11 +724,13 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	FLANHIP_REQUIRE( int64_t( o->dft ) * W < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "dft_size * window_size overflows the int product of AudioPV.cpp:99" );
 	const bool mr = mr_size( o->dft, W );
 	const bool bs = !mr && bs_size( o->dft, W );
-	o->any = !fft_size( o->dft ) && !mr && !bs;
+	BigPlan big_plan{};
+	o->big = !mr && !bs && big_size( o->dft, W, &big_plan );
+	o->any = !fft_size( o->dft ) && !mr && !bs && !o->big;
 	o->head_len = o->any ? 0 : std::max( W - o->hop, 0 );        // (the direct-sum path overlap-adds whole frames from its own scratch: no chain heads)
 	const int overlap = ( W + o->hop - 1 ) / o->hop;              // frames covering one output sample
-	const int kind = o->any ? 0 : synth_fast_kind( o->dft, W, o->hop );
-	const int slots = o->any ? any_target_chains( bins ) : mr ? mr_target_chains( o->dft, W ) : bs ? bs_target_chains( o->dft, W ) : kind == 0 ? generic_target_chains( o->dft ) : ( kind == 2 && o->dft == 4096 ) ? cu_count() * ring_teams11( W ) : fast_target_chains( o->dft, true );
+	const int kind = ( o->any || o->big ) ? 0 : synth_fast_kind( o->dft, W, o->hop );
+	const int slots = o->any ? any_target_chains( bins ) : mr ? mr_target_chains( o->dft, W ) : bs ? bs_target_chains( o->dft, W ) : o->big ? big_target_chains() : kind == 0 ? generic_target_chains( o->dft ) : ( kind == 2 && o->dft == 4096 ) ? cu_count() * ring_teams11( W ) : fast_target_chains( o->dft, true );
 	o->L = choose_chain_length( ch, F, o->any ? 1 : std::max( overlap - 1, 1 ), slots );
 	o->chains_per_channel = int( ( F + o->L - 1 ) / o->L );
 	const int64_t chains = int64_t( o->chains_per_channel ) * ch;
@@ -728,6 +756,14 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 		o->any_spec_offset = o->total_bytes;
 		o->any_frames_offset = o->any_spec_offset + ( ( size_t( ch ) * size_t( F ) * size_t( bins ) * sizeof( cf ) + 255 ) & ~size_t( 255 ) );
 		o->total_bytes = o->any_frames_offset + ( ( size_t( ch ) * size_t( F ) * size_t( W ) * sizeof( float ) + 255 ) & ~size_t( 255 ) );
+		}
+	o->big_out_offset = o->big_head_offset = 0;
+	if( o->big )
+		{
+		// the units' partial output streams [P][ch][F hop] and heads [P][chains][head_len] (pv_kernels_big.h)
+		o->big_out_offset = o->total_bytes;
+		o->big_head_offset = o->big_out_offset + ( ( size_t( big_plan.P ) * size_t( ch ) * size_t( F ) * size_t( o->hop ) * sizeof( float ) + 255 ) & ~size_t( 255 ) );
+		o->total_bytes = o->big_head_offset + ( ( size_t( big_plan.P ) * size_t( chains ) * size_t( o->head_len ) * sizeof( float ) + 255 ) & ~size_t( 255 ) );
 		}
 	o->flags_offset = o->total_bytes;
 	o->total_bytes += ( sizeof( int ) * size_t( bins + 1 ) + 255 ) & ~size_t( 255 );
@@ -905,6 +941,23 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 		FLANHIP_CHECK( hipGetLastError() );
 		rc = FLANHIP_OK;
 		}
+	else if( BigPlan big_plan{}; lay.big && big_size( lay.dft, W, &big_plan ) )
+		{
+		const int64_t blocks = big_blocks( chains, big_plan.P );
+		FLANHIP_REQUIRE( blocks < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
+		const BigSynthExtra e{ reinterpret_cast<float*>( reinterpret_cast<char*>( d_ws ) + lay.big_out_offset ), reinterpret_cast<float*>( reinterpret_cast<char*>( d_ws ) + lay.big_head_offset ) };
+		const size_t lds = big_synth_lds( big_plan.C2, W );
+		auto kern = big_plan.C2 == 4096 ? k_synthesize_big<8> : big_plan.C2 == 2048 ? k_synthesize_big<4> : k_synthesize_big<2>;
+		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+		hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( MR_THREADS ), lds, s, p, big_plan, e );
+		FLANHIP_CHECK( hipGetLastError() );
+		// the units' streams and the chains' heads added up in a fixed order (no separate fix-up for these sizes)
+		const int64_t total = ch * p.out_len;
+		FLANHIP_REQUIRE( ( total + 255 ) / 256 < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "output too long for one launch" );
+		if( total > 0 ) hipLaunchKernelGGL( k_big_reduce, dim3( (unsigned) ( ( total + 255 ) / 256 ) ), dim3( 256 ), 0, s, p, big_plan, e );
+		FLANHIP_CHECK( hipGetLastError() );
+		rc = FLANHIP_OK;
+		}
 	else if( BsPlan bs_plan{}; bs_size( lay.dft, W, &bs_plan ) )
 		{
 		FLANHIP_REQUIRE( plan->d_bs_tw && plan->d_bs_chirp && plan->d_bs_bh, FLANHIP_ERR_UNSUPPORTED, "chirp-z plan and tables disagree" );
@@ -935,7 +988,7 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 		default: set_error( "unsupported dft size %d", lay.dft );
 		}
 	if( rc ) return rc;
-	if( ( stages & 8 ) && p.head_len > 0 && p.chains_per_channel > 1 && !self_fix )
+	if( ( stages & 8 ) && p.head_len > 0 && p.chains_per_channel > 1 && !self_fix && !lay.big )
 		{
 		const bool quads = p.hop % 4 == 0 && ( W / 2 ) % 4 == 0 && p.head_len % 4 == 0 && p.out_len % 4 == 0
 			&& ( reinterpret_cast<uintptr_t>( p.out ) & 15 ) == 0 && ( reinterpret_cast<uintptr_t>( p.head ) & 15 ) == 0;

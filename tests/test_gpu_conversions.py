@@ -121,6 +121,14 @@ CASES = [
     ("dft4094_sine", 1, 48000, 2048, 512, 4094, "sine"),
     ("dft2998_one_frame", 1, 100, 1024, 256, 2998, "noise"),
     ("dft2998_zeros", 1, 5000, 1024, 256, 2998, "zeros"),
+    # ... and, since round 5, sizes above 16384 with a power-of-two factor of at least 1024 in their half (pv_kernels_big.h: residue pairs of C1 x C2)
+    ("dft32768_win4096", 1, 60000, 4096, 1024, 32768, "noise"),
+    ("dft65536_win2048_stereo_ragged", 2, 23456, 2048, 512, 65536, "noise"),
+    ("dft24576_three_residues", 1, 40000, 4096, 1024, 24576, "noise"),
+    ("dft32768_win12000_two_segments", 1, 60000, 12000, 3000, 32768, "noise"),
+    ("dft18432_c2_1024", 1, 30000, 2048, 512, 18432, "noise"),
+    ("dft32768_sine", 1, 48000, 4096, 1024, 32768, "sine"),
+    ("dft32768_one_frame", 1, 100, 4096, 1024, 32768, "noise"),
     ("dft66", 1, 3000, 64, 16, 66, "noise"),
     ("dft6_win4", 1, 300, 4, 2, 6, "noise"),
     ("dft3000_sine", 1, 48000, 2048, 512, 3000, "sine"),
@@ -701,7 +709,7 @@ def test_cancellation_is_scoped_to_the_stream_waited_on(fa):
     fa.check(lib.flanhip_stream_destroy(sB))
 
 
-@pytest.mark.parametrize("W,hop,dft", [(2048, 512, 3000), (4096, 1024, 16384), (600, 150, 1000), (1024, 256, 2998), (2048, 512, 5998)])
+@pytest.mark.parametrize("W,hop,dft", [(2048, 512, 3000), (4096, 1024, 16384), (600, 150, 1000), (1024, 256, 2998), (2048, 512, 5998), (4096, 1024, 32768)])
 def test_mixed_radix_kernels_against_the_direct_sums(fa, W, hop, dft):
     """The mixed-radix FFT kernels (pv_kernels_mr.h) against the transform's definition summed in fp64 (pv_kernels_any.h, the force_direct hook)
     on the same input: PVs agree like two FFT backends do, audio from the SAME PV to 1e-6."""
