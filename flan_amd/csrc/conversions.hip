@@ -25,8 +25,9 @@ namespace flanhip {
 
 static constexpr size_t kMaxLds = 160 * 1024;   // gfx950: 160 KiB LDS per CU, one workgroup may take all of it
 
-// dft sizes: powers of two in [32, 8192] have FFT kernels (tuned or LDS-resident); every other EVEN size the reference would hand to FFTW
-// (FFTHelper.cpp:16-26) -- 3000, 16384 ... -- runs the direct-sum kernels of pv_kernels_any.h.  Odd sizes are refused: the reference's own
+// dft sizes: powers of two in [32, 8192] have FFT kernels (tuned or LDS-resident); of the other EVEN sizes the reference would hand to FFTW
+// (FFTHelper.cpp:16-26) the mixed-radix, chirp-z and residue-pair kernels serve what mr_size / bs_size / big_size below say, and the direct-sum
+// kernels of pv_kernels_any.h the rest.  Odd sizes are refused: the reference's own
 // PVBuffer derives the dft size as ( bins - 1 ) * 2 (PVBuffer.cpp:356-359), so an odd one does not survive its own round trip.
 static constexpr int kMaxAnyDft = 1 << 20;
 static bool fft_size( int dft ) { return is_pow2( dft ) && dft >= 32 && dft <= 8192; }
