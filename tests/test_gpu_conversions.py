@@ -312,7 +312,10 @@ def test_fused_round_trip_equals_unfused(fa):
                                  (1, 40000, 4096, 1024, 8192), (2, 30000, 2048, 300, 4096), (3, 500000, 2000, 500, 4096), (2, 200000, 4000, 1000, 4096),
                                  # the mixed-radix kernels: sums kept by the analysis kernel (ping-pong sizes, with and without the large odd radices) or by
                                  # the pre-pass kernel on its behalf (in place: 12000)
-                                 (2, 300000, 2048, 512, 3000), (1, 120000, 1024, 256, 2002), (1, 200000, 2048, 512, 12000), (1, 60000, 600, 150, 1000)]:
+                                 (2, 300000, 2048, 512, 3000), (1, 120000, 1024, 256, 2002), (1, 200000, 2048, 512, 12000), (1, 60000, 600, 150, 1000),
+                                 # the chirp-z kernels (sums kept by the ping-pong kernels, with and without the tables in registers; by the pre-pass kernel for the
+                                 # in-place layout) and the residue-pair kernels above 16384 (pre-pass kernel on their behalf)
+                                 (2, 300000, 2048, 512, 2998), (1, 120000, 1024, 256, 2018), (1, 200000, 2048, 512, 5998), (2, 400000, 4096, 1024, 32768)]:
         x = O.noise(ch, n, seed=31)
         F = O.num_pv_frames(n, hop)
         bins = dft // 2 + 1
@@ -478,11 +481,58 @@ def test_random_smooth_sizes(fa, ch, n, W, hop, dft):
     assert rms <= 1e-5 * max(scale, 1.0)
 
 
+def _random_chirp_and_big_shapes(count, seed):
+    """seeded shapes for the chirp-z kernels (pv_kernels_bs.h: half the size with a prime factor above 13, both layouts, M = 128 ... 8192) and for the
+    residue-pair kernels above 16384 (pv_kernels_big.h: C1 = 2 ... 9 and 32, C2 = 1024 ... 4096, windows of one to three segments); windows up to the
+    dft, hops up to beyond the window, ragged lengths, one to three channels"""
+    rng = np.random.default_rng(seed)
+    primes = [67, 101, 131, 257, 331, 509, 521, 769, 1009, 1031, 1499, 2039, 2053, 2999, 4093]
+    chirp = sorted({2 * p * a for p in primes for a in (1, 2, 3, 4, 6) if 64 <= p * a <= 4096})
+    big = [2 * 1024 * c1 for c1 in (9, 10, 11, 14, 18)] + [2 * 2048 * c1 for c1 in (5, 7, 9)] + [2 * 4096 * c1 for c1 in (2, 3, 4, 5, 6, 8, 32)]
+    shapes = []
+    for i in range(count):
+        is_big = i % 3 == 2
+        dft = int(rng.choice(big if is_big else chirp))
+        if is_big:
+            W = int(rng.choice([1024, 2048, 4096, 5000, 8192, 12000]))
+            W = min(W, dft, (2 ** 31 - 1) // dft)      # (dft x window beyond int32 is refused: the reference's own product overflows, AudioPV.cpp:99)
+        else:
+            W = dft if rng.random() < 0.4 else int(rng.integers(max(dft // 8, 2), dft + 1))
+        hop = int(rng.integers(max(W // 16, 1), 2 * W)) if rng.random() < 0.25 else int(rng.integers(max(W // 8, 1), W + 1))
+        ch = int(rng.integers(1, 4))
+        frames = int(rng.integers(1, 12 if is_big else 30))
+        n = max(int(frames * hop + rng.integers(-hop // 2, hop // 2 + 1)), 1)
+        shapes.append((ch, n, W, hop, dft))
+    return shapes
+
+
+@pytest.mark.parametrize("ch,n,W,hop,dft", _random_chirp_and_big_shapes(30, 20261005), ids=lambda v: str(v))
+def test_random_chirp_z_and_big_sizes(fa, ch, n, W, hop, dft):
+    sr = 48000.0
+    x = O.noise(ch, n, seed=ch * 13 + W + hop)
+    ref = O.analyze(x, sr, W, hop, dft)
+    got = fa.analyze(x, sr, W, hop, dft)
+    assert got.shape == ref.shape and np.all(np.isfinite(got))
+    ar = np.float32(sr) / np.float32(hop)
+    rel_m, wrms_f, same, turns = p1_metrics(got, ref, float(ar))
+    if O.lib.oracle_hop_size(sr, ar) != hop:
+        pytest.skip("hop %d is not recovered from sample_rate / analysis_rate in fp32 (PVBuffer.cpp:381-384): synthesis undefined" % hop)
+    out_ref, _ = O.synthesize(ref, sr, ar, W)
+    out_got, flag = fa.synthesize(ref, sr, ar, W)
+    assert out_got.shape == out_ref.shape and flag == 0
+    scale = max(float(np.sqrt(np.mean(out_ref.astype(np.float64) ** 2))), 1e-30)
+    rms = float(np.sqrt(np.mean((out_got.astype(np.float64) - out_ref.astype(np.float64)) ** 2)))
+    print("\n[chirp / big %s] P1 rel_m=%.2e wrms_df=%.2e same=%.4f  P2 rms=%.2e (signal rms %.2e)" % ((ch, n, W, hop, dft), rel_m, wrms_f, same, rms, scale))
+    assert rel_m <= 1e-5
+    assert wrms_f <= 2e-3 * max(sr / dft / 23.4, 1.0)
+    assert rms <= 1e-5 * max(scale, 1.0)
+
+
 @pytest.mark.parametrize("n", [0, 1, 2, 3])
 def test_degenerate_lengths(fa, n):
     """empty and near-empty signals: one frame of (almost) silence through every dft class, like the reference would produce"""
     sr = 48000.0
-    for (W, hop, dft) in ((2048, 512, 2048), (2048, 128, 4096), (256, 64, 256)):
+    for (W, hop, dft) in ((2048, 512, 2048), (2048, 128, 4096), (256, 64, 256), (1024, 256, 1024), (512, 128, 512), (1024, 256, 2998), (4096, 1024, 32768)):
         x = O.noise(2, max(n, 1), seed=5)[:, :n].copy()
         ref = O.analyze(x, sr, W, hop, dft)
         got = fa.analyze(x, sr, W, hop, dft)
