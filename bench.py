@@ -380,7 +380,7 @@ def main():
             kname, tk, b = "k_synthesize", t_sy_main, BYTES_SYNTHESIS
         achieved = frames_per_step * b / (tk * 1e-3) / 1e9
         # HBM bytes per launch of that kernel: not measurable from inside this process (PMC counters need rocprofv3), so the figure comes
-        # from the committed PMC profile of this same workload and build (tools/scripts/profile_bench.sh -> profiles/r04_hbm_traffic.json:
+        # from the committed PMC profile of this same workload and build (tools/scripts/profile_bench.sh -> profiles/r05_hbm_traffic.json:
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, with the unit and gfx950 corrections the file explains) and is
         # labelled with its source; null for any other workload shape
         # the profile carries the hash of the kernel sources it was taken on (flan_amd/build.py: kernel_source_hash): a profile of other
@@ -389,14 +389,14 @@ def main():
         try:
             if ch == 8 and abs(args.seconds - 60.0) < 1e-9 and DFT == 2048 and HOP == 512 and WINDOW == 2048:
                 from flan_amd.build import kernel_source_hash
-                path = os.path.join(ROOT, "profiles", "r04_hbm_traffic.json")
+                path = os.path.join(ROOT, "profiles", "r05_hbm_traffic.json")
                 with open(path) as fh:
                     prof = json.load(fh)
                 if prof.get("kernel_source_hash") == kernel_source_hash():
                     traffic = prof[kname]["traffic_bytes"]
-                    traffic_source = "profiles/r04_hbm_traffic.json"
+                    traffic_source = "profiles/r05_hbm_traffic.json"
                 else:
-                    traffic_source = "profiles/r04_hbm_traffic.json was taken on other kernel sources (%s, now %s): not quoted" % (str(prof.get("kernel_source_hash"))[:12], kernel_source_hash()[:12])
+                    traffic_source = "profiles/r05_hbm_traffic.json was taken on other kernel sources (%s, now %s): not quoted" % (str(prof.get("kernel_source_hash"))[:12], kernel_source_hash()[:12])
         except Exception as e:
             traffic, traffic_source = None, "no traffic profile: " + repr(e)
         # what a plain device-to-device copy of the same number of bytes reaches on this box (quote the measured
@@ -422,13 +422,13 @@ def main():
                     "copy_peak_measured": copy_gbs}
         # The bound that actually holds these kernels is the vector ALU, not HBM: the launch's VALU instruction mix, priced per
         # class with the measured issue costs, against the launch's own cycles.  PMC counters cannot be read from inside the process: the mix is
-        # the committed profile's (profiles/r04_valu_roofline.json, tools/make_valu_roofline.py), quoted only while the kernel sources' hash
+        # the committed profile's (profiles/r05_valu_roofline.json, tools/make_valu_roofline.py), quoted only while the kernel sources' hash
         # matches; the duration is the one measured live above, the clock the one the profile measured (GRBM_GUI_ACTIVE)
         roofline_valu = None
         try:
             if ch == 8 and abs(args.seconds - 60.0) < 1e-9 and DFT == 2048 and HOP == 512 and WINDOW == 2048 and not args.unfused:
                 from flan_amd.build import kernel_source_hash
-                with open(os.path.join(ROOT, "profiles", "r04_valu_roofline.json")) as fh:
+                with open(os.path.join(ROOT, "profiles", "r05_valu_roofline.json")) as fh:
                     vp_ = json.load(fh)
                 if vp_.get("kernel_source_hash") == kernel_source_hash():
                     k_ = vp_[kname]
@@ -437,9 +437,9 @@ def main():
                     roofline_valu = {"bound": "valu", "kernel": kname, "priced_simd_cycles": k_["priced_simd_cycles_per_launch"], "launch_cycles": int(cycles),
                                      "frac": round(k_["priced_simd_cycles_per_launch"] / cycles, 4), "clock_ghz": clock, "insts_valu": k_["insts_valu"],
                                      "full_rate_floor_frac": round(k_["full_rate_floor_cycles"] / cycles, 4),
-                                     "source": "profiles/r04_valu_roofline.json (SQ_INSTS_VALU_* per class x profiles/r03_a_issue_model.txt prices; LDS, VMEM and scalar issue not included)"}
+                                     "source": "profiles/r05_valu_roofline.json (SQ_INSTS_VALU_* per class x profiles/r03_a_issue_model.txt prices; LDS, VMEM and scalar issue not included)"}
                 else:
-                    roofline_valu = {"frac": None, "source": "profiles/r04_valu_roofline.json was taken on other kernel sources: not quoted"}
+                    roofline_valu = {"frac": None, "source": "profiles/r05_valu_roofline.json was taken on other kernel sources: not quoted"}
         except Exception as e:
             roofline_valu = {"frac": None, "source": "no instruction-mix profile: " + repr(e)}
         extra["roofline_valu"] = roofline_valu
@@ -698,8 +698,11 @@ def other_configs(fa, torch, dev):
     # ---- the reference API's own defaults: convert_to_PV() = ( 2048, 128, 4096 ) (Audio.h:158-163), and ( 2048, 512, 4096 )
     # ... and ( 4096, 1024, 4096 ): window = dft, the plain STFT call at that size (the team kernels' one-buffer-set variants)
     # ... and the two power-of-two sizes below the metric's: ( 1024, 256, 1024 ) -- the classic setting -- and ( 512, 128, 512 ) (pv_kernels_v3.h, round 5)
+    # ... and two sizes FFTW plans like any other (FFTHelper.cpp:16-26): ( 2048, 512, 2998 ), half the size 1499 a prime (Bluestein's chirp-z form,
+    # pv_kernels_bs.h), and ( 4096, 1024, 32768 ) (residue pairs, pv_kernels_big.h: a 2.95 GB PV) -- both direct sums until round 5
     for (hop, tag, Wd, dft) in ((128, "api_default_2048_128_4096", 2048, 4096), (512, "dft4096_hop512", 2048, 4096), (1024, "window4096_hop1024_dft4096", 4096, 4096),
-                                (256, "dft1024_window1024_hop256", 1024, 1024), (128, "dft512_window512_hop128", 512, 512)):
+                                (256, "dft1024_window1024_hop256", 1024, 1024), (128, "dft512_window512_hop128", 512, 512),
+                                (512, "dft2998_window2048_hop512_chirp_z", 2048, 2998), (1024, "dft32768_window4096_hop1024", 4096, 32768)):
         bins = dft // 2 + 1
         Fd = int(lib.flanhip_num_pv_frames(n, hop))
         ard = SR / hop
