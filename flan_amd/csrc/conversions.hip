@@ -540,20 +540,21 @@ static int self_carry_group( int dft, int W, int hop, int chains_per_channel )
 // flanhip_analyze_dev_fused always leaves convert_to_audio's pre-pass in the workspace.  The tuned kernels and the generic
 // ones up to dft 2048 accumulate the sums while they have every f in a register; the generic kernels for dft >= 4096 keep no
 // such state (64 bins per lane), so there the pre-pass kernel itself is run on the fresh PV on the analysis' behalf.
-static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft, flanhip_MF * d_out, void * d_fused_ws, hipStream_t s, bool * left_group_sums );
+static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft, flanhip_MF * d_out, void * d_fused_ws, hipStream_t s, bool * left_group_sums, int * epoch );
 
 // The note "this workspace holds group totals too" (which lets the dft 2048 synthesis skip its scan kernel) is written only once the producing
 // launch has been accepted, and withdrawn before it is attempted: a launch that fails leaves the workspace marked as needing the scan.
 int launch_analyze( const float * d_audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft, flanhip_MF * d_out, void * d_fused_ws, hipStream_t s )
 	{
 	bool left_group_sums = false;
+	int epoch = 0;
 	if( d_fused_ws ) note_workspace_producer( d_fused_ws, 0 );
-	const int rc = launch_analyze_body( d_audio, ch, n, sr, W, hop, dft, d_out, d_fused_ws, s, &left_group_sums );
-	if( !rc && d_fused_ws && left_group_sums ) note_workspace_producer( d_fused_ws, 1 );
+	const int rc = launch_analyze_body( d_audio, ch, n, sr, W, hop, dft, d_out, d_fused_ws, s, &left_group_sums, &epoch );
+	if( !rc && d_fused_ws && left_group_sums ) note_workspace_producer( d_fused_ws, 1, epoch );
 	return rc;
 	}
 
-static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft, flanhip_MF * d_out, void * d_fused_ws, hipStream_t s, bool * left_group_sums )
+static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, float sr, int W, int hop, int dft, flanhip_MF * d_out, void * d_fused_ws, hipStream_t s, bool * left_group_sums, int * epoch )
 	{
 	FLANHIP_REQUIRE( d_audio && d_out, FLANHIP_ERR_INVALID_ARG, "null buffer" );
 	FLANHIP_REQUIRE( ch > 0 && n >= 0 && W >= 2 && hop >= 1 && sr > 0.0f, FLANHIP_ERR_INVALID_ARG, "bad sizes" );
@@ -599,6 +600,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 		SynthLayout & lay = fused_lay;
 		if( int rc = synth_layout( ch, p.F, dft / 2 + 1, sr, p.analysis_rate, W, &lay ) ) return rc;
 		p.nan_epoch = next_epoch();
+		*epoch = p.nan_epoch;
 		if( kernel_sums )
 			{
 			p.L = lay.L;
@@ -833,10 +835,13 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	const int stages = prepass_only ? 3 : ( stage_mask & 0xF );
 	// The dft 2048 analysis kernel leaves group totals beside the chain sums (launch_analyze notes that for this workspace): the dft 2048
 	// synthesis kernel then works out its own carries and the scan kernel is not launched.  Any other producer or shape: the scan runs.
+	int noted_epoch = 0;
 	const bool self_carry = presummed == 1 && !prepass_only && !d_carry_in && !d_total_out && debug_options().syn_variant != 2
-		&& self_carry_group( lay.dft, W, lay.hop, lay.chains_per_channel ) != 0 && workspace_producer( d_ws ) == 1;
+		&& self_carry_group( lay.dft, W, lay.hop, lay.chains_per_channel ) != 0 && workspace_producer( d_ws, &noted_epoch ) == 1;
 	if( self_carry )
 		{
+		// the note is the host's; what is IN the workspace is checked by the kernel against it (two callers racing on one workspace: flag 2, not silence)
+		p.expect_epoch = noted_epoch;
 		p.group_sums = reinterpret_cast<const double*>( reinterpret_cast<char*>( d_ws ) + lay.group_offset );
 		p.groups_per_channel = lay.groups_per_channel;
 		// up to 40 groups per channel the synthesis kernel adds the totals of the groups before its own itself (no kernel in front: measured

@@ -273,21 +273,22 @@ int choose_chain_length( int64_t num_channels, int64_t num_frames, int min_len, 
 	}
 
 static std::mutex g_ws_mutex;
-static std::map<const void*, int> g_ws_producer;
-void note_workspace_producer( const void * d_ws, int kind )
+static std::map<const void*, std::pair<int, int>> g_ws_producer;
+void note_workspace_producer( const void * d_ws, int kind, int epoch )
 	{
 	std::lock_guard<std::mutex> lock( g_ws_mutex );
 	if( !kind ) { g_ws_producer.erase( d_ws ); return; }
 	// addresses the library never sees freed (a caller's own allocator) would pile up: forgetting everything is always safe -- a workspace
 	// without a note gets the scan kernel
 	if( g_ws_producer.size() >= 1024 ) g_ws_producer.clear();
-	g_ws_producer[d_ws] = kind;
+	g_ws_producer[d_ws] = std::make_pair( kind, epoch );
 	}
-int workspace_producer( const void * d_ws )
+int workspace_producer( const void * d_ws, int * epoch )
 	{
 	std::lock_guard<std::mutex> lock( g_ws_mutex );
 	auto it = g_ws_producer.find( d_ws );
-	return it == g_ws_producer.end() ? 0 : it->second;
+	if( epoch ) *epoch = it == g_ws_producer.end() ? 0 : it->second.second;
+	return it == g_ws_producer.end() ? 0 : it->second.first;
 	}
 
 // ---- cancellation inside a launch (defines.h:49-62: the reference polls its flag once per frame, AudioPV.cpp:49,115) -----------------

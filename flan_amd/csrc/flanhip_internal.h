@@ -104,8 +104,8 @@ struct SynthLayout { int hop, dft, L, chains_per_channel, head_len, groups_per_c
 	bool big; size_t big_out_offset, big_head_offset; };      // big: a dft size above 16384 served by pv_kernels_big.h; its units' partial output streams and heads
 // which producer last left its pre-pass in a synthesis workspace (host-side note, keyed by the workspace pointer, written when the
 // producer is launched and read when flanhip_synthesize_dev_fused is): 1 = chain sums AND group sums (the dft 2048 analysis kernel)
-void note_workspace_producer( const void * d_ws, int kind );
-int workspace_producer( const void * d_ws );
+void note_workspace_producer( const void * d_ws, int kind, int epoch = 0 );   // epoch: what the producer's kernel leaves in the workspace's tag word [2]
+int workspace_producer( const void * d_ws, int * epoch = nullptr );
 int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, SynthLayout * out );
 
 // Interpolators: a named kind (FLANHIP_INTERP_LINEAR .. _SINE) or a live table registered with flanhip_interp_table_create (processors_ext.hip)

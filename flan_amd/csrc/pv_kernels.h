@@ -302,6 +302,8 @@ struct SynthParams
 	int total_only;           // k_phase_scan2 leaves the chain sums untouched (only total_out is produced)
 	int * nan_words;          // optional (pre-pass run on behalf of a producer): the producer's { flag, -, epoch } words to write
 	int nan_epoch;
+	int expect_epoch;          // non-zero: what the host's note says the producer of this workspace left in nan_in[2]; anything else there means ANOTHER producer
+	                           // wrote the workspace in between (two callers racing on one workspace): nan_flag |= 2, the output is not to be trusted
 	const int * skip_words;   // optional: the pre-pass retires at once when words [4] and [2] agree (the producer of the PV left the sums)
 	const int * cancel;        // optional: the launching thread's cancel word (see AnalyzeParams)
 	const double * group_sums; // optional (dft 2048 / 4096 team kernels): the producer's per-group sums [ch][groups][bins] -- a scan over THEM (k_phase_scan2<SEG, true>:

@@ -811,6 +811,7 @@ __global__ __launch_bounds__( 512 ) void k_phase_scan2( SynthParams p )
 	if( !GROUPS && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 )
 		{
 		if( p.nan_in && p.nan_flag && p.nan_in[0] == p.nan_in[2] && p.nan_in[2] != 0 ) atomicOr( p.nan_flag, 1 );
+		if( p.expect_epoch && p.nan_in && p.nan_flag && p.nan_in[2] != p.expect_epoch ) atomicOr( p.nan_flag, 2 );   // the sums in this workspace are not the noted producer's
 		// the sums become carries below: a handed-over pre-pass is good for one convert_to_audio only
 		if( p.skip_words ) const_cast<int*>( p.skip_words )[4] = 0;
 		}

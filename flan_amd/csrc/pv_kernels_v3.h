@@ -603,6 +603,7 @@ __global__ __launch_bounds__( 64 * WAVES, OCC ) void k_synthesize_v3( SynthParam
 		if( tid == 0 && blockIdx.x == 0 )
 			{
 			if( p.nan_in && p.nan_flag && p.nan_in[0] == p.nan_in[2] && p.nan_in[2] != 0 ) atomicOr( p.nan_flag, 1 );
+			if( p.expect_epoch && p.nan_in && p.nan_flag && p.nan_in[2] != p.expect_epoch ) atomicOr( p.nan_flag, 2 );   // the sums in this workspace are not the noted producer's
 			if( p.skip_words ) const_cast<int*>( p.skip_words )[4] = 0;              // a handed-over pre-pass is good for one convert_to_audio (k_sums_and_groups has read the word: a launch ago)
 			}
 		__syncthreads();

@@ -121,7 +121,9 @@ int flanhip_synthesize(const flanhip_MF * pv, int64_t num_channels, int64_t num_
                        float * out, int * nan_flag, volatile int * cancel);
 /* Device form.  d_workspace must hold flanhip_synthesize_workspace_bytes(...) bytes for the SAME arguments (and the same
  * setting of the debug knobs FLANHIP_CHAIN_LEN / FLANHIP_TARGET_CHAINS / FLANHIP_FORCE_GENERIC, which change the layout and
- * are read per call); d_nan_flag (may be NULL) is a device int that is OR-ed with 1 on NaN/Inf (the caller zeroes it). */
+ * are read per call); d_nan_flag (may be NULL) is a device int that is OR-ed with 1 on NaN/Inf (the caller zeroes it), and with 2 by
+ * flanhip_synthesize_dev_fused when the workspace does not hold what the library noted its last producer left there (two callers racing on one
+ * workspace between an analysis and its synthesis: the output is then not to be trusted). */
 size_t flanhip_synthesize_workspace_bytes(int64_t num_channels, int64_t num_pv_frames, int num_bins,
                                           float sample_rate, float analysis_rate, int window_size);
 int flanhip_synthesize_dev(const flanhip_MF * d_pv, int64_t num_channels, int64_t num_pv_frames, int num_bins,

@@ -354,6 +354,54 @@ def test_fused_round_trip_equals_unfused(fa):
         assert res[0][2] == res[1][2] == 0
 
 
+@pytest.mark.parametrize("W,hop,dft", [(2048, 512, 2048), (1024, 256, 1024), (2048, 512, 4096)])
+def test_a_workspace_written_by_another_producer_is_reported(fa, W, hop, dft):
+    """Which producer filled a synthesis workspace is a host-side note (core.hip); what is IN the workspace carries the producer's epoch, and the
+    synthesis kernels that take their carries from the analysis' group totals check the one against the other: a workspace another producer wrote
+    in between (two callers racing on one workspace) raises bit 1 of the flag (value 2) instead of passing silently.  Emulated by copying a second
+    round trip's workspace over the first's behind the library's back."""
+    import ctypes
+    lib = fa.lib
+    sr = 48000.0
+    ch, n = 2, 300000
+    F = O.num_pv_frames(n, hop)
+    bins = dft // 2 + 1
+    ar = np.float32(sr) / np.float32(hop)
+
+    def dev_alloc(nbytes):
+        p = ctypes.c_void_p()
+        fa.check(lib.flanhip_malloc(ctypes.byref(p), nbytes))
+        return p
+    ws_bytes = lib.flanhip_synthesize_workspace_bytes(ch, F, bins, sr, ar, W)
+    d_x = [dev_alloc(ch * n * 4) for _ in range(2)]
+    d_pv = [dev_alloc(ch * F * bins * 8) for _ in range(2)]
+    d_ws = [dev_alloc(ws_bytes) for _ in range(2)]
+    d_out, d_flag = dev_alloc(ch * F * hop * 4), dev_alloc(4)
+    try:
+        for i in range(2):
+            x = O.noise(ch, n, seed=100 + i)
+            fa.check(lib.flanhip_memcpy_h2d(d_x[i], x.ctypes.data_as(ctypes.c_void_p), x.nbytes, None))
+            fa.check(lib.flanhip_analyze_dev_fused(d_x[i], ch, n, sr, W, hop, dft, d_pv[i], d_ws[i], None))
+        flag = np.zeros(1, np.int32)
+
+        def synth(i):
+            fa.check(lib.flanhip_memset(d_flag, 0, 4, None))
+            fa.check(lib.flanhip_synthesize_dev_fused(d_pv[i], ch, F, bins, sr, ar, W, d_out, d_ws[i], d_flag, None))
+            fa.check(lib.flanhip_memcpy_d2h(flag.ctypes.data_as(ctypes.c_void_p), d_flag, 4, None))
+            fa.check(lib.flanhip_stream_synchronize(None))
+            return int(flag[0])
+        assert synth(0) == 0 and synth(1) == 0 and synth(0) == 0               # the producers' own workspaces, in any order, as often as wanted
+        host = np.empty(ws_bytes, np.uint8)
+        fa.check(lib.flanhip_memcpy_d2h(host.ctypes.data_as(ctypes.c_void_p), d_ws[1], ws_bytes, None))
+        fa.check(lib.flanhip_stream_synchronize(None))
+        fa.check(lib.flanhip_memcpy_h2d(d_ws[0], host.ctypes.data_as(ctypes.c_void_p), ws_bytes, None))
+        assert synth(0) & 2                                                    # workspace 0 now holds producer 1's sums: reported
+        assert synth(1) == 0
+    finally:
+        for p in d_x + d_pv + d_ws + [d_out, d_flag]:
+            lib.flanhip_free(p)
+
+
 @pytest.mark.parametrize("dft,hop,ch,n,W", [(2048, 512, 8, 300000, 2048), (4096, 512, 4, 600000, 2048), (4096, 128, 2, 400000, 2048), (4096, 1024, 4, 1400000, 2048),
                                             (2048, 512, 3, 900000, 2048), (4096, 1024, 4, 1400000, 4096), (4096, 512, 4, 600000, 3072), (2048, 512, 1, 2000000, 2048),
                                             (4096, 441, 4, 600000, 2048), (4096, 500, 2, 900000, 2000), (1024, 256, 8, 600000, 1024), (1024, 512, 3, 900000, 768), (1024, 128, 1, 2000000, 1024), (512, 128, 2, 400000, 512), (512, 256, 5, 300000, 512)])
