@@ -218,7 +218,8 @@ Audio PV::convert_to_audio( flan_CANCEL_ARG_CPP ) const
 	const int waited = flanhip_wait_cancellable_fn( nullptr, detail::poll_canceller, &canceller );   // flan_CANCEL_POINT while the kernels run
 	if( waited == FLANHIP_ERR_CANCELLED ) return Audio::create_null();
 	if( !detail::report( waited, "convert_to_audio" ) ) return Audio::create_null();
-	if( nan_flag )                                             // AudioPV.cpp:88-89
+	if( nan_flag & 2 ) { detail::report( FLANHIP_ERR_INVALID_ARG, "convert_to_audio (the synthesis workspace was overwritten by another producer)" ); return Audio::create_null(); }
+	if( nan_flag & 1 )                                         // AudioPV.cpp:88-89
 		std::cout << "flan::convert_to_audio recieved a nan or infinite value. This often happens when dividing by zero in an earlier algorithm.";
 	if( canceller ) return Audio::create_null();
 	return AudioBuffer::adopt_device( af, std::move( out ) );
