@@ -62,7 +62,7 @@ __device__ __forceinline__ MF phase_vocode_bin( float re, float im, float & prev
 	float analysis_rate, bool use_wrapping )
 	{
 	const float phase = atan2_fast( im, re );                                         // std::arg
-	const float phase_diff = float( double( phase ) - double( prev_phase ) );         // :44 (double subtraction, narrowed)
+	const float phase_diff = phase - prev_phase;                                      // :44 ( == float( double( phase ) - double( prev ) ): the double difference of two floats is exact, its narrowing the fp32 subtraction's own rounding )
 	prev_phase = phase;                                                               // :45
 	const float delta_phase = phase_diff - expected_phase_diff;                       // :48
 	const float wrapped = use_wrapping ? delta_phase - FLANHIP_PI2_F * round_half_away( div_pi2( delta_phase ) ) : delta_phase; // :39-42,49 (roundf, exactly: pv_math.h)
@@ -201,8 +201,8 @@ __global__ __launch_bounds__( 64 * WAVES * T ) void k_analyze( AnalyzeParams p )
 				if( emit )
 					{
 					row[k] = mf;
-					if constexpr( !LEAN ) sum[q] += double( mf.f / p.analysis_rate * FLANHIP_PI2_F );
-					bad |= isnan( mf.m ) || isnan( mf.f ) || isinf( mf.m ) || isinf( mf.f );
+					if constexpr( !LEAN ) sum[q] += double( div_c( mf.f, p.ar_div ) * FLANHIP_PI2_F );      // (the exact constant division: pv_math.h)
+					bad |= !( __builtin_fabsf( mf.m ) <= 3.4028235e38f ) || !( __builtin_fabsf( mf.f ) <= 3.4028235e38f );
 					}
 				}
 			}
@@ -219,8 +219,8 @@ __global__ __launch_bounds__( 64 * WAVES * T ) void k_analyze( AnalyzeParams p )
 			if( emit )
 				{
 				row[C] = mf;
-				if constexpr( !LEAN ) sum[E] += double( mf.f / p.analysis_rate * FLANHIP_PI2_F );
-				bad |= isnan( mf.m ) || isnan( mf.f ) || isinf( mf.m ) || isinf( mf.f );
+				if constexpr( !LEAN ) sum[E] += double( div_c( mf.f, p.ar_div ) * FLANHIP_PI2_F );
+				bad |= !( __builtin_fabsf( mf.m ) <= 3.4028235e38f ) || !( __builtin_fabsf( mf.f ) <= 3.4028235e38f );
 				}
 			}
 		team_sync<TEAM>();

@@ -86,7 +86,8 @@ __global__ __launch_bounds__( MR_THREADS, 2 ) void k_analyze_big( AnalyzeParams 
 	const int C = pl.C, C1 = pl.C1, C2 = pl.C2, W = p.window_size, hop = p.hop, dft = 2 * C;
 	int64_t chain; int unit;
 	if( !big_block( int64_t( p.chains_per_channel ) * p.num_channels, pl.P, chain, unit ) ) return;
-	if( cancel_seen( cancel_peek( p.cancel ) ) ) return;
+	__shared__ int s_cancel;                                                            // (one thread's reading for the whole block: the word may rise between two wavefronts' reads)
+	if( tid == 0 ) s_cancel = cancel_peek( p.cancel );
 	cf * s_tw = reinterpret_cast<cf*>( smem );
 	cf * bufA = s_tw + C2, * bufB = bufA + padded_len( C2 + 1 );
 	for( int j = tid; j < C2; j += MR_THREADS ) s_tw[j] = p.tw[int64_t( j ) * C1];     // exp( -2 pi i j / C2 )
@@ -106,6 +107,7 @@ __global__ __launch_bounds__( MR_THREADS, 2 ) void k_analyze_big( AnalyzeParams 
 	for( int q = 0; q < Q; ++q ) { prevA[q] = 0.0f; prevB[q] = 0.0f; }                   // AudioPV.cpp:44
 	const v4f_t kcC = mr_kc_value( C, p.tw2[C], p.sample_rate, p.analysis_rate, dft );
 	__syncthreads();
+	if( s_cancel ) return;
 
 	for( int64_t t = ( t0 > 0 ? t0 - 1 : t0 ); t < t1; ++t )                           // (the frame before the chain only lends its phases: phase_vocoder.cpp:45)
 		{
@@ -193,7 +195,8 @@ __global__ __launch_bounds__( MR_THREADS, 2 ) void k_synthesize_big( SynthParams
 	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;
 	int64_t chain; int unit;
 	if( !big_block( chains, pl.P, chain, unit ) ) return;
-	if( cancel_seen( cancel_peek( p.cancel ) ) ) return;
+	__shared__ int s_cancel;
+	if( tid == 0 ) s_cancel = cancel_peek( p.cancel );
 	cf * s_tw = reinterpret_cast<cf*>( smem );
 	cf * bufA = s_tw + C2, * bufB = bufA + padded_len( C2 + 1 );
 	float * ring = reinterpret_cast<float*>( bufB + padded_len( C2 + 1 ) );            // [wpad]
@@ -225,6 +228,7 @@ __global__ __launch_bounds__( MR_THREADS, 2 ) void k_synthesize_big( SynthParams
 		}
 	if( ka == 0 && tid == 0 ) phC = carry[C];
 	__syncthreads();
+	if( s_cancel ) return;
 
 	auto polar_of = [&]( MF mf, double & ph ) -> cf                                    // AudioPV.cpp:117-120, phase_vocoder.cpp:55-61
 		{
