@@ -317,7 +317,7 @@ static int run_synth_v3( const SynthParams & p, hipStream_t s )
 	{
 	using L = V3Lds<LOG2C>;
 	FLANHIP_REQUIRE( ( int64_t( WAVES ) * p.L + 2 ) * ( ( L::C + 1 ) * 8 ) < ( int64_t( 1 ) << 32 ), FLANHIP_ERR_UNSUPPORTED, "chain length too large for the dft 1024 / 512 kernel" );
-	const size_t lds = L::bytes( WAVES, false );
+	const size_t lds = L::bytes( WAVES, false ) + ( HOPQ == 0 ? size_t( WAVES ) * size_t( ( p.window_size + 63 ) & ~63 ) * 4 : 0 );   // (HOPQ 0: a ring of `window` floats per wavefront behind the buffers)
 	auto kern = k_synthesize_v3<LOG2C, WAVES, HOPQ, OCC>;
 	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 	const int64_t blocks = int64_t( ( p.chains_per_channel + WAVES - 1 ) / WAVES ) * p.num_channels;
@@ -326,9 +326,11 @@ static int run_synth_v3( const SynthParams & p, hipStream_t s )
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;
 	}
+static int synth_fast_kind( int dft, int W, int hop );
 template<int LOG2C, int WAVES, int OCC>
 static int run_synth_v3_hopq( const SynthParams & p, hipStream_t s )
 	{
+	if( synth_fast_kind( 2 << LOG2C, p.window_size, p.hop ) == 2 ) return run_synth_v3<LOG2C, 0, WAVES, OCC>( p, s );
 	switch( p.hop / 128 )
 		{
 		case 1: return run_synth_v3<LOG2C, 1, WAVES, OCC>( p, s );
@@ -392,7 +394,7 @@ static int synth_fast_kind( int dft, int W, int hop )
 	{
 	if( !( dft == 2048 || dft == 4096 || v3_size( dft ) ) || hop > W || hop < 1 || force_generic() ) return 0;
 	const int hq = hop / 128;
-	if( v3_size( dft ) ) return ( hop % 128 == 0 && ( hq == 1 || hq == 2 || hq == 4 || hq == 8 ) && W % 128 == 0 ) ? 1 : 0;   // (no LDS-ring form at these sizes: the generic kernels)
+	if( v3_size( dft ) ) return ( hop % 128 == 0 && ( hq == 1 || hq == 2 || hq == 4 || ( hq == 8 && dft == 1024 ) ) && W % 128 == 0 ) ? 1 : 2;   // (2: k_synthesize_v3's LDS-ring form, round 5)
 	if( hop % 128 == 0 && ( hq == 1 || hq == 2 || hq == 4 || hq == 8 ) && W % 128 == 0 ) return 1;
 	return 2;
 	}
@@ -527,7 +529,7 @@ static int self_carry_group( int dft, int W, int hop, int chains_per_channel )
 	const int kind = synth_fast_kind( dft, W, hop );
 	int g = 0;
 	// the LDS-ring form of the dft 4096 team synthesis (any hop, any window up to 2048: four teams per block like the analysis) takes the totals too
-	if( kind == 2 ) g = ( dft == 4096 && W <= 2048 && !debug_options().syn11_old && !debug_options().ana11_old ) ? 4 : 0;
+	if( kind == 2 ) g = ( dft == 4096 && W <= 2048 && !debug_options().syn11_old && !debug_options().ana11_old ) ? 4 : v3_size( dft ) ? group_size_of( dft ) : 0;
 	else if( kind != 1 ) return 0;
 	else if( dft == 2048 || v3_size( dft ) ) g = group_size_of( dft );
 	else if( dft == 4096 && W % 256 == 0 && ( hop == 128 || hop % 256 == 0 ) && !debug_options().syn11_old && !debug_options().ana11_old ) g = 4;   // (windows above 2048: the WBIG variants)

@@ -95,6 +95,12 @@ CASES = [
     ("dft512_hop256_win384", 1, 30000, 384, 256, 512, "noise"),
     ("dft512_short", 2, 700, 512, 128, 512, "noise"),
     ("dft512_sine", 1, 48000, 512, 128, 512, "sine"),
+    # ... and off their grid (hops that are no multiple of 128, windows that are none): the tuned analysis, the synthesis with its accumulator as an LDS ring
+    ("dft1024_win1000_hop250", 2, 30000, 1000, 250, 1024, "noise"),
+    ("dft1024_hop300", 1, 30000, 1024, 300, 1024, "noise"),
+    ("dft1024_win999_hop333_ragged", 3, 12345, 999, 333, 1024, "noise"),
+    ("dft512_win500_hop125", 2, 20000, 500, 125, 512, "noise"),
+    ("dft512_hop100", 1, 20000, 512, 100, 512, "noise"),
     ("dft8192", 1, 40000, 4096, 1024, 8192, "noise"),
     ("dft64", 1, 3000, 64, 16, 64, "noise"),
     ("dft32_win32", 1, 1000, 32, 8, 32, "noise"),
@@ -310,6 +316,7 @@ def test_fused_round_trip_equals_unfused(fa):
     # dft 8192 (and 4096 through the generic kernels): block-wide teams walk the chains; they leave the sums like every other analysis kernel
     for (ch, n, W, hop, dft) in [(2, 70000, 2048, 512, 2048), (1, 30000, 2048, 128, 4096), (2, 20000, 1024, 256, 1024), (1, 9000, 400, 100, 512), (2, 40000, 512, 128, 512), (3, 90000, 1024, 512, 1024),
                                  (1, 40000, 4096, 1024, 8192), (2, 30000, 2048, 300, 4096), (3, 500000, 2000, 500, 4096), (2, 200000, 4000, 1000, 4096),
+                                 (3, 500000, 1000, 250, 1024), (2, 30000, 1024, 300, 1024), (4, 300000, 500, 125, 512), (1, 20000, 512, 100, 512),
                                  # the mixed-radix kernels: sums kept by the analysis kernel (ping-pong sizes, with and without the large odd radices) or by
                                  # the pre-pass kernel on its behalf (in place: 12000)
                                  (2, 300000, 2048, 512, 3000), (1, 120000, 1024, 256, 2002), (1, 200000, 2048, 512, 12000), (1, 60000, 600, 150, 1000),
@@ -404,12 +411,13 @@ def test_a_workspace_written_by_another_producer_is_reported(fa, W, hop, dft):
 
 @pytest.mark.parametrize("dft,hop,ch,n,W", [(2048, 512, 8, 300000, 2048), (4096, 512, 4, 600000, 2048), (4096, 128, 2, 400000, 2048), (4096, 1024, 4, 1400000, 2048),
                                             (2048, 512, 3, 900000, 2048), (4096, 1024, 4, 1400000, 4096), (4096, 512, 4, 600000, 3072), (2048, 512, 1, 2000000, 2048),
-                                            (4096, 441, 4, 600000, 2048), (4096, 500, 2, 900000, 2000), (1024, 256, 8, 600000, 1024), (1024, 512, 3, 900000, 768), (1024, 128, 1, 2000000, 1024), (512, 128, 2, 400000, 512), (512, 256, 5, 300000, 512)])
+                                            (4096, 441, 4, 600000, 2048), (4096, 500, 2, 900000, 2000), (1024, 256, 8, 600000, 1024), (1024, 512, 3, 900000, 768), (1024, 128, 1, 2000000, 1024), (512, 128, 2, 400000, 512), (512, 256, 5, 300000, 512),
+                                            (1024, 250, 4, 600000, 1000), (1024, 300, 2, 900000, 1024), (512, 125, 3, 400000, 500)])
 def test_carry_prologue_equals_scan_kernel(fa, dft, hop, ch, n, W):
     """Fused round trip: the synthesis kernels that take their chains' carries from a scan over the analysis' GROUP totals plus the chain sums
     (dft 2048 / 1024: groups of 8 chains; dft 4096 team kernels and dft 512: groups of 4, the last group of a channel short; also the team kernels'
     one-buffer-set variants for windows above 2048) against the same launch with the scan over the chains themselves in front (synthesis variant 2); 147-977 chains per
-    channel: the same prefix sums associated group-wise -- audio bit for bit, NaN flag clear."""
+    channel: the same prefix sums in another association -- audio bit for bit but for the rare sample a carry's last bit decides (see below), NaN flag clear."""
     import ctypes
     lib = fa.lib
     sr = 48000.0
@@ -444,7 +452,13 @@ def test_carry_prologue_equals_scan_kernel(fa, dft, hop, ch, n, W):
         lib.flanhip_debug_option(fa.DEBUG_SYN_VARIANT, 0)
         lib.flanhip_free(d_x)
     assert outs[0][1] == 0 and outs[2][1] == 0
-    assert np.array_equal(outs[0][0].view(np.uint32), outs[2][0].view(np.uint32))
+    # The two forms add the same sums in two associations (groups of 8 / 4 chains, then the groups; against segments of 16 - 64 chains): carries
+    # equal to ~1e-15, and a carry's last bits decide a sample only where some frame's phase lies that close to a rounding boundary of its float
+    # -- no chain in most launches, one or two in a few (tools/carry_forms_agree.py: 3 of 96 shape x seed pairs, 22 - 151 samples of 1.2 - 2.4 M, one
+    # ulp each).  So: bit for bit but for a few samples in a few chains, those by one ulp of the signal's scale.
+    differing = int((outs[0][0].view(np.uint32) != outs[2][0].view(np.uint32)).sum())
+    assert differing <= 4e-4 * outs[0][0].size
+    assert np.abs(outs[0][0].astype(np.float64) - outs[2][0].astype(np.float64)).max() <= 2.4e-7
     assert np.abs(outs[0][0]).max() > 0.1
 
 
