@@ -418,8 +418,8 @@ template<int WAVES, int HOPQ, int ABL = 0>
 static int run_synth_v2( const SynthParams & p, const FastTables & tb, hipStream_t s )
 	{
 	FLANHIP_REQUIRE( ( int64_t( WAVES ) * p.L + 2 ) * 8200 < ( int64_t( 1 ) << 32 ), FLANHIP_ERR_UNSUPPORTED, "chain length too large for the dft 2048 kernel" );   // 32-bit byte offsets inside a block's frames
-	const size_t lds = V2LdsSyn::bytes( WAVES );
-	static_assert( V2LdsSyn::bytes( WAVES ) <= kMaxLds, "LDS budget" );
+	const size_t lds = V2LdsSyn::bytes( WAVES ) + ( HOPQ == 0 ? size_t( WAVES ) * size_t( ( p.window_size + 63 ) & ~63 ) * 4 : 0 );   // (HOPQ 0: a ring of `window` floats per wavefront behind the buffers)
+	static_assert( V2LdsSyn::bytes( WAVES ) + size_t( WAVES ) * 2048 * 4 <= kMaxLds, "LDS budget" );
 	auto kern = k_synthesize_v2<WAVES, HOPQ, ABL>;
 	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 	static_assert( WAVES == 8, "SynthLayout::groups_per_channel counts groups of 8 chains" );
@@ -506,7 +506,7 @@ static int run_synth_fast_hop( const SynthParams & p, const FastTables & tb, hip
 		}
 	if( synth_fast_kind( 2 << LOG2C, p.window_size, p.hop ) == 2 )                // any other hop <= window: ring accumulator in LDS
 		{
-		if constexpr( LOG2C == 10 ) return run_synth_fast<LOG2C, kSynWaves10, 0>( p, tb, s );
+		if constexpr( LOG2C == 10 ) return debug_options().syn_variant == 3 ? run_synth_fast<LOG2C, kSynWaves10, 0>( p, tb, s ) : run_synth_v2<8, 0>( p, tb, s );   // (round 5: k_synthesize_v2's ring form; SYN_VARIANT 3: the round-1 kernel, A/B)
 		else if( !debug_options().syn11_old ) return p.window_size <= 2048 ? run_synth_eo_team_ring<4, false>( p, tb, s ) : run_synth_eo_team_ring<3, true>( p, tb, s );
 		else return ring_waves11( p.window_size ) == 4 ? run_synth_fast<LOG2C, 4, 0>( p, tb, s ) : run_synth_fast<LOG2C, 3, 0>( p, tb, s );
 		}
@@ -529,7 +529,7 @@ static int self_carry_group( int dft, int W, int hop, int chains_per_channel )
 	const int kind = synth_fast_kind( dft, W, hop );
 	int g = 0;
 	// the LDS-ring form of the dft 4096 team synthesis (any hop, any window up to 2048: four teams per block like the analysis) takes the totals too
-	if( kind == 2 ) g = ( dft == 4096 && W <= 2048 && !debug_options().syn11_old && !debug_options().ana11_old ) ? 4 : v3_size( dft ) ? group_size_of( dft ) : 0;
+	if( kind == 2 ) g = ( dft == 4096 && W <= 2048 && !debug_options().syn11_old && !debug_options().ana11_old ) ? 4 : ( v3_size( dft ) || ( dft == 2048 && debug_options().syn_variant != 3 ) ) ? group_size_of( dft ) : 0;
 	else if( kind != 1 ) return 0;
 	else if( dft == 2048 || v3_size( dft ) ) g = group_size_of( dft );
 	else if( dft == 4096 && W % 256 == 0 && ( hop == 128 || hop % 256 == 0 ) && !debug_options().syn11_old && !debug_options().ana11_old ) g = 4;   // (windows above 2048: the WBIG variants)

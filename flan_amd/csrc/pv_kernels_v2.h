@@ -565,7 +565,11 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 	{
 	using L = V2LdsSyn;
 	constexpr int C = 1024, E = 16, H = 8, NT = 64 * WAVES;
-	static_assert( HOPQ == 1 || HOPQ == 2 || HOPQ == 4 || HOPQ == 8, "hop 128 / 256 / 512 / 1024" );
+	static_assert( HOPQ == 0 || HOPQ == 1 || HOPQ == 2 || HOPQ == 4 || HOPQ == 8, "hop 128 / 256 / 512 / 1024, or 0: any hop <= window, any window <= dft" );
+	// RING (HOPQ = 0, round 5): the overlap-add accumulator as a ring of `window` floats per wavefront in LDS instead of registers -- hops that are no multiple
+	// of 128 (300, 441 ...), windows that are none (2000, 1800 ...): those ran the round-1 kernel (k_synthesize_fast) until now.  Samples leave one by
+	// one (4-byte stores), the chains' overlaps through k_ola_fixup.
+	constexpr bool RING = HOPQ == 0;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	cf * s = reinterpret_cast<cf*>( smem );
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -595,7 +599,11 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 	const int64_t t0 = int64_t( chain_in_channel ) * p.L;
 	const int64_t t1 = min( t0 + int64_t( p.L ), p.F );
 	const bool last_chain = chain_in_channel == p.chains_per_channel - 1;
-	constexpr int hop = 128 * HOPQ;
+	const int hop = RING ? p.hop : 128 * HOPQ;
+	const int wpad = ( W + 63 ) & ~63;
+	float * ring = reinterpret_cast<float*>( s + L::BUF + WAVES * L::BUF_LEN ) + wave * wpad;      // RING only
+	if constexpr( RING ) { for( int i = lane; i < wpad; i += 64 ) ring[i] = 0.0f; }
+	int ring_base = 0;
 	float * out1 = p.out + int64_t( channel ) * p.out_len;
 	cf * out2 = reinterpret_cast<cf*>( out1 );
 	cf * head2 = reinterpret_cast<cf*>( p.head + chain * p.head_len );
@@ -623,7 +631,25 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 	// Exactly one store instruction per step, never inside a branch: lanes that fall outside the output are pointed at a 512-byte dump
 	// area in the workspace, so the number of stores in flight behind the row request is static (counted wait, see the loop)
 	cf * dump2 = reinterpret_cast<cf*>( p.dump ) + lane;
-	const bool fix = p.fix_state != nullptr;                                    // this launch adds the chains' overlaps itself (below)
+	const bool fix = !RING && p.fix_state != nullptr;                           // this launch adds the chains' overlaps itself (below)
+	float * head1 = p.head + chain * p.head_len;
+	int64_t pos_of_ring = chain_start;                                           // RING: ring[ring_base] <-> this absolute sample
+	// RING: the oldest `count` samples of the ring leave (and are cleared); sample by sample like the generic kernels (pv_kernels.h)
+	auto ring_emit = [&]( int count )
+		{
+		for( int e = lane; e < count; e += 64 )
+			{
+			float v = 0.0f;
+			if( e < W )
+				{
+				int j = ring_base + e; if( j >= W ) j -= W;
+				v = ring[j]; ring[j] = 0.0f;
+				}
+			const int64_t a = pos_of_ring + e;
+			if( a < own_start ) head1[a - chain_start] = v;
+			else if( a >= 0 && a < p.out_len ) out1[a] = v;
+			}
+		};
 	auto emit_step = [&]( int64_t a0, cf v )
 		{
 		const int64_t a = a0 + 2 * lane;
@@ -880,6 +906,31 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 		if constexpr( ( ABL & 8 ) == 0 )                                        // ABL 8 (timing only): no transform
 		fft_fast<10>( z, buf, s_tw1, s_tw3, lane );
 		// ---- G = fft( conj Z ): x[2n] = G[n].x, x[2n+1] = -G[n].y; window and overlap-add (AudioPV.cpp:122-134)
+		if constexpr( RING )
+			{
+			#pragma unroll
+			for( int q = 0; q < E; ++q )
+				{
+				const cf w = s_win[64 * q];
+				const int s0 = 2 * ( lane + 64 * q );
+				if( s0 < W )
+					{
+					int j = ring_base + s0; if( j >= W ) j -= W;
+					ring[j] += z[q].x * w.x;
+					if( s0 + 1 < W ) { int j1 = j + 1; if( j1 >= W ) j1 -= W; ring[j1] += ( -z[q].y ) * w.y; }
+					}
+				}
+			wave_sync();
+			ring_emit( hop );
+			wave_sync();
+			pos_of_ring += hop;
+			ring_base = ( hop < W ) ? ring_base + hop : 0;
+			if( ring_base >= W ) ring_base -= W;
+			pos += hop;
+			rel += hop;
+			if constexpr( !LAST ) bins_of_row();
+			return false;
+			}
 		#pragma unroll
 		for( int q = 0; q < E; ++q )
 			{
@@ -924,6 +975,22 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 	// flush the partial sums that the next chain's head completes; the last chain zero-fills to the end of the output
 	const int64_t ring_end = pos + ( W - hop );
 	const int64_t flush_end = last_chain ? max( ring_end, p.out_len ) : ring_end;
+	if constexpr( RING )
+		{
+		for( int64_t a = pos + lane; a < flush_end; a += 64 )
+			{
+			float v = 0.0f;
+			if( a < ring_end )
+				{
+				int j = ring_base + int( a - pos ); if( j >= W ) j -= W;
+				v = ring[j];
+				}
+			if( a < own_start ) head1[a - chain_start] = v;
+			else if( a >= 0 && a < p.out_len ) out1[a] = v;
+			}
+		st.flush( lane );
+		return;
+		}
 	if( !fix || last_chain )
 		{
 		#pragma unroll
