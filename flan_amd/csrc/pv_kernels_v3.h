@@ -531,6 +531,18 @@ __global__ __launch_bounds__( 64 * WAVES, OCC ) void k_synthesize_v3( SynthParam
 	// RING: the oldest `count` samples of the ring leave (and are cleared); sample by sample like the generic kernels (pv_kernels.h)
 	auto ring_emit = [&]( int count, bool clear )
 		{
+		if( clear && count <= W && pos_of_ring >= own_start && pos_of_ring >= 0 && pos_of_ring + count <= p.out_len )
+			{
+			// the whole step lies in the output proper (every step past the chain's head but a channel's very first and last): a scalar base, no
+			// per-sample routing
+			float * const dst = out1 + pos_of_ring;
+			for( int e = lane; e < count; e += 64 )
+				{
+				int j = ring_base + e; if( j >= W ) j -= W;
+				dst[e] = ring[j]; ring[j] = 0.0f;
+				}
+			return;
+			}
 		for( int e = lane; e < count; e += 64 )
 			{
 			float v = 0.0f;
@@ -784,6 +796,7 @@ __global__ __launch_bounds__( 64 * WAVES, OCC ) void k_synthesize_v3( SynthParam
 				const int s0 = 2 * ( lane + 64 * q );
 				if( s0 < W )
 					{
+					// (a read, an addition and a write per sample: the LDS's own float add, ds_add_f32, was measured THREE times slower here)
 					int j = ring_base + s0; if( j >= W ) j -= W;
 					ring[j] += z[q].x * w.x;
 					if( s0 + 1 < W ) { int j1 = j + 1; if( j1 >= W ) j1 -= W; ring[j1] += ( -z[q].y ) * w.y; }
