@@ -388,8 +388,8 @@ static int run_analyze_fast( const AnalyzeParams & p, const FastTables & tb, hip
 // 256 / 512 / 1024, window a multiple of 128); 2: accumulator as an LDS ring (any hop <= window, any window <= dft).
 // dft 4096 with the LDS ring: the wavefronts (chains) per block that fit beside the tables -- four up to a window of ~2500 samples, three beyond
 static int ring_waves11( int W ) { return FastLds<11>::bytes( 4 ) + FastLds<11>::ring_bytes( 4, W ) <= kMaxLds ? 4 : 3; }
-// ... and with the team kernels' ring variant (round 5: k_synthesize_eo_team<.., -1, ..>): chains (teams) per block -- four up to a window of 2048, three beyond
-static int ring_teams11( int W ) { return debug_options().syn11_old ? ring_waves11( W ) : W <= 2048 ? 4 : 3; }
+// ... and with the team kernels' ring variant (round 5: k_synthesize_eo_team<.., -1, ..>): chains (teams) per block -- four (windows above 2048: since the fourth ring took the window table's place in LDS; three before)
+static int ring_teams11( int W ) { return debug_options().syn11_old ? ring_waves11( W ) : 4; }   // (windows above 2048: the fourth ring in the window table's place, pv_kernels_eo.h WINGLOB)
 static int synth_fast_kind( int dft, int W, int hop )
 	{
 	if( !( dft == 2048 || dft == 4096 || v3_size( dft ) ) || hop > W || hop < 1 || force_generic() ) return 0;
@@ -449,7 +449,7 @@ template<int TEAMS, bool WBIG>
 static int run_synth_eo_team_ring( const SynthParams & p, const FastTables & tb, hipStream_t s )
 	{
 	using L = typename std::conditional<WBIG, EoLdsBig, EoLds>::type;
-	const size_t lds = L::bytes( TEAMS ) + size_t( TEAMS ) * size_t( ( p.window_size + 63 ) & ~63 ) * 4;     // one A / B buffer set per team, then the rings
+	const size_t lds = L::bytes( TEAMS ) + size_t( WBIG ? TEAMS - 1 : TEAMS ) * size_t( ( p.window_size + 63 ) & ~63 ) * 4;     // one A / B buffer set per team, then the rings (windows above 2048: the last team's in the window table's place)
 	FLANHIP_REQUIRE( lds <= kMaxLds && p.window_size <= ( WBIG ? 4096 : 2048 ), FLANHIP_ERR_UNSUPPORTED, "window too long for the LDS ring" );
 	auto kern = k_synthesize_eo_team<TEAMS, -1, WBIG>;
 	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
@@ -507,7 +507,7 @@ static int run_synth_fast_hop( const SynthParams & p, const FastTables & tb, hip
 	if( synth_fast_kind( 2 << LOG2C, p.window_size, p.hop ) == 2 )                // any other hop <= window: ring accumulator in LDS
 		{
 		if constexpr( LOG2C == 10 ) return debug_options().syn_variant == 3 ? run_synth_fast<LOG2C, kSynWaves10, 0>( p, tb, s ) : run_synth_v2<8, 0>( p, tb, s );   // (round 5: k_synthesize_v2's ring form; SYN_VARIANT 3: the round-1 kernel, A/B)
-		else if( !debug_options().syn11_old ) return p.window_size <= 2048 ? run_synth_eo_team_ring<4, false>( p, tb, s ) : run_synth_eo_team_ring<3, true>( p, tb, s );
+		else if( !debug_options().syn11_old ) return p.window_size <= 2048 ? run_synth_eo_team_ring<4, false>( p, tb, s ) : run_synth_eo_team_ring<4, true>( p, tb, s );
 		else return ring_waves11( p.window_size ) == 4 ? run_synth_fast<LOG2C, 4, 0>( p, tb, s ) : run_synth_fast<LOG2C, 3, 0>( p, tb, s );
 		}
 	if constexpr( LOG2C == 11 ) switch( p.hop / 128 )                              // (dft 2048's register-accumulator hops are all v2's, above)
@@ -529,7 +529,7 @@ static int self_carry_group( int dft, int W, int hop, int chains_per_channel )
 	const int kind = synth_fast_kind( dft, W, hop );
 	int g = 0;
 	// the LDS-ring form of the dft 4096 team synthesis (any hop, any window up to 2048: four teams per block like the analysis) takes the totals too
-	if( kind == 2 ) g = ( dft == 4096 && W <= 2048 && !debug_options().syn11_old && !debug_options().ana11_old ) ? 4 : ( v3_size( dft ) || ( dft == 2048 && debug_options().syn_variant != 3 ) ) ? group_size_of( dft ) : 0;
+	if( kind == 2 ) g = ( dft == 4096 && !debug_options().syn11_old && !debug_options().ana11_old ) ? 4 : ( v3_size( dft ) || ( dft == 2048 && debug_options().syn_variant != 3 ) ) ? group_size_of( dft ) : 0;
 	else if( kind != 1 ) return 0;
 	else if( dft == 2048 || v3_size( dft ) ) g = group_size_of( dft );
 	else if( dft == 4096 && W % 256 == 0 && ( hop == 128 || hop % 256 == 0 ) && !debug_options().syn11_old && !debug_options().ana11_old ) g = 4;   // (windows above 2048: the WBIG variants)

@@ -85,6 +85,9 @@ template<bool ONE_SET> __device__ __forceinline__ int team_stage_slot( int bin, 
 	else return base_two_sets + bin;
 	}
 
+// (an index the compiler cannot prove loop-invariant: the window loads of the ring form stay inside the frame loop instead of 32 registers)
+__device__ __forceinline__ int eo_opaque( int v ) { asm volatile( "" : "+v"( v ) ); return v; }
+
 struct TeamSync
 	{
 	lds_u32 * flag; unsigned target; int lane;
@@ -482,6 +485,11 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 	{
 	using L = typename std::conditional<WBIG, EoLdsBig, EoLds>::type;
 	constexpr bool RING = HS < 0;
+	// WINGLOB (the ring form at windows above 2048, round 5): the scaled window is read from memory, sample pair by sample pair, and the fourth team's
+	// ring takes the window table's 16 KB of LDS -- four teams per block instead of three (three rings of 16 KB beside the buffers, not four: 151 KB), which
+	// is what the ANALYSIS in front pays for too, its chains being cut to the synthesis' layout ((4000, 1000, 4096): 50 -> 60 M frames/s)
+	constexpr bool WINGLOB = RING && WBIG;
+	static_assert( !WINGLOB || TEAMS == 4, "the fourth ring sits in the window table's place" );
 	constexpr int C = 1024, N2 = 2048, Q = 4, NT = 128 * TEAMS;
 	const int hop = RING ? p.hop : HS ? 256 * HS : 128;
 	constexpr bool DOUBLE = !WBIG && !RING;
@@ -499,12 +507,12 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 		v4f_t * twq = reinterpret_cast<v4f_t*>( s + L::TWQ );
 		for( int k = tid; k < 512; k += NT ) { const cf a = tb.w2[k], b = tb.w2[2 * k]; twq[k] = v4f_t{ a.x, -a.y, b.x, b.y }; }
 		float * win = reinterpret_cast<float*>( s + L::WIN );
-		for( int i = tid; i < WMAX; i += NT ) win[i] = ( i < W ) ? p.window[i] * p.window_scale : 0.0f;   // AudioPV.cpp:102
+		if constexpr( !WINGLOB ) { for( int i = tid; i < WMAX; i += NT ) win[i] = ( i < W ) ? p.window[i] * p.window_scale : 0.0f; }   // AudioPV.cpp:102
 		}
 	cf * const buf0 = s + L::BUF + team * ( DOUBLE ? 4 : 2 ) * L::BUF_LEN;      // set b: A at buf0 + 2 b BUF_LEN, B behind it
 	// RING: the teams' overlap-add rings behind the buffers, Wr floats each (W rounded up to a whole number of wavefront rows)
 	const int Wr = ( W + 63 ) & ~63;
-	float * const ring = reinterpret_cast<float*>( s + L::BUF + TEAMS * 2 * L::BUF_LEN ) + team * Wr;
+	float * const ring = ( WINGLOB && team == 3 ) ? reinterpret_cast<float*>( s + L::WIN ) : reinterpret_cast<float*>( s + L::BUF + TEAMS * 2 * L::BUF_LEN ) + team * Wr;
 	if constexpr( RING ) { for( int i = lane + 64 * role; i < Wr; i += 128 ) ring[i] = 0.0f; }
 	TeamSync team_sync{ (lds_u32*) reinterpret_cast<unsigned*>( buf0 + 1087 ), 0u, lane };
 	if( role == 0 && lane == 0 ) *team_sync.flag = 0u;
@@ -847,14 +855,16 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 					#pragma unroll
 					for( int q = 0; q < WQ; ++q )
 						{
-						const v4f_t wv = s_win[64 * q];
 						const int s0 = 4 * ( lane + 64 * q ) + 2 * role;
 						if( s0 < W )
 							{
+							float w0, w1;
+							if constexpr( WINGLOB ) { const cf g = *reinterpret_cast<const cf*>( p.window + eo_opaque( s0 ) ); w0 = g.x * p.window_scale; w1 = g.y * p.window_scale; }   // ( W % 4 == 0 here: s0 + 1 < W )
+							else { const v4f_t wv = s_win[64 * q]; w0 = role ? wv.z : wv.x; w1 = role ? wv.w : wv.y; }
 							int i0 = ring_base + s0; i0 -= ( i0 >= Wr ) ? Wr : 0;
 							cf * slot = reinterpret_cast<cf*>( ring + i0 );
 							const cf r = *slot;
-							*slot = mk( r.x + z[q].x * ( role ? wv.z : wv.x ), r.y + ( -z[q].y ) * ( role ? wv.w : wv.y ) );
+							*slot = mk( r.x + z[q].x * w0, r.y + ( -z[q].y ) * w1 );
 							}
 						}
 					}
@@ -863,16 +873,23 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 					#pragma unroll
 					for( int q = 0; q < WQ; ++q )
 						{
-						const v4f_t wv = s_win[64 * q];
 						const int s0 = 4 * ( lane + 64 * q ) + 2 * role;
 						if( s0 < W )
 							{
+							float w0, w1 = 0.0f;
+							if constexpr( WINGLOB )
+								{
+								const int so = eo_opaque( s0 );
+								w0 = p.window[so] * p.window_scale;
+								if( s0 + 1 < W ) w1 = p.window[so + 1] * p.window_scale;
+								}
+							else { const v4f_t wv = s_win[64 * q]; w0 = role ? wv.z : wv.x; w1 = role ? wv.w : wv.y; }
 							int i0 = ring_base + s0; i0 -= ( i0 >= Wr ) ? Wr : 0;
-							ring[i0] += z[q].x * ( role ? wv.z : wv.x );
+							ring[i0] += z[q].x * w0;
 							if( s0 + 1 < W )
 								{
 								int i1 = i0 + 1; i1 -= ( i1 >= Wr ) ? Wr : 0;
-								ring[i1] += ( -z[q].y ) * ( role ? wv.w : wv.y );
+								ring[i1] += ( -z[q].y ) * w1;
 								}
 							}
 						}

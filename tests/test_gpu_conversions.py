@@ -319,7 +319,7 @@ def test_fused_round_trip_equals_unfused(fa):
     for (ch, n, W, hop, dft) in [(2, 70000, 2048, 512, 2048), (1, 30000, 2048, 128, 4096), (2, 20000, 1024, 256, 1024), (1, 9000, 400, 100, 512), (2, 40000, 512, 128, 512), (3, 90000, 1024, 512, 1024),
                                  (1, 40000, 4096, 1024, 8192), (2, 30000, 2048, 300, 4096), (3, 500000, 2000, 500, 4096), (2, 200000, 4000, 1000, 4096),
                                  (3, 500000, 1000, 250, 1024), (2, 30000, 1024, 300, 1024), (4, 300000, 500, 125, 512), (1, 20000, 512, 100, 512),
-                                 (2, 300000, 2048, 300, 2048), (3, 200000, 2000, 500, 2048), (1, 40000, 1800, 450, 2048),
+                                 (2, 300000, 2048, 300, 2048), (3, 200000, 2000, 500, 2048), (1, 40000, 1800, 450, 2048), (3, 700000, 3000, 750, 4096), (2, 90000, 4094, 441, 4096),
                                  # the mixed-radix kernels: sums kept by the analysis kernel (ping-pong sizes, with and without the large odd radices) or by
                                  # the pre-pass kernel on its behalf (in place: 12000)
                                  (2, 300000, 2048, 512, 3000), (1, 120000, 1024, 256, 2002), (1, 200000, 2048, 512, 12000), (1, 60000, 600, 150, 1000),
@@ -416,7 +416,7 @@ def test_a_workspace_written_by_another_producer_is_reported(fa, W, hop, dft):
                                             (2048, 512, 3, 900000, 2048), (4096, 1024, 4, 1400000, 4096), (4096, 512, 4, 600000, 3072), (2048, 512, 1, 2000000, 2048),
                                             (4096, 441, 4, 600000, 2048), (4096, 500, 2, 900000, 2000), (1024, 256, 8, 600000, 1024), (1024, 512, 3, 900000, 768), (1024, 128, 1, 2000000, 1024), (512, 128, 2, 400000, 512), (512, 256, 5, 300000, 512),
                                             (1024, 250, 4, 600000, 1000), (1024, 300, 2, 900000, 1024), (512, 125, 3, 400000, 500),
-                                            (2048, 441, 4, 600000, 2048), (2048, 500, 2, 900000, 2000)])
+                                            (2048, 441, 4, 600000, 2048), (2048, 500, 2, 900000, 2000), (4096, 1000, 4, 1400000, 4000), (4096, 441, 2, 900000, 3000)])
 def test_carry_prologue_equals_scan_kernel(fa, dft, hop, ch, n, W):
     """Fused round trip: the synthesis kernels that take their chains' carries from a scan over the analysis' GROUP totals plus the chain sums
     (dft 2048 / 1024: groups of 8 chains; dft 4096 team kernels and dft 512: groups of 4, the last group of a channel short; also the team kernels'
