@@ -1,4 +1,4 @@
-// bs_plan.h -- which dft sizes run the chirp-z (Bluestein) kernels of pv_kernels_bs.h, and their pass lists (host and device agree through the
+// bs_plan.h -- which dft sizes run the chirp-z (Bluestein) kernels of pv_kernels_bs.h and the residue-pair kernels of pv_kernels_big.h, and their pass lists (host and device agree through the
 // struct; core.hip builds the tables from it, conversions.hip picks the kernels by it).
 //
 // The reference hands ANY size to FFTW (FFTHelper.cpp:16-26: fftwf_plan_dft_r2c_1d / c2r_1d), which serves sizes with a large prime factor
@@ -9,6 +9,7 @@
 // their twiddles read through L1 (C <= 4096: dft sizes up to 8192).  Beyond, and below C = 64, the direct sums of pv_kernels_any.h stay.
 #pragma once
 #include <cstdint>
+#include <initializer_list>
 
 namespace flanhip {
 
@@ -50,6 +51,47 @@ inline bool bs_make_plan( int dft, BsPlan * out )
 		{
 		pl.magic[i] = NS > 1 ? unsigned( ( uint64_t( 1 ) << 32 ) / unsigned( NS ) ) + 1u : 0u;
 		pl.stride[i] = (unsigned short) ( M / ( NS * pl.radix[i] ) );
+		}
+	*out = pl;
+	return true;
+	}
+
+// ---- sizes above 16384 (pv_kernels_big.h): half the size C = C1 x C2, C2 = the largest power of two in it up to 4096 (at least 1024), C1 <= 256 -------
+constexpr int BIG_MAX_C1 = 256, BIG_MIN_C2 = 1024, BIG_MAX_C2 = 4096;
+
+struct BigPlan
+	{
+	int C, C1, C2, P;        // P = C1 / 2 + 1 units per chain
+	int N1;                  // segments of C2 complex points the window reaches into ( ceil( ceil( W / 2 ) / C2 ) )
+	int limit;               // complex points of a segment that can be non-zero ( min( C2, ceil( W / 2 ) ) )
+	BsPlan fft;              // the C2-point transform's passes ( M = C2 )
+	};
+
+inline bool big_make_plan( int dft, int W, BigPlan * out )
+	{
+	if( dft < 4 || dft % 2 ) return false;
+	const int C = dft / 2;
+	int C2 = 1;
+	while( C % ( C2 * 2 ) == 0 && C2 * 2 <= BIG_MAX_C2 ) C2 *= 2;
+	if( C2 < BIG_MIN_C2 ) return false;
+	const int C1 = C / C2;
+	if( C1 < 2 || C1 > BIG_MAX_C1 ) return false;
+	BigPlan pl{};
+	pl.C = C; pl.C1 = C1; pl.C2 = C2; pl.P = C1 / 2 + 1;
+	const int half = ( W + 1 ) / 2;
+	pl.N1 = ( half + C2 - 1 ) / C2;
+	pl.limit = half < C2 ? half : C2;
+	BsPlan & f = pl.fft;
+	f.C = C2; f.M = C2; f.sign_c = 1.0f; f.win_lds = 0;
+	int rest = C2, n = 0;
+	auto take = [&]( int r ) { while( rest % r == 0 && n < BS_MAX_PASSES ) { f.radix[n++] = (unsigned char) r; rest /= r; } };
+	take( 8 ); take( 4 ); take( 2 );
+	if( rest != 1 ) return false;
+	f.npass = n;
+	for( int i = 0, NS = 1; i < n; NS *= f.radix[i], ++i )
+		{
+		f.magic[i] = NS > 1 ? unsigned( ( uint64_t( 1 ) << 32 ) / unsigned( NS ) ) + 1u : 0u;
+		f.stride[i] = (unsigned short) ( C2 / ( NS * f.radix[i] ) );
 		}
 	*out = pl;
 	return true;

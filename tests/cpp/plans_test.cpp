@@ -1,0 +1,74 @@
+// plans_test.cpp -- the host arithmetic that decides which dft sizes the chirp-z and the residue-pair kernels serve (flan_amd/csrc/bs_plan.h), checked
+// over EVERY even size up to 2^20 on the CPU: a plan's factors multiply to what the kernels transform, the strides and magic numbers the passes divide
+// by are right for every index they meet, and the two families never claim the same size.
+#include "../../flan_amd/csrc/bs_plan.h"
+#include <cstdio>
+#include <cstdlib>
+using namespace flanhip;
+
+static int fails = 0;
+#define CHECK( c, ... ) do { if( !( c ) ) { if( fails++ < 20 ) { std::printf( "FAILED %s:%d: ", __FILE__, __LINE__ ); std::printf( __VA_ARGS__ ); std::printf( "\n" ); } } } while( 0 )
+
+static void check_passes( const BsPlan & f, int M, int dft )
+	{
+	long prod = 1;
+	for( int i = 0, NS = 1; i < f.npass; NS *= f.radix[i], ++i )
+		{
+		const int r = f.radix[i];
+		CHECK( r == 8 || r == 4 || r == 2, "dft %d: radix %d", dft, r );
+		CHECK( i > 0 || r == 8, "dft %d: the first pass is a radix-8 one", dft );
+		CHECK( f.stride[i] == M / ( NS * r ), "dft %d pass %d: stride", dft, i );
+		if( NS > 1 )
+			for( int j = 0; j < M / r; j += ( M / r > 4096 ? 7 : 1 ) )                  // j / NS through the magic number, as mr_pass does it
+				{
+				const unsigned q = unsigned( ( (unsigned long long) (unsigned) j * f.magic[i] ) >> 32 );
+				CHECK( int( q ) == j / NS, "dft %d pass %d: %d / %d by magic = %u", dft, i, j, NS, q );
+				}
+		prod *= r;
+		}
+	CHECK( prod == M, "dft %d: radices multiply to %ld, not %d", dft, prod, M );
+	}
+
+int main()
+	{
+	int n_bs = 0, n_big = 0;
+	for( int dft = 4; dft <= ( 1 << 20 ); dft += 2 )
+		{
+		BsPlan bs{}; BigPlan big{};
+		const bool is_bs = bs_make_plan( dft, &bs );
+		const bool is_big = dft > 16384 && big_make_plan( dft, 4096, &big );
+		const int C = dft / 2;
+		if( is_bs )
+			{
+			++n_bs;
+			CHECK( bs.C == C && bs.M >= 2 * C - 1 && bs.M <= BS_MAX_M && ( bs.M & ( bs.M - 1 ) ) == 0 && bs.M < 4 * C, "dft %d: M = %d", dft, bs.M );
+			CHECK( C >= BS_MIN_C && !bs_has_small_factors_only( C ), "dft %d is no chirp-z size", dft );
+			CHECK( bs.sign_c == ( ( C & 1 ) ? -1.0f : 1.0f ), "dft %d: sign", dft );
+			if( dft % 97 == 0 || dft < 20000 ) check_passes( bs, bs.M, dft );
+			}
+		if( is_big )
+			{
+			++n_big;
+			CHECK( big.C == C && big.C1 * big.C2 == C && big.C2 >= BIG_MIN_C2 && big.C2 <= BIG_MAX_C2 && ( big.C2 & ( big.C2 - 1 ) ) == 0, "dft %d: C1 x C2 = %d x %d", dft, big.C1, big.C2 );
+			CHECK( big.C1 >= 2 && big.C1 <= BIG_MAX_C1 && big.P == big.C1 / 2 + 1, "dft %d: C1 = %d, P = %d", dft, big.C1, big.P );
+			CHECK( ( C / big.C2 ) % 2 == 1 || big.C2 == BIG_MAX_C2, "dft %d: C2 = %d is not the largest power of two", dft, big.C2 );
+			CHECK( big.N1 == ( 2048 + big.C2 - 1 ) / big.C2 && big.limit == ( 2048 < big.C2 ? 2048 : big.C2 ), "dft %d: a window of 4096 samples = 2048 points in segments of C2 = %d", dft, big.C2 );
+			if( dft % 1024 == 0 ) check_passes( big.fft, big.C2, dft );
+			}
+		CHECK( !( is_bs && is_big ), "dft %d claimed twice", dft );
+		}
+	// windows: segments and the limit of the first pass
+	for( int W : { 2, 5, 4096, 4097, 8192, 8193, 12000, 32768 } )
+		{
+		BigPlan big{};
+		CHECK( big_make_plan( 32768, W, &big ), "dft 32768, window %d", W );
+		const int half = ( W + 1 ) / 2;
+		CHECK( big.N1 == ( half + 4095 ) / 4096 && big.limit == ( half < 4096 ? half : 4096 ), "window %d: N1 = %d, limit = %d", W, big.N1, big.limit );
+		}
+	BigPlan big{}; BsPlan bs{};
+	CHECK( !big_make_plan( 20000, 4096, &big ), "20000 = 2 x 10^4 holds 2^4 only" );
+	CHECK( !bs_make_plan( 3000, &bs ) && bs_make_plan( 2998, &bs ) && bs.M == 4096, "3000 is smooth, 2998 = 2 x 1499 is not" );
+	CHECK( bs_make_plan( 8186, &bs ) && bs.M == 8192 && !bs_make_plan( 8198, &bs ), "the chirp-z sizes end where M = 8192 does" );
+	std::printf( "%d chirp-z sizes, %d sizes above 16384; %s\n", n_bs, n_big, fails ? "FAILED" : "PASSED" );
+	return fails ? 1 : 0;
+	}
