@@ -4,5 +4,6 @@
 #pragma once
 namespace flanhip {
 typedef float cf __attribute__(( ext_vector_type( 2 ) ));
+typedef float v4f_t __attribute__(( ext_vector_type( 4 ) ));   // four floats as one register tuple (16-byte LDS / global accesses: per-bin constant tables)
 struct d2 { double x, y; };   // a complex number in double (tables evaluated on the host: the unit circle of the direct sums, Bluestein's chirp)
 }

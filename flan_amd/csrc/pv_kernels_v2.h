@@ -33,7 +33,6 @@ struct V2Lds
 	static constexpr size_t bytes( int waves ) { return size_t( BUF + waves * BUF_LEN ) * 8; }
 	};
 
-typedef float v4f_t __attribute__(( ext_vector_type( 4 ) ));
 
 #ifdef FLANHIP_STAMPS
 // Diagnostic build only (tools/scripts/build_diag.sh stamps): where does a frame spend its cycles?  s_memtime between the sections of the
