@@ -13,6 +13,7 @@
 #include "pv_kernels_mr.h"
 #include "pv_kernels_bs.h"
 #include "pv_kernels_big.h"
+#include "team_launch.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -563,13 +564,15 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	FLANHIP_REQUIRE( W <= dft, FLANHIP_ERR_INVALID_ARG, "window_size larger than dft_size" );
 	FLANHIP_REQUIRE( dft_size_ok( dft ), FLANHIP_ERR_UNSUPPORTED, "dft_size must be even, at least 4 and at most 2^20" );
 	if( int rc = require_device() ) return rc;
+	// dft 8192 / 16384 on the team kernels' grid of windows and hops (pv_kernels_team.h, round 6): before the round-1 / mixed-radix kernels of those sizes
+	const bool team = team_shape( dft, W, hop ) && n >= 2 && n < ( int64_t( 1 ) << 31 ) - 65536;
 	MrPlan mr_plan{};
-	const bool mr = mr_size( dft, W, &mr_plan );
+	const bool mr = !team && mr_size( dft, W, &mr_plan );
 	BsPlan bs_plan{};
-	const bool bs = !mr && bs_size( dft, W, &bs_plan );
+	const bool bs = !team && !mr && bs_size( dft, W, &bs_plan );
 	BigPlan big_plan{};
-	const bool big = !mr && !bs && big_size( dft, W, &big_plan );
-	const bool any = !fft_size( dft ) && !mr && !bs && !big;
+	const bool big = !team && !mr && !bs && big_size( dft, W, &big_plan );
+	const bool any = !team && !fft_size( dft ) && !mr && !bs && !big;
 	std::shared_ptr<const PlanRef> plan_ref;                                        // (held until the kernels below are launched)
 	if( int rc = get_plan( W, dft, &plan_ref ) ) return rc;
 	const Plan * plan = &plan_ref->plan;
@@ -582,7 +585,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	// (hop: the dft 2048 kernel addresses a block's samples by 32-bit byte offsets from the block's first frame -- up to 8 chains of <= ~512 frames,
 	// env overrides aside -- and the generic kernels serve the hops that would not fit: nothing anybody analyses with)
 	const bool fast = ( dft == 2048 || dft == 4096 || v3_size( dft ) ) && n >= 2 && n < ( int64_t( 1 ) << 31 ) - 8192 && hop <= 65536 && !force_generic();
-	int target_chains = any ? any_target_chains( dft / 2 + 1 ) : mr ? mr_target_chains( dft, W ) : bs ? bs_target_chains( dft, W ) : big ? big_target_chains() : fast ? fast_target_chains( dft, false ) : generic_target_chains( dft );
+	int target_chains = team ? team_target_chains( dft ) : any ? any_target_chains( dft / 2 + 1 ) : mr ? mr_target_chains( dft, W ) : bs ? bs_target_chains( dft, W ) : big ? big_target_chains() : fast ? fast_target_chains( dft, false ) : generic_target_chains( dft );
 	p.L = choose_chain_length( ch, p.F, any ? 7 : 1, target_chains );
 	p.chains_per_channel = int( ( p.F + p.L - 1 ) / p.L );
 	p.sample_rate = sr;
@@ -633,6 +636,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 		return FLANHIP_OK;
 		};
 
+	if( team ) return run_analyze_team( p, *plan, dft, s );                       // (keeps the chain sums: kernel_sums)
 	if( any )
 		{
 		std::shared_ptr<const UnitRef> unit_ref;
@@ -727,15 +731,16 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	FLANHIP_REQUIRE( W <= o->dft, FLANHIP_ERR_INVALID_ARG, "window_size larger than dft size" );
 	FLANHIP_REQUIRE( dft_size_ok( o->dft ), FLANHIP_ERR_UNSUPPORTED, "dft size must be even, at least 4 and at most 2^20" );
 	FLANHIP_REQUIRE( int64_t( o->dft ) * W < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "dft_size * window_size overflows the int product of AudioPV.cpp:99" );
-	const bool mr = mr_size( o->dft, W );
-	const bool bs = !mr && bs_size( o->dft, W );
+	const bool team = team_shape( o->dft, W, o->hop );
+	const bool mr = !team && mr_size( o->dft, W );
+	const bool bs = !team && !mr && bs_size( o->dft, W );
 	BigPlan big_plan{};
-	o->big = !mr && !bs && big_size( o->dft, W, &big_plan );
-	o->any = !fft_size( o->dft ) && !mr && !bs && !o->big;
+	o->big = !team && !mr && !bs && big_size( o->dft, W, &big_plan );
+	o->any = !team && !fft_size( o->dft ) && !mr && !bs && !o->big;
 	o->head_len = o->any ? 0 : std::max( W - o->hop, 0 );        // (the direct-sum path overlap-adds whole frames from its own scratch: no chain heads)
 	const int overlap = ( W + o->hop - 1 ) / o->hop;              // frames covering one output sample
 	const int kind = ( o->any || o->big ) ? 0 : synth_fast_kind( o->dft, W, o->hop );
-	const int slots = o->any ? any_target_chains( bins ) : mr ? mr_target_chains( o->dft, W ) : bs ? bs_target_chains( o->dft, W ) : o->big ? big_target_chains() : kind == 0 ? generic_target_chains( o->dft ) : ( kind == 2 && o->dft == 4096 ) ? cu_count() * ring_teams11( W ) : fast_target_chains( o->dft, true );
+	const int slots = team ? team_target_chains( o->dft ) : o->any ? any_target_chains( bins ) : mr ? mr_target_chains( o->dft, W ) : bs ? bs_target_chains( o->dft, W ) : o->big ? big_target_chains() : kind == 0 ? generic_target_chains( o->dft ) : ( kind == 2 && o->dft == 4096 ) ? cu_count() * ring_teams11( W ) : fast_target_chains( o->dft, true );
 	o->L = choose_chain_length( ch, F, o->any ? 1 : std::max( overlap - 1, 1 ), slots );
 	o->chains_per_channel = int( ( F + o->L - 1 ) / o->L );
 	const int64_t chains = int64_t( o->chains_per_channel ) * ch;
@@ -939,6 +944,7 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 		FLANHIP_CHECK( hipGetLastError() );
 		rc = FLANHIP_OK;
 		}
+	else if( team_shape( lay.dft, W, lay.hop ) ) rc = run_synth_team( p, *plan, lay.dft, s );
 	else if( MrPlan mr_plan{}; mr_size( lay.dft, W, &mr_plan ) )
 		{
 		const size_t lds = mr_synth_lds( mr_plan.C, W, mr_plan.win_lds, mr_plan.kc_lds );

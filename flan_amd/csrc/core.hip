@@ -50,7 +50,7 @@ static float hann_host( float x )
 PlanRef::~PlanRef()
 	{
 	(void) hipFree( plan.d_window ); (void) hipFree( plan.d_tw ); (void) hipFree( plan.d_tw2 ); (void) hipFree( plan.d_tw1f ); (void) hipFree( plan.d_tw3f );
-	(void) hipFree( plan.d_bs_tw ); (void) hipFree( plan.d_bs_chirp ); (void) hipFree( plan.d_bs_bh );
+	(void) hipFree( plan.d_bs_tw ); (void) hipFree( plan.d_bs_chirp ); (void) hipFree( plan.d_bs_bh ); (void) hipFree( plan.d_team );
 	(void) hipGetLastError();
 	}
 static std::mutex g_plan_mutex;
@@ -60,6 +60,30 @@ static std::map<PlanKey, std::shared_ptr<const PlanRef>> & plan_map() { static a
 static std::vector<PlanKey> & plan_lru() { static auto * v = new std::vector<PlanKey>; return *v; }   // the evictable plans, most recently used last
 static constexpr size_t kEvictablePlans = 8;            // per device
 static bool plan_is_permanent( int dft_size ) { return is_pow2( dft_size ) && dft_size >= 32 && dft_size <= 8192; }
+
+// exp( -2 pi i num / den ) rounded to float from an octant-reduced evaluation in long double: exact at the quarter turns and exactly symmetric
+// ( the value at pi - a is the value at a with its real part negated, ... ), which the team kernels rely on where one bin is reached twice
+static cf unit_minus_exact( int64_t num, int64_t den )
+	{
+	const int64_t n = ( ( num % den ) + den ) % den;
+	const int64_t o = ( 8 * n ) / den, r = 8 * n - o * den;                       // octant, and the rest in 1 / ( 8 den ) turns
+	const long double two_pi = 6.283185307179586476925286766559005768L;
+	const long double a = two_pi * ( long double )( ( o & 1 ) ? den - r : r ) / ( long double )( 8 * den );   // in [0, pi / 4]
+	const float c = float( cosl( a ) ), s = float( sinl( a ) );
+	float x, y;                                                                     // ( cos, sin ) of 2 pi n / den
+	switch( int( o ) )
+		{
+		case 0: x = c; y = s; break;
+		case 1: x = s; y = c; break;
+		case 2: x = -s; y = c; break;
+		case 3: x = -c; y = s; break;
+		case 4: x = -c; y = -s; break;
+		case 5: x = -s; y = -c; break;
+		case 6: x = s; y = -c; break;
+		default: x = c; y = -s; break;
+		}
+	return cf{ x, y == 0.0f ? 0.0f : -y };
+	}
 
 int get_plan( int window_size, int dft_size, std::shared_ptr<const PlanRef> * out )
 	{
@@ -105,6 +129,21 @@ int get_plan( int window_size, int dft_size, std::shared_ptr<const PlanRef> * ou
 		FLANHIP_CHECK( hipMalloc( &plan.d_tw3f, sizeof( cf ) * tw3.size() ) );
 		FLANHIP_CHECK( hipMemcpy( plan.d_tw1f, tw1.data(), sizeof( cf ) * tw1.size(), hipMemcpyHostToDevice ) );
 		FLANHIP_CHECK( hipMemcpy( plan.d_tw3f, tw3.data(), sizeof( cf ) * tw3.size(), hipMemcpyHostToDevice ) );
+		}
+	if( const int R = team_radix( dft_size ) )
+		{
+		// the team kernels' tables (pv_kernels_team.h)
+		const TeamTableLayout l = team_table_layout( R );
+		const int64_t CT = int64_t( 1024 ) * R;
+		std::vector<cf> t( size_t( l.total ) );
+		for( int r = 1; r < 16; ++r ) for( int k = 0; k < 16; ++k ) t[size_t( l.tw1 + ( r - 1 ) * 16 + k )] = unit_minus_exact( int64_t( r ) * k, 256 );
+		for( int r = 1; r < 4; ++r ) for( int j = 0; j < 256; ++j ) t[size_t( l.tw3 + ( r - 1 ) * 256 + j )] = unit_minus_exact( int64_t( r ) * j, 1024 );
+		for( int r = 1; r < R; ++r ) for( int k = 0; k < 512; ++k ) t[size_t( l.twj + ( r - 1 ) * 512 + k )] = unit_minus_exact( int64_t( r ) * k, CT );
+		for( int j = 0; j < R / 2; ++j ) for( int k = 0; k < 512; ++k ) t[size_t( l.tws + j * 512 + k )] = unit_minus_exact( k + 1024 * int64_t( j ), 2 * CT );
+		for( int j = 0; j < R; ++j ) t[size_t( l.two + j )] = unit_minus_exact( 512 + 1024 * int64_t( j ), 2 * CT );
+		for( int r = 0; r < R; ++r ) t[size_t( l.two + R + r )] = unit_minus_exact( 512 * int64_t( r ), CT );
+		FLANHIP_CHECK( hipMalloc( &plan.d_team, sizeof( cf ) * t.size() ) );
+		FLANHIP_CHECK( hipMemcpy( plan.d_team, t.data(), sizeof( cf ) * t.size(), hipMemcpyHostToDevice ) );
 		}
 	if( BsPlan bp{}; bs_make_plan( dft_size, &bp ) )
 		{

@@ -50,7 +50,12 @@ struct Plan
 	cf * d_bs_tw = nullptr;    // chirp-z sizes (bs_plan.h): [M] exp(-2 pi i j / M)
 	d2 * d_bs_chirp = nullptr; //                            [C] exp(+pi i n^2 / C), in double
 	d2 * d_bs_bh = nullptr;    //                            [M] the chirp's transform / M, in double
+	cf * d_team = nullptr;     // dft 8192 / 16384 (pv_kernels_team.h, R = dft / 2048): tw1 [240], tw3 [768], twj [(R-1) 512], tws [(R/2) 512], two [2 R], back to back
 	};
+// offsets (in cf) of the team kernels' tables inside Plan::d_team
+inline int team_radix( int dft_size ) { return dft_size == 8192 ? 4 : dft_size == 16384 ? 8 : 0; }
+struct TeamTableLayout { int tw1, tw3, twj, tws, two, total; };
+inline TeamTableLayout team_table_layout( int R ) { TeamTableLayout l; l.tw1 = 0; l.tw3 = 240; l.twj = 1008; l.tws = l.twj + ( R - 1 ) * 512; l.two = l.tws + ( R / 2 ) * 512; l.total = l.two + 2 * R; return l; }
 struct PlanRef { Plan plan; PlanRef() = default; PlanRef( const PlanRef & ) = delete; PlanRef & operator=( const PlanRef & ) = delete; ~PlanRef(); };   // owns the tables
 int get_plan( int window_size, int dft_size, std::shared_ptr<const PlanRef> * out );   // keep the reference until the kernels that read the tables are launched
 

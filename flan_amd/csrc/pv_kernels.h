@@ -516,7 +516,7 @@ __global__ __launch_bounds__( 64 * WAVES * T ) void k_synthesize( SynthParams p 
 	}
 
 // out[head region of chain c] += head[c]  for every chain c >= 1 of a channel (fixed order => deterministic).
-__global__ __launch_bounds__( 256 ) void k_ola_fixup( SynthParams p )
+static __global__ __launch_bounds__( 256 ) void k_ola_fixup( SynthParams p )
 	{
 	const int64_t chain = blockIdx.x;
 	const int chain_in_channel = int( chain % p.chains_per_channel );
@@ -534,7 +534,7 @@ __global__ __launch_bounds__( 256 ) void k_ola_fixup( SynthParams p )
 // The same sixteen bytes at a time, for the shapes whose heads start on 16-byte boundaries (hop, window / 2, the head length and the channel
 // length multiples of 4 samples, 16-byte aligned buffers: every tuned shape): one thread per float4 of every boundary, ( chain, quad ) flat over
 // the grid -- a quarter of the memory instructions and no idle first block per channel (8 ch x 60 s: 10 -> 6 us)
-__global__ __launch_bounds__( 256 ) void k_ola_fixup4( SynthParams p )
+static __global__ __launch_bounds__( 256 ) void k_ola_fixup4( SynthParams p )
 	{
 	typedef float f4 __attribute__(( ext_vector_type( 4 ) ));
 	const int quads = p.head_len / 4, per_channel = p.chains_per_channel - 1;      // boundaries of a channel

@@ -650,7 +650,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p
 // One thread per (chain, bin): the chain's phase increments summed in double and folded once (the running phase of
 // phase_vocoder.cpp:57-59 modulo pi2); NaN/Inf scan of PVBuffer::is_nan_or_inf.  Streaming read of the PV with 8 rows in
 // flight per thread.
-__global__ __launch_bounds__( 256 ) void k_phase_sums2( SynthParams p )
+static __global__ __launch_bounds__( 256 ) void k_phase_sums2( SynthParams p )
 	{
 	if( p.skip_words && p.skip_words[4] == p.skip_words[2] && p.skip_words[2] != 0 ) return;   // already there (flanhip_modify_time_dev_fused)
 	const int64_t chain = blockIdx.x;

@@ -1,0 +1,103 @@
+// team.hip -- launchers of the dft 8192 / 16384 team kernels (pv_kernels_team.h; Conversions/AudioPV.cpp:12-139 at the sizes FFTHelper.cpp:16-26
+// hands to FFTW like any other).
+#include "team_launch.h"
+#include <type_traits>
+#include "pv_kernels_team.h"
+
+namespace flanhip {
+
+// ( window / 128 R, hop / 128 R ) the synthesis is instantiated for
+#define FLANHIP_TEAM_SHAPES( X ) X( 4, 1 ) X( 4, 2 ) X( 8, 1 ) X( 8, 2 ) X( 8, 4 ) X( 16, 2 ) X( 16, 4 ) X( 16, 8 )
+
+bool team_shape( int dft, int W, int hop )
+	{
+	const int R = team_radix( dft );
+	if( !R || debug_options().force_generic || debug_options().force_direct ) return false;
+	const int step = 128 * R;
+	if( W % step || hop % step || hop > W ) return false;
+	const int wq = W / step, hs = hop / step;
+#define X( WQ, HS ) if( wq == WQ && hs == HS ) return true;
+	FLANHIP_TEAM_SHAPES( X )
+#undef X
+	return false;
+	}
+
+int team_target_chains( int dft )
+	{
+	if( const int v = debug_options().target_chains ) { if( v > 0 ) return v; }
+	return cu_count() * ( team_radix( dft ) == 4 ? 2 : 1 );
+	}
+
+static TeamTables team_tables( const Plan & plan, int R )
+	{
+	const TeamTableLayout l = team_table_layout( R );
+	return TeamTables{ plan.d_team + l.tw1, plan.d_team + l.tw3, plan.d_team + l.twj, plan.d_team + l.tws, plan.d_team + l.two, plan.d_window };
+	}
+
+template<int R, int WQ, bool SUMS>
+static int launch_analyze_team( const AnalyzeParams & p, const TeamTables & tb, hipStream_t s )
+	{
+	const size_t lds = TeamLds<R>::bytes();
+	static_assert( ( TeamLds<R>::bytes() + 64 ) * ( R == 4 ? 2 : 1 ) <= 160 * 1024, "LDS budget" );
+	auto kern = k_analyze_team<R, WQ, SUMS>;
+	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;       // a block = a chain
+	FLANHIP_REQUIRE( chains < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
+	hipLaunchKernelGGL( kern, dim3( (unsigned) chains ), dim3( 64 * R ), lds, s, p, tb );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+template<int R, int WQ, int HS>
+static int launch_synth_team( const SynthParams & p, const TeamTables & tb, hipStream_t s )
+	{
+	const size_t lds = TeamLds<R>::bytes();
+	auto kern = k_synthesize_team<R, WQ, HS>;
+	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;
+	FLANHIP_REQUIRE( chains < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
+	hipLaunchKernelGGL( kern, dim3( (unsigned) chains ), dim3( 64 * R ), lds, s, p, tb );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+template<int R>
+static int run_analyze_team_r( const AnalyzeParams & p, const TeamTables & tb, hipStream_t s )
+	{
+	switch( p.window_size / ( 128 * R ) )
+		{
+		case 4:  return p.sums ? launch_analyze_team<R, 4, true>( p, tb, s ) : launch_analyze_team<R, 4, false>( p, tb, s );
+		case 8:  return p.sums ? launch_analyze_team<R, 8, true>( p, tb, s ) : launch_analyze_team<R, 8, false>( p, tb, s );
+		case 16: return p.sums ? launch_analyze_team<R, 16, true>( p, tb, s ) : launch_analyze_team<R, 16, false>( p, tb, s );
+		}
+	return FLANHIP_ERR_UNSUPPORTED;
+	}
+
+int run_analyze_team( const AnalyzeParams & p, const Plan & plan, int dft, hipStream_t s )
+	{
+	const int R = team_radix( dft );
+	FLANHIP_REQUIRE( R && plan.d_team && team_shape( dft, p.window_size, p.hop ), FLANHIP_ERR_UNSUPPORTED, "not a team shape" );
+	FLANHIP_REQUIRE( p.n < ( int64_t( 1 ) << 31 ) - 65536, FLANHIP_ERR_UNSUPPORTED, "channel too long for 32-bit sample offsets" );
+	const TeamTables tb = team_tables( plan, R );
+	return R == 4 ? run_analyze_team_r<4>( p, tb, s ) : run_analyze_team_r<8>( p, tb, s );
+	}
+
+template<int R>
+static int run_synth_team_r( const SynthParams & p, const TeamTables & tb, hipStream_t s )
+	{
+	const int wq = p.window_size / ( 128 * R ), hs = p.hop / ( 128 * R );
+#define X( WQ, HS ) if( wq == WQ && hs == HS ) return launch_synth_team<R, WQ, HS>( p, tb, s );
+	FLANHIP_TEAM_SHAPES( X )
+#undef X
+	return FLANHIP_ERR_UNSUPPORTED;
+	}
+
+int run_synth_team( const SynthParams & p, const Plan & plan, int dft, hipStream_t s )
+	{
+	const int R = team_radix( dft );
+	FLANHIP_REQUIRE( R && plan.d_team && team_shape( dft, p.window_size, p.hop ), FLANHIP_ERR_UNSUPPORTED, "not a team shape" );
+	const TeamTables tb = team_tables( plan, R );
+	return R == 4 ? run_synth_team_r<4>( p, tb, s ) : run_synth_team_r<8>( p, tb, s );
+	}
+
+} // namespace flanhip

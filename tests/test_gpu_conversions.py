@@ -102,6 +102,31 @@ CASES = [
     ("dft512_win500_hop125", 2, 20000, 500, 125, 512, "noise"),
     ("dft512_hop100", 1, 20000, 512, 100, 512, "noise"),
     ("dft8192", 1, 40000, 4096, 1024, 8192, "noise"),
+    # dft 8192 / 16384 on the grid of the team kernels (pv_kernels_team.h, round 6: teams of 4 / 8 wavefronts, a 1024-point register transform each):
+    # window = 4 / 8 / 16 steps of 512 (1024) samples, hops of 1 / 2 / 4 / 8 steps
+    ("dft8192_win8192_hop2048_stereo_ragged", 2, 123457, 8192, 2048, 8192, "noise"),
+    ("dft8192_win2048_hop512", 1, 40000, 2048, 512, 8192, "noise"),
+    ("dft8192_win2048_hop1024_3ch", 3, 30000, 2048, 1024, 8192, "noise"),
+    ("dft8192_win4096_hop512", 1, 40000, 4096, 512, 8192, "noise"),
+    ("dft8192_win4096_hop2048", 2, 50000, 4096, 2048, 8192, "noise"),
+    ("dft8192_win8192_hop1024", 1, 60000, 8192, 1024, 8192, "noise"),
+    ("dft8192_win8192_hop4096", 1, 90000, 8192, 4096, 8192, "noise"),
+    ("dft8192_sine", 1, 96000, 8192, 2048, 8192, "sine"),
+    ("dft8192_one_frame", 1, 300, 8192, 2048, 8192, "noise"),
+    ("dft8192_short", 2, 5000, 4096, 1024, 8192, "noise"),
+    ("dft8192_zeros", 1, 20000, 8192, 2048, 8192, "zeros"),
+    ("dft8192_off_grid_win4000_hop1000", 1, 40000, 4000, 1000, 8192, "noise"),         # (the round-1 kernels)
+    ("dft16384_win16384_hop4096_stereo_ragged", 2, 234567, 16384, 4096, 16384, "noise"),
+    ("dft16384_win8192_hop2048", 1, 90000, 8192, 2048, 16384, "noise"),
+    ("dft16384_win4096_hop2048", 2, 50000, 4096, 2048, 16384, "noise"),
+    ("dft16384_win8192_hop1024", 1, 60000, 8192, 1024, 16384, "noise"),
+    ("dft16384_win8192_hop4096", 1, 90000, 8192, 4096, 16384, "noise"),
+    ("dft16384_win16384_hop2048", 1, 120000, 16384, 2048, 16384, "noise"),
+    ("dft16384_win16384_hop8192", 1, 150000, 16384, 8192, 16384, "noise"),
+    ("dft16384_sine", 1, 96000, 4096, 1024, 16384, "sine"),
+    ("dft16384_one_frame", 1, 300, 4096, 1024, 16384, "noise"),
+    ("dft16384_zeros", 1, 20000, 4096, 1024, 16384, "zeros"),
+    ("dft16384_off_grid_win4096_hop512", 1, 30000, 4096, 512, 16384, "noise"),          # (the mixed-radix kernels)
     ("dft64", 1, 3000, 64, 16, 64, "noise"),
     ("dft32_win32", 1, 1000, 32, 8, 32, "noise"),
     ("hop_eq_window", 1, 20000, 1024, 1024, 1024, "noise"),
