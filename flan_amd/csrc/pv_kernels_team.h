@@ -38,17 +38,46 @@ struct TeamTables
 	const float * window; // [W]
 	};
 
-template<int R> struct TeamLds
+// WP: sample pairs of the window table in LDS (64 R WQ: the window as [r][q][lane] pairs -- pair R ( lane + 64 q ) + r --, so that a wavefront reads
+// consecutive slots), 0: the window is read from memory (windows above 8192 samples)
+template<int R, int TEAMS, int WP> struct TeamLds
 	{
 	static constexpr int S = 1024;
 	static constexpr int TW1 = 0;                          // [15][16]
 	static constexpr int TW3 = TW1 + 240;                  // [3][256]
 	static constexpr int TWJ = TW3 + 768;                  // [R-1][512]
 	static constexpr int TWS = TWJ + ( R - 1 ) * 512;      // [R/2][512]  (analysis: halved; synthesis: conjugated)
-	static constexpr int BUF = TWS + ( R / 2 ) * 512;
-	static constexpr int BUF_LEN = S + S / 16 + 1;         // slot PAD( 1024 ) = 1088 included
-	static constexpr int ORPH = BUF + R * BUF_LEN;         // analysis: [64][R] E_r[512] of the last 64 frames; synthesis: [R] spectrum values of bins 512 + 1024 r
-	static constexpr size_t bytes() { return size_t( ORPH + 64 * R ) * 8; }
+	static constexpr int WIN = TWS + ( R / 2 ) * 512;      // [WP]
+	static constexpr int TEAM0 = WIN + WP;                 // per team:
+	static constexpr int BUF_LEN = S + S / 16 + 1;         //   R buffers; slot PAD( 1024 ) = 1088 included
+	static constexpr int ORPH = R * BUF_LEN;               //   analysis: [64][R] E_r[512] of the last 64 frames; synthesis: [R] spectrum values of bins 512 + 1024 r
+	static constexpr int FLAG = ORPH + 64 * R;             //   the team's meeting counter (TEAMS > 1)
+	static constexpr int TEAM_LEN = FLAG + 2;
+	static constexpr size_t bytes() { return size_t( TEAM0 + TEAMS * TEAM_LEN ) * 8; }
+	};
+
+// The R wavefronts of a team meet.  One team per block: the block barrier.  Several: a counter in the team's LDS, as the dft 4096 kernels' TeamSync
+// (pv_kernels_eo.h) -- s_barrier would hold every team of the block to the pace of the slowest wavefront, every frame
+template<int R, bool BLOCK> struct TeamMeet
+	{
+	lds_u32 * flag; unsigned target; int lane;
+	__device__ __forceinline__ void meet()
+		{
+		if constexpr( BLOCK ) lds_block_sync();
+		else
+			{
+			target += R;
+			asm volatile( "s_waitcnt lgkmcnt(0)" ::: "memory" );
+			if( lane == 0 ) (void) __hip_atomic_fetch_add( flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP );
+			for( int spins = 0; spins < ( 1 << 22 ); ++spins )
+				{
+				const unsigned v = __builtin_amdgcn_readfirstlane( __hip_atomic_load( flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP ) );
+				if( v >= target ) break;
+				__builtin_amdgcn_s_sleep( FLANHIP_TEAM_SLEEP );
+				}
+			asm volatile( "" ::: "memory" );
+			}
+		}
 	};
 
 __device__ __forceinline__ cf cmul_f( cf a, cf w )        // a w, fused like the joins of pv_kernels_eo.h
@@ -62,37 +91,54 @@ __device__ __forceinline__ cf cmul_fc( cf a, cf w )       // a conj( w )
 // x exp( -i pi r / R ) = x w16^( 16 r / 2 R )
 template<int R, int r> __device__ __forceinline__ cf mul_half_turn( cf a ) { return mul_w16<( 8 / R ) * r>( a ); }
 
-template<int R, int WQ, bool SUMS>
-__global__ __launch_bounds__( 64 * R, 2 ) void k_analyze_team( AnalyzeParams p, TeamTables tb )
+template<int R, int TEAMS, int WQ, bool SUMS, bool WINLDS>
+__global__ __launch_bounds__( 64 * R * TEAMS, 2 ) void k_analyze_team( AnalyzeParams p, TeamTables tb )
 	{
-	using L = TeamLds<R>;
+	using L = TeamLds<R, TEAMS, WINLDS ? 64 * R * WQ : 0>;
 	static_assert( R == 4 || R == 8, "teams of four or eight wavefronts" );
-	constexpr int S = 1024, CT = S * R, KQ = 8 / R, NT = 64 * R, NB = 2 * R;      // NB: bins per k-group
+	constexpr int S = 1024, CT = S * R, KQ = 8 / R, NT = 64 * R * TEAMS, NB = 2 * R;      // NB: bins per k-group
 	constexpr int NV = 8, NG = NB / NV;                                            // bins per vector stream, streams per group
 	typedef float VB __attribute__(( ext_vector_type( NV ) ));
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	cf * s = reinterpret_cast<cf*>( smem );
-	const int tid = threadIdx.x, lane = tid & 63, role = __builtin_amdgcn_readfirstlane( tid >> 6 );
+	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane( tid >> 6 ), team = wave / R, role = wave % R;
 	const int W = p.window_size, hop = p.hop;
 
-	// cancellation (core.hip): the team meets at block barriers, so the decision is the block's
+	// cancellation (core.hip): a team meets in its frame loop, so the decision is the block's
 	__shared__ int s_cancel;
 	if( tid == 0 ) s_cancel = cancel_peek( p.cancel );
 	for( int i = tid; i < 240; i += NT ) s[L::TW1 + i] = tb.tw1[i];
 	for( int i = tid; i < 768; i += NT ) s[L::TW3 + i] = tb.tw3[i];
 	for( int i = tid; i < ( R - 1 ) * 512; i += NT ) s[L::TWJ + i] = tb.twj[i];
 	for( int i = tid; i < ( R / 2 ) * 512; i += NT ) { const cf a = tb.tws[i]; s[L::TWS + i] = mk( 0.5f * a.x, 0.5f * a.y ); }
+	if constexpr( WINLDS )
+		{
+		// pair n = R m + r, m = lane + 64 q  ->  slot ( r WQ + q ) 64 + lane
+		for( int n = tid; n < 64 * R * WQ; n += NT )
+			{
+			const int r = n % R, m = n / R;
+			s[L::WIN + ( r * WQ + ( m >> 6 ) ) * 64 + ( m & 63 )] = *reinterpret_cast<const cf*>( tb.window + 2 * n );
+			}
+		}
+	cf * const buf0 = s + L::TEAM0 + team * L::TEAM_LEN;
+	TeamMeet<R, TEAMS == 1> team_sync{ (lds_u32*) reinterpret_cast<unsigned*>( buf0 + L::FLAG ), 0u, lane };
+	if( role == 0 && lane == 0 ) *team_sync.flag = 0u;
 	__syncthreads();
 	if( s_cancel ) return;
 	const cf * s_tw1 = s + L::TW1;
 	const cf * s_tw3 = s + L::TW3;
-	cf * const buf0 = s + L::BUF;
+	const cf * s_win = s + L::WIN + role * WQ * 64 + lane;
 	cf * const mybuf = buf0 + role * L::BUF_LEN;
-	cf * const orph = s + L::ORPH;
+	cf * const orph = buf0 + L::ORPH;
 
-	const int64_t chain = blockIdx.x;
-	const int channel = int( chain / p.chains_per_channel );
-	const int64_t t0 = int64_t( chain % p.chains_per_channel ) * p.L;
+	// a block is a GROUP: TEAMS consecutive chains of one channel (the last group of a channel may be short: its spare teams retire here)
+	const int gpc = ( p.chains_per_channel + TEAMS - 1 ) / TEAMS;
+	const int gchannel = int( blockIdx.x ) / gpc, group = int( blockIdx.x ) % gpc;
+	const int chain_in_channel = group * TEAMS + team;
+	if( chain_in_channel >= p.chains_per_channel ) return;
+	const int64_t chain = int64_t( gchannel ) * p.chains_per_channel + chain_in_channel;
+	const int channel = gchannel;
+	const int64_t t0 = int64_t( chain_in_channel ) * p.L;
 	const int64_t t1 = min( t0 + int64_t( p.L ), p.F );
 	const float * x = p.audio + int64_t( channel ) * p.n;
 	const bool use_wrapping = p.analysis_rate < p.sample_rate;                // phase_vocoder.cpp:37
@@ -147,14 +193,21 @@ __global__ __launch_bounds__( 64 * R, 2 ) void k_analyze_team( AnalyzeParams p, 
 		};
 	auto load_window = [&]()
 		{
-		#pragma unroll
-		for( int q = 0; q < WQ; ++q ) win[q] = *reinterpret_cast<const cf*>( tb.window + eo_opaque( 2 * R * ( lane + 64 * q ) + 2 * role ) );
+		if constexpr( !WINLDS )
+			{
+			#pragma unroll
+			for( int q = 0; q < WQ; ++q ) win[q] = *reinterpret_cast<const cf*>( tb.window + eo_opaque( 2 * R * ( lane + 64 * q ) + 2 * role ) );
+			}
 		};
 	auto transform_frame = [&]( int fi )
 		{
 		cf z[16];
 		#pragma unroll
-		for( int q = 0; q < WQ; ++q ) z[q] = mk( raw[q].x * win[q].x, raw[q].y * win[q].y );      // AudioPV.cpp:65
+		for( int q = 0; q < WQ; ++q )
+			{
+			const cf wv = WINLDS ? s_win[64 * q] : win[q];
+			z[q] = mk( raw[q].x * wv.x, raw[q].y * wv.y );                         // AudioPV.cpp:65
+			}
 		#pragma unroll
 		for( int q = WQ; q < 16; ++q ) z[q] = mk( 0.0f, 0.0f );
 		fft_fast<10>( z, mybuf, s_tw1, s_tw3, lane );
@@ -302,16 +355,16 @@ __global__ __launch_bounds__( 64 * R, 2 ) void k_analyze_team( AnalyzeParams p, 
 	load_window();
 	if( frame_inside( tfirst ) ) load_residue( tfirst, inside ); else load_residue( tfirst, outside );
 	transform_frame( 0 );
-	lds_block_sync();
+	team_sync.meet();
 	auto iteration = [&]( int i, auto halo_tag )
 		{
 		const int64_t t = tfirst + i, tn = min( t + 1, t1 - 1 );               // (the last frame requests itself again: nobody waits for it)
 		if( frame_inside( tn ) ) bins_of_frame( t, tn, halo_tag, inside ); else bins_of_frame( t, tn, halo_tag, outside );
 		if( ( i & 63 ) == 63 || i == frames - 1 ) flush_orphans( t - ( i & 63 ), ( i & 63 ) + 1 );
 		load_window();                                                          // (under the barrier: the bins' temporaries are dead)
-		lds_block_sync();                                                       // nobody writes the next frame's E_r before everybody has read this one's
+		team_sync.meet();                                                       // nobody writes the next frame's E_r before everybody has read this one's
 		if( i + 1 < frames ) transform_frame( i + 1 );
-		lds_block_sync();                                                       // the next frame's E_r are written
+		team_sync.meet();                                                       // the next frame's E_r are written
 		};
 	if( t0 > 0 ) iteration( 0, std::true_type{} ); else iteration( 0, std::false_type{} );
 	for( int i = 1; i < frames; ++i ) iteration( i, std::false_type{} );
@@ -351,17 +404,17 @@ __global__ __launch_bounds__( 64 * R, 2 ) void k_analyze_team( AnalyzeParams p, 
 
 // =================================================================================================================
 // PV::convert_to_audio (Conversions/AudioPV.cpp:86-139), dft 8192 / 16384: see the head of the file.  HS = hop / 128 R, WQ = W / 128 R.
-template<int R, int WQ, int HS>
-__global__ __launch_bounds__( 64 * R, 2 ) void k_synthesize_team( SynthParams p, TeamTables tb )
+template<int R, int TEAMS, int WQ, int HS, bool WINLDS>
+__global__ __launch_bounds__( 64 * R * TEAMS, 2 ) void k_synthesize_team( SynthParams p, TeamTables tb )
 	{
-	using L = TeamLds<R>;
+	using L = TeamLds<R, TEAMS, WINLDS ? 64 * R * WQ : 0>;
 	static_assert( R == 4 || R == 8, "teams of four or eight wavefronts" );
 	static_assert( HS >= 1 && HS <= WQ, "hop <= window" );
-	constexpr int S = 1024, CT = S * R, KQ = 8 / R, NT = 64 * R, NB = 2 * R, STEP = 128 * R;
+	constexpr int S = 1024, CT = S * R, KQ = 8 / R, NT = 64 * R * TEAMS, NB = 2 * R, STEP = 128 * R;
 	constexpr int hop = HS * STEP, W = WQ * STEP;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	cf * s = reinterpret_cast<cf*>( smem );
-	const int tid = threadIdx.x, lane = tid & 63, role = __builtin_amdgcn_readfirstlane( tid >> 6 );
+	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane( tid >> 6 ), team = wave / R, role = wave % R;
 
 	__shared__ int s_cancel;
 	if( tid == 0 ) s_cancel = cancel_peek( p.cancel );
@@ -369,17 +422,32 @@ __global__ __launch_bounds__( 64 * R, 2 ) void k_synthesize_team( SynthParams p,
 	for( int i = tid; i < 768; i += NT ) s[L::TW3 + i] = tb.tw3[i];
 	for( int i = tid; i < ( R - 1 ) * 512; i += NT ) s[L::TWJ + i] = tb.twj[i];
 	for( int i = tid; i < ( R / 2 ) * 512; i += NT ) { const cf a = tb.tws[i]; s[L::TWS + i] = mk( a.x, -a.y ); }     // exp( +2 pi i b / 2 CT )
+	if constexpr( WINLDS )
+		{
+		for( int n = tid; n < 64 * R * WQ; n += NT )                            // AudioPV.cpp:102; the analysis kernel's layout
+			{
+			const int r = n % R, m = n / R;
+			const cf g = *reinterpret_cast<const cf*>( tb.window + 2 * n );
+			s[L::WIN + ( r * WQ + ( m >> 6 ) ) * 64 + ( m & 63 )] = mk( g.x * p.window_scale, g.y * p.window_scale );
+			}
+		}
+	cf * const buf0 = s + L::TEAM0 + team * L::TEAM_LEN;
+	TeamMeet<R, TEAMS == 1> team_sync{ (lds_u32*) reinterpret_cast<unsigned*>( buf0 + L::FLAG ), 0u, lane };
+	if( role == 0 && lane == 0 ) *team_sync.flag = 0u;
 	__syncthreads();
 	if( s_cancel ) return;
 	const cf * s_tw1 = s + L::TW1;
 	const cf * s_tw3 = s + L::TW3;
-	cf * const buf0 = s + L::BUF;
+	const cf * s_win = s + L::WIN + role * WQ * 64 + lane;
 	cf * const mybuf = buf0 + role * L::BUF_LEN;
-	cf * const xorph = s + L::ORPH;
+	cf * const xorph = buf0 + L::ORPH;
 
-	const int64_t chain = blockIdx.x;
-	const int channel = int( chain / p.chains_per_channel );
-	const int chain_in_channel = int( chain % p.chains_per_channel );
+	const int gpc = ( p.chains_per_channel + TEAMS - 1 ) / TEAMS;
+	const int gchannel = int( blockIdx.x ) / gpc, group = int( blockIdx.x ) % gpc;
+	const int chain_in_channel = group * TEAMS + team;
+	if( chain_in_channel >= p.chains_per_channel ) return;
+	const int64_t chain = int64_t( gchannel ) * p.chains_per_channel + chain_in_channel;
+	const int channel = gchannel;
 	const int64_t t0 = int64_t( chain_in_channel ) * p.L;
 	const int64_t t1 = min( t0 + int64_t( p.L ), p.F );
 	const bool last_chain = chain_in_channel == p.chains_per_channel - 1;
@@ -437,8 +505,15 @@ __global__ __launch_bounds__( 64 * R, 2 ) void k_synthesize_team( SynthParams p,
 	cf win[WQ];
 	auto load_window = [&]()
 		{
-		#pragma unroll
-		for( int q = 0; q < WQ; ++q ) win[q] = *reinterpret_cast<const cf*>( tb.window + eo_opaque( 2 * R * ( lane + 64 * q ) + 2 * role ) );
+		if constexpr( !WINLDS )
+			{
+			#pragma unroll
+			for( int q = 0; q < WQ; ++q )
+				{
+				const cf g = *reinterpret_cast<const cf*>( tb.window + eo_opaque( 2 * R * ( lane + 64 * q ) + 2 * role ) );
+				win[q] = mk( g.x * p.window_scale, g.y * p.window_scale );
+				}
+			}
 		};
 	// Zc[j], Zc[N-j] from X[j] = a, X[N-j] = b and w = exp( +2 pi i j / 2N ) (k_synthesize_v2's merge)
 	auto merge_pair = []( cf a, cf b, float wx, float wy, cf & zj, cf & zn )
@@ -574,7 +649,7 @@ __global__ __launch_bounds__( 64 * R, 2 ) void k_synthesize_team( SynthParams p,
 	load_row( t0 );
 	bins_of_row();
 	load_window();
-	lds_block_sync();
+	team_sync.meet();
 	int64_t pos = chain_start;
 	for( int i = 0; i < frames; ++i )
 		{
@@ -591,17 +666,18 @@ __global__ __launch_bounds__( 64 * R, 2 ) void k_synthesize_team( SynthParams p,
 		#pragma unroll
 		for( int q = 0; q < WQ; ++q )
 			{
-			acc[q].x += z[q].x * ( win[q].x * p.window_scale );
-			acc[q].y += ( -z[q].y ) * ( win[q].y * p.window_scale );
+			const cf wv = WINLDS ? s_win[64 * q] : win[q];
+			acc[q].x += z[q].x * wv.x;
+			acc[q].y += ( -z[q].y ) * wv.y;
 			}
 		#pragma unroll
 		for( int q = 0; q < HS; ++q ) emit_step( pos + STEP * q, acc[q] );
 		#pragma unroll
 		for( int q = 0; q < WQ; ++q ) acc[q] = ( q + HS < WQ ) ? acc[q + HS] : mk( 0.0f, 0.0f );
 		pos += hop;
-		lds_block_sync();                                                       // nobody writes the next frame's A_r before everybody has transformed this one's
+		team_sync.meet();                                                       // nobody writes the next frame's A_r before everybody has transformed this one's
 		if( i + 1 < frames ) { bins_of_row(); load_window(); }
-		lds_block_sync();                                                       // the next frame's A_r are written
+		team_sync.meet();                                                       // the next frame's A_r are written
 		}
 	// flush the partial sums that the next chain's head completes; the last chain zero-fills to the end of the output
 	const int64_t ring_end = pos + ( W - hop );

@@ -22,10 +22,13 @@ bool team_shape( int dft, int W, int hop )
 	return false;
 	}
 
+// teams (chains) per block: two teams of four wavefronts share one set of tables and the window; a team of eight has the CU to itself
+template<int R> struct TeamsPerBlock { static constexpr int value = R == 4 ? 2 : 1; };
+int team_group_size( int dft ) { return team_radix( dft ) == 4 ? 2 : 1; }
 int team_target_chains( int dft )
 	{
 	if( const int v = debug_options().target_chains ) { if( v > 0 ) return v; }
-	return cu_count() * ( team_radix( dft ) == 4 ? 2 : 1 );
+	return cu_count() * team_group_size( dft );
 	}
 
 static TeamTables team_tables( const Plan & plan, int R )
@@ -34,16 +37,22 @@ static TeamTables team_tables( const Plan & plan, int R )
 	return TeamTables{ plan.d_team + l.tw1, plan.d_team + l.tw3, plan.d_team + l.twj, plan.d_team + l.tws, plan.d_team + l.two, plan.d_window };
 	}
 
+// the window lives in LDS up to 8192 samples (64 R WQ pairs)
+template<int R, int WQ> struct TeamWinLds { static constexpr bool value = 128 * R * WQ <= 8192; };
+
 template<int R, int WQ, bool SUMS>
 static int launch_analyze_team( const AnalyzeParams & p, const TeamTables & tb, hipStream_t s )
 	{
-	const size_t lds = TeamLds<R>::bytes();
-	static_assert( ( TeamLds<R>::bytes() + 64 ) * ( R == 4 ? 2 : 1 ) <= 160 * 1024, "LDS budget" );
-	auto kern = k_analyze_team<R, WQ, SUMS>;
+	constexpr int TEAMS = TeamsPerBlock<R>::value;
+	constexpr bool WINLDS = TeamWinLds<R, WQ>::value;
+	using L = TeamLds<R, TEAMS, WINLDS ? 64 * R * WQ : 0>;
+	const size_t lds = L::bytes();
+	static_assert( L::bytes() + 64 <= 160 * 1024, "LDS budget" );
+	auto kern = k_analyze_team<R, TEAMS, WQ, SUMS, WINLDS>;
 	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
-	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;       // a block = a chain
+	const int64_t chains = int64_t( ( p.chains_per_channel + TEAMS - 1 ) / TEAMS ) * p.num_channels;       // a block = a group of TEAMS chains of one channel
 	FLANHIP_REQUIRE( chains < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
-	hipLaunchKernelGGL( kern, dim3( (unsigned) chains ), dim3( 64 * R ), lds, s, p, tb );
+	hipLaunchKernelGGL( kern, dim3( (unsigned) chains ), dim3( 64 * R * TEAMS ), lds, s, p, tb );
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;
 	}
@@ -51,12 +60,16 @@ static int launch_analyze_team( const AnalyzeParams & p, const TeamTables & tb, 
 template<int R, int WQ, int HS>
 static int launch_synth_team( const SynthParams & p, const TeamTables & tb, hipStream_t s )
 	{
-	const size_t lds = TeamLds<R>::bytes();
-	auto kern = k_synthesize_team<R, WQ, HS>;
+	constexpr int TEAMS = TeamsPerBlock<R>::value;
+	constexpr bool WINLDS = TeamWinLds<R, WQ>::value;
+	using L = TeamLds<R, TEAMS, WINLDS ? 64 * R * WQ : 0>;
+	const size_t lds = L::bytes();
+	static_assert( L::bytes() + 64 <= 160 * 1024, "LDS budget" );
+	auto kern = k_synthesize_team<R, TEAMS, WQ, HS, WINLDS>;
 	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
-	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;
+	const int64_t chains = int64_t( ( p.chains_per_channel + TEAMS - 1 ) / TEAMS ) * p.num_channels;
 	FLANHIP_REQUIRE( chains < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
-	hipLaunchKernelGGL( kern, dim3( (unsigned) chains ), dim3( 64 * R ), lds, s, p, tb );
+	hipLaunchKernelGGL( kern, dim3( (unsigned) chains ), dim3( 64 * R * TEAMS ), lds, s, p, tb );
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;
 	}
