@@ -285,7 +285,7 @@ def test_chain_length_invariance(fa):
     synthesis equal to rounding of the overlap partial sums"""
     x = O.noise(2, 60000, seed=8)
     sr = 48000.0
-    for (W, hop, dft) in ((2048, 512, 2048), (1024, 256, 1024), (512, 128, 512)):
+    for (W, hop, dft) in ((2048, 512, 2048), (1024, 256, 1024), (512, 128, 512), (4096, 1024, 8192), (4096, 1024, 16384)):
         res = []
         for L in (4, 7, 64):
             with fa.debug_options(chain_len=L):
@@ -297,6 +297,34 @@ def test_chain_length_invariance(fa):
         for k in (1, 2):
             d = np.abs(res[0][1].astype(np.float64) - res[k][1].astype(np.float64))
             assert d.max() <= 2e-6
+
+
+@pytest.mark.parametrize("W,hop,dft,n", [(2048, 512, 8192, 150000), (4096, 1024, 16384, 300000), (8192, 2048, 8192, 420000)])
+def test_team_kernels_long_chains(fa, W, hop, dft, n):
+    """dft 8192 / 16384 (pv_kernels_team.h): chains of more than 64 frames, so that the batches of the k = 512 group (one frame per lane, worked off every
+    64 frames) are crossed -- against the oracle, and bit for bit against short chains"""
+    x = O.noise(2, n, seed=77)
+    sr = 48000.0
+    ref = O.analyze(x, sr, W, hop, dft)
+    ar = np.float32(sr) / np.float32(hop)
+    out_ref, _ = O.synthesize(ref, sr, ar, W)
+    res = []
+    for L in (150, 65, 9):
+        with fa.debug_options(chain_len=L):
+            pv = fa.analyze(x, sr, W, hop, dft)
+            out, _ = fa.synthesize(ref, sr, ar, W)
+        res.append((pv, out))
+    rel_m, wrms_f, same, turns = p1_metrics(res[0][0], ref, sr / hop)
+    rms = float(np.sqrt(np.mean((res[0][1].astype(np.float64) - out_ref.astype(np.float64)) ** 2)))
+    print("\n[team long chains %d %d %d] rel_m=%.3e wrms_df=%.3e same=%.4f  P2 rms=%.3e" % (W, hop, dft, rel_m, wrms_f, same, rms))
+    assert rel_m <= 1e-5 and wrms_f <= 5e-4 and same >= 0.985 and rms <= 1e-5
+    # the orphan bins by themselves (512 + 1024 j): the same bar
+    orph = np.arange(512, dft // 2, 1024)
+    rel_o, wrms_o, same_o, _ = p1_metrics(res[0][0][:, :, orph], ref[:, :, orph], sr / hop)
+    assert rel_o <= 1e-5 and same_o >= 0.97
+    for k in (1, 2):
+        assert np.array_equal(res[0][0].view(np.uint32), res[k][0].view(np.uint32))
+        assert np.abs(res[0][1].astype(np.float64) - res[k][1].astype(np.float64)).max() <= 2e-6
 
 
 def test_errors(fa):
@@ -311,13 +339,13 @@ def test_errors(fa):
     assert e.value.code == flan_amd.ERR_INVALID_ARG
 
 
-@pytest.mark.parametrize("dft,hop", [(2048, 512), (4096, 128), (2048, 1024), (2048, 256), (4096, 1024), (1024, 256), (1024, 1024), (512, 128), (512, 256)])
+@pytest.mark.parametrize("dft,hop", [(2048, 512), (4096, 128), (2048, 1024), (2048, 256), (4096, 1024), (1024, 256), (1024, 1024), (512, 128), (512, 256), (8192, 512), (8192, 1024), (16384, 1024)])
 def test_generic_and_tuned_kernels_agree(fa, dft, hop):
     """dft 512 ... 4096 have tuned kernels (pv_kernels_v2.h, _v3.h, _eo.h); the force_generic hook routes the same call through the
     generic ones (pv_kernels.h).  Both must sit within the parity tolerances of the oracle and of each other."""
     x = O.noise(2, 70000, seed=21)
     sr = 48000.0
-    W = min(2048, dft)
+    W = min(2048, dft) if dft <= 8192 else 4096       # (dft 8192 / 16384: the team kernels against the round-1 block kernels / the mixed-radix kernels)
     ref = O.analyze(x, sr, W, hop, dft)
     out_ref, _ = O.synthesize(ref, sr, np.float32(sr) / np.float32(hop), W)
     res = {}
@@ -342,7 +370,7 @@ def test_fused_round_trip_equals_unfused(fa):
     sr = 48000.0
     # dft 8192 (and 4096 through the generic kernels): block-wide teams walk the chains; they leave the sums like every other analysis kernel
     for (ch, n, W, hop, dft) in [(2, 70000, 2048, 512, 2048), (1, 30000, 2048, 128, 4096), (2, 20000, 1024, 256, 1024), (1, 9000, 400, 100, 512), (2, 40000, 512, 128, 512), (3, 90000, 1024, 512, 1024),
-                                 (1, 40000, 4096, 1024, 8192), (2, 30000, 2048, 300, 4096), (3, 500000, 2000, 500, 4096), (2, 200000, 4000, 1000, 4096),
+                                 (1, 40000, 4096, 1024, 8192), (2, 400000, 8192, 2048, 8192), (3, 300000, 4096, 1024, 16384), (1, 100000, 4000, 1000, 8192), (2, 30000, 2048, 300, 4096), (3, 500000, 2000, 500, 4096), (2, 200000, 4000, 1000, 4096),
                                  (3, 500000, 1000, 250, 1024), (2, 30000, 1024, 300, 1024), (4, 300000, 500, 125, 512), (1, 20000, 512, 100, 512),
                                  (2, 300000, 2048, 300, 2048), (3, 200000, 2000, 500, 2048), (1, 40000, 1800, 450, 2048), (3, 700000, 3000, 750, 4096), (2, 90000, 4094, 441, 4096),
                                  # the mixed-radix kernels: sums kept by the analysis kernel (ping-pong sizes, with and without the large odd radices) or by
