@@ -58,7 +58,8 @@ def parse_args(argv=None):
     ap.add_argument("--preroll-ms", type=float, default=80.0,
                     help="untimed device warm-up before the W warm-up steps: the same steps run for this long so that the GPU's clocks "
                          "have settled (a just-woken MI355X runs the same launch ~20 %% slower for its first ~40 ms); 0 disables")
-    ap.add_argument("--pcie", action="store_true", help="also time the host-buffer entry points (PCIe inclusive; reported in 'pcie_inclusive', never in 'value')")
+    ap.add_argument("--pcie", action="store_true", help="(default since round 6) also time the host-buffer entry points (PCIe inclusive; reported in 'pcie_inclusive', never in 'value')")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg (SURVEY 8d: reported separately, by default)")
     ap.add_argument("--window", type=int, default=2048, help="2048: the BASELINE metric")
     ap.add_argument("--hop", type=int, default=512, help="512: the BASELINE metric; 128 with --dft 4096 is the reference API's default call")
     ap.add_argument("--dft", type=int, default=2048,
@@ -403,25 +404,32 @@ def main():
             traffic, traffic_source = None, "no traffic profile: " + repr(e)
         # what a plain device-to-device copy of the same number of bytes reaches on this box (quote the measured
         # copy rate beside the 8 TB/s spec); read + written bytes, like the algorithmic figure
+        # (round 6: the library's own 16-bytes-per-lane streaming copy, flanhip_copy_dev -- torch's copy_ measured 5.4 TB/s where this chip's
+        # float4 copy reaches ~6.3, MI355X_MICROARCH.md; quoting the kernels against the slower one flattered them)
         copy_gbs = None
         try:
-            src = pv.view(-1)[: frames_per_step * b // 8]          # half the bytes read, half written
+            cnt = (frames_per_step * b // 8) & ~3                  # floats: half the bytes read, half written
+            src = pv.view(-1)[:cnt]
             dst = torch.empty_like(src)
-            dst.copy_(src)
-            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            c0.record()
-            for _ in range(10):
-                dst.copy_(src)
-            c1.record()
-            torch.cuda.synchronize()
-            copy_gbs = round(2 * src.numel() * 4 / (c0.elapsed_time(c1) / 10 * 1e-3) / 1e9, 1)
+            fa.check(fa.lib.flanhip_copy_dev(ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), cnt, ctypes.c_void_p(stream)))
+            best = None
+            for _ in range(3):
+                c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                c0.record()
+                for _ in range(10):
+                    fa.check(fa.lib.flanhip_copy_dev(ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), cnt, ctypes.c_void_p(stream)))
+                c1.record()
+                torch.cuda.synchronize()
+                t = c0.elapsed_time(c1) / 10
+                best = t if best is None else min(best, t)
+            copy_gbs = round(2 * cnt * 4 / (best * 1e-3) / 1e9, 1)
             del dst
         except Exception:
             copy_gbs = None
         roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "launch_ms": round(tk, 4), "algorithmic_bytes_per_launch": frames_per_step * b,
-                    "copy_peak_measured": copy_gbs}
+                    "copy_peak_measured": copy_gbs, "copy_peak_kind": "flanhip_copy_dev: 16 B per lane, grid-stride, the same bytes read + written"}
         # The bound that actually holds these kernels is the vector ALU, not HBM: the launch's VALU instruction mix, priced per
         # class with the measured issue costs, against the launch's own cycles.  PMC counters cannot be read from inside the process: the mix is
         # the committed profile's (profiles/r05_valu_roofline.json, tools/make_valu_roofline.py), quoted only while the kernel sources' hash
@@ -474,7 +482,7 @@ def main():
         del finals, outs, wss
 
     # the host-buffer C ABI (flanhip_analyze / flanhip_synthesize): upload, kernels, download -- for DESIGN.md, never the metric
-    if rank == 0 and args.pcie:
+    if rank == 0 and world == 1 and not args.no_pcie and ( args.pcie or ( ch * n <= 8 * 60 * 48000 and DFT <= 4096 ) ):
         import numpy as np
         x_host = audio.cpu().numpy()
         fa.analyze(x_host[:1, :48000], SR, WINDOW, HOP, DFT)
@@ -705,6 +713,8 @@ def other_configs(fa, torch, dev):
     # pv_kernels_bs.h), and ( 4096, 1024, 32768 ) (residue pairs, pv_kernels_big.h: a 2.95 GB PV) -- both direct sums until round 5
     for (hop, tag, Wd, dft) in ((128, "api_default_2048_128_4096", 2048, 4096), (512, "dft4096_hop512", 2048, 4096), (1024, "window4096_hop1024_dft4096", 4096, 4096),
                                 (256, "dft1024_window1024_hop256", 1024, 1024), (128, "dft512_window512_hop128", 512, 512),
+                                # ... and dft 8192 / 16384: teams of four / eight wavefronts per chain (pv_kernels_team.h, round 6; before: the round-1 block kernels 0.92 ms, mixed radix 4.4 ms)
+                                (2048, "dft8192_window8192_hop2048", 8192, 8192), (1024, "dft16384_window4096_hop1024", 4096, 16384),
                                 (512, "dft2998_window2048_hop512_chirp_z", 2048, 2998), (1024, "dft32768_window4096_hop1024", 4096, 32768)):
         bins = dft // 2 + 1
         Fd = int(lib.flanhip_num_pv_frames(n, hop))

@@ -122,6 +122,7 @@ _SIGS = {
     "flanhip_allgather_audio": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "flanhip_noise_dev": (C.c_int, [_vp, _i64, _i64, C.c_uint32, _vp]),
     "flanhip_sqdiff_dev": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "flanhip_copy_dev": (C.c_int, [_vp, _vp, _i64, _vp]),
 }
 
 EXPORTS = sorted(_SIGS)

@@ -1139,7 +1139,22 @@ size_t flanhip_synthesize_workspace_bytes( int64_t ch, int64_t F, int bins, floa
 	{
 	SynthLayout lay;
 	if( synth_layout( ch, F, bins, sr, ar, W, &lay ) ) return 0;
-	return lay.total_bytes;
+	size_t bytes = lay.total_bytes;
+	// dft 1024 / 512: the A/B hook FLANHIP_DEBUG_ANA_VARIANT selects kernel configurations with other group sizes and chain counts, i.e. another
+	// layout; a workspace sized under one setting of the hook holds every other's
+	if( v3_size( lay.dft ) )
+		{
+		DebugOptions & o = debug_options();
+		const int keep = o.ana_variant;
+		for( int v = 0; v < 3; ++v )
+			{
+			o.ana_variant = v;
+			SynthLayout alt;
+			if( !synth_layout( ch, F, bins, sr, ar, W, &alt ) ) bytes = std::max( bytes, alt.total_bytes );
+			}
+		o.ana_variant = keep;
+		}
+	return bytes;
 	}
 
 int flanhip_synthesize_dev( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins, float sr, float ar, int W,

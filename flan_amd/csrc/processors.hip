@@ -910,6 +910,12 @@ extern "C" int flanhip_stretch_map_const_dev( float factor, float * d_map, int64
 	{
 	FLANHIP_REQUIRE( d_map && F > 0 && bins > 0 && hop >= 1, FLANHIP_ERR_INVALID_ARG, "bad arguments" );
 	if( int rc = require_device() ) return rc;
+	// (the closed-form kernel stores four floats at a time and assumes such a store spans at most two rows: rows of one or two bins take the scanning kernel)
+	if( bins < 3 )
+		{
+		if( int rc = flanhip_fill_dev( d_map, F * bins, factor, stream ) ) return rc;
+		return flanhip_stretch_map_dev( d_map, F, bins, sr, hop, d_max, stream );
+		}
 	const int64_t blocks = ( F + kConstRows - 1 ) / kConstRows;
 	FLANHIP_REQUIRE( blocks < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many frames for one launch" );
 	static thread_local ConstSumMarks marks;

@@ -973,8 +973,10 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 			bins_of_row();
 			if( fix && has_head && i == i_pub )
 				{
-				// the wait for row i + 1 has retired every store issued before that row was requested: the head's among them
-				asm volatile( "" ::: "memory" );
+				// the head's stores went out iterations ago and the wait for row i + 1 has retired them with everything else issued before that row was
+				// requested -- but that is the compiler's counted wait, not a statement of this source: the queue is drained explicitly (once per chain:
+				// this iteration's HOPQ stores are all that is in flight; ADVICE r05, interleaved A/B in profiles/r06_ab_publish_drain.txt)
+				asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
 				if( lane == 0 ) old_h = __hip_atomic_exchange( word_h, tag_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
 				asm volatile( "" ::: "memory" );
 				published = true;

@@ -29,6 +29,25 @@ __global__ __launch_bounds__( 256 ) void k_fill( float * p, int64_t count, float
 	if( tid < count - rest0 ) p[rest0 + tid] = v;
 	}
 
+// The yardstick bench.py quotes the kernels against ("verify on the box with a copy kernel"): 16 bytes per lane and access, grid-stride,
+// non-temporal both ways -- what a streaming kernel of this chip can move, read + written
+__global__ __launch_bounds__( 256 ) void k_copy16( const float * __restrict__ src, float * __restrict__ dst, int64_t quads )
+	{
+	typedef float f4 __attribute__(( ext_vector_type( 4 ) ));
+	const f4 * s = reinterpret_cast<const f4*>( src );
+	f4 * d = reinterpret_cast<f4*>( dst );
+	const int64_t stride = int64_t( gridDim.x ) * blockDim.x;
+	int64_t i = int64_t( blockIdx.x ) * blockDim.x + threadIdx.x;
+	for( ; i + 3 * stride < quads; i += 4 * stride )
+		{
+		const f4 a = __builtin_nontemporal_load( s + i ), b = __builtin_nontemporal_load( s + i + stride );
+		const f4 c = __builtin_nontemporal_load( s + i + 2 * stride ), e = __builtin_nontemporal_load( s + i + 3 * stride );
+		__builtin_nontemporal_store( a, d + i ); __builtin_nontemporal_store( b, d + i + stride );
+		__builtin_nontemporal_store( c, d + i + 2 * stride ); __builtin_nontemporal_store( e, d + i + 3 * stride );
+		}
+	for( ; i < quads; i += stride ) __builtin_nontemporal_store( __builtin_nontemporal_load( s + i ), d + i );
+	}
+
 __device__ __forceinline__ uint32_t hash32( uint32_t x )
 	{
 	x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
@@ -90,6 +109,18 @@ int flanhip_noise_dev( float * d_out, int64_t ch, int64_t n, uint32_t seed, void
 	if( int rc = require_device() ) return rc;
 	const unsigned bx = (unsigned) std::min<int64_t>( ( n + 255 ) / 256, 2048 );
 	hipLaunchKernelGGL( k_noise, dim3( bx, (unsigned) ch ), dim3( 256 ), 0, (hipStream_t) stream, d_out, n, seed );
+	FLANHIP_CHECK( hipGetLastError() );
+	return FLANHIP_OK;
+	}
+
+int flanhip_copy_dev( const float * d_src, float * d_dst, int64_t count, void * stream )
+	{
+	FLANHIP_REQUIRE( d_src && d_dst && count > 0 && count % 4 == 0, FLANHIP_ERR_INVALID_ARG, "bad arguments (a multiple of four floats)" );
+	FLANHIP_REQUIRE( ( ( reinterpret_cast<uintptr_t>( d_src ) | reinterpret_cast<uintptr_t>( d_dst ) ) & 15 ) == 0, FLANHIP_ERR_INVALID_ARG, "16-byte aligned buffers" );
+	if( int rc = require_device() ) return rc;
+	const int64_t quads = count / 4;
+	const unsigned blocks = (unsigned) std::min<int64_t>( ( quads + 255 ) / 256, int64_t( cu_count() ) * 16 );
+	hipLaunchKernelGGL( k_copy16, dim3( blocks ), dim3( 256 ), 0, (hipStream_t) stream, d_src, d_dst, quads );
 	FLANHIP_CHECK( hipGetLastError() );
 	return FLANHIP_OK;
 	}

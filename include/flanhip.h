@@ -441,6 +441,8 @@ int flanhip_allgather_audio(void * comm, float * d_all, int64_t count_per_rank, 
 
 /* ---- synthetic input + comparison utilities (bench / tests; defined by this project) -------------- */
 int flanhip_noise_dev(float * d_out, int64_t num_channels, int64_t num_audio_frames, uint32_t seed, void * stream);
+/* a plain streaming copy, 16 bytes per lane: the measured-copy yardstick bench.py quotes beside the 8 TB/s spec (count: floats, a multiple of 4) */
+int flanhip_copy_dev(const float * d_src, float * d_dst, int64_t count, void * stream);
 /* sum of squares of (a - b) and of b, as doubles: d_result[0] = sum (a-b)^2, d_result[1] = sum b^2 */
 int flanhip_sqdiff_dev(const float * d_a, const float * d_b, int64_t count, double * d_result, void * stream);
 

@@ -587,7 +587,7 @@ def test_stretch_map_kernel_has_no_spills_and_survives_odd_grids(fa):
         assert mx[0] == ref.max(), (F, bins)
 
 
-@pytest.mark.parametrize("F,bins", [(1, 1), (469, 1025), (5626, 1025), (37, 65), (3000, 257), (100000, 9)])
+@pytest.mark.parametrize("F,bins", [(1, 1), (469, 1025), (5626, 1025), (37, 65), (3000, 257), (100000, 9), (500, 1), (700, 2), (300, 3), (1000, 4)])
 def test_constant_stretch_map_in_closed_form(fa, F, bins):
     """flanhip_stretch_map_const_dev: the map of a CONSTANT factor from the number alone -- the running fp32 sum of a constant reproduced without running
     it (flan_amd/csrc/const_sum.h; tools/check_const_sum.cpp checks it step by step on the CPU) -- against the checker's sequential scan of the filled

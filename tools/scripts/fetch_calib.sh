@@ -1,5 +1,6 @@
 # FETCH_SIZE / WRITE_SIZE of known byte counts in the PV kernels' access shapes (tools/ubench/fetch_calib.hip): the calibration
 # MI355X_MICROARCH.md asks for before an absolute HBM byte figure is trusted.  Separate PMC passes, no tracing alongside.
+: ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it): an empty root would turn cd / rm -rf below into operations on /}
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp

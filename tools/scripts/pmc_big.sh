@@ -1,4 +1,5 @@
 # SQ and HBM counters of the above-16384 kernels at (4096, 1024, 32768), 8 ch x 60 s; summary in gpurun_out/big_counters.txt
+: ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it): an empty root would turn cd / rm -rf below into operations on /}
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp

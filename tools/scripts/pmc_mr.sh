@@ -1,4 +1,5 @@
 # SQ counters of the mixed-radix kernels at (2048, 512, 3000), 8 ch x 60 s
+: ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it): an empty root would turn cd / rm -rf below into operations on /}
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp

@@ -1,5 +1,6 @@
 #!/bin/bash
 # two SQ passes over one kernel variant (wave-time breakdown + LDS): tools/scripts/pmc_quick.sh <tag> <run_variant.py args...>
+: ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it): an empty root would turn cd / rm -rf below into operations on /}
 set -e
 R=$GRAFT_REPO_ROOT
 TAG=$1; shift

@@ -1,4 +1,5 @@
 # SQ counters of the conversion kernels at a given shape: bash tools/scripts/pmc_shape.sh WINDOW HOP DFT  (8 ch x 60 s; summary in gpurun_out/shape_sq_counters.txt)
+: ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it): an empty root would turn cd / rm -rf below into operations on /}
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp

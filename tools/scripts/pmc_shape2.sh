@@ -1,5 +1,6 @@
 # SQ counters of the conversion kernels at a given shape and kernel configuration: bash tools/scripts/pmc_shape2.sh WINDOW HOP DFT VARIANT TAG
 # (8 ch x 60 s; summary in gpurun_out/sq_TAG.txt)
+: ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it): an empty root would turn cd / rm -rf below into operations on /}
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp

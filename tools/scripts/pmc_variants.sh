@@ -1,5 +1,6 @@
 #!/bin/bash
 # PMC passes over one kernel variant:  tools/scripts/pmc_variants.sh <tag> <run_variant.py args...>   -> gpurun_out/pmc_<tag>.txt
+: ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it): an empty root would turn cd / rm -rf below into operations on /}
 set -e
 R=$GRAFT_REPO_ROOT
 TAG=$1; shift

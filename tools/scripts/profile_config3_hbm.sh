@@ -1,4 +1,5 @@
 # HBM traffic (PMC, separate passes) of every frame processor at the config 3 size; summary per kernel in gpurun_out/config3_hbm_summary.txt
+: ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it): an empty root would turn cd / rm -rf below into operations on /}
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 # per-kernel times of Audio::resample for the rate pairs given (default: the slow ones)
+: ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it): an empty root would turn cd / rm -rf below into operations on /}
 set -e
 R=$GRAFT_REPO_ROOT
 PAIRS=${@:-"192000:48000 192000:44100 48000:44100 44100:48001"}

@@ -1,5 +1,6 @@
 # Audio::resample 96 -> 48 kHz (config 5's stage, k_resample_ols3): kernel time, SQ counters (what a wavefront's time goes into) and HBM traffic,
 # separate PMC passes; summaries in gpurun_out/resample_sq_counters.txt / resample_hbm_counters.txt / resample_kernel_stats.csv
+: ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it): an empty root would turn cd / rm -rf below into operations on /}
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 # kernel-trace summaries of the secondary shapes (dft 4096 = the API default size; config 4 whole on one GPU)
+: ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it): an empty root would turn cd / rm -rf below into operations on /}
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 # per-kernel times of the stretch stage (tools/bench_stretch.py) under rocprofv3; summary in gpurun_out/mtc_kernel_stats.csv
+: ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it): an empty root would turn cd / rm -rf below into operations on /}
 set -e
 R=$GRAFT_REPO_ROOT
 

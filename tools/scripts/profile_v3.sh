@@ -1,9 +1,9 @@
 # round 5: the dft 1024 / 512 kernels (pv_kernels_v3.h): configurations A/B, kernel stats and SQ counters of the product configuration
+: ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it): an empty root would turn cd / rm -rf below into operations on /}
 set -e
 R=$GRAFT_REPO_ROOT
 cd $R
-sed -i 's/^for cfg in .*; do$/for cfg in "1024 256 1024 0 1 2" "512 128 512 0 1 2"; do/' tools/scripts/v3_variants.sh
-bash tools/scripts/v3_variants.sh > /dev/null
+V3_CFGS="1024 256 1024 0 1 2;512 128 512 0 1 2" bash tools/scripts/v3_variants.sh > /dev/null
 cp gpurun_out/v3_variants.txt gpurun_out/r05_v3_variants.txt
 cd /tmp && export TMPDIR=/tmp
 for cfg in "1024 256 1024" "512 128 512"; do

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 3, stall attribution of the dft 2048 pair on the bench shape:
 #   PMC passes (instruction fetch / I-cache, LDS, instruction classes, wave-time split, clock) -> gpurun_out/r03_attr_pmc.txt
+: ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it): an empty root would turn cd / rm -rf below into operations on /}
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp

@@ -1,3 +1,4 @@
+: ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it): an empty root would turn cd / rm -rf below into operations on /}
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out

@@ -1,4 +1,5 @@
 # bench.py's headline numbers for every library built by build_flag_variants.sh -> gpurun_out/flag_variants.txt
+: ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it): an empty root would turn cd / rm -rf below into operations on /}
 R=$GRAFT_REPO_ROOT
 : > $R/gpurun_out/flag_variants.txt
 for so in $R/tools/ubench/variants/libflanhip_*.so; do

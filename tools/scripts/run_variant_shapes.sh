@@ -1,3 +1,4 @@
+: ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it): an empty root would turn cd / rm -rf below into operations on /}
 R=$GRAFT_REPO_ROOT
 for name in base nopk nopk_topdown; do
   so=$R/tools/ubench/variants/libflanhip_$name.so

@@ -1,4 +1,5 @@
 # SQ instruction counters of the dft 4096 kernels (hop 512 and the API default hop 128) -> gpurun_out/sq_dft4096.txt
+: ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it): an empty root would turn cd / rm -rf below into operations on /}
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 # one iteration of config 3, dispatch by dispatch (duration, gap to the previous dispatch), from a rocprofv3 kernel trace
+: ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it): an empty root would turn cd / rm -rf below into operations on /}
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp

@@ -3,7 +3,8 @@
 mkdir -p gpurun_out
 out=gpurun_out/v3_variants.txt
 : > $out
-for cfg in "1024 256 1024 0 1 2" "512 128 512 0 1 2"; do
+IFS=';' read -ra V3_LIST <<< "${V3_CFGS:-1024 256 1024 0 1 2;512 128 512 0 1 2}"      # "W H D variant..." separated by ;
+for cfg in "${V3_LIST[@]}"; do
 	set -- $cfg; W=$1; H=$2; D=$3; shift 3
 	for v in "$@"; do
 		python bench.py --window $W --hop $H --dft $D --no-cpu --no-configs --steps 20 --warmup 5 --kernel-variant 4=$v > gpurun_out/v3_tmp.json 2> gpurun_out/v3_tmp.err

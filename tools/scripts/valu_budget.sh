@@ -1,5 +1,6 @@
 # Per-phase VALU budget of the dft 2048 kernels: one SQ PMC pass over the phase-ablated variants (diagnostic library
 # tools/ubench/libflanhip_ablations.so, built by tools/scripts/build_diag.sh ablations) -> gpurun_out/valu_budget.txt
+: ${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it): an empty root would turn cd / rm -rf below into operations on /}
 set -e
 R=$GRAFT_REPO_ROOT
 export FLAN_AMD_LIB=$R/tools/ubench/libflanhip_ablations.so
