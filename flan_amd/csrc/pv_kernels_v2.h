@@ -107,6 +107,17 @@ struct Stamps
 
 // (round_half_away_v, polar_tail / polar_v: pv_math.h)
 
+// Before a chain publishes its head's tag from inside the frame loop (k_synthesize_v2 / _v3): every store this wavefront has issued has retired.
+// FLANHIP_PUBLISH_DRAIN=0 is the A/B partner (round 5's form: the compiler's counted wait for the next row as the only proof)
+#ifndef FLANHIP_PUBLISH_DRAIN
+#define FLANHIP_PUBLISH_DRAIN 1
+#endif
+__device__ __forceinline__ void publish_drain()
+	{
+	if constexpr( FLANHIP_PUBLISH_DRAIN != 0 ) asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+	else asm volatile( "" ::: "memory" );
+	}
+
 // =================================================================================================================
 // Audio::convert_to_PV (Conversions/AudioPV.cpp:12-78), dft 2048
 // =================================================================================================================
@@ -976,7 +987,7 @@ __global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_v2( SynthParams p, 
 				// the head's stores went out iterations ago and the wait for row i + 1 has retired them with everything else issued before that row was
 				// requested -- but that is the compiler's counted wait, not a statement of this source: the queue is drained explicitly (once per chain:
 				// this iteration's HOPQ stores are all that is in flight; ADVICE r05, interleaved A/B in profiles/r06_ab_publish_drain.txt)
-				asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+				publish_drain();
 				if( lane == 0 ) old_h = __hip_atomic_exchange( word_h, tag_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
 				asm volatile( "" ::: "memory" );
 				published = true;

@@ -840,7 +840,7 @@ __global__ __launch_bounds__( 64 * WAVES, OCC ) void k_synthesize_v3( SynthParam
 			bins_of_row();
 			if( fix && has_head && i == i_pub )
 				{
-				asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );                // (the head's stores have retired: an explicit drain, once per chain -- pv_kernels_v2.h)
+				publish_drain();                                                 // (the head's stores have retired: an explicit drain, once per chain -- pv_kernels_v2.h)
 				if( lane == 0 ) old_h = __hip_atomic_exchange( word_h, tag_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
 				asm volatile( "" ::: "memory" );
 				published = true;
