@@ -64,6 +64,9 @@ def parse_args(argv=None):
     ap.add_argument("--hop", type=int, default=512, help="512: the BASELINE metric; 128 with --dft 4096 is the reference API's default call")
     ap.add_argument("--dft", type=int, default=2048,
                     help="2048: the primary measurement; 4096: the literal convert_to_PV(2048,512) default of the reference API (SURVEY 8)")
+    ap.add_argument("--config4-seconds", type=float, default=600.0,
+                    help="N > 1: seconds per channel of the BASELINE config 4 leg (8 ch x 600 s per rank); tests rehearse it with a few seconds")
+    ap.add_argument("--no-config4", action="store_true", help="N > 1: skip the config 4 leg")
     ap.add_argument("--plan-only", action="store_true",
                     help="no GPU work: the ranks rendezvous over gloo, agree on the plan and rank 0 prints it (what tests/ use to cover the launcher on CPU)")
     return ap.parse_args(argv)
@@ -131,6 +134,157 @@ def cpu_fft_share(frames, dft, per_frame_seconds):
     return round(per / per_frame_seconds, 3), round(per * 1e6, 2)
 
 
+class GatherLegs:
+    """N > 1: the output reassembly of the north star -- ONE in-place all-gather of float[world x channels][samples] -- behind the round trip, through
+    the library's C ABI (flanhip_comm_unique_id / flanhip_comm_init / flanhip_allgather_audio: ncclAllGather over xGMI, collective.hip).  The
+    communicator id travels from rank 0 over the job's own torch.distributed group; if any rank cannot bind RCCL through the C ABI, every rank uses
+    torch.distributed.all_gather_into_tensor instead (`api` / `err` say which)."""
+
+    def __init__(self, fa, torch, dist, sharding, rank, world, dev, ctl_dev):
+        self.fa, self.torch, self.dist, self.sharding = fa, torch, dist, sharding
+        self.rank, self.world, self.dev, self.ctl_dev = rank, world, dev, ctl_dev
+        self.comm, self.err = None, None
+        lib = fa.lib
+        uid = ctypes.create_string_buffer(128)
+        ok = 1
+        if rank == 0:
+            rc = lib.flanhip_comm_unique_id(uid)
+            if rc != 0:
+                ok, self.err = 0, "flanhip_comm_unique_id: %s" % fa.last_error()
+        t = torch.tensor(list(uid.raw) + [ok], dtype=torch.uint8, device=dev)
+        dist.broadcast(t, src=0)
+        raw = bytes(t.cpu().tolist())
+        if raw[128]:
+            comm = ctypes.c_void_p()
+            rc = lib.flanhip_comm_init(ctypes.create_string_buffer(raw[:128], 128), world, rank, ctypes.byref(comm))
+            if rc == 0 and comm.value:
+                self.comm = comm
+            else:
+                ok, self.err = 0, "flanhip_comm_init: %s" % fa.last_error()
+        else:
+            ok = 0
+        if sharding.min_over_ranks(dist, 1 if self.comm else 0, ctl_dev) < 1:
+            if self.comm:
+                lib.flanhip_comm_destroy(self.comm)
+            self.comm = None
+            self.err = self.err or "another rank could not bind RCCL through the C ABI"
+        self.api = "flanhip_allgather_audio: ncclAllGather in place through the C ABI" if self.comm else "torch.distributed.all_gather_into_tensor in place (C-ABI communicator not available)"
+        self.nranks = world if self.comm else dist.get_world_size()
+        self.side = torch.cuda.Stream(device=dev)
+
+    def close(self):
+        if self.comm:
+            self.fa.lib.flanhip_comm_destroy(self.comm)
+            self.comm = None
+
+    def legs(self, audio, pv, ws, ch, n, W, HOP, DFT, steps, warmup, timed_region, unfused=False):
+        fa, torch, dist, rank, world = self.fa, self.torch, self.dist, self.rank, self.world
+        lib = fa.lib
+        F = int(lib.flanhip_num_pv_frames(n, HOP))
+        bins, ar = DFT // 2 + 1, SR / HOP
+        count = ch * F * HOP                                      # floats per rank
+        finals = [torch.empty((world * ch, F * HOP), dtype=torch.float32, device=self.dev) for _ in range(2)]
+        mine = [f[rank * ch: rank * ch + ch] for f in finals]    # this rank's slot: the synthesis writes it in place
+        nan_flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        main = torch.cuda.current_stream()
+        side = self.side
+        stream = main.cuda_stream
+
+        def compute(b):
+            if unfused:
+                fa.analyze_dev(audio, ch, n, SR, W, HOP, DFT, pv, stream)
+            else:
+                fa.analyze_dev_fused(audio, ch, n, SR, W, HOP, DFT, pv, ws, stream)
+            fa.synthesize_dev_stages(pv, ch, F, bins, SR, ar, W, mine[b], ws, nan_flag, 0 if unfused else 1, 0xF, stream)
+
+        pending = [None, None]
+
+        def gather_on(b, s):
+            """the in-place all-gather of finals[b], behind everything issued on stream s so far"""
+            if self.comm:
+                fa.check(lib.flanhip_allgather_audio(self.comm, ctypes.c_void_p(finals[b].data_ptr()), count, rank, ctypes.c_void_p(s.cuda_stream)))
+                ev = torch.cuda.Event()
+                ev.record(s)
+                return ev
+            with torch.cuda.stream(s):
+                return dist.all_gather_into_tensor(finals[b], mine[b], async_op=True)
+
+        def wait_for(h):
+            if h is None:
+                return
+            if self.comm:
+                torch.cuda.current_stream().wait_event(h)
+            else:
+                h.wait()
+
+        def step_then_gather():
+            compute(0)
+            wait_for(gather_on(0, main))
+
+        counter = [0]
+
+        def step_overlapped():
+            b = counter[0] & 1
+            counter[0] += 1
+            wait_for(pending[b])                                  # the gather that last used this buffer
+            compute(b)
+            done = torch.cuda.Event()
+            done.record(main)
+            side.wait_event(done)
+            pending[b] = gather_on(b, side)
+
+        def drain():
+            for b in (0, 1):
+                wait_for(pending[b])
+                pending[b] = None
+            main.wait_stream(side)
+
+        res = {}
+        res["overlapped_s"] = timed_region(step_overlapped, drain, steps, warmup)
+        # what arrived: every slot of both buffers against the sum its owner reports for its own slot
+        ok = True
+        for b in (0, 1):
+            sums = finals[b].view(world, -1).sum(dim=1, dtype=torch.float64)
+            own = sums[rank].reshape(1).clone()
+            alls = [torch.empty_like(own) for _ in range(world)]
+            dist.all_gather(alls, own)
+            want = torch.cat(alls)
+            ok = ok and bool(torch.all(torch.abs(sums - want) <= 1e-9 * torch.abs(want) + 1e-12).item()) and bool(torch.all(torch.isfinite(sums)).item())
+        assert ok, "an all-gathered slot does not hold what its owner computed"
+        res["slots_verified"] = ok
+        res["compute_only_s"] = timed_region(lambda: compute(0), lambda: None, steps, warmup)
+        res["then_gather_s"] = timed_region(step_then_gather, lambda: None, steps, warmup)
+        reps = 5
+        res["gather_alone_ms"] = 1e3 * timed_region(lambda: wait_for(gather_on(0, main)), lambda: None, reps, 2) / reps
+        del finals, mine
+        return res
+
+    def config4(self, seconds, timed_region):
+        """BASELINE config 4 (64 ch x 10 min over 8 GPUs): this rank's 8 ch x `seconds` s through the same three legs, a few steps each"""
+        fa, torch, rank, world = self.fa, self.torch, self.rank, self.world
+        lib = fa.lib
+        W, HOP, DFT, ch = 2048, 512, 2048, 8
+        n = int(seconds * SR)
+        F = int(lib.flanhip_num_pv_frames(n, HOP))
+        bins, ar = DFT // 2 + 1, SR / HOP
+        audio = torch.empty((ch, n), dtype=torch.float32, device=self.dev)
+        fa.check(lib.flanhip_noise_dev(ctypes.c_void_p(audio.data_ptr()), ch, n, 4321 + rank, None))
+        pv = torch.empty((ch, F, bins, 2), dtype=torch.float32, device=self.dev)
+        ws = torch.empty(fa.synthesize_workspace_bytes(ch, F, bins, SR, ar, W), dtype=torch.uint8, device=self.dev)
+        steps, warmup = 3, 1
+        legs = self.legs(audio, pv, ws, ch, n, W, HOP, DFT, steps, warmup, timed_region)
+        frames = world * ch * F
+        out = {"workload": "BASELINE config 4: %d ch x %.0f s over %d GPU(s), 8 ch per rank: convert_to_PV(2048,512,2048) -> convert_to_audio -> in-place all-gather of the output" % (world * ch, seconds, world),
+               "steps": steps, "warmup": warmup, "frames_per_step": frames, "allgather_bytes_per_rank": ch * F * HOP * 4, "api": self.api, "nranks": self.nranks,
+               "slots_verified": legs["slots_verified"], "allgather_ms_alone": round(legs["gather_alone_ms"], 3)}
+        for key, tag in (("compute_only_s", "compute_only"), ("then_gather_s", "compute_then_allgather"), ("overlapped_s", "overlapped")):
+            t = legs[key] / steps
+            out[tag] = {"ms_per_step": round(t * 1e3, 4), "frames_per_s": round(frames / t, 1)}
+        del audio, pv, ws
+        torch.cuda.empty_cache()
+        return out
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -163,9 +317,17 @@ def main():
             dist.all_gather_object(plans, mine)
             dist.barrier()
         if rank == 0:
+            from flan_amd import sharding
+            n4 = int(args.config4_seconds * SR)
+            F4 = n4 // HOP + 1
+            c4 = {"workload": "BASELINE config 4: %d ch x %.0f s over %d GPUs, 8 ch per rank" % (8 * world, args.config4_seconds, world),
+                  "channels_per_gpu": 8, "frames_per_step": world * 8 * F4,
+                  "allgather": sharding.inplace_allgather_plan(world, 8, F4 * HOP),
+                  "legs": ["compute_only", "compute_then_allgather", "overlapped"]} if world > 1 and not args.no_config4 else None
             print(json.dumps({"plan_only": True, "metric": baseline_metric(), "n_gpus": world, "scaling": "weak",
                               "config": {"workload": "%d ch x %.0f s per GPU" % (ch, args.seconds), "parallelism": parallelism},
-                              "total_channels": world * ch, "frames_per_step": sum(p["frames"] for p in plans), "ranks": plans}), flush=True)
+                              "total_channels": world * ch, "frames_per_step": sum(p["frames"] for p in plans), "ranks": plans,
+                              "allgather": sharding.inplace_allgather_plan(world, ch, F * HOP) if world > 1 else None, "config4": c4}), flush=True)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -261,69 +423,27 @@ def main():
                 step()
             torch.cuda.synchronize()
             preroll_steps += 10
-    # ---- N > 1: the north star's path ends with ONE all-gather that reassembles the output, so the timed step of a multi-GPU job includes it --
-    # overlapped: batch i's output travels (one batch of point-to-point operations straight into the final channel-major buffer, on a side
-    # stream) while batch i + 1 is analysed and synthesised, two output buffers in turn; with --gather-chunks K > 1 the rank's channels are
-    # additionally cut into K chunks per batch, each sent as soon as it is done (smaller launches: slower compute).  `value` is that;
-    # `value_compute_only` (the K steps without the gather: >= 6x at N = 8 by construction, channels being independent) stands beside it.
-    # Every side buffer is allocated BEFORE the first collective and the ranks agree (one all-reduce) that all of them got theirs: a rank that
-    # cannot allocate would otherwise leave the others waiting in a collective for ever.  Past that point nothing is caught: an error inside a
-    # collective ends the rank, and the launcher ends the job -- a failed job, not a hung one.
+    # ---- N > 1: the north star's path ends with ONE all-gather that reassembles the output, so the timed step of a multi-GPU job includes it:
+    # every step is analysis -> synthesis straight into this rank's slot of the final channel-major buffer -> ONE in-place ncclAllGather of that buffer,
+    # issued through the library's own C ABI (flanhip_comm_init / flanhip_allgather_audio, collective.hip) on a side stream, so that batch i's
+    # gather travels under batch i + 1's compute (two final buffers in turn).  `value` is that; `value_compute_only` (>= 6x at N = 8 by construction,
+    # channels being independent) and `value_compute_then_gather` (the same collective, not overlapped) stand beside it.  The communicator is set up
+    # BEFORE anything is timed and the ranks agree (one all-reduce) that all of them have theirs; if the C-ABI binding cannot be had the same steps run
+    # with torch.distributed's all_gather_into_tensor and the line says so.  Past that point nothing is caught: an error inside a collective ends the
+    # rank, and the launcher ends the job -- a failed job, not a hung one.
     use_gather = distributed and not args.no_gather and not share_gpu
-    gather_err = None
-    if use_gather:
-        chunks = max(1, min(args.gather_chunks, ch))
-        while ch % chunks:
-            chunks -= 1
-        k = ch // chunks
-        side_ok, side_err = 1, None
-        try:
-            side = torch.cuda.Stream(device=dev)
-            outs = [out, torch.empty_like(out)]
-            finals = [torch.empty((world * ch, F * HOP), dtype=torch.float32, device=dev) for _ in range(2)]
-            wss = [torch.empty(fa.synthesize_workspace_bytes(k, F, BINS, SR, ar, WINDOW), dtype=torch.uint8, device=dev) for _ in range(chunks)]
-        except Exception as e:
-            side_ok, side_err = 0, repr(e)
-        if sharding.min_over_ranks(dist, side_ok, ctl_dev) < 1:
-            use_gather, gather_err = False, "a rank could not allocate the gather buffers: " + str(side_err)
-    if use_gather:
-        pending = [[], []]
-        counter = [0]
+    gather = GatherLegs(fa, torch, dist, sharding, rank, world, dev, ctl_dev) if use_gather else None
 
-        def step_with_gather():
-            i = counter[0]
-            counter[0] += 1
-            b = i & 1
-            for r in pending[b]:                     # the gather that last used this pair of buffers
-                r.wait()
-            pending[b] = []
-            torch.cuda.current_stream().wait_stream(side)
-            for c in range(chunks):
-                c0 = c * k
-                o = outs[b][c0:c0 + k]
-                analyze(audio[c0:c0 + k], pv[c0:c0 + k], wss[c], k)
-                synthesize(pv[c0:c0 + k], o, wss[c], k)
-                done = torch.cuda.Event()
-                done.record()
-                side.wait_event(done)
-                with torch.cuda.stream(side):
-                    pending[b] += sharding.gather_chunk_into(dist, finals[b], o, rank, world, ch, c0)
-
-        def drain():
-            for b in (0, 1):
-                for r in pending[b]:
-                    r.wait()
-                pending[b] = []
-            torch.cuda.current_stream().wait_stream(side)
-
-    def timed_region(step_fn, finish_fn):
+    def timed_region(step_fn, finish_fn, steps=None, warmup=None):
         """W untimed steps, then exactly K steps between barriers + device synchronisation; the slowest rank's time"""
-        for _ in range(args.warmup):
+        steps = args.steps if steps is None else steps
+        warmup = args.warmup if warmup is None else warmup
+        for _ in range(warmup):
             step_fn()
         finish_fn()
         sync_all()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             step_fn()
         finish_fn()
         sync_all()
@@ -331,11 +451,11 @@ def main():
         return sharding.max_over_ranks(dist, dt, ctl_dev) if distributed else dt
 
     elapsed_compute = None
+    legs = None
     if use_gather:
-        elapsed = timed_region(step_with_gather, drain)
-        for b in (0, 1):
-            assert bool(torch.equal(finals[b][rank * ch: rank * ch + ch], outs[b])), "the gathered buffer must hold this rank's channels in place"
-        elapsed_compute = timed_region(step, lambda: None)
+        # the headline shape with the gather: the K timed steps of the contract are the overlapped ones
+        legs = gather.legs(audio, pv, ws, ch, n, WINDOW, HOP, DFT, args.steps, args.warmup, timed_region, unfused=args.unfused)
+        elapsed, elapsed_compute = legs["overlapped_s"], legs["compute_only_s"]
     else:
         elapsed = timed_region(step, lambda: None)
     ms_per_step = 1e3 * elapsed / args.steps
@@ -456,33 +576,28 @@ def main():
         extra["roundtrip_hbm"] = {"achieved_GBs": round(frames_per_step * BYTES_ROUNDTRIP / (ms_per_step * 1e-3) / 1e9, 1),
                                   "frac_of_8TBs": round(frames_per_step * BYTES_ROUNDTRIP / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
-    # ---- the same all-gather on its own (not overlapped), for the record beside the overlapped step the metric is quoted on ----
-    if gather_err:
-        extra["allgather"] = {"error": gather_err}
-    elif use_gather:
-        nranks = dist.get_world_size()
-        for _ in range(2):
-            gathered = sharding.gather_output(dist, out, world)
-        sync_all()
-        t0 = time.perf_counter()
-        reps = 5
-        for _ in range(reps):
-            gathered = sharding.gather_output(dist, out, world)
-        sync_all()
-        tg = sharding.max_over_ranks(dist, (time.perf_counter() - t0) / reps, ctl_dev)
-        assert gathered.shape == (world * ch, F * HOP)
-        del gathered
-        t_compute = elapsed_compute / args.steps
-        extra["allgather"] = {"nranks": nranks, "ms_alone": round(tg * 1e3, 3), "bytes_per_rank": out.numel() * 4,
+    # ---- the gather legs for the record, and BASELINE config 4's shape (64 ch x 10 min over 8 GPUs = 8 ch x 600 s per rank) through the same steps ----
+    if use_gather:
+        t_compute, t_then, t_over = (legs[k] / args.steps for k in ("compute_only_s", "then_gather_s", "overlapped_s"))
+        extra["allgather"] = {"nranks": gather.nranks, "api": gather.api, "api_error": gather.err, "ms_alone": round(legs["gather_alone_ms"], 3),
+                              "bytes_per_rank": ch * F * HOP * 4, "slots_verified": legs["slots_verified"],
                               "frames_per_s_compute_only": round(value_compute_only, 1),
-                              "frames_per_s_compute_then_gather": round(world * frames_per_step / (t_compute + tg), 1),
+                              "frames_per_s_compute_then_gather": round(world * frames_per_step / t_then, 1),
                               "frames_per_s_gather_overlapped": round(value, 1),
-                              "overlapped_step_ms": round(ms_per_step, 4), "compute_only_step_ms": round(t_compute * 1e3, 4), "channel_chunks": chunks,
-                              "overlap": "gather of batch i (side stream, p2p batch into the final layout) under the compute of batch i + 1"}
-        del finals, outs, wss
+                              "overlapped_step_ms": round(t_over * 1e3, 4), "compute_then_gather_step_ms": round(t_then * 1e3, 4), "compute_only_step_ms": round(t_compute * 1e3, 4),
+                              "overlap": "ONE in-place all-gather of the final [rank][channel][sample] buffer per step, on a side stream under the next step's compute (two buffers in turn)"}
+        if not args.no_config4 and DFT == 2048 and HOP == 512 and WINDOW == 2048:
+            del audio, pv, out, ws
+            torch.cuda.empty_cache()
+            try:
+                extra["config4"] = gather.config4(args.config4_seconds, timed_region)
+            except Exception as e:                    # (an allocation that does not fit, say: the headline line is not lost to it; errors INSIDE a collective are not caught)
+                if "out of memory" not in repr(e).lower():
+                    raise
+                extra["config4"] = {"error": repr(e)}
 
     # the host-buffer C ABI (flanhip_analyze / flanhip_synthesize): upload, kernels, download -- for DESIGN.md, never the metric
-    if rank == 0 and world == 1 and not args.no_pcie and ( args.pcie or ( ch * n <= 8 * 60 * 48000 and DFT <= 4096 ) ):
+    if rank == 0 and world == 1 and not use_gather and not args.no_pcie and ( args.pcie or ( ch * n <= 8 * 60 * 48000 and DFT <= 4096 ) ):
         import numpy as np
         x_host = audio.cpu().numpy()
         fa.analyze(x_host[:1, :48000], SR, WINDOW, HOP, DFT)
@@ -498,7 +613,7 @@ def main():
         del pv_host, out_host
 
     # ---- the other BASELINE configurations, timed the same way (device resident, events, after the same warm-up) ----
-    if rank == 0 and world == 1 and not args.no_configs:
+    if rank == 0 and world == 1 and not args.no_configs and not use_gather:
         del pv, out, ws
         torch.cuda.empty_cache()
         try:
@@ -544,15 +659,18 @@ def main():
         line["value_includes_gather"] = bool(use_gather)
         # how the timed steps reassemble the output: one batch of point-to-point sends / receives per step straight into the final channel-major buffer
         # on a side stream (the same bytes over the same xGMI links as north_star's one in-place ncclAllGather, whose form is value_compute_then_gather)
-        line["gather_kind"] = ("overlapped batch of isend / irecv into the final [rank][channel][sample] buffer; the collective form "
-                               "(all_gather_into_tensor, in place) is value_compute_then_gather") if use_gather else None
+        line["gather_kind"] = ("one in-place all-gather of the final [rank][channel][sample] buffer per step (%s), on a side stream under the next step's compute; "
+                               "the same collective not overlapped is value_compute_then_gather" % gather.api) if use_gather else None
         line["value_compute_only"] = round(value_compute_only, 1) if value_compute_only else None
         line["value_gather_overlapped"] = ag.get("frames_per_s_gather_overlapped")
         line["value_compute_then_gather"] = ag.get("frames_per_s_compute_then_gather")
         line["rccl_nranks"] = ag.get("nranks")
+        line["config4"] = extra.pop("config4", None)                       # N > 1: BASELINE config 4's shape per rank -- compute only, compute then all-gather, overlapped
         line["device_warmup"] = {"preroll_ms": args.preroll_ms, "preroll_steps": preroll_steps, "cold": cold}
         line.update(extra)
         print(json.dumps(line), flush=True)
+    if gather is not None:
+        gather.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

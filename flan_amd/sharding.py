@@ -39,6 +39,16 @@ def gather_output(dist, local_out, world_size):
     return gathered
 
 
+def inplace_allgather_plan(world_size, ch_local, samples):
+    """The in-place all-gather that reassembles the output (flanhip_allgather_audio / ncclAllGather): rank r's shard of
+    ch_local x samples floats sits at element offset r * count of the final float[world * ch_local][samples] buffer, count = ch_local * samples --
+    the send buffer IS recv + rank * count, so the gathered buffer is the final channel-major AudioBuffer with no re-layout."""
+    count = ch_local * samples
+    return {"count_per_rank": count, "bytes_per_rank": 4 * count, "total_bytes": 4 * count * world_size,
+            "send_offsets": [r * count for r in range(world_size)],
+            "channel_rows": [[r * ch_local, (r + 1) * ch_local] for r in range(world_size)]}
+
+
 def gather_chunk_into(dist, final, local_chunk, rank, world_size, ch_local, c0):
     """The all-gather of ONE channel chunk, written straight into the final layout: rank r's channels [c0, c0 + k) of its
     ch_local land in final[r * ch_local + c0 : r * ch_local + c0 + k].  One batch of point-to-point operations (every slice is

@@ -38,6 +38,17 @@ def test_bench_spawns_its_ranks(gpus):
     assert plan["frames_per_step"] == gpus * 8 * (60 * 48000 // 512 + 1)
     assert [p["rank"] for p in plan["ranks"]] == list(range(gpus))
     assert [p["channels"] for p in plan["ranks"]] == [[8 * r, 8 * r + 8] for r in range(gpus)]
+    if gpus > 1:
+        # the output reassembly: one in-place all-gather, every rank's shard already at its final offset; and BASELINE config 4's shape (8 ch x 600 s per rank)
+        out_len = (60 * 48000 // 512 + 1) * 512
+        ag = plan["allgather"]
+        assert ag["count_per_rank"] == 8 * out_len and ag["send_offsets"] == [r * 8 * out_len for r in range(gpus)] and ag["total_bytes"] == 4 * 8 * out_len * gpus
+        c4 = plan["config4"]
+        F4 = 600 * 48000 // 512 + 1
+        assert c4["channels_per_gpu"] == 8 and c4["frames_per_step"] == gpus * 8 * F4
+        assert c4["allgather"]["bytes_per_rank"] == 8 * F4 * 512 * 4 and c4["legs"] == ["compute_only", "compute_then_allgather", "overlapped"]
+    else:
+        assert plan["allgather"] is None and plan["config4"] is None
 
 
 def test_a_failing_rank_fails_the_launch():
@@ -69,6 +80,33 @@ def _gather_worker(rank, world, port, ch_local, n):
     assert torch.equal(final, sharding.gather_output(dist, local, world))          # the same buffer as the plain all-gather
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _inplace_worker(rank, world, port, ch_local, n):
+    from flan_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    plan = sharding.inplace_allgather_plan(world, ch_local, n)
+    final = torch.full((world * ch_local * n,), -1.0)
+    lo = plan["send_offsets"][rank]
+    mine = final[lo: lo + plan["count_per_rank"]]
+    mine.copy_(torch.arange(ch_local * n, dtype=torch.float32) + 1000.0 * rank)            # the synthesis writes the rank's slot of the final buffer
+    # what ncclAllGather( recv + rank * count, recv, count ) does, spelled with gloo: every slot from its owner, the own one left in place
+    slots = [final[o: o + plan["count_per_rank"]] for o in plan["send_offsets"]]
+    dist.all_gather(slots, mine.clone())
+    want = torch.cat([torch.arange(ch_local * n, dtype=torch.float32) + 1000.0 * r for r in range(world)])
+    assert torch.equal(final, want)
+    rows = final.view(world * ch_local, n)
+    for r, (a, b) in enumerate(plan["channel_rows"]):                                     # ... and the buffer IS channel-major: rank r's channels are rows [a, b)
+        assert torch.equal(rows[a:b].reshape(-1), torch.arange(ch_local * n, dtype=torch.float32) + 1000.0 * r)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_inplace_allgather_plan_is_the_final_layout(world):
+    mp.spawn(_inplace_worker, args=(world, _free_port(), 4, 129), nprocs=world, join=True)
 
 
 @pytest.mark.parametrize("world", [2, 4])
