@@ -579,7 +579,7 @@ def synthesize_dev_stages(d_pv, ch, F, bins, sample_rate, analysis_rate, window,
 DEBUG_CHAIN_LEN, DEBUG_TARGET_CHAINS, DEBUG_FORCE_GENERIC, DEBUG_NO_FAST_DIV = 0, 1, 2, 3
 DEBUG_ANA_VARIANT, DEBUG_SYN_VARIANT, DEBUG_ANA4096_OLD, DEBUG_SYN4096_OLD, DEBUG_RESAMPLE_DIRECT, DEBUG_FORCE_DIRECT, DEBUG_INLINE_FIXUP, DEBUG_WIDE_OFFSETS = 4, 5, 6, 7, 8, 9, 10, 11
 _DEBUG_NAMES = {"chain_len": 0, "target_chains": 1, "force_generic": 2, "no_fast_div": 3, "ana_variant": 4, "syn_variant": 5,
-                "ana4096_old": 6, "syn4096_old": 7, "resample_direct": 8, "force_direct": 9, "inline_fixup": 10, "wide_offsets": 11}
+                "ana4096_old": 6, "syn4096_old": 7, "resample_direct": 8, "force_direct": 9, "inline_fixup": 10, "wide_offsets": 11, "no_sub": 12}
 
 
 class debug_options:

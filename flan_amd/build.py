@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libflanhip.so")
-SOURCES = ["core.hip", "conversions.hip", "team.hip", "processors.hip", "processors_ext.hip", "processors_arrange.hip", "resample.hip", "utility.hip", "collective.hip", "transfer.hip"]
+SOURCES = ["core.hip", "conversions.hip", "team.hip", "sub.hip", "processors.hip", "processors_ext.hip", "processors_arrange.hip", "resample.hip", "utility.hip", "collective.hip", "transfer.hip"]
 # -ffp-contract=off: the per-bin phase-vocoder arithmetic must round every fp32 operation individually, like the
 # reference; the FFT butterflies call fmaf explicitly where a fused multiply-add is wanted.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -20,7 +20,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # on the bench shape the synthesis kernel is 18 % faster without it (0.152 -> 0.125 ms), dft 4096 9 % (profiles/r02_e_*); same IEEE
 # operations either way, results bit-identical.
 NO_PK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-EXTRA = {"conversions.hip": NO_PK, "team.hip": NO_PK}
+EXTRA = {"conversions.hip": NO_PK, "team.hip": NO_PK, "sub.hip": NO_PK}
 
 
 def kernel_source_hash():
@@ -28,7 +28,7 @@ def kernel_source_hash():
     file with its flags): profiles/ stamp their numbers with it, and bench.py quotes a profile only for the kernels it was taken on."""
     import hashlib
     h = hashlib.sha256()
-    names = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + ["conversions.hip", "core.hip", "team.hip"]
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + ["conversions.hip", "core.hip", "team.hip", "sub.hip"]
     for name in names:
         with open(os.path.join(CSRC, name), "rb") as fh:
             h.update(name.encode() + b"\0" + fh.read())

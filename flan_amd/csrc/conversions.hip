@@ -14,6 +14,7 @@
 #include "pv_kernels_bs.h"
 #include "pv_kernels_big.h"
 #include "team_launch.h"
+#include "sub_launch.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -527,6 +528,7 @@ static bool synth_fast_ok( int dft, int W, int hop ) { return synth_fast_kind( d
 // pair (a block = 8 one-wavefront chains of a channel), 4 for the dft 4096 team kernels (4 teams per block); 0: no group totals for this shape.
 static int self_carry_group( int dft, int W, int hop, int chains_per_channel )
 	{
+	if( sub_shape( dft, W, hop ) ) return 0;                                      // (pv_kernels_sub.h: carries from the scan kernel)
 	const int kind = synth_fast_kind( dft, W, hop );
 	int g = 0;
 	// the LDS-ring form of the dft 4096 team synthesis (any hop, any window up to 2048: four teams per block like the analysis) takes the totals too
@@ -566,6 +568,8 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	if( int rc = require_device() ) return rc;
 	// dft 8192 / 16384 on the team kernels' grid of windows and hops (pv_kernels_team.h, round 6): before the round-1 / mixed-radix kernels of those sizes
 	const bool team = team_shape( dft, W, hop ) && n >= 2 && n < ( int64_t( 1 ) << 31 ) - 65536;
+	// dft 512 / 256 on the grid of the kernels with several chains per wavefront (pv_kernels_sub.h, round 6): before the one-wavefront / generic kernels
+	const bool sub = sub_shape( dft, W, hop ) && n >= 2 && n < ( int64_t( 1 ) << 31 ) - 8192;
 	MrPlan mr_plan{};
 	const bool mr = !team && mr_size( dft, W, &mr_plan );
 	BsPlan bs_plan{};
@@ -585,7 +589,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	// (hop: the dft 2048 kernel addresses a block's samples by 32-bit byte offsets from the block's first frame -- up to 8 chains of <= ~512 frames,
 	// env overrides aside -- and the generic kernels serve the hops that would not fit: nothing anybody analyses with)
 	const bool fast = ( dft == 2048 || dft == 4096 || v3_size( dft ) ) && n >= 2 && n < ( int64_t( 1 ) << 31 ) - 8192 && hop <= 65536 && !force_generic();
-	int target_chains = team ? team_target_chains( dft ) : any ? any_target_chains( dft / 2 + 1 ) : mr ? mr_target_chains( dft, W ) : bs ? bs_target_chains( dft, W ) : big ? big_target_chains() : fast ? fast_target_chains( dft, false ) : generic_target_chains( dft );
+	int target_chains = team ? team_target_chains( dft ) : sub ? sub_target_chains( dft ) : any ? any_target_chains( dft / 2 + 1 ) : mr ? mr_target_chains( dft, W ) : bs ? bs_target_chains( dft, W ) : big ? big_target_chains() : fast ? fast_target_chains( dft, false ) : generic_target_chains( dft );
 	p.L = choose_chain_length( ch, p.F, any ? 7 : 1, target_chains );
 	p.chains_per_channel = int( ( p.F + p.L - 1 ) / p.L );
 	p.sample_rate = sr;
@@ -614,7 +618,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 			p.nan_out = reinterpret_cast<int*>( reinterpret_cast<char*>( d_fused_ws ) + lay.carry_bytes + lay.head_bytes );
 			}
 		// the dft 2048 kernel (and the dft 4096 team kernel) also leaves one total per group of 8 (4) chains: the synthesis kernel then needs no scan kernel in front of it
-		const bool groups_too = fast && kernel_sums && self_carry_group( dft, W, hop, lay.chains_per_channel ) != 0;
+		const bool groups_too = fast && !sub && kernel_sums && self_carry_group( dft, W, hop, lay.chains_per_channel ) != 0;
 		p.group_sums = groups_too ? reinterpret_cast<double*>( reinterpret_cast<char*>( d_fused_ws ) + lay.group_offset ) : nullptr;
 		p.groups_per_channel = lay.groups_per_channel;
 		*left_group_sums = groups_too;
@@ -637,6 +641,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 		};
 
 	if( team ) return run_analyze_team( p, *plan, dft, s );                       // (keeps the chain sums: kernel_sums)
+	if( sub ) return run_analyze_sub( p, dft, s );
 	if( any )
 		{
 		std::shared_ptr<const UnitRef> unit_ref;
@@ -732,6 +737,7 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	FLANHIP_REQUIRE( dft_size_ok( o->dft ), FLANHIP_ERR_UNSUPPORTED, "dft size must be even, at least 4 and at most 2^20" );
 	FLANHIP_REQUIRE( int64_t( o->dft ) * W < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "dft_size * window_size overflows the int product of AudioPV.cpp:99" );
 	const bool team = team_shape( o->dft, W, o->hop );
+	const bool sub = sub_shape( o->dft, W, o->hop );
 	const bool mr = !team && mr_size( o->dft, W );
 	const bool bs = !team && !mr && bs_size( o->dft, W );
 	BigPlan big_plan{};
@@ -739,8 +745,8 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	o->any = !team && !fft_size( o->dft ) && !mr && !bs && !o->big;
 	o->head_len = o->any ? 0 : std::max( W - o->hop, 0 );        // (the direct-sum path overlap-adds whole frames from its own scratch: no chain heads)
 	const int overlap = ( W + o->hop - 1 ) / o->hop;              // frames covering one output sample
-	const int kind = ( o->any || o->big ) ? 0 : synth_fast_kind( o->dft, W, o->hop );
-	const int slots = team ? team_target_chains( o->dft ) : o->any ? any_target_chains( bins ) : mr ? mr_target_chains( o->dft, W ) : bs ? bs_target_chains( o->dft, W ) : o->big ? big_target_chains() : kind == 0 ? generic_target_chains( o->dft ) : ( kind == 2 && o->dft == 4096 ) ? cu_count() * ring_teams11( W ) : fast_target_chains( o->dft, true );
+	const int kind = ( o->any || o->big || sub ) ? 0 : synth_fast_kind( o->dft, W, o->hop );
+	const int slots = team ? team_target_chains( o->dft ) : sub ? sub_target_chains( o->dft ) : o->any ? any_target_chains( bins ) : mr ? mr_target_chains( o->dft, W ) : bs ? bs_target_chains( o->dft, W ) : o->big ? big_target_chains() : kind == 0 ? generic_target_chains( o->dft ) : ( kind == 2 && o->dft == 4096 ) ? cu_count() * ring_teams11( W ) : fast_target_chains( o->dft, true );
 	o->L = choose_chain_length( ch, F, o->any ? 1 : std::max( overlap - 1, 1 ), slots );
 	o->chains_per_channel = int( ( F + o->L - 1 ) / o->L );
 	const int64_t chains = int64_t( o->chains_per_channel ) * ch;
@@ -945,6 +951,7 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 		rc = FLANHIP_OK;
 		}
 	else if( team_shape( lay.dft, W, lay.hop ) ) rc = run_synth_team( p, *plan, lay.dft, s );
+	else if( sub_shape( lay.dft, W, lay.hop ) ) rc = run_synth_sub( p, lay.dft, s );
 	else if( MrPlan mr_plan{}; mr_size( lay.dft, W, &mr_plan ) )
 		{
 		const size_t lds = mr_synth_lds( mr_plan.C, W, mr_plan.win_lds, mr_plan.kc_lds );
@@ -1113,6 +1120,7 @@ void flanhip_debug_option( int which, int value )
 		case FLANHIP_DEBUG_FORCE_DIRECT:    o.force_direct = value; break;
 		case FLANHIP_DEBUG_INLINE_FIXUP:    o.inline_fixup = value; break;
 		case FLANHIP_DEBUG_WIDE_OFFSETS:    o.wide_offsets = value; break;
+		case FLANHIP_DEBUG_NO_SUB:          o.no_sub = value; break;
 		default: break;
 		}
 	}

@@ -78,6 +78,7 @@ struct DebugOptions
 	int resample_direct = 0;                   // 1: the 2:1 block convolver always as direct sums; 2: its radix-16 generation (k_resample_ols2)
 	int wide_offsets = 0;                      // 1: 64-bit element offsets where a kernel would choose 32-bit ones by the grid's size (k_stretch_map)
 	int inline_fixup = 0;                      // the dft 2048 synthesis kernel adding the chains' overlaps itself instead of k_ola_fixup in a launch of its own: 0 where its chains are long enough (the library's choice), 1 always, 2 never
+	int no_sub = 0;                            // 1: dft 512 / 256 never on the several-chains-per-wavefront kernels (pv_kernels_sub.h): the one-wavefront kernels of pv_kernels_v3.h / the generic ones (A/B)
 	int force_direct = 0;                      // 1: dft sizes without power-of-two kernels as direct fp64 sums (pv_kernels_any.h), never the mixed-radix kernels
 	};
 DebugOptions & debug_options();
