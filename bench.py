@@ -826,11 +826,12 @@ def other_configs(fa, torch, dev):
 
     # ---- the reference API's own defaults: convert_to_PV() = ( 2048, 128, 4096 ) (Audio.h:158-163), and ( 2048, 512, 4096 )
     # ... and ( 4096, 1024, 4096 ): window = dft, the plain STFT call at that size (the team kernels' one-buffer-set variants)
-    # ... and the two power-of-two sizes below the metric's: ( 1024, 256, 1024 ) -- the classic setting -- and ( 512, 128, 512 ) (pv_kernels_v3.h, round 5)
+    # ... and the power-of-two sizes below the metric's: ( 1024, 256, 1024 ) -- the classic setting -- (pv_kernels_v3.h, round 5), ( 512, 128, 512 ) and ( 256, 64, 256 )
+    # (pv_kernels_sub.h, round 6: several chains per wavefront)
     # ... and two sizes FFTW plans like any other (FFTHelper.cpp:16-26): ( 2048, 512, 2998 ), half the size 1499 a prime (Bluestein's chirp-z form,
     # pv_kernels_bs.h), and ( 4096, 1024, 32768 ) (residue pairs, pv_kernels_big.h: a 2.95 GB PV) -- both direct sums until round 5
     for (hop, tag, Wd, dft) in ((128, "api_default_2048_128_4096", 2048, 4096), (512, "dft4096_hop512", 2048, 4096), (1024, "window4096_hop1024_dft4096", 4096, 4096),
-                                (256, "dft1024_window1024_hop256", 1024, 1024), (128, "dft512_window512_hop128", 512, 512),
+                                (256, "dft1024_window1024_hop256", 1024, 1024), (128, "dft512_window512_hop128", 512, 512), (64, "dft256_window256_hop64", 256, 256),
                                 # ... and dft 8192 / 16384: teams of four / eight wavefronts per chain (pv_kernels_team.h, round 6; before: the round-1 block kernels 0.92 ms, mixed radix 4.4 ms)
                                 (2048, "dft8192_window8192_hop2048", 8192, 8192), (1024, "dft16384_window4096_hop1024", 4096, 16384),
                                 (512, "dft2998_window2048_hop512_chirp_z", 2048, 2998), (1024, "dft32768_window4096_hop1024", 4096, 32768)):

@@ -583,7 +583,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 
 	AnalyzeParams p{};
 	p.audio = d_audio; p.out = reinterpret_cast<MF*>( d_out );
-	p.window = plan->d_window; p.tw = plan->d_tw; p.tw2 = plan->d_tw2;
+	p.window = plan->d_window; p.tw = plan->d_tw; p.tw2 = plan->d_tw2; p.dump = plan->d_dump;
 	p.n = n; p.F = n / hop + 1;                                   // AudioPV.cpp:17
 	p.num_channels = int( ch ); p.window_size = W; p.hop = hop;
 	// (hop: the dft 2048 kernel addresses a block's samples by 32-bit byte offsets from the block's first frame -- up to 8 chains of <= ~512 frames,

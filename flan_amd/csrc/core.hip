@@ -50,7 +50,7 @@ static float hann_host( float x )
 PlanRef::~PlanRef()
 	{
 	(void) hipFree( plan.d_window ); (void) hipFree( plan.d_tw ); (void) hipFree( plan.d_tw2 ); (void) hipFree( plan.d_tw1f ); (void) hipFree( plan.d_tw3f );
-	(void) hipFree( plan.d_bs_tw ); (void) hipFree( plan.d_bs_chirp ); (void) hipFree( plan.d_bs_bh ); (void) hipFree( plan.d_team );
+	(void) hipFree( plan.d_bs_tw ); (void) hipFree( plan.d_bs_chirp ); (void) hipFree( plan.d_bs_bh ); (void) hipFree( plan.d_team ); (void) hipFree( plan.d_dump );
 	(void) hipGetLastError();
 	}
 static std::mutex g_plan_mutex;
@@ -117,6 +117,7 @@ int get_plan( int window_size, int dft_size, std::shared_ptr<const PlanRef> * ou
 	FLANHIP_CHECK( hipMemcpy( plan.d_window, win.data(), sizeof( float ) * window_size, hipMemcpyHostToDevice ) );
 	FLANHIP_CHECK( hipMemcpy( plan.d_tw, tw.data(), sizeof( cf ) * C, hipMemcpyHostToDevice ) );
 	FLANHIP_CHECK( hipMemcpy( plan.d_tw2, tw2.data(), sizeof( cf ) * ( C + 1 ), hipMemcpyHostToDevice ) );
+	FLANHIP_CHECK( hipMalloc( &plan.d_dump, 1024 ) );
 	if( dft_size == 2048 || dft_size == 4096 )
 		{
 		const int R3 = C / 256;

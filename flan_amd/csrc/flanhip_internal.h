@@ -50,6 +50,7 @@ struct Plan
 	cf * d_bs_tw = nullptr;    // chirp-z sizes (bs_plan.h): [M] exp(-2 pi i j / M)
 	d2 * d_bs_chirp = nullptr; //                            [C] exp(+pi i n^2 / C), in double
 	d2 * d_bs_bh = nullptr;    //                            [M] the chirp's transform / M, in double
+	float * d_dump = nullptr;  // 1 KB nobody reads: the target of stores that must be issued but not land (AnalyzeParams::dump)
 	cf * d_team = nullptr;     // dft 8192 / 16384 (pv_kernels_team.h, R = dft / 2048): tw1 [240], tw3 [768], twj [(R-1) 512], tws [(R/2) 512], two [2 R], back to back
 	};
 // offsets (in cf) of the team kernels' tables inside Plan::d_team

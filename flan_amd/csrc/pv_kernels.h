@@ -45,6 +45,7 @@ struct AnalyzeParams
 	double * group_sums;      // optional (dft 2048 kernel, blocks = groups of 8 chains of one channel): [ch][groups][bins] folded sums of each group's chains
 	int groups_per_channel;
 	const int * cancel;       // optional: the launching thread's cancel word (core.hip); a wavefront that finds it set when it starts walks no chain
+	float * dump;             // 1 KB of device memory nobody reads (the plan's): where lanes whose MFs are not to be written store them instead of branching (pv_kernels_sub.h)
 	};
 
 // Is the launch being cancelled?  cancel_peek() issues ONE read past the caches (the word is fine-grained memory) -- at the top of a kernel, so

@@ -236,8 +236,15 @@ __global__ __launch_bounds__( 64 * WAVES, OCC ) void k_analyze_sub( AnalyzeParam
 		#pragma unroll
 		for( int q = H; q < E; ++q ) z[q] = load_pair( tn, q, next_fast );    // the upper half is in LDS now: its registers are free
 		const unsigned roff = unsigned( t - tb0 ) * unsigned( ( C + 1 ) * 8 );
+		// (a lane whose frame is not to be written -- the surplus iterations of a short last chain, a spare group -- stores into the dump area: the
+		// stores are never inside a branch, so that the wait for the next frame's samples can COUNT them; behind a branch it is a wait for all of them)
 		cf * rowk = reinterpret_cast<cf*>( rb + ( roff + l8 ) );
 		cf * rowm = reinterpret_cast<cf*>( rb + ( roff + unsigned( C * 8 ) - l8 ) );
+		if( !halo && !store_ok )
+			{
+			rowk = reinterpret_cast<cf*>( p.dump ) + ( lane & 15 );               // (everything the stores below reach lies inside the area's 128 slots)
+			rowm = reinterpret_cast<cf*>( p.dump ) + 112 + ( lane & 15 );
+			}
 		cf outk[halo ? 1 : H], outm[halo ? 1 : H];
 		#pragma unroll
 		for( int gq = 0; gq < H / NP; ++gq )
@@ -310,13 +317,15 @@ __global__ __launch_bounds__( 64 * WAVES, OCC ) void k_analyze_sub( AnalyzeParam
 		if constexpr( !halo )
 			{
 			// the MFs leave together at the frame's end, BEHIND every request for the next frame's samples (memory operations retire in order)
-			if( store_ok )
 				{
 				#pragma unroll
 				for( int q = 0; q < H; ++q )
 					{
 					if constexpr( ( ABL & 2 ) != 0 ) asm volatile( "" :: "v"( outk[q].x ), "v"( outk[q].y ), "v"( outm[q].x ), "v"( outm[q].y ) );
-					else if constexpr( ( ABL & 4 ) != 0 ) { rowk[LP * q] = outk[q]; rowm[-LP * q] = outm[q]; }
+					// 16 lanes per chain: a store instruction's four 128-byte segments all end in partial cache lines, and streamed past the L2 (non-temporal) every
+					// one of them is a partial write to memory -- plain stores let the L2 put the lines together (ablation, round 6: 0.216 -> 0.167 ms; at 32 lanes
+					// per chain the two forms measure the same)
+					else if constexpr( ( ABL & 4 ) != 0 || LP == 16 ) { rowk[LP * q] = outk[q]; rowm[-LP * q] = outm[q]; }
 					else
 						{
 						__builtin_nontemporal_store( outk[q], rowk + LP * q );

@@ -6,7 +6,7 @@
 namespace flanhip {
 
 #ifndef FLANHIP_SUB_OCC
-#define FLANHIP_SUB_OCC 4
+#define FLANHIP_SUB_OCC 3
 #endif
 #ifndef FLANHIP_SUB_NV
 #define FLANHIP_SUB_NV 4
@@ -28,7 +28,9 @@ bool sub_shape( int dft, int W, int hop )
 int sub_target_chains( int dft )
 	{
 	if( const int v = debug_options().target_chains ) { if( v > 0 ) return v; }
-	return cu_count() * 4 * kSubOcc * ( 64 / sub_lanes( dft ) );
+	// two wavefronts per SIMD's worth of chains, although the registers are capped for three (no spills at 168): measured (profiles/r06_sub_chains.txt) the
+	// longer chains win -- fewer halo frames, a shorter scan -- and a third resident wavefront buys nothing (the kernels are issue- and store-bound)
+	return cu_count() * 4 * 2 * ( 64 / sub_lanes( dft ) );
 	}
 
 template<int LOG2C, int LP, bool SUMS>

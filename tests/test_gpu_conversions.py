@@ -101,6 +101,21 @@ CASES = [
     ("dft1024_win999_hop333_ragged", 3, 12345, 999, 333, 1024, "noise"),
     ("dft512_win500_hop125", 2, 20000, 500, 125, 512, "noise"),
     ("dft512_hop100", 1, 20000, 512, 100, 512, "noise"),
+    # dft 512 / 256 on the grid of the kernels with several chains per wavefront (pv_kernels_sub.h, round 6: 32 / 16 lanes per chain): hops of 1, 2, 4, 8 steps of
+    # 64 / 32 samples, windows that are multiples of a step; short last chains, spare lane groups, one frame
+    ("dft256_ragged_3ch", 3, 12345, 256, 64, 256, "noise"),
+    ("dft256_hop32", 1, 20000, 256, 32, 256, "noise"),
+    ("dft256_hop128_win192", 2, 20000, 192, 128, 256, "noise"),
+    ("dft256_hop256", 1, 20000, 256, 256, 256, "noise"),
+    ("dft256_one_frame", 1, 50, 256, 64, 256, "noise"),
+    ("dft256_sine", 1, 48000, 256, 64, 256, "sine"),
+    ("dft256_zeros", 1, 5000, 256, 64, 256, "zeros"),
+    ("dft256_5ch_long", 5, 200000, 256, 64, 256, "noise"),
+    ("dft512_hop64", 1, 30000, 512, 64, 512, "noise"),
+    ("dft512_hop512_win512", 2, 40000, 512, 512, 512, "noise"),
+    ("dft512_7ch_ragged", 7, 54321, 512, 128, 512, "noise"),
+    ("dft512_one_frame", 1, 100, 512, 128, 512, "noise"),
+    ("dft512_zeros", 1, 5000, 512, 128, 512, "zeros"),
     ("dft8192", 1, 40000, 4096, 1024, 8192, "noise"),
     # dft 8192 / 16384 on the grid of the team kernels (pv_kernels_team.h, round 6: teams of 4 / 8 wavefronts, a 1024-point register transform each):
     # window = 4 / 8 / 16 steps of 512 (1024) samples, hops of 1 / 2 / 4 / 8 steps
@@ -208,7 +223,8 @@ def test_analysis_parity(fa, name, ch, n, W, hop, dft, kind):
     # (a pure tone through a short transform: the bins at 1e-6 of the peak hold rounding noise for a phase in the oracle too, f there is anybody's within
     # an analysis rate, and with few bins per frame their m^2 df^2 is what the weighted figure consists of -- 7.2e-4 Hz at dft 512 from the tuned and 7.7e-4
     # from the generic kernels alike, tools/dbg_sine.py)
-    assert wrms_f <= (1e-3 if kind == "sine" and dft == 512 else max(5e-4, 1e-7 * sr / hop))     # (the exception is dft 512's alone: 7.2e-4 .. 7.7e-4 measured)
+    # (the exception is dft 512's and dft 256's: 6.7e-4 .. 7.7e-4 and 6.3e-4 .. 6.5e-4 measured, from every kernel generation alike -- tools/dbg_sine_small.py)
+    assert wrms_f <= (1e-3 if kind == "sine" and dft in (256, 512) else max(5e-4, 1e-7 * sr / hop))
     if kind == "noise":
         assert turns <= max(3, got[..., 0].size // 100000)
         # share of f words that are bit for bit the oracle's.  What is left differs by one rounding of the transform (two FFTs in two operation
@@ -219,6 +235,10 @@ def test_analysis_parity(fa, name, ch, n, W, hop, dft, kind):
         # the chirp products and the split in double it measures 0.9795-0.981 at hop 256 where one transform gives 0.984 (all in fp32: 0.978)
         if chirp_z_size(dft):
             floor -= 0.006
+        # (hop = dft / 8 at the small sizes: twice the analysis rate per bin width of the hop = dft / 4 shapes the floors were taken on -- 0.927 at
+        # (256, 32, 256), from the kernels of pv_kernels_sub.h and from their predecessors alike: test_sub_kernels_agree_with_their_predecessors)
+        if dft <= 512 and hop * 8 <= dft:
+            floor -= 0.03
         assert same >= floor
 
 
@@ -285,7 +305,7 @@ def test_chain_length_invariance(fa):
     synthesis equal to rounding of the overlap partial sums"""
     x = O.noise(2, 60000, seed=8)
     sr = 48000.0
-    for (W, hop, dft) in ((2048, 512, 2048), (1024, 256, 1024), (512, 128, 512), (4096, 1024, 8192), (4096, 1024, 16384)):
+    for (W, hop, dft) in ((2048, 512, 2048), (1024, 256, 1024), (512, 128, 512), (256, 64, 256), (4096, 1024, 8192), (4096, 1024, 16384)):
         res = []
         for L in (4, 7, 64):
             with fa.debug_options(chain_len=L):
@@ -327,6 +347,30 @@ def test_team_kernels_long_chains(fa, W, hop, dft, n):
         assert np.abs(res[0][1].astype(np.float64) - res[k][1].astype(np.float64)).max() <= 2e-6
 
 
+@pytest.mark.parametrize("W,hop,dft", [(512, 128, 512), (512, 256, 512), (384, 64, 512), (256, 64, 256), (256, 32, 256), (192, 128, 256)])
+def test_sub_kernels_agree_with_their_predecessors(fa, W, hop, dft):
+    """dft 512 / 256 with several chains per wavefront (pv_kernels_sub.h) against the kernels they replaced (FLANHIP_DEBUG_NO_SUB: the one-wavefront kernels of
+    pv_kernels_v3.h at dft 512, the generic ones at dft 256): both within the oracle's tolerances, and of each other; chains of 40 frames so that the batches
+    of bin C/2 (one frame per lane of a chain's lane group) are crossed"""
+    x = O.noise(3, 100000, seed=5)
+    sr = 48000.0
+    ar = np.float32(sr) / np.float32(hop)
+    ref = O.analyze(x, sr, W, hop, dft)
+    out_ref, _ = O.synthesize(ref, sr, ar, W)
+    res = {}
+    for mode in (0, 1):
+        with fa.debug_options(no_sub=mode, chain_len=40):
+            pv = fa.analyze(x, sr, W, hop, dft)
+            out, _ = fa.synthesize(ref, sr, ar, W)
+        rel_m, wrms_f, same, turns = p1_metrics(pv, ref, sr / hop)
+        rms = float(np.sqrt(np.mean((out.astype(np.float64) - out_ref.astype(np.float64)) ** 2)))
+        print("\n[sub kernels off=%d (%d, %d, %d)] rel_m=%.3e wrms_df=%.3e same=%.4f  P2 rms=%.3e" % (mode, W, hop, dft, rel_m, wrms_f, same, rms))
+        assert rel_m <= 1e-5 and wrms_f <= 2e-3 and rms <= 1e-5 and same >= 0.92
+        res[mode] = (pv, out, same)
+    assert abs(res[0][2] - res[1][2]) <= 0.01                       # the share of f words that are bit for bit the oracle's: the same class of kernel
+    assert np.abs(res[0][1].astype(np.float64) - res[1][1].astype(np.float64)).max() <= 5e-6
+
+
 def test_errors(fa):
     import flan_amd
     x = np.zeros((1, 1000), np.float32)
@@ -339,7 +383,7 @@ def test_errors(fa):
     assert e.value.code == flan_amd.ERR_INVALID_ARG
 
 
-@pytest.mark.parametrize("dft,hop", [(2048, 512), (4096, 128), (2048, 1024), (2048, 256), (4096, 1024), (1024, 256), (1024, 1024), (512, 128), (512, 256), (8192, 512), (8192, 1024), (16384, 1024)])
+@pytest.mark.parametrize("dft,hop", [(2048, 512), (4096, 128), (2048, 1024), (2048, 256), (4096, 1024), (1024, 256), (1024, 1024), (512, 128), (512, 256), (256, 64), (256, 32), (8192, 512), (8192, 1024), (16384, 1024)])
 def test_generic_and_tuned_kernels_agree(fa, dft, hop):
     """dft 512 ... 4096 have tuned kernels (pv_kernels_v2.h, _v3.h, _eo.h); the force_generic hook routes the same call through the
     generic ones (pv_kernels.h).  Both must sit within the parity tolerances of the oracle and of each other."""
@@ -370,7 +414,7 @@ def test_fused_round_trip_equals_unfused(fa):
     sr = 48000.0
     # dft 8192 (and 4096 through the generic kernels): block-wide teams walk the chains; they leave the sums like every other analysis kernel
     for (ch, n, W, hop, dft) in [(2, 70000, 2048, 512, 2048), (1, 30000, 2048, 128, 4096), (2, 20000, 1024, 256, 1024), (1, 9000, 400, 100, 512), (2, 40000, 512, 128, 512), (3, 90000, 1024, 512, 1024),
-                                 (1, 40000, 4096, 1024, 8192), (2, 400000, 8192, 2048, 8192), (3, 300000, 4096, 1024, 16384), (1, 100000, 4000, 1000, 8192), (2, 30000, 2048, 300, 4096), (3, 500000, 2000, 500, 4096), (2, 200000, 4000, 1000, 4096),
+                                 (3, 300000, 256, 64, 256), (2, 100000, 512, 64, 512), (1, 40000, 4096, 1024, 8192), (2, 400000, 8192, 2048, 8192), (3, 300000, 4096, 1024, 16384), (1, 100000, 4000, 1000, 8192), (2, 30000, 2048, 300, 4096), (3, 500000, 2000, 500, 4096), (2, 200000, 4000, 1000, 4096),
                                  (3, 500000, 1000, 250, 1024), (2, 30000, 1024, 300, 1024), (4, 300000, 500, 125, 512), (1, 20000, 512, 100, 512),
                                  (2, 300000, 2048, 300, 2048), (3, 200000, 2000, 500, 2048), (1, 40000, 1800, 450, 2048), (3, 700000, 3000, 750, 4096), (2, 90000, 4094, 441, 4096),
                                  # the mixed-radix kernels: sums kept by the analysis kernel (ping-pong sizes, with and without the large odd radices) or by
