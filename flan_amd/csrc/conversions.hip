@@ -22,8 +22,9 @@ namespace flanhip {
 
 // dft 2048 has ONE kernel generation (pv_kernels_v2.h); flanhip_debug_option's ANA / SYN_VARIANT select the phase-ablated instantiations of
 // diagnostic builds (FLANHIP_ABLATIONS: 101 ... for the analysis, 102 ... for the synthesis) and, for the synthesis, 2 = behind the scan
-// kernel even where it could work out its own carries.  dft 4096 keeps its round-1 kernels as the A/B predecessor (ANA4096_OLD / SYN4096_OLD)
-// -- they are also what windows that are no multiple of 256 run.  All per calling thread (core.hip: debug_options).
+// kernel even where it could work out its own carries.  The A/B predecessor of EVERY tuned size is the generic kernel pair of pv_kernels.h
+// (FORCE_GENERIC; at dft 4096 also per kernel: ANA4096_OLD / SYN4096_OLD) -- round 1's own tuned kernels for dft 2048 / 4096 (k_analyze_fast,
+// k_synthesize_fast) and the spare configurations of the dft 1024 / 512 kernels were retired in round 6.  All per calling thread (core.hip: debug_options).
 
 static constexpr size_t kMaxLds = 160 * 1024;   // gfx950: 160 KiB LDS per CU, one workgroup may take all of it
 
@@ -193,18 +194,14 @@ static int run_analyze( const AnalyzeParams & p, hipStream_t s )
 	}
 
 // Tuned kernels.  dft 2048: 16 complex points per lane, <= 256 VGPRs -> 2 wavefronts per SIMD: one 8-wave block per CU
-// (LDS 94 KB; 164 KB with the fused sums), 2048 resident chains.
-// dft 4096: 32 complex points per lane need ~400 registers: 4-wave blocks, ONE wavefront per SIMD, so that the compiler may use
-// the 256 AGPRs as spill space instead of scratch memory (6-wave blocks at 256 VGPRs spilled 400-850 B per lane to scratch and
-// ran synthesis 3.3x slower); 1024 resident chains.
-static constexpr int kSynWaves10 = 8, kWaves11 = 4;
+// (LDS 94 KB; 164 KB with the fused sums), 2048 resident chains.  dft 4096: teams of two such wavefronts (pv_kernels_eo.h), 1024 resident chains.
 // dft 1024 / 512 (pv_kernels_v3.h): { index, wavefronts per block = chains per group, wavefronts per SIMD the registers are capped for, bins per vector
-// stream, frames the sample requests run ahead }.  Entry 0 is the product (measured, profiles/r05_v3_variants.txt: dft 1024 is as fast at two, three and
-// four wavefronts per SIMD in the analysis and 10 % faster at four in the synthesis; dft 512 is bound by the latency of its four passes' LDS round
-// trips and wants wavefronts, but spills under a 128-register cap); the others are the A/B partners behind
-// flanhip_debug_option( FLANHIP_DEBUG_ANA_VARIANT, index ) -- both kernels of a pair follow it: the group size is part of the workspace layout.
-#define FLANHIP_V3_CFGS_9( X ) X( 0, 8, 4, 4, 1 ) X( 1, 4, 3, 4, 1 ) X( 2, 8, 2, 8, 1 )
-#define FLANHIP_V3_CFGS_8( X ) X( 0, 4, 3, 4, 1 ) X( 1, 8, 4, 4, 1 ) X( 2, 8, 2, 4, 1 )
+// stream, frames the sample requests run ahead }.  One configuration per size since round 6 (the occupancy experiment of round 5 ran three: dft 1024 is as
+// fast at two, three and four wavefronts per SIMD in the analysis and 10 % faster at four in the synthesis -- profiles/r05_v3_variants.txt; its partners
+// ( 4, 3, 4 ), ( 8, 2, 8 ) at dft 1024 and ( 8, 4, 4 ), ( 8, 2, 4 ) at dft 512 are in the history, not in the library).  dft 512 on the grid of
+// pv_kernels_sub.h runs those kernels; this configuration serves its other shapes and FLANHIP_DEBUG_NO_SUB.
+#define FLANHIP_V3_CFGS_9( X ) X( 0, 8, 4, 4, 1 )
+#define FLANHIP_V3_CFGS_8( X ) X( 0, 4, 3, 4, 1 )
 struct V3Cfg { int waves, occ, nv; };
 static V3Cfg v3_cfg( int dft )
 	{
@@ -371,49 +368,22 @@ static int run_analyze_eo_team( const AnalyzeParams & p, const FastTables & tb, 
 	return FLANHIP_OK;
 	}
 
-template<int LOG2C, int WAVES, bool SUMS>
-static int run_analyze_fast( const AnalyzeParams & p, const FastTables & tb, hipStream_t s )
-	{
-	const size_t lds = FastLds<LOG2C>::bytes( WAVES, SUMS );
-	static_assert( FastLds<LOG2C>::bytes( WAVES, SUMS ) <= kMaxLds, "LDS budget" );
-	auto kern = k_analyze_fast<LOG2C, WAVES, SUMS>;
-	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
-	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;
-	const int64_t blocks = ( chains + WAVES - 1 ) / WAVES;
-	FLANHIP_REQUIRE( blocks < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
-	hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( 64 * WAVES ), lds, s, p, tb );
-	FLANHIP_CHECK( hipGetLastError() );
-	return FLANHIP_OK;
-	}
-
 // Which tuned synthesis kernel serves this shape?  0: none (generic kernels); 1: overlap-add accumulator in registers (hop 128 /
 // 256 / 512 / 1024, window a multiple of 128); 2: accumulator as an LDS ring (any hop <= window, any window <= dft).
-// dft 4096 with the LDS ring: the wavefronts (chains) per block that fit beside the tables -- four up to a window of ~2500 samples, three beyond
-static int ring_waves11( int W ) { return FastLds<11>::bytes( 4 ) + FastLds<11>::ring_bytes( 4, W ) <= kMaxLds ? 4 : 3; }
-// ... and with the team kernels' ring variant (round 5: k_synthesize_eo_team<.., -1, ..>): chains (teams) per block -- four (windows above 2048: since the fourth ring took the window table's place in LDS; three before)
-static int ring_teams11( int W ) { return debug_options().syn11_old ? ring_waves11( W ) : 4; }   // (windows above 2048: the fourth ring in the window table's place, pv_kernels_eo.h WINGLOB)
 static int synth_fast_kind( int dft, int W, int hop )
 	{
 	if( !( dft == 2048 || dft == 4096 || v3_size( dft ) ) || hop > W || hop < 1 || force_generic() ) return 0;
 	const int hq = hop / 128;
 	if( v3_size( dft ) ) return ( hop % 128 == 0 && ( hq == 1 || hq == 2 || hq == 4 || ( hq == 8 && dft == 1024 ) ) && W % 128 == 0 ) ? 1 : 2;   // (2: k_synthesize_v3's LDS-ring form, round 5)
+	if( dft == 4096 )
+		{
+		// the team kernels (pv_kernels_eo.h): accumulator in registers on the grid (hop 128 / 256 / 512 / 1024, windows that are multiples of 256), as an LDS ring
+		// otherwise; FLANHIP_DEBUG_SYN4096_OLD: the generic kernels (pv_kernels.h), the A/B predecessor
+		if( debug_options().syn11_old ) return 0;
+		return ( W % 256 == 0 && ( hop == 128 || hop == 256 || hop == 512 || hop == 1024 ) ) ? 1 : 2;
+		}
 	if( hop % 128 == 0 && ( hq == 1 || hq == 2 || hq == 4 || hq == 8 ) && W % 128 == 0 ) return 1;
 	return 2;
-	}
-
-template<int LOG2C, int WAVES, int HOPQ>
-static int run_synth_fast( const SynthParams & p, const FastTables & tb, hipStream_t s )
-	{
-	const size_t lds = FastLds<LOG2C>::bytes( WAVES ) + ( HOPQ == 0 ? FastLds<LOG2C>::ring_bytes( WAVES, p.window_size ) : 0 );
-	static_assert( FastLds<LOG2C>::bytes( WAVES ) <= kMaxLds, "LDS budget" );
-	FLANHIP_REQUIRE( lds <= kMaxLds, FLANHIP_ERR_UNSUPPORTED, "window too long for the LDS ring" );
-	auto kern = k_synthesize_fast<LOG2C, WAVES, HOPQ>;
-	FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
-	const int64_t chains = int64_t( p.chains_per_channel ) * p.num_channels;
-	const int64_t blocks = ( chains + WAVES - 1 ) / WAVES;
-	hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( 64 * WAVES ), lds, s, p, tb );
-	FLANHIP_CHECK( hipGetLastError() );
-	return FLANHIP_OK;
 	}
 
 template<int WAVES, int HOPQ, int ABL = 0>
@@ -465,9 +435,10 @@ static int run_synth_eo_team_ring( const SynthParams & p, const FastTables & tb,
 template<int LOG2C>
 static int run_synth_fast_hop( const SynthParams & p, const FastTables & tb, hipStream_t s )
 	{
-	if( LOG2C == 10 && synth_fast_kind( 2 << LOG2C, p.window_size, p.hop ) == 1 )
+	const int kind = synth_fast_kind( 2 << LOG2C, p.window_size, p.hop );
+	if constexpr( LOG2C == 10 )
 		{
-		// v2: the register-accumulator hops of dft 2048
+		if( kind == 2 ) return run_synth_v2<8, 0>( p, tb, s );                     // any hop <= window, any window: the accumulator as an LDS ring (round 5)
 #ifdef FLANHIP_ABLATIONS
 		if( debug_options().syn_variant == 102 && p.hop == 512 ) return run_synth_v2<8, 4, 2>( p, tb, s );
 		if( debug_options().syn_variant == 104 && p.hop == 512 ) return run_synth_v2<8, 4, 4>( p, tb, s );
@@ -482,44 +453,23 @@ static int run_synth_fast_hop( const SynthParams & p, const FastTables & tb, hip
 			case 4: return run_synth_v2<8, 4>( p, tb, s );
 			case 8: return run_synth_v2<8, 8>( p, tb, s );
 			}
+		return FLANHIP_ERR_UNSUPPORTED;
 		}
-	if( LOG2C == 11 && !debug_options().syn11_old && p.window_size <= 2048 && synth_fast_kind( 2 << LOG2C, p.window_size, p.hop ) == 1 )
+	else
 		{
-		// dft 4096, window <= 2048, hop 128 / 256 / 512 / 1024: teams of two wavefronts, two 1024-point transforms per frame (pv_kernels_eo.h)
-		if( p.hop == 128 && p.window_size % 256 == 0 ) return run_synth_eo_team<4, 0>( p, tb, s );
-		if( p.hop % 256 == 0 && p.window_size % 256 == 0 ) switch( p.hop / 256 )
-			{
-			case 1: return run_synth_eo_team<4, 1>( p, tb, s );
-			case 2: return run_synth_eo_team<4, 2>( p, tb, s );
-			case 4: return run_synth_eo_team<4, 4>( p, tb, s );
-			}
-		}
-	if( LOG2C == 11 && !debug_options().syn11_old && p.window_size > 2048 && p.window_size % 256 == 0 && synth_fast_kind( 2 << LOG2C, p.window_size, p.hop ) == 1 )
-		{
-		// dft 4096 with windows above 2048 (window = dft is the plain STFT call): the same teams with full-length transforms, one buffer set
-		// (pv_kernels_eo.h: WBIG)
+		// dft 4096: teams of two wavefronts, two 1024-point transforms per frame (pv_kernels_eo.h); windows above 2048 (window = dft is the plain STFT
+		// call) the same teams with full-length transforms and one buffer set (WBIG)
+		const bool wbig = p.window_size > 2048;
+		if( kind == 2 ) return wbig ? run_synth_eo_team_ring<4, true>( p, tb, s ) : run_synth_eo_team_ring<4, false>( p, tb, s );
 		switch( p.hop )
 			{
-			case 128:  return run_synth_eo_team<4, 0, true>( p, tb, s );
-			case 256:  return run_synth_eo_team<4, 1, true>( p, tb, s );
-			case 512:  return run_synth_eo_team<4, 2, true>( p, tb, s );
-			case 1024: return run_synth_eo_team<4, 4, true>( p, tb, s );
+			case 128:  return wbig ? run_synth_eo_team<4, 0, true>( p, tb, s ) : run_synth_eo_team<4, 0>( p, tb, s );
+			case 256:  return wbig ? run_synth_eo_team<4, 1, true>( p, tb, s ) : run_synth_eo_team<4, 1>( p, tb, s );
+			case 512:  return wbig ? run_synth_eo_team<4, 2, true>( p, tb, s ) : run_synth_eo_team<4, 2>( p, tb, s );
+			case 1024: return wbig ? run_synth_eo_team<4, 4, true>( p, tb, s ) : run_synth_eo_team<4, 4>( p, tb, s );
 			}
+		return FLANHIP_ERR_UNSUPPORTED;
 		}
-	if( synth_fast_kind( 2 << LOG2C, p.window_size, p.hop ) == 2 )                // any other hop <= window: ring accumulator in LDS
-		{
-		if constexpr( LOG2C == 10 ) return debug_options().syn_variant == 3 ? run_synth_fast<LOG2C, kSynWaves10, 0>( p, tb, s ) : run_synth_v2<8, 0>( p, tb, s );   // (round 5: k_synthesize_v2's ring form; SYN_VARIANT 3: the round-1 kernel, A/B)
-		else if( !debug_options().syn11_old ) return p.window_size <= 2048 ? run_synth_eo_team_ring<4, false>( p, tb, s ) : run_synth_eo_team_ring<4, true>( p, tb, s );
-		else return ring_waves11( p.window_size ) == 4 ? run_synth_fast<LOG2C, 4, 0>( p, tb, s ) : run_synth_fast<LOG2C, 3, 0>( p, tb, s );
-		}
-	if constexpr( LOG2C == 11 ) switch( p.hop / 128 )                              // (dft 2048's register-accumulator hops are all v2's, above)
-		{
-		case 1: return run_synth_fast<LOG2C, kWaves11, 1>( p, tb, s );
-		case 2: return run_synth_fast<LOG2C, kWaves11, 2>( p, tb, s );
-		case 4: return run_synth_fast<LOG2C, kWaves11, 4>( p, tb, s );
-		case 8: return run_synth_fast<LOG2C, kWaves11, 8>( p, tb, s );
-		}
-	return FLANHIP_ERR_UNSUPPORTED;
 	}
 
 static bool synth_fast_ok( int dft, int W, int hop ) { return synth_fast_kind( dft, W, hop ) != 0; }
@@ -532,10 +482,10 @@ static int self_carry_group( int dft, int W, int hop, int chains_per_channel )
 	const int kind = synth_fast_kind( dft, W, hop );
 	int g = 0;
 	// the LDS-ring form of the dft 4096 team synthesis (any hop, any window up to 2048: four teams per block like the analysis) takes the totals too
-	if( kind == 2 ) g = ( dft == 4096 && !debug_options().syn11_old && !debug_options().ana11_old ) ? 4 : ( v3_size( dft ) || ( dft == 2048 && debug_options().syn_variant != 3 ) ) ? group_size_of( dft ) : 0;
+	if( kind == 2 ) g = dft == 4096 ? ( debug_options().ana11_old ? 0 : 4 ) : group_size_of( dft );
 	else if( kind != 1 ) return 0;
 	else if( dft == 2048 || v3_size( dft ) ) g = group_size_of( dft );
-	else if( dft == 4096 && W % 256 == 0 && ( hop == 128 || hop % 256 == 0 ) && !debug_options().syn11_old && !debug_options().ana11_old ) g = 4;   // (windows above 2048: the WBIG variants)
+	else if( dft == 4096 && !debug_options().ana11_old ) g = 4;                   // (windows above 2048: the WBIG variants)
 	// any number of groups (their carries come from a scan of their own); with few chains per channel the scan over the chains themselves is as
 	// short and the groups' epilogue and prologue are pure cost (a 5 s mono file: 118 chains, 68 against 73 us per round trip)
 	if( chains_per_channel < 128 ) g = 0;
@@ -588,7 +538,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	p.num_channels = int( ch ); p.window_size = W; p.hop = hop;
 	// (hop: the dft 2048 kernel addresses a block's samples by 32-bit byte offsets from the block's first frame -- up to 8 chains of <= ~512 frames,
 	// env overrides aside -- and the generic kernels serve the hops that would not fit: nothing anybody analyses with)
-	const bool fast = ( dft == 2048 || dft == 4096 || v3_size( dft ) ) && n >= 2 && n < ( int64_t( 1 ) << 31 ) - 8192 && hop <= 65536 && !force_generic();
+	const bool fast = ( dft == 2048 || ( dft == 4096 && !debug_options().ana11_old ) || v3_size( dft ) ) && n >= 2 && n < ( int64_t( 1 ) << 31 ) - 8192 && hop <= 65536 && !force_generic();
 	int target_chains = team ? team_target_chains( dft ) : sub ? sub_target_chains( dft ) : any ? any_target_chains( dft / 2 + 1 ) : mr ? mr_target_chains( dft, W ) : bs ? bs_target_chains( dft, W ) : big ? big_target_chains() : fast ? fast_target_chains( dft, false ) : generic_target_chains( dft );
 	p.L = choose_chain_length( ch, p.F, any ? 7 : 1, target_chains );
 	p.chains_per_channel = int( ( p.F + p.L - 1 ) / p.L );
@@ -600,7 +550,6 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	p.sums = nullptr; p.nan_out = nullptr; p.nan_epoch = 0;
 	p.cancel = thread_cancel_word( s );                                           // kernels stop starting chains when the thread's wait raises it (core.hip)
 	// windows above 2048: the WBIG team kernels (pv_kernels_eo.h)
-	const bool team_big = fast && dft == 4096 && W > 2048 && !debug_options().ana11_old;
 	const bool kernel_sums = !any && !big && ( !mr || mr_pingpong( mr_plan.C ) ) && ( !bs || bs_pingpong( bs_plan.M ) );   // every power-of-two analysis kernel keeps the sums, and the mixed-radix one where its LDS has room; for the rest the pre-pass kernel runs on the analysis' behalf
 	SynthLayout fused_lay{};
 	if( d_fused_ws )
@@ -695,18 +644,14 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 		FastTables tb{ plan->d_tw1f, plan->d_tw3f, plan->d_tw2 };
 		if( v3_size( dft ) ) return p.sums ? run_analyze_v3_cfg<true>( dft, p, s ) : run_analyze_v3_cfg<false>( dft, p, s );
 		if( dft == 2048 ) return p.sums ? run_analyze_v2_variant<true>( debug_options().ana_variant, p, tb, s ) : run_analyze_v2_variant<false>( debug_options().ana_variant, p, tb, s );
-		if( dft == 4096 && W <= 2048 && !debug_options().ana11_old )
+		if( W <= 2048 )
 			{
 			// teams of two wavefronts, two E / O buffer sets, one meeting per frame (0.27 ms for 8 ch x 60 s with the fused round trip's chain sums,
 			// 0.28 without; one set and two meetings: +7 %; the round-1 kernel: 0.44)
 			return p.sums ? run_analyze_eo_team<4, true, 2, true>( p, tb, s ) : run_analyze_eo_team<4, false, 2, true>( p, tb, s );
 			}
-		if( team_big )
-			{
-			// windows up to the whole transform: the same decomposition with full-length E / O inputs, one buffer set (pv_kernels_eo.h: WBIG)
-			return p.sums ? run_analyze_eo_team<4, true, 2, false, true>( p, tb, s ) : run_analyze_eo_team<4, false, 2, false, true>( p, tb, s );
-			}
-		return p.sums ? run_analyze_fast<11, kWaves11, true>( p, tb, s ) : run_analyze_fast<11, kWaves11, false>( p, tb, s );
+		// windows up to the whole transform: the same decomposition with full-length E / O inputs, one buffer set (pv_kernels_eo.h: WBIG)
+		return p.sums ? run_analyze_eo_team<4, true, 2, false, true>( p, tb, s ) : run_analyze_eo_team<4, false, 2, false, true>( p, tb, s );
 		}
 
 	int rc = FLANHIP_ERR_UNSUPPORTED;
@@ -746,7 +691,7 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	o->head_len = o->any ? 0 : std::max( W - o->hop, 0 );        // (the direct-sum path overlap-adds whole frames from its own scratch: no chain heads)
 	const int overlap = ( W + o->hop - 1 ) / o->hop;              // frames covering one output sample
 	const int kind = ( o->any || o->big || sub ) ? 0 : synth_fast_kind( o->dft, W, o->hop );
-	const int slots = team ? team_target_chains( o->dft ) : sub ? sub_target_chains( o->dft ) : o->any ? any_target_chains( bins ) : mr ? mr_target_chains( o->dft, W ) : bs ? bs_target_chains( o->dft, W ) : o->big ? big_target_chains() : kind == 0 ? generic_target_chains( o->dft ) : ( kind == 2 && o->dft == 4096 ) ? cu_count() * ring_teams11( W ) : fast_target_chains( o->dft, true );
+	const int slots = team ? team_target_chains( o->dft ) : sub ? sub_target_chains( o->dft ) : o->any ? any_target_chains( bins ) : mr ? mr_target_chains( o->dft, W ) : bs ? bs_target_chains( o->dft, W ) : o->big ? big_target_chains() : kind == 0 ? generic_target_chains( o->dft ) : fast_target_chains( o->dft, true );
 	o->L = choose_chain_length( ch, F, o->any ? 1 : std::max( overlap - 1, 1 ), slots );
 	o->chains_per_channel = int( ( F + o->L - 1 ) / o->L );
 	const int64_t chains = int64_t( o->chains_per_channel ) * ch;

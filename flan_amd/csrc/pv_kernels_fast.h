@@ -1,4 +1,6 @@
-// pv_kernels_fast.h -- tuned analysis / synthesis kernels for dft 2048 and 4096 (C = 1024 / 2048 complex points).
+// pv_kernels_fast.h -- the register transform (fft_fast) and the pre-pass kernels shared by the tuned conversion kernels.  (Round 1's own kernels for
+// dft 2048 / 4096, k_analyze_fast / k_synthesize_fast, lived here until round 6: every shape they served has a successor -- pv_kernels_v2.h, pv_kernels_eo.h --
+// and the generic kernels of pv_kernels.h are the A/B predecessor of every tuned size.)  What follows describes the design they introduced:
 //
 // Same chain decomposition as pv_kernels.h (one wavefront walks L consecutive frames of one channel, state in
 // registers), restructured around what limits the generic kernels on gfx950:
@@ -129,521 +131,6 @@ __device__ __forceinline__ void fft_fast( cf ( &z )[( 1 << LOG2C ) / 64], cf * b
 			}
 		}
 	wave_sync();
-	}
-
-__device__ __forceinline__ void load_tables( cf * s, const FastTables & t, const float * window, int W, float scale, int C, int tid, int nthreads )
-	{
-	const int n1 = fast_tw1_len(), n3 = fast_tw3_len( C );
-	for( int i = tid; i < n1; i += nthreads ) s[i] = t.tw1[i];
-	for( int i = tid; i < n3; i += nthreads ) s[n1 + i] = t.tw3[i];
-	for( int i = tid; i < C; i += nthreads ) s[n1 + n3 + i] = t.w2[i];
-	float * win = reinterpret_cast<float*>( s + n1 + n3 + C );
-	for( int i = tid; i < 2 * C; i += nthreads ) win[i] = ( i < W ) ? window[i] * scale : 0.0f;
-	}
-
-// =================================================================================================================
-// Audio::convert_to_PV (Conversions/AudioPV.cpp:12-78)
-// =================================================================================================================
-template<int LOG2C, int WAVES, bool SUMS>
-__global__ __launch_bounds__( 64 * WAVES ) void k_analyze_fast( AnalyzeParams p, FastTables tb )
-	{
-	using L = FastLds<LOG2C>;
-	constexpr int C = 1 << LOG2C;
-	constexpr int E = C / 64;
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	cf * s = reinterpret_cast<cf*>( smem );
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	load_tables( s, tb, p.window, p.window_size, 1.0f, C, tid, 64 * WAVES );
-	__syncthreads();
-	const cf * s_tw1 = s + L::TW1;
-	const cf * s_tw3 = s + L::TW3;
-	const cf * s_w2 = s + L::W2 + lane;
-	const cf * s_win = s + L::WIN + lane;
-	cf * buf = s + L::BUF + wave * L::BUF_LEN;
-
-	const int64_t chain = int64_t( blockIdx.x ) * WAVES + wave;
-	if( chain >= int64_t( p.chains_per_channel ) * p.num_channels || cancel_seen( cancel_peek( p.cancel ) ) ) return;   // (cancelled: core.hip)
-	const int channel = int( chain / p.chains_per_channel );
-	const int64_t t0 = int64_t( chain % p.chains_per_channel ) * p.L;
-	const int64_t t1 = min( t0 + int64_t( p.L ), p.F );
-	const float * x = p.audio + int64_t( channel ) * p.n;
-	const int W = p.window_size, hop = p.hop;
-	const bool w_whole = ( W & 127 ) == 0;
-	const bool use_wrapping = p.analysis_rate < p.sample_rate;                // phase_vocoder.cpp:37
-	const int padl = lane + ( lane >> 4 );
-	const cf * mirror = buf + ( C * 17 ) / 16 - ( lane + ( ( lane + 15 ) >> 4 ) );   // PAD( M - lane ) = 17 M / 16 + this, M % 64 == 0
-	using VB = v8f;                                                           // bins evaluated together (pv_math.h)
-	constexpr int NV = 8;
-
-	// per-lane constants: bin frequency (PVBuffer.cpp:443-446), expected phase advance (phase_vocoder.cpp:47)
-	// (the division by dft, a power of two, is exactly a multiplication; bin_frequency is recomputed per use, 2 instructions)
-	const float rdft = 1.0f / float( 2 * C );
-	auto bin_frequency = [&]( int q ) { return float( ( q < E ) ? lane + 64 * q : C ) * p.sample_rate * rdft; };
-	// ... and so is the expected phase advance (7 instructions) -- registers are the scarce resource of this kernel
-	auto expected_advance = [&]( int q ) { return div_c( bin_frequency( q ), p.ar_div ) * FLANHIP_PI2_F; };
-	float prev[E + 1];
-	#pragma unroll
-	for( int q = 0; q <= E; ++q ) prev[q] = 0.0f;                             // AudioPV.cpp:44
-
-	// raw samples of frame t (AudioPV.cpp:52-62) in the natural register layout raw[q] = ( x[2i], x[2i+1] ), i = lane + 64 q.
-	// Issued one frame ahead of their use so that the HBM/L2 latency hides under the previous frame's per-bin math.
-	// Always exactly E 8-byte loads per lane and no load inside a branch: the number of outstanding memory operations is
-	// then static, so the compiler waits with a counted s_waitcnt for these loads only instead of draining the MF
-	// stores issued after them.  Frames that stick out of the signal read from clamped addresses and are patched by
-	// fix_raw() (pure register arithmetic under a wave-uniform branch).
-	struct __attribute__(( packed, aligned( 4 ) )) f2u { float x, y; };      // pair at any 4-byte aligned address
-	// (32-bit sample indices: the host routes channels of 2^31 samples or more to the generic kernel)
-	const int n32 = int( p.n );
-	auto load_raw = [&]( int64_t t, cf ( &raw )[E] )
-		{
-		const int start = int( int64_t( hop ) * t - W / 2 );
-		#pragma unroll
-		for( int q = 0; q < E; ++q )
-			{
-			const int a0c = min( max( start + 2 * ( lane + 64 * q ), 0 ), n32 - 2 );   // n >= 2 on this path (host check)
-			const f2u v = *reinterpret_cast<const f2u*>( x + a0c );
-			raw[q] = mk( v.x, v.y );
-			}
-		};
-	auto frame_is_interior = [&]( int64_t t )
-		{
-		const int64_t start = int64_t( hop ) * t - W / 2;
-		return w_whole && start >= 0 && start + 2 * int64_t( C ) <= p.n;
-		};
-	auto fix_raw = [&]( int64_t t, cf ( &raw )[E] )
-		{
-		const int start = int( int64_t( hop ) * t - W / 2 );
-		#pragma unroll
-		for( int q = 0; q < E; ++q )
-			{
-			const int s0 = 2 * ( lane + 64 * q );
-			const int a0 = start + s0;
-			const int d = a0 - min( max( a0, 0 ), n32 - 2 );                     // 0: pair loaded as is; -1 / +1: shifted by one; else outside
-			float v0 = ( d == 0 ) ? raw[q].x : ( d == 1 ? raw[q].y : 0.0f );
-			float v1 = ( d == 0 ) ? raw[q].y : ( d == -1 ? raw[q].x : 0.0f );
-			if( s0 >= W ) v0 = 0.0f;                                             // AudioPV.cpp:65 (also keeps Inf * 0 out)
-			if( s0 + 1 >= W ) v1 = 0.0f;
-			raw[q] = mk( v0, v1 );
-			}
-		};
-	// window (AudioPV.cpp:60; the table is zero beyond W, :65), transform, and leave Z both in z[] and (natural order) in
-	// buf[] for the mirror reads
-	auto transform_frame = [&]( int64_t t, cf ( &z )[E] )
-		{
-		if( !frame_is_interior( t ) ) fix_raw( t, z );
-		#pragma unroll
-		for( int q = 0; q < E; ++q )
-			{
-			const cf w = s_win[64 * q];
-			z[q] = mk( z[q].x * w.x, z[q].y * w.y );
-			}
-		fft_fast<LOG2C>( z, buf, s_tw1, s_tw3, lane );
-		#pragma unroll
-		for( int q = 0; q < E; ++q ) buf[padl + 68 * q] = z[q];
-		wave_sync();
-		};
-
-	// bin k = lane + 64 q of the real transform from Z[k] (own register) and Z[C-k] (mirror lane, through LDS)
-	auto split_bin = [&]( const cf ( &z )[E], int q, cf z0, float & re, float & im )
-		{
-		const cf zk = z[q];
-		const cf zm = mirror[-68 * q];                                    // k = 0 reads a junk slot, overridden below
-		const cf w = s_w2[64 * q];
-		const float ax = 0.5f * ( zk.x + zm.x ), ay = 0.5f * ( zk.y - zm.y );
-		const float dx = zk.x - zm.x, dy = zk.y + zm.y;
-		re = ax + 0.5f * __builtin_fmaf( w.x, dy, w.y * dx );
-		im = ay - 0.5f * __builtin_fmaf( w.x, dx, -( w.y * dy ) );
-		if( q == 0 ) { re = ( lane == 0 ) ? z0.x + z0.y : re; im = ( lane == 0 ) ? 0.0f : im; }
-		};
-
-	// fused round trip: per-chain sums of the phase increments convert_to_audio will integrate (its pre-pass, done here
-	// while f is in a register), and a NaN/Inf flag for PVBuffer::is_nan_or_inf
-	// The sums live in LDS (double [E+1][64] per wave): 34 more VGPRs would push the kernel into scratch spills, whose
-	// reloads count as memory operations and defeat the counted waits above.
-	// dft 4096 (one wavefront per SIMD, up to 512 registers with the AGPRs as spill space, and no LDS to spare): the sums are a
-	// register array there.
-	constexpr bool SUMS_REG = SUMS && LOG2C >= 11;
-	double * s_sum = reinterpret_cast<double*>( s + L::BUF + WAVES * L::BUF_LEN ) + wave * L::SUM_LEN + lane;
-	double r_sum[SUMS_REG ? E + 1 : 1];
-	auto sum_of = [&]( int q ) -> double & { if constexpr( SUMS_REG ) return r_sum[q]; else return s_sum[64 * q]; };
-	if constexpr( SUMS )
-		{
-		#pragma unroll
-		for( int q = 0; q <= E; ++q ) sum_of( q ) = 0.0;
-		}
-	bool bad = false;
-
-	cf z[E], zn[E];
-	if( t0 > 0 )
-		{
-		// halo: only the phases of frame t0-1 are needed (phase_vocoder.cpp:45 leaves them in phase_buffer)
-		load_raw( t0 - 1, z );
-		transform_frame( t0 - 1, z );
-		const cf z0 = buf[0];
-		load_raw( t0, zn );
-		#pragma unroll
-		for( int q0 = 0; q0 < E; q0 += NV )
-			{
-			VB re, im;
-			#pragma unroll
-			for( int i = 0; i < NV; ++i ) { float r, m; split_bin( z, q0 + i, z0, r, m ); re[i] = r; im[i] = m; }
-			const VB ph2 = atan2_fast_v( im, re );
-			#pragma unroll
-			for( int i = 0; i < NV; ++i ) prev[q0 + i] = ph2[i];
-			}
-		prev[E] = atan2_fast( 0.0f, z0.x - z0.y );
-		wave_sync();
-		}
-	else load_raw( t0, zn );
-
-	for( int64_t t = t0; t < t1; ++t )
-		{
-		#pragma unroll
-		for( int q = 0; q < E; ++q ) z[q] = zn[q];
-		transform_frame( t, z );
-		const cf z0 = buf[0];
-		load_raw( min( t + 1, t1 - 1 ), zn );                                  // prefetch (the last frame re-reads itself): in flight during the per-bin math below
-		cf * row = reinterpret_cast<cf*>( p.out + ( int64_t( channel ) * p.F + t ) * ( C + 1 ) );
-		cf * rowp = row + lane;
-		#pragma unroll
-		for( int q0 = 0; q0 < E; q0 += NV )
-			{
-			// NV bins per iteration (k = lane + 64 (q0 + i)), evaluated as one vector stream: NV/2 independent packed
-			// instructions per step of every dependent chain (pv_math.h)
-			VB re, im, pv, binf;
-			#pragma unroll
-			for( int i = 0; i < NV; ++i )
-				{
-				float r, m;
-				split_bin( z, q0 + i, z0, r, m );
-				re[i] = r; im[i] = m; pv[i] = prev[q0 + i]; binf[i] = bin_frequency( q0 + i );
-				}
-			// phase_vocoder.cpp:37-52 (AudioPV.cpp:69-73); the dft 2048 kernels' per-bin code (pv_math.h: polar_v shares the reciprocal between
-			// atan2 and the magnitude; run-time constants as scalar operands)
-			VB phase, m;
-			polar_v( re, im, phase, m );
-			const VB phase_diff = phase - pv;                                    // == float( double(phase) - double(prev) ), :44
-			const VB delta_phase = phase_diff - div_c_each( binf, p.ar_div ) * vsplat<VB>( FLANHIP_PI2_F );    // :47-48
-			VB wrapped = delta_phase;
-			if( use_wrapping ) wrapped = delta_phase - vsplat<VB>( FLANHIP_PI2_F ) * round_half_away_v( div_pi2_v( delta_phase ) );   // :39-42,49
-			VB war;
-			#pragma unroll
-			for( int i = 0; i < NV; ++i ) war[i] = wrapped[i] * p.analysis_rate;
-			const VB f = binf + div_pi2_v( war );                               // :50-52
-			#pragma unroll
-			for( int i = 0; i < NV; ++i )
-				{
-				prev[q0 + i] = phase[i];                                         // :45
-				__builtin_nontemporal_store( cf{ m[i], f[i] }, rowp + 64 * ( q0 + i ) );   // (written once, read by another kernel later: see k_analyze_v2)
-				}
-			if constexpr( SUMS )
-				{
-				const VB term = div_c_each( f, p.ar_div ) * vsplat<VB>( FLANHIP_PI2_F );                       // phase_vocoder.cpp:57-58
-				#pragma unroll
-				for( int i = 0; i < NV; ++i )
-					{
-					sum_of( q0 + i ) += double( term[i] );
-					bad |= !( __builtin_fabsf( m[i] ) <= 3.4028235e38f ) || !( __builtin_fabsf( f[i] ) <= 3.4028235e38f );
-					}
-				}
-			}
-			{
-			const float re = z0.x - z0.y;
-			const float phase = atan2_fast( 0.0f, re );
-			const float phase_diff = float( double( phase ) - double( prev[E] ) );
-			prev[E] = phase;
-			const float delta_phase = phase_diff - expected_advance( E );
-			const float wrapped = use_wrapping ? delta_phase - FLANHIP_PI2_F * round_half_away( div_pi2( delta_phase ) ) : delta_phase;
-			const float delta_frequency = div_pi2( wrapped * p.analysis_rate );
-			const float f = bin_frequency( E ) + delta_frequency;
-			row[C] = mk( __builtin_fabsf( re ), f );   // every lane holds the same Nyquist value: an unconditional store keeps the
-			                                                    // number of outstanding memory operations static (counted s_waitcnt, no drain)
-			if constexpr( SUMS )
-				{
-				sum_of( E ) += double( div_c( f, p.ar_div ) * FLANHIP_PI2_F );
-				bad |= !( __builtin_fabsf( re ) <= 3.4028235e38f ) || !( __builtin_fabsf( f ) <= 3.4028235e38f );
-				}
-			}
-		wave_sync();
-		}
-	if constexpr( SUMS )
-		{
-		double * dst = p.sums + chain * ( C + 1 );
-		#pragma unroll
-		for( int q = 0; q <= E; ++q )
-			{
-			const double sq = sum_of( q );
-			const double v = ( __builtin_fabs( sq ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( sq ) : fold_phase_any( sq );
-			if( q < E ) dst[lane + 64 * q] = v;
-			else if( lane == 0 ) dst[C] = v;
-			}
-		const bool any_bad = __any( bad );
-		if( p.nan_out && lane == 0 )
-			{
-			// no clearing pass: the flag word is "set" when it equals this launch's epoch (written beside it by chain 0)
-			if( chain == 0 ) { p.nan_out[2] = p.nan_epoch; p.nan_out[4] = p.nan_epoch; }   // [4]: the sums of this epoch are in the workspace
-			if( any_bad ) p.nan_out[0] = p.nan_epoch;
-			}
-		}
-	}
-
-// =================================================================================================================
-// PV::convert_to_audio (Conversions/AudioPV.cpp:86-139); HOPQ = hop / 128 for the hops 128 / 256 / 512 / 1024 (overlap-add
-// accumulator in registers); HOPQ = 0: any hop <= window, any window, accumulator = a ring of W floats per wave in LDS
-// =================================================================================================================
-template<int LOG2C, int WAVES, int HOPQ>
-__global__ __launch_bounds__( 64 * WAVES ) void k_synthesize_fast( SynthParams p, FastTables tb )
-	{
-	using L = FastLds<LOG2C>;
-	constexpr int C = 1 << LOG2C;
-	constexpr int E = C / 64;
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	cf * s = reinterpret_cast<cf*>( smem );
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	load_tables( s, tb, p.window, p.window_size, p.window_scale, C, tid, 64 * WAVES );   // AudioPV.cpp:102: hann * window_scale
-	__syncthreads();
-	const cf * s_tw1 = s + L::TW1;
-	const cf * s_tw3 = s + L::TW3;
-	const cf * s_w2 = s + L::W2 + lane;
-	const cf * s_win = s + L::WIN + lane;
-	cf * buf = s + L::BUF + wave * L::BUF_LEN;
-
-	const int64_t chain = int64_t( blockIdx.x ) * WAVES + wave;
-	if( chain >= int64_t( p.chains_per_channel ) * p.num_channels || cancel_seen( cancel_peek( p.cancel ) ) ) return;   // (cancelled: core.hip)
-	const int channel = int( chain / p.chains_per_channel );
-	const int chain_in_channel = int( chain % p.chains_per_channel );
-	const int64_t t0 = int64_t( chain_in_channel ) * p.L;
-	const int64_t t1 = min( t0 + int64_t( p.L ), p.F );
-	const bool last_chain = chain_in_channel == p.chains_per_channel - 1;
-	const int W = p.window_size;
-	constexpr bool RING = HOPQ == 0;
-	const int hop = RING ? p.hop : 128 * HOPQ;
-	// register accumulator: everything is in cf units (sample pairs), positions are even because hop, W/2 are multiples of 64;
-	// ring accumulator: float units
-	float * out1 = p.out + int64_t( channel ) * p.out_len;
-	float * head1 = p.head + chain * p.head_len;
-	cf * out2 = reinterpret_cast<cf*>( out1 );
-	cf * head2 = reinterpret_cast<cf*>( head1 );
-	const int rlen = L::ring_len( W );
-	float * ring = reinterpret_cast<float*>( s + L::BUF + WAVES * L::BUF_LEN ) + wave * rlen;   // RING only
-	if constexpr( RING )
-		{
-		for( int i = lane; i < rlen; i += 64 ) ring[i] = 0.0f;
-		wave_sync();
-		}
-	int ring_base = 0;                                                         // ring[ring_base] <-> absolute sample `pos`
-	const int64_t chain_start = int64_t( hop ) * t0 - W / 2;
-	const int64_t own_start = chain_in_channel == 0 ? INT64_MIN : chain_start + p.head_len;
-	const int padl = lane + ( lane >> 4 );
-	const cf * mirror = buf + ( C * 17 ) / 16 - ( lane + ( ( lane + 15 ) >> 4 ) );
-
-	double ph[E + 1];                                                          // phase_buffer (AudioPV.cpp:105) on entry to the chain
-	#pragma unroll
-	for( int q = 0; q <= E; ++q ) ph[q] = p.carry[chain * ( C + 1 ) + ( q < E ? lane + 64 * q : C )];
-	cf acc[E];                                                             // overlap-add accumulator: acc[q] <-> samples pos + 128 q + 2 lane (+1)
-	#pragma unroll
-	for( int q = 0; q < E; ++q ) acc[q] = mk( 0.0f, 0.0f );
-
-	// one 128-sample step of finished (or partial) output leaves the chain
-	// Exactly one store instruction per step, never inside a branch (static count of outstanding memory operations, see
-	// k_analyze_fast): lanes that fall outside the output are pointed at a 512-byte dump area in the workspace.
-	cf * dump2 = reinterpret_cast<cf*>( p.dump ) + lane;
-	auto emit_step = [&]( int64_t a0, cf v )
-		{
-		const int64_t a = a0 + 2 * lane;
-#ifndef FLANHIP_STATIC_EMIT   /* measured: the branchy form is 10 % faster than redirecting out-of-range lanes to a dump area */
-		(void) dump2;
-		if( a0 < own_start ) head2[( a - chain_start ) >> 1] = v;
-		else if( a >= 0 && a < p.out_len ) out2[a >> 1] = v;
-#else
-		cf * dst = ( a0 < own_start ) ? head2 + ( ( a - chain_start ) >> 1 ) : out2 + ( a >> 1 );
-		if( a0 >= own_start && !( a >= 0 && a < p.out_len ) ) dst = dump2;
-		*dst = v;
-#endif
-		};
-
-	// MF row of frame t in the natural layout ( m, f ) of bin lane + 64 q; loaded one frame ahead of its use
-	auto load_row = [&]( int64_t t, cf ( &mfr )[E], cf & mfny )
-		{
-		const cf * row = reinterpret_cast<const cf*>( p.pv + ( int64_t( channel ) * p.F + t ) * ( C + 1 ) );
-		const cf * rowp = row + lane;
-		#pragma unroll
-		for( int q = 0; q < E; ++q ) mfr[q] = __builtin_nontemporal_load( rowp + 64 * q );   // the PV is read once
-		mfny = __builtin_nontemporal_load( row + C );
-		};
-	cf mfr[E], mfny;
-	load_row( t0, mfr, mfny );
-
-	int64_t pos = chain_start;
-	for( int64_t t = t0; t < t1; ++t )
-		{
-		// ---- inverse phase vocoder per bin (AudioPV.cpp:117-120, phase_vocoder.cpp:55-61)
-		cf z[E];
-		float mn;
-		bool slow = false;
-		// f / analysis_rate of the whole row under ONE test of the divisor's plan (see k_synthesize_v2)
-		float dv[E + 1];
-		if( p.ar_div.exact )
-			{
-			const float dc = p.ar_div.c, drc = p.ar_div.rc;
-			auto div_exact = [&]( float x ) { const float q0 = x * drc; return __builtin_fmaf( __builtin_fmaf( -q0, dc, x ), drc, q0 ); };   // pv_math.h: div_c
-			#pragma unroll
-			for( int q = 0; q < E; ++q ) dv[q] = div_exact( mfr[q].y );
-			dv[E] = div_exact( mfny.y );
-			}
-		else
-			{
-			#pragma unroll
-			for( int q = 0; q < E; ++q ) dv[q] = mfr[q].y / p.ar_div.c;
-			dv[E] = mfny.y / p.ar_div.c;
-			}
-		#pragma unroll
-		for( int q = 0; q < E; ++q )
-			{
-			ph[q] += double( dv[q] * FLANHIP_PI2_F );                            // phase_vocoder.cpp:57-58
-			slow |= !( __builtin_fabs( ph[q] ) < double( FLANHIP_SINCOS_FAST_LIMIT ) );
-			z[q].x = mfr[q].x;                                                   // m
-			}
-		ph[E] += double( dv[E] * FLANHIP_PI2_F );
-		slow |= !( __builtin_fabs( ph[E] ) < double( FLANHIP_SINCOS_FAST_LIMIT ) );
-		mn = mfny.x;
-#ifndef FLANHIP_STATIC_EMIT
-		if( t + 1 < t1 ) load_row( t + 1, mfr, mfny );                          // prefetch: in flight during the transform below
-#else
-		load_row( min( t + 1, t1 - 1 ), mfr, mfny );                            // prefetch (the last frame re-reads itself): in flight during the transform below
-#endif
-		cf xn;
-		if( __any( slow ) )
-			{
-			// a phase outside the range the fast helpers are exact for (or a NaN): the general routines for this frame
-			#pragma unroll
-			for( int q = 0; q < E; ++q )
-				{
-				ph[q] = fold_phase_any( ph[q] );
-				const float2 sc = sincos_wide( float( ph[q] ) );
-				z[q] = mk( z[q].x * sc.y, z[q].x * sc.x );
-				}
-			ph[E] = fold_phase_any( ph[E] );
-			const float2 sc = sincos_wide( float( ph[E] ) );
-			xn = mk( mn * sc.y, mn * sc.x );
-			}
-		else
-			{
-			#pragma unroll
-			for( int q0 = 0; q0 < E; q0 += 4 )
-				{
-				// four bins per iteration as one vector stream (pv_math.h): two independent packed instructions per step
-				v4f th, m4;
-				#pragma unroll
-				for( int i = 0; i < 4; ++i )
-					{
-					ph[q0 + i] = fold_phase_loop( ph[q0 + i] );                 // phase_vocoder.cpp:59 (the four-instruction fold, pv_math.h)
-					th[i] = float( ph[q0 + i] );
-					m4[i] = z[q0 + i].x;
-					}
-				v4f sn, cs;
-				sincos_fast_v( th, sn, cs );
-				const v4f xr = m4 * cs, xi = m4 * sn;                            // std::polar, :60
-				#pragma unroll
-				for( int i = 0; i < 4; ++i ) z[q0 + i] = cf{ xr[i], xi[i] };
-				__builtin_amdgcn_sched_barrier( 0 );                            // four bins at a time: keeps the temporaries of 16 bins from overlapping
-				}
-			ph[E] = fold_phase_loop( ph[E] );
-			float sn, cs;
-			sincos_fast( float( ph[E] ), sn, cs );
-			xn = mk( mn * cs, mn * sn );
-			}
-		// ---- merge X[0..C] into the half-size spectrum: needs X[k] (own) and X[C-k] (mirror lane): one LDS exchange
-		#pragma unroll
-		for( int q = 0; q < E; ++q ) buf[padl + 68 * q] = z[q];
-		if( lane == 0 ) buf[( C * 17 ) / 16] = xn;                              // slot PAD( C )
-		wave_sync();
-		#pragma unroll
-		for( int q = 0; q < E; ++q )
-			{
-			cf xk = z[q];
-			cf xm = mirror[-68 * q];                                        // X[ C - k ]; k = 0 pairs with X[C]
-			if( q == 0 ) { xk.y = ( lane == 0 ) ? 0.0f : xk.y; xm.y = ( lane == 0 ) ? 0.0f : xm.y; }   // c2r ignores Im X[0], Im X[C]
-			const cf w = s_w2[64 * q];
-			const float ax = xk.x + xm.x, ay = xk.y - xm.y;                     // A = X[k] + conj X[C-k]
-			const float dx = xk.x - xm.x, dy = xk.y + xm.y;                     // D = X[k] - conj X[C-k]
-			const float c = w.x, sgn = -w.y;                                    // exp(+2 pi i k / N)
-			const float bx = __builtin_fmaf( c, dx, -( sgn * dy ) ), by = __builtin_fmaf( c, dy, sgn * dx );
-			z[q] = mk( ax - by, -( ay + bx ) );                        // conj( A + iB ): forward FFT of it = conj of the inverse
-			__builtin_amdgcn_sched_barrier( 0 );
-			}
-		wave_sync();
-		fft_fast<LOG2C>( z, buf, s_tw1, s_tw3, lane );
-		// ---- G = fft( conj Z ): x[2n] = G[n].x, x[2n+1] = -G[n].y; window and overlap-add (AudioPV.cpp:122-134)
-		if constexpr( !RING )
-			{
-			#pragma unroll
-			for( int q = 0; q < E; ++q )
-				{
-				const cf w = s_win[64 * q];                                 // zero beyond W
-				acc[q].x += z[q].x * w.x;
-				acc[q].y += ( -z[q].y ) * w.y;
-				}
-			#pragma unroll
-			for( int q = 0; q < ( RING ? 1 : HOPQ ); ++q ) emit_step( pos + 128 * q, acc[q] );
-			#pragma unroll
-			for( int q = 0; q < E; ++q ) acc[q] = ( q + HOPQ < E ) ? acc[q + HOPQ] : mk( 0.0f, 0.0f );
-			}
-		else
-			{
-			#pragma unroll
-			for( int q = 0; q < E; ++q )
-				{
-				const cf w = s_win[64 * q];
-				const int s0 = 2 * ( lane + 64 * q );
-				if( s0 < W )
-					{
-					int i0 = ring_base + s0; if( i0 >= W ) i0 -= W;
-					ring[i0] += z[q].x * w.x;
-					if( s0 + 1 < W )
-						{
-						int i1 = i0 + 1; if( i1 >= W ) i1 -= W;
-						ring[i1] += ( -z[q].y ) * w.y;
-						}
-					}
-				}
-			wave_sync();
-			// the oldest `hop` samples are complete as far as this chain is concerned: emit and clear them (hop <= W)
-			for( int e = lane; e < hop; e += 64 )
-				{
-				int i = ring_base + e; if( i >= W ) i -= W;
-				const float v = ring[i];
-				ring[i] = 0.0f;
-				const int64_t a = pos + e;
-				if( a < own_start ) head1[a - chain_start] = v;
-				else if( a >= 0 && a < p.out_len ) out1[a] = v;
-				}
-			wave_sync();
-			ring_base += hop; if( ring_base >= W ) ring_base -= W;
-			}
-		pos += hop;
-		}
-	// flush the partial sums that the next chain's head completes; the last chain zero-fills to the end of the output
-	const int64_t ring_end = pos + ( W - hop );
-	const int64_t flush_end = last_chain ? max( ring_end, p.out_len ) : ring_end;
-	if constexpr( !RING )
-		{
-		#pragma unroll
-		for( int q = 0; q < E; ++q )
-			{
-			const int64_t a0 = pos + 128 * q;
-			if( a0 < flush_end ) emit_step( a0, acc[q] );
-			}
-		for( int64_t a0 = pos + 128 * E; a0 < flush_end; a0 += 128 ) emit_step( a0, mk( 0.0f, 0.0f ) );
-		}
-	else
-		for( int64_t a = pos + lane; a < flush_end; a += 64 )
-			{
-			float v = 0.0f;
-			if( a < ring_end ) { int i = ring_base + int( a - pos ); if( i >= W ) i -= W; v = ring[i]; }
-			if( a < own_start ) head1[a - chain_start] = v;
-			else if( a >= 0 && a < p.out_len ) out1[a] = v;
-			}
 	}
 
 // ---- pre-pass kernels (all sizes) --------------------------------------------------------------------------------

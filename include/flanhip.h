@@ -162,10 +162,9 @@ int flanhip_synthesize_dev_stages(const flanhip_MF * d_pv, int64_t num_channels,
 #define FLANHIP_DEBUG_FORCE_GENERIC   2   /* 1: never the tuned dft 2048 / 4096 kernels */
 #define FLANHIP_DEBUG_NO_FAST_DIV     3   /* 1: hardware division by the analysis rate */
 #define FLANHIP_DEBUG_ANA_VARIANT     4   /* dft 2048 analysis: ablated instantiations (diagnostic builds only) */
-#define FLANHIP_DEBUG_SYN_VARIANT     5   /* dft 2048 synthesis: 2 = behind the scan kernel even where it could work out its own carries; 3 = hops / windows off the
-                                            128-sample grid through the round-1 kernel instead of k_synthesize_v2's LDS-ring form (A/B predecessor); ablations */
-#define FLANHIP_DEBUG_ANA4096_OLD     6   /* 1: the round-1 dft 4096 analysis kernel instead of the team kernel (A/B predecessor) */
-#define FLANHIP_DEBUG_SYN4096_OLD     7   /* 1: the round-1 dft 4096 synthesis kernel */
+#define FLANHIP_DEBUG_SYN_VARIANT     5   /* dft 2048 synthesis: 2 = behind the scan kernel even where it could work out its own carries; ablations */
+#define FLANHIP_DEBUG_ANA4096_OLD     6   /* 1: the generic block-per-chain analysis kernel (pv_kernels.h) instead of the dft 4096 team kernel (A/B predecessor) */
+#define FLANHIP_DEBUG_SYN4096_OLD     7   /* 1: the generic dft 4096 synthesis kernel */
 #define FLANHIP_DEBUG_RESAMPLE_DIRECT 8   /* 1: Audio::resample's 2:1 block convolver always as direct fp64 sums in the checker's operation order
                                            * (default: fp64 overlap-save FFT convolution, the reference's own method, r8brain/CDSPBlockConvolver.h:242-344,
                                            * for float streams of at least 8 blocks); 2: the convolver's 256-thread radix-16 generation (A/B predecessor) */

@@ -759,10 +759,10 @@ def test_special_signals(fa, dft, hop):
 
 @pytest.mark.parametrize("hop", [128, 256, 512, 1024])
 def test_dft4096_kernel_generations_agree(fa, hop):
-    """dft 4096, window 2048: the round-2 kernels (two 1024-point transforms per frame: pv_kernels_eo.h; teams of two wavefronts in the fused
-    round trip and in synthesis) against the round-1 ones (one 2048-point register transform per wavefront) on the same input: the same
-    per-bin arithmetic behind two FFT factorisations -- PVs agree like two FFT backends do (magnitudes 1e-7, most f bit for bit), audio from
-    the SAME PV to 1e-6."""
+    """dft 4096, window 2048: the team kernels (two 1024-point register transforms per frame: pv_kernels_eo.h) against their A/B predecessor, the generic
+    block-per-chain kernels of pv_kernels.h (FLANHIP_DEBUG_ANA4096_OLD / SYN4096_OLD; until round 6 these hooks selected round 1's own tuned kernels, now
+    retired), on the same input: the same per-bin arithmetic behind two FFT factorisations -- PVs agree like two FFT backends do (magnitudes 1e-7, most f bit
+    for bit), audio from the SAME PV to 1e-6."""
     sr, W, dft = 48000.0, 2048, 4096
     x = O.noise(2, 60000 + 7 * hop, seed=hop)
     ar = np.float32(sr) / np.float32(hop)
@@ -1022,46 +1022,3 @@ def test_overlap_fixup_inside_the_kernel_equals_the_separate_launch(fa, ch, seco
                 raise AssertionError("launch %d: %d samples differ, first at %s" % (rep, bad.shape[0], bad[0].tolist()))
 
 
-@pytest.mark.parametrize("W,hop,dft", [(1024, 256, 1024), (512, 128, 512)])
-def test_v3_kernel_configurations_agree(fa, W, hop, dft):
-    """The dft 1024 / 512 kernels are built for several block shapes (wavefronts per block = chains per group, registers per wavefront, bins per
-    vector stream: conversions.hip, FLANHIP_V3_CFGS_*); index 0 ships, the others are its A/B partners.  Same arithmetic per frame: the PV bit for
-    bit, the fused round trip's audio to the rounding of the overlap partial sums at the chain boundaries (the chain length follows the group size)."""
-    import ctypes
-    lib = fa.lib
-    sr = 48000.0
-    ch, n = 3, 700000
-    x = O.noise(ch, n, seed=dft)
-    F = O.num_pv_frames(n, hop)
-    bins = dft // 2 + 1
-    ar = np.float32(sr) / np.float32(hop)
-
-    def dev_alloc(nbytes):
-        p = ctypes.c_void_p()
-        fa.check(lib.flanhip_malloc(ctypes.byref(p), nbytes))
-        return p
-    d_x = dev_alloc(x.nbytes)
-    fa.check(lib.flanhip_memcpy_h2d(d_x, x.ctypes.data_as(ctypes.c_void_p), x.nbytes, None))
-    res = []
-    try:
-        for variant in (0, 1, 2):
-            lib.flanhip_debug_option(fa.DEBUG_ANA_VARIANT, variant)
-            ws_bytes = lib.flanhip_synthesize_workspace_bytes(ch, F, bins, sr, ar, W)
-            d_pv, d_out, d_ws, d_flag = dev_alloc(ch * F * bins * 8), dev_alloc(ch * F * hop * 4), dev_alloc(ws_bytes), dev_alloc(4)
-            fa.check(lib.flanhip_memset(d_flag, 0, 4, None))
-            fa.check(lib.flanhip_analyze_dev_fused(d_x, ch, n, sr, W, hop, dft, d_pv, d_ws, None))
-            fa.check(lib.flanhip_synthesize_dev_fused(d_pv, ch, F, bins, sr, ar, W, d_out, d_ws, d_flag, None))
-            pv = np.empty((ch, F, bins, 2), np.float32); out = np.empty((ch, F * hop), np.float32)
-            fa.check(lib.flanhip_memcpy_d2h(pv.ctypes.data_as(ctypes.c_void_p), d_pv, pv.nbytes, None))
-            fa.check(lib.flanhip_memcpy_d2h(out.ctypes.data_as(ctypes.c_void_p), d_out, out.nbytes, None))
-            fa.check(lib.flanhip_stream_synchronize(None))
-            res.append((pv, out))
-            for p in (d_pv, d_out, d_ws, d_flag):
-                lib.flanhip_free(p)
-    finally:
-        lib.flanhip_debug_option(fa.DEBUG_ANA_VARIANT, 0)
-        lib.flanhip_free(d_x)
-    for k in range(1, len(res)):
-        assert np.array_equal(res[0][0].view(np.uint32), res[k][0].view(np.uint32)), k
-        assert np.abs(res[0][1].astype(np.float64) - res[k][1].astype(np.float64)).max() <= 2e-6, k
-    assert np.abs(res[0][1]).max() > 0.1
