@@ -1022,3 +1022,50 @@ def test_overlap_fixup_inside_the_kernel_equals_the_separate_launch(fa, ch, seco
                 raise AssertionError("launch %d: %d samples differ, first at %s" % (rep, bad.shape[0], bad[0].tolist()))
 
 
+
+
+@pytest.mark.parametrize("ch,seconds,W,hop,dft", [(2, 20.0, 2048, 512, 2048), (3, 7.3, 2048, 512, 2048), (5, 11.1, 1024, 512, 1024), (4, 20.0, 2048, 1024, 2048)])
+def test_overlap_protocol_soak_on_two_streams(fa, ch, seconds, W, hop, dft):
+    """The chains' overlaps added inside the synthesis kernels (pv_kernels_v2.h / _v3.h: a tagged word per boundary, the head's owner publishing from inside
+    its frame loop behind an explicit drain, the tail's owner adding or depositing) rest on in-order retirement and agent-scope stores across the XCDs' private
+    L2s.  The long soak lives in tools/soak_fixup.py (30 000 launches, profiles/r05_soak_fixup.json); this is its short form in the suite: 250 fused round
+    trips per shape on each of TWO streams at once (a workspace each; launches overlap on the device), every eighth pair of outputs compared BIT FOR BIT with
+    the separate-launch form (k_ola_fixup4).  1000 launches per stream over the four shapes."""
+    import ctypes
+    import torch
+    dev = torch.device("cuda", 0)
+    sr = 48000.0
+    n = int(seconds * sr)
+    bins = dft // 2 + 1
+    F = int(fa.lib.flanhip_num_pv_frames(n, hop))
+    ar = sr / hop
+    audio = torch.empty((ch, n), dtype=torch.float32, device=dev)
+    fa.check(fa.lib.flanhip_noise_dev(ctypes.c_void_p(audio.data_ptr()), ch, n, 4321, None))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    bufs = [(torch.empty((ch, F, bins, 2), dtype=torch.float32, device=dev), torch.empty((ch, F * hop), dtype=torch.float32, device=dev),
+             torch.empty(fa.synthesize_workspace_bytes(ch, F, bins, sr, ar, W), dtype=torch.uint8, device=dev)) for _ in streams]
+
+    def step(i):
+        pv, out, ws = bufs[i]
+        st = int(streams[i].cuda_stream)
+        fa.analyze_dev_fused(audio, ch, n, sr, W, hop, dft, pv, ws, st)
+        fa.synthesize_dev_fused(pv, ch, F, bins, sr, ar, W, out, ws, None, st)
+    launches, bad, checked = 250, 0, 0
+    try:
+        with fa.debug_options(inline_fixup=2):                       # the separate launch: the yardstick
+            step(0)
+            torch.cuda.synchronize()
+            want = bufs[0][1].clone()
+        with fa.debug_options(inline_fixup=1):                       # inside the kernel, whatever the chain length
+            for r in range(launches):
+                step(0)
+                step(1)
+                if r % 8 == 7 or r == launches - 1:
+                    torch.cuda.synchronize()
+                    for i in range(2):
+                        checked += 1
+                        bad += 0 if torch.equal(bufs[i][1].view(torch.int32), want.view(torch.int32)) else 1
+    finally:
+        torch.cuda.synchronize()
+    print("\n[soak %d ch x %g s (%d, %d, %d)] %d launches on two streams, %d outputs compared, %d differing" % (ch, seconds, W, hop, dft, 2 * launches, checked, bad))
+    assert checked >= 60 and bad == 0
