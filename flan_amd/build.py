@@ -63,10 +63,17 @@ def build(verbose=False, force=False):
                 print(line, flush=True)
             if os.path.exists(stamp):
                 os.remove(stamp)
-            procs.append((src, subprocess.Popen(cmd), stamp, line))
+            procs.append((src, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True), stamp, line))
     failed = []
     for src, proc, stamp, line in procs:
-        if proc.wait() != 0:
+        _, err = proc.communicate()
+        # NO_PK is a device feature handed to both passes of hipcc (-Xarch_device cannot forward -Xclang): the HOST pass answers "'-packed-fp32-ops' is not a
+        # recognized feature for this target (ignoring feature)" five times per file.  The device pass honours it (0 v_pk_*_f32 in the gfx950 assembly against
+        # 88 749 without: VERDICT r05); the host pass's remark is dropped here so that it does not read as "the flag is ignored"
+        err = "\n".join(ln for ln in err.splitlines() if "is not a recognized feature for this target" not in ln)
+        if err.strip():
+            sys.stderr.write(err + "\n")
+        if proc.returncode != 0:
             failed.append(src)
         else:
             with open(stamp, "w") as f:
