@@ -503,7 +503,7 @@ def main():
             kname, tk, b = "k_synthesize", t_sy_main, BYTES_SYNTHESIS
         achieved = frames_per_step * b / (tk * 1e-3) / 1e9
         # HBM bytes per launch of that kernel: not measurable from inside this process (PMC counters need rocprofv3), so the figure comes
-        # from the committed PMC profile of this same workload and build (tools/scripts/profile_bench.sh -> profiles/r05_hbm_traffic.json:
+        # from the committed PMC profile of this same workload and build (tools/scripts/profile_bench.sh -> profiles/r06_hbm_traffic.json:
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, with the unit and gfx950 corrections the file explains) and is
         # labelled with its source; null for any other workload shape
         # the profile carries the hash of the kernel sources it was taken on (flan_amd/build.py: kernel_source_hash): a profile of other
@@ -512,14 +512,14 @@ def main():
         try:
             if ch == 8 and abs(args.seconds - 60.0) < 1e-9 and DFT == 2048 and HOP == 512 and WINDOW == 2048:
                 from flan_amd.build import kernel_source_hash
-                path = os.path.join(ROOT, "profiles", "r05_hbm_traffic.json")
+                path = os.path.join(ROOT, "profiles", "r06_hbm_traffic.json")
                 with open(path) as fh:
                     prof = json.load(fh)
                 if prof.get("kernel_source_hash") == kernel_source_hash():
                     traffic = prof[kname]["traffic_bytes"]
-                    traffic_source = "profiles/r05_hbm_traffic.json"
+                    traffic_source = "profiles/r06_hbm_traffic.json"
                 else:
-                    traffic_source = "profiles/r05_hbm_traffic.json was taken on other kernel sources (%s, now %s): not quoted" % (str(prof.get("kernel_source_hash"))[:12], kernel_source_hash()[:12])
+                    traffic_source = "profiles/r06_hbm_traffic.json was taken on other kernel sources (%s, now %s): not quoted" % (str(prof.get("kernel_source_hash"))[:12], kernel_source_hash()[:12])
         except Exception as e:
             traffic, traffic_source = None, "no traffic profile: " + repr(e)
         # what a plain device-to-device copy of the same number of bytes reaches on this box (quote the measured
@@ -552,13 +552,13 @@ def main():
                     "copy_peak_measured": copy_gbs, "copy_peak_kind": "flanhip_copy_dev: 16 B per lane, grid-stride, the same bytes read + written"}
         # The bound that actually holds these kernels is the vector ALU, not HBM: the launch's VALU instruction mix, priced per
         # class with the measured issue costs, against the launch's own cycles.  PMC counters cannot be read from inside the process: the mix is
-        # the committed profile's (profiles/r05_valu_roofline.json, tools/make_valu_roofline.py), quoted only while the kernel sources' hash
+        # the committed profile's (profiles/r06_valu_roofline.json, tools/make_valu_roofline.py), quoted only while the kernel sources' hash
         # matches; the duration is the one measured live above, the clock the one the profile measured (GRBM_GUI_ACTIVE)
         roofline_valu = None
         try:
             if ch == 8 and abs(args.seconds - 60.0) < 1e-9 and DFT == 2048 and HOP == 512 and WINDOW == 2048 and not args.unfused:
                 from flan_amd.build import kernel_source_hash
-                with open(os.path.join(ROOT, "profiles", "r05_valu_roofline.json")) as fh:
+                with open(os.path.join(ROOT, "profiles", "r06_valu_roofline.json")) as fh:
                     vp_ = json.load(fh)
                 if vp_.get("kernel_source_hash") == kernel_source_hash():
                     k_ = vp_[kname]
@@ -567,9 +567,9 @@ def main():
                     roofline_valu = {"bound": "valu", "kernel": kname, "priced_simd_cycles": k_["priced_simd_cycles_per_launch"], "launch_cycles": int(cycles),
                                      "frac": round(k_["priced_simd_cycles_per_launch"] / cycles, 4), "clock_ghz": clock, "insts_valu": k_["insts_valu"],
                                      "full_rate_floor_frac": round(k_["full_rate_floor_cycles"] / cycles, 4),
-                                     "source": "profiles/r05_valu_roofline.json (SQ_INSTS_VALU_* per class x profiles/r03_a_issue_model.txt prices; LDS, VMEM and scalar issue not included)"}
+                                     "source": "profiles/r06_valu_roofline.json (SQ_INSTS_VALU_* per class x profiles/r03_a_issue_model.txt prices; LDS, VMEM and scalar issue not included)"}
                 else:
-                    roofline_valu = {"frac": None, "source": "profiles/r05_valu_roofline.json was taken on other kernel sources: not quoted"}
+                    roofline_valu = {"frac": None, "source": "profiles/r06_valu_roofline.json was taken on other kernel sources: not quoted"}
         except Exception as e:
             roofline_valu = {"frac": None, "source": "no instruction-mix profile: " + repr(e)}
         extra["roofline_valu"] = roofline_valu
