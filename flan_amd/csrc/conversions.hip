@@ -110,10 +110,11 @@ static bool big_size( int dft, int W, BigPlan * pl = nullptr )
 	{
 	BigPlan t;
 	if( fft_size( dft ) || debug_options().force_direct || dft <= 16384 || !big_make_plan( dft, W, &t ) ) return false;
-	if( big_synth_lds( t.C2, W ) > kMaxLds ) return false;
+	// (the synthesis' overlap-add ring of W floats: in LDS where it fits beside the two transforms, in the workspace otherwise -- big_ring_in_workspace)
 	if( pl ) *pl = t;
 	return true;
 	}
+static bool big_ring_in_workspace( const BigPlan & pl, int W ) { return big_synth_lds( pl.C2, W ) > kMaxLds; }
 static int big_target_chains() { return cu_count(); }        // one block per CU, a chain is P blocks: P rounds
 
 static bool dft_size_ok( int dft ) { return dft >= 4 && dft % 2 == 0 && dft <= kMaxAnyDft; }
@@ -718,13 +719,18 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 		o->any_frames_offset = o->any_spec_offset + ( ( size_t( ch ) * size_t( F ) * size_t( bins ) * sizeof( cf ) + 255 ) & ~size_t( 255 ) );
 		o->total_bytes = o->any_frames_offset + ( ( size_t( ch ) * size_t( F ) * size_t( W ) * sizeof( float ) + 255 ) & ~size_t( 255 ) );
 		}
-	o->big_out_offset = o->big_head_offset = 0;
+	o->big_out_offset = o->big_head_offset = o->big_ring_offset = 0;
 	if( o->big )
 		{
 		// the units' partial output streams [P][ch][F hop] and heads [P][chains][head_len] (pv_kernels_big.h)
 		o->big_out_offset = o->total_bytes;
 		o->big_head_offset = o->big_out_offset + ( ( size_t( big_plan.P ) * size_t( ch ) * size_t( F ) * size_t( o->hop ) * sizeof( float ) + 255 ) & ~size_t( 255 ) );
 		o->total_bytes = o->big_head_offset + ( ( size_t( big_plan.P ) * size_t( chains ) * size_t( o->head_len ) * sizeof( float ) + 255 ) & ~size_t( 255 ) );
+		if( big_ring_in_workspace( big_plan, W ) )
+			{
+			o->big_ring_offset = o->total_bytes;
+			o->total_bytes += ( size_t( big_plan.P ) * size_t( chains ) * size_t( ( W + 3 ) & ~3 ) * sizeof( float ) + 255 ) & ~size_t( 255 );
+			}
 		}
 	o->flags_offset = o->total_bytes;
 	o->total_bytes += ( sizeof( int ) * size_t( bins + 1 ) + 255 ) & ~size_t( 255 );
@@ -911,8 +917,10 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 		{
 		const int64_t blocks = big_blocks( chains, big_plan.P );
 		FLANHIP_REQUIRE( blocks < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
-		const BigSynthExtra e{ reinterpret_cast<float*>( reinterpret_cast<char*>( d_ws ) + lay.big_out_offset ), reinterpret_cast<float*>( reinterpret_cast<char*>( d_ws ) + lay.big_head_offset ) };
-		const size_t lds = big_synth_lds( big_plan.C2, W );
+		const bool ring_ws = lay.big_ring_offset != 0;
+		const BigSynthExtra e{ reinterpret_cast<float*>( reinterpret_cast<char*>( d_ws ) + lay.big_out_offset ), reinterpret_cast<float*>( reinterpret_cast<char*>( d_ws ) + lay.big_head_offset ),
+			ring_ws ? reinterpret_cast<float*>( reinterpret_cast<char*>( d_ws ) + lay.big_ring_offset ) : nullptr };
+		const size_t lds = ring_ws ? big_analyze_lds( big_plan.C2 ) : big_synth_lds( big_plan.C2, W );
 		auto kern = big_plan.C2 == 4096 ? k_synthesize_big<8> : big_plan.C2 == 2048 ? k_synthesize_big<4> : k_synthesize_big<2>;
 		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 		hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( MR_THREADS ), lds, s, p, big_plan, e );

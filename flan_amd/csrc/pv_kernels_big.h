@@ -145,6 +145,9 @@ struct BigSynthExtra
 	{
 	float * part_out;         // [P][ch][out_len]   a unit's share of the output
 	float * part_head;        // [P][chains][head_len]
+	float * ring_ws;          // [P][chains][wpad] or null: the units' overlap-add rings in the workspace, for windows whose ring does not fit the LDS beside the
+	                          // transforms (above ~14 k samples: convert_to_PV( 32768, 8192, 32768 ), a PaulStretch-style call, ran the direct sums until round 6).
+	                          // A ring is its block's alone and stays in that CU's L1 / the XCD's L2; the block barriers order its accesses like the LDS ring's
 	};
 
 template<int Q>
@@ -161,7 +164,7 @@ __global__ __launch_bounds__( MR_THREADS, 2 ) void k_synthesize_big( SynthParams
 	if( tid == 0 ) s_cancel = cancel_peek( p.cancel );
 	cf * s_tw = reinterpret_cast<cf*>( smem );
 	cf * bufA = s_tw + C2, * bufB = bufA + padded_len( C2 + 1 );
-	float * ring = reinterpret_cast<float*>( bufB + padded_len( C2 + 1 ) );            // [wpad]
+	float * ring = e.ring_ws ? e.ring_ws + ( int64_t( unit ) * chains + chain ) * wpad : reinterpret_cast<float*>( bufB + padded_len( C2 + 1 ) );   // [wpad]
 	for( int j = tid; j < C2; j += MR_THREADS ) s_tw[j] = p.tw[int64_t( j ) * C1];
 	for( int i = tid; i < wpad; i += MR_THREADS ) ring[i] = 0.0f;
 	BsTables tb{ s_tw, nullptr, nullptr };

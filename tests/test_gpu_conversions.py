@@ -177,6 +177,11 @@ CASES = [
     ("dft18432_c2_1024", 1, 30000, 2048, 512, 18432, "noise"),
     ("dft32768_sine", 1, 48000, 4096, 1024, 32768, "sine"),
     ("dft32768_one_frame", 1, 100, 4096, 1024, 32768, "noise"),
+    # ... with windows whose overlap-add ring does not fit the LDS beside the transforms (above ~14 k samples: the ring in the workspace, round 6) -- window = dft
+    # = 32768 at hop 8192 is the PaulStretch-style call
+    ("dft32768_win32768_hop8192", 1, 300000, 32768, 8192, 32768, "noise"),
+    ("dft65536_win20000_hop5000_stereo", 2, 150000, 20000, 5000, 65536, "noise"),
+    ("dft32768_win16384_hop1024", 1, 60000, 16384, 1024, 32768, "noise"),
     ("dft66", 1, 3000, 64, 16, 66, "noise"),
     ("dft6_win4", 1, 300, 4, 2, 6, "noise"),
     ("dft3000_sine", 1, 48000, 2048, 512, 3000, "sine"),
