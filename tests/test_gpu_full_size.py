@@ -111,6 +111,77 @@ def test_full_size_properties(name, ch, seconds, monkeypatch):
         assert bool(torch.equal(out_c.view(torch.int32), out2[c:c + 1].view(torch.int32)))
 
 
+@pytest.mark.parametrize("w,hop,dft,ch,seconds", [(512, 128, 512, 8, 600), (256, 64, 256, 8, 300), (8192, 2048, 8192, 8, 600), (4096, 1024, 16384, 8, 300)])
+def test_round6_kernel_families_at_full_size(w, hop, dft, ch, seconds):
+    """The kernels of round 6 (pv_kernels_sub.h: dft 512 / 256, several chains per wavefront; pv_kernels_team.h: dft 8192 / 16384, teams of wavefronts) on
+    long inputs (PVs of 3.7 - 7.4 GB, chains of hundreds of frames in several rounds), through size-independent properties: head parity against the oracle,
+    the PV bit for bit and the audio to re-association under another chain cut, per-channel calls == the all-channel call, and the analysis of the signal's
+    last 20 s as a signal of its own == the long run's last rows (the far end of every 32-bit offset)."""
+    import torch
+    import flan_amd as fa
+    lib = fa.lib
+    dev = torch.device("cuda", 0)
+    bins, ar = dft // 2 + 1, SR / hop
+    n = seconds * 48000
+    F = int(lib.flanhip_num_pv_frames(n, hop))
+    x = torch.empty((ch, n), dtype=torch.float32, device=dev)
+    fa.check(lib.flanhip_noise_dev(_p(x), ch, n, 777, None))
+    pv = torch.empty((ch, F, bins, 2), dtype=torch.float32, device=dev)
+    out = torch.empty((ch, F * hop), dtype=torch.float32, device=dev)
+    ws = torch.empty(fa.synthesize_workspace_bytes(ch, F, bins, SR, ar, w), dtype=torch.uint8, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    fa.analyze_dev(x, ch, n, SR, w, hop, dft, pv)
+    fa.synthesize_dev(pv, ch, F, bins, SR, ar, w, out, ws, flag)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0 and bool(torch.isfinite(out).all())
+    # ---- head parity (channel 0 and the last one)
+    K = 120
+    n_head = (K + 2 * (w // hop)) * hop
+    for c in (0, ch - 1):
+        x_head = x[c:c + 1, :n_head].cpu().numpy()
+        pv_ref = O.analyze(x_head, SR, w, hop, dft)[:, :K]
+        pv_got = pv[c:c + 1, :K].cpu().numpy()
+        m_r, m_g = pv_ref[..., 0].astype(np.float64), pv_got[..., 0].astype(np.float64)
+        rel_m = np.sqrt(np.sum((m_g - m_r) ** 2) / np.sum(m_r ** 2))
+        same_f = np.mean(pv_ref[..., 1].view(np.uint32) == pv_got[..., 1].view(np.uint32))
+        out_ref, _ = O.synthesize(pv_got, SR, np.float32(SR) / np.float32(hop), w)       # identical PV in (P2)
+        valid = (K - w // hop) * hop
+        rms = np.sqrt(np.mean((out[c, :valid].cpu().numpy().astype(np.float64) - out_ref[0, :valid]) ** 2))
+        print("\n[(%d, %d, %d) %d ch x %d s, ch %d] head P1 rel_m=%.2e  f bit-identical=%.4f   head P2 rms=%.2e" % (w, hop, dft, ch, seconds, c, rel_m, same_f, rms))
+        assert rel_m <= 1e-5 and same_f >= 0.95 and rms <= 1e-5
+    # ---- another chain cut
+    pv2 = torch.empty_like(pv)
+    out2 = torch.empty_like(out)
+    with fa.debug_options(chain_len=53):
+        ws53 = torch.empty(fa.synthesize_workspace_bytes(ch, F, bins, SR, ar, w), dtype=torch.uint8, device=dev)
+        fa.analyze_dev(x, ch, n, SR, w, hop, dft, pv2)
+        fa.synthesize_dev(pv2, ch, F, bins, SR, ar, w, out2, ws53, flag)
+    torch.cuda.synchronize()
+    assert bool(torch.equal(pv.view(torch.int32), pv2.view(torch.int32)))
+    dmax = float((out - out2).abs().max())
+    print("[(%d, %d, %d)] chain length 53 vs default: PV bit-identical, audio max |d| = %.2e" % (w, hop, dft, dmax))
+    assert dmax <= 5e-6
+    del pv2, out2, ws53
+    # ---- one channel alone == its rows of the all-channel call
+    for c in (0, ch - 1):
+        pv_c = torch.empty((1, F, bins, 2), dtype=torch.float32, device=dev)
+        fa.analyze_dev(x[c:c + 1], 1, n, SR, w, hop, dft, pv_c)
+        torch.cuda.synchronize()
+        assert bool(torch.equal(pv_c.view(torch.int32), pv[c:c + 1].view(torch.int32)))
+        del pv_c
+    # ---- the last 20 s as a signal of its own: its rows (past the frames whose windows reach back over its start) are the long run's last rows
+    tail_frames = (20 * 48000) // hop
+    start = (n // hop - tail_frames) * hop                     # (a multiple of the hop: the tail's frame t' is the long run's frame start / hop + t')
+    xt = x[:, start:].contiguous()
+    Ft = int(lib.flanhip_num_pv_frames(n - start, hop))
+    pvt = torch.empty((ch, Ft, bins, 2), dtype=torch.float32, device=dev)
+    fa.analyze_dev(xt, ch, n - start, SR, w, hop, dft, pvt)
+    torch.cuda.synchronize()
+    skip = w // hop + 2
+    assert F - (start // hop) == Ft
+    assert bool(torch.equal(pvt[:, skip:].contiguous().view(torch.int32), pv[:, start // hop + skip:].contiguous().view(torch.int32)))
+
+
 def test_repeated_runs_are_bit_identical():
     """the same buffers through the fused and the unfused round trip 40 times each: every PV and every output bit-identical to the
     first (no race between chains, no dependence on what an earlier step left in the workspace)"""
