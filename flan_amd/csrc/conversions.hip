@@ -479,7 +479,7 @@ static bool synth_fast_ok( int dft, int W, int hop ) { return synth_fast_kind( d
 // pair (a block = 8 one-wavefront chains of a channel), 4 for the dft 4096 team kernels (4 teams per block); 0: no group totals for this shape.
 static int self_carry_group( int dft, int W, int hop, int chains_per_channel )
 	{
-	if( sub_shape( dft, W, hop ) ) return 0;                                      // (pv_kernels_sub.h: carries from the scan kernel)
+	if( sub_shape( dft, W, hop ) ) return chains_per_channel < 128 ? 0 : sub_group_size( dft );   // (pv_kernels_sub.h: a block's 8 / 16 chains)
 	const int kind = synth_fast_kind( dft, W, hop );
 	int g = 0;
 	// the LDS-ring form of the dft 4096 team synthesis (any hop, any window up to 2048: four teams per block like the analysis) takes the totals too
@@ -568,7 +568,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 			p.nan_out = reinterpret_cast<int*>( reinterpret_cast<char*>( d_fused_ws ) + lay.carry_bytes + lay.head_bytes );
 			}
 		// the dft 2048 kernel (and the dft 4096 team kernel) also leaves one total per group of 8 (4) chains: the synthesis kernel then needs no scan kernel in front of it
-		const bool groups_too = fast && !sub && kernel_sums && self_carry_group( dft, W, hop, lay.chains_per_channel ) != 0;
+		const bool groups_too = ( fast || sub ) && kernel_sums && self_carry_group( dft, W, hop, lay.chains_per_channel ) != 0;
 		p.group_sums = groups_too ? reinterpret_cast<double*>( reinterpret_cast<char*>( d_fused_ws ) + lay.group_offset ) : nullptr;
 		p.groups_per_channel = lay.groups_per_channel;
 		*left_group_sums = groups_too;
@@ -698,7 +698,7 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	const int64_t chains = int64_t( o->chains_per_channel ) * ch;
 	o->carry_bytes = ( size_t( chains ) * bins * sizeof( double ) + 255 ) & ~size_t( 255 );
 	o->head_bytes = ( size_t( chains ) * o->head_len * sizeof( float ) + 255 ) & ~size_t( 255 );
-	const int gsize = o->any ? 8 : group_size_of( o->dft );        // self_carry_group
+	const int gsize = o->any ? 8 : sub ? sub_group_size( o->dft ) : group_size_of( o->dft );        // self_carry_group
 	o->groups_per_channel = ( o->chains_per_channel + gsize - 1 ) / gsize;
 	o->group_offset = o->carry_bytes + o->head_bytes + 1024;       // tail: NaN flag (4 B at +0), dump area (512 B at +512); then the group sums
 	o->group_bytes = ( size_t( ch ) * o->groups_per_channel * bins * sizeof( double ) + 255 ) & ~size_t( 255 );
@@ -838,8 +838,8 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 		p.groups_per_channel = lay.groups_per_channel;
 		const dim3 grid( (unsigned) ( ( bins + 255 ) / 256 ), (unsigned) lay.groups_per_channel, (unsigned) ch );
 		FLANHIP_REQUIRE( lay.groups_per_channel <= 65535 && ch <= 65535, FLANHIP_ERR_UNSUPPORTED, "too many groups / channels for one launch" );
-		if( sums_in_group_kernel ) { if( gsize == 8 ) hipLaunchKernelGGL( k_sums_and_groups<8>, grid, dim3( 256 ), 0, s, p, gs ); else hipLaunchKernelGGL( k_sums_and_groups<4>, grid, dim3( 256 ), 0, s, p, gs ); }
-		else if( gsize == 8 ) hipLaunchKernelGGL( k_group_sums<8>, grid, dim3( 256 ), 0, s, p, gs ); else hipLaunchKernelGGL( k_group_sums<4>, grid, dim3( 256 ), 0, s, p, gs );
+		if( sums_in_group_kernel ) { if( gsize == 16 ) hipLaunchKernelGGL( k_sums_and_groups<16>, grid, dim3( 256 ), 0, s, p, gs ); else if( gsize == 8 ) hipLaunchKernelGGL( k_sums_and_groups<8>, grid, dim3( 256 ), 0, s, p, gs ); else hipLaunchKernelGGL( k_sums_and_groups<4>, grid, dim3( 256 ), 0, s, p, gs ); }
+		else if( gsize == 16 ) hipLaunchKernelGGL( k_group_sums<16>, grid, dim3( 256 ), 0, s, p, gs ); else if( gsize == 8 ) hipLaunchKernelGGL( k_group_sums<8>, grid, dim3( 256 ), 0, s, p, gs ); else hipLaunchKernelGGL( k_group_sums<4>, grid, dim3( 256 ), 0, s, p, gs );
 		FLANHIP_CHECK( hipGetLastError() );
 		p.group_sums = gs;
 		const bool scan_groups = p.groups_per_channel > 40;

@@ -410,21 +410,43 @@ __global__ __launch_bounds__( 64 * WAVES, OCC ) void k_analyze_sub( AnalyzeParam
 			bad |= !( __builtin_fabs( sq ) <= 1.7976931348623157e308 );              // a NaN / Inf frequency poisons its sum
 			return ( __builtin_fabs( sq ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( sq ) : fold_phase_any( sq );
 			};
+		// ... to the workspace (what k_phase_sums2 would compute) and -- staged in this chain's now idle transform buffer -- into the block's total: one total
+		// per group of NCH chains lets the synthesis kernel work out its own carries from a scan over the GROUPS (an eighth / a sixteenth of the chains; none
+		// at all up to 40 groups per channel): see k_analyze_v2
 		double * dst = p.sums + chain * ( C + 1 );
+		double * stage = reinterpret_cast<double*>( buf );
 		#pragma unroll
 		for( int q = 0; q < H; ++q )
 			{
 			const double a = fold( sumk[q] ), b = fold( summ[q] );
 			if( active ) { dst[l + LP * q] = a; dst[C - l - LP * q] = b; }
+			stage[l + LP * q] = a; stage[C - l - LP * q] = b;
 			}
 		const double vx = fold( sumx );
 		if( active && l == 0 ) dst[C / 2] = vx;
+		if( l == 0 ) stage[C / 2] = vx;
 		bad = bad && active;
 		const bool any_bad = __any( bad );
 		if( p.nan_out && lane == 0 )
 			{
 			if( blockIdx.x == 0 && wave == 0 ) { p.nan_out[2] = p.nan_epoch; p.nan_out[4] = p.nan_epoch; }
 			if( any_bad ) p.nan_out[0] = p.nan_epoch;
+			}
+		if( p.group_sums )
+			{
+			__syncthreads();
+			const int live = min( NCH, p.chains_per_channel - group * NCH );          // chains of this block that are chains of the channel
+			double * gdst = p.group_sums + ( int64_t( channel ) * groups + group ) * ( C + 1 );
+			for( int bin = tid; bin <= C; bin += NT )
+				{
+				double run = 0.0;
+				for( int w = 0; w < live; ++w )
+					{
+					const double v = run + reinterpret_cast<const double*>( s + L::buf0( true ) + w * L::BUF_LEN )[bin];
+					run = ( __builtin_fabs( v ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_fast( v ) : fold_phase_any( v );
+					}
+				gdst[bin] = run;
+				}
 			}
 		}
 	}
@@ -507,6 +529,75 @@ __global__ __launch_bounds__( 64 * WAVES, OCC ) void k_synthesize_sub( SynthPara
 		};
 	// phase_buffer (AudioPV.cpp:105) on entry to the chain
 	double phk[H], phm[H], phx;
+	if( p.group_sums )
+		{
+		// No scan over the chains ran: `carry` still holds the chains' own sums.  The running phase on entry to a chain = the carry of its group (group_carry,
+		// from a scan over the group totals, or the totals of the groups before this one added up here) + the chains of this group before it, added and folded
+		// in order -- k_synthesize_v2's carry prologue with NCH chains per block: one thread per bin, every load ahead of the dependent additions; every chain's
+		// carries land in its (still idle) transform buffer
+		auto fold = []( double r ) { return ( __builtin_fabs( r ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_loop( r ) : fold_phase_any( r ); };
+		const double * gs = ( p.group_carry ? p.group_carry : p.group_sums ) + int64_t( channel ) * groups * ( C + 1 );
+		const double * sums0 = p.carry + ( int64_t( channel ) * p.chains_per_channel + int64_t( group ) * NCH ) * ( C + 1 );
+		const int live = min( NCH, p.chains_per_channel - group * NCH );
+		constexpr int NB = ( C + NT ) / NT;                                       // bins per thread
+		int bins_of[NB]; bool has[NB]; double run[NB];
+		#pragma unroll
+		for( int b = 0; b < NB; ++b ) { bins_of[b] = tid + NT * b; has[b] = bins_of[b] <= C; if( !has[b] ) bins_of[b] = C; run[b] = 0.0; }
+		double vc[NB][NCH];
+		#pragma unroll
+		for( int b = 0; b < NB; ++b )
+			{
+			#pragma unroll
+			for( int w = 0; w < NCH; ++w ) vc[b][w] = ( w < live ) ? sums0[int64_t( w ) * ( C + 1 ) + bins_of[b]] : 0.0;
+			}
+		if( p.group_carry )
+			{
+			#pragma unroll
+			for( int b = 0; b < NB; ++b ) run[b] = gs[int64_t( group ) * ( C + 1 ) + bins_of[b]];
+			}
+		else
+			{
+			for( int g0 = 0; g0 < group; g0 += 16 )
+				{
+				double v[NB][16];
+				#pragma unroll
+				for( int b = 0; b < NB; ++b )
+					{
+					#pragma unroll
+					for( int u = 0; u < 16; ++u ) v[b][u] = ( g0 + u < group ) ? gs[int64_t( g0 + u ) * ( C + 1 ) + bins_of[b]] : 0.0;
+					}
+				#pragma unroll
+				for( int u = 0; u < 16; ++u )
+					{
+					#pragma unroll
+					for( int b = 0; b < NB; ++b ) run[b] = fold( run[b] + v[b][u] );       // + 0.0 past the end: fold( x ) of a folded x is x
+					}
+				}
+			}
+		#pragma unroll
+		for( int w = 0; w < NCH; ++w )
+			{
+			#pragma unroll
+			for( int b = 0; b < NB; ++b )
+				{
+				if( has[b] ) reinterpret_cast<double*>( s + L::buf0( false ) + w * L::BUF_LEN )[bins_of[b]] = run[b];
+				run[b] = fold( run[b] + vc[b][w] );
+				}
+			}
+		if( tid == 0 && blockIdx.x == 0 )
+			{
+			if( p.nan_in && p.nan_flag && p.nan_in[0] == p.nan_in[2] && p.nan_in[2] != 0 ) atomicOr( p.nan_flag, 1 );
+			if( p.expect_epoch && p.nan_in && p.nan_flag && p.nan_in[2] != p.expect_epoch ) atomicOr( p.nan_flag, 2 );   // the sums in this workspace are not the noted producer's
+			if( p.skip_words ) const_cast<int*>( p.skip_words )[4] = 0;              // a handed-over pre-pass is good for one convert_to_audio
+			}
+		__syncthreads();
+		const double * mine = reinterpret_cast<const double*>( buf );
+		#pragma unroll
+		for( int q = 0; q < H; ++q ) { phk[q] = mine[l + LP * q]; phm[q] = mine[C - l - LP * q]; }
+		phx = mine[C / 2];
+		wave_sync();
+		}
+	else
 		{
 		const double * carry = p.carry + chain * ( C + 1 );
 		#pragma unroll

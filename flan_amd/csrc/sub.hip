@@ -25,6 +25,8 @@ bool sub_shape( int dft, int W, int hop )
 	return hq == 1 || hq == 2 || hq == 4 || hq == 8;
 	}
 
+int sub_group_size( int dft ) { return sub_lanes( dft ) ? kSubWaves * ( 64 / sub_lanes( dft ) ) : 0; }
+
 int sub_target_chains( int dft )
 	{
 	if( const int v = debug_options().target_chains ) { if( v > 0 ) return v; }
