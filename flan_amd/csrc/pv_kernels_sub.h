@@ -9,8 +9,10 @@
 // wavefront is data, not control: every group walks L + 1 (L) iterations; a channel's first chain has no halo frame (its halo iteration's phases are
 // replaced by zeros, AudioPV.cpp:44), its last chain may be short (its surplus iterations load clamped rows and store nothing), spare groups of a channel's
 // last wavefront repeat the last chain without storing.
-// Analysis: Conversions/AudioPV.cpp:12-78, phase_vocoder.cpp:37-52; synthesis: AudioPV.cpp:86-139, phase_vocoder.cpp:55-61.  Carries: k_phase_scan2 over
-// the chain sums (left by the fused analysis or k_phase_sums2); the chains' overlaps: k_ola_fixup4.
+// Analysis: Conversions/AudioPV.cpp:12-78, phase_vocoder.cpp:37-52; synthesis: AudioPV.cpp:86-139, phase_vocoder.cpp:55-61.  Carries: the analysis leaves chain
+// sums and one total per block (a group = the block's 8 / 16 chains), a scan over the GROUP totals gives every group's carry and the synthesis block's prologue
+// works out its chains' carries from that and the chain sums (k_synthesize_v2's form; a PV from elsewhere: k_sums_and_groups); few chains per channel: k_phase_scan2
+// over the chain sums.  The chains' overlaps: k_ola_fixup4.
 #pragma once
 #include "pv_kernels_v2.h"
 

@@ -13,16 +13,18 @@
 //   each of j = 1 .. R - 1 twice (bit-identical: the twiddle tables are exactly symmetric), j = 0 is DC / Nyquist;
 //   k = 512 is its own mirror: the R bins 512 + 1024 j.  Every wavefront leaves its E_r[512] in a ring of 64 frames in LDS, and once per 64 frames (and at
 //   the chain's end) wavefront r works off bin 512 + 1024 r of the whole batch, one frame per lane (k_analyze_v2 does the same with its bin C / 2).
-// One buffer set: two block barriers per frame (the transform uses its buffer as scratch).  Window and hop are multiples of 128 R samples (a sample pair per
-// lane and q-step: q < WQ = W / 128 R); the window is read from memory (L1 / L2: 16 sample pairs per lane do not fit the registers beside the state,
-// 32 KB do not fit the LDS of two blocks per CU).
+// One buffer set: two team meetings per frame (the transform uses its buffer as scratch).  Window and hop are multiples of 128 R samples (a sample pair per
+// lane and q-step: q < WQ = W / 128 R).  dft 8192: TWO teams per block share one set of tables and the window table, which is what makes room for the window
+// in LDS ([r][q][lane] pairs, up to 8192 samples) -- read through L2 at the end of the bins phase (first version) the window loads sat behind the frame's 16 MF
+// stores in the wavefront's memory queue, and the wait for them was a wait for the stores' acknowledgement; dft 16384: one team per block and the
+// block barrier; windows above 8192 samples are read from memory.
 //
 // Synthesis (AudioPV.cpp:86-139): the mirror image.  Per frame a wavefront runs the inverse phase vocoder on its 16 bins, merges the pairs into the
 // half-size spectrum Zc (conjugated), and leaves  A_r[k] = w^(r k) DFT_R( Zc[k + 1024 .] )[r]  (and the same at 1024 - k) in buffer r, every r; behind a
 // barrier wavefront r transforms A_r: output points g[R m + r], samples 2 ( R m + r ) (+1), windows them and overlap-adds into registers (WQ pairs per lane);
 // a finished hop leaves as HS = hop / 128 R stores of 8 bytes per lane.  Bin 512 + 1024 r is wavefront r's every frame (all lanes alike, one bin's
 // worth of arithmetic), the R spectrum values meet in LDS and every wavefront works out its own A_r[512].
-// Carries: from k_phase_scan2 (the chain sums from the fused analysis or from k_phase_sums2); overlaps of neighbouring chains: k_ola_fixup.
+// Carries: from k_phase_scan2 (the chain sums from the fused analysis or from k_phase_sums2); overlaps of neighbouring chains: k_ola_fixup4.
 #pragma once
 #include "pv_kernels_eo.h"
 

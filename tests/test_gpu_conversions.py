@@ -609,6 +609,50 @@ def test_random_shapes(fa, ch, n, W, hop, dft):
     assert rms <= 1e-5 * max(scale, 1.0)
 
 
+def _random_round6_shapes(count, seed):
+    """seeded shapes ON the grids of round 6's kernel families (pv_kernels_sub.h: dft 512 / 256, windows and hops multiples of 64 / 32 samples, hop 1 / 2 / 4 / 8
+    steps; pv_kernels_team.h: dft 8192 / 16384, windows of 4 / 8 / 16 steps of 512 / 1024 samples): ragged lengths from less than a hop to a few hundred frames,
+    1 - 6 channels, and a forced chain length in a third of them (short last chains, spare lane groups, chains of one frame)"""
+    rng = np.random.default_rng(seed)
+    shapes = []
+    for i in range(count):
+        dft = int(rng.choice([256, 512, 512, 8192, 16384]))
+        if dft <= 512:
+            step = dft // 8
+            hop = step * int(rng.choice([1, 2, 4, 8]))
+            W = step * int(rng.integers(max(hop // step, 1), 9))
+        else:
+            step = dft // 16
+            wq = int(rng.choice([4, 8, 16]))
+            hs = int(rng.choice([h for h in (1, 2, 4, 8) if h <= wq and (wq, h) in ((4, 1), (4, 2), (8, 1), (8, 2), (8, 4), (16, 2), (16, 4), (16, 8))]))
+            W, hop = wq * step, hs * step
+        ch = int(rng.integers(1, 7))
+        frames = int(rng.choice([1, 2, 3, 5, 17, 40, 90, 300])) if dft <= 512 else int(rng.choice([1, 2, 3, 9, 30, 70]))
+        n = max(int(frames * hop + rng.integers(-hop // 2, hop // 2 + 1)), 2)
+        chain_len = int(rng.choice([0, 0, 1, 3, 8, 33]))
+        shapes.append((ch, n, W, hop, dft, chain_len))
+    return shapes
+
+
+@pytest.mark.parametrize("ch,n,W,hop,dft,chain_len", _random_round6_shapes(40, 20261006), ids=lambda v: str(v))
+def test_random_shapes_of_the_round6_families(fa, ch, n, W, hop, dft, chain_len):
+    sr = 48000.0
+    x = O.noise(ch, n, seed=ch * 11 + W + hop)
+    ref = O.analyze(x, sr, W, hop, dft)
+    ar = np.float32(sr) / np.float32(hop)
+    out_ref, _ = O.synthesize(ref, sr, ar, W)
+    with fa.debug_options(chain_len=chain_len):
+        got = fa.analyze(x, sr, W, hop, dft)
+        out_got, flag = fa.synthesize(ref, sr, ar, W)
+    assert got.shape == ref.shape and out_got.shape == out_ref.shape and flag == 0
+    rel_m, wrms_f, same, turns = p1_metrics(got, ref, float(ar))
+    scale = max(float(np.sqrt(np.mean(out_ref.astype(np.float64) ** 2))), 1e-30)
+    rms = float(np.sqrt(np.mean((out_got.astype(np.float64) - out_ref.astype(np.float64)) ** 2)))
+    print("\n[round-6 random %s] P1 rel_m=%.2e wrms_df=%.2e same=%.4f  P2 rms=%.2e (signal rms %.2e)" % ((ch, n, W, hop, dft, chain_len), rel_m, wrms_f, same, rms, scale))
+    assert rel_m <= 1e-5 and wrms_f <= 2e-3 * max(sr / dft / 23.4, 1.0) and rms <= 1e-5 * max(scale, 1.0)
+    assert same >= 0.90
+
+
 def _random_smooth_shapes(count, seed):
     """seeded shapes for the mixed-radix kernels (pv_kernels_mr.h): dft = 2 C with C a product of 2, 3, 5, 7, 11, 13 (not a power of two), ping-pong
     and in-place sizes, plans with and without the large odd radices; windows up to the dft, hops up to beyond the window, ragged lengths"""
