@@ -373,4 +373,34 @@ __global__ __launch_bounds__( 512 ) void k_phase_scan2( SynthParams p )
 	if( !GROUPS && p.total_out && live && seg == SEG - 1 ) p.total_out[int64_t( channel ) * p.num_bins + k] = run;   // the running phase after the last chain
 	}
 
+// The same scan where a channel has FEW chains and a row has many bins (dft 8192 / 16384 team kernels: 64 / 32 chains per channel at 8 channels, 4097 / 8193
+// bins): one thread per ( channel, bin ) holds the whole column -- every chain sum requested before the first dependent addition, no LDS, no block barrier,
+// one trip to memory each way.  k_phase_scan2<16> took 25 us for the 64 x 4097 x 8 sums of (8192, 2048, 8192) (segments of 4 chains through LDS: two dependent
+// memory round trips per thread); this takes the bandwidth's time.  Plain scans only (no carry_in / total_out: frame-range sharding keeps k_phase_scan2).
+template<int MAXC>
+__global__ __launch_bounds__( 256 ) void k_phase_scan_flat( SynthParams p )
+	{
+	const int k = blockIdx.x * 256 + threadIdx.x, channel = blockIdx.y;
+	if( threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 )
+		{
+		if( p.nan_in && p.nan_flag && p.nan_in[0] == p.nan_in[2] && p.nan_in[2] != 0 ) atomicOr( p.nan_flag, 1 );
+		if( p.expect_epoch && p.nan_in && p.nan_flag && p.nan_in[2] != p.expect_epoch ) atomicOr( p.nan_flag, 2 );   // the sums in this workspace are not the noted producer's
+		if( p.skip_words ) const_cast<int*>( p.skip_words )[4] = 0;                // the sums become carries below: a handed-over pre-pass is good for one convert_to_audio
+		}
+	if( k >= p.num_bins ) return;
+	const int n = p.chains_per_channel;
+	double * c = p.carry + int64_t( channel ) * n * p.num_bins + k;
+	double held[MAXC];
+	#pragma unroll
+	for( int i = 0; i < MAXC; ++i ) held[i] = ( i < n ) ? c[int64_t( i ) * p.num_bins] : 0.0;
+	double run = 0.0;
+	#pragma unroll
+	for( int i = 0; i < MAXC; ++i )
+		{
+		if( i < n ) c[int64_t( i ) * p.num_bins] = run;                            // phase_buffer on entry to chain i
+		const double v = run + held[i];
+		run = ( __builtin_fabs( v ) < FLANHIP_FOLD_FAST_LIMIT ) ? fold_phase_loop( v ) : fold_phase_any( v );
+		}
+	}
+
 } // namespace flanhip
