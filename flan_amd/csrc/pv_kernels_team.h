@@ -212,9 +212,13 @@ __global__ __launch_bounds__( 64 * R * TEAMS, 2 ) void k_analyze_team( AnalyzePa
 			}
 		#pragma unroll
 		for( int q = WQ; q < 16; ++q ) z[q] = mk( 0.0f, 0.0f );
-		fft_fast<10>( z, mybuf, s_tw1, s_tw3, lane );
+		// (the lane number through an empty asm: the transform's lane-derived LDS addresses are loop invariants the compiler otherwise keeps -- and, at 256
+		// registers, spills: a scratch reload in here is a wait for the frame's MF stores)
+		const int lo = eo_opaque( lane );
+		fft_fast<10>( z, mybuf, s_tw1, s_tw3, lo );
+		const int padl_o = lo + ( lo >> 4 );
 		#pragma unroll
-		for( int q = 0; q < 16; ++q ) mybuf[padl + 68 * q] = z[q];                 // natural order: slot PAD( lane + 64 q )
+		for( int q = 0; q < 16; ++q ) mybuf[padl_o + 68 * q] = z[q];               // natural order: slot PAD( lane + 64 q )
 		if( lane == 0 )
 			{
 			mybuf[1088] = z[0];                                                    // E_r[1024] = E_r[0]: the k = 0 group's mirror
