@@ -705,10 +705,11 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	o->total_bytes = o->group_offset + 2 * o->group_bytes;             // the producer's group totals, then the group carries the synthesis' own scan over them leaves
 	// the dft 2048 / 1024 / 512 synthesis kernels add the overlaps of neighbouring chains themselves (pv_kernels_v2.h, _v3.h): a state word per chain and a second side buffer
 	o->fix_offset = o->tail_offset = 0;
-	if( !o->any && !mr && ( o->dft == 2048 || v3_size( o->dft ) ) && kind == 1 && o->head_len > 0 )
+	// (round 6: the dft 4096 team synthesis too, a word per WAVEFRONT of a chain: pv_kernels_eo.h)
+	if( ( team || ( !o->any && !mr && ( o->dft == 2048 || v3_size( o->dft ) || o->dft == 4096 ) && kind == 1 ) ) && o->head_len > 0 )
 		{
 		o->fix_offset = o->total_bytes;
-		o->tail_offset = o->fix_offset + ( ( size_t( chains ) * sizeof( int ) + 255 ) & ~size_t( 255 ) );
+		o->tail_offset = o->fix_offset + ( ( size_t( chains ) * 8 * sizeof( int ) + 255 ) & ~size_t( 255 ) );
 		o->total_bytes = o->tail_offset + o->head_bytes;
 		}
 	o->any_spec_offset = o->any_frames_offset = 0;
@@ -781,7 +782,7 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	p.skip_words = presummed == 2 ? p.nan_in : nullptr;
 	p.carry_in = d_carry_in; p.total_out = d_total_out; p.total_only = prepass_only ? 1 : 0;
 	p.cancel = thread_cancel_word( s );
-	// the dft 2048 synthesis kernel adds the chains' overlaps itself where its chains are long enough to publish their heads from inside the frame
+	// the register-accumulator synthesis kernels (dft 512 ... 16384 on their grids) add the chains' overlaps themselves where their chains are long enough to publish their heads from inside the frame
 	// loop (round 5: -2 % of the bench shape's step, -6 % of the stereo minute's; chains of a few frames would publish at their ends and pay
 	// the exchange there: +8 % at 1 ch x 5 s, so those keep k_ola_fixup as a launch of its own).  FLANHIP_DEBUG_INLINE_FIXUP: 1 always, 2 never.
 	const int fix_hook = debug_options().inline_fixup;

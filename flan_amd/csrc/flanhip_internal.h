@@ -106,7 +106,7 @@ int next_epoch();
 // (channel, group, bin) behind the 1024-byte tail -- what lets the synthesis kernel compute its own carries (no scan kernel)
 struct SynthLayout { int hop, dft, L, chains_per_channel, head_len, groups_per_channel; size_t carry_bytes, head_bytes, group_offset, group_bytes, total_bytes;
 	size_t flags_offset;              // bins + 1 words for a producer's own notes (PV::modify_time: which columns of the time map run backwards)
-	size_t fix_offset, tail_offset;   // k_synthesize_v2's own overlap fix-up: a state word per chain, then a second side buffer the size of the heads' (0: not this shape)
+	size_t fix_offset, tail_offset;   // the synthesis kernels' own overlap fix-up: eight state words per chain (one per wavefront of a team), then a second side buffer the size of the heads' (0: not this shape)
 	bool any; size_t any_spec_offset, any_frames_offset;      // any: a dft size without FFT kernels (pv_kernels_any.h) and its scratch in the workspace
 	bool big; size_t big_out_offset, big_head_offset, big_ring_offset; };      // big: a dft size above 16384 served by pv_kernels_big.h; its units' partial output streams and heads
 // which producer last left its pre-pass in a synthesis workspace (host-side note, keyed by the workspace pointer, written when the

@@ -312,7 +312,7 @@ struct SynthParams
 	double * group_carry;      // carries from that and the chain sums in `carry` (which it leaves untouched): the scan over the chains is not launched
 	// k_synthesize_v2 adding the chains' overlaps itself (no k_ola_fixup launch, round 4): one state word per boundary, a side buffer for a
 	// chain's LAST partial sums beside `head` (its first ones), this launch's tag
-	int * fix_state;           // optional [chains]: word c belongs to the boundary between chain c - 1 and chain c of a channel
+	int * fix_state;           // optional [chains] (team kernels: [chains][wavefronts of a team]): word c belongs to the boundary between chain c - 1 and chain c of a channel
 	float * tail;              // [ch][chains][W-hop]
 	int fix_tag;               // ( epoch << 2 ): | 1 = the boundary's tail is in `tail`, | 2 = its head is in `head`
 	};

@@ -480,6 +480,96 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_analyze_eo_team( AnalyzeParam
 // HS = -1 (round 5): ANY hop <= window and any window -- the overlap-add accumulator is a ring of W floats per team in LDS instead of registers (one A / B
 // buffer set: the ring takes the second set's place; windows above 2048: three teams per block).  Both wavefronts add their windowed halves into the
 // ring, meet, and between that meeting and the next (the one that guards the A / B buffers anyway) send off and clear the hop samples that are final.
+// One wavefront's side of the chains' overlaps added inside a team synthesis kernel instead of by k_ola_fixup4 (round 6; k_synthesize_v2's protocol, whose
+// words explain it: a tagged word per boundary, written by atomic exchange; the head's owner says so from inside its frame loop once the head's last store
+// has been issued, behind a drained queue; the tail's owner looks a frame before its end and adds the head to its accumulator as it leaves, or deposits the
+// tail; whoever finds the other side's tag adds -- tail + head, one addition per sample, k_ola_fixup4's bits).  Every WAVEFRONT of a team runs it for its own
+// part of a boundary -- the samples STEP q + jl (+1) behind it, q < WQ, the same set in the tail's owner and in the head's -- under a word of its own
+// (word wpc chain + role), so the team never meets over it.
+template<int WQ, int STEP>
+struct ChainOverlap
+	{
+	bool on, has_head, has_tail, published;
+	int tag_tail, tag_head;
+	int * word_h, * word_t;
+	int old_h, seen_t;                                                          // (lane 0's: what the head word held before this chain's tag; what the tail word holds)
+	__device__ __forceinline__ void init( const SynthParams & p, bool active, int64_t chain, int wpc, int role, bool first_chain, bool last_chain )
+		{
+		on = active && p.fix_state != nullptr;
+		has_head = !first_chain; has_tail = !last_chain; published = false;
+		tag_tail = p.fix_tag | 1; tag_head = p.fix_tag | 2;
+		word_h = p.fix_state + ( wpc * chain + role ); word_t = p.fix_state + ( wpc * ( chain + 1 ) + role );      // (used under `on` only)
+		old_h = 0; seen_t = 0;
+		}
+	// behind frame i of `frames`, its stores issued: head_done = every store of the chain's head has been issued
+	__device__ __forceinline__ void after_frame( int i, int frames, bool head_done, int lane )
+		{
+		if( !on ) return;
+		if( has_tail && i == frames - 2 && lane == 0 ) seen_t = __hip_atomic_load( word_t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+		if( has_head && !published && head_done )
+			{
+			publish_drain();
+			if( lane == 0 ) old_h = __hip_atomic_exchange( word_h, tag_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+			asm volatile( "" ::: "memory" );
+			published = true;
+			}
+		}
+	// the end of the chain (a channel's last chain: behind its flush).  acc: the partial sums of the W - hop samples from `pos` on
+	__device__ __forceinline__ void finish( const SynthParams & p, const cf ( & acc )[WQ], int jl, int64_t chain, int64_t chain_start, int64_t pos, cf * out2, int lane )
+		{
+		if( !on ) return;
+		if( has_head && !published )
+			{
+			// a chain too short to have published from its loop (a channel's last): now, behind a drained queue
+			asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+			if( lane == 0 ) old_h = __hip_atomic_exchange( word_h, tag_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+			}
+		if( has_tail )
+			{
+			// this chain's tail meets the next chain's head
+			const cf * head_next = reinterpret_cast<const cf*>( p.head + ( chain + 1 ) * p.head_len );
+			cf * tail_next = reinterpret_cast<cf*>( p.tail + ( chain + 1 ) * p.head_len );
+			bool add = __builtin_amdgcn_readfirstlane( seen_t ) == tag_head;         // the neighbour's head was complete a frame ago
+			if( !add )
+				{
+				// not yet: leave the tail where the neighbour will find it, BEHIND a drained queue, and say so; if its tag has appeared meanwhile the addition is ours after all
+				#pragma unroll
+				for( int q = 0; q < WQ; ++q ) { const int j = STEP * q + jl; if( j < p.head_len ) st_agent( tail_next + ( j >> 1 ), acc[q] ); }
+				asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+				int old = 0;
+				if( lane == 0 ) old = __hip_atomic_exchange( word_t, tag_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT );
+				add = __builtin_amdgcn_readfirstlane( old ) == tag_head;
+				}
+			if( add )
+				{
+				#pragma unroll
+				for( int q = 0; q < WQ; ++q )
+					{
+					const int j = STEP * q + jl;
+					const int64_t a = pos + j;
+					if( j < p.head_len && a >= 0 && a < p.out_len )
+						{
+						const cf h = ld_agent( head_next + ( j >> 1 ) );
+						out2[a >> 1] = mk( acc[q].x + h.x, acc[q].y + h.y );
+						}
+					}
+				}
+			}
+		if( has_head && __builtin_amdgcn_readfirstlane( old_h ) == tag_tail )
+			{
+			// this chain's head meets the previous chain's tail, which was there when the head's tag went out
+			const cf * tl = reinterpret_cast<const cf*>( p.tail + chain * p.head_len );
+			const cf * hd = reinterpret_cast<const cf*>( p.head + chain * p.head_len );
+			for( int j = jl; j < p.head_len; j += STEP )
+				{
+				const cf t = ld_agent( tl + ( j >> 1 ) ), h = ld_agent( hd + ( j >> 1 ) );
+				const int64_t a = chain_start + j;
+				if( a >= 0 && a < p.out_len ) out2[a >> 1] = mk( t.x + h.x, t.y + h.y );
+				}
+			}
+		}
+	};
+
 template<int TEAMS, int HS, bool WBIG = false>                               // HS = hop / 256; 0: hop 128; -1: any hop, ring accumulator
 __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthParams p, FastTables tb )
 	{
@@ -542,6 +632,10 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 	const int padl = lane + ( lane >> 4 );
 	const int mir = ( C * 17 ) / 16 - ( lane + ( ( lane + 15 ) >> 4 ) );
 	const int k0 = lane + 256 * role;                                           // k of this wavefront's first quad
+	// the chains' overlaps added here (ChainOverlap above): the register forms only, where the workspace holds the words (p.fix_state)
+	ChainOverlap<WBIG ? 16 : 8, 256> ov;
+	ov.init( p, !RING && active, chain, 2, role, chain_in_channel == 0, last_chain );
+	const bool fix = ov.on;
 
 	// running phases (AudioPV.cpp:105) on entry to the chain: [q][0..3] = bins k, 2048-k, 1024-k, 1024+k; the odd wavefront also 512, 1536
 	double ph[Q][4], phs[2] = { 0.0, 0.0 };
@@ -569,15 +663,20 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 		const int64_t a = a0 + 4 * lane + 2 * role;
 		cf * dst = ( a0 < own_start ) ? head2 + ( ( a - chain_start ) >> 1 ) : out2 + ( a >> 1 );
 		if( a0 >= own_start && !( a >= 0 && a < p.out_len ) ) dst = dump2;
-		*dst = v;
+		if( fix && a0 < own_start ) st_agent( dst, v );                          // (the head another wavefront may come to add up: the end of the kernel)
+		else *dst = v;
 		};
 	// hop 128: one 128-sample half step -- the lanes 32 part .. 32 part + 31 of v hold samples a0 + 4 ( lane & 31 ) + 2 role (+1); the other lanes dump
 	auto emit_half = [&]( int64_t a0, cf v, int part )
 		{
 		const int64_t a = a0 + 4 * ( lane & 31 ) + 2 * role;
 		cf * dst = ( a0 < own_start ) ? head2 + ( ( a - chain_start ) >> 1 ) : out2 + ( a >> 1 );
-		if( ( lane >> 5 ) != part || ( a0 >= own_start && !( a >= 0 && a < p.out_len ) ) ) dst = dump2;
-		*dst = v;
+		const bool idle = ( lane >> 5 ) != part;
+		if( idle || ( a0 >= own_start && !( a >= 0 && a < p.out_len ) ) ) dst = dump2;
+		// (the head at agent scope -- but never the idle half's stores into the dump area: 32 lanes of every wavefront writing ONE line through to memory
+		// made the hop 128 launch twice as long)
+		if( fix && a0 < own_start ) { if( !idle ) st_agent( dst, v ); }
+		else *dst = v;
 		};
 	auto rotate_half = []( float a, float b, bool low ) -> float          // lanes 0..31 <- a's lanes 32..63, lanes 32..63 <- b's lanes 0..31
 		{
@@ -934,7 +1033,11 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 				#pragma unroll
 				for( int q = 0; q < WQ; ++q ) acc[q] = ( q + HS < WQ ) ? acc[q + HS] : mk( 0.0f, 0.0f );
 				}
-			if constexpr( !RING ) pos += hop;
+			if constexpr( !RING )
+				{
+				pos += hop;
+				ov.after_frame( i, frames, pos >= own_start, lane );
+				}
 			}
 		// one buffer set: nobody may write the next frame's A / B before both wavefronts have transformed this one's (the transform uses its
 		// buffer as scratch).  Two sets: the next frame goes to the other set
@@ -963,6 +1066,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 		ring_emit( pos, W - hop );
 		for( int64_t a = ring_end + lane + 64 * role; a < flush_end; a += 128 ) if( a >= 0 && a < p.out_len ) out1[a] = 0.0f;
 		}
+	else if( fix && !last_chain ) {}                                             // (the tail meets the next chain's head below)
 	else if constexpr( HS == 0 )
 		{
 		// W - hop = 1920 (3968) samples = 7.5 (15.5) steps: by halves (the next chain writes from ring_end on itself)
@@ -984,6 +1088,7 @@ __global__ __launch_bounds__( 128 * TEAMS ) void k_synthesize_eo_team( SynthPara
 			}
 		for( int64_t a0 = pos + 256 * WQ; a0 < flush_end; a0 += 256 ) emit_step( a0, mk( 0.0f, 0.0f ) );
 		}
+	if constexpr( !RING ) ov.finish( p, acc, 4 * lane + 2 * role, chain, chain_start, pos, out2, lane );
 	}
 
 } // namespace flanhip

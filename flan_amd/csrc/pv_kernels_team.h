@@ -487,13 +487,18 @@ __global__ __launch_bounds__( 64 * R * TEAMS, 2 ) void k_synthesize_team( SynthP
 	#pragma unroll
 	for( int q = 0; q < WQ; ++q ) acc[q] = mk( 0.0f, 0.0f );
 
+	// the chains' overlaps added here (ChainOverlap, pv_kernels_eo.h): a word per wavefront of a chain, where the workspace holds them (p.fix_state)
+	ChainOverlap<WQ, STEP> ov;
+	ov.init( p, true, chain, R, role, chain_in_channel == 0, last_chain );
+	const bool fix = ov.on;
 	cf * dump2 = reinterpret_cast<cf*>( p.dump ) + lane;
 	auto emit_step = [&]( int64_t a0, cf v )
 		{
 		const int64_t a = a0 + 2 * R * lane + 2 * role;
 		cf * dst = ( a0 < own_start ) ? head2 + ( ( a - chain_start ) >> 1 ) : out2 + ( a >> 1 );
 		if( a0 >= own_start && !( a >= 0 && a < p.out_len ) ) dst = dump2;
-		*dst = v;
+		if( fix && a0 < own_start ) st_agent( dst, v );                          // (the head another wavefront may come to add up)
+		else *dst = v;
 		};
 	cf mf[KQ][NB], mfo;
 	auto load_row = [&]( int64_t t )
@@ -681,6 +686,7 @@ __global__ __launch_bounds__( 64 * R * TEAMS, 2 ) void k_synthesize_team( SynthP
 		#pragma unroll
 		for( int q = 0; q < WQ; ++q ) acc[q] = ( q + HS < WQ ) ? acc[q + HS] : mk( 0.0f, 0.0f );
 		pos += hop;
+		ov.after_frame( i, frames, pos >= own_start, lane );
 		team_sync.meet();                                                       // nobody writes the next frame's A_r before everybody has transformed this one's
 		if( i + 1 < frames ) { bins_of_row(); load_window(); }
 		team_sync.meet();                                                       // the next frame's A_r are written
@@ -688,13 +694,17 @@ __global__ __launch_bounds__( 64 * R * TEAMS, 2 ) void k_synthesize_team( SynthP
 	// flush the partial sums that the next chain's head completes; the last chain zero-fills to the end of the output
 	const int64_t ring_end = pos + ( W - hop );
 	const int64_t flush_end = last_chain ? max( ring_end, p.out_len ) : ring_end;
-	#pragma unroll
-	for( int q = 0; q < WQ; ++q )
+	if( !fix || last_chain )
 		{
-		const int64_t a0 = pos + STEP * q;
-		if( a0 < flush_end ) emit_step( a0, acc[q] );
+		#pragma unroll
+		for( int q = 0; q < WQ; ++q )
+			{
+			const int64_t a0 = pos + STEP * q;
+			if( a0 < flush_end ) emit_step( a0, acc[q] );
+			}
+		for( int64_t a0 = pos + STEP * WQ; a0 < flush_end; a0 += STEP ) emit_step( a0, mk( 0.0f, 0.0f ) );
 		}
-	for( int64_t a0 = pos + STEP * WQ; a0 < flush_end; a0 += STEP ) emit_step( a0, mk( 0.0f, 0.0f ) );
+	ov.finish( p, acc, 2 * R * lane + 2 * role, chain, chain_start, pos, out2, lane );
 	}
 
 } // namespace flanhip

@@ -170,7 +170,7 @@ int flanhip_synthesize_dev_stages(const flanhip_MF * d_pv, int64_t num_channels,
                                            * for float streams of at least 8 blocks); 2: the convolver's 256-thread radix-16 generation (A/B predecessor) */
 #define FLANHIP_DEBUG_FORCE_DIRECT    9   /* 1: dft sizes without power-of-two kernels as direct fp64 sums (the transform's definition: pv_kernels_any.h),
                                            * never the mixed-radix FFT kernels (pv_kernels_mr.h): the checker-order path, for A/B */
-#define FLANHIP_DEBUG_INLINE_FIXUP   10   /* the dft 2048 synthesis kernel adding the overlaps of neighbouring chains itself (a tagged word per boundary, the
+#define FLANHIP_DEBUG_INLINE_FIXUP   10   /* the dft 512 ... 16384 synthesis kernels adding the overlaps of neighbouring chains themselves (a tagged word per boundary, the
                                            * head's owner publishing from inside its frame loop; agent-scope side buffers) instead of k_ola_fixup in a launch of
                                            * its own -- the same sums.  0: where the chains are long enough (the default), 1: always, 2: never */
 #define FLANHIP_DEBUG_WIDE_OFFSETS   11   /* 1: kernels that choose 32-bit element offsets for grids below 2^30 elements (k_stretch_map) take their 64-bit

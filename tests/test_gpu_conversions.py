@@ -1033,6 +1033,24 @@ def test_plan_caches_are_bounded_and_evicted_sizes_come_back(fa):
     (3, 9, 768, 512, {"dft": 1024, "chain_len": 3}),
     (8, 30, 512, 128, {"dft": 512}),
     (2, 9, 512, 256, {"dft": 512, "chain_len": 4}),
+    # the dft 4096 team kernel (pv_kernels_eo.h, round 6): a word per wavefront of a chain; hop 128 (half steps), 256 .. 1024, windows up to the transform
+    (2, 60, 2048, 128, {"dft": 4096}),
+    (8, 20, 2048, 512, {"dft": 4096}),
+    (3, 9, 2048, 256, {"dft": 4096, "chain_len": 8}),
+    (2, 9, 1024, 1024, {"dft": 4096, "chain_len": 1}),
+    (2, 9, 2048, 1024, {"dft": 4096, "chain_len": 2}),
+    (5, 13, 4096, 1024, {"dft": 4096}),
+    (2, 7, 4096, 128, {"dft": 4096}),
+    (3, 5, 3072, 512, {"dft": 4096, "chain_len": 6}),
+    (2, 5, 1536, 512, {"dft": 4096, "chain_len": 2}),
+    # the dft 8192 / 16384 team kernels (pv_kernels_team.h): a word per wavefront of a chain, four or eight of them
+    (8, 20, 8192, 2048, {"dft": 8192}),
+    (2, 30, 4096, 512, {"dft": 8192, "chain_len": 8}),
+    (2, 20, 2048, 512, {"dft": 8192, "chain_len": 3}),
+    (3, 11, 8192, 4096, {"dft": 8192, "chain_len": 1}),
+    (3, 30, 16384, 4096, {"dft": 16384}),
+    (2, 30, 4096, 1024, {"dft": 16384, "chain_len": 4}),
+    (2, 20, 8192, 1024, {"dft": 16384}),
 ])
 def test_overlap_fixup_inside_the_kernel_equals_the_separate_launch(fa, ch, seconds, W, hop, hooks):
     """k_synthesize_v2 adds the overlaps of neighbouring chains itself (a tagged word per boundary; the head's owner publishes from inside its frame
@@ -1073,7 +1091,8 @@ def test_overlap_fixup_inside_the_kernel_equals_the_separate_launch(fa, ch, seco
 
 
 
-@pytest.mark.parametrize("ch,seconds,W,hop,dft", [(2, 20.0, 2048, 512, 2048), (3, 7.3, 2048, 512, 2048), (5, 11.1, 1024, 512, 1024), (4, 20.0, 2048, 1024, 2048)])
+@pytest.mark.parametrize("ch,seconds,W,hop,dft", [(2, 20.0, 2048, 512, 2048), (3, 7.3, 2048, 512, 2048), (5, 11.1, 1024, 512, 1024), (4, 20.0, 2048, 1024, 2048),
+                                                    (2, 30.0, 2048, 128, 4096), (3, 9.0, 4096, 1024, 4096), (2, 30.0, 8192, 2048, 8192), (2, 30.0, 4096, 1024, 16384)])
 def test_overlap_protocol_soak_on_two_streams(fa, ch, seconds, W, hop, dft):
     """The chains' overlaps added inside the synthesis kernels (pv_kernels_v2.h / _v3.h: a tagged word per boundary, the head's owner publishing from inside
     its frame loop behind an explicit drain, the tail's owner adding or depositing) rest on in-order retirement and agent-scope stores across the XCDs' private
