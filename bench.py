@@ -829,12 +829,14 @@ def other_configs(fa, torch, dev):
     # ... and the power-of-two sizes below the metric's: ( 1024, 256, 1024 ) -- the classic setting -- (pv_kernels_v3.h, round 5), ( 512, 128, 512 ) and ( 256, 64, 256 )
     # (pv_kernels_sub.h, round 6: several chains per wavefront)
     # ... and two sizes FFTW plans like any other (FFTHelper.cpp:16-26): ( 2048, 512, 2998 ), half the size 1499 a prime (Bluestein's chirp-z form,
-    # pv_kernels_bs.h), and ( 4096, 1024, 32768 ) (residue pairs, pv_kernels_big.h: a 2.95 GB PV) -- both direct sums until round 5
+    # pv_kernels_bs.h), and ( 4096, 1024, 32768 ) (residue pairs, pv_kernels_big.h: a 2.95 GB PV) -- both direct sums until round 5; ( 4096, 1024, 20000 ): the
+    # residue pairs with a mixed-radix inner transform (20000 = 2 x 4 x 2500; round 6, direct sums before)
     for (hop, tag, Wd, dft) in ((128, "api_default_2048_128_4096", 2048, 4096), (512, "dft4096_hop512", 2048, 4096), (1024, "window4096_hop1024_dft4096", 4096, 4096),
                                 (256, "dft1024_window1024_hop256", 1024, 1024), (128, "dft512_window512_hop128", 512, 512), (64, "dft256_window256_hop64", 256, 256),
                                 # ... and dft 8192 / 16384: teams of four / eight wavefronts per chain (pv_kernels_team.h, round 6; before: the round-1 block kernels 0.92 ms, mixed radix 4.4 ms)
                                 (2048, "dft8192_window8192_hop2048", 8192, 8192), (1024, "dft16384_window4096_hop1024", 4096, 16384),
-                                (512, "dft2998_window2048_hop512_chirp_z", 2048, 2998), (1024, "dft32768_window4096_hop1024", 4096, 32768)):
+                                (512, "dft2998_window2048_hop512_chirp_z", 2048, 2998), (1024, "dft32768_window4096_hop1024", 4096, 32768),
+                                (1024, "dft20000_window4096_hop1024_mixed_radix", 4096, 20000)):
         bins = dft // 2 + 1
         Fd = int(lib.flanhip_num_pv_frames(n, hop))
         ard = SR / hop

@@ -56,16 +56,46 @@ inline bool bs_make_plan( int dft, BsPlan * out )
 	return true;
 	}
 
-// ---- sizes above 16384 (pv_kernels_big.h): half the size C = C1 x C2, C2 = the largest power of two in it up to 4096 (at least 1024), C1 <= 256 -------
-constexpr int BIG_MAX_C1 = 256, BIG_MIN_C2 = 1024, BIG_MAX_C2 = 4096;
+// ---- sizes above 16384 (pv_kernels_big.h): half the size C = C1 x C2, C1 <= 256 residues of a C2-point transform in LDS ---------------------------------
+// C2 = the largest power of two in C up to 4096 where that is at least 1024 and leaves C1 <= 256 (32768, 65536, 24576 ...: radix 8 / 4 / 2 passes, the
+// round-5 kernels); otherwise (round 6: 20000 = 2 x 2^4 5^4, 44100, 48000, 100000 ...) the largest divisor of C between 256 and 4096 that is a product of
+// 2 ... 13 and leaves 2 <= C1 <= 256 -- the same kernels with pv_kernels_mr.h's odd-radix passes (`mixed`).  Sizes whose half has no such divisor (a prime
+// factor above 13 in every one: 2 x 10007 ...) stay on the direct sums.
+constexpr int BIG_MAX_C1 = 256, BIG_MIN_C2 = 1024, BIG_MAX_C2 = 4096, BIG_MIN_C2_MIXED = 256, BIG_MAX_PASSES = 12;
+
+struct BigFft
+	{
+	int M, npass;
+	unsigned char radix[BIG_MAX_PASSES];         // C2 = product; 8 / 4 / 2, then 13 / 11 / 7 / 5 / 3
+	unsigned magic[BIG_MAX_PASSES];              // (MrPlan::magic, ::stride)
+	unsigned short stride[BIG_MAX_PASSES];
+	};
 
 struct BigPlan
 	{
 	int C, C1, C2, P;        // P = C1 / 2 + 1 units per chain
 	int N1;                  // segments of C2 complex points the window reaches into ( ceil( ceil( W / 2 ) / C2 ) )
 	int limit;               // complex points of a segment that can be non-zero ( min( C2, ceil( W / 2 ) ) )
-	BsPlan fft;              // the C2-point transform's passes ( M = C2 )
+	int mixed;               // C2 is no power of two: odd-radix passes, bins guarded ( C2 < 512 Q ); 2: a radix 11 or 13 among them (an instantiation of their own)
+	BigFft fft;              // the C2-point transform's passes
 	};
+
+inline bool big_fft_plan( int C2, BigFft * f )
+	{
+	*f = BigFft{};
+	f->M = C2;
+	int rest = C2, n = 0;
+	auto take = [&]( int r ) { while( rest % r == 0 && n < BIG_MAX_PASSES ) { f->radix[n++] = (unsigned char) r; rest /= r; } };
+	take( 8 ); take( 4 ); take( 2 ); take( 13 ); take( 11 ); take( 7 ); take( 5 ); take( 3 );
+	if( rest != 1 ) return false;
+	f->npass = n;
+	for( int i = 0, NS = 1; i < n; NS *= f->radix[i], ++i )
+		{
+		f->magic[i] = NS > 1 ? unsigned( ( uint64_t( 1 ) << 32 ) / unsigned( NS ) ) + 1u : 0u;
+		f->stride[i] = (unsigned short) ( C2 / ( NS * f->radix[i] ) );
+		}
+	return true;
+	}
 
 inline bool big_make_plan( int dft, int W, BigPlan * out )
 	{
@@ -73,26 +103,25 @@ inline bool big_make_plan( int dft, int W, BigPlan * out )
 	const int C = dft / 2;
 	int C2 = 1;
 	while( C % ( C2 * 2 ) == 0 && C2 * 2 <= BIG_MAX_C2 ) C2 *= 2;
-	if( C2 < BIG_MIN_C2 ) return false;
+	bool mixed = false;
+	if( C2 < BIG_MIN_C2 || C / C2 > BIG_MAX_C1 )
+		{
+		mixed = true;
+		C2 = 0;
+		for( int d = BIG_MAX_C2; d >= BIG_MIN_C2_MIXED; --d )
+			if( C % d == 0 && C / d >= 2 && C / d <= BIG_MAX_C1 && bs_has_small_factors_only( d ) ) { C2 = d; break; }
+		if( !C2 ) return false;
+		}
 	const int C1 = C / C2;
 	if( C1 < 2 || C1 > BIG_MAX_C1 ) return false;
 	BigPlan pl{};
 	pl.C = C; pl.C1 = C1; pl.C2 = C2; pl.P = C1 / 2 + 1;
+	pl.mixed = mixed ? 1 : 0;
+	if( mixed && ( C2 % 11 == 0 || C2 % 13 == 0 ) ) pl.mixed = 2;
 	const int half = ( W + 1 ) / 2;
 	pl.N1 = ( half + C2 - 1 ) / C2;
 	pl.limit = half < C2 ? half : C2;
-	BsPlan & f = pl.fft;
-	f.C = C2; f.M = C2; f.sign_c = 1.0f; f.win_lds = 0;
-	int rest = C2, n = 0;
-	auto take = [&]( int r ) { while( rest % r == 0 && n < BS_MAX_PASSES ) { f.radix[n++] = (unsigned char) r; rest /= r; } };
-	take( 8 ); take( 4 ); take( 2 );
-	if( rest != 1 ) return false;
-	f.npass = n;
-	for( int i = 0, NS = 1; i < n; NS *= f.radix[i], ++i )
-		{
-		f.magic[i] = NS > 1 ? unsigned( ( uint64_t( 1 ) << 32 ) / unsigned( NS ) ) + 1u : 0u;
-		f.stride[i] = (unsigned short) ( C2 / ( NS * f.radix[i] ) );
-		}
+	if( !big_fft_plan( C2, &pl.fft ) ) return false;
 	*out = pl;
 	return true;
 	}

@@ -104,8 +104,8 @@ static int bs_target_chains( int dft, int W )
 	return cu_count() * std::max( 1, bs_blocks_per_cu( pl, W ) );
 	}
 
-// ... and the sizes above 16384 the residue-pair kernels serve (pv_kernels_big.h): half the size = C1 x C2 with C2 = 1024 ... 4096 a power of two,
-// C1 <= 256, the synthesis' ring within what the two transforms leave of a CU's LDS
+// ... and the sizes above 16384 the residue-pair kernels serve (pv_kernels_big.h): half the size = C1 x C2 with C2 = 1024 ... 4096 a power of two, or
+// (round 6) any product of 2 ... 13 between 256 and 4096, C1 <= 256 (bs_plan.h: big_make_plan)
 static bool big_size( int dft, int W, BigPlan * pl = nullptr )
 	{
 	BigPlan t;
@@ -621,7 +621,10 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 		const int64_t blocks = big_blocks( int64_t( p.chains_per_channel ) * ch, big_plan.P );
 		FLANHIP_REQUIRE( blocks < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
 		const size_t lds = big_analyze_lds( big_plan.C2 );
-		auto kern = big_plan.C2 == 4096 ? k_analyze_big<8> : big_plan.C2 == 2048 ? k_analyze_big<4> : k_analyze_big<2>;
+		const int bq = ( big_plan.C2 + MR_THREADS - 1 ) / MR_THREADS;                 // bins of a residue per thread
+		auto kern = big_plan.mixed == 2 ? ( bq > 4 ? k_analyze_big<8, 2> : bq > 2 ? k_analyze_big<4, 2> : k_analyze_big<2, 2> )
+			: big_plan.mixed ? ( bq > 4 ? k_analyze_big<8, 1> : bq > 2 ? k_analyze_big<4, 1> : k_analyze_big<2, 1> )
+			: big_plan.C2 == 4096 ? k_analyze_big<8> : big_plan.C2 == 2048 ? k_analyze_big<4> : k_analyze_big<2>;
 		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 		hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( MR_THREADS ), lds, s, p, big_plan );
 		FLANHIP_CHECK( hipGetLastError() );
@@ -926,7 +929,10 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 		const BigSynthExtra e{ reinterpret_cast<float*>( reinterpret_cast<char*>( d_ws ) + lay.big_out_offset ), reinterpret_cast<float*>( reinterpret_cast<char*>( d_ws ) + lay.big_head_offset ),
 			ring_ws ? reinterpret_cast<float*>( reinterpret_cast<char*>( d_ws ) + lay.big_ring_offset ) : nullptr };
 		const size_t lds = ring_ws ? big_analyze_lds( big_plan.C2 ) : big_synth_lds( big_plan.C2, W );
-		auto kern = big_plan.C2 == 4096 ? k_synthesize_big<8> : big_plan.C2 == 2048 ? k_synthesize_big<4> : k_synthesize_big<2>;
+		const int bq = ( big_plan.C2 + MR_THREADS - 1 ) / MR_THREADS;
+		auto kern = big_plan.mixed == 2 ? ( bq > 4 ? k_synthesize_big<8, 2> : bq > 2 ? k_synthesize_big<4, 2> : k_synthesize_big<2, 2> )
+			: big_plan.mixed ? ( bq > 4 ? k_synthesize_big<8, 1> : bq > 2 ? k_synthesize_big<4, 1> : k_synthesize_big<2, 1> )
+			: big_plan.C2 == 4096 ? k_synthesize_big<8> : big_plan.C2 == 2048 ? k_synthesize_big<4> : k_synthesize_big<2>;
 		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 		hipLaunchKernelGGL( kern, dim3( (unsigned) blocks ), dim3( MR_THREADS ), lds, s, p, big_plan, e );
 		FLANHIP_CHECK( hipGetLastError() );

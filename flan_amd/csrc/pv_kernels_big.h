@@ -2,7 +2,9 @@
 // which FFTW plans like any other size (reference: FFTHelper.cpp:16-26; Audio.h:158-163 constrains nothing) and which ran as direct sums here until
 // round 5 (pv_kernels_any.h: O( window x bins ) per frame, ~0.4 s for 8 ch x 60 s at dft 32768).
 //
-// Half the size C = C1 x C2 with C2 = 4096 ( 2048, 1024 ) complex points -- what a block transforms in LDS -- and C1 = 2 ... 256.  Decimation in frequency:
+// Half the size C = C1 x C2 with C2 = 4096 ( 2048, 1024 ) complex points -- what a block transforms in LDS -- and C1 = 2 ... 256; round 6 (MIXED): any C2
+// between 256 and 4096 that is a product of 2 ... 13, for the sizes whose half holds less than 2^10 as a power of two (20000, 44100, 48000, 100000 ...:
+// bs_plan.h), with pv_kernels_mr.h's odd-radix passes and the threads' bins guarded (C2 < 512 Q).  Decimation in frequency:
 //     Z[ k1 + C1 k2 ] = fft_C2( y_k1 )[ k2 ],     y_k1[ n2 ] = w_C^( n2 k1 ) sum_n1 z[ n2 + C2 n1 ] w_C1^( n1 k1 )
 // and a frame is shorter than C2 complex points unless the window is above 2 C2 samples, so the inner sum is one term: the zero-padded transform IS C1
 // separate C2-point transforms of the frame times a twiddle (longer windows: the sum over the segments that are not zero).
@@ -39,8 +41,61 @@ __device__ __forceinline__ bool big_block( int64_t chains, int P, int64_t & chai
 	}
 inline int64_t big_blocks( int64_t chains, int P ) { return ( ( chains + 7 ) / 8 ) * 8 * int64_t( P ); }
 
+// forward transform of the C2 points in `a`, in place (natural order in and out); points from `limit` on are zero on entry and need not have been written.
+// Powers of two: the chirp-z kernels' first pass (radix 8, reads no point from `limit` on), then 8 / 4 / 2; MIXED: the tail is zeroed, then every radix of the plan
+// (MIXED = 1: 2 ... 7; 2: 11 and 13 as well -- their butterflies of 2 x 13 points spill ~450 bytes per thread, which only the plans that hold one pay)
+template<int MIXED> __device__ __forceinline__ void big_fft( cf * a, const cf * tw, const BigFft & f, int limit, int tid )
+	{
+	int NS = 1, i = 0;
+	if constexpr( MIXED )
+		{
+		for( int j = limit + tid; j < f.M; j += MR_THREADS ) a[PAD( j )] = mk( 0.0f, 0.0f );
+		__syncthreads();
+		}
+	else
+		{
+		bs_pass0<false, false>( a, a, f.M, limit, nullptr, nullptr, tid );
+		NS = 8; i = 1;
+		}
+	for( ; i < f.npass; ++i )
+		{
+		const int r = f.radix[i];
+		bool done = true;
+		switch( r )
+			{
+			case 8:  mr_pass<8, false>( a, a, tw, f.M, NS, f.magic[i], f.stride[i], tid ); break;
+			case 4:  mr_pass<4, false>( a, a, tw, f.M, NS, f.magic[i], f.stride[i], tid ); break;
+			case 2:  mr_pass<2, false>( a, a, tw, f.M, NS, f.magic[i], f.stride[i], tid ); break;
+			default: done = false; break;
+			}
+		if constexpr( MIXED > 0 )
+			{
+			if( !done )
+				{
+				done = true;
+				switch( r )
+					{
+					case 3:  mr_pass<3, false>( a, a, tw, f.M, NS, f.magic[i], f.stride[i], tid ); break;
+					case 5:  mr_pass<5, false>( a, a, tw, f.M, NS, f.magic[i], f.stride[i], tid ); break;
+					case 7:  mr_pass<7, false>( a, a, tw, f.M, NS, f.magic[i], f.stride[i], tid ); break;
+					default: done = false; break;
+					}
+				}
+			}
+		if constexpr( MIXED > 1 )
+			{
+			if( !done )
+				{
+				if( r == 11 ) mr_pass<11, false>( a, a, tw, f.M, NS, f.magic[i], f.stride[i], tid );
+				else mr_pass<13, false>( a, a, tw, f.M, NS, f.magic[i], f.stride[i], tid );
+				}
+			}
+		NS *= r;
+		}
+	}
+
 // ---- Audio::convert_to_PV (Conversions/AudioPV.cpp:12-78) -------------------------------------------------------------------------------
-template<int Q>                                                                      // Q = C2 / 512: bins of a residue per thread
+template<int Q, int MIXED = 0>                                                       // Q = ceil( C2 / 512 ) (2, 4, 8): bins of a residue per thread
 __global__ __launch_bounds__( MR_THREADS, 2 ) void k_analyze_big( AnalyzeParams p, BigPlan pl )
 	{
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -53,7 +108,6 @@ __global__ __launch_bounds__( MR_THREADS, 2 ) void k_analyze_big( AnalyzeParams 
 	cf * s_tw = reinterpret_cast<cf*>( smem );
 	cf * bufA = s_tw + C2, * bufB = bufA + padded_len( C2 + 1 );
 	for( int j = tid; j < C2; j += MR_THREADS ) s_tw[j] = p.tw[int64_t( j ) * C1];     // exp( -2 pi i j / C2 )
-	BsTables tb{ s_tw, nullptr, nullptr };
 
 	const int ka = unit, kb = ( C1 - unit ) % C1;
 	const bool paired = ka != kb;
@@ -96,8 +150,8 @@ __global__ __launch_bounds__( MR_THREADS, 2 ) void k_analyze_big( AnalyzeParams 
 			if( paired ) bufB[PAD( n2 )] = cmul( sb, p.tw[n2 * kb] );
 			}
 		__syncthreads();
-		bs_fft<false, false>( bufA, bufA, tb, pl.fft, pl.limit, tid );
-		if( paired ) bs_fft<false, false>( bufB, bufB, tb, pl.fft, pl.limit, tid );
+		big_fft<MIXED>( bufA, s_tw, pl.fft, pl.limit, tid );
+		if( paired ) big_fft<MIXED>( bufB, s_tw, pl.fft, pl.limit, tid );
 
 		// the real transform's bins, each phase-vocoded (AudioPV.cpp:69-73): Z[k] from this residue, Z[C - k] from the other (see the header)
 		MF * row = p.out + ( int64_t( channel ) * p.F + t ) * ( C + 1 );
@@ -117,6 +171,7 @@ __global__ __launch_bounds__( MR_THREADS, 2 ) void k_analyze_big( AnalyzeParams 
 			{
 			__builtin_amdgcn_sched_barrier( 0 );                                            // (bin after bin: interleaved, the Q bodies' temporaries spill)
 			const int k2 = big_opaque( tid ) + MR_THREADS * q;
+			if( MIXED && k2 >= C2 ) continue;
 			const cf za = bufA[PAD( k2 )];
 			if( ka == 0 )
 				{
@@ -150,7 +205,7 @@ struct BigSynthExtra
 	                          // A ring is its block's alone and stays in that CU's L1 / the XCD's L2; the block barriers order its accesses like the LDS ring's
 	};
 
-template<int Q>
+template<int Q, int MIXED = 0>
 __global__ __launch_bounds__( MR_THREADS, 2 ) void k_synthesize_big( SynthParams p, BigPlan pl, BigSynthExtra e )
 	{
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -167,7 +222,6 @@ __global__ __launch_bounds__( MR_THREADS, 2 ) void k_synthesize_big( SynthParams
 	float * ring = e.ring_ws ? e.ring_ws + ( int64_t( unit ) * chains + chain ) * wpad : reinterpret_cast<float*>( bufB + padded_len( C2 + 1 ) );   // [wpad]
 	for( int j = tid; j < C2; j += MR_THREADS ) s_tw[j] = p.tw[int64_t( j ) * C1];
 	for( int i = tid; i < wpad; i += MR_THREADS ) ring[i] = 0.0f;
-	BsTables tb{ s_tw, nullptr, nullptr };
 
 	const int ka = unit, kb = ( C1 - unit ) % C1;
 	const bool paired = ka != kb;
@@ -187,7 +241,7 @@ __global__ __launch_bounds__( MR_THREADS, 2 ) void k_synthesize_big( SynthParams
 	#pragma unroll
 	for( int q = 0; q < Q; ++q )
 		{
-		const int k2 = tid + MR_THREADS * q;
+		const int k2 = ( MIXED && tid + MR_THREADS * q >= C2 ) ? 0 : tid + MR_THREADS * q;     // (bins past the residue's end: never used)
 		phA[q] = carry[ka + C1 * k2];
 		phB[q] = carry[kb + C1 * k2];
 		}
@@ -226,12 +280,18 @@ __global__ __launch_bounds__( MR_THREADS, 2 ) void k_synthesize_big( SynthParams
 		const MF * row = p.pv + ( int64_t( channel ) * p.F + t ) * ( C + 1 );
 		MF ma[Q], mb[Q];
 		#pragma unroll
-		for( int q = 0; q < Q; ++q ) { const int k2 = big_opaque( tid ) + MR_THREADS * q; ma[q] = row[ka + C1 * k2]; if( paired ) mb[q] = row[kb + C1 * k2]; }
+		for( int q = 0; q < Q; ++q )
+			{
+			int k2 = big_opaque( tid ) + MR_THREADS * q;
+			if( MIXED && k2 >= C2 ) k2 = 0;
+			ma[q] = row[ka + C1 * k2]; if( paired ) mb[q] = row[kb + C1 * k2];
+			}
 		#pragma unroll
 		for( int q = 0; q < Q; ++q )
 			{
 			__builtin_amdgcn_sched_barrier( 0 );                                            // (bin after bin: interleaved, the Q bodies' temporaries spill)
 			const int k2 = big_opaque( tid ) + MR_THREADS * q;
+			if( MIXED && k2 >= C2 ) continue;
 			bufA[PAD( k2 )] = polar_of( ma[q], phA[q] );
 			__builtin_amdgcn_sched_barrier( 0 );
 			if( paired ) bufB[PAD( k2 )] = polar_of( mb[q], phB[q] );
@@ -244,6 +304,7 @@ __global__ __launch_bounds__( MR_THREADS, 2 ) void k_synthesize_big( SynthParams
 			{
 			__builtin_amdgcn_sched_barrier( 0 );
 			const int k2 = big_opaque( tid ) + MR_THREADS * q;
+			if( MIXED && k2 >= C2 ) continue;
 			if( ka == 0 )
 				{
 				// residue 0 mirrors itself: k = C1 k2 <-> C - k = C1 ( C2 - k2 );  k2 = 0: X[0] with X[C]
@@ -265,23 +326,23 @@ __global__ __launch_bounds__( MR_THREADS, 2 ) void k_synthesize_big( SynthParams
 				}
 			else
 				{
-				// the middle residue mirrors itself: ( k2, C2 - 1 - k2 )
+				// the middle residue mirrors itself: ( k2, C2 - 1 - k2 ); an odd C2 (MIXED) has a bin that is its own mirror there: C / 2
 				const int m2 = C2 - 1 - k2;
-				if( k2 < m2 )
+				if( k2 <= m2 )
 					{
 					const cf xk = bufA[PAD( k2 )], xm = bufA[PAD( m2 )];
 					bufA[PAD( k2 )] = merge( ka + C1 * k2, xk, xm );
-					bufA[PAD( m2 )] = merge( ka + C1 * m2, xm, xk );
+					if( k2 != m2 ) bufA[PAD( m2 )] = merge( ka + C1 * m2, xm, xk );
 					}
 				}
 			}
 		__syncthreads();
-		bs_fft<false, false>( bufA, bufA, tb, pl.fft, C2, tid );
-		if( paired ) bs_fft<false, false>( bufB, bufB, tb, pl.fft, C2, tid );
+		big_fft<MIXED>( bufA, s_tw, pl.fft, C2, tid );
+		if( paired ) big_fft<MIXED>( bufB, s_tw, pl.fft, C2, tid );
 		// this unit's share of G[n] = fft_C( conj Z )[n]:  x[2n] = G[n].x, x[2n+1] = -G[n].y (AudioPV.cpp:122); window, accumulate (:133-134)
 		for( int n = tid; 2 * n < W; n += MR_THREADS )
 			{
-			const int r = n & ( C2 - 1 );
+			const int r = MIXED ? n % C2 : n & ( C2 - 1 );
 			cf gsum = bufA[PAD( r )];
 			if( ka ) gsum = cmul( gsum, p.tw[( int64_t( n ) * ka ) % C] );
 			if( paired ) gsum = cadd( gsum, cmul( bufB[PAD( r )], p.tw[( int64_t( n ) * kb ) % C] ) );

@@ -182,6 +182,19 @@ CASES = [
     ("dft32768_win32768_hop8192", 1, 300000, 32768, 8192, 32768, "noise"),
     ("dft65536_win20000_hop5000_stereo", 2, 150000, 20000, 5000, 65536, "noise"),
     ("dft32768_win16384_hop1024", 1, 60000, 16384, 1024, 32768, "noise"),
+    # ... and (round 6) the sizes above 16384 whose half holds less than 2^10 as a power of two: C2 = any product of 2 ... 13 up to 4096 (bs_plan.h: `mixed`) --
+    # 20000 = 2 x 4 x 2500, 44100 = 2 x 6 x 3675, 48000 = 2 x 6 x 4000 (two segments), 22050 (C1, C2 odd: the bin C / 2 mirrors itself), 100000 = 2 x 16 x 5^5,
+    # 17836 = 2 x 7 x ( 2 x 7^2 x 13 ), 19602 = 2 x 3 x ( 3^3 x 11^2 )
+    ("dft20000_win4096", 1, 60000, 4096, 1024, 20000, "noise"),
+    ("dft44100_stereo_ragged", 2, 23456, 2048, 512, 44100, "noise"),
+    ("dft48000_win12000_two_segments", 1, 60000, 12000, 3000, 48000, "noise"),
+    ("dft22050_odd_halves", 1, 40000, 4096, 1024, 22050, "noise"),
+    ("dft100000_win4096", 1, 40000, 4096, 1024, 100000, "noise"),
+    ("dft17836_radix13", 1, 30000, 2048, 512, 17836, "noise"),
+    ("dft19602_radix11", 1, 30000, 2048, 512, 19602, "noise"),
+    ("dft20000_win20000_hop5000", 1, 200000, 20000, 5000, 20000, "noise"),
+    ("dft20000_sine", 1, 48000, 4096, 1024, 20000, "sine"),
+    ("dft20000_one_frame", 1, 100, 4096, 1024, 20000, "noise"),
     ("dft66", 1, 3000, 64, 16, 66, "noise"),
     ("dft6_win4", 1, 300, 4, 2, 6, "noise"),
     ("dft3000_sine", 1, 48000, 2048, 512, 3000, "sine"),
@@ -427,7 +440,7 @@ def test_fused_round_trip_equals_unfused(fa):
                                  (2, 300000, 2048, 512, 3000), (1, 120000, 1024, 256, 2002), (1, 200000, 2048, 512, 12000), (1, 60000, 600, 150, 1000),
                                  # the chirp-z kernels (sums kept by the ping-pong kernels, with and without the tables in registers; by the pre-pass kernel for the
                                  # in-place layout) and the residue-pair kernels above 16384 (pre-pass kernel on their behalf)
-                                 (2, 300000, 2048, 512, 2998), (1, 120000, 1024, 256, 2018), (1, 200000, 2048, 512, 5998), (2, 400000, 4096, 1024, 32768)]:
+                                 (2, 300000, 2048, 512, 2998), (1, 120000, 1024, 256, 2018), (1, 200000, 2048, 512, 5998), (2, 400000, 4096, 1024, 32768), (2, 300000, 4096, 1024, 20000)]:
         x = O.noise(ch, n, seed=31)
         F = O.num_pv_frames(n, hop)
         bins = dft // 2 + 1
@@ -744,7 +757,7 @@ def test_random_chirp_z_and_big_sizes(fa, ch, n, W, hop, dft):
 def test_degenerate_lengths(fa, n):
     """empty and near-empty signals: one frame of (almost) silence through every dft class, like the reference would produce"""
     sr = 48000.0
-    for (W, hop, dft) in ((2048, 512, 2048), (2048, 128, 4096), (256, 64, 256), (1024, 256, 1024), (512, 128, 512), (1024, 256, 2998), (4096, 1024, 32768)):
+    for (W, hop, dft) in ((2048, 512, 2048), (2048, 128, 4096), (256, 64, 256), (1024, 256, 1024), (512, 128, 512), (1024, 256, 2998), (4096, 1024, 32768), (4096, 1024, 20000), (8192, 2048, 8192)):
         x = O.noise(2, max(n, 1), seed=5)[:, :n].copy()
         ref = O.analyze(x, sr, W, hop, dft)
         got = fa.analyze(x, sr, W, hop, dft)
@@ -971,7 +984,8 @@ def test_cancellation_is_scoped_to_the_stream_waited_on(fa):
     fa.check(lib.flanhip_stream_destroy(sB))
 
 
-@pytest.mark.parametrize("W,hop,dft", [(2048, 512, 3000), (4096, 1024, 16384), (600, 150, 1000), (1024, 256, 2998), (2048, 512, 5998), (4096, 1024, 32768)])
+@pytest.mark.parametrize("W,hop,dft", [(2048, 512, 3000), (4096, 1024, 16384), (600, 150, 1000), (1024, 256, 2998), (2048, 512, 5998), (4096, 1024, 32768),
+                                       (4096, 1024, 20000), (2048, 512, 22050), (2048, 512, 17836)])
 def test_mixed_radix_kernels_against_the_direct_sums(fa, W, hop, dft):
     """The mixed-radix FFT kernels (pv_kernels_mr.h) against the transform's definition summed in fp64 (pv_kernels_any.h, the force_direct hook)
     on the same input: PVs agree like two FFT backends do, audio from the SAME PV to 1e-6."""
