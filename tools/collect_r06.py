@@ -12,7 +12,7 @@ DST = os.path.join(ROOT, "profiles")
 names = {"kernel_stats.csv": "r06_kernel_stats.csv", "sq_summary.txt": "r06_sq_counters.txt", "inst_classes.txt": "r06_inst_classes.txt",
          "hbm_summary.txt": "r06_hbm_counters.txt", "prof_kt.json": "r06_bench_profiled.json", "bench.json": "r06_bench.json",
          "config3_timeline.txt": "r06_config3_timeline.txt", "shapes_r06_all.txt": "r06_shapes.txt"}
-for tag in ("api_default", "dft4096_hop512", "dft8192", "dft16384", "dft512", "dft256"):
+for tag in ("api_default", "dft4096_hop512", "dft8192", "dft16384", "dft512", "dft256", "big"):
     names["counters_r06_%s.txt" % tag] = "r06_%s_counters.txt" % tag
     names["kernel_stats_r06_%s.csv" % tag] = "r06_%s_kernel_stats.csv" % tag
 for a, b in names.items():

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Soak of the synchronisation inside the synthesis kernels (the chains' overlaps added by whichever chain finishes its half last: pv_kernels_v2.h /
-_v3.h): the same fused round trip launched N times per shape -- back to back, so that launches overlap on the device, and on two streams at once with
+_v3.h, round 6: pv_kernels_eo.h / _team.h): the same fused round trip launched N times per shape -- back to back, so that launches overlap on the device, and on two streams at once with
 a workspace each -- every output compared BIT FOR BIT with the first launch's and with the separate-launch form (k_ola_fixup).  Any ordering the
 protocol does not cover shows as a differing sample.
 
-    python tools/soak_fixup.py [launches per shape, default 1500]"""
+    python tools/soak_fixup.py [launches per shape, default 1500] [team: the round-6 shapes only]"""
 import ctypes
 import json
 import os
@@ -18,7 +18,13 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 SR = 48000.0
 dev = torch.device("cuda", 0)
 shapes = [(8, 60.0, 2048, 512, 2048), (2, 60.0, 2048, 512, 2048), (3, 7.3, 2048, 512, 2048), (8, 600.0, 2048, 512, 2048), (1, 200.0, 2048, 128, 2048),
-          (8, 60.0, 1024, 256, 1024), (5, 11.1, 1024, 512, 1024), (8, 60.0, 512, 128, 512), (2, 33.3, 512, 256, 512), (4, 20.0, 2048, 1024, 2048)]
+          (8, 60.0, 1024, 256, 1024), (5, 11.1, 1024, 512, 1024), (8, 60.0, 512, 128, 512), (2, 33.3, 512, 256, 512), (4, 20.0, 2048, 1024, 2048),
+          # round 6: the team kernels' form of the protocol (a word per wavefront of a chain: pv_kernels_eo.h ChainOverlap) -- dft 4096 (hop 128 by half steps, 512,
+          # window = dft), 8192, 16384
+          (2, 60.0, 2048, 128, 4096), (8, 60.0, 2048, 512, 4096), (3, 21.0, 4096, 1024, 4096), (8, 60.0, 8192, 2048, 8192), (2, 60.0, 4096, 512, 8192),
+          (8, 60.0, 4096, 1024, 16384), (2, 60.0, 16384, 4096, 16384)]
+if len(sys.argv) > 2 and sys.argv[2] == "team":
+    shapes = shapes[10:]
 report = {}
 for (ch, seconds, W, HOP, DFT) in shapes:
     n = int(seconds * SR)
