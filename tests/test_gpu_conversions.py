@@ -1005,6 +1005,59 @@ def test_mixed_radix_kernels_against_the_direct_sums(fa, W, hop, dft):
     assert rel_m <= 5e-7 and same_f >= 0.95 and d <= 1e-6
 
 
+def _big_mixed_plan(dft):
+    """bs_plan.h: big_make_plan's choice for a size above 16384 -- (C1, C2, mixed) or None (the host arithmetic restated: tests/cpp/plans_test.cpp holds the original)"""
+    def smooth(c):
+        for r in (2, 3, 5, 7, 11, 13):
+            while c % r == 0:
+                c //= r
+        return c == 1
+    C = dft // 2
+    c2 = 1
+    while C % (c2 * 2) == 0 and c2 * 2 <= 4096:
+        c2 *= 2
+    if c2 >= 1024 and C // c2 <= 256:
+        return (C // c2, c2, False) if C // c2 >= 2 else None
+    for d in range(4096, 255, -1):
+        if C % d == 0 and 2 <= C // d <= 256 and smooth(d):
+            return (C // d, d, True)
+    return None
+
+
+def test_random_mixed_radix_sizes_above_16384_against_the_direct_sums(fa):
+    """Round 6: the residue-pair kernels with a mixed-radix inner transform (bs_plan.h `mixed`), twelve seeded random sizes between 16386 and 300000 that the plan
+    serves that way, random windows (one to three segments) and hops, against the direct sums on the same input -- incl. odd C1 / C2 and every odd radix."""
+    rng = np.random.default_rng(606)
+    sr = 48000.0
+    done, radices = 0, set()
+    while done < 12:
+        dft = 2 * int(rng.integers(8193, 150000))
+        plan = _big_mixed_plan(dft)
+        if plan is None or not plan[2]:
+            continue
+        C1, C2, _ = plan
+        W = int(rng.integers(64, min(dft, 3 * 2 * C2, 12000)))
+        hop = max(1, W // int(rng.integers(2, 9)))
+        for r in (3, 5, 7, 11, 13):
+            if C2 % r == 0:
+                radices.add(r)
+        x = O.noise(1 + done % 2, 6 * W + int(rng.integers(0, 999)), seed=dft)
+        ar = np.float32(sr) / np.float32(hop)
+        pv_fft = fa.analyze(x, sr, W, hop, dft)
+        out_fft, _ = fa.synthesize(pv_fft, sr, ar, W)
+        with fa.debug_options(force_direct=1):
+            pv_def = fa.analyze(x, sr, W, hop, dft)
+            out_def, _ = fa.synthesize(pv_fft, sr, ar, W)
+        m0, m1 = pv_def[..., 0].astype(np.float64), pv_fft[..., 0].astype(np.float64)
+        rel_m = np.sqrt(np.sum((m0 - m1) ** 2) / np.sum(m0 ** 2))
+        same_f = np.mean(pv_def[..., 1].view(np.uint32) == pv_fft[..., 1].view(np.uint32))
+        d = np.abs(out_fft.astype(np.float64) - out_def.astype(np.float64)).max()
+        print("\n[dft %d = 2 x %d x %d, W %d, hop %d] rel_m %.2e  f bit-identical %.4f  audio max diff %.2e" % (dft, C1, C2, W, hop, rel_m, same_f, d))
+        assert rel_m <= 5e-7 and same_f >= 0.95 and d <= 1e-6, (dft, W, hop)
+        done += 1
+    assert radices >= {3, 5, 7}, radices
+
+
 def test_plan_caches_are_bounded_and_evicted_sizes_come_back(fa):
     """The plan / unit-circle caches keep only the most recently used few of the sizes without tuned kernels (core.hip get_plan, conversions.hip
     get_unit_circle): a sweep over more sizes than they hold, mixed-radix and direct-sum, then the first sizes again -- the results of a size whose
