@@ -398,6 +398,9 @@ def main():
 
     def sync_all():
         if distributed:
+            # (the device drained first: the library's own communicator (flanhip_allgather_audio, side stream) and the process group's never have
+            # collectives in flight at the same time -- two communicators' kernels waiting for each other's peers is the one way this job could hang)
+            torch.cuda.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
 
