@@ -38,7 +38,7 @@ static bool fft_size( int dft ) { return is_pow2( dft ) && dft >= 32 && dft <= 8
 // tables and state within the LDS of a CU for this window
 static int mr_blocks_per_cu( const MrPlan & pl, int W )
 	{
-	const size_t lds = std::max( mr_analyze_lds( pl.C, W, pl.win_lds, pl.kc_lds ), mr_synth_lds( pl.C, W, pl.win_lds, pl.kc_lds ) );
+	const size_t lds = std::max( mr_analyze_lds( pl.C, W, pl.win_lds, pl.kc_lds ), mr_synth_lds( pl.C, W, pl.win_lds, pl.kc_lds, pl.ring_ws != 0 ) );
 	if( lds > kMaxLds ) return 0;
 	return int( std::min<size_t>( mr_pingpong( pl.C ) ? 2 : 1, kMaxLds / lds ) );      // (blocks of 8 wavefronts; four / two wavefronts per SIMD: the kernels' register budgets)
 	}
@@ -50,9 +50,16 @@ static bool mr_size( int dft, int W, MrPlan * pl = nullptr )
 	int best_blocks = 0;
 	for( int kc = 0; kc < 2; ++kc ) for( int wl = 0; wl < 2; ++wl )
 		{
-		MrPlan t = best; t.kc_lds = kc; t.win_lds = wl;
+		MrPlan t = best; t.kc_lds = kc; t.win_lds = wl; t.ring_ws = 0;
 		const int b = mr_blocks_per_cu( t, W );
 		if( b > best_blocks || ( b == best_blocks && b > 0 && kc + wl >= best.kc_lds + best.win_lds ) ) { best = t; best_blocks = b; }
+		}
+	if( best_blocks == 0 )
+		{
+		// the synthesis' ring does not fit beside the transform and the running phases (windows above ~6000 samples at dft 16384): the ring in the workspace
+		MrPlan t = best; t.kc_lds = 0; t.win_lds = 0; t.ring_ws = 1;
+		best_blocks = mr_blocks_per_cu( t, W );
+		if( best_blocks > 0 ) best = t;
 		}
 	if( best_blocks == 0 ) return false;
 	if( pl ) *pl = best;
@@ -723,6 +730,13 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 		o->any_frames_offset = o->any_spec_offset + ( ( size_t( ch ) * size_t( F ) * size_t( bins ) * sizeof( cf ) + 255 ) & ~size_t( 255 ) );
 		o->total_bytes = o->any_frames_offset + ( ( size_t( ch ) * size_t( F ) * size_t( W ) * sizeof( float ) + 255 ) & ~size_t( 255 ) );
 		}
+	o->mr_ring_offset = 0;
+	if( MrPlan mp{}; mr && mr_size( o->dft, W, &mp ) && mp.ring_ws )
+		{
+		// the mixed-radix synthesis' overlap-add rings [chains][W], where they do not fit the LDS (MrPlan::ring_ws)
+		o->mr_ring_offset = o->total_bytes;
+		o->total_bytes += ( size_t( chains ) * size_t( ( W + 3 ) & ~3 ) * sizeof( float ) + 255 ) & ~size_t( 255 );
+		}
 	o->big_out_offset = o->big_head_offset = o->big_ring_offset = 0;
 	if( o->big )
 		{
@@ -913,7 +927,9 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	else if( sub_shape( lay.dft, W, lay.hop ) ) rc = run_synth_sub( p, lay.dft, s );
 	else if( MrPlan mr_plan{}; mr_size( lay.dft, W, &mr_plan ) )
 		{
-		const size_t lds = mr_synth_lds( mr_plan.C, W, mr_plan.win_lds, mr_plan.kc_lds );
+		const size_t lds = mr_synth_lds( mr_plan.C, W, mr_plan.win_lds, mr_plan.kc_lds, mr_plan.ring_ws != 0 );
+		FLANHIP_REQUIRE( !mr_plan.ring_ws || lay.mr_ring_offset != 0, FLANHIP_ERR_UNSUPPORTED, "the workspace holds no ring for this plan" );
+		p.ring_ws = mr_plan.ring_ws ? reinterpret_cast<float*>( reinterpret_cast<char*>( d_ws ) + lay.mr_ring_offset ) : nullptr;
 		FLANHIP_REQUIRE( mr_plan_fits_kernels( mr_plan ), FLANHIP_ERR_UNSUPPORTED, "mixed-radix plan and kernels disagree" );
 		auto kern = !mr_pingpong( mr_plan.C ) ? k_synthesize_mr<false, true> : mr_plan_is_big( mr_plan ) ? k_synthesize_mr<true, true> : k_synthesize_mr<true, false>;
 		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );

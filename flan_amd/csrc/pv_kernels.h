@@ -315,6 +315,7 @@ struct SynthParams
 	int * fix_state;           // optional [chains] (team kernels: [chains][wavefronts of a team]): word c belongs to the boundary between chain c - 1 and chain c of a channel
 	float * tail;              // [ch][chains][W-hop]
 	int fix_tag;               // ( epoch << 2 ): | 1 = the boundary's tail is in `tail`, | 2 = its head is in `head`
+	float * ring_ws;           // k_synthesize_mr with MrPlan::ring_ws: [chains][( W + 3 ) & ~3] -- the blocks' overlap-add rings, where they do not fit the LDS
 	};
 
 // (the pre-pass kernels k_phase_sums2 / k_phase_scan2 that serve every size live in pv_kernels_fast.h)

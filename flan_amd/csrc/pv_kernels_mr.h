@@ -26,6 +26,8 @@ struct MrPlan
 	int C, npass;
 	int win_lds;                                 // synthesis: the scaled window in LDS (not for C = 8192 with a 4096 window: read through L1 there)
 	int kc_lds;                                  // per-bin constants { split twiddle, bin frequency, expected phase advance } in LDS (where that costs no resident block)
+	int ring_ws;                                 // synthesis: the overlap-add ring in the workspace (SynthParams::ring_ws), for windows it does not fit the LDS with (round 6:
+	                                             // ( 8192, 512, 16384 ) off the team grid and every window above ~6000 at dft 16384 ran the direct sums, 0.8 s for 8 ch x 60 s)
 	unsigned char radix[MR_MAX_PASSES];          // C = product; 16s first (in-place plans only; their passes want the short sub-transform lengths), then 8 / 4 / 2, then the odd ones
 	unsigned magic[MR_MAX_PASSES];               // floor( 2^32 / NS ) + 1 of the pass (NS = the product of the radices before it): j / NS = mulhi( j, magic ) for j < 2^13
 	unsigned short stride[MR_MAX_PASSES];        // C / ( NS R ) of the pass: the twiddle step per position inside a sub-transform (no division in the kernel)
@@ -59,7 +61,7 @@ inline bool mr_make_plan( int dft, MrPlan * out )
 inline bool mr_pingpong( int C ) { return C <= MR_TW_LDS_MAX_C; }
 inline size_t mr_lds_common( int C, bool kc_lds ) { return ( C <= MR_TW_LDS_MAX_C ? size_t( C ) * 8 : 0 ) + ( mr_pingpong( C ) ? 2 : 1 ) * size_t( padded_len( C + 1 ) ) * 8 + ( kc_lds ? size_t( C + 1 ) * 16 : 0 ); }
 inline size_t mr_analyze_lds( int C, int W, bool win_lds, bool kc_lds ) { (void) W; (void) win_lds; return mr_lds_common( C, kc_lds ) + ( mr_pingpong( C ) ? size_t( C + 1 ) * 8 : 0 ) + size_t( C + 4 ) * 4; }   // the chain's phase sums (ping-pong sizes: the fused round trip's pre-pass, kept by the kernel itself), previous phases (the window is read from memory beside the samples)
-inline size_t mr_synth_lds( int C, int W, bool win_lds, bool kc_lds ) { return mr_lds_common( C, kc_lds ) + ( win_lds ? 2 : 1 ) * size_t( ( W + 3 ) & ~3 ) * 4 + size_t( C + 2 ) * 8; }   // scaled window, ring, running phases
+inline size_t mr_synth_lds( int C, int W, bool win_lds, bool kc_lds, bool ring_ws = false ) { return mr_lds_common( C, kc_lds ) + ( ( win_lds ? 1 : 0 ) + ( ring_ws ? 0 : 1 ) ) * size_t( ( W + 3 ) & ~3 ) * 4 + size_t( C + 2 ) * 8; }   // scaled window, ring (unless in the workspace), running phases
 
 // ---- register DFTs: powers of two from fft_device.h, odd primes by the symmetric direct form ---------------------------------------
 // X[k] = v0 + sum_j ( a_j cos( 2 pi j k / R ) - i b_j sin( 2 pi j k / R ) ),  a_j = v[j] + v[R-j],  b_j = v[j] - v[R-j],  j = 1 .. (R-1)/2;
@@ -383,8 +385,11 @@ __global__ __launch_bounds__( MR_THREADS, PP ? 4 : 2 ) void k_synthesize_mr( Syn
 	const MrLds l = mr_carve<PP>( smem, p.tw, C, kc_lds, tid );
 	cf * buf = l.buf;
 	double * s_ph = reinterpret_cast<double*>( l.state );                             // [C + 2] (l.state is 8-byte aligned)
-	float * ring = reinterpret_cast<float*>( s_ph + ( C + 2 ) );                       // [wpad]
-	float * s_win = ring + wpad;                                                      // [wpad], if win_lds: the scaled window (AudioPV.cpp:102)
+	// the overlap-add ring: [wpad] floats behind the running phases, or (MrPlan::ring_ws) this block's own stretch of the workspace -- it stays in the CU's L1 / the
+	// XCD's L2, and the block barriers order its accesses exactly as they order the LDS ring's (k_synthesize_big: BigSynthExtra::ring_ws)
+	float * const lds_ring = reinterpret_cast<float*>( s_ph + ( C + 2 ) );
+	float * ring = pl.ring_ws ? p.ring_ws + int64_t( blockIdx.x ) * wpad : lds_ring;
+	float * s_win = pl.ring_ws ? lds_ring : lds_ring + wpad;                          // [wpad], if win_lds: the scaled window (AudioPV.cpp:102)
 	// (either an LDS read or a global one, in arms of their own: `c ? lds[i] : mem[i]` becomes one FLAT load through a selected pointer)
 	auto win = [&]( int i ) { float v; if( win_lds ) { v = s_win[i]; asm volatile( "" : "+v"( v ) ); } else v = p.window[i] * p.window_scale; return v; };
 	for( int i = tid; i < W; i += MR_THREADS ) { ring[i] = 0.0f; if( win_lds ) s_win[i] = p.window[i] * p.window_scale; }

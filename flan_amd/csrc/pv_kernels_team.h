@@ -409,15 +409,15 @@ __global__ __launch_bounds__( 64 * R * TEAMS, 2 ) void k_analyze_team( AnalyzePa
 
 
 // =================================================================================================================
-// PV::convert_to_audio (Conversions/AudioPV.cpp:86-139), dft 8192 / 16384: see the head of the file.  HS = hop / 128 R, WQ = W / 128 R.
+// PV::convert_to_audio (Conversions/AudioPV.cpp:86-139), dft 8192 / 16384: see the head of the file.  HS = hop / 128 R (0: hop = 64 R, half a step), WQ = W / 128 R.
 template<int R, int TEAMS, int WQ, int HS, bool WINLDS>
 __global__ __launch_bounds__( 64 * R * TEAMS, 2 ) void k_synthesize_team( SynthParams p, TeamTables tb )
 	{
 	using L = TeamLds<R, TEAMS, WINLDS ? 64 * R * WQ : 0>;
 	static_assert( R == 4 || R == 8, "teams of four or eight wavefronts" );
-	static_assert( HS >= 1 && HS <= WQ, "hop <= window" );
+	static_assert( HS >= 0 && HS <= WQ, "hop <= window; HS = 0: half a step" );
 	constexpr int S = 1024, CT = S * R, KQ = 8 / R, NT = 64 * R * TEAMS, NB = 2 * R, STEP = 128 * R;
-	constexpr int hop = HS * STEP, W = WQ * STEP;
+	constexpr int hop = HS ? HS * STEP : STEP / 2, W = WQ * STEP;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	cf * s = reinterpret_cast<cf*>( smem );
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane( tid >> 6 ), team = wave / R, role = wave % R;
@@ -499,6 +499,23 @@ __global__ __launch_bounds__( 64 * R * TEAMS, 2 ) void k_synthesize_team( SynthP
 		if( a0 >= own_start && !( a >= 0 && a < p.out_len ) ) dst = dump2;
 		if( fix && a0 < own_start ) st_agent( dst, v );                          // (the head another wavefront may come to add up)
 		else *dst = v;
+		};
+	// HS = 0 (hop = half a step: the reference API's hop = window / 16 at window = dft / 2 -- ( 4096, 256, 8192 ), ( 8192, 512, 16384 )): a finished hop is the lower 32
+	// lanes of acc[0], and the accumulator moves on by 32 lanes (k_synthesize_eo_team's hop 128: one v_permlane32_swap and one select per register).  The lanes
+	// 32 part .. 32 part + 31 of v hold samples a0 + 2 R ( lane & 31 ) + 2 role (+1); the other lanes dump (never at agent scope: pv_kernels_eo.h)
+	auto emit_half = [&]( int64_t a0, cf v, int part )
+		{
+		const int64_t a = a0 + 2 * R * ( lane & 31 ) + 2 * role;
+		cf * dst = ( a0 < own_start ) ? head2 + ( ( a - chain_start ) >> 1 ) : out2 + ( a >> 1 );
+		const bool idle = ( lane >> 5 ) != part;
+		if( idle || ( a0 >= own_start && !( a >= 0 && a < p.out_len ) ) ) dst = dump2;
+		if( fix && a0 < own_start ) { if( !idle ) st_agent( dst, v ); }
+		else *dst = v;
+		};
+	auto rotate_half = []( float a, float b, bool low ) -> float          // lanes 0..31 <- a's lanes 32..63, lanes 32..63 <- b's lanes 0..31
+		{
+		const auto r = __builtin_amdgcn_permlane32_swap( __float_as_uint( a ), __float_as_uint( b ), false, false );
+		return __uint_as_float( low ? r[1] : r[0] );
 		};
 	cf mf[KQ][NB], mfo;
 	auto load_row = [&]( int64_t t )
@@ -681,10 +698,24 @@ __global__ __launch_bounds__( 64 * R * TEAMS, 2 ) void k_synthesize_team( SynthP
 			acc[q].x += z[q].x * wv.x;
 			acc[q].y += ( -z[q].y ) * wv.y;
 			}
-		#pragma unroll
-		for( int q = 0; q < HS; ++q ) emit_step( pos + STEP * q, acc[q] );
-		#pragma unroll
-		for( int q = 0; q < WQ; ++q ) acc[q] = ( q + HS < WQ ) ? acc[q + HS] : mk( 0.0f, 0.0f );
+		if constexpr( HS == 0 )
+			{
+			emit_half( pos, acc[0], 0 );
+			const bool low = lane < 32;
+			#pragma unroll
+			for( int q = 0; q < WQ; ++q )
+				{
+				const cf nxt = ( q + 1 < WQ ) ? acc[q + 1] : mk( 0.0f, 0.0f );
+				acc[q] = mk( rotate_half( acc[q].x, nxt.x, low ), rotate_half( acc[q].y, nxt.y, low ) );
+				}
+			}
+		else
+			{
+			#pragma unroll
+			for( int q = 0; q < HS; ++q ) emit_step( pos + STEP * q, acc[q] );
+			#pragma unroll
+			for( int q = 0; q < WQ; ++q ) acc[q] = ( q + HS < WQ ) ? acc[q + HS] : mk( 0.0f, 0.0f );
+			}
 		pos += hop;
 		ov.after_frame( i, frames, pos >= own_start, lane );
 		team_sync.meet();                                                       // nobody writes the next frame's A_r before everybody has transformed this one's
@@ -696,13 +727,27 @@ __global__ __launch_bounds__( 64 * R * TEAMS, 2 ) void k_synthesize_team( SynthP
 	const int64_t flush_end = last_chain ? max( ring_end, p.out_len ) : ring_end;
 	if( !fix || last_chain )
 		{
-		#pragma unroll
-		for( int q = 0; q < WQ; ++q )
+		if constexpr( HS == 0 )
 			{
-			const int64_t a0 = pos + STEP * q;
-			if( a0 < flush_end ) emit_step( a0, acc[q] );
+			// W - hop = WQ - 1/2 steps: by halves (the next chain writes from ring_end on itself)
+			#pragma unroll
+			for( int h = 0; h < 2 * WQ; ++h )
+				{
+				const int64_t a0 = pos + ( STEP / 2 ) * h;
+				if( a0 < flush_end ) emit_half( a0, acc[h >> 1], h & 1 );
+				}
+			for( int64_t a0 = pos + STEP * WQ; a0 < flush_end; a0 += STEP / 2 ) emit_half( a0, mk( 0.0f, 0.0f ), 0 );
 			}
-		for( int64_t a0 = pos + STEP * WQ; a0 < flush_end; a0 += STEP ) emit_step( a0, mk( 0.0f, 0.0f ) );
+		else
+			{
+			#pragma unroll
+			for( int q = 0; q < WQ; ++q )
+				{
+				const int64_t a0 = pos + STEP * q;
+				if( a0 < flush_end ) emit_step( a0, acc[q] );
+				}
+			for( int64_t a0 = pos + STEP * WQ; a0 < flush_end; a0 += STEP ) emit_step( a0, mk( 0.0f, 0.0f ) );
+			}
 		}
 	ov.finish( p, acc, 2 * R * lane + 2 * role, chain, chain_start, pos, out2, lane );
 	}

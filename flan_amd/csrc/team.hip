@@ -6,16 +6,17 @@
 
 namespace flanhip {
 
-// ( window / 128 R, hop / 128 R ) the synthesis is instantiated for
-#define FLANHIP_TEAM_SHAPES( X ) X( 4, 1 ) X( 4, 2 ) X( 8, 1 ) X( 8, 2 ) X( 8, 4 ) X( 16, 2 ) X( 16, 4 ) X( 16, 8 )
+// ( window / 128 R, hop / 128 R ) the synthesis is instantiated for; hop 0 = HALF a step (64 R samples): with it hop = window / 16 is served at window = dft / 2
+// and dft / 4 -- the reference API's default ratio, ( 4096, 256, 8192 ) and ( 8192, 512, 16384 ) -- and ( 16, 1 ) serves it at window = dft
+#define FLANHIP_TEAM_SHAPES( X ) X( 4, 0 ) X( 4, 1 ) X( 4, 2 ) X( 8, 0 ) X( 8, 1 ) X( 8, 2 ) X( 8, 4 ) X( 16, 1 ) X( 16, 2 ) X( 16, 4 ) X( 16, 8 )
 
 bool team_shape( int dft, int W, int hop )
 	{
 	const int R = team_radix( dft );
 	if( !R || debug_options().force_generic || debug_options().force_direct ) return false;
 	const int step = 128 * R;
-	if( W % step || hop % step || hop > W ) return false;
-	const int wq = W / step, hs = hop / step;
+	if( W % step || ( hop % step && 2 * hop != step ) || hop > W || hop < 1 ) return false;
+	const int wq = W / step, hs = hop / step;                                 // ( 0: half a step)
 #define X( WQ, HS ) if( wq == WQ && hs == HS ) return true;
 	FLANHIP_TEAM_SHAPES( X )
 #undef X
@@ -98,7 +99,7 @@ int run_analyze_team( const AnalyzeParams & p, const Plan & plan, int dft, hipSt
 template<int R>
 static int run_synth_team_r( const SynthParams & p, const TeamTables & tb, hipStream_t s )
 	{
-	const int wq = p.window_size / ( 128 * R ), hs = p.hop / ( 128 * R );
+	const int wq = p.window_size / ( 128 * R ), hs = p.hop / ( 128 * R );       // ( 0: half a step -- team_shape has admitted nothing else below a step)
 #define X( WQ, HS ) if( wq == WQ && hs == HS ) return launch_synth_team<R, WQ, HS>( p, tb, s );
 	FLANHIP_TEAM_SHAPES( X )
 #undef X

@@ -195,6 +195,22 @@ CASES = [
     ("dft20000_win20000_hop5000", 1, 200000, 20000, 5000, 20000, "noise"),
     ("dft20000_sine", 1, 48000, 4096, 1024, 20000, "sine"),
     ("dft20000_one_frame", 1, 100, 4096, 1024, 20000, "noise"),
+    # the team kernels at hop = window / 16 (the reference API's default ratio scaled up): half a step of 64 R samples at window = dft / 2 and dft / 4, a whole one at window = dft
+    ("dft8192_win4096_hop256_default_ratio", 1, 90000, 4096, 256, 8192, "noise"),
+    ("dft16384_win8192_hop512_default_ratio", 1, 150000, 8192, 512, 16384, "noise"),
+    ("dft8192_win2048_hop256_half_step_stereo_ragged", 2, 40123, 2048, 256, 8192, "noise"),
+    ("dft16384_win4096_hop512_half_step", 1, 70000, 4096, 512, 16384, "noise"),
+    ("dft8192_win8192_hop512", 1, 120000, 8192, 512, 8192, "noise"),
+    ("dft16384_win16384_hop1024", 1, 200000, 16384, 1024, 16384, "noise"),
+    ("dft8192_half_step_one_frame", 1, 100, 4096, 256, 8192, "noise"),
+    ("dft8192_half_step_sine", 1, 48000, 4096, 256, 8192, "sine"),
+    # the mixed-radix kernels with their overlap-add ring in the workspace (windows the ring does not fit the LDS with: above ~6000 samples at dft 16384 off the team grid,
+    # above ~10000 at dft 15000 -- direct sums until round 6: 0.8 s for 8 ch x 60 s at ( 8192, 512, 16384 ))
+    ("dft16384_win8192_hop256_ring_in_workspace", 1, 120000, 8192, 256, 16384, "noise"),
+    ("dft16384_win10000_hop2500_stereo_ragged", 2, 90123, 10000, 2500, 16384, "noise"),
+    ("dft16384_win16384_hop4100", 1, 200000, 16384, 4100, 16384, "noise"),
+    ("dft15000_win14000_hop3500", 1, 150000, 14000, 3500, 15000, "noise"),
+    ("dft16384_win8192_hop256_one_frame", 1, 100, 8192, 256, 16384, "noise"),
     ("dft66", 1, 3000, 64, 16, 66, "noise"),
     ("dft6_win4", 1, 300, 4, 2, 6, "noise"),
     ("dft3000_sine", 1, 48000, 2048, 512, 3000, "sine"),
@@ -985,7 +1001,7 @@ def test_cancellation_is_scoped_to_the_stream_waited_on(fa):
 
 
 @pytest.mark.parametrize("W,hop,dft", [(2048, 512, 3000), (4096, 1024, 16384), (600, 150, 1000), (1024, 256, 2998), (2048, 512, 5998), (4096, 1024, 32768),
-                                       (4096, 1024, 20000), (2048, 512, 22050), (2048, 512, 17836)])
+                                       (4096, 1024, 20000), (2048, 512, 22050), (2048, 512, 17836), (8192, 256, 16384), (10000, 2500, 16384)])
 def test_mixed_radix_kernels_against_the_direct_sums(fa, W, hop, dft):
     """The mixed-radix FFT kernels (pv_kernels_mr.h) against the transform's definition summed in fp64 (pv_kernels_any.h, the force_direct hook)
     on the same input: PVs agree like two FFT backends do, audio from the SAME PV to 1e-6."""
@@ -1118,6 +1134,13 @@ def test_plan_caches_are_bounded_and_evicted_sizes_come_back(fa):
     (3, 30, 16384, 4096, {"dft": 16384}),
     (2, 30, 4096, 1024, {"dft": 16384, "chain_len": 4}),
     (2, 20, 8192, 1024, {"dft": 16384}),
+    # ... at half a step (hop = 64 R samples: half steps leave by the lower 32 lanes) and at hop = window / 16 of a full window
+    (2, 30, 4096, 256, {"dft": 8192}),
+    (3, 9, 2048, 256, {"dft": 8192, "chain_len": 9}),
+    (2, 30, 8192, 512, {"dft": 16384}),
+    (2, 9, 4096, 512, {"dft": 16384, "chain_len": 8}),
+    (2, 30, 8192, 512, {"dft": 8192}),
+    (2, 30, 16384, 1024, {"dft": 16384, "chain_len": 16}),
 ])
 def test_overlap_fixup_inside_the_kernel_equals_the_separate_launch(fa, ch, seconds, W, hop, hooks):
     """k_synthesize_v2 adds the overlaps of neighbouring chains itself (a tagged word per boundary; the head's owner publishes from inside its frame
