@@ -6,7 +6,10 @@
 // 2 ... 13 (those run pv_kernels_mr.h), 64 <= C; the C-point transform as a circular convolution of length M = the power of two >= 2 C - 1:
 //   Z[k] = conj( w[k] ) sum_n ( z[n] conj( w[n] ) ) w[k - n],   w[n] = exp( + pi i n^2 / C )        ( n k = ( n^2 + k^2 - ( k - n )^2 ) / 2 )
 // Two layouts: M <= 4096 with two LDS buffers (ping-pong passes, C <= 2048: dft sizes up to 4096); M = 8192 with one buffer, passes in place and
-// their twiddles read through L1 (C <= 4096: dft sizes up to 8192).  Beyond, and below C = 64, the direct sums of pv_kernels_any.h stay.
+// their twiddles read through L1 (C <= 4096: dft sizes up to 8192).  Round 6, a third one (`glob`): M = 16384 ... 2^18 (C up to 131072: dft sizes up to 262144) with
+// both buffers and what crosses frames in a stretch of device memory per block (ping-pong passes through L2) -- for the sizes above 8192 that nothing else serves,
+// which ran the direct sums (O( window x bins ) per frame: ( 9998, 2499, 9998 ) 150 ms for 8 ch x 60 s).  Below C = 64, and above 262144 where neither this nor
+// the residue pairs of pv_kernels_big.h apply, the direct sums of pv_kernels_any.h stay.
 #pragma once
 #include <cstdint>
 #include <initializer_list>
@@ -14,11 +17,13 @@
 namespace flanhip {
 
 constexpr int BS_MIN_C = 64, BS_MAX_M = 8192, BS_PP_MAX_M = 4096, BS_MAX_PASSES = 6;
+constexpr int BSG_MAX_M = 1 << 18;           // six radix-8 passes; j / NS by the passes' magic numbers stays exact ( ( M / 8 )^2 < 2^32 ), strides fit 16 bits
 
 struct BsPlan
 	{
 	int C, M, npass;
 	int win_lds;                                 // synthesis: the scaled window in LDS
+	int glob;                                    // M above 8192: buffers and state in device memory (BsTables::scratch), ping-pong passes
 	float sign_c;                                // ( -1 )^C:  w[C - k] = sign_c w[k]
 	unsigned char radix[BS_MAX_PASSES];          // M = product; 8s first (the first pass is always a radix-8 one: M >= 128), then 4 / 2 (in place: 16s first)
 	unsigned magic[BS_MAX_PASSES];               // floor( 2^32 / NS ) + 1 of the pass (MrPlan::magic)
@@ -38,9 +43,10 @@ inline bool bs_make_plan( int dft, BsPlan * out )
 	if( C < BS_MIN_C || bs_has_small_factors_only( C ) ) return false;
 	int M = 128;
 	while( M < 2 * C - 1 ) M *= 2;
-	if( M > BS_MAX_M ) return false;
+	if( M > BSG_MAX_M ) return false;
 	BsPlan pl{};
 	pl.C = C; pl.M = M;
+	pl.glob = M > BS_MAX_M ? 1 : 0;
 	pl.sign_c = ( C & 1 ) ? -1.0f : 1.0f;
 	int rest = M, n = 0;
 	auto take = [&]( int r ) { while( rest % r == 0 && n < BS_MAX_PASSES ) { pl.radix[n++] = (unsigned char) r; rest /= r; } };
@@ -122,6 +128,17 @@ inline bool big_make_plan( int dft, int W, BigPlan * out )
 	pl.N1 = ( half + C2 - 1 ) / C2;
 	pl.limit = half < C2 ? half : C2;
 	if( !big_fft_plan( C2, &pl.fft ) ) return false;
+	*out = pl;
+	return true;
+	}
+
+// Which sizes the chirp-z kernels serve: every chirp-z size up to 8192; above, the `glob` layout for what the residue pairs do not serve (they come first above 16384)
+inline bool bs_plan_in_use( int dft, BsPlan * out )
+	{
+	BsPlan pl{};
+	if( !bs_make_plan( dft, &pl ) ) return false;
+	BigPlan big{};
+	if( pl.glob && dft > 16384 && big_make_plan( dft, 2, &big ) ) return false;
 	*out = pl;
 	return true;
 	}

@@ -85,6 +85,7 @@ static bool bs_hoist( const BsPlan & pl, int W )
 	}
 static int bs_blocks_per_cu( const BsPlan & pl, int W )
 	{
+	if( pl.glob ) return 2;                                                     // (no LDS: buffers and state in device memory; two blocks' stretches of it per CU stay L2-sized)
 	const size_t lds = bs_lds( pl, W );
 	if( lds > kMaxLds ) return 0;
 	return int( std::min<size_t>( bs_pingpong( pl.M ) ? 2 : 1, kMaxLds / lds ) );
@@ -92,7 +93,14 @@ static int bs_blocks_per_cu( const BsPlan & pl, int W )
 static bool bs_size( int dft, int W, BsPlan * pl = nullptr )
 	{
 	BsPlan best;
-	if( fft_size( dft ) || debug_options().force_direct || !bs_make_plan( dft, &best ) ) return false;
+	if( fft_size( dft ) || debug_options().force_direct || !bs_plan_in_use( dft, &best ) ) return false;
+	if( best.glob )
+		{
+		// M above 8192 (round 6): for what nothing else serves (bs_plan_in_use: the residue-pair kernels come first where their plan exists)
+		best.win_lds = 0;
+		if( pl ) *pl = best;
+		return true;
+		}
 	int best_blocks = 0;
 	for( int wl = 0; wl < 2; ++wl )
 		{
@@ -642,8 +650,22 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 		const int64_t chains = int64_t( p.chains_per_channel ) * ch;
 		FLANHIP_REQUIRE( chains < ( int64_t( 1 ) << 31 ), FLANHIP_ERR_UNSUPPORTED, "too many chains for one launch" );
 		FLANHIP_REQUIRE( plan->d_bs_tw && plan->d_bs_chirp && plan->d_bs_bh, FLANHIP_ERR_UNSUPPORTED, "chirp-z plan and tables disagree" );
+		BsTables g{ plan->d_bs_tw, plan->d_bs_chirp, plan->d_bs_bh };
+		if( bs_plan.glob )
+			{
+			// buffers and state of every block in device memory: convert_to_PV has no workspace argument, so the stretch is the stream's own (allocated and freed in
+			// stream order around the launch)
+			g.scratch_stride = bsg_block_bytes( bs_plan.C, bs_plan.M, W );
+			void * scratch = nullptr;
+			FLANHIP_CHECK( hipMallocAsync( &scratch, g.scratch_stride * size_t( chains ), s ) );
+			g.scratch = static_cast<unsigned char*>( scratch );
+			hipLaunchKernelGGL( ( k_analyze_bs<true, false, true> ), dim3( (unsigned) chains ), dim3( MR_THREADS ), 0, s, p, bs_plan, g );
+			const hipError_t launched = hipGetLastError();
+			FLANHIP_CHECK( hipFreeAsync( scratch, s ) );
+			FLANHIP_CHECK( launched );
+			return prepass_on_behalf();
+			}
 		const size_t lds = bs_analyze_lds( bs_plan.C, bs_plan.M );
-		const BsTables g{ plan->d_bs_tw, plan->d_bs_chirp, plan->d_bs_bh };
 		auto kern = !bs_pingpong( bs_plan.M ) ? k_analyze_bs<false, false> : bs_hoist( bs_plan, W ) ? k_analyze_bs<true, true> : k_analyze_bs<true, false>;
 		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
 		hipLaunchKernelGGL( kern, dim3( (unsigned) chains ), dim3( MR_THREADS ), lds, s, p, bs_plan, g );
@@ -729,6 +751,13 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 		o->any_spec_offset = o->total_bytes;
 		o->any_frames_offset = o->any_spec_offset + ( ( size_t( ch ) * size_t( F ) * size_t( bins ) * sizeof( cf ) + 255 ) & ~size_t( 255 ) );
 		o->total_bytes = o->any_frames_offset + ( ( size_t( ch ) * size_t( F ) * size_t( W ) * sizeof( float ) + 255 ) & ~size_t( 255 ) );
+		}
+	o->bsg_offset = 0;
+	if( BsPlan bp{}; bs && bs_size( o->dft, W, &bp ) && bp.glob )
+		{
+		// the chirp-z kernels' buffers and state in device memory (BsPlan::glob: M above 8192), a stretch per chain
+		o->bsg_offset = o->total_bytes;
+		o->total_bytes += bsg_block_bytes( bp.C, bp.M, W ) * size_t( chains );
 		}
 	o->mr_ring_offset = 0;
 	if( MrPlan mp{}; mr && mr_size( o->dft, W, &mp ) && mp.ring_ws )
@@ -962,11 +991,21 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	else if( BsPlan bs_plan{}; bs_size( lay.dft, W, &bs_plan ) )
 		{
 		FLANHIP_REQUIRE( plan->d_bs_tw && plan->d_bs_chirp && plan->d_bs_bh, FLANHIP_ERR_UNSUPPORTED, "chirp-z plan and tables disagree" );
-		const size_t lds = bs_synth_lds( bs_plan.C, bs_plan.M, W, bs_plan.win_lds != 0 );
-		const BsTables g{ plan->d_bs_tw, plan->d_bs_chirp, plan->d_bs_bh };
-		auto kern = !bs_pingpong( bs_plan.M ) ? k_synthesize_bs<false, false> : bs_hoist( bs_plan, W ) ? k_synthesize_bs<true, true> : k_synthesize_bs<true, false>;
-		FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
-		hipLaunchKernelGGL( kern, dim3( (unsigned) chains ), dim3( MR_THREADS ), lds, s, p, bs_plan, g );
+		BsTables g{ plan->d_bs_tw, plan->d_bs_chirp, plan->d_bs_bh };
+		if( bs_plan.glob )
+			{
+			FLANHIP_REQUIRE( lay.bsg_offset != 0, FLANHIP_ERR_UNSUPPORTED, "the workspace holds no chirp-z stretch for this plan" );
+			g.scratch = reinterpret_cast<unsigned char*>( d_ws ) + lay.bsg_offset;
+			g.scratch_stride = bsg_block_bytes( bs_plan.C, bs_plan.M, W );
+			hipLaunchKernelGGL( ( k_synthesize_bs<true, false, true> ), dim3( (unsigned) chains ), dim3( MR_THREADS ), 0, s, p, bs_plan, g );
+			}
+		else
+			{
+			const size_t lds = bs_synth_lds( bs_plan.C, bs_plan.M, W, bs_plan.win_lds != 0 );
+			auto kern = !bs_pingpong( bs_plan.M ) ? k_synthesize_bs<false, false> : bs_hoist( bs_plan, W ) ? k_synthesize_bs<true, true> : k_synthesize_bs<true, false>;
+			FLANHIP_CHECK( hipFuncSetAttribute( reinterpret_cast<const void*>( kern ), hipFuncAttributeMaxDynamicSharedMemorySize, int( lds ) ) );
+			hipLaunchKernelGGL( kern, dim3( (unsigned) chains ), dim3( MR_THREADS ), lds, s, p, bs_plan, g );
+			}
 		FLANHIP_CHECK( hipGetLastError() );
 		rc = FLANHIP_OK;
 		}

@@ -146,7 +146,7 @@ int get_plan( int window_size, int dft_size, std::shared_ptr<const PlanRef> * ou
 		FLANHIP_CHECK( hipMalloc( &plan.d_team, sizeof( cf ) * t.size() ) );
 		FLANHIP_CHECK( hipMemcpy( plan.d_team, t.data(), sizeof( cf ) * t.size(), hipMemcpyHostToDevice ) );
 		}
-	if( BsPlan bp{}; bs_make_plan( dft_size, &bp ) )
+	if( BsPlan bp{}; bs_plan_in_use( dft_size, &bp ) )
 		{
 		// Bluestein's tables (pv_kernels_bs.h), all evaluated in double: the chirp from n^2 mod 2 C (exact integers), its transform by a radix-2 FFT
 		const int M = bp.M;

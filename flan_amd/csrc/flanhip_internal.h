@@ -109,6 +109,7 @@ struct SynthLayout { int hop, dft, L, chains_per_channel, head_len, groups_per_c
 	size_t fix_offset, tail_offset;   // the synthesis kernels' own overlap fix-up: eight state words per chain (one per wavefront of a team), then a second side buffer the size of the heads' (0: not this shape)
 	bool any; size_t any_spec_offset, any_frames_offset;      // any: a dft size without FFT kernels (pv_kernels_any.h) and its scratch in the workspace
 	size_t mr_ring_offset;            // the mixed-radix synthesis' rings in the workspace (0: in LDS)
+	size_t bsg_offset;                // the chirp-z kernels' buffers and state in the workspace (BsPlan::glob; 0: in LDS)
 	bool big; size_t big_out_offset, big_head_offset, big_ring_offset; };      // big: a dft size above 16384 served by pv_kernels_big.h; its units' partial output streams and heads
 // which producer last left its pre-pass in a synthesis workspace (host-side note, keyed by the workspace pointer, written when the
 // producer is launched and read when flanhip_synthesize_dev_fused is): 1 = chain sums AND group sums (the dft 2048 analysis kernel)

@@ -23,7 +23,12 @@ struct BsTables
 	const cf * tw;        // [M]  exp( -2 pi i j / M )
 	const d2 * chirp;     // [C]  w[n], in double
 	const d2 * bh;        // [M]  fft_M( b ) / M, in double
+	unsigned char * scratch = nullptr;   // BsPlan::glob: [blocks][scratch_stride] bytes -- a block's two buffers and what it keeps across frames (bsg_block_bytes)
+	size_t scratch_stride = 0;
 	};
+// BsPlan::glob, bytes of device memory per block: two frames of padded_len( M + 1 ) points, running phases / phase sums ( C + 2 doubles ), previous phases ( C + 4
+// floats ), the synthesis' ring ( W floats )
+inline size_t bsg_block_bytes( int C, int M, int W ) { return ( 2 * size_t( padded_len( M + 1 ) ) * 8 + size_t( C + 2 ) * 8 + size_t( C + 4 ) * 4 + size_t( ( W + 3 ) & ~3 ) * 4 + 255 ) & ~size_t( 255 ); }
 // a float point times a table entry kept in double, rounded once: the three chirp products of a transform cost three roundings, not nine (in
 // fp32, tables and products, the share of f bit for bit the oracle's fell just under the floor the tests hold sizes like 2998 to: 0.978 for 0.98)
 __device__ __forceinline__ cf cmul_d( cf a, d2 w )
@@ -118,9 +123,19 @@ template<bool PP, bool MUL> __device__ __forceinline__ cf * bs_fft( cf * a, cf *
 	}
 
 struct BsLds { BsTables tb; cf * buf, * buf2; unsigned char * state; };
-template<bool PP> __device__ __forceinline__ BsLds bs_carve( unsigned char * smem, const BsTables & g, int M, int tid )
+template<bool PP, bool GLOB = false> __device__ __forceinline__ BsLds bs_carve( unsigned char * smem, const BsTables & g, int M, int tid )
 	{
 	BsLds l;
+	if constexpr( GLOB )
+		{
+		// everything in the block's stretch of device memory; the twiddles stay where they are (read through L1 / L2)
+		cf * base = reinterpret_cast<cf*>( g.scratch + size_t( blockIdx.x ) * g.scratch_stride );
+		l.tb = g;
+		l.buf = base;
+		l.buf2 = base + padded_len( M + 1 );
+		l.state = reinterpret_cast<unsigned char*>( base + 2 * padded_len( M + 1 ) );
+		return l;
+		}
 	cf * s_tw = reinterpret_cast<cf*>( smem );
 	l.tb = g;
 	l.buf = s_tw + ( PP ? M : 0 );
@@ -135,16 +150,18 @@ template<bool PP> __device__ __forceinline__ BsLds bs_carve( unsigned char * sme
 // frame -- its eight entries of bh, its four chirp values, per-bin constants and window samples -- so it reads them once, into registers (72 of
 // them: two wavefronts per SIMD, which is what one block per CU of the M = 4096 layout comes to anyway), and the next frame's samples are requested
 // under this frame's bins.  Without it a frame waited for L2 three times (12.8 us a frame at dft 2998; the passes themselves are ~4).
-template<bool PP, bool HOIST>
+// GLOB (round 6, BsPlan::glob): M = 16384 ... 2^18 -- the ping-pong kernel with its buffers and its state in device memory (no LDS at all)
+template<bool PP, bool HOIST, bool GLOB = false>
 __global__ __launch_bounds__( MR_THREADS, ( PP && !HOIST ) ? 4 : 2 ) void k_analyze_bs( AnalyzeParams p, BsPlan pl, BsTables g )
 	{
 	static_assert( PP || !HOIST, "HOIST is a ping-pong layout" );
+	static_assert( !GLOB || ( PP && !HOIST ), "GLOB is a ping-pong layout" );
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = threadIdx.x;
 	const int C = pl.C, M = pl.M, W = p.window_size, hop = p.hop, dft = 2 * C;
 	__shared__ int s_cancel;
 	if( tid == 0 ) s_cancel = cancel_peek( p.cancel );
-	const BsLds l = bs_carve<PP>( smem, g, M, tid );
+	const BsLds l = bs_carve<PP, GLOB>( smem, g, M, tid );
 	cf * buf = l.buf;
 	const bool sums = PP && p.sums != nullptr;                                        // (k_analyze_mr: the fused round trip's pre-pass inside the kernel)
 	double * s_sum = reinterpret_cast<double*>( l.state );                            // [C + 1] (PP)
@@ -306,10 +323,11 @@ __global__ __launch_bounds__( MR_THREADS, ( PP && !HOIST ) ? 4 : 2 ) void k_anal
 
 // ---- PV::convert_to_audio (Conversions/AudioPV.cpp:86-139): one block per chain, from the carries of the common pre-pass ------------------
 // (HOIST as in k_analyze_bs: bh, chirp, split twiddles and the scaled window in registers; the next frame's PV row requested under the passes)
-template<bool PP, bool HOIST>
+template<bool PP, bool HOIST, bool GLOB = false>
 __global__ __launch_bounds__( MR_THREADS, ( PP && !HOIST ) ? 4 : 2 ) void k_synthesize_bs( SynthParams p, BsPlan pl, BsTables g )
 	{
 	static_assert( PP || !HOIST, "HOIST is a ping-pong layout" );
+	static_assert( !GLOB || ( PP && !HOIST ), "GLOB is a ping-pong layout" );
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int tid = threadIdx.x;
 	const int C = pl.C, M = pl.M, W = p.window_size, hop = p.hop;
@@ -317,7 +335,7 @@ __global__ __launch_bounds__( MR_THREADS, ( PP && !HOIST ) ? 4 : 2 ) void k_synt
 	const bool win_lds = pl.win_lds != 0;
 	__shared__ int s_cancel;
 	if( tid == 0 ) s_cancel = cancel_peek( p.cancel );
-	const BsLds l = bs_carve<PP>( smem, g, M, tid );
+	const BsLds l = bs_carve<PP, GLOB>( smem, g, M, tid );
 	cf * buf = l.buf;
 	double * s_ph = reinterpret_cast<double*>( l.state );                             // [C + 2]
 	float * ring = reinterpret_cast<float*>( s_ph + ( C + 2 ) );                       // [wpad]

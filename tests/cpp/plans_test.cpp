@@ -31,7 +31,7 @@ template<class Plan> static void check_passes( const Plan & f, int M, int dft, b
 
 int main()
 	{
-	int n_bs = 0, n_big = 0, n_mixed = 0;
+	int n_bs = 0, n_big = 0, n_mixed = 0, n_used = 0;
 	for( int dft = 4; dft <= ( 1 << 20 ); dft += 2 )
 		{
 		BsPlan bs{}; BigPlan big{};
@@ -41,7 +41,8 @@ int main()
 		if( is_bs )
 			{
 			++n_bs;
-			CHECK( bs.C == C && bs.M >= 2 * C - 1 && bs.M <= BS_MAX_M && ( bs.M & ( bs.M - 1 ) ) == 0 && bs.M < 4 * C, "dft %d: M = %d", dft, bs.M );
+			CHECK( bs.C == C && bs.M >= 2 * C - 1 && bs.M <= BSG_MAX_M && ( bs.M & ( bs.M - 1 ) ) == 0 && bs.M < 4 * C, "dft %d: M = %d", dft, bs.M );
+			CHECK( ( bs.glob != 0 ) == ( bs.M > BS_MAX_M ), "dft %d: M = %d, glob %d", dft, bs.M, bs.glob );
 			CHECK( C >= BS_MIN_C && !bs_has_small_factors_only( C ), "dft %d is no chirp-z size", dft );
 			CHECK( bs.sign_c == ( ( C & 1 ) ? -1.0f : 1.0f ), "dft %d: sign", dft );
 			if( dft % 97 == 0 || dft < 20000 ) check_passes( bs, bs.M, dft );
@@ -76,7 +77,11 @@ int main()
 			CHECK( big.N1 == ( 2048 + big.C2 - 1 ) / big.C2 && big.limit == ( 2048 < big.C2 ? 2048 : big.C2 ), "dft %d: a window of 4096 samples = 2048 points in segments of C2 = %d", dft, big.C2 );
 			if( dft % 1024 == 0 || ( big.mixed && dft % 100 == 0 ) ) check_passes( big.fft, big.C2, dft, !big.mixed );
 			}
-		CHECK( !( is_bs && is_big ), "dft %d claimed twice", dft );
+		BsPlan used{};
+		const bool in_use = bs_plan_in_use( dft, &used );
+		CHECK( in_use == ( is_bs && !( bs.glob && is_big ) ), "dft %d: chirp-z plan in use %d, plan %d, glob %d, residue pairs %d", dft, int( in_use ), int( is_bs ), bs.glob, int( is_big ) );
+		if( in_use ) ++n_used;
+		CHECK( !( is_bs && !bs.glob && is_big ), "dft %d claimed twice", dft );
 		}
 	// windows: segments and the limit of the first pass
 	for( int W : { 2, 5, 4096, 4097, 8192, 8193, 12000, 32768 } )
@@ -92,7 +97,10 @@ int main()
 	CHECK( big_make_plan( 32768, 4096, &big ) && !big.mixed && big.C2 == 4096, "32768 stays a power-of-two plan" );
 	CHECK( !big_make_plan( 2 * 10007, 4096, &big ), "2 x 10007: a prime half" );
 	CHECK( !bs_make_plan( 3000, &bs ) && bs_make_plan( 2998, &bs ) && bs.M == 4096, "3000 is smooth, 2998 = 2 x 1499 is not" );
-	CHECK( bs_make_plan( 8186, &bs ) && bs.M == 8192 && !bs_make_plan( 8198, &bs ), "the chirp-z sizes end where M = 8192 does" );
-	std::printf( "%d chirp-z sizes, %d sizes above 16384 (%d of them mixed-radix); %s\n", n_bs, n_big, n_mixed, fails ? "FAILED" : "PASSED" );
+	CHECK( bs_make_plan( 8186, &bs ) && bs.M == 8192 && !bs.glob && bs_make_plan( 8198, &bs ) && bs.M == 16384 && bs.glob, "M = 8192 is the last LDS layout; 8198 = 2 x 4099 runs in device memory" );
+	CHECK( bs_plan_in_use( 9998, &bs ) && bs.M == 16384 && bs_plan_in_use( 30002, &bs ) && bs.M == 32768, "9998 and 30002 (no residue-pair plan): in device memory" );
+	CHECK( !bs_plan_in_use( 180360, &bs ) && bs_make_plan( 180360, &bs ), "180360 = 2 x 167 x 540 has a residue-pair plan: that comes first" );
+	CHECK( !bs_make_plan( 2 * 131101, &bs ), "2 x 131101: M would be 2^19" );
+	std::printf( "%d chirp-z plans (%d in use), %d sizes above 16384 with residue pairs (%d of them mixed-radix); %s\n", n_bs, n_used, n_big, n_mixed, fails ? "FAILED" : "PASSED" );
 	return fails ? 1 : 0;
 	}

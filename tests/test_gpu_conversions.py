@@ -211,6 +211,15 @@ CASES = [
     ("dft16384_win16384_hop4100", 1, 200000, 16384, 4100, 16384, "noise"),
     ("dft15000_win14000_hop3500", 1, 150000, 14000, 3500, 15000, "noise"),
     ("dft16384_win8192_hop256_one_frame", 1, 100, 8192, 256, 16384, "noise"),
+    # Bluestein's form with its buffers in device memory (BsPlan::glob, round 6): sizes above 8192 with a prime factor above 13 in every divisor of their half --
+    # 9998 = 2 x 4999, 10002 = 2 x 3 x 1667 (M = 16384), 30002 = 2 x 7 x 2143 (above 16384, no residue-pair plan: M = 32768) -- the direct sums until now
+    ("dft9998_chirp_in_memory", 1, 60000, 4096, 1024, 9998, "noise"),
+    ("dft9998_full_window_stereo_ragged", 2, 50123, 9998, 2499, 9998, "noise"),
+    ("dft10002_win2000", 1, 30000, 2000, 500, 10002, "noise"),
+    ("dft30002_win8000", 1, 60000, 8000, 2000, 30002, "noise"),
+    ("dft9998_sine", 1, 48000, 4096, 1024, 9998, "sine"),
+    ("dft9998_one_frame", 1, 100, 4096, 1024, 9998, "noise"),
+    ("dft9998_zeros", 1, 20000, 4096, 1024, 9998, "zeros"),
     ("dft66", 1, 3000, 64, 16, 66, "noise"),
     ("dft6_win4", 1, 300, 4, 2, 6, "noise"),
     ("dft3000_sine", 1, 48000, 2048, 512, 3000, "sine"),
@@ -220,9 +229,12 @@ CASES = [
 
 
 def chirp_z_size(dft):
-    """bs_plan.h: half the size with a prime factor above 13, 64 <= dft / 2 <= 4096"""
+    """bs_plan.h: half the size with a prime factor above 13, 64 <= dft / 2 <= 4096 -- or (round 6, the layout in device memory) up to 131072 where no
+    residue-pair plan exists (bs_plan_in_use)"""
     c = dft // 2
-    if dft % 2 or c < 64 or c > 4096:
+    if dft % 2 or c < 64 or c > 131072:
+        return False
+    if c > 4096 and dft > 16384 and _big_mixed_plan(dft) is not None:
         return False
     for r in (2, 3, 5, 7, 11, 13):
         while c % r == 0:
@@ -1001,7 +1013,8 @@ def test_cancellation_is_scoped_to_the_stream_waited_on(fa):
 
 
 @pytest.mark.parametrize("W,hop,dft", [(2048, 512, 3000), (4096, 1024, 16384), (600, 150, 1000), (1024, 256, 2998), (2048, 512, 5998), (4096, 1024, 32768),
-                                       (4096, 1024, 20000), (2048, 512, 22050), (2048, 512, 17836), (8192, 256, 16384), (10000, 2500, 16384)])
+                                       (4096, 1024, 20000), (2048, 512, 22050), (2048, 512, 17836), (8192, 256, 16384), (10000, 2500, 16384),
+                                       (4096, 1024, 9998), (2000, 500, 10002), (8000, 2000, 30002)])
 def test_mixed_radix_kernels_against_the_direct_sums(fa, W, hop, dft):
     """The mixed-radix FFT kernels (pv_kernels_mr.h) against the transform's definition summed in fp64 (pv_kernels_any.h, the force_direct hook)
     on the same input: PVs agree like two FFT backends do, audio from the SAME PV to 1e-6."""

@@ -2,7 +2,7 @@
 """Where are the cliffs?  Round trips (fused analysis -> synthesis) over a grid of plausible shapes -- dft a power of two 256 ... 32768, window = dft, dft / 2, dft / 4,
 hop = window / 2 ... window / 32 -- on one input (default 4 ch x 30 s), in one process: G bins/s per shape, so that a shape off every tuned grid shows as an outlier.
 
-    python tools/shape_sweep.py [channels] [seconds]"""
+    python tools/shape_sweep.py [channels] [seconds] [odd: windows / hops off every grid, dft sizes that are no power of two]"""
 import ctypes
 import os
 import sys
@@ -20,12 +20,21 @@ n = int(seconds * SR)
 audio = torch.empty((ch, n), dtype=torch.float32, device=dev)
 fa.check(fa.lib.flanhip_noise_dev(ctypes.c_void_p(audio.data_ptr()), ch, n, 99, None))
 rows = []
-for lg in range(8, 16):
-    dft = 1 << lg
-    for wd in (1, 2, 4):
-        W = dft // wd
-        for hd in (2, 4, 8, 16, 32):
-            hop = W // hd
+shapes = []
+if len(sys.argv) > 3 and sys.argv[3] == "odd":
+    # windows and hops off every grid, dft sizes that are no power of two (mixed radix, chirp-z, residue pairs, and one size only the direct sums serve)
+    for dft in [int(v) for v in os.environ.get("SWEEP_DFTS", "1024,2048,4096,8192,16384,32768,3000,4410,6000,10000,12000,15000,20000,22050,44100,48000,2998,8186,9998").split(",")]:
+        for W in sorted({min(dft, 1000), min(dft, 2000), (dft // 2) | 1 if dft > 8 else dft, dft - 2 if dft % 4 else dft - 6, dft}):
+            for hop in (W // 4, max(W // 7, 1), 441 if W >= 882 else W // 3):
+                shapes.append((dft, W, hop))
+else:
+    for lg in range(8, 16):
+        for wd in (1, 2, 4):
+            for hd in (2, 4, 8, 16, 32):
+                shapes.append((1 << lg, (1 << lg) // wd, ((1 << lg) // wd) // hd))
+for (dft, W, hop) in shapes:
+    if True:
+        if True:
             if hop < 8:
                 continue
             F = int(fa.lib.flanhip_num_pv_frames(n, hop))
@@ -35,7 +44,11 @@ for lg in range(8, 16):
             ar = SR / hop
             pv = torch.empty((ch, F, bins, 2), dtype=torch.float32, device=dev)
             out = torch.empty((ch, F * hop), dtype=torch.float32, device=dev)
-            ws = torch.empty(fa.synthesize_workspace_bytes(ch, F, bins, SR, ar, W), dtype=torch.uint8, device=dev)
+            wsb = fa.synthesize_workspace_bytes(ch, F, bins, SR, ar, W)
+            if wsb == 0:                                           # refused (dft x window overflows the int product of AudioPV.cpp:99 ...)
+                print("dft %5d  W %5d  hop %5d   refused: %s" % (dft, W, hop, fa.last_error()), flush=True)
+                continue
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
 
             def rt():
                 fa.analyze_dev_fused(audio, ch, n, SR, W, hop, dft, pv, ws, None)
