@@ -100,6 +100,95 @@ template<bool PP, bool MUL> __device__ __forceinline__ void bs_pass0( cf * src, 
 		}
 	}
 
+// ---- BsPlan::glob: the passes between two buffers in device memory.  Four butterflies per thread and trip, every load of the trip requested before the
+// first butterfly is worked out (src and dst are different buffers: __restrict__ lets the loads pass the stores) -- a trip is one round trip to L2, not four
+template<int R> __device__ __forceinline__ void bsg_pass( const cf * __restrict__ src, cf * __restrict__ dst, const cf * __restrict__ tw, int M, int NS, unsigned magic, int stride, int tid )
+	{
+	constexpr int B = R == 8 ? 4 : 8;
+	const int NB = M / R;
+	for( int j0 = tid; j0 < NB; j0 += B * MR_THREADS )
+		{
+		cf v[B][R];
+		#pragma unroll
+		for( int b = 0; b < B; ++b )
+			{
+			const int j = min( j0 + MR_THREADS * b, NB - 1 );
+			#pragma unroll
+			for( int r = 0; r < R; ++r ) v[b][r] = src[PAD( j + r * NB )];
+			}
+		#pragma unroll
+		for( int b = 0; b < B; ++b )
+			{
+			const int j = j0 + MR_THREADS * b;
+			if( j >= NB ) continue;
+			const int k = NS > 1 ? j - int( __umulhi( unsigned( j ), magic ) ) * NS : 0;      // j % NS (exact up to M = 2^18: bs_plan.h)
+			if( NS > 1 )
+				{
+				const int step = k * stride;
+				#pragma unroll
+				for( int r = 1; r < R; ++r ) v[b][r] = cmul( v[b][r], tw[r * step] );
+				}
+			dft_reg<R>( v[b] );
+			const int base = ( j - k ) * R + k;
+			#pragma unroll
+			for( int r = 0; r < R; ++r ) dst[PAD( base + r * NS )] = v[b][r];
+			}
+		}
+	__syncthreads();
+	}
+// the first pass (radix 8, no twiddles): MUL = false: points from `limit` on are zero; MUL = true: conj( src[i] bh[i] )
+template<bool MUL> __device__ __forceinline__ void bsg_pass0( const cf * __restrict__ src, cf * __restrict__ dst, int M, int limit, const d2 * __restrict__ bh, int tid )
+	{
+	constexpr int B = 2;
+	const int NB = M / 8;
+	for( int j0 = tid; j0 < NB; j0 += B * MR_THREADS )
+		{
+		cf v[B][8];
+		#pragma unroll
+		for( int b = 0; b < B; ++b )
+			{
+			const int j = min( j0 + MR_THREADS * b, NB - 1 );
+			#pragma unroll
+			for( int r = 0; r < 8; ++r )
+				{
+				const int idx = j + r * NB;
+				if constexpr( MUL ) v[b][r] = conj_f( cmul_d( src[PAD( idx )], bh[idx] ) );
+				else v[b][r] = idx < limit ? src[PAD( idx )] : mk( 0.0f, 0.0f );
+				}
+			}
+		#pragma unroll
+		for( int b = 0; b < B; ++b )
+			{
+			const int j = j0 + MR_THREADS * b;
+			if( j >= NB ) continue;
+			dft_reg<8>( v[b] );
+			#pragma unroll
+			for( int r = 0; r < 8; ++r ) dst[PAD( j * 8 + r )] = v[b][r];
+			}
+		}
+	__syncthreads();
+	}
+template<bool MUL> __device__ __forceinline__ cf * bsg_fft( cf * a, cf * b, const BsTables & tb, const BsPlan & pl, int limit, int tid )
+	{
+	cf * src = a, * dst = b;
+	bsg_pass0<MUL>( src, dst, pl.M, limit, tb.bh, tid );
+	{ cf * t = src; src = dst; dst = t; }
+	int NS = 8;
+	for( int i = 1; i < pl.npass; ++i )
+		{
+		const int r = pl.radix[i];
+		switch( r )
+			{
+			case 8:  bsg_pass<8>( src, dst, tb.tw, pl.M, NS, pl.magic[i], pl.stride[i], tid ); break;
+			case 4:  bsg_pass<4>( src, dst, tb.tw, pl.M, NS, pl.magic[i], pl.stride[i], tid ); break;
+			default: bsg_pass<2>( src, dst, tb.tw, pl.M, NS, pl.magic[i], pl.stride[i], tid ); break;
+			}
+		NS *= r;
+		{ cf * t = src; src = dst; dst = t; }
+		}
+	return src;
+	}
+
 // forward transform of the M points in `a` (natural order in and out), the first pass as above; returns where the result stands
 template<bool PP, bool MUL> __device__ __forceinline__ cf * bs_fft( cf * a, cf * b, const BsTables & tb, const BsPlan & pl, int limit, int tid, const d2 * bhr = nullptr )
 	{
@@ -152,7 +241,7 @@ template<bool PP, bool GLOB = false> __device__ __forceinline__ BsLds bs_carve( 
 // under this frame's bins.  Without it a frame waited for L2 three times (12.8 us a frame at dft 2998; the passes themselves are ~4).
 // GLOB (round 6, BsPlan::glob): M = 16384 ... 2^18 -- the ping-pong kernel with its buffers and its state in device memory (no LDS at all)
 template<bool PP, bool HOIST, bool GLOB = false>
-__global__ __launch_bounds__( MR_THREADS, ( PP && !HOIST ) ? 4 : 2 ) void k_analyze_bs( AnalyzeParams p, BsPlan pl, BsTables g )
+__global__ __launch_bounds__( MR_THREADS, ( PP && !HOIST && !GLOB ) ? 4 : 2 ) void k_analyze_bs( AnalyzeParams p, BsPlan pl, BsTables g )
 	{
 	static_assert( PP || !HOIST, "HOIST is a ping-pong layout" );
 	static_assert( !GLOB || ( PP && !HOIST ), "GLOB is a ping-pong layout" );
@@ -249,8 +338,8 @@ __global__ __launch_bounds__( MR_THREADS, ( PP && !HOIST ) ? 4 : 2 ) void k_anal
 				}
 			}
 		__syncthreads();
-		cf * const A = bs_fft<PP, false>( in, other, l.tb, pl, C, tid );
-		const cf * const R = bs_fft<PP, true>( A, A == in ? other : in, l.tb, pl, M, tid, HOIST ? bhr : nullptr );
+		cf * const A = GLOB ? bsg_fft<false>( in, other, l.tb, pl, C, tid ) : bs_fft<PP, false>( in, other, l.tb, pl, C, tid );
+		const cf * const R = GLOB ? bsg_fft<true>( A, A == in ? other : in, l.tb, pl, M, tid ) : bs_fft<PP, true>( A, A == in ? other : in, l.tb, pl, M, tid, HOIST ? bhr : nullptr );
 		if constexpr( HOIST ) { if( t + 1 < t1 ) request( t + 1 ); }
 
 		// the real transform's bins from the half-size one, each phase-vocoded (AudioPV.cpp:69-73);  Z[k] = conj( w[k] R[k] ),  w[C - k] = +- w[k]
@@ -324,7 +413,7 @@ __global__ __launch_bounds__( MR_THREADS, ( PP && !HOIST ) ? 4 : 2 ) void k_anal
 // ---- PV::convert_to_audio (Conversions/AudioPV.cpp:86-139): one block per chain, from the carries of the common pre-pass ------------------
 // (HOIST as in k_analyze_bs: bh, chirp, split twiddles and the scaled window in registers; the next frame's PV row requested under the passes)
 template<bool PP, bool HOIST, bool GLOB = false>
-__global__ __launch_bounds__( MR_THREADS, ( PP && !HOIST ) ? 4 : 2 ) void k_synthesize_bs( SynthParams p, BsPlan pl, BsTables g )
+__global__ __launch_bounds__( MR_THREADS, ( PP && !HOIST && !GLOB ) ? 4 : 2 ) void k_synthesize_bs( SynthParams p, BsPlan pl, BsTables g )
 	{
 	static_assert( PP || !HOIST, "HOIST is a ping-pong layout" );
 	static_assert( !GLOB || ( PP && !HOIST ), "GLOB is a ping-pong layout" );
@@ -444,8 +533,8 @@ __global__ __launch_bounds__( MR_THREADS, ( PP && !HOIST ) ? 4 : 2 ) void k_synt
 				}
 			}
 		__syncthreads();
-		cf * const A = bs_fft<PP, false>( buf, l.buf2, l.tb, pl, C, tid );
-		const cf * const R = bs_fft<PP, true>( A, A == buf ? l.buf2 : buf, l.tb, pl, M, tid, HOIST ? bhr : nullptr );   // (lands in buf: two transforms of equally many passes)
+		cf * const A = GLOB ? bsg_fft<false>( buf, l.buf2, l.tb, pl, C, tid ) : bs_fft<PP, false>( buf, l.buf2, l.tb, pl, C, tid );
+		const cf * const R = GLOB ? bsg_fft<true>( A, A == buf ? l.buf2 : buf, l.tb, pl, M, tid ) : bs_fft<PP, true>( A, A == buf ? l.buf2 : buf, l.tb, pl, M, tid, HOIST ? bhr : nullptr );   // (lands in buf: two transforms of equally many passes)
 		// G[n] = conj( w[n] R[n] ) = fft_C( conj Z )[n]:  x[2n] = G[n].x, x[2n+1] = -G[n].y (AudioPV.cpp:122); window, accumulate (:133-134)
 		auto accumulate = [&]( int n, d2 ch, float wa0, float wa1 )
 			{
