@@ -26,9 +26,9 @@ public:
 	// ---- conversions ----
 	/** Windowed STFT + per-bin phase vocoding (Conversions/AudioPV.cpp:12-78).  dft_size: any EVEN size >= window_size up to 2^20 (the reference hands it
 	 *  to FFTW as it is, FFTHelper.cpp:16-26).  Powers of two from 32 to 16384 run register / LDS FFT kernels (tuned ones at 256 ... 16384); sizes whose
-	 *  half factors into 2 ... 13 a mixed-radix transform; sizes with a larger prime factor, up to 8192, Bluestein's chirp-z form; sizes above 16384 whose
-	 *  half is C1 <= 256 times a product of 2 ... 13 up to 4096 (32768, 20000, 44100, 48000 ...) a two-level split; only what none of these serves (above
-	 *  8192 with a large prime factor in the half) falls to the direct sums (O( window x bins ) per frame, same results).
+	 *  half factors into 2 ... 13 a mixed-radix transform; sizes above 16384 whose half is C1 <= 256 times a product of 2 ... 13 up to 4096 (32768, 20000,
+	 *  44100, 48000 ...) a two-level split; every other size up to 262144 (a large prime factor in the half) Bluestein's chirp-z form; only above that
+	 *  what none of these serves falls to the direct sums (O( window x bins ) per frame, same results).
 	 *  An odd size, or one below the window, returns a null PV. */
 	PV convert_to_PV( Frame window_size = 2048, Frame hop = 128, Frame dft_size = 4096, flan_CANCEL_ARG ) const;  // Audio.h:158-163
 	/** Stereo only: mid/side first (AudioPV.cpp:80-84). */
