@@ -839,7 +839,10 @@ def other_configs(fa, torch, dev):
                                 # ... and dft 8192 / 16384: teams of four / eight wavefronts per chain (pv_kernels_team.h, round 6; before: the round-1 block kernels 0.92 ms, mixed radix 4.4 ms)
                                 (2048, "dft8192_window8192_hop2048", 8192, 8192), (1024, "dft16384_window4096_hop1024", 4096, 16384),
                                 (512, "dft2998_window2048_hop512_chirp_z", 2048, 2998), (1024, "dft32768_window4096_hop1024", 4096, 32768),
-                                (1024, "dft20000_window4096_hop1024_mixed_radix", 4096, 20000)):
+                                (1024, "dft20000_window4096_hop1024_mixed_radix", 4096, 20000),
+                                # ... the reference API's default ratio (window = dft / 2, hop = window / 16) at dft 16384: the team kernels at half a step (round 6; it ran the
+                                # DIRECT SUMS before: 786 ms), and a size with a large prime factor above 8192 (9998 = 2 x 4999): chirp-z in device memory (round 6; ~150 ms before)
+                                (512, "dft16384_window8192_hop512_api_ratio", 8192, 16384), (2499, "dft9998_window9998_hop2499_chirp_z_in_memory", 9998, 9998)):
         bins = dft // 2 + 1
         Fd = int(lib.flanhip_num_pv_frames(n, hop))
         ard = SR / hop

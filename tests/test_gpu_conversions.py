@@ -1014,7 +1014,7 @@ def test_cancellation_is_scoped_to_the_stream_waited_on(fa):
 
 @pytest.mark.parametrize("W,hop,dft", [(2048, 512, 3000), (4096, 1024, 16384), (600, 150, 1000), (1024, 256, 2998), (2048, 512, 5998), (4096, 1024, 32768),
                                        (4096, 1024, 20000), (2048, 512, 22050), (2048, 512, 17836), (8192, 256, 16384), (10000, 2500, 16384),
-                                       (4096, 1024, 9998), (2000, 500, 10002), (8000, 2000, 30002)])
+                                       (4096, 1024, 9998), (2000, 500, 10002), (8000, 2000, 30002), (4096, 1024, 262142)])   # (262142 = 2 x ( 2^17 - 1 ): the largest chirp-z size, M = 2^18)
 def test_mixed_radix_kernels_against_the_direct_sums(fa, W, hop, dft):
     """The mixed-radix FFT kernels (pv_kernels_mr.h) against the transform's definition summed in fp64 (pv_kernels_any.h, the force_direct hook)
     on the same input: PVs agree like two FFT backends do, audio from the SAME PV to 1e-6."""
