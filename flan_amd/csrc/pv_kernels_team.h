@@ -98,6 +98,7 @@ __global__ __launch_bounds__( 64 * R * TEAMS, 2 ) void k_analyze_team( AnalyzePa
 	{
 	using L = TeamLds<R, TEAMS, WINLDS ? 64 * R * WQ : 0>;
 	static_assert( R == 4 || R == 8, "teams of four or eight wavefronts" );
+	static_assert( WQ == 2 || WQ == 4 || WQ == 8 || WQ == 16, "window / 128 R" );
 	constexpr int S = 1024, CT = S * R, KQ = 8 / R, NT = 64 * R * TEAMS, NB = 2 * R;      // NB: bins per k-group
 	constexpr int NV = 8, NG = NB / NV;                                            // bins per vector stream, streams per group
 	typedef float VB __attribute__(( ext_vector_type( NV ) ));
@@ -409,15 +410,17 @@ __global__ __launch_bounds__( 64 * R * TEAMS, 2 ) void k_analyze_team( AnalyzePa
 
 
 // =================================================================================================================
-// PV::convert_to_audio (Conversions/AudioPV.cpp:86-139), dft 8192 / 16384: see the head of the file.  HS = hop / 128 R (0: hop = 64 R, half a step), WQ = W / 128 R.
+// PV::convert_to_audio (Conversions/AudioPV.cpp:86-139), dft 8192 / 16384: see the head of the file.  HS = hop / 128 R (0: hop = 64 R, half a step; -4 / -8: a quarter / an eighth), WQ = W / 128 R.
 template<int R, int TEAMS, int WQ, int HS, bool WINLDS>
 __global__ __launch_bounds__( 64 * R * TEAMS, 2 ) void k_synthesize_team( SynthParams p, TeamTables tb )
 	{
 	using L = TeamLds<R, TEAMS, WINLDS ? 64 * R * WQ : 0>;
 	static_assert( R == 4 || R == 8, "teams of four or eight wavefronts" );
-	static_assert( HS >= 0 && HS <= WQ, "hop <= window; HS = 0: half a step" );
+	static_assert( HS <= WQ && ( HS >= 0 || HS == -4 || HS == -8 ), "hop <= window; HS = 0: half a step, -4 / -8: a quarter / an eighth" );
 	constexpr int S = 1024, CT = S * R, KQ = 8 / R, NT = 64 * R * TEAMS, NB = 2 * R, STEP = 128 * R;
-	constexpr int hop = HS ? HS * STEP : STEP / 2, W = WQ * STEP;
+	constexpr int FR = HS > 0 ? 1 : HS == 0 ? 2 : -HS;                          // a hop is 1 / FR of a step below a whole step: LN = 64 / FR lanes of an accumulator register
+	constexpr int LN = 64 / FR;
+	constexpr int hop = HS > 0 ? HS * STEP : STEP / FR, W = WQ * STEP;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	cf * s = reinterpret_cast<cf*>( smem );
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane( tid >> 6 ), team = wave / R, role = wave % R;
@@ -503,11 +506,14 @@ __global__ __launch_bounds__( 64 * R * TEAMS, 2 ) void k_synthesize_team( SynthP
 	// HS = 0 (hop = half a step: the reference API's hop = window / 16 at window = dft / 2 -- ( 4096, 256, 8192 ), ( 8192, 512, 16384 )): a finished hop is the lower 32
 	// lanes of acc[0], and the accumulator moves on by 32 lanes (k_synthesize_eo_team's hop 128: one v_permlane32_swap and one select per register).  The lanes
 	// 32 part .. 32 part + 31 of v hold samples a0 + 2 R ( lane & 31 ) + 2 role (+1); the other lanes dump (never at agent scope: pv_kernels_eo.h)
+	// (HS = -4 / -8, hop = a quarter / an eighth of a step -- the reference API's default hop 128 kept while dft and window grow: ( 2048, 128, 8192 ),
+	// ( 2048, 128, 16384 ): the same with 16 / 8 lanes per hop, the accumulator moving on through ds_bpermute)
 	auto emit_half = [&]( int64_t a0, cf v, int part )
 		{
-		const int64_t a = a0 + 2 * R * ( lane & 31 ) + 2 * role;
+		const int lp = lane - LN * part;                                           // the lane's place in the part
+		const int64_t a = a0 + 2 * R * lp + 2 * role;
 		cf * dst = ( a0 < own_start ) ? head2 + ( ( a - chain_start ) >> 1 ) : out2 + ( a >> 1 );
-		const bool idle = ( lane >> 5 ) != part;
+		const bool idle = lp < 0 || lp >= LN;
 		if( idle || ( a0 >= own_start && !( a >= 0 && a < p.out_len ) ) ) dst = dump2;
 		if( fix && a0 < own_start ) { if( !idle ) st_agent( dst, v ); }
 		else *dst = v;
@@ -709,6 +715,22 @@ __global__ __launch_bounds__( 64 * R * TEAMS, 2 ) void k_synthesize_team( SynthP
 				acc[q] = mk( rotate_half( acc[q].x, nxt.x, low ), rotate_half( acc[q].y, nxt.y, low ) );
 				}
 			}
+		else if constexpr( HS < 0 )
+			{
+			// the accumulator moves on by LN lanes: new acc[q] = { lanes LN .. 63 of acc[q], lanes 0 .. LN - 1 of acc[q + 1] }
+			emit_half( pos, acc[0], 0 );
+			const int from = ( ( lane + LN ) & 63 ) * 4;
+			const bool keep = lane < 64 - LN;
+			cf rot = mk( __int_as_float( __builtin_amdgcn_ds_bpermute( from, __float_as_int( acc[0].x ) ) ), __int_as_float( __builtin_amdgcn_ds_bpermute( from, __float_as_int( acc[0].y ) ) ) );
+			#pragma unroll
+			for( int q = 0; q < WQ; ++q )
+				{
+				cf nxt = mk( 0.0f, 0.0f );
+				if( q + 1 < WQ ) nxt = mk( __int_as_float( __builtin_amdgcn_ds_bpermute( from, __float_as_int( acc[q + 1].x ) ) ), __int_as_float( __builtin_amdgcn_ds_bpermute( from, __float_as_int( acc[q + 1].y ) ) ) );
+				acc[q] = mk( keep ? rot.x : nxt.x, keep ? rot.y : nxt.y );
+				rot = nxt;
+				}
+			}
 		else
 			{
 			#pragma unroll
@@ -727,16 +749,16 @@ __global__ __launch_bounds__( 64 * R * TEAMS, 2 ) void k_synthesize_team( SynthP
 	const int64_t flush_end = last_chain ? max( ring_end, p.out_len ) : ring_end;
 	if( !fix || last_chain )
 		{
-		if constexpr( HS == 0 )
+		if constexpr( HS <= 0 )
 			{
-			// W - hop = WQ - 1/2 steps: by halves (the next chain writes from ring_end on itself)
+			// W - hop = WQ - 1 / FR steps: by parts of a step (the next chain writes from ring_end on itself)
 			#pragma unroll
-			for( int h = 0; h < 2 * WQ; ++h )
+			for( int h = 0; h < FR * WQ; ++h )
 				{
-				const int64_t a0 = pos + ( STEP / 2 ) * h;
-				if( a0 < flush_end ) emit_half( a0, acc[h >> 1], h & 1 );
+				const int64_t a0 = pos + ( STEP / FR ) * h;
+				if( a0 < flush_end ) emit_half( a0, acc[h / FR], h % FR );
 				}
-			for( int64_t a0 = pos + STEP * WQ; a0 < flush_end; a0 += STEP / 2 ) emit_half( a0, mk( 0.0f, 0.0f ), 0 );
+			for( int64_t a0 = pos + STEP * WQ; a0 < flush_end; a0 += STEP / FR ) emit_half( a0, mk( 0.0f, 0.0f ), 0 );
 			}
 		else
 			{

@@ -8,15 +8,24 @@ namespace flanhip {
 
 // ( window / 128 R, hop / 128 R ) the synthesis is instantiated for; hop 0 = HALF a step (64 R samples): with it hop = window / 16 is served at window = dft / 2
 // and dft / 4 -- the reference API's default ratio, ( 4096, 256, 8192 ) and ( 8192, 512, 16384 ) -- and ( 16, 1 ) serves it at window = dft
-#define FLANHIP_TEAM_SHAPES( X ) X( 4, 0 ) X( 4, 1 ) X( 4, 2 ) X( 8, 0 ) X( 8, 1 ) X( 8, 2 ) X( 8, 4 ) X( 16, 1 ) X( 16, 2 ) X( 16, 4 ) X( 16, 8 )
+// ... hop -4 / -8 = a QUARTER / an EIGHTH of a step: the API's default hop 128 kept while the sizes grow -- ( 2048, 128, 8192 ) = ( 4, -4 ), ( 2048, 128, 16384 ) =
+// ( 2, -8 ), ( 4096, 128, 8192 ) = ( 8, -4 ), ( 4096, 256, 16384 ) = ( 4, -4 ) ...
+#define FLANHIP_TEAM_SHAPES( X ) X( 4, 0 ) X( 4, 1 ) X( 4, 2 ) X( 8, 0 ) X( 8, 1 ) X( 8, 2 ) X( 8, 4 ) X( 16, 1 ) X( 16, 2 ) X( 16, 4 ) X( 16, 8 ) \
+	X( 2, 0 ) X( 2, 1 ) X( 2, -4 ) X( 2, -8 ) X( 4, -4 ) X( 4, -8 ) X( 8, -4 ) X( 8, -8 ) X( 16, -4 )
 
 bool team_shape( int dft, int W, int hop )
 	{
 	const int R = team_radix( dft );
 	if( !R || debug_options().force_generic || debug_options().force_direct ) return false;
 	const int step = 128 * R;
-	if( W % step || ( hop % step && 2 * hop != step ) || hop > W || hop < 1 ) return false;
-	const int wq = W / step, hs = hop / step;                                 // ( 0: half a step)
+	if( W % step || hop > W || hop < 1 ) return false;
+	const int wq = W / step;
+	int hs;                                                                   // whole steps; 0: half a step; -4 / -8: a quarter / an eighth
+	if( hop % step == 0 ) hs = hop / step;
+	else if( 2 * hop == step ) hs = 0;
+	else if( 4 * hop == step ) hs = -4;
+	else if( 8 * hop == step ) hs = -8;
+	else return false;
 #define X( WQ, HS ) if( wq == WQ && hs == HS ) return true;
 	FLANHIP_TEAM_SHAPES( X )
 #undef X
@@ -80,6 +89,7 @@ static int run_analyze_team_r( const AnalyzeParams & p, const TeamTables & tb, h
 	{
 	switch( p.window_size / ( 128 * R ) )
 		{
+		case 2:  return p.sums ? launch_analyze_team<R, 2, true>( p, tb, s ) : launch_analyze_team<R, 2, false>( p, tb, s );
 		case 4:  return p.sums ? launch_analyze_team<R, 4, true>( p, tb, s ) : launch_analyze_team<R, 4, false>( p, tb, s );
 		case 8:  return p.sums ? launch_analyze_team<R, 8, true>( p, tb, s ) : launch_analyze_team<R, 8, false>( p, tb, s );
 		case 16: return p.sums ? launch_analyze_team<R, 16, true>( p, tb, s ) : launch_analyze_team<R, 16, false>( p, tb, s );
@@ -99,7 +109,8 @@ int run_analyze_team( const AnalyzeParams & p, const Plan & plan, int dft, hipSt
 template<int R>
 static int run_synth_team_r( const SynthParams & p, const TeamTables & tb, hipStream_t s )
 	{
-	const int wq = p.window_size / ( 128 * R ), hs = p.hop / ( 128 * R );       // ( 0: half a step -- team_shape has admitted nothing else below a step)
+	const int step = 128 * R, wq = p.window_size / step;
+	const int hs = p.hop % step == 0 ? p.hop / step : 2 * p.hop == step ? 0 : 4 * p.hop == step ? -4 : -8;      // (team_shape has admitted nothing else)
 #define X( WQ, HS ) if( wq == WQ && hs == HS ) return launch_synth_team<R, WQ, HS>( p, tb, s );
 	FLANHIP_TEAM_SHAPES( X )
 #undef X

@@ -204,6 +204,17 @@ CASES = [
     ("dft16384_win16384_hop1024", 1, 200000, 16384, 1024, 16384, "noise"),
     ("dft8192_half_step_one_frame", 1, 100, 4096, 256, 8192, "noise"),
     ("dft8192_half_step_sine", 1, 48000, 4096, 256, 8192, "sine"),
+    # ... and with the API's default hop 128 kept while the sizes grow: a quarter / an eighth of a step (16 / 8 lanes per hop, the accumulator moving on through ds_bpermute),
+    # windows of two steps
+    ("dft8192_win2048_hop128_quarter_step", 1, 50000, 2048, 128, 8192, "noise"),
+    ("dft16384_win2048_hop128_eighth_step", 1, 50000, 2048, 128, 16384, "noise"),
+    ("dft8192_win4096_hop128_stereo_ragged", 2, 30123, 4096, 128, 8192, "noise"),
+    ("dft16384_win4096_hop256_quarter_step", 1, 60000, 4096, 256, 16384, "noise"),
+    ("dft8192_win1024_hop128_two_steps", 1, 30000, 1024, 128, 8192, "noise"),
+    ("dft16384_win2048_hop1024_two_steps", 1, 60000, 2048, 1024, 16384, "noise"),
+    ("dft16384_win2048_hop512_two_steps_half", 1, 60000, 2048, 512, 16384, "noise"),
+    ("dft8192_win8192_hop128_sixteen_steps_quarter", 1, 60000, 8192, 128, 8192, "noise"),
+    ("dft8192_quarter_step_one_frame", 1, 100, 2048, 128, 8192, "noise"),
     # the mixed-radix kernels with their overlap-add ring in the workspace (windows the ring does not fit the LDS with: above ~6000 samples at dft 16384 off the team grid,
     # above ~10000 at dft 15000 -- direct sums until round 6: 0.8 s for 8 ch x 60 s at ( 8192, 512, 16384 ))
     ("dft16384_win8192_hop256_ring_in_workspace", 1, 120000, 8192, 256, 16384, "noise"),
@@ -1154,6 +1165,11 @@ def test_plan_caches_are_bounded_and_evicted_sizes_come_back(fa):
     (2, 9, 4096, 512, {"dft": 16384, "chain_len": 8}),
     (2, 30, 8192, 512, {"dft": 8192}),
     (2, 30, 16384, 1024, {"dft": 16384, "chain_len": 16}),
+    # ... at a quarter / an eighth of a step
+    (2, 20, 2048, 128, {"dft": 8192}),
+    (2, 20, 2048, 128, {"dft": 16384}),
+    (3, 5, 4096, 128, {"dft": 8192, "chain_len": 33}),
+    (2, 9, 1024, 128, {"dft": 8192, "chain_len": 7}),
 ])
 def test_overlap_fixup_inside_the_kernel_equals_the_separate_launch(fa, ch, seconds, W, hop, hooks):
     """k_synthesize_v2 adds the overlaps of neighbouring chains itself (a tagged word per boundary; the head's owner publishes from inside its frame
