@@ -100,11 +100,13 @@ int flanhip_host_free(void * hptr);
 /* ---- Audio::convert_to_PV  (Conversions/AudioPV.cpp:12-78, phase_vocoder.cpp:5-53, WindowFunctions.cpp:10-13) - */
 /* audio: float[ch][n]; out: MF[ch][F][dft/2+1] with F = flanhip_num_pv_frames(n, hop), written to *num_pv_frames. */
 /* dft_size: any even size in [4, 2^20] with window_size <= dft_size (FFTHelper.cpp:16-26 hands the caller's size to FFTW as it is).  Which
- * kernels serve a size: powers of two in [32, 8192] tuned or LDS-resident FFT kernels; other sizes whose half factors
- * into 2 ... 13, up to 16384, mixed-radix FFT kernels; sizes whose half (64 ... 4096) has a larger prime factor Bluestein's chirp-z form;
- * sizes above 16384 whose half is a multiple of 1024, up to 2^20, residue-pair kernels; anything else the transform's definition summed in
- * fp64 (pv_kernels_any.h): O( window x bins ) per frame, same results.  flanhip_synthesize_workspace_bytes includes the scratch a size
- * needs (direct sums: one PV's worth of spectra + frames x window floats; above 16384: dft / 8192 + 1 output streams). */
+ * kernels serve a size: powers of two in [32, 16384] tuned or LDS-resident FFT kernels; other sizes whose half factors
+ * into 2 ... 13, up to 16384, mixed-radix FFT kernels; sizes above 16384 whose half is C1 <= 256 times a product of 2 ... 13 up to 4096 (32768 ... 2^20,
+ * 20000, 44100, 48000 ...) residue-pair kernels; every other size whose half is 64 ... 131072 (a larger prime factor) Bluestein's chirp-z form -- in LDS up
+ * to dft 8192, in device memory above (convert_to_PV takes that stretch from the stream: hipMallocAsync / hipFreeAsync around the launch); anything else
+ * the transform's definition summed in fp64 (pv_kernels_any.h): O( window x bins ) per frame, same results.  flanhip_synthesize_workspace_bytes includes
+ * the scratch a size needs (direct sums: one PV's worth of spectra + frames x window floats; residue pairs: C1 / 2 + 1 output streams; chirp-z in
+ * device memory: two frames of the transform's length per chain). */
 int flanhip_analyze(const float * audio, int64_t num_channels, int64_t num_audio_frames, float sample_rate,
                     int window_size, int hop, int dft_size,
                     flanhip_MF * out, int64_t * num_pv_frames, volatile int * cancel);
