@@ -11,7 +11,7 @@ namespace flanhip {
 // ... hop -4 / -8 = a QUARTER / an EIGHTH of a step: the API's default hop 128 kept while the sizes grow -- ( 2048, 128, 8192 ) = ( 4, -4 ), ( 2048, 128, 16384 ) =
 // ( 2, -8 ), ( 4096, 128, 8192 ) = ( 8, -4 ), ( 4096, 256, 16384 ) = ( 4, -4 ) ...
 #define FLANHIP_TEAM_SHAPES( X ) X( 4, 0 ) X( 4, 1 ) X( 4, 2 ) X( 8, 0 ) X( 8, 1 ) X( 8, 2 ) X( 8, 4 ) X( 16, 1 ) X( 16, 2 ) X( 16, 4 ) X( 16, 8 ) \
-	X( 2, 0 ) X( 2, 1 ) X( 2, -4 ) X( 2, -8 ) X( 4, -4 ) X( 4, -8 ) X( 8, -4 ) X( 8, -8 ) X( 16, -4 )
+	X( 2, 0 ) X( 2, 1 ) X( 2, -4 ) X( 2, -8 ) X( 4, -4 ) X( 4, -8 ) X( 8, -4 ) X( 8, -8 ) X( 16, 0 ) X( 16, -4 )
 
 bool team_shape( int dft, int W, int hop )
 	{

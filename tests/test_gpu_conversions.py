@@ -215,6 +215,8 @@ CASES = [
     ("dft16384_win2048_hop512_two_steps_half", 1, 60000, 2048, 512, 16384, "noise"),
     ("dft8192_win8192_hop128_sixteen_steps_quarter", 1, 60000, 8192, 128, 8192, "noise"),
     ("dft8192_quarter_step_one_frame", 1, 100, 2048, 128, 8192, "noise"),
+    ("dft16384_win16384_hop512_sixteen_steps_half", 1, 150000, 16384, 512, 16384, "noise"),
+    ("dft8192_win8192_hop256_sixteen_steps_half_stereo", 2, 60123, 8192, 256, 8192, "noise"),
     # the mixed-radix kernels with their overlap-add ring in the workspace (windows the ring does not fit the LDS with: above ~6000 samples at dft 16384 off the team grid,
     # above ~10000 at dft 15000 -- direct sums until round 6: 0.8 s for 8 ch x 60 s at ( 8192, 512, 16384 ))
     ("dft16384_win8192_hop256_ring_in_workspace", 1, 120000, 8192, 256, 16384, "noise"),
