@@ -33,36 +33,34 @@ else:
             for hd in (2, 4, 8, 16, 32):
                 shapes.append((1 << lg, (1 << lg) // wd, ((1 << lg) // wd) // hd))
 for (dft, W, hop) in shapes:
-    if True:
-        if True:
-            if hop < 8:
-                continue
-            F = int(fa.lib.flanhip_num_pv_frames(n, hop))
-            bins = dft // 2 + 1
-            if ch * F * bins * 8 > 12e9:
-                continue
-            ar = SR / hop
-            pv = torch.empty((ch, F, bins, 2), dtype=torch.float32, device=dev)
-            out = torch.empty((ch, F * hop), dtype=torch.float32, device=dev)
-            wsb = fa.synthesize_workspace_bytes(ch, F, bins, SR, ar, W)
-            if wsb == 0:                                           # refused (dft x window overflows the int product of AudioPV.cpp:99 ...)
-                print("dft %5d  W %5d  hop %5d   refused: %s" % (dft, W, hop, fa.last_error()), flush=True)
-                continue
-            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    if hop < 8:
+        continue
+    F = int(fa.lib.flanhip_num_pv_frames(n, hop))
+    bins = dft // 2 + 1
+    if ch * F * bins * 8 > 12e9:
+        continue
+    ar = SR / hop
+    pv = torch.empty((ch, F, bins, 2), dtype=torch.float32, device=dev)
+    out = torch.empty((ch, F * hop), dtype=torch.float32, device=dev)
+    wsb = fa.synthesize_workspace_bytes(ch, F, bins, SR, ar, W)
+    if wsb == 0:                                           # refused (dft x window overflows the int product of AudioPV.cpp:99 ...)
+        print("dft %5d  W %5d  hop %5d   refused: %s" % (dft, W, hop, fa.last_error()), flush=True)
+        continue
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
 
-            def rt():
-                fa.analyze_dev_fused(audio, ch, n, SR, W, hop, dft, pv, ws, None)
-                fa.synthesize_dev_fused(pv, ch, F, bins, SR, ar, W, out, ws, None, None)
-            rt()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            reps = 0
-            while reps < 3 or (time.perf_counter() - t0 < 0.05 and reps < 50):
-                rt()
-                reps += 1
-            torch.cuda.synchronize()
-            ms = (time.perf_counter() - t0) / reps * 1e3
-            gb = ch * F * bins / ms / 1e6
-            rows.append((dft, W, hop, ms, gb))
-            print("dft %5d  W %5d  hop %5d   %9.3f ms  %7.1f G bins/s%s" % (dft, W, hop, ms, gb, "   <-- " if gb < 60 else ""), flush=True)
-            del pv, out, ws
+    def rt():
+        fa.analyze_dev_fused(audio, ch, n, SR, W, hop, dft, pv, ws, None)
+        fa.synthesize_dev_fused(pv, ch, F, bins, SR, ar, W, out, ws, None, None)
+    rt()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 3 or (time.perf_counter() - t0 < 0.05 and reps < 50):
+        rt()
+        reps += 1
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    gb = ch * F * bins / ms / 1e6
+    rows.append((dft, W, hop, ms, gb))
+    print("dft %5d  W %5d  hop %5d   %9.3f ms  %7.1f G bins/s%s" % (dft, W, hop, ms, gb, "   <-- " if gb < 60 else ""), flush=True)
+    del pv, out, ws
