@@ -836,6 +836,7 @@ def other_configs(fa, torch, dev):
     # residue pairs with a mixed-radix inner transform (20000 = 2 x 4 x 2500; round 6, direct sums before)
     for (hop, tag, Wd, dft) in ((128, "api_default_2048_128_4096", 2048, 4096), (512, "dft4096_hop512", 2048, 4096), (1024, "window4096_hop1024_dft4096", 4096, 4096),
                                 (256, "dft1024_window1024_hop256", 1024, 1024), (128, "dft512_window512_hop128", 512, 512), (64, "dft256_window256_hop64", 256, 256),
+                                (32, "dft128_window128_hop32", 128, 128),
                                 # ... and dft 8192 / 16384: teams of four / eight wavefronts per chain (pv_kernels_team.h, round 6; before: the round-1 block kernels 0.92 ms, mixed radix 4.4 ms)
                                 (2048, "dft8192_window8192_hop2048", 8192, 8192), (1024, "dft16384_window4096_hop1024", 4096, 16384),
                                 (512, "dft2998_window2048_hop512_chirp_z", 2048, 2998), (1024, "dft32768_window4096_hop1024", 4096, 32768),

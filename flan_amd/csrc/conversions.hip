@@ -885,8 +885,8 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 		p.groups_per_channel = lay.groups_per_channel;
 		const dim3 grid( (unsigned) ( ( bins + 255 ) / 256 ), (unsigned) lay.groups_per_channel, (unsigned) ch );
 		FLANHIP_REQUIRE( lay.groups_per_channel <= 65535 && ch <= 65535, FLANHIP_ERR_UNSUPPORTED, "too many groups / channels for one launch" );
-		if( sums_in_group_kernel ) { if( gsize == 16 ) hipLaunchKernelGGL( k_sums_and_groups<16>, grid, dim3( 256 ), 0, s, p, gs ); else if( gsize == 8 ) hipLaunchKernelGGL( k_sums_and_groups<8>, grid, dim3( 256 ), 0, s, p, gs ); else hipLaunchKernelGGL( k_sums_and_groups<4>, grid, dim3( 256 ), 0, s, p, gs ); }
-		else if( gsize == 16 ) hipLaunchKernelGGL( k_group_sums<16>, grid, dim3( 256 ), 0, s, p, gs ); else if( gsize == 8 ) hipLaunchKernelGGL( k_group_sums<8>, grid, dim3( 256 ), 0, s, p, gs ); else hipLaunchKernelGGL( k_group_sums<4>, grid, dim3( 256 ), 0, s, p, gs );
+		if( sums_in_group_kernel ) { if( gsize == 32 ) hipLaunchKernelGGL( k_sums_and_groups<32>, grid, dim3( 256 ), 0, s, p, gs ); else if( gsize == 16 ) hipLaunchKernelGGL( k_sums_and_groups<16>, grid, dim3( 256 ), 0, s, p, gs ); else if( gsize == 8 ) hipLaunchKernelGGL( k_sums_and_groups<8>, grid, dim3( 256 ), 0, s, p, gs ); else hipLaunchKernelGGL( k_sums_and_groups<4>, grid, dim3( 256 ), 0, s, p, gs ); }
+		else if( gsize == 32 ) hipLaunchKernelGGL( k_group_sums<32>, grid, dim3( 256 ), 0, s, p, gs ); else if( gsize == 16 ) hipLaunchKernelGGL( k_group_sums<16>, grid, dim3( 256 ), 0, s, p, gs ); else if( gsize == 8 ) hipLaunchKernelGGL( k_group_sums<8>, grid, dim3( 256 ), 0, s, p, gs ); else hipLaunchKernelGGL( k_group_sums<4>, grid, dim3( 256 ), 0, s, p, gs );
 		FLANHIP_CHECK( hipGetLastError() );
 		p.group_sums = gs;
 		const bool scan_groups = p.groups_per_channel > 40;

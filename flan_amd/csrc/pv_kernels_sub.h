@@ -1,9 +1,9 @@
-// pv_kernels_sub.h -- dft 512 and 256 (C = 256 / 128 complex points per frame): SEVERAL CHAINS PER WAVEFRONT (round 6).
+// pv_kernels_sub.h -- dft 512, 256 and 128 (C = 256 / 128 / 64 complex points per frame): SEVERAL CHAINS PER WAVEFRONT (round 6).
 //
 // pv_kernels_v3.h walks one chain per wavefront with E = C / 64 points per lane: 4 at dft 512 (four dependent LDS exchanges of four points, two bin pairs
 // per lane and frame -- 1.8 x the dft 1024 kernel's cost per bin), 2 at dft 256 (which therefore ran the generic kernels).  Here a lane always holds E = 8
 // points -- the dft 1024 kernel's instruction mix: 8 x 8 x ( C / 64 ), two exchanges, four bin pairs per lane and frame -- and a chain takes LP = C / 8
-// lanes: 32 at dft 512, 16 at dft 256.  The G = 64 / LP lane groups of a wavefront walk G CONSECUTIVE CHAINS of one channel side by side, frame for
+// lanes: 32 at dft 512, 16 at dft 256, 8 at dft 128 (added at the round's end: the generic kernels ran it at 50 G bins/s, these at 137).  The G = 64 / LP lane groups of a wavefront walk G CONSECUTIVE CHAINS of one channel side by side, frame for
 // frame; nothing crosses between the groups (a chain is a chain: previous phases, running phases, overlap-add accumulator are a lane's own), so there are
 // no cross-lane operations in the frame loop beyond the transform's own exchanges, each group in its own LDS buffer.  What differs between the groups of a
 // wavefront is data, not control: every group walks L + 1 (L) iterations; a channel's first chain has no halo frame (its halo iteration's phases are
@@ -21,9 +21,9 @@ namespace flanhip {
 template<int LOG2C, int LP> struct SubLds
 	{
 	static constexpr int C = 1 << LOG2C;
-	static_assert( C == 8 * LP && ( LP == 32 || LP == 16 ), "eight points per lane; dft 512 / 256" );
+	static_assert( C == 8 * LP && ( LP == 32 || LP == 16 || LP == 8 ), "eight points per lane; dft 512 / 256 / 128" );
 	static constexpr int G = 64 / LP;                        // chains per wavefront
-	static constexpr int R2 = C / 64;                        // radix of the last pass (4 / 2), G butterflies per lane
+	static constexpr int R2 = C / 64;                        // radix of the last pass (4 / 2; 1 at dft 128: the pass only carries the elements back to their lanes), G butterflies per lane
 	static constexpr int QS = LP + LP / 8;                   // slots between elements i and i + LP (one lane's consecutive points)
 	static constexpr int TW1 = 0;                            // [7][8]        exp( -2 pi i r k / 64 )
 	static constexpr int TW2 = TW1 + 56;                     // [R2 - 1][64]  exp( -2 pi i r j / C )
@@ -90,7 +90,7 @@ __device__ __forceinline__ void fft_sub( cf ( &z )[8], cf * buf, const cf * s, i
 			for( int r = 0; r < R2; ++r ) v[r] = rp[QS * b + 72 * r];
 			#pragma unroll
 			for( int r = 1; r < R2; ++r ) v[r] = cmul( v[r], tp[LP * b + ( r - 1 ) * 64] );
-			dft_reg<R2>( v );
+			if constexpr( R2 > 1 ) dft_reg<R2>( v );
 			#pragma unroll
 			for( int r = 0; r < R2; ++r ) z[b + G * r] = v[r];
 			}
@@ -327,7 +327,7 @@ __global__ __launch_bounds__( 64 * WAVES, OCC ) void k_analyze_sub( AnalyzeParam
 					// 16 lanes per chain: a store instruction's four 128-byte segments all end in partial cache lines, and streamed past the L2 (non-temporal) every
 					// one of them is a partial write to memory -- plain stores let the L2 put the lines together (ablation, round 6: 0.216 -> 0.167 ms; at 32 lanes
 					// per chain the two forms measure the same)
-					else if constexpr( ( ABL & 4 ) != 0 || LP == 16 ) { rowk[LP * q] = outk[q]; rowm[-LP * q] = outm[q]; }
+					else if constexpr( ( ABL & 4 ) != 0 || LP <= 16 ) { rowk[LP * q] = outk[q]; rowm[-LP * q] = outm[q]; }
 					else
 						{
 						__builtin_nontemporal_store( outk[q], rowk + LP * q );

@@ -1,4 +1,4 @@
-// sub.hip -- launchers of the dft 512 / 256 kernels with several chains per wavefront (pv_kernels_sub.h; Conversions/AudioPV.cpp:12-139).
+// sub.hip -- launchers of the dft 512 / 256 / 128 kernels with several chains per wavefront (pv_kernels_sub.h; Conversions/AudioPV.cpp:12-139).
 #include "sub_launch.h"
 #include <type_traits>
 #include "pv_kernels_sub.h"
@@ -13,7 +13,7 @@ namespace flanhip {
 #endif
 static constexpr int kSubWaves = 4, kSubOcc = FLANHIP_SUB_OCC, kSubNv = FLANHIP_SUB_NV;          // wavefronts per block, wavefronts per SIMD the registers are capped for
 
-static int sub_lanes( int dft ) { return dft == 512 ? 32 : dft == 256 ? 16 : 0; }
+static int sub_lanes( int dft ) { return dft == 512 ? 32 : dft == 256 ? 16 : dft == 128 ? 8 : 0; }
 
 bool sub_shape( int dft, int W, int hop )
 	{
@@ -57,6 +57,7 @@ int run_analyze_sub( const AnalyzeParams & p, int dft, hipStream_t s )
 	FLANHIP_REQUIRE( sub_shape( dft, p.window_size, p.hop ), FLANHIP_ERR_UNSUPPORTED, "not a shape of the dft 512 / 256 kernels" );
 	FLANHIP_REQUIRE( p.n >= 2 && p.n < ( int64_t( 1 ) << 31 ) - 8192, FLANHIP_ERR_UNSUPPORTED, "channel length outside the 32-bit sample offsets" );
 	if( dft == 512 ) return p.sums ? launch_analyze_sub<8, 32, true>( p, s ) : launch_analyze_sub<8, 32, false>( p, s );
+	if( dft == 128 ) return p.sums ? launch_analyze_sub<6, 8, true>( p, s ) : launch_analyze_sub<6, 8, false>( p, s );
 	return p.sums ? launch_analyze_sub<7, 16, true>( p, s ) : launch_analyze_sub<7, 16, false>( p, s );
 	}
 
@@ -92,7 +93,7 @@ static int run_synth_sub_hop( const SynthParams & p, hipStream_t s )
 int run_synth_sub( const SynthParams & p, int dft, hipStream_t s )
 	{
 	FLANHIP_REQUIRE( sub_shape( dft, p.window_size, p.hop ), FLANHIP_ERR_UNSUPPORTED, "not a shape of the dft 512 / 256 kernels" );
-	return dft == 512 ? run_synth_sub_hop<8, 32>( p, s ) : run_synth_sub_hop<7, 16>( p, s );
+	return dft == 512 ? run_synth_sub_hop<8, 32>( p, s ) : dft == 128 ? run_synth_sub_hop<6, 8>( p, s ) : run_synth_sub_hop<7, 16>( p, s );
 	}
 
 } // namespace flanhip

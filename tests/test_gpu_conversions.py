@@ -111,6 +111,15 @@ CASES = [
     ("dft256_sine", 1, 48000, 256, 64, 256, "sine"),
     ("dft256_zeros", 1, 5000, 256, 64, 256, "zeros"),
     ("dft256_5ch_long", 5, 200000, 256, 64, 256, "noise"),
+    # dft 128 on the same kernels: eight lanes per chain, eight chains per wavefront (the last pass only carries the elements back to their lanes)
+    ("dft128_ragged_3ch", 3, 12345, 128, 32, 128, "noise"),
+    ("dft128_hop16", 1, 20000, 128, 16, 128, "noise"),
+    ("dft128_hop64_win96", 2, 20000, 96, 64, 128, "noise"),
+    ("dft128_hop128", 1, 20000, 128, 128, 128, "noise"),
+    ("dft128_one_frame", 1, 50, 128, 32, 128, "noise"),
+    ("dft128_sine", 1, 48000, 128, 32, 128, "sine"),
+    ("dft128_zeros", 1, 5000, 128, 32, 128, "zeros"),
+    ("dft128_5ch_long", 5, 300000, 128, 32, 128, "noise"),
     ("dft512_hop64", 1, 30000, 512, 64, 512, "noise"),
     ("dft512_hop512_win512", 2, 40000, 512, 512, 512, "noise"),
     ("dft512_7ch_ragged", 7, 54321, 512, 128, 512, "noise"),
@@ -406,10 +415,11 @@ def test_team_kernels_long_chains(fa, W, hop, dft, n):
         assert np.abs(res[0][1].astype(np.float64) - res[k][1].astype(np.float64)).max() <= 2e-6
 
 
-@pytest.mark.parametrize("W,hop,dft", [(512, 128, 512), (512, 256, 512), (384, 64, 512), (256, 64, 256), (256, 32, 256), (192, 128, 256)])
+@pytest.mark.parametrize("W,hop,dft", [(512, 128, 512), (512, 256, 512), (384, 64, 512), (256, 64, 256), (256, 32, 256), (192, 128, 256),
+                                       (128, 32, 128), (128, 16, 128), (96, 64, 128)])
 def test_sub_kernels_agree_with_their_predecessors(fa, W, hop, dft):
-    """dft 512 / 256 with several chains per wavefront (pv_kernels_sub.h) against the kernels they replaced (FLANHIP_DEBUG_NO_SUB: the one-wavefront kernels of
-    pv_kernels_v3.h at dft 512, the generic ones at dft 256): both within the oracle's tolerances, and of each other; chains of 40 frames so that the batches
+    """dft 512 / 256 / 128 with several chains per wavefront (pv_kernels_sub.h) against the kernels they replaced (FLANHIP_DEBUG_NO_SUB: the one-wavefront kernels of
+    pv_kernels_v3.h at dft 512, the generic ones at dft 256 / 128): both within the oracle's tolerances, and of each other; chains of 40 frames so that the batches
     of bin C/2 (one frame per lane of a chain's lane group) are crossed"""
     x = O.noise(3, 100000, seed=5)
     sr = 48000.0
@@ -424,7 +434,8 @@ def test_sub_kernels_agree_with_their_predecessors(fa, W, hop, dft):
         rel_m, wrms_f, same, turns = p1_metrics(pv, ref, sr / hop)
         rms = float(np.sqrt(np.mean((out.astype(np.float64) - out_ref.astype(np.float64)) ** 2)))
         print("\n[sub kernels off=%d (%d, %d, %d)] rel_m=%.3e wrms_df=%.3e same=%.4f  P2 rms=%.3e" % (mode, W, hop, dft, rel_m, wrms_f, same, rms))
-        assert rel_m <= 1e-5 and wrms_f <= 2e-3 and rms <= 1e-5 and same >= 0.92
+        # (the share of f words bit for bit the oracle's falls with the bin width per analysis rate: 0.927 at (256, 32, 256), 0.888 at (128, 16, 128) -- from either class of kernel)
+        assert rel_m <= 1e-5 and wrms_f <= 2e-3 and rms <= 1e-5 and same >= (0.92 if dft >= 256 else 0.85)
         res[mode] = (pv, out, same)
     assert abs(res[0][2] - res[1][2]) <= 0.01                       # the share of f words that are bit for bit the oracle's: the same class of kernel
     assert np.abs(res[0][1].astype(np.float64) - res[1][1].astype(np.float64)).max() <= 5e-6

@@ -28,12 +28,12 @@ if len(sys.argv) > 3 and sys.argv[3] == "odd":
             for hop in (W // 4, max(W // 7, 1), 441 if W >= 882 else W // 3):
                 shapes.append((dft, W, hop))
 else:
-    for lg in range(8, 16):
+    for lg in range(int(os.environ.get("SWEEP_LG0", "8")), int(os.environ.get("SWEEP_LG1", "16"))):
         for wd in (1, 2, 4):
             for hd in (2, 4, 8, 16, 32):
                 shapes.append((1 << lg, (1 << lg) // wd, ((1 << lg) // wd) // hd))
 for (dft, W, hop) in shapes:
-    if hop < 8:
+    if hop < 2:
         continue
     F = int(fa.lib.flanhip_num_pv_frames(n, hop))
     bins = dft // 2 + 1
