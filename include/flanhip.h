@@ -177,7 +177,7 @@ int flanhip_synthesize_dev_stages(const flanhip_MF * d_pv, int64_t num_channels,
                                            * its own -- the same sums.  0: where the chains are long enough (the default), 1: always, 2: never */
 #define FLANHIP_DEBUG_WIDE_OFFSETS   11   /* 1: kernels that choose 32-bit element offsets for grids below 2^30 elements (k_stretch_map) take their 64-bit
                                            * form whatever the size: the path of multi-gigabyte grids, testable on small ones */
-#define FLANHIP_DEBUG_NO_SUB         12   /* 1: dft 512 / 256 never on the kernels with several chains per wavefront (pv_kernels_sub.h, round 6): A/B against
+#define FLANHIP_DEBUG_NO_SUB         12   /* 1: dft 512 / 256 / 128 never on the kernels with several chains per wavefront (pv_kernels_sub.h, round 6): A/B against
                                              the one-wavefront kernels (dft 512) / the generic ones (dft 256) */
 void flanhip_debug_option(int which, int value);
 /* Scratch (private memory) bytes per lane of a kernel whose hand-counted s_waitcnt values are only right while the compiler emits no memory
