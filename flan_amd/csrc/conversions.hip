@@ -556,7 +556,8 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	// env overrides aside -- and the generic kernels serve the hops that would not fit: nothing anybody analyses with)
 	const bool fast = ( dft == 2048 || ( dft == 4096 && !debug_options().ana11_old ) || v3_size( dft ) ) && n >= 2 && n < ( int64_t( 1 ) << 31 ) - 8192 && hop <= 65536 && !force_generic();
 	int target_chains = team ? team_target_chains( dft ) : sub ? sub_target_chains( dft ) : any ? any_target_chains( dft / 2 + 1 ) : mr ? mr_target_chains( dft, W ) : bs ? bs_target_chains( dft, W ) : big ? big_target_chains() : fast ? fast_target_chains( dft, false ) : generic_target_chains( dft );
-	p.L = choose_chain_length( ch, p.F, any ? 7 : 1, target_chains );
+	const int block_group = team ? team_group_size( dft ) : sub ? sub_group_size( dft ) : fast ? group_size_of( dft ) : 1;      // chains per block of the kernels this call runs
+	p.L = choose_chain_length( ch, p.F, any ? 7 : 1, target_chains, block_group );
 	p.chains_per_channel = int( ( p.F + p.L - 1 ) / p.L );
 	p.sample_rate = sr;
 	p.analysis_rate = sr / hop;                                   // AudioPV.cpp:26 (float / int)
@@ -725,7 +726,8 @@ int synth_layout( int64_t ch, int64_t F, int bins, float sr, float ar, int W, Sy
 	const int overlap = ( W + o->hop - 1 ) / o->hop;              // frames covering one output sample
 	const int kind = ( o->any || o->big || sub ) ? 0 : synth_fast_kind( o->dft, W, o->hop );
 	const int slots = team ? team_target_chains( o->dft ) : sub ? sub_target_chains( o->dft ) : o->any ? any_target_chains( bins ) : mr ? mr_target_chains( o->dft, W ) : bs ? bs_target_chains( o->dft, W ) : o->big ? big_target_chains() : kind == 0 ? generic_target_chains( o->dft ) : fast_target_chains( o->dft, true );
-	o->L = choose_chain_length( ch, F, o->any ? 1 : std::max( overlap - 1, 1 ), slots );
+	const int block_group = team ? team_group_size( o->dft ) : sub ? sub_group_size( o->dft ) : kind != 0 ? group_size_of( o->dft ) : 1;
+	o->L = choose_chain_length( ch, F, o->any ? 1 : std::max( overlap - 1, 1 ), slots, block_group );
 	o->chains_per_channel = int( ( F + o->L - 1 ) / o->L );
 	const int64_t chains = int64_t( o->chains_per_channel ) * ch;
 	o->carry_bytes = ( size_t( chains ) * bins * sizeof( double ) + 255 ) & ~size_t( 255 );

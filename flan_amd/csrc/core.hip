@@ -288,7 +288,7 @@ int cu_count()
 	return n;
 	}
 
-int choose_chain_length( int64_t num_channels, int64_t num_frames, int min_len, int target_chains )
+int choose_chain_length( int64_t num_channels, int64_t num_frames, int min_len, int target_chains, int group )
 	{
 	if( const int v = debug_options().chain_len ) { if( v > 0 ) return std::max( v, min_len ); }     // (tests: results must not depend on the cut)
 	// One wavefront per chain.  target_chains = the wavefronts the chip holds at once for this kernel.  All chains run
@@ -309,6 +309,31 @@ int choose_chain_length( int64_t num_channels, int64_t num_frames, int min_len, 
 	if( L < min_len ) L = min_len;
 	while( num_channels * ( ( num_frames + L - 1 ) / L ) > slots && L < num_frames ) ++L;
 	if( L > ( int64_t( 1 ) << 30 ) ) L = int64_t( 1 ) << 30;
+	// A block of the tuned kernels is a GROUP of `group` consecutive chains of ONE channel (8 wavefronts at dft 2048, 4 teams at dft 4096, 8 ... 32 chains of the
+	// dft 512 ... 128 kernels): with fewer chains per channel than that its other wavefronts idle -- 1024 channels of half a second each are 2 chains per channel at
+	// the cut above, blocks of 8 wavefronts with 2 at work, four rounds of them: 1.13 ms where 8 ch x 60 s, the same frames, take 0.27 (round 6,
+	// tools/input_sweep.py).  So: shorter chains that fill whole groups where that costs fewer block rounds x frames.  Cost of a cut: rounds of resident blocks x
+	// ( L + 2 frame slots for the halo frame and a chain's fixed part ); only a cut that is 10 % cheaper replaces the one above.
+	if( group > 1 )
+		{
+		const int64_t bslots = std::max<int64_t>( target_chains / group, 1 );
+		auto cost = [&]( int64_t len )
+			{
+			const int64_t cpc = ( num_frames + len - 1 ) / len, blocks = num_channels * ( ( cpc + group - 1 ) / group );
+			return ( ( blocks + bslots - 1 ) / bslots ) * ( len + 2 );
+			};
+		int64_t best = L, best_cost = cost( L );
+		for( int64_t m = 1; m <= 64; ++m )
+			{
+			const int64_t cpc = m * group;
+			if( cpc > num_frames ) break;
+			const int64_t len = ( num_frames + cpc - 1 ) / cpc;
+			if( len < std::max<int64_t>( min_len, 4 ) ) break;
+			const int64_t c = cost( len );
+			if( c * 10 < best_cost * 9 && len < best ) { best = len; best_cost = c; }
+			}
+		L = best;
+		}
 	return int( L );
 	}
 

@@ -66,7 +66,7 @@ struct DivPlan { float c, rc; int exact; };
 int get_div_plan( float c, DivPlan * out );
 
 // Chain length heuristics (frames per wavefront-chain)
-int choose_chain_length( int64_t num_channels, int64_t num_frames, int min_len, int target_chains );
+int choose_chain_length( int64_t num_channels, int64_t num_frames, int min_len, int target_chains, int group = 1 );   // group: chains per block of the kernels (core.hip)
 // flanhip_debug_option (include/flanhip.h): per-thread test / A-B hooks, all off by default
 struct DebugOptions
 	{
