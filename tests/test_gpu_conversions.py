@@ -387,6 +387,33 @@ def test_chain_length_invariance(fa):
             assert d.max() <= 2e-6
 
 
+@pytest.mark.parametrize("W,hop,dft", [(2048, 512, 2048), (2048, 128, 4096), (512, 128, 512), (128, 32, 128), (8192, 2048, 8192)])
+def test_many_short_channels_fill_the_kernels_blocks(fa, W, hop, dft):
+    """A batch of many short channels (round 6, core.hip choose_chain_length): the cut is made for the kernels' BLOCKS -- groups of 8 wavefronts / 4 teams / 8 ... 32
+    chains of ONE channel -- so that few chains per channel do not leave most of a block idle.  600 channels of 0.4 s: the library's own cut against one chain per
+    channel and against chains of four frames -- the PV bit for bit, the audio to the rounding of the overlaps' partial sums -- and against the oracle on a few channels."""
+    ch, n = 600, 19200
+    x = O.noise(ch, n, seed=606)
+    sr = 48000.0
+    ar = np.float32(sr) / np.float32(hop)
+    pv = fa.analyze(x, sr, W, hop, dft)
+    out, _ = fa.synthesize(pv, sr, ar, W)
+    for L in (1024, 4):                                            # (1024 frames: more than a channel has)
+        with fa.debug_options(chain_len=L):
+            pv2 = fa.analyze(x, sr, W, hop, dft)
+            out2, _ = fa.synthesize(pv, sr, ar, W)
+        assert np.array_equal(pv.view(np.uint32), pv2.view(np.uint32)), L
+        assert np.abs(out.astype(np.float64) - out2.astype(np.float64)).max() <= 2e-6, L
+    sel = [0, 1, 299, 598, 599]
+    ref = O.analyze(x[sel], sr, W, hop, dft)
+    rel_m, wrms_f, same, turns = p1_metrics(pv[sel], ref, sr / hop)
+    out_ref, _ = O.synthesize(ref, sr, ar, W)
+    out_sel, _ = fa.synthesize(ref, sr, ar, W)
+    rms = float(np.sqrt(np.mean((out_sel.astype(np.float64) - out_ref.astype(np.float64)) ** 2)))
+    print("\n[600 short channels (%d, %d, %d)] rel_m=%.3e wrms_df=%.3e same=%.4f  P2 rms=%.3e" % (W, hop, dft, rel_m, wrms_f, same, rms))
+    assert rel_m <= 1e-5 and wrms_f <= 2e-3 and rms <= 1e-5 and same >= 0.85
+
+
 @pytest.mark.parametrize("W,hop,dft,n", [(2048, 512, 8192, 150000), (4096, 1024, 16384, 300000), (8192, 2048, 8192, 420000)])
 def test_team_kernels_long_chains(fa, W, hop, dft, n):
     """dft 8192 / 16384 (pv_kernels_team.h): chains of more than 64 frames, so that the batches of the k = 512 group (one frame per lane, worked off every
