@@ -111,7 +111,9 @@ def test_full_size_properties(name, ch, seconds, monkeypatch):
         assert bool(torch.equal(out_c.view(torch.int32), out2[c:c + 1].view(torch.int32)))
 
 
-@pytest.mark.parametrize("w,hop,dft,ch,seconds", [(512, 128, 512, 8, 600), (256, 64, 256, 8, 300), (8192, 2048, 8192, 8, 600), (4096, 1024, 16384, 8, 300)])
+@pytest.mark.parametrize("w,hop,dft,ch,seconds", [(512, 128, 512, 8, 600), (256, 64, 256, 8, 300), (8192, 2048, 8192, 8, 600), (4096, 1024, 16384, 8, 300),
+                                                  # ... at fractions of a step (the API's default ratio and its default hop at the larger sizes) and dft 128
+                                                  (4096, 256, 8192, 8, 120), (2048, 128, 16384, 4, 60), (128, 32, 128, 8, 300)])
 def test_round6_kernel_families_at_full_size(w, hop, dft, ch, seconds):
     """The kernels of round 6 (pv_kernels_sub.h: dft 512 / 256, several chains per wavefront; pv_kernels_team.h: dft 8192 / 16384, teams of wavefronts) on
     long inputs (PVs of 3.7 - 7.4 GB, chains of hundreds of frames in several rounds), through size-independent properties: head parity against the oracle,
@@ -148,7 +150,7 @@ def test_round6_kernel_families_at_full_size(w, hop, dft, ch, seconds):
         valid = (K - w // hop) * hop
         rms = np.sqrt(np.mean((out[c, :valid].cpu().numpy().astype(np.float64) - out_ref[0, :valid]) ** 2))
         print("\n[(%d, %d, %d) %d ch x %d s, ch %d] head P1 rel_m=%.2e  f bit-identical=%.4f   head P2 rms=%.2e" % (w, hop, dft, ch, seconds, c, rel_m, same_f, rms))
-        assert rel_m <= 1e-5 and same_f >= 0.95 and rms <= 1e-5
+        assert rel_m <= 1e-5 and same_f >= (0.95 if dft >= 256 else 0.90) and rms <= 1e-5      # (dft 128: 0.935 from every kernel generation, tests/test_gpu_conversions.py)
     # ---- another chain cut
     pv2 = torch.empty_like(pv)
     out2 = torch.empty_like(out)
