@@ -903,10 +903,11 @@ int launch_synthesize( const flanhip_MF * d_pv, int64_t ch, int64_t F, int bins,
 	if( ( stages & 2 ) && !self_carry && !group_kernel )
 		{
 		const int64_t cols = ch * bins;
-		(void) cols;
 		// segments of at most 32 chains where that keeps 16 bins (128 contiguous bytes) per block row (pv_kernels_fast.h; 8 bins per block: slower)
 		// few chains per channel and rows of thousands of bins (the dft 8192 / 16384 team kernels' layouts): a thread per column (round 6)
-		const bool flat = p.chains_per_channel <= 64 && bins >= 2049 && !d_carry_in && !d_total_out && !prepass_only;
+		// ... or many channels of few chains each (a batch of short clips: 1024 channels x 8 chains took k_phase_scan2 0.39 ms -- 33 792 blocks of 512 threads with
+		// half a segment's work each -- and this one 0.0x: tools/short_channel_experiment.py)
+		const bool flat = p.chains_per_channel <= 64 && ( bins >= 2049 || cols >= 65536 ) && !d_carry_in && !d_total_out && !prepass_only;
 		if( flat && p.chains_per_channel <= 32 ) hipLaunchKernelGGL( k_phase_scan_flat<32>, dim3( (unsigned) ( ( bins + 255 ) / 256 ), (unsigned) ch ), dim3( 256 ), 0, s, p );
 		else if( flat ) hipLaunchKernelGGL( k_phase_scan_flat<64>, dim3( (unsigned) ( ( bins + 255 ) / 256 ), (unsigned) ch ), dim3( 256 ), 0, s, p );
 		else if( p.chains_per_channel <= 512 ) hipLaunchKernelGGL( k_phase_scan2<16>, dim3( (unsigned) ( ( bins + 31 ) / 32 ), (unsigned) ch ), dim3( 512 ), 0, s, p );
