@@ -322,15 +322,19 @@ int choose_chain_length( int64_t num_channels, int64_t num_frames, int min_len, 
 			const int64_t cpc = ( num_frames + len - 1 ) / len, blocks = num_channels * ( ( cpc + group - 1 ) / group );
 			return ( ( blocks + bslots - 1 ) / bslots ) * ( len + 2 );
 			};
-		int64_t best = L, best_cost = cost( L );
-		for( int64_t m = 1; m <= 64; ++m )
+		// (candidates: whole groups per channel, from one group up -- longer chains than the cut above too: 24 channels x 20 s are 85 chains per channel there, 11 blocks
+		// per channel, 264 blocks for 256 CUs: a second round for eight blocks; 80 chains per channel fit one.  tools/channel_sweep.py)
+		const int64_t first_cost = cost( L );
+		int64_t best = L, best_cost = first_cost;
+		for( int64_t m = 1; m <= 4096; ++m )
 			{
 			const int64_t cpc = m * group;
 			if( cpc > num_frames ) break;
 			const int64_t len = ( num_frames + cpc - 1 ) / cpc;
 			if( len < std::max<int64_t>( min_len, 4 ) ) break;
+			if( len > cap && rounds > 1 ) continue;                                  // (very long inputs keep their rounds of chains of at most ~512 frames)
 			const int64_t c = cost( len );
-			if( c * 10 < best_cost * 9 && len < best ) { best = len; best_cost = c; }
+			if( c * 10 < first_cost * 9 && c < best_cost ) { best = len; best_cost = c; }
 			}
 		L = best;
 		}
