@@ -567,7 +567,7 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	p.sums = nullptr; p.nan_out = nullptr; p.nan_epoch = 0;
 	p.cancel = thread_cancel_word( s );                                           // kernels stop starting chains when the thread's wait raises it (core.hip)
 	// windows above 2048: the WBIG team kernels (pv_kernels_eo.h)
-	const bool kernel_sums = !any && !big && ( !mr || mr_pingpong( mr_plan.C ) ) && ( !bs || bs_pingpong( bs_plan.M ) );   // every power-of-two analysis kernel keeps the sums, and the mixed-radix one where its LDS has room; for the rest the pre-pass kernel runs on the analysis' behalf
+	bool kernel_sums = !any && !big && ( !mr || mr_pingpong( mr_plan.C ) ) && ( !bs || bs_pingpong( bs_plan.M ) );   // every power-of-two analysis kernel keeps the sums, and the mixed-radix one where its LDS has room; for the rest the pre-pass kernel runs on the analysis' behalf
 	SynthLayout fused_lay{};
 	if( d_fused_ws )
 		{
@@ -576,6 +576,11 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 		if( int rc = synth_layout( ch, p.F, dft / 2 + 1, sr, p.analysis_rate, W, &lay ) ) return rc;
 		p.nan_epoch = next_epoch();
 		*epoch = p.nan_epoch;
+		// A SHORT input at a large window / hop ratio (the reference API's default call on a few seconds of sound: ( 2048, 128, 4096 ), ratio 16): the synthesis' chains
+		// are at least window / hop - 1 = 15 frames long, the analysis' own cut would be 4 -- walking the synthesis' chains costs the launch eleven frames of latency
+		// (2 ch x 5 s: 0.196 ms fused against 0.150 as two plain calls, tools/unfused_sweep.py).  There the analysis keeps its own cut and the pre-pass kernel sums
+		// the rows on its behalf, like behind the kernels that keep no sums.
+		if( kernel_sums && lay.L >= p.L + 8 && int64_t( p.chains_per_channel ) * ch <= target_chains ) kernel_sums = false;
 		if( kernel_sums )
 			{
 			p.L = lay.L;
@@ -606,8 +611,8 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 		return FLANHIP_OK;
 		};
 
-	if( team ) return run_analyze_team( p, *plan, dft, s );                       // (keeps the chain sums: kernel_sums)
-	if( sub ) return run_analyze_sub( p, dft, s );
+	if( team ) { if( int rc = run_analyze_team( p, *plan, dft, s ) ) return rc; return prepass_on_behalf(); }    // (keeps the chain sums where kernel_sums says so)
+	if( sub ) { if( int rc = run_analyze_sub( p, dft, s ) ) return rc; return prepass_on_behalf(); }
 	if( any )
 		{
 		std::shared_ptr<const UnitRef> unit_ref;
@@ -676,16 +681,16 @@ static int launch_analyze_body( const float * d_audio, int64_t ch, int64_t n, fl
 	if( fast )
 		{
 		FastTables tb{ plan->d_tw1f, plan->d_tw3f, plan->d_tw2 };
-		if( v3_size( dft ) ) return p.sums ? run_analyze_v3_cfg<true>( dft, p, s ) : run_analyze_v3_cfg<false>( dft, p, s );
-		if( dft == 2048 ) return p.sums ? run_analyze_v2_variant<true>( debug_options().ana_variant, p, tb, s ) : run_analyze_v2_variant<false>( debug_options().ana_variant, p, tb, s );
-		if( W <= 2048 )
-			{
-			// teams of two wavefronts, two E / O buffer sets, one meeting per frame (0.27 ms for 8 ch x 60 s with the fused round trip's chain sums,
-			// 0.28 without; one set and two meetings: +7 %; the round-1 kernel: 0.44)
-			return p.sums ? run_analyze_eo_team<4, true, 2, true>( p, tb, s ) : run_analyze_eo_team<4, false, 2, true>( p, tb, s );
-			}
+		int rc;
+		if( v3_size( dft ) ) rc = p.sums ? run_analyze_v3_cfg<true>( dft, p, s ) : run_analyze_v3_cfg<false>( dft, p, s );
+		else if( dft == 2048 ) rc = p.sums ? run_analyze_v2_variant<true>( debug_options().ana_variant, p, tb, s ) : run_analyze_v2_variant<false>( debug_options().ana_variant, p, tb, s );
+		// teams of two wavefronts, two E / O buffer sets, one meeting per frame (0.27 ms for 8 ch x 60 s with the fused round trip's chain sums,
+		// 0.28 without; one set and two meetings: +7 %; the round-1 kernel: 0.44)
+		else if( W <= 2048 ) rc = p.sums ? run_analyze_eo_team<4, true, 2, true>( p, tb, s ) : run_analyze_eo_team<4, false, 2, true>( p, tb, s );
 		// windows up to the whole transform: the same decomposition with full-length E / O inputs, one buffer set (pv_kernels_eo.h: WBIG)
-		return p.sums ? run_analyze_eo_team<4, true, 2, false, true>( p, tb, s ) : run_analyze_eo_team<4, false, 2, false, true>( p, tb, s );
+		else rc = p.sums ? run_analyze_eo_team<4, true, 2, false, true>( p, tb, s ) : run_analyze_eo_team<4, false, 2, false, true>( p, tb, s );
+		if( rc ) return rc;
+		return prepass_on_behalf();                                                 // (a short input on its own cut: the sums by the pre-pass kernel)
 		}
 
 	int rc = FLANHIP_ERR_UNSUPPORTED;
