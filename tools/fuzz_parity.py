@@ -36,6 +36,14 @@ for it in range(N):
         ch = 1
         if (n // hop + 1) * (dft // 2 + 1) > 6e7:
             continue
+    c = dft // 2
+    for q in (2, 3, 5, 7, 11, 13):
+        while c % q == 0:
+            c //= q
+    if c > 1 and ch * (n // hop + 1) * float(dft // 2) ** 2 > 2e10:     # (the oracle's transform of a size with a large prime factor is O( N^2 ): minutes on one core)
+        ch = 1
+        if (n // hop + 1) * float(dft // 2) ** 2 > 2e10:
+            continue
     x = O.noise(ch, n, seed=1000 + it)
     ar = np.float32(sr) / np.float32(hop)
     ref = O.analyze(x, sr, W, hop, dft)
